@@ -1,0 +1,39 @@
+"""Seeded input builders shared by the fixture generator (make_golden*.py, runs the reference) and
+the parity tests (run the oracle / the HIP path).  numpy's MT19937 stream is platform independent,
+so fixtures store only the reference's OUTPUTS plus the seed; inputs and weights are re-created."""
+import numpy as np
+
+ENCODER_CASES = [("c128_t5", 128, 5, 3, 1024), ("c128_t33", 128, 33, 2, 1024), ("c192_t33", 192, 33, 2, 1024),
+                 ("c256_t130", 256, 130, 1, 1024), ("c192_t7", 192, 7, 4, 1024)]
+
+
+def fill_params(module, seed, scale=0.08):
+    """Deterministic weights: MT19937 normals in named_parameters() order; norm gains centred on 1."""
+    import torch
+    rng = np.random.RandomState(seed)
+    with torch.no_grad():
+        for name, p in module.named_parameters():
+            v = rng.standard_normal(size=tuple(p.shape)).astype(np.float32) * scale
+            if name.endswith("norm.weight") or name.endswith("ln.weight") or "norm1.weight" in name \
+                    or "norm2.weight" in name:
+                v = 1.0 + v
+            p.copy_(torch.from_numpy(v))
+
+
+def rand_bias(rng, G, H, T, n_real):
+    """[G,H,T,T] bias with the collator's padding pattern: pad key columns are -inf for every row."""
+    b = (rng.standard_normal((G, H, T, T)) * 0.7).astype(np.float32)
+    for g in range(G):
+        b[g, :, :, n_real[g]:] = -np.inf
+    return b
+
+
+def encoder_case(variant, C, T, G):
+    """-> seed, x [G,T,C], bias [G,8,T,T], gy [G,T,C], n_real"""
+    seed = (1000 * C + 10 * T + (1 if variant == "fq" else 0)) % 100003
+    rng = np.random.RandomState(seed)
+    x = rng.standard_normal((G, T, C)).astype(np.float32)
+    n_real = [T] + [max(2, T - 1 - 3 * g) for g in range(1, G)]
+    bias = rand_bias(rng, G, 8, T, n_real)
+    gy = rng.standard_normal((G, T, C)).astype(np.float32)
+    return seed, x, bias, gy, n_real
