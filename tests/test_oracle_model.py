@@ -1,0 +1,178 @@
+"""Pins the oracle's model path (EncoderLayer, bias assembly, full forward, loss, LR, metrics) to the
+reference's outputs (tests/golden/g4..g7).  fp32 both sides, same torch build -> tight tolerances."""
+import os
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+
+from inputs import ENCODER_CASES, encoder_case
+from mobgt_amd import synth
+from oracle import model_oracle as mo
+from oracle import collator_oracle as co
+
+TOL = dict(rtol=2e-5, atol=2e-6)
+
+
+def load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name))
+
+
+def seeded_state(names_shapes, seed, scale=0.08):
+    """Same stream as tests/golden/inputs.fill_params, keyed by parameter name order."""
+    rng = np.random.RandomState(seed)
+    sd = {}
+    for name, shape in names_shapes:
+        v = rng.standard_normal(size=tuple(shape)).astype(np.float32) * scale
+        if name.endswith("norm.weight") or name.endswith("ln.weight") or "norm1.weight" in name or "norm2.weight" in name:
+            v = 1.0 + v
+        sd[name] = torch.from_numpy(v).requires_grad_(True)
+    return sd
+
+
+def encoder_param_list(variant, C, ffn):
+    ps = [("self_attention_norm.weight", (C,)), ("self_attention_norm.bias", (C,))]
+    for n in ("linear_q", "linear_k", "linear_v", "output_layer"):
+        ps += [(f"self_attention.{n}.weight", (C, C)), (f"self_attention.{n}.bias", (C,))]
+    norms = ["ffn_norm"] if variant == "stock" else ["ffn_norm1", "ffn_norm2"]
+    for n in norms:
+        ps += [(f"{n}.weight", (C,)), (f"{n}.bias", (C,))]
+    ps += [("ffn.layer1.weight", (ffn, C)), ("ffn.layer1.bias", (ffn,)), ("ffn.layer2.weight", (C, ffn)), ("ffn.layer2.bias", (C,))]
+    return ps
+
+
+@pytest.mark.parametrize("variant", ["stock", "fq"])
+@pytest.mark.parametrize("case", ENCODER_CASES, ids=[c[0] for c in ENCODER_CASES])
+def test_encoder_layer_g4(golden_dir, variant, case):
+    z = load(golden_dir, "g4_encoder.npz")
+    cname, C, T, G, ffn = case
+    name = f"{variant}/{cname}"
+    seed, x, bias, gy, _ = encoder_case(variant, C, T, G)
+    sd = seeded_state([("L." + n, s) for n, s in encoder_param_list(variant, C, ffn)], seed + 1)
+    x = torch.from_numpy(x).requires_grad_(True)
+    bias = torch.from_numpy(bias).requires_grad_(True)
+    fn = mo.encoder_layer_stock if variant == "stock" else mo.encoder_layer_fq
+    y = fn(sd, "L", x, bias, 8)
+    y.backward(torch.from_numpy(gy))
+    np.testing.assert_allclose(y.detach().numpy(), z[f"{name}/y"], **TOL)
+    np.testing.assert_allclose(x.grad.numpy(), z[f"{name}/dx"], rtol=1e-4, atol=1e-5)
+    db = bias.grad.numpy()
+    db = db if T <= 40 else db[:, :, ::7, :]
+    np.testing.assert_allclose(db, z[f"{name}/dbias"], rtol=1e-4, atol=1e-6)
+    for pn, p in sd.items():
+        key = pn[2:]
+        if f"{name}/grad_none/{key}" in z:
+            assert p.grad is None
+            continue
+        g = p.grad.double()
+        ref = z[f"{name}/gstat/{key}"]
+        np.testing.assert_allclose([g.sum().item(), g.norm().item()], ref, rtol=1e-3, atol=1e-4)
+
+
+def _batch(z, prefix, fields, float_fields=("attn_bias", "time_normal")):
+    b = SimpleNamespace()
+    for f in fields:
+        a = z[f"{prefix}{f}"]
+        t = torch.from_numpy(a.astype(np.float32) if f in float_fields else (a if a.dtype == np.bool_ else a.astype(np.int64)))
+        setattr(b, f, t)
+    return b
+
+
+STOCK_FIELDS = ("idx", "attn_bias", "attn_edge_type", "rel_pos", "in_degree", "out_degree", "x", "edge_input", "y", "adj")
+FQ_FIELDS = STOCK_FIELDS + ("time", "adj1", "time_normal", "user", "cat", "poi_pos")
+
+
+def stock_param_list(hidden=128, ffn=256, H=8, L=2, n_class=65):
+    ps = [("atom_encoder.weight", (512 * 9 + 1, hidden)), ("edge_encoder.weight", (512 * 3 + 1, H)),
+          ("edge_dis_encoder.weight", (128 * H * H, 1)), ("rel_pos_encoder.weight", (512, H)),
+          ("in_degree_encoder.weight", (512, hidden)), ("out_degree_encoder.weight", (512, hidden))]
+    for l in range(L):
+        ps += [(f"layers.{l}.{n}", s) for n, s in encoder_param_list("stock", hidden, ffn)]
+    ps += [("final_ln.weight", (hidden,)), ("final_ln.bias", (hidden,)),
+           ("downstream_out_proj.weight", (n_class, hidden)), ("downstream_out_proj.bias", (n_class,)),
+           ("graph_token.weight", (1, hidden)), ("graph_token_virtual_distance.weight", (1, H))]
+    return ps
+
+
+def test_stock_bias_and_logits_g5_g6(golden_dir):
+    z5, z6 = load(golden_dir, "g5_bias.npz"), load(golden_dir, "g6_e2e.npz")
+    sd = seeded_state(stock_param_list(), 77)
+    b = _batch(z5, "stock/batch/", STOCK_FIELDS)
+    bias = mo.assemble_bias(sd, b, 8, 20, "stock")
+    ref = z5["stock/bias"]
+    assert np.array_equal(np.isinf(bias.detach().numpy()), np.isinf(ref))
+    fin = np.isfinite(ref)
+    np.testing.assert_allclose(bias.detach().numpy()[fin], ref[fin], **TOL)
+    # table gradients for a fixed upstream grad
+    gb = torch.from_numpy(z5["stock/gbias"])
+    (torch.where(torch.isfinite(bias), bias, torch.zeros_like(bias)) * gb).sum().backward()
+    for pn in ("rel_pos_encoder.weight", "edge_encoder.weight", "edge_dis_encoder.weight", "graph_token_virtual_distance.weight"):
+        g = sd[pn].grad.numpy()
+        g = g if g.size <= 4096 else g[:4096]
+        if pn in ("rel_pos_encoder.weight", "edge_encoder.weight"):
+            g = g.copy()
+            g[0] = 0                                   # nn.Embedding(padding_idx=0): no gradient to row 0
+        np.testing.assert_allclose(g, z5[f"stock/dtable/{pn}"], rtol=1e-4, atol=1e-5)
+    for p in sd.values():
+        p.grad = None
+    logits = mo.graphormer_stock_forward(sd, b, 2, 8, 20)
+    np.testing.assert_allclose(logits.detach().numpy(), z6["stock/logits"], rtol=1e-4, atol=1e-5)
+    loss = torch.nn.functional.cross_entropy(logits, b.y.view(-1))
+    np.testing.assert_allclose(loss.item(), z6["stock/loss"], rtol=1e-5)
+
+
+def _universe(z6):
+    return synth.Universe(P=64, n_cat=8, n_user=8, poi_table=z6["uni/poi_table"], graph_adj=z6["uni/graph_adj"],
+                          graph_dist=z6["uni/graph_dist"], graph_cat=z6["uni/graph_cat"], distance=z6["uni/distance"])
+
+
+@pytest.mark.parametrize("tag,ds", [("fsq", "foursquaregraph"), ("gow", "gowalla_nevda")])
+def test_fq_bias_logits_loss_grads_g5_g6(golden_dir, tag, ds):
+    z5, z6 = load(golden_dir, "g5_bias.npz"), load(golden_dir, "g6_e2e.npz")
+    consts = mo.fq_constants(_universe(z6), ds)
+    assert consts.num_bins == int(z5[f"{tag}/num_bins"])
+    names = [str(n) for n in z6[f"{tag}/param_names"]]
+    shapes = [eval(str(s)) for s in z6[f"{tag}/param_shapes"]]
+    sd = seeded_state(list(zip(names, shapes)), 78)
+    b = _batch(z5, f"{tag}/batch/", FQ_FIELDS)
+    bias = mo.assemble_bias(sd, b, 8, 20, "fq")
+    ref = z5[f"{tag}/bias"]
+    fin = np.isfinite(ref)
+    assert np.array_equal(np.isfinite(bias.detach().numpy()), fin)
+    np.testing.assert_allclose(bias.detach().numpy()[fin], ref[fin], **TOL)
+    kw = dict(n_layers=2, H=8, D=20)
+    logits, cat_logits = mo.graphormer_fq_forward(sd, b, consts, **kw)
+    np.testing.assert_allclose(logits.detach().numpy(), z6[f"{tag}/logits"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(cat_logits.detach().numpy(), z6[f"{tag}/cat_logits"], rtol=1e-4, atol=1e-5)
+    # the golden loss was taken from training_step on a module in eval() mode (no dropout)
+    loss = mo.fq_training_loss(sd, b, consts, **kw)
+    np.testing.assert_allclose(loss.item(), z6[f"{tag}/loss"], rtol=1e-5)
+    loss.backward()
+    for pn, p in sd.items():
+        if f"{tag}/grad_none/{pn}" in z6:
+            assert p.grad is None, pn
+            continue
+        g = p.grad.double()
+        if pn in ("edge_encoder.weight", "rel_pos_encoder.weight", "poi_pos_encoder.weight", "in_degree_encoder.weight",
+                  "out_degree_encoder.weight", "fre_embed_model.weight", "time_embed_model_48.weight"):
+            g = g.clone()
+            g[0] = 0                                   # padding_idx=0 rows receive no gradient in the reference
+        np.testing.assert_allclose([g.sum().item(), g.norm().item()], z6[f"{tag}/gstat/{pn}"], rtol=2e-3, atol=1e-6, err_msg=pn)
+
+
+def test_lr_loss_metrics_g7(golden_dir):
+    z = load(golden_dir, "g7_lr_loss.npz")
+    w, t, lr, end, power = z["lr/args"]
+    ref = z["lr/values"]
+    got = [mo.polynomial_decay_lr(i + 1, w, t, lr, end, power) for i in range(len(ref))]
+    np.testing.assert_allclose(got, ref, rtol=1e-12, atol=0)
+    logits = torch.from_numpy(z["gtl/logits"]).requires_grad_(True)
+    loss = mo.gradient_tail_loss(logits, torch.from_numpy(z["gtl/targets"]), 0.2)
+    loss.backward()
+    np.testing.assert_allclose(loss.item(), z["gtl/loss"], rtol=1e-6)
+    np.testing.assert_allclose(logits.grad.numpy(), z["gtl/dlogits"], rtol=1e-5, atol=1e-8)
+    acc, ndcg = mo.get_acc(z["acc/target"], z["acc/scores"])
+    np.testing.assert_allclose(acc, z["acc/acc"])
+    np.testing.assert_allclose(ndcg, z["acc/ndcg"])
+    np.testing.assert_allclose(mo.mrr_metric(z["acc/target"], z["acc/scores"]), z["acc/mrr"])
