@@ -1,0 +1,176 @@
+/*
+ * mobgt_hip.h -- C ABI of libmobgt_hip.so, the MI355X (gfx950) hot path of MobGT.
+ *
+ * This is the drop-in boundary.  The reference (Yukayo/MobGT) is pure
+ * Python/PyTorch + one Cython file, so "the reference's FFI for this path" is the set of Python
+ * call sites listed next to each entry point below; the binding a maintainer adds is a ctypes
+ * stub (INTEGRATION.md shows it; mobgt_amd/_lib.py is the one this repo ships).
+ *
+ * Conventions
+ *   - every entry point returns 0 on success, a hipError_t (>0) from the launch, or a negative
+ *     MOBGT_E* code for an argument the kernels cannot take;
+ *   - all pointers are DEVICE pointers unless the name ends in _host; the caller owns every buffer;
+ *   - no allocation, no synchronisation, no host<->device copy inside: each call enqueues kernels
+ *     on `stream` (a hipStream_t passed as void*) and returns, so calls can be captured in a hipGraph;
+ *   - `dtype` arguments: MOBGT_F32 = 0, MOBGT_BF16 = 1; index tensors: MOBGT_I64 / I32 / I16 / U8;
+ *   - G graphs, H heads, T = N+1 tokens (token 0 = graph token), N padded nodes, d = head width
+ *     (16, 24 or 32), D = multi_hop_max_dist (<= 32), F edge-feature columns.
+ */
+#ifndef MOBGT_HIP_H
+#define MOBGT_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MOBGT_F32 0
+#define MOBGT_BF16 1
+
+#define MOBGT_I64 0
+#define MOBGT_I32 1
+#define MOBGT_I16 2
+#define MOBGT_U8 3
+
+#define MOBGT_EBADDIM (-1)   /* unsupported head width / hop count / size            */
+#define MOBGT_EALIGN (-2)    /* pointer or stride violates the documented alignment  */
+#define MOBGT_EDTYPE (-3)    /* unknown dtype code                                   */
+
+/* Library / device identification (no GPU work). */
+int mobgt_abi_version(void);
+const char* mobgt_build_info(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * Bias-fused multi-head attention.  Replaces the body of MultiHeadAttention.forward between the
+ * three input projections and the output projection:
+ *     graphormer/model.py:436-455   (view/transpose, q*scale, matmul, +attn_bias, softmax, dropout,
+ *     graphormer/model_fqandtoyo.py:1687-1706    matmul, transpose/contiguous/view)
+ *
+ * q,k,v,out : [G, T, H*d] row-major with row strides ldq/ldk/ldv/ldo (elements); head h occupies
+ *             columns [h*d, (h+1)*d).  dtype `io_dtype` (f32 or bf16); 16-byte aligned rows.
+ * bias      : [G, H, T, ld_bias] `bias_dtype`, bias[g,h,i,j] added unscaled to the score of query i,
+ *             key j; ld_bias % 32 == 0, ld_bias >= roundup(T,32); columns >= T are ignored.
+ *             -inf entries are honoured (probability exactly 0).
+ * lse       : [G, H, T] f32 out, natural-log sum of exp of the biased scores (needed by bwd).
+ * scale     : q is multiplied by it BEFORE the dot product (reference: att_size ** -0.5).
+ * dropout_p : attention dropout on the probabilities (model.py:451); 0 disables.  The keep mask is
+ *             a pure function of (seed, g, h, i, j) -- see mobgt_dropout_keep_host() -- so the backward
+ *             regenerates it.  `seed_dev` (may be NULL) is a device uint64 added to `seed` (lets a
+ *             captured graph advance the seed without re-capture).
+ */
+int mobgt_attn_bias_fwd(const void* q, const void* k, const void* v, const void* bias,
+                        void* out, float* lse,
+                        int G, int H, int T, int d,
+                        int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, int64_t ld_bias,
+                        float scale, float dropout_p, uint64_t seed, const uint64_t* seed_dev,
+                        int io_dtype, int bias_dtype, void* stream);
+
+/* Backward of the above (autograd of model.py:442-453).
+ * bias_t : [G, H, T, ld_bias] the same bias with query/key transposed (bias_t[g,h,j,i] = bias[g,h,i,j]),
+ *          produced by mobgt_build_bias / mobgt_bias_pack; read by the dK/dV pass.
+ * dout   : [G, T, H*d] (ldo), gradient of `out`.
+ * dq,dk,dv : [G, T, H*d] `io_dtype`, row strides lddq/lddk/lddv; fully overwritten.
+ * dbias  : [G, H, T, ld_bias] f32 or NULL.  accumulate_dbias != 0: dbias += dS (the bias is shared by
+ *          all L layers, model.py:207-208); == 0: dbias = dS.  Columns >= T are left untouched.
+ * delta  : [G, H, T] f32 workspace (rowsum(dout*out)), written by the first pass.
+ */
+int mobgt_attn_bias_bwd(const void* q, const void* k, const void* v, const void* bias, const void* bias_t,
+                        const void* out, const float* lse, const void* dout,
+                        void* dq, void* dk, void* dv, float* dbias, float* delta,
+                        int G, int H, int T, int d,
+                        int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo,
+                        int64_t lddq, int64_t lddk, int64_t lddv, int64_t ld_bias,
+                        float scale, float dropout_p, uint64_t seed, const uint64_t* seed_dev,
+                        int accumulate_dbias, int io_dtype, int bias_dtype, void* stream);
+
+/* Host-side statement of the dropout keep rule used by both kernels (for tests / replay).
+ * Returns 1 if probability element (g,h,i,j) is kept. */
+int mobgt_dropout_keep_host(uint64_t seed, int H, int T, int g, int h, int i, int j, float dropout_p);
+
+/* ------------------------------------------------------------------------------------------------
+ * Re-layout of a caller-supplied attention bias into the padded row-major + transposed pair the
+ * attention kernels read.  Used when EncoderLayer/MultiHeadAttention are called with an arbitrary
+ * `attn_bias` tensor (model.py:479-481), i.e. not produced by mobgt_build_bias.
+ * src: [G,H,T,T] with element strides (s_g, s_h, s_i, s_j) (s_h may be 0 for a broadcast head dim).
+ */
+int mobgt_bias_pack(const void* src, int src_dtype, int64_t s_g, int64_t s_h, int64_t s_i, int64_t s_j,
+                    void* bias, void* bias_t, int bias_dtype,
+                    int G, int H, int T, int64_t ld_bias, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Attention-bias assembly fused with the multi-hop edge-feature reduce.  Replaces
+ *     graphormer/model.py:126-190            (stock: rel_pos + virtual-token column + edge term + 2*attn_bias)
+ *     graphormer/model_fqandtoyo.py:1143-1216 (fq: additionally poi_pos; fp16 rounding points)
+ *
+ * attn_bias : [G, T, T] f32 (0 / -inf from the collator, collator.py:57-64); counted twice (model.py:190)
+ * rel_pos   : [G, N, N] indices into rel_table [n_rel, H]    (dtype idx_dtype)
+ * poi_pos   : [G, N, N] indices into poi_table [n_poi, H], or NULL (stock variant)
+ * edge_input: [G, N, N, D_in, F] indices (edge_dtype) into the fused hop table; only the first
+ *             D = min(D_in, multi_hop_max_dist) hops are read (model.py:163)
+ * hop_table : [D, n_edge, H] f32 = sum_h' edge_encoder[e,h'] * edge_dis_encoder[d,h',h] (model.py:166-176),
+ *             built by the host module with the fq variant's fp16 rounding points applied when asked;
+ *             the per-pair reduce is  sum_d mean_f hop_table[d, edge_input[..,d,f], :] / spd  (model.py:180-182)
+ * vdist     : [H] graph_token_virtual_distance.weight (added to column 0 of rows 1..N only, model.py:139-151)
+ * bias, bias_t : outputs, [G, H, T, ld_bias] bias_dtype (see mobgt_attn_bias_fwd); columns T..ld_bias-1 = -inf
+ */
+int mobgt_build_bias(const float* attn_bias, const void* rel_pos, const void* poi_pos, const void* edge_input,
+                     const float* rel_table, const float* poi_table, const float* hop_table, const float* vdist,
+                     void* bias, void* bias_t,
+                     int G, int N, int H, int D_in, int D, int F, int n_rel, int n_poi, int n_edge,
+                     int64_t ld_bias, int idx_dtype, int edge_dtype, int bias_dtype, void* stream);
+
+/* Backward of mobgt_build_bias: scatters dbias [G,H,T,ld_bias] f32 (sum over layers) into the table
+ * gradients (all f32, ACCUMULATED into -- zero them first):
+ *   d_rel_table [n_rel,H], d_poi_table [n_poi,H] (or NULL), d_hop_table [D,n_edge,H], d_vdist [H].
+ * Entries where attn_bias is -inf carry no gradient and are skipped.
+ */
+int mobgt_build_bias_bwd(const float* dbias, const float* attn_bias, const void* rel_pos, const void* poi_pos,
+                         const void* edge_input,
+                         float* d_rel_table, float* d_poi_table, float* d_hop_table, float* d_vdist,
+                         int G, int N, int H, int D_in, int D, int F, int n_rel, int n_poi, int n_edge,
+                         int64_t ld_bias, int idx_dtype, int edge_dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Batched shortest-path preprocessing on the device.  Replaces, for a whole padded batch,
+ *     graphormer/algos.pyx:9-54   floyd_warshall   (bit-exact M and path, 510 sentinel, k-sequential)
+ *     graphormer/algos.pyx:57-96  get_all_edges + gen_edge_input (first D hops only; node-0 quirk kept)
+ *     graphormer/wrapper.py:55-61,97-98 and the +1 / pad-0 shifts of collator.py:76-93
+ *
+ * counts   : [G, N, N] int32 transition counts (0 = no edge), rows/cols >= n_nodes[g] ignored
+ * n_nodes  : [G] int32 real node count per graph
+ * spd      : [G, N, N] int16 out: raw M (0..510) for real pairs, -1 for padding   (wrapper.py:61)
+ * path     : [G, N, N] int16 out: raw path matrix, -1 for padding
+ * rel_pos  : [G, N, N] int16 out: M+1 for real pairs, 0 for padding                (collator.py:76-83)
+ * edge_input: [G, N, N, D, 1] uint8 out: hop feature+1 (= count+3 on an edge, 1 on a non-edge hop of a
+ *             truncated path, 0 = no hop / padding)                                 (collator.py:86-93)
+ * in_degree/out_degree: [G, N] int16 out: row-sum+1 / col-sum+1 of the 0/1 adjacency, 0 for padding
+ *             (wrapper.py:97-98 naming kept; collator.py:11-18)
+ * work     : scratch, mobgt_spd_workspace_bytes(G, N) bytes
+ * Counts above 252 saturate the uint8 hop feature (the reference's edge tables have 128 rows).
+ */
+int64_t mobgt_spd_workspace_bytes(int G, int N);
+int mobgt_spd_batched(const int32_t* counts, const int32_t* n_nodes,
+                      int16_t* spd, int16_t* path, int16_t* rel_pos, uint8_t* edge_input,
+                      int16_t* in_degree, int16_t* out_degree, void* work,
+                      int G, int N, int D, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Embedding gathers.
+ *   out[r, :] = sum_t table_t[idx_t[r], :]   for up to 4 tables of equal width C   (f32)
+ * Replaces the node-feature gathers of model.py:193-203 (atom + in-degree + out-degree) and of
+ * model_fqandtoyo.py:1259-1264,1288-1298 (POI / category / time-slot / degree / position rows).
+ * idx_t: [R] int64 or int32 (idx_dtype); a negative index contributes nothing.
+ */
+int mobgt_embed_gather_sum(const float* const* tables_host, const void* const* idx_host, int n_tables,
+                           float* out, int64_t R, int C, int64_t ld_out, int idx_dtype, void* stream);
+/* Backward: d_table_t[idx_t[r], :] += dout[r, :] (f32 atomics); rows with idx == skip_idx_t or < 0 are skipped
+ * (nn.Embedding(padding_idx=0) semantics when skip = 0, pass -1 to keep every row). */
+int mobgt_embed_scatter_add(float* const* d_tables_host, const void* const* idx_host, const int64_t* skip_idx_host,
+                            int n_tables, const float* dout, int64_t R, int C, int64_t ld_dout,
+                            int idx_dtype, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MOBGT_HIP_H */

@@ -1,0 +1,77 @@
+"""ctypes binding of libmobgt_hip.so (the C ABI declared in include/mobgt_hip.h).
+
+There is no CPU fallback: importing this module works anywhere (so that CPU-only tests can check
+the exported symbols), but every compute entry point raises if the library is missing, and the
+library itself only contains gfx950 code objects.
+"""
+import ctypes
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmobgt_hip.so")
+CSRC = os.path.join(_HERE, "csrc")
+
+F32, BF16 = 0, 1
+I64, I32, I16, U8 = 0, 1, 2, 3
+
+_c = ctypes
+_vp, _i, _i64, _f, _u64 = _c.c_void_p, _c.c_int, _c.c_int64, _c.c_float, _c.c_uint64
+
+SIGNATURES = {
+    "mobgt_abi_version": (_i, []),
+    "mobgt_build_info": (_c.c_char_p, []),
+    "mobgt_attn_bias_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i64, _i64, _i64, _i64, _i64,
+                                 _f, _f, _u64, _vp, _i, _i, _vp]),
+    "mobgt_attn_bias_bwd": (_i, [_vp] * 13 + [_i, _i, _i, _i] + [_i64] * 8 + [_f, _f, _u64, _vp, _i, _i, _i, _vp]),
+    "mobgt_dropout_keep_host": (_i, [_u64, _i, _i, _i, _i, _i, _i, _f]),
+    "mobgt_bias_pack": (_i, [_vp, _i, _i64, _i64, _i64, _i64, _vp, _vp, _i, _i, _i, _i, _i64, _vp]),
+    "mobgt_build_bias": (_i, [_vp] * 10 + [_i] * 9 + [_i64, _i, _i, _i, _vp]),
+    "mobgt_build_bias_bwd": (_i, [_vp] * 9 + [_i] * 9 + [_i64, _i, _i, _vp]),
+    "mobgt_spd_workspace_bytes": (_i64, [_i, _i]),
+    "mobgt_spd_batched": (_i, [_vp] * 9 + [_i, _i, _i, _vp]),
+    "mobgt_embed_gather_sum": (_i, [_vp, _vp, _i, _vp, _i64, _i, _i64, _i, _vp]),
+    "mobgt_embed_scatter_add": (_i, [_vp, _vp, _vp, _i, _vp, _i64, _i, _i64, _i, _vp]),
+}
+
+_lib = None
+
+
+def build(force=False):
+    """Compile every HIP source for gfx950 (hipcc cross-compiles without a GPU)."""
+    srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h"))]
+    srcs.append(os.path.join(os.path.dirname(_HERE), "include", "mobgt_hip.h"))
+    stale = force or not os.path.exists(LIB_PATH) or \
+        any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs)
+    if stale:
+        subprocess.check_call(["make", "-s", "-j4", "-C", CSRC])
+    return LIB_PATH
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: the MobGT hot path has no CPU fallback. "
+                "Build it with `python -c 'import __graft_entry__ as g; g.build()'` (needs hipcc).")
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)          # AttributeError here = header/library mismatch
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+    return _lib
+
+
+class MobgtError(RuntimeError):
+    pass
+
+
+_ERR = {-1: "unsupported dimension (MOBGT_EBADDIM)", -2: "alignment/stride violation (MOBGT_EALIGN)",
+        -3: "unknown dtype code (MOBGT_EDTYPE)"}
+
+
+def check(rc, what):
+    if rc != 0:
+        raise MobgtError(f"{what} failed: {_ERR.get(rc, f'hipError_t {rc}')}")

@@ -1,0 +1,599 @@
+// Bias-fused multi-head attention for MobGT on gfx950 (MI355X): forward, dQ/dBias pass, dK/dV pass.
+//
+// Replaces graphormer/model.py:436-455 (== model_fqandtoyo.py:1687-1706) and its autograd.
+//
+// Orientation ("swapped QK^T"): every product is issued so that the softmax axis lies in a lane's
+// registers.  With v_mfma_f32_32x32x16_bf16 computing S^T = K_tile (A) x Q^T (B), lane (n, hi) holds,
+// thanks to the kappa() row permutation on the A operand, the 16 CONTIGUOUS keys key0+16*hi .. +15 of
+// query row q0+n.  Consequences:
+//   * the bias tile (the dominant HBM stream: H*T*T elements per graph per layer) is loaded as
+//     16 contiguous elements per lane straight into the accumulator (bias is the MFMA's C operand:
+//     the "+ attn_bias" of model.py:445 costs no VALU);
+//   * row max / row sum are 16 in-register ops + one cross-half exchange (wave shuffle);
+//   * P (and dS in the backward) is already the B operand of the following P.V product, no LDS trip.
+// K and V^T (fwd), K/V/K^T (dQ pass), Q/dO and their transposes (dK/dV pass) are staged per 64-row
+// chunk in LDS as bf16; fp32 inputs are rounded to bf16 while staging, accumulation is fp32.
+#include "common.h"
+#include "mobgt_hip.h"
+
+namespace {
+
+constexpr int KC = 64;        // keys (or queries, in the dK/dV pass) staged per LDS chunk = 2 MFMA tiles
+constexpr int ROWP = 40;      // row-major tile row pitch in bf16 (32 + 8: odd multiple of 16 B)
+constexpr int COLP = KC + 8;  // transposed tile row pitch in bf16 (144 B = 9 * 16 B)
+
+struct AttnParams {
+    const void *q, *k, *v, *bias, *bias_t, *out, *dout;
+    void *o, *dq, *dk, *dv;
+    float* lse;
+    const float* lse_in;
+    float *dbias, *delta;
+    int G, H, T;
+    int64_t ldq, ldk, ldv, ldo, lddq, lddk, lddv, ld_bias;
+    float scale, inv_keep;
+    uint32_t drop_thr;
+    uint64_t seed;
+    const uint64_t* seed_dev;
+    int accumulate;
+};
+
+// Stage a [KC x D] row-major slab (rows row0.., row stride ld, head column offset already applied)
+// into LDS as bf16: row-major into `rm` (if RM) and transposed into `tr` (if TR).  Rows >= T and
+// columns >= D are zero-filled; `mul` scales the values (1 or the softmax scale).
+template <int D, typename TQ, int NT, bool RM, bool TR>
+__device__ __forceinline__ void stage_slab(const TQ* __restrict__ src, int64_t ld, int row0, int T, float mul,
+                                           bf16_t (*rm)[ROWP], bf16_t (*tr)[COLP]) {
+    for (int it = threadIdx.x; it < KC * 4; it += NT) {
+        const int r = it >> 2, c0 = (it & 3) * 8;
+        float v[8];
+        if (c0 < D && row0 + r < T) {
+            load8(src + (int64_t)(row0 + r) * ld + c0, v);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] *= mul;
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = 0.f;
+        }
+        const bf16x8 b = pack8(v);
+        if (RM) *reinterpret_cast<bf16x8*>(&rm[r][c0]) = b;
+        if (TR) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) tr[c0 + i][r] = b[i];
+        }
+    }
+}
+
+template <typename TQ>
+__device__ __forceinline__ void load_frag(const TQ* rowptr, bool valid, float mul, bf16x8& f, float (*keep)[8] = nullptr) {
+    float v[8];
+    if (valid) {
+        load8(rowptr, v);
+    } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = 0.f;
+    }
+    if (keep) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) (*keep)[i] = v[i];
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] *= mul;
+    f = pack8(v);
+}
+
+__device__ __forceinline__ float xhalf(float v) { return __shfl_xor(v, 32, 64); }
+
+// =================================================================================== forward
+template <int D, typename TQ, typename TB, int NW, bool DROP>
+__global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const AttnParams p) {
+    constexpr int KS = (D + 15) / 16;
+    constexpr int NT = NW * 64;
+    __shared__ __attribute__((aligned(16))) bf16_t Ks[KC][ROWP];
+    __shared__ __attribute__((aligned(16))) bf16_t Vt[32][COLP];
+
+    const int T = p.T, H = p.H;
+    const int nQ = (T + 32 * NW - 1) / (32 * NW);
+    const int lid = xcd_remap(blockIdx.x, gridDim.x);
+    const int qt = lid % nQ, gh = lid / nQ;
+    const int g = gh / H, h = gh % H;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n = lane & 31, hi = lane >> 5;
+    const int my_q = qt * 32 * NW + wave * 32 + n;
+    const bool q_ok = my_q < T;
+    const int qc = q_ok ? my_q : T - 1;
+
+    const TQ* Q = reinterpret_cast<const TQ*>(p.q) + (int64_t)g * T * p.ldq + h * D;
+    const TQ* K = reinterpret_cast<const TQ*>(p.k) + (int64_t)g * T * p.ldk + h * D;
+    const TQ* V = reinterpret_cast<const TQ*>(p.v) + (int64_t)g * T * p.ldv + h * D;
+    const TB* brow = reinterpret_cast<const TB*>(p.bias) + ((int64_t)gh * T + qc) * p.ld_bias + 16 * hi;
+
+    bf16x8 qf[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+        load_frag(Q + (int64_t)qc * p.ldq + ks * 16 + 8 * hi, q_ok && (ks * 16 + 8 * hi < D), p.scale, qf[ks]);
+
+    uint32_t rowh = 0;
+    uint64_t seed = 0;
+    if (DROP) {
+        seed = p.seed + (p.seed_dev ? *p.seed_dev : 0ull);
+        rowh = dropout_row_hash(seed, (uint32_t)(gh * T + qc));
+    }
+
+    float m = MOBGT_NEG_BIG, l = 0.f;
+    f32x16 o;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) o[i] = 0.f;
+
+    BiasRegs<TB> bcur, bnext;
+    bcur.load(brow);
+
+    const int nchunk = (T + KC - 1) / KC;
+    for (int c = 0; c < nchunk; ++c) {
+        __syncthreads();
+        stage_slab<D, TQ, NT, true, false>(K, p.ldk, c * KC, T, 1.f, Ks, nullptr);
+        stage_slab<D, TQ, NT, false, true>(V, p.ldv, c * KC, T, 1.f, nullptr, Vt);
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int key0 = c * KC + t * 32;
+            if (key0 >= T) break;
+            f32x16 s;
+            bcur.to_acc(s);
+            if (key0 + 32 < T) bnext.load(brow + key0 + 32);       // prefetch the next bias tile
+            if (key0 + 32 > T) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i)
+                    if (key0 + 16 * hi + i >= T) s[i] = -INFINITY;
+            }
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const bf16x8 a = *reinterpret_cast<const bf16x8*>(&Ks[t * 32 + kappa(n)][ks * 16 + 8 * hi]);
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, qf[ks], s, 0, 0, 0);
+            }
+            // online softmax over this lane's 16 keys + the partner half's 16
+            float tmax = s[0];
+#pragma unroll
+            for (int i = 1; i < 16; ++i) tmax = fmaxf(tmax, s[i]);
+            tmax = fmaxf(tmax, xhalf(tmax));
+            const float m_new = fmaxf(m, tmax);
+            if (__any(m_new > m)) {
+                const float alpha = exp2f((m - m_new) * MOBGT_LOG2E);
+#pragma unroll
+                for (int i = 0; i < 16; ++i) o[i] *= alpha;
+                l *= alpha;
+                m = m_new;
+            }
+            const float ms = m * MOBGT_LOG2E;
+            float pr[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                pr[i] = exp2f(fmaf(s[i], MOBGT_LOG2E, -ms));
+                l += pr[i];
+            }
+            if (DROP) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const uint32_t bits = dropout_bits16(seed, rowh, (uint32_t)(key0 + 16 * hi + i));
+                    pr[i] = bits >= p.drop_thr ? pr[i] * p.inv_keep : 0.f;
+                }
+            }
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                float pv[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) pv[j] = pr[8 * s2 + j];
+                const bf16x8 pb = pack8(pv);
+                const bf16x8 a = *reinterpret_cast<const bf16x8*>(&Vt[kappa(n)][t * 32 + 16 * hi + 8 * s2]);
+                o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, pb, o, 0, 0, 0);
+            }
+            bcur = bnext;
+        }
+    }
+
+    const float ltot = l + xhalf(l);
+    const float inv = 1.f / ltot;
+    if (q_ok) {
+        TQ* O = reinterpret_cast<TQ*>(p.o) + ((int64_t)g * T + my_q) * p.ldo + h * D + 16 * hi;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            if (16 * hi + 8 * j < D) {
+                float v[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v[i] = o[8 * j + i] * inv;
+                store8(O + 8 * j, v);
+            }
+        }
+        if (hi == 0) p.lse[(int64_t)gh * T + my_q] = m + logf(ltot);
+    }
+}
+
+// ======================================================================= backward, pass 1: dQ + dBias
+// Same decomposition as the forward (one wave = 32 query rows, sweep over keys).
+template <int D, typename TQ, typename TB, int NW, bool DROP>
+__global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(const AttnParams p) {
+    constexpr int KS = (D + 15) / 16;
+    constexpr int NT = NW * 64;
+    __shared__ __attribute__((aligned(16))) bf16_t Ks[KC][ROWP];
+    __shared__ __attribute__((aligned(16))) bf16_t Vs[KC][ROWP];
+    __shared__ __attribute__((aligned(16))) bf16_t Kt[32][COLP];
+
+    const int T = p.T, H = p.H;
+    const int nQ = (T + 32 * NW - 1) / (32 * NW);
+    const int lid = xcd_remap(blockIdx.x, gridDim.x);
+    const int qt = lid % nQ, gh = lid / nQ;
+    const int g = gh / H, h = gh % H;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n = lane & 31, hi = lane >> 5;
+    const int my_q = qt * 32 * NW + wave * 32 + n;
+    const bool q_ok = my_q < T;
+    const int qc = q_ok ? my_q : T - 1;
+
+    const TQ* Q = reinterpret_cast<const TQ*>(p.q) + (int64_t)g * T * p.ldq + h * D;
+    const TQ* K = reinterpret_cast<const TQ*>(p.k) + (int64_t)g * T * p.ldk + h * D;
+    const TQ* V = reinterpret_cast<const TQ*>(p.v) + (int64_t)g * T * p.ldv + h * D;
+    const TQ* O = reinterpret_cast<const TQ*>(p.out) + (int64_t)g * T * p.ldo + h * D;
+    const TQ* dO = reinterpret_cast<const TQ*>(p.dout) + (int64_t)g * T * p.ldo + h * D;
+    const TB* brow = reinterpret_cast<const TB*>(p.bias) + ((int64_t)gh * T + qc) * p.ld_bias + 16 * hi;
+    float* dbrow = p.dbias ? p.dbias + ((int64_t)gh * T + qc) * p.ld_bias + 16 * hi : nullptr;
+
+    bf16x8 qf[KS], dof[KS];
+    float dpart = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        const bool ok = q_ok && (ks * 16 + 8 * hi < D);
+        load_frag(Q + (int64_t)qc * p.ldq + ks * 16 + 8 * hi, ok, p.scale, qf[ks]);
+        float dov[8], ov[8];
+        load_frag(dO + (int64_t)qc * p.ldo + ks * 16 + 8 * hi, ok, 1.f, dof[ks], &dov);
+        bf16x8 unused;
+        load_frag(O + (int64_t)qc * p.ldo + ks * 16 + 8 * hi, ok, 1.f, unused, &ov);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) dpart = fmaf(dov[i], ov[i], dpart);
+    }
+    const float delta = dpart + xhalf(dpart);                      // rowsum(dO * O)
+    if (q_ok && hi == 0) p.delta[(int64_t)gh * T + my_q] = delta;
+    const float lse2 = p.lse_in[(int64_t)gh * T + qc] * MOBGT_LOG2E;
+
+    uint32_t rowh = 0;
+    uint64_t seed = 0;
+    if (DROP) {
+        seed = p.seed + (p.seed_dev ? *p.seed_dev : 0ull);
+        rowh = dropout_row_hash(seed, (uint32_t)(gh * T + qc));
+    }
+
+    f32x16 dq;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) dq[i] = 0.f;
+
+    BiasRegs<TB> bcur, bnext;
+    bcur.load(brow);
+
+    const int nchunk = (T + KC - 1) / KC;
+    for (int c = 0; c < nchunk; ++c) {
+        __syncthreads();
+        stage_slab<D, TQ, NT, true, true>(K, p.ldk, c * KC, T, 1.f, Ks, Kt);
+        stage_slab<D, TQ, NT, true, false>(V, p.ldv, c * KC, T, 1.f, Vs, nullptr);
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int key0 = c * KC + t * 32;
+            if (key0 >= T) break;
+            f32x16 s, dp;
+            bcur.to_acc(s);
+            if (key0 + 32 < T) bnext.load(brow + key0 + 32);
+            const bool tail = key0 + 32 > T;
+            if (tail) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i)
+                    if (key0 + 16 * hi + i >= T) s[i] = -INFINITY;
+            }
+#pragma unroll
+            for (int i = 0; i < 16; ++i) dp[i] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const bf16x8 ak = *reinterpret_cast<const bf16x8*>(&Ks[t * 32 + kappa(n)][ks * 16 + 8 * hi]);
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ak, qf[ks], s, 0, 0, 0);
+                const bf16x8 av = *reinterpret_cast<const bf16x8*>(&Vs[t * 32 + kappa(n)][ks * 16 + 8 * hi]);
+                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, dof[ks], dp, 0, 0, 0);
+            }
+            float ds[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const float pr = exp2f(fmaf(s[i], MOBGT_LOG2E, -lse2));
+                float dpv = dp[i];
+                if (DROP) {
+                    const uint32_t bits = dropout_bits16(seed, rowh, (uint32_t)(key0 + 16 * hi + i));
+                    dpv = bits >= p.drop_thr ? dpv * p.inv_keep : 0.f;
+                }
+                ds[i] = pr * (dpv - delta);
+            }
+            if (dbrow && q_ok) {
+                float* dst = dbrow + key0;
+                if (!tail) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        float4 v = make_float4(ds[4 * j], ds[4 * j + 1], ds[4 * j + 2], ds[4 * j + 3]);
+                        if (p.accumulate) {
+                            const float4 old = reinterpret_cast<const float4*>(dst)[j];
+                            v.x += old.x; v.y += old.y; v.z += old.z; v.w += old.w;
+                        }
+                        reinterpret_cast<float4*>(dst)[j] = v;
+                    }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 16; ++i)
+                        if (key0 + 16 * hi + i < T) dst[i] = p.accumulate ? dst[i] + ds[i] : ds[i];
+                }
+            }
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                float dv8[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) dv8[j] = ds[8 * s2 + j];
+                const bf16x8 db = pack8(dv8);
+                const bf16x8 a = *reinterpret_cast<const bf16x8*>(&Kt[kappa(n)][t * 32 + 16 * hi + 8 * s2]);
+                dq = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, db, dq, 0, 0, 0);
+            }
+            bcur = bnext;
+        }
+    }
+
+    if (q_ok) {
+        TQ* DQ = reinterpret_cast<TQ*>(p.dq) + ((int64_t)g * T + my_q) * p.lddq + h * D + 16 * hi;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            if (16 * hi + 8 * j < D) {
+                float v[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v[i] = dq[8 * j + i] * p.scale;
+                store8(DQ + 8 * j, v);
+            }
+        }
+    }
+}
+
+// ======================================================================= backward, pass 2: dK + dV
+// One wave = 32 keys (on the lanes), sweep over queries; reads the TRANSPOSED bias so that a lane's
+// 16 accumulator registers are again 16 contiguous elements (queries q0+16*hi .. +15 of its key row).
+template <int D, typename TQ, typename TB, int NW, bool DROP>
+__global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_kernel(const AttnParams p) {
+    constexpr int KS = (D + 15) / 16;
+    constexpr int NT = NW * 64;
+    __shared__ __attribute__((aligned(16))) bf16_t Qs[KC][ROWP];
+    __shared__ __attribute__((aligned(16))) bf16_t dOs[KC][ROWP];
+    __shared__ __attribute__((aligned(16))) bf16_t Qt[32][COLP];
+    __shared__ __attribute__((aligned(16))) bf16_t dOt[32][COLP];
+    __shared__ __attribute__((aligned(16))) float lseS[KC];
+    __shared__ __attribute__((aligned(16))) float dlS[KC];
+
+    const int T = p.T, H = p.H;
+    const int nK = (T + 32 * NW - 1) / (32 * NW);
+    const int lid = xcd_remap(blockIdx.x, gridDim.x);
+    const int kt = lid % nK, gh = lid / nK;
+    const int g = gh / H, h = gh % H;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n = lane & 31, hi = lane >> 5;
+    const int my_k = kt * 32 * NW + wave * 32 + n;
+    const bool k_ok = my_k < T;
+    const int kc = k_ok ? my_k : T - 1;
+
+    const TQ* Q = reinterpret_cast<const TQ*>(p.q) + (int64_t)g * T * p.ldq + h * D;
+    const TQ* K = reinterpret_cast<const TQ*>(p.k) + (int64_t)g * T * p.ldk + h * D;
+    const TQ* V = reinterpret_cast<const TQ*>(p.v) + (int64_t)g * T * p.ldv + h * D;
+    const TQ* dO = reinterpret_cast<const TQ*>(p.dout) + (int64_t)g * T * p.ldo + h * D;
+    const TB* brow = reinterpret_cast<const TB*>(p.bias_t) + ((int64_t)gh * T + kc) * p.ld_bias + 16 * hi;
+
+    bf16x8 kf[KS], vf[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        const bool ok = k_ok && (ks * 16 + 8 * hi < D);
+        load_frag(K + (int64_t)kc * p.ldk + ks * 16 + 8 * hi, ok, 1.f, kf[ks]);
+        load_frag(V + (int64_t)kc * p.ldv + ks * 16 + 8 * hi, ok, 1.f, vf[ks]);
+    }
+    uint64_t seed = 0;
+    if (DROP) seed = p.seed + (p.seed_dev ? *p.seed_dev : 0ull);
+
+    f32x16 dk, dv;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { dk[i] = 0.f; dv[i] = 0.f; }
+
+    BiasRegs<TB> bcur, bnext;
+    bcur.load(brow);
+
+    const int nchunk = (T + KC - 1) / KC;
+    for (int c = 0; c < nchunk; ++c) {
+        __syncthreads();
+        stage_slab<D, TQ, NT, true, true>(Q, p.ldq, c * KC, T, p.scale, Qs, Qt);
+        stage_slab<D, TQ, NT, true, true>(dO, p.ldo, c * KC, T, 1.f, dOs, dOt);
+        for (int it = threadIdx.x; it < KC; it += NT) {
+            const int q = c * KC + it;
+            lseS[it] = q < T ? p.lse_in[(int64_t)gh * T + q] * MOBGT_LOG2E : 0.f;
+            dlS[it] = q < T ? p.delta[(int64_t)gh * T + q] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int q0 = c * KC + t * 32;
+            if (q0 >= T) break;
+            f32x16 s, dp;
+            bcur.to_acc(s);
+            if (q0 + 32 < T) bnext.load(brow + q0 + 32);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) dp[i] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const bf16x8 aq = *reinterpret_cast<const bf16x8*>(&Qs[t * 32 + kappa(n)][ks * 16 + 8 * hi]);
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq, kf[ks], s, 0, 0, 0);
+                const bf16x8 ad = *reinterpret_cast<const bf16x8*>(&dOs[t * 32 + kappa(n)][ks * 16 + 8 * hi]);
+                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ad, vf[ks], dp, 0, 0, 0);
+            }
+            float lse16[16], dl16[16];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float4 a = *reinterpret_cast<const float4*>(&lseS[t * 32 + 16 * hi + 4 * j]);
+                const float4 b = *reinterpret_cast<const float4*>(&dlS[t * 32 + 16 * hi + 4 * j]);
+                lse16[4 * j] = a.x; lse16[4 * j + 1] = a.y; lse16[4 * j + 2] = a.z; lse16[4 * j + 3] = a.w;
+                dl16[4 * j] = b.x; dl16[4 * j + 1] = b.y; dl16[4 * j + 2] = b.z; dl16[4 * j + 3] = b.w;
+            }
+            float pd[16], ds[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int q = q0 + 16 * hi + i;
+                float pr = exp2f(fmaf(s[i], MOBGT_LOG2E, -lse16[i]));
+                if (q >= T || !k_ok) pr = 0.f;
+                float dpv = dp[i], prd = pr;
+                if (DROP) {
+                    const uint32_t rowh = dropout_row_hash(seed, (uint32_t)(gh * T + (q < T ? q : T - 1)));
+                    const uint32_t bits = dropout_bits16(seed, rowh, (uint32_t)kc);
+                    const bool keep = bits >= p.drop_thr;
+                    dpv = keep ? dpv * p.inv_keep : 0.f;
+                    prd = keep ? pr * p.inv_keep : 0.f;
+                }
+                pd[i] = prd;
+                ds[i] = pr * (dpv - dl16[i]);
+            }
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                float a8[8], b8[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { a8[j] = pd[8 * s2 + j]; b8[j] = ds[8 * s2 + j]; }
+                const bf16x8 pb = pack8(a8), db = pack8(b8);
+                const bf16x8 ado = *reinterpret_cast<const bf16x8*>(&dOt[kappa(n)][t * 32 + 16 * hi + 8 * s2]);
+                dv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ado, pb, dv, 0, 0, 0);
+                const bf16x8 aq = *reinterpret_cast<const bf16x8*>(&Qt[kappa(n)][t * 32 + 16 * hi + 8 * s2]);
+                dk = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq, db, dk, 0, 0, 0);
+            }
+            bcur = bnext;
+        }
+    }
+
+    if (k_ok) {
+        TQ* DK = reinterpret_cast<TQ*>(p.dk) + ((int64_t)g * T + my_k) * p.lddk + h * D + 16 * hi;
+        TQ* DV = reinterpret_cast<TQ*>(p.dv) + ((int64_t)g * T + my_k) * p.lddv + h * D + 16 * hi;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            if (16 * hi + 8 * j < D) {
+                float a[8], b[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) { a[i] = dk[8 * j + i]; b[i] = dv[8 * j + i]; }
+                store8(DK + 8 * j, a);
+                store8(DV + 8 * j, b);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------ dispatch
+enum Pass { FWD, BWD_DQ, BWD_DKV };
+
+template <Pass PASS, int D, typename TQ, typename TB, int NW, bool DROP>
+hipError_t launch_one(const AttnParams& p, hipStream_t st) {
+    const int tiles = (p.T + 32 * NW - 1) / (32 * NW);
+    const dim3 grid((unsigned)(p.G * p.H * tiles)), block(NW * 64);
+    if (PASS == FWD) hipLaunchKernelGGL((attn_fwd_kernel<D, TQ, TB, NW, DROP>), grid, block, 0, st, p);
+    else if (PASS == BWD_DQ) hipLaunchKernelGGL((attn_bwd_dq_kernel<D, TQ, TB, NW, DROP>), grid, block, 0, st, p);
+    else hipLaunchKernelGGL((attn_bwd_dkv_kernel<D, TQ, TB, NW, DROP>), grid, block, 0, st, p);
+    return hipGetLastError();
+}
+
+template <Pass PASS, int D, typename TQ, typename TB>
+hipError_t launch_nw(const AttnParams& p, bool drop, hipStream_t st) {
+    // small graphs: fewer waves per workgroup -> more workgroups to spread over the 256 CUs
+    const int nw = p.T <= 32 ? 1 : (p.T <= 64 ? 2 : 4);
+    if (drop) {
+        if (nw == 1) return launch_one<PASS, D, TQ, TB, 1, true>(p, st);
+        if (nw == 2) return launch_one<PASS, D, TQ, TB, 2, true>(p, st);
+        return launch_one<PASS, D, TQ, TB, 4, true>(p, st);
+    }
+    if (nw == 1) return launch_one<PASS, D, TQ, TB, 1, false>(p, st);
+    if (nw == 2) return launch_one<PASS, D, TQ, TB, 2, false>(p, st);
+    return launch_one<PASS, D, TQ, TB, 4, false>(p, st);
+}
+
+template <Pass PASS, typename TQ, typename TB>
+int launch_d(const AttnParams& p, int d, bool drop, hipStream_t st) {
+    switch (d) {
+        case 16: return (int)launch_nw<PASS, 16, TQ, TB>(p, drop, st);
+        case 24: return (int)launch_nw<PASS, 24, TQ, TB>(p, drop, st);
+        case 32: return (int)launch_nw<PASS, 32, TQ, TB>(p, drop, st);
+        default: return MOBGT_EBADDIM;
+    }
+}
+
+template <Pass PASS>
+int launch(const AttnParams& p, int d, int io_dtype, int bias_dtype, bool drop, hipStream_t st) {
+    if (io_dtype == MOBGT_F32 && bias_dtype == MOBGT_F32) return launch_d<PASS, float, float>(p, d, drop, st);
+    if (io_dtype == MOBGT_F32 && bias_dtype == MOBGT_BF16) return launch_d<PASS, float, bf16_t>(p, d, drop, st);
+    if (io_dtype == MOBGT_BF16 && bias_dtype == MOBGT_F32) return launch_d<PASS, bf16_t, float>(p, d, drop, st);
+    if (io_dtype == MOBGT_BF16 && bias_dtype == MOBGT_BF16) return launch_d<PASS, bf16_t, bf16_t>(p, d, drop, st);
+    return MOBGT_EDTYPE;
+}
+
+bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+int check_common(int G, int H, int T, int d, int64_t ld_bias, int io_dtype, int64_t lds_min_mult) {
+    if (G <= 0 || H <= 0 || T <= 0) return MOBGT_EBADDIM;
+    if (d != 16 && d != 24 && d != 32) return MOBGT_EBADDIM;
+    if (ld_bias % 32 != 0 || ld_bias < T) return MOBGT_EALIGN;
+    (void)io_dtype; (void)lds_min_mult;
+    return 0;
+}
+
+void set_dropout(AttnParams& p, float dropout_p, uint64_t seed, const uint64_t* seed_dev) {
+    p.drop_thr = dropout_p > 0.f ? dropout_threshold(dropout_p) : 0u;
+    p.inv_keep = p.drop_thr ? 1.f / (1.f - (float)p.drop_thr / 65536.f) : 1.f;
+    p.seed = seed;
+    p.seed_dev = seed_dev;
+}
+
+}  // namespace
+
+extern "C" int mobgt_attn_bias_fwd(const void* q, const void* k, const void* v, const void* bias, void* out, float* lse,
+                                   int G, int H, int T, int d, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo,
+                                   int64_t ld_bias, float scale, float dropout_p, uint64_t seed,
+                                   const uint64_t* seed_dev, int io_dtype, int bias_dtype, void* stream) {
+    int rc = check_common(G, H, T, d, ld_bias, io_dtype, 8);
+    if (rc) return rc;
+    if (!aligned16(q) || !aligned16(k) || !aligned16(v) || !aligned16(out) || !aligned16(bias)) return MOBGT_EALIGN;
+    if ((ldq | ldk | ldv | ldo) % 8 != 0) return MOBGT_EALIGN;
+    AttnParams p = {};
+    p.q = q; p.k = k; p.v = v; p.bias = bias; p.o = out; p.lse = lse;
+    p.G = G; p.H = H; p.T = T;
+    p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo; p.ld_bias = ld_bias;
+    p.scale = scale;
+    set_dropout(p, dropout_p, seed, seed_dev);
+    return launch<FWD>(p, d, io_dtype, bias_dtype, p.drop_thr != 0, (hipStream_t)stream);
+}
+
+extern "C" int mobgt_attn_bias_bwd(const void* q, const void* k, const void* v, const void* bias, const void* bias_t,
+                                   const void* out, const float* lse, const void* dout, void* dq, void* dk, void* dv,
+                                   float* dbias, float* delta, int G, int H, int T, int d, int64_t ldq, int64_t ldk,
+                                   int64_t ldv, int64_t ldo, int64_t lddq, int64_t lddk, int64_t lddv, int64_t ld_bias,
+                                   float scale, float dropout_p, uint64_t seed, const uint64_t* seed_dev,
+                                   int accumulate_dbias, int io_dtype, int bias_dtype, void* stream) {
+    int rc = check_common(G, H, T, d, ld_bias, io_dtype, 8);
+    if (rc) return rc;
+    if (!aligned16(q) || !aligned16(k) || !aligned16(v) || !aligned16(out) || !aligned16(dout) || !aligned16(bias) ||
+        !aligned16(bias_t) || !aligned16(dq) || !aligned16(dk) || !aligned16(dv) || !aligned16(dbias))
+        return MOBGT_EALIGN;
+    if ((ldq | ldk | ldv | ldo | lddq | lddk | lddv) % 8 != 0) return MOBGT_EALIGN;
+    AttnParams p = {};
+    p.q = q; p.k = k; p.v = v; p.bias = bias; p.bias_t = bias_t; p.out = out; p.dout = dout; p.lse_in = lse;
+    p.dq = dq; p.dk = dk; p.dv = dv; p.dbias = dbias; p.delta = delta;
+    p.G = G; p.H = H; p.T = T;
+    p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo; p.lddq = lddq; p.lddk = lddk; p.lddv = lddv;
+    p.ld_bias = ld_bias;
+    p.scale = scale;
+    p.accumulate = accumulate_dbias;
+    set_dropout(p, dropout_p, seed, seed_dev);
+    const bool drop = p.drop_thr != 0;
+    rc = launch<BWD_DQ>(p, d, io_dtype, bias_dtype, drop, (hipStream_t)stream);
+    if (rc) return rc;
+    return launch<BWD_DKV>(p, d, io_dtype, bias_dtype, drop, (hipStream_t)stream);
+}
+
+extern "C" int mobgt_dropout_keep_host(uint64_t seed, int H, int T, int g, int h, int i, int j, float dropout_p) {
+    const uint32_t thr = dropout_p > 0.f ? dropout_threshold(dropout_p) : 0u;
+    if (!thr) return 1;
+    const uint32_t rowh = dropout_row_hash(seed, (uint32_t)((g * H + h) * T + i));
+    return dropout_bits16(seed, rowh, (uint32_t)j) >= thr ? 1 : 0;
+}

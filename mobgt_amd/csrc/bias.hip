@@ -1,0 +1,312 @@
+// Attention-bias assembly for MobGT on gfx950: fused table gathers + multi-hop edge reduce
+// (graphormer/model.py:126-190, model_fqandtoyo.py:1143-1216), its backward (scatter of dBias into the
+// table gradients), and the re-layout of a caller-supplied bias.
+//
+// One workgroup owns a 32x32 tile of (query node i, key node j) pairs of one graph and produces all H
+// heads of it.  The hop table (sum over h' of edge_encoder x edge_dis_encoder, [D, n_edge, H] f32) is
+// read through L1/L2 (it is a few tens of KB); the per-pair inputs (D*F hop indices, rel_pos, poi_pos,
+// attn_bias) are read once, coalesced along j; the outputs are written twice -- row-major for the
+// forward / dQ pass and transposed (through an LDS tile) for the dK/dV pass -- both coalesced.
+#include "common.h"
+#include "mobgt_hip.h"
+
+namespace {
+
+constexpr int TILE = 32;
+constexpr int MAXH = 32;
+
+template <typename T> __device__ __forceinline__ T to_out(float v);
+template <> __device__ __forceinline__ float to_out<float>(float v) { return v; }
+template <> __device__ __forceinline__ bf16_t to_out<bf16_t>(float v) { return (bf16_t)v; }
+
+__device__ __forceinline__ float ld_as_float(const float* p) { return *p; }
+__device__ __forceinline__ float ld_as_float(const bf16_t* p) { return (float)*p; }
+
+template <typename TI> __device__ __forceinline__ int ld_idx(const void* base, int64_t off) {
+    return (int)reinterpret_cast<const TI*>(base)[off];
+}
+
+// ------------------------------------------------------------------------------------ bias_pack
+template <typename TS, typename TB>
+__global__ __launch_bounds__(256) void bias_pack_kernel(const TS* __restrict__ src, int64_t s_g, int64_t s_h, int64_t s_i,
+                                                       int64_t s_j, TB* __restrict__ bias, TB* __restrict__ bias_t,
+                                                       int H, int T, int64_t ld) {
+    __shared__ float tile[TILE][TILE + 1];
+    const int gh = blockIdx.z, g = gh / H, h = gh % H;
+    const int i0 = blockIdx.y * TILE, j0 = blockIdx.x * TILE;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;      // 32 x 8
+    const TS* s = src + g * s_g + h * s_h;
+    TB* b = bias + (int64_t)gh * T * ld;
+    TB* bt = bias_t ? bias_t + (int64_t)gh * T * ld : nullptr;
+#pragma unroll
+    for (int r = 0; r < TILE; r += 8) {
+        const int i = i0 + ty + r, j = j0 + tx;
+        float v = -INFINITY;
+        if (i < T && j < T) v = ld_as_float(s + i * s_i + j * s_j);
+        tile[ty + r][tx] = v;
+        if (i < T && j < ld) b[(int64_t)i * ld + j] = to_out<TB>(v);
+    }
+    if (!bt) return;
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < TILE; r += 8) {
+        const int j = j0 + ty + r, i = i0 + tx;                  // transposed walk: contiguous along i
+        if (j < T && i < ld) bt[(int64_t)j * ld + i] = to_out<TB>(tile[tx][ty + r]);
+    }
+}
+
+// ------------------------------------------------------------------------------------ build_bias
+struct BuildParams {
+    const float* attn_bias;
+    const void *rel_pos, *poi_pos, *edge_input;
+    const float *rel_table, *poi_table, *hop_table, *vdist;
+    void *bias, *bias_t;
+    const float* dbias;
+    float *d_rel, *d_poi, *d_hop, *d_vdist;
+    int G, N, H, D_in, D, F, n_rel, n_poi, n_edge;
+    int64_t ld;
+};
+
+// SPD divisor of model.py:158-163: pad(0) -> 1, k > 1 -> k-1, clamp to [0, D]
+__device__ __forceinline__ float spd_divisor(int rp, int D) {
+    int s = rp == 0 ? 1 : rp;
+    s = s > 1 ? s - 1 : s;
+    if (D > 0) s = s < 0 ? 0 : (s > D ? D : s);
+    return (float)s;
+}
+
+template <typename TI, typename TE, typename TB, int HH>
+__global__ __launch_bounds__(256) void build_bias_kernel(const BuildParams p) {
+    __shared__ float tile[HH][TILE][TILE + 1];
+    const int g = blockIdx.z;
+    const int N = p.N, T = N + 1;
+    const int i0 = blockIdx.y * TILE, j0 = blockIdx.x * TILE;    // token coordinates (0 = graph token)
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const float inv_f = 1.f / (float)p.F;
+    TB* B = reinterpret_cast<TB*>(p.bias);
+    TB* BT = reinterpret_cast<TB*>(p.bias_t);
+
+#pragma unroll 1
+    for (int r = 0; r < TILE; r += 8) {
+        const int ti = i0 + ty + r, tj = j0 + tx;                // token indices
+        float acc[HH];
+        bool live = ti < T && tj < T;
+        float ab = 0.f;
+        if (live) ab = p.attn_bias[((int64_t)g * T + ti) * T + tj];
+#pragma unroll
+        for (int h = 0; h < HH; ++h) acc[h] = live ? 2.f * ab : -INFINITY;     // attn_bias counted twice (model.py:127,190)
+        if (live && ti >= 1 && tj == 0) {
+#pragma unroll
+            for (int h = 0; h < HH; ++h) acc[h] += p.vdist[h];                 // virtual-token column (model.py:139-151)
+        }
+        if (live && ti >= 1 && tj >= 1) {
+            const int64_t pair = ((int64_t)g * N + (ti - 1)) * N + (tj - 1);
+            const int rp = ld_idx<TI>(p.rel_pos, pair);
+            const float* rrow = p.rel_table + (int64_t)rp * HH;
+#pragma unroll
+            for (int h = 0; h < HH; ++h) acc[h] += rrow[h];
+            if (p.poi_pos) {
+                const int pp = ld_idx<TI>(p.poi_pos, pair);
+                const float* prow = p.poi_table + (int64_t)pp * HH;
+#pragma unroll
+                for (int h = 0; h < HH; ++h) acc[h] += prow[h];
+            }
+            if (p.edge_input) {
+                float e[HH];
+#pragma unroll
+                for (int h = 0; h < HH; ++h) e[h] = 0.f;
+                const int64_t ebase = pair * p.D_in * p.F;
+                for (int d = 0; d < p.D; ++d) {
+                    for (int f = 0; f < p.F; ++f) {
+                        const int idx = ld_idx<TE>(p.edge_input, ebase + (int64_t)d * p.F + f);
+                        const float* hrow = p.hop_table + ((int64_t)d * p.n_edge + idx) * HH;
+#pragma unroll
+                        for (int h = 0; h < HH; ++h) e[h] += hrow[h];
+                    }
+                }
+                const float inv = inv_f / spd_divisor(rp, p.D);
+#pragma unroll
+                for (int h = 0; h < HH; ++h) acc[h] += e[h] * inv;
+            }
+        }
+#pragma unroll
+        for (int h = 0; h < HH; ++h) {
+            tile[h][ty + r][tx] = acc[h];
+            if (ti < T && tj < p.ld) B[(((int64_t)g * HH + h) * T + ti) * p.ld + tj] = to_out<TB>(acc[h]);
+        }
+    }
+    if (!BT) return;
+    __syncthreads();
+#pragma unroll 1
+    for (int r = 0; r < TILE; r += 8) {
+        const int tj = j0 + ty + r, ti = i0 + tx;
+        if (tj < T && ti < p.ld) {
+#pragma unroll
+            for (int h = 0; h < HH; ++h)
+                BT[(((int64_t)g * HH + h) * T + tj) * p.ld + ti] = to_out<TB>(tile[h][tx][ty + r]);
+        }
+    }
+}
+
+// --------------------------------------------------------------------------------- build_bias_bwd
+// dbias[g,h,i,j] (f32, summed over layers) -> d_rel_table[rel_pos], d_poi_table[poi_pos],
+// d_hop_table[d, edge_input[d], :] (scaled by 1/(F*spd)), d_vdist.  Per-workgroup LDS accumulation of
+// the two small index tables, global f32 atomics for the hop table and the flush.
+template <typename TI, typename TE, int HH>
+__global__ __launch_bounds__(256) void build_bias_bwd_kernel(const BuildParams p, int lds_rel, int lds_poi) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* s_rel = smem;                                  // [lds_rel][HH]
+    float* s_poi = smem + (size_t)lds_rel * HH;           // [lds_poi][HH]
+    float* s_vd = s_poi + (size_t)lds_poi * HH;           // [HH]
+    for (int t = threadIdx.x; t < (lds_rel + lds_poi + 1) * HH; t += blockDim.x) smem[t] = 0.f;
+    __syncthreads();
+
+    const int g = blockIdx.z;
+    const int N = p.N, T = N + 1;
+    const int i0 = blockIdx.y * TILE, j0 = blockIdx.x * TILE;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const float inv_f = 1.f / (float)p.F;
+
+#pragma unroll 1
+    for (int r = 0; r < TILE; r += 8) {
+        const int ti = i0 + ty + r, tj = j0 + tx;
+        if (!(ti >= 1 && ti < T && tj < T)) continue;
+        const float ab = p.attn_bias[((int64_t)g * T + ti) * T + tj];
+        if (ab == -INFINITY) continue;                    // -inf entries: probability 0, no gradient
+        float gr[HH];
+#pragma unroll
+        for (int h = 0; h < HH; ++h) gr[h] = p.dbias[(((int64_t)g * HH + h) * T + ti) * p.ld + tj];
+        if (tj == 0) {
+#pragma unroll
+            for (int h = 0; h < HH; ++h) atomicAdd(&s_vd[h], gr[h]);
+            continue;
+        }
+        const int64_t pair = ((int64_t)g * N + (ti - 1)) * N + (tj - 1);
+        const int rp = ld_idx<TI>(p.rel_pos, pair);
+        {
+            float* dst = rp < lds_rel ? s_rel + (size_t)rp * HH : p.d_rel + (int64_t)rp * HH;
+#pragma unroll
+            for (int h = 0; h < HH; ++h) atomicAdd(&dst[h], gr[h]);
+        }
+        if (p.poi_pos) {
+            const int pp = ld_idx<TI>(p.poi_pos, pair);
+            float* dst = pp < lds_poi ? s_poi + (size_t)pp * HH : p.d_poi + (int64_t)pp * HH;
+#pragma unroll
+            for (int h = 0; h < HH; ++h) atomicAdd(&dst[h], gr[h]);
+        }
+        if (p.edge_input) {
+            const float inv = inv_f / spd_divisor(rp, p.D);
+            const int64_t ebase = pair * p.D_in * p.F;
+            for (int d = 0; d < p.D; ++d)
+                for (int f = 0; f < p.F; ++f) {
+                    const int idx = ld_idx<TE>(p.edge_input, ebase + (int64_t)d * p.F + f);
+                    float* dst = p.d_hop + ((int64_t)d * p.n_edge + idx) * HH;
+#pragma unroll
+                    for (int h = 0; h < HH; ++h) atomicAdd(&dst[h], gr[h] * inv);
+                }
+        }
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < lds_rel * HH; t += blockDim.x)
+        if (s_rel[t] != 0.f) atomicAdd(&p.d_rel[t], s_rel[t]);
+    if (p.d_poi)
+        for (int t = threadIdx.x; t < lds_poi * HH; t += blockDim.x)
+            if (s_poi[t] != 0.f) atomicAdd(&p.d_poi[t], s_poi[t]);
+    for (int t = threadIdx.x; t < HH; t += blockDim.x)
+        if (s_vd[t] != 0.f) atomicAdd(&p.d_vdist[t], s_vd[t]);
+}
+
+template <typename TI, typename TE, typename TB>
+int launch_build(const BuildParams& p, hipStream_t st) {
+    const int T = p.N + 1;
+    const int nt = (int)((p.ld + TILE - 1) / TILE);
+    const dim3 grid(nt, (T + TILE - 1) / TILE, p.G), block(256);
+    if (p.H == 8) hipLaunchKernelGGL((build_bias_kernel<TI, TE, TB, 8>), grid, block, 0, st, p);
+    else if (p.H == 4) hipLaunchKernelGGL((build_bias_kernel<TI, TE, TB, 4>), grid, block, 0, st, p);
+    else return MOBGT_EBADDIM;
+    return (int)hipGetLastError();
+}
+
+template <typename TI, typename TE>
+int launch_build_b(const BuildParams& p, int bias_dtype, hipStream_t st) {
+    if (bias_dtype == MOBGT_F32) return launch_build<TI, TE, float>(p, st);
+    if (bias_dtype == MOBGT_BF16) return launch_build<TI, TE, bf16_t>(p, st);
+    return MOBGT_EDTYPE;
+}
+
+template <typename TI, typename TE>
+int launch_build_bwd(const BuildParams& p, hipStream_t st) {
+    const int T = p.N + 1;
+    const dim3 grid((T + TILE - 1) / TILE, (T + TILE - 1) / TILE, p.G), block(256);
+    const int lds_rel = p.n_rel < 512 ? p.n_rel : 512;
+    const int lds_poi = p.poi_pos ? (p.n_poi < 1024 ? p.n_poi : 1024) : 0;
+    const size_t shm = (size_t)(lds_rel + lds_poi + 1) * p.H * sizeof(float);
+    if (p.H == 8) hipLaunchKernelGGL((build_bias_bwd_kernel<TI, TE, 8>), grid, block, shm, st, p, lds_rel, lds_poi);
+    else if (p.H == 4) hipLaunchKernelGGL((build_bias_bwd_kernel<TI, TE, 4>), grid, block, shm, st, p, lds_rel, lds_poi);
+    else return MOBGT_EBADDIM;
+    return (int)hipGetLastError();
+}
+
+#define DISPATCH_IDX(FN, ...)                                                                      \
+    do {                                                                                           \
+        if (idx_dtype == MOBGT_I64 && edge_dtype == MOBGT_I64) return FN<int64_t, int64_t>(__VA_ARGS__); \
+        if (idx_dtype == MOBGT_I64 && edge_dtype == MOBGT_U8) return FN<int64_t, uint8_t>(__VA_ARGS__);  \
+        if (idx_dtype == MOBGT_I32 && edge_dtype == MOBGT_I32) return FN<int32_t, int32_t>(__VA_ARGS__); \
+        if (idx_dtype == MOBGT_I16 && edge_dtype == MOBGT_U8) return FN<int16_t, uint8_t>(__VA_ARGS__);  \
+        if (idx_dtype == MOBGT_I32 && edge_dtype == MOBGT_U8) return FN<int32_t, uint8_t>(__VA_ARGS__);  \
+        return MOBGT_EDTYPE;                                                                       \
+    } while (0)
+
+}  // namespace
+
+extern "C" int mobgt_bias_pack(const void* src, int src_dtype, int64_t s_g, int64_t s_h, int64_t s_i, int64_t s_j,
+                               void* bias, void* bias_t, int bias_dtype, int G, int H, int T, int64_t ld_bias,
+                               void* stream) {
+    if (G <= 0 || H <= 0 || T <= 0) return MOBGT_EBADDIM;
+    if (ld_bias % 32 != 0 || ld_bias < T) return MOBGT_EALIGN;
+    const int nt = (int)(ld_bias / TILE);
+    const dim3 grid(nt, nt, G * H), block(256);
+    hipStream_t st = (hipStream_t)stream;
+#define PACK(TS, TB)                                                                                              \
+    hipLaunchKernelGGL((bias_pack_kernel<TS, TB>), grid, block, 0, st, reinterpret_cast<const TS*>(src), s_g, s_h, \
+                       s_i, s_j, reinterpret_cast<TB*>(bias), reinterpret_cast<TB*>(bias_t), H, T, ld_bias)
+    if (src_dtype == MOBGT_F32 && bias_dtype == MOBGT_F32) PACK(float, float);
+    else if (src_dtype == MOBGT_F32 && bias_dtype == MOBGT_BF16) PACK(float, bf16_t);
+    else if (src_dtype == MOBGT_BF16 && bias_dtype == MOBGT_F32) PACK(bf16_t, float);
+    else if (src_dtype == MOBGT_BF16 && bias_dtype == MOBGT_BF16) PACK(bf16_t, bf16_t);
+    else return MOBGT_EDTYPE;
+#undef PACK
+    return (int)hipGetLastError();
+}
+
+extern "C" int mobgt_build_bias(const float* attn_bias, const void* rel_pos, const void* poi_pos, const void* edge_input,
+                                const float* rel_table, const float* poi_table, const float* hop_table,
+                                const float* vdist, void* bias, void* bias_t, int G, int N, int H, int D_in, int D, int F,
+                                int n_rel, int n_poi, int n_edge, int64_t ld_bias, int idx_dtype, int edge_dtype,
+                                int bias_dtype, void* stream) {
+    if (G <= 0 || N <= 0 || H > MAXH || D < 0 || D > D_in || F <= 0) return MOBGT_EBADDIM;
+    if (ld_bias % 32 != 0 || ld_bias < N + 1) return MOBGT_EALIGN;
+    BuildParams p = {};
+    p.attn_bias = attn_bias; p.rel_pos = rel_pos; p.poi_pos = poi_pos; p.edge_input = D > 0 ? edge_input : nullptr;
+    p.rel_table = rel_table; p.poi_table = poi_table; p.hop_table = hop_table; p.vdist = vdist;
+    p.bias = bias; p.bias_t = bias_t;
+    p.G = G; p.N = N; p.H = H; p.D_in = D_in; p.D = D; p.F = F; p.n_rel = n_rel; p.n_poi = n_poi; p.n_edge = n_edge;
+    p.ld = ld_bias;
+    hipStream_t st = (hipStream_t)stream;
+    DISPATCH_IDX(launch_build_b, p, bias_dtype, st);
+}
+
+extern "C" int mobgt_build_bias_bwd(const float* dbias, const float* attn_bias, const void* rel_pos, const void* poi_pos,
+                                    const void* edge_input, float* d_rel_table, float* d_poi_table, float* d_hop_table,
+                                    float* d_vdist, int G, int N, int H, int D_in, int D, int F, int n_rel, int n_poi,
+                                    int n_edge, int64_t ld_bias, int idx_dtype, int edge_dtype, void* stream) {
+    if (G <= 0 || N <= 0 || H > MAXH || D < 0 || D > D_in || F <= 0) return MOBGT_EBADDIM;
+    BuildParams p = {};
+    p.dbias = dbias; p.attn_bias = attn_bias; p.rel_pos = rel_pos; p.poi_pos = poi_pos;
+    p.edge_input = D > 0 ? edge_input : nullptr;
+    p.d_rel = d_rel_table; p.d_poi = d_poi_table; p.d_hop = d_hop_table; p.d_vdist = d_vdist;
+    p.G = G; p.N = N; p.H = H; p.D_in = D_in; p.D = D; p.F = F; p.n_rel = n_rel; p.n_poi = n_poi; p.n_edge = n_edge;
+    p.ld = ld_bias;
+    hipStream_t st = (hipStream_t)stream;
+    DISPATCH_IDX(launch_build_bwd, p, st);
+}

@@ -1,0 +1,103 @@
+// Shared device helpers for the gfx950 kernels (wave64, MFMA 32x32x16 bf16).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef __bf16 bf16_t;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+#define MOBGT_LOG2E 1.4426950408889634f
+#define MOBGT_LN2 0.6931471805599453f
+#define MOBGT_NEG_BIG (-1.0e30f)
+
+// MFMA row permutation.  v_mfma_f32_32x32x16_bf16 leaves output row m = (i&3) + 8*(i>>2) + 4*hi in
+// accumulator register i of lane half hi.  Feeding the A operand's row m from logical row kappa(m)
+// makes register i of half hi hold logical row 16*hi + i: 16 CONTIGUOUS keys (or head columns) per
+// lane, so bias tiles, dBias tiles and outputs move as 16-byte vectors.
+__device__ __forceinline__ int kappa(int m) { return 16 * ((m >> 2) & 1) + 4 * (m >> 3) + (m & 3); }
+
+__device__ __forceinline__ float bf16_lo(uint32_t w) { return __builtin_bit_cast(float, w << 16); }
+__device__ __forceinline__ float bf16_hi(uint32_t w) { return __builtin_bit_cast(float, w & 0xffff0000u); }
+
+// 8 contiguous elements -> fp32 registers.  p must be 16-byte aligned.
+__device__ __forceinline__ void load8(const float* p, float (&v)[8]) {
+    const float4 a = *reinterpret_cast<const float4*>(p);
+    const float4 b = *reinterpret_cast<const float4*>(p + 4);
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
+    v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+}
+__device__ __forceinline__ void load8(const bf16_t* p, float (&v)[8]) {
+    const uint4 a = *reinterpret_cast<const uint4*>(p);
+    v[0] = bf16_lo(a.x); v[1] = bf16_hi(a.x); v[2] = bf16_lo(a.y); v[3] = bf16_hi(a.y);
+    v[4] = bf16_lo(a.z); v[5] = bf16_hi(a.z); v[6] = bf16_lo(a.w); v[7] = bf16_hi(a.w);
+}
+__device__ __forceinline__ void store8(float* p, const float (&v)[8]) {
+    *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+    *reinterpret_cast<float4*>(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
+}
+__device__ __forceinline__ void store8(bf16_t* p, const float (&v)[8]) {
+    bf16x8 o;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o[i] = (bf16_t)v[i];
+    *reinterpret_cast<bf16x8*>(p) = o;
+}
+__device__ __forceinline__ bf16x8 pack8(const float (&v)[8]) {
+    bf16x8 o;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o[i] = (bf16_t)v[i];
+    return o;
+}
+
+// 16 contiguous bias elements -> the accumulator registers of one lane.
+template <typename TB> struct BiasRegs;
+template <> struct BiasRegs<float> {
+    float4 r[4];
+    __device__ __forceinline__ void load(const float* p) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) r[i] = reinterpret_cast<const float4*>(p)[i];
+    }
+    __device__ __forceinline__ void to_acc(f32x16& s) const {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { s[4 * i] = r[i].x; s[4 * i + 1] = r[i].y; s[4 * i + 2] = r[i].z; s[4 * i + 3] = r[i].w; }
+    }
+};
+template <> struct BiasRegs<bf16_t> {
+    uint4 r[2];
+    __device__ __forceinline__ void load(const bf16_t* p) {
+        r[0] = reinterpret_cast<const uint4*>(p)[0];
+        r[1] = reinterpret_cast<const uint4*>(p)[1];
+    }
+    __device__ __forceinline__ void to_acc(f32x16& s) const {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            s[8 * i + 0] = bf16_lo(r[i].x); s[8 * i + 1] = bf16_hi(r[i].x);
+            s[8 * i + 2] = bf16_lo(r[i].y); s[8 * i + 3] = bf16_hi(r[i].y);
+            s[8 * i + 4] = bf16_lo(r[i].z); s[8 * i + 5] = bf16_hi(r[i].z);
+            s[8 * i + 6] = bf16_lo(r[i].w); s[8 * i + 7] = bf16_hi(r[i].w);
+        }
+    }
+};
+
+// ---- attention dropout: keep(seed, row, key) -- a pure function so fwd and bwd agree --------------
+__host__ __device__ __forceinline__ uint32_t mix32(uint32_t x) {
+    x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+    return x;
+}
+// row = (g*H + h)*T + i ; returns 16 random bits for key j
+__host__ __device__ __forceinline__ uint32_t dropout_row_hash(uint64_t seed, uint32_t row) {
+    return mix32(row ^ (uint32_t)seed);
+}
+__host__ __device__ __forceinline__ uint32_t dropout_bits16(uint64_t seed, uint32_t row_hash, uint32_t key) {
+    const uint32_t w = mix32(row_hash + (key >> 1) * 0x9E3779B9u + (uint32_t)(seed >> 32));
+    return (key & 1u) ? (w >> 16) : (w & 0xffffu);
+}
+__host__ __device__ __forceinline__ uint32_t dropout_threshold(float p) { return (uint32_t)(p * 65536.0f + 0.5f); }
+
+// Bijective XCD-aware block remap: blocks b and b+8 share an XCD (round-robin dispatch), so give
+// each XCD a contiguous run of logical ids (neighbouring q-tiles of one (graph, head) share K/V in L2).
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    const int xcd = bid & 7, idx = bid >> 3;
+    const int q = nwg >> 3, r = nwg & 7;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}

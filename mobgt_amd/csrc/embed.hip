@@ -1,0 +1,95 @@
+// Embedding gathers for the node features (graphormer/model.py:193-203, model_fqandtoyo.py:1259-1264,
+// 1288-1298): out[r,:] = sum_t table_t[idx_t[r],:], one wave per output row, 16-byte lanes, and the
+// matching scatter-add backward (f32 atomics; rows equal to the table's padding index are skipped,
+// which is nn.Embedding(padding_idx=0)'s gradient rule).
+#include "common.h"
+#include "mobgt_hip.h"
+
+namespace {
+
+constexpr int MAXT = 4;
+
+struct EmbedParams {
+    const float* tables[MAXT];
+    float* d_tables[MAXT];
+    const void* idx[MAXT];
+    int64_t skip[MAXT];
+    int n_tables;
+    float* out;
+    const float* dout;
+    int64_t R, ld;
+    int C;
+};
+
+template <typename TI>
+__global__ __launch_bounds__(256) void gather_sum_kernel(const EmbedParams p) {
+    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= p.R) return;
+    const int lane = threadIdx.x & 63;
+    int64_t rows[MAXT];
+#pragma unroll
+    for (int t = 0; t < MAXT; ++t) rows[t] = t < p.n_tables ? (int64_t)reinterpret_cast<const TI*>(p.idx[t])[r] : -1;
+    for (int c = lane * 4; c < p.C; c += 256) {
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int t = 0; t < MAXT; ++t) {
+            if (t < p.n_tables && rows[t] >= 0) {
+                const float4 v = *reinterpret_cast<const float4*>(p.tables[t] + rows[t] * p.C + c);
+                acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+            }
+        }
+        *reinterpret_cast<float4*>(p.out + r * p.ld + c) = acc;
+    }
+}
+
+template <typename TI>
+__global__ __launch_bounds__(256) void scatter_add_kernel(const EmbedParams p) {
+    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= p.R) return;
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int t = 0; t < MAXT; ++t) {
+        if (t >= p.n_tables) break;
+        const int64_t row = (int64_t)reinterpret_cast<const TI*>(p.idx[t])[r];
+        if (row < 0 || row == p.skip[t]) continue;
+        float* dst = p.d_tables[t] + row * p.C;
+        for (int c = lane; c < p.C; c += 64) atomicAdd(dst + c, p.dout[r * p.ld + c]);
+    }
+}
+
+}  // namespace
+
+extern "C" int mobgt_embed_gather_sum(const float* const* tables_host, const void* const* idx_host, int n_tables,
+                                      float* out, int64_t R, int C, int64_t ld_out, int idx_dtype, void* stream) {
+    if (n_tables < 1 || n_tables > MAXT || C <= 0 || C % 4 != 0 || ld_out % 4 != 0) return MOBGT_EBADDIM;
+    if (R <= 0) return 0;
+    EmbedParams p = {};
+    for (int t = 0; t < n_tables; ++t) { p.tables[t] = tables_host[t]; p.idx[t] = idx_host[t]; }
+    p.n_tables = n_tables; p.out = out; p.R = R; p.C = C; p.ld = ld_out;
+    const dim3 grid((unsigned)((R + 3) / 4)), block(256);
+    hipStream_t st = (hipStream_t)stream;
+    if (idx_dtype == MOBGT_I64) hipLaunchKernelGGL(gather_sum_kernel<int64_t>, grid, block, 0, st, p);
+    else if (idx_dtype == MOBGT_I32) hipLaunchKernelGGL(gather_sum_kernel<int32_t>, grid, block, 0, st, p);
+    else if (idx_dtype == MOBGT_I16) hipLaunchKernelGGL(gather_sum_kernel<int16_t>, grid, block, 0, st, p);
+    else return MOBGT_EDTYPE;
+    return (int)hipGetLastError();
+}
+
+extern "C" int mobgt_embed_scatter_add(float* const* d_tables_host, const void* const* idx_host,
+                                       const int64_t* skip_idx_host, int n_tables, const float* dout, int64_t R, int C,
+                                       int64_t ld_dout, int idx_dtype, void* stream) {
+    if (n_tables < 1 || n_tables > MAXT || C <= 0) return MOBGT_EBADDIM;
+    if (R <= 0) return 0;
+    EmbedParams p = {};
+    for (int t = 0; t < n_tables; ++t) {
+        p.d_tables[t] = d_tables_host[t]; p.idx[t] = idx_host[t]; p.skip[t] = skip_idx_host ? skip_idx_host[t] : -1;
+    }
+    p.n_tables = n_tables; p.dout = dout; p.R = R; p.C = C; p.ld = ld_dout;
+    const dim3 grid((unsigned)((R + 3) / 4)), block(256);
+    hipStream_t st = (hipStream_t)stream;
+    if (idx_dtype == MOBGT_I64) hipLaunchKernelGGL(scatter_add_kernel<int64_t>, grid, block, 0, st, p);
+    else if (idx_dtype == MOBGT_I32) hipLaunchKernelGGL(scatter_add_kernel<int32_t>, grid, block, 0, st, p);
+    else if (idx_dtype == MOBGT_I16) hipLaunchKernelGGL(scatter_add_kernel<int16_t>, grid, block, 0, st, p);
+    else return MOBGT_EDTYPE;
+    return (int)hipGetLastError();
+}

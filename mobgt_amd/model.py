@@ -1,0 +1,209 @@
+"""Drop-in counterparts of `graphormer/model.py` (stock Graphormer) on MI355X.
+
+Same constructor arguments, `forward` signatures and state_dict names as the reference
+(`model.py:393-489` for FeedForwardNetwork / MultiHeadAttention / EncoderLayer, `model.py:23-217` for
+Graphormer), so reference checkpoints load unchanged.  What differs is where the work runs:
+
+* the score/bias/softmax/dropout/PV chain of `MultiHeadAttention.forward` (model.py:436-455) is ONE HIP
+  kernel (`mobgt_attn_bias_fwd`) and its autograd is two more (`mobgt_attn_bias_bwd`);
+* the bias assembly of `Graphormer.forward` (model.py:126-190: table gathers, permutes, slice-adds and
+  the multi-hop edge reduce with its [G,N,N,D,H] temporaries) is `mobgt_build_bias`;
+* node features (model.py:193-203) are one gather-sum kernel;
+* the dense projections / FFN stay on hipBLASLt through torch (they are library GEMMs, not hot ops).
+
+Lightning glue, FLAG, ogb/ZINC branches of the reference are out of scope.
+"""
+import math
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import ops
+
+
+def init_bert_params(module, n_layers):
+    """model.py:14-20"""
+    if isinstance(module, nn.Linear):
+        module.weight.data.normal_(mean=0.0, std=0.02 / math.sqrt(n_layers))
+        if module.bias is not None:
+            module.bias.data.zero_()
+    if isinstance(module, nn.Embedding):
+        module.weight.data.normal_(mean=0.0, std=0.02)
+
+
+def no_grad_row0(weight):
+    """nn.Embedding(padding_idx=0): row 0 is read like any other row but never receives a gradient."""
+    return torch.cat([weight[:1].detach(), weight[1:]], dim=0)
+
+
+def hop_table_from(edge_weight, edge_dis_weight, H, D, fp16_roundtrip=False):
+    """[D, n_edge, H] table T[d,e,h] = sum_h' edge_encoder[e,h'] * edge_dis_encoder[d,h',h]
+    (model.py:166-176: embedding -> bmm with `edge_dis_encoder.weight.reshape(-1,H,H)[:D]`).  Because the
+    per-pair work is linear in the gathered rows, gathering from this product replaces the reference's
+    gather + [G*N*N, H] x [H, H] bmm per hop.  Row 0 of the edge table is `padding_idx` (no gradient).
+    fp16_roundtrip reproduces model_fqandtoyo.py:1178-1198: operands rounded to fp16, fp32 accumulate,
+    product rounded to fp16 (exact for F == 1, which is every MobGT dataset)."""
+    W = edge_dis_weight.reshape(-1, H, H)[:D]
+    enc = no_grad_row0(edge_weight)
+    if fp16_roundtrip:
+        return torch.matmul(enc.half().float().unsqueeze(0), W.half().float()).half().float()
+    return torch.matmul(enc.unsqueeze(0), W)
+
+
+class FeedForwardNetwork(nn.Module):
+    """model.py:393-405"""
+
+    def __init__(self, hidden_size, ffn_size, dropout_rate):
+        super().__init__()
+        self.layer1 = nn.Linear(hidden_size, ffn_size)
+        self.gelu = nn.GELU()
+        self.layer2 = nn.Linear(ffn_size, hidden_size)
+
+    def forward(self, x):
+        return self.layer2(self.gelu(self.layer1(x)))
+
+
+_layer_counter = [0]
+
+
+class MultiHeadAttention(nn.Module):
+    """model.py:408-460.  `attn_bias` may be a torch tensor broadcastable to [G,H,T,T] (reference call
+    convention) or an `ops.PackedBias` (what Graphormer.forward passes, already in kernel layout)."""
+
+    def __init__(self, hidden_size, attention_dropout_rate, num_heads):
+        super().__init__()
+        self.num_heads = num_heads
+        self.att_size = att_size = hidden_size // num_heads
+        self.scale = att_size ** -0.5
+        self.linear_q = nn.Linear(hidden_size, num_heads * att_size)
+        self.linear_k = nn.Linear(hidden_size, num_heads * att_size)
+        self.linear_v = nn.Linear(hidden_size, num_heads * att_size)
+        self.att_dropout = nn.Dropout(attention_dropout_rate)
+        self.output_layer = nn.Linear(num_heads * att_size, hidden_size)
+        _layer_counter[0] += 1
+        self._seed_salt = (_layer_counter[0] * 0x9E3779B97F4A7C15) & 0x7FFFFFFFFFFFFFFF
+        self._pack_cache = None
+        self.seed_dev = None            # optional device int64 scalar: advanced by the trainer each step
+
+    def _packed(self, attn_bias, G, T, ref):
+        if isinstance(attn_bias, ops.PackedBias):
+            return attn_bias
+        if attn_bias is None:
+            attn_bias = torch.zeros(1, 1, T, T, device=ref.device)
+        key = (attn_bias.data_ptr(), attn_bias._version, tuple(attn_bias.shape), attn_bias.requires_grad)
+        cache = MultiHeadAttention._shared_cache
+        if cache.get("key") != key:
+            cache["key"] = key
+            cache["pack"] = ops.pack_bias(attn_bias, G, self.num_heads, T)
+        return cache["pack"]
+
+    _shared_cache = {}
+
+    def forward(self, q, k, v, attn_bias=None, mask=None):
+        if mask is not None:
+            raise NotImplementedError("mask is None at every call site of the reference (model.py:208)")
+        orig_q_size = q.size()
+        G, T = q.shape[0], q.shape[1]
+        pack = self._packed(attn_bias, G, T, q)
+        p_drop = self.att_dropout.p if self.training else 0.0
+        seed = self._seed_salt
+        if p_drop > 0 and self.seed_dev is None:
+            seed = (seed + int(torch.randint(0, 2 ** 31 - 1, (1,)).item())) & 0x7FFFFFFFFFFFFFFF
+        if q is k and k is v:
+            w = torch.cat([self.linear_q.weight, self.linear_k.weight, self.linear_v.weight], dim=0)
+            b = torch.cat([self.linear_q.bias, self.linear_k.bias, self.linear_v.bias], dim=0)
+            x = ops.attention_qkv(F.linear(q, w, b), pack, self.scale, p_drop, seed, self.seed_dev)
+        else:
+            x = ops.attention(self.linear_q(q), self.linear_k(k), self.linear_v(v), pack, self.scale, p_drop, seed,
+                              self.seed_dev)
+        x = self.output_layer(x)
+        assert x.size() == orig_q_size
+        return x
+
+
+class EncoderLayer(nn.Module):
+    """model.py:463-489 (pre-LN)."""
+
+    def __init__(self, hidden_size, ffn_size, dropout_rate, attention_dropout_rate, num_heads):
+        super().__init__()
+        self.self_attention_norm = nn.LayerNorm(hidden_size)
+        self.self_attention = MultiHeadAttention(hidden_size, attention_dropout_rate, num_heads)
+        self.self_attention_dropout = nn.Dropout(dropout_rate)
+        self.ffn_norm = nn.LayerNorm(hidden_size)
+        self.ffn = FeedForwardNetwork(hidden_size, ffn_size, dropout_rate)
+        self.ffn_dropout = nn.Dropout(dropout_rate)
+
+    def forward(self, x, attn_bias=None, mask=None):
+        y = self.self_attention_norm(x)
+        y = self.self_attention(y, y, y, attn_bias, mask=mask)
+        y = self.self_attention_dropout(y)
+        x = x + y
+        y = self.ffn_norm(x)
+        y = self.ffn(y)
+        y = self.ffn_dropout(y)
+        return x + y
+
+
+class Graphormer(nn.Module):
+    """model.py:23-217 without the Lightning / ogb / FLAG branches.  `num_class` replaces the
+    `get_dataset(dataset_name)["num_class"]` lookup (model.py:84-86)."""
+
+    def __init__(self, n_layers, num_heads, hidden_dim, dropout_rate, intput_dropout_rate, weight_decay, ffn_dim,
+                 dataset_name, warmup_updates, tot_updates, peak_lr, end_lr, edge_type, multi_hop_max_dist,
+                 attention_dropout_rate, num_class=1, bias_dtype=torch.float32, **_unused):
+        super().__init__()
+        self.num_heads = num_heads
+        self.atom_encoder = nn.Embedding(512 * 9 + 1, hidden_dim, padding_idx=0)
+        self.edge_encoder = nn.Embedding(512 * 3 + 1, num_heads, padding_idx=0)
+        self.edge_type = edge_type
+        if self.edge_type == "multi_hop":
+            self.edge_dis_encoder = nn.Embedding(128 * num_heads * num_heads, 1)
+        self.rel_pos_encoder = nn.Embedding(512, num_heads, padding_idx=0)
+        self.in_degree_encoder = nn.Embedding(512, hidden_dim, padding_idx=0)
+        self.out_degree_encoder = nn.Embedding(512, hidden_dim, padding_idx=0)
+        self.input_dropout = nn.Dropout(intput_dropout_rate)
+        self.layers = nn.ModuleList([EncoderLayer(hidden_dim, ffn_dim, dropout_rate, attention_dropout_rate, num_heads)
+                                     for _ in range(n_layers)])
+        self.final_ln = nn.LayerNorm(hidden_dim)
+        self.downstream_out_proj = nn.Linear(hidden_dim, num_class)
+        self.graph_token = nn.Embedding(1, hidden_dim)
+        self.graph_token_virtual_distance = nn.Embedding(1, num_heads)
+        self.dataset_name = dataset_name
+        self.warmup_updates, self.tot_updates = warmup_updates, tot_updates
+        self.peak_lr, self.end_lr, self.weight_decay = peak_lr, end_lr, weight_decay
+        self.multi_hop_max_dist = multi_hop_max_dist
+        self.hidden_dim = hidden_dim
+        self.bias_dtype = bias_dtype
+        self.apply(lambda module: init_bert_params(module, n_layers=n_layers))
+
+    def assemble_bias(self, batched_data):
+        """model.py:126-190 -> ops.PackedBias"""
+        H = self.num_heads
+        edge_input = batched_data.edge_input
+        D = edge_input.shape[3]
+        if self.multi_hop_max_dist > 0:
+            D = min(D, self.multi_hop_max_dist)
+        if self.edge_type != "multi_hop":
+            raise NotImplementedError("only edge_type='multi_hop' is used by MobGT (README.md:62)")
+        hop = hop_table_from(self.edge_encoder.weight, self.edge_dis_encoder.weight, H, D)
+        rel = no_grad_row0(self.rel_pos_encoder.weight)
+        return ops.build_bias(batched_data.attn_bias, batched_data.rel_pos, None, edge_input, rel, None, hop,
+                              self.graph_token_virtual_distance.weight, D, dtype=self.bias_dtype)
+
+    def forward(self, batched_data, perturb=None):
+        x = batched_data.x
+        in_degree = out_degree = batched_data.in_degree            # model.py:118 (aliasing kept)
+        n_graph = x.size(0)
+        bias = self.assemble_bias(batched_data)
+        if x.shape[2] != 1:
+            raise NotImplementedError("MobGT items have one feature column (wrapper.py:37)")
+        node_feature = ops.embed_gather_sum(
+            [self.atom_encoder.weight, self.in_degree_encoder.weight, self.out_degree_encoder.weight],
+            [x[:, :, 0].long(), in_degree.long(), out_degree.long()], padding_idx=[0, 0, 0])
+        graph_token_feature = self.graph_token.weight.unsqueeze(0).repeat(n_graph, 1, 1)
+        output = self.input_dropout(torch.cat([graph_token_feature, node_feature], dim=1))
+        for enc_layer in self.layers:
+            output = enc_layer(output, bias, mask=None)
+        output = self.final_ln(output)
+        return self.downstream_out_proj(output[:, 0, :])

@@ -1,0 +1,321 @@
+"""torch-facing wrappers of the C ABI (include/mobgt_hip.h): device pointers, strides and the current
+HIP stream go in, autograd comes out.  PyTorch is plumbing here (memory, streams, autograd graph);
+all arithmetic of the hot path happens in libmobgt_hip.so.  No CPU fallback exists.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import F32, BF16, I64, I32, I16, U8, check
+
+_DT = {torch.float32: F32, torch.bfloat16: BF16}
+_IT = {torch.int64: I64, torch.int32: I32, torch.int16: I16, torch.uint8: U8}
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+def _require_cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("mobgt_amd ops run on the GPU only (there is no CPU fallback); got a CPU tensor")
+
+
+def round_up(x, m):
+    return (x + m - 1) // m * m
+
+
+class PackedBias:
+    """The attention bias in kernel layout: `bias` [G,H,T,ld] row-major and `bias_t` (query/key
+    transposed), ld = roundup(T,32), pad columns -inf; plus the f32 dBias accumulator shared by all
+    layers of one step and the autograd token that orders its consumer after every layer's backward."""
+
+    def __init__(self, G, H, T, dtype, device):
+        self.G, self.H, self.T = G, H, T
+        self.ld = round_up(T, 32)
+        self.dtype = dtype
+        self.bias = torch.empty(G, H, T, self.ld, dtype=dtype, device=device)
+        self.bias_t = torch.empty(G, H, T, self.ld, dtype=dtype, device=device)
+        self.dbias = None
+        self.n_bwd = 0
+        self.needs_grad = False
+        self.token = None
+
+    def dense(self):
+        """[G,H,T,T] float32 copy (tests)."""
+        return self.bias[..., : self.T].float()
+
+    def grad_buffer(self):
+        if self.dbias is None:
+            # columns >= T are never written by the kernels; keep them zero
+            self.dbias = torch.zeros(self.G, self.H, self.T, self.ld, dtype=torch.float32, device=self.bias.device)
+        return self.dbias
+
+
+# ------------------------------------------------------------------------------------- bias pack
+class _PackFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, src, pack):
+        G, H, T = pack.G, pack.H, pack.T
+        s = src.expand(G, H, T, T)
+        st = s.stride()
+        check(_lib.lib().mobgt_bias_pack(_p(s), _DT[s.dtype], st[0], st[1], st[2], st[3], _p(pack.bias), _p(pack.bias_t),
+                                         _DT[pack.dtype], G, H, T, pack.ld, _stream()), "mobgt_bias_pack")
+        ctx.pack = pack
+        ctx.src_shape = src.shape
+        ctx.src_dtype = src.dtype
+        return torch.zeros(1, device=src.device)
+
+    @staticmethod
+    def backward(ctx, _g):
+        pack = ctx.pack
+        if pack.dbias is None:
+            return torch.zeros(ctx.src_shape, dtype=ctx.src_dtype, device=pack.bias.device), None
+        g = pack.dbias[..., : pack.T]
+        if tuple(ctx.src_shape) != tuple(g.shape):          # broadcast source: reduce
+            g = g.sum_to_size(ctx.src_shape)
+        return g.to(ctx.src_dtype), None
+
+
+def pack_bias(attn_bias, G, H, T, dtype=None):
+    """Caller-supplied [G,H,T,T] (or broadcastable) bias -> PackedBias (model.py:445 semantics)."""
+    _require_cuda(attn_bias)
+    if attn_bias.dtype not in _DT:
+        attn_bias = attn_bias.float()
+    if attn_bias.dim() == 3:
+        attn_bias = attn_bias.unsqueeze(1)
+    pack = PackedBias(G, H, T, dtype or attn_bias.dtype, attn_bias.device)
+    pack.needs_grad = attn_bias.requires_grad and torch.is_grad_enabled()
+    pack.token = _PackFn.apply(attn_bias, pack)
+    return pack
+
+
+# ------------------------------------------------------------------------------------- build bias
+class _BuildBiasFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, rel_table, poi_table, hop_table, vdist, pack, attn_bias, rel_pos, poi_pos, edge_input, D):
+        G, N = rel_pos.shape[:2]
+        H = rel_table.shape[1]
+        has_edge = edge_input is not None and D > 0
+        D_in = edge_input.shape[3] if has_edge else 0
+        F = edge_input.shape[4] if has_edge else 1
+        idx_dt = _IT[rel_pos.dtype]
+        edge_dt = _IT[edge_input.dtype] if has_edge else U8
+        n_poi = poi_table.shape[0] if poi_table is not None else 0
+        n_edge = hop_table.shape[1] if has_edge else 0
+        args = (G, N, H, D_in, D if has_edge else 0, F, rel_table.shape[0], n_poi, n_edge, pack.ld, idx_dt, edge_dt)
+        check(_lib.lib().mobgt_build_bias(_p(attn_bias), _p(rel_pos), _p(poi_pos), _p(edge_input if has_edge else None),
+                                          _p(rel_table), _p(poi_table), _p(hop_table if has_edge else None), _p(vdist),
+                                          _p(pack.bias), _p(pack.bias_t), *args, _DT[pack.dtype], _stream()),
+              "mobgt_build_bias")
+        ctx.pack, ctx.args = pack, args
+        ctx.idx = (attn_bias, rel_pos, poi_pos, edge_input if has_edge else None)
+        ctx.shapes = (rel_table.shape, None if poi_table is None else poi_table.shape,
+                      hop_table.shape if has_edge else None, vdist.shape)
+        return torch.zeros(1, device=rel_table.device)
+
+    @staticmethod
+    def backward(ctx, _g):
+        pack = ctx.pack
+        dev = pack.bias.device
+        rs, ps, hs, vs = ctx.shapes
+        d_rel = torch.zeros(rs, device=dev)
+        d_poi = torch.zeros(ps, device=dev) if ps is not None else None
+        d_hop = torch.zeros(hs, device=dev) if hs is not None else None
+        d_vd = torch.zeros(vs, device=dev)
+        if pack.dbias is not None:
+            attn_bias, rel_pos, poi_pos, edge_input = ctx.idx
+            a = ctx.args
+            check(_lib.lib().mobgt_build_bias_bwd(_p(pack.dbias), _p(attn_bias), _p(rel_pos), _p(poi_pos), _p(edge_input),
+                                                  _p(d_rel), _p(d_poi), _p(d_hop), _p(d_vd), *a, _stream()),
+                  "mobgt_build_bias_bwd")
+        return d_rel, d_poi, d_hop, d_vd, None, None, None, None, None, None
+
+
+def build_bias(attn_bias, rel_pos, poi_pos, edge_input, rel_table, poi_table, hop_table, vdist, D, dtype=torch.float32):
+    """Fused bias assembly (model.py:126-190 / model_fqandtoyo.py:1143-1216) -> PackedBias.
+    `hop_table` [D, n_edge, H] is the (differentiable) product of the edge and hop-distance tables."""
+    _require_cuda(attn_bias, rel_pos, rel_table)
+    G, N = rel_pos.shape[:2]
+    H = rel_table.shape[1]
+    pack = PackedBias(G, H, N + 1, dtype, rel_table.device)
+    pack.needs_grad = torch.is_grad_enabled() and any(
+        t is not None and t.requires_grad for t in (rel_table, poi_table, hop_table, vdist))
+    f = lambda t: None if t is None else t.contiguous()
+    pack.token = _BuildBiasFn.apply(f(rel_table.float()), f(None if poi_table is None else poi_table.float()),
+                                    f(None if hop_table is None else hop_table.float()), f(vdist.float().reshape(-1)),
+                                    pack, f(attn_bias.float()), f(rel_pos), f(poi_pos), f(edge_input), int(D))
+    return pack
+
+
+# -------------------------------------------------------------------------------------- attention
+def _check_rows(*ts):
+    for t in ts:
+        if t.stride(-1) != 1 or t.stride(-2) % 8 != 0 or t.data_ptr() % 16 != 0:
+            raise RuntimeError("mobgt attention: q/k/v rows must be unit-stride, 16-byte aligned, row stride % 8 == 0")
+
+
+def _attn_fwd(q, k, v, pack, scale, p_drop, seed, seed_dev):
+    G, T, C = q.shape
+    H = pack.H
+    out = torch.empty(G, T, C, dtype=q.dtype, device=q.device)
+    lse = torch.empty(G, H, T, dtype=torch.float32, device=q.device)
+    _check_rows(q, k, v)
+    check(_lib.lib().mobgt_attn_bias_fwd(_p(q), _p(k), _p(v), _p(pack.bias), _p(out), _p(lse), G, H, T, C // H,
+                                         q.stride(1), k.stride(1), v.stride(1), C, pack.ld, scale, p_drop, seed,
+                                         _p(seed_dev), _DT[q.dtype], _DT[pack.dtype], _stream()), "mobgt_attn_bias_fwd")
+    return out, lse
+
+
+def _attn_bwd(q, k, v, out, lse, dout, dq, dk, dv, pack, scale, p_drop, seed, seed_dev):
+    G, T, C = q.shape
+    H = pack.H
+    dbias = None
+    acc = 0
+    if pack.needs_grad:
+        dbias = pack.grad_buffer()
+        acc = 1 if pack.n_bwd > 0 else 0
+        pack.n_bwd += 1
+    delta = torch.empty(G, H, T, dtype=torch.float32, device=q.device)
+    check(_lib.lib().mobgt_attn_bias_bwd(_p(q), _p(k), _p(v), _p(pack.bias), _p(pack.bias_t), _p(out), _p(lse), _p(dout),
+                                         _p(dq), _p(dk), _p(dv), _p(dbias), _p(delta), G, H, T, C // H,
+                                         q.stride(1), k.stride(1), v.stride(1), C, dq.stride(1), dk.stride(1),
+                                         dv.stride(1), pack.ld, scale, p_drop, seed, _p(seed_dev), acc,
+                                         _DT[q.dtype], _DT[pack.dtype], _stream()), "mobgt_attn_bias_bwd")
+
+
+class _AttnFn(torch.autograd.Function):
+    """q, k, v: [G,T,C] (possibly strided views); returns [G,T,C]."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, token, pack, scale, p_drop, seed, seed_dev):
+        out, lse = _attn_fwd(q, k, v, pack, scale, p_drop, seed, seed_dev)
+        ctx.save_for_backward(q, k, v, out, lse)
+        ctx.misc = (pack, scale, p_drop, seed, seed_dev)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        q, k, v, out, lse = ctx.saved_tensors
+        pack, scale, p_drop, seed, seed_dev = ctx.misc
+        dout = dout.contiguous()
+        dq, dk, dv = torch.empty_like(out), torch.empty_like(out), torch.empty_like(out)
+        _attn_bwd(q, k, v, out, lse, dout, dq, dk, dv, pack, scale, p_drop, seed, seed_dev)
+        return dq, dk, dv, None, None, None, None, None, None
+
+
+class _AttnQKVFn(torch.autograd.Function):
+    """qkv: [G,T,3C] (one fused projection); returns [G,T,C]; gradient comes back fused as well."""
+
+    @staticmethod
+    def forward(ctx, qkv, token, pack, scale, p_drop, seed, seed_dev):
+        C = qkv.shape[2] // 3
+        q, k, v = qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:]
+        out, lse = _attn_fwd(q, k, v, pack, scale, p_drop, seed, seed_dev)
+        ctx.save_for_backward(qkv, out, lse)
+        ctx.misc = (pack, scale, p_drop, seed, seed_dev)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        qkv, out, lse = ctx.saved_tensors
+        pack, scale, p_drop, seed, seed_dev = ctx.misc
+        C = qkv.shape[2] // 3
+        q, k, v = qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:]
+        dqkv = torch.empty_like(qkv)
+        _attn_bwd(q, k, v, out, lse, dout.contiguous(), dqkv[..., :C], dqkv[..., C:2 * C], dqkv[..., 2 * C:], pack,
+                  scale, p_drop, seed, seed_dev)
+        return dqkv, None, None, None, None, None, None
+
+
+def attention(q, k, v, pack, scale, p_drop=0.0, seed=0, seed_dev=None):
+    _require_cuda(q, k, v)
+    return _AttnFn.apply(q, k, v, pack.token, pack, float(scale), float(p_drop), int(seed), seed_dev)
+
+
+def attention_qkv(qkv, pack, scale, p_drop=0.0, seed=0, seed_dev=None):
+    _require_cuda(qkv)
+    if qkv.shape[2] % 24 != 0:
+        raise RuntimeError("fused qkv width must be 3*C with C % 8 == 0")
+    return _AttnQKVFn.apply(qkv.contiguous(), pack.token, pack, float(scale), float(p_drop), int(seed), seed_dev)
+
+
+def dropout_keep_mask(seed, G, H, T, p_drop):
+    """Host replay of the kernels' keep rule (tests): bool [G,H,T,T]."""
+    import numpy as np
+    lib = _lib.lib()
+    m = np.zeros((G, H, T, T), dtype=bool)
+    for g in range(G):
+        for h in range(H):
+            for i in range(T):
+                for j in range(T):
+                    m[g, h, i, j] = bool(lib.mobgt_dropout_keep_host(seed, H, T, g, h, i, j, p_drop))
+    return m
+
+
+# ------------------------------------------------------------------------------------------- spd
+def spd_batched(counts, n_nodes, D):
+    """counts [G,N,N] int32 (device), n_nodes [G] int32 -> dict of device tensors (see mobgt_spd_batched)."""
+    _require_cuda(counts, n_nodes)
+    G, N = counts.shape[:2]
+    dev = counts.device
+    out = dict(
+        spd=torch.empty(G, N, N, dtype=torch.int16, device=dev), path=torch.empty(G, N, N, dtype=torch.int16, device=dev),
+        rel_pos=torch.empty(G, N, N, dtype=torch.int16, device=dev),
+        edge_input=torch.empty(G, N, N, D, 1, dtype=torch.uint8, device=dev),
+        in_degree=torch.empty(G, N, dtype=torch.int16, device=dev), out_degree=torch.empty(G, N, dtype=torch.int16, device=dev))
+    work = torch.empty(16, dtype=torch.uint8, device=dev)
+    check(_lib.lib().mobgt_spd_batched(_p(counts.contiguous()), _p(n_nodes.contiguous()), _p(out["spd"]), _p(out["path"]),
+                                       _p(out["rel_pos"]), _p(out["edge_input"]), _p(out["in_degree"]),
+                                       _p(out["out_degree"]), _p(work), G, N, D, _stream()), "mobgt_spd_batched")
+    return out
+
+
+# ----------------------------------------------------------------------------------------- embed
+def _ptr_array(ts):
+    arr = (ctypes.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
+    return arr
+
+
+class _GatherSumFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, skip, n_tables, *args):
+        tables, idx = args[:n_tables], args[n_tables:]
+        R = idx[0].numel()
+        C = tables[0].shape[1]
+        out = torch.empty(R, C, dtype=torch.float32, device=tables[0].device)
+        check(_lib.lib().mobgt_embed_gather_sum(_ptr_array(tables), _ptr_array(idx), n_tables, _p(out), R, C, C,
+                                                _IT[idx[0].dtype], _stream()), "mobgt_embed_gather_sum")
+        ctx.idx, ctx.skip = idx, skip
+        ctx.shapes = [t.shape for t in tables]
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        dout = dout.contiguous()
+        n = len(ctx.shapes)
+        grads = [torch.zeros(s, dtype=torch.float32, device=dout.device) for s in ctx.shapes]
+        skip = (ctypes.c_int64 * n)(*ctx.skip)
+        R, C = dout.shape
+        check(_lib.lib().mobgt_embed_scatter_add(_ptr_array(grads), _ptr_array(ctx.idx), skip, n, _p(dout), R, C, C,
+                                                 _IT[ctx.idx[0].dtype], _stream()), "mobgt_embed_scatter_add")
+        return (None, None, *grads, *([None] * n))
+
+
+def embed_gather_sum(tables, indices, padding_idx=None):
+    """sum_t tables[t][indices[t]] -> [*indices[0].shape, C].  f32 tables of equal width; indices share
+    dtype and shape; negative index = no contribution.  `padding_idx[t]` rows get no gradient."""
+    _require_cuda(*tables, *indices)
+    n = len(tables)
+    shape = indices[0].shape
+    skip = tuple(-1 if (padding_idx is None or padding_idx[t] is None) else int(padding_idx[t]) for t in range(n))
+    idx = [i.contiguous().reshape(-1) for i in indices]
+    tabs = [t.float().contiguous() for t in tables]
+    out = _GatherSumFn.apply(skip, n, *tabs, *idx)
+    return out.view(*shape, tabs[0].shape[1])

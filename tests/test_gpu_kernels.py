@@ -1,0 +1,348 @@
+"""Parity of the HIP kernels (through the C ABI) against the oracle, on a real MI355X.
+
+Tolerances (stated per SURVEY/BASELINE "fp32 tolerance; bit-exact for integer SPD indexing"):
+  * integer outputs (spd, path, rel_pos, edge_input, degrees): bit-exact;
+  * attention: operands are rounded to bf16 for the MFMA (fp32 accumulate / softmax).  Against an fp32
+    oracle fed the SAME bf16-rounded operands: |err| <= 4e-3 * scale-of-output; against the untouched
+    fp32 oracle: <= 2e-2 (bf16 has 8 significand bits);
+  * bias assembly (fp32 tables, fp32 output): rtol 1e-5 / atol 1e-5.
+"""
+import os
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from mobgt_amd import ops, synth            # noqa: E402
+from oracle import algos_oracle as ao       # noqa: E402
+from oracle import model_oracle as mo       # noqa: E402
+
+DEV = "cuda"
+
+
+def bf16r(t):
+    return t.to(torch.bfloat16).float()
+
+
+def make_bias(rng, G, H, T, n_real, scale=0.7):
+    b = (rng.standard_normal((G, H, T, T)) * scale).astype(np.float32)
+    for g in range(G):
+        b[g, :, :, n_real[g]:] = -np.inf
+    return torch.from_numpy(b)
+
+
+def ref_attention(q, k, v, bias, H, scale, keep=None, inv_keep=1.0, round_ops=True):
+    """model.py:436-455 on [G,T,C] inputs, fp32 CPU; optional bf16 rounding of the MFMA operands."""
+    G, T, C = q.shape
+    d = C // H
+    qs = q * scale
+    if round_ops:
+        qs, k, v = bf16r(qs), bf16r(k), bf16r(v)
+    qh = qs.view(G, T, H, d).transpose(1, 2)
+    kh = k.view(G, T, H, d).transpose(1, 2)
+    vh = v.view(G, T, H, d).transpose(1, 2)
+    s = qh @ kh.transpose(2, 3) + bias
+    p = torch.softmax(s, dim=3)
+    if keep is not None:
+        p = p * keep * inv_keep
+    o = p @ vh
+    return o.transpose(1, 2).reshape(G, T, C)
+
+
+CASES = [(2, 8, 1, 16), (2, 8, 5, 16), (3, 8, 33, 16), (2, 8, 64, 24), (2, 8, 65, 24), (1, 8, 130, 32),
+         (2, 4, 97, 32), (1, 8, 200, 16)]
+
+
+@pytest.mark.parametrize("G,H,T,d", CASES)
+@pytest.mark.parametrize("bias_dtype", [torch.float32, torch.bfloat16])
+def test_attention_fwd_bwd_f32(G, H, T, d, bias_dtype):
+    rng = np.random.RandomState(1000 * T + d)
+    C = H * d
+    n_real = [T] + [max(1, T - 1 - 3 * g) for g in range(1, G)]
+    q, k, v, gy = (torch.from_numpy(rng.standard_normal((G, T, C)).astype(np.float32)) for _ in range(4))
+    bias = make_bias(rng, G, H, T, n_real)
+    scale = d ** -0.5
+    if bias_dtype == torch.bfloat16:
+        bias = bf16r(bias)
+    # oracle (fp32, same rounded operands) with autograd
+    qr, kr, vr, br = (t.clone().requires_grad_(True) for t in (q, k, v, bias))
+    ref = ref_attention(qr, kr, vr, br, H, scale)
+    ref.backward(gy)
+    # device
+    qd, kd, vd = (t.to(DEV).requires_grad_(True) for t in (q, k, v))
+    bd = bias.to(DEV).requires_grad_(True)
+    pack = ops.pack_bias(bd, G, H, T, dtype=bias_dtype)
+    out = ops.attention(qd, kd, vd, pack, scale)
+    out.backward(gy.to(DEV))
+    torch.cuda.synchronize()
+    # packed layouts
+    dense = pack.bias[..., :T].float().cpu()
+    assert torch.equal(torch.isinf(dense), torch.isinf(bias))
+    assert torch.equal(dense[torch.isfinite(bias)], bias[torch.isfinite(bias)])
+    assert torch.equal(pack.bias_t[..., :T].float().cpu(), dense.transpose(2, 3))
+    assert bool(torch.isinf(pack.bias[..., T:]).all())
+    tol = 4e-3
+    np.testing.assert_allclose(out.detach().cpu().numpy(), ref.detach().numpy(), atol=tol, rtol=tol)
+    full = ref_attention(q, k, v, bias, H, scale, round_ops=False)
+    np.testing.assert_allclose(out.detach().cpu().numpy(), full.numpy(), atol=2e-2, rtol=2e-2)
+    # gradients: dS and P are rounded to bf16 inside the backward MFMAs as well
+    gt = 1.5e-2
+    for name, got, want in (("dq", qd.grad, qr.grad), ("dk", kd.grad, kr.grad), ("dv", vd.grad, vr.grad)):
+        w = want.numpy()
+        np.testing.assert_allclose(got.cpu().numpy(), w, atol=gt * max(1.0, np.abs(w).max()), rtol=gt, err_msg=name)
+    db = bd.grad.cpu().numpy()
+    np.testing.assert_allclose(db, br.grad.numpy(), atol=2e-3, rtol=2e-2)
+
+
+@pytest.mark.parametrize("G,H,T,d", [(2, 8, 33, 16), (2, 8, 70, 24), (1, 8, 130, 32)])
+def test_attention_bf16_io(G, H, T, d):
+    rng = np.random.RandomState(7 * T + d)
+    C = H * d
+    q, k, v, gy = (bf16r(torch.from_numpy(rng.standard_normal((G, T, C)).astype(np.float32))) for _ in range(4))
+    bias = bf16r(make_bias(rng, G, H, T, [T] * G))
+    scale = d ** -0.5
+    qr, kr, vr = (t.clone().requires_grad_(True) for t in (q, k, v))
+    ref = ref_attention(qr, kr, vr, bias, H, scale)
+    ref.backward(gy)
+    qd, kd, vd = (t.to(DEV).to(torch.bfloat16).requires_grad_(True) for t in (q, k, v))
+    pack = ops.pack_bias(bias.to(DEV), G, H, T, dtype=torch.bfloat16)
+    out = ops.attention(qd, kd, vd, pack, scale)
+    assert out.dtype == torch.bfloat16
+    out.backward(gy.to(DEV).to(torch.bfloat16))
+    np.testing.assert_allclose(out.float().cpu().numpy(), ref.detach().numpy(), atol=1.2e-2, rtol=1.2e-2)
+    for got, want in ((qd.grad, qr.grad), (kd.grad, kr.grad), (vd.grad, vr.grad)):
+        w = want.numpy()
+        np.testing.assert_allclose(got.float().cpu().numpy(), w, atol=2.5e-2 * max(1.0, np.abs(w).max()), rtol=2.5e-2)
+
+
+def test_attention_fused_qkv_matches_separate():
+    G, H, T, d = 2, 8, 45, 16
+    C = H * d
+    rng = np.random.RandomState(3)
+    qkv = torch.from_numpy(rng.standard_normal((G, T, 3 * C)).astype(np.float32)).to(DEV)
+    bias = make_bias(rng, G, H, T, [T, T - 7]).to(DEV)
+    gy = torch.from_numpy(rng.standard_normal((G, T, C)).astype(np.float32)).to(DEV)
+    pack = ops.pack_bias(bias, G, H, T)
+    a = qkv.clone().requires_grad_(True)
+    o1 = ops.attention_qkv(a, pack, d ** -0.5)
+    o1.backward(gy)
+    q, k, v = (qkv[..., i * C:(i + 1) * C].contiguous().requires_grad_(True) for i in range(3))
+    o2 = ops.attention(q, k, v, pack, d ** -0.5)
+    o2.backward(gy)
+    assert torch.equal(o1, o2)
+    assert torch.equal(a.grad, torch.cat([q.grad, k.grad, v.grad], dim=2))
+
+
+def test_attention_dropout_replay():
+    """Training-mode attention dropout: the keep mask is a pure function of (seed, g, h, i, j); replay it on
+    the host and compare with the oracle using the same mask (SURVEY §5 'Randomness')."""
+    G, H, T, d, p = 2, 8, 37, 16, 0.1
+    C = H * d
+    rng = np.random.RandomState(11)
+    q, k, v, gy = (torch.from_numpy(rng.standard_normal((G, T, C)).astype(np.float32)) for _ in range(4))
+    bias = make_bias(rng, G, H, T, [T, T - 5])
+    seed = 0x1234567890ABCDEF
+    keep = torch.from_numpy(ops.dropout_keep_mask(seed, G, H, T, p)).float()
+    thr = int(p * 65536 + 0.5)
+    frac = 1.0 - keep.mean().item()
+    assert abs(frac - p) < 0.02
+    inv_keep = 1.0 / (1.0 - thr / 65536.0)
+    qr, kr, vr = (t.clone().requires_grad_(True) for t in (q, k, v))
+    ref = ref_attention(qr, kr, vr, bias, H, d ** -0.5, keep=keep, inv_keep=inv_keep)
+    ref.backward(gy)
+    qd, kd, vd = (t.to(DEV).requires_grad_(True) for t in (q, k, v))
+    pack = ops.pack_bias(bias.to(DEV), G, H, T)
+    seed_dev = torch.tensor([5], dtype=torch.int64, device=DEV)
+    out = ops.attention(qd, kd, vd, pack, d ** -0.5, p_drop=p, seed=seed - 5, seed_dev=seed_dev)
+    out.backward(gy.to(DEV))
+    np.testing.assert_allclose(out.detach().cpu().numpy(), ref.detach().numpy(), atol=5e-3, rtol=5e-3)
+    for got, want in ((qd.grad, qr.grad), (kd.grad, kr.grad), (vd.grad, vr.grad)):
+        w = want.numpy()
+        np.testing.assert_allclose(got.cpu().numpy(), w, atol=1.5e-2 * max(1.0, np.abs(w).max()), rtol=1.5e-2)
+
+
+def test_attention_linearity_in_v_large():
+    """Size-independent property at the c5 shape (T=785, d=32): attention is linear in V, and rows of P sum
+    to 1 (V = ones -> output = ones)."""
+    G, H, T, d = 2, 8, 785, 32
+    C = H * d
+    g = torch.Generator(device="cpu").manual_seed(0)
+    q = torch.randn(G, T, C, generator=g).to(DEV)
+    k = torch.randn(G, T, C, generator=g).to(DEV)
+    v1 = torch.randn(G, T, C, generator=g).to(DEV)
+    v2 = torch.randn(G, T, C, generator=g).to(DEV)
+    bias = torch.randn(G, H, T, T, generator=g)
+    bias[1, :, :, 700:] = float("-inf")
+    pack = ops.pack_bias(bias.to(DEV), G, H, T, dtype=torch.bfloat16)
+    sc = d ** -0.5
+    ones = ops.attention(q, k, torch.ones_like(v1), pack, sc)
+    np.testing.assert_allclose(ones.cpu().numpy(), 1.0, atol=4e-3)
+    o1, o2 = ops.attention(q, k, v1, pack, sc), ops.attention(q, k, v2, pack, sc)
+    o12 = ops.attention(q, k, v1 + v2, pack, sc)
+    np.testing.assert_allclose(o12.cpu().numpy(), (o1 + o2).cpu().numpy(), atol=3e-2)
+
+
+# ----------------------------------------------------------------------------------------- bias assembly
+def _g5_batch(z, prefix, fields):
+    b = SimpleNamespace()
+    for f in fields:
+        a = z[f"{prefix}{f}"]
+        if f in ("attn_bias", "time_normal"):
+            t = torch.from_numpy(a.astype(np.float32))
+        elif a.dtype == np.bool_:
+            t = torch.from_numpy(a)
+        else:
+            t = torch.from_numpy(a.astype(np.int64))
+        setattr(b, f, t)
+    return b
+
+
+def _seeded(shape, seed, scale=0.08):
+    return torch.from_numpy(np.random.RandomState(seed).standard_normal(shape).astype(np.float32) * scale)
+
+
+@pytest.mark.parametrize("variant,tag,narrow", [("stock", "stock", False), ("fq", "fsq", False), ("fq", "gow", True)])
+def test_build_bias_fwd_bwd(golden_dir, variant, tag, narrow):
+    z = np.load(os.path.join(golden_dir, "g5_bias.npz"))
+    fields = ["attn_bias", "rel_pos", "edge_input"] + (["poi_pos"] if variant == "fq" else [])
+    b = _g5_batch(z, f"{tag}/batch/", fields)
+    H, D = 8, 20
+    n_edge = 1537 if variant == "stock" else 128
+    sd = {"rel_pos_encoder.weight": _seeded((512, H), 1), "edge_encoder.weight": _seeded((n_edge, H), 2),
+          "edge_dis_encoder.weight": _seeded((128 * H * H, 1), 3), "graph_token_virtual_distance.weight": _seeded((1, H), 4)}
+    if variant == "fq":
+        sd["poi_pos_encoder.weight"] = _seeded((int(z[f"{tag}/num_bins"]), H), 5)
+    for t in sd.values():
+        t.requires_grad_(True)
+    ref = mo.assemble_bias(sd, b, H, D, variant)
+    gb = _seeded(tuple(ref.shape), 6, 1.0)
+    (torch.where(torch.isfinite(ref), ref, torch.zeros_like(ref)) * gb).sum().backward()
+
+    from mobgt_amd.model import hop_table_from, no_grad_row0
+    dsd = {k: v.detach().clone().to(DEV).requires_grad_(True) for k, v in sd.items()}
+    Dk = min(D, b.edge_input.shape[3])
+    hop = hop_table_from(dsd["edge_encoder.weight"], dsd["edge_dis_encoder.weight"], H, Dk, fp16_roundtrip=(variant == "fq"))
+    rel_pos, edge_input = b.rel_pos.to(DEV), b.edge_input.to(DEV)
+    poi_pos = b.poi_pos.to(DEV) if variant == "fq" else None
+    if narrow:
+        rel_pos, edge_input, poi_pos = rel_pos.to(torch.int16), edge_input.to(torch.uint8), poi_pos.to(torch.int16)
+    poi_tab = no_grad_row0(dsd["poi_pos_encoder.weight"]) if variant == "fq" else None
+    pack = ops.build_bias(b.attn_bias.to(DEV), rel_pos, poi_pos, edge_input, no_grad_row0(dsd["rel_pos_encoder.weight"]),
+                          poi_tab, hop, dsd["graph_token_virtual_distance.weight"], Dk)
+    got = pack.dense().cpu()
+    r = ref.detach()
+    assert torch.equal(torch.isfinite(got), torch.isfinite(r))
+    fin = torch.isfinite(r)
+    np.testing.assert_allclose(got[fin].numpy(), r[fin].numpy(), rtol=1e-5, atol=1e-5 if variant == "stock" else 1e-4)
+    assert torch.equal(pack.bias_t[..., :pack.T].float().cpu(), got.transpose(2, 3))
+    # backward: feed dBias straight into the accumulator the attention layers would have filled
+    T = pack.T
+    pack.needs_grad = True
+    pack.grad_buffer()[..., :T] = gb.to(DEV)
+    pack.token.backward()
+    for kname in sd:
+        want = sd[kname].grad.clone()
+        if kname in ("rel_pos_encoder.weight", "edge_encoder.weight", "poi_pos_encoder.weight"):
+            want[0] = 0                                  # padding_idx=0 (model.py:63,66)
+        gotg = dsd[kname].grad.cpu()
+        np.testing.assert_allclose(gotg.numpy(), want.numpy(), rtol=2e-3, atol=2e-5, err_msg=kname)
+
+
+# ------------------------------------------------------------------------------------------------ spd
+def _spd_case(counts_list, D=20):
+    G = len(counts_list)
+    N = max(c.shape[0] for c in counts_list)
+    counts = np.zeros((G, N, N), np.int32)
+    n_nodes = np.zeros(G, np.int32)
+    for g, c in enumerate(counts_list):
+        n = c.shape[0]
+        counts[g, :n, :n] = c
+        n_nodes[g] = n
+    out = ops.spd_batched(torch.from_numpy(counts).to(DEV), torch.from_numpy(n_nodes).to(DEV), D)
+    return {k: v.cpu().numpy() for k, v in out.items()}, N
+
+
+def _check_spd(counts_list, D=20):
+    out, N = _spd_case(counts_list, D)
+    for g, c in enumerate(counts_list):
+        n = c.shape[0]
+        adj = c != 0
+        M, path = ao.floyd_warshall(adj)
+        assert np.array_equal(out["spd"][g, :n, :n], M), g
+        assert np.array_equal(out["path"][g, :n, :n], path), g
+        assert (out["spd"][g, n:, :] == -1).all() and (out["spd"][g, :, n:] == -1).all()
+        rp = np.zeros((N, N), np.int64)
+        rp[:n, :n] = M + 1
+        assert np.array_equal(out["rel_pos"][g], rp)
+        feat = np.zeros((n, n, 1), np.int64)
+        feat[adj, 0] = c[adj] + 2
+        md = int(M.max())
+        ei = ao.gen_edge_input(md, path, feat).astype(np.int64) if md > 0 else np.zeros((n, n, 0, 1), np.int64)
+        want = np.zeros((N, N, D, 1), np.int64)
+        dd = min(D, ei.shape[2])
+        want[:n, :n, :dd] = ei[:, :, :dd] + 1
+        assert np.array_equal(out["edge_input"][g].astype(np.int64), want), g
+        ind = np.zeros(N, np.int64)
+        outd = np.zeros(N, np.int64)
+        ind[:n] = adj.sum(1) + 1
+        outd[:n] = adj.sum(0) + 1
+        assert np.array_equal(out["in_degree"][g], ind) and np.array_equal(out["out_degree"][g], outd)
+
+
+def test_spd_golden_graphs(golden_dir):
+    z = np.load(os.path.join(golden_dir, "g1_algos.npz"))
+    graphs = [z[f"{n}/counts"].astype(np.int64) for n in z["names"] if n != "cycle600"]
+    _check_spd(graphs)
+    # and directly against the reference's own outputs
+    out, N = _spd_case(graphs)
+    for g, name in enumerate([n for n in z["names"] if n != "cycle600"]):
+        n = graphs[g].shape[0]
+        assert np.array_equal(out["spd"][g, :n, :n], z[f"{name}/M"])
+        assert np.array_equal(out["path"][g, :n, :n], z[f"{name}/path"])
+        ref = z[f"{name}/edge_input20"].astype(np.int64) + 1
+        dd = ref.shape[2]
+        assert np.array_equal(out["edge_input"][g, :n, :n, :dd].astype(np.int64), ref)
+
+
+def test_spd_random_and_large(golden_dir):
+    rng = np.random.RandomState(5)
+    graphs = [synth.random_digraph(rng, n, p) for n, p in ((1, 0.5), (2, 0.5), (9, 0.3), (31, 0.1), (64, 0.05), (100, 0.03))]
+    graphs += [synth.make_trajectory(rng, 2000, n, 4)["edge_type"] for n in (3, 50, 120)]
+    _check_spd(graphs)
+    _check_spd(graphs, D=5)
+    # global-memory path (N > 272) and the N > 510 sentinel case
+    big = [synth.make_trajectory(rng, 2000, 300, 4)["edge_type"], synth.random_digraph(rng, 290, 0.01)]
+    _check_spd(big)
+    z = np.load(os.path.join(golden_dir, "g1_algos.npz"))
+    c = z["cycle600/counts"].astype(np.int64)
+    out, _ = _spd_case([c])
+    assert np.array_equal(out["spd"][0], z["cycle600/M"])
+    assert np.array_equal(out["path"][0], z["cycle600/path"])
+
+
+# ---------------------------------------------------------------------------------------------- embed
+def test_embed_gather_sum_and_grad():
+    rng = np.random.RandomState(2)
+    C = 192
+    t1 = torch.from_numpy(rng.standard_normal((50, C)).astype(np.float32))
+    t2 = torch.from_numpy(rng.standard_normal((128, C)).astype(np.float32))
+    t3 = torch.from_numpy(rng.standard_normal((128, C)).astype(np.float32))
+    i1 = torch.from_numpy(rng.randint(-1, 50, size=(4, 9)))
+    i2 = torch.from_numpy(rng.randint(0, 128, size=(4, 9)))
+    i3 = torch.from_numpy(rng.randint(0, 128, size=(4, 9)))
+    gy = torch.from_numpy(rng.standard_normal((4, 9, C)).astype(np.float32))
+    a, b, c = (t.clone().requires_grad_(True) for t in (t1, t2, t3))
+    ref = torch.where((i1 >= 0).unsqueeze(-1), a[i1.clamp(min=0)], torch.zeros(())) + b[i2] + c[i3]
+    ref.backward(gy)
+    ad, bd, cd = (t.to(DEV).requires_grad_(True) for t in (t1, t2, t3))
+    out = ops.embed_gather_sum([ad, bd, cd], [i1.to(DEV), i2.to(DEV), i3.to(DEV)], padding_idx=[None, 0, 0])
+    out.backward(gy.to(DEV))
+    np.testing.assert_allclose(out.detach().cpu().numpy(), ref.detach().numpy(), rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(ad.grad.cpu().numpy(), a.grad.numpy(), rtol=1e-5, atol=1e-5)
+    for got, want in ((bd.grad, b.grad), (cd.grad, c.grad)):
+        w = want.clone()
+        w[0] = 0
+        np.testing.assert_allclose(got.cpu().numpy(), w.numpy(), rtol=1e-5, atol=1e-5)
