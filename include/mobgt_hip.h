@@ -155,6 +155,25 @@ int mobgt_spd_batched(const int32_t* counts, const int32_t* n_nodes,
                       int16_t* in_degree, int16_t* out_degree, void* work,
                       int G, int N, int D, void* stream);
 
+
+/* Single-graph entry points with the reference's own call signatures, for the per-item drop-in path
+ * (wrapper.py:55-60 calls algos.floyd_warshall(adj) and algos.gen_edge_input(max_dist, path, edge_feat)).
+ *   mobgt_floyd_warshall  <- graphormer/algos.pyx:9-54   adj [n,n] int64 (non-zero = edge) -> M, path [n,n] int64
+ *   mobgt_gen_edge_input  <- graphormer/algos.pyx:65-96  path [n,n] int64 (ANY path matrix), edge_feat [n,n,F] int64
+ *                            -> out [n,n,max_dist,F] float32, -1 fill.  *err_flag (device int) is set non-zero
+ *                            when a path has more hops than max_dist (the reference raises IndexError) or the
+ *                            path matrix does not terminate.
+ * `work` for mobgt_floyd_warshall: mobgt_floyd_warshall_workspace_bytes(n) bytes of device scratch.
+ */
+int64_t mobgt_floyd_warshall_workspace_bytes(int n);
+int mobgt_floyd_warshall(const int64_t* adj, int n, int64_t* M, int64_t* path, void* work, void* stream);
+/* graphormer/algos.pyx:57-62 for one pair: out_nodes [n+2] int32 receives the intermediate nodes of the
+ * path i -> j, *out_len their count (-1: the path matrix does not terminate); work: 2n+4 int32. */
+int mobgt_get_all_edges(const int64_t* path, int n, int i, int j, int32_t* out_nodes, int32_t* out_len,
+                        int32_t* work, void* stream);
+int mobgt_gen_edge_input(int max_dist, const int64_t* path, const int64_t* edge_feat, int n, int F,
+                         float* out, int* err_flag, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Embedding gathers.
  *   out[r, :] = sum_t table_t[idx_t[r], :]   for up to 4 tables of equal width C   (f32)

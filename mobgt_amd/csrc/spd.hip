@@ -142,6 +142,12 @@ extern "C" int mobgt_spd_batched(const int32_t* counts, const int32_t* n_nodes, 
     hipStream_t st = (hipStream_t)stream;
     if (N <= LDS_M_MAX_N) {
         const size_t shm = (size_t)N * N * sizeof(int16_t);
+        static bool attr_set = false;
+        if (!attr_set) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fw_kernel<true>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, LDS_M_MAX_N * LDS_M_MAX_N * 2);
+            attr_set = true;
+        }
         hipLaunchKernelGGL(fw_kernel<true>, dim3(G), dim3(FW_THREADS), shm, st, counts, n_nodes, spd, path, in_degree,
                            out_degree, N);
     } else {
@@ -156,5 +162,146 @@ extern "C" int mobgt_spd_batched(const int32_t* counts, const int32_t* n_nodes, 
     } else {
         return MOBGT_EBADDIM;
     }
+    return (int)hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// Single-graph entry points with the reference's own call signatures (algos.pyx:9, :65), for the
+// per-item drop-in path (wrapper.py:55-60).  Unlike the batched kernels above they take an ARBITRARY
+// path matrix / feature tensor and emit up to max_dist hops, as gen_edge_input does.
+namespace {
+
+__global__ __launch_bounds__(256) void fw_io_kernel(const int64_t* __restrict__ adj, int32_t* __restrict__ counts, int n) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e < n * n) counts[e] = adj[e] != 0 ? 1 : 0;
+}
+
+__global__ __launch_bounds__(256) void widen_kernel(const int16_t* __restrict__ a, const int16_t* __restrict__ b,
+                                                    int64_t* __restrict__ A, int64_t* __restrict__ B, int n) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e < n * n) { A[e] = a[e]; B[e] = b[e]; }
+}
+
+__global__ __launch_bounds__(256) void fill_kernel(float* __restrict__ p, int64_t n, float v) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e < n) p[e] = v;
+}
+
+// one thread per ordered pair; LIFO of pending targets in dynamic LDS, depth = cap (>= max_dist hops)
+__global__ __launch_bounds__(64) void edge_paths_generic_kernel(const int64_t* __restrict__ path, const int64_t* __restrict__ feat,
+                                                                float* __restrict__ out, int* __restrict__ err,
+                                                                int n, int F, int max_dist, int cap) {
+    extern __shared__ __attribute__((aligned(16))) int16_t gstack[];   // [cap][64]
+    const int e = blockIdx.x * 64 + threadIdx.x;
+    if (e >= n * n) return;
+    const int i = e / n, j = e - i * n;
+    if (i == j || path[e] == UNREACH) return;                          // algos.pyx:86-90
+    const int tid = threadIdx.x;
+    int size = 1, top = 0, emitted = 0, a = i;
+    gstack[tid] = (int16_t)j;
+    long guard = 4L * n + 2L * max_dist + 8;
+    float* dst = out + (int64_t)e * max_dist * F;
+    while (size > 0 && guard-- > 0) {
+        const int t = gstack[top * 64 + tid];
+        const int k = (int)path[(int64_t)a * n + t];
+        if (k == 0) {
+            if (emitted >= max_dist) { atomicExch(err, 1); return; }  // the reference raises IndexError here
+            const int64_t* src = feat + ((int64_t)a * n + t) * F;
+            for (int f = 0; f < F; ++f) dst[(int64_t)emitted * F + f] = (float)(double)src[f];
+            ++emitted;
+            a = t;
+            top = top == 0 ? cap - 1 : top - 1;
+            --size;
+        } else {
+            top = top == cap - 1 ? 0 : top + 1;
+            gstack[top * 64 + tid] = (int16_t)k;
+            if (size < cap) ++size; else { atomicExch(err, 2); return; }   // deeper than any valid path
+        }
+    }
+    if (guard <= 0) atomicExch(err, 3);
+}
+
+}  // namespace
+
+extern "C" int mobgt_floyd_warshall(const int64_t* adj, int n, int64_t* M, int64_t* path, void* work, void* stream) {
+    // work: n*n int32 counts + 2*n*n int16 + n*n int16 + n*n*1 uint8 + 2*n int16 + 4 int32
+    if (n <= 0 || n > 32000) return MOBGT_EBADDIM;
+    hipStream_t st = (hipStream_t)stream;
+    char* w = (char*)work;
+    const size_t nn = (size_t)n * n;
+    int32_t* counts = (int32_t*)w;                w += (nn * 4 + 15) / 16 * 16;
+    int16_t* spd = (int16_t*)w;                   w += (nn * 2 + 15) / 16 * 16;
+    int16_t* pth = (int16_t*)w;                   w += (nn * 2 + 15) / 16 * 16;
+    int16_t* rel = (int16_t*)w;                   w += (nn * 2 + 15) / 16 * 16;
+    uint8_t* ei = (uint8_t*)w;                    w += (nn + 15) / 16 * 16;
+    int16_t* indeg = (int16_t*)w;                 w += ((size_t)n * 2 + 15) / 16 * 16;
+    int16_t* outdeg = (int16_t*)w;                w += ((size_t)n * 2 + 15) / 16 * 16;
+    int32_t* nn_dev = (int32_t*)w;
+    hipError_t e = hipMemcpyAsync(nn_dev, &n, sizeof(int), hipMemcpyHostToDevice, st);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(fw_io_kernel, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, st, adj, counts, n);
+    int rc = mobgt_spd_batched(counts, nn_dev, spd, pth, rel, ei, indeg, outdeg, nullptr, 1, n, 1, stream);
+    if (rc) return rc;
+    hipLaunchKernelGGL(widen_kernel, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, st, spd, pth, M, path, n);
+    return (int)hipGetLastError();
+}
+
+extern "C" int64_t mobgt_floyd_warshall_workspace_bytes(int n) {
+    const size_t nn = (size_t)n * n;
+    return (int64_t)(nn * 4 + nn * 2 * 3 + nn + (size_t)n * 4 + 256 + 16 * 8);
+}
+
+extern "C" int mobgt_gen_edge_input(int max_dist, const int64_t* path, const int64_t* edge_feat, int n, int F,
+                                    float* out, int* err_flag, void* stream) {
+    if (n <= 0 || F <= 0 || max_dist < 0) return MOBGT_EBADDIM;
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t total = (int64_t)n * n * max_dist * F;
+    hipError_t e = hipMemsetAsync(err_flag, 0, sizeof(int), st);
+    if (e != hipSuccess) return (int)e;
+    if (total == 0) return 0;
+    hipLaunchKernelGGL(fill_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, out, total, -1.0f);
+    int cap = max_dist + 1 < n + 1 ? max_dist + 1 : n + 1;      // a simple path has at most n-1 hops
+    if (cap < 2) cap = 2;
+    if (cap > 510) cap = 511;
+    const size_t shm = (size_t)cap * 64 * sizeof(int16_t);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(edge_paths_generic_kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 511 * 64 * 2);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(edge_paths_generic_kernel, dim3((unsigned)(((int64_t)n * n + 63) / 64)), dim3(64), shm, st, path,
+                       edge_feat, out, err_flag, n, F, max_dist, cap);
+    return (int)hipGetLastError();
+}
+
+namespace {
+// algos.pyx:57-62 for ONE pair, iteratively (single lane; this is an API-parity helper, not a hot path)
+__global__ void get_all_edges_kernel(const int64_t* __restrict__ path, int n, int i, int j, int32_t* __restrict__ out,
+                                     int32_t* __restrict__ out_len, int32_t* __restrict__ stack) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    int size = 1, len = 0, a = i;
+    stack[0] = j;
+    long guard = 8L * n + 16;
+    while (size > 0 && guard-- > 0) {
+        const int t = stack[size - 1];
+        const int k = (int)path[(int64_t)a * n + t];
+        if (k == 0) {
+            if (size > 1) { if (len < n + 1) out[len] = t; ++len; }   // the bottom target is j itself
+            a = t;
+            --size;
+        } else {
+            if (size >= 2 * n + 2) { *out_len = -1; return; }
+            stack[size++] = k;
+        }
+    }
+    *out_len = guard <= 0 ? -1 : len;
+}
+}  // namespace
+
+extern "C" int mobgt_get_all_edges(const int64_t* path, int n, int i, int j, int32_t* out_nodes, int32_t* out_len,
+                                   int32_t* work, void* stream) {
+    if (n <= 0 || i < 0 || j < 0 || i >= n || j >= n) return MOBGT_EBADDIM;
+    hipLaunchKernelGGL(get_all_edges_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, path, n, i, j, out_nodes, out_len, work);
     return (int)hipGetLastError();
 }

@@ -1,0 +1,151 @@
+"""Device-side batch construction: raw trajectories -> padded `Batch1` on the GPU in one pass.
+
+This is the default data path of the trainer / bench.  It replaces the per-sample
+`wrapper.preprocess_item` + `algos` calls and the per-batch `collator_*` of the reference
+(`wrapper.py:25-102`, `collator.py:310-458`) with: one host-side packing of the raw dicts
+(`gen_pickles.py:820-832` format) into padded arrays, one H2D copy each, `mobgt_spd_batched` for
+SPD / path / first-D-hop edge features / degrees, and a gather from a precomputed distance-bin table for
+`poi_pos`.  Index tensors stay narrow on the device (int16 / uint8 instead of the reference's int64):
+the kernels are templated on the index type, and `.long()` views give the reference dtypes when needed.
+Every field equals what the reference pipeline produces for the same trajectories (tests/test_gpu_data.py).
+"""
+import numpy as np
+import torch
+
+from . import ops
+from .collator import Batch1, freedman_diaconis_bins
+
+
+def make_bin_table(distance, dtype=np.int16):
+    """(P+1)x(P+1) distance matrix -> (num_bins, bin ids): bin[a,b] = np.digitize(distance[a,b], edges) with the
+    Freedman-Diaconis edges of collator.py:430-433.  Computed once instead of per batch."""
+    d = np.asarray(distance)
+    dm = np.delete(np.delete(d, 0, axis=0), 0, axis=1)
+    num_bins, edges = freedman_diaconis_bins(dm - dm.min(), True)
+    return num_bins, edges, np.digitize(d, edges).astype(dtype)
+
+
+class DeviceBatch1(Batch1):
+    """`Batch1` whose model-unused fields (adj, adj1, attn_edge_type, feature_matrix) are derived on first
+    access from the packed counts, so the hot path does not pay for them."""
+    _fields = ("idx", "attn_bias", "rel_pos", "in_degree", "out_degree", "x", "edge_input", "y", "time", "time_normal",
+               "user", "cat", "poi_pos")
+
+    def __init__(self, counts, n_nodes, **kw):
+        for f in self._fields:
+            setattr(self, f, kw[f])
+        self._feature_matrix = None
+        self._counts, self._n_nodes = counts, n_nodes
+
+    def to(self, device):
+        for f in self._fields:
+            setattr(self, f, getattr(self, f).to(device))
+        self._counts, self._n_nodes = self._counts.to(device), self._n_nodes.to(device)
+        return self
+
+    @property
+    def adj1(self):                                                   # wrapper.py:73-76, collator.py:386
+        return self._counts != 0
+
+    @property
+    def adj(self):                                                    # wrapper.py:67-81, collator.py:384
+        G, N = self._counts.shape[:2]
+        a = torch.zeros(G, N + 1, N + 1, dtype=torch.bool, device=self._counts.device)
+        a[:, :N, :N] = self._counts != 0
+        ar = torch.arange(N + 1, device=a.device)
+        n = self._n_nodes.long().view(G, 1)
+        inside = ar.view(1, -1) <= n                                  # positions 0..n of each graph
+        tok = ar.view(1, -1) == n                                     # the virtual token sits at index n
+        a |= tok.unsqueeze(2) & inside.unsqueeze(1)
+        a |= inside.unsqueeze(2) & tok.unsqueeze(1)
+        return a
+
+    @property
+    def attn_edge_type(self):                                         # wrapper.py:49-53, collator.py:412-417
+        G, N = self._counts.shape[:2]
+        t = torch.zeros(G, N + 1, N + 1, 1, dtype=torch.long, device=self._counts.device)
+        c = self._counts.long()
+        t[:, :N, :N, 0] = torch.where(c != 0, c + 2, c)
+        return t
+
+
+class DeviceCollator:
+    """callable(list of raw trajectory dicts) -> DeviceBatch1 on `device`.
+    Mirrors `partial(collator_foursquare, max_node=30000, multi_hop_max_dist=D, rel_pos_max=R)` (data.py:289-294)
+    applied to `preprocess_item`-ed items."""
+
+    def __init__(self, device, bin_table=None, multi_hop_max_dist=20, rel_pos_max=1024, max_node=30000):
+        self.device = torch.device(device)
+        self.D = int(multi_hop_max_dist)
+        self.rel_pos_max = int(rel_pos_max)
+        self.max_node = int(max_node)
+        self.bin_table = None
+        if bin_table is not None:
+            self.bin_table = torch.as_tensor(bin_table).to(self.device)
+
+    def pack_host(self, trajs, idx0=0):
+        """Raw dicts -> padded numpy arrays (pinned-memory friendly); no graph algorithm runs on the host."""
+        trajs = [t for t in trajs if t is not None and len(t["node_name"]) <= self.max_node]
+        G = len(trajs)
+        n = np.array([len(t["node_name"]) for t in trajs], dtype=np.int32)
+        N = int(n.max())
+        counts = np.zeros((G, N, N), dtype=np.int32)
+        x = np.zeros((G, N, 1), dtype=np.int32)
+        time = np.zeros((G, N, 1), dtype=np.int32)
+        cat = np.zeros((G, N, 1), dtype=np.int32)
+        time_normal = np.zeros((G, N, 1), dtype=np.float32)
+        for g, t in enumerate(trajs):
+            k = n[g]
+            counts[g, :k, :k] = t["edge_type"]
+            x[g, :k, 0] = t["node_name"]                              # wrapper +1 then collator -1 (App. A)
+            time[g, :k, 0] = t["time"]
+            cat[g, :k, 0] = t["cat"]
+            time_normal[g, :k, 0] = t["time_normal"]
+        user = np.array([[int(t["user"][0]) + 1] for t in trajs], dtype=np.int32)       # wrapper.py:39
+        y = np.array([int(t["target"][0]) for t in trajs], dtype=np.int64)              # collator.py:367
+        idx = np.arange(idx0, idx0 + G, dtype=np.int64)
+        return dict(counts=counts, n_nodes=n, x=x, time=time, cat=cat, time_normal=time_normal, user=user, y=y, idx=idx)
+
+    def __call__(self, trajs, idx0=0):
+        h = self.pack_host(trajs, idx0)
+        d = {k: torch.from_numpy(v).to(self.device, non_blocking=True) for k, v in h.items()}
+        return self.finish(d)
+
+    def finish(self, d):
+        counts, n_nodes = d["counts"], d["n_nodes"]
+        G, N = counts.shape[:2]
+        T = N + 1
+        sp = ops.spd_batched(counts, n_nodes, self.D)
+        ar = torch.arange(T, device=self.device)
+        real_tok = ar.view(1, T) <= n_nodes.view(G, 1)                # token 0 + n real nodes
+        attn_bias = torch.zeros(G, T, T, device=self.device)
+        attn_bias.masked_fill_(~real_tok.view(G, 1, T), float("-inf"))              # collator.py:57-64
+        if self.rel_pos_max <= 510:                                                  # collator.py:354-358
+            far = sp["spd"] >= self.rel_pos_max
+            attn_bias[:, 1:, 1:].masked_fill_(far, float("-inf"))
+        x = d["x"]
+        if self.bin_table is not None:
+            xi = x[:, :, 0].long()
+            poi_pos = self.bin_table[xi.unsqueeze(2), xi.unsqueeze(1)]
+            real = xi != 0
+            poi_pos = torch.where(real.unsqueeze(2) & real.unsqueeze(1), poi_pos, torch.zeros_like(poi_pos))
+        else:
+            poi_pos = torch.zeros(G, N, N, dtype=torch.int16, device=self.device)
+        return DeviceBatch1(counts, n_nodes, idx=d["idx"], attn_bias=attn_bias, rel_pos=sp["rel_pos"],
+                            in_degree=sp["in_degree"], out_degree=sp["out_degree"], x=x, edge_input=sp["edge_input"],
+                            y=d["y"], time=d["time"], time_normal=d["time_normal"], user=d["user"], cat=d["cat"],
+                            poi_pos=poi_pos)
+
+
+def shard_indices(n_samples, rank, world_size, epoch=0, seed=0, shuffle=True):
+    """torch DistributedSampler semantics (what Lightning's DDP uses, entry.py:141): permutation seeded by
+    seed+epoch, padded by wrap-around to a multiple of world_size, strided by rank."""
+    if shuffle:
+        g = torch.Generator()
+        g.manual_seed(seed + epoch)
+        order = torch.randperm(n_samples, generator=g).tolist()
+    else:
+        order = list(range(n_samples))
+    total = (n_samples + world_size - 1) // world_size * world_size
+    order += order[: total - len(order)]
+    return order[rank:total:world_size]

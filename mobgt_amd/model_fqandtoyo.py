@@ -1,0 +1,315 @@
+"""Drop-in counterpart of `graphormer/model_fqandtoyo.py` -- the Graphormer `entry.py:10` actually
+runs -- for the `foursquaregraph` and `gowalla_*` datasets, on MI355X.
+
+State-dict names and shapes equal the reference's (checked against the golden parameter list in
+tests/golden/g6_e2e.npz), including the parameters the reference defines but never uses in `forward`
+(`time_encoder`, `atom_encoder`, `poi_embed_model`, `fuse_embed`, `cat_embed_model`,
+`embed_fuse_model1`, every `self_attention_norm`).
+
+Differences in HOW (never in WHAT):
+* bias assembly + multi-hop edge reduce, the attention core and the node-feature gathers are HIP kernels
+  (`mobgt_amd.ops`);
+* the reference's per-sample Python loops (model_fqandtoyo.py:1257-1269, 1353-1358) become batched
+  gathers and two small GEMMs over all nodes; padded positions are masked to zero afterwards, as the
+  reference leaves them;
+* `embed_fuse_model3` / `final_ln` / ELU are evaluated for the graph token only -- the reference computes
+  them for tokens 0..N-1 but reads `[:, 0, :]` alone (model_fqandtoyo.py:1394-1396), so the other rows
+  never reach an output or a gradient.
+"""
+import os
+import pickle
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import ops
+from .lr import PolynomialDecayLR
+from .model import FeedForwardNetwork, MultiHeadAttention, hop_table_from, no_grad_row0
+from .modelGNN import GCN
+
+node_dim = 2000          # model_fqandtoyo.py:567
+
+
+def freedman_diaconis_bins(x, return_bins=False):
+    """model_fqandtoyo.py:570-577 / collator.py:301-308 (len(x) = rows of the matrix)."""
+    iqr = np.subtract(*np.percentile(x, [75, 25]))
+    binsize = 2 * iqr * np.power(len(x), -1 / 3)
+    bins = np.ceil((np.max(x) - np.min(x)) / binsize)
+    if return_bins:
+        return int(bins), np.histogram(x, int(bins))[1]
+    return int(bins)
+
+
+def calculate_laplacian_matrix(adj_mat, mat_type="hat_rw_normd_lap_mat"):
+    """model_fqandtoyo.py:456-486: (D+I)^-1 (A+I) with row-sum degrees (the only type the model uses)."""
+    if mat_type != "hat_rw_normd_lap_mat":
+        raise ValueError(f"ERROR: {mat_type} is unknown.")
+    adj = np.asarray(adj_mat, dtype=np.float64)
+    n = adj.shape[0]
+    deg = np.sum(adj, axis=1) + 1.0
+    return (adj + np.identity(n)) / deg[:, None]
+
+
+def GradientTailLoss(inputs, targets, alpha=0.25, beta=1, k=1):
+    """model_fqandtoyo.py:545-550 (device taken from `inputs` instead of the hard-coded "cuda")."""
+    one_hot = torch.zeros_like(inputs)
+    one_hot.scatter_(1, targets[:len(inputs)].view(-1, 1), 1)
+    prob = torch.sigmoid(inputs)
+    loss = -alpha * (1 - prob) ** k * one_hot * torch.log(prob) - (1 - one_hot) * beta * prob ** k * torch.log(1 - prob)
+    return loss.mean()
+
+
+class UserEmbeddings(nn.Module):
+    def __init__(self, num_users, embedding_dim):
+        super().__init__()
+        self.user_embedding = nn.Embedding(num_embeddings=num_users, embedding_dim=embedding_dim)
+
+    def forward(self, user_idx):
+        return self.user_embedding(user_idx)
+
+
+class CategoryEmbeddings(nn.Module):
+    def __init__(self, num_cats, embedding_dim, padding_idx=0):
+        super().__init__()
+        self.cat_embedding = nn.Embedding(num_embeddings=num_cats, embedding_dim=embedding_dim, padding_idx=padding_idx)
+
+    def forward(self, cat_idx):
+        return self.cat_embedding(cat_idx)
+
+
+class FuseEmbeddings(nn.Module):
+    """model_fqandtoyo.py:440-455"""
+
+    def __init__(self, user_embed_dim, poi_embed_dim):
+        super().__init__()
+        embed_dim = user_embed_dim + poi_embed_dim
+        self.fuse_embed = nn.Linear(embed_dim, embed_dim)
+        self.leaky_relu = nn.LeakyReLU(0.2)
+
+    def forward(self, user_embed, poi_embed):
+        return self.leaky_relu(self.fuse_embed(torch.cat((user_embed, poi_embed), user_embed.dim() - 1)))
+
+
+class LearnablePositionalEncoding(nn.Module):
+    """model_fqandtoyo.py:328-358; only the parameter lives here, the adds are fused into the gathers."""
+
+    def __init__(self, d_model, max_len, dropout=0.1):
+        super().__init__()
+        self.dropout = nn.Dropout(p=dropout)
+        self.pe = nn.Parameter(torch.empty(d_model, max_len))
+        nn.init.uniform_(self.pe, -0.02, 0.02)
+
+
+class EncoderLayer(nn.Module):
+    """model_fqandtoyo.py:1714-1743: attention WITHOUT pre-norm, LN1 before the FFN, LN2 on the output
+    (`self_attention_norm` exists for checkpoint compatibility and is unused, as in the reference)."""
+
+    def __init__(self, hidden_size, ffn_size, dropout_rate, attention_dropout_rate, num_heads):
+        super().__init__()
+        self.self_attention_norm = nn.LayerNorm(hidden_size)
+        self.self_attention = MultiHeadAttention(hidden_size, attention_dropout_rate, num_heads)
+        self.self_attention_dropout = nn.Dropout(dropout_rate)
+        self.ffn_norm1 = nn.LayerNorm(hidden_size)
+        self.ffn_norm2 = nn.LayerNorm(hidden_size)
+        self.ffn = FeedForwardNetwork(hidden_size, ffn_size, dropout_rate)
+        self.ffn_dropout = nn.Dropout(dropout_rate)
+
+    def forward(self, x, attn_bias=None, mask=None):
+        y = self.self_attention(x, x, x, attn_bias, mask=mask)
+        y = self.self_attention_dropout(y)
+        x = x + y
+        y = self.ffn_norm1(x)
+        y = self.ffn(y)
+        y = self.ffn_dropout(y)
+        x = x + y
+        return self.ffn_norm2(x)
+
+
+def load_universe(dataset_name, root=".."):
+    """Read what the reference constructor reads (model_fqandtoyo.py:650-700 / 787-838, 893 / 772): the four
+    Graph_*.csv files and the POI distance pickle, relative to `root` (the reference uses cwd = graphormer/)."""
+    import pandas as pd
+    from .synth import Universe
+    path = os.path.join(root, "dataset", dataset_name, "raw")
+    raw_X = pd.read_csv(os.path.join(path, "Graph_poi.csv"))
+    pkl = {"foursquaregraph": "tky_distance.pkl", "gowalla_nevda": "gowalla_distance.pkl",
+           "gowalla_7day": "gowalla_distance.pkl"}[dataset_name]
+    with open(os.path.join(root, "dataset", "poi_data", pkl), "rb") as f:
+        dist = pickle.load(f, encoding="iso-8859-1")
+    return Universe(P=len(raw_X), n_cat=0, n_user=0, poi_table=raw_X.to_numpy().astype(np.float64),
+                    graph_adj=pd.read_csv(os.path.join(path, "Graph_adj.csv")).to_numpy(),
+                    graph_dist=pd.read_csv(os.path.join(path, "Graph_dist.csv")).to_numpy(),
+                    graph_cat=pd.read_csv(os.path.join(path, "Graph_cat.csv")).to_numpy(),
+                    distance=np.asarray(dist), poi_columns=tuple(raw_X.columns))
+
+
+class Graphormer(nn.Module):
+    """model_fqandtoyo.py:580-1432 for dataset_name in {foursquaregraph, gowalla_nevda, gowalla_7day}.
+    `universe` (a `synth.Universe`) replaces the CSV / pickle reads when given; `num_bins` overrides the
+    Freedman-Diaconis bin count (needed when no distance matrix is materialised, e.g. P = 100k)."""
+
+    def __init__(self, n_layers, num_heads, hidden_dim, dropout_rate, intput_dropout_rate, weight_decay, ffn_dim,
+                 dataset_name, warmup_updates, tot_updates, peak_lr, end_lr, edge_type, multi_hop_max_dist,
+                 attention_dropout_rate, flag=False, flag_m=3, flag_step_size=1e-3, flag_mag=1e-3, lr_step=2,
+                 universe=None, num_bins=None, bias_dtype=torch.float32, gcn_dtype=torch.float32):
+        super().__init__()
+        if dataset_name not in ("foursquaregraph", "gowalla_nevda", "gowalla_7day"):
+            raise NotImplementedError(f"dataset_name={dataset_name!r}: only the POI-graph datasets are in scope")
+        if edge_type != "multi_hop":
+            raise NotImplementedError("only edge_type='multi_hop' is used by MobGT (README.md:62)")
+        fsq = dataset_name == "foursquaregraph"
+        self.num_virtual_tokens = 1
+        self.num_heads = num_heads
+        self.dataset_name = dataset_name
+        self.edge_type = edge_type
+        self.edge_encoder = nn.Embedding(128, num_heads, padding_idx=0)
+        self.edge_dis_encoder = nn.Embedding(128 * num_heads * num_heads, 1)
+        self.rel_pos_encoder = nn.Embedding(512, num_heads, padding_idx=0)
+        if fsq:
+            self.time_encoder = nn.Embedding(48, 512)                 # unused in forward (:786)
+
+        uni = universe if universe is not None else load_universe(dataset_name)
+        raw_X = uni.poi_table
+        P = raw_X.shape[0]
+        cats = raw_X[:, 4]
+        uniq = np.unique(cats)                                        # sklearn OneHotEncoder: sorted categories
+        num_cats = len(uniq)
+        onehot = (cats[:, None] == uniq[None, :]).astype(np.float32)
+        X = np.zeros((P, 3 + num_cats), dtype=np.float32)
+        X[:, 0] = raw_X[:, 1]
+        X[:, 1:num_cats + 1] = onehot
+        X[:, num_cats + 1] = raw_X[:, 2]
+        X[:, num_cats + 2] = raw_X[:, 3]
+        C_X = (np.arange(1, num_cats + 1)[:, None] == uniq[None, :]).astype(np.float32)
+        self.register_buffer("X", torch.from_numpy(X), persistent=False)
+        self.register_buffer("C_X", torch.from_numpy(C_X), persistent=False)
+        self.register_buffer("D_A", torch.from_numpy(calculate_laplacian_matrix(uni.graph_dist)).float().to(gcn_dtype),
+                             persistent=False)
+        self.register_buffer("C_A", torch.from_numpy(calculate_laplacian_matrix(uni.graph_cat)).float(), persistent=False)
+        # POI id (1..P) -> category id (1..n_cat); row 0 = pad.  Replaces poi_idx2cat_idx_dict (:1106-1108)
+        poi2cat = np.zeros(P + 1, dtype=np.int64)
+        poi2cat[raw_X[:, 0].astype(np.int64)] = cats.astype(np.int64)
+        self.register_buffer("poi2cat", torch.from_numpy(poi2cat), persistent=False)
+        if fsq:
+            self.atom_encoder = nn.Embedding(P, hidden_dim, padding_idx=0)   # unused in forward (:811)
+
+        self.gcn_nfeat, self.gcn_nhid = X.shape[1], [16, 64]
+        self.poi_embed_model = GCN(ninput=self.gcn_nfeat, nhid=self.gcn_nhid, noutput=hidden_dim, dropout=0.3)  # unused
+        self.fuse_embed = nn.Linear(2 * hidden_dim, hidden_dim)                                                  # unused
+        self.user_embed_dim = self.poi_embed_dim = hidden_dim
+        self.time_embed_dim = self.cat_embed_dim = 32
+        self.num_users = 937 if dataset_name == "gowalla_7day" else 1080
+        self.poi_distance_model = GCN(ninput=self.gcn_nfeat, nhid=self.gcn_nhid, noutput=hidden_dim, dropout=0.3)
+        self.poi_cat_model = GCN(ninput=C_X.shape[1], nhid=self.gcn_nhid, noutput=self.cat_embed_dim, dropout=0.1)
+        self.user_embed_model = UserEmbeddings(self.num_users, self.user_embed_dim)
+        self.time_embed_model_48 = nn.Embedding(48 + 1 if fsq else 48, self.time_embed_dim, padding_idx=0)
+        self.cat_embed_model = CategoryEmbeddings(num_cats if fsq else num_cats + 1, self.cat_embed_dim)        # unused
+        C = hidden_dim + self.time_embed_dim + self.cat_embed_dim
+        Cout = hidden_dim * 2 + self.time_embed_dim + self.cat_embed_dim
+        self.cat_decoder = nn.Linear(Cout, num_cats if fsq else num_cats + 1)
+        self.embed_fuse_model1 = FuseEmbeddings(self.user_embed_dim, self.poi_embed_dim)                         # unused
+        self.embed_fuse_model2 = FuseEmbeddings(self.poi_embed_dim, self.time_embed_dim)
+        self.embed_fuse_model3 = FuseEmbeddings(self.user_embed_dim, C)
+        self.embed_fuse_model4 = FuseEmbeddings(self.poi_embed_dim + self.time_embed_dim, self.cat_embed_dim)
+        self.pos_embed = LearnablePositionalEncoding(node_dim, C)
+        self.in_degree_encoder = nn.Embedding(128, C, padding_idx=0)
+        self.out_degree_encoder = nn.Embedding(128, C, padding_idx=0)
+        freq_col = list(uni.poi_columns).index("checkin_cnt" if dataset_name == "gowalla_7day" else "check_freq")
+        self.fre_embed_model = nn.Embedding(int(raw_X[:, freq_col].max()) + 1, C, padding_idx=0)
+        self.output_dropout = nn.Dropout(intput_dropout_rate)
+        if num_bins is None:
+            d = uni.distance
+            dm = np.delete(d, 0, axis=0)
+            if not fsq:
+                dm = np.delete(dm, 0, axis=1)        # the foursquaregraph branch discards its column delete (:894)
+            num_bins = freedman_diaconis_bins(dm - dm.min())
+        self.poi_pos_encoder = nn.Embedding(num_bins, num_heads, padding_idx=0)
+
+        self.input_dropout = nn.Dropout(intput_dropout_rate)
+        self.layers = nn.ModuleList([EncoderLayer(C, ffn_dim, dropout_rate, attention_dropout_rate, num_heads)
+                                     for _ in range(n_layers)])
+        self.final_ln = nn.LayerNorm(Cout)
+        self.out_proj = nn.Linear(Cout, P if fsq else P + 1)
+        self.ELU = nn.ELU()
+        self.graph_token = nn.Embedding(self.num_virtual_tokens, C)
+        self.graph_token_virtual_distance = nn.Embedding(self.num_virtual_tokens, num_heads)
+
+        self.warmup_updates, self.tot_updates = warmup_updates, tot_updates
+        self.peak_lr, self.end_lr, self.weight_decay = peak_lr, end_lr, weight_decay
+        self.multi_hop_max_dist = multi_hop_max_dist
+        self.hidden_dim = hidden_dim
+        self.bias_dtype = bias_dtype
+        self.gcn_dtype = gcn_dtype
+        # NB: the reference's `self.apply(init_bert_params)` is commented out here (:1099): default torch init.
+
+    # ------------------------------------------------------------------------------------------------
+    def assemble_bias(self, batched_data):
+        """model_fqandtoyo.py:1143-1216 -> ops.PackedBias (fp16 rounding points of :1178-1198 kept)."""
+        H = self.num_heads
+        edge_input = batched_data.edge_input
+        D = edge_input.shape[3]
+        if self.multi_hop_max_dist > 0:
+            D = min(D, self.multi_hop_max_dist)
+        hop = hop_table_from(self.edge_encoder.weight, self.edge_dis_encoder.weight, H, D, fp16_roundtrip=True)
+        return ops.build_bias(batched_data.attn_bias, batched_data.rel_pos, batched_data.poi_pos, edge_input,
+                              no_grad_row0(self.rel_pos_encoder.weight), no_grad_row0(self.poi_pos_encoder.weight), hop,
+                              self.graph_token_virtual_distance.weight, D, dtype=self.bias_dtype)
+
+    def node_features(self, batched_data):
+        """model_fqandtoyo.py:1222-1342 -> [G, N+1, C] (graph token first)."""
+        x = batched_data.x[:, :, 0].long()                                    # [G,N] POI ids, 0 = pad
+        G, N = x.shape
+        real = x != 0
+        poidist = self.poi_distance_model(self.X, self.D_A)                # :1236
+        catemb = self.poi_cat_model(self.C_X, self.C_A)                                        # :1237
+        slot = (batched_data.time_normal[:, :, 0] * 48).long()                                 # :1262
+        neg = torch.full_like(x, -1)
+        poi_idx = torch.where(real, x - 1, neg)                                                # :1264
+        time_idx = torch.where(real, slot, neg)
+        cat_idx = torch.where(real, self.poi2cat[x] - 1, neg)                                  # :1259
+        # [poi ; time] and the category row, gathered for every position in one pass each
+        pt = ops.embed_gather_concat([poidist, self.time_embed_model_48.weight], [poi_idx, time_idx], padding_idx=[None, 0])
+        f2 = self.embed_fuse_model2.leaky_relu(self.embed_fuse_model2.fuse_embed(pt))          # :1268
+        ce = ops.embed_gather_sum([catemb], [cat_idx])
+        nf = self.embed_fuse_model4(f2, ce)                                                    # :1269
+        nf = nf * real.unsqueeze(-1).to(nf.dtype)                                              # pads stay 0
+        # + fre_embed(0) + degree rows + positional rows pe[1..n] (:1287-1298, :348-351)
+        pos = torch.arange(1, N + 1, device=x.device).unsqueeze(0).expand(G, N)
+        pos_idx = torch.where(real & (pos <= real.sum(1, keepdim=True)), pos, neg)
+        add = ops.embed_gather_sum(
+            [self.fre_embed_model.weight, self.in_degree_encoder.weight, self.out_degree_encoder.weight, self.pos_embed.pe],
+            [torch.zeros_like(x), batched_data.in_degree.long(), batched_data.out_degree.long(), pos_idx],
+            padding_idx=[0, 0, 0, None])
+        nf = self.pos_embed.dropout(nf.float() + add)                                          # :358
+        tok = self.graph_token.weight.unsqueeze(0).repeat(G, 1, 1) + self.pos_embed.pe[0]      # :1338-1342
+        tok = self.pos_embed.dropout(tok)
+        return torch.cat([tok, nf], dim=1)
+
+    def forward(self, batched_data, perturb=None):
+        bias = self.assemble_bias(batched_data)
+        output = self.input_dropout(self.node_features(batched_data))
+        for enc_layer in self.layers:                                                          # :1347-1352
+            output = enc_layer(output, bias, mask=None)
+        user_embedding = self.user_embed_model(batched_data.user.long() - 1).reshape(output.shape[0], -1)   # :1239-1240
+        tok = self.embed_fuse_model3(output[:, 0, :].float(), user_embedding)                  # :1353-1358, q = 0 only
+        tok = self.output_dropout(self.ELU(self.final_ln(tok)))                                # :1360-1364
+        return [self.out_proj(tok), self.cat_decoder(tok)]                                     # :1394-1396
+
+    def training_step(self, batched_data, batch_idx=0):
+        """model_fqandtoyo.py:1446-1460: y-1 targets, GradientTailLoss(alpha=0.2) on the POI logits only."""
+        y_hat = self(batched_data)[0]
+        return GradientTailLoss(y_hat.float(), batched_data.y.long() - 1, 0.2)
+
+    def configure_optimizers(self, capturable=False, fused=None):
+        """model_fqandtoyo.py:1599-1616"""
+        kw = {}
+        if capturable:
+            kw["capturable"] = True
+        if fused is not None:
+            kw["fused"] = fused
+        optimizer = torch.optim.AdamW(self.parameters(), lr=self.peak_lr, weight_decay=self.weight_decay, **kw)
+        scheduler = PolynomialDecayLR(optimizer, warmup_updates=self.warmup_updates, tot_updates=self.tot_updates,
+                                      lr=self.peak_lr, end_lr=self.end_lr, power=1.0)
+        return [optimizer], [{"scheduler": scheduler, "name": "learning_rate", "interval": "step", "frequency": 1}]

@@ -319,3 +319,50 @@ def embed_gather_sum(tables, indices, padding_idx=None):
     tabs = [t.float().contiguous() for t in tables]
     out = _GatherSumFn.apply(skip, n, *tabs, *idx)
     return out.view(*shape, tabs[0].shape[1])
+
+
+class _GatherConcatFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, skip, n_tables, *args):
+        tables, idx = args[:n_tables], args[n_tables:]
+        R = idx[0].numel()
+        widths = [t.shape[1] for t in tables]
+        ctot = sum(widths)
+        out = torch.empty(R, ctot, dtype=torch.float32, device=tables[0].device)
+        off = 0
+        for t in range(n_tables):
+            dst = ctypes.c_void_p(out.data_ptr() + 4 * off)
+            check(_lib.lib().mobgt_embed_gather_sum(_ptr_array([tables[t]]), _ptr_array([idx[t]]), 1, dst, R, widths[t],
+                                                    ctot, _IT[idx[t].dtype], _stream()), "mobgt_embed_gather_sum")
+            off += widths[t]
+        ctx.idx, ctx.skip, ctx.widths = idx, skip, widths
+        ctx.shapes = [t.shape for t in tables]
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        dout = dout.contiguous()
+        n = len(ctx.shapes)
+        R, ctot = dout.shape
+        grads = [torch.zeros(s, dtype=torch.float32, device=dout.device) for s in ctx.shapes]
+        off = 0
+        for t in range(n):
+            src = ctypes.c_void_p(dout.data_ptr() + 4 * off)
+            skip = (ctypes.c_int64 * 1)(ctx.skip[t])
+            check(_lib.lib().mobgt_embed_scatter_add(_ptr_array([grads[t]]), _ptr_array([ctx.idx[t]]), skip, 1, src, R,
+                                                     ctx.widths[t], ctot, _IT[ctx.idx[t].dtype], _stream()),
+                  "mobgt_embed_scatter_add")
+            off += ctx.widths[t]
+        return (None, None, *grads, *([None] * n))
+
+
+def embed_gather_concat(tables, indices, padding_idx=None):
+    """cat_t tables[t][indices[t]] along the feature axis -> [*shape, sum C_t] (widths multiples of 4)."""
+    _require_cuda(*tables, *indices)
+    n = len(tables)
+    shape = indices[0].shape
+    skip = tuple(-1 if (padding_idx is None or padding_idx[t] is None) else int(padding_idx[t]) for t in range(n))
+    idx = [i.contiguous().reshape(-1) for i in indices]
+    tabs = [t.float().contiguous() for t in tables]
+    out = _GatherConcatFn.apply(skip, n, *tabs, *idx)
+    return out.view(*shape, out.shape[1])

@@ -1,0 +1,151 @@
+"""Train-step driver: what Lightning's fit loop + DDP plugin do for the reference (`entry.py:141-161`,
+`model_fqandtoyo.py:1434-1478, 1599-1616`), written for one process per GPU over RCCL.
+
+* `FlatGrads`: every trainable parameter's `.grad` is a view into ONE flat fp32 buffer, so zeroing is one
+  memset and the data-parallel exchange is ONE all-reduce (RCCL over xGMI).  Parameters the model never
+  uses (25 tensors in the fq variant) keep `grad = None`, exactly as under the reference, so
+  AdamW skips them the same way.
+* `TrainStep`: forward + loss + backward (+ all-reduce) + AdamW + PolynomialDecayLR.  With
+  `use_graph=True` the forward/backward and the optimizer step are captured in hipGraphs per batch
+  (static shapes per pre-collated batch); the learning rate and the dropout seed live in device scalars
+  so a replay sees new values without re-capture.
+"""
+import torch
+import torch.distributed as dist
+
+from .lr import PolynomialDecayLR
+
+
+class FlatGrads:
+    def __init__(self, params, dtype=torch.float32):
+        self.params = [p for p in params if p.requires_grad]
+        n = sum(p.numel() for p in self.params)
+        dev = self.params[0].device
+        self.flat = torch.zeros(n, dtype=dtype, device=dev)
+        off = 0
+        for p in self.params:
+            p.grad = self.flat[off:off + p.numel()].view_as(p)
+            off += p.numel()
+
+    def zero(self):
+        self.flat.zero_()
+
+    def all_reduce_mean(self, group=None):
+        """mean of the gradients over ranks (DDP semantics); no-op for world size 1."""
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
+            self.flat.div_(dist.get_world_size(group))
+
+
+def used_parameters(model, loss_fn):
+    """One dry-run backward: the parameters that receive a gradient (the others stay grad=None)."""
+    for p in model.parameters():
+        p.grad = None
+    loss_fn().backward()
+    used = [p for p in model.parameters() if p.grad is not None]
+    for p in model.parameters():
+        p.grad = None
+    return used
+
+
+def broadcast_parameters(model, src=0):
+    """DDP's construction-time broadcast: every rank starts from rank `src`'s weights."""
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        for t in list(model.parameters()) + list(model.buffers()):
+            dist.broadcast(t.data, src)
+
+
+class TrainStep:
+    def __init__(self, model, batches, autocast_dtype=None, use_graph=True, seed=1):
+        self.model = model
+        self.batches = batches
+        self.autocast_dtype = autocast_dtype
+        dev = next(model.parameters()).device
+        self.device = dev
+        self.seed_dev = torch.tensor([seed], dtype=torch.int64, device=dev)
+        for m in model.modules():
+            if hasattr(m, "seed_dev"):
+                m.seed_dev = self.seed_dev
+        model.train()
+        used = used_parameters(model, lambda: self._loss(batches[0]))
+        self.flat = FlatGrads(used)
+        self.lr_dev = torch.tensor(float(model.peak_lr), dtype=torch.float32, device=dev)
+        self.opt = torch.optim.AdamW(model.parameters(), lr=self.lr_dev, weight_decay=model.weight_decay,
+                                     capturable=True, fused=True)
+        self.sched_state = dict(step_count=1, warmup=model.warmup_updates, tot=model.tot_updates, lr=model.peak_lr,
+                                end_lr=model.end_lr, power=1.0)
+        self._set_lr()
+        self.use_graph = use_graph
+        self.graphs = {}
+        self.loss_out = torch.zeros((), device=dev)
+        self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+    # learning rate of lr.py:17-31, kept in a device scalar so captured optimizer graphs see it
+    def _set_lr(self):
+        s = self.sched_state
+        c = s["step_count"]
+        if c <= s["warmup"]:
+            lr = c / float(s["warmup"]) * s["lr"]
+        elif c >= s["tot"]:
+            lr = s["end_lr"]
+        else:
+            pct = 1 - (c - s["warmup"]) / (s["tot"] - s["warmup"])
+            lr = (s["lr"] - s["end_lr"]) * pct ** s["power"] + s["end_lr"]
+        self.lr_dev.fill_(lr)
+
+    def _loss(self, batch):
+        if self.autocast_dtype is not None:
+            with torch.autocast(device_type="cuda", dtype=self.autocast_dtype):
+                return self.model.training_step(batch, 0)
+        return self.model.training_step(batch, 0)
+
+    def _fwd_bwd(self, batch):
+        self.flat.zero()
+        self.seed_dev.add_(1)                      # new dropout masks each step (attention kernels read it on device)
+        loss = self._loss(batch)
+        loss.backward()
+        self.loss_out.copy_(loss.detach())
+
+    def _capture(self, i):
+        batch = self.batches[i]
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):                 # warm-up on a side stream (allocator, lazy inits)
+            self._fwd_bwd(batch)
+        torch.cuda.current_stream().wait_stream(s)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, pool=self.pool):
+            self._fwd_bwd(batch)
+        return g
+
+    def prepare(self):
+        """Capture one forward/backward graph per batch and one optimizer graph."""
+        if not self.use_graph:
+            return
+        self.pool = torch.cuda.graph_pool_handle()
+        for i in range(len(self.batches)):
+            self.graphs[i] = self._capture(i)
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            self.opt.step()
+        torch.cuda.current_stream().wait_stream(s)
+        self.opt_graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.opt_graph, pool=self.pool):
+            self.opt.step()
+
+    def step(self, i):
+        """One optimizer step on pre-collated batch i (model_fqandtoyo.py:1434-1478 + optimizer + scheduler)."""
+        if self.use_graph:
+            self.graphs[i % len(self.batches)].replay()
+        else:
+            self._fwd_bwd(self.batches[i % len(self.batches)])
+        if self.world > 1:
+            self.flat.all_reduce_mean()
+        if self.use_graph:
+            self.opt_graph.replay()
+        else:
+            self.opt.step()
+        self.sched_state["step_count"] += 1
+        self._set_lr()
+        return self.loss_out

@@ -94,7 +94,9 @@ def test_attention_fwd_bwd_f32(G, H, T, d, bias_dtype):
         w = want.numpy()
         np.testing.assert_allclose(got.cpu().numpy(), w, atol=gt * max(1.0, np.abs(w).max()), rtol=gt, err_msg=name)
     db = bd.grad.cpu().numpy()
-    np.testing.assert_allclose(db, br.grad.numpy(), atol=2e-3, rtol=2e-2)
+    # dS = P*(dP - delta): dP comes from bf16-rounded dO,V while delta = rowsum(dO*O) is fp32, so the
+    # cancellation leaves an absolute error of ~2^-8 * |dP| (same class as dq/dk/dv above)
+    np.testing.assert_allclose(db, br.grad.numpy(), atol=2.5e-2, rtol=2e-2)
 
 
 @pytest.mark.parametrize("G,H,T,d", [(2, 8, 33, 16), (2, 8, 70, 24), (1, 8, 130, 32)])
@@ -112,7 +114,7 @@ def test_attention_bf16_io(G, H, T, d):
     out = ops.attention(qd, kd, vd, pack, scale)
     assert out.dtype == torch.bfloat16
     out.backward(gy.to(DEV).to(torch.bfloat16))
-    np.testing.assert_allclose(out.float().cpu().numpy(), ref.detach().numpy(), atol=1.2e-2, rtol=1.2e-2)
+    np.testing.assert_allclose(out.detach().float().cpu().numpy(), ref.detach().numpy(), atol=1.2e-2, rtol=1.2e-2)
     for got, want in ((qd.grad, qr.grad), (kd.grad, kr.grad), (vd.grad, vr.grad)):
         w = want.numpy()
         np.testing.assert_allclose(got.float().cpu().numpy(), w, atol=2.5e-2 * max(1.0, np.abs(w).max()), rtol=2.5e-2)
@@ -248,7 +250,9 @@ def test_build_bias_fwd_bwd(golden_dir, variant, tag, narrow):
         if kname in ("rel_pos_encoder.weight", "edge_encoder.weight", "poi_pos_encoder.weight"):
             want[0] = 0                                  # padding_idx=0 (model.py:63,66)
         gotg = dsd[kname].grad.cpu()
-        np.testing.assert_allclose(gotg.numpy(), want.numpy(), rtol=2e-3, atol=2e-5, err_msg=kname)
+        # fq: the reference back-propagates through .half() casts (fp16 gradients, model_fqandtoyo.py:1178-1198)
+        fp16_path = variant == "fq" and kname in ("edge_encoder.weight", "edge_dis_encoder.weight")
+        np.testing.assert_allclose(gotg.numpy(), want.numpy(), rtol=2e-3, atol=2e-3 if fp16_path else 2e-5, err_msg=kname)
 
 
 # ------------------------------------------------------------------------------------------------ spd

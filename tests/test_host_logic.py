@@ -1,0 +1,117 @@
+"""CPU-side checks of the product's host logic: the C-ABI library loads and exports every symbol of
+include/mobgt_hip.h (no compute without a GPU), the drop-in collators reproduce the reference's batches
+(goldens G2/G3), LR schedule / loss / state-dict names match the reference (G6/G7)."""
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from mobgt_amd import _lib, synth, collator as pc
+from oracle import collator_oracle as co
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    _lib.build()
+    hdr = open(os.path.join(ROOT, "include", "mobgt_hip.h")).read()
+    declared = set(re.findall(r"\b(mobgt_[a-z0-9_]+)\s*\(", hdr))
+    assert declared, "no declarations parsed"
+    handle = _lib.lib()
+    for name in declared:
+        assert hasattr(handle, name), f"{name} declared in mobgt_hip.h but not exported"
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    assert handle.mobgt_abi_version() == 1
+    assert b"gfx950" in handle.mobgt_build_info()
+    # pure host helper: deterministic keep rule
+    a = [handle.mobgt_dropout_keep_host(42, 8, 33, 1, 2, 3, j, 0.1) for j in range(2000)]
+    assert a == [handle.mobgt_dropout_keep_host(42, 8, 33, 1, 2, 3, j, 0.1) for j in range(2000)]
+    assert 0.05 < 1 - np.mean(a) < 0.15
+    assert all(handle.mobgt_dropout_keep_host(42, 8, 33, 1, 2, 3, j, 0.0) for j in range(50))
+
+
+def test_ops_refuse_cpu_tensors():
+    from mobgt_amd import ops
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ops.pack_bias(torch.zeros(1, 8, 4, 4), 1, 8, 4)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ops.attention(torch.zeros(1, 4, 128), torch.zeros(1, 4, 128), torch.zeros(1, 4, 128), None, 0.25)
+
+
+def _items(z):
+    trajs = [{k: z[f"traj{i}/{k}"] for k in ("node_name", "edge_type", "target", "time", "time_normal", "user", "cat")}
+             for i in range(int(z["trajcount"]))]
+    return [co.preprocess_item(synth.trajectory_to_item(t, idx=i)) for i, t in enumerate(trajs)]
+
+
+def _cmp(z, prefix, b, fields):
+    for f in fields:
+        ref, got = z[f"{prefix}{f}"], getattr(b, f).numpy()
+        assert got.shape == ref.shape, (f, got.shape, ref.shape)
+        assert np.array_equal(got.astype(ref.dtype) if ref.dtype.kind != "f" else got, ref), f
+
+
+STOCK = ("idx", "attn_bias", "attn_edge_type", "rel_pos", "in_degree", "out_degree", "x", "edge_input", "y", "adj")
+
+
+def test_stock_collator_matches_reference(golden_dir):
+    z = np.load(os.path.join(golden_dir, "g2_collator.npz"))
+    items = _items(z)
+    b = pc.collator(items, max_node=512, multi_hop_max_dist=20, rel_pos_max=1024)
+    assert isinstance(b, pc.Batch) and len(b) == 8
+    _cmp(z, "stock/", b, STOCK)
+    _cmp(z, "stock_masked/", pc.collator(items, max_node=12, multi_hop_max_dist=5, rel_pos_max=3), STOCK)
+    assert b.to("cpu") is b
+
+
+def test_poi_collators_match_reference(golden_dir):
+    z = np.load(os.path.join(golden_dir, "g3_collator_fq.npz"))
+    items = _items(z)
+    pc.register_poi_distance("tky_distance.pkl", z["distance"])
+    pc.register_poi_distance("gowalla_distance.pkl", z["distance"])
+    fields = STOCK + ("time", "adj1", "time_normal", "user", "cat", "poi_pos")
+    bf = pc.collator_foursquare(items, max_node=30000, multi_hop_max_dist=20, rel_pos_max=1024)
+    _cmp(z, "fsq/", bf, fields)
+    _cmp(z, "gow/", pc.collator_gowalla(items, max_node=30000, multi_hop_max_dist=20, rel_pos_max=1024), fields)
+    assert tuple(bf.feature_matrix.shape) == tuple(z["fsq/feature_matrix_shape"])
+    assert pc.poi_distance("tky_distance.pkl")["num_bins"] == int(z["num_bins"])
+
+
+def test_lr_schedule_and_loss_match_reference(golden_dir):
+    from mobgt_amd.lr import PolynomialDecayLR
+    from mobgt_amd.model_fqandtoyo import GradientTailLoss
+    z = np.load(os.path.join(golden_dir, "g7_lr_loss.npz"))
+    w, t, lr, end, power = z["lr/args"]
+    p = torch.nn.Parameter(torch.zeros(1))
+    opt = torch.optim.AdamW([p], lr=lr)
+    sched = PolynomialDecayLR(opt, warmup_updates=int(w), tot_updates=int(t), lr=lr, end_lr=end, power=power)
+    got = [opt.param_groups[0]["lr"]]
+    for _ in range(len(z["lr/values"]) - 1):
+        opt.step()
+        sched.step()
+        got.append(opt.param_groups[0]["lr"])
+    np.testing.assert_allclose(got, z["lr/values"], rtol=1e-12)
+    logits = torch.from_numpy(z["gtl/logits"]).requires_grad_(True)
+    loss = GradientTailLoss(logits, torch.from_numpy(z["gtl/targets"]), 0.2)
+    loss.backward()
+    np.testing.assert_allclose(loss.item(), z["gtl/loss"], rtol=1e-6)
+    np.testing.assert_allclose(logits.grad.numpy(), z["gtl/dlogits"], rtol=1e-5, atol=1e-8)
+
+
+def test_state_dict_names_match_reference(golden_dir):
+    """Reference checkpoints must load: same parameter names and shapes, in the same order."""
+    from mobgt_amd.model_fqandtoyo import Graphormer
+    z6 = np.load(os.path.join(golden_dir, "g6_e2e.npz"))
+    uni = synth.Universe(P=64, n_cat=8, n_user=8, poi_table=z6["uni/poi_table"], graph_adj=z6["uni/graph_adj"],
+                         graph_dist=z6["uni/graph_dist"], graph_cat=z6["uni/graph_cat"], distance=z6["uni/distance"])
+    args = dict(n_layers=2, num_heads=8, hidden_dim=128, dropout_rate=0.1, intput_dropout_rate=0.1, weight_decay=0.01,
+                ffn_dim=256, warmup_updates=10, tot_updates=100, peak_lr=2e-4, end_lr=1e-9, edge_type="multi_hop",
+                multi_hop_max_dist=20, attention_dropout_rate=0.1)
+    for tag, ds in (("fsq", "foursquaregraph"), ("gow", "gowalla_nevda")):
+        m = Graphormer(dataset_name=ds, universe=uni, **args)
+        names = [n for n, _ in m.named_parameters()]
+        shapes = [str(tuple(p.shape)) for _, p in m.named_parameters()]
+        assert names == [str(n) for n in z6[f"{tag}/param_names"]]
+        assert shapes == [str(s) for s in z6[f"{tag}/param_shapes"]]
