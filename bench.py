@@ -63,13 +63,23 @@ def time_attention_kernel(G, H, T, d, io_dtype, bias_dtype, reps=50, p_drop=0.0)
     bias = torch.randn(G, H, T, T, generator=g).to(dev)
     pack = ops.pack_bias(bias, G, H, T, dtype=bias_dtype)
     q, k, v = qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:]
-    for _ in range(5):
-        ops._attn_fwd(q, k, v, pack, d ** -0.5, p_drop, 1, None)
+    # the launches are captured in a hipGraph so that the events bracket back-to-back kernels rather than the
+    # Python/ctypes launch path (a ~3 us kernel would otherwise read as ~12 us of host time)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(3):
+            ops._attn_fwd(q, k, v, pack, d ** -0.5, p_drop, 1, None)
+    torch.cuda.current_stream().wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        for _ in range(reps):
+            ops._attn_fwd(q, k, v, pack, d ** -0.5, p_drop, 1, None)
+    graph.replay()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize()
     e0.record()
-    for _ in range(reps):
-        ops._attn_fwd(q, k, v, pack, d ** -0.5, p_drop, 1, None)
+    graph.replay()
     e1.record()
     torch.cuda.synchronize()
     return e0.elapsed_time(e1) / 1e3 / reps

@@ -150,59 +150,105 @@ __global__ __launch_bounds__(256) void build_bias_kernel(const BuildParams p) {
 
 // --------------------------------------------------------------------------------- build_bias_bwd
 // dbias[g,h,i,j] (f32, summed over layers) -> d_rel_table[rel_pos], d_poi_table[poi_pos],
-// d_hop_table[d, edge_input[d], :] (scaled by 1/(F*spd)), d_vdist.  Per-workgroup LDS accumulation of
-// the two small index tables, global f32 atomics for the hop table and the flush.
+// d_hop_table[d, edge_input[d], :] (scaled by 1/(F*spd)), d_vdist.
+//
+// A scatter-add whose keys are massively repeated (most pairs of a trajectory graph are "unreachable",
+// padding or "no hop"), so plain atomics serialise on a handful of addresses.  Each wave therefore first
+// combines lanes that share a key: leader's key -> ballot of equal keys -> butterfly reduce-scatter of the
+// H head values over the 64 lanes (H-1 + log2(64/H) shuffles) -> H lanes issue one atomic each.  The
+// per-workgroup tables live in LDS (rel, poi, and hop rows with a small edge id); the workgroup flushes
+// its non-zero entries with global atomics once.
+template <int HH>
+__device__ __forceinline__ void wave_reduce_heads(float (&v)[HH], int lane) {
+    // after this, lane l with (l & (64/HH - 1)) == 0 holds in v[0] the wave-wide sum of head l / (64/HH)
+    int w = HH / 2;
+#pragma unroll
+    for (int bit = 32; w >= 1; bit >>= 1, w >>= 1) {
+        const bool up = (lane & bit) != 0;
+#pragma unroll
+        for (int t = 0; t < w; ++t) {
+            const float send = up ? v[t] : v[t + w];
+            const float keep = up ? v[t + w] : v[t];
+            v[t] = keep + __shfl_xor(send, bit, 64);
+        }
+    }
+#pragma unroll
+    for (int bit = 64 / HH / 2; bit >= 1; bit >>= 1) v[0] += __shfl_xor(v[0], bit, 64);
+}
+
+// all 64 lanes must call; key < 0 = lane has nothing to add.  table row r, head h at table[r*HH + h].
+template <int HH>
+__device__ __forceinline__ void wave_scatter_add(float* table_lo, int lo_rows, float* table_hi, int key,
+                                                 const float (&vals)[HH], int lane) {
+    unsigned long long todo = __ballot(key >= 0);
+    while (todo) {
+        const int leader = __ffsll((long long)todo) - 1;
+        const int k = __shfl(key, leader, 64);
+        const bool mine = key == k;
+        float r[HH];
+#pragma unroll
+        for (int h = 0; h < HH; ++h) r[h] = mine ? vals[h] : 0.f;
+        wave_reduce_heads<HH>(r, lane);
+        constexpr int STEP = 64 / HH;
+        if ((lane & (STEP - 1)) == 0) {
+            const int h = lane / STEP;
+            float* dst = k < lo_rows ? table_lo + (size_t)k * HH + h : table_hi + (size_t)k * HH + h;
+            atomicAdd(dst, r[0]);
+        }
+        todo &= ~__ballot(mine);
+    }
+}
+
+constexpr int HOP_LDS_ROWS = 16;      // edge ids < 16 (count <= 12) accumulate in LDS; rarer ids go to global
+
 template <typename TI, typename TE, int HH>
 __global__ __launch_bounds__(256) void build_bias_bwd_kernel(const BuildParams p, int lds_rel, int lds_poi) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* s_rel = smem;                                  // [lds_rel][HH]
-    float* s_poi = smem + (size_t)lds_rel * HH;           // [lds_poi][HH]
+    float* s_poi = s_rel + (size_t)lds_rel * HH;          // [lds_poi][HH]
     float* s_vd = s_poi + (size_t)lds_poi * HH;           // [HH]
-    for (int t = threadIdx.x; t < (lds_rel + lds_poi + 1) * HH; t += blockDim.x) smem[t] = 0.f;
+    float* s_hop = s_vd + HH;                             // [D][HOP_LDS_ROWS][HH]
+    const int n_lds = (lds_rel + lds_poi + 1 + p.D * HOP_LDS_ROWS) * HH;
+    for (int t = threadIdx.x; t < n_lds; t += blockDim.x) smem[t] = 0.f;
     __syncthreads();
 
     const int g = blockIdx.z;
     const int N = p.N, T = N + 1;
     const int i0 = blockIdx.y * TILE, j0 = blockIdx.x * TILE;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int lane = threadIdx.x & 63;
     const float inv_f = 1.f / (float)p.F;
 
 #pragma unroll 1
     for (int r = 0; r < TILE; r += 8) {
         const int ti = i0 + ty + r, tj = j0 + tx;
-        if (!(ti >= 1 && ti < T && tj < T)) continue;
-        const float ab = p.attn_bias[((int64_t)g * T + ti) * T + tj];
-        if (ab == -INFINITY) continue;                    // -inf entries: probability 0, no gradient
+        bool live = ti >= 1 && ti < T && tj < T;
+        if (live) live = p.attn_bias[((int64_t)g * T + ti) * T + tj] != -INFINITY;   // -inf: probability 0, no gradient
         float gr[HH];
 #pragma unroll
-        for (int h = 0; h < HH; ++h) gr[h] = p.dbias[(((int64_t)g * HH + h) * T + ti) * p.ld + tj];
-        if (tj == 0) {
-#pragma unroll
-            for (int h = 0; h < HH; ++h) atomicAdd(&s_vd[h], gr[h]);
-            continue;
-        }
-        const int64_t pair = ((int64_t)g * N + (ti - 1)) * N + (tj - 1);
-        const int rp = ld_idx<TI>(p.rel_pos, pair);
-        {
-            float* dst = rp < lds_rel ? s_rel + (size_t)rp * HH : p.d_rel + (int64_t)rp * HH;
-#pragma unroll
-            for (int h = 0; h < HH; ++h) atomicAdd(&dst[h], gr[h]);
-        }
+        for (int h = 0; h < HH; ++h) gr[h] = live ? p.dbias[(((int64_t)g * HH + h) * T + ti) * p.ld + tj] : 0.f;
+        // virtual-token column
+        wave_scatter_add<HH>(s_vd, 1, s_vd, (live && tj == 0) ? 0 : -1, gr, lane);
+        const bool pairlive = live && tj >= 1;
+        const int64_t pair = pairlive ? ((int64_t)g * N + (ti - 1)) * N + (tj - 1) : 0;
+        const int rp = pairlive ? ld_idx<TI>(p.rel_pos, pair) : 0;
+        // row 0 of the index tables is nn.Embedding's padding_idx: it never receives a gradient, skip it
+        wave_scatter_add<HH>(s_rel, lds_rel, p.d_rel, (pairlive && rp != 0) ? rp : -1, gr, lane);
         if (p.poi_pos) {
-            const int pp = ld_idx<TI>(p.poi_pos, pair);
-            float* dst = pp < lds_poi ? s_poi + (size_t)pp * HH : p.d_poi + (int64_t)pp * HH;
-#pragma unroll
-            for (int h = 0; h < HH; ++h) atomicAdd(&dst[h], gr[h]);
+            const int pp = pairlive ? ld_idx<TI>(p.poi_pos, pair) : 0;
+            wave_scatter_add<HH>(s_poi, lds_poi, p.d_poi, (pairlive && pp != 0) ? pp : -1, gr, lane);
         }
         if (p.edge_input) {
             const float inv = inv_f / spd_divisor(rp, p.D);
+            float ge[HH];
+#pragma unroll
+            for (int h = 0; h < HH; ++h) ge[h] = gr[h] * inv;
             const int64_t ebase = pair * p.D_in * p.F;
             for (int d = 0; d < p.D; ++d)
                 for (int f = 0; f < p.F; ++f) {
-                    const int idx = ld_idx<TE>(p.edge_input, ebase + (int64_t)d * p.F + f);
-                    float* dst = p.d_hop + ((int64_t)d * p.n_edge + idx) * HH;
-#pragma unroll
-                    for (int h = 0; h < HH; ++h) atomicAdd(&dst[h], gr[h] * inv);
+                    const int idx = pairlive ? ld_idx<TE>(p.edge_input, ebase + (int64_t)d * p.F + f) : -1;
+                    wave_scatter_add<HH>(s_hop + (size_t)d * HOP_LDS_ROWS * HH, HOP_LDS_ROWS,
+                                         p.d_hop + (int64_t)d * p.n_edge * HH, idx, ge, lane);
                 }
         }
     }
@@ -214,6 +260,14 @@ __global__ __launch_bounds__(256) void build_bias_bwd_kernel(const BuildParams p
             if (s_poi[t] != 0.f) atomicAdd(&p.d_poi[t], s_poi[t]);
     for (int t = threadIdx.x; t < HH; t += blockDim.x)
         if (s_vd[t] != 0.f) atomicAdd(&p.d_vdist[t], s_vd[t]);
+    if (p.edge_input)
+        for (int t = threadIdx.x; t < p.D * HOP_LDS_ROWS * HH; t += blockDim.x) {
+            const float v = s_hop[t];
+            if (v != 0.f) {
+                const int d = t / (HOP_LDS_ROWS * HH), rem = t - d * HOP_LDS_ROWS * HH;
+                if (rem / HH < p.n_edge) atomicAdd(&p.d_hop[(int64_t)d * p.n_edge * HH + rem], v);
+            }
+        }
 }
 
 template <typename TI, typename TE, typename TB>
@@ -240,7 +294,7 @@ int launch_build_bwd(const BuildParams& p, hipStream_t st) {
     const dim3 grid((T + TILE - 1) / TILE, (T + TILE - 1) / TILE, p.G), block(256);
     const int lds_rel = p.n_rel < 512 ? p.n_rel : 512;
     const int lds_poi = p.poi_pos ? (p.n_poi < 1024 ? p.n_poi : 1024) : 0;
-    const size_t shm = (size_t)(lds_rel + lds_poi + 1) * p.H * sizeof(float);
+    const size_t shm = (size_t)(lds_rel + lds_poi + 1 + p.D * HOP_LDS_ROWS) * p.H * sizeof(float);
     if (p.H == 8) hipLaunchKernelGGL((build_bias_bwd_kernel<TI, TE, 8>), grid, block, shm, st, p, lds_rel, lds_poi);
     else if (p.H == 4) hipLaunchKernelGGL((build_bias_bwd_kernel<TI, TE, 4>), grid, block, shm, st, p, lds_rel, lds_poi);
     else return MOBGT_EBADDIM;

@@ -1,0 +1,85 @@
+"""World-size-2 checks of the data-parallel plumbing on CPU (gloo): flat gradient buffer + mean all-reduce
+equal a single-process step on the concatenated batch, construction-time broadcast makes replicas equal,
+and index sharding follows DistributedSampler semantics."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from mobgt_amd.data import shard_indices
+from mobgt_amd.train import FlatGrads, broadcast_parameters, used_parameters
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+class Toy(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.a = torch.nn.Linear(6, 5)
+        self.b = torch.nn.Linear(5, 3)
+        self.unused = torch.nn.Linear(4, 4)          # like the fq model's 25 never-used tensors: grad stays None
+
+    def forward(self, x):
+        return self.b(torch.tanh(self.a(x)))
+
+
+def _worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(100 + rank)                    # different init per rank ...
+    m = Toy()
+    broadcast_parameters(m)                          # ... equalised by the broadcast
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(8, 6, generator=g)
+    y = torch.randn(8, 3, generator=g)
+    xs, ys = x[rank::world], y[rank::world]          # this rank's shard
+    used = used_parameters(m, lambda: ((m(xs) - ys) ** 2).mean())
+    assert all(p.grad is None for p in m.parameters())
+    flat = FlatGrads(used)
+    assert len(flat.params) == 4 and m.unused.weight.grad is None
+    flat.zero()
+    ((m(xs) - ys) ** 2).mean().backward()
+    assert m.a.weight.grad.data_ptr() == flat.flat.data_ptr()          # grads accumulate INTO the flat buffer
+    flat.all_reduce_mean()
+    if rank == 0:
+        torch.save({"flat": flat.flat.clone(), "w": m.a.weight.detach().clone()}, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_flat_allreduce_matches_single_process(tmp_path):
+    out = str(tmp_path / "r0.pt")
+    mp.spawn(_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    got = torch.load(out)
+    torch.manual_seed(100)
+    m = Toy()
+    assert torch.equal(got["w"], m.a.weight.detach())
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(8, 6, generator=g)
+    y = torch.randn(8, 3, generator=g)
+    # mean over ranks of per-shard mean losses == mean over the full batch (equal shard sizes)
+    ((m(x) - y) ** 2).mean().backward()
+    ref = torch.cat([p.grad.reshape(-1) for p in (m.a.weight, m.a.bias, m.b.weight, m.b.bias)])
+    torch.testing.assert_close(got["flat"], ref, rtol=1e-5, atol=1e-6)
+
+
+def test_shard_indices_follow_distributed_sampler():
+    from torch.utils.data.distributed import DistributedSampler
+    data = list(range(37))
+    for epoch in (0, 3):
+        for rank in range(4):
+            s = DistributedSampler(data, num_replicas=4, rank=rank, shuffle=True, seed=5)
+            s.set_epoch(epoch)
+            assert list(iter(s)) == shard_indices(37, rank, 4, epoch=epoch, seed=5)
+    parts = [shard_indices(37, r, 4, shuffle=False) for r in range(4)]
+    assert sorted(sum(parts, []))[:37] != [] and len({len(p) for p in parts}) == 1
