@@ -85,18 +85,30 @@ def time_attention_kernel(G, H, T, d, io_dtype, bias_dtype, reps=50, p_drop=0.0)
     return e0.elapsed_time(e1) / 1e3 / reps
 
 
-def cpu_baseline(model, batches, uni, seconds, max_steps=6):
+def usable_cores():
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:                                            # cgroup v2 CPU quota of the container, if any
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(per))))
+    except Exception:
+        pass
+    return n
+
+
+def cpu_baseline(model, batches, uni, seconds, max_steps=40):
     """The oracle (CPU restatement of the reference, oracle/model_oracle.py) timed on the host cores for the
-    same step definition on the same batches: forward + GradientTailLoss + backward + AdamW, train mode."""
+    same step definition on the same batches: forward + GradientTailLoss + backward + AdamW, train mode.
+    torch CPU eager does not scale to hundreds of threads on these small ops (256 threads measured 1000x
+    slower than 8), so the thread count is probed over {8, 16, 32} <= usable cores and the fastest is used."""
     from oracle import model_oracle as mo
     from types import SimpleNamespace
-    torch.set_num_threads(os.cpu_count() or 1)
     # constants as model_fqandtoyo.__init__ derives them; taken from the already-built module so that the
     # baseline does not spend a minute re-inverting the 7856^2 degree matrix (not part of a step)
     p2c = model.poi2cat.cpu().numpy()
     consts = SimpleNamespace(X=model.X.float().cpu(), D_A=model.D_A.float().cpu(), C_X=model.C_X.float().cpu(),
                              C_A=model.C_A.float().cpu(), poi2cat={i: int(c) for i, c in enumerate(p2c)})
-    sd ={k: v.detach().float().cpu().clone().requires_grad_(True) for k, v in model.state_dict().items()}
+    sd = {k: v.detach().float().cpu().clone().requires_grad_(True) for k, v in model.state_dict().items()}
     opt = torch.optim.AdamW(list(sd.values()), lr=2e-4, weight_decay=0.01)
     cb = []
     for b in batches:
@@ -106,22 +118,38 @@ def cpu_baseline(model, batches, uni, seconds, max_steps=6):
             setattr(c, f, t.float() if t.dtype.is_floating_point else t.long())
         cb.append(c)
     kw = dict(n_layers=6, H=8, D=20, p=0.1, p_in=0.1, p_att=0.1, training=True)
-    n, t_used, G = 0, 0.0, len(cb[0].y)
-    while n < max_steps and (t_used < seconds or n < 2):
-        b = cb[n % len(cb)]
+    G = len(cb[0].y)
+
+    def one_step(i):
+        b = cb[i % len(cb)]
         t0 = time.perf_counter()
         opt.zero_grad(set_to_none=True)
         loss = mo.fq_training_loss(sd, b, consts, **kw)
         loss.backward()
         opt.step()
-        dt = time.perf_counter() - t0
-        if n > 0:                                   # first step = warm-up
-            t_used += dt
+        return time.perf_counter() - t0
+
+    cores = usable_cores()
+    cands = [c for c in (8, 16, 32) if c <= cores] or [cores]
+    best, best_t = cands[0], None
+    for c in cands:                                 # probe: 1 warm-up + 1 timed step on batch 0
+        torch.set_num_threads(c)
+        one_step(0)
+        t = one_step(0)
+        if best_t is None or t < best_t:
+            best, best_t = c, t
+        if t > seconds:
+            break
+    torch.set_num_threads(best)
+    one_step(0)
+    n, t_used = 0, 0.0
+    while n < max_steps and t_used < seconds:
+        t_used += one_step(n)
         n += 1
-    steps = n - 1
-    return dict(value=G * steps / t_used, unit="check-ins/s", cores=torch.get_num_threads(), kind="port",
-                sample=f"{steps} train steps (fwd+loss+bwd+AdamW, fp32, train mode) of the oracle on the same "
-                       f"pre-collated S-FSQ batches, after 1 warm-up step; {t_used:.1f} s of CPU work")
+    return dict(value=G * n / t_used, unit="check-ins/s", cores=best, kind="port",
+                sample=f"{n} train steps (fwd+loss+bwd+AdamW, fp32, train mode, {best} torch threads of {cores} usable "
+                       f"cores) of the oracle cycling over the same pre-collated S-FSQ batches, after warm-up; "
+                       f"{t_used:.1f} s of CPU work")
 
 
 def main():
