@@ -157,7 +157,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const AttnParams p) {
             tmax = fmaxf(tmax, xhalf(tmax));
             const float m_new = fmaxf(m, tmax);
             if (__any(m_new > m)) {
-                const float alpha = exp2f((m - m_new) * MOBGT_LOG2E);
+                const float alpha = fast_exp2((m - m_new) * MOBGT_LOG2E);
 #pragma unroll
                 for (int i = 0; i < 16; ++i) o[i] *= alpha;
                 l *= alpha;
@@ -167,7 +167,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const AttnParams p) {
             float pr[16];
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
-                pr[i] = exp2f(fmaf(s[i], MOBGT_LOG2E, -ms));
+                pr[i] = fast_exp2(fmaf(s[i], MOBGT_LOG2E, -ms));
                 l += pr[i];
             }
             if (DROP) {
@@ -298,7 +298,7 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(const AttnParams p
             float ds[16];
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
-                const float pr = exp2f(fmaf(s[i], MOBGT_LOG2E, -lse2));
+                const float pr = fast_exp2(fmaf(s[i], MOBGT_LOG2E, -lse2));
                 float dpv = dp[i];
                 if (DROP) {
                     const uint32_t bits = dropout_bits16(seed, rowh, (uint32_t)(key0 + 16 * hi + i));
@@ -438,7 +438,7 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_kernel(const AttnParams 
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const int q = q0 + 16 * hi + i;
-                float pr = exp2f(fmaf(s[i], MOBGT_LOG2E, -lse16[i]));
+                float pr = fast_exp2(fmaf(s[i], MOBGT_LOG2E, -lse16[i]));
                 if (q >= T || !k_ok) pr = 0.f;
                 float dpv = dp[i], prd = pr;
                 if (DROP) {

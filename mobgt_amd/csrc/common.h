@@ -17,6 +17,10 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 // lane, so bias tiles, dBias tiles and outputs move as 16-byte vectors.
 __device__ __forceinline__ int kappa(int m) { return 16 * ((m >> 2) & 1) + 4 * (m >> 3) + (m & 3); }
 
+// raw v_exp_f32: inputs here are <= 0 (score minus running max / LSE), so the denormal-range fix-up that
+// exp2f() adds (v_ldexp + compare + select per element) buys nothing; -inf -> 0 exactly.
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
 __device__ __forceinline__ float bf16_lo(uint32_t w) { return __builtin_bit_cast(float, w << 16); }
 __device__ __forceinline__ float bf16_hi(uint32_t w) { return __builtin_bit_cast(float, w & 0xffff0000u); }
 

@@ -1,0 +1,26 @@
+"""Developer tool: torch.profiler table of one eager train step of the bench workload (GPU box only)."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import bench
+from mobgt_amd import synth
+from mobgt_amd.data import DeviceCollator, make_bin_table
+from mobgt_amd.model_fqandtoyo import Graphormer
+from mobgt_amd.train import TrainStep
+
+P = int(os.environ.get("P", "7856"))
+dev = torch.device("cuda", 0)
+uni = synth.make_universe(P=P, n_cat=300, n_user=1080, seed=1)
+nb, _, table = make_bin_table(uni.distance)
+model = Graphormer(universe=uni, num_bins=nb + 2, bias_dtype=torch.bfloat16, gcn_dtype=torch.bfloat16, **bench.MODEL_ARGS).to(dev)
+coll = DeviceCollator(dev, bin_table=table)
+batches = [coll(synth.make_batch_of_trajectories(seed=1001 + i, G=16, P=P, n_user=1080, cat_of_poi=uni.cat_of_poi)) for i in range(2)]
+ts = TrainStep(model, batches, autocast_dtype=torch.bfloat16, use_graph=False)
+for i in range(3):
+    ts.step(i)
+torch.cuda.synchronize()
+from torch.profiler import profile, ProfilerActivity
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True) as prof:
+    ts.step(1)
+    torch.cuda.synchronize()
+print(prof.key_averages(group_by_input_shape=True).table(sort_by="cuda_time_total", row_limit=45, max_name_column_width=48, max_shapes_column_width=60))
