@@ -41,6 +41,9 @@ def parse():
     ap.add_argument("--n-batches", type=int, default=8, help="distinct pre-collated batches cycled through")
     ap.add_argument("--pois", type=int, default=7856)
     ap.add_argument("--dtype", choices=["bf16", "f32"], default="bf16")
+    ap.add_argument("--gemm-dtype", choices=["bf16", "f32"], default="f32",
+                    help="dtype of the library GEMMs (projections / FFN / head); attention MFMA operands, the bias "
+                         "and the GCN adjacency product follow --dtype")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -187,7 +190,7 @@ def main():
         shapes.append((len(b), b.x.shape[1] + 1))
     torch.cuda.synchronize()
 
-    ts = TrainStep(model, batches, autocast_dtype=torch.bfloat16 if bf16 else None, use_graph=not args.no_graph,
+    ts = TrainStep(model, batches, autocast_dtype=torch.bfloat16 if (bf16 and args.gemm_dtype == "bf16") else None, use_graph=not args.no_graph,
                    seed=args.seed)
     ts.prepare()
     for i in range(args.warmup):
@@ -212,12 +215,13 @@ def main():
 
     if rank == 0:
         H, d, C = 8, 24, 192
-        io_dt = torch.bfloat16 if bf16 else torch.float32
-        s_x, s_b = (2, 2) if bf16 else (4, 4)
+        io_dt = torch.bfloat16 if (bf16 and args.gemm_dtype == "bf16") else torch.float32
+        b_dt = torch.bfloat16 if bf16 else torch.float32
+        s_x, s_b = (2 if io_dt == torch.bfloat16 else 4), (2 if bf16 else 4)
         # dominant hand kernel of the named path: the bias-fused attention forward, at the shapes the timed region ran
         used = [shapes[(args.warmup + i) % len(shapes)] for i in range(args.steps)]
         uniq = sorted(set(used))
-        dur = {s: time_attention_kernel(s[0], H, s[1], d, io_dt, io_dt, p_drop=0.1) for s in uniq}
+        dur = {s: time_attention_kernel(s[0], H, s[1], d, io_dt, b_dt, p_drop=0.1) for s in uniq}
         tot_b = sum(attn_algorithmic_bytes(g, t, C, H, s_x, s_b) for g, t in used)
         tot_t = sum(dur[s] for s in used)
         achieved = tot_b / tot_t / 1e9
@@ -225,8 +229,8 @@ def main():
                     frac=achieved / HBM_PEAK_GBS, traffic=None,
                     bytes_per_launch=tot_b / len(used), avg_launch_us=tot_t / len(used) * 1e6)
         # the same kernel at the HBM-roofline stress shape (BASELINE configs[4]: G16 x 784 nodes, C 256, d 32)
-        t5 = time_attention_kernel(16, 8, 785, 32, io_dt, io_dt, reps=30)
-        b5 = attn_algorithmic_bytes(16, 785, 256, 8, s_x, s_b)
+        t5 = time_attention_kernel(16, 8, 785, 32, b_dt, b_dt, reps=30)
+        b5 = attn_algorithmic_bytes(16, 785, 256, 8, s_b, s_b)
         roof5 = dict(kernel="attn_fwd_kernel", workload="c5 G16 T785 C256 d32", bound="hbm", achieved=b5 / t5 / 1e9,
                      peak=HBM_PEAK_GBS, unit="GB/s", frac=b5 / t5 / 1e9 / HBM_PEAK_GBS, avg_launch_us=t5 * 1e6,
                      bytes_per_launch=b5)
@@ -243,7 +247,11 @@ def main():
                                    "dropout 0.1, fwd+GradientTailLoss+bwd+allreduce+AdamW" % args.pois,
                        "global_batch": G_total, "per_gpu_batch": args.batch_size,
                        "padded_nodes_per_batch": [s[1] - 1 for s in shapes], "parallelism": f"dp{world}",
-                       "hip_graphs": not args.no_graph},
+                       "hip_graphs": not args.no_graph,
+                       "precision": {"attention_mfma_operands": args.dtype, "attn_bias": args.dtype,
+                                     "attention_io": "bf16" if io_dt == torch.bfloat16 else "f32",
+                                     "gcn_adjacency_product": args.dtype, "library_gemms": args.gemm_dtype if bf16 else "f32",
+                                     "accumulate_softmax_layernorm_adamw": "f32"}},
             "final_loss": loss,
             "roofline": roof, "roofline_stress": roof5, "cpu_baseline": cpu,
         }

@@ -208,7 +208,8 @@ __global__ __launch_bounds__(256) void build_bias_bwd_kernel(const BuildParams p
     float* s_poi = s_rel + (size_t)lds_rel * HH;          // [lds_poi][HH]
     float* s_vd = s_poi + (size_t)lds_poi * HH;           // [HH]
     float* s_hop = s_vd + HH;                             // [D][HOP_LDS_ROWS][HH]
-    const int n_lds = (lds_rel + lds_poi + 1 + p.D * HOP_LDS_ROWS) * HH;
+    float* s_len = s_hop + (size_t)p.D * HOP_LDS_ROWS * HH;   // [D+1][HH]: sums keyed by the number of real hops
+    const int n_lds = (lds_rel + lds_poi + 1 + p.D * HOP_LDS_ROWS + p.D + 1) * HH;
     for (int t = threadIdx.x; t < n_lds; t += blockDim.x) smem[t] = 0.f;
     __syncthreads();
 
@@ -244,12 +245,35 @@ __global__ __launch_bounds__(256) void build_bias_bwd_kernel(const BuildParams p
 #pragma unroll
             for (int h = 0; h < HH; ++h) ge[h] = gr[h] * inv;
             const int64_t ebase = pair * p.D_in * p.F;
-            for (int d = 0; d < p.D; ++d)
-                for (int f = 0; f < p.F; ++f) {
-                    const int idx = pairlive ? ld_idx<TE>(p.edge_input, ebase + (int64_t)d * p.F + f) : -1;
+            // Fast path (F == 1, the MobGT case): a pair's hop list is "L real hops, then zeros" (algos.pyx fills
+            // the tail with -1, collator.py:87 shifts it to 0).  The zero tail goes to table row 0 of every
+            // later hop slot -- a sum over pairs keyed by L alone -- so only the L real hops need a scatter.
+            int L = 0;
+            bool clean = true;
+            if (p.F == 1 && pairlive) {
+                bool tail = false;
+                for (int d = 0; d < p.D; ++d) {
+                    const int idx = ld_idx<TE>(p.edge_input, ebase + d);
+                    if (idx == 0) tail = true;
+                    else if (tail) clean = false;
+                    else L = d + 1;
+                }
+            }
+            if (p.F == 1 && !__any(!clean)) {
+                wave_scatter_add<HH>(s_len, p.D + 1, s_len, pairlive ? L : -1, ge, lane);
+                for (int d = 0; __any(d < L); ++d) {
+                    const int idx = (pairlive && d < L) ? ld_idx<TE>(p.edge_input, ebase + d) : -1;
                     wave_scatter_add<HH>(s_hop + (size_t)d * HOP_LDS_ROWS * HH, HOP_LDS_ROWS,
                                          p.d_hop + (int64_t)d * p.n_edge * HH, idx, ge, lane);
                 }
+            } else {
+                for (int d = 0; d < p.D; ++d)
+                    for (int f = 0; f < p.F; ++f) {
+                        const int idx = pairlive ? ld_idx<TE>(p.edge_input, ebase + (int64_t)d * p.F + f) : -1;
+                        wave_scatter_add<HH>(s_hop + (size_t)d * HOP_LDS_ROWS * HH, HOP_LDS_ROWS,
+                                             p.d_hop + (int64_t)d * p.n_edge * HH, idx, ge, lane);
+                    }
+            }
         }
     }
     __syncthreads();
@@ -260,6 +284,15 @@ __global__ __launch_bounds__(256) void build_bias_bwd_kernel(const BuildParams p
             if (s_poi[t] != 0.f) atomicAdd(&p.d_poi[t], s_poi[t]);
     for (int t = threadIdx.x; t < HH; t += blockDim.x)
         if (s_vd[t] != 0.f) atomicAdd(&p.d_vdist[t], s_vd[t]);
+    if (p.edge_input) {
+        // zero tails: hop slot d receives, in table row 0, every pair with fewer than d+1 real hops
+        for (int t = threadIdx.x; t < p.D * HH; t += blockDim.x) {
+            const int d = t / HH, h = t - d * HH;
+            float acc = 0.f;
+            for (int l = 0; l <= d; ++l) acc += s_len[l * HH + h];
+            if (acc != 0.f) atomicAdd(&p.d_hop[(int64_t)d * p.n_edge * HH + h], acc);
+        }
+    }
     if (p.edge_input)
         for (int t = threadIdx.x; t < p.D * HOP_LDS_ROWS * HH; t += blockDim.x) {
             const float v = s_hop[t];
@@ -294,7 +327,7 @@ int launch_build_bwd(const BuildParams& p, hipStream_t st) {
     const dim3 grid((T + TILE - 1) / TILE, (T + TILE - 1) / TILE, p.G), block(256);
     const int lds_rel = p.n_rel < 512 ? p.n_rel : 512;
     const int lds_poi = p.poi_pos ? (p.n_poi < 1024 ? p.n_poi : 1024) : 0;
-    const size_t shm = (size_t)(lds_rel + lds_poi + 1 + p.D * HOP_LDS_ROWS) * p.H * sizeof(float);
+    const size_t shm = (size_t)(lds_rel + lds_poi + 1 + p.D * HOP_LDS_ROWS + p.D + 1) * p.H * sizeof(float);
     if (p.H == 8) hipLaunchKernelGGL((build_bias_bwd_kernel<TI, TE, 8>), grid, block, shm, st, p, lds_rel, lds_poi);
     else if (p.H == 4) hipLaunchKernelGGL((build_bias_bwd_kernel<TI, TE, 4>), grid, block, shm, st, p, lds_rel, lds_poi);
     else return MOBGT_EBADDIM;

@@ -138,11 +138,11 @@ class EncoderLayer(nn.Module):
         y = self.self_attention_norm(x)
         y = self.self_attention(y, y, y, attn_bias, mask=mask)
         y = self.self_attention_dropout(y)
-        x = x + y
+        x = x + y.to(x.dtype)          # same-dtype add: the mixed fp32+bf16 elementwise kernel is ~20x slower on ROCm
         y = self.ffn_norm(x)
         y = self.ffn(y)
         y = self.ffn_dropout(y)
-        return x + y
+        return x + y.to(x.dtype)
 
 
 class Graphormer(nn.Module):

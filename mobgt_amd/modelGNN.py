@@ -1,12 +1,69 @@
 """`graphormer/modelGNN.py:21-74`: GraphConvolution / GCN with a dense normalised adjacency.  These are
-plain library GEMMs (hipBLASLt through torch); they produce the POI / category tables the node-feature
-gathers read (model_fqandtoyo.py:1236-1237).  Parameter names and init match the reference."""
+library GEMMs (hipBLASLt through torch), not hand kernels; they produce the POI / category tables the
+node-feature gathers read (model_fqandtoyo.py:1236-1237) and run inside every train step.  Parameter
+names and init match the reference.  Two MI355X-minded changes in HOW the same maths is evaluated:
+
+* the first layer's input X is a constant, so `A (X W)` is evaluated as `(A X) W` with `A X` computed once
+  (fp32) — that removes one P x P product from the forward and one from the backward of every step;
+* weight gradients `X^T dS` have a tiny output and K = P (7856): a plain GEMM call runs them on one or two
+  workgroups (measured 153 us each), so they are evaluated split-K as a batched GEMM + a sum.
+"""
 import math
 
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
 from torch.nn import Parameter
+
+
+def mm_tn_splitk(x, g, max_chunks=32):
+    """x^T @ g for tall-skinny x [P,a], g [P,b] (P >> a,b): split the long K axis over a batch dimension."""
+    P = x.shape[0]
+    s = max((c for c in range(1, max_chunks + 1) if P % c == 0), default=1)
+    if s == 1 or P < 2048:
+        return x.t() @ g
+    return torch.bmm(x.view(s, P // s, -1).transpose(1, 2), g.view(s, P // s, -1)).sum(0)
+
+
+class _GraphConvFn(torch.autograd.Function):
+    """out = adj @ (x @ W) + b   (modelGNN.py:38-44), with the big product in adj's dtype."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, adj):
+        support = x @ weight
+        out = torch.mm(adj, support.to(adj.dtype)).float()
+        if bias is not None:
+            out = out + bias
+        ctx.save_for_backward(x, weight, adj)
+        ctx.has_bias = bias is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, weight, adj = ctx.saved_tensors
+        d_support = torch.mm(adj.t(), g.to(adj.dtype)).float()
+        dW = mm_tn_splitk(x, d_support)
+        dx = d_support @ weight.t() if ctx.needs_input_grad[0] else None
+        db = g.sum(0) if ctx.has_bias else None
+        return dx, dW, db, None
+
+
+class _PreAggConvFn(torch.autograd.Function):
+    """out = (adj @ x) @ W + b with the constant product ax = adj @ x supplied by the caller."""
+
+    @staticmethod
+    def forward(ctx, ax, weight, bias):
+        out = ax @ weight
+        if bias is not None:
+            out = out + bias
+        ctx.save_for_backward(ax)
+        ctx.has_bias = bias is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (ax,) = ctx.saved_tensors
+        return None, mm_tn_splitk(ax, g), (g.sum(0) if ctx.has_bias else None)
 
 
 class GraphConvolution(nn.Module):
@@ -27,15 +84,13 @@ class GraphConvolution(nn.Module):
         if self.bias is not None:
             self.bias.data.uniform_(-stdv, stdv)
 
-    def forward(self, input, adj):
+    def forward(self, input, adj, adj_input=None):
         # X.W stays fp32 (raw features such as lat/lon need the mantissa); only the big dense adjacency
         # product runs in `adj`'s dtype (fp32, or bf16 in the bf16 configuration)
         with torch.autocast(device_type=input.device.type, enabled=False):
-            support = torch.mm(input.float(), self.weight)
-            output = torch.mm(adj, support.to(adj.dtype)).float()
-            if self.bias is not None:
-                output = output + self.bias
-        return output
+            if adj_input is not None:
+                return _PreAggConvFn.apply(adj_input, self.weight, self.bias)
+            return _GraphConvFn.apply(input.float(), self.weight, self.bias, adj)
 
 
 class GCN(nn.Module):
@@ -48,8 +103,9 @@ class GCN(nn.Module):
         for i in range(len(channels) - 1):
             self.gcn.append(GraphConvolution(channels[i], channels[i + 1]))
 
-    def forward(self, x, adj):
+    def forward(self, x, adj, adj_x=None):
+        """`adj_x` = adj @ x precomputed (x is a constant feature matrix in MobGT): skips the first P x P product."""
         for i in range(len(self.gcn) - 1):
-            x = self.leaky_relu(self.gcn[i](x, adj))
+            x = self.leaky_relu(self.gcn[i](x, adj, adj_x if i == 0 else None))
         x = F.dropout(x, self.dropout, training=self.training)
         return self.gcn[-1](x, adj)

@@ -119,11 +119,11 @@ class EncoderLayer(nn.Module):
     def forward(self, x, attn_bias=None, mask=None):
         y = self.self_attention(x, x, x, attn_bias, mask=mask)
         y = self.self_attention_dropout(y)
-        x = x + y
+        x = x + y.to(x.dtype)          # same-dtype add: the mixed fp32+bf16 elementwise kernel is ~20x slower on ROCm
         y = self.ffn_norm1(x)
         y = self.ffn(y)
         y = self.ffn_dropout(y)
-        x = x + y
+        x = x + y.to(x.dtype)          # same-dtype add: the mixed fp32+bf16 elementwise kernel is ~20x slower on ROCm
         return self.ffn_norm2(x)
 
 
@@ -185,9 +185,13 @@ class Graphormer(nn.Module):
         C_X = (np.arange(1, num_cats + 1)[:, None] == uniq[None, :]).astype(np.float32)
         self.register_buffer("X", torch.from_numpy(X), persistent=False)
         self.register_buffer("C_X", torch.from_numpy(C_X), persistent=False)
-        self.register_buffer("D_A", torch.from_numpy(calculate_laplacian_matrix(uni.graph_dist)).float().to(gcn_dtype),
-                             persistent=False)
-        self.register_buffer("C_A", torch.from_numpy(calculate_laplacian_matrix(uni.graph_cat)).float(), persistent=False)
+        d_a = torch.from_numpy(calculate_laplacian_matrix(uni.graph_dist)).float()
+        # A.X for the constant POI feature matrix, once, in fp32 (see modelGNN.GCN.forward)
+        self.register_buffer("D_AX", d_a @ torch.from_numpy(X), persistent=False)
+        self.register_buffer("D_A", d_a.to(gcn_dtype), persistent=False)
+        c_a = torch.from_numpy(calculate_laplacian_matrix(uni.graph_cat)).float()
+        self.register_buffer("C_A", c_a, persistent=False)
+        self.register_buffer("C_AX", c_a @ torch.from_numpy(C_X), persistent=False)
         # POI id (1..P) -> category id (1..n_cat); row 0 = pad.  Replaces poi_idx2cat_idx_dict (:1106-1108)
         poi2cat = np.zeros(P + 1, dtype=np.int64)
         poi2cat[raw_X[:, 0].astype(np.int64)] = cats.astype(np.int64)
@@ -262,8 +266,8 @@ class Graphormer(nn.Module):
         x = batched_data.x[:, :, 0].long()                                    # [G,N] POI ids, 0 = pad
         G, N = x.shape
         real = x != 0
-        poidist = self.poi_distance_model(self.X, self.D_A)                # :1236
-        catemb = self.poi_cat_model(self.C_X, self.C_A)                                        # :1237
+        poidist = self.poi_distance_model(self.X, self.D_A, self.D_AX)            # :1236
+        catemb = self.poi_cat_model(self.C_X, self.C_A, self.C_AX)                                    # :1237
         slot = (batched_data.time_normal[:, :, 0] * 48).long()                                 # :1262
         neg = torch.full_like(x, -1)
         poi_idx = torch.where(real, x - 1, neg)                                                # :1264
