@@ -177,14 +177,21 @@ __device__ __forceinline__ void wave_reduce_heads(float (&v)[HH], int lane) {
 }
 
 // all 64 lanes must call; key < 0 = lane has nothing to add.  table row r, head h at table[r*HH + h].
+// Adaptive: a key shared by >= 8 lanes of the wave ("unreachable", padding, "no hop", ...) is combined
+// in registers and costs H atomics; keys held by only a few lanes (the distinct SPDs / distance bins along
+// a trajectory) go straight to the atomic unit, where they do not collide anyway.
 template <int HH>
 __device__ __forceinline__ void wave_scatter_add(float* table_lo, int lo_rows, float* table_hi, int key,
                                                  const float (&vals)[HH], int lane) {
     unsigned long long todo = __ballot(key >= 0);
-    while (todo) {
+    unsigned long long light = 0;
+    for (int it = 0; it < 8 && todo; ++it) {
         const int leader = __ffsll((long long)todo) - 1;
         const int k = __shfl(key, leader, 64);
         const bool mine = key == k;
+        const unsigned long long same = __ballot(mine) & todo;
+        todo &= ~same;
+        if (__popcll(same) < 8) { light |= same; continue; }
         float r[HH];
 #pragma unroll
         for (int h = 0; h < HH; ++h) r[h] = mine ? vals[h] : 0.f;
@@ -195,7 +202,12 @@ __device__ __forceinline__ void wave_scatter_add(float* table_lo, int lo_rows, f
             float* dst = k < lo_rows ? table_lo + (size_t)k * HH + h : table_hi + (size_t)k * HH + h;
             atomicAdd(dst, r[0]);
         }
-        todo &= ~__ballot(mine);
+    }
+    light |= todo;
+    if ((light >> lane) & 1ull) {
+        float* dst = key < lo_rows ? table_lo + (size_t)key * HH : table_hi + (size_t)key * HH;
+#pragma unroll
+        for (int h = 0; h < HH; ++h) atomicAdd(dst + h, vals[h]);
     }
 }
 
