@@ -231,9 +231,15 @@ def main():
         # the same kernel at the HBM-roofline stress shape (BASELINE configs[4]: G16 x 784 nodes, C 256, d 32)
         t5 = time_attention_kernel(16, 8, 785, 32, b_dt, b_dt, reps=30)
         b5 = attn_algorithmic_bytes(16, 785, 256, 8, s_b, s_b)
+        traffic5 = None
+        try:        # PMC-measured HBM bytes per launch (profiles/attn_pmc.json: separate rocprofv3 --pmc passes, corrected)
+            if bf16:
+                traffic5 = json.load(open(os.path.join(ROOT, "profiles", "attn_pmc.json")))["c5_G16_H8_T785_d32_bf16"]["traffic_bytes"]
+        except Exception:
+            pass
         roof5 = dict(kernel="attn_fwd_kernel", workload="c5 G16 T785 C256 d32", bound="hbm", achieved=b5 / t5 / 1e9,
-                     peak=HBM_PEAK_GBS, unit="GB/s", frac=b5 / t5 / 1e9 / HBM_PEAK_GBS, avg_launch_us=t5 * 1e6,
-                     bytes_per_launch=b5)
+                     peak=HBM_PEAK_GBS, unit="GB/s", frac=b5 / t5 / 1e9 / HBM_PEAK_GBS, traffic=traffic5,
+                     avg_launch_us=t5 * 1e6, bytes_per_launch=b5)
         cpu = None
         if not args.no_cpu_baseline:
             cpu = cpu_baseline(model, batches, uni, args.cpu_seconds)
