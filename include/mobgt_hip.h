@@ -189,6 +189,35 @@ int mobgt_embed_scatter_add(float* const* d_tables_host, const void* const* idx_
                             int n_tables, const float* dout, int64_t R, int C, int64_t ld_dout,
                             int idx_dtype, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Fused elementwise / normalisation pieces of EncoderLayer.forward between the library GEMMs
+ * (graphormer/model.py:479-489, model_fqandtoyo.py:1731-1743) and their backward.  R rows (= G*T tokens),
+ * C columns (<= 512).  The residual stream and all statistics are f32; `act_dtype` (MOBGT_F32 / MOBGT_BF16)
+ * is the dtype of the GEMM-facing tensors y, z, dz, dy.  Dropout (nn.Dropout on the branch output,
+ * model.py:482,487) uses the attention kernels' counter hash keyed by (seed [+ *seed_dev], salt, row, column).
+ *
+ * fwd:  x1 = x + dropout(y)          (y == NULL: x1 is not written, x1 := x)
+ *       z  = LayerNorm(x1; ln_w, ln_b, eps 1e-5) written as act_dtype (z) and/or f32 (z32); ln_w == NULL: skipped
+ * bwd:  dx1 = dres + LayerNorm_bwd(dz + dz32)   -> grad of the residual input x
+ *       dy  = dropout_bwd(dx1)                  -> grad of the branch output y (dy == NULL: skipped)
+ *       dgamma/dbeta [C] += LayerNorm affine grads, dbias [C] += column sums of dy (bias grad of the Linear
+ *       that produced y); all three accumulate with f32 atomics -- zero them first.
+ */
+int mobgt_dropout_add_ln_fwd(const float* x, const void* y, float* x1, const float* ln_w, const float* ln_b,
+                             void* z, float* z32, float* mean, float* rstd, int64_t R, int C,
+                             float dropout_p, uint64_t seed, const uint64_t* seed_dev, uint32_t salt,
+                             int act_dtype, void* stream);
+int mobgt_dropout_add_ln_bwd(const void* dz, const float* dz32, const float* dres, const float* x1,
+                             const float* mean, const float* rstd, const float* ln_w, float* dx1, void* dy,
+                             float* dgamma, float* dbeta, float* dbias, int64_t R, int C, float dropout_p,
+                             uint64_t seed, const uint64_t* seed_dev, uint32_t salt, int act_dtype, void* stream);
+/* Exact-erf GELU (nn.GELU, model.py:398): h = gelu(u);  du = dh * gelu'(u) with dbias [C] += colsum(du). */
+int mobgt_gelu_fwd(const void* u, void* h, int64_t n, int act_dtype, void* stream);
+int mobgt_gelu_bwd_colsum(const void* dh, const void* u, void* du, float* dbias, int64_t R, int C,
+                          int act_dtype, void* stream);
+/* out [C] (f32) += column sums of g [R,C]: the bias gradient of a Linear layer. */
+int mobgt_colsum(const void* g, float* out, int64_t R, int C, int act_dtype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

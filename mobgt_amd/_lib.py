@@ -34,6 +34,11 @@ SIGNATURES = {
     "mobgt_floyd_warshall": (_i, [_vp, _i, _vp, _vp, _vp, _vp]),
     "mobgt_gen_edge_input": (_i, [_i, _vp, _vp, _i, _i, _vp, _vp, _vp]),
     "mobgt_get_all_edges": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "mobgt_dropout_add_ln_fwd": (_i, [_vp] * 9 + [_i64, _i, _f, _u64, _vp, _c.c_uint32, _i, _vp]),
+    "mobgt_dropout_add_ln_bwd": (_i, [_vp] * 12 + [_i64, _i, _f, _u64, _vp, _c.c_uint32, _i, _vp]),
+    "mobgt_gelu_fwd": (_i, [_vp, _vp, _i64, _i, _vp]),
+    "mobgt_gelu_bwd_colsum": (_i, [_vp, _vp, _vp, _vp, _i64, _i, _i, _vp]),
+    "mobgt_colsum": (_i, [_vp, _vp, _i64, _i, _i, _vp]),
     "mobgt_embed_gather_sum": (_i, [_vp, _vp, _i, _vp, _i64, _i, _i64, _i, _vp]),
     "mobgt_embed_scatter_add": (_i, [_vp, _vp, _vp, _i, _vp, _i64, _i, _i64, _i, _vp]),
 }

@@ -1,0 +1,304 @@
+// Fused elementwise / normalisation kernels of the encoder layer (graphormer/model.py:479-489,
+// model_fqandtoyo.py:1731-1743): everything between the library GEMMs and the attention core.
+//
+//   dropout_add_ln  : x1 = x + dropout(y);  z = LayerNorm(x1)          (model.py:482-485)
+//   gelu / gelu_bwd : exact-erf GELU of the FFN (model.py:398) and its backward
+//   colsum          : bias gradients of the Linear layers (column sums of the output gradient)
+//
+// One wave owns whole rows (C <= 512 columns, lane l owns columns l, l+64, ...), so LayerNorm statistics are
+// two wave reductions and -- because a lane owns the SAME columns in every row it visits -- the per-column
+// gradient sums (dgamma, dbeta, dbias) accumulate in registers across rows and leave the workgroup as one
+// f32 atomic per column.  Residual stream and statistics are f32; GEMM-facing tensors are f32 or bf16.
+// Dropout uses the same counter hash as the attention kernels (common.h), regenerated in the backward.
+#include "common.h"
+#include "mobgt_hip.h"
+
+namespace {
+
+constexpr int MAXC_PER_LANE = 8;     // C <= 512
+constexpr int ROWS_PER_WG = 16;      // 4 waves x 4 rows
+
+template <typename T> __device__ __forceinline__ float ldf(const T* p, int64_t i);
+template <> __device__ __forceinline__ float ldf<float>(const float* p, int64_t i) { return p[i]; }
+template <> __device__ __forceinline__ float ldf<bf16_t>(const bf16_t* p, int64_t i) { return (float)p[i]; }
+template <typename T> __device__ __forceinline__ void stf(T* p, int64_t i, float v);
+template <> __device__ __forceinline__ void stf<float>(float* p, int64_t i, float v) { p[i] = v; }
+template <> __device__ __forceinline__ void stf<bf16_t>(bf16_t* p, int64_t i, float v) { p[i] = (bf16_t)v; }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+struct LnParams {
+    const float* x;        // residual in  [R,C] f32
+    const void* y;         // branch output [R,C] (A) or null
+    float* x1;             // residual out [R,C] f32 (may alias x when y == null)
+    const float *w, *b;    // LayerNorm affine or null
+    void* z;               // LN output (A) or null
+    float* z32;            // LN output f32 or null
+    float *mean, *rstd;    // [R]
+    // backward
+    const void* dz;        // grad of LN output (A) or null
+    const float* dz32;     // grad of LN output f32 or null (added to dz)
+    const float* dres;     // grad arriving at x1 from downstream, f32 or null
+    float* dx1;            // out: total grad at x1 (f32) = grad of the residual input
+    void* dy;              // out: grad of the branch output y (A) or null
+    float *dgamma, *dbeta, *dbias;   // [C] accumulated (atomics) or null
+    int64_t R;
+    int C;
+    float inv_keep;
+    uint32_t thr;
+    uint64_t seed;
+    const uint64_t* seed_dev;
+    uint32_t salt;
+};
+
+template <typename TA>
+__global__ __launch_bounds__(256) void dropout_add_ln_fwd_kernel(const LnParams p) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint64_t seed = p.thr ? p.seed + (p.seed_dev ? *p.seed_dev : 0ull) : 0ull;
+    const float invC = 1.f / (float)p.C;
+    for (int rr = wave; rr < ROWS_PER_WG; rr += 4) {
+        const int64_t r = (int64_t)blockIdx.x * ROWS_PER_WG + rr;
+        if (r >= p.R) break;
+        float v[MAXC_PER_LANE];
+        const uint32_t rowh = p.thr ? dropout_row_hash(seed, (uint32_t)r ^ p.salt) : 0u;
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < MAXC_PER_LANE; ++k) {
+            const int c = lane + 64 * k;
+            float t = 0.f;
+            if (c < p.C) {
+                t = p.x[r * p.C + c];
+                if (p.y) {
+                    float yv = ldf<TA>(reinterpret_cast<const TA*>(p.y), r * p.C + c);
+                    if (p.thr) yv = dropout_bits16(seed, rowh, (uint32_t)c) >= p.thr ? yv * p.inv_keep : 0.f;
+                    t += yv;
+                    p.x1[r * p.C + c] = t;
+                }
+            }
+            v[k] = t;
+            s += t;
+        }
+        if (!p.w) continue;
+        const float mu = wave_sum(s) * invC;
+        float q = 0.f;
+#pragma unroll
+        for (int k = 0; k < MAXC_PER_LANE; ++k) {
+            const int c = lane + 64 * k;
+            const float d = c < p.C ? v[k] - mu : 0.f;
+            q += d * d;
+        }
+        const float rs = rsqrtf(wave_sum(q) * invC + 1e-5f);
+        if (lane == 0) { p.mean[r] = mu; p.rstd[r] = rs; }
+#pragma unroll
+        for (int k = 0; k < MAXC_PER_LANE; ++k) {
+            const int c = lane + 64 * k;
+            if (c < p.C) {
+                const float o = (v[k] - mu) * rs * p.w[c] + p.b[c];
+                if (p.z) stf<TA>(reinterpret_cast<TA*>(p.z), r * p.C + c, o);
+                if (p.z32) p.z32[r * p.C + c] = o;
+            }
+        }
+    }
+}
+
+template <typename TA>
+__global__ __launch_bounds__(256) void dropout_add_ln_bwd_kernel(const LnParams p) {
+    __shared__ float red[3][4][64 * MAXC_PER_LANE];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint64_t seed = p.thr ? p.seed + (p.seed_dev ? *p.seed_dev : 0ull) : 0ull;
+    const float invC = 1.f / (float)p.C;
+    float ag[MAXC_PER_LANE], ab[MAXC_PER_LANE], ay[MAXC_PER_LANE];
+#pragma unroll
+    for (int k = 0; k < MAXC_PER_LANE; ++k) { ag[k] = 0.f; ab[k] = 0.f; ay[k] = 0.f; }
+    for (int rr = wave; rr < ROWS_PER_WG; rr += 4) {
+        const int64_t r = (int64_t)blockIdx.x * ROWS_PER_WG + rr;
+        if (r >= p.R) break;
+        float dxv[MAXC_PER_LANE];
+#pragma unroll
+        for (int k = 0; k < MAXC_PER_LANE; ++k) dxv[k] = 0.f;
+        if (p.w) {
+            const float mu = p.mean[r], rs = p.rstd[r];
+            float xh[MAXC_PER_LANE], g[MAXC_PER_LANE];
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int k = 0; k < MAXC_PER_LANE; ++k) {
+                const int c = lane + 64 * k;
+                xh[k] = 0.f; g[k] = 0.f;
+                if (c < p.C) {
+                    float d = 0.f;
+                    if (p.dz) d += ldf<TA>(reinterpret_cast<const TA*>(p.dz), r * p.C + c);
+                    if (p.dz32) d += p.dz32[r * p.C + c];
+                    xh[k] = (p.x1[r * p.C + c] - mu) * rs;
+                    g[k] = d * p.w[c];
+                    ag[k] += d * xh[k];
+                    ab[k] += d;
+                    s1 += g[k];
+                    s2 += g[k] * xh[k];
+                }
+            }
+            s1 = wave_sum(s1) * invC;
+            s2 = wave_sum(s2) * invC;
+#pragma unroll
+            for (int k = 0; k < MAXC_PER_LANE; ++k) dxv[k] = rs * (g[k] - s1 - xh[k] * s2);
+        }
+        const uint32_t rowh = p.thr ? dropout_row_hash(seed, (uint32_t)r ^ p.salt) : 0u;
+#pragma unroll
+        for (int k = 0; k < MAXC_PER_LANE; ++k) {
+            const int c = lane + 64 * k;
+            if (c < p.C) {
+                float t = dxv[k];
+                if (p.dres) t += p.dres[r * p.C + c];
+                if (p.dx1) p.dx1[r * p.C + c] = t;
+                if (p.dy) {
+                    float yv = t;
+                    if (p.thr) yv = dropout_bits16(seed, rowh, (uint32_t)c) >= p.thr ? t * p.inv_keep : 0.f;
+                    stf<TA>(reinterpret_cast<TA*>(p.dy), r * p.C + c, yv);
+                    ay[k] += yv;
+                }
+            }
+        }
+    }
+    // column sums: registers -> LDS across the 4 waves -> one atomic per column per workgroup
+#pragma unroll
+    for (int k = 0; k < MAXC_PER_LANE; ++k) {
+        red[0][wave][lane + 64 * k] = ag[k];
+        red[1][wave][lane + 64 * k] = ab[k];
+        red[2][wave][lane + 64 * k] = ay[k];
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < p.C; c += 256) {
+        if (p.dgamma) {
+            atomicAdd(&p.dgamma[c], red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c]);
+            atomicAdd(&p.dbeta[c], red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c]);
+        }
+        if (p.dbias) atomicAdd(&p.dbias[c], red[2][0][c] + red[2][1][c] + red[2][2][c] + red[2][3][c]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------- GELU
+__device__ __forceinline__ float gelu_f(float u) { return 0.5f * u * (1.f + erff(u * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_grad(float u) {
+    const float cdf = 0.5f * (1.f + erff(u * 0.70710678118654752f));
+    const float pdf = 0.3989422804014327f * __expf(-0.5f * u * u);
+    return cdf + u * pdf;
+}
+
+template <typename TA>
+__global__ __launch_bounds__(256) void gelu_fwd_kernel(const TA* __restrict__ u, TA* __restrict__ h, int64_t n) {
+    const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i >= n) return;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if (i + k < n) stf<TA>(h, i + k, gelu_f(ldf<TA>(u, i + k)));
+}
+
+// du = dh * gelu'(u); dbias[c] += colsum(du).  Column-major ownership: thread t of the workgroup owns the
+// columns t, t+256, ... and walks ROWS rows.
+template <typename TA, bool GELU>
+__global__ __launch_bounds__(256) void colsum_kernel(const TA* __restrict__ dh, const TA* __restrict__ u, TA* __restrict__ du,
+                                                     float* __restrict__ dbias, int64_t R, int C, int rows_per_wg) {
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_wg;
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float acc = 0.f;
+        for (int rr = 0; rr < rows_per_wg; ++rr) {
+            const int64_t r = r0 + rr;
+            if (r >= R) break;
+            float g = ldf<TA>(dh, r * C + c);
+            if (GELU) {
+                g *= gelu_grad(ldf<TA>(u, r * C + c));
+                stf<TA>(du, r * C + c, g);
+            }
+            acc += g;
+        }
+        if (dbias) atomicAdd(&dbias[c], acc);
+    }
+}
+
+void set_drop(LnParams& p, float dropout_p, uint64_t seed, const uint64_t* seed_dev, uint32_t salt) {
+    p.thr = dropout_p > 0.f ? dropout_threshold(dropout_p) : 0u;
+    p.inv_keep = p.thr ? 1.f / (1.f - (float)p.thr / 65536.f) : 1.f;
+    p.seed = seed; p.seed_dev = seed_dev; p.salt = salt;
+}
+
+}  // namespace
+
+extern "C" int mobgt_dropout_add_ln_fwd(const float* x, const void* y, float* x1, const float* ln_w, const float* ln_b,
+                                        void* z, float* z32, float* mean, float* rstd, int64_t R, int C,
+                                        float dropout_p, uint64_t seed, const uint64_t* seed_dev, uint32_t salt,
+                                        int act_dtype, void* stream) {
+    if (R <= 0) return 0;
+    if (C <= 0 || C > 64 * MAXC_PER_LANE) return MOBGT_EBADDIM;
+    LnParams p = {};
+    p.x = x; p.y = y; p.x1 = x1; p.w = ln_w; p.b = ln_b; p.z = z; p.z32 = z32; p.mean = mean; p.rstd = rstd;
+    p.R = R; p.C = C;
+    set_drop(p, y ? dropout_p : 0.f, seed, seed_dev, salt);
+    const dim3 grid((unsigned)((R + ROWS_PER_WG - 1) / ROWS_PER_WG)), block(256);
+    hipStream_t st = (hipStream_t)stream;
+    if (act_dtype == MOBGT_F32) hipLaunchKernelGGL(dropout_add_ln_fwd_kernel<float>, grid, block, 0, st, p);
+    else if (act_dtype == MOBGT_BF16) hipLaunchKernelGGL(dropout_add_ln_fwd_kernel<bf16_t>, grid, block, 0, st, p);
+    else return MOBGT_EDTYPE;
+    return (int)hipGetLastError();
+}
+
+extern "C" int mobgt_dropout_add_ln_bwd(const void* dz, const float* dz32, const float* dres, const float* x1,
+                                        const float* mean, const float* rstd, const float* ln_w, float* dx1, void* dy,
+                                        float* dgamma, float* dbeta, float* dbias, int64_t R, int C, float dropout_p,
+                                        uint64_t seed, const uint64_t* seed_dev, uint32_t salt, int act_dtype,
+                                        void* stream) {
+    if (R <= 0) return 0;
+    if (C <= 0 || C > 64 * MAXC_PER_LANE) return MOBGT_EBADDIM;
+    LnParams p = {};
+    p.dz = dz; p.dz32 = dz32; p.dres = dres; p.x1 = const_cast<float*>(x1); p.mean = const_cast<float*>(mean);
+    p.rstd = const_cast<float*>(rstd); p.w = ln_w; p.dx1 = dx1; p.dy = dy; p.dgamma = dgamma; p.dbeta = dbeta;
+    p.dbias = dbias; p.R = R; p.C = C;
+    set_drop(p, dy ? dropout_p : 0.f, seed, seed_dev, salt);
+    const dim3 grid((unsigned)((R + ROWS_PER_WG - 1) / ROWS_PER_WG)), block(256);
+    hipStream_t st = (hipStream_t)stream;
+    if (act_dtype == MOBGT_F32) hipLaunchKernelGGL(dropout_add_ln_bwd_kernel<float>, grid, block, 0, st, p);
+    else if (act_dtype == MOBGT_BF16) hipLaunchKernelGGL(dropout_add_ln_bwd_kernel<bf16_t>, grid, block, 0, st, p);
+    else return MOBGT_EDTYPE;
+    return (int)hipGetLastError();
+}
+
+extern "C" int mobgt_gelu_fwd(const void* u, void* h, int64_t n, int act_dtype, void* stream) {
+    if (n <= 0) return 0;
+    const dim3 grid((unsigned)((n + 1023) / 1024)), block(256);
+    hipStream_t st = (hipStream_t)stream;
+    if (act_dtype == MOBGT_F32)
+        hipLaunchKernelGGL(gelu_fwd_kernel<float>, grid, block, 0, st, (const float*)u, (float*)h, n);
+    else if (act_dtype == MOBGT_BF16)
+        hipLaunchKernelGGL(gelu_fwd_kernel<bf16_t>, grid, block, 0, st, (const bf16_t*)u, (bf16_t*)h, n);
+    else return MOBGT_EDTYPE;
+    return (int)hipGetLastError();
+}
+
+extern "C" int mobgt_gelu_bwd_colsum(const void* dh, const void* u, void* du, float* dbias, int64_t R, int C,
+                                     int act_dtype, void* stream) {
+    if (R <= 0 || C <= 0) return 0;
+    const int rows = 16;
+    const dim3 grid((unsigned)((R + rows - 1) / rows)), block(256);
+    hipStream_t st = (hipStream_t)stream;
+    if (act_dtype == MOBGT_F32)
+        hipLaunchKernelGGL((colsum_kernel<float, true>), grid, block, 0, st, (const float*)dh, (const float*)u, (float*)du, dbias, R, C, rows);
+    else if (act_dtype == MOBGT_BF16)
+        hipLaunchKernelGGL((colsum_kernel<bf16_t, true>), grid, block, 0, st, (const bf16_t*)dh, (const bf16_t*)u, (bf16_t*)du, dbias, R, C, rows);
+    else return MOBGT_EDTYPE;
+    return (int)hipGetLastError();
+}
+
+extern "C" int mobgt_colsum(const void* g, float* out, int64_t R, int C, int act_dtype, void* stream) {
+    if (R <= 0 || C <= 0) return 0;
+    const int rows = 16;
+    const dim3 grid((unsigned)((R + rows - 1) / rows)), block(256);
+    hipStream_t st = (hipStream_t)stream;
+    if (act_dtype == MOBGT_F32)
+        hipLaunchKernelGGL((colsum_kernel<float, false>), grid, block, 0, st, (const float*)g, (const float*)nullptr, (float*)nullptr, out, R, C, rows);
+    else if (act_dtype == MOBGT_BF16)
+        hipLaunchKernelGGL((colsum_kernel<bf16_t, false>), grid, block, 0, st, (const bf16_t*)g, (const bf16_t*)nullptr, (bf16_t*)nullptr, out, R, C, rows);
+    else return MOBGT_EDTYPE;
+    return (int)hipGetLastError();
+}

@@ -1,0 +1,163 @@
+"""One autograd node per EncoderLayer (graphormer/model.py:479-489, model_fqandtoyo.py:1731-1743).
+
+The reference's layer is ~25 eager kernel launches forward and ~70 backward, almost all
+of them tiny at MobGT's sizes (G*T = a few hundred rows).  Here the forward is
+    [LN] -> QKV GEMM -> attention -> out GEMM -> dropout+residual+LN -> FFN GEMM -> GELU -> FFN GEMM ->
+    dropout+residual[+LN]
+i.e. 4 library GEMMs (bias in the epilogue), the HIP attention kernel and 3-4 fused HIP elementwise kernels
+(`csrc/layer.hip`); the backward mirrors it with 8 GEMMs, 2 attention kernels and 4-5 fused kernels that also
+produce every bias / LayerNorm gradient (column sums accumulated in registers), so no separate reduce,
+dropout-mask, cast or accumulate kernels remain.  The residual stream and all statistics are fp32; the
+GEMM-facing activations are fp32 or bf16 (`act_dtype`).
+"""
+import ctypes
+
+import torch
+
+from . import _lib, ops
+from ._lib import check
+from .ops import _p, _stream, _DT
+
+
+def _mm_f32(a, b):
+    """a @ b with an fp32 result (weight gradients go to fp32 master gradients)."""
+    if a.dtype == torch.float32:
+        return a @ b
+    return (a @ b).float()
+
+
+def _k1_fwd(x, y, x1, w, b, z, z32, mean, rstd, R, C, p, seed, seed_dev, salt, act):
+    check(_lib.lib().mobgt_dropout_add_ln_fwd(_p(x), _p(y), _p(x1), _p(w), _p(b), _p(z), _p(z32), _p(mean), _p(rstd), R, C,
+                                              p, seed, _p(seed_dev), salt, act, _stream()), "mobgt_dropout_add_ln_fwd")
+
+
+def _k1_bwd(dz, dz32, dres, x1, mean, rstd, w, dx1, dy, dgamma, dbeta, dbias, R, C, p, seed, seed_dev, salt, act):
+    check(_lib.lib().mobgt_dropout_add_ln_bwd(_p(dz), _p(dz32), _p(dres), _p(x1), _p(mean), _p(rstd), _p(w), _p(dx1), _p(dy),
+                                              _p(dgamma), _p(dbeta), _p(dbias), R, C, p, seed, _p(seed_dev), salt, act,
+                                              _stream()), "mobgt_dropout_add_ln_bwd")
+
+
+class LayerConfig:
+    """Per-call constants of one fused layer (not tensors that need gradients)."""
+
+    def __init__(self, variant, num_heads, scale, p_drop, p_att, seed, seed_dev, salt, pack, act_dtype):
+        self.variant, self.H, self.scale = variant, num_heads, scale
+        self.p, self.p_att = float(p_drop), float(p_att)
+        self.seed, self.seed_dev, self.salt = int(seed), seed_dev, int(salt) & 0xFFFFFFFF
+        self.pack = pack
+        self.act_dtype = act_dtype
+
+
+class _FusedLayerFn(torch.autograd.Function):
+    """params (fp32 masters, reference names):
+       fq   : wq, bq, wk, bk, wv, bv, wo, bo, n1 = ffn_norm1, nx = ffn_norm2, w1, b1, w2, b2
+       stock: wq, bq, wk, bk, wv, bv, wo, bo, n1 = ffn_norm,  nx = self_attention_norm, w1, b1, w2, b2
+    `shadows`: (wqkv [3C,C], bqkv [3C], wo, bo, w1, b1, w2, b2) in act_dtype (the fused masters when fp32)."""
+
+    @staticmethod
+    def forward(ctx, x, token, cfg, shadows, wq, bq, wk, bk, wv, bv, wo, bo, n1w, n1b, nxw, nxb, w1, b1, w2, b2):
+        # wq/wk/wv (+ biases) are views of one fused [3C, C] storage (MultiHeadAttention.fuse_qkv_storage); they
+        # are separate arguments only so that autograd has an edge to each reference-named parameter.
+        G, T, C = x.shape
+        R = G * T
+        A = cfg.act_dtype
+        act = _DT[A]
+        dev = x.device
+        s_wqkv, s_bqkv, s_wo, s_bo, s_w1, s_b1, s_w2, s_b2 = shadows
+        x = x.contiguous()
+        f32 = dict(dtype=torch.float32, device=dev)
+        stats = torch.empty(6, R, **f32)
+        seed, sd, salt = cfg.seed, cfg.seed_dev, cfg.salt
+        stock = cfg.variant == "stock"
+        if stock:                                                     # y = self_attention_norm(x)  (model.py:480)
+            xa = torch.empty(R, C, dtype=A, device=dev)
+            _k1_fwd(x, None, None, nxw, nxb, xa, None, stats[0], stats[1], R, C, 0.0, seed, sd, salt, act)
+        else:
+            xa = x.view(R, C) if A == torch.float32 else x.view(R, C).to(A)
+        qkv = torch.addmm(s_bqkv, xa, s_wqkv.t()).view(G, T, 3 * C)
+        q, k, v = qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:]
+        a, lse = ops._attn_fwd(q, k, v, cfg.pack, cfg.scale, cfg.p_att, seed ^ (salt * 0x9E3779B1), sd)
+        y = torch.addmm(s_bo, a.view(R, C), s_wo.t())
+        x1 = torch.empty(R, C, **f32)
+        z = torch.empty(R, C, dtype=A, device=dev)
+        _k1_fwd(x, y, x1, n1w, n1b, z, None, stats[2], stats[3], R, C, cfg.p, seed, sd, salt + 1, act)
+        u = torch.addmm(s_b1, z, s_w1.t())
+        h = torch.empty_like(u)
+        check(_lib.lib().mobgt_gelu_fwd(_p(u), _p(h), u.numel(), act, _stream()), "mobgt_gelu_fwd")
+        f = torch.addmm(s_b2, h, s_w2.t())
+        x2 = torch.empty(R, C, **f32)
+        if stock:                                                     # x = x + dropout(ffn(...))  (model.py:485-488)
+            _k1_fwd(x1, f, x2, None, None, None, None, None, None, R, C, cfg.p, seed, sd, salt + 2, act)
+            out = x2
+        else:                                                         # ... then ffn_norm2 (model_fqandtoyo.py:1742)
+            out = torch.empty(R, C, **f32)
+            _k1_fwd(x1, f, x2, nxw, nxb, None, out, stats[4], stats[5], R, C, cfg.p, seed, sd, salt + 2, act)
+        ctx.cfg = cfg
+        ctx.shapes = (G, T, C)
+        ctx.save_for_backward(x, xa, qkv, a, lse, x1, z, u, h, x2, stats, s_wqkv, s_wo, s_w1, s_w2, n1w, nxw)
+        return out.view(G, T, C)
+
+    @staticmethod
+    def backward(ctx, dout):
+        cfg = ctx.cfg
+        G, T, C = ctx.shapes
+        R = G * T
+        x, xa, qkv, a, lse, x1, z, u, h, x2, stats, s_wqkv, s_wo, s_w1, s_w2, n1w, nxw = ctx.saved_tensors
+        A = cfg.act_dtype
+        act = _DT[A]
+        dev = dout.device
+        seed, sd, salt = cfg.seed, cfg.seed_dev, cfg.salt
+        stock = cfg.variant == "stock"
+        F = s_w1.shape[0]
+        dout = dout.contiguous().view(R, C).float()
+        # every small gradient of the layer in ONE zero-filled buffer:
+        # [dbqkv 3C | dbo C | db1 F | db2 C | dn1w C | dn1b C | dnxw C | dnxb C]
+        small = torch.zeros(3 * C + C + F + C + 4 * C, dtype=torch.float32, device=dev)
+        o = [0]
+
+        def take(n):
+            t = small[o[0]:o[0] + n]
+            o[0] += n
+            return t
+        dbqkv, dbo, db1, db2, dn1w, dn1b, dnxw, dnxb = take(3 * C), take(C), take(F), take(C), take(C), take(C), take(C), take(C)
+        df = torch.empty(R, C, dtype=A, device=dev)
+        if stock:
+            dx2 = dout                                                # grad at x2 = x1 + dropout(f)
+            _k1_bwd(None, None, dout, x2, None, None, None, None, df, None, None, db2, R, C, cfg.p, seed, sd, salt + 2, act)
+        else:
+            dx2 = torch.empty(R, C, dtype=torch.float32, device=dev)  # through ffn_norm2
+            _k1_bwd(None, dout, None, x2, stats[4], stats[5], nxw, dx2, df, dnxw, dnxb, db2, R, C, cfg.p, seed, sd,
+                    salt + 2, act)
+        dh = df @ s_w2
+        dw2 = _mm_f32(df.t(), h)
+        du = torch.empty_like(u)
+        check(_lib.lib().mobgt_gelu_bwd_colsum(_p(dh), _p(u), _p(du), _p(db1), R, F, act, _stream()), "mobgt_gelu_bwd_colsum")
+        dz = du @ s_w1
+        dw1 = _mm_f32(du.t(), z)
+        dx1 = torch.empty(R, C, dtype=torch.float32, device=dev)
+        dy = torch.empty(R, C, dtype=A, device=dev)
+        _k1_bwd(dz, None, dx2, x1, stats[2], stats[3], n1w, dx1, dy, dn1w, dn1b, dbo, R, C, cfg.p, seed, sd, salt + 1, act)
+        da = (dy @ s_wo).view(G, T, C)
+        dwo = _mm_f32(dy.t(), a.view(R, C))
+        dqkv = torch.empty(G, T, 3 * C, dtype=A, device=dev)
+        q, k, v = qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:]
+        ops._attn_bwd(q, k, v, a, lse, da, dqkv[..., :C], dqkv[..., C:2 * C], dqkv[..., 2 * C:], cfg.pack, cfg.scale,
+                      cfg.p_att, seed ^ (salt * 0x9E3779B1), sd)
+        dqkv2 = dqkv.view(R, 3 * C)
+        check(_lib.lib().mobgt_colsum(_p(dqkv2), _p(dbqkv), R, 3 * C, act, _stream()), "mobgt_colsum")
+        dwqkv = _mm_f32(dqkv2.t(), xa)
+        if stock:                                                     # back through self_attention_norm
+            dz0 = dqkv2 @ s_wqkv
+            dx = torch.empty(R, C, dtype=torch.float32, device=dev)
+            _k1_bwd(dz0, None, dx1, x.view(R, C), stats[0], stats[1], nxw, dx, None, dnxw, dnxb, None, R, C, 0.0, seed, sd,
+                    salt, act)
+        elif A == torch.float32:
+            dx = torch.addmm(dx1, dqkv2, s_wqkv)
+        else:
+            dx = dx1 + (dqkv2 @ s_wqkv).float()
+        return (dx.view(G, T, C), None, None, None, dwqkv[:C], dbqkv[:C], dwqkv[C:2 * C], dbqkv[C:2 * C], dwqkv[2 * C:],
+                dbqkv[2 * C:], dwo, dbo, dn1w, dn1b, dnxw, dnxb, dw1, db1, dw2, db2)
+
+
+def fused_encoder_layer(x, pack, cfg, shadows, params):
+    return _FusedLayerFn.apply(x, pack.token, cfg, shadows, *params)

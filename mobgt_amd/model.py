@@ -86,6 +86,27 @@ class MultiHeadAttention(nn.Module):
         self._pack_cache = None
         self.seed_dev = None            # optional device int64 scalar: advanced by the trainer each step
 
+    def fuse_qkv_storage(self):
+        """Make linear_q/k/v.weight (and .bias) views of one [3C, C] (and [3C]) tensor so that the QKV projection
+        is a single GEMM without a per-step concatenation.  Parameter objects, names and values are unchanged
+        (state_dict / optimizer are unaffected); re-run after .to(device) / load_state_dict re-allocations."""
+        ws = [self.linear_q.weight, self.linear_k.weight, self.linear_v.weight]
+        bs = [self.linear_q.bias, self.linear_k.bias, self.linear_v.bias]
+        C = ws[0].shape[0]
+        fw = getattr(self, "_wqkv", None)
+        ok = fw is not None and fw.device == ws[0].device and all(
+            w.data_ptr() == fw.data_ptr() + i * C * w.shape[1] * 4 for i, w in enumerate(ws)) and all(
+            b.data_ptr() == self._bqkv.data_ptr() + i * C * 4 for i, b in enumerate(bs))
+        if not ok:
+            with torch.no_grad():
+                fw = torch.cat([w.detach().float() for w in ws], dim=0).contiguous()
+                fb = torch.cat([b.detach().float() for b in bs], dim=0).contiguous()
+                for i, (w, b) in enumerate(zip(ws, bs)):
+                    w.data = fw[i * C:(i + 1) * C]
+                    b.data = fb[i * C:(i + 1) * C]
+            self._wqkv, self._bqkv = fw, fb
+        return self._wqkv, self._bqkv
+
     def _packed(self, attn_bias, G, T, ref):
         if isinstance(attn_bias, ops.PackedBias):
             return attn_bias
@@ -122,8 +143,73 @@ class MultiHeadAttention(nn.Module):
         return x
 
 
+_fused_layer_ids = [0]
+
+
+def fused_layer_forward(layer, variant, x, attn_bias, n1, nx):
+    """Run one EncoderLayer as a single fused autograd node (mobgt_amd/fused_layer.py).  `n1` is the LayerNorm in
+    front of the FFN, `nx` the variant's other LayerNorm (self_attention_norm for model.py, ffn_norm2 for fq)."""
+    from .fused_layer import LayerConfig, fused_encoder_layer
+    mha = layer.self_attention
+    G, T, C = x.shape
+    pack = mha._packed(attn_bias, G, T, x)
+    wqkv, bqkv = mha.fuse_qkv_storage()
+    act = getattr(layer, "act_dtype", torch.float32)
+    masters = (wqkv, bqkv, mha.output_layer.weight, mha.output_layer.bias, layer.ffn.layer1.weight, layer.ffn.layer1.bias,
+               layer.ffn.layer2.weight, layer.ffn.layer2.bias)
+    if act == torch.float32:
+        shadows = tuple(m.detach() for m in masters)
+    else:
+        sh = getattr(layer, "_shadows", None)
+        if sh is None or sh[0].device != x.device or sh[0].dtype != act:
+            sh = tuple(torch.empty_like(m, dtype=act) for m in masters)
+            layer._shadows = sh
+            layer._shadow_fresh = False
+        if not getattr(layer, "_shadow_fresh", False):          # the model refreshes all layers in one call
+            torch._foreach_copy_(list(sh), [m.detach() for m in masters])
+        layer._shadow_fresh = False
+        shadows = sh
+    training = layer.training
+    p = layer.self_attention_dropout.p if training else 0.0
+    p_att = mha.att_dropout.p if training else 0.0
+    seed = mha._seed_salt
+    if (p > 0 or p_att > 0) and mha.seed_dev is None:
+        seed = (seed + int(torch.randint(0, 2 ** 31 - 1, (1,)).item())) & 0x7FFFFFFFFFFFFFFF
+    if not hasattr(layer, "_fused_id"):
+        _fused_layer_ids[0] += 1
+        layer._fused_id = _fused_layer_ids[0]
+    cfg = LayerConfig(variant, mha.num_heads, mha.scale, p, p_att, seed, mha.seed_dev, layer._fused_id * 8, pack, act)
+    params = (mha.linear_q.weight, mha.linear_q.bias, mha.linear_k.weight, mha.linear_k.bias, mha.linear_v.weight,
+              mha.linear_v.bias, mha.output_layer.weight, mha.output_layer.bias, n1.weight, n1.bias, nx.weight, nx.bias,
+              layer.ffn.layer1.weight, layer.ffn.layer1.bias, layer.ffn.layer2.weight, layer.ffn.layer2.bias)
+    return fused_encoder_layer(x.float(), pack, cfg, shadows, params)
+
+
+def refresh_shadows(layers):
+    """bf16 copies of every layer's GEMM weights in ONE multi-tensor copy (call once per forward)."""
+    dst, src = [], []
+    for layer in layers:
+        if getattr(layer, "act_dtype", torch.float32) == torch.float32 or not layer.fused:
+            continue
+        mha = layer.self_attention
+        wqkv, bqkv = mha.fuse_qkv_storage()
+        masters = (wqkv, bqkv, mha.output_layer.weight, mha.output_layer.bias, layer.ffn.layer1.weight, layer.ffn.layer1.bias,
+                   layer.ffn.layer2.weight, layer.ffn.layer2.bias)
+        sh = getattr(layer, "_shadows", None)
+        if sh is None or sh[0].device != wqkv.device or sh[0].dtype != layer.act_dtype:
+            sh = tuple(torch.empty_like(m, dtype=layer.act_dtype) for m in masters)
+            layer._shadows = sh
+        dst += list(sh)
+        src += [m.detach() for m in masters]
+        layer._shadow_fresh = True
+    if dst:
+        torch._foreach_copy_(dst, src)
+
+
 class EncoderLayer(nn.Module):
     """model.py:463-489 (pre-LN)."""
+    fused = True                 # one fused autograd node per layer on the GPU; False = op-by-op torch + HIP attention
+    act_dtype = torch.float32    # dtype of the GEMM-facing activations in the fused path (fp32 or bf16)
 
     def __init__(self, hidden_size, ffn_size, dropout_rate, attention_dropout_rate, num_heads):
         super().__init__()
@@ -135,6 +221,8 @@ class EncoderLayer(nn.Module):
         self.ffn_dropout = nn.Dropout(dropout_rate)
 
     def forward(self, x, attn_bias=None, mask=None):
+        if self.fused and x.is_cuda and mask is None:
+            return fused_layer_forward(self, "stock", x, attn_bias, self.ffn_norm, self.self_attention_norm)
         y = self.self_attention_norm(x)
         y = self.self_attention(y, y, y, attn_bias, mask=mask)
         y = self.self_attention_dropout(y)
@@ -151,7 +239,8 @@ class Graphormer(nn.Module):
 
     def __init__(self, n_layers, num_heads, hidden_dim, dropout_rate, intput_dropout_rate, weight_decay, ffn_dim,
                  dataset_name, warmup_updates, tot_updates, peak_lr, end_lr, edge_type, multi_hop_max_dist,
-                 attention_dropout_rate, num_class=1, bias_dtype=torch.float32, **_unused):
+                 attention_dropout_rate, num_class=1, bias_dtype=torch.float32, act_dtype=torch.float32, fused_layers=True,
+                 **_unused):
         super().__init__()
         self.num_heads = num_heads
         self.atom_encoder = nn.Embedding(512 * 9 + 1, hidden_dim, padding_idx=0)
@@ -165,6 +254,8 @@ class Graphormer(nn.Module):
         self.input_dropout = nn.Dropout(intput_dropout_rate)
         self.layers = nn.ModuleList([EncoderLayer(hidden_dim, ffn_dim, dropout_rate, attention_dropout_rate, num_heads)
                                      for _ in range(n_layers)])
+        for layer in self.layers:
+            layer.act_dtype, layer.fused = act_dtype, fused_layers
         self.final_ln = nn.LayerNorm(hidden_dim)
         self.downstream_out_proj = nn.Linear(hidden_dim, num_class)
         self.graph_token = nn.Embedding(1, hidden_dim)
@@ -196,6 +287,7 @@ class Graphormer(nn.Module):
         in_degree = out_degree = batched_data.in_degree            # model.py:118 (aliasing kept)
         n_graph = x.size(0)
         bias = self.assemble_bias(batched_data)
+        refresh_shadows(self.layers)
         if x.shape[2] != 1:
             raise NotImplementedError("MobGT items have one feature column (wrapper.py:37)")
         node_feature = ops.embed_gather_sum(

@@ -26,7 +26,8 @@ import torch.nn.functional as F
 
 from . import ops
 from .lr import PolynomialDecayLR
-from .model import FeedForwardNetwork, MultiHeadAttention, hop_table_from, no_grad_row0
+from .model import (FeedForwardNetwork, MultiHeadAttention, hop_table_from, no_grad_row0, fused_layer_forward,
+                    refresh_shadows)
 from .modelGNN import GCN
 
 node_dim = 2000          # model_fqandtoyo.py:567
@@ -116,7 +117,12 @@ class EncoderLayer(nn.Module):
         self.ffn = FeedForwardNetwork(hidden_size, ffn_size, dropout_rate)
         self.ffn_dropout = nn.Dropout(dropout_rate)
 
+    fused = True
+    act_dtype = torch.float32
+
     def forward(self, x, attn_bias=None, mask=None):
+        if self.fused and x.is_cuda and mask is None:
+            return fused_layer_forward(self, "fq", x, attn_bias, self.ffn_norm1, self.ffn_norm2)
         y = self.self_attention(x, x, x, attn_bias, mask=mask)
         y = self.self_attention_dropout(y)
         x = x + y.to(x.dtype)          # same-dtype add: the mixed fp32+bf16 elementwise kernel is ~20x slower on ROCm
@@ -153,7 +159,8 @@ class Graphormer(nn.Module):
     def __init__(self, n_layers, num_heads, hidden_dim, dropout_rate, intput_dropout_rate, weight_decay, ffn_dim,
                  dataset_name, warmup_updates, tot_updates, peak_lr, end_lr, edge_type, multi_hop_max_dist,
                  attention_dropout_rate, flag=False, flag_m=3, flag_step_size=1e-3, flag_mag=1e-3, lr_step=2,
-                 universe=None, num_bins=None, bias_dtype=torch.float32, gcn_dtype=torch.float32):
+                 universe=None, num_bins=None, bias_dtype=torch.float32, gcn_dtype=torch.float32,
+                 act_dtype=torch.float32, fused_layers=True):
         super().__init__()
         if dataset_name not in ("foursquaregraph", "gowalla_nevda", "gowalla_7day"):
             raise NotImplementedError(f"dataset_name={dataset_name!r}: only the POI-graph datasets are in scope")
@@ -234,6 +241,8 @@ class Graphormer(nn.Module):
         self.input_dropout = nn.Dropout(intput_dropout_rate)
         self.layers = nn.ModuleList([EncoderLayer(C, ffn_dim, dropout_rate, attention_dropout_rate, num_heads)
                                      for _ in range(n_layers)])
+        for layer in self.layers:
+            layer.act_dtype, layer.fused = act_dtype, fused_layers
         self.final_ln = nn.LayerNorm(Cout)
         self.out_proj = nn.Linear(Cout, P if fsq else P + 1)
         self.ELU = nn.ELU()
@@ -293,6 +302,7 @@ class Graphormer(nn.Module):
 
     def forward(self, batched_data, perturb=None):
         bias = self.assemble_bias(batched_data)
+        refresh_shadows(self.layers)
         output = self.input_dropout(self.node_features(batched_data))
         for enc_layer in self.layers:                                                          # :1347-1352
             output = enc_layer(output, bias, mask=None)

@@ -1,0 +1,99 @@
+"""EncoderLayer parity on the GPU against the reference's own outputs (golden G4: y, dx, dbias and every
+parameter gradient for a fixed upstream gradient), for both layer variants, the fused single-node path and
+the op-by-op path, fp32 and bf16 GEMM-facing activations.
+
+Tolerance: the attention MFMA operands are bf16 (fp32 accumulate) in every configuration -> 2e-2 on
+outputs / input gradients relative to their scale; bf16 activations add the GEMM operands' rounding -> 4e-2.
+Parameter-gradient norms within 3 % (5 % with bf16 activations); d(linear_k.bias) is exactly 0 in exact
+arithmetic and is compared with an absolute tolerance.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from inputs import ENCODER_CASES, encoder_case              # noqa: E402
+from test_oracle_model import encoder_param_list, seeded_state   # noqa: E402
+
+DEV = "cuda"
+
+
+def build_layer(variant, C, ffn, seed):
+    if variant == "stock":
+        from mobgt_amd.model import EncoderLayer
+    else:
+        from mobgt_amd.model_fqandtoyo import EncoderLayer
+    layer = EncoderLayer(C, ffn, 0.1, 0.1, 8)
+    sd = {k[2:]: v.detach() for k, v in seeded_state([("L." + n, s) for n, s in encoder_param_list(variant, C, ffn)], seed).items()}
+    layer.load_state_dict(sd, strict=True)
+    return layer.to(DEV).eval()
+
+
+@pytest.mark.parametrize("variant", ["stock", "fq"])
+@pytest.mark.parametrize("case", ENCODER_CASES, ids=[c[0] for c in ENCODER_CASES])
+@pytest.mark.parametrize("mode", ["fused_f32", "fused_bf16", "unfused"])
+def test_encoder_layer_matches_reference_g4(golden_dir, variant, case, mode):
+    z = np.load(os.path.join(golden_dir, "g4_encoder.npz"))
+    cname, C, T, G, ffn = case
+    name = f"{variant}/{cname}"
+    seed, x, bias, gy, _ = encoder_case(variant, C, T, G)
+    layer = build_layer(variant, C, ffn, seed + 1)
+    layer.fused = mode != "unfused"
+    layer.act_dtype = torch.bfloat16 if mode == "fused_bf16" else torch.float32
+    xd = torch.from_numpy(x).to(DEV).requires_grad_(True)
+    bd = torch.from_numpy(bias).to(DEV).requires_grad_(True)
+    y = layer(xd, bd, mask=None)
+    y.backward(torch.from_numpy(gy).to(DEV))
+    torch.cuda.synchronize()
+    tol = 4e-2 if mode == "fused_bf16" else 2e-2
+    ref_y, ref_dx = z[f"{name}/y"], z[f"{name}/dx"]
+    np.testing.assert_allclose(y.detach().cpu().numpy(), ref_y, atol=tol * max(1.0, np.abs(ref_y).max()), rtol=tol)
+    np.testing.assert_allclose(xd.grad.cpu().numpy(), ref_dx, atol=tol * max(1.0, np.abs(ref_dx).max()), rtol=tol)
+    db = bd.grad.cpu().numpy()
+    db = db if T <= 40 else db[:, :, ::7, :]
+    ref_db = z[f"{name}/dbias"]
+    np.testing.assert_allclose(db, ref_db, atol=tol * max(1.0, np.abs(ref_db).max()), rtol=tol)
+    bad = []
+    gtol = 5e-2 if mode == "fused_bf16" else 3e-2
+    for pn, p in layer.named_parameters():
+        if f"{name}/grad_none/{pn}" in z:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, pn
+            continue
+        rs, rn = z[f"{name}/gstat/{pn}"]
+        gn = p.grad.double().norm().item()
+        if not np.isclose(gn, rn, rtol=gtol, atol=2e-2):
+            bad.append((pn, gn, float(rn)))
+        if f"{name}/grad/{pn}" in z:
+            ref = z[f"{name}/grad/{pn}"]
+            np.testing.assert_allclose(p.grad.cpu().numpy(), ref, atol=gtol * max(1.0, np.abs(ref).max()), rtol=gtol, err_msg=pn)
+    assert not bad, bad
+
+
+def test_fused_layer_dropout_statistics():
+    """Training mode: dropout masks differ per site and per seed, keep rate ~ 1-p, and the layer stays unbiased
+    (mean over many seeds approaches the eval output for a linear probe)."""
+    from mobgt_amd.model_fqandtoyo import EncoderLayer
+    torch.manual_seed(0)
+    C, T, G = 192, 12, 4
+    layer = EncoderLayer(C, 256, 0.1, 0.1, 8).to(DEV)
+    x = torch.randn(G, T, C, device=DEV)
+    bias = torch.zeros(G, 8, T, T, device=DEV)
+    layer.eval()
+    ref = layer(x, bias)
+    layer.train()
+    seed_dev = torch.zeros(1, dtype=torch.int64, device=DEV)
+    layer.self_attention.seed_dev = seed_dev
+    outs = []
+    for i in range(64):
+        seed_dev.fill_(i)
+        outs.append(layer(x, bias))
+    outs = torch.stack(outs)
+    assert not torch.equal(outs[0], outs[1])
+    seed_dev.fill_(0)
+    assert torch.equal(layer(x, bias), outs[0])               # same seed -> same masks
+    err = (outs.mean(0) - ref).abs().mean().item()
+    spread = (outs[0] - ref).abs().mean().item()
+    assert err < 0.35 * spread
