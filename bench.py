@@ -45,6 +45,7 @@ def parse():
                     help="dtype of the library GEMMs (projections / FFN / head); attention MFMA operands, the bias "
                          "and the GCN adjacency product follow --dtype")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--unfused", action="store_true", help="op-by-op encoder layers (torch ops + HIP attention)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--seed", type=int, default=1)
@@ -178,7 +179,9 @@ def main():
     uni = synth.make_universe(P=args.pois, n_cat=300, n_user=1080, seed=args.seed)
     num_bins, _, table = make_bin_table(uni.distance)
     model = Graphormer(universe=uni, num_bins=num_bins + 2, bias_dtype=torch.bfloat16 if bf16 else torch.float32,
-                       gcn_dtype=torch.bfloat16 if bf16 else torch.float32, **MODEL_ARGS).to(dev)
+                       gcn_dtype=torch.bfloat16 if bf16 else torch.float32,
+                       act_dtype=torch.bfloat16 if (bf16 and args.gemm_dtype == "bf16") else torch.float32,
+                       fused_layers=not args.unfused, **MODEL_ARGS).to(dev)
     broadcast_parameters(model)
     coll = DeviceCollator(dev, bin_table=table, multi_hop_max_dist=20, rel_pos_max=1024)
     batches, shapes = [], []
@@ -190,7 +193,7 @@ def main():
         shapes.append((len(b), b.x.shape[1] + 1))
     torch.cuda.synchronize()
 
-    ts = TrainStep(model, batches, autocast_dtype=torch.bfloat16 if (bf16 and args.gemm_dtype == "bf16") else None, use_graph=not args.no_graph,
+    ts = TrainStep(model, batches, autocast_dtype=torch.bfloat16 if (bf16 and args.gemm_dtype == "bf16" and args.unfused) else None, use_graph=not args.no_graph,
                    seed=args.seed)
     ts.prepare()
     for i in range(args.warmup):
@@ -253,7 +256,7 @@ def main():
                                    "dropout 0.1, fwd+GradientTailLoss+bwd+allreduce+AdamW" % args.pois,
                        "global_batch": G_total, "per_gpu_batch": args.batch_size,
                        "padded_nodes_per_batch": [s[1] - 1 for s in shapes], "parallelism": f"dp{world}",
-                       "hip_graphs": not args.no_graph,
+                       "hip_graphs": not args.no_graph, "fused_encoder_layers": not args.unfused,
                        "precision": {"attention_mfma_operands": args.dtype, "attn_bias": args.dtype,
                                      "attention_io": "bf16" if io_dt == torch.bfloat16 else "f32",
                                      "gcn_adjacency_product": args.dtype, "library_gemms": args.gemm_dtype if bf16 else "f32",

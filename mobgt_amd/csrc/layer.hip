@@ -16,7 +16,7 @@
 namespace {
 
 constexpr int MAXC_PER_LANE = 8;     // C <= 512
-constexpr int ROWS_PER_WG = 16;      // 4 waves x 4 rows
+constexpr int MAX_ROWS_PER_WG = 16;  // 4 waves x up to 4 rows; fewer rows per workgroup when R is small (fill 256 CUs)
 
 template <typename T> __device__ __forceinline__ float ldf(const T* p, int64_t i);
 template <> __device__ __forceinline__ float ldf<float>(const float* p, int64_t i) { return p[i]; }
@@ -53,6 +53,7 @@ struct LnParams {
     uint64_t seed;
     const uint64_t* seed_dev;
     uint32_t salt;
+    int rows_per_wg;
 };
 
 template <typename TA>
@@ -60,8 +61,8 @@ __global__ __launch_bounds__(256) void dropout_add_ln_fwd_kernel(const LnParams 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint64_t seed = p.thr ? p.seed + (p.seed_dev ? *p.seed_dev : 0ull) : 0ull;
     const float invC = 1.f / (float)p.C;
-    for (int rr = wave; rr < ROWS_PER_WG; rr += 4) {
-        const int64_t r = (int64_t)blockIdx.x * ROWS_PER_WG + rr;
+    for (int rr = wave; rr < p.rows_per_wg; rr += 4) {
+        const int64_t r = (int64_t)blockIdx.x * p.rows_per_wg + rr;
         if (r >= p.R) break;
         float v[MAXC_PER_LANE];
         const uint32_t rowh = p.thr ? dropout_row_hash(seed, (uint32_t)r ^ p.salt) : 0u;
@@ -114,8 +115,8 @@ __global__ __launch_bounds__(256) void dropout_add_ln_bwd_kernel(const LnParams 
     float ag[MAXC_PER_LANE], ab[MAXC_PER_LANE], ay[MAXC_PER_LANE];
 #pragma unroll
     for (int k = 0; k < MAXC_PER_LANE; ++k) { ag[k] = 0.f; ab[k] = 0.f; ay[k] = 0.f; }
-    for (int rr = wave; rr < ROWS_PER_WG; rr += 4) {
-        const int64_t r = (int64_t)blockIdx.x * ROWS_PER_WG + rr;
+    for (int rr = wave; rr < p.rows_per_wg; rr += 4) {
+        const int64_t r = (int64_t)blockIdx.x * p.rows_per_wg + rr;
         if (r >= p.R) break;
         float dxv[MAXC_PER_LANE];
 #pragma unroll
@@ -218,6 +219,13 @@ __global__ __launch_bounds__(256) void colsum_kernel(const TA* __restrict__ dh, 
     }
 }
 
+int pick_rows(int64_t R) {
+    // >= ~1024 workgroups when possible: 4 rows (one per wave) up to 16 rows per workgroup
+    int rows = 4;
+    while (rows < MAX_ROWS_PER_WG && (R + rows - 1) / rows > 2048) rows *= 2;
+    return rows;
+}
+
 void set_drop(LnParams& p, float dropout_p, uint64_t seed, const uint64_t* seed_dev, uint32_t salt) {
     p.thr = dropout_p > 0.f ? dropout_threshold(dropout_p) : 0u;
     p.inv_keep = p.thr ? 1.f / (1.f - (float)p.thr / 65536.f) : 1.f;
@@ -236,7 +244,8 @@ extern "C" int mobgt_dropout_add_ln_fwd(const float* x, const void* y, float* x1
     p.x = x; p.y = y; p.x1 = x1; p.w = ln_w; p.b = ln_b; p.z = z; p.z32 = z32; p.mean = mean; p.rstd = rstd;
     p.R = R; p.C = C;
     set_drop(p, y ? dropout_p : 0.f, seed, seed_dev, salt);
-    const dim3 grid((unsigned)((R + ROWS_PER_WG - 1) / ROWS_PER_WG)), block(256);
+    p.rows_per_wg = pick_rows(R);
+    const dim3 grid((unsigned)((R + p.rows_per_wg - 1) / p.rows_per_wg)), block(256);
     hipStream_t st = (hipStream_t)stream;
     if (act_dtype == MOBGT_F32) hipLaunchKernelGGL(dropout_add_ln_fwd_kernel<float>, grid, block, 0, st, p);
     else if (act_dtype == MOBGT_BF16) hipLaunchKernelGGL(dropout_add_ln_fwd_kernel<bf16_t>, grid, block, 0, st, p);
@@ -256,7 +265,8 @@ extern "C" int mobgt_dropout_add_ln_bwd(const void* dz, const float* dz32, const
     p.rstd = const_cast<float*>(rstd); p.w = ln_w; p.dx1 = dx1; p.dy = dy; p.dgamma = dgamma; p.dbeta = dbeta;
     p.dbias = dbias; p.R = R; p.C = C;
     set_drop(p, dy ? dropout_p : 0.f, seed, seed_dev, salt);
-    const dim3 grid((unsigned)((R + ROWS_PER_WG - 1) / ROWS_PER_WG)), block(256);
+    p.rows_per_wg = pick_rows(R);
+    const dim3 grid((unsigned)((R + p.rows_per_wg - 1) / p.rows_per_wg)), block(256);
     hipStream_t st = (hipStream_t)stream;
     if (act_dtype == MOBGT_F32) hipLaunchKernelGGL(dropout_add_ln_bwd_kernel<float>, grid, block, 0, st, p);
     else if (act_dtype == MOBGT_BF16) hipLaunchKernelGGL(dropout_add_ln_bwd_kernel<bf16_t>, grid, block, 0, st, p);
@@ -279,7 +289,7 @@ extern "C" int mobgt_gelu_fwd(const void* u, void* h, int64_t n, int act_dtype, 
 extern "C" int mobgt_gelu_bwd_colsum(const void* dh, const void* u, void* du, float* dbias, int64_t R, int C,
                                      int act_dtype, void* stream) {
     if (R <= 0 || C <= 0) return 0;
-    const int rows = 16;
+    const int rows = pick_rows(R);
     const dim3 grid((unsigned)((R + rows - 1) / rows)), block(256);
     hipStream_t st = (hipStream_t)stream;
     if (act_dtype == MOBGT_F32)
@@ -292,7 +302,7 @@ extern "C" int mobgt_gelu_bwd_colsum(const void* dh, const void* u, void* du, fl
 
 extern "C" int mobgt_colsum(const void* g, float* out, int64_t R, int C, int act_dtype, void* stream) {
     if (R <= 0 || C <= 0) return 0;
-    const int rows = 16;
+    const int rows = pick_rows(R);
     const dim3 grid((unsigned)((R + rows - 1) / rows)), block(256);
     hipStream_t st = (hipStream_t)stream;
     if (act_dtype == MOBGT_F32)

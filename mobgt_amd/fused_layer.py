@@ -19,10 +19,21 @@ from ._lib import check
 from .ops import _p, _stream, _DT
 
 
+_MM_OUT_DTYPE = [None]
+
+
 def _mm_f32(a, b):
     """a @ b with an fp32 result (weight gradients go to fp32 master gradients)."""
     if a.dtype == torch.float32:
         return a @ b
+    if _MM_OUT_DTYPE[0] is None:
+        try:
+            torch.mm(a, b, out_dtype=torch.float32)
+            _MM_OUT_DTYPE[0] = True
+        except Exception:
+            _MM_OUT_DTYPE[0] = False
+    if _MM_OUT_DTYPE[0]:
+        return torch.mm(a, b, out_dtype=torch.float32)      # bf16 operands, fp32 accumulate AND fp32 result
     return (a @ b).float()
 
 

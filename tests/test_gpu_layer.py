@@ -64,6 +64,12 @@ def test_encoder_layer_matches_reference_g4(golden_dir, variant, case, mode):
             continue
         rs, rn = z[f"{name}/gstat/{pn}"]
         gn = p.grad.double().norm().item()
+        if pn.endswith("linear_k.bias"):
+            # exactly 0 in exact arithmetic (softmax is invariant to a per-query shift of all keys); the reference
+            # leaves fp32 round-off, bf16 MFMA operands leave ~1e-2 of the neighbouring bias gradients
+            vb = z[f"{name}/gstat/{pn.replace('linear_k', 'linear_v')}"][1]
+            assert gn <= 2e-2 * vb + 1e-3, (pn, gn, vb)
+            continue
         if not np.isclose(gn, rn, rtol=gtol, atol=2e-2):
             bad.append((pn, gn, float(rn)))
         if f"{name}/grad/{pn}" in z:
