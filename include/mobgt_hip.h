@@ -215,6 +215,11 @@ int mobgt_dropout_add_ln_bwd(const void* dz, const float* dz32, const float* dre
 int mobgt_gelu_fwd(const void* u, void* h, int64_t n, int act_dtype, void* stream);
 int mobgt_gelu_bwd_colsum(const void* dh, const void* u, void* du, float* dbias, int64_t R, int C,
                           int act_dtype, void* stream);
+/* GradientTailLoss(inputs, targets, alpha) of graphormer/model_fqandtoyo.py:545-550 (beta = k = 1) and its
+ * gradient in one pass: logits [G,V] f32, targets [G] int64 (class ids) -> *loss (f32 scalar, overwritten) and
+ * dlogits [G,V] = d(loss)/d(logits). */
+int mobgt_gradient_tail_loss(const float* logits, const int64_t* targets, float* dlogits, float* loss,
+                             int64_t G, int64_t V, float alpha, void* stream);
 /* out [C] (f32) += column sums of g [R,C]: the bias gradient of a Linear layer. */
 int mobgt_colsum(const void* g, float* out, int64_t R, int C, int act_dtype, void* stream);
 

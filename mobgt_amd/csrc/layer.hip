@@ -312,3 +312,53 @@ extern "C" int mobgt_colsum(const void* g, float* out, int64_t R, int C, int act
     else return MOBGT_EDTYPE;
     return (int)hipGetLastError();
 }
+
+// ------------------------------------------------------------------------------------------------
+// GradientTailLoss (graphormer/model_fqandtoyo.py:545-550), forward value and d(loss)/d(logits) in one pass:
+//   p = sigmoid(z);  loss = mean( -alpha*(1-p)*onehot*log(p) - (1-onehot)*p*log(1-p) )      (beta = k = 1)
+// The reference evaluates it as ~12 elementwise kernels forward and ~15 backward over [G, P+1].
+namespace {
+__global__ __launch_bounds__(256) void gtl_kernel(const float* __restrict__ z, const int64_t* __restrict__ target,
+                                                  float* __restrict__ dz, float* __restrict__ loss, int64_t G, int64_t V,
+                                                  float alpha) {
+    const int64_t n = G * V;
+    const float inv_n = 1.f / (float)n;
+    float acc = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const int64_t g = i / V, c = i - g * V;
+        const float x = z[i];
+        const float p = 1.f / (1.f + __expf(-x));
+        const float q = 1.f - p;
+        float l, d;
+        if (target[g] == c) {
+            const float lp = logf(p);
+            l = -alpha * q * lp;
+            d = alpha * p * q * lp - alpha * q * q;
+        } else {
+            const float lq = logf(q);
+            l = -p * lq;
+            d = -p * q * lq + p * p;
+        }
+        acc += l;
+        dz[i] = d * inv_n;
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    __shared__ float part[4];
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(loss, (part[0] + part[1] + part[2] + part[3]) * inv_n);
+}
+}  // namespace
+
+extern "C" int mobgt_gradient_tail_loss(const float* logits, const int64_t* targets, float* dlogits, float* loss,
+                                        int64_t G, int64_t V, float alpha, void* stream) {
+    if (G <= 0 || V <= 0) return MOBGT_EBADDIM;
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(loss, 0, sizeof(float), st);
+    if (e != hipSuccess) return (int)e;
+    const int64_t n = G * V;
+    const unsigned blocks = (unsigned)((n + 1023) / 1024 < 1024 ? (n + 1023) / 1024 : 1024);
+    hipLaunchKernelGGL(gtl_kernel, dim3(blocks ? blocks : 1), dim3(256), 0, st, logits, targets, dlogits, loss, G, V, alpha);
+    return (int)hipGetLastError();
+}

@@ -24,6 +24,15 @@ _MM_OUT_DTYPE = [None]
 
 def _mm_f32(a, b):
     """a @ b with an fp32 result (weight gradients go to fp32 master gradients)."""
+    M, R = a.shape
+    N = b.shape[1]
+    if M * N <= 256 * 256 and R >= 256:
+        # one output tile and a long K (= rows): a plain GEMM call leaves 255 CUs idle; split K over a batch axis
+        s = max((c for c in (16, 8, 4, 2) if R % c == 0), default=1)
+        if s > 1:
+            at = a.reshape(M, s, R // s).permute(1, 0, 2)
+            part = torch.bmm(at, b.reshape(s, R // s, N))
+            return part.float().sum(0) if part.dtype != torch.float32 else part.sum(0)
     if a.dtype == torch.float32:
         return a @ b
     if _MM_OUT_DTYPE[0] is None:

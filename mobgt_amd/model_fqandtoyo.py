@@ -90,7 +90,10 @@ class FuseEmbeddings(nn.Module):
         self.leaky_relu = nn.LeakyReLU(0.2)
 
     def forward(self, user_embed, poi_embed):
-        return self.leaky_relu(self.fuse_embed(torch.cat((user_embed, poi_embed), user_embed.dim() - 1)))
+        x = torch.cat((user_embed, poi_embed), user_embed.dim() - 1)
+        if x.is_cuda:
+            return self.leaky_relu(ops.linear_splitk(x.float(), self.fuse_embed.weight, self.fuse_embed.bias))
+        return self.leaky_relu(self.fuse_embed(x))
 
 
 class LearnablePositionalEncoding(nn.Module):
@@ -284,7 +287,8 @@ class Graphormer(nn.Module):
         cat_idx = torch.where(real, self.poi2cat[x] - 1, neg)                                  # :1259
         # [poi ; time] and the category row, gathered for every position in one pass each
         pt = ops.embed_gather_concat([poidist, self.time_embed_model_48.weight], [poi_idx, time_idx], padding_idx=[None, 0])
-        f2 = self.embed_fuse_model2.leaky_relu(self.embed_fuse_model2.fuse_embed(pt))          # :1268
+        f2 = self.embed_fuse_model2.leaky_relu(
+            ops.linear_splitk(pt, self.embed_fuse_model2.fuse_embed.weight, self.embed_fuse_model2.fuse_embed.bias))   # :1268
         ce = ops.embed_gather_sum([catemb], [cat_idx])
         nf = self.embed_fuse_model4(f2, ce)                                                    # :1269
         nf = nf * real.unsqueeze(-1).to(nf.dtype)                                              # pads stay 0
@@ -314,7 +318,7 @@ class Graphormer(nn.Module):
     def training_step(self, batched_data, batch_idx=0):
         """model_fqandtoyo.py:1446-1460: y-1 targets, GradientTailLoss(alpha=0.2) on the POI logits only."""
         y_hat = self(batched_data)[0]
-        return GradientTailLoss(y_hat.float(), batched_data.y.long() - 1, 0.2)
+        return ops.gradient_tail_loss(y_hat, batched_data.y.long() - 1, 0.2)
 
     def configure_optimizers(self, capturable=False, fused=None):
         """model_fqandtoyo.py:1599-1616"""

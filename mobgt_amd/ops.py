@@ -366,3 +366,57 @@ def embed_gather_concat(tables, indices, padding_idx=None):
     tabs = [t.float().contiguous() for t in tables]
     out = _GatherConcatFn.apply(skip, n, *tabs, *idx)
     return out.view(*shape, out.shape[1])
+
+
+# ------------------------------------------------------------------------------------------ loss
+class _GradientTailLossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, targets, alpha):
+        logits = logits.float().contiguous()
+        G, V = logits.shape
+        dlogits = torch.empty_like(logits)
+        loss = torch.empty((), dtype=torch.float32, device=logits.device)
+        check(_lib.lib().mobgt_gradient_tail_loss(_p(logits), _p(targets.long().contiguous()), _p(dlogits), _p(loss), G, V,
+                                                  float(alpha), _stream()), "mobgt_gradient_tail_loss")
+        ctx.save_for_backward(dlogits)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        (dlogits,) = ctx.saved_tensors
+        return dlogits * g, None, None
+
+
+def gradient_tail_loss(logits, targets, alpha=0.25):
+    """model_fqandtoyo.py:545-550 (beta = k = 1): value and gradient from one HIP kernel."""
+    _require_cuda(logits, targets)
+    return _GradientTailLossFn.apply(logits, targets[: logits.shape[0]].reshape(-1), alpha)
+
+
+# ------------------------------------------------------------------------------- small linear layers
+class _LinearSplitKFn(torch.autograd.Function):
+    """y = x W^T + b for a few hundred rows: the weight gradient g^T x has K = rows and a tiny output, which a
+    plain GEMM call maps onto one workgroup (measured 60-150 us in fp32); evaluate it split-K as a batched GEMM."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        ctx.save_for_backward(x, w)
+        return torch.addmm(b, x, w.t())
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w = ctx.saved_tensors
+        g = g.contiguous()
+        R = x.shape[0]
+        s = max((c for c in (16, 8, 4, 2) if R % c == 0 and R // c >= 16), default=1)
+        if s > 1:
+            dw = torch.bmm(g.view(s, R // s, -1).transpose(1, 2), x.view(s, R // s, -1)).sum(0)
+        else:
+            dw = g.t() @ x
+        return g @ w, dw, g.sum(0)
+
+
+def linear_splitk(x, weight, bias):
+    shape = x.shape
+    y = _LinearSplitKFn.apply(x.reshape(-1, shape[-1]).contiguous(), weight, bias)
+    return y.view(*shape[:-1], weight.shape[0])

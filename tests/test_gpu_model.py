@@ -198,3 +198,13 @@ def test_fq_graphormer_logits_loss_grads_g6(golden_dir, tag, ds, narrow):
     np.testing.assert_allclose(loss.item(), z6[f"{tag}/loss"], rtol=1e-3)
     loss.backward()
     _check_grads(m, z6, tag)
+
+
+def test_gradient_tail_loss_kernel_matches_reference_g7(golden_dir):
+    from mobgt_amd import ops
+    z = _load(golden_dir, "g7_lr_loss.npz")
+    logits = torch.from_numpy(z["gtl/logits"]).to(DEV).requires_grad_(True)
+    loss = ops.gradient_tail_loss(logits, torch.from_numpy(z["gtl/targets"]).to(DEV), 0.2)
+    (loss * 3.0).backward()
+    np.testing.assert_allclose(loss.item(), z["gtl/loss"], rtol=2e-6)
+    np.testing.assert_allclose(logits.grad.cpu().numpy(), 3.0 * z["gtl/dlogits"], rtol=2e-5, atol=1e-8)

@@ -12,10 +12,10 @@ P = int(os.environ.get("P", "7856"))
 dev = torch.device("cuda", 0)
 uni = synth.make_universe(P=P, n_cat=300, n_user=1080, seed=1)
 nb, _, table = make_bin_table(uni.distance)
-model = Graphormer(universe=uni, num_bins=nb + 2, bias_dtype=torch.bfloat16, gcn_dtype=torch.bfloat16, **bench.MODEL_ARGS).to(dev)
+model = Graphormer(universe=uni, num_bins=nb + 2, bias_dtype=torch.bfloat16, gcn_dtype=torch.bfloat16, act_dtype=torch.bfloat16, **bench.MODEL_ARGS).to(dev)
 coll = DeviceCollator(dev, bin_table=table)
 batches = [coll(synth.make_batch_of_trajectories(seed=1001 + i, G=16, P=P, n_user=1080, cat_of_poi=uni.cat_of_poi)) for i in range(2)]
-ts = TrainStep(model, batches, autocast_dtype=torch.bfloat16, use_graph=False)
+ts = TrainStep(model, batches, autocast_dtype=None, use_graph=False)
 for i in range(3):
     ts.step(i)
 torch.cuda.synchronize()
@@ -23,4 +23,7 @@ from torch.profiler import profile, ProfilerActivity
 with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True) as prof:
     ts.step(1)
     torch.cuda.synchronize()
-print(prof.key_averages(group_by_input_shape=True).table(sort_by="cuda_time_total", row_limit=45, max_name_column_width=48, max_shapes_column_width=60))
+rows = [e for e in prof.key_averages(group_by_input_shape=True) if e.key in ("aten::mm", "aten::addmm", "aten::bmm", "aten::sum", "aten::mean", "aten::cat", "aten::zeros", "aten::fill_", "aten::copy_", "aten::add", "aten::mul", "aten::index", "aten::embedding", "aten::where")]
+rows.sort(key=lambda e: -e.device_time_total)
+for e in rows[:45]:
+    print(f"{e.key:14s} n={e.count:3d} cuda_us={e.device_time_total:9.1f} shapes={str(e.input_shapes)[:110]}")
