@@ -41,7 +41,7 @@ def parse():
     ap.add_argument("--n-batches", type=int, default=8, help="distinct pre-collated batches cycled through")
     ap.add_argument("--pois", type=int, default=7856)
     ap.add_argument("--dtype", choices=["bf16", "f32"], default="bf16")
-    ap.add_argument("--gemm-dtype", choices=["bf16", "f32"], default="f32",
+    ap.add_argument("--gemm-dtype", choices=["bf16", "f32"], default="bf16",
                     help="dtype of the library GEMMs (projections / FFN / head); attention MFMA operands, the bias "
                          "and the GCN adjacency product follow --dtype")
     ap.add_argument("--no-graph", action="store_true")

@@ -220,6 +220,11 @@ int mobgt_gelu_bwd_colsum(const void* dh, const void* u, void* du, float* dbias,
  * dlogits [G,V] = d(loss)/d(logits). */
 int mobgt_gradient_tail_loss(const float* logits, const int64_t* targets, float* dlogits, float* loss,
                              int64_t G, int64_t V, float alpha, void* stream);
+/* nn.Dropout at the model's input/output/positional/GCN sites (model.py:206, model_fqandtoyo.py:358,1347,1364;
+ * modelGNN.py:71): y = keep ? x/(1-p) : 0 with the kernels' counter hash keyed by (seed [+ *seed_dev], salt,
+ * i / row_len, i % row_len).  The backward is the same call applied to dy. */
+int mobgt_dropout(const float* x, float* y, int64_t n, int row_len, float dropout_p, uint64_t seed,
+                  const uint64_t* seed_dev, uint32_t salt, void* stream);
 /* out [C] (f32) += column sums of g [R,C]: the bias gradient of a Linear layer. */
 int mobgt_colsum(const void* g, float* out, int64_t R, int C, int act_dtype, void* stream);
 

@@ -362,3 +362,32 @@ extern "C" int mobgt_gradient_tail_loss(const float* logits, const int64_t* targ
     hipLaunchKernelGGL(gtl_kernel, dim3(blocks ? blocks : 1), dim3(256), 0, st, logits, targets, dlogits, loss, G, V, alpha);
     return (int)hipGetLastError();
 }
+
+// ------------------------------------------------------------------------------------------------
+// Stand-alone dropout (nn.Dropout at the model's input / output / positional / GCN sites), same counter hash
+// as everywhere else: y = keep(seed, salt, row, col) ? x / (1-p) : 0.  The backward is the same call on dy.
+namespace {
+__global__ __launch_bounds__(256) void dropout_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t n, int row_len,
+                                                      uint32_t thr, float inv_keep, uint64_t seed0,
+                                                      const uint64_t* __restrict__ seed_dev, uint32_t salt) {
+    const uint64_t seed = seed0 + (seed_dev ? *seed_dev : 0ull);
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / row_len;
+        const uint32_t c = (uint32_t)(i - r * row_len);
+        const uint32_t rowh = dropout_row_hash(seed, (uint32_t)r ^ salt);
+        y[i] = dropout_bits16(seed, rowh, c) >= thr ? x[i] * inv_keep : 0.f;
+    }
+}
+}  // namespace
+
+extern "C" int mobgt_dropout(const float* x, float* y, int64_t n, int row_len, float dropout_p, uint64_t seed,
+                             const uint64_t* seed_dev, uint32_t salt, void* stream) {
+    if (n <= 0) return 0;
+    if (row_len <= 0) return MOBGT_EBADDIM;
+    const uint32_t thr = dropout_p > 0.f ? dropout_threshold(dropout_p) : 0u;
+    const float inv_keep = thr ? 1.f / (1.f - (float)thr / 65536.f) : 1.f;
+    const unsigned blocks = (unsigned)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+    hipLaunchKernelGGL(dropout_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, y, n, row_len, thr, inv_keep, seed,
+                       seed_dev, salt);
+    return (int)hipGetLastError();
+}

@@ -36,6 +36,10 @@ def _mm_f32(a, b):
     if a.dtype == torch.float32:
         return a @ b
     if _MM_OUT_DTYPE[0] is None:
+        import os
+        if os.environ.get("MOBGT_NO_OUT_DTYPE"):
+            _MM_OUT_DTYPE[0] = False
+    if _MM_OUT_DTYPE[0] is None:
         try:
             torch.mm(a, b, out_dtype=torch.float32)
             _MM_OUT_DTYPE[0] = True

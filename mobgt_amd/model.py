@@ -187,6 +187,9 @@ def fused_layer_forward(layer, variant, x, attn_bias, n1, nx):
 
 def refresh_shadows(layers):
     """bf16 copies of every layer's GEMM weights in ONE multi-tensor copy (call once per forward)."""
+    import os
+    if os.environ.get("MOBGT_NO_BATCHED_SHADOWS"):
+        return
     dst, src = [], []
     for layer in layers:
         if getattr(layer, "act_dtype", torch.float32) == torch.float32 or not layer.fused:
@@ -294,7 +297,7 @@ class Graphormer(nn.Module):
             [self.atom_encoder.weight, self.in_degree_encoder.weight, self.out_degree_encoder.weight],
             [x[:, :, 0].long(), in_degree.long(), out_degree.long()], padding_idx=[0, 0, 0])
         graph_token_feature = self.graph_token.weight.unsqueeze(0).repeat(n_graph, 1, 1)
-        output = self.input_dropout(torch.cat([graph_token_feature, node_feature], dim=1))
+        output = ops.dropout(torch.cat([graph_token_feature, node_feature], dim=1), self.input_dropout.p, self.training, 0x1003)
         for enc_layer in self.layers:
             output = enc_layer(output, bias, mask=None)
         output = self.final_ln(output)

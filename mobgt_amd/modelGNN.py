@@ -107,5 +107,9 @@ class GCN(nn.Module):
         """`adj_x` = adj @ x precomputed (x is a constant feature matrix in MobGT): skips the first P x P product."""
         for i in range(len(self.gcn) - 1):
             x = self.leaky_relu(self.gcn[i](x, adj, adj_x if i == 0 else None))
-        x = F.dropout(x, self.dropout, training=self.training)
+        if x.is_cuda:
+            from . import ops
+            x = ops.dropout(x, self.dropout, self.training, 0x2000 + self.gcn[-1].out_features)
+        else:
+            x = F.dropout(x, self.dropout, training=self.training)
         return self.gcn[-1](x, adj)

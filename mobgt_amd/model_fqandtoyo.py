@@ -299,20 +299,20 @@ class Graphormer(nn.Module):
             [self.fre_embed_model.weight, self.in_degree_encoder.weight, self.out_degree_encoder.weight, self.pos_embed.pe],
             [torch.zeros_like(x), batched_data.in_degree.long(), batched_data.out_degree.long(), pos_idx],
             padding_idx=[0, 0, 0, None])
-        nf = self.pos_embed.dropout(nf.float() + add)                                          # :358
+        nf = ops.dropout(nf.float() + add, self.pos_embed.dropout.p, self.training, 0x1001)        # :358
         tok = self.graph_token.weight.unsqueeze(0).repeat(G, 1, 1) + self.pos_embed.pe[0]      # :1338-1342
-        tok = self.pos_embed.dropout(tok)
+        tok = ops.dropout(tok, self.pos_embed.dropout.p, self.training, 0x1002)
         return torch.cat([tok, nf], dim=1)
 
     def forward(self, batched_data, perturb=None):
         bias = self.assemble_bias(batched_data)
         refresh_shadows(self.layers)
-        output = self.input_dropout(self.node_features(batched_data))
+        output = ops.dropout(self.node_features(batched_data), self.input_dropout.p, self.training, 0x1003)
         for enc_layer in self.layers:                                                          # :1347-1352
             output = enc_layer(output, bias, mask=None)
         user_embedding = self.user_embed_model(batched_data.user.long() - 1).reshape(output.shape[0], -1)   # :1239-1240
         tok = self.embed_fuse_model3(output[:, 0, :].float(), user_embedding)                  # :1353-1358, q = 0 only
-        tok = self.output_dropout(self.ELU(self.final_ln(tok)))                                # :1360-1364
+        tok = ops.dropout(self.ELU(self.final_ln(tok)), self.output_dropout.p, self.training, 0x1004)   # :1360-1364
         return [self.out_proj(tok), self.cat_decoder(tok)]                                     # :1394-1396
 
     def training_step(self, batched_data, batch_idx=0):

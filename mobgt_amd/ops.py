@@ -420,3 +420,44 @@ def linear_splitk(x, weight, bias):
     shape = x.shape
     y = _LinearSplitKFn.apply(x.reshape(-1, shape[-1]).contiguous(), weight, bias)
     return y.view(*shape[:-1], weight.shape[0])
+
+
+# --------------------------------------------------------------------------------------- dropout
+_DROPOUT_STATE = {"seed_dev": None, "seed": 0x5DEECE66D}
+
+
+def set_dropout_state(seed_dev=None, seed=None):
+    """Device seed scalar (advanced by the trainer, visible to captured graphs) and host seed for ops.dropout."""
+    _DROPOUT_STATE["seed_dev"] = seed_dev
+    if seed is not None:
+        _DROPOUT_STATE["seed"] = int(seed)
+
+
+class _DropoutFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, p, seed, seed_dev, salt):
+        x = x.contiguous()
+        y = torch.empty_like(x)
+        row = x.shape[-1] if x.dim() > 1 else x.numel()
+        check(_lib.lib().mobgt_dropout(_p(x), _p(y), x.numel(), row, p, seed, _p(seed_dev), salt, _stream()), "mobgt_dropout")
+        ctx.misc = (p, seed, seed_dev, salt, row)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        p, seed, seed_dev, salt, row = ctx.misc
+        g = g.contiguous()
+        dx = torch.empty_like(g)
+        check(_lib.lib().mobgt_dropout(_p(g), _p(dx), g.numel(), row, p, seed, _p(seed_dev), salt, _stream()), "mobgt_dropout")
+        return dx, None, None, None, None
+
+
+def dropout(x, p, training, salt):
+    """nn.Dropout replacement for the model-level sites; mask = f(seed state, salt, element index)."""
+    if not training or p <= 0.0:
+        return x
+    _require_cuda(x)
+    seed, seed_dev = _DROPOUT_STATE["seed"], _DROPOUT_STATE["seed_dev"]
+    if seed_dev is None:
+        seed = (seed + int(torch.randint(0, 2 ** 31 - 1, (1,)).item())) & 0x7FFFFFFFFFFFFFFF
+    return _DropoutFn.apply(x.float(), float(p), int(seed), seed_dev, int(salt) & 0xFFFFFFFF)

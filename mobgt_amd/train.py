@@ -10,6 +10,8 @@
   (static shapes per pre-collated batch); the learning rate and the dropout seed live in device scalars
   so a replay sees new values without re-capture.
 """
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -84,8 +86,14 @@ class TrainStep:
         for m in model.modules():
             if hasattr(m, "seed_dev"):
                 m.seed_dev = self.seed_dev
+        from . import ops
+        ops.set_dropout_state(self.seed_dev, seed)
         model.train()
-        used = used_parameters(model, lambda: self._loss(batches[0]))
+        # One side stream for the dry run, the warm-ups and every capture: autograd's AccumulateGrad nodes are
+        # created on the stream of the first backward and must match the capture stream later on.
+        self.stream = torch.cuda.Stream(device=dev) if use_graph else None
+        with self._on_stream():
+            used = used_parameters(model, lambda: self._loss(batches[0]))
         self.flat = FlatGrads(used)
         self.lr_dev = torch.tensor(float(model.peak_lr), dtype=torch.float32, device=dev)
         self.opt = torch.optim.AdamW(model.parameters(), lr=self.lr_dev, weight_decay=model.weight_decay,
@@ -97,6 +105,17 @@ class TrainStep:
         self.graphs = {}
         self.loss_out = torch.zeros((), device=dev)
         self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+    def _on_stream(self):
+        import contextlib
+        if self.stream is None:
+            return contextlib.nullcontext()
+        self.stream.wait_stream(torch.cuda.current_stream())
+        return torch.cuda.stream(self.stream)
+
+    def _join(self):
+        if self.stream is not None:
+            torch.cuda.current_stream().wait_stream(self.stream)
 
     # learning rate of lr.py:17-31, kept in a device scalar so captured optimizer graphs see it
     def _set_lr(self):
@@ -127,13 +146,13 @@ class TrainStep:
 
     def _capture(self, i):
         batch = self.batches[i]
-        s = torch.cuda.Stream()
-        s.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(s):                 # warm-up on a side stream (allocator, lazy inits)
+        with self._on_stream():                    # warm-up on the side stream (allocator, lazy inits)
             self._fwd_bwd(batch)
-        torch.cuda.current_stream().wait_stream(s)
+        self._join()
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g, pool=self.pool):
+        # private memory pool per graph: the graphs are replayed in data order, not capture order, and a shared
+        # pool is only safe for capture-order replay (measured: NaNs on the second lap with a shared pool)
+        with torch.cuda.graph(g, pool=self.pool if os.environ.get("MOBGT_SHARED_POOL") else None, stream=self.stream):
             self._fwd_bwd(batch)
         return g
 
@@ -144,13 +163,11 @@ class TrainStep:
         self.pool = torch.cuda.graph_pool_handle()
         for i in range(len(self.batches)):
             self.graphs[i] = self._capture(i)
-        s = torch.cuda.Stream()
-        s.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(s):
+        with self._on_stream():
             self.opt.step()
-        torch.cuda.current_stream().wait_stream(s)
+        self._join()
         self.opt_graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.opt_graph, pool=self.pool):
+        with torch.cuda.graph(self.opt_graph, stream=self.stream):
             self.opt.step()
 
     def step(self, i):
