@@ -163,11 +163,19 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    # MOBGT_TEST_SHARED_GPU=1: developer switch to exercise the multi-rank code path on a ONE-GPU box (all ranks on
+    # cuda:0, gloo instead of RCCL).  Never set by the driver; numbers from such a run are meaningless.
+    shared = os.environ.get("MOBGT_TEST_SHARED_GPU") == "1"
+    if shared:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if shared:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     from mobgt_amd import synth
     from mobgt_amd.data import DeviceCollator, make_bin_table

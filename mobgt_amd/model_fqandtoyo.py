@@ -320,6 +320,19 @@ class Graphormer(nn.Module):
         y_hat = self(batched_data)[0]
         return ops.gradient_tail_loss(y_hat, batched_data.y.long() - 1, 0.2)
 
+    def validation_step(self, batched_data, batch_idx=0):
+        """model_fqandtoyo.py:1483-1495"""
+        return {"y_pred": self(batched_data), "y_true": batched_data.y.long() - 1}
+
+    def test_step(self, batched_data, batch_idx=0):
+        """model_fqandtoyo.py:1530-1544"""
+        return {"y_pred": self(batched_data), "y_true": batched_data.y.long() - 1, "idx": batched_data.idx}
+
+    def test_epoch_end(self, outputs):
+        """model_fqandtoyo.py:1546-1597: ACC / NDCG @1/5/10/20 and MRR over all test samples."""
+        from .metrics import evaluate_outputs
+        return evaluate_outputs(outputs)
+
     def configure_optimizers(self, capturable=False, fused=None):
         """model_fqandtoyo.py:1599-1616"""
         kw = {}

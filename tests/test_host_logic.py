@@ -115,3 +115,21 @@ def test_state_dict_names_match_reference(golden_dir):
         shapes = [str(tuple(p.shape)) for _, p in m.named_parameters()]
         assert names == [str(n) for n in z6[f"{tag}/param_names"]]
         assert shapes == [str(s) for s in z6[f"{tag}/param_shapes"]]
+
+
+def test_metrics_match_reference_g7(golden_dir):
+    from mobgt_amd import metrics
+    z = np.load(os.path.join(golden_dir, "g7_lr_loss.npz"))
+    scores, target = torch.from_numpy(z["acc/scores"]), torch.from_numpy(z["acc/target"])
+    acc, ndcg = metrics.get_acc(target, scores)
+    np.testing.assert_allclose(acc, z["acc/acc"])
+    np.testing.assert_allclose(ndcg, z["acc/ndcg"], rtol=1e-12)
+    np.testing.assert_allclose(metrics.MRR_metric(target, scores), z["acc/mrr"], rtol=1e-12)
+    # the reference stops at the first zero target (model_fqandtoyo.py:88-89)
+    t2 = target.clone()
+    t2[5] = 0
+    a2, _ = metrics.get_acc(t2, scores)
+    a5, _ = metrics.get_acc(target[:5], scores[:5])
+    np.testing.assert_allclose(a2, a5)
+    out = metrics.evaluate_outputs([{"y_pred": [scores, None], "y_true": target}])
+    assert abs(out["acc@10"] - z["acc/acc"][0, 0] / len(target)) < 1e-12 and 0 <= out["mrr"] <= 1
