@@ -50,6 +50,22 @@ def _mm_f32(a, b):
     return (a @ b).float()
 
 
+_ADDMM_OUT_DTYPE = [None]
+
+
+def _addmm_f32(c, a, b):
+    """c (fp32) + a @ b (bf16 operands) with an fp32 result."""
+    if _ADDMM_OUT_DTYPE[0] is None:
+        try:
+            torch.addmm(c, a, b, out_dtype=torch.float32)
+            _ADDMM_OUT_DTYPE[0] = True
+        except Exception:
+            _ADDMM_OUT_DTYPE[0] = False
+    if _ADDMM_OUT_DTYPE[0]:
+        return torch.addmm(c, a, b, out_dtype=torch.float32)
+    return c + (a @ b).float()
+
+
 def _k1_fwd(x, y, x1, w, b, z, z32, mean, rstd, R, C, p, seed, seed_dev, salt, act):
     check(_lib.lib().mobgt_dropout_add_ln_fwd(_p(x), _p(y), _p(x1), _p(w), _p(b), _p(z), _p(z32), _p(mean), _p(rstd), R, C,
                                               p, seed, _p(seed_dev), salt, act, _stream()), "mobgt_dropout_add_ln_fwd")
@@ -79,7 +95,7 @@ class _FusedLayerFn(torch.autograd.Function):
     `shadows`: (wqkv [3C,C], bqkv [3C], wo, bo, w1, b1, w2, b2) in act_dtype (the fused masters when fp32)."""
 
     @staticmethod
-    def forward(ctx, x, token, cfg, shadows, wq, bq, wk, bk, wv, bv, wo, bo, n1w, n1b, nxw, nxb, w1, b1, w2, b2):
+    def forward(ctx, x, token, cfg, shadows, xa_pre, wq, bq, wk, bk, wv, bv, wo, bo, n1w, n1b, nxw, nxb, w1, b1, w2, b2):
         # wq/wk/wv (+ biases) are views of one fused [3C, C] storage (MultiHeadAttention.fuse_qkv_storage); they
         # are separate arguments only so that autograd has an edge to each reference-named parameter.
         G, T, C = x.shape
@@ -97,7 +113,12 @@ class _FusedLayerFn(torch.autograd.Function):
             xa = torch.empty(R, C, dtype=A, device=dev)
             _k1_fwd(x, None, None, nxw, nxb, xa, None, stats[0], stats[1], R, C, 0.0, seed, sd, salt, act)
         else:
-            xa = x.view(R, C) if A == torch.float32 else x.view(R, C).to(A)
+            if A == torch.float32:
+                xa = x.view(R, C)
+            elif xa_pre is not None and xa_pre.dtype == A and xa_pre.numel() == R * C:
+                xa = xa_pre.view(R, C)                             # written by the previous layer's LayerNorm kernel
+            else:
+                xa = x.view(R, C).to(A)
         qkv = torch.addmm(s_bqkv, xa, s_wqkv.t()).view(G, T, 3 * C)
         q, k, v = qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:]
         a, lse = ops._attn_fwd(q, k, v, cfg.pack, cfg.scale, cfg.p_att, seed ^ (salt * 0x9E3779B1), sd)
@@ -115,7 +136,9 @@ class _FusedLayerFn(torch.autograd.Function):
             out = x2
         else:                                                         # ... then ffn_norm2 (model_fqandtoyo.py:1742)
             out = torch.empty(R, C, **f32)
-            _k1_fwd(x1, f, x2, nxw, nxb, None, out, stats[4], stats[5], R, C, cfg.p, seed, sd, salt + 2, act)
+            out_a = torch.empty(R, C, dtype=A, device=dev) if A != torch.float32 else None
+            _k1_fwd(x1, f, x2, nxw, nxb, out_a, out, stats[4], stats[5], R, C, cfg.p, seed, sd, salt + 2, act)
+            cfg.out_act = out_a                                       # bf16 copy for the next layer's QKV GEMM
         ctx.cfg = cfg
         ctx.shapes = (G, T, C)
         ctx.save_for_backward(x, xa, qkv, a, lse, x1, z, u, h, x2, stats, s_wqkv, s_wo, s_w1, s_w2, n1w, nxw)
@@ -178,10 +201,14 @@ class _FusedLayerFn(torch.autograd.Function):
         elif A == torch.float32:
             dx = torch.addmm(dx1, dqkv2, s_wqkv)
         else:
-            dx = dx1 + (dqkv2 @ s_wqkv).float()
-        return (dx.view(G, T, C), None, None, None, dwqkv[:C], dbqkv[:C], dwqkv[C:2 * C], dbqkv[C:2 * C], dwqkv[2 * C:],
+            dx = _addmm_f32(dx1, dqkv2, s_wqkv)
+        return (dx.view(G, T, C), None, None, None, None, dwqkv[:C], dbqkv[:C], dwqkv[C:2 * C], dbqkv[C:2 * C], dwqkv[2 * C:],
                 dbqkv[2 * C:], dwo, dbo, dn1w, dn1b, dnxw, dnxb, dw1, db1, dw2, db2)
 
 
-def fused_encoder_layer(x, pack, cfg, shadows, params):
-    return _FusedLayerFn.apply(x, pack.token, cfg, shadows, *params)
+def fused_encoder_layer(x, pack, cfg, shadows, params, xa_pre=None):
+    cfg.out_act = None
+    out = _FusedLayerFn.apply(x, pack.token, cfg, shadows, xa_pre, *params)
+    if cfg.out_act is not None:
+        out._mobgt_act = cfg.out_act          # picked up by the next fused layer (same Python tensor object)
+    return out

@@ -182,7 +182,7 @@ def fused_layer_forward(layer, variant, x, attn_bias, n1, nx):
     params = (mha.linear_q.weight, mha.linear_q.bias, mha.linear_k.weight, mha.linear_k.bias, mha.linear_v.weight,
               mha.linear_v.bias, mha.output_layer.weight, mha.output_layer.bias, n1.weight, n1.bias, nx.weight, nx.bias,
               layer.ffn.layer1.weight, layer.ffn.layer1.bias, layer.ffn.layer2.weight, layer.ffn.layer2.bias)
-    return fused_encoder_layer(x.float(), pack, cfg, shadows, params)
+    return fused_encoder_layer(x.float(), pack, cfg, shadows, params, xa_pre=getattr(x, "_mobgt_act", None))
 
 
 def refresh_shadows(layers):
