@@ -219,6 +219,8 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     loss = float(ts.loss_out.item())
+    if loss != loss or abs(loss) == float("inf"):
+        raise SystemExit(f"bench.py: training diverged (final loss {loss}) -- the timing would be meaningless")
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -25,6 +25,13 @@ def mm_tn_splitk(x, g, max_chunks=32):
     return torch.bmm(x.view(s, P // s, -1).transpose(1, 2), g.view(s, P // s, -1)).sum(0)
 
 
+def _colsum(g):
+    if g.is_cuda:
+        from . import ops
+        return ops.colsum(g)
+    return g.sum(0)
+
+
 class _GraphConvFn(torch.autograd.Function):
     """out = adj @ (x @ W) + b   (modelGNN.py:38-44), with the big product in adj's dtype."""
 
@@ -44,7 +51,7 @@ class _GraphConvFn(torch.autograd.Function):
         d_support = torch.mm(adj.t(), g.to(adj.dtype)).float()
         dW = mm_tn_splitk(x, d_support)
         dx = d_support @ weight.t() if ctx.needs_input_grad[0] else None
-        db = g.sum(0) if ctx.has_bias else None
+        db = _colsum(g) if ctx.has_bias else None
         return dx, dW, db, None
 
 
@@ -63,7 +70,7 @@ class _PreAggConvFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         (ax,) = ctx.saved_tensors
-        return None, mm_tn_splitk(ax, g), (g.sum(0) if ctx.has_bias else None)
+        return None, mm_tn_splitk(ax, g), (_colsum(g) if ctx.has_bias else None)
 
 
 class GraphConvolution(nn.Module):
@@ -103,8 +110,12 @@ class GCN(nn.Module):
         for i in range(len(channels) - 1):
             self.gcn.append(GraphConvolution(channels[i], channels[i + 1]))
 
-    def forward(self, x, adj, adj_x=None):
-        """`adj_x` = adj @ x precomputed (x is a constant feature matrix in MobGT): skips the first P x P product."""
+    def forward(self, x, adj, adj_x=None, rows=None):
+        """`adj_x` = adj @ x precomputed (x is a constant feature matrix in MobGT): skips the first P x P product.
+        `rows` (int64 [R]): return only these rows of the output table, i.e. evaluate the LAST layer as
+        adj[rows] @ (h W) + b.  The model reads the table only at the batch's POI ids
+        (model_fqandtoyo.py:1264), so for R << P this replaces a P x P product (and its transpose in the
+        backward) by an R x P one without changing any value that is used."""
         for i in range(len(self.gcn) - 1):
             x = self.leaky_relu(self.gcn[i](x, adj, adj_x if i == 0 else None))
         if x.is_cuda:
@@ -112,4 +123,6 @@ class GCN(nn.Module):
             x = ops.dropout(x, self.dropout, self.training, 0x2000 + self.gcn[-1].out_features)
         else:
             x = F.dropout(x, self.dropout, training=self.training)
+        if rows is not None:
+            return self.gcn[-1](x, adj.index_select(0, rows))
         return self.gcn[-1](x, adj)

@@ -278,19 +278,31 @@ class Graphormer(nn.Module):
         x = batched_data.x[:, :, 0].long()                                    # [G,N] POI ids, 0 = pad
         G, N = x.shape
         real = x != 0
-        poidist = self.poi_distance_model(self.X, self.D_A, self.D_AX)            # :1236
+        P = self.X.shape[0]
+        rows_only = G * N * 2 <= P                      # the table is read at <= G*N rows (:1264): compute only those
+        if rows_only:
+            poidist = self.poi_distance_model(self.X, self.D_A, self.D_AX, rows=(x - 1).clamp(min=0).reshape(-1))
+        else:
+            poidist = self.poi_distance_model(self.X, self.D_A, self.D_AX)        # :1236
+        ops.trace_nan("poidist", poidist)
         catemb = self.poi_cat_model(self.C_X, self.C_A, self.C_AX)                                    # :1237
         slot = (batched_data.time_normal[:, :, 0] * 48).long()                                 # :1262
         neg = torch.full_like(x, -1)
-        poi_idx = torch.where(real, x - 1, neg)                                                # :1264
+        if rows_only:                                   # row p of the compact table belongs to position p
+            poi_idx = torch.where(real, torch.arange(G * N, device=x.device).view(G, N), neg)
+        else:
+            poi_idx = torch.where(real, x - 1, neg)                                            # :1264
         time_idx = torch.where(real, slot, neg)
         cat_idx = torch.where(real, self.poi2cat[x] - 1, neg)                                  # :1259
         # [poi ; time] and the category row, gathered for every position in one pass each
         pt = ops.embed_gather_concat([poidist, self.time_embed_model_48.weight], [poi_idx, time_idx], padding_idx=[None, 0])
         f2 = self.embed_fuse_model2.leaky_relu(
             ops.linear_splitk(pt, self.embed_fuse_model2.fuse_embed.weight, self.embed_fuse_model2.fuse_embed.bias))   # :1268
+        ops.trace_nan("pt", pt)
+        ops.trace_nan("f2", f2)
         ce = ops.embed_gather_sum([catemb], [cat_idx])
         nf = self.embed_fuse_model4(f2, ce)                                                    # :1269
+        ops.trace_nan("fuse4", nf)
         nf = nf * real.unsqueeze(-1).to(nf.dtype)                                              # pads stay 0
         # + fre_embed(0) + degree rows + positional rows pe[1..n] (:1287-1298, :348-351)
         pos = torch.arange(1, N + 1, device=x.device).unsqueeze(0).expand(G, N)
@@ -308,12 +320,17 @@ class Graphormer(nn.Module):
         bias = self.assemble_bias(batched_data)
         refresh_shadows(self.layers)
         output = ops.dropout(self.node_features(batched_data), self.input_dropout.p, self.training, 0x1003)
-        for enc_layer in self.layers:                                                          # :1347-1352
+        ops.trace_nan("x0", output)
+        for li, enc_layer in enumerate(self.layers):                                           # :1347-1352
             output = enc_layer(output, bias, mask=None)
+            ops.trace_nan(f"layer{li}", output)
         user_embedding = self.user_embed_model(batched_data.user.long() - 1).reshape(output.shape[0], -1)   # :1239-1240
         tok = self.embed_fuse_model3(output[:, 0, :].float(), user_embedding)                  # :1353-1358, q = 0 only
         tok = ops.dropout(self.ELU(self.final_ln(tok)), self.output_dropout.p, self.training, 0x1004)   # :1360-1364
-        return [self.out_proj(tok), self.cat_decoder(tok)]                                     # :1394-1396
+        ops.trace_nan("tok", tok)
+        logits = self.out_proj(tok)
+        ops.trace_nan("logits", logits)
+        return [logits, self.cat_decoder(tok)]                                                 # :1394-1396
 
     def training_step(self, batched_data, batch_idx=0):
         """model_fqandtoyo.py:1446-1460: y-1 targets, GradientTailLoss(alpha=0.2) on the POI logits only."""

@@ -413,7 +413,7 @@ class _LinearSplitKFn(torch.autograd.Function):
             dw = torch.bmm(g.view(s, R // s, -1).transpose(1, 2), x.view(s, R // s, -1)).sum(0)
         else:
             dw = g.t() @ x
-        return g @ w, dw, g.sum(0)
+        return g @ w, dw, colsum(g)
 
 
 def linear_splitk(x, weight, bias):
@@ -461,3 +461,47 @@ def dropout(x, p, training, salt):
     if seed_dev is None:
         seed = (seed + int(torch.randint(0, 2 ** 31 - 1, (1,)).item())) & 0x7FFFFFFFFFFFFFFF
     return _DropoutFn.apply(x.float(), float(p), int(seed), seed_dev, int(salt) & 0xFFFFFFFF)
+
+
+# ------------------------------------------------------------------------------ debug: NaN tracer
+_NAN_TRACE = {"flags": None, "names": [], "on": False}
+
+
+def nan_trace_enable(device, slots=256):
+    _NAN_TRACE.update(flags=torch.zeros(slots, dtype=torch.float32, device=device), names=[], on=True)
+
+
+def trace_nan(name, t, grad=True):
+    """Debug aid (off by default): record inside the running stream / captured graph whether `t` (and its
+    gradient) contains a NaN, without keeping `t` alive."""
+    if not _NAN_TRACE["on"] or t is None:
+        return t
+    names, flags = _NAN_TRACE["names"], _NAN_TRACE["flags"]
+    if name not in names:
+        names.append(name)
+        if grad:
+            names.append("d/" + name)
+    i = names.index(name)
+    flags[i:i + 1].copy_(torch.isnan(t.detach()).any().float().reshape(1))
+    if grad and t.requires_grad:
+        j = names.index("d/" + name)
+        def _hook(g, j=j):
+            flags[j:j + 1].copy_(torch.isnan(g).any().float().reshape(1))
+            return None
+        t.register_hook(_hook)
+    return t
+
+
+def nan_trace_report():
+    f = _NAN_TRACE["flags"].cpu().tolist()
+    return [(n, bool(f[i])) for i, n in enumerate(_NAN_TRACE["names"])]
+
+
+def colsum(g):
+    """Column sums of a 2-D f32/bf16 tensor as f32 [C] (bias gradient of a Linear / GraphConvolution)."""
+    _require_cuda(g)
+    g = g.contiguous()
+    R, C = g.shape
+    out = torch.zeros(C, dtype=torch.float32, device=g.device)
+    check(_lib.lib().mobgt_colsum(_p(g), _p(out), R, C, _DT[g.dtype], _stream()), "mobgt_colsum")
+    return out

@@ -27,12 +27,28 @@ if os.environ.get('NODROP'):
     args.update(dropout_rate=0.0, intput_dropout_rate=0.0, attention_dropout_rate=0.0)
 print({k: args[k] for k in ('dropout_rate','intput_dropout_rate','attention_dropout_rate')})
 model = Graphormer(universe=uni, num_bins=nb + 2, **kw, **args).to(dev)
+from mobgt_amd import ops
+if os.environ.get('TRACE'):
+    ops.nan_trace_enable(dev)
 ts = TrainStep(model, batches, use_graph=graph)
 ts.prepare()
 for i in range(int(sys.argv[3]) if len(sys.argv) > 3 else 120):
     l = float(ts.step(i).item())
+    if os.environ.get('TRACE'):
+        gbad = [n for n, p in model.named_parameters() if p.grad is not None and not torch.isfinite(p.grad).all()]
+        pbad = [n for n, p in model.named_parameters() if not torch.isfinite(p).all()]
+        if gbad or pbad:
+            print("step", i, "batch", i % 8, "loss", l, "non-finite grads:", gbad[:6], len(gbad), "params:", pbad[:4], len(pbad))
+            print([n for n, f in ops.nan_trace_report() if f])
+            for n, p in model.named_parameters():
+                if p.grad is not None and not torch.isfinite(p.grad).all():
+                    g = p.grad
+                    print("   ", n, tuple(g.shape), "nan", int(torch.isnan(g).sum()), "inf", int(torch.isinf(g).sum()))
+            break
     if l != l:
         print("first NaN at step", i, "batch", i % 8)
+        if os.environ.get('TRACE'):
+            print([n for n, f in ops.nan_trace_report() if f])
         bad = [n for n, p in model.named_parameters() if p.grad is not None and not torch.isfinite(p.grad).all()]
         print("non-finite grads:", bad[:12])
         break
