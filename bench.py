@@ -192,10 +192,19 @@ def main():
                        fused_layers=not args.unfused, **MODEL_ARGS).to(dev)
     broadcast_parameters(model)
     coll = DeviceCollator(dev, bin_table=table, multi_hop_max_dist=20, rel_pos_max=1024)
+    # Length-bucketed sharding (SURVEY §8e hazard): every rank draws the SAME pool of world x n_batches batches,
+    # the pool is ordered by padded size and dealt round-robin, so that at each synchronous step all ranks work
+    # on batches of neighbouring size (per-rank work is still n_batches x 16 trajectories: weak scaling).
+    pool = []
+    for i in range(args.n_batches * world):
+        trajs = synth.make_batch_of_trajectories(seed=1000 + i, G=args.batch_size, P=args.pois, n_user=1080,
+                                                 cat_of_poi=uni.cat_of_poi, hi=256)
+        pool.append((max(len(t["node_name"]) for t in trajs), i, trajs))
+    pool.sort(key=lambda e: (e[0], e[1]))
+    order = sorted(range(args.n_batches), key=lambda j: pool[j * world][1])   # size-mixed order over time
+    mine = [pool[j * world + rank] for j in order]                            # same slot order on all ranks
     batches, shapes = [], []
-    for i in range(args.n_batches):
-        trajs = synth.make_batch_of_trajectories(seed=1000 * (rank + 1) + i, G=args.batch_size, P=args.pois,
-                                                 n_user=1080, cat_of_poi=uni.cat_of_poi, hi=256)
+    for _, _, trajs in mine:
         b = coll(trajs)
         batches.append(b)
         shapes.append((len(b), b.x.shape[1] + 1))

@@ -220,10 +220,12 @@ __global__ __launch_bounds__(256) void colsum_kernel(const TA* __restrict__ dh, 
 }
 
 int pick_rows(int64_t R) {
-    // >= ~1024 workgroups when possible: 4 rows (one per wave) up to 16 rows per workgroup
-    int rows = 4;
-    while (rows < MAX_ROWS_PER_WG && (R + rows - 1) / rows > 2048) rows *= 2;
-    return rows;
+    // 4 rows (one per wave) per workgroup while that gives <= 512 workgroups, more rows beyond: every
+    // workgroup ends with one f32 atomic per column onto the SAME C addresses, and that contention (not the
+    // streaming) set the kernel time at R = 12.5k rows (measured 54 us with 3140 workgroups)
+    int rows = (int)((R + 511) / 512);
+    rows = (rows + 3) / 4 * 4;
+    return rows < 4 ? 4 : rows;
 }
 
 void set_drop(LnParams& p, float dropout_p, uint64_t seed, const uint64_t* seed_dev, uint32_t salt) {

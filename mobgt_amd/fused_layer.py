@@ -22,32 +22,44 @@ from .ops import _p, _stream, _DT
 _MM_OUT_DTYPE = [None]
 
 
-def _mm_f32(a, b):
-    """a @ b with an fp32 result (weight gradients go to fp32 master gradients)."""
-    M, R = a.shape
-    N = b.shape[1]
-    if M * N <= 256 * 256 and R >= 256:
-        # one output tile and a long K (= rows): a plain GEMM call leaves 255 CUs idle; split K over a batch axis
-        s = max((c for c in (16, 8, 4, 2) if R % c == 0), default=1)
-        if s > 1:
-            at = a.reshape(M, s, R // s).permute(1, 0, 2)
-            part = torch.bmm(at, b.reshape(s, R // s, N))
-            return part.float().sum(0) if part.dtype != torch.float32 else part.sum(0)
-    if a.dtype == torch.float32:
-        return a @ b
+def _split_factor(R, tiles):
+    """Divisor s of R so that s * tiles fills the chip (>= ~512 workgroups) while each slice keeps K >= 32."""
+    want = max(1, (512 + tiles - 1) // tiles)
+    best = 1
+    for s in range(1, 257):
+        if R % s == 0 and R // s >= 32:
+            best = s
+            if s >= want:
+                break
+    return best
+
+
+def _mm_tn_f32(g, x):
+    """g^T @ x for row-major g [R,M], x [R,N] with an fp32 result -- the weight gradient of a Linear layer.
+    The output is small and K = R is long, so K is split over a batch axis (strided views, no copies):
+    a plain GEMM call maps a 192x192 output onto ONE workgroup and leaves the other 255 CUs idle."""
+    R, M = g.shape
+    N = x.shape[1]
+    tiles = ((M + 63) // 64) * ((N + 63) // 64)
+    s = _split_factor(R, tiles) if tiles < 256 else 1
+    if s > 1:
+        part = torch.bmm(g.view(s, R // s, M).transpose(1, 2), x.view(s, R // s, N))
+        return part.float().sum(0) if part.dtype != torch.float32 else part.sum(0)
+    if g.dtype == torch.float32:
+        return g.t() @ x
     if _MM_OUT_DTYPE[0] is None:
         import os
         if os.environ.get("MOBGT_NO_OUT_DTYPE"):
             _MM_OUT_DTYPE[0] = False
     if _MM_OUT_DTYPE[0] is None:
         try:
-            torch.mm(a, b, out_dtype=torch.float32)
+            torch.mm(g.t(), x, out_dtype=torch.float32)
             _MM_OUT_DTYPE[0] = True
         except Exception:
             _MM_OUT_DTYPE[0] = False
     if _MM_OUT_DTYPE[0]:
-        return torch.mm(a, b, out_dtype=torch.float32)      # bf16 operands, fp32 accumulate AND fp32 result
-    return (a @ b).float()
+        return torch.mm(g.t(), x, out_dtype=torch.float32)      # bf16 operands, fp32 accumulate AND fp32 result
+    return (g.t() @ x).float()
 
 
 _ADDMM_OUT_DTYPE = [None]
@@ -176,23 +188,23 @@ class _FusedLayerFn(torch.autograd.Function):
             _k1_bwd(None, dout, None, x2, stats[4], stats[5], nxw, dx2, df, dnxw, dnxb, db2, R, C, cfg.p, seed, sd,
                     salt + 2, act)
         dh = df @ s_w2
-        dw2 = _mm_f32(df.t(), h)
+        dw2 = _mm_tn_f32(df, h)
         du = torch.empty_like(u)
         check(_lib.lib().mobgt_gelu_bwd_colsum(_p(dh), _p(u), _p(du), _p(db1), R, F, act, _stream()), "mobgt_gelu_bwd_colsum")
         dz = du @ s_w1
-        dw1 = _mm_f32(du.t(), z)
+        dw1 = _mm_tn_f32(du, z)
         dx1 = torch.empty(R, C, dtype=torch.float32, device=dev)
         dy = torch.empty(R, C, dtype=A, device=dev)
         _k1_bwd(dz, None, dx2, x1, stats[2], stats[3], n1w, dx1, dy, dn1w, dn1b, dbo, R, C, cfg.p, seed, sd, salt + 1, act)
         da = (dy @ s_wo).view(G, T, C)
-        dwo = _mm_f32(dy.t(), a.view(R, C))
+        dwo = _mm_tn_f32(dy, a.view(R, C))
         dqkv = torch.empty(G, T, 3 * C, dtype=A, device=dev)
         q, k, v = qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:]
         ops._attn_bwd(q, k, v, a, lse, da, dqkv[..., :C], dqkv[..., C:2 * C], dqkv[..., 2 * C:], cfg.pack, cfg.scale,
                       cfg.p_att, seed ^ (salt * 0x9E3779B1), sd)
         dqkv2 = dqkv.view(R, 3 * C)
         check(_lib.lib().mobgt_colsum(_p(dqkv2), _p(dbqkv), R, 3 * C, act, _stream()), "mobgt_colsum")
-        dwqkv = _mm_f32(dqkv2.t(), xa)
+        dwqkv = _mm_tn_f32(dqkv2, xa)
         if stock:                                                     # back through self_attention_norm
             dz0 = dqkv2 @ s_wqkv
             dx = torch.empty(R, C, dtype=torch.float32, device=dev)
