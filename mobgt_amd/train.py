@@ -57,6 +57,53 @@ class FlatGrads:
             self.flat.div_(dist.get_world_size(group))
 
 
+def flat_order(model, used):
+    """Order of the used parameters inside the flat buffers: every attention's q/k/v weights (then biases) are
+    adjacent, so that its fused [3C, C] projection storage is one slice of the flat parameter buffer."""
+    used_ids = {id(p) for p in used}
+    order, seen = [], set()
+    for m in model.modules():
+        if all(hasattr(m, a) for a in ("linear_q", "linear_k", "linear_v")):
+            grp = [m.linear_q.weight, m.linear_k.weight, m.linear_v.weight, m.linear_q.bias, m.linear_k.bias, m.linear_v.bias]
+            if all(id(p) in used_ids for p in grp):
+                for p in grp:
+                    order.append(p)
+                    seen.add(id(p))
+    return order + [p for p in used if id(p) not in seen]
+
+
+class FlatParams:
+    """All trained parameters as views of ONE fp32 buffer (same order as FlatGrads): AdamW becomes a single fused
+    launch over one tensor instead of a multi-tensor sweep over ~130.  Parameter objects, names and values are
+    unchanged (state_dict keeps working); untrained parameters are left alone, as the reference's optimizer
+    skips them (their grad is None)."""
+
+    def __init__(self, model, params):
+        self.params = params
+        n = sum(p.numel() for p in params)
+        flat = torch.empty(n, dtype=torch.float32, device=params[0].device)
+        off = 0
+        with torch.no_grad():
+            for p in params:
+                v = flat[off:off + p.numel()].view_as(p)
+                v.copy_(p.data)
+                p.data = v
+                off += p.numel()
+        self.tensor = torch.nn.Parameter(flat)
+        # re-point the attention modules' fused-QKV handles at the new storage
+        for m in model.modules():
+            if hasattr(m, "fuse_qkv_storage") and hasattr(m, "_wqkv"):
+                w, b = m.linear_q.weight, m.linear_q.bias
+                C = w.shape[0]
+                nxt_w = m.linear_k.weight.data_ptr() == w.data_ptr() + w.numel() * 4
+                nxt_b = m.linear_k.bias.data_ptr() == b.data_ptr() + b.numel() * 4
+                if nxt_w and nxt_b:
+                    wo = (w.data_ptr() - flat.data_ptr()) // 4
+                    bo = (b.data_ptr() - flat.data_ptr()) // 4
+                    m._wqkv = flat[wo:wo + 3 * C * w.shape[1]].view(3 * C, w.shape[1])
+                    m._bqkv = flat[bo:bo + 3 * C]
+
+
 def used_parameters(model, loss_fn):
     """One dry-run backward: the parameters that receive a gradient (the others stay grad=None)."""
     for p in model.parameters():
@@ -94,9 +141,12 @@ class TrainStep:
         self.stream = torch.cuda.Stream(device=dev) if use_graph else None
         with self._on_stream():
             used = used_parameters(model, lambda: self._loss(batches[0]))
+        used = flat_order(model, used)
         self.flat = FlatGrads(used)
+        self.flat_params = FlatParams(model, used)
+        self.flat_params.tensor.grad = self.flat.flat
         self.lr_dev = torch.tensor(float(model.peak_lr), dtype=torch.float32, device=dev)
-        self.opt = torch.optim.AdamW(model.parameters(), lr=self.lr_dev, weight_decay=model.weight_decay,
+        self.opt = torch.optim.AdamW([self.flat_params.tensor], lr=self.lr_dev, weight_decay=model.weight_decay,
                                      capturable=True, fused=True)
         self.sched_state = dict(step_count=1, warmup=model.warmup_updates, tot=model.tot_updates, lr=model.peak_lr,
                                 end_lr=model.end_lr, power=1.0)
