@@ -16,7 +16,6 @@
 namespace {
 
 constexpr int MAXC_PER_LANE = 8;     // C <= 512
-constexpr int MAX_ROWS_PER_WG = 16;  // 4 waves x up to 4 rows; fewer rows per workgroup when R is small (fill 256 CUs)
 
 template <typename T> __device__ __forceinline__ float ldf(const T* p, int64_t i);
 template <> __device__ __forceinline__ float ldf<float>(const float* p, int64_t i) { return p[i]; }
@@ -203,7 +202,7 @@ template <typename TA, bool GELU>
 __global__ __launch_bounds__(256) void colsum_kernel(const TA* __restrict__ dh, const TA* __restrict__ u, TA* __restrict__ du,
                                                      float* __restrict__ dbias, int64_t R, int C, int rows_per_wg) {
     const int64_t r0 = (int64_t)blockIdx.x * rows_per_wg;
-    for (int c = threadIdx.x; c < C; c += 256) {
+    for (int c = blockIdx.y * 256 + threadIdx.x; c < C; c += 256 * gridDim.y) {    // grid.y = column chunks of 256
         float acc = 0.f;
         for (int rr = 0; rr < rows_per_wg; ++rr) {
             const int64_t r = r0 + rr;
@@ -292,7 +291,7 @@ extern "C" int mobgt_gelu_bwd_colsum(const void* dh, const void* u, void* du, fl
                                      int act_dtype, void* stream) {
     if (R <= 0 || C <= 0) return 0;
     const int rows = pick_rows(R);
-    const dim3 grid((unsigned)((R + rows - 1) / rows)), block(256);
+    const dim3 grid((unsigned)((R + rows - 1) / rows), (unsigned)((C + 255) / 256)), block(256);
     hipStream_t st = (hipStream_t)stream;
     if (act_dtype == MOBGT_F32)
         hipLaunchKernelGGL((colsum_kernel<float, true>), grid, block, 0, st, (const float*)dh, (const float*)u, (float*)du, dbias, R, C, rows);
@@ -305,7 +304,7 @@ extern "C" int mobgt_gelu_bwd_colsum(const void* dh, const void* u, void* du, fl
 extern "C" int mobgt_colsum(const void* g, float* out, int64_t R, int C, int act_dtype, void* stream) {
     if (R <= 0 || C <= 0) return 0;
     const int rows = pick_rows(R);
-    const dim3 grid((unsigned)((R + rows - 1) / rows)), block(256);
+    const dim3 grid((unsigned)((R + rows - 1) / rows), (unsigned)((C + 255) / 256)), block(256);
     hipStream_t st = (hipStream_t)stream;
     if (act_dtype == MOBGT_F32)
         hipLaunchKernelGGL((colsum_kernel<float, false>), grid, block, 0, st, (const float*)g, (const float*)nullptr, (float*)nullptr, out, R, C, rows);

@@ -41,7 +41,8 @@ def _mm_tn_f32(g, x):
     R, M = g.shape
     N = x.shape[1]
     tiles = ((M + 63) // 64) * ((N + 63) // 64)
-    s = _split_factor(R, tiles) if tiles < 256 else 1
+    # split only where a plain GEMM call is starved: <= 12 output tiles, or a very long K
+    s = _split_factor(R, tiles) if (tiles <= 12 or (R >= 4096 and tiles < 256)) else 1
     if s > 1:
         part = torch.bmm(g.view(s, R // s, M).transpose(1, 2), x.view(s, R // s, N))
         return part.float().sum(0) if part.dtype != torch.float32 else part.sum(0)
@@ -171,7 +172,7 @@ class _FusedLayerFn(torch.autograd.Function):
         dout = dout.contiguous().view(R, C).float()
         # every small gradient of the layer in ONE zero-filled buffer:
         # [dbqkv 3C | dbo C | db1 F | db2 C | dn1w C | dn1b C | dnxw C | dnxb C]
-        small = torch.zeros(3 * C + C + F + C + 4 * C, dtype=torch.float32, device=dev)
+        small = ops.zeros_f32((3 * C + C + F + C + 4 * C,), dev)
         o = [0]
 
         def take(n):

@@ -27,6 +27,47 @@ def _require_cuda(*ts):
             raise RuntimeError("mobgt_amd ops run on the GPU only (there is no CPU fallback); got a CPU tensor")
 
 
+class ZeroArena:
+    """One f32 buffer zeroed ONCE per step from which the step's many small zero-initialised accumulators
+    (bias / LayerNorm / table gradients that kernels add into) are carved, instead of one fill launch each."""
+
+    def __init__(self, device, n=1 << 20):
+        self.buf = torch.zeros(n, dtype=torch.float32, device=device)
+        self.off = 0
+
+    def reset(self):
+        self.buf.zero_()
+        self.off = 0
+
+    def take(self, n):
+        n4 = (n + 3) // 4 * 4                         # keep 16-byte alignment of every slice
+        if self.off + n4 > self.buf.numel():
+            return None
+        t = self.buf[self.off:self.off + n]
+        self.off += n4
+        return t
+
+
+_ARENA = [None]
+
+
+def set_zero_arena(arena):
+    _ARENA[0] = arena
+
+
+def zeros_f32(shape, device):
+    """torch.zeros(shape, f32) -- from the step's zero arena when one is active (see ZeroArena)."""
+    n = 1
+    for d in (shape if isinstance(shape, (tuple, list, torch.Size)) else (shape,)):
+        n *= int(d)
+    a = _ARENA[0]
+    if a is not None and a.buf.device == torch.device(device):
+        t = a.take(n)
+        if t is not None:
+            return t.view(shape)
+    return torch.zeros(shape, dtype=torch.float32, device=device)
+
+
 def round_up(x, m):
     return (x + m - 1) // m * m
 
@@ -125,10 +166,10 @@ class _BuildBiasFn(torch.autograd.Function):
         pack = ctx.pack
         dev = pack.bias.device
         rs, ps, hs, vs = ctx.shapes
-        d_rel = torch.zeros(rs, device=dev)
-        d_poi = torch.zeros(ps, device=dev) if ps is not None else None
-        d_hop = torch.zeros(hs, device=dev) if hs is not None else None
-        d_vd = torch.zeros(vs, device=dev)
+        d_rel = zeros_f32(rs, dev)
+        d_poi = zeros_f32(ps, dev) if ps is not None else None
+        d_hop = zeros_f32(hs, dev) if hs is not None else None
+        d_vd = zeros_f32(vs, dev)
         if pack.dbias is not None:
             attn_bias, rel_pos, poi_pos, edge_input = ctx.idx
             a = ctx.args
@@ -502,6 +543,6 @@ def colsum(g):
     _require_cuda(g)
     g = g.contiguous()
     R, C = g.shape
-    out = torch.zeros(C, dtype=torch.float32, device=g.device)
+    out = zeros_f32((C,), g.device)
     check(_lib.lib().mobgt_colsum(_p(g), _p(out), R, C, _DT[g.dtype], _stream()), "mobgt_colsum")
     return out

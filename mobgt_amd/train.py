@@ -135,6 +135,8 @@ class TrainStep:
                 m.seed_dev = self.seed_dev
         from . import ops
         ops.set_dropout_state(self.seed_dev, seed)
+        self.arena = ops.ZeroArena(dev)
+        ops.set_zero_arena(self.arena)
         model.train()
         # One side stream for the dry run, the warm-ups and every capture: autograd's AccumulateGrad nodes are
         # created on the stream of the first backward and must match the capture stream later on.
@@ -188,6 +190,7 @@ class TrainStep:
 
     def _fwd_bwd(self, batch):
         self.flat.release()
+        self.arena.reset()                         # one fill for all small zero-initialised accumulators of the step
         self.seed_dev.add_(1)                      # new dropout masks each step (attention kernels read it on device)
         loss = self._loss(batch)
         loss.backward()
