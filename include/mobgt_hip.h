@@ -227,6 +227,13 @@ int mobgt_dropout(const float* x, float* y, int64_t n, int row_len, float dropou
                   const uint64_t* seed_dev, uint32_t salt, void* stream);
 /* out [C] (f32) += column sums of g [R,C]: the bias gradient of a Linear layer. */
 int mobgt_colsum(const void* g, float* out, int64_t R, int C, int act_dtype, void* stream);
+/* Weight / bias gradient of an nn.Linear y = x W^T + b (model.py:388-403, 406-463; what autograd's
+ * F.linear backward computes as dy^T x and dy.sum(0)):  dw [M,N] (f32, row pitch ldw) += g^T x and, when db is
+ * not null, db [M] += column sums of g, for g [R,M] (row pitch ldg) and x [R,N] (row pitch ldx), both bf16
+ * (act_dtype must be MOBGT_BF16).  M, N, ldg, ldx even; g, x 4-byte aligned.  Split over R across the grid with
+ * f32 atomics into dw/db, which the caller zero-initialises (or pre-loads with a gradient to accumulate into). */
+int mobgt_linear_wgrad(const void* g, int64_t ldg, const void* x, int64_t ldx, float* dw, int64_t ldw, float* db,
+                       int64_t R, int M, int N, int act_dtype, void* stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,175 @@
+// Weight gradient of a Linear layer: dW [M,N] (f32) += g^T x for row-major bf16 g [R,M] (grad of the layer's
+// output) and x [R,N] (its input), plus optionally db [M] += column sums of g -- the `weight.grad` / `bias.grad`
+// of every nn.Linear in the encoder layer (graphormer/model.py:388-403, 406-463; autograd of F.linear).
+//
+// Shape of the problem at MobGT's sizes: the output is tiny (192x192 ... 576x192) and the contraction runs over
+// the R = G*T rows of the batch (2-13 k).  A library GEMM call maps that onto 9-27 workgroups of 4 waves, each
+// walking the whole of R: pure latency.  Here a workgroup owns one 32x32 output tile and its SIXTEEN waves
+// split R between them (wave w takes row slabs w, w+16, ...); partial tiles meet in LDS and one thread per
+// output element sums the 16 partials: no partial-sum buffer, no second launch.  A first version split R over
+// ~340 four-wave workgroups with f32 atomics on every partial tile (1.4 M atomic lanes at R = 2432) and took
+// 30-50 us; cross-workgroup splitting is therefore limited to the 2-7 ways that fill the chip (see the launcher).
+//
+// Both operands are contracted over their ROW index, so the 8 consecutive k-values an MFMA lane supplies live
+// in 8 different rows.  No LDS transpose: lane (i, kq) of v_mfma_f32_16x16x32_bf16 reads one dword = columns
+// (2i, 2i+1) from each of its 8 rows, splits low / high halves into an "even-column" and an "odd-column"
+// operand, and the 2x2 MFMAs produce the 32x32 tile with rows 2i+a and columns 2j+b.
+#include "common.h"
+#include "mobgt_hip.h"
+#include <stdlib.h>
+
+namespace {
+
+constexpr int TILE = 32;
+constexpr int KSTEP = 32;            // rows contracted by one 16x16x32 MFMA
+constexpr int NWAVE = 16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+struct WgradParams {
+    const uint16_t* g;  int64_t ldg;     // [R,M] bf16
+    const uint16_t* x;  int64_t ldx;     // [R,N] bf16
+    float* dw;  int64_t ldw;             // [M,N] f32, accumulated
+    float* db;                           // [M] f32, accumulated, or null
+    int R, M, N;
+    int tiles_n;
+    int k_per_wg;                        // multiple of NWAVE * KSTEP when gridDim.y > 1
+};
+
+__device__ __forceinline__ void split_pairs(const uint32_t (&d)[8], bf16x8& even, bf16x8& odd) {
+    uint32_t e[4], o[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        e[j] = __builtin_amdgcn_perm(d[2 * j + 1], d[2 * j], 0x05040100u);      // lo16(d0) | lo16(d1) << 16
+        o[j] = __builtin_amdgcn_perm(d[2 * j + 1], d[2 * j], 0x07060302u);      // hi16(d0) | hi16(d1) << 16
+    }
+    even = __builtin_bit_cast(bf16x8, e);
+    odd = __builtin_bit_cast(bf16x8, o);
+}
+
+struct Slab {
+    uint32_t g[8], x[8];
+    __device__ __forceinline__ void load(const uint16_t* gp, const uint16_t* xp, int64_t ldg, int64_t ldx, int r0, int k1,
+                                         bool m_ok, bool n_ok) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int r = r0 + j;
+            const bool ok = r < k1;
+            g[j] = ok && m_ok ? *reinterpret_cast<const uint32_t*>(gp + (int64_t)r * ldg) : 0u;
+            x[j] = ok && n_ok ? *reinterpret_cast<const uint32_t*>(xp + (int64_t)r * ldx) : 0u;
+        }
+    }
+};
+
+__global__ __launch_bounds__(NWAVE * 64) void wgrad_kernel(const WgradParams p) {
+    __shared__ float part[NWAVE / 2][TILE * TILE];     // 32 KB: the upper 8 waves hand their tiles to the lower 8 first
+    __shared__ float colpart[NWAVE][TILE];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = lane & 15, kq = lane >> 4;
+    const int m0 = (blockIdx.x / p.tiles_n) * TILE, n0 = (blockIdx.x % p.tiles_n) * TILE;
+    const int k0 = blockIdx.y * p.k_per_wg;
+    const int k1 = min(p.R, k0 + p.k_per_wg);
+    const bool want_db = p.db != nullptr && n0 == 0;
+    const bool m_ok = m0 + 2 * i < p.M, n_ok = n0 + 2 * i < p.N;      // M, N even: a pair is in or out together
+    const uint16_t* gp = p.g + m0 + 2 * i;
+    const uint16_t* xp = p.x + n0 + 2 * i;
+
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float se = 0.f, so = 0.f;
+
+    int kb = k0 + wave * KSTEP;
+    Slab cur, nxt;
+    if (kb < k1) cur.load(gp, xp, p.ldg, p.ldx, kb + 8 * kq, k1, m_ok, n_ok);
+    for (; kb < k1; kb += NWAVE * KSTEP) {
+        const int kn = kb + NWAVE * KSTEP;
+        if (kn < k1) nxt.load(gp, xp, p.ldg, p.ldx, kn + 8 * kq, k1, m_ok, n_ok);      // in flight during the MFMAs
+        bf16x8 ge, go, xe, xo;
+        split_pairs(cur.g, ge, go);
+        split_pairs(cur.x, xe, xo);
+        acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ge, xe, acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ge, xo, acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(go, xe, acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(go, xo, acc[1][1], 0, 0, 0);
+        if (want_db) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { se += bf16_lo(cur.g[j]); so += bf16_hi(cur.g[j]); }
+        }
+        if (kn < k1) cur = nxt;
+    }
+
+    // register v of lane (j = lane & 15, q = lane >> 4) is MFMA row 4q + v, column j; operand row i / column j
+    // stand for tile rows 2i+a and columns 2j+b
+    if (wave >= NWAVE / 2) {
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) part[wave - NWAVE / 2][(2 * (4 * kq + v) + a) * TILE + 2 * i + b] = acc[a][b][v];
+    }
+    __syncthreads();
+    if (wave < NWAVE / 2) {
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) part[wave][(2 * (4 * kq + v) + a) * TILE + 2 * i + b] += acc[a][b][v];
+    }
+    if (want_db) {
+        se += __shfl_xor(se, 16, 64); se += __shfl_xor(se, 32, 64);
+        so += __shfl_xor(so, 16, 64); so += __shfl_xor(so, 32, 64);
+        if (kq == 0) { colpart[wave][2 * i] = se; colpart[wave][2 * i + 1] = so; }
+    }
+    __syncthreads();
+    {
+        const int e = threadIdx.x, r = e >> 5, c = e & 31;
+        float s = 0.f;
+#pragma unroll
+        for (int w = 0; w < NWAVE / 2; ++w) s += part[w][e];
+        if (m0 + r < p.M && n0 + c < p.N) {
+            float* dst = p.dw + (int64_t)(m0 + r) * p.ldw + n0 + c;
+            if (gridDim.y > 1) atomicAdd(dst, s); else *dst += s;
+        }
+        if (want_db && e < TILE && m0 + e < p.M) {
+            float t = 0.f;
+#pragma unroll
+            for (int w = 0; w < NWAVE; ++w) t += colpart[w][e];
+            if (gridDim.y > 1) atomicAdd(p.db + m0 + e, t); else p.db[m0 + e] += t;
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int mobgt_linear_wgrad(const void* g, int64_t ldg, const void* x, int64_t ldx, float* dw, int64_t ldw,
+                                  float* db, int64_t R, int M, int N, int act_dtype, void* stream) {
+    if (act_dtype != MOBGT_BF16) return MOBGT_EDTYPE;
+    if (R < 0 || M <= 0 || N <= 0 || (M & 1) || (N & 1) || (ldg & 1) || (ldx & 1) || R > 0x7fffffff) return MOBGT_EBADDIM;
+    if (((uintptr_t)g & 3) || ((uintptr_t)x & 3)) return MOBGT_EALIGN;
+    if (R == 0) return 0;
+    WgradParams p;
+    p.g = reinterpret_cast<const uint16_t*>(g); p.ldg = ldg;
+    p.x = reinterpret_cast<const uint16_t*>(x); p.ldx = ldx;
+    p.dw = dw; p.ldw = ldw; p.db = db;
+    p.R = (int)R; p.M = M; p.N = N;
+    const int tiles_m = (M + TILE - 1) / TILE;
+    p.tiles_n = (N + TILE - 1) / TILE;
+    const int tiles = tiles_m * p.tiles_n;
+    // A 1024-thread workgroup fills a CU, so up to ~256 workgroups run at once: when the tiles alone do not
+    // reach that, R is also split over gridDim.y (>= one 512-row slab per workgroup) and the few partial tiles
+    // per output are combined with f32 atomics.  Measured (MI355X, R = 2432): 192x192 5 splits 7.5 us vs 12.9 us
+    // unsplit; 576x192 2 splits 10.8 vs 13.3; R = 12560, 256x256 4 splits 21 vs 46 (incl. two zero fills).
+    const int slab = NWAVE * KSTEP;
+    int splits = 256 / tiles;
+    const int max_splits = (int)((R + slab - 1) / slab);
+    if (splits > max_splits) splits = max_splits;
+    if (splits < 1) splits = 1;
+    p.k_per_wg = (int)(((R + splits - 1) / splits + slab - 1) / slab) * slab;
+    splits = (int)((R + p.k_per_wg - 1) / p.k_per_wg);
+    hipLaunchKernelGGL(wgrad_kernel, dim3(tiles, splits), dim3(NWAVE * 64), 0, (hipStream_t)stream, p);
+    return (int)hipGetLastError();
+}

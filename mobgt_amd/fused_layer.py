@@ -34,8 +34,25 @@ def _split_factor(R, tiles):
     return best
 
 
+def _wgrad_hip(dtype, M, N):
+    """True when the weight gradient of an [M,N] Linear goes to csrc/wgrad.hip.  Its 32x32 output tiles
+    re-read g / x once per tile column / row: past ~128 k outputs (c5's 768x256 and 256x1024: 48 / 50 us vs
+    29 us) the library's split-K GEMM with its 64x64+ tiles is the faster one."""
+    return dtype == torch.bfloat16 and M % 2 == 0 and N % 2 == 0 and M * N <= 131072
+
+
+def _wgrad(g, x, db=None):
+    """Weight gradient g^T @ x (fp32) of a Linear layer; bf16 operands go to the split-K MFMA kernel
+    (csrc/wgrad.hip), which also accumulates the bias gradient g.sum(0) into `db` when given."""
+    if _wgrad_hip(g.dtype, g.shape[1], x.shape[1]):
+        return ops.linear_wgrad(g, x, db=db)[0]
+    if db is not None:
+        check(_lib.lib().mobgt_colsum(_p(g), _p(db), g.shape[0], g.shape[1], _DT[g.dtype], _stream()), "mobgt_colsum")
+    return _mm_tn_f32(g, x)
+
+
 def _mm_tn_f32(g, x):
-    """g^T @ x for row-major g [R,M], x [R,N] with an fp32 result -- the weight gradient of a Linear layer.
+    """g^T @ x for row-major g [R,M], x [R,N] with an fp32 result (library path: fp32 operands).
     The output is small and K = R is long, so K is split over a batch axis (strided views, no copies):
     a plain GEMM call maps a 192x192 output onto ONE workgroup and leaves the other 255 CUs idle."""
     R, M = g.shape
@@ -189,23 +206,24 @@ class _FusedLayerFn(torch.autograd.Function):
             _k1_bwd(None, dout, None, x2, stats[4], stats[5], nxw, dx2, df, dnxw, dnxb, db2, R, C, cfg.p, seed, sd,
                     salt + 2, act)
         dh = df @ s_w2
-        dw2 = _mm_tn_f32(df, h)
+        dw2 = _wgrad(df, h)
         du = torch.empty_like(u)
-        check(_lib.lib().mobgt_gelu_bwd_colsum(_p(dh), _p(u), _p(du), _p(db1), R, F, act, _stream()), "mobgt_gelu_bwd_colsum")
+        db1_in_wgrad = _wgrad_hip(A, F, C)                            # then b1's gradient rides on the dW1 kernel
+        check(_lib.lib().mobgt_gelu_bwd_colsum(_p(dh), _p(u), _p(du), _p(None if db1_in_wgrad else db1), R, F, act,
+                                               _stream()), "mobgt_gelu_bwd_colsum")
         dz = du @ s_w1
-        dw1 = _mm_tn_f32(du, z)
+        dw1 = _wgrad(du, z, db=db1 if db1_in_wgrad else None)
         dx1 = torch.empty(R, C, dtype=torch.float32, device=dev)
         dy = torch.empty(R, C, dtype=A, device=dev)
         _k1_bwd(dz, None, dx2, x1, stats[2], stats[3], n1w, dx1, dy, dn1w, dn1b, dbo, R, C, cfg.p, seed, sd, salt + 1, act)
         da = (dy @ s_wo).view(G, T, C)
-        dwo = _mm_tn_f32(dy, a.view(R, C))
+        dwo = _wgrad(dy, a.view(R, C))
         dqkv = torch.empty(G, T, 3 * C, dtype=A, device=dev)
         q, k, v = qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:]
         ops._attn_bwd(q, k, v, a, lse, da, dqkv[..., :C], dqkv[..., C:2 * C], dqkv[..., 2 * C:], cfg.pack, cfg.scale,
                       cfg.p_att, seed ^ (salt * 0x9E3779B1), sd)
         dqkv2 = dqkv.view(R, 3 * C)
-        check(_lib.lib().mobgt_colsum(_p(dqkv2), _p(dbqkv), R, 3 * C, act, _stream()), "mobgt_colsum")
-        dwqkv = _mm_tn_f32(dqkv2, xa)
+        dwqkv = _wgrad(dqkv2, xa, db=dbqkv)
         if stock:                                                     # back through self_attention_norm
             dz0 = dqkv2 @ s_wqkv
             dx = torch.empty(R, C, dtype=torch.float32, device=dev)

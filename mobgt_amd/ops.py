@@ -538,6 +538,22 @@ def nan_trace_report():
     return [(n, bool(f[i])) for i, n in enumerate(_NAN_TRACE["names"])]
 
 
+def linear_wgrad(g, x, with_bias=False, db=None):
+    """(dW, db) of y = x W^T + b from g = dL/dy: dW [M,N] = g^T x (f32) and db [M] = g.sum(0) (f32, or None),
+    for bf16 row-major g [R,M], x [R,N] (row strides may exceed the width: column slices are fine).
+    `db`: an existing zero-initialised f32 [M] to accumulate the bias gradient into."""
+    _require_cuda(g)
+    R, M = g.shape
+    N = x.shape[1]
+    assert g.dtype == torch.bfloat16 and x.dtype == torch.bfloat16 and g.stride(1) == 1 and x.stride(1) == 1
+    dw = zeros_f32((M, N), g.device)
+    if db is None and with_bias:
+        db = zeros_f32((M,), g.device)
+    check(_lib.lib().mobgt_linear_wgrad(_p(g), g.stride(0), _p(x), x.stride(0), _p(dw), N, _p(db), R, M, N, _DT[g.dtype],
+                                        _stream()), "mobgt_linear_wgrad")
+    return dw, db
+
+
 def colsum(g):
     """Column sums of a 2-D f32/bf16 tensor as f32 [C] (bias gradient of a Linear / GraphConvolution)."""
     _require_cuda(g)

@@ -103,3 +103,24 @@ def test_fused_layer_dropout_statistics():
     err = (outs.mean(0) - ref).abs().mean().item()
     spread = (outs[0] - ref).abs().mean().item()
     assert err < 0.35 * spread
+
+
+@pytest.mark.parametrize("R,M,N", [(2432, 192, 192), (2432, 576, 192), (37, 6, 10), (1, 64, 64), (12560, 256, 1024),
+                                   (100, 130, 66)])
+def test_linear_wgrad_matches_fp32_reference(R, M, N):
+    """dW = g^T x and db = g.sum(0) of the split-K MFMA kernel (csrc/wgrad.hip) against torch fp64 on the same
+    bf16-rounded operands: only fp32 accumulation-order error remains (atol 1e-3 * sqrt(R) * |g||x| scale)."""
+    from mobgt_amd import ops
+    gen = torch.Generator().manual_seed(R + M + N)
+    g = torch.randn(R, M, generator=gen).to(DEV).bfloat16()
+    x = torch.randn(R, N, generator=gen).to(DEV).bfloat16()
+    dw, db = ops.linear_wgrad(g, x, with_bias=True)
+    ref = g.double().t() @ x.double()
+    tol = 2e-5 * (R ** 0.5) * 4
+    np.testing.assert_allclose(dw.cpu().numpy(), ref.cpu().numpy(), rtol=1e-4, atol=tol)
+    np.testing.assert_allclose(db.cpu().numpy(), g.double().sum(0).cpu().numpy(), rtol=1e-4, atol=tol)
+    # column slices of a wider buffer (the fused QKV layout) and accumulation into an existing gradient
+    wide = torch.randn(R, 2 * M + 2, generator=gen).to(DEV).bfloat16()
+    gs = wide[:, 2:2 + M]
+    dw2, _ = ops.linear_wgrad(gs, x)
+    np.testing.assert_allclose(dw2.cpu().numpy(), (gs.double().t() @ x.double()).cpu().numpy(), rtol=1e-4, atol=tol)
