@@ -188,6 +188,17 @@ int mobgt_embed_gather_sum(const float* const* tables_host, const void* const* i
 int mobgt_embed_scatter_add(float* const* d_tables_host, const void* const* idx_host, const int64_t* skip_idx_host,
                             int n_tables, const float* dout, int64_t R, int C, int64_t ld_dout,
                             int idx_dtype, void* stream);
+/* Every row index the node-feature gathers of model_fqandtoyo.py:1259-1264 (POI / time-slot / category),
+ * :1287-1298 + :348-351 (positional rows 1..n) need, derived from the padded batch in one launch.
+ *   x [G,N] int64 POI ids (0 = pad) and time_normal [G,N] f32, both with element strides (g, n);
+ *   poi2cat [P+1] int64 (row 0 = pad).
+ * idx [6][G*N] int64 (-1 = "no row" in 0..3):
+ *   0: POI row  (rows_only ? the position g*N+n in a per-batch table : x-1)       1: (long)(time_normal*48)
+ *   2: poi2cat[x]-1      3: n+1 where n+1 <= number of real nodes of graph g      4: max(x-1, 0)      5: zeros
+ * real [G*N] f32: 1 for real nodes, 0 for padding. */
+int mobgt_node_index(const int64_t* x, int64_t xs_g, int64_t xs_n, const float* time_normal, int64_t ts_g,
+                     int64_t ts_n, const int64_t* poi2cat, int64_t* idx, float* real, int G, int N, int rows_only,
+                     void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Fused elementwise / normalisation pieces of EncoderLayer.forward between the library GEMMs

@@ -93,3 +93,54 @@ extern "C" int mobgt_embed_scatter_add(float* const* d_tables_host, const void* 
     else return MOBGT_EDTYPE;
     return (int)hipGetLastError();
 }
+
+// ---- index derivation for the node features ---------------------------------------------------------------
+namespace {
+
+struct NodeIndexParams {
+    const int64_t* x; int64_t xs_g, xs_n;           // POI ids [G,N] (0 = pad), element strides
+    const float* tn;  int64_t ts_g, ts_n;           // time_normal [G,N]
+    const int64_t* poi2cat;                          // [P+1]
+    int64_t* idx;                                    // [6][G*N]
+    float* real;                                     // [G*N]
+    int G, N, rows_only;
+};
+
+// one workgroup per graph: count the real nodes (the positional rows stop there), then write all six index
+// rows and the mask for its N positions
+__global__ __launch_bounds__(256) void node_index_kernel(const NodeIndexParams p) {
+    __shared__ int s_cnt[4];
+    const int g = blockIdx.x;
+    int cnt = 0;
+    for (int n = threadIdx.x; n < p.N; n += 256) cnt += p.x[g * p.xs_g + n * p.xs_n] != 0;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
+    if ((threadIdx.x & 63) == 0) s_cnt[threadIdx.x >> 6] = cnt;
+    __syncthreads();
+    cnt = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+    const int64_t GN = (int64_t)p.G * p.N;
+    for (int n = threadIdx.x; n < p.N; n += 256) {
+        const int64_t r = (int64_t)g * p.N + n;
+        const int64_t poi = p.x[g * p.xs_g + n * p.xs_n];
+        const bool real = poi != 0;
+        const int64_t slot = (int64_t)(p.tn[g * p.ts_g + n * p.ts_n] * 48.f);
+        p.idx[0 * GN + r] = real ? (p.rows_only ? r : poi - 1) : -1;
+        p.idx[1 * GN + r] = real ? slot : -1;
+        p.idx[2 * GN + r] = real ? p.poi2cat[poi] - 1 : -1;
+        p.idx[3 * GN + r] = real && n + 1 <= cnt ? n + 1 : -1;
+        p.idx[4 * GN + r] = poi > 0 ? poi - 1 : 0;
+        p.idx[5 * GN + r] = 0;
+        p.real[r] = real ? 1.f : 0.f;
+    }
+}
+
+}  // namespace
+
+extern "C" int mobgt_node_index(const int64_t* x, int64_t xs_g, int64_t xs_n, const float* time_normal, int64_t ts_g,
+                                int64_t ts_n, const int64_t* poi2cat, int64_t* idx, float* real, int G, int N,
+                                int rows_only, void* stream) {
+    if (G <= 0 || N <= 0) return 0;
+    NodeIndexParams p = {x, xs_g, xs_n, time_normal, ts_g, ts_n, poi2cat, idx, real, G, N, rows_only};
+    hipLaunchKernelGGL(node_index_kernel, dim3(G), dim3(256), 0, (hipStream_t)stream, p);
+    return (int)hipGetLastError();
+}

@@ -25,6 +25,27 @@ def mm_tn_splitk(x, g, max_chunks=32):
     return torch.bmm(x.view(s, P // s, -1).transpose(1, 2), g.view(s, P // s, -1)).sum(0)
 
 
+_OUT_DTYPE = [None]
+
+
+def _mm_f32(a, b, bias=None):
+    """a @ b (+ bias) with an fp32 result for fp32 or bf16 operands: one GEMM launch, no cast / add kernels."""
+    if a.dtype == torch.float32:
+        return torch.addmm(bias, a, b) if bias is not None else a @ b
+    if _OUT_DTYPE[0] is None:
+        try:
+            torch.mm(a[:8, :8].contiguous(), b[:8, :8].contiguous(), out_dtype=torch.float32)
+            _OUT_DTYPE[0] = True
+        except Exception:
+            _OUT_DTYPE[0] = False
+    if _OUT_DTYPE[0]:
+        if bias is not None:
+            return torch.addmm(bias, a, b, out_dtype=torch.float32)
+        return torch.mm(a, b, out_dtype=torch.float32)
+    out = (a @ b).float()
+    return out + bias if bias is not None else out
+
+
 def _colsum(g):
     if g.is_cuda:
         from . import ops
@@ -38,9 +59,7 @@ class _GraphConvFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, adj):
         support = x @ weight
-        out = torch.mm(adj, support.to(adj.dtype)).float()
-        if bias is not None:
-            out = out + bias
+        out = _mm_f32(adj, support.to(adj.dtype), bias)             # bias in the GEMM epilogue, fp32 result
         ctx.save_for_backward(x, weight, adj)
         ctx.has_bias = bias is not None
         return out
@@ -48,7 +67,7 @@ class _GraphConvFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         x, weight, adj = ctx.saved_tensors
-        d_support = torch.mm(adj.t(), g.to(adj.dtype)).float()
+        d_support = _mm_f32(adj.t(), g.to(adj.dtype))
         dW = mm_tn_splitk(x, d_support)
         dx = d_support @ weight.t() if ctx.needs_input_grad[0] else None
         db = _colsum(g) if ctx.has_bias else None
@@ -60,9 +79,7 @@ class _PreAggConvFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, ax, weight, bias):
-        out = ax @ weight
-        if bias is not None:
-            out = out + bias
+        out = torch.addmm(bias, ax, weight) if bias is not None else ax @ weight
         ctx.save_for_backward(ax)
         ctx.has_bias = bias is not None
         return out

@@ -277,23 +277,19 @@ class Graphormer(nn.Module):
         """model_fqandtoyo.py:1222-1342 -> [G, N+1, C] (graph token first)."""
         x = batched_data.x[:, :, 0].long()                                    # [G,N] POI ids, 0 = pad
         G, N = x.shape
-        real = x != 0
         P = self.X.shape[0]
         rows_only = G * N * 2 <= P                      # the table is read at <= G*N rows (:1264): compute only those
+        # every gather index of :1259-1264 / :1287-1298 in one launch: POI row (in the compact per-batch table
+        # when rows_only: row p belongs to position p), time slot (:1262), category row (:1259), positional
+        # row 1..n (:348-351), GCN row, zeros
+        idx, real = ops.node_index(x, batched_data.time_normal[:, :, 0].float(), self.poi2cat, rows_only)
+        poi_idx, time_idx, cat_idx, pos_idx, gcn_rows, zero_idx = idx.unbind(0)
         if rows_only:
-            poidist = self.poi_distance_model(self.X, self.D_A, self.D_AX, rows=(x - 1).clamp(min=0).reshape(-1))
+            poidist = self.poi_distance_model(self.X, self.D_A, self.D_AX, rows=gcn_rows.reshape(-1))
         else:
             poidist = self.poi_distance_model(self.X, self.D_A, self.D_AX)        # :1236
         ops.trace_nan("poidist", poidist)
         catemb = self.poi_cat_model(self.C_X, self.C_A, self.C_AX)                                    # :1237
-        slot = (batched_data.time_normal[:, :, 0] * 48).long()                                 # :1262
-        neg = torch.full_like(x, -1)
-        if rows_only:                                   # row p of the compact table belongs to position p
-            poi_idx = torch.where(real, torch.arange(G * N, device=x.device).view(G, N), neg)
-        else:
-            poi_idx = torch.where(real, x - 1, neg)                                            # :1264
-        time_idx = torch.where(real, slot, neg)
-        cat_idx = torch.where(real, self.poi2cat[x] - 1, neg)                                  # :1259
         # [poi ; time] and the category row, gathered for every position in one pass each
         pt = ops.embed_gather_concat([poidist, self.time_embed_model_48.weight], [poi_idx, time_idx], padding_idx=[None, 0])
         f2 = self.embed_fuse_model2.leaky_relu(
@@ -303,13 +299,11 @@ class Graphormer(nn.Module):
         ce = ops.embed_gather_sum([catemb], [cat_idx])
         nf = self.embed_fuse_model4(f2, ce)                                                    # :1269
         ops.trace_nan("fuse4", nf)
-        nf = nf * real.unsqueeze(-1).to(nf.dtype)                                              # pads stay 0
+        nf = nf * real.unsqueeze(-1)                                                           # pads stay 0
         # + fre_embed(0) + degree rows + positional rows pe[1..n] (:1287-1298, :348-351)
-        pos = torch.arange(1, N + 1, device=x.device).unsqueeze(0).expand(G, N)
-        pos_idx = torch.where(real & (pos <= real.sum(1, keepdim=True)), pos, neg)
         add = ops.embed_gather_sum(
             [self.fre_embed_model.weight, self.in_degree_encoder.weight, self.out_degree_encoder.weight, self.pos_embed.pe],
-            [torch.zeros_like(x), batched_data.in_degree.long(), batched_data.out_degree.long(), pos_idx],
+            [zero_idx, batched_data.in_degree.long(), batched_data.out_degree.long(), pos_idx],
             padding_idx=[0, 0, 0, None])
         nf = ops.dropout(nf.float() + add, self.pos_embed.dropout.p, self.training, 0x1001)        # :358
         tok = self.graph_token.weight.unsqueeze(0).repeat(G, 1, 1) + self.pos_embed.pe[0]      # :1338-1342

@@ -349,6 +349,21 @@ class _GatherSumFn(torch.autograd.Function):
         return (None, None, *grads, *([None] * n))
 
 
+def node_index(x, time_normal, poi2cat, rows_only):
+    """Row indices of the node-feature gathers (model_fqandtoyo.py:1259-1264, 1287-1298) in one launch.
+    x [G,N] int64 POI ids, time_normal [G,N] f32 -> (idx [6,G,N] int64, real [G,N] f32); rows of idx:
+    POI row, time slot, category row, positional row (all -1 where there is none), GCN row max(x-1,0), zeros."""
+    _require_cuda(x, time_normal, poi2cat)
+    assert x.dtype == torch.int64 and time_normal.dtype == torch.float32 and poi2cat.dtype == torch.int64
+    G, N = x.shape
+    idx = torch.empty(6, G, N, dtype=torch.int64, device=x.device)
+    real = torch.empty(G, N, dtype=torch.float32, device=x.device)
+    check(_lib.lib().mobgt_node_index(_p(x), x.stride(0), x.stride(1), _p(time_normal), time_normal.stride(0),
+                                      time_normal.stride(1), _p(poi2cat), _p(idx), _p(real), G, N, int(bool(rows_only)),
+                                      _stream()), "mobgt_node_index")
+    return idx, real
+
+
 def embed_gather_sum(tables, indices, padding_idx=None):
     """sum_t tables[t][indices[t]] -> [*indices[0].shape, C].  f32 tables of equal width; indices share
     dtype and shape; negative index = no contribution.  `padding_idx[t]` rows get no gradient."""
