@@ -71,18 +71,24 @@ int mobgt_attn_bias_fwd(const void* q, const void* k, const void* v, const void*
  *          produced by mobgt_build_bias / mobgt_bias_pack; read by the dK/dV pass.
  * dout   : [G, T, H*d] (ldo), gradient of `out`.
  * dq,dk,dv : [G, T, H*d] `io_dtype`, row strides lddq/lddk/lddv; fully overwritten.
- * dbias  : [G, H, T, ld_bias] f32 or NULL.  accumulate_dbias != 0: dbias += dS (the bias is shared by
- *          all L layers, model.py:207-208); == 0: dbias = dS.  Columns >= T are left untouched.
+ * dbias  : [G, H, T, ld_bias] or NULL; columns >= T are left untouched.  The bias is shared by all L layers
+ *          (model.py:207-208), so its gradient is a sum over layers; two ways to form it:
+ *          dbias_dtype MOBGT_F32 : one f32 buffer; accumulate_dbias != 0: dbias += dS (read-modify-write),
+ *                                  == 0: dbias = dS;
+ *          dbias_dtype MOBGT_BF16: this layer's own bf16 slice, written once (dbias = dS; accumulate_dbias
+ *                                  ignored); mobgt_build_bias_bwd sums the L slices.  A quarter of the f32
+ *                                  path's HBM traffic per layer; dS is rounded to bf16 exactly as it is for
+ *                                  the dQ / dK contractions.
  * delta  : [G, H, T] f32 workspace (rowsum(dout*out)), written by the first pass.
  */
 int mobgt_attn_bias_bwd(const void* q, const void* k, const void* v, const void* bias, const void* bias_t,
                         const void* out, const float* lse, const void* dout,
-                        void* dq, void* dk, void* dv, float* dbias, float* delta,
+                        void* dq, void* dk, void* dv, void* dbias, float* delta,
                         int G, int H, int T, int d,
                         int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo,
                         int64_t lddq, int64_t lddk, int64_t lddv, int64_t ld_bias,
                         float scale, float dropout_p, uint64_t seed, const uint64_t* seed_dev,
-                        int accumulate_dbias, int io_dtype, int bias_dtype, void* stream);
+                        int accumulate_dbias, int dbias_dtype, int io_dtype, int bias_dtype, void* stream);
 
 /* Host-side statement of the dropout keep rule used by both kernels (for tests / replay).
  * Returns 1 if probability element (g,h,i,j) is kept. */
@@ -120,12 +126,16 @@ int mobgt_build_bias(const float* attn_bias, const void* rel_pos, const void* po
                      int G, int N, int H, int D_in, int D, int F, int n_rel, int n_poi, int n_edge,
                      int64_t ld_bias, int idx_dtype, int edge_dtype, int bias_dtype, void* stream);
 
-/* Backward of mobgt_build_bias: scatters dbias [G,H,T,ld_bias] f32 (sum over layers) into the table
- * gradients (all f32, ACCUMULATED into -- zero them first):
+/* Backward of mobgt_build_bias: scatters the bias gradient (sum over layers) into the table gradients
+ * (all f32, ACCUMULATED into -- zero them first):
  *   d_rel_table [n_rel,H], d_poi_table [n_poi,H] (or NULL), d_hop_table [D,n_edge,H], d_vdist [H].
+ * dbias: dbias_dtype MOBGT_F32: one [G,H,T,ld_bias] f32 buffer already summed over layers (n_slices ignored);
+ *        MOBGT_BF16: n_slices bf16 buffers of that shape, slice_stride ELEMENTS apart (one per layer, as written
+ *        by mobgt_attn_bias_bwd), summed here in f32.
  * Entries where attn_bias is -inf carry no gradient and are skipped.
  */
-int mobgt_build_bias_bwd(const float* dbias, const float* attn_bias, const void* rel_pos, const void* poi_pos,
+int mobgt_build_bias_bwd(const void* dbias, int dbias_dtype, int n_slices, int64_t slice_stride,
+                         const float* attn_bias, const void* rel_pos, const void* poi_pos,
                          const void* edge_input,
                          float* d_rel_table, float* d_poi_table, float* d_hop_table, float* d_vdist,
                          int G, int N, int H, int D_in, int D, int F, int n_rel, int n_poi, int n_edge,

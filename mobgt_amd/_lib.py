@@ -23,11 +23,11 @@ SIGNATURES = {
     "mobgt_build_info": (_c.c_char_p, []),
     "mobgt_attn_bias_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i64, _i64, _i64, _i64, _i64,
                                  _f, _f, _u64, _vp, _i, _i, _vp]),
-    "mobgt_attn_bias_bwd": (_i, [_vp] * 13 + [_i, _i, _i, _i] + [_i64] * 8 + [_f, _f, _u64, _vp, _i, _i, _i, _vp]),
+    "mobgt_attn_bias_bwd": (_i, [_vp] * 13 + [_i, _i, _i, _i] + [_i64] * 8 + [_f, _f, _u64, _vp, _i, _i, _i, _i, _vp]),
     "mobgt_dropout_keep_host": (_i, [_u64, _i, _i, _i, _i, _i, _i, _f]),
     "mobgt_bias_pack": (_i, [_vp, _i, _i64, _i64, _i64, _i64, _vp, _vp, _i, _i, _i, _i, _i64, _vp]),
     "mobgt_build_bias": (_i, [_vp] * 10 + [_i] * 9 + [_i64, _i, _i, _i, _vp]),
-    "mobgt_build_bias_bwd": (_i, [_vp] * 9 + [_i] * 9 + [_i64, _i, _i, _vp]),
+    "mobgt_build_bias_bwd": (_i, [_vp, _i, _i, _i64] + [_vp] * 8 + [_i] * 9 + [_i64, _i, _i, _vp]),
     "mobgt_spd_workspace_bytes": (_i64, [_i, _i]),
     "mobgt_spd_batched": (_i, [_vp] * 9 + [_i, _i, _i, _vp]),
     "mobgt_floyd_warshall_workspace_bytes": (_i64, [_i]),

@@ -27,7 +27,9 @@ struct AttnParams {
     void *o, *dq, *dk, *dv;
     float* lse;
     const float* lse_in;
-    float *dbias, *delta;
+    void* dbias;              // f32 (read-modify-write when `accumulate`) or bf16 (write-only slice of this layer)
+    int dbias_bf16;
+    float* delta;
     int G, H, T;
     int64_t ldq, ldk, ldv, ldo, lddq, lddk, lddv, ld_bias;
     float scale, inv_keep;
@@ -234,7 +236,9 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(const AttnParams p
     const TQ* O = reinterpret_cast<const TQ*>(p.out) + (int64_t)g * T * p.ldo + h * D;
     const TQ* dO = reinterpret_cast<const TQ*>(p.dout) + (int64_t)g * T * p.ldo + h * D;
     const TB* brow = reinterpret_cast<const TB*>(p.bias) + ((int64_t)gh * T + qc) * p.ld_bias + 16 * hi;
-    float* dbrow = p.dbias ? p.dbias + ((int64_t)gh * T + qc) * p.ld_bias + 16 * hi : nullptr;
+    const int64_t dboff = ((int64_t)gh * T + qc) * p.ld_bias + 16 * hi;
+    float* dbrow = p.dbias && !p.dbias_bf16 ? reinterpret_cast<float*>(p.dbias) + dboff : nullptr;
+    bf16_t* dbrow16 = p.dbias && p.dbias_bf16 ? reinterpret_cast<bf16_t*>(p.dbias) + dboff : nullptr;
 
     bf16x8 qf[KS], dof[KS];
     float dpart = 0.f;
@@ -330,6 +334,17 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(const AttnParams p
 #pragma unroll
                 for (int j = 0; j < 8; ++j) dv8[j] = ds[8 * s2 + j];
                 const bf16x8 db = pack8(dv8);
+                // bf16 dBias: the very values the dQ / dK contractions use, written once (no read-modify-write;
+                // the layers' slices are summed by the consumer)
+                if (dbrow16 && q_ok) {
+                    bf16_t* dst = dbrow16 + key0 + 8 * s2;
+                    if (!tail) *reinterpret_cast<bf16x8*>(dst) = db;
+                    else {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j)
+                            if (key0 + 16 * hi + 8 * s2 + j < T) dst[j] = db[j];
+                    }
+                }
                 const bf16x8 a = *reinterpret_cast<const bf16x8*>(&Kt[kappa(n)][t * 32 + 16 * hi + 8 * s2]);
                 dq = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, db, dq, 0, 0, 0);
             }
@@ -566,10 +581,10 @@ extern "C" int mobgt_attn_bias_fwd(const void* q, const void* k, const void* v, 
 
 extern "C" int mobgt_attn_bias_bwd(const void* q, const void* k, const void* v, const void* bias, const void* bias_t,
                                    const void* out, const float* lse, const void* dout, void* dq, void* dk, void* dv,
-                                   float* dbias, float* delta, int G, int H, int T, int d, int64_t ldq, int64_t ldk,
+                                   void* dbias, float* delta, int G, int H, int T, int d, int64_t ldq, int64_t ldk,
                                    int64_t ldv, int64_t ldo, int64_t lddq, int64_t lddk, int64_t lddv, int64_t ld_bias,
                                    float scale, float dropout_p, uint64_t seed, const uint64_t* seed_dev,
-                                   int accumulate_dbias, int io_dtype, int bias_dtype, void* stream) {
+                                   int accumulate_dbias, int dbias_dtype, int io_dtype, int bias_dtype, void* stream) {
     int rc = check_common(G, H, T, d, ld_bias, io_dtype, 8);
     if (rc) return rc;
     if (!aligned16(q) || !aligned16(k) || !aligned16(v) || !aligned16(out) || !aligned16(dout) || !aligned16(bias) ||
@@ -584,6 +599,8 @@ extern "C" int mobgt_attn_bias_bwd(const void* q, const void* k, const void* v, 
     p.ld_bias = ld_bias;
     p.scale = scale;
     p.accumulate = accumulate_dbias;
+    if (dbias_dtype != MOBGT_F32 && dbias_dtype != MOBGT_BF16) return MOBGT_EDTYPE;
+    p.dbias_bf16 = dbias_dtype == MOBGT_BF16;
     set_dropout(p, dropout_p, seed, seed_dev);
     const bool drop = p.drop_thr != 0;
     rc = launch<BWD_DQ>(p, d, io_dtype, bias_dtype, drop, (hipStream_t)stream);

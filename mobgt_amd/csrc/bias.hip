@@ -61,7 +61,9 @@ struct BuildParams {
     const void *rel_pos, *poi_pos, *edge_input;
     const float *rel_table, *poi_table, *hop_table, *vdist;
     void *bias, *bias_t;
-    const float* dbias;
+    const void* dbias;            // f32, or n_slices bf16 slices (one per layer) `slice_stride` elements apart
+    int dbias_bf16, n_slices;
+    int64_t slice_stride;
     float *d_rel, *d_poi, *d_hop, *d_vdist;
     int G, N, H, D_in, D, F, n_rel, n_poi, n_edge;
     int64_t ld;
@@ -239,7 +241,19 @@ __global__ __launch_bounds__(256) void build_bias_bwd_kernel(const BuildParams p
         if (live) live = p.attn_bias[((int64_t)g * T + ti) * T + tj] != -INFINITY;   // -inf: probability 0, no gradient
         float gr[HH];
 #pragma unroll
-        for (int h = 0; h < HH; ++h) gr[h] = live ? p.dbias[(((int64_t)g * HH + h) * T + ti) * p.ld + tj] : 0.f;
+        for (int h = 0; h < HH; ++h) {
+            const int64_t at = (((int64_t)g * HH + h) * T + ti) * p.ld + tj;
+            float v = 0.f;
+            if (live) {
+                if (p.dbias_bf16) {
+                    const bf16_t* src = reinterpret_cast<const bf16_t*>(p.dbias) + at;
+                    for (int l = 0; l < p.n_slices; ++l) v += (float)src[l * p.slice_stride];
+                } else {
+                    v = reinterpret_cast<const float*>(p.dbias)[at];
+                }
+            }
+            gr[h] = v;
+        }
         // virtual-token column
         wave_scatter_add<HH>(s_vd, 1, s_vd, (live && tj == 0) ? 0 : -1, gr, lane);
         const bool pairlive = live && tj >= 1;
@@ -395,13 +409,16 @@ extern "C" int mobgt_build_bias(const float* attn_bias, const void* rel_pos, con
     DISPATCH_IDX(launch_build_b, p, bias_dtype, st);
 }
 
-extern "C" int mobgt_build_bias_bwd(const float* dbias, const float* attn_bias, const void* rel_pos, const void* poi_pos,
+extern "C" int mobgt_build_bias_bwd(const void* dbias, int dbias_dtype, int n_slices, int64_t slice_stride,
+                                    const float* attn_bias, const void* rel_pos, const void* poi_pos,
                                     const void* edge_input, float* d_rel_table, float* d_poi_table, float* d_hop_table,
                                     float* d_vdist, int G, int N, int H, int D_in, int D, int F, int n_rel, int n_poi,
                                     int n_edge, int64_t ld_bias, int idx_dtype, int edge_dtype, void* stream) {
-    if (G <= 0 || N <= 0 || H > MAXH || D < 0 || D > D_in || F <= 0) return MOBGT_EBADDIM;
+    if (G <= 0 || N <= 0 || H > MAXH || D < 0 || D > D_in || F <= 0 || n_slices < 1) return MOBGT_EBADDIM;
+    if (dbias_dtype != MOBGT_F32 && dbias_dtype != MOBGT_BF16) return MOBGT_EDTYPE;
     BuildParams p = {};
-    p.dbias = dbias; p.attn_bias = attn_bias; p.rel_pos = rel_pos; p.poi_pos = poi_pos;
+    p.dbias = dbias; p.dbias_bf16 = dbias_dtype == MOBGT_BF16; p.n_slices = p.dbias_bf16 ? n_slices : 1;
+    p.slice_stride = slice_stride; p.attn_bias = attn_bias; p.rel_pos = rel_pos; p.poi_pos = poi_pos;
     p.edge_input = D > 0 ? edge_input : nullptr;
     p.d_rel = d_rel_table; p.d_poi = d_poi_table; p.d_hop = d_hop_table; p.d_vdist = d_vdist;
     p.G = G; p.N = N; p.H = H; p.D_in = D_in; p.D = D; p.F = F; p.n_rel = n_rel; p.n_poi = n_poi; p.n_edge = n_edge;

@@ -84,7 +84,8 @@ class PackedBias:
         self.bias = torch.empty(G, H, T, self.ld, dtype=dtype, device=device)
         self.bias_t = torch.empty(G, H, T, self.ld, dtype=dtype, device=device)
         self.dbias = None
-        self.n_bwd = 0
+        self.n_use = 0            # attention forward passes that will want a bias gradient (one per layer)
+        self.n_bwd = 0            # backward passes that have delivered theirs
         self.needs_grad = False
         self.token = None
 
@@ -92,11 +93,41 @@ class PackedBias:
         """[G,H,T,T] float32 copy (tests)."""
         return self.bias[..., : self.T].float()
 
+    @property
+    def sliced(self):
+        """bf16 bias: every layer writes its own bf16 dBias slice (write-only, a quarter of the HBM traffic of
+        the f32 read-modify-write accumulator) and the consumer sums them; f32 bias: one f32 accumulator."""
+        return self.dtype == torch.bfloat16
+
     def grad_buffer(self):
         if self.dbias is None:
             # columns >= T are never written by the kernels; keep them zero
-            self.dbias = torch.zeros(self.G, self.H, self.T, self.ld, dtype=torch.float32, device=self.bias.device)
+            shape = (self.G, self.H, self.T, self.ld)
+            if self.sliced:
+                # every element a consumer reads (columns < T) is written by the backward pass: no fill
+                self.dbias = torch.empty((max(self.n_use, 1),) + shape, dtype=torch.bfloat16, device=self.bias.device)
+            else:
+                self.dbias = torch.zeros(shape, dtype=torch.float32, device=self.bias.device)
         return self.dbias
+
+    def next_grad_slice(self):
+        """(buffer for this backward pass, accumulate flag)."""
+        buf = self.grad_buffer()
+        i = self.n_bwd
+        self.n_bwd += 1
+        if not self.sliced:
+            return buf, 1 if i > 0 else 0
+        if i >= buf.shape[0]:
+            raise RuntimeError("PackedBias: more attention backward passes than forward uses of this bias")
+        return buf[i], 0
+
+    def grad_total(self):
+        """Sum over layers as f32 [G,H,T,T] (tests, caller-supplied-bias gradient)."""
+        if self.dbias is None:
+            return None
+        if self.sliced:
+            return self.dbias[: max(self.n_bwd, 1), ..., : self.T].float().sum(0)
+        return self.dbias[..., : self.T]
 
 
 # ------------------------------------------------------------------------------------- bias pack
@@ -118,7 +149,7 @@ class _PackFn(torch.autograd.Function):
         pack = ctx.pack
         if pack.dbias is None:
             return torch.zeros(ctx.src_shape, dtype=ctx.src_dtype, device=pack.bias.device), None
-        g = pack.dbias[..., : pack.T]
+        g = pack.grad_total()
         if tuple(ctx.src_shape) != tuple(g.shape):          # broadcast source: reduce
             g = g.sum_to_size(ctx.src_shape)
         return g.to(ctx.src_dtype), None
@@ -173,7 +204,10 @@ class _BuildBiasFn(torch.autograd.Function):
         if pack.dbias is not None:
             attn_bias, rel_pos, poi_pos, edge_input = ctx.idx
             a = ctx.args
-            check(_lib.lib().mobgt_build_bias_bwd(_p(pack.dbias), _p(attn_bias), _p(rel_pos), _p(poi_pos), _p(edge_input),
+            n_sl = max(pack.n_bwd, 1) if pack.sliced else 1
+            stride = pack.dbias.stride(0) if pack.sliced else 0
+            check(_lib.lib().mobgt_build_bias_bwd(_p(pack.dbias), _DT[pack.dbias.dtype], n_sl, stride,
+                                                  _p(attn_bias), _p(rel_pos), _p(poi_pos), _p(edge_input),
                                                   _p(d_rel), _p(d_poi), _p(d_hop), _p(d_vd), *a, _stream()),
                   "mobgt_build_bias_bwd")
         return d_rel, d_poi, d_hop, d_vd, None, None, None, None, None, None
@@ -208,6 +242,8 @@ def _attn_fwd(q, k, v, pack, scale, p_drop, seed, seed_dev):
     out = torch.empty(G, T, C, dtype=q.dtype, device=q.device)
     lse = torch.empty(G, H, T, dtype=torch.float32, device=q.device)
     _check_rows(q, k, v)
+    if pack.needs_grad:
+        pack.n_use += 1
     check(_lib.lib().mobgt_attn_bias_fwd(_p(q), _p(k), _p(v), _p(pack.bias), _p(out), _p(lse), G, H, T, C // H,
                                          q.stride(1), k.stride(1), v.stride(1), C, pack.ld, scale, p_drop, seed,
                                          _p(seed_dev), _DT[q.dtype], _DT[pack.dtype], _stream()), "mobgt_attn_bias_fwd")
@@ -220,15 +256,14 @@ def _attn_bwd(q, k, v, out, lse, dout, dq, dk, dv, pack, scale, p_drop, seed, se
     dbias = None
     acc = 0
     if pack.needs_grad:
-        dbias = pack.grad_buffer()
-        acc = 1 if pack.n_bwd > 0 else 0
-        pack.n_bwd += 1
+        dbias, acc = pack.next_grad_slice()
     delta = torch.empty(G, H, T, dtype=torch.float32, device=q.device)
     check(_lib.lib().mobgt_attn_bias_bwd(_p(q), _p(k), _p(v), _p(pack.bias), _p(pack.bias_t), _p(out), _p(lse), _p(dout),
                                          _p(dq), _p(dk), _p(dv), _p(dbias), _p(delta), G, H, T, C // H,
                                          q.stride(1), k.stride(1), v.stride(1), C, dq.stride(1), dk.stride(1),
                                          dv.stride(1), pack.ld, scale, p_drop, seed, _p(seed_dev), acc,
-                                         _DT[q.dtype], _DT[pack.dtype], _stream()), "mobgt_attn_bias_bwd")
+                                         _DT[dbias.dtype] if dbias is not None else F32, _DT[q.dtype], _DT[pack.dtype],
+                                         _stream()), "mobgt_attn_bias_bwd")
 
 
 class _AttnFn(torch.autograd.Function):

@@ -255,6 +255,43 @@ def test_build_bias_fwd_bwd(golden_dir, variant, tag, narrow):
         np.testing.assert_allclose(gotg.numpy(), want.numpy(), rtol=2e-3, atol=2e-3 if fp16_path else 2e-5, err_msg=kname)
 
 
+def test_build_bias_bwd_sums_bf16_layer_slices(golden_dir):
+    """bf16 bias: each layer leaves its own bf16 dBias slice and mobgt_build_bias_bwd sums them in f32.  Same
+    table gradients as the f32 accumulator holding the sum of those (bf16-rounded) slices."""
+    from mobgt_amd.model import hop_table_from, no_grad_row0
+    z = np.load(os.path.join(golden_dir, "g5_bias.npz"))
+    b = _g5_batch(z, "fsq/batch/", ["attn_bias", "rel_pos", "edge_input", "poi_pos"])
+    H, D, L = 8, 20, 3
+    sd = {"rel_pos_encoder.weight": _seeded((512, H), 1), "edge_encoder.weight": _seeded((128, H), 2),
+          "edge_dis_encoder.weight": _seeded((128 * H * H, 1), 3), "graph_token_virtual_distance.weight": _seeded((1, H), 4),
+          "poi_pos_encoder.weight": _seeded((int(z["fsq/num_bins"]), H), 5)}
+    G, N = b.rel_pos.shape[:2]
+    T = N + 1
+    slices = (torch.randn(L, G, H, T, T, generator=torch.Generator().manual_seed(11)) * 0.1).bfloat16()
+    Dk = min(D, b.edge_input.shape[3])
+    grads = {}
+    for dtype in (torch.float32, torch.bfloat16):
+        dsd = {k: v.detach().clone().to(DEV).requires_grad_(True) for k, v in sd.items()}
+        hop = hop_table_from(dsd["edge_encoder.weight"], dsd["edge_dis_encoder.weight"], H, Dk, fp16_roundtrip=True)
+        pack = ops.build_bias(b.attn_bias.to(DEV), b.rel_pos.to(DEV), b.poi_pos.to(DEV), b.edge_input.to(DEV),
+                              no_grad_row0(dsd["rel_pos_encoder.weight"]), no_grad_row0(dsd["poi_pos_encoder.weight"]), hop,
+                              dsd["graph_token_virtual_distance.weight"], Dk, dtype=dtype)
+        pack.needs_grad = True
+        if dtype == torch.float32:
+            pack.grad_buffer()[..., :T] = slices.float().sum(0).to(DEV)
+        else:
+            pack.n_use = L
+            pack.grad_buffer()[..., :T] = slices.to(DEV)
+            pack.n_bwd = L
+            assert pack.dbias.shape[0] == L and pack.dbias.dtype == torch.bfloat16
+        pack.token.backward()
+        grads[dtype] = {k: v.grad.cpu() for k, v in dsd.items() if v.grad is not None}
+    assert set(grads[torch.float32]) == set(grads[torch.bfloat16]) and len(grads[torch.float32]) == 5
+    for k in grads[torch.float32]:
+        np.testing.assert_allclose(grads[torch.bfloat16][k].numpy(), grads[torch.float32][k].numpy(), rtol=1e-4, atol=1e-5,
+                                   err_msg=k)
+
+
 # ------------------------------------------------------------------------------------------------ spd
 def _spd_case(counts_list, D=20):
     G = len(counts_list)

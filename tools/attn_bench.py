@@ -20,10 +20,12 @@ def run_bwd(G, H, T, d, dt=torch.bfloat16, reps=10):
     out, lse = ops._attn_fwd(q, k, v, pack, d ** -0.5, 0.0, 1, None)
     dq, dk, dv = (torch.empty_like(q) for _ in range(3))
     for _ in range(3):
+        pack.n_bwd = 0
         ops._attn_bwd(q, k, v, out, lse, do, dq, dk, dv, pack, d ** -0.5, 0.0, 1, None)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize(); e0.record()
     for _ in range(reps):
+        pack.n_bwd = 0
         ops._attn_bwd(q, k, v, out, lse, do, dq, dk, dv, pack, d ** -0.5, 0.0, 1, None)
     e1.record(); torch.cuda.synchronize()
     t = e0.elapsed_time(e1) / 1e3 / reps
