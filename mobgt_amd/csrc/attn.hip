@@ -39,23 +39,53 @@ struct AttnParams {
     int accumulate;
 };
 
-// Stage a [KC x D] row-major slab (rows row0.., row stride ld, head column offset already applied)
-// into LDS as bf16: row-major into `rm` (if RM) and transposed into `tr` (if TR).  Rows >= T and
-// columns >= D are zero-filled; `mul` scales the values (1 or the softmax scale).
-template <int D, typename TQ, int NT, bool RM, bool TR>
-__device__ __forceinline__ void stage_slab(const TQ* __restrict__ src, int64_t ld, int row0, int T, float mul,
-                                           bf16_t (*rm)[ROWP], bf16_t (*tr)[COLP]) {
-    for (int it = threadIdx.x; it < KC * 4; it += NT) {
-        const int r = it >> 2, c0 = (it & 3) * 8;
-        float v[8];
-        if (c0 < D && row0 + r < T) {
-            load8(src + (int64_t)(row0 + r) * ld + c0, v);
+// Staging of a [KC x D] row-major slab (rows row0.., row stride ld, head column offset already applied) into
+// LDS as bf16, split in two halves so that the global loads of chunk c+1 are IN FLIGHT while chunk c is being
+// computed: `load` pulls the slab into registers (KC*4/NT pieces of 8 elements per thread; rows >= T and
+// columns >= D read as zero), `store` -- one chunk later -- scales by `mul`, rounds to bf16 and writes the
+// row-major image `rm` (if RM) and/or the transposed image `tr` (if TR).  A kernel's time here is the serial
+// chain of its chunks (3-4 co-resident workgroups per CU never saturate anything), so taking two L2 round
+// trips out of every chunk matters more than any instruction count.
+template <typename TQ> struct Raw8;
+template <> struct Raw8<bf16_t> {
+    uint4 r;
+    __device__ __forceinline__ void load(const bf16_t* p) { r = *reinterpret_cast<const uint4*>(p); }
+    __device__ __forceinline__ void zero() { r = make_uint4(0u, 0u, 0u, 0u); }
+    __device__ __forceinline__ void get(float (&v)[8]) const {
+        v[0] = bf16_lo(r.x); v[1] = bf16_hi(r.x); v[2] = bf16_lo(r.y); v[3] = bf16_hi(r.y);
+        v[4] = bf16_lo(r.z); v[5] = bf16_hi(r.z); v[6] = bf16_lo(r.w); v[7] = bf16_hi(r.w);
+    }
+};
+template <> struct Raw8<float> {
+    float4 a, b;
+    __device__ __forceinline__ void load(const float* p) {
+        a = *reinterpret_cast<const float4*>(p); b = *reinterpret_cast<const float4*>(p + 4);
+    }
+    __device__ __forceinline__ void zero() { a = make_float4(0.f, 0.f, 0.f, 0.f); b = make_float4(0.f, 0.f, 0.f, 0.f); }
+    __device__ __forceinline__ void get(float (&v)[8]) const {
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+    }
+};
+
+template <int D, typename TQ, int NT>
+struct Slab {
+    static constexpr int ITEMS = KC * 4 / NT;
+    Raw8<TQ> it[ITEMS];
+    __device__ __forceinline__ void load(const TQ* __restrict__ src, int64_t ld, int row0, int T) {
 #pragma unroll
-            for (int i = 0; i < 8; ++i) v[i] *= mul;
-        } else {
-#pragma unroll
-            for (int i = 0; i < 8; ++i) v[i] = 0.f;
+        for (int k = 0; k < ITEMS; ++k) {
+            const int e = threadIdx.x + k * NT, r = e >> 2, c0 = (e & 3) * 8;
+            if (c0 < D && row0 + r < T) it[k].load(src + (int64_t)(row0 + r) * ld + c0);
+            else it[k].zero();
         }
+    }
+    template <bool RM, bool TR>
+    static __device__ __forceinline__ void put(const Raw8<TQ>& x, int e, float mul, bf16_t (*rm)[ROWP], bf16_t (*tr)[COLP]) {
+        const int r = e >> 2, c0 = (e & 3) * 8;
+        float v[8];
+        x.get(v);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] *= mul;
         const bf16x8 b = pack8(v);
         if (RM) *reinterpret_cast<bf16x8*>(&rm[r][c0]) = b;
         if (TR) {
@@ -63,7 +93,24 @@ __device__ __forceinline__ void stage_slab(const TQ* __restrict__ src, int64_t l
             for (int i = 0; i < 8; ++i) tr[c0 + i][r] = b[i];
         }
     }
-}
+    template <bool RM, bool TR>
+    __device__ __forceinline__ void store(float mul, bf16_t (*rm)[ROWP], bf16_t (*tr)[COLP]) const {
+#pragma unroll
+        for (int k = 0; k < ITEMS; ++k) put<RM, TR>(it[k], threadIdx.x + k * NT, mul, rm, tr);
+    }
+    // load + store of one chunk, piece by piece (the single-chunk kernels of graphs with T <= 64: nothing to overlap)
+    template <bool RM, bool TR>
+    static __device__ __forceinline__ void direct(const TQ* __restrict__ src, int64_t ld, int row0, int T, float mul,
+                                                  bf16_t (*rm)[ROWP], bf16_t (*tr)[COLP]) {
+        for (int e = threadIdx.x; e < KC * 4; e += NT) {
+            const int r = e >> 2, c0 = (e & 3) * 8;
+            Raw8<TQ> x;
+            if (c0 < D && row0 + r < T) x.load(src + (int64_t)(row0 + r) * ld + c0);
+            else x.zero();
+            put<RM, TR>(x, e, mul, rm, tr);
+        }
+    }
+};
 
 template <typename TQ>
 __device__ __forceinline__ void load_frag(const TQ* rowptr, bool valid, float mul, bf16x8& f, float (*keep)[8] = nullptr) {
@@ -126,22 +173,45 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const AttnParams p) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) o[i] = 0.f;
 
-    BiasRegs<TB> bcur, bnext;
-    bcur.load(brow);
+    // Bias prefetch ring: tile j's 16 elements per lane are requested PF = 4 tiles (128 keys) before they are
+    // used -- each wave keeps four 2 KB bias loads in flight.  One tile ahead left ~2 KB x 20 waves per CU in
+    // flight at best, which at ~2 us loaded latency is ~2.5 TB/s chip-wide: the kernel was latency-bound.
+    constexpr bool PIPE = NW == 4;                     // NW < 4 is launched for T <= 64 only: one chunk, two tiles
+    constexpr int RING = PIPE ? 4 : 2;
+    BiasRegs<TB> ring[RING];
+#pragma unroll
+    for (int j = 0; j < RING; ++j)
+        if (j * 32 < T) ring[j].load(brow + j * 32);
 
     const int nchunk = (T + KC - 1) / KC;
-    for (int c = 0; c < nchunk; ++c) {
+    Slab<D, TQ, PIPE ? NT : KC * 4> kreg, vreg;        // (one dummy piece when not pipelined)
+    if (PIPE) {
+        kreg.load(K, p.ldk, 0, T);
+        vreg.load(V, p.ldv, 0, T);
+    }
+
+    auto chunk = [&](const int c, BiasRegs<TB>& b0, BiasRegs<TB>& b1) {
+        __syncthreads();                                   // the previous chunk's LDS readers are done
+        if (PIPE) {
+            kreg.template store<true, false>(1.f, Ks, nullptr);
+            vreg.template store<false, true>(1.f, nullptr, Vt);
+        } else {
+            Slab<D, TQ, NT>::template direct<true, false>(K, p.ldk, c * KC, T, 1.f, Ks, nullptr);
+            Slab<D, TQ, NT>::template direct<false, true>(V, p.ldv, c * KC, T, 1.f, nullptr, Vt);
+        }
         __syncthreads();
-        stage_slab<D, TQ, NT, true, false>(K, p.ldk, c * KC, T, 1.f, Ks, nullptr);
-        stage_slab<D, TQ, NT, false, true>(V, p.ldv, c * KC, T, 1.f, nullptr, Vt);
-        __syncthreads();
+        if (PIPE && c + 1 < nchunk) {                      // next chunk's K / V: in flight during this chunk's MFMAs
+            kreg.load(K, p.ldk, (c + 1) * KC, T);
+            vreg.load(V, p.ldv, (c + 1) * KC, T);
+        }
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             const int key0 = c * KC + t * 32;
             if (key0 >= T) break;
+            BiasRegs<TB>& bt = t == 0 ? b0 : b1;
             f32x16 s;
-            bcur.to_acc(s);
-            if (key0 + 32 < T) bnext.load(brow + key0 + 32);       // prefetch the next bias tile
+            bt.to_acc(s);
+            if (PIPE && key0 + 128 < T) bt.load(brow + key0 + 128);        // refill this ring slot: 4 tiles ahead
             if (key0 + 32 > T) {
 #pragma unroll
                 for (int i = 0; i < 16; ++i)
@@ -176,7 +246,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const AttnParams p) {
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
                     const uint32_t bits = dropout_bits16(seed, rowh, (uint32_t)(key0 + 16 * hi + i));
-                    pr[i] = bits >= p.drop_thr ? pr[i] * p.inv_keep : 0.f;
+                    pr[i] = bits >= p.drop_thr ? pr[i] : 0.f;              // 1/(1-p) is applied once, to the output row
                 }
             }
 #pragma unroll
@@ -188,12 +258,16 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const AttnParams p) {
                 const bf16x8 a = *reinterpret_cast<const bf16x8*>(&Vt[kappa(n)][t * 32 + 16 * hi + 8 * s2]);
                 o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, pb, o, 0, 0, 0);
             }
-            bcur = bnext;
         }
+    };
+
+    for (int c = 0; c < nchunk; c += 2) {
+        chunk(c, ring[0], ring[1]);
+        if (PIPE && c + 1 < nchunk) chunk(c + 1, ring[RING - 2], ring[RING - 1]);
     }
 
     const float ltot = l + xhalf(l);
-    const float inv = 1.f / ltot;
+    const float inv = (DROP ? p.inv_keep : 1.f) / ltot;
     if (q_ok) {
         TQ* O = reinterpret_cast<TQ*>(p.o) + ((int64_t)g * T + my_q) * p.ldo + h * D + 16 * hi;
 #pragma unroll
@@ -272,11 +346,26 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(const AttnParams p
     bcur.load(brow);
 
     const int nchunk = (T + KC - 1) / KC;
+    constexpr bool PIPE = NW == 4;
+    Slab<D, TQ, PIPE ? NT : KC * 4> kreg, vreg;
+    if (PIPE) {
+        kreg.load(K, p.ldk, 0, T);
+        vreg.load(V, p.ldv, 0, T);
+    }
     for (int c = 0; c < nchunk; ++c) {
         __syncthreads();
-        stage_slab<D, TQ, NT, true, true>(K, p.ldk, c * KC, T, 1.f, Ks, Kt);
-        stage_slab<D, TQ, NT, true, false>(V, p.ldv, c * KC, T, 1.f, Vs, nullptr);
+        if (PIPE) {
+            kreg.template store<true, true>(1.f, Ks, Kt);
+            vreg.template store<true, false>(1.f, Vs, nullptr);
+        } else {
+            Slab<D, TQ, NT>::template direct<true, true>(K, p.ldk, c * KC, T, 1.f, Ks, Kt);
+            Slab<D, TQ, NT>::template direct<true, false>(V, p.ldv, c * KC, T, 1.f, Vs, nullptr);
+        }
         __syncthreads();
+        if (PIPE && c + 1 < nchunk) {
+            kreg.load(K, p.ldk, (c + 1) * KC, T);
+            vreg.load(V, p.ldv, (c + 1) * KC, T);
+        }
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             const int key0 = c * KC + t * 32;
@@ -303,12 +392,12 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(const AttnParams p
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const float pr = fast_exp2(fmaf(s[i], MOBGT_LOG2E, -lse2));
-                float dpv = dp[i];
+                float dd = DROP ? fmaf(dp[i], p.inv_keep, -delta) : dp[i] - delta;
                 if (DROP) {
                     const uint32_t bits = dropout_bits16(seed, rowh, (uint32_t)(key0 + 16 * hi + i));
-                    dpv = bits >= p.drop_thr ? dpv * p.inv_keep : 0.f;
+                    dd = bits >= p.drop_thr ? dd : -delta;
                 }
-                ds[i] = pr * (dpv - delta);
+                ds[i] = pr * dd;
             }
             if (dbrow && q_ok) {
                 float* dst = dbrow + key0;
@@ -379,6 +468,7 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_kernel(const AttnParams 
     __shared__ __attribute__((aligned(16))) bf16_t dOt[32][COLP];
     __shared__ __attribute__((aligned(16))) float lseS[KC];
     __shared__ __attribute__((aligned(16))) float dlS[KC];
+    __shared__ __attribute__((aligned(16))) uint32_t rowhS[DROP ? KC : 4];      // dropout row hashes of the chunk's queries
 
     const int T = p.T, H = p.H;
     const int nK = (T + 32 * NW - 1) / (32 * NW);
@@ -415,16 +505,43 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_kernel(const AttnParams 
     bcur.load(brow);
 
     const int nchunk = (T + KC - 1) / KC;
+    constexpr bool PIPE = NW == 4;
+    Slab<D, TQ, PIPE ? NT : KC * 4> qreg, doreg;
+    if (PIPE) {
+        qreg.load(Q, p.ldq, 0, T);
+        doreg.load(dO, p.ldo, 0, T);
+    }
+    float lse_r = 0.f, dl_r = 0.f;                         // thread it < KC carries query it of the chunk (NT >= KC)
+    auto load_rowstats = [&](const int c) {
+        const int q = c * KC + (int)threadIdx.x;
+        const bool ok = threadIdx.x < KC && q < T;
+        lse_r = ok ? p.lse_in[(int64_t)gh * T + q] : 0.f;
+        dl_r = ok ? p.delta[(int64_t)gh * T + q] : 0.f;
+    };
+    load_rowstats(0);
     for (int c = 0; c < nchunk; ++c) {
         __syncthreads();
-        stage_slab<D, TQ, NT, true, true>(Q, p.ldq, c * KC, T, p.scale, Qs, Qt);
-        stage_slab<D, TQ, NT, true, true>(dO, p.ldo, c * KC, T, 1.f, dOs, dOt);
-        for (int it = threadIdx.x; it < KC; it += NT) {
-            const int q = c * KC + it;
-            lseS[it] = q < T ? p.lse_in[(int64_t)gh * T + q] * MOBGT_LOG2E : 0.f;
-            dlS[it] = q < T ? p.delta[(int64_t)gh * T + q] : 0.f;
+        if (PIPE) {
+            qreg.template store<true, true>(p.scale, Qs, Qt);
+            doreg.template store<true, true>(1.f, dOs, dOt);
+        } else {
+            Slab<D, TQ, NT>::template direct<true, true>(Q, p.ldq, c * KC, T, p.scale, Qs, Qt);
+            Slab<D, TQ, NT>::template direct<true, true>(dO, p.ldo, c * KC, T, 1.f, dOs, dOt);
+        }
+        if (threadIdx.x < KC) {
+            const int q = c * KC + (int)threadIdx.x;
+            lseS[threadIdx.x] = lse_r * MOBGT_LOG2E;
+            dlS[threadIdx.x] = dl_r;
+            if (DROP) rowhS[threadIdx.x] = dropout_row_hash(seed, (uint32_t)(gh * T + (q < T ? q : T - 1)));
         }
         __syncthreads();
+        if (c + 1 < nchunk) {
+            if (PIPE) {
+                qreg.load(Q, p.ldq, (c + 1) * KC, T);
+                doreg.load(dO, p.ldo, (c + 1) * KC, T);
+            }
+            load_rowstats(c + 1);
+        }
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             const int q0 = c * KC + t * 32;
@@ -449,22 +566,29 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_kernel(const AttnParams 
                 lse16[4 * j] = a.x; lse16[4 * j + 1] = a.y; lse16[4 * j + 2] = a.z; lse16[4 * j + 3] = a.w;
                 dl16[4 * j] = b.x; dl16[4 * j + 1] = b.y; dl16[4 * j + 2] = b.z; dl16[4 * j + 3] = b.w;
             }
+            uint32_t rh16[16];
+            if (DROP) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const uint4 a = *reinterpret_cast<const uint4*>(&rowhS[t * 32 + 16 * hi + 4 * j]);
+                    rh16[4 * j] = a.x; rh16[4 * j + 1] = a.y; rh16[4 * j + 2] = a.z; rh16[4 * j + 3] = a.w;
+                }
+            }
             float pd[16], ds[16];
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const int q = q0 + 16 * hi + i;
                 float pr = fast_exp2(fmaf(s[i], MOBGT_LOG2E, -lse16[i]));
                 if (q >= T || !k_ok) pr = 0.f;
-                float dpv = dp[i], prd = pr;
+                float dd = DROP ? fmaf(dp[i], p.inv_keep, -dl16[i]) : dp[i] - dl16[i];
+                float prd = pr;                                    // 1/(1-p) of dV is applied once, at the end
                 if (DROP) {
-                    const uint32_t rowh = dropout_row_hash(seed, (uint32_t)(gh * T + (q < T ? q : T - 1)));
-                    const uint32_t bits = dropout_bits16(seed, rowh, (uint32_t)kc);
-                    const bool keep = bits >= p.drop_thr;
-                    dpv = keep ? dpv * p.inv_keep : 0.f;
-                    prd = keep ? pr * p.inv_keep : 0.f;
+                    const bool keep = dropout_bits16(seed, rh16[i], (uint32_t)kc) >= p.drop_thr;
+                    dd = keep ? dd : -dl16[i];
+                    prd = keep ? pr : 0.f;
                 }
                 pd[i] = prd;
-                ds[i] = pr * (dpv - dl16[i]);
+                ds[i] = pr * dd;
             }
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
@@ -489,7 +613,7 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_kernel(const AttnParams 
             if (16 * hi + 8 * j < D) {
                 float a[8], b[8];
 #pragma unroll
-                for (int i = 0; i < 8; ++i) { a[i] = dk[8 * j + i]; b[i] = dv[8 * j + i]; }
+                for (int i = 0; i < 8; ++i) { a[i] = dk[8 * j + i]; b[i] = DROP ? dv[8 * j + i] * p.inv_keep : dv[8 * j + i]; }
                 store8(DK + 8 * j, a);
                 store8(DV + 8 * j, b);
             }
