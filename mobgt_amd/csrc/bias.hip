@@ -182,18 +182,23 @@ __device__ __forceinline__ void wave_reduce_heads(float (&v)[HH], int lane) {
 // Adaptive: a key shared by >= 8 lanes of the wave ("unreachable", padding, "no hop", ...) is combined
 // in registers and costs H atomics; keys held by only a few lanes (the distinct SPDs / distance bins along
 // a trajectory) go straight to the atomic unit, where they do not collide anyway.
+constexpr int MAX_LIGHT = 2;
+
 template <int HH>
 __device__ __forceinline__ void wave_scatter_add(float* table_lo, int lo_rows, float* table_hi, int key,
                                                  const float (&vals)[HH], int lane) {
     unsigned long long todo = __ballot(key >= 0);
     unsigned long long light = 0;
-    for (int it = 0; it < 8 && todo; ++it) {
+    // probing costs ~25 instructions per distinct key: stop after MAX_LIGHT keys that turned out to be rare --
+    // whatever is still unprobed then goes to the atomic unit directly, like the rare keys themselves
+    int misses = 0;
+    for (int it = 0; it < 8 && todo && misses < MAX_LIGHT; ++it) {
         const int leader = __ffsll((long long)todo) - 1;
         const int k = __shfl(key, leader, 64);
         const bool mine = key == k;
         const unsigned long long same = __ballot(mine) & todo;
         todo &= ~same;
-        if (__popcll(same) < 8) { light |= same; continue; }
+        if (__popcll(same) < 8) { light |= same; ++misses; continue; }
         float r[HH];
 #pragma unroll
         for (int h = 0; h < HH; ++h) r[h] = mine ? vals[h] : 0.f;
@@ -215,8 +220,24 @@ __device__ __forceinline__ void wave_scatter_add(float* table_lo, int lo_rows, f
 
 constexpr int HOP_LDS_ROWS = 16;      // edge ids < 16 (count <= 12) accumulate in LDS; rarer ids go to global
 
-template <typename TI, typename TE, int HH>
+// Hop-table gradient on the matrix core (HOPMM: F == 1, 8 heads, D <= HOP_DMAX).  d_hop[d, e, h] is a histogram
+// of 8-vectors keyed by the edge id of hop d: per hop slot, onehot(e)^T [16 ids x pairs] times ge [pairs x 8].
+// One v_mfma_f32_16x16x32_bf16 contracts 32 pairs: the A operand is built from 8 staged edge bytes per lane
+// (byte == my row ? 1 : 0), the B operand holds ge split into bf16 hi (columns 0-7) and lo (columns 8-15) parts,
+// so the sum is exact to ~2^-17, and the [16 x 16] result of every hop slot stays in 4 registers per lane for the
+// whole tile.  This replaces 20 ballot/shuffle key-combining rounds per 64 pairs (~5000 VALU instructions; the
+// kernel ran at 54 % VALU utilisation with 68 % of wave time parked) by ~1300 + 40 MFMAs.  Edge ids >= 16 (a
+// transition seen > 14 times in one trajectory) go to the atomic unit directly.
+constexpr int HOP_DMAX = 20;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+
+template <typename TI, typename TE, int HH, bool HOPMM>
 __global__ __launch_bounds__(256) void build_bias_bwd_kernel(const BuildParams p, int lds_rel, int lds_poi) {
+    __shared__ __attribute__((aligned(16))) uint8_t hop_e[HOPMM ? 4 : 1][HOPMM ? HOP_DMAX : 1][64];     // [wave][d][pair]
+    __shared__ __attribute__((aligned(16))) bf16_t hop_b[HOPMM ? 4 : 1][2][16][HOPMM ? 32 : 1];         // [wave][half][col][pair]
+    f32x4_t hacc[HOPMM ? HOP_DMAX : 1];
+#pragma unroll
+    for (int d = 0; d < (HOPMM ? HOP_DMAX : 1); ++d) hacc[d] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* s_rel = smem;                                  // [lds_rel][HH]
     float* s_poi = s_rel + (size_t)lds_rel * HH;          // [lds_poi][HH]
@@ -269,8 +290,53 @@ __global__ __launch_bounds__(256) void build_bias_bwd_kernel(const BuildParams p
             const float inv = inv_f / spd_divisor(rp, p.D);
             float ge[HH];
 #pragma unroll
-            for (int h = 0; h < HH; ++h) ge[h] = gr[h] * inv;
+            for (int h = 0; h < HH; ++h) ge[h] = pairlive ? gr[h] * inv : 0.f;      // (the virtual-token column has no hops)
             const int64_t ebase = pair * p.D_in * p.F;
+            if (HOPMM) {
+                const int wave = threadIdx.x >> 6, half = lane >> 5, k = lane & 31;
+                __syncthreads();                                   // the previous round's operand reads are done
+#pragma unroll
+                for (int h = 0; h < HH; ++h) {
+                    const bf16_t hi = (bf16_t)ge[h];
+                    hop_b[wave][half][h][k] = hi;
+                    hop_b[wave][half][8 + h][k] = (bf16_t)(ge[h] - (float)hi);
+                }
+#pragma unroll
+                for (int d = 0; d < HOP_DMAX; ++d) {
+                    if (d < p.D) {
+                        int idx = pairlive ? ld_idx<TE>(p.edge_input, ebase + d) : 0;
+                        if (idx >= 16) {                           // rare id: straight to the atomic unit
+                            if (idx < p.n_edge) {
+#pragma unroll
+                                for (int h = 0; h < HH; ++h)
+                                    atomicAdd(&p.d_hop[((int64_t)d * p.n_edge + idx) * HH + h], ge[h]);
+                            }
+                            idx = 255;
+                        }
+                        hop_e[wave][d][lane] = (uint8_t)idx;
+                    }
+                }
+                __syncthreads();
+                const int m = lane & 15, kq = lane >> 4;
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf) {
+                    const bf16x8 bop = *reinterpret_cast<const bf16x8*>(&hop_b[wave][hf][m][8 * kq]);
+#pragma unroll
+                    for (int d = 0; d < HOP_DMAX; ++d) {
+                        if (d < p.D) {
+                            const uint2 eb = *reinterpret_cast<const uint2*>(&hop_e[wave][d][hf * 32 + 8 * kq]);
+                            bf16x8 aop;
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) {
+                                const uint32_t byte = ((j < 4 ? eb.x : eb.y) >> (8 * (j & 3))) & 0xffu;
+                                aop[j] = byte == (uint32_t)m ? (bf16_t)1.0f : (bf16_t)0.0f;
+                            }
+                            hacc[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aop, bop, hacc[d], 0, 0, 0);
+                        }
+                    }
+                }
+                continue;
+            }
             // Fast path (F == 1, the MobGT case): a pair's hop list is "L real hops, then zeros" (algos.pyx fills
             // the tail with -1, collator.py:87 shifts it to 0).  The zero tail goes to table row 0 of every
             // later hop slot -- a sum over pairs keyed by L alone -- so only the L real hops need a scatter.
@@ -299,6 +365,21 @@ __global__ __launch_bounds__(256) void build_bias_bwd_kernel(const BuildParams p
                         wave_scatter_add<HH>(s_hop + (size_t)d * HOP_LDS_ROWS * HH, HOP_LDS_ROWS,
                                              p.d_hop + (int64_t)d * p.n_edge * HH, idx, ge, lane);
                     }
+            }
+        }
+    }
+    if (HOPMM && p.edge_input) {
+        // register v of lane (n = lane & 15, q = lane >> 4) holds row (edge id) 4q + v, column n: hi part of head n
+        // for n < 8, lo part of head n - 8 otherwise
+        const int n = lane & 15, q = lane >> 4;
+#pragma unroll
+        for (int d = 0; d < HOP_DMAX; ++d) {
+            if (d < p.D) {
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const float tot = hacc[d][v] + __shfl_xor(hacc[d][v], 8, 64);
+                    if (n < 8 && tot != 0.f) atomicAdd(&s_hop[((size_t)d * HOP_LDS_ROWS + 4 * q + v) * HH + n], tot);
+                }
             }
         }
     }
@@ -354,8 +435,10 @@ int launch_build_bwd(const BuildParams& p, hipStream_t st) {
     const int lds_rel = p.n_rel < 512 ? p.n_rel : 512;
     const int lds_poi = p.poi_pos ? (p.n_poi < 1024 ? p.n_poi : 1024) : 0;
     const size_t shm = (size_t)(lds_rel + lds_poi + 1 + p.D * HOP_LDS_ROWS + p.D + 1) * p.H * sizeof(float);
-    if (p.H == 8) hipLaunchKernelGGL((build_bias_bwd_kernel<TI, TE, 8>), grid, block, shm, st, p, lds_rel, lds_poi);
-    else if (p.H == 4) hipLaunchKernelGGL((build_bias_bwd_kernel<TI, TE, 4>), grid, block, shm, st, p, lds_rel, lds_poi);
+    const bool hopmm = p.edge_input && p.F == 1 && p.H == 8 && p.D <= HOP_DMAX;
+    if (hopmm) hipLaunchKernelGGL((build_bias_bwd_kernel<TI, TE, 8, true>), grid, block, shm, st, p, lds_rel, lds_poi);
+    else if (p.H == 8) hipLaunchKernelGGL((build_bias_bwd_kernel<TI, TE, 8, false>), grid, block, shm, st, p, lds_rel, lds_poi);
+    else if (p.H == 4) hipLaunchKernelGGL((build_bias_bwd_kernel<TI, TE, 4, false>), grid, block, shm, st, p, lds_rel, lds_poi);
     else return MOBGT_EBADDIM;
     return (int)hipGetLastError();
 }

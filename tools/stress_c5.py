@@ -23,11 +23,14 @@ h = coll.pack_host(trajs)
 d = {k: torch.from_numpy(v).to(dev) for k, v in h.items()}
 torch.cuda.synchronize(); e0.record(); b2 = coll.finish(d); e1.record(); torch.cuda.synchronize()
 print(f"synth {t1-t0:.2f}s, collate(host pack + H2D + device) {t2-t1:.3f}s, device part {e0.elapsed_time(e1):.2f} ms for {G} graphs of {N} nodes")
-ts = TrainStep(model, [batch], use_graph=False)
+ts = TrainStep(model, [batch], use_graph=bool(int(os.environ.get('GRAPH', '0'))))
+ts.prepare()
 for i in range(3): ts.step(0)
 torch.cuda.synchronize(); t = time.perf_counter()
-for i in range(5): ts.step(0)
-torch.cuda.synchronize(); dt = (time.perf_counter() - t) / 5
+for i in range(5):
+    ta = time.perf_counter(); ts.step(0); tb = time.perf_counter(); torch.cuda.synchronize(); tc = time.perf_counter()
+    print(f"  step {i}: launch {1e3*(tb-ta):.2f} ms, drain {1e3*(tc-tb):.2f} ms, reserved {torch.cuda.memory_reserved()/2**30:.2f} GiB")
+dt = (time.perf_counter() - t) / 5
 print(f"train step {dt*1e3:.2f} ms -> {G/dt:.1f} check-ins/s")
 from torch.profiler import profile, ProfilerActivity
 with profile(activities=[ProfilerActivity.CUDA]) as prof:
