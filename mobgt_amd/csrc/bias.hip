@@ -160,6 +160,12 @@ __global__ __launch_bounds__(256) void build_bias_kernel(const BuildParams p) {
 // H head values over the 64 lanes (H-1 + log2(64/H) shuffles) -> H lanes issue one atomic each.  The
 // per-workgroup tables live in LDS (rel, poi, and hop rows with a small edge id); the workgroup flushes
 // its non-zero entries with global atomics once.
+// atomic add on a pointer KNOWN to be LDS: a generic float* here compiles to flat_atomic_add_f32
+typedef __attribute__((address_space(3))) float lds_float;
+__device__ __forceinline__ void lds_add(float* p, float v) {
+    __hip_atomic_fetch_add((lds_float*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
 template <int HH>
 __device__ __forceinline__ void wave_reduce_heads(float (&v)[HH], int lane) {
     // after this, lane l with (l & (64/HH - 1)) == 0 holds in v[0] the wave-wide sum of head l / (64/HH)
@@ -206,15 +212,20 @@ __device__ __forceinline__ void wave_scatter_add(float* table_lo, int lo_rows, f
         constexpr int STEP = 64 / HH;
         if ((lane & (STEP - 1)) == 0) {
             const int h = lane / STEP;
-            float* dst = k < lo_rows ? table_lo + (size_t)k * HH + h : table_hi + (size_t)k * HH + h;
-            atomicAdd(dst, r[0]);
+            // two explicit paths: a select of an LDS and a global pointer compiles to flat_atomic_add_f32
+            if (k < lo_rows) lds_add(table_lo + (size_t)k * HH + h, r[0]);
+            else atomicAdd(table_hi + (size_t)k * HH + h, r[0]);
         }
     }
     light |= todo;
     if ((light >> lane) & 1ull) {
-        float* dst = key < lo_rows ? table_lo + (size_t)key * HH : table_hi + (size_t)key * HH;
+        if (key < lo_rows) {
 #pragma unroll
-        for (int h = 0; h < HH; ++h) atomicAdd(dst + h, vals[h]);
+            for (int h = 0; h < HH; ++h) lds_add(table_lo + (size_t)key * HH + h, vals[h]);
+        } else {
+#pragma unroll
+            for (int h = 0; h < HH; ++h) atomicAdd(table_hi + (size_t)key * HH + h, vals[h]);
+        }
     }
 }
 
@@ -233,8 +244,9 @@ typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 
 template <typename TI, typename TE, int HH, bool HOPMM>
 __global__ __launch_bounds__(256) void build_bias_bwd_kernel(const BuildParams p, int lds_rel, int lds_poi) {
-    __shared__ __attribute__((aligned(16))) uint8_t hop_e[HOPMM ? 4 : 1][HOPMM ? HOP_DMAX : 1][64];     // [wave][d][pair]
+    __shared__ __attribute__((aligned(16))) uint16_t hop_e[HOPMM ? 4 : 1][HOPMM ? HOP_DMAX : 1][64];    // [wave][d][pair] one-hot
     __shared__ __attribute__((aligned(16))) bf16_t hop_b[HOPMM ? 4 : 1][2][16][HOPMM ? 32 : 1];         // [wave][half][col][pair]
+    __shared__ __attribute__((aligned(16))) float gr_s[4][HH][2][32];                                    // [wave][head][row][col]
     f32x4_t hacc[HOPMM ? HOP_DMAX : 1];
 #pragma unroll
     for (int d = 0; d < (HOPMM ? HOP_DMAX : 1); ++d) hacc[d] = f32x4_t{0.f, 0.f, 0.f, 0.f};
@@ -248,42 +260,95 @@ __global__ __launch_bounds__(256) void build_bias_bwd_kernel(const BuildParams p
     for (int t = threadIdx.x; t < n_lds; t += blockDim.x) smem[t] = 0.f;
     __syncthreads();
 
-    const int g = blockIdx.z;
     const int N = p.N, T = N + 1;
-    const int i0 = blockIdx.y * TILE, j0 = blockIdx.x * TILE;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
     const int lane = threadIdx.x & 63;
     const float inv_f = 1.f / (float)p.F;
-
+    // A workgroup walks tiles blockIdx.x, blockIdx.x + gridDim.x, ... and flushes its LDS tables ONCE at the end:
+    // with one tile per workgroup a long-trajectory batch (T = 785: 10 000 tiles) flushed ~100 M f32 atomics
+    // (every tile touches most SPD / distance-bin rows) and spent ~3 ms doing so.
+    const int nt = (T + TILE - 1) / TILE;
+    const int n_tiles = nt * nt * p.G;
+#pragma unroll 1
+    for (int tile_id = blockIdx.x; tile_id < n_tiles; tile_id += gridDim.x) {
+    const int g = tile_id / (nt * nt);
+    const int i0 = ((tile_id / nt) % nt) * TILE, j0 = (tile_id % nt) * TILE;
 #pragma unroll 1
     for (int r = 0; r < TILE; r += 8) {
         const int ti = i0 + ty + r, tj = j0 + tx;
-        bool live = ti >= 1 && ti < T && tj < T;
-        if (live) live = p.attn_bias[((int64_t)g * T + ti) * T + tj] != -INFINITY;   // -inf: probability 0, no gradient
+        // Every load of this round is issued up front, keyed on the index range only: the chain
+        // attn_bias -> (live?) -> dBias -> rel_pos -> hop ids used to be 4-5 dependent memory round trips per round
+        // at 3 waves per SIMD (~13 k cycles per round).
+        const bool inr = ti >= 1 && ti < T && tj < T;
+        const bool pairin = inr && tj >= 1;
+        const int64_t pair = pairin ? ((int64_t)g * N + (ti - 1)) * N + (tj - 1) : 0;
+        const float ab = inr ? p.attn_bias[((int64_t)g * T + ti) * T + tj] : -INFINITY;
+        const int rp_raw = pairin ? ld_idx<TI>(p.rel_pos, pair) : 0;
+        const int pp_raw = (pairin && p.poi_pos) ? ld_idx<TI>(p.poi_pos, pair) : 0;
+        const int64_t ebase = pair * p.D_in * p.F;
+        int hop_id[HOPMM ? HOP_DMAX : 1];
+        if (HOPMM) {
+#pragma unroll
+            for (int d = 0; d < HOP_DMAX; ++d) hop_id[d] = (d < p.D && pairin) ? ld_idx<TE>(p.edge_input, ebase + d) : 0;
+        }
         float gr[HH];
 #pragma unroll
-        for (int h = 0; h < HH; ++h) {
-            const int64_t at = (((int64_t)g * HH + h) * T + ti) * p.ld + tj;
-            float v = 0.f;
-            if (live) {
-                if (p.dbias_bf16) {
-                    const bf16_t* src = reinterpret_cast<const bf16_t*>(p.dbias) + at;
-                    for (int l = 0; l < p.n_slices; ++l) v += (float)src[l * p.slice_stride];
-                } else {
-                    v = reinterpret_cast<const float*>(p.dbias)[at];
+        for (int h = 0; h < HH; ++h) gr[h] = 0.f;
+        if (p.dbias_bf16) {
+            // bf16 layer slices: the wave's 64 pairs are 2 rows x 32 columns x HH heads = 2*HH row segments of 64 B per
+            // slice -- ONE 16-byte-per-lane load instruction per slice (lane = (head, row, 8-column part)) instead of
+            // HH two-byte loads per pair, and up to 12 slices in flight at once.  The f32 sums go through a
+            // wave-private LDS tile to the lanes that own the pairs.
+            const int wv = threadIdx.x >> 6;
+            const int seg = lane >> 2, part = lane & 3, sh = seg >> 1, srow = seg & 1;
+            const int row = i0 + r + 2 * wv + srow;
+            float s8[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) s8[i] = 0.f;
+            if (seg < 2 * HH && row >= 1 && row < T) {
+                const bf16_t* src = reinterpret_cast<const bf16_t*>(p.dbias) + (((int64_t)g * HH + sh) * T + row) * p.ld + j0 + 8 * part;
+                for (int l = 0; l < p.n_slices; l += 12) {
+                    uint4 t[12];
+#pragma unroll
+                    for (int u = 0; u < 12; ++u)
+                        t[u] = l + u < p.n_slices ? *reinterpret_cast<const uint4*>(src + (l + u) * p.slice_stride) : make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+                    for (int u = 0; u < 12; ++u) {
+                        s8[0] += bf16_lo(t[u].x); s8[1] += bf16_hi(t[u].x); s8[2] += bf16_lo(t[u].y); s8[3] += bf16_hi(t[u].y);
+                        s8[4] += bf16_lo(t[u].z); s8[5] += bf16_hi(t[u].z); s8[6] += bf16_lo(t[u].w); s8[7] += bf16_hi(t[u].w);
+                    }
                 }
             }
-            gr[h] = v;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            if (seg < 2 * HH) {
+                float* dst = &gr_s[wv][sh][srow][8 * part];
+                *reinterpret_cast<float4*>(dst) = make_float4(s8[0], s8[1], s8[2], s8[3]);
+                *reinterpret_cast<float4*>(dst + 4) = make_float4(s8[4], s8[5], s8[6], s8[7]);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int h = 0; h < HH; ++h) gr[h] = gr_s[wv][h][lane >> 5][lane & 31];
+        } else if (inr) {
+            const int64_t at0 = ((int64_t)g * HH * T + ti) * p.ld + tj;          // head 0; heads are T * ld apart
+            const int64_t hs = (int64_t)T * p.ld;
+#pragma unroll
+            for (int h = 0; h < HH; ++h) gr[h] = reinterpret_cast<const float*>(p.dbias)[at0 + h * hs];
+        }
+        const bool live = inr && ab != -INFINITY;                 // -inf: probability 0, no gradient
+        if (!live) {
+#pragma unroll
+            for (int h = 0; h < HH; ++h) gr[h] = 0.f;
         }
         // virtual-token column
         wave_scatter_add<HH>(s_vd, 1, s_vd, (live && tj == 0) ? 0 : -1, gr, lane);
         const bool pairlive = live && tj >= 1;
-        const int64_t pair = pairlive ? ((int64_t)g * N + (ti - 1)) * N + (tj - 1) : 0;
-        const int rp = pairlive ? ld_idx<TI>(p.rel_pos, pair) : 0;
+        const int rp = pairlive ? rp_raw : 0;
         // row 0 of the index tables is nn.Embedding's padding_idx: it never receives a gradient, skip it
         wave_scatter_add<HH>(s_rel, lds_rel, p.d_rel, (pairlive && rp != 0) ? rp : -1, gr, lane);
         if (p.poi_pos) {
-            const int pp = pairlive ? ld_idx<TI>(p.poi_pos, pair) : 0;
+            const int pp = pairlive ? pp_raw : 0;
             wave_scatter_add<HH>(s_poi, lds_poi, p.d_poi, (pairlive && pp != 0) ? pp : -1, gr, lane);
         }
         if (p.edge_input) {
@@ -291,10 +356,12 @@ __global__ __launch_bounds__(256) void build_bias_bwd_kernel(const BuildParams p
             float ge[HH];
 #pragma unroll
             for (int h = 0; h < HH; ++h) ge[h] = pairlive ? gr[h] * inv : 0.f;      // (the virtual-token column has no hops)
-            const int64_t ebase = pair * p.D_in * p.F;
             if (HOPMM) {
                 const int wave = threadIdx.x >> 6, half = lane >> 5, k = lane & 31;
-                __syncthreads();                                   // the previous round's operand reads are done
+                // the staging areas are private to the wave and LDS executes a wave's instructions in order, so only
+                // the COMPILER has to be kept from moving this round's writes above the previous round's reads
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
 #pragma unroll
                 for (int h = 0; h < HH; ++h) {
                     const bf16_t hi = (bf16_t)ge[h];
@@ -304,34 +371,33 @@ __global__ __launch_bounds__(256) void build_bias_bwd_kernel(const BuildParams p
 #pragma unroll
                 for (int d = 0; d < HOP_DMAX; ++d) {
                     if (d < p.D) {
-                        int idx = pairlive ? ld_idx<TE>(p.edge_input, ebase + d) : 0;
-                        if (idx >= 16) {                           // rare id: straight to the atomic unit
-                            if (idx < p.n_edge) {
+                        const int idx = pairlive ? hop_id[d] : 0;
+                        if (idx >= 16 && idx < p.n_edge) {         // rare id: straight to the atomic unit
 #pragma unroll
-                                for (int h = 0; h < HH; ++h)
-                                    atomicAdd(&p.d_hop[((int64_t)d * p.n_edge + idx) * HH + h], ge[h]);
-                            }
-                            idx = 255;
+                            for (int h = 0; h < HH; ++h) atomicAdd(&p.d_hop[((int64_t)d * p.n_edge + idx) * HH + h], ge[h]);
                         }
-                        hop_e[wave][d][lane] = (uint8_t)idx;
+                        // staged as a 16-bit one-hot mask (bit e); 0 = "no row here"
+                        hop_e[wave][d][lane] = idx < 16 ? (uint16_t)(1u << idx) : (uint16_t)0;
                     }
                 }
-                __syncthreads();
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                // A operand of lane (row m, k-group kq): [pair's id == m] for 8 pairs = bit m of 8 one-hot masks.
+                // Rotating a dword of two masks left by 14 - m puts those two bits at positions 14 and 30, and
+                // 0x4000 is bf16 2.0: two instructions per pair of pairs, the factor 2 is undone at the flush.
                 const int m = lane & 15, kq = lane >> 4;
+                const uint32_t rot = (uint32_t)(m - 14) & 31u;      // rotate RIGHT by m - 14 (mod 32)
 #pragma unroll
                 for (int hf = 0; hf < 2; ++hf) {
                     const bf16x8 bop = *reinterpret_cast<const bf16x8*>(&hop_b[wave][hf][m][8 * kq]);
 #pragma unroll
                     for (int d = 0; d < HOP_DMAX; ++d) {
                         if (d < p.D) {
-                            const uint2 eb = *reinterpret_cast<const uint2*>(&hop_e[wave][d][hf * 32 + 8 * kq]);
-                            bf16x8 aop;
+                            const uint4 eb = *reinterpret_cast<const uint4*>(&hop_e[wave][d][hf * 32 + 8 * kq]);
+                            uint32_t w[4] = {eb.x, eb.y, eb.z, eb.w};
 #pragma unroll
-                            for (int j = 0; j < 8; ++j) {
-                                const uint32_t byte = ((j < 4 ? eb.x : eb.y) >> (8 * (j & 3))) & 0xffu;
-                                aop[j] = byte == (uint32_t)m ? (bf16_t)1.0f : (bf16_t)0.0f;
-                            }
-                            hacc[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aop, bop, hacc[d], 0, 0, 0);
+                            for (int j = 0; j < 4; ++j) w[j] = __builtin_amdgcn_alignbit(w[j], w[j], rot) & 0x40004000u;
+                            hacc[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w), bop, hacc[d], 0, 0, 0);
                         }
                     }
                 }
@@ -368,6 +434,7 @@ __global__ __launch_bounds__(256) void build_bias_bwd_kernel(const BuildParams p
             }
         }
     }
+    }   // tiles
     if (HOPMM && p.edge_input) {
         // register v of lane (n = lane & 15, q = lane >> 4) holds row (edge id) 4q + v, column n: hi part of head n
         // for n < 8, lo part of head n - 8 otherwise
@@ -377,8 +444,8 @@ __global__ __launch_bounds__(256) void build_bias_bwd_kernel(const BuildParams p
             if (d < p.D) {
 #pragma unroll
                 for (int v = 0; v < 4; ++v) {
-                    const float tot = hacc[d][v] + __shfl_xor(hacc[d][v], 8, 64);
-                    if (n < 8 && tot != 0.f) atomicAdd(&s_hop[((size_t)d * HOP_LDS_ROWS + 4 * q + v) * HH + n], tot);
+                    const float tot = 0.5f * (hacc[d][v] + __shfl_xor(hacc[d][v], 8, 64));   // one-hot entries are 2.0
+                    if (n < 8 && tot != 0.f) lds_add(&s_hop[((size_t)d * HOP_LDS_ROWS + 4 * q + v) * HH + n], tot);
                 }
             }
         }
@@ -431,7 +498,9 @@ int launch_build_b(const BuildParams& p, int bias_dtype, hipStream_t st) {
 template <typename TI, typename TE>
 int launch_build_bwd(const BuildParams& p, hipStream_t st) {
     const int T = p.N + 1;
-    const dim3 grid((T + TILE - 1) / TILE, (T + TILE - 1) / TILE, p.G), block(256);
+    const int nt = (T + TILE - 1) / TILE;
+    const int n_tiles = nt * nt * p.G;
+    const dim3 grid(n_tiles < 768 ? n_tiles : 768), block(256);          // <= 3 workgroups per CU, each walks its tiles
     const int lds_rel = p.n_rel < 512 ? p.n_rel : 512;
     const int lds_poi = p.poi_pos ? (p.n_poi < 1024 ? p.n_poi : 1024) : 0;
     const size_t shm = (size_t)(lds_rel + lds_poi + 1 + p.D * HOP_LDS_ROWS + p.D + 1) * p.H * sizeof(float);
