@@ -34,17 +34,19 @@ def _split_factor(R, tiles):
     return best
 
 
-def _wgrad_hip(dtype, M, N):
-    """True when the weight gradient of an [M,N] Linear goes to csrc/wgrad.hip.  Its 32x32 output tiles
-    re-read g / x once per tile column / row: past ~128 k outputs (c5's 768x256 and 256x1024: 48 / 50 us vs
-    29 us) the library's split-K GEMM with its 64x64+ tiles is the faster one."""
-    return dtype == torch.bfloat16 and M % 2 == 0 and N % 2 == 0 and M * N <= 131072
+def _wgrad_hip(dtype, M, N, R):
+    """True when the weight gradient of an [M,N] Linear over R rows goes to csrc/wgrad.hip.  Its 32x32 output
+    tiles re-read g / x once per tile column / row: with many rows AND more than ~128 k outputs (c5's 768x256
+    and 256x1024 at R = 12 560: 48 / 50 us vs 29 us) the library's split-K GEMM with its 64x64+ tiles is the
+    faster one; at R <= 4096 the kernel is on par or ahead for the 1024x192 FFN shapes as well (9 vs 10.6 us at
+    R = 800, 16.6 vs 17.9 at R = 2432) and saves the reduce launch."""
+    return dtype == torch.bfloat16 and M % 2 == 0 and N % 2 == 0 and (M * N <= 131072 or R <= 4096)
 
 
 def _wgrad(g, x, db=None):
     """Weight gradient g^T @ x (fp32) of a Linear layer; bf16 operands go to the split-K MFMA kernel
     (csrc/wgrad.hip), which also accumulates the bias gradient g.sum(0) into `db` when given."""
-    if _wgrad_hip(g.dtype, g.shape[1], x.shape[1]):
+    if _wgrad_hip(g.dtype, g.shape[1], x.shape[1], g.shape[0]):
         return ops.linear_wgrad(g, x, db=db)[0]
     if db is not None:
         check(_lib.lib().mobgt_colsum(_p(g), _p(db), g.shape[0], g.shape[1], _DT[g.dtype], _stream()), "mobgt_colsum")
@@ -208,7 +210,7 @@ class _FusedLayerFn(torch.autograd.Function):
         dh = df @ s_w2
         dw2 = _wgrad(df, h)
         du = torch.empty_like(u)
-        db1_in_wgrad = _wgrad_hip(A, F, C)                            # then b1's gradient rides on the dW1 kernel
+        db1_in_wgrad = _wgrad_hip(A, F, C, R)                         # then b1's gradient rides on the dW1 kernel
         check(_lib.lib().mobgt_gelu_bwd_colsum(_p(dh), _p(u), _p(du), _p(None if db1_in_wgrad else db1), R, F, act,
                                                _stream()), "mobgt_gelu_bwd_colsum")
         dz = du @ s_w1

@@ -135,7 +135,9 @@ class TrainStep:
                 m.seed_dev = self.seed_dev
         from . import ops
         ops.set_dropout_state(self.seed_dev, seed)
-        self.arena = ops.ZeroArena(dev)
+        # room for every gradient that kernels accumulate into (all but the few huge matrices torch's GEMMs write)
+        n_arena = sum(p.numel() for p in model.parameters() if p.numel() <= (1 << 20))
+        self.arena = ops.ZeroArena(dev, n=max(1 << 20, int(n_arena * 1.1) + (1 << 16)))
         ops.set_zero_arena(self.arena)
         model.train()
         # One side stream for the dry run, the warm-ups and every capture: autograd's AccumulateGrad nodes are

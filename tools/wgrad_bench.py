@@ -1,5 +1,6 @@
 """Developer tool: time mobgt_linear_wgrad against torch's GEMM paths at the encoder's weight-gradient shapes."""
-import sys, torch
+import os, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from mobgt_amd import ops
 from mobgt_amd.fused_layer import _mm_tn_f32
 
@@ -18,7 +19,7 @@ def timeit(f, n=50):
     e0.record(); g.replay(); e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / n * 1e3
 
-for R, M, N in [(2432, 192, 192), (2432, 576, 192), (12560, 256, 256), (12560, 768, 256), (12560, 256, 1024)]:
+for R, M, N in [(2432, 192, 192), (2432, 576, 192), (2432, 1024, 192), (2432, 192, 1024), (800, 1024, 192), (800, 192, 1024), (12560, 256, 256), (12560, 768, 256), (12560, 256, 1024)]:
     g = torch.randn(R, M, device="cuda").bfloat16(); x = torch.randn(R, N, device="cuda").bfloat16()
     a = timeit(lambda: ops.linear_wgrad(g, x, with_bias=True))
     b = timeit(lambda: _mm_tn_f32(g, x))
