@@ -141,6 +141,19 @@ int mobgt_build_bias_bwd(const void* dbias, int dbias_dtype, int n_slices, int64
                          int G, int N, int H, int D_in, int D, int F, int n_rel, int n_poi, int n_edge,
                          int64_t ld_bias, int idx_dtype, int edge_dtype, void* stream);
 
+/* Hop table of the multi-hop edge term (model.py:166-176; fq: model_fqandtoyo.py:1178-1198):
+ *   table[d, e, h] = sum_h' edge_encoder[e, h'] * edge_dis_encoder[d, h', h]     [D, n_edge, H] f32
+ * from edge_encoder.weight [n_edge, H] and edge_dis_encoder.weight viewed as [>= D, H, H].  fp16_roundtrip != 0
+ * applies the fq variant's rounding points (operands and product rounded to fp16, fp32 accumulate).
+ * Backward: d_edge_encoder [n_edge, H] (row 0 = padding_idx: written as zero) and d_edge_dis_encoder [D, H, H],
+ * both overwritten; with fp16_roundtrip the gradients are rounded to fp16 where autograd would pass them back
+ * through the reference's `.half()` casts. */
+int mobgt_hop_table_fwd(const float* edge_encoder, const float* edge_dis_encoder, float* table, int D, int n_edge,
+                        int H, int fp16_roundtrip, void* stream);
+int mobgt_hop_table_bwd(const float* d_table, const float* edge_encoder, const float* edge_dis_encoder,
+                        float* d_edge_encoder, float* d_edge_dis_encoder, int D, int n_edge, int H,
+                        int fp16_roundtrip, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Batched shortest-path preprocessing on the device.  Replaces, for a whole padded batch,
  *     graphormer/algos.pyx:9-54   floyd_warshall   (bit-exact M and path, 510 sentinel, k-sequential)

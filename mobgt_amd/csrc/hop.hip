@@ -1,0 +1,70 @@
+// Hop table of the multi-hop edge term and its gradient.
+//   T[d, e, h] = sum_h' edge_encoder[e, h'] * edge_dis_encoder[d, h', h]          (model.py:166-176)
+// is what the reference evaluates per PAIR (gather + [G*N*N, H] x [H, H] bmm per hop); the term is linear in the
+// gathered rows, so this repo evaluates it once per step as a [D, n_edge, H] table that build_bias gathers from
+// (DESIGN 3.2).  n_edge * H * H * D is ~160 k multiply-adds: one small launch each way instead of the ~30
+// cast / cat / matmul / copy launches the same few lines cost through autograd.
+// fp16_roundtrip reproduces model_fqandtoyo.py:1178-1198 exactly for F = 1: operands rounded to fp16, fp32
+// accumulate, product rounded to fp16 -- and, in the backward, the gradient rounded to fp16 wherever autograd
+// passes it back through one of those `.half()` casts.
+#include "common.h"
+#include "mobgt_hip.h"
+
+namespace {
+
+__device__ __forceinline__ float r16(float v, bool on) { return on ? (float)(_Float16)v : v; }
+
+__global__ __launch_bounds__(256) void hop_table_fwd_kernel(const float* __restrict__ enc, const float* __restrict__ w,
+                                                            float* __restrict__ tab, int D, int E, int H, int rt) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= D * E * H) return;
+    const int h = i % H, e = (i / H) % E, d = i / (H * E);
+    float acc = 0.f;
+    for (int k = 0; k < H; ++k) acc += r16(enc[e * H + k], rt) * r16(w[(d * H + k) * H + h], rt);
+    tab[i] = r16(acc, rt);
+}
+
+// threads [0, E*H): d_enc[e, k] = sum_{d,h} g[d,e,h] * W[d,k,h]   (row 0 = padding_idx: zero)
+// threads [E*H, E*H + D*H*H): d_w[d, k, h] = sum_e enc[e,k] * g[d,e,h]
+__global__ __launch_bounds__(256) void hop_table_bwd_kernel(const float* __restrict__ dtab, const float* __restrict__ enc,
+                                                            const float* __restrict__ w, float* __restrict__ d_enc,
+                                                            float* __restrict__ d_w, int D, int E, int H, int rt) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < E * H) {
+        const int k = i % H, e = i / H;
+        float acc = 0.f;
+        if (e != 0) {
+            for (int d = 0; d < D; ++d)
+                for (int h = 0; h < H; ++h) acc += r16(dtab[(d * E + e) * H + h], rt) * r16(w[(d * H + k) * H + h], rt);
+        }
+        d_enc[i] = r16(acc, rt);
+        return;
+    }
+    const int j = i - E * H;
+    if (j >= D * H * H) return;
+    const int h = j % H, k = (j / H) % H, d = j / (H * H);
+    float acc = 0.f;
+    for (int e = 0; e < E; ++e) acc += r16(enc[e * H + k], rt) * r16(dtab[(d * E + e) * H + h], rt);
+    d_w[j] = r16(acc, rt);
+}
+
+}  // namespace
+
+extern "C" int mobgt_hop_table_fwd(const float* edge_encoder, const float* edge_dis_encoder, float* table, int D,
+                                   int n_edge, int H, int fp16_roundtrip, void* stream) {
+    if (D <= 0 || n_edge <= 0 || H <= 0) return MOBGT_EBADDIM;
+    const int n = D * n_edge * H;
+    hipLaunchKernelGGL(hop_table_fwd_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, edge_encoder,
+                       edge_dis_encoder, table, D, n_edge, H, fp16_roundtrip);
+    return (int)hipGetLastError();
+}
+
+extern "C" int mobgt_hop_table_bwd(const float* d_table, const float* edge_encoder, const float* edge_dis_encoder,
+                                   float* d_edge_encoder, float* d_edge_dis_encoder, int D, int n_edge, int H,
+                                   int fp16_roundtrip, void* stream) {
+    if (D <= 0 || n_edge <= 0 || H <= 0) return MOBGT_EBADDIM;
+    const int n = n_edge * H + D * H * H;
+    hipLaunchKernelGGL(hop_table_bwd_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, d_table,
+                       edge_encoder, edge_dis_encoder, d_edge_encoder, d_edge_dis_encoder, D, n_edge, H, fp16_roundtrip);
+    return (int)hipGetLastError();
+}

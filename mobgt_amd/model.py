@@ -44,6 +44,9 @@ def hop_table_from(edge_weight, edge_dis_weight, H, D, fp16_roundtrip=False):
     gather + [G*N*N, H] x [H, H] bmm per hop.  Row 0 of the edge table is `padding_idx` (no gradient).
     fp16_roundtrip reproduces model_fqandtoyo.py:1178-1198: operands rounded to fp16, fp32 accumulate,
     product rounded to fp16 (exact for F == 1, which is every MobGT dataset)."""
+    if edge_weight.is_cuda and edge_weight.dtype == torch.float32 and edge_dis_weight.dtype == torch.float32:
+        from . import ops
+        return ops.hop_table(edge_weight, edge_dis_weight, H, D, fp16_roundtrip)     # one launch each way
     W = edge_dis_weight.reshape(-1, H, H)[:D]
     enc = no_grad_row0(edge_weight)
     if fp16_roundtrip:

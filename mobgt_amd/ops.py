@@ -384,6 +384,39 @@ class _GatherSumFn(torch.autograd.Function):
         return (None, None, *grads, *([None] * n))
 
 
+class _HopTableFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, edge_weight, edge_dis_weight, H, D, fp16_roundtrip):
+        E = edge_weight.shape[0]
+        ew, dw = edge_weight.contiguous(), edge_dis_weight.contiguous()
+        tab = torch.empty(D, E, H, dtype=torch.float32, device=ew.device)
+        check(_lib.lib().mobgt_hop_table_fwd(_p(ew), _p(dw), _p(tab), D, E, H, int(fp16_roundtrip), _stream()),
+              "mobgt_hop_table_fwd")
+        ctx.save_for_backward(ew, dw)
+        ctx.misc = (H, D, int(fp16_roundtrip), edge_dis_weight.shape)
+        return tab
+
+    @staticmethod
+    def backward(ctx, dtab):
+        ew, dw = ctx.saved_tensors
+        H, D, rt, dis_shape = ctx.misc
+        E = ew.shape[0]
+        d_ew = torch.empty_like(ew)
+        d_dw = zeros_f32(tuple(dis_shape), ew.device)            # rows of hop slots >= D get no gradient
+        check(_lib.lib().mobgt_hop_table_bwd(_p(dtab.contiguous()), _p(ew), _p(dw), _p(d_ew), _p(d_dw), D, E, H, rt,
+                                             _stream()), "mobgt_hop_table_bwd")
+        return d_ew, d_dw, None, None, None
+
+
+def hop_table(edge_weight, edge_dis_weight, H, D, fp16_roundtrip=False):
+    """[D, n_edge, H] hop table T[d,e,:] = edge_encoder[e,:] . W_d (model.py:166-176) with the fq variant's fp16
+    rounding points (model_fqandtoyo.py:1178-1198) and nn.Embedding(padding_idx=0)'s "row 0 gets no gradient"."""
+    _require_cuda(edge_weight, edge_dis_weight)
+    assert edge_weight.dtype == torch.float32 and edge_dis_weight.dtype == torch.float32
+    assert edge_dis_weight.numel() >= D * H * H
+    return _HopTableFn.apply(edge_weight, edge_dis_weight, H, D, fp16_roundtrip)
+
+
 def node_index(x, time_normal, poi2cat, rows_only):
     """Row indices of the node-feature gathers (model_fqandtoyo.py:1259-1264, 1287-1298) in one launch.
     x [G,N] int64 POI ids, time_normal [G,N] f32 -> (idx [6,G,N] int64, real [G,N] f32); rows of idx:
