@@ -223,6 +223,13 @@ int mobgt_node_index(const int64_t* x, int64_t xs_g, int64_t xs_n, const float* 
                      int64_t ts_n, const int64_t* poi2cat, int64_t* idx, float* real, int G, int N, int rows_only,
                      void* stream);
 
+/* Evaluation (model_fqandtoyo.py:48-90 get_acc, :122-131 MRR_metric): for every row of scores [G,V] f32 the number
+ * of classes ranked ahead of target[g] (class id, int64): rank[2g] counts strictly larger scores plus equal scores
+ * at a LOWER index (a stable descending top-k: "target is in the top k" <=> rank[2g] < k, its position is rank[2g]);
+ * rank[2g+1] counts equal scores at a HIGHER index instead (the reference's reversed ascending argsort in
+ * MRR_metric).  -1 for a target outside [0, V). */
+int mobgt_target_rank(const float* scores, const int64_t* target, int32_t* rank, int64_t G, int64_t V, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Fused elementwise / normalisation pieces of EncoderLayer.forward between the library GEMMs
  * (graphormer/model.py:479-489, model_fqandtoyo.py:1731-1743) and their backward.  R rows (= G*T tokens),

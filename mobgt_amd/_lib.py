@@ -46,6 +46,7 @@ SIGNATURES = {
     "mobgt_embed_scatter_add": (_i, [_vp, _vp, _vp, _i, _vp, _i64, _i, _i64, _i, _vp]),
     "mobgt_hop_table_fwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "mobgt_hop_table_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "mobgt_target_rank": (_i, [_vp, _vp, _vp, _i64, _i64, _vp]),
     "mobgt_node_index": (_i, [_vp, _i64, _i64, _vp, _i64, _i64, _vp, _vp, _vp, _i, _i, _i, _vp]),
 }
 

@@ -144,3 +144,52 @@ extern "C" int mobgt_node_index(const int64_t* x, int64_t xs_g, int64_t xs_n, co
     hipLaunchKernelGGL(node_index_kernel, dim3(G), dim3(256), 0, (hipStream_t)stream, p);
     return (int)hipGetLastError();
 }
+
+// ---- evaluation: rank of the target class in each row of the logits --------------------------------------
+namespace {
+
+// One workgroup per row.  Everything get_acc (model_fqandtoyo.py:48-90: "is the target among the top-k indices,
+// and at which position") and MRR_metric (:122-131: position of the target in the descending argsort) need is
+// the number of classes ranked ahead of the target: strictly larger scores, plus -- among equal scores -- the
+// classes a given sort puts first (lower index for a stable descending top-k; HIGHER index for the reference's
+// reversed ascending argsort).  Both counts are returned; for distinct scores they coincide.
+__global__ __launch_bounds__(256) void target_rank_kernel(const float* __restrict__ scores, const int64_t* __restrict__ target,
+                                                          int32_t* __restrict__ rank, int64_t V) {
+    __shared__ int s_g[4], s_lo[4], s_hi[4];
+    const int64_t row = blockIdx.x;
+    const int64_t t = target[row];
+    const float* s = scores + row * V;
+    int greater = 0, tie_lo = 0, tie_hi = 0;
+    if (t >= 0 && t < V) {
+        const float ts = s[t];
+        for (int64_t c = threadIdx.x; c < V; c += 256) {
+            const float v = s[c];
+            greater += v > ts;
+            tie_lo += (v == ts) & (c < t);
+            tie_hi += (v == ts) & (c > t);
+        }
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        greater += __shfl_xor(greater, o, 64);
+        tie_lo += __shfl_xor(tie_lo, o, 64);
+        tie_hi += __shfl_xor(tie_hi, o, 64);
+    }
+    if ((threadIdx.x & 63) == 0) { s_g[threadIdx.x >> 6] = greater; s_lo[threadIdx.x >> 6] = tie_lo; s_hi[threadIdx.x >> 6] = tie_hi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int g = s_g[0] + s_g[1] + s_g[2] + s_g[3];
+        const bool ok = t >= 0 && t < V;
+        rank[2 * row] = ok ? g + s_lo[0] + s_lo[1] + s_lo[2] + s_lo[3] : -1;
+        rank[2 * row + 1] = ok ? g + s_hi[0] + s_hi[1] + s_hi[2] + s_hi[3] : -1;
+    }
+}
+
+}  // namespace
+
+extern "C" int mobgt_target_rank(const float* scores, const int64_t* target, int32_t* rank, int64_t G, int64_t V,
+                                 void* stream) {
+    if (G <= 0 || V <= 0) return 0;
+    hipLaunchKernelGGL(target_rank_kernel, dim3((unsigned)G), dim3(256), 0, (hipStream_t)stream, scores, target, rank, V);
+    return (int)hipGetLastError();
+}

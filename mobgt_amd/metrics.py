@@ -17,11 +17,16 @@ def get_acc(target, scores):
     acc, ndcg = np.zeros((4, 1)), np.zeros((4, 1))
     if stop == 0:
         return acc, ndcg
-    _, idx = scores[:stop].topk(20, dim=1)
-    hit = idx == target[:stop].unsqueeze(1)                            # at most one True per row
-    rank = hit.float().argmax(dim=1)                                   # position of the hit (0 when no hit)
-    found = hit.any(dim=1)
-    gain = 1.0 / torch.log2(rank.double() + 2.0)
+    if scores.is_cuda:                                                 # one rank kernel instead of a top-k + search
+        from . import ops
+        rank = ops.target_rank(scores[:stop], target[:stop])[:, 0].long()
+        found = (rank >= 0) & (rank < 20)
+    else:
+        _, idx = scores[:stop].topk(20, dim=1)
+        hit = idx == target[:stop].unsqueeze(1)                        # at most one True per row
+        rank = hit.float().argmax(dim=1)                               # position of the hit (0 when no hit)
+        found = hit.any(dim=1)
+    gain = 1.0 / torch.log2(rank.clamp(min=0).double() + 2.0)
     for row, k in ((3, 20), (0, 10), (1, 5), (2, 1)):
         m = found & (rank < k)
         acc[row] = float(m.sum())
@@ -33,6 +38,10 @@ def MRR_metric(target, scores):
     """Sum over rows of 1 / rank of the target under a descending sort (ties: numpy argsort order of the
     reference is approximated by counting strictly greater scores plus earlier-index... see note)."""
     target = torch.as_tensor(target).reshape(-1).to(scores.device)
+    if scores.is_cuda:
+        from . import ops
+        r_idx = ops.target_rank(scores, target)[:, 1]
+        return float((1.0 / (r_idx.double() + 1.0)).sum())
     s = scores.double()
     t = s.gather(1, target.long().unsqueeze(1))
     # reference: rec_list = argsort(row)[::-1]; r_idx = position of the target.  For distinct scores this is the

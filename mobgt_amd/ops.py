@@ -142,7 +142,7 @@ class _PackFn(torch.autograd.Function):
         ctx.pack = pack
         ctx.src_shape = src.shape
         ctx.src_dtype = src.dtype
-        return torch.zeros(1, device=src.device)
+        return zeros_f32((1,), src.device)
 
     @staticmethod
     def backward(ctx, _g):
@@ -190,7 +190,7 @@ class _BuildBiasFn(torch.autograd.Function):
         ctx.idx = (attn_bias, rel_pos, poi_pos, edge_input if has_edge else None)
         ctx.shapes = (rel_table.shape, None if poi_table is None else poi_table.shape,
                       hop_table.shape if has_edge else None, vdist.shape)
-        return torch.zeros(1, device=rel_table.device)
+        return zeros_f32((1,), rel_table.device)
 
     @staticmethod
     def backward(ctx, _g):
@@ -376,7 +376,7 @@ class _GatherSumFn(torch.autograd.Function):
     def backward(ctx, dout):
         dout = dout.contiguous()
         n = len(ctx.shapes)
-        grads = [torch.zeros(s, dtype=torch.float32, device=dout.device) for s in ctx.shapes]
+        grads = [zeros_f32(tuple(s), dout.device) for s in ctx.shapes]
         skip = (ctypes.c_int64 * n)(*ctx.skip)
         R, C = dout.shape
         check(_lib.lib().mobgt_embed_scatter_add(_ptr_array(grads), _ptr_array(ctx.idx), skip, n, _p(dout), R, C, C,
@@ -415,6 +415,18 @@ def hop_table(edge_weight, edge_dis_weight, H, D, fp16_roundtrip=False):
     assert edge_weight.dtype == torch.float32 and edge_dis_weight.dtype == torch.float32
     assert edge_dis_weight.numel() >= D * H * H
     return _HopTableFn.apply(edge_weight, edge_dis_weight, H, D, fp16_roundtrip)
+
+
+def target_rank(scores, target):
+    """[G,2] int32: number of classes ranked ahead of target[g] in scores[g] (column 0: ties broken towards the
+    lower index = stable top-k; column 1: towards the higher index = the reference's reversed argsort)."""
+    _require_cuda(scores, target)
+    scores = scores.float().contiguous()
+    target = target.reshape(-1).long().contiguous()
+    G, V = scores.shape
+    rank = torch.empty(G, 2, dtype=torch.int32, device=scores.device)
+    check(_lib.lib().mobgt_target_rank(_p(scores), _p(target), _p(rank), G, V, _stream()), "mobgt_target_rank")
+    return rank
 
 
 def node_index(x, time_normal, poi2cat, rows_only):
@@ -468,7 +480,7 @@ class _GatherConcatFn(torch.autograd.Function):
         dout = dout.contiguous()
         n = len(ctx.shapes)
         R, ctot = dout.shape
-        grads = [torch.zeros(s, dtype=torch.float32, device=dout.device) for s in ctx.shapes]
+        grads = [zeros_f32(tuple(s), dout.device) for s in ctx.shapes]
         off = 0
         for t in range(n):
             src = ctypes.c_void_p(dout.data_ptr() + 4 * off)

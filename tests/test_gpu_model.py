@@ -208,3 +208,77 @@ def test_gradient_tail_loss_kernel_matches_reference_g7(golden_dir):
     (loss * 3.0).backward()
     np.testing.assert_allclose(loss.item(), z["gtl/loss"], rtol=2e-6)
     np.testing.assert_allclose(logits.grad.cpu().numpy(), 3.0 * z["gtl/dlogits"], rtol=2e-5, atol=1e-8)
+
+
+def test_metrics_rank_kernel_matches_reference_g7(golden_dir):
+    """get_acc / MRR_metric through mobgt_target_rank against the reference's own numbers (golden G7), the
+    first-zero-target stop included, and the tie rules of both rank columns on a crafted row."""
+    from mobgt_amd import metrics, ops
+    z = np.load(os.path.join(golden_dir, "g7_lr_loss.npz"))
+    scores, target = torch.from_numpy(z["acc/scores"]).to(DEV), torch.from_numpy(z["acc/target"]).to(DEV)
+    acc, ndcg = metrics.get_acc(target, scores)
+    np.testing.assert_allclose(acc, z["acc/acc"])
+    np.testing.assert_allclose(ndcg, z["acc/ndcg"], rtol=1e-12)
+    np.testing.assert_allclose(metrics.MRR_metric(target, scores), z["acc/mrr"], rtol=1e-12)
+    t2 = target.clone()
+    t2[5] = 0
+    np.testing.assert_allclose(metrics.get_acc(t2, scores)[0], metrics.get_acc(target[:5], scores[:5])[0])
+    s = torch.tensor([[1.0, 3.0, 3.0, 0.5, 3.0, 2.0]], device=DEV)
+    r = ops.target_rank(s, torch.tensor([2], device=DEV)).cpu().tolist()
+    assert r == [[1, 1]]                       # one equal score before index 2, one after; nothing strictly greater
+    assert ops.target_rank(s, torch.tensor([5], device=DEV)).cpu().tolist() == [[3, 3]]
+    assert ops.target_rank(s, torch.tensor([9], device=DEV)).cpu().tolist() == [[-1, -1]]
+
+
+def test_node_index_kernel_matches_index_expressions():
+    """mobgt_node_index against the index expressions of model_fqandtoyo.py:1259-1264 / :348-351 written with torch."""
+    from mobgt_amd import ops
+    g = torch.Generator().manual_seed(5)
+    G, N, P = 5, 37, 300
+    x = torch.randint(1, P + 1, (G, N), generator=g)
+    lens = torch.tensor([37, 1, 20, 36, 5])
+    x[torch.arange(N).unsqueeze(0) >= lens.unsqueeze(1)] = 0
+    tn = torch.rand(G, N, 1, generator=g)
+    poi2cat = torch.randint(1, 40, (P + 1,), generator=g)
+    poi2cat[0] = 0
+    for rows_only in (False, True):
+        idx, real = ops.node_index(x.to(DEV), tn[:, :, 0].to(DEV), poi2cat.to(DEV), rows_only)
+        idx, real = idx.cpu(), real.cpu()
+        m = x != 0
+        neg = torch.full_like(x, -1)
+        want_poi = torch.where(m, torch.arange(G * N).view(G, N) if rows_only else x - 1, neg)
+        pos = torch.arange(1, N + 1).unsqueeze(0).expand(G, N)
+        assert torch.equal(idx[0], want_poi)
+        assert torch.equal(idx[1], torch.where(m, (tn[:, :, 0] * 48).long(), neg))
+        assert torch.equal(idx[2], torch.where(m, poi2cat[x] - 1, neg))
+        assert torch.equal(idx[3], torch.where(m & (pos <= m.sum(1, keepdim=True)), pos, neg))
+        assert torch.equal(idx[4], (x - 1).clamp(min=0))
+        assert torch.equal(idx[5], torch.zeros_like(x))
+        assert torch.equal(real, m.float())
+
+
+@pytest.mark.parametrize("fp16", [False, True])
+def test_hop_table_kernel_matches_torch_expression(fp16):
+    """mobgt_hop_table_fwd/bwd against the torch expression of model.py:166-176 (fp16: the rounding points of
+    model_fqandtoyo.py:1178-1198, forward AND the fp16-rounded gradients autograd sends back through the casts)."""
+    from mobgt_amd import ops
+    from mobgt_amd.model import no_grad_row0
+    H, D, E = 8, 20, 128
+    g = torch.Generator().manual_seed(2)
+    ew = (torch.randn(E, H, generator=g) * 0.3)
+    dw = (torch.randn(128 * H * H, 1, generator=g) * 0.3)
+    up = torch.randn(D, E, H, generator=g)
+    a, b = ew.clone().requires_grad_(True), dw.clone().requires_grad_(True)
+    W = b.reshape(-1, H, H)[:D]
+    enc = no_grad_row0(a)
+    ref = (torch.matmul(enc.half().float().unsqueeze(0), W.half().float()).half().float() if fp16
+           else torch.matmul(enc.unsqueeze(0), W))
+    (ref * up).sum().backward()
+    c, d = ew.clone().to(DEV).requires_grad_(True), dw.clone().to(DEV).requires_grad_(True)
+    got = ops.hop_table(c, d, H, D, fp16)
+    (got * up.to(DEV)).sum().backward()
+    tol = dict(rtol=2e-3, atol=2e-3) if fp16 else dict(rtol=1e-5, atol=1e-5)     # fp16: one ulp where a sum sits on a tie
+    np.testing.assert_allclose(got.detach().cpu().numpy(), ref.detach().numpy(), **tol)
+    np.testing.assert_allclose(c.grad.cpu().numpy(), a.grad.numpy(), **tol)
+    np.testing.assert_allclose(d.grad.cpu().numpy(), b.grad.numpy(), **tol)
+    assert float(c.grad[0].abs().max()) == 0.0 and float(d.grad.reshape(-1, H, H)[D:].abs().max()) == 0.0
