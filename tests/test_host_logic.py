@@ -133,3 +133,29 @@ def test_metrics_match_reference_g7(golden_dir):
     np.testing.assert_allclose(a2, a5)
     out = metrics.evaluate_outputs([{"y_pred": [scores, None], "y_true": target}])
     assert abs(out["acc@10"] - z["acc/acc"][0, 0] / len(target)) < 1e-12 and 0 <= out["mrr"] <= 1
+
+
+def test_lightning_checkpoint_round_trip(tmp_path):
+    """entry.py:71-93: a Lightning .ckpt keeps the model's parameters under "state_dict" with the reference's
+    names; loading copies into the existing (possibly QKV-fused) parameters, strict=False like the reference."""
+    from mobgt_amd import checkpoint
+    from mobgt_amd.model import EncoderLayer
+    torch.manual_seed(0)
+    a, b = EncoderLayer(64, 128, 0.1, 0.1, 8), EncoderLayer(64, 128, 0.1, 0.1, 8)
+    b.self_attention.fuse_qkv_storage()                       # destination already in the fused layout
+    path = tmp_path / "m.ckpt"
+    checkpoint.save_lightning_checkpoint(a, path, epoch=3, hyper_parameters={"n_layers": 1})
+    ck = torch.load(path, weights_only=False)
+    assert set(ck) == {"state_dict", "epoch", "hyper_parameters"}
+    ck["state_dict"]["not_in_model.weight"] = torch.zeros(2)
+    torch.save(ck, path)
+    missing, unexpected = checkpoint.load_lightning_checkpoint(b, path)
+    assert list(unexpected) == ["not_in_model.weight"] and list(missing) == []
+    for (ka, va), (kb, vb) in zip(a.state_dict().items(), b.state_dict().items()):
+        assert ka == kb and torch.equal(va, vb)
+    wq = b.self_attention.linear_q.weight
+    wqkv, _ = b.self_attention.fuse_qkv_storage()
+    assert wq.data_ptr() == wqkv.data_ptr() and torch.equal(wqkv[:64], a.self_attention.linear_q.weight)
+    ck["state_dict"]["ffn.layer1.weight"] = torch.zeros(3, 3)
+    with pytest.raises(ValueError):
+        checkpoint.load_lightning_checkpoint(b, ck)
