@@ -169,7 +169,8 @@ int mobgt_hop_table_bwd(const float* d_table, const float* edge_encoder, const f
  *             truncated path, 0 = no hop / padding)                                 (collator.py:86-93)
  * in_degree/out_degree: [G, N] int16 out: row-sum+1 / col-sum+1 of the 0/1 adjacency, 0 for padding
  *             (wrapper.py:97-98 naming kept; collator.py:11-18)
- * work     : scratch, mobgt_spd_workspace_bytes(G, N) bytes
+ * work     : scratch, mobgt_spd_workspace_bytes(G, N) bytes (272 < N <= 1088: per-row publication flags and rows of
+ *            the multi-workgroup Floyd-Warshall; zeroed by the call itself)
  * Counts above 252 saturate the uint8 hop feature (the reference's edge tables have 128 rows).
  */
 int64_t mobgt_spd_workspace_bytes(int G, int N);

@@ -83,6 +83,162 @@ __global__ __launch_bounds__(FW_THREADS) void fw_kernel(const int32_t* __restric
     }
 }
 
+// ---- long graphs: one graph over SEVERAL workgroups -------------------------------------------------------------
+// A graph with N > 272 nodes does not fit one CU's LDS, and one workgroup walking N^2 pairs N times out of global
+// memory took ~120 ms for 16 graphs of 784 nodes (15 of 16 CUs idle per graph slot).  Here FW_PARTS workgroups
+// share a graph: each keeps a block of ROWS of M in its LDS.  Step k of algos.pyx:35-45 needs, beyond the
+// workgroup's own rows, only row k as it stands after step k-1 -- so the owner of row k+1 updates that row FIRST
+// in step k, publishes it (into the spd output array, which nobody reads until the end) and raises flag[k+1];
+// the other workgroups wait on that flag only.  No grid-wide barrier per step: workgroups run ahead as far as
+// the rows they need have been published.  The update itself is the reference's, bit for bit: strict '>',
+// "last improving k", literal 510 sentinel (rows whose M[i][k] is 510 cannot improve and are skipped).
+// Visibility across CUs / XCDs (MI355X_MICROARCH "inter-workgroup visibility", the sc1 form): every store of a
+// published row and of its flag is an agent-scope (sc1, write-through) store, drained (s_waitcnt vmcnt(0) in
+// every storing wave + workgroup barrier) before the flag is raised; every load of the flag and of the row is
+// an agent-scope (sc1) load.  A release/acquire pair per step (L2 write-back + invalidate) cost ~15 us x N steps.
+constexpr int FW_PARTS = 16;
+constexpr int FW_SPLIT_THREADS = 512;
+constexpr int FW_SPLIT_MAX_N = 1088;     // ceil(N/16) rows x N x 2 B + one row <= 160 KiB
+
+__global__ __launch_bounds__(FW_SPLIT_THREADS) void fw_split_kernel(const int32_t* __restrict__ counts,
+                                                                    const int32_t* __restrict__ n_nodes, int16_t* spd,
+                                                                    int16_t* __restrict__ path, int16_t* __restrict__ in_degree,
+                                                                    int16_t* __restrict__ out_degree, int* flags, int* done,
+                                                                    uint32_t* pub, int N, int g0) {
+    extern __shared__ __attribute__((aligned(16))) int16_t lds16[];
+    // workgroups b and b+8 land on the same XCD (round-robin dispatch): when the graph count allows, give every
+    // graph's FW_PARTS workgroups one XCD, so that published rows travel through that XCD's L2 only (speed only)
+    const int gc = gridDim.x / FW_PARTS;
+    int gl = blockIdx.x / FW_PARTS, part = blockIdx.x % FW_PARTS;
+    if (gc % 8 == 0) {
+        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+        gl = xcd * (gc / 8) + slot / FW_PARTS;
+        part = slot % FW_PARTS;
+    }
+    const int g = g0 + gl;
+    const int n = n_nodes[g];
+    const int tid = threadIdx.x;
+    const int32_t* C = counts + (int64_t)g * N * N;
+    int16_t* Mg = spd + (int64_t)g * N * N;
+    int16_t* Pg = path + (int64_t)g * N * N;
+    int* flag = flags + (int64_t)g * N;
+    const int npw = ((N + 7) & ~7) / 2;                              // words per published row
+    uint32_t* pubg = pub + (int64_t)g * N * npw;
+    const int rpw = (n + FW_PARTS - 1) / FW_PARTS;                  // rows per workgroup
+    const int r0 = part * rpw, r1 = min(n, r0 + rpw), rows = max(0, r1 - r0);
+    const int np = (n + 7) & ~7;                                     // LDS row pitch
+    int16_t* M = lds16;                                              // [rpw][np]
+    int16_t* rowk = lds16 + (size_t)rpw * np;                        // [np]
+
+    // padding rows / columns of the outputs and the degrees are split over the graph's workgroups by row
+    for (int i = part; i < N; i += FW_PARTS) {
+        if (i >= n) {
+            for (int j = tid; j < N; j += FW_SPLIT_THREADS) { Mg[(int64_t)i * N + j] = -1; Pg[(int64_t)i * N + j] = -1; }
+            if (tid == 0) { in_degree[(int64_t)g * N + i] = 0; out_degree[(int64_t)g * N + i] = 0; }
+        }
+    }
+    if (rows == 0) return;                                            // (nobody waits for a workgroup without rows)
+    for (int i = r0 + tid; i < r1; i += FW_SPLIT_THREADS) {           // wrapper.py:97-98, +1
+        int rs = 0, cs = 0;
+        for (int j = 0; j < n; ++j) { rs += C[(int64_t)i * N + j] != 0; cs += C[(int64_t)j * N + i] != 0; }
+        in_degree[(int64_t)g * N + i] = (int16_t)(rs + 1);
+        out_degree[(int64_t)g * N + i] = (int16_t)(cs + 1);
+    }
+    // init (algos.pyx:27-32)
+    for (int e = tid; e < rows * np; e += FW_SPLIT_THREADS) {
+        const int il = e / np, j = e - il * np, i = r0 + il;
+        if (j < n) {
+            M[il * np + j] = (int16_t)(i == j ? 0 : (C[(int64_t)i * N + j] != 0 ? 1 : UNREACH));
+            Pg[(int64_t)i * N + j] = 0;
+        } else {
+            M[il * np + j] = 0;                                       // padding columns: the minimum, never relaxed
+        }
+    }
+    __syncthreads();
+    auto publish = [&](int r) {                                       // row r (owned here) -> pub row r, flag[r] = 1
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(M + (size_t)(r - r0) * np);
+        for (int w = tid; w < np / 2; w += FW_SPLIT_THREADS)
+            __hip_atomic_store(pubg + (int64_t)r * npw + w, src[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // every storing wave drains its stores ...
+        __syncthreads();                                              // ... before the flag goes up
+        if (tid == 0) __hip_atomic_store(&flag[r], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+    // algos.pyx:38-45 for rows [il0, il1) of this workgroup except `skip`.  A thread owns one PAIR of columns (one
+    // dword of every row) and walks the rows four at a time, so that the LDS reads of four independent rows are in
+    // flight together: one row at a time, each row paid a full LDS round trip (measured ~15 us per step).
+    uint32_t* M32 = reinterpret_cast<uint32_t*>(M);
+    const uint32_t* rowk32 = reinterpret_cast<const uint32_t*>(rowk);
+    const int npw2 = np / 2;
+    auto relax_rows = [&](int k, int il0, int il1, int skip) {
+        for (int w = tid; w < npw2; w += FW_SPLIT_THREADS) {
+            const uint32_t rk = rowk32[w];
+            const int lo = (int)(rk & 0xffffu), hi = (int)(rk >> 16);
+            for (int il = il0; il < il1; il += 4) {
+                int mk[4];
+                uint32_t m2[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int r = il + u;
+                    const bool on = r < il1 && r != skip;
+                    mk[u] = on ? (int)M[r * np + k] : UNREACH;
+                    m2[u] = on ? M32[r * npw2 + w] : 0u;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    if (mk[u] >= UNREACH) continue;               // 510 + x > anything stored: no improvement
+                    const int r = il + u;
+                    const int m0 = (int)(m2[u] & 0xffffu), m1 = (int)(m2[u] >> 16);
+                    const int c0 = mk[u] + lo, c1 = mk[u] + hi;
+                    const bool u0 = m0 > c0, u1 = m1 > c1;        // (padding columns hold 0: never improved)
+                    if (u0 | u1) {
+                        M32[r * npw2 + w] = (uint32_t)(u0 ? c0 : m0) | ((uint32_t)(u1 ? c1 : m1) << 16);
+                        int16_t* prow = Pg + (int64_t)(r0 + r) * N + 2 * w;
+                        if (u0) prow[0] = (int16_t)k;
+                        if (u1) prow[1] = (int16_t)k;
+                    }
+                }
+            }
+        }
+    };
+    if (r0 == 0) publish(0);
+    for (int k = 0; k < n; ++k) {
+        if (k >= r0 && k < r1) {                                      // my own row, current through step k-1
+            for (int j = tid; j < np; j += FW_SPLIT_THREADS) rowk[j] = M[(k - r0) * np + j];
+        } else {
+            if (tid == 0) {
+                while (__hip_atomic_load(&flag[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) __builtin_amdgcn_s_sleep(1);
+            }
+            __syncthreads();
+            uint32_t* dst = reinterpret_cast<uint32_t*>(rowk);
+            for (int w = tid; w < np / 2; w += FW_SPLIT_THREADS)
+                dst[w] = __hip_atomic_load(pubg + (int64_t)k * npw + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+        const int nxt = k + 1;
+        const bool own_next = nxt < n && nxt >= r0 && nxt < r1;
+        if (own_next) {                                               // the row everybody waits for next: first
+            relax_rows(k, nxt - r0, nxt - r0 + 1, -1);
+            __syncthreads();
+            publish(nxt);
+        }
+        relax_rows(k, 0, rows, own_next ? nxt - r0 : -1);
+        __syncthreads();                                              // rowk is rewritten in the next step
+    }
+    // algos.pyx:48-52 + padding columns
+    for (int e = tid; e < rows * N; e += FW_SPLIT_THREADS) {
+        const int il = e / N, j = e - il * N, i = r0 + il;
+        const int64_t at = (int64_t)i * N + j;
+        if (j < n) {
+            int v = M[il * np + j];
+            if (v >= UNREACH) { v = UNREACH; Pg[at] = UNREACH; }
+            Mg[at] = (int16_t)v;
+        } else {
+            Mg[at] = -1;
+            Pg[at] = -1;
+        }
+    }
+}
+
 // one thread per ordered pair: rel_pos and the first D hop features
 __global__ __launch_bounds__(256) void edge_path_kernel(const int32_t* __restrict__ counts, const int32_t* __restrict__ n_nodes,
                                                         const int16_t* __restrict__ spd, const int16_t* __restrict__ path,
@@ -130,8 +286,10 @@ __global__ __launch_bounds__(256) void edge_path_kernel(const int32_t* __restric
 }  // namespace
 
 extern "C" int64_t mobgt_spd_workspace_bytes(int G, int N) {
-    (void)G; (void)N;
-    return 16;          // the FW pass works in place in `spd` / LDS; kept for ABI stability
+    // long graphs (fw_split_kernel): one "row published" flag per (graph, row) + one arrival counter per graph
+    if (G <= 0 || N <= LDS_M_MAX_N || N > FW_SPLIT_MAX_N) return 16;
+    const int64_t npw = ((N + 7) & ~7) / 2;                           // + the published rows, [G][N][npw] words
+    return ((int64_t)G * N + G) * (int64_t)sizeof(int) + (int64_t)G * N * npw * 4 + 16;
 }
 
 extern "C" int mobgt_spd_batched(const int32_t* counts, const int32_t* n_nodes, int16_t* spd, int16_t* path,
@@ -150,6 +308,31 @@ extern "C" int mobgt_spd_batched(const int32_t* counts, const int32_t* n_nodes, 
         }
         hipLaunchKernelGGL(fw_kernel<true>, dim3(G), dim3(FW_THREADS), shm, st, counts, n_nodes, spd, path, in_degree,
                            out_degree, N);
+    } else if (N <= FW_SPLIT_MAX_N && work != nullptr) {
+        int* flags = reinterpret_cast<int*>(work);
+        int* done = flags + (int64_t)G * N;
+        uint32_t* pub = reinterpret_cast<uint32_t*>(done + G);
+        if (hipMemsetAsync(work, 0, ((size_t)G * N + G) * sizeof(int), st) != hipSuccess) return MOBGT_EBADDIM;
+        const int rpw = (N + FW_PARTS - 1) / FW_PARTS, np = (N + 7) & ~7;
+        const size_t shm = ((size_t)rpw * np + np) * sizeof(int16_t);
+        static int cus = 0;
+        if (cus == 0) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fw_split_kernel),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            int dev = 0;
+            hipDeviceProp_t prop;
+            if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return MOBGT_EBADDIM;
+            cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 1;
+        }
+        // the workgroups of a graph wait for each other: never launch more than can be resident at once
+        const int per_cu = shm <= 72 * 1024 ? 2 : 1;                 // (allocation granularity: no tight fits)
+        int chunk = (cus * per_cu) / FW_PARTS;
+        if (chunk < 1) return MOBGT_EBADDIM;
+        for (int g0 = 0; g0 < G; g0 += chunk) {
+            const int gc = G - g0 < chunk ? G - g0 : chunk;
+            hipLaunchKernelGGL(fw_split_kernel, dim3(gc * FW_PARTS), dim3(FW_SPLIT_THREADS), shm, st, counts, n_nodes, spd,
+                               path, in_degree, out_degree, flags, done, pub, N, g0);
+        }
     } else {
         hipLaunchKernelGGL(fw_kernel<false>, dim3(G), dim3(FW_THREADS), 0, st, counts, n_nodes, spd, path, in_degree,
                            out_degree, N);

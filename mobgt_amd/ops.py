@@ -346,7 +346,7 @@ def spd_batched(counts, n_nodes, D):
         rel_pos=torch.empty(G, N, N, dtype=torch.int16, device=dev),
         edge_input=torch.empty(G, N, N, D, 1, dtype=torch.uint8, device=dev),
         in_degree=torch.empty(G, N, dtype=torch.int16, device=dev), out_degree=torch.empty(G, N, dtype=torch.int16, device=dev))
-    work = torch.empty(16, dtype=torch.uint8, device=dev)
+    work = torch.empty(int(_lib.lib().mobgt_spd_workspace_bytes(G, N)), dtype=torch.uint8, device=dev)
     check(_lib.lib().mobgt_spd_batched(_p(counts.contiguous()), _p(n_nodes.contiguous()), _p(out["spd"]), _p(out["path"]),
                                        _p(out["rel_pos"]), _p(out["edge_input"]), _p(out["in_degree"]),
                                        _p(out["out_degree"]), _p(work), G, N, D, _stream()), "mobgt_spd_batched")

@@ -357,6 +357,11 @@ def test_spd_random_and_large(golden_dir):
     # global-memory path (N > 272) and the N > 510 sentinel case
     big = [synth.make_trajectory(rng, 2000, 300, 4)["edge_type"], synth.random_digraph(rng, 290, 0.01)]
     _check_spd(big)
+    # multi-workgroup path: more graphs than one launch holds resident (chunk loop), ragged sizes down to n = 1
+    # (workgroups without rows), a graph count that is not a multiple of 8 (plain block -> graph mapping)
+    many = [synth.make_trajectory(rng, 2000, 280, 3)["edge_type"]]
+    many += [synth.random_digraph(rng, int(n), 0.08) for n in rng.randint(1, 60, size=34)]
+    _check_spd(many)
     z = np.load(os.path.join(golden_dir, "g1_algos.npz"))
     c = z["cycle600/counts"].astype(np.int64)
     out, _ = _spd_case([c])
