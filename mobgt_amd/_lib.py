@@ -71,6 +71,10 @@ def lib():
             raise RuntimeError(
                 f"{LIB_PATH} is missing: the MobGT hot path has no CPU fallback. "
                 "Build it with `python -c 'import __graft_entry__ as g; g.build()'` (needs hipcc).")
+        # torch first: the library must bind to the HIP runtime torch has loaded (its own libamdhip64).  Loaded
+        # before torch it pulls in /opt/rocm's copy, and the process then holds two runtimes -- kernels registered
+        # with one, torch's streams and buffers owned by the other (every launch fails with hipErrorNoDevice).
+        import torch  # noqa: F401
         handle = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(handle, name)          # AttributeError here = header/library mismatch

@@ -35,6 +35,6 @@ print(f"train step {dt*1e3:.2f} ms -> {G/dt:.1f} check-ins/s")
 from torch.profiler import profile, ProfilerActivity
 with profile(activities=[ProfilerActivity.CUDA]) as prof:
     ts.step(0); torch.cuda.synchronize()
-rows = sorted(prof.key_averages(), key=lambda e: -e.device_time_total)[:16]
+rows = sorted(prof.key_averages(), key=lambda e: -e.device_time_total)[:int(os.environ.get("TOP", 16))]
 for e in rows:
     print(f"{e.key[:90]:90s} n={e.count:4d} total_us={e.device_time_total:10.1f}")
