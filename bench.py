@@ -21,6 +21,19 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+# The train step's library GEMMs (tall-skinny, a few hundred rows) are sensitive to hipBLASLt's algorithm choice:
+# let PyTorch's TunableOp pick per shape during the eager warm-up passes that precede graph capture (<= 30 ms of
+# trials per new shape, ~20 s for the ~120 shapes of the default run; measured +8.6 % check-ins/s).  Must be set
+# before torch is imported; `--no-gemm-autotune` (or the variables themselves) turns it off.
+if "--no-gemm-autotune" not in sys.argv:
+    import tempfile
+    os.environ.setdefault("PYTORCH_TUNABLEOP_ENABLED", "1")
+    os.environ.setdefault("PYTORCH_TUNABLEOP_TUNING", "1")
+    os.environ.setdefault("PYTORCH_TUNABLEOP_MAX_TUNING_DURATION_MS", "30")
+    os.environ.setdefault("PYTORCH_TUNABLEOP_VERBOSE", "0")
+    os.environ.setdefault("PYTORCH_TUNABLEOP_FILENAME",
+                          os.path.join(tempfile.gettempdir(), "mobgt_tunableop_%d_pid" + str(os.getpid()) + ".csv"))
+
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
@@ -47,6 +60,7 @@ def parse():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--unfused", action="store_true", help="op-by-op encoder layers (torch ops + HIP attention)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-gemm-autotune", action="store_true", help="leave hipBLASLt's default algorithm choice (no TunableOp)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--seed", type=int, default=1)
     return ap.parse_args()
@@ -275,7 +289,7 @@ def main():
                                    "dropout 0.1, fwd+GradientTailLoss+bwd+allreduce+AdamW" % args.pois,
                        "global_batch": G_total, "per_gpu_batch": args.batch_size,
                        "padded_nodes_per_batch": [s[1] - 1 for s in shapes], "parallelism": f"dp{world}",
-                       "hip_graphs": not args.no_graph, "fused_encoder_layers": not args.unfused,
+                       "gemm_autotune": "torch TunableOp (hipBLASLt algorithm per shape)" if os.environ.get("PYTORCH_TUNABLEOP_ENABLED") == "1" else "off", "hip_graphs": not args.no_graph, "fused_encoder_layers": not args.unfused,
                        "precision": {"attention_mfma_operands": args.dtype, "attn_bias": args.dtype,
                                      "attention_io": "bf16" if io_dt == torch.bfloat16 else "f32",
                                      "gcn_adjacency_product": args.dtype, "library_gemms": args.gemm_dtype if bf16 else "f32",
