@@ -59,6 +59,7 @@ def parse():
                          "and the GCN adjacency product follow --dtype")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--unfused", action="store_true", help="op-by-op encoder layers (torch ops + HIP attention)")
+    ap.add_argument("--no-overlap", action="store_true", help="N > 1: one all-reduce after the whole backward instead of two overlapped buckets")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gemm-autotune", action="store_true", help="leave hipBLASLt's default algorithm choice (no TunableOp)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -224,7 +225,7 @@ def main():
         shapes.append((len(b), b.x.shape[1] + 1))
     torch.cuda.synchronize()
 
-    ts = TrainStep(model, batches, autocast_dtype=torch.bfloat16 if (bf16 and args.gemm_dtype == "bf16" and args.unfused) else None, use_graph=not args.no_graph,
+    ts = TrainStep(model, batches, autocast_dtype=torch.bfloat16 if (bf16 and args.gemm_dtype == "bf16" and args.unfused) else None, use_graph=not args.no_graph, overlap=not args.no_overlap,
                    seed=args.seed)
     ts.prepare()
     for i in range(args.warmup):

@@ -85,9 +85,15 @@ class MultiHeadAttention(nn.Module):
         self.att_dropout = nn.Dropout(attention_dropout_rate)
         self.output_layer = nn.Linear(num_heads * att_size, hidden_size)
         _layer_counter[0] += 1
-        self._seed_salt = (_layer_counter[0] * 0x9E3779B97F4A7C15) & 0x7FFFFFFFFFFFFFFF
+        self.set_layer_index(_layer_counter[0])     # stand-alone layers: a process-wide count; models renumber 1..L
         self._pack_cache = None
         self.seed_dev = None            # optional device int64 scalar: advanced by the trainer each step
+
+    def set_layer_index(self, index):
+        """Dropout masks are a pure function of (seed, step, layer index, element): a model numbers its layers
+        1..L so that two instances built the same way draw the same masks."""
+        self._layer_index = int(index)
+        self._seed_salt = (self._layer_index * 0x9E3779B97F4A7C15) & 0x7FFFFFFFFFFFFFFF
 
     def fuse_qkv_storage(self):
         """Make linear_q/k/v.weight (and .bias) views of one [3C, C] (and [3C]) tensor so that the QKV projection
@@ -146,7 +152,6 @@ class MultiHeadAttention(nn.Module):
         return x
 
 
-_fused_layer_ids = [0]
 
 
 def fused_layer_forward(layer, variant, x, attn_bias, n1, nx):
@@ -178,10 +183,7 @@ def fused_layer_forward(layer, variant, x, attn_bias, n1, nx):
     seed = mha._seed_salt
     if (p > 0 or p_att > 0) and mha.seed_dev is None:
         seed = (seed + int(torch.randint(0, 2 ** 31 - 1, (1,)).item())) & 0x7FFFFFFFFFFFFFFF
-    if not hasattr(layer, "_fused_id"):
-        _fused_layer_ids[0] += 1
-        layer._fused_id = _fused_layer_ids[0]
-    cfg = LayerConfig(variant, mha.num_heads, mha.scale, p, p_att, seed, mha.seed_dev, layer._fused_id * 8, pack, act)
+    cfg = LayerConfig(variant, mha.num_heads, mha.scale, p, p_att, seed, mha.seed_dev, mha._layer_index * 8, pack, act)
     params = (mha.linear_q.weight, mha.linear_q.bias, mha.linear_k.weight, mha.linear_k.bias, mha.linear_v.weight,
               mha.linear_v.bias, mha.output_layer.weight, mha.output_layer.bias, n1.weight, n1.bias, nx.weight, nx.bias,
               layer.ffn.layer1.weight, layer.ffn.layer1.bias, layer.ffn.layer2.weight, layer.ffn.layer2.bias)
@@ -260,8 +262,9 @@ class Graphormer(nn.Module):
         self.input_dropout = nn.Dropout(intput_dropout_rate)
         self.layers = nn.ModuleList([EncoderLayer(hidden_dim, ffn_dim, dropout_rate, attention_dropout_rate, num_heads)
                                      for _ in range(n_layers)])
-        for layer in self.layers:
+        for li, layer in enumerate(self.layers):
             layer.act_dtype, layer.fused = act_dtype, fused_layers
+            layer.self_attention.set_layer_index(li + 1)
         self.final_ln = nn.LayerNorm(hidden_dim)
         self.downstream_out_proj = nn.Linear(hidden_dim, num_class)
         self.graph_token = nn.Embedding(1, hidden_dim)

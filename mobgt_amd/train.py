@@ -44,11 +44,18 @@ class FlatGrads:
         for p in self.params:
             p.grad = None
 
-    def gather(self):
-        """After backward: one multi-tensor copy of all gradients into the flat buffer, then re-attach."""
-        src = [p.grad if p.grad is not None else torch.zeros_like(v) for p, v in zip(self.params, self.views)]
-        torch._foreach_copy_(self.views, src)
-        self.attach()
+    def gather(self, start=0, stop=None, grads=None):
+        """After backward: one multi-tensor copy of the gradients of params[start:stop] into the flat buffer
+        (`grads`: explicit gradient tensors, e.g. from torch.autograd.grad), then re-attach those views."""
+        stop = len(self.params) if stop is None else stop
+        ps, vs = self.params[start:stop], self.views[start:stop]
+        if grads is None:
+            grads = [p.grad for p in ps]
+        src = [g if g is not None else torch.zeros_like(v) for g, v in zip(grads, vs)]
+        if src:
+            torch._foreach_copy_(vs, src)
+        for p, v in zip(ps, vs):
+            p.grad = v
 
     def all_reduce_mean(self, group=None):
         """mean of the gradients over ranks (DDP semantics); no-op for world size 1."""
@@ -57,11 +64,27 @@ class FlatGrads:
             self.flat.div_(dist.get_world_size(group))
 
 
+def head_parameters(model, used):
+    """The used parameters of `model.head_modules` (gradient complete once the backward has reached the encoder
+    output), in `used` order; [] when the model does not declare a head."""
+    names = getattr(model, "head_modules", ())
+    ids = set()
+    for n in names:
+        m = getattr(model, n, None)
+        if m is not None:
+            ids |= {id(p) for p in m.parameters()}
+    return [p for p in used if id(p) in ids]
+
+
 def flat_order(model, used):
-    """Order of the used parameters inside the flat buffers: every attention's q/k/v weights (then biases) are
-    adjacent, so that its fused [3C, C] projection storage is one slice of the flat parameter buffer."""
+    """Order of the used parameters inside the flat buffers: the head's parameters first (one contiguous bucket
+    whose all-reduce can start early), then every attention's q/k/v weights (then biases) adjacent, so that its
+    fused [3C, C] projection storage is one slice of the flat parameter buffer, then the rest."""
     used_ids = {id(p) for p in used}
     order, seen = [], set()
+    for p in head_parameters(model, used):
+        order.append(p)
+        seen.add(id(p))
     for m in model.modules():
         if all(hasattr(m, a) for a in ("linear_q", "linear_k", "linear_v")):
             grp = [m.linear_q.weight, m.linear_k.weight, m.linear_v.weight, m.linear_q.bias, m.linear_k.bias, m.linear_v.bias]
@@ -123,7 +146,7 @@ def broadcast_parameters(model, src=0):
 
 
 class TrainStep:
-    def __init__(self, model, batches, autocast_dtype=None, use_graph=True, seed=1):
+    def __init__(self, model, batches, autocast_dtype=None, use_graph=True, seed=1, overlap=True):
         self.model = model
         self.batches = batches
         self.autocast_dtype = autocast_dtype
@@ -147,6 +170,8 @@ class TrainStep:
             used = used_parameters(model, lambda: self._loss(batches[0]))
         used = flat_order(model, used)
         self.flat = FlatGrads(used)
+        self.n_head = len(head_parameters(model, used))              # params[:n_head] = the early bucket
+        self.n_head_elems = sum(p.numel() for p in used[:self.n_head])
         self.flat_params = FlatParams(model, used)
         self.flat_params.tensor.grad = self.flat.flat
         self.lr_dev = torch.tensor(float(model.peak_lr), dtype=torch.float32, device=dev)
@@ -159,6 +184,12 @@ class TrainStep:
         self.graphs = {}
         self.loss_out = torch.zeros((), device=dev)
         self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        # Data parallel: split the backward at the encoder output so that the head bucket's all-reduce (61 % of the
+        # bytes, ready after ~20 kernels) runs on RCCL's stream while the rest of the backward is still executing.
+        # (overlap="force": the two-phase path at world size 1 as well -- tests)
+        self.overlap = bool(overlap and use_graph and (self.world > 1 or overlap == "force") and self.n_head > 0
+                            and hasattr(model, "_enc_out"))
+        self.graphs_b, self._g_enc = {}, {}
 
     def _on_stream(self):
         import contextlib
@@ -199,6 +230,24 @@ class TrainStep:
         self.flat.gather()
         self.loss_out.copy_(loss.detach())
 
+    # ---- the same step in two phases (data parallel): [forward, loss, head backward] | [rest of the backward]
+    def _phase_a(self, batch, i):
+        self.flat.release()
+        self.arena.reset()
+        self.seed_dev.add_(1)
+        loss = self._loss(batch)
+        enc = self.model._enc_out
+        head = self.flat.params[:self.n_head]
+        grads = torch.autograd.grad(loss, head + [enc], allow_unused=True)     # frees only the nodes it ran
+        self.flat.gather(0, self.n_head, grads=list(grads[:-1]))
+        self._g_enc[i] = (enc, grads[-1])
+        self.loss_out.copy_(loss.detach())
+
+    def _phase_b(self, i):
+        enc, g_enc = self._g_enc[i]
+        torch.autograd.backward([enc], [g_enc])
+        self.flat.gather(self.n_head, None)
+
     def _capture(self, i):
         batch = self.batches[i]
         with self._on_stream():                    # warm-up on the side stream (allocator, lazy inits)
@@ -207,8 +256,18 @@ class TrainStep:
         g = torch.cuda.CUDAGraph()
         # private memory pool per graph: the graphs are replayed in data order, not capture order, and a shared
         # pool is only safe for capture-order replay (measured: NaNs on the second lap with a shared pool)
-        with torch.cuda.graph(g, pool=self.pool if os.environ.get("MOBGT_SHARED_POOL") else None, stream=self.stream):
-            self._fwd_bwd(batch)
+        if not self.overlap:
+            with torch.cuda.graph(g, pool=self.pool if os.environ.get("MOBGT_SHARED_POOL") else None, stream=self.stream):
+                self._fwd_bwd(batch)
+            return g
+        # two graphs over ONE autograd graph: phase B is captured right after phase A and replays its kernels on the
+        # activations phase A's replay leaves at the same addresses (A's private pool; nothing else writes there)
+        with torch.cuda.graph(g, stream=self.stream):
+            self._phase_a(batch, i)
+        gb = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gb, stream=self.stream):
+            self._phase_b(i)
+        self.graphs_b[i] = gb
         return g
 
     def prepare(self):
@@ -227,12 +286,25 @@ class TrainStep:
 
     def step(self, i):
         """One optimizer step on pre-collated batch i (model_fqandtoyo.py:1434-1478 + optimizer + scheduler)."""
-        if self.use_graph:
-            self.graphs[i % len(self.batches)].replay()
+        if self.overlap:
+            j = i % len(self.batches)
+            na = self.n_head_elems
+            self.graphs[j].replay()
+            if self.world > 1:
+                wa = dist.all_reduce(self.flat.flat[:na], op=dist.ReduceOp.SUM, async_op=True)   # overlaps phase B
+            self.graphs_b[j].replay()
+            if self.world > 1:
+                wb = dist.all_reduce(self.flat.flat[na:], op=dist.ReduceOp.SUM, async_op=True)
+                wa.wait()
+                wb.wait()
+                self.flat.flat.div_(self.world)
         else:
-            self._fwd_bwd(self.batches[i % len(self.batches)])
-        if self.world > 1:
-            self.flat.all_reduce_mean()
+            if self.use_graph:
+                self.graphs[i % len(self.batches)].replay()
+            else:
+                self._fwd_bwd(self.batches[i % len(self.batches)])
+            if self.world > 1:
+                self.flat.all_reduce_mean()
         if self.use_graph:
             self.opt_graph.replay()
         else:

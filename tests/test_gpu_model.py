@@ -282,3 +282,40 @@ def test_hop_table_kernel_matches_torch_expression(fp16):
     np.testing.assert_allclose(c.grad.cpu().numpy(), a.grad.numpy(), **tol)
     np.testing.assert_allclose(d.grad.cpu().numpy(), b.grad.numpy(), **tol)
     assert float(c.grad[0].abs().max()) == 0.0 and float(d.grad.reshape(-1, H, H)[D:].abs().max()) == 0.0
+
+
+def test_two_phase_backward_matches_single_phase():
+    """train.TrainStep's data-parallel path splits the backward at the encoder output (head bucket all-reduced
+    while the rest runs).  Same gradients and the same parameters after two steps as the single-graph step."""
+    from mobgt_amd.model_fqandtoyo import Graphormer
+    from mobgt_amd.train import TrainStep
+    # (learning rate ~0: Adam's first steps are sign-like, so the f32-atomics ordering noise of the gradients would
+    # otherwise flip individual updates and make the two runs drift apart by ~1e-3 in the loss)
+    args = dict(n_layers=2, num_heads=8, hidden_dim=64, dropout_rate=0.1, intput_dropout_rate=0.1, weight_decay=0.0,
+                ffn_dim=128, warmup_updates=10, tot_updates=100, peak_lr=1e-12, end_lr=1e-13, edge_type="multi_hop",
+                multi_hop_max_dist=20, attention_dropout_rate=0.1, dataset_name="foursquaregraph")
+    uni = synth.make_universe(P=400, n_cat=12, n_user=1080, seed=3)
+    nb, _, table = make_bin_table(uni.distance)
+    coll = DeviceCollator(DEV, bin_table=table)
+    batches = [coll(synth.make_batch_of_trajectories(seed=10 + i, G=4, P=400, n_user=1080, cat_of_poi=uni.cat_of_poi))
+               for i in range(2)]
+    res = {}
+    for mode in (False, "again", "force"):
+        torch.manual_seed(0)
+        model = Graphormer(universe=uni, num_bins=nb + 2, bias_dtype=torch.bfloat16, gcn_dtype=torch.bfloat16,
+                           act_dtype=torch.bfloat16, **args).to(DEV)
+        ts = TrainStep(model, batches, use_graph=True, seed=5, overlap="force" if mode == "force" else False)
+        ts.prepare()
+        assert ts.overlap == (mode == "force")
+        losses = []
+        for i in range(3):
+            losses.append(float(ts.step(i)))
+        res[mode] = (losses, ts.flat.flat.clone(), ts.flat_params.tensor.detach().clone())
+    (l0, g0, p0), (l1, g1, p1) = res[False], res["force"]
+    print("single", l0, "again", res["again"][0], "two-phase", l1)
+    np.testing.assert_allclose(l0, res["again"][0], rtol=1e-5)
+    np.testing.assert_allclose(l0, l1, rtol=1e-5)
+    scale = float(g0.abs().max())
+    np.testing.assert_allclose(g1.cpu().numpy(), g0.cpu().numpy(), atol=1e-4 * scale)     # atomics order only
+    np.testing.assert_allclose(p1.cpu().numpy(), p0.cpu().numpy(), atol=1e-9)
+    assert float(g0.abs().max()) > 0
