@@ -614,6 +614,15 @@ extern "C" int mobgt_colsum(const void* g, float* out, int64_t R, int C, int act
 //   p = sigmoid(z);  loss = mean( -alpha*(1-p)*onehot*log(p) - (1-onehot)*p*log(1-p) )      (beta = k = 1)
 // The reference evaluates it as ~12 elementwise kernels forward and ~15 backward over [G, P+1].
 namespace {
+constexpr int GTL_MAX_BLOCKS = 1024;
+// per-workgroup partial sums and the arrival ticket of the last-workgroup reduction below (stream-ordered use)
+__device__ float gtl_partial[GTL_MAX_BLOCKS];
+__device__ unsigned int gtl_ticket = 0;
+
+// *loss is OVERWRITTEN by the last workgroup to arrive (sum of the per-workgroup partials in index order): no
+// zero-fill of *loss before the launch.  A hipMemsetAsync(loss, 0, 4) node in front of an atomicAdd version was
+// observed not to take effect inside replayed hipGraphs (the scalar kept a stale value and the loss read
+// "stale + loss", found in the 2-rank run), so the kernel no longer depends on any prior state of *loss.
 __global__ __launch_bounds__(256) void gtl_kernel(const float* __restrict__ z, const int64_t* __restrict__ target,
                                                   float* __restrict__ dz, float* __restrict__ loss, int64_t G, int64_t V,
                                                   float alpha) {
@@ -641,9 +650,30 @@ __global__ __launch_bounds__(256) void gtl_kernel(const float* __restrict__ z, c
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) acc += __shfl_xor(acc, o, 64);
     __shared__ float part[4];
+    __shared__ bool last;
     if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
     __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(loss, (part[0] + part[1] + part[2] + part[3]) * inv_n);
+    if (threadIdx.x == 0) {
+        __hip_atomic_store(&gtl_partial[blockIdx.x], part[0] + part[1] + part[2] + part[3], __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+        __threadfence();
+        const unsigned int t = __hip_atomic_fetch_add(&gtl_ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        last = t == gridDim.x - 1;
+    }
+    __syncthreads();
+    if (!last) return;
+    float tot = 0.f;
+    for (unsigned int b = threadIdx.x; b < gridDim.x; b += 256)
+        tot += __hip_atomic_load(&gtl_partial[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) tot += __shfl_xor(tot, o, 64);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = tot;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        *loss = (part[0] + part[1] + part[2] + part[3]) * inv_n;
+        __hip_atomic_store(&gtl_ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 }
 }  // namespace
 
@@ -651,10 +681,8 @@ extern "C" int mobgt_gradient_tail_loss(const float* logits, const int64_t* targ
                                         int64_t G, int64_t V, float alpha, void* stream) {
     if (G <= 0 || V <= 0) return MOBGT_EBADDIM;
     hipStream_t st = (hipStream_t)stream;
-    hipError_t e = hipMemsetAsync(loss, 0, sizeof(float), st);
-    if (e != hipSuccess) return (int)e;
     const int64_t n = G * V;
-    const unsigned blocks = (unsigned)((n + 1023) / 1024 < 1024 ? (n + 1023) / 1024 : 1024);
+    const unsigned blocks = (unsigned)((n + 1023) / 1024 < GTL_MAX_BLOCKS ? (n + 1023) / 1024 : GTL_MAX_BLOCKS);
     hipLaunchKernelGGL(gtl_kernel, dim3(blocks ? blocks : 1), dim3(256), 0, st, logits, targets, dlogits, loss, G, V, alpha);
     return (int)hipGetLastError();
 }
