@@ -134,7 +134,7 @@ extern "C" int mobgt_embed_scatter_add(float* const* d_tables_host, const void* 
     }
     p.n_tables = n_tables; p.dout = dout; p.R = R; p.C = C; p.ld = ld_dout;
     hipStream_t st = (hipStream_t)stream;
-    if (C <= 64 * RUN_MAXK && R >= 256) {
+    if (C <= 64 * RUN_MAXK && R >= 4096) {            // (few rows: atomics do not pile up, and 16 sequential rows per wave cost latency)
         const dim3 grid((unsigned)((R + 4 * RUN_ROWS - 1) / (4 * RUN_ROWS))), block(256);
         if (idx_dtype == MOBGT_I64) hipLaunchKernelGGL(scatter_add_runs_kernel<int64_t>, grid, block, 0, st, p);
         else if (idx_dtype == MOBGT_I32) hipLaunchKernelGGL(scatter_add_runs_kernel<int32_t>, grid, block, 0, st, p);
