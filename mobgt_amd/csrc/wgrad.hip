@@ -60,13 +60,13 @@ struct Slab {
     }
 };
 
-__global__ __launch_bounds__(NWAVE * 64) void wgrad_kernel(const WgradParams p) {
+__device__ __forceinline__ void wgrad_body(const WgradParams& p, const int tile, const int split, const int nsplit) {
     __shared__ float part[NWAVE / 2][TILE * TILE];     // 32 KB: the upper 8 waves hand their tiles to the lower 8 first
     __shared__ float colpart[NWAVE][TILE];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i = lane & 15, kq = lane >> 4;
-    const int m0 = (blockIdx.x / p.tiles_n) * TILE, n0 = (blockIdx.x % p.tiles_n) * TILE;
-    const int k0 = blockIdx.y * p.k_per_wg;
+    const int m0 = (tile / p.tiles_n) * TILE, n0 = (tile % p.tiles_n) * TILE;
+    const int k0 = split * p.k_per_wg;
     const int k1 = min(p.R, k0 + p.k_per_wg);
     const bool want_db = p.db != nullptr && n0 == 0;
     const bool m_ok = m0 + 2 * i < p.M, n_ok = n0 + 2 * i < p.N;      // M, N even: a pair is in or out together
@@ -132,18 +132,87 @@ __global__ __launch_bounds__(NWAVE * 64) void wgrad_kernel(const WgradParams p) 
         for (int w = 0; w < NWAVE / 2; ++w) s += part[w][e];
         if (m0 + r < p.M && n0 + c < p.N) {
             float* dst = p.dw + (int64_t)(m0 + r) * p.ldw + n0 + c;
-            if (gridDim.y > 1) atomicAdd(dst, s); else *dst += s;
+            if (nsplit > 1) atomicAdd(dst, s); else *dst += s;
         }
         if (want_db && e < TILE && m0 + e < p.M) {
             float t = 0.f;
 #pragma unroll
             for (int w = 0; w < NWAVE; ++w) t += colpart[w][e];
-            if (gridDim.y > 1) atomicAdd(p.db + m0 + e, t); else p.db[m0 + e] += t;
+            if (nsplit > 1) atomicAdd(p.db + m0 + e, t); else p.db[m0 + e] += t;
         }
     }
 }
 
+__global__ __launch_bounds__(NWAVE * 64) void wgrad_kernel(const WgradParams p) {
+    wgrad_body(p, blockIdx.x, blockIdx.y, gridDim.y);
+}
+
+// Up to four independent problems in ONE launch (the four Linear layers of an encoder layer: nothing depends on a
+// weight gradient, so they are all issued at the end of the layer's backward).  A kernel inside a replayed graph
+// costs ~4.5 us whatever it does; three fewer launches per layer are worth more than any tuning of the kernel.
+constexpr int WG_GROUP = 4;
+struct WgradGroup {
+    WgradParams p[WG_GROUP];
+    int first[WG_GROUP + 1];           // first workgroup of each problem; first[n] = total
+    int tiles[WG_GROUP], splits[WG_GROUP];
+    int n;
+};
+
+__global__ __launch_bounds__(NWAVE * 64) void wgrad_group_kernel(const WgradGroup grp) {
+    int q = 0;
+#pragma unroll
+    for (int t = 1; t < WG_GROUP; ++t)
+        if (t < grp.n && (int)blockIdx.x >= grp.first[t]) q = t;
+    const int local = blockIdx.x - grp.first[q];
+    wgrad_body(grp.p[q], local % grp.tiles[q], local / grp.tiles[q], grp.splits[q]);
+}
+
+int fill_problem(WgradParams& p, const void* g, int64_t ldg, const void* x, int64_t ldx, float* dw, int64_t ldw, float* db,
+                 int64_t R, int M, int N, int target_wgs, int* tiles_out, int* splits_out) {
+    if (R <= 0 || M <= 0 || N <= 0 || (M & 1) || (N & 1) || (ldg & 1) || (ldx & 1) || R > 0x7fffffff) return MOBGT_EBADDIM;
+    if (((uintptr_t)g & 3) || ((uintptr_t)x & 3)) return MOBGT_EALIGN;
+    p.g = reinterpret_cast<const uint16_t*>(g); p.ldg = ldg;
+    p.x = reinterpret_cast<const uint16_t*>(x); p.ldx = ldx;
+    p.dw = dw; p.ldw = ldw; p.db = db;
+    p.R = (int)R; p.M = M; p.N = N;
+    const int tiles_m = (M + TILE - 1) / TILE;
+    p.tiles_n = (N + TILE - 1) / TILE;
+    const int tiles = tiles_m * p.tiles_n;
+    const int slab = NWAVE * KSTEP;
+    int splits = target_wgs / tiles;
+    const int max_splits = (int)((R + slab - 1) / slab);
+    if (splits > max_splits) splits = max_splits;
+    if (splits < 1) splits = 1;
+    p.k_per_wg = (int)(((R + splits - 1) / splits + slab - 1) / slab) * slab;
+    *splits_out = (int)((R + p.k_per_wg - 1) / p.k_per_wg);
+    *tiles_out = tiles;
+    return 0;
+}
+
 }  // namespace
+
+extern "C" int mobgt_linear_wgrad_group(int n, const void* const* g, const int64_t* ldg, const void* const* x,
+                                        const int64_t* ldx, float* const* dw, const int64_t* ldw, float* const* db,
+                                        int64_t R, const int* M, const int* N, int act_dtype, void* stream) {
+    if (act_dtype != MOBGT_BF16) return MOBGT_EDTYPE;
+    if (n < 1 || n > WG_GROUP) return MOBGT_EBADDIM;
+    if (R == 0) return 0;
+    WgradGroup grp;
+    grp.n = n;
+    int total = 0;
+    for (int q = 0; q < n; ++q) {
+        // the problems share the chip: aim at ~256 workgroups for all of them together
+        const int rc = fill_problem(grp.p[q], g[q], ldg[q], x[q], ldx[q], dw[q], ldw[q], db ? db[q] : nullptr, R, M[q], N[q],
+                                    256 / n, &grp.tiles[q], &grp.splits[q]);
+        if (rc) return rc;
+        grp.first[q] = total;
+        total += grp.tiles[q] * grp.splits[q];
+    }
+    for (int q = n; q <= WG_GROUP; ++q) grp.first[q] = total;
+    for (int q = n; q < WG_GROUP; ++q) { grp.tiles[q] = 1; grp.splits[q] = 1; grp.p[q] = grp.p[0]; }
+    hipLaunchKernelGGL(wgrad_group_kernel, dim3(total), dim3(NWAVE * 64), 0, (hipStream_t)stream, grp);
+    return (int)hipGetLastError();
+}
 
 extern "C" int mobgt_linear_wgrad(const void* g, int64_t ldg, const void* x, int64_t ldx, float* dw, int64_t ldw,
                                   float* db, int64_t R, int M, int N, int act_dtype, void* stream) {

@@ -43,6 +43,42 @@ def _wgrad_hip(dtype, M, N, R):
     return dtype == torch.bfloat16 and M % 2 == 0 and N % 2 == 0 and (M * N <= 131072 or R <= 4096)
 
 
+class _WgradBatch:
+    """Collects the weight-gradient problems of one layer's backward and issues those that go to csrc/wgrad.hip as
+    ONE grouped launch at the end (nothing downstream depends on a weight gradient)."""
+
+    def __init__(self):
+        self.items = []
+
+    def add(self, g, x, db=None):
+        """-> the dW tensor (filled when `flush` runs), or an immediately computed one for the library path."""
+        if not _wgrad_hip(g.dtype, g.shape[1], x.shape[1], g.shape[0]):
+            return _wgrad(g, x, db)
+        dw = ops.zeros_f32((g.shape[1], x.shape[1]), g.device)
+        self.items.append((g, x, dw, db))
+        return dw
+
+    def flush(self):
+        it = self.items
+        if not it:
+            return
+        n = len(it)
+        R = it[0][0].shape[0]
+        vp, i64, ci = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int
+        garr = (vp * n)(*[t[0].data_ptr() for t in it])
+        xarr = (vp * n)(*[t[1].data_ptr() for t in it])
+        warr = (vp * n)(*[t[2].data_ptr() for t in it])
+        barr = (vp * n)(*[(t[3].data_ptr() if t[3] is not None else None) for t in it])
+        ldg = (i64 * n)(*[t[0].stride(0) for t in it])
+        ldx = (i64 * n)(*[t[1].stride(0) for t in it])
+        ldw = (i64 * n)(*[t[2].shape[1] for t in it])
+        M = (ci * n)(*[t[0].shape[1] for t in it])
+        N = (ci * n)(*[t[1].shape[1] for t in it])
+        check(_lib.lib().mobgt_linear_wgrad_group(n, garr, ldg, xarr, ldx, warr, ldw, barr, R, M, N, _DT[it[0][0].dtype],
+                                                  _stream()), "mobgt_linear_wgrad_group")
+        self.items = []
+
+
 def _wgrad(g, x, db=None):
     """Weight gradient g^T @ x (fp32) of a Linear layer; bf16 operands go to the split-K MFMA kernel
     (csrc/wgrad.hip), which also accumulates the bias gradient g.sum(0) into `db` when given."""
@@ -208,24 +244,26 @@ class _FusedLayerFn(torch.autograd.Function):
             _k1_bwd(None, dout, None, x2, stats[4], stats[5], nxw, dx2, df, dnxw, dnxb, db2, R, C, cfg.p, seed, sd,
                     salt + 2, act)
         dh = df @ s_w2
-        dw2 = _wgrad(df, h)
+        wb = _WgradBatch()
+        dw2 = wb.add(df, h)
         du = torch.empty_like(u)
         db1_in_wgrad = _wgrad_hip(A, F, C, R)                         # then b1's gradient rides on the dW1 kernel
         check(_lib.lib().mobgt_gelu_bwd_colsum(_p(dh), _p(u), _p(du), _p(None if db1_in_wgrad else db1), R, F, act,
                                                _stream()), "mobgt_gelu_bwd_colsum")
         dz = du @ s_w1
-        dw1 = _wgrad(du, z, db=db1 if db1_in_wgrad else None)
+        dw1 = wb.add(du, z, db=db1 if db1_in_wgrad else None)
         dx1 = torch.empty(R, C, dtype=torch.float32, device=dev)
         dy = torch.empty(R, C, dtype=A, device=dev)
         _k1_bwd(dz, None, dx2, x1, stats[2], stats[3], n1w, dx1, dy, dn1w, dn1b, dbo, R, C, cfg.p, seed, sd, salt + 1, act)
         da = (dy @ s_wo).view(G, T, C)
-        dwo = _wgrad(dy, a.view(R, C))
+        dwo = wb.add(dy, a.view(R, C))
         dqkv = torch.empty(G, T, 3 * C, dtype=A, device=dev)
         q, k, v = qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:]
         ops._attn_bwd(q, k, v, a, lse, da, dqkv[..., :C], dqkv[..., C:2 * C], dqkv[..., 2 * C:], cfg.pack, cfg.scale,
                       cfg.p_att, seed ^ (salt * 0x9E3779B1), sd)
         dqkv2 = dqkv.view(R, 3 * C)
-        dwqkv = _wgrad(dqkv2, xa, db=dbqkv)
+        dwqkv = wb.add(dqkv2, xa, db=dbqkv)
+        wb.flush()
         if stock:                                                     # back through self_attention_norm
             dz0 = dqkv2 @ s_wqkv
             dx = torch.empty(R, C, dtype=torch.float32, device=dev)
