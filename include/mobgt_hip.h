@@ -276,8 +276,8 @@ int mobgt_colsum(const void* g, float* out, int64_t R, int C, int act_dtype, voi
  * f32 atomics into dw/db, which the caller zero-initialises (or pre-loads with a gradient to accumulate into). */
 int mobgt_linear_wgrad(const void* g, int64_t ldg, const void* x, int64_t ldx, float* dw, int64_t ldw, float* db,
                        int64_t R, int M, int N, int act_dtype, void* stream);
-/* The same for n <= 4 independent Linear layers over the same R rows in ONE launch (host arrays of n entries each;
- * db may be NULL, or hold NULL entries): the four weight gradients of an encoder layer. */
+/* The same for n <= 32 independent Linear layers over the same R rows in ONE launch (host arrays of n entries each;
+ * db may be NULL, or hold NULL entries): the weight gradients of all encoder layers of a backward pass. */
 int mobgt_linear_wgrad_group(int n, const void* const* g, const int64_t* ldg, const void* const* x, const int64_t* ldx,
                              float* const* dw, const int64_t* ldw, float* const* db, int64_t R, const int* M,
                              const int* N, int act_dtype, void* stream);

@@ -147,10 +147,10 @@ __global__ __launch_bounds__(NWAVE * 64) void wgrad_kernel(const WgradParams p) 
     wgrad_body(p, blockIdx.x, blockIdx.y, gridDim.y);
 }
 
-// Up to four independent problems in ONE launch (the four Linear layers of an encoder layer: nothing depends on a
-// weight gradient, so they are all issued at the end of the layer's backward).  A kernel inside a replayed graph
+// Up to 32 independent problems in ONE launch (the four Linear layers of every encoder layer: nothing depends on a
+// weight gradient, so they are all issued together at the end of the backward pass).  A kernel inside a replayed graph
 // costs ~4.5 us whatever it does; three fewer launches per layer are worth more than any tuning of the kernel.
-constexpr int WG_GROUP = 4;
+constexpr int WG_GROUP = 32;
 struct WgradGroup {
     WgradParams p[WG_GROUP];
     int first[WG_GROUP + 1];           // first workgroup of each problem; first[n] = total

@@ -45,7 +45,10 @@ def _wgrad_hip(dtype, M, N, R):
 
 class _WgradBatch:
     """Collects the weight-gradient problems of one layer's backward and issues those that go to csrc/wgrad.hip as
-    ONE grouped launch at the end (nothing downstream depends on a weight gradient)."""
+    ONE grouped launch at the end of that backward (nothing downstream depends on a weight gradient).  Deferring
+    further -- one launch for all layers when the autograd engine finishes the pass -- was tried and dropped: the
+    engine's AccumulateGrad clones a gradient that anything else still references (here: the pending list), i.e.
+    it would copy the buffers before they are filled."""
 
     def __init__(self):
         self.items = []
