@@ -224,6 +224,19 @@ int mobgt_node_index(const int64_t* x, int64_t xs_g, int64_t xs_n, const float* 
                      int64_t ts_n, const int64_t* poi2cat, int64_t* idx, float* real, int G, int N, int rows_only,
                      void* stream);
 
+/* nn.Linear on a handful of rows (G <= 16, K <= 512, K % 4 == 0; f32): y [G,V] = x [G,K] w[V,K]^T + b[V] -- the
+ * classifier head out_proj on the graph tokens (model_fqandtoyo.py:1394) -- and its backward: dx [G,K] (or NULL),
+ * dw [V,K] and db [V] (or NULL), all OVERWRITTEN.  Each product streams w / writes dw exactly once. */
+int mobgt_skinny_linear_fwd(const float* x, const float* w, const float* b, float* y, int G, int K, int V, void* stream);
+int mobgt_skinny_linear_bwd(const float* dy, const float* x, const float* w, float* dx, float* dw, float* db, int G, int K,
+                            int V, void* stream);
+
+/* Rows of a bf16 matrix a [*, ld] gathered and transposed in one pass: out_rows [R, C] = a[rows[j], 0:C] and
+ * out_t [C, R] = out_rows^T (the operands of the "rows only" last GCN layer, modelGNN.py:38-44 restricted to the
+ * batch's POI rows).  R, C, ld multiples of 8; pointers 16-byte aligned. */
+int mobgt_gather_rows_t(const void* a, int64_t ld, const int64_t* rows, void* out_rows, void* out_t, int R, int C,
+                        void* stream);
+
 /* Evaluation (model_fqandtoyo.py:48-90 get_acc, :122-131 MRR_metric): for every row of scores [G,V] f32 the number
  * of classes ranked ahead of target[g] (class id, int64): rank[2g] counts strictly larger scores plus equal scores
  * at a LOWER index (a stable descending top-k: "target is in the top k" <=> rank[2g] < k, its position is rank[2g]);

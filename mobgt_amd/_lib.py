@@ -48,6 +48,9 @@ SIGNATURES = {
     "mobgt_hop_table_fwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "mobgt_hop_table_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "mobgt_target_rank": (_i, [_vp, _vp, _vp, _i64, _i64, _vp]),
+    "mobgt_skinny_linear_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    "mobgt_skinny_linear_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    "mobgt_gather_rows_t": (_i, [_vp, _i64, _vp, _vp, _vp, _i, _i, _vp]),
     "mobgt_node_index": (_i, [_vp, _i64, _i64, _vp, _i64, _i64, _vp, _vp, _vp, _i, _i, _i, _vp]),
 }
 

@@ -1,0 +1,201 @@
+// y = x W^T + b for a handful of rows (G <= 16) and a wide output: the classifier head of MobGT,
+// out_proj = nn.Linear(448, P+1) on the G graph tokens (model_fqandtoyo.py:1394; f32).  A GEMM with M = 16 is a
+// bandwidth problem -- every weight is used 16 times -- that the library runs at 0.5 TB/s (28 us forward, 29 + 26 us
+// for the two backward products at V = 7857); these kernels stream W once per product.
+//   forward : one wave per output column v; lane l keeps its slice of all G rows of x in registers, reads its slice
+//             of W[v,:] as 16-byte pieces, and the G partial dot products are combined by a butterfly reduce-scatter.
+//   dx      : a workgroup owns 8 columns k of dx and streams the 32-byte column block W[:, k0:k0+8] over all v
+//             (dy staged through LDS in chunks); 32 v-lanes per column are combined in LDS.  No atomics.
+//   dW, db  : a workgroup owns 16 rows v: dW[v,k] = sum_g dy[g,v] x[g,k] with x in registers, coalesced stores.
+#include "common.h"
+#include "mobgt_hip.h"
+
+namespace {
+
+constexpr int GMAX = 16;
+constexpr int KCH = 2;                       // K <= 512: lane l owns k = 4l + 256c .. +3, c < KCH
+
+__device__ __forceinline__ void reduce16(float (&v)[GMAX], int lane) {
+    // afterwards lane l holds in v[0] the wave-wide sum of value (l >> 2) & 15
+    int w = GMAX / 2;
+#pragma unroll
+    for (int bit = 32; w >= 1; bit >>= 1, w >>= 1) {
+        const bool up = (lane & bit) != 0;
+#pragma unroll
+        for (int t = 0; t < w; ++t) {
+            const float send = up ? v[t] : v[t + w];
+            const float keep = up ? v[t + w] : v[t];
+            v[t] = keep + __shfl_xor(send, bit, 64);
+        }
+    }
+    v[0] += __shfl_xor(v[0], 2, 64);
+    v[0] += __shfl_xor(v[0], 1, 64);
+}
+
+__global__ __launch_bounds__(256) void skinny_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                         const float* __restrict__ b, float* __restrict__ y, int G, int K, int V) {
+    const int lane = threadIdx.x & 63;
+    const int wave_id = blockIdx.x * 4 + (threadIdx.x >> 6), n_waves = gridDim.x * 4;
+    float xr[GMAX][KCH][4];
+#pragma unroll
+    for (int g = 0; g < GMAX; ++g)
+#pragma unroll
+        for (int c = 0; c < KCH; ++c) {
+            const int k = 4 * lane + 256 * c;
+            float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (g < G && k < K) t = *reinterpret_cast<const float4*>(x + (int64_t)g * K + k);
+            xr[g][c][0] = t.x; xr[g][c][1] = t.y; xr[g][c][2] = t.z; xr[g][c][3] = t.w;
+        }
+    // the row of W for the NEXT column is requested before the current one is consumed (a wave handles ~8 columns
+    // one after the other: without the prefetch every column paid a full memory round trip)
+    float4 wv[KCH], wn[KCH];
+    auto load_row = [&](int v, float4 (&dst)[KCH]) {
+#pragma unroll
+        for (int c = 0; c < KCH; ++c) {
+            const int k = 4 * lane + 256 * c;
+            dst[c] = (v < V && k < K) ? *reinterpret_cast<const float4*>(w + (int64_t)v * K + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    load_row(wave_id, wv);
+    for (int v = wave_id; v < V; v += n_waves) {
+        load_row(v + n_waves, wn);
+        float acc[GMAX];
+#pragma unroll
+        for (int g = 0; g < GMAX; ++g) {
+            float s = 0.f;
+#pragma unroll
+            for (int c = 0; c < KCH; ++c)
+                s += xr[g][c][0] * wv[c].x + xr[g][c][1] * wv[c].y + xr[g][c][2] * wv[c].z + xr[g][c][3] * wv[c].w;
+            acc[g] = s;
+        }
+        reduce16(acc, lane);
+        const int g = (lane >> 2) & 15;
+        if ((lane & 3) == 0 && g < G) y[(int64_t)g * V + v] = acc[0] + (b ? b[v] : 0.f);
+#pragma unroll
+        for (int c = 0; c < KCH; ++c) wv[c] = wn[c];
+    }
+}
+
+constexpr int DX_KB = 8;                     // columns of dx per workgroup
+constexpr int DX_VL = 32;                    // v-lanes per column (256 threads)
+constexpr int DX_CHUNK = 512;                // rows of dy staged per round
+
+constexpr int DX_SPLIT = 8;                  // workgroups along V per column block (f32 atomics into the zeroed dx)
+
+__global__ __launch_bounds__(256) void skinny_dx_kernel(const float* __restrict__ dy, const float* __restrict__ w,
+                                                        float* __restrict__ dx, int G, int K, int V) {
+    __shared__ float sdy[GMAX][DX_CHUNK];
+    __shared__ float red[DX_VL][DX_KB][GMAX + 1];
+    const int kk = threadIdx.x & (DX_KB - 1), vl = threadIdx.x / DX_KB;
+    const int k = blockIdx.x * DX_KB + kk;
+    float acc[GMAX];
+#pragma unroll
+    for (int g = 0; g < GMAX; ++g) acc[g] = 0.f;
+    const int vper = ((V + DX_SPLIT - 1) / DX_SPLIT + DX_CHUNK - 1) / DX_CHUNK * DX_CHUNK;
+    const int vbeg = blockIdx.y * vper, vstop = min(V, vbeg + vper);
+    for (int v0 = vbeg; v0 < vstop; v0 += DX_CHUNK) {
+        __syncthreads();
+        for (int e = threadIdx.x; e < GMAX * DX_CHUNK; e += 256) {
+            const int g = e / DX_CHUNK, j = e - g * DX_CHUNK;
+            sdy[g][j] = (g < G && v0 + j < vstop) ? dy[(int64_t)g * V + v0 + j] : 0.f;
+        }
+        __syncthreads();
+        float wv[DX_CHUNK / DX_VL];                                    // this thread's 16 rows of the chunk, all in flight
+#pragma unroll
+        for (int i = 0; i < DX_CHUNK / DX_VL; ++i) {
+            const int v = v0 + vl + DX_VL * i;
+            wv[i] = (k < K && v < vstop) ? w[(int64_t)v * K + k] : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < DX_CHUNK / DX_VL; ++i) {
+#pragma unroll
+            for (int g = 0; g < GMAX; ++g) acc[g] += sdy[g][vl + DX_VL * i] * wv[i];
+        }
+    }
+#pragma unroll
+    for (int g = 0; g < GMAX; ++g) red[vl][kk][g] = acc[g];
+    __syncthreads();
+    if (threadIdx.x < DX_KB * GMAX) {
+        const int g = threadIdx.x / DX_KB, k2 = threadIdx.x % DX_KB;
+        float s = 0.f;
+#pragma unroll 8
+        for (int l = 0; l < DX_VL; ++l) s += red[l][k2][g];
+        const int kc = blockIdx.x * DX_KB + k2;
+        if (g < G && kc < K) atomicAdd(&dx[(int64_t)g * K + kc], s);
+    }
+}
+
+constexpr int DW_ROWS = 16;                  // rows v of dW per workgroup
+
+__global__ __launch_bounds__(256) void skinny_dw_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                        float* __restrict__ dw, float* __restrict__ db, int G, int K, int V) {
+    __shared__ float sdy[DW_ROWS][GMAX];
+    const int v0 = blockIdx.x * DW_ROWS;
+    {
+        const int j = threadIdx.x / GMAX, g = threadIdx.x % GMAX;         // 256 = 16 x 16
+        sdy[j][g] = (g < G && v0 + j < V) ? dy[(int64_t)g * V + v0 + j] : 0.f;
+    }
+    float xr[GMAX][KCH];
+#pragma unroll
+    for (int g = 0; g < GMAX; ++g)
+#pragma unroll
+        for (int c = 0; c < KCH; ++c) {
+            const int k = threadIdx.x + 256 * c;
+            xr[g][c] = (g < G && k < K) ? x[(int64_t)g * K + k] : 0.f;
+        }
+    __syncthreads();
+    for (int j = 0; j < DW_ROWS && v0 + j < V; ++j) {
+#pragma unroll
+        for (int c = 0; c < KCH; ++c) {
+            const int k = threadIdx.x + 256 * c;
+            if (k < K) {
+                float s = 0.f;
+#pragma unroll
+                for (int g = 0; g < GMAX; ++g) s += sdy[j][g] * xr[g][c];
+                dw[(int64_t)(v0 + j) * K + k] = s;
+            }
+        }
+    }
+    if (db && threadIdx.x < DW_ROWS && v0 + (int)threadIdx.x < V) {
+        float s = 0.f;
+#pragma unroll
+        for (int g = 0; g < GMAX; ++g) s += sdy[threadIdx.x][g];
+        db[v0 + threadIdx.x] = s;
+    }
+}
+
+__global__ __launch_bounds__(256) void skinny_zero_kernel(float* __restrict__ p, int n) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) p[i] = 0.f;
+}
+
+int check_dims(int G, int K, int V) {
+    if (G <= 0 || G > GMAX || K <= 0 || K > 256 * KCH || (K & 3) || V <= 0) return MOBGT_EBADDIM;
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int mobgt_skinny_linear_fwd(const float* x, const float* w, const float* b, float* y, int G, int K, int V,
+                                       void* stream) {
+    const int rc = check_dims(G, K, V);
+    if (rc) return rc;
+    if (((uintptr_t)x | (uintptr_t)w) & 15) return MOBGT_EALIGN;
+    const int blocks = (V + 31) / 32 < 256 ? (V + 31) / 32 : 256;        // ~8 columns per wave: x is loaded once per wave
+    hipLaunchKernelGGL(skinny_fwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, w, b, y, G, K, V);
+    return (int)hipGetLastError();
+}
+
+extern "C" int mobgt_skinny_linear_bwd(const float* dy, const float* x, const float* w, float* dx, float* dw, float* db,
+                                       int G, int K, int V, void* stream) {
+    const int rc = check_dims(G, K, V);
+    if (rc) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    if (dx) {
+        // dx is accumulated across the DX_SPLIT workgroups of a column block: zero it first (a kernel, not a memset node)
+        hipLaunchKernelGGL(skinny_zero_kernel, dim3((G * K + 255) / 256), dim3(256), 0, st, dx, G * K);
+        hipLaunchKernelGGL(skinny_dx_kernel, dim3((K + DX_KB - 1) / DX_KB, DX_SPLIT), dim3(256), 0, st, dy, w, dx, G, K, V);
+    }
+    if (dw) hipLaunchKernelGGL(skinny_dw_kernel, dim3((V + DW_ROWS - 1) / DW_ROWS), dim3(256), 0, st, dy, x, dw, db, G, K, V);
+    return (int)hipGetLastError();
+}

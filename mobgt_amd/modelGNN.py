@@ -57,21 +57,59 @@ class _GraphConvFn(torch.autograd.Function):
     """out = adj @ (x @ W) + b   (modelGNN.py:38-44), with the big product in adj's dtype."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, adj):
+    def forward(ctx, x, weight, bias, adj, adj_t=None):
         support = x @ weight
         out = _mm_f32(adj, support.to(adj.dtype), bias)             # bias in the GEMM epilogue, fp32 result
-        ctx.save_for_backward(x, weight, adj)
+        ctx.save_for_backward(x, weight, adj, adj_t)
         ctx.has_bias = bias is not None
         return out
 
     @staticmethod
     def backward(ctx, g):
-        x, weight, adj = ctx.saved_tensors
-        d_support = _mm_f32(adj.t(), g.to(adj.dtype))
+        x, weight, adj, adj_t = ctx.saved_tensors
+        # adj is a constant: with a stored transpose the backward product streams rows like the forward one
+        # (measured 60 us for adj.t() @ g through the library's transposed-operand path vs 42 us)
+        d_support = _mm_f32(adj_t if adj_t is not None else adj.t(), g.to(adj.dtype))
         dW = mm_tn_splitk(x, d_support)
         dx = d_support @ weight.t() if ctx.needs_input_grad[0] else None
         db = _colsum(g) if ctx.has_bias else None
-        return dx, dW, db, None
+        return dx, dW, db, None, None
+
+
+class _RowsConvFn(torch.autograd.Function):
+    """out = adj[rows] @ (x @ W) + b for R << P rows of a bf16 adjacency, both skinny products on the split-K MFMA
+    kernel of csrc/wgrad.hip instead of the library:
+      forward   adj[rows] @ s  is  (adj[rows]^T)^T @ s  -- "g^T x" with g = adj[rows]^T [P,R], x = s [P,C]
+                (K = P rows, a 608 x 192 output: the library ran it on ~30 workgroups, 51 us; here ~8 us + a
+                9 MB transpose);
+      backward  d_s = adj[rows]^T @ g  is "g^T x" with g = adj[rows] [R,P], x = dout [R,C]  (59 us -> ~18 us)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, adj, rows):
+        from . import ops
+        support = x @ weight                                           # [P,C] f32
+        a_rows, a_rows_t = ops.gather_rows_t(adj, rows)                # [R,P] and its transpose [P,R], one pass
+        out = ops.linear_wgrad(a_rows_t, support.to(torch.bfloat16))[0]     # [R,C] f32
+        if bias is not None:
+            out = out + bias
+        ctx.save_for_backward(x, weight, a_rows)
+        ctx.has_bias = bias is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        from . import ops
+        x, weight, a_rows = ctx.saved_tensors
+        d_support = ops.linear_wgrad(a_rows, g.to(torch.bfloat16).contiguous())[0]      # [P,C] f32
+        dW = mm_tn_splitk(x, d_support)
+        dx = d_support @ weight.t() if ctx.needs_input_grad[0] else None
+        db = _colsum(g) if ctx.has_bias else None
+        return dx, dW, db, None, None
+
+
+def _rows_conv_ok(x, adj, rows):
+    return (x.is_cuda and adj.dtype == torch.bfloat16 and adj.shape[1] % 8 == 0 and adj.stride(0) % 8 == 0
+            and rows.numel() % 8 == 0 and rows.numel() * 2 <= adj.shape[0] and rows.numel() <= 4096)
 
 
 class _PreAggConvFn(torch.autograd.Function):
@@ -108,13 +146,13 @@ class GraphConvolution(nn.Module):
         if self.bias is not None:
             self.bias.data.uniform_(-stdv, stdv)
 
-    def forward(self, input, adj, adj_input=None):
+    def forward(self, input, adj, adj_input=None, adj_t=None):
         # X.W stays fp32 (raw features such as lat/lon need the mantissa); only the big dense adjacency
         # product runs in `adj`'s dtype (fp32, or bf16 in the bf16 configuration)
         with torch.autocast(device_type=input.device.type, enabled=False):
             if adj_input is not None:
                 return _PreAggConvFn.apply(adj_input, self.weight, self.bias)
-            return _GraphConvFn.apply(input.float(), self.weight, self.bias, adj)
+            return _GraphConvFn.apply(input.float(), self.weight, self.bias, adj, adj_t)
 
 
 class GCN(nn.Module):
@@ -127,19 +165,23 @@ class GCN(nn.Module):
         for i in range(len(channels) - 1):
             self.gcn.append(GraphConvolution(channels[i], channels[i + 1]))
 
-    def forward(self, x, adj, adj_x=None, rows=None):
+    def forward(self, x, adj, adj_x=None, rows=None, adj_t=None):
         """`adj_x` = adj @ x precomputed (x is a constant feature matrix in MobGT): skips the first P x P product.
         `rows` (int64 [R]): return only these rows of the output table, i.e. evaluate the LAST layer as
         adj[rows] @ (h W) + b.  The model reads the table only at the batch's POI ids
         (model_fqandtoyo.py:1264), so for R << P this replaces a P x P product (and its transpose in the
         backward) by an R x P one without changing any value that is used."""
         for i in range(len(self.gcn) - 1):
-            x = self.leaky_relu(self.gcn[i](x, adj, adj_x if i == 0 else None))
+            x = self.leaky_relu(self.gcn[i](x, adj, adj_x if i == 0 else None, adj_t))
         if x.is_cuda:
             from . import ops
             x = ops.dropout(x, self.dropout, self.training, 0x2000 + self.gcn[-1].out_features)
         else:
             x = F.dropout(x, self.dropout, training=self.training)
         if rows is not None:
-            return self.gcn[-1](x, adj.index_select(0, rows))
-        return self.gcn[-1](x, adj)
+            last = self.gcn[-1]
+            if _rows_conv_ok(x, adj, rows):
+                with torch.autocast(device_type=x.device.type, enabled=False):
+                    return _RowsConvFn.apply(x.float(), last.weight, last.bias, adj, rows)
+            return last(x, adj.index_select(0, rows))
+        return self.gcn[-1](x, adj, None, adj_t)

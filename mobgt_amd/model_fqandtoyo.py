@@ -199,6 +199,9 @@ class Graphormer(nn.Module):
         # A.X for the constant POI feature matrix, once, in fp32 (see modelGNN.GCN.forward)
         self.register_buffer("D_AX", d_a @ torch.from_numpy(X), persistent=False)
         self.register_buffer("D_A", d_a.to(gcn_dtype), persistent=False)
+        # the constant's transpose, stored once: the backward's adj^T @ g then streams rows like the forward
+        self.register_buffer("D_A_T", d_a.t().contiguous().to(gcn_dtype) if gcn_dtype != torch.float32 else None,
+                             persistent=False)
         c_a = torch.from_numpy(calculate_laplacian_matrix(uni.graph_cat)).float()
         self.register_buffer("C_A", c_a, persistent=False)
         self.register_buffer("C_AX", c_a @ torch.from_numpy(C_X), persistent=False)
@@ -286,9 +289,9 @@ class Graphormer(nn.Module):
         idx, real = ops.node_index(x, batched_data.time_normal[:, :, 0].float(), self.poi2cat, rows_only)
         poi_idx, time_idx, cat_idx, pos_idx, gcn_rows, zero_idx = idx.unbind(0)
         if rows_only:
-            poidist = self.poi_distance_model(self.X, self.D_A, self.D_AX, rows=gcn_rows.reshape(-1))
+            poidist = self.poi_distance_model(self.X, self.D_A, self.D_AX, rows=gcn_rows.reshape(-1), adj_t=self.D_A_T)
         else:
-            poidist = self.poi_distance_model(self.X, self.D_A, self.D_AX)        # :1236
+            poidist = self.poi_distance_model(self.X, self.D_A, self.D_AX, adj_t=self.D_A_T)        # :1236
         ops.trace_nan("poidist", poidist)
         catemb = self.poi_cat_model(self.C_X, self.C_A, self.C_AX)                                    # :1237
         # [poi ; time] and the category row, gathered for every position in one pass each
@@ -324,7 +327,10 @@ class Graphormer(nn.Module):
         tok = self.embed_fuse_model3(output[:, 0, :].float(), user_embedding)                  # :1353-1358, q = 0 only
         tok = ops.dropout(self.ELU(self.final_ln(tok)), self.output_dropout.p, self.training, 0x1004)   # :1360-1364
         ops.trace_nan("tok", tok)
-        logits = self.out_proj(tok)
+        if ops.skinny_linear_ok(tok, self.out_proj.weight):
+            logits = ops.skinny_linear(tok, self.out_proj.weight, self.out_proj.bias)      # :1394, M = G rows
+        else:
+            logits = self.out_proj(tok)
         ops.trace_nan("logits", logits)
         return [logits, self.cat_decoder(tok)]                                                 # :1394-1396
 

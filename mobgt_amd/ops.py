@@ -3,6 +3,7 @@ HIP stream go in, autograd comes out.  PyTorch is plumbing here (memory, streams
 all arithmetic of the hot path happens in libmobgt_hip.so.  No CPU fallback exists.
 """
 import ctypes
+import os
 
 import torch
 
@@ -415,6 +416,69 @@ def hop_table(edge_weight, edge_dis_weight, H, D, fp16_roundtrip=False):
     assert edge_weight.dtype == torch.float32 and edge_dis_weight.dtype == torch.float32
     assert edge_dis_weight.numel() >= D * H * H
     return _HopTableFn.apply(edge_weight, edge_dis_weight, H, D, fp16_roundtrip)
+
+
+class _SkinnyLinearFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        x, w = x.contiguous(), weight.contiguous()
+        if x.data_ptr() % 16:
+            x = x.clone()
+        G, K = x.shape
+        V = w.shape[0]
+        # measured at G = 16, K = 448, V = 7857: the library's forward / dx products 28.6 / 29 us, the kernels here
+        # 38 / 32 us (one W row in flight per wave; 32-byte column pieces) -- but dW + db 9.5 us vs 26 us + a reduce.
+        # So only the weight / bias gradient goes to csrc/skinny.hip; `MOBGT_SKINNY_ALL=1` routes all three (tests).
+        ctx.all_hip = bool(os.environ.get("MOBGT_SKINNY_ALL"))
+        if ctx.all_hip:
+            y = torch.empty(G, V, dtype=torch.float32, device=x.device)
+            check(_lib.lib().mobgt_skinny_linear_fwd(_p(x), _p(w), _p(bias), _p(y), G, K, V, _stream()),
+                  "mobgt_skinny_linear_fwd")
+        else:
+            y = torch.addmm(bias, x, w.t()) if bias is not None else x @ w.t()
+        ctx.save_for_backward(x, w)
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        G, K = x.shape
+        V = w.shape[0]
+        dy = dy.contiguous()
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x) if ctx.all_hip else dy @ w
+        dw = torch.empty_like(w) if ctx.needs_input_grad[1] else None
+        db = torch.empty(V, dtype=torch.float32, device=x.device) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+        check(_lib.lib().mobgt_skinny_linear_bwd(_p(dy), _p(x), _p(w), _p(dx if ctx.all_hip else None), _p(dw), _p(db),
+                                                 G, K, V, _stream()), "mobgt_skinny_linear_bwd")
+        return dx, dw, db
+
+
+def skinny_linear_ok(x, weight):
+    return (x.is_cuda and x.dim() == 2 and x.dtype == torch.float32 and weight.dtype == torch.float32
+            and 0 < x.shape[0] <= 16 and x.shape[1] % 4 == 0 and x.shape[1] <= 512 and weight.shape[0] >= 1024
+            and weight.is_contiguous() and weight.data_ptr() % 16 == 0)
+
+
+def skinny_linear(x, weight, bias=None):
+    """F.linear(x, weight, bias) for a handful of rows and a wide output (the classifier head): one pass over the
+    weight per product instead of a GEMM with M = 16."""
+    _require_cuda(x, weight)
+    return _SkinnyLinearFn.apply(x, weight, bias)
+
+
+def gather_rows_t(a, rows):
+    """(a[rows], a[rows]^T) for a bf16 matrix in one pass: [R,C] and [C,R] contiguous."""
+    _require_cuda(a, rows)
+    assert a.dtype == torch.bfloat16 and a.stride(1) == 1 and rows.dtype == torch.int64
+    R, C = rows.numel(), a.shape[1]
+    out = torch.empty(R, C, dtype=a.dtype, device=a.device)
+    out_t = torch.empty(C, R, dtype=a.dtype, device=a.device)
+    check(_lib.lib().mobgt_gather_rows_t(_p(a), a.stride(0), _p(rows.contiguous()), _p(out), _p(out_t), R, C, _stream()),
+          "mobgt_gather_rows_t")
+    return out, out_t
 
 
 def target_rank(scores, target):

@@ -392,3 +392,38 @@ def test_embed_gather_sum_and_grad():
         w = want.clone()
         w[0] = 0
         np.testing.assert_allclose(got.cpu().numpy(), w.numpy(), rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("all_hip", [False, True])
+@pytest.mark.parametrize("G,K,V", [(16, 448, 7857), (5, 448, 1030), (1, 64, 2048), (16, 512, 1024)])
+def test_skinny_linear_matches_torch(G, K, V, all_hip, monkeypatch):
+    """mobgt_skinny_linear_fwd/bwd (the classifier head, M = G rows) against F.linear in fp64; the product path uses
+    the dW/db kernel only, MOBGT_SKINNY_ALL=1 exercises the forward and dx kernels as well."""
+    if all_hip:
+        monkeypatch.setenv("MOBGT_SKINNY_ALL", "1")
+    else:
+        monkeypatch.delenv("MOBGT_SKINNY_ALL", raising=False)
+    gen = torch.Generator().manual_seed(G + K + V)
+    x = torch.randn(G, K, generator=gen)
+    w = torch.randn(V, K, generator=gen) * 0.05
+    b = torch.randn(V, generator=gen)
+    gy = torch.randn(G, V, generator=gen)
+    xr, wr, br = (t.double().requires_grad_(True) for t in (x, w, b))
+    torch.nn.functional.linear(xr, wr, br).backward(gy.double())
+    xd, wd, bd = (t.to(DEV).requires_grad_(True) for t in (x, w, b))
+    assert ops.skinny_linear_ok(xd, wd)
+    y = ops.skinny_linear(xd, wd, bd)
+    y.backward(gy.to(DEV))
+    ref = torch.nn.functional.linear(x.double(), w.double(), b.double())
+    np.testing.assert_allclose(y.detach().cpu().numpy(), ref.numpy(), rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(xd.grad.cpu().numpy(), xr.grad.numpy(), rtol=1e-4, atol=2e-3)
+    np.testing.assert_allclose(wd.grad.cpu().numpy(), wr.grad.numpy(), rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(bd.grad.cpu().numpy(), br.grad.numpy(), rtol=1e-4, atol=1e-4)
+
+
+def test_gather_rows_t():
+    gen = torch.Generator().manual_seed(4)
+    a = torch.randn(300, 136, generator=gen).bfloat16().to(DEV)
+    rows = torch.randint(0, 300, (72,), generator=gen).to(DEV)
+    r, rt = ops.gather_rows_t(a, rows)
+    assert torch.equal(r, a[rows]) and torch.equal(rt, a[rows].t().contiguous())
