@@ -285,7 +285,9 @@ int mobgt_colsum(const void* g, float* out, int64_t R, int C, int act_dtype, voi
 /* Weight / bias gradient of an nn.Linear y = x W^T + b (model.py:388-403, 406-463; what autograd's
  * F.linear backward computes as dy^T x and dy.sum(0)):  dw [M,N] (f32, row pitch ldw) += g^T x and, when db is
  * not null, db [M] += column sums of g, for g [R,M] (row pitch ldg) and x [R,N] (row pitch ldx), both bf16
- * (act_dtype must be MOBGT_BF16).  M, N, ldg, ldx even; g, x 4-byte aligned.  Split over R across the grid with
+ * (act_dtype MOBGT_BF16) or both f32 (MOBGT_F32: rounded to bf16 while loading -- bf16 MFMA operands, f32
+ * accumulate -- exactly what a cast kernel in front would produce).  M, N, ldg, ldx even; g, x 4-byte (8-byte for
+ * f32) aligned.  Split over R across the grid with
  * f32 atomics into dw/db, which the caller zero-initialises (or pre-loads with a gradient to accumulate into). */
 int mobgt_linear_wgrad(const void* g, int64_t ldg, const void* x, int64_t ldx, float* dw, int64_t ldw, float* db,
                        int64_t R, int M, int N, int act_dtype, void* stream);

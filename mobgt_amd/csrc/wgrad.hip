@@ -33,6 +33,7 @@ struct WgradParams {
     int R, M, N;
     int tiles_n;
     int k_per_wg;                        // multiple of NWAVE * KSTEP when gridDim.y > 1
+    int in_f32;                          // operands are f32 in memory (ldg / ldx in f32 elements), rounded to bf16 here
 };
 
 __device__ __forceinline__ void split_pairs(const uint32_t (&d)[8], bf16x8& even, bf16x8& odd) {
@@ -46,20 +47,38 @@ __device__ __forceinline__ void split_pairs(const uint32_t (&d)[8], bf16x8& even
     odd = __builtin_bit_cast(bf16x8, o);
 }
 
+// two adjacent f32 columns -> one dword of two bf16 (round to nearest even, like a cast kernel in front would)
+__device__ __forceinline__ uint32_t pack_pair(const float* p) {
+    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+    const float2 v = *reinterpret_cast<const float2*>(p);
+    bf16x2 o;
+    o[0] = (bf16_t)v.x;
+    o[1] = (bf16_t)v.y;
+    return __builtin_bit_cast(uint32_t, o);
+}
+
 struct Slab {
     uint32_t g[8], x[8];
-    __device__ __forceinline__ void load(const uint16_t* gp, const uint16_t* xp, int64_t ldg, int64_t ldx, int r0, int k1,
+    // gp / xp point at this lane's column pair of row 0 (as bf16 elements, or -- F32 -- as f32 elements)
+    template <bool F32>
+    __device__ __forceinline__ void load(const void* gp, const void* xp, int64_t ldg, int64_t ldx, int r0, int k1,
                                          bool m_ok, bool n_ok) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int r = r0 + j;
             const bool ok = r < k1;
-            g[j] = ok && m_ok ? *reinterpret_cast<const uint32_t*>(gp + (int64_t)r * ldg) : 0u;
-            x[j] = ok && n_ok ? *reinterpret_cast<const uint32_t*>(xp + (int64_t)r * ldx) : 0u;
+            if (F32) {
+                g[j] = ok && m_ok ? pack_pair(reinterpret_cast<const float*>(gp) + (int64_t)r * ldg) : 0u;
+                x[j] = ok && n_ok ? pack_pair(reinterpret_cast<const float*>(xp) + (int64_t)r * ldx) : 0u;
+            } else {
+                g[j] = ok && m_ok ? *reinterpret_cast<const uint32_t*>(reinterpret_cast<const uint16_t*>(gp) + (int64_t)r * ldg) : 0u;
+                x[j] = ok && n_ok ? *reinterpret_cast<const uint32_t*>(reinterpret_cast<const uint16_t*>(xp) + (int64_t)r * ldx) : 0u;
+            }
         }
     }
 };
 
+template <bool F32>
 __device__ __forceinline__ void wgrad_body(const WgradParams& p, const int tile, const int split, const int nsplit) {
     __shared__ float part[NWAVE / 2][TILE * TILE];     // 32 KB: the upper 8 waves hand their tiles to the lower 8 first
     __shared__ float colpart[NWAVE][TILE];
@@ -70,8 +89,8 @@ __device__ __forceinline__ void wgrad_body(const WgradParams& p, const int tile,
     const int k1 = min(p.R, k0 + p.k_per_wg);
     const bool want_db = p.db != nullptr && n0 == 0;
     const bool m_ok = m0 + 2 * i < p.M, n_ok = n0 + 2 * i < p.N;      // M, N even: a pair is in or out together
-    const uint16_t* gp = p.g + m0 + 2 * i;
-    const uint16_t* xp = p.x + n0 + 2 * i;
+    const void* gp = F32 ? (const void*)(reinterpret_cast<const float*>(p.g) + m0 + 2 * i) : (const void*)(p.g + m0 + 2 * i);
+    const void* xp = F32 ? (const void*)(reinterpret_cast<const float*>(p.x) + n0 + 2 * i) : (const void*)(p.x + n0 + 2 * i);
 
     f32x4 acc[2][2];
 #pragma unroll
@@ -82,10 +101,10 @@ __device__ __forceinline__ void wgrad_body(const WgradParams& p, const int tile,
 
     int kb = k0 + wave * KSTEP;
     Slab cur, nxt;
-    if (kb < k1) cur.load(gp, xp, p.ldg, p.ldx, kb + 8 * kq, k1, m_ok, n_ok);
+    if (kb < k1) cur.template load<F32>(gp, xp, p.ldg, p.ldx, kb + 8 * kq, k1, m_ok, n_ok);
     for (; kb < k1; kb += NWAVE * KSTEP) {
         const int kn = kb + NWAVE * KSTEP;
-        if (kn < k1) nxt.load(gp, xp, p.ldg, p.ldx, kn + 8 * kq, k1, m_ok, n_ok);      // in flight during the MFMAs
+        if (kn < k1) nxt.template load<F32>(gp, xp, p.ldg, p.ldx, kn + 8 * kq, k1, m_ok, n_ok);      // in flight during the MFMAs
         bf16x8 ge, go, xe, xo;
         split_pairs(cur.g, ge, go);
         split_pairs(cur.x, xe, xo);
@@ -144,7 +163,8 @@ __device__ __forceinline__ void wgrad_body(const WgradParams& p, const int tile,
 }
 
 __global__ __launch_bounds__(NWAVE * 64) void wgrad_kernel(const WgradParams p) {
-    wgrad_body(p, blockIdx.x, blockIdx.y, gridDim.y);
+    if (p.in_f32) wgrad_body<true>(p, blockIdx.x, blockIdx.y, gridDim.y);
+    else wgrad_body<false>(p, blockIdx.x, blockIdx.y, gridDim.y);
 }
 
 // Up to 32 independent problems in ONE launch (the four Linear layers of every encoder layer: nothing depends on a
@@ -164,13 +184,15 @@ __global__ __launch_bounds__(NWAVE * 64) void wgrad_group_kernel(const WgradGrou
     for (int t = 1; t < WG_GROUP; ++t)
         if (t < grp.n && (int)blockIdx.x >= grp.first[t]) q = t;
     const int local = blockIdx.x - grp.first[q];
-    wgrad_body(grp.p[q], local % grp.tiles[q], local / grp.tiles[q], grp.splits[q]);
+    if (grp.p[q].in_f32) wgrad_body<true>(grp.p[q], local % grp.tiles[q], local / grp.tiles[q], grp.splits[q]);
+    else wgrad_body<false>(grp.p[q], local % grp.tiles[q], local / grp.tiles[q], grp.splits[q]);
 }
 
 int fill_problem(WgradParams& p, const void* g, int64_t ldg, const void* x, int64_t ldx, float* dw, int64_t ldw, float* db,
-                 int64_t R, int M, int N, int target_wgs, int* tiles_out, int* splits_out) {
+                 int64_t R, int M, int N, int target_wgs, int* tiles_out, int* splits_out, int in_f32) {
     if (R <= 0 || M <= 0 || N <= 0 || (M & 1) || (N & 1) || (ldg & 1) || (ldx & 1) || R > 0x7fffffff) return MOBGT_EBADDIM;
-    if (((uintptr_t)g & 3) || ((uintptr_t)x & 3)) return MOBGT_EALIGN;
+    if (((uintptr_t)g & (in_f32 ? 7 : 3)) || ((uintptr_t)x & (in_f32 ? 7 : 3))) return MOBGT_EALIGN;
+    p.in_f32 = in_f32;
     p.g = reinterpret_cast<const uint16_t*>(g); p.ldg = ldg;
     p.x = reinterpret_cast<const uint16_t*>(x); p.ldx = ldx;
     p.dw = dw; p.ldw = ldw; p.db = db;
@@ -194,7 +216,7 @@ int fill_problem(WgradParams& p, const void* g, int64_t ldg, const void* x, int6
 extern "C" int mobgt_linear_wgrad_group(int n, const void* const* g, const int64_t* ldg, const void* const* x,
                                         const int64_t* ldx, float* const* dw, const int64_t* ldw, float* const* db,
                                         int64_t R, const int* M, const int* N, int act_dtype, void* stream) {
-    if (act_dtype != MOBGT_BF16) return MOBGT_EDTYPE;
+    if (act_dtype != MOBGT_BF16 && act_dtype != MOBGT_F32) return MOBGT_EDTYPE;
     if (n < 1 || n > WG_GROUP) return MOBGT_EBADDIM;
     if (R == 0) return 0;
     WgradGroup grp;
@@ -203,7 +225,7 @@ extern "C" int mobgt_linear_wgrad_group(int n, const void* const* g, const int64
     for (int q = 0; q < n; ++q) {
         // the problems share the chip: aim at ~256 workgroups for all of them together
         const int rc = fill_problem(grp.p[q], g[q], ldg[q], x[q], ldx[q], dw[q], ldw[q], db ? db[q] : nullptr, R, M[q], N[q],
-                                    256 / n, &grp.tiles[q], &grp.splits[q]);
+                                    256 / n, &grp.tiles[q], &grp.splits[q], act_dtype == MOBGT_F32);
         if (rc) return rc;
         grp.first[q] = total;
         total += grp.tiles[q] * grp.splits[q];
@@ -216,29 +238,16 @@ extern "C" int mobgt_linear_wgrad_group(int n, const void* const* g, const int64
 
 extern "C" int mobgt_linear_wgrad(const void* g, int64_t ldg, const void* x, int64_t ldx, float* dw, int64_t ldw,
                                   float* db, int64_t R, int M, int N, int act_dtype, void* stream) {
-    if (act_dtype != MOBGT_BF16) return MOBGT_EDTYPE;
-    if (R < 0 || M <= 0 || N <= 0 || (M & 1) || (N & 1) || (ldg & 1) || (ldx & 1) || R > 0x7fffffff) return MOBGT_EBADDIM;
-    if (((uintptr_t)g & 3) || ((uintptr_t)x & 3)) return MOBGT_EALIGN;
+    if (act_dtype != MOBGT_BF16 && act_dtype != MOBGT_F32) return MOBGT_EDTYPE;
     if (R == 0) return 0;
-    WgradParams p;
-    p.g = reinterpret_cast<const uint16_t*>(g); p.ldg = ldg;
-    p.x = reinterpret_cast<const uint16_t*>(x); p.ldx = ldx;
-    p.dw = dw; p.ldw = ldw; p.db = db;
-    p.R = (int)R; p.M = M; p.N = N;
-    const int tiles_m = (M + TILE - 1) / TILE;
-    p.tiles_n = (N + TILE - 1) / TILE;
-    const int tiles = tiles_m * p.tiles_n;
     // A 1024-thread workgroup fills a CU, so up to ~256 workgroups run at once: when the tiles alone do not
     // reach that, R is also split over gridDim.y (>= one 512-row slab per workgroup) and the few partial tiles
     // per output are combined with f32 atomics.  Measured (MI355X, R = 2432): 192x192 5 splits 7.5 us vs 12.9 us
     // unsplit; 576x192 2 splits 10.8 vs 13.3; R = 12560, 256x256 4 splits 21 vs 46 (incl. two zero fills).
-    const int slab = NWAVE * KSTEP;
-    int splits = 256 / tiles;
-    const int max_splits = (int)((R + slab - 1) / slab);
-    if (splits > max_splits) splits = max_splits;
-    if (splits < 1) splits = 1;
-    p.k_per_wg = (int)(((R + splits - 1) / splits + slab - 1) / slab) * slab;
-    splits = (int)((R + p.k_per_wg - 1) / p.k_per_wg);
+    WgradParams p;
+    int tiles = 0, splits = 0;
+    const int rc = fill_problem(p, g, ldg, x, ldx, dw, ldw, db, R, M, N, 256, &tiles, &splits, act_dtype == MOBGT_F32);
+    if (rc) return rc;
     hipLaunchKernelGGL(wgrad_kernel, dim3(tiles, splits), dim3(NWAVE * 64), 0, (hipStream_t)stream, p);
     return (int)hipGetLastError();
 }

@@ -16,8 +16,15 @@ import torch.nn.functional as F
 from torch.nn import Parameter
 
 
-def mm_tn_splitk(x, g, max_chunks=32):
-    """x^T @ g for tall-skinny x [P,a], g [P,b] (P >> a,b): split the long K axis over a batch dimension."""
+def mm_tn_splitk(x, g, max_chunks=32, bf16_operands=False):
+    """x^T @ g for tall-skinny x [P,a], g [P,b] (P >> a,b): split the long K axis over a batch dimension.
+    `bf16_operands` (the bf16 configuration): the split-K MFMA kernel of csrc/wgrad.hip instead, f32 operands rounded
+    to bf16 while loading, f32 accumulate (21 us + a reduce -> ~8 us for the [64 x 7856] x [7856 x 192] case)."""
+    if (bf16_operands and x.is_cuda and x.dtype == torch.float32 and g.dtype == torch.float32 and x.shape[1] % 2 == 0
+            and g.shape[1] % 2 == 0 and x.is_contiguous() and g.is_contiguous()
+            and x.data_ptr() % 8 == 0 and g.data_ptr() % 8 == 0):
+        from . import ops
+        return ops.linear_wgrad(x, g)[0]
     P = x.shape[0]
     s = max((c for c in range(1, max_chunks + 1) if P % c == 0), default=1)
     if s == 1 or P < 2048:
@@ -70,7 +77,7 @@ class _GraphConvFn(torch.autograd.Function):
         # adj is a constant: with a stored transpose the backward product streams rows like the forward one
         # (measured 60 us for adj.t() @ g through the library's transposed-operand path vs 42 us)
         d_support = _mm_f32(adj_t if adj_t is not None else adj.t(), g.to(adj.dtype))
-        dW = mm_tn_splitk(x, d_support)
+        dW = mm_tn_splitk(x, d_support, bf16_operands=adj.dtype == torch.bfloat16)
         dx = d_support @ weight.t() if ctx.needs_input_grad[0] else None
         db = _colsum(g) if ctx.has_bias else None
         return dx, dW, db, None, None
@@ -101,7 +108,7 @@ class _RowsConvFn(torch.autograd.Function):
         from . import ops
         x, weight, a_rows = ctx.saved_tensors
         d_support = ops.linear_wgrad(a_rows, g.to(torch.bfloat16).contiguous())[0]      # [P,C] f32
-        dW = mm_tn_splitk(x, d_support)
+        dW = mm_tn_splitk(x, d_support, bf16_operands=True)
         dx = d_support @ weight.t() if ctx.needs_input_grad[0] else None
         db = _colsum(g) if ctx.has_bias else None
         return dx, dW, db, None, None

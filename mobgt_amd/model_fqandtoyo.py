@@ -92,7 +92,8 @@ class FuseEmbeddings(nn.Module):
     def forward(self, user_embed, poi_embed):
         x = torch.cat((user_embed, poi_embed), user_embed.dim() - 1)
         if x.is_cuda:
-            return self.leaky_relu(ops.linear_splitk(x.float(), self.fuse_embed.weight, self.fuse_embed.bias))
+            return self.leaky_relu(ops.linear_splitk(x.float(), self.fuse_embed.weight, self.fuse_embed.bias,
+                                                     getattr(self, "bf16_wgrad", False)))
         return self.leaky_relu(self.fuse_embed(x))
 
 
@@ -250,6 +251,9 @@ class Graphormer(nn.Module):
         for li, layer in enumerate(self.layers):
             layer.act_dtype, layer.fused = act_dtype, fused_layers
             layer.self_attention.set_layer_index(li + 1)
+        self.act_dtype = act_dtype
+        for m in (self.embed_fuse_model2, self.embed_fuse_model3, self.embed_fuse_model4):
+            m.bf16_wgrad = act_dtype == torch.bfloat16       # bf16 configuration: weight gradients with bf16 MFMA operands
         self.final_ln = nn.LayerNorm(Cout)
         self.out_proj = nn.Linear(Cout, P if fsq else P + 1)
         self.ELU = nn.ELU()
@@ -297,7 +301,8 @@ class Graphormer(nn.Module):
         # [poi ; time] and the category row, gathered for every position in one pass each
         pt = ops.embed_gather_concat([poidist, self.time_embed_model_48.weight], [poi_idx, time_idx], padding_idx=[None, 0])
         f2 = self.embed_fuse_model2.leaky_relu(
-            ops.linear_splitk(pt, self.embed_fuse_model2.fuse_embed.weight, self.embed_fuse_model2.fuse_embed.bias))   # :1268
+            ops.linear_splitk(pt, self.embed_fuse_model2.fuse_embed.weight, self.embed_fuse_model2.fuse_embed.bias,
+                              self.act_dtype == torch.bfloat16))                                             # :1268
         ops.trace_nan("pt", pt)
         ops.trace_nan("f2", f2)
         ce = ops.embed_gather_sum([catemb], [cat_idx])

@@ -599,8 +599,9 @@ class _LinearSplitKFn(torch.autograd.Function):
     plain GEMM call maps onto one workgroup (measured 60-150 us in fp32); evaluate it split-K as a batched GEMM."""
 
     @staticmethod
-    def forward(ctx, x, w, b):
+    def forward(ctx, x, w, b, bf16_wgrad):
         ctx.save_for_backward(x, w)
+        ctx.bf16_wgrad = bf16_wgrad
         return torch.addmm(b, x, w.t())
 
     @staticmethod
@@ -608,17 +609,23 @@ class _LinearSplitKFn(torch.autograd.Function):
         x, w = ctx.saved_tensors
         g = g.contiguous()
         R = x.shape[0]
+        if (ctx.bf16_wgrad and g.dtype == torch.float32 and x.dtype == torch.float32 and g.shape[1] % 2 == 0
+                and x.shape[1] % 2 == 0 and R <= 4096 and g.data_ptr() % 8 == 0 and x.data_ptr() % 8 == 0):
+            # bf16 configuration: weight AND bias gradient from the split-K MFMA kernel (operands rounded to bf16 while
+            # loading); the library's split-K path took 27-31 us + a reduce for these 224-wide layers
+            dw, db = linear_wgrad(g, x, with_bias=True)
+            return g @ w, dw, db, None
         s = max((c for c in (16, 8, 4, 2) if R % c == 0 and R // c >= 16), default=1)
         if s > 1:
             dw = torch.bmm(g.view(s, R // s, -1).transpose(1, 2), x.view(s, R // s, -1)).sum(0)
         else:
             dw = g.t() @ x
-        return g @ w, dw, colsum(g)
+        return g @ w, dw, colsum(g), None
 
 
-def linear_splitk(x, weight, bias):
+def linear_splitk(x, weight, bias, bf16_wgrad=False):
     shape = x.shape
-    y = _LinearSplitKFn.apply(x.reshape(-1, shape[-1]).contiguous(), weight, bias)
+    y = _LinearSplitKFn.apply(x.reshape(-1, shape[-1]).contiguous(), weight, bias, bf16_wgrad)
     return y.view(*shape[:-1], weight.shape[0])
 
 
@@ -704,7 +711,7 @@ def linear_wgrad(g, x, with_bias=False, db=None):
     _require_cuda(g)
     R, M = g.shape
     N = x.shape[1]
-    assert g.dtype == torch.bfloat16 and x.dtype == torch.bfloat16 and g.stride(1) == 1 and x.stride(1) == 1
+    assert g.dtype == x.dtype and g.dtype in (torch.bfloat16, torch.float32) and g.stride(1) == 1 and x.stride(1) == 1
     dw = zeros_f32((M, N), g.device)
     if db is None and with_bias:
         db = zeros_f32((M,), g.device)

@@ -120,6 +120,13 @@ def test_linear_wgrad_matches_fp32_reference(R, M, N):
     np.testing.assert_allclose(dw.cpu().numpy(), ref.cpu().numpy(), rtol=1e-4, atol=tol)
     np.testing.assert_allclose(db.cpu().numpy(), g.double().sum(0).cpu().numpy(), rtol=1e-4, atol=tol)
     # column slices of a wider buffer (the fused QKV layout) and accumulation into an existing gradient
+    # f32 operands: rounded to bf16 while loading -- identical to casting first
+    g32 = torch.randn(R, M, generator=gen).to(DEV)
+    x32 = torch.randn(R, N, generator=gen).to(DEV)
+    dw32, db32 = ops.linear_wgrad(g32, x32, with_bias=True)
+    gb, xb = g32.bfloat16(), x32.bfloat16()
+    np.testing.assert_allclose(dw32.cpu().numpy(), (gb.double().t() @ xb.double()).cpu().numpy(), rtol=1e-4, atol=tol)
+    np.testing.assert_allclose(db32.cpu().numpy(), gb.double().sum(0).cpu().numpy(), rtol=1e-4, atol=tol)
     wide = torch.randn(R, 2 * M + 2, generator=gen).to(DEV).bfloat16()
     gs = wide[:, 2:2 + M]
     dw2, _ = ops.linear_wgrad(gs, x)
