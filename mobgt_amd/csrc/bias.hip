@@ -269,12 +269,14 @@ __global__ __launch_bounds__(256) void build_bias_bwd_kernel(const BuildParams p
     // (every tile touches most SPD / distance-bin rows) and spent ~3 ms doing so.
     const int nt = (T + TILE - 1) / TILE;
     const int n_tiles = nt * nt * p.G;
+    // the unit of work is one 8-row round of a tile (4 per tile): short batches (16 graphs x 41 tokens = 64 tiles)
+    // then still spread over 256 workgroups instead of 64 that each run their four rounds back to back
 #pragma unroll 1
-    for (int tile_id = blockIdx.x; tile_id < n_tiles; tile_id += gridDim.x) {
+    for (int unit = blockIdx.x; unit < 4 * n_tiles; unit += gridDim.x) {
+    const int tile_id = unit >> 2, r = (unit & 3) * 8;
     const int g = tile_id / (nt * nt);
     const int i0 = ((tile_id / nt) % nt) * TILE, j0 = (tile_id % nt) * TILE;
-#pragma unroll 1
-    for (int r = 0; r < TILE; r += 8) {
+    {
         const int ti = i0 + ty + r, tj = j0 + tx;
         // Every load of this round is issued up front, keyed on the index range only: the chain
         // attn_bias -> (live?) -> dBias -> rel_pos -> hop ids used to be 4-5 dependent memory round trips per round
@@ -500,7 +502,7 @@ int launch_build_bwd(const BuildParams& p, hipStream_t st) {
     const int T = p.N + 1;
     const int nt = (T + TILE - 1) / TILE;
     const int n_tiles = nt * nt * p.G;
-    const dim3 grid(n_tiles < 768 ? n_tiles : 768), block(256);          // <= 3 workgroups per CU, each walks its tiles
+    const dim3 grid(4 * n_tiles < 768 ? 4 * n_tiles : 768), block(256);   // <= 3 workgroups per CU, each walks its units
     const int lds_rel = p.n_rel < 512 ? p.n_rel : 512;
     const int lds_poi = p.poi_pos ? (p.n_poi < 1024 ? p.n_poi : 1024) : 0;
     const size_t shm = (size_t)(lds_rel + lds_poi + 1 + p.D * HOP_LDS_ROWS + p.D + 1) * p.H * sizeof(float);
