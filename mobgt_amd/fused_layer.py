@@ -53,11 +53,12 @@ class _WgradBatch:
     def __init__(self):
         self.items = []
 
-    def add(self, g, x, db=None):
-        """-> the dW tensor (filled when `flush` runs), or an immediately computed one for the library path."""
+    def add(self, g, x, db=None, sink=None):
+        """-> the dW tensor (filled when `flush` runs), or an immediately computed one for the library path.
+        `sink`: a zero-initialised [M,N] f32 destination (the trainer's flat gradient slice) to accumulate into."""
         if not _wgrad_hip(g.dtype, g.shape[1], x.shape[1], g.shape[0]):
             return _wgrad(g, x, db)
-        dw = ops.zeros_f32((g.shape[1], x.shape[1]), g.device)
+        dw = sink[:] if sink is not None else ops.zeros_f32((g.shape[1], x.shape[1]), g.device)
         self.items.append((g, x, dw, db))
         return dw
 
@@ -210,6 +211,14 @@ class _FusedLayerFn(torch.autograd.Function):
             out_a = torch.empty(R, C, dtype=A, device=dev) if A != torch.float32 else None
             _k1_fwd(x1, f, x2, nxw, nxb, out_a, out, stats[4], stats[5], R, C, cfg.p, seed, sd, salt + 2, act)
             cfg.out_act = out_a                                       # bf16 copy for the next layer's QKV GEMM
+        # destinations for the four weight gradients in the trainer's flat buffer, if it registered any (q/k/v are
+        # adjacent there exactly when they are adjacent in the fused [3C, C] parameter storage)
+        sq, sk, sv = ops.grad_sink(wq), ops.grad_sink(wk), ops.grad_sink(wv)
+        s_qkv = None
+        if sq is not None and sk is not None and sv is not None and sq.is_contiguous() \
+                and sk.data_ptr() == sq.data_ptr() + 4 * sq.numel() and sv.data_ptr() == sk.data_ptr() + 4 * sk.numel():
+            s_qkv = torch.as_strided(sq, (3 * C, C), (C, 1))
+        ctx.sinks = (s_qkv, ops.grad_sink(wo), ops.grad_sink(w1), ops.grad_sink(w2))
         ctx.cfg = cfg
         ctx.shapes = (G, T, C)
         ctx.save_for_backward(x, xa, qkv, a, lse, x1, z, u, h, x2, stats, s_wqkv, s_wo, s_w1, s_w2, n1w, nxw)
@@ -248,24 +257,25 @@ class _FusedLayerFn(torch.autograd.Function):
                     salt + 2, act)
         dh = df @ s_w2
         wb = _WgradBatch()
-        dw2 = wb.add(df, h)
+        k_qkv, k_wo, k_w1, k_w2 = ctx.sinks                          # gradient sinks (or None)
+        dw2 = wb.add(df, h, sink=k_w2)
         du = torch.empty_like(u)
         db1_in_wgrad = _wgrad_hip(A, F, C, R)                         # then b1's gradient rides on the dW1 kernel
         check(_lib.lib().mobgt_gelu_bwd_colsum(_p(dh), _p(u), _p(du), _p(None if db1_in_wgrad else db1), R, F, act,
                                                _stream()), "mobgt_gelu_bwd_colsum")
         dz = du @ s_w1
-        dw1 = wb.add(du, z, db=db1 if db1_in_wgrad else None)
+        dw1 = wb.add(du, z, db=db1 if db1_in_wgrad else None, sink=k_w1)
         dx1 = torch.empty(R, C, dtype=torch.float32, device=dev)
         dy = torch.empty(R, C, dtype=A, device=dev)
         _k1_bwd(dz, None, dx2, x1, stats[2], stats[3], n1w, dx1, dy, dn1w, dn1b, dbo, R, C, cfg.p, seed, sd, salt + 1, act)
         da = (dy @ s_wo).view(G, T, C)
-        dwo = wb.add(dy, a.view(R, C))
+        dwo = wb.add(dy, a.view(R, C), sink=k_wo)
         dqkv = torch.empty(G, T, 3 * C, dtype=A, device=dev)
         q, k, v = qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:]
         ops._attn_bwd(q, k, v, a, lse, da, dqkv[..., :C], dqkv[..., C:2 * C], dqkv[..., 2 * C:], cfg.pack, cfg.scale,
                       cfg.p_att, seed ^ (salt * 0x9E3779B1), sd)
         dqkv2 = dqkv.view(R, 3 * C)
-        dwqkv = wb.add(dqkv2, xa, db=dbqkv)
+        dwqkv = wb.add(dqkv2, xa, db=dbqkv, sink=k_qkv)
         wb.flush()
         if stock:                                                     # back through self_attention_norm
             dz0 = dqkv2 @ s_wqkv

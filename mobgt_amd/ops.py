@@ -69,6 +69,30 @@ def zeros_f32(shape, device):
     return torch.zeros(shape, dtype=torch.float32, device=device)
 
 
+# ---- gradient sinks: where a trainer wants a parameter's gradient written (train.FlatGrads) ------------------
+_GRAD_SINKS = {}
+
+
+def set_grad_sinks(params, views):
+    """params[i]'s gradient belongs at views[i] (a slice of the trainer's flat gradient buffer, zeroed before every
+    backward).  Kernels that produce a large gradient write it THERE and return that view, so the trainer's
+    gather has nothing to copy for it.  Keyed by the parameter's storage address; `None` clears."""
+    import weakref
+    _GRAD_SINKS.clear()
+    if params is not None:
+        for p, v in zip(params, views):
+            _GRAD_SINKS[p.data_ptr()] = (weakref.ref(p), v)
+
+
+def grad_sink(param):
+    """The registered destination of `param`'s gradient, or None.  The entry must belong to this very tensor
+    object: addresses get reused, and a stale entry would redirect some other model's gradient."""
+    e = _GRAD_SINKS.get(param.data_ptr())
+    if e is not None and e[0]() is param and e[1].shape == param.shape:
+        return e[1]
+    return None
+
+
 def round_up(x, m):
     return (x + m - 1) // m * m
 
@@ -438,6 +462,7 @@ class _SkinnyLinearFn(torch.autograd.Function):
             y = torch.addmm(bias, x, w.t()) if bias is not None else x @ w.t()
         ctx.save_for_backward(x, w)
         ctx.has_bias = bias is not None
+        ctx.sink = grad_sink(weight)
         return y
 
     @staticmethod
@@ -449,7 +474,9 @@ class _SkinnyLinearFn(torch.autograd.Function):
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x) if ctx.all_hip else dy @ w
-        dw = torch.empty_like(w) if ctx.needs_input_grad[1] else None
+        dw = None
+        if ctx.needs_input_grad[1]:
+            dw = ctx.sink[:] if ctx.sink is not None else torch.empty_like(w)      # (a fresh view object of the sink)
         db = torch.empty(V, dtype=torch.float32, device=x.device) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
         check(_lib.lib().mobgt_skinny_linear_bwd(_p(dy), _p(x), _p(w), _p(dx if ctx.all_hip else None), _p(dw), _p(db),
                                                  G, K, V, _stream()), "mobgt_skinny_linear_bwd")

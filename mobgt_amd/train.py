@@ -51,9 +51,11 @@ class FlatGrads:
         ps, vs = self.params[start:stop], self.views[start:stop]
         if grads is None:
             grads = [p.grad for p in ps]
-        src = [g if g is not None else torch.zeros_like(v) for g, v in zip(grads, vs)]
-        if src:
-            torch._foreach_copy_(vs, src)
+        # nothing to copy for a gradient that was written in place (ops.grad_sink) or that does not exist (the flat
+        # buffer is zeroed before every backward)
+        todo = [(v, g) for g, v in zip(grads, vs) if g is not None and g.data_ptr() != v.data_ptr()]
+        if todo:
+            torch._foreach_copy_([v for v, _ in todo], [g for _, g in todo])
         for p, v in zip(ps, vs):
             p.grad = v
 
@@ -159,8 +161,8 @@ class TrainStep:
         from . import ops
         ops.set_dropout_state(self.seed_dev, seed)
         # room for every gradient that kernels accumulate into (all but the few huge matrices torch's GEMMs write)
-        n_arena = sum(p.numel() for p in model.parameters() if p.numel() <= (1 << 20))
-        self.arena = ops.ZeroArena(dev, n=max(1 << 20, int(n_arena * 1.1) + (1 << 16)))
+        n_arena = sum(p.numel() for p in model.parameters() if p.numel() <= (1 << 16))
+        self.arena = ops.ZeroArena(dev, n=max(1 << 20, int(n_arena * 1.5) + (1 << 18)))
         ops.set_zero_arena(self.arena)
         model.train()
         # One side stream for the dry run, the warm-ups and every capture: autograd's AccumulateGrad nodes are
@@ -173,6 +175,7 @@ class TrainStep:
         self.n_head = len(head_parameters(model, used))              # params[:n_head] = the early bucket
         self.n_head_elems = sum(p.numel() for p in used[:self.n_head])
         self.flat_params = FlatParams(model, used)
+        ops.set_grad_sinks(self.flat.params, self.flat.views)        # big gradients are written in place (no gather copy)
         self.flat_params.tensor.grad = self.flat.flat
         self.lr_dev = torch.tensor(float(model.peak_lr), dtype=torch.float32, device=dev)
         self.opt = torch.optim.AdamW([self.flat_params.tensor], lr=self.lr_dev, weight_decay=model.weight_decay,
@@ -223,6 +226,7 @@ class TrainStep:
 
     def _fwd_bwd(self, batch):
         self.flat.release()
+        self.flat.zero()                           # in-place gradient sinks accumulate into it; unused slots stay zero
         self.arena.reset()                         # one fill for all small zero-initialised accumulators of the step
         self.seed_dev.add_(1)                      # new dropout masks each step (attention kernels read it on device)
         loss = self._loss(batch)
@@ -233,6 +237,7 @@ class TrainStep:
     # ---- the same step in two phases (data parallel): [forward, loss, head backward] | [rest of the backward]
     def _phase_a(self, batch, i):
         self.flat.release()
+        self.flat.zero()
         self.arena.reset()
         self.seed_dev.add_(1)
         loss = self._loss(batch)
