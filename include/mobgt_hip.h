@@ -297,6 +297,14 @@ int mobgt_linear_wgrad_group(int n, const void* const* g, const int64_t* ldg, co
                              float* const* dw, const int64_t* ldw, float* const* db, int64_t R, const int* M,
                              const int* N, int act_dtype, void* stream);
 
+/* torch.optim.AdamW (defaults of model_fqandtoyo.py:1599-1616) over one flat f32 parameter buffer of n elements, in
+ * place, with device-resident learning rate and step counter (step t = *step_dev - step_base >= 1) so that a captured
+ * graph advances on replay; optionally refreshes a bf16 copy of the parameters (shadow_bf16, may be NULL).
+ * All f32 pointers 16-byte aligned. */
+int mobgt_adamw_flat(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, void* shadow_bf16, int64_t n,
+                     const float* lr_dev, const int64_t* step_dev, int64_t step_base, float beta1, float beta2, float eps,
+                     float weight_decay, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -50,6 +50,7 @@ SIGNATURES = {
     "mobgt_target_rank": (_i, [_vp, _vp, _vp, _i64, _i64, _vp]),
     "mobgt_skinny_linear_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "mobgt_skinny_linear_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    "mobgt_adamw_flat": (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _i64, _f, _f, _f, _f, _vp]),
     "mobgt_gather_rows_t": (_i, [_vp, _i64, _vp, _vp, _vp, _i, _i, _vp]),
     "mobgt_node_index": (_i, [_vp, _i64, _i64, _vp, _i64, _i64, _vp, _vp, _vp, _i, _i, _i, _vp]),
 }

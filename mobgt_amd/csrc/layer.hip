@@ -715,3 +715,66 @@ extern "C" int mobgt_dropout(const float* x, float* y, int64_t n, int row_len, f
                        seed_dev, salt);
     return (int)hipGetLastError();
 }
+
+// ------------------------------------------------------------------------------------------------
+// AdamW over the trainer's flat parameter buffer (torch.optim.AdamW defaults of model_fqandtoyo.py:1599-1616:
+// decoupled weight decay, bias-corrected moments, eps outside the square root), one pass that also refreshes the
+// bf16 shadow copy the layer GEMMs read.  lr and the step count are DEVICE scalars, so a captured graph sees new
+// values on every replay: t = *step_dev - step_base (the trainer's per-step counter, advanced once per step).
+namespace {
+__global__ __launch_bounds__(256) void adamw_flat_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                         float* __restrict__ v, bf16_t* __restrict__ shadow, int64_t n,
+                                                         const float* __restrict__ lr_dev, const int64_t* __restrict__ step_dev,
+                                                         int64_t step_base, float beta1, float beta2, float eps, float wd) {
+    const float lr = *lr_dev;
+    const float t = (float)(*step_dev - step_base);
+    const float bc1 = 1.f - powf(beta1, t), bc2 = 1.f - powf(beta2, t);
+    const float step_size = lr / bc1, inv_sqrt_bc2 = rsqrtf(bc2), decay = 1.f - lr * wd;
+    const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i >= n) return;
+    if (i + 4 <= n) {
+        float4 pp = *reinterpret_cast<float4*>(p + i);
+        const float4 gg = *reinterpret_cast<const float4*>(g + i);
+        float4 mm = *reinterpret_cast<float4*>(m + i), vv = *reinterpret_cast<float4*>(v + i);
+        float* P = &pp.x; const float* G = &gg.x; float* M = &mm.x; float* V = &vv.x;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            M[k] = beta1 * M[k] + (1.f - beta1) * G[k];
+            V[k] = beta2 * V[k] + (1.f - beta2) * G[k] * G[k];
+            P[k] = P[k] * decay - step_size * M[k] / (sqrtf(V[k]) * inv_sqrt_bc2 + eps);
+        }
+        *reinterpret_cast<float4*>(p + i) = pp;
+        *reinterpret_cast<float4*>(m + i) = mm;
+        *reinterpret_cast<float4*>(v + i) = vv;
+        if (shadow) {
+            typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+            bf16x4 o;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) o[k] = (bf16_t)P[k];
+            *reinterpret_cast<bf16x4*>(shadow + i) = o;
+        }
+    } else {
+        for (int64_t j = i; j < n; ++j) {
+            const float gj = g[j];
+            const float mj = beta1 * m[j] + (1.f - beta1) * gj;
+            const float vj = beta2 * v[j] + (1.f - beta2) * gj * gj;
+            const float pj = p[j] * decay - step_size * mj / (sqrtf(vj) * inv_sqrt_bc2 + eps);
+            m[j] = mj; v[j] = vj; p[j] = pj;
+            if (shadow) shadow[j] = (bf16_t)pj;
+        }
+    }
+}
+}  // namespace
+
+extern "C" int mobgt_adamw_flat(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, void* shadow_bf16,
+                                int64_t n, const float* lr_dev, const int64_t* step_dev, int64_t step_base, float beta1,
+                                float beta2, float eps, float weight_decay, void* stream) {
+    if (n <= 0) return 0;
+    if (((uintptr_t)params | (uintptr_t)grads | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15) return MOBGT_EALIGN;
+    if (shadow_bf16 && ((uintptr_t)shadow_bf16 & 7)) return MOBGT_EALIGN;
+    const int64_t blocks = (n + 1023) / 1024;
+    hipLaunchKernelGGL(adamw_flat_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, params, grads, exp_avg,
+                       exp_avg_sq, reinterpret_cast<bf16_t*>(shadow_bf16), n, lr_dev, step_dev, step_base, beta1, beta2, eps,
+                       weight_decay);
+    return (int)hipGetLastError();
+}

@@ -199,6 +199,9 @@ def refresh_shadows(layers):
     for layer in layers:
         if getattr(layer, "act_dtype", torch.float32) == torch.float32 or not layer.fused:
             continue
+        if getattr(layer, "_shadow_external", False):       # kept current by the trainer's optimizer kernel
+            layer._shadow_fresh = True
+            continue
         mha = layer.self_attention
         wqkv, bqkv = mha.fuse_qkv_storage()
         masters = (wqkv, bqkv, mha.output_layer.weight, mha.output_layer.bias, layer.ffn.layer1.weight, layer.ffn.layer1.bias,

@@ -18,17 +18,23 @@ import torch.distributed as dist
 from .lr import PolynomialDecayLR
 
 
+def flat_offsets(params, align=8):
+    """Element offset of every parameter inside the flat buffers (each slot starts on a multiple of `align` elements,
+    so f32 slices are 32-byte and bf16 shadow slices 16-byte aligned) and the total length."""
+    offs, off = [], 0
+    for p in params:
+        offs.append(off)
+        off += (p.numel() + align - 1) // align * align
+    return offs, off
+
+
 class FlatGrads:
     def __init__(self, params, dtype=torch.float32):
         self.params = [p for p in params if p.requires_grad]
-        n = sum(p.numel() for p in self.params)
+        self.offsets, n = flat_offsets(self.params)
         dev = self.params[0].device
         self.flat = torch.zeros(n, dtype=dtype, device=dev)
-        self.views = []
-        off = 0
-        for p in self.params:
-            self.views.append(self.flat[off:off + p.numel()].view_as(p))
-            off += p.numel()
+        self.views = [self.flat[o:o + p.numel()].view_as(p) for p, o in zip(self.params, self.offsets)]
         self.attach()
 
     def attach(self):
@@ -105,15 +111,13 @@ class FlatParams:
 
     def __init__(self, model, params):
         self.params = params
-        n = sum(p.numel() for p in params)
-        flat = torch.empty(n, dtype=torch.float32, device=params[0].device)
-        off = 0
+        self.offsets, n = flat_offsets(params)
+        flat = torch.zeros(n, dtype=torch.float32, device=params[0].device)
         with torch.no_grad():
-            for p in params:
+            for p, off in zip(params, self.offsets):
                 v = flat[off:off + p.numel()].view_as(p)
                 v.copy_(p.data)
                 p.data = v
-                off += p.numel()
         self.tensor = torch.nn.Parameter(flat)
         # re-point the attention modules' fused-QKV handles at the new storage
         for m in model.modules():
@@ -173,13 +177,20 @@ class TrainStep:
         used = flat_order(model, used)
         self.flat = FlatGrads(used)
         self.n_head = len(head_parameters(model, used))              # params[:n_head] = the early bucket
-        self.n_head_elems = sum(p.numel() for p in used[:self.n_head])
+        self.n_head_elems = self.flat.offsets[self.n_head] if self.n_head < len(used) else self.flat.flat.numel()
         self.flat_params = FlatParams(model, used)
         ops.set_grad_sinks(self.flat.params, self.flat.views)        # big gradients are written in place (no gather copy)
         self.flat_params.tensor.grad = self.flat.flat
         self.lr_dev = torch.tensor(float(model.peak_lr), dtype=torch.float32, device=dev)
-        self.opt = torch.optim.AdamW([self.flat_params.tensor], lr=self.lr_dev, weight_decay=model.weight_decay,
-                                     capturable=True, fused=True)
+        # AdamW (model_fqandtoyo.py:1599-1616 defaults) as ONE kernel over the flat buffers that also refreshes the bf16
+        # shadow weights the layer GEMMs read (csrc/layer.hip: mobgt_adamw_flat); its step count is the per-step device
+        # counter `seed_dev` minus a base fixed at the first optimizer call
+        n = self.flat.flat.numel()
+        self.exp_avg = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.exp_avg_sq = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.shadow_flat = self._attach_shadows()
+        self._step_base = None
+        self.betas, self.eps = (0.9, 0.999), 1e-8
         self.sched_state = dict(step_count=1, warmup=model.warmup_updates, tot=model.tot_updates, lr=model.peak_lr,
                                 end_lr=model.end_lr, power=1.0)
         self._set_lr()
@@ -193,6 +204,42 @@ class TrainStep:
         self.overlap = bool(overlap and use_graph and (self.world > 1 or overlap == "force") and self.n_head > 0
                             and hasattr(model, "_enc_out"))
         self.graphs_b, self._g_enc = {}, {}
+
+    def _attach_shadows(self):
+        """bf16 copy of the whole flat parameter buffer; the fused layers' shadow weights become views of it, kept
+        current by the optimizer kernel instead of a per-step multi-tensor copy (model.refresh_shadows skips them)."""
+        layers = [l for l in getattr(self.model, "layers", []) if getattr(l, "fused", False)
+                  and getattr(l, "act_dtype", torch.float32) == torch.bfloat16]
+        if not layers:
+            return None
+        flat = self.flat_params.tensor.detach()
+        shadow = flat.to(torch.bfloat16)
+        base = flat.data_ptr()
+        for layer in layers:
+            mha = layer.self_attention
+            wqkv, bqkv = mha.fuse_qkv_storage()
+            masters = (wqkv, bqkv, mha.output_layer.weight, mha.output_layer.bias, layer.ffn.layer1.weight,
+                       layer.ffn.layer1.bias, layer.ffn.layer2.weight, layer.ffn.layer2.bias)
+            views = []
+            for m in masters:
+                off = (m.data_ptr() - base) // 4
+                if off < 0 or off + m.numel() > flat.numel() or not m.is_contiguous():
+                    return None                                         # not a slice of the flat buffer: keep the copies
+                views.append(shadow[off:off + m.numel()].view(m.shape))
+            layer._shadows = tuple(views)
+            layer._shadow_external = True
+        return shadow
+
+    def _opt_step(self):
+        from . import _lib
+        from .ops import _p, _stream
+        if self._step_base is None:                  # t = 1 on this very call; the counter advances once per step
+            self._step_base = int(self.seed_dev.item()) - 1
+        n = self.flat.flat.numel()
+        _lib.check(_lib.lib().mobgt_adamw_flat(_p(self.flat_params.tensor), _p(self.flat.flat), _p(self.exp_avg),
+                                               _p(self.exp_avg_sq), _p(self.shadow_flat), n, _p(self.lr_dev),
+                                               _p(self.seed_dev), self._step_base, self.betas[0], self.betas[1], self.eps,
+                                               float(self.model.weight_decay), _stream()), "mobgt_adamw_flat")
 
     def _on_stream(self):
         import contextlib
@@ -283,11 +330,11 @@ class TrainStep:
         for i in range(len(self.batches)):
             self.graphs[i] = self._capture(i)
         with self._on_stream():
-            self.opt.step()
+            self._opt_step()
         self._join()
         self.opt_graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.opt_graph, stream=self.stream):
-            self.opt.step()
+            self._opt_step()
 
     def step(self, i):
         """One optimizer step on pre-collated batch i (model_fqandtoyo.py:1434-1478 + optimizer + scheduler)."""
@@ -313,7 +360,7 @@ class TrainStep:
         if self.use_graph:
             self.opt_graph.replay()
         else:
-            self.opt.step()
+            self._opt_step()
         self.sched_state["step_count"] += 1
         self._set_lr()
         return self.loss_out

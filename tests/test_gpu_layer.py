@@ -131,3 +131,33 @@ def test_linear_wgrad_matches_fp32_reference(R, M, N):
     gs = wide[:, 2:2 + M]
     dw2, _ = ops.linear_wgrad(gs, x)
     np.testing.assert_allclose(dw2.cpu().numpy(), (gs.double().t() @ x.double()).cpu().numpy(), rtol=1e-4, atol=tol)
+
+
+def test_adamw_flat_matches_torch_adamw():
+    """mobgt_adamw_flat (one pass over the flat buffers, device lr / step counter, bf16 shadow) against
+    torch.optim.AdamW for five steps with changing learning rates."""
+    from mobgt_amd import _lib
+    from mobgt_amd.ops import _p, _stream
+    gen = torch.Generator().manual_seed(3)
+    n = 10007
+    p0 = torch.randn(n, generator=gen)
+    ref = torch.nn.Parameter(p0.clone().double())
+    opt = torch.optim.AdamW([ref], lr=1e-3, weight_decay=0.01)
+    p = p0.clone().to(DEV)
+    m, v = torch.zeros_like(p), torch.zeros_like(p)
+    sh = torch.zeros(n, dtype=torch.bfloat16, device=DEV)
+    lr_dev = torch.zeros((), dtype=torch.float32, device=DEV)
+    step_dev = torch.tensor([40], dtype=torch.int64, device=DEV)
+    for it in range(5):
+        g = torch.randn(n, generator=gen) * (0.1 + it)
+        lr = 1e-3 * (it + 1)
+        for grp in opt.param_groups:
+            grp["lr"] = lr
+        ref.grad = g.double()
+        opt.step()
+        lr_dev.fill_(lr)
+        step_dev.add_(1)
+        _lib.check(_lib.lib().mobgt_adamw_flat(_p(p), _p(g.to(DEV)), _p(m), _p(v), _p(sh), n, _p(lr_dev), _p(step_dev), 40,
+                                               0.9, 0.999, 1e-8, 0.01, _stream()), "mobgt_adamw_flat")
+        np.testing.assert_allclose(p.cpu().numpy(), ref.detach().float().numpy(), rtol=2e-5, atol=2e-6)
+    assert torch.equal(sh, p.bfloat16())
