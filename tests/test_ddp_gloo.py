@@ -52,7 +52,9 @@ def _worker(rank, world, port, out):
     assert m.a.weight.grad.data_ptr() == flat.flat.data_ptr()          # grads accumulate INTO the flat buffer
     flat.all_reduce_mean()
     if rank == 0:
-        torch.save({"flat": flat.flat.clone(), "w": m.a.weight.detach().clone()}, out)
+        # (slots in the flat buffer are padded to multiples of 8 elements: read the gradients through the views)
+        torch.save({"flat": torch.cat([v.reshape(-1) for v in flat.views]).clone(), "w": m.a.weight.detach().clone(),
+                    "padded": flat.flat.numel(), "offsets": list(flat.offsets)}, out)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -71,6 +73,7 @@ def test_flat_allreduce_matches_single_process(tmp_path):
     ((m(x) - y) ** 2).mean().backward()
     ref = torch.cat([p.grad.reshape(-1) for p in (m.a.weight, m.a.bias, m.b.weight, m.b.bias)])
     torch.testing.assert_close(got["flat"], ref, rtol=1e-5, atol=1e-6)
+    assert got["padded"] % 8 == 0 and all(o % 8 == 0 for o in got["offsets"])
 
 
 def test_shard_indices_follow_distributed_sampler():
