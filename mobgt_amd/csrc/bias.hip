@@ -79,17 +79,17 @@ __device__ __forceinline__ float spd_divisor(int rp, int D) {
 
 template <typename TI, typename TE, typename TB, int HH>
 __global__ __launch_bounds__(256) void build_bias_kernel(const BuildParams p) {
-    __shared__ float tile[HH][TILE][TILE + 1];
+    // one workgroup = one 8-row round of a 32x32 tile (blockIdx.y = 4 * tile row + round): a short batch
+    // (16 graphs x 41 tokens = 64 tiles) still spreads over 256 workgroups
+    __shared__ float tile[HH][8][TILE + 1];
     const int g = blockIdx.z;
     const int N = p.N, T = N + 1;
-    const int i0 = blockIdx.y * TILE, j0 = blockIdx.x * TILE;    // token coordinates (0 = graph token)
+    const int i0 = (blockIdx.y >> 2) * TILE, r = (blockIdx.y & 3) * 8, j0 = blockIdx.x * TILE;    // token coordinates
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
     const float inv_f = 1.f / (float)p.F;
     TB* B = reinterpret_cast<TB*>(p.bias);
     TB* BT = reinterpret_cast<TB*>(p.bias_t);
-
-#pragma unroll 1
-    for (int r = 0; r < TILE; r += 8) {
+    {
         const int ti = i0 + ty + r, tj = j0 + tx;                // token indices
         float acc[HH];
         bool live = ti < T && tj < T;
@@ -133,20 +133,24 @@ __global__ __launch_bounds__(256) void build_bias_kernel(const BuildParams p) {
         }
 #pragma unroll
         for (int h = 0; h < HH; ++h) {
-            tile[h][ty + r][tx] = acc[h];
+            tile[h][ty][tx] = acc[h];
             if (ti < T && tj < p.ld) B[(((int64_t)g * HH + h) * T + ti) * p.ld + tj] = to_out<TB>(acc[h]);
         }
     }
     if (!BT) return;
     __syncthreads();
-#pragma unroll 1
-    for (int r = 0; r < TILE; r += 8) {
-        const int tj = j0 + ty + r, ti = i0 + tx;
-        if (tj < T && ti < p.ld) {
+    // transposed copy: row tj of bias_t receives the 8 consecutive queries i0+r .. i0+r+7 of this round
+    for (int e = threadIdx.x; e < HH * TILE; e += 256) {
+        const int h = e / TILE, c = e % TILE;
+        const int tj = j0 + c;
+        if (tj >= T) continue;
+        // ld is a multiple of 32 and i0 + r of 8: the 8 elements are in range and 16-byte aligned -> one (bf16) or
+        // two (f32) 16-byte stores
+        TB* dst = BT + (((int64_t)g * HH + h) * T + tj) * p.ld + i0 + r;
+        float v8[8];
 #pragma unroll
-            for (int h = 0; h < HH; ++h)
-                BT[(((int64_t)g * HH + h) * T + tj) * p.ld + ti] = to_out<TB>(tile[h][tx][ty + r]);
-        }
+        for (int q = 0; q < 8; ++q) v8[q] = tile[h][q][c];
+        store8(dst, v8);
     }
 }
 
@@ -483,7 +487,7 @@ template <typename TI, typename TE, typename TB>
 int launch_build(const BuildParams& p, hipStream_t st) {
     const int T = p.N + 1;
     const int nt = (int)((p.ld + TILE - 1) / TILE);
-    const dim3 grid(nt, (T + TILE - 1) / TILE, p.G), block(256);
+    const dim3 grid(nt, 4 * ((T + TILE - 1) / TILE), p.G), block(256);
     if (p.H == 8) hipLaunchKernelGGL((build_bias_kernel<TI, TE, TB, 8>), grid, block, 0, st, p);
     else if (p.H == 4) hipLaunchKernelGGL((build_bias_kernel<TI, TE, TB, 4>), grid, block, 0, st, p);
     else return MOBGT_EBADDIM;
