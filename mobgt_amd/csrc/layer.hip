@@ -498,6 +498,17 @@ int pick_rows(int64_t R) {
     // 4 rows (one per wave) per workgroup while that gives <= 512 workgroups, more rows beyond: every
     // workgroup ends with one f32 atomic per column onto the SAME C addresses, and that contention (not the
     // streaming) set the kernel time at R = 12.5k rows (measured 54 us with 3140 workgroups)
+    // Few rows: aim at ~64 workgroups rather than one row per wave (R = 608: 152 workgroups x 576 atomics on the
+    // same addresses cost more than walking 3 rows per wave).
+    int64_t wgs = R / 16;
+    wgs = wgs < 64 ? 64 : (wgs > 512 ? 512 : wgs);
+    int rows = (int)((R + wgs - 1) / wgs);
+    rows = (rows + 3) / 4 * 4;
+    return rows < 4 ? 4 : rows;
+}
+
+// kernels without a per-workgroup atomic tail: one row per wave while that gives <= 512 workgroups
+int pick_rows_stream(int64_t R) {
     int rows = (int)((R + 511) / 512);
     rows = (rows + 3) / 4 * 4;
     return rows < 4 ? 4 : rows;
@@ -521,7 +532,7 @@ extern "C" int mobgt_dropout_add_ln_fwd(const float* x, const void* y, float* x1
     p.x = x; p.y = y; p.x1 = x1; p.w = ln_w; p.b = ln_b; p.z = z; p.z32 = z32; p.mean = mean; p.rstd = rstd;
     p.R = R; p.C = C;
     set_drop(p, y ? dropout_p : 0.f, seed, seed_dev, salt);
-    p.rows_per_wg = pick_rows(R);
+    p.rows_per_wg = pick_rows_stream(R);
     const dim3 grid((unsigned)((R + p.rows_per_wg - 1) / p.rows_per_wg)), block(256);
     hipStream_t st = (hipStream_t)stream;
     const bool v4 = C % 4 == 0 && C <= 256 * V4_CH;
