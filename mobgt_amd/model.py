@@ -290,7 +290,7 @@ class Graphormer(nn.Module):
         if self.edge_type != "multi_hop":
             raise NotImplementedError("only edge_type='multi_hop' is used by MobGT (README.md:62)")
         hop = hop_table_from(self.edge_encoder.weight, self.edge_dis_encoder.weight, H, D)
-        rel = no_grad_row0(self.rel_pos_encoder.weight)
+        rel = self.rel_pos_encoder.weight      # padding_idx = 0: build_bias_bwd never adds into row 0
         return ops.build_bias(batched_data.attn_bias, batched_data.rel_pos, None, edge_input, rel, None, hop,
                               self.graph_token_virtual_distance.weight, D, dtype=self.bias_dtype)
 

@@ -278,7 +278,9 @@ class Graphormer(nn.Module):
             D = min(D, self.multi_hop_max_dist)
         hop = hop_table_from(self.edge_encoder.weight, self.edge_dis_encoder.weight, H, D, fp16_roundtrip=True)
         return ops.build_bias(batched_data.attn_bias, batched_data.rel_pos, batched_data.poi_pos, edge_input,
-                              no_grad_row0(self.rel_pos_encoder.weight), no_grad_row0(self.poi_pos_encoder.weight), hop,
+                              # (padding_idx = 0: build_bias_bwd never adds into row 0 of these two tables, so the
+                              # tables go in as they are -- no cat / split / zero-fill launches around the kernel)
+                              self.rel_pos_encoder.weight, self.poi_pos_encoder.weight, hop,
                               self.graph_token_virtual_distance.weight, D, dtype=self.bias_dtype)
 
     def node_features(self, batched_data):
@@ -337,6 +339,8 @@ class Graphormer(nn.Module):
         else:
             logits = self.out_proj(tok)
         ops.trace_nan("logits", logits)
+        if getattr(self, "_poi_logits_only", False):     # training_step reads logits[0] only (:1446-1460)
+            return [logits, None]
         return [logits, self.cat_decoder(tok)]                                                 # :1394-1396
 
     # modules whose parameters only receive gradient from the part of the graph ABOVE the encoder output: their
@@ -345,7 +349,11 @@ class Graphormer(nn.Module):
 
     def training_step(self, batched_data, batch_idx=0):
         """model_fqandtoyo.py:1446-1460: y-1 targets, GradientTailLoss(alpha=0.2) on the POI logits only."""
-        y_hat = self(batched_data)[0]
+        self._poi_logits_only = True
+        try:
+            y_hat = self(batched_data)[0]
+        finally:
+            self._poi_logits_only = False
         return ops.gradient_tail_loss(y_hat, batched_data.y.long() - 1, 0.2)
 
     def validation_step(self, batched_data, batch_idx=0):

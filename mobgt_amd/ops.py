@@ -611,7 +611,24 @@ class _GradientTailLossFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         (dlogits,) = ctx.saved_tensors
+        if g.data_ptr() == unit_grad(g.device).data_ptr():      # d(loss)/d(loss) = 1 supplied by the trainer: no multiply
+            return dlogits, None, None
         return dlogits * g, None, None
+
+
+_UNIT = {}
+
+
+def unit_grad(device):
+    """A persistent scalar 1.0 per device.  `loss.backward(gradient=unit_grad(dev))` saves autograd's ones_like fill
+    and lets the loss node skip its multiplication by one."""
+    device = torch.device(device)
+    key = (device.type, device.index if device.index is not None else (torch.cuda.current_device() if device.type == "cuda" else 0))
+    t = _UNIT.get(key)
+    if t is None:
+        t = torch.ones((), dtype=torch.float32, device=device)
+        _UNIT[key] = t
+    return t
 
 
 def gradient_tail_loss(logits, targets, alpha=0.25):

@@ -15,6 +15,7 @@ import os
 import torch
 import torch.distributed as dist
 
+from . import ops
 from .lr import PolynomialDecayLR
 
 
@@ -277,7 +278,7 @@ class TrainStep:
         self.arena.reset()                         # one fill for all small zero-initialised accumulators of the step
         self.seed_dev.add_(1)                      # new dropout masks each step (attention kernels read it on device)
         loss = self._loss(batch)
-        loss.backward()
+        loss.backward(gradient=ops.unit_grad(loss.device))
         self.flat.gather()
         self.loss_out.copy_(loss.detach())
 
@@ -290,7 +291,7 @@ class TrainStep:
         loss = self._loss(batch)
         enc = self.model._enc_out
         head = self.flat.params[:self.n_head]
-        grads = torch.autograd.grad(loss, head + [enc], allow_unused=True)     # frees only the nodes it ran
+        grads = torch.autograd.grad(loss, head + [enc], grad_outputs=ops.unit_grad(loss.device), allow_unused=True)   # frees only the nodes it ran
         self.flat.gather(0, self.n_head, grads=list(grads[:-1]))
         self._g_enc[i] = (enc, grads[-1])
         self.loss_out.copy_(loss.detach())
