@@ -297,6 +297,18 @@ int mobgt_linear_wgrad_group(int n, const void* const* g, const int64_t* ldg, co
                              float* const* dw, const int64_t* ldw, float* const* db, int64_t R, const int* M,
                              const int* N, int act_dtype, void* stream);
 
+/* Token assembly at the encoder input (model_fqandtoyo.py:1287-1298, 348-358, 1338-1347) in one launch:
+ *   out[g,0,:] = drop_in(drop_pos(token + pe0));  out[g,1+n,:] = drop_in(drop_pos(nf[g,n,:] * real[g,n] + add[g,n,:]))
+ * nf, add [G,N,C], real [G,N], token, pe0 [C], out [G,N+1,C], all f32; p_pos / p_in the two dropout probabilities
+ * (0 = off), masks from the library's counter hash with the given salts (row numbering g*N+n / g / g*T+t).
+ * Backward: d_nf, d_add [G,N,C] overwritten; d_token [C] ACCUMULATED (sum over graphs; zero it first). */
+int mobgt_assemble_tokens_fwd(const float* nf, const float* real, const float* add, const float* token, const float* pe0,
+                              float* out, int G, int N, int C, float p_pos, float p_in, uint64_t seed,
+                              const uint64_t* seed_dev, uint32_t salt_nf, uint32_t salt_tok, uint32_t salt_in, void* stream);
+int mobgt_assemble_tokens_bwd(const float* dout, const float* real, float* d_nf, float* d_add, float* d_token, int G, int N,
+                              int C, float p_pos, float p_in, uint64_t seed, const uint64_t* seed_dev, uint32_t salt_nf,
+                              uint32_t salt_tok, uint32_t salt_in, void* stream);
+
 /* torch.optim.AdamW (defaults of model_fqandtoyo.py:1599-1616) over one flat f32 parameter buffer of n elements, in
  * place, with device-resident learning rate and step counter (step t = *step_dev - step_base >= 1) so that a captured
  * graph advances on replay; optionally refreshes a bf16 copy of the parameters (shadow_bf16, may be NULL).

@@ -789,3 +789,93 @@ extern "C" int mobgt_adamw_flat(float* params, const float* grads, float* exp_av
                        weight_decay);
     return (int)hipGetLastError();
 }
+
+// ------------------------------------------------------------------------------------------------
+// Token assembly at the encoder input (model_fqandtoyo.py:1287-1298, 348-358, 1338-1347), one launch each way:
+//   out[g, 0,   :] = drop_in( drop_pos( graph_token + pe[0] ) )
+//   out[g, 1+n, :] = drop_in( drop_pos( nf[g,n,:] * real[g,n] + add[g,n,:] ) )
+// drop_pos = LearnablePositionalEncoding's dropout (:358), drop_in = input_dropout (:1347); the masks are the very
+// ones the stand-alone dropout launches drew (same salts, same row numbering: g*N+n and g for drop_pos, g*T+t for
+// drop_in), so this replaces -- bit for bit -- a multiply, an add, a repeat, an add, three dropouts and a cat.
+namespace {
+struct TokParams {
+    const float *nf, *real, *add, *token, *pe0;
+    float* out;
+    const float* dout;
+    float *d_nf, *d_add, *d_token;           // d_token [C]: accumulated with atomics (zero it first)
+    int G, N, C;
+    uint32_t thr_pos, thr_in;
+    float keep_pos, keep_in;                 // 1 / (1 - p)
+    uint64_t seed;
+    const uint64_t* seed_dev;
+    uint32_t salt_nf, salt_tok, salt_in;
+};
+
+template <bool BWD>
+__global__ __launch_bounds__(256) void assemble_tokens_kernel(const TokParams p) {
+    const int T = p.N + 1;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);          // one wave per output row (g, t)
+    if (row >= (int64_t)p.G * T) return;
+    const int lane = threadIdx.x & 63;
+    const int g = (int)(row / T), t = (int)(row - (int64_t)g * T);
+    const uint64_t seed = p.seed + (p.seed_dev ? *p.seed_dev : 0ull);
+    const bool tok = t == 0;
+    const uint32_t r1 = tok ? (uint32_t)g : (uint32_t)(g * p.N + (t - 1));
+    const uint32_t h1 = p.thr_pos ? dropout_row_hash(seed, r1 ^ (tok ? p.salt_tok : p.salt_nf)) : 0u;
+    const uint32_t h2 = p.thr_in ? dropout_row_hash(seed, (uint32_t)row ^ p.salt_in) : 0u;
+    const int64_t src = ((int64_t)g * p.N + (t - 1)) * p.C;
+    const float rl = tok ? 1.f : p.real[(int64_t)g * p.N + (t - 1)];
+    for (int c = lane; c < p.C; c += 64) {
+        float scale = 1.f;
+        if (p.thr_pos) scale = dropout_bits16(seed, h1, (uint32_t)c) >= p.thr_pos ? p.keep_pos : 0.f;
+        if (p.thr_in) scale *= dropout_bits16(seed, h2, (uint32_t)c) >= p.thr_in ? p.keep_in : 0.f;
+        if (!BWD) {
+            const float v = tok ? p.token[c] + p.pe0[c] : p.nf[src + c] * rl + p.add[src + c];
+            p.out[row * p.C + c] = v * scale;
+        } else {
+            const float d = p.dout[row * p.C + c] * scale;
+            if (tok) {
+                if (d != 0.f) atomicAdd(&p.d_token[c], d);
+            } else {
+                p.d_nf[src + c] = d * rl;
+                p.d_add[src + c] = d;
+            }
+        }
+    }
+}
+
+void fill_tok(TokParams& p, float p_pos, float p_in, uint64_t seed, const uint64_t* seed_dev, uint32_t s_nf, uint32_t s_tok,
+              uint32_t s_in) {
+    p.thr_pos = p_pos > 0.f ? dropout_threshold(p_pos) : 0u;
+    p.thr_in = p_in > 0.f ? dropout_threshold(p_in) : 0u;
+    p.keep_pos = p.thr_pos ? 1.f / (1.f - (float)p.thr_pos / 65536.f) : 1.f;
+    p.keep_in = p.thr_in ? 1.f / (1.f - (float)p.thr_in / 65536.f) : 1.f;
+    p.seed = seed; p.seed_dev = seed_dev; p.salt_nf = s_nf; p.salt_tok = s_tok; p.salt_in = s_in;
+}
+}  // namespace
+
+extern "C" int mobgt_assemble_tokens_fwd(const float* nf, const float* real, const float* add, const float* token,
+                                         const float* pe0, float* out, int G, int N, int C, float p_pos, float p_in,
+                                         uint64_t seed, const uint64_t* seed_dev, uint32_t salt_nf, uint32_t salt_tok,
+                                         uint32_t salt_in, void* stream) {
+    if (G <= 0 || N < 0 || C <= 0) return MOBGT_EBADDIM;
+    TokParams p = {};
+    p.nf = nf; p.real = real; p.add = add; p.token = token; p.pe0 = pe0; p.out = out; p.G = G; p.N = N; p.C = C;
+    fill_tok(p, p_pos, p_in, seed, seed_dev, salt_nf, salt_tok, salt_in);
+    const int64_t rows = (int64_t)G * (N + 1);
+    hipLaunchKernelGGL(assemble_tokens_kernel<false>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, p);
+    return (int)hipGetLastError();
+}
+
+extern "C" int mobgt_assemble_tokens_bwd(const float* dout, const float* real, float* d_nf, float* d_add, float* d_token,
+                                         int G, int N, int C, float p_pos, float p_in, uint64_t seed,
+                                         const uint64_t* seed_dev, uint32_t salt_nf, uint32_t salt_tok, uint32_t salt_in,
+                                         void* stream) {
+    if (G <= 0 || N < 0 || C <= 0) return MOBGT_EBADDIM;
+    TokParams p = {};
+    p.dout = dout; p.real = real; p.d_nf = d_nf; p.d_add = d_add; p.d_token = d_token; p.G = G; p.N = N; p.C = C;
+    fill_tok(p, p_pos, p_in, seed, seed_dev, salt_nf, salt_tok, salt_in);
+    const int64_t rows = (int64_t)G * (N + 1);
+    hipLaunchKernelGGL(assemble_tokens_kernel<true>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, p);
+    return (int)hipGetLastError();
+}

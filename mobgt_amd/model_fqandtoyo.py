@@ -310,21 +310,21 @@ class Graphormer(nn.Module):
         ce = ops.embed_gather_sum([catemb], [cat_idx])
         nf = self.embed_fuse_model4(f2, ce)                                                    # :1269
         ops.trace_nan("fuse4", nf)
-        nf = nf * real.unsqueeze(-1)                                                           # pads stay 0
+        # (pads stay 0: the multiplication by `real` happens inside assemble_tokens)
         # + fre_embed(0) + degree rows + positional rows pe[1..n] (:1287-1298, :348-351)
         add = ops.embed_gather_sum(
             [self.fre_embed_model.weight, self.in_degree_encoder.weight, self.out_degree_encoder.weight, self.pos_embed.pe],
             [zero_idx, batched_data.in_degree.long(), batched_data.out_degree.long(), pos_idx],
             padding_idx=[0, 0, 0, None])
-        nf = ops.dropout(nf.float() + add, self.pos_embed.dropout.p, self.training, 0x1001)        # :358
-        tok = self.graph_token.weight.unsqueeze(0).repeat(G, 1, 1) + self.pos_embed.pe[0]      # :1338-1342
-        tok = ops.dropout(tok, self.pos_embed.dropout.p, self.training, 0x1002)
-        return torch.cat([tok, nf], dim=1)
+        # nf * real + add -> pos_embed dropout (:358); graph token + pe[0] -> the same dropout (:1338-1342); cat;
+        # input_dropout (:1347): one launch
+        return ops.assemble_tokens(nf, real, add, self.graph_token.weight, self.pos_embed.pe[0], self.pos_embed.dropout.p,
+                                   self.input_dropout.p, self.training)
 
     def forward(self, batched_data, perturb=None):
         bias = self.assemble_bias(batched_data)
         refresh_shadows(self.layers)
-        output = ops.dropout(self.node_features(batched_data), self.input_dropout.p, self.training, 0x1003)
+        output = self.node_features(batched_data)
         ops.trace_nan("x0", output)
         for li, enc_layer in enumerate(self.layers):                                           # :1347-1352
             output = enc_layer(output, bias, mask=None)

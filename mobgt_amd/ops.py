@@ -714,6 +714,49 @@ def dropout(x, p, training, salt):
     return _DropoutFn.apply(x.float(), float(p), int(seed), seed_dev, int(salt) & 0xFFFFFFFF)
 
 
+class _AssembleTokensFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, nf, real, add, token, pe0, p_pos, p_in, seed, seed_dev, salts):
+        G, N, C = nf.shape
+        nf, add, real = nf.contiguous(), add.contiguous(), real.contiguous()
+        shapes = (token.shape, pe0.shape)
+        token, pe0 = token.reshape(-1).contiguous(), pe0.reshape(-1).contiguous()
+        out = torch.empty(G, N + 1, C, dtype=torch.float32, device=nf.device)
+        check(_lib.lib().mobgt_assemble_tokens_fwd(_p(nf), _p(real), _p(add), _p(token), _p(pe0), _p(out), G, N, C, p_pos, p_in,
+                                                   seed, _p(seed_dev), salts[0], salts[1], salts[2], _stream()),
+              "mobgt_assemble_tokens_fwd")
+        ctx.save_for_backward(real)
+        ctx.misc = (G, N, C, p_pos, p_in, seed, seed_dev, salts, shapes)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (real,) = ctx.saved_tensors
+        G, N, C, p_pos, p_in, seed, seed_dev, salts, (tshape, pshape) = ctx.misc
+        dout = dout.contiguous()
+        d_nf = torch.empty(G, N, C, dtype=torch.float32, device=dout.device)
+        d_add = torch.empty(G, N, C, dtype=torch.float32, device=dout.device)
+        d_tok = zeros_f32((C,), dout.device)
+        check(_lib.lib().mobgt_assemble_tokens_bwd(_p(dout), _p(real), _p(d_nf), _p(d_add), _p(d_tok), G, N, C, p_pos, p_in, seed,
+                                                   _p(seed_dev), salts[0], salts[1], salts[2], _stream()),
+              "mobgt_assemble_tokens_bwd")
+        return d_nf, None, d_add, d_tok.view(tshape), d_tok.view(pshape), None, None, None, None, None
+
+
+def assemble_tokens(nf, real, add, token, pe0, p_pos, p_in, training, salts=(0x1001, 0x1002, 0x1003)):
+    """[G,N+1,C] encoder input: graph token row (+ pe[0]) and the node features (* real + add), each through the
+    positional dropout and then the input dropout -- one launch forward, one backward (see mobgt_assemble_tokens_fwd).
+    `token` and `pe0` are [C]-sized; their gradient is the same per-column sum over graphs."""
+    _require_cuda(nf, add, token, pe0)
+    if not training:
+        p_pos = p_in = 0.0
+    seed, seed_dev = _DROPOUT_STATE["seed"], _DROPOUT_STATE["seed_dev"]
+    if seed_dev is None and (p_pos > 0 or p_in > 0):
+        seed = (seed + int(torch.randint(0, 2 ** 31 - 1, (1,)).item())) & 0x7FFFFFFFFFFFFFFF
+    return _AssembleTokensFn.apply(nf.float(), real.float(), add.float(), token.float(), pe0.float(), float(p_pos),
+                                   float(p_in), int(seed), seed_dev, tuple(int(s) & 0xFFFFFFFF for s in salts))
+
+
 # ------------------------------------------------------------------------------ debug: NaN tracer
 _NAN_TRACE = {"flags": None, "names": [], "on": False}
 
