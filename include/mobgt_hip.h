@@ -216,13 +216,15 @@ int mobgt_embed_scatter_add(float* const* d_tables_host, const void* const* idx_
  * :1287-1298 + :348-351 (positional rows 1..n) need, derived from the padded batch in one launch.
  *   x [G,N] int64 POI ids (0 = pad) and time_normal [G,N] f32, both with element strides (g, n);
  *   poi2cat [P+1] int64 (row 0 = pad).
- * idx [6][G*N] int64 (-1 = "no row" in 0..3):
+ * idx [8][G*N] int64 (-1 = "no row" in 0..3):
  *   0: POI row  (rows_only ? the position g*N+n in a per-batch table : x-1)       1: (long)(time_normal*48)
  *   2: poi2cat[x]-1      3: n+1 where n+1 <= number of real nodes of graph g      4: max(x-1, 0)      5: zeros
+ *   6, 7: in_degree / out_degree [G*N] (contiguous; deg_dtype MOBGT_I64 / I32 / I16) widened to int64 -- left
+ *         untouched when in_degree is NULL
  * real [G*N] f32: 1 for real nodes, 0 for padding. */
 int mobgt_node_index(const int64_t* x, int64_t xs_g, int64_t xs_n, const float* time_normal, int64_t ts_g,
-                     int64_t ts_n, const int64_t* poi2cat, int64_t* idx, float* real, int G, int N, int rows_only,
-                     void* stream);
+                     int64_t ts_n, const int64_t* poi2cat, const void* in_degree, const void* out_degree, int deg_dtype,
+                     int64_t* idx, float* real, int G, int N, int rows_only, void* stream);
 
 /* nn.Linear on a handful of rows (G <= 16, K <= 512, K % 4 == 0; f32): y [G,V] = x [G,K] w[V,K]^T + b[V] -- the
  * classifier head out_proj on the graph tokens (model_fqandtoyo.py:1394) -- and its backward: dx [G,K] (or NULL),

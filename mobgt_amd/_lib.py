@@ -54,7 +54,7 @@ SIGNATURES = {
     "mobgt_assemble_tokens_bwd": (_i, [_vp] * 5 + [_i, _i, _i, _f, _f, _u64, _vp, _c.c_uint32, _c.c_uint32, _c.c_uint32, _vp]),
     "mobgt_adamw_flat": (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _i64, _f, _f, _f, _f, _vp]),
     "mobgt_gather_rows_t": (_i, [_vp, _i64, _vp, _vp, _vp, _i, _i, _vp]),
-    "mobgt_node_index": (_i, [_vp, _i64, _i64, _vp, _i64, _i64, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    "mobgt_node_index": (_i, [_vp, _i64, _i64, _vp, _i64, _i64, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _vp]),
 }
 
 _lib = None

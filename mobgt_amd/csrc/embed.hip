@@ -157,7 +157,9 @@ struct NodeIndexParams {
     const int64_t* x; int64_t xs_g, xs_n;           // POI ids [G,N] (0 = pad), element strides
     const float* tn;  int64_t ts_g, ts_n;           // time_normal [G,N]
     const int64_t* poi2cat;                          // [P+1]
-    int64_t* idx;                                    // [6][G*N]
+    const void *indeg, *outdeg;                      // [G*N] degrees (deg_dtype), or null
+    int deg_dtype;
+    int64_t* idx;                                    // [8][G*N]
     float* real;                                     // [G*N]
     int G, N, rows_only;
 };
@@ -186,6 +188,14 @@ __global__ __launch_bounds__(256) void node_index_kernel(const NodeIndexParams p
         p.idx[3 * GN + r] = real && n + 1 <= cnt ? n + 1 : -1;
         p.idx[4 * GN + r] = poi > 0 ? poi - 1 : 0;
         p.idx[5 * GN + r] = 0;
+        if (p.indeg) {
+            int64_t a, b;
+            if (p.deg_dtype == MOBGT_I16) { a = reinterpret_cast<const int16_t*>(p.indeg)[r]; b = reinterpret_cast<const int16_t*>(p.outdeg)[r]; }
+            else if (p.deg_dtype == MOBGT_I32) { a = reinterpret_cast<const int32_t*>(p.indeg)[r]; b = reinterpret_cast<const int32_t*>(p.outdeg)[r]; }
+            else { a = reinterpret_cast<const int64_t*>(p.indeg)[r]; b = reinterpret_cast<const int64_t*>(p.outdeg)[r]; }
+            p.idx[6 * GN + r] = a;
+            p.idx[7 * GN + r] = b;
+        }
         p.real[r] = real ? 1.f : 0.f;
     }
 }
@@ -193,10 +203,12 @@ __global__ __launch_bounds__(256) void node_index_kernel(const NodeIndexParams p
 }  // namespace
 
 extern "C" int mobgt_node_index(const int64_t* x, int64_t xs_g, int64_t xs_n, const float* time_normal, int64_t ts_g,
-                                int64_t ts_n, const int64_t* poi2cat, int64_t* idx, float* real, int G, int N,
-                                int rows_only, void* stream) {
+                                int64_t ts_n, const int64_t* poi2cat, const void* in_degree, const void* out_degree,
+                                int deg_dtype, int64_t* idx, float* real, int G, int N, int rows_only, void* stream) {
     if (G <= 0 || N <= 0) return 0;
-    NodeIndexParams p = {x, xs_g, xs_n, time_normal, ts_g, ts_n, poi2cat, idx, real, G, N, rows_only};
+    if (in_degree && deg_dtype != MOBGT_I64 && deg_dtype != MOBGT_I32 && deg_dtype != MOBGT_I16) return MOBGT_EDTYPE;
+    NodeIndexParams p = {x, xs_g, xs_n, time_normal, ts_g, ts_n, poi2cat, in_degree, out_degree, deg_dtype, idx, real, G, N,
+                         rows_only};
     hipLaunchKernelGGL(node_index_kernel, dim3(G), dim3(256), 0, (hipStream_t)stream, p);
     return (int)hipGetLastError();
 }

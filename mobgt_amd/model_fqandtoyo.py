@@ -292,8 +292,9 @@ class Graphormer(nn.Module):
         # every gather index of :1259-1264 / :1287-1298 in one launch: POI row (in the compact per-batch table
         # when rows_only: row p belongs to position p), time slot (:1262), category row (:1259), positional
         # row 1..n (:348-351), GCN row, zeros
-        idx, real = ops.node_index(x, batched_data.time_normal[:, :, 0].float(), self.poi2cat, rows_only)
-        poi_idx, time_idx, cat_idx, pos_idx, gcn_rows, zero_idx = idx.unbind(0)
+        idx, real = ops.node_index(x, batched_data.time_normal[:, :, 0].float(), self.poi2cat, rows_only,
+                                   batched_data.in_degree, batched_data.out_degree)
+        poi_idx, time_idx, cat_idx, pos_idx, gcn_rows, zero_idx, in_deg, out_deg = idx.unbind(0)
         if rows_only:
             poidist = self.poi_distance_model(self.X, self.D_A, self.D_AX, rows=gcn_rows.reshape(-1), adj_t=self.D_A_T)
         else:
@@ -314,7 +315,7 @@ class Graphormer(nn.Module):
         # + fre_embed(0) + degree rows + positional rows pe[1..n] (:1287-1298, :348-351)
         add = ops.embed_gather_sum(
             [self.fre_embed_model.weight, self.in_degree_encoder.weight, self.out_degree_encoder.weight, self.pos_embed.pe],
-            [zero_idx, batched_data.in_degree.long(), batched_data.out_degree.long(), pos_idx],
+            [zero_idx, in_deg, out_deg, pos_idx],
             padding_idx=[0, 0, 0, None])
         # nf * real + add -> pos_embed dropout (:358); graph token + pe[0] -> the same dropout (:1338-1342); cat;
         # input_dropout (:1347): one launch

@@ -520,18 +520,24 @@ def target_rank(scores, target):
     return rank
 
 
-def node_index(x, time_normal, poi2cat, rows_only):
+def node_index(x, time_normal, poi2cat, rows_only, in_degree=None, out_degree=None):
     """Row indices of the node-feature gathers (model_fqandtoyo.py:1259-1264, 1287-1298) in one launch.
-    x [G,N] int64 POI ids, time_normal [G,N] f32 -> (idx [6,G,N] int64, real [G,N] f32); rows of idx:
-    POI row, time slot, category row, positional row (all -1 where there is none), GCN row max(x-1,0), zeros."""
+    x [G,N] int64 POI ids, time_normal [G,N] f32 -> (idx [8,G,N] int64, real [G,N] f32); rows of idx:
+    POI row, time slot, category row, positional row (all -1 where there is none), GCN row max(x-1,0), zeros,
+    in-degree, out-degree (the last two only when the [G,N] degree tensors are given; widened to int64)."""
     _require_cuda(x, time_normal, poi2cat)
     assert x.dtype == torch.int64 and time_normal.dtype == torch.float32 and poi2cat.dtype == torch.int64
     G, N = x.shape
-    idx = torch.empty(6, G, N, dtype=torch.int64, device=x.device)
+    idx = torch.empty(8, G, N, dtype=torch.int64, device=x.device)
     real = torch.empty(G, N, dtype=torch.float32, device=x.device)
+    deg_dt = I64
+    if in_degree is not None:
+        in_degree, out_degree = in_degree.reshape(G, N).contiguous(), out_degree.reshape(G, N).contiguous()
+        assert in_degree.dtype == out_degree.dtype and in_degree.dtype in _IT
+        deg_dt = _IT[in_degree.dtype]
     check(_lib.lib().mobgt_node_index(_p(x), x.stride(0), x.stride(1), _p(time_normal), time_normal.stride(0),
-                                      time_normal.stride(1), _p(poi2cat), _p(idx), _p(real), G, N, int(bool(rows_only)),
-                                      _stream()), "mobgt_node_index")
+                                      time_normal.stride(1), _p(poi2cat), _p(in_degree), _p(out_degree), deg_dt, _p(idx),
+                                      _p(real), G, N, int(bool(rows_only)), _stream()), "mobgt_node_index")
     return idx, real
 
 

@@ -242,7 +242,9 @@ def test_node_index_kernel_matches_index_expressions():
     poi2cat = torch.randint(1, 40, (P + 1,), generator=g)
     poi2cat[0] = 0
     for rows_only in (False, True):
-        idx, real = ops.node_index(x.to(DEV), tn[:, :, 0].to(DEV), poi2cat.to(DEV), rows_only)
+        indeg = torch.randint(0, 9, (G, N), generator=g).to(torch.int16)
+        outdeg = torch.randint(0, 9, (G, N), generator=g).to(torch.int16)
+        idx, real = ops.node_index(x.to(DEV), tn[:, :, 0].to(DEV), poi2cat.to(DEV), rows_only, indeg.to(DEV), outdeg.to(DEV))
         idx, real = idx.cpu(), real.cpu()
         m = x != 0
         neg = torch.full_like(x, -1)
@@ -254,6 +256,7 @@ def test_node_index_kernel_matches_index_expressions():
         assert torch.equal(idx[3], torch.where(m & (pos <= m.sum(1, keepdim=True)), pos, neg))
         assert torch.equal(idx[4], (x - 1).clamp(min=0))
         assert torch.equal(idx[5], torch.zeros_like(x))
+        assert torch.equal(idx[6], indeg.long()) and torch.equal(idx[7], outdeg.long())
         assert torch.equal(real, m.float())
 
 
