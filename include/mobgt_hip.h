@@ -311,6 +311,17 @@ int mobgt_assemble_tokens_bwd(const float* dout, const float* real, float* d_nf,
                               int C, float p_pos, float p_in, uint64_t seed, const uint64_t* seed_dev, uint32_t salt_nf,
                               uint32_t salt_tok, uint32_t salt_in, void* stream);
 
+/* Head activation chain on the graph-token rows (model_fqandtoyo.py:1353-1364), u [R,C] f32, C <= 512:
+ *   out = dropout(ELU(LayerNorm(LeakyReLU_slope(u)) * ln_w + ln_b))   (mean / rstd [R] saved for the backward)
+ * Backward: du [R,C] overwritten; dgamma, dbeta [C] ACCUMULATED (zero them first).  Dropout: the library's counter
+ * hash, row r of salt `salt` (identical to mobgt_dropout on the [R,C] tensor). */
+int mobgt_head_act_fwd(const float* u, const float* ln_w, const float* ln_b, float* out, float* mean, float* rstd, int R,
+                       int C, float eps, float slope, float dropout_p, uint64_t seed, const uint64_t* seed_dev,
+                       uint32_t salt, void* stream);
+int mobgt_head_act_bwd(const float* dout, const float* u, const float* ln_w, const float* ln_b, const float* mean,
+                       const float* rstd, float* du, float* dgamma, float* dbeta, int R, int C, float eps, float slope,
+                       float dropout_p, uint64_t seed, const uint64_t* seed_dev, uint32_t salt, void* stream);
+
 /* torch.optim.AdamW (defaults of model_fqandtoyo.py:1599-1616) over one flat f32 parameter buffer of n elements, in
  * place, with device-resident learning rate and step counter (step t = *step_dev - step_base >= 1) so that a captured
  * graph advances on replay; optionally refreshes a bf16 copy of the parameters (shadow_bf16, may be NULL).

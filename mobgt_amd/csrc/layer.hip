@@ -879,3 +879,119 @@ extern "C" int mobgt_assemble_tokens_bwd(const float* dout, const float* real, f
     hipLaunchKernelGGL(assemble_tokens_kernel<true>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, p);
     return (int)hipGetLastError();
 }
+
+// ------------------------------------------------------------------------------------------------
+// Head activation chain on the G graph-token rows (model_fqandtoyo.py:1353-1364):
+//   out = dropout( ELU( LayerNorm( LeakyReLU_0.2(u) ) ) )
+// one wave per row (C <= 512), forward and backward one launch each instead of four + five.
+namespace {
+struct HeadParams {
+    const float *u, *w, *b;
+    float *out, *mean, *rstd;
+    const float* dout;
+    float *du, *dgamma, *dbeta;           // dgamma / dbeta accumulated with atomics (zero them first)
+    int R, C;
+    float eps, slope, inv_keep;
+    uint32_t thr;
+    uint64_t seed;
+    const uint64_t* seed_dev;
+    uint32_t salt;
+};
+
+template <bool BWD>
+__global__ __launch_bounds__(256) void head_act_kernel(const HeadParams p) {
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= p.R) return;
+    const int lane = threadIdx.x & 63;
+    const uint64_t seed = p.thr ? p.seed + (p.seed_dev ? *p.seed_dev : 0ull) : 0ull;
+    const uint32_t rowh = p.thr ? dropout_row_hash(seed, (uint32_t)r ^ p.salt) : 0u;
+    const float invC = 1.f / (float)p.C;
+    float a[MAXC_PER_LANE], uu[MAXC_PER_LANE];
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < MAXC_PER_LANE; ++k) {
+        const int c = lane + 64 * k;
+        uu[k] = c < p.C ? p.u[(int64_t)r * p.C + c] : 0.f;
+        a[k] = uu[k] > 0.f ? uu[k] : p.slope * uu[k];
+        s += c < p.C ? a[k] : 0.f;
+    }
+    float mu, rs;
+    if (!BWD) {
+        mu = wave_sum(s) * invC;
+        float q = 0.f;
+#pragma unroll
+        for (int k = 0; k < MAXC_PER_LANE; ++k) {
+            const float d = lane + 64 * k < p.C ? a[k] - mu : 0.f;
+            q += d * d;
+        }
+        rs = rsqrtf(wave_sum(q) * invC + p.eps);
+        if (lane == 0) { p.mean[r] = mu; p.rstd[r] = rs; }
+    } else {
+        mu = p.mean[r];
+        rs = p.rstd[r];
+    }
+    float g[MAXC_PER_LANE], xh[MAXC_PER_LANE];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < MAXC_PER_LANE; ++k) {
+        const int c = lane + 64 * k;
+        g[k] = 0.f; xh[k] = 0.f;
+        if (c < p.C) {
+            xh[k] = (a[k] - mu) * rs;
+            const float z = xh[k] * p.w[c] + p.b[c];
+            const float keep = p.thr ? (dropout_bits16(seed, rowh, (uint32_t)c) >= p.thr ? p.inv_keep : 0.f) : 1.f;
+            if (!BWD) {
+                p.out[(int64_t)r * p.C + c] = (z > 0.f ? z : expm1f(z)) * keep;
+            } else {
+                const float dz = p.dout[(int64_t)r * p.C + c] * keep * (z > 0.f ? 1.f : expf(z));      // ELU'(z) = e^z for z <= 0
+                atomicAdd(&p.dgamma[c], dz * xh[k]);
+                atomicAdd(&p.dbeta[c], dz);
+                g[k] = dz * p.w[c];
+                s1 += g[k];
+                s2 += g[k] * xh[k];
+            }
+        }
+    }
+    if (!BWD) return;
+    s1 = wave_sum(s1) * invC;
+    s2 = wave_sum(s2) * invC;
+#pragma unroll
+    for (int k = 0; k < MAXC_PER_LANE; ++k) {
+        const int c = lane + 64 * k;
+        if (c < p.C) {
+            const float da = rs * (g[k] - s1 - xh[k] * s2);
+            p.du[(int64_t)r * p.C + c] = da * (uu[k] > 0.f ? 1.f : p.slope);
+        }
+    }
+}
+}  // namespace
+
+extern "C" int mobgt_head_act_fwd(const float* u, const float* ln_w, const float* ln_b, float* out, float* mean, float* rstd,
+                                  int R, int C, float eps, float slope, float dropout_p, uint64_t seed,
+                                  const uint64_t* seed_dev, uint32_t salt, void* stream) {
+    if (R <= 0) return 0;
+    if (C <= 0 || C > 64 * MAXC_PER_LANE) return MOBGT_EBADDIM;
+    HeadParams p = {};
+    p.u = u; p.w = ln_w; p.b = ln_b; p.out = out; p.mean = mean; p.rstd = rstd; p.R = R; p.C = C; p.eps = eps; p.slope = slope;
+    p.thr = dropout_p > 0.f ? dropout_threshold(dropout_p) : 0u;
+    p.inv_keep = p.thr ? 1.f / (1.f - (float)p.thr / 65536.f) : 1.f;
+    p.seed = seed; p.seed_dev = seed_dev; p.salt = salt;
+    hipLaunchKernelGGL(head_act_kernel<false>, dim3((R + 3) / 4), dim3(256), 0, (hipStream_t)stream, p);
+    return (int)hipGetLastError();
+}
+
+extern "C" int mobgt_head_act_bwd(const float* dout, const float* u, const float* ln_w, const float* ln_b, const float* mean,
+                                  const float* rstd, float* du, float* dgamma, float* dbeta, int R, int C, float eps,
+                                  float slope, float dropout_p, uint64_t seed, const uint64_t* seed_dev, uint32_t salt,
+                                  void* stream) {
+    if (R <= 0) return 0;
+    if (C <= 0 || C > 64 * MAXC_PER_LANE) return MOBGT_EBADDIM;
+    HeadParams p = {};
+    p.dout = dout; p.u = u; p.w = ln_w; p.b = ln_b; p.mean = const_cast<float*>(mean); p.rstd = const_cast<float*>(rstd);
+    p.du = du; p.dgamma = dgamma; p.dbeta = dbeta; p.R = R; p.C = C; p.eps = eps; p.slope = slope;
+    p.thr = dropout_p > 0.f ? dropout_threshold(dropout_p) : 0u;
+    p.inv_keep = p.thr ? 1.f / (1.f - (float)p.thr / 65536.f) : 1.f;
+    p.seed = seed; p.seed_dev = seed_dev; p.salt = salt;
+    hipLaunchKernelGGL(head_act_kernel<true>, dim3((R + 3) / 4), dim3(256), 0, (hipStream_t)stream, p);
+    return (int)hipGetLastError();
+}

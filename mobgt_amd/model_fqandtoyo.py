@@ -332,8 +332,16 @@ class Graphormer(nn.Module):
             ops.trace_nan(f"layer{li}", output)
         self._enc_out = output           # train.TrainStep: everything after this point is the "head" (see head_modules)
         user_embedding = self.user_embed_model(batched_data.user.long() - 1).reshape(output.shape[0], -1)   # :1239-1240
-        tok = self.embed_fuse_model3(output[:, 0, :].float(), user_embedding)                  # :1353-1358, q = 0 only
-        tok = ops.dropout(self.ELU(self.final_ln(tok)), self.output_dropout.p, self.training, 0x1004)   # :1360-1364
+        fuse3 = self.embed_fuse_model3
+        if output.is_cuda and self.final_ln.weight.shape[0] <= 512:
+            # Linear of FuseEmbeddings, then LeakyReLU -> final_ln -> ELU -> output dropout in ONE launch (:1353-1364)
+            x3 = torch.cat((output[:, 0, :].float(), user_embedding), 1)
+            u3 = ops.linear_splitk(x3, fuse3.fuse_embed.weight, fuse3.fuse_embed.bias, getattr(fuse3, "bf16_wgrad", False))
+            tok = ops.head_act(u3, self.final_ln.weight, self.final_ln.bias, self.final_ln.eps, 0.2, self.output_dropout.p,
+                               self.training, 0x1004)
+        else:
+            tok = fuse3(output[:, 0, :].float(), user_embedding)                               # :1353-1358, q = 0 only
+            tok = ops.dropout(self.ELU(self.final_ln(tok)), self.output_dropout.p, self.training, 0x1004)   # :1360-1364
         ops.trace_nan("tok", tok)
         if ops.skinny_linear_ok(tok, self.out_proj.weight):
             logits = ops.skinny_linear(tok, self.out_proj.weight, self.out_proj.bias)      # :1394, M = G rows

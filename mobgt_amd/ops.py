@@ -720,6 +720,44 @@ def dropout(x, p, training, salt):
     return _DropoutFn.apply(x.float(), float(p), int(seed), seed_dev, int(salt) & 0xFFFFFFFF)
 
 
+class _HeadActFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, u, w, b, eps, slope, p_drop, seed, seed_dev, salt):
+        u, w, b = u.contiguous(), w.contiguous(), b.contiguous()
+        R, C = u.shape
+        out = torch.empty_like(u)
+        stats = torch.empty(2, R, dtype=torch.float32, device=u.device)
+        check(_lib.lib().mobgt_head_act_fwd(_p(u), _p(w), _p(b), _p(out), _p(stats[0]), _p(stats[1]), R, C, eps, slope, p_drop,
+                                            seed, _p(seed_dev), salt, _stream()), "mobgt_head_act_fwd")
+        ctx.save_for_backward(u, w, b, stats)
+        ctx.misc = (eps, slope, p_drop, seed, seed_dev, salt)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        u, w, b, stats = ctx.saved_tensors
+        eps, slope, p_drop, seed, seed_dev, salt = ctx.misc
+        R, C = u.shape
+        du = torch.empty_like(u)
+        dg, db = zeros_f32((C,), u.device), zeros_f32((C,), u.device)
+        check(_lib.lib().mobgt_head_act_bwd(_p(dout.contiguous()), _p(u), _p(w), _p(b), _p(stats[0]), _p(stats[1]), _p(du),
+                                            _p(dg), _p(db), R, C, eps, slope, p_drop, seed, _p(seed_dev), salt, _stream()),
+              "mobgt_head_act_bwd")
+        return du, dg, db, None, None, None, None, None, None
+
+
+def head_act(u, ln_weight, ln_bias, eps, slope, p_drop, training, salt):
+    """dropout(ELU(LayerNorm(LeakyReLU(u)))) on a few rows (the classifier head's activation chain) in one launch."""
+    _require_cuda(u, ln_weight, ln_bias)
+    if not training:
+        p_drop = 0.0
+    seed, seed_dev = _DROPOUT_STATE["seed"], _DROPOUT_STATE["seed_dev"]
+    if seed_dev is None and p_drop > 0:
+        seed = (seed + int(torch.randint(0, 2 ** 31 - 1, (1,)).item())) & 0x7FFFFFFFFFFFFFFF
+    return _HeadActFn.apply(u.float(), ln_weight, ln_bias, float(eps), float(slope), float(p_drop), int(seed), seed_dev,
+                            int(salt) & 0xFFFFFFFF)
+
+
 class _AssembleTokensFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, nf, real, add, token, pe0, p_pos, p_in, seed, seed_dev, salts):

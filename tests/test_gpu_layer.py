@@ -161,3 +161,28 @@ def test_adamw_flat_matches_torch_adamw():
                                                0.9, 0.999, 1e-8, 0.01, _stream()), "mobgt_adamw_flat")
         np.testing.assert_allclose(p.cpu().numpy(), ref.detach().float().numpy(), rtol=2e-5, atol=2e-6)
     assert torch.equal(sh, p.bfloat16())
+
+
+@pytest.mark.parametrize("p_drop", [0.0, 0.3])
+def test_head_act_matches_torch_chain(p_drop):
+    """mobgt_head_act_fwd/bwd against LeakyReLU -> LayerNorm -> ELU -> (the library's own) dropout built from torch ops."""
+    from mobgt_amd import ops
+    gen = torch.Generator().manual_seed(9)
+    R, C = 16, 448
+    u = torch.randn(R, C, generator=gen).to(DEV)
+    w = (1 + 0.1 * torch.randn(C, generator=gen)).to(DEV)
+    b = (0.1 * torch.randn(C, generator=gen)).to(DEV)
+    gy = torch.randn(R, C, generator=gen).to(DEV)
+    ops.set_dropout_state(torch.tensor([3], dtype=torch.int64, device=DEV), 11)
+    ua, wa, ba = (t.clone().requires_grad_(True) for t in (u, w, b))
+    ref = torch.nn.functional.elu(torch.nn.functional.layer_norm(torch.nn.functional.leaky_relu(ua, 0.2), (C,), wa, ba, 1e-5))
+    ref = ops.dropout(ref, p_drop, True, 0x1004)
+    ref.backward(gy)
+    ub, wb, bb = (t.clone().requires_grad_(True) for t in (u, w, b))
+    got = ops.head_act(ub, wb, bb, 1e-5, 0.2, p_drop, True, 0x1004)
+    got.backward(gy)
+    np.testing.assert_allclose(got.detach().cpu().numpy(), ref.detach().cpu().numpy(), rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(ub.grad.cpu().numpy(), ua.grad.cpu().numpy(), rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(wb.grad.cpu().numpy(), wa.grad.cpu().numpy(), rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(bb.grad.cpu().numpy(), ba.grad.cpu().numpy(), rtol=1e-4, atol=1e-4)
+    ops.set_dropout_state(None, None)
