@@ -311,6 +311,14 @@ int mobgt_assemble_tokens_bwd(const float* dout, const float* real, float* d_nf,
                               int C, float p_pos, float p_in, uint64_t seed, const uint64_t* seed_dev, uint32_t salt_nf,
                               uint32_t salt_tok, uint32_t salt_in, void* stream);
 
+/* Epilogue of a GraphConvolution inside GCN.forward (modelGNN.py:38-44, 62-71): y = dropout(LeakyReLU_slope(x + bias)),
+ * [R,C] f32, C % 4 == 0, bias [C] or NULL, dropout_p 0 = off (mask: the library's counter hash, row r, salt `salt`).
+ * Backward: dx overwritten from dy and the saved OUTPUT y; dbias [C] (or NULL) ACCUMULATED (zero it first). */
+int mobgt_bias_act_fwd(const float* x, const float* bias, float* y, int64_t R, int C, float slope, float dropout_p,
+                       uint64_t seed, const uint64_t* seed_dev, uint32_t salt, void* stream);
+int mobgt_bias_act_bwd(const float* dy, const float* y, float* dx, float* dbias, int64_t R, int C, float slope,
+                       float dropout_p, uint64_t seed, const uint64_t* seed_dev, uint32_t salt, void* stream);
+
 /* Head activation chain on the graph-token rows (model_fqandtoyo.py:1353-1364), u [R,C] f32, C <= 512:
  *   out = dropout(ELU(LayerNorm(LeakyReLU_slope(u)) * ln_w + ln_b))   (mean / rstd [R] saved for the backward)
  * Backward: du [R,C] overwritten; dgamma, dbeta [C] ACCUMULATED (zero them first).  Dropout: the library's counter

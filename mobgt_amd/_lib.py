@@ -52,6 +52,8 @@ SIGNATURES = {
     "mobgt_skinny_linear_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "mobgt_assemble_tokens_fwd": (_i, [_vp] * 6 + [_i, _i, _i, _f, _f, _u64, _vp, _c.c_uint32, _c.c_uint32, _c.c_uint32, _vp]),
     "mobgt_assemble_tokens_bwd": (_i, [_vp] * 5 + [_i, _i, _i, _f, _f, _u64, _vp, _c.c_uint32, _c.c_uint32, _c.c_uint32, _vp]),
+    "mobgt_bias_act_fwd": (_i, [_vp, _vp, _vp, _i64, _i, _f, _f, _u64, _vp, _c.c_uint32, _vp]),
+    "mobgt_bias_act_bwd": (_i, [_vp, _vp, _vp, _vp, _i64, _i, _f, _f, _u64, _vp, _c.c_uint32, _vp]),
     "mobgt_head_act_fwd": (_i, [_vp] * 6 + [_i, _i, _f, _f, _f, _u64, _vp, _c.c_uint32, _vp]),
     "mobgt_head_act_bwd": (_i, [_vp] * 9 + [_i, _i, _f, _f, _f, _u64, _vp, _c.c_uint32, _vp]),
     "mobgt_adamw_flat": (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _i64, _f, _f, _f, _f, _vp]),

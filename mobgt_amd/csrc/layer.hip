@@ -995,3 +995,97 @@ extern "C" int mobgt_head_act_bwd(const float* dout, const float* u, const float
     hipLaunchKernelGGL(head_act_kernel<true>, dim3((R + 3) / 4), dim3(256), 0, (hipStream_t)stream, p);
     return (int)hipGetLastError();
 }
+
+// ------------------------------------------------------------------------------------------------
+// y = dropout( LeakyReLU_slope( x + bias ) ) on [R,C] f32 (C % 4 == 0) -- the epilogue of a GraphConvolution inside
+// GCN.forward (modelGNN.py:38-44, 62-71) -- and its backward, which also produces the bias gradient:
+// dx = dy * mask / keep * (y > 0 ? 1 : slope)  (y carries the sign of the pre-activation wherever the mask kept it),
+// dbias[c] += colsum(dx).  Thread = 4 consecutive columns, the 4 waves of a workgroup take different rows.
+namespace {
+struct BiasActParams {
+    const float *x, *bias, *dy, *y_in;
+    float *y, *dx, *dbias;
+    int64_t R;
+    int C, rows_per_wg;
+    float slope, inv_keep;
+    uint32_t thr;
+    uint64_t seed;
+    const uint64_t* seed_dev;
+    uint32_t salt;
+};
+
+template <bool BWD>
+__global__ __launch_bounds__(256) void bias_act_kernel(const BiasActParams p) {
+    __shared__ float red[4][256];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = 256 * blockIdx.y + 4 * lane;
+    const int64_t r0 = (int64_t)blockIdx.x * p.rows_per_wg;
+    const int nrow = (int)min((int64_t)p.rows_per_wg, p.R - r0);
+    const uint64_t seed = p.thr ? p.seed + (p.seed_dev ? *p.seed_dev : 0ull) : 0ull;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    float b4[4] = {0.f, 0.f, 0.f, 0.f};
+    if (!BWD && p.bias && c < p.C) ld4<float>(p.bias + c, b4);
+    if (c < p.C) {
+        for (int rr = wave; rr < nrow; rr += 4) {
+            const int64_t r = r0 + rr;
+            const uint32_t rowh = p.thr ? dropout_row_hash(seed, (uint32_t)r ^ p.salt) : 0u;
+            float v[4], o[4];
+            if (!BWD) {
+                ld4<float>(p.x + r * p.C + c, v);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float t = v[i] + b4[i];
+                    const float a = t > 0.f ? t : p.slope * t;
+                    const float keep = p.thr ? (dropout_bits16(seed, rowh, (uint32_t)(c + i)) >= p.thr ? p.inv_keep : 0.f) : 1.f;
+                    o[i] = a * keep;
+                }
+                st4<float>(p.y + r * p.C + c, o);
+            } else {
+                float y4[4];
+                ld4<float>(p.dy + r * p.C + c, v);
+                ld4<float>(p.y_in + r * p.C + c, y4);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float keep = p.thr ? (dropout_bits16(seed, rowh, (uint32_t)(c + i)) >= p.thr ? p.inv_keep : 0.f) : 1.f;
+                    o[i] = v[i] * keep * (y4[i] > 0.f ? 1.f : p.slope);
+                    acc[i] += o[i];
+                }
+                st4<float>(p.dx + r * p.C + c, o);
+            }
+        }
+    }
+    if (!BWD || !p.dbias) return;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) red[wave][4 * lane + i] = acc[i];
+    __syncthreads();
+    const int cc = 256 * blockIdx.y + threadIdx.x;
+    if (cc < p.C) atomicAdd(&p.dbias[cc], red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+int launch_bias_act(BiasActParams& p, bool bwd, float dropout_p, hipStream_t st) {
+    if (p.R <= 0) return 0;
+    if (p.C <= 0 || (p.C & 3)) return MOBGT_EBADDIM;
+    p.thr = dropout_p > 0.f ? dropout_threshold(dropout_p) : 0u;
+    p.inv_keep = p.thr ? 1.f / (1.f - (float)p.thr / 65536.f) : 1.f;
+    p.rows_per_wg = bwd ? pick_rows(p.R) : pick_rows_stream(p.R);
+    const dim3 grid((unsigned)((p.R + p.rows_per_wg - 1) / p.rows_per_wg), (unsigned)((p.C + 255) / 256)), block(256);
+    if (bwd) hipLaunchKernelGGL(bias_act_kernel<true>, grid, block, 0, st, p);
+    else hipLaunchKernelGGL(bias_act_kernel<false>, grid, block, 0, st, p);
+    return (int)hipGetLastError();
+}
+}  // namespace
+
+extern "C" int mobgt_bias_act_fwd(const float* x, const float* bias, float* y, int64_t R, int C, float slope, float dropout_p,
+                                  uint64_t seed, const uint64_t* seed_dev, uint32_t salt, void* stream) {
+    BiasActParams p = {};
+    p.x = x; p.bias = bias; p.y = y; p.R = R; p.C = C; p.slope = slope; p.seed = seed; p.seed_dev = seed_dev; p.salt = salt;
+    return launch_bias_act(p, false, dropout_p, (hipStream_t)stream);
+}
+
+extern "C" int mobgt_bias_act_bwd(const float* dy, const float* y, float* dx, float* dbias, int64_t R, int C, float slope,
+                                  float dropout_p, uint64_t seed, const uint64_t* seed_dev, uint32_t salt, void* stream) {
+    BiasActParams p = {};
+    p.dy = dy; p.y_in = y; p.dx = dx; p.dbias = dbias; p.R = R; p.C = C; p.slope = slope; p.seed = seed; p.seed_dev = seed_dev;
+    p.salt = salt;
+    return launch_bias_act(p, true, dropout_p, (hipStream_t)stream);
+}

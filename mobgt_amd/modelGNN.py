@@ -153,13 +153,15 @@ class GraphConvolution(nn.Module):
         if self.bias is not None:
             self.bias.data.uniform_(-stdv, stdv)
 
-    def forward(self, input, adj, adj_input=None, adj_t=None):
+    def forward(self, input, adj, adj_input=None, adj_t=None, bias=True):
         # X.W stays fp32 (raw features such as lat/lon need the mantissa); only the big dense adjacency
-        # product runs in `adj`'s dtype (fp32, or bf16 in the bf16 configuration)
+        # product runs in `adj`'s dtype (fp32, or bf16 in the bf16 configuration).  bias=False: the caller adds it
+        # (GCN.forward fuses bias + LeakyReLU + dropout into one launch).
+        b = self.bias if bias else None
         with torch.autocast(device_type=input.device.type, enabled=False):
             if adj_input is not None:
-                return _PreAggConvFn.apply(adj_input, self.weight, self.bias)
-            return _GraphConvFn.apply(input.float(), self.weight, self.bias, adj, adj_t)
+                return _PreAggConvFn.apply(adj_input, self.weight, b)
+            return _GraphConvFn.apply(input.float(), self.weight, b, adj, adj_t)
 
 
 class GCN(nn.Module):
@@ -178,13 +180,22 @@ class GCN(nn.Module):
         adj[rows] @ (h W) + b.  The model reads the table only at the batch's POI ids
         (model_fqandtoyo.py:1264), so for R << P this replaces a P x P product (and its transpose in the
         backward) by an R x P one without changing any value that is used."""
-        for i in range(len(self.gcn) - 1):
-            x = self.leaky_relu(self.gcn[i](x, adj, adj_x if i == 0 else None, adj_t))
-        if x.is_cuda:
+        n_hidden = len(self.gcn) - 1
+        if x.is_cuda and all(g.out_features % 4 == 0 and g.bias is not None for g in self.gcn[:-1]):
             from . import ops
-            x = ops.dropout(x, self.dropout, self.training, 0x2000 + self.gcn[-1].out_features)
+            for i in range(n_hidden):       # bias + LeakyReLU (+ the dropout in front of the last layer) in one launch
+                h = self.gcn[i](x, adj, adj_x if i == 0 else None, adj_t, bias=False)
+                x = ops.bias_act(h, self.gcn[i].bias, self.leaky_relu.negative_slope,
+                                 self.dropout if i == n_hidden - 1 else 0.0, self.training,
+                                 0x2000 + self.gcn[-1].out_features)
         else:
-            x = F.dropout(x, self.dropout, training=self.training)
+            for i in range(n_hidden):
+                x = self.leaky_relu(self.gcn[i](x, adj, adj_x if i == 0 else None, adj_t))
+            if x.is_cuda:
+                from . import ops
+                x = ops.dropout(x, self.dropout, self.training, 0x2000 + self.gcn[-1].out_features)
+            else:
+                x = F.dropout(x, self.dropout, training=self.training)
         if rows is not None:
             last = self.gcn[-1]
             if _rows_conv_ok(x, adj, rows):

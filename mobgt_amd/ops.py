@@ -720,6 +720,41 @@ def dropout(x, p, training, salt):
     return _DropoutFn.apply(x.float(), float(p), int(seed), seed_dev, int(salt) & 0xFFFFFFFF)
 
 
+class _BiasActFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, bias, slope, p_drop, seed, seed_dev, salt):
+        x = x.contiguous()
+        R, C = x.shape
+        y = torch.empty_like(x)
+        check(_lib.lib().mobgt_bias_act_fwd(_p(x), _p(bias), _p(y), R, C, slope, p_drop, seed, _p(seed_dev), salt, _stream()),
+              "mobgt_bias_act_fwd")
+        ctx.save_for_backward(y)
+        ctx.misc = (slope, p_drop, seed, seed_dev, salt, bias is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        slope, p_drop, seed, seed_dev, salt, has_bias = ctx.misc
+        R, C = y.shape
+        dx = torch.empty_like(y)
+        db = zeros_f32((C,), y.device) if has_bias else None
+        check(_lib.lib().mobgt_bias_act_bwd(_p(dy.contiguous()), _p(y), _p(dx), _p(db), R, C, slope, p_drop, seed, _p(seed_dev),
+                                            salt, _stream()), "mobgt_bias_act_bwd")
+        return dx, db, None, None, None, None, None
+
+
+def bias_act(x, bias, slope, p_drop, training, salt):
+    """dropout(leaky_relu(x + bias, slope)) on a 2-D f32 tensor in one launch; the backward also yields bias.grad."""
+    _require_cuda(x)
+    if not training:
+        p_drop = 0.0
+    seed, seed_dev = _DROPOUT_STATE["seed"], _DROPOUT_STATE["seed_dev"]
+    if seed_dev is None and p_drop > 0:
+        seed = (seed + int(torch.randint(0, 2 ** 31 - 1, (1,)).item())) & 0x7FFFFFFFFFFFFFFF
+    return _BiasActFn.apply(x.float(), bias, float(slope), float(p_drop), int(seed), seed_dev, int(salt) & 0xFFFFFFFF)
+
+
 class _HeadActFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, u, w, b, eps, slope, p_drop, seed, seed_dev, salt):

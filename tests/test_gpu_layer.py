@@ -186,3 +186,27 @@ def test_head_act_matches_torch_chain(p_drop):
     np.testing.assert_allclose(wb.grad.cpu().numpy(), wa.grad.cpu().numpy(), rtol=1e-4, atol=1e-4)
     np.testing.assert_allclose(bb.grad.cpu().numpy(), ba.grad.cpu().numpy(), rtol=1e-4, atol=1e-4)
     ops.set_dropout_state(None, None)
+
+
+@pytest.mark.parametrize("p_drop,has_bias", [(0.0, True), (0.3, True), (0.3, False)])
+def test_bias_act_matches_torch_chain(p_drop, has_bias):
+    from mobgt_amd import ops
+    gen = torch.Generator().manual_seed(12)
+    R, C = 777, 64
+    x = torch.randn(R, C, generator=gen).to(DEV)
+    b = torch.randn(C, generator=gen).to(DEV) if has_bias else None
+    gy = torch.randn(R, C, generator=gen).to(DEV)
+    ops.set_dropout_state(torch.tensor([5], dtype=torch.int64, device=DEV), 21)
+    xa = x.clone().requires_grad_(True)
+    ba = b.clone().requires_grad_(True) if has_bias else None
+    ref = ops.dropout(torch.nn.functional.leaky_relu(xa + ba if has_bias else xa, 0.2), p_drop, True, 0x2040)
+    ref.backward(gy)
+    xb = x.clone().requires_grad_(True)
+    bb = b.clone().requires_grad_(True) if has_bias else None
+    got = ops.bias_act(xb, bb, 0.2, p_drop, True, 0x2040)
+    got.backward(gy)
+    np.testing.assert_allclose(got.detach().cpu().numpy(), ref.detach().cpu().numpy(), rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(xb.grad.cpu().numpy(), xa.grad.cpu().numpy(), rtol=1e-6, atol=1e-6)
+    if has_bias:
+        np.testing.assert_allclose(bb.grad.cpu().numpy(), ba.grad.cpu().numpy(), rtol=1e-4, atol=1e-4)
+    ops.set_dropout_state(None, None)
