@@ -214,7 +214,7 @@ int mobgt_embed_scatter_add(float* const* d_tables_host, const void* const* idx_
                             int idx_dtype, void* stream);
 /* Every row index the node-feature gathers of model_fqandtoyo.py:1259-1264 (POI / time-slot / category),
  * :1287-1298 + :348-351 (positional rows 1..n) need, derived from the padded batch in one launch.
- *   x [G,N] int64 POI ids (0 = pad) and time_normal [G,N] f32, both with element strides (g, n);
+ *   x [G,N] POI ids (0 = pad; x_dtype MOBGT_I64 / I32) and time_normal [G,N] f32, both with element strides (g, n);
  *   poi2cat [P+1] int64 (row 0 = pad).
  * idx [8][G*N] int64 (-1 = "no row" in 0..3):
  *   0: POI row  (rows_only ? the position g*N+n in a per-batch table : x-1)       1: (long)(time_normal*48)
@@ -222,7 +222,7 @@ int mobgt_embed_scatter_add(float* const* d_tables_host, const void* const* idx_
  *   6, 7: in_degree / out_degree [G*N] (contiguous; deg_dtype MOBGT_I64 / I32 / I16) widened to int64 -- left
  *         untouched when in_degree is NULL
  * real [G*N] f32: 1 for real nodes, 0 for padding. */
-int mobgt_node_index(const int64_t* x, int64_t xs_g, int64_t xs_n, const float* time_normal, int64_t ts_g,
+int mobgt_node_index(const void* x, int x_dtype, int64_t xs_g, int64_t xs_n, const float* time_normal, int64_t ts_g,
                      int64_t ts_n, const int64_t* poi2cat, const void* in_degree, const void* out_degree, int deg_dtype,
                      int64_t* idx, float* real, int G, int N, int rows_only, void* stream);
 
@@ -273,10 +273,11 @@ int mobgt_gelu_fwd(const void* u, void* h, int64_t n, int act_dtype, void* strea
 int mobgt_gelu_bwd_colsum(const void* dh, const void* u, void* du, float* dbias, int64_t R, int C,
                           int act_dtype, void* stream);
 /* GradientTailLoss(inputs, targets, alpha) of graphormer/model_fqandtoyo.py:545-550 (beta = k = 1) and its
- * gradient in one pass: logits [G,V] f32, targets [G] int64 (class ids) -> *loss (f32 scalar, overwritten) and
- * dlogits [G,V] = d(loss)/d(logits). */
-int mobgt_gradient_tail_loss(const float* logits, const int64_t* targets, float* dlogits, float* loss,
-                             int64_t G, int64_t V, float alpha, void* stream);
+ * gradient in one pass: logits [G,V] f32, targets [G] int64 -> *loss (f32 scalar, overwritten) and
+ * dlogits [G,V] = d(loss)/d(logits).  The class id of row g is targets[g] + target_offset (training_step's
+ * `batched_data.y - 1`, model_fqandtoyo.py:1446-1460, without a launch for the subtraction). */
+int mobgt_gradient_tail_loss(const float* logits, const int64_t* targets, int64_t target_offset, float* dlogits,
+                             float* loss, int64_t G, int64_t V, float alpha, void* stream);
 /* nn.Dropout at the model's input/output/positional/GCN sites (model.py:206, model_fqandtoyo.py:358,1347,1364;
  * modelGNN.py:71): y = keep ? x/(1-p) : 0 with the kernels' counter hash keyed by (seed [+ *seed_dev], salt,
  * i / row_len, i % row_len).  The backward is the same call applied to dy. */
@@ -333,10 +334,27 @@ int mobgt_head_act_bwd(const float* dout, const float* u, const float* ln_w, con
 /* torch.optim.AdamW (defaults of model_fqandtoyo.py:1599-1616) over one flat f32 parameter buffer of n elements, in
  * place, with device-resident learning rate and step counter (step t = *step_dev - step_base >= 1) so that a captured
  * graph advances on replay; optionally refreshes a bf16 copy of the parameters (shadow_bf16, may be NULL).
- * All f32 pointers 16-byte aligned. */
+ * Learning rate: *lr_dev, or -- when `sched` (5 device floats: warmup_updates, tot_updates, peak lr, end lr, step
+ * offset) is given -- PolynomialDecayLR of graphormer/lr.py:17-31 with power 1 evaluated at step_count = t + offset
+ * inside the kernel (no per-step host write).  All f32 pointers 16-byte aligned. */
 int mobgt_adamw_flat(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, void* shadow_bf16, int64_t n,
-                     const float* lr_dev, const int64_t* step_dev, int64_t step_base, float beta1, float beta2, float eps,
-                     float weight_decay, void* stream);
+                     const float* lr_dev, const float* sched, const int64_t* step_dev, int64_t step_base, float beta1,
+                     float beta2, float eps, float weight_decay, void* stream);
+
+/* Start of a training step (the trainer's `optimizer.zero_grad()` + per-step counter): zero-fills two f32 buffers
+ * (element counts multiples of 4, 16-byte aligned; either may be empty) and adds 1 to *counter (may be NULL). */
+int mobgt_step_prologue(float* zero_a, int64_t n_a, float* zero_b, int64_t n_b, int64_t* counter, void* stream);
+
+/* Input of the classifier head, graph-token rows only (model_fqandtoyo.py:1239-1240 `user_embed_model(user - 1)`,
+ * :1353-1358 `embed_fuse_model3(output[p][0], user_embedding[p])`'s concatenation):
+ *   x3[g, :] = [ enc[g, 0, 0:C] | table[user[g] + user_offset, 0:U] ]      enc [G,T,C] f32, table [n_rows,U] f32,
+ *   user [G] (MOBGT_I64 / I32); an out-of-range user row reads as zeros.
+ * bwd: denc [G,T,C] = 0 except denc[g,0,:] = dx3[g,0:C];  dtable[user[g]+user_offset, :] += dx3[g, C:] (atomic; the
+ * caller zero-fills dtable). */
+int mobgt_head_input_fwd(const float* enc, const void* user, int user_dtype, int64_t user_offset, const float* table,
+                         int64_t n_rows, float* x3, int G, int T, int C, int U, void* stream);
+int mobgt_head_input_bwd(const float* dx3, const void* user, int user_dtype, int64_t user_offset, float* denc,
+                         float* dtable, int64_t n_rows, int G, int T, int C, int U, void* stream);
 
 #ifdef __cplusplus
 }

@@ -38,7 +38,7 @@ SIGNATURES = {
     "mobgt_dropout_add_ln_bwd": (_i, [_vp] * 12 + [_i64, _i, _f, _u64, _vp, _c.c_uint32, _i, _vp]),
     "mobgt_gelu_fwd": (_i, [_vp, _vp, _i64, _i, _vp]),
     "mobgt_gelu_bwd_colsum": (_i, [_vp, _vp, _vp, _vp, _i64, _i, _i, _vp]),
-    "mobgt_gradient_tail_loss": (_i, [_vp, _vp, _vp, _vp, _i64, _i64, _f, _vp]),
+    "mobgt_gradient_tail_loss": (_i, [_vp, _vp, _i64, _vp, _vp, _i64, _i64, _f, _vp]),
     "mobgt_dropout": (_i, [_vp, _vp, _i64, _i, _f, _u64, _vp, _c.c_uint32, _vp]),
     "mobgt_colsum": (_i, [_vp, _vp, _i64, _i, _i, _vp]),
     "mobgt_linear_wgrad_group": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _i, _vp]),
@@ -56,9 +56,12 @@ SIGNATURES = {
     "mobgt_bias_act_bwd": (_i, [_vp, _vp, _vp, _vp, _i64, _i, _f, _f, _u64, _vp, _c.c_uint32, _vp]),
     "mobgt_head_act_fwd": (_i, [_vp] * 6 + [_i, _i, _f, _f, _f, _u64, _vp, _c.c_uint32, _vp]),
     "mobgt_head_act_bwd": (_i, [_vp] * 9 + [_i, _i, _f, _f, _f, _u64, _vp, _c.c_uint32, _vp]),
-    "mobgt_adamw_flat": (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _i64, _f, _f, _f, _f, _vp]),
+    "mobgt_adamw_flat": (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _vp]),
+    "mobgt_step_prologue": (_i, [_vp, _i64, _vp, _i64, _vp, _vp]),
+    "mobgt_head_input_fwd": (_i, [_vp, _vp, _i, _i64, _vp, _i64, _vp, _i, _i, _i, _i, _vp]),
+    "mobgt_head_input_bwd": (_i, [_vp, _vp, _i, _i64, _vp, _vp, _i64, _i, _i, _i, _i, _vp]),
     "mobgt_gather_rows_t": (_i, [_vp, _i64, _vp, _vp, _vp, _i, _i, _vp]),
-    "mobgt_node_index": (_i, [_vp, _i64, _i64, _vp, _i64, _i64, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _vp]),
+    "mobgt_node_index": (_i, [_vp, _i, _i64, _i64, _vp, _i64, _i64, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _vp]),
 }
 
 _lib = None

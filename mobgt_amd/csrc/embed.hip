@@ -154,7 +154,7 @@ extern "C" int mobgt_embed_scatter_add(float* const* d_tables_host, const void* 
 namespace {
 
 struct NodeIndexParams {
-    const int64_t* x; int64_t xs_g, xs_n;           // POI ids [G,N] (0 = pad), element strides
+    const void* x; int x_dtype; int64_t xs_g, xs_n; // POI ids [G,N] (0 = pad; int64 or int32), element strides
     const float* tn;  int64_t ts_g, ts_n;           // time_normal [G,N]
     const int64_t* poi2cat;                          // [P+1]
     const void *indeg, *outdeg;                      // [G*N] degrees (deg_dtype), or null
@@ -170,7 +170,12 @@ __global__ __launch_bounds__(256) void node_index_kernel(const NodeIndexParams p
     __shared__ int s_cnt[4];
     const int g = blockIdx.x;
     int cnt = 0;
-    for (int n = threadIdx.x; n < p.N; n += 256) cnt += p.x[g * p.xs_g + n * p.xs_n] != 0;
+    const bool x32 = p.x_dtype == MOBGT_I32;
+    auto poi_at = [&](int n) -> int64_t {
+        const int64_t o = g * p.xs_g + n * p.xs_n;
+        return x32 ? (int64_t)reinterpret_cast<const int32_t*>(p.x)[o] : reinterpret_cast<const int64_t*>(p.x)[o];
+    };
+    for (int n = threadIdx.x; n < p.N; n += 256) cnt += poi_at(n) != 0;
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
     if ((threadIdx.x & 63) == 0) s_cnt[threadIdx.x >> 6] = cnt;
@@ -179,7 +184,7 @@ __global__ __launch_bounds__(256) void node_index_kernel(const NodeIndexParams p
     const int64_t GN = (int64_t)p.G * p.N;
     for (int n = threadIdx.x; n < p.N; n += 256) {
         const int64_t r = (int64_t)g * p.N + n;
-        const int64_t poi = p.x[g * p.xs_g + n * p.xs_n];
+        const int64_t poi = poi_at(n);
         const bool real = poi != 0;
         const int64_t slot = (int64_t)(p.tn[g * p.ts_g + n * p.ts_n] * 48.f);
         p.idx[0 * GN + r] = real ? (p.rows_only ? r : poi - 1) : -1;
@@ -202,12 +207,13 @@ __global__ __launch_bounds__(256) void node_index_kernel(const NodeIndexParams p
 
 }  // namespace
 
-extern "C" int mobgt_node_index(const int64_t* x, int64_t xs_g, int64_t xs_n, const float* time_normal, int64_t ts_g,
+extern "C" int mobgt_node_index(const void* x, int x_dtype, int64_t xs_g, int64_t xs_n, const float* time_normal, int64_t ts_g,
                                 int64_t ts_n, const int64_t* poi2cat, const void* in_degree, const void* out_degree,
                                 int deg_dtype, int64_t* idx, float* real, int G, int N, int rows_only, void* stream) {
     if (G <= 0 || N <= 0) return 0;
     if (in_degree && deg_dtype != MOBGT_I64 && deg_dtype != MOBGT_I32 && deg_dtype != MOBGT_I16) return MOBGT_EDTYPE;
-    NodeIndexParams p = {x, xs_g, xs_n, time_normal, ts_g, ts_n, poi2cat, in_degree, out_degree, deg_dtype, idx, real, G, N,
+    if (x_dtype != MOBGT_I64 && x_dtype != MOBGT_I32) return MOBGT_EDTYPE;
+    NodeIndexParams p = {x, x_dtype, xs_g, xs_n, time_normal, ts_g, ts_n, poi2cat, in_degree, out_degree, deg_dtype, idx, real, G, N,
                          rows_only};
     hipLaunchKernelGGL(node_index_kernel, dim3(G), dim3(256), 0, (hipStream_t)stream, p);
     return (int)hipGetLastError();

@@ -635,8 +635,8 @@ __device__ unsigned int gtl_ticket = 0;
 // observed not to take effect inside replayed hipGraphs (the scalar kept a stale value and the loss read
 // "stale + loss", found in the 2-rank run), so the kernel no longer depends on any prior state of *loss.
 __global__ __launch_bounds__(256) void gtl_kernel(const float* __restrict__ z, const int64_t* __restrict__ target,
-                                                  float* __restrict__ dz, float* __restrict__ loss, int64_t G, int64_t V,
-                                                  float alpha) {
+                                                  int64_t target_offset, float* __restrict__ dz, float* __restrict__ loss,
+                                                  int64_t G, int64_t V, float alpha) {
     const int64_t n = G * V;
     const float inv_n = 1.f / (float)n;
     float acc = 0.f;
@@ -646,7 +646,7 @@ __global__ __launch_bounds__(256) void gtl_kernel(const float* __restrict__ z, c
         const float p = 1.f / (1.f + __expf(-x));
         const float q = 1.f - p;
         float l, d;
-        if (target[g] == c) {
+        if (target[g] + target_offset == c) {
             const float lp = logf(p);
             l = -alpha * q * lp;
             d = alpha * p * q * lp - alpha * q * q;
@@ -688,13 +688,14 @@ __global__ __launch_bounds__(256) void gtl_kernel(const float* __restrict__ z, c
 }
 }  // namespace
 
-extern "C" int mobgt_gradient_tail_loss(const float* logits, const int64_t* targets, float* dlogits, float* loss,
-                                        int64_t G, int64_t V, float alpha, void* stream) {
+extern "C" int mobgt_gradient_tail_loss(const float* logits, const int64_t* targets, int64_t target_offset, float* dlogits,
+                                        float* loss, int64_t G, int64_t V, float alpha, void* stream) {
     if (G <= 0 || V <= 0) return MOBGT_EBADDIM;
     hipStream_t st = (hipStream_t)stream;
     const int64_t n = G * V;
     const unsigned blocks = (unsigned)((n + 1023) / 1024 < GTL_MAX_BLOCKS ? (n + 1023) / 1024 : GTL_MAX_BLOCKS);
-    hipLaunchKernelGGL(gtl_kernel, dim3(blocks ? blocks : 1), dim3(256), 0, st, logits, targets, dlogits, loss, G, V, alpha);
+    hipLaunchKernelGGL(gtl_kernel, dim3(blocks ? blocks : 1), dim3(256), 0, st, logits, targets, target_offset, dlogits, loss,
+                       G, V, alpha);
     return (int)hipGetLastError();
 }
 
@@ -735,10 +736,17 @@ extern "C" int mobgt_dropout(const float* x, float* y, int64_t n, int row_len, f
 namespace {
 __global__ __launch_bounds__(256) void adamw_flat_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                          float* __restrict__ v, bf16_t* __restrict__ shadow, int64_t n,
-                                                         const float* __restrict__ lr_dev, const int64_t* __restrict__ step_dev,
+                                                         const float* __restrict__ lr_dev, const float* __restrict__ sched,
+                                                         const int64_t* __restrict__ step_dev,
                                                          int64_t step_base, float beta1, float beta2, float eps, float wd) {
-    const float lr = *lr_dev;
     const float t = (float)(*step_dev - step_base);
+    float lr;
+    if (sched) {            // PolynomialDecayLR (lr.py:17-31, power = 1) evaluated at its step_count = t + offset
+        const float w = sched[0], tot = sched[1], peak = sched[2], end = sched[3], c = t + sched[4];
+        lr = c <= w ? c / w * peak : (c >= tot ? end : (peak - end) * (1.f - (c - w) / (tot - w)) + end);
+    } else {
+        lr = *lr_dev;
+    }
     const float bc1 = 1.f - powf(beta1, t), bc2 = 1.f - powf(beta2, t);
     const float step_size = lr / bc1, inv_sqrt_bc2 = rsqrtf(bc2), decay = 1.f - lr * wd;
     const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
@@ -778,14 +786,15 @@ __global__ __launch_bounds__(256) void adamw_flat_kernel(float* __restrict__ p, 
 }  // namespace
 
 extern "C" int mobgt_adamw_flat(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, void* shadow_bf16,
-                                int64_t n, const float* lr_dev, const int64_t* step_dev, int64_t step_base, float beta1,
-                                float beta2, float eps, float weight_decay, void* stream) {
+                                int64_t n, const float* lr_dev, const float* sched, const int64_t* step_dev,
+                                int64_t step_base, float beta1, float beta2, float eps, float weight_decay, void* stream) {
     if (n <= 0) return 0;
+    if (!lr_dev && !sched) return MOBGT_EBADDIM;
     if (((uintptr_t)params | (uintptr_t)grads | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15) return MOBGT_EALIGN;
     if (shadow_bf16 && ((uintptr_t)shadow_bf16 & 7)) return MOBGT_EALIGN;
     const int64_t blocks = (n + 1023) / 1024;
     hipLaunchKernelGGL(adamw_flat_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, params, grads, exp_avg,
-                       exp_avg_sq, reinterpret_cast<bf16_t*>(shadow_bf16), n, lr_dev, step_dev, step_base, beta1, beta2, eps,
+                       exp_avg_sq, reinterpret_cast<bf16_t*>(shadow_bf16), n, lr_dev, sched, step_dev, step_base, beta1, beta2, eps,
                        weight_decay);
     return (int)hipGetLastError();
 }
@@ -1088,4 +1097,98 @@ extern "C" int mobgt_bias_act_bwd(const float* dy, const float* y, float* dx, fl
     p.dy = dy; p.y_in = y; p.dx = dx; p.dbias = dbias; p.R = R; p.C = C; p.slope = slope; p.seed = seed; p.seed_dev = seed_dev;
     p.salt = salt;
     return launch_bias_act(p, true, dropout_p, (hipStream_t)stream);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Start of a training step: zero the flat gradient buffer and the zero arena, advance the step counter (dropout
+// seeds, AdamW's t) -- one launch instead of two fills and an add.
+namespace {
+__global__ __launch_bounds__(256) void step_prologue_kernel(float4* __restrict__ a, int64_t na, float4* __restrict__ b, int64_t nb,
+                                                            int64_t* __restrict__ counter) {
+    const int64_t n = na + nb;
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        if (i < na) a[i] = z; else b[i - na] = z;
+    }
+    if (counter && blockIdx.x == 0 && threadIdx.x == 0) *counter += 1;
+}
+}  // namespace
+
+extern "C" int mobgt_step_prologue(float* zero_a, int64_t n_a, float* zero_b, int64_t n_b, int64_t* counter, void* stream) {
+    if (n_a < 0 || n_b < 0 || (n_a & 3) || (n_b & 3)) return MOBGT_EBADDIM;
+    if (((uintptr_t)zero_a | (uintptr_t)zero_b) & 15) return MOBGT_EALIGN;
+    const int64_t n4 = (n_a + n_b) / 4;
+    int64_t blocks = (n4 + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(step_prologue_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<float4*>(zero_a), n_a / 4, reinterpret_cast<float4*>(zero_b), n_b / 4, counter);
+    return (int)hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// Input of the classifier head (model_fqandtoyo.py:1239-1240, 1353-1358 for q = 0): row g = [ encoder output of the
+// graph token | user_embedding[user[g] + user_offset] ], and its backward: d(enc) [G,T,C] is zero except the token
+// rows, the user rows are added into the table gradient (pre-zeroed by the caller).  Replaces a cast, a subtraction,
+// an index_select and a cat forward; two fills, two copies and the embedding backward.
+namespace {
+struct HeadInParams {
+    const float* enc; float* x3; const float* table; const void* user; int user_dtype; int64_t user_offset;
+    const float* dx3; float* denc; float* dtable;
+    int G, T, C, U; int64_t n_rows;
+};
+__device__ __forceinline__ int64_t head_user(const HeadInParams& p, int g) {
+    const int64_t u = p.user_dtype == MOBGT_I32 ? (int64_t)reinterpret_cast<const int32_t*>(p.user)[g]
+                                                 : reinterpret_cast<const int64_t*>(p.user)[g];
+    return u + p.user_offset;
+}
+__global__ __launch_bounds__(256) void head_input_fwd_kernel(const HeadInParams p) {
+    const int W = p.C + p.U;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= p.G * W) return;
+    const int g = i / W, c = i - g * W;
+    float v;
+    if (c < p.C) {
+        v = p.enc[(int64_t)g * p.T * p.C + c];
+    } else {
+        const int64_t u = head_user(p, g);
+        v = (u >= 0 && u < p.n_rows) ? p.table[u * p.U + (c - p.C)] : 0.f;
+    }
+    p.x3[i] = v;
+}
+__global__ __launch_bounds__(256) void head_input_bwd_kernel(const HeadInParams p) {
+    const int W = p.C + p.U;
+    const int64_t n1 = (int64_t)p.G * p.T * p.C;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n1) {
+        const int64_t row = i / p.C;
+        const int c = (int)(i - row * p.C);
+        const int64_t g = row / p.T;
+        p.denc[i] = (row - g * p.T == 0) ? p.dx3[g * W + c] : 0.f;
+    } else if (i < n1 + (int64_t)p.G * p.U) {
+        const int64_t j = i - n1;
+        const int g = (int)(j / p.U), c = (int)(j - (int64_t)g * p.U);
+        const int64_t u = head_user(p, g);
+        if (u >= 0 && u < p.n_rows) atomicAdd(&p.dtable[u * p.U + c], p.dx3[(int64_t)g * W + p.C + c]);
+    }
+}
+}  // namespace
+
+extern "C" int mobgt_head_input_fwd(const float* enc, const void* user, int user_dtype, int64_t user_offset, const float* table,
+                                    int64_t n_rows, float* x3, int G, int T, int C, int U, void* stream) {
+    if (G <= 0 || T <= 0 || C <= 0 || U <= 0) return MOBGT_EBADDIM;
+    if (user_dtype != MOBGT_I64 && user_dtype != MOBGT_I32) return MOBGT_EDTYPE;
+    HeadInParams p = {enc, x3, table, user, user_dtype, user_offset, nullptr, nullptr, nullptr, G, T, C, U, n_rows};
+    hipLaunchKernelGGL(head_input_fwd_kernel, dim3((G * (C + U) + 255) / 256), dim3(256), 0, (hipStream_t)stream, p);
+    return (int)hipGetLastError();
+}
+
+extern "C" int mobgt_head_input_bwd(const float* dx3, const void* user, int user_dtype, int64_t user_offset, float* denc,
+                                    float* dtable, int64_t n_rows, int G, int T, int C, int U, void* stream) {
+    if (G <= 0 || T <= 0 || C <= 0 || U <= 0) return MOBGT_EBADDIM;
+    if (user_dtype != MOBGT_I64 && user_dtype != MOBGT_I32) return MOBGT_EDTYPE;
+    HeadInParams p = {nullptr, nullptr, nullptr, user, user_dtype, user_offset, dx3, denc, dtable, G, T, C, U, n_rows};
+    const int64_t n = (int64_t)G * T * C + (int64_t)G * U;
+    hipLaunchKernelGGL(head_input_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, p);
+    return (int)hipGetLastError();
 }

@@ -125,8 +125,9 @@ def _mm_tn_f32(g, x):
 _ADDMM_OUT_DTYPE = [None]
 
 
-def _addmm_f32(c, a, b):
-    """c (fp32) + a @ b (bf16 operands) with an fp32 result."""
+def _addmm_f32(c, a, b, inplace=False):
+    """c (fp32) + a @ b (bf16 operands) with an fp32 result.  `inplace`: c is a scratch buffer of the caller and
+    receives the result (beta = 1 GEMM straight onto it; out-of-place, addmm first copies c into a new tensor)."""
     if _ADDMM_OUT_DTYPE[0] is None:
         try:
             torch.addmm(c, a, b, out_dtype=torch.float32)
@@ -134,6 +135,8 @@ def _addmm_f32(c, a, b):
         except Exception:
             _ADDMM_OUT_DTYPE[0] = False
     if _ADDMM_OUT_DTYPE[0]:
+        if inplace:
+            return torch.ops.aten.addmm.dtype_out(c, a, b, torch.float32, out=c)
         return torch.addmm(c, a, b, out_dtype=torch.float32)
     return c + (a @ b).float()
 
@@ -282,10 +285,10 @@ class _FusedLayerFn(torch.autograd.Function):
             dx = torch.empty(R, C, dtype=torch.float32, device=dev)
             _k1_bwd(dz0, None, dx1, x.view(R, C), stats[0], stats[1], nxw, dx, None, dnxw, dnxb, None, R, C, 0.0, seed, sd,
                     salt, act)
-        elif A == torch.float32:
-            dx = torch.addmm(dx1, dqkv2, s_wqkv)
+        elif A == torch.float32:                                      # dx1 is this function's own buffer: accumulate onto it
+            dx = torch.addmm(dx1, dqkv2, s_wqkv, out=dx1)
         else:
-            dx = _addmm_f32(dx1, dqkv2, s_wqkv)
+            dx = _addmm_f32(dx1, dqkv2, s_wqkv, inplace=True)
         return (dx.view(G, T, C), None, None, None, None, dwqkv[:C], dbqkv[:C], dwqkv[C:2 * C], dbqkv[C:2 * C], dwqkv[2 * C:],
                 dbqkv[2 * C:], dwo, dbo, dn1w, dn1b, dnxw, dnxb, dw1, db1, dw2, db2)
 

@@ -285,7 +285,9 @@ class Graphormer(nn.Module):
 
     def node_features(self, batched_data):
         """model_fqandtoyo.py:1222-1342 -> [G, N+1, C] (graph token first)."""
-        x = batched_data.x[:, :, 0].long()                                    # [G,N] POI ids, 0 = pad
+        x = batched_data.x[:, :, 0]                                           # [G,N] POI ids, 0 = pad
+        if x.dtype not in (torch.int64, torch.int32):
+            x = x.long()
         G, N = x.shape
         P = self.X.shape[0]
         rows_only = G * N * 2 <= P                      # the table is read at <= G*N rows (:1264): compute only those
@@ -319,7 +321,7 @@ class Graphormer(nn.Module):
             padding_idx=[0, 0, 0, None])
         # nf * real + add -> pos_embed dropout (:358); graph token + pe[0] -> the same dropout (:1338-1342); cat;
         # input_dropout (:1347): one launch
-        return ops.assemble_tokens(nf, real, add, self.graph_token.weight, self.pos_embed.pe[0], self.pos_embed.dropout.p,
+        return ops.assemble_tokens(nf, real, add, self.graph_token.weight, self.pos_embed.pe, self.pos_embed.dropout.p,
                                    self.input_dropout.p, self.training)
 
     def forward(self, batched_data, perturb=None):
@@ -331,15 +333,18 @@ class Graphormer(nn.Module):
             output = enc_layer(output, bias, mask=None)
             ops.trace_nan(f"layer{li}", output)
         self._enc_out = output           # train.TrainStep: everything after this point is the "head" (see head_modules)
-        user_embedding = self.user_embed_model(batched_data.user.long() - 1).reshape(output.shape[0], -1)   # :1239-1240
         fuse3 = self.embed_fuse_model3
-        if output.is_cuda and self.final_ln.weight.shape[0] <= 512:
-            # Linear of FuseEmbeddings, then LeakyReLU -> final_ln -> ELU -> output dropout in ONE launch (:1353-1364)
-            x3 = torch.cat((output[:, 0, :].float(), user_embedding), 1)
+        user = batched_data.user
+        if output.is_cuda and self.final_ln.weight.shape[0] <= 512 and output.dtype == torch.float32 \
+                and user.dtype in (torch.int64, torch.int32) and user.numel() == output.shape[0]:
+            # [graph-token row | user_embed_model(user - 1)] in one launch (:1239-1240), the Linear of FuseEmbeddings,
+            # then LeakyReLU -> final_ln -> ELU -> output dropout in ONE launch (:1353-1364)
+            x3 = ops.head_input(output, self.user_embed_model.user_embedding.weight, user, -1)
             u3 = ops.linear_splitk(x3, fuse3.fuse_embed.weight, fuse3.fuse_embed.bias, getattr(fuse3, "bf16_wgrad", False))
             tok = ops.head_act(u3, self.final_ln.weight, self.final_ln.bias, self.final_ln.eps, 0.2, self.output_dropout.p,
                                self.training, 0x1004)
         else:
+            user_embedding = self.user_embed_model(user.long() - 1).reshape(output.shape[0], -1)   # :1239-1240
             tok = fuse3(output[:, 0, :].float(), user_embedding)                               # :1353-1358, q = 0 only
             tok = ops.dropout(self.ELU(self.final_ln(tok)), self.output_dropout.p, self.training, 0x1004)   # :1360-1364
         ops.trace_nan("tok", tok)
@@ -363,7 +368,7 @@ class Graphormer(nn.Module):
             y_hat = self(batched_data)[0]
         finally:
             self._poi_logits_only = False
-        return ops.gradient_tail_loss(y_hat, batched_data.y.long() - 1, 0.2)
+        return ops.gradient_tail_loss(y_hat, batched_data.y, 0.2, target_offset=-1)
 
     def validation_step(self, batched_data, batch_idx=0):
         """model_fqandtoyo.py:1483-1495"""

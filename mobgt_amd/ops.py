@@ -399,13 +399,14 @@ class _GatherSumFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dout):
-        dout = dout.contiguous()
+        if dout.stride(1) != 1 or dout.stride(0) % 4 or dout.data_ptr() % 16:      # column slices of a wider matrix are fine
+            dout = dout.contiguous()
         n = len(ctx.shapes)
         grads = [zeros_f32(tuple(s), dout.device) for s in ctx.shapes]
         skip = (ctypes.c_int64 * n)(*ctx.skip)
         R, C = dout.shape
-        check(_lib.lib().mobgt_embed_scatter_add(_ptr_array(grads), _ptr_array(ctx.idx), skip, n, _p(dout), R, C, C,
-                                                 _IT[ctx.idx[0].dtype], _stream()), "mobgt_embed_scatter_add")
+        check(_lib.lib().mobgt_embed_scatter_add(_ptr_array(grads), _ptr_array(ctx.idx), skip, n, _p(dout), R, C,
+                                                 dout.stride(0), _IT[ctx.idx[0].dtype], _stream()), "mobgt_embed_scatter_add")
         return (None, None, *grads, *([None] * n))
 
 
@@ -522,11 +523,11 @@ def target_rank(scores, target):
 
 def node_index(x, time_normal, poi2cat, rows_only, in_degree=None, out_degree=None):
     """Row indices of the node-feature gathers (model_fqandtoyo.py:1259-1264, 1287-1298) in one launch.
-    x [G,N] int64 POI ids, time_normal [G,N] f32 -> (idx [8,G,N] int64, real [G,N] f32); rows of idx:
+    x [G,N] int64/int32 POI ids, time_normal [G,N] f32 -> (idx [8,G,N] int64, real [G,N] f32); rows of idx:
     POI row, time slot, category row, positional row (all -1 where there is none), GCN row max(x-1,0), zeros,
     in-degree, out-degree (the last two only when the [G,N] degree tensors are given; widened to int64)."""
     _require_cuda(x, time_normal, poi2cat)
-    assert x.dtype == torch.int64 and time_normal.dtype == torch.float32 and poi2cat.dtype == torch.int64
+    assert x.dtype in (torch.int64, torch.int32) and time_normal.dtype == torch.float32 and poi2cat.dtype == torch.int64
     G, N = x.shape
     idx = torch.empty(8, G, N, dtype=torch.int64, device=x.device)
     real = torch.empty(G, N, dtype=torch.float32, device=x.device)
@@ -535,7 +536,7 @@ def node_index(x, time_normal, poi2cat, rows_only, in_degree=None, out_degree=No
         in_degree, out_degree = in_degree.reshape(G, N).contiguous(), out_degree.reshape(G, N).contiguous()
         assert in_degree.dtype == out_degree.dtype and in_degree.dtype in _IT
         deg_dt = _IT[in_degree.dtype]
-    check(_lib.lib().mobgt_node_index(_p(x), x.stride(0), x.stride(1), _p(time_normal), time_normal.stride(0),
+    check(_lib.lib().mobgt_node_index(_p(x), _IT[x.dtype], x.stride(0), x.stride(1), _p(time_normal), time_normal.stride(0),
                                       time_normal.stride(1), _p(poi2cat), _p(in_degree), _p(out_degree), deg_dt, _p(idx),
                                       _p(real), G, N, int(bool(rows_only)), _stream()), "mobgt_node_index")
     return idx, real
@@ -604,13 +605,13 @@ def embed_gather_concat(tables, indices, padding_idx=None):
 # ------------------------------------------------------------------------------------------ loss
 class _GradientTailLossFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, logits, targets, alpha):
+    def forward(ctx, logits, targets, alpha, target_offset):
         logits = logits.float().contiguous()
         G, V = logits.shape
         dlogits = torch.empty_like(logits)
         loss = torch.empty((), dtype=torch.float32, device=logits.device)
-        check(_lib.lib().mobgt_gradient_tail_loss(_p(logits), _p(targets.long().contiguous()), _p(dlogits), _p(loss), G, V,
-                                                  float(alpha), _stream()), "mobgt_gradient_tail_loss")
+        check(_lib.lib().mobgt_gradient_tail_loss(_p(logits), _p(targets.long().contiguous()), int(target_offset), _p(dlogits),
+                                                  _p(loss), G, V, float(alpha), _stream()), "mobgt_gradient_tail_loss")
         ctx.save_for_backward(dlogits)
         return loss
 
@@ -618,8 +619,8 @@ class _GradientTailLossFn(torch.autograd.Function):
     def backward(ctx, g):
         (dlogits,) = ctx.saved_tensors
         if g.data_ptr() == unit_grad(g.device).data_ptr():      # d(loss)/d(loss) = 1 supplied by the trainer: no multiply
-            return dlogits, None, None
-        return dlogits * g, None, None
+            return dlogits, None, None, None
+        return dlogits * g, None, None, None
 
 
 _UNIT = {}
@@ -637,10 +638,11 @@ def unit_grad(device):
     return t
 
 
-def gradient_tail_loss(logits, targets, alpha=0.25):
-    """model_fqandtoyo.py:545-550 (beta = k = 1): value and gradient from one HIP kernel."""
+def gradient_tail_loss(logits, targets, alpha=0.25, target_offset=0):
+    """model_fqandtoyo.py:545-550 (beta = k = 1): value and gradient from one HIP kernel.  Row g's class is
+    targets[g] + target_offset (the training step's `y - 1` without a launch for it)."""
     _require_cuda(logits, targets)
-    return _GradientTailLossFn.apply(logits, targets[: logits.shape[0]].reshape(-1), alpha)
+    return _GradientTailLossFn.apply(logits, targets[: logits.shape[0]].reshape(-1), alpha, target_offset)
 
 
 # ------------------------------------------------------------------------------- small linear layers
@@ -793,13 +795,48 @@ def head_act(u, ln_weight, ln_bias, eps, slope, p_drop, training, salt):
                             int(salt) & 0xFFFFFFFF)
 
 
+class _HeadInputFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, enc, table, user, offset):
+        G, T, C = enc.shape
+        U = table.shape[1]
+        x3 = torch.empty(G, C + U, dtype=torch.float32, device=enc.device)
+        check(_lib.lib().mobgt_head_input_fwd(_p(enc), _p(user), _IT[user.dtype], offset, _p(table), table.shape[0], _p(x3),
+                                              G, T, C, U, _stream()), "mobgt_head_input_fwd")
+        ctx.user, ctx.misc = user, (G, T, C, U, offset, table.shape)
+        ctx.sink = grad_sink(table)
+        return x3
+
+    @staticmethod
+    def backward(ctx, dx3):
+        G, T, C, U, offset, tshape = ctx.misc
+        dx3 = dx3.contiguous()
+        denc = torch.empty(G, T, C, dtype=torch.float32, device=dx3.device)
+        dtable = ctx.sink[:] if ctx.sink is not None else zeros_f32(tuple(tshape), dx3.device)
+        check(_lib.lib().mobgt_head_input_bwd(_p(dx3), _p(ctx.user), _IT[ctx.user.dtype], offset, _p(denc), _p(dtable),
+                                              tshape[0], G, T, C, U, _stream()), "mobgt_head_input_bwd")
+        return denc, dtable, None, None
+
+
+def head_input(enc, user_table, user, user_offset=0):
+    """[G, C+U] input of the classifier head: the graph-token row of the encoder output next to the user's embedding row
+    `user_table[user + user_offset]` (model_fqandtoyo.py:1239-1240, 1353-1358) -- one launch each way."""
+    _require_cuda(enc, user_table, user)
+    assert enc.dtype == torch.float32 and user_table.dtype == torch.float32 and user.dtype in (torch.int64, torch.int32)
+    assert user_table.is_contiguous()
+    return _HeadInputFn.apply(enc.contiguous(), user_table, user.reshape(-1).contiguous(), int(user_offset))
+
+
 class _AssembleTokensFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, nf, real, add, token, pe0, p_pos, p_in, seed, seed_dev, salts):
         G, N, C = nf.shape
         nf, add, real = nf.contiguous(), add.contiguous(), real.contiguous()
         shapes = (token.shape, pe0.shape)
-        token, pe0 = token.reshape(-1).contiguous(), pe0.reshape(-1).contiguous()
+        token = token.reshape(-1).contiguous()
+        # pe0: row 0 of the positional table, or the whole [L, C] table (then its gradient is one [L, C] tensor with
+        # row 0 filled in -- no select_backward fill + copy)
+        pe0 = pe0.contiguous() if pe0.dim() == 2 and pe0.shape[0] > 1 else pe0.reshape(-1).contiguous()
         out = torch.empty(G, N + 1, C, dtype=torch.float32, device=nf.device)
         check(_lib.lib().mobgt_assemble_tokens_fwd(_p(nf), _p(real), _p(add), _p(token), _p(pe0), _p(out), G, N, C, p_pos, p_in,
                                                    seed, _p(seed_dev), salts[0], salts[1], salts[2], _stream()),
@@ -815,17 +852,23 @@ class _AssembleTokensFn(torch.autograd.Function):
         dout = dout.contiguous()
         d_nf = torch.empty(G, N, C, dtype=torch.float32, device=dout.device)
         d_add = torch.empty(G, N, C, dtype=torch.float32, device=dout.device)
-        d_tok = zeros_f32((C,), dout.device)
+        if len(pshape) == 2 and pshape[0] > 1:
+            d_pe = zeros_f32(tuple(pshape), dout.device)
+            d_tok = d_pe[0]                       # d(token) = d(pe[0]): the same column sums
+        else:
+            d_tok = zeros_f32((C,), dout.device)
+            d_pe = d_tok.view(pshape)
         check(_lib.lib().mobgt_assemble_tokens_bwd(_p(dout), _p(real), _p(d_nf), _p(d_add), _p(d_tok), G, N, C, p_pos, p_in, seed,
                                                    _p(seed_dev), salts[0], salts[1], salts[2], _stream()),
               "mobgt_assemble_tokens_bwd")
-        return d_nf, None, d_add, d_tok.view(tshape), d_tok.view(pshape), None, None, None, None, None
+        return d_nf, None, d_add, d_tok.view(tshape), d_pe, None, None, None, None, None
 
 
 def assemble_tokens(nf, real, add, token, pe0, p_pos, p_in, training, salts=(0x1001, 0x1002, 0x1003)):
     """[G,N+1,C] encoder input: graph token row (+ pe[0]) and the node features (* real + add), each through the
     positional dropout and then the input dropout -- one launch forward, one backward (see mobgt_assemble_tokens_fwd).
-    `token` and `pe0` are [C]-sized; their gradient is the same per-column sum over graphs."""
+    `token` is [C]-sized; `pe0` is pe[0] or the whole positional table [L, C] (row 0 is used); the gradient of both is
+    the same per-column sum over graphs."""
     _require_cuda(nf, add, token, pe0)
     if not training:
         p_pos = p_in = 0.0

@@ -167,7 +167,7 @@ class TrainStep:
         ops.set_dropout_state(self.seed_dev, seed)
         # room for every gradient that kernels accumulate into (all but the few huge matrices torch's GEMMs write)
         n_arena = sum(p.numel() for p in model.parameters() if p.numel() <= (1 << 16))
-        self.arena = ops.ZeroArena(dev, n=max(1 << 20, int(n_arena * 1.5) + (1 << 18)))
+        self.arena = ops.ZeroArena(dev, n=(max(1 << 21, int(n_arena * 1.5) + (1 << 18)) + 3) // 4 * 4)
         ops.set_zero_arena(self.arena)
         model.train()
         # One side stream for the dry run, the warm-ups and every capture: autograd's AccumulateGrad nodes are
@@ -194,17 +194,23 @@ class TrainStep:
         self.betas, self.eps = (0.9, 0.999), 1e-8
         self.sched_state = dict(step_count=1, warmup=model.warmup_updates, tot=model.tot_updates, lr=model.peak_lr,
                                 end_lr=model.end_lr, power=1.0)
+        # PolynomialDecayLR with power 1 is evaluated inside the optimizer kernel from the device step counter (no
+        # per-step host write of the learning rate); `lr_dev` mirrors it for inspection and serves any other schedule
+        s = self.sched_state
+        # (5th entry: offset between the kernel's step count and the schedule's -- prepare() runs one warm-up call)
+        self.sched_dev = torch.tensor([float(s["warmup"]), float(s["tot"]), float(s["lr"]), float(s["end_lr"]), 0.0],
+                                      dtype=torch.float32, device=dev) if s["power"] == 1.0 and s["warmup"] > 0 else None
         self._set_lr()
         self.use_graph = use_graph
         self.graphs = {}
-        self.loss_out = torch.zeros((), device=dev)
+        self._loss_ref = torch.zeros((), device=dev)          # the loss tensor of the step that ran last
         self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
         # Data parallel: split the backward at the encoder output so that the head bucket's all-reduce (61 % of the
         # bytes, ready after ~20 kernels) runs on RCCL's stream while the rest of the backward is still executing.
         # (overlap="force": the two-phase path at world size 1 as well -- tests)
         self.overlap = bool(overlap and use_graph and (self.world > 1 or overlap == "force") and self.n_head > 0
                             and hasattr(model, "_enc_out"))
-        self.graphs_b, self._g_enc = {}, {}
+        self.graphs_b, self._g_enc, self._loss_slots = {}, {}, {}
 
     def _attach_shadows(self):
         """bf16 copy of the whole flat parameter buffer; the fused layers' shadow weights become views of it, kept
@@ -239,7 +245,8 @@ class TrainStep:
         n = self.flat.flat.numel()
         _lib.check(_lib.lib().mobgt_adamw_flat(_p(self.flat_params.tensor), _p(self.flat.flat), _p(self.exp_avg),
                                                _p(self.exp_avg_sq), _p(self.shadow_flat), n, _p(self.lr_dev),
-                                               _p(self.seed_dev), self._step_base, self.betas[0], self.betas[1], self.eps,
+                                               _p(self.sched_dev), _p(self.seed_dev), self._step_base, self.betas[0],
+                                               self.betas[1], self.eps,
                                                float(self.model.weight_decay), _stream()), "mobgt_adamw_flat")
 
     def _on_stream(self):
@@ -264,7 +271,9 @@ class TrainStep:
         else:
             pct = 1 - (c - s["warmup"]) / (s["tot"] - s["warmup"])
             lr = (s["lr"] - s["end_lr"]) * pct ** s["power"] + s["end_lr"]
-        self.lr_dev.fill_(lr)
+        self.lr = lr
+        if self.sched_dev is None:
+            self.lr_dev.fill_(lr)
 
     def _loss(self, batch):
         if self.autocast_dtype is not None:
@@ -272,29 +281,46 @@ class TrainStep:
                 return self.model.training_step(batch, 0)
         return self.model.training_step(batch, 0)
 
-    def _fwd_bwd(self, batch):
+    def _prologue(self):
+        """Zero the flat gradient buffer (in-place gradient sinks accumulate into it; unused slots stay zero) and the
+        zero arena (all small zero-initialised accumulators of the step), advance the step counter (new dropout masks,
+        AdamW's t): one launch."""
+        from . import _lib
+        from .ops import _p, _stream
         self.flat.release()
-        self.flat.zero()                           # in-place gradient sinks accumulate into it; unused slots stay zero
-        self.arena.reset()                         # one fill for all small zero-initialised accumulators of the step
-        self.seed_dev.add_(1)                      # new dropout masks each step (attention kernels read it on device)
+        self.arena.off = 0
+        _lib.check(_lib.lib().mobgt_step_prologue(_p(self.flat.flat), self.flat.flat.numel(), _p(self.arena.buf),
+                                                  self.arena.buf.numel(), _p(self.seed_dev), _stream()), "mobgt_step_prologue")
+
+    def _fwd_bwd(self, batch, slot=None):
+        self._prologue()
         loss = self._loss(batch)
         loss.backward(gradient=ops.unit_grad(loss.device))
         self.flat.gather()
-        self.loss_out.copy_(loss.detach())
+        self._keep_loss(loss, slot)
+
+    def _keep_loss(self, loss, slot):
+        """The loss scalar stays where the loss kernel wrote it (a graph's static output), no copy launch."""
+        loss = loss.detach()
+        if slot is None:
+            self._loss_ref = loss
+        else:
+            self._loss_slots[slot] = loss
+
+    @property
+    def loss_out(self):
+        return self._loss_ref
 
     # ---- the same step in two phases (data parallel): [forward, loss, head backward] | [rest of the backward]
     def _phase_a(self, batch, i):
-        self.flat.release()
-        self.flat.zero()
-        self.arena.reset()
-        self.seed_dev.add_(1)
+        self._prologue()
         loss = self._loss(batch)
         enc = self.model._enc_out
         head = self.flat.params[:self.n_head]
         grads = torch.autograd.grad(loss, head + [enc], grad_outputs=ops.unit_grad(loss.device), allow_unused=True)   # frees only the nodes it ran
         self.flat.gather(0, self.n_head, grads=list(grads[:-1]))
         self._g_enc[i] = (enc, grads[-1])
-        self.loss_out.copy_(loss.detach())
+        self._keep_loss(loss, i)
 
     def _phase_b(self, i):
         enc, g_enc = self._g_enc[i]
@@ -311,7 +337,7 @@ class TrainStep:
         # pool is only safe for capture-order replay (measured: NaNs on the second lap with a shared pool)
         if not self.overlap:
             with torch.cuda.graph(g, pool=self.pool if os.environ.get("MOBGT_SHARED_POOL") else None, stream=self.stream):
-                self._fwd_bwd(batch)
+                self._fwd_bwd(batch, slot=i)
             return g
         # two graphs over ONE autograd graph: phase B is captured right after phase A and replays its kernels on the
         # activations phase A's replay leaves at the same addresses (A's private pool; nothing else writes there)
@@ -331,6 +357,8 @@ class TrainStep:
         for i in range(len(self.batches)):
             self.graphs[i] = self._capture(i)
         with self._on_stream():
+            if self.sched_dev is not None:
+                self.sched_dev[4] = -1.0             # the warm-up call is optimizer call 1 and runs at lr(0) = 0
             self._opt_step()
         self._join()
         self.opt_graph = torch.cuda.CUDAGraph()
@@ -339,6 +367,8 @@ class TrainStep:
 
     def step(self, i):
         """One optimizer step on pre-collated batch i (model_fqandtoyo.py:1434-1478 + optimizer + scheduler)."""
+        if self.use_graph:
+            self._loss_ref = self._loss_slots[i % len(self.batches)]
         if self.overlap:
             j = i % len(self.batches)
             na = self.n_head_elems

@@ -157,10 +157,79 @@ def test_adamw_flat_matches_torch_adamw():
         opt.step()
         lr_dev.fill_(lr)
         step_dev.add_(1)
-        _lib.check(_lib.lib().mobgt_adamw_flat(_p(p), _p(g.to(DEV)), _p(m), _p(v), _p(sh), n, _p(lr_dev), _p(step_dev), 40,
+        _lib.check(_lib.lib().mobgt_adamw_flat(_p(p), _p(g.to(DEV)), _p(m), _p(v), _p(sh), n, _p(lr_dev), None, _p(step_dev), 40,
                                                0.9, 0.999, 1e-8, 0.01, _stream()), "mobgt_adamw_flat")
         np.testing.assert_allclose(p.cpu().numpy(), ref.detach().float().numpy(), rtol=2e-5, atol=2e-6)
     assert torch.equal(sh, p.bfloat16())
+
+
+def test_adamw_flat_device_schedule_matches_polynomial_decay():
+    """The in-kernel learning-rate schedule (sched = warmup, total, peak, end, offset) against torch.optim.AdamW driven
+    by the host formula of lr.py:17-31 (power 1): warm-up, decay and the flat tail, with a step offset."""
+    from mobgt_amd import _lib
+    from mobgt_amd.ops import _p, _stream
+
+    def host_lr(c, warm=3, tot=7, peak=2e-3, end=1e-4):
+        if c <= warm:
+            return c / float(warm) * peak
+        if c >= tot:
+            return end
+        return (peak - end) * (1 - (c - warm) / (tot - warm)) + end
+    gen = torch.Generator().manual_seed(4)
+    n = 4099
+    p0 = torch.randn(n, generator=gen)
+    ref = torch.nn.Parameter(p0.clone().double())
+    opt = torch.optim.AdamW([ref], lr=1e-3, weight_decay=0.01)
+    p = p0.clone().to(DEV)
+    m, v = torch.zeros_like(p), torch.zeros_like(p)
+    sched = torch.tensor([3.0, 7.0, 2e-3, 1e-4, 1.0], device=DEV)      # offset +1: optimizer call t runs at lr(t + 1)
+    step_dev = torch.tensor([10], dtype=torch.int64, device=DEV)
+    for it in range(9):
+        g = torch.randn(n, generator=gen)
+        for grp in opt.param_groups:
+            grp["lr"] = host_lr(it + 2)
+        ref.grad = g.double()
+        opt.step()
+        step_dev.add_(1)
+        _lib.check(_lib.lib().mobgt_adamw_flat(_p(p), _p(g.to(DEV)), _p(m), _p(v), None, n, None, _p(sched), _p(step_dev), 10,
+                                               0.9, 0.999, 1e-8, 0.01, _stream()), "mobgt_adamw_flat")
+        np.testing.assert_allclose(p.cpu().numpy(), ref.detach().float().numpy(), rtol=2e-5, atol=2e-6)
+
+
+def test_step_prologue_zeroes_both_buffers_and_bumps_the_counter():
+    from mobgt_amd import _lib
+    from mobgt_amd.ops import _p, _stream
+    a = torch.randn(100003 * 4, device=DEV)
+    b = torch.randn(52, device=DEV)
+    guard = a[-4:].clone()
+    c = torch.tensor([41], dtype=torch.int64, device=DEV)
+    _lib.check(_lib.lib().mobgt_step_prologue(_p(a), a.numel() - 4, _p(b), b.numel(), _p(c), _stream()), "mobgt_step_prologue")
+    assert int(c.item()) == 42
+    assert not a[:-4].any() and not b.any() and torch.equal(a[-4:], guard)
+    _lib.check(_lib.lib().mobgt_step_prologue(None, 0, _p(guard), 4, None, _stream()), "mobgt_step_prologue")
+    assert not guard.any() and int(c.item()) == 42
+
+
+@pytest.mark.parametrize("idt", [torch.int32, torch.int64])
+def test_head_input_matches_torch_chain(idt):
+    """mobgt_head_input_fwd/bwd against cat(output[:, 0, :], embedding(user - 1)) and its autograd."""
+    from mobgt_amd import ops
+    gen = torch.Generator().manual_seed(12)
+    G, T, C, U, NU = 16, 9, 192, 128, 50
+    enc = torch.randn(G, T, C, generator=gen).to(DEV)
+    table = torch.randn(NU, U, generator=gen).to(DEV)
+    user = torch.randint(1, NU + 1, (G, 1), generator=gen)
+    user[3] = user[7]                                             # a repeated user: its row receives two gradient rows
+    gy = torch.randn(G, C + U, generator=gen).to(DEV)
+    ea, ta = enc.clone().requires_grad_(True), table.clone().requires_grad_(True)
+    ref = torch.cat((ea[:, 0, :], torch.nn.functional.embedding(user.to(DEV).long().view(-1) - 1, ta)), 1)
+    ref.backward(gy)
+    eb, tb = enc.clone().requires_grad_(True), table.clone().requires_grad_(True)
+    got = ops.head_input(eb, tb, user.to(idt).to(DEV), -1)
+    got.backward(gy)
+    assert torch.equal(got, ref)
+    assert torch.equal(eb.grad, ea.grad)
+    np.testing.assert_allclose(tb.grad.cpu().numpy(), ta.grad.cpu().numpy(), rtol=1e-6, atol=1e-6)
 
 
 @pytest.mark.parametrize("p_drop", [0.0, 0.3])

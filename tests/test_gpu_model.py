@@ -208,6 +208,9 @@ def test_gradient_tail_loss_kernel_matches_reference_g7(golden_dir):
     (loss * 3.0).backward()
     np.testing.assert_allclose(loss.item(), z["gtl/loss"], rtol=2e-6)
     np.testing.assert_allclose(logits.grad.cpu().numpy(), 3.0 * z["gtl/dlogits"], rtol=2e-5, atol=1e-8)
+    # `y - 1` folded into the kernel (training_step): same numbers from the 1-based targets
+    l2 = ops.gradient_tail_loss(logits.detach(), torch.from_numpy(z["gtl/targets"]).to(DEV) + 1, 0.2, target_offset=-1)
+    assert l2.item() == loss.item()
 
 
 def test_metrics_rank_kernel_matches_reference_g7(golden_dir):
@@ -244,7 +247,8 @@ def test_node_index_kernel_matches_index_expressions():
     for rows_only in (False, True):
         indeg = torch.randint(0, 9, (G, N), generator=g).to(torch.int16)
         outdeg = torch.randint(0, 9, (G, N), generator=g).to(torch.int16)
-        idx, real = ops.node_index(x.to(DEV), tn[:, :, 0].to(DEV), poi2cat.to(DEV), rows_only, indeg.to(DEV), outdeg.to(DEV))
+        xd = x.to(DEV) if rows_only else x.to(torch.int32).to(DEV)         # both id widths
+        idx, real = ops.node_index(xd, tn[:, :, 0].to(DEV), poi2cat.to(DEV), rows_only, indeg.to(DEV), outdeg.to(DEV))
         idx, real = idx.cpu(), real.cpu()
         m = x != 0
         neg = torch.full_like(x, -1)
