@@ -341,6 +341,23 @@ int mobgt_adamw_flat(float* params, const float* grads, float* exp_avg, float* e
                      const float* lr_dev, const float* sched, const int64_t* step_dev, int64_t step_base, float beta1,
                      float beta2, float eps, float weight_decay, void* stream);
 
+/* The encoder layer's small GEMMs with the following elementwise step fused (graphormer/model.py:388-403, 406-463;
+ * model_fqandtoyo.py:1641-1712 and the autograd of those F.linear calls): bf16 operands, f32 accumulate.
+ *   acc[M,N] = A[M,K] x op(B)        A row-major (lda);  b_is_kn = 0: B is [N,K] (an nn.Linear weight, forward),
+ *                                     b_is_kn = 1: B is [K,N] (the same weight seen from dX = dY W)
+ *   bias [N] bf16 or NULL is added to acc first.  Then, by `epilogue`:
+ *     MOBGT_GEMM_BIAS     C (bf16) = acc
+ *     MOBGT_GEMM_GELU     C (bf16) = u = acc,  aux_out (bf16, ldc) = gelu(u)  (exact erf; from the rounded u)
+ *     MOBGT_GEMM_GELU_BWD C (bf16) = acc * gelu'(aux_in[m,n])   aux_in = u, bf16 (ldc)
+ *     MOBGT_GEMM_ADD      C (f32)  = acc + aux_in[m,n]          aux_in f32 (ldc); may alias C
+ * K % 32 == 0, N % 8 == 0, lda / ldc % 8 == 0 (ldb % 8 == 0, or % 2 == 0 when b_is_kn), 16-byte aligned pointers. */
+#define MOBGT_GEMM_BIAS 0
+#define MOBGT_GEMM_GELU 1
+#define MOBGT_GEMM_GELU_BWD 2
+#define MOBGT_GEMM_ADD 3
+int mobgt_layer_gemm(const void* a, int64_t lda, const void* b, int64_t ldb, int b_is_kn, const void* bias, void* c,
+                     int64_t ldc, int epilogue, const void* aux_in, void* aux_out, int M, int N, int K, void* stream);
+
 /* Start of a training step (the trainer's `optimizer.zero_grad()` + per-step counter): zero-fills two f32 buffers
  * (element counts multiples of 4, 16-byte aligned; either may be empty) and adds 1 to *counter (may be NULL). */
 int mobgt_step_prologue(float* zero_a, int64_t n_a, float* zero_b, int64_t n_b, int64_t* counter, void* stream);

@@ -1,0 +1,223 @@
+// The encoder layer's eight small GEMMs (graphormer/model.py:388-403 FeedForwardNetwork, :406-463
+// MultiHeadAttention's linear_q/k/v and output_layer; model_fqandtoyo.py:1641-1712) and their data gradients, bf16
+// operands / f32 accumulate, with the elementwise step that follows each of them fused into the epilogue.
+//
+// Shape of the problem: M = G*T rows (a few hundred), N and K in {C, 3C, F} = {192, 576, 1024}.  134 MFLOP and
+// ~1 MB per call: nothing but latency.  A library GEMM picks (per shape, by noisy timing) among kernels that walk the
+// whole of K in one wave -- 5 us when the pick is good, 9-21 us when it is not (K = 1024, or a non-MFMA kernel for
+// 608x192x192), and the elementwise step (GELU, its derivative, the residual add) is one more launch.  Here a workgroup
+// owns a 32x64 output tile, its four waves SPLIT K (wave w takes k-steps w, w+4, ...), partial tiles meet in LDS
+// and every thread finishes 8 adjacent outputs of one row: bias, GELU (u and h from one pass), GELU' * acc, or
+// acc + addend, stored as one 16- or 32-byte vector.
+//
+// Operands come straight from global memory (everything is L2 / MALL resident), one 16-byte load per MFMA operand:
+//   A [M,K] row-major: lane (i, kq) of v_mfma_f32_16x16x32_bf16 supplies A[row i][8kq .. 8kq+7].
+//   B as [N,K] (nn.Linear weight, forward):  the same for column j.
+//   B as [K,N] (the weight seen from the backward pass, dX = dY W): the 8 k-values of a lane live in 8 rows; the lane
+//     reads one dword = columns (2j, 2j+1) of each row and splits low / high halves into an even-column and an
+//     odd-column operand (v_perm_b32) -- no transposed copy of the weights, no LDS transpose.
+#include "common.h"
+#include "mobgt_hip.h"
+
+namespace {
+
+constexpr int BM = 32, BN = 64, KSTEP = 32, NW = 4;
+constexpr int LDP = BN + 4;                      // LDS row stride (floats): lanes of one store hit 2 x 32 distinct banks
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+enum { EPI_BIAS = 0, EPI_GELU = 1, EPI_GELU_BWD = 2, EPI_ADD = 3 };
+
+struct GemmParams {
+    const uint16_t* A; int64_t lda;
+    const uint16_t* B; int64_t ldb;
+    const uint16_t* bias;                        // [N] bf16 or null
+    void* C; int64_t ldc;                        // bf16, or f32 for EPI_ADD
+    const void* aux_in;                          // EPI_GELU_BWD: u [M,N] bf16 (ld = ldc); EPI_ADD: addend [M,N] f32 (ld = ldc)
+    uint16_t* aux_out;                           // EPI_GELU: h = gelu(u) [M,N] bf16 (ld = ldc)
+    int M, N, K;
+};
+
+__device__ __forceinline__ float gelu_f(float u) { return 0.5f * u * (1.f + erff(u * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_grad(float u) {
+    const float cdf = 0.5f * (1.f + erff(u * 0.70710678118654752f));
+    const float pdf = 0.3989422804014327f * __expf(-0.5f * u * u);
+    return cdf + u * pdf;
+}
+
+__device__ __forceinline__ void split_pairs(const uint32_t (&d)[8], bf16x8& even, bf16x8& odd) {
+    uint32_t e[4], o[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        e[j] = __builtin_amdgcn_perm(d[2 * j + 1], d[2 * j], 0x05040100u);
+        o[j] = __builtin_amdgcn_perm(d[2 * j + 1], d[2 * j], 0x07060302u);
+    }
+    even = __builtin_bit_cast(bf16x8, e);
+    odd = __builtin_bit_cast(bf16x8, o);
+}
+
+// one k-step's operands of one lane
+template <bool BKN> struct Frags;
+template <> struct Frags<false> {
+    uint4 a[2], b[4];
+    __device__ __forceinline__ void load(const GemmParams& p, const uint16_t* const (&ap)[2], const uint16_t* const (&bp)[4], int k) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) a[t] = *reinterpret_cast<const uint4*>(ap[t] + k);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) b[t] = *reinterpret_cast<const uint4*>(bp[t] + k);
+    }
+    __device__ __forceinline__ bf16x8 B(int t) const { return __builtin_bit_cast(bf16x8, b[t]); }
+};
+template <> struct Frags<true> {
+    uint4 a[2];
+    uint32_t b[2][8];
+    // bp[bb] points at B[8kq][n0 + 32bb + 2j]
+    __device__ __forceinline__ void load(const GemmParams& p, const uint16_t* const (&ap)[2], const uint16_t* const (&bp)[4], int k) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) a[t] = *reinterpret_cast<const uint4*>(ap[t] + k);
+#pragma unroll
+        for (int bb = 0; bb < 2; ++bb)
+#pragma unroll
+            for (int r = 0; r < 8; ++r) b[bb][r] = *reinterpret_cast<const uint32_t*>(bp[bb] + (int64_t)(k + r) * p.ldb);
+    }
+};
+
+template <bool BKN, int EPI>
+__global__ __launch_bounds__(NW * 64) void layer_gemm_kernel(const GemmParams p) {
+    __shared__ float part[NW][BM * LDP];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = lane & 15, kq = lane >> 4;
+    const int tiles_n = (p.N + BN - 1) / BN;
+    const int m0 = (blockIdx.x / tiles_n) * BM, n0 = (blockIdx.x % tiles_n) * BN;
+
+    // rows / columns past the edge are clamped for the loads (their products are never stored)
+    const uint16_t* ap[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) ap[t] = p.A + (int64_t)min(m0 + 16 * t + i, p.M - 1) * p.lda + 8 * kq;
+    const uint16_t* bp[4];
+    if (BKN) {
+#pragma unroll
+        for (int bb = 0; bb < 2; ++bb) bp[bb] = p.B + (int64_t)(8 * kq) * p.ldb + min(n0 + 32 * bb + 2 * i, p.N - 2);
+        bp[2] = bp[3] = nullptr;
+    } else {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) bp[t] = p.B + (int64_t)min(n0 + 16 * t + i, p.N - 1) * p.ldb + 8 * kq;
+    }
+
+    f32x4 acc[2][4];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    int k = wave * KSTEP;
+    Frags<BKN> cur, nxt;
+    if (k < p.K) cur.load(p, ap, bp, k);
+    for (; k < p.K; k += NW * KSTEP) {
+        const int kn = k + NW * KSTEP;
+        if (kn < p.K) nxt.load(p, ap, bp, kn);
+        bf16x8 bf[4];
+        if constexpr (BKN) {
+            split_pairs(cur.b[0], bf[0], bf[1]);
+            split_pairs(cur.b[1], bf[2], bf[3]);
+        } else {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) bf[t] = cur.B(t);
+        }
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            const bf16x8 af = __builtin_bit_cast(bf16x8, cur.a[a]);
+#pragma unroll
+            for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bf[b], acc[a][b], 0, 0, 0);
+        }
+        if (kn < p.K) cur = nxt;
+    }
+
+    // register v of lane (j = lane & 15, q = lane >> 4) is MFMA row 4q + v, column j.  B as [N,K]: operand b covers
+    // columns 16b + j.  B as [K,N]: operands (2bb, 2bb+1) are the even / odd columns 32bb + 2j (+1).
+    float* mine = part[wave];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int col = BKN ? 32 * (b >> 1) + 2 * i + (b & 1) : 16 * b + i;
+#pragma unroll
+            for (int v = 0; v < 4; ++v) mine[(16 * a + 4 * kq + v) * LDP + col] = acc[a][b][v];
+        }
+    __syncthreads();
+
+    const int r = threadIdx.x >> 3, c = (threadIdx.x & 7) * 8;
+    const int row = m0 + r, col = n0 + c;
+    if (row >= p.M || col >= p.N) return;
+    float s[8];
+    {
+        const float4 x0 = *reinterpret_cast<const float4*>(&part[0][r * LDP + c]);
+        const float4 x1 = *reinterpret_cast<const float4*>(&part[0][r * LDP + c + 4]);
+        s[0] = x0.x; s[1] = x0.y; s[2] = x0.z; s[3] = x0.w; s[4] = x1.x; s[5] = x1.y; s[6] = x1.z; s[7] = x1.w;
+    }
+    const int nw_used = min(NW, (p.K + KSTEP - 1) / KSTEP);
+    for (int w = 1; w < nw_used; ++w) {
+        const float4 x0 = *reinterpret_cast<const float4*>(&part[w][r * LDP + c]);
+        const float4 x1 = *reinterpret_cast<const float4*>(&part[w][r * LDP + c + 4]);
+        s[0] += x0.x; s[1] += x0.y; s[2] += x0.z; s[3] += x0.w; s[4] += x1.x; s[5] += x1.y; s[6] += x1.z; s[7] += x1.w;
+    }
+    if (p.bias) {
+        float bv[8];
+        load8(reinterpret_cast<const bf16_t*>(p.bias) + col, bv);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s[e] += bv[e];
+    }
+    const int64_t o = (int64_t)row * p.ldc + col;
+    if constexpr (EPI == EPI_BIAS) {
+        store8(reinterpret_cast<bf16_t*>(p.C) + o, s);
+    } else if constexpr (EPI == EPI_GELU) {
+        // h from the ROUNDED pre-activation, as a separate GELU launch reading the bf16 u would compute it
+        const bf16x8 u8 = pack8(s);
+        *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16_t*>(p.C) + o) = u8;
+        float h[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) h[e] = gelu_f((float)u8[e]);
+        store8(reinterpret_cast<bf16_t*>(p.aux_out) + o, h);
+    } else if constexpr (EPI == EPI_GELU_BWD) {
+        float u[8];
+        load8(reinterpret_cast<const bf16_t*>(p.aux_in) + o, u);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s[e] *= gelu_grad(u[e]);
+        store8(reinterpret_cast<bf16_t*>(p.C) + o, s);
+    } else {
+        float t[8];
+        load8(reinterpret_cast<const float*>(p.aux_in) + o, t);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s[e] += t[e];
+        store8(reinterpret_cast<float*>(p.C) + o, s);
+    }
+}
+
+template <bool BKN>
+int launch(const GemmParams& p, int epilogue, hipStream_t st) {
+    const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
+    const dim3 grid(tiles), block(NW * 64);
+    switch (epilogue) {
+        case EPI_BIAS: hipLaunchKernelGGL((layer_gemm_kernel<BKN, EPI_BIAS>), grid, block, 0, st, p); break;
+        case EPI_GELU: hipLaunchKernelGGL((layer_gemm_kernel<BKN, EPI_GELU>), grid, block, 0, st, p); break;
+        case EPI_GELU_BWD: hipLaunchKernelGGL((layer_gemm_kernel<BKN, EPI_GELU_BWD>), grid, block, 0, st, p); break;
+        case EPI_ADD: hipLaunchKernelGGL((layer_gemm_kernel<BKN, EPI_ADD>), grid, block, 0, st, p); break;
+        default: return MOBGT_EBADDIM;
+    }
+    return (int)hipGetLastError();
+}
+
+}  // namespace
+
+extern "C" int mobgt_layer_gemm(const void* a, int64_t lda, const void* b, int64_t ldb, int b_is_kn, const void* bias,
+                                void* c, int64_t ldc, int epilogue, const void* aux_in, void* aux_out, int M, int N, int K,
+                                void* stream) {
+    if (M <= 0 || N <= 0 || K <= 0 || (K % KSTEP) || (N & 7) || (lda & 7) || (ldc & 7)) return MOBGT_EBADDIM;
+    if (b_is_kn ? (ldb & 1) : (ldb & 7)) return MOBGT_EBADDIM;
+    if (((uintptr_t)a | (uintptr_t)c | (uintptr_t)bias | (uintptr_t)aux_in | (uintptr_t)aux_out) & 15) return MOBGT_EALIGN;
+    if ((uintptr_t)b & (b_is_kn ? 3 : 15)) return MOBGT_EALIGN;
+    if (epilogue == EPI_GELU && !aux_out) return MOBGT_EBADDIM;
+    if ((epilogue == EPI_GELU_BWD || epilogue == EPI_ADD) && !aux_in) return MOBGT_EBADDIM;
+    GemmParams p = {reinterpret_cast<const uint16_t*>(a), lda, reinterpret_cast<const uint16_t*>(b), ldb,
+                    reinterpret_cast<const uint16_t*>(bias), c, ldc, aux_in, reinterpret_cast<uint16_t*>(aux_out), M, N, K};
+    return b_is_kn ? launch<true>(p, epilogue, (hipStream_t)stream) : launch<false>(p, epilogue, (hipStream_t)stream);
+}

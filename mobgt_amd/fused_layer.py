@@ -123,6 +123,8 @@ def _mm_tn_f32(g, x):
 
 
 _ADDMM_OUT_DTYPE = [None]
+import os as _os
+_OWN_GEMM = [_os.environ.get("MOBGT_LIBRARY_GEMM") != "1"]     # MOBGT_LIBRARY_GEMM=1: the layer's GEMMs through torch (A/B runs)
 
 
 def _addmm_f32(c, a, b, inplace=False):
@@ -194,17 +196,29 @@ class _FusedLayerFn(torch.autograd.Function):
                 xa = xa_pre.view(R, C)                             # written by the previous layer's LayerNorm kernel
             else:
                 xa = x.view(R, C).to(A)
-        qkv = torch.addmm(s_bqkv, xa, s_wqkv.t()).view(G, T, 3 * C)
+        # bf16 configuration at MobGT's sizes: the split-K MFMA kernel of csrc/gemm.hip (GELU fused after FFN layer 1);
+        # otherwise the library
+        own = _OWN_GEMM[0] and ops.layer_gemm_ok(xa, s_wqkv) and ops.layer_gemm_ok(xa, s_w1) and C % 32 == 0 \
+            and s_w1.shape[0] % 32 == 0
+        ctx.own_gemm = own
+        if own:
+            qkv = ops.layer_gemm(xa, s_wqkv, s_bqkv).view(G, T, 3 * C)
+        else:
+            qkv = torch.addmm(s_bqkv, xa, s_wqkv.t()).view(G, T, 3 * C)
         q, k, v = qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:]
         a, lse = ops._attn_fwd(q, k, v, cfg.pack, cfg.scale, cfg.p_att, seed ^ (salt * 0x9E3779B1), sd)
-        y = torch.addmm(s_bo, a.view(R, C), s_wo.t())
+        y = ops.layer_gemm(a.view(R, C), s_wo, s_bo) if own else torch.addmm(s_bo, a.view(R, C), s_wo.t())
         x1 = torch.empty(R, C, **f32)
         z = torch.empty(R, C, dtype=A, device=dev)
         _k1_fwd(x, y, x1, n1w, n1b, z, None, stats[2], stats[3], R, C, cfg.p, seed, sd, salt + 1, act)
-        u = torch.addmm(s_b1, z, s_w1.t())
-        h = torch.empty_like(u)
-        check(_lib.lib().mobgt_gelu_fwd(_p(u), _p(h), u.numel(), act, _stream()), "mobgt_gelu_fwd")
-        f = torch.addmm(s_b2, h, s_w2.t())
+        if own:
+            u, h = ops.layer_gemm(z, s_w1, s_b1, epilogue=ops.GEMM_GELU)
+            f = ops.layer_gemm(h, s_w2, s_b2)
+        else:
+            u = torch.addmm(s_b1, z, s_w1.t())
+            h = torch.empty_like(u)
+            check(_lib.lib().mobgt_gelu_fwd(_p(u), _p(h), u.numel(), act, _stream()), "mobgt_gelu_fwd")
+            f = torch.addmm(s_b2, h, s_w2.t())
         x2 = torch.empty(R, C, **f32)
         if stock:                                                     # x = x + dropout(ffn(...))  (model.py:485-488)
             _k1_fwd(x1, f, x2, None, None, None, None, None, None, R, C, cfg.p, seed, sd, salt + 2, act)
@@ -258,20 +272,24 @@ class _FusedLayerFn(torch.autograd.Function):
             dx2 = torch.empty(R, C, dtype=torch.float32, device=dev)  # through ffn_norm2
             _k1_bwd(None, dout, None, x2, stats[4], stats[5], nxw, dx2, df, dnxw, dnxb, db2, R, C, cfg.p, seed, sd,
                     salt + 2, act)
-        dh = df @ s_w2
+        own = ctx.own_gemm
         wb = _WgradBatch()
         k_qkv, k_wo, k_w1, k_w2 = ctx.sinks                          # gradient sinks (or None)
         dw2 = wb.add(df, h, sink=k_w2)
-        du = torch.empty_like(u)
         db1_in_wgrad = _wgrad_hip(A, F, C, R)                         # then b1's gradient rides on the dW1 kernel
-        check(_lib.lib().mobgt_gelu_bwd_colsum(_p(dh), _p(u), _p(du), _p(None if db1_in_wgrad else db1), R, F, act,
-                                               _stream()), "mobgt_gelu_bwd_colsum")
-        dz = du @ s_w1
+        if own and db1_in_wgrad:
+            du = ops.layer_gemm(df, s_w2, None, True, ops.GEMM_GELU_BWD, aux_in=u)      # (df W2) * gelu'(u), one launch
+        else:
+            dh = df @ s_w2
+            du = torch.empty_like(u)
+            check(_lib.lib().mobgt_gelu_bwd_colsum(_p(dh), _p(u), _p(du), _p(None if db1_in_wgrad else db1), R, F, act,
+                                                   _stream()), "mobgt_gelu_bwd_colsum")
+        dz = ops.layer_gemm(du, s_w1, None, True) if own else du @ s_w1
         dw1 = wb.add(du, z, db=db1 if db1_in_wgrad else None, sink=k_w1)
         dx1 = torch.empty(R, C, dtype=torch.float32, device=dev)
         dy = torch.empty(R, C, dtype=A, device=dev)
         _k1_bwd(dz, None, dx2, x1, stats[2], stats[3], n1w, dx1, dy, dn1w, dn1b, dbo, R, C, cfg.p, seed, sd, salt + 1, act)
-        da = (dy @ s_wo).view(G, T, C)
+        da = (ops.layer_gemm(dy, s_wo, None, True) if own else dy @ s_wo).view(G, T, C)
         dwo = wb.add(dy, a.view(R, C), sink=k_wo)
         dqkv = torch.empty(G, T, 3 * C, dtype=A, device=dev)
         q, k, v = qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:]
@@ -281,12 +299,14 @@ class _FusedLayerFn(torch.autograd.Function):
         dwqkv = wb.add(dqkv2, xa, db=dbqkv, sink=k_qkv)
         wb.flush()
         if stock:                                                     # back through self_attention_norm
-            dz0 = dqkv2 @ s_wqkv
+            dz0 = ops.layer_gemm(dqkv2, s_wqkv, None, True) if own else dqkv2 @ s_wqkv
             dx = torch.empty(R, C, dtype=torch.float32, device=dev)
             _k1_bwd(dz0, None, dx1, x.view(R, C), stats[0], stats[1], nxw, dx, None, dnxw, dnxb, None, R, C, 0.0, seed, sd,
                     salt, act)
         elif A == torch.float32:                                      # dx1 is this function's own buffer: accumulate onto it
             dx = torch.addmm(dx1, dqkv2, s_wqkv, out=dx1)
+        elif own:
+            dx = ops.layer_gemm(dqkv2, s_wqkv, None, True, ops.GEMM_ADD, aux_in=dx1)     # dx1 + dqkv Wqkv, f32, in place
         else:
             dx = _addmm_f32(dx1, dqkv2, s_wqkv, inplace=True)
         return (dx.view(G, T, C), None, None, None, None, dwqkv[:C], dbqkv[:C], dwqkv[C:2 * C], dbqkv[C:2 * C], dwqkv[2 * C:],

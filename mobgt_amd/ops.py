@@ -879,6 +879,49 @@ def assemble_tokens(nf, real, add, token, pe0, p_pos, p_in, training, salts=(0x1
                                    float(p_in), int(seed), seed_dev, tuple(int(s) & 0xFFFFFFFF for s in salts))
 
 
+# ------------------------------------------------------------------- the encoder layer's small GEMMs
+GEMM_BIAS, GEMM_GELU, GEMM_GELU_BWD, GEMM_ADD = 0, 1, 2, 3
+
+
+def layer_gemm_ok(a, b, b_is_kn=False):
+    """Shapes / layouts mobgt_layer_gemm takes: bf16, row-major, K % 32 == 0, N % 8 == 0, rows of at most 64 k elements
+    of work per CU-filling launch (the library's big-tile kernels win on large M)."""
+    if a.dtype != torch.bfloat16 or b.dtype != torch.bfloat16 or a.dim() != 2 or b.dim() != 2:
+        return False
+    M, K = a.shape
+    N = b.shape[1] if b_is_kn else b.shape[0]
+    if (b.shape[0] if b_is_kn else b.shape[1]) != K:
+        return False
+    return (K % 32 == 0 and N % 8 == 0 and a.stride(1) == 1 and b.stride(1) == 1 and a.stride(0) % 8 == 0
+            and b.stride(0) % (2 if b_is_kn else 8) == 0 and a.data_ptr() % 16 == 0 and b.data_ptr() % 16 == 0
+            and M <= 4096)
+
+
+def layer_gemm(a, b, bias=None, b_is_kn=False, epilogue=GEMM_BIAS, aux_in=None):
+    """acc = a @ (b if b_is_kn else b.T) (+ bias) with the epilogues of mobgt_layer_gemm (include/mobgt_hip.h):
+    GEMM_BIAS -> C bf16;  GEMM_GELU -> (u, gelu(u)) bf16;  GEMM_GELU_BWD -> acc * gelu'(aux_in) bf16;
+    GEMM_ADD -> acc + aux_in, f32, written IN PLACE into aux_in.  No autograd: the fused layer calls it both ways."""
+    _require_cuda(a, b)
+    M, K = a.shape
+    N = b.shape[1] if b_is_kn else b.shape[0]
+    dev = a.device
+    aux_out = None
+    if epilogue == GEMM_ADD:
+        assert aux_in.dtype == torch.float32 and aux_in.shape == (M, N) and aux_in.is_contiguous()
+        c = aux_in
+    else:
+        c = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+        if epilogue == GEMM_GELU:
+            aux_out = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+        elif epilogue == GEMM_GELU_BWD:
+            assert aux_in.dtype == torch.bfloat16 and aux_in.shape == (M, N) and aux_in.is_contiguous()
+    if bias is not None:
+        assert bias.dtype == torch.bfloat16 and bias.numel() == N and bias.is_contiguous()
+    check(_lib.lib().mobgt_layer_gemm(_p(a), a.stride(0), _p(b), b.stride(0), int(b_is_kn), _p(bias), _p(c), N, epilogue,
+                                      _p(aux_in), _p(aux_out), M, N, K, _stream()), "mobgt_layer_gemm")
+    return (c, aux_out) if epilogue == GEMM_GELU else c
+
+
 # ------------------------------------------------------------------------------ debug: NaN tracer
 _NAN_TRACE = {"flags": None, "names": [], "on": False}
 

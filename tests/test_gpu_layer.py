@@ -279,3 +279,37 @@ def test_bias_act_matches_torch_chain(p_drop, has_bias):
     if has_bias:
         np.testing.assert_allclose(bb.grad.cpu().numpy(), ba.grad.cpu().numpy(), rtol=1e-4, atol=1e-4)
     ops.set_dropout_state(None, None)
+
+
+@pytest.mark.parametrize("M,N,K", [(608, 576, 192), (608, 192, 1024), (37, 1024, 192), (608, 192, 576), (16, 8, 32)])
+def test_layer_gemm_epilogues_match_torch(M, N, K):
+    """mobgt_layer_gemm, both weight orientations and all four epilogues, against f64 products of the same bf16 operands
+    (tolerance: bf16 rounding of the result, 2^-8 relative)."""
+    from mobgt_amd import ops
+    gen = torch.Generator().manual_seed(M + N + K)
+    a = (torch.randn(M + 3, K, generator=gen) / K ** 0.5).to(DEV).bfloat16()[:M]
+    w_nk = torch.randn(N, K, generator=gen).to(DEV).bfloat16()
+    w_kn = torch.randn(K, N, generator=gen).to(DEV).bfloat16()
+    bias = torch.randn(N, generator=gen).to(DEV).bfloat16()
+    tol = dict(rtol=1e-2, atol=1e-2)
+    for kn, w in ((False, w_nk), (True, w_kn)):
+        assert ops.layer_gemm_ok(a, w, kn)
+        acc = a.double() @ (w.double() if kn else w.double().t())
+        ref = acc + bias.double()
+        c = ops.layer_gemm(a, w, bias, kn)
+        np.testing.assert_allclose(c.float().cpu().numpy(), ref.float().cpu().numpy(), **tol)
+        c0 = ops.layer_gemm(a, w, None, kn)
+        np.testing.assert_allclose(c0.float().cpu().numpy(), acc.float().cpu().numpy(), **tol)
+        u, h = ops.layer_gemm(a, w, bias, kn, ops.GEMM_GELU)
+        assert torch.equal(u, c)
+        assert torch.equal(h, torch.nn.functional.gelu(u.float()).bfloat16()) or \
+            (h.float() - torch.nn.functional.gelu(u.float())).abs().max() < 2e-2
+        du = ops.layer_gemm(a, w, None, kn, ops.GEMM_GELU_BWD, aux_in=u)
+        ud = u.double().requires_grad_(True)
+        torch.nn.functional.gelu(ud).backward(acc)
+        np.testing.assert_allclose(du.float().cpu().numpy(), ud.grad.float().cpu().numpy(), **tol)
+        addend = torch.randn(M, N, generator=gen).to(DEV)
+        want = addend.double() + acc
+        got = ops.layer_gemm(a, w, None, kn, ops.GEMM_ADD, aux_in=addend)
+        assert got.data_ptr() == addend.data_ptr()
+        np.testing.assert_allclose(got.cpu().numpy(), want.float().cpu().numpy(), rtol=1e-4, atol=1e-4)
