@@ -212,6 +212,15 @@ int mobgt_embed_gather_sum(const float* const* tables_host, const void* const* i
 int mobgt_embed_scatter_add(float* const* d_tables_host, const void* const* idx_host, const int64_t* skip_idx_host,
                             int n_tables, const float* dout, int64_t R, int C, int64_t ld_dout,
                             int idx_dtype, void* stream);
+/* Concatenation instead of the sum (`torch.cat((poi_embed, time_embed), -1)` of FuseEmbeddings,
+ * model_fqandtoyo.py:1262-1268, on gathered rows): out[r, off_t : off_t + widths[t]] = table_t[idx_t[r], :] with
+ * off_t = widths[0] + .. + widths[t-1] (zeros where idx < 0); widths multiples of 4, sum <= ld_out.  The scatter adds
+ * dout's column blocks back into the tables (atomics; rows equal to skip_idx[t] or negative are skipped). */
+int mobgt_embed_gather_concat(const float* const* tables, const void* const* indices, const int* widths, int n_tables,
+                              float* out, int64_t R, int64_t ld_out, int idx_dtype, void* stream);
+int mobgt_embed_scatter_concat(float* const* d_tables, const void* const* indices, const int64_t* skip_idx,
+                               const int* widths, int n_tables, const float* dout, int64_t R, int64_t ld_dout,
+                               int idx_dtype, void* stream);
 /* Every row index the node-feature gathers of model_fqandtoyo.py:1259-1264 (POI / time-slot / category),
  * :1287-1298 + :348-351 (positional rows 1..n) need, derived from the padded batch in one launch.
  *   x [G,N] POI ids (0 = pad; x_dtype MOBGT_I64 / I32) and time_normal [G,N] f32, both with element strides (g, n);
@@ -302,11 +311,12 @@ int mobgt_linear_wgrad_group(int n, const void* const* g, const int64_t* ldg, co
 
 /* Token assembly at the encoder input (model_fqandtoyo.py:1287-1298, 348-358, 1338-1347) in one launch:
  *   out[g,0,:] = drop_in(drop_pos(token + pe0));  out[g,1+n,:] = drop_in(drop_pos(nf[g,n,:] * real[g,n] + add[g,n,:]))
- * nf, add [G,N,C], real [G,N], token, pe0 [C], out [G,N+1,C], all f32; p_pos / p_in the two dropout probabilities
- * (0 = off), masks from the library's counter hash with the given salts (row numbering g*N+n / g / g*T+t).
+ * nf, add [G,N,C], real [G,N], token, pe0 [C], out [G,N+1,C], all f32 (out_bf16: optional bf16 copy of out, the
+ * first layer's GEMM operand, or NULL); p_pos / p_in the two dropout probabilities (0 = off), masks from the library's
+ * counter hash with the given salts (row numbering g*N+n / g / g*T+t).
  * Backward: d_nf, d_add [G,N,C] overwritten; d_token [C] ACCUMULATED (sum over graphs; zero it first). */
 int mobgt_assemble_tokens_fwd(const float* nf, const float* real, const float* add, const float* token, const float* pe0,
-                              float* out, int G, int N, int C, float p_pos, float p_in, uint64_t seed,
+                              float* out, void* out_bf16, int G, int N, int C, float p_pos, float p_in, uint64_t seed,
                               const uint64_t* seed_dev, uint32_t salt_nf, uint32_t salt_tok, uint32_t salt_in, void* stream);
 int mobgt_assemble_tokens_bwd(const float* dout, const float* real, float* d_nf, float* d_add, float* d_token, int G, int N,
                               int C, float p_pos, float p_in, uint64_t seed, const uint64_t* seed_dev, uint32_t salt_nf,

@@ -45,12 +45,14 @@ SIGNATURES = {
     "mobgt_linear_wgrad": (_i, [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _i, _i, _i, _vp]),
     "mobgt_embed_gather_sum": (_i, [_vp, _vp, _i, _vp, _i64, _i, _i64, _i, _vp]),
     "mobgt_embed_scatter_add": (_i, [_vp, _vp, _vp, _i, _vp, _i64, _i, _i64, _i, _vp]),
+    "mobgt_embed_gather_concat": (_i, [_vp, _vp, _vp, _i, _vp, _i64, _i64, _i, _vp]),
+    "mobgt_embed_scatter_concat": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _i64, _i64, _i, _vp]),
     "mobgt_hop_table_fwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "mobgt_hop_table_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "mobgt_target_rank": (_i, [_vp, _vp, _vp, _i64, _i64, _vp]),
     "mobgt_skinny_linear_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "mobgt_skinny_linear_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
-    "mobgt_assemble_tokens_fwd": (_i, [_vp] * 6 + [_i, _i, _i, _f, _f, _u64, _vp, _c.c_uint32, _c.c_uint32, _c.c_uint32, _vp]),
+    "mobgt_assemble_tokens_fwd": (_i, [_vp] * 7 + [_i, _i, _i, _f, _f, _u64, _vp, _c.c_uint32, _c.c_uint32, _c.c_uint32, _vp]),
     "mobgt_assemble_tokens_bwd": (_i, [_vp] * 5 + [_i, _i, _i, _f, _f, _u64, _vp, _c.c_uint32, _c.c_uint32, _c.c_uint32, _vp]),
     "mobgt_bias_act_fwd": (_i, [_vp, _vp, _vp, _i64, _i, _f, _f, _u64, _vp, _c.c_uint32, _vp]),
     "mobgt_bias_act_bwd": (_i, [_vp, _vp, _vp, _vp, _i64, _i, _f, _f, _u64, _vp, _c.c_uint32, _vp]),

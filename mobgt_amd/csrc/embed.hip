@@ -57,6 +57,43 @@ __global__ __launch_bounds__(256) void scatter_add_kernel(const EmbedParams p) {
     }
 }
 
+// Concatenation instead of the sum: out[r, off_t : off_t + W_t] = table_t[idx_t[r], :] (zeros where idx < 0), and the
+// matching scatter -- `[poi ; time]` of model_fqandtoyo.py:1262-1268 in one launch each way.
+struct ConcatParams {
+    const float* tables[MAXT];
+    float* d_tables[MAXT];
+    const void* idx[MAXT];
+    int64_t skip[MAXT];
+    int width[MAXT], coff[MAXT];
+    int n_tables;
+    float* out;
+    const float* dout;
+    int64_t R, ld;
+};
+
+template <typename TI, bool BWD>
+__global__ __launch_bounds__(256) void gather_concat_kernel(const ConcatParams p) {
+    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= p.R) return;
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int t = 0; t < MAXT; ++t) {
+        if (t >= p.n_tables) break;
+        const int64_t row = (int64_t)reinterpret_cast<const TI*>(p.idx[t])[r];
+        const int W = p.width[t];
+        if (!BWD) {
+            for (int c = lane * 4; c < W; c += 256) {
+                const float4 v = row >= 0 ? *reinterpret_cast<const float4*>(p.tables[t] + row * W + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+                *reinterpret_cast<float4*>(p.out + r * p.ld + p.coff[t] + c) = v;
+            }
+        } else {
+            if (row < 0 || row == p.skip[t]) continue;
+            float* dst = p.d_tables[t] + row * W;
+            for (int c = lane; c < W; c += 64) atomicAdd(dst + c, p.dout[r * p.ld + p.coff[t] + c]);
+        }
+    }
+}
+
 // Run-length variant (C <= 512): a wave walks RUN_ROWS consecutive rows and keeps the sum of a run of EQUAL indices
 // in registers, flushing with atomics only when the index changes.  Along a trajectory the degree rows (and the
 // shared frequency row) repeat for long stretches: at G*N = 12.5 k rows the plain kernel spent 120 us per call
@@ -217,6 +254,53 @@ extern "C" int mobgt_node_index(const void* x, int x_dtype, int64_t xs_g, int64_
                          rows_only};
     hipLaunchKernelGGL(node_index_kernel, dim3(G), dim3(256), 0, (hipStream_t)stream, p);
     return (int)hipGetLastError();
+}
+
+namespace {
+template <bool BWD>
+int launch_concat(const ConcatParams& p, int idx_dtype, hipStream_t st) {
+    const dim3 grid((unsigned)((p.R + 3) / 4)), block(256);
+    if (idx_dtype == MOBGT_I64) hipLaunchKernelGGL((gather_concat_kernel<int64_t, BWD>), grid, block, 0, st, p);
+    else if (idx_dtype == MOBGT_I32) hipLaunchKernelGGL((gather_concat_kernel<int32_t, BWD>), grid, block, 0, st, p);
+    else if (idx_dtype == MOBGT_I16) hipLaunchKernelGGL((gather_concat_kernel<int16_t, BWD>), grid, block, 0, st, p);
+    else return MOBGT_EDTYPE;
+    return (int)hipGetLastError();
+}
+int fill_concat(ConcatParams& p, const void* const* idx_host, const int* widths, int n_tables, int64_t R, int64_t ld) {
+    if (n_tables < 1 || n_tables > MAXT || ld % 4 != 0) return MOBGT_EBADDIM;
+    int off = 0;
+    for (int t = 0; t < n_tables; ++t) {
+        if (widths[t] <= 0 || widths[t] % 4 != 0) return MOBGT_EBADDIM;
+        p.idx[t] = idx_host[t]; p.width[t] = widths[t]; p.coff[t] = off;
+        off += widths[t];
+    }
+    if (off > ld) return MOBGT_EBADDIM;
+    p.n_tables = n_tables; p.R = R; p.ld = ld;
+    return 0;
+}
+}  // namespace
+
+extern "C" int mobgt_embed_gather_concat(const float* const* tables_host, const void* const* idx_host, const int* widths_host,
+                                         int n_tables, float* out, int64_t R, int64_t ld_out, int idx_dtype, void* stream) {
+    ConcatParams p = {};
+    const int rc = fill_concat(p, idx_host, widths_host, n_tables, R, ld_out);
+    if (rc) return rc;
+    if (R <= 0) return 0;
+    for (int t = 0; t < n_tables; ++t) p.tables[t] = tables_host[t];
+    p.out = out;
+    return launch_concat<false>(p, idx_dtype, (hipStream_t)stream);
+}
+
+extern "C" int mobgt_embed_scatter_concat(float* const* d_tables_host, const void* const* idx_host, const int64_t* skip_idx_host,
+                                          const int* widths_host, int n_tables, const float* dout, int64_t R, int64_t ld_dout,
+                                          int idx_dtype, void* stream) {
+    ConcatParams p = {};
+    const int rc = fill_concat(p, idx_host, widths_host, n_tables, R, ld_dout);
+    if (rc) return rc;
+    if (R <= 0) return 0;
+    for (int t = 0; t < n_tables; ++t) { p.d_tables[t] = d_tables_host[t]; p.skip[t] = skip_idx_host ? skip_idx_host[t] : -1; }
+    p.dout = dout;
+    return launch_concat<true>(p, idx_dtype, (hipStream_t)stream);
 }
 
 // ---- evaluation: rank of the target class in each row of the logits --------------------------------------

@@ -21,8 +21,9 @@
 
 namespace {
 
-constexpr int BM = 32, BN = 64, KSTEP = 32, NW = 4;
-constexpr int LDP = BN + 4;                      // LDS row stride (floats): lanes of one store hit 2 x 32 distinct banks
+constexpr int BM = 32, KSTEP = 32;
+// Two tilings: 32x64 outputs / 4 waves, and -- long K, narrow N (FFN layer 2 and its data gradient: 57 tiles of the
+// first kind, 8 serial k-steps per wave) -- 32x32 outputs / 8 waves.  NB = number of 16-column MFMA operands.
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
 enum { EPI_BIAS = 0, EPI_GELU = 1, EPI_GELU_BWD = 2, EPI_ADD = 3 };
@@ -56,33 +57,35 @@ __device__ __forceinline__ void split_pairs(const uint32_t (&d)[8], bf16x8& even
 }
 
 // one k-step's operands of one lane
-template <bool BKN> struct Frags;
-template <> struct Frags<false> {
-    uint4 a[2], b[4];
-    __device__ __forceinline__ void load(const GemmParams& p, const uint16_t* const (&ap)[2], const uint16_t* const (&bp)[4], int k) {
+template <bool BKN, int NB> struct Frags;
+template <int NB> struct Frags<false, NB> {
+    uint4 a[2], b[NB];
+    __device__ __forceinline__ void load(const GemmParams& p, const uint16_t* const (&ap)[2], const uint16_t* const (&bp)[NB], int k) {
 #pragma unroll
         for (int t = 0; t < 2; ++t) a[t] = *reinterpret_cast<const uint4*>(ap[t] + k);
 #pragma unroll
-        for (int t = 0; t < 4; ++t) b[t] = *reinterpret_cast<const uint4*>(bp[t] + k);
+        for (int t = 0; t < NB; ++t) b[t] = *reinterpret_cast<const uint4*>(bp[t] + k);
     }
     __device__ __forceinline__ bf16x8 B(int t) const { return __builtin_bit_cast(bf16x8, b[t]); }
 };
-template <> struct Frags<true> {
+template <int NB> struct Frags<true, NB> {
     uint4 a[2];
-    uint32_t b[2][8];
+    uint32_t b[NB / 2][8];
     // bp[bb] points at B[8kq][n0 + 32bb + 2j]
-    __device__ __forceinline__ void load(const GemmParams& p, const uint16_t* const (&ap)[2], const uint16_t* const (&bp)[4], int k) {
+    __device__ __forceinline__ void load(const GemmParams& p, const uint16_t* const (&ap)[2], const uint16_t* const (&bp)[NB], int k) {
 #pragma unroll
         for (int t = 0; t < 2; ++t) a[t] = *reinterpret_cast<const uint4*>(ap[t] + k);
 #pragma unroll
-        for (int bb = 0; bb < 2; ++bb)
+        for (int bb = 0; bb < NB / 2; ++bb)
 #pragma unroll
             for (int r = 0; r < 8; ++r) b[bb][r] = *reinterpret_cast<const uint32_t*>(bp[bb] + (int64_t)(k + r) * p.ldb);
     }
 };
 
-template <bool BKN, int EPI>
+template <bool BKN, int EPI, int NB, int NW>
 __global__ __launch_bounds__(NW * 64) void layer_gemm_kernel(const GemmParams p) {
+    constexpr int BN = 16 * NB;
+    constexpr int LDP = BN + 4;                  // LDS row stride (floats): the lanes of one store spread over all banks
     __shared__ float part[NW][BM * LDP];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i = lane & 15, kq = lane >> 4;
@@ -93,41 +96,41 @@ __global__ __launch_bounds__(NW * 64) void layer_gemm_kernel(const GemmParams p)
     const uint16_t* ap[2];
 #pragma unroll
     for (int t = 0; t < 2; ++t) ap[t] = p.A + (int64_t)min(m0 + 16 * t + i, p.M - 1) * p.lda + 8 * kq;
-    const uint16_t* bp[4];
+    const uint16_t* bp[NB];
     if (BKN) {
 #pragma unroll
-        for (int bb = 0; bb < 2; ++bb) bp[bb] = p.B + (int64_t)(8 * kq) * p.ldb + min(n0 + 32 * bb + 2 * i, p.N - 2);
-        bp[2] = bp[3] = nullptr;
+        for (int bb = 0; bb < NB; ++bb)
+            bp[bb] = bb < NB / 2 ? p.B + (int64_t)(8 * kq) * p.ldb + min(n0 + 32 * bb + 2 * i, p.N - 2) : nullptr;
     } else {
 #pragma unroll
-        for (int t = 0; t < 4; ++t) bp[t] = p.B + (int64_t)min(n0 + 16 * t + i, p.N - 1) * p.ldb + 8 * kq;
+        for (int t = 0; t < NB; ++t) bp[t] = p.B + (int64_t)min(n0 + 16 * t + i, p.N - 1) * p.ldb + 8 * kq;
     }
 
-    f32x4 acc[2][4];
+    f32x4 acc[2][NB];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int b = 0; b < NB; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     int k = wave * KSTEP;
-    Frags<BKN> cur, nxt;
+    Frags<BKN, NB> cur, nxt;
     if (k < p.K) cur.load(p, ap, bp, k);
     for (; k < p.K; k += NW * KSTEP) {
         const int kn = k + NW * KSTEP;
         if (kn < p.K) nxt.load(p, ap, bp, kn);
-        bf16x8 bf[4];
+        bf16x8 bf[NB];
         if constexpr (BKN) {
-            split_pairs(cur.b[0], bf[0], bf[1]);
-            split_pairs(cur.b[1], bf[2], bf[3]);
+#pragma unroll
+            for (int bb = 0; bb < NB / 2; ++bb) split_pairs(cur.b[bb], bf[2 * bb], bf[2 * bb + 1]);
         } else {
 #pragma unroll
-            for (int t = 0; t < 4; ++t) bf[t] = cur.B(t);
+            for (int t = 0; t < NB; ++t) bf[t] = cur.B(t);
         }
 #pragma unroll
         for (int a = 0; a < 2; ++a) {
             const bf16x8 af = __builtin_bit_cast(bf16x8, cur.a[a]);
 #pragma unroll
-            for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bf[b], acc[a][b], 0, 0, 0);
+            for (int b = 0; b < NB; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bf[b], acc[a][b], 0, 0, 0);
         }
         if (kn < p.K) cur = nxt;
     }
@@ -138,14 +141,16 @@ __global__ __launch_bounds__(NW * 64) void layer_gemm_kernel(const GemmParams p)
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int b = 0; b < 4; ++b) {
+        for (int b = 0; b < NB; ++b) {
             const int col = BKN ? 32 * (b >> 1) + 2 * i + (b & 1) : 16 * b + i;
 #pragma unroll
             for (int v = 0; v < 4; ++v) mine[(16 * a + 4 * kq + v) * LDP + col] = acc[a][b][v];
         }
     __syncthreads();
 
-    const int r = threadIdx.x >> 3, c = (threadIdx.x & 7) * 8;
+    constexpr int TPR = BN / 8;                  // threads per output row, 8 adjacent columns each
+    if (threadIdx.x >= BM * TPR) return;
+    const int r = threadIdx.x / TPR, c = (threadIdx.x % TPR) * 8;
     const int row = m0 + r, col = n0 + c;
     if (row >= p.M || col >= p.N) return;
     float s[8];
@@ -192,15 +197,15 @@ __global__ __launch_bounds__(NW * 64) void layer_gemm_kernel(const GemmParams p)
     }
 }
 
-template <bool BKN>
+template <bool BKN, int NB, int NW>
 int launch(const GemmParams& p, int epilogue, hipStream_t st) {
-    const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
+    const int tiles = ((p.M + BM - 1) / BM) * ((p.N + 16 * NB - 1) / (16 * NB));
     const dim3 grid(tiles), block(NW * 64);
     switch (epilogue) {
-        case EPI_BIAS: hipLaunchKernelGGL((layer_gemm_kernel<BKN, EPI_BIAS>), grid, block, 0, st, p); break;
-        case EPI_GELU: hipLaunchKernelGGL((layer_gemm_kernel<BKN, EPI_GELU>), grid, block, 0, st, p); break;
-        case EPI_GELU_BWD: hipLaunchKernelGGL((layer_gemm_kernel<BKN, EPI_GELU_BWD>), grid, block, 0, st, p); break;
-        case EPI_ADD: hipLaunchKernelGGL((layer_gemm_kernel<BKN, EPI_ADD>), grid, block, 0, st, p); break;
+        case EPI_BIAS: hipLaunchKernelGGL((layer_gemm_kernel<BKN, EPI_BIAS, NB, NW>), grid, block, 0, st, p); break;
+        case EPI_GELU: hipLaunchKernelGGL((layer_gemm_kernel<BKN, EPI_GELU, NB, NW>), grid, block, 0, st, p); break;
+        case EPI_GELU_BWD: hipLaunchKernelGGL((layer_gemm_kernel<BKN, EPI_GELU_BWD, NB, NW>), grid, block, 0, st, p); break;
+        case EPI_ADD: hipLaunchKernelGGL((layer_gemm_kernel<BKN, EPI_ADD, NB, NW>), grid, block, 0, st, p); break;
         default: return MOBGT_EBADDIM;
     }
     return (int)hipGetLastError();
@@ -219,5 +224,10 @@ extern "C" int mobgt_layer_gemm(const void* a, int64_t lda, const void* b, int64
     if ((epilogue == EPI_GELU_BWD || epilogue == EPI_ADD) && !aux_in) return MOBGT_EBADDIM;
     GemmParams p = {reinterpret_cast<const uint16_t*>(a), lda, reinterpret_cast<const uint16_t*>(b), ldb,
                     reinterpret_cast<const uint16_t*>(bias), c, ldc, aux_in, reinterpret_cast<uint16_t*>(aux_out), M, N, K};
-    return b_is_kn ? launch<true>(p, epilogue, (hipStream_t)stream) : launch<false>(p, epilogue, (hipStream_t)stream);
+    // few 32x64 tiles AND a long K: narrower tiles, twice the waves on K
+    const int tiles64 = ((M + BM - 1) / BM) * ((N + 63) / 64);
+    const bool narrow = K >= 512 && tiles64 < 128;
+    hipStream_t st = (hipStream_t)stream;
+    if (narrow) return b_is_kn ? launch<true, 2, 8>(p, epilogue, st) : launch<false, 2, 8>(p, epilogue, st);
+    return b_is_kn ? launch<true, 4, 4>(p, epilogue, st) : launch<false, 4, 4>(p, epilogue, st);
 }

@@ -810,6 +810,7 @@ namespace {
 struct TokParams {
     const float *nf, *real, *add, *token, *pe0;
     float* out;
+    bf16_t* out16;                           // optional bf16 copy of out (the first layer's GEMM operand)
     const float* dout;
     float *d_nf, *d_add, *d_token;           // d_token [C]: accumulated with atomics (zero it first)
     int G, N, C;
@@ -841,6 +842,7 @@ __global__ __launch_bounds__(256) void assemble_tokens_kernel(const TokParams p)
         if (!BWD) {
             const float v = tok ? p.token[c] + p.pe0[c] : p.nf[src + c] * rl + p.add[src + c];
             p.out[row * p.C + c] = v * scale;
+            if (p.out16) p.out16[row * p.C + c] = (bf16_t)(v * scale);
         } else {
             const float d = p.dout[row * p.C + c] * scale;
             if (tok) {
@@ -864,12 +866,13 @@ void fill_tok(TokParams& p, float p_pos, float p_in, uint64_t seed, const uint64
 }  // namespace
 
 extern "C" int mobgt_assemble_tokens_fwd(const float* nf, const float* real, const float* add, const float* token,
-                                         const float* pe0, float* out, int G, int N, int C, float p_pos, float p_in,
-                                         uint64_t seed, const uint64_t* seed_dev, uint32_t salt_nf, uint32_t salt_tok,
-                                         uint32_t salt_in, void* stream) {
+                                         const float* pe0, float* out, void* out_bf16, int G, int N, int C, float p_pos,
+                                         float p_in, uint64_t seed, const uint64_t* seed_dev, uint32_t salt_nf,
+                                         uint32_t salt_tok, uint32_t salt_in, void* stream) {
     if (G <= 0 || N < 0 || C <= 0) return MOBGT_EBADDIM;
     TokParams p = {};
     p.nf = nf; p.real = real; p.add = add; p.token = token; p.pe0 = pe0; p.out = out; p.G = G; p.N = N; p.C = C;
+    p.out16 = reinterpret_cast<bf16_t*>(out_bf16);
     fill_tok(p, p_pos, p_in, seed, seed_dev, salt_nf, salt_tok, salt_in);
     const int64_t rows = (int64_t)G * (N + 1);
     hipLaunchKernelGGL(assemble_tokens_kernel<false>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, p);

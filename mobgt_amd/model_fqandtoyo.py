@@ -322,7 +322,8 @@ class Graphormer(nn.Module):
         # nf * real + add -> pos_embed dropout (:358); graph token + pe[0] -> the same dropout (:1338-1342); cat;
         # input_dropout (:1347): one launch
         return ops.assemble_tokens(nf, real, add, self.graph_token.weight, self.pos_embed.pe, self.pos_embed.dropout.p,
-                                   self.input_dropout.p, self.training)
+                                   self.input_dropout.p, self.training,
+                                   bf16_copy=self.act_dtype == torch.bfloat16 and getattr(self.layers[0], "fused", False))
 
     def forward(self, batched_data, perturb=None):
         bias = self.assemble_bias(batched_data)

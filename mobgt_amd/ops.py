@@ -563,12 +563,9 @@ class _GatherConcatFn(torch.autograd.Function):
         widths = [t.shape[1] for t in tables]
         ctot = sum(widths)
         out = torch.empty(R, ctot, dtype=torch.float32, device=tables[0].device)
-        off = 0
-        for t in range(n_tables):
-            dst = ctypes.c_void_p(out.data_ptr() + 4 * off)
-            check(_lib.lib().mobgt_embed_gather_sum(_ptr_array([tables[t]]), _ptr_array([idx[t]]), 1, dst, R, widths[t],
-                                                    ctot, _IT[idx[t].dtype], _stream()), "mobgt_embed_gather_sum")
-            off += widths[t]
+        warr = (ctypes.c_int * n_tables)(*widths)
+        check(_lib.lib().mobgt_embed_gather_concat(_ptr_array(tables), _ptr_array(idx), warr, n_tables, _p(out), R, ctot,
+                                                   _IT[idx[0].dtype], _stream()), "mobgt_embed_gather_concat")
         ctx.idx, ctx.skip, ctx.widths = idx, skip, widths
         ctx.shapes = [t.shape for t in tables]
         return out
@@ -579,14 +576,10 @@ class _GatherConcatFn(torch.autograd.Function):
         n = len(ctx.shapes)
         R, ctot = dout.shape
         grads = [zeros_f32(tuple(s), dout.device) for s in ctx.shapes]
-        off = 0
-        for t in range(n):
-            src = ctypes.c_void_p(dout.data_ptr() + 4 * off)
-            skip = (ctypes.c_int64 * 1)(ctx.skip[t])
-            check(_lib.lib().mobgt_embed_scatter_add(_ptr_array([grads[t]]), _ptr_array([ctx.idx[t]]), skip, 1, src, R,
-                                                     ctx.widths[t], ctot, _IT[ctx.idx[t].dtype], _stream()),
-                  "mobgt_embed_scatter_add")
-            off += ctx.widths[t]
+        skip = (ctypes.c_int64 * n)(*ctx.skip)
+        warr = (ctypes.c_int * n)(*ctx.widths)
+        check(_lib.lib().mobgt_embed_scatter_concat(_ptr_array(grads), _ptr_array(ctx.idx), skip, warr, n, _p(dout), R, ctot,
+                                                    _IT[ctx.idx[0].dtype], _stream()), "mobgt_embed_scatter_concat")
         return (None, None, *grads, *([None] * n))
 
 
@@ -829,7 +822,7 @@ def head_input(enc, user_table, user, user_offset=0):
 
 class _AssembleTokensFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, nf, real, add, token, pe0, p_pos, p_in, seed, seed_dev, salts):
+    def forward(ctx, nf, real, add, token, pe0, p_pos, p_in, seed, seed_dev, salts, side):
         G, N, C = nf.shape
         nf, add, real = nf.contiguous(), add.contiguous(), real.contiguous()
         shapes = (token.shape, pe0.shape)
@@ -838,9 +831,12 @@ class _AssembleTokensFn(torch.autograd.Function):
         # row 0 filled in -- no select_backward fill + copy)
         pe0 = pe0.contiguous() if pe0.dim() == 2 and pe0.shape[0] > 1 else pe0.reshape(-1).contiguous()
         out = torch.empty(G, N + 1, C, dtype=torch.float32, device=nf.device)
-        check(_lib.lib().mobgt_assemble_tokens_fwd(_p(nf), _p(real), _p(add), _p(token), _p(pe0), _p(out), G, N, C, p_pos, p_in,
-                                                   seed, _p(seed_dev), salts[0], salts[1], salts[2], _stream()),
+        out16 = torch.empty(G, N + 1, C, dtype=torch.bfloat16, device=nf.device) if side is not None else None
+        check(_lib.lib().mobgt_assemble_tokens_fwd(_p(nf), _p(real), _p(add), _p(token), _p(pe0), _p(out), _p(out16), G, N, C,
+                                                   p_pos, p_in, seed, _p(seed_dev), salts[0], salts[1], salts[2], _stream()),
               "mobgt_assemble_tokens_fwd")
+        if side is not None:
+            side.append(out16)
         ctx.save_for_backward(real)
         ctx.misc = (G, N, C, p_pos, p_in, seed, seed_dev, salts, shapes)
         return out
@@ -861,22 +857,27 @@ class _AssembleTokensFn(torch.autograd.Function):
         check(_lib.lib().mobgt_assemble_tokens_bwd(_p(dout), _p(real), _p(d_nf), _p(d_add), _p(d_tok), G, N, C, p_pos, p_in, seed,
                                                    _p(seed_dev), salts[0], salts[1], salts[2], _stream()),
               "mobgt_assemble_tokens_bwd")
-        return d_nf, None, d_add, d_tok.view(tshape), d_pe, None, None, None, None, None
+        return d_nf, None, d_add, d_tok.view(tshape), d_pe, None, None, None, None, None, None
 
 
-def assemble_tokens(nf, real, add, token, pe0, p_pos, p_in, training, salts=(0x1001, 0x1002, 0x1003)):
+def assemble_tokens(nf, real, add, token, pe0, p_pos, p_in, training, salts=(0x1001, 0x1002, 0x1003), bf16_copy=False):
     """[G,N+1,C] encoder input: graph token row (+ pe[0]) and the node features (* real + add), each through the
     positional dropout and then the input dropout -- one launch forward, one backward (see mobgt_assemble_tokens_fwd).
     `token` is [C]-sized; `pe0` is pe[0] or the whole positional table [L, C] (row 0 is used); the gradient of both is
-    the same per-column sum over graphs."""
+    the same per-column sum over graphs.  `bf16_copy`: the kernel also writes the result in bf16 and hangs it on the
+    returned tensor as `_mobgt_act` (what the first fused encoder layer feeds its QKV GEMM)."""
     _require_cuda(nf, add, token, pe0)
     if not training:
         p_pos = p_in = 0.0
     seed, seed_dev = _DROPOUT_STATE["seed"], _DROPOUT_STATE["seed_dev"]
     if seed_dev is None and (p_pos > 0 or p_in > 0):
         seed = (seed + int(torch.randint(0, 2 ** 31 - 1, (1,)).item())) & 0x7FFFFFFFFFFFFFFF
-    return _AssembleTokensFn.apply(nf.float(), real.float(), add.float(), token.float(), pe0.float(), float(p_pos),
-                                   float(p_in), int(seed), seed_dev, tuple(int(s) & 0xFFFFFFFF for s in salts))
+    side = [] if bf16_copy else None
+    out = _AssembleTokensFn.apply(nf.float(), real.float(), add.float(), token.float(), pe0.float(), float(p_pos),
+                                  float(p_in), int(seed), seed_dev, tuple(int(s) & 0xFFFFFFFF for s in salts), side)
+    if side:
+        out._mobgt_act = side[0]          # bf16 copy for the first fused layer's QKV GEMM (no cast launch)
+    return out
 
 
 # ------------------------------------------------------------------- the encoder layer's small GEMMs

@@ -168,7 +168,6 @@ class TrainStep:
         # room for every gradient that kernels accumulate into (all but the few huge matrices torch's GEMMs write)
         n_arena = sum(p.numel() for p in model.parameters() if p.numel() <= (1 << 16))
         self.arena = ops.ZeroArena(dev, n=(max(1 << 21, int(n_arena * 1.5) + (1 << 18)) + 3) // 4 * 4)
-        ops.set_zero_arena(self.arena)
         model.train()
         # One side stream for the dry run, the warm-ups and every capture: autograd's AccumulateGrad nodes are
         # created on the stream of the first backward and must match the capture stream later on.
@@ -289,6 +288,7 @@ class TrainStep:
         from .ops import _p, _stream
         self.flat.release()
         self.arena.off = 0
+        ops.set_zero_arena(self.arena)             # valid from here to the end of this backward pass only
         _lib.check(_lib.lib().mobgt_step_prologue(_p(self.flat.flat), self.flat.flat.numel(), _p(self.arena.buf),
                                                   self.arena.buf.numel(), _p(self.seed_dev), _stream()), "mobgt_step_prologue")
 
@@ -296,6 +296,7 @@ class TrainStep:
         self._prologue()
         loss = self._loss(batch)
         loss.backward(gradient=ops.unit_grad(loss.device))
+        ops.set_zero_arena(None)
         self.flat.gather()
         self._keep_loss(loss, slot)
 
@@ -325,6 +326,7 @@ class TrainStep:
     def _phase_b(self, i):
         enc, g_enc = self._g_enc[i]
         torch.autograd.backward([enc], [g_enc])
+        ops.set_zero_arena(None)
         self.flat.gather(self.n_head, None)
 
     def _capture(self, i):

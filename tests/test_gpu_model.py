@@ -326,3 +326,28 @@ def test_two_phase_backward_matches_single_phase():
     np.testing.assert_allclose(g1.cpu().numpy(), g0.cpu().numpy(), atol=1e-4 * scale)     # atomics order only
     np.testing.assert_allclose(p1.cpu().numpy(), p0.cpu().numpy(), atol=1e-9)
     assert float(g0.abs().max()) > 0
+
+
+def test_embed_gather_concat_matches_torch_cat_of_embeddings():
+    """mobgt_embed_gather_concat / _scatter_concat against cat(embedding, embedding) and its autograd: rows with index
+    -1 read as zeros, the padding row of the second table gets no gradient."""
+    from mobgt_amd import ops
+    g = torch.Generator().manual_seed(21)
+    R, W1, W2 = 203, 128, 32
+    t1 = torch.randn(50, W1, generator=g).to(DEV)
+    t2 = torch.randn(49, W2, generator=g).to(DEV)
+    i1 = torch.randint(-1, 50, (7, 29), generator=g).to(DEV)
+    i2 = torch.randint(-1, 49, (7, 29), generator=g).to(DEV)
+    gy = torch.randn(7, 29, W1 + W2, generator=g).to(DEV)
+    a1, a2 = t1.clone().requires_grad_(True), t2.clone().requires_grad_(True)
+    e1 = torch.nn.functional.embedding(i1.clamp(min=0), a1) * (i1 >= 0).unsqueeze(-1)
+    e2 = torch.nn.functional.embedding(i2.clamp(min=0), a2) * ((i2 >= 0) & (i2 != 0)).unsqueeze(-1) \
+        + (torch.nn.functional.embedding(i2.clamp(min=0), a2) * (i2 == 0).unsqueeze(-1)).detach()
+    ref = torch.cat((e1, e2), -1)
+    ref.backward(gy)
+    b1, b2 = t1.clone().requires_grad_(True), t2.clone().requires_grad_(True)
+    got = ops.embed_gather_concat([b1, b2], [i1, i2], padding_idx=[None, 0])
+    got.backward(gy)
+    assert torch.equal(got, ref)
+    np.testing.assert_allclose(b1.grad.cpu().numpy(), a1.grad.cpu().numpy(), rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(b2.grad.cpu().numpy(), a2.grad.cpu().numpy(), rtol=1e-5, atol=1e-5)
