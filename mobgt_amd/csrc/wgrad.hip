@@ -22,7 +22,7 @@ namespace {
 
 constexpr int TILE = 32;
 constexpr int KSTEP = 32;            // rows contracted by one 16x16x32 MFMA
-constexpr int NWAVE = 16;
+constexpr int SHORT_R = 1024;        // up to here 8 waves per workgroup, 16 beyond
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
 struct WgradParams {
@@ -78,9 +78,11 @@ struct Slab {
     }
 };
 
-template <bool F32>
+// NWAVE waves per workgroup: 16, or 8 when R is short (R = 608: 19 k-steps -- sixteen waves would mostly idle, and a
+// 1024-thread workgroup leaves room for only two per CU where the grouped launch wants 528 of them at once)
+template <bool F32, int NWAVE>
 __device__ __forceinline__ void wgrad_body(const WgradParams& p, const int tile, const int split, const int nsplit) {
-    __shared__ float part[NWAVE / 2][TILE * TILE];     // 32 KB: the upper 8 waves hand their tiles to the lower 8 first
+    __shared__ float part[NWAVE / 2][TILE * TILE];     // the upper half of the waves hand their tiles to the lower half first
     __shared__ float colpart[NWAVE][TILE];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i = lane & 15, kq = lane >> 4;
@@ -144,8 +146,8 @@ __device__ __forceinline__ void wgrad_body(const WgradParams& p, const int tile,
         if (kq == 0) { colpart[wave][2 * i] = se; colpart[wave][2 * i + 1] = so; }
     }
     __syncthreads();
-    {
-        const int e = threadIdx.x, r = e >> 5, c = e & 31;
+    for (int e = threadIdx.x; e < TILE * TILE; e += NWAVE * 64) {
+        const int r = e >> 5, c = e & 31;
         float s = 0.f;
 #pragma unroll
         for (int w = 0; w < NWAVE / 2; ++w) s += part[w][e];
@@ -153,6 +155,9 @@ __device__ __forceinline__ void wgrad_body(const WgradParams& p, const int tile,
             float* dst = p.dw + (int64_t)(m0 + r) * p.ldw + n0 + c;
             if (nsplit > 1) atomicAdd(dst, s); else *dst += s;
         }
+    }
+    {
+        const int e = threadIdx.x;
         if (want_db && e < TILE && m0 + e < p.M) {
             float t = 0.f;
 #pragma unroll
@@ -162,9 +167,10 @@ __device__ __forceinline__ void wgrad_body(const WgradParams& p, const int tile,
     }
 }
 
+template <int NWAVE>
 __global__ __launch_bounds__(NWAVE * 64) void wgrad_kernel(const WgradParams p) {
-    if (p.in_f32) wgrad_body<true>(p, blockIdx.x, blockIdx.y, gridDim.y);
-    else wgrad_body<false>(p, blockIdx.x, blockIdx.y, gridDim.y);
+    if (p.in_f32) wgrad_body<true, NWAVE>(p, blockIdx.x, blockIdx.y, gridDim.y);
+    else wgrad_body<false, NWAVE>(p, blockIdx.x, blockIdx.y, gridDim.y);
 }
 
 // Up to 32 independent problems in ONE launch (the four Linear layers of every encoder layer: nothing depends on a
@@ -178,18 +184,19 @@ struct WgradGroup {
     int n;
 };
 
+template <int NWAVE>
 __global__ __launch_bounds__(NWAVE * 64) void wgrad_group_kernel(const WgradGroup grp) {
     int q = 0;
 #pragma unroll
     for (int t = 1; t < WG_GROUP; ++t)
         if (t < grp.n && (int)blockIdx.x >= grp.first[t]) q = t;
     const int local = blockIdx.x - grp.first[q];
-    if (grp.p[q].in_f32) wgrad_body<true>(grp.p[q], local % grp.tiles[q], local / grp.tiles[q], grp.splits[q]);
-    else wgrad_body<false>(grp.p[q], local % grp.tiles[q], local / grp.tiles[q], grp.splits[q]);
+    if (grp.p[q].in_f32) wgrad_body<true, NWAVE>(grp.p[q], local % grp.tiles[q], local / grp.tiles[q], grp.splits[q]);
+    else wgrad_body<false, NWAVE>(grp.p[q], local % grp.tiles[q], local / grp.tiles[q], grp.splits[q]);
 }
 
 int fill_problem(WgradParams& p, const void* g, int64_t ldg, const void* x, int64_t ldx, float* dw, int64_t ldw, float* db,
-                 int64_t R, int M, int N, int target_wgs, int* tiles_out, int* splits_out, int in_f32) {
+                 int64_t R, int M, int N, int target_wgs, int* tiles_out, int* splits_out, int in_f32, int nwave) {
     if (R <= 0 || M <= 0 || N <= 0 || (M & 1) || (N & 1) || (ldg & 1) || (ldx & 1) || R > 0x7fffffff) return MOBGT_EBADDIM;
     if (((uintptr_t)g & (in_f32 ? 7 : 3)) || ((uintptr_t)x & (in_f32 ? 7 : 3))) return MOBGT_EALIGN;
     p.in_f32 = in_f32;
@@ -200,7 +207,7 @@ int fill_problem(WgradParams& p, const void* g, int64_t ldg, const void* x, int6
     const int tiles_m = (M + TILE - 1) / TILE;
     p.tiles_n = (N + TILE - 1) / TILE;
     const int tiles = tiles_m * p.tiles_n;
-    const int slab = NWAVE * KSTEP;
+    const int slab = nwave * KSTEP;
     int splits = target_wgs / tiles;
     const int max_splits = (int)((R + slab - 1) / slab);
     if (splits > max_splits) splits = max_splits;
@@ -222,17 +229,19 @@ extern "C" int mobgt_linear_wgrad_group(int n, const void* const* g, const int64
     WgradGroup grp;
     grp.n = n;
     int total = 0;
+    const int nwave = R <= SHORT_R ? 8 : 16;
     for (int q = 0; q < n; ++q) {
         // the problems share the chip: aim at ~256 workgroups for all of them together
         const int rc = fill_problem(grp.p[q], g[q], ldg[q], x[q], ldx[q], dw[q], ldw[q], db ? db[q] : nullptr, R, M[q], N[q],
-                                    256 / n, &grp.tiles[q], &grp.splits[q], act_dtype == MOBGT_F32);
+                                    256 / n, &grp.tiles[q], &grp.splits[q], act_dtype == MOBGT_F32, nwave);
         if (rc) return rc;
         grp.first[q] = total;
         total += grp.tiles[q] * grp.splits[q];
     }
     for (int q = n; q <= WG_GROUP; ++q) grp.first[q] = total;
     for (int q = n; q < WG_GROUP; ++q) { grp.tiles[q] = 1; grp.splits[q] = 1; grp.p[q] = grp.p[0]; }
-    hipLaunchKernelGGL(wgrad_group_kernel, dim3(total), dim3(NWAVE * 64), 0, (hipStream_t)stream, grp);
+    if (nwave == 8) hipLaunchKernelGGL(wgrad_group_kernel<8>, dim3(total), dim3(8 * 64), 0, (hipStream_t)stream, grp);
+    else hipLaunchKernelGGL(wgrad_group_kernel<16>, dim3(total), dim3(16 * 64), 0, (hipStream_t)stream, grp);
     return (int)hipGetLastError();
 }
 
@@ -246,8 +255,11 @@ extern "C" int mobgt_linear_wgrad(const void* g, int64_t ldg, const void* x, int
     // unsplit; 576x192 2 splits 10.8 vs 13.3; R = 12560, 256x256 4 splits 21 vs 46 (incl. two zero fills).
     WgradParams p;
     int tiles = 0, splits = 0;
-    const int rc = fill_problem(p, g, ldg, x, ldx, dw, ldw, db, R, M, N, 256, &tiles, &splits, act_dtype == MOBGT_F32);
+    const int nwave = R <= SHORT_R ? 8 : 16;
+    const int rc = fill_problem(p, g, ldg, x, ldx, dw, ldw, db, R, M, N, nwave == 8 ? 512 : 256, &tiles, &splits,
+                                act_dtype == MOBGT_F32, nwave);
     if (rc) return rc;
-    hipLaunchKernelGGL(wgrad_kernel, dim3(tiles, splits), dim3(NWAVE * 64), 0, (hipStream_t)stream, p);
+    if (nwave == 8) hipLaunchKernelGGL(wgrad_kernel<8>, dim3(tiles, splits), dim3(8 * 64), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL(wgrad_kernel<16>, dim3(tiles, splits), dim3(16 * 64), 0, (hipStream_t)stream, p);
     return (int)hipGetLastError();
 }
