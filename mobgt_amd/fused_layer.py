@@ -236,6 +236,13 @@ class _FusedLayerFn(torch.autograd.Function):
                 and sk.data_ptr() == sq.data_ptr() + 4 * sq.numel() and sv.data_ptr() == sk.data_ptr() + 4 * sk.numel():
             s_qkv = torch.as_strided(sq, (3 * C, C), (C, 1))
         ctx.sinks = (s_qkv, ops.grad_sink(wo), ops.grad_sink(w1), ops.grad_sink(w2))
+        # the block of small gradients [dbq dbk dbv | dbo | db1 | db2 | dn1w | dn1b | dnxw | dnxb]: one slice of the flat
+        # buffer when the trainer laid these parameters out in that order (train.flat_order)
+        ctx.small_sink = None
+        chain = [ops.grad_sink(t) for t in (bq, bk, bv, bo, b1, b2, n1w, n1b, nxw, nxb)]
+        if all(t is not None and t.is_contiguous() for t in chain) and \
+                all(chain[j + 1].data_ptr() == chain[j].data_ptr() + 4 * chain[j].numel() for j in range(len(chain) - 1)):
+            ctx.small_sink = torch.as_strided(chain[0], (sum(t.numel() for t in chain),), (1,))
         ctx.cfg = cfg
         ctx.shapes = (G, T, C)
         ctx.save_for_backward(x, xa, qkv, a, lse, x1, z, u, h, x2, stats, s_wqkv, s_wo, s_w1, s_w2, n1w, nxw)
@@ -256,7 +263,7 @@ class _FusedLayerFn(torch.autograd.Function):
         dout = dout.contiguous().view(R, C).float()
         # every small gradient of the layer in ONE zero-filled buffer:
         # [dbqkv 3C | dbo C | db1 F | db2 C | dn1w C | dn1b C | dnxw C | dnxb C]
-        small = ops.zeros_f32((3 * C + C + F + C + 4 * C,), dev)
+        small = ctx.small_sink if ctx.small_sink is not None else ops.zeros_f32((3 * C + C + F + C + 4 * C,), dev)
         o = [0]
 
         def take(n):

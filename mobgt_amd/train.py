@@ -94,13 +94,32 @@ def flat_order(model, used):
     for p in head_parameters(model, used):
         order.append(p)
         seen.add(id(p))
+    def take(grp):
+        if all(id(p) in used_ids and id(p) not in seen for p in grp):
+            for p in grp:
+                order.append(p)
+                seen.add(id(p))
+            return True
+        return False
+    layers = [m for m in model.modules() if hasattr(m, "self_attention") and hasattr(m, "ffn")]
+    attn_done = set()
+    for layer in layers:
+        # an encoder layer: q/k/v weights, then -- in the order of the fused backward's block of small gradients
+        # (fused_layer._FusedLayerFn.backward) -- q/k/v biases, output bias, FFN biases, the two LayerNorms: that block
+        # is then ONE slice of the flat gradient buffer and nothing of it needs a gather copy
+        m = layer.self_attention
+        if not all(hasattr(m, a) for a in ("linear_q", "linear_k", "linear_v", "output_layer")):
+            continue
+        n1, nx = ((layer.ffn_norm1, layer.ffn_norm2) if hasattr(layer, "ffn_norm1")
+                  else (getattr(layer, "ffn_norm", None), getattr(layer, "self_attention_norm", None)))
+        if n1 is None or nx is None:
+            continue
+        if take([m.linear_q.weight, m.linear_k.weight, m.linear_v.weight, m.linear_q.bias, m.linear_k.bias, m.linear_v.bias,
+                 m.output_layer.bias, layer.ffn.layer1.bias, layer.ffn.layer2.bias, n1.weight, n1.bias, nx.weight, nx.bias]):
+            attn_done.add(id(m))
     for m in model.modules():
-        if all(hasattr(m, a) for a in ("linear_q", "linear_k", "linear_v")):
-            grp = [m.linear_q.weight, m.linear_k.weight, m.linear_v.weight, m.linear_q.bias, m.linear_k.bias, m.linear_v.bias]
-            if all(id(p) in used_ids for p in grp):
-                for p in grp:
-                    order.append(p)
-                    seen.add(id(p))
+        if id(m) not in attn_done and all(hasattr(m, a) for a in ("linear_q", "linear_k", "linear_v")):
+            take([m.linear_q.weight, m.linear_k.weight, m.linear_v.weight, m.linear_q.bias, m.linear_k.bias, m.linear_v.bias])
     return order + [p for p in used if id(p) not in seen]
 
 

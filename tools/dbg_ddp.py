@@ -38,5 +38,5 @@ for i in range(5):
     with torch.no_grad():
         model.eval(); lg = model(batches[(i + 1) % len(batches)])[0].float(); model.train()
     extra = f" next-batch eval logits absmax {float(lg.abs().max()):.3f} mean {float(lg.mean()):.4f} nan {bool(torch.isnan(lg).any())}"
-    print(f"rank {rank} step {i} loss {l:.6f} |g| {float(g.norm()):.4e} g finite {bool(torch.isfinite(g).all())} |p| {float(p.detach().norm()):.6f} lr {float(ts.lr_dev):.3e}" + extra, flush=True)
+    print(f"rank {rank} step {i} loss {l:.6f} |g| {float(g.norm()):.4e} g finite {bool(torch.isfinite(g).all())} |p| {float(p.detach().norm()):.6f} lr {ts.lr:.3e}" + extra, flush=True)
 dist.barrier()
