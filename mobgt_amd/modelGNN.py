@@ -53,6 +53,20 @@ def _mm_f32(a, b, bias=None):
     return out + bias if bias is not None else out
 
 
+import os as _os
+_SMALL_GEMM = _os.environ.get("MOBGT_SMALL_GEMM", "1") != "0"
+
+
+def _mm_small(a, b, b_is_nk=False):
+    """a @ b (or a @ b.T) in f32.  Short contractions (K <= 64: the GCN's `input @ weight` and its data gradient) go to the
+    one-wave-per-tile MFMA kernel of csrc/sgemm.hip; the library's kernels for such shapes are all ramp-up."""
+    if _SMALL_GEMM and a.is_cuda and a.shape[1] <= 64 and a.dtype == torch.float32 and b.dtype == torch.float32 \
+            and a.stride(1) == 1 and b.stride(1) == 1:
+        from . import ops
+        return ops.small_gemm(a, b, None, b_is_nk)
+    return a @ (b.t() if b_is_nk else b)
+
+
 def _colsum(g):
     if g.is_cuda:
         from . import ops
@@ -65,7 +79,7 @@ class _GraphConvFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, bias, adj, adj_t=None):
-        support = x @ weight
+        support = _mm_small(x, weight)
         out = _mm_f32(adj, support.to(adj.dtype), bias)             # bias in the GEMM epilogue, fp32 result
         ctx.save_for_backward(x, weight, adj, adj_t)
         ctx.has_bias = bias is not None
@@ -78,7 +92,7 @@ class _GraphConvFn(torch.autograd.Function):
         # (measured 60 us for adj.t() @ g through the library's transposed-operand path vs 42 us)
         d_support = _mm_f32(adj_t if adj_t is not None else adj.t(), g.to(adj.dtype))
         dW = mm_tn_splitk(x, d_support, bf16_operands=adj.dtype == torch.bfloat16)
-        dx = d_support @ weight.t() if ctx.needs_input_grad[0] else None
+        dx = _mm_small(d_support, weight, True) if ctx.needs_input_grad[0] else None
         db = _colsum(g) if ctx.has_bias else None
         return dx, dW, db, None, None
 
@@ -94,7 +108,7 @@ class _RowsConvFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, adj, rows):
         from . import ops
-        support = x @ weight                                           # [P,C] f32
+        support = _mm_small(x, weight)                                 # [P,C] f32
         a_rows, a_rows_t = ops.gather_rows_t(adj, rows)                # [R,P] and its transpose [P,R], one pass
         out = ops.linear_wgrad(a_rows_t, support.to(torch.bfloat16))[0]     # [R,C] f32
         if bias is not None:
@@ -109,7 +123,7 @@ class _RowsConvFn(torch.autograd.Function):
         x, weight, a_rows = ctx.saved_tensors
         d_support = ops.linear_wgrad(a_rows, g.to(torch.bfloat16).contiguous())[0]      # [P,C] f32
         dW = mm_tn_splitk(x, d_support, bf16_operands=True)
-        dx = d_support @ weight.t() if ctx.needs_input_grad[0] else None
+        dx = _mm_small(d_support, weight, True) if ctx.needs_input_grad[0] else None
         db = _colsum(g) if ctx.has_bias else None
         return dx, dW, db, None, None
 

@@ -313,3 +313,23 @@ def test_layer_gemm_epilogues_match_torch(M, N, K):
         got = ops.layer_gemm(a, w, None, kn, ops.GEMM_ADD, aux_in=addend)
         assert got.data_ptr() == addend.data_ptr()
         np.testing.assert_allclose(got.cpu().numpy(), want.float().cpu().numpy(), rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("M,N,K", [(7856, 64, 16), (300, 32, 64), (301, 17, 303), (16, 320, 320), (5, 3, 2)])
+def test_small_gemm_f32_matches_torch(M, N, K):
+    """mobgt_small_gemm_f32 (both B orientations, bias, strided A, ragged M / N / K) against f64 products: f32 accuracy."""
+    from mobgt_amd import ops
+    gen = torch.Generator().manual_seed(M * 7 + N)
+    wide = torch.randn(M, K + 5, generator=gen).to(DEV)
+    a = wide[:, 2:2 + K]                                       # row-strided, unaligned view
+    a2 = torch.randn(M, K, generator=gen).to(DEV)
+    bias = torch.randn(N, generator=gen).to(DEV)
+    for nk in (False, True):
+        b = torch.randn((N, K) if nk else (K, N), generator=gen).to(DEV)
+        bd = b.double().t() if nk else b.double()
+        for aa in (a, a2):
+            want = (aa.double() @ bd + bias.double()).float()
+            got = ops.small_gemm(aa, b, bias, nk)
+            np.testing.assert_allclose(got.cpu().numpy(), want.cpu().numpy(), rtol=2e-5, atol=2e-5 * K ** 0.5)
+        np.testing.assert_allclose(ops.small_gemm(a2, b, None, nk).cpu().numpy(), (a2.double() @ bd).float().cpu().numpy(),
+                                   rtol=2e-5, atol=2e-5 * K ** 0.5)
