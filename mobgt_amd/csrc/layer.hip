@@ -1019,6 +1019,7 @@ struct BiasActParams {
     float *y, *dx, *dbias;
     int64_t R;
     int C, rows_per_wg;
+    int lpr;                                 // lanes per row: 64, or C/4 for narrow matrices (a wave then walks 64/lpr rows at once)
     float slope, inv_keep;
     uint32_t thr;
     uint64_t seed;
@@ -1030,7 +1031,8 @@ template <bool BWD>
 __global__ __launch_bounds__(256) void bias_act_kernel(const BiasActParams p) {
     __shared__ float red[4][256];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int c = 256 * blockIdx.y + 4 * lane;
+    const int rpw = 64 / p.lpr, sub = lane / p.lpr;          // the GCN's 16- and 64-wide layers would leave 94 / 75 % of
+    const int c = 256 * blockIdx.y + 4 * (lane % p.lpr);     // a wave idle with one row per wave
     const int64_t r0 = (int64_t)blockIdx.x * p.rows_per_wg;
     const int nrow = (int)min((int64_t)p.rows_per_wg, p.R - r0);
     const uint64_t seed = p.thr ? p.seed + (p.seed_dev ? *p.seed_dev : 0ull) : 0ull;
@@ -1038,7 +1040,7 @@ __global__ __launch_bounds__(256) void bias_act_kernel(const BiasActParams p) {
     float b4[4] = {0.f, 0.f, 0.f, 0.f};
     if (!BWD && p.bias && c < p.C) ld4<float>(p.bias + c, b4);
     if (c < p.C) {
-        for (int rr = wave; rr < nrow; rr += 4) {
+        for (int rr = wave * rpw + sub; rr < nrow; rr += 4 * rpw) {
             const int64_t r = r0 + rr;
             const uint32_t rowh = p.thr ? dropout_row_hash(seed, (uint32_t)r ^ p.salt) : 0u;
             float v[4], o[4];
@@ -1071,7 +1073,14 @@ __global__ __launch_bounds__(256) void bias_act_kernel(const BiasActParams p) {
     for (int i = 0; i < 4; ++i) red[wave][4 * lane + i] = acc[i];
     __syncthreads();
     const int cc = 256 * blockIdx.y + threadIdx.x;
-    if (cc < p.C) atomicAdd(&p.dbias[cc], red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+    if (cc < p.C && threadIdx.x < 4 * p.lpr) {
+        float t = 0.f;
+        for (int sr = 0; sr < rpw; ++sr) {                  // the lanes (sub-rows) that own this column
+            const int e = 4 * (sr * p.lpr) + threadIdx.x;
+            t += red[0][e] + red[1][e] + red[2][e] + red[3][e];
+        }
+        atomicAdd(&p.dbias[cc], t);
+    }
 }
 
 int launch_bias_act(BiasActParams& p, bool bwd, float dropout_p, hipStream_t st) {
@@ -1079,7 +1088,11 @@ int launch_bias_act(BiasActParams& p, bool bwd, float dropout_p, hipStream_t st)
     if (p.C <= 0 || (p.C & 3)) return MOBGT_EBADDIM;
     p.thr = dropout_p > 0.f ? dropout_threshold(dropout_p) : 0u;
     p.inv_keep = p.thr ? 1.f / (1.f - (float)p.thr / 65536.f) : 1.f;
+    p.lpr = 64;
+    const int q = p.C / 4;
+    if (q < 64 && (64 % q) == 0) p.lpr = q;
     p.rows_per_wg = bwd ? pick_rows(p.R) : pick_rows_stream(p.R);
+    if (p.rows_per_wg < 4 * (64 / p.lpr)) p.rows_per_wg = 4 * (64 / p.lpr);       // one sweep of the four waves
     const dim3 grid((unsigned)((p.R + p.rows_per_wg - 1) / p.rows_per_wg), (unsigned)((p.C + 255) / 256)), block(256);
     if (bwd) hipLaunchKernelGGL(bias_act_kernel<true>, grid, block, 0, st, p);
     else hipLaunchKernelGGL(bias_act_kernel<false>, grid, block, 0, st, p);

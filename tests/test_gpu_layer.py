@@ -257,11 +257,12 @@ def test_head_act_matches_torch_chain(p_drop):
     ops.set_dropout_state(None, None)
 
 
+@pytest.mark.parametrize("C", [16, 64, 192])          # 4 / 16 lanes per row (a wave walks several rows), and the wide layout
 @pytest.mark.parametrize("p_drop,has_bias", [(0.0, True), (0.3, True), (0.3, False)])
-def test_bias_act_matches_torch_chain(p_drop, has_bias):
+def test_bias_act_matches_torch_chain(p_drop, has_bias, C):
     from mobgt_amd import ops
     gen = torch.Generator().manual_seed(12)
-    R, C = 777, 64
+    R = 777
     x = torch.randn(R, C, generator=gen).to(DEV)
     b = torch.randn(C, generator=gen).to(DEV) if has_bias else None
     gy = torch.randn(R, C, generator=gen).to(DEV)
