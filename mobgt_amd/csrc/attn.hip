@@ -37,6 +37,7 @@ struct AttnParams {
     uint64_t seed;
     const uint64_t* seed_dev;
     int accumulate;
+    int n_first;              // attn_bwd_both_kernel: workgroups of the dQ part
 };
 
 // Staging of a [KC x D] row-major slab (rows row0.., row stride ld, head column offset already applied) into
@@ -286,7 +287,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const AttnParams p) {
 // ======================================================================= backward, pass 1: dQ + dBias
 // Same decomposition as the forward (one wave = 32 query rows, sweep over keys).
 template <int D, typename TQ, typename TB, int NW, bool DROP>
-__global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(const AttnParams p) {
+__device__ __forceinline__ void attn_bwd_dq_body(const AttnParams& p, const int bid, const int nwg) {
     constexpr int KS = (D + 15) / 16;
     constexpr int NT = NW * 64;
     __shared__ __attribute__((aligned(16))) bf16_t Ks[KC][ROWP];
@@ -295,7 +296,7 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(const AttnParams p
 
     const int T = p.T, H = p.H;
     const int nQ = (T + 32 * NW - 1) / (32 * NW);
-    const int lid = xcd_remap(blockIdx.x, gridDim.x);
+    const int lid = xcd_remap(bid, nwg);
     const int qt = lid % nQ, gh = lid / nQ;
     const int g = gh / H, h = gh % H;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -455,11 +456,18 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(const AttnParams p
     }
 }
 
+template <int D, typename TQ, typename TB, int NW, bool DROP>
+__global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(const AttnParams p) {
+    attn_bwd_dq_body<D, TQ, TB, NW, DROP>(p, blockIdx.x, gridDim.x);
+}
+
 // ======================================================================= backward, pass 2: dK + dV
 // One wave = 32 keys (on the lanes), sweep over queries; reads the TRANSPOSED bias so that a lane's
 // 16 accumulator registers are again 16 contiguous elements (queries q0+16*hi .. +15 of its key row).
-template <int D, typename TQ, typename TB, int NW, bool DROP>
-__global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_kernel(const AttnParams p) {
+// OWN_DELTA: rowsum(dO * O) is recomputed here instead of read from the dQ pass's `delta` output, so that the two
+// passes can share ONE launch (attn_bwd_both_kernel).
+template <int D, typename TQ, typename TB, int NW, bool DROP, bool OWN_DELTA>
+__device__ __forceinline__ void attn_bwd_dkv_body(const AttnParams& p, const int bid, const int nwg) {
     constexpr int KS = (D + 15) / 16;
     constexpr int NT = NW * 64;
     __shared__ __attribute__((aligned(16))) bf16_t Qs[KC][ROWP];
@@ -472,7 +480,7 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_kernel(const AttnParams 
 
     const int T = p.T, H = p.H;
     const int nK = (T + 32 * NW - 1) / (32 * NW);
-    const int lid = xcd_remap(blockIdx.x, gridDim.x);
+    const int lid = xcd_remap(bid, nwg);
     const int kt = lid % nK, gh = lid / nK;
     const int g = gh / H, h = gh % H;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -516,7 +524,23 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_kernel(const AttnParams 
         const int q = c * KC + (int)threadIdx.x;
         const bool ok = threadIdx.x < KC && q < T;
         lse_r = ok ? p.lse_in[(int64_t)gh * T + q] : 0.f;
-        dl_r = ok ? p.delta[(int64_t)gh * T + q] : 0.f;
+        if (!OWN_DELTA) {
+            dl_r = ok ? p.delta[(int64_t)gh * T + q] : 0.f;
+        } else {
+            float d = 0.f;
+            if (ok) {
+                const TQ* O = reinterpret_cast<const TQ*>(p.out) + (int64_t)g * T * p.ldo + h * D;
+#pragma unroll
+                for (int e = 0; e < D; e += 8) {
+                    float a[8], b[8];
+                    load8(dO + (int64_t)q * p.ldo + e, a);
+                    load8(O + (int64_t)q * p.ldo + e, b);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) d = fmaf(a[j], b[j], d);
+                }
+            }
+            dl_r = d;
+        }
     };
     load_rowstats(0);
     for (int c = 0; c < nchunk; ++c) {
@@ -621,13 +645,38 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_kernel(const AttnParams 
     }
 }
 
+template <int D, typename TQ, typename TB, int NW, bool DROP>
+__global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_kernel(const AttnParams p) {
+    attn_bwd_dkv_body<D, TQ, TB, NW, DROP, false>(p, blockIdx.x, gridDim.x);
+}
+
+// Both backward passes in one launch (small graphs: each pass alone is 128-256 workgroups of 1-2 waves -- a fraction of
+// the chip -- and nothing but latency; side by side they take the time of the longer one): the first n_first workgroups
+// run the dQ / dBias pass, the rest the dK / dV pass.
+template <int D, typename TQ, typename TB, int NW, bool DROP>
+__global__ __launch_bounds__(NW * 64) void attn_bwd_both_kernel(const AttnParams p) {
+    if ((int)blockIdx.x < p.n_first) attn_bwd_dq_body<D, TQ, TB, NW, DROP>(p, blockIdx.x, p.n_first);
+    else attn_bwd_dkv_body<D, TQ, TB, NW, DROP, true>(p, blockIdx.x - p.n_first, gridDim.x - p.n_first);
+}
+
 // ------------------------------------------------------------------------------------ dispatch
-enum Pass { FWD, BWD_DQ, BWD_DKV };
+enum Pass { FWD, BWD_DQ, BWD_DKV, BWD_BOTH };
 
 template <Pass PASS, int D, typename TQ, typename TB, int NW, bool DROP>
 hipError_t launch_one(const AttnParams& p, hipStream_t st) {
     const int tiles = (p.T + 32 * NW - 1) / (32 * NW);
     const dim3 grid((unsigned)(p.G * p.H * tiles)), block(NW * 64);
+    if constexpr (PASS == BWD_BOTH) {
+        if constexpr (NW < 4) {
+            AttnParams q = p;
+            q.n_first = p.G * p.H * tiles;
+            hipLaunchKernelGGL((attn_bwd_both_kernel<D, TQ, TB, NW, DROP>), dim3(2 * grid.x), block, 0, st, q);
+        } else {
+            hipLaunchKernelGGL((attn_bwd_dq_kernel<D, TQ, TB, NW, DROP>), grid, block, 0, st, p);
+            hipLaunchKernelGGL((attn_bwd_dkv_kernel<D, TQ, TB, NW, DROP>), grid, block, 0, st, p);
+        }
+        return hipGetLastError();
+    }
     if (PASS == FWD) hipLaunchKernelGGL((attn_fwd_kernel<D, TQ, TB, NW, DROP>), grid, block, 0, st, p);
     else if (PASS == BWD_DQ) hipLaunchKernelGGL((attn_bwd_dq_kernel<D, TQ, TB, NW, DROP>), grid, block, 0, st, p);
     else hipLaunchKernelGGL((attn_bwd_dkv_kernel<D, TQ, TB, NW, DROP>), grid, block, 0, st, p);
@@ -727,9 +776,8 @@ extern "C" int mobgt_attn_bias_bwd(const void* q, const void* k, const void* v, 
     p.dbias_bf16 = dbias_dtype == MOBGT_BF16;
     set_dropout(p, dropout_p, seed, seed_dev);
     const bool drop = p.drop_thr != 0;
-    rc = launch<BWD_DQ>(p, d, io_dtype, bias_dtype, drop, (hipStream_t)stream);
-    if (rc) return rc;
-    return launch<BWD_DKV>(p, d, io_dtype, bias_dtype, drop, (hipStream_t)stream);
+    // T <= 64: both passes in one launch; larger graphs: dQ pass, then dK/dV pass (it reads the dQ pass's `delta`)
+    return launch<BWD_BOTH>(p, d, io_dtype, bias_dtype, drop, (hipStream_t)stream);
 }
 
 extern "C" int mobgt_dropout_keep_host(uint64_t seed, int H, int T, int g, int h, int i, int j, float dropout_p) {
