@@ -309,6 +309,15 @@ int mobgt_linear_wgrad_group(int n, const void* const* g, const int64_t* ldg, co
                              float* const* dw, const int64_t* ldw, float* const* db, int64_t R, const int* M,
                              const int* N, int act_dtype, void* stream);
 
+/* End of an encoder layer's backward in ONE launch (R <= 1024 rows): the weight gradients of mobgt_linear_wgrad_group
+ * (same arguments) and, side by side with them, the layer's input gradient  c[gM,gN] (f32) += a[gM,gK] x b_kn[gK,gN]
+ * (bf16 operands; mobgt_layer_gemm's MOBGT_GEMM_ADD with b_is_kn = 1, in place) -- `dx = dx1 + dqkv Wqkv`, which needs
+ * the same dqkv as the weight gradients and nothing they produce. */
+int mobgt_layer_backward_tail(int n, const void* const* g, const int64_t* ldg, const void* const* x, const int64_t* ldx,
+                              float* const* dw, const int64_t* ldw, float* const* db, int64_t R, const int* M,
+                              const int* N, int act_dtype, const void* a, int64_t lda, const void* b_kn, int64_t ldb,
+                              float* c, int64_t ldc, int gM, int gN, int gK, void* stream);
+
 /* Token assembly at the encoder input (model_fqandtoyo.py:1287-1298, 348-358, 1338-1347) in one launch:
  *   out[g,0,:] = drop_in(drop_pos(token + pe0));  out[g,1+n,:] = drop_in(drop_pos(nf[g,n,:] * real[g,n] + add[g,n,:]))
  * nf, add [G,N,C], real [G,N], token, pe0 [C], out [G,N+1,C], all f32 (out_bf16: optional bf16 copy of out, the

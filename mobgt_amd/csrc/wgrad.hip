@@ -16,6 +16,7 @@
 // operand, and the 2x2 MFMAs produce the 32x32 tile with rows 2i+a and columns 2j+b.
 #include "common.h"
 #include "mobgt_hip.h"
+#include "gemm_body.h"
 #include <stdlib.h>
 
 namespace {
@@ -182,15 +183,26 @@ struct WgradGroup {
     int first[WG_GROUP + 1];           // first workgroup of each problem; first[n] = total
     int tiles[WG_GROUP], splits[WG_GROUP];
     int n;
+    // Optional passenger (8-wave launches only): the layer's last data-gradient GEMM dx = dx1 + dqkv Wqkv, which depends
+    // on the same dqkv as the weight gradients and on nothing they produce -- its n_tail workgroups lead the grid.
+    mobgt_gemm::GemmParams tail;
+    int n_tail;
 };
 
 template <int NWAVE>
 __global__ __launch_bounds__(NWAVE * 64) void wgrad_group_kernel(const WgradGroup grp) {
+    if constexpr (NWAVE == 8) {
+        if ((int)blockIdx.x < grp.n_tail) {
+            mobgt_gemm::layer_gemm_body<true, mobgt_gemm::EPI_ADD, 2, 8>(grp.tail, blockIdx.x);
+            return;
+        }
+    }
+    const int bid = (int)blockIdx.x - grp.n_tail;
     int q = 0;
 #pragma unroll
     for (int t = 1; t < WG_GROUP; ++t)
-        if (t < grp.n && (int)blockIdx.x >= grp.first[t]) q = t;
-    const int local = blockIdx.x - grp.first[q];
+        if (t < grp.n && bid >= grp.first[t]) q = t;
+    const int local = bid - grp.first[q];
     if (grp.p[q].in_f32) wgrad_body<true, NWAVE>(grp.p[q], local % grp.tiles[q], local / grp.tiles[q], grp.splits[q]);
     else wgrad_body<false, NWAVE>(grp.p[q], local % grp.tiles[q], local / grp.tiles[q], grp.splits[q]);
 }
@@ -220,16 +232,23 @@ int fill_problem(WgradParams& p, const void* g, int64_t ldg, const void* x, int6
 
 }  // namespace
 
-extern "C" int mobgt_linear_wgrad_group(int n, const void* const* g, const int64_t* ldg, const void* const* x,
-                                        const int64_t* ldx, float* const* dw, const int64_t* ldw, float* const* db,
-                                        int64_t R, const int* M, const int* N, int act_dtype, void* stream) {
+namespace {
+int launch_group(int n, const void* const* g, const int64_t* ldg, const void* const* x, const int64_t* ldx, float* const* dw,
+                 const int64_t* ldw, float* const* db, int64_t R, const int* M, const int* N, int act_dtype,
+                 const mobgt_gemm::GemmParams* tail, void* stream) {
     if (act_dtype != MOBGT_BF16 && act_dtype != MOBGT_F32) return MOBGT_EDTYPE;
     if (n < 1 || n > WG_GROUP) return MOBGT_EBADDIM;
     if (R == 0) return 0;
     WgradGroup grp;
     grp.n = n;
+    grp.n_tail = 0;
     int total = 0;
     const int nwave = R <= SHORT_R ? 8 : 16;
+    if (tail) {
+        if (nwave != 8) return MOBGT_EBADDIM;
+        grp.tail = *tail;
+        grp.n_tail = ((tail->M + 31) / 32) * ((tail->N + 31) / 32);
+    }
     for (int q = 0; q < n; ++q) {
         // the problems share the chip: aim at ~256 workgroups for all of them together
         const int rc = fill_problem(grp.p[q], g[q], ldg[q], x[q], ldx[q], dw[q], ldw[q], db ? db[q] : nullptr, R, M[q], N[q],
@@ -240,9 +259,28 @@ extern "C" int mobgt_linear_wgrad_group(int n, const void* const* g, const int64
     }
     for (int q = n; q <= WG_GROUP; ++q) grp.first[q] = total;
     for (int q = n; q < WG_GROUP; ++q) { grp.tiles[q] = 1; grp.splits[q] = 1; grp.p[q] = grp.p[0]; }
-    if (nwave == 8) hipLaunchKernelGGL(wgrad_group_kernel<8>, dim3(total), dim3(8 * 64), 0, (hipStream_t)stream, grp);
+    if (nwave == 8) hipLaunchKernelGGL(wgrad_group_kernel<8>, dim3(total + grp.n_tail), dim3(8 * 64), 0, (hipStream_t)stream, grp);
     else hipLaunchKernelGGL(wgrad_group_kernel<16>, dim3(total), dim3(16 * 64), 0, (hipStream_t)stream, grp);
     return (int)hipGetLastError();
+}
+}  // namespace
+
+extern "C" int mobgt_linear_wgrad_group(int n, const void* const* g, const int64_t* ldg, const void* const* x,
+                                        const int64_t* ldx, float* const* dw, const int64_t* ldw, float* const* db,
+                                        int64_t R, const int* M, const int* N, int act_dtype, void* stream) {
+    return launch_group(n, g, ldg, x, ldx, dw, ldw, db, R, M, N, act_dtype, nullptr, stream);
+}
+
+extern "C" int mobgt_layer_backward_tail(int n, const void* const* g, const int64_t* ldg, const void* const* x,
+                                         const int64_t* ldx, float* const* dw, const int64_t* ldw, float* const* db,
+                                         int64_t R, const int* M, const int* N, int act_dtype, const void* a, int64_t lda,
+                                         const void* b_kn, int64_t ldb, float* c, int64_t ldc, int gM, int gN, int gK,
+                                         void* stream) {
+    if (gM <= 0 || gN <= 0 || gK <= 0 || (gK % 32) || (gN & 7) || (lda & 7) || (ldc & 7) || (ldb & 1)) return MOBGT_EBADDIM;
+    if ((((uintptr_t)a | (uintptr_t)c) & 15) || ((uintptr_t)b_kn & 3)) return MOBGT_EALIGN;
+    mobgt_gemm::GemmParams t = {reinterpret_cast<const uint16_t*>(a), lda, reinterpret_cast<const uint16_t*>(b_kn), ldb, nullptr,
+                                c, ldc, c, nullptr, gM, gN, gK};
+    return launch_group(n, g, ldg, x, ldx, dw, ldw, db, R, M, N, act_dtype, &t, stream);
 }
 
 extern "C" int mobgt_linear_wgrad(const void* g, int64_t ldg, const void* x, int64_t ldx, float* dw, int64_t ldw,

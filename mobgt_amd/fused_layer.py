@@ -62,10 +62,12 @@ class _WgradBatch:
         self.items.append((g, x, dw, db))
         return dw
 
-    def flush(self):
+    def flush(self, tail=None):
+        """One launch for all queued weight gradients; `tail` = (a [M,K] bf16, w [K,N] bf16, c [M,N] f32): c += a @ w rides
+        in the same launch (mobgt_layer_backward_tail).  Returns True if the tail was taken along."""
         it = self.items
         if not it:
-            return
+            return False
         n = len(it)
         R = it[0][0].shape[0]
         vp, i64, ci = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int
@@ -78,9 +80,19 @@ class _WgradBatch:
         ldw = (i64 * n)(*[t[2].shape[1] for t in it])
         M = (ci * n)(*[t[0].shape[1] for t in it])
         N = (ci * n)(*[t[1].shape[1] for t in it])
+        self.items = []
+        if tail is not None and R <= 1024:
+            a, w, c = tail
+            if (a.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and c.dtype == torch.float32 and a.shape[1] % 32 == 0
+                    and w.shape[1] % 8 == 0 and a.is_contiguous() and w.is_contiguous() and c.is_contiguous()):
+                check(_lib.lib().mobgt_layer_backward_tail(n, garr, ldg, xarr, ldx, warr, ldw, barr, R, M, N, _DT[it[0][0].dtype],
+                                                           _p(a), a.stride(0), _p(w), w.stride(0), _p(c), c.stride(0),
+                                                           a.shape[0], w.shape[1], a.shape[1], _stream()),
+                      "mobgt_layer_backward_tail")
+                return True
         check(_lib.lib().mobgt_linear_wgrad_group(n, garr, ldg, xarr, ldx, warr, ldw, barr, R, M, N, _DT[it[0][0].dtype],
                                                   _stream()), "mobgt_linear_wgrad_group")
-        self.items = []
+        return False
 
 
 def _wgrad(g, x, db=None):
@@ -124,6 +136,7 @@ def _mm_tn_f32(g, x):
 
 _ADDMM_OUT_DTYPE = [None]
 import os as _os
+_TAIL = [_os.environ.get("MOBGT_NO_TAIL") != "1"]
 _OWN_GEMM = [_os.environ.get("MOBGT_LIBRARY_GEMM") != "1"]     # MOBGT_LIBRARY_GEMM=1: the layer's GEMMs through torch (A/B runs)
 
 
@@ -304,8 +317,11 @@ class _FusedLayerFn(torch.autograd.Function):
                       cfg.p_att, seed ^ (salt * 0x9E3779B1), sd)
         dqkv2 = dqkv.view(R, 3 * C)
         dwqkv = wb.add(dqkv2, xa, db=dbqkv, sink=k_qkv)
-        wb.flush()
-        if stock:                                                     # back through self_attention_norm
+        # fq variant, own GEMMs: dx = dx1 + dqkv Wqkv rides in the weight-gradient launch
+        rode = wb.flush(tail=(dqkv2, s_wqkv, dx1) if (own and not stock and _TAIL[0]) else None)
+        if rode:
+            dx = dx1
+        elif stock:                                                     # back through self_attention_norm
             dz0 = ops.layer_gemm(dqkv2, s_wqkv, None, True) if own else dqkv2 @ s_wqkv
             dx = torch.empty(R, C, dtype=torch.float32, device=dev)
             _k1_bwd(dz0, None, dx1, x.view(R, C), stats[0], stats[1], nxw, dx, None, dnxw, dnxb, None, R, C, 0.0, seed, sd,

@@ -334,3 +334,34 @@ def test_small_gemm_f32_matches_torch(M, N, K):
             np.testing.assert_allclose(got.cpu().numpy(), want.cpu().numpy(), rtol=2e-5, atol=2e-5 * K ** 0.5)
         np.testing.assert_allclose(ops.small_gemm(a2, b, None, nk).cpu().numpy(), (a2.double() @ bd).float().cpu().numpy(),
                                    rtol=2e-5, atol=2e-5 * K ** 0.5)
+
+
+def test_layer_backward_tail_matches_separate_launches():
+    """mobgt_layer_backward_tail (weight gradients + the dx GEMM in one launch) against mobgt_linear_wgrad_group followed
+    by mobgt_layer_gemm(MOBGT_GEMM_ADD): bit-identical results."""
+    from mobgt_amd import ops
+    from mobgt_amd.fused_layer import _WgradBatch
+    gen = torch.Generator().manual_seed(44)
+    R, C = 599, 192
+    dqkv = torch.randn(R, 3 * C, generator=gen).to(DEV).bfloat16()
+    xa = torch.randn(R, C, generator=gen).to(DEV).bfloat16()
+    dy = torch.randn(R, C, generator=gen).to(DEV).bfloat16()
+    a = torch.randn(R, C, generator=gen).to(DEV).bfloat16()
+    wqkv = torch.randn(3 * C, C, generator=gen).to(DEV).bfloat16()
+    dx1 = torch.randn(R, C, generator=gen).to(DEV)
+    res = []
+    for with_tail in (False, True):
+        wb = _WgradBatch()
+        db = torch.zeros(3 * C, device=DEV)
+        dw1 = wb.add(dqkv, xa, db=db)
+        dw2 = wb.add(dy, a)
+        c = dx1.clone()
+        rode = wb.flush(tail=(dqkv, wqkv, c) if with_tail else None)
+        assert rode == with_tail
+        if not with_tail:
+            ops.layer_gemm(dqkv, wqkv, None, True, ops.GEMM_ADD, aux_in=c)
+        res.append((dw1.clone(), dw2.clone(), db.clone(), c))
+    for u, v in zip(*res):
+        assert torch.equal(u, v)
+    want = dx1.double() + dqkv.double() @ wqkv.double()
+    np.testing.assert_allclose(res[1][3].cpu().numpy(), want.float().cpu().numpy(), rtol=1e-3, atol=1e-2)
