@@ -338,7 +338,7 @@ def test_small_gemm_f32_matches_torch(M, N, K):
 
 def test_layer_backward_tail_matches_separate_launches():
     """mobgt_layer_backward_tail (weight gradients + the dx GEMM in one launch) against mobgt_linear_wgrad_group followed
-    by mobgt_layer_gemm(MOBGT_GEMM_ADD): bit-identical results."""
+    by mobgt_layer_gemm(MOBGT_GEMM_ADD): the same dx bit for bit, the same weight gradients up to atomic ordering."""
     from mobgt_amd import ops
     from mobgt_amd.fused_layer import _WgradBatch
     gen = torch.Generator().manual_seed(44)
@@ -361,7 +361,8 @@ def test_layer_backward_tail_matches_separate_launches():
         if not with_tail:
             ops.layer_gemm(dqkv, wqkv, None, True, ops.GEMM_ADD, aux_in=c)
         res.append((dw1.clone(), dw2.clone(), db.clone(), c))
-    for u, v in zip(*res):
-        assert torch.equal(u, v)
+    for u, v in zip(res[0][:3], res[1][:3]):          # split-R partial tiles meet through f32 atomics: order-dependent rounding
+        np.testing.assert_allclose(u.cpu().numpy(), v.cpu().numpy(), rtol=1e-5, atol=1e-3)
+    assert torch.equal(res[0][3], res[1][3])          # the GEMM itself is deterministic
     want = dx1.double() + dqkv.double() @ wqkv.double()
     np.testing.assert_allclose(res[1][3].cpu().numpy(), want.float().cpu().numpy(), rtol=1e-3, atol=1e-2)
