@@ -647,6 +647,8 @@ class _LinearSplitKFn(torch.autograd.Function):
     def forward(ctx, x, w, b, bf16_wgrad):
         ctx.save_for_backward(x, w)
         ctx.bf16_wgrad = bf16_wgrad
+        if _small_linear(x, w) & 1:
+            return small_gemm(x, w, b, True)
         return torch.addmm(b, x, w.t())
 
     @staticmethod
@@ -659,13 +661,25 @@ class _LinearSplitKFn(torch.autograd.Function):
             # bf16 configuration: weight AND bias gradient from the split-K MFMA kernel (operands rounded to bf16 while
             # loading); the library's split-K path took 27-31 us + a reduce for these 224-wide layers
             dw, db = linear_wgrad(g, x, with_bias=True)
-            return g @ w, dw, db, None
+            return (small_gemm(g, w) if _small_linear(g, w) & 2 else g @ w), dw, db, None
         s = max((c for c in (16, 8, 4, 2) if R % c == 0 and R // c >= 16), default=1)
         if s > 1:
             dw = torch.bmm(g.view(s, R // s, -1).transpose(1, 2), x.view(s, R // s, -1)).sum(0)
         else:
             dw = g.t() @ x
         return g @ w, dw, colsum(g), None
+
+
+_SMALL_LINEAR = int(__import__("os").environ.get("MOBGT_SMALL_LINEAR", "1"))
+
+
+def _small_linear(x, w):
+    """Bit mask (1: forward, 2: data gradient) -- FuseEmbeddings-sized Linear layers on csrc/sgemm.hip."""
+    ok = (x.is_cuda and x.dtype == torch.float32 and w.dtype == torch.float32 and x.dim() == 2 and x.shape[0] <= 1024
+          and max(w.shape) <= 512 and x.stride(1) == 1 and w.is_contiguous())
+    if not ok:
+        return 0
+    return _SMALL_LINEAR if x.shape[0] <= 64 else (_SMALL_LINEAR & 1)     # data gradient: the head's 16 rows only
 
 
 def linear_splitk(x, weight, bias, bf16_wgrad=False):
