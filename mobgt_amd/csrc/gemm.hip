@@ -62,5 +62,6 @@ extern "C" int mobgt_layer_gemm(const void* a, int64_t lda, const void* b, int64
     const bool narrow = K >= 512 && tiles64 < 128;
     hipStream_t st = (hipStream_t)stream;
     if (narrow) return b_is_kn ? launch<true, 2, 8>(p, epilogue, st) : launch<false, 2, 8>(p, epilogue, st);
+    if (tiles64 < 128) return b_is_kn ? launch<true, 2, 4>(p, epilogue, st) : launch<false, 2, 4>(p, epilogue, st);
     return b_is_kn ? launch<true, 4, 4>(p, epilogue, st) : launch<false, 4, 4>(p, epilogue, st);
 }

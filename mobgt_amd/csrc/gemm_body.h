@@ -6,8 +6,9 @@
 namespace mobgt_gemm {
 
 constexpr int BM = 32, KSTEP = 32;
-// Two tilings: 32x64 outputs / 4 waves, and -- long K, narrow N (FFN layer 2 and its data gradient: 57 tiles of the
-// first kind, 8 serial k-steps per wave) -- 32x32 outputs / 8 waves.  NB = number of 16-column MFMA operands.
+// Tilings: 32x64 outputs / 4 waves; when that gives < 128 workgroups (N = C: output projection, FFN layer 2 and their
+// data gradients), 32x32 outputs with 4 waves (K < 512) or 8 waves (K >= 512: 8 serial k-steps per wave otherwise).
+// NB = number of 16-column MFMA operands.
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
 enum { EPI_BIAS = 0, EPI_GELU = 1, EPI_GELU_BWD = 2, EPI_ADD = 3 };
