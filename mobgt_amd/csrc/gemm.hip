@@ -26,7 +26,8 @@ using namespace mobgt_gemm;
 
 template <bool BKN, int EPI, int NB, int NW>
 __global__ __launch_bounds__(NW * 64) void layer_gemm_kernel(const GemmParams p) {
-    layer_gemm_body<BKN, EPI, NB, NW>(p, blockIdx.x);
+    __shared__ __attribute__((aligned(16))) float lds[gemm_lds_floats<NB, NW>()];
+    layer_gemm_body<BKN, EPI, NB, NW>(p, blockIdx.x, lds);
 }
 
 

@@ -67,11 +67,14 @@ template <int NB> struct Frags<true, NB> {
     }
 };
 
+// LDS floats the body needs (the caller owns the buffer, so that kernels hosting several bodies can overlay them)
+template <int NB, int NW> constexpr int gemm_lds_floats() { return NW * BM * (16 * NB + 4); }
+
 template <bool BKN, int EPI, int NB, int NW>
-__device__ __forceinline__ void layer_gemm_body(const GemmParams& p, const int bid) {
+__device__ __forceinline__ void layer_gemm_body(const GemmParams& p, const int bid, float* __restrict__ lds) {
     constexpr int BN = 16 * NB;
     constexpr int LDP = BN + 4;                  // LDS row stride (floats): the lanes of one store spread over all banks
-    __shared__ float part[NW][BM * LDP];
+    float (*part)[BM * LDP] = reinterpret_cast<float (*)[BM * LDP]>(lds);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i = lane & 15, kq = lane >> 4;
     const int tiles_n = (p.N + BN - 1) / BN;

@@ -81,10 +81,15 @@ struct Slab {
 
 // NWAVE waves per workgroup: 16, or 8 when R is short (R = 608: 19 k-steps -- sixteen waves would mostly idle, and a
 // 1024-thread workgroup leaves room for only two per CU where the grouped launch wants 528 of them at once)
+// LDS (owned by the kernel, so that the f32 / bf16 instantiations and a passenger GEMM body overlay one buffer): NWAVE/2
+// partial tiles -- the upper half of the waves hand their tiles to the lower half first -- and NWAVE column partials
+template <int NWAVE> constexpr int wgrad_lds_floats() { return (NWAVE / 2) * TILE * TILE + NWAVE * TILE; }
+
 template <bool F32, int NWAVE>
-__device__ __forceinline__ void wgrad_body(const WgradParams& p, const int tile, const int split, const int nsplit) {
-    __shared__ float part[NWAVE / 2][TILE * TILE];     // the upper half of the waves hand their tiles to the lower half first
-    __shared__ float colpart[NWAVE][TILE];
+__device__ __forceinline__ void wgrad_body(const WgradParams& p, const int tile, const int split, const int nsplit,
+                                           float* __restrict__ lds) {
+    float (*part)[TILE * TILE] = reinterpret_cast<float (*)[TILE * TILE]>(lds);
+    float (*colpart)[TILE] = reinterpret_cast<float (*)[TILE]>(lds + (NWAVE / 2) * TILE * TILE);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i = lane & 15, kq = lane >> 4;
     const int m0 = (tile / p.tiles_n) * TILE, n0 = (tile % p.tiles_n) * TILE;
@@ -170,8 +175,9 @@ __device__ __forceinline__ void wgrad_body(const WgradParams& p, const int tile,
 
 template <int NWAVE>
 __global__ __launch_bounds__(NWAVE * 64) void wgrad_kernel(const WgradParams p) {
-    if (p.in_f32) wgrad_body<true, NWAVE>(p, blockIdx.x, blockIdx.y, gridDim.y);
-    else wgrad_body<false, NWAVE>(p, blockIdx.x, blockIdx.y, gridDim.y);
+    __shared__ __attribute__((aligned(16))) float lds[wgrad_lds_floats<NWAVE>()];
+    if (p.in_f32) wgrad_body<true, NWAVE>(p, blockIdx.x, blockIdx.y, gridDim.y, lds);
+    else wgrad_body<false, NWAVE>(p, blockIdx.x, blockIdx.y, gridDim.y, lds);
 }
 
 // Up to 32 independent problems in ONE launch (the four Linear layers of every encoder layer: nothing depends on a
@@ -191,9 +197,11 @@ struct WgradGroup {
 
 template <int NWAVE>
 __global__ __launch_bounds__(NWAVE * 64) void wgrad_group_kernel(const WgradGroup grp) {
+    constexpr int LDS_W = wgrad_lds_floats<NWAVE>(), LDS_G = NWAVE == 8 ? mobgt_gemm::gemm_lds_floats<2, 8>() : 0;
+    __shared__ __attribute__((aligned(16))) float lds[LDS_W > LDS_G ? LDS_W : LDS_G];      // one body runs per workgroup
     if constexpr (NWAVE == 8) {
         if ((int)blockIdx.x < grp.n_tail) {
-            mobgt_gemm::layer_gemm_body<true, mobgt_gemm::EPI_ADD, 2, 8>(grp.tail, blockIdx.x);
+            mobgt_gemm::layer_gemm_body<true, mobgt_gemm::EPI_ADD, 2, 8>(grp.tail, blockIdx.x, lds);
             return;
         }
     }
@@ -203,8 +211,8 @@ __global__ __launch_bounds__(NWAVE * 64) void wgrad_group_kernel(const WgradGrou
     for (int t = 1; t < WG_GROUP; ++t)
         if (t < grp.n && bid >= grp.first[t]) q = t;
     const int local = bid - grp.first[q];
-    if (grp.p[q].in_f32) wgrad_body<true, NWAVE>(grp.p[q], local % grp.tiles[q], local / grp.tiles[q], grp.splits[q]);
-    else wgrad_body<false, NWAVE>(grp.p[q], local % grp.tiles[q], local / grp.tiles[q], grp.splits[q]);
+    if (grp.p[q].in_f32) wgrad_body<true, NWAVE>(grp.p[q], local % grp.tiles[q], local / grp.tiles[q], grp.splits[q], lds);
+    else wgrad_body<false, NWAVE>(grp.p[q], local % grp.tiles[q], local / grp.tiles[q], grp.splits[q], lds);
 }
 
 int fill_problem(WgradParams& p, const void* g, int64_t ldg, const void* x, int64_t ldx, float* dw, int64_t ldw, float* db,
