@@ -363,9 +363,11 @@ int mobgt_adamw_flat(float* params, const float* grads, float* exp_avg, float* e
 /* Small f32 GEMMs of the GCN / FuseEmbeddings / head path (graphormer/modelGNN.py:38-44; model_fqandtoyo.py:444-456 and
  * the data gradients autograd derives from them): c[M,N] = a[M,K] x B (+ bias[N]), all f32, full-f32 products on the
  * matrix core, one wave per 16-row output tile.  b_is_nk = 0: b is [K,N] (x @ W, adj @ support, g @ W);
- * b_is_nk = 1: b is [N,K] (F.linear's weight, g @ W^T).  Any M, N, K >= 1 and any row strides (elements). */
-int mobgt_small_gemm_f32(const float* a, int64_t lda, const float* b, int64_t ldb, int b_is_nk, const float* bias, float* c,
-                         int64_t ldc, int M, int N, int K, void* stream);
+ * b_is_nk = 1: b is [N,K] (F.linear's weight, g @ W^T).  Any M, N, K >= 1 and any row strides (elements).
+ * c_dtype MOBGT_F32, or MOBGT_BF16: the result rounded to bf16 on the way out (`support` as the bf16 adjacency
+ * product's operand -- no cast launch). */
+int mobgt_small_gemm_f32(const float* a, int64_t lda, const float* b, int64_t ldb, int b_is_nk, const float* bias, void* c,
+                         int64_t ldc, int c_dtype, int M, int N, int K, void* stream);
 
 /* The encoder layer's small GEMMs with the following elementwise step fused (graphormer/model.py:388-403, 406-463;
  * model_fqandtoyo.py:1641-1712 and the autograd of those F.linear calls): bf16 operands, f32 accumulate.

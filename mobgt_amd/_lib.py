@@ -61,7 +61,7 @@ SIGNATURES = {
     "mobgt_head_act_fwd": (_i, [_vp] * 6 + [_i, _i, _f, _f, _f, _u64, _vp, _c.c_uint32, _vp]),
     "mobgt_head_act_bwd": (_i, [_vp] * 9 + [_i, _i, _f, _f, _f, _u64, _vp, _c.c_uint32, _vp]),
     "mobgt_adamw_flat": (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _vp]),
-    "mobgt_small_gemm_f32": (_i, [_vp, _i64, _vp, _i64, _i, _vp, _vp, _i64, _i, _i, _i, _vp]),
+    "mobgt_small_gemm_f32": (_i, [_vp, _i64, _vp, _i64, _i, _vp, _vp, _i64, _i, _i, _i, _i, _vp]),
     "mobgt_layer_gemm": (_i, [_vp, _i64, _vp, _i64, _i, _vp, _vp, _i64, _i, _vp, _vp, _i, _i, _i, _vp]),
     "mobgt_step_prologue": (_i, [_vp, _i64, _vp, _i64, _vp, _vp]),
     "mobgt_head_input_fwd": (_i, [_vp, _vp, _i, _i64, _vp, _i64, _vp, _i, _i, _i, _i, _vp]),

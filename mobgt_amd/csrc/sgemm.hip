@@ -19,7 +19,8 @@ struct SgemmParams {
     const float* A; int64_t lda;
     const float* B; int64_t ldb;
     const float* bias;
-    float* C; int64_t ldc;
+    void* C; int64_t ldc;
+    int c_bf16;                                  // store the result as bf16 (the adjacency product's operand) instead of f32
     int M, N, K;
 };
 
@@ -91,7 +92,10 @@ __global__ __launch_bounds__(64) void sgemm_kernel(const SgemmParams p) {
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
             const int r = m0 + 4 * kq + v;
-            if (r < p.M) p.C[(int64_t)r * p.ldc + c] = acc[b][v] + bv;
+            if (r < p.M) {
+                if (p.c_bf16) reinterpret_cast<bf16_t*>(p.C)[(int64_t)r * p.ldc + c] = (bf16_t)(acc[b][v] + bv);
+                else reinterpret_cast<float*>(p.C)[(int64_t)r * p.ldc + c] = acc[b][v] + bv;
+            }
         }
     }
 }
@@ -113,10 +117,11 @@ int launch(const SgemmParams& p, bool b_nk, bool vec, hipStream_t st) {
 }  // namespace
 
 extern "C" int mobgt_small_gemm_f32(const float* a, int64_t lda, const float* b, int64_t ldb, int b_is_nk, const float* bias,
-                                    float* c, int64_t ldc, int M, int N, int K, void* stream) {
+                                    void* c, int64_t ldc, int c_dtype, int M, int N, int K, void* stream) {
     if (M <= 0 || N <= 0 || K <= 0) return MOBGT_EBADDIM;
-    if (((uintptr_t)a | (uintptr_t)b | (uintptr_t)c) & 3) return MOBGT_EALIGN;
-    SgemmParams p = {a, lda, b, ldb, bias, c, ldc, M, N, K};
+    if (c_dtype != MOBGT_F32 && c_dtype != MOBGT_BF16) return MOBGT_EDTYPE;
+    if ((((uintptr_t)a | (uintptr_t)b) & 3) || ((uintptr_t)c & (c_dtype == MOBGT_F32 ? 3 : 1))) return MOBGT_EALIGN;
+    SgemmParams p = {a, lda, b, ldb, bias, c, ldc, c_dtype == MOBGT_BF16, M, N, K};
     // float4 operand loads: every row 16-byte aligned and K a whole number of 16-deep steps
     const bool vec = (K % 16 == 0) && (lda % 4 == 0) && (((uintptr_t)a & 15) == 0) &&
                      (!b_is_nk || ((ldb % 4 == 0) && (((uintptr_t)b & 15) == 0)));

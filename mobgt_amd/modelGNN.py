@@ -57,14 +57,14 @@ import os as _os
 _SMALL_GEMM = _os.environ.get("MOBGT_SMALL_GEMM", "1") != "0"
 
 
-def _mm_small(a, b, b_is_nk=False):
+def _mm_small(a, b, b_is_nk=False, out_dtype=torch.float32):
     """a @ b (or a @ b.T) in f32.  Short contractions (K <= 64: the GCN's `input @ weight` and its data gradient) go to the
     one-wave-per-tile MFMA kernel of csrc/sgemm.hip; the library's kernels for such shapes are all ramp-up."""
     if _SMALL_GEMM and a.is_cuda and a.shape[1] <= 64 and a.dtype == torch.float32 and b.dtype == torch.float32 \
             and a.stride(1) == 1 and b.stride(1) == 1:
         from . import ops
-        return ops.small_gemm(a, b, None, b_is_nk)
-    return a @ (b.t() if b_is_nk else b)
+        return ops.small_gemm(a, b, None, b_is_nk, out_dtype=out_dtype)
+    return (a @ (b.t() if b_is_nk else b)).to(out_dtype)
 
 
 def _colsum(g):
@@ -79,8 +79,8 @@ class _GraphConvFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, bias, adj, adj_t=None):
-        support = _mm_small(x, weight)
-        out = _mm_f32(adj, support.to(adj.dtype), bias)             # bias in the GEMM epilogue, fp32 result
+        support = _mm_small(x, weight, out_dtype=adj.dtype)         # (bf16 adjacency: rounded on the way out, no cast launch)
+        out = _mm_f32(adj, support, bias)                           # bias in the GEMM epilogue, fp32 result
         ctx.save_for_backward(x, weight, adj, adj_t)
         ctx.has_bias = bias is not None
         return out
@@ -108,9 +108,9 @@ class _RowsConvFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, adj, rows):
         from . import ops
-        support = _mm_small(x, weight)                                 # [P,C] f32
+        support = _mm_small(x, weight, out_dtype=torch.bfloat16)       # [P,C], rounded to bf16 on the way out
         a_rows, a_rows_t = ops.gather_rows_t(adj, rows)                # [R,P] and its transpose [P,R], one pass
-        out = ops.linear_wgrad(a_rows_t, support.to(torch.bfloat16))[0]     # [R,C] f32
+        out = ops.linear_wgrad(a_rows_t, support)[0]                   # [R,C] f32
         if bias is not None:
             out = out + bias
         ctx.save_for_backward(x, weight, a_rows)

@@ -895,7 +895,7 @@ def assemble_tokens(nf, real, add, token, pe0, p_pos, p_in, training, salts=(0x1
 
 
 # ------------------------------------------------------------------- small f32 GEMMs (GCN / fuse / head)
-def small_gemm(a, b, bias=None, b_is_nk=False, out=None):
+def small_gemm(a, b, bias=None, b_is_nk=False, out=None, out_dtype=torch.float32):
     """a [M,K] @ (b.T if b_is_nk else b) (+ bias) -> f32 [M,N] on csrc/sgemm.hip (one wave per 16-row tile, f32 MFMA).
     No autograd.  Operands may be row-strided views (unit column stride)."""
     _require_cuda(a, b)
@@ -906,9 +906,9 @@ def small_gemm(a, b, bias=None, b_is_nk=False, out=None):
     assert (b.shape[1] if b_is_nk else b.shape[0]) == K
     if bias is not None:
         assert bias.dtype == torch.float32 and bias.numel() == N and bias.is_contiguous()
-    c = out if out is not None else torch.empty(M, N, dtype=torch.float32, device=a.device)
+    c = out if out is not None else torch.empty(M, N, dtype=out_dtype, device=a.device)
     check(_lib.lib().mobgt_small_gemm_f32(_p(a), a.stride(0), _p(b), b.stride(0), int(b_is_nk), _p(bias), _p(c), c.stride(0),
-                                          M, N, K, _stream()), "mobgt_small_gemm_f32")
+                                          _DT[c.dtype], M, N, K, _stream()), "mobgt_small_gemm_f32")
     return c
 
 

@@ -334,6 +334,8 @@ def test_small_gemm_f32_matches_torch(M, N, K):
             np.testing.assert_allclose(got.cpu().numpy(), want.cpu().numpy(), rtol=2e-5, atol=2e-5 * K ** 0.5)
         np.testing.assert_allclose(ops.small_gemm(a2, b, None, nk).cpu().numpy(), (a2.double() @ bd).float().cpu().numpy(),
                                    rtol=2e-5, atol=2e-5 * K ** 0.5)
+        # bf16 result = the f32 result rounded
+        assert torch.equal(ops.small_gemm(a2, b, bias, nk, out_dtype=torch.bfloat16), ops.small_gemm(a2, b, bias, nk).bfloat16())
 
 
 def test_layer_backward_tail_matches_separate_launches():
