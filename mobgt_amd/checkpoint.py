@@ -28,7 +28,12 @@ def load_lightning_checkpoint(model, path_or_dict, strict=False):
     bad = [k for k, v in sd.items() if k in own and tuple(own[k].shape) != tuple(v.shape)]
     if bad:
         raise ValueError("checkpoint tensors with a different shape than the model's: " + ", ".join(bad[:8]))
-    return model.load_state_dict(sd, strict=strict)        # bf16 shadow weights are re-derived every forward
+    res = model.load_state_dict(sd, strict=strict)
+    # stand-alone models re-derive their bf16 shadow weights every forward; shadows owned by a train.TrainStep built
+    # BEFORE this load are refreshed here (its optimizer kernel only rewrites them at the next step)
+    from .model import sync_external_shadows
+    sync_external_shadows(model)
+    return res
 
 
 def save_lightning_checkpoint(model, path, **extra):

@@ -217,6 +217,15 @@ def refresh_shadows(layers):
         torch._foreach_copy_(dst, src)
 
 
+def sync_external_shadows(model):
+    """bf16 shadow weights owned by a trainer (train.TrainStep keeps them current from inside its optimizer kernel) go
+    stale when something else writes the parameters; writers call this to have them re-derived."""
+    ref = model.__dict__.get("_shadow_sync")
+    fn = ref() if ref is not None else None
+    if fn is not None:
+        fn()
+
+
 class EncoderLayer(nn.Module):
     """model.py:463-489 (pre-LN)."""
     fused = True                 # one fused autograd node per layer on the GPU; False = op-by-op torch + HIP attention

@@ -325,7 +325,37 @@ class Graphormer(nn.Module):
                                    self.input_dropout.p, self.training,
                                    bf16_copy=self.act_dtype == torch.bfloat16 and getattr(self.layers[0], "fused", False))
 
+    def validate_batch(self, batched_data):
+        """Index ranges nn.Embedding would check in the reference (IndexError there; the gather kernels here do not
+        bounds-check per element).  One reduction + one host read per batch OBJECT, remembered on it -- so a
+        pre-collated batch is checked in the eager dry run and costs nothing inside a captured step."""
+        if getattr(batched_data, "_mobgt_validated", None) is self or not batched_data.x.is_cuda:
+            return
+        if torch.cuda.is_current_stream_capturing():
+            return
+        P = self.X.shape[0]
+        lim = [("x", batched_data.x, P + 1), ("in_degree", batched_data.in_degree, self.in_degree_encoder.num_embeddings),
+               ("out_degree", batched_data.out_degree, self.out_degree_encoder.num_embeddings),
+               ("rel_pos", batched_data.rel_pos, self.rel_pos_encoder.num_embeddings),
+               ("poi_pos", batched_data.poi_pos, self.poi_pos_encoder.num_embeddings),
+               ("edge_input", batched_data.edge_input, self.edge_encoder.num_embeddings),
+               ("user", batched_data.user, self.num_users + 1),
+               ("y", batched_data.y, self.out_proj.out_features + 1)]
+        mx = torch.stack([t.max().long() if t.numel() else torch.zeros((), dtype=torch.long, device=t.device)
+                          for _, t, _ in lim]).tolist()
+        tmax = float(batched_data.time_normal.max()) if batched_data.time_normal.numel() else 0.0
+        for (name, _, n), m in zip(lim, mx):
+            if m >= n:
+                raise IndexError(f"batch.{name} has index {m}, out of range for a table of {n} rows")
+        if int(tmax * 48) >= self.time_embed_model_48.num_embeddings:
+            raise IndexError(f"batch.time_normal {tmax} maps to a time slot outside the {self.time_embed_model_48.num_embeddings}-row table")
+        try:
+            batched_data._mobgt_validated = self
+        except AttributeError:
+            pass
+
     def forward(self, batched_data, perturb=None):
+        self.validate_batch(batched_data)
         bias = self.assemble_bias(batched_data)
         refresh_shadows(self.layers)
         output = self.node_features(batched_data)

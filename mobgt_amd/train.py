@@ -16,7 +16,8 @@ import torch
 import torch.distributed as dist
 
 from . import ops
-from .lr import PolynomialDecayLR
+from .model import sync_external_shadows
+from .lr import polynomial_decay_lr
 
 
 def flat_offsets(params, align=8):
@@ -153,15 +154,21 @@ class FlatParams:
                     m._bqkv = flat[bo:bo + 3 * C]
 
 
-def used_parameters(model, loss_fn):
-    """One dry-run backward: the parameters that receive a gradient (the others stay grad=None)."""
+def used_parameters(model, loss_fns):
+    """Dry-run backward passes: the parameters that receive a gradient from ANY of them (the others stay grad=None,
+    as under the reference, whose optimizer then skips them).  `loss_fns`: one callable per pre-collated batch -- a
+    parameter may be reached on some batches only."""
+    if callable(loss_fns):
+        loss_fns = [loss_fns]
+    hit = set()
+    for fn in loss_fns:
+        for p in model.parameters():
+            p.grad = None
+        fn().backward()
+        hit |= {id(p) for p in model.parameters() if p.grad is not None}
     for p in model.parameters():
         p.grad = None
-    loss_fn().backward()
-    used = [p for p in model.parameters() if p.grad is not None]
-    for p in model.parameters():
-        p.grad = None
-    return used
+    return [p for p in model.parameters() if id(p) in hit]
 
 
 def broadcast_parameters(model, src=0):
@@ -169,6 +176,7 @@ def broadcast_parameters(model, src=0):
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
         for t in list(model.parameters()) + list(model.buffers()):
             dist.broadcast(t.data, src)
+        sync_external_shadows(model)
 
 
 class TrainStep:
@@ -192,7 +200,7 @@ class TrainStep:
         # created on the stream of the first backward and must match the capture stream later on.
         self.stream = torch.cuda.Stream(device=dev) if use_graph else None
         with self._on_stream():
-            used = used_parameters(model, lambda: self._loss(batches[0]))
+            used = used_parameters(model, [lambda b=b: self._loss(b) for b in batches])
         used = flat_order(model, used)
         self.flat = FlatGrads(used)
         self.n_head = len(head_parameters(model, used))              # params[:n_head] = the early bucket
@@ -215,7 +223,7 @@ class TrainStep:
         # PolynomialDecayLR with power 1 is evaluated inside the optimizer kernel from the device step counter (no
         # per-step host write of the learning rate); `lr_dev` mirrors it for inspection and serves any other schedule
         s = self.sched_state
-        # (5th entry: offset between the kernel's step count and the schedule's -- prepare() runs one warm-up call)
+        # (5th entry: offset between the kernel's step count t and the schedule's step_count; both start at 1)
         self.sched_dev = torch.tensor([float(s["warmup"]), float(s["tot"]), float(s["lr"]), float(s["end_lr"]), 0.0],
                                       dtype=torch.float32, device=dev) if s["power"] == 1.0 and s["warmup"] > 0 else None
         self._set_lr()
@@ -229,6 +237,7 @@ class TrainStep:
         self.overlap = bool(overlap and use_graph and (self.world > 1 or overlap == "force") and self.n_head > 0
                             and hasattr(model, "_enc_out"))
         self.graphs_b, self._g_enc, self._loss_slots = {}, {}, {}
+        self.comm = True        # False: skip the gradient exchange (bench.py measures the exposed all-reduce time that way)
 
     def _attach_shadows(self):
         """bf16 copy of the whole flat parameter buffer; the fused layers' shadow weights become views of it, kept
@@ -240,6 +249,7 @@ class TrainStep:
         flat = self.flat_params.tensor.detach()
         shadow = flat.to(torch.bfloat16)
         base = flat.data_ptr()
+        plan = []
         for layer in layers:
             mha = layer.self_attention
             wqkv, bqkv = mha.fuse_qkv_storage()
@@ -249,11 +259,23 @@ class TrainStep:
             for m in masters:
                 off = (m.data_ptr() - base) // 4
                 if off < 0 or off + m.numel() > flat.numel() or not m.is_contiguous():
-                    return None                                         # not a slice of the flat buffer: keep the copies
+                    return None                      # not a slice of the flat buffer: every layer keeps its own copies
                 views.append(shadow[off:off + m.numel()].view(m.shape))
-            layer._shadows = tuple(views)
+            plan.append((layer, tuple(views)))
+        for layer, views in plan:                    # all layers validated: only now hand the views over
+            layer._shadows = views
             layer._shadow_external = True
+        import weakref
+        self.model._shadow_sync = weakref.WeakMethod(self.sync_shadows)
         return shadow
+
+    def sync_shadows(self):
+        """Re-derive the bf16 shadow weights from the fp32 masters.  The optimizer kernel keeps them current step by
+        step; anything ELSE that writes parameters after this TrainStep was built (checkpoint load, broadcast, manual
+        edits) must call this (checkpoint.load_lightning_checkpoint and train.broadcast_parameters do)."""
+        if getattr(self, "shadow_flat", None) is not None:
+            with torch.no_grad():
+                self.shadow_flat.copy_(self.flat_params.tensor)
 
     def _opt_step(self):
         from . import _lib
@@ -281,17 +303,9 @@ class TrainStep:
     # learning rate of lr.py:17-31, kept in a device scalar so captured optimizer graphs see it
     def _set_lr(self):
         s = self.sched_state
-        c = s["step_count"]
-        if c <= s["warmup"]:
-            lr = c / float(s["warmup"]) * s["lr"]
-        elif c >= s["tot"]:
-            lr = s["end_lr"]
-        else:
-            pct = 1 - (c - s["warmup"]) / (s["tot"] - s["warmup"])
-            lr = (s["lr"] - s["end_lr"]) * pct ** s["power"] + s["end_lr"]
-        self.lr = lr
+        self.lr = polynomial_decay_lr(s["step_count"], s["warmup"], s["tot"], s["lr"], s["end_lr"], s["power"])
         if self.sched_dev is None:
-            self.lr_dev.fill_(lr)
+            self.lr_dev.fill_(self.lr)
 
     def _loss(self, batch):
         if self.autocast_dtype is not None:
@@ -377,10 +391,21 @@ class TrainStep:
         self.pool = torch.cuda.graph_pool_handle()
         for i in range(len(self.batches)):
             self.graphs[i] = self._capture(i)
+        # One eager optimizer call before the capture (first-launch initialisation must not happen inside a capture),
+        # made side-effect free: parameters, shadows and both Adam moments are put back, so the first replayed step is
+        # AdamW's t = 1 on fresh moments, exactly like torch.optim.AdamW's first step -- on every rank alike.
         with self._on_stream():
-            if self.sched_dev is not None:
-                self.sched_dev[4] = -1.0             # the warm-up call is optimizer call 1 and runs at lr(0) = 0
-            self._opt_step()
+            with torch.no_grad():
+                saved = self.flat_params.tensor.detach().clone()
+                self._step_base = int(self.seed_dev.item()) - 1
+                self._opt_step()
+                self.flat_params.tensor.copy_(saved)
+                self.exp_avg.zero_()
+                self.exp_avg_sq.zero_()
+                self.flat.flat.zero_()
+                self.sync_shadows()
+            # every later prologue (one per replayed step) advances the counter by one: t = counter - base = 1, 2, ...
+            self._step_base = int(self.seed_dev.item())
         self._join()
         self.opt_graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.opt_graph, stream=self.stream):
@@ -393,11 +418,12 @@ class TrainStep:
         if self.overlap:
             j = i % len(self.batches)
             na = self.n_head_elems
+            comm = self.world > 1 and self.comm
             self.graphs[j].replay()
-            if self.world > 1:
+            if comm:
                 wa = dist.all_reduce(self.flat.flat[:na], op=dist.ReduceOp.SUM, async_op=True)   # overlaps phase B
             self.graphs_b[j].replay()
-            if self.world > 1:
+            if comm:
                 wb = dist.all_reduce(self.flat.flat[na:], op=dist.ReduceOp.SUM, async_op=True)
                 wa.wait()
                 wb.wait()
@@ -407,7 +433,7 @@ class TrainStep:
                 self.graphs[i % len(self.batches)].replay()
             else:
                 self._fwd_bwd(self.batches[i % len(self.batches)])
-            if self.world > 1:
+            if self.world > 1 and self.comm:
                 self.flat.all_reduce_mean()
         if self.use_graph:
             self.opt_graph.replay()

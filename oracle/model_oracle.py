@@ -132,10 +132,15 @@ def graphormer_stock_forward(sd, batch, n_layers, H, D, p=0.0, p_in=0.0, p_att=0
 
 
 # ------------------------------------------------------------------------------------ fq Graphormer
-def calculate_laplacian_matrix(adj_mat):
-    """model_fqandtoyo.py:456-486, mat_type 'hat_rw_normd_lap_mat': (D+I)^-1 (A+I), row-sum degrees."""
+def calculate_laplacian_matrix(adj_mat, diag_inverse=False):
+    """model_fqandtoyo.py:456-486, mat_type 'hat_rw_normd_lap_mat': (D+I)^-1 (A+I), row-sum degrees.
+    `diag_inverse`: D+I is diagonal, so its inverse is the reciprocal of the diagonal -- the same matrix without the
+    reference's O(P^3) `matrix_power(-1)` (a minute at P = 7856); tests/test_oracle_model.py pins the two against each
+    other at P = 64."""
     adj = np.asarray(adj_mat, dtype=np.float64)
     n = adj.shape[0]
+    if diag_inverse:
+        return (adj + np.identity(n)) / (np.sum(adj, axis=1) + 1.0)[:, None]
     deg = np.diag(np.sum(adj, axis=1))
     return np.matmul(np.linalg.matrix_power(deg + np.identity(n), -1), adj + np.identity(n))
 
@@ -146,9 +151,10 @@ def freedman_diaconis_bins(x):
     return int(np.ceil((np.max(x) - np.min(x)) / binsize))
 
 
-def fq_constants(uni, dataset_name):
+def fq_constants(uni, dataset_name, diag_inverse=False, num_bins=None):
     """The non-trainable tensors `model_fqandtoyo.Graphormer.__init__` derives from Graph_*.csv and the
-    distance pickle (:650-700 gowalla, :787-838 foursquaregraph)."""
+    distance pickle (:650-700 gowalla, :787-838 foursquaregraph).  `diag_inverse`: see calculate_laplacian_matrix;
+    `num_bins`: skip the Freedman-Diaconis pass over the distance matrix (the caller knows the table size)."""
     raw_X = uni.poi_table
     cats = raw_X[:, 4]
     uniq = np.unique(cats)                               # OneHotEncoder category order = sorted unique
@@ -161,17 +167,18 @@ def fq_constants(uni, dataset_name):
     X[:, num_cats + 1] = raw_X[:, 2]
     X[:, num_cats + 2] = raw_X[:, 3]
     C_X = (np.arange(1, num_cats + 1)[:, None] == uniq[None, :]).astype(np.float32)
-    d = uni.distance
-    if dataset_name == "foursquaregraph":
-        dm = np.delete(d, 0, axis=0)                     # :893-894: only the row delete takes effect
-    else:
-        dm = np.delete(np.delete(d, 0, axis=0), 0, axis=1)
-    num_bins = freedman_diaconis_bins(dm - dm.min())
+    if num_bins is None:
+        d = uni.distance
+        if dataset_name == "foursquaregraph":
+            dm = np.delete(d, 0, axis=0)                 # :893-894: only the row delete takes effect
+        else:
+            dm = np.delete(np.delete(d, 0, axis=0), 0, axis=1)
+        num_bins = freedman_diaconis_bins(dm - dm.min())
     return SimpleNamespace(
         X=torch.from_numpy(X),
-        D_A=torch.from_numpy(calculate_laplacian_matrix(uni.graph_dist)).float(),
+        D_A=torch.from_numpy(calculate_laplacian_matrix(uni.graph_dist, diag_inverse)).float(),
         C_X=torch.from_numpy(C_X),
-        C_A=torch.from_numpy(calculate_laplacian_matrix(uni.graph_cat)).float(),
+        C_A=torch.from_numpy(calculate_laplacian_matrix(uni.graph_cat, diag_inverse)).float(),
         poi2cat={int(r[0]): int(r[4]) for r in raw_X},
         num_cats=num_cats, num_bins=num_bins, P=P,
     )

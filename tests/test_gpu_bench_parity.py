@@ -1,0 +1,178 @@
+"""Oracle parity of the configuration `bench.py` actually times: the S-FSQ model built by
+`mobgt_amd.workloads.build("fsq")` -- P = 7856, 6 layers, bf16 bias / activations / GCN adjacency, `rows_only` last GCN
+layer (`modelGNN._RowsConvFn`), fused encoder layers -- on two S-FSQ batches, against `oracle.model_oracle` in fp32 on
+the CPU (reference: model_fqandtoyo.py:1123-1432, modelGNN.py:38-74).
+
+Tolerances (bf16 operands with fp32 accumulation on the GPU side, fp32 reference):
+  logits          max |err| <= 3e-2            (values are O(1))
+  loss            rtol 2e-3
+  gradients       ELEMENTWISE: |err| <= 0.08 * rms(ref) + 0.05 * |ref|, and relative L2 error <= 4e-2 --
+                  a transposed / permuted / mis-scaled gradient fails both.
+Checked once eagerly (model.eval()) and once through `TrainStep(use_graph=True)` (hipGraph replay, flat gradient
+buffer, gradient sinks) with every dropout rate 0, i.e. the very code path the benchmark replays.
+"""
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from mobgt_amd import synth, workloads                              # noqa: E402
+from oracle import model_oracle as mo                                # noqa: E402
+
+DEV = "cuda"
+GRAD_PARAMS = ["out_proj.weight", "out_proj.bias", "layers.0.self_attention.linear_q.weight", "layers.3.self_attention.linear_k.weight",
+               "layers.5.self_attention.linear_v.weight", "layers.2.self_attention.output_layer.weight", "layers.1.ffn.layer1.weight",
+               "layers.4.ffn.layer2.weight", "layers.5.ffn_norm1.weight", "layers.0.ffn_norm2.bias", "rel_pos_encoder.weight",
+               "poi_pos_encoder.weight", "edge_encoder.weight", "edge_dis_encoder.weight", "graph_token_virtual_distance.weight",
+               "poi_distance_model.gcn.0.weight", "poi_distance_model.gcn.1.weight", "poi_distance_model.gcn.2.weight",
+               "poi_distance_model.gcn.2.bias", "poi_cat_model.gcn.2.weight", "embed_fuse_model2.fuse_embed.weight",
+               "embed_fuse_model4.fuse_embed.weight", "embed_fuse_model3.fuse_embed.weight", "time_embed_model_48.weight",
+               "in_degree_encoder.weight", "pos_embed.pe", "graph_token.weight", "user_embed_model.user_embedding.weight"]
+
+
+def cpu_batch(b):
+    c = SimpleNamespace()
+    for f in ("attn_bias", "rel_pos", "poi_pos", "edge_input", "x", "in_degree", "out_degree", "user", "y", "time_normal"):
+        t = getattr(b, f).cpu()
+        setattr(c, f, t.float() if t.dtype.is_floating_point else t.long())
+    return c
+
+
+def oracle_consts(uni, model, name):
+    w = workloads.WORKLOADS[name]
+    return mo.fq_constants(uni, w["model"]["dataset_name"], diag_inverse=True, num_bins=model.poi_pos_encoder.num_embeddings)
+
+
+def oracle_step(sd0, batch, consts, n_layers):
+    sd = {k: v.detach().float().cpu().clone().requires_grad_(True) for k, v in sd0.items()}
+    logits, _ = mo.graphormer_fq_forward(sd, batch, consts, n_layers=n_layers, H=8, D=20)
+    loss = mo.gradient_tail_loss(logits, batch.y - 1, 0.2)
+    loss.backward()
+    return logits.detach(), float(loss), {k: (None if v.grad is None else v.grad) for k, v in sd.items()}
+
+
+def check_grad(name, got, ref, report):
+    got, ref = got.detach().float().cpu().numpy().astype(np.float64), ref.numpy().astype(np.float64)
+    assert got.shape == ref.shape, name
+    rms = float(np.sqrt((ref ** 2).mean()))
+    err = np.abs(got - ref)
+    rel_l2 = float(np.sqrt(((got - ref) ** 2).sum()) / max(np.sqrt((ref ** 2).sum()), 1e-30))
+    worst = float((err / (0.08 * rms + 0.05 * np.abs(ref) + 1e-30)).max())
+    report.append((name, rms, rel_l2, worst))
+    return rel_l2 <= 4e-2 and worst <= 1.0
+
+
+@pytest.fixture(scope="module")
+def fsq():
+    uni, model, coll = workloads.build("fsq", DEV, seed=1, model_overrides=dict(dropout_rate=0.0, intput_dropout_rate=0.0,
+                                                                               attention_dropout_rate=0.0))
+    pool = workloads.make_pool("fsq", 2, 16, uni)
+    batches = [coll(t) for t in pool]
+    # GCN / positional dropouts are constructor constants of the reference (0.3 / 0.1 / 0.1): eval() turns them off for
+    # the eager check; the TrainStep check zeroes them on the module
+    consts = oracle_consts(uni, model, "fsq")
+    sd0 = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    ref = [oracle_step(sd0, cpu_batch(b), consts, 6) for b in batches]
+    return uni, model, batches, sd0, ref
+
+
+def test_benched_model_takes_the_rows_only_bf16_path(fsq):
+    uni, model, batches, _, _ = fsq
+    G, N = batches[0].x.shape[:2]
+    assert G * N * 2 <= model.X.shape[0], "bench batches must take the rows_only GCN path (model_fqandtoyo.node_features)"
+    assert model.D_A.dtype == torch.bfloat16 and model.bias_dtype == torch.bfloat16 and model.act_dtype == torch.bfloat16
+    assert all(l.fused and l.act_dtype == torch.bfloat16 for l in model.layers)
+
+
+def test_eager_eval_logits_loss_and_elementwise_gradients_vs_oracle(fsq):
+    uni, model, batches, sd0, ref = fsq
+    model.load_state_dict(sd0)
+    model.eval()
+    for b, (ref_logits, ref_loss, ref_grads) in zip(batches, ref):
+        for p in model.parameters():
+            p.grad = None
+        logits = model(b)[0]
+        err = float((logits.detach().float().cpu() - ref_logits).abs().max())
+        assert err <= 3e-2, f"max |logit err| {err}"
+        loss = model.training_step(b, 0)
+        np.testing.assert_allclose(float(loss), ref_loss, rtol=2e-3)
+        loss.backward()
+        report, ok = [], True
+        params = dict(model.named_parameters())
+        for name in GRAD_PARAMS:
+            assert ref_grads[name] is not None and params[name].grad is not None, name
+            ok &= check_grad(name, params[name].grad, ref_grads[name], report)
+        for r in report:
+            print("%-48s rms %.3e  relL2 %.4f  worst %.3f" % r)
+        assert ok, [r for r in report if r[2] > 4e-2 or r[3] > 1.0]
+        # parameters the reference never reaches stay without a gradient here too
+        for name, g in ref_grads.items():
+            if g is None:
+                assert params[name].grad is None or float(params[name].grad.abs().sum()) == 0.0, name
+
+
+def test_graph_replayed_train_step_vs_oracle(fsq):
+    """The benchmark's own step: TrainStep(use_graph=True) -> hipGraph replay -> flat gradient buffer; all dropouts 0."""
+    from mobgt_amd.train import TrainStep
+    uni, model, batches, sd0, ref = fsq
+    model.load_state_dict(sd0)
+    model.train()
+    model.poi_distance_model.dropout = 0.0
+    model.poi_cat_model.dropout = 0.0
+    model.pos_embed.dropout.p = 0.0
+    ts = TrainStep(model, batches, use_graph=True, seed=1)
+    ts.prepare()
+    # prepare() must leave parameters and Adam moments untouched (side-effect-free optimizer warm-up)
+    for k, v in model.state_dict().items():
+        assert torch.equal(v, sd0[k].to(v.device)), k
+    assert float(ts.exp_avg.abs().max()) == 0.0 and float(ts.exp_avg_sq.abs().max()) == 0.0
+    params = dict(model.named_parameters())
+    for i, (ref_logits, ref_loss, ref_grads) in enumerate(ref):
+        if i > 0:           # the oracle's gradients were taken at the initial weights: undo the optimizer step
+            with torch.no_grad():
+                model.load_state_dict(sd0)
+                ts.sync_shadows()
+        loss = float(ts.step(i))
+        np.testing.assert_allclose(loss, ref_loss, rtol=2e-3)
+        report, ok = [], True
+        for name in GRAD_PARAMS:
+            ok &= check_grad(name, params[name].grad, ref_grads[name], report)
+        assert ok, [r for r in report if r[2] > 4e-2 or r[3] > 1.0]
+    # first optimizer step is AdamW's t = 1: every element with a gradient moved by ~lr(1) * sign(g), nothing else moved
+    lr1 = 2e-4 / 40000
+    p_new, p_old = params["out_proj.bias"].detach().float().cpu(), sd0["out_proj.bias"].float().cpu()
+    g = ref[-1][2]["out_proj.bias"]
+    big = g.abs() > 1e-6
+    step = (p_old * (1 - lr1 * 0.01) - p_new)[big]
+    np.testing.assert_allclose(step.numpy(), (lr1 * torch.sign(g[big])).numpy(), rtol=2e-2, atol=lr1 * 1e-2)
+
+
+def test_rows_only_gcn_layer_vs_oracle_gcn_rows():
+    """`GCN.forward(rows=...)` -- the bf16 `_RowsConvFn` path with `gather_rows_t` and the stored transpose -- against the
+    same rows of the oracle's dense fp32 GCN (modelGNN.py:38-74), forward and the gradients of all three layers."""
+    from mobgt_amd.modelGNN import GCN, _rows_conv_ok
+    uni = synth.make_universe(P=2000, n_cat=20, n_user=8, seed=9)
+    consts = mo.fq_constants(uni, "foursquaregraph", diag_inverse=True, num_bins=4)
+    torch.manual_seed(3)
+    g = GCN(ninput=consts.X.shape[1], nhid=[16, 64], noutput=128, dropout=0.3).to(DEV).eval()
+    X, A = consts.X.to(DEV), consts.D_A.to(DEV)
+    A16, A16t = A.bfloat16(), A.t().contiguous().bfloat16()
+    rows = torch.randperm(2000, generator=torch.Generator().manual_seed(1))[:608].to(DEV)
+    h_probe = torch.zeros(2000, 64, device=DEV)
+    assert _rows_conv_ok(h_probe, A16, rows)
+    out = g(X, A16, A @ X, rows=rows, adj_t=A16t)
+    up = torch.randn(608, 128, generator=torch.Generator().manual_seed(2)).to(DEV)
+    (out * up).sum().backward()
+    sd = {"m." + k: v.detach().cpu().clone().requires_grad_(True) for k, v in g.state_dict().items()}
+    ref = mo.gcn(sd, "m", consts.X, consts.D_A, 0.3, False)[rows.cpu()]
+    (ref * up.cpu()).sum().backward()
+    np.testing.assert_allclose(out.detach().cpu().numpy(), ref.detach().numpy(), rtol=2e-2, atol=2e-2 * float(ref.abs().max()))
+    report, ok = [], True
+    for k, p in g.named_parameters():
+        ok &= check_grad(k, p.grad, sd["m." + k].grad, report)
+    for r in report:
+        print("%-20s rms %.3e  relL2 %.4f  worst %.3f" % r)
+    assert ok, report

@@ -1,0 +1,138 @@
+"""`train.TrainStep` on a real MI355X: the graph-replayed optimizer trajectory against torch.optim.AdamW +
+PolynomialDecayLR (model_fqandtoyo.py:1599-1616, lr.py:7-34), bf16 shadow-weight maintenance across checkpoint loads,
+and the data-parallel invariant (identical parameters and Adam moments on every rank) with two ranks."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from mobgt_amd import synth                                          # noqa: E402
+from mobgt_amd.data import DeviceCollator, make_bin_table           # noqa: E402
+
+DEV = "cuda"
+ARGS = dict(n_layers=2, num_heads=8, hidden_dim=64, dropout_rate=0.1, intput_dropout_rate=0.1, weight_decay=0.01,
+            ffn_dim=128, warmup_updates=4, tot_updates=100, peak_lr=1e-3, end_lr=1e-9, edge_type="multi_hop",
+            multi_hop_max_dist=20, attention_dropout_rate=0.1, dataset_name="foursquaregraph")
+
+
+def _setup(seed=0, **over):
+    from mobgt_amd.model_fqandtoyo import Graphormer
+    uni = synth.make_universe(P=400, n_cat=12, n_user=1080, seed=3)
+    nb, _, table = make_bin_table(uni.distance)
+    torch.manual_seed(seed)
+    model = Graphormer(universe=uni, num_bins=nb + 2, bias_dtype=torch.bfloat16, gcn_dtype=torch.bfloat16,
+                       act_dtype=torch.bfloat16, **dict(ARGS, **over)).to(DEV)
+    coll = DeviceCollator(DEV, bin_table=table)
+    batches = [coll(synth.make_batch_of_trajectories(seed=10 + i, G=4, P=400, n_user=1080, cat_of_poi=uni.cat_of_poi))
+               for i in range(2)]
+    return model, batches
+
+
+@pytest.mark.parametrize("use_graph", [True, False])
+def test_train_step_trajectory_matches_torch_adamw_and_polynomial_decay(use_graph):
+    """Five steps at a realistic learning rate: feeding each step's gradient (as the step computed it) to
+    torch.optim.AdamW + the reference's scheduler reproduces the parameters -- i.e. the first replayed step is AdamW's
+    t = 1 on zero moments at lr(1), the k-th at lr(k) (the old warm-up consumed t = 1 on a stale gradient)."""
+    from mobgt_amd.lr import PolynomialDecayLR
+    from mobgt_amd.train import TrainStep
+    model, batches = _setup()
+    ts = TrainStep(model, batches, use_graph=use_graph, seed=5)
+    ts.prepare()
+    assert float(ts.exp_avg.abs().max()) == 0.0 and float(ts.exp_avg_sq.abs().max()) == 0.0
+    ref = torch.nn.Parameter(ts.flat_params.tensor.detach().double().clone())
+    opt = torch.optim.AdamW([ref], lr=ARGS["peak_lr"], weight_decay=ARGS["weight_decay"])
+    sched = PolynomialDecayLR(opt, ARGS["warmup_updates"], ARGS["tot_updates"], ARGS["peak_lr"], ARGS["end_lr"], 1.0)
+    for i in range(6):
+        ts.step(i)
+        ref.grad = ts.flat.flat.double().clone()
+        opt.step()
+        sched.step()
+        got, want = ts.flat_params.tensor.detach().double().cpu().numpy(), ref.detach().cpu().numpy()
+        # fp32 parameters vs a float64 reference: a few ulps of the parameter per step
+        np.testing.assert_allclose(got, want, rtol=0, atol=2e-7 * (i + 1) + 1e-6 * ARGS["peak_lr"])
+    if ts.shadow_flat is not None:
+        assert torch.equal(ts.shadow_flat, ts.flat_params.tensor.detach().bfloat16())
+
+
+def test_shadows_follow_checkpoint_loads_made_after_the_trainer_exists():
+    """TrainStep owns the fused layers' bf16 shadow weights; load_lightning_checkpoint after its
+    construction must refresh them, otherwise the next forward multiplies with the OLD weights."""
+    from mobgt_amd import checkpoint
+    from mobgt_amd.train import TrainStep
+    model, batches = _setup()
+    ts = TrainStep(model, batches, use_graph=False, seed=5)
+    assert ts.shadow_flat is not None and all(getattr(l, "_shadow_external", False) for l in model.layers)
+    sd = {k: (v.detach().cpu() * 1.5 if "ffn.layer1.weight" in k or "linear_q.weight" in k else v.detach().cpu())
+          for k, v in model.state_dict().items()}
+    checkpoint.load_lightning_checkpoint(model, {"state_dict": sd})
+    for layer in model.layers:
+        wqkv = layer.self_attention.fuse_qkv_storage()[0]
+        assert torch.equal(layer._shadows[0], wqkv.detach().bfloat16())
+        assert torch.equal(layer._shadows[4], layer.ffn.layer1.weight.detach().bfloat16())
+    model.eval()
+    with torch.no_grad():
+        a = model(batches[0])[0].clone()
+        ts.shadow_flat.zero_()                      # prove the forward really reads the shadows ...
+        b = model(batches[0])[0].clone()
+        ts.sync_shadows()                           # ... and that sync_shadows restores them
+        c = model(batches[0])[0]
+    assert not torch.equal(a, b) and torch.equal(a, c)
+
+
+def test_out_of_range_indices_raise_like_nn_embedding():
+    """the gather kernels do not bounds-check; the model validates each batch object once."""
+    model, batches = _setup()
+    model.eval()
+    b = batches[0]
+    model(b)
+    import copy
+    bad = copy.copy(b)
+    bad.in_degree = b.in_degree.clone()
+    bad.in_degree[0, 0] = 128
+    bad._mobgt_validated = None
+    with pytest.raises(IndexError):
+        model(bad)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def test_two_rank_train_step_keeps_replicas_identical(tmp_path):
+    """Two data-parallel ranks of TrainStep (RCCL when the box has two GPUs, otherwise gloo with both ranks on cuda:0):
+    after three steps on different per-rank data every rank holds bit-identical parameters, Adam moments and bf16
+    shadows, and the averaged gradient buffer is the same on both."""
+    port = _free_port()
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(os.path.dirname(__file__), "_ddp_worker.py"), str(tmp_path), "3"],
+                                      env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    outs = []
+    for p in procs:
+        try:
+            o, _ = p.communicate(timeout=600)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        outs.append(o.decode(errors="replace"))
+    assert all(p.returncode == 0 for p in procs), "\n".join(outs)
+    a, b = (torch.load(os.path.join(tmp_path, f"rank{r}.pt")) for r in range(2))
+    print("backend", a["backend"], "overlap", a["overlap"], "losses", a["losses"], b["losses"])
+    assert a["overlap"] and b["overlap"]                       # world size 2 takes the two-phase (overlapped) path
+    assert a["losses"] != b["losses"]                          # different data per rank
+    for k in ("params", "exp_avg", "exp_avg_sq", "grads", "shadow"):
+        assert torch.equal(a[k], b[k]), k
+    assert float(a["exp_avg"].abs().max()) > 0 and all(np.isfinite(a["losses"]))

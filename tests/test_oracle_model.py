@@ -176,3 +176,15 @@ def test_lr_loss_metrics_g7(golden_dir):
     np.testing.assert_allclose(acc, z["acc/acc"])
     np.testing.assert_allclose(ndcg, z["acc/ndcg"])
     np.testing.assert_allclose(mo.mrr_metric(z["acc/target"], z["acc/scores"]), z["acc/mrr"])
+
+
+def test_diag_inverse_laplacian_equals_matrix_power():
+    """The O(P^2) form of (D+I)^-1 (A+I) the big-P parity tests use is the reference's matrix_power(-1) form."""
+    uni = synth.make_universe(P=64, n_cat=8, n_user=8, seed=5)
+    a = mo.calculate_laplacian_matrix(uni.graph_dist)
+    b = mo.calculate_laplacian_matrix(uni.graph_dist, diag_inverse=True)
+    np.testing.assert_allclose(b, a, rtol=1e-14, atol=0)
+    c1, c2 = mo.fq_constants(uni, "foursquaregraph"), mo.fq_constants(uni, "foursquaregraph", diag_inverse=True, num_bins=7)
+    np.testing.assert_allclose(c2.D_A.numpy(), c1.D_A.numpy(), rtol=1e-7)
+    np.testing.assert_allclose(c2.C_A.numpy(), c1.C_A.numpy(), rtol=1e-7)
+    assert c2.num_bins == 7 and torch.equal(c1.X, c2.X)
