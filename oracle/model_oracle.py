@@ -83,7 +83,7 @@ def _edge_term(sd, rel_pos, edge_input, H, D, fp16_roundtrip):
     if D > 0:
         rel_pos_ = rel_pos_.clamp(0, D)
         edge_input = edge_input[:, :, :, :D, :]
-    e = F.embedding(edge_input, sd["edge_encoder.weight"])          # [G,N,N,D,F,H]
+    e = F.embedding(edge_input, sd["edge_encoder.weight"], padding_idx=0)     # [G,N,N,D,F,H]; nn.Embedding(padding_idx=0)
     if fp16_roundtrip:
         e = torch.cat([e[j].mean(-2).unsqueeze(0).half() for j in range(len(edge_input))], dim=0).float()
     else:
@@ -103,9 +103,11 @@ def assemble_bias(sd, batch, H, D, variant):
     """model.py:126-190 (variant 'stock') / model_fqandtoyo.py:1143-1216 (variant 'fq')."""
     attn_bias, rel_pos = batch.attn_bias, batch.rel_pos
     g = attn_bias.clone().unsqueeze(1).repeat(1, H, 1, 1)
-    rel = F.embedding(rel_pos, sd["rel_pos_encoder.weight"]).permute(0, 3, 1, 2)
+    # (every table below is an nn.Embedding(..., padding_idx=0) in the reference, model.py:47-60 / model_fqandtoyo.py:
+    # 638-642, 756-788: row 0 is read like any other row but never receives a gradient)
+    rel = F.embedding(rel_pos, sd["rel_pos_encoder.weight"], padding_idx=0).permute(0, 3, 1, 2)
     if variant == "fq":
-        rel = rel + F.embedding(batch.poi_pos, sd["poi_pos_encoder.weight"]).permute(0, 3, 1, 2)
+        rel = rel + F.embedding(batch.poi_pos, sd["poi_pos_encoder.weight"], padding_idx=0).permute(0, 3, 1, 2)
     g[:, :, 1:, 1:] = g[:, :, 1:, 1:] + rel
     t = sd["graph_token_virtual_distance.weight"].view(1, H, 1).unsqueeze(-2)
     g[:, :, 1:, :1] = g[:, :, 1:, :1] + t            # column 0 only; the row-0 add is commented out upstream
@@ -120,9 +122,9 @@ def graphormer_stock_forward(sd, batch, n_layers, H, D, p=0.0, p_in=0.0, p_att=0
     in_degree = out_degree = batch.in_degree         # model.py:118 aliases out_degree to in_degree
     n_graph = x.size(0)
     bias = assemble_bias(sd, batch, H, D, "stock")
-    node = F.embedding(x, sd["atom_encoder.weight"]).sum(dim=-2)
-    node = node + F.embedding(in_degree, sd["in_degree_encoder.weight"]) \
-        + F.embedding(out_degree, sd["out_degree_encoder.weight"])
+    node = F.embedding(x, sd["atom_encoder.weight"], padding_idx=0).sum(dim=-2)
+    node = node + F.embedding(in_degree, sd["in_degree_encoder.weight"], padding_idx=0) \
+        + F.embedding(out_degree, sd["out_degree_encoder.weight"], padding_idx=0)
     tok = sd["graph_token.weight"].unsqueeze(0).repeat(n_graph, 1, 1)
     out = F.dropout(torch.cat([tok, node], dim=1), p_in, training)
     for l in range(n_layers):
@@ -213,13 +215,14 @@ def graphormer_fq_forward(sd, batch, consts, n_layers, H, D, p=0.0, p_in=0.0, p_
     for pi in range(G):                                                               # :1257-1269
         n = int(indx[pi][0])
         cat_e = catemb[torch.LongTensor([consts.poi2cat[int(x[pi][q])] - 1 for q in range(n)])]
-        time_e = F.embedding((batch.time_normal[pi][:n] * 48).long(), sd["time_embed_model_48.weight"]).squeeze(1)
+        time_e = F.embedding((batch.time_normal[pi][:n] * 48).long(), sd["time_embed_model_48.weight"], padding_idx=0).squeeze(1)
         poi_e = poidist[x[pi][:n] - 1].squeeze(1)
         f2 = fuse(sd, "embed_fuse_model2", poi_e, time_e)
         node_features[pi][:n] = fuse(sd, "embed_fuse_model4", f2, cat_e)
-    node_features = node_features + sd["fre_embed_model.weight"][0] \
-        + F.embedding(batch.in_degree, sd["in_degree_encoder.weight"]) \
-        + F.embedding(batch.out_degree, sd["out_degree_encoder.weight"])             # :1287-1298 (poi_freq all zero)
+    # :1287-1298; poi_freq is all zero (:1243), i.e. the padding row of fre_embed_model: read, never trained
+    node_features = node_features + F.embedding(torch.zeros(1, dtype=torch.long), sd["fre_embed_model.weight"], padding_idx=0)[0] \
+        + F.embedding(batch.in_degree, sd["in_degree_encoder.weight"], padding_idx=0) \
+        + F.embedding(batch.out_degree, sd["out_degree_encoder.weight"], padding_idx=0)
     pe = sd["pos_embed.pe"]
     nf = node_features.clone()
     for i in range(G):                                                                # :348-351 'node_reverse'

