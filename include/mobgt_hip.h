@@ -174,6 +174,10 @@ int mobgt_hop_table_bwd(const float* d_table, const float* edge_encoder, const f
  * Counts above 252 saturate the uint8 hop feature (the reference's edge tables have 128 rows).
  */
 int64_t mobgt_spd_workspace_bytes(int G, int N);
+/* Bound (in 100 MHz wall-clock ticks; < 0 restores the default, 200 ms) on how long a workgroup of the multi-workgroup
+ * Floyd-Warshall waits for a row another workgroup publishes before its graph is handed to the single-workgroup redo
+ * pass.  0 forces the redo pass for every long graph (tests). */
+int mobgt_spd_set_spin_limit(int64_t ticks_100mhz);
 int mobgt_spd_batched(const int32_t* counts, const int32_t* n_nodes,
                       int16_t* spd, int16_t* path, int16_t* rel_pos, uint8_t* edge_input,
                       int16_t* in_degree, int16_t* out_degree, void* work,

@@ -25,9 +25,10 @@ template <bool IN_LDS>
 __global__ __launch_bounds__(FW_THREADS) void fw_kernel(const int32_t* __restrict__ counts, const int32_t* __restrict__ n_nodes,
                                                         int16_t* __restrict__ spd, int16_t* __restrict__ path,
                                                         int16_t* __restrict__ in_degree, int16_t* __restrict__ out_degree,
-                                                        int N) {
+                                                        int N, const int* __restrict__ only_if) {
     extern __shared__ __attribute__((aligned(16))) int16_t Ml[];
     const int g = blockIdx.x;
+    if (only_if && only_if[g] == 0) return;             // redo pass after fw_split_kernel: only graphs that gave up
     const int n = n_nodes[g];
     const int32_t* C = counts + (int64_t)g * N * N;
     int16_t* Mg = spd + (int64_t)g * N * N;
@@ -99,13 +100,21 @@ __global__ __launch_bounds__(FW_THREADS) void fw_kernel(const int32_t* __restric
 constexpr int FW_PARTS = 16;
 constexpr int FW_SPLIT_THREADS = 512;
 constexpr int FW_SPLIT_MAX_N = 1088;     // ceil(N/16) rows x N x 2 B + one row <= 160 KiB
+// A workgroup waits for rows other workgroups publish.  Launches are sized to the device's resident capacity, but
+// nothing guarantees that capacity while other streams (RCCL, a second graph, another process) hold CUs or LDS: a
+// waiter whose producer cannot be scheduled would spin forever.  Every wait is therefore bounded in WALL time
+// (s_memrealtime, 100 MHz); a workgroup that runs out raises its graph's `gave_up` flag and leaves, every other
+// workgroup of that graph follows at its next wait, and mobgt_spd_batched re-runs exactly those graphs with the
+// single-workgroup kernel (slower, same result).  A whole 16 x 784 batch takes ~8 ms; 200 ms is far outside it.
+__device__ long long g_fw_spin_ticks = 20000000;      // 200 ms; mobgt_spd_set_spin_limit (tests) overrides
 
 __global__ __launch_bounds__(FW_SPLIT_THREADS) void fw_split_kernel(const int32_t* __restrict__ counts,
                                                                     const int32_t* __restrict__ n_nodes, int16_t* spd,
                                                                     int16_t* __restrict__ path, int16_t* __restrict__ in_degree,
-                                                                    int16_t* __restrict__ out_degree, int* flags, int* done,
+                                                                    int16_t* __restrict__ out_degree, int* flags, int* gave_up,
                                                                     uint32_t* pub, int N, int g0) {
     extern __shared__ __attribute__((aligned(16))) int16_t lds16[];
+    __shared__ int leave_s;
     // workgroups b and b+8 land on the same XCD (round-robin dispatch): when the graph count allows, give every
     // graph's FW_PARTS workgroups one XCD, so that published rows travel through that XCD's L2 only (speed only)
     const int gc = gridDim.x / FW_PARTS;
@@ -206,9 +215,21 @@ __global__ __launch_bounds__(FW_SPLIT_THREADS) void fw_split_kernel(const int32_
             for (int j = tid; j < np; j += FW_SPLIT_THREADS) rowk[j] = M[(k - r0) * np + j];
         } else {
             if (tid == 0) {
-                while (__hip_atomic_load(&flag[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) __builtin_amdgcn_s_sleep(1);
+                const long long t0 = wall_clock64(), limit = g_fw_spin_ticks;
+                int leave = 0;
+                while (__hip_atomic_load(&flag[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+                    __builtin_amdgcn_s_sleep(1);
+                    if (__hip_atomic_load(&gave_up[g], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 ||
+                        wall_clock64() - t0 > limit) {
+                        __hip_atomic_store(&gave_up[g], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        leave = 1;
+                        break;
+                    }
+                }
+                leave_s = leave;
             }
             __syncthreads();
+            if (leave_s) return;                                      // the redo pass recomputes this graph
             uint32_t* dst = reinterpret_cast<uint32_t*>(rowk);
             for (int w = tid; w < np / 2; w += FW_SPLIT_THREADS)
                 dst[w] = __hip_atomic_load(pubg + (int64_t)k * npw + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -285,6 +306,11 @@ __global__ __launch_bounds__(256) void edge_path_kernel(const int32_t* __restric
 
 }  // namespace
 
+extern "C" int mobgt_spd_set_spin_limit(int64_t ticks_100mhz) {
+    const long long v = ticks_100mhz < 0 ? 20000000 : (long long)ticks_100mhz;
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_fw_spin_ticks), &v, sizeof(v));
+}
+
 extern "C" int64_t mobgt_spd_workspace_bytes(int G, int N) {
     // long graphs (fw_split_kernel): one "row published" flag per (graph, row) + one arrival counter per graph
     if (G <= 0 || N <= LDS_M_MAX_N || N > FW_SPLIT_MAX_N) return 16;
@@ -307,35 +333,43 @@ extern "C" int mobgt_spd_batched(const int32_t* counts, const int32_t* n_nodes, 
             attr_set = true;
         }
         hipLaunchKernelGGL(fw_kernel<true>, dim3(G), dim3(FW_THREADS), shm, st, counts, n_nodes, spd, path, in_degree,
-                           out_degree, N);
+                           out_degree, N, nullptr);
     } else if (N <= FW_SPLIT_MAX_N && work != nullptr) {
         int* flags = reinterpret_cast<int*>(work);
-        int* done = flags + (int64_t)G * N;
-        uint32_t* pub = reinterpret_cast<uint32_t*>(done + G);
+        int* gave_up = flags + (int64_t)G * N;
+        uint32_t* pub = reinterpret_cast<uint32_t*>(gave_up + G);
         if (hipMemsetAsync(work, 0, ((size_t)G * N + G) * sizeof(int), st) != hipSuccess) return MOBGT_EBADDIM;
         const int rpw = (N + FW_PARTS - 1) / FW_PARTS, np = (N + 7) & ~7;
         const size_t shm = ((size_t)rpw * np + np) * sizeof(int16_t);
-        static int cus = 0;
-        if (cus == 0) {
+        static bool attr_set = false;
+        if (!attr_set) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fw_split_kernel),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            int dev = 0;
-            hipDeviceProp_t prop;
-            if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return MOBGT_EBADDIM;
-            cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 1;
+            attr_set = true;
         }
-        // the workgroups of a graph wait for each other: never launch more than can be resident at once
-        const int per_cu = shm <= 72 * 1024 ? 2 : 1;                 // (allocation granularity: no tight fits)
+        // The workgroups of a graph wait for each other: never launch more than THIS device can hold at once
+        // (CU count and the occupancy the runtime computes for this LDS size, queried per call -- the process may
+        // drive several devices).  Co-residency can still be lost to other streams; the bounded waits cover that.
+        int dev = 0, cus = 0, per_cu = 0;
+        if (hipGetDevice(&dev) != hipSuccess ||
+            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+            return MOBGT_EBADDIM;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fw_split_kernel, FW_SPLIT_THREADS, shm) != hipSuccess || per_cu < 1)
+            per_cu = 1;
+        if (per_cu > 2) per_cu = 2;                                    // (allocation granularity: no tight fits)
         int chunk = (cus * per_cu) / FW_PARTS;
         if (chunk < 1) return MOBGT_EBADDIM;
         for (int g0 = 0; g0 < G; g0 += chunk) {
             const int gc = G - g0 < chunk ? G - g0 : chunk;
             hipLaunchKernelGGL(fw_split_kernel, dim3(gc * FW_PARTS), dim3(FW_SPLIT_THREADS), shm, st, counts, n_nodes, spd,
-                               path, in_degree, out_degree, flags, done, pub, N, g0);
+                               path, in_degree, out_degree, flags, gave_up, pub, N, g0);
         }
+        // redo pass: graphs whose workgroups gave up waiting (none in an undisturbed run: G early exits)
+        hipLaunchKernelGGL(fw_kernel<false>, dim3(G), dim3(FW_THREADS), 0, st, counts, n_nodes, spd, path, in_degree,
+                           out_degree, N, gave_up);
     } else {
         hipLaunchKernelGGL(fw_kernel<false>, dim3(G), dim3(FW_THREADS), 0, st, counts, n_nodes, spd, path, in_degree,
-                           out_degree, N);
+                           out_degree, N, nullptr);
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return (int)e;

@@ -369,6 +369,30 @@ def test_spd_random_and_large(golden_dir):
     assert np.array_equal(out["path"][0], z["cycle600/path"])
 
 
+def test_split_floyd_warshall_gives_up_cleanly_and_survives_contention():
+    """the 16 workgroups of a long graph wait for each other.  (a) With the wait bound forced to 0 every
+    waiter gives up at once and the single-workgroup redo pass must deliver the same bit-exact result; (b) with the
+    default bound, a second stream saturating the chip with large GEMMs must neither hang the launch nor change it."""
+    from mobgt_amd import _lib
+    rng = np.random.RandomState(12)
+    graphs = [synth.make_trajectory(rng, 2000, 400, 3)["edge_type"], synth.random_digraph(rng, 310, 0.01),
+              synth.make_trajectory(rng, 2000, 64, 3)["edge_type"]]
+    lib = _lib.lib()
+    try:
+        _lib.check(lib.mobgt_spd_set_spin_limit(0), "mobgt_spd_set_spin_limit")
+        _check_spd(graphs)
+    finally:
+        _lib.check(lib.mobgt_spd_set_spin_limit(-1), "mobgt_spd_set_spin_limit")
+    side = torch.cuda.Stream()
+    a = torch.randn(8192, 8192, device=DEV, dtype=torch.bfloat16)
+    with torch.cuda.stream(side):
+        for _ in range(40):
+            a @ a
+    _check_spd(graphs)                                   # runs while the side stream is busy
+    torch.cuda.synchronize()
+    _check_spd(graphs)
+
+
 # ---------------------------------------------------------------------------------------------- embed
 def test_embed_gather_sum_and_grad():
     rng = np.random.RandomState(2)
