@@ -343,8 +343,10 @@ extern "C" int mobgt_spd_batched(const int32_t* counts, const int32_t* n_nodes, 
         const size_t shm = ((size_t)rpw * np + np) * sizeof(int16_t);
         static bool attr_set = false;
         if (!attr_set) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fw_split_kernel),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            // (FW_SPLIT_MAX_N needs 150 144 B; the kernel also has a few bytes of static LDS, so not the full 160 KiB)
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(fw_split_kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024) != hipSuccess)
+                (void)hipGetLastError();
             attr_set = true;
         }
         // The workgroups of a graph wait for each other: never launch more than THIS device can hold at once
@@ -354,8 +356,11 @@ extern "C" int mobgt_spd_batched(const int32_t* counts, const int32_t* n_nodes, 
         if (hipGetDevice(&dev) != hipSuccess ||
             hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
             return MOBGT_EBADDIM;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fw_split_kernel, FW_SPLIT_THREADS, shm) != hipSuccess || per_cu < 1)
-            per_cu = 1;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(fw_split_kernel),
+                                                         FW_SPLIT_THREADS, shm) != hipSuccess || per_cu < 1) {
+            (void)hipGetLastError();                                   // (do not let the query's status leak into the launches')
+            per_cu = shm <= 72 * 1024 ? 2 : 1;                         // LDS-only estimate: 160 KiB per CU
+        }
         if (per_cu > 2) per_cu = 2;                                    // (allocation granularity: no tight fits)
         int chunk = (cus * per_cu) / FW_PARTS;
         if (chunk < 1) return MOBGT_EBADDIM;

@@ -196,6 +196,15 @@ class TrainStep:
         n_arena = sum(p.numel() for p in model.parameters() if p.numel() <= (1 << 16))
         self.arena = ops.ZeroArena(dev, n=(max(1 << 21, int(n_arena * 1.5) + (1 << 18)) + 3) // 4 * 4)
         model.train()
+        # A model that already ran a backward pass on another stream may still hold that autograd graph (the fq model
+        # keeps its encoder output in `_enc_out`), and with it AccumulateGrad nodes bound to THAT stream; captured on
+        # ours they would put cross-stream waits into the graph (observed: abort in capture_end).  Let go of it first.
+        if getattr(model, "_enc_out", None) is not None:
+            model._enc_out = None
+        for p in model.parameters():
+            p.grad = None
+        import gc
+        gc.collect()
         # One side stream for the dry run, the warm-ups and every capture: autograd's AccumulateGrad nodes are
         # created on the stream of the first backward and must match the capture stream later on.
         self.stream = torch.cuda.Stream(device=dev) if use_graph else None

@@ -7,12 +7,13 @@ Tolerances (bf16 operands with fp32 accumulation on the GPU side, fp32 reference
   logits          max |err| <= 3e-2            (values are O(1))
   loss            rtol 2e-3
   gradients       ELEMENTWISE: |err| <= 0.15 * rms_nz(ref) + 0.05 * |ref| (rms over the non-zero reference entries:
-                  embedding tables get gradient in a few rows only), entries the reference leaves exactly zero (padding
-                  rows, untouched table rows) must be exactly zero here too, and relative L2 error <= 4e-2 -- a
-                  transposed / permuted / mis-scaled gradient fails all three.  Measured in round 2: relative L2
-                  0.6-1.4 %, worst element 0.02-0.5 rms.  One documented exception, `time_embed_model_48.weight`: its
-                  gradient is a heavily cancelling sum (rms 5e-7, 20-40x below its neighbours), so the ~1 % bf16 noise of
-                  the upstream activations is ~10 % of what is left: relative L2 <= 0.2, elements within 2.5 rms.
+                  embedding tables get gradient in a few rows only) for 99.9 % of the entries and 4x that for every
+                  entry; entries the reference leaves exactly zero (padding rows, untouched table rows) must be exactly
+                  zero here too; relative L2 error <= 4e-2 -- a transposed / permuted / mis-scaled gradient fails all
+                  of them.  Measured in round 2: relative L2 0.6-2.5 %, 99.9 % of the entries within 0.05 rms.  The 4x
+                  allowance for the last 0.1 % is for derivative KINKS: LeakyReLU(0.2) / ELU pre-activations that sit
+                  within bf16 round-off of zero take the other branch on one side, which moves one whole row of the
+                  Linear's weight gradient by a few per cent (seen in embed_fuse_model3 rows 54 / 166, model4 row 17).
 The oracle's explicit fp16 casts (model_fqandtoyo.py:1178-1198) flush per-pair gradients below 6e-8 when run without
 the loss scaling the reference's `--precision 16` provides; the oracle step is therefore evaluated at loss x 65536 and
 the gradients divided back (exact in fp32), which only changes `edge_encoder` / `edge_dis_encoder`.
@@ -65,7 +66,7 @@ def oracle_step(sd0, batch, consts, n_layers):
     return logits.detach(), float(loss.detach()), {k: (None if v.grad is None else v.grad / LOSS_SCALE) for k, v in sd.items()}
 
 
-LOOSE = {"time_embed_model_48.weight": (0.2, 2.5)}          # (relative L2, k of k * rms_nz): see the module docstring
+MAX_REL_L2, K_RMS, KINK = 4e-2, 0.15, 4.0
 
 
 def check_grad(name, got, ref, report):
@@ -75,15 +76,16 @@ def check_grad(name, got, ref, report):
     rms = float(np.sqrt((ref[nz] ** 2).mean())) if nz.any() else 0.0
     err = np.abs(got - ref)
     rel_l2 = float(np.sqrt(((got - ref) ** 2).sum()) / max(np.sqrt((ref ** 2).sum()), 1e-30))
-    max_rel, k = LOOSE.get(name, (4e-2, 0.15))
-    worst = float((err[nz] / (k * rms + 0.05 * np.abs(ref[nz]))).max()) if nz.any() else 0.0
+    ratio = err[nz] / (K_RMS * rms + 0.05 * np.abs(ref[nz])) if nz.any() else np.zeros(1)
+    worst = float(np.quantile(ratio, 0.999)) if ratio.size >= 2000 else float(ratio.max())
     stray = float(np.abs(got[~nz]).max()) if (~nz).any() else 0.0      # where the reference has exactly 0
-    report.append((name, rms, rel_l2, worst, stray))
-    return rel_l2 <= max_rel and worst <= 1.0 and stray <= 1e-3 * rms
+    row = (name, rms, rel_l2, worst, float(ratio.max()), stray)
+    report.append(row)
+    return not bad_rows([row])
 
 
 def bad_rows(report):
-    return [r for r in report if r[2] > LOOSE.get(r[0], (4e-2,))[0] or r[3] > 1.0 or r[4] > 1e-3 * r[1]]
+    return [r for r in report if r[2] > MAX_REL_L2 or r[3] > 1.0 or r[4] > KINK or r[5] > 1e-3 * r[1]]
 
 
 @pytest.fixture(scope="module")
@@ -128,7 +130,7 @@ def test_eager_eval_logits_loss_and_elementwise_gradients_vs_oracle(fsq):
             assert ref_grads[name] is not None and params[name].grad is not None, name
             ok &= check_grad(name, params[name].grad, ref_grads[name], report)
         for r in report:
-            print("%-48s rms_nz %.3e  relL2 %.4f  worst %.3f  stray %.1e" % r)
+            print("%-48s rms_nz %.3e  relL2 %.4f  q999 %.3f  max %.3f  stray %.1e" % r)
         assert ok, bad_rows(report)
         # parameters the reference never reaches stay without a gradient here too
         for name, g in ref_grads.items():
@@ -198,5 +200,5 @@ def test_rows_only_gcn_layer_vs_oracle_gcn_rows():
     for k, p in g.named_parameters():
         ok &= check_grad(k, p.grad, sd["m." + k].grad, report)
     for r in report:
-        print("%-20s rms_nz %.3e  relL2 %.4f  worst %.3f  stray %.1e" % r)
+        print("%-20s rms_nz %.3e  relL2 %.4f  q999 %.3f  max %.3f  stray %.1e" % r)
     assert ok, report
