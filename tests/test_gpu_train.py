@@ -54,8 +54,8 @@ def test_train_step_trajectory_matches_torch_adamw_and_polynomial_decay(use_grap
         opt.step()
         sched.step()
         got, want = ts.flat_params.tensor.detach().double().cpu().numpy(), ref.detach().cpu().numpy()
-        # fp32 parameters vs a float64 reference: a few ulps of the parameter per step
-        np.testing.assert_allclose(got, want, rtol=0, atol=2e-7 * (i + 1) + 1e-6 * ARGS["peak_lr"])
+        # fp32 parameters vs a float64 reference: an ulp or two of the parameter per step (values reach |4|)
+        np.testing.assert_allclose(got, want, rtol=1.5e-7 * (i + 1), atol=2e-7 * (i + 1) + 1e-6 * ARGS["peak_lr"])
     if ts.shadow_flat is not None:
         assert torch.equal(ts.shadow_flat, ts.flat_params.tensor.detach().bfloat16())
 
