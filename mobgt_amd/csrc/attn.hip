@@ -13,6 +13,8 @@
 //   * P (and dS in the backward) is already the B operand of the following P.V product, no LDS trip.
 // K and V^T (fwd), K/V/K^T (dQ pass), Q/dO and their transposes (dK/dV pass) are staged per 64-row
 // chunk in LDS as bf16; fp32 inputs are rounded to bf16 while staging, accumulation is fp32.
+#include <type_traits>
+
 #include "common.h"
 #include "mobgt_hip.h"
 
@@ -34,6 +36,7 @@ struct AttnParams {
     int64_t ldq, ldk, ldv, ldo, lddq, lddk, lddv, ld_bias;
     float scale, inv_keep;
     uint32_t drop_thr;
+    int thr_s;                // drop_thr - 32768: the signed 16-bit form the v2 keep rule compares against (common.h)
     uint64_t seed;
     const uint64_t* seed_dev;
     int accumulate;
@@ -52,6 +55,7 @@ template <> struct Raw8<bf16_t> {
     uint4 r;
     __device__ __forceinline__ void load(const bf16_t* p) { r = *reinterpret_cast<const uint4*>(p); }
     __device__ __forceinline__ void zero() { r = make_uint4(0u, 0u, 0u, 0u); }
+    __device__ __forceinline__ bf16x8 as_bf16() const { return __builtin_bit_cast(bf16x8, r); }
     __device__ __forceinline__ void get(float (&v)[8]) const {
         v[0] = bf16_lo(r.x); v[1] = bf16_hi(r.x); v[2] = bf16_lo(r.y); v[3] = bf16_hi(r.y);
         v[4] = bf16_lo(r.z); v[5] = bf16_hi(r.z); v[6] = bf16_lo(r.w); v[7] = bf16_hi(r.w);
@@ -63,6 +67,7 @@ template <> struct Raw8<float> {
         a = *reinterpret_cast<const float4*>(p); b = *reinterpret_cast<const float4*>(p + 4);
     }
     __device__ __forceinline__ void zero() { a = make_float4(0.f, 0.f, 0.f, 0.f); b = make_float4(0.f, 0.f, 0.f, 0.f); }
+    __device__ __forceinline__ bf16x8 as_bf16() const { float v[8]; get(v); return pack8(v); }
     __device__ __forceinline__ void get(float (&v)[8]) const {
         v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
     }
@@ -80,27 +85,33 @@ struct Slab {
             else it[k].zero();
         }
     }
-    template <bool RM, bool TR>
+    template <bool RM, bool TR, bool UNIT>
     static __device__ __forceinline__ void put(const Raw8<TQ>& x, int e, float mul, bf16_t (*rm)[ROWP], bf16_t (*tr)[COLP]) {
         const int r = e >> 2, c0 = (e & 3) * 8;
-        float v[8];
-        x.get(v);
+        bf16x8 b;
+        if (UNIT) {
+            b = x.as_bf16();                                  // bf16 in, no scaling: the 16 bytes as they are
+        } else {
+            float v[8];
+            x.get(v);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) v[i] *= mul;
-        const bf16x8 b = pack8(v);
+            for (int i = 0; i < 8; ++i) v[i] *= mul;
+            b = pack8(v);
+        }
         if (RM) *reinterpret_cast<bf16x8*>(&rm[r][c0]) = b;
         if (TR) {
 #pragma unroll
             for (int i = 0; i < 8; ++i) tr[c0 + i][r] = b[i];
         }
     }
-    template <bool RM, bool TR>
+    // UNIT: mul == 1 (then bf16 input is copied as it is, no unpack / multiply / repack)
+    template <bool RM, bool TR, bool UNIT = false>
     __device__ __forceinline__ void store(float mul, bf16_t (*rm)[ROWP], bf16_t (*tr)[COLP]) const {
 #pragma unroll
-        for (int k = 0; k < ITEMS; ++k) put<RM, TR>(it[k], threadIdx.x + k * NT, mul, rm, tr);
+        for (int k = 0; k < ITEMS; ++k) put<RM, TR, UNIT>(it[k], threadIdx.x + k * NT, mul, rm, tr);
     }
     // load + store of one chunk, piece by piece (the single-chunk kernels of graphs with T <= 64: nothing to overlap)
-    template <bool RM, bool TR>
+    template <bool RM, bool TR, bool UNIT = false>
     static __device__ __forceinline__ void direct(const TQ* __restrict__ src, int64_t ld, int row0, int T, float mul,
                                                   bf16_t (*rm)[ROWP], bf16_t (*tr)[COLP]) {
         for (int e = threadIdx.x; e < KC * 4; e += NT) {
@@ -108,7 +119,7 @@ struct Slab {
             Raw8<TQ> x;
             if (c0 < D && row0 + r < T) x.load(src + (int64_t)(row0 + r) * ld + c0);
             else x.zero();
-            put<RM, TR>(x, e, mul, rm, tr);
+            put<RM, TR, UNIT>(x, e, mul, rm, tr);
         }
     }
 };
@@ -131,7 +142,29 @@ __device__ __forceinline__ void load_frag(const TQ* rowptr, bool valid, float mu
     f = pack8(v);
 }
 
-__device__ __forceinline__ float xhalf(float v) { return __shfl_xor(v, 32, 64); }
+// Exchange with the partner lane (lane ^ 32).  v_permlane32_swap swaps the upper half of its first operand with the
+// lower half of its second in ONE VALU instruction (__shfl_xor lowers to ds_bpermute_b32, an LDS round trip of ~100
+// cycles in the serial chain of every tile).  Given the same value in both operands, `lo` ends up holding the lower
+// half's value in all 64 lanes and `hi` the upper half's.
+__device__ __forceinline__ void half_values(float v, float& lo, float& hi) {
+    // inline asm, not __builtin_amdgcn_permlane32_swap: with both operands derived from one value hipcc (ROCm 7.2) drops
+    // the builtin's second result and uses the first twice (seen in the .s: v_add_f32 v, v0, v0 after the swap).
+    // s_nop 1 = the 2 wait states the hazard rule wants between a VALU write of an operand and the swap.
+    uint32_t a = __builtin_bit_cast(uint32_t, v), b = a;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    lo = __builtin_bit_cast(float, a);
+    hi = __builtin_bit_cast(float, b);
+}
+__device__ __forceinline__ float xhalf_max(float v) {        // max(v, partner's v)
+    float lo, hi;
+    half_values(v, lo, hi);
+    return fmaxf(lo, hi);
+}
+__device__ __forceinline__ float xhalf_sum(float v) {        // v + partner's v
+    float lo, hi;
+    half_values(v, lo, hi);
+    return lo + hi;
+}
 
 // =================================================================================== forward
 template <int D, typename TQ, typename TB, int NW, bool DROP>
@@ -185,6 +218,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const AttnParams p) {
         if (j * 32 < T) ring[j].load(brow + j * 32);
 
     const int nchunk = (T + KC - 1) / KC;
+    const int last_tile_key = ((T - 1) >> 5) << 5;
     Slab<D, TQ, PIPE ? NT : KC * 4> kreg, vreg;        // (one dummy piece when not pipelined)
     if (PIPE) {
         kreg.load(K, p.ldk, 0, T);
@@ -194,11 +228,11 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const AttnParams p) {
     auto chunk = [&](const int c, BiasRegs<TB>& b0, BiasRegs<TB>& b1) {
         __syncthreads();                                   // the previous chunk's LDS readers are done
         if (PIPE) {
-            kreg.template store<true, false>(1.f, Ks, nullptr);
-            vreg.template store<false, true>(1.f, nullptr, Vt);
+            kreg.template store<true, false, true>(1.f, Ks, nullptr);
+            vreg.template store<false, true, true>(1.f, nullptr, Vt);
         } else {
-            Slab<D, TQ, NT>::template direct<true, false>(K, p.ldk, c * KC, T, 1.f, Ks, nullptr);
-            Slab<D, TQ, NT>::template direct<false, true>(V, p.ldv, c * KC, T, 1.f, nullptr, Vt);
+            Slab<D, TQ, NT>::template direct<true, false, true>(K, p.ldk, c * KC, T, 1.f, Ks, nullptr);
+            Slab<D, TQ, NT>::template direct<false, true, true>(V, p.ldv, c * KC, T, 1.f, nullptr, Vt);
         }
         __syncthreads();
         if (PIPE && c + 1 < nchunk) {                      // next chunk's K / V: in flight during this chunk's MFMAs
@@ -212,7 +246,9 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const AttnParams p) {
             BiasRegs<TB>& bt = t == 0 ? b0 : b1;
             f32x16 s;
             bt.to_acc(s);
-            if (PIPE && key0 + 128 < T) bt.load(brow + key0 + 128);        // refill this ring slot: 4 tiles ahead
+            // refill this ring slot 4 tiles ahead; past the end the LAST tile is re-read instead (a branch around the
+            // load made the compiler copy the ring slot on the other path: 8 v_mov per tile)
+            if (PIPE) bt.load(brow + min(key0 + 128, last_tile_key));
             if (key0 + 32 > T) {
 #pragma unroll
                 for (int i = 0; i < 16; ++i)
@@ -227,7 +263,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const AttnParams p) {
             float tmax = s[0];
 #pragma unroll
             for (int i = 1; i < 16; ++i) tmax = fmaxf(tmax, s[i]);
-            tmax = fmaxf(tmax, xhalf(tmax));
+            tmax = xhalf_max(tmax);
             const float m_new = fmaxf(m, tmax);
             if (__any(m_new > m)) {
                 const float alpha = fast_exp2((m - m_new) * MOBGT_LOG2E);
@@ -243,11 +279,13 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const AttnParams p) {
                 pr[i] = fast_exp2(fmaf(s[i], MOBGT_LOG2E, -ms));
                 l += pr[i];
             }
-            if (DROP) {
+            if (DROP) {                                                    // rule v2 (common.h): this lane's 16 keys = one block
+                const uint32_t hb = attn_drop_block(seed, rowh, (uint32_t)((key0 >> 4) + hi));
 #pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const uint32_t bits = dropout_bits16(seed, rowh, (uint32_t)(key0 + 16 * hi + i));
-                    pr[i] = bits >= p.drop_thr ? pr[i] : 0.f;              // 1/(1-p) is applied once, to the output row
+                for (int m = 0; m < 8; ++m) {
+                    const uint32_t w = attn_drop_word(hb, attn_drop_mult(m));
+                    pr[2 * m] = attn_drop_keep_even(w, p.thr_s) ? pr[2 * m] : 0.f;     // 1/(1-p) is applied once, to the output row
+                    pr[2 * m + 1] = attn_drop_keep_odd(w, p.thr_s) ? pr[2 * m + 1] : 0.f;
                 }
             }
 #pragma unroll
@@ -267,7 +305,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const AttnParams p) {
         if (PIPE && c + 1 < nchunk) chunk(c + 1, ring[RING - 2], ring[RING - 1]);
     }
 
-    const float ltot = l + xhalf(l);
+    const float ltot = xhalf_sum(l);
     const float inv = (DROP ? p.inv_keep : 1.f) / ltot;
     if (q_ok) {
         TQ* O = reinterpret_cast<TQ*>(p.o) + ((int64_t)g * T + my_q) * p.ldo + h * D + 16 * hi;
@@ -328,7 +366,7 @@ __device__ __forceinline__ void attn_bwd_dq_body(const AttnParams& p, const int 
 #pragma unroll
         for (int i = 0; i < 8; ++i) dpart = fmaf(dov[i], ov[i], dpart);
     }
-    const float delta = dpart + xhalf(dpart);                      // rowsum(dO * O)
+    const float delta = xhalf_sum(dpart);                          // rowsum(dO * O)
     if (q_ok && hi == 0) p.delta[(int64_t)gh * T + my_q] = delta;
     const float lse2 = p.lse_in[(int64_t)gh * T + qc] * MOBGT_LOG2E;
 
@@ -356,11 +394,11 @@ __device__ __forceinline__ void attn_bwd_dq_body(const AttnParams& p, const int 
     for (int c = 0; c < nchunk; ++c) {
         __syncthreads();
         if (PIPE) {
-            kreg.template store<true, true>(1.f, Ks, Kt);
-            vreg.template store<true, false>(1.f, Vs, nullptr);
+            kreg.template store<true, true, true>(1.f, Ks, Kt);
+            vreg.template store<true, false, true>(1.f, Vs, nullptr);
         } else {
-            Slab<D, TQ, NT>::template direct<true, true>(K, p.ldk, c * KC, T, 1.f, Ks, Kt);
-            Slab<D, TQ, NT>::template direct<true, false>(V, p.ldv, c * KC, T, 1.f, Vs, nullptr);
+            Slab<D, TQ, NT>::template direct<true, true, true>(K, p.ldk, c * KC, T, 1.f, Ks, Kt);
+            Slab<D, TQ, NT>::template direct<true, false, true>(V, p.ldv, c * KC, T, 1.f, Vs, nullptr);
         }
         __syncthreads();
         if (PIPE && c + 1 < nchunk) {
@@ -390,15 +428,22 @@ __device__ __forceinline__ void attn_bwd_dq_body(const AttnParams& p, const int 
                 dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, dof[ks], dp, 0, 0, 0);
             }
             float ds[16];
+            uint32_t hb = 0;
+            if (DROP) hb = attn_drop_block(seed, rowh, (uint32_t)((key0 >> 4) + hi));     // rule v2: 16 keys = one block
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const float pr = fast_exp2(fmaf(s[i], MOBGT_LOG2E, -lse2));
-                float dd = DROP ? fmaf(dp[i], p.inv_keep, -delta) : dp[i] - delta;
-                if (DROP) {
-                    const uint32_t bits = dropout_bits16(seed, rowh, (uint32_t)(key0 + 16 * hi + i));
-                    dd = bits >= p.drop_thr ? dd : -delta;
+            for (int m = 0; m < 8; ++m) {
+                const uint32_t w = DROP ? attn_drop_word(hb, attn_drop_mult(m)) : 0u;
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int i = 2 * m + u;
+                    const float pr = fast_exp2(fmaf(s[i], MOBGT_LOG2E, -lse2));
+                    float dd = DROP ? fmaf(dp[i], p.inv_keep, -delta) : dp[i] - delta;
+                    if (DROP) {
+                        const bool keep = u ? attn_drop_keep_odd(w, p.thr_s) : attn_drop_keep_even(w, p.thr_s);
+                        dd = keep ? dd : -delta;
+                    }
+                    ds[i] = pr * dd;
                 }
-                ds[i] = pr * dd;
             }
             if (dbrow && q_ok) {
                 float* dst = dbrow + key0;
@@ -476,7 +521,9 @@ __device__ __forceinline__ void attn_bwd_dkv_body(const AttnParams& p, const int
     __shared__ __attribute__((aligned(16))) bf16_t dOt[32][COLP];
     __shared__ __attribute__((aligned(16))) float lseS[KC];
     __shared__ __attribute__((aligned(16))) float dlS[KC];
-    __shared__ __attribute__((aligned(16))) uint32_t rowhS[DROP ? KC : 4];      // dropout row hashes of the chunk's queries
+    // dropout rule v2 (common.h): the w words of the chunk's 2 tiles x this workgroup's 2*NW key blocks x 8 key pairs x
+    // 32 query rows, built cooperatively while the chunk is staged (one block hash + 8 mads per entry, 2 entries per thread)
+    __shared__ __attribute__((aligned(16))) uint32_t dropW[DROP ? 2 : 1][DROP ? NW * 2 : 1][DROP ? 8 : 1][DROP ? 32 : 4];
 
     const int T = p.T, H = p.H;
     const int nK = (T + 32 * NW - 1) / (32 * NW);
@@ -499,11 +546,14 @@ __device__ __forceinline__ void attn_bwd_dkv_body(const AttnParams& p, const int
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
         const bool ok = k_ok && (ks * 16 + 8 * hi < D);
-        load_frag(K + (int64_t)kc * p.ldk + ks * 16 + 8 * hi, ok, 1.f, kf[ks]);
+        // the softmax scale rides on this lane's K fragment (S = Q . (scale K)); Q is then staged as it is -- a plain
+        // 16-byte copy for bf16 input -- and dK = scale . dS^T Q gets the factor once, at the end
+        load_frag(K + (int64_t)kc * p.ldk + ks * 16 + 8 * hi, ok, p.scale, kf[ks]);
         load_frag(V + (int64_t)kc * p.ldv + ks * 16 + 8 * hi, ok, 1.f, vf[ks]);
     }
     uint64_t seed = 0;
     if (DROP) seed = p.seed + (p.seed_dev ? *p.seed_dev : 0ull);
+    const int drop_sh = (n & 1) ? 0 : 16, thr_hi = p.thr_s * 65536;
 
     f32x16 dk, dv;
 #pragma unroll
@@ -546,17 +596,27 @@ __device__ __forceinline__ void attn_bwd_dkv_body(const AttnParams& p, const int
     for (int c = 0; c < nchunk; ++c) {
         __syncthreads();
         if (PIPE) {
-            qreg.template store<true, true>(p.scale, Qs, Qt);
-            doreg.template store<true, true>(1.f, dOs, dOt);
+            qreg.template store<true, true, true>(1.f, Qs, Qt);
+            doreg.template store<true, true, true>(1.f, dOs, dOt);
         } else {
-            Slab<D, TQ, NT>::template direct<true, true>(Q, p.ldq, c * KC, T, p.scale, Qs, Qt);
-            Slab<D, TQ, NT>::template direct<true, true>(dO, p.ldo, c * KC, T, 1.f, dOs, dOt);
+            Slab<D, TQ, NT>::template direct<true, true, true>(Q, p.ldq, c * KC, T, 1.f, Qs, Qt);
+            Slab<D, TQ, NT>::template direct<true, true, true>(dO, p.ldo, c * KC, T, 1.f, dOs, dOt);
         }
         if (threadIdx.x < KC) {
             const int q = c * KC + (int)threadIdx.x;
             lseS[threadIdx.x] = lse_r * MOBGT_LOG2E;
             dlS[threadIdx.x] = dl_r;
-            if (DROP) rowhS[threadIdx.x] = dropout_row_hash(seed, (uint32_t)(gh * T + (q < T ? q : T - 1)));
+            (void)q;
+        }
+        if (DROP) {
+            for (int e = threadIdx.x; e < 2 * NW * 2 * 32; e += NT) {
+                const int row = e & 31, kbl = (e >> 5) % (NW * 2), t = e / (NW * 64);
+                const int q = c * KC + t * 32 + row;
+                const uint32_t rh = dropout_row_hash(seed, (uint32_t)(gh * T + (q < T ? q : T - 1)));
+                const uint32_t hb = attn_drop_block(seed, rh, (uint32_t)(kt * 2 * NW + kbl));
+#pragma unroll
+                for (int m = 0; m < 8; ++m) dropW[t][kbl][m][row] = attn_drop_word(hb, attn_drop_mult(m));
+            }
         }
         __syncthreads();
         if (c + 1 < nchunk) {
@@ -590,24 +650,26 @@ __device__ __forceinline__ void attn_bwd_dkv_body(const AttnParams& p, const int
                 lse16[4 * j] = a.x; lse16[4 * j + 1] = a.y; lse16[4 * j + 2] = a.z; lse16[4 * j + 3] = a.w;
                 dl16[4 * j] = b.x; dl16[4 * j + 1] = b.y; dl16[4 * j + 2] = b.z; dl16[4 * j + 3] = b.w;
             }
-            uint32_t rh16[16];
+            uint32_t w16[16];                                      // this key's pair word for each of the 16 query rows
             if (DROP) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const uint4 a = *reinterpret_cast<const uint4*>(&rowhS[t * 32 + 16 * hi + 4 * j]);
-                    rh16[4 * j] = a.x; rh16[4 * j + 1] = a.y; rh16[4 * j + 2] = a.z; rh16[4 * j + 3] = a.w;
+                    const uint4 a = *reinterpret_cast<const uint4*>(&dropW[t][wave * 2 + (n >> 4)][(n & 15) >> 1][16 * hi + 4 * j]);
+                    w16[4 * j] = a.x; w16[4 * j + 1] = a.y; w16[4 * j + 2] = a.z; w16[4 * j + 3] = a.w;
                 }
             }
+            const bool tail = q0 + 32 > T;
             float pd[16], ds[16];
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
-                const int q = q0 + 16 * hi + i;
                 float pr = fast_exp2(fmaf(s[i], MOBGT_LOG2E, -lse16[i]));
-                if (q >= T || !k_ok) pr = 0.f;
+                // rows >= T of the last tile (keys >= T live in lanes whose columns are never stored)
+                if (tail && q0 + 16 * hi + i >= T) pr = 0.f;
                 float dd = DROP ? fmaf(dp[i], p.inv_keep, -dl16[i]) : dp[i] - dl16[i];
                 float prd = pr;                                    // 1/(1-p) of dV is applied once, at the end
                 if (DROP) {
-                    const bool keep = dropout_bits16(seed, rh16[i], (uint32_t)kc) >= p.drop_thr;
+                    // even key: low half of w, moved to the top by the lane's shift; odd key: high half (common.h)
+                    const bool keep = (int)(w16[i] << drop_sh) >= thr_hi;
                     dd = keep ? dd : -dl16[i];
                     prd = keep ? pr : 0.f;
                 }
@@ -637,7 +699,7 @@ __device__ __forceinline__ void attn_bwd_dkv_body(const AttnParams& p, const int
             if (16 * hi + 8 * j < D) {
                 float a[8], b[8];
 #pragma unroll
-                for (int i = 0; i < 8; ++i) { a[i] = dk[8 * j + i]; b[i] = DROP ? dv[8 * j + i] * p.inv_keep : dv[8 * j + i]; }
+                for (int i = 0; i < 8; ++i) { a[i] = dk[8 * j + i] * p.scale; b[i] = DROP ? dv[8 * j + i] * p.inv_keep : dv[8 * j + i]; }
                 store8(DK + 8 * j, a);
                 store8(DV + 8 * j, b);
             }
@@ -729,6 +791,7 @@ int check_common(int G, int H, int T, int d, int64_t ld_bias, int io_dtype, int6
 void set_dropout(AttnParams& p, float dropout_p, uint64_t seed, const uint64_t* seed_dev) {
     p.drop_thr = dropout_p > 0.f ? dropout_threshold(dropout_p) : 0u;
     p.inv_keep = p.drop_thr ? 1.f / (1.f - (float)p.drop_thr / 65536.f) : 1.f;
+    p.thr_s = (int)p.drop_thr - 32768;
     p.seed = seed;
     p.seed_dev = seed_dev;
 }
@@ -784,5 +847,5 @@ extern "C" int mobgt_dropout_keep_host(uint64_t seed, int H, int T, int g, int h
     const uint32_t thr = dropout_p > 0.f ? dropout_threshold(dropout_p) : 0u;
     if (!thr) return 1;
     const uint32_t rowh = dropout_row_hash(seed, (uint32_t)((g * H + h) * T + i));
-    return dropout_bits16(seed, rowh, (uint32_t)j) >= thr ? 1 : 0;
+    return attn_drop_keep(seed, rowh, (uint32_t)j, (int)thr - 32768) ? 1 : 0;
 }
