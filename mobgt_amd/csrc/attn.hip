@@ -351,7 +351,25 @@ __device__ __forceinline__ void attn_bwd_dq_body(const AttnParams& p, const int 
     const TB* brow = reinterpret_cast<const TB*>(p.bias) + ((int64_t)gh * T + qc) * p.ld_bias + 16 * hi;
     const int64_t dboff = ((int64_t)gh * T + qc) * p.ld_bias + 16 * hi;
     float* dbrow = p.dbias && !p.dbias_bf16 ? reinterpret_cast<float*>(p.dbias) + dboff : nullptr;
-    bf16_t* dbrow16 = p.dbias && p.dbias_bf16 ? reinterpret_cast<bf16_t*>(p.dbias) + dboff : nullptr;
+    // bf16 dBias goes out through LDS: written straight from the MFMA layout, a store instruction carried 64 separate
+    // 16-byte pieces (two per row) and the 158 MB of dBias at c5 took 75 of the pass's 128 us (2.1 TB/s; without the
+    // writes the pass ran in 53 us).  A wave's chunk of dS is 32 rows x 64 keys x 2 B = one 128-byte line per row: the
+    // tile is parked in LDS in the MFMA layout and read back row-contiguously, 8 full lines per store instruction.
+    __shared__ __attribute__((aligned(16))) bf16_t dSs[NW][32][KC + 8];
+    const bool db16 = p.dbias && p.dbias_bf16;
+    bf16_t* db16_base = reinterpret_cast<bf16_t*>(p.dbias) + ((int64_t)gh * T + qt * 32 * NW + wave * 32) * p.ld_bias;
+    auto flush_dbias = [&](const int c) {
+        if (!db16) return;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int row = (lane >> 3) + 8 * j, col = c * KC + 8 * (lane & 7);
+            const bf16x8 v = *reinterpret_cast<const bf16x8*>(&dSs[wave][row][8 * (lane & 7)]);
+            // columns [T, ld_bias) exist in the buffer and receive the zeros that masked keys produce; a tile that
+            // lies entirely beyond ld_bias was never computed
+            if (qt * 32 * NW + wave * 32 + row < T && col + 8 <= p.ld_bias)
+                *reinterpret_cast<bf16x8*>(db16_base + (int64_t)row * p.ld_bias + col) = v;
+        }
+    };
 
     bf16x8 qf[KS], dof[KS];
     float dpart = 0.f;
@@ -381,17 +399,22 @@ __device__ __forceinline__ void attn_bwd_dq_body(const AttnParams& p, const int 
 #pragma unroll
     for (int i = 0; i < 16; ++i) dq[i] = 0.f;
 
-    BiasRegs<TB> bcur, bnext;
-    bcur.load(brow);
-
+    // bias prefetch ring as in the forward: four 2 KB tiles in flight per wave (one tile ahead, the pass ran at the
+    // same speed with and without dropout -- it was waiting for its bias tiles, not computing)
     const int nchunk = (T + KC - 1) / KC;
+    const int last_tile_key = ((T - 1) >> 5) << 5;
     constexpr bool PIPE = NW == 4;
+    constexpr int RING = PIPE ? 4 : 2;
+    BiasRegs<TB> ring[RING];
+#pragma unroll
+    for (int j = 0; j < RING; ++j)
+        if (j * 32 < T) ring[j].load(brow + j * 32);
     Slab<D, TQ, PIPE ? NT : KC * 4> kreg, vreg;
     if (PIPE) {
         kreg.load(K, p.ldk, 0, T);
         vreg.load(V, p.ldv, 0, T);
     }
-    for (int c = 0; c < nchunk; ++c) {
+    auto chunk = [&](const int c, BiasRegs<TB>& b0, BiasRegs<TB>& b1) {
         __syncthreads();
         if (PIPE) {
             kreg.template store<true, true, true>(1.f, Ks, Kt);
@@ -409,9 +432,10 @@ __device__ __forceinline__ void attn_bwd_dq_body(const AttnParams& p, const int 
         for (int t = 0; t < 2; ++t) {
             const int key0 = c * KC + t * 32;
             if (key0 >= T) break;
+            BiasRegs<TB>& bt = t == 0 ? b0 : b1;
             f32x16 s, dp;
-            bcur.to_acc(s);
-            if (key0 + 32 < T) bnext.load(brow + key0 + 32);
+            bt.to_acc(s);
+            if (PIPE) bt.load(brow + min(key0 + 128, last_tile_key));      // refill this slot: 4 tiles ahead
             const bool tail = key0 + 32 > T;
             if (tail) {
 #pragma unroll
@@ -469,22 +493,19 @@ __device__ __forceinline__ void attn_bwd_dq_body(const AttnParams& p, const int 
 #pragma unroll
                 for (int j = 0; j < 8; ++j) dv8[j] = ds[8 * s2 + j];
                 const bf16x8 db = pack8(dv8);
-                // bf16 dBias: the very values the dQ / dK contractions use, written once (no read-modify-write;
-                // the layers' slices are summed by the consumer)
-                if (dbrow16 && q_ok) {
-                    bf16_t* dst = dbrow16 + key0 + 8 * s2;
-                    if (!tail) *reinterpret_cast<bf16x8*>(dst) = db;
-                    else {
-#pragma unroll
-                        for (int j = 0; j < 8; ++j)
-                            if (key0 + 16 * hi + 8 * s2 + j < T) dst[j] = db[j];
-                    }
-                }
+                // bf16 dBias: the very values the dQ / dK contractions use, written once (no read-modify-write; the
+                // layers' slices are summed by the consumer).  Parked in a wave-private LDS tile here and written out
+                // by `flush_dbias` as whole 128-byte rows per chunk.
+                if (db16) *reinterpret_cast<bf16x8*>(&dSs[wave][n][t * 32 + 16 * hi + 8 * s2]) = db;
                 const bf16x8 a = *reinterpret_cast<const bf16x8*>(&Kt[kappa(n)][t * 32 + 16 * hi + 8 * s2]);
                 dq = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, db, dq, 0, 0, 0);
             }
-            bcur = bnext;
         }
+        flush_dbias(c);
+    };
+    for (int c = 0; c < nchunk; c += 2) {
+        chunk(c, ring[0], ring[1]);
+        if (PIPE && c + 1 < nchunk) chunk(c + 1, ring[RING - 2], ring[RING - 1]);
     }
 
     if (q_ok) {
@@ -549,7 +570,8 @@ __device__ __forceinline__ void attn_bwd_dkv_body(const AttnParams& p, const int
         // the softmax scale rides on this lane's K fragment (S = Q . (scale K)); Q is then staged as it is -- a plain
         // 16-byte copy for bf16 input -- and dK = scale . dS^T Q gets the factor once, at the end
         load_frag(K + (int64_t)kc * p.ldk + ks * 16 + 8 * hi, ok, p.scale, kf[ks]);
-        load_frag(V + (int64_t)kc * p.ldv + ks * 16 + 8 * hi, ok, 1.f, vf[ks]);
+        // (with dropout, 1/(1-p) of dP rides on this lane's V fragment)
+        load_frag(V + (int64_t)kc * p.ldv + ks * 16 + 8 * hi, ok, DROP ? p.inv_keep : 1.f, vf[ks]);
     }
     uint64_t seed = 0;
     if (DROP) seed = p.seed + (p.seed_dev ? *p.seed_dev : 0ull);
@@ -559,11 +581,16 @@ __device__ __forceinline__ void attn_bwd_dkv_body(const AttnParams& p, const int
 #pragma unroll
     for (int i = 0; i < 16; ++i) { dk[i] = 0.f; dv[i] = 0.f; }
 
-    BiasRegs<TB> bcur, bnext;
-    bcur.load(brow);
-
     const int nchunk = (T + KC - 1) / KC;
+    const int last_tile_q = ((T - 1) >> 5) << 5;
     constexpr bool PIPE = NW == 4;
+    // two slots, refilled two tiles ahead (this pass is compute-bound and short of registers: a 4-deep ring as in the
+    // other two passes cost 26 VGPRs and bought nothing)
+    constexpr int RING = 2;
+    BiasRegs<TB> ring[RING];
+#pragma unroll
+    for (int j = 0; j < RING; ++j)
+        if (j * 32 < T) ring[j].load(brow + j * 32);
     Slab<D, TQ, PIPE ? NT : KC * 4> qreg, doreg;
     if (PIPE) {
         qreg.load(Q, p.ldq, 0, T);
@@ -593,7 +620,7 @@ __device__ __forceinline__ void attn_bwd_dkv_body(const AttnParams& p, const int
         }
     };
     load_rowstats(0);
-    for (int c = 0; c < nchunk; ++c) {
+    auto chunk = [&](const int c, BiasRegs<TB>& b0, BiasRegs<TB>& b1) {
         __syncthreads();
         if (PIPE) {
             qreg.template store<true, true, true>(1.f, Qs, Qt);
@@ -630,9 +657,10 @@ __device__ __forceinline__ void attn_bwd_dkv_body(const AttnParams& p, const int
         for (int t = 0; t < 2; ++t) {
             const int q0 = c * KC + t * 32;
             if (q0 >= T) break;
+            BiasRegs<TB>& bt = t == 0 ? b0 : b1;
             f32x16 s, dp;
-            bcur.to_acc(s);
-            if (q0 + 32 < T) bnext.load(brow + q0 + 32);
+            bt.to_acc(s);
+            if (PIPE) bt.load(brow + min(q0 + 64, last_tile_q));           // refill this slot: 2 tiles ahead
 #pragma unroll
             for (int i = 0; i < 16; ++i) dp[i] = 0.f;
 #pragma unroll
@@ -642,54 +670,54 @@ __device__ __forceinline__ void attn_bwd_dkv_body(const AttnParams& p, const int
                 const bf16x8 ad = *reinterpret_cast<const bf16x8*>(&dOs[t * 32 + kappa(n)][ks * 16 + 8 * hi]);
                 dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ad, vf[ks], dp, 0, 0, 0);
             }
-            float lse16[16], dl16[16];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float4 a = *reinterpret_cast<const float4*>(&lseS[t * 32 + 16 * hi + 4 * j]);
-                const float4 b = *reinterpret_cast<const float4*>(&dlS[t * 32 + 16 * hi + 4 * j]);
-                lse16[4 * j] = a.x; lse16[4 * j + 1] = a.y; lse16[4 * j + 2] = a.z; lse16[4 * j + 3] = a.w;
-                dl16[4 * j] = b.x; dl16[4 * j + 1] = b.y; dl16[4 * j + 2] = b.z; dl16[4 * j + 3] = b.w;
-            }
-            uint32_t w16[16];                                      // this key's pair word for each of the 16 query rows
-            if (DROP) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const uint4 a = *reinterpret_cast<const uint4*>(&dropW[t][wave * 2 + (n >> 4)][(n & 15) >> 1][16 * hi + 4 * j]);
-                    w16[4 * j] = a.x; w16[4 * j + 1] = a.y; w16[4 * j + 2] = a.z; w16[4 * j + 3] = a.w;
-                }
-            }
             const bool tail = q0 + 32 > T;
-            float pd[16], ds[16];
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                float pr = fast_exp2(fmaf(s[i], MOBGT_LOG2E, -lse16[i]));
-                // rows >= T of the last tile (keys >= T live in lanes whose columns are never stored)
-                if (tail && q0 + 16 * hi + i >= T) pr = 0.f;
-                float dd = DROP ? fmaf(dp[i], p.inv_keep, -dl16[i]) : dp[i] - dl16[i];
-                float prd = pr;                                    // 1/(1-p) of dV is applied once, at the end
-                if (DROP) {
-                    // even key: low half of w, moved to the top by the lane's shift; odd key: high half (common.h)
-                    const bool keep = (int)(w16[i] << drop_sh) >= thr_hi;
-                    dd = keep ? dd : -dl16[i];
-                    prd = keep ? pr : 0.f;
-                }
-                pd[i] = prd;
-                ds[i] = pr * dd;
-            }
+            // eight query rows at a time (row statistics, dropout words, P and dS of a half are dead before the next
+            // half starts: ~50 fewer live registers than all sixteen at once)
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
+                float lse8[8], dl8[8];
+                uint32_t w8[8];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int r0 = t * 32 + 16 * hi + 8 * s2 + 4 * j;
+                    const float4 a = *reinterpret_cast<const float4*>(&lseS[r0]);
+                    const float4 b = *reinterpret_cast<const float4*>(&dlS[r0]);
+                    lse8[4 * j] = a.x; lse8[4 * j + 1] = a.y; lse8[4 * j + 2] = a.z; lse8[4 * j + 3] = a.w;
+                    dl8[4 * j] = b.x; dl8[4 * j + 1] = b.y; dl8[4 * j + 2] = b.z; dl8[4 * j + 3] = b.w;
+                    if (DROP) {     // this key's pair word for each query row (dropout rule v2, common.h)
+                        const uint4 w = *reinterpret_cast<const uint4*>(
+                            &dropW[t][wave * 2 + (n >> 4)][(n & 15) >> 1][16 * hi + 8 * s2 + 4 * j]);
+                        w8[4 * j] = w.x; w8[4 * j + 1] = w.y; w8[4 * j + 2] = w.z; w8[4 * j + 3] = w.w;
+                    }
+                }
                 float a8[8], b8[8];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) { a8[j] = pd[8 * s2 + j]; b8[j] = ds[8 * s2 + j]; }
+                for (int j = 0; j < 8; ++j) {
+                    const int i = 8 * s2 + j;
+                    float pr = fast_exp2(fmaf(s[i], MOBGT_LOG2E, -lse8[j]));
+                    // rows >= T of the last tile (keys >= T live in lanes whose columns are never stored)
+                    if (tail && q0 + 16 * hi + i >= T) pr = 0.f;
+                    if (DROP) {
+                        // dS = P (M dP / (1-p) - delta) = X dP' - P delta with X = M P (what dV sums) and dP' = dO (V / (1-p))
+                        // even key: low half of w, moved to the top by the lane's shift; odd key: high half
+                        const bool keep = (int)(w8[j] << drop_sh) >= thr_hi;
+                        const float x = keep ? pr : 0.f;           // 1/(1-p) of dV is applied once, at the end
+                        a8[j] = x;
+                        b8[j] = fmaf(x, dp[i], -pr * dl8[j]);
+                    } else {
+                        a8[j] = pr;
+                        b8[j] = pr * (dp[i] - dl8[j]);
+                    }
+                }
                 const bf16x8 pb = pack8(a8), db = pack8(b8);
                 const bf16x8 ado = *reinterpret_cast<const bf16x8*>(&dOt[kappa(n)][t * 32 + 16 * hi + 8 * s2]);
                 dv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ado, pb, dv, 0, 0, 0);
                 const bf16x8 aq = *reinterpret_cast<const bf16x8*>(&Qt[kappa(n)][t * 32 + 16 * hi + 8 * s2]);
                 dk = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq, db, dk, 0, 0, 0);
             }
-            bcur = bnext;
         }
-    }
+    };
+    for (int c = 0; c < nchunk; ++c) chunk(c, ring[0], ring[1]);
 
     if (k_ok) {
         TQ* DK = reinterpret_cast<TQ*>(p.dk) + ((int64_t)g * T + my_k) * p.lddk + h * D + 16 * hi;
@@ -707,6 +735,7 @@ __device__ __forceinline__ void attn_bwd_dkv_body(const AttnParams& p, const int
     }
 }
 
+// (tried: amdgpu_waves_per_eu(3), i.e. <= 168 VGPRs instead of 184 -- 19 dwords of scratch per lane in the loop, 103 -> 123 us)
 template <int D, typename TQ, typename TB, int NW, bool DROP>
 __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_kernel(const AttnParams p) {
     attn_bwd_dkv_body<D, TQ, TB, NW, DROP, false>(p, blockIdx.x, gridDim.x);

@@ -12,7 +12,7 @@ g = torch.Generator().manual_seed(0)
 q, k, v, do = (torch.randn(G, T, C, generator=g).cuda().to(dt) for _ in range(4))
 bias = torch.randn(G, H, T, T, generator=g).cuda()
 pack = ops.pack_bias(bias, G, H, T, dtype=dt)
-pack.needs_grad = True
+pack.needs_grad = os.environ.get('NODBIAS') != '1'
 dq, dk, dv = (torch.empty_like(q) for _ in range(3))
 for _ in range(int(os.environ.get("REPS", 10))):
     out, lse = ops._attn_fwd(q, k, v, pack, d ** -0.5, p_drop, 1, None)
