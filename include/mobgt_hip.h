@@ -390,6 +390,24 @@ int mobgt_small_gemm_f32(const float* a, int64_t lda, const float* b, int64_t ld
 int mobgt_layer_gemm(const void* a, int64_t lda, const void* b, int64_t ldb, int b_is_kn, const void* bias, void* c,
                      int64_t ldc, int epilogue, const void* aux_in, void* aux_out, int M, int N, int K, void* stream);
 
+/* The three `dropout_add_ln` steps of an encoder layer whose result is the A operand of a GEMM over the model width,
+ * fused into that GEMM as its prologue (csrc/lngemm.hip; bf16 activations, C <= 256, C % 32 == 0).  Arithmetic, dropout
+ * masks and side outputs are those of mobgt_dropout_add_ln_fwd / _bwd followed by mobgt_layer_gemm:
+ *   fwd  x1 = x + dropout(y);  z = LayerNorm(x1);  out = z . weight^T + bias   (weight [N, C]; epilogue 0 = bias,
+ *        1 = GELU: out = u, aux_out = gelu(u))          -- model.py:482-485 + :397-398 (FFN layer 1)
+ *   bwd  dx1 = dres + LayerNorm'(dz + dz32);  dy = dropout'(dx1);  out = dy . weight_kn  (weight_kn [C, N]; epilogue 0,
+ *        or 2 = out * gelu'(aux_in)); dgamma / dbeta / dbias [C] accumulate (zero them first).
+ */
+int mobgt_ln_gemm_fwd(const float* x, const void* y, float* x1, const float* ln_w, const float* ln_b, void* z,
+                      float* mean, float* rstd, int64_t R, int C, float dropout_p, uint64_t seed,
+                      const uint64_t* seed_dev, uint32_t salt, const void* weight, int64_t ldw, const void* bias,
+                      void* out, int64_t ld_out, int epilogue, void* aux_out, int N, void* stream);
+int mobgt_ln_gemm_bwd(const void* dz, const float* dz32, const float* dres, const float* x1, const float* mean,
+                      const float* rstd, const float* ln_w, float* dx1, void* dy, float* dgamma, float* dbeta,
+                      float* dbias, int64_t R, int C, float dropout_p, uint64_t seed, const uint64_t* seed_dev,
+                      uint32_t salt, const void* weight_kn, int64_t ldw, void* out, int64_t ld_out, int epilogue,
+                      const void* aux_in, int N, void* stream);
+
 /* Start of a training step (the trainer's `optimizer.zero_grad()` + per-step counter): zero-fills two f32 buffers
  * (element counts multiples of 4, 16-byte aligned; either may be empty) and adds 1 to *counter (may be NULL). */
 int mobgt_step_prologue(float* zero_a, int64_t n_a, float* zero_b, int64_t n_b, int64_t* counter, void* stream);

@@ -64,6 +64,8 @@ SIGNATURES = {
     "mobgt_adamw_flat": (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _vp]),
     "mobgt_small_gemm_f32": (_i, [_vp, _i64, _vp, _i64, _i, _vp, _vp, _i64, _i, _i, _i, _i, _vp]),
     "mobgt_layer_gemm": (_i, [_vp, _i64, _vp, _i64, _i, _vp, _vp, _i64, _i, _vp, _vp, _i, _i, _i, _vp]),
+    "mobgt_ln_gemm_fwd": (_i, [_vp] * 8 + [_i64, _i, _f, _u64, _vp, _c.c_uint32, _vp, _i64, _vp, _vp, _i64, _i, _vp, _i, _vp]),
+    "mobgt_ln_gemm_bwd": (_i, [_vp] * 12 + [_i64, _i, _f, _u64, _vp, _c.c_uint32, _vp, _i64, _vp, _i64, _i, _vp, _i, _vp]),
     "mobgt_step_prologue": (_i, [_vp, _i64, _vp, _i64, _vp, _vp]),
     "mobgt_head_input_fwd": (_i, [_vp, _vp, _i, _i64, _vp, _i64, _vp, _i, _i, _i, _i, _vp]),
     "mobgt_head_input_bwd": (_i, [_vp, _vp, _i, _i64, _vp, _vp, _i64, _i, _i, _i, _i, _vp]),

@@ -136,6 +136,7 @@ def _mm_tn_f32(g, x):
 
 _ADDMM_OUT_DTYPE = [None]
 import os as _os
+_os_ln = _os
 _TAIL = [_os.environ.get("MOBGT_NO_TAIL") != "1"]
 _OWN_GEMM = [_os.environ.get("MOBGT_LIBRARY_GEMM") != "1"]     # MOBGT_LIBRARY_GEMM=1: the layer's GEMMs through torch (A/B runs)
 
@@ -159,6 +160,46 @@ def _addmm_f32(c, a, b, inplace=False):
 def _k1_fwd(x, y, x1, w, b, z, z32, mean, rstd, R, C, p, seed, seed_dev, salt, act):
     check(_lib.lib().mobgt_dropout_add_ln_fwd(_p(x), _p(y), _p(x1), _p(w), _p(b), _p(z), _p(z32), _p(mean), _p(rstd), R, C,
                                               p, seed, _p(seed_dev), salt, act, _stream()), "mobgt_dropout_add_ln_fwd")
+
+
+_LN_GEMM = [_os_ln.environ.get("MOBGT_NO_LN_GEMM") != "1"]      # MOBGT_NO_LN_GEMM=1: the two-launch form (A/B runs, tests)
+# Measured on the S-FSQ step (608 rows, C = 192), kernel durations inside the replayed graph:
+#   forward   dropout_add_ln 4.8 us + FFN-1 GEMM 5.2 us  ->  fused 9.1 us
+#   backward  dropout_add_ln' 5.7 us + GEMM 5.7 us       ->  fused 12.9 - 14.4 us (the first column tile of every row block
+#             also reduces dgamma / dbeta / dbias and is the last workgroup to finish)
+# i.e. the gaps between dependent launches of a replayed graph are ~0.1 us; what a stage costs is its own ramp-up + one
+# memory round trip, and fusing two stages saves only the intermediate's round trip.  The forward fusion is on by
+# default, the two backward ones only with MOBGT_LN_GEMM_BWD=1 (kept: parity-tested, and the better trade at other sizes).
+_LN_GEMM_BWD = [_os_ln.environ.get("MOBGT_LN_GEMM_BWD") == "1"]
+
+
+def _ln_gemm_ok(C, *ts):
+    """csrc/lngemm.hip: bf16 activations, model width a multiple of 32 up to 256, contiguous operands."""
+    return (_LN_GEMM[0] and C % 32 == 0 and C <= 256
+            and all(t is None or (t.is_contiguous() and t.data_ptr() % 16 == 0) for t in ts))
+
+
+def _ln_gemm_fwd(x, y, x1, w, b, z, mean, rstd, R, C, p, seed, seed_dev, salt, weight, bias, epilogue):
+    """x1 = x + dropout(y); z = LayerNorm(x1); out = z @ weight.T + bias [-> GELU] in ONE launch (mobgt_ln_gemm_fwd)."""
+    N = weight.shape[0]
+    out = torch.empty(R, N, dtype=torch.bfloat16, device=x.device)
+    aux = torch.empty(R, N, dtype=torch.bfloat16, device=x.device) if epilogue == ops.GEMM_GELU else None
+    check(_lib.lib().mobgt_ln_gemm_fwd(_p(x), _p(y), _p(x1), _p(w), _p(b), _p(z), _p(mean), _p(rstd), R, C, p, seed,
+                                       _p(seed_dev), salt, _p(weight), weight.stride(0), _p(bias), _p(out), N, epilogue,
+                                       _p(aux), N, _stream()), "mobgt_ln_gemm_fwd")
+    return (out, aux) if aux is not None else out
+
+
+def _ln_gemm_bwd(dz, dz32, dres, x1, mean, rstd, w, dx1, dy, dgamma, dbeta, dbias, R, C, p, seed, seed_dev, salt, weight_kn,
+                 epilogue, aux_in):
+    """dx1 = dres + LayerNorm'(dz + dz32); dy = dropout'(dx1); out = dy @ weight_kn [* gelu'(aux_in)] in ONE launch."""
+    N = weight_kn.shape[1]
+    out = torch.empty(R, N, dtype=torch.bfloat16, device=x1.device)
+    check(_lib.lib().mobgt_ln_gemm_bwd(_p(dz), _p(dz32), _p(dres), _p(x1), _p(mean), _p(rstd), _p(w), _p(dx1), _p(dy),
+                                       _p(dgamma), _p(dbeta), _p(dbias), R, C, p, seed, _p(seed_dev), salt, _p(weight_kn),
+                                       weight_kn.stride(0), _p(out), N, epilogue, _p(aux_in), N, _stream()),
+          "mobgt_ln_gemm_bwd")
+    return out
 
 
 def _k1_bwd(dz, dz32, dres, x1, mean, rstd, w, dx1, dy, dgamma, dbeta, dbias, R, C, p, seed, seed_dev, salt, act):
@@ -223,11 +264,18 @@ class _FusedLayerFn(torch.autograd.Function):
         y = ops.layer_gemm(a.view(R, C), s_wo, s_bo) if own else torch.addmm(s_bo, a.view(R, C), s_wo.t())
         x1 = torch.empty(R, C, **f32)
         z = torch.empty(R, C, dtype=A, device=dev)
-        _k1_fwd(x, y, x1, n1w, n1b, z, None, stats[2], stats[3], R, C, cfg.p, seed, sd, salt + 1, act)
-        if own:
+        fuse_ln = own and A == torch.bfloat16 and _ln_gemm_ok(C, x, y, s_w1, s_b1, s_w2, s_wo)
+        ctx.fuse_ln = fuse_ln
+        if fuse_ln:             # x1 = x + dropout(y), z = LN(x1), u = z W1^T + b1, h = gelu(u): one launch
+            u, h = _ln_gemm_fwd(x, y, x1, n1w, n1b, z, stats[2], stats[3], R, C, cfg.p, seed, sd, salt + 1, s_w1, s_b1,
+                                ops.GEMM_GELU)
+            f = ops.layer_gemm(h, s_w2, s_b2)
+        elif own:
+            _k1_fwd(x, y, x1, n1w, n1b, z, None, stats[2], stats[3], R, C, cfg.p, seed, sd, salt + 1, act)
             u, h = ops.layer_gemm(z, s_w1, s_b1, epilogue=ops.GEMM_GELU)
             f = ops.layer_gemm(h, s_w2, s_b2)
         else:
+            _k1_fwd(x, y, x1, n1w, n1b, z, None, stats[2], stats[3], R, C, cfg.p, seed, sd, salt + 1, act)
             u = torch.addmm(s_b1, z, s_w1.t())
             h = torch.empty_like(u)
             check(_lib.lib().mobgt_gelu_fwd(_p(u), _p(h), u.numel(), act, _stream()), "mobgt_gelu_fwd")
@@ -285,19 +333,27 @@ class _FusedLayerFn(torch.autograd.Function):
             return t
         dbqkv, dbo, db1, db2, dn1w, dn1b, dnxw, dnxb = take(3 * C), take(C), take(F), take(C), take(C), take(C), take(C), take(C)
         df = torch.empty(R, C, dtype=A, device=dev)
+        own = ctx.own_gemm
+        fuse_ln = ctx.fuse_ln and _LN_GEMM_BWD[0]
+        db1_in_wgrad = _wgrad_hip(A, F, C, R)                         # then b1's gradient rides on the dW1 kernel
+        du = None
         if stock:
             dx2 = dout                                                # grad at x2 = x1 + dropout(f)
             _k1_bwd(None, None, dout, x2, None, None, None, None, df, None, None, db2, R, C, cfg.p, seed, sd, salt + 2, act)
         else:
             dx2 = torch.empty(R, C, dtype=torch.float32, device=dev)  # through ffn_norm2
-            _k1_bwd(None, dout, None, x2, stats[4], stats[5], nxw, dx2, df, dnxw, dnxb, db2, R, C, cfg.p, seed, sd,
-                    salt + 2, act)
-        own = ctx.own_gemm
+            if fuse_ln and db1_in_wgrad:    # ffn_norm2' + dropout' -> df, du = (df W2) * gelu'(u): one launch
+                du = _ln_gemm_bwd(None, dout, None, x2, stats[4], stats[5], nxw, dx2, df, dnxw, dnxb, db2, R, C, cfg.p,
+                                  seed, sd, salt + 2, s_w2, ops.GEMM_GELU_BWD, u)
+            else:
+                _k1_bwd(None, dout, None, x2, stats[4], stats[5], nxw, dx2, df, dnxw, dnxb, db2, R, C, cfg.p, seed, sd,
+                        salt + 2, act)
         wb = _WgradBatch()
         k_qkv, k_wo, k_w1, k_w2 = ctx.sinks                          # gradient sinks (or None)
         dw2 = wb.add(df, h, sink=k_w2)
-        db1_in_wgrad = _wgrad_hip(A, F, C, R)                         # then b1's gradient rides on the dW1 kernel
-        if own and db1_in_wgrad:
+        if du is not None:
+            pass
+        elif own and db1_in_wgrad:
             du = ops.layer_gemm(df, s_w2, None, True, ops.GEMM_GELU_BWD, aux_in=u)      # (df W2) * gelu'(u), one launch
         else:
             dh = df @ s_w2
@@ -308,8 +364,12 @@ class _FusedLayerFn(torch.autograd.Function):
         dw1 = wb.add(du, z, db=db1 if db1_in_wgrad else None, sink=k_w1)
         dx1 = torch.empty(R, C, dtype=torch.float32, device=dev)
         dy = torch.empty(R, C, dtype=A, device=dev)
-        _k1_bwd(dz, None, dx2, x1, stats[2], stats[3], n1w, dx1, dy, dn1w, dn1b, dbo, R, C, cfg.p, seed, sd, salt + 1, act)
-        da = (ops.layer_gemm(dy, s_wo, None, True) if own else dy @ s_wo).view(G, T, C)
+        if fuse_ln:             # ffn_norm1' + residual + dropout' -> dy, da = dy Wo: one launch
+            da = _ln_gemm_bwd(dz, None, dx2, x1, stats[2], stats[3], n1w, dx1, dy, dn1w, dn1b, dbo, R, C, cfg.p, seed, sd,
+                              salt + 1, s_wo, ops.GEMM_BIAS, None).view(G, T, C)
+        else:
+            _k1_bwd(dz, None, dx2, x1, stats[2], stats[3], n1w, dx1, dy, dn1w, dn1b, dbo, R, C, cfg.p, seed, sd, salt + 1, act)
+            da = (ops.layer_gemm(dy, s_wo, None, True) if own else dy @ s_wo).view(G, T, C)
         dwo = wb.add(dy, a.view(R, C), sink=k_wo)
         dqkv = torch.empty(G, T, 3 * C, dtype=A, device=dev)
         q, k, v = qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:]

@@ -368,3 +368,51 @@ def test_layer_backward_tail_matches_separate_launches():
     assert torch.equal(res[0][3], res[1][3])          # the GEMM itself is deterministic
     want = dx1.double() + dqkv.double() @ wqkv.double()
     np.testing.assert_allclose(res[1][3].cpu().numpy(), want.float().cpu().numpy(), rtol=1e-3, atol=1e-2)
+
+
+@pytest.mark.parametrize("variant", ["fq", "stock"])
+def test_ln_prologue_gemms_match_the_two_launch_form(variant):
+    """csrc/lngemm.hip: dropout_add_ln as the prologue of the GEMM that consumes it (FFN layer 1 forward, the GELU'
+    GEMM and the output-projection data gradient backward) against the separate launches -- same arithmetic and the
+    same dropout masks, so outputs and every gradient agree to bf16 round-off (the row reductions run in another order)."""
+    from mobgt_amd import fused_layer
+    from mobgt_amd.model import EncoderLayer as StockLayer
+    from mobgt_amd.model_fqandtoyo import EncoderLayer as FqLayer
+    torch.manual_seed(3)
+    G, T, C, H = 5, 37, 192, 8
+    layer = (FqLayer if variant == "fq" else StockLayer)(C, 256, 0.1, 0.1, H).to(DEV)
+    layer.act_dtype = torch.bfloat16
+    layer.train()
+    seed_dev = torch.tensor([11], dtype=torch.int64, device=DEV)
+    layer.self_attention.seed_dev = seed_dev             # fixed device seed: both runs draw the same masks
+    x0 = torch.randn(G, T, C, device=DEV)
+    bias = torch.randn(G, H, T, T, device=DEV) * 0.3
+    gy = torch.randn(G, T, C, device=DEV)
+    res = {}
+    for on in (True, False):
+        fused_layer._LN_GEMM[0] = on
+        fused_layer._LN_GEMM_BWD[0] = on
+        try:
+            for p in layer.parameters():
+                p.grad = None
+            x = x0.clone().requires_grad_(True)
+            y = layer(x, bias)
+            y.backward(gy)
+            torch.cuda.synchronize()
+            res[on] = (y.detach().clone(), x.grad.clone(), {n: p.grad.clone() for n, p in layer.named_parameters() if p.grad is not None})
+        finally:
+            fused_layer._LN_GEMM[0] = True
+            fused_layer._LN_GEMM_BWD[0] = False
+    (ya, dxa, ga), (yb, dxb, gb) = res[True], res[False]
+
+    def close(a, b, name):
+        scale = float(b.abs().max()) + 1e-12
+        err = float((a - b).abs().max())
+        assert err <= 1.5e-2 * scale, (name, err, scale)
+    close(ya, yb, "y")
+    close(dxa, dxb, "dx")
+    assert ga.keys() == gb.keys()
+    for n in ga:
+        if n.endswith("linear_k.bias"):
+            continue                                      # exactly zero in exact arithmetic: round-off only
+        close(ga[n], gb[n], n)

@@ -12,7 +12,7 @@ P = int(os.environ.get("P", "7856"))
 dev = torch.device("cuda", 0)
 uni = synth.make_universe(P=P, n_cat=300, n_user=1080, seed=1)
 nb, _, table = make_bin_table(uni.distance)
-model = Graphormer(universe=uni, num_bins=nb + 2, bias_dtype=torch.bfloat16, gcn_dtype=torch.bfloat16, act_dtype=torch.bfloat16, **bench.MODEL_ARGS).to(dev)
+model = Graphormer(universe=uni, num_bins=nb + 2, bias_dtype=torch.bfloat16, gcn_dtype=torch.bfloat16, act_dtype=torch.bfloat16, **__import__("mobgt_amd.workloads", fromlist=["x"]).FSQ_MODEL_ARGS).to(dev)
 coll = DeviceCollator(dev, bin_table=table)
 batches = [coll(synth.make_batch_of_trajectories(seed=1001 + i, G=16, P=P, n_user=1080, cat_of_poi=uni.cat_of_poi)) for i in range(2)]
 ts = TrainStep(model, batches, autocast_dtype=None, use_graph=False)
