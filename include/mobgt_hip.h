@@ -373,6 +373,17 @@ int mobgt_adamw_flat(float* params, const float* grads, float* exp_avg, float* e
 int mobgt_small_gemm_f32(const float* a, int64_t lda, const float* b, int64_t ldb, int b_is_nk, const float* bias, void* c,
                          int64_t ldc, int c_dtype, int M, int N, int K, void* stream);
 
+/* GraphConvolution's adjacency product `torch.spmm(adj, support)` (graphormer/modelGNN.py:38-44) for a normalised
+ * adjacency held as CSR (csrc/spmm.hip) -- the form that exists at P = 100 000 POIs (BASELINE configs[4]).
+ *   mobgt_spmm_csr        out[i,:] = bias + sum_e val[e] b[col[e],:]  over the entries e of row (rows ? rows[i] : i);
+ *                         rowptr int64 [n+1], col int32, val f32; b [n_cols, C] f32 (ldb), out [R, C] f32 (ld_out), C % 4 == 0.
+ *   mobgt_spmm_csr_t_rows db[col[e],:] += val[e] g[i,:]  (autograd of the row-subset product; db zero-initialised, atomics).
+ */
+int mobgt_spmm_csr(const int64_t* rowptr, const int32_t* col, const float* val, const int64_t* rows, const float* b,
+                   int64_t ldb, const float* bias, float* out, int64_t ld_out, int64_t R, int C, void* stream);
+int mobgt_spmm_csr_t_rows(const int64_t* rowptr, const int32_t* col, const float* val, const int64_t* rows,
+                          const float* g, int64_t ldg, float* db, int64_t ld_db, int64_t R, int C, void* stream);
+
 /* The encoder layer's small GEMMs with the following elementwise step fused (graphormer/model.py:388-403, 406-463;
  * model_fqandtoyo.py:1641-1712 and the autograd of those F.linear calls): bf16 operands, f32 accumulate.
  *   acc[M,N] = A[M,K] x op(B)        A row-major (lda);  b_is_kn = 0: B is [N,K] (an nn.Linear weight, forward),

@@ -1,0 +1,101 @@
+// GraphConvolution's adjacency product (graphormer/modelGNN.py:38-44: `torch.spmm(adj, support)`) for a POI graph held as
+// CSR.  The dense normalised adjacency the reference builds ((D+I)^-1 (A+I), model_fqandtoyo.py:481-486) has P^2 entries:
+// 123 MB in bf16 at P = 7 856 (streamed four times per step) and simply does not exist at P = 100 000 (S-BIG, BASELINE
+// configs[4]: 20 GB in bf16, 80 GB in the reference's float64 construction).  With ~30 neighbours per POI the product is
+// a gather of ~30 rows of `support` per output row.
+//
+//   spmm      out[i, :]  = bias + sum_e val[e] * B[col[e], :]       e in [rowptr[r], rowptr[r+1]),  r = rows ? rows[i] : i
+//   spmm_t    dB[col[e], :] += val[e] * g[i, :]                      the transposed product for a row SUBSET (atomics);
+//             the full transposed product is `spmm` on the stored CSR of the transpose.
+//
+// One wave per output row, 16-byte lanes over the feature axis (C = 64 / 128: 256 / 512 contiguous bytes per gathered
+// row), the neighbour loop unrolled by four so that four independent row reads are in flight.  HBM/L2-bound gather;
+// f32 in, f32 accumulate, f32 out (the dense path's bf16 rounding of the adjacency does not arise).
+#include "common.h"
+#include "mobgt_hip.h"
+
+namespace {
+
+struct SpmmParams {
+    const int64_t* rowptr;     // [n_rows_of_A + 1]
+    const int32_t* col;        // [nnz]
+    const float* val;          // [nnz]
+    const int64_t* rows;       // [R] row subset of A, or null (then R = n_rows_of_A)
+    const float* B;            // [n_cols_of_A, C] (ldb)
+    const float* bias;         // [C] or null
+    float* out;                // spmm: [R, C] (ldo);  spmm_t: dB [n_cols_of_A, C] (ldo), accumulated
+    const float* g;            // spmm_t: [R, C] (ldg)
+    int64_t R, ldb, ldo, ldg;
+    int C;
+};
+
+__global__ __launch_bounds__(256) void spmm_kernel(const SpmmParams p) {
+    const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= p.R) return;
+    const int lane = threadIdx.x & 63;
+    const int64_t r = p.rows ? p.rows[i] : i;
+    const int64_t e0 = p.rowptr[r], e1 = p.rowptr[r + 1];
+    for (int c = lane * 4; c < p.C; c += 256) {
+        float4 acc = p.bias ? *reinterpret_cast<const float4*>(p.bias + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        int64_t e = e0;
+        for (; e + 4 <= e1; e += 4) {
+            float4 v[4];
+            float w[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                w[u] = p.val[e + u];
+                v[u] = *reinterpret_cast<const float4*>(p.B + (int64_t)p.col[e + u] * p.ldb + c);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                acc.x = fmaf(w[u], v[u].x, acc.x); acc.y = fmaf(w[u], v[u].y, acc.y);
+                acc.z = fmaf(w[u], v[u].z, acc.z); acc.w = fmaf(w[u], v[u].w, acc.w);
+            }
+        }
+        for (; e < e1; ++e) {
+            const float w = p.val[e];
+            const float4 v = *reinterpret_cast<const float4*>(p.B + (int64_t)p.col[e] * p.ldb + c);
+            acc.x = fmaf(w, v.x, acc.x); acc.y = fmaf(w, v.y, acc.y); acc.z = fmaf(w, v.z, acc.z); acc.w = fmaf(w, v.w, acc.w);
+        }
+        *reinterpret_cast<float4*>(p.out + i * p.ldo + c) = acc;
+    }
+}
+
+__global__ __launch_bounds__(256) void spmm_t_rows_kernel(const SpmmParams p) {
+    const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= p.R) return;
+    const int lane = threadIdx.x & 63;
+    const int64_t r = p.rows ? p.rows[i] : i;
+    const int64_t e0 = p.rowptr[r], e1 = p.rowptr[r + 1];
+    for (int c = lane; c < p.C; c += 64) {
+        const float gv = p.g[i * p.ldg + c];
+        if (gv == 0.f) continue;
+        for (int64_t e = e0; e < e1; ++e) atomicAdd(p.out + (int64_t)p.col[e] * p.ldo + c, p.val[e] * gv);
+    }
+}
+
+}  // namespace
+
+extern "C" int mobgt_spmm_csr(const int64_t* rowptr, const int32_t* col, const float* val, const int64_t* rows,
+                              const float* b, int64_t ldb, const float* bias, float* out, int64_t ld_out, int64_t R, int C,
+                              void* stream) {
+    if (R <= 0) return 0;
+    if (C <= 0 || (C & 3) || (ldb & 3) || (ld_out & 3)) return MOBGT_EBADDIM;
+    if (((uintptr_t)b | (uintptr_t)out | (uintptr_t)bias) & 15) return MOBGT_EALIGN;
+    SpmmParams p = {};
+    p.rowptr = rowptr; p.col = col; p.val = val; p.rows = rows; p.B = b; p.bias = bias; p.out = out;
+    p.R = R; p.ldb = ldb; p.ldo = ld_out; p.C = C;
+    hipLaunchKernelGGL(spmm_kernel, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, (hipStream_t)stream, p);
+    return (int)hipGetLastError();
+}
+
+extern "C" int mobgt_spmm_csr_t_rows(const int64_t* rowptr, const int32_t* col, const float* val, const int64_t* rows,
+                                     const float* g, int64_t ldg, float* db, int64_t ld_db, int64_t R, int C, void* stream) {
+    if (R <= 0) return 0;
+    if (C <= 0) return MOBGT_EBADDIM;
+    SpmmParams p = {};
+    p.rowptr = rowptr; p.col = col; p.val = val; p.rows = rows; p.g = g; p.out = db;
+    p.R = R; p.ldg = ldg; p.ldo = ld_db; p.C = C;
+    hipLaunchKernelGGL(spmm_t_rows_kernel, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, (hipStream_t)stream, p);
+    return (int)hipGetLastError();
+}

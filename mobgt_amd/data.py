@@ -74,7 +74,11 @@ class DeviceCollator:
     Mirrors `partial(collator_foursquare, max_node=30000, multi_hop_max_dist=D, rel_pos_max=R)` (data.py:289-294)
     applied to `preprocess_item`-ed items."""
 
-    def __init__(self, device, bin_table=None, multi_hop_max_dist=20, rel_pos_max=1024, max_node=30000):
+    def __init__(self, device, bin_table=None, multi_hop_max_dist=20, rel_pos_max=1024, max_node=30000, coords=None,
+                 bin_edges=None):
+        """`bin_table`: (P+1) x (P+1) precomputed distance-bin ids (make_bin_table).  For universes where that table
+        cannot exist (P = 100 000), `coords` [(P+1), 2] lat / lon + `bin_edges`: poi_pos = digitize(haversine) is then
+        evaluated for the batch's pairs on the device."""
         self.device = torch.device(device)
         self.D = int(multi_hop_max_dist)
         self.rel_pos_max = int(rel_pos_max)
@@ -82,6 +86,10 @@ class DeviceCollator:
         self.bin_table = None
         if bin_table is not None:
             self.bin_table = torch.as_tensor(bin_table).to(self.device)
+        self.coords = self.bin_edges = None
+        if coords is not None:
+            self.coords = torch.as_tensor(np.radians(np.asarray(coords, dtype=np.float64))).to(self.device)
+            self.bin_edges = torch.as_tensor(np.asarray(bin_edges, dtype=np.float64)).to(self.device)
 
     def pack_host(self, trajs, idx0=0):
         """Raw dicts -> padded numpy arrays (pinned-memory friendly); no graph algorithm runs on the host."""
@@ -127,6 +135,15 @@ class DeviceCollator:
         if self.bin_table is not None:
             xi = x[:, :, 0].long()
             poi_pos = self.bin_table[xi.unsqueeze(2), xi.unsqueeze(1)]
+            real = xi != 0
+            poi_pos = torch.where(real.unsqueeze(2) & real.unsqueeze(1), poi_pos, torch.zeros_like(poi_pos))
+        elif self.coords is not None:
+            xi = x[:, :, 0].long()
+            ll = self.coords[xi]                                                     # [G,N,2] radians, float64
+            lat1, lon1, lat2, lon2 = ll[:, :, None, 0], ll[:, :, None, 1], ll[:, None, :, 0], ll[:, None, :, 1]
+            h = torch.sin((lat2 - lat1) / 2) ** 2 + torch.cos(lat1) * torch.cos(lat2) * torch.sin((lon2 - lon1) / 2) ** 2
+            dist = 2 * 6371.0 * torch.asin(torch.sqrt(h.clamp(0.0, 1.0)))          # synth.haversine_km
+            poi_pos = torch.bucketize(dist, self.bin_edges, right=True).to(torch.int16)   # == np.digitize(dist, edges)
             real = xi != 0
             poi_pos = torch.where(real.unsqueeze(2) & real.unsqueeze(1), poi_pos, torch.zeros_like(poi_pos))
         else:

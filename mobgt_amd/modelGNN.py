@@ -133,6 +133,73 @@ def _rows_conv_ok(x, adj, rows):
             and rows.numel() % 8 == 0 and rows.numel() * 2 <= adj.shape[0] and rows.numel() <= 4096)
 
 
+class CsrAdj:
+    """The normalised adjacency (D+I)^-1 (A+I) as CSR on the device, with the CSR of its transpose (the backward's
+    `adj^T @ g` is then the same gather kernel).  rowptr int64 [P+1], col int32 [nnz], val f32 [nnz]."""
+
+    def __init__(self, rowptr, col, val, t_rowptr, t_col, t_val):
+        self.rowptr, self.col, self.val = rowptr, col, val
+        self.t_rowptr, self.t_col, self.t_val = t_rowptr, t_col, t_val
+        self.shape = (rowptr.numel() - 1, t_rowptr.numel() - 1)
+        self.dtype = torch.float32
+
+    @staticmethod
+    def from_scipy(a):
+        """scipy.sparse matrix -> (six CPU tensors) in the order of the constructor."""
+        a = a.tocsr()
+        a.sort_indices()
+        t = a.T.tocsr()
+        t.sort_indices()
+        f = lambda m: (torch.from_numpy(m.indptr.astype("int64")), torch.from_numpy(m.indices.astype("int32")),
+                       torch.from_numpy(m.data.astype("float32")))
+        return f(a) + f(t)
+
+
+def spmm(adj, b, bias=None, rows=None, transposed=False):
+    """adj[rows] @ b (+ bias) through csrc/spmm.hip; `transposed`: adj^T @ b (all rows)."""
+    from . import _lib
+    from .ops import _p, _stream
+    rp, col, val = (adj.t_rowptr, adj.t_col, adj.t_val) if transposed else (adj.rowptr, adj.col, adj.val)
+    b = b.contiguous()
+    R = rows.numel() if rows is not None else rp.numel() - 1
+    C = b.shape[1]
+    out = torch.empty(R, C, dtype=torch.float32, device=b.device)
+    _lib.check(_lib.lib().mobgt_spmm_csr(_p(rp), _p(col), _p(val), _p(rows), _p(b), b.stride(0), _p(bias), _p(out), C, R, C,
+                                         _stream()), "mobgt_spmm_csr")
+    return out
+
+
+class _SpConvFn(torch.autograd.Function):
+    """out = adj[rows] @ (x @ W) + b with a CSR adjacency (modelGNN.py:38-44); rows = None: every row."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, adj, rows):
+        support = _mm_small(x, weight)                                  # [P, C] f32
+        out = spmm(adj, support, bias, rows)
+        ctx.save_for_backward(x, weight)
+        ctx.adj, ctx.rows, ctx.has_bias = adj, rows, bias is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        from . import _lib, ops
+        from .ops import _p, _stream
+        x, weight = ctx.saved_tensors
+        adj, rows = ctx.adj, ctx.rows
+        g = g.contiguous()
+        if rows is None:
+            d_support = spmm(adj, g, transposed=True)                   # adj^T @ g: a gather over the stored transpose
+        else:                                                           # adj[rows]^T @ g: scatter of R rows
+            d_support = torch.zeros(adj.shape[1], g.shape[1], dtype=torch.float32, device=g.device)
+            _lib.check(_lib.lib().mobgt_spmm_csr_t_rows(_p(adj.rowptr), _p(adj.col), _p(adj.val), _p(rows), _p(g), g.stride(0),
+                                                        _p(d_support), d_support.stride(0), rows.numel(), g.shape[1],
+                                                        _stream()), "mobgt_spmm_csr_t_rows")
+        dW = mm_tn_splitk(x, d_support, bf16_operands=True)
+        dx = _mm_small(d_support, weight, True) if ctx.needs_input_grad[0] else None
+        db = _colsum(g) if ctx.has_bias else None
+        return dx, dW, db, None, None
+
+
 class _PreAggConvFn(torch.autograd.Function):
     """out = (adj @ x) @ W + b with the constant product ax = adj @ x supplied by the caller."""
 
@@ -175,6 +242,8 @@ class GraphConvolution(nn.Module):
         with torch.autocast(device_type=input.device.type, enabled=False):
             if adj_input is not None:
                 return _PreAggConvFn.apply(adj_input, self.weight, b)
+            if isinstance(adj, CsrAdj):
+                return _SpConvFn.apply(input.float(), self.weight, b, adj, None)
             return _GraphConvFn.apply(input.float(), self.weight, b, adj, adj_t)
 
 
@@ -210,6 +279,10 @@ class GCN(nn.Module):
                 x = ops.dropout(x, self.dropout, self.training, 0x2000 + self.gcn[-1].out_features)
             else:
                 x = F.dropout(x, self.dropout, training=self.training)
+        if isinstance(adj, CsrAdj):
+            last = self.gcn[-1]
+            with torch.autocast(device_type=x.device.type, enabled=False):
+                return _SpConvFn.apply(x.float(), last.weight, last.bias, adj, rows)
         if rows is not None:
             last = self.gcn[-1]
             if _rows_conv_ok(x, adj, rows):

@@ -196,13 +196,27 @@ class Graphormer(nn.Module):
         C_X = (np.arange(1, num_cats + 1)[:, None] == uniq[None, :]).astype(np.float32)
         self.register_buffer("X", torch.from_numpy(X), persistent=False)
         self.register_buffer("C_X", torch.from_numpy(C_X), persistent=False)
-        d_a = torch.from_numpy(calculate_laplacian_matrix(uni.graph_dist)).float()
-        # A.X for the constant POI feature matrix, once, in fp32 (see modelGNN.GCN.forward)
-        self.register_buffer("D_AX", d_a @ torch.from_numpy(X), persistent=False)
-        self.register_buffer("D_A", d_a.to(gcn_dtype), persistent=False)
-        # the constant's transpose, stored once: the backward's adj^T @ g then streams rows like the forward
-        self.register_buffer("D_A_T", d_a.t().contiguous().to(gcn_dtype) if gcn_dtype != torch.float32 else None,
-                             persistent=False)
+        self.sparse_adj = not isinstance(uni.graph_dist, np.ndarray)
+        if self.sparse_adj:
+            # P too large for a dense P x P adjacency (S-BIG: 100 000 POIs): the same (D+I)^-1 (A+I) as CSR, its transpose
+            # as CSR, A.X once on the host (scipy); the GCN then runs on csrc/spmm.hip (modelGNN.CsrAdj)
+            from scipy import sparse
+            from .modelGNN import CsrAdj
+            a = sparse.csr_matrix(uni.graph_dist, dtype=np.float64)
+            deg = np.asarray(a.sum(axis=1)).reshape(-1) + 1.0
+            a_hat = sparse.diags(1.0 / deg) @ (a + sparse.identity(P, format="csr"))
+            self.register_buffer("D_AX", torch.from_numpy(np.asarray(a_hat @ X.astype(np.float64), dtype=np.float32)), persistent=False)
+            for name, t in zip(("D_A_rowptr", "D_A_col", "D_A_val", "D_AT_rowptr", "D_AT_col", "D_AT_val"), CsrAdj.from_scipy(a_hat)):
+                self.register_buffer(name, t, persistent=False)
+            self.D_A = self.D_A_T = None
+        else:
+            d_a = torch.from_numpy(calculate_laplacian_matrix(uni.graph_dist)).float()
+            # A.X for the constant POI feature matrix, once, in fp32 (see modelGNN.GCN.forward)
+            self.register_buffer("D_AX", d_a @ torch.from_numpy(X), persistent=False)
+            self.register_buffer("D_A", d_a.to(gcn_dtype), persistent=False)
+            # the constant's transpose, stored once: the backward's adj^T @ g then streams rows like the forward
+            self.register_buffer("D_A_T", d_a.t().contiguous().to(gcn_dtype) if gcn_dtype != torch.float32 else None,
+                                 persistent=False)
         c_a = torch.from_numpy(calculate_laplacian_matrix(uni.graph_cat)).float()
         self.register_buffer("C_A", c_a, persistent=False)
         self.register_buffer("C_AX", c_a @ torch.from_numpy(C_X), persistent=False)
@@ -297,7 +311,11 @@ class Graphormer(nn.Module):
         idx, real = ops.node_index(x, batched_data.time_normal[:, :, 0].float(), self.poi2cat, rows_only,
                                    batched_data.in_degree, batched_data.out_degree)
         poi_idx, time_idx, cat_idx, pos_idx, gcn_rows, zero_idx, in_deg, out_deg = idx.unbind(0)
-        if rows_only:
+        if self.sparse_adj:
+            from .modelGNN import CsrAdj
+            adj = CsrAdj(self.D_A_rowptr, self.D_A_col, self.D_A_val, self.D_AT_rowptr, self.D_AT_col, self.D_AT_val)
+            poidist = self.poi_distance_model(self.X, adj, self.D_AX, rows=gcn_rows.reshape(-1) if rows_only else None)
+        elif rows_only:
             poidist = self.poi_distance_model(self.X, self.D_A, self.D_AX, rows=gcn_rows.reshape(-1), adj_t=self.D_A_T)
         else:
             poidist = self.poi_distance_model(self.X, self.D_A, self.D_AX, adj_t=self.D_A_T)        # :1236

@@ -82,6 +82,75 @@ def make_universe(P=64, n_cat=8, n_user=8, seed=0, with_distance=True, adj_per_r
                     graph_dist=graph_dist, graph_cat=graph_cat, distance=distance)
 
 
+@dataclass
+class SparseUniverse:
+    """A POI universe too large for dense P x P matrices (S-BIG, BASELINE configs[4]: P = 100 000).  Same role as
+    `Universe`, with `graph_dist` as a scipy CSR 0/1 matrix ("within `radius_km`", foursquare_process.py:648-754) and the
+    (P+1) x (P+1) distance pickle replaced by what it is computed from -- coordinates -- plus fixed bin edges."""
+    P: int
+    n_cat: int
+    n_user: int
+    poi_table: np.ndarray          # [P, 6] float64: POI ID, checkin_cnt, lat, lon, cat, check_freq
+    graph_dist: object             # scipy.sparse.csr_matrix [P, P] float32 0/1
+    graph_cat: np.ndarray          # [n_cat, n_cat] float32
+    coords: np.ndarray             # [P+1, 2] float64 lat, lon; row 0 = pad POI
+    bin_edges: np.ndarray          # [num_bins + 1] float64 km: poi_pos = np.digitize(haversine, bin_edges)
+    num_bins: int
+    distance: Optional[np.ndarray] = None
+    graph_adj: Optional[np.ndarray] = None
+    poi_columns: tuple = ("POI ID", "checkin_cnt", "lat", "lon", "cat", "check_freq")
+
+    @property
+    def cat_of_poi(self):
+        return self.poi_table[:, 4].astype(np.int64)
+
+
+def make_sparse_universe(P=100000, n_cat=300, n_user=1080, seed=0, radius_km=3.0, target_degree=32, num_bins=64) -> SparseUniverse:
+    """Seeded synthetic city whose "within radius_km" graph has ~target_degree neighbours per POI whatever P is (the
+    Gaussian spread grows with sqrt(P): avg neighbours = r^2 P / (4 sigma^2)); neighbours from a k-d tree, never P^2."""
+    from scipy import sparse
+    from scipy.spatial import cKDTree
+    rng = np.random.RandomState(seed)
+    sigma_km = radius_km * np.sqrt(P / (4.0 * target_degree))
+    xy = rng.randn(P, 2) * sigma_km                                   # local east / north kilometres
+    lat = 35.68 + xy[:, 1] / 110.574
+    lon = 139.76 + xy[:, 0] / (111.320 * np.cos(np.radians(35.68)))
+    cat = rng.randint(1, n_cat + 1, size=P)
+    cat[:n_cat] = np.arange(1, n_cat + 1)
+    checkin_cnt = rng.randint(1, 200, size=P)
+    check_freq = rng.randint(1, 10, size=P)
+    poi_table = np.stack([np.arange(1, P + 1), checkin_cnt, lat, lon, cat, check_freq], 1).astype(np.float64)
+    pairs = cKDTree(xy).query_pairs(r=radius_km, output_type="ndarray")
+    # keep exactly the pairs whose HAVERSINE distance is within the radius (what the collator's poi_pos is computed from)
+    d = haversine_km(lat[pairs[:, 0]], lon[pairs[:, 0]], lat[pairs[:, 1]], lon[pairs[:, 1]])
+    pairs = pairs[(d <= radius_km) & (d > 0)]
+    rows = np.concatenate([pairs[:, 0], pairs[:, 1]])
+    cols = np.concatenate([pairs[:, 1], pairs[:, 0]])
+    graph_dist = sparse.csr_matrix((np.ones(rows.size, dtype=np.float32), (rows, cols)), shape=(P, P))
+    graph_dist.sum_duplicates()
+    graph_dist.data[:] = 1.0
+    graph_cat = rng.randint(0, 5, size=(n_cat, n_cat)).astype(np.float32)
+    coords = np.zeros((P + 1, 2), dtype=np.float64)
+    coords[1:, 0], coords[1:, 1] = lat, lon
+    # bin edges from a sample of pair distances (the reference derives them from the full matrix it cannot have here)
+    a, b = rng.randint(0, P, size=200000), rng.randint(0, P, size=200000)
+    sample = haversine_km(lat[a], lon[a], lat[b], lon[b])
+    bin_edges = np.linspace(0.0, float(sample.max()) * 1.25, num_bins + 1)
+    return SparseUniverse(P=P, n_cat=n_cat, n_user=n_user, poi_table=poi_table, graph_dist=graph_dist, graph_cat=graph_cat,
+                          coords=coords, bin_edges=bin_edges, num_bins=num_bins)
+
+
+def densify(uni: SparseUniverse) -> Universe:
+    """The same universe with dense matrices (small P only): what the oracle / the dense product path consume."""
+    lat, lon = uni.coords[1:, 0], uni.coords[1:, 1]
+    d = haversine_km(lat[:, None], lon[:, None], lat[None, :], lon[None, :])
+    distance = np.zeros((uni.P + 1, uni.P + 1), dtype=np.float64)
+    distance[1:, 1:] = d
+    return Universe(P=uni.P, n_cat=uni.n_cat, n_user=uni.n_user, poi_table=uni.poi_table,
+                    graph_adj=np.zeros((uni.P, uni.P), dtype=np.float32), graph_dist=np.asarray(uni.graph_dist.todense(), dtype=np.float32),
+                    graph_cat=uni.graph_cat, distance=distance)
+
+
 def sample_num_nodes(rng, n, dist="fsq", lo=2, hi=256):
     """Per-trajectory node counts.  'fsq': clip(round(exp(N(1.5,1.2))), 2, 256)."""
     if dist == "fsq":

@@ -1,0 +1,117 @@
+"""The CSR form of the POI graph (S-BIG, BASELINE configs[4]: P = 100 000, where no dense P x P adjacency exists):
+csrc/spmm.hip against dense products, the coordinate-based distance bins against np.digitize on the dense distance
+matrix, and the whole fq model on a sparse universe against the oracle fed with the SAME universe densified
+(reference: modelGNN.py:38-74, model_fqandtoyo.py:456-486, collator.py:428-437)."""
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from mobgt_amd import synth, workloads                                # noqa: E402
+from mobgt_amd.data import DeviceCollator                              # noqa: E402
+from mobgt_amd.modelGNN import CsrAdj, spmm, _SpConvFn                 # noqa: E402
+from oracle import model_oracle as mo                                   # noqa: E402
+
+DEV = "cuda"
+
+
+def _csr(P, seed):
+    from scipy import sparse
+    rng = np.random.RandomState(seed)
+    a = sparse.random(P, P, density=0.01, random_state=rng, format="csr", dtype=np.float32)
+    a.data = rng.rand(a.nnz).astype(np.float32) + 0.1
+    return a
+
+
+def test_spmm_kernels_match_dense_products():
+    P, C = 1500, 128
+    a = _csr(P, 0)
+    adj = CsrAdj(*[t.to(DEV) for t in CsrAdj.from_scipy(a)])
+    dense = torch.from_numpy(a.toarray()).to(DEV)
+    g = torch.Generator().manual_seed(1)
+    b = torch.randn(P, C, generator=g).to(DEV)
+    bias = torch.randn(C, generator=g).to(DEV)
+    np.testing.assert_allclose(spmm(adj, b, bias).cpu().numpy(), (dense @ b + bias).cpu().numpy(), rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(spmm(adj, b, transposed=True).cpu().numpy(), (dense.t() @ b).cpu().numpy(), rtol=1e-5, atol=1e-5)
+    rows = torch.randperm(P, generator=g)[:333].to(DEV)
+    np.testing.assert_allclose(spmm(adj, b, None, rows).cpu().numpy(), (dense[rows] @ b).cpu().numpy(), rtol=1e-5, atol=1e-5)
+    # autograd of the layer, all rows and a row subset, against the dense expression
+    for rws in (None, rows):
+        x = torch.randn(P, 64, generator=g).to(DEV)
+        w = (torch.randn(64, C, generator=g) * 0.1).to(DEV)
+        up = torch.randn(P if rws is None else 333, C, generator=g).to(DEV)
+        xa, wa, ba = (t.clone().requires_grad_(True) for t in (x, w, bias))
+        ref = (dense if rws is None else dense[rws]) @ (xa @ wa) + ba
+        (ref * up).sum().backward()
+        xb, wb, bb = (t.clone().requires_grad_(True) for t in (x, w, bias))
+        out = _SpConvFn.apply(xb, wb, bb, adj, rws)
+        (out * up).sum().backward()
+        np.testing.assert_allclose(out.detach().cpu().numpy(), ref.detach().cpu().numpy(), rtol=1e-4, atol=1e-4)
+        np.testing.assert_allclose(xb.grad.cpu().numpy(), xa.grad.cpu().numpy(), rtol=1e-3, atol=1e-3)
+        np.testing.assert_allclose(bb.grad.cpu().numpy(), ba.grad.cpu().numpy(), rtol=1e-4, atol=1e-3)
+        # dW goes through the bf16-operand weight-gradient kernel (K = P rows)
+        scale = float(wa.grad.abs().max())
+        np.testing.assert_allclose(wb.grad.cpu().numpy(), wa.grad.cpu().numpy(), rtol=0, atol=2e-2 * scale)
+
+
+def _cpu_batch(b):
+    c = SimpleNamespace()
+    for f in ("attn_bias", "rel_pos", "poi_pos", "edge_input", "x", "in_degree", "out_degree", "user", "y", "time_normal"):
+        t = getattr(b, f).cpu()
+        setattr(c, f, t.float() if t.dtype.is_floating_point else t.long())
+    return c
+
+
+def test_sparse_universe_model_matches_oracle_on_the_densified_universe():
+    from mobgt_amd.model_fqandtoyo import Graphormer
+    P = 1500
+    uni = synth.make_sparse_universe(P=P, n_cat=20, n_user=1080, seed=2)
+    dense = synth.densify(uni)
+    torch.manual_seed(4)
+    args = dict(workloads.COMMON, n_layers=2, hidden_dim=128, dataset_name="foursquaregraph", ffn_dim=256)
+    model = Graphormer(universe=uni, num_bins=uni.num_bins + 2, **args).to(DEV).eval()
+    coll = DeviceCollator(DEV, coords=uni.coords, bin_edges=uni.bin_edges)
+    trajs = synth.make_batch_of_trajectories(seed=5, G=6, P=P, n_user=1080, cat_of_poi=uni.cat_of_poi, n_nodes=[40, 3, 17, 64, 9, 25])
+    batch = coll(trajs)
+    # distance bins from coordinates == np.digitize on the dense distance matrix
+    x = batch.x[:, :, 0].cpu().numpy()
+    want = np.digitize(dense.distance[x[:, :, None], x[:, None, :]], uni.bin_edges)
+    want[(x[:, :, None] == 0) | (x[:, None, :] == 0)] = 0
+    assert np.array_equal(batch.poi_pos.cpu().numpy().astype(np.int64), want)
+    # G*N*2 <= P: the rows-only last layer; then the full-table path on a larger batch fraction
+    assert batch.x.shape[0] * batch.x.shape[1] * 2 <= P
+    consts = mo.fq_constants(dense, "foursquaregraph", diag_inverse=True, num_bins=uni.num_bins + 2)
+    sd = {k: v.detach().float().cpu().clone().requires_grad_(True) for k, v in model.state_dict().items()}
+    cb = _cpu_batch(batch)
+    ref, _ = mo.graphormer_fq_forward(sd, cb, consts, n_layers=2, H=8, D=20)
+    ref_loss = mo.gradient_tail_loss(ref, cb.y - 1, 0.2)
+    ref_loss.backward()
+    logits = model(batch)[0]
+    np.testing.assert_allclose(logits.detach().cpu().numpy(), ref.detach().numpy(), rtol=2e-2, atol=2e-2)
+    loss = model.training_step(batch, 0)
+    np.testing.assert_allclose(float(loss.detach()), float(ref_loss.detach()), rtol=1e-3)
+    loss.backward()
+    for name in ("poi_distance_model.gcn.0.weight", "poi_distance_model.gcn.1.weight", "poi_distance_model.gcn.2.weight",
+                 "poi_distance_model.gcn.1.bias", "poi_distance_model.gcn.2.bias"):
+        got = dict(model.named_parameters())[name].grad.cpu().numpy().astype(np.float64)
+        want = sd[name].grad.numpy().astype(np.float64)
+        rel = np.sqrt(((got - want) ** 2).sum()) / np.sqrt((want ** 2).sum())
+        assert rel <= 3e-2, (name, rel)
+
+
+def test_big_workload_builds_and_steps_at_reduced_p():
+    """workloads.build("big") end to end (CSR universe, coordinate bins, C = 256 / d = 32 / 12 layers) at P = 5 000 and
+    N = 96 so that it runs in seconds: finite loss, parameters move."""
+    from mobgt_amd.train import TrainStep
+    uni, model, coll = workloads.build("big", DEV, seed=1, P=5000)
+    trajs = synth.make_batch_of_trajectories(seed=8, G=4, P=5000, n_user=1080, cat_of_poi=uni.cat_of_poi, n_nodes=[96, 50, 7, 96])
+    batches = [coll(trajs)]
+    ts = TrainStep(model, batches, use_graph=True, seed=1)
+    ts.prepare()
+    p0 = ts.flat_params.tensor.detach().clone()
+    losses = [float(ts.step(i)) for i in range(3)]
+    assert all(np.isfinite(losses)), losses
+    assert float((ts.flat_params.tensor.detach() - p0).abs().max()) > 0
