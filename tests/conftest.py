@@ -6,6 +6,9 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+TESTS = os.path.join(ROOT, "tests")
+if TESTS not in sys.path:
+    sys.path.insert(0, TESTS)
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 if GOLDEN not in sys.path:
     sys.path.insert(0, GOLDEN)

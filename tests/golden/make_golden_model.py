@@ -28,6 +28,13 @@ def cpu_cuda_alias():
         torch.Tensor.to = orig
 
 
+def grad_sample(g):
+    """What the fixtures keep of a parameter gradient: all of it up to 4096 elements, every 7th row of a larger matrix
+    (enough to catch a transposed, permuted or mis-scaled gradient; keeps each fixture in the MB range)."""
+    g = np.asarray(g)
+    return g if g.size <= 4096 or g.ndim < 2 else g[::7]
+
+
 def make_g4():
     import model as rmodel
     import model_fqandtoyo as rfq
@@ -59,8 +66,7 @@ def make_g4():
                     continue
                 g = p.grad.numpy()
                 out[f"{name}/gstat/{pn}"] = np.array([g.sum(dtype=np.float64), np.sqrt((g.astype(np.float64) ** 2).sum())])
-                if g.size <= 2048:
-                    out[f"{name}/grad/{pn}"] = g
+                out[f"{name}/grad/{pn}"] = grad_sample(g)
             out[f"{name}/pstat"] = np.array([sum(float(p.detach().double().sum()) for p in layer.parameters())])
     out["names"] = np.array(names)
     save("g4_encoder.npz", **out)
@@ -127,6 +133,8 @@ def make_g5_g6():
         else:
             g = p.grad.double()
             out6[f"stock/gstat/{pn}"] = np.array([g.sum().item(), g.norm().item()])
+            if p.grad.numel() <= 65536:
+                out6[f"stock/grad/{pn}"] = grad_sample(p.grad.numpy())
     # bias gradient parity inputs: d(graph_attn_bias) -> table grads for a fixed upstream grad
     m.zero_grad()
     rng = np.random.RandomState(5)
@@ -179,6 +187,8 @@ def make_g5_g6():
             else:
                 g = p.grad.double()
                 out6[f"{tag}/gstat/{pn}"] = np.array([g.sum().item(), g.norm().item()])
+                if p.grad.numel() <= 65536:
+                    out6[f"{tag}/grad/{pn}"] = grad_sample(p.grad.numpy())
     save("g5_bias.npz", **out5)
     save("g6_e2e.npz", **out6)
 

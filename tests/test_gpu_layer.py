@@ -15,6 +15,8 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
+from gradcheck import grad_errors, grad_sample                      # noqa: E402
+
 from inputs import ENCODER_CASES, encoder_case              # noqa: E402
 from test_oracle_model import encoder_param_list, seeded_state   # noqa: E402
 
@@ -72,9 +74,12 @@ def test_encoder_layer_matches_reference_g4(golden_dir, variant, case, mode):
             continue
         if not np.isclose(gn, rn, rtol=gtol, atol=2e-2):
             bad.append((pn, gn, float(rn)))
-        if f"{name}/grad/{pn}" in z:
-            ref = z[f"{name}/grad/{pn}"]
-            np.testing.assert_allclose(p.grad.cpu().numpy(), ref, atol=gtol * max(1.0, np.abs(ref).max()), rtol=gtol, err_msg=pn)
+        # ELEMENTWISE against the reference's gradient (golden G4 keeps all of it, or every 7th row of a large matrix),
+        # tolerance scaled by the RMS of the reference: relative L2 <= gtol, elements within 0.15 rms + 5 %
+        ref = z[f"{name}/grad/{pn}"]
+        rms, rel_l2, q999, mx, stray = grad_errors(grad_sample(p.grad.cpu().numpy()), ref)
+        if rel_l2 > gtol or q999 > 1.0 or mx > 4.0:
+            bad.append((pn, "elementwise", rel_l2, q999, mx))
     assert not bad, bad
 
 

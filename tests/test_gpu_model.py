@@ -14,6 +14,8 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
+from gradcheck import grad_errors, grad_sample                      # noqa: E402
+
 from mobgt_amd import algos, synth, wrapper                      # noqa: E402
 from mobgt_amd import collator as pc                             # noqa: E402
 from mobgt_amd.data import DeviceCollator, make_bin_table       # noqa: E402
@@ -147,6 +149,18 @@ def _check_grads(model, z, tag, rtol=5e-2):
         # reference leaves fp32 round-off (1e-8) there, the bf16 MFMA operands leave ~1e-4
         if not np.isclose(g.norm().item(), ref_norm, rtol=rtol, atol=1e-3):
             bad.append((pn, g.norm().item(), float(ref_norm)))
+        # ELEMENTWISE against the reference's gradient (golden G6: parameters up to 64 k elements, large matrices by every
+        # 7th row): relative L2 <= 4 %, elements within 0.15 rms + 5 % (tests/gradcheck.py)
+        if f"{tag}/grad/{pn}" in z and not pn.endswith("linear_k.bias"):
+            rms, rel_l2, q999, mx, stray = grad_errors(grad_sample(p.grad.cpu().numpy()), z[f"{tag}/grad/{pn}"])
+            # relative-L2 allowance 8 % instead of 4 % for three tables: the edge tables (the reference's explicit fp16
+            # casts, model_fqandtoyo.py:1178-1198, flush per-pair gradients below 6e-8 in this un-scaled golden run --
+            # tests/test_gpu_bench_parity.py evaluates them at loss x 65536) and the time-slot table (its gradient is a
+            # heavily cancelling sum, rms 20-40x below its neighbours: round-off of the attention's bf16 operands is
+            # 5 % of what is left)
+            lim = 8e-2 if pn.startswith("edge_") or pn.startswith("time_embed") else 4e-2
+            if rel_l2 > lim or q999 > 1.0 or mx > 4.0 or stray > 1e-3 * rms + 1e-12:
+                bad.append((pn, "elementwise", rel_l2, q999, mx, stray))
     assert not bad, bad
 
 

@@ -8,6 +8,7 @@ import pytest
 import torch
 
 from inputs import ENCODER_CASES, encoder_case
+from gradcheck import grad_sample
 from mobgt_amd import synth
 from oracle import model_oracle as mo
 from oracle import collator_oracle as co
@@ -68,6 +69,9 @@ def test_encoder_layer_g4(golden_dir, variant, case):
         g = p.grad.double()
         ref = z[f"{name}/gstat/{key}"]
         np.testing.assert_allclose([g.sum().item(), g.norm().item()], ref, rtol=1e-3, atol=1e-4)
+        # elementwise against the reference's own gradient (all of it, or every 7th row of a large matrix)
+        refg = z[f"{name}/grad/{key}"]
+        np.testing.assert_allclose(grad_sample(p.grad.numpy()), refg, rtol=2e-3, atol=2e-4 * float(np.abs(refg).max()) + 1e-7, err_msg=pn)
 
 
 def _batch(z, prefix, fields, float_fields=("attn_bias", "time_normal")):
@@ -157,6 +161,9 @@ def test_fq_bias_logits_loss_grads_g5_g6(golden_dir, tag, ds):
                   "out_degree_encoder.weight", "time_embed_model_48.weight"):
             assert float(g[0].abs().sum()) == 0.0, pn  # padding_idx=0 rows receive no gradient in the reference
         np.testing.assert_allclose([g.sum().item(), g.norm().item()], z6[f"{tag}/gstat/{pn}"], rtol=2e-3, atol=1e-6, err_msg=pn)
+        if f"{tag}/grad/{pn}" in z6:           # elementwise (parameters up to 64 k elements; large ones by every 7th row)
+            refg = z6[f"{tag}/grad/{pn}"]
+            np.testing.assert_allclose(grad_sample(p.grad.numpy()), refg, rtol=5e-3, atol=1e-3 * float(np.abs(refg).max()) + 1e-9, err_msg=pn)
 
 
 def test_lr_loss_metrics_g7(golden_dir):
