@@ -163,6 +163,13 @@ def fused_layer_forward(layer, variant, x, attn_bias, n1, nx):
     pack = mha._packed(attn_bias, G, T, x)
     wqkv, bqkv = mha.fuse_qkv_storage()
     act = getattr(layer, "act_dtype", torch.float32)
+    # AMP (the reference trains with --precision 16, README.md:62): under torch.autocast the layer takes its bf16
+    # configuration -- bf16 GEMM operands / activations, fp32 residual stream, statistics and master weights -- whatever
+    # `act_dtype` says; fp16 autocast maps to bf16 too (no fp16 instantiation exists; bf16 is the MFMA operand type).
+    # The node itself then runs with autocast off: its dtypes are explicit.
+    amp = x.is_cuda and torch.is_autocast_enabled("cuda")
+    if amp:
+        act = torch.bfloat16
     masters = (wqkv, bqkv, mha.output_layer.weight, mha.output_layer.bias, layer.ffn.layer1.weight, layer.ffn.layer1.bias,
                layer.ffn.layer2.weight, layer.ffn.layer2.bias)
     if act == torch.float32:
@@ -173,7 +180,8 @@ def fused_layer_forward(layer, variant, x, attn_bias, n1, nx):
             sh = tuple(torch.empty_like(m, dtype=act) for m in masters)
             layer._shadows = sh
             layer._shadow_fresh = False
-        if not getattr(layer, "_shadow_fresh", False):          # the model refreshes all layers in one call
+        if not getattr(layer, "_shadow_fresh", False) or act != getattr(layer, "act_dtype", torch.float32):
+            # (stand-alone layers, and AMP on a layer configured for fp32: copy here; a model refreshes all layers in one call)
             torch._foreach_copy_(list(sh), [m.detach() for m in masters])
         layer._shadow_fresh = False
         shadows = sh
@@ -187,6 +195,9 @@ def fused_layer_forward(layer, variant, x, attn_bias, n1, nx):
     params = (mha.linear_q.weight, mha.linear_q.bias, mha.linear_k.weight, mha.linear_k.bias, mha.linear_v.weight,
               mha.linear_v.bias, mha.output_layer.weight, mha.output_layer.bias, n1.weight, n1.bias, nx.weight, nx.bias,
               layer.ffn.layer1.weight, layer.ffn.layer1.bias, layer.ffn.layer2.weight, layer.ffn.layer2.bias)
+    if amp:
+        with torch.autocast("cuda", enabled=False):
+            return fused_encoder_layer(x.float(), pack, cfg, shadows, params, xa_pre=getattr(x, "_mobgt_act", None))
     return fused_encoder_layer(x.float(), pack, cfg, shadows, params, xa_pre=getattr(x, "_mobgt_act", None))
 
 

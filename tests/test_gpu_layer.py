@@ -421,3 +421,69 @@ def test_ln_prologue_gemms_match_the_two_launch_form(variant):
         if n.endswith("linear_k.bias"):
             continue                                      # exactly zero in exact arithmetic: round-off only
         close(ga[n], gb[n], n)
+
+
+def test_torch_library_attention_op_autograd_autocast_no_grad():
+    """the attention core as a dispatcher-visible op (`torch.ops.mobgt.attention_forward`) -- values and
+    gradients equal the reference expression of model.py:436-455; under torch.autocast it runs the bf16-I/O kernels; it
+    works under torch.no_grad; the schema / fake implementation pass torch.library.opcheck."""
+    from mobgt_amd import torch_ops
+    g = torch.Generator().manual_seed(9)
+    G, H, T, d = 3, 8, 29, 24
+    C = H * d
+    q, k, v, gy = (torch.randn(G, T, C, generator=g).to(DEV) for _ in range(4))
+    bias = (torch.randn(G, H, T, T, generator=g) * 0.5).to(DEV)
+    bias[1, :, :, 20:] = float("-inf")
+
+    def ref(q, k, v, b):
+        r = lambda t: t.bfloat16().float()                 # the kernels' MFMA operands are bf16
+        s = (r(q * d ** -0.5).view(G, T, H, d).transpose(1, 2) @ r(k).view(G, T, H, d).transpose(1, 2).transpose(2, 3)) + b
+        return (torch.softmax(s, 3) @ r(v).view(G, T, H, d).transpose(1, 2)).transpose(1, 2).reshape(G, T, C)
+    a = [t.clone().requires_grad_(True) for t in (q, k, v, bias)]
+    ref(*a).backward(gy)
+    b = [t.clone().requires_grad_(True) for t in (q, k, v, bias)]
+    out = torch_ops.attention(b[0], b[1], b[2], b[3], H)
+    out.backward(gy)
+    np.testing.assert_allclose(out.detach().cpu().numpy(), ref(q, k, v, bias).cpu().numpy(), atol=4e-3, rtol=4e-3)
+    for x, y, n in zip(b, a, "qkvb"):
+        scale = float(y.grad.abs().max())
+        np.testing.assert_allclose(x.grad.cpu().numpy(), y.grad.cpu().numpy(), atol=2e-2 * scale, rtol=2e-2, err_msg=n)
+    with torch.no_grad():
+        o2 = torch_ops.attention(q, k, v, bias, H)
+    assert not o2.requires_grad and torch.equal(o2, out.detach())
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        o3 = torch_ops.attention(q, k, v, bias, H)
+    assert o3.dtype == torch.bfloat16
+    np.testing.assert_allclose(o3.float().cpu().numpy(), out.detach().cpu().numpy(), atol=3e-2, rtol=3e-2)
+    torch.library.opcheck(torch.ops.mobgt.attention_forward.default, (q, k, v, bias, H, d ** -0.5, 0.0, 0),
+                          test_utils=("test_schema", "test_faketensor"))
+
+
+def test_fused_layer_under_autocast_takes_the_bf16_configuration():
+    """AMP (README.md:62 --precision 16): a layer configured for fp32 activations, run under torch.autocast, gives what the
+    same layer configured with act_dtype = bf16 gives, forward and backward; without autocast it stays fp32."""
+    from mobgt_amd.model_fqandtoyo import EncoderLayer
+    torch.manual_seed(5)
+    G, T, C, H = 4, 33, 192, 8
+    layer = EncoderLayer(C, 256, 0.1, 0.1, H).to(DEV).eval()
+    x0 = torch.randn(G, T, C, device=DEV)
+    bias = torch.randn(G, H, T, T, device=DEV) * 0.3
+    gy = torch.randn(G, T, C, device=DEV)
+    res = {}
+    for mode in ("fp32", "amp", "bf16"):
+        layer.act_dtype = torch.bfloat16 if mode == "bf16" else torch.float32
+        for p in layer.parameters():
+            p.grad = None
+        x = x0.clone().requires_grad_(True)
+        if mode == "amp":
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                y = layer(x, bias)
+        else:
+            y = layer(x, bias)
+        assert y.dtype == torch.float32                       # the residual stream stays fp32
+        y.backward(gy)
+        res[mode] = (y.detach().clone(), x.grad.clone(), layer.ffn.layer1.weight.grad.clone())
+    for a, b in zip(res["amp"], res["bf16"]):
+        assert torch.equal(a, b)
+    assert not torch.equal(res["amp"][0], res["fp32"][0])
+    np.testing.assert_allclose(res["amp"][0].cpu().numpy(), res["fp32"][0].cpu().numpy(), atol=5e-2, rtol=5e-2)
