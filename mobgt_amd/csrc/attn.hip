@@ -544,7 +544,8 @@ __device__ __forceinline__ void attn_bwd_dkv_body(const AttnParams& p, const int
     __shared__ __attribute__((aligned(16))) float dlS[KC];
     // dropout rule v2 (common.h): the w words of the chunk's 2 tiles x this workgroup's 2*NW key blocks x 8 key pairs x
     // 32 query rows, built cooperatively while the chunk is staged (one block hash + 8 mads per entry, 2 entries per thread)
-    __shared__ __attribute__((aligned(16))) uint32_t dropW[DROP ? 2 : 1][DROP ? NW * 2 : 1][DROP ? 8 : 1][DROP ? 32 : 4];
+    // (rows padded to 36 words: at 32 every row starts on bank 0 or 32 and a lane group's 16 rows collide 8 ways)
+    __shared__ __attribute__((aligned(16))) uint32_t dropW[DROP ? 2 : 1][DROP ? NW * 2 : 1][DROP ? 8 : 1][DROP ? 36 : 4];
 
     const int T = p.T, H = p.H;
     const int nK = (T + 32 * NW - 1) / (32 * NW);
@@ -670,7 +671,8 @@ __device__ __forceinline__ void attn_bwd_dkv_body(const AttnParams& p, const int
                 const bf16x8 ad = *reinterpret_cast<const bf16x8*>(&dOs[t * 32 + kappa(n)][ks * 16 + 8 * hi]);
                 dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ad, vf[ks], dp, 0, 0, 0);
             }
-            const bool tail = q0 + 32 > T;
+            // (query rows >= T of the last tile need no masking: their bias_t columns are -inf -- both pack kernels write
+            // the padding so -- hence P = 0 and dS = 0 there; keys >= T live in lanes whose columns are never stored)
             // eight query rows at a time (row statistics, dropout words, P and dS of a half are dead before the next
             // half starts: ~50 fewer live registers than all sixteen at once)
 #pragma unroll
@@ -694,9 +696,7 @@ __device__ __forceinline__ void attn_bwd_dkv_body(const AttnParams& p, const int
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     const int i = 8 * s2 + j;
-                    float pr = fast_exp2(fmaf(s[i], MOBGT_LOG2E, -lse8[j]));
-                    // rows >= T of the last tile (keys >= T live in lanes whose columns are never stored)
-                    if (tail && q0 + 16 * hi + i >= T) pr = 0.f;
+                    const float pr = fast_exp2(fmaf(s[i], MOBGT_LOG2E, -lse8[j]));
                     if (DROP) {
                         // dS = P (M dP / (1-p) - delta) = X dP' - P delta with X = M P (what dV sums) and dP' = dO (V / (1-p))
                         // even key: low half of w, moved to the top by the lane's shift; odd key: high half
