@@ -1,0 +1,164 @@
+// GraphConvolution's adjacency product (graphormer/modelGNN.py:38-44 `torch.spmm(adj, support)`) for the DENSE-ish POI
+// graph of the Foursquare / Gowalla universes, from a BITMASK of the adjacency.
+//
+// The reference's adjacency is (D+I)^-1 (A+I) with a 0/1 "within 3 km" matrix A (model_fqandtoyo.py:481-486): every
+// non-zero of row i equals 1/(deg_i + 1).  Streaming it as a dense bf16 matrix costs 123 MB per product at P = 7 856
+// (39-44 us at ~3 TB/s, twice per step = 7.6 % of the S-FSQ step); as CSR it costs one gathered row of the operand per
+// non-zero (443 MB of L2 traffic at 2.8 % density, measured slower in round 1).  The structure says: ONE BIT per entry
+// (7.7 MB, L2 / MALL resident) and one f32 per row:
+//     out[i, :] = rscale[i] * sum_k bit(i, k) * (bscale[k] *) X[k, :]  (+ bias)
+// -- `rscale` = 1/(deg+1) for the forward product A X;  for the transposed product A^T G the mask of the transpose and
+// `bscale` = 1/(deg+1) on the operand's rows.  The product runs on v_mfma_f32_16x16x32_bf16: a lane's A operand (8
+// consecutive k of one row) is ONE BYTE of the mask, expanded to 8 bf16 ones / zeros by a 256-entry LDS table (one
+// ds_read_b128, no VALU); the B operand is X rounded to bf16 on the fly (what the dense path's bf16 `support` was), f32
+// accumulate, split-K over the waves of a workgroup, partial tiles meet in LDS.  With the GCN evaluated as (A X) W
+// instead of A (X W) the operand is 16 wide (modelGNN.GCN), i.e. 120 k MFMAs per product in all.
+#include "common.h"
+#include "mobgt_hip.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+struct MaskGemmParams {
+    const uint32_t* mask; int64_t ldm;      // [M, ldm] words, bit (k & 31) of word k >> 5 = entry (row, k); bits >= K are zero
+    const float* X; int64_t ldx;            // [K, N] f32
+    const float* bscale;                    // [K] or null
+    const float* rscale;                    // [M] or null
+    const float* bias;                      // [N] or null
+    float* out; int64_t ldo;                // [M, N] f32
+    int M, K, N;
+};
+
+// NB 16-column operands, NWAVE waves splitting K, RT 16-row tiles per workgroup
+template <int NB, int NWAVE, int RT, bool BSCALE>
+__global__ __launch_bounds__(NWAVE * 64) void mask_gemm_kernel(const MaskGemmParams p) {
+    constexpr int BM = 16 * RT, BN = 16 * NB, LDP = BN + 4;
+    __shared__ __attribute__((aligned(16))) uint4 lut[256];
+    __shared__ __attribute__((aligned(16))) float part[NWAVE][BM * LDP];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = lane & 15, kq = lane >> 4;
+    const int m0 = blockIdx.x * BM;
+    for (int b = threadIdx.x; b < 256; b += NWAVE * 64) {
+        uint32_t d[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) d[j] = ((b >> (2 * j)) & 1 ? 0x3F80u : 0u) | ((b >> (2 * j + 1)) & 1 ? 0x3F800000u : 0u);
+        lut[b] = make_uint4(d[0], d[1], d[2], d[3]);
+    }
+    __syncthreads();
+
+    const uint32_t* mrow[RT];
+#pragma unroll
+    for (int a = 0; a < RT; ++a) mrow[a] = p.mask + (int64_t)min(m0 + 16 * a + i, p.M - 1) * p.ldm;
+    f32x4 acc[RT][NB];
+#pragma unroll
+    for (int a = 0; a < RT; ++a)
+#pragma unroll
+        for (int b = 0; b < NB; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nsteps = (p.K + 31) >> 5;
+    struct Step {
+        uint32_t w[RT];
+        float x[NB][8];
+    };
+    // (k past K: the mask bits there are zero, so the operand only has to be finite -- the index is clamped, nothing is
+    // predicated per element)
+    auto load = [&](Step& s, const int ks) {
+#pragma unroll
+        for (int a = 0; a < RT; ++a) s.w[a] = mrow[a][ks];
+        const int k0 = 32 * ks + 8 * kq;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const int k = min(k0 + r, p.K - 1);
+            const float sc = BSCALE ? p.bscale[k] : 1.f;
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                const float v = p.X[(int64_t)k * p.ldx + 16 * b + i];
+                s.x[b][r] = BSCALE ? v * sc : v;
+            }
+        }
+    };
+    // A wave's k-steps are independent loads: keep DEPTH of them in flight (one step ahead, the kernel ran at the pace of
+    // one L2 round trip per step: 35 us for 16 steps per wave)
+    // Each wave owns a CONTIGUOUS block of k-steps: its successive mask words share cache lines (strided over the waves,
+    // every 64-byte line of a mask row was touched by 16 different waves at 16 different times).
+    constexpr int DEPTH = 2;
+    const int per = (nsteps + NWAVE - 1) / NWAVE;
+    const int s0 = wave * per, s1 = min(nsteps, s0 + per);
+    Step ring[DEPTH];
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d)
+        if (s0 + d < s1) load(ring[d], s0 + d);
+    auto compute = [&](const Step& cur) {
+        bf16x8 bf[NB];
+#pragma unroll
+        for (int b = 0; b < NB; ++b) bf[b] = pack8(cur.x[b]);
+#pragma unroll
+        for (int a = 0; a < RT; ++a) {
+            const bf16x8 af = __builtin_bit_cast(bf16x8, lut[(cur.w[a] >> (8 * kq)) & 0xffu]);
+#pragma unroll
+            for (int b = 0; b < NB; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bf[b], acc[a][b], 0, 0, 0);
+        }
+    };
+    for (int ks = s0; ks < s1; ks += DEPTH) {
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d) {
+            const int k = ks + d;
+            if (k < s1) {
+                compute(ring[d]);
+                if (k + DEPTH < s1) load(ring[d], k + DEPTH);
+            }
+        }
+    }
+
+    // register v of lane (j = lane & 15, q = lane >> 4) is MFMA row 4q + v, column j
+    float* mine = part[wave];
+#pragma unroll
+    for (int a = 0; a < RT; ++a)
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) mine[(16 * a + 4 * kq + v) * LDP + 16 * b + i] = acc[a][b][v];
+    __syncthreads();
+    for (int e = threadIdx.x; e < BM * (BN / 4); e += NWAVE * 64) {
+        const int r = e / (BN / 4), c = (e % (BN / 4)) * 4;
+        const int row = m0 + r;
+        if (row >= p.M || c >= p.N) continue;
+        float4 s = *reinterpret_cast<const float4*>(&part[0][r * LDP + c]);
+#pragma unroll
+        for (int w = 1; w < NWAVE; ++w) {
+            const float4 t = *reinterpret_cast<const float4*>(&part[w][r * LDP + c]);
+            s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+        }
+        const float rs = p.rscale ? p.rscale[row] : 1.f;
+        float4 b4 = p.bias ? *reinterpret_cast<const float4*>(p.bias + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        s.x = fmaf(s.x, rs, b4.x); s.y = fmaf(s.y, rs, b4.y); s.z = fmaf(s.z, rs, b4.z); s.w = fmaf(s.w, rs, b4.w);
+        *reinterpret_cast<float4*>(p.out + (int64_t)row * p.ldo + c) = s;
+    }
+}
+
+}  // namespace
+
+extern "C" int mobgt_mask_gemm(const uint32_t* mask, int64_t ld_mask_words, const float* x, int64_t ldx, const float* bscale,
+                               const float* rscale, const float* bias, float* out, int64_t ld_out, int M, int K, int N,
+                               void* stream) {
+    if (M <= 0 || K <= 0) return 0;
+    if (N <= 0 || (N & 15) || N > 64 || (ld_out & 3) || ld_mask_words * 32 < K) return MOBGT_EBADDIM;
+    if (((uintptr_t)out | (uintptr_t)bias) & 15) return MOBGT_EALIGN;
+    MaskGemmParams p = {mask, ld_mask_words, x, ldx, bscale, rscale, bias, out, ld_out, M, K, N};
+    hipStream_t st = (hipStream_t)stream;
+    // every workgroup walks ALL of X: tall row blocks (64 rows share each operand load) and 16 waves on K keep both the
+    // L2 -> CU traffic (P/64 x |X|) and the per-wave chain of k-steps short
+    const bool bs = bscale != nullptr;
+    if (N == 16) {
+        if (bs) hipLaunchKernelGGL((mask_gemm_kernel<1, 16, 4, true>), dim3((M + 63) / 64), dim3(1024), 0, st, p);
+        else hipLaunchKernelGGL((mask_gemm_kernel<1, 16, 4, false>), dim3((M + 63) / 64), dim3(1024), 0, st, p);
+    } else if (N == 32) {
+        if (bs) hipLaunchKernelGGL((mask_gemm_kernel<2, 16, 2, true>), dim3((M + 31) / 32), dim3(1024), 0, st, p);
+        else hipLaunchKernelGGL((mask_gemm_kernel<2, 16, 2, false>), dim3((M + 31) / 32), dim3(1024), 0, st, p);
+    } else {
+        if (bs) hipLaunchKernelGGL((mask_gemm_kernel<4, 8, 2, true>), dim3((M + 31) / 32), dim3(512), 0, st, p);
+        else hipLaunchKernelGGL((mask_gemm_kernel<4, 8, 2, false>), dim3((M + 31) / 32), dim3(512), 0, st, p);
+    }
+    return (int)hipGetLastError();
+}

@@ -133,6 +133,81 @@ def _rows_conv_ok(x, adj, rows):
             and rows.numel() % 8 == 0 and rows.numel() * 2 <= adj.shape[0] and rows.numel() <= 4096)
 
 
+class MaskAdj:
+    """The reference's normalised adjacency (D+I)^-1 (A+I) for a 0/1 matrix A as what it IS: a bit per entry plus one
+    scale per row (csrc/maskgemm.hip).  `mask` / `mask_t`: uint32 words [P, ceil(P/32)] of A+I and of its transpose,
+    `scale` f32 [P] = 1/(deg+1)."""
+
+    def __init__(self, mask, mask_t, scale):
+        self.mask, self.mask_t, self.scale = mask, mask_t, scale
+        self.shape = (scale.numel(), scale.numel())
+        self.dtype = torch.float32
+
+    @staticmethod
+    def from_dense01(adj01):
+        """0/1 numpy matrix A (zero diagonal) -> (mask, mask_t, scale) CPU tensors, or None if A is not 0/1."""
+        import numpy as np
+        a = np.asarray(adj01)
+        if not (np.all((a == 0) | (a == 1)) and not np.any(np.diagonal(a))):
+            return None
+        P = a.shape[0]
+        m = (a != 0) | np.eye(P, dtype=bool)
+        words = (P + 31) // 32
+
+        def pack(b):
+            by = np.packbits(b, axis=1, bitorder="little")
+            pad = np.zeros((P, words * 4), dtype=np.uint8)
+            pad[:, :by.shape[1]] = by
+            return torch.from_numpy(pad.view(np.uint32).astype(np.int64).astype(np.int32).reshape(P, words))
+        scale = torch.from_numpy((1.0 / (a.sum(axis=1).astype(np.float64) + 1.0)).astype(np.float32))
+        return pack(m), pack(m.T.copy()), scale
+
+
+def mask_gemm(adj, x, transposed=False, bias=None):
+    """adj @ x (or adj^T @ x) -> f32 [P, N] through csrc/maskgemm.hip; x f32 [P, N], N in {16, 32, 48, 64}."""
+    from . import _lib
+    from .ops import _p, _stream
+    x = x.contiguous()
+    P, N = x.shape
+    out = torch.empty(P, N, dtype=torch.float32, device=x.device)
+    mask = adj.mask_t if transposed else adj.mask
+    _lib.check(_lib.lib().mobgt_mask_gemm(_p(mask), mask.shape[1], _p(x), x.stride(0), _p(adj.scale if transposed else None),
+                                          _p(None if transposed else adj.scale), _p(bias), _p(out), N, P, P, N, _stream()),
+               "mobgt_mask_gemm")
+    return out
+
+
+class _MaskConvFn(torch.autograd.Function):
+    """out = adj @ (x @ W) + b evaluated as (adj @ x) @ W + b: the P x P product then has the layer's INPUT width (16 for
+    the second GraphConvolution) instead of its output width (64), and so has its transposed twin in the backward."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, adj):
+        ax = mask_gemm(adj, x)                                          # [P, in] f32
+        out = _mm_small(ax, weight)                                     # [P, out]  (K = in <= 64)
+        if bias is not None:
+            out = out + bias
+        ctx.save_for_backward(ax, weight)
+        ctx.adj, ctx.has_bias = adj, bias is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        ax, weight = ctx.saved_tensors
+        g = g.contiguous()
+        dW = mm_tn_splitk(ax, g, bf16_operands=True)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dax = _mm_small(g, weight, True)                            # g @ W^T  [P, in]
+            dx = mask_gemm(ctx.adj, dax, transposed=True)               # adj^T @ dax
+        db = _colsum(g) if ctx.has_bias else None
+        return dx, dW, db, None
+
+
+def _mask_conv_ok(x, weight):
+    return x.is_cuda and x.shape[1] in (16, 32, 48, 64) and weight.shape[0] == x.shape[1] and weight.shape[0] <= 64
+
+
 class CsrAdj:
     """The normalised adjacency (D+I)^-1 (A+I) as CSR on the device, with the CSR of its transpose (the backward's
     `adj^T @ g` is then the same gather kernel).  rowptr int64 [P+1], col int32 [nnz], val f32 [nnz]."""
@@ -234,7 +309,7 @@ class GraphConvolution(nn.Module):
         if self.bias is not None:
             self.bias.data.uniform_(-stdv, stdv)
 
-    def forward(self, input, adj, adj_input=None, adj_t=None, bias=True):
+    def forward(self, input, adj, adj_input=None, adj_t=None, bias=True, mask_adj=None):
         # X.W stays fp32 (raw features such as lat/lon need the mantissa); only the big dense adjacency
         # product runs in `adj`'s dtype (fp32, or bf16 in the bf16 configuration).  bias=False: the caller adds it
         # (GCN.forward fuses bias + LeakyReLU + dropout into one launch).
@@ -244,6 +319,8 @@ class GraphConvolution(nn.Module):
                 return _PreAggConvFn.apply(adj_input, self.weight, b)
             if isinstance(adj, CsrAdj):
                 return _SpConvFn.apply(input.float(), self.weight, b, adj, None)
+            if mask_adj is not None and _mask_conv_ok(input, self.weight):
+                return _MaskConvFn.apply(input.float(), self.weight, b, mask_adj)
             return _GraphConvFn.apply(input.float(), self.weight, b, adj, adj_t)
 
 
@@ -257,7 +334,7 @@ class GCN(nn.Module):
         for i in range(len(channels) - 1):
             self.gcn.append(GraphConvolution(channels[i], channels[i + 1]))
 
-    def forward(self, x, adj, adj_x=None, rows=None, adj_t=None):
+    def forward(self, x, adj, adj_x=None, rows=None, adj_t=None, mask_adj=None):
         """`adj_x` = adj @ x precomputed (x is a constant feature matrix in MobGT): skips the first P x P product.
         `rows` (int64 [R]): return only these rows of the output table, i.e. evaluate the LAST layer as
         adj[rows] @ (h W) + b.  The model reads the table only at the batch's POI ids
@@ -267,13 +344,13 @@ class GCN(nn.Module):
         if x.is_cuda and all(g.out_features % 4 == 0 and g.bias is not None for g in self.gcn[:-1]):
             from . import ops
             for i in range(n_hidden):       # bias + LeakyReLU (+ the dropout in front of the last layer) in one launch
-                h = self.gcn[i](x, adj, adj_x if i == 0 else None, adj_t, bias=False)
+                h = self.gcn[i](x, adj, adj_x if i == 0 else None, adj_t, bias=False, mask_adj=mask_adj)
                 x = ops.bias_act(h, self.gcn[i].bias, self.leaky_relu.negative_slope,
                                  self.dropout if i == n_hidden - 1 else 0.0, self.training,
                                  0x2000 + self.gcn[-1].out_features)
         else:
             for i in range(n_hidden):
-                x = self.leaky_relu(self.gcn[i](x, adj, adj_x if i == 0 else None, adj_t))
+                x = self.leaky_relu(self.gcn[i](x, adj, adj_x if i == 0 else None, adj_t, mask_adj=mask_adj))
             if x.is_cuda:
                 from . import ops
                 x = ops.dropout(x, self.dropout, self.training, 0x2000 + self.gcn[-1].out_features)
@@ -289,4 +366,4 @@ class GCN(nn.Module):
                 with torch.autocast(device_type=x.device.type, enabled=False):
                     return _RowsConvFn.apply(x.float(), last.weight, last.bias, adj, rows)
             return last(x, adj.index_select(0, rows))
-        return self.gcn[-1](x, adj, None, adj_t)
+        return self.gcn[-1](x, adj, None, adj_t, mask_adj=mask_adj)

@@ -209,6 +209,7 @@ class Graphormer(nn.Module):
             for name, t in zip(("D_A_rowptr", "D_A_col", "D_A_val", "D_AT_rowptr", "D_AT_col", "D_AT_val"), CsrAdj.from_scipy(a_hat)):
                 self.register_buffer(name, t, persistent=False)
             self.D_A = self.D_A_T = None
+            self.D_mask = self.D_mask_t = self.D_scale = None
         else:
             d_a = torch.from_numpy(calculate_laplacian_matrix(uni.graph_dist)).float()
             # A.X for the constant POI feature matrix, once, in fp32 (see modelGNN.GCN.forward)
@@ -217,6 +218,15 @@ class Graphormer(nn.Module):
             # the constant's transpose, stored once: the backward's adj^T @ g then streams rows like the forward
             self.register_buffer("D_A_T", d_a.t().contiguous().to(gcn_dtype) if gcn_dtype != torch.float32 else None,
                                  persistent=False)
+            # bf16 configuration: the 0/1 structure of the adjacency as a bitmask + row scale (modelGNN.MaskAdj); the
+            # hidden GraphConvolution layers then never stream the dense matrix (the rows-only last layer still gathers
+            # its <= G*N rows from it)
+            packed = None
+            if gcn_dtype == torch.bfloat16 and os.environ.get("MOBGT_NO_MASK_ADJ") != "1":
+                from .modelGNN import MaskAdj
+                packed = MaskAdj.from_dense01(uni.graph_dist)
+            for name, t in zip(("D_mask", "D_mask_t", "D_scale"), packed if packed is not None else (None, None, None)):
+                self.register_buffer(name, t, persistent=False)
         c_a = torch.from_numpy(calculate_laplacian_matrix(uni.graph_cat)).float()
         self.register_buffer("C_A", c_a, persistent=False)
         self.register_buffer("C_AX", c_a @ torch.from_numpy(C_X), persistent=False)
@@ -315,10 +325,13 @@ class Graphormer(nn.Module):
             from .modelGNN import CsrAdj
             adj = CsrAdj(self.D_A_rowptr, self.D_A_col, self.D_A_val, self.D_AT_rowptr, self.D_AT_col, self.D_AT_val)
             poidist = self.poi_distance_model(self.X, adj, self.D_AX, rows=gcn_rows.reshape(-1) if rows_only else None)
-        elif rows_only:
-            poidist = self.poi_distance_model(self.X, self.D_A, self.D_AX, rows=gcn_rows.reshape(-1), adj_t=self.D_A_T)
         else:
-            poidist = self.poi_distance_model(self.X, self.D_A, self.D_AX, adj_t=self.D_A_T)        # :1236
+            mask_adj = None
+            if getattr(self, "D_mask", None) is not None:
+                from .modelGNN import MaskAdj
+                mask_adj = MaskAdj(self.D_mask, self.D_mask_t, self.D_scale)
+            poidist = self.poi_distance_model(self.X, self.D_A, self.D_AX, rows=gcn_rows.reshape(-1) if rows_only else None,
+                                              adj_t=self.D_A_T, mask_adj=mask_adj)                  # :1236
         ops.trace_nan("poidist", poidist)
         catemb = self.poi_cat_model(self.C_X, self.C_A, self.C_AX)                                    # :1237
         # [poi ; time] and the category row, gathered for every position in one pass each

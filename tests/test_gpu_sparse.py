@@ -115,3 +115,36 @@ def test_big_workload_builds_and_steps_at_reduced_p():
     losses = [float(ts.step(i)) for i in range(3)]
     assert all(np.isfinite(losses)), losses
     assert float((ts.flat_params.tensor.detach() - p0).abs().max()) > 0
+
+
+def test_mask_gemm_matches_the_dense_normalised_adjacency():
+    """csrc/maskgemm.hip: (D+I)^-1 (A+I) @ X and its transpose from a bitmask + row scale, against the dense fp32
+    expression (model_fqandtoyo.py:481-486) with X rounded to bf16 (the kernel's MFMA operand), and the layer's autograd."""
+    from mobgt_amd.modelGNN import MaskAdj, mask_gemm, _MaskConvFn
+    from mobgt_amd.model_fqandtoyo import calculate_laplacian_matrix
+    for P in (333, 1000):
+        uni = synth.make_universe(P=P, n_cat=8, n_user=8, seed=P)
+        dense = torch.from_numpy(calculate_laplacian_matrix(uni.graph_dist)).float().to(DEV)
+        adj = MaskAdj(*[t.to(DEV) for t in MaskAdj.from_dense01(uni.graph_dist)])
+        g = torch.Generator().manual_seed(P)
+        for N in (16, 64):
+            x = torch.randn(P, N, generator=g).to(DEV)
+            xr = x.bfloat16().float()
+            np.testing.assert_allclose(mask_gemm(adj, x).cpu().numpy(), (dense @ xr).cpu().numpy(), rtol=1e-4, atol=1e-5)
+            want_t = dense.t() @ (x * 1.0)                      # (the kernel scales the operand's rows BEFORE rounding)
+            got_t = mask_gemm(adj, x, transposed=True)
+            np.testing.assert_allclose(got_t.cpu().numpy(), want_t.cpu().numpy(), rtol=2e-2, atol=2e-2 * float(want_t.abs().max()))
+        x = torch.randn(P, 16, generator=g).to(DEV)
+        w = (torch.randn(16, 64, generator=g) * 0.2).to(DEV)
+        b = torch.randn(64, generator=g).to(DEV)
+        up = torch.randn(P, 64, generator=g).to(DEV)
+        xa, wa, ba = (t.clone().requires_grad_(True) for t in (x, w, b))
+        ref = dense @ (xa @ wa) + ba
+        (ref * up).sum().backward()
+        xb, wb, bb = (t.clone().requires_grad_(True) for t in (x, w, b))
+        out = _MaskConvFn.apply(xb, wb, bb, adj)
+        (out * up).sum().backward()
+        for got, want, n in ((out, ref, "out"), (xb.grad, xa.grad, "dx"), (wb.grad, wa.grad, "dW"), (bb.grad, ba.grad, "db")):
+            scale = float(want.detach().abs().max())
+            np.testing.assert_allclose(got.detach().cpu().numpy(), want.detach().cpu().numpy(), rtol=0, atol=2e-2 * scale, err_msg=n)
+    assert MaskAdj.from_dense01(uni.graph_dist * 2.0) is None       # not a 0/1 matrix: the dense path stays
