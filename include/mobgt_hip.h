@@ -382,10 +382,15 @@ int mobgt_small_gemm_f32(const float* a, int64_t lda, const float* b, int64_t ld
 /* The same adjacency product from a BITMASK of the adjacency (csrc/maskgemm.hip) -- for the reference's
  * (D+I)^-1 (A+I) with a 0/1 matrix A, whose non-zeros of row i all equal 1/(deg_i + 1) (model_fqandtoyo.py:481-486):
  *   out[i,:] = rscale[i] * sum_k bit(i,k) * bscale[k] * x[k,:] + bias          (rscale / bscale / bias may be null)
- * mask: [M, ld_mask_words] uint32, bit (k & 31) of word (k >> 5) of row i = entry (i,k), bits >= K zero; x [K,N] f32 (rounded
- * to bf16 as MFMA operand, f32 accumulate), out [M,N] f32, N in {16, 32, 48, 64}. */
+ * mask: [M, ld_mask_words] uint32 (ld_mask_words % 4 == 0 and * 32 >= roundup(K, 128)), bit (k & 31) of word (k >> 5) of
+ * row i = entry (i,k), bits >= K zero; x [K,N] f32 (rounded
+ * to bf16 as MFMA operand, f32 accumulate), out [M,N] f32, N in {16, 32, 48, 64}.
+ * work: mobgt_mask_gemm_workspace_bytes(K, N) bytes of device scratch (the operand transposed to bf16 [N][K], written by
+ * a first small launch so that the product reads 16 bytes per MFMA operand). */
+int64_t mobgt_mask_gemm_workspace_bytes(int K, int N);
 int mobgt_mask_gemm(const uint32_t* mask, int64_t ld_mask_words, const float* x, int64_t ldx, const float* bscale,
-                    const float* rscale, const float* bias, float* out, int64_t ld_out, int M, int K, int N, void* stream);
+                    const float* rscale, const float* bias, float* out, int64_t ld_out, void* work, int M, int K, int N,
+                    void* stream);
 int mobgt_spmm_csr(const int64_t* rowptr, const int32_t* col, const float* val, const int64_t* rows, const float* b,
                    int64_t ldb, const float* bias, float* out, int64_t ld_out, int64_t R, int C, void* stream);
 int mobgt_spmm_csr_t_rows(const int64_t* rowptr, const int32_t* col, const float* val, const int64_t* rows,

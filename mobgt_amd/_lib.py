@@ -66,7 +66,8 @@ SIGNATURES = {
     "mobgt_layer_gemm": (_i, [_vp, _i64, _vp, _i64, _i, _vp, _vp, _i64, _i, _vp, _vp, _i, _i, _i, _vp]),
     "mobgt_ln_gemm_fwd": (_i, [_vp] * 8 + [_i64, _i, _f, _u64, _vp, _c.c_uint32, _vp, _i64, _vp, _vp, _i64, _i, _vp, _i, _vp]),
     "mobgt_ln_gemm_bwd": (_i, [_vp] * 12 + [_i64, _i, _f, _u64, _vp, _c.c_uint32, _vp, _i64, _vp, _i64, _i, _vp, _i, _vp]),
-    "mobgt_mask_gemm": (_i, [_vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _vp]),
+    "mobgt_mask_gemm_workspace_bytes": (_i64, [_i, _i]),
+    "mobgt_mask_gemm": (_i, [_vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _vp, _i, _i, _i, _vp]),
     "mobgt_spmm_csr": (_i, [_vp] * 5 + [_i64, _vp, _vp, _i64, _i64, _i, _vp]),
     "mobgt_spmm_csr_t_rows": (_i, [_vp] * 5 + [_i64, _vp, _i64, _i64, _i, _vp]),
     "mobgt_step_prologue": (_i, [_vp, _i64, _vp, _i64, _vp, _vp]),

@@ -21,8 +21,9 @@ namespace {
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
 struct MaskGemmParams {
-    const uint32_t* mask; int64_t ldm;      // [M, ldm] words, bit (k & 31) of word k >> 5 = entry (row, k); bits >= K are zero
+    const uint32_t* mask; int64_t ldm;      // [M, ldm] words (ldm % 4 == 0, ldm * 32 >= roundup(K, 128)), bit (k & 31) of word k >> 5 = entry (row, k); bits >= K zero
     const float* X; int64_t ldx;            // [K, N] f32
+    const uint16_t* Xt; int64_t ldxt;       // [N, ldxt] bf16: X transposed (and scaled by bscale), zero beyond K -- or null
     const float* bscale;                    // [K] or null
     const float* rscale;                    // [M] or null
     const float* bias;                      // [N] or null
@@ -30,8 +31,27 @@ struct MaskGemmParams {
     int M, K, N;
 };
 
+// xt[n][k] = bf16(x[k][n] * bscale[k]), zero for K <= k < ldxt: 64 k x N per workgroup through an LDS tile, so that both the
+// reads (rows of x) and the writes (128-byte runs of xt) are contiguous
+__global__ __launch_bounds__(256) void xt_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ bscale,
+                                                 uint16_t* __restrict__ xt, int64_t ldxt, int K, int N) {
+    __shared__ float tile[64][65];
+    const int k0 = blockIdx.x * 64;
+    for (int e = threadIdx.x; e < 64 * N; e += 256) {
+        const int kk = e / N, n = e % N, k = k0 + kk;
+        float v = 0.f;
+        if (k < K) v = x[(int64_t)k * ldx + n] * (bscale ? bscale[k] : 1.f);
+        tile[kk][n] = v;
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < N * 64; e += 256) {
+        const int n = e / 64, kk = e % 64;
+        if (k0 + kk < ldxt) xt[(int64_t)n * ldxt + k0 + kk] = __builtin_bit_cast(uint16_t, (bf16_t)tile[kk][n]);
+    }
+}
+
 // NB 16-column operands, NWAVE waves splitting K, RT 16-row tiles per workgroup
-template <int NB, int NWAVE, int RT, bool BSCALE>
+template <int NB, int NWAVE, int RT>
 __global__ __launch_bounds__(NWAVE * 64) void mask_gemm_kernel(const MaskGemmParams p) {
     constexpr int BM = 16 * RT, BN = 16 * NB, LDP = BN + 4;
     __shared__ __attribute__((aligned(16))) uint4 lut[256];
@@ -57,58 +77,45 @@ __global__ __launch_bounds__(NWAVE * 64) void mask_gemm_kernel(const MaskGemmPar
         for (int b = 0; b < NB; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int nsteps = (p.K + 31) >> 5;
-    struct Step {
-        uint32_t w[RT];
-        float x[NB][8];
+    // Loads come in GROUPS of four k-steps: one 16-byte load of four mask words per row tile (a workgroup's 64 mask rows
+    // are 63 KB, twice the CU's L1: word-by-word, every step paid an L2 round trip) and four 16-byte B operands -- 8
+    // consecutive k of one column from the transposed bf16 copy (xt_kernel).  Each wave owns a contiguous, 4-aligned block
+    // of k-steps and keeps the next group in flight.
+    struct Group {
+        uint4 w[RT];
+        uint4 b[4][NB];
     };
-    // (k past K: the mask bits there are zero, so the operand only has to be finite -- the index is clamped, nothing is
-    // predicated per element)
-    auto load = [&](Step& s, const int ks) {
-#pragma unroll
-        for (int a = 0; a < RT; ++a) s.w[a] = mrow[a][ks];
-        const int k0 = 32 * ks + 8 * kq;
-#pragma unroll
-        for (int r = 0; r < 8; ++r) {
-            const int k = min(k0 + r, p.K - 1);
-            const float sc = BSCALE ? p.bscale[k] : 1.f;
-#pragma unroll
-            for (int b = 0; b < NB; ++b) {
-                const float v = p.X[(int64_t)k * p.ldx + 16 * b + i];
-                s.x[b][r] = BSCALE ? v * sc : v;
-            }
-        }
-    };
-    // A wave's k-steps are independent loads: keep DEPTH of them in flight (one step ahead, the kernel ran at the pace of
-    // one L2 round trip per step: 35 us for 16 steps per wave)
-    // Each wave owns a CONTIGUOUS block of k-steps: its successive mask words share cache lines (strided over the waves,
-    // every 64-byte line of a mask row was touched by 16 different waves at 16 different times).
-    constexpr int DEPTH = 2;
-    const int per = (nsteps + NWAVE - 1) / NWAVE;
+    const int per = ((nsteps + NWAVE - 1) / NWAVE + 3) & ~3;
     const int s0 = wave * per, s1 = min(nsteps, s0 + per);
-    Step ring[DEPTH];
+    auto load = [&](Group& g, const int ks) {                     // ks % 4 == 0; rows are padded to whole groups
 #pragma unroll
-    for (int d = 0; d < DEPTH; ++d)
-        if (s0 + d < s1) load(ring[d], s0 + d);
-    auto compute = [&](const Step& cur) {
-        bf16x8 bf[NB];
+        for (int a = 0; a < RT; ++a) g.w[a] = *reinterpret_cast<const uint4*>(mrow[a] + ks);
 #pragma unroll
-        for (int b = 0; b < NB; ++b) bf[b] = pack8(cur.x[b]);
+        for (int u = 0; u < 4; ++u)
 #pragma unroll
-        for (int a = 0; a < RT; ++a) {
-            const bf16x8 af = __builtin_bit_cast(bf16x8, lut[(cur.w[a] >> (8 * kq)) & 0xffu]);
-#pragma unroll
-            for (int b = 0; b < NB; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bf[b], acc[a][b], 0, 0, 0);
-        }
+            for (int b = 0; b < NB; ++b)
+                g.b[u][b] = *reinterpret_cast<const uint4*>(p.Xt + (int64_t)(16 * b + i) * p.ldxt + 32 * (ks + u) + 8 * kq);
     };
-    for (int ks = s0; ks < s1; ks += DEPTH) {
+    auto compute = [&](const Group& g, const int ks) {
 #pragma unroll
-        for (int d = 0; d < DEPTH; ++d) {
-            const int k = ks + d;
-            if (k < s1) {
-                compute(ring[d]);
-                if (k + DEPTH < s1) load(ring[d], k + DEPTH);
+        for (int u = 0; u < 4; ++u) {
+            if (ks + u >= s1) break;
+#pragma unroll
+            for (int a = 0; a < RT; ++a) {
+                const uint32_t w = u == 0 ? g.w[a].x : (u == 1 ? g.w[a].y : (u == 2 ? g.w[a].z : g.w[a].w));
+                const bf16x8 af = __builtin_bit_cast(bf16x8, lut[(w >> (8 * kq)) & 0xffu]);
+#pragma unroll
+                for (int b = 0; b < NB; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, __builtin_bit_cast(bf16x8, g.b[u][b]), acc[a][b], 0, 0, 0);
             }
         }
+    };
+    Group cur, nxt;
+    if (s0 < s1) load(cur, s0);
+    for (int ks = s0; ks < s1; ks += 4) {
+        if (ks + 4 < s1) load(nxt, ks + 4);
+        compute(cur, ks);
+        if (ks + 4 < s1) cur = nxt;
     }
 
     // register v of lane (j = lane & 15, q = lane >> 4) is MFMA row 4q + v, column j
@@ -139,26 +146,27 @@ __global__ __launch_bounds__(NWAVE * 64) void mask_gemm_kernel(const MaskGemmPar
 
 }  // namespace
 
+extern "C" int64_t mobgt_mask_gemm_workspace_bytes(int K, int N) {
+    return (int64_t)N * (((int64_t)K + 127) / 128 * 128) * 2;
+}
+
 extern "C" int mobgt_mask_gemm(const uint32_t* mask, int64_t ld_mask_words, const float* x, int64_t ldx, const float* bscale,
-                               const float* rscale, const float* bias, float* out, int64_t ld_out, int M, int K, int N,
-                               void* stream) {
+                               const float* rscale, const float* bias, float* out, int64_t ld_out, void* work, int M, int K,
+                               int N, void* stream) {
     if (M <= 0 || K <= 0) return 0;
-    if (N <= 0 || (N & 15) || N > 64 || (ld_out & 3) || ld_mask_words * 32 < K) return MOBGT_EBADDIM;
-    if (((uintptr_t)out | (uintptr_t)bias) & 15) return MOBGT_EALIGN;
-    MaskGemmParams p = {mask, ld_mask_words, x, ldx, bscale, rscale, bias, out, ld_out, M, K, N};
+    if (N <= 0 || (N & 15) || N > 64 || (ld_out & 3) || ld_mask_words * 32 < K || !work) return MOBGT_EBADDIM;
+    if (((uintptr_t)out | (uintptr_t)bias | (uintptr_t)work) & 15) return MOBGT_EALIGN;
+    const int64_t ldxt = ((int64_t)K + 127) / 128 * 128;          // whole groups of four k-steps
+    if (ld_mask_words % 4 || ld_mask_words * 32 < ldxt) return MOBGT_EBADDIM;
+    MaskGemmParams p = {mask, ld_mask_words, x, ldx, reinterpret_cast<const uint16_t*>(work), ldxt, bscale, rscale, bias, out,
+                        ld_out, M, K, N};
     hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(xt_kernel, dim3((unsigned)(ldxt / 64)), dim3(256), 0, st, x, ldx, bscale, reinterpret_cast<uint16_t*>(work),
+                       ldxt, K, N);
     // every workgroup walks ALL of X: tall row blocks (64 rows share each operand load) and 16 waves on K keep both the
     // L2 -> CU traffic (P/64 x |X|) and the per-wave chain of k-steps short
-    const bool bs = bscale != nullptr;
-    if (N == 16) {
-        if (bs) hipLaunchKernelGGL((mask_gemm_kernel<1, 16, 4, true>), dim3((M + 63) / 64), dim3(1024), 0, st, p);
-        else hipLaunchKernelGGL((mask_gemm_kernel<1, 16, 4, false>), dim3((M + 63) / 64), dim3(1024), 0, st, p);
-    } else if (N == 32) {
-        if (bs) hipLaunchKernelGGL((mask_gemm_kernel<2, 16, 2, true>), dim3((M + 31) / 32), dim3(1024), 0, st, p);
-        else hipLaunchKernelGGL((mask_gemm_kernel<2, 16, 2, false>), dim3((M + 31) / 32), dim3(1024), 0, st, p);
-    } else {
-        if (bs) hipLaunchKernelGGL((mask_gemm_kernel<4, 8, 2, true>), dim3((M + 31) / 32), dim3(512), 0, st, p);
-        else hipLaunchKernelGGL((mask_gemm_kernel<4, 8, 2, false>), dim3((M + 31) / 32), dim3(512), 0, st, p);
-    }
+    if (N == 16) hipLaunchKernelGGL((mask_gemm_kernel<1, 16, 4>), dim3((M + 63) / 64), dim3(1024), 0, st, p);
+    else if (N == 32) hipLaunchKernelGGL((mask_gemm_kernel<2, 16, 2>), dim3((M + 31) / 32), dim3(1024), 0, st, p);
+    else hipLaunchKernelGGL((mask_gemm_kernel<4, 8, 2>), dim3((M + 31) / 32), dim3(512), 0, st, p);
     return (int)hipGetLastError();
 }

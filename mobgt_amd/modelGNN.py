@@ -152,7 +152,7 @@ class MaskAdj:
             return None
         P = a.shape[0]
         m = (a != 0) | np.eye(P, dtype=bool)
-        words = (P + 31) // 32
+        words = (P + 127) // 128 * 4                                   # whole groups of four 32-bit words per row
 
         def pack(b):
             by = np.packbits(b, axis=1, bitorder="little")
@@ -170,10 +170,11 @@ def mask_gemm(adj, x, transposed=False, bias=None):
     x = x.contiguous()
     P, N = x.shape
     out = torch.empty(P, N, dtype=torch.float32, device=x.device)
+    work = torch.empty(int(_lib.lib().mobgt_mask_gemm_workspace_bytes(P, N)), dtype=torch.uint8, device=x.device)
     mask = adj.mask_t if transposed else adj.mask
     _lib.check(_lib.lib().mobgt_mask_gemm(_p(mask), mask.shape[1], _p(x), x.stride(0), _p(adj.scale if transposed else None),
-                                          _p(None if transposed else adj.scale), _p(bias), _p(out), N, P, P, N, _stream()),
-               "mobgt_mask_gemm")
+                                          _p(None if transposed else adj.scale), _p(bias), _p(out), N, _p(work), P, P, N,
+                                          _stream()), "mobgt_mask_gemm")
     return out
 
 
