@@ -379,6 +379,22 @@ int mobgt_small_gemm_f32(const float* a, int64_t lda, const float* b, int64_t ld
  *                         rowptr int64 [n+1], col int32, val f32; b [n_cols, C] f32 (ldb), out [R, C] f32 (ld_out), C % 4 == 0.
  *   mobgt_spmm_csr_t_rows db[col[e],:] += val[e] g[i,:]  (autograd of the row-subset product; db zero-initialised, atomics).
  */
+/* The whole 3-layer GCN of a SMALL dense graph (graphormer/modelGNN.py:53-74 on the ~300-node category graph,
+ * model_fqandtoyo.py:1237) as ONE launch each way (csrc/smallgcn.hip): ceil(n/16) co-resident workgroups that meet at
+ * `counter` (int[1], ZERO on entry) between the layers.
+ *   forward   h1 = leaky(ax w0 + b0);  t = a h1;  h2 = dropout(leaky(t w1 + b1));  t2 = a h2;  out = t2 w2 + b2
+ *             ax = a @ x precomputed [n,K0]; a [n,n]; w* [in,out] row-major; h1/t [n,H1], h2/t2 [n,H2] are kept for the
+ *             backward; out [n,H3].  (H1, H2, H3) = (16, 64, 32) (the widths MobGT uses; others: MOBGT_EBADDIM); n <= 4096.  Dropout mask / slope as mobgt_bias_act_fwd.
+ *   backward  g = d(out); a_t = a^T [n,n]; dw* / db* are ACCUMULATED (f32 atomics: zero them first); dt2 [n,H2] and
+ *             dt [n,H1] are scratch. */
+int mobgt_small_gcn_fwd(const float* ax, const float* a, const float* w0, const float* b0, const float* w1, const float* b1,
+                        const float* w2, const float* b2, float* h1, float* t, float* h2, float* t2, float* out, int* counter,
+                        int n, int K0, int H1, int H2, int H3, float slope, float dropout_p, uint64_t seed,
+                        const uint64_t* seed_dev, uint32_t salt, void* stream);
+int mobgt_small_gcn_bwd(const float* g, const float* ax, const float* a_t, const float* w1, const float* w2, const float* h1,
+                        const float* t, const float* h2, const float* t2, float* dw0, float* db0, float* dw1, float* db1,
+                        float* dw2, float* db2, float* dt2, float* dt, int* counter, int n, int K0, int H1, int H2, int H3,
+                        float slope, float dropout_p, uint64_t seed, const uint64_t* seed_dev, uint32_t salt, void* stream);
 /* The same adjacency product from a BITMASK of the adjacency (csrc/maskgemm.hip) -- for the reference's
  * (D+I)^-1 (A+I) with a 0/1 matrix A, whose non-zeros of row i all equal 1/(deg_i + 1) (model_fqandtoyo.py:481-486):
  *   out[i,:] = rscale[i] * sum_k bit(i,k) * bscale[k] * x[k,:] + bias          (rscale / bscale / bias may be null)

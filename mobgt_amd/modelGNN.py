@@ -9,6 +9,7 @@ names and init match the reference.  Two MI355X-minded changes in HOW the same m
   workgroups (measured 153 us each), so they are evaluated split-K as a batched GEMM + a sum.
 """
 import math
+import os
 
 import torch
 import torch.nn as nn
@@ -325,6 +326,67 @@ class GraphConvolution(nn.Module):
             return _GraphConvFn.apply(input.float(), self.weight, b, adj, adj_t)
 
 
+def _small_gcn_ok(gcn, x, adj, adj_x, adj_t):
+    """The whole network as one launch each way (csrc/smallgcn.hip): a 3-layer GCN on a small dense f32 graph whose
+    constant first product adj @ x and transpose are supplied."""
+    if os.environ.get("MOBGT_NO_SMALL_GCN") == "1" or len(gcn.gcn) != 3:
+        return False
+    if not (torch.is_tensor(adj) and adj.is_cuda and adj.dtype == torch.float32 and adj.dim() == 2 and adj.is_contiguous()):
+        return False
+    if adj_x is None or adj_t is None or adj_x.dtype != torch.float32 or adj_t.dtype != torch.float32:
+        return False
+    n = adj.shape[0]
+    if n > 1024 or adj.shape[1] != n or tuple(adj_t.shape) != (n, n) or adj_x.shape[0] != n:
+        return False
+    if adj_x.shape[1] != gcn.gcn[0].in_features or not adj_x.is_contiguous() or not adj_t.is_contiguous():
+        return False
+    h1, h2, h3 = (g.out_features for g in gcn.gcn)
+    return all(g.bias is not None and g.weight.dtype == torch.float32 and g.weight.data_ptr() % 16 == 0 for g in gcn.gcn) and \
+        (h1, h2, h3) == (16, 64, 32) and gcn.gcn[1].in_features == h1 and gcn.gcn[2].in_features == h2
+
+
+class _SmallGcnFn(torch.autograd.Function):
+    """graphormer/modelGNN.py:53-74 for a small graph: forward and backward are one persistent launch each."""
+
+    @staticmethod
+    def forward(ctx, ax, a, a_t, w0, b0, w1, b1, w2, b2, slope, p_drop, seed, seed_dev, salt):
+        from . import _lib, ops
+        from .ops import _p, _stream
+        n, K0 = ax.shape
+        H1, H2, H3 = w0.shape[1], w1.shape[1], w2.shape[1]
+        ws = [w.contiguous() for w in (w0, b0, w1, b1, w2, b2)]
+        keep = torch.empty(n * (2 * H1 + 2 * H2), dtype=torch.float32, device=ax.device)
+        h1, t, h2, t2 = keep.split([n * H1, n * H1, n * H2, n * H2])
+        out = torch.empty(n, H3, dtype=torch.float32, device=ax.device)
+        counter = ops.zeros_f32((4,), ax.device)                 # zero bits = zero ints
+        _lib.check(_lib.lib().mobgt_small_gcn_fwd(_p(ax), _p(a), *[_p(w) for w in ws], _p(h1), _p(t), _p(h2), _p(t2), _p(out),
+                                                  _p(counter), n, K0, H1, H2, H3, slope, p_drop, seed, _p(seed_dev), salt,
+                                                  _stream()), "mobgt_small_gcn_fwd")
+        ctx.save_for_backward(ax, a_t, ws[2], ws[4], keep)
+        ctx.misc = (slope, p_drop, seed, seed_dev, salt, n, K0, H1, H2, H3)
+        ctx.sinks = [ops.grad_sink(w) for w in (w0, b0, w1, b1, w2, b2)]
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        from . import _lib, ops
+        from .ops import _p, _stream
+        ax, a_t, w1, w2, keep = ctx.saved_tensors
+        slope, p_drop, seed, seed_dev, salt, n, K0, H1, H2, H3 = ctx.misc
+        h1, t, h2, t2 = keep.split([n * H1, n * H1, n * H2, n * H2])
+        shapes = [(K0, H1), (H1,), (H1, H2), (H2,), (H2, H3), (H3,)]
+        # the kernel ACCUMULATES its workgroups' partial sums: into the trainer's (zeroed) flat gradient when it
+        # registered one, else into fresh zeros
+        grads = [s[:] if s is not None else ops.zeros_f32(shape, ax.device) for s, shape in zip(ctx.sinks, shapes)]
+        scratch = torch.empty(n * (H1 + H2), dtype=torch.float32, device=ax.device)
+        counter = ops.zeros_f32((4,), ax.device)
+        _lib.check(_lib.lib().mobgt_small_gcn_bwd(_p(g.contiguous()), _p(ax), _p(a_t), _p(w1), _p(w2), _p(h1), _p(t), _p(h2),
+                                                  _p(t2), *[_p(x) for x in grads], _p(scratch[n * H1:]), _p(scratch[:n * H1]),
+                                                  _p(counter), n, K0, H1, H2, H3, slope, p_drop, seed, _p(seed_dev), salt,
+                                                  _stream()), "mobgt_small_gcn_bwd")
+        return (None, None, None, *grads, None, None, None, None, None)
+
+
 class GCN(nn.Module):
     def __init__(self, ninput, nhid, noutput, dropout):
         super().__init__()
@@ -342,6 +404,15 @@ class GCN(nn.Module):
         (model_fqandtoyo.py:1264), so for R << P this replaces a P x P product (and its transpose in the
         backward) by an R x P one without changing any value that is used."""
         n_hidden = len(self.gcn) - 1
+        if rows is None and mask_adj is None and x.is_cuda and _small_gcn_ok(self, x, adj, adj_x, adj_t):
+            from . import ops
+            p_drop = self.dropout if self.training else 0.0
+            seed, seed_dev = ops.dropout_seed(p_drop)
+            g0, g1, g2 = self.gcn
+            with torch.autocast(device_type="cuda", enabled=False):
+                return _SmallGcnFn.apply(adj_x, adj, adj_t, g0.weight, g0.bias, g1.weight, g1.bias, g2.weight, g2.bias,
+                                         float(self.leaky_relu.negative_slope), float(p_drop), seed, seed_dev,
+                                         (0x2000 + g2.out_features) & 0xFFFFFFFF)
         if x.is_cuda and all(g.out_features % 4 == 0 and g.bias is not None for g in self.gcn[:-1]):
             from . import ops
             for i in range(n_hidden):       # bias + LeakyReLU (+ the dropout in front of the last layer) in one launch

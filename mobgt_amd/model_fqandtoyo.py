@@ -229,6 +229,7 @@ class Graphormer(nn.Module):
                 self.register_buffer(name, t, persistent=False)
         c_a = torch.from_numpy(calculate_laplacian_matrix(uni.graph_cat)).float()
         self.register_buffer("C_A", c_a, persistent=False)
+        self.register_buffer("C_A_T", c_a.t().contiguous(), persistent=False)
         self.register_buffer("C_AX", c_a @ torch.from_numpy(C_X), persistent=False)
         # POI id (1..P) -> category id (1..n_cat); row 0 = pad.  Replaces poi_idx2cat_idx_dict (:1106-1108)
         poi2cat = np.zeros(P + 1, dtype=np.int64)
@@ -333,7 +334,7 @@ class Graphormer(nn.Module):
             poidist = self.poi_distance_model(self.X, self.D_A, self.D_AX, rows=gcn_rows.reshape(-1) if rows_only else None,
                                               adj_t=self.D_A_T, mask_adj=mask_adj)                  # :1236
         ops.trace_nan("poidist", poidist)
-        catemb = self.poi_cat_model(self.C_X, self.C_A, self.C_AX)                                    # :1237
+        catemb = self.poi_cat_model(self.C_X, self.C_A, self.C_AX, adj_t=self.C_A_T)                                    # :1237
         # [poi ; time] and the category row, gathered for every position in one pass each
         pt = ops.embed_gather_concat([poidist, self.time_embed_model_48.weight], [poi_idx, time_idx], padding_idx=[None, 0])
         f2 = self.embed_fuse_model2.leaky_relu(

@@ -753,6 +753,15 @@ class _BiasActFn(torch.autograd.Function):
         return dx, db, None, None, None, None, None
 
 
+def dropout_seed(p_drop):
+    """(host seed, device step counter or None) for one dropout site -- what `dropout` / `bias_act` use: without a device
+    counter every call draws a fresh host seed."""
+    seed, seed_dev = _DROPOUT_STATE["seed"], _DROPOUT_STATE["seed_dev"]
+    if seed_dev is None and p_drop > 0:
+        seed = (seed + int(torch.randint(0, 2 ** 31 - 1, (1,)).item())) & 0x7FFFFFFFFFFFFFFF
+    return int(seed), seed_dev
+
+
 def bias_act(x, bias, slope, p_drop, training, salt):
     """dropout(leaky_relu(x + bias, slope)) on a 2-D f32 tensor in one launch; the backward also yields bias.grad."""
     _require_cuda(x)
