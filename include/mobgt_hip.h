@@ -379,6 +379,23 @@ int mobgt_small_gemm_f32(const float* a, int64_t lda, const float* b, int64_t ld
  *                         rowptr int64 [n+1], col int32, val f32; b [n_cols, C] f32 (ldb), out [R, C] f32 (ld_out), C % 4 == 0.
  *   mobgt_spmm_csr_t_rows db[col[e],:] += val[e] g[i,:]  (autograd of the row-subset product; db zero-initialised, atomics).
  */
+/* Everything of an fq encoder layer that is row-local, in ONE launch (csrc/chain.hip; graphormer/model.py:455, :388-403,
+ * model_fqandtoyo.py:1731-1743):  y = a wo^T + bo;  x1 = x + dropout(y);  z = ffn_norm1(x1);  u = z w1^T + b1;
+ * h = gelu(u);  f = h w2^T + b2;  x2 = x1 + dropout(f);  out = ffn_norm2(x2);  qkv_next = out wq_next^T + bq_next.
+ * a [R,C] bf16; x [R,C] f32; weights bf16 [out,in] PACKED by mobgt_pack_mfma_b; biases bf16; LayerNorm weights f32.
+ * Written: x1, x2, out f32 [R,C]; z, out_a (= bf16(out)) [R,C], u, h [R,F], qkv_next [R,3C] bf16; mean / rstd [R] f32 of
+ * both norms.  wq_next / bq_next / qkv_next null for the last layer.  Dropout masks: those of mobgt_dropout_add_ln_fwd
+ * with salt1 / salt2.  (C, F) in {(192, 1024), (256, 1024)}. */
+/* bf16 weight [N,K] row-major -> MFMA operand order (chain.hip): the 16 bytes W[16g + j][32s + 8q .. +7] go to byte offset
+ * ((g K/32 + s) 64 + j + 16q) * 16, so that a wave's B-operand load is one contiguous KB.  n <= 32 jobs in one launch;
+ * N % 16 == 0, K % 32 == 0. */
+int mobgt_pack_mfma_b(int n, const void* const* src, void* const* dst, const int* N, const int* K, void* stream);
+int mobgt_layer_chain_fwd(const void* a, const float* x, const void* wo, const void* bo, const float* n1w, const float* n1b,
+                          const void* w1, const void* b1, const void* w2, const void* b2, const float* nxw, const float* nxb,
+                          const void* wq_next, const void* bq_next, float* x1, void* z, void* u, void* h, float* x2, float* out,
+                          void* out_a, void* qkv_next, float* mean1, float* rstd1, float* mean2, float* rstd2, int64_t R, int C,
+                          int F, float dropout_p, uint64_t seed, const uint64_t* seed_dev, uint32_t salt1, uint32_t salt2,
+                          void* stream);
 /* The whole 3-layer GCN of a SMALL dense graph (graphormer/modelGNN.py:53-74 on the ~300-node category graph,
  * model_fqandtoyo.py:1237) as ONE launch each way (csrc/smallgcn.hip): ceil(n/16) co-resident workgroups that meet at
  * `counter` (int[1], ZERO on entry) between the layers.

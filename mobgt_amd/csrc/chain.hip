@@ -1,0 +1,401 @@
+// Everything of an encoder layer that is ROW-LOCAL, as one launch (graphormer/model.py:479-489 /
+// model_fqandtoyo.py:1731-1743, the fq layer: post-LayerNorm after the attention AND after the FFN):
+//
+//     y   = a Wo^T + bo                      output_layer of MultiHeadAttention (model.py:455)
+//     x1  = x + dropout(y);  z = ffn_norm1(x1)
+//     u   = z W1^T + b1;  h = gelu(u)        FeedForwardNetwork (model.py:388-403)
+//     f   = h W2^T + b2
+//     x2  = x1 + dropout(f);  out = ffn_norm2(x2)
+//     qkv' = out Wqkv'^T + bqkv'             the NEXT layer's linear_q/k/v (model.py:436-438), when there is one
+//
+// Only softmax(QK^T)V mixes rows; the rest of the layer is four GEMMs against weights plus per-row work.  As separate
+// launches (out-proj GEMM, LN+FFN1, FFN2, dropout+LN, QKV GEMM) these were 30 us of the S-FSQ layer's 36 us forward
+// for 134 MFLOP: each launch costs ~4.5 us of ramp + one memory round trip whatever it computes.  Here a workgroup owns
+// 32 rows and walks the whole chain: the 32-row activations never leave LDS (bf16 MFMA operands; the f32 residual stream
+// next to them), the weights stream from L2 (1.08 MB per layer and workgroup: the per-CU L2 bandwidth, ~8 us, is the
+// bound), and what the backward needs (x1, z, u, h, x2, the LayerNorm statistics) is written on the way.  The layer is
+// then TWO launches forward: attention, and this.
+//
+// GEMM inside the workgroup: 12 waves; a wave owns 16-column groups of the output (all 32 rows, the whole K), so there is
+// no split-K and no partial-tile exchange; v_mfma_f32_16x16x32_bf16, A from LDS (16 bytes per lane), B straight from
+// global (W is [N,K] row-major: 16 bytes per lane, 64-byte runs per weight row), the next chunk of <= 8 k-steps in
+// flight while the current one is multiplied.  Rounding points are those of the separate launches (y, u, h, f, qkv
+// rounded to bf16 exactly where a bf16 tensor used to be written), and the dropout masks are the same hashes
+// (mobgt_dropout_add_ln_fwd's), so the existing backward applies unchanged.
+#include "common.h"
+#include "mobgt_hip.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+constexpr int NW = 12, NT = NW * 64;
+
+struct ChainParams {
+    const uint16_t* a;                       // [R,C] bf16 attention output
+    const float* x;                          // [R,C] f32 layer input (residual stream)
+    const uint16_t *wo, *bo, *w1, *b1, *w2, *b2, *wq, *bq;      // bf16: [C,C] [C] [F,C] [F] [C,F] [C] [3C,C] [3C]  (wq null: last layer)
+    const float *n1w, *n1b, *nxw, *nxb;      // ffn_norm1, ffn_norm2
+    float *x1, *x2, *out;                    // [R,C] f32
+    uint16_t *z, *u, *h, *out_a, *qkv;       // bf16 [R,C] [R,F] [R,F] [R,C] [R,3C]
+    float *mean1, *rstd1, *mean2, *rstd2;    // [R]
+    int R;
+    uint32_t thr;
+    float inv_keep;
+    uint64_t seed;
+    const uint64_t* seed_dev;
+    uint32_t salt1, salt2;
+};
+
+// in-kernel timeline for tools/chain_debug.py (-DCH_DEBUG): stamps of workgroup 0 / thread 0, written at the end
+#ifdef CH_DEBUG
+__device__ int* g_chain_dbg = nullptr;
+#define STAMP_DECL int st_[16] = {}
+#define STAMP(i) st_[i] = (int)wall_clock64()
+#define STAMP_DUMP() do { if (g_chain_dbg && blockIdx.x == 0 && threadIdx.x == 0) for (int q_ = 0; q_ < 16; ++q_) g_chain_dbg[q_] = st_[q_]; } while (0)
+#else
+#define STAMP_DECL
+#define STAMP(i)
+#define STAMP_DUMP()
+#endif
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+// erf by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7, far below the bf16 rounding of h): erff() is ~40 instructions,
+// and here ONE compute unit applies GELU to 16 x 1024 pre-activations per layer
+__device__ __forceinline__ float erf_as(float x) {
+    const float ax = fabsf(x);
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.f));
+    float y = fmaf(1.061405429f, t, -1.453152027f);
+    y = fmaf(y, t, 1.421413741f);
+    y = fmaf(y, t, -0.284496736f);
+    y = fmaf(y, t, 0.254829592f);
+    y = 1.f - y * t * __expf(-ax * ax);
+    return copysignf(y, x);
+}
+__device__ __forceinline__ float gelu_f(float u) { return 0.5f * u * (1.f + erf_as(u * 0.70710678118654752f)); }
+__device__ __forceinline__ float bf16_round(float v) { return (float)(bf16_t)v; }
+__device__ __forceinline__ uint16_t bf16_bits(float v) { return __builtin_bit_cast(uint16_t, (bf16_t)v); }
+__device__ __forceinline__ float bf16_val(uint16_t b) { return __builtin_bit_cast(float, (uint32_t)b << 16); }
+
+// out[BM x N] = A[BM x K] (LDS, bf16, row stride LDA elements) x W[N x K]^T (global bf16, PACKED in MFMA operand order by
+// mobgt_pack_mfma_b: the 16 bytes lane l = j + 16 q feeds to k-step s of column group g -- W[16 g + j][32 s + 8 q ..] -- sit
+// at ((g S + s) 64 + l) * 16 bytes, so a wave's operand load is ONE contiguous KB.  Read straight from the row-major
+// weight, adjacent lanes hit 16 different rows and the load unit serialises them: measured 15 bytes/clk per CU, a quarter
+// of the L1 rate, 37 us for the chain).  Wave w owns the
+// 16-column groups w, w + NW, ...; `epi(g, acc)` receives a finished group: acc[t][v] = out[16 t + 4 q + v][16 g + j] for
+// lane (j = lane & 15, q = lane >> 4).  TWO chunks of B operands are in flight ahead of the one being multiplied (the
+// per-CU L1 bandwidth is the kernel's bound: ~100 KB must be outstanding per CU to reach it); for K <= 256 the A operands
+// of the whole K live in registers for all of the wave's groups.
+template <int BM, int N, int K, int LDA, typename EPI>
+__device__ __forceinline__ void wg_gemm(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W, EPI&& epi) {
+    constexpr int MT = BM / 16;
+    constexpr int S = K / 32;                        // k-steps per group
+    constexpr int CH = S <= 8 ? S : 8;               // k-steps per chunk
+    constexpr int CPG = S / CH;                      // chunks per group
+    constexpr bool AREG = S <= 8;                    // A operands held in registers
+    static_assert(K % 32 == 0 && S % CH == 0 && N % 16 == 0, "shape");
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = lane & 15, q = lane >> 4;
+    constexpr int G = N / 16;
+    const int ng = wave < G ? (G - wave + NW - 1) / NW : 0;       // this wave's groups
+    const int nchunks = ng * CPG;
+    if (nchunks == 0) return;
+    const uint16_t* a0 = A + j * LDA + 8 * q;
+    uint4 afr[AREG ? MT : 1][AREG ? S : 1];
+    if constexpr (AREG) {
+#pragma unroll
+        for (int t = 0; t < MT; ++t)
+#pragma unroll
+            for (int s = 0; s < S; ++s) afr[t][s] = *reinterpret_cast<const uint4*>(a0 + 16 * t * LDA + 32 * s);
+    }
+    auto load = [&](uint4 (&b)[CH], int c) {                      // W is PACKED: one contiguous KB per (group, k-step)
+        const int g = wave + (c / CPG) * NW, s0 = (c % CPG) * CH;
+        const uint16_t* wp = W + ((int64_t)(g * S + s0) * 64 + lane) * 8;
+#pragma unroll
+        for (int s = 0; s < CH; ++s) b[s] = *reinterpret_cast<const uint4*>(wp + 512 * s);
+    };
+    f32x4 acc[MT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    auto compute = [&](const uint4 (&b)[CH], int c) {
+        const int s0 = (c % CPG) * CH;
+#pragma unroll
+        for (int s = 0; s < CH; ++s) {
+            const bf16x8 bf = __builtin_bit_cast(bf16x8, b[s]);
+#pragma unroll
+            for (int t = 0; t < MT; ++t) {
+                bf16x8 af;
+                if constexpr (AREG) af = __builtin_bit_cast(bf16x8, afr[t][s]);
+                else af = *reinterpret_cast<const bf16x8*>(a0 + 16 * t * LDA + 32 * (s0 + s));
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bf, acc[t], 0, 0, 0);
+            }
+        }
+        if (c % CPG == CPG - 1) {
+            epi(wave + (c / CPG) * NW, acc);
+#pragma unroll
+            for (int t = 0; t < MT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    uint4 b0[CH], b1[CH], b2[CH];
+    load(b0, 0);
+    if (nchunks > 1) load(b1, 1);
+    for (int c = 0; c < nchunks; c += 3) {
+        if (c + 2 < nchunks) load(b2, c + 2);
+        compute(b0, c);
+        if (c + 1 >= nchunks) break;
+        if (c + 3 < nchunks) load(b0, c + 3);
+        compute(b1, c + 1);
+        if (c + 2 >= nchunks) break;
+        if (c + 4 < nchunks) load(b1, c + 4);
+        compute(b2, c + 2);
+    }
+}
+
+// xb[r][:] (f32, LDS) -> LayerNorm -> `dst_a` (bf16, LDS, the next GEMM's A operand) + global copies; also writes the
+// pre-norm rows (x1 / x2) and the statistics.  Wave w takes rows w, w + NW, ...
+template <int BM, int C, int LDX, int LDA>
+__device__ __forceinline__ void ln_rows(const float* __restrict__ xb, uint16_t* __restrict__ dst_a, const float* __restrict__ w,
+                                        const float* __restrict__ b, float* __restrict__ g_pre, uint16_t* __restrict__ g_bf,
+                                        float* __restrict__ g_f32, float* __restrict__ g_mean, float* __restrict__ g_rstd,
+                                        int r0, int R) {
+    constexpr int PER = (C + 63) / 64;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int r = wave; r < BM; r += NW) {
+        const int64_t row = r0 + r;
+        float v[PER], s = 0.f;
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const int c = lane + 64 * k;
+            v[k] = c < C ? xb[r * LDX + c] : 0.f;
+            s += v[k];
+        }
+        const float mu = wave_sum(s) * (1.f / C);
+        float qq = 0.f;
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const float d = lane + 64 * k < C ? v[k] - mu : 0.f;
+            qq += d * d;
+        }
+        const float rs = rsqrtf(wave_sum(qq) * (1.f / C) + 1e-5f);
+        const bool on = row < R;
+        if (on && lane == 0) { g_mean[row] = mu; g_rstd[row] = rs; }
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const int c = lane + 64 * k;
+            if (c < C) {
+                const float o = (v[k] - mu) * rs * w[c] + b[c];
+                const uint16_t ob = bf16_bits(o);
+                dst_a[r * LDA + c] = ob;
+                if (on) {
+                    g_pre[row * C + c] = v[k];
+                    g_bf[row * C + c] = ob;
+                    if (g_f32) g_f32[row * C + c] = o;
+                }
+            }
+        }
+    }
+}
+
+// rows of an LDS bf16 tile [BM][LD] -> global [R][N], 16 bytes per thread
+template <int BM, int N, int LD>
+__device__ __forceinline__ void store_rows(const uint16_t* __restrict__ src, uint16_t* __restrict__ dst, int r0, int R) {
+    for (int e = threadIdx.x; e < BM * (N / 8); e += NT) {
+        const int r = e / (N / 8), c = (e % (N / 8)) * 8;
+        if (r0 + r < R) *reinterpret_cast<uint4*>(dst + (int64_t)(r0 + r) * N + c) = *reinterpret_cast<const uint4*>(src + r * LD + c);
+    }
+}
+
+template <int BM, int C, int F>
+__global__ __launch_bounds__(NT) void layer_chain_fwd_kernel(const ChainParams p) {
+    constexpr int LDA = C + 8, LDH = F + 8, LDX = C + 4, MT = BM / 16;
+    static_assert(3 * C + 8 <= LDH, "the qkv tile reuses the u tile");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float* xb = reinterpret_cast<float*>(smem_raw);                              // [BM][LDX] f32: x -> x1 -> x2
+    uint16_t* ab = reinterpret_cast<uint16_t*>(xb + BM * LDX);                   // [BM][LDA] bf16: a -> z -> out_a
+    uint16_t* hb = ab + BM * LDA;                                                // [BM][LDH] bf16: h
+    uint16_t* ub = hb + BM * LDH;                                                // [BM][LDH] bf16: u, later the next layer's qkv
+    const int r0 = blockIdx.x * BM;
+    const int lane = threadIdx.x & 63;
+    const int j = lane & 15, q = lane >> 4;
+    const uint64_t seed = p.thr ? p.seed + (p.seed_dev ? *p.seed_dev : 0ull) : 0ull;
+    STAMP_DECL;
+    STAMP(0);
+
+    // this block's rows of a (bf16) and x (f32) -> LDS; rows past R are clamped (their results are never stored)
+    for (int e = threadIdx.x; e < BM * (C / 8); e += NT) {
+        const int r = e / (C / 8), c = (e % (C / 8)) * 8;
+        *reinterpret_cast<uint4*>(ab + r * LDA + c) = *reinterpret_cast<const uint4*>(p.a + (int64_t)min(r0 + r, p.R - 1) * C + c);
+    }
+    for (int e = threadIdx.x; e < BM * (C / 4); e += NT) {
+        const int r = e / (C / 4), c = (e % (C / 4)) * 4;
+        *reinterpret_cast<float4*>(xb + r * LDX + c) = *reinterpret_cast<const float4*>(p.x + (int64_t)min(r0 + r, p.R - 1) * C + c);
+    }
+    __syncthreads();
+    STAMP(1);
+
+    // ---- y = a Wo^T + bo;  x1 = x + dropout(y)
+    wg_gemm<BM, C, C, LDA>(ab, p.wo, [&](int g, const f32x4 (&acc)[MT]) {
+        const int col = 16 * g + j;
+        const float bias = bf16_val(p.bo[col]);
+#pragma unroll
+        for (int t = 0; t < MT; ++t)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const int r = 16 * t + 4 * q + v;
+                float y = bf16_round(acc[t][v] + bias);
+                if (p.thr) {
+                    const uint32_t rowh = dropout_row_hash(seed, (uint32_t)(r0 + r) ^ p.salt1);
+                    y = dropout_bits16(seed, rowh, (uint32_t)col) >= p.thr ? y * p.inv_keep : 0.f;
+                }
+                xb[r * LDX + col] += y;
+            }
+    });
+    __syncthreads();
+    STAMP(2);
+    // ---- z = ffn_norm1(x1)
+    ln_rows<BM, C, LDX, LDA>(xb, ab, p.n1w, p.n1b, p.x1, p.z, nullptr, p.mean1, p.rstd1, r0, p.R);
+    __syncthreads();
+    STAMP(3);
+    // ---- u = z W1^T + b1;  h = gelu(u)  (h from the ROUNDED pre-activation, as the separate launches computed it)
+    wg_gemm<BM, F, C, LDA>(ab, p.w1, [&](int g, const f32x4 (&acc)[MT]) {
+        const int col = 16 * g + j;
+        const float bias = bf16_val(p.b1[col]);
+#pragma unroll
+        for (int t = 0; t < MT; ++t)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const int r = 16 * t + 4 * q + v;
+                const uint16_t ubits = bf16_bits(acc[t][v] + bias);
+                ub[r * LDH + col] = ubits;
+                hb[r * LDH + col] = bf16_bits(gelu_f(bf16_val(ubits)));
+            }
+    });
+    __syncthreads();
+    STAMP(4);
+    store_rows<BM, F, LDH>(ub, p.u, r0, p.R);
+    store_rows<BM, F, LDH>(hb, p.h, r0, p.R);
+    STAMP(5);
+    // ---- f = h W2^T + b2;  x2 = x1 + dropout(f)
+    wg_gemm<BM, C, F, LDH>(hb, p.w2, [&](int g, const f32x4 (&acc)[MT]) {
+        const int col = 16 * g + j;
+        const float bias = bf16_val(p.b2[col]);
+#pragma unroll
+        for (int t = 0; t < MT; ++t)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const int r = 16 * t + 4 * q + v;
+                float f = bf16_round(acc[t][v] + bias);
+                if (p.thr) {
+                    const uint32_t rowh = dropout_row_hash(seed, (uint32_t)(r0 + r) ^ p.salt2);
+                    f = dropout_bits16(seed, rowh, (uint32_t)col) >= p.thr ? f * p.inv_keep : 0.f;
+                }
+                xb[r * LDX + col] += f;
+            }
+    });
+    __syncthreads();
+    STAMP(6);
+    // ---- out = ffn_norm2(x2)  (f32 residual stream + the bf16 copy the next QKV GEMM multiplies)
+    ln_rows<BM, C, LDX, LDA>(xb, ab, p.nxw, p.nxb, p.x2, p.out_a, p.out, p.mean2, p.rstd2, r0, p.R);
+    if (!p.wq) return;
+    __syncthreads();
+    STAMP(7);
+    // ---- the next layer's qkv = out Wqkv^T + bqkv
+    wg_gemm<BM, 3 * C, C, LDA>(ab, p.wq, [&](int g, const f32x4 (&acc)[MT]) {
+        const int col = 16 * g + j;
+        const float bias = bf16_val(p.bq[col]);
+#pragma unroll
+        for (int t = 0; t < MT; ++t)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) ub[(16 * t + 4 * q + v) * LDH + col] = bf16_bits(acc[t][v] + bias);
+    });
+    __syncthreads();
+    STAMP(8);
+    store_rows<BM, 3 * C, LDH>(ub, p.qkv, r0, p.R);
+    STAMP(9);
+    STAMP_DUMP();
+}
+
+struct PackJobs {
+    const uint16_t* src[32];
+    uint16_t* dst[32];
+    int N[32], K[32];
+    int first_block[33];                     // job i owns blocks [first_block[i], first_block[i + 1]); 256 pieces per block
+};
+
+// dst[((g S + s) 64 + l) * 8 + e] = src[(16 g + (l & 15)) K + 32 s + 8 (l >> 4) + e]: 16-byte pieces, writes contiguous
+__global__ __launch_bounds__(256) void pack_mfma_b_kernel(const PackJobs jobs, int njobs) {
+    int job = 0;
+    while (job + 1 < njobs && (int)blockIdx.x >= jobs.first_block[job + 1]) ++job;
+    const int K = jobs.K[job], S = K / 32;
+    const int64_t piece = (int64_t)(blockIdx.x - jobs.first_block[job]) * 256 + threadIdx.x;
+    if (piece >= (int64_t)jobs.N[job] * K / 8) return;
+    const int l = (int)(piece & 63);
+    const int64_t gs = piece >> 6;
+    const int g = (int)(gs / S), s_ = (int)(gs % S);
+    const uint16_t* from = jobs.src[job] + (int64_t)(16 * g + (l & 15)) * K + 32 * s_ + 8 * (l >> 4);
+    *reinterpret_cast<uint4*>(jobs.dst[job] + piece * 8) = *reinterpret_cast<const uint4*>(from);
+}
+
+template <int BM, int C, int F>
+int launch(const ChainParams& p, hipStream_t st) {
+    constexpr size_t lds = BM * (C + 4) * 4 + BM * (C + 8) * 2 + 2 * BM * (F + 8) * 2;
+    static_assert(lds <= 152 * 1024, "LDS plan");
+    int rc = (int)hipFuncSetAttribute((const void*)layer_chain_fwd_kernel<BM, C, F>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (rc) return rc;
+    hipLaunchKernelGGL((layer_chain_fwd_kernel<BM, C, F>), dim3((p.R + BM - 1) / BM), dim3(NT), lds, st, p);
+    return (int)hipGetLastError();
+}
+
+}  // namespace
+
+extern "C" int mobgt_pack_mfma_b(int n, const void* const* src, void* const* dst, const int* N, const int* K, void* stream) {
+    if (n <= 0) return 0;
+    if (n > 32) return MOBGT_EBADDIM;
+    PackJobs jobs = {};
+    int blocks = 0;
+    for (int i = 0; i < n; ++i) {
+        if (N[i] <= 0 || K[i] <= 0 || (N[i] & 15) || (K[i] & 31)) return MOBGT_EBADDIM;
+        if (((uintptr_t)src[i] | (uintptr_t)dst[i]) & 15) return MOBGT_EALIGN;
+        jobs.src[i] = (const uint16_t*)src[i]; jobs.dst[i] = (uint16_t*)dst[i]; jobs.N[i] = N[i]; jobs.K[i] = K[i];
+        jobs.first_block[i] = blocks;
+        blocks += (int)(((int64_t)N[i] * K[i] / 8 + 255) / 256);
+    }
+    jobs.first_block[n] = blocks;
+    hipLaunchKernelGGL(pack_mfma_b_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, jobs, n);
+    return (int)hipGetLastError();
+}
+
+#ifdef CH_DEBUG
+extern "C" int mobgt_chain_debug_buffer(int* buf) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_chain_dbg), &buf, sizeof(buf)); }
+#endif
+
+extern "C" int mobgt_layer_chain_fwd(const void* a, const float* x, const void* wo, const void* bo, const float* n1w,
+                                     const float* n1b, const void* w1, const void* b1, const void* w2, const void* b2,
+                                     const float* nxw, const float* nxb, const void* wq_next, const void* bq_next, float* x1,
+                                     void* z, void* u, void* h, float* x2, float* out, void* out_a, void* qkv_next,
+                                     float* mean1, float* rstd1, float* mean2, float* rstd2, int64_t R, int C, int F,
+                                     float dropout_p, uint64_t seed, const uint64_t* seed_dev, uint32_t salt1, uint32_t salt2,
+                                     void* stream) {
+    if (R <= 0) return 0;
+    if (R > 0x7fffffff) return MOBGT_EBADDIM;
+    if (((uintptr_t)a | (uintptr_t)x | (uintptr_t)wo | (uintptr_t)w1 | (uintptr_t)w2 | (uintptr_t)wq_next | (uintptr_t)h | (uintptr_t)u | (uintptr_t)qkv_next) & 15)
+        return MOBGT_EALIGN;
+    if ((wq_next == nullptr) != (qkv_next == nullptr)) return MOBGT_EBADDIM;
+    ChainParams p = {};
+    typedef const uint16_t* cu;
+    p.a = (cu)a; p.x = x; p.wo = (cu)wo; p.bo = (cu)bo; p.w1 = (cu)w1; p.b1 = (cu)b1; p.w2 = (cu)w2; p.b2 = (cu)b2;
+    p.wq = (cu)wq_next; p.bq = (cu)bq_next; p.n1w = n1w; p.n1b = n1b; p.nxw = nxw; p.nxb = nxb;
+    p.x1 = x1; p.x2 = x2; p.out = out; p.z = (uint16_t*)z; p.u = (uint16_t*)u; p.h = (uint16_t*)h; p.out_a = (uint16_t*)out_a;
+    p.qkv = (uint16_t*)qkv_next; p.mean1 = mean1; p.rstd1 = rstd1; p.mean2 = mean2; p.rstd2 = rstd2; p.R = (int)R;
+    p.thr = dropout_p > 0.f ? dropout_threshold(dropout_p) : 0u;
+    p.inv_keep = p.thr ? 1.f / (1.f - (float)p.thr / 65536.f) : 1.f;
+    p.seed = seed; p.seed_dev = seed_dev; p.salt1 = salt1; p.salt2 = salt2;
+    hipStream_t st = (hipStream_t)stream;
+    if (C == 192 && F == 1024) return launch<16, 192, 1024>(p, st);
+    if (C == 256 && F == 1024) return launch<16, 256, 1024>(p, st);
+    return MOBGT_EBADDIM;                    // the instantiated widths: MobGT's hidden 128 / 192 (+ 64 of embeddings), ffn 1024
+}

@@ -171,6 +171,13 @@ _LN_GEMM = [_os_ln.environ.get("MOBGT_NO_LN_GEMM") != "1"]      # MOBGT_NO_LN_GE
 # memory round trip, and fusing two stages saves only the intermediate's round trip.  The forward fusion is on by
 # default, the two backward ones only with MOBGT_LN_GEMM_BWD=1 (kept: parity-tested, and the better trade at other sizes).
 _LN_GEMM_BWD = [_os_ln.environ.get("MOBGT_LN_GEMM_BWD") == "1"]
+# csrc/chain.hip: out-proj -> LN -> FFN -> LN -> the next layer's QKV in one launch (MOBGT_NO_CHAIN=1: the separate launches)
+_CHAIN = [_os_ln.environ.get("MOBGT_NO_CHAIN") != "1"]
+
+
+def _chain_ok(C, F, *ts):
+    return (_CHAIN[0] and (C, F) in ((192, 1024), (256, 1024))
+            and all(t is None or (t.is_contiguous() and t.data_ptr() % 16 == 0) for t in ts))
 
 
 def _ln_gemm_ok(C, *ts):
@@ -217,6 +224,9 @@ class LayerConfig:
         self.seed, self.seed_dev, self.salt = int(seed), seed_dev, int(salt) & 0xFFFFFFFF
         self.pack = pack
         self.act_dtype = act_dtype
+        self.next_qkv = None      # (packed wqkv, bqkv) of the NEXT fused layer: its QKV projection rides in this layer's chain
+        self.packed = None        # (wo, w1, w2) of this layer in MFMA operand order (model.pack_layer_weights)
+        self.out_act = self.out_qkv = None
 
 
 class _FusedLayerFn(torch.autograd.Function):
@@ -226,7 +236,7 @@ class _FusedLayerFn(torch.autograd.Function):
     `shadows`: (wqkv [3C,C], bqkv [3C], wo, bo, w1, b1, w2, b2) in act_dtype (the fused masters when fp32)."""
 
     @staticmethod
-    def forward(ctx, x, token, cfg, shadows, xa_pre, wq, bq, wk, bk, wv, bv, wo, bo, n1w, n1b, nxw, nxb, w1, b1, w2, b2):
+    def forward(ctx, x, token, cfg, shadows, xa_pre, qkv_pre, wq, bq, wk, bk, wv, bv, wo, bo, n1w, n1b, nxw, nxb, w1, b1, w2, b2):
         # wq/wk/wv (+ biases) are views of one fused [3C, C] storage (MultiHeadAttention.fuse_qkv_storage); they
         # are separate arguments only so that autograd has an edge to each reference-named parameter.
         G, T, C = x.shape
@@ -255,12 +265,66 @@ class _FusedLayerFn(torch.autograd.Function):
         own = _OWN_GEMM[0] and ops.layer_gemm_ok(xa, s_wqkv) and ops.layer_gemm_ok(xa, s_w1) and C % 32 == 0 \
             and s_w1.shape[0] % 32 == 0
         ctx.own_gemm = own
-        if own:
+        if qkv_pre is not None and qkv_pre.dtype == A and qkv_pre.numel() == 3 * R * C and not stock:
+            qkv = qkv_pre.view(G, T, 3 * C)                            # written by the previous layer's chain kernel
+        elif own:
             qkv = ops.layer_gemm(xa, s_wqkv, s_bqkv).view(G, T, 3 * C)
         else:
             qkv = torch.addmm(s_bqkv, xa, s_wqkv.t()).view(G, T, 3 * C)
         q, k, v = qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:]
         a, lse = ops._attn_fwd(q, k, v, cfg.pack, cfg.scale, cfg.p_att, seed ^ (salt * 0x9E3779B1), sd)
+        F = s_w1.shape[0]
+        cfg.out_qkv = None
+        use_chain = (not stock and own and A == torch.bfloat16 and cfg.packed is not None
+                     and _chain_ok(C, F, x, a, s_bo, s_b1, s_b2, n1w, n1b, nxw, nxb, *cfg.packed))
+        ctx.fuse_ln = use_chain
+        if use_chain:               # everything row-local of the layer (+ the next layer's QKV projection) in one launch
+            bf = dict(dtype=A, device=dev)
+            x1, x2, out = torch.empty(R, C, **f32), torch.empty(R, C, **f32), torch.empty(R, C, **f32)
+            z, out_a = torch.empty(R, C, **bf), torch.empty(R, C, **bf)
+            u, h = torch.empty(R, F, **bf), torch.empty(R, F, **bf)
+            nq = cfg.next_qkv
+            if nq is not None and not (nq[0].dtype == A and tuple(nq[0].shape) == (3 * C, C) and nq[0].is_contiguous()
+                                       and nq[0].data_ptr() % 16 == 0):
+                nq = None
+            qkv_next = torch.empty(R, 3 * C, **bf) if nq is not None else None
+            p_wo, p_w1, p_w2 = cfg.packed
+            check(_lib.lib().mobgt_layer_chain_fwd(_p(a), _p(x), _p(p_wo), _p(s_bo), _p(n1w), _p(n1b), _p(p_w1), _p(s_b1), _p(p_w2),
+                                                   _p(s_b2), _p(nxw), _p(nxb), _p(nq[0] if nq else None),
+                                                   _p(nq[1] if nq else None), _p(x1), _p(z), _p(u), _p(h), _p(x2), _p(out),
+                                                   _p(out_a), _p(qkv_next), _p(stats[2]), _p(stats[3]), _p(stats[4]),
+                                                   _p(stats[5]), R, C, F, cfg.p, seed, _p(sd), (salt + 1) & 0xFFFFFFFF,
+                                                   (salt + 2) & 0xFFFFFFFF, _stream()), "mobgt_layer_chain_fwd")
+            cfg.out_act, cfg.out_qkv = out_a, qkv_next
+        else:
+            out, x1, z, u, h, x2 = _FusedLayerFn._tail_launches(ctx, cfg, x, a, stats, shadows, own, stock, n1w, n1b, nxw, nxb,
+                                                                R, C, A, act, dev)
+        # destinations for the four weight gradients in the trainer's flat buffer, if it registered any (q/k/v are
+        # adjacent there exactly when they are adjacent in the fused [3C, C] parameter storage)
+        sq, sk, sv = ops.grad_sink(wq), ops.grad_sink(wk), ops.grad_sink(wv)
+        s_qkv = None
+        if sq is not None and sk is not None and sv is not None and sq.is_contiguous() \
+                and sk.data_ptr() == sq.data_ptr() + 4 * sq.numel() and sv.data_ptr() == sk.data_ptr() + 4 * sk.numel():
+            s_qkv = torch.as_strided(sq, (3 * C, C), (C, 1))
+        ctx.sinks = (s_qkv, ops.grad_sink(wo), ops.grad_sink(w1), ops.grad_sink(w2))
+        # the block of small gradients [dbq dbk dbv | dbo | db1 | db2 | dn1w | dn1b | dnxw | dnxb]: one slice of the flat
+        # buffer when the trainer laid these parameters out in that order (train.flat_order)
+        ctx.small_sink = None
+        chain = [ops.grad_sink(t) for t in (bq, bk, bv, bo, b1, b2, n1w, n1b, nxw, nxb)]
+        if all(t is not None and t.is_contiguous() for t in chain) and \
+                all(chain[j + 1].data_ptr() == chain[j].data_ptr() + 4 * chain[j].numel() for j in range(len(chain) - 1)):
+            ctx.small_sink = torch.as_strided(chain[0], (sum(t.numel() for t in chain),), (1,))
+        ctx.cfg = cfg
+        ctx.shapes = (G, T, C)
+        ctx.save_for_backward(x, xa, qkv, a, lse, x1, z, u, h, x2, stats, s_wqkv, s_wo, s_w1, s_w2, n1w, nxw)
+        return out.view(G, T, C)
+
+    @staticmethod
+    def _tail_launches(ctx, cfg, x, a, stats, shadows, own, stock, n1w, n1b, nxw, nxb, R, C, A, act, dev):
+        """out-proj ... second LayerNorm as separate launches (every configuration the chain kernel does not cover)."""
+        s_wqkv, s_bqkv, s_wo, s_bo, s_w1, s_b1, s_w2, s_b2 = shadows
+        seed, sd, salt = cfg.seed, cfg.seed_dev, cfg.salt
+        f32 = dict(dtype=torch.float32, device=dev)
         y = ops.layer_gemm(a.view(R, C), s_wo, s_bo) if own else torch.addmm(s_bo, a.view(R, C), s_wo.t())
         x1 = torch.empty(R, C, **f32)
         z = torch.empty(R, C, dtype=A, device=dev)
@@ -289,25 +353,7 @@ class _FusedLayerFn(torch.autograd.Function):
             out_a = torch.empty(R, C, dtype=A, device=dev) if A != torch.float32 else None
             _k1_fwd(x1, f, x2, nxw, nxb, out_a, out, stats[4], stats[5], R, C, cfg.p, seed, sd, salt + 2, act)
             cfg.out_act = out_a                                       # bf16 copy for the next layer's QKV GEMM
-        # destinations for the four weight gradients in the trainer's flat buffer, if it registered any (q/k/v are
-        # adjacent there exactly when they are adjacent in the fused [3C, C] parameter storage)
-        sq, sk, sv = ops.grad_sink(wq), ops.grad_sink(wk), ops.grad_sink(wv)
-        s_qkv = None
-        if sq is not None and sk is not None and sv is not None and sq.is_contiguous() \
-                and sk.data_ptr() == sq.data_ptr() + 4 * sq.numel() and sv.data_ptr() == sk.data_ptr() + 4 * sk.numel():
-            s_qkv = torch.as_strided(sq, (3 * C, C), (C, 1))
-        ctx.sinks = (s_qkv, ops.grad_sink(wo), ops.grad_sink(w1), ops.grad_sink(w2))
-        # the block of small gradients [dbq dbk dbv | dbo | db1 | db2 | dn1w | dn1b | dnxw | dnxb]: one slice of the flat
-        # buffer when the trainer laid these parameters out in that order (train.flat_order)
-        ctx.small_sink = None
-        chain = [ops.grad_sink(t) for t in (bq, bk, bv, bo, b1, b2, n1w, n1b, nxw, nxb)]
-        if all(t is not None and t.is_contiguous() for t in chain) and \
-                all(chain[j + 1].data_ptr() == chain[j].data_ptr() + 4 * chain[j].numel() for j in range(len(chain) - 1)):
-            ctx.small_sink = torch.as_strided(chain[0], (sum(t.numel() for t in chain),), (1,))
-        ctx.cfg = cfg
-        ctx.shapes = (G, T, C)
-        ctx.save_for_backward(x, xa, qkv, a, lse, x1, z, u, h, x2, stats, s_wqkv, s_wo, s_w1, s_w2, n1w, nxw)
-        return out.view(G, T, C)
+        return out, x1, z, u, h, x2
 
     @staticmethod
     def backward(ctx, dout):
@@ -392,13 +438,15 @@ class _FusedLayerFn(torch.autograd.Function):
             dx = ops.layer_gemm(dqkv2, s_wqkv, None, True, ops.GEMM_ADD, aux_in=dx1)     # dx1 + dqkv Wqkv, f32, in place
         else:
             dx = _addmm_f32(dx1, dqkv2, s_wqkv, inplace=True)
-        return (dx.view(G, T, C), None, None, None, None, dwqkv[:C], dbqkv[:C], dwqkv[C:2 * C], dbqkv[C:2 * C], dwqkv[2 * C:],
+        return (dx.view(G, T, C), None, None, None, None, None, dwqkv[:C], dbqkv[:C], dwqkv[C:2 * C], dbqkv[C:2 * C], dwqkv[2 * C:],
                 dbqkv[2 * C:], dwo, dbo, dn1w, dn1b, dnxw, dnxb, dw1, db1, dw2, db2)
 
 
-def fused_encoder_layer(x, pack, cfg, shadows, params, xa_pre=None):
-    cfg.out_act = None
-    out = _FusedLayerFn.apply(x, pack.token, cfg, shadows, xa_pre, *params)
+def fused_encoder_layer(x, pack, cfg, shadows, params, xa_pre=None, qkv_pre=None):
+    cfg.out_act = cfg.out_qkv = None
+    out = _FusedLayerFn.apply(x, pack.token, cfg, shadows, xa_pre, qkv_pre, *params)
     if cfg.out_act is not None:
         out._mobgt_act = cfg.out_act          # picked up by the next fused layer (same Python tensor object)
+    if cfg.out_qkv is not None:
+        out._mobgt_qkv = cfg.out_qkv          # ... and its QKV projection, already computed by this layer's chain kernel
     return out

@@ -154,9 +154,11 @@ class MultiHeadAttention(nn.Module):
 
 
 
-def fused_layer_forward(layer, variant, x, attn_bias, n1, nx):
+def fused_layer_forward(layer, variant, x, attn_bias, n1, nx, next_layer=None):
     """Run one EncoderLayer as a single fused autograd node (mobgt_amd/fused_layer.py).  `n1` is the LayerNorm in
-    front of the FFN, `nx` the variant's other LayerNorm (self_attention_norm for model.py, ffn_norm2 for fq)."""
+    front of the FFN, `nx` the variant's other LayerNorm (self_attention_norm for model.py, ffn_norm2 for fq).
+    `next_layer`: the EncoderLayer the caller will run next ON THIS LAYER'S OUTPUT (fq variant): its QKV projection then
+    rides in this layer's last launch."""
     from .fused_layer import LayerConfig, fused_encoder_layer
     mha = layer.self_attention
     G, T, C = x.shape
@@ -192,13 +194,23 @@ def fused_layer_forward(layer, variant, x, attn_bias, n1, nx):
     if (p > 0 or p_att > 0) and mha.seed_dev is None:
         seed = (seed + int(torch.randint(0, 2 ** 31 - 1, (1,)).item())) & 0x7FFFFFFFFFFFFFFF
     cfg = LayerConfig(variant, mha.num_heads, mha.scale, p, p_att, seed, mha.seed_dev, mha._layer_index * 8, pack, act)
+    # the next layer's QKV projection rides in this layer's chain kernel (csrc/chain.hip) when that layer is fused, has
+    # the same activation dtype and its bf16 shadows are current (refresh_shadows / the trainer refreshed ALL layers)
+    nxt = next_layer
+    if (nxt is not None and act != torch.float32 and not amp and getattr(nxt, "fused", False)
+            and getattr(nxt, "act_dtype", None) == act and getattr(nxt, "_packed_fresh", False)
+            and nxt._packed[0].device == x.device):
+        cfg.next_qkv = (nxt._packed[0], nxt._shadows[1])
+    if getattr(layer, "_packed_fresh", False) and act != torch.float32 and not amp:
+        cfg.packed = layer._packed[1:]                    # (wo, w1, w2) in MFMA operand order
     params = (mha.linear_q.weight, mha.linear_q.bias, mha.linear_k.weight, mha.linear_k.bias, mha.linear_v.weight,
               mha.linear_v.bias, mha.output_layer.weight, mha.output_layer.bias, n1.weight, n1.bias, nx.weight, nx.bias,
               layer.ffn.layer1.weight, layer.ffn.layer1.bias, layer.ffn.layer2.weight, layer.ffn.layer2.bias)
     if amp:
         with torch.autocast("cuda", enabled=False):
             return fused_encoder_layer(x.float(), pack, cfg, shadows, params, xa_pre=getattr(x, "_mobgt_act", None))
-    return fused_encoder_layer(x.float(), pack, cfg, shadows, params, xa_pre=getattr(x, "_mobgt_act", None))
+    return fused_encoder_layer(x.float(), pack, cfg, shadows, params, xa_pre=getattr(x, "_mobgt_act", None),
+                               qkv_pre=getattr(x, "_mobgt_qkv", None))
 
 
 def refresh_shadows(layers):
@@ -226,6 +238,44 @@ def refresh_shadows(layers):
         layer._shadow_fresh = True
     if dst:
         torch._foreach_copy_(dst, src)
+    pack_layer_weights(layers)
+
+
+def pack_layer_weights(layers):
+    """MFMA-operand-order copies of the fused fq layers' bf16 GEMM weights (csrc/chain.hip reads a wave's B operand as one
+    contiguous KB), all layers in one launch (two beyond 8 layers); `layer._packed` = (wqkv, wo, w1, w2) packed."""
+    import ctypes
+    from . import fused_layer, _lib
+    from .ops import _stream
+    if not fused_layer._CHAIN[0]:
+        return
+    jobs = []
+    for layer in layers:
+        layer._packed_fresh = False
+        sh = getattr(layer, "_shadows", None)
+        if (sh is None or not getattr(layer, "fused", False) or not getattr(layer, "_shadow_fresh", False)
+                or not hasattr(layer, "ffn_norm2") or sh[0].dtype != torch.bfloat16 or not sh[0].is_cuda):
+            continue
+        C, F = sh[2].shape[0], sh[4].shape[0]
+        if (C, F) not in ((192, 1024), (256, 1024)):
+            continue
+        pk = getattr(layer, "_packed", None)
+        if pk is None or pk[0].device != sh[0].device:
+            pk = tuple(torch.empty_like(sh[i]) for i in (0, 2, 4, 6))
+            layer._packed = pk
+        for d, i in zip(pk, (0, 2, 4, 6)):
+            if not sh[i].is_contiguous():
+                break
+            jobs.append((sh[i], d))
+        else:
+            layer._packed_fresh = True
+    for o in range(0, len(jobs), 32):
+        part = jobs[o:o + 32]
+        n = len(part)
+        vp, ci = ctypes.c_void_p, ctypes.c_int
+        _lib.check(_lib.lib().mobgt_pack_mfma_b(n, (vp * n)(*[a.data_ptr() for a, _ in part]), (vp * n)(*[b.data_ptr() for _, b in part]),
+                                                (ci * n)(*[a.shape[0] for a, _ in part]), (ci * n)(*[a.shape[1] for a, _ in part]),
+                                                _stream()), "mobgt_pack_mfma_b")
 
 
 def sync_external_shadows(model):

@@ -124,9 +124,9 @@ class EncoderLayer(nn.Module):
     fused = True
     act_dtype = torch.float32
 
-    def forward(self, x, attn_bias=None, mask=None):
+    def forward(self, x, attn_bias=None, mask=None, next_layer=None):
         if self.fused and x.is_cuda and mask is None:
-            return fused_layer_forward(self, "fq", x, attn_bias, self.ffn_norm1, self.ffn_norm2)
+            return fused_layer_forward(self, "fq", x, attn_bias, self.ffn_norm1, self.ffn_norm2, next_layer=next_layer)
         y = self.self_attention(x, x, x, attn_bias, mask=mask)
         y = self.self_attention_dropout(y)
         x = x + y.to(x.dtype)          # same-dtype add: the mixed fp32+bf16 elementwise kernel is ~20x slower on ROCm
@@ -393,7 +393,8 @@ class Graphormer(nn.Module):
         output = self.node_features(batched_data)
         ops.trace_nan("x0", output)
         for li, enc_layer in enumerate(self.layers):                                           # :1347-1352
-            output = enc_layer(output, bias, mask=None)
+            # (the layer that follows is named so that its QKV projection can ride in this layer's last launch)
+            output = enc_layer(output, bias, mask=None, next_layer=self.layers[li + 1] if li + 1 < len(self.layers) else None)
             ops.trace_nan(f"layer{li}", output)
         self._enc_out = output           # train.TrainStep: everything after this point is the "head" (see head_modules)
         fuse3 = self.embed_fuse_model3

@@ -487,3 +487,57 @@ def test_fused_layer_under_autocast_takes_the_bf16_configuration():
         assert torch.equal(a, b)
     assert not torch.equal(res["amp"][0], res["fp32"][0])
     np.testing.assert_allclose(res["amp"][0].cpu().numpy(), res["fp32"][0].cpu().numpy(), atol=5e-2, rtol=5e-2)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("C,G,T,p", [(192, 5, 37, 0.1), (192, 3, 11, 0.0), (256, 2, 70, 0.1)])
+def test_layer_chain_kernel_matches_the_separate_launches(C, G, T, p):
+    """csrc/chain.hip: out-proj -> LN -> FFN -> LN -> the NEXT layer's QKV projection as one launch per layer, against the
+    separate launches (MOBGT_NO_CHAIN path) on a 3-layer fq stack: same rounding points, same dropout masks, so outputs
+    and every gradient agree to bf16 round-off (full-K accumulation here, split-K there)."""
+    from mobgt_amd import fused_layer
+    from mobgt_amd.model import refresh_shadows
+    from mobgt_amd.model_fqandtoyo import EncoderLayer as FqLayer
+    torch.manual_seed(5)
+    H = 8
+    layers = torch.nn.ModuleList([FqLayer(C, 1024, p, p, H) for _ in range(3)]).to(DEV)
+    for li, l in enumerate(layers):
+        l.act_dtype = torch.bfloat16
+        l.self_attention.set_layer_index(li + 1)
+        l.self_attention.seed_dev = torch.tensor([11], dtype=torch.int64, device=DEV)     # both runs draw the same masks
+    layers.train()
+    x0 = torch.randn(G, T, C, device=DEV)
+    bias = torch.randn(G, H, T, T, device=DEV) * 0.3
+    gy = torch.randn(G, T, C, device=DEV)
+    res = {}
+    for on in (True, False):
+        fused_layer._CHAIN[0] = on
+        try:
+            for q in layers.parameters():
+                q.grad = None
+            x = x0.clone().requires_grad_(True)
+            refresh_shadows(layers)
+            y = x
+            rode = []
+            for li, l in enumerate(layers):
+                y = l(y, bias, next_layer=layers[li + 1] if li + 1 < len(layers) else None)
+                rode.append(getattr(y, "_mobgt_qkv", None) is not None)
+            assert rode == ([True, True, False] if on else [False, False, False])     # the QKV projections did ride along
+            y.backward(gy)
+            torch.cuda.synchronize()
+            res[on] = (y.detach().clone(), x.grad.clone(), {n: q.grad.clone() for n, q in layers.named_parameters() if q.grad is not None})
+        finally:
+            fused_layer._CHAIN[0] = True
+    (ya, dxa, ga), (yb, dxb, gb) = res[True], res[False]
+
+    def close(a, b, name):
+        scale = float(b.abs().max()) + 1e-12
+        err = float((a - b).abs().max())
+        assert err <= 2e-2 * scale, (name, err, scale)
+    close(ya, yb, "y")
+    close(dxa, dxb, "dx")
+    assert ga.keys() == gb.keys()
+    for n in ga:
+        if n.endswith("linear_k.bias"):
+            continue                                      # exactly zero in exact arithmetic: round-off only
+        close(ga[n], gb[n], n)
