@@ -388,14 +388,27 @@ int mobgt_small_gemm_f32(const float* a, int64_t lda, const float* b, int64_t ld
  * with salt1 / salt2.  (C, F) in {(192, 1024), (256, 1024)}. */
 /* bf16 weight [N,K] row-major -> MFMA operand order (chain.hip): the 16 bytes W[16g + j][32s + 8q .. +7] go to byte offset
  * ((g K/32 + s) 64 + j + 16q) * 16, so that a wave's B-operand load is one contiguous KB.  n <= 32 jobs in one launch;
- * N % 16 == 0, K % 32 == 0. */
-int mobgt_pack_mfma_b(int n, const void* const* src, void* const* dst, const int* N, const int* K, void* stream);
+ * N % 16 == 0, K % 32 == 0.  transposed[i] != 0: src is [K,N] row-major and its TRANSPOSE is packed (the operand of
+ * dX = dY W); transposed may be null. */
+int mobgt_pack_mfma_b(int n, const void* const* src, void* const* dst, const int* N, const int* K, const int* transposed,
+                      void* stream);
 int mobgt_layer_chain_fwd(const void* a, const float* x, const void* wo, const void* bo, const float* n1w, const float* n1b,
                           const void* w1, const void* b1, const void* w2, const void* b2, const float* nxw, const float* nxb,
                           const void* wq_next, const void* bq_next, float* x1, void* z, void* u, void* h, float* x2, float* out,
                           void* out_a, void* qkv_next, float* mean1, float* rstd1, float* mean2, float* rstd2, int64_t R, int C,
                           int F, float dropout_p, uint64_t seed, const uint64_t* seed_dev, uint32_t salt1, uint32_t salt2,
                           void* stream);
+/* The same chain backwards, from d(out) to the gradient of the attention output (csrc/chain.hip):
+ *   dx2 = ffn_norm2'(dout);  df = dropout'(dx2);  du = (df w2) * gelu'(u);  dz = du w1;  dx1 = dx2 + ffn_norm1'(dz);
+ *   dy = dropout'(dx1);  da = dy wo.
+ * w2t / w1t / wot: the weights' transposes packed by mobgt_pack_mfma_b(transposed = 1).  Written: df, dy, da [R,C], du [R,F]
+ * bf16; dx1 [R,C] f32.  ACCUMULATED (f32 atomics, zero them first): dnxw, dnxb, db2 (= column sums of df), dn1w, dn1b,
+ * dbo (= column sums of dy), [C] each. */
+int mobgt_layer_chain_bwd(const float* dout, const float* x2, const float* x1, const void* u, const float* mean1,
+                          const float* rstd1, const float* mean2, const float* rstd2, const float* n1w, const float* nxw,
+                          const void* w2t, const void* w1t, const void* wot, void* df, void* du, void* dy, void* da, float* dx1,
+                          float* dnxw, float* dnxb, float* db2, float* dn1w, float* dn1b, float* dbo, int64_t R, int C, int F,
+                          float dropout_p, uint64_t seed, const uint64_t* seed_dev, uint32_t salt1, uint32_t salt2, void* stream);
 /* The whole 3-layer GCN of a SMALL dense graph (graphormer/modelGNN.py:53-74 on the ~300-node category graph,
  * model_fqandtoyo.py:1237) as ONE launch each way (csrc/smallgcn.hip): ceil(n/16) co-resident workgroups that meet at
  * `counter` (int[1], ZERO on entry) between the layers.

@@ -64,6 +64,36 @@ __device__ __forceinline__ float wave_sum(float v) {
     for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
 }
+// sum over the 16 lanes of a DPP row (every lane gets it): two quad permutes, then the mirrors of 8 and of 16 lanes --
+// four v_add with a DPP operand, where a __shfl_xor butterfly is four ds_bpermute round trips (the LayerNorm passes
+// were 1.5 us each with those)
+__device__ __forceinline__ float dpp_add(float v, const int ctrl_sel) {
+    const int x = __builtin_bit_cast(int, v);
+    int y;
+    if (ctrl_sel == 0) y = __builtin_amdgcn_update_dpp(x, x, 0xB1, 0xf, 0xf, false);        // quad_perm [1,0,3,2]
+    else if (ctrl_sel == 1) y = __builtin_amdgcn_update_dpp(x, x, 0x4E, 0xf, 0xf, false);   // quad_perm [2,3,0,1]
+    else if (ctrl_sel == 2) y = __builtin_amdgcn_update_dpp(x, x, 0x141, 0xf, 0xf, false);  // row_half_mirror
+    else y = __builtin_amdgcn_update_dpp(x, x, 0x140, 0xf, 0xf, false);                     // row_mirror
+    return v + __builtin_bit_cast(float, y);
+}
+__device__ __forceinline__ float row16_sum(float v) {
+    v = dpp_add(v, 0);
+    v = dpp_add(v, 1);
+    v = dpp_add(v, 2);
+    return dpp_add(v, 3);
+}
+
+// sum over the wave, every lane gets it: the DPP row sum, then the two row broadcasts of gfx9 (lane 63 ends up with the
+// total) and a readlane
+__device__ __forceinline__ float wave64_sum(float v) {
+    v = row16_sum(v);
+    int x = __builtin_bit_cast(int, v);
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false));      // row_bcast:15 -> rows 1, 3
+    x = __builtin_bit_cast(int, v);
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false));      // row_bcast:31 -> rows 2, 3
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+
 // erf by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7, far below the bf16 rounding of h): erff() is ~40 instructions,
 // and here ONE compute unit applies GELU to 16 x 1024 pre-activations per layer
 __device__ __forceinline__ float erf_as(float x) {
@@ -156,7 +186,8 @@ __device__ __forceinline__ void wg_gemm(const uint16_t* __restrict__ A, const ui
 }
 
 // xb[r][:] (f32, LDS) -> LayerNorm -> `dst_a` (bf16, LDS, the next GEMM's A operand) + global copies; also writes the
-// pre-norm rows (x1 / x2) and the statistics.  Wave w takes rows w, w + NW, ...
+// pre-norm rows (x1 / x2) and the statistics.  One wave per row (rows w, w + NW, ...), 256-byte runs to global; two-pass
+// mean / variance as mobgt_dropout_add_ln_fwd.
 template <int BM, int C, int LDX, int LDA>
 __device__ __forceinline__ void ln_rows(const float* __restrict__ xb, uint16_t* __restrict__ dst_a, const float* __restrict__ w,
                                         const float* __restrict__ b, float* __restrict__ g_pre, uint16_t* __restrict__ g_bf,
@@ -164,6 +195,13 @@ __device__ __forceinline__ void ln_rows(const float* __restrict__ xb, uint16_t* 
                                         int r0, int R) {
     constexpr int PER = (C + 63) / 64;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float wv[PER], bv[PER];
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        const int c = min(lane + 64 * k, C - 1);
+        wv[k] = w[c];
+        bv[k] = b[c];
+    }
     for (int r = wave; r < BM; r += NW) {
         const int64_t row = r0 + r;
         float v[PER], s = 0.f;
@@ -173,21 +211,21 @@ __device__ __forceinline__ void ln_rows(const float* __restrict__ xb, uint16_t* 
             v[k] = c < C ? xb[r * LDX + c] : 0.f;
             s += v[k];
         }
-        const float mu = wave_sum(s) * (1.f / C);
+        const float mu = wave64_sum(s) * (1.f / C);
         float qq = 0.f;
 #pragma unroll
         for (int k = 0; k < PER; ++k) {
             const float d = lane + 64 * k < C ? v[k] - mu : 0.f;
             qq += d * d;
         }
-        const float rs = rsqrtf(wave_sum(qq) * (1.f / C) + 1e-5f);
+        const float rs = rsqrtf(wave64_sum(qq) * (1.f / C) + 1e-5f);
         const bool on = row < R;
         if (on && lane == 0) { g_mean[row] = mu; g_rstd[row] = rs; }
 #pragma unroll
         for (int k = 0; k < PER; ++k) {
             const int c = lane + 64 * k;
             if (c < C) {
-                const float o = (v[k] - mu) * rs * w[c] + b[c];
+                const float o = (v[k] - mu) * rs * wv[k] + bv[k];
                 const uint16_t ob = bf16_bits(o);
                 dst_a[r * LDA + c] = ob;
                 if (on) {
@@ -323,6 +361,7 @@ struct PackJobs {
     const uint16_t* src[32];
     uint16_t* dst[32];
     int N[32], K[32];
+    int transposed[32];                      // src is [K][N] row-major: pack its transpose
     int first_block[33];                     // job i owns blocks [first_block[i], first_block[i + 1]); 256 pieces per block
 };
 
@@ -336,8 +375,18 @@ __global__ __launch_bounds__(256) void pack_mfma_b_kernel(const PackJobs jobs, i
     const int l = (int)(piece & 63);
     const int64_t gs = piece >> 6;
     const int g = (int)(gs / S), s_ = (int)(gs % S);
-    const uint16_t* from = jobs.src[job] + (int64_t)(16 * g + (l & 15)) * K + 32 * s_ + 8 * (l >> 4);
-    *reinterpret_cast<uint4*>(jobs.dst[job] + piece * 8) = *reinterpret_cast<const uint4*>(from);
+    if (!jobs.transposed[job]) {
+        const uint16_t* from = jobs.src[job] + (int64_t)(16 * g + (l & 15)) * K + 32 * s_ + 8 * (l >> 4);
+        *reinterpret_cast<uint4*>(jobs.dst[job] + piece * 8) = *reinterpret_cast<const uint4*>(from);
+    } else {                                 // W'[n][k] = src[k][n]: eight 2-byte reads, the 16 lanes of a k-block side by side
+        const int N = jobs.N[job];
+        const uint16_t* from = jobs.src[job] + (int64_t)(32 * s_ + 8 * (l >> 4)) * N + 16 * g + (l & 15);
+        uint16_t e[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) e[i] = from[(int64_t)i * N];
+        *reinterpret_cast<uint4*>(jobs.dst[job] + piece * 8) =
+            make_uint4(e[0] | (uint32_t)e[1] << 16, e[2] | (uint32_t)e[3] << 16, e[4] | (uint32_t)e[5] << 16, e[6] | (uint32_t)e[7] << 16);
+    }
 }
 
 template <int BM, int C, int F>
@@ -350,9 +399,207 @@ int launch(const ChainParams& p, hipStream_t st) {
     return (int)hipGetLastError();
 }
 
+
+// ---- the same chain backwards: from d(out) down to the gradient of the attention output ------------------------------
+//     dx2 = ffn_norm2'(dout);  df = dropout'(dx2)                      [dnxw, dnxb, db2]
+//     du  = (df W2) * gelu'(u)
+//     dz  = du W1
+//     dx1 = dx2 + ffn_norm1'(dz);  dy = dropout'(dx1)                  [dn1w, dn1b, dbo]
+//     da  = dy Wo
+// (mobgt_dropout_add_ln_bwd, mobgt_layer_gemm GELU_BWD / plain, mobgt_dropout_add_ln_bwd, mobgt_layer_gemm as five
+// launches: 28.7 us of the S-FSQ layer's backward.)  The weights are the TRANSPOSES packed in operand order (dX = dY W:
+// W is the [K][N] operand).  df, du, dy (the weight-gradient GEMMs read them), da (the attention backward) and dx1 (the
+// residual gradient the QKV data gradient is added to) go to global memory; the six column sums leave the workgroup as one
+// atomic per column.
+struct ChainBwdParams {
+    const float *dout, *x2, *x1;             // [R,C] f32
+    const uint16_t* u;                       // [R,F] bf16
+    const float *mean1, *rstd1, *mean2, *rstd2, *n1w, *nxw;
+    const uint16_t *w2t, *w1t, *wot;         // packed transposes: (N=F,K=C), (N=C,K=F), (N=C,K=C)
+    uint16_t *df, *du, *dy, *da;             // bf16 [R,C] [R,F] [R,C] [R,C]
+    float* dx1;                              // [R,C] f32
+    float *dnxw, *dnxb, *db2, *dn1w, *dn1b, *dbo;     // [C] f32, accumulated
+    int R;
+    uint32_t thr;
+    float inv_keep;
+    uint64_t seed;
+    const uint64_t* seed_dev;
+    uint32_t salt1, salt2;
+};
+
+// gelu'(u) = Phi(u) + u phi(u); the exponential of the A&S erf IS phi's
+__device__ __forceinline__ float gelu_grad_f(float u) {
+    const float ax = fabsf(u) * 0.70710678118654752f;
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.f));
+    float y = fmaf(1.061405429f, t, -1.453152027f);
+    y = fmaf(y, t, 1.421413741f);
+    y = fmaf(y, t, -0.284496736f);
+    y = fmaf(y, t, 0.254829592f);
+    const float e = __expf(-ax * ax);
+    const float erf = copysignf(1.f - y * t * e, u);
+    return fmaf(u * 0.3989422804014327f, e, 0.5f * (1.f + erf));
+}
+
+// LayerNorm backward of the block's rows (one wave per row): d (the gradient at the norm's output) comes from `d_lds`
+// (f32 [BM][LDX]) or from global `d_g`; xhat from the saved pre-norm rows and statistics; `res` (LDS f32, or null) is added;
+// the result goes to `dx_lds` (f32, LDS), optionally `dx_g` (global f32), and its dropout'ed bf16 form to `dy_lds` (the next
+// GEMM's A operand) and `dy_g`.  Column sums of (d * xhat, d, dy) over the block's rows are accumulated into `red`
+// ([3][NW][C] f32, LDS; the caller reduces over the waves).
+template <int BM, int C, int LDX, int LDA>
+__device__ __forceinline__ void ln_bwd_rows(const float* __restrict__ d_lds, const float* __restrict__ d_g,
+                                            const float* __restrict__ xpre, const float* __restrict__ g_mean,
+                                            const float* __restrict__ g_rstd, const float* __restrict__ w,
+                                            const float* res, float* dx_lds, float* __restrict__ dx_g,
+                                            uint16_t* __restrict__ dy_lds, uint16_t* __restrict__ dy_g, float* __restrict__ red,
+                                            int r0, int R, uint32_t thr, float inv_keep, uint64_t seed, uint32_t salt) {
+    constexpr int PER = (C + 63) / 64;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float wv[PER], ag[PER], ab[PER], ay[PER];
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        wv[k] = w[min(lane + 64 * k, C - 1)];
+        ag[k] = ab[k] = ay[k] = 0.f;
+    }
+    for (int r = wave; r < BM; r += NW) {
+        const int64_t row = min(r0 + r, R - 1);
+        const bool on = r0 + r < R;
+        const float mu = g_mean[row], rs = g_rstd[row];
+        float d[PER], xh[PER], gg[PER], s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const int c = min(lane + 64 * k, C - 1);
+            const bool in = lane + 64 * k < C && on;
+            const float dv = d_lds ? d_lds[r * LDX + c] : d_g[row * C + c];
+            d[k] = in ? dv : 0.f;
+            xh[k] = in ? (xpre[row * C + c] - mu) * rs : 0.f;
+            gg[k] = d[k] * wv[k];
+            ag[k] += d[k] * xh[k];
+            ab[k] += d[k];
+            s1 += gg[k];
+            s2 += gg[k] * xh[k];
+        }
+        s1 = wave64_sum(s1) * (1.f / C);
+        s2 = wave64_sum(s2) * (1.f / C);
+        const uint32_t rowh = thr ? dropout_row_hash(seed, (uint32_t)(r0 + r) ^ salt) : 0u;
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const int c = lane + 64 * k;
+            if (c < C) {
+                float t = rs * (gg[k] - s1 - xh[k] * s2);
+                if (res) t += res[r * LDX + c];
+                if (!on) t = 0.f;
+                dx_lds[r * LDX + c] = t;
+                float yv = t;
+                if (thr) yv = dropout_bits16(seed, rowh, (uint32_t)c) >= thr ? t * inv_keep : 0.f;
+                ay[k] += yv;
+                const uint16_t yb = bf16_bits(yv);
+                dy_lds[r * LDA + c] = yb;
+                if (on) {
+                    if (dx_g) dx_g[row * C + c] = t;
+                    dy_g[row * C + c] = yb;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        const int c = lane + 64 * k;
+        if (c < C) {
+            red[(0 * NW + wave) * C + c] = ag[k];
+            red[(1 * NW + wave) * C + c] = ab[k];
+            red[(2 * NW + wave) * C + c] = ay[k];
+        }
+    }
+}
+
+template <int C>
+__device__ __forceinline__ void flush_colsums(const float* __restrict__ red, float* g0, float* g1, float* g2) {
+    for (int e = threadIdx.x; e < 3 * C; e += NT) {
+        const int which = e / C, c = e % C;
+        float s = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) s += red[(which * NW + w) * C + c];
+        atomicAdd((which == 0 ? g0 : (which == 1 ? g1 : g2)) + c, s);
+    }
+}
+
+template <int BM, int C, int F>
+__global__ __launch_bounds__(NT) void layer_chain_bwd_kernel(const ChainBwdParams p) {
+    constexpr int LDA = C + 8, LDH = F + 8, LDX = C + 4, MT = BM / 16;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float* dxb = reinterpret_cast<float*>(smem_raw);                             // [BM][LDX] f32: dx2, then dx1
+    float* dzb = dxb + BM * LDX;                                                 // [BM][LDX] f32: dz (bf16-rounded values)
+    float* red = dzb + BM * LDX;                                                 // [3][NW][C] f32 column-sum partials
+    uint16_t* gb = reinterpret_cast<uint16_t*>(red + 3 * NW * C);                // [BM][LDA] bf16: df, then dy
+    uint16_t* ub = gb + BM * LDA;                                                // [BM][LDH] bf16: u, later da
+    uint16_t* dub = ub + BM * LDH;                                               // [BM][LDH] bf16: du
+    const int r0 = blockIdx.x * BM;
+    const int lane = threadIdx.x & 63;
+    const int j = lane & 15, q = lane >> 4;
+    const uint64_t seed = p.thr ? p.seed + (p.seed_dev ? *p.seed_dev : 0ull) : 0ull;
+
+    for (int e = threadIdx.x; e < BM * (F / 8); e += NT) {                        // the block's rows of u -> LDS
+        const int r = e / (F / 8), c = (e % (F / 8)) * 8;
+        *reinterpret_cast<uint4*>(ub + r * LDH + c) = *reinterpret_cast<const uint4*>(p.u + (int64_t)min(r0 + r, p.R - 1) * F + c);
+    }
+    // ---- dx2 = ffn_norm2'(dout);  df = dropout'(dx2)
+    ln_bwd_rows<BM, C, LDX, LDA>(nullptr, p.dout, p.x2, p.mean2, p.rstd2, p.nxw, nullptr, dxb, nullptr, gb, p.df, red, r0, p.R,
+                                 p.thr, p.inv_keep, seed, p.salt2);
+    __syncthreads();
+    flush_colsums<C>(red, p.dnxw, p.dnxb, p.db2);
+    // ---- du = (df W2) * gelu'(u)
+    wg_gemm<BM, F, C, LDA>(gb, p.w2t, [&](int g, const f32x4 (&acc)[MT]) {
+        const int col = 16 * g + j;
+#pragma unroll
+        for (int t = 0; t < MT; ++t)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const int r = 16 * t + 4 * q + v;
+                dub[r * LDH + col] = bf16_bits(acc[t][v] * gelu_grad_f(bf16_val(ub[r * LDH + col])));
+            }
+    });
+    __syncthreads();
+    store_rows<BM, F, LDH>(dub, p.du, r0, p.R);
+    // ---- dz = du W1  (rounded to bf16 where the separate launch wrote a bf16 tensor)
+    wg_gemm<BM, C, F, LDH>(dub, p.w1t, [&](int g, const f32x4 (&acc)[MT]) {
+        const int col = 16 * g + j;
+#pragma unroll
+        for (int t = 0; t < MT; ++t)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) dzb[(16 * t + 4 * q + v) * LDX + col] = bf16_round(acc[t][v]);
+    });
+    __syncthreads();
+    // ---- dx1 = dx2 + ffn_norm1'(dz);  dy = dropout'(dx1)
+    ln_bwd_rows<BM, C, LDX, LDA>(dzb, nullptr, p.x1, p.mean1, p.rstd1, p.n1w, dxb, dxb, p.dx1, gb, p.dy, red, r0, p.R, p.thr,
+                                 p.inv_keep, seed, p.salt1);
+    __syncthreads();
+    flush_colsums<C>(red, p.dn1w, p.dn1b, p.dbo);
+    // ---- da = dy Wo
+    wg_gemm<BM, C, C, LDA>(gb, p.wot, [&](int g, const f32x4 (&acc)[MT]) {
+        const int col = 16 * g + j;
+#pragma unroll
+        for (int t = 0; t < MT; ++t)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) ub[(16 * t + 4 * q + v) * LDH + col] = bf16_bits(acc[t][v]);
+    });
+    __syncthreads();
+    store_rows<BM, C, LDH>(ub, p.da, r0, p.R);
+}
+
+template <int BM, int C, int F>
+int launch_bwd(const ChainBwdParams& p, hipStream_t st) {
+    constexpr size_t lds = 2 * BM * (C + 4) * 4 + 3 * NW * C * 4 + BM * (C + 8) * 2 + 2 * BM * (F + 8) * 2;
+    static_assert(lds <= 152 * 1024, "LDS plan");
+    int rc = (int)hipFuncSetAttribute((const void*)layer_chain_bwd_kernel<BM, C, F>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (rc) return rc;
+    hipLaunchKernelGGL((layer_chain_bwd_kernel<BM, C, F>), dim3((p.R + BM - 1) / BM), dim3(NT), lds, st, p);
+    return (int)hipGetLastError();
+}
+
 }  // namespace
 
-extern "C" int mobgt_pack_mfma_b(int n, const void* const* src, void* const* dst, const int* N, const int* K, void* stream) {
+extern "C" int mobgt_pack_mfma_b(int n, const void* const* src, void* const* dst, const int* N, const int* K,
+                                 const int* transposed, void* stream) {
     if (n <= 0) return 0;
     if (n > 32) return MOBGT_EBADDIM;
     PackJobs jobs = {};
@@ -361,6 +608,7 @@ extern "C" int mobgt_pack_mfma_b(int n, const void* const* src, void* const* dst
         if (N[i] <= 0 || K[i] <= 0 || (N[i] & 15) || (K[i] & 31)) return MOBGT_EBADDIM;
         if (((uintptr_t)src[i] | (uintptr_t)dst[i]) & 15) return MOBGT_EALIGN;
         jobs.src[i] = (const uint16_t*)src[i]; jobs.dst[i] = (uint16_t*)dst[i]; jobs.N[i] = N[i]; jobs.K[i] = K[i];
+        jobs.transposed[i] = transposed ? transposed[i] : 0;
         jobs.first_block[i] = blocks;
         blocks += (int)(((int64_t)N[i] * K[i] / 8 + 255) / 256);
     }
@@ -398,4 +646,28 @@ extern "C" int mobgt_layer_chain_fwd(const void* a, const float* x, const void* 
     if (C == 192 && F == 1024) return launch<16, 192, 1024>(p, st);
     if (C == 256 && F == 1024) return launch<16, 256, 1024>(p, st);
     return MOBGT_EBADDIM;                    // the instantiated widths: MobGT's hidden 128 / 192 (+ 64 of embeddings), ffn 1024
+}
+
+extern "C" int mobgt_layer_chain_bwd(const float* dout, const float* x2, const float* x1, const void* u, const float* mean1,
+                                     const float* rstd1, const float* mean2, const float* rstd2, const float* n1w,
+                                     const float* nxw, const void* w2t, const void* w1t, const void* wot, void* df, void* du,
+                                     void* dy, void* da, float* dx1, float* dnxw, float* dnxb, float* db2, float* dn1w,
+                                     float* dn1b, float* dbo, int64_t R, int C, int F, float dropout_p, uint64_t seed,
+                                     const uint64_t* seed_dev, uint32_t salt1, uint32_t salt2, void* stream) {
+    if (R <= 0) return 0;
+    if (R > 0x7fffffff) return MOBGT_EBADDIM;
+    if (((uintptr_t)u | (uintptr_t)w2t | (uintptr_t)w1t | (uintptr_t)wot | (uintptr_t)du | (uintptr_t)da) & 15) return MOBGT_EALIGN;
+    ChainBwdParams p = {};
+    typedef const uint16_t* cu;
+    p.dout = dout; p.x2 = x2; p.x1 = x1; p.u = (cu)u; p.mean1 = mean1; p.rstd1 = rstd1; p.mean2 = mean2; p.rstd2 = rstd2;
+    p.n1w = n1w; p.nxw = nxw; p.w2t = (cu)w2t; p.w1t = (cu)w1t; p.wot = (cu)wot;
+    p.df = (uint16_t*)df; p.du = (uint16_t*)du; p.dy = (uint16_t*)dy; p.da = (uint16_t*)da; p.dx1 = dx1;
+    p.dnxw = dnxw; p.dnxb = dnxb; p.db2 = db2; p.dn1w = dn1w; p.dn1b = dn1b; p.dbo = dbo; p.R = (int)R;
+    p.thr = dropout_p > 0.f ? dropout_threshold(dropout_p) : 0u;
+    p.inv_keep = p.thr ? 1.f / (1.f - (float)p.thr / 65536.f) : 1.f;
+    p.seed = seed; p.seed_dev = seed_dev; p.salt1 = salt1; p.salt2 = salt2;
+    hipStream_t st = (hipStream_t)stream;
+    if (C == 192 && F == 1024) return launch_bwd<16, 192, 1024>(p, st);
+    if (C == 256 && F == 1024) return launch_bwd<16, 256, 1024>(p, st);
+    return MOBGT_EBADDIM;
 }

@@ -173,6 +173,7 @@ _LN_GEMM = [_os_ln.environ.get("MOBGT_NO_LN_GEMM") != "1"]      # MOBGT_NO_LN_GE
 _LN_GEMM_BWD = [_os_ln.environ.get("MOBGT_LN_GEMM_BWD") == "1"]
 # csrc/chain.hip: out-proj -> LN -> FFN -> LN -> the next layer's QKV in one launch (MOBGT_NO_CHAIN=1: the separate launches)
 _CHAIN = [_os_ln.environ.get("MOBGT_NO_CHAIN") != "1"]
+_CHAIN_BWD = [_os_ln.environ.get("MOBGT_NO_CHAIN_BWD") != "1"]      # ... and the same chain backwards (d(out) -> d(attention out))
 
 
 def _chain_ok(C, F, *ts):
@@ -226,6 +227,7 @@ class LayerConfig:
         self.act_dtype = act_dtype
         self.next_qkv = None      # (packed wqkv, bqkv) of the NEXT fused layer: its QKV projection rides in this layer's chain
         self.packed = None        # (wo, w1, w2) of this layer in MFMA operand order (model.pack_layer_weights)
+        self.packed_t = None      # (w2^T, w1^T, wo^T) likewise, for the backward chain
         self.out_act = self.out_qkv = None
 
 
@@ -278,6 +280,8 @@ class _FusedLayerFn(torch.autograd.Function):
         use_chain = (not stock and own and A == torch.bfloat16 and cfg.packed is not None
                      and _chain_ok(C, F, x, a, s_bo, s_b1, s_b2, n1w, n1b, nxw, nxb, *cfg.packed))
         ctx.fuse_ln = use_chain
+        ctx.chain_bwd = bool(use_chain and _CHAIN_BWD[0] and cfg.packed_t is not None
+                             and all(t.is_contiguous() and t.data_ptr() % 16 == 0 for t in cfg.packed_t))
         if use_chain:               # everything row-local of the layer (+ the next layer's QKV projection) in one launch
             bf = dict(dtype=A, device=dev)
             x1, x2, out = torch.empty(R, C, **f32), torch.empty(R, C, **f32), torch.empty(R, C, **f32)
@@ -356,6 +360,50 @@ class _FusedLayerFn(torch.autograd.Function):
         return out, x1, z, u, h, x2
 
     @staticmethod
+    def _bwd_launches(ctx, cfg, wb, dout, x1, z, u, h, x2, a, stats, s_wo, s_w1, s_w2, n1w, nxw, dbo, db1, db2, dn1w, dn1b, dnxw,
+                      dnxb, G, T, C, F, A, act, dev, own, stock, db1_in_wgrad):
+        """d(out) ... d(attention out) as separate launches (every configuration the backward chain does not cover)."""
+        R = G * T
+        seed, sd, salt = cfg.seed, cfg.seed_dev, cfg.salt
+        k_qkv, k_wo, k_w1, k_w2 = ctx.sinks
+        df = torch.empty(R, C, dtype=A, device=dev)
+        fuse_ln = ctx.fuse_ln and _LN_GEMM_BWD[0]
+        du = None
+        if stock:
+            dx2 = dout                                                # grad at x2 = x1 + dropout(f)
+            _k1_bwd(None, None, dout, x2, None, None, None, None, df, None, None, db2, R, C, cfg.p, seed, sd, salt + 2, act)
+        else:
+            dx2 = torch.empty(R, C, dtype=torch.float32, device=dev)  # through ffn_norm2
+            if fuse_ln and db1_in_wgrad:    # ffn_norm2' + dropout' -> df, du = (df W2) * gelu'(u): one launch
+                du = _ln_gemm_bwd(None, dout, None, x2, stats[4], stats[5], nxw, dx2, df, dnxw, dnxb, db2, R, C, cfg.p,
+                                  seed, sd, salt + 2, s_w2, ops.GEMM_GELU_BWD, u)
+            else:
+                _k1_bwd(None, dout, None, x2, stats[4], stats[5], nxw, dx2, df, dnxw, dnxb, db2, R, C, cfg.p, seed, sd,
+                        salt + 2, act)
+        dw2 = wb.add(df, h, sink=k_w2)
+        if du is not None:
+            pass
+        elif own and db1_in_wgrad:
+            du = ops.layer_gemm(df, s_w2, None, True, ops.GEMM_GELU_BWD, aux_in=u)      # (df W2) * gelu'(u), one launch
+        else:
+            dh = df @ s_w2
+            du = torch.empty_like(u)
+            check(_lib.lib().mobgt_gelu_bwd_colsum(_p(dh), _p(u), _p(du), _p(None if db1_in_wgrad else db1), R, F, act,
+                                                   _stream()), "mobgt_gelu_bwd_colsum")
+        dz = ops.layer_gemm(du, s_w1, None, True) if own else du @ s_w1
+        dw1 = wb.add(du, z, db=db1 if db1_in_wgrad else None, sink=k_w1)
+        dx1 = torch.empty(R, C, dtype=torch.float32, device=dev)
+        dy = torch.empty(R, C, dtype=A, device=dev)
+        if fuse_ln:             # ffn_norm1' + residual + dropout' -> dy, da = dy Wo: one launch
+            da = _ln_gemm_bwd(dz, None, dx2, x1, stats[2], stats[3], n1w, dx1, dy, dn1w, dn1b, dbo, R, C, cfg.p, seed, sd,
+                              salt + 1, s_wo, ops.GEMM_BIAS, None).view(G, T, C)
+        else:
+            _k1_bwd(dz, None, dx2, x1, stats[2], stats[3], n1w, dx1, dy, dn1w, dn1b, dbo, R, C, cfg.p, seed, sd, salt + 1, act)
+            da = (ops.layer_gemm(dy, s_wo, None, True) if own else dy @ s_wo).view(G, T, C)
+        dwo = wb.add(dy, a.view(R, C), sink=k_wo)
+        return da, dx1, dw2, dw1, dwo
+
+    @staticmethod
     def backward(ctx, dout):
         cfg = ctx.cfg
         G, T, C = ctx.shapes
@@ -378,45 +426,30 @@ class _FusedLayerFn(torch.autograd.Function):
             o[0] += n
             return t
         dbqkv, dbo, db1, db2, dn1w, dn1b, dnxw, dnxb = take(3 * C), take(C), take(F), take(C), take(C), take(C), take(C), take(C)
-        df = torch.empty(R, C, dtype=A, device=dev)
         own = ctx.own_gemm
-        fuse_ln = ctx.fuse_ln and _LN_GEMM_BWD[0]
-        db1_in_wgrad = _wgrad_hip(A, F, C, R)                         # then b1's gradient rides on the dW1 kernel
-        du = None
-        if stock:
-            dx2 = dout                                                # grad at x2 = x1 + dropout(f)
-            _k1_bwd(None, None, dout, x2, None, None, None, None, df, None, None, db2, R, C, cfg.p, seed, sd, salt + 2, act)
-        else:
-            dx2 = torch.empty(R, C, dtype=torch.float32, device=dev)  # through ffn_norm2
-            if fuse_ln and db1_in_wgrad:    # ffn_norm2' + dropout' -> df, du = (df W2) * gelu'(u): one launch
-                du = _ln_gemm_bwd(None, dout, None, x2, stats[4], stats[5], nxw, dx2, df, dnxw, dnxb, db2, R, C, cfg.p,
-                                  seed, sd, salt + 2, s_w2, ops.GEMM_GELU_BWD, u)
-            else:
-                _k1_bwd(None, dout, None, x2, stats[4], stats[5], nxw, dx2, df, dnxw, dnxb, db2, R, C, cfg.p, seed, sd,
-                        salt + 2, act)
         wb = _WgradBatch()
         k_qkv, k_wo, k_w1, k_w2 = ctx.sinks                          # gradient sinks (or None)
-        dw2 = wb.add(df, h, sink=k_w2)
-        if du is not None:
-            pass
-        elif own and db1_in_wgrad:
-            du = ops.layer_gemm(df, s_w2, None, True, ops.GEMM_GELU_BWD, aux_in=u)      # (df W2) * gelu'(u), one launch
+        db1_in_wgrad = _wgrad_hip(A, F, C, R)                         # then b1's gradient rides on the dW1 kernel
+        if getattr(ctx, "chain_bwd", False) and db1_in_wgrad and not stock:
+            # d(out) -> ffn_norm2' -> dropout' -> (W2, gelu') -> W1 -> ffn_norm1' + residual -> dropout' -> Wo: one launch
+            bf = dict(dtype=A, device=dev)
+            df, dy, da = torch.empty(R, C, **bf), torch.empty(R, C, **bf), torch.empty(R, C, **bf)
+            du = torch.empty(R, F, **bf)
+            dx1 = torch.empty(R, C, dtype=torch.float32, device=dev)
+            w2t, w1t, wot = cfg.packed_t
+            check(_lib.lib().mobgt_layer_chain_bwd(_p(dout), _p(x2), _p(x1), _p(u), _p(stats[2]), _p(stats[3]), _p(stats[4]),
+                                                   _p(stats[5]), _p(n1w), _p(nxw), _p(w2t), _p(w1t), _p(wot), _p(df), _p(du),
+                                                   _p(dy), _p(da), _p(dx1), _p(dnxw), _p(dnxb), _p(db2), _p(dn1w), _p(dn1b),
+                                                   _p(dbo), R, C, F, cfg.p, seed, _p(sd), (salt + 1) & 0xFFFFFFFF,
+                                                   (salt + 2) & 0xFFFFFFFF, _stream()), "mobgt_layer_chain_bwd")
+            da = da.view(G, T, C)
+            dw2 = wb.add(df, h, sink=k_w2)
+            dw1 = wb.add(du, z, db=db1, sink=k_w1)
+            dwo = wb.add(dy, a.view(R, C), sink=k_wo)
         else:
-            dh = df @ s_w2
-            du = torch.empty_like(u)
-            check(_lib.lib().mobgt_gelu_bwd_colsum(_p(dh), _p(u), _p(du), _p(None if db1_in_wgrad else db1), R, F, act,
-                                                   _stream()), "mobgt_gelu_bwd_colsum")
-        dz = ops.layer_gemm(du, s_w1, None, True) if own else du @ s_w1
-        dw1 = wb.add(du, z, db=db1 if db1_in_wgrad else None, sink=k_w1)
-        dx1 = torch.empty(R, C, dtype=torch.float32, device=dev)
-        dy = torch.empty(R, C, dtype=A, device=dev)
-        if fuse_ln:             # ffn_norm1' + residual + dropout' -> dy, da = dy Wo: one launch
-            da = _ln_gemm_bwd(dz, None, dx2, x1, stats[2], stats[3], n1w, dx1, dy, dn1w, dn1b, dbo, R, C, cfg.p, seed, sd,
-                              salt + 1, s_wo, ops.GEMM_BIAS, None).view(G, T, C)
-        else:
-            _k1_bwd(dz, None, dx2, x1, stats[2], stats[3], n1w, dx1, dy, dn1w, dn1b, dbo, R, C, cfg.p, seed, sd, salt + 1, act)
-            da = (ops.layer_gemm(dy, s_wo, None, True) if own else dy @ s_wo).view(G, T, C)
-        dwo = wb.add(dy, a.view(R, C), sink=k_wo)
+            da, dx1, dw2, dw1, dwo = _FusedLayerFn._bwd_launches(ctx, cfg, wb, dout, x1, z, u, h, x2, a, stats, s_wo, s_w1, s_w2,
+                                                                n1w, nxw, dbo, db1, db2, dn1w, dn1b, dnxw, dnxb, G, T, C, F, A,
+                                                                act, dev, own, stock, db1_in_wgrad)
         dqkv = torch.empty(G, T, 3 * C, dtype=A, device=dev)
         q, k, v = qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:]
         ops._attn_bwd(q, k, v, a, lse, da, dqkv[..., :C], dqkv[..., C:2 * C], dqkv[..., 2 * C:], cfg.pack, cfg.scale,

@@ -203,6 +203,8 @@ def fused_layer_forward(layer, variant, x, attn_bias, n1, nx, next_layer=None):
         cfg.next_qkv = (nxt._packed[0], nxt._shadows[1])
     if getattr(layer, "_packed_fresh", False) and act != torch.float32 and not amp:
         cfg.packed = layer._packed[1:]                    # (wo, w1, w2) in MFMA operand order
+        if getattr(layer, "_packed_t_fresh", False):
+            cfg.packed_t = layer._packed_t                # (w2^T, w1^T, wo^T)
     params = (mha.linear_q.weight, mha.linear_q.bias, mha.linear_k.weight, mha.linear_k.bias, mha.linear_v.weight,
               mha.linear_v.bias, mha.output_layer.weight, mha.output_layer.bias, n1.weight, n1.bias, nx.weight, nx.bias,
               layer.ffn.layer1.weight, layer.ffn.layer1.bias, layer.ffn.layer2.weight, layer.ffn.layer2.bias)
@@ -243,39 +245,46 @@ def refresh_shadows(layers):
 
 def pack_layer_weights(layers):
     """MFMA-operand-order copies of the fused fq layers' bf16 GEMM weights (csrc/chain.hip reads a wave's B operand as one
-    contiguous KB), all layers in one launch (two beyond 8 layers); `layer._packed` = (wqkv, wo, w1, w2) packed."""
+    contiguous KB), all layers in one launch (one per 32 weights): `layer._packed` = (wqkv, wo, w1, w2) packed for the
+    forward chain and, when gradients are enabled, `layer._packed_t` = (w2^T, w1^T, wo^T) for the backward chain."""
     import ctypes
     from . import fused_layer, _lib
     from .ops import _stream
     if not fused_layer._CHAIN[0]:
         return
+    want_t = torch.is_grad_enabled() and fused_layer._CHAIN_BWD[0]
     jobs = []
     for layer in layers:
-        layer._packed_fresh = False
+        layer._packed_fresh = layer._packed_t_fresh = False
         sh = getattr(layer, "_shadows", None)
         if (sh is None or not getattr(layer, "fused", False) or not getattr(layer, "_shadow_fresh", False)
                 or not hasattr(layer, "ffn_norm2") or sh[0].dtype != torch.bfloat16 or not sh[0].is_cuda):
             continue
         C, F = sh[2].shape[0], sh[4].shape[0]
-        if (C, F) not in ((192, 1024), (256, 1024)):
+        if (C, F) not in ((192, 1024), (256, 1024)) or not all(sh[i].is_contiguous() for i in (0, 2, 4, 6)):
             continue
         pk = getattr(layer, "_packed", None)
         if pk is None or pk[0].device != sh[0].device:
             pk = tuple(torch.empty_like(sh[i]) for i in (0, 2, 4, 6))
             layer._packed = pk
         for d, i in zip(pk, (0, 2, 4, 6)):
-            if not sh[i].is_contiguous():
-                break
-            jobs.append((sh[i], d))
-        else:
-            layer._packed_fresh = True
+            jobs.append((sh[i], d, sh[i].shape[0], sh[i].shape[1], 0))
+        layer._packed_fresh = True
+        if want_t and any(p.requires_grad for p in layer.parameters()):
+            pt = getattr(layer, "_packed_t", None)
+            if pt is None or pt[0].device != sh[0].device:
+                pt = tuple(torch.empty_like(sh[i]) for i in (6, 4, 2))
+                layer._packed_t = pt
+            for d, i in zip(pt, (6, 4, 2)):          # dX = dY W: W [K = out, N = in] is the operand, packed as [N][K]
+                jobs.append((sh[i], d, sh[i].shape[1], sh[i].shape[0], 1))
+            layer._packed_t_fresh = True
     for o in range(0, len(jobs), 32):
         part = jobs[o:o + 32]
         n = len(part)
         vp, ci = ctypes.c_void_p, ctypes.c_int
-        _lib.check(_lib.lib().mobgt_pack_mfma_b(n, (vp * n)(*[a.data_ptr() for a, _ in part]), (vp * n)(*[b.data_ptr() for _, b in part]),
-                                                (ci * n)(*[a.shape[0] for a, _ in part]), (ci * n)(*[a.shape[1] for a, _ in part]),
-                                                _stream()), "mobgt_pack_mfma_b")
+        _lib.check(_lib.lib().mobgt_pack_mfma_b(n, (vp * n)(*[j[0].data_ptr() for j in part]), (vp * n)(*[j[1].data_ptr() for j in part]),
+                                                (ci * n)(*[j[2] for j in part]), (ci * n)(*[j[3] for j in part]),
+                                                (ci * n)(*[j[4] for j in part]), _stream()), "mobgt_pack_mfma_b")
 
 
 def sync_external_shadows(model):

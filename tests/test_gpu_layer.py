@@ -510,8 +510,9 @@ def test_layer_chain_kernel_matches_the_separate_launches(C, G, T, p):
     bias = torch.randn(G, H, T, T, device=DEV) * 0.3
     gy = torch.randn(G, T, C, device=DEV)
     res = {}
-    for on in (True, False):
-        fused_layer._CHAIN[0] = on
+    for mode in ("both", "forward", "off"):                # chain kernels forward + backward / forward only / neither
+        fused_layer._CHAIN[0] = mode != "off"
+        fused_layer._CHAIN_BWD[0] = mode == "both"
         try:
             for q in layers.parameters():
                 q.grad = None
@@ -522,22 +523,25 @@ def test_layer_chain_kernel_matches_the_separate_launches(C, G, T, p):
             for li, l in enumerate(layers):
                 y = l(y, bias, next_layer=layers[li + 1] if li + 1 < len(layers) else None)
                 rode.append(getattr(y, "_mobgt_qkv", None) is not None)
-            assert rode == ([True, True, False] if on else [False, False, False])     # the QKV projections did ride along
+            assert rode == ([True, True, False] if mode != "off" else [False, False, False])     # the QKV projections did ride along
+            assert y.grad_fn.chain_bwd == (mode == "both")
             y.backward(gy)
             torch.cuda.synchronize()
-            res[on] = (y.detach().clone(), x.grad.clone(), {n: q.grad.clone() for n, q in layers.named_parameters() if q.grad is not None})
+            res[mode] = (y.detach().clone(), x.grad.clone(), {n: q.grad.clone() for n, q in layers.named_parameters() if q.grad is not None})
         finally:
-            fused_layer._CHAIN[0] = True
-    (ya, dxa, ga), (yb, dxb, gb) = res[True], res[False]
+            fused_layer._CHAIN[0] = fused_layer._CHAIN_BWD[0] = True
 
     def close(a, b, name):
         scale = float(b.abs().max()) + 1e-12
         err = float((a - b).abs().max())
         assert err <= 2e-2 * scale, (name, err, scale)
-    close(ya, yb, "y")
-    close(dxa, dxb, "dx")
-    assert ga.keys() == gb.keys()
-    for n in ga:
-        if n.endswith("linear_k.bias"):
-            continue                                      # exactly zero in exact arithmetic: round-off only
-        close(ga[n], gb[n], n)
+    yb, dxb, gb = res["off"]
+    for mode in ("both", "forward"):
+        ya, dxa, ga = res[mode]
+        close(ya, yb, mode + " y")
+        close(dxa, dxb, mode + " dx")
+        assert ga.keys() == gb.keys()
+        for n in ga:
+            if n.endswith("linear_k.bias"):
+                continue                                      # exactly zero in exact arithmetic: round-off only
+            close(ga[n], gb[n], mode + " " + n)
