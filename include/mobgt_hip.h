@@ -245,6 +245,8 @@ int mobgt_node_index(const void* x, int x_dtype, int64_t xs_g, int64_t xs_n, con
 int mobgt_skinny_linear_fwd(const float* x, const float* w, const float* b, float* y, int G, int K, int V, void* stream);
 int mobgt_skinny_linear_bwd(const float* dy, const float* x, const float* w, float* dx, float* dw, float* db, int G, int K,
                             int V, void* stream);
+/* dx = dy @ w alone, on the matrix cores (csrc/skinny.hip): dx [G,K] f32 must be ZERO on entry (f32 atomics); K % 16 == 0. */
+int mobgt_skinny_linear_dx(const float* dy, const float* w, float* dx, int G, int K, int V, void* stream);
 
 /* Rows of a bf16 matrix a [*, ld] gathered and transposed in one pass: out_rows [R, C] = a[rows[j], 0:C] and
  * out_t [C, R] = out_rows^T (the operands of the "rows only" last GCN layer, modelGNN.py:38-44 restricted to the
@@ -307,6 +309,12 @@ int mobgt_colsum(const void* g, float* out, int64_t R, int C, int act_dtype, voi
  * f32 atomics into dw/db, which the caller zero-initialises (or pre-loads with a gradient to accumulate into). */
 int mobgt_linear_wgrad(const void* g, int64_t ldg, const void* x, int64_t ldx, float* dw, int64_t ldw, float* db,
                        int64_t R, int M, int N, int act_dtype, void* stream);
+/* ... with f32 operands and the activation derivative m(.) of mobgt_small_gemm_f32_act applied to g and / or x while they
+ * are loaded (g_mask / x_mask: the activation's output, the operand's layout; either may be null).  db_of_x: db is [N] and
+ * receives the column sums of the (masked) x instead of g. */
+int mobgt_linear_wgrad_masked(const float* g, int64_t ldg, const float* x, int64_t ldx, const float* g_mask, const float* x_mask,
+                              float m_pos, float m_neg, float m_zero, float* dw, int64_t ldw, float* db, int db_of_x, int64_t R,
+                              int M, int N, void* stream);
 /* The same for n <= 32 independent Linear layers over the same R rows in ONE launch (host arrays of n entries each;
  * db may be NULL, or hold NULL entries): the weight gradients of all encoder layers of a backward pass. */
 int mobgt_linear_wgrad_group(int n, const void* const* g, const int64_t* ldg, const void* const* x, const int64_t* ldx,
@@ -372,6 +380,15 @@ int mobgt_adamw_flat(float* params, const float* grads, float* exp_avg, float* e
  * product's operand -- no cast launch). */
 int mobgt_small_gemm_f32(const float* a, int64_t lda, const float* b, int64_t ldb, int b_is_nk, const float* bias, void* c,
                          int64_t ldc, int c_dtype, int M, int N, int K, void* stream);
+/* The same product with what surrounds it in GraphConvolution / FuseEmbeddings (modelGNN.py:66-72, model_fqandtoyo.py:452-455):
+ *   epilogue (leaky != 0):   c = dropout(leaky_relu(acc + bias, slope))  -- dropout mask as mobgt_bias_act_fwd (salt);
+ *   prologue (a_mask given): a[r][k] *= m(a_mask[r][k]),  m(y) = y > 0 ? m_pos : (y < 0 ? m_neg : m_zero)
+ *                            -- the derivative of that activation, taken from its OUTPUT y, applied to an incoming
+ *                            gradient while it is loaded (a_mask has a's layout and lda). */
+int mobgt_small_gemm_f32_act(const float* a, int64_t lda, const float* a_mask, float m_pos, float m_neg, float m_zero,
+                             const float* b, int64_t ldb, int b_is_nk, const float* bias, int leaky, float slope,
+                             float dropout_p, uint64_t seed, const uint64_t* seed_dev, uint32_t salt, void* c, int64_t ldc,
+                             int c_dtype, int M, int N, int K, void* stream);
 
 /* GraphConvolution's adjacency product `torch.spmm(adj, support)` (graphormer/modelGNN.py:38-44) for a normalised
  * adjacency held as CSR (csrc/spmm.hip) -- the form that exists at P = 100 000 POIs (BASELINE configs[4]).
@@ -387,7 +404,7 @@ int mobgt_small_gemm_f32(const float* a, int64_t lda, const float* b, int64_t ld
  * both norms.  wq_next / bq_next / qkv_next null for the last layer.  Dropout masks: those of mobgt_dropout_add_ln_fwd
  * with salt1 / salt2.  (C, F) in {(192, 1024), (256, 1024)}. */
 /* bf16 weight [N,K] row-major -> MFMA operand order (chain.hip): the 16 bytes W[16g + j][32s + 8q .. +7] go to byte offset
- * ((g K/32 + s) 64 + j + 16q) * 16, so that a wave's B-operand load is one contiguous KB.  n <= 32 jobs in one launch;
+ * ((g K/32 + s) 64 + j + 16q) * 16, so that a wave's B-operand load is one contiguous KB.  n <= 96 jobs in one launch;
  * N % 16 == 0, K % 32 == 0.  transposed[i] != 0: src is [K,N] row-major and its TRANSPOSE is packed (the operand of
  * dX = dY W); transposed may be null. */
 int mobgt_pack_mfma_b(int n, const void* const* src, void* const* dst, const int* N, const int* K, const int* transposed,

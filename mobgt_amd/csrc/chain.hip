@@ -357,12 +357,14 @@ __global__ __launch_bounds__(NT) void layer_chain_fwd_kernel(const ChainParams p
     STAMP_DUMP();
 }
 
+constexpr int PACK_MAX = 96;                 // 12 layers x (4 forward + 3 transposed) weights in one launch
+
 struct PackJobs {
-    const uint16_t* src[32];
-    uint16_t* dst[32];
-    int N[32], K[32];
-    int transposed[32];                      // src is [K][N] row-major: pack its transpose
-    int first_block[33];                     // job i owns blocks [first_block[i], first_block[i + 1]); 256 pieces per block
+    const uint16_t* src[PACK_MAX];
+    uint16_t* dst[PACK_MAX];
+    int N[PACK_MAX], K[PACK_MAX];
+    int transposed[PACK_MAX];                      // src is [K][N] row-major: pack its transpose
+    int first_block[PACK_MAX + 1];                     // job i owns blocks [first_block[i], first_block[i + 1]); 256 pieces per block
 };
 
 // dst[((g S + s) 64 + l) * 8 + e] = src[(16 g + (l & 15)) K + 32 s + 8 (l >> 4) + e]: 16-byte pieces, writes contiguous
@@ -601,7 +603,7 @@ int launch_bwd(const ChainBwdParams& p, hipStream_t st) {
 extern "C" int mobgt_pack_mfma_b(int n, const void* const* src, void* const* dst, const int* N, const int* K,
                                  const int* transposed, void* stream) {
     if (n <= 0) return 0;
-    if (n > 32) return MOBGT_EBADDIM;
+    if (n > PACK_MAX) return MOBGT_EBADDIM;
     PackJobs jobs = {};
     int blocks = 0;
     for (int i = 0; i < n; ++i) {

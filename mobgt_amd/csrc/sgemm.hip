@@ -22,7 +22,22 @@ struct SgemmParams {
     void* C; int64_t ldc;
     int c_bf16;                                  // store the result as bf16 (the adjacency product's operand) instead of f32
     int M, N, K;
+    // optional epilogue: y = dropout(leaky_relu(acc + bias)) -- GraphConvolution / FuseEmbeddings' activation (modelGNN.py:
+    // 66-72, model_fqandtoyo.py:452-455) without a launch of its own; the mask is mobgt_bias_act_fwd's
+    int act;
+    float slope;
+    uint32_t thr;
+    float inv_keep;
+    uint64_t seed;
+    const uint64_t* seed_dev;
+    uint32_t salt;
+    // optional prologue on A: A[r][k] *= m(amask[r][k]), m(y) = y > 0 ? mpos : (y < 0 ? mneg : mzero) -- the derivative
+    // of that activation applied to an incoming gradient while it is loaded (amask = the activation's OUTPUT, ld = lda)
+    const float* amask;
+    float mpos, mneg, mzero;
 };
+
+__device__ __forceinline__ float act_mask(float y, float pos, float neg, float zer) { return y > 0.f ? pos : (y < 0.f ? neg : zer); }
 
 // 4 consecutive k-values of one row, zero past `kmax`; VEC: the row is 16-byte aligned and fully inside
 template <bool VEC>
@@ -36,7 +51,8 @@ __device__ __forceinline__ float4 load_k4(const float* row, int k, int kmax) {
     return v;
 }
 
-template <int NB, bool B_NK, bool VEC>
+// EXT: the activation epilogue / masked-A prologue are compiled in (the plain product keeps its register count and speed)
+template <int NB, bool B_NK, bool VEC, bool EXT = false>
 __global__ __launch_bounds__(64) void sgemm_kernel(const SgemmParams p) {
     const int lane = threadIdx.x;
     const int i = lane & 15, kq = lane >> 4;
@@ -61,14 +77,24 @@ __global__ __launch_bounds__(64) void sgemm_kernel(const SgemmParams p) {
         return v;
     };
 
-    float4 a_cur = load_k4<VEC>(arow, 4 * kq, p.K), a_nxt = a_cur;
+    const float* mrow = (EXT && p.amask) ? p.amask + (int64_t)min(m0 + i, p.M - 1) * p.lda : nullptr;
+    auto load_a = [&](int k) -> float4 {
+        float4 v = load_k4<VEC>(arow, k, p.K);
+        if (EXT && mrow) {
+            const float4 y = load_k4<VEC>(mrow, k, p.K);
+            v.x *= act_mask(y.x, p.mpos, p.mneg, p.mzero); v.y *= act_mask(y.y, p.mpos, p.mneg, p.mzero);
+            v.z *= act_mask(y.z, p.mpos, p.mneg, p.mzero); v.w *= act_mask(y.w, p.mpos, p.mneg, p.mzero);
+        }
+        return v;
+    };
+    float4 a_cur = load_a(4 * kq), a_nxt = a_cur;
     float4 b_cur[NB], b_nxt[NB];
 #pragma unroll
     for (int b = 0; b < NB; ++b) { b_cur[b] = load_b(b, 4 * kq); b_nxt[b] = b_cur[b]; }
     for (int k0 = 0; k0 < p.K; k0 += 16) {
         const int kn = k0 + 16 + 4 * kq;
         if (k0 + 16 < p.K) {
-            a_nxt = load_k4<VEC>(arow, kn, p.K);
+            a_nxt = load_a(kn);
 #pragma unroll
             for (int b = 0; b < NB; ++b) b_nxt[b] = load_b(b, kn);
         }
@@ -84,6 +110,7 @@ __global__ __launch_bounds__(64) void sgemm_kernel(const SgemmParams p) {
         for (int b = 0; b < NB; ++b) b_cur[b] = b_nxt[b];
     }
     // register v of lane (j = lane & 15, q = lane >> 4) is output row 4q + v, column j of its 16x16 block
+    const uint64_t seed = (EXT && p.thr) ? p.seed + (p.seed_dev ? *p.seed_dev : 0ull) : 0ull;
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
         const int c = n0 + 16 * b + i;
@@ -93,44 +120,83 @@ __global__ __launch_bounds__(64) void sgemm_kernel(const SgemmParams p) {
         for (int v = 0; v < 4; ++v) {
             const int r = m0 + 4 * kq + v;
             if (r < p.M) {
-                if (p.c_bf16) reinterpret_cast<bf16_t*>(p.C)[(int64_t)r * p.ldc + c] = (bf16_t)(acc[b][v] + bv);
-                else reinterpret_cast<float*>(p.C)[(int64_t)r * p.ldc + c] = acc[b][v] + bv;
+                float o = acc[b][v] + bv;
+                if (EXT && p.act) {
+                    o = o > 0.f ? o : p.slope * o;
+                    if (p.thr) {
+                        const uint32_t rowh = dropout_row_hash(seed, (uint32_t)r ^ p.salt);
+                        o = dropout_bits16(seed, rowh, (uint32_t)c) >= p.thr ? o * p.inv_keep : 0.f;
+                    }
+                }
+                if (p.c_bf16) reinterpret_cast<bf16_t*>(p.C)[(int64_t)r * p.ldc + c] = (bf16_t)o;
+                else reinterpret_cast<float*>(p.C)[(int64_t)r * p.ldc + c] = o;
             }
         }
     }
 }
 
-template <int NB>
-int launch(const SgemmParams& p, bool b_nk, bool vec, hipStream_t st) {
+template <int NB, bool EXT>
+int launch_x(const SgemmParams& p, bool b_nk, bool vec, hipStream_t st) {
     const int tiles = ((p.M + 15) / 16) * ((p.N + 16 * NB - 1) / (16 * NB));
     const dim3 grid(tiles), block(64);
     if (b_nk) {
-        if (vec) hipLaunchKernelGGL((sgemm_kernel<NB, true, true>), grid, block, 0, st, p);
-        else hipLaunchKernelGGL((sgemm_kernel<NB, true, false>), grid, block, 0, st, p);
+        if (vec) hipLaunchKernelGGL((sgemm_kernel<NB, true, true, EXT>), grid, block, 0, st, p);
+        else hipLaunchKernelGGL((sgemm_kernel<NB, true, false, EXT>), grid, block, 0, st, p);
     } else {
-        if (vec) hipLaunchKernelGGL((sgemm_kernel<NB, false, true>), grid, block, 0, st, p);
-        else hipLaunchKernelGGL((sgemm_kernel<NB, false, false>), grid, block, 0, st, p);
+        if (vec) hipLaunchKernelGGL((sgemm_kernel<NB, false, true, EXT>), grid, block, 0, st, p);
+        else hipLaunchKernelGGL((sgemm_kernel<NB, false, false, EXT>), grid, block, 0, st, p);
     }
     return (int)hipGetLastError();
 }
 
+template <int NB>
+int launch(const SgemmParams& p, bool b_nk, bool vec, hipStream_t st) {
+    return (p.act || p.amask) ? launch_x<NB, true>(p, b_nk, vec, st) : launch_x<NB, false>(p, b_nk, vec, st);
+}
+
+}  // namespace
+
+namespace {
+int run(SgemmParams& p, int b_is_nk, int c_dtype, void* stream) {
+    if (p.M <= 0 || p.N <= 0 || p.K <= 0) return MOBGT_EBADDIM;
+    if (c_dtype != MOBGT_F32 && c_dtype != MOBGT_BF16) return MOBGT_EDTYPE;
+    if ((((uintptr_t)p.A | (uintptr_t)p.B | (uintptr_t)p.amask) & 3) || ((uintptr_t)p.C & (c_dtype == MOBGT_F32 ? 3 : 1))) return MOBGT_EALIGN;
+    p.c_bf16 = c_dtype == MOBGT_BF16;
+    // float4 operand loads: every row 16-byte aligned and K a whole number of 16-deep steps
+    const bool vec = (p.K % 16 == 0) && (p.lda % 4 == 0) && ((((uintptr_t)p.A | (uintptr_t)p.amask) & 15) == 0) &&
+                     (!b_is_nk || ((p.ldb % 4 == 0) && (((uintptr_t)p.B & 15) == 0)));
+    hipStream_t st = (hipStream_t)stream;
+    // columns per wave: wide tiles reuse the A operand, narrow ones give more waves; aim at >= ~256 waves
+    const int rows16 = (p.M + 15) / 16;
+    int nb = 4;
+    while (nb > 1 && (rows16 * ((p.N + 16 * nb - 1) / (16 * nb)) < 256 || p.N <= 16 * (nb / 2))) nb >>= 1;
+    if (nb == 4) return launch<4>(p, b_is_nk != 0, vec, st);
+    if (nb == 2) return launch<2>(p, b_is_nk != 0, vec, st);
+    return launch<1>(p, b_is_nk != 0, vec, st);
+}
 }  // namespace
 
 extern "C" int mobgt_small_gemm_f32(const float* a, int64_t lda, const float* b, int64_t ldb, int b_is_nk, const float* bias,
                                     void* c, int64_t ldc, int c_dtype, int M, int N, int K, void* stream) {
-    if (M <= 0 || N <= 0 || K <= 0) return MOBGT_EBADDIM;
-    if (c_dtype != MOBGT_F32 && c_dtype != MOBGT_BF16) return MOBGT_EDTYPE;
-    if ((((uintptr_t)a | (uintptr_t)b) & 3) || ((uintptr_t)c & (c_dtype == MOBGT_F32 ? 3 : 1))) return MOBGT_EALIGN;
-    SgemmParams p = {a, lda, b, ldb, bias, c, ldc, c_dtype == MOBGT_BF16, M, N, K};
-    // float4 operand loads: every row 16-byte aligned and K a whole number of 16-deep steps
-    const bool vec = (K % 16 == 0) && (lda % 4 == 0) && (((uintptr_t)a & 15) == 0) &&
-                     (!b_is_nk || ((ldb % 4 == 0) && (((uintptr_t)b & 15) == 0)));
-    hipStream_t st = (hipStream_t)stream;
-    // columns per wave: wide tiles reuse the A operand, narrow ones give more waves; aim at >= ~256 waves
-    const int rows16 = (M + 15) / 16;
-    int nb = 4;
-    while (nb > 1 && (rows16 * ((N + 16 * nb - 1) / (16 * nb)) < 256 || N <= 16 * (nb / 2))) nb >>= 1;
-    if (nb == 4) return launch<4>(p, b_is_nk != 0, vec, st);
-    if (nb == 2) return launch<2>(p, b_is_nk != 0, vec, st);
-    return launch<1>(p, b_is_nk != 0, vec, st);
+    SgemmParams p = {};
+    p.A = a; p.lda = lda; p.B = b; p.ldb = ldb; p.bias = bias; p.C = c; p.ldc = ldc; p.M = M; p.N = N; p.K = K;
+    return run(p, b_is_nk, c_dtype, stream);
+}
+
+/* The same product with the activation that follows it (epilogue) and / or the derivative of the activation that precedes
+ * it (prologue on A) -- see include/mobgt_hip.h. */
+extern "C" int mobgt_small_gemm_f32_act(const float* a, int64_t lda, const float* a_mask, float m_pos, float m_neg, float m_zero,
+                                        const float* b, int64_t ldb, int b_is_nk, const float* bias, int leaky, float slope,
+                                        float dropout_p, uint64_t seed, const uint64_t* seed_dev, uint32_t salt, void* c,
+                                        int64_t ldc, int c_dtype, int M, int N, int K, void* stream) {
+    SgemmParams p = {};
+    p.A = a; p.lda = lda; p.B = b; p.ldb = ldb; p.bias = bias; p.C = c; p.ldc = ldc; p.M = M; p.N = N; p.K = K;
+    p.amask = a_mask; p.mpos = m_pos; p.mneg = m_neg; p.mzero = m_zero;
+    p.act = leaky; p.slope = slope;
+    if (leaky && dropout_p > 0.f) {
+        p.thr = dropout_threshold(dropout_p);
+        p.inv_keep = 1.f / (1.f - (float)p.thr / 65536.f);
+        p.seed = seed; p.seed_dev = seed_dev; p.salt = salt;
+    }
+    return run(p, b_is_nk, c_dtype, stream);
 }

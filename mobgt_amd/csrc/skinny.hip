@@ -125,6 +125,49 @@ __global__ __launch_bounds__(256) void skinny_dx_kernel(const float* __restrict_
     }
 }
 
+// dx on the matrix cores: a workgroup owns 64 rows v of W (staged in LDS by 16-byte coalesced loads -- the 4-byte column
+// walks of skinny_dx_kernel ran at a quarter of the L1 rate) and multiplies dy[:, v-chunk] (16 x 64) into it with
+// v_mfma_f32_16x16x4_f32 (G <= 16 rows is exactly one tile); the [16 x K] partial leaves as f32 atomics (dx zeroed by
+// the caller).  123 workgroups at V = 7857: W is read once, at full rate.
+constexpr int DXM_ROWS = 64;
+typedef __attribute__((ext_vector_type(4))) float f32x4_;
+
+__global__ __launch_bounds__(256) void skinny_dx_mfma_kernel(const float* __restrict__ dy, const float* __restrict__ w,
+                                                             float* __restrict__ dx, int G, int K, int V) {
+    extern __shared__ __attribute__((aligned(16))) float smem_dx[];
+    const int LD = K + 16 - (K & 63) + ((K & 63) > 16 ? 64 : 0);          // LD % 64 == 16: the 4 k of an operand on different banks
+    float* wl = smem_dx;                                                  // [DXM_ROWS][LD]
+    float* dyl = wl + DXM_ROWS * LD;                                      // [16][DXM_ROWS + 4]
+    const int v0 = blockIdx.x * DXM_ROWS;
+    const int nv = min(DXM_ROWS, V - v0);
+    const int kq4 = K >> 2;
+    for (int e = threadIdx.x; e < DXM_ROWS * kq4; e += 256) {
+        const int r = e / kq4, c = (e % kq4) * 4;
+        float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (r < nv) t = *reinterpret_cast<const float4*>(w + (int64_t)(v0 + r) * K + c);
+        *reinterpret_cast<float4*>(wl + r * LD + c) = t;
+    }
+    for (int e = threadIdx.x; e < GMAX * DXM_ROWS; e += 256) {
+        const int g = e / DXM_ROWS, r = e % DXM_ROWS;
+        dyl[g * (DXM_ROWS + 4) + r] = (g < G && r < nv) ? dy[(int64_t)g * V + v0 + r] : 0.f;
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = lane & 15, q = lane >> 4;
+    float a[DXM_ROWS / 4];
+#pragma unroll
+    for (int s_ = 0; s_ < DXM_ROWS / 4; ++s_) a[s_] = dyl[j * (DXM_ROWS + 4) + 4 * s_ + q];
+    for (int t = wave; t < (K >> 4); t += 4) {
+        f32x4_ acc = {0.f, 0.f, 0.f, 0.f};
+        const float* bp = wl + q * LD + 16 * t + j;
+#pragma unroll
+        for (int s_ = 0; s_ < DXM_ROWS / 4; ++s_) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s_], bp[4 * s_ * LD], acc, 0, 0, 0);
+#pragma unroll
+        for (int v = 0; v < 4; ++v)
+            if (4 * q + v < G) atomicAdd(&dx[(int64_t)(4 * q + v) * K + 16 * t + j], acc[v]);
+    }
+}
+
 constexpr int DW_ROWS = 16;                  // rows v of dW per workgroup
 
 __global__ __launch_bounds__(256) void skinny_dw_kernel(const float* __restrict__ dy, const float* __restrict__ x,
@@ -197,5 +240,19 @@ extern "C" int mobgt_skinny_linear_bwd(const float* dy, const float* x, const fl
         hipLaunchKernelGGL(skinny_dx_kernel, dim3((K + DX_KB - 1) / DX_KB, DX_SPLIT), dim3(256), 0, st, dy, w, dx, G, K, V);
     }
     if (dw) hipLaunchKernelGGL(skinny_dw_kernel, dim3((V + DW_ROWS - 1) / DW_ROWS), dim3(256), 0, st, dy, x, dw, db, G, K, V);
+    return (int)hipGetLastError();
+}
+
+/* dx = dy @ w only (dx must be ZERO on entry: f32 atomics), on the matrix cores; K % 16 == 0. */
+extern "C" int mobgt_skinny_linear_dx(const float* dy, const float* w, float* dx, int G, int K, int V, void* stream) {
+    const int rc = check_dims(G, K, V);
+    if (rc) return rc;
+    if ((K & 15) || ((uintptr_t)w & 15)) return MOBGT_EBADDIM;
+    const int LD = K + 16 - (K & 63) + ((K & 63) > 16 ? 64 : 0);
+    const size_t lds = ((size_t)DXM_ROWS * LD + GMAX * (DXM_ROWS + 4)) * sizeof(float);
+    if (lds > 152 * 1024) return MOBGT_EBADDIM;
+    int rc2 = (int)hipFuncSetAttribute((const void*)skinny_dx_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (rc2) return rc2;
+    hipLaunchKernelGGL(skinny_dx_mfma_kernel, dim3((V + DXM_ROWS - 1) / DXM_ROWS), dim3(256), lds, (hipStream_t)stream, dy, w, dx, G, K, V);
     return (int)hipGetLastError();
 }

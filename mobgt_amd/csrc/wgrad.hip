@@ -35,6 +35,13 @@ struct WgradParams {
     int tiles_n;
     int k_per_wg;                        // multiple of NWAVE * KSTEP when gridDim.y > 1
     int in_f32;                          // operands are f32 in memory (ldg / ldx in f32 elements), rounded to bf16 here
+    // f32 operands only: g (x) is multiplied by m(gmask) (m(xmask)) while loading, m(y) = y > 0 ? mpos : (y < 0 ? mneg :
+    // mzero) -- the derivative of dropout(leaky_relu(.)) from its output, so that the gradient at the pre-activation never
+    // exists as a tensor.  A mask has its operand's layout and leading dimension.
+    const float* gmask;
+    const float* xmask;
+    float mpos, mneg, mzero;
+    int db_x;                            // db [N] += column sums of (the masked) x instead of g
 };
 
 __device__ __forceinline__ void split_pairs(const uint32_t (&d)[8], bf16x8& even, bf16x8& odd) {
@@ -58,8 +65,31 @@ __device__ __forceinline__ uint32_t pack_pair(const float* p) {
     return __builtin_bit_cast(uint32_t, o);
 }
 
+__device__ __forceinline__ uint32_t pack_pair_masked(const float* p, const float* m, float pos, float neg, float zer) {
+    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+    const float2 v = *reinterpret_cast<const float2*>(p);
+    const float2 y = *reinterpret_cast<const float2*>(m);
+    bf16x2 o;
+    o[0] = (bf16_t)(v.x * (y.x > 0.f ? pos : (y.x < 0.f ? neg : zer)));
+    o[1] = (bf16_t)(v.y * (y.y > 0.f ? pos : (y.y < 0.f ? neg : zer)));
+    return __builtin_bit_cast(uint32_t, o);
+}
+
 struct Slab {
     uint32_t g[8], x[8];
+    template <bool F32>
+    __device__ __forceinline__ void load_masked(const WgradParams& p, const void* gp, const void* xp, const float* gm, const float* xm,
+                                                int r0, int k1, bool m_ok, bool n_ok) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int r = r0 + j;
+            const bool ok = r < k1;
+            const float* gq = reinterpret_cast<const float*>(gp) + (int64_t)r * p.ldg;
+            const float* xq = reinterpret_cast<const float*>(xp) + (int64_t)r * p.ldx;
+            g[j] = !(ok && m_ok) ? 0u : (gm ? pack_pair_masked(gq, gm + (int64_t)r * p.ldg, p.mpos, p.mneg, p.mzero) : pack_pair(gq));
+            x[j] = !(ok && n_ok) ? 0u : (xm ? pack_pair_masked(xq, xm + (int64_t)r * p.ldx, p.mpos, p.mneg, p.mzero) : pack_pair(xq));
+        }
+    }
     // gp / xp point at this lane's column pair of row 0 (as bf16 elements, or -- F32 -- as f32 elements)
     template <bool F32>
     __device__ __forceinline__ void load(const void* gp, const void* xp, int64_t ldg, int64_t ldx, int r0, int k1,
@@ -95,7 +125,7 @@ __device__ __forceinline__ void wgrad_body(const WgradParams& p, const int tile,
     const int m0 = (tile / p.tiles_n) * TILE, n0 = (tile % p.tiles_n) * TILE;
     const int k0 = split * p.k_per_wg;
     const int k1 = min(p.R, k0 + p.k_per_wg);
-    const bool want_db = p.db != nullptr && n0 == 0;
+    const bool want_db = p.db != nullptr && (p.db_x ? m0 == 0 : n0 == 0);
     const bool m_ok = m0 + 2 * i < p.M, n_ok = n0 + 2 * i < p.N;      // M, N even: a pair is in or out together
     const void* gp = F32 ? (const void*)(reinterpret_cast<const float*>(p.g) + m0 + 2 * i) : (const void*)(p.g + m0 + 2 * i);
     const void* xp = F32 ? (const void*)(reinterpret_cast<const float*>(p.x) + n0 + 2 * i) : (const void*)(p.x + n0 + 2 * i);
@@ -107,12 +137,19 @@ __device__ __forceinline__ void wgrad_body(const WgradParams& p, const int tile,
         for (int b = 0; b < 2; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
     float se = 0.f, so = 0.f;
 
+    const bool masked = F32 && (p.gmask || p.xmask);
+    const float* gm = masked && p.gmask ? p.gmask + m0 + 2 * i : nullptr;
+    const float* xm = masked && p.xmask ? p.xmask + n0 + 2 * i : nullptr;
+    auto fetch = [&](Slab& s_, int r0_) {
+        if (masked) s_.template load_masked<F32>(p, gp, xp, gm, xm, r0_, k1, m_ok, n_ok);
+        else s_.template load<F32>(gp, xp, p.ldg, p.ldx, r0_, k1, m_ok, n_ok);
+    };
     int kb = k0 + wave * KSTEP;
     Slab cur, nxt;
-    if (kb < k1) cur.template load<F32>(gp, xp, p.ldg, p.ldx, kb + 8 * kq, k1, m_ok, n_ok);
+    if (kb < k1) fetch(cur, kb + 8 * kq);
     for (; kb < k1; kb += NWAVE * KSTEP) {
         const int kn = kb + NWAVE * KSTEP;
-        if (kn < k1) nxt.template load<F32>(gp, xp, p.ldg, p.ldx, kn + 8 * kq, k1, m_ok, n_ok);      // in flight during the MFMAs
+        if (kn < k1) fetch(nxt, kn + 8 * kq);      // in flight during the MFMAs
         bf16x8 ge, go, xe, xo;
         split_pairs(cur.g, ge, go);
         split_pairs(cur.x, xe, xo);
@@ -122,7 +159,10 @@ __device__ __forceinline__ void wgrad_body(const WgradParams& p, const int tile,
         acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(go, xo, acc[1][1], 0, 0, 0);
         if (want_db) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) { se += bf16_lo(cur.g[j]); so += bf16_hi(cur.g[j]); }
+            for (int j = 0; j < 8; ++j) {
+                const uint32_t d = p.db_x ? cur.x[j] : cur.g[j];
+                se += bf16_lo(d); so += bf16_hi(d);
+            }
         }
         if (kn < k1) cur = nxt;
     }
@@ -164,11 +204,12 @@ __device__ __forceinline__ void wgrad_body(const WgradParams& p, const int tile,
     }
     {
         const int e = threadIdx.x;
-        if (want_db && e < TILE && m0 + e < p.M) {
+        const int c0 = p.db_x ? n0 : m0;
+        if (want_db && e < TILE && c0 + e < (p.db_x ? p.N : p.M)) {
             float t = 0.f;
 #pragma unroll
             for (int w = 0; w < NWAVE; ++w) t += colpart[w][e];
-            if (nsplit > 1) atomicAdd(p.db + m0 + e, t); else p.db[m0 + e] += t;
+            if (nsplit > 1) atomicAdd(p.db + c0 + e, t); else p.db[c0 + e] += t;
         }
     }
 }
@@ -220,6 +261,7 @@ int fill_problem(WgradParams& p, const void* g, int64_t ldg, const void* x, int6
     if (R <= 0 || M <= 0 || N <= 0 || (M & 1) || (N & 1) || (ldg & 1) || (ldx & 1) || R > 0x7fffffff) return MOBGT_EBADDIM;
     if (((uintptr_t)g & (in_f32 ? 7 : 3)) || ((uintptr_t)x & (in_f32 ? 7 : 3))) return MOBGT_EALIGN;
     p.in_f32 = in_f32;
+    p.gmask = p.xmask = nullptr; p.mpos = p.mneg = p.mzero = 1.f; p.db_x = 0;
     p.g = reinterpret_cast<const uint16_t*>(g); p.ldg = ldg;
     p.x = reinterpret_cast<const uint16_t*>(x); p.ldx = ldx;
     p.dw = dw; p.ldw = ldw; p.db = db;
@@ -305,6 +347,23 @@ extern "C" int mobgt_linear_wgrad(const void* g, int64_t ldg, const void* x, int
     const int rc = fill_problem(p, g, ldg, x, ldx, dw, ldw, db, R, M, N, nwave == 8 ? 512 : 256, &tiles, &splits,
                                 act_dtype == MOBGT_F32, nwave);
     if (rc) return rc;
+    if (nwave == 8) hipLaunchKernelGGL(wgrad_kernel<8>, dim3(tiles, splits), dim3(8 * 64), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL(wgrad_kernel<16>, dim3(tiles, splits), dim3(16 * 64), 0, (hipStream_t)stream, p);
+    return (int)hipGetLastError();
+}
+
+/* f32 operands with the derivative of dropout(leaky_relu(.)) applied to g and / or x while loading (see WgradParams). */
+extern "C" int mobgt_linear_wgrad_masked(const float* g, int64_t ldg, const float* x, int64_t ldx, const float* g_mask,
+                                         const float* x_mask, float m_pos, float m_neg, float m_zero, float* dw, int64_t ldw,
+                                         float* db, int db_of_x, int64_t R, int M, int N, void* stream) {
+    if (R == 0) return 0;
+    if (((uintptr_t)g_mask | (uintptr_t)x_mask) & 7) return MOBGT_EALIGN;
+    WgradParams p;
+    int tiles = 0, splits = 0;
+    const int nwave = R <= SHORT_R ? 8 : 16;
+    const int rc = fill_problem(p, g, ldg, x, ldx, dw, ldw, db, R, M, N, nwave == 8 ? 512 : 256, &tiles, &splits, 1, nwave);
+    if (rc) return rc;
+    p.gmask = g_mask; p.xmask = x_mask; p.mpos = m_pos; p.mneg = m_neg; p.mzero = m_zero; p.db_x = db_of_x;
     if (nwave == 8) hipLaunchKernelGGL(wgrad_kernel<8>, dim3(tiles, splits), dim3(8 * 64), 0, (hipStream_t)stream, p);
     else hipLaunchKernelGGL(wgrad_kernel<16>, dim3(tiles, splits), dim3(16 * 64), 0, (hipStream_t)stream, p);
     return (int)hipGetLastError();

@@ -245,7 +245,7 @@ def refresh_shadows(layers):
 
 def pack_layer_weights(layers):
     """MFMA-operand-order copies of the fused fq layers' bf16 GEMM weights (csrc/chain.hip reads a wave's B operand as one
-    contiguous KB), all layers in one launch (one per 32 weights): `layer._packed` = (wqkv, wo, w1, w2) packed for the
+    contiguous KB), all layers in one launch (up to 96 weights): `layer._packed` = (wqkv, wo, w1, w2) packed for the
     forward chain and, when gradients are enabled, `layer._packed_t` = (w2^T, w1^T, wo^T) for the backward chain."""
     import ctypes
     from . import fused_layer, _lib
@@ -278,8 +278,8 @@ def pack_layer_weights(layers):
             for d, i in zip(pt, (6, 4, 2)):          # dX = dY W: W [K = out, N = in] is the operand, packed as [N][K]
                 jobs.append((sh[i], d, sh[i].shape[1], sh[i].shape[0], 1))
             layer._packed_t_fresh = True
-    for o in range(0, len(jobs), 32):
-        part = jobs[o:o + 32]
+    for o in range(0, len(jobs), 96):
+        part = jobs[o:o + 96]
         n = len(part)
         vp, ci = ctypes.c_void_p, ctypes.c_int
         _lib.check(_lib.lib().mobgt_pack_mfma_b(n, (vp * n)(*[j[0].data_ptr() for j in part]), (vp * n)(*[j[1].data_ptr() for j in part]),

@@ -206,6 +206,43 @@ class _MaskConvFn(torch.autograd.Function):
         return dx, dW, db, None
 
 
+class _ConvActFn(torch.autograd.Function):
+    """A hidden GraphConvolution with its activation, y = dropout(leaky_relu((adj @ x) W + b)) (modelGNN.py:38-44, 66-72),
+    without a launch for the activation either way: forward, bias + LeakyReLU + dropout are the small GEMM's epilogue;
+    backward, the derivative m(y) is applied to the incoming gradient while the weight-gradient kernel and the data-gradient
+    GEMM load it (bias gradient = column sums of the masked gradient, from the weight-gradient kernel).
+    `ax`: the precomputed adj @ x of the first layer (x constant), else `adj` is a MaskAdj and adj @ x is a mask GEMM."""
+
+    @staticmethod
+    def forward(ctx, x, ax, weight, bias, adj, slope, p_drop, seed, seed_dev, salt):
+        from . import ops
+        t = ax if ax is not None else mask_gemm(adj, x)                 # [P, in] f32
+        y = ops.small_gemm(t, weight, bias, leaky=slope, drop=(p_drop, seed, seed_dev, salt) if p_drop > 0 else None)
+        ctx.save_for_backward(t, weight, y)
+        ctx.adj = adj if ax is None else None
+        ctx.mv = ops.act_mask_values(slope, p_drop)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        from . import ops
+        t, weight, y = ctx.saved_tensors
+        g = g.contiguous()
+        db = ops.zeros_f32((weight.shape[1],), g.device)
+        dW = ops.linear_wgrad_masked(t, g, x_mask=y, mask_vals=ctx.mv, db=db, db_of_x=True)      # t^T (g * m(y)), db = colsum
+        dx = None
+        if ctx.adj is not None and ctx.needs_input_grad[0]:
+            dt = ops.small_gemm(g, weight, b_is_nk=True, a_mask=(y, *ctx.mv))                    # (g * m(y)) W^T  [P, in]
+            dx = mask_gemm(ctx.adj, dt, transposed=True)                                         # adj^T @ dt
+        return dx, None, dW, db, None, None, None, None, None, None
+
+
+def _conv_act_ok(t_cols, weight, bias):
+    return (os.environ.get("MOBGT_NO_CONV_ACT") != "1" and weight.is_cuda and weight.dtype == torch.float32 and bias is not None
+            and weight.shape[0] == t_cols and t_cols <= 64 and t_cols % 2 == 0 and weight.shape[1] % 2 == 0
+            and weight.is_contiguous())
+
+
 def _mask_conv_ok(x, weight):
     return x.is_cuda and x.shape[1] in (16, 32, 48, 64) and weight.shape[0] == x.shape[1] and weight.shape[0] <= 64
 
@@ -416,10 +453,22 @@ class GCN(nn.Module):
         if x.is_cuda and all(g.out_features % 4 == 0 and g.bias is not None for g in self.gcn[:-1]):
             from . import ops
             for i in range(n_hidden):       # bias + LeakyReLU (+ the dropout in front of the last layer) in one launch
-                h = self.gcn[i](x, adj, adj_x if i == 0 else None, adj_t, bias=False, mask_adj=mask_adj)
-                x = ops.bias_act(h, self.gcn[i].bias, self.leaky_relu.negative_slope,
-                                 self.dropout if i == n_hidden - 1 else 0.0, self.training,
-                                 0x2000 + self.gcn[-1].out_features)
+                p_drop = self.dropout if (i == n_hidden - 1 and self.training) else 0.0
+                salt = 0x2000 + self.gcn[-1].out_features
+                gc = self.gcn[i]
+                pre = adj_x if i == 0 else None
+                # (bitmask-adjacency layers only: that is the bf16 configuration, whose weight gradients already round
+                # their operands to bf16; the first layer's f32 product and the f32 configuration keep their exact path)
+                if (pre is None and mask_adj is not None and not isinstance(adj, CsrAdj) and x.dtype == torch.float32
+                        and _mask_conv_ok(x, gc.weight) and _conv_act_ok(x.shape[1], gc.weight, gc.bias)):
+                    # ... and no launch for the activation at all: GEMM epilogue forward, masked operand loads backward
+                    seed, seed_dev = ops.dropout_seed(p_drop)
+                    with torch.autocast(device_type="cuda", enabled=False):
+                        x = _ConvActFn.apply(None if pre is not None else x, pre, gc.weight, gc.bias, mask_adj,
+                                             float(self.leaky_relu.negative_slope), float(p_drop), seed, seed_dev, salt)
+                    continue
+                h = gc(x, adj, pre, adj_t, bias=False, mask_adj=mask_adj)
+                x = ops.bias_act(h, gc.bias, self.leaky_relu.negative_slope, p_drop, self.training, salt)
         else:
             for i in range(n_hidden):
                 x = self.leaky_relu(self.gcn[i](x, adj, adj_x if i == 0 else None, adj_t, mask_adj=mask_adj))

@@ -91,9 +91,9 @@ class FuseEmbeddings(nn.Module):
 
     def forward(self, user_embed, poi_embed):
         x = torch.cat((user_embed, poi_embed), user_embed.dim() - 1)
-        if x.is_cuda:
-            return self.leaky_relu(ops.linear_splitk(x.float(), self.fuse_embed.weight, self.fuse_embed.bias,
-                                                     getattr(self, "bf16_wgrad", False)))
+        if x.is_cuda:           # Linear + LeakyReLU in one launch (the activation rides in the GEMM's epilogue)
+            return ops.linear_splitk(x.float(), self.fuse_embed.weight, self.fuse_embed.bias, getattr(self, "bf16_wgrad", False),
+                                     slope=self.leaky_relu.negative_slope)
         return self.leaky_relu(self.fuse_embed(x))
 
 
@@ -337,9 +337,9 @@ class Graphormer(nn.Module):
         catemb = self.poi_cat_model(self.C_X, self.C_A, self.C_AX, adj_t=self.C_A_T)                                    # :1237
         # [poi ; time] and the category row, gathered for every position in one pass each
         pt = ops.embed_gather_concat([poidist, self.time_embed_model_48.weight], [poi_idx, time_idx], padding_idx=[None, 0])
-        f2 = self.embed_fuse_model2.leaky_relu(
-            ops.linear_splitk(pt, self.embed_fuse_model2.fuse_embed.weight, self.embed_fuse_model2.fuse_embed.bias,
-                              self.act_dtype == torch.bfloat16))                                             # :1268
+        f2 = ops.linear_splitk(pt, self.embed_fuse_model2.fuse_embed.weight, self.embed_fuse_model2.fuse_embed.bias,
+                               self.act_dtype == torch.bfloat16,
+                               slope=self.embed_fuse_model2.leaky_relu.negative_slope)                       # :1268
         ops.trace_nan("pt", pt)
         ops.trace_nan("f2", f2)
         ce = ops.embed_gather_sum([catemb], [cat_idx])

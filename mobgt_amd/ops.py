@@ -473,7 +473,11 @@ class _SkinnyLinearFn(torch.autograd.Function):
         V = w.shape[0]
         dy = dy.contiguous()
         dx = None
-        if ctx.needs_input_grad[0]:
+        dx_mfma = ctx.needs_input_grad[0] and not ctx.all_hip and K % 16 == 0 and K <= 512 and not os.environ.get("MOBGT_SKINNY_DX_LIB")
+        if dx_mfma:     # one pass over W at the full L1 rate (the library's 16x16 tiles: 26 us at V = 7857, K = 448)
+            dx = zeros_f32((G, K), x.device)
+            check(_lib.lib().mobgt_skinny_linear_dx(_p(dy), _p(w), _p(dx), G, K, V, _stream()), "mobgt_skinny_linear_dx")
+        elif ctx.needs_input_grad[0]:
             dx = torch.empty_like(x) if ctx.all_hip else dy @ w
         dw = None
         if ctx.needs_input_grad[1]:
@@ -641,33 +645,51 @@ def gradient_tail_loss(logits, targets, alpha=0.25, target_offset=0):
 # ------------------------------------------------------------------------------- small linear layers
 class _LinearSplitKFn(torch.autograd.Function):
     """y = x W^T + b for a few hundred rows: the weight gradient g^T x has K = rows and a tiny output, which a
-    plain GEMM call maps onto one workgroup (measured 60-150 us in fp32); evaluate it split-K as a batched GEMM."""
+    plain GEMM call maps onto one workgroup (measured 60-150 us in fp32); evaluate it split-K as a batched GEMM.
+    `slope`: y = leaky_relu(x W^T + b, slope) (FuseEmbeddings, model_fqandtoyo.py:452-455) -- the activation in the GEMM's
+    epilogue, its derivative applied to the incoming gradient while the two backward products load it."""
 
     @staticmethod
-    def forward(ctx, x, w, b, bf16_wgrad):
-        ctx.save_for_backward(x, w)
+    def forward(ctx, x, w, b, bf16_wgrad, slope):
         ctx.bf16_wgrad = bf16_wgrad
+        ctx.slope = slope
         if _small_linear(x, w) & 1:
-            return small_gemm(x, w, b, True)
-        return torch.addmm(b, x, w.t())
+            y = small_gemm(x, w, b, True, leaky=slope)
+        else:
+            y = torch.addmm(b, x, w.t())
+            if slope is not None:
+                y = torch.nn.functional.leaky_relu(y, slope)
+        ctx.save_for_backward(x, w, y if slope is not None else None)
+        return y
 
     @staticmethod
     def backward(ctx, g):
-        x, w = ctx.saved_tensors
+        x, w, y = ctx.saved_tensors
         g = g.contiguous()
         R = x.shape[0]
-        if (ctx.bf16_wgrad and g.dtype == torch.float32 and x.dtype == torch.float32 and g.shape[1] % 2 == 0
-                and x.shape[1] % 2 == 0 and R <= 4096 and g.data_ptr() % 8 == 0 and x.data_ptr() % 8 == 0):
+        hip_wgrad = (ctx.bf16_wgrad and g.dtype == torch.float32 and x.dtype == torch.float32 and g.shape[1] % 2 == 0
+                     and x.shape[1] % 2 == 0 and R <= 4096 and g.data_ptr() % 8 == 0 and x.data_ptr() % 8 == 0)
+        if y is not None:
+            mv = act_mask_values(ctx.slope, 0.0)
+            # (the head's 16 rows: a few hundred rows and the data gradient's [K,N] operand walk make csrc/sgemm.hip slower
+            # than the library GEMM + one elementwise launch -- measured 10.4 vs 9.6 us at R = 608)
+            if (hip_wgrad and R <= 64 and small_gemm_ok(g, w) and y.is_contiguous() and y.data_ptr() % 8 == 0
+                    and max(w.shape) <= 512):
+                db = zeros_f32((g.shape[1],), g.device)
+                dw = linear_wgrad_masked(g, x, g_mask=y, mask_vals=mv, db=db)
+                return small_gemm(g, w, a_mask=(y, *mv)), dw, db, None, None
+            g = torch.ops.aten.leaky_relu_backward(g, y, ctx.slope, True)      # (from the activation's result)
+        if hip_wgrad:
             # bf16 configuration: weight AND bias gradient from the split-K MFMA kernel (operands rounded to bf16 while
             # loading); the library's split-K path took 27-31 us + a reduce for these 224-wide layers
             dw, db = linear_wgrad(g, x, with_bias=True)
-            return (small_gemm(g, w) if _small_linear(g, w) & 2 else g @ w), dw, db, None
+            return (small_gemm(g, w) if _small_linear(g, w) & 2 else g @ w), dw, db, None, None
         s = max((c for c in (16, 8, 4, 2) if R % c == 0 and R // c >= 16), default=1)
         if s > 1:
             dw = torch.bmm(g.view(s, R // s, -1).transpose(1, 2), x.view(s, R // s, -1)).sum(0)
         else:
             dw = g.t() @ x
-        return g @ w, dw, colsum(g), None
+        return g @ w, dw, colsum(g), None, None
 
 
 _SMALL_LINEAR = int(__import__("os").environ.get("MOBGT_SMALL_LINEAR", "1"))
@@ -682,9 +704,10 @@ def _small_linear(x, w):
     return _SMALL_LINEAR if x.shape[0] <= 64 else (_SMALL_LINEAR & 1)     # data gradient: the head's 16 rows only
 
 
-def linear_splitk(x, weight, bias, bf16_wgrad=False):
+def linear_splitk(x, weight, bias, bf16_wgrad=False, slope=None):
+    """F.linear(x, weight, bias) [-> leaky_relu(slope)] for a few hundred rows (see _LinearSplitKFn)."""
     shape = x.shape
-    y = _LinearSplitKFn.apply(x.reshape(-1, shape[-1]).contiguous(), weight, bias, bf16_wgrad)
+    y = _LinearSplitKFn.apply(x.reshape(-1, shape[-1]).contiguous(), weight, bias, bf16_wgrad, slope)
     return y.view(*shape[:-1], weight.shape[0])
 
 
@@ -904,9 +927,11 @@ def assemble_tokens(nf, real, add, token, pe0, p_pos, p_in, training, salts=(0x1
 
 
 # ------------------------------------------------------------------- small f32 GEMMs (GCN / fuse / head)
-def small_gemm(a, b, bias=None, b_is_nk=False, out=None, out_dtype=torch.float32):
+def small_gemm(a, b, bias=None, b_is_nk=False, out=None, out_dtype=torch.float32, leaky=None, drop=None, a_mask=None):
     """a [M,K] @ (b.T if b_is_nk else b) (+ bias) -> f32 [M,N] on csrc/sgemm.hip (one wave per 16-row tile, f32 MFMA).
-    No autograd.  Operands may be row-strided views (unit column stride)."""
+    No autograd.  Operands may be row-strided views (unit column stride).
+    `leaky` (slope): LeakyReLU on the way out; `drop` = (p, seed, seed_dev, salt): then dropout (mobgt_bias_act_fwd's mask).
+    `a_mask` = (y, pos, neg, zero): a is multiplied elementwise by m(y) while it is loaded (y: a's shape and row stride)."""
     _require_cuda(a, b)
     assert a.dtype == torch.float32 and b.dtype == torch.float32 and a.dim() == 2 and b.dim() == 2
     assert a.stride(1) == 1 and b.stride(1) == 1
@@ -916,9 +941,46 @@ def small_gemm(a, b, bias=None, b_is_nk=False, out=None, out_dtype=torch.float32
     if bias is not None:
         assert bias.dtype == torch.float32 and bias.numel() == N and bias.is_contiguous()
     c = out if out is not None else torch.empty(M, N, dtype=out_dtype, device=a.device)
-    check(_lib.lib().mobgt_small_gemm_f32(_p(a), a.stride(0), _p(b), b.stride(0), int(b_is_nk), _p(bias), _p(c), c.stride(0),
-                                          _DT[c.dtype], M, N, K, _stream()), "mobgt_small_gemm_f32")
+    if leaky is None and a_mask is None:
+        check(_lib.lib().mobgt_small_gemm_f32(_p(a), a.stride(0), _p(b), b.stride(0), int(b_is_nk), _p(bias), _p(c), c.stride(0),
+                                              _DT[c.dtype], M, N, K, _stream()), "mobgt_small_gemm_f32")
+        return c
+    y, pos, neg, zer = a_mask if a_mask is not None else (None, 1.0, 1.0, 1.0)
+    if y is not None:
+        assert y.dtype == torch.float32 and y.shape == a.shape and y.stride(1) == 1 and y.stride(0) == a.stride(0)
+    p_drop, seed, seed_dev, salt = drop if drop is not None else (0.0, 0, None, 0)
+    check(_lib.lib().mobgt_small_gemm_f32_act(_p(a), a.stride(0), _p(y), float(pos), float(neg), float(zer), _p(b), b.stride(0),
+                                              int(b_is_nk), _p(bias), int(leaky is not None), float(leaky or 0.0), float(p_drop),
+                                              int(seed), _p(seed_dev), int(salt) & 0xFFFFFFFF, _p(c), c.stride(0), _DT[c.dtype],
+                                              M, N, K, _stream()), "mobgt_small_gemm_f32_act")
     return c
+
+
+def act_mask_values(slope, p_drop):
+    """(pos, neg, zero) of m(y) = d dropout(leaky_relu(u)) / du read off the OUTPUT y: a kept positive is scaled by 1/keep, a
+    kept negative by slope/keep; y == 0 is a dropped element (gradient 0) when dropout is on, else LeakyReLU'(0) = slope."""
+    if p_drop and p_drop > 0.0:
+        thr = int(p_drop * 65536.0 + 0.5)
+        ik = 1.0 / (1.0 - thr / 65536.0)
+        return ik, slope * ik, 0.0
+    return 1.0, slope, slope
+
+
+def linear_wgrad_masked(g, x, g_mask=None, x_mask=None, mask_vals=(1.0, 1.0, 1.0), db=None, db_of_x=False, dw=None):
+    """dW [M,N] = (g * m(g_mask))^T (x * m(x_mask)) for f32 row-major g [R,M], x [R,N] (operands rounded to bf16 while
+    loading, f32 accumulate); db (zero-initialised f32): += column sums of the masked g ([M]) or, `db_of_x`, x ([N])."""
+    _require_cuda(g, x)
+    R, M = g.shape
+    N = x.shape[1]
+    assert g.dtype == torch.float32 and x.dtype == torch.float32 and g.stride(1) == 1 and x.stride(1) == 1
+    for m, t in ((g_mask, g), (x_mask, x)):
+        assert m is None or (m.dtype == torch.float32 and m.shape == t.shape and m.stride() == t.stride())
+    if dw is None:
+        dw = zeros_f32((M, N), g.device)
+    check(_lib.lib().mobgt_linear_wgrad_masked(_p(g), g.stride(0), _p(x), x.stride(0), _p(g_mask), _p(x_mask), float(mask_vals[0]),
+                                               float(mask_vals[1]), float(mask_vals[2]), _p(dw), N, _p(db), int(db_of_x), R, M, N,
+                                               _stream()), "mobgt_linear_wgrad_masked")
+    return dw
 
 
 def small_gemm_ok(a, b):

@@ -545,3 +545,27 @@ def test_layer_chain_kernel_matches_the_separate_launches(C, G, T, p):
             if n.endswith("linear_k.bias"):
                 continue                                      # exactly zero in exact arithmetic: round-off only
             close(ga[n], gb[n], mode + " " + n)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("R,K,N", [(608, 160, 160), (37, 192, 192), (16, 448, 224)])
+def test_linear_with_leaky_epilogue_matches_torch(R, K, N):
+    """ops.linear_splitk(..., slope): FuseEmbeddings' Linear + LeakyReLU (model_fqandtoyo.py:452-455) with the activation in
+    the GEMM's epilogue and its derivative applied to the gradient inside the two backward products, against torch fp32
+    (weight gradient: operands rounded to bf16 while loading, hence the tolerance)."""
+    from mobgt_amd import ops
+    torch.manual_seed(R)
+    x = torch.randn(R, K, device=DEV, requires_grad=True)
+    lin = torch.nn.Linear(K, N).to(DEV)
+    gy = torch.randn(R, N, device=DEV)
+    y = ops.linear_splitk(x, lin.weight, lin.bias, True, slope=0.2)
+    y.backward(gy)
+    got = (y.detach().clone(), x.grad.clone(), lin.weight.grad.clone(), lin.bias.grad.clone())
+    x.grad = None
+    lin.zero_grad()
+    yr = torch.nn.functional.leaky_relu(lin(x), 0.2)
+    yr.backward(gy)
+    torch.testing.assert_close(got[0], yr.detach(), rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(got[1], x.grad, rtol=1e-4, atol=1e-4)
+    for u, v in ((got[2], lin.weight.grad), (got[3], lin.bias.grad)):
+        assert float((u - v).abs().max()) <= 1e-2 * float(v.abs().max())

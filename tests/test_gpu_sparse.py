@@ -196,3 +196,41 @@ def test_small_gcn_single_launch_matches_the_layer_by_layer_path(n, k0, training
         net(x, a, ax, adj_t=a_t).backward(gout)
     s.synchronize()
     assert all(torch.isfinite(p.grad).all() for p in net.parameters())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("training", [True, False])
+def test_gcn_hidden_layers_without_activation_launches_match_the_bias_act_path(training, monkeypatch):
+    """modelGNN._ConvActFn (bias + LeakyReLU + dropout in the small GEMM's epilogue; their derivative applied while the
+    backward's weight-gradient kernel and data-gradient GEMM load the incoming gradient) against the same GCN with
+    separate mobgt_bias_act launches: same dropout masks, so values and every gradient agree (bf16 operand rounding of
+    the weight gradients aside)."""
+    from mobgt_amd.modelGNN import GCN, MaskAdj
+    dev = torch.device("cuda")
+    P = 1000
+    g = torch.Generator().manual_seed(7)
+    a01 = (torch.rand(P, P, generator=g) < 0.02)
+    a01 = (a01 | a01.t()).float()
+    a01.fill_diagonal_(0)
+    madj = MaskAdj(*[t.to(dev) for t in MaskAdj.from_dense01(a01.numpy())])
+    deg = a01.sum(1) + 1
+    a = ((a01 + torch.eye(P)) / deg[:, None]).to(dev)
+    x = torch.rand(P, 32, generator=g).to(dev)
+    ax = (a @ x).contiguous()
+    net = GCN(32, [16, 64], 128, dropout=0.3).to(dev).train(training)
+    gout = torch.randn(P, 128, generator=g).to(dev)
+
+    def run(fused):
+        monkeypatch.setenv("MOBGT_NO_CONV_ACT", "0" if fused else "1")
+        torch.manual_seed(5)
+        net.zero_grad()
+        out = net(x, a.bfloat16(), ax, adj_t=a.t().contiguous().bfloat16(), mask_adj=madj)
+        out.backward(gout)
+        return out.detach().clone(), [p.grad.clone() for p in net.parameters()]
+
+    o1, g1 = run(True)
+    o0, g0 = run(False)
+    torch.testing.assert_close(o1, o0, rtol=2e-2, atol=2e-2 * float(o0.abs().max()))
+    for (name, _), u, v in zip(net.named_parameters(), g1, g0):
+        scale = float(v.abs().max()) + 1e-12
+        assert float((u - v).abs().max()) <= 2e-2 * scale, (name, float((u - v).abs().max()), scale)
