@@ -125,46 +125,68 @@ __global__ __launch_bounds__(256) void skinny_dx_kernel(const float* __restrict_
     }
 }
 
-// dx on the matrix cores: a workgroup owns 64 rows v of W (staged in LDS by 16-byte coalesced loads -- the 4-byte column
-// walks of skinny_dx_kernel ran at a quarter of the L1 rate) and multiplies dy[:, v-chunk] (16 x 64) into it with
-// v_mfma_f32_16x16x4_f32 (G <= 16 rows is exactly one tile); the [16 x K] partial leaves as f32 atomics (dx zeroed by
-// the caller).  123 workgroups at V = 7857: W is read once, at full rate.
-constexpr int DXM_ROWS = 64;
+// dx on the matrix cores.  dx[g][k] = sum_v dy[g][v] W[v][k]: G <= 16 rows is exactly one v_mfma_f32_16x16x4_f32 tile, and
+// the f32 MFMA rate (256 FLOP/clk/CU) wants >= ~100 CUs on it.  A workgroup owns ONE 16-column tile of dx and an eighth of
+// V: 8 x K/16 workgroups (224 at K = 448), each streaming its [V/8 x 16] column block of W by 16-byte loads (a 64-byte run
+// per weight row: the load unit runs at full rate, unlike the 4-byte column walks of skinny_dx_kernel) through LDS; its four
+// waves split the rows, meet in LDS, and 256 f32 atomics per workgroup fold the eight V-slices (dx zeroed by the caller).
+// A row-owning layout (64 rows x all K per workgroup) was tried first: 123 x 7168 atomics made it 18 us.
+constexpr int DXM_ROWS = 256;                // rows of W per staged chunk
+constexpr int DXM_VSPLIT = 8;
 typedef __attribute__((ext_vector_type(4))) float f32x4_;
 
 __global__ __launch_bounds__(256) void skinny_dx_mfma_kernel(const float* __restrict__ dy, const float* __restrict__ w,
                                                              float* __restrict__ dx, int G, int K, int V) {
-    extern __shared__ __attribute__((aligned(16))) float smem_dx[];
-    const int LD = K + 16 - (K & 63) + ((K & 63) > 16 ? 64 : 0);          // LD % 64 == 16: the 4 k of an operand on different banks
-    float* wl = smem_dx;                                                  // [DXM_ROWS][LD]
-    float* dyl = wl + DXM_ROWS * LD;                                      // [16][DXM_ROWS + 4]
-    const int v0 = blockIdx.x * DXM_ROWS;
-    const int nv = min(DXM_ROWS, V - v0);
-    const int kq4 = K >> 2;
-    for (int e = threadIdx.x; e < DXM_ROWS * kq4; e += 256) {
-        const int r = e / kq4, c = (e % kq4) * 4;
-        float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (r < nv) t = *reinterpret_cast<const float4*>(w + (int64_t)(v0 + r) * K + c);
-        *reinterpret_cast<float4*>(wl + r * LD + c) = t;
-    }
-    for (int e = threadIdx.x; e < GMAX * DXM_ROWS; e += 256) {
-        const int g = e / DXM_ROWS, r = e % DXM_ROWS;
-        dyl[g * (DXM_ROWS + 4) + r] = (g < G && r < nv) ? dy[(int64_t)g * V + v0 + r] : 0.f;
-    }
-    __syncthreads();
+    __shared__ __attribute__((aligned(16))) float wl[DXM_ROWS][16];            // W[v0 + r][k0 .. k0 + 15]
+    __shared__ __attribute__((aligned(16))) float dyl[GMAX][DXM_ROWS + 4];     // dy[g][v0 + r]
+    __shared__ float part[4][16][17];
+    const int k0 = blockIdx.x * 16;
+    const int vper = ((V + DXM_VSPLIT - 1) / DXM_VSPLIT + 3) & ~3;
+    const int vbeg = blockIdx.y * vper, vend = min(V, vbeg + vper);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int j = lane & 15, q = lane >> 4;
-    float a[DXM_ROWS / 4];
+    f32x4_ acc = {0.f, 0.f, 0.f, 0.f};
+    float4 wr[DXM_ROWS * 4 / 256];
+    float dr[GMAX * DXM_ROWS / 256];
+    auto fetch = [&](int v0) {                                                 // the next chunk rides in registers during the MFMAs
+        const int nv = min(DXM_ROWS, vend - v0);
 #pragma unroll
-    for (int s_ = 0; s_ < DXM_ROWS / 4; ++s_) a[s_] = dyl[j * (DXM_ROWS + 4) + 4 * s_ + q];
-    for (int t = wave; t < (K >> 4); t += 4) {
-        f32x4_ acc = {0.f, 0.f, 0.f, 0.f};
-        const float* bp = wl + q * LD + 16 * t + j;
+        for (int u = 0; u < DXM_ROWS * 4 / 256; ++u) {                         // 4 lanes x 16 bytes per weight row
+            const int e = threadIdx.x + 256 * u, r = e >> 2, c = (e & 3) * 4;
+            wr[u] = r < nv ? *reinterpret_cast<const float4*>(w + (int64_t)(v0 + r) * K + k0 + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
 #pragma unroll
-        for (int s_ = 0; s_ < DXM_ROWS / 4; ++s_) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s_], bp[4 * s_ * LD], acc, 0, 0, 0);
+        for (int u = 0; u < GMAX * DXM_ROWS / 256; ++u) {
+            const int e = threadIdx.x + 256 * u, g = e / DXM_ROWS, r = e % DXM_ROWS;
+            dr[u] = (g < G && r < nv) ? dy[(int64_t)g * V + v0 + r] : 0.f;
+        }
+    };
+    if (vbeg < vend) fetch(vbeg);
+    for (int v0 = vbeg; v0 < vend; v0 += DXM_ROWS) {
+        __syncthreads();
 #pragma unroll
-        for (int v = 0; v < 4; ++v)
-            if (4 * q + v < G) atomicAdd(&dx[(int64_t)(4 * q + v) * K + 16 * t + j], acc[v]);
+        for (int u = 0; u < DXM_ROWS * 4 / 256; ++u) {
+            const int e = threadIdx.x + 256 * u;
+            *reinterpret_cast<float4*>(&wl[e >> 2][(e & 3) * 4]) = wr[u];
+        }
+#pragma unroll
+        for (int u = 0; u < GMAX * DXM_ROWS / 256; ++u) {
+            const int e = threadIdx.x + 256 * u;
+            dyl[e / DXM_ROWS][e % DXM_ROWS] = dr[u];
+        }
+        __syncthreads();
+        if (v0 + DXM_ROWS < vend) fetch(v0 + DXM_ROWS);
+        const int rb = wave * (DXM_ROWS / 4);                                   // this wave's 64 rows of the chunk
+#pragma unroll
+        for (int s_ = 0; s_ < DXM_ROWS / 16; ++s_)
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(dyl[j][rb + 4 * s_ + q], wl[rb + 4 * s_ + q][j], acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int v = 0; v < 4; ++v) part[wave][4 * q + v][j] = acc[v];
+    __syncthreads();
+    {
+        const int g = threadIdx.x >> 4, c = threadIdx.x & 15;
+        if (g < G) atomicAdd(&dx[(int64_t)g * K + k0 + c], part[0][g][c] + part[1][g][c] + part[2][g][c] + part[3][g][c]);
     }
 }
 
@@ -248,11 +270,6 @@ extern "C" int mobgt_skinny_linear_dx(const float* dy, const float* w, float* dx
     const int rc = check_dims(G, K, V);
     if (rc) return rc;
     if ((K & 15) || ((uintptr_t)w & 15)) return MOBGT_EBADDIM;
-    const int LD = K + 16 - (K & 63) + ((K & 63) > 16 ? 64 : 0);
-    const size_t lds = ((size_t)DXM_ROWS * LD + GMAX * (DXM_ROWS + 4)) * sizeof(float);
-    if (lds > 152 * 1024) return MOBGT_EBADDIM;
-    int rc2 = (int)hipFuncSetAttribute((const void*)skinny_dx_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (rc2) return rc2;
-    hipLaunchKernelGGL(skinny_dx_mfma_kernel, dim3((V + DXM_ROWS - 1) / DXM_ROWS), dim3(256), lds, (hipStream_t)stream, dy, w, dx, G, K, V);
+    hipLaunchKernelGGL(skinny_dx_mfma_kernel, dim3(K / 16, DXM_VSPLIT), dim3(256), 0, (hipStream_t)stream, dy, w, dx, G, K, V);
     return (int)hipGetLastError();
 }
