@@ -167,6 +167,7 @@ class _PackFn(torch.autograd.Function):
         ctx.pack = pack
         ctx.src_shape = src.shape
         ctx.src_dtype = src.dtype
+        ctx.set_materialize_grads(False)
         return zeros_f32((1,), src.device)
 
     @staticmethod
@@ -212,6 +213,7 @@ class _BuildBiasFn(torch.autograd.Function):
                                           _p(pack.bias), _p(pack.bias_t), *args, _DT[pack.dtype], _stream()),
               "mobgt_build_bias")
         ctx.pack, ctx.args = pack, args
+        ctx.set_materialize_grads(False)          # the token carries no gradient: no zero-fill launch to materialise one
         ctx.idx = (attn_bias, rel_pos, poi_pos, edge_input if has_edge else None)
         ctx.shapes = (rel_table.shape, None if poi_table is None else poi_table.shape,
                       hop_table.shape if has_edge else None, vdist.shape)
