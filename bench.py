@@ -150,6 +150,43 @@ def time_attention(G, H, T, d, io_dtype, bias_dtype, reps=50, p_drop=0.1, backwa
 
 
 # ------------------------------------------------------------------------------------------ CPU baseline
+def chain_fwd_bytes(R, C, F):
+    """Algorithmic HBM bytes of one mobgt_layer_chain_fwd launch: the layer's bf16 weights once (Wo, W1, W2, next Wqkv),
+    a (bf16) and x (f32) in; x1, x2, out (f32), z, out_a, qkv (bf16), u, h (bf16) out."""
+    weights = 2 * (C * C + 2 * F * C + 3 * C * C)
+    return weights + R * (2 * C + 4 * C) + R * (3 * 4 * C + 2 * 2 * C + 2 * 3 * C + 2 * 2 * F)
+
+
+def time_chain(R, C, F, reps=50, p_drop=0.1):
+    """Seconds per launch of mobgt_layer_chain_fwd (csrc/chain.hip) on R rows, weights packed as the model packs them."""
+    import ctypes
+    from mobgt_amd import _lib
+    from mobgt_amd.ops import _p, _stream
+    lib = _lib.lib()
+    bf = lambda *s: (torch.randn(*s, device="cuda") * 0.05).bfloat16()
+
+    def pack(w):
+        out = torch.empty_like(w)
+        vp, ci = ctypes.c_void_p, ctypes.c_int
+        _lib.check(lib.mobgt_pack_mfma_b(1, (vp * 1)(w.data_ptr()), (vp * 1)(out.data_ptr()), (ci * 1)(w.shape[0]),
+                                         (ci * 1)(w.shape[1]), None, _stream()), "mobgt_pack_mfma_b")
+        return out
+    a, x = bf(R, C), torch.randn(R, C, device="cuda")
+    wo, w1, w2, wq = pack(bf(C, C)), pack(bf(F, C)), pack(bf(C, F)), pack(bf(3 * C, C))
+    bo, b1, b2, bq = bf(C), bf(F), bf(C), bf(3 * C)
+    ln = [torch.ones(C, device="cuda"), torch.zeros(C, device="cuda"), torch.ones(C, device="cuda"), torch.zeros(C, device="cuda")]
+    x1, x2, out = (torch.empty(R, C, device="cuda") for _ in range(3))
+    z, out_a, u, h, qkv = bf(R, C), bf(R, C), bf(R, F), bf(R, F), bf(R, 3 * C)
+    st = torch.empty(4, R, device="cuda")
+
+    def fn():
+        _lib.check(lib.mobgt_layer_chain_fwd(_p(a), _p(x), _p(wo), _p(bo), _p(ln[0]), _p(ln[1]), _p(w1), _p(b1), _p(w2), _p(b2),
+                                             _p(ln[2]), _p(ln[3]), _p(wq), _p(bq), _p(x1), _p(z), _p(u), _p(h), _p(x2), _p(out),
+                                             _p(out_a), _p(qkv), _p(st[0]), _p(st[1]), _p(st[2]), _p(st[3]), R, C, F, p_drop, 1, None,
+                                             9, 10, _stream()), "mobgt_layer_chain_fwd")
+    return _graph_time(fn, reps)
+
+
 def usable_cores():
     n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     try:                                            # cgroup v2 CPU quota of the container, if any
@@ -384,6 +421,19 @@ def main():
         roof = dict(kernel="attn_fwd_kernel<DROP=true>", bound="hbm", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s",
                     frac=achieved / HBM_PEAK_GBS, traffic=(pmc.get("c5_fwd_drop_bf16", {}).get("traffic_bytes") if name == "big" and bf16 else None),
                     bytes_per_launch=tot_b / len(used), avg_launch_us=tot_t / len(used) * 1e6)
+        # ... and the kernel that now takes the largest share of the timed step: the row-local chain of an encoder layer
+        roofc = None
+        F = m["ffn_dim"]
+        if io_dt == torch.bfloat16 and (C, F) in ((192, 1024), (256, 1024)) and not args.unfused:
+            rows = sorted(set(g * t for g, t in used))
+            durc = {r: time_chain(r, C, F, reps=50 if r < 4096 else 10, p_drop=m["dropout_rate"]) for r in rows}
+            tb = sum(chain_fwd_bytes(g * t, C, F) for g, t in used)
+            tt_ = sum(durc[g * t] for g, t in used)
+            roofc = dict(kernel="layer_chain_fwd_kernel", bound="hbm", achieved=tb / tt_ / 1e9, peak=HBM_PEAK_GBS, unit="GB/s",
+                         frac=tb / tt_ / 1e9 / HBM_PEAK_GBS, traffic=None, bytes_per_launch=tb / len(used),
+                         avg_launch_us=tt_ / len(used) * 1e6,
+                         note="not HBM-bound at this size: ceil(R/16) workgroups each stream the layer's 1.08 MB of packed "
+                              "weights through one CU's L1 (64 B/clk); see DESIGN.md 3.5")
         roof5 = roof5b = None
         if not args.no_stress:
             # the same kernels at the HBM-roofline stress shape (BASELINE configs[4]: G16 x 784 nodes, C 256, d 32), training
@@ -422,7 +472,8 @@ def main():
                                      "accumulate_softmax_layernorm_adamw": "f32"}},
             "final_loss": loss, "ms_per_step_chunks": [round(c, 4) for c in chunk_ms],
             "rccl_ranks": rccl_ranks, "allreduce_exposed_us": exposed_us,
-            "parity": parity, "roofline": roof, "roofline_stress": roof5, "roofline_stress_bwd": roof5b, "cpu_baseline": cpu,
+            "parity": parity, "roofline": roof, "roofline_chain": roofc, "roofline_stress": roof5, "roofline_stress_bwd": roof5b,
+            "cpu_baseline": cpu,
         }
         print(json.dumps(out))
     if world > 1:
