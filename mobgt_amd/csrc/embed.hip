@@ -94,6 +94,53 @@ __global__ __launch_bounds__(256) void gather_concat_kernel(const ConcatParams p
     }
 }
 
+
+// Several gathers of one position list in ONE launch, each with its own destination (model_fqandtoyo.py:1259-1298: the
+// [poi ; time] rows, the category rows and the additive degree / frequency / positional rows were three launches forward
+// and three backward): job t copies table_t[idx_t[r], :] to buf_t[r, coff_t : coff_t + W_t] (zeros where idx < 0), or ADDS it
+// there when accum_t (jobs run in order inside the wave that owns row r: a sum of tables is a copy followed by adds).
+// Backward: buf_t is the gradient buffer, scattered with f32 atomics into d_table_t (rows equal to skip_t excepted).
+constexpr int MAXJ = 8;
+struct MultiParams {
+    const float* tables[MAXJ];
+    float* d_tables[MAXJ];
+    const void* idx[MAXJ];
+    int64_t skip[MAXJ];
+    int width[MAXJ], coff[MAXJ], accum[MAXJ];
+    float* buf[MAXJ];
+    int64_t ld[MAXJ];
+    int n;
+    int64_t R;
+};
+
+template <typename TI, bool BWD>
+__global__ __launch_bounds__(256) void gather_multi_kernel(const MultiParams p) {
+    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= p.R) return;
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int t = 0; t < MAXJ; ++t) {
+        if (t >= p.n) break;
+        const int64_t row = (int64_t)reinterpret_cast<const TI*>(p.idx[t])[r];
+        const int W = p.width[t];
+        float* b = p.buf[t] + r * p.ld[t] + p.coff[t];
+        if (!BWD) {
+            for (int c = lane * 4; c < W; c += 256) {
+                float4 v = row >= 0 ? *reinterpret_cast<const float4*>(p.tables[t] + row * W + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+                if (p.accum[t]) {
+                    const float4 o = *reinterpret_cast<const float4*>(b + c);
+                    v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+                }
+                *reinterpret_cast<float4*>(b + c) = v;
+            }
+        } else {
+            if (row < 0 || row == p.skip[t] || !p.d_tables[t]) continue;
+            float* dst = p.d_tables[t] + row * W;
+            for (int c = lane; c < W; c += 64) atomicAdd(dst + c, b[c]);
+        }
+    }
+}
+
 // Run-length variant (C <= 512): a wave walks RUN_ROWS consecutive rows and keeps the sum of a run of EQUAL indices
 // in registers, flushing with atomics only when the index changes.  Along a trajectory the degree rows (and the
 // shared frequency row) repeat for long stretches: at G*N = 12.5 k rows the plain kernel spent 120 us per call
@@ -395,5 +442,36 @@ extern "C" int mobgt_gather_rows_t(const void* a, int64_t ld, const int64_t* row
     hipLaunchKernelGGL(gather_rows_t_kernel, dim3((C + 63) / 64, (R + 63) / 64), dim3(256), 0, (hipStream_t)stream,
                        reinterpret_cast<const uint16_t*>(a), ld, rows, reinterpret_cast<uint16_t*>(out_rows),
                        reinterpret_cast<uint16_t*>(out_t), R, C);
+    return (int)hipGetLastError();
+}
+
+/* n <= 8 gathers of one position list in one launch (see gather_multi_kernel); backward != 0: the scatter-add of the
+ * gradient buffers into d_tables (null entries skipped). */
+extern "C" int mobgt_embed_gather_multi(int n, const float* const* tables, float* const* d_tables, const void* const* idx,
+                                        const int64_t* skip, const int* width, const int* coff, const int* accum,
+                                        float* const* buf, const int64_t* ld, int64_t R, int idx_dtype, int backward,
+                                        void* stream) {
+    if (n < 1 || n > MAXJ) return MOBGT_EBADDIM;
+    if (R <= 0) return 0;
+    MultiParams p = {};
+    for (int t = 0; t < n; ++t) {
+        if (width[t] <= 0 || (width[t] & 3) || (coff[t] & 3) || (ld[t] & 3) || !buf[t]) return MOBGT_EBADDIM;
+        if (((uintptr_t)buf[t] | (uintptr_t)(tables ? tables[t] : nullptr)) & 15) return MOBGT_EALIGN;
+        p.tables[t] = tables ? tables[t] : nullptr;
+        p.d_tables[t] = d_tables ? d_tables[t] : nullptr;
+        p.idx[t] = idx[t]; p.skip[t] = skip ? skip[t] : -1;
+        p.width[t] = width[t]; p.coff[t] = coff[t]; p.accum[t] = accum ? accum[t] : 0;
+        p.buf[t] = buf[t]; p.ld[t] = ld[t];
+    }
+    p.n = n; p.R = R;
+    const dim3 grid((unsigned)((R + 3) / 4)), block(256);
+    hipStream_t st = (hipStream_t)stream;
+    if (idx_dtype == MOBGT_I64) {
+        if (backward) hipLaunchKernelGGL((gather_multi_kernel<int64_t, true>), grid, block, 0, st, p);
+        else hipLaunchKernelGGL((gather_multi_kernel<int64_t, false>), grid, block, 0, st, p);
+    } else if (idx_dtype == MOBGT_I32) {
+        if (backward) hipLaunchKernelGGL((gather_multi_kernel<int32_t, true>), grid, block, 0, st, p);
+        else hipLaunchKernelGGL((gather_multi_kernel<int32_t, false>), grid, block, 0, st, p);
+    } else return MOBGT_EDTYPE;
     return (int)hipGetLastError();
 }

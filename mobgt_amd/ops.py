@@ -601,6 +601,82 @@ def embed_gather_concat(tables, indices, padding_idx=None):
     return out.view(*shape, out.shape[1])
 
 
+# ------------------------------------------------------------------ several gathers of one position list, one launch
+class _GatherMultiFn(torch.autograd.Function):
+    """outs[o][r, coff : coff + W] (=, or += when accum) tables[t][idx[t][r], :] for the jobs `spec` = [(o, coff, accum,
+    skip)], one per table; `outs_shape` = [(width_o)].  Columns of an output that no job writes are left unwritten (the
+    caller fills them: FuseEmbeddings' first Linear writes its result next to the category rows)."""
+
+    @staticmethod
+    def forward(ctx, spec, out_widths, n, *args):
+        tables, idx = args[:n], args[n:]
+        R = idx[0].numel()
+        dev = tables[0].device
+        outs = [torch.empty(R, w, dtype=torch.float32, device=dev) for w in out_widths]
+        ci, i64, vp = ctypes.c_int, ctypes.c_int64, ctypes.c_void_p
+        check(_lib.lib().mobgt_embed_gather_multi(
+            n, _ptr_array(tables), None, _ptr_array(idx), (i64 * n)(*[sp[3] for sp in spec]),
+            (ci * n)(*[t.shape[1] for t in tables]), (ci * n)(*[sp[1] for sp in spec]), (ci * n)(*[int(sp[2]) for sp in spec]),
+            (vp * n)(*[outs[sp[0]].data_ptr() for sp in spec]), (i64 * n)(*[outs[sp[0]].stride(0) for sp in spec]), R,
+            _IT[idx[0].dtype], 0, _stream()), "mobgt_embed_gather_multi")
+        ctx.idx, ctx.spec, ctx.n = idx, spec, n
+        ctx.shapes = [t.shape for t in tables]
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *douts):
+        n, spec = ctx.n, ctx.spec
+        dev = ctx.idx[0].device
+        R = ctx.idx[0].numel()
+        gbuf = []
+        for g in douts:
+            if g is not None and (g.stride(1) != 1 or g.stride(0) % 4 or g.data_ptr() % 16 or g.dtype != torch.float32):
+                g = g.float().contiguous()
+            gbuf.append(g)
+        grads = [zeros_f32(tuple(sh), dev) if (ctx.needs_input_grad[3 + t] and gbuf[spec[t][0]] is not None) else None
+                 for t, sh in enumerate(ctx.shapes)]
+        jobs = [t for t in range(n) if grads[t] is not None]
+        if jobs:
+            m = len(jobs)
+            ci, i64, vp = ctypes.c_int, ctypes.c_int64, ctypes.c_void_p
+            check(_lib.lib().mobgt_embed_gather_multi(
+                m, None, (vp * m)(*[grads[t].data_ptr() for t in jobs]), (vp * m)(*[ctx.idx[t].data_ptr() for t in jobs]),
+                (i64 * m)(*[spec[t][3] for t in jobs]), (ci * m)(*[ctx.shapes[t][1] for t in jobs]),
+                (ci * m)(*[spec[t][1] for t in jobs]), None, (vp * m)(*[gbuf[spec[t][0]].data_ptr() for t in jobs]),
+                (i64 * m)(*[gbuf[spec[t][0]].stride(0) for t in jobs]), R, _IT[ctx.idx[0].dtype], 1, _stream()),
+                "mobgt_embed_gather_multi")
+        return (None, None, None, *grads, *([None] * n))
+
+
+def embed_gather_multi(jobs, out_widths):
+    """jobs = [(table, index, out, coff, accum, padding_idx)]: table[index] -> columns [coff, coff + W) of output `out`
+    (copied, or added when `accum`) -- all in one launch each way.  -> list of [R, out_widths[o]] f32 tensors."""
+    n = len(jobs)
+    tabs = [j[0].float().contiguous() for j in jobs]
+    idx = [j[1].contiguous().reshape(-1) for j in jobs]
+    _require_cuda(*tabs, *idx)
+    spec = tuple((int(j[2]), int(j[3]), bool(j[4]), -1 if j[5] is None else int(j[5])) for j in jobs)
+    return list(_GatherMultiFn.apply(spec, tuple(out_widths), n, *tabs, *idx))
+
+
+class _JoinColsFn(torch.autograd.Function):
+    """`whole` [R, W] whose leading columns were filled IN PLACE by the op that produced `part` (a view of those columns):
+    makes the result depend on both; backward hands `part` its columns of the gradient (a view, no launch)."""
+
+    @staticmethod
+    def forward(ctx, whole, part):
+        ctx.w = part.shape[1]
+        return whole.detach().view_as(whole)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, g[:, :ctx.w]
+
+
+def join_cols(whole, part):
+    return _JoinColsFn.apply(whole, part)
+
+
 # ------------------------------------------------------------------------------------------ loss
 class _GradientTailLossFn(torch.autograd.Function):
     @staticmethod
@@ -645,6 +721,13 @@ def gradient_tail_loss(logits, targets, alpha=0.25, target_offset=0):
 
 
 # ------------------------------------------------------------------------------- small linear layers
+class _OutRef:
+    """A destination buffer handed to an autograd Function as a plain Python object (not as a tensor input)."""
+
+    def __init__(self, t):
+        self.t = t.detach()
+
+
 class _LinearSplitKFn(torch.autograd.Function):
     """y = x W^T + b for a few hundred rows: the weight gradient g^T x has K = rows and a tiny output, which a
     plain GEMM call maps onto one workgroup (measured 60-150 us in fp32); evaluate it split-K as a batched GEMM.
@@ -652,11 +735,14 @@ class _LinearSplitKFn(torch.autograd.Function):
     epilogue, its derivative applied to the incoming gradient while the two backward products load it."""
 
     @staticmethod
-    def forward(ctx, x, w, b, bf16_wgrad, slope):
+    def forward(ctx, x, w, b, bf16_wgrad, slope, out=None):
         ctx.bf16_wgrad = bf16_wgrad
         ctx.slope = slope
         if _small_linear(x, w) & 1:
-            y = small_gemm(x, w, b, True, leaky=slope)
+            # (`out`: an _OutRef to a column slice of a wider buffer; the result is a fresh view of it, not an input)
+            y = small_gemm(x, w, b, True, leaky=slope, out=out.t if out is not None else None)
+            if out is not None:
+                y = y.view_as(y)
         else:
             y = torch.addmm(b, x, w.t())
             if slope is not None:
@@ -667,7 +753,8 @@ class _LinearSplitKFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         x, w, y = ctx.saved_tensors
-        g = g.contiguous()
+        if y is None or y.is_contiguous():
+            g = g.contiguous()                  # (else: a strided gradient goes straight into leaky_relu_backward below)
         R = x.shape[0]
         hip_wgrad = (ctx.bf16_wgrad and g.dtype == torch.float32 and x.dtype == torch.float32 and g.shape[1] % 2 == 0
                      and x.shape[1] % 2 == 0 and R <= 4096 and g.data_ptr() % 8 == 0 and x.data_ptr() % 8 == 0)
@@ -679,19 +766,19 @@ class _LinearSplitKFn(torch.autograd.Function):
                     and max(w.shape) <= 512):
                 db = zeros_f32((g.shape[1],), g.device)
                 dw = linear_wgrad_masked(g, x, g_mask=y, mask_vals=mv, db=db)
-                return small_gemm(g, w, a_mask=(y, *mv)), dw, db, None, None
-            g = torch.ops.aten.leaky_relu_backward(g, y, ctx.slope, True)      # (from the activation's result)
+                return small_gemm(g, w, a_mask=(y, *mv)), dw, db, None, None, None
+            g = torch.ops.aten.leaky_relu_backward(g, y, ctx.slope, True).contiguous()      # (from the activation's result)
         if hip_wgrad:
             # bf16 configuration: weight AND bias gradient from the split-K MFMA kernel (operands rounded to bf16 while
             # loading); the library's split-K path took 27-31 us + a reduce for these 224-wide layers
             dw, db = linear_wgrad(g, x, with_bias=True)
-            return (small_gemm(g, w) if _small_linear(g, w) & 2 else g @ w), dw, db, None, None
+            return (small_gemm(g, w) if _small_linear(g, w) & 2 else g @ w), dw, db, None, None, None
         s = max((c for c in (16, 8, 4, 2) if R % c == 0 and R // c >= 16), default=1)
         if s > 1:
             dw = torch.bmm(g.view(s, R // s, -1).transpose(1, 2), x.view(s, R // s, -1)).sum(0)
         else:
             dw = g.t() @ x
-        return g @ w, dw, colsum(g), None, None
+        return g @ w, dw, colsum(g), None, None, None
 
 
 _SMALL_LINEAR = int(__import__("os").environ.get("MOBGT_SMALL_LINEAR", "1"))
@@ -706,11 +793,15 @@ def _small_linear(x, w):
     return _SMALL_LINEAR if x.shape[0] <= 64 else (_SMALL_LINEAR & 1)     # data gradient: the head's 16 rows only
 
 
-def linear_splitk(x, weight, bias, bf16_wgrad=False, slope=None):
-    """F.linear(x, weight, bias) [-> leaky_relu(slope)] for a few hundred rows (see _LinearSplitKFn)."""
+def linear_splitk(x, weight, bias, bf16_wgrad=False, slope=None, out=None):
+    """F.linear(x, weight, bias) [-> leaky_relu(slope)] for a few hundred rows (see _LinearSplitKFn).  `out`: a 2-D f32
+    view (unit column stride) that receives the result -- only honoured on the csrc/sgemm.hip path, check the return."""
     shape = x.shape
-    y = _LinearSplitKFn.apply(x.reshape(-1, shape[-1]).contiguous(), weight, bias, bf16_wgrad, slope)
-    return y.view(*shape[:-1], weight.shape[0])
+    x2 = x.reshape(-1, shape[-1]).contiguous()
+    if out is not None and not (_small_linear(x2, weight) & 1 and out.shape == (x2.shape[0], weight.shape[0])):
+        out = None
+    y = _LinearSplitKFn.apply(x2, weight, bias, bf16_wgrad, slope, _OutRef(out) if out is not None else None)
+    return y if out is not None else y.view(*shape[:-1], weight.shape[0])
 
 
 # --------------------------------------------------------------------------------------- dropout
