@@ -451,3 +451,57 @@ def test_gather_rows_t():
     rows = torch.randint(0, 300, (72,), generator=gen).to(DEV)
     r, rt = ops.gather_rows_t(a, rows)
     assert torch.equal(r, a[rows]) and torch.equal(rt, a[rows].t().contiguous())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,K", [(192, 192), (1024, 192), (192, 1024), (576, 192), (32, 64)])
+def test_pack_mfma_b_layout_is_bit_exact(N, K):
+    """mobgt_pack_mfma_b: the 16 bytes W[16g + j][32s + 8q .. +7] land at ((g K/32 + s) 64 + j + 16q) * 16 bytes -- for the
+    weight itself and for the transpose of a [K,N] weight -- bit for bit (the chain kernels' B operand order)."""
+    import ctypes
+    from mobgt_amd import _lib
+    from mobgt_amd.ops import _stream
+    torch.manual_seed(N + K)
+    w = torch.randn(N, K, device=DEV).bfloat16()                       # [N,K]: packed as it is
+    wt_src = w.t().contiguous()                                          # [K,N]: packed transposed -> the same operand
+    outs = [torch.empty(N * K, dtype=torch.bfloat16, device=DEV) for _ in range(2)]
+    vp, ci = ctypes.c_void_p, ctypes.c_int
+    _lib.check(_lib.lib().mobgt_pack_mfma_b(2, (vp * 2)(w.data_ptr(), wt_src.data_ptr()), (vp * 2)(outs[0].data_ptr(), outs[1].data_ptr()),
+                                            (ci * 2)(N, N), (ci * 2)(K, K), (ci * 2)(0, 1), _stream()), "mobgt_pack_mfma_b")
+    torch.cuda.synchronize()
+    S = K // 32
+    g, s, q, j, e = np.meshgrid(np.arange(N // 16), np.arange(S), np.arange(4), np.arange(16), np.arange(8), indexing="ij")
+    want = w.cpu().view(torch.int16).numpy()[16 * g + j, 32 * s + 8 * q + e].reshape(-1)     # order (g, s, q, j, e) = ((g S + s) 64 + 16 q + j) 8 + e
+    for o in outs:
+        np.testing.assert_array_equal(o.cpu().view(torch.int16).numpy(), want)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("idt", [torch.int64, torch.int32])
+def test_embed_gather_multi_matches_torch_indexing(idt):
+    """ops.embed_gather_multi: concatenated and summed gathers of one position list in one launch (zeros for negative
+    indices, `accum` jobs added on top), and the scatter-add backward that skips padding rows -- against torch indexing."""
+    from mobgt_amd import ops
+    torch.manual_seed(3)
+    R = 301
+    tabs = [torch.randn(n, w, device=DEV, requires_grad=True) for n, w in ((50, 128), (49, 32), (30, 32), (10, 192), (128, 192), (2000, 192))]
+    idx = [torch.randint(-1 if t in (0, 5) else 0, tab.shape[0], (R,), device=DEV).to(idt) for t, tab in enumerate(tabs)]
+    pad = [None, 0, None, 0, 0, None]
+    jobs = [(tabs[0], idx[0], 0, 0, False, pad[0]), (tabs[1], idx[1], 0, 128, False, pad[1]), (tabs[2], idx[2], 1, 160, False, pad[2]),
+            (tabs[3], idx[3], 2, 0, False, pad[3]), (tabs[4], idx[4], 2, 0, True, pad[4]), (tabs[5], idx[5], 2, 0, True, pad[5])]
+    pt, x4, add = ops.embed_gather_multi(jobs, [160, 192, 192])
+
+    def take(t):
+        i = idx[t].long()
+        return torch.where((i >= 0)[:, None], tabs[t][i.clamp(min=0)], torch.zeros((), device=DEV))
+    torch.testing.assert_close(pt, torch.cat((take(0), take(1)), 1), rtol=0, atol=0)
+    torch.testing.assert_close(x4[:, 160:], take(2), rtol=0, atol=0)
+    torch.testing.assert_close(add, take(3) + take(4) + take(5), rtol=1e-6, atol=1e-6)
+    g_pt, g_x4, g_add = torch.randn_like(pt), torch.randn_like(x4), torch.randn_like(add)
+    torch.autograd.backward([pt, x4, add], [g_pt, g_x4, g_add])
+    srcs = [g_pt[:, :128], g_pt[:, 128:], g_x4[:, 160:], g_add, g_add, g_add]
+    for t, tab in enumerate(tabs):
+        i = idx[t].long()
+        keep = (i >= 0) & ((i != pad[t]) if pad[t] is not None else torch.ones_like(i, dtype=torch.bool))
+        want = torch.zeros_like(tab).index_add_(0, i[keep], srcs[t][keep])
+        torch.testing.assert_close(tab.grad, want, rtol=1e-5, atol=1e-5)
