@@ -19,7 +19,7 @@ lib = _lib.lib()
 def pack(w):
     out = torch.empty_like(w)
     vp, ci = ctypes.c_void_p, ctypes.c_int
-    _lib.check(lib.mobgt_pack_mfma_b(1, (vp * 1)(w.data_ptr()), (vp * 1)(out.data_ptr()), (ci * 1)(w.shape[0]), (ci * 1)(w.shape[1]),
+    _lib.check(lib.mobgt_pack_mfma_b(1, (vp * 1)(w.data_ptr()), (vp * 1)(out.data_ptr()), (ci * 1)(w.shape[0]), (ci * 1)(w.shape[1]), None,
                                      _stream()), "pack")
     return out
 
