@@ -505,6 +505,10 @@ int mobgt_ln_gemm_bwd(const void* dz, const float* dz32, const float* dres, cons
 /* Start of a training step (the trainer's `optimizer.zero_grad()` + per-step counter): zero-fills two f32 buffers
  * (element counts multiples of 4, 16-byte aligned; either may be empty) and adds 1 to *counter (may be NULL). */
 int mobgt_step_prologue(float* zero_a, int64_t n_a, float* zero_b, int64_t n_b, int64_t* counter, void* stream);
+/* ... leaving zero_a[skip_begin, skip_end) untouched: the slice of the flat gradient buffer that a kernel of the backward
+ * pass OVERWRITES in full (out_proj's weight gradient: 61 % of the S-FSQ model's gradient bytes need no zeroing). */
+int mobgt_step_prologue_skip(float* zero_a, int64_t n_a, int64_t skip_begin, int64_t skip_end, float* zero_b, int64_t n_b,
+                             int64_t* counter, void* stream);
 
 /* Input of the classifier head, graph-token rows only (model_fqandtoyo.py:1239-1240 `user_embed_model(user - 1)`,
  * :1353-1358 `embed_fuse_model3(output[p][0], user_embedding[p])`'s concatenation):

@@ -1121,25 +1121,37 @@ extern "C" int mobgt_bias_act_bwd(const float* dy, const float* y, float* dx, fl
 // seeds, AdamW's t) -- one launch instead of two fills and an add.
 namespace {
 __global__ __launch_bounds__(256) void step_prologue_kernel(float4* __restrict__ a, int64_t na, float4* __restrict__ b, int64_t nb,
-                                                            int64_t* __restrict__ counter) {
+                                                            int64_t hole0, int64_t hole1, int64_t* __restrict__ counter) {
     const int64_t n = na + nb;
     const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-        if (i < na) a[i] = z; else b[i - na] = z;
+        if (i < na) {
+            if (i < hole0 || i >= hole1) a[i] = z;
+        } else {
+            b[i - na] = z;
+        }
     }
     if (counter && blockIdx.x == 0 && threadIdx.x == 0) *counter += 1;
 }
 }  // namespace
 
 extern "C" int mobgt_step_prologue(float* zero_a, int64_t n_a, float* zero_b, int64_t n_b, int64_t* counter, void* stream) {
+    return mobgt_step_prologue_skip(zero_a, n_a, 0, 0, zero_b, n_b, counter, stream);
+}
+
+extern "C" int mobgt_step_prologue_skip(float* zero_a, int64_t n_a, int64_t skip_begin, int64_t skip_end, float* zero_b, int64_t n_b,
+                                        int64_t* counter, void* stream) {
     if (n_a < 0 || n_b < 0 || (n_a & 3) || (n_b & 3)) return MOBGT_EBADDIM;
+    if (skip_begin < 0 || skip_end < skip_begin || skip_end > n_a) return MOBGT_EBADDIM;
+    const int64_t hole0 = (skip_begin + 3) / 4, hole1 = skip_end / 4;           // whole float4s inside the hole only
     if (((uintptr_t)zero_a | (uintptr_t)zero_b) & 15) return MOBGT_EALIGN;
     const int64_t n4 = (n_a + n_b) / 4;
     int64_t blocks = (n4 + 255) / 256;
     if (blocks > 4096) blocks = 4096;
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(step_prologue_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
-                       reinterpret_cast<float4*>(zero_a), n_a / 4, reinterpret_cast<float4*>(zero_b), n_b / 4, counter);
+                       reinterpret_cast<float4*>(zero_a), n_a / 4, reinterpret_cast<float4*>(zero_b), n_b / 4, hole0,
+                       hole1 > hole0 ? hole1 : hole0, counter);
     return (int)hipGetLastError();
 }
 

@@ -59,6 +59,9 @@ class FlatGrads:
         ps, vs = self.params[start:stop], self.views[start:stop]
         if grads is None:
             grads = [p.grad for p in ps]
+        for k in getattr(self, "zero_if_missing", ()):        # slots the per-step zeroing skips (TrainStep._skip)
+            if start <= k < stop and grads[k - start] is None:
+                vs[k - start].zero_()
         # nothing to copy for a gradient that was written in place (ops.grad_sink) or that does not exist (the flat
         # buffer is zeroed before every backward)
         todo = [(v, g) for g, v in zip(grads, vs) if g is not None and g.data_ptr() != v.data_ptr()]
@@ -216,6 +219,17 @@ class TrainStep:
         self.n_head_elems = self.flat.offsets[self.n_head] if self.n_head < len(used) else self.flat.flat.numel()
         self.flat_params = FlatParams(model, used)
         ops.set_grad_sinks(self.flat.params, self.flat.views)        # big gradients are written in place (no gather copy)
+        # The classifier's weight gradient (61 % of the S-FSQ model's gradient bytes) is OVERWRITTEN in full by every backward
+        # pass -- by the skinny weight-gradient kernel writing into its sink, or by the gather's copy of a library result --
+        # so the per-step zeroing leaves that slice alone (it is zeroed by hand in the one case nothing writes it: a step in
+        # which the parameter received no gradient)
+        self._skip = None
+        w = getattr(getattr(model, "out_proj", None), "weight", None)
+        if w is not None and os.environ.get("MOBGT_ZERO_ALL") != "1":
+            for i, q in enumerate(self.flat.params):
+                if q is w and w.numel() >= (1 << 20):
+                    self._skip = (i, int(self.flat.offsets[i]), int(self.flat.offsets[i]) + w.numel())
+                    self.flat.zero_if_missing = (i,)
         self.flat_params.tensor.grad = self.flat.flat
         self.lr_dev = torch.tensor(float(model.peak_lr), dtype=torch.float32, device=dev)
         # AdamW (model_fqandtoyo.py:1599-1616 defaults) as ONE kernel over the flat buffers that also refreshes the bf16
@@ -331,8 +345,10 @@ class TrainStep:
         self.flat.release()
         self.arena.off = 0
         ops.set_zero_arena(self.arena)             # valid from here to the end of this backward pass only
-        _lib.check(_lib.lib().mobgt_step_prologue(_p(self.flat.flat), self.flat.flat.numel(), _p(self.arena.buf),
-                                                  self.arena.buf.numel(), _p(self.seed_dev), _stream()), "mobgt_step_prologue")
+        lo, hi = (self._skip[1], self._skip[2]) if self._skip is not None else (0, 0)
+        _lib.check(_lib.lib().mobgt_step_prologue_skip(_p(self.flat.flat), self.flat.flat.numel(), lo, hi, _p(self.arena.buf),
+                                                       self.arena.buf.numel(), _p(self.seed_dev), _stream()),
+                   "mobgt_step_prologue_skip")
 
     def _fwd_bwd(self, batch, slot=None):
         self._prologue()
