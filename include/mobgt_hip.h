@@ -323,6 +323,10 @@ int mobgt_linear_wgrad(const void* g, int64_t ldg, const void* x, int64_t ldx, f
 int mobgt_linear_wgrad_masked(const float* g, int64_t ldg, const float* x, int64_t ldx, const float* g_mask, const float* x_mask,
                               float m_pos, float m_neg, float m_zero, float* dw, int64_t ldw, float* db, int db_of_x, int64_t R,
                               int M, int N, void* stream);
+/* dw [M,N] (ZERO on entry) = g^T x + out_bias[n] on every row: the same split-K kernel used as a skinny product with a
+ * bias -- `adj[rows] @ support + b` of the last GraphConvolution (modelGNN.py:38-44) without an add launch. */
+int mobgt_linear_wgrad_bias(const void* g, int64_t ldg, const void* x, int64_t ldx, const float* out_bias, float* dw,
+                            int64_t ldw, int64_t R, int M, int N, int act_dtype, void* stream);
 /* The same for n <= 32 independent Linear layers over the same R rows in ONE launch (host arrays of n entries each;
  * db may be NULL, or hold NULL entries): the weight gradients of all encoder layers of a backward pass. */
 int mobgt_linear_wgrad_group(int n, const void* const* g, const int64_t* ldg, const void* const* x, const int64_t* ldx,

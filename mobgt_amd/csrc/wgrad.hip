@@ -42,6 +42,7 @@ struct WgradParams {
     const float* xmask;
     float mpos, mneg, mzero;
     int db_x;                            // db [N] += column sums of (the masked) x instead of g
+    const float* out_bias;               // [N] or null: added to every row of dw (the product used as  A^T B + bias)
 };
 
 __device__ __forceinline__ void split_pairs(const uint32_t (&d)[8], bf16x8& even, bf16x8& odd) {
@@ -199,6 +200,7 @@ __device__ __forceinline__ void wgrad_body(const WgradParams& p, const int tile,
         for (int w = 0; w < NWAVE / 2; ++w) s += part[w][e];
         if (m0 + r < p.M && n0 + c < p.N) {
             float* dst = p.dw + (int64_t)(m0 + r) * p.ldw + n0 + c;
+            if (p.out_bias && split == 0) s += p.out_bias[n0 + c];
             if (nsplit > 1) atomicAdd(dst, s); else *dst += s;
         }
     }
@@ -261,7 +263,7 @@ int fill_problem(WgradParams& p, const void* g, int64_t ldg, const void* x, int6
     if (R <= 0 || M <= 0 || N <= 0 || (M & 1) || (N & 1) || (ldg & 1) || (ldx & 1) || R > 0x7fffffff) return MOBGT_EBADDIM;
     if (((uintptr_t)g & (in_f32 ? 7 : 3)) || ((uintptr_t)x & (in_f32 ? 7 : 3))) return MOBGT_EALIGN;
     p.in_f32 = in_f32;
-    p.gmask = p.xmask = nullptr; p.mpos = p.mneg = p.mzero = 1.f; p.db_x = 0;
+    p.gmask = p.xmask = nullptr; p.mpos = p.mneg = p.mzero = 1.f; p.db_x = 0; p.out_bias = nullptr;
     p.g = reinterpret_cast<const uint16_t*>(g); p.ldg = ldg;
     p.x = reinterpret_cast<const uint16_t*>(x); p.ldx = ldx;
     p.dw = dw; p.ldw = ldw; p.db = db;
@@ -364,6 +366,24 @@ extern "C" int mobgt_linear_wgrad_masked(const float* g, int64_t ldg, const floa
     const int rc = fill_problem(p, g, ldg, x, ldx, dw, ldw, db, R, M, N, nwave == 8 ? 512 : 256, &tiles, &splits, 1, nwave);
     if (rc) return rc;
     p.gmask = g_mask; p.xmask = x_mask; p.mpos = m_pos; p.mneg = m_neg; p.mzero = m_zero; p.db_x = db_of_x;
+    if (nwave == 8) hipLaunchKernelGGL(wgrad_kernel<8>, dim3(tiles, splits), dim3(8 * 64), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL(wgrad_kernel<16>, dim3(tiles, splits), dim3(16 * 64), 0, (hipStream_t)stream, p);
+    return (int)hipGetLastError();
+}
+
+/* dw [M,N] (zero on entry) = g^T x + out_bias[n] on every row: the split-K product used as a skinny "A^T B + bias"
+ * (the last GraphConvolution on the batch's rows, modelGNN.py:38-44). */
+extern "C" int mobgt_linear_wgrad_bias(const void* g, int64_t ldg, const void* x, int64_t ldx, const float* out_bias, float* dw,
+                                       int64_t ldw, int64_t R, int M, int N, int act_dtype, void* stream) {
+    if (act_dtype != MOBGT_BF16 && act_dtype != MOBGT_F32) return MOBGT_EDTYPE;
+    if (R == 0) return 0;
+    WgradParams p;
+    int tiles = 0, splits = 0;
+    const int nwave = R <= SHORT_R ? 8 : 16;
+    const int rc = fill_problem(p, g, ldg, x, ldx, dw, ldw, nullptr, R, M, N, nwave == 8 ? 512 : 256, &tiles, &splits,
+                                act_dtype == MOBGT_F32, nwave);
+    if (rc) return rc;
+    p.out_bias = out_bias;
     if (nwave == 8) hipLaunchKernelGGL(wgrad_kernel<8>, dim3(tiles, splits), dim3(8 * 64), 0, (hipStream_t)stream, p);
     else hipLaunchKernelGGL(wgrad_kernel<16>, dim3(tiles, splits), dim3(16 * 64), 0, (hipStream_t)stream, p);
     return (int)hipGetLastError();

@@ -111,9 +111,7 @@ class _RowsConvFn(torch.autograd.Function):
         from . import ops
         support = _mm_small(x, weight, out_dtype=torch.bfloat16)       # [P,C], rounded to bf16 on the way out
         a_rows, a_rows_t = ops.gather_rows_t(adj, rows)                # [R,P] and its transpose [P,R], one pass
-        out = ops.linear_wgrad(a_rows_t, support)[0]                   # [R,C] f32
-        if bias is not None:
-            out = out + bias
+        out = ops.linear_wgrad(a_rows_t, support, out_bias=bias)[0]    # [R,C] f32 (+ bias, inside the kernel)
         ctx.save_for_backward(x, weight, a_rows)
         ctx.has_bias = bias is not None
         return out

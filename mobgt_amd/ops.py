@@ -1158,15 +1158,21 @@ def nan_trace_report():
     return [(n, bool(f[i])) for i, n in enumerate(_NAN_TRACE["names"])]
 
 
-def linear_wgrad(g, x, with_bias=False, db=None):
+def linear_wgrad(g, x, with_bias=False, db=None, out_bias=None):
     """(dW, db) of y = x W^T + b from g = dL/dy: dW [M,N] = g^T x (f32) and db [M] = g.sum(0) (f32, or None),
     for bf16 row-major g [R,M], x [R,N] (row strides may exceed the width: column slices are fine).
-    `db`: an existing zero-initialised f32 [M] to accumulate the bias gradient into."""
+    `db`: an existing zero-initialised f32 [M] to accumulate the bias gradient into.
+    `out_bias` (f32 [N]): added to every row of the product (the kernel used as a skinny `A^T B + bias`)."""
     _require_cuda(g)
     R, M = g.shape
     N = x.shape[1]
     assert g.dtype == x.dtype and g.dtype in (torch.bfloat16, torch.float32) and g.stride(1) == 1 and x.stride(1) == 1
     dw = zeros_f32((M, N), g.device)
+    if out_bias is not None:
+        assert db is None and not with_bias and out_bias.dtype == torch.float32 and out_bias.numel() == N
+        check(_lib.lib().mobgt_linear_wgrad_bias(_p(g), g.stride(0), _p(x), x.stride(0), _p(out_bias.contiguous()), _p(dw), N, R, M, N,
+                                                 _DT[g.dtype], _stream()), "mobgt_linear_wgrad_bias")
+        return dw, None
     if db is None and with_bias:
         db = zeros_f32((M,), g.device)
     check(_lib.lib().mobgt_linear_wgrad(_p(g), g.stride(0), _p(x), x.stride(0), _p(dw), N, _p(db), R, M, N, _DT[g.dtype],
