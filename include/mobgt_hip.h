@@ -327,6 +327,10 @@ int mobgt_linear_wgrad_masked(const float* g, int64_t ldg, const float* x, int64
  * bias -- `adj[rows] @ support + b` of the last GraphConvolution (modelGNN.py:38-44) without an add launch. */
 int mobgt_linear_wgrad_bias(const void* g, int64_t ldg, const void* x, int64_t ldx, const float* out_bias, float* dw,
                             int64_t ldw, int64_t R, int M, int N, int act_dtype, void* stream);
+/* g bf16 [R,M], x f32 [R,N] (rounded to bf16 while loading): dw (ZERO on entry) = g^T x and db_x [N] (zero on entry, or null)
+ * += column sums of x: d(support) = adj[rows]^T dout and b.grad = dout.sum(0) of the rows-only GraphConvolution's backward. */
+int mobgt_linear_wgrad_mixed(const void* g_bf16, int64_t ldg, const float* x_f32, int64_t ldx, float* dw, int64_t ldw,
+                             float* db_x, int64_t R, int M, int N, void* stream);
 /* The same for n <= 32 independent Linear layers over the same R rows in ONE launch (host arrays of n entries each;
  * db may be NULL, or hold NULL entries): the weight gradients of all encoder layers of a backward pass. */
 int mobgt_linear_wgrad_group(int n, const void* const* g, const int64_t* ldg, const void* const* x, const int64_t* ldx,

@@ -34,7 +34,8 @@ struct WgradParams {
     int R, M, N;
     int tiles_n;
     int k_per_wg;                        // multiple of NWAVE * KSTEP when gridDim.y > 1
-    int in_f32;                          // operands are f32 in memory (ldg / ldx in f32 elements), rounded to bf16 here
+    int in_f32;                          // 1: operands are f32 in memory (ldg / ldx in f32 elements), rounded to bf16 here;
+                                         // 2 (single-problem launches): g bf16, x f32
     // f32 operands only: g (x) is multiplied by m(gmask) (m(xmask)) while loading, m(y) = y > 0 ? mpos : (y < 0 ? mneg :
     // mzero) -- the derivative of dropout(leaky_relu(.)) from its output, so that the gradient at the pre-activation never
     // exists as a tensor.  A mask has its operand's layout and leading dimension.
@@ -92,20 +93,17 @@ struct Slab {
         }
     }
     // gp / xp point at this lane's column pair of row 0 (as bf16 elements, or -- F32 -- as f32 elements)
-    template <bool F32>
+    template <bool GF32, bool XF32>
     __device__ __forceinline__ void load(const void* gp, const void* xp, int64_t ldg, int64_t ldx, int r0, int k1,
                                          bool m_ok, bool n_ok) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int r = r0 + j;
             const bool ok = r < k1;
-            if (F32) {
-                g[j] = ok && m_ok ? pack_pair(reinterpret_cast<const float*>(gp) + (int64_t)r * ldg) : 0u;
-                x[j] = ok && n_ok ? pack_pair(reinterpret_cast<const float*>(xp) + (int64_t)r * ldx) : 0u;
-            } else {
-                g[j] = ok && m_ok ? *reinterpret_cast<const uint32_t*>(reinterpret_cast<const uint16_t*>(gp) + (int64_t)r * ldg) : 0u;
-                x[j] = ok && n_ok ? *reinterpret_cast<const uint32_t*>(reinterpret_cast<const uint16_t*>(xp) + (int64_t)r * ldx) : 0u;
-            }
+            if (GF32) g[j] = ok && m_ok ? pack_pair(reinterpret_cast<const float*>(gp) + (int64_t)r * ldg) : 0u;
+            else g[j] = ok && m_ok ? *reinterpret_cast<const uint32_t*>(reinterpret_cast<const uint16_t*>(gp) + (int64_t)r * ldg) : 0u;
+            if (XF32) x[j] = ok && n_ok ? pack_pair(reinterpret_cast<const float*>(xp) + (int64_t)r * ldx) : 0u;
+            else x[j] = ok && n_ok ? *reinterpret_cast<const uint32_t*>(reinterpret_cast<const uint16_t*>(xp) + (int64_t)r * ldx) : 0u;
         }
     }
 };
@@ -116,7 +114,7 @@ struct Slab {
 // partial tiles -- the upper half of the waves hand their tiles to the lower half first -- and NWAVE column partials
 template <int NWAVE> constexpr int wgrad_lds_floats() { return (NWAVE / 2) * TILE * TILE + NWAVE * TILE; }
 
-template <bool F32, int NWAVE>
+template <bool F32, int NWAVE, bool XF32 = F32>
 __device__ __forceinline__ void wgrad_body(const WgradParams& p, const int tile, const int split, const int nsplit,
                                            float* __restrict__ lds) {
     float (*part)[TILE * TILE] = reinterpret_cast<float (*)[TILE * TILE]>(lds);
@@ -129,7 +127,7 @@ __device__ __forceinline__ void wgrad_body(const WgradParams& p, const int tile,
     const bool want_db = p.db != nullptr && (p.db_x ? m0 == 0 : n0 == 0);
     const bool m_ok = m0 + 2 * i < p.M, n_ok = n0 + 2 * i < p.N;      // M, N even: a pair is in or out together
     const void* gp = F32 ? (const void*)(reinterpret_cast<const float*>(p.g) + m0 + 2 * i) : (const void*)(p.g + m0 + 2 * i);
-    const void* xp = F32 ? (const void*)(reinterpret_cast<const float*>(p.x) + n0 + 2 * i) : (const void*)(p.x + n0 + 2 * i);
+    const void* xp = XF32 ? (const void*)(reinterpret_cast<const float*>(p.x) + n0 + 2 * i) : (const void*)(p.x + n0 + 2 * i);
 
     f32x4 acc[2][2];
 #pragma unroll
@@ -143,7 +141,7 @@ __device__ __forceinline__ void wgrad_body(const WgradParams& p, const int tile,
     const float* xm = masked && p.xmask ? p.xmask + n0 + 2 * i : nullptr;
     auto fetch = [&](Slab& s_, int r0_) {
         if (masked) s_.template load_masked<F32>(p, gp, xp, gm, xm, r0_, k1, m_ok, n_ok);
-        else s_.template load<F32>(gp, xp, p.ldg, p.ldx, r0_, k1, m_ok, n_ok);
+        else s_.template load<F32, XF32>(gp, xp, p.ldg, p.ldx, r0_, k1, m_ok, n_ok);
     };
     int kb = k0 + wave * KSTEP;
     Slab cur, nxt;
@@ -219,7 +217,8 @@ __device__ __forceinline__ void wgrad_body(const WgradParams& p, const int tile,
 template <int NWAVE>
 __global__ __launch_bounds__(NWAVE * 64) void wgrad_kernel(const WgradParams p) {
     __shared__ __attribute__((aligned(16))) float lds[wgrad_lds_floats<NWAVE>()];
-    if (p.in_f32) wgrad_body<true, NWAVE>(p, blockIdx.x, blockIdx.y, gridDim.y, lds);
+    if (p.in_f32 == 2) wgrad_body<false, NWAVE, true>(p, blockIdx.x, blockIdx.y, gridDim.y, lds);      // g bf16, x f32
+    else if (p.in_f32) wgrad_body<true, NWAVE>(p, blockIdx.x, blockIdx.y, gridDim.y, lds);
     else wgrad_body<false, NWAVE>(p, blockIdx.x, blockIdx.y, gridDim.y, lds);
 }
 
@@ -261,7 +260,7 @@ __global__ __launch_bounds__(NWAVE * 64) void wgrad_group_kernel(const WgradGrou
 int fill_problem(WgradParams& p, const void* g, int64_t ldg, const void* x, int64_t ldx, float* dw, int64_t ldw, float* db,
                  int64_t R, int M, int N, int target_wgs, int* tiles_out, int* splits_out, int in_f32, int nwave) {
     if (R <= 0 || M <= 0 || N <= 0 || (M & 1) || (N & 1) || (ldg & 1) || (ldx & 1) || R > 0x7fffffff) return MOBGT_EBADDIM;
-    if (((uintptr_t)g & (in_f32 ? 7 : 3)) || ((uintptr_t)x & (in_f32 ? 7 : 3))) return MOBGT_EALIGN;
+    if (((uintptr_t)g & (in_f32 == 1 ? 7 : 3)) || ((uintptr_t)x & (in_f32 ? 7 : 3))) return MOBGT_EALIGN;
     p.in_f32 = in_f32;
     p.gmask = p.xmask = nullptr; p.mpos = p.mneg = p.mzero = 1.f; p.db_x = 0; p.out_bias = nullptr;
     p.g = reinterpret_cast<const uint16_t*>(g); p.ldg = ldg;
@@ -384,6 +383,23 @@ extern "C" int mobgt_linear_wgrad_bias(const void* g, int64_t ldg, const void* x
                                 act_dtype == MOBGT_F32, nwave);
     if (rc) return rc;
     p.out_bias = out_bias;
+    if (nwave == 8) hipLaunchKernelGGL(wgrad_kernel<8>, dim3(tiles, splits), dim3(8 * 64), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL(wgrad_kernel<16>, dim3(tiles, splits), dim3(16 * 64), 0, (hipStream_t)stream, p);
+    return (int)hipGetLastError();
+}
+
+/* g bf16 [R,M], x f32 [R,N] (rounded to bf16 while loading): dw (ZERO on entry) = g^T x, db [N] (zero on entry, or null)
+ * += column sums of x -- the backward of the rows-only GraphConvolution: d(support) = adj[rows]^T dout and
+ * b.grad = dout.sum(0) from the f32 gradient as it arrives (no cast, no column-sum launch). */
+extern "C" int mobgt_linear_wgrad_mixed(const void* g_bf16, int64_t ldg, const float* x_f32, int64_t ldx, float* dw, int64_t ldw,
+                                        float* db_x, int64_t R, int M, int N, void* stream) {
+    if (R == 0) return 0;
+    WgradParams p;
+    int tiles = 0, splits = 0;
+    const int nwave = R <= SHORT_R ? 8 : 16;
+    const int rc = fill_problem(p, g_bf16, ldg, x_f32, ldx, dw, ldw, db_x, R, M, N, nwave == 8 ? 512 : 256, &tiles, &splits, 2, nwave);
+    if (rc) return rc;
+    p.db_x = 1;
     if (nwave == 8) hipLaunchKernelGGL(wgrad_kernel<8>, dim3(tiles, splits), dim3(8 * 64), 0, (hipStream_t)stream, p);
     else hipLaunchKernelGGL(wgrad_kernel<16>, dim3(tiles, splits), dim3(16 * 64), 0, (hipStream_t)stream, p);
     return (int)hipGetLastError();

@@ -119,11 +119,23 @@ class _RowsConvFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         from . import ops
+        from . import _lib
+        from .ops import _p, _stream
         x, weight, a_rows = ctx.saved_tensors
-        d_support = ops.linear_wgrad(a_rows, g.to(torch.bfloat16).contiguous())[0]      # [P,C] f32
+        g = g.contiguous()
+        R, P = a_rows.shape
+        C = g.shape[1]
+        if g.dtype == torch.float32 and C % 2 == 0 and g.data_ptr() % 8 == 0:
+            # the f32 gradient as it arrives: rounded to bf16 while loading, bias gradient = its column sums, one launch
+            d_support = ops.zeros_f32((P, C), g.device)
+            db = ops.zeros_f32((C,), g.device) if ctx.has_bias else None
+            _lib.check(_lib.lib().mobgt_linear_wgrad_mixed(_p(a_rows), a_rows.stride(0), _p(g), g.stride(0), _p(d_support), C,
+                                                           _p(db), R, P, C, _stream()), "mobgt_linear_wgrad_mixed")
+        else:
+            d_support = ops.linear_wgrad(a_rows, g.to(torch.bfloat16).contiguous())[0]      # [P,C] f32
+            db = _colsum(g) if ctx.has_bias else None
         dW = mm_tn_splitk(x, d_support, bf16_operands=True)
         dx = _mm_small(d_support, weight, True) if ctx.needs_input_grad[0] else None
-        db = _colsum(g) if ctx.has_bias else None
         return dx, dW, db, None, None
 
 
