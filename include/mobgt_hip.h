@@ -364,6 +364,10 @@ int mobgt_assemble_tokens_bwd(const float* dout, const float* real, float* d_nf,
  * Backward: dx overwritten from dy and the saved OUTPUT y; dbias [C] (or NULL) ACCUMULATED (zero it first). */
 int mobgt_bias_act_fwd(const float* x, const float* bias, float* y, int64_t R, int C, float slope, float dropout_p,
                        uint64_t seed, const uint64_t* seed_dev, uint32_t salt, void* stream);
+/* mobgt_bias_act_fwd that also writes y transposed as bf16 [C][ld_t] (ld_t >= R): the next bitmask adjacency product's
+ * operand (mobgt_mask_gemm with x null). */
+int mobgt_bias_act_fwd_t(const float* x, const float* bias, float* y, void* y_t_bf16, int64_t ld_t, int64_t R, int C, float slope,
+                         float dropout_p, uint64_t seed, const uint64_t* seed_dev, uint32_t salt, void* stream);
 int mobgt_bias_act_bwd(const float* dy, const float* y, float* dx, float* dbias, int64_t R, int C, float slope,
                        float dropout_p, uint64_t seed, const uint64_t* seed_dev, uint32_t salt, void* stream);
 
@@ -400,11 +404,13 @@ int mobgt_small_gemm_f32(const float* a, int64_t lda, const float* b, int64_t ld
  *   epilogue (leaky != 0):   c = dropout(leaky_relu(acc + bias, slope))  -- dropout mask as mobgt_bias_act_fwd (salt);
  *   prologue (a_mask given): a[r][k] *= m(a_mask[r][k]),  m(y) = y > 0 ? m_pos : (y < 0 ? m_neg : m_zero)
  *                            -- the derivative of that activation, taken from its OUTPUT y, applied to an incoming
- *                            gradient while it is loaded (a_mask has a's layout and lda). */
+ *                            gradient while it is loaded (a_mask has a's layout and lda);
+ *   c_t_bf16 (optional):     the result times c_t_scale[row] (or 1) also -- or only, with c null -- as bf16 TRANSPOSED
+ *                            [N][ld_t]: the operand layout of mobgt_mask_gemm, which then needs no transpose launch. */
 int mobgt_small_gemm_f32_act(const float* a, int64_t lda, const float* a_mask, float m_pos, float m_neg, float m_zero,
                              const float* b, int64_t ldb, int b_is_nk, const float* bias, int leaky, float slope,
                              float dropout_p, uint64_t seed, const uint64_t* seed_dev, uint32_t salt, void* c, int64_t ldc,
-                             int c_dtype, int M, int N, int K, void* stream);
+                             int c_dtype, void* c_t_bf16, int64_t ld_t, const float* c_t_scale, int M, int N, int K, void* stream);
 
 /* GraphConvolution's adjacency product `torch.spmm(adj, support)` (graphormer/modelGNN.py:38-44) for a normalised
  * adjacency held as CSR (csrc/spmm.hip) -- the form that exists at P = 100 000 POIs (BASELINE configs[4]).
@@ -465,7 +471,8 @@ int mobgt_small_gcn_bwd(const float* g, const float* ax, const float* a_t, const
  * row i = entry (i,k), bits >= K zero; x [K,N] f32 (rounded
  * to bf16 as MFMA operand, f32 accumulate), out [M,N] f32, N in {16, 32, 48, 64}.
  * work: mobgt_mask_gemm_workspace_bytes(K, N) bytes of device scratch (the operand transposed to bf16 [N][K], written by
- * a first small launch so that the product reads 16 bytes per MFMA operand). */
+ * a first small launch so that the product reads 16 bytes per MFMA operand).  x null: `work` ALREADY holds that operand
+ * (bf16 [N][roundup(K,128)], times bscale, zero beyond K), written by the kernel that produced x. */
 int64_t mobgt_mask_gemm_workspace_bytes(int K, int N);
 int mobgt_mask_gemm(const uint32_t* mask, int64_t ld_mask_words, const float* x, int64_t ldx, const float* bscale,
                     const float* rscale, const float* bias, float* out, int64_t ld_out, void* work, int M, int K, int N,

@@ -1026,6 +1026,8 @@ struct BiasActParams {
     uint64_t seed;
     const uint64_t* seed_dev;
     uint32_t salt;
+    bf16_t* yt;                              // forward, optional: y transposed as bf16 [C][ldt] (the bitmask adjacency product's
+    int64_t ldt;                             // operand layout, csrc/maskgemm.hip: no transpose launch in front of it)
 };
 
 template <bool BWD>
@@ -1055,6 +1057,10 @@ __global__ __launch_bounds__(256) void bias_act_kernel(const BiasActParams p) {
                     o[i] = a * keep;
                 }
                 st4<float>(p.y + r * p.C + c, o);
+                if (p.yt) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) p.yt[(int64_t)(c + i) * p.ldt + r] = (bf16_t)o[i];
+                }
             } else {
                 float y4[4];
                 ld4<float>(p.dy + r * p.C + c, v);
@@ -1105,6 +1111,16 @@ extern "C" int mobgt_bias_act_fwd(const float* x, const float* bias, float* y, i
                                   uint64_t seed, const uint64_t* seed_dev, uint32_t salt, void* stream) {
     BiasActParams p = {};
     p.x = x; p.bias = bias; p.y = y; p.R = R; p.C = C; p.slope = slope; p.seed = seed; p.seed_dev = seed_dev; p.salt = salt;
+    return launch_bias_act(p, false, dropout_p, (hipStream_t)stream);
+}
+
+extern "C" int mobgt_bias_act_fwd_t(const float* x, const float* bias, float* y, void* y_t_bf16, int64_t ld_t, int64_t R, int C,
+                                    float slope, float dropout_p, uint64_t seed, const uint64_t* seed_dev, uint32_t salt,
+                                    void* stream) {
+    if (y_t_bf16 && ld_t < R) return MOBGT_EBADDIM;
+    BiasActParams p = {};
+    p.x = x; p.bias = bias; p.y = y; p.R = R; p.C = C; p.slope = slope; p.seed = seed; p.seed_dev = seed_dev; p.salt = salt;
+    p.yt = reinterpret_cast<bf16_t*>(y_t_bf16); p.ldt = ld_t;
     return launch_bias_act(p, false, dropout_p, (hipStream_t)stream);
 }
 

@@ -161,8 +161,10 @@ extern "C" int mobgt_mask_gemm(const uint32_t* mask, int64_t ld_mask_words, cons
     MaskGemmParams p = {mask, ld_mask_words, x, ldx, reinterpret_cast<const uint16_t*>(work), ldxt, bscale, rscale, bias, out,
                         ld_out, M, K, N};
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(xt_kernel, dim3((unsigned)(ldxt / 64)), dim3(256), 0, st, x, ldx, bscale, reinterpret_cast<uint16_t*>(work),
-                       ldxt, K, N);
+    // x null: `work` already holds the operand transposed (bf16 [N][ldxt], scaled, zero beyond K) -- written by its producer
+    // (mobgt_bias_act_fwd_t / mobgt_small_gemm_f32_act), no transpose launch
+    if (x) hipLaunchKernelGGL(xt_kernel, dim3((unsigned)(ldxt / 64)), dim3(256), 0, st, x, ldx, bscale, reinterpret_cast<uint16_t*>(work),
+                              ldxt, K, N);
     // every workgroup walks ALL of X: tall row blocks (64 rows share each operand load) and 16 waves on K keep both the
     // L2 -> CU traffic (P/64 x |X|) and the per-wave chain of k-steps short
     if (N == 16) hipLaunchKernelGGL((mask_gemm_kernel<1, 16, 4>), dim3((M + 63) / 64), dim3(1024), 0, st, p);

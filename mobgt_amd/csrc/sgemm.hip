@@ -35,6 +35,11 @@ struct SgemmParams {
     // of that activation applied to an incoming gradient while it is loaded (amask = the activation's OUTPUT, ld = lda)
     const float* amask;
     float mpos, mneg, mzero;
+    // optional: the result (times ct_scale[row]) ALSO / ONLY (C null) as bf16 transposed [N][ldt] -- the operand layout of the
+    // bitmask adjacency product (csrc/maskgemm.hip), so that no transpose launch stands between the two
+    bf16_t* ct;
+    int64_t ldt;
+    const float* ct_scale;
 };
 
 __device__ __forceinline__ float act_mask(float y, float pos, float neg, float zer) { return y > 0.f ? pos : (y < 0.f ? neg : zer); }
@@ -128,8 +133,11 @@ __global__ __launch_bounds__(64) void sgemm_kernel(const SgemmParams p) {
                         o = dropout_bits16(seed, rowh, (uint32_t)c) >= p.thr ? o * p.inv_keep : 0.f;
                     }
                 }
-                if (p.c_bf16) reinterpret_cast<bf16_t*>(p.C)[(int64_t)r * p.ldc + c] = (bf16_t)o;
-                else reinterpret_cast<float*>(p.C)[(int64_t)r * p.ldc + c] = o;
+                if (p.C) {
+                    if (p.c_bf16) reinterpret_cast<bf16_t*>(p.C)[(int64_t)r * p.ldc + c] = (bf16_t)o;
+                    else reinterpret_cast<float*>(p.C)[(int64_t)r * p.ldc + c] = o;
+                }
+                if (EXT && p.ct) p.ct[(int64_t)c * p.ldt + r] = (bf16_t)(p.ct_scale ? o * p.ct_scale[r] : o);
             }
         }
     }
@@ -151,7 +159,7 @@ int launch_x(const SgemmParams& p, bool b_nk, bool vec, hipStream_t st) {
 
 template <int NB>
 int launch(const SgemmParams& p, bool b_nk, bool vec, hipStream_t st) {
-    return (p.act || p.amask) ? launch_x<NB, true>(p, b_nk, vec, st) : launch_x<NB, false>(p, b_nk, vec, st);
+    return (p.act || p.amask || p.ct) ? launch_x<NB, true>(p, b_nk, vec, st) : launch_x<NB, false>(p, b_nk, vec, st);
 }
 
 }  // namespace
@@ -161,6 +169,7 @@ int run(SgemmParams& p, int b_is_nk, int c_dtype, void* stream) {
     if (p.M <= 0 || p.N <= 0 || p.K <= 0) return MOBGT_EBADDIM;
     if (c_dtype != MOBGT_F32 && c_dtype != MOBGT_BF16) return MOBGT_EDTYPE;
     if ((((uintptr_t)p.A | (uintptr_t)p.B | (uintptr_t)p.amask) & 3) || ((uintptr_t)p.C & (c_dtype == MOBGT_F32 ? 3 : 1))) return MOBGT_EALIGN;
+    if (!p.C && !p.ct) return MOBGT_EBADDIM;
     p.c_bf16 = c_dtype == MOBGT_BF16;
     // float4 operand loads: every row 16-byte aligned and K a whole number of 16-deep steps
     const bool vec = (p.K % 16 == 0) && (p.lda % 4 == 0) && ((((uintptr_t)p.A | (uintptr_t)p.amask) & 15) == 0) &&
@@ -188,8 +197,11 @@ extern "C" int mobgt_small_gemm_f32(const float* a, int64_t lda, const float* b,
 extern "C" int mobgt_small_gemm_f32_act(const float* a, int64_t lda, const float* a_mask, float m_pos, float m_neg, float m_zero,
                                         const float* b, int64_t ldb, int b_is_nk, const float* bias, int leaky, float slope,
                                         float dropout_p, uint64_t seed, const uint64_t* seed_dev, uint32_t salt, void* c,
-                                        int64_t ldc, int c_dtype, int M, int N, int K, void* stream) {
+                                        int64_t ldc, int c_dtype, void* c_t_bf16, int64_t ld_t, const float* c_t_scale, int M,
+                                        int N, int K, void* stream) {
     SgemmParams p = {};
+    if (c_t_bf16 && ld_t < M) return MOBGT_EBADDIM;
+    p.ct = reinterpret_cast<bf16_t*>(c_t_bf16); p.ldt = ld_t; p.ct_scale = c_t_scale;
     p.A = a; p.lda = lda; p.B = b; p.ldb = ldb; p.bias = bias; p.C = c; p.ldc = ldc; p.M = M; p.N = N; p.K = K;
     p.amask = a_mask; p.mpos = m_pos; p.mneg = m_neg; p.mzero = m_zero;
     p.act = leaky; p.slope = slope;

@@ -174,15 +174,37 @@ class MaskAdj:
         return pack(m), pack(m.T.copy()), scale
 
 
-def mask_gemm(adj, x, transposed=False, bias=None):
-    """adj @ x (or adj^T @ x) -> f32 [P, N] through csrc/maskgemm.hip; x f32 [P, N], N in {16, 32, 48, 64}."""
+_XT_WORK = {}
+
+
+def xt_workspace(device, P, N, slot=0):
+    """The bitmask product's operand buffer, bf16 [N, roundup(P, 128)], kept per (device, P, N, slot) and ZERO beyond column P
+    (the kernels that fill it write columns < P only): a producer that writes its result there transposed
+    (ops.bias_act(yt=), ops.small_gemm(ct=)) saves the transpose launch in front of `mask_gemm`."""
+    key = (str(device), int(P), int(N), int(slot))
+    t = _XT_WORK.get(key)
+    if t is None:
+        t = _XT_WORK[key] = torch.zeros(N, (P + 127) // 128 * 128, dtype=torch.bfloat16, device=device)
+    return t
+
+
+def mask_gemm(adj, x, transposed=False, bias=None, xt=None):
+    """adj @ x (or adj^T @ x) -> f32 [P, N] through csrc/maskgemm.hip; x f32 [P, N], N in {16, 32, 48, 64}.
+    `xt` (an `xt_workspace` that already holds x transposed -- for the transposed product: times adj.scale per row of x):
+    x itself is not read."""
     from . import _lib
     from .ops import _p, _stream
+    mask = adj.mask_t if transposed else adj.mask
+    if xt is not None:
+        N, P = xt.shape[0], adj.scale.numel()
+        out = torch.empty(P, N, dtype=torch.float32, device=xt.device)
+        _lib.check(_lib.lib().mobgt_mask_gemm(_p(mask), mask.shape[1], None, 0, None, _p(None if transposed else adj.scale),
+                                              _p(bias), _p(out), N, _p(xt), P, P, N, _stream()), "mobgt_mask_gemm")
+        return out
     x = x.contiguous()
     P, N = x.shape
     out = torch.empty(P, N, dtype=torch.float32, device=x.device)
     work = torch.empty(int(_lib.lib().mobgt_mask_gemm_workspace_bytes(P, N)), dtype=torch.uint8, device=x.device)
-    mask = adj.mask_t if transposed else adj.mask
     _lib.check(_lib.lib().mobgt_mask_gemm(_p(mask), mask.shape[1], _p(x), x.stride(0), _p(adj.scale if transposed else None),
                                           _p(None if transposed else adj.scale), _p(bias), _p(out), N, _p(work), P, P, N,
                                           _stream()), "mobgt_mask_gemm")
@@ -224,9 +246,10 @@ class _ConvActFn(torch.autograd.Function):
     `ax`: the precomputed adj @ x of the first layer (x constant), else `adj` is a MaskAdj and adj @ x is a mask GEMM."""
 
     @staticmethod
-    def forward(ctx, x, ax, weight, bias, adj, slope, p_drop, seed, seed_dev, salt):
+    def forward(ctx, x, ax, weight, bias, adj, slope, p_drop, seed, seed_dev, salt, xt=None):
         from . import ops
-        t = ax if ax is not None else mask_gemm(adj, x)                 # [P, in] f32
+        # (`xt`: x already transposed to the product's operand layout by the launch that produced it)
+        t = ax if ax is not None else mask_gemm(adj, x, xt=xt.t if xt is not None else None)       # [P, in] f32
         y = ops.small_gemm(t, weight, bias, leaky=slope, drop=(p_drop, seed, seed_dev, salt) if p_drop > 0 else None)
         ctx.save_for_backward(t, weight, y)
         ctx.adj = adj if ax is None else None
@@ -242,9 +265,13 @@ class _ConvActFn(torch.autograd.Function):
         dW = ops.linear_wgrad_masked(t, g, x_mask=y, mask_vals=ctx.mv, db=db, db_of_x=True)      # t^T (g * m(y)), db = colsum
         dx = None
         if ctx.adj is not None and ctx.needs_input_grad[0]:
-            dt = ops.small_gemm(g, weight, b_is_nk=True, a_mask=(y, *ctx.mv))                    # (g * m(y)) W^T  [P, in]
-            dx = mask_gemm(ctx.adj, dt, transposed=True)                                         # adj^T @ dt
-        return dx, None, dW, db, None, None, None, None, None, None
+            # dt = (g * m(y)) W^T [P, in] leaves the GEMM transposed, scaled by 1/(deg+1) and in bf16 -- the operand of
+            # adj^T @ dt -- and nowhere else
+            P, K = t.shape
+            buf = xt_workspace(g.device, P, K, slot=1)
+            ops.small_gemm(g, weight, b_is_nk=True, a_mask=(y, *ctx.mv), ct=(buf, ctx.adj.scale, True))
+            dx = mask_gemm(ctx.adj, None, transposed=True, xt=buf)                               # adj^T @ dt
+        return dx, None, dW, db, None, None, None, None, None, None, None
 
 
 def _conv_act_ok(t_cols, weight, bias):
@@ -473,12 +500,23 @@ class GCN(nn.Module):
                         and _mask_conv_ok(x, gc.weight) and _conv_act_ok(x.shape[1], gc.weight, gc.bias)):
                     # ... and no launch for the activation at all: GEMM epilogue forward, masked operand loads backward
                     seed, seed_dev = ops.dropout_seed(p_drop)
+                    xt = getattr(x, "_mobgt_xt", None)
                     with torch.autocast(device_type="cuda", enabled=False):
                         x = _ConvActFn.apply(None if pre is not None else x, pre, gc.weight, gc.bias, mask_adj,
-                                             float(self.leaky_relu.negative_slope), float(p_drop), seed, seed_dev, salt)
+                                             float(self.leaky_relu.negative_slope), float(p_drop), seed, seed_dev, salt,
+                                             ops._OutRef(xt) if xt is not None else None)
                     continue
                 h = gc(x, adj, pre, adj_t, bias=False, mask_adj=mask_adj)
-                x = ops.bias_act(h, gc.bias, self.leaky_relu.negative_slope, p_drop, self.training, salt)
+                # when the next layer is a bitmask product, the activation also leaves its result in that product's operand
+                # layout (no transpose launch)
+                nxt = self.gcn[i + 1] if i + 1 < n_hidden else None
+                yt = None
+                if (nxt is not None and mask_adj is not None and not isinstance(adj, CsrAdj) and h.dim() == 2
+                        and h.shape[1] in (16, 32, 48, 64) and _conv_act_ok(h.shape[1], nxt.weight, nxt.bias)):
+                    yt = xt_workspace(h.device, h.shape[0], h.shape[1], slot=0)
+                x = ops.bias_act(h, gc.bias, self.leaky_relu.negative_slope, p_drop, self.training, salt, yt=yt)
+                if yt is not None:
+                    x._mobgt_xt = yt
         else:
             for i in range(n_hidden):
                 x = self.leaky_relu(self.gcn[i](x, adj, adj_x if i == 0 else None, adj_t, mask_adj=mask_adj))

@@ -847,12 +847,13 @@ def dropout(x, p, training, salt):
 
 class _BiasActFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, bias, slope, p_drop, seed, seed_dev, salt):
+    def forward(ctx, x, bias, slope, p_drop, seed, seed_dev, salt, yt=None):
         x = x.contiguous()
         R, C = x.shape
         y = torch.empty_like(x)
-        check(_lib.lib().mobgt_bias_act_fwd(_p(x), _p(bias), _p(y), R, C, slope, p_drop, seed, _p(seed_dev), salt, _stream()),
-              "mobgt_bias_act_fwd")
+        check(_lib.lib().mobgt_bias_act_fwd_t(_p(x), _p(bias), _p(y), _p(yt.t if yt is not None else None),
+                                              yt.t.stride(0) if yt is not None else 0, R, C, slope, p_drop, seed, _p(seed_dev), salt,
+                                              _stream()), "mobgt_bias_act_fwd_t")
         ctx.save_for_backward(y)
         ctx.misc = (slope, p_drop, seed, seed_dev, salt, bias is not None)
         return y
@@ -866,7 +867,7 @@ class _BiasActFn(torch.autograd.Function):
         db = zeros_f32((C,), y.device) if has_bias else None
         check(_lib.lib().mobgt_bias_act_bwd(_p(dy.contiguous()), _p(y), _p(dx), _p(db), R, C, slope, p_drop, seed, _p(seed_dev),
                                             salt, _stream()), "mobgt_bias_act_bwd")
-        return dx, db, None, None, None, None, None
+        return dx, db, None, None, None, None, None, None
 
 
 def dropout_seed(p_drop):
@@ -878,15 +879,17 @@ def dropout_seed(p_drop):
     return int(seed), seed_dev
 
 
-def bias_act(x, bias, slope, p_drop, training, salt):
-    """dropout(leaky_relu(x + bias, slope)) on a 2-D f32 tensor in one launch; the backward also yields bias.grad."""
+def bias_act(x, bias, slope, p_drop, training, salt, yt=None):
+    """dropout(leaky_relu(x + bias, slope)) on a 2-D f32 tensor in one launch; the backward also yields bias.grad.
+    `yt`: a bf16 [C, ld >= R] buffer that also receives the result transposed (modelGNN.xt_workspace)."""
     _require_cuda(x)
     if not training:
         p_drop = 0.0
     seed, seed_dev = _DROPOUT_STATE["seed"], _DROPOUT_STATE["seed_dev"]
     if seed_dev is None and p_drop > 0:
         seed = (seed + int(torch.randint(0, 2 ** 31 - 1, (1,)).item())) & 0x7FFFFFFFFFFFFFFF
-    return _BiasActFn.apply(x.float(), bias, float(slope), float(p_drop), int(seed), seed_dev, int(salt) & 0xFFFFFFFF)
+    return _BiasActFn.apply(x.float(), bias, float(slope), float(p_drop), int(seed), seed_dev, int(salt) & 0xFFFFFFFF,
+                            _OutRef(yt) if yt is not None else None)
 
 
 class _HeadActFn(torch.autograd.Function):
@@ -1020,11 +1023,13 @@ def assemble_tokens(nf, real, add, token, pe0, p_pos, p_in, training, salts=(0x1
 
 
 # ------------------------------------------------------------------- small f32 GEMMs (GCN / fuse / head)
-def small_gemm(a, b, bias=None, b_is_nk=False, out=None, out_dtype=torch.float32, leaky=None, drop=None, a_mask=None):
+def small_gemm(a, b, bias=None, b_is_nk=False, out=None, out_dtype=torch.float32, leaky=None, drop=None, a_mask=None, ct=None):
     """a [M,K] @ (b.T if b_is_nk else b) (+ bias) -> f32 [M,N] on csrc/sgemm.hip (one wave per 16-row tile, f32 MFMA).
     No autograd.  Operands may be row-strided views (unit column stride).
     `leaky` (slope): LeakyReLU on the way out; `drop` = (p, seed, seed_dev, salt): then dropout (mobgt_bias_act_fwd's mask).
-    `a_mask` = (y, pos, neg, zero): a is multiplied elementwise by m(y) while it is loaded (y: a's shape and row stride)."""
+    `a_mask` = (y, pos, neg, zero): a is multiplied elementwise by m(y) while it is loaded (y: a's shape and row stride).
+    `ct` = (buffer bf16 [N, ld], row_scale f32 [M] or None, only): the result (times row_scale) also as bf16 TRANSPOSED into
+    `buffer` (modelGNN.xt_workspace: the bitmask adjacency product's operand); `only`: no [M,N] result at all (returns None)."""
     _require_cuda(a, b)
     assert a.dtype == torch.float32 and b.dtype == torch.float32 and a.dim() == 2 and b.dim() == 2
     assert a.stride(1) == 1 and b.stride(1) == 1
@@ -1033,8 +1038,9 @@ def small_gemm(a, b, bias=None, b_is_nk=False, out=None, out_dtype=torch.float32
     assert (b.shape[1] if b_is_nk else b.shape[0]) == K
     if bias is not None:
         assert bias.dtype == torch.float32 and bias.numel() == N and bias.is_contiguous()
-    c = out if out is not None else torch.empty(M, N, dtype=out_dtype, device=a.device)
-    if leaky is None and a_mask is None:
+    only_t = ct is not None and ct[2]
+    c = None if only_t else (out if out is not None else torch.empty(M, N, dtype=out_dtype, device=a.device))
+    if leaky is None and a_mask is None and ct is None:
         check(_lib.lib().mobgt_small_gemm_f32(_p(a), a.stride(0), _p(b), b.stride(0), int(b_is_nk), _p(bias), _p(c), c.stride(0),
                                               _DT[c.dtype], M, N, K, _stream()), "mobgt_small_gemm_f32")
         return c
@@ -1044,8 +1050,10 @@ def small_gemm(a, b, bias=None, b_is_nk=False, out=None, out_dtype=torch.float32
     p_drop, seed, seed_dev, salt = drop if drop is not None else (0.0, 0, None, 0)
     check(_lib.lib().mobgt_small_gemm_f32_act(_p(a), a.stride(0), _p(y), float(pos), float(neg), float(zer), _p(b), b.stride(0),
                                               int(b_is_nk), _p(bias), int(leaky is not None), float(leaky or 0.0), float(p_drop),
-                                              int(seed), _p(seed_dev), int(salt) & 0xFFFFFFFF, _p(c), c.stride(0), _DT[c.dtype],
-                                              M, N, K, _stream()), "mobgt_small_gemm_f32_act")
+                                              int(seed), _p(seed_dev), int(salt) & 0xFFFFFFFF, _p(c), c.stride(0) if c is not None else N,
+                                              _DT[c.dtype] if c is not None else F32, _p(ct[0] if ct else None),
+                                              ct[0].stride(0) if ct else 0, _p(ct[1] if ct else None), M, N, K, _stream()),
+          "mobgt_small_gemm_f32_act")
     return c
 
 
