@@ -319,10 +319,11 @@ int mobgt_linear_wgrad(const void* g, int64_t ldg, const void* x, int64_t ldx, f
                        int64_t R, int M, int N, int act_dtype, void* stream);
 /* ... with f32 operands and the activation derivative m(.) of mobgt_small_gemm_f32_act applied to g and / or x while they
  * are loaded (g_mask / x_mask: the activation's output, the operand's layout; either may be null).  db_of_x: db is [N] and
- * receives the column sums of the (masked) x instead of g. */
+ * receives the column sums of the (masked) x instead of g.  g_masked_out (optional, g's layout, f32): the masked g itself,
+ * for a data-gradient GEMM that follows. */
 int mobgt_linear_wgrad_masked(const float* g, int64_t ldg, const float* x, int64_t ldx, const float* g_mask, const float* x_mask,
-                              float m_pos, float m_neg, float m_zero, float* dw, int64_t ldw, float* db, int db_of_x, int64_t R,
-                              int M, int N, void* stream);
+                              float m_pos, float m_neg, float m_zero, float* g_masked_out, float* dw, int64_t ldw, float* db,
+                              int db_of_x, int64_t R, int M, int N, void* stream);
 /* dw [M,N] (ZERO on entry) = g^T x + out_bias[n] on every row: the same split-K kernel used as a skinny product with a
  * bias -- `adj[rows] @ support + b` of the last GraphConvolution (modelGNN.py:38-44) without an add launch. */
 int mobgt_linear_wgrad_bias(const void* g, int64_t ldg, const void* x, int64_t ldx, const float* out_bias, float* dw,

@@ -46,7 +46,7 @@ SIGNATURES = {
     "mobgt_layer_backward_tail": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _i, _vp, _i64, _vp, _i64, _vp, _i64,
                                        _i, _i, _i, _vp]),
     "mobgt_linear_wgrad": (_i, [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _i, _i, _i, _vp]),
-    "mobgt_linear_wgrad_masked": (_i, [_vp, _i64, _vp, _i64, _vp, _vp, _f, _f, _f, _vp, _i64, _vp, _i, _i64, _i, _i, _vp]),
+    "mobgt_linear_wgrad_masked": (_i, [_vp, _i64, _vp, _i64, _vp, _vp, _f, _f, _f, _vp, _vp, _i64, _vp, _i, _i64, _i, _i, _vp]),
     "mobgt_linear_wgrad_bias": (_i, [_vp, _i64, _vp, _i64, _vp, _vp, _i64, _i64, _i, _i, _i, _vp]),
     "mobgt_linear_wgrad_mixed": (_i, [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _i, _i, _vp]),
     "mobgt_embed_gather_sum": (_i, [_vp, _vp, _i, _vp, _i64, _i, _i64, _i, _vp]),

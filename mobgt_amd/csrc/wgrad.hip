@@ -44,6 +44,8 @@ struct WgradParams {
     float mpos, mneg, mzero;
     int db_x;                            // db [N] += column sums of (the masked) x instead of g
     const float* out_bias;               // [N] or null: added to every row of dw (the product used as  A^T B + bias)
+    float* gm_out;                       // or null: the masked g (f32, g's layout) written out by the first tile column --
+                                         // the data-gradient GEMM that follows then needs no elementwise launch either
 };
 
 __device__ __forceinline__ void split_pairs(const uint32_t (&d)[8], bf16x8& even, bf16x8& odd) {
@@ -67,13 +69,17 @@ __device__ __forceinline__ uint32_t pack_pair(const float* p) {
     return __builtin_bit_cast(uint32_t, o);
 }
 
-__device__ __forceinline__ uint32_t pack_pair_masked(const float* p, const float* m, float pos, float neg, float zer) {
+__device__ __forceinline__ uint32_t pack_pair_masked(const float* p, const float* m, float pos, float neg, float zer,
+                                                     float* keep = nullptr) {
     typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
-    const float2 v = *reinterpret_cast<const float2*>(p);
+    float2 v = *reinterpret_cast<const float2*>(p);
     const float2 y = *reinterpret_cast<const float2*>(m);
+    v.x *= y.x > 0.f ? pos : (y.x < 0.f ? neg : zer);
+    v.y *= y.y > 0.f ? pos : (y.y < 0.f ? neg : zer);
+    if (keep) *reinterpret_cast<float2*>(keep) = v;
     bf16x2 o;
-    o[0] = (bf16_t)(v.x * (y.x > 0.f ? pos : (y.x < 0.f ? neg : zer)));
-    o[1] = (bf16_t)(v.y * (y.y > 0.f ? pos : (y.y < 0.f ? neg : zer)));
+    o[0] = (bf16_t)v.x;
+    o[1] = (bf16_t)v.y;
     return __builtin_bit_cast(uint32_t, o);
 }
 
@@ -81,14 +87,15 @@ struct Slab {
     uint32_t g[8], x[8];
     template <bool F32>
     __device__ __forceinline__ void load_masked(const WgradParams& p, const void* gp, const void* xp, const float* gm, const float* xm,
-                                                int r0, int k1, bool m_ok, bool n_ok) {
+                                                int r0, int k1, bool m_ok, bool n_ok, float* gkeep = nullptr) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int r = r0 + j;
             const bool ok = r < k1;
             const float* gq = reinterpret_cast<const float*>(gp) + (int64_t)r * p.ldg;
             const float* xq = reinterpret_cast<const float*>(xp) + (int64_t)r * p.ldx;
-            g[j] = !(ok && m_ok) ? 0u : (gm ? pack_pair_masked(gq, gm + (int64_t)r * p.ldg, p.mpos, p.mneg, p.mzero) : pack_pair(gq));
+            g[j] = !(ok && m_ok) ? 0u : (gm ? pack_pair_masked(gq, gm + (int64_t)r * p.ldg, p.mpos, p.mneg, p.mzero,
+                                                               gkeep ? gkeep + (int64_t)r * p.ldg : nullptr) : pack_pair(gq));
             x[j] = !(ok && n_ok) ? 0u : (xm ? pack_pair_masked(xq, xm + (int64_t)r * p.ldx, p.mpos, p.mneg, p.mzero) : pack_pair(xq));
         }
     }
@@ -139,8 +146,9 @@ __device__ __forceinline__ void wgrad_body(const WgradParams& p, const int tile,
     const bool masked = F32 && (p.gmask || p.xmask);
     const float* gm = masked && p.gmask ? p.gmask + m0 + 2 * i : nullptr;
     const float* xm = masked && p.xmask ? p.xmask + n0 + 2 * i : nullptr;
+    float* gkeep = (masked && gm && p.gm_out && n0 == 0) ? p.gm_out + m0 + 2 * i : nullptr;
     auto fetch = [&](Slab& s_, int r0_) {
-        if (masked) s_.template load_masked<F32>(p, gp, xp, gm, xm, r0_, k1, m_ok, n_ok);
+        if (masked) s_.template load_masked<F32>(p, gp, xp, gm, xm, r0_, k1, m_ok, n_ok, gkeep);
         else s_.template load<F32, XF32>(gp, xp, p.ldg, p.ldx, r0_, k1, m_ok, n_ok);
     };
     int kb = k0 + wave * KSTEP;
@@ -262,7 +270,7 @@ int fill_problem(WgradParams& p, const void* g, int64_t ldg, const void* x, int6
     if (R <= 0 || M <= 0 || N <= 0 || (M & 1) || (N & 1) || (ldg & 1) || (ldx & 1) || R > 0x7fffffff) return MOBGT_EBADDIM;
     if (((uintptr_t)g & (in_f32 == 1 ? 7 : 3)) || ((uintptr_t)x & (in_f32 ? 7 : 3))) return MOBGT_EALIGN;
     p.in_f32 = in_f32;
-    p.gmask = p.xmask = nullptr; p.mpos = p.mneg = p.mzero = 1.f; p.db_x = 0; p.out_bias = nullptr;
+    p.gmask = p.xmask = nullptr; p.mpos = p.mneg = p.mzero = 1.f; p.db_x = 0; p.out_bias = nullptr; p.gm_out = nullptr;
     p.g = reinterpret_cast<const uint16_t*>(g); p.ldg = ldg;
     p.x = reinterpret_cast<const uint16_t*>(x); p.ldx = ldx;
     p.dw = dw; p.ldw = ldw; p.db = db;
@@ -355,8 +363,8 @@ extern "C" int mobgt_linear_wgrad(const void* g, int64_t ldg, const void* x, int
 
 /* f32 operands with the derivative of dropout(leaky_relu(.)) applied to g and / or x while loading (see WgradParams). */
 extern "C" int mobgt_linear_wgrad_masked(const float* g, int64_t ldg, const float* x, int64_t ldx, const float* g_mask,
-                                         const float* x_mask, float m_pos, float m_neg, float m_zero, float* dw, int64_t ldw,
-                                         float* db, int db_of_x, int64_t R, int M, int N, void* stream) {
+                                         const float* x_mask, float m_pos, float m_neg, float m_zero, float* g_masked_out,
+                                         float* dw, int64_t ldw, float* db, int db_of_x, int64_t R, int M, int N, void* stream) {
     if (R == 0) return 0;
     if (((uintptr_t)g_mask | (uintptr_t)x_mask) & 7) return MOBGT_EALIGN;
     WgradParams p;
@@ -365,6 +373,7 @@ extern "C" int mobgt_linear_wgrad_masked(const float* g, int64_t ldg, const floa
     const int rc = fill_problem(p, g, ldg, x, ldx, dw, ldw, db, R, M, N, nwave == 8 ? 512 : 256, &tiles, &splits, 1, nwave);
     if (rc) return rc;
     p.gmask = g_mask; p.xmask = x_mask; p.mpos = m_pos; p.mneg = m_neg; p.mzero = m_zero; p.db_x = db_of_x;
+    p.gm_out = g_mask ? g_masked_out : nullptr;
     if (nwave == 8) hipLaunchKernelGGL(wgrad_kernel<8>, dim3(tiles, splits), dim3(8 * 64), 0, (hipStream_t)stream, p);
     else hipLaunchKernelGGL(wgrad_kernel<16>, dim3(tiles, splits), dim3(16 * 64), 0, (hipStream_t)stream, p);
     return (int)hipGetLastError();

@@ -767,6 +767,14 @@ class _LinearSplitKFn(torch.autograd.Function):
                 db = zeros_f32((g.shape[1],), g.device)
                 dw = linear_wgrad_masked(g, x, g_mask=y, mask_vals=mv, db=db)
                 return small_gemm(g, w, a_mask=(y, *mv)), dw, db, None, None, None
+            if (hip_wgrad and g.stride(1) == 1 and y.stride() == g.stride() and g.data_ptr() % 8 == 0 and y.data_ptr() % 8 == 0
+                    and g.stride(0) % 2 == 0):
+                # the weight-gradient kernel applies the activation's derivative while it loads g, sums the bias gradient and
+                # leaves the masked g for the (library) data-gradient GEMM: no elementwise launch
+                gm = torch.empty_strided(g.shape, g.stride(), dtype=torch.float32, device=g.device)
+                db = zeros_f32((g.shape[1],), g.device)
+                dw = linear_wgrad_masked(g, x, g_mask=y, mask_vals=mv, db=db, g_out=gm)
+                return gm @ w, dw, db, None, None, None
             g = torch.ops.aten.leaky_relu_backward(g, y, ctx.slope, True).contiguous()      # (from the activation's result)
         if hip_wgrad:
             # bf16 configuration: weight AND bias gradient from the split-K MFMA kernel (operands rounded to bf16 while
@@ -1067,9 +1075,10 @@ def act_mask_values(slope, p_drop):
     return 1.0, slope, slope
 
 
-def linear_wgrad_masked(g, x, g_mask=None, x_mask=None, mask_vals=(1.0, 1.0, 1.0), db=None, db_of_x=False, dw=None):
+def linear_wgrad_masked(g, x, g_mask=None, x_mask=None, mask_vals=(1.0, 1.0, 1.0), db=None, db_of_x=False, dw=None, g_out=None):
     """dW [M,N] = (g * m(g_mask))^T (x * m(x_mask)) for f32 row-major g [R,M], x [R,N] (operands rounded to bf16 while
-    loading, f32 accumulate); db (zero-initialised f32): += column sums of the masked g ([M]) or, `db_of_x`, x ([N])."""
+    loading, f32 accumulate); db (zero-initialised f32): += column sums of the masked g ([M]) or, `db_of_x`, x ([N]).
+    `g_out` (f32, g's shape and strides): also receives g * m(g_mask) (for the data-gradient GEMM that follows)."""
     _require_cuda(g, x)
     R, M = g.shape
     N = x.shape[1]
@@ -1078,9 +1087,10 @@ def linear_wgrad_masked(g, x, g_mask=None, x_mask=None, mask_vals=(1.0, 1.0, 1.0
         assert m is None or (m.dtype == torch.float32 and m.shape == t.shape and m.stride() == t.stride())
     if dw is None:
         dw = zeros_f32((M, N), g.device)
+    assert g_out is None or (g_mask is not None and g_out.shape == g.shape and g_out.stride() == g.stride())
     check(_lib.lib().mobgt_linear_wgrad_masked(_p(g), g.stride(0), _p(x), x.stride(0), _p(g_mask), _p(x_mask), float(mask_vals[0]),
-                                               float(mask_vals[1]), float(mask_vals[2]), _p(dw), N, _p(db), int(db_of_x), R, M, N,
-                                               _stream()), "mobgt_linear_wgrad_masked")
+                                               float(mask_vals[1]), float(mask_vals[2]), _p(g_out), _p(dw), N, _p(db), int(db_of_x),
+                                               R, M, N, _stream()), "mobgt_linear_wgrad_masked")
     return dw
 
 
