@@ -229,10 +229,13 @@ int mobgt_embed_scatter_concat(float* const* d_tables, const void* const* indice
  * table_t[idx_t[r], :] (width_t columns, zeros where idx < 0) to buf_t[r, coff_t : coff_t + width_t] (row stride ld_t), or ADDS
  * it there when accum_t (jobs run in order: a sum of tables is a copy followed by adds) -- `[poi ; time]`, the category rows
  * and the additive degree / frequency / positional rows of model_fqandtoyo.py:1259-1298.  backward != 0: buf_t is the
- * gradient buffer, scatter-added into d_table_t (f32 atomics; rows equal to skip_t and null d_tables skipped). */
+ * gradient buffer, scatter-added into d_table_t (f32 atomics; rows equal to skip_t and null d_tables skipped); extra_row0
+ * (optional, [width of job extra_job]) is added to ROW 0 of d_table[extra_job] -- the graph token's share of pe[0]'s
+ * gradient (model_fqandtoyo.py:1338-1342), so that the positional table has ONE gradient producer. */
 int mobgt_embed_gather_multi(int n, const float* const* tables, float* const* d_tables, const void* const* idx,
                              const int64_t* skip, const int* width, const int* coff, const int* accum, float* const* buf,
-                             const int64_t* ld, int64_t R, int idx_dtype, int backward, void* stream);
+                             const int64_t* ld, int64_t R, int idx_dtype, int backward, const float* extra_row0, int extra_job,
+                             void* stream);
 /* Every row index the node-feature gathers of model_fqandtoyo.py:1259-1264 (POI / time-slot / category),
  * :1287-1298 + :348-351 (positional rows 1..n) need, derived from the padded batch in one launch.
  *   x [G,N] POI ids (0 = pad; x_dtype MOBGT_I64 / I32) and time_normal [G,N] f32, both with element strides (g, n);

@@ -53,7 +53,7 @@ SIGNATURES = {
     "mobgt_embed_scatter_add": (_i, [_vp, _vp, _vp, _i, _vp, _i64, _i, _i64, _i, _vp]),
     "mobgt_embed_gather_concat": (_i, [_vp, _vp, _vp, _i, _vp, _i64, _i64, _i, _vp]),
     "mobgt_embed_scatter_concat": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _i64, _i64, _i, _vp]),
-    "mobgt_embed_gather_multi": (_i, [_i] + [_vp] * 9 + [_i64, _i, _i, _vp]),
+    "mobgt_embed_gather_multi": (_i, [_i] + [_vp] * 9 + [_i64, _i, _i, _vp, _i, _vp]),
     "mobgt_hop_table_fwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "mobgt_hop_table_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "mobgt_target_rank": (_i, [_vp, _vp, _vp, _i64, _i64, _vp]),

@@ -111,13 +111,17 @@ struct MultiParams {
     int64_t ld[MAXJ];
     int n;
     int64_t R;
+    const float* extra_src;                 // backward, optional: a [W] vector added to ROW 0 of d_tables[extra_job] (the
+    int extra_job;                          // graph-token row's share of pe[0]'s gradient, model_fqandtoyo.py:1338-1342)
 };
 
 template <typename TI, bool BWD>
 __global__ __launch_bounds__(256) void gather_multi_kernel(const MultiParams p) {
     const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (r >= p.R) return;
     const int lane = threadIdx.x & 63;
+    if (BWD && p.extra_src && blockIdx.x == 0 && threadIdx.x < 64 && p.d_tables[p.extra_job])
+        for (int c = lane; c < p.width[p.extra_job]; c += 64) atomicAdd(p.d_tables[p.extra_job] + c, p.extra_src[c]);
+    if (r >= p.R) return;
 #pragma unroll
     for (int t = 0; t < MAXJ; ++t) {
         if (t >= p.n) break;
@@ -450,8 +454,9 @@ extern "C" int mobgt_gather_rows_t(const void* a, int64_t ld, const int64_t* row
 extern "C" int mobgt_embed_gather_multi(int n, const float* const* tables, float* const* d_tables, const void* const* idx,
                                         const int64_t* skip, const int* width, const int* coff, const int* accum,
                                         float* const* buf, const int64_t* ld, int64_t R, int idx_dtype, int backward,
-                                        void* stream) {
+                                        const float* extra_row0, int extra_job, void* stream) {
     if (n < 1 || n > MAXJ) return MOBGT_EBADDIM;
+    if (extra_row0 && (extra_job < 0 || extra_job >= n || !backward)) return MOBGT_EBADDIM;
     if (R <= 0) return 0;
     MultiParams p = {};
     for (int t = 0; t < n; ++t) {
@@ -463,7 +468,7 @@ extern "C" int mobgt_embed_gather_multi(int n, const float* const* tables, float
         p.width[t] = width[t]; p.coff[t] = coff[t]; p.accum[t] = accum ? accum[t] : 0;
         p.buf[t] = buf[t]; p.ld[t] = ld[t];
     }
-    p.n = n; p.R = R;
+    p.n = n; p.R = R; p.extra_src = extra_row0; p.extra_job = extra_job;
     const dim3 grid((unsigned)((R + 3) / 4)), block(256);
     hipStream_t st = (hipStream_t)stream;
     if (idx_dtype == MOBGT_I64) {

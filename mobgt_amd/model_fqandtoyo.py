@@ -363,7 +363,8 @@ class Graphormer(nn.Module):
         # input_dropout (:1347): one launch
         return ops.assemble_tokens(nf.view(G, N, -1), real, add.view(G, N, -1), self.graph_token.weight, self.pos_embed.pe, self.pos_embed.dropout.p,
                                    self.input_dropout.p, self.training,
-                                   bf16_copy=self.act_dtype == torch.bfloat16 and getattr(self.layers[0], "fused", False))
+                                   bf16_copy=self.act_dtype == torch.bfloat16 and getattr(self.layers[0], "fused", False),
+                                   pe_row0_via_gather=True)
 
     def validate_batch(self, batched_data):
         """Index ranges nn.Embedding would check in the reference (IndexError there; the gather kernels here do not

@@ -601,6 +601,9 @@ def embed_gather_concat(tables, indices, padding_idx=None):
     return out.view(*shape, out.shape[1])
 
 
+_ROW0_PENDING = {}      # table data_ptr -> [W] f32 gradient of its row 0 produced elsewhere, consumed by _GatherMultiFn.backward
+
+
 # ------------------------------------------------------------------ several gathers of one position list, one launch
 class _GatherMultiFn(torch.autograd.Function):
     """outs[o][r, coff : coff + W] (=, or += when accum) tables[t][idx[t][r], :] for the jobs `spec` = [(o, coff, accum,
@@ -618,8 +621,9 @@ class _GatherMultiFn(torch.autograd.Function):
             n, _ptr_array(tables), None, _ptr_array(idx), (i64 * n)(*[sp[3] for sp in spec]),
             (ci * n)(*[t.shape[1] for t in tables]), (ci * n)(*[sp[1] for sp in spec]), (ci * n)(*[int(sp[2]) for sp in spec]),
             (vp * n)(*[outs[sp[0]].data_ptr() for sp in spec]), (i64 * n)(*[outs[sp[0]].stride(0) for sp in spec]), R,
-            _IT[idx[0].dtype], 0, _stream()), "mobgt_embed_gather_multi")
+            _IT[idx[0].dtype], 0, None, 0, _stream()), "mobgt_embed_gather_multi")
         ctx.idx, ctx.spec, ctx.n = idx, spec, n
+        ctx.ptrs = [t.data_ptr() for t in tables]
         ctx.shapes = [t.shape for t in tables]
         return tuple(outs)
 
@@ -639,12 +643,18 @@ class _GatherMultiFn(torch.autograd.Function):
         if jobs:
             m = len(jobs)
             ci, i64, vp = ctypes.c_int, ctypes.c_int64, ctypes.c_void_p
+            # a row-0 gradient another node left for one of these tables (assemble_tokens: the graph token's pe[0])
+            extra, extra_job = None, 0
+            for k, t in enumerate(jobs):
+                pend = _ROW0_PENDING.pop(ctx.ptrs[t], None)
+                if pend is not None:
+                    extra, extra_job = pend, k
             check(_lib.lib().mobgt_embed_gather_multi(
                 m, None, (vp * m)(*[grads[t].data_ptr() for t in jobs]), (vp * m)(*[ctx.idx[t].data_ptr() for t in jobs]),
                 (i64 * m)(*[spec[t][3] for t in jobs]), (ci * m)(*[ctx.shapes[t][1] for t in jobs]),
                 (ci * m)(*[spec[t][1] for t in jobs]), None, (vp * m)(*[gbuf[spec[t][0]].data_ptr() for t in jobs]),
-                (i64 * m)(*[gbuf[spec[t][0]].stride(0) for t in jobs]), R, _IT[ctx.idx[0].dtype], 1, _stream()),
-                "mobgt_embed_gather_multi")
+                (i64 * m)(*[gbuf[spec[t][0]].stride(0) for t in jobs]), R, _IT[ctx.idx[0].dtype], 1, _p(extra), extra_job,
+                _stream()), "mobgt_embed_gather_multi")
         return (None, None, None, *grads, *([None] * n))
 
 
@@ -972,7 +982,8 @@ def head_input(enc, user_table, user, user_offset=0):
 
 class _AssembleTokensFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, nf, real, add, token, pe0, p_pos, p_in, seed, seed_dev, salts, side):
+    def forward(ctx, nf, real, add, token, pe0, p_pos, p_in, seed, seed_dev, salts, side, row0_via_gather=False):
+        ctx.pe_ptr = pe0.data_ptr() if (row0_via_gather and pe0.dim() == 2 and pe0.shape[0] > 1) else None
         G, N, C = nf.shape
         nf, add, real = nf.contiguous(), add.contiguous(), real.contiguous()
         shapes = (token.shape, pe0.shape)
@@ -998,7 +1009,10 @@ class _AssembleTokensFn(torch.autograd.Function):
         dout = dout.contiguous()
         d_nf = torch.empty(G, N, C, dtype=torch.float32, device=dout.device)
         d_add = torch.empty(G, N, C, dtype=torch.float32, device=dout.device)
-        if len(pshape) == 2 and pshape[0] > 1:
+        if ctx.pe_ptr is not None:
+            d_tok = zeros_f32((C,), dout.device)
+            d_pe = None
+        elif len(pshape) == 2 and pshape[0] > 1:
             d_pe = zeros_f32(tuple(pshape), dout.device)
             d_tok = d_pe[0]                       # d(token) = d(pe[0]): the same column sums
         else:
@@ -1007,10 +1021,16 @@ class _AssembleTokensFn(torch.autograd.Function):
         check(_lib.lib().mobgt_assemble_tokens_bwd(_p(dout), _p(real), _p(d_nf), _p(d_add), _p(d_tok), G, N, C, p_pos, p_in, seed,
                                                    _p(seed_dev), salts[0], salts[1], salts[2], _stream()),
               "mobgt_assemble_tokens_bwd")
-        return d_nf, None, d_add, d_tok.view(tshape), d_pe, None, None, None, None, None, None
+        if ctx.pe_ptr is not None:
+            # the positional table's other consumer (the gather of pe[1..n]) adds this row-0 share inside ITS scatter launch:
+            # one gradient producer for the table, no [L, C] zero table here and no table-sized add after
+            _ROW0_PENDING[ctx.pe_ptr] = d_tok
+            return d_nf, None, d_add, d_tok.view(tshape), None, None, None, None, None, None, None, None
+        return d_nf, None, d_add, d_tok.view(tshape), d_pe, None, None, None, None, None, None, None
 
 
-def assemble_tokens(nf, real, add, token, pe0, p_pos, p_in, training, salts=(0x1001, 0x1002, 0x1003), bf16_copy=False):
+def assemble_tokens(nf, real, add, token, pe0, p_pos, p_in, training, salts=(0x1001, 0x1002, 0x1003), bf16_copy=False,
+                    pe_row0_via_gather=False):
     """[G,N+1,C] encoder input: graph token row (+ pe[0]) and the node features (* real + add), each through the
     positional dropout and then the input dropout -- one launch forward, one backward (see mobgt_assemble_tokens_fwd).
     `token` is [C]-sized; `pe0` is pe[0] or the whole positional table [L, C] (row 0 is used); the gradient of both is
@@ -1023,8 +1043,11 @@ def assemble_tokens(nf, real, add, token, pe0, p_pos, p_in, training, salts=(0x1
     if seed_dev is None and (p_pos > 0 or p_in > 0):
         seed = (seed + int(torch.randint(0, 2 ** 31 - 1, (1,)).item())) & 0x7FFFFFFFFFFFFFFF
     side = [] if bf16_copy else None
+    # `pe_row0_via_gather`: `pe0` is the whole positional table AND its rows 1.. reach `add` through ops.embed_gather_multi in
+    # the same autograd graph: that node's backward then adds the token row's gradient to pe[0] (see _ROW0_PENDING)
     out = _AssembleTokensFn.apply(nf.float(), real.float(), add.float(), token.float(), pe0.float(), float(p_pos),
-                                  float(p_in), int(seed), seed_dev, tuple(int(s) & 0xFFFFFFFF for s in salts), side)
+                                  float(p_in), int(seed), seed_dev, tuple(int(s) & 0xFFFFFFFF for s in salts), side,
+                                  bool(pe_row0_via_gather and pe0.requires_grad and torch.is_grad_enabled()))
     if side:
         out._mobgt_act = side[0]          # bf16 copy for the first fused layer's QKV GEMM (no cast launch)
     return out
