@@ -410,11 +410,13 @@ int mobgt_small_gemm_f32(const float* a, int64_t lda, const float* b, int64_t ld
  *                            -- the derivative of that activation, taken from its OUTPUT y, applied to an incoming
  *                            gradient while it is loaded (a_mask has a's layout and lda);
  *   c_t_bf16 (optional):     the result times c_t_scale[row] (or 1) also -- or only, with c null -- as bf16 TRANSPOSED
- *                            [N][ld_t]: the operand layout of mobgt_mask_gemm, which then needs no transpose launch. */
+ *                            [N][ld_t]: the operand layout of mobgt_mask_gemm, which then needs no transpose launch;
+ *   k_b (0 = K):             b as [K,N] has only k_b <= K rows: a is zero-padded to a whole number of 16-deep k-steps
+ *                            (16-byte operand loads for a 303-wide input). */
 int mobgt_small_gemm_f32_act(const float* a, int64_t lda, const float* a_mask, float m_pos, float m_neg, float m_zero,
                              const float* b, int64_t ldb, int b_is_nk, const float* bias, int leaky, float slope,
                              float dropout_p, uint64_t seed, const uint64_t* seed_dev, uint32_t salt, void* c, int64_t ldc,
-                             int c_dtype, void* c_t_bf16, int64_t ld_t, const float* c_t_scale, int M, int N, int K, void* stream);
+                             int c_dtype, void* c_t_bf16, int64_t ld_t, const float* c_t_scale, int M, int N, int K, int k_b, void* stream);
 
 /* GraphConvolution's adjacency product `torch.spmm(adj, support)` (graphormer/modelGNN.py:38-44) for a normalised
  * adjacency held as CSR (csrc/spmm.hip) -- the form that exists at P = 100 000 POIs (BASELINE configs[4]).

@@ -69,7 +69,7 @@ SIGNATURES = {
     "mobgt_head_act_bwd": (_i, [_vp] * 9 + [_i, _i, _f, _f, _f, _u64, _vp, _c.c_uint32, _vp]),
     "mobgt_adamw_flat": (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _vp]),
     "mobgt_small_gemm_f32": (_i, [_vp, _i64, _vp, _i64, _i, _vp, _vp, _i64, _i, _i, _i, _i, _vp]),
-    "mobgt_small_gemm_f32_act": (_i, [_vp, _i64, _vp, _f, _f, _f, _vp, _i64, _i, _vp, _i, _f, _f, _u64, _vp, _c.c_uint32, _vp, _i64, _i, _vp, _i64, _vp, _i, _i, _i, _vp]),
+    "mobgt_small_gemm_f32_act": (_i, [_vp, _i64, _vp, _f, _f, _f, _vp, _i64, _i, _vp, _i, _f, _f, _u64, _vp, _c.c_uint32, _vp, _i64, _i, _vp, _i64, _vp, _i, _i, _i, _i, _vp]),
     "mobgt_layer_gemm": (_i, [_vp, _i64, _vp, _i64, _i, _vp, _vp, _i64, _i, _vp, _vp, _i, _i, _i, _vp]),
     "mobgt_ln_gemm_fwd": (_i, [_vp] * 8 + [_i64, _i, _f, _u64, _vp, _c.c_uint32, _vp, _i64, _vp, _vp, _i64, _i, _vp, _i, _vp]),
     "mobgt_ln_gemm_bwd": (_i, [_vp] * 12 + [_i64, _i, _f, _u64, _vp, _c.c_uint32, _vp, _i64, _vp, _i64, _i, _vp, _i, _vp]),

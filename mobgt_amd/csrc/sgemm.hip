@@ -40,6 +40,7 @@ struct SgemmParams {
     bf16_t* ct;
     int64_t ldt;
     const float* ct_scale;
+    int Kb;                                      // rows of a [K,N] B that exist (<= K: A zero-padded to a whole number of k-steps)
 };
 
 __device__ __forceinline__ float act_mask(float y, float pos, float neg, float zer) { return y > 0.f ? pos : (y < 0.f ? neg : zer); }
@@ -75,10 +76,10 @@ __global__ __launch_bounds__(64) void sgemm_kernel(const SgemmParams p) {
         if (B_NK) return load_k4<VEC>(p.B + (int64_t)col[b] * p.ldb, k, p.K);
         float4 v;
         const float* q = p.B + col[b];
-        v.x = k < p.K ? q[(int64_t)k * p.ldb] : 0.f;
-        v.y = k + 1 < p.K ? q[(int64_t)(k + 1) * p.ldb] : 0.f;
-        v.z = k + 2 < p.K ? q[(int64_t)(k + 2) * p.ldb] : 0.f;
-        v.w = k + 3 < p.K ? q[(int64_t)(k + 3) * p.ldb] : 0.f;
+        v.x = k < p.Kb ? q[(int64_t)k * p.ldb] : 0.f;
+        v.y = k + 1 < p.Kb ? q[(int64_t)(k + 1) * p.ldb] : 0.f;
+        v.z = k + 2 < p.Kb ? q[(int64_t)(k + 2) * p.ldb] : 0.f;
+        v.w = k + 3 < p.Kb ? q[(int64_t)(k + 3) * p.ldb] : 0.f;
         return v;
     };
 
@@ -167,6 +168,8 @@ int launch(const SgemmParams& p, bool b_nk, bool vec, hipStream_t st) {
 namespace {
 int run(SgemmParams& p, int b_is_nk, int c_dtype, void* stream) {
     if (p.M <= 0 || p.N <= 0 || p.K <= 0) return MOBGT_EBADDIM;
+    if (p.Kb <= 0) p.Kb = p.K;
+    if (p.Kb > p.K || (b_is_nk && p.Kb != p.K)) return MOBGT_EBADDIM;
     if (c_dtype != MOBGT_F32 && c_dtype != MOBGT_BF16) return MOBGT_EDTYPE;
     if ((((uintptr_t)p.A | (uintptr_t)p.B | (uintptr_t)p.amask) & 3) || ((uintptr_t)p.C & (c_dtype == MOBGT_F32 ? 3 : 1))) return MOBGT_EALIGN;
     if (!p.C && !p.ct) return MOBGT_EBADDIM;
@@ -198,8 +201,9 @@ extern "C" int mobgt_small_gemm_f32_act(const float* a, int64_t lda, const float
                                         const float* b, int64_t ldb, int b_is_nk, const float* bias, int leaky, float slope,
                                         float dropout_p, uint64_t seed, const uint64_t* seed_dev, uint32_t salt, void* c,
                                         int64_t ldc, int c_dtype, void* c_t_bf16, int64_t ld_t, const float* c_t_scale, int M,
-                                        int N, int K, void* stream) {
+                                        int N, int K, int k_b, void* stream) {
     SgemmParams p = {};
+    p.Kb = k_b;
     if (c_t_bf16 && ld_t < M) return MOBGT_EBADDIM;
     p.ct = reinterpret_cast<bf16_t*>(c_t_bf16); p.ldt = ld_t; p.ct_scale = c_t_scale;
     p.A = a; p.lda = lda; p.B = b; p.ldb = ldb; p.bias = bias; p.C = c; p.ldc = ldc; p.M = M; p.N = N; p.K = K;

@@ -249,8 +249,15 @@ class _ConvActFn(torch.autograd.Function):
     def forward(ctx, x, ax, weight, bias, adj, slope, p_drop, seed, seed_dev, salt, xt=None):
         from . import ops
         # (`xt`: x already transposed to the product's operand layout by the launch that produced it)
-        t = ax if ax is not None else mask_gemm(adj, x, xt=xt.t if xt is not None else None)       # [P, in] f32
-        y = ops.small_gemm(t, weight, bias, leaky=slope, drop=(p_drop, seed, seed_dev, salt) if p_drop > 0 else None)
+        # `ax` may be zero-padded to a whole number of 16-deep k-steps (a 303-wide input as 304 columns: 16-byte operand loads,
+        # an even width for the weight-gradient kernel); then `xt` is where the NEXT bitmask product wants y transposed
+        if ax is not None:
+            t = ax
+            y = ops.small_gemm(t, weight, bias, leaky=slope, drop=(p_drop, seed, seed_dev, salt) if p_drop > 0 else None,
+                               k_b=weight.shape[0], ct=(xt.t, None, False) if xt is not None else None)
+        else:
+            t = mask_gemm(adj, x, xt=xt.t if xt is not None else None)  # [P, in] f32
+            y = ops.small_gemm(t, weight, bias, leaky=slope, drop=(p_drop, seed, seed_dev, salt) if p_drop > 0 else None)
         ctx.save_for_backward(t, weight, y)
         ctx.adj = adj if ax is None else None
         ctx.mv = ops.act_mask_values(slope, p_drop)
@@ -263,6 +270,7 @@ class _ConvActFn(torch.autograd.Function):
         g = g.contiguous()
         db = ops.zeros_f32((weight.shape[1],), g.device)
         dW = ops.linear_wgrad_masked(t, g, x_mask=y, mask_vals=ctx.mv, db=db, db_of_x=True)      # t^T (g * m(y)), db = colsum
+        dW = dW[:weight.shape[0]]                                                                # (rows of the zero padding)
         dx = None
         if ctx.adj is not None and ctx.needs_input_grad[0]:
             # dt = (g * m(y)) W^T [P, in] leaves the GEMM transposed, scaled by 1/(deg+1) and in bf16 -- the operand of
@@ -478,6 +486,9 @@ class GCN(nn.Module):
         (model_fqandtoyo.py:1264), so for R << P this replaces a P x P product (and its transpose in the
         backward) by an R x P one without changing any value that is used."""
         n_hidden = len(self.gcn) - 1
+        adj_x_pad = None
+        if adj_x is not None and adj_x.shape[1] != self.gcn[0].in_features:      # zero-padded columns (see _ConvActFn)
+            adj_x_pad, adj_x = adj_x, adj_x[:, :self.gcn[0].in_features]
         if rows is None and mask_adj is None and x.is_cuda and _small_gcn_ok(self, x, adj, adj_x, adj_t):
             from . import ops
             p_drop = self.dropout if self.training else 0.0
@@ -494,8 +505,23 @@ class GCN(nn.Module):
                 salt = 0x2000 + self.gcn[-1].out_features
                 gc = self.gcn[i]
                 pre = adj_x if i == 0 else None
+                pre_pad = adj_x_pad if i == 0 else None
                 # (bitmask-adjacency layers only: that is the bf16 configuration, whose weight gradients already round
                 # their operands to bf16; the first layer's f32 product and the f32 configuration keep their exact path)
+                # first layer with a zero-padded A X (model_fqandtoyo: 303 -> 304 columns) in front of a bitmask layer: the same
+                # node with `ax`, which also writes its result transposed for that next product
+                if (pre_pad is not None and mask_adj is not None and not isinstance(adj, CsrAdj) and i + 1 < n_hidden
+                        and pre_pad.dtype == torch.float32 and pre_pad.is_contiguous() and pre_pad.shape[1] % 16 == 0
+                        and 0 <= pre_pad.shape[1] - gc.in_features < 16 and gc.bias is not None and gc.out_features in (16, 32, 48, 64)
+                        and gc.weight.is_contiguous() and os.environ.get("MOBGT_NO_CONV_ACT") != "1"
+                        and _conv_act_ok(gc.out_features, self.gcn[i + 1].weight, self.gcn[i + 1].bias)):
+                    seed, seed_dev = ops.dropout_seed(p_drop)
+                    yt = xt_workspace(pre_pad.device, pre_pad.shape[0], gc.out_features, slot=0)
+                    with torch.autocast(device_type="cuda", enabled=False):
+                        x = _ConvActFn.apply(None, pre_pad, gc.weight, gc.bias, None, float(self.leaky_relu.negative_slope),
+                                             float(p_drop), seed, seed_dev, salt, ops._OutRef(yt))
+                    x._mobgt_xt = yt
+                    continue
                 if (pre is None and mask_adj is not None and not isinstance(adj, CsrAdj) and x.dtype == torch.float32
                         and _mask_conv_ok(x, gc.weight) and _conv_act_ok(x.shape[1], gc.weight, gc.bias)):
                     # ... and no launch for the activation at all: GEMM epilogue forward, masked operand loads backward

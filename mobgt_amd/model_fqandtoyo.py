@@ -213,7 +213,7 @@ class Graphormer(nn.Module):
         else:
             d_a = torch.from_numpy(calculate_laplacian_matrix(uni.graph_dist)).float()
             # A.X for the constant POI feature matrix, once, in fp32 (see modelGNN.GCN.forward)
-            self.register_buffer("D_AX", d_a @ torch.from_numpy(X), persistent=False)
+            d_ax = d_a @ torch.from_numpy(X)
             self.register_buffer("D_A", d_a.to(gcn_dtype), persistent=False)
             # the constant's transpose, stored once: the backward's adj^T @ g then streams rows like the forward
             self.register_buffer("D_A_T", d_a.t().contiguous().to(gcn_dtype) if gcn_dtype != torch.float32 else None,
@@ -225,6 +225,11 @@ class Graphormer(nn.Module):
             if gcn_dtype == torch.bfloat16 and os.environ.get("MOBGT_NO_MASK_ADJ") != "1":
                 from .modelGNN import MaskAdj
                 packed = MaskAdj.from_dense01(uni.graph_dist)
+            if packed is not None and d_ax.shape[1] % 16:
+                # bitmask configuration: A X zero-padded to whole 16-deep k-steps (303 -> 304 columns) for the first
+                # GraphConvolution's GEMM + activation node (modelGNN._ConvActFn); GCN.forward slices it for any other path
+                d_ax = torch.nn.functional.pad(d_ax, (0, 16 - d_ax.shape[1] % 16))
+            self.register_buffer("D_AX", d_ax.contiguous(), persistent=False)
             for name, t in zip(("D_mask", "D_mask_t", "D_scale"), packed if packed is not None else (None, None, None)):
                 self.register_buffer(name, t, persistent=False)
         c_a = torch.from_numpy(calculate_laplacian_matrix(uni.graph_cat)).float()

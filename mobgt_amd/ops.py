@@ -1054,24 +1054,26 @@ def assemble_tokens(nf, real, add, token, pe0, p_pos, p_in, training, salts=(0x1
 
 
 # ------------------------------------------------------------------- small f32 GEMMs (GCN / fuse / head)
-def small_gemm(a, b, bias=None, b_is_nk=False, out=None, out_dtype=torch.float32, leaky=None, drop=None, a_mask=None, ct=None):
+def small_gemm(a, b, bias=None, b_is_nk=False, out=None, out_dtype=torch.float32, leaky=None, drop=None, a_mask=None, ct=None,
+               k_b=None):
     """a [M,K] @ (b.T if b_is_nk else b) (+ bias) -> f32 [M,N] on csrc/sgemm.hip (one wave per 16-row tile, f32 MFMA).
     No autograd.  Operands may be row-strided views (unit column stride).
     `leaky` (slope): LeakyReLU on the way out; `drop` = (p, seed, seed_dev, salt): then dropout (mobgt_bias_act_fwd's mask).
     `a_mask` = (y, pos, neg, zero): a is multiplied elementwise by m(y) while it is loaded (y: a's shape and row stride).
     `ct` = (buffer bf16 [N, ld], row_scale f32 [M] or None, only): the result (times row_scale) also as bf16 TRANSPOSED into
-    `buffer` (modelGNN.xt_workspace: the bitmask adjacency product's operand); `only`: no [M,N] result at all (returns None)."""
+    `buffer` (modelGNN.xt_workspace: the bitmask adjacency product's operand); `only`: no [M,N] result at all (returns None).
+    `k_b`: b ([K,N] form) has only k_b <= a.shape[1] rows: a's trailing columns are zero padding."""
     _require_cuda(a, b)
     assert a.dtype == torch.float32 and b.dtype == torch.float32 and a.dim() == 2 and b.dim() == 2
     assert a.stride(1) == 1 and b.stride(1) == 1
     M, K = a.shape
     N = b.shape[0] if b_is_nk else b.shape[1]
-    assert (b.shape[1] if b_is_nk else b.shape[0]) == K
+    assert (b.shape[1] if b_is_nk else b.shape[0]) == (K if k_b is None else k_b) and (k_b is None or (not b_is_nk and k_b <= K))
     if bias is not None:
         assert bias.dtype == torch.float32 and bias.numel() == N and bias.is_contiguous()
     only_t = ct is not None and ct[2]
     c = None if only_t else (out if out is not None else torch.empty(M, N, dtype=out_dtype, device=a.device))
-    if leaky is None and a_mask is None and ct is None:
+    if leaky is None and a_mask is None and ct is None and k_b is None:
         check(_lib.lib().mobgt_small_gemm_f32(_p(a), a.stride(0), _p(b), b.stride(0), int(b_is_nk), _p(bias), _p(c), c.stride(0),
                                               _DT[c.dtype], M, N, K, _stream()), "mobgt_small_gemm_f32")
         return c
@@ -1083,7 +1085,8 @@ def small_gemm(a, b, bias=None, b_is_nk=False, out=None, out_dtype=torch.float32
                                               int(b_is_nk), _p(bias), int(leaky is not None), float(leaky or 0.0), float(p_drop),
                                               int(seed), _p(seed_dev), int(salt) & 0xFFFFFFFF, _p(c), c.stride(0) if c is not None else N,
                                               _DT[c.dtype] if c is not None else F32, _p(ct[0] if ct else None),
-                                              ct[0].stride(0) if ct else 0, _p(ct[1] if ct else None), M, N, K, _stream()),
+                                              ct[0].stride(0) if ct else 0, _p(ct[1] if ct else None), M, N, K, int(k_b or 0),
+                                              _stream()),
           "mobgt_small_gemm_f32_act")
     return c
 
