@@ -340,28 +340,40 @@ class Graphormer(nn.Module):
                                               adj_t=self.D_A_T, mask_adj=mask_adj)                  # :1236
         ops.trace_nan("poidist", poidist)
         catemb = self.poi_cat_model(self.C_X, self.C_A, self.C_AX, adj_t=self.C_A_T)                                    # :1237
-        # every gathered row of :1259-1298 in ONE launch: [poi ; time] -> pt, the category row -> the trailing columns of
-        # fuse4's input, fre_embed(0) + degree rows + positional rows pe[1..n] (:1287-1298, :348-351) summed -> add
         Wp, Wt, Wc, C = poidist.shape[1], self.time_embed_model_48.weight.shape[1], catemb.shape[1], self.pos_embed.pe.shape[1]
-        pt, x4, add = ops.embed_gather_multi(
-            [(poidist, poi_idx, 0, 0, False, None), (self.time_embed_model_48.weight, time_idx, 0, Wp, False, 0),
-             (catemb, cat_idx, 1, Wp + Wt, False, None),
-             (self.fre_embed_model.weight, zero_idx, 2, 0, False, 0), (self.in_degree_encoder.weight, in_deg, 2, 0, True, 0),
-             (self.out_degree_encoder.weight, out_deg, 2, 0, True, 0), (self.pos_embed.pe, pos_idx, 2, 0, True, None)],
-            [Wp + Wt, Wp + Wt + Wc, C])
-        # fuse2 (:1268) writes straight into the leading columns of fuse4's input (:1269): no torch.cat
-        f2 = ops.linear_splitk(pt, self.embed_fuse_model2.fuse_embed.weight, self.embed_fuse_model2.fuse_embed.bias,
-                               self.act_dtype == torch.bfloat16, slope=self.embed_fuse_model2.leaky_relu.negative_slope,
-                               out=x4[:, :Wp + Wt])
+        f4 = self.embed_fuse_model4
+        one_launch = G * N <= 4096
+        if one_launch:
+            # every gathered row of :1259-1298 in ONE launch: [poi ; time] -> pt, the category row -> the trailing columns of
+            # fuse4's input, fre_embed(0) + degree rows + positional rows pe[1..n] (:1287-1298, :348-351) summed -> add
+            pt, x4, add = ops.embed_gather_multi(
+                [(poidist, poi_idx, 0, 0, False, None), (self.time_embed_model_48.weight, time_idx, 0, Wp, False, 0),
+                 (catemb, cat_idx, 1, Wp + Wt, False, None),
+                 (self.fre_embed_model.weight, zero_idx, 2, 0, False, 0), (self.in_degree_encoder.weight, in_deg, 2, 0, True, 0),
+                 (self.out_degree_encoder.weight, out_deg, 2, 0, True, 0), (self.pos_embed.pe, pos_idx, 2, 0, True, None)],
+                [Wp + Wt, Wp + Wt + Wc, C])
+            # fuse2 (:1268) writes straight into the leading columns of fuse4's input (:1269): no torch.cat
+            f2 = ops.linear_splitk(pt, self.embed_fuse_model2.fuse_embed.weight, self.embed_fuse_model2.fuse_embed.bias,
+                                   self.act_dtype == torch.bfloat16, slope=self.embed_fuse_model2.leaky_relu.negative_slope,
+                                   out=x4[:, :Wp + Wt])
+            if f2.data_ptr() == x4.data_ptr():
+                x4 = ops.join_cols(x4, f2)
+            else:                                                               # (the library path wrote elsewhere)
+                x4 = torch.cat((f2, x4[:, Wp + Wt:]), 1)
+            nf = ops.linear_splitk(x4, f4.fuse_embed.weight, f4.fuse_embed.bias, getattr(f4, "bf16_wgrad", False),
+                                   slope=f4.leaky_relu.negative_slope)
+        else:
+            # many positions (S-BIG: 12.5 k rows): the separate gathers, whose backward combines runs of equal indices in
+            # registers (scatter_add_runs_kernel) instead of serialising thousands of atomics on a handful of degree rows
+            pt = ops.embed_gather_concat([poidist, self.time_embed_model_48.weight], [poi_idx, time_idx], padding_idx=[None, 0])
+            f2 = ops.linear_splitk(pt, self.embed_fuse_model2.fuse_embed.weight, self.embed_fuse_model2.fuse_embed.bias,
+                                   self.act_dtype == torch.bfloat16, slope=self.embed_fuse_model2.leaky_relu.negative_slope)
+            nf = f4(f2, ops.embed_gather_sum([catemb], [cat_idx]))
+            add = ops.embed_gather_sum(
+                [self.fre_embed_model.weight, self.in_degree_encoder.weight, self.out_degree_encoder.weight, self.pos_embed.pe],
+                [zero_idx, in_deg, out_deg, pos_idx], padding_idx=[0, 0, 0, None])
         ops.trace_nan("pt", pt)
         ops.trace_nan("f2", f2)
-        if f2.data_ptr() == x4.data_ptr():
-            x4 = ops.join_cols(x4, f2)
-        else:                                                                   # (the library path wrote elsewhere)
-            x4 = torch.cat((f2, x4[:, Wp + Wt:]), 1)
-        f4 = self.embed_fuse_model4
-        nf = ops.linear_splitk(x4, f4.fuse_embed.weight, f4.fuse_embed.bias, getattr(f4, "bf16_wgrad", False),
-                               slope=f4.leaky_relu.negative_slope)
         ops.trace_nan("fuse4", nf)
         # (pads stay 0: the multiplication by `real` happens inside assemble_tokens)
         # nf * real + add -> pos_embed dropout (:358); graph token + pe[0] -> the same dropout (:1338-1342); cat;
@@ -369,7 +381,7 @@ class Graphormer(nn.Module):
         return ops.assemble_tokens(nf.view(G, N, -1), real, add.view(G, N, -1), self.graph_token.weight, self.pos_embed.pe, self.pos_embed.dropout.p,
                                    self.input_dropout.p, self.training,
                                    bf16_copy=self.act_dtype == torch.bfloat16 and getattr(self.layers[0], "fused", False),
-                                   pe_row0_via_gather=True)
+                                   pe_row0_via_gather=one_launch)
 
     def validate_batch(self, batched_data):
         """Index ranges nn.Embedding would check in the reference (IndexError there; the gather kernels here do not
