@@ -359,6 +359,12 @@ int mobgt_layer_backward_tail(int n, const void* const* g, const int64_t* ldg, c
 int mobgt_assemble_tokens_fwd(const float* nf, const float* real, const float* add, const float* token, const float* pe0,
                               float* out, void* out_bf16, int G, int N, int C, float p_pos, float p_in, uint64_t seed,
                               const uint64_t* seed_dev, uint32_t salt_nf, uint32_t salt_tok, uint32_t salt_in, void* stream);
+/* mobgt_assemble_tokens_fwd plus the FIRST encoder layer's QKV projection (qkv [G*(N+1), 3C] bf16 = rows wqkv^T + bqkv, weight
+ * packed by mobgt_pack_mfma_b) in one launch (csrc/chain.hip); out_bf16 is required; C in {192, 256}. */
+int mobgt_assemble_tokens_qkv(const float* nf, const float* real, const float* add, const float* token, const float* pe0,
+                              float* out, void* out_bf16, const void* wqkv_packed, const void* bqkv, void* qkv, int G, int N, int C,
+                              float p_pos, float p_in, uint64_t seed, const uint64_t* seed_dev, uint32_t salt_nf,
+                              uint32_t salt_tok, uint32_t salt_in, void* stream);
 int mobgt_assemble_tokens_bwd(const float* dout, const float* real, float* d_nf, float* d_add, float* d_token, int G, int N,
                               int C, float p_pos, float p_in, uint64_t seed, const uint64_t* seed_dev, uint32_t salt_nf,
                               uint32_t salt_tok, uint32_t salt_in, void* stream);

@@ -402,6 +402,70 @@ int launch(const ChainParams& p, hipStream_t st) {
 }
 
 
+// ---- the encoder's input rows and the FIRST layer's QKV projection in one launch ---------------------------------------------
+// mobgt_assemble_tokens_fwd (model_fqandtoyo.py:1287-1298, 348-358, 1338-1347: graph token + pe[0], node features * mask +
+// additive rows, positional and input dropout) for 16 rows per workgroup, then qkv = rows Wqkv^T + bqkv from LDS -- what
+// every later layer gets from the previous layer's chain launch.  Masks, salts and row numbering are assemble_tokens_kernel's.
+struct AsmQkvParams {
+    const float *nf, *real, *add, *token, *pe0;
+    float* out;                              // [G*T, C] f32
+    uint16_t* out16;                         // [G*T, C] bf16
+    const uint16_t *wq, *bq;                 // packed [3C,C], [3C]
+    uint16_t* qkv;                           // [G*T, 3C] bf16
+    int G, N;
+    uint32_t thr_pos, thr_in;
+    float keep_pos, keep_in;
+    uint64_t seed;
+    const uint64_t* seed_dev;
+    uint32_t salt_nf, salt_tok, salt_in;
+};
+
+template <int C>
+__global__ __launch_bounds__(NT) void assemble_qkv_kernel(const AsmQkvParams p) {
+    constexpr int BM = 16, LDA = C + 8, LDQ = 3 * C + 8;
+    __shared__ __attribute__((aligned(16))) uint16_t ab[BM * LDA];
+    __shared__ __attribute__((aligned(16))) uint16_t qb[BM * LDQ];
+    const int T = p.N + 1;
+    const int64_t rows = (int64_t)p.G * T;
+    const int r0 = blockIdx.x * BM;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint64_t seed = p.seed + (p.seed_dev ? *p.seed_dev : 0ull);
+    for (int r = wave; r < BM; r += NW) {
+        const int64_t row = r0 + r;
+        const bool on = row < rows;
+        const int g = on ? (int)(row / T) : 0, t = on ? (int)(row - (int64_t)g * T) : 0;
+        const bool tok = t == 0;
+        const uint32_t r1 = tok ? (uint32_t)g : (uint32_t)(g * p.N + (t - 1));
+        const uint32_t h1 = p.thr_pos ? dropout_row_hash(seed, r1 ^ (tok ? p.salt_tok : p.salt_nf)) : 0u;
+        const uint32_t h2 = p.thr_in ? dropout_row_hash(seed, (uint32_t)row ^ p.salt_in) : 0u;
+        const int64_t src = ((int64_t)g * p.N + (t - 1)) * C;
+        const float rl = (tok || !on) ? 1.f : p.real[(int64_t)g * p.N + (t - 1)];
+        for (int c = lane; c < C; c += 64) {
+            float o = 0.f;
+            if (on) {
+                float scale = 1.f;
+                if (p.thr_pos) scale = dropout_bits16(seed, h1, (uint32_t)c) >= p.thr_pos ? p.keep_pos : 0.f;
+                if (p.thr_in) scale *= dropout_bits16(seed, h2, (uint32_t)c) >= p.thr_in ? p.keep_in : 0.f;
+                const float v = tok ? p.token[c] + p.pe0[c] : p.nf[src + c] * rl + p.add[src + c];
+                o = v * scale;
+                p.out[row * C + c] = o;
+                p.out16[row * C + c] = bf16_bits(o);
+            }
+            ab[r * LDA + c] = bf16_bits(o);
+        }
+    }
+    __syncthreads();
+    const int j = lane & 15, q = lane >> 4;
+    wg_gemm<BM, 3 * C, C, LDA>(ab, p.wq, [&](int gq, const f32x4 (&acc)[1]) {
+        const int col = 16 * gq + j;
+        const float bias = bf16_val(p.bq[col]);
+#pragma unroll
+        for (int v = 0; v < 4; ++v) qb[(4 * q + v) * LDQ + col] = bf16_bits(acc[0][v] + bias);
+    });
+    __syncthreads();
+    store_rows<BM, 3 * C, LDQ>(qb, p.qkv, r0, (int)rows);
+}
+
 // ---- the same chain backwards: from d(out) down to the gradient of the attention output ------------------------------
 //     dx2 = ffn_norm2'(dout);  df = dropout'(dx2)                      [dnxw, dnxb, db2]
 //     du  = (df W2) * gelu'(u)
@@ -672,4 +736,28 @@ extern "C" int mobgt_layer_chain_bwd(const float* dout, const float* x2, const f
     if (C == 192 && F == 1024) return launch_bwd<16, 192, 1024>(p, st);
     if (C == 256 && F == 1024) return launch_bwd<16, 256, 1024>(p, st);
     return MOBGT_EBADDIM;
+}
+
+extern "C" int mobgt_assemble_tokens_qkv(const float* nf, const float* real, const float* add, const float* token,
+                                         const float* pe0, float* out, void* out_bf16, const void* wqkv_packed, const void* bqkv,
+                                         void* qkv, int G, int N, int C, float p_pos, float p_in, uint64_t seed,
+                                         const uint64_t* seed_dev, uint32_t salt_nf, uint32_t salt_tok, uint32_t salt_in,
+                                         void* stream) {
+    if (G <= 0 || N < 0 || !out_bf16 || !wqkv_packed || !bqkv || !qkv) return MOBGT_EBADDIM;
+    if (((uintptr_t)wqkv_packed | (uintptr_t)qkv) & 15) return MOBGT_EALIGN;
+    AsmQkvParams p = {};
+    p.nf = nf; p.real = real; p.add = add; p.token = token; p.pe0 = pe0; p.out = out; p.out16 = (uint16_t*)out_bf16;
+    p.wq = (const uint16_t*)wqkv_packed; p.bq = (const uint16_t*)bqkv; p.qkv = (uint16_t*)qkv; p.G = G; p.N = N;
+    p.thr_pos = p_pos > 0.f ? dropout_threshold(p_pos) : 0u;
+    p.thr_in = p_in > 0.f ? dropout_threshold(p_in) : 0u;
+    p.keep_pos = p.thr_pos ? 1.f / (1.f - (float)p.thr_pos / 65536.f) : 1.f;
+    p.keep_in = p.thr_in ? 1.f / (1.f - (float)p.thr_in / 65536.f) : 1.f;
+    p.seed = seed; p.seed_dev = seed_dev; p.salt_nf = salt_nf; p.salt_tok = salt_tok; p.salt_in = salt_in;
+    const int64_t rows = (int64_t)G * (N + 1);
+    const dim3 grid((unsigned)((rows + 15) / 16)), block(NT);
+    hipStream_t st = (hipStream_t)stream;
+    if (C == 192) hipLaunchKernelGGL(assemble_qkv_kernel<192>, grid, block, 0, st, p);
+    else if (C == 256) hipLaunchKernelGGL(assemble_qkv_kernel<256>, grid, block, 0, st, p);
+    else return MOBGT_EBADDIM;
+    return (int)hipGetLastError();
 }

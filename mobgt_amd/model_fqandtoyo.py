@@ -378,10 +378,16 @@ class Graphormer(nn.Module):
         # (pads stay 0: the multiplication by `real` happens inside assemble_tokens)
         # nf * real + add -> pos_embed dropout (:358); graph token + pe[0] -> the same dropout (:1338-1342); cat;
         # input_dropout (:1347): one launch
+        # the first encoder layer's QKV projection rides in the same launch when its packed weights are current (chain kernels)
+        l0 = self.layers[0]
+        first_qkv = None
+        if (getattr(l0, "fused", False) and getattr(l0, "_packed_fresh", False) and getattr(l0, "act_dtype", None) == torch.bfloat16
+                and not torch.is_autocast_enabled("cuda")):
+            first_qkv = (l0._packed[0], l0._shadows[1])
         return ops.assemble_tokens(nf.view(G, N, -1), real, add.view(G, N, -1), self.graph_token.weight, self.pos_embed.pe, self.pos_embed.dropout.p,
                                    self.input_dropout.p, self.training,
                                    bf16_copy=self.act_dtype == torch.bfloat16 and getattr(self.layers[0], "fused", False),
-                                   pe_row0_via_gather=one_launch)
+                                   pe_row0_via_gather=one_launch, first_qkv=first_qkv)
 
     def validate_batch(self, batched_data):
         """Index ranges nn.Embedding would check in the reference (IndexError there; the gather kernels here do not

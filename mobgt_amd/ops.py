@@ -982,7 +982,7 @@ def head_input(enc, user_table, user, user_offset=0):
 
 class _AssembleTokensFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, nf, real, add, token, pe0, p_pos, p_in, seed, seed_dev, salts, side, row0_via_gather=False):
+    def forward(ctx, nf, real, add, token, pe0, p_pos, p_in, seed, seed_dev, salts, side, row0_via_gather=False, qkv_w=None):
         ctx.pe_ptr = pe0.data_ptr() if (row0_via_gather and pe0.dim() == 2 and pe0.shape[0] > 1) else None
         G, N, C = nf.shape
         nf, add, real = nf.contiguous(), add.contiguous(), real.contiguous()
@@ -993,11 +993,22 @@ class _AssembleTokensFn(torch.autograd.Function):
         pe0 = pe0.contiguous() if pe0.dim() == 2 and pe0.shape[0] > 1 else pe0.reshape(-1).contiguous()
         out = torch.empty(G, N + 1, C, dtype=torch.float32, device=nf.device)
         out16 = torch.empty(G, N + 1, C, dtype=torch.bfloat16, device=nf.device) if side is not None else None
-        check(_lib.lib().mobgt_assemble_tokens_fwd(_p(nf), _p(real), _p(add), _p(token), _p(pe0), _p(out), _p(out16), G, N, C,
-                                                   p_pos, p_in, seed, _p(seed_dev), salts[0], salts[1], salts[2], _stream()),
-              "mobgt_assemble_tokens_fwd")
-        if side is not None:
+        if qkv_w is not None and out16 is not None and C in (192, 256):
+            # ... and the first encoder layer's QKV projection from the same launch (csrc/chain.hip): qkv_w = _OutRefs of the
+            # packed [3C, C] weight and the bf16 bias
+            qkv = torch.empty(G * (N + 1), 3 * C, dtype=torch.bfloat16, device=nf.device)
+            check(_lib.lib().mobgt_assemble_tokens_qkv(_p(nf), _p(real), _p(add), _p(token), _p(pe0), _p(out), _p(out16),
+                                                       _p(qkv_w[0].t), _p(qkv_w[1].t), _p(qkv), G, N, C, p_pos, p_in, seed,
+                                                       _p(seed_dev), salts[0], salts[1], salts[2], _stream()),
+                  "mobgt_assemble_tokens_qkv")
             side.append(out16)
+            side.append(qkv)
+        else:
+            check(_lib.lib().mobgt_assemble_tokens_fwd(_p(nf), _p(real), _p(add), _p(token), _p(pe0), _p(out), _p(out16), G, N, C,
+                                                       p_pos, p_in, seed, _p(seed_dev), salts[0], salts[1], salts[2], _stream()),
+                  "mobgt_assemble_tokens_fwd")
+            if side is not None:
+                side.append(out16)
         ctx.save_for_backward(real)
         ctx.misc = (G, N, C, p_pos, p_in, seed, seed_dev, salts, shapes)
         return out
@@ -1025,12 +1036,12 @@ class _AssembleTokensFn(torch.autograd.Function):
             # the positional table's other consumer (the gather of pe[1..n]) adds this row-0 share inside ITS scatter launch:
             # one gradient producer for the table, no [L, C] zero table here and no table-sized add after
             _ROW0_PENDING[ctx.pe_ptr] = d_tok
-            return d_nf, None, d_add, d_tok.view(tshape), None, None, None, None, None, None, None, None
-        return d_nf, None, d_add, d_tok.view(tshape), d_pe, None, None, None, None, None, None, None
+            return d_nf, None, d_add, d_tok.view(tshape), None, None, None, None, None, None, None, None, None
+        return d_nf, None, d_add, d_tok.view(tshape), d_pe, None, None, None, None, None, None, None, None
 
 
 def assemble_tokens(nf, real, add, token, pe0, p_pos, p_in, training, salts=(0x1001, 0x1002, 0x1003), bf16_copy=False,
-                    pe_row0_via_gather=False):
+                    pe_row0_via_gather=False, first_qkv=None):
     """[G,N+1,C] encoder input: graph token row (+ pe[0]) and the node features (* real + add), each through the
     positional dropout and then the input dropout -- one launch forward, one backward (see mobgt_assemble_tokens_fwd).
     `token` is [C]-sized; `pe0` is pe[0] or the whole positional table [L, C] (row 0 is used); the gradient of both is
@@ -1047,9 +1058,12 @@ def assemble_tokens(nf, real, add, token, pe0, p_pos, p_in, training, salts=(0x1
     # the same autograd graph: that node's backward then adds the token row's gradient to pe[0] (see _ROW0_PENDING)
     out = _AssembleTokensFn.apply(nf.float(), real.float(), add.float(), token.float(), pe0.float(), float(p_pos),
                                   float(p_in), int(seed), seed_dev, tuple(int(s) & 0xFFFFFFFF for s in salts), side,
-                                  bool(pe_row0_via_gather and pe0.requires_grad and torch.is_grad_enabled()))
+                                  bool(pe_row0_via_gather and pe0.requires_grad and torch.is_grad_enabled()),
+                                  (_OutRef(first_qkv[0]), _OutRef(first_qkv[1])) if (first_qkv is not None and bf16_copy) else None)
     if side:
         out._mobgt_act = side[0]          # bf16 copy for the first fused layer's QKV GEMM (no cast launch)
+        if len(side) > 1:
+            out._mobgt_qkv = side[1]      # `first_qkv` = (packed wqkv, bqkv) of that layer: its QKV projection, from this launch
     return out
 
 
