@@ -207,7 +207,8 @@ __device__ __forceinline__ void wgrad_body(const WgradParams& p, const int tile,
         if (m0 + r < p.M && n0 + c < p.N) {
             float* dst = p.dw + (int64_t)(m0 + r) * p.ldw + n0 + c;
             if (p.out_bias && split == 0) s += p.out_bias[n0 + c];
-            if (nsplit > 1) atomicAdd(dst, s); else *dst += s;
+            // always the atomic form: nothing waits for its result, where `*dst += s` ends every workgroup on a load round trip
+            atomicAdd(dst, s);
         }
     }
     {
@@ -217,7 +218,7 @@ __device__ __forceinline__ void wgrad_body(const WgradParams& p, const int tile,
             float t = 0.f;
 #pragma unroll
             for (int w = 0; w < NWAVE; ++w) t += colpart[w][e];
-            if (nsplit > 1) atomicAdd(p.db + c0 + e, t); else p.db[c0 + e] += t;
+            atomicAdd(p.db + c0 + e, t);
         }
     }
 }
