@@ -93,27 +93,40 @@ __global__ __launch_bounds__(64) void sgemm_kernel(const SgemmParams p) {
         }
         return v;
     };
-    float4 a_cur = load_a(4 * kq), a_nxt = a_cur;
-    float4 b_cur[NB], b_nxt[NB];
+    // operands of TWO steps are in flight ahead of the one being multiplied (a ring of three register slots: a wave is alone
+    // on its tile, and with one step of lookahead every 16-deep step paid most of a memory round trip -- 12-19 of them per
+    // product at K = 192-304)
+    constexpr int D = 3;
+    float4 a_r[D], b_r[D][NB];
 #pragma unroll
-    for (int b = 0; b < NB; ++b) { b_cur[b] = load_b(b, 4 * kq); b_nxt[b] = b_cur[b]; }
-    for (int k0 = 0; k0 < p.K; k0 += 16) {
-        const int kn = k0 + 16 + 4 * kq;
-        if (k0 + 16 < p.K) {
-            a_nxt = load_a(kn);
+    for (int u = 0; u < D - 1; ++u) {
+        const int k = 16 * u + 4 * kq;
+        const bool live = 16 * u < p.K;
+        a_r[u] = live ? load_a(k) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-            for (int b = 0; b < NB; ++b) b_nxt[b] = load_b(b, kn);
+        for (int b = 0; b < NB; ++b) b_r[u][b] = live ? load_b(b, k) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    for (int k0 = 0; k0 < p.K; k0 += 16 * D) {
+#pragma unroll
+        for (int u = 0; u < D; ++u) {
+            const int kc = k0 + 16 * u;
+            if (kc < p.K) {
+                const int kp = kc + 16 * (D - 1);
+                const int slot = (u + D - 1) % D;
+                if (kp < p.K) {
+                    a_r[slot] = load_a(kp + 4 * kq);
+#pragma unroll
+                    for (int b = 0; b < NB; ++b) b_r[slot][b] = load_b(b, kp + 4 * kq);
+                }
+#pragma unroll
+                for (int b = 0; b < NB; ++b) {
+                    acc[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_r[u].x, b_r[u][b].x, acc[b], 0, 0, 0);
+                    acc[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_r[u].y, b_r[u][b].y, acc[b], 0, 0, 0);
+                    acc[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_r[u].z, b_r[u][b].z, acc[b], 0, 0, 0);
+                    acc[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_r[u].w, b_r[u][b].w, acc[b], 0, 0, 0);
+                }
+            }
         }
-#pragma unroll
-        for (int b = 0; b < NB; ++b) {
-            acc[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur.x, b_cur[b].x, acc[b], 0, 0, 0);
-            acc[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur.y, b_cur[b].y, acc[b], 0, 0, 0);
-            acc[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur.z, b_cur[b].z, acc[b], 0, 0, 0);
-            acc[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur.w, b_cur[b].w, acc[b], 0, 0, 0);
-        }
-        a_cur = a_nxt;
-#pragma unroll
-        for (int b = 0; b < NB; ++b) b_cur[b] = b_nxt[b];
     }
     // register v of lane (j = lane & 15, q = lane >> 4) is output row 4q + v, column j of its 16x16 block
     const uint64_t seed = (EXT && p.thr) ? p.seed + (p.seed_dev ? *p.seed_dev : 0ull) : 0ull;
