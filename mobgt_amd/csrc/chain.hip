@@ -120,8 +120,33 @@ __device__ __forceinline__ float bf16_val(uint16_t b) { return __builtin_bit_cas
 // lane (j = lane & 15, q = lane >> 4).  TWO chunks of B operands are in flight ahead of the one being multiplied (the
 // per-CU L1 bandwidth is the kernel's bound: ~100 KB must be outstanding per CU to reach it); for K <= 256 the A operands
 // of the whole K live in registers for all of the wave's groups.
+// The first two weight chunks of a wave's share of a GEMM, requested EARLY: issue() before the LayerNorm pass / the
+// staging barrier that precedes the product, so that their round trip overlaps it instead of opening the GEMM (four
+// products per launch each started on an idle ~1 us wait).
+template <int N, int K>
+struct WPre {
+    static constexpr int S = K / 32, CH = S <= 8 ? S : 8, CPG = S / CH, G = N / 16;
+    uint4 b0[CH], b1[CH];
+    static __device__ __forceinline__ int nchunks() {
+        const int wave = threadIdx.x >> 6;
+        return (wave < G ? (G - wave + NW - 1) / NW : 0) * CPG;
+    }
+    static __device__ __forceinline__ void load(const uint16_t* __restrict__ W, uint4 (&b)[CH], int c) {
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        const int g = wave + (c / CPG) * NW, s0 = (c % CPG) * CH;          // W is PACKED: one contiguous KB per (group, k-step)
+        const uint16_t* wp = W + ((int64_t)(g * S + s0) * 64 + lane) * 8;
+#pragma unroll
+        for (int s = 0; s < CH; ++s) b[s] = *reinterpret_cast<const uint4*>(wp + 512 * s);
+    }
+    __device__ __forceinline__ void issue(const uint16_t* __restrict__ W) {
+        const int n = nchunks();
+        if (n > 0) load(W, b0, 0);
+        if (n > 1) load(W, b1, 1);
+    }
+};
+
 template <int BM, int N, int K, int LDA, typename EPI>
-__device__ __forceinline__ void wg_gemm(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W, EPI&& epi) {
+__device__ __forceinline__ void wg_gemm(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W, EPI&& epi, WPre<N, K>& pre) {
     constexpr int MT = BM / 16;
     constexpr int S = K / 32;                        // k-steps per group
     constexpr int CH = S <= 8 ? S : 8;               // k-steps per chunk
@@ -142,12 +167,7 @@ __device__ __forceinline__ void wg_gemm(const uint16_t* __restrict__ A, const ui
 #pragma unroll
             for (int s = 0; s < S; ++s) afr[t][s] = *reinterpret_cast<const uint4*>(a0 + 16 * t * LDA + 32 * s);
     }
-    auto load = [&](uint4 (&b)[CH], int c) {                      // W is PACKED: one contiguous KB per (group, k-step)
-        const int g = wave + (c / CPG) * NW, s0 = (c % CPG) * CH;
-        const uint16_t* wp = W + ((int64_t)(g * S + s0) * 64 + lane) * 8;
-#pragma unroll
-        for (int s = 0; s < CH; ++s) b[s] = *reinterpret_cast<const uint4*>(wp + 512 * s);
-    };
+    auto load = [&](uint4 (&b)[CH], int c) { WPre<N, K>::load(W, b, c); };
     f32x4 acc[MT];
 #pragma unroll
     for (int t = 0; t < MT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -170,9 +190,9 @@ __device__ __forceinline__ void wg_gemm(const uint16_t* __restrict__ A, const ui
             for (int t = 0; t < MT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
     };
-    uint4 b0[CH], b1[CH], b2[CH];
-    load(b0, 0);
-    if (nchunks > 1) load(b1, 1);
+    uint4 (&b0)[CH] = pre.b0;
+    uint4 (&b1)[CH] = pre.b1;                        // chunks 0 and 1: requested by pre.issue()
+    uint4 b2[CH];
     for (int c = 0; c < nchunks; c += 3) {
         if (c + 2 < nchunks) load(b2, c + 2);
         compute(b0, c);
@@ -263,6 +283,8 @@ __global__ __launch_bounds__(NT) void layer_chain_fwd_kernel(const ChainParams p
     STAMP_DECL;
     STAMP(0);
 
+    WPre<C, C> pre1;
+    pre1.issue(p.wo);
     // this block's rows of a (bf16) and x (f32) -> LDS; rows past R are clamped (their results are never stored)
     for (int e = threadIdx.x; e < BM * (C / 8); e += NT) {
         const int r = e / (C / 8), c = (e % (C / 8)) * 8;
@@ -276,6 +298,7 @@ __global__ __launch_bounds__(NT) void layer_chain_fwd_kernel(const ChainParams p
     STAMP(1);
 
     // ---- y = a Wo^T + bo;  x1 = x + dropout(y)
+    WPre<F, C> pre2;
     wg_gemm<BM, C, C, LDA>(ab, p.wo, [&](int g, const f32x4 (&acc)[MT]) {
         const int col = 16 * g + j;
         const float bias = bf16_val(p.bo[col]);
@@ -291,14 +314,16 @@ __global__ __launch_bounds__(NT) void layer_chain_fwd_kernel(const ChainParams p
                 }
                 xb[r * LDX + col] += y;
             }
-    });
-    __syncthreads();
+    }, pre1);
+    pre2.issue(p.w1);                 // (BEFORE the barrier: measured better than after it -- the request travels while the
+    __syncthreads();                  // wave waits for the slower waves' epilogues)
     STAMP(2);
     // ---- z = ffn_norm1(x1)
     ln_rows<BM, C, LDX, LDA>(xb, ab, p.n1w, p.n1b, p.x1, p.z, nullptr, p.mean1, p.rstd1, r0, p.R);
     __syncthreads();
     STAMP(3);
     // ---- u = z W1^T + b1;  h = gelu(u)  (h from the ROUNDED pre-activation, as the separate launches computed it)
+    WPre<C, F> pre3;
     wg_gemm<BM, F, C, LDA>(ab, p.w1, [&](int g, const f32x4 (&acc)[MT]) {
         const int col = 16 * g + j;
         const float bias = bf16_val(p.b1[col]);
@@ -311,13 +336,15 @@ __global__ __launch_bounds__(NT) void layer_chain_fwd_kernel(const ChainParams p
                 ub[r * LDH + col] = ubits;
                 hb[r * LDH + col] = bf16_bits(gelu_f(bf16_val(ubits)));
             }
-    });
+    }, pre2);
+    pre3.issue(p.w2);
     __syncthreads();
     STAMP(4);
     store_rows<BM, F, LDH>(ub, p.u, r0, p.R);
     store_rows<BM, F, LDH>(hb, p.h, r0, p.R);
     STAMP(5);
     // ---- f = h W2^T + b2;  x2 = x1 + dropout(f)
+    WPre<3 * C, C> pre4;
     wg_gemm<BM, C, F, LDH>(hb, p.w2, [&](int g, const f32x4 (&acc)[MT]) {
         const int col = 16 * g + j;
         const float bias = bf16_val(p.b2[col]);
@@ -333,7 +360,8 @@ __global__ __launch_bounds__(NT) void layer_chain_fwd_kernel(const ChainParams p
                 }
                 xb[r * LDX + col] += f;
             }
-    });
+    }, pre3);
+    if (p.wq) pre4.issue(p.wq);
     __syncthreads();
     STAMP(6);
     // ---- out = ffn_norm2(x2)  (f32 residual stream + the bf16 copy the next QKV GEMM multiplies)
@@ -349,7 +377,7 @@ __global__ __launch_bounds__(NT) void layer_chain_fwd_kernel(const ChainParams p
         for (int t = 0; t < MT; ++t)
 #pragma unroll
             for (int v = 0; v < 4; ++v) ub[(16 * t + 4 * q + v) * LDH + col] = bf16_bits(acc[t][v] + bias);
-    });
+    }, pre4);
     __syncthreads();
     STAMP(8);
     store_rows<BM, 3 * C, LDH>(ub, p.qkv, r0, p.R);
@@ -444,6 +472,8 @@ __global__ __launch_bounds__(NT) void assemble_qkv_kernel(const AsmQkvParams p) 
     const int r0 = blockIdx.x * BM;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint64_t seed = p.seed + (p.seed_dev ? *p.seed_dev : 0ull);
+    WPre<3 * C, C> pre;
+    pre.issue(p.wq);
     for (int r = wave; r < BM; r += NW) {
         const int64_t row = r0 + r;
         const bool on = row < rows;
@@ -475,7 +505,7 @@ __global__ __launch_bounds__(NT) void assemble_qkv_kernel(const AsmQkvParams p) 
         const float bias = bf16_val(p.bq[col]);
 #pragma unroll
         for (int v = 0; v < 4; ++v) qb[(4 * q + v) * LDQ + col] = bf16_bits(acc[0][v] + bias);
-    });
+    }, pre);
     __syncthreads();
     store_rows<BM, 3 * C, LDQ>(qb, p.qkv, r0, (int)rows);
 }
@@ -618,6 +648,8 @@ __global__ __launch_bounds__(NT) void layer_chain_bwd_kernel(const ChainBwdParam
     const int j = lane & 15, q = lane >> 4;
     const uint64_t seed = p.thr ? p.seed + (p.seed_dev ? *p.seed_dev : 0ull) : 0ull;
 
+    WPre<F, C> pre1;
+    pre1.issue(p.w2t);
     for (int e = threadIdx.x; e < BM * (F / 8); e += NT) {                        // the block's rows of u -> LDS
         const int r = e / (F / 8), c = (e % (F / 8)) * 8;
         *reinterpret_cast<uint4*>(ub + r * LDH + c) = *reinterpret_cast<const uint4*>(p.u + (int64_t)min(r0 + r, p.R - 1) * F + c);
@@ -628,6 +660,7 @@ __global__ __launch_bounds__(NT) void layer_chain_bwd_kernel(const ChainBwdParam
     __syncthreads();
     flush_colsums<C>(red, p.dnxw, p.dnxb, p.db2);
     // ---- du = (df W2) * gelu'(u)
+    WPre<C, F> pre2;
     wg_gemm<BM, F, C, LDA>(gb, p.w2t, [&](int g, const f32x4 (&acc)[MT]) {
         const int col = 16 * g + j;
 #pragma unroll
@@ -637,17 +670,20 @@ __global__ __launch_bounds__(NT) void layer_chain_bwd_kernel(const ChainBwdParam
                 const int r = 16 * t + 4 * q + v;
                 dub[r * LDH + col] = bf16_bits(acc[t][v] * gelu_grad_f(bf16_val(ub[r * LDH + col])));
             }
-    });
+    }, pre1);
+    pre2.issue(p.w1t);
     __syncthreads();
     store_rows<BM, F, LDH>(dub, p.du, r0, p.R);
     // ---- dz = du W1  (rounded to bf16 where the separate launch wrote a bf16 tensor)
+    WPre<C, C> pre3;
     wg_gemm<BM, C, F, LDH>(dub, p.w1t, [&](int g, const f32x4 (&acc)[MT]) {
         const int col = 16 * g + j;
 #pragma unroll
         for (int t = 0; t < MT; ++t)
 #pragma unroll
             for (int v = 0; v < 4; ++v) dzb[(16 * t + 4 * q + v) * LDX + col] = bf16_round(acc[t][v]);
-    });
+    }, pre2);
+    pre3.issue(p.wot);
     __syncthreads();
     // ---- dx1 = dx2 + ffn_norm1'(dz);  dy = dropout'(dx1)
     ln_bwd_rows<BM, C, LDX, LDA>(dzb, nullptr, p.x1, p.mean1, p.rstd1, p.n1w, dxb, dxb, p.dx1, gb, p.dy, red, r0, p.R, p.thr,
@@ -661,7 +697,7 @@ __global__ __launch_bounds__(NT) void layer_chain_bwd_kernel(const ChainBwdParam
         for (int t = 0; t < MT; ++t)
 #pragma unroll
             for (int v = 0; v < 4; ++v) ub[(16 * t + 4 * q + v) * LDH + col] = bf16_bits(acc[t][v]);
-    });
+    }, pre3);
     __syncthreads();
     store_rows<BM, C, LDH>(ub, p.da, r0, p.R);
 }
