@@ -208,20 +208,32 @@ __device__ __forceinline__ void wg_gemm(const uint16_t* __restrict__ A, const ui
 // xb[r][:] (f32, LDS) -> LayerNorm -> `dst_a` (bf16, LDS, the next GEMM's A operand) + global copies; also writes the
 // pre-norm rows (x1 / x2) and the statistics.  One wave per row (rows w, w + NW, ...), 256-byte runs to global; two-pass
 // mean / variance as mobgt_dropout_add_ln_fwd.
+// a LayerNorm's weight and bias at this lane's columns, requested at kernel start (a global load inside the norm pass is one
+// more exposed round trip per pass)
+template <int C>
+struct LnW {
+    static constexpr int PER = (C + 63) / 64;
+    float w[PER], b[PER];
+    __device__ __forceinline__ void issue(const float* __restrict__ wp, const float* __restrict__ bp) {
+        const int lane = threadIdx.x & 63;
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const int c = min(lane + 64 * k, C - 1);
+            w[k] = wp[c];
+            b[k] = bp ? bp[c] : 0.f;
+        }
+    }
+};
+
 template <int BM, int C, int LDX, int LDA>
-__device__ __forceinline__ void ln_rows(const float* __restrict__ xb, uint16_t* __restrict__ dst_a, const float* __restrict__ w,
-                                        const float* __restrict__ b, float* __restrict__ g_pre, uint16_t* __restrict__ g_bf,
+__device__ __forceinline__ void ln_rows(const float* __restrict__ xb, uint16_t* __restrict__ dst_a, const LnW<C>& lw,
+                                        float* __restrict__ g_pre, uint16_t* __restrict__ g_bf,
                                         float* __restrict__ g_f32, float* __restrict__ g_mean, float* __restrict__ g_rstd,
                                         int r0, int R) {
     constexpr int PER = (C + 63) / 64;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    float wv[PER], bv[PER];
-#pragma unroll
-    for (int k = 0; k < PER; ++k) {
-        const int c = min(lane + 64 * k, C - 1);
-        wv[k] = w[c];
-        bv[k] = b[c];
-    }
+    const float (&wv)[PER] = lw.w;
+    const float (&bv)[PER] = lw.b;
     for (int r = wave; r < BM; r += NW) {
         const int64_t row = r0 + r;
         float v[PER], s = 0.f;
@@ -285,6 +297,9 @@ __global__ __launch_bounds__(NT) void layer_chain_fwd_kernel(const ChainParams p
 
     WPre<C, C> pre1;
     pre1.issue(p.wo);
+    LnW<C> ln1, ln2;
+    ln1.issue(p.n1w, p.n1b);
+    ln2.issue(p.nxw, p.nxb);
     // this block's rows of a (bf16) and x (f32) -> LDS; rows past R are clamped (their results are never stored)
     for (int e = threadIdx.x; e < BM * (C / 8); e += NT) {
         const int r = e / (C / 8), c = (e % (C / 8)) * 8;
@@ -319,7 +334,7 @@ __global__ __launch_bounds__(NT) void layer_chain_fwd_kernel(const ChainParams p
     __syncthreads();                  // wave waits for the slower waves' epilogues)
     STAMP(2);
     // ---- z = ffn_norm1(x1)
-    ln_rows<BM, C, LDX, LDA>(xb, ab, p.n1w, p.n1b, p.x1, p.z, nullptr, p.mean1, p.rstd1, r0, p.R);
+    ln_rows<BM, C, LDX, LDA>(xb, ab, ln1, p.x1, p.z, nullptr, p.mean1, p.rstd1, r0, p.R);
     __syncthreads();
     STAMP(3);
     // ---- u = z W1^T + b1;  h = gelu(u)  (h from the ROUNDED pre-activation, as the separate launches computed it)
@@ -365,7 +380,7 @@ __global__ __launch_bounds__(NT) void layer_chain_fwd_kernel(const ChainParams p
     __syncthreads();
     STAMP(6);
     // ---- out = ffn_norm2(x2)  (f32 residual stream + the bf16 copy the next QKV GEMM multiplies)
-    ln_rows<BM, C, LDX, LDA>(xb, ab, p.nxw, p.nxb, p.x2, p.out_a, p.out, p.mean2, p.rstd2, r0, p.R);
+    ln_rows<BM, C, LDX, LDA>(xb, ab, ln2, p.x2, p.out_a, p.out, p.mean2, p.rstd2, r0, p.R);
     if (!p.wq) return;
     __syncthreads();
     STAMP(7);
@@ -555,25 +570,47 @@ __device__ __forceinline__ float gelu_grad_f(float u) {
 // the result goes to `dx_lds` (f32, LDS), optionally `dx_g` (global f32), and its dropout'ed bf16 form to `dy_lds` (the next
 // GEMM's A operand) and `dy_g`.  Column sums of (d * xhat, d, dy) over the block's rows are accumulated into `red`
 // ([3][NW][C] f32, LDS; the caller reduces over the waves).
+// what a LayerNorm backward pass reads of its SAVED forward (pre-norm rows, statistics, weight) for this wave's rows,
+// requested early: for the second norm of the backward chain at kernel start, two GEMMs ahead of its use
+template <int BM, int C>
+struct LnBwdPre {
+    static constexpr int PER = (C + 63) / 64, NR = (BM + NW - 1) / NW;
+    float w[PER], x[NR][PER], mu[NR], rs[NR];
+    __device__ __forceinline__ void issue(const float* __restrict__ xpre, const float* __restrict__ g_mean,
+                                          const float* __restrict__ g_rstd, const float* __restrict__ wp, int r0, int R) {
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+        for (int k = 0; k < PER; ++k) w[k] = wp[min(lane + 64 * k, C - 1)];
+#pragma unroll
+        for (int i = 0; i < NR; ++i) {
+            const int64_t row = min(r0 + min(wave + NW * i, BM - 1), R - 1);
+            mu[i] = g_mean[row];
+            rs[i] = g_rstd[row];
+#pragma unroll
+            for (int k = 0; k < PER; ++k) x[i][k] = xpre[row * C + min(lane + 64 * k, C - 1)];
+        }
+    }
+};
+
 template <int BM, int C, int LDX, int LDA>
 __device__ __forceinline__ void ln_bwd_rows(const float* __restrict__ d_lds, const float* __restrict__ d_g,
-                                            const float* __restrict__ xpre, const float* __restrict__ g_mean,
-                                            const float* __restrict__ g_rstd, const float* __restrict__ w,
+                                            const LnBwdPre<BM, C>& pre,
                                             const float* res, float* dx_lds, float* __restrict__ dx_g,
                                             uint16_t* __restrict__ dy_lds, uint16_t* __restrict__ dy_g, float* __restrict__ red,
                                             int r0, int R, uint32_t thr, float inv_keep, uint64_t seed, uint32_t salt) {
     constexpr int PER = (C + 63) / 64;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    float wv[PER], ag[PER], ab[PER], ay[PER];
+    const float (&wv)[PER] = pre.w;
+    float ag[PER], ab[PER], ay[PER];
 #pragma unroll
-    for (int k = 0; k < PER; ++k) {
-        wv[k] = w[min(lane + 64 * k, C - 1)];
-        ag[k] = ab[k] = ay[k] = 0.f;
-    }
-    for (int r = wave; r < BM; r += NW) {
+    for (int k = 0; k < PER; ++k) ag[k] = ab[k] = ay[k] = 0.f;
+#pragma unroll
+    for (int i = 0; i < LnBwdPre<BM, C>::NR; ++i) {
+        const int r = wave + NW * i;
+        if (r >= BM) break;
         const int64_t row = min(r0 + r, R - 1);
         const bool on = r0 + r < R;
-        const float mu = g_mean[row], rs = g_rstd[row];
+        const float mu = pre.mu[i], rs = pre.rs[i];
         float d[PER], xh[PER], gg[PER], s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int k = 0; k < PER; ++k) {
@@ -581,7 +618,7 @@ __device__ __forceinline__ void ln_bwd_rows(const float* __restrict__ d_lds, con
             const bool in = lane + 64 * k < C && on;
             const float dv = d_lds ? d_lds[r * LDX + c] : d_g[row * C + c];
             d[k] = in ? dv : 0.f;
-            xh[k] = in ? (xpre[row * C + c] - mu) * rs : 0.f;
+            xh[k] = in ? (pre.x[i][k] - mu) * rs : 0.f;
             gg[k] = d[k] * wv[k];
             ag[k] += d[k] * xh[k];
             ab[k] += d[k];
@@ -650,12 +687,15 @@ __global__ __launch_bounds__(NT) void layer_chain_bwd_kernel(const ChainBwdParam
 
     WPre<F, C> pre1;
     pre1.issue(p.w2t);
+    LnBwdPre<BM, C> lp2, lp1;
+    lp2.issue(p.x2, p.mean2, p.rstd2, p.nxw, r0, p.R);
+    lp1.issue(p.x1, p.mean1, p.rstd1, p.n1w, r0, p.R);        // (used two GEMMs from here)
     for (int e = threadIdx.x; e < BM * (F / 8); e += NT) {                        // the block's rows of u -> LDS
         const int r = e / (F / 8), c = (e % (F / 8)) * 8;
         *reinterpret_cast<uint4*>(ub + r * LDH + c) = *reinterpret_cast<const uint4*>(p.u + (int64_t)min(r0 + r, p.R - 1) * F + c);
     }
     // ---- dx2 = ffn_norm2'(dout);  df = dropout'(dx2)
-    ln_bwd_rows<BM, C, LDX, LDA>(nullptr, p.dout, p.x2, p.mean2, p.rstd2, p.nxw, nullptr, dxb, nullptr, gb, p.df, red, r0, p.R,
+    ln_bwd_rows<BM, C, LDX, LDA>(nullptr, p.dout, lp2, nullptr, dxb, nullptr, gb, p.df, red, r0, p.R,
                                  p.thr, p.inv_keep, seed, p.salt2);
     __syncthreads();
     flush_colsums<C>(red, p.dnxw, p.dnxb, p.db2);
@@ -686,7 +726,7 @@ __global__ __launch_bounds__(NT) void layer_chain_bwd_kernel(const ChainBwdParam
     pre3.issue(p.wot);
     __syncthreads();
     // ---- dx1 = dx2 + ffn_norm1'(dz);  dy = dropout'(dx1)
-    ln_bwd_rows<BM, C, LDX, LDA>(dzb, nullptr, p.x1, p.mean1, p.rstd1, p.n1w, dxb, dxb, p.dx1, gb, p.dy, red, r0, p.R, p.thr,
+    ln_bwd_rows<BM, C, LDX, LDA>(dzb, nullptr, lp1, dxb, dxb, p.dx1, gb, p.dy, red, r0, p.R, p.thr,
                                  p.inv_keep, seed, p.salt1);
     __syncthreads();
     flush_colsums<C>(red, p.dn1w, p.dn1b, p.dbo);
