@@ -165,9 +165,10 @@ extern "C" int mobgt_mask_gemm(const uint32_t* mask, int64_t ld_mask_words, cons
     // (mobgt_bias_act_fwd_t / mobgt_small_gemm_f32_act), no transpose launch
     if (x) hipLaunchKernelGGL(xt_kernel, dim3((unsigned)(ldxt / 64)), dim3(256), 0, st, x, ldx, bscale, reinterpret_cast<uint16_t*>(work),
                               ldxt, K, N);
-    // every workgroup walks ALL of X: tall row blocks (64 rows share each operand load) and 16 waves on K keep both the
-    // L2 -> CU traffic (P/64 x |X|) and the per-wave chain of k-steps short
-    if (N == 16) hipLaunchKernelGGL((mask_gemm_kernel<1, 16, 4>), dim3((M + 63) / 64), dim3(1024), 0, st, p);
+    // every workgroup walks ALL of X: row blocks of 32 (two row tiles share each operand load) and 16 waves on K keep both the
+    // L2 -> CU traffic (P/32 x |X|) and the per-wave chain of k-steps short
+    // (N = 16, measured at M = K = 7856: 64 rows x 16 waves 14.5 us, 32 rows x 16 waves 11.9, 32 x 8 waves 12.1, 16 x 16 19.4)
+    if (N == 16) hipLaunchKernelGGL((mask_gemm_kernel<1, 16, 2>), dim3((M + 31) / 32), dim3(1024), 0, st, p);
     else if (N == 32) hipLaunchKernelGGL((mask_gemm_kernel<2, 16, 2>), dim3((M + 31) / 32), dim3(1024), 0, st, p);
     else hipLaunchKernelGGL((mask_gemm_kernel<4, 8, 2>), dim3((M + 31) / 32), dim3(512), 0, st, p);
     return (int)hipGetLastError();
