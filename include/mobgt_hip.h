@@ -454,12 +454,19 @@ int mobgt_layer_chain_fwd(const void* a, const float* x, const void* wo, const v
  *   dy = dropout'(dx1);  da = dy wo.
  * w2t / w1t / wot: the weights' transposes packed by mobgt_pack_mfma_b(transposed = 1).  Written: df, dy, da [R,C], du [R,F]
  * bf16; dx1 [R,C] f32.  ACCUMULATED (f32 atomics, zero them first): dnxw, dnxb, db2 (= column sums of df), dn1w, dn1b,
- * dbo (= column sums of dy), [C] each. */
+ * dbo (= column sums of dy), [C] each.
+ * What the layer ABOVE may leave to this launch (all optional): tail_dqkv [R,3C] bf16 + tail_wqkv_t (its Wqkv^T, packed): `dout`
+ * then holds only that layer's dx1 and dout + dqkv Wqkv is formed here, per row block; wg_*: n_wg <= 4 weight-gradient
+ * problems dW [M,N] += g^T x (+ db [M] += column sums of g) over the same R rows, bf16 operands as mobgt_linear_wgrad, run
+ * by extra workgroups of this launch on the compute units its 16-row blocks leave idle. */
 int mobgt_layer_chain_bwd(const float* dout, const float* x2, const float* x1, const void* u, const float* mean1,
                           const float* rstd1, const float* mean2, const float* rstd2, const float* n1w, const float* nxw,
                           const void* w2t, const void* w1t, const void* wot, void* df, void* du, void* dy, void* da, float* dx1,
                           float* dnxw, float* dnxb, float* db2, float* dn1w, float* dn1b, float* dbo, int64_t R, int C, int F,
-                          float dropout_p, uint64_t seed, const uint64_t* seed_dev, uint32_t salt1, uint32_t salt2, void* stream);
+                          float dropout_p, uint64_t seed, const uint64_t* seed_dev, uint32_t salt1, uint32_t salt2,
+                          const void* tail_dqkv, const void* tail_wqkv_t, int n_wg, const void* const* wg_g,
+                          const int64_t* wg_ldg, const void* const* wg_x, const int64_t* wg_ldx, float* const* wg_dw,
+                          const int64_t* wg_ldw, float* const* wg_db, const int* wg_M, const int* wg_N, void* stream);
 /* The whole 3-layer GCN of a SMALL dense graph (graphormer/modelGNN.py:53-74 on the ~300-node category graph,
  * model_fqandtoyo.py:1237) as ONE launch each way (csrc/smallgcn.hip): ceil(n/16) co-resident workgroups that meet at
  * `counter` (int[1], ZERO on entry) between the layers.

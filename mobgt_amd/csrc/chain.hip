@@ -24,6 +24,7 @@
 // (mobgt_dropout_add_ln_fwd's), so the existing backward applies unchanged.
 #include "common.h"
 #include "mobgt_hip.h"
+#include "wgrad_body.h"
 
 namespace {
 
@@ -120,12 +121,15 @@ __device__ __forceinline__ float bf16_val(uint16_t b) { return __builtin_bit_cas
 // lane (j = lane & 15, q = lane >> 4).  TWO chunks of B operands are in flight ahead of the one being multiplied (the
 // per-CU L1 bandwidth is the kernel's bound: ~100 KB must be outstanding per CU to reach it); for K <= 256 the A operands
 // of the whole K live in registers for all of the wave's groups.
+// k-steps per chunk of B operands: the whole K when it is <= 8 steps, else the largest of 8 .. 4 that divides it
+constexpr int chunk_steps(int S) { return S <= 8 ? S : (S % 8 == 0 ? 8 : (S % 7 == 0 ? 7 : (S % 6 == 0 ? 6 : (S % 5 == 0 ? 5 : 4)))); }
+
 // The first two weight chunks of a wave's share of a GEMM, requested EARLY: issue() before the LayerNorm pass / the
 // staging barrier that precedes the product, so that their round trip overlaps it instead of opening the GEMM (four
 // products per launch each started on an idle ~1 us wait).
 template <int N, int K>
 struct WPre {
-    static constexpr int S = K / 32, CH = S <= 8 ? S : 8, CPG = S / CH, G = N / 16;
+    static constexpr int S = K / 32, CH = chunk_steps(S), CPG = S / CH, G = N / 16;
     uint4 b0[CH], b1[CH];
     static __device__ __forceinline__ int nchunks() {
         const int wave = threadIdx.x >> 6;
@@ -149,7 +153,7 @@ template <int BM, int N, int K, int LDA, typename EPI>
 __device__ __forceinline__ void wg_gemm(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W, EPI&& epi, WPre<N, K>& pre) {
     constexpr int MT = BM / 16;
     constexpr int S = K / 32;                        // k-steps per group
-    constexpr int CH = S <= 8 ? S : 8;               // k-steps per chunk
+    constexpr int CH = chunk_steps(S);               // k-steps per chunk
     constexpr int CPG = S / CH;                      // chunks per group
     constexpr bool AREG = S <= 8;                    // A operands held in registers
     static_assert(K % 32 == 0 && S % CH == 0 && N % 16 == 0, "shape");
@@ -550,6 +554,14 @@ struct ChainBwdParams {
     uint64_t seed;
     const uint64_t* seed_dev;
     uint32_t salt1, salt2;
+    // What the layer ABOVE left undone (optional).  Its input gradient is dx1 + dqkv Wqkv: `dout` then holds only dx1 and the
+    // product is finished here, per row block, in front of the first norm (t_dqkv [R,3C] bf16, t_wqt = Wqkv^T packed);
+    // and its four weight-gradient problems ride in this launch as extra workgroups (blockIdx >= n_chain) on the ~200
+    // compute units the 16-row chain workgroups leave idle -- the layer above then has NO launch after its attention backward.
+    const uint16_t *t_dqkv, *t_wqt;
+    mobgt_wgrad::WgradParams wg[4];
+    int wg_first[5], wg_tiles[4], wg_splits[4];
+    int n_wg, n_chain;
 };
 
 // gelu'(u) = Phi(u) + u phi(u); the exponential of the A&S erf IS phi's
@@ -680,11 +692,24 @@ __global__ __launch_bounds__(NT) void layer_chain_bwd_kernel(const ChainBwdParam
     uint16_t* gb = reinterpret_cast<uint16_t*>(red + 3 * NW * C);                // [BM][LDA] bf16: df, then dy
     uint16_t* ub = gb + BM * LDA;                                                // [BM][LDH] bf16: u, later da
     uint16_t* dub = ub + BM * LDH;                                               // [BM][LDH] bf16: du
+    if ((int)blockIdx.x >= p.n_chain) {          // passenger: one 32 x 32 tile of one of the upper layer's weight gradients
+        const int bid = (int)blockIdx.x - p.n_chain;
+        int qn = 0;
+#pragma unroll
+        for (int t = 1; t < 4; ++t)
+            if (t < p.n_wg && bid >= p.wg_first[t]) qn = t;
+        const int local = bid - p.wg_first[qn];
+        mobgt_wgrad::wgrad_body<false, NW>(p.wg[qn], local % p.wg_tiles[qn], local / p.wg_tiles[qn], p.wg_splits[qn],
+                                           reinterpret_cast<float*>(smem_raw));
+        return;
+    }
     const int r0 = blockIdx.x * BM;
     const int lane = threadIdx.x & 63;
     const int j = lane & 15, q = lane >> 4;
     const uint64_t seed = p.thr ? p.seed + (p.seed_dev ? *p.seed_dev : 0ull) : 0ull;
 
+    WPre<C, 3 * C> pre0;
+    if (p.t_dqkv) pre0.issue(p.t_wqt);
     WPre<F, C> pre1;
     pre1.issue(p.w2t);
     LnBwdPre<BM, C> lp2, lp1;
@@ -694,8 +719,28 @@ __global__ __launch_bounds__(NT) void layer_chain_bwd_kernel(const ChainBwdParam
         const int r = e / (F / 8), c = (e % (F / 8)) * 8;
         *reinterpret_cast<uint4*>(ub + r * LDH + c) = *reinterpret_cast<const uint4*>(p.u + (int64_t)min(r0 + r, p.R - 1) * F + c);
     }
+    if (p.t_dqkv) {
+        // ---- the upper layer's input gradient, finished here: dout <- dx1 (what `dout` holds) + dqkv Wqkv
+        for (int e = threadIdx.x; e < BM * (C / 4); e += NT) {
+            const int r = e / (C / 4), c = (e % (C / 4)) * 4;
+            *reinterpret_cast<float4*>(dzb + r * LDX + c) = *reinterpret_cast<const float4*>(p.dout + (int64_t)min(r0 + r, p.R - 1) * C + c);
+        }
+        for (int e = threadIdx.x; e < BM * (3 * C / 8); e += NT) {
+            const int r = e / (3 * C / 8), c = (e % (3 * C / 8)) * 8;
+            *reinterpret_cast<uint4*>(dub + r * LDH + c) = *reinterpret_cast<const uint4*>(p.t_dqkv + (int64_t)min(r0 + r, p.R - 1) * (3 * C) + c);
+        }
+        __syncthreads();
+        wg_gemm<BM, C, 3 * C, LDH>(dub, p.t_wqt, [&](int g, const f32x4 (&acc)[MT]) {
+            const int col = 16 * g + j;
+#pragma unroll
+            for (int t = 0; t < MT; ++t)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) dzb[(16 * t + 4 * q + v) * LDX + col] += acc[t][v];
+        }, pre0);
+        __syncthreads();
+    }
     // ---- dx2 = ffn_norm2'(dout);  df = dropout'(dx2)
-    ln_bwd_rows<BM, C, LDX, LDA>(nullptr, p.dout, lp2, nullptr, dxb, nullptr, gb, p.df, red, r0, p.R,
+    ln_bwd_rows<BM, C, LDX, LDA>(p.t_dqkv ? dzb : nullptr, p.dout, lp2, nullptr, dxb, nullptr, gb, p.df, red, r0, p.R,
                                  p.thr, p.inv_keep, seed, p.salt2);
     __syncthreads();
     flush_colsums<C>(red, p.dnxw, p.dnxb, p.db2);
@@ -745,10 +790,10 @@ __global__ __launch_bounds__(NT) void layer_chain_bwd_kernel(const ChainBwdParam
 template <int BM, int C, int F>
 int launch_bwd(const ChainBwdParams& p, hipStream_t st) {
     constexpr size_t lds = 2 * BM * (C + 4) * 4 + 3 * NW * C * 4 + BM * (C + 8) * 2 + 2 * BM * (F + 8) * 2;
-    static_assert(lds <= 152 * 1024, "LDS plan");
+    static_assert(lds <= 152 * 1024 && lds >= mobgt_wgrad::wgrad_lds_floats<NW>() * sizeof(float), "LDS plan");
     int rc = (int)hipFuncSetAttribute((const void*)layer_chain_bwd_kernel<BM, C, F>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (rc) return rc;
-    hipLaunchKernelGGL((layer_chain_bwd_kernel<BM, C, F>), dim3((p.R + BM - 1) / BM), dim3(NT), lds, st, p);
+    hipLaunchKernelGGL((layer_chain_bwd_kernel<BM, C, F>), dim3(p.n_chain + (p.n_wg ? p.wg_first[p.n_wg] : 0)), dim3(NT), lds, st, p);
     return (int)hipGetLastError();
 }
 
@@ -811,10 +856,15 @@ extern "C" int mobgt_layer_chain_bwd(const float* dout, const float* x2, const f
                                      const float* nxw, const void* w2t, const void* w1t, const void* wot, void* df, void* du,
                                      void* dy, void* da, float* dx1, float* dnxw, float* dnxb, float* db2, float* dn1w,
                                      float* dn1b, float* dbo, int64_t R, int C, int F, float dropout_p, uint64_t seed,
-                                     const uint64_t* seed_dev, uint32_t salt1, uint32_t salt2, void* stream) {
+                                     const uint64_t* seed_dev, uint32_t salt1, uint32_t salt2, const void* tail_dqkv,
+                                     const void* tail_wqkv_t, int n_wg, const void* const* wg_g, const int64_t* wg_ldg,
+                                     const void* const* wg_x, const int64_t* wg_ldx, float* const* wg_dw, const int64_t* wg_ldw,
+                                     float* const* wg_db, const int* wg_M, const int* wg_N, void* stream) {
     if (R <= 0) return 0;
-    if (R > 0x7fffffff) return MOBGT_EBADDIM;
-    if (((uintptr_t)u | (uintptr_t)w2t | (uintptr_t)w1t | (uintptr_t)wot | (uintptr_t)du | (uintptr_t)da) & 15) return MOBGT_EALIGN;
+    if (R > 0x7fffffff || n_wg < 0 || n_wg > 4) return MOBGT_EBADDIM;
+    if (((uintptr_t)u | (uintptr_t)w2t | (uintptr_t)w1t | (uintptr_t)wot | (uintptr_t)du | (uintptr_t)da | (uintptr_t)tail_dqkv |
+         (uintptr_t)tail_wqkv_t | (uintptr_t)dout) & 15) return MOBGT_EALIGN;
+    if ((tail_dqkv == nullptr) != (tail_wqkv_t == nullptr)) return MOBGT_EBADDIM;
     ChainBwdParams p = {};
     typedef const uint16_t* cu;
     p.dout = dout; p.x2 = x2; p.x1 = x1; p.u = (cu)u; p.mean1 = mean1; p.rstd1 = rstd1; p.mean2 = mean2; p.rstd2 = rstd2;
@@ -824,6 +874,19 @@ extern "C" int mobgt_layer_chain_bwd(const float* dout, const float* x2, const f
     p.thr = dropout_p > 0.f ? dropout_threshold(dropout_p) : 0u;
     p.inv_keep = p.thr ? 1.f / (1.f - (float)p.thr / 65536.f) : 1.f;
     p.seed = seed; p.seed_dev = seed_dev; p.salt1 = salt1; p.salt2 = salt2;
+    p.t_dqkv = (cu)tail_dqkv; p.t_wqt = (cu)tail_wqkv_t;
+    p.n_chain = (int)((R + 15) / 16);
+    p.n_wg = n_wg;
+    int total = 0;
+    for (int i = 0; i < n_wg; ++i) {             // the passengers: bf16 operands, R rows, 12 waves per workgroup like the chain's
+        const int rc = mobgt_wgrad::fill_problem(p.wg[i], wg_g[i], wg_ldg[i], wg_x[i], wg_ldx[i], wg_dw[i], wg_ldw[i],
+                                                 wg_db ? wg_db[i] : nullptr, R, wg_M[i], wg_N[i], 64, &p.wg_tiles[i],
+                                                 &p.wg_splits[i], 0, NW);
+        if (rc) return rc;
+        p.wg_first[i] = total;
+        total += p.wg_tiles[i] * p.wg_splits[i];
+    }
+    for (int i = n_wg; i <= 4; ++i) p.wg_first[i] = total;
     hipStream_t st = (hipStream_t)stream;
     if (C == 192 && F == 1024) return launch_bwd<16, 192, 1024>(p, st);
     if (C == 256 && F == 1024) return launch_bwd<16, 256, 1024>(p, st);

@@ -176,6 +176,38 @@ _CHAIN = [_os_ln.environ.get("MOBGT_NO_CHAIN") != "1"]
 _CHAIN_BWD = [_os_ln.environ.get("MOBGT_NO_CHAIN_BWD") != "1"]      # ... and the same chain backwards (d(out) -> d(attention out))
 
 
+# ---- what a layer's backward may leave to the backward of the layer BELOW it --------------------------------------------------
+# After its attention backward a layer still owes (a) its input gradient dx = dx1 + dqkv Wqkv and (b) four weight gradients: one
+# launch of ~9 us that keeps ~530 workgroups busy for a moment.  The next thing on the device is the lower layer's chain_bwd
+# launch: 38 workgroups on 38 of 256 compute units for 16 us.  So, when the layer below is a fused layer that will run
+# chain_bwd (its forward produced this layer's qkv), this layer returns dx1 as its input gradient, parks (dqkv, Wqkv^T, the
+# four problems) under that tensor's address, and the lower layer's chain launch finishes dx per row block in front of its
+# first norm and runs the weight gradients as extra workgroups (csrc/chain.hip).  A parked entry that no layer picks up is
+# an error, raised when the backward pass ends -- never a silently incomplete gradient.
+_DEFER = [_os_ln.environ.get("MOBGT_NO_DEFER_TAIL") != "1"]
+_PENDING_TAIL = {}
+_PENDING_CB = [False]
+
+
+def _complete_pending(pend):
+    """The parked work as its own launch (what the layer would have issued itself): dx1 += dqkv Wqkv and the four dW."""
+    wb = _WgradBatch()
+    wb.items = pend["items"]
+    if not wb.flush(tail=(pend["dqkv"], pend["wqkv"], pend["dx1"])):
+        ops.layer_gemm(pend["dqkv"], pend["wqkv"], None, True, ops.GEMM_ADD, aux_in=pend["dx1"])
+
+
+def _pending_check():
+    _PENDING_CB[0] = False
+    if _PENDING_TAIL:
+        left = list(_PENDING_TAIL.values())
+        _PENDING_TAIL.clear()
+        for pend in left:                        # finish the arithmetic, then say that the protocol was broken
+            _complete_pending(pend)
+        raise RuntimeError("mobgt fused layer: a deferred input gradient was not consumed by the layer below "
+                           "(was the layer's input used by something else as well?); set MOBGT_NO_DEFER_TAIL=1")
+
+
 def _chain_ok(C, F, *ts):
     return (_CHAIN[0] and (C, F) in ((192, 1024), (256, 1024))
             and all(t is None or (t.is_contiguous() and t.data_ptr() % 16 == 0) for t in ts))
@@ -225,9 +257,10 @@ class LayerConfig:
         self.seed, self.seed_dev, self.salt = int(seed), seed_dev, int(salt) & 0xFFFFFFFF
         self.pack = pack
         self.act_dtype = act_dtype
+        self.from_layer = False   # the layer's input is the output of another fused layer (model.fused_layer_forward)
         self.next_qkv = None      # (packed wqkv, bqkv) of the NEXT fused layer: its QKV projection rides in this layer's chain
         self.packed = None        # (wo, w1, w2) of this layer in MFMA operand order (model.pack_layer_weights)
-        self.packed_t = None      # (w2^T, w1^T, wo^T) likewise, for the backward chain
+        self.packed_t = None      # (w2^T, w1^T, wo^T, wqkv^T) likewise, for the backward chain
         self.out_act = self.out_qkv = None
 
 
@@ -282,6 +315,9 @@ class _FusedLayerFn(torch.autograd.Function):
         ctx.fuse_ln = use_chain
         ctx.chain_bwd = bool(use_chain and _CHAIN_BWD[0] and cfg.packed_t is not None
                              and all(t.is_contiguous() and t.data_ptr() % 16 == 0 for t in cfg.packed_t))
+        # the layer below produced this layer's qkv in ITS chain launch and will run chain_bwd: it can host what this layer's
+        # backward leaves undone (see _PENDING_TAIL)
+        ctx.below_hosts = bool(cfg.from_layer and qkv_pre is not None and ctx.chain_bwd and len(cfg.packed_t) > 3)
         if use_chain:               # everything row-local of the layer (+ the next layer's QKV projection) in one launch
             bf = dict(dtype=A, device=dev)
             x1, x2, out = torch.empty(R, C, **f32), torch.empty(R, C, **f32), torch.empty(R, C, **f32)
@@ -430,18 +466,37 @@ class _FusedLayerFn(torch.autograd.Function):
         wb = _WgradBatch()
         k_qkv, k_wo, k_w1, k_w2 = ctx.sinks                          # gradient sinks (or None)
         db1_in_wgrad = _wgrad_hip(A, F, C, R)                         # then b1's gradient rides on the dW1 kernel
+        pend = _PENDING_TAIL.pop(dout.data_ptr(), None) if _PENDING_TAIL else None
+        host = pend is not None and getattr(ctx, "chain_bwd", False) and db1_in_wgrad and not stock and pend["R"] == R
+        if pend is not None and not host:
+            _complete_pending(pend)                                   # this layer cannot host it: finish it right here
+            pend = None
         if getattr(ctx, "chain_bwd", False) and db1_in_wgrad and not stock:
             # d(out) -> ffn_norm2' -> dropout' -> (W2, gelu') -> W1 -> ffn_norm1' + residual -> dropout' -> Wo: one launch
             bf = dict(dtype=A, device=dev)
             df, dy, da = torch.empty(R, C, **bf), torch.empty(R, C, **bf), torch.empty(R, C, **bf)
             du = torch.empty(R, F, **bf)
             dx1 = torch.empty(R, C, dtype=torch.float32, device=dev)
-            w2t, w1t, wot = cfg.packed_t
+            w2t, w1t, wot = cfg.packed_t[:3]
+            vp, i64, ci = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int
+            if pend is not None:
+                # ... and, hosted for the layer above: its input gradient is finished in front of the first norm (`dout` holds
+                # its dx1), its four weight gradients run as extra workgroups of this launch
+                it = pend["items"]
+                n = len(it)
+                extra = (_p(pend["dqkv"]), _p(pend["wqt"]), n, (vp * n)(*[t[0].data_ptr() for t in it]),
+                         (i64 * n)(*[t[0].stride(0) for t in it]), (vp * n)(*[t[1].data_ptr() for t in it]),
+                         (i64 * n)(*[t[1].stride(0) for t in it]), (vp * n)(*[t[2].data_ptr() for t in it]),
+                         (i64 * n)(*[t[2].shape[1] for t in it]),
+                         (vp * n)(*[(t[3].data_ptr() if t[3] is not None else None) for t in it]),
+                         (ci * n)(*[t[0].shape[1] for t in it]), (ci * n)(*[t[1].shape[1] for t in it]))
+            else:
+                extra = (None, None, 0, None, None, None, None, None, None, None, None, None)
             check(_lib.lib().mobgt_layer_chain_bwd(_p(dout), _p(x2), _p(x1), _p(u), _p(stats[2]), _p(stats[3]), _p(stats[4]),
                                                    _p(stats[5]), _p(n1w), _p(nxw), _p(w2t), _p(w1t), _p(wot), _p(df), _p(du),
                                                    _p(dy), _p(da), _p(dx1), _p(dnxw), _p(dnxb), _p(db2), _p(dn1w), _p(dn1b),
                                                    _p(dbo), R, C, F, cfg.p, seed, _p(sd), (salt + 1) & 0xFFFFFFFF,
-                                                   (salt + 2) & 0xFFFFFFFF, _stream()), "mobgt_layer_chain_bwd")
+                                                   (salt + 2) & 0xFFFFFFFF, *extra, _stream()), "mobgt_layer_chain_bwd")
             da = da.view(G, T, C)
             dw2 = wb.add(df, h, sink=k_w2)
             dw1 = wb.add(du, z, db=db1, sink=k_w1)
@@ -456,8 +511,24 @@ class _FusedLayerFn(torch.autograd.Function):
                       cfg.p_att, seed ^ (salt * 0x9E3779B1), sd)
         dqkv2 = dqkv.view(R, 3 * C)
         dwqkv = wb.add(dqkv2, xa, db=dbqkv, sink=k_qkv)
-        # fq variant, own GEMMs: dx = dx1 + dqkv Wqkv rides in the weight-gradient launch
-        rode = wb.flush(tail=(dqkv2, s_wqkv, dx1) if (own and not stock and _TAIL[0]) else None)
+        defer = (_DEFER[0] and getattr(ctx, "below_hosts", False) and own and not stock and _TAIL[0] and len(wb.items) == 4
+                 and R <= 1024 and dx1.data_ptr() % 16 == 0 and dqkv2.is_contiguous() and ctx.small_sink is not None
+                 and all(k is not None for k in ctx.sinks))
+        if defer:
+            # nothing more is launched for this layer: the chain launch of the layer below finishes dx and the weight gradients
+            # (parked as FRESH views of the gradient buffers: autograd's AccumulateGrad clones a returned gradient that anything
+            # else still references, and the clone -- taken before the buffers are filled -- would later be copied over them)
+            items = [(g_, x_, dw_[:], db_[:] if db_ is not None else None) for g_, x_, dw_, db_ in wb.items]
+            _PENDING_TAIL[dx1.data_ptr()] = dict(dx1=dx1[:], dqkv=dqkv2, wqkv=s_wqkv, wqt=cfg.packed_t[3], items=items, R=R)
+            wb.items = []
+            if not _PENDING_CB[0]:
+                _PENDING_CB[0] = True
+                torch.autograd.Variable._execution_engine.queue_callback(_pending_check)
+            rode = True
+            dx = dx1
+        else:
+            # fq variant, own GEMMs: dx = dx1 + dqkv Wqkv rides in the weight-gradient launch
+            rode = wb.flush(tail=(dqkv2, s_wqkv, dx1) if (own and not stock and _TAIL[0]) else None)
         if rode:
             dx = dx1
         elif stock:                                                     # back through self_attention_norm
@@ -482,4 +553,5 @@ def fused_encoder_layer(x, pack, cfg, shadows, params, xa_pre=None, qkv_pre=None
         out._mobgt_act = cfg.out_act          # picked up by the next fused layer (same Python tensor object)
     if cfg.out_qkv is not None:
         out._mobgt_qkv = cfg.out_qkv          # ... and its QKV projection, already computed by this layer's chain kernel
+        out._mobgt_from_layer = True          # (the consumer's backward may leave its tail to this layer's: _PENDING_TAIL)
     return out

@@ -194,6 +194,7 @@ def fused_layer_forward(layer, variant, x, attn_bias, n1, nx, next_layer=None):
     if (p > 0 or p_att > 0) and mha.seed_dev is None:
         seed = (seed + int(torch.randint(0, 2 ** 31 - 1, (1,)).item())) & 0x7FFFFFFFFFFFFFFF
     cfg = LayerConfig(variant, mha.num_heads, mha.scale, p, p_att, seed, mha.seed_dev, mha._layer_index * 8, pack, act)
+    cfg.from_layer = bool(getattr(x, "_mobgt_from_layer", False))
     # the next layer's QKV projection rides in this layer's chain kernel (csrc/chain.hip) when that layer is fused, has
     # the same activation dtype and its bf16 shadows are current (refresh_shadows / the trainer refreshed ALL layers)
     nxt = next_layer
@@ -246,7 +247,7 @@ def refresh_shadows(layers):
 def pack_layer_weights(layers):
     """MFMA-operand-order copies of the fused fq layers' bf16 GEMM weights (csrc/chain.hip reads a wave's B operand as one
     contiguous KB), all layers in one launch (up to 96 weights): `layer._packed` = (wqkv, wo, w1, w2) packed for the
-    forward chain and, when gradients are enabled, `layer._packed_t` = (w2^T, w1^T, wo^T) for the backward chain."""
+    forward chain and, when gradients are enabled, `layer._packed_t` = (w2^T, w1^T, wo^T, wqkv^T) for the backward chain."""
     import ctypes
     from . import fused_layer, _lib
     from .ops import _stream
@@ -273,9 +274,9 @@ def pack_layer_weights(layers):
         if want_t and any(p.requires_grad for p in layer.parameters()):
             pt = getattr(layer, "_packed_t", None)
             if pt is None or pt[0].device != sh[0].device:
-                pt = tuple(torch.empty_like(sh[i]) for i in (6, 4, 2))
+                pt = tuple(torch.empty_like(sh[i]) for i in (6, 4, 2, 0))
                 layer._packed_t = pt
-            for d, i in zip(pt, (6, 4, 2)):          # dX = dY W: W [K = out, N = in] is the operand, packed as [N][K]
+            for d, i in zip(pt, (6, 4, 2, 0)):       # dX = dY W: W [K = out, N = in] is the operand, packed as [N][K]
                 jobs.append((sh[i], d, sh[i].shape[1], sh[i].shape[0], 1))
             layer._packed_t_fresh = True
     for o in range(0, len(jobs), 96):
