@@ -194,8 +194,11 @@ __device__ __forceinline__ void wave_reduce_heads(float (&v)[HH], int lane) {
 // a trajectory) go straight to the atomic unit, where they do not collide anyway.
 constexpr int MAX_LIGHT = 2;
 
+// The LDS table is laid out [head][row] with an ODD row stride `lo_stride`: one instruction adds one head of up to 64
+// different rows -- distinct banks unless rows collide mod 32 -- and the H lanes of a combined key hit H different banks.
+// ([row][head] put the 64 lanes of an instruction on 4 banks: the LDS was busy half of the kernel's time.)
 template <int HH>
-__device__ __forceinline__ void wave_scatter_add(float* table_lo, int lo_rows, float* table_hi, int key,
+__device__ __forceinline__ void wave_scatter_add(float* table_lo, int lo_rows, int lo_stride, float* table_hi, int key,
                                                  const float (&vals)[HH], int lane) {
     unsigned long long todo = __ballot(key >= 0);
     unsigned long long light = 0;
@@ -217,7 +220,7 @@ __device__ __forceinline__ void wave_scatter_add(float* table_lo, int lo_rows, f
         if ((lane & (STEP - 1)) == 0) {
             const int h = lane / STEP;
             // two explicit paths: a select of an LDS and a global pointer compiles to flat_atomic_add_f32
-            if (k < lo_rows) lds_add(table_lo + (size_t)k * HH + h, r[0]);
+            if (k < lo_rows) lds_add(table_lo + h * lo_stride + k, r[0]);
             else atomicAdd(table_hi + (size_t)k * HH + h, r[0]);
         }
     }
@@ -225,7 +228,68 @@ __device__ __forceinline__ void wave_scatter_add(float* table_lo, int lo_rows, f
     if ((light >> lane) & 1ull) {
         if (key < lo_rows) {
 #pragma unroll
-            for (int h = 0; h < HH; ++h) lds_add(table_lo + (size_t)key * HH + h, vals[h]);
+            for (int h = 0; h < HH; ++h) lds_add(table_lo + h * lo_stride + key, vals[h]);
+        } else {
+#pragma unroll
+            for (int h = 0; h < HH; ++h) atomicAdd(table_hi + (size_t)key * HH + h, vals[h]);
+        }
+    }
+}
+
+// LDS FLOAT atomics are serial on gfx950: ds_add_f32 costs ~3 cycles per ACTIVE LANE (193 cycles per full wave instruction
+// whatever the addresses) against 8 cycles for ds_add_u32 and 13 for ds_add_u64 (tools/micro/lds_rate.hip).  The rel / poi
+// tables receive one add per lane, head and round (distinct SPDs / distance bins along a row: nothing to combine), and with
+// float atomics the LDS was busy two thirds of the kernel's time.  They are therefore kept in 64-bit FIXED POINT: values
+// scaled by 2^k with k chosen per launch from a strided sample of the gradient (sample maximum -> 2^34), added with
+// ds_add_u64, converted back at the flush.  An addend is exact unless it is below 2^-10 of the sample maximum, then it is
+// rounded to 2^-34 of it; one that is 2^12 times LARGER than the sample maximum (or not finite) does not fit the headroom
+// left for 2^16 adds per entry and goes straight to the global f32 table, as do all of them when the sample is all zero.
+typedef __attribute__((address_space(3))) unsigned long long lds_u64;
+constexpr float FX_LIMIT = 0x1p46f;
+__device__ __forceinline__ unsigned long long to_fx(float x, float scale, bool& ok) {
+    const float y = rintf(x * scale);
+    ok = fabsf(y) < FX_LIMIT;                              // false for NaN / inf / scale == 0 (no usable sample)
+    const float hi = floorf(y * 0x1p-32f);
+    const float lo = fmaf(hi, -0x1p32f, y);                // in [0, 2^32), an integer
+    return ((unsigned long long)(uint32_t)(int32_t)hi << 32) | (unsigned long long)(uint32_t)lo;
+}
+__device__ __forceinline__ void lds_add_fx(unsigned long long* p, unsigned long long v) {
+    __hip_atomic_fetch_add((lds_u64*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+// wave_scatter_add for a fixed-point LDS table: fx[h] = to_fx(vals[h]), fx_ok = all of them fit
+template <int HH>
+__device__ __forceinline__ void wave_scatter_add_fx(unsigned long long* table_lo, int lo_rows, int lo_stride, float* table_hi,
+                                                    int key, const float (&vals)[HH], const unsigned long long (&fx)[HH],
+                                                    bool fx_ok, float scale, int lane) {
+    unsigned long long todo = __ballot(key >= 0);
+    unsigned long long light = 0;
+    int misses = 0;
+    for (int it = 0; it < 8 && todo && misses < MAX_LIGHT; ++it) {
+        const int leader = __ffsll((long long)todo) - 1;
+        const int k = __shfl(key, leader, 64);
+        const bool mine = key == k;
+        const unsigned long long same = __ballot(mine) & todo;
+        todo &= ~same;
+        if (__popcll(same) < 8) { light |= same; ++misses; continue; }
+        float r[HH];
+#pragma unroll
+        for (int h = 0; h < HH; ++h) r[h] = mine ? vals[h] : 0.f;
+        wave_reduce_heads<HH>(r, lane);
+        constexpr int STEP = 64 / HH;
+        bool ok;
+        const unsigned long long q = to_fx(r[0], scale, ok);
+        if ((lane & (STEP - 1)) == 0) {
+            const int h = lane / STEP;
+            if (k < lo_rows && ok) lds_add_fx(table_lo + h * lo_stride + k, q);
+            else atomicAdd(table_hi + (size_t)k * HH + h, r[0]);
+        }
+    }
+    light |= todo;
+    if ((light >> lane) & 1ull) {
+        if (key < lo_rows && fx_ok) {
+#pragma unroll
+            for (int h = 0; h < HH; ++h) lds_add_fx(table_lo + h * lo_stride + key, fx[h]);
         } else {
 #pragma unroll
             for (int h = 0; h < HH; ++h) atomicAdd(table_hi + (size_t)key * HH + h, vals[h]);
@@ -246,42 +310,99 @@ constexpr int HOP_LDS_ROWS = 16;      // edge ids < 16 (count <= 12) accumulate 
 constexpr int HOP_DMAX = 20;
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 
-template <typename TI, typename TE, int HH, bool HOPMM>
-__global__ __launch_bounds__(256) void build_bias_bwd_kernel(const BuildParams p, int lds_rel, int lds_poi) {
-    __shared__ __attribute__((aligned(16))) uint16_t hop_e[HOPMM ? 4 : 1][HOPMM ? HOP_DMAX : 1][64];    // [wave][d][pair] one-hot
-    __shared__ __attribute__((aligned(16))) bf16_t hop_b[HOPMM ? 4 : 1][2][16][HOPMM ? 32 : 1];         // [wave][half][col][pair]
-    __shared__ __attribute__((aligned(16))) float gr_s[4][HH][2][32];                                    // [wave][head][row][col]
+constexpr int HOP_STRIDE = HOP_LDS_ROWS + 1;
+__host__ __device__ constexpr int odd(int n) { return n | 1; }
+// LDS dwords of the per-workgroup tables: rel, poi (64-bit fixed point), vdist, hop rows, hop-length sums (f32) -- each
+// [head][odd stride]
+__host__ __device__ inline int bwd_lds_dwords(int lds_rel, int lds_poi, int D, int H) {
+    return (2 * (odd(lds_rel) + odd(lds_poi)) + 1 + D * HOP_STRIDE + odd(D + 1)) * H;
+}
+
+// NW waves per workgroup, each wave owning ONE row x 64 columns of a unit (its row segments of the bf16 gradient slices are
+// whole 128-byte lines: with 2 rows x 32 columns every line was fetched twice, by two workgroups): 4 waves for short
+// batches (more units to spread), 8 for long ones (one workgroup per CU shares ONE set of tables among 8 waves: the
+// 4-wave form needed 78 KB of LDS and 308 registers, i.e. ran one wave per SIMD with every latency exposed).
+template <typename TI, typename TE, int HH, bool HOPMM, int NW>
+__global__ __launch_bounds__(NW * 64) void build_bias_bwd_kernel(const BuildParams p, int lds_rel, int lds_poi) {
+    __shared__ __attribute__((aligned(16))) uint16_t hop_e[HOPMM ? NW : 1][HOPMM ? HOP_DMAX : 1][64];    // [wave][d][pair] one-hot
+    // (the MFMA's B staging [half][col][pair] bf16 overlays the wave's gr_s tile: both are private to the wave, LDS runs a
+    // wave's instructions in order, and gr_s is dead once gr[] has been read)
+    __shared__ __attribute__((aligned(16))) float gr_s[NW][HH][64];                                       // [wave][head][col]
+    static_assert(!HOPMM || sizeof(float) * HH * 64 >= sizeof(bf16_t) * 2 * 16 * 32, "hop_b overlays gr_s");
+    __shared__ float wmax_s[NW];
     f32x4_t hacc[HOPMM ? HOP_DMAX : 1];
 #pragma unroll
     for (int d = 0; d < (HOPMM ? HOP_DMAX : 1); ++d) hacc[d] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* s_rel = smem;                                  // [lds_rel][HH]
-    float* s_poi = s_rel + (size_t)lds_rel * HH;          // [lds_poi][HH]
-    float* s_vd = s_poi + (size_t)lds_poi * HH;           // [HH]
-    float* s_hop = s_vd + HH;                             // [D][HOP_LDS_ROWS][HH]
-    float* s_len = s_hop + (size_t)p.D * HOP_LDS_ROWS * HH;   // [D+1][HH]: sums keyed by the number of real hops
-    const int n_lds = (lds_rel + lds_poi + 1 + p.D * HOP_LDS_ROWS + p.D + 1) * HH;
+    const int st_rel = odd(lds_rel), st_poi = odd(lds_poi), st_len = odd(p.D + 1);
+    unsigned long long* s_rel = reinterpret_cast<unsigned long long*>(smem);      // [HH][st_rel] fixed point
+    unsigned long long* s_poi = s_rel + (size_t)st_rel * HH;                      // [HH][st_poi] fixed point
+    float* s_vd = reinterpret_cast<float*>(s_poi + (size_t)st_poi * HH);          // [HH]
+    float* s_hop = s_vd + HH;                             // [D][HH][HOP_STRIDE]
+    float* s_len = s_hop + (size_t)p.D * HOP_STRIDE * HH;     // [HH][st_len]: sums keyed by the number of real hops
+    const int n_lds = bwd_lds_dwords(lds_rel, lds_poi, p.D, HH);
     for (int t = threadIdx.x; t < n_lds; t += blockDim.x) smem[t] = 0.f;
-    __syncthreads();
 
     const int N = p.N, T = N + 1;
-    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-    const int lane = threadIdx.x & 63;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const float inv_f = 1.f / (float)p.F;
+    // fixed-point scale from a strided sample of the gradient (the same 16 positions x threads in every workgroup: L2 hits
+    // after the first; bf16: first and last layer slice, times the number of slices)
+    float fx_scale = 0.f, fx_inv = 0.f;
+    {
+        const int64_t total = (int64_t)p.G * HH * T * p.ld;
+        float m = 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int64_t at = (((int64_t)(threadIdx.x * 4 + q) * total) / (4 * NW * 64)) & ~(int64_t)7;
+            const int col = (int)(at % p.ld);              // (columns >= T are padding nobody has to have written)
+            if (p.dbias_bf16) {
+                const bf16_t* src = reinterpret_cast<const bf16_t*>(p.dbias) + at;
+                const uint4 a = *reinterpret_cast<const uint4*>(src);
+                const uint4 b = *reinterpret_cast<const uint4*>(src + (int64_t)(p.n_slices - 1) * p.slice_stride);
+                const uint32_t w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    if (col + 2 * (i & 3) < T) m = fmaxf(m, fabsf(bf16_lo(w[i])));
+                    if (col + 2 * (i & 3) + 1 < T) m = fmaxf(m, fabsf(bf16_hi(w[i])));
+                }
+            } else {
+                const float4 a = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p.dbias) + at);
+                const float4 b = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p.dbias) + at + 4);
+                const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+                    if (col + i < T) m = fmaxf(m, fabsf(v[i]));
+            }
+        }
+#pragma unroll
+        for (int bit = 32; bit >= 1; bit >>= 1) m = fmaxf(m, __shfl_xor(m, bit, 64));
+        if (lane == 0) wmax_s[wv] = m;
+        __syncthreads();
+        m = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) m = fmaxf(m, wmax_s[w]);
+        if (p.dbias_bf16) m *= (float)p.n_slices;
+        if (m > 0.f && m < INFINITY) {                     // (NaN fails both)
+            int e = 34 - ilogbf(m);
+            e = e > 120 ? 120 : (e < -120 ? -120 : e);
+            fx_scale = ldexpf(1.f, e);
+            fx_inv = ldexpf(1.f, -e);
+        }
+    }
+    // (the barrier above also orders the zeroing of the tables before their first use)
     // A workgroup walks tiles blockIdx.x, blockIdx.x + gridDim.x, ... and flushes its LDS tables ONCE at the end:
     // with one tile per workgroup a long-trajectory batch (T = 785: 10 000 tiles) flushed ~100 M f32 atomics
     // (every tile touches most SPD / distance-bin rows) and spent ~3 ms doing so.
-    const int nt = (T + TILE - 1) / TILE;
-    const int n_tiles = nt * nt * p.G;
-    // the unit of work is one 8-row round of a tile (4 per tile): short batches (16 graphs x 41 tokens = 64 tiles)
-    // then still spread over 256 workgroups instead of 64 that each run their four rounds back to back
+    // the unit of work is NW rows x 64 columns; consecutive units are neighbours along the row
+    const int njt = (T + 63) / 64, nib = (T + NW - 1) / NW;
+    const int n_units = njt * nib * p.G;
 #pragma unroll 1
-    for (int unit = blockIdx.x; unit < 4 * n_tiles; unit += gridDim.x) {
-    const int tile_id = unit >> 2, r = (unit & 3) * 8;
-    const int g = tile_id / (nt * nt);
-    const int i0 = ((tile_id / nt) % nt) * TILE, j0 = (tile_id % nt) * TILE;
+    for (int unit = blockIdx.x; unit < n_units; unit += gridDim.x) {
+    const int g = unit / (njt * nib);
+    const int j0 = (unit % njt) * 64;
     {
-        const int ti = i0 + ty + r, tj = j0 + tx;
+        const int ti = ((unit / njt) % nib) * NW + wv, tj = j0 + lane;
         // Every load of this round is issued up front, keyed on the index range only: the chain
         // attn_bias -> (live?) -> dBias -> rel_pos -> hop ids used to be 4-5 dependent memory round trips per round
         // at 3 waves per SIMD (~13 k cycles per round).
@@ -292,27 +413,46 @@ __global__ __launch_bounds__(256) void build_bias_bwd_kernel(const BuildParams p
         const int rp_raw = pairin ? ld_idx<TI>(p.rel_pos, pair) : 0;
         const int pp_raw = (pairin && p.poi_pos) ? ld_idx<TI>(p.poi_pos, pair) : 0;
         const int64_t ebase = pair * p.D_in * p.F;
-        int hop_id[HOPMM ? HOP_DMAX : 1];
+        // a pair's hop ids: D_in bytes (4-byte aligned when D_in % 4 == 0) as dwords -- 5 loads instead of 20
+        constexpr bool HOPW = HOPMM && sizeof(TE) == 1;
+        uint32_t hop_w[HOPW ? HOP_DMAX / 4 : 1];
+        int hop_id[(HOPMM && !HOPW) ? HOP_DMAX : 1];
+        const bool hop_words = HOPW && (p.D_in & 3) == 0;
         if (HOPMM) {
+            if (HOPW && hop_words) {
 #pragma unroll
-            for (int d = 0; d < HOP_DMAX; ++d) hop_id[d] = (d < p.D && pairin) ? ld_idx<TE>(p.edge_input, ebase + d) : 0;
+                for (int w = 0; w < HOP_DMAX / 4; ++w)
+                    hop_w[w] = (4 * w < p.D && pairin)
+                                   ? *reinterpret_cast<const uint32_t*>(reinterpret_cast<const uint8_t*>(p.edge_input) + ebase + 4 * w)
+                                   : 0u;
+            } else if (HOPW) {
+#pragma unroll
+                for (int w = 0; w < HOP_DMAX / 4; ++w) {
+                    uint32_t v = 0;
+#pragma unroll
+                    for (int b = 0; b < 4; ++b)
+                        if (4 * w + b < p.D && pairin) v |= (uint32_t)ld_idx<TE>(p.edge_input, ebase + 4 * w + b) << (8 * b);
+                    hop_w[w] = v;
+                }
+            } else {
+#pragma unroll
+                for (int d = 0; d < HOP_DMAX; ++d) hop_id[d] = (d < p.D && pairin) ? ld_idx<TE>(p.edge_input, ebase + d) : 0;
+            }
         }
         float gr[HH];
 #pragma unroll
         for (int h = 0; h < HH; ++h) gr[h] = 0.f;
         if (p.dbias_bf16) {
-            // bf16 layer slices: the wave's 64 pairs are 2 rows x 32 columns x HH heads = 2*HH row segments of 64 B per
-            // slice -- ONE 16-byte-per-lane load instruction per slice (lane = (head, row, 8-column part)) instead of
+            // bf16 layer slices: the wave's 64 pairs are 1 row x 64 columns x HH heads = HH row segments of 128 B per
+            // slice -- ONE 16-byte-per-lane load instruction per slice (lane = (head, 8-column part)) instead of
             // HH two-byte loads per pair, and up to 12 slices in flight at once.  The f32 sums go through a
             // wave-private LDS tile to the lanes that own the pairs.
-            const int wv = threadIdx.x >> 6;
-            const int seg = lane >> 2, part = lane & 3, sh = seg >> 1, srow = seg & 1;
-            const int row = i0 + r + 2 * wv + srow;
+            const int sh = lane >> 3, part = lane & 7;
             float s8[8];
 #pragma unroll
             for (int i = 0; i < 8; ++i) s8[i] = 0.f;
-            if (seg < 2 * HH && row >= 1 && row < T) {
-                const bf16_t* src = reinterpret_cast<const bf16_t*>(p.dbias) + (((int64_t)g * HH + sh) * T + row) * p.ld + j0 + 8 * part;
+            if (sh < HH && ti >= 1 && ti < T && j0 + 8 * part < p.ld) {
+                const bf16_t* src = reinterpret_cast<const bf16_t*>(p.dbias) + (((int64_t)g * HH + sh) * T + ti) * p.ld + j0 + 8 * part;
                 for (int l = 0; l < p.n_slices; l += 12) {
                     uint4 t[12];
 #pragma unroll
@@ -327,15 +467,15 @@ __global__ __launch_bounds__(256) void build_bias_bwd_kernel(const BuildParams p
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
-            if (seg < 2 * HH) {
-                float* dst = &gr_s[wv][sh][srow][8 * part];
+            if (sh < HH) {
+                float* dst = &gr_s[wv][sh][8 * part];
                 *reinterpret_cast<float4*>(dst) = make_float4(s8[0], s8[1], s8[2], s8[3]);
                 *reinterpret_cast<float4*>(dst + 4) = make_float4(s8[4], s8[5], s8[6], s8[7]);
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
-            for (int h = 0; h < HH; ++h) gr[h] = gr_s[wv][h][lane >> 5][lane & 31];
+            for (int h = 0; h < HH; ++h) gr[h] = gr_s[wv][h][lane];
         } else if (inr) {
             const int64_t at0 = ((int64_t)g * HH * T + ti) * p.ld + tj;          // head 0; heads are T * ld apart
             const int64_t hs = (int64_t)T * p.ld;
@@ -348,14 +488,22 @@ __global__ __launch_bounds__(256) void build_bias_bwd_kernel(const BuildParams p
             for (int h = 0; h < HH; ++h) gr[h] = 0.f;
         }
         // virtual-token column
-        wave_scatter_add<HH>(s_vd, 1, s_vd, (live && tj == 0) ? 0 : -1, gr, lane);
+        wave_scatter_add<HH>(s_vd, 1, 1, s_vd, (live && tj == 0) ? 0 : -1, gr, lane);
         const bool pairlive = live && tj >= 1;
         const int rp = pairlive ? rp_raw : 0;
         // row 0 of the index tables is nn.Embedding's padding_idx: it never receives a gradient, skip it
-        wave_scatter_add<HH>(s_rel, lds_rel, p.d_rel, (pairlive && rp != 0) ? rp : -1, gr, lane);
+        unsigned long long gfx[HH];
+        bool gfx_ok = true;
+#pragma unroll
+        for (int h = 0; h < HH; ++h) {
+            bool ok;
+            gfx[h] = to_fx(gr[h], fx_scale, ok);
+            gfx_ok = gfx_ok && ok;
+        }
+        wave_scatter_add_fx<HH>(s_rel, lds_rel, st_rel, p.d_rel, (pairlive && rp != 0) ? rp : -1, gr, gfx, gfx_ok, fx_scale, lane);
         if (p.poi_pos) {
             const int pp = pairlive ? pp_raw : 0;
-            wave_scatter_add<HH>(s_poi, lds_poi, p.d_poi, (pairlive && pp != 0) ? pp : -1, gr, lane);
+            wave_scatter_add_fx<HH>(s_poi, lds_poi, st_poi, p.d_poi, (pairlive && pp != 0) ? pp : -1, gr, gfx, gfx_ok, fx_scale, lane);
         }
         if (p.edge_input) {
             const float inv = inv_f / spd_divisor(rp, p.D);
@@ -364,6 +512,7 @@ __global__ __launch_bounds__(256) void build_bias_bwd_kernel(const BuildParams p
             for (int h = 0; h < HH; ++h) ge[h] = pairlive ? gr[h] * inv : 0.f;      // (the virtual-token column has no hops)
             if (HOPMM) {
                 const int wave = threadIdx.x >> 6, half = lane >> 5, k = lane & 31;
+                bf16_t (*hop_b)[16][32] = reinterpret_cast<bf16_t (*)[16][32]>(&gr_s[wave][0][0]);       // [half][col][pair]
                 // the staging areas are private to the wave and LDS executes a wave's instructions in order, so only
                 // the COMPILER has to be kept from moving this round's writes above the previous round's reads
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -371,13 +520,14 @@ __global__ __launch_bounds__(256) void build_bias_bwd_kernel(const BuildParams p
 #pragma unroll
                 for (int h = 0; h < HH; ++h) {
                     const bf16_t hi = (bf16_t)ge[h];
-                    hop_b[wave][half][h][k] = hi;
-                    hop_b[wave][half][8 + h][k] = (bf16_t)(ge[h] - (float)hi);
+                    hop_b[half][h][k] = hi;
+                    hop_b[half][8 + h][k] = (bf16_t)(ge[h] - (float)hi);
                 }
 #pragma unroll
                 for (int d = 0; d < HOP_DMAX; ++d) {
                     if (d < p.D) {
-                        const int idx = pairlive ? hop_id[d] : 0;
+                        const int raw = HOPW ? (int)((hop_w[HOPW ? d / 4 : 0] >> (8 * (d & 3))) & 0xffu) : hop_id[HOPW ? 0 : d];
+                        const int idx = pairlive ? raw : 0;
                         if (idx >= 16 && idx < p.n_edge) {         // rare id: straight to the atomic unit
 #pragma unroll
                             for (int h = 0; h < HH; ++h) atomicAdd(&p.d_hop[((int64_t)d * p.n_edge + idx) * HH + h], ge[h]);
@@ -395,7 +545,7 @@ __global__ __launch_bounds__(256) void build_bias_bwd_kernel(const BuildParams p
                 const uint32_t rot = (uint32_t)(m - 14) & 31u;      // rotate RIGHT by m - 14 (mod 32)
 #pragma unroll
                 for (int hf = 0; hf < 2; ++hf) {
-                    const bf16x8 bop = *reinterpret_cast<const bf16x8*>(&hop_b[wave][hf][m][8 * kq]);
+                    const bf16x8 bop = *reinterpret_cast<const bf16x8*>(&hop_b[hf][m][8 * kq]);
 #pragma unroll
                     for (int d = 0; d < HOP_DMAX; ++d) {
                         if (d < p.D) {
@@ -424,17 +574,17 @@ __global__ __launch_bounds__(256) void build_bias_bwd_kernel(const BuildParams p
                 }
             }
             if (p.F == 1 && !__any(!clean)) {
-                wave_scatter_add<HH>(s_len, p.D + 1, s_len, pairlive ? L : -1, ge, lane);
+                wave_scatter_add<HH>(s_len, p.D + 1, st_len, s_len, pairlive ? L : -1, ge, lane);
                 for (int d = 0; __any(d < L); ++d) {
                     const int idx = (pairlive && d < L) ? ld_idx<TE>(p.edge_input, ebase + d) : -1;
-                    wave_scatter_add<HH>(s_hop + (size_t)d * HOP_LDS_ROWS * HH, HOP_LDS_ROWS,
+                    wave_scatter_add<HH>(s_hop + (size_t)d * HOP_STRIDE * HH, HOP_LDS_ROWS, HOP_STRIDE,
                                          p.d_hop + (int64_t)d * p.n_edge * HH, idx, ge, lane);
                 }
             } else {
                 for (int d = 0; d < p.D; ++d)
                     for (int f = 0; f < p.F; ++f) {
                         const int idx = pairlive ? ld_idx<TE>(p.edge_input, ebase + (int64_t)d * p.F + f) : -1;
-                        wave_scatter_add<HH>(s_hop + (size_t)d * HOP_LDS_ROWS * HH, HOP_LDS_ROWS,
+                        wave_scatter_add<HH>(s_hop + (size_t)d * HOP_STRIDE * HH, HOP_LDS_ROWS, HOP_STRIDE,
                                              p.d_hop + (int64_t)d * p.n_edge * HH, idx, ge, lane);
                     }
             }
@@ -451,17 +601,21 @@ __global__ __launch_bounds__(256) void build_bias_bwd_kernel(const BuildParams p
 #pragma unroll
                 for (int v = 0; v < 4; ++v) {
                     const float tot = 0.5f * (hacc[d][v] + __shfl_xor(hacc[d][v], 8, 64));   // one-hot entries are 2.0
-                    if (n < 8 && tot != 0.f) lds_add(&s_hop[((size_t)d * HOP_LDS_ROWS + 4 * q + v) * HH + n], tot);
+                    if (n < 8 && tot != 0.f) lds_add(&s_hop[((size_t)d * HH + n) * HOP_STRIDE + 4 * q + v], tot);
                 }
             }
         }
     }
     __syncthreads();
-    for (int t = threadIdx.x; t < lds_rel * HH; t += blockDim.x)
-        if (s_rel[t] != 0.f) atomicAdd(&p.d_rel[t], s_rel[t]);
+    for (int t = threadIdx.x; t < lds_rel * HH; t += blockDim.x) {
+        const long long v = (long long)s_rel[(t % HH) * st_rel + t / HH];
+        if (v != 0) atomicAdd(&p.d_rel[t], (float)v * fx_inv);
+    }
     if (p.d_poi)
-        for (int t = threadIdx.x; t < lds_poi * HH; t += blockDim.x)
-            if (s_poi[t] != 0.f) atomicAdd(&p.d_poi[t], s_poi[t]);
+        for (int t = threadIdx.x; t < lds_poi * HH; t += blockDim.x) {
+            const long long v = (long long)s_poi[(t % HH) * st_poi + t / HH];
+            if (v != 0) atomicAdd(&p.d_poi[t], (float)v * fx_inv);
+        }
     for (int t = threadIdx.x; t < HH; t += blockDim.x)
         if (s_vd[t] != 0.f) atomicAdd(&p.d_vdist[t], s_vd[t]);
     if (p.edge_input) {
@@ -469,17 +623,15 @@ __global__ __launch_bounds__(256) void build_bias_bwd_kernel(const BuildParams p
         for (int t = threadIdx.x; t < p.D * HH; t += blockDim.x) {
             const int d = t / HH, h = t - d * HH;
             float acc = 0.f;
-            for (int l = 0; l <= d; ++l) acc += s_len[l * HH + h];
+            for (int l = 0; l <= d; ++l) acc += s_len[h * st_len + l];
             if (acc != 0.f) atomicAdd(&p.d_hop[(int64_t)d * p.n_edge * HH + h], acc);
         }
     }
     if (p.edge_input)
         for (int t = threadIdx.x; t < p.D * HOP_LDS_ROWS * HH; t += blockDim.x) {
-            const float v = s_hop[t];
-            if (v != 0.f) {
-                const int d = t / (HOP_LDS_ROWS * HH), rem = t - d * HOP_LDS_ROWS * HH;
-                if (rem / HH < p.n_edge) atomicAdd(&p.d_hop[(int64_t)d * p.n_edge * HH + rem], v);
-            }
+            const int d = t / (HOP_LDS_ROWS * HH), rem = t - d * HOP_LDS_ROWS * HH;      // rem = row * HH + head
+            const float v = s_hop[((size_t)d * HH + rem % HH) * HOP_STRIDE + rem / HH];
+            if (v != 0.f && rem / HH < p.n_edge) atomicAdd(&p.d_hop[(int64_t)d * p.n_edge * HH + rem], v);
         }
 }
 
@@ -504,17 +656,33 @@ int launch_build_b(const BuildParams& p, int bias_dtype, hipStream_t st) {
 template <typename TI, typename TE>
 int launch_build_bwd(const BuildParams& p, hipStream_t st) {
     const int T = p.N + 1;
-    const int nt = (T + TILE - 1) / TILE;
-    const int n_tiles = nt * nt * p.G;
-    const dim3 grid(4 * n_tiles < 768 ? 4 * n_tiles : 768), block(256);   // <= 3 workgroups per CU, each walks its units
+    const int64_t pairs = (int64_t)p.G * T * T;
     const int lds_rel = p.n_rel < 512 ? p.n_rel : 512;
     const int lds_poi = p.poi_pos ? (p.n_poi < 1024 ? p.n_poi : 1024) : 0;
-    const size_t shm = (size_t)(lds_rel + lds_poi + 1 + p.D * HOP_LDS_ROWS + p.D + 1) * p.H * sizeof(float);
+    const size_t shm = (size_t)bwd_lds_dwords(lds_rel, lds_poi, p.D, p.H) * sizeof(float);
     const bool hopmm = p.edge_input && p.F == 1 && p.H == 8 && p.D <= HOP_DMAX;
-    if (hopmm) hipLaunchKernelGGL((build_bias_bwd_kernel<TI, TE, 8, true>), grid, block, shm, st, p, lds_rel, lds_poi);
-    else if (p.H == 8) hipLaunchKernelGGL((build_bias_bwd_kernel<TI, TE, 8, false>), grid, block, shm, st, p, lds_rel, lds_poi);
-    else if (p.H == 4) hipLaunchKernelGGL((build_bias_bwd_kernel<TI, TE, 4, false>), grid, block, shm, st, p, lds_rel, lds_poi);
-    else return MOBGT_EBADDIM;
+    // long batches: 8-wave workgroups, one per CU (each walks its units); short ones: 4-wave workgroups, up to 3 per CU
+    // (more than 64 KB of dynamic LDS has to be asked for, per kernel)
+#define BWD_LDS(K) do { if (shm > 48 * 1024 && hipFuncSetAttribute((const void*)(K), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm) != hipSuccess) return MOBGT_EBADDIM; } while (0)
+    if (hopmm && pairs >= (1 << 20)) {
+        const dim3 grid(256), block(512);
+        BWD_LDS((build_bias_bwd_kernel<TI, TE, 8, true, 8>));
+        hipLaunchKernelGGL((build_bias_bwd_kernel<TI, TE, 8, true, 8>), grid, block, shm, st, p, lds_rel, lds_poi);
+        return (int)hipGetLastError();
+    }
+    const int n_units = ((T + 63) / 64) * ((T + 3) / 4) * p.G;
+    const dim3 grid(n_units < 768 ? n_units : 768), block(256);
+    if (hopmm) {
+        BWD_LDS((build_bias_bwd_kernel<TI, TE, 8, true, 4>));
+        hipLaunchKernelGGL((build_bias_bwd_kernel<TI, TE, 8, true, 4>), grid, block, shm, st, p, lds_rel, lds_poi);
+    } else if (p.H == 8) {
+        BWD_LDS((build_bias_bwd_kernel<TI, TE, 8, false, 4>));
+        hipLaunchKernelGGL((build_bias_bwd_kernel<TI, TE, 8, false, 4>), grid, block, shm, st, p, lds_rel, lds_poi);
+    } else if (p.H == 4) {
+        BWD_LDS((build_bias_bwd_kernel<TI, TE, 4, false, 4>));
+        hipLaunchKernelGGL((build_bias_bwd_kernel<TI, TE, 4, false, 4>), grid, block, shm, st, p, lds_rel, lds_poi);
+    } else return MOBGT_EBADDIM;
+#undef BWD_LDS
     return (int)hipGetLastError();
 }
 

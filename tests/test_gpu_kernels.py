@@ -292,6 +292,66 @@ def test_build_bias_bwd_sums_bf16_layer_slices(golden_dir):
                                    err_msg=k)
 
 
+def test_build_bias_long_batch_form_matches_the_oracle():
+    """G x T^2 >= 2^20 pairs selects the 8-wave workgroups of mobgt_build_bias_bwd (one row x 64 columns per wave, hop ids
+    read as dwords, [head][row] LDS tables): forward and all five table gradients vs oracle.assemble_bias on synthetic
+    trajectories-like indices (narrow device dtypes, bf16 layer slices)."""
+    from mobgt_amd.model import hop_table_from, no_grad_row0
+    rs = np.random.RandomState(3)
+    G, N, H, D, L, n_bins, n_edge = 5, 460, 8, 20, 2, 700, 128
+    T = N + 1
+    b = SimpleNamespace()
+    ii, jj = np.meshgrid(np.arange(N), np.arange(N), indexing="ij")
+    spd = np.abs(ii - jj) + 1                                           # path-like graph: SPD = |i - j| (+1: 0 is padding)
+    rel = np.broadcast_to(spd, (G, N, N)).copy()
+    rel[rs.rand(G, N, N) < 0.2] = 510                                   # unreachable
+    n_nodes = [N, N - 37, 300, N, 411]
+    edge = rs.randint(1, 6, size=(G, N, N, D))
+    edge[rs.rand(G, N, N, D) < 0.02] = rs.randint(16, 40)               # rare ids: the direct-atomic path
+    hops = np.minimum(np.where(rel == 510, 0, rel - 1), D)
+    edge[np.arange(D)[None, None, None, :] >= hops[..., None]] = 0      # L real hops, then zeros
+    poi = rs.randint(1, n_bins, size=(G, N, N))
+    attn = np.zeros((G, T, T), np.float32)
+    for g, n in enumerate(n_nodes):
+        rel[g, n:, :] = 0; rel[g, :, n:] = 0; poi[g, n:, :] = 0; poi[g, :, n:] = 0; edge[g, n:] = 0; edge[g, :, n:] = 0
+        attn[g, :, n + 1:] = -np.inf
+    b.attn_bias = torch.from_numpy(attn)
+    b.rel_pos, b.poi_pos, b.edge_input = (torch.from_numpy(a.astype(np.int64)) for a in (rel, poi, edge[..., None]))
+    sd = {"rel_pos_encoder.weight": _seeded((512, H), 1), "edge_encoder.weight": _seeded((n_edge, H), 2),
+          "edge_dis_encoder.weight": _seeded((128 * H * H, 1), 3), "graph_token_virtual_distance.weight": _seeded((1, H), 4),
+          "poi_pos_encoder.weight": _seeded((n_bins, H), 5)}
+    for t in sd.values():
+        t.requires_grad_(True)
+    ref = mo.assemble_bias(sd, b, H, D, "fq")
+    slices = (torch.randn(L, G, H, T, T, generator=torch.Generator().manual_seed(11)) * 0.1).bfloat16()
+    gb = slices.float().sum(0)
+    (torch.where(torch.isfinite(ref), ref, torch.zeros_like(ref)) * gb).sum().backward()
+
+    dsd = {k: v.detach().clone().to(DEV).requires_grad_(True) for k, v in sd.items()}
+    hop = hop_table_from(dsd["edge_encoder.weight"], dsd["edge_dis_encoder.weight"], H, D, fp16_roundtrip=True)
+    pack = ops.build_bias(b.attn_bias.to(DEV), b.rel_pos.to(DEV).to(torch.int16), b.poi_pos.to(DEV).to(torch.int16),
+                          b.edge_input.to(DEV).to(torch.uint8), no_grad_row0(dsd["rel_pos_encoder.weight"]),
+                          no_grad_row0(dsd["poi_pos_encoder.weight"]), hop, dsd["graph_token_virtual_distance.weight"], D,
+                          dtype=torch.bfloat16)
+    got, r = pack.dense().float().cpu(), ref.detach()
+    assert torch.equal(torch.isfinite(got), torch.isfinite(r))
+    fin = torch.isfinite(r)
+    np.testing.assert_allclose(got[fin].numpy(), r[fin].numpy(), rtol=8e-3, atol=2e-3)          # bf16 storage
+    pack.needs_grad = True
+    pack.n_use = L
+    pack.grad_buffer()[..., :T] = slices.to(DEV)
+    pack.n_bwd = L
+    pack.token.backward()
+    for kname in sd:
+        want = sd[kname].grad.clone()
+        if kname != "graph_token_virtual_distance.weight" and kname != "edge_dis_encoder.weight":
+            want[0] = 0
+        gotg = dsd[kname].grad.cpu()
+        scale = float(want.abs().max())
+        # sums of ~10^5..10^6 f32 terms in a different order (+ the reference's fp16 gradients on the edge tables)
+        np.testing.assert_allclose(gotg.numpy(), want.numpy(), rtol=3e-3, atol=2e-3 * max(scale, 1.0), err_msg=kname)
+
+
 # ------------------------------------------------------------------------------------------------ spd
 def _spd_case(counts_list, D=20):
     G = len(counts_list)

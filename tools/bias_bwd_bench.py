@@ -1,7 +1,7 @@
 """Developer tool: build_bias / build_bias_bwd alone at the c5-like shape (for rocprofv3 --kernel-trace / --pmc)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import torch, bench
+import torch
 from mobgt_amd import synth, ops
 from mobgt_amd.data import DeviceCollator, make_bin_table
 from mobgt_amd.model_fqandtoyo import Graphormer
@@ -9,7 +9,8 @@ P, N, G, L = 7856, int(os.environ.get("N", 784)), 16, int(os.environ.get("L", 12
 dev = torch.device("cuda", 0)
 uni = synth.make_universe(P=P, n_cat=300, n_user=1080, seed=1)
 nb, _, table = make_bin_table(uni.distance)
-args = dict(bench.MODEL_ARGS); args.update(n_layers=1, hidden_dim=192, multi_hop_max_dist=int(os.environ.get("DH", 20)))
+from mobgt_amd.workloads import FSQ_MODEL_ARGS
+args = dict(FSQ_MODEL_ARGS); args.update(n_layers=1, hidden_dim=192, multi_hop_max_dist=int(os.environ.get("DH", 20)))
 model = Graphormer(universe=uni, num_bins=nb + 2, bias_dtype=torch.bfloat16, gcn_dtype=torch.bfloat16, act_dtype=torch.bfloat16, **args).to(dev)
 coll = DeviceCollator(dev, bin_table=table)
 trajs = synth.make_batch_of_trajectories(seed=5, G=G, P=P, n_user=1080, cat_of_poi=uni.cat_of_poi, n_nodes=[N] * G)
