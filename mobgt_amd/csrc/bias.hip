@@ -118,6 +118,33 @@ __global__ __launch_bounds__(256) void build_bias_kernel(const BuildParams p) {
 #pragma unroll
                 for (int h = 0; h < HH; ++h) e[h] = 0.f;
                 const int64_t ebase = pair * p.D_in * p.F;
+                if (sizeof(TE) == 1 && HH == 8 && p.F == 1 && p.D <= 20 && (p.D_in & 3) == 0) {
+                    // The MobGT case.  The plain loop below is D dependent round trips (id -> table row): the ids
+                    // arrive as 5 dwords, then the rows are requested five hops at a time (same summation order).
+                    uint32_t w[5];
+#pragma unroll
+                    for (int k = 0; k < 5; ++k)
+                        w[k] = 4 * k < p.D ? *reinterpret_cast<const uint32_t*>(reinterpret_cast<const uint8_t*>(p.edge_input) + ebase + 4 * k) : 0u;
+#pragma unroll
+                    for (int d0 = 0; d0 < 20; d0 += 5) {
+                        float4 lo[5], hi[5];
+#pragma unroll
+                        for (int j = 0; j < 5; ++j) {
+                            const int d = d0 + j;
+                            const int idx = (int)((w[d >> 2] >> (8 * (d & 3))) & 0xffu);
+                            const float4* hrow = reinterpret_cast<const float4*>(p.hop_table + ((int64_t)(d < p.D ? d : 0) * p.n_edge + idx) * 8);
+                            lo[j] = hrow[0];
+                            hi[j] = hrow[1];
+                        }
+#pragma unroll
+                        for (int j = 0; j < 5; ++j) {
+                            if (d0 + j < p.D) {
+                                e[0] += lo[j].x; e[1] += lo[j].y; e[2] += lo[j].z; e[3] += lo[j].w;
+                                e[HH > 4 ? 4 : 0] += hi[j].x; e[HH > 5 ? 5 : 0] += hi[j].y; e[HH > 6 ? 6 : 0] += hi[j].z; e[HH > 7 ? 7 : 0] += hi[j].w;
+                            }
+                        }
+                    }
+                } else
                 for (int d = 0; d < p.D; ++d) {
                     for (int f = 0; f < p.F; ++f) {
                         const int idx = ld_idx<TE>(p.edge_input, ebase + (int64_t)d * p.F + f);

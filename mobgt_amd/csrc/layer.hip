@@ -10,6 +10,7 @@
 // gradient sums (dgamma, dbeta, dbias) accumulate in registers across rows and leave the workgroup as one
 // f32 atomic per column.  Residual stream and statistics are f32; GEMM-facing tensors are f32 or bf16.
 // Dropout uses the same counter hash as the attention kernels (common.h), regenerated in the backward.
+#include <cstdlib>
 #include "common.h"
 #include "mobgt_hip.h"
 
@@ -207,25 +208,29 @@ template <> __device__ __forceinline__ void st4<bf16_t>(bf16_t* p, const float (
     *reinterpret_cast<bf16x4*>(p) = o;
 }
 
-template <typename TA>
+// U rows per wave in flight per sweep: 2 for short batches, 8 for long ones (at R = 12 560 a workgroup owns ~25 rows:
+// with 2 per wave that was four dependent sweeps of loads)
+template <typename TA, int U>
 __global__ __launch_bounds__(256) void dropout_add_ln_fwd_v4_kernel(const LnParams p) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint64_t seed = p.thr ? p.seed + (p.seed_dev ? *p.seed_dev : 0ull) : 0ull;
     const float invC = 1.f / (float)p.C;
     const TA* Y = reinterpret_cast<const TA*>(p.y);
     TA* Z = reinterpret_cast<TA*>(p.z);
-    for (int rr = wave; rr < p.rows_per_wg; rr += 8) {
-        int64_t r[2];
-        bool on[2];
-        float v[2][V4_CH][4];
-        float s[2] = {0.f, 0.f};
+    for (int rr = wave; rr < p.rows_per_wg; rr += 4 * U) {
+        int64_t r[U];
+        bool on[U];
+        float v[U][V4_CH][4];
+        float s[U];
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
+        for (int u = 0; u < U; ++u) s[u] = 0.f;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
             r[u] = (int64_t)blockIdx.x * p.rows_per_wg + rr + 4 * u;
             on[u] = rr + 4 * u < p.rows_per_wg && r[u] < p.R;
         }
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
+        for (int u = 0; u < U; ++u) {
             const uint32_t rowh = (p.thr && on[u]) ? dropout_row_hash(seed, (uint32_t)r[u] ^ p.salt) : 0u;
 #pragma unroll
             for (int k = 0; k < V4_CH; ++k) {
@@ -250,11 +255,13 @@ __global__ __launch_bounds__(256) void dropout_add_ln_fwd_v4_kernel(const LnPara
             }
         }
         if (!p.w) continue;
-        float mu[2], q[2] = {0.f, 0.f}, rs[2];
+        float mu[U], q[U], rs[U];
 #pragma unroll
-        for (int u = 0; u < 2; ++u) mu[u] = wave_sum(s[u]) * invC;
+        for (int u = 0; u < U; ++u) q[u] = 0.f;
 #pragma unroll
-        for (int u = 0; u < 2; ++u)
+        for (int u = 0; u < U; ++u) mu[u] = wave_sum(s[u]) * invC;
+#pragma unroll
+        for (int u = 0; u < U; ++u)
 #pragma unroll
             for (int k = 0; k < V4_CH; ++k)
                 if (256 * k + 4 * lane < p.C) {
@@ -262,9 +269,9 @@ __global__ __launch_bounds__(256) void dropout_add_ln_fwd_v4_kernel(const LnPara
                     for (int i = 0; i < 4; ++i) { const float d = v[u][k][i] - mu[u]; q[u] += d * d; }
                 }
 #pragma unroll
-        for (int u = 0; u < 2; ++u) rs[u] = rsqrtf(wave_sum(q[u]) * invC + 1e-5f);
+        for (int u = 0; u < U; ++u) rs[u] = rsqrtf(wave_sum(q[u]) * invC + 1e-5f);
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
+        for (int u = 0; u < U; ++u) {
             if (!on[u]) continue;
             if (lane == 0) { p.mean[r[u]] = mu[u]; p.rstd[r[u]] = rs[u]; }
 #pragma unroll
@@ -284,7 +291,7 @@ __global__ __launch_bounds__(256) void dropout_add_ln_fwd_v4_kernel(const LnPara
     }
 }
 
-template <typename TA>
+template <typename TA, int U>
 __global__ __launch_bounds__(256) void dropout_add_ln_bwd_v4_kernel(const LnParams p) {
     __shared__ float red[3][4][256 * V4_CH];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -297,25 +304,27 @@ __global__ __launch_bounds__(256) void dropout_add_ln_bwd_v4_kernel(const LnPara
     for (int k = 0; k < V4_CH; ++k)
 #pragma unroll
         for (int i = 0; i < 4; ++i) { ag[k][i] = 0.f; ab[k][i] = 0.f; ay[k][i] = 0.f; }
-    for (int rr = wave; rr < p.rows_per_wg; rr += 8) {
-        int64_t r[2];
-        bool on[2];
-        float xh[2][V4_CH][4], gg[2][V4_CH][4], dxv[2][V4_CH][4];
-        float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f}, rs[2] = {0.f, 0.f};
+    for (int rr = wave; rr < p.rows_per_wg; rr += 4 * U) {
+        int64_t r[U];
+        bool on[U];
+        float xh[U][V4_CH][4], gg[U][V4_CH][4], dxv[U][V4_CH][4];
+        float s1[U], s2[U], rs[U];
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
+        for (int u = 0; u < U; ++u) { s1[u] = 0.f; s2[u] = 0.f; rs[u] = 0.f; }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
             r[u] = (int64_t)blockIdx.x * p.rows_per_wg + rr + 4 * u;
             on[u] = rr + 4 * u < p.rows_per_wg && r[u] < p.R;
         }
 #pragma unroll
-        for (int u = 0; u < 2; ++u)
+        for (int u = 0; u < U; ++u)
 #pragma unroll
             for (int k = 0; k < V4_CH; ++k)
 #pragma unroll
                 for (int i = 0; i < 4; ++i) { xh[u][k][i] = 0.f; gg[u][k][i] = 0.f; dxv[u][k][i] = 0.f; }
         if (p.w) {
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
+            for (int u = 0; u < U; ++u) {
                 if (!on[u]) continue;
                 const float mu = p.mean[r[u]];
                 rs[u] = p.rstd[r[u]];
@@ -341,16 +350,16 @@ __global__ __launch_bounds__(256) void dropout_add_ln_bwd_v4_kernel(const LnPara
                 }
             }
 #pragma unroll
-            for (int u = 0; u < 2; ++u) { s1[u] = wave_sum(s1[u]) * invC; s2[u] = wave_sum(s2[u]) * invC; }
+            for (int u = 0; u < U; ++u) { s1[u] = wave_sum(s1[u]) * invC; s2[u] = wave_sum(s2[u]) * invC; }
 #pragma unroll
-            for (int u = 0; u < 2; ++u)
+            for (int u = 0; u < U; ++u)
 #pragma unroll
                 for (int k = 0; k < V4_CH; ++k)
 #pragma unroll
                     for (int i = 0; i < 4; ++i) dxv[u][k][i] = rs[u] * (gg[u][k][i] - s1[u] - xh[u][k][i] * s2[u]);
         }
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
+        for (int u = 0; u < U; ++u) {
             if (!on[u]) continue;
             const uint32_t rowh = p.thr ? dropout_row_hash(seed, (uint32_t)r[u] ^ p.salt) : 0u;
 #pragma unroll
@@ -442,7 +451,7 @@ __global__ __launch_bounds__(256) void colsum_kernel(const TA* __restrict__ dh, 
 // C % 4 == 0: a workgroup covers 256 columns x rows_per_wg rows; lane l owns the four consecutive columns 4l..4l+3
 // (8- / 16-byte accesses), the four waves take different rows (two in flight each), LDS combines them and the
 // workgroup leaves one atomic per column.
-template <typename TA, bool GELU>
+template <typename TA, bool GELU, int U>
 __global__ __launch_bounds__(256) void colsum_v4_kernel(const TA* __restrict__ dh, const TA* __restrict__ u, TA* __restrict__ du,
                                                         float* __restrict__ dbias, int64_t R, int C, int rows_per_wg) {
     __shared__ float red[4][256];
@@ -452,27 +461,28 @@ __global__ __launch_bounds__(256) void colsum_v4_kernel(const TA* __restrict__ d
     const int nrow = (int)min((int64_t)rows_per_wg, R - r0);
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
     if (c < C) {
-        for (int rr = wave; rr < nrow; rr += 8) {
-            const bool two = rr + 4 < nrow;
-            float g0[4], g1[4] = {0.f, 0.f, 0.f, 0.f}, u0[4], u1[4];
-            ld4<TA>(dh + (r0 + rr) * C + c, g0);
-            if (GELU) ld4<TA>(u + (r0 + rr) * C + c, u0);
-            if (two) {
-                ld4<TA>(dh + (r0 + rr + 4) * C + c, g1);
-                if (GELU) ld4<TA>(u + (r0 + rr + 4) * C + c, u1);
-            }
-            if (GELU) {
+        // U rows per wave in flight per sweep (2 for short batches, 8 for long ones)
+        for (int rr = wave; rr < nrow; rr += 4 * U) {
+            float g[U][4], uu[U][4];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) g0[i] *= gelu_grad(u0[i]);
-                st4<TA>(du + (r0 + rr) * C + c, g0);
-                if (two) {
+            for (int k = 0; k < U; ++k) {
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) g1[i] *= gelu_grad(u1[i]);
-                    st4<TA>(du + (r0 + rr + 4) * C + c, g1);
+                for (int i = 0; i < 4; ++i) g[k][i] = 0.f;
+                if (rr + 4 * k < nrow) {
+                    ld4<TA>(dh + (r0 + rr + 4 * k) * C + c, g[k]);
+                    if (GELU) ld4<TA>(u + (r0 + rr + 4 * k) * C + c, uu[k]);
                 }
             }
 #pragma unroll
-            for (int i = 0; i < 4; ++i) acc[i] += g0[i] + g1[i];
+            for (int k = 0; k < U; ++k) {
+                if (GELU && rr + 4 * k < nrow) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) g[k][i] *= gelu_grad(uu[k][i]);
+                    st4<TA>(du + (r0 + rr + 4 * k) * C + c, g[k]);
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[i] += g[k][i];
+            }
         }
     }
     if (!dbias) return;
@@ -501,8 +511,9 @@ int pick_rows(int64_t R) {
     // Few rows: aim at ~128 workgroups (8 rows each, two per wave: one sweep) rather than one row per wave -- measured
     // on the whole step at R = 608: 12 rows (51 workgroups) 13.89 k check-ins/s, 8 rows (76) 14.05 k, 4 rows (152
     // workgroups x 576 atomics on the same addresses) 13.85 k.
+    static const int cap = getenv("MOBGT_ROWS_CAP") ? atoi(getenv("MOBGT_ROWS_CAP")) : 256;
     int64_t wgs = R / 16;
-    wgs = wgs < 128 ? 128 : (wgs > 512 ? 512 : wgs);
+    wgs = wgs < 128 ? 128 : (wgs > cap ? cap : wgs);     // (256 vs 512 at R = 12 560: 11.33 vs 11.45 ms per S-BIG step)
     int rows = (int)((R + wgs - 1) / wgs);
     rows = (rows + 3) / 4 * 4;
     return rows < 4 ? 4 : rows;
@@ -510,7 +521,8 @@ int pick_rows(int64_t R) {
 
 // kernels without a per-workgroup atomic tail: one row per wave while that gives <= 512 workgroups
 int pick_rows_stream(int64_t R) {
-    int rows = (int)((R + 511) / 512);
+    static const int cap = getenv("MOBGT_ROWS_STREAM_CAP") ? atoi(getenv("MOBGT_ROWS_STREAM_CAP")) : 4096;
+    int rows = (int)((R + cap - 1) / cap);
     rows = (rows + 3) / 4 * 4;
     return rows < 4 ? 4 : rows;
 }
@@ -538,10 +550,12 @@ extern "C" int mobgt_dropout_add_ln_fwd(const float* x, const void* y, float* x1
     hipStream_t st = (hipStream_t)stream;
     const bool v4 = C % 4 == 0 && C <= 256 * V4_CH;
     if (act_dtype == MOBGT_F32) {
-        if (v4) hipLaunchKernelGGL(dropout_add_ln_fwd_v4_kernel<float>, grid, block, 0, st, p);
+        if (v4 && p.rows_per_wg > 8) hipLaunchKernelGGL((dropout_add_ln_fwd_v4_kernel<float, 8>), grid, block, 0, st, p);
+        else if (v4) hipLaunchKernelGGL((dropout_add_ln_fwd_v4_kernel<float, 2>), grid, block, 0, st, p);
         else hipLaunchKernelGGL(dropout_add_ln_fwd_kernel<float>, grid, block, 0, st, p);
     } else if (act_dtype == MOBGT_BF16) {
-        if (v4) hipLaunchKernelGGL(dropout_add_ln_fwd_v4_kernel<bf16_t>, grid, block, 0, st, p);
+        if (v4 && p.rows_per_wg > 8) hipLaunchKernelGGL((dropout_add_ln_fwd_v4_kernel<bf16_t, 8>), grid, block, 0, st, p);
+        else if (v4) hipLaunchKernelGGL((dropout_add_ln_fwd_v4_kernel<bf16_t, 2>), grid, block, 0, st, p);
         else hipLaunchKernelGGL(dropout_add_ln_fwd_kernel<bf16_t>, grid, block, 0, st, p);
     } else return MOBGT_EDTYPE;
     return (int)hipGetLastError();
@@ -564,10 +578,12 @@ extern "C" int mobgt_dropout_add_ln_bwd(const void* dz, const float* dz32, const
     hipStream_t st = (hipStream_t)stream;
     const bool v4 = C % 4 == 0 && C <= 256 * V4_CH;
     if (act_dtype == MOBGT_F32) {
-        if (v4) hipLaunchKernelGGL(dropout_add_ln_bwd_v4_kernel<float>, grid, block, 0, st, p);
+        if (v4 && p.rows_per_wg > 8) hipLaunchKernelGGL((dropout_add_ln_bwd_v4_kernel<float, 8>), grid, block, 0, st, p);
+        else if (v4) hipLaunchKernelGGL((dropout_add_ln_bwd_v4_kernel<float, 2>), grid, block, 0, st, p);
         else hipLaunchKernelGGL(dropout_add_ln_bwd_kernel<float>, grid, block, 0, st, p);
     } else if (act_dtype == MOBGT_BF16) {
-        if (v4) hipLaunchKernelGGL(dropout_add_ln_bwd_v4_kernel<bf16_t>, grid, block, 0, st, p);
+        if (v4 && p.rows_per_wg > 8) hipLaunchKernelGGL((dropout_add_ln_bwd_v4_kernel<bf16_t, 8>), grid, block, 0, st, p);
+        else if (v4) hipLaunchKernelGGL((dropout_add_ln_bwd_v4_kernel<bf16_t, 2>), grid, block, 0, st, p);
         else hipLaunchKernelGGL(dropout_add_ln_bwd_kernel<bf16_t>, grid, block, 0, st, p);
     } else return MOBGT_EDTYPE;
     return (int)hipGetLastError();
@@ -596,10 +612,10 @@ extern "C" int mobgt_gelu_bwd_colsum(const void* dh, const void* u, void* du, fl
     const dim3 grid((unsigned)((R + rows - 1) / rows), (unsigned)((C + 255) / 256)), block(256);
     hipStream_t st = (hipStream_t)stream;
     if (act_dtype == MOBGT_F32) {
-        if (v4) hipLaunchKernelGGL((colsum_v4_kernel<float, true>), grid, block, 0, st, (const float*)dh, (const float*)u, (float*)du, dbias, R, C, rows);
+        if (v4) hipLaunchKernelGGL((colsum_v4_kernel<float, true, 2>), grid, block, 0, st, (const float*)dh, (const float*)u, (float*)du, dbias, R, C, rows);
         else hipLaunchKernelGGL((colsum_kernel<float, true>), grid, block, 0, st, (const float*)dh, (const float*)u, (float*)du, dbias, R, C, rows);
     } else if (act_dtype == MOBGT_BF16) {
-        if (v4) hipLaunchKernelGGL((colsum_v4_kernel<bf16_t, true>), grid, block, 0, st, (const bf16_t*)dh, (const bf16_t*)u, (bf16_t*)du, dbias, R, C, rows);
+        if (v4) hipLaunchKernelGGL((colsum_v4_kernel<bf16_t, true, 2>), grid, block, 0, st, (const bf16_t*)dh, (const bf16_t*)u, (bf16_t*)du, dbias, R, C, rows);
         else hipLaunchKernelGGL((colsum_kernel<bf16_t, true>), grid, block, 0, st, (const bf16_t*)dh, (const bf16_t*)u, (bf16_t*)du, dbias, R, C, rows);
     } else return MOBGT_EDTYPE;
     return (int)hipGetLastError();
@@ -612,10 +628,12 @@ extern "C" int mobgt_colsum(const void* g, float* out, int64_t R, int C, int act
     const dim3 grid((unsigned)((R + rows - 1) / rows), (unsigned)((C + 255) / 256)), block(256);
     hipStream_t st = (hipStream_t)stream;
     if (act_dtype == MOBGT_F32) {
-        if (v4) hipLaunchKernelGGL((colsum_v4_kernel<float, false>), grid, block, 0, st, (const float*)g, (const float*)nullptr, (float*)nullptr, out, R, C, rows);
+        if (v4 && rows > 8) hipLaunchKernelGGL((colsum_v4_kernel<float, false, 8>), grid, block, 0, st, (const float*)g, (const float*)nullptr, (float*)nullptr, out, R, C, rows);
+        else if (v4) hipLaunchKernelGGL((colsum_v4_kernel<float, false, 2>), grid, block, 0, st, (const float*)g, (const float*)nullptr, (float*)nullptr, out, R, C, rows);
         else hipLaunchKernelGGL((colsum_kernel<float, false>), grid, block, 0, st, (const float*)g, (const float*)nullptr, (float*)nullptr, out, R, C, rows);
     } else if (act_dtype == MOBGT_BF16) {
-        if (v4) hipLaunchKernelGGL((colsum_v4_kernel<bf16_t, false>), grid, block, 0, st, (const bf16_t*)g, (const bf16_t*)nullptr, (bf16_t*)nullptr, out, R, C, rows);
+        if (v4 && rows > 8) hipLaunchKernelGGL((colsum_v4_kernel<bf16_t, false, 8>), grid, block, 0, st, (const bf16_t*)g, (const bf16_t*)nullptr, (bf16_t*)nullptr, out, R, C, rows);
+        else if (v4) hipLaunchKernelGGL((colsum_v4_kernel<bf16_t, false, 2>), grid, block, 0, st, (const bf16_t*)g, (const bf16_t*)nullptr, (bf16_t*)nullptr, out, R, C, rows);
         else hipLaunchKernelGGL((colsum_kernel<bf16_t, false>), grid, block, 0, st, (const bf16_t*)g, (const bf16_t*)nullptr, (bf16_t*)nullptr, out, R, C, rows);
     } else return MOBGT_EDTYPE;
     return (int)hipGetLastError();

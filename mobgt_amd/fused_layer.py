@@ -105,6 +105,9 @@ def _wgrad(g, x, db=None):
     return _mm_tn_f32(g, x)
 
 
+_BMM_OUT_DTYPE = [None]
+
+
 def _mm_tn_f32(g, x):
     """g^T @ x for row-major g [R,M], x [R,N] with an fp32 result (library path: fp32 operands).
     The output is small and K = R is long, so K is split over a batch axis (strided views, no copies):
@@ -115,7 +118,16 @@ def _mm_tn_f32(g, x):
     # split only where a plain GEMM call is starved: <= 12 output tiles, or a very long K
     s = _split_factor(R, tiles) if (tiles <= 12 or (R >= 4096 and tiles < 256)) else 1
     if s > 1:
-        part = torch.bmm(g.view(s, R // s, M).transpose(1, 2), x.view(s, R // s, N))
+        ga, xa = g.view(s, R // s, M).transpose(1, 2), x.view(s, R // s, N)
+        if g.dtype != torch.float32 and _BMM_OUT_DTYPE[0] is None:
+            try:
+                torch.bmm(ga[:1], xa[:1], out_dtype=torch.float32)
+                _BMM_OUT_DTYPE[0] = True
+            except Exception:
+                _BMM_OUT_DTYPE[0] = False
+        if g.dtype != torch.float32 and _BMM_OUT_DTYPE[0]:
+            return torch.bmm(ga, xa, out_dtype=torch.float32).sum(0)    # f32 partial sums: no cast launch, no bf16 rounding
+        part = torch.bmm(ga, xa)
         return part.float().sum(0) if part.dtype != torch.float32 else part.sum(0)
     if g.dtype == torch.float32:
         return g.t() @ x
