@@ -9,7 +9,7 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmobgt_hip.so")
+LIB_PATH = os.environ.get("MOBGT_HIP_LIB") or os.path.join(_HERE, "libmobgt_hip.so")     # (override: A/B runs of two builds)
 CSRC = os.path.join(_HERE, "csrc")
 
 F32, BF16 = 0, 1

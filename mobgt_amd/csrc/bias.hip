@@ -7,6 +7,7 @@
 // read through L1/L2 (it is a few tens of KB); the per-pair inputs (D*F hop indices, rel_pos, poi_pos,
 // attn_bias) are read once, coalesced along j; the outputs are written twice -- row-major for the
 // forward / dQ pass and transposed (through an LDS tile) for the dK/dV pass -- both coalesced.
+#include <cstdlib>
 #include "common.h"
 #include "mobgt_hip.h"
 
@@ -691,8 +692,10 @@ int launch_build_bwd(const BuildParams& p, hipStream_t st) {
     // long batches: 8-wave workgroups, one per CU (each walks its units); short ones: 4-wave workgroups, up to 3 per CU
     // (more than 64 KB of dynamic LDS has to be asked for, per kernel)
 #define BWD_LDS(K) do { if (shm > 48 * 1024 && hipFuncSetAttribute((const void*)(K), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm) != hipSuccess) return MOBGT_EBADDIM; } while (0)
-    if (hopmm && pairs >= (1 << 20)) {
-        const dim3 grid(256), block(512);
+    static const int64_t long_from = getenv("MOBGT_BIAS_BWD_LONG") ? atoll(getenv("MOBGT_BIAS_BWD_LONG")) : (1 << 20);
+    if (hopmm && pairs >= long_from) {
+        const int n_units8 = ((T + 63) / 64) * ((T + 7) / 8) * p.G;
+        const dim3 grid(n_units8 < 256 ? n_units8 : 256), block(512);
         BWD_LDS((build_bias_bwd_kernel<TI, TE, 8, true, 8>));
         hipLaunchKernelGGL((build_bias_bwd_kernel<TI, TE, 8, true, 8>), grid, block, shm, st, p, lds_rel, lds_poi);
         return (int)hipGetLastError();
