@@ -291,9 +291,12 @@ __global__ __launch_bounds__(256) void dropout_add_ln_fwd_v4_kernel(const LnPara
     }
 }
 
-template <typename TA, int U>
-__global__ __launch_bounds__(256) void dropout_add_ln_bwd_v4_kernel(const LnParams p) {
-    __shared__ float red[3][4][256 * V4_CH];
+// NWV waves per workgroup: 4, or 16 for long batches -- every workgroup ends with one f32 atomic per column onto the SAME
+// addresses, ~75 ns each in a row, so at R = 12 560 the 256-512 four-wave workgroups the rows need to be in flight spent
+// ~20 of their 27 us queueing there: 64 workgroups of 16 waves keep as many rows in flight with a quarter of the atomics.
+template <typename TA, int U, int NWV>
+__global__ __launch_bounds__(NWV * 64) void dropout_add_ln_bwd_v4_kernel(const LnParams p) {
+    __shared__ float red[3][NWV][256 * V4_CH];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint64_t seed = p.thr ? p.seed + (p.seed_dev ? *p.seed_dev : 0ull) : 0ull;
     const float invC = 1.f / (float)p.C;
@@ -304,7 +307,7 @@ __global__ __launch_bounds__(256) void dropout_add_ln_bwd_v4_kernel(const LnPara
     for (int k = 0; k < V4_CH; ++k)
 #pragma unroll
         for (int i = 0; i < 4; ++i) { ag[k][i] = 0.f; ab[k][i] = 0.f; ay[k][i] = 0.f; }
-    for (int rr = wave; rr < p.rows_per_wg; rr += 4 * U) {
+    for (int rr = wave; rr < p.rows_per_wg; rr += NWV * U) {
         int64_t r[U];
         bool on[U];
         float xh[U][V4_CH][4], gg[U][V4_CH][4], dxv[U][V4_CH][4];
@@ -313,8 +316,8 @@ __global__ __launch_bounds__(256) void dropout_add_ln_bwd_v4_kernel(const LnPara
         for (int u = 0; u < U; ++u) { s1[u] = 0.f; s2[u] = 0.f; rs[u] = 0.f; }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            r[u] = (int64_t)blockIdx.x * p.rows_per_wg + rr + 4 * u;
-            on[u] = rr + 4 * u < p.rows_per_wg && r[u] < p.R;
+            r[u] = (int64_t)blockIdx.x * p.rows_per_wg + rr + NWV * u;
+            on[u] = rr + NWV * u < p.rows_per_wg && r[u] < p.R;
         }
 #pragma unroll
         for (int u = 0; u < U; ++u)
@@ -390,7 +393,7 @@ __global__ __launch_bounds__(256) void dropout_add_ln_bwd_v4_kernel(const LnPara
             }
         }
     }
-    // column sums: registers -> LDS across the 4 waves -> one atomic per column per workgroup
+    // column sums: registers -> LDS across the waves -> one atomic per column per workgroup
 #pragma unroll
     for (int k = 0; k < V4_CH; ++k)
 #pragma unroll
@@ -400,12 +403,15 @@ __global__ __launch_bounds__(256) void dropout_add_ln_bwd_v4_kernel(const LnPara
             red[2][wave][256 * k + 4 * lane + i] = ay[k][i];
         }
     __syncthreads();
-    for (int c = threadIdx.x; c < p.C; c += 256) {
+    for (int c = threadIdx.x; c < p.C; c += NWV * 64) {
+        float t0 = 0.f, t1 = 0.f, t2 = 0.f;
+#pragma unroll
+        for (int w = 0; w < NWV; ++w) { t0 += red[0][w][c]; t1 += red[1][w][c]; t2 += red[2][w][c]; }
         if (p.dgamma) {
-            atomicAdd(&p.dgamma[c], red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c]);
-            atomicAdd(&p.dbeta[c], red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c]);
+            atomicAdd(&p.dgamma[c], t0);
+            atomicAdd(&p.dbeta[c], t1);
         }
-        if (p.dbias) atomicAdd(&p.dbias[c], red[2][0][c] + red[2][1][c] + red[2][2][c] + red[2][3][c]);
+        if (p.dbias) atomicAdd(&p.dbias[c], t2);
     }
 }
 
@@ -451,10 +457,10 @@ __global__ __launch_bounds__(256) void colsum_kernel(const TA* __restrict__ dh, 
 // C % 4 == 0: a workgroup covers 256 columns x rows_per_wg rows; lane l owns the four consecutive columns 4l..4l+3
 // (8- / 16-byte accesses), the four waves take different rows (two in flight each), LDS combines them and the
 // workgroup leaves one atomic per column.
-template <typename TA, bool GELU, int U>
-__global__ __launch_bounds__(256) void colsum_v4_kernel(const TA* __restrict__ dh, const TA* __restrict__ u, TA* __restrict__ du,
+template <typename TA, bool GELU, int U, int NWV>
+__global__ __launch_bounds__(NWV * 64) void colsum_v4_kernel(const TA* __restrict__ dh, const TA* __restrict__ u, TA* __restrict__ du,
                                                         float* __restrict__ dbias, int64_t R, int C, int rows_per_wg) {
-    __shared__ float red[4][256];
+    __shared__ float red[NWV][256];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t r0 = (int64_t)blockIdx.x * rows_per_wg;
     const int c = 256 * blockIdx.y + 4 * lane;
@@ -462,23 +468,23 @@ __global__ __launch_bounds__(256) void colsum_v4_kernel(const TA* __restrict__ d
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
     if (c < C) {
         // U rows per wave in flight per sweep (2 for short batches, 8 for long ones)
-        for (int rr = wave; rr < nrow; rr += 4 * U) {
+        for (int rr = wave; rr < nrow; rr += NWV * U) {
             float g[U][4], uu[U][4];
 #pragma unroll
             for (int k = 0; k < U; ++k) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) g[k][i] = 0.f;
-                if (rr + 4 * k < nrow) {
-                    ld4<TA>(dh + (r0 + rr + 4 * k) * C + c, g[k]);
-                    if (GELU) ld4<TA>(u + (r0 + rr + 4 * k) * C + c, uu[k]);
+                if (rr + NWV * k < nrow) {
+                    ld4<TA>(dh + (r0 + rr + NWV * k) * C + c, g[k]);
+                    if (GELU) ld4<TA>(u + (r0 + rr + NWV * k) * C + c, uu[k]);
                 }
             }
 #pragma unroll
             for (int k = 0; k < U; ++k) {
-                if (GELU && rr + 4 * k < nrow) {
+                if (GELU && rr + NWV * k < nrow) {
 #pragma unroll
                     for (int i = 0; i < 4; ++i) g[k][i] *= gelu_grad(uu[k][i]);
-                    st4<TA>(du + (r0 + rr + 4 * k) * C + c, g[k]);
+                    st4<TA>(du + (r0 + rr + NWV * k) * C + c, g[k]);
                 }
 #pragma unroll
                 for (int i = 0; i < 4; ++i) acc[i] += g[k][i];
@@ -490,7 +496,12 @@ __global__ __launch_bounds__(256) void colsum_v4_kernel(const TA* __restrict__ d
     for (int i = 0; i < 4; ++i) red[wave][4 * lane + i] = acc[i];
     __syncthreads();
     const int cc = 256 * blockIdx.y + threadIdx.x;
-    if (cc < C) atomicAdd(&dbias[cc], red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+    if (threadIdx.x < 256 && cc < C) {
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < NWV; ++w) t += red[w][threadIdx.x];
+        atomicAdd(&dbias[cc], t);
+    }
 }
 
 template <typename TA>
@@ -573,17 +584,21 @@ extern "C" int mobgt_dropout_add_ln_bwd(const void* dz, const float* dz32, const
     p.rstd = const_cast<float*>(rstd); p.w = ln_w; p.dx1 = dx1; p.dy = dy; p.dgamma = dgamma; p.dbeta = dbeta;
     p.dbias = dbias; p.R = R; p.C = C;
     set_drop(p, dy ? dropout_p : 0.f, seed, seed_dev, salt);
-    p.rows_per_wg = pick_rows(R);
-    const dim3 grid((unsigned)((R + p.rows_per_wg - 1) / p.rows_per_wg)), block(256);
-    hipStream_t st = (hipStream_t)stream;
     const bool v4 = C % 4 == 0 && C <= 256 * V4_CH;
+    static const int64_t wide_from = getenv("MOBGT_LN_WIDE_FROM") ? atoll(getenv("MOBGT_LN_WIDE_FROM")) : 4096;
+    const bool wide = v4 && R >= wide_from;
+    static const int wide_wgs = getenv("MOBGT_LN_WIDE_WGS") ? atoi(getenv("MOBGT_LN_WIDE_WGS")) : 256;    // S-BIG step: 64 / 128 / 256 / 384 / 512 -> 11.22 / 10.95 / 10.58-10.70 / 10.94 / 10.79 ms (narrow form: 11.06)
+    p.rows_per_wg = wide ? (int)((R + wide_wgs - 1) / wide_wgs) : pick_rows(R);
+    if (wide) p.rows_per_wg = (p.rows_per_wg + 15) / 16 * 16;
+    const dim3 grid((unsigned)((R + p.rows_per_wg - 1) / p.rows_per_wg)), block(256), wgrid = grid;
+    hipStream_t st = (hipStream_t)stream;
     if (act_dtype == MOBGT_F32) {
-        if (v4 && p.rows_per_wg > 8) hipLaunchKernelGGL((dropout_add_ln_bwd_v4_kernel<float, 8>), grid, block, 0, st, p);
-        else if (v4) hipLaunchKernelGGL((dropout_add_ln_bwd_v4_kernel<float, 2>), grid, block, 0, st, p);
+        if (v4 && wide) hipLaunchKernelGGL((dropout_add_ln_bwd_v4_kernel<float, 2, 16>), wgrid, dim3(1024), 0, st, p);
+        else if (v4) hipLaunchKernelGGL((dropout_add_ln_bwd_v4_kernel<float, 2, 4>), grid, block, 0, st, p);
         else hipLaunchKernelGGL(dropout_add_ln_bwd_kernel<float>, grid, block, 0, st, p);
     } else if (act_dtype == MOBGT_BF16) {
-        if (v4 && p.rows_per_wg > 8) hipLaunchKernelGGL((dropout_add_ln_bwd_v4_kernel<bf16_t, 8>), grid, block, 0, st, p);
-        else if (v4) hipLaunchKernelGGL((dropout_add_ln_bwd_v4_kernel<bf16_t, 2>), grid, block, 0, st, p);
+        if (v4 && wide) hipLaunchKernelGGL((dropout_add_ln_bwd_v4_kernel<bf16_t, 2, 16>), wgrid, dim3(1024), 0, st, p);
+        else if (v4) hipLaunchKernelGGL((dropout_add_ln_bwd_v4_kernel<bf16_t, 2, 4>), grid, block, 0, st, p);
         else hipLaunchKernelGGL(dropout_add_ln_bwd_kernel<bf16_t>, grid, block, 0, st, p);
     } else return MOBGT_EDTYPE;
     return (int)hipGetLastError();
@@ -607,15 +622,20 @@ extern "C" int mobgt_gelu_fwd(const void* u, void* h, int64_t n, int act_dtype, 
 extern "C" int mobgt_gelu_bwd_colsum(const void* dh, const void* u, void* du, float* dbias, int64_t R, int C,
                                      int act_dtype, void* stream) {
     if (R <= 0 || C <= 0) return 0;
-    const int rows = pick_rows(R);
+    static const int64_t wide_from = getenv("MOBGT_LN_WIDE_FROM") ? atoll(getenv("MOBGT_LN_WIDE_FROM")) : 4096;
+    static const int wide_wgs = getenv("MOBGT_COLSUM_WIDE_WGS") ? atoi(getenv("MOBGT_COLSUM_WIDE_WGS")) : 128;
+    const bool wide = C % 4 == 0 && R >= wide_from;
+    const int rows = wide ? (int)((R + wide_wgs - 1) / wide_wgs) : pick_rows(R);
     const bool v4 = C % 4 == 0 && (((uintptr_t)dh | (uintptr_t)u | (uintptr_t)du) & 15) == 0;
     const dim3 grid((unsigned)((R + rows - 1) / rows), (unsigned)((C + 255) / 256)), block(256);
     hipStream_t st = (hipStream_t)stream;
     if (act_dtype == MOBGT_F32) {
-        if (v4) hipLaunchKernelGGL((colsum_v4_kernel<float, true, 2>), grid, block, 0, st, (const float*)dh, (const float*)u, (float*)du, dbias, R, C, rows);
+        if (v4 && wide) hipLaunchKernelGGL((colsum_v4_kernel<float, true, 2, 16>), grid, dim3(1024), 0, st, (const float*)dh, (const float*)u, (float*)du, dbias, R, C, rows);
+        else if (v4) hipLaunchKernelGGL((colsum_v4_kernel<float, true, 2, 4>), grid, block, 0, st, (const float*)dh, (const float*)u, (float*)du, dbias, R, C, rows);
         else hipLaunchKernelGGL((colsum_kernel<float, true>), grid, block, 0, st, (const float*)dh, (const float*)u, (float*)du, dbias, R, C, rows);
     } else if (act_dtype == MOBGT_BF16) {
-        if (v4) hipLaunchKernelGGL((colsum_v4_kernel<bf16_t, true, 2>), grid, block, 0, st, (const bf16_t*)dh, (const bf16_t*)u, (bf16_t*)du, dbias, R, C, rows);
+        if (v4 && wide) hipLaunchKernelGGL((colsum_v4_kernel<bf16_t, true, 2, 16>), grid, dim3(1024), 0, st, (const bf16_t*)dh, (const bf16_t*)u, (bf16_t*)du, dbias, R, C, rows);
+        else if (v4) hipLaunchKernelGGL((colsum_v4_kernel<bf16_t, true, 2, 4>), grid, block, 0, st, (const bf16_t*)dh, (const bf16_t*)u, (bf16_t*)du, dbias, R, C, rows);
         else hipLaunchKernelGGL((colsum_kernel<bf16_t, true>), grid, block, 0, st, (const bf16_t*)dh, (const bf16_t*)u, (bf16_t*)du, dbias, R, C, rows);
     } else return MOBGT_EDTYPE;
     return (int)hipGetLastError();
@@ -623,17 +643,20 @@ extern "C" int mobgt_gelu_bwd_colsum(const void* dh, const void* u, void* du, fl
 
 extern "C" int mobgt_colsum(const void* g, float* out, int64_t R, int C, int act_dtype, void* stream) {
     if (R <= 0 || C <= 0) return 0;
-    const int rows = pick_rows(R);
+    static const int64_t wide_from = getenv("MOBGT_LN_WIDE_FROM") ? atoll(getenv("MOBGT_LN_WIDE_FROM")) : 4096;
+    static const int wide_wgs = getenv("MOBGT_COLSUM_WIDE_WGS") ? atoi(getenv("MOBGT_COLSUM_WIDE_WGS")) : 128;
+    const bool wide = C % 4 == 0 && R >= wide_from;
+    const int rows = wide ? (int)((R + wide_wgs - 1) / wide_wgs) : pick_rows(R);
     const bool v4 = C % 4 == 0 && ((uintptr_t)g & 15) == 0;
     const dim3 grid((unsigned)((R + rows - 1) / rows), (unsigned)((C + 255) / 256)), block(256);
     hipStream_t st = (hipStream_t)stream;
     if (act_dtype == MOBGT_F32) {
-        if (v4 && rows > 8) hipLaunchKernelGGL((colsum_v4_kernel<float, false, 8>), grid, block, 0, st, (const float*)g, (const float*)nullptr, (float*)nullptr, out, R, C, rows);
-        else if (v4) hipLaunchKernelGGL((colsum_v4_kernel<float, false, 2>), grid, block, 0, st, (const float*)g, (const float*)nullptr, (float*)nullptr, out, R, C, rows);
+        if (v4 && wide) hipLaunchKernelGGL((colsum_v4_kernel<float, false, 2, 16>), grid, dim3(1024), 0, st, (const float*)g, (const float*)nullptr, (float*)nullptr, out, R, C, rows);
+        else if (v4) hipLaunchKernelGGL((colsum_v4_kernel<float, false, 2, 4>), grid, block, 0, st, (const float*)g, (const float*)nullptr, (float*)nullptr, out, R, C, rows);
         else hipLaunchKernelGGL((colsum_kernel<float, false>), grid, block, 0, st, (const float*)g, (const float*)nullptr, (float*)nullptr, out, R, C, rows);
     } else if (act_dtype == MOBGT_BF16) {
-        if (v4 && rows > 8) hipLaunchKernelGGL((colsum_v4_kernel<bf16_t, false, 8>), grid, block, 0, st, (const bf16_t*)g, (const bf16_t*)nullptr, (bf16_t*)nullptr, out, R, C, rows);
-        else if (v4) hipLaunchKernelGGL((colsum_v4_kernel<bf16_t, false, 2>), grid, block, 0, st, (const bf16_t*)g, (const bf16_t*)nullptr, (bf16_t*)nullptr, out, R, C, rows);
+        if (v4 && wide) hipLaunchKernelGGL((colsum_v4_kernel<bf16_t, false, 2, 16>), grid, dim3(1024), 0, st, (const bf16_t*)g, (const bf16_t*)nullptr, (bf16_t*)nullptr, out, R, C, rows);
+        else if (v4) hipLaunchKernelGGL((colsum_v4_kernel<bf16_t, false, 2, 4>), grid, block, 0, st, (const bf16_t*)g, (const bf16_t*)nullptr, (bf16_t*)nullptr, out, R, C, rows);
         else hipLaunchKernelGGL((colsum_kernel<bf16_t, false>), grid, block, 0, st, (const bf16_t*)g, (const bf16_t*)nullptr, (bf16_t*)nullptr, out, R, C, rows);
     } else return MOBGT_EDTYPE;
     return (int)hipGetLastError();
