@@ -78,19 +78,23 @@ __device__ __forceinline__ float spd_divisor(int rp, int D) {
     return (float)s;
 }
 
-template <typename TI, typename TE, typename TB, int HH>
+template <typename TI, typename TE, typename TB, int HH, int RND>
 __global__ __launch_bounds__(256) void build_bias_kernel(const BuildParams p) {
-    // one workgroup = one 8-row round of a 32x32 tile (blockIdx.y = 4 * tile row + round): a short batch
-    // (16 graphs x 41 tokens = 64 tiles) still spreads over 256 workgroups
-    __shared__ float tile[HH][8][TILE + 1];
+    // RND = 1: one workgroup = one 8-row round of a 32x32 tile (blockIdx.y = 4 * tile row + round): a short batch
+    // (16 graphs x 41 tokens = 64 tiles) still spreads over 256 workgroups.  RND = 4 (long batches): the four rounds of a
+    // tile one after the other, so that a row of the transposed copy receives 64 contiguous bytes instead of 16 (with
+    // parts compiled out at c5: the 16-byte transposed stores were 132 of the kernel's 442 us, the hop-row gathers 223)
+    __shared__ float tile[HH][8 * RND][TILE + 1];
     const int g = blockIdx.z;
     const int N = p.N, T = N + 1;
-    const int i0 = (blockIdx.y >> 2) * TILE, r = (blockIdx.y & 3) * 8, j0 = blockIdx.x * TILE;    // token coordinates
+    const int i0 = (RND == 1 ? (blockIdx.y >> 2) : blockIdx.y) * TILE, j0 = blockIdx.x * TILE;    // token coordinates
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
     const float inv_f = 1.f / (float)p.F;
     TB* B = reinterpret_cast<TB*>(p.bias);
     TB* BT = reinterpret_cast<TB*>(p.bias_t);
-    {
+#pragma unroll 1
+    for (int rd = 0; rd < RND; ++rd) {
+        const int r = RND == 1 ? (blockIdx.y & 3) * 8 : rd * 8;
         const int ti = i0 + ty + r, tj = j0 + tx;                // token indices
         float acc[HH];
         bool live = ti < T && tj < T;
@@ -161,23 +165,24 @@ __global__ __launch_bounds__(256) void build_bias_kernel(const BuildParams p) {
         }
 #pragma unroll
         for (int h = 0; h < HH; ++h) {
-            tile[h][ty][tx] = acc[h];
+            tile[h][RND == 1 ? ty : ty + r][tx] = acc[h];
             if (ti < T && tj < p.ld) B[(((int64_t)g * HH + h) * T + ti) * p.ld + tj] = to_out<TB>(acc[h]);
         }
     }
     if (!BT) return;
     __syncthreads();
-    // transposed copy: row tj of bias_t receives the 8 consecutive queries i0+r .. i0+r+7 of this round
-    for (int e = threadIdx.x; e < HH * TILE; e += 256) {
-        const int h = e / TILE, c = e % TILE;
+    // transposed copy: row tj of bias_t receives the 8 * RND consecutive queries of this workgroup, 8 per thread
+    for (int e = threadIdx.x; e < HH * TILE * RND; e += 256) {
+        const int piece = e % RND, c = (e / RND) % TILE, h = e / (RND * TILE);
         const int tj = j0 + c;
         if (tj >= T) continue;
+        const int r = RND == 1 ? (blockIdx.y & 3) * 8 : 8 * piece;
         // ld is a multiple of 32 and i0 + r of 8: the 8 elements are in range and 16-byte aligned -> one (bf16) or
         // two (f32) 16-byte stores
         TB* dst = BT + (((int64_t)g * HH + h) * T + tj) * p.ld + i0 + r;
         float v8[8];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) v8[q] = tile[h][q][c];
+        for (int q = 0; q < 8; ++q) v8[q] = tile[h][(RND == 1 ? 0 : r) + q][c];
         store8(dst, v8);
     }
 }
@@ -668,8 +673,11 @@ int launch_build(const BuildParams& p, hipStream_t st) {
     const int T = p.N + 1;
     const int nt = (int)((p.ld + TILE - 1) / TILE);
     const dim3 grid(nt, 4 * ((T + TILE - 1) / TILE), p.G), block(256);
-    if (p.H == 8) hipLaunchKernelGGL((build_bias_kernel<TI, TE, TB, 8>), grid, block, 0, st, p);
-    else if (p.H == 4) hipLaunchKernelGGL((build_bias_kernel<TI, TE, TB, 4>), grid, block, 0, st, p);
+    if (p.H == 8 && (int64_t)p.G * T * T >= (1 << 20)) {
+        const dim3 grid4(nt, (T + TILE - 1) / TILE, p.G);
+        hipLaunchKernelGGL((build_bias_kernel<TI, TE, TB, 8, 4>), grid4, block, 0, st, p);
+    } else if (p.H == 8) hipLaunchKernelGGL((build_bias_kernel<TI, TE, TB, 8, 1>), grid, block, 0, st, p);
+    else if (p.H == 4) hipLaunchKernelGGL((build_bias_kernel<TI, TE, TB, 4, 1>), grid, block, 0, st, p);
     else return MOBGT_EBADDIM;
     return (int)hipGetLastError();
 }

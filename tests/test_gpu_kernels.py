@@ -337,6 +337,8 @@ def test_build_bias_long_batch_form_matches_the_oracle():
     assert torch.equal(torch.isfinite(got), torch.isfinite(r))
     fin = torch.isfinite(r)
     np.testing.assert_allclose(got[fin].numpy(), r[fin].numpy(), rtol=8e-3, atol=2e-3)          # bf16 storage
+    assert torch.equal(pack.bias_t[..., :pack.T].float().cpu(), got.transpose(2, 3))             # 4-round tiles of the long form
+    assert bool(torch.isinf(pack.bias_t[..., pack.T:]).all())                                     # padding columns: -inf
     pack.needs_grad = True
     pack.n_use = L
     pack.grad_buffer()[..., :T] = slices.to(DEV)
