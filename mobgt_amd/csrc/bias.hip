@@ -281,7 +281,7 @@ typedef __attribute__((address_space(3))) unsigned long long lds_u64;
 constexpr float FX_LIMIT = 0x1p46f;
 __device__ __forceinline__ unsigned long long to_fx(float x, float scale, bool& ok) {
     const float y = rintf(x * scale);
-    ok = fabsf(y) < FX_LIMIT;                              // false for NaN / inf / scale == 0 (no usable sample)
+    ok = fabsf(y) < FX_LIMIT;                              // false for NaN / inf, and for every x under a NaN scale
     const float hi = floorf(y * 0x1p-32f);
     const float lo = fmaf(hi, -0x1p32f, y);                // in [0, 2^32), an integer
     return ((unsigned long long)(uint32_t)(int32_t)hi << 32) | (unsigned long long)(uint32_t)lo;
@@ -381,7 +381,7 @@ __global__ __launch_bounds__(NW * 64) void build_bias_bwd_kernel(const BuildPara
     const float inv_f = 1.f / (float)p.F;
     // fixed-point scale from a strided sample of the gradient (the same 16 positions x threads in every workgroup: L2 hits
     // after the first; bf16: first and last layer slice, times the number of slices)
-    float fx_scale = 0.f, fx_inv = 0.f;
+    float fx_scale = __builtin_nanf(""), fx_inv = 0.f;     // NaN scale = no usable sample: to_fx says 'does not fit' for every addend
     {
         const int64_t total = (int64_t)p.G * HH * T * p.ld;
         float m = 0.f;

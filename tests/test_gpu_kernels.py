@@ -292,6 +292,72 @@ def test_build_bias_bwd_sums_bf16_layer_slices(golden_dir):
                                    err_msg=k)
 
 
+@pytest.mark.parametrize("case", ["lonely", "outlier", "nan"])
+def test_build_bias_bwd_fixed_point_fallbacks(case):
+    """The rel / poi table gradients are summed in 64-bit fixed point scaled from a strided SAMPLE of the gradient
+    (csrc/bias.hip: 4 x 8 elements per thread, 2048 positions in the long-batch form).  What the sample cannot vouch for
+    must still come out right: a gradient that is zero wherever the sample looks ('lonely': every add takes the global f32
+    path), one unsampled element 1e9 times the rest ('outlier': it alone goes to the global table, the others keep their
+    precision), and a NaN (poisons exactly the rows a float sum would)."""
+    from mobgt_amd.model import hop_table_from, no_grad_row0
+    rs = np.random.RandomState(4)
+    G, N, H, D, n_bins = 5, 460, 8, 4, 300
+    T = N + 1
+    ld = (T + 31) // 32 * 32
+    total = G * H * T * ld
+    sampled = set()
+    for k in range(2048):                               # the kernel's sample positions (8 waves x 64 lanes x 4)
+        at = (k * total // 2048) & ~7
+        sampled.update(range(at, at + 8))
+    def free_pair(g, h, i, j):                          # first unsampled live element at or after (g, h, i, j)
+        while ((g * H + h) * T + i) * ld + j in sampled:
+            j += 1
+        return g, h, i, j
+    rel = torch.from_numpy(rs.randint(1, 400, size=(G, N, N))).to(DEV)
+    poi = torch.from_numpy(rs.randint(1, n_bins, size=(G, N, N))).to(DEV)
+    edge = torch.zeros(G, N, N, D, 1, dtype=torch.uint8, device=DEV)
+    attn = torch.zeros(G, T, T, device=DEV)
+    gen = torch.Generator().manual_seed(5)
+    if case == "lonely":
+        gb = torch.zeros(G, H, T, T)
+        for at, v in ((free_pair(4, 3, 200, 17), 0.37), (free_pair(0, 5, 1, 2), -1.5)):
+            gb[at] = v
+        special = None
+    else:
+        gb = torch.randn(G, H, T, T, generator=gen) * 1e-3
+        special = free_pair(1, 2, 30, 40)
+        gb[special] = 1e6 if case == "outlier" else float("nan")
+    sd = {"rel_pos_encoder.weight": _seeded((512, H), 1), "edge_encoder.weight": _seeded((128, H), 2),
+          "edge_dis_encoder.weight": _seeded((128 * H * H, 1), 3), "graph_token_virtual_distance.weight": _seeded((1, H), 4),
+          "poi_pos_encoder.weight": _seeded((n_bins, H), 5)}
+    dsd = {k: v.detach().clone().to(DEV).requires_grad_(True) for k, v in sd.items()}
+    hop = hop_table_from(dsd["edge_encoder.weight"], dsd["edge_dis_encoder.weight"], H, D, fp16_roundtrip=True)
+    pack = ops.build_bias(attn, rel.to(torch.int16), poi.to(torch.int16), edge, no_grad_row0(dsd["rel_pos_encoder.weight"]),
+                          no_grad_row0(dsd["poi_pos_encoder.weight"]), hop, dsd["graph_token_virtual_distance.weight"], D)
+    pack.needs_grad = True
+    buf = pack.grad_buffer()
+    buf.zero_()
+    buf[..., :T] = gb.to(DEV)
+    pack.token.backward()
+    g64 = gb.to(DEV).double()[:, :, 1:, 1:].permute(0, 2, 3, 1).reshape(-1, H)
+    for name, idx in (("rel_pos_encoder.weight", rel), ("poi_pos_encoder.weight", poi)):
+        want = torch.zeros(sd[name].shape, dtype=torch.float64, device=DEV)
+        want.index_add_(0, idx.reshape(-1), g64)
+        want = want.float().cpu()
+        have = dsd[name].grad.cpu()
+        assert torch.equal(torch.isnan(want), torch.isnan(have)), name
+        hit = torch.zeros(want.shape[0], dtype=torch.bool)
+        if special is not None:
+            hit[int(idx[special[0], special[2] - 1, special[3] - 1])] = True       # the row the special element lands in
+        if case == "nan":
+            assert bool(torch.isnan(have[hit]).any()) and not bool(torch.isnan(have[~hit]).any())
+        rows = ~hit
+        # every other row: sums of ~2 000 terms of 1e-3 (or the two lonely values), f32-sum accuracy
+        np.testing.assert_allclose(have[rows].numpy(), want[rows].numpy(), rtol=2e-5, atol=2e-7, err_msg=name)
+        if case == "outlier":
+            np.testing.assert_allclose(have[hit].numpy(), want[hit].numpy(), rtol=1e-6, err_msg=name)
+
+
 def test_build_bias_long_batch_form_matches_the_oracle():
     """G x T^2 >= 2^20 pairs selects the 8-wave workgroups of mobgt_build_bias_bwd (one row x 64 columns per wave, hop ids
     read as dwords, [head][row] LDS tables): forward and all five table gradients vs oracle.assemble_bias on synthetic

@@ -4,7 +4,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from mobgt_amd import ops
 dev = torch.device("cuda")
-R, C, F = 608, 192, 1024
+R, C, F = int(os.environ.get("R", 608)), int(os.environ.get("C", 192)), 1024
 
 
 def timeit(fn, n=20, reps=50):
