@@ -569,3 +569,49 @@ def test_linear_with_leaky_epilogue_matches_torch(R, K, N):
     torch.testing.assert_close(got[1], x.grad, rtol=1e-4, atol=1e-4)
     for u, v in ((got[2], lin.weight.grad), (got[3], lin.bias.grad)):
         assert float((u - v).abs().max()) <= 1e-2 * float(v.abs().max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("R", [600, 5000])
+def test_layernorm_backward_and_column_sums_short_and_long_batches(R):
+    """mobgt_dropout_add_ln_bwd / mobgt_colsum / mobgt_gelu_bwd_colsum vs torch autograd: R = 600 runs the four-wave
+    workgroups, R = 5000 (>= 4096) the sixteen-wave long-batch forms of csrc/layer.hip (same results, fewer
+    same-address atomics)."""
+    from mobgt_amd import _lib
+    from mobgt_amd.fused_layer import _k1_bwd
+    from mobgt_amd.ops import _p, _stream
+    C, F = 256, 1024
+    g = torch.Generator().manual_seed(R)
+    x1 = torch.randn(R, C, generator=g).to(DEV).requires_grad_(True)
+    w = (1 + 0.1 * torch.randn(C, generator=g)).to(DEV).requires_grad_(True)
+    b = (0.1 * torch.randn(C, generator=g)).to(DEV).requires_grad_(True)
+    dz = torch.randn(R, C, generator=g).to(DEV).bfloat16()
+    dres = torch.randn(R, C, generator=g).to(DEV)
+    z = torch.nn.functional.layer_norm(x1, (C,), w, b, 1e-5)
+    (z * dz.float()).sum().backward()
+    mean = x1.detach().mean(1)
+    rstd = (x1.detach().var(1, unbiased=False) + 1e-5).rsqrt()
+    dx1 = torch.empty(R, C, device=DEV)
+    dy = torch.empty(R, C, device=DEV, dtype=torch.bfloat16)
+    dgamma, dbeta, dbias = (torch.zeros(C, device=DEV) for _ in range(3))
+    _k1_bwd(dz, None, dres, x1.detach(), mean, rstd, w.detach(), dx1, dy, dgamma, dbeta, dbias, R, C, 0.0, 0, None, 0, _lib.BF16)
+    want_dx = x1.grad + dres
+    np.testing.assert_allclose(dx1.cpu().numpy(), want_dx.cpu().numpy(), rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(dy.float().cpu().numpy(), want_dx.cpu().numpy(), rtol=8e-3, atol=1e-3)      # bf16 copy, p = 0
+    s = float(R) ** 0.5
+    np.testing.assert_allclose(dgamma.cpu().numpy(), w.grad.cpu().numpy(), rtol=1e-4, atol=2e-5 * s)
+    np.testing.assert_allclose(dbeta.cpu().numpy(), b.grad.cpu().numpy(), rtol=1e-4, atol=2e-5 * s)
+    np.testing.assert_allclose(dbias.cpu().numpy(), want_dx.sum(0).cpu().numpy(), rtol=1e-4, atol=2e-5 * s)      # f32 sums
+    # column sums of a bf16 [R, F] gradient, plain and through gelu'
+    dh = torch.randn(R, F, generator=g).to(DEV).bfloat16()
+    u = torch.randn(R, F, generator=g).to(DEV).bfloat16()
+    out = torch.zeros(F, device=DEV)
+    _lib.check(_lib.lib().mobgt_colsum(_p(dh), _p(out), R, F, _lib.BF16, _stream()), "mobgt_colsum")
+    np.testing.assert_allclose(out.cpu().numpy(), dh.float().sum(0).cpu().numpy(), rtol=1e-4, atol=2e-5 * s)
+    du = torch.empty_like(dh)
+    db1 = torch.zeros(F, device=DEV)
+    _lib.check(_lib.lib().mobgt_gelu_bwd_colsum(_p(dh), _p(u), _p(du), _p(db1), R, F, _lib.BF16, _stream()), "mobgt_gelu_bwd_colsum")
+    uf = u.float().requires_grad_(True)
+    (torch.nn.functional.gelu(uf) * dh.float()).sum().backward()
+    np.testing.assert_allclose(du.float().cpu().numpy(), uf.grad.cpu().numpy(), rtol=8e-3, atol=2e-3)
+    np.testing.assert_allclose(db1.cpu().numpy(), uf.grad.sum(0).cpu().numpy(), rtol=1e-4, atol=1e-4 * s)
