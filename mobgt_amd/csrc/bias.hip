@@ -85,6 +85,20 @@ __global__ __launch_bounds__(256) void build_bias_kernel(const BuildParams p) {
     // tile one after the other, so that a row of the transposed copy receives 64 contiguous bytes instead of 16 (with
     // parts compiled out at c5: the 16-byte transposed stores were 132 of the kernel's 442 us, the hop-row gathers 223)
     __shared__ float tile[HH][8 * RND][TILE + 1];
+    // long batches: the hop-table rows of the small edge ids (transition counts < 16: nearly all of them) wait in LDS --
+    // the L1 path then carries only the index loads and the stores, and a hop row arrives in ~64 cycles instead of ~500
+    constexpr int HOPL = 16;
+    __shared__ __attribute__((aligned(16))) float hop_s[RND == 4 ? 20 : 1][RND == 4 ? HOPL : 1][8];
+    const bool hop_lds = RND == 4 && HH == 8 && p.edge_input && p.D <= 20;
+    if (hop_lds) {
+        for (int e = threadIdx.x; e < 20 * HOPL * 2; e += 256) {
+            const int d = e / (HOPL * 2), id = (e >> 1) % HOPL, half = e & 1;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (d < p.D && id < p.n_edge) v = *reinterpret_cast<const float4*>(p.hop_table + ((int64_t)d * p.n_edge + id) * 8 + 4 * half);
+            *reinterpret_cast<float4*>(&hop_s[RND == 4 ? d : 0][RND == 4 ? id : 0][4 * half]) = v;
+        }
+        __syncthreads();
+    }
     const int g = blockIdx.z;
     const int N = p.N, T = N + 1;
     const int i0 = (RND == 1 ? (blockIdx.y >> 2) : blockIdx.y) * TILE, j0 = blockIdx.x * TILE;    // token coordinates
@@ -137,9 +151,15 @@ __global__ __launch_bounds__(256) void build_bias_kernel(const BuildParams p) {
                         for (int j = 0; j < 5; ++j) {
                             const int d = d0 + j;
                             const int idx = (int)((w[d >> 2] >> (8 * (d & 3))) & 0xffu);
-                            const float4* hrow = reinterpret_cast<const float4*>(p.hop_table + ((int64_t)(d < p.D ? d : 0) * p.n_edge + idx) * 8);
-                            lo[j] = hrow[0];
-                            hi[j] = hrow[1];
+                            if (hop_lds && idx < HOPL) {
+                                const float4* hrow = reinterpret_cast<const float4*>(&hop_s[RND == 4 ? d : 0][RND == 4 ? idx : 0][0]);
+                                lo[j] = hrow[0];
+                                hi[j] = hrow[1];
+                            } else {
+                                const float4* hrow = reinterpret_cast<const float4*>(p.hop_table + ((int64_t)(d < p.D ? d : 0) * p.n_edge + idx) * 8);
+                                lo[j] = hrow[0];
+                                hi[j] = hrow[1];
+                            }
                         }
 #pragma unroll
                         for (int j = 0; j < 5; ++j) {
