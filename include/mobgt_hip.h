@@ -429,6 +429,10 @@ int mobgt_small_gemm_f32_act(const float* a, int64_t lda, const float* a_mask, f
  *   mobgt_spmm_csr        out[i,:] = bias + sum_e val[e] b[col[e],:]  over the entries e of row (rows ? rows[i] : i);
  *                         rowptr int64 [n+1], col int32, val f32; b [n_cols, C] f32 (ldb), out [R, C] f32 (ld_out), C % 4 == 0.
  *   mobgt_spmm_csr_t_rows db[col[e],:] += val[e] g[i,:]  (autograd of the row-subset product; db zero-initialised, atomics).
+ *   mobgt_spmm_csr_t_rows_gather  the same gradient WITHOUT atomics, from the CSR of the TRANSPOSE (t_*): db [P, C] is
+ *                         written in full (no zero-fill needed); `rows` [R] int64 may repeat a row.  head int32 [P] must be
+ *                         all -1 on entry and is all -1 again on return (stream order); nxt int32 [R] is scratch.
+ *                         C % 4 == 0, C <= 512.  Three launches: thread the subset into per-row lists, gather, unthread.
  */
 /* Everything of an fq encoder layer that is row-local, in ONE launch (csrc/chain.hip; graphormer/model.py:455, :388-403,
  * model_fqandtoyo.py:1731-1743):  y = a wo^T + bo;  x1 = x + dropout(y);  z = ffn_norm1(x1);  u = z w1^T + b1;
@@ -500,6 +504,9 @@ int mobgt_spmm_csr(const int64_t* rowptr, const int32_t* col, const float* val, 
                    int64_t ldb, const float* bias, float* out, int64_t ld_out, int64_t R, int C, void* stream);
 int mobgt_spmm_csr_t_rows(const int64_t* rowptr, const int32_t* col, const float* val, const int64_t* rows,
                           const float* g, int64_t ldg, float* db, int64_t ld_db, int64_t R, int C, void* stream);
+int mobgt_spmm_csr_t_rows_gather(const int64_t* t_rowptr, const int32_t* t_col, const float* t_val, const int64_t* rows,
+                                 int* head, int* nxt, const float* g, int64_t ldg, float* db, int64_t ld_db, int64_t P,
+                                 int64_t R, int C, void* stream);
 
 /* The encoder layer's small GEMMs with the following elementwise step fused (graphormer/model.py:388-403, 406-463;
  * model_fqandtoyo.py:1641-1712 and the autograd of those F.linear calls): bf16 operands, f32 accumulate.

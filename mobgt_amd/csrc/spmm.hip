@@ -5,7 +5,8 @@
 // a gather of ~30 rows of `support` per output row.
 //
 //   spmm      out[i, :]  = bias + sum_e val[e] * B[col[e], :]       e in [rowptr[r], rowptr[r+1]),  r = rows ? rows[i] : i
-//   spmm_t    dB[col[e], :] += val[e] * g[i, :]                      the transposed product for a row SUBSET (atomics);
+//   spmm_t    dB[col[e], :] += val[e] * g[i, :]                      the transposed product for a row SUBSET (atomics;
+//             mobgt_spmm_csr_t_rows_gather below: the same product as a gather over the CSR of the transpose);
 //             the full transposed product is `spmm` on the stored CSR of the transpose.
 //
 // One wave per output row, 16-byte lanes over the feature axis (C = 64 / 128: 256 / 512 contiguous bytes per gathered
@@ -74,7 +75,86 @@ __global__ __launch_bounds__(256) void spmm_t_rows_kernel(const SpmmParams p) {
     }
 }
 
+// The row-subset transposed product WITHOUT atomics (the scatter above adds ~400 MB per S-BIG step through the memory-side
+// atomic units: 306 us).  With the CSR of the transpose, destination row j gathers over its in-edges (i -> j) and keeps
+// those whose source i is one of the subset's rows; `rows` may name a row several times, so the subset is first threaded
+// into per-row lists: head[i] = last k with rows[k] == i (or -1), nxt[k] = the previous such k.
+//   link   : nxt[k] = atomicExch(&head[rows[k]], k)          (head is all -1 on entry)
+//   gather : db[j,:] = sum over in-edges e of j, over the list k of t_col[e]:  t_val[e] * g[k,:]      (every row written)
+//   unlink : head[rows[k]] = -1
+__global__ __launch_bounds__(256) void rows_link_kernel(const int64_t* __restrict__ rows, int R, int* __restrict__ head,
+                                                        int* __restrict__ nxt, int unlink) {
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= R) return;
+    if (unlink) head[rows[k]] = -1;
+    else nxt[k] = atomicExch(&head[rows[k]], k);
+}
+
+struct SpmmTgParams {
+    const int64_t* t_rowptr; const int32_t* t_col; const float* t_val;
+    const int* head; const int* nxt;
+    const float* g; float* out;
+    int64_t P, ldg, ldo;
+    int C;
+};
+
+__global__ __launch_bounds__(256) void spmm_t_gather_kernel(const SpmmTgParams p) {
+    const int64_t j = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (j >= p.P) return;
+    const int lane = threadIdx.x & 63;
+    const int64_t e0 = p.t_rowptr[j], e1 = p.t_rowptr[j + 1];
+    // C <= 512: up to two float4 per lane
+    float4 acc[2] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
+    for (int64_t eb = e0; eb < e1; eb += 64) {
+        const int64_t e = eb + lane;
+        int k = -1;
+        float v = 0.f;
+        if (e < e1) { k = p.head[p.t_col[e]]; v = p.t_val[e]; }
+        unsigned long long hits = __ballot(k >= 0);
+        while (hits) {
+            const int l = __ffsll((long long)hits) - 1;
+            hits &= hits - 1;
+            int kk = __shfl(k, l, 64);
+            const float vv = __shfl(v, l, 64);
+            while (kk >= 0) {
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int c = lane * 4 + 256 * u;
+                    if (c < p.C) {
+                        const float4 gv = *reinterpret_cast<const float4*>(p.g + (int64_t)kk * p.ldg + c);
+                        acc[u].x = fmaf(vv, gv.x, acc[u].x); acc[u].y = fmaf(vv, gv.y, acc[u].y);
+                        acc[u].z = fmaf(vv, gv.z, acc[u].z); acc[u].w = fmaf(vv, gv.w, acc[u].w);
+                    }
+                }
+                kk = p.nxt[kk];
+            }
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int c = lane * 4 + 256 * u;
+        if (c < p.C) *reinterpret_cast<float4*>(p.out + j * p.ldo + c) = acc[u];
+    }
+}
+
 }  // namespace
+
+extern "C" int mobgt_spmm_csr_t_rows_gather(const int64_t* t_rowptr, const int32_t* t_col, const float* t_val, const int64_t* rows,
+                                            int* head, int* nxt, const float* g, int64_t ldg, float* db, int64_t ld_db, int64_t P,
+                                            int64_t R, int C, void* stream) {
+    if (R <= 0 || P <= 0) return 0;
+    if (C <= 0 || (C & 3) || C > 512 || (ldg & 3) || (ld_db & 3) || R > 0x7fffffff) return MOBGT_EBADDIM;
+    if (((uintptr_t)g | (uintptr_t)db) & 15) return MOBGT_EALIGN;
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 lgrid((unsigned)((R + 255) / 256)), block(256);
+    hipLaunchKernelGGL(rows_link_kernel, lgrid, block, 0, st, rows, (int)R, head, nxt, 0);
+    SpmmTgParams p = {};
+    p.t_rowptr = t_rowptr; p.t_col = t_col; p.t_val = t_val; p.head = head; p.nxt = nxt; p.g = g; p.out = db;
+    p.P = P; p.ldg = ldg; p.ldo = ld_db; p.C = C;
+    hipLaunchKernelGGL(spmm_t_gather_kernel, dim3((unsigned)((P + 3) / 4)), block, 0, st, p);
+    hipLaunchKernelGGL(rows_link_kernel, lgrid, block, 0, st, rows, (int)R, head, nxt, 1);
+    return (int)hipGetLastError();
+}
 
 extern "C" int mobgt_spmm_csr(const int64_t* rowptr, const int32_t* col, const float* val, const int64_t* rows,
                               const float* b, int64_t ldb, const float* bias, float* out, int64_t ld_out, int64_t R, int C,

@@ -328,6 +328,10 @@ def spmm(adj, b, bias=None, rows=None, transposed=False):
     return out
 
 
+import os as _os_sp
+_SP_GATHER = [_os_sp.environ.get("MOBGT_SPMM_SCATTER") != "1"]     # MOBGT_SPMM_SCATTER=1: the atomic scatter (A/B runs, tests)
+
+
 class _SpConvFn(torch.autograd.Function):
     """out = adj[rows] @ (x @ W) + b with a CSR adjacency (modelGNN.py:38-44); rows = None: every row."""
 
@@ -348,6 +352,18 @@ class _SpConvFn(torch.autograd.Function):
         g = g.contiguous()
         if rows is None:
             d_support = spmm(adj, g, transposed=True)                   # adj^T @ g: a gather over the stored transpose
+        elif _SP_GATHER[0] and g.shape[1] % 4 == 0 and g.shape[1] <= 512:
+            # adj[rows]^T @ g as a gather over the stored transpose (no atomics, every row written: no zero fill)
+            P = adj.shape[1]
+            head = getattr(adj, "_rows_head", None)
+            if head is None or head.device != g.device:
+                head = adj._rows_head = torch.full((adj.shape[0],), -1, dtype=torch.int32, device=g.device)
+            nxt = torch.empty(rows.numel(), dtype=torch.int32, device=g.device)
+            d_support = torch.empty(P, g.shape[1], dtype=torch.float32, device=g.device)
+            _lib.check(_lib.lib().mobgt_spmm_csr_t_rows_gather(_p(adj.t_rowptr), _p(adj.t_col), _p(adj.t_val), _p(rows), _p(head),
+                                                               _p(nxt), _p(g), g.stride(0), _p(d_support), d_support.stride(0),
+                                                               P, rows.numel(), g.shape[1], _stream()),
+                       "mobgt_spmm_csr_t_rows_gather")
         else:                                                           # adj[rows]^T @ g: scatter of R rows
             d_support = torch.zeros(adj.shape[1], g.shape[1], dtype=torch.float32, device=g.device)
             _lib.check(_lib.lib().mobgt_spmm_csr_t_rows(_p(adj.rowptr), _p(adj.col), _p(adj.val), _p(rows), _p(g), g.stride(0),

@@ -38,11 +38,15 @@ def test_spmm_kernels_match_dense_products():
     np.testing.assert_allclose(spmm(adj, b, transposed=True).cpu().numpy(), (dense.t() @ b).cpu().numpy(), rtol=1e-5, atol=1e-5)
     rows = torch.randperm(P, generator=g)[:333].to(DEV)
     np.testing.assert_allclose(spmm(adj, b, None, rows).cpu().numpy(), (dense[rows] @ b).cpu().numpy(), rtol=1e-5, atol=1e-5)
-    # autograd of the layer, all rows and a row subset, against the dense expression
-    for rws in (None, rows):
+    # autograd of the layer: all rows, a row subset, and a subset that names rows twice (a POI visited twice in a batch);
+    # the subsets' transposed product both as the gather over the stored transpose and as the atomic scatter
+    from mobgt_amd import modelGNN
+    rows_dup = torch.cat([rows, rows[:50], rows[:7]])
+    for rws, gather in ((None, True), (rows, True), (rows, False), (rows_dup, True), (rows_dup, False)):
+        modelGNN._SP_GATHER[0] = gather
         x = torch.randn(P, 64, generator=g).to(DEV)
         w = (torch.randn(64, C, generator=g) * 0.1).to(DEV)
-        up = torch.randn(P if rws is None else 333, C, generator=g).to(DEV)
+        up = torch.randn(P if rws is None else rws.numel(), C, generator=g).to(DEV)
         xa, wa, ba = (t.clone().requires_grad_(True) for t in (x, w, bias))
         ref = (dense if rws is None else dense[rws]) @ (xa @ wa) + ba
         (ref * up).sum().backward()
@@ -55,6 +59,8 @@ def test_spmm_kernels_match_dense_products():
         # dW goes through the bf16-operand weight-gradient kernel (K = P rows)
         scale = float(wa.grad.abs().max())
         np.testing.assert_allclose(wb.grad.cpu().numpy(), wa.grad.cpu().numpy(), rtol=0, atol=2e-2 * scale)
+    modelGNN._SP_GATHER[0] = True
+    assert bool((adj._rows_head == -1).all())                # the per-row lists are unthreaded again after every call
 
 
 def _cpu_batch(b):
