@@ -258,6 +258,10 @@ int mobgt_skinny_linear_bwd(const float* dy, const float* x, const float* w, flo
                             int V, void* stream);
 /* dx = dy @ w alone, on the matrix cores (csrc/skinny.hip): dx [G,K] f32 must be ZERO on entry (f32 atomics); K % 16 == 0. */
 int mobgt_skinny_linear_dx(const float* dy, const float* w, float* dx, int G, int K, int V, void* stream);
+/* Both gradients of the skinny Linear in one launch (csrc/skinny.hip): dx = dy @ w [G,K] (ZERO on entry: f32 atomics;
+ * K % 16 == 0), dw = dy^T x [V,K] (overwritten), db = column sums of dy [V] or NULL. */
+int mobgt_skinny_linear_bwd_both(const float* dy, const float* x, const float* w, float* dx, float* dw, float* db,
+                                 int G, int K, int V, void* stream);
 
 /* Rows of a bf16 matrix a [*, ld] gathered and transposed in one pass: out_rows [R, C] = a[rows[j], 0:C] and
  * out_t [C, R] = out_rows^T (the operands of the "rows only" last GCN layer, modelGNN.py:38-44 restricted to the

@@ -135,14 +135,14 @@ constexpr int DXM_ROWS = 256;                // rows of W per staged chunk
 constexpr int DXM_VSPLIT = 8;
 typedef __attribute__((ext_vector_type(4))) float f32x4_;
 
-__global__ __launch_bounds__(256) void skinny_dx_mfma_kernel(const float* __restrict__ dy, const float* __restrict__ w,
-                                                             float* __restrict__ dx, int G, int K, int V) {
+__device__ __forceinline__ void skinny_dx_mfma_body(const float* __restrict__ dy, const float* __restrict__ w,
+                                                    float* __restrict__ dx, int G, int K, int V, int bx, int by) {
     __shared__ __attribute__((aligned(16))) float wl[DXM_ROWS][16];            // W[v0 + r][k0 .. k0 + 15]
     __shared__ __attribute__((aligned(16))) float dyl[GMAX][DXM_ROWS + 4];     // dy[g][v0 + r]
     __shared__ float part[4][16][17];
-    const int k0 = blockIdx.x * 16;
+    const int k0 = bx * 16;
     const int vper = ((V + DXM_VSPLIT - 1) / DXM_VSPLIT + 3) & ~3;
-    const int vbeg = blockIdx.y * vper, vend = min(V, vbeg + vper);
+    const int vbeg = by * vper, vend = min(V, vbeg + vper);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int j = lane & 15, q = lane >> 4;
     f32x4_ acc = {0.f, 0.f, 0.f, 0.f};
@@ -190,12 +190,17 @@ __global__ __launch_bounds__(256) void skinny_dx_mfma_kernel(const float* __rest
     }
 }
 
+__global__ __launch_bounds__(256) void skinny_dx_mfma_kernel(const float* __restrict__ dy, const float* __restrict__ w,
+                                                             float* __restrict__ dx, int G, int K, int V) {
+    skinny_dx_mfma_body(dy, w, dx, G, K, V, blockIdx.x, blockIdx.y);
+}
+
 constexpr int DW_ROWS = 16;                  // rows v of dW per workgroup
 
-__global__ __launch_bounds__(256) void skinny_dw_kernel(const float* __restrict__ dy, const float* __restrict__ x,
-                                                        float* __restrict__ dw, float* __restrict__ db, int G, int K, int V) {
+__device__ __forceinline__ void skinny_dw_body(const float* __restrict__ dy, const float* __restrict__ x,
+                                               float* __restrict__ dw, float* __restrict__ db, int G, int K, int V, int bx) {
     __shared__ float sdy[DW_ROWS][GMAX];
-    const int v0 = blockIdx.x * DW_ROWS;
+    const int v0 = bx * DW_ROWS;
     {
         const int j = threadIdx.x / GMAX, g = threadIdx.x % GMAX;         // 256 = 16 x 16
         sdy[j][g] = (g < G && v0 + j < V) ? dy[(int64_t)g * V + v0 + j] : 0.f;
@@ -227,6 +232,21 @@ __global__ __launch_bounds__(256) void skinny_dw_kernel(const float* __restrict_
         for (int g = 0; g < GMAX; ++g) s += sdy[threadIdx.x][g];
         db[v0 + threadIdx.x] = s;
     }
+}
+
+__global__ __launch_bounds__(256) void skinny_dw_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                        float* __restrict__ dw, float* __restrict__ db, int G, int K, int V) {
+    skinny_dw_body(dy, x, dw, db, G, K, V, blockIdx.x);
+}
+
+// Both gradients of the classifier in ONE launch: they share nothing but dy, each is a ~8 us launch of a few hundred
+// workgroups, and neither depends on the other -- the first K/16 x 8 workgroups run the dx body, the rest the dW body.
+__global__ __launch_bounds__(256) void skinny_bwd_both_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                              const float* __restrict__ w, float* __restrict__ dx,
+                                                              float* __restrict__ dw, float* __restrict__ db, int G, int K, int V) {
+    const int ndx = (K / 16) * DXM_VSPLIT;
+    if ((int)blockIdx.x < ndx) skinny_dx_mfma_body(dy, w, dx, G, K, V, blockIdx.x % (K / 16), blockIdx.x / (K / 16));
+    else skinny_dw_body(dy, x, dw, db, G, K, V, blockIdx.x - ndx);
 }
 
 __global__ __launch_bounds__(256) void skinny_zero_kernel(float* __restrict__ p, int n) {
@@ -271,5 +291,16 @@ extern "C" int mobgt_skinny_linear_dx(const float* dy, const float* w, float* dx
     if (rc) return rc;
     if ((K & 15) || ((uintptr_t)w & 15)) return MOBGT_EBADDIM;
     hipLaunchKernelGGL(skinny_dx_mfma_kernel, dim3(K / 16, DXM_VSPLIT), dim3(256), 0, (hipStream_t)stream, dy, w, dx, G, K, V);
+    return (int)hipGetLastError();
+}
+
+/* dx = dy @ w (dx ZERO on entry, K % 16 == 0) and dw = dy^T x (+ db = column sums of dy) in one launch. */
+extern "C" int mobgt_skinny_linear_bwd_both(const float* dy, const float* x, const float* w, float* dx, float* dw, float* db,
+                                            int G, int K, int V, void* stream) {
+    const int rc = check_dims(G, K, V);
+    if (rc) return rc;
+    if ((K & 15) || ((uintptr_t)w & 15) || !dx || !dw) return MOBGT_EBADDIM;
+    const int blocks = (K / 16) * DXM_VSPLIT + (V + DW_ROWS - 1) / DW_ROWS;
+    hipLaunchKernelGGL(skinny_bwd_both_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dy, x, w, dx, dw, db, G, K, V);
     return (int)hipGetLastError();
 }

@@ -476,15 +476,21 @@ class _SkinnyLinearFn(torch.autograd.Function):
         dy = dy.contiguous()
         dx = None
         dx_mfma = ctx.needs_input_grad[0] and not ctx.all_hip and K % 16 == 0 and K <= 512 and not os.environ.get("MOBGT_SKINNY_DX_LIB")
+        both = dx_mfma and ctx.needs_input_grad[1] and not os.environ.get("MOBGT_SKINNY_TWO_LAUNCHES")
         if dx_mfma:     # one pass over W at the full L1 rate (the library's 16x16 tiles: 26 us at V = 7857, K = 448)
             dx = zeros_f32((G, K), x.device)
-            check(_lib.lib().mobgt_skinny_linear_dx(_p(dy), _p(w), _p(dx), G, K, V, _stream()), "mobgt_skinny_linear_dx")
+            if not both:
+                check(_lib.lib().mobgt_skinny_linear_dx(_p(dy), _p(w), _p(dx), G, K, V, _stream()), "mobgt_skinny_linear_dx")
         elif ctx.needs_input_grad[0]:
             dx = torch.empty_like(x) if ctx.all_hip else dy @ w
         dw = None
         if ctx.needs_input_grad[1]:
             dw = ctx.sink[:] if ctx.sink is not None else torch.empty_like(w)      # (a fresh view object of the sink)
         db = torch.empty(V, dtype=torch.float32, device=x.device) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+        if both:        # dx and dW (+ db) share nothing but dy: one launch, the first workgroups run the dx body
+            check(_lib.lib().mobgt_skinny_linear_bwd_both(_p(dy), _p(x), _p(w), _p(dx), _p(dw), _p(db), G, K, V, _stream()),
+                  "mobgt_skinny_linear_bwd_both")
+            return dx, dw, db
         check(_lib.lib().mobgt_skinny_linear_bwd(_p(dy), _p(x), _p(w), _p(dx if ctx.all_hip else None), _p(dw), _p(db),
                                                  G, K, V, _stream()), "mobgt_skinny_linear_bwd")
         return dx, dw, db
