@@ -407,7 +407,9 @@ __global__ __launch_bounds__(NW * 64) void build_bias_bwd_kernel(const BuildPara
         float m = 0.f;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const int64_t at = (((int64_t)(threadIdx.x * 4 + q) * total) / (4 * NW * 64)) & ~(int64_t)7;
+            int64_t at = (((int64_t)(threadIdx.x * 4 + q) * total) / (4 * NW * 64)) & ~(int64_t)7;
+            if (at + 8 > total) at = (total - 8) & ~(int64_t)7;       // tiny batches: stay inside the buffer
+            if (at < 0) continue;
             const int col = (int)(at % p.ld);              // (columns >= T are padding nobody has to have written)
             if (p.dbias_bf16) {
                 const bf16_t* src = reinterpret_cast<const bf16_t*>(p.dbias) + at;
