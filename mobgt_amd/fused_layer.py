@@ -197,6 +197,7 @@ _CHAIN_BWD = [_os_ln.environ.get("MOBGT_NO_CHAIN_BWD") != "1"]      # ... and th
 # first norm and runs the weight gradients as extra workgroups (csrc/chain.hip).  A parked entry that no layer picks up is
 # an error, raised when the backward pass ends -- never a silently incomplete gradient.
 _DEFER = [_os_ln.environ.get("MOBGT_NO_DEFER_TAIL") != "1"]
+_DEFER_MAX_R = [int(_os_ln.environ.get("MOBGT_DEFER_MAX_R", "4096"))]      # S-GOW: 1024 / 2048 / 4096 / 16384 -> 18.96 / 19.33 / 19.65 / 19.5 k check-ins/s
 _PENDING_TAIL = {}
 _PENDING_CB = [False]
 
@@ -524,7 +525,7 @@ class _FusedLayerFn(torch.autograd.Function):
         dqkv2 = dqkv.view(R, 3 * C)
         dwqkv = wb.add(dqkv2, xa, db=dbqkv, sink=k_qkv)
         defer = (_DEFER[0] and getattr(ctx, "below_hosts", False) and own and not stock and _TAIL[0] and len(wb.items) == 4
-                 and R <= 1024 and dx1.data_ptr() % 16 == 0 and dqkv2.is_contiguous() and ctx.small_sink is not None
+                 and R <= _DEFER_MAX_R[0] and dx1.data_ptr() % 16 == 0 and dqkv2.is_contiguous() and ctx.small_sink is not None
                  and all(k is not None for k in ctx.sinks))
         if defer:
             # nothing more is launched for this layer: the chain launch of the layer below finishes dx and the weight gradients
