@@ -81,7 +81,7 @@ class _WgradBatch:
         M = (ci * n)(*[t[0].shape[1] for t in it])
         N = (ci * n)(*[t[1].shape[1] for t in it])
         self.items = []
-        if tail is not None and R <= 1024:
+        if tail is not None and R <= 1024:           # (the tail GEMM of mobgt_layer_backward_tail is sized for <= 1024 rows)
             a, w, c = tail
             if (a.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and c.dtype == torch.float32 and a.shape[1] % 32 == 0
                     and w.shape[1] % 8 == 0 and a.is_contiguous() and w.is_contiguous() and c.is_contiguous()):

@@ -791,7 +791,7 @@ class _LinearSplitKFn(torch.autograd.Function):
                 db = zeros_f32((g.shape[1],), g.device)
                 dw = linear_wgrad_masked(g, x, g_mask=y, mask_vals=mv, db=db, g_out=gm)
                 # (own GEMM: the library's pick for this 608 x 192 x 192 product varied between 5 and 13 us from run to run)
-                dx = small_gemm(gm, w) if (small_gemm_ok(gm, w) and R <= 1024 and max(w.shape) <= 512) else gm @ w
+                dx = small_gemm(gm, w) if (small_gemm_ok(gm, w) and R <= _SMALL_ROWS and max(w.shape) <= 512) else gm @ w
                 return dx, dw, db, None, None, None
             g = torch.ops.aten.leaky_relu_backward(g, y, ctx.slope, True).contiguous()      # (from the activation's result)
         if hip_wgrad:
@@ -808,11 +808,12 @@ class _LinearSplitKFn(torch.autograd.Function):
 
 
 _SMALL_LINEAR = int(__import__("os").environ.get("MOBGT_SMALL_LINEAR", "1"))
+_SMALL_ROWS = int(__import__("os").environ.get("MOBGT_SMALL_ROWS", "4096"))       # rows up to which csrc/sgemm.hip takes these layers
 
 
 def _small_linear(x, w):
     """Bit mask (1: forward, 2: data gradient) -- FuseEmbeddings-sized Linear layers on csrc/sgemm.hip."""
-    ok = (x.is_cuda and x.dtype == torch.float32 and w.dtype == torch.float32 and x.dim() == 2 and x.shape[0] <= 1024
+    ok = (x.is_cuda and x.dtype == torch.float32 and w.dtype == torch.float32 and x.dim() == 2 and x.shape[0] <= _SMALL_ROWS
           and max(w.shape) <= 512 and x.stride(1) == 1 and w.is_contiguous())
     if not ok:
         return 0
