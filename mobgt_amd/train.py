@@ -435,6 +435,18 @@ class TrainStep:
         self.opt_graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.opt_graph, stream=self.stream):
             self._opt_step()
+        # Single process, no all-reduce between backward and optimizer: the optimizer rides at the end of every batch's
+        # graph -- one graph launch per step instead of two (the boundary between two replayed graphs idles the device
+        # for ~8.7 us: `tools/prof_gaps.sh`).  Every warm-up has run by now, so this second capture only records.
+        self.fused_opt = (not self.overlap and not (self.world > 1 and self.comm)
+                          and os.environ.get("MOBGT_FUSED_OPT_GRAPH", "1") != "0")
+        if self.fused_opt:
+            for i in range(len(self.batches)):
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, stream=self.stream):
+                    self._fwd_bwd(self.batches[i], slot=i)
+                    self._opt_step()
+                self.graphs[i] = g
 
     def step(self, i):
         """One optimizer step on pre-collated batch i (model_fqandtoyo.py:1434-1478 + optimizer + scheduler)."""
@@ -461,7 +473,8 @@ class TrainStep:
             if self.world > 1 and self.comm:
                 self.flat.all_reduce_mean()
         if self.use_graph:
-            self.opt_graph.replay()
+            if not getattr(self, "fused_opt", False):
+                self.opt_graph.replay()
         else:
             self._opt_step()
         self.sched_state["step_count"] += 1
