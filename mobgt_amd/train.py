@@ -438,7 +438,7 @@ class TrainStep:
         # Single process, no all-reduce between backward and optimizer: the optimizer rides at the end of every batch's
         # graph -- one graph launch per step instead of two (the boundary between two replayed graphs idles the device
         # for ~8.7 us: `tools/prof_gaps.sh`).  Every warm-up has run by now, so this second capture only records.
-        self.fused_opt = (not self.overlap and not (self.world > 1 and self.comm)
+        self.fused_opt = (not self.overlap and self.world == 1           # (never with ranks: `comm` may be toggled later)
                           and os.environ.get("MOBGT_FUSED_OPT_GRAPH", "1") != "0")
         if self.fused_opt:
             for i in range(len(self.batches)):
