@@ -401,8 +401,14 @@ __global__ __launch_bounds__(NW * 64) void build_bias_bwd_kernel(const BuildPara
     const float inv_f = 1.f / (float)p.F;
     // fixed-point scale from a strided sample of the gradient (the same 16 positions x threads in every workgroup: L2 hits
     // after the first; bf16: first and last layer slice, times the number of slices)
+    // (short batches -- one unit per workgroup -- keep f32 LDS tables in the same memory: their few hundred adds do not
+    // repay the sample's extra memory round trip and barrier: 25 vs 22 us at c2)
+    constexpr bool FX = NW == 8;
+    float* f_rel = reinterpret_cast<float*>(s_rel);       // !FX: [HH][st_rel] f32
+    float* f_poi = f_rel + (size_t)st_rel * HH;           // !FX: [HH][st_poi] f32
     float fx_scale = __builtin_nanf(""), fx_inv = 0.f;     // NaN scale = no usable sample: to_fx says 'does not fit' for every addend
-    {
+    if constexpr (!FX) __syncthreads();
+    if constexpr (FX) {
         const int64_t total = (int64_t)p.G * HH * T * p.ld;
         float m = 0.f;
 #pragma unroll
@@ -547,18 +553,26 @@ __global__ __launch_bounds__(NW * 64) void build_bias_bwd_kernel(const BuildPara
         const bool pairlive = live && tj >= 1;
         const int rp = pairlive ? rp_raw : 0;
         // row 0 of the index tables is nn.Embedding's padding_idx: it never receives a gradient, skip it
-        unsigned long long gfx[HH];
-        bool gfx_ok = true;
+        if constexpr (FX) {
+            unsigned long long gfx[HH];
+            bool gfx_ok = true;
 #pragma unroll
-        for (int h = 0; h < HH; ++h) {
-            bool ok;
-            gfx[h] = to_fx(gr[h], fx_scale, ok);
-            gfx_ok = gfx_ok && ok;
-        }
-        wave_scatter_add_fx<HH>(s_rel, lds_rel, st_rel, p.d_rel, (pairlive && rp != 0) ? rp : -1, gr, gfx, gfx_ok, fx_scale, lane);
-        if (p.poi_pos) {
-            const int pp = pairlive ? pp_raw : 0;
-            wave_scatter_add_fx<HH>(s_poi, lds_poi, st_poi, p.d_poi, (pairlive && pp != 0) ? pp : -1, gr, gfx, gfx_ok, fx_scale, lane);
+            for (int h = 0; h < HH; ++h) {
+                bool ok;
+                gfx[h] = to_fx(gr[h], fx_scale, ok);
+                gfx_ok = gfx_ok && ok;
+            }
+            wave_scatter_add_fx<HH>(s_rel, lds_rel, st_rel, p.d_rel, (pairlive && rp != 0) ? rp : -1, gr, gfx, gfx_ok, fx_scale, lane);
+            if (p.poi_pos) {
+                const int pp = pairlive ? pp_raw : 0;
+                wave_scatter_add_fx<HH>(s_poi, lds_poi, st_poi, p.d_poi, (pairlive && pp != 0) ? pp : -1, gr, gfx, gfx_ok, fx_scale, lane);
+            }
+        } else {
+            wave_scatter_add<HH>(f_rel, lds_rel, st_rel, p.d_rel, (pairlive && rp != 0) ? rp : -1, gr, lane);
+            if (p.poi_pos) {
+                const int pp = pairlive ? pp_raw : 0;
+                wave_scatter_add<HH>(f_poi, lds_poi, st_poi, p.d_poi, (pairlive && pp != 0) ? pp : -1, gr, lane);
+            }
         }
         if (p.edge_input) {
             const float inv = inv_f / spd_divisor(rp, p.D);
@@ -663,13 +677,15 @@ __global__ __launch_bounds__(NW * 64) void build_bias_bwd_kernel(const BuildPara
     }
     __syncthreads();
     for (int t = threadIdx.x; t < lds_rel * HH; t += blockDim.x) {
-        const long long v = (long long)s_rel[(t % HH) * st_rel + t / HH];
-        if (v != 0) atomicAdd(&p.d_rel[t], (float)v * fx_inv);
+        const int at = (t % HH) * st_rel + t / HH;
+        const float v = FX ? (float)(long long)s_rel[at] * fx_inv : f_rel[at];
+        if (v != 0.f) atomicAdd(&p.d_rel[t], v);
     }
     if (p.d_poi)
         for (int t = threadIdx.x; t < lds_poi * HH; t += blockDim.x) {
-            const long long v = (long long)s_poi[(t % HH) * st_poi + t / HH];
-            if (v != 0) atomicAdd(&p.d_poi[t], (float)v * fx_inv);
+            const int at = (t % HH) * st_poi + t / HH;
+            const float v = FX ? (float)(long long)s_poi[at] * fx_inv : f_poi[at];
+            if (v != 0.f) atomicAdd(&p.d_poi[t], v);
         }
     for (int t = threadIdx.x; t < HH; t += blockDim.x)
         if (s_vd[t] != 0.f) atomicAdd(&p.d_vdist[t], s_vd[t]);
