@@ -419,7 +419,9 @@ def main():
         except Exception:
             pass
         roof = dict(kernel="attn_fwd_kernel<DROP=true>", bound="hbm", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s",
-                    frac=achieved / HBM_PEAK_GBS, traffic=(pmc.get("c5_fwd_drop_bf16", {}).get("traffic_bytes") if name == "big" and bf16 else None),
+                    frac=achieved / HBM_PEAK_GBS,
+                    traffic=(pmc.get("c5_fwd_drop_bf16", {}).get("traffic_bytes") if name == "big" and bf16 else
+                             (pmc.get("fsq_attn_fwd_drop_bf16", {}).get("traffic_bytes") if name == "fsq" and bf16 else None)),
                     bytes_per_launch=tot_b / len(used), avg_launch_us=tot_t / len(used) * 1e6)
         # ... and the kernel that now takes the largest share of the timed step: the row-local chain of an encoder layer
         roofc = None
@@ -430,7 +432,9 @@ def main():
             tb = sum(chain_fwd_bytes(g * t, C, F) for g, t in used)
             tt_ = sum(durc[g * t] for g, t in used)
             roofc = dict(kernel="layer_chain_fwd_kernel", bound="hbm", achieved=tb / tt_ / 1e9, peak=HBM_PEAK_GBS, unit="GB/s",
-                         frac=tb / tt_ / 1e9 / HBM_PEAK_GBS, traffic=None, bytes_per_launch=tb / len(used),
+                         frac=tb / tt_ / 1e9 / HBM_PEAK_GBS,
+                         traffic=(pmc.get("fsq_chain_fwd", {}).get("traffic_bytes") if name == "fsq" and C == 192 else None),
+                         bytes_per_launch=tb / len(used),
                          avg_launch_us=tt_ / len(used) * 1e6,
                          note="not HBM-bound at this size: ceil(R/16) workgroups each stream the layer's 1.08 MB of packed "
                               "weights through one CU's L1 (64 B/clk); see DESIGN.md 3.5")
