@@ -41,6 +41,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true", help="skip the eval-step comparison with the oracle")
     ap.add_argument("--no-stress", action="store_true", help="skip the c5-shape attention roofline measurements")
+    ap.add_argument("--no-live-pmc", action="store_true",
+                    help="do not start rocprofv3 child passes for roofline.traffic / mfma_busy_pct (fall back to profiles/attn_pmc.json)")
     ap.add_argument("--no-gemm-autotune", action="store_true", help="leave hipBLASLt's default algorithm choice (no TunableOp)")
     ap.add_argument("--cpu-seconds", type=float, default=14.0)
     ap.add_argument("--seed", type=int, default=1)
@@ -61,7 +63,7 @@ def self_launch(args):
     return subprocess.call(cmd, env=env)
 
 
-ARGS = parse() if __name__ == "__main__" else argparse.Namespace(gpus=1, no_gemm_autotune=True)
+ARGS = parse() if __name__ == "__main__" else argparse.Namespace(gpus=1, no_gemm_autotune=True, no_live_pmc=True)
 if ARGS.gpus > 1 and "WORLD_SIZE" not in os.environ and __name__ == "__main__":
     raise SystemExit(self_launch(ARGS))
 
@@ -121,32 +123,125 @@ def _graph_time(fn, reps):
     return e0.elapsed_time(e1) / 1e3 / reps
 
 
+ROTATE_MIN_SET_BYTES = 32 << 20       # input sets at least this large are rotated (smaller ones are cache-resident in the step too)
+ROTATE_TOTAL_BYTES = 768 << 20        # ... over enough distinct sets that a set's lines have left the 256 MiB Infinity Cache
+
+
 def time_attention(G, H, T, d, io_dtype, bias_dtype, reps=50, p_drop=0.1, backward=False):
-    """(forward s, backward s or None) per launch of mobgt_attn_bias_fwd / mobgt_attn_bias_bwd (dQ + dK/dV passes) in the
-    TRAINING instantiation (attention dropout p_drop, bf16 dBias slices when the bias is bf16)."""
+    """(forward s, backward s or None, number of input sets) per launch of mobgt_attn_bias_fwd / mobgt_attn_bias_bwd (dQ +
+    dK/dV passes) in the TRAINING instantiation (attention dropout p_drop, bf16 dBias slices when the bias is bf16).
+
+    Large shapes (c5: 177 MB read per forward launch) ROTATE over distinct Q/K/V/bias sets so that no launch finds its
+    inputs in the 256 MiB Infinity Cache -- inside the S-BIG step a layer's bias was last read ~800 us and > 500 MB of
+    traffic earlier.  Round 2 replayed ONE set back to back: a warm-cache figure (55 us) that the step's own rocprof
+    numbers (65 us) did not reproduce.  Small shapes (S-FSQ: ~1 MB) keep one set: in the step they
+    are cache-resident as well (the bias is re-read by six layers within 0.3 ms)."""
     from mobgt_amd import ops
     C = H * d
+    s_x = 2 if io_dtype == torch.bfloat16 else 4
+    s_b = 2 if bias_dtype == torch.bfloat16 else 4
+    set_bytes = attn_fwd_bytes(G, T, C, H, s_x, s_b)
+    n_sets = 1 if set_bytes < ROTATE_MIN_SET_BYTES else max(3, -(-ROTATE_TOTAL_BYTES // set_bytes))
     g = torch.Generator(device="cpu").manual_seed(0)
-    qkv = torch.randn(G, T, 3 * C, generator=g).to("cuda").to(io_dtype)
-    bias = torch.randn(G, H, T, T, generator=g).to("cuda")
-    pack = ops.pack_bias(bias, G, H, T, dtype=bias_dtype)
-    del bias
-    q, k, v = qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:]
-    t_f = _graph_time(lambda: ops._attn_fwd(q, k, v, pack, d ** -0.5, p_drop, 1, None), reps)
+    sets = []
+    for _ in range(n_sets):
+        qkv = torch.randn(G, T, 3 * C, generator=g).to("cuda").to(io_dtype)
+        bias = torch.randn(G, H, T, T, generator=g).to("cuda")
+        pack = ops.pack_bias(bias, G, H, T, dtype=bias_dtype)
+        del bias
+        sets.append(dict(qkv=qkv, pack=pack, q=qkv[..., :C], k=qkv[..., C:2 * C], v=qkv[..., 2 * C:]))
+    reps = -(-reps // n_sets) * n_sets
+    it = [0]
+
+    def fwd():
+        s = sets[it[0] % n_sets]
+        it[0] += 1
+        ops._attn_fwd(s["q"], s["k"], s["v"], s["pack"], d ** -0.5, p_drop, 1, None)
+    t_f = _graph_time(fwd, reps)
     t_b = None
     if backward:
-        out, lse = ops._attn_fwd(q, k, v, pack, d ** -0.5, p_drop, 1, None)
-        dout = torch.randn(G, T, C, generator=g).to("cuda").to(io_dtype)
-        dqkv = torch.empty_like(qkv)
-        pack.needs_grad, pack.n_use = True, 1
-        pack.grad_buffer()
+        for s in sets:
+            s["out"], s["lse"] = ops._attn_fwd(s["q"], s["k"], s["v"], s["pack"], d ** -0.5, p_drop, 1, None)
+            s["dout"] = torch.randn(G, T, C, generator=g).to("cuda").to(io_dtype)
+            s["dqkv"] = torch.empty_like(s["qkv"])
+            s["pack"].needs_grad, s["pack"].n_use = True, 1
+            s["pack"].grad_buffer()
+        it[0] = 0
 
         def bwd():
-            pack.n_bwd = 0
-            ops._attn_bwd(q, k, v, out, lse, dout, dqkv[..., :C], dqkv[..., C:2 * C], dqkv[..., 2 * C:], pack, d ** -0.5,
-                          p_drop, 1, None)
+            s = sets[it[0] % n_sets]
+            it[0] += 1
+            s["pack"].n_bwd = 0
+            dqkv = s["dqkv"]
+            ops._attn_bwd(s["q"], s["k"], s["v"], s["out"], s["lse"], s["dout"], dqkv[..., :C], dqkv[..., C:2 * C], dqkv[..., 2 * C:],
+                          s["pack"], d ** -0.5, p_drop, 1, None)
         t_b = _graph_time(bwd, reps)
-    return t_f, t_b
+    return t_f, t_b, n_sets
+
+
+# ---------------------------------------------------------------------------------------- live PMC counters
+def live_pmc(shapes, p_drop, keep_dir=None, timeout=300):
+    """HBM traffic and MFMA-busy % of the attention kernels at `shapes` = [(G, T, d), ...] (distinct d; bf16), measured NOW:
+    three child runs of `rocprofv3 --pmc <set> --kernel-trace -- python3 tools/attn_bwd_bench.py` (counters in their own
+    passes, never with --stats / tracing domains: MI355X_MICROARCH.md "HBM" and "rocprofv3 PMC slots").  FETCH_SIZE /
+    WRITE_SIZE are KB; FETCH_SIZE is doubled (gfx950 tallies 128-B requests of 16-B/lane streaming reads at 64 B),
+    WRITE_SIZE is exact.  MFMA-busy % = SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x 256 CUs x kernel cycles), kernel cycles =
+    GRBM_GUI_ACTIVE / 8 (rocprofv3 sums GRBM over the 8 XCDs).  -> {d: {"fwd" | "dq" | "dkv" | "both": {...}}}, or None
+    when rocprofv3 is missing or a pass fails (the bench line then falls back to profiles/attn_pmc.json and says so)."""
+    import csv
+    import glob
+    import re
+    import shutil
+    import tempfile
+    if shutil.which("rocprofv3") is None or os.environ.get("MOBGT_NO_LIVE_PMC") == "1":
+        return None
+    tool = os.path.join(ROOT, "tools", "attn_bwd_bench.py")
+    passes = {"fetch": ["FETCH_SIZE"], "write": ["WRITE_SIZE"],
+              "sq": ["SQ_VALU_MFMA_BUSY_CYCLES", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_VALU",
+                     "SQ_INSTS_VALU", "SQ_BUSY_CYCLES", "GRBM_GUI_ACTIVE"]}
+    acc = {}
+    tmp = tempfile.mkdtemp(prefix="mobgt_pmc_")
+    env = dict(os.environ, REPS="4", P=str(p_drop), SHAPES=",".join("%d:%d:%d" % s for s in shapes), TMPDIR=tmp)
+    for k in list(env):
+        if k.startswith("PYTORCH_TUNABLEOP"):
+            del env[k]
+    pat = re.compile(r"attn_(fwd|bwd_dq|bwd_dkv|bwd_both)_kernel(?:<|ILi)(\d+)")
+    try:
+        for name, counters in passes.items():
+            out = os.path.join(tmp, name)
+            cmd = ["rocprofv3", "--pmc"] + counters + ["--kernel-trace", "--output-format", "csv", "-d", out, "-o", "r", "--",
+                                                       sys.executable, tool]
+            r = subprocess.run(cmd, env=env, cwd=tmp, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=timeout)
+            files = glob.glob(os.path.join(out, "**", "r_counter_collection.csv"), recursive=True)
+            if r.returncode != 0 or not files:
+                return None
+            if keep_dir:
+                os.makedirs(keep_dir, exist_ok=True)
+                shutil.copy(files[0], os.path.join(keep_dir, f"attn_pmc_{name}.csv"))
+            for row in csv.DictReader(open(files[0])):
+                m = pat.search(row["Kernel_Name"])
+                if m:
+                    kern = {"fwd": "fwd", "bwd_dq": "dq", "bwd_dkv": "dkv", "bwd_both": "both"}[m.group(1)]
+                    acc.setdefault(int(m.group(2)), {}).setdefault(kern, {}).setdefault(row["Counter_Name"], []).append(
+                        float(row["Counter_Value"]))
+    except Exception:
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    res = {}
+    for dd, kerns in acc.items():
+        for kern, cs in kerns.items():
+            m = {c: sum(v[1:]) / max(len(v) - 1, 1) for c, v in cs.items()}           # first (cold) launch skipped
+            if not all(c in m for c in ("FETCH_SIZE", "WRITE_SIZE", "SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE")):
+                return None
+            cyc = max(m["GRBM_GUI_ACTIVE"] / 8.0, 1.0)
+            res.setdefault(dd, {})[kern] = dict(
+                traffic_bytes=int(m["FETCH_SIZE"] * 2048 + m["WRITE_SIZE"] * 1024),
+                fetch_bytes_corrected=int(m["FETCH_SIZE"] * 2048), write_bytes=int(m["WRITE_SIZE"] * 1024),
+                mfma_busy_pct=round(100.0 * m["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024.0 * cyc), 2),
+                valu_busy_pct=round(100.0 * m.get("SQ_ACTIVE_INST_VALU", 0.0) * 4 / (1024.0 * cyc), 2),
+                wait_any_frac=round(m.get("SQ_WAIT_ANY", 0.0) / max(m.get("SQ_WAVE_CYCLES", 1.0), 1.0), 3))
+    return res or None
 
 
 # ------------------------------------------------------------------------------------------ CPU baseline
@@ -371,6 +466,28 @@ def main():
     loss = float(ts.loss_out.item())
     if loss != loss or abs(loss) == float("inf"):
         raise SystemExit(f"bench.py: training diverged (final loss {loss}) -- the timing would be meaningless")
+    # A short timed region (the driver's default call asks for 20 steps = 15 ms of work) is honoured exactly -- `value` is
+    # those K steps -- and a 200-step measurement of the same loop is reported beside it so that the line can be judged
+    # against run-to-run noise
+    long_run = None
+    if args.steps < 100:
+        k_long = 200
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        t1 = time.perf_counter()
+        for i in range(k_long):
+            ts.step(args.warmup + args.steps + i)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t1
+        if world > 1:
+            tl = torch.tensor([el], device=dev, dtype=torch.float64)
+            dist.all_reduce(tl, op=dist.ReduceOp.MAX)
+            el = float(tl.item())
+        long_run = dict(steps=k_long, ms_per_step=el / k_long * 1e3, value=args.batch_size * world * k_long / el)
     rccl_ranks, exposed_us = None, None
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
@@ -409,20 +526,41 @@ def main():
         # at the shapes the timed region ran
         used = [shapes[(args.warmup + i) % len(shapes)] for i in range(args.steps)]
         uniq = sorted(set(used))
-        dur = {s: time_attention(s[0], H, s[1], d, io_dt, b_dt, p_drop=p_att, reps=50 if s[1] < 400 else 20)[0] for s in uniq}
+        timed = {s: time_attention(s[0], H, s[1], d, io_dt, b_dt, p_drop=p_att, reps=50 if s[1] < 400 else 24) for s in uniq}
+        dur = {s: v[0] for s, v in timed.items()}
         tot_b = sum(attn_fwd_bytes(g, t, C, H, s_x, s_b) for g, t in used)
         tot_t = sum(dur[s] for s in used)
         achieved = tot_b / tot_t / 1e9
-        pmc = {}
-        try:        # PMC-measured HBM bytes per launch (separate rocprofv3 --pmc passes, corrected per the guide)
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "attn_pmc.json")))
-        except Exception:
-            pass
+        # PMC counters of the attention kernels, measured in this run by rocprofv3 child processes (separate --pmc passes,
+        # corrected per the guide): at the most frequent timed shape and at the c5 stress shape.  Fallback (no rocprofv3,
+        # --no-live-pmc): the figures of profiles/attn_pmc.json, labelled as such.
+        mode_shape = max(uniq, key=lambda sh: (used.count(sh), sh[1]))
+        pmc_live, pmc_file = None, {}
+        if bf16 and io_dt == torch.bfloat16 and not args.no_live_pmc and world == 1:
+            want = [(mode_shape[0], mode_shape[1], d)]
+            if not args.no_stress and d != 32:
+                want.append((16, 785, 32))
+            pmc_live = live_pmc(want, p_att, keep_dir=os.path.join(ROOT, "gpurun_out", "pmc_live"))
+        if pmc_live is None:
+            try:
+                pmc_file = json.load(open(os.path.join(ROOT, "profiles", "attn_pmc.json")))
+            except Exception:
+                pass
+
+        def pmc_of(dd, kern, file_key):
+            """(traffic bytes, MFMA-busy %, source) of one kernel"""
+            if pmc_live is not None and dd in pmc_live and kern in pmc_live[dd]:
+                e = pmc_live[dd][kern]
+                return e["traffic_bytes"], e["mfma_busy_pct"], "live: rocprofv3 --pmc child passes of this run", e
+            e = pmc_file.get(file_key, {}) if bf16 else {}
+            return e.get("traffic_bytes"), e.get("mfma_busy_pct"), ("profiles/attn_pmc.json (earlier run)" if e else None), e
+        big_shape = name == "big"
+        tr, mb, src, _ = pmc_of(d, "fwd", "c5_fwd_drop_bf16" if big_shape else ("fsq_attn_fwd_drop_bf16" if name == "fsq" else "-"))
         roof = dict(kernel="attn_fwd_kernel<DROP=true>", bound="hbm", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s",
-                    frac=achieved / HBM_PEAK_GBS,
-                    traffic=(pmc.get("c5_fwd_drop_bf16", {}).get("traffic_bytes") if name == "big" and bf16 else
-                             (pmc.get("fsq_attn_fwd_drop_bf16", {}).get("traffic_bytes") if name == "fsq" and bf16 else None)),
-                    bytes_per_launch=tot_b / len(used), avg_launch_us=tot_t / len(used) * 1e6)
+                    frac=achieved / HBM_PEAK_GBS, traffic=tr, mfma_busy_pct=mb, counters_source=src,
+                    counters_shape="G%d T%d d%d" % (mode_shape[0], mode_shape[1], d),
+                    bytes_per_launch=tot_b / len(used), avg_launch_us=tot_t / len(used) * 1e6,
+                    input_sets_rotated=max(v[2] for v in timed.values()))
         # ... and the kernel that now takes the largest share of the timed step: the row-local chain of an encoder layer
         roofc = None
         F = m["ffn_dim"]
@@ -431,29 +569,40 @@ def main():
             durc = {r: time_chain(r, C, F, reps=50 if r < 4096 else 10, p_drop=m["dropout_rate"]) for r in rows}
             tb = sum(chain_fwd_bytes(g * t, C, F) for g, t in used)
             tt_ = sum(durc[g * t] for g, t in used)
+            if not pmc_file:
+                try:
+                    pmc_file = json.load(open(os.path.join(ROOT, "profiles", "attn_pmc.json")))
+                except Exception:
+                    pass
             roofc = dict(kernel="layer_chain_fwd_kernel", bound="hbm", achieved=tb / tt_ / 1e9, peak=HBM_PEAK_GBS, unit="GB/s",
                          frac=tb / tt_ / 1e9 / HBM_PEAK_GBS,
-                         traffic=(pmc.get("fsq_chain_fwd", {}).get("traffic_bytes") if name == "fsq" and C == 192 else None),
+                         traffic=(pmc_file.get("fsq_chain_fwd", {}).get("traffic_bytes") if name == "fsq" and C == 192 else None),
+                         counters_source="profiles/attn_pmc.json (earlier run)",
                          bytes_per_launch=tb / len(used),
                          avg_launch_us=tt_ / len(used) * 1e6,
-                         note="not HBM-bound at this size: ceil(R/16) workgroups each stream the layer's 1.08 MB of packed "
-                              "weights through one CU's L1 (64 B/clk); see DESIGN.md 3.5")
+                         note="not HBM-bound at this size: the workgroups stream the layer's packed weights through their "
+                              "CUs' L1; see DESIGN.md 3.5")
         roof5 = roof5b = None
         if not args.no_stress:
             # the same kernels at the HBM-roofline stress shape (BASELINE configs[4]: G16 x 784 nodes, C 256, d 32), training
-            # instantiation (attention dropout 0.1, bf16 dBias slices): forward, and both backward passes together
-            t5f, t5b = time_attention(16, 8, 785, 32, b_dt, b_dt, reps=20, p_drop=0.1, backward=True)
+            # instantiation (attention dropout 0.1, bf16 dBias slices): forward, and both backward passes together; the
+            # launches rotate over distinct input sets (see time_attention) -- the in-step, cold-cache figure
+            t5f, t5b, nset5 = time_attention(16, 8, 785, 32, b_dt, b_dt, reps=24, p_drop=0.1, backward=True)
             b5f = attn_fwd_bytes(16, 785, 256, 8, s_b, s_b)
             b5b = attn_bwd_bytes(16, 785, 256, 8, s_b, s_b, s_g)
+            tr, mb, src, e = pmc_of(32, "fwd", "c5_fwd_drop_bf16")
             roof5 = dict(kernel="attn_fwd_kernel<DROP=true>", workload="c5 G16 T785 C256 d32, dropout 0.1", bound="hbm",
                          achieved=b5f / t5f / 1e9, peak=HBM_PEAK_GBS, unit="GB/s", frac=b5f / t5f / 1e9 / HBM_PEAK_GBS,
-                         traffic=pmc.get("c5_fwd_drop_bf16", {}).get("traffic_bytes") if bf16 else None,
-                         avg_launch_us=t5f * 1e6, bytes_per_launch=b5f)
+                         traffic=tr, mfma_busy_pct=mb, valu_busy_pct=e.get("valu_busy_pct"), wait_any_frac=e.get("wait_any_frac"),
+                         counters_source=src, avg_launch_us=t5f * 1e6, bytes_per_launch=b5f, input_sets_rotated=nset5)
+            trq, mbq, srcq, _ = pmc_of(32, "dq", "c5_bwd_dq_drop_bf16")
+            trk, mbk, _, _ = pmc_of(32, "dkv", "c5_bwd_dkv_drop_bf16")
             roof5b = dict(kernel="attn_bwd_dq_kernel + attn_bwd_dkv_kernel", workload="c5 G16 T785 C256 d32, dropout 0.1",
                           bound="hbm", achieved=b5b / t5b / 1e9, peak=HBM_PEAK_GBS, unit="GB/s",
                           frac=b5b / t5b / 1e9 / HBM_PEAK_GBS,
-                          traffic=pmc.get("c5_bwd_drop_bf16", {}).get("traffic_bytes") if bf16 else None,
-                          avg_launch_us=t5b * 1e6, bytes_per_launch=b5b)
+                          traffic=(trq + trk) if (trq is not None and trk is not None) else None,
+                          mfma_busy_pct={"dq": mbq, "dkv": mbk}, counters_source=srcq,
+                          avg_launch_us=t5b * 1e6, bytes_per_launch=b5b, input_sets_rotated=nset5)
         parity = None
         if not args.no_parity and uni.distance is not None:
             parity = oracle_parity(model, batches, uni, n_layers)
@@ -474,7 +623,7 @@ def main():
                                      "attention_io": "bf16" if io_dt == torch.bfloat16 else "f32",
                                      "gcn_adjacency_product": args.dtype, "library_gemms": args.gemm_dtype if bf16 else "f32",
                                      "accumulate_softmax_layernorm_adamw": "f32"}},
-            "final_loss": loss, "ms_per_step_chunks": [round(c, 4) for c in chunk_ms],
+            "final_loss": loss, "ms_per_step_chunks": [round(c, 4) for c in chunk_ms], "long_run": long_run,
             "rccl_ranks": rccl_ranks, "allreduce_exposed_us": exposed_us,
             "parity": parity, "roofline": roof, "roofline_chain": roofc, "roofline_stress": roof5, "roofline_stress_bwd": roof5b,
             "cpu_baseline": cpu,

@@ -93,6 +93,12 @@ int mobgt_attn_bias_bwd(const void* q, const void* k, const void* v, const void*
 /* Host-side statement of the dropout keep rule used by both kernels (for tests / replay).
  * Returns 1 if probability element (g,h,i,j) is kept. */
 int mobgt_dropout_keep_host(uint64_t seed, int H, int T, int g, int h, int i, int j, float dropout_p);
+/* The same for the whole [G,H,T,T] mask at once (host memory, 1 byte per element). */
+int mobgt_attn_dropout_mask_host(uint64_t seed, int G, int H, int T, float dropout_p, uint8_t* out);
+/* Host replay of the keep rule of every other dropout site of the step (nn.Dropout at model.py:476-488,
+ * model_fqandtoyo.py:358, 1347, 1364, modelGNN.py:72): out[r*C + c] = 1 if element c of row (row0 + r) is kept;
+ * `seed` = host seed + device step counter, `salt` = the site's constant. */
+int mobgt_dropout_mask_host(uint64_t seed, uint32_t salt, int64_t row0, int64_t R, int C, float dropout_p, uint8_t* out);
 
 /* ------------------------------------------------------------------------------------------------
  * Re-layout of a caller-supplied attention bias into the padded row-major + transposed pair the

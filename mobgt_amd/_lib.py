@@ -16,7 +16,7 @@ F32, BF16 = 0, 1
 I64, I32, I16, U8 = 0, 1, 2, 3
 
 _c = ctypes
-_vp, _i, _i64, _f, _u64 = _c.c_void_p, _c.c_int, _c.c_int64, _c.c_float, _c.c_uint64
+_vp, _i, _i64, _f, _u64, _u32 = _c.c_void_p, _c.c_int, _c.c_int64, _c.c_float, _c.c_uint64, _c.c_uint32
 
 SIGNATURES = {
     "mobgt_abi_version": (_i, []),
@@ -25,6 +25,8 @@ SIGNATURES = {
                                  _f, _f, _u64, _vp, _i, _i, _vp]),
     "mobgt_attn_bias_bwd": (_i, [_vp] * 13 + [_i, _i, _i, _i] + [_i64] * 8 + [_f, _f, _u64, _vp, _i, _i, _i, _i, _vp]),
     "mobgt_dropout_keep_host": (_i, [_u64, _i, _i, _i, _i, _i, _i, _f]),
+    "mobgt_attn_dropout_mask_host": (_i, [_u64, _i, _i, _i, _f, _vp]),
+    "mobgt_dropout_mask_host": (_i, [_u64, _u32, _i64, _i64, _i, _f, _vp]),
     "mobgt_bias_pack": (_i, [_vp, _i, _i64, _i64, _i64, _i64, _vp, _vp, _i, _i, _i, _i, _i64, _vp]),
     "mobgt_build_bias": (_i, [_vp] * 10 + [_i] * 9 + [_i64, _i, _i, _i, _vp]),
     "mobgt_build_bias_bwd": (_i, [_vp, _i, _i, _i64] + [_vp] * 8 + [_i] * 9 + [_i64, _i, _i, _vp]),

@@ -878,3 +878,29 @@ extern "C" int mobgt_dropout_keep_host(uint64_t seed, int H, int T, int g, int h
     const uint32_t rowh = dropout_row_hash(seed, (uint32_t)((g * H + h) * T + i));
     return attn_drop_keep(seed, rowh, (uint32_t)j, (int)thr - 32768) ? 1 : 0;
 }
+
+// Bulk forms of the host replay (tests replay whole masks into the oracle; one ctypes call per element is too slow at
+// T = 785): out[((g*H + h)*T + i)*T + j] = keep of probability (g,h,i,j) ...
+extern "C" int mobgt_attn_dropout_mask_host(uint64_t seed, int G, int H, int T, float dropout_p, uint8_t* out) {
+    if (G < 0 || H <= 0 || T <= 0 || !out) return MOBGT_EBADDIM;
+    const uint32_t thr = dropout_p > 0.f ? dropout_threshold(dropout_p) : 0u;
+    for (int64_t row = 0; row < (int64_t)G * H * T; ++row) {
+        const uint32_t rowh = dropout_row_hash(seed, (uint32_t)row);
+        uint8_t* o = out + row * T;
+        for (int j = 0; j < T; ++j) o[j] = (!thr || attn_drop_keep(seed, rowh, (uint32_t)j, (int)thr - 32768)) ? 1 : 0;
+    }
+    return 0;
+}
+
+// ... and of the rule every OTHER dropout site of the step uses (residual branches, token assembly, head, GCN: csrc/layer.hip,
+// chain.hip, lngemm.hip, sgemm.hip, smallgcn.hip): out[r*C + c] = dropout_bits16(seed, hash(seed, (row0 + r) ^ salt), c) >= thr.
+extern "C" int mobgt_dropout_mask_host(uint64_t seed, uint32_t salt, int64_t row0, int64_t R, int C, float dropout_p, uint8_t* out) {
+    if (R < 0 || C <= 0 || !out) return MOBGT_EBADDIM;
+    const uint32_t thr = dropout_p > 0.f ? dropout_threshold(dropout_p) : 0u;
+    for (int64_t r = 0; r < R; ++r) {
+        const uint32_t rowh = dropout_row_hash(seed, (uint32_t)(row0 + r) ^ salt);
+        uint8_t* o = out + r * C;
+        for (int c = 0; c < C; ++c) o[c] = (!thr || dropout_bits16(seed, rowh, (uint32_t)c) >= thr) ? 1 : 0;
+    }
+    return 0;
+}

@@ -41,9 +41,12 @@ struct SmallGcnParams {
 // Hand-over between the layers.  NO fences: an agent-scope release / acquire pair is a write-back and an invalidate of the
 // XCD's whole L2 (measured: ~10 us per hand-over, and the kernels after this one start on a cold L2).  Instead the rows
 // that cross workgroups are written and read with agent-scope RELAXED atomics -- `sc1` stores that write through and
-// `sc1` loads that do not trust a non-coherent line (coh_store / coh_load below); __syncthreads() waits for the
-// wave's stores to be acknowledged (vmcnt 0) before thread 0 announces the workgroup.
+// `sc1` loads that do not trust a non-coherent line (coh_store / coh_load below).  EVERY wave waits for its own stores to
+// be acknowledged (explicit `s_waitcnt vmcnt(0)`: on gfx950 __syncthreads() is a bare s_barrier when the compiler sees no
+// pending LDS-DMA, it does NOT drain the vector-memory counter) before the workgroup barrier that precedes thread 0's
+// announcement -- otherwise the rows of waves 1..3 can still be in flight when another workgroup passes the counter.
 __device__ __forceinline__ void grid_barrier(int* counter, const int target) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) {
         __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -142,10 +142,14 @@ __global__ __launch_bounds__(256) void spmm_t_gather_kernel(const SpmmTgParams p
 extern "C" int mobgt_spmm_csr_t_rows_gather(const int64_t* t_rowptr, const int32_t* t_col, const float* t_val, const int64_t* rows,
                                             int* head, int* nxt, const float* g, int64_t ldg, float* db, int64_t ld_db, int64_t P,
                                             int64_t R, int C, void* stream) {
-    if (R <= 0 || P <= 0) return 0;
+    if (P <= 0) return 0;
     if (C <= 0 || (C & 3) || C > 512 || (ldg & 3) || (ld_db & 3) || R > 0x7fffffff) return MOBGT_EBADDIM;
     if (((uintptr_t)g | (uintptr_t)db) & 15) return MOBGT_EALIGN;
     hipStream_t st = (hipStream_t)stream;
+    if (R <= 0) {      // an empty row subset: the contract is "every row of db is written", so the result is all zeros
+        if (ld_db == C) return (int)hipMemsetAsync(db, 0, (size_t)P * C * sizeof(float), st);
+        return (int)hipMemset2DAsync(db, (size_t)ld_db * sizeof(float), 0, (size_t)C * sizeof(float), (size_t)P, st);
+    }
     const dim3 lgrid((unsigned)((R + 255) / 256)), block(256);
     hipLaunchKernelGGL(rows_link_kernel, lgrid, block, 0, st, rows, (int)R, head, nxt, 0);
     SpmmTgParams p = {};

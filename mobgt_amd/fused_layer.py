@@ -198,8 +198,31 @@ _CHAIN_BWD = [_os_ln.environ.get("MOBGT_NO_CHAIN_BWD") != "1"]      # ... and th
 # an error, raised when the backward pass ends -- never a silently incomplete gradient.
 _DEFER = [_os_ln.environ.get("MOBGT_NO_DEFER_TAIL") != "1"]
 _DEFER_MAX_R = [int(_os_ln.environ.get("MOBGT_DEFER_MAX_R", "4096"))]      # S-GOW: 1024 / 2048 / 4096 / 16384 -> 18.96 / 19.33 / 19.65 / 19.5 k check-ins/s
-_PENDING_TAIL = {}
-_PENDING_CB = [False]
+_PENDING_TAIL = {}          # (graph task id, device index, address of dx1) -> parked work; see _pending_key
+_PENDING_CB = [None]        # graph task id for which the end-of-backward check is queued
+
+
+def _task_id():
+    """Id of the autograd graph task (one per top-level backward / autograd.grad call) this code runs under, -1 outside."""
+    fn = getattr(torch._C, "_current_graph_task_id", None)
+    return int(fn()) if fn is not None else -1
+
+
+def _pending_key(t):
+    return (_task_id(), t.device.index, t.data_ptr())
+
+
+def _drop_stale_pending():
+    """Entries parked by a backward pass that is not the running one: that pass died before its end-of-backward callback
+    ran (an exception in some backward function -- the engine then skips the callbacks).  Their buffers belong to a graph
+    that no longer exists: drop them, never feed them to a kernel.  (An entry holds views of its buffers, so while it is
+    parked no other tensor can be allocated at its address: a key of the RUNNING task always names the tensor it was
+    parked under.)"""
+    tid = _task_id()
+    if _PENDING_CB[0] is not None and _PENDING_CB[0] != tid:
+        _PENDING_CB[0] = None
+    for k in [k for k in _PENDING_TAIL if k[0] != tid]:
+        del _PENDING_TAIL[k]
 
 
 def _complete_pending(pend):
@@ -211,12 +234,21 @@ def _complete_pending(pend):
 
 
 def _pending_check():
-    _PENDING_CB[0] = False
-    if _PENDING_TAIL:
-        left = list(_PENDING_TAIL.values())
-        _PENDING_TAIL.clear()
-        for pend in left:                        # finish the arithmetic, then say that the protocol was broken
-            _complete_pending(pend)
+    """End of a backward pass (autograd engine callback): nothing may still be parked.  If the lower layer's output had a
+    second consumer whose gradient reached the engine's input buffer FIRST, the buffer's sum is a new tensor, no layer
+    recognises it and the entry is still here: the weight gradients are completed, the input gradient cannot be repaired
+    (the sum was taken without dqkv Wqkv) -- hence the error, never a silent result.  (Had dx1 arrived first, the engine
+    accumulates in place into it and the hosted product lands on top: correct.)"""
+    tid = _task_id()
+    _PENDING_CB[0] = None
+    mine = [k for k in _PENDING_TAIL if k[0] == tid or tid == -1]
+    if mine:
+        left = [_PENDING_TAIL.pop(k) for k in mine]
+        try:
+            for pend in left:                    # finish the arithmetic, then say that the protocol was broken
+                _complete_pending(pend)
+        finally:
+            _PENDING_TAIL.clear()
         raise RuntimeError("mobgt fused layer: a deferred input gradient was not consumed by the layer below "
                            "(was the layer's input used by something else as well?); set MOBGT_NO_DEFER_TAIL=1")
 
@@ -479,7 +511,9 @@ class _FusedLayerFn(torch.autograd.Function):
         wb = _WgradBatch()
         k_qkv, k_wo, k_w1, k_w2 = ctx.sinks                          # gradient sinks (or None)
         db1_in_wgrad = _wgrad_hip(A, F, C, R)                         # then b1's gradient rides on the dW1 kernel
-        pend = _PENDING_TAIL.pop(dout.data_ptr(), None) if _PENDING_TAIL else None
+        if _PENDING_TAIL or _PENDING_CB[0] is not None:
+            _drop_stale_pending()
+        pend = _PENDING_TAIL.pop(_pending_key(dout), None) if _PENDING_TAIL else None
         host = pend is not None and getattr(ctx, "chain_bwd", False) and db1_in_wgrad and not stock and pend["R"] == R
         if pend is not None and not host:
             _complete_pending(pend)                                   # this layer cannot host it: finish it right here
@@ -532,10 +566,10 @@ class _FusedLayerFn(torch.autograd.Function):
             # (parked as FRESH views of the gradient buffers: autograd's AccumulateGrad clones a returned gradient that anything
             # else still references, and the clone -- taken before the buffers are filled -- would later be copied over them)
             items = [(g_, x_, dw_[:], db_[:] if db_ is not None else None) for g_, x_, dw_, db_ in wb.items]
-            _PENDING_TAIL[dx1.data_ptr()] = dict(dx1=dx1[:], dqkv=dqkv2, wqkv=s_wqkv, wqt=cfg.packed_t[3], items=items, R=R)
+            _PENDING_TAIL[_pending_key(dx1)] = dict(dx1=dx1[:], dqkv=dqkv2, wqkv=s_wqkv, wqt=cfg.packed_t[3], items=items, R=R)
             wb.items = []
-            if not _PENDING_CB[0]:
-                _PENDING_CB[0] = True
+            if _PENDING_CB[0] != _task_id():
+                _PENDING_CB[0] = _task_id()
                 torch.autograd.Variable._execution_engine.queue_callback(_pending_check)
             rode = True
             dx = dx1

@@ -35,3 +35,16 @@ class PolynomialDecayLR(LRScheduler):
 
     def get_lr(self):
         return [polynomial_decay_lr(self._step_count, **self.schedule)] * len(self.optimizer.param_groups)
+
+    def load_state_dict(self, state_dict):
+        """Also accepts a state written by the REFERENCE scheduler (graphormer/lr.py:9-15 keeps warmup_updates, tot_updates,
+        lr, end_lr, power as plain attributes, so its state_dict has them at top level): they are folded into `schedule`,
+        which is what get_lr reads."""
+        state_dict = dict(state_dict)
+        sched = dict(state_dict.pop("schedule", self.schedule))
+        for k in ("warmup_updates", "tot_updates", "lr", "end_lr", "power"):
+            if k in state_dict:
+                sched[k] = state_dict.pop(k)
+        super().load_state_dict(state_dict)
+        self.schedule = sched
+

@@ -206,6 +206,10 @@ def fused_layer_forward(layer, variant, x, attn_bias, n1, nx, next_layer=None):
         cfg.packed = layer._packed[1:]                    # (wo, w1, w2) in MFMA operand order
         if getattr(layer, "_packed_t_fresh", False):
             cfg.packed_t = layer._packed_t                # (w2^T, w1^T, wo^T)
+    # like `_shadow_fresh` above: a pack is good for the ONE forward that follows the refresh (refresh_shadows /
+    # pack_layer_weights run once per model forward); a later stand-alone call of this layer re-copies its shadows and
+    # must not pair them with the old pack
+    layer._packed_fresh = layer._packed_t_fresh = False
     params = (mha.linear_q.weight, mha.linear_q.bias, mha.linear_k.weight, mha.linear_k.bias, mha.linear_v.weight,
               mha.linear_v.bias, mha.output_layer.weight, mha.output_layer.bias, n1.weight, n1.bias, nx.weight, nx.bias,
               layer.ffn.layer1.weight, layer.ffn.layer1.bias, layer.ffn.layer2.weight, layer.ffn.layer2.bias)

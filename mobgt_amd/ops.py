@@ -350,16 +350,22 @@ def attention_qkv(qkv, pack, scale, p_drop=0.0, seed=0, seed_dev=None):
 
 
 def dropout_keep_mask(seed, G, H, T, p_drop):
-    """Host replay of the kernels' keep rule (tests): bool [G,H,T,T]."""
+    """Host replay of the attention kernels' keep rule (tests): bool [G,H,T,T] (mobgt_attn_dropout_mask_host)."""
     import numpy as np
-    lib = _lib.lib()
-    m = np.zeros((G, H, T, T), dtype=bool)
-    for g in range(G):
-        for h in range(H):
-            for i in range(T):
-                for j in range(T):
-                    m[g, h, i, j] = bool(lib.mobgt_dropout_keep_host(seed, H, T, g, h, i, j, p_drop))
-    return m
+    m = np.empty((G, H, T, T), dtype=np.uint8)
+    check(_lib.lib().mobgt_attn_dropout_mask_host(int(seed) & 0xFFFFFFFFFFFFFFFF, G, H, T, float(p_drop), m.ctypes.data),
+          "mobgt_attn_dropout_mask_host")
+    return m.astype(bool)
+
+
+def dropout_site_mask(seed, salt, R, C, p_drop, row0=0):
+    """Host replay of the keep rule of every non-attention dropout site (tests): bool [R,C]; `seed` = host seed + device
+    step counter, `salt` = the site's constant, rows numbered from `row0` (mobgt_dropout_mask_host)."""
+    import numpy as np
+    m = np.empty((R, C), dtype=np.uint8)
+    check(_lib.lib().mobgt_dropout_mask_host(int(seed) & 0xFFFFFFFFFFFFFFFF, int(salt) & 0xFFFFFFFF, int(row0), R, C, float(p_drop),
+                                             m.ctypes.data), "mobgt_dropout_mask_host")
+    return m.astype(bool)
 
 
 # ------------------------------------------------------------------------------------------- spd

@@ -28,7 +28,16 @@ def layer_norm(sd, prefix, x):
     return F.layer_norm(x, (w.shape[0],), w, sd[prefix + ".bias"], 1e-5)
 
 
-def multi_head_attention(sd, prefix, q, k, v, attn_bias, num_heads, p_drop=0.0, training=False):
+def _dropout(x, p, training, drop=None, site=None):
+    """nn.Dropout / F.dropout.  `drop`: optional callable (x, p, site) -> tensor standing in for torch's generator in
+    training mode -- the parity tests pass the keep masks the device drew (mobgt_*_mask_host), so that a training-mode step
+    of the HIP path can be compared element by element; `site` names the call (see the callers)."""
+    if drop is not None and training and p > 0:
+        return drop(x, p, site)
+    return F.dropout(x, p, training)
+
+
+def multi_head_attention(sd, prefix, q, k, v, attn_bias, num_heads, p_drop=0.0, training=False, drop=None):
     """model.py:424-460 / model_fqandtoyo.py:1675-1711 (mask branch is dead: every caller passes None)."""
     orig = q.size()
     B = q.size(0)
@@ -42,7 +51,7 @@ def multi_head_attention(sd, prefix, q, k, v, attn_bias, num_heads, p_drop=0.0, 
     if attn_bias is not None:
         x = x + attn_bias                           # unscaled bias (:445)
     x = torch.softmax(x, dim=3)
-    x = F.dropout(x, p_drop, training)
+    x = _dropout(x, p_drop, training, drop, (prefix, "att"))
     x = x.matmul(v)
     x = x.transpose(1, 2).contiguous().view(B, -1, num_heads * d)
     x = linear(sd, prefix + ".output_layer", x)
@@ -55,21 +64,21 @@ def feed_forward(sd, prefix, x):
     return linear(sd, prefix + ".layer2", F.gelu(linear(sd, prefix + ".layer1", x)))
 
 
-def encoder_layer_stock(sd, prefix, x, attn_bias, num_heads, p=0.0, p_att=0.0, training=False):
+def encoder_layer_stock(sd, prefix, x, attn_bias, num_heads, p=0.0, p_att=0.0, training=False, drop=None):
     """model.py:479-489 (pre-LN)."""
     y = layer_norm(sd, prefix + ".self_attention_norm", x)
-    y = multi_head_attention(sd, prefix + ".self_attention", y, y, y, attn_bias, num_heads, p_att, training)
-    x = x + F.dropout(y, p, training)
+    y = multi_head_attention(sd, prefix + ".self_attention", y, y, y, attn_bias, num_heads, p_att, training, drop)
+    x = x + _dropout(y, p, training, drop, (prefix, "res1"))
     y = feed_forward(sd, prefix + ".ffn", layer_norm(sd, prefix + ".ffn_norm", x))
-    return x + F.dropout(y, p, training)
+    return x + _dropout(y, p, training, drop, (prefix, "res2"))
 
 
-def encoder_layer_fq(sd, prefix, x, attn_bias, num_heads, p=0.0, p_att=0.0, training=False):
+def encoder_layer_fq(sd, prefix, x, attn_bias, num_heads, p=0.0, p_att=0.0, training=False, drop=None):
     """model_fqandtoyo.py:1731-1743: no pre-norm on attention; LN1 before FFN; LN2 on the output."""
-    y = multi_head_attention(sd, prefix + ".self_attention", x, x, x, attn_bias, num_heads, p_att, training)
-    x = x + F.dropout(y, p, training)
+    y = multi_head_attention(sd, prefix + ".self_attention", x, x, x, attn_bias, num_heads, p_att, training, drop)
+    x = x + _dropout(y, p, training, drop, (prefix, "res1"))
     y = feed_forward(sd, prefix + ".ffn", layer_norm(sd, prefix + ".ffn_norm1", x))
-    x = x + F.dropout(y, p, training)
+    x = x + _dropout(y, p, training, drop, (prefix, "res2"))
     return layer_norm(sd, prefix + ".ffn_norm2", x)
 
 
@@ -116,7 +125,7 @@ def assemble_bias(sd, batch, H, D, variant):
 
 
 # ------------------------------------------------------------------------------- stock Graphormer
-def graphormer_stock_forward(sd, batch, n_layers, H, D, p=0.0, p_in=0.0, p_att=0.0, training=False):
+def graphormer_stock_forward(sd, batch, n_layers, H, D, p=0.0, p_in=0.0, p_att=0.0, training=False, drop=None):
     """model.py:111-217 (non-PCQM branch: downstream_out_proj on the graph token)."""
     x = batch.x
     in_degree = out_degree = batch.in_degree         # model.py:118 aliases out_degree to in_degree
@@ -126,9 +135,9 @@ def graphormer_stock_forward(sd, batch, n_layers, H, D, p=0.0, p_in=0.0, p_att=0
     node = node + F.embedding(in_degree, sd["in_degree_encoder.weight"], padding_idx=0) \
         + F.embedding(out_degree, sd["out_degree_encoder.weight"], padding_idx=0)
     tok = sd["graph_token.weight"].unsqueeze(0).repeat(n_graph, 1, 1)
-    out = F.dropout(torch.cat([tok, node], dim=1), p_in, training)
+    out = _dropout(torch.cat([tok, node], dim=1), p_in, training, drop, "input")
     for l in range(n_layers):
-        out = encoder_layer_stock(sd, f"layers.{l}", out, bias, H, p, p_att, training)
+        out = encoder_layer_stock(sd, f"layers.{l}", out, bias, H, p, p_att, training, drop)
     out = layer_norm(sd, "final_ln", out)
     return linear(sd, "downstream_out_proj", out[:, 0, :])
 
@@ -186,12 +195,12 @@ def fq_constants(uni, dataset_name, diag_inverse=False, num_bins=None):
     )
 
 
-def gcn(sd, prefix, x, adj, p_drop, training):
+def gcn(sd, prefix, x, adj, p_drop, training, drop=None):
     """modelGNN.py:53-74 with GraphConvolution :21-50 (dense adj)."""
     n = len([k for k in sd if k.startswith(prefix + ".gcn.") and k.endswith(".weight")])
     for i in range(n - 1):
         x = F.leaky_relu(torch.mm(adj, torch.mm(x, sd[f"{prefix}.gcn.{i}.weight"])) + sd[f"{prefix}.gcn.{i}.bias"], 0.2)
-    x = F.dropout(x, p_drop, training)
+    x = _dropout(x, p_drop, training, drop, (prefix, "gcn"))
     return torch.mm(adj, torch.mm(x, sd[f"{prefix}.gcn.{n - 1}.weight"])) + sd[f"{prefix}.gcn.{n - 1}.bias"]
 
 
@@ -201,15 +210,15 @@ def fuse(sd, prefix, a, b):
 
 
 def graphormer_fq_forward(sd, batch, consts, n_layers, H, D, p=0.0, p_in=0.0, p_att=0.0, training=False,
-                          hidden=128, time_dim=32, cat_dim=32):
+                          hidden=128, time_dim=32, cat_dim=32, drop=None):
     """model_fqandtoyo.py:1123-1432 for foursquaregraph / gowalla_*: returns (poi_logits, cat_logits)."""
     x = batch.x
     G, N = x.size()[:2]
     C = hidden + time_dim + cat_dim
     bias = assemble_bias(sd, batch, H, D, "fq")
     indx = (x != 0).sum(dim=-2)                                                       # :1225-1228
-    poidist = gcn(sd, "poi_distance_model", consts.X, consts.D_A, 0.3, training)      # :1236
-    catemb = gcn(sd, "poi_cat_model", consts.C_X, consts.C_A, 0.1, training)          # :1237
+    poidist = gcn(sd, "poi_distance_model", consts.X, consts.D_A, 0.3, training, drop)      # :1236
+    catemb = gcn(sd, "poi_cat_model", consts.C_X, consts.C_A, 0.1, training, drop)          # :1237
     user_emb = torch.squeeze(F.embedding(batch.user - 1, sd["user_embed_model.user_embedding.weight"]))  # :1239-1240
     node_features = torch.zeros(G, N, C)
     for pi in range(G):                                                               # :1257-1269
@@ -228,17 +237,17 @@ def graphormer_fq_forward(sd, batch, consts, n_layers, H, D, p=0.0, p_in=0.0, p_
     for i in range(G):                                                                # :348-351 'node_reverse'
         n = int(indx[i][0])
         nf[i][:n] = nf[i][:n] + pe[1:n + 1]
-    nf = F.dropout(nf, 0.1, training)                                                 # LearnablePositionalEncoding dropout :358
+    nf = _dropout(nf, 0.1, training, drop, "pos_nodes")                               # LearnablePositionalEncoding dropout :358
     tok = sd["graph_token.weight"].unsqueeze(0).repeat(G, 1, 1) + pe[0]               # :1338-1342 'pos0'
-    tok = F.dropout(tok, 0.1, training)
-    out = F.dropout(torch.cat([tok, nf], dim=1), p_in, training)
+    tok = _dropout(tok, 0.1, training, drop, "pos_token")
+    out = _dropout(torch.cat([tok, nf], dim=1), p_in, training, drop, "input")
     for l in range(n_layers):                                                         # :1347-1352
-        out = encoder_layer_fq(sd, f"layers.{l}", out, bias, H, p, p_att, training)
+        out = encoder_layer_fq(sd, f"layers.{l}", out, bias, H, p, p_att, training, drop)
     rows = []
     for pi in range(G):                                                               # :1353-1358 (q over N, not N+1)
         rows.append(torch.stack([fuse(sd, "embed_fuse_model3", out[pi][q], user_emb[pi]) for q in range(N)]))
     tmp = torch.stack(rows)
-    o = F.dropout(F.elu(layer_norm(sd, "final_ln", tmp)), p_in, training)             # :1360-1364
+    o = _dropout(F.elu(layer_norm(sd, "final_ln", tmp)), p_in, training, drop, "output")   # :1360-1364
     return linear(sd, "out_proj", o[:, 0, :]), linear(sd, "cat_decoder", o[:, 0, :])  # :1394-1396
 
 

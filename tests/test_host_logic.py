@@ -32,6 +32,45 @@ def test_library_exports_every_declared_symbol():
     assert all(handle.mobgt_dropout_keep_host(42, 8, 33, 1, 2, 3, j, 0.0) for j in range(50))
 
 
+def test_bulk_dropout_mask_replay_matches_the_per_element_rule_and_the_oracle_hook():
+    """mobgt_attn_dropout_mask_host == mobgt_dropout_keep_host elementwise; mobgt_dropout_mask_host: rows are numbered
+    from row0 (a slice of a mask equals the mask of the slice), p = 0 keeps everything; the oracle's `drop` hook receives
+    every site of a training-mode layer and is inert in eval mode."""
+    from mobgt_amd import ops
+    from oracle import model_oracle as mo
+    handle = _lib.lib()
+    G, H, T = 2, 3, 37
+    m = ops.dropout_keep_mask(0xABCDEF0123456789, G, H, T, 0.1)
+    ref = np.array([[[[handle.mobgt_dropout_keep_host(0xABCDEF0123456789, H, T, g, h, i, j, 0.1) for j in range(T)]
+                      for i in range(T)] for h in range(H)] for g in range(G)], dtype=bool)
+    assert np.array_equal(m, ref) and 0.05 < 1 - m.mean() < 0.15
+    full = ops.dropout_site_mask(77, 0x1003, 40, 192, 0.1)
+    assert np.array_equal(full[13:29], ops.dropout_site_mask(77, 0x1003, 16, 192, 0.1, row0=13))
+    assert 0.07 < 1 - full.mean() < 0.13 and ops.dropout_site_mask(77, 0x1003, 5, 8, 0.0).all()
+    assert not np.array_equal(full, ops.dropout_site_mask(78, 0x1003, 40, 192, 0.1))          # next step: new mask
+    assert not np.array_equal(full, ops.dropout_site_mask(77, 0x1004, 40, 192, 0.1))          # other site: other mask
+    torch.manual_seed(0)
+    C, Hh = 16, 2
+    sd = {}
+    for name, shape in (("self_attention.linear_q", (C, C)), ("self_attention.linear_k", (C, C)), ("self_attention.linear_v", (C, C)),
+                        ("self_attention.output_layer", (C, C)), ("ffn.layer1", (32, C)), ("ffn.layer2", (C, 32))):
+        sd[f"L.{name}.weight"], sd[f"L.{name}.bias"] = torch.randn(*shape) * 0.2, torch.zeros(shape[0])
+    for n in ("ffn_norm1", "ffn_norm2"):
+        sd[f"L.{n}.weight"], sd[f"L.{n}.bias"] = torch.ones(C), torch.zeros(C)
+    x = torch.randn(2, 5, C)
+    seen = []
+
+    def drop(t, p, site):
+        seen.append((site, tuple(t.shape), p))
+        return t
+    y_eval = mo.encoder_layer_fq(sd, "L", x, None, Hh, 0.1, 0.2, False, drop=drop)
+    assert not seen
+    y_train = mo.encoder_layer_fq(sd, "L", x, None, Hh, 0.1, 0.2, True, drop=drop)
+    assert [s[0] for s in seen] == [("L.self_attention", "att"), ("L", "res1"), ("L", "res2")]
+    assert seen[0][1] == (2, Hh, 5, 5) and seen[0][2] == 0.2 and seen[1][1] == (2, 5, C)
+    assert torch.equal(y_eval, y_train)                # an all-keep hook is the eval-mode layer
+
+
 def test_ops_refuse_cpu_tensors():
     from mobgt_amd import ops
     with pytest.raises(RuntimeError, match="no CPU fallback"):
