@@ -41,6 +41,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true", help="skip the eval-step comparison with the oracle")
     ap.add_argument("--no-stress", action="store_true", help="skip the c5-shape attention roofline measurements")
+    ap.add_argument("--no-loop", action="store_true", help="skip the fresh-batch-every-step measurement (value_with_collate)")
+    ap.add_argument("--loop-steps", type=int, default=300, help="timed steps of the fresh-batch loop")
     ap.add_argument("--no-live-pmc", action="store_true",
                     help="do not start rocprofv3 child passes for roofline.traffic / mfma_busy_pct (fall back to profiles/attn_pmc.json)")
     ap.add_argument("--no-gemm-autotune", action="store_true", help="leave hipBLASLt's default algorithm choice (no TunableOp)")
@@ -242,6 +244,38 @@ def live_pmc(shapes, p_drop, keep_dir=None, timeout=300):
                 valu_busy_pct=round(100.0 * m.get("SQ_ACTIVE_INST_VALU", 0.0) * 4 / (1024.0 * cyc), 2),
                 wait_any_frac=round(m.get("SQ_WAIT_ANY", 0.0) / max(m.get("SQ_WAVE_CYCLES", 1.0), 1.0), 3))
     return res or None
+
+
+# --------------------------------------------------------------------------------- fresh batch every step
+def time_epoch_loop(model, coll, name, uni, args):
+    """check-ins/s of train.EpochLoop over a pool of raw trajectories: epoch 0 warms up (captures one step graph per shape
+    bucket that occurs), then whole epochs are timed until --loop-steps steps have run.  Every timed step packs 16 raw
+    trajectories on the host, copies them to the device and replays [collate + forward + loss + backward + AdamW]."""
+    from mobgt_amd import workloads
+    from mobgt_amd.train import EpochLoop
+    n_pool = 8 if name == "big" else 64
+    pool = workloads.make_pool(name, n_pool, args.batch_size, uni, seed0=5000)
+    dataset = [t for trajs in pool for t in trajs]
+    loop = EpochLoop(model, coll, dataset, batch_size=args.batch_size, seed=args.seed, use_graph=True)
+    loop.run_epoch(0)
+    loop.run_epoch(1)                                  # (a second lap: buckets the first shuffle did not produce)
+    torch.cuda.synchronize()
+    graphs_before = len(loop.slots)
+    steps, ep = 0, 2
+    t0 = time.perf_counter()
+    while steps < args.loop_steps:
+        steps += loop.run_epoch(ep)["steps"]
+        ep += 1
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    loss = float(loop.ts.loss_out.item())
+    if loss != loss:
+        raise RuntimeError("loop diverged")
+    return dict(value=args.batch_size * steps / el, unit="check-ins/s", ms_per_step=el / steps * 1e3, steps=steps,
+                dataset_trajectories=len(dataset), shape_buckets=sorted(k[1] for k in loop.slots),
+                graphs_captured_inside_timed_region=len(loop.slots) - graphs_before, final_loss=loss,
+                what="fresh batch every step: host pack of raw trajectories + H2D + device collate (SPD / edge paths / "
+                     "degrees / distance bins) + forward + loss + backward + AdamW, hipGraph per shape bucket")
 
 
 # ------------------------------------------------------------------------------------------ CPU baseline
@@ -603,6 +637,16 @@ def main():
                           traffic=(trq + trk) if (trq is not None and trk is not None) else None,
                           mfma_busy_pct={"dq": mbq, "dkv": mbk}, counters_source=srcq,
                           avg_launch_us=t5b * 1e6, bytes_per_launch=b5b, input_sets_rotated=nset5)
+        # ---- the same step fed like the reference feeds it: a NEW batch every step (data.py:282-295), collated inside the
+        # replayed step (train.EpochLoop: raw trajectories -> pinned staging -> one H2D copy -> [DeviceCollator.finish +
+        # forward + loss + backward + AdamW] as one graph per shape bucket).  Secondary metric of SURVEY 8(d): check-ins/s
+        # INCLUDING collate / preprocess; its CPU counterpart is cpu_baseline.with_collate.
+        with_collate = None
+        if world == 1 and not args.no_loop and not args.no_graph:
+            try:
+                with_collate = time_epoch_loop(model, coll, name, uni, args)
+            except Exception as e:                       # never lose the headline line over the secondary figure
+                with_collate = dict(error=repr(e))
         parity = None
         if not args.no_parity and uni.distance is not None:
             parity = oracle_parity(model, batches, uni, n_layers)
@@ -624,6 +668,7 @@ def main():
                                      "gcn_adjacency_product": args.dtype, "library_gemms": args.gemm_dtype if bf16 else "f32",
                                      "accumulate_softmax_layernorm_adamw": "f32"}},
             "final_loss": loss, "ms_per_step_chunks": [round(c, 4) for c in chunk_ms], "long_run": long_run,
+            "value_with_collate": with_collate,
             "rccl_ranks": rccl_ranks, "allreduce_exposed_us": exposed_us,
             "parity": parity, "roofline": roof, "roofline_chain": roofc, "roofline_stress": roof5, "roofline_stress_bwd": roof5b,
             "cpu_baseline": cpu,

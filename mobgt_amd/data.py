@@ -91,17 +91,27 @@ class DeviceCollator:
             self.coords = torch.as_tensor(np.radians(np.asarray(coords, dtype=np.float64))).to(self.device)
             self.bin_edges = torch.as_tensor(np.asarray(bin_edges, dtype=np.float64)).to(self.device)
 
-    def pack_host(self, trajs, idx0=0):
-        """Raw dicts -> padded numpy arrays (pinned-memory friendly); no graph algorithm runs on the host."""
+    def pack_host(self, trajs, idx0=0, n_pad=None, out=None):
+        """Raw dicts -> padded numpy arrays (pinned-memory friendly); no graph algorithm runs on the host.
+        `n_pad`: pad to this many nodes instead of the batch maximum (bucketed shapes: the extra positions are padding
+        exactly like the collator's own, collator.py:11-101); `out`: pre-allocated arrays to fill (RawLayout.views)."""
         trajs = [t for t in trajs if t is not None and len(t["node_name"]) <= self.max_node]
         G = len(trajs)
         n = np.array([len(t["node_name"]) for t in trajs], dtype=np.int32)
-        N = int(n.max())
-        counts = np.zeros((G, N, N), dtype=np.int32)
-        x = np.zeros((G, N, 1), dtype=np.int32)
-        time = np.zeros((G, N, 1), dtype=np.int32)
-        cat = np.zeros((G, N, 1), dtype=np.int32)
-        time_normal = np.zeros((G, N, 1), dtype=np.float32)
+        N = int(n.max()) if n_pad is None else int(n_pad)
+        if N < int(n.max()):
+            raise ValueError(f"n_pad {N} is smaller than the longest trajectory ({int(n.max())})")
+        if out is not None:
+            for k in ("counts", "x", "time", "cat", "time_normal"):
+                out[k][...] = 0
+            counts, x, time, cat, time_normal = out["counts"], out["x"], out["time"], out["cat"], out["time_normal"]
+            assert counts.shape == (G, N, N), (counts.shape, G, N)
+        else:
+            counts = np.zeros((G, N, N), dtype=np.int32)
+            x = np.zeros((G, N, 1), dtype=np.int32)
+            time = np.zeros((G, N, 1), dtype=np.int32)
+            cat = np.zeros((G, N, 1), dtype=np.int32)
+            time_normal = np.zeros((G, N, 1), dtype=np.float32)
         for g, t in enumerate(trajs):
             k = n[g]
             counts[g, :k, :k] = t["edge_type"]
@@ -111,11 +121,14 @@ class DeviceCollator:
             time_normal[g, :k, 0] = t["time_normal"]
         user = np.array([[int(t["user"][0]) + 1] for t in trajs], dtype=np.int32)       # wrapper.py:39
         y = np.array([int(t["target"][0]) for t in trajs], dtype=np.int64)              # collator.py:367
-        idx = np.arange(idx0, idx0 + G, dtype=np.int64)
+        idx = np.arange(idx0, idx0 + G, dtype=np.int64) if np.isscalar(idx0) else np.asarray(idx0, dtype=np.int64)
+        if out is not None:
+            out["n_nodes"][...], out["user"][...], out["y"][...], out["idx"][...] = n, user, y, idx
+            return out
         return dict(counts=counts, n_nodes=n, x=x, time=time, cat=cat, time_normal=time_normal, user=user, y=y, idx=idx)
 
-    def __call__(self, trajs, idx0=0):
-        h = self.pack_host(trajs, idx0)
+    def __call__(self, trajs, idx0=0, n_pad=None):
+        h = self.pack_host(trajs, idx0, n_pad=n_pad)
         d = {k: torch.from_numpy(v).to(self.device, non_blocking=True) for k, v in h.items()}
         return self.finish(d)
 
@@ -152,6 +165,51 @@ class DeviceCollator:
                             in_degree=sp["in_degree"], out_degree=sp["out_degree"], x=x, edge_input=sp["edge_input"],
                             y=d["y"], time=d["time"], time_normal=d["time_normal"], user=d["user"], cat=d["cat"],
                             poi_pos=poi_pos)
+
+
+# ---- bucketed shapes for a loop over FRESH batches (train.TrainStep.run_epoch) ------------------------------------------------
+# A hipGraph has static shapes, and the reference feeds a new batch every step (data.py:282-295): the padded node count of
+# a batch is therefore rounded UP to one of a few sizes and one step graph is kept per (G, size).  Rounding up only adds
+# padding positions, which the collator already produces for every graph shorter than the batch maximum (-inf key columns,
+# zero indices): logits, loss and gradients do not change (tests/test_gpu_loop.py).
+BUCKETS = (8, 16, 24, 32, 48, 64, 96, 128, 192, 256, 384, 512, 768, 1024)
+
+
+def bucket_nodes(n, buckets=BUCKETS):
+    """Smallest bucket >= n (beyond the largest: the next multiple of 256)."""
+    for b in buckets:
+        if n <= b:
+            return b
+    return (n + 255) // 256 * 256
+
+
+class RawLayout:
+    """The raw (un-collated) arrays of one (G, N) bucket packed into ONE byte buffer, so that a step's input is one
+    host-to-device copy: 8-byte fields first, every field 16-byte aligned."""
+    FIELDS = (("y", np.int64, lambda G, N: (G,)), ("idx", np.int64, lambda G, N: (G,)),
+              ("counts", np.int32, lambda G, N: (G, N, N)), ("x", np.int32, lambda G, N: (G, N, 1)),
+              ("time", np.int32, lambda G, N: (G, N, 1)), ("cat", np.int32, lambda G, N: (G, N, 1)),
+              ("time_normal", np.float32, lambda G, N: (G, N, 1)), ("n_nodes", np.int32, lambda G, N: (G,)),
+              ("user", np.int32, lambda G, N: (G, 1)))
+
+    def __init__(self, G, N):
+        self.G, self.N = int(G), int(N)
+        self.offsets, off = {}, 0
+        for name, dt, shape in self.FIELDS:
+            shp = shape(self.G, self.N)
+            nbytes = int(np.prod(shp)) * np.dtype(dt).itemsize
+            self.offsets[name] = (off, nbytes, dt, shp)
+            off = (off + nbytes + 15) // 16 * 16
+        self.nbytes = off
+
+    def views_np(self, buf):
+        """numpy views of a host uint8 array (e.g. `pinned_tensor.numpy()`)"""
+        return {k: buf[o:o + n].view(dt).reshape(shp) for k, (o, n, dt, shp) in self.offsets.items()}
+
+    def views_torch(self, buf):
+        """typed torch views of a (device) uint8 tensor"""
+        tdt = {np.int64: torch.int64, np.int32: torch.int32, np.float32: torch.float32}
+        return {k: buf[o:o + n].view(tdt[dt]).view(*shp) for k, (o, n, dt, shp) in self.offsets.items()}
 
 
 def shard_indices(n_samples, rank, world_size, epoch=0, seed=0, shuffle=True):

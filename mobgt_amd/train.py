@@ -182,10 +182,32 @@ def broadcast_parameters(model, src=0):
         sync_external_shadows(model)
 
 
+def assert_same_across_ranks(digest, what, device=None):
+    """All-gather `digest` (bytes, same length everywhere) over the default process group; every rank raises RuntimeError
+    naming the ranks that differ from rank 0.  No-op without a process group or with one rank."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() <= 1:
+        return
+    world = dist.get_world_size()
+    mine = torch.frombuffer(bytearray(digest), dtype=torch.uint8).clone()
+    if dist.get_backend() == "nccl":
+        mine = mine.to(device if device is not None else torch.device("cuda", torch.cuda.current_device()))
+    got = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(got, mine)
+    got = [t.cpu() for t in got]
+    bad = [r for r, t in enumerate(got) if not torch.equal(t, got[0])]
+    if bad:
+        raise RuntimeError(f"mobgt: {what} differs between rank 0 and ranks {bad} -- refusing to all-reduce")
+
+
 class TrainStep:
-    def __init__(self, model, batches, autocast_dtype=None, use_graph=True, seed=1, overlap=True):
+    def __init__(self, model, batches, autocast_dtype=None, use_graph=True, seed=1, overlap=True, batch_fn=None):
+        """`batches`: pre-collated batches resident on the device (their tensors are the static inputs of the captured
+        graphs).  `batch_fn`: optional callable applied to a batch INSIDE the step (and so inside its graph) before the model
+        sees it -- `EpochLoop` passes raw, un-collated arrays + `DeviceCollator.finish`, so that collating a fresh batch is
+        part of the replayed step.  More batches can be added after `prepare()` with `add_batch`."""
         self.model = model
-        self.batches = batches
+        self.batches = list(batches)
+        self.batch_fn = batch_fn
         self.autocast_dtype = autocast_dtype
         dev = next(model.parameters()).device
         self.device = dev
@@ -261,6 +283,25 @@ class TrainStep:
                             and hasattr(model, "_enc_out"))
         self.graphs_b, self._g_enc, self._loss_slots = {}, {}, {}
         self.comm = True        # False: skip the gradient exchange (bench.py measures the exposed all-reduce time that way)
+        self._prepared = False
+        self.check_layout_across_ranks()
+
+    def layout_digest(self):
+        """Hash of what every rank must agree on before one flat buffer can be all-reduced: which parameters are trained,
+        in which order, at which offsets (`used_parameters` is computed per rank from that rank's own batches)."""
+        import hashlib
+        names = {id(p): n for n, p in self.model.named_parameters()}
+        h = hashlib.sha256()
+        for p, off in zip(self.flat.params, self.flat.offsets):
+            h.update(("%s:%d:%d;" % (names.get(id(p), "?"), off, p.numel())).encode())
+        h.update(("n=%d;head=%d" % (self.flat.flat.numel(), self.n_head_elems)).encode())
+        return h.digest()[:8]
+
+    def check_layout_across_ranks(self):
+        """All-gather the layout digest and abort on a mismatch (a rank whose dry-run batches never reach some parameter
+        would otherwise all-reduce a differently laid out buffer: silent garbage)."""
+        assert_same_across_ranks(self.layout_digest(), "flat parameter / gradient layout (different sets of trained parameters?)",
+                                 self.device)
 
     def _attach_shadows(self):
         """bf16 copy of the whole flat parameter buffer; the fused layers' shadow weights become views of it, kept
@@ -331,6 +372,8 @@ class TrainStep:
             self.lr_dev.fill_(self.lr)
 
     def _loss(self, batch):
+        if self.batch_fn is not None:
+            batch = self.batch_fn(batch)
         if self.autocast_dtype is not None:
             with torch.autocast(device_type="cuda", dtype=self.autocast_dtype):
                 return self.model.training_step(batch, 0)
@@ -390,7 +433,11 @@ class TrainStep:
     def _capture(self, i):
         batch = self.batches[i]
         with self._on_stream():                    # warm-up on the side stream (allocator, lazy inits)
+            # ... which must not count as a training step: the step counter (dropout stream, AdamW's t) is put back, so that
+            # a replayed sequence draws the masks an eager sequence draws, however many graphs were captured on the way
+            saved = self.seed_dev.clone()
             self._fwd_bwd(batch)
+            self.seed_dev.copy_(saved)
         self._join()
         g = torch.cuda.CUDAGraph()
         # private memory pool per graph: the graphs are replayed in data order, not capture order, and a shared
@@ -442,11 +489,26 @@ class TrainStep:
                           and os.environ.get("MOBGT_FUSED_OPT_GRAPH", "1") != "0")
         if self.fused_opt:
             for i in range(len(self.batches)):
-                g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, stream=self.stream):
-                    self._fwd_bwd(self.batches[i], slot=i)
-                    self._opt_step()
-                self.graphs[i] = g
+                self._capture_with_opt(i)
+        self._prepared = True
+
+    def _capture_with_opt(self, i):
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=self.stream):
+            self._fwd_bwd(self.batches[i], slot=i)
+            self._opt_step()
+        self.graphs[i] = g
+
+    def add_batch(self, batch):
+        """Register one more static batch (a new shape bucket of EpochLoop) and, in graph mode after `prepare()`, capture
+        its step graph now (the capture's eager warm-up pass leaves the step counter and the parameters untouched)."""
+        self.batches.append(batch)
+        i = len(self.batches) - 1
+        if self.use_graph and self._prepared:
+            self.graphs[i] = self._capture(i)
+            if self.fused_opt:
+                self._capture_with_opt(i)
+        return i
 
     def step(self, i):
         """One optimizer step on pre-collated batch i (model_fqandtoyo.py:1434-1478 + optimizer + scheduler)."""
@@ -480,3 +542,143 @@ class TrainStep:
         self.sched_state["step_count"] += 1
         self._set_lr()
         return self.loss_out
+
+
+class EpochLoop:
+    """The fit loop over the training set (Lightning's `trainer.fit` on `train_dataloader`: entry.py:141-161,
+    data.py:282-295), one process per GPU: a NEW batch every step, collated on the device inside the replayed step.
+
+    * sampler: `data.shard_indices` = torch's DistributedSampler (shuffle by seed + epoch, wrap-around padding, stride by
+      rank); consecutive runs of `batch_size` indices form the batches (`drop_last=False`, as the reference's DataLoader);
+    * shapes: a batch's padded node count is rounded up to a bucket (`data.BUCKETS`); every (G, bucket) owns ONE packed
+      static input buffer on the device and ONE step graph = `DeviceCollator.finish` (SPD / edge paths / degrees / distance
+      bins) + forward + loss + backward + AdamW, captured the first time the bucket occurs;
+    * a step on the host: pack the NEXT batch's raw trajectories into a pinned staging buffer and start its host-to-device
+      copy on a side stream (while the GPU runs the current step), then -- on the compute stream -- one device-to-device
+      copy of the staged bytes into the bucket's static buffer and one graph replay.
+    """
+
+    def __init__(self, model, collator, dataset, batch_size=16, seed=1, use_graph=True, overlap=True, buckets=None, rank=None,
+                 world=None, shuffle=True, autocast_dtype=None):
+        from .data import BUCKETS
+        self.model, self.collator, self.dataset = model, collator, dataset
+        self.batch_size, self.seed, self.shuffle = int(batch_size), int(seed), shuffle
+        self.buckets = tuple(buckets or BUCKETS)
+        ddp = dist.is_available() and dist.is_initialized()
+        self.rank = rank if rank is not None else (dist.get_rank() if ddp else 0)
+        self.world = world if world is not None else (dist.get_world_size() if ddp else 1)
+        self.device = next(model.parameters()).device
+        self.copy_stream = torch.cuda.Stream(device=self.device)
+        self.slots = {}
+        self.ts = None
+        self._ts_args = dict(autocast_dtype=autocast_dtype, use_graph=use_graph, seed=seed, overlap=overlap)
+        self.steps_done = 0
+        self.limits = None
+
+    # ---- data order -----------------------------------------------------------------------------------------------------
+    def batches_of_epoch(self, epoch):
+        from .data import shard_indices
+        idx = shard_indices(len(self.dataset), self.rank, self.world, epoch=epoch, seed=self.seed, shuffle=self.shuffle)
+        B = self.batch_size
+        return [idx[i:i + B] for i in range(0, len(idx), B)]
+
+    # ---- buckets --------------------------------------------------------------------------------------------------------
+    def _slot(self, G, N):
+        from .data import RawLayout
+        key = (G, N)
+        s = self.slots.get(key)
+        if s is None:
+            lay = RawLayout(G, N)
+            buf = torch.zeros(lay.nbytes, dtype=torch.uint8, device=self.device)
+            s = dict(layout=lay, buf=buf, views=lay.views_torch(buf), index=None, stages=[], turn=0)
+            for _ in range(2):
+                pin = torch.zeros(lay.nbytes, dtype=torch.uint8).pin_memory()
+                s["stages"].append(dict(pin=pin, np=lay.views_np(pin.numpy()), dev=torch.empty_like(buf), ready=torch.cuda.Event(),
+                                        free=None))
+            self.slots[key] = s
+        return s
+
+    def _check_host(self, h):
+        """What nn.Embedding would raise on in the reference (IndexError), checked on the host arrays of a fresh batch --
+        the captured step cannot look at values (model.validate_batch does this for pre-collated batches)."""
+        m = self.model
+        if self.limits is None:
+            self.limits = dict(x=m.X.shape[0], user=m.num_users, y=m.out_proj.out_features, edge=m.edge_encoder.num_embeddings,
+                               deg=m.in_degree_encoder.num_embeddings, slots=m.time_embed_model_48.num_embeddings)
+        L = self.limits
+        nz = h["counts"] != 0
+        bad = None
+        if int(h["x"].max()) > L["x"]:
+            bad = ("x", int(h["x"].max()), L["x"] + 1)
+        elif int(h["user"].max()) > L["user"]:
+            bad = ("user", int(h["user"].max()), L["user"] + 1)
+        elif int(h["y"].max()) > L["y"]:
+            bad = ("y", int(h["y"].max()), L["y"] + 1)
+        elif int(h["counts"].max()) + 3 >= L["edge"]:
+            bad = ("edge_input", int(h["counts"].max()) + 3, L["edge"])
+        elif max(int(nz.sum(1).max()), int(nz.sum(2).max())) + 1 >= L["deg"]:
+            bad = ("degree", max(int(nz.sum(1).max()), int(nz.sum(2).max())) + 1, L["deg"])
+        elif int(float(h["time_normal"].max()) * 48) >= L["slots"]:
+            bad = ("time_normal", float(h["time_normal"].max()), L["slots"])
+        if bad:
+            raise IndexError(f"batch.{bad[0]} has index {bad[1]}, out of range for a table of {bad[2]} rows")
+
+    def _stage(self, ids):
+        """Host half of a step's input: raw trajectories -> the bucket's pinned buffer -> async copy to a device staging
+        buffer on the copy stream.  Returns (slot, stage)."""
+        from .data import bucket_nodes
+        trajs = [self.dataset[i] for i in ids]
+        trajs = [t for t in trajs if t is not None and len(t["node_name"]) <= self.collator.max_node]
+        G = len(trajs)
+        N = bucket_nodes(max(len(t["node_name"]) for t in trajs), self.buckets)
+        slot = self._slot(G, N)
+        st = slot["stages"][slot["turn"]]
+        slot["turn"] ^= 1
+        if st["free"] is not None:
+            st["free"].synchronize()                   # its previous device-to-device copy has been executed
+        self.collator.pack_host(trajs, idx0=ids[:G] if len(ids) == G else 0, n_pad=N, out=st["np"])
+        self._check_host(st["np"])
+        with torch.cuda.stream(self.copy_stream):
+            st["dev"].copy_(st["pin"], non_blocking=True)
+            st["ready"].record(self.copy_stream)
+        return slot, st
+
+    def _ensure_trainer(self, slot):
+        """The first batch builds the TrainStep (dry run for the trained-parameter set, flat buffers, optimizer graph)."""
+        if self.ts is None:
+            self.ts = TrainStep(self.model, [slot["views"]], batch_fn=self.collator.finish, **self._ts_args)
+            self.ts.prepare()
+            slot["index"] = 0
+        elif slot["index"] is None:
+            slot["index"] = self.ts.add_batch(slot["views"])
+
+    def _launch(self, slot, st):
+        cur = torch.cuda.current_stream()                # (graphs replay on the current stream)
+        cur.wait_event(st["ready"])
+        slot["buf"].copy_(st["dev"], non_blocking=True)
+        if st["free"] is None:
+            st["free"] = torch.cuda.Event()
+        st["free"].record(cur)
+        if slot["index"] is None or self.ts is None:
+            self._ensure_trainer(slot)                   # (dry run / capture on the data that is now in the static buffer)
+        return self.ts.step(slot["index"])
+
+    def run_epoch(self, epoch=0, max_steps=None, on_step=None):
+        """One pass over this rank's shard.  Returns dict(steps, graphs, sample_ids); `on_step(step, loss_tensor)` is called
+        after each launch (reading the loss there synchronises -- do it sparingly)."""
+        batches = self.batches_of_epoch(epoch)
+        if max_steps is not None:
+            batches = batches[:max_steps]
+        seen = []
+        if not batches:
+            return dict(steps=0, graphs=len(self.slots), sample_ids=seen)
+        nxt = self._stage(batches[0])
+        for j, ids in enumerate(batches):
+            slot, st = nxt
+            loss = self._launch(slot, st)                # asynchronous: the GPU works on step j ...
+            nxt = self._stage(batches[j + 1]) if j + 1 < len(batches) else None          # ... while the host packs j + 1
+            seen.extend(ids)
+            self.steps_done += 1
+            if on_step is not None:
+                on_step(self.steps_done, loss)
+        return dict(steps=len(batches), graphs=len(self.slots), sample_ids=seen)

@@ -86,3 +86,30 @@ def test_shard_indices_follow_distributed_sampler():
             assert list(iter(s)) == shard_indices(37, rank, 4, epoch=epoch, seed=5)
     parts = [shard_indices(37, r, 4, shuffle=False) for r in range(4)]
     assert sorted(sum(parts, []))[:37] != [] and len({len(p) for p in parts}) == 1
+
+
+def _digest_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from mobgt_amd.train import assert_same_across_ranks
+    assert_same_across_ranks(b"same-lay", "layout")                       # equal digests: passes on every rank
+    try:
+        assert_same_across_ranks(b"layout-%d" % (rank > 0), "flat parameter / gradient layout")
+        res = "no error"
+    except RuntimeError as e:
+        res = str(e)
+    torch.save(res, out + str(rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_layout_digest_mismatch_aborts_on_every_rank(tmp_path):
+    """train.TrainStep all-gathers a hash of its flat layout at construction (VERDICT r2 #5b): ranks whose sets of trained
+    parameters differ must not all-reduce one another's buffers."""
+    out = str(tmp_path / "r")
+    mp.spawn(_digest_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    for r in range(2):
+        msg = torch.load(out + str(r))
+        assert "differs between rank 0 and ranks [1]" in msg and "refusing to all-reduce" in msg, msg
+

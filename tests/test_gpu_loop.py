@@ -1,0 +1,124 @@
+"""The training loop over FRESH batches (`train.EpochLoop`; reference: Lightning's fit loop over
+`DataLoader(shuffle=True, collate_fn=partial(collator_foursquare / collator_gowalla, ...))`, data.py:282-295,
+entry.py:141-161): shape buckets, step graphs that contain the device collate, the sampler.
+
+  * a batch padded up to its bucket gives the logits / loss / gradients of the unpadded batch (the extra positions are
+    collator padding: -inf key columns, zero indices -- collator.py:11-101): logits to 2e-5, loss to 1e-6 relative;
+  * the packed raw layout round-trips and `pack_host(n_pad=, out=)` equals the plain pack + padding;
+  * graph mode == eager mode step by step (same dropout counters, same kernels): identical loss sequence over the first
+    steps of an epoch, including steps that capture a new bucket's graph lazily (the capture's warm-up pass must not
+    advance the dropout / AdamW step counter);
+  * one epoch over the 4 970-trajectory S-GOW training pool visits exactly the DistributedSampler's sample set of its
+    rank (world 1, and rank 1 of 2), with one graph per (G, bucket) that occurred.
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from mobgt_amd import workloads                                           # noqa: E402
+from mobgt_amd.data import BUCKETS, RawLayout, bucket_nodes, shard_indices  # noqa: E402
+from mobgt_amd.train import EpochLoop                                      # noqa: E402
+
+DEV = "cuda"
+
+
+def test_bucket_rounding_and_raw_layout_roundtrip():
+    assert [bucket_nodes(n) for n in (1, 8, 9, 24, 25, 129, 814, 1024, 1025)] == [8, 8, 16, 24, 32, 192, 1024, 1024, 1280]
+    lay = RawLayout(16, 24)
+    assert all(o % 16 == 0 for o, _, _, _ in lay.offsets.values()) and lay.nbytes % 16 == 0
+    buf = np.zeros(lay.nbytes, dtype=np.uint8)
+    v = lay.views_np(buf)
+    rng = np.random.RandomState(0)
+    for k, a in v.items():
+        a[...] = rng.randint(0, 100, size=a.shape).astype(a.dtype)
+    t = lay.views_torch(torch.from_numpy(buf.copy()))
+    for k, a in v.items():
+        assert np.array_equal(t[k].numpy(), a), k
+
+
+@pytest.fixture(scope="module")
+def fsq_small():
+    uni, model, coll = workloads.build("fsq", DEV, seed=1, P=1500, model_overrides=dict(n_layers=2))
+    return uni, model, coll
+
+
+def test_bucket_padded_batch_equals_the_unpadded_batch(fsq_small):
+    uni, model, coll = fsq_small
+    from mobgt_amd import synth
+    trajs = synth.make_batch_of_trajectories(seed=21, G=6, P=1500, n_user=1080, cat_of_poi=uni.cat_of_poi, n_nodes=[17, 3, 9, 2, 11, 5])
+    a = coll(trajs)
+    b = coll(trajs, n_pad=bucket_nodes(17))
+    assert a.x.shape[1] == 17 and b.x.shape[1] == 24
+    # the padded collate is the unpadded one + padding
+    for f in ("x", "in_degree", "out_degree", "time_normal"):
+        assert torch.equal(getattr(b, f)[:, :17], getattr(a, f)), f
+        assert int(getattr(b, f)[:, 17:].abs().sum()) == 0, f
+    for f in ("rel_pos", "poi_pos"):
+        assert torch.equal(getattr(b, f)[:, :17, :17], getattr(a, f)), f
+        assert int(getattr(b, f)[:, 17:].abs().sum()) == 0 and int(getattr(b, f)[:, :, 17:].abs().sum()) == 0, f
+    assert torch.equal(b.edge_input[:, :17, :17], a.edge_input) and int(b.edge_input[:, 17:].abs().sum()) == 0
+    assert bool(torch.isinf(b.attn_bias[:, :, 18:]).all()) and torch.equal(b.attn_bias[:, :18, :18], a.attn_bias)
+    model.eval()
+    outs = []
+    for batch in (a, b):
+        for p in model.parameters():
+            p.grad = None
+        logits = model(batch)[0]
+        loss = model.training_step(batch, 0)
+        loss.backward()
+        outs.append((logits.detach().float().cpu(), float(loss.detach()), {n: p.grad.detach().float().cpu().clone()
+                                                                         for n, p in model.named_parameters() if p.grad is not None}))
+    (la, lossa, ga), (lb, lossb, gb) = outs
+    np.testing.assert_allclose(lb.numpy(), la.numpy(), rtol=0, atol=2e-5)
+    np.testing.assert_allclose(lossb, lossa, rtol=1e-6)
+    assert ga.keys() == gb.keys()
+    for n in ga:
+        scale = float(ga[n].abs().max())
+        np.testing.assert_allclose(gb[n].numpy(), ga[n].numpy(), rtol=0, atol=2e-3 * scale + 1e-12, err_msg=n)
+
+
+def _dataset(name, uni, n_batches, seed0):
+    return [t for trajs in workloads.make_pool(name, n_batches, 16, uni, seed0=seed0) for t in trajs]
+
+
+def test_graph_loop_equals_eager_loop_step_by_step():
+    """Two models built identically; one loop replays graphs (captured lazily per bucket), the other runs eagerly."""
+    losses = []
+    for use_graph in (True, False):
+        uni, model, coll = workloads.build("fsq", DEV, seed=1, model_overrides=dict(n_layers=2, peak_lr=2e-3, warmup_updates=4,
+                                                                                  tot_updates=100))
+        data = _dataset("fsq", uni, 6, 7000)
+        loop = EpochLoop(model, coll, data, batch_size=16, seed=3, use_graph=use_graph)
+        seq = []
+        loop.run_epoch(0, max_steps=6, on_step=lambda k, l: seq.append(float(l.item())))
+        losses.append((seq, sorted(loop.slots)))
+    (a, ka), (b, kb) = losses
+    assert ka == kb and len(ka) >= 2, ka            # several buckets, i.e. lazily captured graphs, took part
+    np.testing.assert_allclose(a, b, rtol=3e-4)      # (f32 atomics order differs run to run; other masks would differ by 1e-2)
+    assert len(set(a)) == len(a)                      # (the steps really differ)
+
+
+@pytest.mark.parametrize("rank,world", [(0, 1), (1, 2)])
+def test_epoch_over_the_s_gow_pool_visits_the_distributed_samplers_set(rank, world):
+    uni, model, coll = workloads.build("gow", DEV, seed=1, model_overrides=dict(n_layers=2))
+    n_train = 4970                                    # gowalla_nevda training graphs
+    data = _dataset("gow", uni, (n_train + 15) // 16, 9000)[:n_train]
+    loop = EpochLoop(model, coll, data, batch_size=16, seed=11, use_graph=True, rank=rank, world=world)
+    res = loop.run_epoch(epoch=2)
+    want = shard_indices(n_train, rank, world, epoch=2, seed=11)
+    assert res["sample_ids"] == want and len(want) == -(-n_train // world)
+    assert res["steps"] == -(-len(want) // 16)
+    # one graph per (G, bucket) that occurred; buckets cover the workload's node counts up to its 814-node tail
+    keys = sorted(loop.slots)
+    assert all(k[1] in BUCKETS for k in keys) and len(keys) == res["graphs"]
+    lens = [len(data[i]["node_name"]) for i in want]
+    assert max(k[1] for k in keys) == bucket_nodes(max(lens))
+    assert len(loop.ts.graphs) == len(keys)
+    assert np.isfinite(float(loop.ts.loss_out.item()))
+    # same epoch seed + rank -> the torch sampler itself
+    from torch.utils.data.distributed import DistributedSampler
+    ds = DistributedSampler(range(n_train), num_replicas=world, rank=rank, shuffle=True, seed=11)
+    ds.set_epoch(2)
+    assert list(ds) == want
