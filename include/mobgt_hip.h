@@ -50,7 +50,8 @@ const char* mobgt_build_info(void);
  * q,k,v,out : [G, T, H*d] row-major with row strides ldq/ldk/ldv/ldo (elements); head h occupies
  *             columns [h*d, (h+1)*d).  dtype `io_dtype` (f32 or bf16); 16-byte aligned rows.
  * bias      : [G, H, T, ld_bias] `bias_dtype`, bias[g,h,i,j] added unscaled to the score of query i,
- *             key j; ld_bias % 32 == 0, ld_bias >= roundup(T,32); columns >= T are ignored.
+ *             key j; ld_bias % 64 == 0, ld_bias >= roundup(T,64) (rows are fetched as whole 64-key segments);
+ *             columns >= T are ignored by the forward / dQ pass and must hold -inf in bias_t (the pack kernels write them).
  *             -inf entries are honoured (probability exactly 0).
  * lse       : [G, H, T] f32 out, natural-log sum of exp of the biased scores (needed by bwd).
  * scale     : q is multiplied by it BEFORE the dot product (reference: att_size ** -0.5).

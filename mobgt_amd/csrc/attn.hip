@@ -166,6 +166,68 @@ __device__ __forceinline__ float xhalf_sum(float v) {        // v + partner's v
     return lo + hi;
 }
 
+// ---- bias tiles: coalesced from HBM, re-distributed through a wave-private LDS image ------------------------------------------
+// The MFMA C operand wants lane (n, hi) to hold 16 contiguous keys of query row n.  Loaded that way (rounds 1-2) a wave's
+// load instruction touched 32 different rows -- 64 separate 16-byte pieces in 32 different 128-byte lines: the texture
+// addresser walks such an instruction one lane per clock (a quarter of its rate for a coalesced one; the same effect was
+// measured on the chain kernel's weight loads), and every line was requested twice, by two tiles 32 keys apart,
+// with 64 KB of other waves' lines in between in a 32 KB L1.  At c5 that is ~50 k texture-addresser cycles per CU per launch
+// for the bias alone.  Now a wave fetches its 32 rows x 64 keys "super-tile" as WHOLE 128-byte row segments (bf16; 8 lanes
+// per row, 8 rows per instruction: 8 full lines per instruction, each line requested once), parks the registers in a
+// wave-private LDS image two chunks later and every lane reads its 16 keys per MFMA tile from there (row pitch +16 B: the
+// 16 rows of a ds_read_b128 lane group fall on different banks).  Rows are line-aligned because ld_bias % 64 == 0.
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+template <typename TB>
+struct BiasStage {
+    static constexpr int SEG = 64 * (int)sizeof(TB);         // bytes of a row segment (64 keys)
+    static constexpr int PITCH = SEG + 16;                   // LDS row pitch
+    static constexpr int NPIECE = SEG / 16;                  // 16-byte pieces per row segment (8 / 16)
+    static constexpr int RPI = 64 / NPIECE;                  // rows per load instruction (8 / 4)
+    static constexpr int NI = 32 / RPI;                      // load instructions per super-tile (4 / 8)
+    static constexpr int BYTES = 32 * PITCH;                 // LDS image of one wave
+    // (native vectors, not HIP's uint4 struct: copying that struct to LDS is a memcpy the optimiser would not split, and the
+    // whole ring then lived in scratch memory)
+    u32x4 r[NI];
+    uint32_t off[NI];          // this lane's byte offset inside the wave's 32-row block, per load instruction
+    // rows beyond row_max belong to nobody: their loads are clamped onto row_max
+    __device__ __forceinline__ void init(int64_t ld, int row_max, int lane) {
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+            off[j] = (uint32_t)min(RPI * j + lane / NPIECE, row_max) * (uint32_t)(ld * (int64_t)sizeof(TB)) + 16u * (uint32_t)(lane % NPIECE);
+    }
+    // `rows`: WAVE-UNIFORM pointer to element [row0][0] of this wave's 32 rows (an SGPR base: the loads then take the
+    // scalar-base + 32-bit-offset form and cost no address arithmetic); c = chunk of 64 columns
+    __device__ __forceinline__ void load(const TB* __restrict__ rows, int c) {
+        const unsigned char* base = reinterpret_cast<const unsigned char*>(rows + c * 64);
+#pragma unroll
+        for (int j = 0; j < NI; ++j) r[j] = *reinterpret_cast<const u32x4*>(base + off[j]);
+    }
+    __device__ __forceinline__ void park(unsigned char* img, int lane) const {
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+            *reinterpret_cast<u32x4*>(img + (RPI * j + lane / NPIECE) * PITCH + 16 * (lane % NPIECE)) = r[j];
+    }
+    // the 16 elements [32 t + 16 hi, +16) of row n -> accumulator registers
+    static __device__ __forceinline__ void to_acc(const unsigned char* img, int n, int hi, int t, f32x16& s) {
+        const unsigned char* src = img + n * PITCH + (32 * t + 16 * hi) * (int)sizeof(TB);
+        if constexpr (sizeof(TB) == 2) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const u32x4 w = reinterpret_cast<const u32x4*>(src)[i];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { s[8 * i + 2 * k] = bf16_lo(w[k]); s[8 * i + 2 * k + 1] = bf16_hi(w[k]); }
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                typedef float f32x4_t __attribute__((ext_vector_type(4)));
+                const f32x4_t w = reinterpret_cast<const f32x4_t*>(src)[i];
+                s[4 * i] = w[0]; s[4 * i + 1] = w[1]; s[4 * i + 2] = w[2]; s[4 * i + 3] = w[3];
+            }
+        }
+    }
+};
+
 // =================================================================================== forward
 template <int D, typename TQ, typename TB, int NW, bool DROP>
 __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const AttnParams p) {
@@ -188,7 +250,11 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const AttnParams p) {
     const TQ* Q = reinterpret_cast<const TQ*>(p.q) + (int64_t)g * T * p.ldq + h * D;
     const TQ* K = reinterpret_cast<const TQ*>(p.k) + (int64_t)g * T * p.ldk + h * D;
     const TQ* V = reinterpret_cast<const TQ*>(p.v) + (int64_t)g * T * p.ldv + h * D;
-    const TB* brow = reinterpret_cast<const TB*>(p.bias) + ((int64_t)gh * T + qc) * p.ld_bias + 16 * hi;
+    __shared__ __attribute__((aligned(16))) unsigned char Bs[NW][BiasStage<TB>::BYTES];
+    const int q0w = qt * 32 * NW + __builtin_amdgcn_readfirstlane(wave) * 32;  // this wave's first query row (an SGPR)
+    const TB* brows = reinterpret_cast<const TB*>(p.bias) + ((int64_t)gh * T + min(q0w, T - 1)) * p.ld_bias;
+    const int brow_max = max(T - 1 - q0w, 0);
+    unsigned char* bimg = Bs[wave];
 
     bf16x8 qf[KS];
 #pragma unroll
@@ -207,25 +273,32 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const AttnParams p) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) o[i] = 0.f;
 
-    // Bias prefetch ring: tile j's 16 elements per lane are requested PF = 4 tiles (128 keys) before they are
-    // used -- each wave keeps four 2 KB bias loads in flight.  One tile ahead left ~2 KB x 20 waves per CU in
+    // Bias prefetch ring: a chunk's 32 x 64 super-tile (4 KB per wave, bf16) is requested two chunks (128 keys) before it
+    // is used -- each wave keeps 8 KB of bias loads in flight.  One tile ahead left ~2 KB x 20 waves per CU in
     // flight at best, which at ~2 us loaded latency is ~2.5 TB/s chip-wide: the kernel was latency-bound.
     constexpr bool PIPE = NW == 4;                     // NW < 4 is launched for T <= 64 only: one chunk, two tiles
-    constexpr int RING = PIPE ? 4 : 2;
-    BiasRegs<TB> ring[RING];
-#pragma unroll
-    for (int j = 0; j < RING; ++j)
-        if (j * 32 < T) ring[j].load(brow + j * 32);
-
     const int nchunk = (T + KC - 1) / KC;
-    const int last_tile_key = ((T - 1) >> 5) << 5;
+    BiasStage<TB> ring[2];
+    ring[0].init(p.ld_bias, brow_max, lane);
+    ring[0].load(brows, 0);
+    if (PIPE) {
+#pragma unroll
+        for (int j = 0; j < BiasStage<TB>::NI; ++j) ring[1].off[j] = ring[0].off[j];
+        ring[1].load(brows, min(1, nchunk - 1));
+    }
+
     Slab<D, TQ, PIPE ? NT : KC * 4> kreg, vreg;        // (one dummy piece when not pipelined)
     if (PIPE) {
         kreg.load(K, p.ldk, 0, T);
         vreg.load(V, p.ldv, 0, T);
     }
 
-    auto chunk = [&](const int c, BiasRegs<TB>& b0, BiasRegs<TB>& b1) {
+    auto chunk = [&](const int c, BiasStage<TB>& bst) {
+        // this wave's bias super-tile: registers -> its LDS image (the image's readers of the previous chunk are this very
+        // wave's earlier ds_reads: LDS operations of one wave complete in order), then the slot is refilled two chunks ahead
+        // (past the end the last chunk is re-read: a branch around the load made the compiler copy the slot)
+        bst.park(bimg, lane);
+        if (PIPE) bst.load(brows, min(c + 2, nchunk - 1));
         __syncthreads();                                   // the previous chunk's LDS readers are done
         if (PIPE) {
             kreg.template store<true, false, true>(1.f, Ks, nullptr);
@@ -243,12 +316,8 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const AttnParams p) {
         for (int t = 0; t < 2; ++t) {
             const int key0 = c * KC + t * 32;
             if (key0 >= T) break;
-            BiasRegs<TB>& bt = t == 0 ? b0 : b1;
             f32x16 s;
-            bt.to_acc(s);
-            // refill this ring slot 4 tiles ahead; past the end the LAST tile is re-read instead (a branch around the
-            // load made the compiler copy the ring slot on the other path: 8 v_mov per tile)
-            if (PIPE) bt.load(brow + min(key0 + 128, last_tile_key));
+            BiasStage<TB>::to_acc(bimg, n, hi, t, s);
             if (key0 + 32 > T) {
 #pragma unroll
                 for (int i = 0; i < 16; ++i)
@@ -301,8 +370,8 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const AttnParams p) {
     };
 
     for (int c = 0; c < nchunk; c += 2) {
-        chunk(c, ring[0], ring[1]);
-        if (PIPE && c + 1 < nchunk) chunk(c + 1, ring[RING - 2], ring[RING - 1]);
+        chunk(c, ring[0]);
+        if (PIPE && c + 1 < nchunk) chunk(c + 1, ring[1]);
     }
 
     const float ltot = xhalf_sum(l);
@@ -348,7 +417,11 @@ __device__ __forceinline__ void attn_bwd_dq_body(const AttnParams& p, const int 
     const TQ* V = reinterpret_cast<const TQ*>(p.v) + (int64_t)g * T * p.ldv + h * D;
     const TQ* O = reinterpret_cast<const TQ*>(p.out) + (int64_t)g * T * p.ldo + h * D;
     const TQ* dO = reinterpret_cast<const TQ*>(p.dout) + (int64_t)g * T * p.ldo + h * D;
-    const TB* brow = reinterpret_cast<const TB*>(p.bias) + ((int64_t)gh * T + qc) * p.ld_bias + 16 * hi;
+    __shared__ __attribute__((aligned(16))) unsigned char Bs[NW][BiasStage<TB>::BYTES];
+    const int q0w = qt * 32 * NW + __builtin_amdgcn_readfirstlane(wave) * 32;  // this wave's first query row (an SGPR)
+    const TB* brows = reinterpret_cast<const TB*>(p.bias) + ((int64_t)gh * T + min(q0w, T - 1)) * p.ld_bias;
+    const int brow_max = max(T - 1 - q0w, 0);
+    unsigned char* bimg = Bs[wave];
     const int64_t dboff = ((int64_t)gh * T + qc) * p.ld_bias + 16 * hi;
     float* dbrow = p.dbias && !p.dbias_bf16 ? reinterpret_cast<float*>(p.dbias) + dboff : nullptr;
     // bf16 dBias goes out through LDS: written straight from the MFMA layout, a store instruction carried 64 separate
@@ -399,22 +472,26 @@ __device__ __forceinline__ void attn_bwd_dq_body(const AttnParams& p, const int 
 #pragma unroll
     for (int i = 0; i < 16; ++i) dq[i] = 0.f;
 
-    // bias prefetch ring as in the forward: four 2 KB tiles in flight per wave (one tile ahead, the pass ran at the
+    // bias prefetch ring as in the forward: two 4 KB super-tiles in flight per wave (one tile ahead, the pass ran at the
     // same speed with and without dropout -- it was waiting for its bias tiles, not computing)
     const int nchunk = (T + KC - 1) / KC;
-    const int last_tile_key = ((T - 1) >> 5) << 5;
     constexpr bool PIPE = NW == 4;
-    constexpr int RING = PIPE ? 4 : 2;
-    BiasRegs<TB> ring[RING];
+    BiasStage<TB> ring[2];
+    ring[0].init(p.ld_bias, brow_max, lane);
+    ring[0].load(brows, 0);
+    if (PIPE) {
 #pragma unroll
-    for (int j = 0; j < RING; ++j)
-        if (j * 32 < T) ring[j].load(brow + j * 32);
+        for (int j = 0; j < BiasStage<TB>::NI; ++j) ring[1].off[j] = ring[0].off[j];
+        ring[1].load(brows, min(1, nchunk - 1));
+    }
     Slab<D, TQ, PIPE ? NT : KC * 4> kreg, vreg;
     if (PIPE) {
         kreg.load(K, p.ldk, 0, T);
         vreg.load(V, p.ldv, 0, T);
     }
-    auto chunk = [&](const int c, BiasRegs<TB>& b0, BiasRegs<TB>& b1) {
+    auto chunk = [&](const int c, BiasStage<TB>& bst) {
+        bst.park(bimg, lane);                                                  // (see the forward kernel)
+        if (PIPE) bst.load(brows, min(c + 2, nchunk - 1));
         __syncthreads();
         if (PIPE) {
             kreg.template store<true, true, true>(1.f, Ks, Kt);
@@ -432,10 +509,8 @@ __device__ __forceinline__ void attn_bwd_dq_body(const AttnParams& p, const int 
         for (int t = 0; t < 2; ++t) {
             const int key0 = c * KC + t * 32;
             if (key0 >= T) break;
-            BiasRegs<TB>& bt = t == 0 ? b0 : b1;
             f32x16 s, dp;
-            bt.to_acc(s);
-            if (PIPE) bt.load(brow + min(key0 + 128, last_tile_key));      // refill this slot: 4 tiles ahead
+            BiasStage<TB>::to_acc(bimg, n, hi, t, s);
             const bool tail = key0 + 32 > T;
             if (tail) {
 #pragma unroll
@@ -504,8 +579,8 @@ __device__ __forceinline__ void attn_bwd_dq_body(const AttnParams& p, const int 
         flush_dbias(c);
     };
     for (int c = 0; c < nchunk; c += 2) {
-        chunk(c, ring[0], ring[1]);
-        if (PIPE && c + 1 < nchunk) chunk(c + 1, ring[RING - 2], ring[RING - 1]);
+        chunk(c, ring[0]);
+        if (PIPE && c + 1 < nchunk) chunk(c + 1, ring[1]);
     }
 
     if (q_ok) {
@@ -562,7 +637,11 @@ __device__ __forceinline__ void attn_bwd_dkv_body(const AttnParams& p, const int
     const TQ* K = reinterpret_cast<const TQ*>(p.k) + (int64_t)g * T * p.ldk + h * D;
     const TQ* V = reinterpret_cast<const TQ*>(p.v) + (int64_t)g * T * p.ldv + h * D;
     const TQ* dO = reinterpret_cast<const TQ*>(p.dout) + (int64_t)g * T * p.ldo + h * D;
-    const TB* brow = reinterpret_cast<const TB*>(p.bias_t) + ((int64_t)gh * T + kc) * p.ld_bias + 16 * hi;
+    __shared__ __attribute__((aligned(16))) unsigned char Bs[NW][BiasStage<TB>::BYTES];
+    const int k0w = kt * 32 * NW + __builtin_amdgcn_readfirstlane(wave) * 32;  // this wave's first key row of bias_t (an SGPR)
+    const TB* brows = reinterpret_cast<const TB*>(p.bias_t) + ((int64_t)gh * T + min(k0w, T - 1)) * p.ld_bias;
+    const int brow_max = max(T - 1 - k0w, 0);
+    unsigned char* bimg = Bs[wave];
 
     bf16x8 kf[KS], vf[KS];
 #pragma unroll
@@ -583,15 +662,12 @@ __device__ __forceinline__ void attn_bwd_dkv_body(const AttnParams& p, const int
     for (int i = 0; i < 16; ++i) { dk[i] = 0.f; dv[i] = 0.f; }
 
     const int nchunk = (T + KC - 1) / KC;
-    const int last_tile_q = ((T - 1) >> 5) << 5;
     constexpr bool PIPE = NW == 4;
-    // two slots, refilled two tiles ahead (this pass is compute-bound and short of registers: a 4-deep ring as in the
-    // other two passes cost 26 VGPRs and bought nothing)
-    constexpr int RING = 2;
-    BiasRegs<TB> ring[RING];
-#pragma unroll
-    for (int j = 0; j < RING; ++j)
-        if (j * 32 < T) ring[j].load(brow + j * 32);
+    // one super-tile (a chunk's 32 keys x 64 queries of bias_t) in registers, requested one chunk ahead (this pass is
+    // compute-bound and short of registers: a deeper ring cost 26 VGPRs and bought nothing)
+    BiasStage<TB> bst;
+    bst.init(p.ld_bias, brow_max, lane);
+    bst.load(brows, 0);
     Slab<D, TQ, PIPE ? NT : KC * 4> qreg, doreg;
     if (PIPE) {
         qreg.load(Q, p.ldq, 0, T);
@@ -621,7 +697,9 @@ __device__ __forceinline__ void attn_bwd_dkv_body(const AttnParams& p, const int
         }
     };
     load_rowstats(0);
-    auto chunk = [&](const int c, BiasRegs<TB>& b0, BiasRegs<TB>& b1) {
+    auto chunk = [&](const int c) {
+        bst.park(bimg, lane);                                                  // (see the forward kernel)
+        if (PIPE) bst.load(brows, min(c + 1, nchunk - 1));
         __syncthreads();
         if (PIPE) {
             qreg.template store<true, true, true>(1.f, Qs, Qt);
@@ -658,10 +736,8 @@ __device__ __forceinline__ void attn_bwd_dkv_body(const AttnParams& p, const int
         for (int t = 0; t < 2; ++t) {
             const int q0 = c * KC + t * 32;
             if (q0 >= T) break;
-            BiasRegs<TB>& bt = t == 0 ? b0 : b1;
             f32x16 s, dp;
-            bt.to_acc(s);
-            if (PIPE) bt.load(brow + min(q0 + 64, last_tile_q));           // refill this slot: 2 tiles ahead
+            BiasStage<TB>::to_acc(bimg, n, hi, t, s);
 #pragma unroll
             for (int i = 0; i < 16; ++i) dp[i] = 0.f;
 #pragma unroll
@@ -717,7 +793,7 @@ __device__ __forceinline__ void attn_bwd_dkv_body(const AttnParams& p, const int
             }
         }
     };
-    for (int c = 0; c < nchunk; ++c) chunk(c, ring[0], ring[1]);
+    for (int c = 0; c < nchunk; ++c) chunk(c);
 
     if (k_ok) {
         TQ* DK = reinterpret_cast<TQ*>(p.dk) + ((int64_t)g * T + my_k) * p.lddk + h * D + 16 * hi;
@@ -812,7 +888,9 @@ bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) ==
 int check_common(int G, int H, int T, int d, int64_t ld_bias, int io_dtype, int64_t lds_min_mult) {
     if (G <= 0 || H <= 0 || T <= 0) return MOBGT_EBADDIM;
     if (d != 16 && d != 24 && d != 32) return MOBGT_EBADDIM;
-    if (ld_bias % 32 != 0 || ld_bias < T) return MOBGT_EALIGN;
+    // 64-column chunks are read as whole row segments (BiasStage): rows must cover roundup(T, 64) columns and start on
+    // 128-byte lines (bf16)
+    if (ld_bias % 64 != 0 || ld_bias < T) return MOBGT_EALIGN;
     (void)io_dtype; (void)lds_min_mult;
     return 0;
 }

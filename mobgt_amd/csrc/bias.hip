@@ -710,9 +710,12 @@ template <typename TI, typename TE, typename TB>
 int launch_build(const BuildParams& p, hipStream_t st) {
     const int T = p.N + 1;
     const int nt = (int)((p.ld + TILE - 1) / TILE);
-    const dim3 grid(nt, 4 * ((T + TILE - 1) / TILE), p.G), block(256);
+    // (tile rows cover all ld columns of the TRANSPOSED copy as well: its columns [T, ld) must read -inf -- the dK/dV pass
+    // relies on it -- and ld = roundup(T, 64) can exceed roundup(T, 32))
+    (void)T;
+    const dim3 grid(nt, 4 * nt, p.G), block(256);
     if (p.H == 8 && (int64_t)p.G * T * T >= (1 << 20)) {
-        const dim3 grid4(nt, (T + TILE - 1) / TILE, p.G);
+        const dim3 grid4(nt, nt, p.G);
         hipLaunchKernelGGL((build_bias_kernel<TI, TE, TB, 8, 4>), grid4, block, 0, st, p);
     } else if (p.H == 8) hipLaunchKernelGGL((build_bias_kernel<TI, TE, TB, 8, 1>), grid, block, 0, st, p);
     else if (p.H == 4) hipLaunchKernelGGL((build_bias_kernel<TI, TE, TB, 4, 1>), grid, block, 0, st, p);

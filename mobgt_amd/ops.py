@@ -99,12 +99,13 @@ def round_up(x, m):
 
 class PackedBias:
     """The attention bias in kernel layout: `bias` [G,H,T,ld] row-major and `bias_t` (query/key
-    transposed), ld = roundup(T,32), pad columns -inf; plus the f32 dBias accumulator shared by all
+    transposed), ld = roundup(T,64) (rows start on 128-byte lines in bf16 and cover whole 64-key chunks: the attention
+    kernels fetch a chunk as full row segments), pad columns -inf; plus the f32 dBias accumulator shared by all
     layers of one step and the autograd token that orders its consumer after every layer's backward."""
 
     def __init__(self, G, H, T, dtype, device):
         self.G, self.H, self.T = G, H, T
-        self.ld = round_up(T, 32)
+        self.ld = round_up(T, 64)
         self.dtype = dtype
         self.bias = torch.empty(G, H, T, self.ld, dtype=dtype, device=device)
         self.bias_t = torch.empty(G, H, T, self.ld, dtype=dtype, device=device)
