@@ -20,6 +20,36 @@
 
 namespace {
 
+// Diagnostic build (-DATTN_STAMP, tools/attn_stamp.sh): the forward kernel sums, per wave, the shader cycles between fixed
+// points of its chunk loop and writes the sums over the first LSE values of its rows.  Never defined in the shipped library.
+#ifdef ATTN_STAMP
+#define STAMP(k)                                                                                   \
+    do {                                                                                           \
+        unsigned long long t_;                                                                     \
+        __builtin_amdgcn_sched_barrier(0);                                                         \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                  \
+        __builtin_amdgcn_sched_barrier(0);                                                         \
+        st_acc[k] += (uint32_t)(t_ - st_last);                                                     \
+        st_last = t_;                                                                              \
+    } while (0)
+#else
+#define STAMP(k)
+#endif
+
+// A/B switches for tools/attn_ab.sh (each variant is its own library; the shipped build uses the defaults)
+#ifndef ATTN_DEADSKIP
+#define ATTN_DEADSKIP 1       // waves whose 32 rows all lie beyond T skip the tile loop
+#endif
+#ifndef ATTN_BWD_DEADSKIP
+#define ATTN_BWD_DEADSKIP 0   // the same in the two backward passes
+#endif
+#ifndef ATTN_BWD_EVEN
+#define ATTN_BWD_EVEN 0       // backward passes: deal the 32-row tiles out evenly over more workgroups (choose_nq)
+#endif
+#ifndef ATTN_PACKED_DROP
+#define ATTN_PACKED_DROP 1    // forward: dropout as a mask on the packed probabilities
+#endif
+
 constexpr int KC = 64;        // keys (or queries, in the dK/dV pass) staged per LDS chunk = 2 MFMA tiles
 constexpr int ROWP = 40;      // row-major tile row pitch in bf16 (32 + 8: odd multiple of 16 B)
 constexpr int COLP = KC + 8;  // transposed tile row pitch in bf16 (144 B = 9 * 16 B)
@@ -41,6 +71,7 @@ struct AttnParams {
     const uint64_t* seed_dev;
     int accumulate;
     int n_first;              // attn_bwd_both_kernel: workgroups of the dQ part
+    int nq;                   // workgroups per (graph, head): the ceil(T/32) 32-row wave tiles are dealt out evenly over them
 };
 
 // Staging of a [KC x D] row-major slab (rows row0.., row stride ld, head column offset already applied) into
@@ -82,6 +113,17 @@ struct Slab {
         for (int k = 0; k < ITEMS; ++k) {
             const int e = threadIdx.x + k * NT, r = e >> 2, c0 = (e & 3) * 8;
             if (c0 < D && row0 + r < T) it[k].load(src + (int64_t)(row0 + r) * ld + c0);
+            else it[k].zero();
+        }
+    }
+    // the same with rows >= T clamped onto row T - 1 instead of zero-filled: no branch around the loads (the compiler's
+    // wait-count bookkeeping stays exact across the chunk loop), and every kernel here multiplies rows >= T by an exact zero
+    // (masked keys: P = 0; queries beyond T in the dK/dV pass: bias_t = -inf) so any FINITE stand-in serves
+    __device__ __forceinline__ void load_clamped(const TQ* __restrict__ src, int64_t ld, int row0, int T) {
+#pragma unroll
+        for (int k = 0; k < ITEMS; ++k) {
+            const int e = threadIdx.x + k * NT, r = e >> 2, c0 = (e & 3) * 8;
+            if (D % 32 == 0 || c0 < D) it[k].load(src + (int64_t)min(row0 + r, T - 1) * ld + c0);
             else it[k].zero();
         }
     }
@@ -228,22 +270,39 @@ struct BiasStage {
     }
 };
 
+
+// The 32-row tiles of one (graph, head) -- nwt = ceil(T / 32), one per wave -- dealt out evenly over nq workgroups of NW
+// waves: workgroup qt owns tiles [qt * nwt / nq, (qt + 1) * nwt / nq), at most NW of them (nq >= ceil(nwt / NW)); a wave beyond
+// its workgroup's count has no rows (row0 = T).  Round 2 gave every workgroup NW consecutive tiles: at T = 785 that is
+// 4,4,4,4,4,4,1 -- 896 workgroups of which every seventh is nearly empty, on 1024 / 768 / 512 resident slots (forward / dQ /
+// dK-dV pass): compute units with four workgroups next to units with three, or a mostly idle last round.  Now the host picks
+// nq (choose_nq below: 8 at c5 -> 1024 workgroups of 3 or 4 live waves, whole rounds on every compute unit).
+__device__ __forceinline__ int wave_row0(int qt, int nq, int T, int wave_uniform, int NWv) {
+    const int nwt = (T + 31) >> 5;
+    const int t0 = qt * nwt / nq, t1 = (qt + 1) * nwt / nq;
+    (void)NWv;
+    return wave_uniform < t1 - t0 ? (t0 + wave_uniform) * 32 : T;
+}
+__device__ __forceinline__ int wg_tile0(int qt, int nq, int T) { return qt * ((T + 31) >> 5) / nq; }
 // =================================================================================== forward
 template <int D, typename TQ, typename TB, int NW, bool DROP>
 __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const AttnParams p) {
     constexpr int KS = (D + 15) / 16;
     constexpr int NT = NW * 64;
-    __shared__ __attribute__((aligned(16))) bf16_t Ks[KC][ROWP];
-    __shared__ __attribute__((aligned(16))) bf16_t Vt[32][COLP];
+    constexpr bool PIPE = NW == 4;                     // NW < 4 is launched for T <= 64 only: one chunk, two tiles
+    constexpr int NB = PIPE ? 2 : 1;                   // K / V images in LDS (double-buffered when there is a chunk loop)
+    __shared__ __attribute__((aligned(16))) bf16_t Ksb[NB][KC][ROWP];
+    __shared__ __attribute__((aligned(16))) bf16_t Vtb[NB][32][COLP];
 
     const int T = p.T, H = p.H;
-    const int nQ = (T + 32 * NW - 1) / (32 * NW);
+    const int nQ = p.nq;
     const int lid = xcd_remap(blockIdx.x, gridDim.x);
     const int qt = lid % nQ, gh = lid / nQ;
     const int g = gh / H, h = gh % H;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int n = lane & 31, hi = lane >> 5;
-    const int my_q = qt * 32 * NW + wave * 32 + n;
+    const int q0w = wave_row0(qt, nQ, T, __builtin_amdgcn_readfirstlane(wave), NW);   // this wave's first query row (an SGPR)
+    const int my_q = q0w + n;
     const bool q_ok = my_q < T;
     const int qc = q_ok ? my_q : T - 1;
 
@@ -251,15 +310,33 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const AttnParams p) {
     const TQ* K = reinterpret_cast<const TQ*>(p.k) + (int64_t)g * T * p.ldk + h * D;
     const TQ* V = reinterpret_cast<const TQ*>(p.v) + (int64_t)g * T * p.ldv + h * D;
     __shared__ __attribute__((aligned(16))) unsigned char Bs[NW][BiasStage<TB>::BYTES];
-    const int q0w = qt * 32 * NW + __builtin_amdgcn_readfirstlane(wave) * 32;  // this wave's first query row (an SGPR)
+    const bool wave_live = !ATTN_DEADSKIP || q0w < T;                          // (wave-uniform)
     const TB* brows = reinterpret_cast<const TB*>(p.bias) + ((int64_t)gh * T + min(q0w, T - 1)) * p.ld_bias;
     const int brow_max = max(T - 1 - q0w, 0);
     unsigned char* bimg = Bs[wave];
 
-    bf16x8 qf[KS];
+    // The prologue's loads are all ISSUED before anything waits, in the order they are needed: the first chunk's K / V rows
+    // (the whole workgroup waits for them at the first barrier), this lane's Q fragment, the first two bias super-tiles, the
+    // second chunk's K / V.  (Round 2 loaded Q, waited, loaded 8 KB of bias per wave, then K / V: at a cold start, with every
+    // wave of the launch in its prologue at once, the first MFMA sat behind three serial round trips.)
+    const int nchunk = (T + KC - 1) / KC;
+    Slab<D, TQ, PIPE ? NT : KC * 4> kreg, vreg;        // (one dummy piece when not pipelined)
+    if (PIPE) {
+        kreg.load_clamped(K, p.ldk, 0, T);
+        vreg.load_clamped(V, p.ldv, 0, T);
+    }
+    Raw8<TQ> qraw[KS];
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks)
-        load_frag(Q + (int64_t)qc * p.ldq + ks * 16 + 8 * hi, q_ok && (ks * 16 + 8 * hi < D), p.scale, qf[ks]);
+    for (int ks = 0; ks < KS; ++ks)          // (a fragment beyond D is read from column 0 and multiplied by zero below)
+        qraw[ks].load(Q + (int64_t)qc * p.ldq + (ks * 16 + 8 * hi < D ? ks * 16 + 8 * hi : 0));
+    BiasStage<TB> ring[2];
+    ring[0].init(p.ld_bias, brow_max, lane);
+    ring[0].load(brows, 0);
+    if (PIPE) {
+#pragma unroll
+        for (int j = 0; j < BiasStage<TB>::NI; ++j) ring[1].off[j] = ring[0].off[j];
+        ring[1].load(brows, min(1, nchunk - 1));
+    }
 
     uint32_t rowh = 0;
     uint64_t seed = 0;
@@ -273,45 +350,56 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const AttnParams p) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) o[i] = 0.f;
 
-    // Bias prefetch ring: a chunk's 32 x 64 super-tile (4 KB per wave, bf16) is requested two chunks (128 keys) before it
-    // is used -- each wave keeps 8 KB of bias loads in flight.  One tile ahead left ~2 KB x 20 waves per CU in
-    // flight at best, which at ~2 us loaded latency is ~2.5 TB/s chip-wide: the kernel was latency-bound.
-    constexpr bool PIPE = NW == 4;                     // NW < 4 is launched for T <= 64 only: one chunk, two tiles
-    const int nchunk = (T + KC - 1) / KC;
-    BiasStage<TB> ring[2];
-    ring[0].init(p.ld_bias, brow_max, lane);
-    ring[0].load(brows, 0);
+    // The chunk loop (T > 64), as the in-kernel stamps of round 3 shaped it (tools/attn_stamp.py: a wave spent 30 % of its
+    // life waiting for loads that had been issued only ONE chunk -- ~1.5 us of its own work -- earlier, whatever the nominal
+    // prefetch distance: vmcnt retires in order, and the compiler drained the counter at the top of every other chunk):
+    //   * bias: a chunk's 32 x 64 super-tile (4 KB per wave, bf16) is requested two chunks before it is parked in LDS;
+    //   * K / V: chunk c + 2 is requested while chunk c is computed; chunk c + 1 goes from registers into the OTHER LDS image
+    //     at the END of chunk c (its loads have then had a whole chunk + this chunk's tiles to arrive), so a chunk needs ONE
+    //     barrier (the next image is complete / this image's readers are done) instead of two;
+    //   * no load sits behind a branch (row and chunk indices are clamped instead; re-read data is never used), the loop is
+    //     unrolled by two with the odd tail peeled, so the compiler's wait counts are exact.
     if (PIPE) {
+        kreg.template store<true, false, true>(1.f, Ksb[0], nullptr);
+        vreg.template store<false, true, true>(1.f, nullptr, Vtb[0]);
+        kreg.load_clamped(K, p.ldk, min(1, nchunk - 1) * KC, T);
+        vreg.load_clamped(V, p.ldv, min(1, nchunk - 1) * KC, T);
+    } else {
+        Slab<D, TQ, NT>::template direct<true, false, true>(K, p.ldk, 0, T, 1.f, Ksb[0], nullptr);
+        Slab<D, TQ, NT>::template direct<false, true, true>(V, p.ldv, 0, T, 1.f, nullptr, Vtb[0]);
+    }
+    bf16x8 qf[KS];
 #pragma unroll
-        for (int j = 0; j < BiasStage<TB>::NI; ++j) ring[1].off[j] = ring[0].off[j];
-        ring[1].load(brows, min(1, nchunk - 1));
+    for (int ks = 0; ks < KS; ++ks) {
+        float v[8];
+        qraw[ks].get(v);
+        const float mul = (q_ok && (ks * 16 + 8 * hi < D)) ? p.scale : 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] *= mul;
+        qf[ks] = pack8(v);
     }
+    __syncthreads();
 
-    Slab<D, TQ, PIPE ? NT : KC * 4> kreg, vreg;        // (one dummy piece when not pipelined)
-    if (PIPE) {
-        kreg.load(K, p.ldk, 0, T);
-        vreg.load(V, p.ldv, 0, T);
-    }
-
-    auto chunk = [&](const int c, BiasStage<TB>& bst) {
+#ifdef ATTN_STAMP
+    uint32_t st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long st_last, st_real0;
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_real0)::"memory");      // 100 MHz wall clock
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_last)::"memory");
+#endif
+    auto chunk = [&](const int c, BiasStage<TB>& bst, const int b) {
+        bf16_t (*Ks)[ROWP] = Ksb[PIPE ? b : 0];
+        bf16_t (*Vt)[COLP] = Vtb[PIPE ? b : 0];
         // this wave's bias super-tile: registers -> its LDS image (the image's readers of the previous chunk are this very
         // wave's earlier ds_reads: LDS operations of one wave complete in order), then the slot is refilled two chunks ahead
         // (past the end the last chunk is re-read: a branch around the load made the compiler copy the slot)
-        bst.park(bimg, lane);
+        if (wave_live) bst.park(bimg, lane);
+        STAMP(0);                                          // waited for this chunk's bias super-tile
+        // (also by a wave without rows -- it re-reads row T - 1, an L2 hit: a load behind a branch would cost every wave its
+        // exact wait counts, see above)
         if (PIPE) bst.load(brows, min(c + 2, nchunk - 1));
-        __syncthreads();                                   // the previous chunk's LDS readers are done
-        if (PIPE) {
-            kreg.template store<true, false, true>(1.f, Ks, nullptr);
-            vreg.template store<false, true, true>(1.f, nullptr, Vt);
-        } else {
-            Slab<D, TQ, NT>::template direct<true, false, true>(K, p.ldk, c * KC, T, 1.f, Ks, nullptr);
-            Slab<D, TQ, NT>::template direct<false, true, true>(V, p.ldv, c * KC, T, 1.f, nullptr, Vt);
-        }
-        __syncthreads();
-        if (PIPE && c + 1 < nchunk) {                      // next chunk's K / V: in flight during this chunk's MFMAs
-            kreg.load(K, p.ldk, (c + 1) * KC, T);
-            vreg.load(V, p.ldv, (c + 1) * KC, T);
-        }
+        // (a wave whose 32 query rows all lie beyond T -- three of the four waves of every (graph, head)'s last workgroup at
+        // T = 785 -- only helps staging K / V: it owns no output, and its tiles would take a ninth of the chip's vector issue)
+        if (wave_live)
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             const int key0 = c * KC + t * 32;
@@ -348,30 +436,60 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const AttnParams p) {
                 pr[i] = fast_exp2(fmaf(s[i], MOBGT_LOG2E, -ms));
                 l += pr[i];
             }
-            if (DROP) {                                                    // rule v2 (common.h): this lane's 16 keys = one block
-                const uint32_t hb = attn_drop_block(seed, rowh, (uint32_t)((key0 >> 4) + hi));
+            // dropout rule v2 (common.h; this lane's 16 keys = one block), applied to the PACKED probabilities: a pair's word w
+            // carries two 16-bit uniforms in the order the pair is packed (even key low), so the pair's keep mask is two packed
+            // 16-bit instructions -- saturating (thr - 1) - w, arithmetic shift by 15 -- and one AND on the packed pair, instead
+            // of a sign extension, two compares and two selects on the f32 values.  1/(1-p) is applied once, to the output row.
+            uint32_t hb = 0;
+            if (DROP) hb = attn_drop_block(seed, rowh, (uint32_t)((key0 >> 4) + hi));
+#if !ATTN_PACKED_DROP
+            if (DROP) {
 #pragma unroll
                 for (int m = 0; m < 8; ++m) {
                     const uint32_t w = attn_drop_word(hb, attn_drop_mult(m));
-                    pr[2 * m] = attn_drop_keep_even(w, p.thr_s) ? pr[2 * m] : 0.f;     // 1/(1-p) is applied once, to the output row
+                    pr[2 * m] = attn_drop_keep_even(w, p.thr_s) ? pr[2 * m] : 0.f;
                     pr[2 * m + 1] = attn_drop_keep_odd(w, p.thr_s) ? pr[2 * m + 1] : 0.f;
                 }
             }
+#endif
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
                 float pv[8];
 #pragma unroll
                 for (int j = 0; j < 8; ++j) pv[j] = pr[8 * s2 + j];
-                const bf16x8 pb = pack8(pv);
+                bf16x8 pb = pack8(pv);
+                if (DROP && ATTN_PACKED_DROP) {
+                    u32x4 pw = __builtin_bit_cast(u32x4, pb);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) pw[k] &= attn_drop_keep_mask2(attn_drop_word(hb, attn_drop_mult(4 * s2 + k)), p.thr_s);
+                    pb = __builtin_bit_cast(bf16x8, pw);
+                }
                 const bf16x8 a = *reinterpret_cast<const bf16x8*>(&Vt[kappa(n)][t * 32 + 16 * hi + 8 * s2]);
                 o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, pb, o, 0, 0, 0);
             }
+            STAMP(4 + t);                                  // one 32-key tile: QK^T, softmax, dropout, PV
+        }
+        if (PIPE) {
+            // chunk c + 1: registers -> the other image; chunk c + 2: requested now; one barrier per chunk
+            kreg.template store<true, false, true>(1.f, Ksb[b ^ 1], nullptr);
+            vreg.template store<false, true, true>(1.f, nullptr, Vtb[b ^ 1]);
+            STAMP(2);                                      // waited for the next chunk's K / V rows, stored them
+            kreg.load_clamped(K, p.ldk, min(c + 2, nchunk - 1) * KC, T);
+            vreg.load_clamped(V, p.ldv, min(c + 2, nchunk - 1) * KC, T);
+            __syncthreads();
+            STAMP(3);                                      // the chunk's barrier
         }
     };
 
-    for (int c = 0; c < nchunk; c += 2) {
-        chunk(c, ring[0]);
-        if (PIPE && c + 1 < nchunk) chunk(c + 1, ring[1]);
+    if (PIPE) {
+        int c = 0;
+        for (; c + 1 < nchunk; c += 2) {
+            chunk(c, ring[0], 0);
+            chunk(c + 1, ring[1], 1);
+        }
+        if (c < nchunk) chunk(c, ring[0], 0);
+    } else {
+        chunk(0, ring[0], 0);
     }
 
     const float ltot = xhalf_sum(l);
@@ -389,6 +507,18 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const AttnParams p) {
         }
         if (hi == 0) p.lse[(int64_t)gh * T + my_q] = m + logf(ltot);
     }
+#ifdef ATTN_STAMP
+    STAMP(6);                                              // epilogue
+    {
+        unsigned long long r1;
+        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(r1)::"memory");
+        st_acc[7] = (uint32_t)(r1 - st_real0);             // wave lifetime in 10 ns units
+        st_acc[6] = (uint32_t)(st_real0 & 0xffffffu);      // start time (10 ns units, low 24 bits: exact in a float)
+    }
+    __syncthreads();
+    if (lane == 0 && q0w + 8 <= T)
+        for (int k = 0; k < 8; ++k) p.lse[(int64_t)gh * T + q0w + k] = (float)st_acc[k];
+#endif
 }
 
 // ======================================================================= backward, pass 1: dQ + dBias
@@ -402,13 +532,14 @@ __device__ __forceinline__ void attn_bwd_dq_body(const AttnParams& p, const int 
     __shared__ __attribute__((aligned(16))) bf16_t Kt[32][COLP];
 
     const int T = p.T, H = p.H;
-    const int nQ = (T + 32 * NW - 1) / (32 * NW);
+    const int nQ = p.nq;
     const int lid = xcd_remap(bid, nwg);
     const int qt = lid % nQ, gh = lid / nQ;
     const int g = gh / H, h = gh % H;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int n = lane & 31, hi = lane >> 5;
-    const int my_q = qt * 32 * NW + wave * 32 + n;
+    const int q0w = wave_row0(qt, nQ, T, __builtin_amdgcn_readfirstlane(wave), NW);   // this wave's first query row (an SGPR)
+    const int my_q = q0w + n;
     const bool q_ok = my_q < T;
     const int qc = q_ok ? my_q : T - 1;
 
@@ -418,7 +549,7 @@ __device__ __forceinline__ void attn_bwd_dq_body(const AttnParams& p, const int 
     const TQ* O = reinterpret_cast<const TQ*>(p.out) + (int64_t)g * T * p.ldo + h * D;
     const TQ* dO = reinterpret_cast<const TQ*>(p.dout) + (int64_t)g * T * p.ldo + h * D;
     __shared__ __attribute__((aligned(16))) unsigned char Bs[NW][BiasStage<TB>::BYTES];
-    const int q0w = qt * 32 * NW + __builtin_amdgcn_readfirstlane(wave) * 32;  // this wave's first query row (an SGPR)
+    const bool wave_live = !ATTN_BWD_DEADSKIP || q0w < T;
     const TB* brows = reinterpret_cast<const TB*>(p.bias) + ((int64_t)gh * T + min(q0w, T - 1)) * p.ld_bias;
     const int brow_max = max(T - 1 - q0w, 0);
     unsigned char* bimg = Bs[wave];
@@ -430,7 +561,7 @@ __device__ __forceinline__ void attn_bwd_dq_body(const AttnParams& p, const int 
     // tile is parked in LDS in the MFMA layout and read back row-contiguously, 8 full lines per store instruction.
     __shared__ __attribute__((aligned(16))) bf16_t dSs[NW][32][KC + 8];
     const bool db16 = p.dbias && p.dbias_bf16;
-    bf16_t* db16_base = reinterpret_cast<bf16_t*>(p.dbias) + ((int64_t)gh * T + qt * 32 * NW + wave * 32) * p.ld_bias;
+    bf16_t* db16_base = reinterpret_cast<bf16_t*>(p.dbias) + ((int64_t)gh * T + min(q0w, T - 1)) * p.ld_bias;
     auto flush_dbias = [&](const int c) {
         if (!db16) return;
 #pragma unroll
@@ -439,7 +570,7 @@ __device__ __forceinline__ void attn_bwd_dq_body(const AttnParams& p, const int 
             const bf16x8 v = *reinterpret_cast<const bf16x8*>(&dSs[wave][row][8 * (lane & 7)]);
             // columns [T, ld_bias) exist in the buffer and receive the zeros that masked keys produce; a tile that
             // lies entirely beyond ld_bias was never computed
-            if (qt * 32 * NW + wave * 32 + row < T && col + 8 <= p.ld_bias)
+            if (q0w + row < T && col + 8 <= p.ld_bias)
                 *reinterpret_cast<bf16x8*>(db16_base + (int64_t)row * p.ld_bias + col) = v;
         }
     };
@@ -490,8 +621,8 @@ __device__ __forceinline__ void attn_bwd_dq_body(const AttnParams& p, const int 
         vreg.load(V, p.ldv, 0, T);
     }
     auto chunk = [&](const int c, BiasStage<TB>& bst) {
-        bst.park(bimg, lane);                                                  // (see the forward kernel)
-        if (PIPE) bst.load(brows, min(c + 2, nchunk - 1));
+        if (wave_live) bst.park(bimg, lane);                                   // (see the forward kernel)
+        if (PIPE) bst.load(brows, min(c + 2, nchunk - 1));                    // (never behind a branch: see the forward)
         __syncthreads();
         if (PIPE) {
             kreg.template store<true, true, true>(1.f, Ks, Kt);
@@ -505,6 +636,7 @@ __device__ __forceinline__ void attn_bwd_dq_body(const AttnParams& p, const int 
             kreg.load(K, p.ldk, (c + 1) * KC, T);
             vreg.load(V, p.ldv, (c + 1) * KC, T);
         }
+        if (wave_live)                                                         // (see the forward kernel)
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             const int key0 = c * KC + t * 32;
@@ -576,7 +708,7 @@ __device__ __forceinline__ void attn_bwd_dq_body(const AttnParams& p, const int 
                 dq = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, db, dq, 0, 0, 0);
             }
         }
-        flush_dbias(c);
+        if (wave_live) flush_dbias(c);
     };
     for (int c = 0; c < nchunk; c += 2) {
         chunk(c, ring[0]);
@@ -623,13 +755,14 @@ __device__ __forceinline__ void attn_bwd_dkv_body(const AttnParams& p, const int
     __shared__ __attribute__((aligned(16))) uint32_t dropW[DROP ? 2 : 1][DROP ? NW * 2 : 1][DROP ? 8 : 1][DROP ? 36 : 4];
 
     const int T = p.T, H = p.H;
-    const int nK = (T + 32 * NW - 1) / (32 * NW);
+    const int nK = p.nq;
     const int lid = xcd_remap(bid, nwg);
     const int kt = lid % nK, gh = lid / nK;
     const int g = gh / H, h = gh % H;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int n = lane & 31, hi = lane >> 5;
-    const int my_k = kt * 32 * NW + wave * 32 + n;
+    const int k0w = wave_row0(kt, nK, T, __builtin_amdgcn_readfirstlane(wave), NW);   // this wave's first key row of bias_t (an SGPR)
+    const int my_k = k0w + n;
     const bool k_ok = my_k < T;
     const int kc = k_ok ? my_k : T - 1;
 
@@ -638,7 +771,7 @@ __device__ __forceinline__ void attn_bwd_dkv_body(const AttnParams& p, const int
     const TQ* V = reinterpret_cast<const TQ*>(p.v) + (int64_t)g * T * p.ldv + h * D;
     const TQ* dO = reinterpret_cast<const TQ*>(p.dout) + (int64_t)g * T * p.ldo + h * D;
     __shared__ __attribute__((aligned(16))) unsigned char Bs[NW][BiasStage<TB>::BYTES];
-    const int k0w = kt * 32 * NW + __builtin_amdgcn_readfirstlane(wave) * 32;  // this wave's first key row of bias_t (an SGPR)
+    const bool wave_live = !ATTN_BWD_DEADSKIP || k0w < T;
     const TB* brows = reinterpret_cast<const TB*>(p.bias_t) + ((int64_t)gh * T + min(k0w, T - 1)) * p.ld_bias;
     const int brow_max = max(T - 1 - k0w, 0);
     unsigned char* bimg = Bs[wave];
@@ -698,8 +831,8 @@ __device__ __forceinline__ void attn_bwd_dkv_body(const AttnParams& p, const int
     };
     load_rowstats(0);
     auto chunk = [&](const int c) {
-        bst.park(bimg, lane);                                                  // (see the forward kernel)
-        if (PIPE) bst.load(brows, min(c + 1, nchunk - 1));
+        if (wave_live) bst.park(bimg, lane);                                   // (see the forward kernel)
+        if (PIPE) bst.load(brows, min(c + 1, nchunk - 1));                    // (never behind a branch: see the forward)
         __syncthreads();
         if (PIPE) {
             qreg.template store<true, true, true>(1.f, Qs, Qt);
@@ -719,7 +852,7 @@ __device__ __forceinline__ void attn_bwd_dkv_body(const AttnParams& p, const int
                 const int row = e & 31, kbl = (e >> 5) % (NW * 2), t = e / (NW * 64);
                 const int q = c * KC + t * 32 + row;
                 const uint32_t rh = dropout_row_hash(seed, (uint32_t)(gh * T + (q < T ? q : T - 1)));
-                const uint32_t hb = attn_drop_block(seed, rh, (uint32_t)(kt * 2 * NW + kbl));
+                const uint32_t hb = attn_drop_block(seed, rh, (uint32_t)(wg_tile0(kt, nK, T) * 2 + kbl));
 #pragma unroll
                 for (int m = 0; m < 8; ++m) dropW[t][kbl][m][row] = attn_drop_word(hb, attn_drop_mult(m));
             }
@@ -732,6 +865,7 @@ __device__ __forceinline__ void attn_bwd_dkv_body(const AttnParams& p, const int
             }
             load_rowstats(c + 1);
         }
+        if (wave_live)                                                         // (see the forward kernel)
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             const int q0 = c * KC + t * 32;
@@ -829,24 +963,81 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_both_kernel(const AttnParams
 // ------------------------------------------------------------------------------------ dispatch
 enum Pass { FWD, BWD_DQ, BWD_DKV, BWD_BOTH };
 
+// Workgroups per (graph, head).  Cost model: every round of resident workgroups costs (workgroups per compute unit in that
+// round) x (live waves per workgroup = nwt / nq); candidates nq0 = ceil(nwt / NW) ... nq0 + 3, fewer workgroups on near-ties
+// (each one stages all of K / V).  c5 (nwt 25, 128 (graph, head)s, 256 CUs): forward cap 4 -> 8 (one round of 1024 instead of
+// 896 uneven ones), dQ pass cap 3 -> 8 (768 + 256 instead of 768 + 128 nearly empty ones), dK/dV pass cap 2 -> 8 (two whole rounds).
+int choose_nq(int GH, int T, int NW, int cap, int cus) {
+    const int nwt = (T + 31) / 32, nq0 = (nwt + NW - 1) / NW;
+    if (nwt <= NW || cap < 1 || cus < 1) return nq0;
+    int best = nq0;
+    double best_cost = 1e30;
+    for (int nq = nq0; nq <= nwt && nq <= nq0 + 3; ++nq) {
+        const long slots = (long)cus * cap;
+        double cost = 0;
+        for (long left = (long)GH * nq; left > 0; left -= slots) {
+            const long in_round = left < slots ? left : slots;
+            cost += (double)((in_round + cus - 1) / cus) * nwt / nq;
+        }
+        if (cost < best_cost * 0.97) { best_cost = cost; best = nq; }
+    }
+    return best;
+}
+
+template <typename K>
+int blocks_per_cu(K kernel, int threads) {
+    int n = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void*>(kernel), threads, 0) != hipSuccess || n < 1) {
+        (void)hipGetLastError();
+        n = 1;
+    }
+    return n;
+}
+
+int cu_count() {
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) {
+            (void)hipGetLastError();
+            cus = 256;
+        }
+    }
+    return cus;
+}
+
 template <Pass PASS, int D, typename TQ, typename TB, int NW, bool DROP>
-hipError_t launch_one(const AttnParams& p, hipStream_t st) {
-    const int tiles = (p.T + 32 * NW - 1) / (32 * NW);
-    const dim3 grid((unsigned)(p.G * p.H * tiles)), block(NW * 64);
+hipError_t launch_one(const AttnParams& p0, hipStream_t st) {
+    const dim3 block(NW * 64);
+    const int GH = p0.G * p0.H;
+    AttnParams p = p0;
     if constexpr (PASS == BWD_BOTH) {
         if constexpr (NW < 4) {
-            AttnParams q = p;
-            q.n_first = p.G * p.H * tiles;
-            hipLaunchKernelGGL((attn_bwd_both_kernel<D, TQ, TB, NW, DROP>), dim3(2 * grid.x), block, 0, st, q);
+            p.nq = ((p.T + 31) / 32 + NW - 1) / NW;
+            p.n_first = GH * p.nq;
+            hipLaunchKernelGGL((attn_bwd_both_kernel<D, TQ, TB, NW, DROP>), dim3(2 * GH * p.nq), block, 0, st, p);
         } else {
-            hipLaunchKernelGGL((attn_bwd_dq_kernel<D, TQ, TB, NW, DROP>), grid, block, 0, st, p);
-            hipLaunchKernelGGL((attn_bwd_dkv_kernel<D, TQ, TB, NW, DROP>), grid, block, 0, st, p);
+            static const int cap_q = blocks_per_cu(attn_bwd_dq_kernel<D, TQ, TB, NW, DROP>, NW * 64);
+            static const int cap_k = blocks_per_cu(attn_bwd_dkv_kernel<D, TQ, TB, NW, DROP>, NW * 64);
+            const int nq0 = ((p.T + 31) / 32 + NW - 1) / NW;
+            p.nq = ATTN_BWD_EVEN ? choose_nq(GH, p.T, NW, cap_q, cu_count()) : nq0;
+            hipLaunchKernelGGL((attn_bwd_dq_kernel<D, TQ, TB, NW, DROP>), dim3(GH * p.nq), block, 0, st, p);
+            p.nq = ATTN_BWD_EVEN ? choose_nq(GH, p.T, NW, cap_k, cu_count()) : nq0;
+            hipLaunchKernelGGL((attn_bwd_dkv_kernel<D, TQ, TB, NW, DROP>), dim3(GH * p.nq), block, 0, st, p);
         }
         return hipGetLastError();
     }
-    if (PASS == FWD) hipLaunchKernelGGL((attn_fwd_kernel<D, TQ, TB, NW, DROP>), grid, block, 0, st, p);
-    else if (PASS == BWD_DQ) hipLaunchKernelGGL((attn_bwd_dq_kernel<D, TQ, TB, NW, DROP>), grid, block, 0, st, p);
-    else hipLaunchKernelGGL((attn_bwd_dkv_kernel<D, TQ, TB, NW, DROP>), grid, block, 0, st, p);
+    if (PASS == FWD) {
+        static const int cap = blocks_per_cu(attn_fwd_kernel<D, TQ, TB, NW, DROP>, NW * 64);
+        p.nq = NW < 4 ? ((p.T + 31) / 32 + NW - 1) / NW : choose_nq(GH, p.T, NW, cap, cu_count());
+        hipLaunchKernelGGL((attn_fwd_kernel<D, TQ, TB, NW, DROP>), dim3(GH * p.nq), block, 0, st, p);
+    } else if (PASS == BWD_DQ) {
+        p.nq = ((p.T + 31) / 32 + NW - 1) / NW;
+        hipLaunchKernelGGL((attn_bwd_dq_kernel<D, TQ, TB, NW, DROP>), dim3(GH * p.nq), block, 0, st, p);
+    } else {
+        p.nq = ((p.T + 31) / 32 + NW - 1) / NW;
+        hipLaunchKernelGGL((attn_bwd_dkv_kernel<D, TQ, TB, NW, DROP>), dim3(GH * p.nq), block, 0, st, p);
+    }
     return hipGetLastError();
 }
 

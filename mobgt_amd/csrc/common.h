@@ -136,6 +136,15 @@ __host__ __device__ __forceinline__ uint32_t attn_drop_word(uint32_t hb, uint32_
 // thr_s = (int)dropout_threshold(p) - 32768
 __host__ __device__ __forceinline__ bool attn_drop_keep_even(uint32_t w, int thr_s) { return (int)(int16_t)(w & 0xffffu) >= thr_s; }
 __host__ __device__ __forceinline__ bool attn_drop_keep_odd(uint32_t w, int thr_s) { return (int)w >= thr_s * 65536; }
+// Both decisions of a pair word at once, as a mask for the PACKED pair (0xffff over a kept half): per 16-bit half,
+// saturating (thr_s - 1) - w is negative exactly when w >= thr_s; the arithmetic shift by 15 spreads the sign.
+typedef short mobgt_i16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t attn_drop_keep_mask2(uint32_t w, int thr_s) {
+    const short t1 = (short)(thr_s - 1);
+    const mobgt_i16x2 tv = {t1, t1};
+    const mobgt_i16x2 d = __builtin_elementwise_sub_sat(tv, __builtin_bit_cast(mobgt_i16x2, w));
+    return __builtin_bit_cast(uint32_t, d >> 15);
+}
 __host__ __device__ __forceinline__ bool attn_drop_keep(uint64_t seed, uint32_t row_hash, uint32_t key, int thr_s) {
     const uint32_t w = attn_drop_word(attn_drop_block(seed, row_hash, key >> 4), attn_drop_mult((int)((key & 15u) >> 1)));
     return (key & 1u) ? attn_drop_keep_odd(w, thr_s) : attn_drop_keep_even(w, thr_s);

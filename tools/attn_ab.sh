@@ -1,23 +1,14 @@
 #!/bin/bash
-# Developer tool (GPU box): A/B of two builds of the library on the c5-shape attention kernels, interleaved (box-to-box and
-# run-to-run spread is larger than the effects looked for).  mobgt_amd/libmobgt_hip_base.so = the baseline build.
-cd /tmp && export TMPDIR=/tmp
-cd "$GRAFT_REPO_ROOT"
-for rep in 1 2; do
-for which in base new; do
-  if [ $which = base ]; then export MOBGT_HIP_LIB=$GRAFT_REPO_ROOT/mobgt_amd/libmobgt_hip_base.so; else unset MOBGT_HIP_LIB; fi
-  REPS=10 P=0.1 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/ab_$which -o r -- python3 tools/attn_bwd_bench.py > /dev/null 2>&1
-  f=$(find gpurun_out/ab_$which -name "r_kernel_stats.csv" | head -1)
-  python3 - "$f" "$which" <<'PY'
-import csv, sys
-out = []
-for r in csv.DictReader(open(sys.argv[1])):
-    n = r["Name"]
-    if "attn" in n:
-        k = "fwd" if "attn_fwd" in n else ("dq" if "bwd_dq" in n else "dkv")
-        out.append("%s %.1f" % (k, float(r["AverageNs"]) / 1e3))
-print(sys.argv[2], " ".join(sorted(out)))
-PY
-  rm -rf gpurun_out/ab_$which
-done
+# Developer tool (build container): variant libraries of the attention kernels for an interleaved A/B on ONE box.
+#   tools/attn_ab.sh name1 "-DFLAG=.." name2 "-DFLAG=.." ...   ->  mobgt_amd/libmobgt_hip_ab_<name>.so each
+# then on the GPU box: python tools/attn_ab.py name1 name2 ...  (the shipped library is always variant "ship")
+set -e
+cd "$(dirname "$0")/../mobgt_amd/csrc"
+FLAGS="-O3 -std=c++17 -fPIC -I../../include --offload-arch=gfx950 -Wno-unused-function -mllvm -amdgpu-mfma-vgpr-form=1 -fno-slp-vectorize"
+OBJS=$(ls *.o | grep -v '^attn.o$')
+while [ $# -ge 2 ]; do
+  /opt/rocm/bin/hipcc $FLAGS $2 -c attn.hip -o /tmp/attn_ab_$1.o
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../libmobgt_hip_ab_$1.so /tmp/attn_ab_$1.o $OBJS
+  echo built libmobgt_hip_ab_$1.so "($2)"
+  shift 2
 done
