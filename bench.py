@@ -28,6 +28,9 @@ def parse():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", choices=["fsq", "gow", "big"], default="fsq")
+    ap.add_argument("--variant", choices=["fq", "stock"], default="fq",
+                    help="fq: model_fqandtoyo.Graphormer (what entry.py trains; the headline); stock: graphormer/model.py's "
+                         "pre-LN Graphormer (C = 128, d = 16) on the same trajectories")
     ap.add_argument("--batch-size", type=int, default=16)
     ap.add_argument("--n-batches", type=int, default=None, help="distinct pre-collated batches cycled through (default 8; big: 2)")
     ap.add_argument("--pois", type=int, default=None, help="override the workload's POI count")
@@ -406,6 +409,55 @@ def cpu_baseline(model, batches, pools, uni, args, n_layers):
                        f"({cores} usable cores), after warm-up; {total:.1f} s of CPU work")
 
 
+def cpu_baseline_stock(model, batches, args, n_layers):
+    """--variant stock: the oracle's model.py restatement (oracle.graphormer_stock_forward) + cross_entropy + AdamW on the host."""
+    from oracle import model_oracle as mo
+    import torch.nn.functional as F
+    sd = {k: v.detach().float().cpu().clone().requires_grad_(True) for k, v in model.state_dict().items()}
+    opt = torch.optim.AdamW(list(sd.values()), lr=2e-4, weight_decay=0.01)
+    cb = _cpu_batches(batches)
+    G = len(cb[0].y)
+    cores = usable_cores()
+    torch.set_num_threads(min(8, cores))
+
+    def one_step(i):
+        b = cb[i % len(cb)]
+        t0 = time.perf_counter()
+        opt.zero_grad(set_to_none=True)
+        logits = mo.graphormer_stock_forward(sd, b, n_layers, 8, 20, p=0.1, p_in=0.1, p_att=0.1, training=True)
+        F.cross_entropy(logits, b.y.view(-1), ignore_index=0).backward()
+        opt.step()
+        return time.perf_counter() - t0
+    one_step(0)
+    n, used = 0, 0.0
+    while (n < 3 or used < args.cpu_seconds) and n < 60:
+        used += one_step(n)
+        n += 1
+    return dict(value=G * n / used, unit="check-ins/s", cores=min(8, cores), kind="port",
+                sample=f"{n} train steps (fwd+cross_entropy+bwd+AdamW, fp32, train mode) of the oracle's model.py restatement "
+                       f"on the same pre-collated batches at {min(8, cores)} torch threads; {used:.1f} s of CPU work")
+
+
+def oracle_parity_stock(model, batches, n_layers):
+    """--variant stock: eval-mode logits and loss of the timed model vs oracle.graphormer_stock_forward on batch 0."""
+    from oracle import model_oracle as mo
+    import torch.nn.functional as F
+    was = model.training
+    model.eval()
+    try:
+        with torch.no_grad():
+            logits = model(batches[0]).float().cpu()
+            loss = float(model.training_step(batches[0], 0))
+            sd = {k: v.detach().float().cpu() for k, v in model.state_dict().items()}
+            b = _cpu_batches(batches[:1])[0]
+            ref = mo.graphormer_stock_forward(sd, b, n_layers, 8, 20)
+            ref_loss = float(F.cross_entropy(ref, b.y.view(-1), ignore_index=0))
+        return dict(loss_hip=loss, loss_oracle=ref_loss, max_abs_logit_err=float((logits - ref).abs().max()),
+                    max_abs_logit=float(ref.abs().max()), mode="eval (dropout off), batch 0, weights after the timed steps")
+    finally:
+        model.train(was)
+
+
 def oracle_parity(model, batches, uni, n_layers):
     """One eval-mode forward + training_step loss of the timed model vs the oracle (fp32, CPU) on batch 0."""
     from oracle import model_oracle as mo
@@ -456,7 +508,8 @@ def main():
     bf16 = args.dtype == "bf16"
     n_batches = args.n_batches or (2 if name == "big" else 8)
     uni, model, coll = workloads.build(name, dev, seed=args.seed, dtype=args.dtype, gemm_dtype=args.gemm_dtype,
-                                       fused=not args.unfused, P=args.pois)
+                                       fused=not args.unfused, P=args.pois, variant=args.variant)
+    stock = args.variant == "stock"
     broadcast_parameters(model)
     # Length-bucketed sharding (SURVEY §8e hazard): every rank draws the SAME pool of world x n_batches batches,
     # the pool is ordered by padded size and dealt round-robin, so that at each synchronous step all ranks work
@@ -549,7 +602,7 @@ def main():
 
     if rank == 0:
         m = w["model"]
-        H, C = m["num_heads"], m["hidden_dim"] + 64
+        H, C = m["num_heads"], m["hidden_dim"] + (0 if stock else 64)
         d = C // H
         io_dt = torch.bfloat16 if (bf16 and args.gemm_dtype == "bf16") else torch.float32
         b_dt = torch.bfloat16 if bf16 else torch.float32
@@ -598,7 +651,7 @@ def main():
         # ... and the kernel that now takes the largest share of the timed step: the row-local chain of an encoder layer
         roofc = None
         F = m["ffn_dim"]
-        if io_dt == torch.bfloat16 and (C, F) in ((192, 1024), (256, 1024)) and not args.unfused:
+        if io_dt == torch.bfloat16 and (C, F) in ((192, 1024), (256, 1024)) and not args.unfused and not stock:
             rows = sorted(set(g * t for g, t in used))
             durc = {r: time_chain(r, C, F, reps=50 if r < 4096 else 10, p_drop=m["dropout_rate"]) for r in rows}
             tb = sum(chain_fwd_bytes(g * t, C, F) for g, t in used)
@@ -642,23 +695,24 @@ def main():
         # forward + loss + backward + AdamW] as one graph per shape bucket).  Secondary metric of SURVEY 8(d): check-ins/s
         # INCLUDING collate / preprocess; its CPU counterpart is cpu_baseline.with_collate.
         with_collate = None
-        if world == 1 and not args.no_loop and not args.no_graph:
+        if world == 1 and not args.no_loop and not args.no_graph and not stock:
             try:
                 with_collate = time_epoch_loop(model, coll, name, uni, args)
             except Exception as e:                       # never lose the headline line over the secondary figure
                 with_collate = dict(error=repr(e))
         parity = None
         if not args.no_parity and uni.distance is not None:
-            parity = oracle_parity(model, batches, uni, n_layers)
+            parity = oracle_parity_stock(model, batches, n_layers) if stock else oracle_parity(model, batches, uni, n_layers)
         cpu = None
         if not args.no_cpu_baseline and uni.distance is not None:
-            cpu = cpu_baseline(model, batches, [t for _, _, t in mine], uni, args, n_layers)
+            cpu = (cpu_baseline_stock(model, batches, args, n_layers) if stock
+                   else cpu_baseline(model, batches, [t for _, _, t in mine], uni, args, n_layers))
         G_total = args.batch_size * world
         out = {
             "metric": "check-ins/sec (train step)", "value": G_total * args.steps / elapsed, "unit": "check-ins/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": workloads.describe(name, args.pois),
+            "config": {"workload": workloads.describe(name, args.pois, args.variant), "variant": args.variant,
                        "global_batch": G_total, "per_gpu_batch": args.batch_size,
                        "padded_nodes_per_batch": [s[1] - 1 for s in shapes], "parallelism": f"dp{world}",
                        "gemm_autotune": "torch TunableOp (hipBLASLt algorithm per shape)" if os.environ.get("PYTORCH_TUNABLEOP_ENABLED") == "1" else "off",

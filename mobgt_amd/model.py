@@ -335,10 +335,12 @@ class Graphormer(nn.Module):
     def __init__(self, n_layers, num_heads, hidden_dim, dropout_rate, intput_dropout_rate, weight_decay, ffn_dim,
                  dataset_name, warmup_updates, tot_updates, peak_lr, end_lr, edge_type, multi_hop_max_dist,
                  attention_dropout_rate, num_class=1, bias_dtype=torch.float32, act_dtype=torch.float32, fused_layers=True,
-                 **_unused):
+                 num_atoms=512 * 9 + 1, **_unused):
+        """`num_atoms`: rows of `atom_encoder` (model.py:44 hard-codes 512 * 9 + 1, the OGB atom vocabulary; a POI universe
+        larger than that -- bench.py --variant stock -- needs one row per POI id)."""
         super().__init__()
         self.num_heads = num_heads
-        self.atom_encoder = nn.Embedding(512 * 9 + 1, hidden_dim, padding_idx=0)
+        self.atom_encoder = nn.Embedding(num_atoms, hidden_dim, padding_idx=0)
         self.edge_encoder = nn.Embedding(512 * 3 + 1, num_heads, padding_idx=0)
         self.edge_type = edge_type
         if self.edge_type == "multi_hop":
@@ -393,5 +395,15 @@ class Graphormer(nn.Module):
         output = ops.dropout(torch.cat([graph_token_feature, node_feature], dim=1), self.input_dropout.p, self.training, 0x1003)
         for enc_layer in self.layers:
             output = enc_layer(output, bias, mask=None)
-        output = self.final_ln(output)
-        return self.downstream_out_proj(output[:, 0, :])
+        self._enc_out = output
+        # (model.py:211-217 normalises every token and then reads the graph token: LayerNorm is per row, so only that row is
+        # normalised here -- same value, same gradient)
+        return self.downstream_out_proj(self.final_ln(output[:, 0, :]))
+
+    head_modules = ("final_ln", "downstream_out_proj")
+
+    def training_step(self, batched_data, batch_idx=0):
+        """model.py:218-285, the generic branch (`loss_fn(y_hat, y_gt)`), with the POI datasets' loss of data.py:76 / :98:
+        NLLLoss(ignore_index=0) on log-probabilities over the classes == cross_entropy(ignore_index=0) on the logits."""
+        logits = self(batched_data)
+        return F.cross_entropy(logits.float(), batched_data.y.view(-1).long(), ignore_index=0)

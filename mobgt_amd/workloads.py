@@ -80,9 +80,14 @@ def make_pool(name, n_batches, G, uni, seed0=1000):
     return pool
 
 
-def build(name, device, seed=1, dtype="bf16", gemm_dtype="bf16", fused=True, P=None, model_overrides=None):
+def build(name, device, seed=1, dtype="bf16", gemm_dtype="bf16", fused=True, P=None, model_overrides=None, variant="fq"):
     """(universe, model on `device`, DeviceCollator) for workload `name`.  dtype "bf16": attention operands / bias /
-    GCN adjacency product in bf16; gemm_dtype "bf16": the encoder layers' GEMM-facing activations too."""
+    GCN adjacency product in bf16; gemm_dtype "bf16": the encoder layers' GEMM-facing activations too.
+    variant "stock": `graphormer/model.py`'s Graphormer (pre-LN EncoderLayer, C = hidden_dim = 128, d = 16 -- the layer
+    BASELINE.json's north_star names) on the same trajectories: atom / degree embeddings, the same bias assembly without
+    the distance-bin table, a (P + 1)-way head on the graph token.  The reference itself cannot run model.py on the POI
+    datasets (data.py:74 leaves `num_class` out; entry.py:10 imports model_fqandtoyo): the variant exists to time and
+    check the stock layer stack under MobGT's batch shapes."""
     from .data import DeviceCollator, make_bin_table
     from .model_fqandtoyo import Graphormer
     w = WORKLOADS[name]
@@ -91,6 +96,17 @@ def build(name, device, seed=1, dtype="bf16", gemm_dtype="bf16", fused=True, P=N
     torch.manual_seed(seed)
     args = dict(w["model"])
     args.update(model_overrides or {})
+    if variant == "stock":
+        from .model import Graphormer as StockGraphormer
+        if name == "big":
+            raise ValueError("variant 'stock' is defined for the fsq / gow workloads")
+        uni = synth.make_universe(P=P, n_cat=w["n_cat"], n_user=w["n_user"], seed=seed)
+        _, _, table = make_bin_table(uni.distance)
+        model = StockGraphormer(num_class=P + 1, num_atoms=P + 1, bias_dtype=torch.bfloat16 if bf16 else torch.float32,
+                                act_dtype=torch.bfloat16 if (bf16 and gemm_dtype == "bf16") else torch.float32,
+                                fused_layers=fused, **args).to(device)
+        coll = DeviceCollator(device, bin_table=table, multi_hop_max_dist=20, rel_pos_max=1024)
+        return uni, model, coll
     kw = dict(bias_dtype=torch.bfloat16 if bf16 else torch.float32, gcn_dtype=torch.bfloat16 if bf16 else torch.float32,
               act_dtype=torch.bfloat16 if (bf16 and gemm_dtype == "bf16") else torch.float32, fused_layers=fused)
     if name == "big":
@@ -105,9 +121,14 @@ def build(name, device, seed=1, dtype="bf16", gemm_dtype="bf16", fused=True, P=N
     return uni, model, coll
 
 
-def describe(name, P=None):
+def describe(name, P=None, variant="fq"):
     w = WORKLOADS[name]
     m = w["model"]
+    if variant == "stock":
+        return ("%s trajectories on model.py's Graphormer (pre-LN EncoderLayer), P=%d, hidden %d (C=%d, d=%d), %d layers, %d heads, "
+                "ffn %d, multi_hop_max_dist %d, dropout %.1f, (P+1)-way head, fwd+cross_entropy+bwd+allreduce+AdamW"
+                % (w["label"], int(P or w["P"]), m["hidden_dim"], m["hidden_dim"], m["hidden_dim"] // m["num_heads"], m["n_layers"],
+                   m["num_heads"], m["ffn_dim"], m["multi_hop_max_dist"], m["dropout_rate"]))
     C = m["hidden_dim"] + 64
     return ("%s: model_fqandtoyo Graphormer, %s, P=%d, hidden %d (C=%d, d=%d), %d layers, %d heads, ffn %d, "
             "multi_hop_max_dist %d, dropout %.1f, fwd+GradientTailLoss+bwd+allreduce+AdamW"

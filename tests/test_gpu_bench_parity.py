@@ -202,3 +202,46 @@ def test_rows_only_gcn_layer_vs_oracle_gcn_rows():
     for r in report:
         print("%-20s rms_nz %.3e  relL2 %.4f  q999 %.3f  max %.3f  stray %.1e" % r)
     assert ok, report
+
+
+def test_stock_variant_of_the_bench_vs_oracle_and_through_trainstep():
+    """`bench.py --variant stock`: graphormer/model.py's pre-LN Graphormer (C 128, d 16, 6 layers) on S-FSQ batches, bf16
+    fused layers: eval logits / cross-entropy loss / elementwise gradients vs oracle.graphormer_stock_forward
+    (model.py:111-217, 463-489), then two hipGraph-replayed TrainStep steps with dropout on (finite, parameters move)."""
+    import torch.nn.functional as F
+    from mobgt_amd.train import TrainStep
+    uni, model, coll = workloads.build("fsq", DEV, seed=1, variant="stock")
+    batches = [coll(t) for t in workloads.make_pool("fsq", 2, 16, uni)]
+    model.eval()
+    sd0 = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    b = cpu_batch(batches[0])
+    sd = {k: v.detach().float().cpu().clone().requires_grad_(True) for k, v in sd0.items()}
+    ref = mo.graphormer_stock_forward(sd, b, 6, 8, 20)
+    ref_loss = F.cross_entropy(ref, b.y.view(-1), ignore_index=0)
+    ref_loss.backward()
+    logits = model(batches[0])
+    err = float((logits.detach().float().cpu() - ref.detach()).abs().max())
+    assert err <= 3e-2 * max(1.0, float(ref.detach().abs().max())), err
+    loss = model.training_step(batches[0], 0)
+    np.testing.assert_allclose(float(loss.detach()), float(ref_loss.detach()), rtol=2e-3)
+    loss.backward()
+    params = dict(model.named_parameters())
+    report, ok = [], True
+    for name in ("downstream_out_proj.weight", "layers.0.self_attention.linear_q.weight", "layers.5.ffn.layer2.weight",
+                 "layers.3.self_attention_norm.weight", "layers.2.ffn_norm.bias", "rel_pos_encoder.weight", "edge_encoder.weight",
+                 "edge_dis_encoder.weight", "atom_encoder.weight", "in_degree_encoder.weight", "graph_token.weight", "final_ln.weight"):
+        ok &= check_grad(name, params[name].grad, sd[name].grad, report)
+    for r in report:
+        print("%-48s rms_nz %.3e  relL2 %.4f  q999 %.3f  max %.3f  stray %.1e" % r)
+    assert ok, bad_rows(report)
+    # (the eager autograd graph above was built on the default stream: let go of it before anything is captured on
+    # TrainStep's stream -- AccumulateGrad nodes bound to another stream abort the capture)
+    del loss, logits, params
+    for prm in model.parameters():
+        prm.grad = None
+    model.train()
+    ts = TrainStep(model, batches, use_graph=True, seed=1)
+    ts.prepare()
+    p0 = ts.flat_params.tensor.detach().clone()
+    losses = [float(ts.step(i)) for i in range(2)]
+    assert all(np.isfinite(losses)) and float((ts.flat_params.tensor.detach() - p0).abs().max()) > 0
