@@ -200,7 +200,8 @@ def assert_same_across_ranks(digest, what, device=None):
 
 
 class TrainStep:
-    def __init__(self, model, batches, autocast_dtype=None, use_graph=True, seed=1, overlap=True, batch_fn=None):
+    def __init__(self, model, batches, autocast_dtype=None, use_graph=True, seed=1, overlap=True, batch_fn=None,
+                 grad_comm_dtype=None):
         """`batches`: pre-collated batches resident on the device (their tensors are the static inputs of the captured
         graphs).  `batch_fn`: optional callable applied to a batch INSIDE the step (and so inside its graph) before the model
         sees it -- `EpochLoop` passes raw, un-collated arrays + `DeviceCollator.finish`, so that collating a fresh batch is
@@ -208,6 +209,10 @@ class TrainStep:
         self.model = model
         self.batches = list(batches)
         self.batch_fn = batch_fn
+        # torch.bfloat16: the gradient exchange moves bf16 (half the bytes over xGMI; RCCL then also SUMS in bf16 -- 8 ranks:
+        # relative error ~2^-8 per element on top of the gradient's own bf16-operand noise); the result is widened back
+        # into the fp32 flat buffer the optimizer reads.  Default None: fp32 exchange (what the parity tests pin).
+        self.grad_comm_dtype = grad_comm_dtype
         self.autocast_dtype = autocast_dtype
         dev = next(model.parameters()).device
         self.device = dev
@@ -284,6 +289,8 @@ class TrainStep:
         self.graphs_b, self._g_enc, self._loss_slots = {}, {}, {}
         self.comm = True        # False: skip the gradient exchange (bench.py measures the exposed all-reduce time that way)
         self._prepared = False
+        self.comm_buf = (torch.empty(self.flat.flat.numel(), dtype=grad_comm_dtype, device=dev)
+                         if (grad_comm_dtype is not None and self.world > 1) else None)
         self.check_layout_across_ranks()
 
     def layout_digest(self):
@@ -519,21 +526,34 @@ class TrainStep:
             na = self.n_head_elems
             comm = self.world > 1 and self.comm
             self.graphs[j].replay()
+            cb = self.comm_buf
             if comm:
-                wa = dist.all_reduce(self.flat.flat[:na], op=dist.ReduceOp.SUM, async_op=True)   # overlaps phase B
+                if cb is not None:
+                    cb[:na].copy_(self.flat.flat[:na])
+                wa = dist.all_reduce((cb if cb is not None else self.flat.flat)[:na], op=dist.ReduceOp.SUM, async_op=True)   # overlaps phase B
             self.graphs_b[j].replay()
             if comm:
-                wb = dist.all_reduce(self.flat.flat[na:], op=dist.ReduceOp.SUM, async_op=True)
+                if cb is not None:
+                    cb[na:].copy_(self.flat.flat[na:])
+                wb = dist.all_reduce((cb if cb is not None else self.flat.flat)[na:], op=dist.ReduceOp.SUM, async_op=True)
                 wa.wait()
                 wb.wait()
-                self.flat.flat.div_(self.world)
+                if cb is not None:
+                    torch.mul(cb, 1.0 / self.world, out=self.flat.flat)          # widen + average in one pass
+                else:
+                    self.flat.flat.div_(self.world)
         else:
             if self.use_graph:
                 self.graphs[i % len(self.batches)].replay()
             else:
                 self._fwd_bwd(self.batches[i % len(self.batches)])
             if self.world > 1 and self.comm:
-                self.flat.all_reduce_mean()
+                if self.comm_buf is not None:
+                    self.comm_buf.copy_(self.flat.flat)
+                    dist.all_reduce(self.comm_buf, op=dist.ReduceOp.SUM)
+                    torch.mul(self.comm_buf, 1.0 / self.world, out=self.flat.flat)
+                else:
+                    self.flat.all_reduce_mean()
         if self.use_graph:
             if not getattr(self, "fused_opt", False):
                 self.opt_graph.replay()

@@ -40,7 +40,8 @@ def main():
     coll = DeviceCollator(dev, bin_table=table)
     batches = [coll(synth.make_batch_of_trajectories(seed=10 + 7 * rank + i, G=4, P=400, n_user=1080, cat_of_poi=uni.cat_of_poi))
                for i in range(2)]                         # different data per rank
-    ts = TrainStep(model, batches, use_graph=True, seed=5)
+    comm = os.environ.get("MOBGT_TEST_GRAD_COMM")
+    ts = TrainStep(model, batches, use_graph=True, seed=5, grad_comm_dtype=torch.bfloat16 if comm == "bf16" else None)
     ts.prepare()
     losses = [float(ts.step(i)) for i in range(steps)]
     torch.cuda.synchronize()

@@ -108,6 +108,47 @@ def _free_port():
     return p
 
 
+def _run_two_ranks(tmp_path, steps, extra_env=None):
+    port = _free_port()
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY="0", **(extra_env or {}))
+        procs.append(subprocess.Popen([sys.executable, os.path.join(os.path.dirname(__file__), "_ddp_worker.py"), str(tmp_path), str(steps)],
+                                      env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    outs = []
+    for p in procs:
+        try:
+            o, _ = p.communicate(timeout=600)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        outs.append(o.decode(errors="replace"))
+    assert all(p.returncode == 0 for p in procs), "\n".join(outs)
+    return [torch.load(os.path.join(tmp_path, f"rank{r}.pt")) for r in range(2)]
+
+
+def test_bf16_gradient_exchange_tracks_the_fp32_exchange(tmp_path):
+    """`TrainStep(grad_comm_dtype=torch.bfloat16)` (half the all-reduce bytes): replicas stay bit-identical, and after three
+    steps the parameters are those of the fp32 exchange up to bf16 rounding of the exchanged gradients: the update per step
+    is lr * m_hat / sqrt(v_hat) ~ lr (AdamW normalises the gradient scale away), so a relative gradient error of 2^-8 moves
+    a parameter by ~lr * 2^-8; bound: 5 % of the total parameter movement."""
+    d32, d16 = tmp_path / "f32", tmp_path / "bf16"
+    d32.mkdir()
+    d16.mkdir()
+    a32, _ = _run_two_ranks(d32, 3)
+    a16, b16 = _run_two_ranks(d16, 3, {"MOBGT_TEST_GRAD_COMM": "bf16"})
+    for k in ("params", "exp_avg", "exp_avg_sq", "grads"):
+        assert torch.equal(a16[k], b16[k]), k
+    rel_g = float((a16["grads"] - a32["grads"]).norm() / a32["grads"].norm())
+    assert rel_g < 5e-2, rel_g      # (third-step gradients after two slightly different updates; same dropout masks; measured 2.1 %)
+    dp = float((a16["params"] - a32["params"]).norm())
+    # the worker's schedule (peak 1e-3, 4 warm-up updates): lr = 2.5e-4, 5e-4, 7.5e-4 -> every parameter moves by <= 1.5e-3
+    n = a32["params"].numel()
+    assert dp < 0.05 * 1.5e-3 * n ** 0.5, (dp, n)
+
+
 def test_two_rank_train_step_keeps_replicas_identical(tmp_path):
     """Two data-parallel ranks of TrainStep (RCCL when the box has two GPUs, otherwise gloo with both ranks on cuda:0):
     after three steps on different per-rank data every rank holds bit-identical parameters, Adam moments and bf16
