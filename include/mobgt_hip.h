@@ -190,6 +190,14 @@ int mobgt_spd_batched(const int32_t* counts, const int32_t* n_nodes,
                       int16_t* in_degree, int16_t* out_degree, void* work,
                       int G, int N, int D, void* stream);
 
+/* The elementwise remainder of collator_foursquare / collator_gowalla on the device (collator.py:57-64, 354-358, 428-437):
+ * attn_bias [G, N+1, N+1] f32 = 0 for key columns 0..n_nodes[g], -inf beyond (and -inf where spd >= rel_pos_max when
+ * rel_pos_max <= 510); poi_pos [G, N, N] int16 = bin_table[x_i, x_j] for real pairs (x != 0), 0 otherwise.
+ * x [G, N] int32 POI ids (0 = pad); spd [G, N, N] int16 (mobgt_spd_batched); bin_table [*, ld_bin] int16 or NULL (then
+ * poi_pos = 0). */
+int mobgt_collate_finish(const int32_t* x, const int32_t* n_nodes, const int16_t* spd, const int16_t* bin_table,
+                         int64_t ld_bin, int rel_pos_max, float* attn_bias, int16_t* poi_pos, int G, int N, void* stream);
+
 
 /* Single-graph entry points with the reference's own call signatures, for the per-item drop-in path
  * (wrapper.py:55-60 calls algos.floyd_warshall(adj) and algos.gen_edge_input(max_dist, path, edge_feat)).

@@ -33,6 +33,7 @@ SIGNATURES = {
     "mobgt_spd_workspace_bytes": (_i64, [_i, _i]),
     "mobgt_spd_batched": (_i, [_vp] * 9 + [_i, _i, _i, _vp]),
     "mobgt_spd_set_spin_limit": (_i, [_i64]),
+    "mobgt_collate_finish": (_i, [_vp, _vp, _vp, _vp, _i64, _i, _vp, _vp, _i, _i, _vp]),
     "mobgt_floyd_warshall_workspace_bytes": (_i64, [_i]),
     "mobgt_floyd_warshall": (_i, [_vp, _i, _vp, _vp, _vp, _vp]),
     "mobgt_gen_edge_input": (_i, [_i, _vp, _vp, _i, _i, _vp, _vp, _vp]),

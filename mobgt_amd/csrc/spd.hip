@@ -388,6 +388,42 @@ extern "C" int mobgt_spd_batched(const int32_t* counts, const int32_t* n_nodes, 
 }
 
 // ------------------------------------------------------------------------------------------------
+// The rest of the fq collators' device work in ONE launch (collator.py:57-64 padding mask of attn_bias, :354-358 the
+// rel_pos_max cut, :428-437 poi_pos = distance bin of (x_i, x_j) on real pairs): ~10 elementwise / index launches of
+// data.DeviceCollator.finish before round 3, which matters now that the collate runs inside every replayed step.
+namespace {
+__global__ __launch_bounds__(256) void collate_finish_kernel(const int32_t* __restrict__ x, const int32_t* __restrict__ n_nodes,
+                                                             const int16_t* __restrict__ spd, const int16_t* __restrict__ bin_table,
+                                                             int64_t ld_bin, int rel_pos_max, float* __restrict__ attn_bias,
+                                                             int16_t* __restrict__ poi_pos, int G, int N) {
+    const int T = N + 1, g = blockIdx.y;
+    const int n = n_nodes[g];
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < (int64_t)T * T; e += (int64_t)gridDim.x * 256) {
+        const int i = (int)(e / T), j = (int)(e - (int64_t)i * T);
+        float ab = j <= n ? 0.f : -INFINITY;                                   // token 0 + n real nodes are keys
+        if (i >= 1 && j >= 1) {
+            const int64_t pair = ((int64_t)g * N + (i - 1)) * N + (j - 1);
+            if (rel_pos_max <= 510 && spd[pair] >= rel_pos_max) ab = -INFINITY;
+            const int xi = x[(int64_t)g * N + (i - 1)], xj = x[(int64_t)g * N + (j - 1)];
+            poi_pos[pair] = (bin_table && xi != 0 && xj != 0) ? bin_table[(int64_t)xi * ld_bin + xj] : (int16_t)0;
+        }
+        attn_bias[(int64_t)g * T * T + e] = ab;
+    }
+}
+}  // namespace
+
+extern "C" int mobgt_collate_finish(const int32_t* x, const int32_t* n_nodes, const int16_t* spd, const int16_t* bin_table,
+                                    int64_t ld_bin, int rel_pos_max, float* attn_bias, int16_t* poi_pos, int G, int N,
+                                    void* stream) {
+    if (G <= 0 || N <= 0) return MOBGT_EBADDIM;
+    const int64_t tt = (int64_t)(N + 1) * (N + 1);
+    const unsigned bx = (unsigned)((tt + 1023) / 1024 < 1 ? 1 : ((tt + 1023) / 1024 > 1024 ? 1024 : (tt + 1023) / 1024));
+    hipLaunchKernelGGL(collate_finish_kernel, dim3(bx, G), dim3(256), 0, (hipStream_t)stream, x, n_nodes, spd, bin_table, ld_bin,
+                       rel_pos_max, attn_bias, poi_pos, G, N);
+    return (int)hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
 // Single-graph entry points with the reference's own call signatures (algos.pyx:9, :65), for the
 // per-item drop-in path (wrapper.py:55-60).  Unlike the batched kernels above they take an ARBITRARY
 // path matrix / feature tensor and emit up to max_dist hops, as gen_edge_input does.

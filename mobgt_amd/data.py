@@ -137,6 +137,22 @@ class DeviceCollator:
         G, N = counts.shape[:2]
         T = N + 1
         sp = ops.spd_batched(counts, n_nodes, self.D)
+        x = d["x"]
+        if (self.coords is None and x.dtype == torch.int32 and n_nodes.dtype == torch.int32 and x.is_contiguous()
+                and (self.bin_table is None or (self.bin_table.dtype == torch.int16 and self.bin_table.is_contiguous()))):
+            # padding mask, rel_pos_max cut and the distance-bin gather in one launch (mobgt_collate_finish)
+            from . import _lib
+            from .ops import _p, _stream
+            attn_bias = torch.empty(G, T, T, device=self.device)
+            poi_pos = torch.empty(G, N, N, dtype=torch.int16, device=self.device)
+            bt = self.bin_table
+            _lib.check(_lib.lib().mobgt_collate_finish(_p(x), _p(n_nodes), _p(sp["spd"]), _p(bt), bt.shape[1] if bt is not None else 0,
+                                                       self.rel_pos_max, _p(attn_bias), _p(poi_pos), G, N, _stream()),
+                       "mobgt_collate_finish")
+            return DeviceBatch1(counts, n_nodes, idx=d["idx"], attn_bias=attn_bias, rel_pos=sp["rel_pos"],
+                                in_degree=sp["in_degree"], out_degree=sp["out_degree"], x=x, edge_input=sp["edge_input"],
+                                y=d["y"], time=d["time"], time_normal=d["time_normal"], user=d["user"], cat=d["cat"],
+                                poi_pos=poi_pos)
         ar = torch.arange(T, device=self.device)
         real_tok = ar.view(1, T) <= n_nodes.view(G, 1)                # token 0 + n real nodes
         attn_bias = torch.zeros(G, T, T, device=self.device)
@@ -144,7 +160,6 @@ class DeviceCollator:
         if self.rel_pos_max <= 510:                                                  # collator.py:354-358
             far = sp["spd"] >= self.rel_pos_max
             attn_bias[:, 1:, 1:].masked_fill_(far, float("-inf"))
-        x = d["x"]
         if self.bin_table is not None:
             xi = x[:, :, 0].long()
             poi_pos = self.bin_table[xi.unsqueeze(2), xi.unsqueeze(1)]

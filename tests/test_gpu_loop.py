@@ -75,6 +75,8 @@ def test_bucket_padded_batch_equals_the_unpadded_batch(fsq_small):
     np.testing.assert_allclose(lossb, lossa, rtol=1e-6)
     assert ga.keys() == gb.keys()
     for n in ga:
+        if n.endswith("linear_k.bias"):
+            continue            # exactly 0 in exact arithmetic (softmax is shift-invariant over keys): round-off on both sides
         scale = float(ga[n].abs().max())
         np.testing.assert_allclose(gb[n].numpy(), ga[n].numpy(), rtol=0, atol=2e-3 * scale + 1e-12, err_msg=n)
 
