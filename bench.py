@@ -681,7 +681,10 @@ def main():
             roof5 = dict(kernel="attn_fwd_kernel<DROP=true>", workload="c5 G16 T785 C256 d32, dropout 0.1", bound="hbm",
                          achieved=b5f / t5f / 1e9, peak=HBM_PEAK_GBS, unit="GB/s", frac=b5f / t5f / 1e9 / HBM_PEAK_GBS,
                          traffic=tr, mfma_busy_pct=mb, valu_busy_pct=e.get("valu_busy_pct"), wait_any_frac=e.get("wait_any_frac"),
-                         counters_source=src, avg_launch_us=t5f * 1e6, bytes_per_launch=b5f, input_sets_rotated=nset5)
+                         counters_source=src, avg_launch_us=t5f * 1e6, bytes_per_launch=b5f, input_sets_rotated=nset5,
+                         cache_state="all inputs rotated through > 768 MB: every launch reads cold HBM (a lower bound of the S-BIG "
+                                     "step, where the one bias all 12 layers share is partly still in the Infinity Cache: "
+                                     "profiles/r3_bench_big_step_summary.txt)")
             trq, mbq, srcq, _ = pmc_of(32, "dq", "c5_bwd_dq_drop_bf16")
             trk, mbk, _, _ = pmc_of(32, "dkv", "c5_bwd_dkv_drop_bf16")
             roof5b = dict(kernel="attn_bwd_dq_kernel + attn_bwd_dkv_kernel", workload="c5 G16 T785 C256 d32, dropout 0.1",
@@ -695,7 +698,10 @@ def main():
         # forward + loss + backward + AdamW] as one graph per shape bucket).  Secondary metric of SURVEY 8(d): check-ins/s
         # INCLUDING collate / preprocess; its CPU counterpart is cpu_baseline.with_collate.
         with_collate = None
-        if world == 1 and not args.no_loop and not args.no_graph and not stock:
+        # (not for `big`: its raw format -- the reference's pickles hold DENSE N x N int64 count matrices, gen_pickles.py:820-832 --
+        # is 16 x 784^2 x 8 B = 79 MB of host arrays per batch, and packing them takes the host 140 ms per step: a statement
+        # about numpy, not about this path)
+        if world == 1 and not args.no_loop and not args.no_graph and not stock and name != "big":
             try:
                 with_collate = time_epoch_loop(model, coll, name, uni, args)
             except Exception as e:                       # never lose the headline line over the secondary figure

@@ -416,6 +416,10 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const AttnParams p) {
                 const bf16x8 a = *reinterpret_cast<const bf16x8*>(&Ks[t * 32 + kappa(n)][ks * 16 + 8 * hi]);
                 s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, qf[ks], s, 0, 0, 0);
             }
+#ifdef ATTN_STAMP_FINE
+            { float d_; asm volatile("v_mov_b32 %0, %1" : "=v"(d_) : "v"(s[15])); asm volatile("" :: "v"(d_)); }
+            STAMP(1);                                      // bias tile from LDS + QK^T result available
+#endif
             // online softmax over this lane's 16 keys + the partner half's 16
             float tmax = s[0];
 #pragma unroll
@@ -467,6 +471,9 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const AttnParams p) {
                 const bf16x8 a = *reinterpret_cast<const bf16x8*>(&Vt[kappa(n)][t * 32 + 16 * hi + 8 * s2]);
                 o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, pb, o, 0, 0, 0);
             }
+#ifdef ATTN_STAMP_FINE
+            { float d_; asm volatile("v_mov_b32 %0, %1" : "=v"(d_) : "v"(o[15])); asm volatile("" :: "v"(d_)); }
+#endif
             STAMP(4 + t);                                  // one 32-key tile: QK^T, softmax, dropout, PV
         }
         if (PIPE) {

@@ -4,7 +4,12 @@
 * `FlatGrads`: every trainable parameter's `.grad` is a view into ONE flat fp32 buffer, so zeroing is one
   memset and the data-parallel exchange is ONE all-reduce (RCCL over xGMI).  Parameters the model never
   uses (25 tensors in the fq variant) keep `grad = None`, exactly as under the reference, so
-  AdamW skips them the same way.
+  AdamW skips them the same way.  DEVIATION (documented in DESIGN.md section 7): a parameter that is used by the model but
+  receives no gradient on ONE particular batch has a zero-filled slot that step and is updated like any other slot (weight
+  decay, moment decay, one global step count), where torch.optim.AdamW would skip it for that step and keep a per-parameter
+  step count.  In the fq / stock models every trained parameter is reached on every batch (tables are reached row-wise:
+  an untouched ROW has a zero gradient under the reference too), so the two agree; a model for which that does not hold
+  should use `configure_optimizers()` instead of the flat kernel.
 * `TrainStep`: forward + loss + backward (+ all-reduce) + AdamW + PolynomialDecayLR.  With
   `use_graph=True` the forward/backward and the optimizer step are captured in hipGraphs per batch
   (static shapes per pre-collated batch); the learning rate and the dropout seed live in device scalars

@@ -15,7 +15,7 @@ for _ in range(5):
     pack = ops.pack_bias(bias, G, H, T, dtype=torch.bfloat16)
     del bias
     sets.append((qkv, pack))
-names = ["bias wait+park", "(unused)", "K/V wait+store", "barrier", "tile 0", "tile 1", "-", "-"]
+names = ["bias wait+park", "(fine build: LDS bias + QK^T until S is available, both tiles)", "K/V wait+store", "barrier", "tile 0 (fine: rest)", "tile 1 (fine: rest)", "-", "-"]
 for rep in range(3):
     for qkv, pack in sets:
         out, lse = ops._attn_fwd(qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:], pack, d ** -0.5, 0.1, 1, None)
@@ -35,3 +35,12 @@ print("wave START times (us after the first): ", " ".join("%.0f:%d" % (edges[i],
 print("last wave ends %.1f us after the first starts; waves starting later than 5 us: %d" % (float(end.max()), int((st > 5).sum())))
 for k in range(6):
     print("%-16s median %8.0f cycles  %5.1f %%" % (names[k], rows[:, k].median(), 100 * float(rows[:, k].median() / tot.median())))
+# what makes a wave slow?
+import numpy as np
+stn, lifen = st.cpu().numpy(), (rows[:, 7] * 0.01).cpu().numpy()
+print("corr(start time, lifetime) = %.2f; corr(start, end) = %.2f" % (np.corrcoef(stn, lifen)[0, 1], np.corrcoef(stn, stn + lifen)[0, 1]))
+order = np.argsort(stn)
+for lo, hi in ((0, 0.25), (0.25, 0.5), (0.5, 0.75), (0.75, 1.0)):
+    sel = order[int(lo * len(order)):int(hi * len(order))]
+    print("start quartile %.2f-%.2f: start %.1f us, lifetime %.1f us, end %.1f us" % (lo, hi, stn[sel].mean(), lifen[sel].mean(), (stn[sel] + lifen[sel]).mean()))
+

@@ -4,7 +4,7 @@
 set -e
 cd "$(dirname "$0")/../mobgt_amd/csrc"
 FLAGS="-O3 -std=c++17 -fPIC -I../../include --offload-arch=gfx950 -Wno-unused-function -mllvm -amdgpu-mfma-vgpr-form=1 -fno-slp-vectorize"
-/opt/rocm/bin/hipcc $FLAGS -DATTN_STAMP -c attn.hip -o /tmp/attn_stamp.o
+/opt/rocm/bin/hipcc $FLAGS -DATTN_STAMP $STAMP_EXTRA -c attn.hip -o /tmp/attn_stamp.o
 OBJS=$(ls *.o | grep -v '^attn.o$')
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../libmobgt_hip_stamp.so /tmp/attn_stamp.o $OBJS
 echo built ../libmobgt_hip_stamp.so
