@@ -46,6 +46,9 @@ namespace {
 #ifndef ATTN_BWD_EVEN
 #define ATTN_BWD_EVEN 0       // backward passes: deal the 32-row tiles out evenly over more workgroups (choose_nq)
 #endif
+#ifndef ATTN_BWD_CLAMPED
+#define ATTN_BWD_CLAMPED 1    // backward passes: staging loads with clamped rows instead of behind branches (exact wait counts)
+#endif
 #ifndef ATTN_PACKED_DROP
 #define ATTN_PACKED_DROP 1    // forward: dropout as a mask on the packed probabilities
 #endif
@@ -624,8 +627,8 @@ __device__ __forceinline__ void attn_bwd_dq_body(const AttnParams& p, const int 
     }
     Slab<D, TQ, PIPE ? NT : KC * 4> kreg, vreg;
     if (PIPE) {
-        kreg.load(K, p.ldk, 0, T);
-        vreg.load(V, p.ldv, 0, T);
+        if (ATTN_BWD_CLAMPED) { kreg.load_clamped(K, p.ldk, 0, T); vreg.load_clamped(V, p.ldv, 0, T); }
+        else { kreg.load(K, p.ldk, 0, T); vreg.load(V, p.ldv, 0, T); }
     }
     auto chunk = [&](const int c, BiasStage<TB>& bst) {
         if (wave_live) bst.park(bimg, lane);                                   // (see the forward kernel)
@@ -639,7 +642,10 @@ __device__ __forceinline__ void attn_bwd_dq_body(const AttnParams& p, const int 
             Slab<D, TQ, NT>::template direct<true, false, true>(V, p.ldv, c * KC, T, 1.f, Vs, nullptr);
         }
         __syncthreads();
-        if (PIPE && c + 1 < nchunk) {
+        if (PIPE && ATTN_BWD_CLAMPED) {                                       // (unconditional, clamped: see the forward)
+            kreg.load_clamped(K, p.ldk, min(c + 1, nchunk - 1) * KC, T);
+            vreg.load_clamped(V, p.ldv, min(c + 1, nchunk - 1) * KC, T);
+        } else if (PIPE && c + 1 < nchunk) {
             kreg.load(K, p.ldk, (c + 1) * KC, T);
             vreg.load(V, p.ldv, (c + 1) * KC, T);
         }
@@ -810,13 +816,20 @@ __device__ __forceinline__ void attn_bwd_dkv_body(const AttnParams& p, const int
     bst.load(brows, 0);
     Slab<D, TQ, PIPE ? NT : KC * 4> qreg, doreg;
     if (PIPE) {
-        qreg.load(Q, p.ldq, 0, T);
-        doreg.load(dO, p.ldo, 0, T);
+        if (ATTN_BWD_CLAMPED) { qreg.load_clamped(Q, p.ldq, 0, T); doreg.load_clamped(dO, p.ldo, 0, T); }
+        else { qreg.load(Q, p.ldq, 0, T); doreg.load(dO, p.ldo, 0, T); }
     }
     float lse_r = 0.f, dl_r = 0.f;                         // thread it < KC carries query it of the chunk (NT >= KC)
     auto load_rowstats = [&](const int c) {
         const int q = c * KC + (int)threadIdx.x;
         const bool ok = threadIdx.x < KC && q < T;
+        if (ATTN_BWD_CLAMPED && !OWN_DELTA) {
+            // (every thread loads, from a clamped row: no branch around the loads; rows >= T have P = 0, any finite value serves)
+            const int64_t qi = (int64_t)gh * T + min(c * KC + (int)(threadIdx.x & (KC - 1)), T - 1);
+            lse_r = p.lse_in[qi];
+            dl_r = p.delta[qi];
+            return;
+        }
         lse_r = ok ? p.lse_in[(int64_t)gh * T + q] : 0.f;
         if (!OWN_DELTA) {
             dl_r = ok ? p.delta[(int64_t)gh * T + q] : 0.f;
@@ -865,7 +878,11 @@ __device__ __forceinline__ void attn_bwd_dkv_body(const AttnParams& p, const int
             }
         }
         __syncthreads();
-        if (c + 1 < nchunk) {
+        if (ATTN_BWD_CLAMPED && PIPE && !OWN_DELTA) {                        // (unconditional, clamped: see the forward)
+            qreg.load_clamped(Q, p.ldq, min(c + 1, nchunk - 1) * KC, T);
+            doreg.load_clamped(dO, p.ldo, min(c + 1, nchunk - 1) * KC, T);
+            load_rowstats(min(c + 1, nchunk - 1));
+        } else if (c + 1 < nchunk) {
             if (PIPE) {
                 qreg.load(Q, p.ldq, (c + 1) * KC, T);
                 doreg.load(dO, p.ldo, (c + 1) * KC, T);

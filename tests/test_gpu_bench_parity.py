@@ -6,10 +6,10 @@ the CPU (reference: model_fqandtoyo.py:1123-1432, modelGNN.py:38-74).
 Tolerances (bf16 operands with fp32 accumulation on the GPU side, fp32 reference):
   logits          max |err| <= 3e-2            (values are O(1))
   loss            rtol 2e-3
-  gradients       ELEMENTWISE: |err| <= 0.15 * rms_nz(ref) + 0.05 * |ref| (rms over the non-zero reference entries:
+  gradients       ELEMENTWISE: |err| <= 0.12 * rms_nz(ref) + 0.05 * |ref| (rms over the non-zero reference entries:
                   embedding tables get gradient in a few rows only) for 99.9 % of the entries and 4x that for every
                   entry; entries the reference leaves exactly zero (padding rows, untouched table rows) must be exactly
-                  zero here too; relative L2 error <= 4e-2 -- a transposed / permuted / mis-scaled gradient fails all
+                  zero here too; relative L2 error <= 3e-2 -- a transposed / permuted / mis-scaled gradient fails all
                   of them.  Measured in round 2: relative L2 0.6-2.5 %, 99.9 % of the entries within 0.05 rms.  The 4x
                   allowance for the last 0.1 % is for derivative KINKS: LeakyReLU(0.2) / ELU pre-activations that sit
                   within bf16 round-off of zero take the other branch on one side, which moves one whole row of the
@@ -66,7 +66,9 @@ def oracle_step(sd0, batch, consts, n_layers):
     return logits.detach(), float(loss.detach()), {k: (None if v.grad is None else v.grad / LOSS_SCALE) for k, v in sd.items()}
 
 
-MAX_REL_L2, K_RMS, KINK = 4e-2, 0.15, 4.0
+MAX_REL_L2, K_RMS, KINK = 3e-2, 0.12, 4.0       # (round 3: tightened from 4e-2 / 0.15 to what is measured -- relative L2
+                                                # <= 2.3 % everywhere; at 0.10 rms one LeakyReLU-kink row of embed_fuse_model3 exceeds
+                                                # the 99.9 % quantile by 8 % -- VERDICT r2 weak #6)
 
 
 def check_grad(name, got, ref, report):
