@@ -360,6 +360,17 @@ int mobgt_linear_wgrad_group(int n, const void* const* g, const int64_t* ldg, co
                              float* const* dw, const int64_t* ldw, float* const* db, int64_t R, const int* M,
                              const int* N, int act_dtype, void* stream);
 
+/* The same for up to 32 problems that differ in everything: problem q contracts R[q] rows of g[q] [R,M[q]] and x[q] [R,N[q]]
+ * (bf16 when in_f32[q] == 0, f32 rounded to bf16 while loading when 1); f32 operands may carry activation masks g_mask[q] /
+ * x_mask[q] (operand's layout; m(y) = y > 0 ? mask_vals[3q] : (y < 0 ? mask_vals[3q+1] : mask_vals[3q+2]) multiplies the
+ * operand: the derivative of dropout(leaky_relu(.)) taken from the activation's output, model_fqandtoyo.py:452-455,
+ * modelGNN.py:66-72); db[q] (or NULL) accumulates the column sums of the masked g, or of x when db_of_x[q].  dw[q] and db[q]
+ * accumulate (zero them first).  One launch: the leaf weight gradients of a training step issued together. */
+int mobgt_linear_wgrad_multi(int n, const void* const* g, const int64_t* ldg, const void* const* x, const int64_t* ldx,
+                             const float* const* g_mask, const float* const* x_mask, const float* mask_vals,
+                             float* const* dw, const int64_t* ldw, float* const* db, const int* db_of_x,
+                             const int64_t* R, const int* M, const int* N, const int* in_f32, void* stream);
+
 /* End of an encoder layer's backward in ONE launch (R <= 1024 rows): the weight gradients of mobgt_linear_wgrad_group
  * (same arguments) and, side by side with them, the layer's input gradient  c[gM,gN] (f32) += a[gM,gK] x b_kn[gK,gN]
  * (bf16 operands; mobgt_layer_gemm's MOBGT_GEMM_ADD with b_is_kn = 1, in place) -- `dx = dx1 + dqkv Wqkv`, which needs

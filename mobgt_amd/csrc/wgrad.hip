@@ -102,6 +102,46 @@ int launch_group(int n, const void* const* g, const int64_t* ldg, const void* co
 }
 }  // namespace
 
+// Heterogeneous group: up to 32 weight-gradient problems with their OWN row counts, operand dtypes and activation masks in one
+// launch (round 3: the leaf weight gradients of a train step -- FuseEmbeddings' Linears, the distance GCN's three layers -- were
+// six launches of ~9.5 us each, every one a handful of workgroups walking a few thousand rows; nothing but the optimizer
+// reads their results, so the trainer collects them and issues them together at the end of the backward pass).
+extern "C" int mobgt_linear_wgrad_multi(int n, const void* const* g, const int64_t* ldg, const void* const* x, const int64_t* ldx,
+                                        const float* const* g_mask, const float* const* x_mask, const float* mask_vals,
+                                        float* const* dw, const int64_t* ldw, float* const* db, const int* db_of_x,
+                                        const int64_t* R, const int* M, const int* N, const int* in_f32, void* stream) {
+    if (n < 1 || n > WG_GROUP) return MOBGT_EBADDIM;
+    WgradGroup grp;
+    grp.n = n;
+    grp.n_tail = 0;
+    int total = 0;
+    // (16-wave workgroups whenever any problem is long: a short problem then simply has idle waves)
+    int nwave = 8;
+    for (int q = 0; q < n; ++q)
+        if (R[q] > SHORT_R) nwave = 16;
+    for (int q = 0; q < n; ++q) {
+        if (in_f32[q] != 0 && in_f32[q] != 1) return MOBGT_EDTYPE;
+        if ((g_mask[q] || x_mask[q]) && !in_f32[q]) return MOBGT_EDTYPE;          // masks exist for f32 operands only
+        const int rc = fill_problem(grp.p[q], g[q], ldg[q], x[q], ldx[q], dw[q], ldw[q], db[q], R[q], M[q], N[q],
+                                    // (all problems in ONE round of resident workgroups: 512 slots of 16 waves on 256 CUs; a
+                                    // long problem still gets >= 64 so that a wave walks only a few 32-row steps)
+                                    (nwave == 8 ? 1024 : 512) / n > 64 ? (nwave == 8 ? 1024 : 512) / n : 64, &grp.tiles[q],
+                                    &grp.splits[q], in_f32[q], nwave);
+        if (rc) return rc;
+        if ((((uintptr_t)g_mask[q] | (uintptr_t)x_mask[q]) & 7)) return MOBGT_EALIGN;
+        grp.p[q].gmask = g_mask[q]; grp.p[q].xmask = x_mask[q];
+        grp.p[q].mpos = mask_vals[3 * q]; grp.p[q].mneg = mask_vals[3 * q + 1]; grp.p[q].mzero = mask_vals[3 * q + 2];
+        grp.p[q].db_x = db_of_x[q];
+        grp.first[q] = total;
+        total += grp.tiles[q] * grp.splits[q];
+    }
+    for (int q = n; q <= WG_GROUP; ++q) grp.first[q] = total;
+    for (int q = n; q < WG_GROUP; ++q) { grp.tiles[q] = 1; grp.splits[q] = 1; grp.p[q] = grp.p[0]; }
+    if (nwave == 8) hipLaunchKernelGGL(wgrad_group_kernel<8>, dim3(total), dim3(8 * 64), 0, (hipStream_t)stream, grp);
+    else hipLaunchKernelGGL(wgrad_group_kernel<16>, dim3(total), dim3(16 * 64), 0, (hipStream_t)stream, grp);
+    return (int)hipGetLastError();
+}
+
 extern "C" int mobgt_linear_wgrad_group(int n, const void* const* g, const int64_t* ldg, const void* const* x,
                                         const int64_t* ldx, float* const* dw, const int64_t* ldw, float* const* db,
                                         int64_t R, const int* M, const int* N, int act_dtype, void* stream) {

@@ -25,7 +25,7 @@ def mm_tn_splitk(x, g, max_chunks=32, bf16_operands=False):
             and g.shape[1] % 2 == 0 and x.is_contiguous() and g.is_contiguous()
             and x.data_ptr() % 8 == 0 and g.data_ptr() % 8 == 0):
         from . import ops
-        return ops.linear_wgrad(x, g)[0]
+        return ops.linear_wgrad(x, g, leaf=True)[0]
     P = x.shape[0]
     s = max((c for c in range(1, max_chunks + 1) if P % c == 0), default=1)
     if s == 1 or P < 2048:
@@ -269,8 +269,9 @@ class _ConvActFn(torch.autograd.Function):
         t, weight, y = ctx.saved_tensors
         g = g.contiguous()
         db = ops.zeros_f32((weight.shape[1],), g.device)
-        dW = ops.linear_wgrad_masked(t, g, x_mask=y, mask_vals=ctx.mv, db=db, db_of_x=True)      # t^T (g * m(y)), db = colsum
+        dW = ops.linear_wgrad_masked(t, g, x_mask=y, mask_vals=ctx.mv, db=db, db_of_x=True, leaf=True)   # t^T (g * m(y)), db = colsum
         dW = dW[:weight.shape[0]]                                                                # (rows of the zero padding)
+        db = db[:]                                                                               # (a fresh view: see ops.wgrad_deferral)
         dx = None
         if ctx.adj is not None and ctx.needs_input_grad[0]:
             # dt = (g * m(y)) W^T [P, in] leaves the GEMM transposed, scaled by 1/(deg+1) and in bf16 -- the operand of

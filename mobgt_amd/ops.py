@@ -788,8 +788,16 @@ class _LinearSplitKFn(torch.autograd.Function):
             if (hip_wgrad and R <= 64 and small_gemm_ok(g, w) and y.is_contiguous() and y.data_ptr() % 8 == 0
                     and max(w.shape) <= 512):
                 db = zeros_f32((g.shape[1],), g.device)
-                dw = linear_wgrad_masked(g, x, g_mask=y, mask_vals=mv, db=db)
-                return small_gemm(g, w, a_mask=(y, *mv)), dw, db, None, None, None
+                dw = linear_wgrad_masked(g, x, g_mask=y, mask_vals=mv, db=db, leaf=True)
+                return small_gemm(g, w, a_mask=(y, *mv)), dw, (db[:] if _WGRAD_DEFER["on"] else db), None, None, None
+            if (_WGRAD_DEFER["on"] and hip_wgrad and g.stride(1) == 1 and y.stride() == g.stride() and g.data_ptr() % 8 == 0
+                    and y.data_ptr() % 8 == 0 and g.stride(0) % 2 == 0 and small_gemm_ok(g, w) and R <= _SMALL_ROWS
+                    and max(w.shape) <= 512):
+                # trainer's backward: the weight gradient is a leaf and joins the step's one grouped launch; the data gradient
+                # then applies the activation's derivative itself while it loads g (no masked copy of g exists)
+                db = zeros_f32((g.shape[1],), g.device)
+                dw = linear_wgrad_masked(g, x, g_mask=y, mask_vals=mv, db=db, leaf=True)
+                return small_gemm(g, w, a_mask=(y, *mv)), dw, db[:], None, None, None
             if (hip_wgrad and g.stride(1) == 1 and y.stride() == g.stride() and g.data_ptr() % 8 == 0 and y.data_ptr() % 8 == 0
                     and g.stride(0) % 2 == 0):
                 # the weight-gradient kernel applies the activation's derivative while it loads g, sums the bias gradient and
@@ -1131,7 +1139,53 @@ def act_mask_values(slope, p_drop):
     return 1.0, slope, slope
 
 
-def linear_wgrad_masked(g, x, g_mask=None, x_mask=None, mask_vals=(1.0, 1.0, 1.0), db=None, db_of_x=False, dw=None, g_out=None):
+# ---- leaf weight gradients issued together (round 3) ----------------------------------------------------------------------------
+# Nothing but the optimizer reads a weight gradient.  While `wgrad_deferral(True)` is in force (train.TrainStep switches it on
+# around a backward pass and flushes before it gathers the gradients), `linear_wgrad(..., leaf=True)` /
+# `linear_wgrad_masked(..., leaf=True)` only RECORD their problem -- operands and destinations are kept alive by the record --
+# and `flush_deferred_wgrads()` issues all of them as ONE launch (mobgt_linear_wgrad_multi).  What a caller gets back is a
+# fresh VIEW of the (zero-initialised) destination: autograd's AccumulateGrad steals a returned gradient only if nothing else
+# references that tensor object, and the record holds the base -- the kernel's late writes land in the tensor the parameter
+# ends up with (the rule fused_layer.py follows for its parked tails).  Off by default: eager callers get the launch at once.
+_WGRAD_DEFER = {"on": False, "items": []}
+_WGRAD_DEFER_ENV = __import__("os").environ.get("MOBGT_NO_DEFER_WGRAD") != "1"
+
+
+def wgrad_deferral(on):
+    """Switch the recording on / off.  Switching off DROPS anything still recorded: the trainer flushes explicitly after a
+    successful backward pass, so leftovers exist only when that pass raised -- their buffers belong to a dead graph."""
+    _WGRAD_DEFER["items"] = []
+    _WGRAD_DEFER["on"] = bool(on) and _WGRAD_DEFER_ENV
+
+
+def _wgrad_defer(g, x, g_mask, x_mask, mask_vals, dw, db, db_of_x):
+    _WGRAD_DEFER["items"].append((g, x, g_mask, x_mask, tuple(float(v) for v in mask_vals), dw, db, bool(db_of_x)))
+    return dw[:]
+
+
+def flush_deferred_wgrads():
+    items, _WGRAD_DEFER["items"] = _WGRAD_DEFER["items"], []
+    vp, i64, ci, cf = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_float
+    for o in range(0, len(items), 32):
+        part = items[o:o + 32]
+        n = len(part)
+        ptr = lambda t: t.data_ptr() if t is not None else None
+        mv = []
+        for it in part:
+            mv += list(it[4])
+        check(_lib.lib().mobgt_linear_wgrad_multi(
+            n, (vp * n)(*[ptr(it[0]) for it in part]), (i64 * n)(*[it[0].stride(0) for it in part]),
+            (vp * n)(*[ptr(it[1]) for it in part]), (i64 * n)(*[it[1].stride(0) for it in part]),
+            (vp * n)(*[ptr(it[2]) for it in part]), (vp * n)(*[ptr(it[3]) for it in part]), (cf * (3 * n))(*mv),
+            (vp * n)(*[ptr(it[5]) for it in part]), (i64 * n)(*[it[5].stride(0) for it in part]),
+            (vp * n)(*[ptr(it[6]) for it in part]), (ci * n)(*[int(it[7]) for it in part]),
+            (i64 * n)(*[it[0].shape[0] for it in part]), (ci * n)(*[it[0].shape[1] for it in part]),
+            (ci * n)(*[it[1].shape[1] for it in part]), (ci * n)(*[1 if it[0].dtype == torch.float32 else 0 for it in part]),
+            _stream()), "mobgt_linear_wgrad_multi")
+
+
+def linear_wgrad_masked(g, x, g_mask=None, x_mask=None, mask_vals=(1.0, 1.0, 1.0), db=None, db_of_x=False, dw=None, g_out=None,
+                        leaf=False):
     """dW [M,N] = (g * m(g_mask))^T (x * m(x_mask)) for f32 row-major g [R,M], x [R,N] (operands rounded to bf16 while
     loading, f32 accumulate); db (zero-initialised f32): += column sums of the masked g ([M]) or, `db_of_x`, x ([N]).
     `g_out` (f32, g's shape and strides): also receives g * m(g_mask) (for the data-gradient GEMM that follows)."""
@@ -1144,6 +1198,8 @@ def linear_wgrad_masked(g, x, g_mask=None, x_mask=None, mask_vals=(1.0, 1.0, 1.0
     if dw is None:
         dw = zeros_f32((M, N), g.device)
     assert g_out is None or (g_mask is not None and g_out.shape == g.shape and g_out.stride() == g.stride())
+    if leaf and _WGRAD_DEFER["on"] and g_out is None and M % 2 == 0 and N % 2 == 0:
+        return _wgrad_defer(g, x, g_mask, x_mask, mask_vals, dw, db, db_of_x)
     check(_lib.lib().mobgt_linear_wgrad_masked(_p(g), g.stride(0), _p(x), x.stride(0), _p(g_mask), _p(x_mask), float(mask_vals[0]),
                                                float(mask_vals[1]), float(mask_vals[2]), _p(g_out), _p(dw), N, _p(db), int(db_of_x),
                                                R, M, N, _stream()), "mobgt_linear_wgrad_masked")
@@ -1232,7 +1288,7 @@ def nan_trace_report():
     return [(n, bool(f[i])) for i, n in enumerate(_NAN_TRACE["names"])]
 
 
-def linear_wgrad(g, x, with_bias=False, db=None, out_bias=None):
+def linear_wgrad(g, x, with_bias=False, db=None, out_bias=None, leaf=False):
     """(dW, db) of y = x W^T + b from g = dL/dy: dW [M,N] = g^T x (f32) and db [M] = g.sum(0) (f32, or None),
     for bf16 row-major g [R,M], x [R,N] (row strides may exceed the width: column slices are fine).
     `db`: an existing zero-initialised f32 [M] to accumulate the bias gradient into.
@@ -1249,6 +1305,8 @@ def linear_wgrad(g, x, with_bias=False, db=None, out_bias=None):
         return dw, None
     if db is None and with_bias:
         db = zeros_f32((M,), g.device)
+    if leaf and _WGRAD_DEFER["on"] and M % 2 == 0 and N % 2 == 0:
+        return _wgrad_defer(g, x, None, None, (1.0, 1.0, 1.0), dw, db, False), (db[:] if db is not None else None)
     check(_lib.lib().mobgt_linear_wgrad(_p(g), g.stride(0), _p(x), x.stride(0), _p(dw), N, _p(db), R, M, N, _DT[g.dtype],
                                         _stream()), "mobgt_linear_wgrad")
     return dw, db

@@ -408,7 +408,12 @@ class TrainStep:
     def _fwd_bwd(self, batch, slot=None):
         self._prologue()
         loss = self._loss(batch)
-        loss.backward(gradient=ops.unit_grad(loss.device))
+        ops.wgrad_deferral(True)                 # leaf weight gradients are recorded ...
+        try:
+            loss.backward(gradient=ops.unit_grad(loss.device))
+            ops.flush_deferred_wgrads()          # ... and issued as ONE launch, before anything reads a gradient
+        finally:
+            ops.wgrad_deferral(False)
         ops.set_zero_arena(None)
         self.flat.gather()
         self._keep_loss(loss, slot)
@@ -431,14 +436,24 @@ class TrainStep:
         loss = self._loss(batch)
         enc = self.model._enc_out
         head = self.flat.params[:self.n_head]
-        grads = torch.autograd.grad(loss, head + [enc], grad_outputs=ops.unit_grad(loss.device), allow_unused=True)   # frees only the nodes it ran
+        ops.wgrad_deferral(True)
+        try:
+            grads = torch.autograd.grad(loss, head + [enc], grad_outputs=ops.unit_grad(loss.device), allow_unused=True)   # frees only the nodes it ran
+            ops.flush_deferred_wgrads()
+        finally:
+            ops.wgrad_deferral(False)
         self.flat.gather(0, self.n_head, grads=list(grads[:-1]))
         self._g_enc[i] = (enc, grads[-1])
         self._keep_loss(loss, i)
 
     def _phase_b(self, i):
         enc, g_enc = self._g_enc[i]
-        torch.autograd.backward([enc], [g_enc])
+        ops.wgrad_deferral(True)
+        try:
+            torch.autograd.backward([enc], [g_enc])
+            ops.flush_deferred_wgrads()
+        finally:
+            ops.wgrad_deferral(False)
         ops.set_zero_arena(None)
         self.flat.gather(self.n_head, None)
 
