@@ -812,7 +812,7 @@ class _LinearSplitKFn(torch.autograd.Function):
         if hip_wgrad:
             # bf16 configuration: weight AND bias gradient from the split-K MFMA kernel (operands rounded to bf16 while
             # loading); the library's split-K path took 27-31 us + a reduce for these 224-wide layers
-            dw, db = linear_wgrad(g, x, with_bias=True)
+            dw, db = linear_wgrad(g, x, with_bias=True, leaf=True)
             return (small_gemm(g, w) if _small_linear(g, w) & 2 else g @ w), dw, db, None, None, None
         s = max((c for c in (16, 8, 4, 2) if R % c == 0 and R // c >= 16), default=1)
         if s > 1:
