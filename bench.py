@@ -274,11 +274,28 @@ def time_epoch_loop(model, coll, name, uni, args):
     loss = float(loop.ts.loss_out.item())
     if loss != loss:
         raise RuntimeError("loop diverged")
+    # the same sequence of step graphs with NO fresh data (each bucket replays on the batch it saw last): what the GPU needs
+    # for this mix of shapes -- the loop's batches are not the 8 pre-collated ones `value` is quoted on
+    from mobgt_amd.data import bucket_nodes
+    seq = []
+    for e in range(2, ep):
+        for ids in loop.batches_of_epoch(e):
+            tr = [dataset[i] for i in ids]
+            seq.append(loop.slots[(len(tr), bucket_nodes(max(len(t["node_name"]) for t in tr), loop.buckets))]["index"])
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in seq:
+        loop.ts.step(i)
+    torch.cuda.synchronize()
+    el_replay = time.perf_counter() - t0
     return dict(value=args.batch_size * steps / el, unit="check-ins/s", ms_per_step=el / steps * 1e3, steps=steps,
+                ms_per_step_same_graphs_no_input=el_replay / len(seq) * 1e3,
                 dataset_trajectories=len(dataset), shape_buckets=sorted(k[1] for k in loop.slots),
                 graphs_captured_inside_timed_region=len(loop.slots) - graphs_before, final_loss=loss,
                 what="fresh batch every step: host pack of raw trajectories + H2D + device collate (SPD / edge paths / "
-                     "degrees / distance bins) + forward + loss + backward + AdamW, hipGraph per shape bucket")
+                     "degrees / distance bins; on the copy stream beside the previous step) + [forward + loss + backward + "
+                     "AdamW] as one hipGraph per shape bucket; ms_per_step_same_graphs_no_input = the same graph sequence "
+                     "replayed without new input")
 
 
 # ------------------------------------------------------------------------------------------ CPU baseline

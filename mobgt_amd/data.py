@@ -132,6 +132,34 @@ class DeviceCollator:
         d = {k: torch.from_numpy(v).to(self.device, non_blocking=True) for k, v in h.items()}
         return self.finish(d)
 
+    def can_finish_into(self):
+        return self.coords is None and (self.bin_table is None or (self.bin_table.dtype == torch.int16 and self.bin_table.is_contiguous()))
+
+    def finish_into(self, v, work=None):
+        """`finish` writing into the pre-allocated views of a BatchLayout buffer (raw fields already in place): two / three
+        launches on the CURRENT stream, no allocation -- train.EpochLoop runs it on its copy stream for the next batch."""
+        from . import _lib
+        from .ops import _p, _stream
+        G, N = v["counts"].shape[:2]
+        lib = _lib.lib()
+        if work is None:
+            work = torch.empty(int(lib.mobgt_spd_workspace_bytes(G, N)), dtype=torch.uint8, device=self.device)
+        _lib.check(lib.mobgt_spd_batched(_p(v["counts"]), _p(v["n_nodes"]), _p(v["spd"]), _p(v["path"]), _p(v["rel_pos"]),
+                                         _p(v["edge_input"]), _p(v["in_degree"]), _p(v["out_degree"]), _p(work), G, N, self.D,
+                                         _stream()), "mobgt_spd_batched")
+        bt = self.bin_table
+        _lib.check(lib.mobgt_collate_finish(_p(v["x"]), _p(v["n_nodes"]), _p(v["spd"]), _p(bt), bt.shape[1] if bt is not None else 0,
+                                            self.rel_pos_max, _p(v["attn_bias"]), _p(v["poi_pos"]), G, N, _stream()),
+                   "mobgt_collate_finish")
+        return work
+
+    @staticmethod
+    def batch_from_views(v):
+        return DeviceBatch1(v["counts"], v["n_nodes"], idx=v["idx"], attn_bias=v["attn_bias"], rel_pos=v["rel_pos"],
+                            in_degree=v["in_degree"], out_degree=v["out_degree"], x=v["x"], edge_input=v["edge_input"],
+                            y=v["y"], time=v["time"], time_normal=v["time_normal"], user=v["user"], cat=v["cat"],
+                            poi_pos=v["poi_pos"])
+
     def finish(self, d):
         counts, n_nodes = d["counts"], d["n_nodes"]
         G, N = counts.shape[:2]
@@ -225,6 +253,40 @@ class RawLayout:
         """typed torch views of a (device) uint8 tensor"""
         tdt = {np.int64: torch.int64, np.int32: torch.int32, np.float32: torch.float32}
         return {k: buf[o:o + n].view(tdt[dt]).view(*shp) for k, (o, n, dt, shp) in self.offsets.items()}
+
+
+class BatchLayout(RawLayout):
+    """RawLayout + everything the device collate derives from it, in one byte buffer: [raw fields | derived fields |
+    scratch].  A staging copy of this buffer is filled on a side stream (H2D of the raw part, then the collate kernels)
+    while the previous step runs; ONE device-to-device copy of [raw | derived] then refreshes the static buffer the bucket's
+    step graph reads."""
+
+    def __init__(self, G, N, D):
+        super().__init__(G, N)
+        self.D = int(D)
+        self.raw_bytes = self.nbytes
+        T = self.N + 1
+        off = self.nbytes
+        derived = (("attn_bias", np.float32, (self.G, T, T)), ("rel_pos", np.int16, (self.G, self.N, self.N)),
+                   ("poi_pos", np.int16, (self.G, self.N, self.N)), ("edge_input", np.uint8, (self.G, self.N, self.N, self.D, 1)),
+                   ("in_degree", np.int16, (self.G, self.N)), ("out_degree", np.int16, (self.G, self.N)))
+        scratch = (("spd", np.int16, (self.G, self.N, self.N)), ("path", np.int16, (self.G, self.N, self.N)))
+        for group in (derived, scratch):
+            for name, dt, shp in group:
+                nbytes = int(np.prod(shp)) * np.dtype(dt).itemsize
+                self.offsets[name] = (off, nbytes, dt, shp)
+                off = (off + nbytes + 15) // 16 * 16
+            if group is derived:
+                self.copy_bytes = off                      # [raw | derived]: what a step's graph reads
+        self.nbytes = off
+
+    def views_torch(self, buf):
+        tdt = {np.int64: torch.int64, np.int32: torch.int32, np.float32: torch.float32, np.int16: torch.int16, np.uint8: torch.uint8}
+        return {k: buf[o:o + n].view(tdt[dt]).view(*shp) for k, (o, n, dt, shp) in self.offsets.items()}
+
+    def views_np(self, buf):
+        """numpy views of the RAW part of a host uint8 array (a pinned staging buffer of raw_bytes)"""
+        return {k: buf[o:o + n].view(dt).reshape(shp) for k, (o, n, dt, shp) in self.offsets.items() if o + n <= self.raw_bytes}
 
 
 def shard_indices(n_samples, rank, world_size, epoch=0, seed=0, shuffle=True):

@@ -586,20 +586,22 @@ class TrainStep:
 
 class EpochLoop:
     """The fit loop over the training set (Lightning's `trainer.fit` on `train_dataloader`: entry.py:141-161,
-    data.py:282-295), one process per GPU: a NEW batch every step, collated on the device inside the replayed step.
+    data.py:282-295), one process per GPU: a NEW batch every step, collated on the device.
 
     * sampler: `data.shard_indices` = torch's DistributedSampler (shuffle by seed + epoch, wrap-around padding, stride by
       rank); consecutive runs of `batch_size` indices form the batches (`drop_last=False`, as the reference's DataLoader);
-    * shapes: a batch's padded node count is rounded up to a bucket (`data.BUCKETS`); every (G, bucket) owns ONE packed
-      static input buffer on the device and ONE step graph = `DeviceCollator.finish` (SPD / edge paths / degrees / distance
-      bins) + forward + loss + backward + AdamW, captured the first time the bucket occurs;
-    * a step on the host: pack the NEXT batch's raw trajectories into a pinned staging buffer and start its host-to-device
-      copy on a side stream (while the GPU runs the current step), then -- on the compute stream -- one device-to-device
-      copy of the staged bytes into the bucket's static buffer and one graph replay.
+    * shapes: a batch's padded node count is rounded up to a bucket (`data.BUCKETS`); every (G, bucket) owns ONE static
+      collated batch on the device, two staging buffers and ONE step graph = forward + loss + backward + AdamW, captured
+      the first time the bucket occurs;
+    * a step on the host: pack the NEXT batch's raw trajectories into a pinned staging buffer and, on the copy stream, start
+      its host-to-device copy and its device collate (`DeviceCollator.finish_into`: SPD / edge paths / degrees / distance
+      bins) while the GPU runs the current step; then -- on the compute stream -- one device-to-device copy of the staged
+      raw + derived bytes into the bucket's static batch and one graph replay.  Collators whose finish needs torch ops
+      (coordinate bins) keep the collate inside the step graph (`batch_fn = finish`; also `MOBGT_LOOP_INGRAPH_COLLATE=1`).
     """
 
     def __init__(self, model, collator, dataset, batch_size=16, seed=1, use_graph=True, overlap=True, buckets=None, rank=None,
-                 world=None, shuffle=True, autocast_dtype=None):
+                 world=None, shuffle=True, autocast_dtype=None, side_collate=True):
         from .data import BUCKETS
         self.model, self.collator, self.dataset = model, collator, dataset
         self.batch_size, self.seed, self.shuffle = int(batch_size), int(seed), shuffle
@@ -614,6 +616,7 @@ class EpochLoop:
         self._ts_args = dict(autocast_dtype=autocast_dtype, use_graph=use_graph, seed=seed, overlap=overlap)
         self.steps_done = 0
         self.limits = None
+        self.side_collate = bool(side_collate) and os.environ.get("MOBGT_LOOP_INGRAPH_COLLATE") != "1"
 
     # ---- data order -----------------------------------------------------------------------------------------------------
     def batches_of_epoch(self, epoch):
@@ -624,17 +627,26 @@ class EpochLoop:
 
     # ---- buckets --------------------------------------------------------------------------------------------------------
     def _slot(self, G, N):
-        from .data import RawLayout
+        from .data import BatchLayout, RawLayout
         key = (G, N)
         s = self.slots.get(key)
         if s is None:
-            lay = RawLayout(G, N)
+            # `side`: the device collate of the NEXT batch runs on the copy stream, beside the current step (whose kernels
+            # leave most of the chip idle); the step graph then reads a collated static batch.  Collators that need torch
+            # ops (coordinate bins, S-BIG) keep the collate inside the step graph (batch_fn = finish).
+            side = self.side_collate and self.collator.can_finish_into()
+            lay = BatchLayout(G, N, self.collator.D) if side else RawLayout(G, N)
             buf = torch.zeros(lay.nbytes, dtype=torch.uint8, device=self.device)
-            s = dict(layout=lay, buf=buf, views=lay.views_torch(buf), index=None, stages=[], turn=0)
+            views = lay.views_torch(buf)
+            s = dict(layout=lay, buf=buf, views=views, index=None, stages=[], turn=0, side=side,
+                     batch=self.collator.batch_from_views(views) if side else views,
+                     copy_bytes=lay.copy_bytes if side else lay.nbytes)
+            raw_bytes = lay.raw_bytes if side else lay.nbytes
             for _ in range(2):
-                pin = torch.zeros(lay.nbytes, dtype=torch.uint8).pin_memory()
-                s["stages"].append(dict(pin=pin, np=lay.views_np(pin.numpy()), dev=torch.empty_like(buf), ready=torch.cuda.Event(),
-                                        free=None))
+                pin = torch.zeros(raw_bytes, dtype=torch.uint8).pin_memory()
+                dev = torch.zeros(lay.nbytes, dtype=torch.uint8, device=self.device)
+                s["stages"].append(dict(pin=pin, np=lay.views_np(pin.numpy()), dev=dev, dev_views=lay.views_torch(dev) if side else None,
+                                        work=None, ready=torch.cuda.Event(), free=None))
             self.slots[key] = s
         return s
 
@@ -679,23 +691,30 @@ class EpochLoop:
         self.collator.pack_host(trajs, idx0=ids[:G] if len(ids) == G else 0, n_pad=N, out=st["np"])
         self._check_host(st["np"])
         with torch.cuda.stream(self.copy_stream):
-            st["dev"].copy_(st["pin"], non_blocking=True)
+            st["dev"][:st["pin"].numel()].copy_(st["pin"], non_blocking=True)
+            if slot["side"]:
+                st["work"] = self.collator.finish_into(st["dev_views"], st["work"])
             st["ready"].record(self.copy_stream)
         return slot, st
 
     def _ensure_trainer(self, slot):
         """The first batch builds the TrainStep (dry run for the trained-parameter set, flat buffers, optimizer graph)."""
         if self.ts is None:
-            self.ts = TrainStep(self.model, [slot["views"]], batch_fn=self.collator.finish, **self._ts_args)
+            self.ts = TrainStep(self.model, [slot["batch"]], batch_fn=self._batch_fn, **self._ts_args)
             self.ts.prepare()
             slot["index"] = 0
         elif slot["index"] is None:
-            slot["index"] = self.ts.add_batch(slot["views"])
+            slot["index"] = self.ts.add_batch(slot["batch"])
+
+    def _batch_fn(self, b):
+        """inside the step: raw views -> collate (in-graph form); an already collated static batch passes through"""
+        return self.collator.finish(b) if isinstance(b, dict) else b
 
     def _launch(self, slot, st):
         cur = torch.cuda.current_stream()                # (graphs replay on the current stream)
         cur.wait_event(st["ready"])
-        slot["buf"].copy_(st["dev"], non_blocking=True)
+        n = slot["copy_bytes"]
+        slot["buf"][:n].copy_(st["dev"][:n], non_blocking=True)
         if st["free"] is None:
             st["free"] = torch.cuda.Event()
         st["free"].record(cur)
