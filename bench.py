@@ -327,12 +327,14 @@ def time_chain(R, C, F, reps=50, p_drop=0.1):
     x1, x2, out = (torch.empty(R, C, device="cuda") for _ in range(3))
     z, out_a, u, h, qkv = bf(R, C), bf(R, C), bf(R, F), bf(R, F), bf(R, 3 * C)
     st = torch.empty(4, R, device="cuda")
+    from mobgt_amd.fused_layer import chain_workspace
+    ws = chain_workspace(a.device)
 
     def fn():
         _lib.check(lib.mobgt_layer_chain_fwd(_p(a), _p(x), _p(wo), _p(bo), _p(ln[0]), _p(ln[1]), _p(w1), _p(b1), _p(w2), _p(b2),
                                              _p(ln[2]), _p(ln[3]), _p(wq), _p(bq), _p(x1), _p(z), _p(u), _p(h), _p(x2), _p(out),
                                              _p(out_a), _p(qkv), _p(st[0]), _p(st[1]), _p(st[2]), _p(st[3]), R, C, F, p_drop, 1, None,
-                                             9, 10, _stream()), "mobgt_layer_chain_fwd")
+                                             9, 10, _p(ws), _stream()), "mobgt_layer_chain_fwd")
     return _graph_time(fn, reps)
 
 

@@ -470,7 +470,7 @@ int mobgt_small_gemm_f32_act(const float* a, int64_t lda, const float* a_mask, f
  * a [R,C] bf16; x [R,C] f32; weights bf16 [out,in] PACKED by mobgt_pack_mfma_b; biases bf16; LayerNorm weights f32.
  * Written: x1, x2, out f32 [R,C]; z, out_a (= bf16(out)) [R,C], u, h [R,F], qkv_next [R,3C] bf16; mean / rstd [R] f32 of
  * both norms.  wq_next / bq_next / qkv_next null for the last layer.  Dropout masks: those of mobgt_dropout_add_ln_fwd
- * with salt1 / salt2.  (C, F) in {(192, 1024), (256, 1024)}. */
+ * with salt1 / salt2.  (C, F) in {(192, 1024), (256, 1024)}.  ws: see mobgt_chain_ws_bytes (may be null). */
 /* bf16 weight [N,K] row-major -> MFMA operand order (chain.hip): the 16 bytes W[16g + j][32s + 8q .. +7] go to byte offset
  * ((g K/32 + s) 64 + j + 16q) * 16, so that a wave's B-operand load is one contiguous KB.  n <= 96 jobs in one launch;
  * N % 16 == 0, K % 32 == 0.  transposed[i] != 0: src is [K,N] row-major and its TRANSPOSE is packed (the operand of
@@ -482,7 +482,7 @@ int mobgt_layer_chain_fwd(const void* a, const float* x, const void* wo, const v
                           const void* wq_next, const void* bq_next, float* x1, void* z, void* u, void* h, float* x2, float* out,
                           void* out_a, void* qkv_next, float* mean1, float* rstd1, float* mean2, float* rstd2, int64_t R, int C,
                           int F, float dropout_p, uint64_t seed, const uint64_t* seed_dev, uint32_t salt1, uint32_t salt2,
-                          void* stream);
+                          void* ws, void* stream);
 /* The same chain backwards, from d(out) to the gradient of the attention output (csrc/chain.hip):
  *   dx2 = ffn_norm2'(dout);  df = dropout'(dx2);  du = (df w2) * gelu'(u);  dz = du w1;  dx1 = dx2 + ffn_norm1'(dz);
  *   dy = dropout'(dx1);  da = dy wo.
@@ -500,7 +500,14 @@ int mobgt_layer_chain_bwd(const float* dout, const float* x2, const float* x1, c
                           float dropout_p, uint64_t seed, const uint64_t* seed_dev, uint32_t salt1, uint32_t salt2,
                           const void* tail_dqkv, const void* tail_wqkv_t, int n_wg, const void* const* wg_g,
                           const int64_t* wg_ldg, const void* const* wg_x, const int64_t* wg_ldx, float* const* wg_dw,
-                          const int64_t* wg_ldw, float* const* wg_db, const int* wg_M, const int* wg_N, void* stream);
+                          const int64_t* wg_ldw, float* const* wg_db, const int* wg_M, const int* wg_N, void* ws, void* stream);
+/* `ws` of the two chain launches: a device buffer of mobgt_chain_ws_bytes() bytes, 16-byte aligned, ZEROED ONCE when it is
+ * allocated and then left alone, used by ONE stream at a time.  With it, batches of R <= 16 * (compute units / 2) rows run
+ * the CLUSTER form: a 16-row block is shared by 4 (R <= 16 * CUs / 4) or 2 workgroups that each stream a quarter / half of
+ * the layer's two big weights and meet once per launch through `ws` (flag-carrying 8-byte words, generation numbers that
+ * never need resetting).  Same results as the one-workgroup form up to the f32 summation order of h w2^T and du w1 (NCL
+ * partial sums).  ws = null: always the one-workgroup form.  MOBGT_CHAIN_NCL=1|2|4 caps the cluster size. */
+int64_t mobgt_chain_ws_bytes(void);
 /* The whole 3-layer GCN of a SMALL dense graph (graphormer/modelGNN.py:53-74 on the ~300-node category graph,
  * model_fqandtoyo.py:1237) as ONE launch each way (csrc/smallgcn.hip): ceil(n/16) co-resident workgroups that meet at
  * `counter` (int[1], ZERO on entry) between the layers.

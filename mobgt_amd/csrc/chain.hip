@@ -46,6 +46,8 @@ struct ChainParams {
     uint64_t seed;
     const uint64_t* seed_dev;
     uint32_t salt1, salt2;
+    uint32_t* ws_gen;                        // cluster form: launch generations and the exchange area (see cluster_sum)
+    uint64_t* ws_ll;
 };
 
 // in-kernel timeline for tools/chain_debug.py (-DCH_DEBUG): stamps of workgroup 0 / thread 0, written at the end
@@ -53,7 +55,7 @@ struct ChainParams {
 __device__ int* g_chain_dbg = nullptr;
 #define STAMP_DECL int st_[16] = {}
 #define STAMP(i) st_[i] = (int)wall_clock64()
-#define STAMP_DUMP() do { if (g_chain_dbg && blockIdx.x == 0 && threadIdx.x == 0) for (int q_ = 0; q_ < 16; ++q_) g_chain_dbg[q_] = st_[q_]; } while (0)
+#define STAMP_DUMP() do { if (g_chain_dbg && threadIdx.x == 0) for (int q_ = 0; q_ < 16; ++q_) g_chain_dbg[blockIdx.x * 16 + q_] = st_[q_]; } while (0)
 #else
 #define STAMP_DECL
 #define STAMP(i)
@@ -127,7 +129,7 @@ constexpr int chunk_steps(int S) { return S <= 8 ? S : (S % 8 == 0 ? 8 : (S % 7 
 // The first two weight chunks of a wave's share of a GEMM, requested EARLY: issue() before the LayerNorm pass / the
 // staging barrier that precedes the product, so that their round trip overlaps it instead of opening the GEMM (four
 // products per launch each started on an idle ~1 us wait).
-template <int N, int K>
+template <int N, int K, int SF = K / 32>
 struct WPre {
     static constexpr int S = K / 32, CH = chunk_steps(S), CPG = S / CH, G = N / 16;
     uint4 b0[CH], b1[CH];
@@ -135,22 +137,25 @@ struct WPre {
         const int wave = threadIdx.x >> 6;
         return (wave < G ? (G - wave + NW - 1) / NW : 0) * CPG;
     }
-    static __device__ __forceinline__ void load(const uint16_t* __restrict__ W, uint4 (&b)[CH], int c) {
+    // (g0, s0): the product multiplies a SLICE of the packed weight -- column groups [g0, g0 + G) and k-steps [s0, s0 + S) of
+    // the SF steps a group has (the cluster kernels: a workgroup owns a column range or a K range of the layer's weight)
+    static __device__ __forceinline__ void load(const uint16_t* __restrict__ W, uint4 (&b)[CH], int c, int g0 = 0, int s0 = 0) {
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-        const int g = wave + (c / CPG) * NW, s0 = (c % CPG) * CH;          // W is PACKED: one contiguous KB per (group, k-step)
-        const uint16_t* wp = W + ((int64_t)(g * S + s0) * 64 + lane) * 8;
+        const int g = g0 + wave + (c / CPG) * NW, st = s0 + (c % CPG) * CH;   // W is PACKED: one contiguous KB per (group, k-step)
+        const uint16_t* wp = W + ((int64_t)(g * SF + st) * 64 + lane) * 8;
 #pragma unroll
         for (int s = 0; s < CH; ++s) b[s] = *reinterpret_cast<const uint4*>(wp + 512 * s);
     }
-    __device__ __forceinline__ void issue(const uint16_t* __restrict__ W) {
+    __device__ __forceinline__ void issue(const uint16_t* __restrict__ W, int g0 = 0, int s0 = 0) {
         const int n = nchunks();
-        if (n > 0) load(W, b0, 0);
-        if (n > 1) load(W, b1, 1);
+        if (n > 0) load(W, b0, 0, g0, s0);
+        if (n > 1) load(W, b1, 1, g0, s0);
     }
 };
 
-template <int BM, int N, int K, int LDA, typename EPI>
-__device__ __forceinline__ void wg_gemm(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W, EPI&& epi, WPre<N, K>& pre) {
+template <int BM, int N, int K, int LDA, typename EPI, int SF = K / 32>
+__device__ __forceinline__ void wg_gemm(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W, EPI&& epi, WPre<N, K, SF>& pre,
+                                        int g0 = 0, int s0 = 0) {
     constexpr int MT = BM / 16;
     constexpr int S = K / 32;                        // k-steps per group
     constexpr int CH = chunk_steps(S);               // k-steps per chunk
@@ -171,12 +176,12 @@ __device__ __forceinline__ void wg_gemm(const uint16_t* __restrict__ A, const ui
 #pragma unroll
             for (int s = 0; s < S; ++s) afr[t][s] = *reinterpret_cast<const uint4*>(a0 + 16 * t * LDA + 32 * s);
     }
-    auto load = [&](uint4 (&b)[CH], int c) { WPre<N, K>::load(W, b, c); };
+    auto load = [&](uint4 (&b)[CH], int c) { WPre<N, K, SF>::load(W, b, c, g0, s0); };
     f32x4 acc[MT];
 #pragma unroll
     for (int t = 0; t < MT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
     auto compute = [&](const uint4 (&b)[CH], int c) {
-        const int s0 = (c % CPG) * CH;
+        const int sc = (c % CPG) * CH;
 #pragma unroll
         for (int s = 0; s < CH; ++s) {
             const bf16x8 bf = __builtin_bit_cast(bf16x8, b[s]);
@@ -184,12 +189,12 @@ __device__ __forceinline__ void wg_gemm(const uint16_t* __restrict__ A, const ui
             for (int t = 0; t < MT; ++t) {
                 bf16x8 af;
                 if constexpr (AREG) af = __builtin_bit_cast(bf16x8, afr[t][s]);
-                else af = *reinterpret_cast<const bf16x8*>(a0 + 16 * t * LDA + 32 * (s0 + s));
+                else af = *reinterpret_cast<const bf16x8*>(a0 + 16 * t * LDA + 32 * (sc + s));
                 acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bf, acc[t], 0, 0, 0);
             }
         }
         if (c % CPG == CPG - 1) {
-            epi(wave + (c / CPG) * NW, acc);
+            epi(wave + (c / CPG) * NW, acc);         // (the group's index INSIDE the slice)
 #pragma unroll
             for (int t = 0; t < MT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
@@ -233,7 +238,9 @@ template <int BM, int C, int LDX, int LDA>
 __device__ __forceinline__ void ln_rows(const float* __restrict__ xb, uint16_t* __restrict__ dst_a, const LnW<C>& lw,
                                         float* __restrict__ g_pre, uint16_t* __restrict__ g_bf,
                                         float* __restrict__ g_f32, float* __restrict__ g_mean, float* __restrict__ g_rstd,
-                                        int r0, int R) {
+                                        int r0, int R, int own_mod = 1, int own_rem = 0) {
+    // (own_mod, own_rem): the cluster kernels run the norm on every member of a cluster (each needs all rows in LDS) and
+    // member `own_rem` of `own_mod` writes the global copies of rows r = own_rem (mod own_mod)
     constexpr int PER = (C + 63) / 64;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const float (&wv)[PER] = lw.w;
@@ -255,7 +262,7 @@ __device__ __forceinline__ void ln_rows(const float* __restrict__ xb, uint16_t* 
             qq += d * d;
         }
         const float rs = rsqrtf(wave64_sum(qq) * (1.f / C) + 1e-5f);
-        const bool on = row < R;
+        const bool on = row < R && (own_mod == 1 || r % own_mod == own_rem);
         if (on && lane == 0) { g_mean[row] = mu; g_rstd[row] = rs; }
 #pragma unroll
         for (int k = 0; k < PER; ++k) {
@@ -265,7 +272,7 @@ __device__ __forceinline__ void ln_rows(const float* __restrict__ xb, uint16_t* 
                 const uint16_t ob = bf16_bits(o);
                 dst_a[r * LDA + c] = ob;
                 if (on) {
-                    g_pre[row * C + c] = v[k];
+                    if (g_pre) g_pre[row * C + c] = v[k];
                     g_bf[row * C + c] = ob;
                     if (g_f32) g_f32[row * C + c] = o;
                 }
@@ -402,6 +409,348 @@ __global__ __launch_bounds__(NT) void layer_chain_fwd_kernel(const ChainParams p
     store_rows<BM, 3 * C, LDH>(ub, p.qkv, r0, p.R);
     STAMP(9);
     STAMP_DUMP();
+}
+
+
+// ---- the CLUSTER form of the two chain kernels (short batches) -------------------------------------------------------------
+// With 16 rows per workgroup a batch of R rows occupies ceil(R / 16) compute units -- 38 of 256 at S-FSQ's R ~ 600 -- and
+// each of them streams the layer's whole 1.08 MB of weights through its own L1 (~8 us, the kernel's floor).  Here a row
+// block belongs to a CLUSTER of NCL workgroups (2 or 4) that split the two big weights: member m owns the column range m of
+// FFN-1 (so of u and h) and of the next QKV projection, and the K range m of FFN-2 (the columns of h it produced).  The small
+// out-projection (73 KB) is computed by every member in full -- cheaper than handing x1 slices around.  Per workgroup a
+// quarter of the weight stream; per launch 4x the compute units.  FFN-2's partial sums need adding, so the members meet ONCE
+// per pass:
+//     forward    FFN-2 partial sums (split-K over the members) -> every member adds them in member order, forms x2, norms it
+//     backward   du W1 partial sums -> dz      (the layer above's tail product dqkv Wqkv is computed by every member in full)
+// The hand-over carries its own flags ("LL": each f32 travels as an 8-byte word {value, tag}, written with ONE sc1 --
+// agent-scope, write-through -- 8-byte store and polled with sc1 loads until the tag is the launch's): no store drain, no
+// barrier, no counter, one memory round trip.  tag = gen[block] + 1, where gen[block] is read by every member when it
+// starts and raised by member 0 once it holds everybody's words (so all members have read it; the next launch -- which
+// cannot start before this one has ended -- sees the new value and never mistakes stale words for its own).  Agent-scope
+// fences would write back / invalidate the XCD's whole L2 (see csrc/smallgcn.hip), and a counter hand-over costs three
+// round trips (measured 2.4-3.2 us per hand-over against ~1.3 here).  Members of a cluster sit on ONE XCD (block ids that
+// agree modulo 8; the sc1 accesses are correct on any placement).
+// Co-residency: the host picks NCL so that the live workgroups fit the device's compute units at one per unit; the poll is
+// bounded and traps.  Rounding: as the one-workgroup form except FFN-2 / du W1, whose f32 sums are added in NCL parts (then
+// rounded to bf16 at the same point).
+constexpr int WS_GEN_INTS = 1024;                                       // gen[<= 256 row blocks] (+ spare)
+constexpr size_t WS_LL_WORDS = (size_t)256 * 16 * 256;                  // <= 256 live workgroups x 16 rows x C <= 256 words of 8 bytes
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+#ifndef LL_STORE_POLICY
+#define LL_STORE_POLICY LL_SC1
+#endif
+constexpr int LL_SC0 = 1, LL_SC1 = 16, LL_VOLATILE = (int)0x80000000;       // buffer-instruction cache policy bits (gfx940+)
+
+// The exchange area of one cluster: NCL slots of BM x C / 2 packets of 16 bytes {v0, tag, v1, tag} -- two f32 of adjacent
+// columns, each with the launch's tag beside it in the same naturally aligned 8 bytes (what a store makes visible together).
+// 16-byte accesses: the load unit takes 16 clocks per wave instruction whatever its width, and 8-byte polls (24 KB of
+// payload per member as 96 KB of words) were 2.2 us of pure issue.
+// cluster_put: this member's partial sums pb [BM][LDX] -> its slot, sc1 (agent scope: written through).
+// cluster_get: epi(k, r, c, sums of columns c and c + 1 over the members in member order) (own partial sums from LDS: the same bits for everybody).  A
+// poll round requests EVERY packet still missing before it looks at any (one round trip per round; polled one by one,
+// twelve missing packets cost twelve round trips: measured 8.9 us).  The first rounds read through the XCD's L2 (sc0: misses
+// only the CU's L1) -- the members of a cluster share an L2 when block ids map to XCDs round-robin (MI300-class parts in SPX
+// mode); on any other placement such a load may keep returning a stale line, so later rounds use sc1.
+template <int BM, int C, int NCL>
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t cluster_area(uint64_t* ws_ll, int blk) {
+    return __builtin_amdgcn_make_buffer_rsrc(ws_ll + (int64_t)blk * NCL * BM * C, 0, NCL * BM * C * 8, 0x00020000);
+}
+template <int BM, int C, int LDX>
+__device__ __forceinline__ void cluster_put(__amdgpu_buffer_rsrc_t area, int m, const float* __restrict__ pb, uint32_t tag) {
+    constexpr int NP = BM * C / 2, EPT = (NP + NT - 1) / NT;
+#pragma unroll
+    for (int k = 0; k < EPT; ++k) {
+        const int e = threadIdx.x + k * NT;
+        if (e < NP) {
+            const int r = e / (C / 2), c = (e % (C / 2)) * 2;
+            const u32x4 v = {__float_as_uint(pb[r * LDX + c]), tag, __float_as_uint(pb[r * LDX + c + 1]), tag};
+            __builtin_amdgcn_raw_buffer_store_b128(v, area, (m * NP + e) * 16, 0, LL_STORE_POLICY);
+        }
+    }
+}
+template <int BM, int C, int LDX, int NCL, typename EPI>
+__device__ __forceinline__ void cluster_get(__amdgpu_buffer_rsrc_t area, int m, const float* __restrict__ pb, uint32_t tag, EPI&& epi,
+                                            int* dbg_rounds = nullptr) {
+    constexpr int NP = BM * C / 2, EPT = (NP + NT - 1) / NT;
+#ifndef LL_NEAR_ROUNDS
+#define LL_NEAR_ROUNDS 24
+#endif
+    constexpr int NEAR_ROUNDS = LL_NEAR_ROUNDS;
+    u32x4 w[EPT][NCL];
+#pragma unroll
+    for (int k = 0; k < EPT; ++k)
+#pragma unroll
+        for (int mm = 0; mm < NCL; ++mm) w[k][mm] = u32x4{0u, 0u, 0u, 0u};         // (tag 0 is never a launch's)
+    int rounds = 0;
+    bool missing;
+    do {
+#pragma unroll
+        for (int k = 0; k < EPT; ++k) {
+            const int e = min(threadIdx.x + k * NT, NP - 1);
+#pragma unroll
+            for (int mm = 0; mm < NCL; ++mm)
+                if (mm != m && (w[k][mm][1] != tag || w[k][mm][3] != tag)) {
+                    if (rounds < NEAR_ROUNDS) w[k][mm] = __builtin_amdgcn_raw_buffer_load_b128(area, (mm * NP + e) * 16, 0, LL_SC0 | LL_VOLATILE);
+                    else w[k][mm] = __builtin_amdgcn_raw_buffer_load_b128(area, (mm * NP + e) * 16, 0, LL_SC1 | LL_VOLATILE);
+                }
+        }
+        asm volatile("" ::: "memory");
+        missing = false;
+#pragma unroll
+        for (int k = 0; k < EPT; ++k)
+#pragma unroll
+            for (int mm = 0; mm < NCL; ++mm) missing |= mm != m && (w[k][mm][1] != tag || w[k][mm][3] != tag);
+        if (++rounds > (1 << 21)) __builtin_trap();                      // seconds: never in a sane run
+    } while (missing);
+    if (dbg_rounds) *dbg_rounds = rounds;
+#pragma unroll
+    for (int k = 0; k < EPT; ++k) {
+        const int e = threadIdx.x + k * NT;
+        if (e < NP) {
+            const int r = e / (C / 2), c = (e % (C / 2)) * 2;
+            const float o0 = pb[r * LDX + c], o1 = pb[r * LDX + c + 1];
+            float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+            for (int mm = 0; mm < NCL; ++mm) {
+                s0 += mm == m ? o0 : __uint_as_float(w[k][mm][0]);
+                s1 += mm == m ? o1 : __uint_as_float(w[k][mm][2]);
+            }
+            epi(k, r, c, s0, s1);                     // (k: which of this thread's packets -- indexes what it preloaded per packet)
+        }
+    }
+}
+// block id -> (row block, member): ids that agree modulo 8 share an XCD; a cluster = NCL consecutive slots of one XCD
+template <int NCL>
+__device__ __forceinline__ void cluster_ids(int bid, int& blk, int& m) {
+    const int xcd = bid & 7, slot = bid >> 3;
+    m = slot % NCL;
+    blk = (slot / NCL) * 8 + xcd;
+}
+
+// rows of an LDS bf16 tile [BM][LD] -> columns [c0, c0 + N) of global [R][LDG]
+template <int BM, int N, int LD>
+__device__ __forceinline__ void store_cols(const uint16_t* __restrict__ src, uint16_t* __restrict__ dst, int ldg, int c0, int r0, int R) {
+    for (int e = threadIdx.x; e < BM * (N / 8); e += NT) {
+        const int r = e / (N / 8), c = (e % (N / 8)) * 8;
+        if (r0 + r < R) *reinterpret_cast<uint4*>(dst + (int64_t)(r0 + r) * ldg + c0 + c) = *reinterpret_cast<const uint4*>(src + r * LD + c);
+    }
+}
+
+template <int BM, int C, int F, int NCL>
+__global__ __launch_bounds__(NT) void layer_chain_fwd_cl_kernel(const ChainParams p) {
+    constexpr int FS = F / NCL, QS = 3 * C / NCL;
+    constexpr int LDA = C + 8, LDHS = FS + 8, LDX = C + 4, MT = BM / 16;
+    static_assert(BM == 16 && FS % 32 == 0 && QS % 16 == 0 && QS <= FS, "cluster split");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float* xb = reinterpret_cast<float*>(smem_raw);                              // [BM][LDX] f32: x -> x1 -> x2
+    float* pb = xb + BM * LDX;                                                   // [BM][LDX] f32: this member's FFN-2 partial sums
+    uint16_t* ab = reinterpret_cast<uint16_t*>(pb + BM * LDX);                   // [BM][LDA] bf16: a -> z -> out_a
+    uint16_t* hb = ab + BM * LDA;                                                // [BM][LDHS] bf16: this member's columns of h
+    uint16_t* ub = hb + BM * LDHS;                                               // [BM][LDHS] bf16: ... of u, later of the next qkv
+    int blk, m;
+    cluster_ids<NCL>((int)blockIdx.x, blk, m);
+    const int r0 = blk * BM;
+    if (r0 >= p.R) return;                                                       // (a whole cluster: nobody waits for it)
+    const int lane = threadIdx.x & 63;
+    const int j = lane & 15, q = lane >> 4;
+    const uint64_t seed = p.thr ? p.seed + (p.seed_dev ? *p.seed_dev : 0ull) : 0ull;
+    STAMP_DECL;
+    STAMP(0);
+
+    // ---- everything read from global memory besides the big weights is requested NOW, in the order of its use: loads return
+    // in issue order, so a late request (a bias inside a GEMM epilogue, the slow sc1 load of `gen`) is waited for together with
+    // whatever was requested before it
+    constexpr int AE = (BM * (C / 8) + NT - 1) / NT, XE = (BM * (C / 4) + NT - 1) / NT;
+    uint4 a_in[AE];
+    float4 x_in[XE];
+#pragma unroll
+    for (int k = 0; k < AE; ++k) {
+        const int e = min(threadIdx.x + k * NT, BM * (C / 8) - 1), r = e / (C / 8), c = (e % (C / 8)) * 8;
+        a_in[k] = *reinterpret_cast<const uint4*>(p.a + (int64_t)min(r0 + r, p.R - 1) * C + c);
+    }
+#pragma unroll
+    for (int k = 0; k < XE; ++k) {
+        const int e = min(threadIdx.x + k * NT, BM * (C / 4) - 1), r = e / (C / 4), c = (e % (C / 4)) * 4;
+        x_in[k] = *reinterpret_cast<const float4*>(p.x + (int64_t)min(r0 + r, p.R - 1) * C + c);
+    }
+    WPre<C, C> pre1;
+    pre1.issue(p.wo);
+    LnW<C> ln1, ln2;
+    ln1.issue(p.n1w, p.n1b);
+    ln2.issue(p.nxw, p.nxb);
+    // biases at this lane's columns: group g of a product belongs to wave g % NW and is that wave's (g / NW)-th
+    const int wave = threadIdx.x >> 6;
+    constexpr int NG1 = (C / 16 + NW - 1) / NW, NG2 = (FS / 16 + NW - 1) / NW, NG4 = (QS / 16 + NW - 1) / NW;
+    constexpr int PE = (BM * C / 2 + NT - 1) / NT;
+    uint16_t bo_l[NG1], b1_l[NG2], bq_l[NG4];
+    uint32_t b2_l[PE];
+#pragma unroll
+    for (int i = 0; i < NG1; ++i) bo_l[i] = p.bo[min(16 * (wave + i * NW), C - 16) + j];
+#pragma unroll
+    for (int i = 0; i < NG2; ++i) b1_l[i] = p.b1[m * FS + min(16 * (wave + i * NW), FS - 16) + j];
+#pragma unroll
+    for (int i = 0; i < NG4; ++i) bq_l[i] = p.wq ? p.bq[m * QS + min(16 * (wave + i * NW), QS - 16) + j] : (uint16_t)0;
+#pragma unroll
+    for (int k = 0; k < PE; ++k) b2_l[k] = *reinterpret_cast<const uint32_t*>(p.b2 + (min((int)threadIdx.x + k * NT, BM * C / 2 - 1) % (C / 2)) * 2);
+    const uint32_t gen = __hip_atomic_load(p.ws_gen + blk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (used at the hand-over)
+#pragma unroll
+    for (int k = 0; k < AE; ++k) {
+        const int e = threadIdx.x + k * NT, r = e / (C / 8), c = (e % (C / 8)) * 8;
+        if (e < BM * (C / 8)) *reinterpret_cast<uint4*>(ab + r * LDA + c) = a_in[k];
+    }
+#pragma unroll
+    for (int k = 0; k < XE; ++k) {
+        const int e = threadIdx.x + k * NT, r = e / (C / 4), c = (e % (C / 4)) * 4;
+        if (e < BM * (C / 4)) *reinterpret_cast<float4*>(xb + r * LDX + c) = x_in[k];
+    }
+    __syncthreads();
+    STAMP(1);
+
+    // ---- y = a Wo^T + bo;  x1 = x + dropout(y): in full on every member
+    WPre<FS, C> pre2;
+    wg_gemm<BM, C, C, LDA>(ab, p.wo, [&](int g, const f32x4 (&acc)[MT]) {
+        const int col = 16 * g + j;
+        float bias = bf16_val(bo_l[0]);
+#pragma unroll
+        for (int i = 1; i < NG1; ++i) bias = g / NW == i ? bf16_val(bo_l[i]) : bias;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const int r = 4 * q + v;
+            float y = bf16_round(acc[0][v] + bias);
+            if (p.thr) {
+                const uint32_t rowh = dropout_row_hash(seed, (uint32_t)(r0 + r) ^ p.salt1);
+                y = dropout_bits16(seed, rowh, (uint32_t)col) >= p.thr ? y * p.inv_keep : 0.f;
+            }
+            xb[r * LDX + col] += y;
+        }
+    }, pre1);
+#ifdef CH_DEBUG_ACK
+    st_[14] = (int)wall_clock64();
+#endif
+    pre2.issue(p.w1, m * (FS / 16));
+#ifdef CH_DEBUG_ACK
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    st_[15] = (int)wall_clock64();
+#endif
+    __syncthreads();
+    STAMP(2);
+    // ---- z = ffn_norm1(x1): every member norms all rows, member m writes rows m (mod NCL)
+    ln_rows<BM, C, LDX, LDA>(xb, ab, ln1, p.x1, p.z, nullptr, p.mean1, p.rstd1, r0, p.R, NCL, m);
+    __syncthreads();
+    STAMP(3);
+    // ---- columns [m FS, (m + 1) FS) of u = z W1^T + b1;  h = gelu(u)
+    WPre<C, FS, F / 32> pre3;
+    wg_gemm<BM, FS, C, LDA>(ab, p.w1, [&](int g, const f32x4 (&acc)[MT]) {
+        const int cl = 16 * g + j;
+        float bias = bf16_val(b1_l[0]);
+#pragma unroll
+        for (int i = 1; i < NG2; ++i) bias = g / NW == i ? bf16_val(b1_l[i]) : bias;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const int r = 4 * q + v;
+            const uint16_t ubits = bf16_bits(acc[0][v] + bias);
+            ub[r * LDHS + cl] = ubits;
+            hb[r * LDHS + cl] = bf16_bits(gelu_f(bf16_val(ubits)));
+        }
+    }, pre2, m * (FS / 16));
+    pre3.issue(p.w2, 0, m * (FS / 32));
+    __syncthreads();
+    STAMP(4);
+    // (u, h leave NOW: stores and loads retire in issue order, so a store in front of the hand-over's polls is waited for there)
+    store_cols<BM, FS, LDHS>(ub, p.u, F, m * FS, r0, p.R);
+    store_cols<BM, FS, LDHS>(hb, p.h, F, m * FS, r0, p.R);
+    // ---- FFN-2 over this member's K range: partial sums of f = h W2^T
+    WPre<QS, C> pre4;
+    if (p.wq) pre4.issue(p.wq, m * (QS / 16));        // (HERE: requested behind this product, the hand-over's polls would wait for it)
+    wg_gemm<BM, C, FS, LDHS>(hb, p.w2, [&](int g, const f32x4 (&acc)[MT]) {
+        const int col = 16 * g + j;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) pb[(4 * q + v) * LDX + col] = acc[0][v];
+    }, pre3, 0, m * (FS / 32));
+    __syncthreads();
+    STAMP(5);
+    // ---- the partial sums change hands;  f = sum in member order + b2;  x2 = x1 + dropout(f)
+    const __amdgpu_buffer_rsrc_t area = cluster_area<BM, C, NCL>(p.ws_ll, blk);
+    cluster_put<BM, C, LDX>(area, m, pb, gen + 1u);
+    STAMP(6);
+#ifdef CH_DEBUG_ACK
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    st_[13] = (int)wall_clock64();
+#endif
+    cluster_get<BM, C, LDX, NCL>(area, m, pb, gen + 1u, [&](int k, int r, int c, float s0, float s1) {
+        float f0 = bf16_round(s0 + bf16_val((uint16_t)b2_l[k])), f1 = bf16_round(s1 + bf16_val((uint16_t)(b2_l[k] >> 16)));
+        if (p.thr) {
+            const uint32_t rowh = dropout_row_hash(seed, (uint32_t)(r0 + r) ^ p.salt2);
+            f0 = dropout_bits16(seed, rowh, (uint32_t)c) >= p.thr ? f0 * p.inv_keep : 0.f;
+            f1 = dropout_bits16(seed, rowh, (uint32_t)(c + 1)) >= p.thr ? f1 * p.inv_keep : 0.f;
+        }
+        xb[r * LDX + c] += f0;
+        xb[r * LDX + c + 1] += f1;
+    }
+#ifdef CH_DEBUG
+    , &st_[11]
+#endif
+    );
+#ifdef CH_DEBUG
+    st_[12] = (int)wall_clock64();
+#endif
+    __syncthreads();
+    // (every thread of this workgroup holds every member's words: all of them have read gen)
+    if (m == 0 && threadIdx.x == 0) __hip_atomic_store(p.ws_gen + blk, gen + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    STAMP(7);
+    // ---- out = ffn_norm2(x2)
+    ln_rows<BM, C, LDX, LDA>(xb, ab, ln2, p.x2, p.out_a, p.out, p.mean2, p.rstd2, r0, p.R, NCL, m);
+    if (!p.wq) return;
+    __syncthreads();
+    STAMP(8);
+    // ---- columns [m QS, (m + 1) QS) of the next layer's qkv = out Wqkv^T + bqkv
+    wg_gemm<BM, QS, C, LDA>(ab, p.wq, [&](int g, const f32x4 (&acc)[MT]) {
+        const int cl = 16 * g + j;
+        float bias = bf16_val(bq_l[0]);
+#pragma unroll
+        for (int i = 1; i < NG4; ++i) bias = g / NW == i ? bf16_val(bq_l[i]) : bias;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) ub[(4 * q + v) * LDHS + cl] = bf16_bits(acc[0][v] + bias);
+    }, pre4, m * (QS / 16));
+    __syncthreads();
+    STAMP(9);
+    store_cols<BM, QS, LDHS>(ub, p.qkv, 3 * C, m * QS, r0, p.R);
+    STAMP(10);
+    STAMP_DUMP();
+}
+
+int device_cus() {
+    static int n = 0;
+    if (!n) {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) n = v;
+        else n = 256;
+    }
+    return n;
+}
+// members per row block: as many (4, 2) as keeps every live workgroup on a compute unit of its own; 1 = the one-workgroup form
+int pick_ncl(int64_t R, const void* ws) {
+    if (!ws) return 1;
+    static int forced = -1;
+    if (forced < 0) {
+        const char* e = getenv("MOBGT_CHAIN_NCL");
+        forced = e ? atoi(e) : 0;
+    }
+    const int nblk = (int)((R + 15) / 16), cus = device_cus() < 256 ? device_cus() : 256;
+    int ncl = nblk * 4 <= cus ? 4 : (nblk * 2 <= cus ? 2 : 1);
+    if ((forced == 1 || forced == 2 || forced == 4) && forced < ncl) ncl = forced;
+    return ncl;
+}
+
+template <int BM, int C, int F, int NCL>
+int launch_cl(const ChainParams& p, hipStream_t st) {
+    constexpr size_t lds = 2 * BM * (C + 4) * 4 + BM * (C + 8) * 2 + 2 * BM * (F / NCL + 8) * 2;
+    int rc = (int)hipFuncSetAttribute((const void*)layer_chain_fwd_cl_kernel<BM, C, F, NCL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (rc) return rc;
+    const int nblk = (p.R + BM - 1) / BM;
+    hipLaunchKernelGGL((layer_chain_fwd_cl_kernel<BM, C, F, NCL>), dim3(8 * NCL * ((nblk + 7) / 8)), dim3(NT), lds, st, p);
+    return (int)hipGetLastError();
 }
 
 constexpr int PACK_MAX = 96;                 // 12 layers x (4 forward + 3 transposed) weights in one launch
@@ -562,6 +911,8 @@ struct ChainBwdParams {
     mobgt_wgrad::WgradParams wg[4];
     int wg_first[5], wg_tiles[4], wg_splits[4];
     int n_wg, n_chain;
+    uint32_t* ws_gen;                        // cluster form: launch generations and the exchange area (see cluster_sum)
+    uint64_t* ws_ll;
 };
 
 // gelu'(u) = Phi(u) + u phi(u); the exponential of the A&S erf IS phi's
@@ -609,7 +960,8 @@ __device__ __forceinline__ void ln_bwd_rows(const float* __restrict__ d_lds, con
                                             const LnBwdPre<BM, C>& pre,
                                             const float* res, float* dx_lds, float* __restrict__ dx_g,
                                             uint16_t* __restrict__ dy_lds, uint16_t* __restrict__ dy_g, float* __restrict__ red,
-                                            int r0, int R, uint32_t thr, float inv_keep, uint64_t seed, uint32_t salt) {
+                                            int r0, int R, uint32_t thr, float inv_keep, uint64_t seed, uint32_t salt,
+                                            int own_mod = 1, int own_rem = 0) {
     constexpr int PER = (C + 63) / 64;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const float (&wv)[PER] = pre.w;
@@ -653,7 +1005,7 @@ __device__ __forceinline__ void ln_bwd_rows(const float* __restrict__ d_lds, con
                 ay[k] += yv;
                 const uint16_t yb = bf16_bits(yv);
                 dy_lds[r * LDA + c] = yb;
-                if (on) {
+                if (on && (own_mod == 1 || r % own_mod == own_rem)) {
                     if (dx_g) dx_g[row * C + c] = t;
                     dy_g[row * C + c] = yb;
                 }
@@ -672,9 +1024,9 @@ __device__ __forceinline__ void ln_bwd_rows(const float* __restrict__ d_lds, con
 }
 
 template <int C>
-__device__ __forceinline__ void flush_colsums(const float* __restrict__ red, float* g0, float* g1, float* g2) {
-    for (int e = threadIdx.x; e < 3 * C; e += NT) {
-        const int which = e / C, c = e % C;
+__device__ __forceinline__ void flush_colsums(const float* __restrict__ red, float* g0, float* g1, float* g2, int c_lo = 0, int c_n = C) {
+    for (int e = threadIdx.x; e < 3 * c_n; e += NT) {
+        const int which = e / c_n, c = c_lo + e % c_n;
         float s = 0.f;
 #pragma unroll
         for (int w = 0; w < NW; ++w) s += red[(which * NW + w) * C + c];
@@ -787,6 +1139,138 @@ __global__ __launch_bounds__(NT) void layer_chain_bwd_kernel(const ChainBwdParam
     store_rows<BM, C, LDH>(ub, p.da, r0, p.R);
 }
 
+
+// the backward chain, cluster form (see layer_chain_fwd_cl_kernel): member m owns the column range m of du (and of u) and of
+// da, and the K range m of dz = du W1; the small products (the layer above's tail dqkv Wqkv, 221 KB) run in full on every member
+template <int BM, int C, int F, int NCL>
+__global__ __launch_bounds__(NT) void layer_chain_bwd_cl_kernel(const ChainBwdParams p) {
+    constexpr int FS = F / NCL, CS = C / NCL;
+    constexpr int LDA = C + 8, LDHS = FS + 8, LDX = C + 4, LDQ = 3 * C + 8, MT = BM / 16;
+    static_assert(BM == 16 && CS % 16 == 0 && FS % 32 == 0 && CS <= FS, "cluster split");
+    static_assert(3 * NW * C * 4 >= BM * LDQ * 2, "the dqkv tile lives where the column-sum partials go later");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float* dxb = reinterpret_cast<float*>(smem_raw);                             // [BM][LDX] f32: dx2, then dx1
+    float* dzb = dxb + BM * LDX;                                                 // [BM][LDX] f32: d(out), later dz
+    float* pb = dzb + BM * LDX;                                                  // [BM][LDX] f32: this member's partial sums of dz
+    float* red = pb + BM * LDX;                                                  // [3][NW][C] f32 column-sum partials
+    uint16_t* tq = reinterpret_cast<uint16_t*>(red);                             //   (before them: [BM][LDQ] bf16, the upper layer's dqkv rows)
+    uint16_t* gb = reinterpret_cast<uint16_t*>(red + 3 * NW * C);                // [BM][LDA] bf16: df, then dy
+    uint16_t* ub = gb + BM * LDA;                                                // [BM][LDHS] bf16: this member's columns of u, later of da
+    uint16_t* dub = ub + BM * LDHS;                                              // [BM][LDHS] bf16: ... of du
+    if ((int)blockIdx.x >= p.n_chain) {          // passenger: one 32 x 32 tile of one of the upper layer's weight gradients
+        const int bid = (int)blockIdx.x - p.n_chain;
+        int qn = 0;
+#pragma unroll
+        for (int t = 1; t < 4; ++t)
+            if (t < p.n_wg && bid >= p.wg_first[t]) qn = t;
+        const int local = bid - p.wg_first[qn];
+        mobgt_wgrad::wgrad_body<false, NW>(p.wg[qn], local % p.wg_tiles[qn], local / p.wg_tiles[qn], p.wg_splits[qn],
+                                           reinterpret_cast<float*>(smem_raw));
+        return;
+    }
+    int blk, m;
+    cluster_ids<NCL>((int)blockIdx.x, blk, m);
+    const int r0 = blk * BM;
+    if (r0 >= p.R) return;
+    const int lane = threadIdx.x & 63;
+    const int j = lane & 15, q = lane >> 4;
+    const uint64_t seed = p.thr ? p.seed + (p.seed_dev ? *p.seed_dev : 0ull) : 0ull;
+
+    WPre<C, 3 * C> pre0;
+    if (p.t_dqkv) pre0.issue(p.t_wqt);
+    WPre<FS, C> pre1;
+    pre1.issue(p.w2t, m * (FS / 16));
+    LnBwdPre<BM, C> lp2, lp1;
+    lp2.issue(p.x2, p.mean2, p.rstd2, p.nxw, r0, p.R);
+    lp1.issue(p.x1, p.mean1, p.rstd1, p.n1w, r0, p.R);
+    for (int e = threadIdx.x; e < BM * (FS / 8); e += NT) {                       // this member's columns of u -> LDS
+        const int r = e / (FS / 8), c = (e % (FS / 8)) * 8;
+        *reinterpret_cast<uint4*>(ub + r * LDHS + c) = *reinterpret_cast<const uint4*>(p.u + (int64_t)min(r0 + r, p.R - 1) * F + m * FS + c);
+    }
+    if (p.t_dqkv) {
+        // ---- the upper layer's input gradient, finished here by every member: dout <- dx1 (what `dout` holds) + dqkv Wqkv
+        for (int e = threadIdx.x; e < BM * (C / 4); e += NT) {
+            const int r = e / (C / 4), c = (e % (C / 4)) * 4;
+            *reinterpret_cast<float4*>(dzb + r * LDX + c) = *reinterpret_cast<const float4*>(p.dout + (int64_t)min(r0 + r, p.R - 1) * C + c);
+        }
+        for (int e = threadIdx.x; e < BM * (3 * C / 8); e += NT) {
+            const int r = e / (3 * C / 8), c = (e % (3 * C / 8)) * 8;
+            *reinterpret_cast<uint4*>(tq + r * LDQ + c) = *reinterpret_cast<const uint4*>(p.t_dqkv + (int64_t)min(r0 + r, p.R - 1) * (3 * C) + c);
+        }
+        __syncthreads();
+        wg_gemm<BM, C, 3 * C, LDQ>(tq, p.t_wqt, [&](int g, const f32x4 (&acc)[MT]) {
+            const int col = 16 * g + j;
+#pragma unroll
+            for (int v = 0; v < 4; ++v) dzb[(4 * q + v) * LDX + col] += acc[0][v];
+        }, pre0);
+        __syncthreads();
+    }
+    // ---- dx2 = ffn_norm2'(dout);  df = dropout'(dx2): all rows on every member, member m writes rows m (mod NCL) and
+    //      the column sums of columns [m CS, (m + 1) CS)
+    const uint32_t gen = __hip_atomic_load(p.ws_gen + blk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // (used at the hand-over)
+    ln_bwd_rows<BM, C, LDX, LDA>(p.t_dqkv ? dzb : nullptr, p.dout, lp2, nullptr, dxb, nullptr, gb, p.df, red, r0, p.R,
+                                 p.thr, p.inv_keep, seed, p.salt2, NCL, m);
+    __syncthreads();
+    flush_colsums<C>(red, p.dnxw, p.dnxb, p.db2, m * CS, CS);
+    // ---- columns [m FS, (m + 1) FS) of du = (df W2) * gelu'(u)
+    WPre<C, FS, F / 32> pre2;
+    wg_gemm<BM, FS, C, LDA>(gb, p.w2t, [&](int g, const f32x4 (&acc)[MT]) {
+        const int cl = 16 * g + j;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const int r = 4 * q + v;
+            dub[r * LDHS + cl] = bf16_bits(acc[0][v] * gelu_grad_f(bf16_val(ub[r * LDHS + cl])));
+        }
+    }, pre1, m * (FS / 16));
+    pre2.issue(p.w1t, 0, m * (FS / 32));
+    __syncthreads();
+    store_cols<BM, FS, LDHS>(dub, p.du, F, m * FS, r0, p.R);            // (not in front of the hand-over's polls: they would wait for it)
+    // ---- dz = du W1 over this member's K range: partial sums
+    WPre<CS, C> pre3;
+    wg_gemm<BM, C, FS, LDHS>(dub, p.w1t, [&](int g, const f32x4 (&acc)[MT]) {
+        const int col = 16 * g + j;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) pb[(4 * q + v) * LDX + col] = acc[0][v];
+    }, pre2, 0, m * (FS / 32));
+    pre3.issue(p.wot, m * (CS / 16));
+    __syncthreads();
+    // ---- the partial sums change hands;  dz = bf16(sum in member order)
+    const __amdgpu_buffer_rsrc_t area = cluster_area<BM, C, NCL>(p.ws_ll, blk);
+    cluster_put<BM, C, LDX>(area, m, pb, gen + 1u);
+    cluster_get<BM, C, LDX, NCL>(area, m, pb, gen + 1u, [&](int, int r, int c, float s0, float s1) {
+        dzb[r * LDX + c] = bf16_round(s0);
+        dzb[r * LDX + c + 1] = bf16_round(s1);
+    });
+    __syncthreads();
+    // (every thread of this workgroup holds every member's words: all of them have read gen)
+    if (m == 0 && threadIdx.x == 0) __hip_atomic_store(p.ws_gen + blk, gen + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // ---- dx1 = dx2 + ffn_norm1'(dz);  dy = dropout'(dx1)
+    ln_bwd_rows<BM, C, LDX, LDA>(dzb, nullptr, lp1, dxb, dxb, p.dx1, gb, p.dy, red, r0, p.R, p.thr,
+                                 p.inv_keep, seed, p.salt1, NCL, m);
+    __syncthreads();
+    flush_colsums<C>(red, p.dn1w, p.dn1b, p.dbo, m * CS, CS);
+    // ---- columns [m CS, (m + 1) CS) of da = dy Wo
+    wg_gemm<BM, CS, C, LDA>(gb, p.wot, [&](int g, const f32x4 (&acc)[MT]) {
+        const int cl = 16 * g + j;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) ub[(4 * q + v) * LDHS + cl] = bf16_bits(acc[0][v]);
+    }, pre3, m * (CS / 16));
+    __syncthreads();
+    store_cols<BM, CS, LDHS>(ub, p.da, C, m * CS, r0, p.R);
+}
+
+template <int BM, int C, int F, int NCL>
+int launch_bwd_cl(ChainBwdParams& p, hipStream_t st) {
+    constexpr size_t lds = 3 * BM * (C + 4) * 4 + 3 * NW * C * 4 + BM * (C + 8) * 2 + 2 * BM * (F / NCL + 8) * 2;
+    static_assert(lds <= 152 * 1024 && lds >= mobgt_wgrad::wgrad_lds_floats<NW>() * sizeof(float), "LDS plan");
+    int rc = (int)hipFuncSetAttribute((const void*)layer_chain_bwd_cl_kernel<BM, C, F, NCL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (rc) return rc;
+    const int nblk = (p.R + BM - 1) / BM;
+    p.n_chain = 8 * NCL * ((nblk + 7) / 8);
+    hipLaunchKernelGGL((layer_chain_bwd_cl_kernel<BM, C, F, NCL>), dim3(p.n_chain + (p.n_wg ? p.wg_first[p.n_wg] : 0)), dim3(NT), lds, st, p);
+    return (int)hipGetLastError();
+}
+
 template <int BM, int C, int F>
 int launch_bwd(const ChainBwdParams& p, hipStream_t st) {
     constexpr size_t lds = 2 * BM * (C + 4) * 4 + 3 * NW * C * 4 + BM * (C + 8) * 2 + 2 * BM * (F + 8) * 2;
@@ -830,9 +1314,10 @@ extern "C" int mobgt_layer_chain_fwd(const void* a, const float* x, const void* 
                                      void* z, void* u, void* h, float* x2, float* out, void* out_a, void* qkv_next,
                                      float* mean1, float* rstd1, float* mean2, float* rstd2, int64_t R, int C, int F,
                                      float dropout_p, uint64_t seed, const uint64_t* seed_dev, uint32_t salt1, uint32_t salt2,
-                                     void* stream) {
+                                     void* ws, void* stream) {
     if (R <= 0) return 0;
     if (R > 0x7fffffff) return MOBGT_EBADDIM;
+    if ((uintptr_t)ws & 15) return MOBGT_EALIGN;
     if (((uintptr_t)a | (uintptr_t)x | (uintptr_t)wo | (uintptr_t)w1 | (uintptr_t)w2 | (uintptr_t)wq_next | (uintptr_t)h | (uintptr_t)u | (uintptr_t)qkv_next) & 15)
         return MOBGT_EALIGN;
     if ((wq_next == nullptr) != (qkv_next == nullptr)) return MOBGT_EBADDIM;
@@ -846,6 +1331,14 @@ extern "C" int mobgt_layer_chain_fwd(const void* a, const float* x, const void* 
     p.inv_keep = p.thr ? 1.f / (1.f - (float)p.thr / 65536.f) : 1.f;
     p.seed = seed; p.seed_dev = seed_dev; p.salt1 = salt1; p.salt2 = salt2;
     hipStream_t st = (hipStream_t)stream;
+    const int ncl = pick_ncl(R, ws);
+    if (ncl > 1) {
+        p.ws_gen = reinterpret_cast<uint32_t*>(ws);
+        p.ws_ll = reinterpret_cast<uint64_t*>(reinterpret_cast<uint32_t*>(ws) + WS_GEN_INTS);
+        if (C == 192 && F == 1024) return ncl == 4 ? launch_cl<16, 192, 1024, 4>(p, st) : launch_cl<16, 192, 1024, 2>(p, st);
+        if (C == 256 && F == 1024) return ncl == 4 ? launch_cl<16, 256, 1024, 4>(p, st) : launch_cl<16, 256, 1024, 2>(p, st);
+        return MOBGT_EBADDIM;
+    }
     if (C == 192 && F == 1024) return launch<16, 192, 1024>(p, st);
     if (C == 256 && F == 1024) return launch<16, 256, 1024>(p, st);
     return MOBGT_EBADDIM;                    // the instantiated widths: MobGT's hidden 128 / 192 (+ 64 of embeddings), ffn 1024
@@ -859,8 +1352,9 @@ extern "C" int mobgt_layer_chain_bwd(const float* dout, const float* x2, const f
                                      const uint64_t* seed_dev, uint32_t salt1, uint32_t salt2, const void* tail_dqkv,
                                      const void* tail_wqkv_t, int n_wg, const void* const* wg_g, const int64_t* wg_ldg,
                                      const void* const* wg_x, const int64_t* wg_ldx, float* const* wg_dw, const int64_t* wg_ldw,
-                                     float* const* wg_db, const int* wg_M, const int* wg_N, void* stream) {
+                                     float* const* wg_db, const int* wg_M, const int* wg_N, void* ws, void* stream) {
     if (R <= 0) return 0;
+    if ((uintptr_t)ws & 15) return MOBGT_EALIGN;
     if (R > 0x7fffffff || n_wg < 0 || n_wg > 4) return MOBGT_EBADDIM;
     if (((uintptr_t)u | (uintptr_t)w2t | (uintptr_t)w1t | (uintptr_t)wot | (uintptr_t)du | (uintptr_t)da | (uintptr_t)tail_dqkv |
          (uintptr_t)tail_wqkv_t | (uintptr_t)dout) & 15) return MOBGT_EALIGN;
@@ -888,9 +1382,21 @@ extern "C" int mobgt_layer_chain_bwd(const float* dout, const float* x2, const f
     }
     for (int i = n_wg; i <= 4; ++i) p.wg_first[i] = total;
     hipStream_t st = (hipStream_t)stream;
+    const int ncl = pick_ncl(R, ws);
+    if (ncl > 1) {
+        p.ws_gen = reinterpret_cast<uint32_t*>(ws);
+        p.ws_ll = reinterpret_cast<uint64_t*>(reinterpret_cast<uint32_t*>(ws) + WS_GEN_INTS);
+        if (C == 192 && F == 1024) return ncl == 4 ? launch_bwd_cl<16, 192, 1024, 4>(p, st) : launch_bwd_cl<16, 192, 1024, 2>(p, st);
+        if (C == 256 && F == 1024) return ncl == 4 ? launch_bwd_cl<16, 256, 1024, 4>(p, st) : launch_bwd_cl<16, 256, 1024, 2>(p, st);
+        return MOBGT_EBADDIM;
+    }
     if (C == 192 && F == 1024) return launch_bwd<16, 192, 1024>(p, st);
     if (C == 256 && F == 1024) return launch_bwd<16, 256, 1024>(p, st);
     return MOBGT_EBADDIM;
+}
+
+extern "C" int64_t mobgt_chain_ws_bytes(void) {
+    return (int64_t)(WS_GEN_INTS * sizeof(uint32_t) + WS_LL_WORDS * sizeof(uint64_t));
 }
 
 extern "C" int mobgt_assemble_tokens_qkv(const float* nf, const float* real, const float* add, const float* token,

@@ -253,6 +253,24 @@ def _pending_check():
                            "(was the layer's input used by something else as well?); set MOBGT_NO_DEFER_TAIL=1")
 
 
+_CHAIN_WS = {}              # device index -> workspace of the chain kernels' cluster form
+
+
+def chain_workspace(dev):
+    """Hand-over counters + exchange buffers of the cluster form of the chain kernels (include/mobgt_hip.h:
+    mobgt_chain_ws_bytes): one per device, zeroed once, for ONE stream at a time (the step's compute stream).  It must exist
+    before a graph capture starts (an eager warm-up step creates it).  MOBGT_CHAIN_NCL=1 -> None (one-workgroup form)."""
+    if _os_ln.environ.get("MOBGT_CHAIN_NCL") == "1":
+        return None
+    key = dev.index if dev.index is not None else torch.cuda.current_device()
+    ws = _CHAIN_WS.get(key)
+    if ws is None:
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("the chain kernels' workspace must be allocated before graph capture: run one eager step first")
+        ws = _CHAIN_WS[key] = torch.zeros(int(_lib.lib().mobgt_chain_ws_bytes()), dtype=torch.uint8, device=dev)
+    return ws
+
+
 def _chain_ok(C, F, *ts):
     return (_CHAIN[0] and (C, F) in ((192, 1024), (256, 1024))
             and all(t is None or (t.is_contiguous() and t.data_ptr() % 16 == 0) for t in ts))
@@ -379,7 +397,7 @@ class _FusedLayerFn(torch.autograd.Function):
                                                    _p(nq[1] if nq else None), _p(x1), _p(z), _p(u), _p(h), _p(x2), _p(out),
                                                    _p(out_a), _p(qkv_next), _p(stats[2]), _p(stats[3]), _p(stats[4]),
                                                    _p(stats[5]), R, C, F, cfg.p, seed, _p(sd), (salt + 1) & 0xFFFFFFFF,
-                                                   (salt + 2) & 0xFFFFFFFF, _stream()), "mobgt_layer_chain_fwd")
+                                                   (salt + 2) & 0xFFFFFFFF, _p(chain_workspace(dev)), _stream()), "mobgt_layer_chain_fwd")
             cfg.out_act, cfg.out_qkv = out_a, qkv_next
         else:
             out, x1, z, u, h, x2 = _FusedLayerFn._tail_launches(ctx, cfg, x, a, stats, shadows, own, stock, n1w, n1b, nxw, nxb,
@@ -543,7 +561,7 @@ class _FusedLayerFn(torch.autograd.Function):
                                                    _p(stats[5]), _p(n1w), _p(nxw), _p(w2t), _p(w1t), _p(wot), _p(df), _p(du),
                                                    _p(dy), _p(da), _p(dx1), _p(dnxw), _p(dnxb), _p(db2), _p(dn1w), _p(dn1b),
                                                    _p(dbo), R, C, F, cfg.p, seed, _p(sd), (salt + 1) & 0xFFFFFFFF,
-                                                   (salt + 2) & 0xFFFFFFFF, *extra, _stream()), "mobgt_layer_chain_bwd")
+                                                   (salt + 2) & 0xFFFFFFFF, *extra, _p(chain_workspace(dev)), _stream()), "mobgt_layer_chain_bwd")
             da = da.view(G, T, C)
             dw2 = wb.add(df, h, sink=k_w2)
             dw1 = wb.add(du, z, db=db1, sink=k_w1)

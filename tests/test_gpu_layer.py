@@ -615,3 +615,89 @@ def test_layernorm_backward_and_column_sums_short_and_long_batches(R):
     (torch.nn.functional.gelu(uf) * dh.float()).sum().backward()
     np.testing.assert_allclose(du.float().cpu().numpy(), uf.grad.cpu().numpy(), rtol=8e-3, atol=2e-3)
     np.testing.assert_allclose(db1.cpu().numpy(), uf.grad.sum(0).cpu().numpy(), rtol=1e-4, atol=1e-4 * s)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("C,R,p", [(192, 185, 0.1), (192, 1040, 0.1), (256, 140, 0.0), (256, 1500, 0.1), (192, 16, 0.1)])
+def test_chain_cluster_form_equals_the_one_workgroup_form(C, R, p):
+    """csrc/chain.hip, cluster form (a 16-row block shared by 4 / 2 workgroups that split the weights and meet through the
+    workspace) against the one-workgroup form (ws = null) through the C ABI, forward and backward (with the upper layer's tail
+    product): everything in front of the first split-K sum is BIT-identical (x1, z, u, h / df, du); behind it the f32 sums
+    are added in 4 / 2 parts before the same bf16 rounding point, so values agree to one bf16 ulp of the rounded
+    intermediate.  Runs every launch twice (the hand-over counters must carry over) and at R = 1040 / 1500 the 2-member
+    form."""
+    import ctypes
+    from mobgt_amd import _lib
+    from mobgt_amd.fused_layer import chain_workspace
+    from mobgt_amd.ops import _p, _stream
+    lib = _lib.lib()
+    F = 1024
+    g = torch.Generator().manual_seed(C + R)
+    bf = lambda *s, k=1.0: (torch.randn(*s, generator=g) * k).to(DEV).bfloat16()
+    f32 = lambda *s, k=1.0: (torch.randn(*s, generator=g) * k).to(DEV)
+
+    def pack(w, transposed=False):
+        out = torch.empty(w.numel(), dtype=torch.bfloat16, device=DEV)
+        vp, ci = ctypes.c_void_p, ctypes.c_int
+        N, K = (w.shape[1], w.shape[0]) if transposed else w.shape
+        _lib.check(lib.mobgt_pack_mfma_b(1, (vp * 1)(w.data_ptr()), (vp * 1)(out.data_ptr()), (ci * 1)(N), (ci * 1)(K),
+                                         (ci * 1)(1 if transposed else 0), _stream()), "mobgt_pack_mfma_b")
+        return out
+    wo, w1, w2, wq = bf(C, C, k=C ** -0.5), bf(F, C, k=C ** -0.5), bf(C, F, k=F ** -0.5), bf(3 * C, C, k=C ** -0.5)
+    bo, b1, b2, bq = bf(C, k=0.1), bf(F, k=0.1), bf(C, k=0.1), bf(3 * C, k=0.1)
+    n1w, n1b, nxw, nxb = 1 + f32(C, k=0.1), f32(C, k=0.1), 1 + f32(C, k=0.1), f32(C, k=0.1)
+    a, x = bf(R, C), f32(R, C)
+    pk = {k: pack(w) for k, w in (("wo", wo), ("w1", w1), ("w2", w2), ("wq", wq))}
+    pkt = {k: pack(w, True) for k, w in (("wo", wo), ("w1", w1), ("w2", w2), ("wq", wq))}
+    ws = chain_workspace(a.device)
+    assert ws is not None and ws.numel() == lib.mobgt_chain_ws_bytes()
+    seed_dev = torch.tensor([5], dtype=torch.int64, device=DEV)
+
+    def forward(w):
+        o = dict(x1=torch.empty(R, C, device=DEV), x2=torch.empty(R, C, device=DEV), out=torch.empty(R, C, device=DEV),
+                 z=bf(R, C), out_a=bf(R, C), u=bf(R, F), h=bf(R, F), qkv=bf(R, 3 * C), st=torch.empty(4, R, device=DEV))
+        for _ in range(2):
+            _lib.check(lib.mobgt_layer_chain_fwd(_p(a), _p(x), _p(pk["wo"]), _p(bo), _p(n1w), _p(n1b), _p(pk["w1"]), _p(b1), _p(pk["w2"]),
+                                                 _p(b2), _p(nxw), _p(nxb), _p(pk["wq"]), _p(bq), _p(o["x1"]), _p(o["z"]), _p(o["u"]),
+                                                 _p(o["h"]), _p(o["x2"]), _p(o["out"]), _p(o["out_a"]), _p(o["qkv"]), _p(o["st"][0]),
+                                                 _p(o["st"][1]), _p(o["st"][2]), _p(o["st"][3]), R, C, F, p, 77, _p(seed_dev), 9, 10,
+                                                 _p(w), _stream()), "mobgt_layer_chain_fwd")
+        torch.cuda.synchronize()
+        return o
+    one, cl = forward(None), forward(ws)
+    for k in ("x1", "z", "u", "h"):
+        assert torch.equal(one[k], cl[k]), k
+    assert torch.equal(one["st"][:2], cl["st"][:2])
+    for k, tol in (("x2", 2 ** -7), ("out", 2 ** -6), ("qkv", 2 ** -5)):
+        d = float((one[k].float() - cl[k].float()).abs().max())
+        frac = float((one[k].float() != cl[k].float()).float().mean())
+        assert d <= tol * max(1.0, float(one[k].float().abs().max())), (k, d)
+        assert frac < 0.2, (k, frac)                       # (most sums round to the same bf16 value)
+
+    # ---- backward, with the upper layer's tail (dout holds its dx1; dout + dqkv Wqkv is finished inside)
+    dout, dqkv = f32(R, C), bf(R, 3 * C, k=0.3)
+    fw = one
+
+    def backward(w):
+        o = dict(df=bf(R, C), du=bf(R, F), dy=bf(R, C), da=bf(R, C), dx1=torch.empty(R, C, device=DEV),
+                 sums=torch.zeros(6, C, device=DEV))
+        for it in range(2):
+            o["sums"].zero_()
+            s = o["sums"]
+            _lib.check(lib.mobgt_layer_chain_bwd(_p(dout), _p(fw["x2"]), _p(fw["x1"]), _p(fw["u"]), _p(fw["st"][0]), _p(fw["st"][1]),
+                                                 _p(fw["st"][2]), _p(fw["st"][3]), _p(n1w), _p(nxw), _p(pkt["w2"]), _p(pkt["w1"]),
+                                                 _p(pkt["wo"]), _p(o["df"]), _p(o["du"]), _p(o["dy"]), _p(o["da"]), _p(o["dx1"]),
+                                                 _p(s[0]), _p(s[1]), _p(s[2]), _p(s[3]), _p(s[4]), _p(s[5]), R, C, F, p, 77, _p(seed_dev),
+                                                 9, 10, _p(dqkv), _p(pkt["wq"]), 0, None, None, None, None, None, None, None, None,
+                                                 None, _p(w), _stream()), "mobgt_layer_chain_bwd")
+        torch.cuda.synchronize()
+        return o
+    one, cl = backward(None), backward(ws)
+    for k in ("df", "du"):
+        assert torch.equal(one[k], cl[k]), k
+    for k in ("dy", "da", "dx1"):
+        sc = max(1.0, float(one[k].float().abs().max()))
+        d = float((one[k].float() - cl[k].float()).abs().max())
+        assert d <= 2 ** -6 * sc, (k, d, sc)
+    sc = one["sums"].abs().amax(1, keepdim=True).clamp_min(1e-6)
+    assert float(((one["sums"] - cl["sums"]).abs() / sc).max()) <= 1e-2       # (f32 atomics in another order + the above)
