@@ -508,6 +508,26 @@ int mobgt_layer_chain_bwd(const float* dout, const float* x2, const float* x1, c
  * never need resetting).  Same results as the one-workgroup form up to the f32 summation order of h w2^T and du w1 (NCL
  * partial sums).  ws = null: always the one-workgroup form.  MOBGT_CHAIN_NCL=1|2|4 caps the cluster size. */
 int64_t mobgt_chain_ws_bytes(void);
+/* The classifier head in front of out_proj, one launch each way (csrc/head.hip; model_fqandtoyo.py:1239-1240, 1353-1364,
+ * FuseEmbeddings 452-455):  x3 = [enc[g, 0, :] | table[user[g] + user_offset]] [G, C+U];  u3 = x3 w3^T + b3 (f32);
+ * out = dropout(ELU(LayerNorm(LeakyReLU_slope(u3)))).  Replaces mobgt_head_input_fwd + a small GEMM + mobgt_head_act_fwd (same
+ * values: full-f32 products, the dropout mask of mobgt_head_act_fwd with `salt`).  Written: x3, u3, out [G, C+U], mean / rstd [G].
+ * C + U in {320, 384}, C and U multiples of 16, G <= 160; user int32 / int64 (MOBGT_I32 / MOBGT_I64); rows of `table` outside
+ * [0, n_rows) read as zero.  ws: mobgt_head_chain_ws_bytes() bytes of device memory, 16-byte aligned, ZEROED ONCE at allocation,
+ * one stream at a time (a 16-row block is shared by (C + U) / 16 workgroups that exchange their tiles of u3 through it).
+ * Backward: dout = d(out) -> du3 [G, C+U] (written: the weight gradient du3^T x3 and the bias gradient are the caller's),
+ * denc [G,T,C] WRITTEN IN FULL (token rows = dx3[:, :C], all other rows zero), dtable += dx3[:, C:] at the users' rows,
+ * dgamma / dbeta += LayerNorm's (f32 atomics: zero them first). */
+int mobgt_head_chain_fwd(const float* enc, const void* user, int user_dtype, int64_t user_offset, const float* table,
+                         int64_t n_rows, const float* w3, const float* b3, const float* ln_w, const float* ln_b, float* x3,
+                         float* u3, float* out, float* mean, float* rstd, int G, int T, int C, int U, float eps, float slope,
+                         float dropout_p, uint64_t seed, const uint64_t* seed_dev, uint32_t salt, void* ws, void* stream);
+int64_t mobgt_head_chain_ws_bytes(void);
+int mobgt_head_chain_bwd(const float* dout, const float* u3, const float* mean, const float* rstd, const void* user,
+                         int user_dtype, int64_t user_offset, int64_t n_rows, const float* w3, const float* ln_w,
+                         const float* ln_b, float* du3, float* denc, float* dtable, float* dgamma, float* dbeta, int G, int T,
+                         int C, int U, float eps, float slope, float dropout_p, uint64_t seed, const uint64_t* seed_dev,
+                         uint32_t salt, void* stream);
 /* The whole 3-layer GCN of a SMALL dense graph (graphormer/modelGNN.py:53-74 on the ~300-node category graph,
  * model_fqandtoyo.py:1237) as ONE launch each way (csrc/smallgcn.hip): ceil(n/16) co-resident workgroups that meet at
  * `counter` (int[1], ZERO on entry) between the layers.

@@ -435,10 +435,17 @@ class Graphormer(nn.Module):
                 and user.dtype in (torch.int64, torch.int32) and user.numel() == output.shape[0]:
             # [graph-token row | user_embed_model(user - 1)] in one launch (:1239-1240), the Linear of FuseEmbeddings,
             # then LeakyReLU -> final_ln -> ELU -> output dropout in ONE launch (:1353-1364)
-            x3 = ops.head_input(output, self.user_embed_model.user_embedding.weight, user, -1)
-            u3 = ops.linear_splitk(x3, fuse3.fuse_embed.weight, fuse3.fuse_embed.bias, getattr(fuse3, "bf16_wgrad", False))
-            tok = ops.head_act(u3, self.final_ln.weight, self.final_ln.bias, self.final_ln.eps, 0.2, self.output_dropout.p,
-                               self.training, 0x1004)
+            utab = self.user_embed_model.user_embedding.weight
+            if ops.head_chain_ok(output, utab, user, fuse3.fuse_embed.weight):
+                # ... and all three in ONE launch each way (csrc/head.hip)
+                tok = ops.head_chain(output, utab, user, -1, fuse3.fuse_embed.weight, fuse3.fuse_embed.bias, self.final_ln.weight,
+                                     self.final_ln.bias, self.final_ln.eps, 0.2, self.output_dropout.p, self.training, 0x1004,
+                                     bf16_wgrad=getattr(fuse3, "bf16_wgrad", False))
+            else:
+                x3 = ops.head_input(output, utab, user, -1)
+                u3 = ops.linear_splitk(x3, fuse3.fuse_embed.weight, fuse3.fuse_embed.bias, getattr(fuse3, "bf16_wgrad", False))
+                tok = ops.head_act(u3, self.final_ln.weight, self.final_ln.bias, self.final_ln.eps, 0.2, self.output_dropout.p,
+                                   self.training, 0x1004)
         else:
             user_embedding = self.user_embed_model(user.long() - 1).reshape(output.shape[0], -1)   # :1239-1240
             tok = fuse3(output[:, 0, :].float(), user_embedding)                               # :1353-1358, q = 0 only

@@ -972,6 +972,87 @@ def head_act(u, ln_weight, ln_bias, eps, slope, p_drop, training, salt):
                             int(salt) & 0xFFFFFFFF)
 
 
+class _HeadChainFn(torch.autograd.Function):
+    """csrc/head.hip: [token row | user row] -> FuseEmbeddings' Linear -> LeakyReLU -> LayerNorm -> ELU -> dropout, one launch
+    each way (head_input + linear_splitk + head_act as separate launches: 16 + 17 us of the S-FSQ step for 16 rows)."""
+
+    @staticmethod
+    def forward(ctx, enc, table, user, offset, w3, b3, ln_w, ln_b, eps, slope, p_drop, seed, seed_dev, salt, bf16_wgrad):
+        G, T, C = enc.shape
+        U = table.shape[1]
+        W = C + U
+        dev = enc.device
+        x3, u3, out = (torch.empty(G, W, dtype=torch.float32, device=dev) for _ in range(3))
+        stats = torch.empty(2, G, dtype=torch.float32, device=dev)
+        check(_lib.lib().mobgt_head_chain_fwd(_p(enc), _p(user), _IT[user.dtype], offset, _p(table), table.shape[0], _p(w3), _p(b3),
+                                              _p(ln_w), _p(ln_b), _p(x3), _p(u3), _p(out), _p(stats[0]), _p(stats[1]), G, T, C, U,
+                                              eps, slope, p_drop, seed, _p(seed_dev), salt, _p(_head_chain_ws(dev)), _stream()),
+              "mobgt_head_chain_fwd")
+        ctx.save_for_backward(x3, u3, stats, w3, ln_w, ln_b)
+        ctx.user = user
+        ctx.misc = (G, T, C, U, offset, tuple(table.shape), eps, slope, p_drop, seed, seed_dev, salt, bf16_wgrad)
+        ctx.sink = grad_sink(table)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x3, u3, stats, w3, ln_w, ln_b = ctx.saved_tensors
+        G, T, C, U, offset, tshape, eps, slope, p_drop, seed, seed_dev, salt, bf16_wgrad = ctx.misc
+        dev = dout.device
+        dout = dout.contiguous()
+        du3 = torch.empty_like(u3)
+        denc = torch.empty(G, T, C, dtype=torch.float32, device=dev)
+        dtable = ctx.sink[:] if ctx.sink is not None else zeros_f32(tshape, dev)
+        dg, dbeta = zeros_f32((C + U,), dev), zeros_f32((C + U,), dev)
+        check(_lib.lib().mobgt_head_chain_bwd(_p(dout), _p(u3), _p(stats[0]), _p(stats[1]), _p(ctx.user), _IT[ctx.user.dtype], offset,
+                                              tshape[0], _p(w3), _p(ln_w), _p(ln_b), _p(du3), _p(denc), _p(dtable), _p(dg), _p(dbeta),
+                                              G, T, C, U, eps, slope, p_drop, seed, _p(seed_dev), salt, _stream()),
+              "mobgt_head_chain_bwd")
+        if bf16_wgrad:
+            dw, db = linear_wgrad(du3, x3, with_bias=True, leaf=True)      # (operands rounded to bf16 while loading)
+        else:
+            dw, db = du3.t() @ x3, colsum(du3)
+        return denc, dtable, None, None, dw, db, dg, dbeta, None, None, None, None, None, None, None
+
+
+_HEAD_WS = {}
+
+
+def _head_chain_ws(dev):
+    """Exchange area of csrc/head.hip's forward (include/mobgt_hip.h: mobgt_head_chain_ws_bytes): one per device, zeroed once,
+    for one stream at a time; it must exist before a graph capture starts (an eager warm-up step creates it)."""
+    key = dev.index if dev.index is not None else torch.cuda.current_device()
+    ws = _HEAD_WS.get(key)
+    if ws is None:
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("the head kernel's workspace must be allocated before graph capture: run one eager step first")
+        ws = _HEAD_WS[key] = torch.zeros(int(_lib.lib().mobgt_head_chain_ws_bytes()), dtype=torch.uint8, device=dev)
+    return ws
+
+
+def head_chain_ok(enc, table, user, w3):
+    W = enc.shape[-1] + table.shape[1]
+    return (enc.is_cuda and enc.dim() == 3 and enc.dtype == torch.float32 and table.dtype == torch.float32 and table.is_contiguous()
+            and W in (320, 384) and tuple(w3.shape) == (W, W) and w3.dtype == torch.float32 and w3.is_contiguous()
+            and user.dtype in (torch.int64, torch.int32) and user.numel() == enc.shape[0] and enc.shape[0] <= 160
+            and enc.shape[-1] % 16 == 0 and table.shape[1] % 16 == 0 and not __import__("os").environ.get("MOBGT_NO_HEAD_CHAIN"))
+
+
+def head_chain(enc, user_table, user, user_offset, w3, b3, ln_weight, ln_bias, eps, slope, p_drop, training, salt, bf16_wgrad=False):
+    """tok [G, C+U] = dropout(ELU(LayerNorm(LeakyReLU(Linear([enc[:, 0] | user_table[user + user_offset]]))))) -- the classifier
+    head in front of out_proj (model_fqandtoyo.py:1239-1240, 1353-1364) in one launch each way.  MOBGT_NO_HEAD_CHAIN=1: callers
+    fall back to head_input + linear_splitk + head_act."""
+    _require_cuda(enc, user_table, user, w3)
+    if not training:
+        p_drop = 0.0
+    seed, seed_dev = _DROPOUT_STATE["seed"], _DROPOUT_STATE["seed_dev"]
+    if seed_dev is None and p_drop > 0:
+        seed = (seed + int(torch.randint(0, 2 ** 31 - 1, (1,)).item())) & 0x7FFFFFFFFFFFFFFF
+    return _HeadChainFn.apply(enc.contiguous(), user_table, user.reshape(-1).contiguous(), int(user_offset), w3, b3.contiguous(),
+                              ln_weight.contiguous(), ln_bias.contiguous(), float(eps), float(slope), float(p_drop), int(seed),
+                              seed_dev, int(salt) & 0xFFFFFFFF, bool(bf16_wgrad))
+
+
 class _HeadInputFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, enc, table, user, offset):

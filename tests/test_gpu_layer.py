@@ -701,3 +701,52 @@ def test_chain_cluster_form_equals_the_one_workgroup_form(C, R, p):
         assert d <= 2 ** -6 * sc, (k, d, sc)
     sc = one["sums"].abs().amax(1, keepdim=True).clamp_min(1e-6)
     assert float(((one["sums"] - cl["sums"]).abs() / sc).max()) <= 1e-2       # (f32 atomics in another order + the above)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("G,T,C,p", [(16, 38, 192, 0.1), (5, 9, 192, 0.0), (16, 20, 256, 0.1), (33, 12, 192, 0.1)])
+def test_head_chain_equals_the_three_launches(G, T, C, p):
+    """csrc/head.hip (token row | user row -> FuseEmbeddings' Linear -> LeakyReLU -> LayerNorm -> ELU -> dropout, one launch
+    each way) against ops.head_input + linear_splitk + head_act: same full-f32 products (another summation order), the
+    same dropout mask; d(enc) must be exactly zero off the token rows."""
+    from mobgt_amd import ops
+    U = 128
+    W = C + U
+    gen = torch.Generator().manual_seed(G * T)
+    enc0 = torch.randn(G, T, C, generator=gen).to(DEV)
+    table = torch.randn(50, U, generator=gen).to(DEV).requires_grad_(True)
+    user = torch.randint(0, 52, (G,), generator=gen).to(DEV)              # (user - 1 in [-1, 50]: -1 and 50 read as zero rows)
+    lin = torch.nn.Linear(W, W).to(DEV)
+    ln = torch.nn.LayerNorm(W).to(DEV)
+    with torch.no_grad():
+        ln.weight.add_(0.1 * torch.randn(W, device=DEV))
+        ln.bias.add_(0.1 * torch.randn(W, device=DEV))
+    gy = torch.randn(G, W, generator=gen).to(DEV)
+    sd = torch.tensor([3], dtype=torch.int64, device=DEV)
+    ops.set_dropout_state(sd, 1234)
+    try:
+        res = []
+        for fused in (True, False):
+            for q in (table, lin.weight, lin.bias, ln.weight, ln.bias):
+                q.grad = None
+            enc = enc0.clone().requires_grad_(True)
+            if fused:
+                assert ops.head_chain_ok(enc, table, user, lin.weight)
+                tok = ops.head_chain(enc, table, user, -1, lin.weight, lin.bias, ln.weight, ln.bias, ln.eps, 0.2, p, True, 0x1004,
+                                     bf16_wgrad=False)
+            else:
+                x3 = ops.head_input(enc, table, user, -1)
+                u3 = ops.linear_splitk(x3, lin.weight, lin.bias, False)
+                tok = ops.head_act(u3, ln.weight, ln.bias, ln.eps, 0.2, p, True, 0x1004)
+            tok.backward(gy)
+            torch.cuda.synchronize()
+            res.append([tok.detach().clone(), enc.grad.clone()] + [q.grad.clone() for q in (table, lin.weight, lin.bias, ln.weight, ln.bias)])
+    finally:
+        ops.set_dropout_state(None, 0)
+    a, b = res
+    assert torch.equal(a[0] == 0, b[0] == 0)                              # the same mask
+    assert float(a[1][:, 1:].abs().max()) == 0.0 and float(b[1][:, 1:].abs().max()) == 0.0
+    for name, x, y in zip(("tok", "denc", "dtable", "dW3", "db3", "dgamma", "dbeta"), a, b):
+        sc = float(y.abs().max()) + 1e-12
+        err = float((x - y).abs().max())
+        assert err <= 2e-5 * max(sc, 1.0) + 1e-5 * sc, (name, err, sc)
