@@ -46,8 +46,9 @@ struct ChainParams {
     uint64_t seed;
     const uint64_t* seed_dev;
     uint32_t salt1, salt2;
-    uint32_t* ws_gen;                        // cluster form: launch generations and the exchange area (see cluster_sum)
+    uint32_t* ws_gen;                        // cluster form: launch generations and the exchange area (see cluster_put / cluster_get)
     uint64_t* ws_ll;
+    int nx;                                  // ... and the number of XCDs that take clusters
 };
 
 // in-kernel timeline for tools/chain_debug.py (-DCH_DEBUG): stamps of workgroup 0 / thread 0, written at the end
@@ -588,12 +589,27 @@ __device__ __forceinline__ void cluster_get(__amdgpu_buffer_rsrc_t area, int m, 
         }
     }
 }
-// block id -> (row block, member): ids that agree modulo 8 share an XCD; a cluster = NCL consecutive slots of one XCD
+// block id -> (row block, member): ids that agree modulo 8 share an XCD; a cluster = NCL consecutive slots of one XCD.  Only
+// the first `nx` XCDs take clusters; the workgroups dealt to the others leave at once (blk = -1).  nx = 8 unless
+// MOBGT_CHAIN_XCDS says otherwise: confining the 152 live workgroups of R = 608 to the 5 XCDs they need cuts the launch's
+// fetches from 13.3 to 10.0 MB (every XCD that takes part pulls the layer's weights into its own L2 once) but the launch
+// gets SLOWER -- forward 11.8 -> 12.4 us, backward 15.0 -> 21.7 us (its weight-gradient passengers are left with 3 XCDs)
 template <int NCL>
-__device__ __forceinline__ void cluster_ids(int bid, int& blk, int& m) {
+__device__ __forceinline__ void cluster_ids(int bid, int nx, int& blk, int& m) {
     const int xcd = bid & 7, slot = bid >> 3;
     m = slot % NCL;
-    blk = (slot / NCL) * 8 + xcd;
+    blk = xcd < nx ? (slot / NCL) * nx + xcd : -1;
+}
+inline int cluster_xcds(int nblk, int ncl) {
+    static int forced = -1;
+    if (forced < 0) {
+        const char* e = getenv("MOBGT_CHAIN_XCDS");
+        forced = e ? atoi(e) : 0;
+    }
+    const int need = (nblk * ncl + 31) / 32;                 // XCDs the live workgroups need at one per compute unit
+    int nx = 8;
+    if (forced >= 1 && forced <= 8) nx = forced > need ? forced : need;
+    return nx < 1 ? 1 : (nx > 8 ? 8 : nx);
 }
 
 // rows of an LDS bf16 tile [BM][LD] -> columns [c0, c0 + N) of global [R][LDG]
@@ -617,9 +633,9 @@ __global__ __launch_bounds__(NT) void layer_chain_fwd_cl_kernel(const ChainParam
     uint16_t* hb = ab + BM * LDA;                                                // [BM][LDHS] bf16: this member's columns of h
     uint16_t* ub = hb + BM * LDHS;                                               // [BM][LDHS] bf16: ... of u, later of the next qkv
     int blk, m;
-    cluster_ids<NCL>((int)blockIdx.x, blk, m);
+    cluster_ids<NCL>((int)blockIdx.x, p.nx, blk, m);
     const int r0 = blk * BM;
-    if (r0 >= p.R) return;                                                       // (a whole cluster: nobody waits for it)
+    if (blk < 0 || r0 >= p.R) return;                                            // (a whole cluster: nobody waits for it)
     const int lane = threadIdx.x & 63;
     const int j = lane & 15, q = lane >> 4;
     const uint64_t seed = p.thr ? p.seed + (p.seed_dev ? *p.seed_dev : 0ull) : 0ull;
@@ -821,7 +837,9 @@ int launch_cl(const ChainParams& p, hipStream_t st) {
     int rc = (int)hipFuncSetAttribute((const void*)layer_chain_fwd_cl_kernel<BM, C, F, NCL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (rc) return rc;
     const int nblk = (p.R + BM - 1) / BM;
-    hipLaunchKernelGGL((layer_chain_fwd_cl_kernel<BM, C, F, NCL>), dim3(8 * NCL * ((nblk + 7) / 8)), dim3(NT), lds, st, p);
+    ChainParams q = p;
+    q.nx = cluster_xcds(nblk, NCL);
+    hipLaunchKernelGGL((layer_chain_fwd_cl_kernel<BM, C, F, NCL>), dim3(8 * NCL * ((nblk + q.nx - 1) / q.nx)), dim3(NT), lds, st, q);
     return (int)hipGetLastError();
 }
 
@@ -983,8 +1001,9 @@ struct ChainBwdParams {
     mobgt_wgrad::WgradParams wg[4];
     int wg_first[5], wg_tiles[4], wg_splits[4];
     int n_wg, n_chain;
-    uint32_t* ws_gen;                        // cluster form: launch generations and the exchange area (see cluster_sum)
+    uint32_t* ws_gen;                        // cluster form: launch generations and the exchange area (see cluster_put / cluster_get)
     uint64_t* ws_ll;
+    int nx;                                  // ... and the number of XCDs that take clusters
 };
 
 // gelu'(u) = Phi(u) + u phi(u); the exponential of the A&S erf IS phi's
@@ -1318,9 +1337,9 @@ __global__ __launch_bounds__(NT) void layer_chain_bwd_cl_kernel(const ChainBwdPa
         return;
     }
     int blk, m;
-    cluster_ids<NCL>((int)blockIdx.x, blk, m);
+    cluster_ids<NCL>((int)blockIdx.x, p.nx, blk, m);
     const int r0 = blk * BM;
-    if (r0 >= p.R) return;
+    if (blk < 0 || r0 >= p.R) return;
     const int lane = threadIdx.x & 63;
     const int j = lane & 15, q = lane >> 4;
     const uint64_t seed = p.thr ? p.seed + (p.seed_dev ? *p.seed_dev : 0ull) : 0ull;
@@ -1417,7 +1436,8 @@ int launch_bwd_cl(ChainBwdParams& p, hipStream_t st) {
     int rc = (int)hipFuncSetAttribute((const void*)layer_chain_bwd_cl_kernel<BM, C, F, NCL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (rc) return rc;
     const int nblk = (p.R + BM - 1) / BM;
-    p.n_chain = 8 * NCL * ((nblk + 7) / 8);
+    p.nx = cluster_xcds(nblk, NCL);
+    p.n_chain = 8 * NCL * ((nblk + p.nx - 1) / p.nx);
     hipLaunchKernelGGL((layer_chain_bwd_cl_kernel<BM, C, F, NCL>), dim3(p.n_chain + (p.n_wg ? p.wg_first[p.n_wg] : 0)), dim3(NT), lds, st, p);
     return (int)hipGetLastError();
 }

@@ -6,7 +6,7 @@
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
 for C in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $C --kernel-trace --output-format csv -d gpurun_out/fpmc_$C -o r -- python3 bench.py --steps 24 --warmup 8 --no-cpu-baseline --no-parity --no-stress ${BENCH_ARGS} > /dev/null 2>&1
+  rocprofv3 --pmc $C --kernel-trace --output-format csv -d gpurun_out/fpmc_$C -o r -- python3 bench.py --steps 24 --warmup 8 --no-cpu-baseline --no-parity --no-stress --no-live-pmc --no-loop ${BENCH_ARGS} > /dev/null 2>&1
 done
 python3 - <<'PY'
 import csv, glob, json, collections
@@ -19,7 +19,7 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
             if r["Counter_Name"] != c:
                 continue
             n = r["Kernel_Name"]
-            k = "attn_fwd" if "attn_fwd_kernel" in n else ("chain_fwd" if "layer_chain_fwd_kernel" in n else ("chain_bwd" if "layer_chain_bwd_kernel" in n else None))
+            k = "attn_fwd" if "attn_fwd_kernel" in n else ("chain_fwd" if "layer_chain_fwd" in n else ("chain_bwd" if "layer_chain_bwd" in n else None))
             if k:
                 acc[k].append(float(r["Counter_Value"]))
     raw[c] = {k: (sum(v) / len(v), len(v)) for k, v in acc.items()}
