@@ -680,14 +680,17 @@ def main():
                     pmc_file = json.load(open(os.path.join(ROOT, "profiles", "attn_pmc.json")))
                 except Exception:
                     pass
-            roofc = dict(kernel="layer_chain_fwd_kernel", bound="hbm", achieved=tb / tt_ / 1e9, peak=HBM_PEAK_GBS, unit="GB/s",
+            cl = all(g * t <= 16 * 128 for g, t in used)             # (rows up to which the chain kernels run their cluster form)
+            pm = pmc_file.get("fsq_chain_fwd", {}) if (name == "fsq" and C == 192 and pmc_file) else {}
+            roofc = dict(kernel="layer_chain_fwd_cl_kernel (cluster form: 4 / 2 workgroups per 16-row block)" if cl else "layer_chain_fwd_kernel",
+                         bound="hbm", achieved=tb / tt_ / 1e9, peak=HBM_PEAK_GBS, unit="GB/s",
                          frac=tb / tt_ / 1e9 / HBM_PEAK_GBS,
-                         traffic=(pmc_file.get("fsq_chain_fwd", {}).get("traffic_bytes") if name == "fsq" and C == 192 else None),
-                         counters_source="profiles/attn_pmc.json (earlier run)",
+                         traffic=pm.get("traffic_bytes"), traffic_rows=pm.get("rows"),
+                         counters_source="profiles/attn_pmc.json (tools/chain_pmc.sh, stand-alone launches at R = %s)" % pm.get("rows") if pm else None,
                          bytes_per_launch=tb / len(used),
                          avg_launch_us=tt_ / len(used) * 1e6,
-                         note="not HBM-bound at this size: the workgroups stream the layer's packed weights through their "
-                              "CUs' L1; see DESIGN.md 3.5")
+                         note="not HBM-bound at this size: per workgroup a chain of latency-bound phases (first touch, weight "
+                              "stream through one L1, two LayerNorms, one hand-over); see DESIGN.md 3.5")
         roof5 = roof5b = None
         if not args.no_stress:
             # the same kernels at the HBM-roofline stress shape (BASELINE configs[4]: G16 x 784 nodes, C 256, d 32), training
