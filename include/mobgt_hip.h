@@ -508,6 +508,17 @@ int mobgt_layer_chain_bwd(const float* dout, const float* x2, const float* x1, c
  * never need resetting).  Same results as the one-workgroup form up to the f32 summation order of h w2^T and du w1 (NCL
  * partial sums).  ws = null: always the one-workgroup form.  MOBGT_CHAIN_NCL=1|2|4 caps the cluster size. */
 int64_t mobgt_chain_ws_bytes(void);
+/* Backward of the encoder input from d(tokens) down to the gathered rows in ONE launch (csrc/tokbwd.hip;
+ * model_fqandtoyo.py:1264-1298, 1338-1347, FuseEmbeddings 444-456) = mobgt_assemble_tokens_bwd + the two data-gradient GEMMs of
+ * FuseEmbeddings-4 / -2 with their LeakyReLU derivatives:  d = dropouts'(dout[g, 1 + n]);  d_add = d;  d_nf = d * real;
+ * dx4 = (d_nf * leaky'(y4)) w4;  d_pt = (dx4[:, :W2] * leaky'(y2)) w2;  d_token += sum of the graph-token rows' d.
+ * y4 [G*N, C] / y2 [G*N, W2] (row stride ld_y2): the two activations' OUTPUTS; w4 [C,C], w2 [W2,W2] row-major (out, in).
+ * Written: d_nf, d_add [G*N, C], dx4 [G*N, C] (row stride ld_dx4), d_pt [G*N, W2]; d_token [C] accumulated (zero it first).
+ * Masks / salts as mobgt_assemble_tokens_bwd.  (C, W2) = (192, 160). */
+int mobgt_token_bwd_chain(const float* dout, const float* real, const float* y4, const float* y2, int64_t ld_y2, const float* w4,
+                          const float* w2, float* d_nf, float* d_add, float* dx4, int64_t ld_dx4, float* d_pt, float* d_token,
+                          int G, int N, int C, int W2, float slope4, float slope2, float p_pos, float p_in, uint64_t seed,
+                          const uint64_t* seed_dev, uint32_t salt_nf, uint32_t salt_tok, uint32_t salt_in, void* stream);
 /* The classifier head in front of out_proj, one launch each way (csrc/head.hip; model_fqandtoyo.py:1239-1240, 1353-1364,
  * FuseEmbeddings 452-455):  x3 = [enc[g, 0, :] | table[user[g] + user_offset]] [G, C+U];  u3 = x3 w3^T + b3 (f32);
  * out = dropout(ELU(LayerNorm(LeakyReLU_slope(u3)))).  Replaces mobgt_head_input_fwd + a small GEMM + mobgt_head_act_fwd (same

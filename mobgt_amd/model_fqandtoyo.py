@@ -362,6 +362,10 @@ class Graphormer(nn.Module):
                 x4 = torch.cat((f2, x4[:, Wp + Wt:]), 1)
             nf = ops.linear_splitk(x4, f4.fuse_embed.weight, f4.fuse_embed.bias, getattr(f4, "bf16_wgrad", False),
                                    slope=f4.leaky_relu.negative_slope)
+            if f2.data_ptr() == x4.data_ptr() and self.act_dtype == torch.bfloat16 and getattr(f4, "bf16_wgrad", False):
+                # the backward of tokens <- nf <- x4 <- pt as ONE launch inside the trainer's step (csrc/tokbwd.hip)
+                ops.register_token_chain(nf, x4, Wp + Wt, f4.fuse_embed.weight, f4.leaky_relu.negative_slope,
+                                         self.embed_fuse_model2.fuse_embed.weight, self.embed_fuse_model2.leaky_relu.negative_slope)
         else:
             # many positions (S-BIG: 12.5 k rows): the separate gathers, whose backward combines runs of equal indices in
             # registers (scatter_add_runs_kernel) instead of serialising thousands of atomics on a handful of degree rows

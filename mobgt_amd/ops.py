@@ -751,6 +751,59 @@ class _OutRef:
         self.t = t.detach()
 
 
+# ---- the encoder input's backward as ONE launch (csrc/tokbwd.hip) ------------------------------------------------------------------
+# assemble_tokens' backward and the data gradients of FuseEmbeddings-4 / -2 are three autograd nodes in a row (tokens <- nf <-
+# x4 = [f2 | cat] <- pt).  Inside the trainer's backward (weight gradients deferred to the grouped launch) they co-operate: the
+# first two only PARK their work and return the buffers their results will live in, the third launches mobgt_token_bwd_chain,
+# which fills all of them.  The consumers of those buffers (the weight-gradient group, the gathers' scatter) run later in
+# stream order.  flush_deferred_wgrads() raises if a parked chain was never completed.
+_TOKEN_CHAIN = {}           # "cur": what model.node_features registered for the forward pass that just ran
+_TOKEN_PENDING = {}         # address of the gradient buffer the next node will receive -> parked work
+
+
+def register_token_chain(nf, x4, w2_width, w4, slope4, w2, slope2):
+    """nf [R, C] = leaky(x4 W4^T + b4), x4[:, :w2_width] = f2 = leaky(pt W2^T + b2) written in place (ops.join_cols): the
+    chain whose backward mobgt_token_bwd_chain covers.  No-op for other widths."""
+    _TOKEN_CHAIN.pop("cur", None)
+    if os.environ.get("MOBGT_NO_TOKEN_BWD_CHAIN") == "1":
+        return
+    if (nf.is_cuda and nf.dtype == torch.float32 and x4.dtype == torch.float32 and nf.dim() == 2 and nf.is_contiguous()
+            and x4.is_contiguous() and tuple(nf.shape) == tuple(x4.shape) and nf.shape[1] == 192 and w2_width == 160
+            and tuple(w4.shape) == (192, 192) and tuple(w2.shape) == (160, 160) and w4.is_contiguous() and w2.is_contiguous()
+            and w4.dtype == torch.float32 and w2.dtype == torch.float32):
+        # (detached: a reference to nf / x4 themselves would keep this forward pass's autograd graph alive past its backward --
+        #  and a live eager graph makes a later hipGraph capture_end crash)
+        _TOKEN_CHAIN["cur"] = dict(nf_ptr=nf.data_ptr(), nf=nf.detach(), x4=x4.detach(), w4=w4.detach(), slope4=float(slope4),
+                                   w2=w2.detach(), slope2=float(slope2))
+
+
+def _token_park_linear(g, w, y):
+    """_LinearSplitKFn.backward inside a parked chain: FuseEmbeddings-4 parks again and returns the buffer dx4 will be written
+    to; FuseEmbeddings-2 launches the kernel and returns d_pt.  None: not part of a parked chain."""
+    pend = _TOKEN_PENDING.get(g.data_ptr())
+    if pend is None:
+        return None
+    ent = pend["ent"]
+    if pend["stage"] == 1 and w.data_ptr() == ent["w4"].data_ptr() and y is not None and y.data_ptr() == ent["nf_ptr"]:
+        del _TOKEN_PENDING[g.data_ptr()]
+        dx4 = torch.empty_like(ent["x4"])
+        pend.update(stage=2, dx4=dx4)
+        _TOKEN_PENDING[dx4.data_ptr()] = pend
+        return dx4
+    if pend["stage"] == 2 and w.data_ptr() == ent["w2"].data_ptr() and y is not None and y.data_ptr() == ent["x4"].data_ptr():
+        del _TOKEN_PENDING[g.data_ptr()]
+        G, N, C, p_pos, p_in, seed, seed_dev, salts = pend["misc"]
+        W2 = ent["w2"].shape[0]
+        d_pt = torch.empty(G * N, W2, dtype=torch.float32, device=g.device)
+        dx4 = pend["dx4"]
+        check(_lib.lib().mobgt_token_bwd_chain(_p(pend["dout"]), _p(pend["real"]), _p(ent["nf"]), _p(ent["x4"]), ent["x4"].stride(0),
+                                               _p(ent["w4"]), _p(ent["w2"]), _p(pend["d_nf"]), _p(pend["d_add"]), _p(dx4), dx4.stride(0),
+                                               _p(d_pt), _p(pend["d_tok"]), G, N, C, W2, ent["slope4"], ent["slope2"], p_pos, p_in, seed,
+                                               _p(seed_dev), salts[0], salts[1], salts[2], _stream()), "mobgt_token_bwd_chain")
+        return d_pt
+    return None
+
+
 class _LinearSplitKFn(torch.autograd.Function):
     """y = x W^T + b for a few hundred rows: the weight gradient g^T x has K = rows and a tiny output, which a
     plain GEMM call maps onto one workgroup (measured 60-150 us in fp32); evaluate it split-K as a batched GEMM.
@@ -789,7 +842,8 @@ class _LinearSplitKFn(torch.autograd.Function):
                     and max(w.shape) <= 512):
                 db = zeros_f32((g.shape[1],), g.device)
                 dw = linear_wgrad_masked(g, x, g_mask=y, mask_vals=mv, db=db, leaf=True)
-                return small_gemm(g, w, a_mask=(y, *mv)), dw, (db[:] if _WGRAD_DEFER["on"] else db), None, None, None
+                dx = _token_park_linear(g, w, y) if _WGRAD_DEFER["on"] else None
+                return (dx if dx is not None else small_gemm(g, w, a_mask=(y, *mv))), dw, (db[:] if _WGRAD_DEFER["on"] else db), None, None, None
             if (_WGRAD_DEFER["on"] and hip_wgrad and g.stride(1) == 1 and y.stride() == g.stride() and g.data_ptr() % 8 == 0
                     and y.data_ptr() % 8 == 0 and g.stride(0) % 2 == 0 and small_gemm_ok(g, w) and R <= _SMALL_ROWS
                     and max(w.shape) <= 512):
@@ -797,7 +851,8 @@ class _LinearSplitKFn(torch.autograd.Function):
                 # then applies the activation's derivative itself while it loads g (no masked copy of g exists)
                 db = zeros_f32((g.shape[1],), g.device)
                 dw = linear_wgrad_masked(g, x, g_mask=y, mask_vals=mv, db=db, leaf=True)
-                return small_gemm(g, w, a_mask=(y, *mv)), dw, db[:], None, None, None
+                dx = _token_park_linear(g, w, y)               # (a parked encoder-input chain: see register_token_chain)
+                return (dx if dx is not None else small_gemm(g, w, a_mask=(y, *mv))), dw, db[:], None, None, None
             if (hip_wgrad and g.stride(1) == 1 and y.stride() == g.stride() and g.data_ptr() % 8 == 0 and y.data_ptr() % 8 == 0
                     and g.stride(0) % 2 == 0):
                 # the weight-gradient kernel applies the activation's derivative while it loads g, sums the bias gradient and
@@ -1089,6 +1144,7 @@ class _AssembleTokensFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, nf, real, add, token, pe0, p_pos, p_in, seed, seed_dev, salts, side, row0_via_gather=False, qkv_w=None):
         ctx.pe_ptr = pe0.data_ptr() if (row0_via_gather and pe0.dim() == 2 and pe0.shape[0] > 1) else None
+        ctx.nf_ptr = nf.data_ptr()
         G, N, C = nf.shape
         nf, add, real = nf.contiguous(), add.contiguous(), real.contiguous()
         shapes = (token.shape, pe0.shape)
@@ -1134,9 +1190,16 @@ class _AssembleTokensFn(torch.autograd.Function):
         else:
             d_tok = zeros_f32((C,), dout.device)
             d_pe = d_tok.view(pshape)
-        check(_lib.lib().mobgt_assemble_tokens_bwd(_p(dout), _p(real), _p(d_nf), _p(d_add), _p(d_tok), G, N, C, p_pos, p_in, seed,
-                                                   _p(seed_dev), salts[0], salts[1], salts[2], _stream()),
-              "mobgt_assemble_tokens_bwd")
+        ent = _TOKEN_CHAIN.get("cur")
+        if (ent is not None and ent["nf_ptr"] == ctx.nf_ptr and _WGRAD_DEFER["on"] and C == ent["nf"].shape[1]
+                and G * N == ent["nf"].shape[0] and not os.environ.get("MOBGT_NO_TOKEN_BWD_CHAIN")):
+            # park: FuseEmbeddings-2's backward, two autograd nodes further down, launches the one kernel that fills d_nf / d_add
+            _TOKEN_PENDING[d_nf.data_ptr()] = dict(stage=1, ent=ent, dout=dout, real=real, d_nf=d_nf, d_add=d_add, d_tok=d_tok,
+                                                   misc=(G, N, C, p_pos, p_in, seed, seed_dev, salts))
+        else:
+            check(_lib.lib().mobgt_assemble_tokens_bwd(_p(dout), _p(real), _p(d_nf), _p(d_add), _p(d_tok), G, N, C, p_pos, p_in, seed,
+                                                       _p(seed_dev), salts[0], salts[1], salts[2], _stream()),
+                  "mobgt_assemble_tokens_bwd")
         if ctx.pe_ptr is not None:
             # the positional table's other consumer (the gather of pe[1..n]) adds this row-0 share inside ITS scatter launch:
             # one gradient producer for the table, no [L, C] zero table here and no table-sized add after
@@ -1245,6 +1308,12 @@ def _wgrad_defer(g, x, g_mask, x_mask, mask_vals, dw, db, db_of_x):
 
 
 def flush_deferred_wgrads():
+    if _TOKEN_PENDING:
+        stages = [p_["stage"] for p_ in _TOKEN_PENDING.values()]
+        _TOKEN_PENDING.clear()
+        _WGRAD_DEFER["items"] = []
+        raise RuntimeError(f"a parked encoder-input backward chain was never completed (stages {stages}): gradients of this "
+                           "step are invalid -- set MOBGT_NO_TOKEN_BWD_CHAIN=1 and report")
     items, _WGRAD_DEFER["items"] = _WGRAD_DEFER["items"], []
     vp, i64, ci, cf = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_float
     for o in range(0, len(items), 32):

@@ -204,3 +204,54 @@ def test_bench_launches_two_ranks_and_reports_them(tmp_path):
     assert j["steps"] == 5 and j["value"] > 0 and np.isfinite(j["final_loss"]) and j["allreduce_exposed_us"] is not None
     assert j["long_run"]["steps"] == 200
 
+
+
+def test_encoder_input_backward_as_one_launch_equals_the_three_launches(monkeypatch):
+    """csrc/tokbwd.hip (assemble_tokens' backward + the data gradients of FuseEmbeddings-4 / -2, parked across three autograd
+    nodes and run as ONE launch inside the trainer's backward) against the three launches (MOBGT_NO_TOKEN_BWD_CHAIN=1): every
+    parameter gradient of one dropout-on S-FSQ batch, same masks; f32 products in another summation order."""
+    from mobgt_amd import ops, workloads
+    uni, model, coll = workloads.build("fsq", "cuda", seed=1, model_overrides=dict(n_layers=2))
+    batch = coll(workloads.make_pool("fsq", 1, 16, uni)[0])
+    model.train()
+    sd = torch.zeros(1, dtype=torch.int64, device="cuda")
+    ops.set_dropout_state(sd, 99)
+    for m in model.modules():
+        if hasattr(m, "seed_dev"):
+            m.seed_dev = sd
+    res = []
+    try:
+        for off in ("0", "1"):
+            monkeypatch.setenv("MOBGT_NO_TOKEN_BWD_CHAIN", off)
+            for p in model.parameters():
+                p.grad = None
+            ops.wgrad_deferral(True)
+            try:
+                loss = model.training_step(batch, 0)
+                parked_before = len(ops._TOKEN_PENDING)
+                loss.backward()
+                assert not ops._TOKEN_PENDING, "the parked chain must have been completed inside backward"
+                ops.flush_deferred_wgrads()
+            finally:
+                ops.wgrad_deferral(False)
+            torch.cuda.synchronize()
+            res.append({n: p.grad.detach().float().clone() for n, p in model.named_parameters() if p.grad is not None})
+            assert parked_before == 0
+    finally:
+        ops.set_dropout_state(None, 0)
+    a, b = res
+    assert a.keys() == b.keys() and len(a) > 50
+    worst = 0.0
+    for n in a:
+        if n.endswith("linear_k.bias"):
+            continue            # exactly 0 in exact arithmetic (softmax is shift-invariant over keys): round-off on both sides
+        sc = float(b[n].abs().max())
+        err = float((a[n] - b[n]).abs().max())
+        worst = max(worst, err / (sc + 1e-30))
+        assert err <= 2e-3 * sc + 1e-9, (n, err, sc)      # (f32 atomics land in another order from run to run: ~5e-4 on the bias tables)
+    print("largest relative difference %.2e" % worst)
+    # the one-launch form really ran: its registration exists for this forward pass and the switch removes it
+    assert ops._TOKEN_CHAIN.get("cur") is None                  # (last pass ran with the switch on)
+    monkeypatch.setenv("MOBGT_NO_TOKEN_BWD_CHAIN", "0")
+    model.training_step(batch, 0)
+    assert ops._TOKEN_CHAIN.get("cur") is not None
