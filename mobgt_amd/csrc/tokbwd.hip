@@ -131,27 +131,37 @@ __global__ __launch_bounds__(TNT) void token_bwd_chain_kernel(const TokBwdParams
     const int64_t j0 = (int64_t)blockIdx.x * TBM;
     TSTAMP_DECL;
     TSTAMP(0);
-    // ---- token assembly backwards + FuseEmbeddings-4's activation derivative: one wave per node row
-    for (int r = wave; r < TBM; r += TNW) {
+    // ---- token assembly backwards + FuseEmbeddings-4's activation derivative: TBM x C elements dealt out flat, every load of a
+    //      thread requested before the first is used (a wave per row took two dependent passes: 3.6 us)
+    constexpr int EPT = TBM * C / TNT;
+    static_assert(TBM * C % TNT == 0, "flat split");
+    float dv[EPT], yv[EPT], rl[EPT];
+#pragma unroll
+    for (int k = 0; k < EPT; ++k) {
+        const int e = threadIdx.x + k * TNT, r = e / C, c = e % C;
+        const int64_t jc = min(j0 + r, R - 1);
+        const int g = (int)(jc / p.N), n = (int)(jc - (int64_t)g * p.N);
+        dv[k] = p.dout[((int64_t)g * T + n + 1) * C + c];
+        yv[k] = p.y4[jc * C + c];
+        rl[k] = p.real[jc];
+    }
+#pragma unroll
+    for (int k = 0; k < EPT; ++k) {
+        const int e = threadIdx.x + k * TNT, r = e / C, c = e % C;
         const int64_t jn = j0 + r;
         const bool on = jn < R;
         const int64_t jc = on ? jn : R - 1;
         const int g = (int)(jc / p.N), n = (int)(jc - (int64_t)g * p.N);
         const int64_t row = (int64_t)g * T + n + 1;
-        const uint32_t h1 = p.thr_pos ? dropout_row_hash(seed, (uint32_t)jc ^ p.salt_nf) : 0u;
-        const uint32_t h2 = p.thr_in ? dropout_row_hash(seed, (uint32_t)row ^ p.salt_in) : 0u;
-        const float rl = p.real[jc];
-        for (int c = lane; c < C; c += 64) {
-            float scale = 1.f;
-            if (p.thr_pos) scale = dropout_bits16(seed, h1, (uint32_t)c) >= p.thr_pos ? p.keep_pos : 0.f;
-            if (p.thr_in) scale *= dropout_bits16(seed, h2, (uint32_t)c) >= p.thr_in ? p.keep_in : 0.f;
-            const float d = on ? p.dout[row * C + c] * scale : 0.f;
-            const float dnf = d * rl;
-            a4[r * LDA + c] = dnf * leaky_grad(p.y4[jc * C + c], p.slope4);
-            if (on) {
-                p.d_add[jn * C + c] = d;
-                p.d_nf[jn * C + c] = dnf;
-            }
+        float scale = 1.f;
+        if (p.thr_pos) scale = dropout_bits16(seed, dropout_row_hash(seed, (uint32_t)jc ^ p.salt_nf), (uint32_t)c) >= p.thr_pos ? p.keep_pos : 0.f;
+        if (p.thr_in) scale *= dropout_bits16(seed, dropout_row_hash(seed, (uint32_t)row ^ p.salt_in), (uint32_t)c) >= p.thr_in ? p.keep_in : 0.f;
+        const float d = on ? dv[k] * scale : 0.f;
+        const float dnf = d * rl[k];
+        a4[r * LDA + c] = dnf * leaky_grad(yv[k], p.slope4);
+        if (on) {
+            p.d_add[jn * C + c] = d;
+            p.d_nf[jn * C + c] = dnf;
         }
     }
     __syncthreads();
