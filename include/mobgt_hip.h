@@ -551,6 +551,15 @@ int mobgt_small_gcn_fwd(const float* ax, const float* a, const float* w0, const 
                         const float* w2, const float* b2, float* h1, float* t, float* h2, float* t2, float* out, int* counter,
                         int n, int K0, int H1, int H2, int H3, float slope, float dropout_p, uint64_t seed,
                         const uint64_t* seed_dev, uint32_t salt, void* stream);
+/* The same launch carrying the step's weight pack (mobgt_pack_mfma_b's jobs, same arguments, pack_n <= 96) as passenger
+ * workgroups on the compute units the network leaves idle: results identical to mobgt_pack_mfma_b followed by
+ * mobgt_small_gcn_fwd, one launch fewer (the pack is 11.7 us of pure data movement beside a 26 us launch that keeps 19 units
+ * busy).  pack_n = 0: plain mobgt_small_gcn_fwd.  Not re-entrant (one host thread launches at a time). */
+int mobgt_small_gcn_fwd_pack(const float* ax, const float* a, const float* w0, const float* b0, const float* w1, const float* b1,
+                             const float* w2, const float* b2, float* h1, float* t, float* h2, float* t2, float* out, int* counter,
+                             int n, int K0, int H1, int H2, int H3, float slope, float dropout_p, uint64_t seed,
+                             const uint64_t* seed_dev, uint32_t salt, int pack_n, const void* const* pack_src, void* const* pack_dst,
+                             const int* pack_N, const int* pack_K, const int* pack_transposed, void* stream);
 int mobgt_small_gcn_bwd(const float* g, const float* ax, const float* a_t, const float* w1, const float* w2, const float* h1,
                         const float* t, const float* h2, const float* t2, float* dw0, float* db0, float* dw1, float* db1,
                         float* dw2, float* db2, float* dt2, float* dt, int* counter, int n, int K0, int H1, int H2, int H3,

@@ -25,6 +25,7 @@
 #include "common.h"
 #include "mobgt_hip.h"
 #include "wgrad_body.h"
+#include "pack_body.h"
 
 namespace {
 
@@ -843,52 +844,10 @@ int launch_cl(const ChainParams& p, hipStream_t st) {
     return (int)hipGetLastError();
 }
 
-constexpr int PACK_MAX = 96;                 // 12 layers x (4 forward + 3 transposed) weights in one launch
+using mobgt_pack::PackJobs;
 
-struct PackJobs {
-    const uint16_t* src[PACK_MAX];
-    uint16_t* dst[PACK_MAX];
-    int N[PACK_MAX], K[PACK_MAX];
-    int transposed[PACK_MAX];                      // src is [K][N] row-major: pack its transpose
-    int first_block[PACK_MAX + 1];                     // job i owns blocks [first_block[i], first_block[i + 1]); 256 pieces per block
-};
-
-// dst[((g S + s) 64 + l) * 8 + e] = src[(16 g + (l & 15)) K + 32 s + 8 (l >> 4) + e]: 16-byte pieces, writes contiguous
-__global__ __launch_bounds__(256) void pack_mfma_b_kernel(const PackJobs jobs, int njobs) {
-    int job = 0;
-    while (job + 1 < njobs && (int)blockIdx.x >= jobs.first_block[job + 1]) ++job;
-    const int K = jobs.K[job], S = K / 32;
-    const int64_t item = (int64_t)(blockIdx.x - jobs.first_block[job]) * 256 + threadIdx.x;
-    if (!jobs.transposed[job]) {
-        const int64_t piece = item;
-        if (piece >= (int64_t)jobs.N[job] * K / 8) return;
-        const int l = (int)(piece & 63);
-        const int64_t gs = piece >> 6;
-        const int g = (int)(gs / S), s_ = (int)(gs % S);
-        const uint16_t* from = jobs.src[job] + (int64_t)(16 * g + (l & 15)) * K + 32 * s_ + 8 * (l >> 4);
-        *reinterpret_cast<uint4*>(jobs.dst[job] + piece * 8) = *reinterpret_cast<const uint4*>(from);
-    } else {
-        // W'[n][k] = src[k][n]: a thread builds the pieces of TWO adjacent columns n (lanes j, j + 1) from eight 4-byte reads
-        // -- a wave reads 64-byte runs of eight source rows -- and writes their 32 contiguous bytes
-        const int64_t piece = 2 * item;
-        if (piece >= (int64_t)jobs.N[job] * K / 8) return;
-        const int N = jobs.N[job];
-        const int l = (int)(piece & 63);                                  // even
-        const int64_t gs = piece >> 6;
-        const int g = (int)(gs / S), s_ = (int)(gs % S);
-        const uint16_t* from = jobs.src[job] + (int64_t)(32 * s_ + 8 * (l >> 4)) * N + 16 * g + (l & 15);
-        uint32_t e[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) e[i] = *reinterpret_cast<const uint32_t*>(from + (int64_t)i * N);
-        uint4 lo, hi;
-        lo.x = (e[0] & 0xffffu) | (e[1] << 16); lo.y = (e[2] & 0xffffu) | (e[3] << 16);
-        lo.z = (e[4] & 0xffffu) | (e[5] << 16); lo.w = (e[6] & 0xffffu) | (e[7] << 16);
-        hi.x = (e[0] >> 16) | (e[1] & 0xffff0000u); hi.y = (e[2] >> 16) | (e[3] & 0xffff0000u);
-        hi.z = (e[4] >> 16) | (e[5] & 0xffff0000u); hi.w = (e[6] >> 16) | (e[7] & 0xffff0000u);
-        uint4* out = reinterpret_cast<uint4*>(jobs.dst[job] + piece * 8);
-        out[0] = lo;
-        out[1] = hi;
-    }
+__global__ __launch_bounds__(256) void pack_mfma_b_kernel(const PackJobs jobs, int njobs, int nvb) {
+    mobgt_pack::pack_blocks<1>(jobs, njobs, (int)blockIdx.x, 0, nvb);
 }
 
 template <int BM, int C, int F>
@@ -1457,21 +1416,11 @@ int launch_bwd(const ChainBwdParams& p, hipStream_t st) {
 extern "C" int mobgt_pack_mfma_b(int n, const void* const* src, void* const* dst, const int* N, const int* K,
                                  const int* transposed, void* stream) {
     if (n <= 0) return 0;
-    if (n > PACK_MAX) return MOBGT_EBADDIM;
     PackJobs jobs = {};
     int blocks = 0;
-    for (int i = 0; i < n; ++i) {
-        if (N[i] <= 0 || K[i] <= 0 || (N[i] & 15) || (K[i] & 31)) return MOBGT_EBADDIM;
-        if (((uintptr_t)src[i] | (uintptr_t)dst[i]) & 15) return MOBGT_EALIGN;
-        if (transposed && transposed[i] && (N[i] & 1)) return MOBGT_EBADDIM;
-        jobs.src[i] = (const uint16_t*)src[i]; jobs.dst[i] = (uint16_t*)dst[i]; jobs.N[i] = N[i]; jobs.K[i] = K[i];
-        jobs.transposed[i] = transposed ? transposed[i] : 0;
-        jobs.first_block[i] = blocks;
-        const int64_t items = (int64_t)N[i] * K[i] / 8 / (jobs.transposed[i] ? 2 : 1);      // a transposed thread builds two pieces
-        blocks += (int)((items + 255) / 256);
-    }
-    jobs.first_block[n] = blocks;
-    hipLaunchKernelGGL(pack_mfma_b_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, jobs, n);
+    const int rc = mobgt_pack::fill_jobs(jobs, n, src, dst, N, K, transposed, &blocks);
+    if (rc) return rc;
+    hipLaunchKernelGGL(pack_mfma_b_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, jobs, n, blocks);
     return (int)hipGetLastError();
 }
 

@@ -15,12 +15,19 @@
 // layer-by-layer path produced.
 #include "common.h"
 #include "mobgt_hip.h"
+#include "pack_body.h"
 
 namespace {
 
 constexpr int RB = 16;               // rows per workgroup
 constexpr int MAXH = 64;             // widest layer
 constexpr int NT = 256;
+#ifndef PACK_U
+#define PACK_U 8
+#endif
+#ifndef PACK_ROUNDS
+#define PACK_ROUNDS 1
+#endif
 
 struct SmallGcnParams {
     const float *AX, *A, *AT;        // [n,K0], [n,n], [n,n] (A^T)
@@ -31,6 +38,7 @@ struct SmallGcnParams {
     float *dt2, *dt;                 // backward scratch [n,H2], [n,H1]
     int* counter;                    // zero on entry
     int n, K0, H1, H2, H3;
+    int nwg;                         // workgroups of the network itself (the forward launch may carry passengers behind them)
     float slope, inv_keep;
     uint32_t thr;
     uint64_t seed;
@@ -288,7 +296,13 @@ __device__ __forceinline__ void tile_product(float* __restrict__ smem, float* __
 }
 
 template <int H1, int H2, int H3>
-__global__ __launch_bounds__(NT) void small_gcn_fwd_kernel(const SmallGcnParams p) {
+__global__ __launch_bounds__(NT) void small_gcn_fwd_kernel(const SmallGcnParams p, const mobgt_pack::PackJobs jobs, int njobs, int nvb) {
+    if ((int)blockIdx.x >= p.nwg) {
+        // passengers: the step's weight pack (mobgt_pack_mfma_b's body) on the compute units this network leaves idle
+        const int np = (int)gridDim.x - p.nwg;
+        for (int vb = (int)blockIdx.x - p.nwg; vb < nvb; vb += PACK_U * np) mobgt_pack::pack_blocks<PACK_U>(jobs, njobs, vb, np, nvb);
+        return;
+    }
     static_assert(H1 <= 32 && H1 * H2 + H2 * H3 <= MAXH * MAXH, "LDS plan");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* tl = smem + OFF_T;
@@ -298,7 +312,7 @@ __global__ __launch_bounds__(NT) void small_gcn_fwd_kernel(const SmallGcnParams 
     float* w2s = w1t + H1 * H2;
     float* w2t = w2s + H2 * H3;
     float* Lc = smem + OFF_LC;
-    const int r0 = blockIdx.x * RB, nwg = gridDim.x;
+    const int r0 = blockIdx.x * RB, nwg = p.nwg;
     const int wave = threadIdx.x >> 6, i = threadIdx.x & 15, kq = (threadIdx.x & 63) >> 4;
     // rows of A early (they serve both adjacency products): then layer 1's own L chunk lives inside the R area
     const bool early = p.n <= KC && p.K0 <= KC;
@@ -435,7 +449,7 @@ __global__ __launch_bounds__(NT) void small_gcn_bwd_kernel(const SmallGcnParams 
     float* w2s = w1t + H1 * H2;
     float* w2t = w2s + H2 * H3;
     float* Lc = smem + OFF_LC;
-    const int r0 = blockIdx.x * RB, nwg = gridDim.x;
+    const int r0 = blockIdx.x * RB, nwg = p.nwg;
     const int wave = threadIdx.x >> 6, i = threadIdx.x & 15, kq = (threadIdx.x & 63) >> 4;
     const bool early = p.n <= KC;                 // rows of A^T once, for both products
     const bool ax_early = p.K0 <= KC;             // rows of AX ride in registers from the first burst to the last layer
@@ -547,10 +561,12 @@ void set_drop(SmallGcnParams& p, float dropout_p, uint64_t seed, const uint64_t*
 
 }  // namespace
 
-extern "C" int mobgt_small_gcn_fwd(const float* ax, const float* a, const float* w0, const float* b0, const float* w1,
-                                   const float* b1, const float* w2, const float* b2, float* h1, float* t, float* h2, float* t2,
-                                   float* out, int* counter, int n, int K0, int H1, int H2, int H3, float slope, float dropout_p,
-                                   uint64_t seed, const uint64_t* seed_dev, uint32_t salt, void* stream) {
+extern "C" int mobgt_small_gcn_fwd_pack(const float* ax, const float* a, const float* w0, const float* b0, const float* w1,
+                                        const float* b1, const float* w2, const float* b2, float* h1, float* t, float* h2, float* t2,
+                                        float* out, int* counter, int n, int K0, int H1, int H2, int H3, float slope, float dropout_p,
+                                        uint64_t seed, const uint64_t* seed_dev, uint32_t salt, int pack_n, const void* const* pack_src,
+                                        void* const* pack_dst, const int* pack_N, const int* pack_K, const int* pack_transposed,
+                                        void* stream) {
     SmallGcnParams p = {};
     p.AX = ax; p.A = a; p.W0 = w0; p.b0 = b0; p.W1 = w1; p.b1 = b1; p.W2 = w2; p.b2 = b2;
     p.h1 = h1; p.t = t; p.h2 = h2; p.t2 = t2; p.out = out; p.counter = counter;
@@ -560,8 +576,29 @@ extern "C" int mobgt_small_gcn_fwd(const float* ax, const float* a, const float*
     set_drop(p, dropout_p, seed, seed_dev, salt);
     if (((uintptr_t)w0 | (uintptr_t)h1 | (uintptr_t)h2) & 15) return MOBGT_EALIGN;
     if ((rc = lds_opt_in((const void*)small_gcn_fwd_kernel<16, 64, 32>))) return rc;
-    hipLaunchKernelGGL((small_gcn_fwd_kernel<16, 64, 32>), dim3((n + RB - 1) / RB), dim3(NT), LDS_FLOATS * sizeof(float), (hipStream_t)stream, p);
+    p.nwg = (n + RB - 1) / RB;
+    static mobgt_pack::PackJobs jobs;            // (by value into the launch; 3 KB -- not on the stack of every call)
+    int nvb = 0, passengers = 0;
+    if (pack_n > 0) {
+        jobs = mobgt_pack::PackJobs{};
+        if ((rc = mobgt_pack::fill_jobs(jobs, pack_n, pack_src, pack_dst, pack_N, pack_K, pack_transposed, &nvb))) return rc;
+        // every workgroup of this launch owns a compute unit's LDS: two rounds of passengers on the units the network leaves free
+        int dev = 0, cus = 256;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
+        passengers = PACK_ROUNDS * (cus > p.nwg ? cus - p.nwg : 1);
+        if (passengers > (nvb + PACK_U - 1) / PACK_U) passengers = (nvb + PACK_U - 1) / PACK_U;
+    }
+    hipLaunchKernelGGL((small_gcn_fwd_kernel<16, 64, 32>), dim3(p.nwg + passengers), dim3(NT), LDS_FLOATS * sizeof(float), (hipStream_t)stream, p,
+                       jobs, pack_n > 0 ? pack_n : 0, nvb);
     return (int)hipGetLastError();
+}
+
+extern "C" int mobgt_small_gcn_fwd(const float* ax, const float* a, const float* w0, const float* b0, const float* w1,
+                                   const float* b1, const float* w2, const float* b2, float* h1, float* t, float* h2, float* t2,
+                                   float* out, int* counter, int n, int K0, int H1, int H2, int H3, float slope, float dropout_p,
+                                   uint64_t seed, const uint64_t* seed_dev, uint32_t salt, void* stream) {
+    return mobgt_small_gcn_fwd_pack(ax, a, w0, b0, w1, b1, w2, b2, h1, t, h2, t2, out, counter, n, K0, H1, H2, H3, slope, dropout_p, seed,
+                                    seed_dev, salt, 0, nullptr, nullptr, nullptr, nullptr, nullptr, stream);
 }
 
 extern "C" int mobgt_small_gcn_bwd(const float* g, const float* ax, const float* a_t, const float* w1, const float* w2,
@@ -579,6 +616,7 @@ extern "C" int mobgt_small_gcn_bwd(const float* g, const float* ax, const float*
     set_drop(p, dropout_p, seed, seed_dev, salt);
     if (((uintptr_t)dt2 | (uintptr_t)dt) & 15) return MOBGT_EALIGN;
     if ((rc = lds_opt_in((const void*)small_gcn_bwd_kernel<16, 64, 32>))) return rc;
+    p.nwg = (n + RB - 1) / RB;
     hipLaunchKernelGGL((small_gcn_bwd_kernel<16, 64, 32>), dim3((n + RB - 1) / RB), dim3(NT), LDS_FLOATS * sizeof(float), (hipStream_t)stream, p);
     return (int)hipGetLastError();
 }

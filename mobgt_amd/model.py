@@ -220,8 +220,40 @@ def fused_layer_forward(layer, variant, x, attn_bias, n1, nx, next_layer=None):
                                qkv_pre=getattr(x, "_mobgt_qkv", None))
 
 
-def refresh_shadows(layers):
-    """bf16 copies of every layer's GEMM weights in ONE multi-tensor copy (call once per forward)."""
+_PENDING_PACK = []          # jobs of a deferred weight pack (see pack_layer_weights(defer=True))
+
+
+def take_pending_pack():
+    """The deferred pack jobs, handed to the launch that will carry them (modelGNN._SmallGcnFn); the list is emptied."""
+    jobs = list(_PENDING_PACK)
+    del _PENDING_PACK[:]
+    return jobs
+
+
+def flush_pending_pack():
+    """Launch a deferred pack that nobody picked up (call in front of the first consumer of `layer._packed`)."""
+    jobs = take_pending_pack()
+    if jobs:
+        _launch_pack(jobs)
+
+
+def _launch_pack(jobs):
+    import ctypes
+    from . import _lib
+    from .ops import _stream
+    for o in range(0, len(jobs), 96):
+        part = jobs[o:o + 96]
+        n = len(part)
+        vp, ci = ctypes.c_void_p, ctypes.c_int
+        _lib.check(_lib.lib().mobgt_pack_mfma_b(n, (vp * n)(*[j[0].data_ptr() for j in part]), (vp * n)(*[j[1].data_ptr() for j in part]),
+                                                (ci * n)(*[j[2] for j in part]), (ci * n)(*[j[3] for j in part]),
+                                                (ci * n)(*[j[4] for j in part]), _stream()), "mobgt_pack_mfma_b")
+
+
+def refresh_shadows(layers, defer_pack=False):
+    """bf16 copies of every layer's GEMM weights in ONE multi-tensor copy (call once per forward).  `defer_pack`: the MFMA-order
+    pack is not launched but left for the category GCN's forward launch to carry (take_pending_pack) -- the caller MUST call
+    flush_pending_pack() in front of the first consumer of the packs."""
     import os
     if os.environ.get("MOBGT_NO_BATCHED_SHADOWS"):
         return
@@ -245,16 +277,15 @@ def refresh_shadows(layers):
         layer._shadow_fresh = True
     if dst:
         torch._foreach_copy_(dst, src)
-    pack_layer_weights(layers)
+    pack_layer_weights(layers, defer=defer_pack)
 
 
-def pack_layer_weights(layers):
+def pack_layer_weights(layers, defer=False):
     """MFMA-operand-order copies of the fused fq layers' bf16 GEMM weights (csrc/chain.hip reads a wave's B operand as one
     contiguous KB), all layers in one launch (up to 96 weights): `layer._packed` = (wqkv, wo, w1, w2) packed for the
     forward chain and, when gradients are enabled, `layer._packed_t` = (w2^T, w1^T, wo^T, wqkv^T) for the backward chain."""
-    import ctypes
-    from . import fused_layer, _lib
-    from .ops import _stream
+    from . import fused_layer
+    flush_pending_pack()                                     # (a pack deferred earlier and never picked up)
     if not fused_layer._CHAIN[0]:
         return
     want_t = torch.is_grad_enabled() and fused_layer._CHAIN_BWD[0]
@@ -283,13 +314,11 @@ def pack_layer_weights(layers):
             for d, i in zip(pt, (6, 4, 2, 0)):       # dX = dY W: W [K = out, N = in] is the operand, packed as [N][K]
                 jobs.append((sh[i], d, sh[i].shape[1], sh[i].shape[0], 1))
             layer._packed_t_fresh = True
-    for o in range(0, len(jobs), 96):
-        part = jobs[o:o + 96]
-        n = len(part)
-        vp, ci = ctypes.c_void_p, ctypes.c_int
-        _lib.check(_lib.lib().mobgt_pack_mfma_b(n, (vp * n)(*[j[0].data_ptr() for j in part]), (vp * n)(*[j[1].data_ptr() for j in part]),
-                                                (ci * n)(*[j[2] for j in part]), (ci * n)(*[j[3] for j in part]),
-                                                (ci * n)(*[j[4] for j in part]), _stream()), "mobgt_pack_mfma_b")
+    import os
+    if defer and jobs and len(jobs) <= 96 and os.environ.get("MOBGT_NO_PACK_PASSENGER") != "1":
+        _PENDING_PACK.extend(jobs)
+    else:
+        _launch_pack(jobs)
 
 
 def sync_external_shadows(model):

@@ -27,7 +27,7 @@ import torch.nn.functional as F
 from . import ops
 from .lr import PolynomialDecayLR
 from .model import (FeedForwardNetwork, MultiHeadAttention, hop_table_from, no_grad_row0, fused_layer_forward,
-                    refresh_shadows)
+                    refresh_shadows, flush_pending_pack)
 from .modelGNN import GCN
 
 node_dim = 2000          # model_fqandtoyo.py:567
@@ -340,6 +340,7 @@ class Graphormer(nn.Module):
                                               adj_t=self.D_A_T, mask_adj=mask_adj)                  # :1236
         ops.trace_nan("poidist", poidist)
         catemb = self.poi_cat_model(self.C_X, self.C_A, self.C_AX, adj_t=self.C_A_T)                                    # :1237
+        flush_pending_pack()                    # (if the one-launch GCN did not take the deferred weight pack along)
         Wp, Wt, Wc, C = poidist.shape[1], self.time_embed_model_48.weight.shape[1], catemb.shape[1], self.pos_embed.pe.shape[1]
         f4 = self.embed_fuse_model4
         one_launch = G * N <= 4096
@@ -425,7 +426,8 @@ class Graphormer(nn.Module):
     def forward(self, batched_data, perturb=None):
         self.validate_batch(batched_data)
         bias = self.assemble_bias(batched_data)
-        refresh_shadows(self.layers)
+        # (the MFMA-order pack of the layer weights rides in the category GCN's forward launch: node_features flushes it)
+        refresh_shadows(self.layers, defer_pack=True)
         output = self.node_features(batched_data)
         ops.trace_nan("x0", output)
         for li, enc_layer in enumerate(self.layers):                                           # :1347-1352
