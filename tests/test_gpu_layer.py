@@ -750,3 +750,52 @@ def test_head_chain_equals_the_three_launches(G, T, C, p):
         sc = float(y.abs().max()) + 1e-12
         err = float((x - y).abs().max())
         assert err <= 2e-5 * max(sc, 1.0) + 1e-5 * sc, (name, err, sc)
+
+
+@pytest.mark.gpu
+def test_weight_pack_as_passenger_of_the_category_gcn_launch_equals_the_pack_launch():
+    """mobgt_small_gcn_fwd_pack (csrc/smallgcn.hip + csrc/pack_body.h): the step's MFMA-order weight pack carried by the category
+    GCN's forward launch as passenger workgroups -- packs bit-identical to mobgt_pack_mfma_b's, the network's outputs
+    bit-identical to the launch without passengers."""
+    import ctypes
+    from mobgt_amd import _lib
+    from mobgt_amd.ops import _p, _stream
+    lib = _lib.lib()
+    g = torch.Generator().manual_seed(3)
+    n, K0, H1, H2, H3 = 300, 300, 16, 64, 32
+    A = (torch.rand(n, n, generator=g) / n).to(DEV)
+    AX = torch.randn(n, K0, generator=g).to(DEV)
+    ws = [torch.randn(K0, H1, generator=g).to(DEV) * 0.1, torch.zeros(H1, device=DEV), torch.randn(H1, H2, generator=g).to(DEV) * 0.1,
+          torch.zeros(H2, device=DEV), torch.randn(H2, H3, generator=g).to(DEV) * 0.1, torch.zeros(H3, device=DEV)]
+    C, F = 192, 1024
+    srcs = [torch.randn(s, generator=g).to(DEV).bfloat16() for _ in range(6) for s in ((3 * C, C), (C, C), (F, C), (C, F))]
+    jobs = [(w, 0) for w in srcs] + [(w, 1) for w in srcs[:12]]                # 24 forward + 12 transposed packs
+
+    def arrays(dsts):
+        nj = len(jobs)
+        vp, ci = ctypes.c_void_p, ctypes.c_int
+        N = [w.shape[1] if t else w.shape[0] for w, t in jobs]
+        K = [w.shape[0] if t else w.shape[1] for w, t in jobs]
+        return nj, (vp * nj)(*[w.data_ptr() for w, _ in jobs]), (vp * nj)(*[d.data_ptr() for d in dsts]), (ci * nj)(*N), (ci * nj)(*K), \
+            (ci * nj)(*[t for _, t in jobs])
+
+    def run(with_pack):
+        outs = [torch.empty(n, w, device=DEV) for w in (H1, H1, H2, H2, H3)]
+        dsts = [torch.zeros(w.numel(), dtype=torch.bfloat16, device=DEV) for w, _ in jobs]
+        counter = torch.zeros(4, dtype=torch.int32, device=DEV)
+        nj, src, dst, N, K, T = arrays(dsts)
+        if with_pack:
+            _lib.check(lib.mobgt_small_gcn_fwd_pack(_p(AX), _p(A), *[_p(w) for w in ws], *[_p(o) for o in outs], _p(counter), n, K0, H1, H2,
+                                                    H3, 0.2, 0.3, 5, None, 7, nj, src, dst, N, K, T, _stream()), "fwd_pack")
+        else:
+            _lib.check(lib.mobgt_pack_mfma_b(nj, src, dst, N, K, T, _stream()), "pack")
+            _lib.check(lib.mobgt_small_gcn_fwd(_p(AX), _p(A), *[_p(w) for w in ws], *[_p(o) for o in outs], _p(counter), n, K0, H1, H2, H3,
+                                               0.2, 0.3, 5, None, 7, _stream()), "fwd")
+        torch.cuda.synchronize()
+        return outs, dsts
+    (o1, d1), (o2, d2) = run(True), run(False)
+    for a, b in zip(o1, o2):
+        assert torch.equal(a, b)
+    for k, (a, b) in enumerate(zip(d1, d2)):
+        assert torch.equal(a, b), k
+    assert float(d1[0].float().abs().sum()) > 0
