@@ -564,6 +564,18 @@ int mobgt_small_gcn_bwd(const float* g, const float* ax, const float* a_t, const
                         const float* t, const float* h2, const float* t2, float* dw0, float* db0, float* dw1, float* db1,
                         float* dw2, float* db2, float* dt2, float* dt, int* counter, int n, int K0, int H1, int H2, int H3,
                         float slope, float dropout_p, uint64_t seed, const uint64_t* seed_dev, uint32_t salt, void* stream);
+/* The same launch carrying mobgt_build_bias_bwd (with_bias != 0: its arguments follow, same meaning) as passenger workgroups
+ * on the compute units the network leaves idle.  Covers the short-batch instantiation only -- idx_dtype MOBGT_I16, edge_dtype
+ * MOBGT_U8, H = 8, F = 1, 0 < D <= 20, G (N+1)^2 < 2^20 -- else MOBGT_EBADDIM (callers then use the two launches).  Results as
+ * the two launches (f32 atomics in another order). */
+int mobgt_small_gcn_bwd_bias(const float* g, const float* ax, const float* a_t, const float* w1, const float* w2, const float* h1,
+                             const float* t, const float* h2, const float* t2, float* dw0, float* db0, float* dw1, float* db1,
+                             float* dw2, float* db2, float* dt2, float* dt, int* counter, int n, int K0, int H1, int H2, int H3,
+                             float slope, float dropout_p, uint64_t seed, const uint64_t* seed_dev, uint32_t salt, int with_bias,
+                             const void* dbias, int dbias_dtype, int n_slices, int64_t slice_stride, const float* attn_bias,
+                             const void* rel_pos, const void* poi_pos, const void* edge_input, float* d_rel_table,
+                             float* d_poi_table, float* d_hop_table, float* d_vdist, int G, int N, int H, int D_in, int D, int F,
+                             int n_rel, int n_poi, int n_edge, int64_t ld_bias, int idx_dtype, int edge_dtype, void* stream);
 /* The same adjacency product from a BITMASK of the adjacency (csrc/maskgemm.hip) -- for the reference's
  * (D+I)^-1 (A+I) with a 0/1 matrix A, whose non-zeros of row i all equal 1/(deg_i + 1) (model_fqandtoyo.py:481-486):
  *   out[i,:] = rscale[i] * sum_k bit(i,k) * bscale[k] * x[k,:] + bias          (rscale / bscale / bias may be null)

@@ -14,7 +14,7 @@
 namespace {
 
 constexpr int TILE = 32;
-constexpr int MAXH = 32;
+constexpr int BIAS_MAXH = 32;
 
 template <typename T> __device__ __forceinline__ T to_out(float v);
 template <> __device__ __forceinline__ float to_out<float>(float v) { return v; }
@@ -375,18 +375,33 @@ __host__ __device__ inline int bwd_lds_dwords(int lds_rel, int lds_poi, int D, i
 // whole 128-byte lines: with 2 rows x 32 columns every line was fetched twice, by two workgroups): 4 waves for short
 // batches (more units to spread), 8 for long ones (one workgroup per CU shares ONE set of tables among 8 waves: the
 // 4-wave form needed 78 KB of LDS and 308 registers, i.e. ran one wave per SIMD with every latency exposed).
+template <bool HOPMM, int NW> __host__ __device__ constexpr size_t bwd_hop_e_bytes() {
+    return (sizeof(uint16_t) * (HOPMM ? NW : 1) * (HOPMM ? HOP_DMAX : 1) * 64 + 15) / 16 * 16;
+}
+// bytes of per-wave staging in front of the tables: hop_e | gr_s | wmax_s, a multiple of 16
+template <int HH, bool HOPMM, int NW> __host__ __device__ constexpr size_t bwd_stage_bytes() {
+    return bwd_hop_e_bytes<HOPMM, NW>() + sizeof(float) * NW * HH * 64 + (sizeof(float) * NW + 15) / 16 * 16;
+}
+// (`bid` of `nblk`: the workgroup's place among those that run this body -- the grid of build_bias_bwd_kernel, or the passenger
+//  workgroups of the category GCN's backward launch, csrc/smallgcn.hip)
 template <typename TI, typename TE, int HH, bool HOPMM, int NW>
-__global__ __launch_bounds__(NW * 64) void build_bias_bwd_kernel(const BuildParams p, int lds_rel, int lds_poi) {
-    __shared__ __attribute__((aligned(16))) uint16_t hop_e[HOPMM ? NW : 1][HOPMM ? HOP_DMAX : 1][64];    // [wave][d][pair] one-hot
+__device__ __forceinline__ void build_bias_bwd_body(const BuildParams& p, int lds_rel, int lds_poi, const int bid, const int nblk) {
+    // per-wave staging in front of the tables, all of it in the launch's DYNAMIC LDS (bwd_stage_bytes): as a passenger of the
+    // category GCN's backward launch (csrc/smallgcn.hip) this body shares that launch's 148.5 KB, and static arrays would come
+    // on top of them
+    extern __shared__ __attribute__((aligned(16))) float smem_all[];
+    typedef uint16_t (*hop_e_t)[HOPMM ? HOP_DMAX : 1][64];
+    typedef float (*gr_s_t)[HH][64];
+    hop_e_t hop_e = reinterpret_cast<hop_e_t>(smem_all);                                                // [wave][d][pair] one-hot
     // (the MFMA's B staging [half][col][pair] bf16 overlays the wave's gr_s tile: both are private to the wave, LDS runs a
     // wave's instructions in order, and gr_s is dead once gr[] has been read)
-    __shared__ __attribute__((aligned(16))) float gr_s[NW][HH][64];                                       // [wave][head][col]
+    gr_s_t gr_s = reinterpret_cast<gr_s_t>(reinterpret_cast<unsigned char*>(smem_all) + bwd_hop_e_bytes<HOPMM, NW>());    // [wave][head][col]
     static_assert(!HOPMM || sizeof(float) * HH * 64 >= sizeof(bf16_t) * 2 * 16 * 32, "hop_b overlays gr_s");
-    __shared__ float wmax_s[NW];
+    float* wmax_s = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(smem_all) + bwd_hop_e_bytes<HOPMM, NW>() + sizeof(float) * NW * HH * 64);
+    float* smem = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(smem_all) + bwd_stage_bytes<HH, HOPMM, NW>());
     f32x4_t hacc[HOPMM ? HOP_DMAX : 1];
 #pragma unroll
     for (int d = 0; d < (HOPMM ? HOP_DMAX : 1); ++d) hacc[d] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-    extern __shared__ __attribute__((aligned(16))) float smem[];
     const int st_rel = odd(lds_rel), st_poi = odd(lds_poi), st_len = odd(p.D + 1);
     unsigned long long* s_rel = reinterpret_cast<unsigned long long*>(smem);      // [HH][st_rel] fixed point
     unsigned long long* s_poi = s_rel + (size_t)st_rel * HH;                      // [HH][st_poi] fixed point
@@ -459,7 +474,7 @@ __global__ __launch_bounds__(NW * 64) void build_bias_bwd_kernel(const BuildPara
     const int njt = (T + 63) / 64, nib = (T + NW - 1) / NW;
     const int n_units = njt * nib * p.G;
 #pragma unroll 1
-    for (int unit = blockIdx.x; unit < n_units; unit += gridDim.x) {
+    for (int unit = bid; unit < n_units; unit += nblk) {
     const int g = unit / (njt * nib);
     const int j0 = (unit % njt) * 64;
     {
@@ -706,6 +721,11 @@ __global__ __launch_bounds__(NW * 64) void build_bias_bwd_kernel(const BuildPara
         }
 }
 
+template <typename TI, typename TE, int HH, bool HOPMM, int NW>
+__global__ __launch_bounds__(NW * 64) void build_bias_bwd_kernel(const BuildParams p, int lds_rel, int lds_poi) {
+    build_bias_bwd_body<TI, TE, HH, HOPMM, NW>(p, lds_rel, lds_poi, (int)blockIdx.x, (int)gridDim.x);
+}
+
 template <typename TI, typename TE, typename TB>
 int launch_build(const BuildParams& p, hipStream_t st) {
     const int T = p.N + 1;
@@ -736,29 +756,30 @@ int launch_build_bwd(const BuildParams& p, hipStream_t st) {
     const int64_t pairs = (int64_t)p.G * T * T;
     const int lds_rel = p.n_rel < 512 ? p.n_rel : 512;
     const int lds_poi = p.poi_pos ? (p.n_poi < 1024 ? p.n_poi : 1024) : 0;
-    const size_t shm = (size_t)bwd_lds_dwords(lds_rel, lds_poi, p.D, p.H) * sizeof(float);
+    const size_t tables = (size_t)bwd_lds_dwords(lds_rel, lds_poi, p.D, p.H) * sizeof(float);
+    size_t shm = 0;
     const bool hopmm = p.edge_input && p.F == 1 && p.H == 8 && p.D <= HOP_DMAX;
     // long batches: 8-wave workgroups, one per CU (each walks its units); short ones: 4-wave workgroups, up to 3 per CU
     // (more than 64 KB of dynamic LDS has to be asked for, per kernel)
-#define BWD_LDS(K) do { if (shm > 48 * 1024 && hipFuncSetAttribute((const void*)(K), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm) != hipSuccess) return MOBGT_EBADDIM; } while (0)
+#define BWD_LDS(K, HH_, HM_, NW_) do { shm = tables + bwd_stage_bytes<HH_, HM_, NW_>(); if (shm > 48 * 1024 && hipFuncSetAttribute((const void*)(K), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm) != hipSuccess) return MOBGT_EBADDIM; } while (0)
     static const int64_t long_from = getenv("MOBGT_BIAS_BWD_LONG") ? atoll(getenv("MOBGT_BIAS_BWD_LONG")) : (1 << 20);
     if (hopmm && pairs >= long_from) {
         const int n_units8 = ((T + 63) / 64) * ((T + 7) / 8) * p.G;
         const dim3 grid(n_units8 < 256 ? n_units8 : 256), block(512);
-        BWD_LDS((build_bias_bwd_kernel<TI, TE, 8, true, 8>));
+        BWD_LDS((build_bias_bwd_kernel<TI, TE, 8, true, 8>), 8, true, 8);
         hipLaunchKernelGGL((build_bias_bwd_kernel<TI, TE, 8, true, 8>), grid, block, shm, st, p, lds_rel, lds_poi);
         return (int)hipGetLastError();
     }
     const int n_units = ((T + 63) / 64) * ((T + 3) / 4) * p.G;
     const dim3 grid(n_units < 768 ? n_units : 768), block(256);
     if (hopmm) {
-        BWD_LDS((build_bias_bwd_kernel<TI, TE, 8, true, 4>));
+        BWD_LDS((build_bias_bwd_kernel<TI, TE, 8, true, 4>), 8, true, 4);
         hipLaunchKernelGGL((build_bias_bwd_kernel<TI, TE, 8, true, 4>), grid, block, shm, st, p, lds_rel, lds_poi);
     } else if (p.H == 8) {
-        BWD_LDS((build_bias_bwd_kernel<TI, TE, 8, false, 4>));
+        BWD_LDS((build_bias_bwd_kernel<TI, TE, 8, false, 4>), 8, false, 4);
         hipLaunchKernelGGL((build_bias_bwd_kernel<TI, TE, 8, false, 4>), grid, block, shm, st, p, lds_rel, lds_poi);
     } else if (p.H == 4) {
-        BWD_LDS((build_bias_bwd_kernel<TI, TE, 4, false, 4>));
+        BWD_LDS((build_bias_bwd_kernel<TI, TE, 4, false, 4>), 4, false, 4);
         hipLaunchKernelGGL((build_bias_bwd_kernel<TI, TE, 4, false, 4>), grid, block, shm, st, p, lds_rel, lds_poi);
     } else return MOBGT_EBADDIM;
 #undef BWD_LDS
@@ -802,7 +823,7 @@ extern "C" int mobgt_build_bias(const float* attn_bias, const void* rel_pos, con
                                 const float* vdist, void* bias, void* bias_t, int G, int N, int H, int D_in, int D, int F,
                                 int n_rel, int n_poi, int n_edge, int64_t ld_bias, int idx_dtype, int edge_dtype,
                                 int bias_dtype, void* stream) {
-    if (G <= 0 || N <= 0 || H > MAXH || D < 0 || D > D_in || F <= 0) return MOBGT_EBADDIM;
+    if (G <= 0 || N <= 0 || H > BIAS_MAXH || D < 0 || D > D_in || F <= 0) return MOBGT_EBADDIM;
     if (ld_bias % 32 != 0 || ld_bias < N + 1) return MOBGT_EALIGN;
     BuildParams p = {};
     p.attn_bias = attn_bias; p.rel_pos = rel_pos; p.poi_pos = poi_pos; p.edge_input = D > 0 ? edge_input : nullptr;
@@ -814,20 +835,34 @@ extern "C" int mobgt_build_bias(const float* attn_bias, const void* rel_pos, con
     DISPATCH_IDX(launch_build_b, p, bias_dtype, st);
 }
 
-extern "C" int mobgt_build_bias_bwd(const void* dbias, int dbias_dtype, int n_slices, int64_t slice_stride,
-                                    const float* attn_bias, const void* rel_pos, const void* poi_pos,
-                                    const void* edge_input, float* d_rel_table, float* d_poi_table, float* d_hop_table,
-                                    float* d_vdist, int G, int N, int H, int D_in, int D, int F, int n_rel, int n_poi,
-                                    int n_edge, int64_t ld_bias, int idx_dtype, int edge_dtype, void* stream) {
-    if (G <= 0 || N <= 0 || H > MAXH || D < 0 || D > D_in || F <= 0 || n_slices < 1) return MOBGT_EBADDIM;
+namespace {
+// arguments of mobgt_build_bias_bwd -> BuildParams (validated); shared with mobgt_small_gcn_bwd_bias (csrc/smallgcn.hip)
+int fill_bias_bwd(BuildParams& p, const void* dbias, int dbias_dtype, int n_slices, int64_t slice_stride, const float* attn_bias,
+                  const void* rel_pos, const void* poi_pos, const void* edge_input, float* d_rel_table, float* d_poi_table,
+                  float* d_hop_table, float* d_vdist, int G, int N, int H, int D_in, int D, int F, int n_rel, int n_poi, int n_edge,
+                  int64_t ld_bias) {
+    if (G <= 0 || N <= 0 || H > BIAS_MAXH || D < 0 || D > D_in || F <= 0 || n_slices < 1) return MOBGT_EBADDIM;
     if (dbias_dtype != MOBGT_F32 && dbias_dtype != MOBGT_BF16) return MOBGT_EDTYPE;
-    BuildParams p = {};
+    p = BuildParams{};
     p.dbias = dbias; p.dbias_bf16 = dbias_dtype == MOBGT_BF16; p.n_slices = p.dbias_bf16 ? n_slices : 1;
     p.slice_stride = slice_stride; p.attn_bias = attn_bias; p.rel_pos = rel_pos; p.poi_pos = poi_pos;
     p.edge_input = D > 0 ? edge_input : nullptr;
     p.d_rel = d_rel_table; p.d_poi = d_poi_table; p.d_hop = d_hop_table; p.d_vdist = d_vdist;
     p.G = G; p.N = N; p.H = H; p.D_in = D_in; p.D = D; p.F = F; p.n_rel = n_rel; p.n_poi = n_poi; p.n_edge = n_edge;
     p.ld = ld_bias;
+    return 0;
+}
+}  // namespace
+
+extern "C" int mobgt_build_bias_bwd(const void* dbias, int dbias_dtype, int n_slices, int64_t slice_stride,
+                                    const float* attn_bias, const void* rel_pos, const void* poi_pos,
+                                    const void* edge_input, float* d_rel_table, float* d_poi_table, float* d_hop_table,
+                                    float* d_vdist, int G, int N, int H, int D_in, int D, int F, int n_rel, int n_poi,
+                                    int n_edge, int64_t ld_bias, int idx_dtype, int edge_dtype, void* stream) {
+    BuildParams p;
+    const int rc = fill_bias_bwd(p, dbias, dbias_dtype, n_slices, slice_stride, attn_bias, rel_pos, poi_pos, edge_input, d_rel_table,
+                                 d_poi_table, d_hop_table, d_vdist, G, N, H, D_in, D, F, n_rel, n_poi, n_edge, ld_bias);
+    if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
     DISPATCH_IDX(launch_build_bwd, p, st);
 }

@@ -16,6 +16,9 @@
 #include "common.h"
 #include "mobgt_hip.h"
 #include "pack_body.h"
+// csrc/bias.hip is compiled as part of THIS translation unit (not on its own): the category GCN's backward launch carries the bias
+// tables' backward (build_bias_bwd_body) as passenger workgroups, and that body lives there with everything it needs
+#include "bias.hip"
 
 namespace {
 
@@ -437,7 +440,13 @@ __device__ __forceinline__ void tile_bgrad(const float* G, float* db) {
 }
 
 template <int H1, int H2, int H3>
-__global__ __launch_bounds__(NT) void small_gcn_bwd_kernel(const SmallGcnParams p) {
+__global__ __launch_bounds__(NT) void small_gcn_bwd_kernel(const SmallGcnParams p, const BuildParams bp, int lds_rel, int lds_poi) {
+    if ((int)blockIdx.x >= p.nwg) {
+        // passengers: the backward of the bias tables (csrc/bias.hip, the short-batch form: int16 indices, uint8 edge ids, 8
+        // heads, hop histogram on the matrix core, 4 waves) -- 21.6 us of its own launch, independent of this network
+        build_bias_bwd_body<int16_t, uint8_t, 8, true, 4>(bp, lds_rel, lds_poi, (int)blockIdx.x - p.nwg, (int)gridDim.x - p.nwg);
+        return;
+    }
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* gl = smem + OFF_T;                     // this workgroup's rows of the current gradient
     float* t2l = gl + RB * LDT;                   // ... and of the saved activations, all fetched up front
@@ -601,11 +610,17 @@ extern "C" int mobgt_small_gcn_fwd(const float* ax, const float* a, const float*
                                     seed_dev, salt, 0, nullptr, nullptr, nullptr, nullptr, nullptr, stream);
 }
 
-extern "C" int mobgt_small_gcn_bwd(const float* g, const float* ax, const float* a_t, const float* w1, const float* w2,
-                                   const float* h1, const float* t, const float* h2, const float* t2, float* dw0, float* db0,
-                                   float* dw1, float* db1, float* dw2, float* db2, float* dt2, float* dt, int* counter, int n,
-                                   int K0, int H1, int H2, int H3, float slope, float dropout_p, uint64_t seed,
-                                   const uint64_t* seed_dev, uint32_t salt, void* stream) {
+extern "C" int mobgt_small_gcn_bwd_bias(const float* g, const float* ax, const float* a_t, const float* w1, const float* w2,
+                                        const float* h1, const float* t, const float* h2, const float* t2, float* dw0, float* db0,
+                                        float* dw1, float* db1, float* dw2, float* db2, float* dt2, float* dt, int* counter, int n,
+                                        int K0, int H1, int H2, int H3, float slope, float dropout_p, uint64_t seed,
+                                        const uint64_t* seed_dev, uint32_t salt,
+                                        // the arguments of mobgt_build_bias_bwd (with_bias != 0), idx int16 / edge uint8 / H = 8
+                                        int with_bias, const void* dbias, int dbias_dtype, int n_slices, int64_t slice_stride,
+                                        const float* attn_bias, const void* rel_pos, const void* poi_pos, const void* edge_input,
+                                        float* d_rel_table, float* d_poi_table, float* d_hop_table, float* d_vdist, int G, int N,
+                                        int H, int D_in, int D, int F, int n_rel, int n_poi, int n_edge, int64_t ld_bias,
+                                        int idx_dtype, int edge_dtype, void* stream) {
     SmallGcnParams p = {};
     p.g = g; p.AX = ax; p.AT = a_t; p.W1 = w1; p.W2 = w2;
     p.h1 = const_cast<float*>(h1); p.t = const_cast<float*>(t); p.h2 = const_cast<float*>(h2); p.t2 = const_cast<float*>(t2);
@@ -617,6 +632,36 @@ extern "C" int mobgt_small_gcn_bwd(const float* g, const float* ax, const float*
     if (((uintptr_t)dt2 | (uintptr_t)dt) & 15) return MOBGT_EALIGN;
     if ((rc = lds_opt_in((const void*)small_gcn_bwd_kernel<16, 64, 32>))) return rc;
     p.nwg = (n + RB - 1) / RB;
-    hipLaunchKernelGGL((small_gcn_bwd_kernel<16, 64, 32>), dim3((n + RB - 1) / RB), dim3(NT), LDS_FLOATS * sizeof(float), (hipStream_t)stream, p);
+    BuildParams bp = {};
+    int lds_rel = 0, lds_poi = 0, passengers = 0;
+    if (with_bias) {
+        if ((rc = fill_bias_bwd(bp, dbias, dbias_dtype, n_slices, slice_stride, attn_bias, rel_pos, poi_pos, edge_input, d_rel_table,
+                                d_poi_table, d_hop_table, d_vdist, G, N, H, D_in, D, F, n_rel, n_poi, n_edge, ld_bias))) return rc;
+        const int T = N + 1;
+        // only the instantiation the short-batch launch of mobgt_build_bias_bwd would pick (see launch_build_bwd)
+        if (idx_dtype != MOBGT_I16 || edge_dtype != MOBGT_U8 || H != 8 || !bp.edge_input || F != 1 || D > HOP_DMAX ||
+            (int64_t)G * T * T >= (1 << 20)) return MOBGT_EBADDIM;
+        lds_rel = bp.n_rel < 512 ? bp.n_rel : 512;
+        lds_poi = bp.poi_pos ? (bp.n_poi < 1024 ? bp.n_poi : 1024) : 0;
+        if ((size_t)bwd_lds_dwords(lds_rel, lds_poi, bp.D, bp.H) * sizeof(float) + bwd_stage_bytes<8, true, 4>() > LDS_FLOATS * sizeof(float))
+            return MOBGT_EBADDIM;
+        const int n_units = ((T + 63) / 64) * ((T + 3) / 4) * G;
+        int dev = 0, cus = 256;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
+        passengers = cus > p.nwg ? cus - p.nwg : 1;            // (every workgroup of this launch owns a compute unit's LDS)
+        if (passengers > n_units) passengers = n_units;
+    }
+    hipLaunchKernelGGL((small_gcn_bwd_kernel<16, 64, 32>), dim3(p.nwg + passengers), dim3(NT), LDS_FLOATS * sizeof(float), (hipStream_t)stream,
+                       p, bp, lds_rel, lds_poi);
     return (int)hipGetLastError();
+}
+
+extern "C" int mobgt_small_gcn_bwd(const float* g, const float* ax, const float* a_t, const float* w1, const float* w2,
+                                   const float* h1, const float* t, const float* h2, const float* t2, float* dw0, float* db0,
+                                   float* dw1, float* db1, float* dw2, float* db2, float* dt2, float* dt, int* counter, int n,
+                                   int K0, int H1, int H2, int H3, float slope, float dropout_p, uint64_t seed,
+                                   const uint64_t* seed_dev, uint32_t salt, void* stream) {
+    return mobgt_small_gcn_bwd_bias(g, ax, a_t, w1, w2, h1, t, h2, t2, dw0, db0, dw1, db1, dw2, db2, dt2, dt, counter, n, K0, H1, H2, H3,
+                                    slope, dropout_p, seed, seed_dev, salt, 0, nullptr, 0, 1, 0, nullptr, nullptr, nullptr, nullptr, nullptr,
+                                    nullptr, nullptr, nullptr, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, stream);
 }

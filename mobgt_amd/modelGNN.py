@@ -487,10 +487,19 @@ class _SmallGcnFn(torch.autograd.Function):
         grads = [s[:] if s is not None else ops.zeros_f32(shape, ax.device) for s, shape in zip(ctx.sinks, shapes)]
         scratch = torch.empty(n * (H1 + H2), dtype=torch.float32, device=ax.device)
         counter = ops.zeros_f32((4,), ax.device)
-        _lib.check(_lib.lib().mobgt_small_gcn_bwd(_p(g.contiguous()), _p(ax), _p(a_t), _p(w1), _p(w2), _p(h1), _p(t), _p(h2),
-                                                  _p(t2), *[_p(x) for x in grads], _p(scratch[n * H1:]), _p(scratch[:n * H1]),
-                                                  _p(counter), n, K0, H1, H2, H3, slope, p_drop, seed, _p(seed_dev), salt,
-                                                  _stream()), "mobgt_small_gcn_bwd")
+        # the bias tables' backward, if its inputs are complete, rides in this launch as passenger workgroups (ops.take_bias_bwd_job)
+        job = ops.take_bias_bwd_job()
+        if job is not None:
+            outs, bias_args = ops.bias_bwd_job_args(job)
+            extra = [1] + bias_args
+        else:
+            extra = [0, None, 0, 1, 0] + [None] * 8 + [0] * 9 + [0, 0, 0]
+        _lib.check(_lib.lib().mobgt_small_gcn_bwd_bias(_p(g.contiguous()), _p(ax), _p(a_t), _p(w1), _p(w2), _p(h1), _p(t), _p(h2),
+                                                       _p(t2), *[_p(x) for x in grads], _p(scratch[n * H1:]), _p(scratch[:n * H1]),
+                                                       _p(counter), n, K0, H1, H2, H3, slope, p_drop, seed, _p(seed_dev), salt,
+                                                       *extra, _stream()), "mobgt_small_gcn_bwd_bias")
+        if job is not None:
+            job["done"] = outs
         return (None, None, None, *grads, None, None, None, None, None)
 
 

@@ -196,6 +196,48 @@ def pack_bias(attn_bias, G, H, T, dtype=None):
 
 
 # ------------------------------------------------------------------------------------- build bias
+# The bias tables' backward (mobgt_build_bias_bwd, 21.6 us of the S-FSQ step) depends on nothing but the dBias slices, which
+# are complete once the last attention backward has run -- long before autograd reaches this node (created first, run last).
+# The category GCN's backward launch (19 compute units busy for 25 us, modelGNN._SmallGcnFn) comes in between and carries it
+# as passenger workgroups: _BuildBiasFn.forward leaves a job here, the GCN's backward takes it (take_bias_bwd_job) and stores
+# the four gradients in it, _BuildBiasFn.backward then only hands them out.  MOBGT_NO_BIAS_BWD_PASSENGER=1: own launch.
+_BIAS_BWD_JOB = {}
+
+
+def _bias_bwd_alloc(shapes, dev):
+    rs, ps, hs, vs = shapes
+    return (zeros_f32(rs, dev), zeros_f32(ps, dev) if ps is not None else None, zeros_f32(hs, dev) if hs is not None else None,
+            zeros_f32(vs, dev))
+
+
+def take_bias_bwd_job():
+    """The pending bias-backward job if its inputs are complete and it is the instantiation the passenger form covers
+    (int16 indices, uint8 edge ids, 8 heads, one edge feature, <= 20 hops, a short batch); None otherwise."""
+    job = _BIAS_BWD_JOB.pop("cur", None)
+    if job is None or os.environ.get("MOBGT_NO_BIAS_BWD_PASSENGER") == "1":
+        return None
+    pack = job["pack"]()
+    if pack is None or pack.dbias is None or not pack.sliced or pack.n_use < 1 or pack.n_bwd < pack.n_use:
+        return None
+    G, N, H, D_in, D, F, n_rel, n_poi, n_edge, ld, idx_dt, edge_dt = job["args"]
+    if not (idx_dt == I16 and edge_dt == U8 and H == 8 and D > 0 and D <= 20 and F == 1 and G * (N + 1) * (N + 1) < (1 << 20)
+            and job["idx"][3] is not None):
+        return None
+    return job
+
+
+def bias_bwd_job_args(job):
+    """-> (outputs, ctypes-ready argument list of mobgt_build_bias_bwd without the stream)."""
+    pack = job["pack"]()
+    outs = _bias_bwd_alloc(job["shapes"], pack.bias.device)
+    attn_bias, rel_pos, poi_pos, edge_input = job["idx"]
+    n_sl = max(pack.n_bwd, 1) if pack.sliced else 1
+    stride = pack.dbias.stride(0) if pack.sliced else 0
+    args = [_p(pack.dbias), _DT[pack.dbias.dtype], n_sl, stride, _p(attn_bias), _p(rel_pos), _p(poi_pos), _p(edge_input),
+            _p(outs[0]), _p(outs[1]), _p(outs[2]), _p(outs[3]), *job["args"]]
+    return outs, args
+
+
 class _BuildBiasFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, rel_table, poi_table, hop_table, vdist, pack, attn_bias, rel_pos, poi_pos, edge_input, D):
@@ -218,17 +260,25 @@ class _BuildBiasFn(torch.autograd.Function):
         ctx.idx = (attn_bias, rel_pos, poi_pos, edge_input if has_edge else None)
         ctx.shapes = (rel_table.shape, None if poi_table is None else poi_table.shape,
                       hop_table.shape if has_edge else None, vdist.shape)
+        import weakref
+        # (weak: the pack's token belongs to this forward pass's autograd graph, which must not outlive its backward)
+        ctx.job = dict(pack=weakref.ref(pack), args=args, idx=ctx.idx, shapes=ctx.shapes, done=None)
+        _BIAS_BWD_JOB.pop("cur", None)
+        if pack.needs_grad:                        # (build_bias() looked at the grad mode: it is off inside Function.forward)
+            _BIAS_BWD_JOB["cur"] = ctx.job
         return zeros_f32((1,), rel_table.device)
 
     @staticmethod
     def backward(ctx, _g):
         pack = ctx.pack
         dev = pack.bias.device
-        rs, ps, hs, vs = ctx.shapes
-        d_rel = zeros_f32(rs, dev)
-        d_poi = zeros_f32(ps, dev) if ps is not None else None
-        d_hop = zeros_f32(hs, dev) if hs is not None else None
-        d_vd = zeros_f32(vs, dev)
+        if ctx.job["done"] is not None:            # computed by the passengers of the category GCN's backward launch
+            d_rel, d_poi, d_hop, d_vd = ctx.job["done"]
+            ctx.job["done"] = None
+            return d_rel, d_poi, d_hop, d_vd, None, None, None, None, None, None
+        if _BIAS_BWD_JOB.get("cur") is ctx.job:
+            del _BIAS_BWD_JOB["cur"]
+        d_rel, d_poi, d_hop, d_vd = _bias_bwd_alloc(ctx.shapes, dev)
         if pack.dbias is not None:
             attn_bias, rel_pos, poi_pos, edge_input = ctx.idx
             a = ctx.args

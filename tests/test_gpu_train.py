@@ -255,3 +255,45 @@ def test_encoder_input_backward_as_one_launch_equals_the_three_launches(monkeypa
     monkeypatch.setenv("MOBGT_NO_TOKEN_BWD_CHAIN", "0")
     model.training_step(batch, 0)
     assert ops._TOKEN_CHAIN.get("cur") is not None
+
+
+def test_bias_tables_backward_as_passenger_of_the_category_gcn_launch(monkeypatch):
+    """mobgt_small_gcn_bwd_bias: the bias tables' backward (csrc/bias.hip: build_bias_bwd_body) carried by the category GCN's
+    backward launch as passenger workgroups, against its own launch (MOBGT_NO_BIAS_BWD_PASSENGER=1): the gradients of the five
+    bias tables and of the category GCN's weights on a dropout-on S-FSQ batch (f32 atomics in another order: ~5e-4)."""
+    from mobgt_amd import ops, workloads
+    uni, model, coll = workloads.build("fsq", "cuda", seed=1, model_overrides=dict(n_layers=2))
+    batch = coll(workloads.make_pool("fsq", 1, 16, uni)[0])
+    model.train()
+    sd = torch.zeros(1, dtype=torch.int64, device="cuda")
+    ops.set_dropout_state(sd, 99)
+    for m in model.modules():
+        if hasattr(m, "seed_dev"):
+            m.seed_dev = sd
+    res, took = [], []
+    real_take = ops.take_bias_bwd_job
+
+    def spy():
+        j = real_take()
+        took.append(j is not None)
+        return j
+    monkeypatch.setattr(ops, "take_bias_bwd_job", spy)
+    try:
+        for off in ("0", "1"):
+            monkeypatch.setenv("MOBGT_NO_BIAS_BWD_PASSENGER", off)
+            for p in model.parameters():
+                p.grad = None
+            model.training_step(batch, 0).backward()
+            torch.cuda.synchronize()
+            res.append({n: p.grad.detach().float().clone() for n, p in model.named_parameters() if p.grad is not None})
+    finally:
+        ops.set_dropout_state(None, 0)
+    assert took == [True, False], took                 # the passenger form ran in the first pass, not in the second
+    a, b = res
+    names = [n for n in a if n.split(".")[0] in ("rel_pos_encoder", "poi_pos_encoder", "edge_encoder", "edge_dis_encoder",
+                                                  "graph_token_virtual_distance", "poi_cat_model")]
+    assert len(names) >= 8, names
+    for n in names:
+        sc = float(b[n].abs().max())
+        err = float((a[n] - b[n]).abs().max())
+        assert sc > 0 and err <= 2e-3 * sc, (n, err, sc)
