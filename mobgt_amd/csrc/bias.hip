@@ -78,8 +78,10 @@ __device__ __forceinline__ float spd_divisor(int rp, int D) {
     return (float)s;
 }
 
+// (bx, by, bz: the workgroup's place in the grid of build_bias_kernel -- or what a passenger workgroup of the category GCN's
+//  forward launch, csrc/smallgcn.hip, derives from its running number)
 template <typename TI, typename TE, typename TB, int HH, int RND>
-__global__ __launch_bounds__(256) void build_bias_kernel(const BuildParams p) {
+__device__ __forceinline__ void build_bias_body(const BuildParams& p, const int bx, const int by, const int bz) {
     // RND = 1: one workgroup = one 8-row round of a 32x32 tile (blockIdx.y = 4 * tile row + round): a short batch
     // (16 graphs x 41 tokens = 64 tiles) still spreads over 256 workgroups.  RND = 4 (long batches): the four rounds of a
     // tile one after the other, so that a row of the transposed copy receives 64 contiguous bytes instead of 16 (with
@@ -99,16 +101,16 @@ __global__ __launch_bounds__(256) void build_bias_kernel(const BuildParams p) {
         }
         __syncthreads();
     }
-    const int g = blockIdx.z;
+    const int g = bz;
     const int N = p.N, T = N + 1;
-    const int i0 = (RND == 1 ? (blockIdx.y >> 2) : blockIdx.y) * TILE, j0 = blockIdx.x * TILE;    // token coordinates
+    const int i0 = (RND == 1 ? (by >> 2) : by) * TILE, j0 = bx * TILE;    // token coordinates
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
     const float inv_f = 1.f / (float)p.F;
     TB* B = reinterpret_cast<TB*>(p.bias);
     TB* BT = reinterpret_cast<TB*>(p.bias_t);
 #pragma unroll 1
     for (int rd = 0; rd < RND; ++rd) {
-        const int r = RND == 1 ? (blockIdx.y & 3) * 8 : rd * 8;
+        const int r = RND == 1 ? (by & 3) * 8 : rd * 8;
         const int ti = i0 + ty + r, tj = j0 + tx;                // token indices
         float acc[HH];
         bool live = ti < T && tj < T;
@@ -196,7 +198,7 @@ __global__ __launch_bounds__(256) void build_bias_kernel(const BuildParams p) {
         const int piece = e % RND, c = (e / RND) % TILE, h = e / (RND * TILE);
         const int tj = j0 + c;
         if (tj >= T) continue;
-        const int r = RND == 1 ? (blockIdx.y & 3) * 8 : 8 * piece;
+        const int r = RND == 1 ? (by & 3) * 8 : 8 * piece;
         // ld is a multiple of 32 and i0 + r of 8: the 8 elements are in range and 16-byte aligned -> one (bf16) or
         // two (f32) 16-byte stores
         TB* dst = BT + (((int64_t)g * HH + h) * T + tj) * p.ld + i0 + r;
@@ -375,6 +377,11 @@ __host__ __device__ inline int bwd_lds_dwords(int lds_rel, int lds_poi, int D, i
 // whole 128-byte lines: with 2 rows x 32 columns every line was fetched twice, by two workgroups): 4 waves for short
 // batches (more units to spread), 8 for long ones (one workgroup per CU shares ONE set of tables among 8 waves: the
 // 4-wave form needed 78 KB of LDS and 308 registers, i.e. ran one wave per SIMD with every latency exposed).
+template <typename TI, typename TE, typename TB, int HH, int RND>
+__global__ __launch_bounds__(256) void build_bias_kernel(const BuildParams p) {
+    build_bias_body<TI, TE, TB, HH, RND>(p, (int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z);
+}
+
 template <bool HOPMM, int NW> __host__ __device__ constexpr size_t bwd_hop_e_bytes() {
     return (sizeof(uint16_t) * (HOPMM ? NW : 1) * (HOPMM ? HOP_DMAX : 1) * 64 + 15) / 16 * 16;
 }
@@ -818,19 +825,32 @@ extern "C" int mobgt_bias_pack(const void* src, int src_dtype, int64_t s_g, int6
     return (int)hipGetLastError();
 }
 
-extern "C" int mobgt_build_bias(const float* attn_bias, const void* rel_pos, const void* poi_pos, const void* edge_input,
-                                const float* rel_table, const float* poi_table, const float* hop_table,
-                                const float* vdist, void* bias, void* bias_t, int G, int N, int H, int D_in, int D, int F,
-                                int n_rel, int n_poi, int n_edge, int64_t ld_bias, int idx_dtype, int edge_dtype,
-                                int bias_dtype, void* stream) {
+namespace {
+// arguments of mobgt_build_bias -> BuildParams (validated); shared with mobgt_small_gcn_fwd_pack (csrc/smallgcn.hip)
+int fill_bias_fwd(BuildParams& p, const float* attn_bias, const void* rel_pos, const void* poi_pos, const void* edge_input,
+                  const float* rel_table, const float* poi_table, const float* hop_table, const float* vdist, void* bias, void* bias_t,
+                  int G, int N, int H, int D_in, int D, int F, int n_rel, int n_poi, int n_edge, int64_t ld_bias) {
     if (G <= 0 || N <= 0 || H > BIAS_MAXH || D < 0 || D > D_in || F <= 0) return MOBGT_EBADDIM;
     if (ld_bias % 32 != 0 || ld_bias < N + 1) return MOBGT_EALIGN;
-    BuildParams p = {};
+    p = BuildParams{};
     p.attn_bias = attn_bias; p.rel_pos = rel_pos; p.poi_pos = poi_pos; p.edge_input = D > 0 ? edge_input : nullptr;
     p.rel_table = rel_table; p.poi_table = poi_table; p.hop_table = hop_table; p.vdist = vdist;
     p.bias = bias; p.bias_t = bias_t;
     p.G = G; p.N = N; p.H = H; p.D_in = D_in; p.D = D; p.F = F; p.n_rel = n_rel; p.n_poi = n_poi; p.n_edge = n_edge;
     p.ld = ld_bias;
+    return 0;
+}
+}  // namespace
+
+extern "C" int mobgt_build_bias(const float* attn_bias, const void* rel_pos, const void* poi_pos, const void* edge_input,
+                                const float* rel_table, const float* poi_table, const float* hop_table,
+                                const float* vdist, void* bias, void* bias_t, int G, int N, int H, int D_in, int D, int F,
+                                int n_rel, int n_poi, int n_edge, int64_t ld_bias, int idx_dtype, int edge_dtype,
+                                int bias_dtype, void* stream) {
+    BuildParams p;
+    const int rc = fill_bias_fwd(p, attn_bias, rel_pos, poi_pos, edge_input, rel_table, poi_table, hop_table, vdist, bias, bias_t, G, N, H,
+                                 D_in, D, F, n_rel, n_poi, n_edge, ld_bias);
+    if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
     DISPATCH_IDX(launch_build_b, p, bias_dtype, st);
 }

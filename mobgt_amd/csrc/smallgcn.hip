@@ -299,11 +299,20 @@ __device__ __forceinline__ void tile_product(float* __restrict__ smem, float* __
 }
 
 template <int H1, int H2, int H3>
-__global__ __launch_bounds__(NT) void small_gcn_fwd_kernel(const SmallGcnParams p, const mobgt_pack::PackJobs jobs, int njobs, int nvb) {
+__global__ __launch_bounds__(NT) void small_gcn_fwd_kernel(const SmallGcnParams p, const mobgt_pack::PackJobs jobs, int njobs, int nvb,
+                                                          const BuildParams fb, int fb_nt) {
     if ((int)blockIdx.x >= p.nwg) {
-        // passengers: the step's weight pack (mobgt_pack_mfma_b's body) on the compute units this network leaves idle
-        const int np = (int)gridDim.x - p.nwg;
-        for (int vb = (int)blockIdx.x - p.nwg; vb < nvb; vb += PACK_U * np) mobgt_pack::pack_blocks<PACK_U>(jobs, njobs, vb, np, nvb);
+        // passengers on the compute units this network leaves idle: the step's weight pack (mobgt_pack_mfma_b's body), then the
+        // bias assembly (csrc/bias.hip: build_bias_body, the short-batch form: int16 indices, uint8 edge ids, bf16 bias, 8 heads)
+        const int np = (int)gridDim.x - p.nwg, pid = (int)blockIdx.x - p.nwg;
+        for (int vb = pid; vb < nvb; vb += PACK_U * np) mobgt_pack::pack_blocks<PACK_U>(jobs, njobs, vb, np, nvb);
+        if (fb_nt > 0) {
+            const int nby = 4 * fb_nt, total = fb_nt * nby * fb.G;
+            for (int vb = pid; vb < total; vb += np) {
+                build_bias_body<int16_t, uint8_t, bf16_t, 8, 1>(fb, vb % fb_nt, (vb / fb_nt) % nby, vb / (fb_nt * nby));
+                __syncthreads();                     // (its LDS tile is reused by the next block this workgroup takes)
+            }
+        }
         return;
     }
     static_assert(H1 <= 32 && H1 * H2 + H2 * H3 <= MAXH * MAXH, "LDS plan");
@@ -575,6 +584,11 @@ extern "C" int mobgt_small_gcn_fwd_pack(const float* ax, const float* a, const f
                                         float* out, int* counter, int n, int K0, int H1, int H2, int H3, float slope, float dropout_p,
                                         uint64_t seed, const uint64_t* seed_dev, uint32_t salt, int pack_n, const void* const* pack_src,
                                         void* const* pack_dst, const int* pack_N, const int* pack_K, const int* pack_transposed,
+                                        // the arguments of mobgt_build_bias (with_bias != 0): idx int16 / edge uint8 / bf16 bias / H = 8
+                                        int with_bias, const float* attn_bias, const void* rel_pos, const void* poi_pos,
+                                        const void* edge_input, const float* rel_table, const float* poi_table, const float* hop_table,
+                                        const float* vdist, void* bias, void* bias_t, int G, int N, int H, int D_in, int D, int F,
+                                        int n_rel, int n_poi, int n_edge, int64_t ld_bias, int idx_dtype, int edge_dtype, int bias_dtype,
                                         void* stream) {
     SmallGcnParams p = {};
     p.AX = ax; p.A = a; p.W0 = w0; p.b0 = b0; p.W1 = w1; p.b1 = b1; p.W2 = w2; p.b2 = b2;
@@ -588,17 +602,30 @@ extern "C" int mobgt_small_gcn_fwd_pack(const float* ax, const float* a, const f
     p.nwg = (n + RB - 1) / RB;
     static mobgt_pack::PackJobs jobs;            // (by value into the launch; 3 KB -- not on the stack of every call)
     int nvb = 0, passengers = 0;
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
+    const int free_cus = cus > p.nwg ? cus - p.nwg : 1;      // (every workgroup of this launch owns a compute unit's LDS)
     if (pack_n > 0) {
         jobs = mobgt_pack::PackJobs{};
         if ((rc = mobgt_pack::fill_jobs(jobs, pack_n, pack_src, pack_dst, pack_N, pack_K, pack_transposed, &nvb))) return rc;
-        // every workgroup of this launch owns a compute unit's LDS: two rounds of passengers on the units the network leaves free
-        int dev = 0, cus = 256;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
-        passengers = PACK_ROUNDS * (cus > p.nwg ? cus - p.nwg : 1);
+        passengers = PACK_ROUNDS * free_cus;
         if (passengers > (nvb + PACK_U - 1) / PACK_U) passengers = (nvb + PACK_U - 1) / PACK_U;
     }
+    BuildParams fb = {};
+    int fb_nt = 0;
+    if (with_bias) {
+        if ((rc = fill_bias_fwd(fb, attn_bias, rel_pos, poi_pos, edge_input, rel_table, poi_table, hop_table, vdist, bias, bias_t, G, N, H,
+                                D_in, D, F, n_rel, n_poi, n_edge, ld_bias))) return rc;
+        // only the instantiation the short-batch launch of mobgt_build_bias would pick (see launch_build)
+        if (idx_dtype != MOBGT_I16 || edge_dtype != MOBGT_U8 || bias_dtype != MOBGT_BF16 || H != 8 ||
+            (int64_t)G * (N + 1) * (N + 1) >= (1 << 20)) return MOBGT_EBADDIM;
+        fb_nt = (int)((ld_bias + 31) / 32);
+        const int blocks = fb_nt * 4 * fb_nt * G;
+        const int want = blocks < free_cus ? blocks : free_cus;
+        if (passengers < want) passengers = want;
+    }
     hipLaunchKernelGGL((small_gcn_fwd_kernel<16, 64, 32>), dim3(p.nwg + passengers), dim3(NT), LDS_FLOATS * sizeof(float), (hipStream_t)stream, p,
-                       jobs, pack_n > 0 ? pack_n : 0, nvb);
+                       jobs, pack_n > 0 ? pack_n : 0, nvb, fb, fb_nt);
     return (int)hipGetLastError();
 }
 
@@ -607,7 +634,8 @@ extern "C" int mobgt_small_gcn_fwd(const float* ax, const float* a, const float*
                                    float* out, int* counter, int n, int K0, int H1, int H2, int H3, float slope, float dropout_p,
                                    uint64_t seed, const uint64_t* seed_dev, uint32_t salt, void* stream) {
     return mobgt_small_gcn_fwd_pack(ax, a, w0, b0, w1, b1, w2, b2, h1, t, h2, t2, out, counter, n, K0, H1, H2, H3, slope, dropout_p, seed,
-                                    seed_dev, salt, 0, nullptr, nullptr, nullptr, nullptr, nullptr, stream);
+                                    seed_dev, salt, 0, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr,
+                                    nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, stream);
 }
 
 extern "C" int mobgt_small_gcn_bwd_bias(const float* g, const float* ax, const float* a_t, const float* w1, const float* w2,

@@ -466,9 +466,12 @@ class _SmallGcnFn(torch.autograd.Function):
         vp, ci = ctypes.c_void_p, ctypes.c_int
         pack = ((vp * nj)(*[j[0].data_ptr() for j in jobs]), (vp * nj)(*[j[1].data_ptr() for j in jobs]), (ci * nj)(*[j[2] for j in jobs]),
                 (ci * nj)(*[j[3] for j in jobs]), (ci * nj)(*[j[4] for j in jobs])) if nj else (None, None, None, None, None)
+        # ... and so does a bias assembly the model deferred (ops.bias_fwd_deferral)
+        bjob = ops.take_bias_fwd_job()
+        bias = [1] + bjob[0] if bjob is not None else [0] + [None] * 10 + [0] * 9 + [0, 0, 0, 0]
         _lib.check(_lib.lib().mobgt_small_gcn_fwd_pack(_p(ax), _p(a), *[_p(w) for w in ws], _p(h1), _p(t), _p(h2), _p(t2), _p(out),
                                                        _p(counter), n, K0, H1, H2, H3, slope, p_drop, seed, _p(seed_dev), salt,
-                                                       nj, *pack, _stream()), "mobgt_small_gcn_fwd_pack")
+                                                       nj, *pack, *bias, _stream()), "mobgt_small_gcn_fwd_pack")
         ctx.save_for_backward(ax, a_t, ws[2], ws[4], keep)
         ctx.misc = (slope, p_drop, seed, seed_dev, salt, n, K0, H1, H2, H3)
         ctx.sinks = [ops.grad_sink(w) for w in (w0, b0, w1, b1, w2, b2)]

@@ -341,6 +341,7 @@ class Graphormer(nn.Module):
         ops.trace_nan("poidist", poidist)
         catemb = self.poi_cat_model(self.C_X, self.C_A, self.C_AX, adj_t=self.C_A_T)                                    # :1237
         flush_pending_pack()                    # (if the one-launch GCN did not take the deferred weight pack along)
+        ops.flush_bias_fwd()                    # (... or the deferred bias assembly)
         Wp, Wt, Wc, C = poidist.shape[1], self.time_embed_model_48.weight.shape[1], catemb.shape[1], self.pos_embed.pe.shape[1]
         f4 = self.embed_fuse_model4
         one_launch = G * N <= 4096
@@ -425,7 +426,12 @@ class Graphormer(nn.Module):
 
     def forward(self, batched_data, perturb=None):
         self.validate_batch(batched_data)
-        bias = self.assemble_bias(batched_data)
+        # (the bias assembly and, below, the weight pack ride in the category GCN's forward launch: node_features flushes both)
+        ops.bias_fwd_deferral(True)
+        try:
+            bias = self.assemble_bias(batched_data)
+        finally:
+            ops.bias_fwd_deferral(False)
         # (the MFMA-order pack of the layer weights rides in the category GCN's forward launch: node_features flushes it)
         refresh_shadows(self.layers, defer_pack=True)
         output = self.node_features(batched_data)

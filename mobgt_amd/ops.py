@@ -204,6 +204,28 @@ def pack_bias(attn_bias, G, H, T, dtype=None):
 _BIAS_BWD_JOB = {}
 
 
+# ... and the bias ASSEMBLY can ride in the category GCN's FORWARD launch (mobgt_small_gcn_fwd_pack): a model that will call the
+# one-launch GCN before anything reads the packed bias switches the deferral on around its assemble_bias (bias_fwd_deferral), and
+# calls flush_bias_fwd() in front of the first consumer.  OPT-IN (MOBGT_BIAS_FWD_PASSENGER=1): that launch already carries the
+# weight pack, and with both the passengers outlast the network -- 36.2 us for 27.4 + 7.0 (measured).
+_BIAS_FWD_DEFER = {"on": False, "job": None}
+
+
+def bias_fwd_deferral(on):
+    _BIAS_FWD_DEFER["on"] = bool(on)
+
+
+def take_bias_fwd_job():
+    job, _BIAS_FWD_DEFER["job"] = _BIAS_FWD_DEFER["job"], None
+    return job
+
+
+def flush_bias_fwd():
+    job = take_bias_fwd_job()
+    if job is not None:
+        check(_lib.lib().mobgt_build_bias(*job[0], _stream()), "mobgt_build_bias")
+
+
 def _bias_bwd_alloc(shapes, dev):
     rs, ps, hs, vs = shapes
     return (zeros_f32(rs, dev), zeros_f32(ps, dev) if ps is not None else None, zeros_f32(hs, dev) if hs is not None else None,
@@ -251,10 +273,16 @@ class _BuildBiasFn(torch.autograd.Function):
         n_poi = poi_table.shape[0] if poi_table is not None else 0
         n_edge = hop_table.shape[1] if has_edge else 0
         args = (G, N, H, D_in, D if has_edge else 0, F, rel_table.shape[0], n_poi, n_edge, pack.ld, idx_dt, edge_dt)
-        check(_lib.lib().mobgt_build_bias(_p(attn_bias), _p(rel_pos), _p(poi_pos), _p(edge_input if has_edge else None),
-                                          _p(rel_table), _p(poi_table), _p(hop_table if has_edge else None), _p(vdist),
-                                          _p(pack.bias), _p(pack.bias_t), *args, _DT[pack.dtype], _stream()),
-              "mobgt_build_bias")
+        fwd_args = [_p(attn_bias), _p(rel_pos), _p(poi_pos), _p(edge_input if has_edge else None), _p(rel_table), _p(poi_table),
+                    _p(hop_table if has_edge else None), _p(vdist), _p(pack.bias), _p(pack.bias_t), *args, _DT[pack.dtype]]
+        flush_bias_fwd()                           # (a deferred assembly nobody picked up)
+        if (_BIAS_FWD_DEFER["on"] and idx_dt == I16 and edge_dt == U8 and pack.dtype == torch.bfloat16 and H == 8
+                and G * (N + 1) * (N + 1) < (1 << 20) and os.environ.get("MOBGT_BIAS_FWD_PASSENGER") == "1"):
+            # left for the category GCN's forward launch to carry (take_bias_fwd_job); the tensors behind the pointers are kept alive
+            _BIAS_FWD_DEFER["job"] = (fwd_args, (attn_bias, rel_pos, poi_pos, edge_input, rel_table, poi_table, hop_table, vdist, pack.bias,
+                                                 pack.bias_t))
+        else:
+            check(_lib.lib().mobgt_build_bias(*fwd_args, _stream()), "mobgt_build_bias")
         ctx.pack, ctx.args = pack, args
         ctx.set_materialize_grads(False)          # the token carries no gradient: no zero-fill launch to materialise one
         ctx.idx = (attn_bias, rel_pos, poi_pos, edge_input if has_edge else None)

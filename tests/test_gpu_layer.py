@@ -786,7 +786,7 @@ def test_weight_pack_as_passenger_of_the_category_gcn_launch_equals_the_pack_lau
         nj, src, dst, N, K, T = arrays(dsts)
         if with_pack:
             _lib.check(lib.mobgt_small_gcn_fwd_pack(_p(AX), _p(A), *[_p(w) for w in ws], *[_p(o) for o in outs], _p(counter), n, K0, H1, H2,
-                                                    H3, 0.2, 0.3, 5, None, 7, nj, src, dst, N, K, T, _stream()), "fwd_pack")
+                                                    H3, 0.2, 0.3, 5, None, 7, nj, src, dst, N, K, T, 0, *([None] * 10), *([0] * 13), _stream()), "fwd_pack")
         else:
             _lib.check(lib.mobgt_pack_mfma_b(nj, src, dst, N, K, T, _stream()), "pack")
             _lib.check(lib.mobgt_small_gcn_fwd(_p(AX), _p(A), *[_p(w) for w in ws], *[_p(o) for o in outs], _p(counter), n, K0, H1, H2, H3,

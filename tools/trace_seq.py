@@ -3,7 +3,7 @@ import csv, sys, glob
 path = sys.argv[1]
 rows = list(csv.DictReader(open(path)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-idx = [i for i, r in enumerate(rows) if "build_bias_kernel" in r["Kernel_Name"]]
+idx = [i for i, r in enumerate(rows) if "step_prologue_kernel" in r["Kernel_Name"]]       # (the first launch of a step)
 k = int(sys.argv[2]) if len(sys.argv) > 2 else -4
 a, b = idx[k], idx[k + 1]
 # rotate so the step starts at its first kernel (the one after adamw)

@@ -4,7 +4,7 @@ import csv, sys, collections, glob
 path = sys.argv[1] if len(sys.argv) > 1 else glob.glob("gpurun_out/prof*/runc/*_kernel_trace.csv")[-1]
 rows = list(csv.DictReader(open(path)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-idx = [i for i, r in enumerate(rows) if "build_bias_kernel" in r["Kernel_Name"]]
+idx = [i for i, r in enumerate(rows) if "step_prologue_kernel" in r["Kernel_Name"]]       # (the first launch of a step)
 k = int(sys.argv[2]) if len(sys.argv) > 2 else -4
 a, b = idx[k], idx[k + 1]
 seg = rows[a:b]
