@@ -28,7 +28,7 @@ from . import ops
 from .lr import PolynomialDecayLR
 from .model import (FeedForwardNetwork, MultiHeadAttention, hop_table_from, no_grad_row0, fused_layer_forward,
                     refresh_shadows, flush_pending_pack)
-from .modelGNN import GCN
+from .modelGNN import GCN, prelaunch_small_gcn
 
 node_dim = 2000          # model_fqandtoyo.py:567
 
@@ -434,6 +434,8 @@ class Graphormer(nn.Module):
             ops.bias_fwd_deferral(False)
         # (the MFMA-order pack of the layer weights rides in the category GCN's forward launch: node_features flushes it)
         refresh_shadows(self.layers, defer_pack=True)
+        # the category GCN (weights only: no batch input) starts now on a side stream, beside the distance GCN's launches
+        prelaunch_small_gcn(self.poi_cat_model, self.C_X, self.C_A, self.C_AX, self.C_A_T)
         output = self.node_features(batched_data)
         ops.trace_nan("x0", output)
         for li, enc_layer in enumerate(self.layers):                                           # :1347-1352
