@@ -17,7 +17,7 @@ import torch.nn.functional as F
 from torch.nn import Parameter
 
 
-def mm_tn_splitk(x, g, max_chunks=32, bf16_operands=False):
+def mm_tn_splitk(x, g, max_chunks=32, bf16_operands=False, dw=None):
     """x^T @ g for tall-skinny x [P,a], g [P,b] (P >> a,b): split the long K axis over a batch dimension.
     `bf16_operands` (the bf16 configuration): the split-K MFMA kernel of csrc/wgrad.hip instead, f32 operands rounded
     to bf16 while loading, f32 accumulate (21 us + a reduce -> ~8 us for the [64 x 7856] x [7856 x 192] case)."""
@@ -25,7 +25,7 @@ def mm_tn_splitk(x, g, max_chunks=32, bf16_operands=False):
             and g.shape[1] % 2 == 0 and x.is_contiguous() and g.is_contiguous()
             and x.data_ptr() % 8 == 0 and g.data_ptr() % 8 == 0):
         from . import ops
-        return ops.linear_wgrad(x, g, leaf=True)[0]
+        return ops.linear_wgrad(x, g, leaf=True, dw=dw)[0]
     P = x.shape[0]
     s = max((c for c in range(1, max_chunks + 1) if P % c == 0), default=1)
     if s == 1 or P < 2048:
@@ -114,6 +114,7 @@ class _RowsConvFn(torch.autograd.Function):
         out = ops.linear_wgrad(a_rows_t, support, out_bias=bias)[0]    # [R,C] f32 (+ bias, inside the kernel)
         ctx.save_for_backward(x, weight, a_rows)
         ctx.has_bias = bias is not None
+        ctx.sinks = (ops.grad_sink(weight), ops.grad_sink(bias) if bias is not None else None)
         return out
 
     @staticmethod
@@ -128,13 +129,13 @@ class _RowsConvFn(torch.autograd.Function):
         if g.dtype == torch.float32 and C % 2 == 0 and g.data_ptr() % 8 == 0:
             # the f32 gradient as it arrives: rounded to bf16 while loading, bias gradient = its column sums, one launch
             d_support = ops.zeros_f32((P, C), g.device)
-            db = ops.zeros_f32((C,), g.device) if ctx.has_bias else None
+            db = (ctx.sinks[1][:] if ctx.sinks[1] is not None else ops.zeros_f32((C,), g.device)) if ctx.has_bias else None
             _lib.check(_lib.lib().mobgt_linear_wgrad_mixed(_p(a_rows), a_rows.stride(0), _p(g), g.stride(0), _p(d_support), C,
                                                            _p(db), R, P, C, _stream()), "mobgt_linear_wgrad_mixed")
         else:
             d_support = ops.linear_wgrad(a_rows, g.to(torch.bfloat16).contiguous())[0]      # [P,C] f32
             db = _colsum(g) if ctx.has_bias else None
-        dW = mm_tn_splitk(x, d_support, bf16_operands=True)
+        dW = mm_tn_splitk(x, d_support, bf16_operands=True, dw=ctx.sinks[0][:] if ctx.sinks[0] is not None else None)
         dx = _mm_small(d_support, weight, True) if ctx.needs_input_grad[0] else None
         return dx, dW, db, None, None
 
@@ -261,6 +262,7 @@ class _ConvActFn(torch.autograd.Function):
         ctx.save_for_backward(t, weight, y)
         ctx.adj = adj if ax is None else None
         ctx.mv = ops.act_mask_values(slope, p_drop)
+        ctx.sinks = (ops.grad_sink(weight), ops.grad_sink(bias) if bias is not None else None)
         return y
 
     @staticmethod
@@ -268,8 +270,15 @@ class _ConvActFn(torch.autograd.Function):
         from . import ops
         t, weight, y = ctx.saved_tensors
         g = g.contiguous()
-        db = ops.zeros_f32((weight.shape[1],), g.device)
-        dW = ops.linear_wgrad_masked(t, g, x_mask=y, mask_vals=ctx.mv, db=db, db_of_x=True, leaf=True)   # t^T (g * m(y)), db = colsum
+        k_w, k_b = ctx.sinks
+        db = k_b[:] if k_b is not None else ops.zeros_f32((weight.shape[1],), g.device)
+        dw_dst = None
+        extra = (t.shape[1] - weight.shape[0]) * weight.shape[1]
+        if k_w is not None and k_w.is_contiguous() and 0 <= extra <= 16:
+            # the parameter's gradient sink, seen with the rows of the zero padding (their zero products land in the slack that
+            # train.flat_offsets leaves behind every slot)
+            dw_dst = torch.as_strided(k_w, (t.shape[1], weight.shape[1]), (weight.shape[1], 1))
+        dW = ops.linear_wgrad_masked(t, g, x_mask=y, mask_vals=ctx.mv, db=db, db_of_x=True, leaf=True, dw=dw_dst)   # t^T (g * m(y)), db = colsum
         dW = dW[:weight.shape[0]]                                                                # (rows of the zero padding)
         db = db[:]                                                                               # (a fresh view: see ops.wgrad_deferral)
         dx = None
@@ -342,6 +351,8 @@ class _SpConvFn(torch.autograd.Function):
         out = spmm(adj, support, bias, rows)
         ctx.save_for_backward(x, weight)
         ctx.adj, ctx.rows, ctx.has_bias = adj, rows, bias is not None
+        from . import ops
+        ctx.sinks = (ops.grad_sink(weight), None)
         return out
 
     @staticmethod
@@ -370,7 +381,7 @@ class _SpConvFn(torch.autograd.Function):
             _lib.check(_lib.lib().mobgt_spmm_csr_t_rows(_p(adj.rowptr), _p(adj.col), _p(adj.val), _p(rows), _p(g), g.stride(0),
                                                         _p(d_support), d_support.stride(0), rows.numel(), g.shape[1],
                                                         _stream()), "mobgt_spmm_csr_t_rows")
-        dW = mm_tn_splitk(x, d_support, bf16_operands=True)
+        dW = mm_tn_splitk(x, d_support, bf16_operands=True, dw=ctx.sinks[0][:] if ctx.sinks[0] is not None else None)
         dx = _mm_small(d_support, weight, True) if ctx.needs_input_grad[0] else None
         db = _colsum(g) if ctx.has_bias else None
         return dx, dW, db, None, None

@@ -228,7 +228,8 @@ class Graphormer(nn.Module):
             if packed is not None and d_ax.shape[1] % 16:
                 # bitmask configuration: A X zero-padded to whole 16-deep k-steps (303 -> 304 columns) for the first
                 # GraphConvolution's GEMM + activation node (modelGNN._ConvActFn); GCN.forward slices it for any other path
-                d_ax = torch.nn.functional.pad(d_ax, (0, 16 - d_ax.shape[1] % 16))
+                self._d_ax_pad = 16 - d_ax.shape[1] % 16
+                d_ax = torch.nn.functional.pad(d_ax, (0, self._d_ax_pad))
             self.register_buffer("D_AX", d_ax.contiguous(), persistent=False)
             for name, t in zip(("D_mask", "D_mask_t", "D_scale"), packed if packed is not None else (None, None, None)):
                 self.register_buffer(name, t, persistent=False)
@@ -250,6 +251,11 @@ class Graphormer(nn.Module):
         self.time_embed_dim = self.cat_embed_dim = 32
         self.num_users = 937 if dataset_name == "gowalla_7day" else 1080
         self.poi_distance_model = GCN(ninput=self.gcn_nfeat, nhid=self.gcn_nhid, noutput=hidden_dim, dropout=0.3)
+        if getattr(self, "_d_ax_pad", 0):
+            # the first layer's weight gradient is computed with the rows of zero products of the padded A X: room for them behind
+            # the gradient's slot in a trainer's flat buffer (train.flat_offsets)
+            w0 = self.poi_distance_model.gcn[0].weight
+            w0._mobgt_flat_slack = self._d_ax_pad * w0.shape[1]
         self.poi_cat_model = GCN(ninput=C_X.shape[1], nhid=self.gcn_nhid, noutput=self.cat_embed_dim, dropout=0.1)
         self.user_embed_model = UserEmbeddings(self.num_users, self.user_embed_dim)
         self.time_embed_model_48 = nn.Embedding(48 + 1 if fsq else 48, self.time_embed_dim, padding_idx=0)

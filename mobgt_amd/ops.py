@@ -226,10 +226,11 @@ def flush_bias_fwd():
         check(_lib.lib().mobgt_build_bias(*job[0], _stream()), "mobgt_build_bias")
 
 
-def _bias_bwd_alloc(shapes, dev):
-    rs, ps, hs, vs = shapes
-    return (zeros_f32(rs, dev), zeros_f32(ps, dev) if ps is not None else None, zeros_f32(hs, dev) if hs is not None else None,
-            zeros_f32(vs, dev))
+def _bias_bwd_alloc(shapes, dev, sinks=(None, None, None, None)):
+    """Destinations of the four table gradients (accumulated into): the parameters' gradient sinks where the trainer registered
+    them (fresh views), else zeros."""
+    return tuple(None if sh is None else (k[:] if (k is not None and tuple(k.shape) == tuple(sh)) else zeros_f32(sh, dev))
+                 for sh, k in zip(shapes, sinks))
 
 
 def take_bias_bwd_job():
@@ -251,7 +252,7 @@ def take_bias_bwd_job():
 def bias_bwd_job_args(job):
     """-> (outputs, ctypes-ready argument list of mobgt_build_bias_bwd without the stream)."""
     pack = job["pack"]()
-    outs = _bias_bwd_alloc(job["shapes"], pack.bias.device)
+    outs = _bias_bwd_alloc(job["shapes"], pack.bias.device, job.get("sinks", (None,) * 4))
     attn_bias, rel_pos, poi_pos, edge_input = job["idx"]
     n_sl = max(pack.n_bwd, 1) if pack.sliced else 1
     stride = pack.dbias.stride(0) if pack.sliced else 0
@@ -262,7 +263,7 @@ def bias_bwd_job_args(job):
 
 class _BuildBiasFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, rel_table, poi_table, hop_table, vdist, pack, attn_bias, rel_pos, poi_pos, edge_input, D):
+    def forward(ctx, rel_table, poi_table, hop_table, vdist, pack, attn_bias, rel_pos, poi_pos, edge_input, D, sinks=(None,) * 4):
         G, N = rel_pos.shape[:2]
         H = rel_table.shape[1]
         has_edge = edge_input is not None and D > 0
@@ -290,7 +291,7 @@ class _BuildBiasFn(torch.autograd.Function):
                       hop_table.shape if has_edge else None, vdist.shape)
         import weakref
         # (weak: the pack's token belongs to this forward pass's autograd graph, which must not outlive its backward)
-        ctx.job = dict(pack=weakref.ref(pack), args=args, idx=ctx.idx, shapes=ctx.shapes, done=None)
+        ctx.job = dict(pack=weakref.ref(pack), args=args, idx=ctx.idx, shapes=ctx.shapes, done=None, sinks=sinks)
         _BIAS_BWD_JOB.pop("cur", None)
         if pack.needs_grad:                        # (build_bias() looked at the grad mode: it is off inside Function.forward)
             _BIAS_BWD_JOB["cur"] = ctx.job
@@ -303,10 +304,10 @@ class _BuildBiasFn(torch.autograd.Function):
         if ctx.job["done"] is not None:            # computed by the passengers of the category GCN's backward launch
             d_rel, d_poi, d_hop, d_vd = ctx.job["done"]
             ctx.job["done"] = None
-            return d_rel, d_poi, d_hop, d_vd, None, None, None, None, None, None
+            return d_rel, d_poi, d_hop, d_vd, None, None, None, None, None, None, None
         if _BIAS_BWD_JOB.get("cur") is ctx.job:
             del _BIAS_BWD_JOB["cur"]
-        d_rel, d_poi, d_hop, d_vd = _bias_bwd_alloc(ctx.shapes, dev)
+        d_rel, d_poi, d_hop, d_vd = _bias_bwd_alloc(ctx.shapes, dev, ctx.job.get("sinks", (None,) * 4))
         if pack.dbias is not None:
             attn_bias, rel_pos, poi_pos, edge_input = ctx.idx
             a = ctx.args
@@ -316,7 +317,7 @@ class _BuildBiasFn(torch.autograd.Function):
                                                   _p(attn_bias), _p(rel_pos), _p(poi_pos), _p(edge_input),
                                                   _p(d_rel), _p(d_poi), _p(d_hop), _p(d_vd), *a, _stream()),
                   "mobgt_build_bias_bwd")
-        return d_rel, d_poi, d_hop, d_vd, None, None, None, None, None, None
+        return d_rel, d_poi, d_hop, d_vd, None, None, None, None, None, None, None
 
 
 def build_bias(attn_bias, rel_pos, poi_pos, edge_input, rel_table, poi_table, hop_table, vdist, D, dtype=torch.float32):
@@ -329,9 +330,13 @@ def build_bias(attn_bias, rel_pos, poi_pos, edge_input, rel_table, poi_table, ho
     pack.needs_grad = torch.is_grad_enabled() and any(
         t is not None and t.requires_grad for t in (rel_table, poi_table, hop_table, vdist))
     f = lambda t: None if t is None else t.contiguous()
+    # gradient sinks of the tables that are trained parameters (looked up on the parameter objects themselves)
+    k_vd = grad_sink(vdist)
+    sinks = (grad_sink(rel_table), grad_sink(poi_table) if poi_table is not None else None, None,
+             k_vd.view(-1) if (k_vd is not None and k_vd.is_contiguous()) else None)
     pack.token = _BuildBiasFn.apply(f(rel_table.float()), f(None if poi_table is None else poi_table.float()),
                                     f(None if hop_table is None else hop_table.float()), f(vdist.float().reshape(-1)),
-                                    pack, f(attn_bias.float()), f(rel_pos), f(poi_pos), f(edge_input), int(D))
+                                    pack, f(attn_bias.float()), f(rel_pos), f(poi_pos), f(edge_input), int(D), sinks)
     return pack
 
 
@@ -507,6 +512,7 @@ class _HopTableFn(torch.autograd.Function):
               "mobgt_hop_table_fwd")
         ctx.save_for_backward(ew, dw)
         ctx.misc = (H, D, int(fp16_roundtrip), edge_dis_weight.shape)
+        ctx.sinks = (grad_sink(edge_weight), grad_sink(edge_dis_weight))
         return tab
 
     @staticmethod
@@ -514,8 +520,9 @@ class _HopTableFn(torch.autograd.Function):
         ew, dw = ctx.saved_tensors
         H, D, rt, dis_shape = ctx.misc
         E = ew.shape[0]
-        d_ew = torch.empty_like(ew)
-        d_dw = zeros_f32(tuple(dis_shape), ew.device)            # rows of hop slots >= D get no gradient
+        k_e, k_d = ctx.sinks
+        d_ew = k_e[:] if k_e is not None else torch.empty_like(ew)          # (written in full)
+        d_dw = k_d[:] if k_d is not None else zeros_f32(tuple(dis_shape), ew.device)     # rows of hop slots >= D get no gradient
         check(_lib.lib().mobgt_hop_table_bwd(_p(dtab.contiguous()), _p(ew), _p(dw), _p(d_ew), _p(d_dw), D, E, H, rt,
                                              _stream()), "mobgt_hop_table_bwd")
         return d_ew, d_dw, None, None, None
@@ -551,6 +558,7 @@ class _SkinnyLinearFn(torch.autograd.Function):
         ctx.save_for_backward(x, w)
         ctx.has_bias = bias is not None
         ctx.sink = grad_sink(weight)
+        ctx.sink_b = grad_sink(bias) if bias is not None else None
         return y
 
     @staticmethod
@@ -571,7 +579,9 @@ class _SkinnyLinearFn(torch.autograd.Function):
         dw = None
         if ctx.needs_input_grad[1]:
             dw = ctx.sink[:] if ctx.sink is not None else torch.empty_like(w)      # (a fresh view object of the sink)
-        db = torch.empty(V, dtype=torch.float32, device=x.device) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+        db = None
+        if ctx.has_bias and ctx.needs_input_grad[2]:      # (written in full by the kernel: the sink needs no zeroing for it)
+            db = ctx.sink_b[:] if ctx.sink_b is not None else torch.empty(V, dtype=torch.float32, device=x.device)
         if both:        # dx and dW (+ db) share nothing but dy: one launch, the first workgroups run the dx body
             check(_lib.lib().mobgt_skinny_linear_bwd_both(_p(dy), _p(x), _p(w), _p(dx), _p(dw), _p(db), G, K, V, _stream()),
                   "mobgt_skinny_linear_bwd_both")
@@ -716,6 +726,7 @@ class _GatherMultiFn(torch.autograd.Function):
         ctx.idx, ctx.spec, ctx.n = idx, spec, n
         ctx.ptrs = [t.data_ptr() for t in tables]
         ctx.shapes = [t.shape for t in tables]
+        ctx.sinks = [grad_sink(t) for t in tables]          # (a table that is a trained parameter: its slice of the flat gradient)
         return tuple(outs)
 
     @staticmethod
@@ -728,8 +739,8 @@ class _GatherMultiFn(torch.autograd.Function):
             if g is not None and (g.stride(1) != 1 or g.stride(0) % 4 or g.data_ptr() % 16 or g.dtype != torch.float32):
                 g = g.float().contiguous()
             gbuf.append(g)
-        grads = [zeros_f32(tuple(sh), dev) if (ctx.needs_input_grad[3 + t] and gbuf[spec[t][0]] is not None) else None
-                 for t, sh in enumerate(ctx.shapes)]
+        grads = [(ctx.sinks[t][:] if ctx.sinks[t] is not None else zeros_f32(tuple(sh), dev))
+                 if (ctx.needs_input_grad[3 + t] and gbuf[spec[t][0]] is not None) else None for t, sh in enumerate(ctx.shapes)]
         jobs = [t for t in range(n) if grads[t] is not None]
         if jobs:
             m = len(jobs)
@@ -902,11 +913,16 @@ class _LinearSplitKFn(torch.autograd.Function):
             if slope is not None:
                 y = torch.nn.functional.leaky_relu(y, slope)
         ctx.save_for_backward(x, w, y if slope is not None else None)
+        ctx.sinks = (grad_sink(w), grad_sink(b) if b is not None else None)
         return y
 
     @staticmethod
     def backward(ctx, g):
         x, w, y = ctx.saved_tensors
+        k_w, k_b = ctx.sinks
+
+        def dst(sink, shape):           # a fresh view of the parameter's gradient sink, or zeros
+            return sink[:] if sink is not None else zeros_f32(shape, g.device)
         if y is None or y.is_contiguous():
             g = g.contiguous()                  # (else: a strided gradient goes straight into leaky_relu_backward below)
         R = x.shape[0]
@@ -918,8 +934,8 @@ class _LinearSplitKFn(torch.autograd.Function):
             # than the library GEMM + one elementwise launch -- measured 10.4 vs 9.6 us at R = 608)
             if (hip_wgrad and R <= 64 and small_gemm_ok(g, w) and y.is_contiguous() and y.data_ptr() % 8 == 0
                     and max(w.shape) <= 512):
-                db = zeros_f32((g.shape[1],), g.device)
-                dw = linear_wgrad_masked(g, x, g_mask=y, mask_vals=mv, db=db, leaf=True)
+                db = dst(k_b, (g.shape[1],))
+                dw = linear_wgrad_masked(g, x, g_mask=y, mask_vals=mv, db=db, leaf=True, dw=dst(k_w, tuple(w.shape)))
                 dx = _token_park_linear(g, w, y) if _WGRAD_DEFER["on"] else None
                 return (dx if dx is not None else small_gemm(g, w, a_mask=(y, *mv))), dw, (db[:] if _WGRAD_DEFER["on"] else db), None, None, None
             if (_WGRAD_DEFER["on"] and hip_wgrad and g.stride(1) == 1 and y.stride() == g.stride() and g.data_ptr() % 8 == 0
@@ -927,8 +943,8 @@ class _LinearSplitKFn(torch.autograd.Function):
                     and max(w.shape) <= 512):
                 # trainer's backward: the weight gradient is a leaf and joins the step's one grouped launch; the data gradient
                 # then applies the activation's derivative itself while it loads g (no masked copy of g exists)
-                db = zeros_f32((g.shape[1],), g.device)
-                dw = linear_wgrad_masked(g, x, g_mask=y, mask_vals=mv, db=db, leaf=True)
+                db = dst(k_b, (g.shape[1],))
+                dw = linear_wgrad_masked(g, x, g_mask=y, mask_vals=mv, db=db, leaf=True, dw=dst(k_w, tuple(w.shape)))
                 dx = _token_park_linear(g, w, y)               # (a parked encoder-input chain: see register_token_chain)
                 return (dx if dx is not None else small_gemm(g, w, a_mask=(y, *mv))), dw, db[:], None, None, None
             if (hip_wgrad and g.stride(1) == 1 and y.stride() == g.stride() and g.data_ptr() % 8 == 0 and y.data_ptr() % 8 == 0
@@ -945,7 +961,7 @@ class _LinearSplitKFn(torch.autograd.Function):
         if hip_wgrad:
             # bf16 configuration: weight AND bias gradient from the split-K MFMA kernel (operands rounded to bf16 while
             # loading); the library's split-K path took 27-31 us + a reduce for these 224-wide layers
-            dw, db = linear_wgrad(g, x, with_bias=True, leaf=True)
+            dw, db = linear_wgrad(g, x, with_bias=True, leaf=True, dw=dst(k_w, tuple(w.shape)), db=dst(k_b, (g.shape[1],)))
             return (small_gemm(g, w) if _small_linear(g, w) & 2 else g @ w), dw, db, None, None, None
         s = max((c for c in (16, 8, 4, 2) if R % c == 0 and R // c >= 16), default=1)
         if s > 1:
@@ -1125,6 +1141,7 @@ class _HeadChainFn(torch.autograd.Function):
         ctx.user = user
         ctx.misc = (G, T, C, U, offset, tuple(table.shape), eps, slope, p_drop, seed, seed_dev, salt, bf16_wgrad)
         ctx.sink = grad_sink(table)
+        ctx.psinks = (grad_sink(w3), grad_sink(b3), grad_sink(ln_w), grad_sink(ln_b))
         return out
 
     @staticmethod
@@ -1136,13 +1153,16 @@ class _HeadChainFn(torch.autograd.Function):
         du3 = torch.empty_like(u3)
         denc = torch.empty(G, T, C, dtype=torch.float32, device=dev)
         dtable = ctx.sink[:] if ctx.sink is not None else zeros_f32(tshape, dev)
-        dg, dbeta = zeros_f32((C + U,), dev), zeros_f32((C + U,), dev)
+        k_w3, k_b3, k_g, k_beta = ctx.psinks
+        dg = k_g[:] if k_g is not None else zeros_f32((C + U,), dev)
+        dbeta = k_beta[:] if k_beta is not None else zeros_f32((C + U,), dev)
         check(_lib.lib().mobgt_head_chain_bwd(_p(dout), _p(u3), _p(stats[0]), _p(stats[1]), _p(ctx.user), _IT[ctx.user.dtype], offset,
                                               tshape[0], _p(w3), _p(ln_w), _p(ln_b), _p(du3), _p(denc), _p(dtable), _p(dg), _p(dbeta),
                                               G, T, C, U, eps, slope, p_drop, seed, _p(seed_dev), salt, _stream()),
               "mobgt_head_chain_bwd")
-        if bf16_wgrad:
-            dw, db = linear_wgrad(du3, x3, with_bias=True, leaf=True)      # (operands rounded to bf16 while loading)
+        if bf16_wgrad:                                                     # (operands rounded to bf16 while loading)
+            dw, db = linear_wgrad(du3, x3, with_bias=True, leaf=True, dw=k_w3[:] if k_w3 is not None else None,
+                                  db=k_b3[:] if k_b3 is not None else None)
         else:
             dw, db = du3.t() @ x3, colsum(du3)
         return denc, dtable, None, None, dw, db, dg, dbeta, None, None, None, None, None, None, None
@@ -1220,7 +1240,8 @@ def head_input(enc, user_table, user, user_offset=0):
 
 class _AssembleTokensFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, nf, real, add, token, pe0, p_pos, p_in, seed, seed_dev, salts, side, row0_via_gather=False, qkv_w=None):
+    def forward(ctx, nf, real, add, token, pe0, p_pos, p_in, seed, seed_dev, salts, side, row0_via_gather=False, qkv_w=None, tok_sink=None):
+        ctx.tok_sink = tok_sink
         ctx.pe_ptr = pe0.data_ptr() if (row0_via_gather and pe0.dim() == 2 and pe0.shape[0] > 1) else None
         ctx.nf_ptr = nf.data_ptr()
         G, N, C = nf.shape
@@ -1259,8 +1280,9 @@ class _AssembleTokensFn(torch.autograd.Function):
         dout = dout.contiguous()
         d_nf = torch.empty(G, N, C, dtype=torch.float32, device=dout.device)
         d_add = torch.empty(G, N, C, dtype=torch.float32, device=dout.device)
+        k_tok = ctx.tok_sink
         if ctx.pe_ptr is not None:
-            d_tok = zeros_f32((C,), dout.device)
+            d_tok = k_tok.view(-1)[:] if (k_tok is not None and k_tok.numel() == C) else zeros_f32((C,), dout.device)
             d_pe = None
         elif len(pshape) == 2 and pshape[0] > 1:
             d_pe = zeros_f32(tuple(pshape), dout.device)
@@ -1282,8 +1304,8 @@ class _AssembleTokensFn(torch.autograd.Function):
             # the positional table's other consumer (the gather of pe[1..n]) adds this row-0 share inside ITS scatter launch:
             # one gradient producer for the table, no [L, C] zero table here and no table-sized add after
             _ROW0_PENDING[ctx.pe_ptr] = d_tok
-            return d_nf, None, d_add, d_tok.view(tshape), None, None, None, None, None, None, None, None, None
-        return d_nf, None, d_add, d_tok.view(tshape), d_pe, None, None, None, None, None, None, None, None
+            return d_nf, None, d_add, d_tok.view(tshape), None, None, None, None, None, None, None, None, None, None
+        return d_nf, None, d_add, d_tok.view(tshape), d_pe, None, None, None, None, None, None, None, None, None
 
 
 def assemble_tokens(nf, real, add, token, pe0, p_pos, p_in, training, salts=(0x1001, 0x1002, 0x1003), bf16_copy=False,
@@ -1305,7 +1327,8 @@ def assemble_tokens(nf, real, add, token, pe0, p_pos, p_in, training, salts=(0x1
     out = _AssembleTokensFn.apply(nf.float(), real.float(), add.float(), token.float(), pe0.float(), float(p_pos),
                                   float(p_in), int(seed), seed_dev, tuple(int(s) & 0xFFFFFFFF for s in salts), side,
                                   bool(pe_row0_via_gather and pe0.requires_grad and torch.is_grad_enabled()),
-                                  (_OutRef(first_qkv[0]), _OutRef(first_qkv[1])) if (first_qkv is not None and bf16_copy) else None)
+                                  (_OutRef(first_qkv[0]), _OutRef(first_qkv[1])) if (first_qkv is not None and bf16_copy) else None,
+                                  grad_sink(token) if token.is_contiguous() else None)
     if side:
         out._mobgt_act = side[0]          # bf16 copy for the first fused layer's QKV GEMM (no cast launch)
         if len(side) > 1:
@@ -1516,7 +1539,7 @@ def nan_trace_report():
     return [(n, bool(f[i])) for i, n in enumerate(_NAN_TRACE["names"])]
 
 
-def linear_wgrad(g, x, with_bias=False, db=None, out_bias=None, leaf=False):
+def linear_wgrad(g, x, with_bias=False, db=None, out_bias=None, leaf=False, dw=None):
     """(dW, db) of y = x W^T + b from g = dL/dy: dW [M,N] = g^T x (f32) and db [M] = g.sum(0) (f32, or None),
     for bf16 row-major g [R,M], x [R,N] (row strides may exceed the width: column slices are fine).
     `db`: an existing zero-initialised f32 [M] to accumulate the bias gradient into.
@@ -1525,7 +1548,8 @@ def linear_wgrad(g, x, with_bias=False, db=None, out_bias=None, leaf=False):
     R, M = g.shape
     N = x.shape[1]
     assert g.dtype == x.dtype and g.dtype in (torch.bfloat16, torch.float32) and g.stride(1) == 1 and x.stride(1) == 1
-    dw = zeros_f32((M, N), g.device)
+    if dw is None:                    # (`dw` / `db`: zeroed f32 destinations the products are ADDED to -- e.g. gradient sinks)
+        dw = zeros_f32((M, N), g.device)
     if out_bias is not None:
         assert db is None and not with_bias and out_bias.dtype == torch.float32 and out_bias.numel() == N
         check(_lib.lib().mobgt_linear_wgrad_bias(_p(g), g.stride(0), _p(x), x.stride(0), _p(out_bias.contiguous()), _p(dw), N, R, M, N,

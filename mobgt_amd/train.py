@@ -27,11 +27,15 @@ from .lr import polynomial_decay_lr
 
 def flat_offsets(params, align=8):
     """Element offset of every parameter inside the flat buffers (each slot starts on a multiple of `align` elements,
-    so f32 slices are 32-byte and bf16 shadow slices 16-byte aligned) and the total length."""
+    so f32 slices are 32-byte and bf16 shadow slices 16-byte aligned) and the total length.  A parameter may ask for unused
+    elements behind its slot (`p._mobgt_flat_slack`): a weight-gradient kernel whose operand is zero-padded by a column (the
+    distance GCN's 303-wide first layer as 304 columns) writes one more row of (zero) products than the parameter has, straight
+    into its gradient sink.  (Slack behind EVERY slot would separate q / k / v and the small per-layer gradients, which the fused
+    layers need adjacent.)"""
     offs, off = [], 0
     for p in params:
         offs.append(off)
-        off += (p.numel() + align - 1) // align * align
+        off += (p.numel() + int(getattr(p, "_mobgt_flat_slack", 0)) + align - 1) // align * align
     return offs, off
 
 

@@ -13,7 +13,7 @@ def spy(dst, src):
     for d, s in zip(dst, src):
         tot += d.numel()
     print("foreach_copy: %d tensors, %d elements" % (len(dst), tot))
-    for d in sorted(dst, key=lambda t: -t.numel())[:12]:
+    for d in sorted(dst, key=lambda t: -t.numel())[:40]:
         print("   ", tuple(d.shape), names.get(d.data_ptr(), "?"))
     return orig(dst, src)
 torch._foreach_copy_ = spy
