@@ -370,6 +370,15 @@ int mobgt_linear_wgrad_multi(int n, const void* const* g, const int64_t* ldg, co
                              const float* const* g_mask, const float* const* x_mask, const float* mask_vals,
                              float* const* dw, const int64_t* ldw, float* const* db, const int* db_of_x,
                              const int64_t* R, const int* M, const int* N, const int* in_f32, void* stream);
+/* The same launch carrying the hop table's backward (with_hop != 0: the arguments of mobgt_hop_table_bwd follow, H = 8,
+ * n_edge <= 256, d_table / edge_dis_encoder 16-byte aligned) as extra workgroups: it needs nothing the group produces, and
+ * nothing but the optimizer reads its results.  n may be 0 only with with_hop == 0. */
+int mobgt_linear_wgrad_multi_hop(int n, const void* const* g, const int64_t* ldg, const void* const* x, const int64_t* ldx,
+                                 const float* const* g_mask, const float* const* x_mask, const float* mask_vals, float* const* dw,
+                                 const int64_t* ldw, float* const* db, const int* db_of_x, const int64_t* R, const int* M,
+                                 const int* N, const int* in_f32, int with_hop, const float* d_table, const float* edge_encoder,
+                                 const float* edge_dis_encoder, float* d_edge_encoder, float* d_edge_dis_encoder, int D, int n_edge,
+                                 int fp16_roundtrip, void* stream);
 
 /* End of an encoder layer's backward in ONE launch (R <= 1024 rows): the weight gradients of mobgt_linear_wgrad_group
  * (same arguments) and, side by side with them, the layer's input gradient  c[gM,gN] (f32) += a[gM,gK] x b_kn[gK,gN]

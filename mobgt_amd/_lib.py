@@ -47,6 +47,7 @@ SIGNATURES = {
     "mobgt_colsum": (_i, [_vp, _vp, _i64, _i, _i, _vp]),
     "mobgt_linear_wgrad_group": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _i, _vp]),
     "mobgt_linear_wgrad_multi": (_i, [_i] + [_vp] * 15 + [_vp]),
+    "mobgt_linear_wgrad_multi_hop": (_i, [_i] + [_vp] * 15 + [_i] + [_vp] * 5 + [_i, _i, _i] + [_vp]),
     "mobgt_layer_backward_tail": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _i, _vp, _i64, _vp, _i64, _vp, _i64,
                                        _i, _i, _i, _vp]),
     "mobgt_linear_wgrad": (_i, [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _i, _i, _i, _vp]),

@@ -9,10 +9,11 @@
 // passes it back through one of those `.half()` casts.
 #include "common.h"
 #include "mobgt_hip.h"
+#include "hop_body.h"
 
 namespace {
 
-__device__ __forceinline__ float r16(float v, bool on) { return on ? (float)(_Float16)v : v; }
+using mobgt_hop::r16;
 
 __global__ __launch_bounds__(256) void hop_table_fwd_kernel(const float* __restrict__ enc, const float* __restrict__ w,
                                                             float* __restrict__ tab, int D, int E, int H, int rt) {
@@ -48,44 +49,9 @@ __global__ __launch_bounds__(256) void hop_table_bwd_kernel(const float* __restr
     d_w[j] = r16(acc, rt);
 }
 
-// H = 8 (every MobGT config).  Blocks [0, D): d_w of hop slot d -- g[d] and enc staged in LDS, 4 threads per
-// output each summing a quarter of the edge ids.  Blocks [D, ..): d_enc, one thread per (e, k), the 8 heads of
-// g[d,e,:] and W[d,k,:] as two 16-byte loads each.  (The generic kernel's dependent scalar loads took 30 us.)
-__global__ __launch_bounds__(256) void hop_table_bwd8_kernel(const float* __restrict__ dtab, const float* __restrict__ enc,
-                                                             const float* __restrict__ w, float* __restrict__ d_enc,
-                                                             float* __restrict__ d_w, int D, int E, int rt) {
-    constexpr int H = 8;
+__global__ __launch_bounds__(256) void hop_table_bwd8_kernel(const mobgt_hop::HopBwd p) {
     extern __shared__ __attribute__((aligned(16))) float sm[];        // [E*H] g[d] | [E*H] enc
-    if ((int)blockIdx.x < D) {
-        const int d = blockIdx.x;
-        float* sg = sm;
-        float* se = sm + E * H;
-        for (int t = threadIdx.x; t < E * H; t += 256) { sg[t] = r16(dtab[(int64_t)d * E * H + t], rt); se[t] = r16(enc[t], rt); }
-        __syncthreads();
-        const int o = threadIdx.x >> 2, part = threadIdx.x & 3, k = o >> 3, h = o & 7;       // 64 outputs x 4 parts
-        const int e0 = (E * part) / 4, e1 = (E * (part + 1)) / 4;
-        float acc = 0.f;
-        for (int e = e0; e < e1; ++e) acc += se[e * H + k] * sg[e * H + h];
-        acc += __shfl_xor(acc, 1, 64);
-        acc += __shfl_xor(acc, 2, 64);
-        if (part == 0) d_w[(d * H + k) * H + h] = r16(acc, rt);
-        return;
-    }
-    const int i = ((int)blockIdx.x - D) * 256 + threadIdx.x;
-    if (i >= E * H) return;
-    const int k = i & 7, e = i >> 3;
-    float acc = 0.f;
-    if (e != 0) {
-        for (int d = 0; d < D; ++d) {
-            const float4* g4 = reinterpret_cast<const float4*>(dtab + ((int64_t)d * E + e) * H);
-            const float4* w4 = reinterpret_cast<const float4*>(w + ((int64_t)d * H + k) * H);
-            const float4 ga = g4[0], gb = g4[1], wa = w4[0], wb = w4[1];
-            acc += r16(ga.x, rt) * r16(wa.x, rt) + r16(ga.y, rt) * r16(wa.y, rt) + r16(ga.z, rt) * r16(wa.z, rt) +
-                   r16(ga.w, rt) * r16(wa.w, rt) + r16(gb.x, rt) * r16(wb.x, rt) + r16(gb.y, rt) * r16(wb.y, rt) +
-                   r16(gb.z, rt) * r16(wb.z, rt) + r16(gb.w, rt) * r16(wb.w, rt);
-        }
-    }
-    d_enc[i] = r16(acc, rt);
+    mobgt_hop::hop_table_bwd8_body(p, (int)blockIdx.x, sm);
 }
 
 }  // namespace
@@ -104,10 +70,9 @@ extern "C" int mobgt_hop_table_bwd(const float* d_table, const float* edge_encod
                                    int fp16_roundtrip, void* stream) {
     if (D <= 0 || n_edge <= 0 || H <= 0) return MOBGT_EBADDIM;
     if (H == 8 && n_edge <= 2048 && ((uintptr_t)d_table & 15) == 0 && ((uintptr_t)edge_dis_encoder & 15) == 0) {
-        const int nb = D + (n_edge * 8 + 255) / 256;
-        hipLaunchKernelGGL(hop_table_bwd8_kernel, dim3(nb), dim3(256), (size_t)2 * n_edge * 8 * sizeof(float),
-                           (hipStream_t)stream, d_table, edge_encoder, edge_dis_encoder, d_edge_encoder,
-                           d_edge_dis_encoder, D, n_edge, fp16_roundtrip);
+        const int nb = mobgt_hop::hop_bwd8_blocks(D, n_edge);
+        const mobgt_hop::HopBwd hp = {d_table, edge_encoder, edge_dis_encoder, d_edge_encoder, d_edge_dis_encoder, D, n_edge, fp16_roundtrip};
+        hipLaunchKernelGGL(hop_table_bwd8_kernel, dim3(nb), dim3(256), (size_t)2 * n_edge * 8 * sizeof(float), (hipStream_t)stream, hp);
         return (int)hipGetLastError();
     }
     const int n = n_edge * H + D * H * H;

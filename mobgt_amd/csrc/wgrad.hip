@@ -18,6 +18,7 @@
 #include "mobgt_hip.h"
 #include "gemm_body.h"
 #include "wgrad_body.h"
+#include "hop_body.h"
 #include <stdlib.h>
 
 namespace {
@@ -45,6 +46,10 @@ struct WgradGroup {
     // on the same dqkv as the weight gradients and on nothing they produce -- its n_tail workgroups lead the grid.
     mobgt_gemm::GemmParams tail;
     int n_tail;
+    // Optional passengers behind the weight-gradient workgroups: the hop table's backward (csrc/hop_body.h), which needs nothing
+    // the group produces and whose results nothing but the optimizer reads
+    mobgt_hop::HopBwd hop;
+    int n_hop, n_wg;                  // hop workgroups; first workgroup that is not a weight-gradient one (n_hop > 0)
 };
 
 template <int NWAVE>
@@ -58,6 +63,10 @@ __global__ __launch_bounds__(NWAVE * 64) void wgrad_group_kernel(const WgradGrou
         }
     }
     const int bid = (int)blockIdx.x - grp.n_tail;
+    if (grp.n_hop > 0 && bid >= grp.n_wg) {
+        mobgt_hop::hop_table_bwd8_body(grp.hop, bid - grp.n_wg, lds);
+        return;
+    }
     int q = 0;
 #pragma unroll
     for (int t = 1; t < WG_GROUP; ++t)
@@ -79,6 +88,7 @@ int launch_group(int n, const void* const* g, const int64_t* ldg, const void* co
     WgradGroup grp;
     grp.n = n;
     grp.n_tail = 0;
+    grp.n_hop = 0; grp.n_wg = 0;
     int total = 0;
     const int nwave = R <= SHORT_R ? 8 : 16;
     if (tail) {
@@ -106,14 +116,19 @@ int launch_group(int n, const void* const* g, const int64_t* ldg, const void* co
 // launch (round 3: the leaf weight gradients of a train step -- FuseEmbeddings' Linears, the distance GCN's three layers -- were
 // six launches of ~9.5 us each, every one a handful of workgroups walking a few thousand rows; nothing but the optimizer
 // reads their results, so the trainer collects them and issues them together at the end of the backward pass).
-extern "C" int mobgt_linear_wgrad_multi(int n, const void* const* g, const int64_t* ldg, const void* const* x, const int64_t* ldx,
-                                        const float* const* g_mask, const float* const* x_mask, const float* mask_vals,
-                                        float* const* dw, const int64_t* ldw, float* const* db, const int* db_of_x,
-                                        const int64_t* R, const int* M, const int* N, const int* in_f32, void* stream) {
+extern "C" int mobgt_linear_wgrad_multi_hop(int n, const void* const* g, const int64_t* ldg, const void* const* x, const int64_t* ldx,
+                                            const float* const* g_mask, const float* const* x_mask, const float* mask_vals,
+                                            float* const* dw, const int64_t* ldw, float* const* db, const int* db_of_x,
+                                            const int64_t* R, const int* M, const int* N, const int* in_f32,
+                                            // the arguments of mobgt_hop_table_bwd (with_hop != 0; H = 8, n_edge <= 256: its 16 n_edge floats of staging live in the group kernel's LDS)
+                                            int with_hop, const float* d_table, const float* edge_encoder, const float* edge_dis_encoder,
+                                            float* d_edge_encoder, float* d_edge_dis_encoder, int D, int n_edge, int fp16_roundtrip,
+                                            void* stream) {
     if (n < 1 || n > WG_GROUP) return MOBGT_EBADDIM;
     WgradGroup grp;
     grp.n = n;
     grp.n_tail = 0;
+    grp.n_hop = 0; grp.n_wg = 0;
     int total = 0;
     // (16-wave workgroups whenever any problem is long: a short problem then simply has idle waves)
     int nwave = 8;
@@ -137,9 +152,24 @@ extern "C" int mobgt_linear_wgrad_multi(int n, const void* const* g, const int64
     }
     for (int q = n; q <= WG_GROUP; ++q) grp.first[q] = total;
     for (int q = n; q < WG_GROUP; ++q) { grp.tiles[q] = 1; grp.splits[q] = 1; grp.p[q] = grp.p[0]; }
+    if (with_hop) {
+        if (D <= 0 || n_edge <= 0 || n_edge > 256 || (((uintptr_t)d_table | (uintptr_t)edge_dis_encoder) & 15)) return MOBGT_EBADDIM;
+        grp.hop = mobgt_hop::HopBwd{d_table, edge_encoder, edge_dis_encoder, d_edge_encoder, d_edge_dis_encoder, D, n_edge, fp16_roundtrip};
+        grp.n_hop = mobgt_hop::hop_bwd8_blocks(D, n_edge);
+        grp.n_wg = total;
+        total += grp.n_hop;
+    }
     if (nwave == 8) hipLaunchKernelGGL(wgrad_group_kernel<8>, dim3(total), dim3(8 * 64), 0, (hipStream_t)stream, grp);
     else hipLaunchKernelGGL(wgrad_group_kernel<16>, dim3(total), dim3(16 * 64), 0, (hipStream_t)stream, grp);
     return (int)hipGetLastError();
+}
+
+extern "C" int mobgt_linear_wgrad_multi(int n, const void* const* g, const int64_t* ldg, const void* const* x, const int64_t* ldx,
+                                        const float* const* g_mask, const float* const* x_mask, const float* mask_vals,
+                                        float* const* dw, const int64_t* ldw, float* const* db, const int* db_of_x,
+                                        const int64_t* R, const int* M, const int* N, const int* in_f32, void* stream) {
+    return mobgt_linear_wgrad_multi_hop(n, g, ldg, x, ldx, g_mask, x_mask, mask_vals, dw, ldw, db, db_of_x, R, M, N, in_f32, 0, nullptr,
+                                        nullptr, nullptr, nullptr, nullptr, 0, 0, 0, stream);
 }
 
 extern "C" int mobgt_linear_wgrad_group(int n, const void* const* g, const int64_t* ldg, const void* const* x,

@@ -523,7 +523,13 @@ class _HopTableFn(torch.autograd.Function):
         k_e, k_d = ctx.sinks
         d_ew = k_e[:] if k_e is not None else torch.empty_like(ew)          # (written in full)
         d_dw = k_d[:] if k_d is not None else zeros_f32(tuple(dis_shape), ew.device)     # rows of hop slots >= D get no gradient
-        check(_lib.lib().mobgt_hop_table_bwd(_p(dtab.contiguous()), _p(ew), _p(dw), _p(d_ew), _p(d_dw), D, E, H, rt,
+        dtab = dtab.contiguous()
+        if (_WGRAD_DEFER["on"] and H == 8 and E <= 256 and dtab.data_ptr() % 16 == 0 and dw.data_ptr() % 16 == 0
+                and os.environ.get("MOBGT_NO_HOP_BWD_PASSENGER") != "1"):
+            # rides in the step's grouped weight-gradient launch (flush_deferred_wgrads): nothing but the optimizer reads these
+            _WGRAD_DEFER["hop"] = (dtab, ew, dw, d_ew, d_dw, D, E, rt)
+            return d_ew[:], d_dw[:], None, None, None
+        check(_lib.lib().mobgt_hop_table_bwd(_p(dtab), _p(ew), _p(dw), _p(d_ew), _p(d_dw), D, E, H, rt,
                                              _stream()), "mobgt_hop_table_bwd")
         return d_ew, d_dw, None, None, None
 
@@ -1400,6 +1406,7 @@ def wgrad_deferral(on):
     """Switch the recording on / off.  Switching off DROPS anything still recorded: the trainer flushes explicitly after a
     successful backward pass, so leftovers exist only when that pass raised -- their buffers belong to a dead graph."""
     _WGRAD_DEFER["items"] = []
+    _WGRAD_DEFER.pop("hop", None)
     _WGRAD_DEFER["on"] = bool(on) and _WGRAD_DEFER_ENV
 
 
@@ -1416,15 +1423,26 @@ def flush_deferred_wgrads():
         raise RuntimeError(f"a parked encoder-input backward chain was never completed (stages {stages}): gradients of this "
                            "step are invalid -- set MOBGT_NO_TOKEN_BWD_CHAIN=1 and report")
     items, _WGRAD_DEFER["items"] = _WGRAD_DEFER["items"], []
+    hop = _WGRAD_DEFER.pop("hop", None)
     vp, i64, ci, cf = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_float
+    if hop is not None and not items:            # nobody to ride with
+        dtab, ew, dw_, d_ew, d_dw, D, E, rt = hop
+        check(_lib.lib().mobgt_hop_table_bwd(_p(dtab), _p(ew), _p(dw_), _p(d_ew), _p(d_dw), D, E, 8, rt, _stream()), "mobgt_hop_table_bwd")
+        hop = None
     for o in range(0, len(items), 32):
         part = items[o:o + 32]
         n = len(part)
+        if hop is not None:                      # (with the first group)
+            dtab, ew, dw_, d_ew, d_dw, D, E, rt = hop
+            hop_args = [1, _p(dtab), _p(ew), _p(dw_), _p(d_ew), _p(d_dw), D, E, rt]
+            hop = None
+        else:
+            hop_args = [0, None, None, None, None, None, 0, 0, 0]
         ptr = lambda t: t.data_ptr() if t is not None else None
         mv = []
         for it in part:
             mv += list(it[4])
-        check(_lib.lib().mobgt_linear_wgrad_multi(
+        check(_lib.lib().mobgt_linear_wgrad_multi_hop(
             n, (vp * n)(*[ptr(it[0]) for it in part]), (i64 * n)(*[it[0].stride(0) for it in part]),
             (vp * n)(*[ptr(it[1]) for it in part]), (i64 * n)(*[it[1].stride(0) for it in part]),
             (vp * n)(*[ptr(it[2]) for it in part]), (vp * n)(*[ptr(it[3]) for it in part]), (cf * (3 * n))(*mv),
@@ -1432,7 +1450,7 @@ def flush_deferred_wgrads():
             (vp * n)(*[ptr(it[6]) for it in part]), (ci * n)(*[int(it[7]) for it in part]),
             (i64 * n)(*[it[0].shape[0] for it in part]), (ci * n)(*[it[0].shape[1] for it in part]),
             (ci * n)(*[it[1].shape[1] for it in part]), (ci * n)(*[1 if it[0].dtype == torch.float32 else 0 for it in part]),
-            _stream()), "mobgt_linear_wgrad_multi")
+            *hop_args, _stream()), "mobgt_linear_wgrad_multi_hop")
 
 
 def linear_wgrad_masked(g, x, g_mask=None, x_mask=None, mask_vals=(1.0, 1.0, 1.0), db=None, db_of_x=False, dw=None, g_out=None,
