@@ -1420,6 +1420,7 @@ def flush_deferred_wgrads():
         stages = [p_["stage"] for p_ in _TOKEN_PENDING.values()]
         _TOKEN_PENDING.clear()
         _WGRAD_DEFER["items"] = []
+        _WGRAD_DEFER.pop("hop", None)
         raise RuntimeError(f"a parked encoder-input backward chain was never completed (stages {stages}): gradients of this "
                            "step are invalid -- set MOBGT_NO_TOKEN_BWD_CHAIN=1 and report")
     items, _WGRAD_DEFER["items"] = _WGRAD_DEFER["items"], []
