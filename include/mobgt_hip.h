@@ -561,21 +561,21 @@ int mobgt_small_gcn_fwd(const float* ax, const float* a, const float* w0, const 
                         int n, int K0, int H1, int H2, int H3, float slope, float dropout_p, uint64_t seed,
                         const uint64_t* seed_dev, uint32_t salt, void* stream);
 /* The same launch carrying, as passenger workgroups on the compute units the network leaves idle,
- *   - the step's weight pack (mobgt_pack_mfma_b's jobs, same arguments, pack_n <= 96; pack_n = 0: none) and
- *   - the bias assembly (with_bias != 0: the arguments of mobgt_build_bias follow, same meaning; only the short-batch
- *     instantiation -- idx_dtype MOBGT_I16, edge_dtype MOBGT_U8, bias_dtype MOBGT_BF16, H = 8, G (N+1)^2 < 2^20 -- else
- *     MOBGT_EBADDIM: callers then use the separate launch).
- * Results identical to the separate launches (the pack is 11.7 us of pure data movement, the bias assembly 7 us, beside a
- * 26 us launch that keeps 19 compute units busy).  Not re-entrant (one host thread launches at a time). */
+ *   - the step's weight pack (mobgt_pack_mfma_b's jobs, same arguments, pack_n <= 96; pack_n = 0: none),
+ *   - the index derivation of the node features (with_node_index != 0: the arguments of mobgt_node_index follow) and
+ *   - the hop table's forward (with_hop != 0: those of mobgt_hop_table_fwd) -- 4.8 us each as launches of their own, all ramp.
+ * Results identical to the separate launches (the pack is 11.7 us of pure data movement beside a 26 us launch that keeps 19
+ * compute units busy).  Nothing in this launch may read what a passenger writes.  Not re-entrant (one host thread at a time). */
 int mobgt_small_gcn_fwd_pack(const float* ax, const float* a, const float* w0, const float* b0, const float* w1, const float* b1,
                              const float* w2, const float* b2, float* h1, float* t, float* h2, float* t2, float* out, int* counter,
                              int n, int K0, int H1, int H2, int H3, float slope, float dropout_p, uint64_t seed,
                              const uint64_t* seed_dev, uint32_t salt, int pack_n, const void* const* pack_src, void* const* pack_dst,
-                             const int* pack_N, const int* pack_K, const int* pack_transposed, int with_bias, const float* attn_bias,
-                             const void* rel_pos, const void* poi_pos, const void* edge_input, const float* rel_table,
-                             const float* poi_table, const float* hop_table, const float* vdist, void* bias, void* bias_t, int G,
-                             int N, int H, int D_in, int D, int F, int n_rel, int n_poi, int n_edge, int64_t ld_bias, int idx_dtype,
-                             int edge_dtype, int bias_dtype, void* stream);
+                             const int* pack_N, const int* pack_K, const int* pack_transposed, int with_node_index, const void* ni_x,
+                             int ni_x_dtype, int64_t ni_xs_g, int64_t ni_xs_n, const float* ni_time_normal, int64_t ni_ts_g,
+                             int64_t ni_ts_n, const int64_t* ni_poi2cat, const void* ni_in_degree, const void* ni_out_degree,
+                             int ni_deg_dtype, int64_t* ni_idx, float* ni_real, int ni_G, int ni_N, int ni_rows_only, int with_hop,
+                             const float* hop_edge_encoder, const float* hop_edge_dis_encoder, float* hop_out, int hop_D,
+                             int hop_n_edge, int hop_H, int hop_fp16_roundtrip, void* stream);
 int mobgt_small_gcn_bwd(const float* g, const float* ax, const float* a_t, const float* w1, const float* w2, const float* h1,
                         const float* t, const float* h2, const float* t2, float* dw0, float* db0, float* dw1, float* db1,
                         float* dw2, float* db2, float* dt2, float* dt, int* counter, int n, int K0, int H1, int H2, int H3,

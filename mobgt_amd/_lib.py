@@ -91,7 +91,8 @@ SIGNATURES = {
     "mobgt_chain_ws_bytes": (_i64, []),
     "mobgt_small_gcn_fwd": (_i, [_vp] * 14 + [_i] * 5 + [_f, _f, _u64, _vp, _c.c_uint32, _vp]),
     "mobgt_small_gcn_fwd_pack": (_i, [_vp] * 14 + [_i] * 5 + [_f, _f, _u64, _vp, _c.c_uint32, _i, _vp, _vp, _vp, _vp, _vp]
-                                 + [_i] + [_vp] * 10 + [_i] * 9 + [_i64, _i, _i, _i, _vp]),
+                                 + [_i, _vp, _i, _i64, _i64, _vp, _i64, _i64, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i]
+                                 + [_i, _vp, _vp, _vp, _i, _i, _i, _i] + [_vp]),
     "mobgt_small_gcn_bwd": (_i, [_vp] * 18 + [_i] * 5 + [_f, _f, _u64, _vp, _c.c_uint32, _vp]),
     "mobgt_small_gcn_bwd_bias": (_i, [_vp] * 18 + [_i] * 5 + [_f, _f, _u64, _vp, _c.c_uint32]
                                  + [_i] + [_vp, _i, _i, _i64] + [_vp] * 8 + [_i] * 9 + [_i64, _i, _i, _vp]),

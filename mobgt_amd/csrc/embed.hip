@@ -4,6 +4,7 @@
 // which is nn.Embedding(padding_idx=0)'s gradient rule).
 #include "common.h"
 #include "mobgt_hip.h"
+#include "front_body.h"
 
 namespace {
 
@@ -240,59 +241,11 @@ extern "C" int mobgt_embed_scatter_add(float* const* d_tables_host, const void* 
 
 // ---- index derivation for the node features ---------------------------------------------------------------
 namespace {
-
-struct NodeIndexParams {
-    const void* x; int x_dtype; int64_t xs_g, xs_n; // POI ids [G,N] (0 = pad; int64 or int32), element strides
-    const float* tn;  int64_t ts_g, ts_n;           // time_normal [G,N]
-    const int64_t* poi2cat;                          // [P+1]
-    const void *indeg, *outdeg;                      // [G*N] degrees (deg_dtype), or null
-    int deg_dtype;
-    int64_t* idx;                                    // [8][G*N]
-    float* real;                                     // [G*N]
-    int G, N, rows_only;
-};
-
-// one workgroup per graph: count the real nodes (the positional rows stop there), then write all six index
-// rows and the mask for its N positions
+using mobgt_front::NodeIndexParams;
 __global__ __launch_bounds__(256) void node_index_kernel(const NodeIndexParams p) {
     __shared__ int s_cnt[4];
-    const int g = blockIdx.x;
-    int cnt = 0;
-    const bool x32 = p.x_dtype == MOBGT_I32;
-    auto poi_at = [&](int n) -> int64_t {
-        const int64_t o = g * p.xs_g + n * p.xs_n;
-        return x32 ? (int64_t)reinterpret_cast<const int32_t*>(p.x)[o] : reinterpret_cast<const int64_t*>(p.x)[o];
-    };
-    for (int n = threadIdx.x; n < p.N; n += 256) cnt += poi_at(n) != 0;
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
-    if ((threadIdx.x & 63) == 0) s_cnt[threadIdx.x >> 6] = cnt;
-    __syncthreads();
-    cnt = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
-    const int64_t GN = (int64_t)p.G * p.N;
-    for (int n = threadIdx.x; n < p.N; n += 256) {
-        const int64_t r = (int64_t)g * p.N + n;
-        const int64_t poi = poi_at(n);
-        const bool real = poi != 0;
-        const int64_t slot = (int64_t)(p.tn[g * p.ts_g + n * p.ts_n] * 48.f);
-        p.idx[0 * GN + r] = real ? (p.rows_only ? r : poi - 1) : -1;
-        p.idx[1 * GN + r] = real ? slot : -1;
-        p.idx[2 * GN + r] = real ? p.poi2cat[poi] - 1 : -1;
-        p.idx[3 * GN + r] = real && n + 1 <= cnt ? n + 1 : -1;
-        p.idx[4 * GN + r] = poi > 0 ? poi - 1 : 0;
-        p.idx[5 * GN + r] = 0;
-        if (p.indeg) {
-            int64_t a, b;
-            if (p.deg_dtype == MOBGT_I16) { a = reinterpret_cast<const int16_t*>(p.indeg)[r]; b = reinterpret_cast<const int16_t*>(p.outdeg)[r]; }
-            else if (p.deg_dtype == MOBGT_I32) { a = reinterpret_cast<const int32_t*>(p.indeg)[r]; b = reinterpret_cast<const int32_t*>(p.outdeg)[r]; }
-            else { a = reinterpret_cast<const int64_t*>(p.indeg)[r]; b = reinterpret_cast<const int64_t*>(p.outdeg)[r]; }
-            p.idx[6 * GN + r] = a;
-            p.idx[7 * GN + r] = b;
-        }
-        p.real[r] = real ? 1.f : 0.f;
-    }
+    mobgt_front::node_index_body(p, (int)blockIdx.x, s_cnt);
 }
-
 }  // namespace
 
 extern "C" int mobgt_node_index(const void* x, int x_dtype, int64_t xs_g, int64_t xs_n, const float* time_normal, int64_t ts_g,

@@ -10,19 +10,14 @@
 #include "common.h"
 #include "mobgt_hip.h"
 #include "hop_body.h"
+#include "front_body.h"
 
 namespace {
 
 using mobgt_hop::r16;
 
-__global__ __launch_bounds__(256) void hop_table_fwd_kernel(const float* __restrict__ enc, const float* __restrict__ w,
-                                                            float* __restrict__ tab, int D, int E, int H, int rt) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= D * E * H) return;
-    const int h = i % H, e = (i / H) % E, d = i / (H * E);
-    float acc = 0.f;
-    for (int k = 0; k < H; ++k) acc += r16(enc[e * H + k], rt) * r16(w[(d * H + k) * H + h], rt);
-    tab[i] = r16(acc, rt);
+__global__ __launch_bounds__(256) void hop_table_fwd_kernel(const mobgt_front::HopFwd p) {
+    mobgt_front::hop_table_fwd_body(p, (int)blockIdx.x);
 }
 
 // Generic H.  threads [0, E*H): d_enc[e, k] = sum_{d,h} g[d,e,h] * W[d,k,h]   (row 0 = padding_idx: zero)
@@ -60,8 +55,8 @@ extern "C" int mobgt_hop_table_fwd(const float* edge_encoder, const float* edge_
                                    int n_edge, int H, int fp16_roundtrip, void* stream) {
     if (D <= 0 || n_edge <= 0 || H <= 0) return MOBGT_EBADDIM;
     const int n = D * n_edge * H;
-    hipLaunchKernelGGL(hop_table_fwd_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, edge_encoder,
-                       edge_dis_encoder, table, D, n_edge, H, fp16_roundtrip);
+    const mobgt_front::HopFwd hp = {edge_encoder, edge_dis_encoder, table, D, n_edge, H, fp16_roundtrip};
+    hipLaunchKernelGGL(hop_table_fwd_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, hp);
     return (int)hipGetLastError();
 }
 

@@ -16,6 +16,7 @@
 #include "common.h"
 #include "mobgt_hip.h"
 #include "pack_body.h"
+#include "front_body.h"
 // csrc/bias.hip is compiled as part of THIS translation unit (not on its own): the category GCN's backward launch carries the bias
 // tables' backward (build_bias_bwd_body) as passenger workgroups, and that body lives there with everything it needs
 #include "bias.hip"
@@ -298,21 +299,31 @@ __device__ __forceinline__ void tile_product(float* __restrict__ smem, float* __
     __syncthreads();
 }
 
+// what rides along in the forward launch besides the weight pack (all optional)
+struct FrontJobs {
+    mobgt_front::NodeIndexParams ni; int ni_on;       // index derivation of the node features (one block per graph)
+    mobgt_front::HopFwd hf; int hf_blocks;            // hop table forward (blocks of 256 entries)
+};
+
 template <int H1, int H2, int H3>
 __global__ __launch_bounds__(NT) void small_gcn_fwd_kernel(const SmallGcnParams p, const mobgt_pack::PackJobs jobs, int njobs, int nvb,
-                                                          const BuildParams fb, int fb_nt) {
+                                                          const FrontJobs fj) {
     if ((int)blockIdx.x >= p.nwg) {
-        // passengers on the compute units this network leaves idle: the step's weight pack (mobgt_pack_mfma_b's body), then the
-        // bias assembly (csrc/bias.hip: build_bias_body, the short-batch form: int16 indices, uint8 edge ids, bf16 bias, 8 heads)
+        // passengers on the compute units this network leaves idle: the step's weight pack (mobgt_pack_mfma_b's body) and two tiny
+        // front-of-step kernels (front_body.h).  (The bias ASSEMBLY was tried here too: with the pack in the same launch the
+        // passengers outlast the network -- 36.2 us for 27.4 + 7.0, measured -- so it keeps its own launch.)
         const int np = (int)gridDim.x - p.nwg, pid = (int)blockIdx.x - p.nwg;
-        for (int vb = pid; vb < nvb; vb += PACK_U * np) mobgt_pack::pack_blocks<PACK_U>(jobs, njobs, vb, np, nvb);
-        if (fb_nt > 0) {
-            const int nby = 4 * fb_nt, total = fb_nt * nby * fb.G;
-            for (int vb = pid; vb < total; vb += np) {
-                build_bias_body<int16_t, uint8_t, bf16_t, 8, 1>(fb, vb % fb_nt, (vb / fb_nt) % nby, vb / (fb_nt * nby));
-                __syncthreads();                     // (its LDS tile is reused by the next block this workgroup takes)
+        // (the two tiny ones first, on the LAST passengers: the first ones carry the largest pack shares)
+        const int rid = np - 1 - pid;
+        if (fj.ni_on) {
+            __shared__ int s_cnt[4];
+            for (int g = rid; g < fj.ni.G; g += np) {
+                mobgt_front::node_index_body(fj.ni, g, s_cnt);
+                __syncthreads();
             }
         }
+        for (int vb = rid; vb < fj.hf_blocks; vb += np) mobgt_front::hop_table_fwd_body(fj.hf, vb);
+        for (int vb = pid; vb < nvb; vb += PACK_U * np) mobgt_pack::pack_blocks<PACK_U>(jobs, njobs, vb, np, nvb);
         return;
     }
     static_assert(H1 <= 32 && H1 * H2 + H2 * H3 <= MAXH * MAXH, "LDS plan");
@@ -584,12 +595,14 @@ extern "C" int mobgt_small_gcn_fwd_pack(const float* ax, const float* a, const f
                                         float* out, int* counter, int n, int K0, int H1, int H2, int H3, float slope, float dropout_p,
                                         uint64_t seed, const uint64_t* seed_dev, uint32_t salt, int pack_n, const void* const* pack_src,
                                         void* const* pack_dst, const int* pack_N, const int* pack_K, const int* pack_transposed,
-                                        // the arguments of mobgt_build_bias (with_bias != 0): idx int16 / edge uint8 / bf16 bias / H = 8
-                                        int with_bias, const float* attn_bias, const void* rel_pos, const void* poi_pos,
-                                        const void* edge_input, const float* rel_table, const float* poi_table, const float* hop_table,
-                                        const float* vdist, void* bias, void* bias_t, int G, int N, int H, int D_in, int D, int F,
-                                        int n_rel, int n_poi, int n_edge, int64_t ld_bias, int idx_dtype, int edge_dtype, int bias_dtype,
-                                        void* stream) {
+                                        // the arguments of mobgt_node_index (with_node_index != 0)
+                                        int with_node_index, const void* ni_x, int ni_x_dtype, int64_t ni_xs_g, int64_t ni_xs_n,
+                                        const float* ni_time_normal, int64_t ni_ts_g, int64_t ni_ts_n, const int64_t* ni_poi2cat,
+                                        const void* ni_in_degree, const void* ni_out_degree, int ni_deg_dtype, int64_t* ni_idx,
+                                        float* ni_real, int ni_G, int ni_N, int ni_rows_only,
+                                        // the arguments of mobgt_hop_table_fwd (with_hop != 0)
+                                        int with_hop, const float* hop_edge_encoder, const float* hop_edge_dis_encoder, float* hop_out,
+                                        int hop_D, int hop_n_edge, int hop_H, int hop_fp16_roundtrip, void* stream) {
     SmallGcnParams p = {};
     p.AX = ax; p.A = a; p.W0 = w0; p.b0 = b0; p.W1 = w1; p.b1 = b1; p.W2 = w2; p.b2 = b2;
     p.h1 = h1; p.t = t; p.h2 = h2; p.t2 = t2; p.out = out; p.counter = counter;
@@ -611,21 +624,25 @@ extern "C" int mobgt_small_gcn_fwd_pack(const float* ax, const float* a, const f
         passengers = PACK_ROUNDS * free_cus;
         if (passengers > (nvb + PACK_U - 1) / PACK_U) passengers = (nvb + PACK_U - 1) / PACK_U;
     }
-    BuildParams fb = {};
-    int fb_nt = 0;
-    if (with_bias) {
-        if ((rc = fill_bias_fwd(fb, attn_bias, rel_pos, poi_pos, edge_input, rel_table, poi_table, hop_table, vdist, bias, bias_t, G, N, H,
-                                D_in, D, F, n_rel, n_poi, n_edge, ld_bias))) return rc;
-        // only the instantiation the short-batch launch of mobgt_build_bias would pick (see launch_build)
-        if (idx_dtype != MOBGT_I16 || edge_dtype != MOBGT_U8 || bias_dtype != MOBGT_BF16 || H != 8 ||
-            (int64_t)G * (N + 1) * (N + 1) >= (1 << 20)) return MOBGT_EBADDIM;
-        fb_nt = (int)((ld_bias + 31) / 32);
-        const int blocks = fb_nt * 4 * fb_nt * G;
-        const int want = blocks < free_cus ? blocks : free_cus;
+    FrontJobs fj = {};
+    if (with_node_index && ni_G > 0 && ni_N > 0) {
+        if (ni_in_degree && ni_deg_dtype != MOBGT_I64 && ni_deg_dtype != MOBGT_I32 && ni_deg_dtype != MOBGT_I16) return MOBGT_EDTYPE;
+        if (ni_x_dtype != MOBGT_I64 && ni_x_dtype != MOBGT_I32) return MOBGT_EDTYPE;
+        fj.ni = mobgt_front::NodeIndexParams{ni_x, ni_x_dtype, ni_xs_g, ni_xs_n, ni_time_normal, ni_ts_g, ni_ts_n, ni_poi2cat, ni_in_degree,
+                                             ni_out_degree, ni_deg_dtype, ni_idx, ni_real, ni_G, ni_N, ni_rows_only};
+        fj.ni_on = 1;
+        if (passengers < (ni_G < free_cus ? ni_G : free_cus)) passengers = ni_G < free_cus ? ni_G : free_cus;
+    }
+    if (with_hop) {
+        if (hop_D <= 0 || hop_n_edge <= 0 || hop_H <= 0) return MOBGT_EBADDIM;
+        fj.hf = mobgt_front::HopFwd{hop_edge_encoder, hop_edge_dis_encoder, hop_out, hop_D, hop_n_edge, hop_H, hop_fp16_roundtrip};
+        fj.hf_blocks = (hop_D * hop_n_edge * hop_H + 255) / 256;
+        const int want = fj.hf_blocks < free_cus ? fj.hf_blocks : free_cus;
         if (passengers < want) passengers = want;
     }
+    static_assert(sizeof(SmallGcnParams) + sizeof(mobgt_pack::PackJobs) + sizeof(FrontJobs) + 16 <= 4096, "kernel arguments");
     hipLaunchKernelGGL((small_gcn_fwd_kernel<16, 64, 32>), dim3(p.nwg + passengers), dim3(NT), LDS_FLOATS * sizeof(float), (hipStream_t)stream, p,
-                       jobs, pack_n > 0 ? pack_n : 0, nvb, fb, fb_nt);
+                       jobs, pack_n > 0 ? pack_n : 0, nvb, fj);
     return (int)hipGetLastError();
 }
 
@@ -634,8 +651,9 @@ extern "C" int mobgt_small_gcn_fwd(const float* ax, const float* a, const float*
                                    float* out, int* counter, int n, int K0, int H1, int H2, int H3, float slope, float dropout_p,
                                    uint64_t seed, const uint64_t* seed_dev, uint32_t salt, void* stream) {
     return mobgt_small_gcn_fwd_pack(ax, a, w0, b0, w1, b1, w2, b2, h1, t, h2, t2, out, counter, n, K0, H1, H2, H3, slope, dropout_p, seed,
-                                    seed_dev, salt, 0, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr,
-                                    nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, stream);
+                                    seed_dev, salt, 0, nullptr, nullptr, nullptr, nullptr, nullptr,
+                                    0, nullptr, 0, 0, 0, nullptr, 0, 0, nullptr, nullptr, nullptr, 0, nullptr, nullptr, 0, 0, 0,
+                                    0, nullptr, nullptr, nullptr, 0, 0, 0, 0, stream);
 }
 
 extern "C" int mobgt_small_gcn_bwd_bias(const float* g, const float* ax, const float* a_t, const float* w1, const float* w2,

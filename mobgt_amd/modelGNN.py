@@ -473,44 +473,55 @@ def _small_gcn_launch(ax, a, ws, slope, p_drop, seed, seed_dev, salt):
     vp, ci = ctypes.c_void_p, ctypes.c_int
     pack = ((vp * nj)(*[j[0].data_ptr() for j in jobs]), (vp * nj)(*[j[1].data_ptr() for j in jobs]), (ci * nj)(*[j[2] for j in jobs]),
             (ci * nj)(*[j[3] for j in jobs]), (ci * nj)(*[j[4] for j in jobs])) if nj else (None, None, None, None, None)
-    # ... and so does a bias assembly the model deferred (ops.bias_fwd_deferral)
-    bjob = ops.take_bias_fwd_job()
-    bias = [1] + bjob[0] if bjob is not None else [0] + [None] * 10 + [0] * 9 + [0, 0, 0, 0]
+    # ... and the hop table's forward / the node features' index derivation (ops.front_deferral)
+    hop, ni = ops.take_front_jobs()
+    front = ([1] + ni[0] if ni is not None else [0, None, 0, 0, 0, None, 0, 0, None, None, None, 0, None, None, 0, 0, 0]) + \
+            ([1] + hop[0] if hop is not None else [0, None, None, None, 0, 0, 0, 0])
     _lib.check(_lib.lib().mobgt_small_gcn_fwd_pack(_p(ax), _p(a), *[_p(w) for w in ws], _p(h1), _p(t), _p(h2), _p(t2), _p(out),
                                                    _p(counter), n, K0, H1, H2, H3, slope, p_drop, seed, _p(seed_dev), salt,
-                                                   nj, *pack, *bias, _stream()), "mobgt_small_gcn_fwd_pack")
+                                                   nj, *pack, *front, _stream()), "mobgt_small_gcn_fwd_pack")
     return keep, out
 
 
 _SIDE = {}                  # device index -> (side stream, pending prelaunch or None)
 
 
-def prelaunch_small_gcn(gcn, x, adj, adj_x, adj_t):
-    """Start the one-launch GCN's forward NOW on a side stream (no autograd: GCN.forward, called later where the reference calls
+def prelaunch_small_gcn(gcn, x, adj, adj_x, adj_t, same_stream=False):
+    """same_stream: launch the one-launch GCN's forward NOW on the calling stream (no autograd: GCN.forward, called later where
+    the reference calls it, finds the result and builds the autograd node there -- so the backward keeps its place behind the
+    bias tables' node).  The model uses this to run the network FIRST in the step, with the front-of-step launches that precede
+    its other consumers as passengers (the weight pack, ops.front_deferral's jobs).  -> True when launched.
+    Otherwise: start the one-launch GCN's forward NOW on a side stream (no autograd: GCN.forward, called later where the reference calls
     it, finds the result, makes the calling stream wait for it and builds the autograd node there -- so the backward keeps
     its place).  The network depends on nothing but its weights and keeps 19 compute units busy for 26 us; the launches of the
     distance GCN that follow on the main stream run beside it.  OPT-IN (MOBGT_GCN_SIDE_STREAM=1) and kept for the record only:
     inside the captured step the fork / join makes the replay SLOWER -- S-FSQ 0.710 ms against 0.664 ms (measured, round 3; the
     same finding as round 2's four-branch experiment: a cross-stream edge of a hipGraph costs more than the launch it hides)."""
     from . import ops
-    if os.environ.get("MOBGT_GCN_SIDE_STREAM") != "1" or not (torch.is_tensor(x) and x.is_cuda):
-        return
+    side_on = os.environ.get("MOBGT_GCN_SIDE_STREAM") == "1"
+    if not (side_on or same_stream) or not (torch.is_tensor(x) and x.is_cuda):
+        return False
     if adj_x is not None and adj_x.shape[1] != gcn.gcn[0].in_features:
         adj_x = adj_x[:, :gcn.gcn[0].in_features]
     if not _small_gcn_ok(gcn, x, adj, adj_x, adj_t):
-        return
-    dev = x.device.index if x.device.index is not None else torch.cuda.current_device()
-    ent = _SIDE.get(dev)
-    if ent is None:
-        if torch.cuda.is_current_stream_capturing():
-            return                                               # (the side stream is created by the eager warm-up step)
-        ent = _SIDE[dev] = [torch.cuda.Stream(device=x.device), None]
-    side = ent[0]
+        return False
     p_drop = gcn.dropout if gcn.training else 0.0
     seed, seed_dev = ops.dropout_seed(p_drop)
     g0, g1, g2 = gcn.gcn
     ws = [w.detach().contiguous() for w in (g0.weight, g0.bias, g1.weight, g1.bias, g2.weight, g2.bias)]
     salt = (0x2000 + g2.out_features) & 0xFFFFFFFF
+    if not side_on:
+        with torch.autocast(device_type="cuda", enabled=False):
+            keep, out = _small_gcn_launch(adj_x, adj, ws, float(gcn.leaky_relu.negative_slope), float(p_drop), seed, seed_dev, salt)
+        gcn._prelaunched = ((float(p_drop), seed, id(seed_dev), salt), (keep, out, None))
+        return True
+    dev = x.device.index if x.device.index is not None else torch.cuda.current_device()
+    ent = _SIDE.get(dev)
+    if ent is None:
+        if torch.cuda.is_current_stream_capturing():
+            return False                                         # (the side stream is created by the eager warm-up step)
+        ent = _SIDE[dev] = [torch.cuda.Stream(device=x.device), None]
+    side = ent[0]
     cur = torch.cuda.current_stream()
     side.wait_stream(cur)
     with torch.cuda.stream(side), torch.autocast(device_type="cuda", enabled=False):
@@ -518,6 +529,7 @@ def prelaunch_small_gcn(gcn, x, adj, adj_x, adj_t):
         ev = torch.cuda.Event()
         ev.record(side)
     gcn._prelaunched = ((float(p_drop), seed, id(seed_dev), salt), (keep, out, ev))
+    return True
 
 
 class _SmallGcnFn(torch.autograd.Function):
@@ -532,10 +544,11 @@ class _SmallGcnFn(torch.autograd.Function):
         if pre is not None:
             # launched earlier on the side stream (prelaunch_small_gcn): this stream waits for it here, in front of its consumer
             keep, out, ev = pre
-            cur = torch.cuda.current_stream()
-            cur.wait_event(ev)
-            keep.record_stream(cur)
-            out.record_stream(cur)
+            if ev is not None:                                   # (None: launched on this stream)
+                cur = torch.cuda.current_stream()
+                cur.wait_event(ev)
+                keep.record_stream(cur)
+                out.record_stream(cur)
         else:
             keep, out = _small_gcn_launch(ax, a, ws, slope, p_drop, seed, seed_dev, salt)
         ctx.save_for_backward(ax, a_t, ws[2], ws[4], keep)
@@ -595,15 +608,17 @@ class GCN(nn.Module):
         if rows is None and mask_adj is None and x.is_cuda and _small_gcn_ok(self, x, adj, adj_x, adj_t):
             from . import ops
             p_drop = self.dropout if self.training else 0.0
-            seed, seed_dev = ops.dropout_seed(p_drop)
             g0, g1, g2 = self.gcn
             salt = (0x2000 + g2.out_features) & 0xFFFFFFFF
             pre = self.__dict__.pop("_prelaunched", None)
-            if pre is not None:
-                if (pre[0][0], pre[0][2], pre[0][3]) == (float(p_drop), id(seed_dev), salt):
-                    seed = pre[0][1]                                    # (the masks the prelaunched pass drew)
-                else:
-                    torch.cuda.current_stream().wait_event(pre[1][2])   # (not what was prelaunched: drop it, but do not race with it)
+            seed_dev = ops._DROPOUT_STATE["seed_dev"]
+            if pre is not None and (pre[0][0], pre[0][2], pre[0][3]) == (float(p_drop), id(seed_dev), salt):
+                seed = pre[0][1]                                        # (the masks the prelaunched pass drew)
+            else:
+                seed, seed_dev = ops.dropout_seed(p_drop)
+                if pre is not None:
+                    if pre[1][2] is not None:
+                        torch.cuda.current_stream().wait_event(pre[1][2])   # (not what was prelaunched: drop it, but do not race with it)
                     pre = None
             with torch.autocast(device_type="cuda", enabled=False):
                 return _SmallGcnFn.apply(adj_x, adj, adj_t, g0.weight, g0.bias, g1.weight, g1.bias, g2.weight, g2.bias,

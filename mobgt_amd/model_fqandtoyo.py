@@ -305,33 +305,43 @@ class Graphormer(nn.Module):
         # NB: the reference's `self.apply(init_bert_params)` is commented out here (:1099): default torch init.
 
     # ------------------------------------------------------------------------------------------------
-    def assemble_bias(self, batched_data):
+    def _hop_depth(self, batched_data):
+        D = batched_data.edge_input.shape[3]
+        return min(D, self.multi_hop_max_dist) if self.multi_hop_max_dist > 0 else D
+
+    def hop_table(self, batched_data):
+        """The [D, n_edge, H] table of edge feature x hop distance products (:1178-1198, once per batch instead of per pair)."""
+        return hop_table_from(self.edge_encoder.weight, self.edge_dis_encoder.weight, self.num_heads, self._hop_depth(batched_data),
+                              fp16_roundtrip=True)
+
+    def gather_indices(self, batched_data):
+        """Every gather index of :1259-1264 / :1287-1298 in one launch: POI row (in the compact per-batch table when rows_only:
+        row p belongs to position p), time slot (:1262), category row (:1259), positional row 1..n (:348-351), GCN row, zeros."""
+        x = batched_data.x[:, :, 0]                                           # [G,N] POI ids, 0 = pad
+        if x.dtype not in (torch.int64, torch.int32):
+            x = x.long()
+        G, N = x.shape
+        rows_only = G * N * 2 <= self.X.shape[0]        # the table is read at <= G*N rows (:1264): compute only those
+        idx, real = ops.node_index(x, batched_data.time_normal[:, :, 0].float(), self.poi2cat, rows_only,
+                                   batched_data.in_degree, batched_data.out_degree)
+        return idx, real, rows_only
+
+    def assemble_bias(self, batched_data, hop=None):
         """model_fqandtoyo.py:1143-1216 -> ops.PackedBias (fp16 rounding points of :1178-1198 kept)."""
-        H = self.num_heads
         edge_input = batched_data.edge_input
-        D = edge_input.shape[3]
-        if self.multi_hop_max_dist > 0:
-            D = min(D, self.multi_hop_max_dist)
-        hop = hop_table_from(self.edge_encoder.weight, self.edge_dis_encoder.weight, H, D, fp16_roundtrip=True)
+        D = self._hop_depth(batched_data)
+        if hop is None:
+            hop = self.hop_table(batched_data)
         return ops.build_bias(batched_data.attn_bias, batched_data.rel_pos, batched_data.poi_pos, edge_input,
                               # (padding_idx = 0: build_bias_bwd never adds into row 0 of these two tables, so the
                               # tables go in as they are -- no cat / split / zero-fill launches around the kernel)
                               self.rel_pos_encoder.weight, self.poi_pos_encoder.weight, hop,
                               self.graph_token_virtual_distance.weight, D, dtype=self.bias_dtype)
 
-    def node_features(self, batched_data):
+    def node_features(self, batched_data, indices=None):
         """model_fqandtoyo.py:1222-1342 -> [G, N+1, C] (graph token first)."""
-        x = batched_data.x[:, :, 0]                                           # [G,N] POI ids, 0 = pad
-        if x.dtype not in (torch.int64, torch.int32):
-            x = x.long()
-        G, N = x.shape
-        P = self.X.shape[0]
-        rows_only = G * N * 2 <= P                      # the table is read at <= G*N rows (:1264): compute only those
-        # every gather index of :1259-1264 / :1287-1298 in one launch: POI row (in the compact per-batch table
-        # when rows_only: row p belongs to position p), time slot (:1262), category row (:1259), positional
-        # row 1..n (:348-351), GCN row, zeros
-        idx, real = ops.node_index(x, batched_data.time_normal[:, :, 0].float(), self.poi2cat, rows_only,
-                                   batched_data.in_degree, batched_data.out_degree)
+        G, N = batched_data.x.shape[:2]
+        idx, real, rows_only = indices if indices is not None else self.gather_indices(batched_data)
         poi_idx, time_idx, cat_idx, pos_idx, gcn_rows, zero_idx, in_deg, out_deg = idx.unbind(0)
         if self.sparse_adj:
             from .modelGNN import CsrAdj
@@ -346,8 +356,6 @@ class Graphormer(nn.Module):
                                               adj_t=self.D_A_T, mask_adj=mask_adj)                  # :1236
         ops.trace_nan("poidist", poidist)
         catemb = self.poi_cat_model(self.C_X, self.C_A, self.C_AX, adj_t=self.C_A_T)                                    # :1237
-        flush_pending_pack()                    # (if the one-launch GCN did not take the deferred weight pack along)
-        ops.flush_bias_fwd()                    # (... or the deferred bias assembly)
         Wp, Wt, Wc, C = poidist.shape[1], self.time_embed_model_48.weight.shape[1], catemb.shape[1], self.pos_embed.pe.shape[1]
         f4 = self.embed_fuse_model4
         one_launch = G * N <= 4096
@@ -432,17 +440,22 @@ class Graphormer(nn.Module):
 
     def forward(self, batched_data, perturb=None):
         self.validate_batch(batched_data)
-        # (the bias assembly and, below, the weight pack ride in the category GCN's forward launch: node_features flushes both)
-        ops.bias_fwd_deferral(True)
+        # The category GCN (weights only: no batch input; one launch that keeps 19 compute units busy) goes FIRST and carries the
+        # step's other front-of-step launches as passenger workgroups: the hop table's forward, the gather indices, the MFMA-order
+        # pack of the layer weights.  Their ops only leave jobs here (front_deferral / defer_pack); the flushes below launch alone
+        # whatever the GCN could not take along (no one-launch form for this shape, MOBGT_NO_*_PASSENGER switches).
+        ops.front_deferral(True)
         try:
-            bias = self.assemble_bias(batched_data)
+            hop = self.hop_table(batched_data)
+            indices = self.gather_indices(batched_data)
         finally:
-            ops.bias_fwd_deferral(False)
-        # (the MFMA-order pack of the layer weights rides in the category GCN's forward launch: node_features flushes it)
+            ops.front_deferral(False)
         refresh_shadows(self.layers, defer_pack=True)
-        # the category GCN (weights only: no batch input) starts now on a side stream, beside the distance GCN's launches
-        prelaunch_small_gcn(self.poi_cat_model, self.C_X, self.C_A, self.C_AX, self.C_A_T)
-        output = self.node_features(batched_data)
+        prelaunch_small_gcn(self.poi_cat_model, self.C_X, self.C_A, self.C_AX, self.C_A_T, same_stream=True)
+        flush_pending_pack()
+        ops.flush_front()
+        bias = self.assemble_bias(batched_data, hop=hop)
+        output = self.node_features(batched_data, indices=indices)
         ops.trace_nan("x0", output)
         for li, enc_layer in enumerate(self.layers):                                           # :1347-1352
             # (the layer that follows is named so that its QKV projection can ride in this layer's last launch)

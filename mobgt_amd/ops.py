@@ -204,26 +204,29 @@ def pack_bias(attn_bias, G, H, T, dtype=None):
 _BIAS_BWD_JOB = {}
 
 
-# ... and the bias ASSEMBLY can ride in the category GCN's FORWARD launch (mobgt_small_gcn_fwd_pack): a model that will call the
-# one-launch GCN before anything reads the packed bias switches the deferral on around its assemble_bias (bias_fwd_deferral), and
-# calls flush_bias_fwd() in front of the first consumer.  OPT-IN (MOBGT_BIAS_FWD_PASSENGER=1): that launch already carries the
-# weight pack, and with both the passengers outlast the network -- 36.2 us for 27.4 + 7.0 (measured).
-_BIAS_FWD_DEFER = {"on": False, "job": None}
+# Two tiny front-of-step launches -- the hop table's forward and the index derivation of the node features, 4.8 us each, all ramp --
+# ride in the category GCN's forward launch as well: inside front_deferral(True) their ops only allocate their outputs and leave a
+# job (take_front_jobs); the model calls the one-launch GCN next and flush_front() behind it (a job nobody took is launched
+# alone there).  MOBGT_NO_FRONT_PASSENGERS=1: own launches.
+_FRONT_DEFER = {"on": False, "hop": None, "ni": None}
 
 
-def bias_fwd_deferral(on):
-    _BIAS_FWD_DEFER["on"] = bool(on)
+def front_deferral(on):
+    _FRONT_DEFER["on"] = bool(on) and os.environ.get("MOBGT_NO_FRONT_PASSENGERS") != "1"
 
 
-def take_bias_fwd_job():
-    job, _BIAS_FWD_DEFER["job"] = _BIAS_FWD_DEFER["job"], None
-    return job
+def take_front_jobs():
+    hop, ni = _FRONT_DEFER["hop"], _FRONT_DEFER["ni"]
+    _FRONT_DEFER["hop"] = _FRONT_DEFER["ni"] = None
+    return hop, ni
 
 
-def flush_bias_fwd():
-    job = take_bias_fwd_job()
-    if job is not None:
-        check(_lib.lib().mobgt_build_bias(*job[0], _stream()), "mobgt_build_bias")
+def flush_front():
+    hop, ni = take_front_jobs()
+    if hop is not None:
+        check(_lib.lib().mobgt_hop_table_fwd(*hop[0], _stream()), "mobgt_hop_table_fwd")
+    if ni is not None:
+        check(_lib.lib().mobgt_node_index(*ni[0], _stream()), "mobgt_node_index")
 
 
 def _bias_bwd_alloc(shapes, dev, sinks=(None, None, None, None)):
@@ -274,16 +277,9 @@ class _BuildBiasFn(torch.autograd.Function):
         n_poi = poi_table.shape[0] if poi_table is not None else 0
         n_edge = hop_table.shape[1] if has_edge else 0
         args = (G, N, H, D_in, D if has_edge else 0, F, rel_table.shape[0], n_poi, n_edge, pack.ld, idx_dt, edge_dt)
-        fwd_args = [_p(attn_bias), _p(rel_pos), _p(poi_pos), _p(edge_input if has_edge else None), _p(rel_table), _p(poi_table),
-                    _p(hop_table if has_edge else None), _p(vdist), _p(pack.bias), _p(pack.bias_t), *args, _DT[pack.dtype]]
-        flush_bias_fwd()                           # (a deferred assembly nobody picked up)
-        if (_BIAS_FWD_DEFER["on"] and idx_dt == I16 and edge_dt == U8 and pack.dtype == torch.bfloat16 and H == 8
-                and G * (N + 1) * (N + 1) < (1 << 20) and os.environ.get("MOBGT_BIAS_FWD_PASSENGER") == "1"):
-            # left for the category GCN's forward launch to carry (take_bias_fwd_job); the tensors behind the pointers are kept alive
-            _BIAS_FWD_DEFER["job"] = (fwd_args, (attn_bias, rel_pos, poi_pos, edge_input, rel_table, poi_table, hop_table, vdist, pack.bias,
-                                                 pack.bias_t))
-        else:
-            check(_lib.lib().mobgt_build_bias(*fwd_args, _stream()), "mobgt_build_bias")
+        check(_lib.lib().mobgt_build_bias(_p(attn_bias), _p(rel_pos), _p(poi_pos), _p(edge_input if has_edge else None), _p(rel_table),
+                                          _p(poi_table), _p(hop_table if has_edge else None), _p(vdist), _p(pack.bias), _p(pack.bias_t),
+                                          *args, _DT[pack.dtype], _stream()), "mobgt_build_bias")
         ctx.pack, ctx.args = pack, args
         ctx.set_materialize_grads(False)          # the token carries no gradient: no zero-fill launch to materialise one
         ctx.idx = (attn_bias, rel_pos, poi_pos, edge_input if has_edge else None)
@@ -508,8 +504,13 @@ class _HopTableFn(torch.autograd.Function):
         E = edge_weight.shape[0]
         ew, dw = edge_weight.contiguous(), edge_dis_weight.contiguous()
         tab = torch.empty(D, E, H, dtype=torch.float32, device=ew.device)
-        check(_lib.lib().mobgt_hop_table_fwd(_p(ew), _p(dw), _p(tab), D, E, H, int(fp16_roundtrip), _stream()),
-              "mobgt_hop_table_fwd")
+        args = [_p(ew), _p(dw), _p(tab), D, E, H, int(fp16_roundtrip)]
+        if _FRONT_DEFER["on"]:
+            if _FRONT_DEFER["hop"] is not None:
+                flush_front()
+            _FRONT_DEFER["hop"] = (args, (ew, dw, tab))          # (rides in the category GCN's forward launch)
+        else:
+            check(_lib.lib().mobgt_hop_table_fwd(*args, _stream()), "mobgt_hop_table_fwd")
         ctx.save_for_backward(ew, dw)
         ctx.misc = (H, D, int(fp16_roundtrip), edge_dis_weight.shape)
         ctx.sinks = (grad_sink(edge_weight), grad_sink(edge_dis_weight))
@@ -649,9 +650,14 @@ def node_index(x, time_normal, poi2cat, rows_only, in_degree=None, out_degree=No
         in_degree, out_degree = in_degree.reshape(G, N).contiguous(), out_degree.reshape(G, N).contiguous()
         assert in_degree.dtype == out_degree.dtype and in_degree.dtype in _IT
         deg_dt = _IT[in_degree.dtype]
-    check(_lib.lib().mobgt_node_index(_p(x), _IT[x.dtype], x.stride(0), x.stride(1), _p(time_normal), time_normal.stride(0),
-                                      time_normal.stride(1), _p(poi2cat), _p(in_degree), _p(out_degree), deg_dt, _p(idx),
-                                      _p(real), G, N, int(bool(rows_only)), _stream()), "mobgt_node_index")
+    args = [_p(x), _IT[x.dtype], x.stride(0), x.stride(1), _p(time_normal), time_normal.stride(0), time_normal.stride(1), _p(poi2cat),
+            _p(in_degree), _p(out_degree), deg_dt, _p(idx), _p(real), G, N, int(bool(rows_only))]
+    if _FRONT_DEFER["on"]:
+        if _FRONT_DEFER["ni"] is not None:
+            flush_front()
+        _FRONT_DEFER["ni"] = (args, (x, time_normal, poi2cat, in_degree, out_degree, idx, real))     # (see front_deferral)
+    else:
+        check(_lib.lib().mobgt_node_index(*args, _stream()), "mobgt_node_index")
     return idx, real
 
 

@@ -754,9 +754,10 @@ def test_head_chain_equals_the_three_launches(G, T, C, p):
 
 @pytest.mark.gpu
 def test_weight_pack_as_passenger_of_the_category_gcn_launch_equals_the_pack_launch():
-    """mobgt_small_gcn_fwd_pack (csrc/smallgcn.hip + csrc/pack_body.h): the step's MFMA-order weight pack carried by the category
-    GCN's forward launch as passenger workgroups -- packs bit-identical to mobgt_pack_mfma_b's, the network's outputs
-    bit-identical to the launch without passengers."""
+    """mobgt_small_gcn_fwd_pack (csrc/smallgcn.hip + csrc/pack_body.h, front_body.h): the step's MFMA-order weight pack, the node
+    features' index derivation and the hop table's forward carried by the category GCN's forward launch as passenger workgroups
+    -- packs bit-identical to mobgt_pack_mfma_b's, indices to mobgt_node_index's, the hop table to mobgt_hop_table_fwd's, the
+    network's outputs bit-identical to the launch without passengers."""
     import ctypes
     from mobgt_amd import _lib
     from mobgt_amd.ops import _p, _stream
@@ -779,23 +780,47 @@ def test_weight_pack_as_passenger_of_the_category_gcn_launch_equals_the_pack_lau
         return nj, (vp * nj)(*[w.data_ptr() for w, _ in jobs]), (vp * nj)(*[d.data_ptr() for d in dsts]), (ci * nj)(*N), (ci * nj)(*K), \
             (ci * nj)(*[t for _, t in jobs])
 
+    # node_index: 16 trajectories of 20 positions (ragged: pads = 0) over 5000 POIs; hop table: 20 hops x 40 edge ids x 8 heads
+    G, N, P = 16, 20, 5000
+    x = torch.randint(1, P + 1, (G, N), generator=g)
+    x[torch.arange(N)[None, :] >= torch.randint(3, N + 1, (G, 1), generator=g)] = 0
+    x = x.to(DEV)
+    tn = torch.rand(G, N, generator=g).to(DEV)
+    poi2cat = torch.randint(0, 300, (P,), generator=g).to(DEV)
+    indeg, outdeg = (torch.randint(0, 64, (G, N), generator=g).to(DEV) for _ in range(2))
+    D, E, H = 20, 40, 8
+    ew, dw = torch.randn(E, H, generator=g).to(DEV), torch.randn(D * H * H, 1, generator=g).to(DEV)
+
+    def front():
+        idx = torch.full((8, G, N), -7, dtype=torch.int64, device=DEV)
+        real = torch.full((G, N), -7.0, device=DEV)
+        tab = torch.full((D, E, H), -7.0, device=DEV)
+        ni = [_p(x), _lib.I64, x.stride(0), x.stride(1), _p(tn), tn.stride(0), tn.stride(1), _p(poi2cat), _p(indeg), _p(outdeg), _lib.I64,
+              _p(idx), _p(real), G, N, 1]
+        hop = [_p(ew), _p(dw), _p(tab), D, E, H, 1]
+        return (idx, real, tab), ni, hop
+
     def run(with_pack):
         outs = [torch.empty(n, w, device=DEV) for w in (H1, H1, H2, H2, H3)]
+        fr, ni, hop = front()
         dsts = [torch.zeros(w.numel(), dtype=torch.bfloat16, device=DEV) for w, _ in jobs]
         counter = torch.zeros(4, dtype=torch.int32, device=DEV)
         nj, src, dst, N, K, T = arrays(dsts)
         if with_pack:
             _lib.check(lib.mobgt_small_gcn_fwd_pack(_p(AX), _p(A), *[_p(w) for w in ws], *[_p(o) for o in outs], _p(counter), n, K0, H1, H2,
-                                                    H3, 0.2, 0.3, 5, None, 7, nj, src, dst, N, K, T, 0, *([None] * 10), *([0] * 13), _stream()), "fwd_pack")
+                                                    H3, 0.2, 0.3, 5, None, 7, nj, src, dst, N, K, T, 1, *ni, 1, *hop, _stream()), "fwd_pack")
         else:
             _lib.check(lib.mobgt_pack_mfma_b(nj, src, dst, N, K, T, _stream()), "pack")
             _lib.check(lib.mobgt_small_gcn_fwd(_p(AX), _p(A), *[_p(w) for w in ws], *[_p(o) for o in outs], _p(counter), n, K0, H1, H2, H3,
                                                0.2, 0.3, 5, None, 7, _stream()), "fwd")
+            _lib.check(lib.mobgt_node_index(*ni, _stream()), "node_index")
+            _lib.check(lib.mobgt_hop_table_fwd(*hop, _stream()), "hop_table_fwd")
         torch.cuda.synchronize()
-        return outs, dsts
+        return outs + list(fr), dsts
     (o1, d1), (o2, d2) = run(True), run(False)
     for a, b in zip(o1, o2):
         assert torch.equal(a, b)
+    assert int((o1[5] == -7).sum()) == 0 and float(o1[7].abs().sum()) > 0
     for k, (a, b) in enumerate(zip(d1, d2)):
         assert torch.equal(a, b), k
     assert float(d1[0].float().abs().sum()) > 0

@@ -305,31 +305,33 @@ def test_bias_tables_backward_as_passenger_of_the_category_gcn_launch(monkeypatc
 
 
 def test_forward_passengers_of_the_category_gcn_launch_change_nothing(monkeypatch):
-    """The bias assembly and the weight pack carried by the category GCN's forward launch (mobgt_small_gcn_fwd_pack) against
-    their own launches (the bias assembly as a passenger is opt-in, MOBGT_BIAS_FWD_PASSENGER=1; MOBGT_NO_PACK_PASSENGER=1 takes
-    the pack out): bit-identical packed bias and logits."""
+    """The weight pack, the hop table's forward and the gather indices carried by the category GCN's forward launch
+    (mobgt_small_gcn_fwd_pack; the model runs that launch first) against their own launches (MOBGT_NO_PACK_PASSENGER=1,
+    MOBGT_NO_FRONT_PASSENGERS=1): bit-identical logits, hop table and indices -- and the launch did take the jobs."""
     from mobgt_amd import ops, workloads
     uni, model, coll = workloads.build("fsq", "cuda", seed=1, model_overrides=dict(n_layers=2))
     batch = coll(workloads.make_pool("fsq", 1, 16, uni)[0])
     model.eval()
     took = []
-    real_take = ops.take_bias_fwd_job
+    real_take = ops.take_front_jobs
 
     def spy():
-        j = real_take()
-        took.append(j is not None)
-        return j
-    monkeypatch.setattr(ops, "take_bias_fwd_job", spy)
+        hop, ni = real_take()
+        took.append((hop is not None, ni is not None))
+        return hop, ni
+    monkeypatch.setattr(ops, "take_front_jobs", spy)
     outs = []
     for off in ("0", "1"):
-        monkeypatch.setenv("MOBGT_BIAS_FWD_PASSENGER", "1" if off == "0" else "0")
+        monkeypatch.setenv("MOBGT_NO_FRONT_PASSENGERS", off)
         monkeypatch.setenv("MOBGT_NO_PACK_PASSENGER", off)
         with torch.no_grad():
             logits = model(batch)[0]
-            pack = model.assemble_bias(batch)                    # (a direct call: launched at once)
+            hop = model.hop_table(batch)                         # (direct calls: launched at once)
+            idx, real, _ = model.gather_indices(batch)
         torch.cuda.synchronize()
-        outs.append((logits.float().clone(), pack.bias.float().clone()))
-    # (the flushes look too: four looks per pass; a job is found by the GCN's launch in the first pass only)
-    assert len(took) == 8 and sum(took[:4]) == 1 and sum(took[4:]) == 0, took
-    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+        outs.append((logits.float().clone(), hop.clone(), idx.clone(), real.clone()))
+    # (the GCN's launch looks, then the model's flush_front: two looks per pass; the jobs are found by the first look of pass 1)
+    assert took == [(True, True), (False, False), (False, False), (False, False)], took
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
     assert torch.isfinite(outs[0][0]).all()
