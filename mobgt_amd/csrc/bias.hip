@@ -8,6 +8,7 @@
 // attn_bias) are read once, coalesced along j; the outputs are written twice -- row-major for the
 // forward / dQ pass and transposed (through an LDS tile) for the dK/dV pass -- both coalesced.
 #include <cstdlib>
+#include <type_traits>
 #include "common.h"
 #include "mobgt_hip.h"
 
@@ -15,6 +16,9 @@ namespace {
 
 constexpr int TILE = 32;
 constexpr int BIAS_MAXH = 32;
+
+typedef float hb2_t __attribute__((ext_vector_type(2)));
+typedef float hb4_t __attribute__((ext_vector_type(4)));
 
 template <typename T> __device__ __forceinline__ T to_out(float v);
 template <> __device__ __forceinline__ float to_out<float>(float v) { return v; }
@@ -78,21 +82,41 @@ __device__ __forceinline__ float spd_divisor(int rp, int D) {
     return (float)s;
 }
 
-// (bx, by, bz: the workgroup's place in the grid of build_bias_kernel -- or what a passenger workgroup of the category GCN's
-//  forward launch, csrc/smallgcn.hip, derives from its running number)
+// (bx, by, bz: the tile; `fill`: bring the tables into LDS first -- a persistent workgroup of the long-batch form does so once)
 template <typename TI, typename TE, typename TB, int HH, int RND>
-__device__ __forceinline__ void build_bias_body(const BuildParams& p, const int bx, const int by, const int bz) {
+__device__ __forceinline__ void build_bias_body(const BuildParams& p, const int bx, const int by, const int bz, const bool fill = true) {
     // RND = 1: one workgroup = one 8-row round of a 32x32 tile (blockIdx.y = 4 * tile row + round): a short batch
     // (16 graphs x 41 tokens = 64 tiles) still spreads over 256 workgroups.  RND = 4 (long batches): the four rounds of a
     // tile one after the other, so that a row of the transposed copy receives 64 contiguous bytes instead of 16 (with
     // parts compiled out at c5: the 16-byte transposed stores were 132 of the kernel's 442 us, the hop-row gathers 223)
-    __shared__ float tile[HH][8 * RND][TILE + 1];
+    // (long batches keep the tile in the output's own 2-byte type -- rounded once, as the direct copy is: a third less LDS, four
+    //  workgroups per compute unit instead of three; row pitch 17 dwords: the transposed reads of the four 8-row pieces fall
+    //  on disjoint banks)
+    constexpr bool NARROW = RND == 4 && sizeof(TB) == 2;
+    typedef typename std::conditional<NARROW, TB, float>::type TT;
+    __shared__ TT tile[HH][8 * RND][TILE + (NARROW ? 2 : 1)];
     // long batches: the hop-table rows of the small edge ids (transition counts < 16: nearly all of them) wait in LDS --
     // the L1 path then carries only the index loads and the stores, and a hop row arrives in ~64 cycles instead of ~500
     constexpr int HOPL = 16;
     __shared__ __attribute__((aligned(16))) float hop_s[RND == 4 ? 20 : 1][RND == 4 ? HOPL : 1][8];
     const bool hop_lds = RND == 4 && HH == 8 && p.edge_input && p.D <= 20;
-    if (hop_lds) {
+    // ... and so do the leading rows of the two position tables (shortest-path lengths and distance bins are small numbers): a
+    // row costs one LDS round trip instead of a dependent gather through the L1 path (80 of the 229 us left without the hop sum)
+    constexpr int TABL = 128;
+    __shared__ __attribute__((aligned(16))) float tab_s[RND == 4 ? 2 : 1][RND == 4 ? TABL : 1][8];
+    const bool tab_lds = RND == 4 && HH == 8;
+    if (tab_lds && fill) {
+        for (int e = threadIdx.x; e < 2 * TABL * 2; e += 256) {
+            const int t = e / (TABL * 2), id = (e >> 1) % TABL, half = e & 1;
+            const float* tab = t ? p.poi_table : p.rel_table;
+            const int rows = t ? p.n_poi : p.n_rel;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (tab && id < rows) v = *reinterpret_cast<const float4*>(tab + (int64_t)id * 8 + 4 * half);
+            *reinterpret_cast<float4*>(&tab_s[RND == 4 ? t : 0][RND == 4 ? id : 0][4 * half]) = v;
+        }
+        if (!hop_lds) __syncthreads();
+    }
+    if (hop_lds && fill) {
         for (int e = threadIdx.x; e < 20 * HOPL * 2; e += 256) {
             const int d = e / (HOPL * 2), id = (e >> 1) % HOPL, half = e & 1;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -108,14 +132,42 @@ __device__ __forceinline__ void build_bias_body(const BuildParams& p, const int 
     const float inv_f = 1.f / (float)p.F;
     TB* B = reinterpret_cast<TB*>(p.bias);
     TB* BT = reinterpret_cast<TB*>(p.bias_t);
+    // (long batches: the direct copy leaves through the tile as well -- 16-byte stores, four lanes per 64-byte row piece)
+    const bool b_via_lds = NARROW && BT != nullptr;
+    // what a pair reads from HBM, all of it requested at the top of its round (the edge ids used to be requested behind the
+    // position rows: 212 -> 185 us at c5; requesting them a whole round ahead on top of that: no gain, 26 registers)
+    const bool fast_edge = sizeof(TE) == 1 && HH == 8 && p.F == 1 && p.D <= 20 && (p.D_in & 3) == 0 && p.edge_input;
+    struct PairIn { float ab; int rp, pp; uint32_t w[5]; };
+    auto fetch = [&](const int rd, PairIn& q) {
+        const int r = RND == 1 ? (by & 3) * 8 : rd * 8;
+        const int ti = i0 + ty + r, tj = j0 + tx;
+        q.ab = 0.f; q.rp = 0; q.pp = 0;
+#pragma unroll
+        for (int k = 0; k < 5; ++k) q.w[k] = 0u;
+        if (ti < T && tj < T) {
+            q.ab = p.attn_bias[((int64_t)g * T + ti) * T + tj];
+            if (ti >= 1 && tj >= 1) {
+                const int64_t pair = ((int64_t)g * N + (ti - 1)) * N + (tj - 1);
+                q.rp = ld_idx<TI>(p.rel_pos, pair);
+                if (p.poi_pos) q.pp = ld_idx<TI>(p.poi_pos, pair);
+                if (fast_edge) {
+                    const uint8_t* eb = reinterpret_cast<const uint8_t*>(p.edge_input) + pair * p.D_in;
+#pragma unroll
+                    for (int k = 0; k < 5; ++k)
+                        if (4 * k < p.D) q.w[k] = *reinterpret_cast<const uint32_t*>(eb + 4 * k);
+                }
+            }
+        }
+    };
 #pragma unroll 1
     for (int rd = 0; rd < RND; ++rd) {
         const int r = RND == 1 ? (by & 3) * 8 : rd * 8;
         const int ti = i0 + ty + r, tj = j0 + tx;                // token indices
         float acc[HH];
         bool live = ti < T && tj < T;
-        float ab = 0.f;
-        if (live) ab = p.attn_bias[((int64_t)g * T + ti) * T + tj];
+        PairIn in;
+        fetch(rd, in);
+        const float ab = in.ab;
 #pragma unroll
         for (int h = 0; h < HH; ++h) acc[h] = live ? 2.f * ab : -INFINITY;     // attn_bias counted twice (model.py:127,190)
         if (live && ti >= 1 && tj == 0) {
@@ -124,13 +176,13 @@ __device__ __forceinline__ void build_bias_body(const BuildParams& p, const int 
         }
         if (live && ti >= 1 && tj >= 1) {
             const int64_t pair = ((int64_t)g * N + (ti - 1)) * N + (tj - 1);
-            const int rp = ld_idx<TI>(p.rel_pos, pair);
-            const float* rrow = p.rel_table + (int64_t)rp * HH;
+            const int rp = in.rp;
+            const float* rrow = tab_lds && rp < TABL ? &tab_s[0][RND == 4 ? rp : 0][0] : p.rel_table + (int64_t)rp * HH;
 #pragma unroll
             for (int h = 0; h < HH; ++h) acc[h] += rrow[h];
             if (p.poi_pos) {
-                const int pp = ld_idx<TI>(p.poi_pos, pair);
-                const float* prow = p.poi_table + (int64_t)pp * HH;
+                const int pp = in.pp;
+                const float* prow = tab_lds && pp < TABL ? &tab_s[RND == 4 ? 1 : 0][RND == 4 ? pp : 0][0] : p.poi_table + (int64_t)pp * HH;
 #pragma unroll
                 for (int h = 0; h < HH; ++h) acc[h] += prow[h];
             }
@@ -139,35 +191,67 @@ __device__ __forceinline__ void build_bias_body(const BuildParams& p, const int 
 #pragma unroll
                 for (int h = 0; h < HH; ++h) e[h] = 0.f;
                 const int64_t ebase = pair * p.D_in * p.F;
-                if (sizeof(TE) == 1 && HH == 8 && p.F == 1 && p.D <= 20 && (p.D_in & 3) == 0) {
+                if (fast_edge) {
                     // The MobGT case.  The plain loop below is D dependent round trips (id -> table row): the ids
                     // arrive as 5 dwords, then the rows are requested five hops at a time (same summation order).
                     uint32_t w[5];
 #pragma unroll
-                    for (int k = 0; k < 5; ++k)
-                        w[k] = 4 * k < p.D ? *reinterpret_cast<const uint32_t*>(reinterpret_cast<const uint8_t*>(p.edge_input) + ebase + 4 * k) : 0u;
+                    for (int k = 0; k < 5; ++k) w[k] = in.w[k];
+                    // (the sums run on pairs of heads: v_pk_add_f32, same order of additions per head)
+                    hb2_t e2[4];
 #pragma unroll
-                    for (int d0 = 0; d0 < 20; d0 += 5) {
-                        float4 lo[5], hi[5];
+                    for (int q = 0; q < 4; ++q) e2[q] = hb2_t{0.f, 0.f};
+                    if (hop_lds && __all(((w[0] | w[1] | w[2] | w[3] | w[4]) & 0xF0F0F0F0u) == 0u)) {
+                        // every id of the wave's pairs is small: all 20 rows from LDS, no per-hop branch (rows of hops >= D are zero)
 #pragma unroll
-                        for (int j = 0; j < 5; ++j) {
-                            const int d = d0 + j;
-                            const int idx = (int)((w[d >> 2] >> (8 * (d & 3))) & 0xffu);
-                            if (hop_lds && idx < HOPL) {
-                                const float4* hrow = reinterpret_cast<const float4*>(&hop_s[RND == 4 ? d : 0][RND == 4 ? idx : 0][0]);
-                                lo[j] = hrow[0];
-                                hi[j] = hrow[1];
-                            } else {
-                                const float4* hrow = reinterpret_cast<const float4*>(p.hop_table + ((int64_t)(d < p.D ? d : 0) * p.n_edge + idx) * 8);
+                        for (int d0 = 0; d0 < 20; d0 += 5) {
+                            hb4_t lo[5], hi[5];
+#pragma unroll
+                            for (int j = 0; j < 5; ++j) {
+                                const int d = d0 + j;
+                                const int idx = (int)((w[d >> 2] >> (8 * (d & 3))) & 0xffu);
+                                const hb4_t* hrow = reinterpret_cast<const hb4_t*>(&hop_s[RND == 4 ? d : 0][RND == 4 ? idx : 0][0]);
                                 lo[j] = hrow[0];
                                 hi[j] = hrow[1];
                             }
+#pragma unroll
+                            for (int j = 0; j < 5; ++j) {
+                                e2[0] += __builtin_shufflevector(lo[j], lo[j], 0, 1);
+                                e2[1] += __builtin_shufflevector(lo[j], lo[j], 2, 3);
+                                e2[2] += __builtin_shufflevector(hi[j], hi[j], 0, 1);
+                                e2[3] += __builtin_shufflevector(hi[j], hi[j], 2, 3);
+                            }
+                            __builtin_amdgcn_sched_barrier(0);       // (five hops' rows in flight, not twenty: registers)
                         }
 #pragma unroll
-                        for (int j = 0; j < 5; ++j) {
-                            if (d0 + j < p.D) {
-                                e[0] += lo[j].x; e[1] += lo[j].y; e[2] += lo[j].z; e[3] += lo[j].w;
-                                e[HH > 4 ? 4 : 0] += hi[j].x; e[HH > 5 ? 5 : 0] += hi[j].y; e[HH > 6 ? 6 : 0] += hi[j].z; e[HH > 7 ? 7 : 0] += hi[j].w;
+                        for (int q = 0; q < 4; ++q) {
+                            e[HH > 2 * q ? 2 * q : 0] = e2[q].x;
+                            e[HH > 2 * q + 1 ? 2 * q + 1 : 0] = e2[q].y;
+                        }
+                    } else {
+#pragma unroll
+                        for (int d0 = 0; d0 < 20; d0 += 5) {
+                            float4 lo[5], hi[5];
+#pragma unroll
+                            for (int j = 0; j < 5; ++j) {
+                                const int d = d0 + j;
+                                const int idx = (int)((w[d >> 2] >> (8 * (d & 3))) & 0xffu);
+                                if (hop_lds && idx < HOPL) {
+                                    const float4* hrow = reinterpret_cast<const float4*>(&hop_s[RND == 4 ? d : 0][RND == 4 ? idx : 0][0]);
+                                    lo[j] = hrow[0];
+                                    hi[j] = hrow[1];
+                                } else {
+                                    const float4* hrow = reinterpret_cast<const float4*>(p.hop_table + ((int64_t)(d < p.D ? d : 0) * p.n_edge + idx) * 8);
+                                    lo[j] = hrow[0];
+                                    hi[j] = hrow[1];
+                                }
+                            }
+#pragma unroll
+                            for (int j = 0; j < 5; ++j) {
+                                if (d0 + j < p.D) {
+                                    e[0] += lo[j].x; e[1] += lo[j].y; e[2] += lo[j].z; e[3] += lo[j].w;
+                                    e[HH > 4 ? 4 : 0] += hi[j].x; e[HH > 5 ? 5 : 0] += hi[j].y; e[HH > 6 ? 6 : 0] += hi[j].z; e[HH > 7 ? 7 : 0] += hi[j].w;
+                                }
                             }
                         }
                     }
@@ -187,12 +271,21 @@ __device__ __forceinline__ void build_bias_body(const BuildParams& p, const int 
         }
 #pragma unroll
         for (int h = 0; h < HH; ++h) {
-            tile[h][RND == 1 ? ty : ty + r][tx] = acc[h];
-            if (ti < T && tj < p.ld) B[(((int64_t)g * HH + h) * T + ti) * p.ld + tj] = to_out<TB>(acc[h]);
+            tile[h][RND == 1 ? ty : ty + r][tx] = (TT)acc[h];
+            if (ti < T && tj < p.ld && !b_via_lds) B[(((int64_t)g * HH + h) * T + ti) * p.ld + tj] = to_out<TB>(acc[h]);
         }
     }
     if (!BT) return;
     __syncthreads();
+    if (b_via_lds) {
+        for (int e = threadIdx.x; e < HH * TILE * 4; e += 256) {
+            const int c8 = e & 3, row = (e >> 2) % TILE, h = e / (4 * TILE);
+            const int ti = i0 + row;
+            if (ti >= T) continue;
+            const uint32_t* src = reinterpret_cast<const uint32_t*>(&tile[h][row][c8 * 8]);
+            *reinterpret_cast<uint4*>(B + (((int64_t)g * HH + h) * T + ti) * p.ld + j0 + c8 * 8) = make_uint4(src[0], src[1], src[2], src[3]);
+        }
+    }
     // transposed copy: row tj of bias_t receives the 8 * RND consecutive queries of this workgroup, 8 per thread
     for (int e = threadIdx.x; e < HH * TILE * RND; e += 256) {
         const int piece = e % RND, c = (e / RND) % TILE, h = e / (RND * TILE);
@@ -204,7 +297,7 @@ __device__ __forceinline__ void build_bias_body(const BuildParams& p, const int 
         TB* dst = BT + (((int64_t)g * HH + h) * T + tj) * p.ld + i0 + r;
         float v8[8];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) v8[q] = tile[h][(RND == 1 ? 0 : r) + q][c];
+        for (int q = 0; q < 8; ++q) v8[q] = (float)tile[h][(RND == 1 ? 0 : r) + q][c];
         store8(dst, v8);
     }
 }
@@ -379,6 +472,27 @@ __host__ __device__ inline int bwd_lds_dwords(int lds_rel, int lds_poi, int D, i
 // 4-wave form needed 78 KB of LDS and 308 registers, i.e. ran one wave per SIMD with every latency exposed).
 template <typename TI, typename TE, typename TB, int HH, int RND>
 __global__ __launch_bounds__(256) void build_bias_kernel(const BuildParams p) {
+    if (RND == 4) {
+        // long batches, a 1-D launch: the four tiles of a 2 x 2 group -- which share every 128-byte line of the two copies, 64
+        // bytes each -- run on ONE XCD in adjacent dispatch slots (workgroups go round-robin over the 8 XCDs), so that its L2
+        // merges the halves before the line is written back
+        // ... and the workgroups are persistent (gridDim.x = a multiple of 32): the tables are brought into LDS once per
+        // workgroup, not once per tile (18 KB x 10.8 k tiles at c5)
+        const int nt = (int)(p.ld / TILE), nt2 = (nt + 1) / 2;
+        const int lid = (int)blockIdx.x;
+        const int xcd = lid & 7, slot = lid >> 3, sub = slot & 3;
+        const int ngrp = nt2 * nt2 * p.G, nq = (int)gridDim.x >> 2;
+        bool fill = true;
+        for (int grp = (slot >> 2) * 8 + xcd; grp < ngrp; grp += nq) {
+            const int bx = 2 * (grp % nt2) + (sub & 1), by = 2 * ((grp / nt2) % nt2) + (sub >> 1), bz = grp / (nt2 * nt2);
+            if (bx < nt && by < nt) {                       // (workgroup-uniform)
+                build_bias_body<TI, TE, TB, HH, RND>(p, bx, by, bz, fill);
+                fill = false;
+                __syncthreads();                            // (the tile is reused)
+            }
+        }
+        return;
+    }
     build_bias_body<TI, TE, TB, HH, RND>(p, (int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z);
 }
 
@@ -742,7 +856,13 @@ int launch_build(const BuildParams& p, hipStream_t st) {
     (void)T;
     const dim3 grid(nt, 4 * nt, p.G), block(256);
     if (p.H == 8 && (int64_t)p.G * T * T >= (1 << 20)) {
-        const dim3 grid4(nt, nt, p.G);
+        const int nt2 = (nt + 1) / 2;
+        int dev = 0, cus = 256;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
+        int64_t want = (int64_t)nt2 * nt2 * p.G * 4;
+        const int64_t resident = (sizeof(TB) == 2 ? 4 : 3) * (int64_t)cus;     // (35 KB of LDS per workgroup; 52 KB with an f32 tile)
+        if (want > resident) want = resident;
+        const dim3 grid4((unsigned)((want + 31) / 32 * 32));
         hipLaunchKernelGGL((build_bias_kernel<TI, TE, TB, 8, 4>), grid4, block, 0, st, p);
     } else if (p.H == 8) hipLaunchKernelGGL((build_bias_kernel<TI, TE, TB, 8, 1>), grid, block, 0, st, p);
     else if (p.H == 4) hipLaunchKernelGGL((build_bias_kernel<TI, TE, TB, 4, 1>), grid, block, 0, st, p);

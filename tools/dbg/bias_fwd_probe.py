@@ -1,0 +1,53 @@
+"""Developer tool: build_bias forward alone at the c5-like shape: id statistics of the batch, a digest of the packed bias (to
+compare kernel variants bit for bit) and REPS launches for rocprofv3 --kernel-trace."""
+import os, sys, hashlib
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import torch
+from mobgt_amd import synth
+from mobgt_amd.data import DeviceCollator, make_bin_table
+from mobgt_amd.model_fqandtoyo import Graphormer
+from mobgt_amd.workloads import FSQ_MODEL_ARGS
+torch.manual_seed(0)
+P, N, G = 7856, int(os.environ.get("N", 784)), 16
+dev = torch.device("cuda", 0)
+uni = synth.make_universe(P=P, n_cat=300, n_user=1080, seed=1)
+nb, _, table = make_bin_table(uni.distance)
+args = dict(FSQ_MODEL_ARGS); args.update(n_layers=1, hidden_dim=192, multi_hop_max_dist=20)
+model = Graphormer(universe=uni, num_bins=nb + 2, bias_dtype=torch.bfloat16, gcn_dtype=torch.bfloat16, act_dtype=torch.bfloat16, **args).to(dev)
+coll = DeviceCollator(dev, bin_table=table)
+batch = coll(synth.make_batch_of_trajectories(seed=5, G=G, P=P, n_user=1080, cat_of_poi=uni.cat_of_poi, n_nodes=[N] * G))
+e = batch.edge_input[..., 0] if batch.edge_input.dim() == 5 else batch.edge_input
+e = e[:, :, :, :20].long()
+print("edge_input", tuple(batch.edge_input.shape), batch.edge_input.dtype, "n_edge", model.edge_encoder.weight.shape[0])
+print("ids == 0: %.4f   ids >= 16: %.5f   ids >= 32: %.5f   max %d" % (float((e == 0).float().mean()), float((e >= 16).float().mean()),
+                                                                   float((e >= 32).float().mean()), int(e.max())))
+allz = (e == 0).all(-1)
+print("pairs with all 20 hops zero: %.4f" % float(allz.float().mean()))
+nz = (e != 0).sum(-1)
+print("hops per pair histogram:", torch.bincount(nz.reshape(-1), minlength=21).tolist())
+# per wave of the kernel (2 query rows x 32 keys): all-zero words
+w = (e.view(G, N, N, 5, 4) != 0).any(-1)                                   # [G,N,N,5] word non-zero
+Np = (N // 32) * 32
+wv = w[:, :Np - Np % 2, :Np].reshape(G, Np // 2, 2, Np // 32, 32, 5).any(4).any(2)
+print("wave-level non-zero words (of 5): mean %.3f" % float(wv.float().sum(-1).mean()))
+print("hop row 0 all zero:", bool((model.edge_encoder.weight[0] == 0).all()))
+with torch.no_grad():
+    for rep in range(int(os.environ.get("REPS", 5))):
+        pack = model.assemble_bias(batch)
+torch.cuda.synchronize()
+h = hashlib.sha256(pack.bias.view(torch.int16).cpu().numpy().tobytes()).hexdigest()[:16]
+ht = hashlib.sha256(pack.bias_t.view(torch.int16).cpu().numpy().tobytes()).hexdigest()[:16] if pack.bias_t is not None else None
+print("digest", h, ht)
+rp, pp = batch.rel_pos.long(), batch.poi_pos.long()
+print("rel_pos: n_rel %d  max %d  >=64: %.4f  >=128: %.4f   poi_pos: n_poi %d  max %d  >=64: %.4f" % (
+    model.rel_pos_encoder.weight.shape[0], int(rp.max()), float((rp >= 64).float().mean()), float((rp >= 128).float().mean()),
+    model.poi_pos_encoder.weight.shape[0], int(pp.max()), float((pp >= 64).float().mean())))
+VARS = [int(v) for v in os.environ.get("VARS", "0,64").split(",")]
+print("interleaved variants", VARS, "x 5 (after the 5 launches above)")
+for rep in range(5):
+    for dbg in VARS:
+        os.environ["MOBGT_BIAS_DBG"] = str(dbg)
+        with torch.no_grad():
+            pack = model.assemble_bias(batch)
+torch.cuda.synchronize()
+os.environ["MOBGT_BIAS_DBG"] = "0"
