@@ -277,6 +277,12 @@ int mobgt_skinny_linear_dx(const float* dy, const float* w, float* dx, int G, in
  * K % 16 == 0), dw = dy^T x [V,K] (overwritten), db = column sums of dy [V] or NULL. */
 int mobgt_skinny_linear_bwd_both(const float* dy, const float* x, const float* w, float* dx, float* dw, float* db,
                                  int G, int K, int V, void* stream);
+/* The classifier and its loss in one launch (training; model_fqandtoyo.py:1394 + GradientTailLoss :545-550 as called at
+ * :1446-1460): logits = x w^T + b [G,V] (stored only when `logits` != NULL), *loss = mean GradientTailLoss(logits, class of row g
+ * = targets[g] + target_offset, alpha), dlogits [G,V] = d loss / d logits.  G <= 16, K % 64 == 0, K <= 448; x, w 16-byte
+ * aligned.  Same formulas as mobgt_gradient_tail_loss; the loss's partial sums are added in a fixed order. */
+int mobgt_skinny_linear_gtl(const float* x, const float* w, const float* b, const int64_t* targets, int64_t target_offset,
+                            float* logits, float* dlogits, float* loss, int G, int K, int V, float alpha, void* stream);
 
 /* Rows of a bf16 matrix a [*, ld] gathered and transposed in one pass: out_rows [R, C] = a[rows[j], 0:C] and
  * out_t [C, R] = out_rows^T (the operands of the "rows only" last GCN layer, modelGNN.py:38-44 restricted to the

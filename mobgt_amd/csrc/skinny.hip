@@ -254,6 +254,132 @@ __global__ __launch_bounds__(256) void skinny_zero_kernel(float* __restrict__ p,
     if (i < n) p[i] = 0.f;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The classifier and its loss in ONE launch (training): logits = x W^T + b on the matrix cores, and GradientTailLoss
+// (model_fqandtoyo.py:545-550, elementwise on sigmoid(logit): csrc/layer.hip gtl_kernel's formulas) applied in the epilogue --
+// d loss / d logits and the loss's partial sums leave the kernel, the logits only when asked for.  The library GEMM (9.2 us at
+// G = 16, K = 320, V = 7856) + the loss kernel (9.1 us) were two launches that are mostly ramp.
+// A wave owns 16 output columns: C[g][v] = sum_k x[g][k] W[v][k] is v_mfma_f32_16x16x4_f32 with A = x (rows g), B = W^T
+// (columns v); lane (j = lane & 15, q = lane >> 4) streams W[v0 + j][16 s + 4 q .. + 3], s < K / 16 -- per load instruction the
+// four q of a weight row read 64 contiguous bytes (a first version gave each lane 64 contiguous bytes, i.e. 64 scattered
+// 16-byte pieces per instruction: 17 us) -- all K / 16 pieces in flight at once; x waits in LDS and is read in the same k order.
+constexpr int FG_WAVES = 2;                  // 32 columns per workgroup: 246 workgroups at V = 7856
+constexpr int FG_MAXB = 2048;
+// The loss's cross-workgroup sum WITHOUT a fence (an agent-scope release writes this XCD's whole L2 back: ~10 us, which is most
+// of what gtl_kernel's 9.1 us were): every workgroup makes ONE 64-bit atomic add that carries its arrival (bits 0-11) and its
+// partial sum in fixed point (bits 12-63, 2^-24 units: integer addition, so the total does not depend on the arrival order);
+// the workgroup whose add returns the last count holds the complete sum in that very return value.  246 adds on ONE address cost
+// 3.5 us (measured), so there are two levels: eight cells 256 bytes apart (workgroup b -> cell b % 8) whose last arrivers add
+// their cell's total into a ninth; its last arriver writes the loss, and every last arriver re-arms its cell.  Partial sums are
+// >= 0; one that is not finite or >= 2^16 (512 losses: a diverged run) raises fg_bad and the loss reads +inf -- so the field
+// cannot overflow (2048 x 2^16 x 2^24 < 2^52).
+__device__ unsigned long long fg_cell[9 * 32];
+__device__ unsigned int fg_bad = 0u;
+
+template <int KT>
+__global__ __launch_bounds__(64 * FG_WAVES) void skinny_fwd_gtl_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                                      const float* __restrict__ b, const int64_t* __restrict__ target,
+                                                                      int64_t target_offset, float* __restrict__ y,
+                                                                      float* __restrict__ dz, float* __restrict__ loss, int G, int V,
+                                                                      float alpha) {
+    constexpr int K = 64 * KT, LDX = K + 4;
+    __shared__ __attribute__((aligned(16))) float xs[GMAX][LDX];
+    __shared__ float part[FG_WAVES];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = lane & 15, q = lane >> 4;
+    const int v0 = ((int)blockIdx.x * FG_WAVES + wave) * 16;
+    const int v = v0 + j;
+    // this lane's weights: all in flight before anything else
+    float4 wr[4 * KT];
+    {
+        const float* wrow = w + (int64_t)(v < V ? v : 0) * K + 4 * q;
+#pragma unroll
+        for (int s_ = 0; s_ < 4 * KT; ++s_)
+            wr[s_] = v < V ? *reinterpret_cast<const float4*>(wrow + 16 * s_) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    const float bv = (b && v < V) ? b[v] : 0.f;
+    int64_t tgt[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) tgt[i] = 4 * q + i < G ? target[4 * q + i] + target_offset : -1;
+    for (int e = threadIdx.x; e < GMAX * (K / 4); e += 64 * FG_WAVES) {
+        const int g = e / (K / 4), c = e % (K / 4);
+        *reinterpret_cast<float4*>(&xs[g][4 * c]) = g < G ? *reinterpret_cast<const float4*>(x + (int64_t)g * K + 4 * c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    __syncthreads();
+    f32x4_ acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s_ = 0; s_ < 4 * KT; ++s_) {
+        const float4 a = *reinterpret_cast<const float4*>(&xs[j][16 * s_ + 4 * q]);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, wr[s_].x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, wr[s_].y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, wr[s_].z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, wr[s_].w, acc, 0, 0, 0);
+    }
+    // lane (j, q) holds C[4 q + i][v0 + j], i < 4
+    const float inv_n = 1.f / ((float)G * (float)V);
+    float lsum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int g = 4 * q + i;
+        if (g >= G || v >= V) continue;
+        const float z = acc[i] + bv;
+        if (y) y[(int64_t)g * V + v] = z;
+        const float p = 1.f / (1.f + __expf(-z));
+        const float pq = 1.f - p;
+        float l, d;
+        if (tgt[i] == v) {
+            const float lp = logf(p);
+            l = -alpha * pq * lp;
+            d = alpha * p * pq * lp - alpha * pq * pq;
+        } else {
+            const float lq = logf(pq);
+            l = -p * lq;
+            d = -p * pq * lq + p * p;
+        }
+        lsum += l;
+        dz[(int64_t)g * V + v] = d * inv_n;
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) lsum += __shfl_xor(lsum, o, 64);
+    if (lane == 0) part[wave] = lsum;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < FG_WAVES; ++k) s += part[k];
+        const bool ok = s >= 0.f && s < 65536.f;                          // (false for NaN)
+        if (!ok) {
+            __hip_atomic_fetch_or(&fg_bad, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __threadfence();                                              // (the rare path may pay for the ordering)
+        }
+        const unsigned long long add = 1ull | ((ok ? (unsigned long long)(s * 16777216.f) : 0ull) << 12);
+        const unsigned int nb = gridDim.x, c = blockIdx.x & 7u;
+        const unsigned int n_c = (nb - c + 7u) >> 3;                      // workgroups that report to cell c
+        const unsigned long long old = __hip_atomic_fetch_add(&fg_cell[32 * c], add, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((old & 0xFFFull) == (unsigned long long)n_c - 1ull) {
+            __hip_atomic_store(&fg_cell[32 * c], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned long long add2 = 1ull | (((old + add) >> 12) << 12);
+            const unsigned long long old2 = __hip_atomic_fetch_add(&fg_cell[32 * 8], add2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if ((old2 & 0xFFFull) == (unsigned long long)(nb < 8u ? nb : 8u) - 1ull) {
+                const unsigned long long tot = (old2 + add2) >> 12;
+                const unsigned int bad = __hip_atomic_exchange(&fg_bad, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                *loss = bad ? INFINITY : (float)((double)tot * (1.0 / 16777216.0) * (double)inv_n);
+                __hip_atomic_store(&fg_cell[32 * 8], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    }
+}
+
+template <int KT>
+int launch_fwd_gtl(const float* x, const float* w, const float* b, const int64_t* target, int64_t target_offset, float* y, float* dz,
+                   float* loss, int G, int V, float alpha, hipStream_t st) {
+    const int blocks = (V + 16 * FG_WAVES - 1) / (16 * FG_WAVES);
+    if (blocks > FG_MAXB) return MOBGT_EBADDIM;
+    hipLaunchKernelGGL((skinny_fwd_gtl_kernel<KT>), dim3(blocks), dim3(64 * FG_WAVES), 0, st, x, w, b, target, target_offset, y, dz, loss,
+                       G, V, alpha);
+    return (int)hipGetLastError();
+}
+
 int check_dims(int G, int K, int V) {
     if (G <= 0 || G > GMAX || K <= 0 || K > 256 * KCH || (K & 3) || V <= 0) return MOBGT_EBADDIM;
     return 0;
@@ -303,4 +429,24 @@ extern "C" int mobgt_skinny_linear_bwd_both(const float* dy, const float* x, con
     const int blocks = (K / 16) * DXM_VSPLIT + (V + DW_ROWS - 1) / DW_ROWS;
     hipLaunchKernelGGL(skinny_bwd_both_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dy, x, w, dx, dw, db, G, K, V);
     return (int)hipGetLastError();
+}
+
+/* logits = x w^T + b, loss = GradientTailLoss(logits, target + target_offset, alpha) and dlogits = d loss / d logits in one
+ * launch (K % 64 == 0, K <= 448; logits may be NULL).  Not re-entrant across streams (one ticket). */
+extern "C" int mobgt_skinny_linear_gtl(const float* x, const float* w, const float* b, const int64_t* targets, int64_t target_offset,
+                                       float* logits, float* dlogits, float* loss, int G, int K, int V, float alpha, void* stream) {
+    const int rc = check_dims(G, K, V);
+    if (rc) return rc;
+    if ((K & 63) || K > 448 || !dlogits || !loss || !targets) return MOBGT_EBADDIM;
+    if (((uintptr_t)x | (uintptr_t)w) & 15) return MOBGT_EALIGN;
+    hipStream_t st = (hipStream_t)stream;
+    switch (K / 64) {
+        case 1: return launch_fwd_gtl<1>(x, w, b, targets, target_offset, logits, dlogits, loss, G, V, alpha, st);
+        case 2: return launch_fwd_gtl<2>(x, w, b, targets, target_offset, logits, dlogits, loss, G, V, alpha, st);
+        case 3: return launch_fwd_gtl<3>(x, w, b, targets, target_offset, logits, dlogits, loss, G, V, alpha, st);
+        case 4: return launch_fwd_gtl<4>(x, w, b, targets, target_offset, logits, dlogits, loss, G, V, alpha, st);
+        case 5: return launch_fwd_gtl<5>(x, w, b, targets, target_offset, logits, dlogits, loss, G, V, alpha, st);
+        case 6: return launch_fwd_gtl<6>(x, w, b, targets, target_offset, logits, dlogits, loss, G, V, alpha, st);
+        default: return launch_fwd_gtl<7>(x, w, b, targets, target_offset, logits, dlogits, loss, G, V, alpha, st);
+    }
 }

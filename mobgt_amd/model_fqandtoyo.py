@@ -484,6 +484,12 @@ class Graphormer(nn.Module):
             tok = fuse3(output[:, 0, :].float(), user_embedding)                               # :1353-1358, q = 0 only
             tok = ops.dropout(self.ELU(self.final_ln(tok)), self.output_dropout.p, self.training, 0x1004)   # :1360-1364
         ops.trace_nan("tok", tok)
+        y_head = getattr(self, "_loss_in_head", None)
+        if y_head is not None and ops.skinny_linear_gtl_ok(tok, self.out_proj.weight):
+            # training_step: the classifier and GradientTailLoss(alpha = 0.2) on y - 1 (:1394, :1446-1460) in ONE launch; the
+            # logits are never stored
+            self._head_loss = ops.skinny_linear_gtl(tok, self.out_proj.weight, self.out_proj.bias, y_head, 0.2, target_offset=-1)
+            return [None, None]
         if ops.skinny_linear_ok(tok, self.out_proj.weight):
             logits = ops.skinny_linear(tok, self.out_proj.weight, self.out_proj.bias)      # :1394, M = G rows
         else:
@@ -500,10 +506,15 @@ class Graphormer(nn.Module):
     def training_step(self, batched_data, batch_idx=0):
         """model_fqandtoyo.py:1446-1460: y-1 targets, GradientTailLoss(alpha=0.2) on the POI logits only."""
         self._poi_logits_only = True
+        self._loss_in_head = batched_data.y              # (forward() may fold the loss into the classifier's launch)
         try:
             y_hat = self(batched_data)[0]
         finally:
             self._poi_logits_only = False
+            self._loss_in_head = None
+        loss = self.__dict__.pop("_head_loss", None)
+        if loss is not None:
+            return loss
         return ops.gradient_tail_loss(y_hat, batched_data.y, 0.2, target_offset=-1)
 
     def validation_step(self, batched_data, batch_idx=0):

@@ -570,32 +570,83 @@ class _SkinnyLinearFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
-        x, w = ctx.saved_tensors
+        return _skinny_backward(ctx, dy)
+
+
+def _skinny_backward(ctx, dy):
+    """dx, dW, db of y = x W^T + b for `dy` (shared by _SkinnyLinearFn and _SkinnyLinearGtlFn; ctx: saved (x, w), all_hip,
+    has_bias, sink, sink_b)."""
+    x, w = ctx.saved_tensors[:2]
+    G, K = x.shape
+    V = w.shape[0]
+    dy = dy.contiguous()
+    dx = None
+    dx_mfma = ctx.needs_input_grad[0] and not ctx.all_hip and K % 16 == 0 and K <= 512 and not os.environ.get("MOBGT_SKINNY_DX_LIB")
+    both = dx_mfma and ctx.needs_input_grad[1] and not os.environ.get("MOBGT_SKINNY_TWO_LAUNCHES")
+    if dx_mfma:     # one pass over W at the full L1 rate (the library's 16x16 tiles: 26 us at V = 7857, K = 448)
+        dx = zeros_f32((G, K), x.device)
+        if not both:
+            check(_lib.lib().mobgt_skinny_linear_dx(_p(dy), _p(w), _p(dx), G, K, V, _stream()), "mobgt_skinny_linear_dx")
+    elif ctx.needs_input_grad[0]:
+        dx = torch.empty_like(x) if ctx.all_hip else dy @ w
+    dw = None
+    if ctx.needs_input_grad[1]:
+        dw = ctx.sink[:] if ctx.sink is not None else torch.empty_like(w)      # (a fresh view object of the sink)
+    db = None
+    if ctx.has_bias and ctx.needs_input_grad[2]:      # (written in full by the kernel: the sink needs no zeroing for it)
+        db = ctx.sink_b[:] if ctx.sink_b is not None else torch.empty(V, dtype=torch.float32, device=x.device)
+    if both:        # dx and dW (+ db) share nothing but dy: one launch, the first workgroups run the dx body
+        check(_lib.lib().mobgt_skinny_linear_bwd_both(_p(dy), _p(x), _p(w), _p(dx), _p(dw), _p(db), G, K, V, _stream()),
+              "mobgt_skinny_linear_bwd_both")
+        return dx, dw, db
+    check(_lib.lib().mobgt_skinny_linear_bwd(_p(dy), _p(x), _p(w), _p(dx if ctx.all_hip else None), _p(dw), _p(db),
+                                             G, K, V, _stream()), "mobgt_skinny_linear_bwd")
+    return dx, dw, db
+
+
+class _SkinnyLinearGtlFn(torch.autograd.Function):
+    """loss = GradientTailLoss(x W^T + b, targets + target_offset, alpha) in ONE launch (csrc/skinny.hip:
+    mobgt_skinny_linear_gtl); the backward is the skinny Linear's, fed with the d loss / d logits the forward left behind."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, targets, alpha, target_offset, logits_out):
+        x, w = x.contiguous(), weight.contiguous()
+        if x.data_ptr() % 16:
+            x = x.clone()
         G, K = x.shape
         V = w.shape[0]
-        dy = dy.contiguous()
-        dx = None
-        dx_mfma = ctx.needs_input_grad[0] and not ctx.all_hip and K % 16 == 0 and K <= 512 and not os.environ.get("MOBGT_SKINNY_DX_LIB")
-        both = dx_mfma and ctx.needs_input_grad[1] and not os.environ.get("MOBGT_SKINNY_TWO_LAUNCHES")
-        if dx_mfma:     # one pass over W at the full L1 rate (the library's 16x16 tiles: 26 us at V = 7857, K = 448)
-            dx = zeros_f32((G, K), x.device)
-            if not both:
-                check(_lib.lib().mobgt_skinny_linear_dx(_p(dy), _p(w), _p(dx), G, K, V, _stream()), "mobgt_skinny_linear_dx")
-        elif ctx.needs_input_grad[0]:
-            dx = torch.empty_like(x) if ctx.all_hip else dy @ w
-        dw = None
-        if ctx.needs_input_grad[1]:
-            dw = ctx.sink[:] if ctx.sink is not None else torch.empty_like(w)      # (a fresh view object of the sink)
-        db = None
-        if ctx.has_bias and ctx.needs_input_grad[2]:      # (written in full by the kernel: the sink needs no zeroing for it)
-            db = ctx.sink_b[:] if ctx.sink_b is not None else torch.empty(V, dtype=torch.float32, device=x.device)
-        if both:        # dx and dW (+ db) share nothing but dy: one launch, the first workgroups run the dx body
-            check(_lib.lib().mobgt_skinny_linear_bwd_both(_p(dy), _p(x), _p(w), _p(dx), _p(dw), _p(db), G, K, V, _stream()),
-                  "mobgt_skinny_linear_bwd_both")
-            return dx, dw, db
-        check(_lib.lib().mobgt_skinny_linear_bwd(_p(dy), _p(x), _p(w), _p(dx if ctx.all_hip else None), _p(dw), _p(db),
-                                                 G, K, V, _stream()), "mobgt_skinny_linear_bwd")
-        return dx, dw, db
+        dz = torch.empty(G, V, dtype=torch.float32, device=x.device)
+        loss = torch.empty((), dtype=torch.float32, device=x.device)
+        y = None
+        if logits_out is not None:
+            y = logits_out.t = torch.empty(G, V, dtype=torch.float32, device=x.device)
+        check(_lib.lib().mobgt_skinny_linear_gtl(_p(x), _p(w), _p(bias), _p(targets.long().contiguous()), int(target_offset), _p(y), _p(dz),
+                                                 _p(loss), G, K, V, float(alpha), _stream()), "mobgt_skinny_linear_gtl")
+        ctx.save_for_backward(x, w, dz)
+        ctx.all_hip = False
+        ctx.has_bias = bias is not None
+        ctx.sink = grad_sink(weight)
+        ctx.sink_b = grad_sink(bias) if bias is not None else None
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        dz = ctx.saved_tensors[2]
+        if g.data_ptr() != unit_grad(g.device).data_ptr():      # (the trainer supplies d loss / d loss = 1: no multiply)
+            dz = dz * g
+        return (*_skinny_backward(ctx, dz), None, None, None, None)
+
+
+def skinny_linear_gtl_ok(x, weight):
+    return (skinny_linear_ok(x, weight) and x.shape[1] % 64 == 0 and x.shape[1] <= 448
+            and os.environ.get("MOBGT_NO_FUSED_LOSS") != "1")
+
+
+def skinny_linear_gtl(x, weight, bias, targets, alpha=0.25, target_offset=0, logits_out=None):
+    """gradient_tail_loss(F.linear(x, weight, bias), targets, alpha, target_offset) for the classifier head (G <= 16 rows).
+    `logits_out`: an _OutRef whose `.t` receives the logits (detached), else they are never stored."""
+    _require_cuda(x, weight, targets)
+    return _SkinnyLinearGtlFn.apply(x, weight, bias, targets[: x.shape[0]].reshape(-1), alpha, target_offset, logits_out)
 
 
 def skinny_linear_ok(x, weight):

@@ -824,3 +824,48 @@ def test_weight_pack_as_passenger_of_the_category_gcn_launch_equals_the_pack_lau
     for k, (a, b) in enumerate(zip(d1, d2)):
         assert torch.equal(a, b), k
     assert float(d1[0].float().abs().sum()) > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("G,K,V", [(16, 320, 7856), (5, 448, 1500), (16, 64, 1024)])
+def test_classifier_and_loss_in_one_launch(G, K, V):
+    """mobgt_skinny_linear_gtl (csrc/skinny.hip): out_proj + GradientTailLoss(alpha = 0.2) on y - 1 (model_fqandtoyo.py:1394,
+    :1446-1460, :545-550) in one launch against (a) the torch restatement of the loss on F.linear in float64 and (b) the two
+    launches it replaces -- loss, and the gradients of the tokens, the weight and the bias; V not a multiple of 32, G < 16."""
+    import types
+    from mobgt_amd import ops
+    from mobgt_amd.model_fqandtoyo import GradientTailLoss
+    g = torch.Generator().manual_seed(11)
+    x0 = torch.randn(G, K, generator=g).to(DEV)
+    lin = torch.nn.Linear(K, V).to(DEV)
+    with torch.no_grad():
+        lin.weight.mul_(3.0)                                  # (logits of a few units: both branches of the loss matter)
+    y = torch.randint(1, V + 1, (G, 1), generator=g).to(DEV)
+    assert ops.skinny_linear_gtl_ok(x0, lin.weight)
+    res = []
+    for mode in ("fused", "two", "ref"):
+        lin.weight.grad = lin.bias.grad = None
+        x = x0.clone().requires_grad_(True)
+        keep = types.SimpleNamespace(t=None)
+        if mode == "fused":
+            loss = ops.skinny_linear_gtl(x, lin.weight, lin.bias, y, 0.2, target_offset=-1, logits_out=keep)
+        elif mode == "two":
+            keep.t = ops.skinny_linear(x, lin.weight, lin.bias)
+            loss = ops.gradient_tail_loss(keep.t, y, 0.2, target_offset=-1)
+        else:
+            keep.t = torch.nn.functional.linear(x.double(), lin.weight.double(), lin.bias.double())
+            loss = GradientTailLoss(keep.t, y.view(-1) - 1, alpha=0.2)
+        loss.backward()
+        torch.cuda.synchronize()
+        res.append([loss.detach().double(), keep.t.detach().double(), x.grad.double(), lin.weight.grad.double().clone(), lin.bias.grad.double().clone()])
+    fused, two, ref = res
+    for name, a, b, c in zip(("loss", "logits", "dx", "dW", "db"), fused, two, ref):
+        sc = float(c.abs().max()) + 1e-30
+        assert float((a - c).abs().max()) <= 2e-5 * sc, (name, "vs float64", float((a - c).abs().max()), sc)
+        assert float((a - b).abs().max()) <= 2e-5 * sc, (name, "vs two launches", float((a - b).abs().max()), sc)
+    # without the logits: nothing but the loss and the gradients leave the kernel
+    x = x0.clone().requires_grad_(True)
+    lin.weight.grad = None
+    loss = ops.skinny_linear_gtl(x, lin.weight, lin.bias, y, 0.2, target_offset=-1)
+    loss.backward()
+    assert torch.equal(loss.detach().double(), fused[0]) and torch.equal(lin.weight.grad.double(), fused[3])
