@@ -264,15 +264,15 @@ __global__ __launch_bounds__(256) void skinny_zero_kernel(float* __restrict__ p,
 // four q of a weight row read 64 contiguous bytes (a first version gave each lane 64 contiguous bytes, i.e. 64 scattered
 // 16-byte pieces per instruction: 17 us) -- all K / 16 pieces in flight at once; x waits in LDS and is read in the same k order.
 constexpr int FG_WAVES = 2;                  // 32 columns per workgroup: 246 workgroups at V = 7856
-constexpr int FG_MAXB = 2048;
+constexpr int FG_MAXB = 1024;               // workgroups per launch (a wave walks over its 16-column tiles)
 // The loss's cross-workgroup sum WITHOUT a fence (an agent-scope release writes this XCD's whole L2 back: ~10 us, which is most
 // of what gtl_kernel's 9.1 us were): every workgroup makes ONE 64-bit atomic add that carries its arrival (bits 0-11) and its
 // partial sum in fixed point (bits 12-63, 2^-24 units: integer addition, so the total does not depend on the arrival order);
 // the workgroup whose add returns the last count holds the complete sum in that very return value.  246 adds on ONE address cost
 // 3.5 us (measured), so there are two levels: eight cells 256 bytes apart (workgroup b -> cell b % 8) whose last arrivers add
 // their cell's total into a ninth; its last arriver writes the loss, and every last arriver re-arms its cell.  Partial sums are
-// >= 0; one that is not finite or >= 2^16 (512 losses: a diverged run) raises fg_bad and the loss reads +inf -- so the field
-// cannot overflow (2048 x 2^16 x 2^24 < 2^52).
+// >= 0; one that is not finite or >= 2^18 (a diverged run) raises fg_bad and the loss reads +inf -- so the field cannot
+// overflow (1024 x 2^18 x 2^24 = 2^52).
 __device__ unsigned long long fg_cell[9 * 32];
 __device__ unsigned int fg_bad = 0u;
 
@@ -287,7 +287,13 @@ __global__ __launch_bounds__(64 * FG_WAVES) void skinny_fwd_gtl_kernel(const flo
     __shared__ float part[FG_WAVES];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int j = lane & 15, q = lane >> 4;
-    const int v0 = ((int)blockIdx.x * FG_WAVES + wave) * 16;
+    float lsum = 0.f;
+    const float inv_n = 1.f / ((float)G * (float)V);
+    int64_t tgt[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) tgt[i] = 4 * q + i < G ? target[4 * q + i] + target_offset : -1;
+    bool first = true;
+    for (int v0 = ((int)blockIdx.x * FG_WAVES + wave) * 16; v0 < V || first; v0 += (int)gridDim.x * FG_WAVES * 16) {
     const int v = v0 + j;
     // this lane's weights: all in flight before anything else
     float4 wr[4 * KT];
@@ -298,14 +304,14 @@ __global__ __launch_bounds__(64 * FG_WAVES) void skinny_fwd_gtl_kernel(const flo
             wr[s_] = v < V ? *reinterpret_cast<const float4*>(wrow + 16 * s_) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
     const float bv = (b && v < V) ? b[v] : 0.f;
-    int64_t tgt[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) tgt[i] = 4 * q + i < G ? target[4 * q + i] + target_offset : -1;
-    for (int e = threadIdx.x; e < GMAX * (K / 4); e += 64 * FG_WAVES) {
-        const int g = e / (K / 4), c = e % (K / 4);
-        *reinterpret_cast<float4*>(&xs[g][4 * c]) = g < G ? *reinterpret_cast<const float4*>(x + (int64_t)g * K + 4 * c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    if (first) {                                      // (every wave passes here exactly once: its first tile may lie beyond V)
+        for (int e = threadIdx.x; e < GMAX * (K / 4); e += 64 * FG_WAVES) {
+            const int g = e / (K / 4), c = e % (K / 4);
+            *reinterpret_cast<float4*>(&xs[g][4 * c]) = g < G ? *reinterpret_cast<const float4*>(x + (int64_t)g * K + 4 * c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        __syncthreads();
+        first = false;
     }
-    __syncthreads();
     f32x4_ acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int s_ = 0; s_ < 4 * KT; ++s_) {
@@ -316,8 +322,6 @@ __global__ __launch_bounds__(64 * FG_WAVES) void skinny_fwd_gtl_kernel(const flo
         acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, wr[s_].w, acc, 0, 0, 0);
     }
     // lane (j, q) holds C[4 q + i][v0 + j], i < 4
-    const float inv_n = 1.f / ((float)G * (float)V);
-    float lsum = 0.f;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int g = 4 * q + i;
@@ -339,6 +343,7 @@ __global__ __launch_bounds__(64 * FG_WAVES) void skinny_fwd_gtl_kernel(const flo
         lsum += l;
         dz[(int64_t)g * V + v] = d * inv_n;
     }
+    }
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) lsum += __shfl_xor(lsum, o, 64);
     if (lane == 0) part[wave] = lsum;
@@ -347,7 +352,7 @@ __global__ __launch_bounds__(64 * FG_WAVES) void skinny_fwd_gtl_kernel(const flo
         float s = 0.f;
 #pragma unroll
         for (int k = 0; k < FG_WAVES; ++k) s += part[k];
-        const bool ok = s >= 0.f && s < 65536.f;                          // (false for NaN)
+        const bool ok = s >= 0.f && s < 262144.f;                         // (false for NaN)
         if (!ok) {
             __hip_atomic_fetch_or(&fg_bad, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __threadfence();                                              // (the rare path may pay for the ordering)
@@ -373,8 +378,8 @@ __global__ __launch_bounds__(64 * FG_WAVES) void skinny_fwd_gtl_kernel(const flo
 template <int KT>
 int launch_fwd_gtl(const float* x, const float* w, const float* b, const int64_t* target, int64_t target_offset, float* y, float* dz,
                    float* loss, int G, int V, float alpha, hipStream_t st) {
-    const int blocks = (V + 16 * FG_WAVES - 1) / (16 * FG_WAVES);
-    if (blocks > FG_MAXB) return MOBGT_EBADDIM;
+    int blocks = (V + 16 * FG_WAVES - 1) / (16 * FG_WAVES);
+    if (blocks > FG_MAXB) blocks = FG_MAXB;
     hipLaunchKernelGGL((skinny_fwd_gtl_kernel<KT>), dim3(blocks), dim3(64 * FG_WAVES), 0, st, x, w, b, target, target_offset, y, dz, loss,
                        G, V, alpha);
     return (int)hipGetLastError();

@@ -827,7 +827,7 @@ def test_weight_pack_as_passenger_of_the_category_gcn_launch_equals_the_pack_lau
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("G,K,V", [(16, 320, 7856), (5, 448, 1500), (16, 64, 1024)])
+@pytest.mark.parametrize("G,K,V", [(16, 320, 7856), (5, 448, 1500), (16, 64, 1024), (16, 384, 100001)])
 def test_classifier_and_loss_in_one_launch(G, K, V):
     """mobgt_skinny_linear_gtl (csrc/skinny.hip): out_proj + GradientTailLoss(alpha = 0.2) on y - 1 (model_fqandtoyo.py:1394,
     :1446-1460, :545-550) in one launch against (a) the torch restatement of the loss on F.linear in float64 and (b) the two
