@@ -315,7 +315,10 @@ def pack_layer_weights(layers, defer=False):
                 jobs.append((sh[i], d, sh[i].shape[1], sh[i].shape[0], 1))
             layer._packed_t_fresh = True
     import os
-    if defer and jobs and len(jobs) <= 96 and os.environ.get("MOBGT_NO_PACK_PASSENGER") != "1":
+    # (as a passenger only while the pack is short next to the 26 us host launch: 6.5 M elements at S-FSQ = 11.7 us alone.  At
+    #  S-BIG -- 18.9 M -- the passengers outlasted the network: 102 us for 28 + 37, measured)
+    small = sum(j[2] * j[3] for j in jobs) <= (8 << 20)
+    if defer and jobs and len(jobs) <= 96 and small and os.environ.get("MOBGT_NO_PACK_PASSENGER") != "1":
         _PENDING_PACK.extend(jobs)
     else:
         _launch_pack(jobs)
