@@ -12,10 +12,6 @@ for f in glob.glob("gpurun_out/bfp/**/r_kernel_trace.csv", recursive=True):
         if "build_bias" in r["Kernel_Name"]:
             ts.append((int(r["Start_Timestamp"]), (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3))
 ts = [t for _, t in sorted(ts)]
-print("first 5:", ts[:5])
-V = os.environ.get("VARS", "0,64").split(",")
-rest = ts[5:]
-for k, v in enumerate(V):
-    print("dbg", v, sorted(rest[k::len(V)]))
+print("build_bias launches (us):", ts)
 PY
 rm -rf gpurun_out/bfp
