@@ -454,8 +454,12 @@ class Graphormer(nn.Module):
         prelaunch_small_gcn(self.poi_cat_model, self.C_X, self.C_A, self.C_AX, self.C_A_T, same_stream=True)
         flush_pending_pack()
         ops.flush_front()
-        bias = self.assemble_bias(batched_data, hop=hop)
-        output = self.node_features(batched_data, indices=indices)
+        try:
+            bias = self.assemble_bias(batched_data, hop=hop)
+            output = self.node_features(batched_data, indices=indices)
+        finally:
+            # (a prelaunched result nobody adopted -- an exception on the way -- must not meet a later, direct call of the GCN)
+            self.poi_cat_model.__dict__.pop("_prelaunched", None)
         ops.trace_nan("x0", output)
         for li, enc_layer in enumerate(self.layers):                                           # :1347-1352
             # (the layer that follows is named so that its QKV projection can ride in this layer's last launch)

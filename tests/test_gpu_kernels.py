@@ -405,6 +405,16 @@ def test_build_bias_long_batch_form_matches_the_oracle():
     np.testing.assert_allclose(got[fin].numpy(), r[fin].numpy(), rtol=8e-3, atol=2e-3)          # bf16 storage
     assert torch.equal(pack.bias_t[..., :pack.T].float().cpu(), got.transpose(2, 3))             # 4-round tiles of the long form
     assert bool(torch.isinf(pack.bias_t[..., pack.T:]).all())                                     # padding columns: -inf
+    # the f32 output of the same long form (f32 tile in LDS, 3 workgroups per CU): the oracle's values to f32 accuracy, and the
+    # bf16 pack above is exactly its rounding
+    with torch.no_grad():
+        pack32 = ops.build_bias(b.attn_bias.to(DEV), b.rel_pos.to(DEV).to(torch.int16), b.poi_pos.to(DEV).to(torch.int16),
+                                b.edge_input.to(DEV).to(torch.uint8), dsd["rel_pos_encoder.weight"], dsd["poi_pos_encoder.weight"],
+                                hop.detach(), dsd["graph_token_virtual_distance.weight"], D, dtype=torch.float32)
+    got32 = pack32.dense().cpu()
+    np.testing.assert_allclose(got32[fin].numpy(), r[fin].numpy(), rtol=1e-4, atol=1e-5)
+    assert torch.equal(got32.bfloat16().float()[fin], got[fin])
+    assert torch.equal(pack32.bias_t[..., :pack32.T].cpu(), got32.transpose(2, 3))
     pack.needs_grad = True
     pack.n_use = L
     pack.grad_buffer()[..., :T] = slices.to(DEV)
