@@ -277,6 +277,9 @@ int mobgt_skinny_linear_dx(const float* dy, const float* w, float* dx, int G, in
  * K % 16 == 0), dw = dy^T x [V,K] (overwritten), db = column sums of dy [V] or NULL. */
 int mobgt_skinny_linear_bwd_both(const float* dy, const float* x, const float* w, float* dx, float* dw, float* db,
                                  int G, int K, int V, void* stream);
+/* logits = x w^T + b [G,V] alone on the matrix cores, one pass over w (csrc/skinny.hip; the kernel of mobgt_skinny_linear_gtl
+ * without the loss): G <= 16, K % 64 == 0, K <= 448; x, w 16-byte aligned.  The library's M = 16 GEMM takes 9-29 us here. */
+int mobgt_skinny_linear_fwd_mfma(const float* x, const float* w, const float* b, float* y, int G, int K, int V, void* stream);
 /* The classifier and its loss in one launch (training; model_fqandtoyo.py:1394 + GradientTailLoss :545-550 as called at
  * :1446-1460): logits = x w^T + b [G,V] (stored only when `logits` != NULL), *loss = mean GradientTailLoss(logits, class of row g
  * = targets[g] + target_offset, alpha), dlogits [G,V] = d loss / d logits.  G <= 16, K % 64 == 0, K <= 448; x, w 16-byte

@@ -103,6 +103,7 @@ SIGNATURES = {
     "mobgt_head_chain_bwd": (_i, [_vp] * 5 + [_i, _i64, _i64] + [_vp] * 8 + [_i, _i, _i, _i, _f, _f, _f, _u64, _vp, _c.c_uint32, _vp]),
     "mobgt_token_bwd_chain": (_i, [_vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _i, _i, _i, _i, _f, _f, _f, _f, _u64, _vp,
                                    _c.c_uint32, _c.c_uint32, _c.c_uint32, _vp]),
+    "mobgt_skinny_linear_fwd_mfma": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "mobgt_skinny_linear_gtl": (_i, [_vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _i, _i, _i, _f, _vp]),
     "mobgt_head_input_fwd": (_i, [_vp, _vp, _i, _i64, _vp, _i64, _vp, _i, _i, _i, _i, _vp]),
     "mobgt_head_input_bwd": (_i, [_vp, _vp, _i, _i64, _vp, _vp, _i64, _i, _i, _i, _i, _vp]),

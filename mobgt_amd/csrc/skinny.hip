@@ -291,7 +291,7 @@ __global__ __launch_bounds__(64 * FG_WAVES) void skinny_fwd_gtl_kernel(const flo
     const float inv_n = 1.f / ((float)G * (float)V);
     int64_t tgt[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) tgt[i] = 4 * q + i < G ? target[4 * q + i] + target_offset : -1;
+    for (int i = 0; i < 4; ++i) tgt[i] = (target && 4 * q + i < G) ? target[4 * q + i] + target_offset : -1;
     bool first = true;
     for (int v0 = ((int)blockIdx.x * FG_WAVES + wave) * 16; v0 < V || first; v0 += (int)gridDim.x * FG_WAVES * 16) {
     const int v = v0 + j;
@@ -328,6 +328,7 @@ __global__ __launch_bounds__(64 * FG_WAVES) void skinny_fwd_gtl_kernel(const flo
         if (g >= G || v >= V) continue;
         const float z = acc[i] + bv;
         if (y) y[(int64_t)g * V + v] = z;
+        if (!target) continue;                        // (the plain forward: mobgt_skinny_linear_fwd_mfma)
         const float p = 1.f / (1.f + __expf(-z));
         const float pq = 1.f - p;
         float l, d;
@@ -344,6 +345,7 @@ __global__ __launch_bounds__(64 * FG_WAVES) void skinny_fwd_gtl_kernel(const flo
         dz[(int64_t)g * V + v] = d * inv_n;
     }
     }
+    if (!target) return;
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) lsum += __shfl_xor(lsum, o, 64);
     if (lane == 0) part[wave] = lsum;
@@ -438,12 +440,32 @@ extern "C" int mobgt_skinny_linear_bwd_both(const float* dy, const float* x, con
 
 /* logits = x w^T + b, loss = GradientTailLoss(logits, target + target_offset, alpha) and dlogits = d loss / d logits in one
  * launch (K % 64 == 0, K <= 448; logits may be NULL).  Not re-entrant across streams (one ticket). */
+namespace {
+int fwd_gtl_dispatch(const float* x, const float* w, const float* b, const int64_t* targets, int64_t target_offset, float* logits,
+                     float* dlogits, float* loss, int G, int K, int V, float alpha, void* stream);
+}
+
+/* y = x w^T + b alone, by the same kernel (K % 64 == 0, K <= 448): one pass over w on the matrix cores. */
+extern "C" int mobgt_skinny_linear_fwd_mfma(const float* x, const float* w, const float* b, float* y, int G, int K, int V, void* stream) {
+    const int rc = check_dims(G, K, V);
+    if (rc) return rc;
+    if ((K & 63) || K > 448 || !y) return MOBGT_EBADDIM;
+    if (((uintptr_t)x | (uintptr_t)w) & 15) return MOBGT_EALIGN;
+    return fwd_gtl_dispatch(x, w, b, nullptr, 0, y, nullptr, nullptr, G, K, V, 0.f, stream);
+}
+
 extern "C" int mobgt_skinny_linear_gtl(const float* x, const float* w, const float* b, const int64_t* targets, int64_t target_offset,
                                        float* logits, float* dlogits, float* loss, int G, int K, int V, float alpha, void* stream) {
     const int rc = check_dims(G, K, V);
     if (rc) return rc;
     if ((K & 63) || K > 448 || !dlogits || !loss || !targets) return MOBGT_EBADDIM;
     if (((uintptr_t)x | (uintptr_t)w) & 15) return MOBGT_EALIGN;
+    return fwd_gtl_dispatch(x, w, b, targets, target_offset, logits, dlogits, loss, G, K, V, alpha, stream);
+}
+
+namespace {
+int fwd_gtl_dispatch(const float* x, const float* w, const float* b, const int64_t* targets, int64_t target_offset, float* logits,
+                     float* dlogits, float* loss, int G, int K, int V, float alpha, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     switch (K / 64) {
         case 1: return launch_fwd_gtl<1>(x, w, b, targets, target_offset, logits, dlogits, loss, G, V, alpha, st);
@@ -455,3 +477,4 @@ extern "C" int mobgt_skinny_linear_gtl(const float* x, const float* w, const flo
         default: return launch_fwd_gtl<7>(x, w, b, targets, target_offset, logits, dlogits, loss, G, V, alpha, st);
     }
 }
+}  // namespace

@@ -430,7 +430,13 @@ class Graphormer(nn.Module):
         self._enc_out = output
         # (model.py:211-217 normalises every token and then reads the graph token: LayerNorm is per row, so only that row is
         # normalised here -- same value, same gradient)
-        return self.downstream_out_proj(self.final_ln(output[:, 0, :]))
+        tok = self.final_ln(output[:, 0, :])
+        proj = self.downstream_out_proj
+        if ops.skinny_linear_ok(tok, proj.weight):
+            # G <= 16 rows against thousands of classes: one pass over the weight per product (csrc/skinny.hip; the library's
+            # M = 16 GEMM took 29 us of the S-FSQ step at K = 128), and the weight gradient lands in its sink
+            return ops.skinny_linear(tok, proj.weight, proj.bias)
+        return proj(tok)
 
     head_modules = ("final_ln", "downstream_out_proj")
 

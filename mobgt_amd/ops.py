@@ -560,6 +560,11 @@ class _SkinnyLinearFn(torch.autograd.Function):
             y = torch.empty(G, V, dtype=torch.float32, device=x.device)
             check(_lib.lib().mobgt_skinny_linear_fwd(_p(x), _p(w), _p(bias), _p(y), G, K, V, _stream()),
                   "mobgt_skinny_linear_fwd")
+        elif K % 64 == 0 and K <= 448 and os.environ.get("MOBGT_SKINNY_FWD_LIB") != "1":
+            # one pass over W on the matrix cores (csrc/skinny.hip; the library's M = 16 GEMM: 9.2 us at K = 320, 29 us at K = 128)
+            y = torch.empty(G, V, dtype=torch.float32, device=x.device)
+            check(_lib.lib().mobgt_skinny_linear_fwd_mfma(_p(x), _p(w), _p(bias), _p(y), G, K, V, _stream()),
+                  "mobgt_skinny_linear_fwd_mfma")
         else:
             y = torch.addmm(bias, x, w.t()) if bias is not None else x @ w.t()
         ctx.save_for_backward(x, w)
