@@ -332,6 +332,12 @@ int mobgt_gelu_bwd_colsum(const void* dh, const void* u, void* du, float* dbias,
  * `batched_data.y - 1`, model_fqandtoyo.py:1446-1460, without a launch for the subtraction). */
 int mobgt_gradient_tail_loss(const float* logits, const int64_t* targets, int64_t target_offset, float* dlogits,
                              float* loss, int64_t G, int64_t V, float alpha, void* stream);
+/* F.cross_entropy(logits, targets, ignore_index = ignore_index) with mean reduction -- the stock variant's training loss
+ * (model.py:218-285; data.py:76 / :98: NLLLoss(ignore_index = 0) on log-softmax outputs) -- and its gradient in one launch
+ * (csrc/layer.hip): *loss, dlogits [G,V] (may be NULL).  G <= 4095, V <= 10 240; a target outside [0, V) counts as ignored for
+ * the gradient (torch raises).  One launch at a time (a device-global cell carries the mean's sum). */
+int mobgt_cross_entropy(const float* logits, const int64_t* targets, int64_t ignore_index, float* dlogits, float* loss, int G,
+                        int V, void* stream);
 /* nn.Dropout at the model's input/output/positional/GCN sites (model.py:206, model_fqandtoyo.py:358,1347,1364;
  * modelGNN.py:71): y = keep ? x/(1-p) : 0 with the kernels' counter hash keyed by (seed [+ *seed_dev], salt,
  * i / row_len, i % row_len).  The backward is the same call applied to dy. */

@@ -742,6 +742,101 @@ extern "C" int mobgt_gradient_tail_loss(const float* logits, const int64_t* targ
 }
 
 // ------------------------------------------------------------------------------------------------
+// cross_entropy(logits, target, ignore_index) with mean reduction over the rows whose target is not ignore_index -- the stock
+// variant's training loss (model.py:218-285 with the POI datasets' NLLLoss(ignore_index = 0) of data.py:76 / :98 on
+// log-softmax outputs) -- value and gradient in ONE launch: torch runs log_softmax, nll_loss and their two backward kernels
+// (24 us at 16 x 7 857).  One workgroup per row: the row stays in registers between the max, the sum and the gradient
+// (V <= 256 x CE_PER: one read of the logits), the mean's sum over rows is one fence-free 64-bit atomic per row (arrival
+// count + fixed point, as in csrc/skinny.hip).  The loss is >= 0.
+namespace {
+constexpr int CE_PER = 40;                         // logits per thread kept in registers: V <= 10 240
+__device__ unsigned long long ce_cell = 0ull;
+__device__ unsigned int ce_bad = 0u;
+
+__device__ __forceinline__ float ce_block_max(float v, float* sh) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return fmaxf(fmaxf(sh[0], sh[1]), fmaxf(sh[2], sh[3]));
+}
+__device__ __forceinline__ float ce_block_sum(float v, float* sh) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+
+__global__ __launch_bounds__(256) void cross_entropy_kernel(const float* __restrict__ z, const int64_t* __restrict__ target,
+                                                           int64_t ignore_index, float* __restrict__ dz, float* __restrict__ loss,
+                                                           int G, int V) {
+    __shared__ float sh[4];
+    const int g = blockIdx.x;
+    // the number of rows that count (every workgroup finds it for itself: G is a handful)
+    int cnt = 0;
+    for (int i = threadIdx.x; i < G; i += 256) cnt += target[i] != ignore_index;
+    const float n_live = ce_block_sum((float)cnt, sh);
+    const int64_t t = target[g];
+    const bool live = t != ignore_index && t >= 0 && t < V;
+    const float* zr = z + (int64_t)g * V;
+    float v[CE_PER];
+    float m = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < CE_PER; ++k) {
+        const int c = threadIdx.x + 256 * k;
+        v[k] = c < V ? zr[c] : -INFINITY;
+        m = fmaxf(m, v[k]);
+    }
+    m = ce_block_max(m, sh);
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < CE_PER; ++k) {
+        v[k] = __expf(v[k] - m);                      // (0 beyond V)
+        s += v[k];
+    }
+    s = ce_block_sum(s, sh);
+    const float inv_s = 1.f / s, scale = (live && n_live > 0.f) ? 1.f / n_live : 0.f;
+    if (dz) {
+        float* dr = dz + (int64_t)g * V;
+#pragma unroll
+        for (int k = 0; k < CE_PER; ++k) {
+            const int c = threadIdx.x + 256 * k;
+            if (c < V) dr[c] = (v[k] * inv_s - (c == t ? 1.f : 0.f)) * scale;
+        }
+    }
+    if (threadIdx.x == 0) {
+        // -log softmax(z)[t] = m + log s - z[t]
+        const float nll = live ? (m + logf(s) - zr[t]) : 0.f;
+        const bool ok = nll >= 0.f && nll < 65536.f;                      // (false for NaN; 4095 rows x 2^16 x 2^24 < 2^52)
+        if (!ok) {
+            __hip_atomic_fetch_or(&ce_bad, nll != nll ? 2u : 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __threadfence();
+        }
+        const unsigned long long add = 1ull | ((ok ? (unsigned long long)((double)nll * 16777216.0) : 0ull) << 12);
+        const unsigned long long old = __hip_atomic_fetch_add(&ce_cell, add, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((old & 0xFFFull) == (unsigned long long)G - 1ull) {
+            const unsigned long long tot = (old + add) >> 12;
+            const unsigned int bad = __hip_atomic_exchange(&ce_bad, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // (no live row: torch returns nan for the mean over nothing)
+            *loss = bad ? ((bad & 2u) ? __builtin_nanf("") : INFINITY)
+                        : (n_live > 0.f ? (float)((double)tot * (1.0 / 16777216.0) / (double)n_live) : __builtin_nanf(""));
+            __hip_atomic_store(&ce_cell, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+}  // namespace
+
+extern "C" int mobgt_cross_entropy(const float* logits, const int64_t* targets, int64_t ignore_index, float* dlogits, float* loss,
+                                   int G, int V, void* stream) {
+    if (G <= 0 || G > 4095 || V <= 0 || V > 256 * CE_PER || !loss) return MOBGT_EBADDIM;
+    hipLaunchKernelGGL(cross_entropy_kernel, dim3(G), dim3(256), 0, (hipStream_t)stream, logits, targets, ignore_index, dlogits, loss, G, V);
+    return (int)hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
 // Stand-alone dropout (nn.Dropout at the model's input / output / positional / GCN sites), same counter hash
 // as everywhere else: y = keep(seed, salt, row, col) ? x / (1-p) : 0.  The backward is the same call on dy.
 namespace {

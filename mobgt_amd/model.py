@@ -444,4 +444,7 @@ class Graphormer(nn.Module):
         """model.py:218-285, the generic branch (`loss_fn(y_hat, y_gt)`), with the POI datasets' loss of data.py:76 / :98:
         NLLLoss(ignore_index=0) on log-probabilities over the classes == cross_entropy(ignore_index=0) on the logits."""
         logits = self(batched_data)
-        return F.cross_entropy(logits.float(), batched_data.y.view(-1).long(), ignore_index=0)
+        y = batched_data.y.view(-1)
+        if ops.cross_entropy_ok(logits, y):
+            return ops.cross_entropy(logits, y, ignore_index=0)           # value + gradient in one launch (csrc/layer.hip)
+        return F.cross_entropy(logits.float(), y.long(), ignore_index=0)

@@ -878,6 +878,38 @@ class _GradientTailLossFn(torch.autograd.Function):
         return dlogits * g, None, None, None
 
 
+class _CrossEntropyFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, targets, ignore_index):
+        logits = logits.float().contiguous()
+        G, V = logits.shape
+        dlogits = torch.empty_like(logits)
+        loss = torch.empty((), dtype=torch.float32, device=logits.device)
+        check(_lib.lib().mobgt_cross_entropy(_p(logits), _p(targets.long().contiguous()), int(ignore_index), _p(dlogits), _p(loss), G, V,
+                                             _stream()), "mobgt_cross_entropy")
+        ctx.save_for_backward(dlogits)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        (dlogits,) = ctx.saved_tensors
+        if g.data_ptr() == unit_grad(g.device).data_ptr():
+            return dlogits, None, None
+        return dlogits * g, None, None
+
+
+def cross_entropy_ok(logits, targets):
+    return (logits.is_cuda and logits.dim() == 2 and 0 < logits.shape[0] <= 4095 and logits.shape[1] <= 10240
+            and targets.numel() == logits.shape[0] and os.environ.get("MOBGT_NO_FUSED_CE") != "1")
+
+
+def cross_entropy(logits, targets, ignore_index=-100):
+    """F.cross_entropy(logits, targets, ignore_index=ignore_index) (mean over the rows that count): value and gradient from one
+    HIP kernel (csrc/layer.hip: cross_entropy_kernel)."""
+    _require_cuda(logits, targets)
+    return _CrossEntropyFn.apply(logits, targets.reshape(-1), ignore_index)
+
+
 _UNIT = {}
 
 

@@ -869,3 +869,28 @@ def test_classifier_and_loss_in_one_launch(G, K, V):
     loss = ops.skinny_linear_gtl(x, lin.weight, lin.bias, y, 0.2, target_offset=-1)
     loss.backward()
     assert torch.equal(loss.detach().double(), fused[0]) and torch.equal(lin.weight.grad.double(), fused[3])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("G,V", [(16, 7857), (3, 1000), (40, 10240)])
+def test_cross_entropy_in_one_launch(G, V):
+    """mobgt_cross_entropy (csrc/layer.hip) -- the stock variant's loss, model.py:218-285 with ignore_index = 0 (data.py:76 / :98)
+    -- against F.cross_entropy in float64: value and gradient, with ignored rows, and with every row ignored (nan, zero
+    gradient -- as torch)."""
+    from mobgt_amd import ops
+    g = torch.Generator().manual_seed(G)
+    z0 = (torch.randn(G, V, generator=g) * 3).to(DEV)
+    y = torch.randint(1, V, (G,), generator=g).to(DEV)
+    y[::3] = 0                                                            # ignored rows
+    for tgt in (y, torch.zeros_like(y)):
+        z = z0.clone().requires_grad_(True)
+        loss = ops.cross_entropy(z, tgt, ignore_index=0)
+        loss.backward()
+        zr = z0.double().clone().requires_grad_(True)
+        ref = torch.nn.functional.cross_entropy(zr, tgt, ignore_index=0)
+        ref.backward()
+        if bool((tgt != 0).any()):
+            assert abs(float(loss) - float(ref)) <= 2e-6 * abs(float(ref)) + 1e-6, (float(loss), float(ref))
+            assert float((z.grad.double() - zr.grad).abs().max()) <= 2e-6 * float(zr.grad.abs().max()) + 1e-9
+        else:
+            assert torch.isnan(loss) and torch.isnan(ref) and float(z.grad.abs().max()) == 0.0
