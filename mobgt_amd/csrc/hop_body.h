@@ -15,7 +15,7 @@ struct HopBwd {
 inline __host__ __device__ int hop_bwd8_blocks(int D, int E) { return D + (E * 8 + 255) / 256; }
 
 // H = 8 (every MobGT config).  Blocks [0, D): d_w of hop slot d -- g[d] and enc staged in LDS (sm: 2 E 8 floats), 4 threads
-// per output each summing a quarter of the edge ids.  Blocks [D, ..): d_enc, one thread per (e, k), the 8 heads of g[d,e,:]
+// per output each summing every fourth edge id.  Blocks [D, ..): d_enc, one thread per (e, k), the 8 heads of g[d,e,:]
 // and W[d,k,:] as two 16-byte loads each.  (The generic kernel's dependent scalar loads took 30 us.)  Threads >= 256 of a
 // wider workgroup idle (they still reach the barrier).
 __device__ __forceinline__ void hop_table_bwd8_body(const HopBwd& p, const int bid, float* __restrict__ sm) {
@@ -26,14 +26,37 @@ __device__ __forceinline__ void hop_table_bwd8_body(const HopBwd& p, const int b
         const int d = bid;
         float* sg = sm;
         float* se = sm + E * H;
-        if (act)
-            for (int t = threadIdx.x; t < E * H; t += 256) { sg[t] = r16(p.dtab[(int64_t)d * E * H + t], rt); se[t] = r16(p.enc[t], rt); }
+        if (act) {
+            // (16-byte loads, four of each array in flight per thread before the first LDS store: written as one load and one
+            //  store per element the loop was a chain of dependent round trips -- 31.6 us at E = 1 537, the stock variant)
+            const float4* g4 = reinterpret_cast<const float4*>(p.dtab + (int64_t)d * E * H);
+            const float4* e4 = reinterpret_cast<const float4*>(p.enc);
+            const int n4 = E * H / 4;
+            for (int t0 = 0; t0 < n4; t0 += 256 * 4) {
+                float4 a[4], b[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int t = t0 + 256 * u + (int)threadIdx.x;
+                    a[u] = t < n4 ? g4[t] : make_float4(0.f, 0.f, 0.f, 0.f);
+                    b[u] = t < n4 ? e4[t] : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int t = t0 + 256 * u + (int)threadIdx.x;
+                    if (t < n4) {
+                        reinterpret_cast<float4*>(sg)[t] = make_float4(r16(a[u].x, rt), r16(a[u].y, rt), r16(a[u].z, rt), r16(a[u].w, rt));
+                        reinterpret_cast<float4*>(se)[t] = make_float4(r16(b[u].x, rt), r16(b[u].y, rt), r16(b[u].z, rt), r16(b[u].w, rt));
+                    }
+                }
+            }
+        }
         __syncthreads();
         if (!act) return;
         const int o = threadIdx.x >> 2, part = threadIdx.x & 3, k = o >> 3, h = o & 7;       // 64 outputs x 4 parts
-        const int e0 = (E * part) / 4, e1 = (E * (part + 1)) / 4;
+        // (the four parts take interleaved edge ids: their LDS reads of one iteration are 32 consecutive floats.  Contiguous
+        //  quarters put all four on the same banks whenever E / 4 * 8 is a multiple of the bank count)
         float acc = 0.f;
-        for (int e = e0; e < e1; ++e) acc += se[e * H + k] * sg[e * H + h];
+        for (int e = part; e < E; e += 4) acc += se[e * H + k] * sg[e * H + h];
         acc += __shfl_xor(acc, 1, 64);
         acc += __shfl_xor(acc, 2, 64);
         if (part == 0) p.d_w[(d * H + k) * H + h] = r16(acc, rt);

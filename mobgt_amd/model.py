@@ -420,10 +420,17 @@ class Graphormer(nn.Module):
         refresh_shadows(self.layers)
         if x.shape[2] != 1:
             raise NotImplementedError("MobGT items have one feature column (wrapper.py:37)")
+        # (one feature column: a view, not a strided copy; the aliased degree tensor is widened to the ids' dtype ONCE)
+        xi = x.reshape(x.shape[0], x.shape[1])
+        if xi.dtype not in (torch.int64, torch.int32):
+            xi = xi.long()
+        deg = in_degree.reshape(xi.shape)
+        if deg.dtype != xi.dtype:
+            deg = deg.to(xi.dtype)
         node_feature = ops.embed_gather_sum(
             [self.atom_encoder.weight, self.in_degree_encoder.weight, self.out_degree_encoder.weight],
-            [x[:, :, 0].long(), in_degree.long(), out_degree.long()], padding_idx=[0, 0, 0])
-        graph_token_feature = self.graph_token.weight.unsqueeze(0).repeat(n_graph, 1, 1)
+            [xi, deg, deg], padding_idx=[0, 0, 0])
+        graph_token_feature = self.graph_token.weight.unsqueeze(0).expand(n_graph, -1, -1)      # (cat reads it strided: no copy)
         output = ops.dropout(torch.cat([graph_token_feature, node_feature], dim=1), self.input_dropout.p, self.training, 0x1003)
         for enc_layer in self.layers:
             output = enc_layer(output, bias, mask=None)
