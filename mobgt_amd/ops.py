@@ -483,6 +483,10 @@ class _GatherSumFn(torch.autograd.Function):
                                                 _IT[idx[0].dtype], _stream()), "mobgt_embed_gather_sum")
         ctx.idx, ctx.skip = idx, skip
         ctx.shapes = [t.shape for t in tables]
+        # gradient sinks of the tables that are trained parameters (a table listed twice keeps separate buffers: autograd adds
+        # the two results, which must not be one memory)
+        ptrs = [t.data_ptr() for t in tables]
+        ctx.sinks = [grad_sink(t) if ptrs.count(t.data_ptr()) == 1 else None for t in tables]
         return out
 
     @staticmethod
@@ -490,7 +494,9 @@ class _GatherSumFn(torch.autograd.Function):
         if dout.stride(1) != 1 or dout.stride(0) % 4 or dout.data_ptr() % 16:      # column slices of a wider matrix are fine
             dout = dout.contiguous()
         n = len(ctx.shapes)
-        grads = [zeros_f32(tuple(s), dout.device) for s in ctx.shapes]
+        # (the scatter ACCUMULATES: a sink -- zeroed by the trainer's prologue -- serves as it is, a fresh view per call)
+        grads = [k[:] if (k is not None and tuple(k.shape) == tuple(s)) else zeros_f32(tuple(s), dout.device)
+                 for s, k in zip(ctx.shapes, ctx.sinks)]
         skip = (ctypes.c_int64 * n)(*ctx.skip)
         R, C = dout.shape
         check(_lib.lib().mobgt_embed_scatter_add(_ptr_array(grads), _ptr_array(ctx.idx), skip, n, _p(dout), R, C,
