@@ -332,6 +332,14 @@ int mobgt_gelu_bwd_colsum(const void* dh, const void* u, void* du, float* dbias,
  * `batched_data.y - 1`, model_fqandtoyo.py:1446-1460, without a launch for the subtraction). */
 int mobgt_gradient_tail_loss(const float* logits, const int64_t* targets, int64_t target_offset, float* dlogits,
                              float* loss, int64_t G, int64_t V, float alpha, void* stream);
+/* final_ln on the graph-token rows (model.py:211-217: the reference normalises every token, then reads row 0 of every graph):
+ * y [G,C] = LayerNorm(enc[g,0,:]; ln_w, ln_b, eps), mean / rstd [G] kept for the backward (csrc/layer.hip).  enc [G,T,C] f32
+ * contiguous, C <= 1024.
+ * bwd: denc [G,T,C] written in full (zero outside the token rows); dgamma / dbeta [C] ACCUMULATE (f32 atomics): zero them. */
+int mobgt_token_ln_fwd(const float* enc, const float* ln_w, const float* ln_b, float* y, float* mean, float* rstd, int G, int T,
+                       int C, float eps, void* stream);
+int mobgt_token_ln_bwd(const float* dy, const float* enc, const float* mean, const float* rstd, const float* ln_w, float* denc,
+                       float* dgamma, float* dbeta, int G, int T, int C, void* stream);
 /* F.cross_entropy(logits, targets, ignore_index = ignore_index) with mean reduction -- the stock variant's training loss
  * (model.py:218-285; data.py:76 / :98: NLLLoss(ignore_index = 0) on log-softmax outputs) -- and its gradient in one launch
  * (csrc/layer.hip): *loss, dlogits [G,V] (may be NULL).  G <= 4095, V <= 10 240; a target outside [0, V) counts as ignored for

@@ -742,6 +742,107 @@ extern "C" int mobgt_gradient_tail_loss(const float* logits, const int64_t* targ
 }
 
 // ------------------------------------------------------------------------------------------------
+// final_ln on the graph-token rows only (model.py:211-217 normalises every token and then reads row 0 of every graph:
+// LayerNorm is per row, so only those rows are normalised -- same value, same gradient).  y[g,:] = LN(enc[g,0,:]); the
+// backward also produces the whole d(enc) [G,T,C], zero outside the token rows.  torch: a strided copy + layer_norm forward,
+// five launches backward (copy, grad-input, gamma/beta, fill, copy).  One workgroup per graph, C <= 1024.
+namespace {
+__device__ __forceinline__ float tl_block_sum(float v, float* sh) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+
+__global__ __launch_bounds__(256) void token_ln_fwd_kernel(const float* __restrict__ enc, const float* __restrict__ w,
+                                                          const float* __restrict__ b, float* __restrict__ y,
+                                                          float* __restrict__ mean, float* __restrict__ rstd, int T, int C, float eps) {
+    __shared__ float sh[4];
+    const int g = blockIdx.x;
+    const float* x = enc + (int64_t)g * T * C;
+    float v[4], s = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int c = threadIdx.x + 256 * k;
+        v[k] = c < C ? x[c] : 0.f;
+        s += v[k];
+    }
+    const float mu = tl_block_sum(s, sh) / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int c = threadIdx.x + 256 * k;
+        const float d = c < C ? v[k] - mu : 0.f;
+        q += d * d;
+    }
+    const float rs = rsqrtf(tl_block_sum(q, sh) / (float)C + eps);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int c = threadIdx.x + 256 * k;
+        if (c < C) y[(int64_t)g * C + c] = (v[k] - mu) * rs * w[c] + b[c];
+    }
+    if (threadIdx.x == 0) { mean[g] = mu; rstd[g] = rs; }
+}
+
+__global__ __launch_bounds__(256) void token_ln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ enc,
+                                                          const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                          const float* __restrict__ w, float* __restrict__ denc,
+                                                          float* __restrict__ dgamma, float* __restrict__ dbeta, int T, int C) {
+    __shared__ float sh[4];
+    const int g = blockIdx.x;
+    float* dx = denc + (int64_t)g * T * C;
+    // rows 1 .. T-1 of this graph receive no gradient from the head
+    const int64_t n4 = ((int64_t)(T - 1) * C) / 4;
+    if ((C & 3) == 0 && ((uintptr_t)dx & 15) == 0) {
+        float4* z = reinterpret_cast<float4*>(dx + C);
+        for (int64_t i = threadIdx.x; i < n4; i += 256) z[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    } else {
+        for (int64_t i = threadIdx.x; i < (int64_t)(T - 1) * C; i += 256) dx[C + i] = 0.f;
+    }
+    const float* x = enc + (int64_t)g * T * C;
+    const float mu = mean[g], rs = rstd[g];
+    float xh[4], gg[4], s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int c = threadIdx.x + 256 * k;
+        xh[k] = gg[k] = 0.f;
+        if (c < C) {
+            const float d = dy[(int64_t)g * C + c];
+            xh[k] = (x[c] - mu) * rs;
+            gg[k] = d * w[c];
+            atomicAdd(&dgamma[c], d * xh[k]);
+            atomicAdd(&dbeta[c], d);
+            s1 += gg[k];
+            s2 += gg[k] * xh[k];
+        }
+    }
+    s1 = tl_block_sum(s1, sh) / (float)C;
+    s2 = tl_block_sum(s2, sh) / (float)C;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int c = threadIdx.x + 256 * k;
+        if (c < C) dx[c] = rs * (gg[k] - s1 - xh[k] * s2);
+    }
+}
+}  // namespace
+
+extern "C" int mobgt_token_ln_fwd(const float* enc, const float* ln_w, const float* ln_b, float* y, float* mean, float* rstd, int G,
+                                  int T, int C, float eps, void* stream) {
+    if (G <= 0 || T <= 0 || C <= 0 || C > 1024) return MOBGT_EBADDIM;
+    hipLaunchKernelGGL(token_ln_fwd_kernel, dim3(G), dim3(256), 0, (hipStream_t)stream, enc, ln_w, ln_b, y, mean, rstd, T, C, eps);
+    return (int)hipGetLastError();
+}
+
+extern "C" int mobgt_token_ln_bwd(const float* dy, const float* enc, const float* mean, const float* rstd, const float* ln_w,
+                                  float* denc, float* dgamma, float* dbeta, int G, int T, int C, void* stream) {
+    if (G <= 0 || T <= 0 || C <= 0 || C > 1024) return MOBGT_EBADDIM;
+    hipLaunchKernelGGL(token_ln_bwd_kernel, dim3(G), dim3(256), 0, (hipStream_t)stream, dy, enc, mean, rstd, ln_w, denc, dgamma, dbeta, T, C);
+    return (int)hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
 // cross_entropy(logits, target, ignore_index) with mean reduction over the rows whose target is not ignore_index -- the stock
 // variant's training loss (model.py:218-285 with the POI datasets' NLLLoss(ignore_index = 0) of data.py:76 / :98 on
 // log-softmax outputs) -- value and gradient in ONE launch: torch runs log_softmax, nll_loss and their two backward kernels

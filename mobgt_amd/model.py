@@ -437,7 +437,10 @@ class Graphormer(nn.Module):
         self._enc_out = output
         # (model.py:211-217 normalises every token and then reads the graph token: LayerNorm is per row, so only that row is
         # normalised here -- same value, same gradient)
-        tok = self.final_ln(output[:, 0, :])
+        if ops.token_layer_norm_ok(output, self.final_ln.weight):
+            tok = ops.token_layer_norm(output, self.final_ln.weight, self.final_ln.bias, self.final_ln.eps)    # one launch each way
+        else:
+            tok = self.final_ln(output[:, 0, :])
         proj = self.downstream_out_proj
         if ops.skinny_linear_ok(tok, proj.weight):
             # G <= 16 rows against thousands of classes: one pass over the weight per product (csrc/skinny.hip; the library's

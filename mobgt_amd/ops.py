@@ -884,6 +884,43 @@ class _GradientTailLossFn(torch.autograd.Function):
         return dlogits * g, None, None, None
 
 
+class _TokenLayerNormFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, enc, weight, bias, eps):
+        enc = enc.contiguous()
+        G, T, C = enc.shape
+        y = torch.empty(G, C, dtype=torch.float32, device=enc.device)
+        stat = torch.empty(2, G, dtype=torch.float32, device=enc.device)
+        check(_lib.lib().mobgt_token_ln_fwd(_p(enc), _p(weight), _p(bias), _p(y), _p(stat[0]), _p(stat[1]), G, T, C, float(eps),
+                                            _stream()), "mobgt_token_ln_fwd")
+        ctx.save_for_backward(enc, weight, stat)
+        ctx.sinks = (grad_sink(weight), grad_sink(bias))
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        enc, weight, stat = ctx.saved_tensors
+        G, T, C = enc.shape
+        denc = torch.empty_like(enc)
+        # (the affine gradients ACCUMULATE: into the parameters' sinks -- zeroed by the trainer's prologue -- or into zeros)
+        dg, db = (k[:] if k is not None else zeros_f32((C,), enc.device) for k in ctx.sinks)
+        check(_lib.lib().mobgt_token_ln_bwd(_p(dy.contiguous()), _p(enc), _p(stat[0]), _p(stat[1]), _p(weight), _p(denc), _p(dg), _p(db),
+                                            G, T, C, _stream()), "mobgt_token_ln_bwd")
+        return denc, dg, db, None
+
+
+def token_layer_norm_ok(enc, weight):
+    return (enc.is_cuda and enc.dim() == 3 and enc.dtype == torch.float32 and weight.dtype == torch.float32
+            and enc.shape[2] <= 1024 and os.environ.get("MOBGT_NO_TOKEN_LN") != "1")
+
+
+def token_layer_norm(enc, weight, bias, eps=1e-5):
+    """LayerNorm of the graph-token rows enc[:, 0, :] of an encoder output [G,T,C] -> [G,C]: one launch each way (the backward
+    writes the whole d(enc), zero outside the token rows)."""
+    _require_cuda(enc, weight, bias)
+    return _TokenLayerNormFn.apply(enc, weight.contiguous(), bias.contiguous(), eps)
+
+
 class _CrossEntropyFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, logits, targets, ignore_index):

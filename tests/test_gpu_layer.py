@@ -894,3 +894,33 @@ def test_cross_entropy_in_one_launch(G, V):
             assert float((z.grad.double() - zr.grad).abs().max()) <= 2e-6 * float(zr.grad.abs().max()) + 1e-9
         else:
             assert torch.isnan(loss) and torch.isnan(ref) and float(z.grad.abs().max()) == 0.0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("G,T,C", [(16, 42, 128), (3, 7, 190), (5, 1, 1024)])
+def test_token_layer_norm(G, T, C):
+    """ops.token_layer_norm (csrc/layer.hip: final_ln on the graph-token rows, model.py:211-217) against torch's LayerNorm on
+    enc[:, 0, :] in float64: value, d(enc) (zero outside the token rows) and the affine gradients."""
+    from mobgt_amd import ops
+    g = torch.Generator().manual_seed(C)
+    enc0 = torch.randn(G, T, C, generator=g).to(DEV)
+    ln = torch.nn.LayerNorm(C).to(DEV)
+    with torch.no_grad():
+        ln.weight.copy_(torch.randn(C, generator=g).to(DEV)); ln.bias.copy_(torch.randn(C, generator=g).to(DEV))
+    gy = torch.randn(G, C, generator=g).to(DEV)
+    enc = enc0.clone().requires_grad_(True)
+    y = ops.token_layer_norm(enc, ln.weight, ln.bias, ln.eps)
+    y.backward(gy)
+    got = [y.detach().double(), enc.grad.double(), ln.weight.grad.double().clone(), ln.bias.grad.double().clone()]
+    ln.weight.grad = ln.bias.grad = None
+    ref_ln = torch.nn.LayerNorm(C).to(DEV).double()
+    with torch.no_grad():
+        ref_ln.weight.copy_(ln.weight.double()); ref_ln.bias.copy_(ln.bias.double())
+    encr = enc0.double().clone().requires_grad_(True)
+    yr = ref_ln(encr[:, 0, :])
+    yr.backward(gy.double())
+    want = [yr.detach(), encr.grad, ref_ln.weight.grad, ref_ln.bias.grad]
+    for name, a, b in zip(("y", "denc", "dgamma", "dbeta"), got, want):
+        assert float((a - b).abs().max()) <= 2e-5 * (float(b.abs().max()) + 1e-12), (name, float((a - b).abs().max()))
+    if T > 1:
+        assert float(got[1][:, 1:].abs().max()) == 0.0
