@@ -55,8 +55,17 @@ __device__ __forceinline__ void hop_table_bwd8_body(const HopBwd& p, const int b
         const int o = threadIdx.x >> 2, part = threadIdx.x & 3, k = o >> 3, h = o & 7;       // 64 outputs x 4 parts
         // (the four parts take interleaved edge ids: their LDS reads of one iteration are 32 consecutive floats.  Contiguous
         //  quarters put all four on the same banks whenever E / 4 * 8 is a multiple of the bank count)
+        // (eight iterations' LDS reads in flight: one read pair per dependent add was ~100 cycles x 385 iterations at E = 1 537)
         float acc = 0.f;
-        for (int e = part; e < E; e += 4) acc += se[e * H + k] * sg[e * H + h];
+        int e = part;
+        for (; e + 28 < E; e += 32) {
+            float a[8], b[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { a[u] = se[(e + 4 * u) * H + k]; b[u] = sg[(e + 4 * u) * H + h]; }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc += a[u] * b[u];
+        }
+        for (; e < E; e += 4) acc += se[e * H + k] * sg[e * H + h];
         acc += __shfl_xor(acc, 1, 64);
         acc += __shfl_xor(acc, 2, 64);
         if (part == 0) p.d_w[(d * H + k) * H + h] = r16(acc, rt);
@@ -68,13 +77,24 @@ __device__ __forceinline__ void hop_table_bwd8_body(const HopBwd& p, const int b
     const int k = i & 7, e = i >> 3;
     float acc = 0.f;
     if (e != 0) {
-        for (int d = 0; d < D; ++d) {
-            const float4* g4 = reinterpret_cast<const float4*>(p.dtab + ((int64_t)d * E + e) * H);
-            const float4* w4 = reinterpret_cast<const float4*>(p.w + ((int64_t)d * H + k) * H);
-            const float4 ga = g4[0], gb = g4[1], wa = w4[0], wb = w4[1];
-            acc += r16(ga.x, rt) * r16(wa.x, rt) + r16(ga.y, rt) * r16(wa.y, rt) + r16(ga.z, rt) * r16(wa.z, rt) +
-                   r16(ga.w, rt) * r16(wa.w, rt) + r16(gb.x, rt) * r16(wb.x, rt) + r16(gb.y, rt) * r16(wb.y, rt) +
-                   r16(gb.z, rt) * r16(wb.z, rt) + r16(gb.w, rt) * r16(wb.w, rt);
+        // (four hop slots' loads in flight at a time: with a run-time D the plain loop waited for every slot's rows in turn --
+        //  20 dependent round trips, most of the kernel's 19 us at E = 1 537; same order of additions)
+        for (int d0 = 0; d0 < D; d0 += 4) {
+            float4 ga[4], gb[4], wa[4], wb[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int d = d0 + u < D ? d0 + u : D - 1;
+                const float4* g4 = reinterpret_cast<const float4*>(p.dtab + ((int64_t)d * E + e) * H);
+                const float4* w4 = reinterpret_cast<const float4*>(p.w + ((int64_t)d * H + k) * H);
+                ga[u] = g4[0]; gb[u] = g4[1]; wa[u] = w4[0]; wb[u] = w4[1];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (d0 + u < D)
+                    acc += r16(ga[u].x, rt) * r16(wa[u].x, rt) + r16(ga[u].y, rt) * r16(wa[u].y, rt) + r16(ga[u].z, rt) * r16(wa[u].z, rt) +
+                           r16(ga[u].w, rt) * r16(wa[u].w, rt) + r16(gb[u].x, rt) * r16(wb[u].x, rt) + r16(gb[u].y, rt) * r16(wb[u].y, rt) +
+                           r16(gb[u].z, rt) * r16(wb[u].z, rt) + r16(gb[u].w, rt) * r16(wb[u].w, rt);
+            }
         }
     }
     p.d_enc[i] = r16(acc, rt);
