@@ -742,6 +742,126 @@ extern "C" int mobgt_gradient_tail_loss(const float* logits, const int64_t* targ
 }
 
 // ------------------------------------------------------------------------------------------------
+// The stock variant's encoder input (model.py:193-205): row (g, 0) = graph_token, row (g, 1 + n) = atom_encoder[x[g,n]] +
+// in_degree_encoder[deg[g,n]] + out_degree_encoder[deg'[g,n]], then input_dropout over the whole [G, T = N+1, C] tensor -- one
+// launch each way instead of gather + cat + dropout (+ index casts) / dropout + reduce + copy + scatter.  The dropout mask is
+// mobgt_dropout's for the same salt: element (row g T + t, column c).  A negative index contributes nothing; row `skip` of
+// a table (padding_idx) is read but receives no gradient.  Backward: f32 atomics into ZEROED (or sink) buffers.
+namespace {
+struct StockTokParams {
+    const void *x, *din, *dout;            // [G, N] indices (idx_dtype)
+    int idx_dtype;
+    const float *atom, *indeg, *outdeg, *gtok;   // [*, C] tables, [C] graph token
+    float *y;                              // [G, T, C]
+    const float* dy;                       // backward
+    float *d_atom, *d_indeg, *d_outdeg, *d_gtok;
+    int G, N, C;
+    int64_t n_atom, n_in, n_out, skip;
+    uint32_t thr; float inv_keep; uint64_t seed; const uint64_t* seed_dev; uint32_t salt;
+};
+__device__ __forceinline__ int64_t st_idx(const void* p, int dt, int64_t i) {
+    return dt == MOBGT_I64 ? reinterpret_cast<const int64_t*>(p)[i]
+         : dt == MOBGT_I32 ? (int64_t)reinterpret_cast<const int32_t*>(p)[i] : (int64_t)reinterpret_cast<const int16_t*>(p)[i];
+}
+template <bool BWD>
+__global__ __launch_bounds__(256) void stock_tokens_kernel(const StockTokParams p) {
+    const int T = p.N + 1, c4 = p.C / 4;
+    const uint64_t seed = p.thr ? p.seed + (p.seed_dev ? *p.seed_dev : 0ull) : 0ull;
+    const int64_t total = (int64_t)p.G * T * c4;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int64_t r = e / c4;
+        const int c = (int)(e - r * c4) * 4;
+        const int g = (int)(r / T), t = (int)(r - (int64_t)g * T);
+        float keep[4] = {1.f, 1.f, 1.f, 1.f};
+        if (p.thr) {
+            const uint32_t rowh = dropout_row_hash(seed, (uint32_t)r ^ p.salt);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) keep[i] = dropout_bits16(seed, rowh, (uint32_t)(c + i)) >= p.thr ? p.inv_keep : 0.f;
+        }
+        int64_t ia = -1, ii = -1, io = -1;
+        if (t > 0) {
+            const int64_t at = (int64_t)g * p.N + (t - 1);
+            ia = st_idx(p.x, p.idx_dtype, at); ii = st_idx(p.din, p.idx_dtype, at); io = st_idx(p.dout, p.idx_dtype, at);
+            if (ia >= p.n_atom) ia = -1;
+            if (ii >= p.n_in) ii = -1;
+            if (io >= p.n_out) io = -1;
+        }
+        if (!BWD) {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            auto add = [&](const float* tab, int64_t i) {
+                if (i < 0) return;
+                const float4 a = *reinterpret_cast<const float4*>(tab + i * p.C + c);
+                v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
+            };
+            if (t == 0) v = *reinterpret_cast<const float4*>(p.gtok + c);
+            else { add(p.atom, ia); add(p.indeg, ii); add(p.outdeg, io); }
+            *reinterpret_cast<float4*>(p.y + r * p.C + c) = make_float4(v.x * keep[0], v.y * keep[1], v.z * keep[2], v.w * keep[3]);
+        } else {
+            const float4 d = *reinterpret_cast<const float4*>(p.dy + r * p.C + c);
+            const float dv[4] = {d.x * keep[0], d.y * keep[1], d.z * keep[2], d.w * keep[3]};
+            auto scat = [&](float* tab, int64_t i) {
+                if (!tab || i < 0 || i == p.skip) return;
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (dv[q] != 0.f) atomicAdd(tab + i * p.C + c + q, dv[q]);
+            };
+            if (t == 0) {
+                if (p.d_gtok) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        if (dv[q] != 0.f) atomicAdd(p.d_gtok + c + q, dv[q]);
+                }
+            } else { scat(p.d_atom, ia); scat(p.d_indeg, ii); scat(p.d_outdeg, io); }
+        }
+    }
+}
+int stock_tok_fill(StockTokParams& p, const void* x, const void* din, const void* dout, int idx_dtype, int G, int N, int C,
+                   int64_t n_atom, int64_t n_in, int64_t n_out, int64_t skip, float dropout_p, uint64_t seed, const uint64_t* seed_dev,
+                   uint32_t salt) {
+    if (G <= 0 || N < 0 || C <= 0 || (C & 3)) return MOBGT_EBADDIM;
+    if (idx_dtype != MOBGT_I64 && idx_dtype != MOBGT_I32 && idx_dtype != MOBGT_I16) return MOBGT_EDTYPE;
+    p = StockTokParams{};
+    p.x = x; p.din = din; p.dout = dout; p.idx_dtype = idx_dtype; p.G = G; p.N = N; p.C = C;
+    p.n_atom = n_atom; p.n_in = n_in; p.n_out = n_out; p.skip = skip;
+    p.thr = dropout_p > 0.f ? dropout_threshold(dropout_p) : 0u;
+    p.inv_keep = p.thr ? 1.f / (1.f - (float)p.thr / 65536.f) : 1.f;
+    p.seed = seed; p.seed_dev = seed_dev; p.salt = salt;
+    return 0;
+}
+}  // namespace
+
+extern "C" int mobgt_stock_tokens_fwd(const void* x, const void* in_degree, const void* out_degree, int idx_dtype, const float* atom,
+                                      const float* indeg, const float* outdeg, const float* graph_token, float* y, int G, int N,
+                                      int C, int64_t n_atom, int64_t n_in, int64_t n_out, float dropout_p, uint64_t seed,
+                                      const uint64_t* seed_dev, uint32_t salt, void* stream) {
+    StockTokParams p;
+    const int rc = stock_tok_fill(p, x, in_degree, out_degree, idx_dtype, G, N, C, n_atom, n_in, n_out, -1, dropout_p, seed, seed_dev, salt);
+    if (rc) return rc;
+    if (((uintptr_t)atom | (uintptr_t)indeg | (uintptr_t)outdeg | (uintptr_t)graph_token | (uintptr_t)y) & 15) return MOBGT_EALIGN;
+    p.atom = atom; p.indeg = indeg; p.outdeg = outdeg; p.gtok = graph_token; p.y = y;
+    const int64_t total = (int64_t)G * (N + 1) * (C / 4);
+    const unsigned blocks = (unsigned)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+    hipLaunchKernelGGL(stock_tokens_kernel<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p);
+    return (int)hipGetLastError();
+}
+
+extern "C" int mobgt_stock_tokens_bwd(const float* dy, const void* x, const void* in_degree, const void* out_degree, int idx_dtype,
+                                      float* d_atom, float* d_indeg, float* d_outdeg, float* d_graph_token, int G, int N, int C,
+                                      int64_t n_atom, int64_t n_in, int64_t n_out, int64_t padding_idx, float dropout_p, uint64_t seed,
+                                      const uint64_t* seed_dev, uint32_t salt, void* stream) {
+    StockTokParams p;
+    const int rc = stock_tok_fill(p, x, in_degree, out_degree, idx_dtype, G, N, C, n_atom, n_in, n_out, padding_idx, dropout_p, seed,
+                                  seed_dev, salt);
+    if (rc) return rc;
+    if ((uintptr_t)dy & 15) return MOBGT_EALIGN;
+    p.dy = dy; p.d_atom = d_atom; p.d_indeg = d_indeg; p.d_outdeg = d_outdeg; p.d_gtok = d_graph_token;
+    const int64_t total = (int64_t)G * (N + 1) * (C / 4);
+    const unsigned blocks = (unsigned)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+    hipLaunchKernelGGL(stock_tokens_kernel<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p);
+    return (int)hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
 // final_ln on the graph-token rows only (model.py:211-217 normalises every token and then reads row 0 of every graph:
 // LayerNorm is per row, so only those rows are normalised -- same value, same gradient).  y[g,:] = LN(enc[g,0,:]); the
 // backward also produces the whole d(enc) [G,T,C], zero outside the token rows.  torch: a strided copy + layer_norm forward,

@@ -427,11 +427,14 @@ class Graphormer(nn.Module):
         deg = in_degree.reshape(xi.shape)
         if deg.dtype != xi.dtype:
             deg = deg.to(xi.dtype)
-        node_feature = ops.embed_gather_sum(
-            [self.atom_encoder.weight, self.in_degree_encoder.weight, self.out_degree_encoder.weight],
-            [xi, deg, deg], padding_idx=[0, 0, 0])
-        graph_token_feature = self.graph_token.weight.unsqueeze(0).expand(n_graph, -1, -1)      # (cat reads it strided: no copy)
-        output = ops.dropout(torch.cat([graph_token_feature, node_feature], dim=1), self.input_dropout.p, self.training, 0x1003)
+        tabs = (self.atom_encoder.weight, self.in_degree_encoder.weight, self.out_degree_encoder.weight)
+        if ops.stock_tokens_ok(xi, *tabs, self.graph_token.weight):
+            # gather + graph token + input dropout: one launch each way (same values, same mask as the three ops below)
+            output = ops.stock_tokens(xi, deg, deg, *tabs, self.graph_token.weight, self.input_dropout.p, self.training, 0x1003)
+        else:
+            node_feature = ops.embed_gather_sum(list(tabs), [xi, deg, deg], padding_idx=[0, 0, 0])
+            graph_token_feature = self.graph_token.weight.unsqueeze(0).expand(n_graph, -1, -1)      # (cat reads it strided: no copy)
+            output = ops.dropout(torch.cat([graph_token_feature, node_feature], dim=1), self.input_dropout.p, self.training, 0x1003)
         for enc_layer in self.layers:
             output = enc_layer(output, bias, mask=None)
         self._enc_out = output

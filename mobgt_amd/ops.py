@@ -884,6 +884,56 @@ class _GradientTailLossFn(torch.autograd.Function):
         return dlogits * g, None, None, None
 
 
+class _StockTokensFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, din, dout, atom, indeg, outdeg, gtok, p, seed, seed_dev, salt, padding_idx):
+        G, N = x.shape
+        C = atom.shape[1]
+        y = torch.empty(G, N + 1, C, dtype=torch.float32, device=atom.device)
+        check(_lib.lib().mobgt_stock_tokens_fwd(_p(x), _p(din), _p(dout), _IT[x.dtype], _p(atom), _p(indeg), _p(outdeg), _p(gtok), _p(y),
+                                                G, N, C, atom.shape[0], indeg.shape[0], outdeg.shape[0], p, seed, _p(seed_dev), salt,
+                                                _stream()), "mobgt_stock_tokens_fwd")
+        ctx.idx = (x, din, dout)
+        ctx.misc = (p, seed, seed_dev, salt, padding_idx, [t.shape for t in (atom, indeg, outdeg, gtok)])
+        # (a table listed twice keeps separate buffers: autograd adds the results, which must not be one memory)
+        ptrs = [t.data_ptr() for t in (atom, indeg, outdeg, gtok)]
+        ctx.sinks = [grad_sink(t) if ptrs.count(t.data_ptr()) == 1 else None for t in (atom, indeg, outdeg, gtok)]
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, din, dout = ctx.idx
+        p, seed, seed_dev, salt, padding_idx, shapes = ctx.misc
+        G, N = x.shape
+        dy = dy.contiguous()
+        C = dy.shape[2]
+        grads = [None if not need else (k[:] if (k is not None and tuple(k.shape) == tuple(sh)) else zeros_f32(tuple(sh), dy.device))
+                 for need, k, sh in zip(ctx.needs_input_grad[3:7], ctx.sinks, shapes)]
+        check(_lib.lib().mobgt_stock_tokens_bwd(_p(dy), _p(x), _p(din), _p(dout), _IT[x.dtype], _p(grads[0]), _p(grads[1]), _p(grads[2]),
+                                                _p(grads[3]), G, N, C, shapes[0][0], shapes[1][0], shapes[2][0], int(padding_idx), p,
+                                                seed, _p(seed_dev), salt, _stream()), "mobgt_stock_tokens_bwd")
+        return (None, None, None, *grads, None, None, None, None, None)
+
+
+def stock_tokens_ok(x, atom, indeg, outdeg, gtok):
+    return (x.is_cuda and x.dim() == 2 and x.dtype in _IT and atom.shape[1] % 4 == 0
+            and all(t.dtype == torch.float32 and t.is_contiguous() and t.data_ptr() % 16 == 0 for t in (atom, indeg, outdeg, gtok))
+            and os.environ.get("MOBGT_NO_STOCK_TOKENS") != "1")
+
+
+def stock_tokens(x, in_degree, out_degree, atom, indeg, outdeg, graph_token, p, training, salt, padding_idx=0):
+    """The stock variant's encoder input [G, N+1, C] (model.py:193-205): graph token row + atom / in-degree / out-degree rows
+    summed, then input dropout -- one launch each way (csrc/layer.hip).  x, in_degree, out_degree: [G,N] indices of one dtype."""
+    _require_cuda(x, atom)
+    if not training:
+        p = 0.0
+    seed, seed_dev = _DROPOUT_STATE["seed"], _DROPOUT_STATE["seed_dev"]
+    if seed_dev is None and p > 0:
+        seed = (seed + int(torch.randint(0, 2 ** 31 - 1, (1,)).item())) & 0x7FFFFFFFFFFFFFFF
+    return _StockTokensFn.apply(x.contiguous(), in_degree.contiguous(), out_degree.contiguous(), atom, indeg, outdeg, graph_token,
+                                float(p), int(seed), seed_dev, int(salt) & 0xFFFFFFFF, int(padding_idx))
+
+
 class _TokenLayerNormFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, enc, weight, bias, eps):

@@ -924,3 +924,47 @@ def test_token_layer_norm(G, T, C):
         assert float((a - b).abs().max()) <= 2e-5 * (float(b.abs().max()) + 1e-12), (name, float((a - b).abs().max()))
     if T > 1:
         assert float(got[1][:, 1:].abs().max()) == 0.0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("idt", [torch.int64, torch.int32])
+def test_stock_encoder_input_in_one_launch(idt, monkeypatch):
+    """ops.stock_tokens (csrc/layer.hip; model.py:193-205) against the three ops it replaces -- embed_gather_sum, cat with the
+    graph token, ops.dropout at the same site -- with the dropout on: bit-identical output (same mask), table / token gradients
+    to f32 summation order; padding rows (index 0) receive no gradient; and against plain torch without dropout."""
+    from mobgt_amd import ops
+    g = torch.Generator().manual_seed(4)
+    G, N, C, P = 16, 41, 128, 900
+    x = torch.randint(0, P, (G, N), generator=g).to(idt).to(DEV)
+    deg = torch.randint(0, 40, (G, N), generator=g).to(idt).to(DEV)
+    tabs = [torch.nn.Parameter(torch.randn(n, C, generator=g).to(DEV)) for n in (P, 512, 512)]
+    gtok = torch.nn.Parameter(torch.randn(1, C, generator=g).to(DEV))
+    gy = torch.randn(G, N + 1, C, generator=g).to(DEV)
+    seed_dev = torch.tensor([7], dtype=torch.int64, device=DEV)
+    ops.set_dropout_state(seed_dev, 1234)
+    try:
+        res = []
+        for fused in (True, False):
+            for q in tabs + [gtok]:
+                q.grad = None
+            if fused:
+                assert ops.stock_tokens_ok(x, *tabs, gtok)
+                y = ops.stock_tokens(x, deg, deg, *tabs, gtok, 0.1, True, 0x1003)
+            else:
+                nf = ops.embed_gather_sum(list(tabs), [x, deg, deg], padding_idx=[0, 0, 0])
+                y = ops.dropout(torch.cat([gtok.unsqueeze(0).expand(G, -1, -1), nf], dim=1), 0.1, True, 0x1003)
+            y.backward(gy)
+            torch.cuda.synchronize()
+            res.append([y.detach().clone()] + [q.grad.clone() for q in tabs + [gtok]])
+        a, b = res
+        assert torch.equal(a[0], b[0]) and int((a[0] == 0).sum()) > 0
+        for k, (u, v) in enumerate(zip(a[1:], b[1:])):
+            assert float((u - v).abs().max()) <= 2e-5 * float(v.abs().max()) + 1e-7, k
+            if k < 3:
+                assert float(u[0].abs().max()) == 0.0
+        y0 = ops.stock_tokens(x, deg, deg, *[t.detach() for t in tabs], gtok.detach(), 0.1, False, 0x1003)
+        ref = torch.cat([gtok.detach().unsqueeze(0).expand(G, -1, -1), tabs[0].detach()[x.long()] + tabs[1].detach()[deg.long()]
+                         + tabs[2].detach()[deg.long()]], dim=1)
+        assert torch.equal(y0, ref)
+    finally:
+        ops.set_dropout_state(None, 0)
