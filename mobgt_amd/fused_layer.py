@@ -591,6 +591,16 @@ class _FusedLayerFn(torch.autograd.Function):
                 torch.autograd.Variable._execution_engine.queue_callback(_pending_check)
             rode = True
             dx = dx1
+        elif (stock and ops._WGRAD_DEFER["on"] and wb.items and R <= _DEFER_MAX_R[0] and all(k is not None for k in ctx.sinks)
+              and all(g_.dtype == torch.bfloat16 and x_.dtype == torch.bfloat16 for g_, x_, _, _ in wb.items)
+              and _os_ln.environ.get("MOBGT_NO_STOCK_WGRAD_DEFER") != "1"):
+            # stock variant inside a train step: nothing downstream reads a weight gradient and all four land in their sinks, so
+            # they join the step's ONE grouped launch (ops.flush_deferred_wgrads) instead of one 7 us launch per layer -- parked
+            # as FRESH views (see above: AccumulateGrad clones a returned gradient that anything else still references)
+            for g_, x_, dw_, db_ in wb.items:
+                ops._WGRAD_DEFER["items"].append((g_, x_, None, None, (1.0, 1.0, 1.0), dw_[:], db_[:] if db_ is not None else None, False))
+            wb.items = []
+            rode = False
         else:
             # fq variant, own GEMMs: dx = dx1 + dqkv Wqkv rides in the weight-gradient launch
             rode = wb.flush(tail=(dqkv2, s_wqkv, dx1) if (own and not stock and _TAIL[0]) else None)
