@@ -334,16 +334,17 @@ int mobgt_gradient_tail_loss(const float* logits, const int64_t* targets, int64_
                              float* loss, int64_t G, int64_t V, float alpha, void* stream);
 /* The stock variant's encoder input in one launch each way (model.py:193-205; csrc/layer.hip): y [G, N+1, C] with row (g, 0) =
  * graph_token and row (g, 1 + n) = atom[x[g,n]] + indeg[in_degree[g,n]] + outdeg[out_degree[g,n]], then input_dropout with
- * mobgt_dropout's mask for the same (seed, salt) over rows g (N+1) + t.  Indices [G,N] of one dtype (MOBGT_I64 / I32 / I16);
+ * mobgt_dropout's mask for the same (seed, salt) over rows g (N+1) + t.  Indices [G,N]: x of idx_dtype, the two degree tensors
+ * of deg_dtype (MOBGT_I64 / I32 / I16 each);
  * a negative or out-of-table index contributes nothing.  C % 4 == 0, tables and y 16-byte aligned.
  * bwd: the table / token gradients ACCUMULATE (f32 atomics: zero them, or pass gradient sinks; NULL = not wanted); row
  * `padding_idx` of every table receives nothing. */
-int mobgt_stock_tokens_fwd(const void* x, const void* in_degree, const void* out_degree, int idx_dtype, const float* atom,
+int mobgt_stock_tokens_fwd(const void* x, const void* in_degree, const void* out_degree, int idx_dtype, int deg_dtype, const float* atom,
                            const float* indeg, const float* outdeg, const float* graph_token, float* y, int G, int N, int C,
                            int64_t n_atom, int64_t n_in, int64_t n_out, float dropout_p, uint64_t seed, const uint64_t* seed_dev,
                            uint32_t salt, void* stream);
 int mobgt_stock_tokens_bwd(const float* dy, const void* x, const void* in_degree, const void* out_degree, int idx_dtype,
-                           float* d_atom, float* d_indeg, float* d_outdeg, float* d_graph_token, int G, int N, int C,
+                           int deg_dtype, float* d_atom, float* d_indeg, float* d_outdeg, float* d_graph_token, int G, int N, int C,
                            int64_t n_atom, int64_t n_in, int64_t n_out, int64_t padding_idx, float dropout_p, uint64_t seed,
                            const uint64_t* seed_dev, uint32_t salt, void* stream);
 /* final_ln on the graph-token rows (model.py:211-217: the reference normalises every token, then reads row 0 of every graph):

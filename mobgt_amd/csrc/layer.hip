@@ -749,8 +749,8 @@ extern "C" int mobgt_gradient_tail_loss(const float* logits, const int64_t* targ
 // a table (padding_idx) is read but receives no gradient.  Backward: f32 atomics into ZEROED (or sink) buffers.
 namespace {
 struct StockTokParams {
-    const void *x, *din, *dout;            // [G, N] indices (idx_dtype)
-    int idx_dtype;
+    const void *x, *din, *dout;            // [G, N] indices (x: idx_dtype; the two degree tensors: deg_dtype)
+    int idx_dtype, deg_dtype;
     const float *atom, *indeg, *outdeg, *gtok;   // [*, C] tables, [C] graph token
     float *y;                              // [G, T, C]
     const float* dy;                       // backward
@@ -781,7 +781,7 @@ __global__ __launch_bounds__(256) void stock_tokens_kernel(const StockTokParams 
         int64_t ia = -1, ii = -1, io = -1;
         if (t > 0) {
             const int64_t at = (int64_t)g * p.N + (t - 1);
-            ia = st_idx(p.x, p.idx_dtype, at); ii = st_idx(p.din, p.idx_dtype, at); io = st_idx(p.dout, p.idx_dtype, at);
+            ia = st_idx(p.x, p.idx_dtype, at); ii = st_idx(p.din, p.deg_dtype, at); io = st_idx(p.dout, p.deg_dtype, at);
             if (ia >= p.n_atom) ia = -1;
             if (ii >= p.n_in) ii = -1;
             if (io >= p.n_out) io = -1;
@@ -815,13 +815,14 @@ __global__ __launch_bounds__(256) void stock_tokens_kernel(const StockTokParams 
         }
     }
 }
-int stock_tok_fill(StockTokParams& p, const void* x, const void* din, const void* dout, int idx_dtype, int G, int N, int C,
+int stock_tok_fill(StockTokParams& p, const void* x, const void* din, const void* dout, int idx_dtype, int deg_dtype, int G, int N, int C,
                    int64_t n_atom, int64_t n_in, int64_t n_out, int64_t skip, float dropout_p, uint64_t seed, const uint64_t* seed_dev,
                    uint32_t salt) {
     if (G <= 0 || N < 0 || C <= 0 || (C & 3)) return MOBGT_EBADDIM;
     if (idx_dtype != MOBGT_I64 && idx_dtype != MOBGT_I32 && idx_dtype != MOBGT_I16) return MOBGT_EDTYPE;
+    if (deg_dtype != MOBGT_I64 && deg_dtype != MOBGT_I32 && deg_dtype != MOBGT_I16) return MOBGT_EDTYPE;
     p = StockTokParams{};
-    p.x = x; p.din = din; p.dout = dout; p.idx_dtype = idx_dtype; p.G = G; p.N = N; p.C = C;
+    p.x = x; p.din = din; p.dout = dout; p.idx_dtype = idx_dtype; p.deg_dtype = deg_dtype; p.G = G; p.N = N; p.C = C;
     p.n_atom = n_atom; p.n_in = n_in; p.n_out = n_out; p.skip = skip;
     p.thr = dropout_p > 0.f ? dropout_threshold(dropout_p) : 0u;
     p.inv_keep = p.thr ? 1.f / (1.f - (float)p.thr / 65536.f) : 1.f;
@@ -830,12 +831,12 @@ int stock_tok_fill(StockTokParams& p, const void* x, const void* din, const void
 }
 }  // namespace
 
-extern "C" int mobgt_stock_tokens_fwd(const void* x, const void* in_degree, const void* out_degree, int idx_dtype, const float* atom,
+extern "C" int mobgt_stock_tokens_fwd(const void* x, const void* in_degree, const void* out_degree, int idx_dtype, int deg_dtype, const float* atom,
                                       const float* indeg, const float* outdeg, const float* graph_token, float* y, int G, int N,
                                       int C, int64_t n_atom, int64_t n_in, int64_t n_out, float dropout_p, uint64_t seed,
                                       const uint64_t* seed_dev, uint32_t salt, void* stream) {
     StockTokParams p;
-    const int rc = stock_tok_fill(p, x, in_degree, out_degree, idx_dtype, G, N, C, n_atom, n_in, n_out, -1, dropout_p, seed, seed_dev, salt);
+    const int rc = stock_tok_fill(p, x, in_degree, out_degree, idx_dtype, deg_dtype, G, N, C, n_atom, n_in, n_out, -1, dropout_p, seed, seed_dev, salt);
     if (rc) return rc;
     if (((uintptr_t)atom | (uintptr_t)indeg | (uintptr_t)outdeg | (uintptr_t)graph_token | (uintptr_t)y) & 15) return MOBGT_EALIGN;
     p.atom = atom; p.indeg = indeg; p.outdeg = outdeg; p.gtok = graph_token; p.y = y;
@@ -846,11 +847,11 @@ extern "C" int mobgt_stock_tokens_fwd(const void* x, const void* in_degree, cons
 }
 
 extern "C" int mobgt_stock_tokens_bwd(const float* dy, const void* x, const void* in_degree, const void* out_degree, int idx_dtype,
-                                      float* d_atom, float* d_indeg, float* d_outdeg, float* d_graph_token, int G, int N, int C,
+                                      int deg_dtype, float* d_atom, float* d_indeg, float* d_outdeg, float* d_graph_token, int G, int N, int C,
                                       int64_t n_atom, int64_t n_in, int64_t n_out, int64_t padding_idx, float dropout_p, uint64_t seed,
                                       const uint64_t* seed_dev, uint32_t salt, void* stream) {
     StockTokParams p;
-    const int rc = stock_tok_fill(p, x, in_degree, out_degree, idx_dtype, G, N, C, n_atom, n_in, n_out, padding_idx, dropout_p, seed,
+    const int rc = stock_tok_fill(p, x, in_degree, out_degree, idx_dtype, deg_dtype, G, N, C, n_atom, n_in, n_out, padding_idx, dropout_p, seed,
                                   seed_dev, salt);
     if (rc) return rc;
     if ((uintptr_t)dy & 15) return MOBGT_EALIGN;

@@ -420,18 +420,19 @@ class Graphormer(nn.Module):
         refresh_shadows(self.layers)
         if x.shape[2] != 1:
             raise NotImplementedError("MobGT items have one feature column (wrapper.py:37)")
-        # (one feature column: a view, not a strided copy; the aliased degree tensor is widened to the ids' dtype ONCE)
+        # (one feature column: a view, not a strided copy)
         xi = x.reshape(x.shape[0], x.shape[1])
         if xi.dtype not in (torch.int64, torch.int32):
             xi = xi.long()
-        deg = in_degree.reshape(xi.shape)
-        if deg.dtype != xi.dtype:
-            deg = deg.to(xi.dtype)
         tabs = (self.atom_encoder.weight, self.in_degree_encoder.weight, self.out_degree_encoder.weight)
-        if ops.stock_tokens_ok(xi, *tabs, self.graph_token.weight):
-            # gather + graph token + input dropout: one launch each way (same values, same mask as the three ops below)
-            output = ops.stock_tokens(xi, deg, deg, *tabs, self.graph_token.weight, self.input_dropout.p, self.training, 0x1003)
+        deg_raw = in_degree.reshape(xi.shape)
+        if (ops.stock_tokens_ok(xi, *tabs, self.graph_token.weight)
+                and deg_raw.dtype in (torch.int64, torch.int32, torch.int16)):
+            # gather + graph token + input dropout: one launch each way (same values, same mask as the three ops below); the
+            # degrees go in in their own dtype
+            output = ops.stock_tokens(xi, deg_raw, deg_raw, *tabs, self.graph_token.weight, self.input_dropout.p, self.training, 0x1003)
         else:
+            deg = deg_raw if deg_raw.dtype == xi.dtype else deg_raw.to(xi.dtype)    # (the aliased degree tensor is widened ONCE)
             node_feature = ops.embed_gather_sum(list(tabs), [xi, deg, deg], padding_idx=[0, 0, 0])
             graph_token_feature = self.graph_token.weight.unsqueeze(0).expand(n_graph, -1, -1)      # (cat reads it strided: no copy)
             output = ops.dropout(torch.cat([graph_token_feature, node_feature], dim=1), self.input_dropout.p, self.training, 0x1003)

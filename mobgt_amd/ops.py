@@ -890,7 +890,7 @@ class _StockTokensFn(torch.autograd.Function):
         G, N = x.shape
         C = atom.shape[1]
         y = torch.empty(G, N + 1, C, dtype=torch.float32, device=atom.device)
-        check(_lib.lib().mobgt_stock_tokens_fwd(_p(x), _p(din), _p(dout), _IT[x.dtype], _p(atom), _p(indeg), _p(outdeg), _p(gtok), _p(y),
+        check(_lib.lib().mobgt_stock_tokens_fwd(_p(x), _p(din), _p(dout), _IT[x.dtype], _IT[din.dtype], _p(atom), _p(indeg), _p(outdeg), _p(gtok), _p(y),
                                                 G, N, C, atom.shape[0], indeg.shape[0], outdeg.shape[0], p, seed, _p(seed_dev), salt,
                                                 _stream()), "mobgt_stock_tokens_fwd")
         ctx.idx = (x, din, dout)
@@ -909,7 +909,7 @@ class _StockTokensFn(torch.autograd.Function):
         C = dy.shape[2]
         grads = [None if not need else (k[:] if (k is not None and tuple(k.shape) == tuple(sh)) else zeros_f32(tuple(sh), dy.device))
                  for need, k, sh in zip(ctx.needs_input_grad[3:7], ctx.sinks, shapes)]
-        check(_lib.lib().mobgt_stock_tokens_bwd(_p(dy), _p(x), _p(din), _p(dout), _IT[x.dtype], _p(grads[0]), _p(grads[1]), _p(grads[2]),
+        check(_lib.lib().mobgt_stock_tokens_bwd(_p(dy), _p(x), _p(din), _p(dout), _IT[x.dtype], _IT[din.dtype], _p(grads[0]), _p(grads[1]), _p(grads[2]),
                                                 _p(grads[3]), G, N, C, shapes[0][0], shapes[1][0], shapes[2][0], int(padding_idx), p,
                                                 seed, _p(seed_dev), salt, _stream()), "mobgt_stock_tokens_bwd")
         return (None, None, None, *grads, None, None, None, None, None)
@@ -923,8 +923,10 @@ def stock_tokens_ok(x, atom, indeg, outdeg, gtok):
 
 def stock_tokens(x, in_degree, out_degree, atom, indeg, outdeg, graph_token, p, training, salt, padding_idx=0):
     """The stock variant's encoder input [G, N+1, C] (model.py:193-205): graph token row + atom / in-degree / out-degree rows
-    summed, then input dropout -- one launch each way (csrc/layer.hip).  x, in_degree, out_degree: [G,N] indices of one dtype."""
+    summed, then input dropout -- one launch each way (csrc/layer.hip).  x [G,N] indices; in_degree, out_degree [G,N] indices of
+    one dtype of their own (int64 / int32 / int16 each: no cast launch)."""
     _require_cuda(x, atom)
+    assert in_degree.dtype == out_degree.dtype and in_degree.dtype in _IT and in_degree.dtype != torch.uint8 and x.dtype != torch.uint8
     if not training:
         p = 0.0
     seed, seed_dev = _DROPOUT_STATE["seed"], _DROPOUT_STATE["seed_dev"]

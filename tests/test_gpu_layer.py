@@ -962,6 +962,9 @@ def test_stock_encoder_input_in_one_launch(idt, monkeypatch):
             assert float((u - v).abs().max()) <= 2e-5 * float(v.abs().max()) + 1e-7, k
             if k < 3:
                 assert float(u[0].abs().max()) == 0.0
+        # the degrees in a narrower dtype of their own (the device collator's int16): no cast, same result
+        y16 = ops.stock_tokens(x, deg.to(torch.int16), deg.to(torch.int16), *[t.detach() for t in tabs], gtok.detach(), 0.1, True, 0x1003)
+        assert torch.equal(y16, a[0])
         y0 = ops.stock_tokens(x, deg, deg, *[t.detach() for t in tabs], gtok.detach(), 0.1, False, 0x1003)
         ref = torch.cat([gtok.detach().unsqueeze(0).expand(G, -1, -1), tabs[0].detach()[x.long()] + tabs[1].detach()[deg.long()]
                          + tabs[2].detach()[deg.long()]], dim=1)
