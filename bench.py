@@ -50,6 +50,9 @@ def parse():
                     help="do not start rocprofv3 child passes for roofline.traffic / mfma_busy_pct (fall back to profiles/attn_pmc.json)")
     ap.add_argument("--no-gemm-autotune", action="store_true", help="leave hipBLASLt's default algorithm choice (no TunableOp)")
     ap.add_argument("--cpu-seconds", type=float, default=14.0)
+    ap.add_argument("--no-sub", action="store_true",
+                    help="headline run only: do not append the secondary workloads (gow, big, stock) as child runs")
+    ap.add_argument("--sub-steps", type=int, default=100, help="timed steps of the gow / stock child runs (big: a tenth)")
     ap.add_argument("--seed", type=int, default=1)
     return ap.parse_args()
 
@@ -247,6 +250,144 @@ def live_pmc(shapes, p_drop, keep_dir=None, timeout=300):
                 valu_busy_pct=round(100.0 * m.get("SQ_ACTIVE_INST_VALU", 0.0) * 4 / (1024.0 * cyc), 2),
                 wait_any_frac=round(m.get("SQ_WAIT_ANY", 0.0) / max(m.get("SQ_WAVE_CYCLES", 1.0), 1.0), 3))
     return res or None
+
+
+def live_chain_pmc(rows, keep_dir=None, timeout=180):
+    """HBM traffic per launch of the chain forward (cluster form where the row count allows it) at `rows` rows, measured NOW
+    like the attention counters: two child runs of `rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE --kernel-trace -- python3
+    tools/chain_pmc.py rows 20` (stand-alone launches, each behind a 64 MB filler: cold L2, as in the step where a layer's
+    weights were last read ~0.5 ms earlier).  -> dict or None."""
+    import csv
+    import glob
+    import shutil
+    import tempfile
+    if shutil.which("rocprofv3") is None or os.environ.get("MOBGT_NO_LIVE_PMC") == "1":
+        return None
+    tool = os.path.join(ROOT, "tools", "chain_pmc.py")
+    tmp = tempfile.mkdtemp(prefix="mobgt_cpmc_")
+    env = dict(os.environ, TMPDIR=tmp)
+    for k in list(env):
+        if k.startswith("PYTORCH_TUNABLEOP"):
+            del env[k]
+    vals = {}
+    try:
+        for c in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(tmp, c)
+            cmd = ["rocprofv3", "--pmc", c, "--kernel-trace", "--output-format", "csv", "-d", out, "-o", "r", "--",
+                   sys.executable, tool, str(rows), "20"]
+            r = subprocess.run(cmd, env=env, cwd=tmp, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=timeout)
+            files = glob.glob(os.path.join(out, "**", "r_counter_collection.csv"), recursive=True)
+            if r.returncode != 0 or not files:
+                return None
+            v = [float(row["Counter_Value"]) for row in csv.DictReader(open(files[0]))
+                 if row["Counter_Name"] == c and "layer_chain_fwd" in row["Kernel_Name"]]
+            if len(v) < 2:
+                return None
+            vals[c] = sum(v[1:]) / (len(v) - 1)
+            if keep_dir:
+                os.makedirs(keep_dir, exist_ok=True)
+                with open(os.path.join(keep_dir, f"chain_pmc_{c}.csv"), "w") as f:
+                    for line in open(files[0]):
+                        if "Counter_Name" in line or "layer_chain" in line:
+                            f.write(line)
+    except Exception:
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    fetch, write = int(vals["FETCH_SIZE"] * 2048), int(vals["WRITE_SIZE"] * 1024)      # KB; FETCH_SIZE doubled on gfx950
+    return dict(rows=rows, traffic_bytes=fetch + write, fetch_bytes_corrected=fetch, write_bytes=write)
+
+
+# ------------------------------------------------------------------------- secondary workloads as child runs
+def run_sub_workloads(args):
+    """The other workloads this repo quotes numbers for, under the SAME clock as the headline:
+    `python bench.py --workload gow`, `--variant stock`, `--workload big` as child processes of this run (each builds its
+    model, captures its graphs, times its steps and checks itself against the oracle where the oracle can run), plus one
+    `rocprofv3 --kernel-trace` child pass of the S-BIG step for the IN-STEP durations of the attention kernels (the one
+    bias all 12 layers share is partly Infinity-Cache-resident there, unlike the all-cold roofline_stress figures)."""
+    import csv
+    import glob
+    import shutil
+    import tempfile
+    me = os.path.abspath(__file__)
+    common = ["--gpus", "1", "--no-sub", "--no-cpu-baseline", "--no-stress", "--no-loop", "--no-live-pmc", "--seed", str(args.seed)]
+    specs = {"gow": ["--workload", "gow", "--steps", str(args.sub_steps), "--warmup", "10"],
+             "stock": ["--variant", "stock", "--steps", str(args.sub_steps), "--warmup", "10"],
+             "big": ["--workload", "big", "--steps", str(max(args.sub_steps // 10, 5)), "--warmup", "3"]}
+    env = dict(os.environ)
+    for k in list(env):
+        if k.startswith("PYTORCH_TUNABLEOP"):          # (each child picks its own file name)
+            del env[k]
+    keep = ("value", "ms_per_step", "steps", "warmup", "final_loss", "long_run", "parity", "ms_per_step_chunks")
+    res = {}
+    for name, extra in specs.items():
+        t0 = time.perf_counter()
+        try:
+            r = subprocess.run([sys.executable, me] + common + extra, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                               timeout=600, text=True)
+            line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+            if r.returncode != 0 or not line:
+                res[name] = dict(error=f"rc {r.returncode}: {r.stderr[-300:]}")
+                continue
+            j = json.loads(line[-1])
+            e = {k: j.get(k) for k in keep}
+            e["workload"] = j["config"]["workload"]
+            e["padded_nodes_per_batch"] = j["config"]["padded_nodes_per_batch"]
+            if j.get("roofline"):
+                e["attn_fwd_at_timed_shapes"] = {k: j["roofline"].get(k) for k in ("achieved", "frac", "avg_launch_us", "bytes_per_launch")}
+            if name == "big":
+                e["parity"] = ("no oracle at P = 100 000 (it would need the dense 100 000^2 adjacency); the sparse path is pinned against "
+                               "the oracle on the same universe densified at P = 1 500 (tests/test_gpu_sparse.py) and the 12-layer "
+                               "stack / bias / attention at this size in tests/test_gpu_c5.py")
+            e["child_wall_s"] = round(time.perf_counter() - t0, 1)
+            res[name] = e
+        except Exception as ex:
+            res[name] = dict(error=repr(ex))
+    # in-step kernel durations of the S-BIG step: one kernel-trace pass (no counters, no --stats)
+    if shutil.which("rocprofv3") is not None and "error" not in res.get("big", {"error": 1}):
+        tmp = tempfile.mkdtemp(prefix="mobgt_bigtrace_")
+        try:
+            cmd = ["rocprofv3", "--kernel-trace", "--output-format", "csv", "-d", os.path.join(tmp, "o"), "-o", "r", "--",
+                   sys.executable, me] + common + ["--workload", "big", "--steps", "6", "--warmup", "2", "--no-parity"]
+            r = subprocess.run(cmd, env=dict(env, TMPDIR=tmp), cwd=tmp, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+            files = glob.glob(os.path.join(tmp, "o", "**", "r_kernel_trace.csv"), recursive=True)
+            if r.returncode == 0 and files:
+                rows = list(csv.DictReader(open(files[0])))
+                rows.sort(key=lambda x: int(x["Start_Timestamp"]))
+                idx = [i for i, x in enumerate(rows) if "step_prologue_kernel" in x["Kernel_Name"]]
+                seg = rows[idx[-3]:idx[-2]]                              # one replayed step (third from the end)
+                wall = (int(rows[idx[-2]]["Start_Timestamp"]) - int(seg[0]["Start_Timestamp"])) / 1e3
+                short = {"attn_fwd_kernel": "attn_fwd_us", "attn_bwd_dq_kernel": "attn_bwd_dq_us", "attn_bwd_dkv_kernel": "attn_bwd_dkv_us",
+                         "attn_bwd_one_kernel": "attn_bwd_one_us", "build_bias_kernel": "build_bias_us", "build_bias_bwd": "build_bias_bwd_us"}
+                durs = {}
+                for x in seg:
+                    for pat, key in short.items():
+                        if pat in x["Kernel_Name"]:
+                            durs.setdefault(key, []).append((int(x["End_Timestamp"]) - int(x["Start_Timestamp"])) / 1e3)
+                            break
+                b5f = attn_fwd_bytes(16, 785, 256, 8, 2, 2)
+                b5b = attn_bwd_bytes(16, 785, 256, 8, 2, 2, 2)
+                ins = dict(step_wall_us_under_profiler=round(wall, 1), kernels_per_step=len(seg),
+                           **{k: round(sum(v) / len(v), 2) for k, v in durs.items()},
+                           launches={k: len(v) for k, v in durs.items()},
+                           source="rocprofv3 --kernel-trace child pass of this run (6 replayed steps, the third from the end)")
+                if "attn_fwd_us" in ins:
+                    ins["attn_fwd_frac_of_8TBs"] = round(b5f / (ins["attn_fwd_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 3)
+                tb = sum(ins.get(k, 0.0) for k in ("attn_bwd_dq_us", "attn_bwd_dkv_us", "attn_bwd_one_us"))
+                if tb > 0:
+                    ins["attn_bwd_frac_of_8TBs"] = round(b5b / (tb * 1e-6) / 1e9 / HBM_PEAK_GBS, 3)
+                res["big"]["in_step"] = ins
+                keep_dir = os.path.join(ROOT, "gpurun_out", "sub_big")
+                os.makedirs(keep_dir, exist_ok=True)
+                with open(os.path.join(keep_dir, "big_step_summary.txt"), "w") as f:
+                    f.write(json.dumps(ins, indent=1) + "\n")
+            else:
+                res["big"]["in_step"] = dict(error=f"rc {r.returncode}")
+        except Exception as ex:
+            res["big"]["in_step"] = dict(error=repr(ex))
+        finally:
+            shutil.rmtree(tmp, ignore_errors=True)
+    return res
 
 
 # --------------------------------------------------------------------------------- fresh batch every step
@@ -457,42 +598,59 @@ def cpu_baseline_stock(model, batches, args, n_layers):
                        f"on the same pre-collated batches at {min(8, cores)} torch threads; {used:.1f} s of CPU work")
 
 
+def _parity_summary(per, what):
+    """Batch 0's figures at the top level (the keys earlier rounds reported) + the worst case over ALL timed batches."""
+    worst = max(per, key=lambda e: e["max_abs_logit_err"])
+    out = dict(per[0])
+    out.update(batches=len(per), worst_batch=per.index(worst), worst_max_abs_logit_err=worst["max_abs_logit_err"],
+               worst_rel_loss_err=max(abs(e["loss_hip"] - e["loss_oracle"]) / max(abs(e["loss_oracle"]), 1e-30) for e in per),
+               per_batch=[dict(loss_hip=e["loss_hip"], loss_oracle=e["loss_oracle"], max_abs_logit_err=e["max_abs_logit_err"]) for e in per],
+               mode=what)
+    return out
+
+
 def oracle_parity_stock(model, batches, n_layers):
-    """--variant stock: eval-mode logits and loss of the timed model vs oracle.graphormer_stock_forward on batch 0."""
+    """--variant stock: eval-mode logits and loss of the timed model vs oracle.graphormer_stock_forward on every timed batch."""
     from oracle import model_oracle as mo
     import torch.nn.functional as F
     was = model.training
     model.eval()
     try:
-        with torch.no_grad():
-            logits = model(batches[0]).float().cpu()
-            loss = float(model.training_step(batches[0], 0))
-            sd = {k: v.detach().float().cpu() for k, v in model.state_dict().items()}
-            b = _cpu_batches(batches[:1])[0]
-            ref = mo.graphormer_stock_forward(sd, b, n_layers, 8, 20)
-            ref_loss = float(F.cross_entropy(ref, b.y.view(-1), ignore_index=0))
-        return dict(loss_hip=loss, loss_oracle=ref_loss, max_abs_logit_err=float((logits - ref).abs().max()),
-                    max_abs_logit=float(ref.abs().max()), mode="eval (dropout off), batch 0, weights after the timed steps")
+        per = []
+        sd = {k: v.detach().float().cpu() for k, v in model.state_dict().items()}
+        for i, bt in enumerate(batches):
+            with torch.no_grad():
+                logits = model(bt).float().cpu()
+                loss = float(model.training_step(bt, i))
+                b = _cpu_batches([bt])[0]
+                ref = mo.graphormer_stock_forward(sd, b, n_layers, 8, 20)
+                ref_loss = float(F.cross_entropy(ref, b.y.view(-1), ignore_index=0))
+            per.append(dict(loss_hip=loss, loss_oracle=ref_loss, max_abs_logit_err=float((logits - ref).abs().max()),
+                            max_abs_logit=float(ref.abs().max())))
+        return _parity_summary(per, "eval (dropout off), every timed batch, weights after the timed steps; top-level keys = batch 0")
     finally:
         model.train(was)
 
 
 def oracle_parity(model, batches, uni, n_layers):
-    """One eval-mode forward + training_step loss of the timed model vs the oracle (fp32, CPU) on batch 0."""
+    """Eval-mode forward + training_step loss of the timed model vs the oracle (fp32, CPU) on EVERY timed batch."""
     from oracle import model_oracle as mo
     was = model.training
     model.eval()
     try:
-        with torch.no_grad():
-            logits = model(batches[0])[0].float().cpu()
-            loss = float(model.training_step(batches[0], 0))
         sd = {k: v.detach().float().cpu() for k, v in model.state_dict().items()}
-        b = _cpu_batches(batches[:1])[0]
-        with torch.no_grad():
-            ref, _ = mo.graphormer_fq_forward(sd, b, _oracle_consts(model, uni), n_layers=n_layers, H=8, D=20, hidden=model.hidden_dim)
-            ref_loss = float(mo.gradient_tail_loss(ref, b.y - 1, 0.2))
-        return dict(loss_hip=loss, loss_oracle=ref_loss, max_abs_logit_err=float((logits - ref).abs().max()),
-                    max_abs_logit=float(ref.abs().max()), mode="eval (dropout off), batch 0, weights after the timed steps")
+        consts = _oracle_consts(model, uni)
+        per = []
+        for i, bt in enumerate(batches):
+            with torch.no_grad():
+                logits = model(bt)[0].float().cpu()
+                loss = float(model.training_step(bt, i))
+                b = _cpu_batches([bt])[0]
+                ref, _ = mo.graphormer_fq_forward(sd, b, consts, n_layers=n_layers, H=8, D=20, hidden=model.hidden_dim)
+                ref_loss = float(mo.gradient_tail_loss(ref, b.y - 1, 0.2))
+            per.append(dict(loss_hip=loss, loss_oracle=ref_loss, max_abs_logit_err=float((logits - ref).abs().max()),
+                            max_abs_logit=float(ref.abs().max())))
+        return _parity_summary(per, "eval (dropout off), every timed batch, weights after the timed steps; top-level keys = batch 0")
     finally:
         model.train(was)
 
@@ -594,14 +752,16 @@ def main():
             dist.all_reduce(tl, op=dist.ReduceOp.MAX)
             el = float(tl.item())
         long_run = dict(steps=k_long, ms_per_step=el / k_long * 1e3, value=args.batch_size * world * k_long / el)
-    rccl_ranks, exposed_us = None, None
+    rccl_ranks, comm_ranks, comm_backend, exposed_us = None, None, None, None
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
         one = torch.ones(1, device=dev)
         dist.all_reduce(one)
-        rccl_ranks = int(one.item())                 # ranks that took part in an all-reduce on the data-path backend
+        comm_backend = str(dist.get_backend())
+        comm_ranks = int(one.item())                 # ranks that took part in an all-reduce on the data-path backend
+        rccl_ranks = comm_ranks if comm_backend == "nccl" else None     # ("nccl" IS RCCL on ROCm; a gloo run is not one)
         # exposed all-reduce time: the same steps once more with the gradient exchange switched off
         k2 = min(args.steps, 100)
         times = []
@@ -681,12 +841,19 @@ def main():
                 except Exception:
                     pass
             cl = all(g * t <= 16 * 128 for g, t in used)             # (rows up to which the chain kernels run their cluster form)
-            pm = pmc_file.get("fsq_chain_fwd", {}) if (name == "fsq" and C == 192 and pmc_file) else {}
+            pm, pm_src = None, None
+            if C == 192 and not args.no_live_pmc and world == 1:
+                mode_rows = max(rows, key=lambda r: sum(1 for g, t in used if g * t == r))
+                pm = live_chain_pmc(mode_rows, keep_dir=os.path.join(ROOT, "gpurun_out", "pmc_live"))
+                pm_src = "live: rocprofv3 --pmc child passes of this run (tools/chain_pmc.py, stand-alone launches behind a 64 MB filler)"
+            if pm is None:
+                pm = pmc_file.get("fsq_chain_fwd", {}) if (name == "fsq" and C == 192 and pmc_file) else {}
+                pm_src = "profiles/attn_pmc.json (tools/chain_pmc.sh, stand-alone launches at R = %s)" % pm.get("rows") if pm else None
             roofc = dict(kernel="layer_chain_fwd_cl_kernel (cluster form: 4 / 2 workgroups per 16-row block)" if cl else "layer_chain_fwd_kernel",
                          bound="hbm", achieved=tb / tt_ / 1e9, peak=HBM_PEAK_GBS, unit="GB/s",
                          frac=tb / tt_ / 1e9 / HBM_PEAK_GBS,
                          traffic=pm.get("traffic_bytes"), traffic_rows=pm.get("rows"),
-                         counters_source="profiles/attn_pmc.json (tools/chain_pmc.sh, stand-alone launches at R = %s)" % pm.get("rows") if pm else None,
+                         counters_source=pm_src,
                          bytes_per_launch=tb / len(used),
                          avg_launch_us=tt_ / len(used) * 1e6,
                          note="not HBM-bound at this size: per workgroup a chain of latency-bound phases (first touch, weight "
@@ -735,6 +902,9 @@ def main():
         if not args.no_cpu_baseline and uni.distance is not None:
             cpu = (cpu_baseline_stock(model, batches, args, n_layers) if stock
                    else cpu_baseline(model, batches, [t for _, _, t in mine], uni, args, n_layers))
+        subs = None
+        if world == 1 and name == "fsq" and not stock and not args.no_sub and not args.no_graph and not args.unfused and bf16:
+            subs = run_sub_workloads(args)
         G_total = args.batch_size * world
         out = {
             "metric": "check-ins/sec (train step)", "value": G_total * args.steps / elapsed, "unit": "check-ins/s",
@@ -751,9 +921,9 @@ def main():
                                      "accumulate_softmax_layernorm_adamw": "f32"}},
             "final_loss": loss, "ms_per_step_chunks": [round(c, 4) for c in chunk_ms], "long_run": long_run,
             "value_with_collate": with_collate,
-            "rccl_ranks": rccl_ranks, "allreduce_exposed_us": exposed_us,
+            "comm_backend": comm_backend, "comm_ranks": comm_ranks, "rccl_ranks": rccl_ranks, "allreduce_exposed_us": exposed_us,
             "parity": parity, "roofline": roof, "roofline_chain": roofc, "roofline_stress": roof5, "roofline_stress_bwd": roof5b,
-            "cpu_baseline": cpu,
+            "cpu_baseline": cpu, "workloads": subs,
         }
         print(json.dumps(out))
     if world > 1:

@@ -104,3 +104,57 @@ def test_attention_backward_properties_at_c5_shape():
     # dS rows sum to zero: sum_j P_ij (dP_ij - delta_i) = 0
     rs = db3.sum(-1)
     assert float(rs.abs().max()) < 2e-2 * float(db3.abs().max()) * 8
+
+
+def _rel_l2(got, want):
+    got, want = got.double(), want.double()
+    return float((got - want).norm() / want.norm().clamp_min(1e-30))
+
+
+def test_gowalla_814_node_graph_bias_and_six_layer_stack_vs_oracle():
+    """BASELINE configs[2]'s tail (collator.py:460-608 pads the batch to its longest trajectory: Gowalla's maximum is 814 nodes,
+    T = 815) on the TIMED S-GOW model (`workloads.build("gow")`: P = 3 679, C = 192, d = 24, 6 layers, ffn 1024, bf16): the
+    assembled bias of the 814-node graph and of a 40-node graph padded to 814 against `oracle.assemble_bias`
+    (model_fqandtoyo.py:1143-1216; split Floyd-Warshall, long-bucket bias assembly, finite SPDs far beyond the 20 hops), and
+    the six encoder layers on that batch's real token rows and bias against `oracle.encoder_layer_fq`
+    (model_fqandtoyo.py:1731-1743), layer by layer -- what tests/test_gpu_c5.py does for S-BIG (VERDICT r3 missing #5b).
+    Tolerances as there: bias half a bf16 ulp of its magnitude; stack relative L2 <= 1e-2, max |err| <= 0.06."""
+    from mobgt_amd import workloads
+    from mobgt_amd.model import refresh_shadows
+    uni, model, coll = workloads.build("gow", DEV, seed=1)
+    trajs = synth.make_batch_of_trajectories(seed=77, G=2, P=uni.P, n_user=1080,
+                                             cat_of_poi=uni.cat_of_poi, n_nodes=[814, 40])
+    batch = coll(trajs)
+    assert tuple(batch.x.shape[:2]) == (2, 814) and len(model.layers) == 6
+    model.eval()
+    with torch.no_grad():
+        pack = model.assemble_bias(batch)
+        T = 815
+        got = pack.bias[:, :, :, :T].float().cpu()
+        sd = {k: v.detach().float().cpu() for k, v in model.state_dict().items()
+              if k.split(".")[0] in ("edge_encoder", "edge_dis_encoder", "rel_pos_encoder", "poi_pos_encoder", "graph_token_virtual_distance")}
+        ref = mo.assemble_bias(sd, _cpu_batch(batch), 8, 20, "fq")
+    assert torch.equal(torch.isinf(got), torch.isinf(ref))
+    assert bool(torch.isinf(ref[1, :, :, 41:]).all()) and not bool(torch.isinf(ref[0]).any())       # padding of the short graph
+    fin = torch.isfinite(ref)
+    err = float((got[fin] - ref[fin]).abs().max())
+    print("bias max|err| %.5f  max|ref| %.4f" % (err, float(ref[fin].abs().max())))
+    assert err <= 2 ** -8 * max(1.0, float(ref[fin].abs().max()))
+    assert torch.equal(pack.bias_t[:, :, :, :T].float().cpu(), got.transpose(2, 3))
+    # SPDs of the long graph reach well beyond multi_hop_max_dist (the clamp of model_fqandtoyo.py:1168-1173 is on the path)
+    assert int(batch.rel_pos[0].max()) > 40
+    with torch.no_grad():
+        refresh_shadows(model.layers)
+        x0 = model.node_features(batch)
+        out, outs = x0, []
+        for li, layer in enumerate(model.layers):
+            out = layer(out, pack, mask=None, next_layer=model.layers[li + 1] if li + 1 < len(model.layers) else None)
+            outs.append(out.float().cpu())
+        sdl = {k: v.detach().float().cpu() for k, v in model.state_dict().items() if k.startswith("layers.")}
+        r = x0.float().cpu()
+        for li in range(len(model.layers)):
+            r = mo.encoder_layer_fq(sdl, f"layers.{li}", r, ref, 8)
+            # (rows of padded positions of the short graph attend over its 41 real keys like any other row: compared too)
+            rel, mx = _rel_l2(outs[li], r), float((outs[li] - r).abs().max())
+            print("layer %d  relL2 %.5f  max|err| %.4f" % (li, rel, mx))
+            assert rel <= 1e-2 and mx <= 0.06, (li, rel, mx)

@@ -200,7 +200,12 @@ def test_bench_launches_two_ranks_and_reports_them(tmp_path):
     lines = [l for l in out.splitlines() if l.startswith("{")]
     assert len(lines) == 1, out[-2000:]
     j = json.loads(lines[0])
-    assert j["n_gpus"] == 2 and j["rccl_ranks"] == 2 and j["config"]["global_batch"] == 32 and j["scaling"] == "weak"
+    assert j["n_gpus"] == 2 and j["comm_ranks"] == 2 and j["config"]["global_batch"] == 32 and j["scaling"] == "weak"
+    # the line says which transport carried the gradients; `rccl_ranks` is filled only by a real RCCL ("nccl") run
+    if env.get("MOBGT_TEST_SHARED_GPU") == "1":
+        assert j["comm_backend"] == "gloo" and j["rccl_ranks"] is None
+    else:
+        assert j["comm_backend"] == "nccl" and j["rccl_ranks"] == 2
     assert j["steps"] == 5 and j["value"] > 0 and np.isfinite(j["final_loss"]) and j["allreduce_exposed_us"] is not None
     assert j["long_run"]["steps"] == 200
 
