@@ -84,9 +84,42 @@ def set_grad_sinks(params, views):
             _GRAD_SINKS[p.data_ptr()] = (weakref.ref(p), v)
 
 
+# A sink is handed to the op that asks for it in its forward and written by that op's backward as if it were its own
+# buffer (also LATER than the backward returns: deferred grouped launches).  That is only sound while ONE node per
+# backward pass produces a parameter's gradient.  A parameter reached twice in one forward (tied weights, a module applied
+# twice, one table in two ops) must therefore not have a sink at all: both nodes would write the same memory and autograd
+# would add the two views of it.  The trainer's dry run counts the requests per forward pass
+# (`sink_census_*`, train.used_parameters) and leaves such parameters out of `set_grad_sinks`: they get fresh buffers,
+# autograd sums them, the gather copies the sum.
+_SINK_CENSUS = {"on": False, "cur": {}, "max": {}}
+
+
+def sink_census_begin():
+    _SINK_CENSUS.update(on=True, cur={}, max={})
+
+
+def sink_census_pass():
+    """A forward pass ends / the next one begins: fold this pass's request counts into the per-parameter maximum."""
+    c = _SINK_CENSUS
+    for k, n in c["cur"].items():
+        if n > c["max"].get(k, 0):
+            c["max"][k] = n
+    c["cur"] = {}
+
+
+def sink_census_end():
+    """-> {id(parameter): most requests seen in one forward pass}"""
+    sink_census_pass()
+    _SINK_CENSUS["on"] = False
+    out, _SINK_CENSUS["max"] = _SINK_CENSUS["max"], {}
+    return out
+
+
 def grad_sink(param):
     """The registered destination of `param`'s gradient, or None.  The entry must belong to this very tensor
     object: addresses get reused, and a stale entry would redirect some other model's gradient."""
+    if _SINK_CENSUS["on"]:
+        _SINK_CENSUS["cur"][id(param)] = _SINK_CENSUS["cur"].get(id(param), 0) + 1
     e = _GRAD_SINKS.get(param.data_ptr())
     if e is not None and e[0]() is param and e[1].shape == param.shape:
         return e[1]

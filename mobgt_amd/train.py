@@ -173,14 +173,24 @@ def used_parameters(model, loss_fns):
     if callable(loss_fns):
         loss_fns = [loss_fns]
     hit = set()
-    for fn in loss_fns:
-        for p in model.parameters():
-            p.grad = None
-        fn().backward()
-        hit |= {id(p) for p in model.parameters() if p.grad is not None}
+    ops.sink_census_begin()
+    try:
+        for fn in loss_fns:
+            for p in model.parameters():
+                p.grad = None
+            ops.sink_census_pass()
+            fn().backward()
+            hit |= {id(p) for p in model.parameters() if p.grad is not None}
+    finally:
+        census = ops.sink_census_end()
     for p in model.parameters():
         p.grad = None
-    return [p for p in model.parameters() if id(p) in hit]
+    used = [p for p in model.parameters() if id(p) in hit]
+    # parameters whose gradient has MORE than one producer per pass (tied / re-applied modules): no in-place sink
+    # (ops.grad_sink: the producers would overwrite each other and autograd would add a buffer to itself)
+    for p in used:
+        p._mobgt_multi_use = census.get(id(p), 0) > 1
+    return used
 
 
 def broadcast_parameters(model, src=0):
@@ -254,7 +264,11 @@ class TrainStep:
         self.n_head = len(head_parameters(model, used))              # params[:n_head] = the early bucket
         self.n_head_elems = self.flat.offsets[self.n_head] if self.n_head < len(used) else self.flat.flat.numel()
         self.flat_params = FlatParams(model, used)
-        ops.set_grad_sinks(self.flat.params, self.flat.views)        # big gradients are written in place (no gather copy)
+        # big gradients are written in place (no gather copy) -- except those of parameters that more than one autograd
+        # node produces per pass (`used_parameters`' census): they keep torch's accumulate-then-copy path
+        single = [(p, v) for p, v in zip(self.flat.params, self.flat.views) if not getattr(p, "_mobgt_multi_use", False)]
+        self.sinkless = [p for p in self.flat.params if getattr(p, "_mobgt_multi_use", False)]
+        ops.set_grad_sinks([p for p, _ in single], [v for _, v in single])
         # The classifier's weight gradient (61 % of the S-FSQ model's gradient bytes) is OVERWRITTEN in full by every backward
         # pass -- by the skinny weight-gradient kernel writing into its sink, or by the gather's copy of a library result --
         # so the per-step zeroing leaves that slice alone (it is zeroed by hand in the one case nothing writes it: a step in

@@ -340,3 +340,51 @@ def test_forward_passengers_of_the_category_gcn_launch_change_nothing(monkeypatc
     for a, b in zip(*outs):
         assert torch.equal(a, b)
     assert torch.isfinite(outs[0][0]).all()
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_parameter_reached_twice_per_pass_gets_no_gradient_sink(use_graph):
+    """gradient sinks are handed to the op that asks in its forward and written as that op's own buffer,
+    also by launches deferred to the end of the backward pass.  A Linear applied TWICE per forward has two producers of its
+    weight gradient; with a sink both would write one buffer and autograd would add that buffer to itself (2 x one
+    contribution, or garbage under deferral).  `train.used_parameters` counts the requests per pass and leaves such a parameter
+    out of `ops.set_grad_sinks`: the gradient must be the SUM of both applications -- checked against torch's own autograd."""
+    import torch.nn.functional as F
+    from mobgt_amd import ops
+    from mobgt_amd.train import TrainStep
+
+    class Tied(torch.nn.Module):
+        peak_lr, end_lr, warmup_updates, tot_updates, weight_decay = 1e-3, 1e-9, 2, 10, 0.0
+
+        def __init__(self):
+            super().__init__()
+            torch.manual_seed(5)
+            self.a = torch.nn.Linear(64, 64)
+            self.b = torch.nn.Linear(64, 32)
+
+        def training_step(self, x, idx):
+            h = ops.linear_splitk(x, self.a.weight, self.a.bias, bf16_wgrad=True, slope=0.2)
+            h = ops.linear_splitk(h, self.a.weight, self.a.bias, bf16_wgrad=True, slope=0.2)      # the same layer again
+            y = ops.linear_splitk(h, self.b.weight, self.b.bias, bf16_wgrad=True)
+            return (y * y).mean()
+
+    model = Tied().to(DEV)
+    x = torch.randn(96, 64, generator=torch.Generator().manual_seed(1)).to(DEV)
+    ts = TrainStep(model, [x], use_graph=use_graph, seed=3)
+    assert getattr(model.a.weight, "_mobgt_multi_use") and getattr(model.a.bias, "_mobgt_multi_use")
+    assert not getattr(model.b.weight, "_mobgt_multi_use")
+    assert ops.grad_sink(model.a.weight) is None and ops.grad_sink(model.b.weight) is not None
+    w0 = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    ts.prepare()
+    ts.step(0)
+    ref = Tied().to(DEV)
+    ref.load_state_dict(w0)
+    h = F.leaky_relu(F.linear(x, ref.a.weight, ref.a.bias), 0.2)
+    h = F.leaky_relu(F.linear(h, ref.a.weight, ref.a.bias), 0.2)
+    y = F.linear(h, ref.b.weight, ref.b.bias)
+    (y * y).mean().backward()
+    for name, p in model.named_parameters():
+        got, want = p.grad.float(), dict(ref.named_parameters())[name].grad
+        rel = float((got - want).norm() / want.norm())
+        print(name, "relL2", rel)
+        assert rel < 2e-2, (name, rel)                 # (weight-gradient operands are rounded to bf16)

@@ -154,11 +154,12 @@ def step_masks(model, batch, step, host_seed):
 @pytest.mark.parametrize("name", ["fsq", "gow"])
 def test_s_fsq_train_step_with_dropout_on_vs_oracle_with_replayed_masks(name):
     """The benchmark's step as it is timed -- dropout 0.1 everywhere (0.3 in the distance GCN), bf16, hipGraph replay --
-    against one oracle step that uses the device's masks.  `gow`: the S-GOW configuration (P = 3 679; a typical batch and
-    one padded to N = 186: multi-chunk attention, long-bucket bias assembly, full-table GCN path)."""
+    against one oracle step that uses the device's masks.  `gow`: the S-GOW configuration (P = 3 679), batches 1 and 4 of
+    the eight batches bench.py times (padded N = 60 and 141: multi-chunk attention, full-table GCN path)."""
     from mobgt_amd.train import TrainStep
     uni, model, coll = workloads.build(name, DEV, seed=1, model_overrides=dict(warmup_updates=4, tot_updates=100, peak_lr=2e-3))
-    batches = [coll(t) for t in workloads.make_pool(name, 2, 16, uni)]
+    pool = workloads.make_pool(name, 2, 16, uni) if name == "fsq" else [workloads.make_pool(name, 8, 16, uni)[i] for i in (1, 4)]
+    batches = [coll(t) for t in pool]
     sd0 = {k: v.detach().clone() for k, v in model.state_dict().items()}
     consts = oracle_consts(uni, model, name)
     host_seed = 5
