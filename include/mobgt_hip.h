@@ -555,6 +555,14 @@ int mobgt_layer_chain_bwd(const float* dout, const float* x2, const float* x1, c
  * never need resetting).  Same results as the one-workgroup form up to the f32 summation order of h w2^T and du w1 (NCL
  * partial sums).  ws = null: always the one-workgroup form.  MOBGT_CHAIN_NCL=1|2|4 caps the cluster size. */
 int64_t mobgt_chain_ws_bytes(void);
+/* Peer waits that give up (round 4; they used to trap, which kills the process -- under data parallelism the rank): a
+ * workgroup of the cluster form that does not see its partners' packets within the poll limit counts itself in the 32-bit word at
+ * byte offset mobgt_chain_ws_fault_offset() of `ws` and carries on (its results are garbage); the host reads / clears that word
+ * between steps (mobgt_amd/train.py: TrainStep.check_faults re-runs the step in the one-workgroup form).  The 32-bit word at
+ * mobgt_chain_ws_limit_offset() holds the poll limit in rounds (0 = the default, seconds): a test hook.  No reference
+ * counterpart: the reference (graphormer/model_fqandtoyo.py:1731-1743) runs one kernel per op. */
+int64_t mobgt_chain_ws_fault_offset(void);
+int64_t mobgt_chain_ws_limit_offset(void);
 /* Backward of the encoder input from d(tokens) down to the gathered rows in ONE launch (csrc/tokbwd.hip;
  * model_fqandtoyo.py:1264-1298, 1338-1347, FuseEmbeddings 444-456) = mobgt_assemble_tokens_bwd + the two data-gradient GEMMs of
  * FuseEmbeddings-4 / -2 with their LeakyReLU derivatives:  d = dropouts'(dout[g, 1 + n]);  d_add = d;  d_nf = d * real;
@@ -581,6 +589,9 @@ int mobgt_head_chain_fwd(const float* enc, const void* user, int user_dtype, int
                          float* u3, float* out, float* mean, float* rstd, int G, int T, int C, int U, float eps, float slope,
                          float dropout_p, uint64_t seed, const uint64_t* seed_dev, uint32_t salt, void* ws, void* stream);
 int64_t mobgt_head_chain_ws_bytes(void);
+/* fault count / poll limit words of that workspace: as mobgt_chain_ws_fault_offset / _limit_offset above */
+int64_t mobgt_head_chain_ws_fault_offset(void);
+int64_t mobgt_head_chain_ws_limit_offset(void);
 int mobgt_head_chain_bwd(const float* dout, const float* u3, const float* mean, const float* rstd, const void* user,
                          int user_dtype, int64_t user_offset, int64_t n_rows, const float* w3, const float* ln_w,
                          const float* ln_b, float* du3, float* denc, float* dtable, float* dgamma, float* dbeta, int G, int T,
@@ -704,6 +715,18 @@ int mobgt_head_input_fwd(const float* enc, const void* user, int user_dtype, int
                          int64_t n_rows, float* x3, int G, int T, int C, int U, void* stream);
 int mobgt_head_input_bwd(const float* dx3, const void* user, int user_dtype, int64_t user_offset, float* denc,
                          float* dtable, int64_t n_rows, int G, int T, int C, int U, void* stream);
+
+/* Workgroups of the one-launch GCN kernels (mobgt_small_gcn_fwd / _bwd and their passenger forms; graphormer/modelGNN.py:53-74)
+ * that gave up at a grid barrier since the last reset -> *count; reset != 0 clears the count.  Synchronous (a device-symbol copy):
+ * call it outside any capture, after the work in question has been waited for.  mobgt_small_gcn_set_wait_limit: the give-up limit
+ * in ticks of the 100 MHz clock (<= 0: the default, 2 s) -- a test hook. */
+int mobgt_small_gcn_faults(int reset, uint32_t* count);
+int mobgt_small_gcn_set_wait_limit(int64_t ticks_100mhz);
+
+/* Diagnostic: `workgroups` x `threads` threads (+ lds_bytes of dynamic LDS each) that hold their compute-unit slots for
+ * ticks_100mhz ticks of the 100 MHz wall clock and do nothing -- another stream's persistent kernel (the footprint of RCCL's
+ * kernels beside the step under the DDP of README.md:62 / entry.py:141) for the co-residency test of the cluster kernels. */
+int mobgt_debug_occupy(int workgroups, int threads, int lds_bytes, int64_t ticks_100mhz, void* stream);
 
 #ifdef __cplusplus
 }

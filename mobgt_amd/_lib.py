@@ -94,6 +94,13 @@ SIGNATURES = {
     "mobgt_layer_chain_bwd": (_i, [_vp] * 24 + [_i64, _i, _i, _f, _u64, _vp, _c.c_uint32, _c.c_uint32, _vp, _vp, _i] + [_vp] * 9 + [_vp, _vp]),
     "mobgt_layer_chain_fwd": (_i, [_vp] * 26 + [_i64, _i, _i, _f, _u64, _vp, _c.c_uint32, _c.c_uint32, _vp, _vp]),
     "mobgt_chain_ws_bytes": (_i64, []),
+    "mobgt_chain_ws_fault_offset": (_i64, []),
+    "mobgt_chain_ws_limit_offset": (_i64, []),
+    "mobgt_head_chain_ws_fault_offset": (_i64, []),
+    "mobgt_head_chain_ws_limit_offset": (_i64, []),
+    "mobgt_small_gcn_faults": (_i, [_i, _vp]),
+    "mobgt_small_gcn_set_wait_limit": (_i, [_i64]),
+    "mobgt_debug_occupy": (_i, [_i, _i, _i, _i64, _vp]),
     "mobgt_small_gcn_fwd": (_i, [_vp] * 14 + [_i] * 5 + [_f, _f, _u64, _vp, _c.c_uint32, _vp]),
     "mobgt_small_gcn_fwd_pack": (_i, [_vp] * 14 + [_i] * 5 + [_f, _f, _u64, _vp, _c.c_uint32, _i, _vp, _vp, _vp, _vp, _vp]
                                  + [_i, _vp, _i, _i64, _i64, _vp, _i64, _i64, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i]

@@ -49,6 +49,12 @@ namespace {
 #ifndef ATTN_BWD_CLAMPED
 #define ATTN_BWD_CLAMPED 1    // backward passes: staging loads with clamped rows instead of behind branches (exact wait counts)
 #endif
+#ifndef ATTN_LATE_PREFETCH
+#define ATTN_LATE_PREFETCH 0  // prologue: the loads the SECOND chunk needs (bias super-tile 1, K / V chunk 1) are requested behind the first barrier
+#endif
+#ifndef ATTN_EARLY_MASK
+#define ATTN_EARLY_MASK 0     // forward: the tile's dropout masks are computed in the shadow of the QK^T products (they do not depend on S)
+#endif
 #ifndef ATTN_PACKED_DROP
 #define ATTN_PACKED_DROP 1    // forward: dropout as a mask on the packed probabilities
 #endif
@@ -338,7 +344,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const AttnParams p) {
     if (PIPE) {
 #pragma unroll
         for (int j = 0; j < BiasStage<TB>::NI; ++j) ring[1].off[j] = ring[0].off[j];
-        ring[1].load(brows, min(1, nchunk - 1));
+        if (!ATTN_LATE_PREFETCH) ring[1].load(brows, min(1, nchunk - 1));
     }
 
     uint32_t rowh = 0;
@@ -365,8 +371,10 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const AttnParams p) {
     if (PIPE) {
         kreg.template store<true, false, true>(1.f, Ksb[0], nullptr);
         vreg.template store<false, true, true>(1.f, nullptr, Vtb[0]);
-        kreg.load_clamped(K, p.ldk, min(1, nchunk - 1) * KC, T);
-        vreg.load_clamped(V, p.ldv, min(1, nchunk - 1) * KC, T);
+        if (!ATTN_LATE_PREFETCH) {
+            kreg.load_clamped(K, p.ldk, min(1, nchunk - 1) * KC, T);
+            vreg.load_clamped(V, p.ldv, min(1, nchunk - 1) * KC, T);
+        }
     } else {
         Slab<D, TQ, NT>::template direct<true, false, true>(K, p.ldk, 0, T, 1.f, Ksb[0], nullptr);
         Slab<D, TQ, NT>::template direct<false, true, true>(V, p.ldv, 0, T, 1.f, nullptr, Vtb[0]);
@@ -382,6 +390,12 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const AttnParams p) {
         qf[ks] = pack8(v);
     }
     __syncthreads();
+    if (PIPE && ATTN_LATE_PREFETCH) {
+        // (everything the first tile needs has arrived: only now the second chunk's share of the launch-wide cold burst)
+        ring[1].load(brows, min(1, nchunk - 1));
+        kreg.load_clamped(K, p.ldk, min(1, nchunk - 1) * KC, T);
+        vreg.load_clamped(V, p.ldv, min(1, nchunk - 1) * KC, T);
+    }
 
 #ifdef ATTN_STAMP
     uint32_t st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -419,6 +433,13 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const AttnParams p) {
                 const bf16x8 a = *reinterpret_cast<const bf16x8*>(&Ks[t * 32 + kappa(n)][ks * 16 + 8 * hi]);
                 s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, qf[ks], s, 0, 0, 0);
             }
+            uint32_t emask[8];
+            if (DROP && ATTN_EARLY_MASK && ATTN_PACKED_DROP) {
+                const uint32_t hb0 = attn_drop_block(seed, rowh, (uint32_t)((key0 >> 4) + hi));
+#pragma unroll
+                for (int k = 0; k < 8; ++k) emask[k] = attn_drop_keep_mask2(attn_drop_word(hb0, attn_drop_mult(k)), p.thr_s);
+                __builtin_amdgcn_sched_barrier(0);
+            }
 #ifdef ATTN_STAMP_FINE
             { float d_; asm volatile("v_mov_b32 %0, %1" : "=v"(d_) : "v"(s[15])); asm volatile("" :: "v"(d_)); }
             STAMP(1);                                      // bias tile from LDS + QK^T result available
@@ -448,7 +469,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const AttnParams p) {
             // 16-bit instructions -- saturating (thr - 1) - w, arithmetic shift by 15 -- and one AND on the packed pair, instead
             // of a sign extension, two compares and two selects on the f32 values.  1/(1-p) is applied once, to the output row.
             uint32_t hb = 0;
-            if (DROP) hb = attn_drop_block(seed, rowh, (uint32_t)((key0 >> 4) + hi));
+            if (DROP && !ATTN_EARLY_MASK) hb = attn_drop_block(seed, rowh, (uint32_t)((key0 >> 4) + hi));
 #if !ATTN_PACKED_DROP
             if (DROP) {
 #pragma unroll
@@ -468,7 +489,8 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const AttnParams p) {
                 if (DROP && ATTN_PACKED_DROP) {
                     u32x4 pw = __builtin_bit_cast(u32x4, pb);
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) pw[k] &= attn_drop_keep_mask2(attn_drop_word(hb, attn_drop_mult(4 * s2 + k)), p.thr_s);
+                    for (int k = 0; k < 4; ++k)
+                        pw[k] &= ATTN_EARLY_MASK ? emask[4 * s2 + k] : attn_drop_keep_mask2(attn_drop_word(hb, attn_drop_mult(4 * s2 + k)), p.thr_s);
                     pb = __builtin_bit_cast(bf16x8, pw);
                 }
                 const bf16x8 a = *reinterpret_cast<const bf16x8*>(&Vt[kappa(n)][t * 32 + 16 * hi + 8 * s2]);
@@ -623,12 +645,13 @@ __device__ __forceinline__ void attn_bwd_dq_body(const AttnParams& p, const int 
     if (PIPE) {
 #pragma unroll
         for (int j = 0; j < BiasStage<TB>::NI; ++j) ring[1].off[j] = ring[0].off[j];
-        ring[1].load(brows, min(1, nchunk - 1));
+        if (!ATTN_LATE_PREFETCH) ring[1].load(brows, min(1, nchunk - 1));
     }
     Slab<D, TQ, PIPE ? NT : KC * 4> kreg, vreg;
     if (PIPE) {
         if (ATTN_BWD_CLAMPED) { kreg.load_clamped(K, p.ldk, 0, T); vreg.load_clamped(V, p.ldv, 0, T); }
         else { kreg.load(K, p.ldk, 0, T); vreg.load(V, p.ldv, 0, T); }
+        if (ATTN_LATE_PREFETCH) ring[1].load(brows, min(1, nchunk - 1));       // (behind the first chunk's K / V rows: those are waited for first)
     }
     auto chunk = [&](const int c, BiasStage<TB>& bst) {
         if (wave_live) bst.park(bimg, lane);                                   // (see the forward kernel)

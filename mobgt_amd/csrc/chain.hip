@@ -504,6 +504,14 @@ __global__ __launch_bounds__(NT) void layer_chain_fwd_kernel(const ChainParams p
 // bounded and traps.  Rounding: as the one-workgroup form except FFN-2 / du W1, whose f32 sums are added in NCL parts (then
 // rounded to bf16 at the same point).
 constexpr int WS_GEN_INTS = 1024;                                       // gen[<= 256 row blocks] (+ spare)
+// A member that does not see its partners' packets within the poll limit GIVES UP instead of trapping (a trap kills the
+// process -- under data parallelism the rank, and with it the job; VERDICT r3 weak #7b): it counts itself in the
+// workspace's fault word and carries on with what it has, so the launch ends, its results are garbage, and the host finds
+// the count at its next check (`mobgt_chain_faults`; train.TrainStep.check_faults re-runs the step in the one-workgroup
+// form).  Never seen in an undisturbed run: all members of a cluster are resident together by construction.
+constexpr int WS_FAULT = WS_GEN_INTS - 1;                               // workgroups that gave up, since the last reset
+constexpr int WS_LIMIT = WS_GEN_INTS - 2;                               // poll rounds before giving up; 0 = the default below
+constexpr uint32_t WS_DEFAULT_ROUNDS = 1u << 21;                        // seconds
 constexpr size_t WS_LL_WORDS = (size_t)256 * 16 * 256;                  // <= 256 live workgroups x 16 rows x C <= 256 words of 8 bytes
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -540,8 +548,8 @@ __device__ __forceinline__ void cluster_put(__amdgpu_buffer_rsrc_t area, int m, 
     }
 }
 template <int BM, int C, int LDX, int NCL, typename EPI>
-__device__ __forceinline__ void cluster_get(__amdgpu_buffer_rsrc_t area, int m, const float* __restrict__ pb, uint32_t tag, EPI&& epi,
-                                            int* dbg_rounds = nullptr) {
+__device__ __forceinline__ void cluster_get(__amdgpu_buffer_rsrc_t area, int m, const float* __restrict__ pb, uint32_t tag, uint32_t* ws_gen,
+                                            EPI&& epi, int* dbg_rounds = nullptr) {
     constexpr int NP = BM * C / 2, EPT = (NP + NT - 1) / NT;
 #ifndef LL_NEAR_ROUNDS
 #define LL_NEAR_ROUNDS 24
@@ -554,6 +562,8 @@ __device__ __forceinline__ void cluster_get(__amdgpu_buffer_rsrc_t area, int m, 
         for (int mm = 0; mm < NCL; ++mm) w[k][mm] = u32x4{0u, 0u, 0u, 0u};         // (tag 0 is never a launch's)
     int rounds = 0;
     bool missing;
+    const uint32_t lim_raw = __builtin_nontemporal_load(ws_gen + WS_LIMIT);          // (host-written, launch-invariant)
+    const int limit = (int)(lim_raw ? lim_raw : WS_DEFAULT_ROUNDS);
     do {
 #pragma unroll
         for (int k = 0; k < EPT; ++k) {
@@ -571,7 +581,11 @@ __device__ __forceinline__ void cluster_get(__amdgpu_buffer_rsrc_t area, int m, 
         for (int k = 0; k < EPT; ++k)
 #pragma unroll
             for (int mm = 0; mm < NCL; ++mm) missing |= mm != m && (w[k][mm][1] != tag || w[k][mm][3] != tag);
-        if (++rounds > (1 << 21)) __builtin_trap();                      // seconds: never in a sane run
+        if (++rounds > limit) {                                          // seconds: never in a sane run
+            // (one count per lane still waiting: non-zero = fault; limit word 0xffffffff = the tests' fault injection)
+            if (missing || lim_raw == 0xffffffffu) atomicAdd(ws_gen + WS_FAULT, 1u);
+            break;
+        }
     } while (missing);
     if (dbg_rounds) *dbg_rounds = rounds;
 #pragma unroll
@@ -767,7 +781,7 @@ __global__ __launch_bounds__(NT) void layer_chain_fwd_cl_kernel(const ChainParam
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     st_[13] = (int)wall_clock64();
 #endif
-    cluster_get<BM, C, LDX, NCL>(area, m, pb, gen + 1u, [&](int k, int r, int c, float s0, float s1) {
+    cluster_get<BM, C, LDX, NCL>(area, m, pb, gen + 1u, p.ws_gen, [&](int k, int r, int c, float s0, float s1) {
         float f0 = bf16_round(s0 + bf16_val((uint16_t)b2_l[k])), f1 = bf16_round(s1 + bf16_val((uint16_t)(b2_l[k] >> 16)));
         if (p.thr) {
             const uint32_t rowh = dropout_row_hash(seed, (uint32_t)(r0 + r) ^ p.salt2);
@@ -1366,7 +1380,7 @@ __global__ __launch_bounds__(NT) void layer_chain_bwd_cl_kernel(const ChainBwdPa
     // ---- the partial sums change hands;  dz = bf16(sum in member order)
     const __amdgpu_buffer_rsrc_t area = cluster_area<BM, C, NCL>(p.ws_ll, blk);
     cluster_put<BM, C, LDX>(area, m, pb, gen + 1u);
-    cluster_get<BM, C, LDX, NCL>(area, m, pb, gen + 1u, [&](int, int r, int c, float s0, float s1) {
+    cluster_get<BM, C, LDX, NCL>(area, m, pb, gen + 1u, p.ws_gen, [&](int, int r, int c, float s0, float s1) {
         dzb[r * LDX + c] = bf16_round(s0);
         dzb[r * LDX + c + 1] = bf16_round(s1);
     });
@@ -1518,6 +1532,8 @@ extern "C" int mobgt_layer_chain_bwd(const float* dout, const float* x2, const f
 extern "C" int64_t mobgt_chain_ws_bytes(void) {
     return (int64_t)(WS_GEN_INTS * sizeof(uint32_t) + WS_LL_WORDS * sizeof(uint64_t));
 }
+extern "C" int64_t mobgt_chain_ws_fault_offset(void) { return (int64_t)WS_FAULT * (int64_t)sizeof(uint32_t); }
+extern "C" int64_t mobgt_chain_ws_limit_offset(void) { return (int64_t)WS_LIMIT * (int64_t)sizeof(uint32_t); }
 
 extern "C" int mobgt_assemble_tokens_qkv(const float* nf, const float* real, const float* add, const float* token,
                                          const float* pe0, float* out, void* out_bf16, const void* wqkv_packed, const void* bqkv,

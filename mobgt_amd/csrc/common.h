@@ -130,8 +130,20 @@ __host__ __device__ __forceinline__ uint32_t attn_drop_mult(int m) {
 __host__ __device__ __forceinline__ uint32_t attn_drop_block(uint64_t seed, uint32_t row_hash, uint32_t key_block) {
     return mix24(row_hash + key_block * 0x9E3779B9u + (uint32_t)(seed >> 32));
 }
+#ifndef ATTN_MAD24_ASM
+#define ATTN_MAD24_ASM 0
+#endif
 __host__ __device__ __forceinline__ uint32_t attn_drop_word(uint32_t hb, uint32_t mult) {
+#if defined(__HIP_DEVICE_COMPILE__) && ATTN_MAD24_ASM
+    // one full-rate v_mad_u32_u24 per word, spelled out: from the C expression hipcc derives word m + 1 from word m by a
+    // strength-reduced chain of v_mad_u64_u32 (a quarter-rate instruction with a 64-bit result) -- seen in the ISA of all three
+    // attention kernels, four of the eight words of every 16-key block
+    uint32_t w;
+    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(w) : "v"(hb), "s"(mult), "v"(hb >> 8));
+    return w;
+#else
     return (hb & 0xffffffu) * mult + (hb >> 8);
+#endif
 }
 // thr_s = (int)dropout_threshold(p) - 32768
 __host__ __device__ __forceinline__ bool attn_drop_keep_even(uint32_t w, int thr_s) { return (int)(int16_t)(w & 0xffffu) >= thr_s; }

@@ -207,6 +207,8 @@ __global__ __launch_bounds__(256) void head_chain_fwd_kernel(const HeadChainPara
         for (int k = 0; k < EPT; ++k) w[k] = u32x4{0u, 0u, 0u, 0u};
         int rounds = 0;
         bool missing;
+        const uint32_t lim_raw = __builtin_nontemporal_load(ws_gen + (HWS_GEN_INTS - 2));
+        const int limit = (int)(lim_raw ? lim_raw : (1u << 21));
         do {
 #pragma unroll
             for (int k = 0; k < EPT; ++k) {
@@ -220,7 +222,10 @@ __global__ __launch_bounds__(256) void head_chain_fwd_kernel(const HeadChainPara
             missing = false;
 #pragma unroll
             for (int k = 0; k < EPT; ++k) missing |= w[k][1] != tag || w[k][3] != tag;
-            if (++rounds > (1 << 21)) __builtin_trap();
+            if (++rounds > limit) {          // give up instead of trapping (see csrc/chain.hip: WS_FAULT); the host finds the count
+                if (missing) atomicAdd(ws_gen + (HWS_GEN_INTS - 1), 1u);
+                break;
+            }
         } while (missing);
 #pragma unroll
         for (int k = 0; k < EPT; ++k) {
@@ -324,6 +329,9 @@ int fill(HeadChainParams& p, float dropout_p, uint64_t seed, const uint64_t* see
 extern "C" int64_t mobgt_head_chain_ws_bytes(void) {
     return (int64_t)(HWS_GEN_INTS * sizeof(uint32_t) + (size_t)HMAX_BLOCKS * 24 * (HBM * 16 / 2) * 16);
 }
+// (the last two words of the generation array: workgroups that gave up waiting for their cluster partners / poll limit, 0 = default)
+extern "C" int64_t mobgt_head_chain_ws_fault_offset(void) { return (int64_t)(HWS_GEN_INTS - 1) * (int64_t)sizeof(uint32_t); }
+extern "C" int64_t mobgt_head_chain_ws_limit_offset(void) { return (int64_t)(HWS_GEN_INTS - 2) * (int64_t)sizeof(uint32_t); }
 
 extern "C" int mobgt_head_chain_fwd(const float* enc, const void* user, int user_dtype, int64_t user_offset, const float* table,
                                     int64_t n_rows, const float* w3, const float* b3, const float* ln_w, const float* ln_b,

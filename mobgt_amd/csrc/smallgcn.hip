@@ -57,15 +57,24 @@ struct SmallGcnParams {
 // be acknowledged (explicit `s_waitcnt vmcnt(0)`: on gfx950 __syncthreads() is a bare s_barrier when the compiler sees no
 // pending LDS-DMA, it does NOT drain the vector-memory counter) before the workgroup barrier that precedes thread 0's
 // announcement -- otherwise the rows of waves 1..3 can still be in flight when another workgroup passes the counter.
+// A workgroup that waits longer than the limit GIVES UP instead of trapping (a trap kills the process; VERDICT r3 weak #7b): it
+// counts itself in g_sg_faults and carries on -- the launch ends, its results are garbage, the host finds the count at its next
+// check (mobgt_small_gcn_faults; train.TrainStep.check_faults).  Never seen in an undisturbed run: the network's <= 19
+// workgroups are resident together on any device that is not completely occupied by other streams' persistent kernels.
+__device__ unsigned int g_sg_faults = 0;
+__device__ long long g_sg_wait_ticks = 200000000LL;                          // 2 s of the 100 MHz clock
 __device__ __forceinline__ void grid_barrier(int* counter, const int target) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) {
         __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const long long t0 = wall_clock64();
+        const long long t0 = wall_clock64(), lim = g_sg_wait_ticks;
         while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
             __builtin_amdgcn_s_sleep(1);
-            if (wall_clock64() - t0 > 200000000LL) __builtin_trap();          // 2 s of a 100 MHz clock: never in a sane run
+            if (wall_clock64() - t0 > lim) {                                 // never in a sane run
+                atomicAdd(&g_sg_faults, 1u);
+                break;
+            }
         }
     }
     __syncthreads();
@@ -710,4 +719,23 @@ extern "C" int mobgt_small_gcn_bwd(const float* g, const float* ax, const float*
     return mobgt_small_gcn_bwd_bias(g, ax, a_t, w1, w2, h1, t, h2, t2, dw0, db0, dw1, db1, dw2, db2, dt2, dt, counter, n, K0, H1, H2, H3,
                                     slope, dropout_p, seed, seed_dev, salt, 0, nullptr, 0, 1, 0, nullptr, nullptr, nullptr, nullptr, nullptr,
                                     nullptr, nullptr, nullptr, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, stream);
+}
+
+// Workgroups of the one-launch GCN kernels that gave up at a grid barrier since the last reset (`reset` != 0 clears the count).
+// Synchronous (hipMemcpyFromSymbol): call it from the host outside any capture, after the work in question has been waited for.
+extern "C" int mobgt_small_gcn_faults(int reset, uint32_t* count) {
+    unsigned int v = 0;
+    hipError_t e = hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_sg_faults), sizeof(v));
+    if (e != hipSuccess) return (int)e;
+    if (count) *count = v;
+    if (reset && v) {
+        const unsigned int z = 0;
+        e = hipMemcpyToSymbol(HIP_SYMBOL(g_sg_faults), &z, sizeof(z));
+    }
+    return (int)e;
+}
+// Test hook: the barrier's give-up limit in ticks of the 100 MHz clock (<= 0: the default of 2 s).
+extern "C" int mobgt_small_gcn_set_wait_limit(int64_t ticks_100mhz) {
+    const long long v = ticks_100mhz > 0 ? ticks_100mhz : 200000000LL;
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_sg_wait_ticks), &v, sizeof(v));
 }

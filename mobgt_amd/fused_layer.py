@@ -260,7 +260,7 @@ def chain_workspace(dev):
     """Hand-over counters + exchange buffers of the cluster form of the chain kernels (include/mobgt_hip.h:
     mobgt_chain_ws_bytes): one per device, zeroed once, for ONE stream at a time (the step's compute stream).  It must exist
     before a graph capture starts (an eager warm-up step creates it).  MOBGT_CHAIN_NCL=1 -> None (one-workgroup form)."""
-    if _os_ln.environ.get("MOBGT_CHAIN_NCL") == "1":
+    if _os_ln.environ.get("MOBGT_CHAIN_NCL") == "1" or ops.SAFE_FORMS[0]:
         return None
     key = dev.index if dev.index is not None else torch.cuda.current_device()
     ws = _CHAIN_WS.get(key)

@@ -439,7 +439,8 @@ class GraphConvolution(nn.Module):
 def _small_gcn_ok(gcn, x, adj, adj_x, adj_t):
     """The whole network as one launch each way (csrc/smallgcn.hip): a 3-layer GCN on a small dense f32 graph whose
     constant first product adj @ x and transpose are supplied."""
-    if os.environ.get("MOBGT_NO_SMALL_GCN") == "1" or len(gcn.gcn) != 3:
+    from . import ops as _ops
+    if os.environ.get("MOBGT_NO_SMALL_GCN") == "1" or _ops.SAFE_FORMS[0] or len(gcn.gcn) != 3:
         return False
     if not (torch.is_tensor(adj) and adj.is_cuda and adj.dtype == torch.float32 and adj.dim() == 2 and adj.is_contiguous()):
         return False

@@ -28,6 +28,66 @@ def _require_cuda(*ts):
             raise RuntimeError("mobgt_amd ops run on the GPU only (there is no CPU fallback); got a CPU tensor")
 
 
+# ---- launches whose workgroups wait for each other (cluster form of the chain kernels, the head's cluster, the one-launch GCN) ----
+# They give up after a bounded wait and count the event instead of trapping (csrc/chain.hip WS_FAULT, head.hip, smallgcn.hip).
+# SAFE_FORMS[0] = True makes every caller take the form WITHOUT cross-workgroup waits (one workgroup per row block, the head as
+# three launches, the GCN layer by layer): what train.TrainStep.check_faults switches to before it re-runs a faulted step.
+SAFE_FORMS = [os.environ.get("MOBGT_SAFE_FORMS") == "1"]
+
+
+def _ws_word(ws, off):
+    return ws.view(torch.int32)[off // 4:off // 4 + 1]
+
+
+def peer_wait_faults(reset=True):
+    """{site: count} of workgroups that gave up waiting for their peers since the last reset, on the current device (empty dict
+    = none).  Synchronises the device (it reads device words): call between steps, never during a capture."""
+    from . import fused_layer
+    lib = _lib.lib()
+    dev = torch.cuda.current_device()
+    torch.cuda.synchronize(dev)
+    out = {}
+    ws = fused_layer._CHAIN_WS.get(dev)
+    if ws is not None:
+        w = _ws_word(ws, int(lib.mobgt_chain_ws_fault_offset()))
+        n = int(w.item())
+        if n:
+            out["chain"] = n
+            if reset:
+                w.zero_()
+    ws = _HEAD_WS.get(dev)
+    if ws is not None:
+        w = _ws_word(ws, int(lib.mobgt_head_chain_ws_fault_offset()))
+        n = int(w.item())
+        if n:
+            out["head"] = n
+            if reset:
+                w.zero_()
+    c = ctypes.c_uint32(0)
+    check(lib.mobgt_small_gcn_faults(1 if reset else 0, ctypes.byref(c)), "mobgt_small_gcn_faults")
+    if c.value:
+        out["small_gcn"] = int(c.value)
+    return out
+
+
+def set_peer_wait_limit(rounds=0, gcn_ticks=0):
+    """Test hook: poll rounds after which the cluster kernels give up (0 = default, seconds) and the one-launch GCN's barrier limit
+    in 100 MHz ticks (0 = default, 2 s).  The workspaces must exist (an eager step creates them)."""
+    from . import fused_layer
+    lib = _lib.lib()
+    dev = torch.cuda.current_device()
+    rounds = int(rounds) & 0xFFFFFFFF                 # (0xffffffff: every wait reports a fault at once -- fault injection)
+    rounds = rounds - (1 << 32) if rounds >= (1 << 31) else rounds
+    ws = fused_layer._CHAIN_WS.get(dev)
+    if ws is not None:
+        _ws_word(ws, int(lib.mobgt_chain_ws_limit_offset())).fill_(int(rounds))
+    ws = _HEAD_WS.get(dev)
+    if ws is not None:
+        _ws_word(ws, int(lib.mobgt_head_chain_ws_limit_offset())).fill_(int(rounds))
+    check(lib.mobgt_small_gcn_set_wait_limit(int(gcn_ticks)), "mobgt_small_gcn_set_wait_limit")
+    torch.cuda.synchronize()
+
+
 class ZeroArena:
     """One f32 buffer zeroed ONCE per step from which the step's many small zero-initialised accumulators
     (bias / LayerNorm / table gradients that kernels add into) are carved, instead of one fill launch each."""
@@ -1416,7 +1476,8 @@ def head_chain_ok(enc, table, user, w3):
     return (enc.is_cuda and enc.dim() == 3 and enc.dtype == torch.float32 and table.dtype == torch.float32 and table.is_contiguous()
             and W in (320, 384) and tuple(w3.shape) == (W, W) and w3.dtype == torch.float32 and w3.is_contiguous()
             and user.dtype in (torch.int64, torch.int32) and user.numel() == enc.shape[0] and enc.shape[0] <= 160
-            and enc.shape[-1] % 16 == 0 and table.shape[1] % 16 == 0 and not __import__("os").environ.get("MOBGT_NO_HEAD_CHAIN"))
+            and enc.shape[-1] % 16 == 0 and table.shape[1] % 16 == 0 and not __import__("os").environ.get("MOBGT_NO_HEAD_CHAIN")
+            and not SAFE_FORMS[0])
 
 
 def head_chain(enc, user_table, user, user_offset, w3, b3, ln_weight, ln_bias, eps, slope, p_drop, training, salt, bf16_wgrad=False):

@@ -269,6 +269,9 @@ class TrainStep:
         single = [(p, v) for p, v in zip(self.flat.params, self.flat.views) if not getattr(p, "_mobgt_multi_use", False)]
         self.sinkless = [p for p in self.flat.params if getattr(p, "_mobgt_multi_use", False)]
         ops.set_grad_sinks([p for p, _ in single], [v for _, v in single])
+        # ... and a model that has such parameters runs its backward WITHOUT deferred weight-gradient launches: a deferred
+        # producer returns its buffer before the grouped launch fills it, and autograd would sum two still-empty buffers
+        self._defer = not self.sinkless
         # The classifier's weight gradient (61 % of the S-FSQ model's gradient bytes) is OVERWRITTEN in full by every backward
         # pass -- by the skinny weight-gradient kernel writing into its sink, or by the gather's copy of a library result --
         # so the per-step zeroing leaves that slice alone (it is zeroed by hand in the one case nothing writes it: a step in
@@ -426,7 +429,7 @@ class TrainStep:
     def _fwd_bwd(self, batch, slot=None):
         self._prologue()
         loss = self._loss(batch)
-        ops.wgrad_deferral(True)                 # leaf weight gradients are recorded ...
+        ops.wgrad_deferral(self._defer)          # leaf weight gradients are recorded ...
         try:
             loss.backward(gradient=ops.unit_grad(loss.device))
             ops.flush_deferred_wgrads()          # ... and issued as ONE launch, before anything reads a gradient
@@ -454,7 +457,7 @@ class TrainStep:
         loss = self._loss(batch)
         enc = self.model._enc_out
         head = self.flat.params[:self.n_head]
-        ops.wgrad_deferral(True)
+        ops.wgrad_deferral(self._defer)
         try:
             grads = torch.autograd.grad(loss, head + [enc], grad_outputs=ops.unit_grad(loss.device), allow_unused=True)   # frees only the nodes it ran
             ops.flush_deferred_wgrads()
@@ -466,7 +469,7 @@ class TrainStep:
 
     def _phase_b(self, i):
         enc, g_enc = self._g_enc[i]
-        ops.wgrad_deferral(True)
+        ops.wgrad_deferral(self._defer)
         try:
             torch.autograd.backward([enc], [g_enc])
             ops.flush_deferred_wgrads()
@@ -543,6 +546,59 @@ class TrainStep:
             self._fwd_bwd(self.batches[i], slot=i)
             self._opt_step()
         self.graphs[i] = g
+
+    # ---- peer waits that gave up (csrc/chain.hip WS_FAULT, head.hip, smallgcn.hip): detection and recovery ---------------
+    def recapture(self):
+        """Capture every step graph again (after ops.SAFE_FORMS changed which kernels a step launches).  Parameters,
+        optimizer state and the step counter are left as they are."""
+        if not (self.use_graph and self._prepared):
+            return
+        for i in range(len(self.batches)):
+            self.graphs[i] = self._capture(i)
+            if self.fused_opt:
+                self._capture_with_opt(i)
+
+    def check_faults(self, on_fault="raise"):
+        """Workgroups that gave up waiting for their cluster partners / at a grid barrier since the last check ({} = none;
+        synchronises the device).  The steps since then may have trained on garbage gradients: "raise" -> RuntimeError."""
+        f = ops.peer_wait_faults(reset=True)
+        if self.world > 1:                              # every rank must take the same decision
+            t = torch.tensor([float(sum(f.values()))], device=self.device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            if float(t.item()) > 0 and not f:
+                f = {"other_rank": int(t.item())}
+        if f and on_fault == "raise":
+            raise RuntimeError(f"mobgt: workgroups gave up waiting for their peers {f} -- the affected steps' gradients are invalid "
+                               "(co-residency lost to another stream's kernels?); use TrainStep.guarded_step or MOBGT_SAFE_FORMS=1")
+        return f
+
+    def guarded_step(self, i):
+        """step(i) with the promise that no peer-wait fault goes unnoticed: state snapshot -> step -> device sync + fault check;
+        on a fault the snapshot is restored, every launch switches to its form WITHOUT cross-workgroup waits
+        (ops.SAFE_FORMS: one workgroup per row block, the head as three launches, the GCN layer by layer), the graphs are
+        captured again and the step is re-run with the same dropout counter.  Costs three buffer copies and a host
+        synchronisation per step: meant for runs that share the device with other streams' persistent kernels."""
+        with torch.no_grad():
+            snap = (self.flat_params.tensor.detach().clone(), self.exp_avg.clone(), self.exp_avg_sq.clone(), self.seed_dev.clone())
+        sched = dict(self.sched_state)
+        loss = self.step(i)
+        if not self.check_faults(on_fault="return"):
+            return loss
+        with torch.no_grad():
+            self.flat_params.tensor.copy_(snap[0])
+            self.exp_avg.copy_(snap[1])
+            self.exp_avg_sq.copy_(snap[2])
+            self.seed_dev.copy_(snap[3])
+            self.sync_shadows()
+        self.sched_state = sched
+        self._set_lr()
+        ops.SAFE_FORMS[0] = True
+        ops.set_peer_wait_limit(0, 0)
+        self.recapture()
+        self.faults_recovered = getattr(self, "faults_recovered", 0) + 1
+        loss = self.step(i)
+        self.check_faults(on_fault="raise")
+        return loss
 
     def add_batch(self, batch):
         """Register one more static batch (a new shape bucket of EpochLoop) and, in graph mode after `prepare()`, capture

@@ -388,3 +388,105 @@ def test_parameter_reached_twice_per_pass_gets_no_gradient_sink(use_graph):
         rel = float((got - want).norm() / want.norm())
         print(name, "relL2", rel)
         assert rel < 2e-2, (name, rel)                 # (weight-gradient operands are rounded to bf16)
+
+
+def _fixed_step_grads(ts, state, i=0):
+    """Gradients (flat buffer) and loss of step i taken from `state` = (params, exp_avg, exp_avg_sq, seed counter)."""
+    with torch.no_grad():
+        ts.flat_params.tensor.copy_(state[0])
+        ts.exp_avg.copy_(state[1])
+        ts.exp_avg_sq.copy_(state[2])
+        ts.seed_dev.copy_(state[3])
+        ts.sync_shadows()
+    loss = float(ts.step(i))
+    torch.cuda.synchronize()
+    return ts.flat.flat.detach().clone(), loss
+
+
+def _state_of(ts):
+    return (ts.flat_params.tensor.detach().clone(), ts.exp_avg.clone(), ts.exp_avg_sq.clone(), ts.seed_dev.clone())
+
+
+def test_step_graph_beside_another_streams_persistent_kernel_never_gives_up():
+    """VERDICT r3 weak #7b: the cluster form of the chain kernels, the head's cluster and the one-launch GCN wait for peer
+    workgroups; under data parallelism the step's graph replays BESIDE RCCL's persistent kernels on the comm stream.  Stand-in:
+    64 (then 150) workgroups that hold compute units on a second stream (mobgt_debug_occupy) while the S-FSQ step graph replays
+    2 000 times.  No workgroup may give up (they used to trap), and a step taken from a fixed state beside the occupier must
+    produce the gradients of the undisturbed step."""
+    from mobgt_amd import _lib, ops, workloads
+    from mobgt_amd.train import TrainStep
+    uni, model, coll = workloads.build("fsq", DEV, seed=1)
+    batches = [coll(t) for t in workloads.make_pool("fsq", 2, 16, uni)]
+    ts = TrainStep(model, batches, use_graph=True, seed=1)
+    ts.prepare()
+    assert not ops.SAFE_FORMS[0]
+    ops.peer_wait_faults(reset=True)
+    state = _state_of(ts)
+    g_ref, loss_ref = _fixed_step_grads(ts, state)
+    side = torch.cuda.Stream()
+    lib = _lib.lib()
+
+    import ctypes
+
+    def occupy(n_wg, ticks):
+        with torch.cuda.stream(side):
+            _lib.check(lib.mobgt_debug_occupy(n_wg, 256, 0, ticks, ctypes.c_void_p(side.cuda_stream)), "mobgt_debug_occupy")
+    # the same step beside 64 occupied compute-unit slots (RCCL's footprint), then beside 150 (fewer free units than the chain
+    # launch has workgroups: members of a cluster then start late -- a delay, never a give-up)
+    for n_wg in (64, 150):
+        occupy(n_wg, 300000)                      # 3 ms
+        g, loss = _fixed_step_grads(ts, state)
+        side.synchronize()
+        assert ops.peer_wait_faults() == {}
+        rel = float((g - g_ref).norm() / g_ref.norm())
+        print("beside %d occupied slots: loss %.6f (undisturbed %.6f), gradient relL2 vs undisturbed %.2e" % (n_wg, loss, loss_ref, rel))
+        assert abs(loss - loss_ref) <= 1e-6 * abs(loss_ref) and rel < 1e-3      # (f32 atomics in a few kernels: not bitwise)
+    for it in range(2000):
+        if it % 4 == 0:
+            occupy(64, 20000)                     # 200 us each, back to back on the side stream
+        ts.step(it)
+    torch.cuda.synchronize()
+    assert ops.peer_wait_faults() == {}
+    assert np.isfinite(float(ts.loss_out))
+
+
+def test_injected_peer_wait_fault_is_detected_and_the_step_rerun_in_the_safe_forms():
+    """A peer wait that gives up sets a fault word instead of trapping; `TrainStep.guarded_step` finds it, restores the
+    snapshot, switches every launch to its form without cross-workgroup waits (ops.SAFE_FORMS), captures the graphs again and
+    re-runs the step.  Fault injection: limit word 0xffffffff makes every cluster wait report a fault and leave at once."""
+    from mobgt_amd import ops, workloads
+    from mobgt_amd.train import TrainStep
+    uni, model, coll = workloads.build("fsq", DEV, seed=1, model_overrides=dict(n_layers=2))
+    batches = [coll(t) for t in workloads.make_pool("fsq", 1, 16, uni)]
+    ts = TrainStep(model, batches, use_graph=True, seed=1)
+    ts.prepare()
+    try:
+        ops.peer_wait_faults(reset=True)
+        state = _state_of(ts)
+        g_ref, loss_ref = _fixed_step_grads(ts, state)
+        p_ref = ts.flat_params.tensor.detach().clone()
+        with torch.no_grad():
+            ts.flat_params.tensor.copy_(state[0]); ts.exp_avg.copy_(state[1]); ts.exp_avg_sq.copy_(state[2]); ts.seed_dev.copy_(state[3])
+            ts.sync_shadows()
+        ops.set_peer_wait_limit(0xFFFFFFFF)
+        with pytest.raises(RuntimeError, match="gave up waiting"):
+            ts.step(0)
+            ts.check_faults()                       # an unguarded step: the fault is at least never silent
+        with torch.no_grad():
+            ts.flat_params.tensor.copy_(state[0]); ts.exp_avg.copy_(state[1]); ts.exp_avg_sq.copy_(state[2]); ts.seed_dev.copy_(state[3])
+            ts.sync_shadows()
+        loss = float(ts.guarded_step(0))
+        torch.cuda.synchronize()
+        assert ts.faults_recovered == 1 and ops.SAFE_FORMS[0]
+        assert ops.peer_wait_faults() == {}
+        g = ts.flat.flat.detach()
+        rel = float((g - g_ref).norm() / g_ref.norm())
+        print("re-run in the safe forms: loss %.6f (cluster forms %.6f), gradient relL2 %.2e" % (loss, loss_ref, rel))
+        # (the forms differ by the order of a few f32 sums in front of bf16 rounding points: DESIGN 7)
+        assert abs(loss - loss_ref) <= 2e-3 * abs(loss_ref) and rel < 2e-2
+        dp = float((ts.flat_params.tensor.detach() - p_ref).abs().max())
+        assert dp <= 2.5 * float(ts.lr)             # one AdamW step from the snapshot, as in the undisturbed run
+        assert int(ts.seed_dev.item()) == int(state[3].item()) + 1
+    finally:
+        ops.SAFE_FORMS[0] = False
+        ops.set_peer_wait_limit(0)
