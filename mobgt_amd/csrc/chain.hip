@@ -351,6 +351,17 @@ __device__ __forceinline__ void ln_rows_hw(const float* __restrict__ xb, uint16_
     }
 }
 
+// rows of the f32 residual tile [BM][LDX] -> global [R][C] (pre-LN layers without a successor in the chain: x2 leaves as it is)
+template <int BM, int C, int LDX>
+__device__ __forceinline__ void store_f32_rows(const float* __restrict__ xb, float* __restrict__ dst, int r0, int R, int own_mod = 1,
+                                               int own_rem = 0) {
+    for (int e = threadIdx.x; e < BM * (C / 4); e += NT) {
+        const int r = e / (C / 4), c = (e % (C / 4)) * 4;
+        if (r0 + r < R && (own_mod == 1 || r % own_mod == own_rem))
+            *reinterpret_cast<float4*>(dst + (int64_t)(r0 + r) * C + c) = *reinterpret_cast<const float4*>(xb + r * LDX + c);
+    }
+}
+
 // rows of an LDS bf16 tile [BM][LD] -> global [R][N], 16 bytes per thread
 template <int BM, int N, int LD>
 __device__ __forceinline__ void store_rows(const uint16_t* __restrict__ src, uint16_t* __restrict__ dst, int r0, int R) {
@@ -380,7 +391,7 @@ __global__ __launch_bounds__(NT) void layer_chain_fwd_kernel(const ChainParams p
     pre1.issue(p.wo);
     LnW<C> ln1, ln2;
     ln1.issue(p.n1w, p.n1b);
-    ln2.issue(p.nxw, p.nxb);
+    if (p.nxw) ln2.issue(p.nxw, p.nxb);           // (null: a pre-LN layer whose successor is not part of this chain -- x2 is the output)
     // this block's rows of a (bf16) and x (f32) -> LDS; rows past R are clamped (their results are never stored)
     for (int e = threadIdx.x; e < BM * (C / 8); e += NT) {
         const int r = e / (C / 8), c = (e % (C / 8)) * 8;
@@ -461,6 +472,11 @@ __global__ __launch_bounds__(NT) void layer_chain_fwd_kernel(const ChainParams p
     __syncthreads();
     STAMP(6);
     // ---- out = ffn_norm2(x2)  (f32 residual stream + the bf16 copy the next QKV GEMM multiplies)
+    //      pre-LN (model.py:479-489): the norm is the NEXT layer's self_attention_norm, the residual stream stays x2 (p.out null)
+    if (!p.nxw) {
+        store_f32_rows<BM, C, LDX>(xb, p.x2, r0, p.R);
+        return;
+    }
     ln_rows<BM, C, LDX, LDA>(xb, ab, ln2, p.x2, p.out_a, p.out, p.mean2, p.rstd2, r0, p.R);
     if (!p.wq) return;
     __syncthreads();
@@ -682,7 +698,7 @@ __global__ __launch_bounds__(NT) void layer_chain_fwd_cl_kernel(const ChainParam
     if constexpr (DEEP) pre2.issue(p.w1, m * (FS / 16));
     LnWH<C> ln1, ln2;
     ln1.issue(p.n1w, p.n1b);
-    ln2.issue(p.nxw, p.nxb);
+    if (p.nxw) ln2.issue(p.nxw, p.nxb);           // (null: see layer_chain_fwd_kernel)
     // biases at this lane's columns: group g of a product belongs to wave g % NW and is that wave's (g / NW)-th
     const int wave = threadIdx.x >> 6;
     constexpr int NG1 = (C / 16 + NW - 1) / NW, NG2 = (FS / 16 + NW - 1) / NW, NG4 = (QS / 16 + NW - 1) / NW;
@@ -802,7 +818,11 @@ __global__ __launch_bounds__(NT) void layer_chain_fwd_cl_kernel(const ChainParam
     // (every thread of this workgroup holds every member's words: all of them have read gen)
     if (m == 0 && threadIdx.x == 0) __hip_atomic_store(p.ws_gen + blk, gen + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     STAMP(7);
-    // ---- out = ffn_norm2(x2)
+    // ---- out = ffn_norm2(x2)   (pre-LN: see layer_chain_fwd_kernel)
+    if (!p.nxw) {
+        store_f32_rows<BM, C, LDX>(xb, p.x2, r0, p.R, NCL, m);
+        return;
+    }
     ln_rows_hw<BM, C, LDX, LDA>(xb, ab, ln2, p.x2, p.out_a, p.out, p.mean2, p.rstd2, r0, p.R, NCL, m);
     if (!p.wq) return;
     __syncthreads();
@@ -971,6 +991,11 @@ struct ChainBwdParams {
     // and its four weight-gradient problems ride in this launch as extra workgroups (blockIdx >= n_chain) on the ~200
     // compute units the 16-row chain workgroups leave idle -- the layer above then has NO launch after its attention backward.
     const uint16_t *t_dqkv, *t_wqt;
+    // pre-LN layers (model.py:479-489): the second norm of the chain is the NEXT layer's self_attention_norm, applied to the
+    // residual stream x2 to form that layer's attention input; the stream itself passes by.  So
+    //     dx2 = dout + norm'(dqkv_next Wqkv_next)      (fq: dx2 = norm'(dout + dqkv_next Wqkv_next))
+    // and without a successor in the chain (nxw null) dx2 = dout.
+    int pre_ln;
     mobgt_wgrad::WgradParams wg[4];
     int wg_first[5], wg_tiles[4], wg_splits[4];
     int n_wg, n_chain;
@@ -1006,6 +1031,17 @@ struct LnBwdPre {
     __device__ __forceinline__ void issue(const float* __restrict__ xpre, const float* __restrict__ g_mean,
                                           const float* __restrict__ g_rstd, const float* __restrict__ wp, int r0, int R) {
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        if (!wp) {          // no norm at this point of the chain (pre-LN, no successor): zeros make norm'(0) + res = res exactly
+#pragma unroll
+            for (int k = 0; k < PER; ++k) w[k] = 0.f;
+#pragma unroll
+            for (int i = 0; i < NR; ++i) {
+                mu[i] = rs[i] = 0.f;
+#pragma unroll
+                for (int k = 0; k < PER; ++k) x[i][k] = 0.f;
+            }
+            return;
+        }
 #pragma unroll
         for (int k = 0; k < PER; ++k) w[k] = wp[min(lane + 64 * k, C - 1)];
 #pragma unroll
@@ -1094,7 +1130,8 @@ __device__ __forceinline__ void flush_colsums(const float* __restrict__ red, flo
         float s = 0.f;
 #pragma unroll
         for (int w = 0; w < NW; ++w) s += red[(which * NW + w) * C + c];
-        atomicAdd((which == 0 ? g0 : (which == 1 ? g1 : g2)) + c, s);
+        float* dst = which == 0 ? g0 : (which == 1 ? g1 : g2);
+        if (dst) atomicAdd(dst + c, s);
     }
 }
 
@@ -1107,6 +1144,12 @@ struct LnBwdPreH {
     __device__ __forceinline__ void issue(const float* __restrict__ xpre, const float* __restrict__ g_mean,
                                           const float* __restrict__ g_rstd, const float* __restrict__ wp, int r0, int R) {
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hl = lane & 31;
+        if (!wp) {          // (see LnBwdPre)
+            mu = rs = 0.f;
+#pragma unroll
+            for (int k = 0; k < PER; ++k) w[k] = x[k] = 0.f;
+            return;
+        }
         const int64_t row = min(r0 + min(2 * wave + (lane >> 5), BM - 1), R - 1);
         mu = g_mean[row];
         rs = g_rstd[row];
@@ -1171,7 +1214,8 @@ __device__ __forceinline__ void flush_colsums_rows(const float* __restrict__ red
         float s = 0.f;
 #pragma unroll
         for (int r = 0; r < BM; ++r) s += red[(which * BM + r) * C + c];
-        atomicAdd((which == 0 ? g0 : (which == 1 ? g1 : g2)) + c, s);
+        float* dst = which == 0 ? g0 : (which == 1 ? g1 : g2);
+        if (dst) atomicAdd(dst + c, s);
     }
 }
 
@@ -1212,8 +1256,17 @@ __global__ __launch_bounds__(NT) void layer_chain_bwd_kernel(const ChainBwdParam
         const int r = e / (F / 8), c = (e % (F / 8)) * 8;
         *reinterpret_cast<uint4*>(ub + r * LDH + c) = *reinterpret_cast<const uint4*>(p.u + (int64_t)min(r0 + r, p.R - 1) * F + c);
     }
+    if (p.pre_ln) {
+        // pre-LN: dout -> dxb (the residual path: added behind the norm's backward), dzb = 0 (+ the tail product below)
+        for (int e = threadIdx.x; e < BM * (C / 4); e += NT) {
+            const int r = e / (C / 4), c = (e % (C / 4)) * 4;
+            *reinterpret_cast<float4*>(dxb + r * LDX + c) = *reinterpret_cast<const float4*>(p.dout + (int64_t)min(r0 + r, p.R - 1) * C + c);
+            *reinterpret_cast<float4*>(dzb + r * LDX + c) = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
     if (p.t_dqkv) {
         // ---- the upper layer's input gradient, finished here: dout <- dx1 (what `dout` holds) + dqkv Wqkv
+        if (!p.pre_ln)
         for (int e = threadIdx.x; e < BM * (C / 4); e += NT) {
             const int r = e / (C / 4), c = (e % (C / 4)) * 4;
             *reinterpret_cast<float4*>(dzb + r * LDX + c) = *reinterpret_cast<const float4*>(p.dout + (int64_t)min(r0 + r, p.R - 1) * C + c);
@@ -1232,7 +1285,11 @@ __global__ __launch_bounds__(NT) void layer_chain_bwd_kernel(const ChainBwdParam
         }, pre0);
         __syncthreads();
     }
-    // ---- dx2 = ffn_norm2'(dout);  df = dropout'(dx2)
+    // ---- dx2 = ffn_norm2'(dout);  df = dropout'(dx2)      (pre-LN: dx2 = dout + norm'(tail product), see ChainBwdParams)
+    if (p.pre_ln) {
+        if (!p.t_dqkv) __syncthreads();
+        ln_bwd_rows<BM, C, LDX, LDA>(dzb, nullptr, lp2, dxb, dxb, nullptr, gb, p.df, red, r0, p.R, p.thr, p.inv_keep, seed, p.salt2);
+    } else
     ln_bwd_rows<BM, C, LDX, LDA>(p.t_dqkv ? dzb : nullptr, p.dout, lp2, nullptr, dxb, nullptr, gb, p.df, red, r0, p.R,
                                  p.thr, p.inv_keep, seed, p.salt2);
     __syncthreads();
@@ -1328,8 +1385,17 @@ __global__ __launch_bounds__(NT) void layer_chain_bwd_cl_kernel(const ChainBwdPa
         const int r = e / (FS / 8), c = (e % (FS / 8)) * 8;
         *reinterpret_cast<uint4*>(ub + r * LDHS + c) = *reinterpret_cast<const uint4*>(p.u + (int64_t)min(r0 + r, p.R - 1) * F + m * FS + c);
     }
+    if (p.pre_ln) {
+        // pre-LN: dout -> dxb (the residual path: added behind the norm's backward), dzb = 0 (+ the tail product below)
+        for (int e = threadIdx.x; e < BM * (C / 4); e += NT) {
+            const int r = e / (C / 4), c = (e % (C / 4)) * 4;
+            *reinterpret_cast<float4*>(dxb + r * LDX + c) = *reinterpret_cast<const float4*>(p.dout + (int64_t)min(r0 + r, p.R - 1) * C + c);
+            *reinterpret_cast<float4*>(dzb + r * LDX + c) = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
     if (p.t_dqkv) {
         // ---- the upper layer's input gradient, finished here by every member: dout <- dx1 (what `dout` holds) + dqkv Wqkv
+        if (!p.pre_ln)
         for (int e = threadIdx.x; e < BM * (C / 4); e += NT) {
             const int r = e / (C / 4), c = (e % (C / 4)) * 4;
             *reinterpret_cast<float4*>(dzb + r * LDX + c) = *reinterpret_cast<const float4*>(p.dout + (int64_t)min(r0 + r, p.R - 1) * C + c);
@@ -1349,6 +1415,11 @@ __global__ __launch_bounds__(NT) void layer_chain_bwd_cl_kernel(const ChainBwdPa
     // ---- dx2 = ffn_norm2'(dout);  df = dropout'(dx2): all rows on every member, member m writes rows m (mod NCL) and
     //      the column sums of columns [m CS, (m + 1) CS)
     const uint32_t gen = __hip_atomic_load(p.ws_gen + blk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // (used at the hand-over)
+    if (p.pre_ln) {
+        if (!p.t_dqkv) __syncthreads();
+        ln_bwd_rows_hw<BM, C, LDX, LDA>(dzb, nullptr, lp2, dxb, dxb, nullptr, gb, p.df, red, r0, p.R, p.thr, p.inv_keep, seed, p.salt2,
+                                        NCL, m);
+    } else
     ln_bwd_rows_hw<BM, C, LDX, LDA>(p.t_dqkv ? dzb : nullptr, p.dout, lp2, nullptr, dxb, nullptr, gb, p.df, red, r0, p.R,
                                  p.thr, p.inv_keep, seed, p.salt2, NCL, m);
     __syncthreads();
@@ -1455,6 +1526,7 @@ extern "C" int mobgt_layer_chain_fwd(const void* a, const float* x, const void* 
     if (((uintptr_t)a | (uintptr_t)x | (uintptr_t)wo | (uintptr_t)w1 | (uintptr_t)w2 | (uintptr_t)wq_next | (uintptr_t)h | (uintptr_t)u | (uintptr_t)qkv_next) & 15)
         return MOBGT_EALIGN;
     if ((wq_next == nullptr) != (qkv_next == nullptr)) return MOBGT_EBADDIM;
+    if (!nxw && wq_next) return MOBGT_EBADDIM;          // (the next projection multiplies the second norm's output)
     ChainParams p = {};
     typedef const uint16_t* cu;
     p.a = (cu)a; p.x = x; p.wo = (cu)wo; p.bo = (cu)bo; p.w1 = (cu)w1; p.b1 = (cu)b1; p.w2 = (cu)w2; p.b2 = (cu)b2;
@@ -1469,16 +1541,18 @@ extern "C" int mobgt_layer_chain_fwd(const void* a, const float* x, const void* 
     if (ncl > 1) {
         p.ws_gen = reinterpret_cast<uint32_t*>(ws);
         p.ws_ll = reinterpret_cast<uint64_t*>(reinterpret_cast<uint32_t*>(ws) + WS_GEN_INTS);
+        if (C == 128 && F == 1024) return ncl == 4 ? launch_cl<16, 128, 1024, 4>(p, st) : launch_cl<16, 128, 1024, 2>(p, st);
         if (C == 192 && F == 1024) return ncl == 4 ? launch_cl<16, 192, 1024, 4>(p, st) : launch_cl<16, 192, 1024, 2>(p, st);
         if (C == 256 && F == 1024) return ncl == 4 ? launch_cl<16, 256, 1024, 4>(p, st) : launch_cl<16, 256, 1024, 2>(p, st);
         return MOBGT_EBADDIM;
     }
+    if (C == 128 && F == 1024) return launch<16, 128, 1024>(p, st);
     if (C == 192 && F == 1024) return launch<16, 192, 1024>(p, st);
     if (C == 256 && F == 1024) return launch<16, 256, 1024>(p, st);
-    return MOBGT_EBADDIM;                    // the instantiated widths: MobGT's hidden 128 / 192 (+ 64 of embeddings), ffn 1024
+    return MOBGT_EBADDIM;                    // the instantiated widths: MobGT's hidden 128 (model.py) / 192 / 256 (+ 64 of embeddings), ffn 1024
 }
 
-extern "C" int mobgt_layer_chain_bwd(const float* dout, const float* x2, const float* x1, const void* u, const float* mean1,
+static int chain_bwd_impl(int pre_ln, const float* dout, const float* x2, const float* x1, const void* u, const float* mean1,
                                      const float* rstd1, const float* mean2, const float* rstd2, const float* n1w,
                                      const float* nxw, const void* w2t, const void* w1t, const void* wot, void* df, void* du,
                                      void* dy, void* da, float* dx1, float* dnxw, float* dnxb, float* db2, float* dn1w,
@@ -1488,6 +1562,8 @@ extern "C" int mobgt_layer_chain_bwd(const float* dout, const float* x2, const f
                                      const void* const* wg_x, const int64_t* wg_ldx, float* const* wg_dw, const int64_t* wg_ldw,
                                      float* const* wg_db, const int* wg_M, const int* wg_N, void* ws, void* stream) {
     if (R <= 0) return 0;
+    if (!pre_ln && !nxw) return MOBGT_EBADDIM;              // (post-LN layers always have their second norm)
+    if (pre_ln && !nxw && tail_dqkv) return MOBGT_EBADDIM;  // (a hosted tail goes back through the successor's norm)
     if ((uintptr_t)ws & 15) return MOBGT_EALIGN;
     if (R > 0x7fffffff || n_wg < 0 || n_wg > 4) return MOBGT_EBADDIM;
     if (((uintptr_t)u | (uintptr_t)w2t | (uintptr_t)w1t | (uintptr_t)wot | (uintptr_t)du | (uintptr_t)da | (uintptr_t)tail_dqkv |
@@ -1503,6 +1579,7 @@ extern "C" int mobgt_layer_chain_bwd(const float* dout, const float* x2, const f
     p.inv_keep = p.thr ? 1.f / (1.f - (float)p.thr / 65536.f) : 1.f;
     p.seed = seed; p.seed_dev = seed_dev; p.salt1 = salt1; p.salt2 = salt2;
     p.t_dqkv = (cu)tail_dqkv; p.t_wqt = (cu)tail_wqkv_t;
+    p.pre_ln = pre_ln ? 1 : 0;
     p.n_chain = (int)((R + 15) / 16);
     p.n_wg = n_wg;
     int total = 0;
@@ -1520,13 +1597,43 @@ extern "C" int mobgt_layer_chain_bwd(const float* dout, const float* x2, const f
     if (ncl > 1) {
         p.ws_gen = reinterpret_cast<uint32_t*>(ws);
         p.ws_ll = reinterpret_cast<uint64_t*>(reinterpret_cast<uint32_t*>(ws) + WS_GEN_INTS);
+        if (C == 128 && F == 1024) return ncl == 4 ? launch_bwd_cl<16, 128, 1024, 4>(p, st) : launch_bwd_cl<16, 128, 1024, 2>(p, st);
         if (C == 192 && F == 1024) return ncl == 4 ? launch_bwd_cl<16, 192, 1024, 4>(p, st) : launch_bwd_cl<16, 192, 1024, 2>(p, st);
         if (C == 256 && F == 1024) return ncl == 4 ? launch_bwd_cl<16, 256, 1024, 4>(p, st) : launch_bwd_cl<16, 256, 1024, 2>(p, st);
         return MOBGT_EBADDIM;
     }
+    if (C == 128 && F == 1024) return launch_bwd<16, 128, 1024>(p, st);
     if (C == 192 && F == 1024) return launch_bwd<16, 192, 1024>(p, st);
     if (C == 256 && F == 1024) return launch_bwd<16, 256, 1024>(p, st);
     return MOBGT_EBADDIM;
+}
+
+#define CHAIN_BWD_ARGS dout, x2, x1, u, mean1, rstd1, mean2, rstd2, n1w, nxw, w2t, w1t, wot, df, du, dy, da, dx1, dnxw, dnxb, db2, dn1w, \
+                       dn1b, dbo, R, C, F, dropout_p, seed, seed_dev, salt1, salt2, tail_dqkv, tail_wqkv_t, n_wg, wg_g, wg_ldg, wg_x,   \
+                       wg_ldx, wg_dw, wg_ldw, wg_db, wg_M, wg_N, ws, stream
+extern "C" int mobgt_layer_chain_bwd(const float* dout, const float* x2, const float* x1, const void* u, const float* mean1,
+                                     const float* rstd1, const float* mean2, const float* rstd2, const float* n1w,
+                                     const float* nxw, const void* w2t, const void* w1t, const void* wot, void* df, void* du,
+                                     void* dy, void* da, float* dx1, float* dnxw, float* dnxb, float* db2, float* dn1w,
+                                     float* dn1b, float* dbo, int64_t R, int C, int F, float dropout_p, uint64_t seed,
+                                     const uint64_t* seed_dev, uint32_t salt1, uint32_t salt2, const void* tail_dqkv,
+                                     const void* tail_wqkv_t, int n_wg, const void* const* wg_g, const int64_t* wg_ldg,
+                                     const void* const* wg_x, const int64_t* wg_ldx, float* const* wg_dw, const int64_t* wg_ldw,
+                                     float* const* wg_db, const int* wg_M, const int* wg_N, void* ws, void* stream) {
+    return chain_bwd_impl(0, CHAIN_BWD_ARGS);
+}
+// The same launch for PRE-LN layers (graphormer/model.py:479-489; see ChainBwdParams::pre_ln): nxw / mean2 / rstd2 / x2 describe the
+// SUCCESSOR's self_attention_norm (null: no successor in the chain), dnxw / dnxb receive that norm's gradients.
+extern "C" int mobgt_layer_chain_bwd_preln(const float* dout, const float* x2, const float* x1, const void* u, const float* mean1,
+                                     const float* rstd1, const float* mean2, const float* rstd2, const float* n1w,
+                                     const float* nxw, const void* w2t, const void* w1t, const void* wot, void* df, void* du,
+                                     void* dy, void* da, float* dx1, float* dnxw, float* dnxb, float* db2, float* dn1w,
+                                     float* dn1b, float* dbo, int64_t R, int C, int F, float dropout_p, uint64_t seed,
+                                     const uint64_t* seed_dev, uint32_t salt1, uint32_t salt2, const void* tail_dqkv,
+                                     const void* tail_wqkv_t, int n_wg, const void* const* wg_g, const int64_t* wg_ldg,
+                                     const void* const* wg_x, const int64_t* wg_ldx, float* const* wg_dw, const int64_t* wg_ldw,
+                                     float* const* wg_db, const int* wg_M, const int* wg_N, void* ws, void* stream) {
+    return chain_bwd_impl(1, CHAIN_BWD_ARGS);
 }
 
 extern "C" int64_t mobgt_chain_ws_bytes(void) {

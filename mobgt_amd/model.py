@@ -194,7 +194,9 @@ def fused_layer_forward(layer, variant, x, attn_bias, n1, nx, next_layer=None):
     if (p > 0 or p_att > 0) and mha.seed_dev is None:
         seed = (seed + int(torch.randint(0, 2 ** 31 - 1, (1,)).item())) & 0x7FFFFFFFFFFFFFFF
     cfg = LayerConfig(variant, mha.num_heads, mha.scale, p, p_att, seed, mha.seed_dev, mha._layer_index * 8, pack, act)
-    cfg.from_layer = bool(getattr(x, "_mobgt_from_layer", False))
+    # (a layer the trainer cuts the backward pass in front of -- train.TrainStep's layer-wise gradient buckets -- finishes its own
+    # input gradient: the layer below runs in another autograd pass and cannot host this one's tail)
+    cfg.from_layer = bool(getattr(x, "_mobgt_from_layer", False)) and not getattr(layer, "_mobgt_cut", False)
     # the next layer's QKV projection rides in this layer's chain kernel (csrc/chain.hip) when that layer is fused, has
     # the same activation dtype and its bf16 shadows are current (refresh_shadows / the trainer refreshed ALL layers)
     nxt = next_layer
@@ -436,7 +438,10 @@ class Graphormer(nn.Module):
             node_feature = ops.embed_gather_sum(list(tabs), [xi, deg, deg], padding_idx=[0, 0, 0])
             graph_token_feature = self.graph_token.weight.unsqueeze(0).expand(n_graph, -1, -1)      # (cat reads it strided: no copy)
             output = ops.dropout(torch.cat([graph_token_feature, node_feature], dim=1), self.input_dropout.p, self.training, 0x1003)
-        for enc_layer in self.layers:
+        self._bias_pack, self._cuts = bias, {}
+        for li, enc_layer in enumerate(self.layers):
+            if getattr(enc_layer, "_mobgt_cut", False):
+                self._cuts[li] = output          # train.TrainStep: the backward pass is cut here (layer-wise gradient buckets)
             output = enc_layer(output, bias, mask=None)
         self._enc_out = output
         # (model.py:211-217 normalises every token and then reads the graph token: LayerNorm is per row, so only that row is

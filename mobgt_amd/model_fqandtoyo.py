@@ -461,7 +461,10 @@ class Graphormer(nn.Module):
             # (a prelaunched result nobody adopted -- an exception on the way -- must not meet a later, direct call of the GCN)
             self.poi_cat_model.__dict__.pop("_prelaunched", None)
         ops.trace_nan("x0", output)
+        self._bias_pack, self._cuts = bias, {}
         for li, enc_layer in enumerate(self.layers):                                           # :1347-1352
+            if getattr(enc_layer, "_mobgt_cut", False):
+                self._cuts[li] = output          # train.TrainStep: the backward pass is cut here (layer-wise gradient buckets)
             # (the layer that follows is named so that its QKV projection can ride in this layer's last launch)
             output = enc_layer(output, bias, mask=None, next_layer=self.layers[li + 1] if li + 1 < len(self.layers) else None)
             ops.trace_nan(f"layer{li}", output)

@@ -100,8 +100,11 @@ def head_parameters(model, used):
 
 def flat_order(model, used):
     """Order of the used parameters inside the flat buffers: the head's parameters first (one contiguous bucket
-    whose all-reduce can start early), then every attention's q/k/v weights (then biases) adjacent, so that its
-    fused [3C, C] projection storage is one slice of the flat parameter buffer, then the rest."""
+    whose all-reduce can start early), then the encoder layers from the LAST to the FIRST -- the order in which the backward
+    pass completes their gradients, so that "everything up to layer k" is one growing prefix of the buffer and can be
+    all-reduced while the layers below are still in their backward (TrainStep's layer-wise buckets) -- each layer as one
+    contiguous run: q/k/v weights adjacent (the fused [3C, C] projection storage is then one slice of the flat parameter
+    buffer), the block of small gradients, then the layer's remaining weights; then the rest."""
     used_ids = {id(p) for p in used}
     order, seen = [], set()
     for p in head_parameters(model, used):
@@ -116,7 +119,7 @@ def flat_order(model, used):
         return False
     layers = [m for m in model.modules() if hasattr(m, "self_attention") and hasattr(m, "ffn")]
     attn_done = set()
-    for layer in layers:
+    for layer in reversed(layers):
         # an encoder layer: q/k/v weights, then -- in the order of the fused backward's block of small gradients
         # (fused_layer._FusedLayerFn.backward) -- q/k/v biases, output bias, FFN biases, the two LayerNorms: that block
         # is then ONE slice of the flat gradient buffer and nothing of it needs a gather copy
@@ -130,6 +133,10 @@ def flat_order(model, used):
         if take([m.linear_q.weight, m.linear_k.weight, m.linear_v.weight, m.linear_q.bias, m.linear_k.bias, m.linear_v.bias,
                  m.output_layer.bias, layer.ffn.layer1.bias, layer.ffn.layer2.bias, n1.weight, n1.bias, nx.weight, nx.bias]):
             attn_done.add(id(m))
+            for p in layer.parameters():              # the rest of this layer (Wo, W1, W2): behind its group, same bucket
+                if id(p) in used_ids and id(p) not in seen:
+                    order.append(p)
+                    seen.add(id(p))
     for m in model.modules():
         if id(m) not in attn_done and all(hasattr(m, a) for a in ("linear_q", "linear_k", "linear_v")):
             take([m.linear_q.weight, m.linear_k.weight, m.linear_v.weight, m.linear_q.bias, m.linear_k.bias, m.linear_v.bias])
@@ -250,6 +257,9 @@ class TrainStep:
         # ours they would put cross-stream waits into the graph (observed: abort in capture_end).  Let go of it first.
         if getattr(model, "_enc_out", None) is not None:
             model._enc_out = None
+        model._bias_pack, model._cuts = None, {}
+        for l in getattr(model, "layers", []):
+            l._mobgt_cut = False
         for p in model.parameters():
             p.grad = None
         import gc
@@ -313,11 +323,47 @@ class TrainStep:
         self.overlap = bool(overlap and use_graph and (self.world > 1 or overlap == "force") and self.n_head > 0
                             and hasattr(model, "_enc_out"))
         self.graphs_b, self._g_enc, self._loss_slots = {}, {}, {}
+        self._plan_buckets()
         self.comm = True        # False: skip the gradient exchange (bench.py measures the exposed all-reduce time that way)
         self._prepared = False
         self.comm_buf = (torch.empty(self.flat.flat.numel(), dtype=grad_comm_dtype, device=dev)
                          if (grad_comm_dtype is not None and self.world > 1) else None)
         self.check_layout_across_ranks()
+
+    def _plan_buckets(self):
+        """Layer-wise gradient buckets (data parallel; VERDICT r3 next #3a).  `flat_order` lays the buffers out as
+        [head | layer L-1 | ... | layer 0 | rest]: the order in which the backward pass completes the gradients.  Phase B -- the
+        backward from the encoder output down -- is cut in front of a few layers into PARTS, each its own hipGraph over the one
+        autograd graph (torch.autograd.grad from the previous cut's gradient to the next cut's activation + that part's
+        parameters); after every part the slice of the flat buffer it completed is all-reduced on RCCL's stream while the next
+        part replays.  What is exposed at the end is the LAST bucket only (node features, GCNs, embedding and bias tables: a few
+        MB) instead of everything behind the head (39 % of the bytes in round 3).  `self.parts`: [(cut layer or None, first
+        parameter, end parameter, first element, end element)], in execution order; [] = the single phase B of round 3.
+        MOBGT_DDP_PARTS: number of parts (default 3; 1 = off)."""
+        self.parts = []
+        layers = list(getattr(self.model, "layers", []))
+        n_parts = int(os.environ.get("MOBGT_DDP_PARTS", "3"))
+        if not self.overlap or len(layers) < 2 or n_parts < 2:
+            return
+        pos = {id(p): i for i, p in enumerate(self.flat.params)}
+        runs, at = [], self.n_head
+        for li in reversed(range(len(layers))):
+            idx = sorted(pos[id(p)] for p in layers[li].parameters() if id(p) in pos)
+            if not idx or idx != list(range(at, at + len(idx))):
+                return                               # (a layer whose parameters are not one run behind its successor's: keep one phase B)
+            at += len(idx)
+            runs.append((li, idx[0], at))
+        # layer groups of (nearly) equal size, top of the stack first; the last part takes what is left of the model
+        n_grp = min(n_parts - 1, len(runs))
+        cuts = [runs[(g + 1) * len(runs) // n_grp - 1] for g in range(n_grp)]      # the LOWEST layer of each group
+        offs = list(self.flat.offsets) + [self.flat.flat.numel()]
+        lo = self.n_head
+        for li, _, hi in cuts:
+            self.parts.append((li, lo, hi, int(offs[lo]), int(offs[hi])))
+            layers[li]._mobgt_cut = True
+            lo = hi
+        n = len(self.flat.params)
+        self.parts.append((None, lo, n, int(offs[lo]), int(offs[n])))
 
     def layout_digest(self):
         """Hash of what every rank must agree on before one flat buffer can be all-reduced: which parameters are trained,
@@ -327,7 +373,7 @@ class TrainStep:
         h = hashlib.sha256()
         for p, off in zip(self.flat.params, self.flat.offsets):
             h.update(("%s:%d:%d;" % (names.get(id(p), "?"), off, p.numel())).encode())
-        h.update(("n=%d;head=%d" % (self.flat.flat.numel(), self.n_head_elems)).encode())
+        h.update(("n=%d;head=%d;parts=%s" % (self.flat.flat.numel(), self.n_head_elems, [p[1:] for p in getattr(self, "parts", [])])).encode())
         return h.digest()[:8]
 
     def check_layout_across_ranks(self):
@@ -478,6 +524,34 @@ class TrainStep:
         ops.set_zero_arena(None)
         self.flat.gather(self.n_head, None)
 
+    def _phase_b_part(self, i, s):
+        """Part s of phase B (see _plan_buckets): from the gradient the previous part left at its cut down to this part's cut."""
+        li, lo, hi, _, _ = self.parts[s]
+        src, g_src = self._g_enc[i]
+        last = li is None
+        ops.wgrad_deferral(self._defer)
+        try:
+            if not last:
+                cut = self.model._cuts[li]
+                grads = torch.autograd.grad([src], self.flat.params[lo:hi] + [cut], grad_outputs=[g_src], allow_unused=True)
+                self._g_enc[i] = (cut, grads[-1])
+                grads = list(grads[:-1])
+            else:
+                # (the bias tables' node hangs off every layer through the pack's token, not off the encoder input: name it)
+                tok = getattr(getattr(self.model, "_bias_pack", None), "token", None)
+                outs, gouts = [src], [g_src]
+                if tok is not None and tok.requires_grad:
+                    outs.append(tok)
+                    gouts.append(torch.zeros_like(tok))
+                torch.autograd.backward(outs, gouts)
+                grads = None
+            ops.flush_deferred_wgrads()
+        finally:
+            ops.wgrad_deferral(False)
+        if last:
+            ops.set_zero_arena(None)
+        self.flat.gather(lo, hi, grads=grads)
+
     def _capture(self, i):
         batch = self.batches[i]
         with self._on_stream():                    # warm-up on the side stream (allocator, lazy inits)
@@ -498,10 +572,19 @@ class TrainStep:
         # activations phase A's replay leaves at the same addresses (A's private pool; nothing else writes there)
         with torch.cuda.graph(g, stream=self.stream):
             self._phase_a(batch, i)
+        if self.parts:
+            gbs = []
+            for s in range(len(self.parts)):
+                gb = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(gb, stream=self.stream):
+                    self._phase_b_part(i, s)
+                gbs.append(gb)
+            self.graphs_b[i] = gbs
+            return g
         gb = torch.cuda.CUDAGraph()
         with torch.cuda.graph(gb, stream=self.stream):
             self._phase_b(i)
-        self.graphs_b[i] = gb
+        self.graphs_b[i] = [gb]
         return g
 
     def prepare(self):
@@ -621,17 +704,23 @@ class TrainStep:
             comm = self.world > 1 and self.comm
             self.graphs[j].replay()
             cb = self.comm_buf
+            # element ranges completed by phase A and by each part of phase B: every one is all-reduced (RCCL's stream) as soon
+            # as the replay that completes it has been enqueued, i.e. beside the replay of the next part
+            bounds = [(0, na)] + ([(e0, e1) for _, _, _, e0, e1 in self.parts] if self.parts else [(na, self.flat.flat.numel())])
+            works = []
+
+            def exchange(e0, e1):
+                if comm and e1 > e0:
+                    if cb is not None:
+                        cb[e0:e1].copy_(self.flat.flat[e0:e1])
+                    works.append(dist.all_reduce((cb if cb is not None else self.flat.flat)[e0:e1], op=dist.ReduceOp.SUM, async_op=True))
+            exchange(*bounds[0])
+            for gb, (e0, e1) in zip(self.graphs_b[j], bounds[1:]):
+                gb.replay()
+                exchange(e0, e1)
             if comm:
-                if cb is not None:
-                    cb[:na].copy_(self.flat.flat[:na])
-                wa = dist.all_reduce((cb if cb is not None else self.flat.flat)[:na], op=dist.ReduceOp.SUM, async_op=True)   # overlaps phase B
-            self.graphs_b[j].replay()
-            if comm:
-                if cb is not None:
-                    cb[na:].copy_(self.flat.flat[na:])
-                wb = dist.all_reduce((cb if cb is not None else self.flat.flat)[na:], op=dist.ReduceOp.SUM, async_op=True)
-                wa.wait()
-                wb.wait()
+                for w in works:
+                    w.wait()
                 if cb is not None:
                     torch.mul(cb, 1.0 / self.world, out=self.flat.flat)          # widen + average in one pass
                 else:

@@ -328,6 +328,8 @@ def test_two_phase_backward_matches_single_phase():
         ts = TrainStep(model, batches, use_graph=True, seed=5, overlap="force" if mode == "force" else False)
         ts.prepare()
         assert ts.overlap == (mode == "force")
+        if mode == "force":          # (round 4: phase B in parts -- [layer 1], [layer 0], [everything below the encoder])
+            assert [p[0] for p in ts.parts] == [1, 0, None] and len(ts.graphs_b[0]) == 3
         losses = []
         for i in range(3):
             losses.append(float(ts.step(i)))

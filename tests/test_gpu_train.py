@@ -423,6 +423,9 @@ def test_step_graph_beside_another_streams_persistent_kernel_never_gives_up():
     ops.peer_wait_faults(reset=True)
     state = _state_of(ts)
     g_ref, loss_ref = _fixed_step_grads(ts, state)
+    g_rep, _ = _fixed_step_grads(ts, state)
+    rep = float((g_rep - g_ref).norm() / g_ref.norm())      # two undisturbed runs of one step: f32 atomics in varying order
+    print("undisturbed repeat: gradient relL2 %.2e" % rep)  # in front of bf16 rounding points (measured 1e-3)
     side = torch.cuda.Stream()
     lib = _lib.lib()
 
@@ -440,7 +443,7 @@ def test_step_graph_beside_another_streams_persistent_kernel_never_gives_up():
         assert ops.peer_wait_faults() == {}
         rel = float((g - g_ref).norm() / g_ref.norm())
         print("beside %d occupied slots: loss %.6f (undisturbed %.6f), gradient relL2 vs undisturbed %.2e" % (n_wg, loss, loss_ref, rel))
-        assert abs(loss - loss_ref) <= 1e-6 * abs(loss_ref) and rel < 1e-3      # (f32 atomics in a few kernels: not bitwise)
+        assert abs(loss - loss_ref) <= 2e-5 * abs(loss_ref) and rel < max(3 * rep, 3e-3)     # (not bitwise even undisturbed)
     for it in range(2000):
         if it % 4 == 0:
             occupy(64, 20000)                     # 200 us each, back to back on the side stream
@@ -490,3 +493,43 @@ def test_injected_peer_wait_fault_is_detected_and_the_step_rerun_in_the_safe_for
     finally:
         ops.SAFE_FORMS[0] = False
         ops.set_peer_wait_limit(0)
+
+
+def test_layerwise_gradient_buckets_on_the_benched_model_match_the_single_graph():
+    """VERDICT r3 next #3a: under data parallelism phase B of the step is cut in front of layers 3 and 0 of the S-FSQ model into
+    three hipGraphs over one autograd graph (train.TrainStep._plan_buckets); the flat buffers are laid out [head | layer 5 | ...
+    | layer 0 | rest] so that what each part completes is ONE slice, all-reduced beside the next part.  Here (one process,
+    overlap="force"): same loss, gradients and parameters as the single-graph step of the same model with the chain kernels'
+    deferred tails and hosted weight gradients on; the layout's invariants; the bytes left for the last, exposed exchange."""
+    from mobgt_amd import workloads
+    from mobgt_amd.train import TrainStep
+    res = {}
+    for mode in (False, "force"):
+        uni, model, coll = workloads.build("fsq", DEV, seed=1, model_overrides=dict(peak_lr=1e-12, end_lr=1e-13))
+        batches = [coll(t) for t in workloads.make_pool("fsq", 2, 16, uni)]
+        ts = TrainStep(model, batches, use_graph=True, seed=5, overlap=mode)
+        ts.prepare()
+        if mode == "force":
+            assert [p[0] for p in ts.parts] == [3, 0, None]
+            names = {id(p): n for n, p in model.named_parameters()}
+            order = [names[id(p)] for p in ts.flat.params]
+            # head first, then layers 5 .. 0 as contiguous runs, then the rest
+            first = {li: min(i for i, n in enumerate(order) if n.startswith(f"layers.{li}.")) for li in range(6)}
+            last = {li: max(i for i, n in enumerate(order) if n.startswith(f"layers.{li}.")) for li in range(6)}
+            assert first[5] == ts.n_head and all(first[li - 1] == last[li] + 1 for li in range(5, 0, -1))
+            assert all(last[li] - first[li] + 1 == 16 for li in range(6))
+            e = [(p[3], p[4]) for p in ts.parts]
+            assert e[0][0] == ts.n_head_elems and e[0][1] == e[1][0] and e[1][1] == e[2][0] and e[2][1] == ts.flat.flat.numel()
+            mb = [4e-6 * (b - a) for a, b in [(0, ts.n_head_elems)] + e]
+            print("bucket MB (head, layers 5-3, layers 2-0, rest):", [round(x, 2) for x in mb])
+            assert mb[-1] <= 4.0            # the only exchange nothing hides
+        losses = [float(ts.step(i)) for i in range(3)]
+        res[mode] = (losses, ts.flat.flat.clone(), ts.flat_params.tensor.detach().clone())
+        del ts, model
+    (l0, g0, p0), (l1, g1, p1) = res[False], res["force"]
+    print("single graph", l0, "parts", l1)
+    np.testing.assert_allclose(l0, l1, rtol=1e-5)
+    rel = float((g1 - g0).norm() / g0.norm())
+    print("gradient relL2 parts vs single graph %.2e" % rel)
+    assert rel < 3e-3                       # (two runs of ONE form differ by ~1e-3: f32 atomics in front of bf16 rounding points)
+    np.testing.assert_allclose(p1.cpu().numpy(), p0.cpu().numpy(), atol=1e-9)
