@@ -517,7 +517,7 @@ int mobgt_small_gemm_f32_act(const float* a, int64_t lda, const float* a_mask, f
  * a [R,C] bf16; x [R,C] f32; weights bf16 [out,in] PACKED by mobgt_pack_mfma_b; biases bf16; LayerNorm weights f32.
  * Written: x1, x2, out f32 [R,C]; z, out_a (= bf16(out)) [R,C], u, h [R,F], qkv_next [R,3C] bf16; mean / rstd [R] f32 of
  * both norms.  wq_next / bq_next / qkv_next null for the last layer.  Dropout masks: those of mobgt_dropout_add_ln_fwd
- * with salt1 / salt2.  (C, F) in {(192, 1024), (256, 1024)}.  ws: see mobgt_chain_ws_bytes (may be null). */
+ * with salt1 / salt2.  (C, F) in {(128, 1024), (192, 1024), (256, 1024)}.  ws: see mobgt_chain_ws_bytes (may be null). */
 /* bf16 weight [N,K] row-major -> MFMA operand order (chain.hip): the 16 bytes W[16g + j][32s + 8q .. +7] go to byte offset
  * ((g K/32 + s) 64 + j + 16q) * 16, so that a wave's B-operand load is one contiguous KB.  n <= 96 jobs in one launch;
  * N % 16 == 0, K % 32 == 0.  transposed[i] != 0: src is [K,N] row-major and its TRANSPOSE is packed (the operand of
@@ -541,6 +541,23 @@ int mobgt_layer_chain_fwd(const void* a, const float* x, const void* wo, const v
  * problems dW [M,N] += g^T x (+ db [M] += column sums of g) over the same R rows, bf16 operands as mobgt_linear_wgrad, run
  * by extra workgroups of this launch on the compute units its 16-row blocks leave idle. */
 int mobgt_layer_chain_bwd(const float* dout, const float* x2, const float* x1, const void* u, const float* mean1,
+                          const float* rstd1, const float* mean2, const float* rstd2, const float* n1w, const float* nxw,
+                          const void* w2t, const void* w1t, const void* wot, void* df, void* du, void* dy, void* da, float* dx1,
+                          float* dnxw, float* dnxb, float* db2, float* dn1w, float* dn1b, float* dbo, int64_t R, int C, int F,
+                          float dropout_p, uint64_t seed, const uint64_t* seed_dev, uint32_t salt1, uint32_t salt2,
+                          const void* tail_dqkv, const void* tail_wqkv_t, int n_wg, const void* const* wg_g,
+                          const int64_t* wg_ldg, const void* const* wg_x, const int64_t* wg_ldx, float* const* wg_dw,
+                          const int64_t* wg_ldw, float* const* wg_db, const int* wg_M, const int* wg_N, void* ws, void* stream);
+/* The two chain launches for PRE-LN layers -- graphormer/model.py:463-489, the EncoderLayer BASELINE.json's north_star names:
+ *     y = self_attention_norm(x); y = attention(y); x = x + dropout(y); y = ffn_norm(x); y = ffn(y); x = x + dropout(y)
+ * (round 4; (C, F) = (128, 1024) is instantiated for it).  Forward = mobgt_layer_chain_fwd with
+ *     n1w / n1b = this layer's ffn_norm;  nxw / nxb = the NEXT layer's self_attention_norm, wq_next / bq_next its QKV projection
+ *     (all four null: no successor in the chain -- then x2 is the only output of the second half);  out = null: the
+ *     residual stream that leaves the layer is x2, out_a / qkv_next / mean2 / rstd2 belong to the next layer's norm.
+ * Backward = mobgt_layer_chain_bwd_preln, same arguments as mobgt_layer_chain_bwd with
+ *     dx2 = dout + nxw-norm'(tail_dqkv tail_wqkv)      (post-LN: dx2 = norm'(dout + tail product))
+ *     dnxw / dnxb: the NEXT layer's self_attention_norm gradients;  nxw null: dx2 = dout, dnxw / dnxb / mean2 / rstd2 unused. */
+int mobgt_layer_chain_bwd_preln(const float* dout, const float* x2, const float* x1, const void* u, const float* mean1,
                           const float* rstd1, const float* mean2, const float* rstd2, const float* n1w, const float* nxw,
                           const void* w2t, const void* w1t, const void* wot, void* df, void* du, void* dy, void* da, float* dx1,
                           float* dnxw, float* dnxb, float* db2, float* dn1w, float* dn1b, float* dbo, int64_t R, int C, int F,

@@ -227,6 +227,10 @@ def _drop_stale_pending():
 
 def _complete_pending(pend):
     """The parked work as its own launch (what the layer would have issued itself): dx1 += dqkv Wqkv and the four dW."""
+    if pend.get("preln"):
+        # (a pre-LN layer's tail goes back through a norm whose parameters and statistics only its host holds)
+        raise RuntimeError("mobgt fused layer (pre-LN): the parked input gradient of a chained layer found no host "
+                           "(was the layer's input used by something else as well?); set MOBGT_NO_DEFER_TAIL=1")
     wb = _WgradBatch()
     wb.items = pend["items"]
     if not wb.flush(tail=(pend["dqkv"], pend["wqkv"], pend["dx1"])):
@@ -272,7 +276,7 @@ def chain_workspace(dev):
 
 
 def _chain_ok(C, F, *ts):
-    return (_CHAIN[0] and (C, F) in ((192, 1024), (256, 1024))
+    return (_CHAIN[0] and (C, F) in ((128, 1024), (192, 1024), (256, 1024))
             and all(t is None or (t.is_contiguous() and t.data_ptr() % 16 == 0) for t in ts))
 
 
@@ -325,6 +329,8 @@ class LayerConfig:
         self.packed = None        # (wo, w1, w2) of this layer in MFMA operand order (model.pack_layer_weights)
         self.packed_t = None      # (w2^T, w1^T, wo^T, wqkv^T) likewise, for the backward chain
         self.out_act = self.out_qkv = None
+        self.next_norm = None     # pre-LN: (weight, bias) of the NEXT layer's self_attention_norm, applied by this layer's chain
+        self.out_preln = False    # ... and this layer's output then carries that layer's normed input + qkv
 
 
 class _FusedLayerFn(torch.autograd.Function):
@@ -334,7 +340,8 @@ class _FusedLayerFn(torch.autograd.Function):
     `shadows`: (wqkv [3C,C], bqkv [3C], wo, bo, w1, b1, w2, b2) in act_dtype (the fused masters when fp32)."""
 
     @staticmethod
-    def forward(ctx, x, token, cfg, shadows, xa_pre, qkv_pre, wq, bq, wk, bk, wv, bv, wo, bo, n1w, n1b, nxw, nxb, w1, b1, w2, b2):
+    def forward(ctx, x, token, cfg, shadows, xa_pre, qkv_pre, wq, bq, wk, bk, wv, bv, wo, bo, n1w, n1b, nxw, nxb, w1, b1, w2, b2,
+                nnw=None, nnb=None):
         # wq/wk/wv (+ biases) are views of one fused [3C, C] storage (MultiHeadAttention.fuse_qkv_storage); they
         # are separate arguments only so that autograd has an edge to each reference-named parameter.
         G, T, C = x.shape
@@ -348,7 +355,14 @@ class _FusedLayerFn(torch.autograd.Function):
         stats = torch.empty(6, R, **f32)
         seed, sd, salt = cfg.seed, cfg.seed_dev, cfg.salt
         stock = cfg.variant == "stock"
-        if stock:                                                     # y = self_attention_norm(x)  (model.py:480)
+        # pre-LN, input normed and projected by the chain launch of the layer below (model.fused_layer_forward: no own norm)
+        chained_in = stock and nxw is None
+        if chained_in:
+            if not (xa_pre is not None and qkv_pre is not None and xa_pre.dtype == A and xa_pre.numel() == R * C
+                    and qkv_pre.dtype == A and qkv_pre.numel() == 3 * R * C):
+                raise RuntimeError("mobgt fused layer (pre-LN): a chained input without its normed copy / qkv")
+            xa = xa_pre.view(R, C)
+        elif stock:                                                   # y = self_attention_norm(x)  (model.py:480)
             xa = torch.empty(R, C, dtype=A, device=dev)
             _k1_fwd(x, None, None, nxw, nxb, xa, None, stats[0], stats[1], R, C, 0.0, seed, sd, salt, act)
         else:
@@ -363,7 +377,7 @@ class _FusedLayerFn(torch.autograd.Function):
         own = _OWN_GEMM[0] and ops.layer_gemm_ok(xa, s_wqkv) and ops.layer_gemm_ok(xa, s_w1) and C % 32 == 0 \
             and s_w1.shape[0] % 32 == 0
         ctx.own_gemm = own
-        if qkv_pre is not None and qkv_pre.dtype == A and qkv_pre.numel() == 3 * R * C and not stock:
+        if qkv_pre is not None and qkv_pre.dtype == A and qkv_pre.numel() == 3 * R * C and (not stock or chained_in):
             qkv = qkv_pre.view(G, T, 3 * C)                            # written by the previous layer's chain kernel
         elif own:
             qkv = ops.layer_gemm(xa, s_wqkv, s_bqkv).view(G, T, 3 * C)
@@ -375,6 +389,17 @@ class _FusedLayerFn(torch.autograd.Function):
         cfg.out_qkv = None
         use_chain = (not stock and own and A == torch.bfloat16 and cfg.packed is not None
                      and _chain_ok(C, F, x, a, s_bo, s_b1, s_b2, n1w, n1b, nxw, nxb, *cfg.packed))
+        # pre-LN chain (round 4): out-projection ... second residual add in one launch, + the NEXT layer's self_attention_norm
+        # and QKV projection when the model named that layer (cfg.next_norm / next_qkv); the backward is the chain's too
+        need_bwd = any(ctx.needs_input_grad)
+        bwd_ok = bool(_CHAIN_BWD[0] and cfg.packed_t is not None and len(cfg.packed_t) > 3
+                      and all(t.is_contiguous() and t.data_ptr() % 16 == 0 for t in cfg.packed_t))
+        stock_chain = (stock and own and A == torch.bfloat16 and cfg.packed is not None and (bwd_ok or not need_bwd)
+                       and _wgrad_hip(A, F, C, R) and _chain_ok(C, F, x, a, s_bo, s_b1, s_b2, n1w, n1b, *cfg.packed))
+        ctx.stock_chain = stock_chain
+        ctx.chained_in = chained_in
+        if chained_in and not stock_chain:
+            raise RuntimeError("mobgt fused layer (pre-LN): the layer below chained into this one, which cannot run its chain kernels")
         ctx.fuse_ln = use_chain
         ctx.chain_bwd = bool(use_chain and _CHAIN_BWD[0] and cfg.packed_t is not None
                              and all(t.is_contiguous() and t.data_ptr() % 16 == 0 for t in cfg.packed_t))
@@ -399,6 +424,28 @@ class _FusedLayerFn(torch.autograd.Function):
                                                    _p(stats[5]), R, C, F, cfg.p, seed, _p(sd), (salt + 1) & 0xFFFFFFFF,
                                                    (salt + 2) & 0xFFFFFFFF, _p(chain_workspace(dev)), _stream()), "mobgt_layer_chain_fwd")
             cfg.out_act, cfg.out_qkv = out_a, qkv_next
+        elif stock_chain:
+            bf = dict(dtype=A, device=dev)
+            x1, x2 = torch.empty(R, C, **f32), torch.empty(R, C, **f32)
+            z = torch.empty(R, C, **bf)
+            u, h = torch.empty(R, F, **bf), torch.empty(R, F, **bf)
+            nq = cfg.next_qkv if nnw is not None else None
+            if nq is not None and not (nq[0].dtype == A and tuple(nq[0].shape) == (3 * C, C) and nq[0].is_contiguous()
+                                       and nq[0].data_ptr() % 16 == 0 and nnw.is_contiguous() and nnb is not None):
+                nq = None
+            ctx.chain_next = nq is not None
+            out_a = torch.empty(R, C, **bf) if nq is not None else None
+            qkv_next = torch.empty(R, 3 * C, **bf) if nq is not None else None
+            p_wo, p_w1, p_w2 = cfg.packed
+            check(_lib.lib().mobgt_layer_chain_fwd(_p(a), _p(x), _p(p_wo), _p(s_bo), _p(n1w), _p(n1b), _p(p_w1), _p(s_b1), _p(p_w2),
+                                                   _p(s_b2), _p(nnw if nq is not None else None), _p(nnb if nq is not None else None),
+                                                   _p(nq[0] if nq else None), _p(nq[1] if nq else None), _p(x1), _p(z), _p(u), _p(h),
+                                                   _p(x2), _p(None), _p(out_a), _p(qkv_next), _p(stats[2]), _p(stats[3]), _p(stats[4]),
+                                                   _p(stats[5]), R, C, F, cfg.p, seed, _p(sd), (salt + 1) & 0xFFFFFFFF,
+                                                   (salt + 2) & 0xFFFFFFFF, _p(chain_workspace(dev)), _stream()), "mobgt_layer_chain_fwd")
+            out = x2                                                  # the residual stream passes the next layer's norm by
+            if nq is not None:
+                cfg.out_act, cfg.out_qkv, cfg.out_preln = out_a, qkv_next, True
         else:
             out, x1, z, u, h, x2 = _FusedLayerFn._tail_launches(ctx, cfg, x, a, stats, shadows, own, stock, n1w, n1b, nxw, nxb,
                                                                 R, C, A, act, dev)
@@ -413,13 +460,20 @@ class _FusedLayerFn(torch.autograd.Function):
         # the block of small gradients [dbq dbk dbv | dbo | db1 | db2 | dn1w | dn1b | dnxw | dnxb]: one slice of the flat
         # buffer when the trainer laid these parameters out in that order (train.flat_order)
         ctx.small_sink = None
-        chain = [ops.grad_sink(t) for t in (bq, bk, bv, bo, b1, b2, n1w, n1b, nxw, nxb)]
+        # (pre-LN chain: the two norm gradients at the end of the block belong to ANOTHER layer when this layer's chain applies its
+        #  successor's norm, and do not exist when the layer below applied this layer's: the block is the first eight, the norms'
+        #  gradients have destinations of their own)
+        chain = [ops.grad_sink(t) for t in ((bq, bk, bv, bo, b1, b2, n1w, n1b) if stock_chain else (bq, bk, bv, bo, b1, b2, n1w, n1b, nxw, nxb))]
         if all(t is not None and t.is_contiguous() for t in chain) and \
                 all(chain[j + 1].data_ptr() == chain[j].data_ptr() + 4 * chain[j].numel() for j in range(len(chain) - 1)):
             ctx.small_sink = torch.as_strided(chain[0], (sum(t.numel() for t in chain),), (1,))
+        if stock_chain:
+            ctx.nx_sinks = (ops.grad_sink(nxw), ops.grad_sink(nxb)) if nxw is not None else (None, None)
+            ctx.nn_sinks = (ops.grad_sink(nnw), ops.grad_sink(nnb)) if getattr(ctx, "chain_next", False) else (None, None)
         ctx.cfg = cfg
         ctx.shapes = (G, T, C)
-        ctx.save_for_backward(x, xa, qkv, a, lse, x1, z, u, h, x2, stats, s_wqkv, s_wo, s_w1, s_w2, n1w, nxw)
+        ctx.save_for_backward(x, xa, qkv, a, lse, x1, z, u, h, x2, stats, s_wqkv, s_wo, s_w1, s_w2, n1w, nxw,
+                              nnw if getattr(ctx, "chain_next", False) else None)
         return out.view(G, T, C)
 
     @staticmethod
@@ -507,7 +561,9 @@ class _FusedLayerFn(torch.autograd.Function):
         cfg = ctx.cfg
         G, T, C = ctx.shapes
         R = G * T
-        x, xa, qkv, a, lse, x1, z, u, h, x2, stats, s_wqkv, s_wo, s_w1, s_w2, n1w, nxw = ctx.saved_tensors
+        x, xa, qkv, a, lse, x1, z, u, h, x2, stats, s_wqkv, s_wo, s_w1, s_w2, n1w, nxw, nnw = ctx.saved_tensors
+        if getattr(ctx, "stock_chain", False):
+            return _FusedLayerFn._backward_preln_chain(ctx, dout, x, xa, qkv, a, lse, x1, z, u, h, x2, stats, s_wqkv, n1w, nxw, nnw)
         A = cfg.act_dtype
         act = _DT[A]
         dev = dout.device
@@ -618,12 +674,98 @@ class _FusedLayerFn(torch.autograd.Function):
         else:
             dx = _addmm_f32(dx1, dqkv2, s_wqkv, inplace=True)
         return (dx.view(G, T, C), None, None, None, None, None, dwqkv[:C], dbqkv[:C], dwqkv[C:2 * C], dbqkv[C:2 * C], dwqkv[2 * C:],
-                dbqkv[2 * C:], dwo, dbo, dn1w, dn1b, dnxw, dnxb, dw1, db1, dw2, db2)
+                dbqkv[2 * C:], dwo, dbo, dn1w, dn1b, dnxw, dnxb, dw1, db1, dw2, db2) + ((None, None) if stock else ())
+
+    @staticmethod
+    def _backward_preln_chain(ctx, dout, x, xa, qkv, a, lse, x1, z, u, h, x2, stats, s_wqkv, n1w, nxw, nnw):
+        """model.py:479-489 backwards through the chain kernel (mobgt_layer_chain_bwd_preln):
+            [hosted for the layer above:  t = dqkv_above Wqkv_above;  dx2 = dout + norm_above'(t)]    else dx2 = dout
+            df = dropout'(dx2);  du = (df W2) gelu'(u);  dz = du W1;  dx1 = dx2 + ffn_norm'(dz);  dy = dropout'(dx1);  da = dy Wo
+        then the attention backward; then either this layer's own norm (a layer without a chained input: dx = dx1 +
+        self_attention_norm'(dqkv Wqkv), two launches) or nothing -- the layer below finishes dx in ITS chain launch."""
+        cfg = ctx.cfg
+        G, T, C = ctx.shapes
+        R = G * T
+        A = cfg.act_dtype
+        act = _DT[A]
+        dev = dout.device
+        seed, sd, salt = cfg.seed, cfg.seed_dev, cfg.salt
+        F = u.shape[1]
+        dout = dout.contiguous().view(R, C).float()
+        n8 = 3 * C + C + F + C + 2 * C
+        small = ctx.small_sink if ctx.small_sink is not None else ops.zeros_f32((n8,), dev)
+        o = [0]
+
+        def take(n):
+            t = small[o[0]:o[0] + n]
+            o[0] += n
+            return t
+        dbqkv, dbo, db1, db2, dn1w, dn1b = take(3 * C), take(C), take(F), take(C), take(C), take(C)
+
+        def dst(sink):
+            return sink[:] if sink is not None else ops.zeros_f32((C,), dev)
+        dnxw, dnxb = (dst(ctx.nx_sinks[0]), dst(ctx.nx_sinks[1])) if nxw is not None else (None, None)
+        dnnw, dnnb = (dst(ctx.nn_sinks[0]), dst(ctx.nn_sinks[1])) if nnw is not None else (None, None)
+        wb = _WgradBatch()
+        k_qkv, k_wo, k_w1, k_w2 = ctx.sinks
+        if _PENDING_TAIL or _PENDING_CB[0] is not None:
+            _drop_stale_pending()
+        pend = _PENDING_TAIL.pop(_pending_key(dout), None) if _PENDING_TAIL else None
+        if pend is not None and not (pend.get("preln") and nnw is not None and pend["R"] == R):
+            _complete_pending(pend)                    # (not this layer's kind of guest: finish it as its own launches)
+            pend = None
+        bf = dict(dtype=A, device=dev)
+        df, dy, da = torch.empty(R, C, **bf), torch.empty(R, C, **bf), torch.empty(R, C, **bf)
+        du = torch.empty(R, F, **bf)
+        dx1 = torch.empty(R, C, dtype=torch.float32, device=dev)
+        w2t, w1t, wot = cfg.packed_t[:3]
+        tail = (_p(pend["dqkv"]), _p(pend["wqt"])) if pend is not None else (None, None)
+        check(_lib.lib().mobgt_layer_chain_bwd_preln(_p(dout), _p(x2), _p(x1), _p(u), _p(stats[2]), _p(stats[3]), _p(stats[4]),
+                                                     _p(stats[5]), _p(n1w), _p(nnw), _p(w2t), _p(w1t), _p(wot), _p(df), _p(du),
+                                                     _p(dy), _p(da), _p(dx1), _p(dnnw), _p(dnnb), _p(db2), _p(dn1w), _p(dn1b),
+                                                     _p(dbo), R, C, F, cfg.p, seed, _p(sd), (salt + 1) & 0xFFFFFFFF,
+                                                     (salt + 2) & 0xFFFFFFFF, *tail, 0, None, None, None, None, None, None, None,
+                                                     None, None, _p(chain_workspace(dev)), _stream()), "mobgt_layer_chain_bwd_preln")
+        dw2 = wb.add(df, h, sink=k_w2)
+        dw1 = wb.add(du, z, db=db1, sink=k_w1)
+        dwo = wb.add(dy, a.view(R, C), sink=k_wo)
+        dqkv = torch.empty(G, T, 3 * C, dtype=A, device=dev)
+        q, k, v = qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:]
+        ops._attn_bwd(q, k, v, a, lse, da.view(G, T, C), dqkv[..., :C], dqkv[..., C:2 * C], dqkv[..., 2 * C:], cfg.pack, cfg.scale,
+                      cfg.p_att, seed ^ (salt * 0x9E3779B1), sd)
+        dqkv2 = dqkv.view(R, 3 * C)
+        dwqkv = wb.add(dqkv2, xa, db=dbqkv, sink=k_qkv)
+        # the four weight gradients: inside a train step they join the step's ONE grouped launch (as the separate-launch stock
+        # layer's do), else their own grouped launch now
+        if (ops._WGRAD_DEFER["on"] and wb.items and R <= _DEFER_MAX_R[0] and all(k_ is not None for k_ in ctx.sinks)
+                and all(g_.dtype == torch.bfloat16 and x_.dtype == torch.bfloat16 for g_, x_, _, _ in wb.items)
+                and _os_ln.environ.get("MOBGT_NO_STOCK_WGRAD_DEFER") != "1"):
+            for g_, x_, dw_, db_ in wb.items:
+                ops._WGRAD_DEFER["items"].append((g_, x_, None, None, (1.0, 1.0, 1.0), dw_[:], db_[:] if db_ is not None else None, False))
+            wb.items = []
+        else:
+            wb.flush()
+        if ctx.chained_in:
+            # nothing more for this layer: the layer below opens its chain launch with  dx2 = dx1 + norm'(dqkv Wqkv)
+            _PENDING_TAIL[_pending_key(dx1)] = dict(dx1=dx1[:], dqkv=dqkv2, wqkv=s_wqkv, wqt=cfg.packed_t[3], items=[], R=R, preln=True)
+            if _PENDING_CB[0] != _task_id():
+                _PENDING_CB[0] = _task_id()
+                torch.autograd.Variable._execution_engine.queue_callback(_pending_check)
+            dx = dx1
+        else:                                                           # back through this layer's own self_attention_norm
+            dz0 = ops.layer_gemm(dqkv2, s_wqkv, None, True)
+            dx = torch.empty(R, C, dtype=torch.float32, device=dev)
+            _k1_bwd(dz0, None, dx1, x.view(R, C), stats[0], stats[1], nxw, dx, None, dnxw, dnxb, None, R, C, 0.0, seed, sd, salt, act)
+        return (dx.view(G, T, C), None, None, None, None, None, dwqkv[:C], dbqkv[:C], dwqkv[C:2 * C], dbqkv[C:2 * C], dwqkv[2 * C:],
+                dbqkv[2 * C:], dwo, dbo, dn1w, dn1b, dnxw, dnxb, dw1, db1, dw2, db2, dnnw, dnnb)
 
 
 def fused_encoder_layer(x, pack, cfg, shadows, params, xa_pre=None, qkv_pre=None):
     cfg.out_act = cfg.out_qkv = None
+    cfg.out_preln = False
     out = _FusedLayerFn.apply(x, pack.token, cfg, shadows, xa_pre, qkv_pre, *params)
+    if cfg.out_preln:
+        out._mobgt_preln = True               # pre-LN: `_mobgt_act` is the NEXT layer's normed input (model.fused_layer_forward)
     if cfg.out_act is not None:
         out._mobgt_act = cfg.out_act          # picked up by the next fused layer (same Python tensor object)
     if cfg.out_qkv is not None:

@@ -200,10 +200,21 @@ def fused_layer_forward(layer, variant, x, attn_bias, n1, nx, next_layer=None):
     # the next layer's QKV projection rides in this layer's chain kernel (csrc/chain.hip) when that layer is fused, has
     # the same activation dtype and its bf16 shadows are current (refresh_shadows / the trainer refreshed ALL layers)
     nxt = next_layer
+    stock = variant == "stock"
     if (nxt is not None and act != torch.float32 and not amp and getattr(nxt, "fused", False)
             and getattr(nxt, "act_dtype", None) == act and getattr(nxt, "_packed_fresh", False)
             and nxt._packed[0].device == x.device):
-        cfg.next_qkv = (nxt._packed[0], nxt._shadows[1])
+        if not stock:
+            cfg.next_qkv = (nxt._packed[0], nxt._shadows[1])
+        else:
+            # pre-LN (model.py:479-489): the next layer's self_attention_norm AND its QKV projection ride in this layer's chain
+            # launch; that layer then has no norm / projection of its own and leaves the norm's backward to this layer's chain
+            # (fused_layer._PENDING_TAIL) -- so not across a cut of the trainer's backward pass, and not without deferral
+            from . import fused_layer as _fl
+            bwd_ok = (not torch.is_grad_enabled()) or (getattr(nxt, "_packed_t_fresh", False) and getattr(layer, "_packed_t_fresh", False))
+            if _fl._DEFER[0] and not getattr(nxt, "_mobgt_cut", False) and getattr(layer, "_packed_fresh", False) and bwd_ok:
+                cfg.next_qkv = (nxt._packed[0], nxt._shadows[1])
+                cfg.next_norm = (nxt.self_attention_norm.weight, nxt.self_attention_norm.bias)
     if getattr(layer, "_packed_fresh", False) and act != torch.float32 and not amp:
         cfg.packed = layer._packed[1:]                    # (wo, w1, w2) in MFMA operand order
         if getattr(layer, "_packed_t_fresh", False):
@@ -212,9 +223,17 @@ def fused_layer_forward(layer, variant, x, attn_bias, n1, nx, next_layer=None):
     # pack_layer_weights run once per model forward); a later stand-alone call of this layer re-copies its shadows and
     # must not pair them with the old pack
     layer._packed_fresh = layer._packed_t_fresh = False
+    # a pre-LN layer whose input was normed and projected by the chain launch of the layer below has no edge to its own
+    # self_attention_norm: that layer's node owns it (next_norm above)
+    chained_in = (stock and not amp and getattr(x, "_mobgt_preln", False) and getattr(x, "_mobgt_qkv", None) is not None
+                  and getattr(x, "_mobgt_act", None) is not None and not getattr(layer, "_mobgt_cut", False))
     params = (mha.linear_q.weight, mha.linear_q.bias, mha.linear_k.weight, mha.linear_k.bias, mha.linear_v.weight,
-              mha.linear_v.bias, mha.output_layer.weight, mha.output_layer.bias, n1.weight, n1.bias, nx.weight, nx.bias,
+              mha.linear_v.bias, mha.output_layer.weight, mha.output_layer.bias, n1.weight, n1.bias,
+              None if chained_in else nx.weight, None if chained_in else nx.bias,
               layer.ffn.layer1.weight, layer.ffn.layer1.bias, layer.ffn.layer2.weight, layer.ffn.layer2.bias)
+    if stock:
+        nn_ = getattr(cfg, "next_norm", None)
+        params = params + ((nn_[0], nn_[1]) if nn_ is not None else (None, None))
     if amp:
         with torch.autocast("cuda", enabled=False):
             return fused_encoder_layer(x.float(), pack, cfg, shadows, params, xa_pre=getattr(x, "_mobgt_act", None))
@@ -283,7 +302,7 @@ def refresh_shadows(layers, defer_pack=False):
 
 
 def pack_layer_weights(layers, defer=False):
-    """MFMA-operand-order copies of the fused fq layers' bf16 GEMM weights (csrc/chain.hip reads a wave's B operand as one
+    """MFMA-operand-order copies of the fused layers' (fq post-LN and, since round 4, model.py's pre-LN) bf16 GEMM weights (csrc/chain.hip reads a wave's B operand as one
     contiguous KB), all layers in one launch (up to 96 weights): `layer._packed` = (wqkv, wo, w1, w2) packed for the
     forward chain and, when gradients are enabled, `layer._packed_t` = (w2^T, w1^T, wo^T, wqkv^T) for the backward chain."""
     from . import fused_layer
@@ -296,10 +315,11 @@ def pack_layer_weights(layers, defer=False):
         layer._packed_fresh = layer._packed_t_fresh = False
         sh = getattr(layer, "_shadows", None)
         if (sh is None or not getattr(layer, "fused", False) or not getattr(layer, "_shadow_fresh", False)
-                or not hasattr(layer, "ffn_norm2") or sh[0].dtype != torch.bfloat16 or not sh[0].is_cuda):
+                or not (hasattr(layer, "ffn_norm2") or hasattr(layer, "self_attention_norm")) or sh[0].dtype != torch.bfloat16
+                or not sh[0].is_cuda):
             continue
         C, F = sh[2].shape[0], sh[4].shape[0]
-        if (C, F) not in ((192, 1024), (256, 1024)) or not all(sh[i].is_contiguous() for i in (0, 2, 4, 6)):
+        if (C, F) not in ((128, 1024), (192, 1024), (256, 1024)) or not all(sh[i].is_contiguous() for i in (0, 2, 4, 6)):
             continue
         pk = getattr(layer, "_packed", None)
         if pk is None or pk[0].device != sh[0].device:
@@ -349,9 +369,9 @@ class EncoderLayer(nn.Module):
         self.ffn = FeedForwardNetwork(hidden_size, ffn_size, dropout_rate)
         self.ffn_dropout = nn.Dropout(dropout_rate)
 
-    def forward(self, x, attn_bias=None, mask=None):
+    def forward(self, x, attn_bias=None, mask=None, next_layer=None):
         if self.fused and x.is_cuda and mask is None:
-            return fused_layer_forward(self, "stock", x, attn_bias, self.ffn_norm, self.self_attention_norm)
+            return fused_layer_forward(self, "stock", x, attn_bias, self.ffn_norm, self.self_attention_norm, next_layer=next_layer)
         y = self.self_attention_norm(x)
         y = self.self_attention(y, y, y, attn_bias, mask=mask)
         y = self.self_attention_dropout(y)
@@ -442,7 +462,8 @@ class Graphormer(nn.Module):
         for li, enc_layer in enumerate(self.layers):
             if getattr(enc_layer, "_mobgt_cut", False):
                 self._cuts[li] = output          # train.TrainStep: the backward pass is cut here (layer-wise gradient buckets)
-            output = enc_layer(output, bias, mask=None)
+            # (the layer that follows is named so that its norm and QKV projection can ride in this layer's chain launch)
+            output = enc_layer(output, bias, mask=None, next_layer=self.layers[li + 1] if li + 1 < len(self.layers) else None)
         self._enc_out = output
         # (model.py:211-217 normalises every token and then reads the graph token: LayerNorm is per row, so only that row is
         # normalised here -- same value, same gradient)

@@ -971,3 +971,66 @@ def test_stock_encoder_input_in_one_launch(idt, monkeypatch):
         assert torch.equal(y0, ref)
     finally:
         ops.set_dropout_state(None, 0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("C,G,T,p", [(128, 16, 38, 0.1), (128, 3, 130, 0.1), (128, 1, 17, 0.0), (256, 9, 130, 0.1)])
+def test_preln_layer_chain_kernel_matches_the_separate_launches(C, G, T, p):
+    """Round 4: the chain kernels for graphormer/model.py's PRE-LN EncoderLayer (:463-489, the layer BASELINE.json's north_star
+    names; C = 128, d = 16): out-projection -> +residual -> ffn_norm -> FFN -> +residual -> the NEXT layer's
+    self_attention_norm -> its QKV projection as one launch per layer, the backward as one launch too (the next layer's
+    norm backward is finished in THIS layer's chain launch: dx2 = dout + norm'(dqkv Wqkv)), against the separate launches
+    (MOBGT_NO_CHAIN path: 7 + 7 launches per layer) on a 3-layer stock stack with dropout on: same rounding points, same
+    masks, so outputs and every gradient agree to bf16 round-off.  Both cluster sizes and the one-workgroup form (R = 608 ->
+    4 members, 390 -> 4, 17 -> 4, 1170 -> 2)."""
+    from mobgt_amd import fused_layer
+    from mobgt_amd.model import EncoderLayer as StockLayer, refresh_shadows
+    torch.manual_seed(5)
+    H = 8
+    layers = torch.nn.ModuleList([StockLayer(C, 1024, p, p, H) for _ in range(3)]).to(DEV)
+    for li, l in enumerate(layers):
+        l.act_dtype = torch.bfloat16
+        l.self_attention.set_layer_index(li + 1)
+        l.self_attention.seed_dev = torch.tensor([11], dtype=torch.int64, device=DEV)     # both runs draw the same masks
+        with torch.no_grad():                           # (norm weights away from their 1 / 0 initialisation)
+            for n in (l.self_attention_norm, l.ffn_norm):
+                n.weight.add_(0.2 * torch.randn_like(n.weight))
+                n.bias.add_(0.2 * torch.randn_like(n.bias))
+    layers.train()
+    x0 = torch.randn(G, T, C, device=DEV)
+    bias = torch.randn(G, H, T, T, device=DEV) * 0.3
+    gy = torch.randn(G, T, C, device=DEV)
+    res = {}
+    for mode in ("chain", "off"):
+        fused_layer._CHAIN[0] = mode != "off"
+        try:
+            for q in layers.parameters():
+                q.grad = None
+            x = x0.clone().requires_grad_(True)
+            refresh_shadows(layers)
+            y = x
+            rode = []
+            for li, l in enumerate(layers):
+                y = l(y, bias, next_layer=layers[li + 1] if li + 1 < len(layers) else None)
+                rode.append(bool(getattr(y, "_mobgt_preln", False)))
+            assert rode == ([True, True, False] if mode == "chain" else [False, False, False])
+            assert bool(getattr(y.grad_fn, "stock_chain", False)) == (mode == "chain")
+            y.backward(gy)
+            torch.cuda.synchronize()
+            res[mode] = (y.detach().clone(), x.grad.clone(), {n: q.grad.clone() for n, q in layers.named_parameters() if q.grad is not None})
+        finally:
+            fused_layer._CHAIN[0] = True
+
+    def close(a, b, name):
+        scale = float(b.abs().max()) + 1e-12
+        err = float((a - b).abs().max())
+        print("%-44s max|err| %.3e of max %.3e" % (name, err, scale))
+        assert err <= 2e-2 * scale, (name, err, scale)
+    (ya, dxa, ga), (yb, dxb, gb) = res["chain"], res["off"]
+    close(ya, yb, "y")
+    close(dxa, dxb, "dx")
+    assert ga.keys() == gb.keys() and len(ga) == 3 * 16
+    for n in ga:
+        if n.endswith("linear_k.bias"):
+            continue                                      # exactly zero in exact arithmetic: round-off only
+        close(ga[n], gb[n], n)

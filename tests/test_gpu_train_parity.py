@@ -128,6 +128,75 @@ def test_fq_layer_with_dropout_on_vs_oracle_with_replayed_masks(mode, monkeypatc
     assert ok, bad_rows(report)
 
 
+@pytest.mark.parametrize("mode", ["bf16_launches", "bf16_chain"])
+def test_stock_two_layer_stack_with_dropout_on_vs_oracle_with_replayed_masks(mode, monkeypatch):
+    """graphormer/model.py:463-489 -- the pre-LN EncoderLayer north_star names -- twice in a row (C 128, d 16, ffn 1024, 8 heads),
+    dropout ON, against oracle.encoder_layer_stock with the device's masks replayed: as separate launches and as the round-4
+    chain kernels (layer 0's launch applies layer 1's self_attention_norm and QKV projection; layer 1's norm backward is
+    finished in layer 0's backward launch).  Outputs, dx, dbias and EVERY parameter gradient of both layers."""
+    from mobgt_amd import fused_layer
+    from mobgt_amd.model import EncoderLayer, refresh_shadows
+    G, H, T, C, F, p, p_att = 4, 8, 53, 128, 1024, 0.1, 0.1
+    monkeypatch.setattr(fused_layer, "_CHAIN", [mode == "bf16_chain"])
+    torch.manual_seed(0)
+    layers = torch.nn.ModuleList([EncoderLayer(C, F, p, p_att, H) for _ in range(2)])
+    for li, layer in enumerate(layers):
+        layer.self_attention.set_layer_index(li + 1)
+        for prm in layer.parameters():             # LayerNorm weights / biases away from (1, 0) so that their gradients matter
+            if prm.dim() == 1:
+                prm.data.add_(0.1 * torch.randn_like(prm))
+    sd = {"L." + k: v.detach().clone().requires_grad_(True) for k, v in layers.state_dict().items()}
+    rng = np.random.RandomState(1)
+    x = torch.from_numpy(rng.standard_normal((G, T, C)).astype(np.float32))
+    gy = torch.from_numpy(rng.standard_normal((G, T, C)).astype(np.float32))
+    bias = torch.from_numpy((rng.standard_normal((G, H, T, T)) * 0.5).astype(np.float32))
+    bias[1, :, :, 40:] = float("-inf")
+    bias[3, :, :, 7:] = float("-inf")
+    step = 11
+    layers = layers.to(DEV).train()
+    seed_dev = torch.tensor([step], dtype=torch.int64, device=DEV)
+    masks = {}
+    for li, layer in enumerate(layers):
+        layer.fused, layer.act_dtype = True, torch.bfloat16
+        layer.self_attention.seed_dev = seed_dev
+        masks.update(layer_masks(f"L.{li}", layer.self_attention, step, G, T, C, H, p, p_att))
+    xr, br = x.clone().requires_grad_(True), bias.clone().requires_grad_(True)
+    ref = xr
+    for li in range(2):
+        ref = mo.encoder_layer_stock(sd, f"L.{li}", ref, br, H, p, p_att, True, drop=_drop_hook(masks))
+    ref.backward(gy)
+    xd, bd = x.to(DEV).requires_grad_(True), bias.to(DEV).requires_grad_(True)
+    refresh_shadows(layers)
+    mid = layers[0](xd, bd, next_layer=layers[1])
+    assert bool(getattr(mid, "_mobgt_preln", False)) == (mode == "bf16_chain")
+    out = layers[1](mid, bd)
+    assert bool(getattr(out.grad_fn, "stock_chain", False)) == (mode == "bf16_chain")
+    out.backward(gy.to(DEV))
+    torch.cuda.synchronize()
+
+    def close(name, got, want, tol):
+        got, want = got.detach().float().cpu().numpy(), want.detach().numpy()
+        nz = want != 0
+        assert np.all(got[~nz] == 0), name
+        scale = float(np.sqrt((want[nz] ** 2).mean()))
+        err = float(np.abs(got - want).max())
+        print("%-36s max|err| %.3e  rms %.3e" % (name, err, scale))
+        assert err <= tol * scale, f"{name}: max |err| {err:.3e} vs rms {scale:.3e}"
+    close("y", out, ref, 8e-2)                      # (two layers deep; the fq one-layer gate is 6e-2)
+    close("dx", xd.grad, xr.grad, 1e-1)
+    close("dbias", bd.grad, br.grad, 2e-1)
+    report, ok = [], True
+    for k, prm in layers.named_parameters():
+        want = sd["L." + k].grad
+        assert want is not None and prm.grad is not None, k
+        if k.endswith("linear_k.bias"):
+            continue            # exactly 0 in exact arithmetic (softmax is shift-invariant over keys): round-off on both sides
+        ok &= check_grad(k, prm.grad, want, report)
+    for r in report:
+        print("%-40s rms_nz %.3e  relL2 %.4f  q999 %.3f  max %.3f  stray %.1e" % r)
+    assert ok, bad_rows(report)
+
+
 def step_masks(model, batch, step, host_seed):
     """Every dropout mask of one fq train step (sites and salts: model_fqandtoyo.py / modelGNN.py / ops.py of this repo)."""
     G, N = batch.x.shape[:2]
