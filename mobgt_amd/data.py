@@ -215,7 +215,11 @@ class DeviceCollator:
 # a batch is therefore rounded UP to one of a few sizes and one step graph is kept per (G, size).  Rounding up only adds
 # padding positions, which the collator already produces for every graph shorter than the batch maximum (-inf key columns,
 # zero indices): logits, loss and gradients do not change (tests/test_gpu_loop.py).
-BUCKETS = (8, 16, 24, 32, 48, 64, 96, 128, 192, 256, 384, 512, 768, 1024)
+# (round 4: steps of 1/16 .. 1/8 of the size instead of round 3's 1/3 .. 1/2 (8, 16, 24, 32, 48, 64, 96, ...): at most ~6-12 % of
+#  padding in N instead of ~33 %.  A bucket costs one captured step graph, taken the first time it occurs.  Measured on the
+#  S-FSQ pool: fresh-batch loop 0.784 -> 0.700 ms per step with steps of 1/8 .. 1/4)
+BUCKETS = (tuple(range(4, 65, 4)) + tuple(range(72, 129, 8)) + tuple(range(144, 257, 16)) + tuple(range(288, 513, 32))
+           + tuple(range(576, 1025, 64)))
 
 
 def bucket_nodes(n, buckets=BUCKETS):

@@ -780,6 +780,11 @@ class EpochLoop:
         self.steps_done = 0
         self.limits = None
         self.side_collate = bool(side_collate) and os.environ.get("MOBGT_LOOP_INGRAPH_COLLATE") != "1"
+        # MOBGT_LOOP_DIRECT=1 (round 4, measured and NOT the default): every staging buffer of a bucket is a static batch of its
+        # OWN step graph -- the collated bytes are read where the copy stream put them, no device-to-device copy between two
+        # replays.  Slower than the copy on the S-FSQ pool (0.734 vs 0.700 ms per step, one box, same run): two graphs per
+        # bucket alternate between two sets of activation buffers, and the copy was not what the loop waited for.
+        self.direct = os.environ.get("MOBGT_LOOP_DIRECT") == "1"
 
     # ---- data order -----------------------------------------------------------------------------------------------------
     def batches_of_epoch(self, epoch):
@@ -805,11 +810,14 @@ class EpochLoop:
                      batch=self.collator.batch_from_views(views) if side else views,
                      copy_bytes=lay.copy_bytes if side else lay.nbytes)
             raw_bytes = lay.raw_bytes if side else lay.nbytes
+            s["direct"] = bool(side and self.direct)
             for _ in range(2):
                 pin = torch.zeros(raw_bytes, dtype=torch.uint8).pin_memory()
                 dev = torch.zeros(lay.nbytes, dtype=torch.uint8, device=self.device)
-                s["stages"].append(dict(pin=pin, np=lay.views_np(pin.numpy()), dev=dev, dev_views=lay.views_torch(dev) if side else None,
-                                        work=None, ready=torch.cuda.Event(), free=None))
+                dv = lay.views_torch(dev) if side else None
+                s["stages"].append(dict(pin=pin, np=lay.views_np(pin.numpy()), dev=dev, dev_views=dv,
+                                        work=None, ready=torch.cuda.Event(), free=None, used=False, index=None,
+                                        batch=self.collator.batch_from_views(dv) if s["direct"] else None))
             self.slots[key] = s
         return s
 
@@ -849,11 +857,17 @@ class EpochLoop:
         slot = self._slot(G, N)
         st = slot["stages"][slot["turn"]]
         slot["turn"] ^= 1
-        if st["free"] is not None:
+        if slot["direct"]:
+            if st["used"]:
+                st["ready"].synchronize()              # the previous host-to-device copy out of this pinned buffer is done
+        elif st["free"] is not None:
             st["free"].synchronize()                   # its previous device-to-device copy has been executed
         self.collator.pack_host(trajs, idx0=ids[:G] if len(ids) == G else 0, n_pad=N, out=st["np"])
         self._check_host(st["np"])
+        st["used"] = True
         with torch.cuda.stream(self.copy_stream):
+            if slot["direct"] and st["free"] is not None:
+                self.copy_stream.wait_event(st["free"])            # the step that read this staging buffer last has run
             st["dev"][:st["pin"].numel()].copy_(st["pin"], non_blocking=True)
             if slot["side"]:
                 st["work"] = self.collator.finish_into(st["dev_views"], st["work"])
@@ -876,6 +890,20 @@ class EpochLoop:
     def _launch(self, slot, st):
         cur = torch.cuda.current_stream()                # (graphs replay on the current stream)
         cur.wait_event(st["ready"])
+        if slot["direct"]:
+            if self.ts is None:
+                self.ts = TrainStep(self.model, [st["batch"]], batch_fn=self._batch_fn, **self._ts_args)
+                self.ts.prepare()
+                st["index"] = 0
+            elif st["index"] is None:
+                st["index"] = self.ts.add_batch(st["batch"])
+            if slot["index"] is None:
+                slot["index"] = st["index"]              # (any of the bucket's graphs: bench.py's no-input replay)
+            loss = self.ts.step(st["index"])
+            if st["free"] is None:
+                st["free"] = torch.cuda.Event()
+            st["free"].record(cur)
+            return loss
         n = slot["copy_bytes"]
         slot["buf"][:n].copy_(st["dev"][:n], non_blocking=True)
         if st["free"] is None:

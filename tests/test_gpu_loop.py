@@ -25,7 +25,7 @@ DEV = "cuda"
 
 
 def test_bucket_rounding_and_raw_layout_roundtrip():
-    assert [bucket_nodes(n) for n in (1, 8, 9, 24, 25, 129, 814, 1024, 1025)] == [8, 8, 16, 24, 32, 192, 1024, 1024, 1280]
+    assert [bucket_nodes(n) for n in (1, 8, 9, 24, 25, 129, 814, 1024, 1025)] == [4, 8, 12, 24, 28, 144, 832, 1024, 1280]
     lay = RawLayout(16, 24)
     assert all(o % 16 == 0 for o, _, _, _ in lay.offsets.values()) and lay.nbytes % 16 == 0
     buf = np.zeros(lay.nbytes, dtype=np.uint8)
@@ -50,7 +50,7 @@ def test_bucket_padded_batch_equals_the_unpadded_batch(fsq_small):
     trajs = synth.make_batch_of_trajectories(seed=21, G=6, P=1500, n_user=1080, cat_of_poi=uni.cat_of_poi, n_nodes=[17, 3, 9, 2, 11, 5])
     a = coll(trajs)
     b = coll(trajs, n_pad=bucket_nodes(17))
-    assert a.x.shape[1] == 17 and b.x.shape[1] == 24
+    assert a.x.shape[1] == 17 and b.x.shape[1] == bucket_nodes(17) == 20
     # the padded collate is the unpadded one + padding
     for f in ("x", "in_degree", "out_degree", "time_normal"):
         assert torch.equal(getattr(b, f)[:, :17], getattr(a, f)), f
@@ -117,7 +117,7 @@ def test_epoch_over_the_s_gow_pool_visits_the_distributed_samplers_set(rank, wor
     assert all(k[1] in BUCKETS for k in keys) and len(keys) == res["graphs"]
     lens = [len(data[i]["node_name"]) for i in want]
     assert max(k[1] for k in keys) == bucket_nodes(max(lens))
-    assert len(loop.ts.graphs) == len(keys)
+    assert len(keys) <= len(loop.ts.graphs) <= 2 * len(keys)       # (round 4: one step graph per staging buffer of a bucket)
     assert np.isfinite(float(loop.ts.loss_out.item()))
     # same epoch seed + rank -> the torch sampler itself
     from torch.utils.data.distributed import DistributedSampler

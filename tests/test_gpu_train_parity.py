@@ -264,5 +264,10 @@ def test_s_fsq_train_step_with_dropout_on_vs_oracle_with_replayed_masks(name):
         # (their few hundred entries have an rms of ~1e-6 and a worst-entry ratio that moves between 1 and 3.2 from run to run:
         # judged by relative L2 and the zero pattern only)
         edge = lambda r: r[0].startswith("edge_")
-        bad = [r for r in report if r[2] > (8e-2 if edge(r) else 4e-2) or (not edge(r) and (r[3] > 3.0 or r[4] > 6.0)) or r[5] > 1e-3 * r[1]]
+        # (round 4, tools/dbg/r4_det_probe.py -> profiles/r4_det_probe.txt: the order of the f32 atomics is NOT what separates these
+        #  gradients from the oracle's -- with the dBias kept in f32 (one accumulator instead of bf16 slices) the position / distance
+        #  tables go from 1.2-2.4 % to 0.9-1.3 %, the edge tables only from 2.5-4.4 % to 1.5-3.2 %: what is left is the bf16 rounding of
+        #  the attention's MFMA operands under heavy cancellation in sums over thousands of pairs, and the reference's own fp16
+        #  rounding points.  A deterministic-order mode would therefore not reach 1 %; the gates are what is measured + margin: 6 %)
+        bad = [r for r in report if r[2] > (6e-2 if edge(r) else 4e-2) or (not edge(r) and (r[3] > 3.0 or r[4] > 6.0)) or r[5] > 1e-3 * r[1]]
         assert not bad, bad
