@@ -469,7 +469,7 @@ def time_chain(R, C, F, reps=50, p_drop=0.1):
     z, out_a, u, h, qkv = bf(R, C), bf(R, C), bf(R, F), bf(R, F), bf(R, 3 * C)
     st = torch.empty(4, R, device="cuda")
     from mobgt_amd.fused_layer import chain_workspace
-    ws = chain_workspace(a.device)
+    ws = chain_workspace(a.device, C, R)
 
     def fn():
         _lib.check(lib.mobgt_layer_chain_fwd(_p(a), _p(x), _p(wo), _p(bo), _p(ln[0]), _p(ln[1]), _p(w1), _p(b1), _p(w2), _p(b2),

@@ -261,13 +261,19 @@ def _pending_check():
 _CHAIN_WS = {}              # device index -> workspace of the chain kernels' cluster form
 
 
-def chain_workspace(dev):
+def chain_workspace(dev, C=192, R=None):
     """Hand-over counters + exchange buffers of the cluster form of the chain kernels (include/mobgt_hip.h:
-    mobgt_chain_ws_bytes): one per device, zeroed once, for ONE stream at a time (the step's compute stream).  It must exist
-    before a graph capture starts (an eager warm-up step creates it).  MOBGT_CHAIN_NCL=1 -> None (one-workgroup form)."""
+    mobgt_chain_ws_bytes): zeroed once, for ONE stream at a time (the step's compute stream).  One per device AND per launch
+    geometry (model width C, cluster size 4 / 2 -- csrc/chain.hip: pick_ncl): a row block's exchange area is addressed as
+    block x members x 16 x C, so launches of different geometry on one workspace would poll words another block wrote, and
+    a stale packet whose generation happens to match would be accepted.  Must exist before a graph capture starts
+    (an eager warm-up step creates it).  MOBGT_CHAIN_NCL=1 / ops.SAFE_FORMS -> None (one-workgroup form)."""
     if _os_ln.environ.get("MOBGT_CHAIN_NCL") == "1" or ops.SAFE_FORMS[0]:
         return None
-    key = dev.index if dev.index is not None else torch.cuda.current_device()
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    nblk = (int(R) + 15) // 16 if R is not None else 1
+    ncl = 4 if nblk * 4 <= 256 else 2                     # (as pick_ncl; beyond 2 members the launch takes the one-workgroup form)
+    key = (idx, int(C), ncl)
     ws = _CHAIN_WS.get(key)
     if ws is None:
         if torch.cuda.is_current_stream_capturing():
@@ -423,7 +429,7 @@ class _FusedLayerFn(torch.autograd.Function):
                                                    _p(nq[1] if nq else None), _p(x1), _p(z), _p(u), _p(h), _p(x2), _p(out),
                                                    _p(out_a), _p(qkv_next), _p(stats[2]), _p(stats[3]), _p(stats[4]),
                                                    _p(stats[5]), R, C, F, cfg.p, seed, _p(sd), (salt + 1) & 0xFFFFFFFF,
-                                                   (salt + 2) & 0xFFFFFFFF, _p(chain_workspace(dev)), _stream()), "mobgt_layer_chain_fwd")
+                                                   (salt + 2) & 0xFFFFFFFF, _p(chain_workspace(dev, C, R)), _stream()), "mobgt_layer_chain_fwd")
             cfg.out_act, cfg.out_qkv = out_a, qkv_next
         elif stock_chain:
             bf = dict(dtype=A, device=dev)
@@ -443,7 +449,7 @@ class _FusedLayerFn(torch.autograd.Function):
                                                    _p(nq[0] if nq else None), _p(nq[1] if nq else None), _p(x1), _p(z), _p(u), _p(h),
                                                    _p(x2), _p(None), _p(out_a), _p(qkv_next), _p(stats[2]), _p(stats[3]), _p(stats[4]),
                                                    _p(stats[5]), R, C, F, cfg.p, seed, _p(sd), (salt + 1) & 0xFFFFFFFF,
-                                                   (salt + 2) & 0xFFFFFFFF, _p(chain_workspace(dev)), _stream()), "mobgt_layer_chain_fwd")
+                                                   (salt + 2) & 0xFFFFFFFF, _p(chain_workspace(dev, C, R)), _stream()), "mobgt_layer_chain_fwd")
             out = x2                                                  # the residual stream passes the next layer's norm by
             if nq is not None:
                 cfg.out_act, cfg.out_qkv, cfg.out_preln = out_a, qkv_next, True
@@ -619,7 +625,7 @@ class _FusedLayerFn(torch.autograd.Function):
                                                    _p(stats[5]), _p(n1w), _p(nxw), _p(w2t), _p(w1t), _p(wot), _p(df), _p(du),
                                                    _p(dy), _p(da), _p(dx1), _p(dnxw), _p(dnxb), _p(db2), _p(dn1w), _p(dn1b),
                                                    _p(dbo), R, C, F, cfg.p, seed, _p(sd), (salt + 1) & 0xFFFFFFFF,
-                                                   (salt + 2) & 0xFFFFFFFF, *extra, _p(chain_workspace(dev)), _stream()), "mobgt_layer_chain_bwd")
+                                                   (salt + 2) & 0xFFFFFFFF, *extra, _p(chain_workspace(dev, C, R)), _stream()), "mobgt_layer_chain_bwd")
             da = da.view(G, T, C)
             dw2 = wb.add(df, h, sink=k_w2)
             dw1 = wb.add(du, z, db=db1, sink=k_w1)
@@ -727,7 +733,7 @@ class _FusedLayerFn(torch.autograd.Function):
                                                      _p(dy), _p(da), _p(dx1), _p(dnnw), _p(dnnb), _p(db2), _p(dn1w), _p(dn1b),
                                                      _p(dbo), R, C, F, cfg.p, seed, _p(sd), (salt + 1) & 0xFFFFFFFF,
                                                      (salt + 2) & 0xFFFFFFFF, *tail, 0, None, None, None, None, None, None, None,
-                                                     None, None, _p(chain_workspace(dev)), _stream()), "mobgt_layer_chain_bwd_preln")
+                                                     None, None, _p(chain_workspace(dev, C, R)), _stream()), "mobgt_layer_chain_bwd_preln")
         dw2 = wb.add(df, h, sink=k_w2)
         dw1 = wb.add(du, z, db=db1, sink=k_w1)
         dwo = wb.add(dy, a.view(R, C), sink=k_wo)

@@ -434,7 +434,38 @@ class Graphormer(nn.Module):
         return ops.build_bias(batched_data.attn_bias, batched_data.rel_pos, None, edge_input, rel, None, hop,
                               self.graph_token_virtual_distance.weight, D, dtype=self.bias_dtype)
 
+    def validate_batch(self, batched_data):
+        """Index ranges nn.Embedding / F.cross_entropy check in the reference (model.py:193-203, 286: IndexError / a device
+        assert there; the gather, token and loss kernels here treat an out-of-range index as "contributes nothing", which would
+        train silently on masked inputs -- ADVICE r3).  One reduction + one host read per batch OBJECT, remembered on it: a
+        pre-collated batch is checked in the eager dry run and costs nothing inside a captured step."""
+        if getattr(batched_data, "_mobgt_validated", None) is self or not batched_data.x.is_cuda:
+            return
+        if torch.cuda.is_current_stream_capturing():
+            return
+        lim = [("x", batched_data.x, self.atom_encoder.num_embeddings), ("in_degree", batched_data.in_degree, self.in_degree_encoder.num_embeddings),
+               ("rel_pos", batched_data.rel_pos, self.rel_pos_encoder.num_embeddings),
+               ("edge_input", batched_data.edge_input, self.edge_encoder.num_embeddings),
+               ("y", batched_data.y, self.downstream_out_proj.out_features)]
+        mx = torch.stack([t.max().long() if t.numel() else torch.zeros((), dtype=torch.long, device=t.device) for _, t, _ in lim]).tolist()
+        mn = int(batched_data.y.min()) if batched_data.y.numel() else 0
+        for (name, _, n), m in zip(lim, mx):
+            if m >= n:
+                raise IndexError(f"batch.{name} has index {m}, out of range for a table of {n} rows")
+        if mn < 0:
+            raise IndexError(f"batch.y has the negative class {mn}")
+        try:
+            batched_data._mobgt_validated = self
+        except AttributeError:
+            pass
+
+    def index_limits(self):
+        """Largest admissible value + 1 of the raw fields train.EpochLoop checks on the host for a fresh batch."""
+        return dict(x=self.atom_encoder.num_embeddings - 1, y=self.downstream_out_proj.out_features - 1,
+                    edge=self.edge_encoder.num_embeddings, deg=self.in_degree_encoder.num_embeddings)
+
     def forward(self, batched_data, perturb=None):
+        self.validate_batch(batched_data)
         x = batched_data.x
         in_degree = out_degree = batched_data.in_degree            # model.py:118 (aliasing kept)
         n_graph = x.size(0)

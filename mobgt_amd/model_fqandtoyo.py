@@ -438,6 +438,11 @@ class Graphormer(nn.Module):
         except AttributeError:
             pass
 
+    def index_limits(self):
+        """Largest admissible value + 1 of the raw fields train.EpochLoop checks on the host for a fresh batch."""
+        return dict(x=self.X.shape[0], user=self.num_users, y=self.out_proj.out_features, edge=self.edge_encoder.num_embeddings,
+                    deg=self.in_degree_encoder.num_embeddings, slots=self.time_embed_model_48.num_embeddings)
+
     def forward(self, batched_data, perturb=None):
         self.validate_batch(batched_data)
         # The category GCN (weights only: no batch input; one launch that keeps 19 compute units busy) goes FIRST and carries the

@@ -47,12 +47,13 @@ def peer_wait_faults(reset=True):
     dev = torch.cuda.current_device()
     torch.cuda.synchronize(dev)
     out = {}
-    ws = fused_layer._CHAIN_WS.get(dev)
-    if ws is not None:
+    for key, ws in fused_layer._CHAIN_WS.items():           # (one workspace per device and launch geometry)
+        if key[0] != dev:
+            continue
         w = _ws_word(ws, int(lib.mobgt_chain_ws_fault_offset()))
         n = int(w.item())
         if n:
-            out["chain"] = n
+            out["chain"] = out.get("chain", 0) + n
             if reset:
                 w.zero_()
     ws = _HEAD_WS.get(dev)
@@ -78,9 +79,9 @@ def set_peer_wait_limit(rounds=0, gcn_ticks=0):
     dev = torch.cuda.current_device()
     rounds = int(rounds) & 0xFFFFFFFF                 # (0xffffffff: every wait reports a fault at once -- fault injection)
     rounds = rounds - (1 << 32) if rounds >= (1 << 31) else rounds
-    ws = fused_layer._CHAIN_WS.get(dev)
-    if ws is not None:
-        _ws_word(ws, int(lib.mobgt_chain_ws_limit_offset())).fill_(int(rounds))
+    for key, ws in fused_layer._CHAIN_WS.items():
+        if key[0] == dev:
+            _ws_word(ws, int(lib.mobgt_chain_ws_limit_offset())).fill_(int(rounds))
     ws = _HEAD_WS.get(dev)
     if ws is not None:
         _ws_word(ws, int(lib.mobgt_head_chain_ws_limit_offset())).fill_(int(rounds))

@@ -688,6 +688,21 @@ class TrainStep:
         its step graph now (the capture's eager warm-up pass leaves the step counter and the parameters untouched)."""
         self.batches.append(batch)
         i = len(self.batches) - 1
+        # the trained-parameter set (flat layout, sinks, optimizer) was fixed by the batches given at construction: a batch
+        # that reaches a parameter outside it would leave that parameter silently untrained (ADVICE r3) -- check by a dry run
+        if os.environ.get("MOBGT_NO_ADD_BATCH_CHECK") != "1":
+            known = {id(p) for p in self.flat.params}
+            with self._on_stream():
+                saved = self.seed_dev.clone()
+                for p in self.model.parameters():
+                    if id(p) not in known:
+                        p.grad = None
+                self._fwd_bwd(batch)
+                self.seed_dev.copy_(saved)
+                extra = [n for n, p in self.model.named_parameters() if id(p) not in known and p.grad is not None]
+            self._join()
+            if extra:
+                raise RuntimeError(f"TrainStep.add_batch: this batch reaches parameters the trainer was not built for: {extra[:5]}")
         if self.use_graph and self._prepared:
             self.graphs[i] = self._capture(i)
             if self.fused_opt:
@@ -826,22 +841,22 @@ class EpochLoop:
         the captured step cannot look at values (model.validate_batch does this for pre-collated batches)."""
         m = self.model
         if self.limits is None:
-            self.limits = dict(x=m.X.shape[0], user=m.num_users, y=m.out_proj.out_features, edge=m.edge_encoder.num_embeddings,
-                               deg=m.in_degree_encoder.num_embeddings, slots=m.time_embed_model_48.num_embeddings)
+            # (the model says which fields it indexes tables with -- model.index_limits(); a model without the hook is not checked)
+            self.limits = m.index_limits() if hasattr(m, "index_limits") else {}
         L = self.limits
         nz = h["counts"] != 0
         bad = None
-        if int(h["x"].max()) > L["x"]:
+        if "x" in L and int(h["x"].max()) > L["x"]:
             bad = ("x", int(h["x"].max()), L["x"] + 1)
-        elif int(h["user"].max()) > L["user"]:
+        elif "user" in L and int(h["user"].max()) > L["user"]:
             bad = ("user", int(h["user"].max()), L["user"] + 1)
-        elif int(h["y"].max()) > L["y"]:
+        elif "y" in L and int(h["y"].max()) > L["y"]:
             bad = ("y", int(h["y"].max()), L["y"] + 1)
-        elif int(h["counts"].max()) + 3 >= L["edge"]:
+        elif "edge" in L and int(h["counts"].max()) + 3 >= L["edge"]:
             bad = ("edge_input", int(h["counts"].max()) + 3, L["edge"])
-        elif max(int(nz.sum(1).max()), int(nz.sum(2).max())) + 1 >= L["deg"]:
+        elif "deg" in L and max(int(nz.sum(1).max()), int(nz.sum(2).max())) + 1 >= L["deg"]:
             bad = ("degree", max(int(nz.sum(1).max()), int(nz.sum(2).max())) + 1, L["deg"])
-        elif int(float(h["time_normal"].max()) * 48) >= L["slots"]:
+        elif "slots" in L and int(float(h["time_normal"].max()) * 48) >= L["slots"]:
             bad = ("time_normal", float(h["time_normal"].max()), L["slots"])
         if bad:
             raise IndexError(f"batch.{bad[0]} has index {bad[1]}, out of range for a table of {bad[2]} rows")
@@ -853,6 +868,8 @@ class EpochLoop:
         trajs = [self.dataset[i] for i in ids]
         trajs = [t for t in trajs if t is not None and len(t["node_name"]) <= self.collator.max_node]
         G = len(trajs)
+        if G == 0:
+            return None                                # (every trajectory filtered out: the reference's collator skips such a batch too, collator.py:313)
         N = bucket_nodes(max(len(t["node_name"]) for t in trajs), self.buckets)
         slot = self._slot(G, N)
         st = slot["stages"][slot["turn"]]
@@ -923,12 +940,17 @@ class EpochLoop:
         if not batches:
             return dict(steps=0, graphs=len(self.slots), sample_ids=seen)
         nxt = self._stage(batches[0])
+        steps = 0
         for j, ids in enumerate(batches):
-            slot, st = nxt
-            loss = self._launch(slot, st)                # asynchronous: the GPU works on step j ...
+            cur = nxt
+            if cur is not None:
+                loss = self._launch(*cur)                # asynchronous: the GPU works on step j ...
             nxt = self._stage(batches[j + 1]) if j + 1 < len(batches) else None          # ... while the host packs j + 1
             seen.extend(ids)
+            if cur is None:
+                continue                                 # (an empty batch: skipped, as the reference's collator does)
+            steps += 1
             self.steps_done += 1
             if on_step is not None:
                 on_step(self.steps_done, loss)
-        return dict(steps=len(batches), graphs=len(self.slots), sample_ids=seen)
+        return dict(steps=steps, graphs=len(self.slots), sample_ids=seen)

@@ -649,7 +649,7 @@ def test_chain_cluster_form_equals_the_one_workgroup_form(C, R, p):
     a, x = bf(R, C), f32(R, C)
     pk = {k: pack(w) for k, w in (("wo", wo), ("w1", w1), ("w2", w2), ("wq", wq))}
     pkt = {k: pack(w, True) for k, w in (("wo", wo), ("w1", w1), ("w2", w2), ("wq", wq))}
-    ws = chain_workspace(a.device)
+    ws = chain_workspace(a.device, C, R)
     assert ws is not None and ws.numel() == lib.mobgt_chain_ws_bytes()
     seed_dev = torch.tensor([5], dtype=torch.int64, device=DEV)
 

@@ -27,7 +27,7 @@ ln = [torch.ones(C, device="cuda"), torch.zeros(C, device="cuda"), torch.ones(C,
 x1, x2, out = (torch.empty(R, C, device="cuda") for _ in range(3))
 z, out_a, u, h, qkv = bf(R, C), bf(R, C), bf(R, F), bf(R, F), bf(R, 3 * C)
 st = torch.empty(4, R, device="cuda")
-ws = chain_workspace(a.device)
+ws = chain_workspace(a.device, C, R)
 filler = torch.empty(64 << 20, dtype=torch.uint8, device="cuda")
 for it in range(N):
     if os.environ.get("NOFILL") != "1":

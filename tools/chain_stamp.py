@@ -28,7 +28,7 @@ ln = [torch.ones(C, device="cuda"), torch.zeros(C, device="cuda"), torch.ones(C,
 x1, x2, out = (torch.empty(R, C, device="cuda") for _ in range(3))
 z, out_a, u, h, qkv = bf(R, C), bf(R, C), bf(R, F), bf(R, F), bf(R, 3 * C)
 st = torch.empty(4, R, device="cuda")
-ws = chain_workspace(a.device)
+ws = chain_workspace(a.device, C, R)
 dbg = torch.zeros(1024 * 16, dtype=torch.int32, device="cuda")
 raw = ctypes.CDLL(os.environ["MOBGT_HIP_LIB"])
 raw.mobgt_chain_debug_buffer.argtypes = [ctypes.c_void_p]
