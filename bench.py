@@ -41,6 +41,8 @@ def parse():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--unfused", action="store_true", help="op-by-op encoder layers (torch ops + HIP attention)")
     ap.add_argument("--no-overlap", action="store_true", help="N > 1: one all-reduce after the whole backward instead of two overlapped buckets")
+    ap.add_argument("--grad-comm", choices=["fp32", "bf16"], default="fp32",
+                    help="N > 1: dtype the gradient buckets are all-reduced in (bf16 halves the bytes; DESIGN 5)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true", help="skip the eval-step comparison with the oracle")
     ap.add_argument("--no-stress", action="store_true", help="skip the c5-shape attention roofline measurements")
@@ -100,9 +102,12 @@ def attn_fwd_bytes(G, T, C, H, s_x, s_b):
     return G * (4 * T * C * s_x + H * T * T * s_b + H * T * 4)
 
 
-def attn_bwd_bytes(G, T, C, H, s_x, s_b, s_g):
-    """DESIGN §3.1, both passes: dQ pass reads Q,K,V,O,dO + writes dQ (6 T C), reads the bias, writes dBias;
-    dK/dV pass reads Q,K,V,O,dO + writes dK,dV (7 T C) and reads the transposed bias; both read LSE."""
+def attn_bwd_bytes(G, T, C, H, s_x, s_b, s_g, one_pass=False):
+    """DESIGN §3.1.  Two passes: dQ pass reads Q,K,V,O,dO + writes dQ (6 T C), reads the bias, writes dBias; dK/dV pass reads
+    Q,K,V,O,dO + writes dK,dV (7 T C) and reads the transposed bias; both read LSE.  ONE pass (round 4, T > 64, bf16): Q,K,V,O,dO
+    read and dQ,dK,dV written once (8 T C), the transposed bias read once, dBias written once, LSE + rowsum(dO O) per row."""
+    if one_pass:
+        return G * (8 * T * C * s_x + H * T * T * (s_b + s_g) + H * T * 8)
     dq = G * (6 * T * C * s_x + H * T * T * (s_b + s_g) + H * T * 8)
     dkv = G * (7 * T * C * s_x + H * T * T * s_b + H * T * 8)
     return dq + dkv
@@ -213,7 +218,7 @@ def live_pmc(shapes, p_drop, keep_dir=None, timeout=300):
     for k in list(env):
         if k.startswith("PYTORCH_TUNABLEOP"):
             del env[k]
-    pat = re.compile(r"attn_(fwd|bwd_dq|bwd_dkv|bwd_both)_kernel(?:<|ILi)(\d+)")
+    pat = re.compile(r"attn_(fwd|bwd_dq|bwd_dkv|bwd_both|bwd_one)_kernel(?:<|ILi)(\d+)")
     try:
         for name, counters in passes.items():
             out = os.path.join(tmp, name)
@@ -229,7 +234,7 @@ def live_pmc(shapes, p_drop, keep_dir=None, timeout=300):
             for row in csv.DictReader(open(files[0])):
                 m = pat.search(row["Kernel_Name"])
                 if m:
-                    kern = {"fwd": "fwd", "bwd_dq": "dq", "bwd_dkv": "dkv", "bwd_both": "both"}[m.group(1)]
+                    kern = {"fwd": "fwd", "bwd_dq": "dq", "bwd_dkv": "dkv", "bwd_both": "both", "bwd_one": "one"}[m.group(1)]
                     acc.setdefault(int(m.group(2)), {}).setdefault(kern, {}).setdefault(row["Counter_Name"], []).append(
                         float(row["Counter_Value"]))
     except Exception:
@@ -366,14 +371,18 @@ def run_sub_workloads(args):
                             durs.setdefault(key, []).append((int(x["End_Timestamp"]) - int(x["Start_Timestamp"])) / 1e3)
                             break
                 b5f = attn_fwd_bytes(16, 785, 256, 8, 2, 2)
-                b5b = attn_bwd_bytes(16, 785, 256, 8, 2, 2, 2)
+                b5b = attn_bwd_bytes(16, 785, 256, 8, 2, 2, 2, one_pass="attn_bwd_one_us" in durs)
+                for pat, key in (("attn_bwd_prep_kernel", "attn_bwd_prep_us"), ("attn_dq_finish_kernel", "attn_dq_finish_us")):
+                    v = [(int(x["End_Timestamp"]) - int(x["Start_Timestamp"])) / 1e3 for x in seg if pat in x["Kernel_Name"]]
+                    if v:
+                        durs[key] = v
                 ins = dict(step_wall_us_under_profiler=round(wall, 1), kernels_per_step=len(seg),
                            **{k: round(sum(v) / len(v), 2) for k, v in durs.items()},
                            launches={k: len(v) for k, v in durs.items()},
                            source="rocprofv3 --kernel-trace child pass of this run (6 replayed steps, the third from the end)")
                 if "attn_fwd_us" in ins:
                     ins["attn_fwd_frac_of_8TBs"] = round(b5f / (ins["attn_fwd_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 3)
-                tb = sum(ins.get(k, 0.0) for k in ("attn_bwd_dq_us", "attn_bwd_dkv_us", "attn_bwd_one_us"))
+                tb = sum(ins.get(k, 0.0) for k in ("attn_bwd_dq_us", "attn_bwd_dkv_us", "attn_bwd_one_us", "attn_bwd_prep_us", "attn_dq_finish_us"))
                 if tb > 0:
                     ins["attn_bwd_frac_of_8TBs"] = round(b5b / (tb * 1e-6) / 1e9 / HBM_PEAK_GBS, 3)
                 res["big"]["in_step"] = ins
@@ -703,7 +712,8 @@ def main():
     torch.cuda.synchronize()
 
     ts = TrainStep(model, batches, autocast_dtype=torch.bfloat16 if (bf16 and args.gemm_dtype == "bf16" and args.unfused) else None,
-                   use_graph=not args.no_graph, overlap=not args.no_overlap, seed=args.seed)
+                   use_graph=not args.no_graph, overlap=not args.no_overlap, seed=args.seed,
+                   grad_comm_dtype=torch.bfloat16 if args.grad_comm == "bf16" else None)
     ts.prepare()
     for i in range(args.warmup):
         ts.step(i)
@@ -874,14 +884,32 @@ def main():
                          cache_state="all inputs rotated through > 768 MB: every launch reads cold HBM (a lower bound of the S-BIG "
                                      "step, where the one bias all 12 layers share is partly still in the Infinity Cache: "
                                      "profiles/r3_bench_big_step_summary.txt)")
-            trq, mbq, srcq, _ = pmc_of(32, "dq", "c5_bwd_dq_drop_bf16")
-            trk, mbk, _, _ = pmc_of(32, "dkv", "c5_bwd_dkv_drop_bf16")
-            roof5b = dict(kernel="attn_bwd_dq_kernel + attn_bwd_dkv_kernel", workload="c5 G16 T785 C256 d32, dropout 0.1",
-                          bound="hbm", achieved=b5b / t5b / 1e9, peak=HBM_PEAK_GBS, unit="GB/s",
-                          frac=b5b / t5b / 1e9 / HBM_PEAK_GBS,
-                          traffic=(trq + trk) if (trq is not None and trk is not None) else None,
-                          mfma_busy_pct={"dq": mbq, "dkv": mbk}, counters_source=srcq,
-                          avg_launch_us=t5b * 1e6, bytes_per_launch=b5b, input_sets_rotated=nset5)
+            from mobgt_amd import ops as _ops
+            one = bool(_ops._ATTN_ONE_PASS[0]) and b_dt == torch.bfloat16
+            b5b2 = b5b
+            if one:
+                b5b = attn_bwd_bytes(16, 785, 256, 8, s_b, s_b, s_g, one_pass=True)
+                tro, mbo, srco, eo = pmc_of(32, "one", "-")
+                roof5b = dict(kernel="attn_bwd_prep_kernel + attn_bwd_one_kernel + attn_dq_finish_kernel (one pass over the bias)",
+                              workload="c5 G16 T785 C256 d32, dropout 0.1", bound="hbm", achieved=b5b / t5b / 1e9, peak=HBM_PEAK_GBS,
+                              unit="GB/s", frac=b5b / t5b / 1e9 / HBM_PEAK_GBS, traffic=tro, mfma_busy_pct={"one": mbo},
+                              valu_busy_pct=eo.get("valu_busy_pct"), wait_any_frac=eo.get("wait_any_frac"),
+                              counters_source=srco, avg_launch_us=t5b * 1e6, bytes_per_launch=b5b, input_sets_rotated=nset5,
+                              two_pass_bytes=b5b2, frac_at_two_pass_bytes=b5b2 / t5b / 1e9 / HBM_PEAK_GBS,
+                              note="round 4: ONE backward pass (S / P / dS once per pair, transposed bias read once, dBias written "
+                                   "once; dQ summed over key blocks by f32 atomics).  `frac` uses the bytes THIS algorithm has to move "
+                                   "(367 MB); rounds 1-3 ran two passes whose 558 MB are kept as two_pass_bytes -- the same launch "
+                                   "time against them is frac_at_two_pass_bytes, the figure comparable with BENCH_r03 (0.375).  The pass "
+                                   "is bound by vector issue and latency, not by HBM: DESIGN 3.1")
+            else:
+                trq, mbq, srcq, _ = pmc_of(32, "dq", "c5_bwd_dq_drop_bf16")
+                trk, mbk, _, _ = pmc_of(32, "dkv", "c5_bwd_dkv_drop_bf16")
+                roof5b = dict(kernel="attn_bwd_dq_kernel + attn_bwd_dkv_kernel", workload="c5 G16 T785 C256 d32, dropout 0.1",
+                              bound="hbm", achieved=b5b / t5b / 1e9, peak=HBM_PEAK_GBS, unit="GB/s",
+                              frac=b5b / t5b / 1e9 / HBM_PEAK_GBS,
+                              traffic=(trq + trk) if (trq is not None and trk is not None) else None,
+                              mfma_busy_pct={"dq": mbq, "dkv": mbk}, counters_source=srcq,
+                              avg_launch_us=t5b * 1e6, bytes_per_launch=b5b, input_sets_rotated=nset5)
         # ---- the same step fed like the reference feeds it: a NEW batch every step (data.py:282-295), collated inside the
         # replayed step (train.EpochLoop: raw trajectories -> pinned staging -> one H2D copy -> [DeviceCollator.finish +
         # forward + loss + backward + AdamW] as one graph per shape bucket).  Secondary metric of SURVEY 8(d): check-ins/s
@@ -921,7 +949,7 @@ def main():
                                      "accumulate_softmax_layernorm_adamw": "f32"}},
             "final_loss": loss, "ms_per_step_chunks": [round(c, 4) for c in chunk_ms], "long_run": long_run,
             "value_with_collate": with_collate,
-            "comm_backend": comm_backend, "comm_ranks": comm_ranks, "rccl_ranks": rccl_ranks, "allreduce_exposed_us": exposed_us,
+            "comm_backend": comm_backend, "comm_ranks": comm_ranks, "grad_comm_dtype": args.grad_comm if world > 1 else None, "rccl_ranks": rccl_ranks, "allreduce_exposed_us": exposed_us,
             "parity": parity, "roofline": roof, "roofline_chain": roofc, "roofline_stress": roof5, "roofline_stress_bwd": roof5b,
             "cpu_baseline": cpu, "workloads": subs,
         }

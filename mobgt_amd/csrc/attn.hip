@@ -71,6 +71,7 @@ struct AttnParams {
     void* dbias;              // f32 (read-modify-write when `accumulate`) or bf16 (write-only slice of this layer)
     int dbias_bf16;
     float* delta;
+    float* dq_acc;            // one-pass backward: [G, T, H * d] f32, zero on entry (this file zero-fills it), the dQ sums
     int G, H, T;
     int64_t ldq, ldk, ldv, ldo, lddq, lddk, lddv, ld_bias;
     float scale, inv_keep;
@@ -1007,6 +1008,326 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_both_kernel(const AttnParams
     else attn_bwd_dkv_body<D, TQ, TB, NW, DROP, true>(p, blockIdx.x - p.n_first, gridDim.x - p.n_first);
 }
 
+
+// ======================================================================= backward in ONE pass (round 4; T > 64, bf16 I/O + bf16 bias)
+// The two passes above form P and dS twice and stream the bias twice (row-major for dQ, transposed for dK / dV).  Here a
+// workgroup of EIGHT waves owns up to 256 keys of one (graph, head) -- keys on the lanes, as in the dK / dV pass: S^T, dP^T, P
+// and dS exist ONCE per (query, key) --, sweeps the queries in chunks of 64 and finishes all four gradients:
+//   * dK^T / dV^T accumulate in registers over the sweep (no sum across workgroups), as before;
+//   * the dS^T tiles (bf16: the very values the dK product multiplies) are parked in an LDS image [256 keys][64 queries]; behind
+//     ONE more barrier per chunk that image is read back TRANSPOSED (ds_read_b64_tr_b16: 4 keys x 16 queries per 16-lane group)
+//       - as 16-byte pieces dBias[query][key .. key + 7] of this layer's row-major slice (what the dQ pass wrote), and
+//       - as the A operand of dQ[16 queries x 16 head columns] += dS[16 x 32 keys] K[32 keys x 16] (v_mfma_f32_16x16x32_bf16; K^T of
+//         the workgroup's keys is staged once): each wave owns ONE 16 x 16 tile of the chunk's 64 x 32 and sums it over all
+//         256 keys, so a chunk leaves the workgroup as 8 KB of f32 atomic adds into a zero-filled accumulator (ceil(T / 256) adds
+//         per element: 54 MB per launch at c5, where 128-key workgroups would add 90 MB);
+//   * rowsum(dO O) comes from a small launch in front (attn_bwd_prep_kernel, which also zero-fills the dQ accumulator): recomputed
+//     per chunk by one wave it was a dependent cold round trip on every chunk's critical path.
+// Bias traffic: bias_t read once + dBias written once (2 x 158 MB at c5; the two passes move 3 x 158 MB); exp, dropout, dS once.
+typedef short mobgt_v4s __attribute__((ext_vector_type(4)));
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ mobgt_v4s lds_tr16(const bf16_t* p) {
+    // per 16-lane group: lane 4q + p supplies the address of row q, columns 4p .. 4p + 3 of a 4 x 16 block; lane i receives
+    // column i of the 4 rows (cdna_hip_programming.md T10).  EXEC must be all ones at every call.
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((mobgt_v4s __attribute__((address_space(3)))*)(p));
+}
+#ifndef ONE_SKIP
+#define ONE_SKIP 0            // timing probes only (tools/attn_ab.sh): 1 = no dBias / dQ section, 2 = no atomics, 3 = no dBias stores, 4 = no DSk parking either
+#endif
+constexpr int ONE_NW = 8;                 // waves per workgroup
+constexpr int DSP = KC + 8;               // pitch (bf16) of the parked dS^T image: 144 B, an odd multiple of 16 B
+constexpr int KTP = 32 * ONE_NW + 8;      // pitch (bf16) of the K^T image: 528 B
+
+template <int D, bool DROP>
+__global__ __launch_bounds__(ONE_NW * 64) void attn_bwd_one_kernel(const AttnParams p) {
+    typedef bf16_t TQ;
+    typedef bf16_t TB;
+    constexpr int NW = ONE_NW, NT = NW * 64, KS = (D + 15) / 16;
+    __shared__ __attribute__((aligned(16))) bf16_t Qs[KC][ROWP];
+    __shared__ __attribute__((aligned(16))) bf16_t dOs[KC][ROWP];
+    __shared__ __attribute__((aligned(16))) bf16_t Qt[32][COLP];
+    __shared__ __attribute__((aligned(16))) bf16_t dOt[32][COLP];
+    __shared__ __attribute__((aligned(16))) float lseS[KC];
+    __shared__ __attribute__((aligned(16))) float dlS[KC];
+    __shared__ __attribute__((aligned(16))) uint32_t dropW[DROP ? 2 : 1][DROP ? NW * 2 : 1][DROP ? 8 : 1][DROP ? 36 : 4];
+    __shared__ __attribute__((aligned(16))) unsigned char Bs[NW][BiasStage<TB>::BYTES];
+    __shared__ __attribute__((aligned(16))) bf16_t DSk[32 * NW][DSP];          // dS^T of the chunk: [key][query]
+    __shared__ __attribute__((aligned(16))) bf16_t KT[32][KTP];               // K^T of the workgroup's keys: [head column][key]
+
+    const int T = p.T, H = p.H;
+    const int nK = p.nq;
+    const int lid = xcd_remap(blockIdx.x, gridDim.x);
+    const int kt = lid % nK, gh = lid / nK;
+    const int g = gh / H, h = gh % H;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = lane & 31, hi = lane >> 5;
+    const int k0g = wg_tile0(kt, nK, T) * 32;                                  // first key of the workgroup
+    const int k0w = wave_row0(kt, nK, T, __builtin_amdgcn_readfirstlane(wave), NW);
+    const int my_k = k0w + n;
+    const bool k_ok = my_k < T;
+    const int kc = k_ok ? my_k : T - 1;
+
+    const TQ* Q = reinterpret_cast<const TQ*>(p.q) + (int64_t)g * T * p.ldq + h * D;
+    const TQ* K = reinterpret_cast<const TQ*>(p.k) + (int64_t)g * T * p.ldk + h * D;
+    const TQ* V = reinterpret_cast<const TQ*>(p.v) + (int64_t)g * T * p.ldv + h * D;
+    const TQ* dO = reinterpret_cast<const TQ*>(p.dout) + (int64_t)g * T * p.ldo + h * D;
+    const TB* brows = reinterpret_cast<const TB*>(p.bias_t) + ((int64_t)gh * T + min(k0w, T - 1)) * p.ld_bias;
+    const int brow_max = max(T - 1 - k0w, 0);
+    unsigned char* bimg = Bs[wave];
+
+    // ---- K^T of the workgroup's keys -> LDS (once): piece e = key e / 4, head columns 8 (e % 4) .. + 7
+    for (int e = tid; e < 32 * NW * 4; e += NT) {
+        const int kk = e >> 2, c0 = (e & 3) * 8;
+        Raw8<TQ> x;
+        if (c0 < D && k0g + kk < T) x.load(K + (int64_t)(k0g + kk) * p.ldk + c0);
+        else x.zero();
+        const bf16x8 b = x.as_bf16();
+#pragma unroll
+        for (int i = 0; i < 8; ++i) KT[c0 + i][kk] = b[i];
+    }
+    bf16x8 kf[KS], vf[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        const bool ok = k_ok && (ks * 16 + 8 * hi < D);
+        load_frag(K + (int64_t)kc * p.ldk + ks * 16 + 8 * hi, ok, p.scale, kf[ks]);
+        load_frag(V + (int64_t)kc * p.ldv + ks * 16 + 8 * hi, ok, DROP ? p.inv_keep : 1.f, vf[ks]);
+    }
+    uint64_t seed = 0;
+    if (DROP) seed = p.seed + (p.seed_dev ? *p.seed_dev : 0ull);
+    const int drop_sh = (n & 1) ? 0 : 16, thr_hi = p.thr_s * 65536;
+    const uint32_t kmask = k_ok ? 0xffffffffu : 0u;             // keys beyond T: their dS must be exact zeros (dBias columns, dQ)
+
+    f32x16 dk, dv;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { dk[i] = 0.f; dv[i] = 0.f; }
+
+    const int nchunk = (T + KC - 1) / KC;
+    BiasStage<TB> bst;
+    bst.init(p.ld_bias, brow_max, lane);
+    // staging of a chunk: threads 0 .. 255 carry one 16-byte piece of Q each, threads 256 .. 511 one of dO
+    const bool is_q = tid < 256;
+    const int se = tid & 255, sr = se >> 2, sc0 = (se & 3) * 8;
+    const TQ* ssrc = is_q ? Q : dO;
+    const int64_t sld = is_q ? p.ldq : p.ldo;
+    bf16_t (*srm)[ROWP] = is_q ? Qs : dOs;
+    bf16_t (*strn)[COLP] = is_q ? Qt : dOt;
+    Raw8<TQ> sreg;
+    auto stage_load = [&](const int c) {
+        if (D % 32 == 0 || sc0 < D) sreg.load(ssrc + (int64_t)min(c * KC + sr, T - 1) * sld + sc0);
+        else sreg.zero();
+    };
+    float lse_r = 0.f, dl_r = 0.f;
+    auto load_rowstats = [&](const int c) {      // thread it < KC carries query it of the chunk (every thread loads: no branch)
+        const int64_t qi = (int64_t)gh * T + min(c * KC + (tid & (KC - 1)), T - 1);
+        lse_r = p.lse_in[qi];
+        dl_r = p.delta[qi];                      // rowsum(dO O): attn_bwd_prep_kernel
+    };
+    // Per chunk TWO barriers:   tiles(c) | A | staging of chunk c + 1, dBias / dQ of chunk c, requests for chunk c + 2 | B
+    // Every wait on a load sits in front of the chunk's stores and atomics in program order and the requests for chunk c + 2
+    // behind them (the counter retires in issue order: the atomics of chunk c then have the whole of tiles(c + 1) to complete,
+    // and no wait count has to be exact across the loop's back edge -- where the compiler's merged counts are conservative).
+    auto stage_store = [&](const int c) {
+        const bf16x8 b = sreg.as_bf16();
+        *reinterpret_cast<bf16x8*>(&srm[sr][sc0]) = b;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) strn[sc0 + i][sr] = b[i];
+        if (tid < KC) {
+            lseS[tid] = lse_r * MOBGT_LOG2E;
+            dlS[tid] = dl_r;
+        }
+        if (DROP) {
+            for (int e = tid; e < 2 * NW * 2 * 32; e += NT) {
+                const int row = e & 31, kbl = (e >> 5) % (NW * 2), t = e / (NW * 64);
+                const int q = c * KC + t * 32 + row;
+                const uint32_t rh = dropout_row_hash(seed, (uint32_t)(gh * T + (q < T ? q : T - 1)));
+                const uint32_t hb = attn_drop_block(seed, rh, (uint32_t)(wg_tile0(kt, nK, T) * 2 + kbl));
+#pragma unroll
+                for (int m = 0; m < 8; ++m) dropW[t][kbl][m][row] = attn_drop_word(hb, attn_drop_mult(m));
+            }
+        }
+        bst.park(bimg, lane);
+    };
+    auto request = [&](const int c) {
+        stage_load(c);
+        load_rowstats(c);
+        bst.load(brows, c);
+    };
+    request(0);
+    stage_store(0);
+    request(min(1, nchunk - 1));
+    __syncthreads();
+
+    for (int c = 0; c < nchunk; ++c) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int q0 = c * KC + t * 32;
+            if (q0 >= T) break;            // (wave-uniform.  The tile's part of DSk keeps the previous chunk's values: they only
+                                           //  reach dBias rows / dQ rows >= T, which are never stored)
+            f32x16 s, dp;
+            BiasStage<TB>::to_acc(bimg, n, hi, t, s);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) dp[i] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const bf16x8 aq = *reinterpret_cast<const bf16x8*>(&Qs[t * 32 + kappa(n)][ks * 16 + 8 * hi]);
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq, kf[ks], s, 0, 0, 0);
+                const bf16x8 ad = *reinterpret_cast<const bf16x8*>(&dOs[t * 32 + kappa(n)][ks * 16 + 8 * hi]);
+                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ad, vf[ks], dp, 0, 0, 0);
+            }
+            // (query rows >= T of the last tile need no masking: their bias_t columns are -inf, hence P = 0 and dS = 0 there)
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                float lse8[8], dl8[8];
+                uint32_t w8[8];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int r0 = t * 32 + 16 * hi + 8 * s2 + 4 * j;
+                    const float4 a = *reinterpret_cast<const float4*>(&lseS[r0]);
+                    const float4 b = *reinterpret_cast<const float4*>(&dlS[r0]);
+                    lse8[4 * j] = a.x; lse8[4 * j + 1] = a.y; lse8[4 * j + 2] = a.z; lse8[4 * j + 3] = a.w;
+                    dl8[4 * j] = b.x; dl8[4 * j + 1] = b.y; dl8[4 * j + 2] = b.z; dl8[4 * j + 3] = b.w;
+                    if (DROP) {
+                        const uint4 w = *reinterpret_cast<const uint4*>(
+                            &dropW[t][wave * 2 + (n >> 4)][(n & 15) >> 1][16 * hi + 8 * s2 + 4 * j]);
+                        w8[4 * j] = w.x; w8[4 * j + 1] = w.y; w8[4 * j + 2] = w.z; w8[4 * j + 3] = w.w;
+                    }
+                }
+                float a8[8], b8[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int i = 8 * s2 + j;
+                    const float pr = fast_exp2(fmaf(s[i], MOBGT_LOG2E, -lse8[j]));
+                    if (DROP) {
+                        const bool keep = (int)(w8[j] << drop_sh) >= thr_hi;
+                        const float x = keep ? pr : 0.f;
+                        a8[j] = x;
+                        b8[j] = fmaf(x, dp[i], -pr * dl8[j]);
+                    } else {
+                        a8[j] = pr;
+                        b8[j] = pr * (dp[i] - dl8[j]);
+                    }
+                }
+                const bf16x8 pb = pack8(a8);
+                u32x4 dbw = __builtin_bit_cast(u32x4, pack8(b8));
+#pragma unroll
+                for (int k = 0; k < 4; ++k) dbw[k] &= kmask;
+                const bf16x8 db = __builtin_bit_cast(bf16x8, dbw);
+                if (ONE_SKIP != 4) *reinterpret_cast<bf16x8*>(&DSk[32 * wave + n][t * 32 + 16 * hi + 8 * s2]) = db;
+                const bf16x8 ado = *reinterpret_cast<const bf16x8*>(&dOt[kappa(n)][t * 32 + 16 * hi + 8 * s2]);
+                dv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ado, pb, dv, 0, 0, 0);
+                const bf16x8 aq = *reinterpret_cast<const bf16x8*>(&Qt[kappa(n)][t * 32 + 16 * hi + 8 * s2]);
+                dk = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq, db, dk, 0, 0, 0);
+            }
+        }
+        __syncthreads();                                        // A: every wave is done with the chunk's images; DSk is complete
+        // (measured and NOT kept: the chunk's stores and atomics issued unconditionally -- lanes without an element storing to a dump
+        //  area / adding zeros to clamped addresses -- so that the wait counts in front of the staging are exact on every path: the
+        //  dump area and the clamped atomics are hot spots, 135 -> 178 us; the stores behind their branches cost ~26 us of the
+        //  launch, the atomics ~9, the transposed reads + products of dQ ~11: profiles/r4_attn_onepass_probes.txt)
+        if (c + 1 < nchunk) stage_store(c + 1);                 // (wave-uniform)
+        if (ONE_SKIP != 1 && ONE_SKIP != 4) {
+            const int i16 = lane & 15, g4 = lane >> 4, q4 = i16 >> 2, p4 = i16 & 3;
+            // ---- dBias: wave w = 16 queries (w & 3) x 128 keys (w >> 2); a lane's piece j: query i16, keys 32 j + 8 g4 .. + 7
+            if (p.dbias && ONE_SKIP != 3) {
+                // (only this workgroup's own key columns: idle waves of a workgroup with fewer than 8 key tiles parked zeros at
+                //  rows that are the NEXT workgroup's keys)
+                const int kend = kt + 1 < nK ? wg_tile0(kt + 1, nK, T) * 32 : (int)p.ld_bias;
+                const int qg = wave & 3, kh = wave >> 2;
+                const int qglob = c * KC + 16 * qg + i16;
+                bf16_t* drow = reinterpret_cast<bf16_t*>(p.dbias) + ((int64_t)gh * T + min(qglob, T - 1)) * p.ld_bias;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int kl = 128 * kh + 32 * j + 8 * g4;
+                    const mobgt_v4s r0 = lds_tr16(&DSk[kl + q4][16 * qg + 4 * p4]);
+                    const mobgt_v4s r1 = lds_tr16(&DSk[kl + 4 + q4][16 * qg + 4 * p4]);
+                    const int kglob = k0g + kl;
+                    if (qglob < T && kglob < kend) {
+                        typedef short v8s __attribute__((ext_vector_type(8)));
+                        const v8s v = {r0[0], r0[1], r0[2], r0[3], r1[0], r1[1], r1[2], r1[3]};
+                        *reinterpret_cast<v8s*>(drow + kglob) = v;
+                    }
+                }
+            }
+            // ---- dQ: wave w owns the 16 x 16 tile (query tile w >> 2, queries 16 ((w >> 1) & 1) .., head columns 16 (w & 1) ..)
+            const int tq = wave >> 2, qh = (wave >> 1) & 1, dh = wave & 1;
+            f32x4v acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < NW; ++ks) {
+                const int kl = 32 * ks + 8 * g4;
+                const mobgt_v4s r0 = lds_tr16(&DSk[kl + q4][tq * 32 + qh * 16 + 4 * p4]);
+                const mobgt_v4s r1 = lds_tr16(&DSk[kl + 4 + q4][tq * 32 + qh * 16 + 4 * p4]);
+                typedef short v8s __attribute__((ext_vector_type(8)));
+                const v8s av = {r0[0], r0[1], r0[2], r0[3], r1[0], r1[1], r1[2], r1[3]};
+                const bf16x8 a = __builtin_bit_cast(bf16x8, av);
+                const bf16x8 b = *reinterpret_cast<const bf16x8*>(&KT[dh * 16 + i16][kl]);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc, 0, 0, 0);
+            }
+            const int dcol = dh * 16 + i16;
+            if (dcol < D) {
+                float* dst = p.dq_acc + ((int64_t)g * T) * (H * D) + h * D + dcol;
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const int qglob = c * KC + tq * 32 + qh * 16 + 4 * g4 + v;
+                    if (qglob < T && ONE_SKIP != 2) atomicAdd(dst + (int64_t)qglob * (H * D), acc[v]);
+                    if (ONE_SKIP == 2 && acc[v] == 12345.678f) dst[0] = acc[v];          // (keeps the products alive)
+                }
+            }
+        }
+        request(min(c + 2, nchunk - 1));
+        __syncthreads();                                        // B: chunk c + 1 is staged; DSk may be overwritten
+    }
+
+    if (k_ok) {
+        TQ* DK = reinterpret_cast<TQ*>(p.dk) + ((int64_t)g * T + my_k) * p.lddk + h * D + 16 * hi;
+        TQ* DV = reinterpret_cast<TQ*>(p.dv) + ((int64_t)g * T + my_k) * p.lddv + h * D + 16 * hi;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            if (16 * hi + 8 * j < D) {
+                float a[8], b[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) { a[i] = dk[8 * j + i] * p.scale; b[i] = DROP ? dv[8 * j + i] * p.inv_keep : dv[8 * j + i]; }
+                store8(DK + 8 * j, a);
+                store8(DV + 8 * j, b);
+            }
+        }
+    }
+}
+
+// In front of the one-pass backward: zero-fill of the f32 dQ accumulator and delta = rowsum(dO O) per (graph, head, query) -- one
+// thread per (row, head): its d columns of dO and O in, its d columns of the accumulator zeroed.  Behind it: scale + cast of dQ.
+template <int D>
+__global__ void attn_bwd_prep_kernel(const bf16_t* __restrict__ dout, const bf16_t* __restrict__ out, int64_t ldo, float* __restrict__ dq_acc,
+                                     float* __restrict__ delta, int G, int H, int T) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)G * T * H) return;
+    const int h = (int)(i % H);
+    const int64_t row = i / H;                               // g * T + q
+    const int g = (int)(row / T), q = (int)(row % T);
+    float d = 0.f;
+#pragma unroll
+    for (int e = 0; e < D; e += 8) {
+        float a[8], b[8];
+        load8(dout + row * ldo + h * D + e, a);
+        load8(out + row * ldo + h * D + e, b);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) d = fmaf(a[j], b[j], d);
+        *reinterpret_cast<float4*>(dq_acc + row * (H * D) + h * D + e) = make_float4(0.f, 0.f, 0.f, 0.f);
+        *reinterpret_cast<float4*>(dq_acc + row * (H * D) + h * D + e + 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    delta[((int64_t)g * H + h) * T + q] = d;
+}
+__global__ void attn_dq_finish_kernel(const float* acc, bf16_t* dq, int64_t rows, int C, int64_t lddq, float scale) {
+    const int64_t e = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 8;
+    if (e >= rows * C) return;
+    const int64_t r = e / C;
+    const int c = (int)(e % C);
+    float v[8];
+    load8(acc + e, v);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] *= scale;
+    store8(dq + r * lddq + c, v);
+}
+
 // ------------------------------------------------------------------------------------ dispatch
 enum Pass { FWD, BWD_DQ, BWD_DKV, BWD_BOTH };
 
@@ -1029,6 +1350,16 @@ int choose_nq(int GH, int T, int NW, int cap, int cus) {
         if (cost < best_cost * 0.97) { best_cost = cost; best = nq; }
     }
     return best;
+}
+
+// MOBGT_ATTN_TWO_PASS=1: the two deterministic passes of rounds 1-3 also where the one-pass kernel applies (A/B runs, tests)
+bool one_pass_off() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("MOBGT_ATTN_TWO_PASS");
+        v = (e && e[0] == '1') ? 1 : 0;
+    }
+    return v == 1;
 }
 
 template <typename K>
@@ -1063,6 +1394,20 @@ hipError_t launch_one(const AttnParams& p0, hipStream_t st) {
             p.nq = ((p.T + 31) / 32 + NW - 1) / NW;
             p.n_first = GH * p.nq;
             hipLaunchKernelGGL((attn_bwd_both_kernel<D, TQ, TB, NW, DROP>), dim3(2 * GH * p.nq), block, 0, st, p);
+        } else if (std::is_same<TQ, bf16_t>::value && std::is_same<TB, bf16_t>::value && p.dq_acc && p.dbias_bf16 && !one_pass_off()) {
+            // ONE pass (attn_bwd_one_kernel): zero the dQ accumulator + rowsum(dO O), the pass, scale + cast of dQ
+            const int C = p.H * D;
+            const int64_t nth = (int64_t)p.G * p.T * p.H;
+            hipLaunchKernelGGL((attn_bwd_prep_kernel<D>), dim3((unsigned)((nth + 255) / 256)), dim3(256), 0, st,
+                               reinterpret_cast<const bf16_t*>(p.dout), reinterpret_cast<const bf16_t*>(p.out), p.ldo, p.dq_acc, p.delta,
+                               p.G, p.H, p.T);
+            p.nq = ((p.T + 31) / 32 + ONE_NW - 1) / ONE_NW;
+            hipLaunchKernelGGL((attn_bwd_one_kernel<D, DROP>), dim3(GH * p.nq), dim3(ONE_NW * 64), 0, st, p);
+            const int64_t n8 = (int64_t)p.G * p.T * C / 8;
+            // (dq rows: q / k / v gradients share a [G, T, 3C] buffer in the fused layer, hence the row stride lddq; one head's
+            //  columns start at h * D inside the C the accumulator holds, and the launcher passes dq already offset to column 0)
+            hipLaunchKernelGGL(attn_dq_finish_kernel, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, st, p.dq_acc,
+                               reinterpret_cast<bf16_t*>(p.dq), (int64_t)p.G * p.T, C, p.lddq, p.scale);
         } else {
             static const int cap_q = blocks_per_cu(attn_bwd_dq_kernel<D, TQ, TB, NW, DROP>, NW * 64);
             static const int cap_k = blocks_per_cu(attn_bwd_dkv_kernel<D, TQ, TB, NW, DROP>, NW * 64);
@@ -1160,12 +1505,12 @@ extern "C" int mobgt_attn_bias_fwd(const void* q, const void* k, const void* v, 
     return launch<FWD>(p, d, io_dtype, bias_dtype, p.drop_thr != 0, (hipStream_t)stream);
 }
 
-extern "C" int mobgt_attn_bias_bwd(const void* q, const void* k, const void* v, const void* bias, const void* bias_t,
+static int attn_bwd_impl(const void* q, const void* k, const void* v, const void* bias, const void* bias_t,
                                    const void* out, const float* lse, const void* dout, void* dq, void* dk, void* dv,
                                    void* dbias, float* delta, int G, int H, int T, int d, int64_t ldq, int64_t ldk,
                                    int64_t ldv, int64_t ldo, int64_t lddq, int64_t lddk, int64_t lddv, int64_t ld_bias,
                                    float scale, float dropout_p, uint64_t seed, const uint64_t* seed_dev,
-                                   int accumulate_dbias, int dbias_dtype, int io_dtype, int bias_dtype, void* stream) {
+                                   int accumulate_dbias, int dbias_dtype, int io_dtype, int bias_dtype, float* dq_acc, void* stream) {
     int rc = check_common(G, H, T, d, ld_bias, io_dtype, 8);
     if (rc) return rc;
     if (!aligned16(q) || !aligned16(k) || !aligned16(v) || !aligned16(out) || !aligned16(dout) || !aligned16(bias) ||
@@ -1175,6 +1520,7 @@ extern "C" int mobgt_attn_bias_bwd(const void* q, const void* k, const void* v, 
     AttnParams p = {};
     p.q = q; p.k = k; p.v = v; p.bias = bias; p.bias_t = bias_t; p.out = out; p.dout = dout; p.lse_in = lse;
     p.dq = dq; p.dk = dk; p.dv = dv; p.dbias = dbias; p.delta = delta;
+    p.dq_acc = (dq_acc && aligned16(dq_acc)) ? dq_acc : nullptr;
     p.G = G; p.H = H; p.T = T;
     p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo; p.lddq = lddq; p.lddk = lddk; p.lddv = lddv;
     p.ld_bias = ld_bias;
@@ -1184,8 +1530,35 @@ extern "C" int mobgt_attn_bias_bwd(const void* q, const void* k, const void* v, 
     p.dbias_bf16 = dbias_dtype == MOBGT_BF16;
     set_dropout(p, dropout_p, seed, seed_dev);
     const bool drop = p.drop_thr != 0;
-    // T <= 64: both passes in one launch; larger graphs: dQ pass, then dK/dV pass (it reads the dQ pass's `delta`)
+    // T <= 64: both passes in one launch; larger graphs: ONE pass when the caller brought the dQ accumulator (bf16 I/O, bf16 bias
+    // and dBias slice), else the dQ pass, then the dK/dV pass (it reads the dQ pass's `delta`)
     return launch<BWD_BOTH>(p, d, io_dtype, bias_dtype, drop, (hipStream_t)stream);
+}
+
+extern "C" int mobgt_attn_bias_bwd(const void* q, const void* k, const void* v, const void* bias, const void* bias_t,
+                                   const void* out, const float* lse, const void* dout, void* dq, void* dk, void* dv,
+                                   void* dbias, float* delta, int G, int H, int T, int d, int64_t ldq, int64_t ldk,
+                                   int64_t ldv, int64_t ldo, int64_t lddq, int64_t lddk, int64_t lddv, int64_t ld_bias,
+                                   float scale, float dropout_p, uint64_t seed, const uint64_t* seed_dev,
+                                   int accumulate_dbias, int dbias_dtype, int io_dtype, int bias_dtype, void* stream) {
+    return attn_bwd_impl(q, k, v, bias, bias_t, out, lse, dout, dq, dk, dv, dbias, delta, G, H, T, d, ldq, ldk, ldv, ldo, lddq, lddk,
+                         lddv, ld_bias, scale, dropout_p, seed, seed_dev, accumulate_dbias, dbias_dtype, io_dtype, bias_dtype,
+                         nullptr, stream);
+}
+
+// The same backward with a scratch accumulator for dQ: dq_acc [G, T, H * d] f32, 16-byte aligned, contents irrelevant on entry
+// and on return.  With it, T > 64, bf16 I/O, a bf16 bias and a bf16 dBias slice the gradients are formed in ONE pass over the
+// bias (attn_bwd_one_kernel: S / P / dS once per pair, bias_t read once, dBias written once, dQ summed over key blocks by f32
+// atomics -- so dQ is then NOT bitwise reproducible from run to run; MOBGT_ATTN_TWO_PASS=1 keeps the two deterministic passes).
+extern "C" int mobgt_attn_bias_bwd_fused(const void* q, const void* k, const void* v, const void* bias, const void* bias_t,
+                                   const void* out, const float* lse, const void* dout, void* dq, void* dk, void* dv,
+                                   void* dbias, float* delta, int G, int H, int T, int d, int64_t ldq, int64_t ldk,
+                                   int64_t ldv, int64_t ldo, int64_t lddq, int64_t lddk, int64_t lddv, int64_t ld_bias,
+                                   float scale, float dropout_p, uint64_t seed, const uint64_t* seed_dev,
+                                   int accumulate_dbias, int dbias_dtype, int io_dtype, int bias_dtype, float* dq_acc, void* stream) {
+    return attn_bwd_impl(q, k, v, bias, bias_t, out, lse, dout, dq, dk, dv, dbias, delta, G, H, T, d, ldq, ldk, ldv, ldo, lddq, lddk,
+                         lddv, ld_bias, scale, dropout_p, seed, seed_dev, accumulate_dbias, dbias_dtype, io_dtype, bias_dtype,
+                         dq_acc, stream);
 }
 
 extern "C" int mobgt_dropout_keep_host(uint64_t seed, int H, int T, int g, int h, int i, int j, float dropout_p) {

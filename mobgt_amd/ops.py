@@ -431,6 +431,9 @@ def build_bias(attn_bias, rel_pos, poi_pos, edge_input, rel_table, poi_table, ho
 
 
 # -------------------------------------------------------------------------------------- attention
+_ATTN_ONE_PASS = [os.environ.get("MOBGT_ATTN_TWO_PASS") != "1"]       # T > 64, bf16: one-pass backward (round 4); =1: the two passes
+
+
 def _check_rows(*ts):
     for t in ts:
         if t.stride(-1) != 1 or t.stride(-2) % 8 != 0 or t.data_ptr() % 16 != 0:
@@ -459,12 +462,19 @@ def _attn_bwd(q, k, v, out, lse, dout, dq, dk, dv, pack, scale, p_drop, seed, se
     if pack.needs_grad:
         dbias, acc = pack.next_grad_slice()
     delta = torch.empty(G, H, T, dtype=torch.float32, device=q.device)
-    check(_lib.lib().mobgt_attn_bias_bwd(_p(q), _p(k), _p(v), _p(pack.bias), _p(pack.bias_t), _p(out), _p(lse), _p(dout),
-                                         _p(dq), _p(dk), _p(dv), _p(dbias), _p(delta), G, H, T, C // H,
-                                         q.stride(1), k.stride(1), v.stride(1), C, dq.stride(1), dk.stride(1),
-                                         dv.stride(1), pack.ld, scale, p_drop, seed, _p(seed_dev), acc,
-                                         _DT[dbias.dtype] if dbias is not None else F32, _DT[q.dtype], _DT[pack.dtype],
-                                         _stream()), "mobgt_attn_bias_bwd")
+    args = (_p(q), _p(k), _p(v), _p(pack.bias), _p(pack.bias_t), _p(out), _p(lse), _p(dout),
+            _p(dq), _p(dk), _p(dv), _p(dbias), _p(delta), G, H, T, C // H,
+            q.stride(1), k.stride(1), v.stride(1), C, dq.stride(1), dk.stride(1),
+            dv.stride(1), pack.ld, scale, p_drop, seed, _p(seed_dev), acc,
+            _DT[dbias.dtype] if dbias is not None else F32, _DT[q.dtype], _DT[pack.dtype])
+    if (T > 64 and q.dtype == torch.bfloat16 and pack.dtype == torch.bfloat16 and dbias is not None
+            and dbias.dtype == torch.bfloat16 and _ATTN_ONE_PASS[0]):
+        # long graphs, training configuration: ONE pass over the bias (csrc/attn.hip: attn_bwd_one_kernel) -- needs an f32
+        # scratch accumulator for dQ (summed over key blocks by atomics)
+        dq_acc = torch.empty(G, T, C, dtype=torch.float32, device=q.device)
+        check(_lib.lib().mobgt_attn_bias_bwd_fused(*args, _p(dq_acc), _stream()), "mobgt_attn_bias_bwd_fused")
+        return
+    check(_lib.lib().mobgt_attn_bias_bwd(*args, _stream()), "mobgt_attn_bias_bwd")
 
 
 class _AttnFn(torch.autograd.Function):

@@ -86,10 +86,15 @@ def _dataset(name, uni, n_batches, seed0):
 
 
 def test_graph_loop_equals_eager_loop_step_by_step():
-    """Two models built identically; one loop replays graphs (captured lazily per bucket), the other runs eagerly."""
+    """Two models built identically; one loop replays graphs (captured lazily per bucket), the other runs eagerly.
+    (Round 4: peak_lr 2e-3 -> 2e-5.  Two runs of ONE form already differ by ~1e-3 in their gradients -- f32 atomics in front of
+    bf16 rounding points, tests/test_gpu_train.py -- and at 2e-3 AdamW's sign-like first steps turned that into 7 % of the loss
+    by step 4 in one run of the suite; what this test is after -- the same batches, masks and step counter in both forms, which
+    would show as 1e-2 -- does not need parameters that move that far.  The optimizer's trajectory is pinned against
+    torch.optim.AdamW in tests/test_gpu_train.py.)"""
     losses = []
     for use_graph in (True, False):
-        uni, model, coll = workloads.build("fsq", DEV, seed=1, model_overrides=dict(n_layers=2, peak_lr=2e-3, warmup_updates=4,
+        uni, model, coll = workloads.build("fsq", DEV, seed=1, model_overrides=dict(n_layers=2, peak_lr=2e-5, warmup_updates=4,
                                                                                   tot_updates=100))
         data = _dataset("fsq", uni, 6, 7000)
         loop = EpochLoop(model, coll, data, batch_size=16, seed=3, use_graph=use_graph)
