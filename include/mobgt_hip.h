@@ -254,9 +254,12 @@ int mobgt_embed_gather_concat(const float* const* tables, const void* const* ind
 int mobgt_embed_scatter_concat(float* const* d_tables, const void* const* indices, const int64_t* skip_idx,
                                const int* widths, int n_tables, const float* dout, int64_t R, int64_t ld_dout,
                                int idx_dtype, void* stream);
-/* n <= 8 such gathers over ONE position list in one launch, each into its own destination: job t copies
+/* n <= 8 such gathers (+ at most three folded tables, below) over ONE position list in one launch, each into its own destination: job t copies
  * table_t[idx_t[r], :] (width_t columns, zeros where idx < 0) to buf_t[r, coff_t : coff_t + width_t] (row stride ld_t), or ADDS
- * it there when accum_t (jobs run in order: a sum of tables is a copy followed by adds) -- `[poi ; time]`, the category rows
+ * it there when accum_t == 1 (jobs run in order: a sum of tables is a copy followed by adds); accum_t == 2 (round 4): table_t
+ * is FOLDED into the last job in front of it that is not itself folded -- same width, read at that job's row index, added in
+ * registers before the job stores (forward only, one job per call may have folded tables; the partial tables of
+ * mobgt_mask_rows_fwd) -- `[poi ; time]`, the category rows
  * and the additive degree / frequency / positional rows of model_fqandtoyo.py:1259-1298.  backward != 0: buf_t is the
  * gradient buffer, scatter-added into d_table_t (f32 atomics; rows equal to skip_t and null d_tables skipped); extra_row0
  * (optional, [width of job extra_job]) is added to ROW 0 of d_table[extra_job] -- the graph token's share of pe[0]'s
@@ -685,6 +688,34 @@ int64_t mobgt_mask_gemm_workspace_bytes(int K, int N);
 int mobgt_mask_gemm(const uint32_t* mask, int64_t ld_mask_words, const float* x, int64_t ldx, const float* bscale,
                     const float* rscale, const float* bias, float* out, int64_t ld_out, void* work, int M, int K, int N,
                     void* stream);
+/* Round 4 -- the distance GCN's hidden and last layer around two bitmask products, rows-only form (csrc/maskgemm.hip;
+ * reference: graphormer/modelGNN.py:38-44 GraphConvolution, :66-72 GCN.forward; model_fqandtoyo.py:1236 the distance GCN over
+ * all P POIs, :1264 its table read at the batch's POI ids only).  Hidden widths 16 and 64 (model_fqandtoyo.py: nhid = [16, 64]).
+ *   mobgt_mask_gemm_l1_fwd   t [M,16] = rscale * (A y0)   (y0t: y0 transposed, bf16 [16][ld_y0t], zero beyond K);
+ *                            y [M,64] = dropout(leaky_relu(t w1 + b1))  (w1 [16,64], mask rule of mobgt_small_gemm_f32_act),
+ *                            yt = y transposed, bf16 [64][ld_yt] (columns >= M untouched); `zero`: zero_floats (% 4 == 0) f32
+ *                            zeroed as a side job (the next call's atomic destinations; may be null);
+ *   mobgt_mask_rows_fwd      u [R,64] = rscale[rows[r]] * (A[rows[r], :] y)  and  parts [4][R,NO] with
+ *                            parts[q] = u[:, 16q : 16q + 16] w2[16q : 16q + 16, :] (+ b2 for q = 0): the last layer's output is
+ *                            parts[0] + parts[1] + parts[2] + parts[3], added by the consumer (mobgt_embed_gather_multi's
+ *                            accumulate jobs) in that order -- no atomics, bit-reproducible;
+ *                            rs_rows [R] = rscale[rows[r]] (may be null);  w2 [64,NO], NO % 4 == 0, NO <= 192;
+ *   mobgt_mask_rows_bwd      dy1 [P,64] = A[rows,:]^T gu  with  gut = gu^T in bf16 [64][roundup(R,128)] (already scaled by
+ *                            rs_rows, zero beyond R);  mask_t: bitmask of A^T;  and the hidden layer's data gradient
+ *                            dtt [16][ld_dtt] = (((dy1 * m(y1)) w1^T) * bscale)^T in bf16 -- the operand of
+ *                            mobgt_mask_gemm(mask_t, x = null) -- with m(y) = y > 0 ? m_pos : (y < 0 ? m_neg : m_zero).
+ * MOBGT_EBADDIM on other widths / leading dimensions, MOBGT_EALIGN on operands that are not 16-byte aligned. */
+int mobgt_mask_gemm_l1_fwd(const uint32_t* mask, int64_t ld_mask_words, const float* rscale, const void* y0t_bf16,
+                           int64_t ld_y0t, float* t, const float* w1, const float* b1, float slope, float dropout_p,
+                           uint64_t seed, const uint64_t* seed_dev, uint32_t salt, float* y, void* yt_bf16, int64_t ld_yt,
+                           void* zero, int64_t zero_floats, int M, int K, void* stream);
+int mobgt_mask_rows_fwd(const uint32_t* mask, int64_t ld_mask_words, const int64_t* rows, const float* rscale,
+                        const void* y1t_bf16, int64_t ld_y1t, const float* w2, const float* b2, float* u, float* parts,
+                        float* rs_rows, int R, int K, int NO, void* stream);
+int64_t mobgt_mask_rows_bwd_lds_bytes(int64_t ld_mask_words, int R);
+int mobgt_mask_rows_bwd(const uint32_t* mask_t, int64_t ld_mask_words, const int64_t* rows, const void* gut_bf16,
+                        int64_t ld_gut, const float* y1, float m_pos, float m_neg, float m_zero, const float* w1,
+                        const float* bscale, float* dy1, void* dtt_bf16, int64_t ld_dtt, int R, int P, void* stream);
 int mobgt_spmm_csr(const int64_t* rowptr, const int32_t* col, const float* val, const int64_t* rows, const float* b,
                    int64_t ldb, const float* bias, float* out, int64_t ld_out, int64_t R, int C, void* stream);
 int mobgt_spmm_csr_t_rows(const int64_t* rowptr, const int32_t* col, const float* val, const int64_t* rows,

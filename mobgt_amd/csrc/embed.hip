@@ -102,6 +102,7 @@ __global__ __launch_bounds__(256) void gather_concat_kernel(const ConcatParams p
 // there when accum_t (jobs run in order inside the wave that owns row r: a sum of tables is a copy followed by adds).
 // Backward: buf_t is the gradient buffer, scattered with f32 atomics into d_table_t (rows equal to skip_t excepted).
 constexpr int MAXJ = 8;
+constexpr int MAXFOLD = 3;
 struct MultiParams {
     const float* tables[MAXJ];
     float* d_tables[MAXJ];
@@ -112,6 +113,8 @@ struct MultiParams {
     int64_t ld[MAXJ];
     int n;
     int64_t R;
+    const float* fold[MAXFOLD];             // forward, optional: n_fold more tables of job fold_job's width, read at that job's
+    int n_fold, fold_job;                   // row and added (in order) to its value before it is stored / accumulated
     const float* extra_src;                 // backward, optional: a [W] vector added to ROW 0 of d_tables[extra_job] (the
     int extra_job;                          // graph-token row's share of pe[0]'s gradient, model_fqandtoyo.py:1338-1342)
 };
@@ -130,8 +133,16 @@ __global__ __launch_bounds__(256) void gather_multi_kernel(const MultiParams p) 
         const int W = p.width[t];
         float* b = p.buf[t] + r * p.ld[t] + p.coff[t];
         if (!BWD) {
+            const bool f1 = p.n_fold > 0 && t == p.fold_job, f2 = p.n_fold > 1 && t == p.fold_job, f3 = p.n_fold > 2 && t == p.fold_job;
             for (int c = lane * 4; c < W; c += 256) {
-                float4 v = row >= 0 ? *reinterpret_cast<const float4*>(p.tables[t] + row * W + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+                const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+                float4 v = row >= 0 ? *reinterpret_cast<const float4*>(p.tables[t] + row * W + c) : z4;
+                const float4 o1 = (f1 && row >= 0) ? *reinterpret_cast<const float4*>(p.fold[0] + row * W + c) : z4;
+                const float4 o2 = (f2 && row >= 0) ? *reinterpret_cast<const float4*>(p.fold[1] + row * W + c) : z4;
+                const float4 o3 = (f3 && row >= 0) ? *reinterpret_cast<const float4*>(p.fold[2] + row * W + c) : z4;
+                if (f1) { v.x += o1.x; v.y += o1.y; v.z += o1.z; v.w += o1.w; }
+                if (f2) { v.x += o2.x; v.y += o2.y; v.z += o2.z; v.w += o2.w; }
+                if (f3) { v.x += o3.x; v.y += o3.y; v.z += o3.z; v.w += o3.w; }
                 if (p.accum[t]) {
                     const float4 o = *reinterpret_cast<const float4*>(b + c);
                     v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
@@ -402,25 +413,39 @@ extern "C" int mobgt_gather_rows_t(const void* a, int64_t ld, const int64_t* row
     return (int)hipGetLastError();
 }
 
-/* n <= 8 gathers of one position list in one launch (see gather_multi_kernel); backward != 0: the scatter-add of the
- * gradient buffers into d_tables (null entries skipped). */
+/* n <= 8 gathers of one position list in one launch (see gather_multi_kernel) + up to three FOLDED tables (accum == 2: added
+ * to the job in front of them, forward only); backward != 0: the scatter-add of the gradient buffers into d_tables (null
+ * entries skipped). */
 extern "C" int mobgt_embed_gather_multi(int n, const float* const* tables, float* const* d_tables, const void* const* idx,
                                         const int64_t* skip, const int* width, const int* coff, const int* accum,
                                         float* const* buf, const int64_t* ld, int64_t R, int idx_dtype, int backward,
                                         const float* extra_row0, int extra_job, void* stream) {
-    if (n < 1 || n > MAXJ) return MOBGT_EBADDIM;
+    if (n < 1 || n > MAXJ + MAXFOLD) return MOBGT_EBADDIM;
     if (extra_row0 && (extra_job < 0 || extra_job >= n || !backward)) return MOBGT_EBADDIM;
     if (R <= 0) return 0;
     MultiParams p = {};
+    int k = 0;
     for (int t = 0; t < n; ++t) {
+        if (accum && accum[t] == 2) {                       // folded into job k - 1
+            if (backward || !tables || !tables[t] || k == 0 || p.n_fold >= MAXFOLD || (p.n_fold && p.fold_job != k - 1) ||
+                width[t] != p.width[k - 1] || extra_row0)
+                return MOBGT_EBADDIM;
+            if ((uintptr_t)tables[t] & 15) return MOBGT_EALIGN;
+            p.fold[p.n_fold++] = tables[t];
+            p.fold_job = k - 1;
+            continue;
+        }
+        if (k >= MAXJ) return MOBGT_EBADDIM;
         if (width[t] <= 0 || (width[t] & 3) || (coff[t] & 3) || (ld[t] & 3) || !buf[t]) return MOBGT_EBADDIM;
         if (((uintptr_t)buf[t] | (uintptr_t)(tables ? tables[t] : nullptr)) & 15) return MOBGT_EALIGN;
-        p.tables[t] = tables ? tables[t] : nullptr;
-        p.d_tables[t] = d_tables ? d_tables[t] : nullptr;
-        p.idx[t] = idx[t]; p.skip[t] = skip ? skip[t] : -1;
-        p.width[t] = width[t]; p.coff[t] = coff[t]; p.accum[t] = accum ? accum[t] : 0;
-        p.buf[t] = buf[t]; p.ld[t] = ld[t];
+        p.tables[k] = tables ? tables[t] : nullptr;
+        p.d_tables[k] = d_tables ? d_tables[t] : nullptr;
+        p.idx[k] = idx[t]; p.skip[k] = skip ? skip[t] : -1;
+        p.width[k] = width[t]; p.coff[k] = coff[t]; p.accum[k] = accum ? accum[t] : 0;
+        p.buf[k] = buf[t]; p.ld[k] = ld[t];
+        ++k;
     }
+    n = k;
     p.n = n; p.R = R; p.extra_src = extra_row0; p.extra_job = extra_job;
     const dim3 grid((unsigned)((R + 3) / 4)), block(256);
     hipStream_t st = (hipStream_t)stream;

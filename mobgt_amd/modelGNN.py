@@ -586,6 +586,108 @@ class _SmallGcnFn(torch.autograd.Function):
         return (None, None, None, *grads, None, None, None, None, None, None)
 
 
+class _DistGcnFn(torch.autograd.Function):
+    """The distance GCN of the fq model (three GraphConvolutions 303 -> 16 -> 64 -> hidden over all P POIs, modelGNN.py:38-44,
+    :66-72; model_fqandtoyo.py:1236) evaluated for the batch's POI rows only (:1264), as THREE launches forward and four
+    backward (round 4; csrc/maskgemm.hip "Round 4"):
+      forward   y0 = leaky((A X) W0 + b0)                         small GEMM on the precomputed, zero-padded A X (+ y0^T bf16)
+                t1 = A y0,  y1 = dropout(leaky(t1 W1 + b1))       bitmask product with the layer in its epilogue (+ y1^T bf16)
+                u = A[rows] y1,  out = u W2 + b2                  bitmask product on the batch's rows; out leaves as four
+                                                                  partial tables (one per 16 columns of u) that the consumer adds
+      backward  dW2 = u^T g, db2;  gu = g W2^T (scaled, transposed, bf16);  dy1 = A[rows]^T gu with dt1 = (dy1 m(y1)) W1^T
+                in its epilogue;  dy0 = A^T dt1;  dW1 = t1^T (dy1 m(y1)), dW0 = (A X)^T (dy0 m(y0)) in the step's grouped
+                weight-gradient launch.
+    The last layer is reassociated -- (A[rows] y1) W2 instead of A[rows] (y1 W2): the P-row product has width 64 instead of
+    `hidden`, and its operand is the bf16 rounding of y1 (was: of y1 W2)."""
+
+    @staticmethod
+    def forward(ctx, ax_pad, mask, mask_t, scale, rows, w0, b0, w1, b1, w2, b2, slope, p_drop, seed, seed_dev, salt):
+        from . import ops, _lib
+        from .ops import _p, _stream
+        P, R, NO = ax_pad.shape[0], rows.numel(), w2.shape[1]
+        dev = ax_pad.device
+        y0t = xt_workspace(dev, P, 16, slot=0)
+        y0 = ops.small_gemm(ax_pad, w0, b0, leaky=slope, k_b=w0.shape[0], ct=(y0t, None, False))
+        y1t = xt_workspace(dev, P, 64, slot=0)
+        t1 = torch.empty(P, 16, dtype=torch.float32, device=dev)
+        y1 = torch.empty(P, 64, dtype=torch.float32, device=dev)
+        u = torch.empty(R, 64, dtype=torch.float32, device=dev)
+        parts = torch.empty(4, R, NO, dtype=torch.float32, device=dev)                # out = parts[0] + parts[1] + parts[2] + parts[3]
+        rs_rows = torch.empty(R, dtype=torch.float32, device=dev)
+        L = _lib.lib()
+        _lib.check(L.mobgt_mask_gemm_l1_fwd(_p(mask), mask.shape[1], _p(scale), _p(y0t), y0t.stride(0), _p(t1), _p(w1), _p(b1),
+                                            float(slope), float(p_drop), int(seed), _p(seed_dev), int(salt) & 0xFFFFFFFF, _p(y1),
+                                            _p(y1t), y1t.stride(0), None, 0, P, P, _stream()), "mobgt_mask_gemm_l1_fwd")
+        _lib.check(L.mobgt_mask_rows_fwd(_p(mask), mask.shape[1], _p(rows), _p(scale), _p(y1t), y1t.stride(0), _p(w2), _p(b2),
+                                         _p(u), _p(parts), _p(rs_rows), R, P, NO, _stream()), "mobgt_mask_rows_fwd")
+        ctx.save_for_backward(ax_pad, y0, t1, y1, u, rs_rows, rows, w0, w1, w2, mask_t, scale)
+        ctx.mv0, ctx.mv1 = ops.act_mask_values(slope, 0.0), ops.act_mask_values(slope, p_drop)
+        ctx.sinks = tuple(ops.grad_sink(t) for t in (w0, b0, w1, b1, w2, b2))
+        # the last layer's output as the four partial tables of its column blocks: the first carries the gradient (d out /
+        # d parts[q] = 1 for every q), the other three are constants to autograd
+        p0, rest = parts[0], parts[1:]
+        ctx.mark_non_differentiable(rest)
+        ctx.set_materialize_grads(False)             # (no zero tensor for `rest`'s absent gradient)
+        return p0, rest
+
+    @staticmethod
+    def backward(ctx, g, _g_rest=None):
+        from . import ops, _lib
+        from .ops import _p, _stream
+        ax_pad, y0, t1, y1, u, rs_rows, rows, w0, w1, w2, mask_t, scale = ctx.saved_tensors
+        k_w0, k_b0, k_w1, k_b1, k_w2, k_b2 = ctx.sinks
+        if g is None:
+            return (None,) * 16
+        g = g.contiguous()
+        dev = g.device
+        P, R = ax_pad.shape[0], rows.numel()
+
+        def dst(k, n):
+            return k[:] if k is not None else ops.zeros_f32((n,), dev)
+        db2 = dst(k_b2, w2.shape[1])
+        dW2 = ops.linear_wgrad_masked(u, g, db=db2, db_of_x=True, leaf=True, dw=k_w2[:] if k_w2 is not None else None)
+        gut = xt_workspace(dev, R, 64, slot=2)
+        ops.small_gemm(g, w2, b_is_nk=True, ct=(gut, rs_rows, True))                 # (rs[rows] * (g W2^T))^T, bf16
+        dy1 = torch.empty(P, 64, dtype=torch.float32, device=dev)
+        dtt = xt_workspace(dev, P, 16, slot=1)
+        _lib.check(_lib.lib().mobgt_mask_rows_bwd(_p(mask_t), mask_t.shape[1], _p(rows), _p(gut), gut.stride(0), _p(y1),
+                                                  float(ctx.mv1[0]), float(ctx.mv1[1]), float(ctx.mv1[2]), _p(w1), _p(scale), _p(dy1),
+                                                  _p(dtt), dtt.stride(0), R, P, _stream()), "mobgt_mask_rows_bwd")
+        db1 = dst(k_b1, 64)
+        dW1 = ops.linear_wgrad_masked(t1, dy1, x_mask=y1, mask_vals=ctx.mv1, db=db1, db_of_x=True, leaf=True,
+                                      dw=k_w1[:] if k_w1 is not None else None)
+        dy0 = mask_gemm(MaskAdj(None, mask_t, scale), None, transposed=True, xt=dtt)  # A^T dt1  [P,16]
+        db0 = dst(k_b0, 16)
+        dw_dst = None
+        extra = (ax_pad.shape[1] - w0.shape[0]) * w0.shape[1]
+        if k_w0 is not None and k_w0.is_contiguous() and 0 <= extra <= 16:
+            # the parameter's gradient sink, seen with the rows of the zero padding (see _ConvActFn.backward)
+            dw_dst = torch.as_strided(k_w0, (ax_pad.shape[1], w0.shape[1]), (w0.shape[1], 1))
+        dW0 = ops.linear_wgrad_masked(ax_pad, dy0, x_mask=y0, mask_vals=ctx.mv0, db=db0, db_of_x=True, leaf=True, dw=dw_dst)
+        dW0 = dW0[:w0.shape[0]]
+        return (None, None, None, None, None, dW0, db0[:], dW1, db1[:], dW2, db2[:], None, None, None, None, None)
+
+
+def _dist_gcn_ok(gcn, adj_x_pad, rows, mask_adj):
+    """The shapes / layouts _DistGcnFn's kernels take (anything else keeps the launch-per-product path)."""
+    if os.environ.get("MOBGT_NO_DIST_GCN_FUSED") == "1" or adj_x_pad is None or rows is None or mask_adj is None or len(gcn.gcn) != 3:
+        return False
+    g0, g1, g2 = gcn.gcn
+    if not (adj_x_pad.is_cuda and adj_x_pad.dtype == torch.float32 and adj_x_pad.is_contiguous() and adj_x_pad.shape[1] % 16 == 0
+            and 0 <= adj_x_pad.shape[1] - g0.in_features < 16):
+        return False
+    if (g0.out_features, g1.in_features, g1.out_features, g2.in_features) != (16, 16, 64, 64) or g2.out_features % 4 or g2.out_features > 192:
+        return False
+    for g in (g0, g1, g2):
+        if g.bias is None or g.weight.dtype != torch.float32 or not g.weight.is_contiguous() or not g.bias.is_contiguous():
+            return False
+    P = adj_x_pad.shape[0]
+    if rows.dtype != torch.int64 or not rows.is_contiguous() or rows.numel() < 1 or mask_adj.scale.numel() != P:
+        return False
+    from . import _lib
+    return int(_lib.lib().mobgt_mask_rows_bwd_lds_bytes(mask_adj.mask_t.shape[1], rows.numel())) <= 120 * 1024
+
+
 class GCN(nn.Module):
     def __init__(self, ninput, nhid, noutput, dropout):
         super().__init__()
@@ -596,12 +698,13 @@ class GCN(nn.Module):
         for i in range(len(channels) - 1):
             self.gcn.append(GraphConvolution(channels[i], channels[i + 1]))
 
-    def forward(self, x, adj, adj_x=None, rows=None, adj_t=None, mask_adj=None):
+    def forward(self, x, adj, adj_x=None, rows=None, adj_t=None, mask_adj=None, parts_ok=False):
         """`adj_x` = adj @ x precomputed (x is a constant feature matrix in MobGT): skips the first P x P product.
         `rows` (int64 [R]): return only these rows of the output table, i.e. evaluate the LAST layer as
         adj[rows] @ (h W) + b.  The model reads the table only at the batch's POI ids
         (model_fqandtoyo.py:1264), so for R << P this replaces a P x P product (and its transpose in the
-        backward) by an R x P one without changing any value that is used."""
+        backward) by an R x P one without changing any value that is used.
+        `parts_ok`: the caller accepts the result as `out` + the tensors in `out._mobgt_parts` (to be ADDED to it, in order)."""
         n_hidden = len(self.gcn) - 1
         adj_x_pad = None
         if adj_x is not None and adj_x.shape[1] != self.gcn[0].in_features:      # zero-padded columns (see _ConvActFn)
@@ -625,6 +728,20 @@ class GCN(nn.Module):
                 return _SmallGcnFn.apply(adj_x, adj, adj_t, g0.weight, g0.bias, g1.weight, g1.bias, g2.weight, g2.bias,
                                          float(self.leaky_relu.negative_slope), float(p_drop), seed, seed_dev, salt,
                                          pre[1] if pre is not None else None)
+        ax_in = adj_x_pad if adj_x_pad is not None else adj_x      # (a width that is already a whole number of k-steps: no padding)
+        if x.is_cuda and not isinstance(adj, CsrAdj) and _dist_gcn_ok(self, ax_in, rows, mask_adj):
+            from . import ops
+            p_drop = self.dropout if self.training else 0.0
+            seed, seed_dev = ops.dropout_seed(p_drop)
+            g0, g1, g2 = self.gcn
+            with torch.autocast(device_type="cuda", enabled=False):
+                p0, rest = _DistGcnFn.apply(ax_in, mask_adj.mask, mask_adj.mask_t, mask_adj.scale, rows, g0.weight, g0.bias,
+                                            g1.weight, g1.bias, g2.weight, g2.bias, float(self.leaky_relu.negative_slope),
+                                            float(p_drop), seed, seed_dev, 0x2000 + g2.out_features)
+            if parts_ok:                 # the caller adds the partial tables itself (model_fqandtoyo.node_features: in its gather)
+                p0._mobgt_parts = tuple(rest.unbind(0))
+                return p0
+            return ((p0 + rest[0]) + rest[1]) + rest[2]
         if x.is_cuda and all(g.out_features % 4 == 0 and g.bias is not None for g in self.gcn[:-1]):
             from . import ops
             for i in range(n_hidden):       # bias + LeakyReLU (+ the dropout in front of the last layer) in one launch

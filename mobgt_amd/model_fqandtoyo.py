@@ -321,7 +321,11 @@ class Graphormer(nn.Module):
         if x.dtype not in (torch.int64, torch.int32):
             x = x.long()
         G, N = x.shape
-        rows_only = G * N * 2 <= self.X.shape[0]        # the table is read at <= G*N rows (:1264): compute only those
+        # the table is read at <= G*N rows (:1264): compute only those.  The row gather of the dense adjacency pays below P/2
+        # rows; the bitmask-rows form of round 4 (modelGNN._DistGcnFn: 1 KB per row, K-split) up to P rows
+        mask_rows = (getattr(self, "D_mask", None) is not None and not self.sparse_adj
+                     and os.environ.get("MOBGT_NO_DIST_GCN_FUSED") != "1")
+        rows_only = G * N * 2 <= self.X.shape[0] or (mask_rows and G * N <= min(self.X.shape[0], 4096))
         idx, real = ops.node_index(x, batched_data.time_normal[:, :, 0].float(), self.poi2cat, rows_only,
                                    batched_data.in_degree, batched_data.out_degree)
         return idx, real, rows_only
@@ -353,7 +357,7 @@ class Graphormer(nn.Module):
                 from .modelGNN import MaskAdj
                 mask_adj = MaskAdj(self.D_mask, self.D_mask_t, self.D_scale)
             poidist = self.poi_distance_model(self.X, self.D_A, self.D_AX, rows=gcn_rows.reshape(-1) if rows_only else None,
-                                              adj_t=self.D_A_T, mask_adj=mask_adj)                  # :1236
+                                              adj_t=self.D_A_T, mask_adj=mask_adj, parts_ok=G * N <= 4096)   # :1236
         ops.trace_nan("poidist", poidist)
         catemb = self.poi_cat_model(self.C_X, self.C_A, self.C_AX, adj_t=self.C_A_T)                                    # :1237
         Wp, Wt, Wc, C = poidist.shape[1], self.time_embed_model_48.weight.shape[1], catemb.shape[1], self.pos_embed.pe.shape[1]
@@ -363,7 +367,10 @@ class Graphormer(nn.Module):
             # every gathered row of :1259-1298 in ONE launch: [poi ; time] -> pt, the category row -> the trailing columns of
             # fuse4's input, fre_embed(0) + degree rows + positional rows pe[1..n] (:1287-1298, :348-351) summed -> add
             pt, x4, add = ops.embed_gather_multi(
-                [(poidist, poi_idx, 0, 0, False, None), (self.time_embed_model_48.weight, time_idx, 0, Wp, False, 0),
+                [(poidist, poi_idx, 0, 0, False, None)] +
+                # (round 4: the distance GCN's output may arrive as partial tables -- modelGNN._DistGcnFn -- added here, in order)
+                [(part, poi_idx, 0, 0, 2, None) for part in getattr(poidist, "_mobgt_parts", ())] +
+                [(self.time_embed_model_48.weight, time_idx, 0, Wp, False, 0),
                  (catemb, cat_idx, 1, Wp + Wt, False, None),
                  (self.fre_embed_model.weight, zero_idx, 2, 0, False, 0), (self.in_degree_encoder.weight, in_deg, 2, 0, True, 0),
                  (self.out_degree_encoder.weight, out_deg, 2, 0, True, 0), (self.pos_embed.pe, pos_idx, 2, 0, True, None)],

@@ -940,12 +940,18 @@ class _GatherMultiFn(torch.autograd.Function):
 
 def embed_gather_multi(jobs, out_widths):
     """jobs = [(table, index, out, coff, accum, padding_idx)]: table[index] -> columns [coff, coff + W) of output `out`
-    (copied, or added when `accum`) -- all in one launch each way.  -> list of [R, out_widths[o]] f32 tensors."""
+    (copied, or added when `accum`; accum = 2: this table's row is added to the PREVIOUS job's before that job stores --
+    a constant partial table of the same shape, no gradient) -- all in one launch each way.
+    -> list of [R, out_widths[o]] f32 tensors."""
     n = len(jobs)
     tabs = [j[0].float().contiguous() for j in jobs]
     idx = [j[1].contiguous().reshape(-1) for j in jobs]
     _require_cuda(*tabs, *idx)
-    spec = tuple((int(j[2]), int(j[3]), bool(j[4]), -1 if j[5] is None else int(j[5])) for j in jobs)
+    # (accum 2: FOLDED into the job in front of it -- same index, same width -- i.e. that job gathers the sum of the tables)
+    spec = tuple((int(j[2]), int(j[3]), int(j[4]), -1 if j[5] is None else int(j[5])) for j in jobs)
+    for k, sp in enumerate(spec):
+        assert sp[2] != 2 or (k > 0 and tabs[k].shape[1] == tabs[k - 1].shape[1] and not tabs[k].requires_grad
+                              and (k < 4 or any(s_[2] != 2 for s_ in spec[k - 3:k]))), "fold job (at most three per gather)"
     return list(_GatherMultiFn.apply(spec, tuple(out_widths), n, *tabs, *idx))
 
 

@@ -4,7 +4,7 @@
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
 tag=${1:-step}; shift
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_${tag} -o r -- python3 bench.py --steps 40 --warmup 10 --no-cpu-baseline --no-parity --no-stress --no-live-pmc --no-loop "$@" > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_bench.err
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_${tag} -o r -- python3 bench.py --steps 40 --warmup 10 --no-cpu-baseline --no-parity --no-stress --no-live-pmc --no-loop --no-sub "$@" > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_bench.err
 f=$(find gpurun_out/prof_${tag} -name "r_kernel_trace.csv" | head -1)
 python3 tools/trace_seq.py "$f" > gpurun_out/${tag}_step_seq.txt
 python3 tools/trace_step.py "$f" -4 40 > gpurun_out/${tag}_step_summary.txt
