@@ -459,6 +459,20 @@ int mobgt_assemble_tokens_qkv(const float* nf, const float* real, const float* a
                               float* out, void* out_bf16, const void* wqkv_packed, const void* bqkv, void* qkv, int G, int N, int C,
                               float p_pos, float p_in, uint64_t seed, const uint64_t* seed_dev, uint32_t salt_nf,
                               uint32_t salt_tok, uint32_t salt_in, void* stream);
+/* Round 4: everything between the GCN tables and the first layer's attention in one launch (csrc/chain.hip,
+ * token_fwd_chain_kernel): the forward of mobgt_embed_gather_multi (model_fqandtoyo.py:1259-1298) with the same job list (n,
+ * tables, idx, width, coff, accum incl. the folded tables; `slot` names each job's destination: 0 = pt [G*N, W2], 1 = the
+ * trailing columns of x4 [G*N, C], 2 = add [G*N, C]), FuseEmbeddings-2 and -4 (model_fqandtoyo.py:444-456, :1268-1269:
+ * x4[:, :W2] = leaky(pt w2^T + b2), nf = leaky(x4 w4^T + b4); F.linear layout, f32, full-f32 MFMA products) and
+ * mobgt_assemble_tokens_qkv.  pt, x4, add, nf are OUTPUTS (what the backward pass and the weight gradients read).
+ * C = 192 and W2 = 160 only (MOBGT_EBADDIM otherwise): the fq model at hidden_dim 128. */
+int mobgt_token_fwd_chain(int n, const float* const* tables, const void* const* idx, const int* width, const int* coff,
+                          const int* accum, const int* slot, int idx_dtype, float* pt, float* x4, float* add, float* nf, int W2,
+                          const float* w2, const float* b2, float slope2, const float* w4, const float* b4, float slope4,
+                          const float* real, const float* token, const float* pe0, float* out, void* out_bf16,
+                          const void* wqkv_packed, const void* bqkv, void* qkv, int G, int N, int C, float p_pos, float p_in,
+                          uint64_t seed, const uint64_t* seed_dev, uint32_t salt_nf, uint32_t salt_tok, uint32_t salt_in,
+                          void* stream);
 int mobgt_assemble_tokens_bwd(const float* dout, const float* real, float* d_nf, float* d_add, float* d_token, int G, int N,
                               int C, float p_pos, float p_in, uint64_t seed, const uint64_t* seed_dev, uint32_t salt_nf,
                               uint32_t salt_tok, uint32_t salt_in, void* stream);

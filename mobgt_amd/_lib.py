@@ -73,6 +73,8 @@ SIGNATURES = {
     "mobgt_skinny_linear_dx": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
     "mobgt_skinny_linear_bwd_both": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "mobgt_assemble_tokens_fwd": (_i, [_vp] * 7 + [_i, _i, _i, _f, _f, _u64, _vp, _c.c_uint32, _c.c_uint32, _c.c_uint32, _vp]),
+    "mobgt_token_fwd_chain": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _f, _vp, _vp, _f,
+                                   _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _f, _u64, _vp, _u32, _u32, _u32, _vp]),
     "mobgt_assemble_tokens_qkv": (_i, [_vp] * 10 + [_i, _i, _i, _f, _f, _u64, _vp, _c.c_uint32, _c.c_uint32, _c.c_uint32, _vp]),
     "mobgt_assemble_tokens_bwd": (_i, [_vp] * 5 + [_i, _i, _i, _f, _f, _u64, _vp, _c.c_uint32, _c.c_uint32, _c.c_uint32, _vp]),
     "mobgt_bias_act_fwd": (_i, [_vp, _vp, _vp, _i64, _i, _f, _f, _u64, _vp, _c.c_uint32, _vp]),

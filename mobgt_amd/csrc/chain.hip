@@ -961,6 +961,246 @@ __global__ __launch_bounds__(NT) void assemble_qkv_kernel(const AsmQkvParams p) 
     store_rows<BM, 3 * C, LDQ>(qb, p.qkv, r0, (int)rows);
 }
 
+// ---- Round 4: everything between the GCN tables and the first layer's attention in ONE launch ---------------------------------
+// model_fqandtoyo.py:1259-1298 (row gathers), :444-456 / :1268-1269 (FuseEmbeddings-2 and -4: Linear + LeakyReLU), :1287-1298,
+// :348-358, :1338-1347 (token assembly, positional and input dropout) and the first encoder layer's QKV projection.  After round 3
+// that was four launches (mobgt_embed_gather_multi -> two small f32 GEMMs -> mobgt_assemble_tokens_qkv, 24-27 us for 608 rows).
+// Here a workgroup owns 16 encoder-input rows (g, t): it gathers its positions' table rows into LDS (the jobs are
+// mobgt_embed_gather_multi's, results also written out: the backward pass and the weight gradients read pt / x4 / nf),
+// runs pt -> f2 = leaky(pt W2^T + b2) -> x4 = [f2 | cat] -> nf = leaky(x4 W4^T + b4) on v_mfma_f32_16x16x4_f32 (FULL f32
+// products, as the small-GEMM launches did: one 16-column block per wave, its whole slice of the f32 weight requested before
+// the gather starts), then continues exactly as assemble_qkv_kernel.  Masks, salts and row numbering are unchanged.
+struct TokGather {                           // mobgt_embed_gather_multi's jobs of the fq model, sorted by destination
+    static constexpr int MAXFOLD = 3, NIDX = 7;
+    const float* s0_tab[2];                  // -> pt: at most two tables side by side ([poi | time]), plain copies
+    const void* s0_idx[2];
+    int s0_w[2], s0_coff[2], n0;
+    const float* fold[MAXFOLD];              // partial tables added to s0_tab[0]'s row (same width, same index)
+    int n_fold;
+    const float* s1_tab;                     // -> the trailing columns of x4 (the category row)
+    const void* s1_idx;
+    int s1_w, s1_coff;
+    const float* s2_tab[4];                  // -> add: the SUM of up to four C-wide rows
+    const void* s2_idx[4];
+    int n2, idx64;
+};
+
+struct TokFwdParams {
+    AsmQkvParams a;                          // a.nf / a.add: the buffers nf and add are WRITTEN to (this launch produces them)
+    TokGather g;
+    float *pt, *x4;                          // [G*N, W2], [G*N, C]
+    const float *w2, *b2, *w4, *b4;          // F.linear layout [out, in], f32
+    float slope2, slope4;
+};
+
+template <int C, int W2>
+__global__ __launch_bounds__(NT) void token_fwd_chain_kernel(const TokFwdParams p) {
+    constexpr int BM = 16, LDA = C + 8, LDQ = 3 * C + 8, LDP = W2 + 4, LDX = C + 4;
+    static_assert(W2 % 16 == 0 && C % 16 == 0 && W2 / 16 <= NW && C / 16 <= NW && W2 < C, "one column block per wave");
+    __shared__ __attribute__((aligned(16))) uint16_t ab[BM * LDA];
+    __shared__ __attribute__((aligned(16))) uint16_t qb[BM * LDQ];
+    __shared__ __attribute__((aligned(16))) float pts[BM * LDP];
+    __shared__ __attribute__((aligned(16))) float x4s[BM * LDX];
+    __shared__ __attribute__((aligned(16))) float adds[BM * LDX];
+    __shared__ __attribute__((aligned(16))) float nfs[BM * LDX];
+    __shared__ int pos_s[BM];
+    __shared__ int idx_s[TokGather::NIDX * BM];
+    const AsmQkvParams& a = p.a;
+    const int T = a.N + 1;
+    const int64_t rows = (int64_t)a.G * T;
+    const int r0 = blockIdx.x * BM;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = lane & 15, kq = lane >> 4;
+    const uint64_t seed = a.seed + (a.seed_dev ? *a.seed_dev : 0ull);
+    // ---- the gathers.  First EVERY index of the tile (16 rows x 7 index lists) in one round trip, into LDS ...
+    if (threadIdx.x < BM * TokGather::NIDX) {
+        const int r = threadIdx.x % BM, which = threadIdx.x / BM;
+        const int64_t row = r0 + r;
+        const bool on = row < rows;
+        const int g = on ? (int)(row / T) : 0, t = on ? (int)(row - (int64_t)g * T) : 0;
+        const bool live = on && t > 0;
+        const int64_t pos = (int64_t)g * a.N + (t - 1);
+        // (selected, not indexed: the argument struct stays in scalar registers)
+        const void* ip = which == 0 ? p.g.s0_idx[0] : which == 1 ? p.g.s0_idx[1] : which == 2 ? p.g.s1_idx
+                       : which == 3 ? p.g.s2_idx[0] : which == 4 ? p.g.s2_idx[1] : which == 5 ? p.g.s2_idx[2] : p.g.s2_idx[3];
+        const bool have = which < 2 ? which < p.g.n0 : (which == 2 ? true : which - 3 < p.g.n2);
+        int v = -1;
+        if (live && have) v = p.g.idx64 ? (int)reinterpret_cast<const int64_t*>(ip)[pos] : reinterpret_cast<const int32_t*>(ip)[pos];
+        idx_s[which * BM + r] = v;
+        if (which == 0) pos_s[r] = live ? (int)pos : -1;
+    }
+    // what the token assembly reads from global memory, requested now: graph token + pe[0] at this lane's columns, `real` of the rows
+    float tokpe[C / 64];
+#pragma unroll
+    for (int u = 0; u < C / 64; ++u) tokpe[u] = a.token[lane + 64 * u] + a.pe0[lane + 64 * u];
+    float rl_pre[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int64_t row = r0 + wave + NW * u;
+        const bool on = row < rows && wave + NW * u < BM;
+        const int g = on ? (int)(row / T) : 0, t = on ? (int)(row - (int64_t)g * T) : 0;
+        rl_pre[u] = (on && t > 0) ? a.real[(int64_t)g * a.N + (t - 1)] : 1.f;
+    }
+    __syncthreads();
+    // ... then ALL table reads of the tile in flight at once: waves 0-7 take [poi (+ partial tables) | time] and the category row
+    // of two rows each, waves 8-11 the four additive rows of four rows each
+    {
+        const int c = lane * 4;
+        const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (wave < 8) {
+            float4 v0[2], v1[2], vc[2], fo[2][TokGather::MAXFOLD];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int r = 2 * wave + u;
+                const int t0 = idx_s[0 * BM + r], t1 = idx_s[1 * BM + r], tc = idx_s[2 * BM + r];
+                v0[u] = (t0 >= 0 && c < p.g.s0_w[0]) ? *reinterpret_cast<const float4*>(p.g.s0_tab[0] + (int64_t)t0 * p.g.s0_w[0] + c) : z4;
+#pragma unroll
+                for (int f = 0; f < TokGather::MAXFOLD; ++f)
+                    fo[u][f] = (f < p.g.n_fold && t0 >= 0 && c < p.g.s0_w[0]) ? *reinterpret_cast<const float4*>(p.g.fold[f] + (int64_t)t0 * p.g.s0_w[0] + c) : z4;
+                v1[u] = (p.g.n0 > 1 && t1 >= 0 && c < p.g.s0_w[1]) ? *reinterpret_cast<const float4*>(p.g.s0_tab[1] + (int64_t)t1 * p.g.s0_w[1] + c) : z4;
+                vc[u] = (tc >= 0 && c < p.g.s1_w) ? *reinterpret_cast<const float4*>(p.g.s1_tab + (int64_t)tc * p.g.s1_w + c) : z4;
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int r = 2 * wave + u, pos = pos_s[r];
+                if (c < W2) *reinterpret_cast<float4*>(pts + r * LDP + c) = z4;      // (columns no table covers)
+                if (c >= W2 && c < C) *reinterpret_cast<float4*>(x4s + r * LDX + c) = z4;
+                float4 val = v0[u];
+#pragma unroll
+                for (int f = 0; f < TokGather::MAXFOLD; ++f) { val.x += fo[u][f].x; val.y += fo[u][f].y; val.z += fo[u][f].z; val.w += fo[u][f].w; }
+                if (c < p.g.s0_w[0]) *reinterpret_cast<float4*>(pts + r * LDP + p.g.s0_coff[0] + c) = val;
+                if (p.g.n0 > 1 && c < p.g.s0_w[1]) *reinterpret_cast<float4*>(pts + r * LDP + p.g.s0_coff[1] + c) = v1[u];
+                if (c < p.g.s1_w) *reinterpret_cast<float4*>(x4s + r * LDX + p.g.s1_coff + c) = vc[u];
+                if (pos >= 0) {                     // what the backward pass reads: pt and the gathered (trailing) columns of x4
+                    if (c < W2) *reinterpret_cast<float4*>(p.pt + (int64_t)pos * W2 + c) = *reinterpret_cast<const float4*>(pts + r * LDP + c);
+                    if (c >= W2 && c < C) *reinterpret_cast<float4*>(p.x4 + (int64_t)pos * C + c) = *reinterpret_cast<const float4*>(x4s + r * LDX + c);
+                }
+            }
+        } else {
+            float4 va[4][4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int r = 4 * (wave - 8) + u;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int tq = idx_s[(3 + q) * BM + r];
+                    va[u][q] = (q < p.g.n2 && tq >= 0 && c < C) ? *reinterpret_cast<const float4*>(p.g.s2_tab[q] + (int64_t)tq * C + c) : z4;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int r = 4 * (wave - 8) + u, pos = pos_s[r];
+                float4 val = va[u][0];
+#pragma unroll
+                for (int q = 1; q < 4; ++q) { val.x += va[u][q].x; val.y += va[u][q].y; val.z += va[u][q].z; val.w += va[u][q].w; }
+                if (c < C) {
+                    *reinterpret_cast<float4*>(adds + r * LDX + c) = val;
+                    if (pos >= 0) *reinterpret_cast<float4*>(const_cast<float*>(a.add) + (int64_t)pos * C + c) = val;
+                }
+            }
+        }
+    }
+    // this wave's 16 output columns of W2 (F.linear: row = output column) and of W4 -- requested only now: issued in front of
+    // the gathers their 88 registers pushed the table reads' destinations into scratch
+    float4 wb2[W2 / 16];
+    if (wave < W2 / 16) {
+#pragma unroll
+        for (int s = 0; s < W2 / 16; ++s) wb2[s] = *reinterpret_cast<const float4*>(p.w2 + (int64_t)(16 * wave + i) * W2 + 16 * s + 4 * kq);
+    }
+    float4 wb4[C / 16];
+    if (wave < C / 16) {
+#pragma unroll
+        for (int s = 0; s < C / 16; ++s) wb4[s] = *reinterpret_cast<const float4*>(p.w4 + (int64_t)(16 * wave + i) * C + 16 * s + 4 * kq);
+    }
+    __syncthreads();
+    // ---- f2 = leaky(pt W2^T + b2) -> the leading W2 columns of x4
+    if (wave < W2 / 16) {
+        f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < W2 / 16; ++s) {
+            const float4 av = *reinterpret_cast<const float4*>(pts + i * LDP + 16 * s + 4 * kq);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, wb2[s].x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, wb2[s].y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, wb2[s].z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, wb2[s].w, acc, 0, 0, 0);
+        }
+        const int col = 16 * wave + i;
+        const float bv = p.b2[col];
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {                       // register v of lane (i, kq): row 4 kq + v, column i of the block
+            const int r = 4 * kq + v;
+            float o = acc[v] + bv;
+            o = o > 0.f ? o : p.slope2 * o;
+            x4s[r * LDX + col] = o;
+            const int pos = pos_s[r];
+            if (pos >= 0) p.x4[(int64_t)pos * C + col] = o;
+        }
+    }
+    WPre<3 * C, C> pre;
+    pre.issue(a.wq);                                        // the QKV weight's first chunks: in flight during the second product
+    __syncthreads();
+    // ---- nf = leaky(x4 W4^T + b4)
+    if (wave < C / 16) {
+        f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < C / 16; ++s) {
+            const float4 av = *reinterpret_cast<const float4*>(x4s + i * LDX + 16 * s + 4 * kq);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, wb4[s].x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, wb4[s].y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, wb4[s].z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, wb4[s].w, acc, 0, 0, 0);
+        }
+        const int col = 16 * wave + i;
+        const float bv = p.b4[col];
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const int r = 4 * kq + v;
+            float o = acc[v] + bv;
+            o = o > 0.f ? o : p.slope4 * o;
+            nfs[r * LDX + col] = o;
+            const int pos = pos_s[r];
+            if (pos >= 0) const_cast<float*>(a.nf)[(int64_t)pos * C + col] = o;
+        }
+    }
+    __syncthreads();
+    // ---- token assembly + dropouts (assemble_qkv_kernel's, with nf / add taken from LDS)
+    for (int r = wave; r < BM; r += NW) {
+        const int64_t row = r0 + r;
+        const bool on = row < rows;
+        const int g = on ? (int)(row / T) : 0, t = on ? (int)(row - (int64_t)g * T) : 0;
+        const bool tok = t == 0;
+        const uint32_t r1 = tok ? (uint32_t)g : (uint32_t)(g * a.N + (t - 1));
+        const uint32_t h1 = a.thr_pos ? dropout_row_hash(seed, r1 ^ (tok ? a.salt_tok : a.salt_nf)) : 0u;
+        const uint32_t h2 = a.thr_in ? dropout_row_hash(seed, (uint32_t)row ^ a.salt_in) : 0u;
+        const float rl = r < NW ? rl_pre[0] : rl_pre[1];
+#pragma unroll
+        for (int u = 0; u < C / 64; ++u) {
+            const int c = lane + 64 * u;
+            float o = 0.f;
+            if (on) {
+                float scale = 1.f;
+                if (a.thr_pos) scale = dropout_bits16(seed, h1, (uint32_t)c) >= a.thr_pos ? a.keep_pos : 0.f;
+                if (a.thr_in) scale *= dropout_bits16(seed, h2, (uint32_t)c) >= a.thr_in ? a.keep_in : 0.f;
+                const float v = tok ? tokpe[u] : nfs[r * LDX + c] * rl + adds[r * LDX + c];
+                o = v * scale;
+                a.out[row * C + c] = o;
+                a.out16[row * C + c] = bf16_bits(o);
+            }
+            ab[r * LDA + c] = bf16_bits(o);
+        }
+    }
+    __syncthreads();
+    const int j = lane & 15, q = lane >> 4;
+    wg_gemm<BM, 3 * C, C, LDA>(ab, a.wq, [&](int gq, const f32x4 (&acc)[1]) {
+        const int col = 16 * gq + j;
+        const float bias = bf16_val(a.bq[col]);
+#pragma unroll
+        for (int v = 0; v < 4; ++v) qb[(4 * q + v) * LDQ + col] = bf16_bits(acc[0][v] + bias);
+    }, pre);
+    __syncthreads();
+    store_rows<BM, 3 * C, LDQ>(qb, a.qkv, r0, (int)rows);
+}
+
 // ---- the same chain backwards: from d(out) down to the gradient of the attention output ------------------------------
 //     dx2 = ffn_norm2'(dout);  df = dropout'(dx2)                      [dnxw, dnxb, db2]
 //     du  = (df W2) * gelu'(u)
@@ -1663,5 +1903,62 @@ extern "C" int mobgt_assemble_tokens_qkv(const float* nf, const float* real, con
     if (C == 192) hipLaunchKernelGGL(assemble_qkv_kernel<192>, grid, block, 0, st, p);
     else if (C == 256) hipLaunchKernelGGL(assemble_qkv_kernel<256>, grid, block, 0, st, p);
     else return MOBGT_EBADDIM;
+    return (int)hipGetLastError();
+}
+
+/* Round 4: mobgt_embed_gather_multi (forward) + FuseEmbeddings-2 + FuseEmbeddings-4 + mobgt_assemble_tokens_qkv as one launch
+ * (see token_fwd_chain_kernel).  C = 192, W2 = 160 (the fq model at hidden_dim 128). */
+extern "C" int mobgt_token_fwd_chain(int n, const float* const* tables, const void* const* idx, const int* width, const int* coff,
+                                     const int* accum, const int* slot, int idx_dtype, float* pt, float* x4, float* add, float* nf,
+                                     int W2, const float* w2, const float* b2, float slope2, const float* w4, const float* b4,
+                                     float slope4, const float* real, const float* token, const float* pe0, float* out,
+                                     void* out_bf16, const void* wqkv_packed, const void* bqkv, void* qkv, int G, int N, int C,
+                                     float p_pos, float p_in, uint64_t seed, const uint64_t* seed_dev, uint32_t salt_nf,
+                                     uint32_t salt_tok, uint32_t salt_in, void* stream) {
+    if (G <= 0 || N < 0 || !out_bf16 || !wqkv_packed || !bqkv || !qkv || !pt || !x4 || !add || !nf || !w2 || !b2 || !w4 || !b4) return MOBGT_EBADDIM;
+    if (C != 192 || W2 != 160 || n < 3 || n > 7 + TokGather::MAXFOLD) return MOBGT_EBADDIM;
+    if (idx_dtype != MOBGT_I64 && idx_dtype != MOBGT_I32) return MOBGT_EDTYPE;
+    if (((uintptr_t)wqkv_packed | (uintptr_t)qkv | (uintptr_t)pt | (uintptr_t)x4 | (uintptr_t)add | (uintptr_t)nf | (uintptr_t)w2 | (uintptr_t)w4) & 15)
+        return MOBGT_EALIGN;
+    TokFwdParams p = {};
+    // the job list, sorted by destination (what the kernel's gather stage is laid out for; anything else: MOBGT_EBADDIM)
+    int last0 = -1;
+    for (int t = 0; t < n; ++t) {
+        if (!tables[t] || ((uintptr_t)tables[t] & 15)) return MOBGT_EALIGN;
+        if (width[t] <= 0 || width[t] > 256 || (width[t] & 3) || (coff[t] & 3)) return MOBGT_EBADDIM;
+        if (accum[t] == 2) {                          // folded into the FIRST pt table
+            if (last0 != 0 || p.g.n0 != 1 || p.g.n_fold >= TokGather::MAXFOLD || width[t] != p.g.s0_w[0]) return MOBGT_EBADDIM;
+            p.g.fold[p.g.n_fold++] = tables[t];
+            continue;
+        }
+        if (slot[t] == 0) {
+            if (p.g.n0 >= 2 || accum[t] || coff[t] + width[t] > W2) return MOBGT_EBADDIM;
+            p.g.s0_tab[p.g.n0] = tables[t]; p.g.s0_idx[p.g.n0] = idx[t]; p.g.s0_w[p.g.n0] = width[t]; p.g.s0_coff[p.g.n0] = coff[t];
+            last0 = p.g.n0++;
+        } else if (slot[t] == 1) {
+            if (p.g.s1_tab || accum[t] || coff[t] < W2 || coff[t] + width[t] > C) return MOBGT_EBADDIM;
+            p.g.s1_tab = tables[t]; p.g.s1_idx = idx[t]; p.g.s1_w = width[t]; p.g.s1_coff = coff[t];
+            last0 = -1;
+        } else if (slot[t] == 2) {
+            if (p.g.n2 >= 4 || width[t] != C || coff[t] != 0 || (accum[t] != 0) != (p.g.n2 > 0)) return MOBGT_EBADDIM;
+            p.g.s2_tab[p.g.n2] = tables[t]; p.g.s2_idx[p.g.n2] = idx[t]; ++p.g.n2;
+            last0 = -1;
+        } else return MOBGT_EBADDIM;
+    }
+    if (p.g.n0 < 1 || !p.g.s1_tab || p.g.n2 < 1) return MOBGT_EBADDIM;
+    for (int q = p.g.n0; q < 2; ++q) { p.g.s0_tab[q] = p.g.s0_tab[0]; p.g.s0_idx[q] = p.g.s0_idx[0]; p.g.s0_w[q] = 4; p.g.s0_coff[q] = 0; }
+    for (int q = p.g.n2; q < 4; ++q) { p.g.s2_tab[q] = p.g.s2_tab[0]; p.g.s2_idx[q] = p.g.s2_idx[0]; }
+    p.g.idx64 = idx_dtype == MOBGT_I64;
+    p.pt = pt; p.x4 = x4; p.w2 = w2; p.b2 = b2; p.w4 = w4; p.b4 = b4; p.slope2 = slope2; p.slope4 = slope4;
+    AsmQkvParams& a = p.a;
+    a.nf = nf; a.real = real; a.add = add; a.token = token; a.pe0 = pe0; a.out = out; a.out16 = (uint16_t*)out_bf16;
+    a.wq = (const uint16_t*)wqkv_packed; a.bq = (const uint16_t*)bqkv; a.qkv = (uint16_t*)qkv; a.G = G; a.N = N;
+    a.thr_pos = p_pos > 0.f ? dropout_threshold(p_pos) : 0u;
+    a.thr_in = p_in > 0.f ? dropout_threshold(p_in) : 0u;
+    a.keep_pos = a.thr_pos ? 1.f / (1.f - (float)a.thr_pos / 65536.f) : 1.f;
+    a.keep_in = a.thr_in ? 1.f / (1.f - (float)a.thr_in / 65536.f) : 1.f;
+    a.seed = seed; a.seed_dev = seed_dev; a.salt_nf = salt_nf; a.salt_tok = salt_tok; a.salt_in = salt_in;
+    const int64_t rows = (int64_t)G * (N + 1);
+    hipLaunchKernelGGL((token_fwd_chain_kernel<192, 160>), dim3((unsigned)((rows + 15) / 16)), dim3(NT), 0, (hipStream_t)stream, p);
     return (int)hipGetLastError();
 }

@@ -363,6 +363,24 @@ class Graphormer(nn.Module):
         Wp, Wt, Wc, C = poidist.shape[1], self.time_embed_model_48.weight.shape[1], catemb.shape[1], self.pos_embed.pe.shape[1]
         f4 = self.embed_fuse_model4
         one_launch = G * N <= 4096
+        # the first encoder layer's QKV projection rides in the token-assembly launch when its packed weights are current (chain
+        # kernels) -- and then (round 4) so do the gathers and the two FuseEmbeddings layers below: they only record their
+        # launches (ops.token_fwd_deferral), ops.assemble_tokens issues mobgt_token_fwd_chain for all of them
+        l0 = self.layers[0]
+        first_qkv = None
+        if (getattr(l0, "fused", False) and getattr(l0, "_packed_fresh", False) and getattr(l0, "act_dtype", None) == torch.bfloat16
+                and not torch.is_autocast_enabled("cuda")):
+            first_qkv = (l0._packed[0], l0._shadows[1])
+        ops.token_fwd_deferral(one_launch and first_qkv is not None and self.act_dtype == torch.bfloat16 and C == 192 and Wp + Wt == 160)
+        try:
+            return self._node_features_tail(batched_data, G, N, poidist, catemb, real, one_launch, first_qkv, Wp, Wt, Wc, C,
+                                            poi_idx, time_idx, cat_idx, pos_idx, zero_idx, in_deg, out_deg)
+        finally:
+            ops.token_fwd_deferral(False)
+
+    def _node_features_tail(self, batched_data, G, N, poidist, catemb, real, one_launch, first_qkv, Wp, Wt, Wc, C,
+                            poi_idx, time_idx, cat_idx, pos_idx, zero_idx, in_deg, out_deg):
+        f4 = self.embed_fuse_model4
         if one_launch:
             # every gathered row of :1259-1298 in ONE launch: [poi ; time] -> pt, the category row -> the trailing columns of
             # fuse4's input, fre_embed(0) + degree rows + positional rows pe[1..n] (:1287-1298, :348-351) summed -> add
@@ -405,12 +423,6 @@ class Graphormer(nn.Module):
         # (pads stay 0: the multiplication by `real` happens inside assemble_tokens)
         # nf * real + add -> pos_embed dropout (:358); graph token + pe[0] -> the same dropout (:1338-1342); cat;
         # input_dropout (:1347): one launch
-        # the first encoder layer's QKV projection rides in the same launch when its packed weights are current (chain kernels)
-        l0 = self.layers[0]
-        first_qkv = None
-        if (getattr(l0, "fused", False) and getattr(l0, "_packed_fresh", False) and getattr(l0, "act_dtype", None) == torch.bfloat16
-                and not torch.is_autocast_enabled("cuda")):
-            first_qkv = (l0._packed[0], l0._shadows[1])
         return ops.assemble_tokens(nf.view(G, N, -1), real, add.view(G, N, -1), self.graph_token.weight, self.pos_embed.pe, self.pos_embed.dropout.p,
                                    self.input_dropout.p, self.training,
                                    bf16_copy=self.act_dtype == torch.bfloat16 and getattr(self.layers[0], "fused", False),

@@ -884,6 +884,30 @@ _ROW0_PENDING = {}      # table data_ptr -> [W] f32 gradient of its row 0 produc
 
 
 # ------------------------------------------------------------------ several gathers of one position list, one launch
+# ---- the encoder input's FORWARD as one launch (round 4; csrc/chain.hip token_fwd_chain_kernel) ---------------------------------------
+# gather -> FuseEmbeddings-2 -> FuseEmbeddings-4 -> token assembly + first QKV are four autograd nodes in a row whose intermediate
+# results nobody reads before the last one has run.  While `token_fwd_deferral(True)` is in force (model_fqandtoyo.node_features
+# switches it on when the last node can take the fused launch), the first three only ALLOCATE their outputs and record their
+# launch; _AssembleTokensFn then issues mobgt_token_fwd_chain, which fills every one of those buffers -- or, if what was
+# recorded is not the chain it knows, `flush_token_fwd()` issues the recorded launches one by one.  The autograd graph, the saved
+# tensors and therefore the whole backward pass are those of the separate launches.
+_TOKEN_FWD = {"on": False, "gather": None, "f2": None, "f4": None, "fused_calls": 0}
+
+
+def token_fwd_deferral(on):
+    """Switch the recording on / off.  Switching it (either way) first launches whatever is still recorded."""
+    flush_token_fwd()
+    _TOKEN_FWD["on"] = bool(on) and os.environ.get("MOBGT_NO_TOKEN_FWD_CHAIN") != "1" and not _NAN_TRACE["on"]
+
+
+def flush_token_fwd():
+    """Issue the recorded launches separately, in order (the fallback of the fused launch)."""
+    for k in ("gather", "f2", "f4"):
+        rec, _TOKEN_FWD[k] = _TOKEN_FWD[k], None
+        if rec is not None:
+            rec["launch"]()
+
+
 class _GatherMultiFn(torch.autograd.Function):
     """outs[o][r, coff : coff + W] (=, or += when accum) tables[t][idx[t][r], :] for the jobs `spec` = [(o, coff, accum,
     skip)], one per table; `outs_shape` = [(width_o)].  Columns of an output that no job writes are left unwritten (the
@@ -896,11 +920,17 @@ class _GatherMultiFn(torch.autograd.Function):
         dev = tables[0].device
         outs = [torch.empty(R, w, dtype=torch.float32, device=dev) for w in out_widths]
         ci, i64, vp = ctypes.c_int, ctypes.c_int64, ctypes.c_void_p
-        check(_lib.lib().mobgt_embed_gather_multi(
-            n, _ptr_array(tables), None, _ptr_array(idx), (i64 * n)(*[sp[3] for sp in spec]),
-            (ci * n)(*[t.shape[1] for t in tables]), (ci * n)(*[sp[1] for sp in spec]), (ci * n)(*[int(sp[2]) for sp in spec]),
-            (vp * n)(*[outs[sp[0]].data_ptr() for sp in spec]), (i64 * n)(*[outs[sp[0]].stride(0) for sp in spec]), R,
-            _IT[idx[0].dtype], 0, None, 0, _stream()), "mobgt_embed_gather_multi")
+
+        def launch():
+            check(_lib.lib().mobgt_embed_gather_multi(
+                n, _ptr_array(tables), None, _ptr_array(idx), (i64 * n)(*[sp[3] for sp in spec]),
+                (ci * n)(*[t.shape[1] for t in tables]), (ci * n)(*[sp[1] for sp in spec]), (ci * n)(*[int(sp[2]) for sp in spec]),
+                (vp * n)(*[outs[sp[0]].data_ptr() for sp in spec]), (i64 * n)(*[outs[sp[0]].stride(0) for sp in spec]), R,
+                _IT[idx[0].dtype], 0, None, 0, _stream()), "mobgt_embed_gather_multi")
+        if _TOKEN_FWD["on"] and _TOKEN_FWD["gather"] is None and len(outs) == 3 and all(i_.dtype == idx[0].dtype for i_ in idx):
+            _TOKEN_FWD["gather"] = dict(launch=launch, tables=tables, idx=idx, spec=spec, outs=outs, R=R)     # (see token_fwd_deferral)
+        else:
+            launch()
         ctx.idx, ctx.spec, ctx.n = idx, spec, n
         ctx.ptrs = [t.data_ptr() for t in tables]
         ctx.shapes = [t.shape for t in tables]
@@ -1210,7 +1240,20 @@ class _LinearSplitKFn(torch.autograd.Function):
         ctx.slope = slope
         if _small_linear(x, w) & 1:
             # (`out`: an _OutRef to a column slice of a wider buffer; the result is a fresh view of it, not an input)
-            y = small_gemm(x, w, b, True, leaky=slope, out=out.t if out is not None else None)
+            gat = _TOKEN_FWD["gather"] if _TOKEN_FWD["on"] else None
+            stage = None
+            if gat is not None and slope is not None and b is not None and x.dtype == torch.float32 and w.dtype == torch.float32:
+                if (_TOKEN_FWD["f2"] is None and out is not None and x.data_ptr() == gat["outs"][0].data_ptr()
+                        and out.t.data_ptr() == gat["outs"][1].data_ptr()):
+                    stage = "f2"
+                elif (_TOKEN_FWD["f2"] is not None and _TOKEN_FWD["f4"] is None and out is None
+                        and x.data_ptr() == gat["outs"][1].data_ptr() and x.is_contiguous()):
+                    stage = "f4"
+            if stage is not None:            # recorded, not launched (token_fwd_deferral): the output buffer exists, its values come later
+                y = out.t if out is not None else torch.empty(x.shape[0], w.shape[0], dtype=torch.float32, device=x.device)
+                _TOKEN_FWD[stage] = dict(launch=lambda: small_gemm(x, w, b, True, leaky=slope, out=y), x=x, w=w, b=b, slope=slope, y=y)
+            else:
+                y = small_gemm(x, w, b, True, leaky=slope, out=out.t if out is not None else None)
             if out is not None:
                 y = y.view_as(y)
         else:
@@ -1544,6 +1587,39 @@ def head_input(enc, user_table, user, user_offset=0):
     return _HeadInputFn.apply(enc.contiguous(), user_table, user.reshape(-1).contiguous(), int(user_offset))
 
 
+def _token_fwd_fused(nf, real, add, token, pe0, out, out16, qkv_w, qkv, G, N, C, p_pos, p_in, seed, seed_dev, salts):
+    """The recorded gather + FuseEmbeddings-2 / -4 (token_fwd_deferral) together with this token assembly + QKV projection as
+    ONE launch -> True; anything else: the recorded launches are issued separately -> False (the caller launches its own)."""
+    gat, f2, f4 = _TOKEN_FWD["gather"], _TOKEN_FWD["f2"], _TOKEN_FWD["f4"]
+    ok = (gat is not None and f2 is not None and f4 is not None and C == 192 and gat["R"] == G * N and len(gat["outs"]) == 3
+          and nf.data_ptr() == f4["y"].data_ptr() and add.data_ptr() == gat["outs"][2].data_ptr()
+          and tuple(f2["w"].shape) == (160, 160) and tuple(f4["w"].shape) == (192, 192)
+          and gat["outs"][0].shape[1] == 160 and gat["outs"][1].shape[1] == 192 and gat["outs"][2].shape[1] == 192
+          and all(t.is_contiguous() for t in (f2["w"], f2["b"], f4["w"], f4["b"], *gat["outs"]))
+          and (pe0.dim() == 1 or pe0.shape[0] >= 1))
+    if not ok:
+        flush_token_fwd()
+        return False
+    tables, idx, spec = gat["tables"], gat["idx"], gat["spec"]
+    n = len(tables)
+    ci = ctypes.c_int
+    rc = (_lib.lib().mobgt_token_fwd_chain(
+        n, _ptr_array(tables), _ptr_array(idx), (ci * n)(*[t.shape[1] for t in tables]), (ci * n)(*[sp[1] for sp in spec]),
+        (ci * n)(*[int(sp[2]) for sp in spec]), (ci * n)(*[sp[0] for sp in spec]), _IT[idx[0].dtype],
+        _p(gat["outs"][0]), _p(gat["outs"][1]), _p(gat["outs"][2]), _p(f4["y"]), 160,
+        _p(f2["w"]), _p(f2["b"]), float(f2["slope"]), _p(f4["w"]), _p(f4["b"]), float(f4["slope"]),
+        _p(real), _p(token), _p(pe0), _p(out), _p(out16), _p(qkv_w[0].t), _p(qkv_w[1].t), _p(qkv), G, N, C, p_pos, p_in, seed,
+        _p(seed_dev), salts[0], salts[1], salts[2], _stream()))
+    if rc == -1:                          # MOBGT_EBADDIM: a job list the kernel's gather stage is not laid out for (nothing was launched)
+        flush_token_fwd()
+        return False
+    check(rc, "mobgt_token_fwd_chain")
+    for k in ("gather", "f2", "f4"):
+        _TOKEN_FWD[k] = None
+    _TOKEN_FWD["fused_calls"] += 1
+    return True
+
+
 class _AssembleTokensFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, nf, real, add, token, pe0, p_pos, p_in, seed, seed_dev, salts, side, row0_via_gather=False, qkv_w=None, tok_sink=None):
@@ -1563,13 +1639,15 @@ class _AssembleTokensFn(torch.autograd.Function):
             # ... and the first encoder layer's QKV projection from the same launch (csrc/chain.hip): qkv_w = _OutRefs of the
             # packed [3C, C] weight and the bf16 bias
             qkv = torch.empty(G * (N + 1), 3 * C, dtype=torch.bfloat16, device=nf.device)
-            check(_lib.lib().mobgt_assemble_tokens_qkv(_p(nf), _p(real), _p(add), _p(token), _p(pe0), _p(out), _p(out16),
-                                                       _p(qkv_w[0].t), _p(qkv_w[1].t), _p(qkv), G, N, C, p_pos, p_in, seed,
-                                                       _p(seed_dev), salts[0], salts[1], salts[2], _stream()),
-                  "mobgt_assemble_tokens_qkv")
+            if not _token_fwd_fused(nf, real, add, token, pe0, out, out16, qkv_w, qkv, G, N, C, p_pos, p_in, seed, seed_dev, salts):
+                check(_lib.lib().mobgt_assemble_tokens_qkv(_p(nf), _p(real), _p(add), _p(token), _p(pe0), _p(out), _p(out16),
+                                                           _p(qkv_w[0].t), _p(qkv_w[1].t), _p(qkv), G, N, C, p_pos, p_in, seed,
+                                                           _p(seed_dev), salts[0], salts[1], salts[2], _stream()),
+                      "mobgt_assemble_tokens_qkv")
             side.append(out16)
             side.append(qkv)
         else:
+            flush_token_fwd()
             check(_lib.lib().mobgt_assemble_tokens_fwd(_p(nf), _p(real), _p(add), _p(token), _p(pe0), _p(out), _p(out16), G, N, C,
                                                        p_pos, p_in, seed, _p(seed_dev), salts[0], salts[1], salts[2], _stream()),
                   "mobgt_assemble_tokens_fwd")

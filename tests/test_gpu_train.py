@@ -309,6 +309,58 @@ def test_bias_tables_backward_as_passenger_of_the_category_gcn_launch(monkeypatc
         assert sc > 0 and err <= 2e-3 * sc, (n, err, sc)
 
 
+def test_encoder_input_forward_in_one_launch_is_bit_identical_to_the_four_launches(monkeypatch):
+    """Round 4: gather + FuseEmbeddings-2 / -4 + token assembly + first QKV as ONE launch (mobgt_token_fwd_chain; the first three
+    autograd nodes only record their launches, ops.token_fwd_deferral) against the four launches (MOBGT_NO_TOKEN_FWD_CHAIN=1):
+    the same f32 MFMA order, the same masks -> the encoder input, its bf16 copy, the first layer's QKV and every buffer the
+    backward pass reads (pt, x4, nf, add: seen through the gradients) are bit-identical, in eval mode and with the dropouts on;
+    eval logits bit-identical; gradients to the run-to-run noise of the atomics in the backward pass.  (Train-mode LOGITS are
+    not compared: the encoder layers draw fresh host seeds per forward pass.)"""
+    from mobgt_amd import ops, workloads
+    uni, model, coll = workloads.build("fsq", "cuda", seed=1, model_overrides=dict(n_layers=2))
+    batch = coll(workloads.make_pool("fsq", 1, 16, uni)[0])
+    seen = []
+    real_nf = model.node_features
+
+    def spy(*a, **k):
+        out = real_nf(*a, **k)
+        seen.append((out.detach().float().clone(), out._mobgt_act.float().clone(), out._mobgt_qkv.float().clone()))
+        return out
+    monkeypatch.setattr(model, "node_features", spy)
+    res = {}
+    for mode in ("eval", "train"):
+        model.train(mode == "train")
+        for off in ("0", "1"):
+            monkeypatch.setenv("MOBGT_NO_TOKEN_FWD_CHAIN", off)
+            ops.set_dropout_state(torch.tensor([3], dtype=torch.int64, device="cuda"), 11)
+            for p in model.parameters():
+                p.grad = None
+            before = ops._TOKEN_FWD["fused_calls"]
+            del seen[:]
+            try:
+                logits = model(batch)[0]
+                loss = model.training_step(batch, 0)
+                loss.backward()
+            finally:
+                ops.set_dropout_state(None, None)
+            torch.cuda.synchronize()
+            took = ops._TOKEN_FWD["fused_calls"] - before
+            assert took == (2 if off == "0" else 0), (mode, off, took)
+            res[(mode, off)] = (logits.detach().float().clone(), seen[0], {n: p.grad.detach().float().clone()
+                                                                          for n, p in model.named_parameters() if p.grad is not None})
+        (la, sa, ga), (lb, sb, gb) = res[(mode, "0")], res[(mode, "1")]
+        for x, y, what in zip(sa, sb, ("encoder input", "bf16 copy", "first qkv")):
+            assert torch.equal(x, y), (mode, what)
+        if mode == "eval":
+            assert torch.equal(la, lb)
+            assert ga.keys() == gb.keys()
+            for n in ga:
+                if n.endswith("linear_k.bias"):
+                    continue        # exactly 0 in exact arithmetic (softmax is shift-invariant over keys): round-off on both sides
+                d = float((ga[n] - gb[n]).norm() / (gb[n].norm() + 1e-30))
+                assert d < 5e-3, (mode, n, d)
+
+
 def test_forward_passengers_of_the_category_gcn_launch_change_nothing(monkeypatch):
     """The weight pack, the hop table's forward and the gather indices carried by the category GCN's forward launch
     (mobgt_small_gcn_fwd_pack; the model runs that launch first) against their own launches (MOBGT_NO_PACK_PASSENGER=1,
