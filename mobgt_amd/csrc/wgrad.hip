@@ -14,6 +14,7 @@
 // in 8 different rows.  No LDS transpose: lane (i, kq) of v_mfma_f32_16x16x32_bf16 reads one dword = columns
 // (2i, 2i+1) from each of its 8 rows, splits low / high halves into an "even-column" and an "odd-column"
 // operand, and the 2x2 MFMAs produce the 32x32 tile with rows 2i+a and columns 2j+b.
+#include <cstdlib>
 #include "common.h"
 #include "mobgt_hip.h"
 #include "gemm_body.h"
@@ -137,11 +138,14 @@ extern "C" int mobgt_linear_wgrad_multi_hop(int n, const void* const* g, const i
     for (int q = 0; q < n; ++q) {
         if (in_f32[q] != 0 && in_f32[q] != 1) return MOBGT_EDTYPE;
         if ((g_mask[q] || x_mask[q]) && !in_f32[q]) return MOBGT_EDTYPE;          // masks exist for f32 operands only
+        // Workgroups per problem: 1024 slots shared by the problems, at least 64 each -- fill_problem caps a problem at one
+        // workgroup per 16-wave slab of rows, i.e. a 7 856-row problem gets its 16 splits and every wave ONE 32-row step: the
+        // launch is load -> MFMA -> reduce -> atomics once, whatever the row count.  (Round 4, tools/dbg/wgrad_group_bench.py, the
+        // S-FSQ step's six problems together: 512 slots 24.4 us, 1024 slots 19.7, more: no change; FEWER workgroups -- one round
+        // of resident ones, 256 -- 30 us: the chain of 32-row steps per wave is what costs, not the second round.)
+        const int slots = 1024;
         const int rc = fill_problem(grp.p[q], g[q], ldg[q], x[q], ldx[q], dw[q], ldw[q], db[q], R[q], M[q], N[q],
-                                    // (all problems in ONE round of resident workgroups: 512 slots of 16 waves on 256 CUs; a
-                                    // long problem still gets >= 64 so that a wave walks only a few 32-row steps)
-                                    (nwave == 8 ? 1024 : 512) / n > 64 ? (nwave == 8 ? 1024 : 512) / n : 64, &grp.tiles[q],
-                                    &grp.splits[q], in_f32[q], nwave);
+                                    slots / n > 64 ? slots / n : 64, &grp.tiles[q], &grp.splits[q], in_f32[q], nwave);
         if (rc) return rc;
         if ((((uintptr_t)g_mask[q] | (uintptr_t)x_mask[q]) & 7)) return MOBGT_EALIGN;
         grp.p[q].gmask = g_mask[q]; grp.p[q].xmask = x_mask[q];

@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 import torch
 from mobgt_amd import _lib
 from mobgt_amd.ops import _stream
-probs = [(16, 320, 320, 0, 0, 1), (592, 192, 192, 1, 0, 1), (592, 160, 160, 1, 0, 1), (7856, 64, 128, 0, 0, 0), (7856, 16, 64, 0, 1, 1), (7856, 304, 16, 0, 1, 1)]
+probs = [(16, 320, 320, 0, 0, 1), (592, 192, 192, 1, 0, 1), (592, 160, 160, 1, 0, 1), (608, 64, 128, 0, 0, 0), (7856, 16, 64, 0, 1, 1), (7856, 304, 16, 0, 1, 1)]
 dev = "cuda"
 data = []
 for R, M, N, mg, mx, hasdb in probs:
@@ -54,3 +54,4 @@ for d in data:
     print("R %5d M %4d N %4d: %.1f us alone" % (d["R"], d["M"], d["N"], timeit(lambda: call([d]))))
 print("all six: %.1f us" % timeit(lambda: call(data)))
 print("the three short ones: %.1f us;  the three long ones: %.1f us" % (timeit(lambda: call(data[:3])), timeit(lambda: call(data[3:]))))
+print("the two 7856-row ones: %.1f us;  304 x 16 alone again: %.1f us" % (timeit(lambda: call(data[4:])), timeit(lambda: call(data[5:]))))
