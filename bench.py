@@ -415,12 +415,24 @@ def time_epoch_loop(model, coll, name, uni, args):
     torch.cuda.synchronize()
     graphs_before = len(loop.slots)
     steps, ep = 0, 2
+    # The host has ~300 us of slack per step here (tools/dbg/r4_loop_probe2.py), so a generation-2 pass of Python's collector
+    # over this process's heap (by now: the oracle's autograd graphs, the CPU baseline, ~10^6 objects -- tens of ms) shows up as
+    # +0.05-0.1 ms per step over a 0.2 s timed region.  What exists is moved out of the collector's sight, as a long-running
+    # trainer would do once after start-up; the loop's own garbage is still collected.
+    import gc
+    gc.collect()
+    gc.freeze()
+    per_epoch = []
     t0 = time.perf_counter()
     while steps < args.loop_steps:
-        steps += loop.run_epoch(ep)["steps"]
+        te = time.perf_counter()
+        n_ep = loop.run_epoch(ep)["steps"]
+        steps += n_ep
         ep += 1
+        per_epoch.append((time.perf_counter() - te) / max(n_ep, 1) * 1e3)          # (host-side: launches run ahead of the GPU)
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
+    gc.unfreeze()
     loss = float(loop.ts.loss_out.item())
     if loss != loss:
         raise RuntimeError("loop diverged")
@@ -439,7 +451,7 @@ def time_epoch_loop(model, coll, name, uni, args):
     torch.cuda.synchronize()
     el_replay = time.perf_counter() - t0
     return dict(value=args.batch_size * steps / el, unit="check-ins/s", ms_per_step=el / steps * 1e3, steps=steps,
-                ms_per_step_same_graphs_no_input=el_replay / len(seq) * 1e3,
+                ms_per_step_same_graphs_no_input=el_replay / len(seq) * 1e3, ms_per_step_by_epoch_host_side=[round(v, 4) for v in per_epoch],
                 dataset_trajectories=len(dataset), shape_buckets=sorted(k[1] for k in loop.slots),
                 graphs_captured_inside_timed_region=len(loop.slots) - graphs_before, final_loss=loss,
                 what="fresh batch every step: host pack of raw trajectories + H2D + device collate (SPD / edge paths / "
