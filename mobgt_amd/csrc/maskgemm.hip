@@ -160,6 +160,9 @@ __global__ __launch_bounds__(NWAVE * 64) void mask_gemm_kernel(const MaskGemmPar
 //                         layer's data gradient ((dy1 * m(y1)) W1^T * bscale)^T in bf16, the operand of A^T (.).
 constexpr int GH = 64;                  // width of the last hidden layer
 constexpr int GI = 16;                  // width of the first hidden layer
+#ifndef MASK_ROWS_ALL_IN_FLIGHT
+#define MASK_ROWS_ALL_IN_FLIGHT 0
+#endif
 constexpr int MASK_ROWS_MAX_NO = 192;   // widest last layer mask_rows_kernel stages in LDS
 
 struct MaskL1Params {
@@ -296,9 +299,10 @@ struct MaskRowsParams {
     int R, K, NO, KS;
 };
 
-// FOUR workgroups per 16-row tile, one per 16 of y1's 64 columns; each walks all of K with 16 waves and has ALL of a wave's
-// operand loads in flight at once (a wave's share is four 128-deep groups at P = 7 856: 20 x 16 bytes per lane), so the launch
-// is two dependent round trips (rows[] -> mask rows / operand) + the epilogue.  u is written once, in a fixed summation order.
+// FOUR workgroups per 16-row tile, one per 16 of y1's 64 columns; each walks all of K with 16 waves (a wave's share is four
+// 128-deep groups at P = 7 856, the next group requested while the current one is multiplied: with all four in flight at once
+// -- MASK_ROWS_ALL_IN_FLIGHT=1 -- the launch measured 13.1 us against 12.0; the same change made mask_gemm_l1_kernel,
+// mask_gemm_kernel and mask_rows_bwd_kernel 1.6-2.1 us SLOWER each).  u is written once, in a fixed summation order.
 // out = u W2 + b2 is linear in u's column blocks: workgroup q writes ITS product u[:, 16q : 16q + 16] W2[16q : 16q + 16, :]
 // (+ b2 for q = 0) to parts[q] with plain stores, and the consumer adds the four tables in a fixed order
 // (mobgt_embed_gather_multi, which gathers these rows anyway): no atomics, no zero-fill, bit-reproducible.
@@ -329,6 +333,7 @@ __global__ __launch_bounds__(1024) void mask_rows_kernel(const MaskRowsParams p)
     const int s0 = wave * per, s1 = min(nsteps, s0 + per);
     const uint16_t* xrow = p.Xt + (int64_t)(BN * q + i) * p.ldxt + 8 * kq;
     struct Group { uint4 w; uint4 b[4]; };
+#if MASK_ROWS_ALL_IN_FLIGHT
     for (int base = s0; base < s1; base += 16) {
         Group g[4];
 #pragma unroll
@@ -348,6 +353,26 @@ __global__ __launch_bounds__(1024) void mask_rows_kernel(const MaskRowsParams p)
                 acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, __builtin_bit_cast(bf16x8, g[j].b[u]), acc, 0, 0, 0);
             }
     }
+#else
+    auto load = [&](Group& g, const int ks) {
+        g.w = *reinterpret_cast<const uint4*>(mrow + ks);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) g.b[u] = *reinterpret_cast<const uint4*>(xrow + 32 * (ks + u));
+    };
+    Group cur, nxt;
+    if (s0 < s1) load(cur, s0);
+    for (int ks = s0; ks < s1; ks += 4) {
+        if (ks + 4 < s1) load(nxt, ks + 4);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (ks + u >= s1) break;
+            const uint32_t w = u == 0 ? cur.w.x : (u == 1 ? cur.w.y : (u == 2 ? cur.w.z : cur.w.w));
+            const bf16x8 af = __builtin_bit_cast(bf16x8, lut[(w >> (8 * kq)) & 0xffu]);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, __builtin_bit_cast(bf16x8, cur.b[u]), acc, 0, 0, 0);
+        }
+        if (ks + 4 < s1) cur = nxt;
+    }
+#endif
     float* mine = part[wave];
 #pragma unroll
     for (int v = 0; v < 4; ++v) mine[(4 * kq + v) * LDP + i] = acc[v];

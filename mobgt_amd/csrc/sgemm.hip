@@ -8,6 +8,7 @@
 //   C[M,N] = A[M,K] x B (+ bias[N])     B as [K,N] (x @ W, adj @ support, g @ W)  or as [N,K] (F.linear, g @ W^T)
 // Lane (i, kq) supplies A[row i][4kq + s] to MFMA s of a 16-deep k-step (one float4 when rows are 16-byte aligned);
 // the B operand uses the same k numbering, so the order of the four MFMAs inside a step is immaterial.
+#include <cstdlib>
 #include "common.h"
 #include "mobgt_hip.h"
 
@@ -157,6 +158,81 @@ __global__ __launch_bounds__(64) void sgemm_kernel(const SgemmParams p) {
     }
 }
 
+// Tall-and-narrow products with a long contraction (the distance GCN's first layer: 7 856 x 304 x 16): one wave per 16-row
+// tile walks 19 dependent 16-deep steps (9.2 us in the S-FSQ step, a chain of load round trips).  Here KS waves share a tile,
+// wave w taking the steps w, w + KS, ...; the partial tiles meet in LDS and wave 0 runs the epilogue.  [K,N] operand, N <= 16,
+// rows 16-byte aligned, K % 16 == 0.
+template <int KS>
+__global__ __launch_bounds__(64 * KS) void sgemm_splitk_kernel(const SgemmParams p) {
+    __shared__ float part[KS][16 * 17];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = lane & 15, kq = lane >> 4;
+    const int m0 = blockIdx.x * 16;
+    const float* arow = p.A + (int64_t)min(m0 + i, p.M - 1) * p.lda;
+    const float* mrow = p.amask ? p.amask + (int64_t)min(m0 + i, p.M - 1) * p.lda : nullptr;
+    const int col = min(i, p.N - 1);
+    const int nsteps = p.K / 16;
+    constexpr int MAXS = 8;                                   // steps per wave held in flight (K <= 16 * KS * MAXS)
+    float4 a_r[MAXS], b_r[MAXS];
+#pragma unroll
+    for (int u = 0; u < MAXS; ++u) {
+        const int s = wave + KS * u, k = 16 * s + 4 * kq;
+        if (s < nsteps) {
+            float4 v = *reinterpret_cast<const float4*>(arow + k);
+            if (mrow) {
+                const float4 y = *reinterpret_cast<const float4*>(mrow + k);
+                v.x *= act_mask(y.x, p.mpos, p.mneg, p.mzero); v.y *= act_mask(y.y, p.mpos, p.mneg, p.mzero);
+                v.z *= act_mask(y.z, p.mpos, p.mneg, p.mzero); v.w *= act_mask(y.w, p.mpos, p.mneg, p.mzero);
+            }
+            a_r[u] = v;
+            const float* q = p.B + col;
+            b_r[u].x = k < p.Kb ? q[(int64_t)k * p.ldb] : 0.f;
+            b_r[u].y = k + 1 < p.Kb ? q[(int64_t)(k + 1) * p.ldb] : 0.f;
+            b_r[u].z = k + 2 < p.Kb ? q[(int64_t)(k + 2) * p.ldb] : 0.f;
+            b_r[u].w = k + 3 < p.Kb ? q[(int64_t)(k + 3) * p.ldb] : 0.f;
+        } else {
+            a_r[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            b_r[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < MAXS; ++u) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a_r[u].x, b_r[u].x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a_r[u].y, b_r[u].y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a_r[u].z, b_r[u].z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a_r[u].w, b_r[u].w, acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int v = 0; v < 4; ++v) part[wave][(4 * kq + v) * 17 + i] = acc[v];
+    __syncthreads();
+    if (wave != 0) return;
+    const uint64_t seed = p.thr ? p.seed + (p.seed_dev ? *p.seed_dev : 0ull) : 0ull;
+    const int c = i;
+    if (c >= p.N) return;
+    const float bv = p.bias ? p.bias[c] : 0.f;
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+        const int r = m0 + 4 * kq + v;
+        if (r >= p.M) continue;
+        float o = bv;
+#pragma unroll
+        for (int w = 0; w < KS; ++w) o += part[w][(4 * kq + v) * 17 + i];
+        if (p.act) {
+            o = o > 0.f ? o : p.slope * o;
+            if (p.thr) {
+                const uint32_t rowh = dropout_row_hash(seed, (uint32_t)r ^ p.salt);
+                o = dropout_bits16(seed, rowh, (uint32_t)c) >= p.thr ? o * p.inv_keep : 0.f;
+            }
+        }
+        if (p.C) {
+            if (p.c_bf16) reinterpret_cast<bf16_t*>(p.C)[(int64_t)r * p.ldc + c] = (bf16_t)o;
+            else reinterpret_cast<float*>(p.C)[(int64_t)r * p.ldc + c] = o;
+        }
+        if (p.ct) p.ct[(int64_t)c * p.ldt + r] = (bf16_t)(p.ct_scale ? o * p.ct_scale[r] : o);
+    }
+}
+
 template <int NB, bool EXT>
 int launch_x(const SgemmParams& p, bool b_nk, bool vec, hipStream_t st) {
     const int tiles = ((p.M + 15) / 16) * ((p.N + 16 * NB - 1) / (16 * NB));
@@ -193,6 +269,11 @@ int run(SgemmParams& p, int b_is_nk, int c_dtype, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     // columns per wave: wide tiles reuse the A operand, narrow ones give more waves; aim at >= ~256 waves
     const int rows16 = (p.M + 15) / 16;
+    static const bool no_splitk = getenv("MOBGT_NO_SGEMM_SPLITK") != nullptr;
+    if (!no_splitk && !b_is_nk && vec && p.N <= 16 && p.K >= 128 && p.K <= 16 * 4 * 8 && rows16 >= 64) {
+        hipLaunchKernelGGL(sgemm_splitk_kernel<4>, dim3(rows16), dim3(256), 0, st, p);
+        return (int)hipGetLastError();
+    }
     int nb = 4;
     while (nb > 1 && (rows16 * ((p.N + 16 * nb - 1) / (16 * nb)) < 256 || p.N <= 16 * (nb / 2))) nb >>= 1;
     if (nb == 4) return launch<4>(p, b_is_nk != 0, vec, st);
