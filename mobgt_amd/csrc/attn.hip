@@ -52,6 +52,9 @@ namespace {
 #ifndef ATTN_LATE_PREFETCH
 #define ATTN_LATE_PREFETCH 0  // prologue: the loads the SECOND chunk needs (bias super-tile 1, K / V chunk 1) are requested behind the first barrier
 #endif
+#ifndef ATTN_PK_F32
+#define ATTN_PK_F32 0
+#endif
 #ifndef ATTN_EARLY_MASK
 #define ATTN_EARLY_MASK 0     // forward: the tile's dropout masks are computed in the shadow of the QK^T products (they do not depend on S)
 #endif
@@ -453,18 +456,54 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const AttnParams p) {
             const float m_new = fmaxf(m, tmax);
             if (__any(m_new > m)) {
                 const float alpha = fast_exp2((m - m_new) * MOBGT_LOG2E);
+#if ATTN_PK_F32
+                {
+                    typedef float f32x2_ __attribute__((ext_vector_type(2)));
+                    const f32x2_ av = {alpha, alpha};
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        f32x2_ ov = {o[2 * i], o[2 * i + 1]};
+                        ov *= av;
+                        o[2 * i] = ov.x;
+                        o[2 * i + 1] = ov.y;
+                    }
+                }
+#else
 #pragma unroll
                 for (int i = 0; i < 16; ++i) o[i] *= alpha;
+#endif
                 l *= alpha;
                 m = m_new;
             }
             const float ms = m * MOBGT_LOG2E;
             float pr[16];
+#if ATTN_PK_F32
+            {
+                // (round 4) the exponent's argument and the row sum as PACKED f32 operations (v_pk_fma_f32 / v_pk_add_f32: two
+                // lanes' worth per issue slot; the build runs with -fno-slp-vectorize, so the compiler forms none by itself)
+                typedef float f32x2_ __attribute__((ext_vector_type(2)));
+                const f32x2_ l2e = {MOBGT_LOG2E, MOBGT_LOG2E}, nms = {-ms, -ms};
+                f32x2_ lacc = {0.f, 0.f};
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const f32x2_ sv = {s[2 * i], s[2 * i + 1]};
+                    const f32x2_ a = __builtin_elementwise_fma(sv, l2e, nms);
+                    f32x2_ e;
+                    e.x = fast_exp2(a.x);
+                    e.y = fast_exp2(a.y);
+                    pr[2 * i] = e.x;
+                    pr[2 * i + 1] = e.y;
+                    lacc += e;
+                }
+                l += lacc.x + lacc.y;
+            }
+#else
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 pr[i] = fast_exp2(fmaf(s[i], MOBGT_LOG2E, -ms));
                 l += pr[i];
             }
+#endif
             // dropout rule v2 (common.h; this lane's 16 keys = one block), applied to the PACKED probabilities: a pair's word w
             // carries two 16-bit uniforms in the order the pair is packed (even key low), so the pair's keep mask is two packed
             // 16-bit instructions -- saturating (thr - 1) - w, arithmetic shift by 15 -- and one AND on the packed pair, instead
@@ -1193,6 +1232,34 @@ __global__ __launch_bounds__(ONE_NW * 64) void attn_bwd_one_kernel(const AttnPar
                     }
                 }
                 float a8[8], b8[8];
+#if ATTN_PK_F32
+                {
+                    // (round 4) packed f32 arithmetic around the exponentials: v_pk_fma_f32 / v_pk_mul_f32, two elements per issue slot
+                    typedef float f32x2_ __attribute__((ext_vector_type(2)));
+                    const f32x2_ l2e = {MOBGT_LOG2E, MOBGT_LOG2E};
+#pragma unroll
+                    for (int j = 0; j < 8; j += 2) {
+                        const int i = 8 * s2 + j;
+                        const f32x2_ sv = {s[i], s[i + 1]}, nl = {-lse8[j], -lse8[j + 1]}, dl2 = {dl8[j], dl8[j + 1]}, dp2 = {dp[i], dp[i + 1]};
+                        const f32x2_ a = __builtin_elementwise_fma(sv, l2e, nl);
+                        f32x2_ pr2;
+                        pr2.x = fast_exp2(a.x);
+                        pr2.y = fast_exp2(a.y);
+                        if (DROP) {
+                            f32x2_ x2;
+                            x2.x = (int)(w8[j] << drop_sh) >= thr_hi ? pr2.x : 0.f;
+                            x2.y = (int)(w8[j + 1] << drop_sh) >= thr_hi ? pr2.y : 0.f;
+                            const f32x2_ b2 = __builtin_elementwise_fma(x2, dp2, -(pr2 * dl2));
+                            a8[j] = x2.x; a8[j + 1] = x2.y;
+                            b8[j] = b2.x; b8[j + 1] = b2.y;
+                        } else {
+                            const f32x2_ b2 = pr2 * (dp2 - dl2);
+                            a8[j] = pr2.x; a8[j + 1] = pr2.y;
+                            b8[j] = b2.x; b8[j + 1] = b2.y;
+                        }
+                    }
+                }
+#else
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     const int i = 8 * s2 + j;
@@ -1207,6 +1274,7 @@ __global__ __launch_bounds__(ONE_NW * 64) void attn_bwd_one_kernel(const AttnPar
                         b8[j] = pr * (dp[i] - dl8[j]);
                     }
                 }
+#endif
                 const bf16x8 pb = pack8(a8);
                 u32x4 dbw = __builtin_bit_cast(u32x4, pack8(b8));
 #pragma unroll
