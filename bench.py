@@ -415,10 +415,9 @@ def time_epoch_loop(model, coll, name, uni, args):
     torch.cuda.synchronize()
     graphs_before = len(loop.slots)
     steps, ep = 0, 2
-    # The host has ~300 us of slack per step here (tools/dbg/r4_loop_probe2.py), so a generation-2 pass of Python's collector
-    # over this process's heap (by now: the oracle's autograd graphs, the CPU baseline, ~10^6 objects -- tens of ms) shows up as
-    # +0.05-0.1 ms per step over a 0.2 s timed region.  What exists is moved out of the collector's sight, as a long-running
-    # trainer would do once after start-up; the loop's own garbage is still collected.
+    # The host has ~300 us of slack per step here (tools/dbg/r4_loop_probe2.py): a generation-2 pass of Python's collector over a
+    # large heap (tens of ms) would show up as +0.05-0.1 ms per step over a 0.2 s timed region.  What exists is moved out of the
+    # collector's sight, as a long-running trainer would do once after start-up; the loop's own garbage is still collected.
     import gc
     gc.collect()
     gc.freeze()
@@ -804,6 +803,23 @@ def main():
     if rank == 0:
         m = w["model"]
         H, C = m["num_heads"], m["hidden_dim"] + (0 if stock else 64)
+        # (round 4: this leg runs FIRST, right behind the timed region.  Behind the roofline legs below -- graph-timed attention /
+        # chain launches over > 1 GB of rotating buffers -- the same loop measured 0.70 instead of 0.63 ms per step while the
+        # replay of the same graphs without new input stayed at 0.61; the cause was not found: tools/dbg/r4_loop_probe{5,6}.py,
+        # which run the c5 stress measurement in front of the loop, do not reproduce it.)
+        # ---- the same step fed like the reference feeds it: a NEW batch every step (data.py:282-295), collated inside the
+        # replayed step (train.EpochLoop: raw trajectories -> pinned staging -> one H2D copy -> [DeviceCollator.finish +
+        # forward + loss + backward + AdamW] as one graph per shape bucket).  Secondary metric of SURVEY 8(d): check-ins/s
+        # INCLUDING collate / preprocess; its CPU counterpart is cpu_baseline.with_collate.
+        with_collate = None
+        # (not for `big`: its raw format -- the reference's pickles hold DENSE N x N int64 count matrices, gen_pickles.py:820-832 --
+        # is 16 x 784^2 x 8 B = 79 MB of host arrays per batch, and packing them takes the host 140 ms per step: a statement
+        # about numpy, not about this path)
+        if world == 1 and not args.no_loop and not args.no_graph and not stock and name != "big":
+            try:
+                with_collate = time_epoch_loop(model, coll, name, uni, args)
+            except Exception as e:                       # never lose the headline line over the secondary figure
+                with_collate = dict(error=repr(e))
         d = C // H
         io_dt = torch.bfloat16 if (bf16 and args.gemm_dtype == "bf16") else torch.float32
         b_dt = torch.bfloat16 if bf16 else torch.float32
@@ -922,19 +938,6 @@ def main():
                               traffic=(trq + trk) if (trq is not None and trk is not None) else None,
                               mfma_busy_pct={"dq": mbq, "dkv": mbk}, counters_source=srcq,
                               avg_launch_us=t5b * 1e6, bytes_per_launch=b5b, input_sets_rotated=nset5)
-        # ---- the same step fed like the reference feeds it: a NEW batch every step (data.py:282-295), collated inside the
-        # replayed step (train.EpochLoop: raw trajectories -> pinned staging -> one H2D copy -> [DeviceCollator.finish +
-        # forward + loss + backward + AdamW] as one graph per shape bucket).  Secondary metric of SURVEY 8(d): check-ins/s
-        # INCLUDING collate / preprocess; its CPU counterpart is cpu_baseline.with_collate.
-        with_collate = None
-        # (not for `big`: its raw format -- the reference's pickles hold DENSE N x N int64 count matrices, gen_pickles.py:820-832 --
-        # is 16 x 784^2 x 8 B = 79 MB of host arrays per batch, and packing them takes the host 140 ms per step: a statement
-        # about numpy, not about this path)
-        if world == 1 and not args.no_loop and not args.no_graph and not stock and name != "big":
-            try:
-                with_collate = time_epoch_loop(model, coll, name, uni, args)
-            except Exception as e:                       # never lose the headline line over the secondary figure
-                with_collate = dict(error=repr(e))
         parity = None
         if not args.no_parity and uni.distance is not None:
             parity = oracle_parity_stock(model, batches, n_layers) if stock else oracle_parity(model, batches, uni, n_layers)
