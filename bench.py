@@ -918,7 +918,8 @@ def main():
             if one:
                 b5b = attn_bwd_bytes(16, 785, 256, 8, s_b, s_b, s_g, one_pass=True)
                 tro, mbo, srco, eo = pmc_of(32, "one", "-")
-                roof5b = dict(kernel="attn_bwd_prep_kernel + attn_bwd_one_kernel + attn_dq_finish_kernel (one pass over the bias)",
+                roof5b = dict(kernel="attn_bwd_one_kernel + attn_dq_finish_kernel (one pass over the bias; rowsum(dO O) inside the pass, the dQ "
+                                     "accumulator re-zeroed by the finishing launch)",
                               workload="c5 G16 T785 C256 d32, dropout 0.1", bound="hbm", achieved=b5b / t5b / 1e9, peak=HBM_PEAK_GBS,
                               unit="GB/s", frac=b5b / t5b / 1e9 / HBM_PEAK_GBS, traffic=tro, mfma_busy_pct={"one": mbo},
                               valu_busy_pct=eo.get("valu_busy_pct"), wait_any_frac=eo.get("wait_any_frac"),

@@ -104,6 +104,15 @@ int mobgt_attn_bias_bwd_fused(const void* q, const void* k, const void* v, const
                         int64_t lddq, int64_t lddk, int64_t lddv, int64_t ld_bias,
                         float scale, float dropout_p, uint64_t seed, const uint64_t* seed_dev,
                         int accumulate_dbias, int dbias_dtype, int io_dtype, int bias_dtype, float* dq_acc, void* stream);
+/* The same with an accumulator the caller keeps ZERO between calls (round 4, second step): dq_acc must be all zeros on entry and is
+ * all zeros again when the call's last launch has run; there is then no launch in front of the pass -- rowsum(dO * O) is formed
+ * inside it from `out` and `dout` -- and `delta` is not written. */
+int mobgt_attn_bias_bwd_fused_z(const void* q, const void* k, const void* v, const void* bias, const void* bias_t,
+                                const void* out, const float* lse, const void* dout, void* dq, void* dk, void* dv,
+                                void* dbias, float* delta, int G, int H, int T, int d, int64_t ldq, int64_t ldk,
+                                int64_t ldv, int64_t ldo, int64_t lddq, int64_t lddk, int64_t lddv, int64_t ld_bias,
+                                float scale, float dropout_p, uint64_t seed, const uint64_t* seed_dev,
+                                int accumulate_dbias, int dbias_dtype, int io_dtype, int bias_dtype, float* dq_acc, void* stream);
 
 /* Host-side statement of the dropout keep rule used by both kernels (for tests / replay).
  * Returns 1 if probability element (g,h,i,j) is kept. */

@@ -74,7 +74,8 @@ struct AttnParams {
     void* dbias;              // f32 (read-modify-write when `accumulate`) or bf16 (write-only slice of this layer)
     int dbias_bf16;
     float* delta;
-    float* dq_acc;            // one-pass backward: [G, T, H * d] f32, zero on entry (this file zero-fills it), the dQ sums
+    float* dq_acc;            // one-pass backward: [G, T, H * d] f32, the dQ sums (zero-filled by a launch in front unless dq_acc_zero)
+    int dq_acc_zero;          // the caller hands the accumulator over ZERO (it is zero again when the call's last launch has run)
     int G, H, T;
     int64_t ldq, ldk, ldv, ldo, lddq, lddk, lddv, ld_bias;
     float scale, inv_keep;
@@ -1110,6 +1111,7 @@ __global__ __launch_bounds__(ONE_NW * 64) void attn_bwd_one_kernel(const AttnPar
     const TQ* K = reinterpret_cast<const TQ*>(p.k) + (int64_t)g * T * p.ldk + h * D;
     const TQ* V = reinterpret_cast<const TQ*>(p.v) + (int64_t)g * T * p.ldv + h * D;
     const TQ* dO = reinterpret_cast<const TQ*>(p.dout) + (int64_t)g * T * p.ldo + h * D;
+    const TQ* Oo = reinterpret_cast<const TQ*>(p.out) + (int64_t)g * T * p.ldo + h * D;
     const TB* brows = reinterpret_cast<const TB*>(p.bias_t) + ((int64_t)gh * T + min(k0w, T - 1)) * p.ld_bias;
     const int brow_max = max(T - 1 - k0w, 0);
     unsigned char* bimg = Bs[wave];
@@ -1150,16 +1152,24 @@ __global__ __launch_bounds__(ONE_NW * 64) void attn_bwd_one_kernel(const AttnPar
     const int64_t sld = is_q ? p.ldq : p.ldo;
     bf16_t (*srm)[ROWP] = is_q ? Qs : dOs;
     bf16_t (*strn)[COLP] = is_q ? Qt : dOt;
-    Raw8<TQ> sreg;
+    Raw8<TQ> sreg, oreg;
+    // (round 4, second step) rowsum(dO O) is formed HERE: the threads that stage a piece of dO also request the same piece of O with
+    // the same two-chunk lead and reduce the products over the four pieces of a row when the chunk is stored -- the launch in
+    // front (attn_bwd_prep_kernel: 10.9 us at c5 for reading dO and O once more and zero-filling the accumulator) is gone; the
+    // accumulator is zero on entry and attn_dq_finish_kernel zeroes it again behind its read.
     auto stage_load = [&](const int c) {
-        if (D % 32 == 0 || sc0 < D) sreg.load(ssrc + (int64_t)min(c * KC + sr, T - 1) * sld + sc0);
-        else sreg.zero();
+        if (D % 32 == 0 || sc0 < D) {
+            sreg.load(ssrc + (int64_t)min(c * KC + sr, T - 1) * sld + sc0);
+            oreg.load((is_q ? ssrc : Oo) + (int64_t)min(c * KC + sr, T - 1) * sld + sc0);      // (Q threads: a second read of their piece, unused)
+        } else {
+            sreg.zero();
+            oreg.zero();
+        }
     };
-    float lse_r = 0.f, dl_r = 0.f;
+    float lse_r = 0.f;
     auto load_rowstats = [&](const int c) {      // thread it < KC carries query it of the chunk (every thread loads: no branch)
         const int64_t qi = (int64_t)gh * T + min(c * KC + (tid & (KC - 1)), T - 1);
         lse_r = p.lse_in[qi];
-        dl_r = p.delta[qi];                      // rowsum(dO O): attn_bwd_prep_kernel
     };
     // Per chunk TWO barriers:   tiles(c) | A | staging of chunk c + 1, dBias / dQ of chunk c, requests for chunk c + 2 | B
     // Every wait on a load sits in front of the chunk's stores and atomics in program order and the requests for chunk c + 2
@@ -1170,9 +1180,17 @@ __global__ __launch_bounds__(ONE_NW * 64) void attn_bwd_one_kernel(const AttnPar
         *reinterpret_cast<bf16x8*>(&srm[sr][sc0]) = b;
 #pragma unroll
         for (int i = 0; i < 8; ++i) strn[sc0 + i][sr] = b[i];
-        if (tid < KC) {
-            lseS[tid] = lse_r * MOBGT_LOG2E;
-            dlS[tid] = dl_r;
+        if (tid < KC) lseS[tid] = lse_r * MOBGT_LOG2E;
+        {
+            float a8[8], o8[8];
+            sreg.get(a8);
+            oreg.get(o8);
+            float d = 0.f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) d = fmaf(a8[i], o8[i], d);
+            d += __shfl_xor(d, 1, 64);                   // the four pieces of a row sit in four neighbouring lanes
+            d += __shfl_xor(d, 2, 64);
+            if (!is_q && (se & 3) == 0) dlS[sr] = d;
         }
         if (DROP) {
             for (int e = tid; e < 2 * NW * 2 * 32; e += NT) {
@@ -1384,13 +1402,15 @@ __global__ void attn_bwd_prep_kernel(const bf16_t* __restrict__ dout, const bf16
     }
     delta[((int64_t)g * H + h) * T + q] = d;
 }
-__global__ void attn_dq_finish_kernel(const float* acc, bf16_t* dq, int64_t rows, int C, int64_t lddq, float scale) {
+__global__ void attn_dq_finish_kernel(float* acc, bf16_t* dq, int64_t rows, int C, int64_t lddq, float scale) {
     const int64_t e = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 8;
     if (e >= rows * C) return;
     const int64_t r = e / C;
     const int c = (int)(e % C);
     float v[8];
     load8(acc + e, v);
+    *reinterpret_cast<float4*>(acc + e) = make_float4(0.f, 0.f, 0.f, 0.f);          // zero again for the next call
+    *reinterpret_cast<float4*>(acc + e + 4) = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
     for (int i = 0; i < 8; ++i) v[i] *= scale;
     store8(dq + r * lddq + c, v);
@@ -1466,9 +1486,10 @@ hipError_t launch_one(const AttnParams& p0, hipStream_t st) {
             // ONE pass (attn_bwd_one_kernel): zero the dQ accumulator + rowsum(dO O), the pass, scale + cast of dQ
             const int C = p.H * D;
             const int64_t nth = (int64_t)p.G * p.T * p.H;
-            hipLaunchKernelGGL((attn_bwd_prep_kernel<D>), dim3((unsigned)((nth + 255) / 256)), dim3(256), 0, st,
-                               reinterpret_cast<const bf16_t*>(p.dout), reinterpret_cast<const bf16_t*>(p.out), p.ldo, p.dq_acc, p.delta,
-                               p.G, p.H, p.T);
+            if (!p.dq_acc_zero)                     // (an accumulator of unknown contents: zero-fill launch in front)
+                hipLaunchKernelGGL((attn_bwd_prep_kernel<D>), dim3((unsigned)((nth + 255) / 256)), dim3(256), 0, st,
+                                   reinterpret_cast<const bf16_t*>(p.dout), reinterpret_cast<const bf16_t*>(p.out), p.ldo, p.dq_acc, p.delta,
+                                   p.G, p.H, p.T);
             p.nq = ((p.T + 31) / 32 + ONE_NW - 1) / ONE_NW;
             hipLaunchKernelGGL((attn_bwd_one_kernel<D, DROP>), dim3(GH * p.nq), dim3(ONE_NW * 64), 0, st, p);
             const int64_t n8 = (int64_t)p.G * p.T * C / 8;
@@ -1578,7 +1599,8 @@ static int attn_bwd_impl(const void* q, const void* k, const void* v, const void
                                    void* dbias, float* delta, int G, int H, int T, int d, int64_t ldq, int64_t ldk,
                                    int64_t ldv, int64_t ldo, int64_t lddq, int64_t lddk, int64_t lddv, int64_t ld_bias,
                                    float scale, float dropout_p, uint64_t seed, const uint64_t* seed_dev,
-                                   int accumulate_dbias, int dbias_dtype, int io_dtype, int bias_dtype, float* dq_acc, void* stream) {
+                                   int accumulate_dbias, int dbias_dtype, int io_dtype, int bias_dtype, float* dq_acc, void* stream,
+                                   int dq_acc_zero = 0) {
     int rc = check_common(G, H, T, d, ld_bias, io_dtype, 8);
     if (rc) return rc;
     if (!aligned16(q) || !aligned16(k) || !aligned16(v) || !aligned16(out) || !aligned16(dout) || !aligned16(bias) ||
@@ -1589,6 +1611,7 @@ static int attn_bwd_impl(const void* q, const void* k, const void* v, const void
     p.q = q; p.k = k; p.v = v; p.bias = bias; p.bias_t = bias_t; p.out = out; p.dout = dout; p.lse_in = lse;
     p.dq = dq; p.dk = dk; p.dv = dv; p.dbias = dbias; p.delta = delta;
     p.dq_acc = (dq_acc && aligned16(dq_acc)) ? dq_acc : nullptr;
+    p.dq_acc_zero = dq_acc_zero;
     p.G = G; p.H = H; p.T = T;
     p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo; p.lddq = lddq; p.lddk = lddk; p.lddv = lddv;
     p.ld_bias = ld_bias;
@@ -1627,6 +1650,19 @@ extern "C" int mobgt_attn_bias_bwd_fused(const void* q, const void* k, const voi
     return attn_bwd_impl(q, k, v, bias, bias_t, out, lse, dout, dq, dk, dv, dbias, delta, G, H, T, d, ldq, ldk, ldv, ldo, lddq, lddk,
                          lddv, ld_bias, scale, dropout_p, seed, seed_dev, accumulate_dbias, dbias_dtype, io_dtype, bias_dtype,
                          dq_acc, stream);
+}
+
+/* mobgt_attn_bias_bwd_fused with an accumulator the caller keeps ZERO between calls: no launch in front of the pass (rowsum(dO O)
+ * is formed inside it), and the finishing launch leaves dq_acc zero again. */
+extern "C" int mobgt_attn_bias_bwd_fused_z(const void* q, const void* k, const void* v, const void* bias, const void* bias_t,
+                                   const void* out, const float* lse, const void* dout, void* dq, void* dk, void* dv,
+                                   void* dbias, float* delta, int G, int H, int T, int d, int64_t ldq, int64_t ldk,
+                                   int64_t ldv, int64_t ldo, int64_t lddq, int64_t lddk, int64_t lddv, int64_t ld_bias,
+                                   float scale, float dropout_p, uint64_t seed, const uint64_t* seed_dev,
+                                   int accumulate_dbias, int dbias_dtype, int io_dtype, int bias_dtype, float* dq_acc, void* stream) {
+    return attn_bwd_impl(q, k, v, bias, bias_t, out, lse, dout, dq, dk, dv, dbias, delta, G, H, T, d, ldq, ldk, ldv, ldo, lddq, lddk,
+                         lddv, ld_bias, scale, dropout_p, seed, seed_dev, accumulate_dbias, dbias_dtype, io_dtype, bias_dtype,
+                         dq_acc, stream, 1);
 }
 
 extern "C" int mobgt_dropout_keep_host(uint64_t seed, int H, int T, int g, int h, int i, int j, float dropout_p) {

@@ -454,6 +454,9 @@ def _attn_fwd(q, k, v, pack, scale, p_drop, seed, seed_dev):
     return out, lse
 
 
+_DQ_ACC = {}
+
+
 def _attn_bwd(q, k, v, out, lse, dout, dq, dk, dv, pack, scale, p_drop, seed, seed_dev):
     G, T, C = q.shape
     H = pack.H
@@ -471,8 +474,19 @@ def _attn_bwd(q, k, v, out, lse, dout, dq, dk, dv, pack, scale, p_drop, seed, se
             and dbias.dtype == torch.bfloat16 and _ATTN_ONE_PASS[0]):
         # long graphs, training configuration: ONE pass over the bias (csrc/attn.hip: attn_bwd_one_kernel) -- needs an f32
         # scratch accumulator for dQ (summed over key blocks by atomics)
-        dq_acc = torch.empty(G, T, C, dtype=torch.float32, device=q.device)
-        check(_lib.lib().mobgt_attn_bias_bwd_fused(*args, _p(dq_acc), _stream()), "mobgt_attn_bias_bwd_fused")
+        if os.environ.get("MOBGT_ATTN_PREP") == "1":           # (the form with a zero-fill + rowsum launch in front: A/B)
+            dq_acc = torch.empty(G, T, C, dtype=torch.float32, device=q.device)
+            check(_lib.lib().mobgt_attn_bias_bwd_fused(*args, _p(dq_acc), _stream()), "mobgt_attn_bias_bwd_fused")
+            return
+        # ONE accumulator per (device, size), zero between calls: the pass adds into it, the finishing launch reads and re-zeroes it
+        # (calls of one stream follow each other; `busy` catches a call that died between its launches)
+        key = (str(q.device), G * T * C)
+        ent = _DQ_ACC.get(key)
+        if ent is None or ent["busy"]:
+            ent = _DQ_ACC[key] = dict(buf=torch.zeros(G * T * C, dtype=torch.float32, device=q.device), busy=False)
+        ent["busy"] = True
+        check(_lib.lib().mobgt_attn_bias_bwd_fused_z(*args, _p(ent["buf"]), _stream()), "mobgt_attn_bias_bwd_fused_z")
+        ent["busy"] = False
         return
     check(_lib.lib().mobgt_attn_bias_bwd(*args, _stream()), "mobgt_attn_bias_bwd")
 
