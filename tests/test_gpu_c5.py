@@ -74,6 +74,41 @@ def test_attention_all_gradients_at_t785_d32_elementwise(p_drop):
     assert float(bd.grad[1, :, :, 700:].abs().max()) == 0.0
 
 
+def test_one_pass_backward_leaves_its_dq_accumulator_zero_and_repeats(monkeypatch):
+    """Round 4, second step (csrc/attn.hip, mobgt_attn_bias_bwd_fused_z): the f32 dQ accumulator is ONE persistent buffer per
+    (device, size) that a call finds zero and leaves zero (the finishing launch re-zeroes it), rowsum(dO O) is formed inside the
+    pass.  Two backward passes in a row (dropout on) give the same dK / dV bit for bit and the same dQ up to the order of its f32
+    atomics; the buffer is all zeros afterwards; the form with the zero-fill + rowsum launch in front (MOBGT_ATTN_PREP=1) agrees."""
+    G, H, T, d = 2, 8, 300, 32
+    C = H * d
+    rng = np.random.RandomState(11)
+    q, k, v, gy = (bf16r(torch.from_numpy(rng.standard_normal((G, T, C)).astype(np.float32))).to(DEV).to(torch.bfloat16) for _ in range(4))
+    bias = bf16r(make_bias(rng, G, H, T, [T, 250])).to(DEV)
+    seed_dev = torch.tensor([3], dtype=torch.int64, device=DEV)
+
+    def run():
+        qd, kd, vd = (x.clone().requires_grad_(True) for x in (q, k, v))
+        bd = bias.clone().requires_grad_(True)
+        pack = ops.pack_bias(bd, G, H, T, dtype=torch.bfloat16)
+        out = ops.attention(qd, kd, vd, pack, d ** -0.5, p_drop=0.1, seed=77, seed_dev=seed_dev)
+        out.backward(gy)
+        torch.cuda.synchronize()
+        return [x.grad.float().clone() for x in (qd, kd, vd, bd)]
+    monkeypatch.delenv("MOBGT_ATTN_PREP", raising=False)
+    a = run()
+    key = (str(q.device), G * T * C)
+    assert key in ops._DQ_ACC and not ops._DQ_ACC[key]["busy"]
+    assert float(ops._DQ_ACC[key]["buf"].abs().max()) == 0.0
+    b = run()
+    assert float(ops._DQ_ACC[key]["buf"].abs().max()) == 0.0
+    assert torch.equal(a[1], b[1]) and torch.equal(a[2], b[2]) and torch.equal(a[3], b[3])
+    assert _rel_l2(b[0], a[0]) < 1e-3
+    monkeypatch.setenv("MOBGT_ATTN_PREP", "1")
+    c = run()
+    assert torch.equal(a[1], c[1]) and torch.equal(a[2], c[2])
+    assert _rel_l2(c[0], a[0]) < 5e-3 and _rel_l2(c[3], a[3]) < 5e-3      # (rowsum(dO O) summed in another order)
+
+
 # --------------------------------------------------------------------------------------- full-size S-BIG
 def _cpu_batch(b, sl=slice(None)):
     c = SimpleNamespace()
