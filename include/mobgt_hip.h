@@ -711,6 +711,17 @@ int64_t mobgt_mask_gemm_workspace_bytes(int K, int N);
 int mobgt_mask_gemm(const uint32_t* mask, int64_t ld_mask_words, const float* x, int64_t ldx, const float* bscale,
                     const float* rscale, const float* bias, float* out, int64_t ld_out, void* work, int M, int K, int N,
                     void* stream);
+/* Round 4 -- a tall-and-narrow small GEMM riding in the bias assembly's launch (csrc/bias.hip):
+ *   c = leaky_relu(a [M,K] @ b [k_b <= K rows, N] + bias)  (+ the result transposed in bf16, as mobgt_small_gemm_f32_act writes it)
+ * is left as a job for the NEXT short-batch mobgt_build_bias launch of this process (H = 8, G (N+1)^2 < 2^20), which runs it in
+ * its split-K form as extra workgroups of the same grid -- the distance GCN's first layer (modelGNN.py:38-44 / 66-72 on the
+ * precomputed A X) depends on parameters only and is as independent of the bias assembly as two launches can be.  Shapes of the
+ * split-K form only: N <= 16, K % 16 == 0, 128 <= K <= 512, a's rows 16-byte aligned, M >= 1024 (MOBGT_EBADDIM otherwise:
+ * launch mobgt_small_gemm_f32_act instead).  a == NULL drops a pending job; mobgt_front_sgemm_pending() != 0: no launch has
+ * taken the job yet.  Host state of the library: one thread. */
+int mobgt_front_sgemm_job(const float* a, int64_t lda, const float* b, int64_t ldb, const float* bias, int leaky, float slope,
+                          float* c, int64_t ldc, void* c_t_bf16, int64_t ld_t, int M, int N, int K, int k_b);
+int mobgt_front_sgemm_pending(void);
 /* Round 4 -- the distance GCN's hidden and last layer around two bitmask products, rows-only form (csrc/maskgemm.hip;
  * reference: graphormer/modelGNN.py:38-44 GraphConvolution, :66-72 GCN.forward; model_fqandtoyo.py:1236 the distance GCN over
  * all P POIs, :1264 its table read at the batch's POI ids only).  Hidden widths 16 and 64 (model_fqandtoyo.py: nhid = [16, 64]).

@@ -91,6 +91,8 @@ SIGNATURES = {
     "mobgt_ln_gemm_bwd": (_i, [_vp] * 12 + [_i64, _i, _f, _u64, _vp, _c.c_uint32, _vp, _i64, _vp, _i64, _i, _vp, _i, _vp]),
     "mobgt_mask_gemm_workspace_bytes": (_i64, [_i, _i]),
     "mobgt_mask_gemm": (_i, [_vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _vp, _i, _i, _i, _vp]),
+    "mobgt_front_sgemm_job": (_i, [_vp, _i64, _vp, _i64, _vp, _i, _f, _vp, _i64, _vp, _i64, _i, _i, _i, _i]),
+    "mobgt_front_sgemm_pending": (_i, []),
     "mobgt_mask_gemm_l1_fwd": (_i, [_vp, _i64, _vp, _vp, _i64, _vp, _vp, _vp, _f, _f, _u64, _vp, _u32, _vp, _vp, _i64, _vp, _i64, _i, _i, _vp]),
     "mobgt_mask_rows_fwd": (_i, [_vp, _i64, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "mobgt_mask_rows_bwd_lds_bytes": (_i64, [_i64, _i]),

@@ -11,6 +11,7 @@
 #include <type_traits>
 #include "common.h"
 #include "mobgt_hip.h"
+#include "sgemm_body.h"
 
 namespace {
 
@@ -470,8 +471,23 @@ __host__ __device__ inline int bwd_lds_dwords(int lds_rel, int lds_poi, int D, i
 // whole 128-byte lines: with 2 rows x 32 columns every line was fetched twice, by two workgroups): 4 waves for short
 // batches (more units to spread), 8 for long ones (one workgroup per CU shares ONE set of tables among 8 waves: the
 // 4-wave form needed 78 KB of LDS and 308 registers, i.e. ran one wave per SIMD with every latency exposed).
+// (round 4) A tall-and-narrow small GEMM left by mobgt_front_sgemm_job rides in the SHORT-batch launch as extra z-slices of the
+// grid: the distance GCN's first layer (parameters only) is as independent of the bias assembly as two launches can be, and
+// both are a few hundred 256-thread workgroups.
+struct SgemmRide {
+    mobgt_sgemm::SgemmParams sg;
+    int tiles, z0;                           // 16-row tiles; first z-slice that belongs to them
+};
+SgemmRide g_front_sg = {};                   // host side, one thread: the job the next short-batch launch takes along
+
 template <typename TI, typename TE, typename TB, int HH, int RND>
-__global__ __launch_bounds__(256) void build_bias_kernel(const BuildParams p) {
+__global__ __launch_bounds__(256) void build_bias_kernel(const BuildParams p, const SgemmRide ride) {
+    if (RND == 1 && ride.tiles > 0 && (int)blockIdx.z >= ride.z0) {
+        __shared__ float sg_part[4][16 * 17];
+        const int tile = (((int)blockIdx.z - ride.z0) * (int)gridDim.y + (int)blockIdx.y) * (int)gridDim.x + (int)blockIdx.x;
+        if (tile < ride.tiles) mobgt_sgemm::sgemm_splitk_tile<4>(ride.sg, tile, sg_part);
+        return;
+    }
     if (RND == 4) {
         // long batches, a 1-D launch: the four tiles of a 2 x 2 group -- which share every 128-byte line of the two copies, 64
         // bytes each -- run on ONE XCD in adjacent dispatch slots (workgroups go round-robin over the 8 XCDs), so that its L2
@@ -863,9 +879,17 @@ int launch_build(const BuildParams& p, hipStream_t st) {
         const int64_t resident = (sizeof(TB) == 2 ? 4 : 3) * (int64_t)cus;     // (35 KB of LDS per workgroup; 52 KB with an f32 tile)
         if (want > resident) want = resident;
         const dim3 grid4((unsigned)((want + 31) / 32 * 32));
-        hipLaunchKernelGGL((build_bias_kernel<TI, TE, TB, 8, 4>), grid4, block, 0, st, p);
-    } else if (p.H == 8) hipLaunchKernelGGL((build_bias_kernel<TI, TE, TB, 8, 1>), grid, block, 0, st, p);
-    else if (p.H == 4) hipLaunchKernelGGL((build_bias_kernel<TI, TE, TB, 4, 1>), grid, block, 0, st, p);
+        hipLaunchKernelGGL((build_bias_kernel<TI, TE, TB, 8, 4>), grid4, block, 0, st, p, SgemmRide{});
+    } else if (p.H == 8) {
+        SgemmRide ride = g_front_sg;                            // (taken by this launch)
+        g_front_sg.tiles = 0;
+        dim3 gr = grid;
+        if (ride.tiles > 0) {
+            ride.z0 = p.G;
+            gr.z = (unsigned)(p.G + (ride.tiles + (int)(grid.x * grid.y) - 1) / (int)(grid.x * grid.y));
+        }
+        hipLaunchKernelGGL((build_bias_kernel<TI, TE, TB, 8, 1>), gr, block, 0, st, p, ride);
+    } else if (p.H == 4) hipLaunchKernelGGL((build_bias_kernel<TI, TE, TB, 4, 1>), grid, block, 0, st, p, SgemmRide{});
     else return MOBGT_EBADDIM;
     return (int)hipGetLastError();
 }
@@ -961,6 +985,27 @@ int fill_bias_fwd(BuildParams& p, const float* attn_bias, const void* rel_pos, c
     return 0;
 }
 }  // namespace
+
+/* Leaves  c = leaky_relu(a [M,K] @ b [k_b <= K rows, N] + bias)  (+ the result transposed in bf16, as mobgt_small_gemm_f32_act
+ * writes it) as a job for the NEXT short-batch mobgt_build_bias launch (H = 8, G (N+1)^2 < 2^20) of this process, which runs it
+ * in its split-K form as extra workgroups (round 4: the distance GCN's first layer, modelGNN.py:38-44 / 66-72 on the
+ * precomputed A X, depends on parameters only).  Shapes of the split-K form only: N <= 16, K % 16 == 0, 128 <= K <= 512, a's rows
+ * 16-byte aligned, M >= 1024 (MOBGT_EBADDIM otherwise).  a == NULL drops a pending job; mobgt_front_sgemm_pending() != 0: no
+ * launch has taken it yet. */
+extern "C" int mobgt_front_sgemm_job(const float* a, int64_t lda, const float* b, int64_t ldb, const float* bias, int leaky,
+                                     float slope, float* c, int64_t ldc, void* c_t_bf16, int64_t ld_t, int M, int N, int K, int k_b) {
+    if (!a) { g_front_sg.tiles = 0; return 0; }
+    if (M < 1024 || N <= 0 || N > 16 || K < 128 || K > 16 * 4 * 8 || (K & 15) || (lda & 3) || k_b <= 0 || k_b > K || !b || (!c && !c_t_bf16))
+        return MOBGT_EBADDIM;
+    if (((uintptr_t)a & 15) || (c_t_bf16 && ld_t < M)) return MOBGT_EALIGN;
+    mobgt_sgemm::SgemmParams p = {};
+    p.A = a; p.lda = lda; p.B = b; p.ldb = ldb; p.bias = bias; p.C = c; p.ldc = ldc; p.M = M; p.N = N; p.K = K; p.Kb = k_b;
+    p.act = leaky; p.slope = slope; p.ct = reinterpret_cast<bf16_t*>(c_t_bf16); p.ldt = ld_t;
+    g_front_sg.sg = p;
+    g_front_sg.tiles = (M + 15) / 16;
+    return 0;
+}
+extern "C" int mobgt_front_sgemm_pending(void) { return g_front_sg.tiles > 0; }
 
 extern "C" int mobgt_build_bias(const float* attn_bias, const void* rel_pos, const void* poi_pos, const void* edge_input,
                                 const float* rel_table, const float* poi_table, const float* hop_table,

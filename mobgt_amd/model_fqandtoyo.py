@@ -479,7 +479,16 @@ class Graphormer(nn.Module):
         flush_pending_pack()
         ops.flush_front()
         try:
+            # (round 4) the distance GCN's first layer, leaky((A X) W0 + b0) over all P POIs -- parameters only, no batch input -- rides
+            # in the bias assembly's launch; modelGNN finds its result when it asks ops.small_gemm for this very product
+            g0 = self.poi_distance_model.gcn[0]
+            if (getattr(self, "D_mask", None) is not None and not self.sparse_adj and self.D_AX.is_cuda and self.D_AX.shape[1] % 16 == 0
+                    and g0.out_features == 16 and g0.bias is not None and 0 <= self.D_AX.shape[1] - g0.in_features < 16):
+                from .modelGNN import xt_workspace
+                ops.front_small_gemm(self.D_AX, g0.weight, g0.bias, float(self.poi_distance_model.leaky_relu.negative_slope),
+                                     g0.weight.shape[0], xt_workspace(self.D_AX.device, self.D_AX.shape[0], g0.out_features, slot=0))
             bias = self.assemble_bias(batched_data, hop=hop)
+            ops.front_small_gemm_flush()
             output = self.node_features(batched_data, indices=indices)
         finally:
             # (a prelaunched result nobody adopted -- an exception on the way -- must not meet a later, direct call of the GCN)

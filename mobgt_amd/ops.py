@@ -1747,6 +1747,13 @@ def small_gemm(a, b, bias=None, b_is_nk=False, out=None, out_dtype=torch.float32
     _require_cuda(a, b)
     assert a.dtype == torch.float32 and b.dtype == torch.float32 and a.dim() == 2 and b.dim() == 2
     assert a.stride(1) == 1 and b.stride(1) == 1
+    pre = _FRONT_SGEMM.get("done")
+    if pre is not None:
+        # this very product rode in the bias assembly's launch (front_small_gemm): its result exists
+        if (pre["key"] == (a.data_ptr(), b.data_ptr(), bias.data_ptr() if bias is not None else 0, leaky, k_b,
+                           ct[0].data_ptr() if ct else 0) and drop is None and a_mask is None and out is None and not b_is_nk):
+            del _FRONT_SGEMM["done"]
+            return pre["c"]
     M, K = a.shape
     N = b.shape[0] if b_is_nk else b.shape[1]
     assert (b.shape[1] if b_is_nk else b.shape[0]) == (K if k_b is None else k_b) and (k_b is None or (not b_is_nk and k_b <= K))
@@ -1770,6 +1777,41 @@ def small_gemm(a, b, bias=None, b_is_nk=False, out=None, out_dtype=torch.float32
                                               _stream()),
           "mobgt_small_gemm_f32_act")
     return c
+
+
+# ---- a small GEMM riding in the bias assembly's launch (round 4) --------------------------------------------------------------------
+_FRONT_SGEMM = {}
+
+
+def front_small_gemm(a, b, bias, leaky, k_b, ct):
+    """Leave  leaky_relu(a @ b[:k_b] + bias)  (+ transposed bf16 copy into ct) for the NEXT short-batch mobgt_build_bias launch
+    (mobgt_front_sgemm_job); `front_small_gemm_flush()` behind that launch turns it into the result `small_gemm` hands out when it
+    is called with these very arguments -- or launches it alone if no launch took it.  False: not a shape of that form."""
+    _FRONT_SGEMM.clear()
+    if (os.environ.get("MOBGT_NO_L0_RIDE") == "1" or not (a.is_cuda and a.dtype == torch.float32 and b.dtype == torch.float32
+            and a.is_contiguous() and b.is_contiguous() and bias is not None and bias.is_contiguous())):
+        return False
+    M, K = a.shape
+    N = b.shape[1]
+    c = torch.empty(M, N, dtype=torch.float32, device=a.device)
+    rc = _lib.lib().mobgt_front_sgemm_job(_p(a), a.stride(0), _p(b), b.stride(0), _p(bias), 1, float(leaky), _p(c), c.stride(0),
+                                          _p(ct), ct.stride(0) if ct is not None else 0, M, N, K, int(k_b))
+    if rc != 0:
+        return False
+    _FRONT_SGEMM["job"] = dict(key=(a.data_ptr(), b.data_ptr(), bias.data_ptr(), leaky, k_b, ct.data_ptr() if ct is not None else 0),
+                               c=c, args=(a, b, bias, leaky, k_b, ct))
+    return True
+
+
+def front_small_gemm_flush():
+    job = _FRONT_SGEMM.pop("job", None)
+    if job is None:
+        return
+    if _lib.lib().mobgt_front_sgemm_pending():             # no launch took it along: drop the job, launch the product alone
+        check(_lib.lib().mobgt_front_sgemm_job(None, 0, None, 0, None, 0, 0.0, None, 0, None, 0, 0, 0, 0, 0), "mobgt_front_sgemm_job")
+        a, b, bias, leaky, k_b, ct = job["args"]
+        job["c"] = small_gemm(a, b, bias, leaky=leaky, k_b=k_b, ct=(ct, None, False) if ct is not None else None)
+    _FRONT_SGEMM["done"] = job
 
 
 def act_mask_values(slope, p_drop):

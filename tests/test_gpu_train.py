@@ -364,7 +364,8 @@ def test_encoder_input_forward_in_one_launch_is_bit_identical_to_the_four_launch
 def test_forward_passengers_of_the_category_gcn_launch_change_nothing(monkeypatch):
     """The weight pack, the hop table's forward and the gather indices carried by the category GCN's forward launch
     (mobgt_small_gcn_fwd_pack; the model runs that launch first) against their own launches (MOBGT_NO_PACK_PASSENGER=1,
-    MOBGT_NO_FRONT_PASSENGERS=1): bit-identical logits, hop table and indices -- and the launch did take the jobs."""
+    MOBGT_NO_FRONT_PASSENGERS=1): bit-identical logits, hop table and indices -- and the launch did take the jobs.  Round 4: the
+    same switch pair covers the distance GCN's first layer riding in the bias assembly's launch (MOBGT_NO_L0_RIDE=1)."""
     from mobgt_amd import ops, workloads
     uni, model, coll = workloads.build("fsq", "cuda", seed=1, model_overrides=dict(n_layers=2))
     batch = coll(workloads.make_pool("fsq", 1, 16, uni)[0])
@@ -381,6 +382,7 @@ def test_forward_passengers_of_the_category_gcn_launch_change_nothing(monkeypatc
     for off in ("0", "1"):
         monkeypatch.setenv("MOBGT_NO_FRONT_PASSENGERS", off)
         monkeypatch.setenv("MOBGT_NO_PACK_PASSENGER", off)
+        monkeypatch.setenv("MOBGT_NO_L0_RIDE", off)        # (round 4: the distance GCN's first layer in the bias assembly's launch)
         with torch.no_grad():
             logits = model(batch)[0]
             hop = model.hop_table(batch)                         # (direct calls: launched at once)
