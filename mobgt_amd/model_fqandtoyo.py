@@ -491,8 +491,10 @@ class Graphormer(nn.Module):
             ops.front_small_gemm_flush()
             output = self.node_features(batched_data, indices=indices)
         finally:
-            # (a prelaunched result nobody adopted -- an exception on the way -- must not meet a later, direct call of the GCN)
+            # (a prelaunched result nobody adopted -- an exception on the way -- must not meet a later, direct call of the GCN;
+            #  the same for a small GEMM no bias launch took along)
             self.poi_cat_model.__dict__.pop("_prelaunched", None)
+            ops.front_small_gemm_drop()
         ops.trace_nan("x0", output)
         self._bias_pack, self._cuts = bias, {}
         for li, enc_layer in enumerate(self.layers):                                           # :1347-1352

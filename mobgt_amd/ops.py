@@ -1814,6 +1814,13 @@ def front_small_gemm_flush():
     _FRONT_SGEMM["done"] = job
 
 
+def front_small_gemm_drop():
+    """Forget a job that is still waiting for a launch (an exception between front_small_gemm and its flush) and an unclaimed result."""
+    if _FRONT_SGEMM.pop("job", None) is not None:
+        check(_lib.lib().mobgt_front_sgemm_job(None, 0, None, 0, None, 0, 0.0, None, 0, None, 0, 0, 0, 0, 0), "mobgt_front_sgemm_job")
+    _FRONT_SGEMM.pop("done", None)
+
+
 def act_mask_values(slope, p_drop):
     """(pos, neg, zero) of m(y) = d dropout(leaky_relu(u)) / du read off the OUTPUT y: a kept positive is scaled by 1/keep, a
     kept negative by slope/keep; y == 0 is a dropped element (gradient 0) when dropout is on, else LeakyReLU'(0) = slope."""
