@@ -373,6 +373,17 @@ int mobgt_stock_tokens_bwd(const float* dy, const void* x, const void* in_degree
                            int deg_dtype, float* d_atom, float* d_indeg, float* d_outdeg, float* d_graph_token, int G, int N, int C,
                            int64_t n_atom, int64_t n_in, int64_t n_out, int64_t padding_idx, float dropout_p, uint64_t seed,
                            const uint64_t* seed_dev, uint32_t salt, void* stream);
+/* Round 4: the stock step's three independent front launches as one grid -- mobgt_stock_tokens_fwd (same arguments), a weight
+ * pack (mobgt_pack_mfma_b's job arrays; n_pack = 0: none) and the hop table's forward (mobgt_hop_table_fwd's arguments;
+ * has_hop = 0: none).  Same results as the three launches; the consumers (mobgt_build_bias, the first encoder layer) follow
+ * on the stream. */
+int mobgt_stock_front_fwd(const void* x, const void* in_degree, const void* out_degree, int idx_dtype, int deg_dtype, const float* atom,
+                          const float* indeg, const float* outdeg, const float* graph_token, float* y, int G, int N,
+                          int C, int64_t n_atom, int64_t n_in, int64_t n_out, float dropout_p, uint64_t seed,
+                          const uint64_t* seed_dev, uint32_t salt, int n_pack, const void* const* pack_src,
+                          void* const* pack_dst, const int* pack_N, const int* pack_K, const int* pack_transposed,
+                          int has_hop, const float* edge_encoder, const float* edge_dis_encoder, float* hop_table, int D,
+                          int n_edge, int H, int fp16_roundtrip, void* stream);
 /* final_ln on the graph-token rows (model.py:211-217: the reference normalises every token, then reads row 0 of every graph):
  * y [G,C] = LayerNorm(enc[g,0,:]; ln_w, ln_b, eps), mean / rstd [G] kept for the backward (csrc/layer.hip).  enc [G,T,C] f32
  * contiguous, C <= 1024.

@@ -13,6 +13,8 @@
 #include <cstdlib>
 #include "common.h"
 #include "mobgt_hip.h"
+#include "front_body.h"
+#include "pack_body.h"
 
 namespace {
 
@@ -763,12 +765,13 @@ __device__ __forceinline__ int64_t st_idx(const void* p, int dt, int64_t i) {
     return dt == MOBGT_I64 ? reinterpret_cast<const int64_t*>(p)[i]
          : dt == MOBGT_I32 ? (int64_t)reinterpret_cast<const int32_t*>(p)[i] : (int64_t)reinterpret_cast<const int16_t*>(p)[i];
 }
+// virtual block `bid` of `nb` (256 threads each) of the grid-stride loop over the [G, T, C / 4] pieces
 template <bool BWD>
-__global__ __launch_bounds__(256) void stock_tokens_kernel(const StockTokParams p) {
+__device__ __forceinline__ void stock_tokens_body(const StockTokParams& p, const int bid, const int nb) {
     const int T = p.N + 1, c4 = p.C / 4;
     const uint64_t seed = p.thr ? p.seed + (p.seed_dev ? *p.seed_dev : 0ull) : 0ull;
     const int64_t total = (int64_t)p.G * T * c4;
-    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+    for (int64_t e = (int64_t)bid * 256 + threadIdx.x; e < total; e += (int64_t)nb * 256) {
         const int64_t r = e / c4;
         const int c = (int)(e - r * c4) * 4;
         const int g = (int)(r / T), t = (int)(r - (int64_t)g * T);
@@ -815,6 +818,21 @@ __global__ __launch_bounds__(256) void stock_tokens_kernel(const StockTokParams 
         }
     }
 }
+template <bool BWD>
+__global__ __launch_bounds__(256) void stock_tokens_kernel(const StockTokParams p) {
+    stock_tokens_body<BWD>(p, (int)blockIdx.x, (int)gridDim.x);
+}
+// The stock step's three front launches as ONE grid (round 4): the encoder input, the hop table's forward and the MFMA-order
+// weight pack are independent of one another (5 + 5 + 8 us alone, each mostly launch ramp); the bias build that reads the hop
+// table and the first layer that reads the other two follow on the stream.  Blocks [0, tok_blocks) run the token rows,
+// the next hop_blocks the hop table, the rest one pack block each.
+__global__ __launch_bounds__(256) void stock_front_kernel(const StockTokParams p, int tok_blocks, const mobgt_front::HopFwd hf,
+                                                          int hop_blocks, const mobgt_pack::PackJobs jobs, int njobs, int nvb) {
+    const int b = (int)blockIdx.x;
+    if (b < tok_blocks) stock_tokens_body<false>(p, b, tok_blocks);
+    else if (b < tok_blocks + hop_blocks) mobgt_front::hop_table_fwd_body(hf, b - tok_blocks);
+    else mobgt_pack::pack_blocks<1>(jobs, njobs, b - tok_blocks - hop_blocks, 0, nvb);
+}
 int stock_tok_fill(StockTokParams& p, const void* x, const void* din, const void* dout, int idx_dtype, int deg_dtype, int G, int N, int C,
                    int64_t n_atom, int64_t n_in, int64_t n_out, int64_t skip, float dropout_p, uint64_t seed, const uint64_t* seed_dev,
                    uint32_t salt) {
@@ -843,6 +861,40 @@ extern "C" int mobgt_stock_tokens_fwd(const void* x, const void* in_degree, cons
     const int64_t total = (int64_t)G * (N + 1) * (C / 4);
     const unsigned blocks = (unsigned)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
     hipLaunchKernelGGL(stock_tokens_kernel<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p);
+    return (int)hipGetLastError();
+}
+
+extern "C" int mobgt_stock_front_fwd(const void* x, const void* in_degree, const void* out_degree, int idx_dtype, int deg_dtype, const float* atom,
+                                     const float* indeg, const float* outdeg, const float* graph_token, float* y, int G, int N,
+                                     int C, int64_t n_atom, int64_t n_in, int64_t n_out, float dropout_p, uint64_t seed,
+                                     const uint64_t* seed_dev, uint32_t salt, int n_pack, const void* const* pack_src,
+                                     void* const* pack_dst, const int* pack_N, const int* pack_K, const int* pack_transposed,
+                                     int has_hop, const float* edge_encoder, const float* edge_dis_encoder, float* hop_table, int D,
+                                     int n_edge, int H, int fp16_roundtrip, void* stream) {
+    StockTokParams p;
+    int rc = stock_tok_fill(p, x, in_degree, out_degree, idx_dtype, deg_dtype, G, N, C, n_atom, n_in, n_out, -1, dropout_p, seed, seed_dev, salt);
+    if (rc) return rc;
+    if (((uintptr_t)atom | (uintptr_t)indeg | (uintptr_t)outdeg | (uintptr_t)graph_token | (uintptr_t)y) & 15) return MOBGT_EALIGN;
+    p.atom = atom; p.indeg = indeg; p.outdeg = outdeg; p.gtok = graph_token; p.y = y;
+    const int64_t total = (int64_t)G * (N + 1) * (C / 4);
+    const int tok_blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+    static mobgt_pack::PackJobs jobs;            // (by value into the launch; 3 KB -- not on the stack of every call)
+    int nvb = 0;
+    if (n_pack > 0) {
+        jobs = mobgt_pack::PackJobs{};
+        rc = mobgt_pack::fill_jobs(jobs, n_pack, pack_src, pack_dst, pack_N, pack_K, pack_transposed, &nvb);
+        if (rc) return rc;
+    }
+    mobgt_front::HopFwd hf = {};
+    int hop_blocks = 0;
+    if (has_hop) {
+        if (D <= 0 || n_edge <= 0 || H <= 0) return MOBGT_EBADDIM;
+        hf = mobgt_front::HopFwd{edge_encoder, edge_dis_encoder, hop_table, D, n_edge, H, fp16_roundtrip};
+        hop_blocks = (D * n_edge * H + 255) / 256;
+    }
+    static_assert(sizeof(StockTokParams) + sizeof(mobgt_pack::PackJobs) + sizeof(mobgt_front::HopFwd) + 32 <= 4096, "kernel arguments");
+    hipLaunchKernelGGL(stock_front_kernel, dim3(tok_blocks + hop_blocks + nvb), dim3(256), 0, (hipStream_t)stream, p, tok_blocks, hf,
+                       hop_blocks, jobs, n_pack > 0 ? n_pack : 0, nvb);
     return (int)hipGetLastError();
 }
 

@@ -14,6 +14,7 @@ Graphormer), so reference checkpoints load unchanged.  What differs is where the
 Lightning glue, FLAG, ogb/ZINC branches of the reference are out of scope.
 """
 import math
+import os
 
 import torch
 import torch.nn as nn
@@ -420,16 +421,21 @@ class Graphormer(nn.Module):
         self.bias_dtype = bias_dtype
         self.apply(lambda module: init_bert_params(module, n_layers=n_layers))
 
-    def assemble_bias(self, batched_data):
-        """model.py:126-190 -> ops.PackedBias"""
-        H = self.num_heads
-        edge_input = batched_data.edge_input
-        D = edge_input.shape[3]
+    def _hop_depth(self, batched_data):
+        D = batched_data.edge_input.shape[3]
         if self.multi_hop_max_dist > 0:
             D = min(D, self.multi_hop_max_dist)
         if self.edge_type != "multi_hop":
             raise NotImplementedError("only edge_type='multi_hop' is used by MobGT (README.md:62)")
-        hop = hop_table_from(self.edge_encoder.weight, self.edge_dis_encoder.weight, H, D)
+        return D
+
+    def assemble_bias(self, batched_data, hop=None):
+        """model.py:126-190 -> ops.PackedBias (`hop`: the hop table when the caller already has it)"""
+        H = self.num_heads
+        edge_input = batched_data.edge_input
+        D = self._hop_depth(batched_data)
+        if hop is None:
+            hop = hop_table_from(self.edge_encoder.weight, self.edge_dis_encoder.weight, H, D)
         rel = self.rel_pos_encoder.weight      # padding_idx = 0: build_bias_bwd never adds into row 0
         return ops.build_bias(batched_data.attn_bias, batched_data.rel_pos, None, edge_input, rel, None, hop,
                               self.graph_token_virtual_distance.weight, D, dtype=self.bias_dtype)
@@ -469,8 +475,6 @@ class Graphormer(nn.Module):
         x = batched_data.x
         in_degree = out_degree = batched_data.in_degree            # model.py:118 (aliasing kept)
         n_graph = x.size(0)
-        bias = self.assemble_bias(batched_data)
-        refresh_shadows(self.layers)
         if x.shape[2] != 1:
             raise NotImplementedError("MobGT items have one feature column (wrapper.py:37)")
         # (one feature column: a view, not a strided copy)
@@ -479,8 +483,28 @@ class Graphormer(nn.Module):
             xi = xi.long()
         tabs = (self.atom_encoder.weight, self.in_degree_encoder.weight, self.out_degree_encoder.weight)
         deg_raw = in_degree.reshape(xi.shape)
-        if (ops.stock_tokens_ok(xi, *tabs, self.graph_token.weight)
-                and deg_raw.dtype in (torch.int64, torch.int32, torch.int16)):
+        one_launch = (ops.stock_tokens_ok(xi, *tabs, self.graph_token.weight)
+                      and deg_raw.dtype in (torch.int64, torch.int32, torch.int16))
+        if one_launch and os.environ.get("MOBGT_NO_STOCK_FRONT") != "1":
+            # round 4: the hop table's forward and the layers' weight pack are left as jobs and ride in the launch of the encoder
+            # input (three independent front launches as one grid); the bias build follows it
+            ops.front_deferral(True)
+            try:
+                hop = hop_table_from(self.edge_encoder.weight, self.edge_dis_encoder.weight, self.num_heads, self._hop_depth(batched_data))
+                refresh_shadows(self.layers, defer_pack=True)
+                output = ops.stock_tokens(xi, deg_raw, deg_raw, *tabs, self.graph_token.weight, self.input_dropout.p, self.training, 0x1003)
+            finally:
+                ops.front_deferral(False)
+                ops.flush_front()
+                flush_pending_pack()
+            bias = self.assemble_bias(batched_data, hop=hop)
+            one_launch = None                                  # (done)
+        else:
+            bias = self.assemble_bias(batched_data)
+            refresh_shadows(self.layers)
+        if one_launch is None:
+            pass
+        elif one_launch:
             # gather + graph token + input dropout: one launch each way (same values, same mask as the three ops below); the
             # degrees go in in their own dtype
             output = ops.stock_tokens(xi, deg_raw, deg_raw, *tabs, self.graph_token.weight, self.input_dropout.p, self.training, 0x1003)

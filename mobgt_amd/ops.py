@@ -1044,9 +1044,31 @@ class _StockTokensFn(torch.autograd.Function):
         G, N = x.shape
         C = atom.shape[1]
         y = torch.empty(G, N + 1, C, dtype=torch.float32, device=atom.device)
-        check(_lib.lib().mobgt_stock_tokens_fwd(_p(x), _p(din), _p(dout), _IT[x.dtype], _IT[din.dtype], _p(atom), _p(indeg), _p(outdeg), _p(gtok), _p(y),
-                                                G, N, C, atom.shape[0], indeg.shape[0], outdeg.shape[0], p, seed, _p(seed_dev), salt,
-                                                _stream()), "mobgt_stock_tokens_fwd")
+        tok = (_p(x), _p(din), _p(dout), _IT[x.dtype], _IT[din.dtype], _p(atom), _p(indeg), _p(outdeg), _p(gtok), _p(y),
+               G, N, C, atom.shape[0], indeg.shape[0], outdeg.shape[0], p, seed, _p(seed_dev), salt)
+        hop, ni = take_front_jobs() if _FRONT_DEFER["on"] else (None, None)
+        if ni is not None:                                       # (not a job of the stock model: launched alone)
+            check(_lib.lib().mobgt_node_index(*ni[0], _stream()), "mobgt_node_index")
+        jobs = []
+        if _FRONT_DEFER["on"]:
+            from .model import take_pending_pack
+            jobs = take_pending_pack()
+        if hop is not None or jobs:
+            # the stock step's front as one grid (csrc/layer.hip stock_front_kernel): these rows, the hop table's forward the
+            # model deferred (front_deferral) and the weight pack it deferred (refresh_shadows(defer_pack=True))
+            import ctypes
+            vp, ci = ctypes.c_void_p, ctypes.c_int
+            for o in range(96, len(jobs), 96):                   # (more than one launch's worth of pack jobs: the rest alone)
+                from .model import _launch_pack
+                _launch_pack(jobs[o:o + 96])
+            part = jobs[:96]
+            nj = len(part)
+            pack = ((vp * nj)(*[j[0].data_ptr() for j in part]), (vp * nj)(*[j[1].data_ptr() for j in part]), (ci * nj)(*[j[2] for j in part]),
+                    (ci * nj)(*[j[3] for j in part]), (ci * nj)(*[j[4] for j in part])) if nj else (None, None, None, None, None)
+            hargs = [1] + hop[0] if hop is not None else [0, None, None, None, 0, 0, 0, 0]
+            check(_lib.lib().mobgt_stock_front_fwd(*tok, nj, *pack, *hargs, _stream()), "mobgt_stock_front_fwd")
+        else:
+            check(_lib.lib().mobgt_stock_tokens_fwd(*tok, _stream()), "mobgt_stock_tokens_fwd")
         ctx.idx = (x, din, dout)
         ctx.misc = (p, seed, seed_dev, salt, padding_idx, [t.shape for t in (atom, indeg, outdeg, gtok)])
         # (a table listed twice keeps separate buffers: autograd adds the results, which must not be one memory)

@@ -974,6 +974,59 @@ def test_stock_encoder_input_in_one_launch(idt, monkeypatch):
 
 
 @pytest.mark.gpu
+def test_stock_front_as_one_grid_is_bit_identical_to_its_three_launches(monkeypatch):
+    """Round 4: the stock model's encoder input, hop table forward and weight pack as one grid (csrc/layer.hip
+    stock_front_kernel via mobgt_stock_front_fwd) against their own launches (MOBGT_NO_STOCK_FRONT=1): the three jobs are
+    independent and each block runs the same body, so the packed weights, the eval logits (through the hop table and the
+    encoder input) and the train-mode encoder input (device-seeded mask) are bit-identical."""
+    from mobgt_amd import ops, workloads, synth
+    uni, model, coll = workloads.build("fsq", DEV, seed=1, P=1500, variant="stock", model_overrides=dict(n_layers=2))
+    batch = coll(synth.make_batch_of_trajectories(seed=21, G=8, P=1500, n_user=1080, cat_of_poi=uni.cat_of_poi,
+                                                  n_nodes=[17, 3, 9, 2, 11, 5, 40, 23]))
+    seen = []
+    real = ops._lib.lib
+    class _Spy:
+        def __init__(self, lib): self._lib = lib
+        def __getattr__(self, name):
+            if name in ("mobgt_stock_front_fwd", "mobgt_stock_tokens_fwd", "mobgt_hop_table_fwd", "mobgt_pack_mfma_b"):
+                seen.append(name)
+            return getattr(self._lib, name)
+    spy = _Spy(real())
+    monkeypatch.setattr(ops._lib, "lib", lambda: spy)
+    rows, tokens = [], ops.stock_tokens
+    monkeypatch.setattr(ops, "stock_tokens", lambda *a, **k: (lambda y: (rows.append(y.detach().clone()), y)[1])(tokens(*a, **k)))
+    ops.set_dropout_state(torch.tensor([3], dtype=torch.int64, device=DEV), 99)
+    try:
+        out = {}
+        for off in ("", "1"):
+            if off:
+                monkeypatch.setenv("MOBGT_NO_STOCK_FRONT", "1")
+            else:
+                monkeypatch.delenv("MOBGT_NO_STOCK_FRONT", raising=False)
+            del seen[:]
+            model.eval()
+            with torch.no_grad():
+                logits = model(batch).clone()
+            packs = [t.clone() for layer in model.layers for t in (getattr(layer, "_packed", None) or ())]
+            model.train()
+            n_eval = list(seen)
+            del seen[:]
+            del rows[:]
+            model.training_step(batch, 0).backward()
+            torch.cuda.synchronize()
+            out[off] = (logits, packs, rows[0], n_eval, list(seen))
+    finally:
+        ops.set_dropout_state(None, 0)
+    a, b = out[""], out["1"]
+    assert a[3].count("mobgt_stock_front_fwd") == 1 and "mobgt_hop_table_fwd" not in a[3] and "mobgt_stock_tokens_fwd" not in a[3]
+    assert a[4].count("mobgt_stock_front_fwd") == 1 and "mobgt_hop_table_fwd" not in a[4] and "mobgt_pack_mfma_b" not in a[4]
+    assert "mobgt_stock_front_fwd" not in b[3] + b[4] and "mobgt_stock_tokens_fwd" in b[4] and "mobgt_hop_table_fwd" in b[4]
+    assert torch.equal(a[0], b[0])
+    assert len(a[1]) == len(b[1]) and all(torch.equal(u, v) for u, v in zip(a[1], b[1]))
+    assert torch.equal(a[2], b[2]) and int((a[2] == 0).sum()) > 0          # (train mode: the input dropout's mask is the same)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("C,G,T,p", [(128, 16, 38, 0.1), (128, 3, 130, 0.1), (128, 1, 17, 0.0), (256, 9, 130, 0.1)])
 def test_preln_layer_chain_kernel_matches_the_separate_launches(C, G, T, p):
     """Round 4: the chain kernels for graphormer/model.py's PRE-LN EncoderLayer (:463-489, the layer BASELINE.json's north_star
