@@ -164,42 +164,54 @@ __global__ __launch_bounds__(256) void gather_multi_kernel(const MultiParams p) 
 constexpr int RUN_ROWS = 16;
 constexpr int RUN_MAXK = 8;
 
-template <typename TI>
+// (round 4) the RUN_ROWS gradient rows are the same for every table: they are read ONCE, all in flight together, into
+// registers (NK <= 4: 64 of them), and so are the wave's indices -- the first form read row after row, table after table, each
+// read behind the previous one's add: 16 x n_tables dependent round trips, 115 us at S-BIG for 13 MB.
+template <typename TI, int NK>
 __global__ __launch_bounds__(256) void scatter_add_runs_kernel(const EmbedParams p) {
     const int lane = threadIdx.x & 63;
     const int64_t r0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * RUN_ROWS;
     if (r0 >= p.R) return;
-    const int nk = (p.C + 63) / 64;
     const int nrow = (int)min((int64_t)RUN_ROWS, p.R - r0);
+    float src[RUN_ROWS][NK];
+#pragma unroll
+    for (int rr = 0; rr < RUN_ROWS; ++rr) {
+        const float* from = p.dout + (r0 + (rr < nrow ? rr : 0)) * p.ld;
+#pragma unroll
+        for (int k = 0; k < NK; ++k) src[rr][k] = (rr < nrow && lane + 64 * k < p.C) ? from[lane + 64 * k] : 0.f;
+    }
 #pragma unroll 1
     for (int t = 0; t < p.n_tables; ++t) {
         const TI* idx = reinterpret_cast<const TI*>(p.idx[t]);
+        // lane rr holds the index of row rr (one load for the wave)
+        const int64_t mine = lane < nrow ? (int64_t)idx[r0 + lane] : -1;
         int64_t cur = -1;
-        float acc[RUN_MAXK];
+        float acc[NK];
 #pragma unroll
-        for (int k = 0; k < RUN_MAXK; ++k) acc[k] = 0.f;
-        for (int rr = 0; rr <= nrow; ++rr) {
+        for (int k = 0; k < NK; ++k) acc[k] = 0.f;
+#pragma unroll
+        for (int rr = 0; rr <= RUN_ROWS; ++rr) {
             int64_t row = -1;
-            if (rr < nrow) {
-                row = (int64_t)idx[r0 + rr];
-                if (row < 0 || row == p.skip[t]) continue;
+            bool live = false;
+            if (rr < RUN_ROWS) {
+                row = __shfl(mine, rr);
+                live = rr < nrow && row >= 0 && row != p.skip[t];
             }
-            if (row != cur) {                                   // (rr == nrow: final flush)
+            if (rr < RUN_ROWS && !live) continue;
+            if (row != cur) {                                   // (rr == RUN_ROWS: final flush)
                 if (cur >= 0) {
                     float* dst = p.d_tables[t] + cur * p.C;
 #pragma unroll
-                    for (int k = 0; k < RUN_MAXK; ++k)
-                        if (k < nk && lane + 64 * k < p.C) atomicAdd(dst + lane + 64 * k, acc[k]);
+                    for (int k = 0; k < NK; ++k)
+                        if (lane + 64 * k < p.C) atomicAdd(dst + lane + 64 * k, acc[k]);
                 }
                 cur = row;
 #pragma unroll
-                for (int k = 0; k < RUN_MAXK; ++k) acc[k] = 0.f;
+                for (int k = 0; k < NK; ++k) acc[k] = 0.f;
             }
-            if (rr < nrow) {
-                const float* src = p.dout + (r0 + rr) * p.ld;
+            if (rr < RUN_ROWS) {
 #pragma unroll
-                for (int k = 0; k < RUN_MAXK; ++k)
-                    if (k < nk && lane + 64 * k < p.C) acc[k] += src[lane + 64 * k];
+                for (int k = 0; k < NK; ++k) acc[k] += src[rr][k];
             }
         }
     }
@@ -236,10 +248,17 @@ extern "C" int mobgt_embed_scatter_add(float* const* d_tables_host, const void* 
     hipStream_t st = (hipStream_t)stream;
     if (C <= 64 * RUN_MAXK && R >= 4096) {            // (few rows: atomics do not pile up, and 16 sequential rows per wave cost latency)
         const dim3 grid((unsigned)((R + 4 * RUN_ROWS - 1) / (4 * RUN_ROWS))), block(256);
-        if (idx_dtype == MOBGT_I64) hipLaunchKernelGGL(scatter_add_runs_kernel<int64_t>, grid, block, 0, st, p);
-        else if (idx_dtype == MOBGT_I32) hipLaunchKernelGGL(scatter_add_runs_kernel<int32_t>, grid, block, 0, st, p);
-        else if (idx_dtype == MOBGT_I16) hipLaunchKernelGGL(scatter_add_runs_kernel<int16_t>, grid, block, 0, st, p);
-        else return MOBGT_EDTYPE;
+        const bool narrow = C <= 256;
+        if (idx_dtype == MOBGT_I64) {
+            if (narrow) hipLaunchKernelGGL((scatter_add_runs_kernel<int64_t, 4>), grid, block, 0, st, p);
+            else hipLaunchKernelGGL((scatter_add_runs_kernel<int64_t, RUN_MAXK>), grid, block, 0, st, p);
+        } else if (idx_dtype == MOBGT_I32) {
+            if (narrow) hipLaunchKernelGGL((scatter_add_runs_kernel<int32_t, 4>), grid, block, 0, st, p);
+            else hipLaunchKernelGGL((scatter_add_runs_kernel<int32_t, RUN_MAXK>), grid, block, 0, st, p);
+        } else if (idx_dtype == MOBGT_I16) {
+            if (narrow) hipLaunchKernelGGL((scatter_add_runs_kernel<int16_t, 4>), grid, block, 0, st, p);
+            else hipLaunchKernelGGL((scatter_add_runs_kernel<int16_t, RUN_MAXK>), grid, block, 0, st, p);
+        } else return MOBGT_EDTYPE;
         return (int)hipGetLastError();
     }
     const dim3 grid((unsigned)((R + 3) / 4)), block(256);

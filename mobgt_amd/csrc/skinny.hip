@@ -133,15 +133,18 @@ __global__ __launch_bounds__(256) void skinny_dx_kernel(const float* __restrict_
 // A row-owning layout (64 rows x all K per workgroup) was tried first: 123 x 7168 atomics made it 18 us.
 constexpr int DXM_ROWS = 256;                // rows of W per staged chunk
 constexpr int DXM_VSPLIT = 8;
+// (round 4) past 32 k classes: 32 slices.  Eight slices are 224 workgroups with one 16 KB chunk each in flight -- 3.6 MB, a
+// quarter of what 8 TB/s x ~2 us of latency needs -- and at V = 100 001 (S-BIG) each walks 49 chunks: 115 us for 358 MB.
+inline int dxm_vsplit(int V) { return V >= 32768 ? 32 : DXM_VSPLIT; }
 typedef __attribute__((ext_vector_type(4))) float f32x4_;
 
 __device__ __forceinline__ void skinny_dx_mfma_body(const float* __restrict__ dy, const float* __restrict__ w,
-                                                    float* __restrict__ dx, int G, int K, int V, int bx, int by) {
+                                                    float* __restrict__ dx, int G, int K, int V, int bx, int by, int vsplit) {
     __shared__ __attribute__((aligned(16))) float wl[DXM_ROWS][16];            // W[v0 + r][k0 .. k0 + 15]
     __shared__ __attribute__((aligned(16))) float dyl[GMAX][DXM_ROWS + 4];     // dy[g][v0 + r]
     __shared__ float part[4][16][17];
     const int k0 = bx * 16;
-    const int vper = ((V + DXM_VSPLIT - 1) / DXM_VSPLIT + 3) & ~3;
+    const int vper = ((V + vsplit - 1) / vsplit + 3) & ~3;
     const int vbeg = by * vper, vend = min(V, vbeg + vper);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int j = lane & 15, q = lane >> 4;
@@ -192,7 +195,7 @@ __device__ __forceinline__ void skinny_dx_mfma_body(const float* __restrict__ dy
 
 __global__ __launch_bounds__(256) void skinny_dx_mfma_kernel(const float* __restrict__ dy, const float* __restrict__ w,
                                                              float* __restrict__ dx, int G, int K, int V) {
-    skinny_dx_mfma_body(dy, w, dx, G, K, V, blockIdx.x, blockIdx.y);
+    skinny_dx_mfma_body(dy, w, dx, G, K, V, blockIdx.x, blockIdx.y, (int)gridDim.y);
 }
 
 constexpr int DW_ROWS = 16;                  // rows v of dW per workgroup
@@ -243,9 +246,10 @@ __global__ __launch_bounds__(256) void skinny_dw_kernel(const float* __restrict_
 // workgroups, and neither depends on the other -- the first K/16 x 8 workgroups run the dx body, the rest the dW body.
 __global__ __launch_bounds__(256) void skinny_bwd_both_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                               const float* __restrict__ w, float* __restrict__ dx,
-                                                              float* __restrict__ dw, float* __restrict__ db, int G, int K, int V) {
-    const int ndx = (K / 16) * DXM_VSPLIT;
-    if ((int)blockIdx.x < ndx) skinny_dx_mfma_body(dy, w, dx, G, K, V, blockIdx.x % (K / 16), blockIdx.x / (K / 16));
+                                                              float* __restrict__ dw, float* __restrict__ db, int G, int K, int V,
+                                                              int vsplit) {
+    const int ndx = (K / 16) * vsplit;
+    if ((int)blockIdx.x < ndx) skinny_dx_mfma_body(dy, w, dx, G, K, V, blockIdx.x % (K / 16), blockIdx.x / (K / 16), vsplit);
     else skinny_dw_body(dy, x, dw, db, G, K, V, blockIdx.x - ndx);
 }
 
@@ -423,7 +427,7 @@ extern "C" int mobgt_skinny_linear_dx(const float* dy, const float* w, float* dx
     const int rc = check_dims(G, K, V);
     if (rc) return rc;
     if ((K & 15) || ((uintptr_t)w & 15)) return MOBGT_EBADDIM;
-    hipLaunchKernelGGL(skinny_dx_mfma_kernel, dim3(K / 16, DXM_VSPLIT), dim3(256), 0, (hipStream_t)stream, dy, w, dx, G, K, V);
+    hipLaunchKernelGGL(skinny_dx_mfma_kernel, dim3(K / 16, dxm_vsplit(V)), dim3(256), 0, (hipStream_t)stream, dy, w, dx, G, K, V);
     return (int)hipGetLastError();
 }
 
@@ -433,8 +437,9 @@ extern "C" int mobgt_skinny_linear_bwd_both(const float* dy, const float* x, con
     const int rc = check_dims(G, K, V);
     if (rc) return rc;
     if ((K & 15) || ((uintptr_t)w & 15) || !dx || !dw) return MOBGT_EBADDIM;
-    const int blocks = (K / 16) * DXM_VSPLIT + (V + DW_ROWS - 1) / DW_ROWS;
-    hipLaunchKernelGGL(skinny_bwd_both_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dy, x, w, dx, dw, db, G, K, V);
+    const int vsplit = dxm_vsplit(V);
+    const int blocks = (K / 16) * vsplit + (V + DW_ROWS - 1) / DW_ROWS;
+    hipLaunchKernelGGL(skinny_bwd_both_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dy, x, w, dx, dw, db, G, K, V, vsplit);
     return (int)hipGetLastError();
 }
 

@@ -216,7 +216,7 @@ def fused_layer_forward(layer, variant, x, attn_bias, n1, nx, next_layer=None):
             if _fl._DEFER[0] and not getattr(nxt, "_mobgt_cut", False) and getattr(layer, "_packed_fresh", False) and bwd_ok:
                 cfg.next_qkv = (nxt._packed[0], nxt._shadows[1])
                 cfg.next_norm = (nxt.self_attention_norm.weight, nxt.self_attention_norm.bias)
-    if getattr(layer, "_packed_fresh", False) and act != torch.float32 and not amp:
+    if getattr(layer, "_packed_fresh", False) is True and act != torch.float32 and not amp:
         cfg.packed = layer._packed[1:]                    # (wo, w1, w2) in MFMA operand order
         if getattr(layer, "_packed_t_fresh", False):
             cfg.packed_t = layer._packed_t                # (w2^T, w1^T, wo^T)
@@ -272,7 +272,7 @@ def _launch_pack(jobs):
                                                 (ci * n)(*[j[4] for j in part]), _stream()), "mobgt_pack_mfma_b")
 
 
-def refresh_shadows(layers, defer_pack=False):
+def refresh_shadows(layers, defer_pack=False, rows=None):
     """bf16 copies of every layer's GEMM weights in ONE multi-tensor copy (call once per forward).  `defer_pack`: the MFMA-order
     pack is not launched but left for the category GCN's forward launch to carry (take_pending_pack) -- the caller MUST call
     flush_pending_pack() in front of the first consumer of the packs."""
@@ -299,10 +299,10 @@ def refresh_shadows(layers, defer_pack=False):
         layer._shadow_fresh = True
     if dst:
         torch._foreach_copy_(dst, src)
-    pack_layer_weights(layers, defer=defer_pack)
+    pack_layer_weights(layers, defer=defer_pack, rows=rows)
 
 
-def pack_layer_weights(layers, defer=False):
+def pack_layer_weights(layers, defer=False, rows=None):
     """MFMA-operand-order copies of the fused layers' (fq post-LN and, since round 4, model.py's pre-LN) bf16 GEMM weights (csrc/chain.hip reads a wave's B operand as one
     contiguous KB), all layers in one launch (up to 96 weights): `layer._packed` = (wqkv, wo, w1, w2) packed for the
     forward chain and, when gradients are enabled, `layer._packed_t` = (w2^T, w1^T, wo^T, wqkv^T) for the backward chain."""
@@ -311,8 +311,12 @@ def pack_layer_weights(layers, defer=False):
     if not fused_layer._CHAIN[0]:
         return
     want_t = torch.is_grad_enabled() and fused_layer._CHAIN_BWD[0]
+    # `rows`: the batch's token rows, when the caller knows them.  Past 4 096 rows the layers run the library's GEMMs (ops.layer_gemm_ok)
+    # and nothing reads the packs but the token-assembly launch, which multiplies by the FIRST layer's QKV weight: S-BIG packed
+    # 96 weights per step (38 us) for that one.
+    qkv0_only = rows is not None and rows > 4096 and not fused_layer._CHAIN_BIG[0]
     jobs = []
-    for layer in layers:
+    for li, layer in enumerate(layers):
         layer._packed_fresh = layer._packed_t_fresh = False
         sh = getattr(layer, "_shadows", None)
         if (sh is None or not getattr(layer, "fused", False) or not getattr(layer, "_shadow_fresh", False)
@@ -326,6 +330,11 @@ def pack_layer_weights(layers, defer=False):
         if pk is None or pk[0].device != sh[0].device:
             pk = tuple(torch.empty_like(sh[i]) for i in (0, 2, 4, 6))
             layer._packed = pk
+        if qkv0_only:
+            if li == 0:
+                jobs.append((sh[0], pk[0], sh[0].shape[0], sh[0].shape[1], 0))
+                layer._packed_fresh = "qkv"                 # (model.fused_layer_forward hands on a pack only when this is True)
+            continue
         for d, i in zip(pk, (0, 2, 4, 6)):
             jobs.append((sh[i], d, sh[i].shape[0], sh[i].shape[1], 0))
         layer._packed_fresh = True

@@ -474,7 +474,7 @@ class Graphormer(nn.Module):
             indices = self.gather_indices(batched_data)
         finally:
             ops.front_deferral(False)
-        refresh_shadows(self.layers, defer_pack=True)
+        refresh_shadows(self.layers, defer_pack=True, rows=batched_data.x.shape[0] * (batched_data.x.shape[1] + 1))
         prelaunch_small_gcn(self.poi_cat_model, self.C_X, self.C_A, self.C_AX, self.C_A_T, same_stream=True)
         flush_pending_pack()
         ops.flush_front()

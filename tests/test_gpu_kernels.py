@@ -556,8 +556,39 @@ def test_embed_gather_sum_and_grad():
         np.testing.assert_allclose(got.cpu().numpy(), w.numpy(), rtol=1e-5, atol=1e-5)
 
 
+@pytest.mark.parametrize("C,R,idt", [(192, 4999, torch.int64), (256, 4096, torch.int32), (448, 5003, torch.int64), (40, 4100, torch.int16)])
+def test_embed_scatter_of_long_batches_run_length_form(C, R, idt):
+    """mobgt_embed_scatter_add from 4 096 rows (S-BIG: 12 560): a wave keeps the sum of a run of equal indices in registers
+    (csrc/embed.hip scatter_add_runs_kernel; round 4: the wave's 16 gradient rows and indices are read once, all in flight).
+    Long stretches of one index, runs that cross the 16-row groups, padding rows (no gradient), negative indices (contribute
+    nothing), a ragged last group; both register widths (C <= 256 / <= 512).  Against index_add_ in float64."""
+    rng = np.random.RandomState(C + R)
+    sizes = (300, 64, 64)
+    tabs = [torch.from_numpy(rng.standard_normal((n, C)).astype(np.float32)) for n in sizes]
+    idx = []
+    for n in sizes:
+        i = rng.randint(0, n, size=R)
+        runs = rng.randint(0, R - 40, size=60)
+        for r0 in runs:
+            i[r0:r0 + rng.randint(2, 40)] = rng.randint(0, n)          # stretches of one row, any alignment
+        idx.append(i)
+    idx[0][rng.randint(0, R, size=50)] = -1
+    gy = torch.from_numpy(rng.standard_normal((R, C)).astype(np.float32))
+    dev_t = [t.to(DEV).requires_grad_(True) for t in tabs]
+    dev_i = [torch.from_numpy(i).to(idt).to(DEV) for i in idx]
+    out = ops.embed_gather_sum(dev_t, dev_i, padding_idx=[None, 0, 0])
+    out.backward(gy.to(DEV))
+    for t, (n, i, pad) in enumerate(zip(sizes, idx, (None, 0, 0))):
+        want = torch.zeros(n, C, dtype=torch.float64)
+        keep = torch.from_numpy(i >= 0)
+        want.index_add_(0, torch.from_numpy(i)[keep].long(), gy.double()[keep])
+        if pad is not None:
+            want[pad] = 0
+        np.testing.assert_allclose(dev_t[t].grad.double().cpu().numpy(), want.numpy(), rtol=1e-5, atol=2e-5 * float(want.abs().max()), err_msg=str(t))
+
+
 @pytest.mark.parametrize("all_hip", [False, True])
-@pytest.mark.parametrize("G,K,V", [(16, 448, 7857), (5, 448, 1030), (1, 64, 2048), (16, 512, 1024)])
+@pytest.mark.parametrize("G,K,V", [(16, 448, 7857), (5, 448, 1030), (1, 64, 2048), (16, 512, 1024), (16, 448, 40001)])
 def test_skinny_linear_matches_torch(G, K, V, all_hip, monkeypatch):
     """mobgt_skinny_linear_fwd/bwd (the classifier head, M = G rows) against F.linear in fp64; the product path uses
     the dW/db kernel only, MOBGT_SKINNY_ALL=1 exercises the forward and dx kernels as well."""
