@@ -384,6 +384,14 @@ int mobgt_stock_front_fwd(const void* x, const void* in_degree, const void* out_
                           void* const* pack_dst, const int* pack_N, const int* pack_K, const int* pack_transposed,
                           int has_hop, const float* edge_encoder, const float* edge_dis_encoder, float* hop_table, int D,
                           int n_edge, int H, int fp16_roundtrip, void* stream);
+/* Round 4: mobgt_stock_tokens_bwd (same arguments) and mobgt_hop_table_bwd (H = 8, n_edge <= 2048, d_hop_table and
+ * edge_dis_encoder 16-byte aligned) as one grid -- independent of one another, both in front of the optimizer. */
+int mobgt_stock_tail_bwd(const float* dy, const void* x, const void* in_degree, const void* out_degree, int idx_dtype,
+                         int deg_dtype, float* d_atom, float* d_indeg, float* d_outdeg, float* d_graph_token, int G, int N, int C,
+                         int64_t n_atom, int64_t n_in, int64_t n_out, int64_t padding_idx, float dropout_p, uint64_t seed,
+                         const uint64_t* seed_dev, uint32_t salt, const float* d_hop_table, const float* edge_encoder,
+                         const float* edge_dis_encoder, float* d_edge_encoder, float* d_edge_dis_encoder, int D, int n_edge,
+                         int H, int fp16_roundtrip, void* stream);
 /* final_ln on the graph-token rows (model.py:211-217: the reference normalises every token, then reads row 0 of every graph):
  * y [G,C] = LayerNorm(enc[g,0,:]; ln_w, ln_b, eps), mean / rstd [G] kept for the backward (csrc/layer.hip).  enc [G,T,C] f32
  * contiguous, C <= 1024.

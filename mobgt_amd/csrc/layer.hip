@@ -15,6 +15,7 @@
 #include "mobgt_hip.h"
 #include "front_body.h"
 #include "pack_body.h"
+#include "hop_body.h"
 
 namespace {
 
@@ -833,6 +834,16 @@ __global__ __launch_bounds__(256) void stock_front_kernel(const StockTokParams p
     else if (b < tok_blocks + hop_blocks) mobgt_front::hop_table_fwd_body(hf, b - tok_blocks);
     else mobgt_pack::pack_blocks<1>(jobs, njobs, b - tok_blocks - hop_blocks, 0, nvb);
 }
+// ... and two of the stock step's tail launches (round 4): the backward of the encoder input (scatter of d(tokens) into the three
+// tables) and the hop table's backward (H = 8; csrc/hop_body.h) read different gradients and write different tables -- 12.9 + 9.6
+// us alone at E = 1 537 edge ids, which is too wide for the grouped weight-gradient launch's hop slot (E <= 256).  Blocks
+// [0, hop_blocks) run the hop body (the long ones first), the rest the token rows; the dynamic LDS is the hop body's.
+__global__ __launch_bounds__(256) void stock_tail_kernel(const StockTokParams p, int tok_blocks, const mobgt_hop::HopBwd hp, int hop_blocks) {
+    extern __shared__ __attribute__((aligned(16))) float tail_sm[];
+    const int b = (int)blockIdx.x;
+    if (b < hop_blocks) mobgt_hop::hop_table_bwd8_body(hp, b, tail_sm);
+    else stock_tokens_body<true>(p, b - hop_blocks, tok_blocks);
+}
 int stock_tok_fill(StockTokParams& p, const void* x, const void* din, const void* dout, int idx_dtype, int deg_dtype, int G, int N, int C,
                    int64_t n_atom, int64_t n_in, int64_t n_out, int64_t skip, float dropout_p, uint64_t seed, const uint64_t* seed_dev,
                    uint32_t salt) {
@@ -1645,5 +1656,30 @@ extern "C" int mobgt_head_input_bwd(const float* dx3, const void* user, int user
     HeadInParams p = {nullptr, nullptr, nullptr, user, user_dtype, user_offset, dx3, denc, dtable, G, T, C, U, n_rows};
     const int64_t n = (int64_t)G * T * C + (int64_t)G * U;
     hipLaunchKernelGGL(head_input_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, p);
+    return (int)hipGetLastError();
+}
+
+extern "C" int mobgt_stock_tail_bwd(const float* dy, const void* x, const void* in_degree, const void* out_degree, int idx_dtype,
+                                    int deg_dtype, float* d_atom, float* d_indeg, float* d_outdeg, float* d_graph_token, int G, int N, int C,
+                                    int64_t n_atom, int64_t n_in, int64_t n_out, int64_t padding_idx, float dropout_p, uint64_t seed,
+                                    const uint64_t* seed_dev, uint32_t salt, const float* d_hop_table, const float* edge_encoder,
+                                    const float* edge_dis_encoder, float* d_edge_encoder, float* d_edge_dis_encoder, int D, int n_edge,
+                                    int H, int fp16_roundtrip, void* stream) {
+    StockTokParams p;
+    int rc = stock_tok_fill(p, x, in_degree, out_degree, idx_dtype, deg_dtype, G, N, C, n_atom, n_in, n_out, padding_idx, dropout_p, seed,
+                            seed_dev, salt);
+    if (rc) return rc;
+    if ((uintptr_t)dy & 15) return MOBGT_EALIGN;
+    if (D <= 0 || n_edge <= 0 || H != 8 || n_edge > 2048) return MOBGT_EBADDIM;
+    if (((uintptr_t)d_hop_table | (uintptr_t)edge_dis_encoder) & 15) return MOBGT_EALIGN;
+    p.dy = dy; p.d_atom = d_atom; p.d_indeg = d_indeg; p.d_outdeg = d_outdeg; p.d_gtok = d_graph_token;
+    const int64_t total = (int64_t)G * (N + 1) * (C / 4);
+    const int tok_blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+    const mobgt_hop::HopBwd hp = {d_hop_table, edge_encoder, edge_dis_encoder, d_edge_encoder, d_edge_dis_encoder, D, n_edge, fp16_roundtrip};
+    const int hop_blocks = mobgt_hop::hop_bwd8_blocks(D, n_edge);
+    const size_t lds = (size_t)2 * n_edge * 8 * sizeof(float);
+    rc = (int)hipFuncSetAttribute((const void*)stock_tail_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (rc) return rc;
+    hipLaunchKernelGGL(stock_tail_kernel, dim3(hop_blocks + tok_blocks), dim3(256), lds, (hipStream_t)stream, p, tok_blocks, hp, hop_blocks);
     return (int)hipGetLastError();
 }

@@ -654,6 +654,12 @@ class _HopTableFn(torch.autograd.Function):
             # rides in the step's grouped weight-gradient launch (flush_deferred_wgrads): nothing but the optimizer reads these
             _WGRAD_DEFER["hop"] = (dtab, ew, dw, d_ew, d_dw, D, E, rt)
             return d_ew[:], d_dw[:], None, None, None
+        if (_WGRAD_DEFER["on"] and H == 8 and E <= 2048 and dtab.data_ptr() % 16 == 0 and dw.data_ptr() % 16 == 0
+                and os.environ.get("MOBGT_NO_STOCK_TAIL") != "1"):
+            # too many edge ids for the grouped launch's hop slot (the stock variant's 1 537): parked until the flush, where it
+            # shares ONE grid with the backward of the stock encoder input when that is parked too (csrc/layer.hip stock_tail_kernel)
+            _WGRAD_DEFER["hop_wide"] = (dtab, ew, dw, d_ew, d_dw, D, E, rt)
+            return d_ew[:], d_dw[:], None, None, None
         check(_lib.lib().mobgt_hop_table_bwd(_p(dtab), _p(ew), _p(dw), _p(d_ew), _p(d_dw), D, E, H, rt,
                                              _stream()), "mobgt_hop_table_bwd")
         return d_ew, d_dw, None, None, None
@@ -1085,9 +1091,17 @@ class _StockTokensFn(torch.autograd.Function):
         C = dy.shape[2]
         grads = [None if not need else (k[:] if (k is not None and tuple(k.shape) == tuple(sh)) else zeros_f32(tuple(sh), dy.device))
                  for need, k, sh in zip(ctx.needs_input_grad[3:7], ctx.sinks, shapes)]
-        check(_lib.lib().mobgt_stock_tokens_bwd(_p(dy), _p(x), _p(din), _p(dout), _IT[x.dtype], _IT[din.dtype], _p(grads[0]), _p(grads[1]), _p(grads[2]),
-                                                _p(grads[3]), G, N, C, shapes[0][0], shapes[1][0], shapes[2][0], int(padding_idx), p,
-                                                seed, _p(seed_dev), salt, _stream()), "mobgt_stock_tokens_bwd")
+        args = [_p(dy), _p(x), _p(din), _p(dout), _IT[x.dtype], _IT[din.dtype], _p(grads[0]), _p(grads[1]), _p(grads[2]),
+                _p(grads[3]), G, N, C, shapes[0][0], shapes[1][0], shapes[2][0], int(padding_idx), p, seed, _p(seed_dev), salt]
+        in_sinks = all((not need) or (k is not None and tuple(k.shape) == tuple(sh))
+                       for need, k, sh in zip(ctx.needs_input_grad[3:7], ctx.sinks, shapes))
+        if _WGRAD_DEFER["on"] and in_sinks and "stock_tok" not in _WGRAD_DEFER and os.environ.get("MOBGT_NO_STOCK_TAIL") != "1":
+            # trainer's backward, every table gradient lands in its sink: nothing reads them before the optimizer, so the launch is
+            # parked until the flush and shares ONE grid with the hop table's backward there (mobgt_stock_tail_bwd); what
+            # autograd gets back are fresh views (AccumulateGrad clones a returned gradient something else still references)
+            _WGRAD_DEFER["stock_tok"] = (args, (dy, x, din, dout, seed_dev, grads))
+            return (None, None, None, *[g_[:] if g_ is not None else None for g_ in grads], None, None, None, None, None)
+        check(_lib.lib().mobgt_stock_tokens_bwd(*args, _stream()), "mobgt_stock_tokens_bwd")
         return (None, None, None, *grads, None, None, None, None, None)
 
 
@@ -1869,7 +1883,8 @@ def wgrad_deferral(on):
     """Switch the recording on / off.  Switching off DROPS anything still recorded: the trainer flushes explicitly after a
     successful backward pass, so leftovers exist only when that pass raised -- their buffers belong to a dead graph."""
     _WGRAD_DEFER["items"] = []
-    _WGRAD_DEFER.pop("hop", None)
+    for k in ("hop", "hop_wide", "stock_tok"):
+        _WGRAD_DEFER.pop(k, None)
     _WGRAD_DEFER["on"] = bool(on) and _WGRAD_DEFER_ENV
 
 
@@ -1883,11 +1898,22 @@ def flush_deferred_wgrads():
         stages = [p_["stage"] for p_ in _TOKEN_PENDING.values()]
         _TOKEN_PENDING.clear()
         _WGRAD_DEFER["items"] = []
-        _WGRAD_DEFER.pop("hop", None)
+        for k in ("hop", "hop_wide", "stock_tok"):
+            _WGRAD_DEFER.pop(k, None)
         raise RuntimeError(f"a parked encoder-input backward chain was never completed (stages {stages}): gradients of this "
                            "step are invalid -- set MOBGT_NO_TOKEN_BWD_CHAIN=1 and report")
     items, _WGRAD_DEFER["items"] = _WGRAD_DEFER["items"], []
     hop = _WGRAD_DEFER.pop("hop", None)
+    tok, wide = _WGRAD_DEFER.pop("stock_tok", None), _WGRAD_DEFER.pop("hop_wide", None)
+    if tok is not None and wide is not None:     # the stock step's tail: both in one grid
+        dtab, ew, dw_, d_ew, d_dw, D, E, rt = wide
+        check(_lib.lib().mobgt_stock_tail_bwd(*tok[0], _p(dtab), _p(ew), _p(dw_), _p(d_ew), _p(d_dw), D, E, 8, rt, _stream()),
+              "mobgt_stock_tail_bwd")
+    elif tok is not None:
+        check(_lib.lib().mobgt_stock_tokens_bwd(*tok[0], _stream()), "mobgt_stock_tokens_bwd")
+    elif wide is not None:
+        dtab, ew, dw_, d_ew, d_dw, D, E, rt = wide
+        check(_lib.lib().mobgt_hop_table_bwd(_p(dtab), _p(ew), _p(dw_), _p(d_ew), _p(d_dw), D, E, 8, rt, _stream()), "mobgt_hop_table_bwd")
     vp, i64, ci, cf = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_float
     if hop is not None and not items:            # nobody to ride with
         dtab, ew, dw_, d_ew, d_dw, D, E, rt = hop

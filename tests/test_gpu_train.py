@@ -396,6 +396,53 @@ def test_forward_passengers_of_the_category_gcn_launch_change_nothing(monkeypatc
     assert torch.isfinite(outs[0][0]).all()
 
 
+def test_stock_tail_as_one_grid_gives_the_gradients_of_its_two_launches(monkeypatch):
+    """Round 4: the backward of the stock encoder input and the hop table's backward (1 537 edge ids: too wide for the grouped
+    weight-gradient launch's hop slot) are parked by the trainer's backward pass and issued as ONE grid at the flush
+    (mobgt_stock_tail_bwd, csrc/layer.hip stock_tail_kernel) -- against their own launches (MOBGT_NO_STOCK_TAIL=1), from one
+    fixed state: the gradients of the six tables agree as closely as two runs of ONE form do (f32 atomics in varying order),
+    and the launch did happen once per step."""
+    from mobgt_amd import _lib, workloads
+    from mobgt_amd.train import TrainStep
+    uni, model, coll = workloads.build("fsq", DEV, seed=1, variant="stock", model_overrides=dict(n_layers=2))
+    batches = [coll(t) for t in workloads.make_pool("fsq", 1, 16, uni)]
+    ts = TrainStep(model, batches, use_graph=False, seed=1)
+    ts.prepare()
+    seen = []
+    real = _lib.lib()
+
+    class _Spy:
+        def __getattr__(self, name):
+            if name in ("mobgt_stock_tail_bwd", "mobgt_stock_tokens_bwd", "mobgt_hop_table_bwd"):
+                seen.append(name)
+            return getattr(real, name)
+    monkeypatch.setattr(_lib, "lib", lambda: _Spy())
+    state = _state_of(ts)
+    names = {id(p): n for n, p in model.named_parameters()}
+    tabs = ("atom_encoder.weight", "in_degree_encoder.weight", "out_degree_encoder.weight", "graph_token.weight",
+            "edge_encoder.weight", "edge_dis_encoder.weight")
+
+    def grads():
+        del seen[:]
+        g, loss = _fixed_step_grads(ts, state)
+        by = {names[id(p)]: v.detach().clone() for p, v in zip(ts.flat.params, ts.flat.views)}
+        return {n: by[n] for n in tabs}, loss, list(seen)
+    monkeypatch.delenv("MOBGT_NO_STOCK_TAIL", raising=False)
+    ga, la, sa = grads()
+    ga2, _, _ = grads()
+    monkeypatch.setenv("MOBGT_NO_STOCK_TAIL", "1")
+    gb, lb, sb = grads()
+    assert sa == ["mobgt_stock_tail_bwd"], sa
+    assert sorted(sb) == ["mobgt_hop_table_bwd", "mobgt_stock_tokens_bwd"], sb
+    assert abs(la - lb) <= 2e-5 * abs(lb)
+    for n in tabs:
+        rep = float((ga2[n] - ga[n]).norm() / (ga[n].norm() + 1e-30))
+        rel = float((gb[n] - ga[n]).norm() / (ga[n].norm() + 1e-30))
+        print("%-28s one grid vs two launches relL2 %.2e (two runs of one form %.2e)" % (n, rel, rep))
+        assert float(ga[n].abs().max()) > 0 and rel < max(3 * rep, 3e-3), (n, rel, rep)
+    assert float(ga["atom_encoder.weight"][0].abs().max()) == 0.0 and float(ga["edge_encoder.weight"][0].abs().max()) == 0.0   # padding rows
+
+
 @pytest.mark.parametrize("use_graph", [False, True])
 def test_parameter_reached_twice_per_pass_gets_no_gradient_sink(use_graph):
     """gradient sinks are handed to the op that asks in its forward and written as that op's own buffer,
