@@ -798,7 +798,9 @@ int mobgt_layer_gemm(const void* a, int64_t lda, const void* b, int64_t ldb, int
  * fused into that GEMM as its prologue (csrc/lngemm.hip; bf16 activations, C <= 256, C % 32 == 0).  Arithmetic, dropout
  * masks and side outputs are those of mobgt_dropout_add_ln_fwd / _bwd followed by mobgt_layer_gemm:
  *   fwd  x1 = x + dropout(y);  z = LayerNorm(x1);  out = z . weight^T + bias   (weight [N, C]; epilogue 0 = bias,
- *        1 = GELU: out = u, aux_out = gelu(u))          -- model.py:482-485 + :397-398 (FFN layer 1)
+ *        1 = GELU: out = u, aux_out = gelu(u))          -- model.py:482-485 + :397-398 (FFN layer 1);
+ *        y == x1 == NULL (round 4): z = LayerNorm(x), no residual -- model.py:480-481, the pre-LN layer's
+ *        self_attention_norm in front of its QKV projection
  *   bwd  dx1 = dres + LayerNorm'(dz + dz32);  dy = dropout'(dx1);  out = dy . weight_kn  (weight_kn [C, N]; epilogue 0,
  *        or 2 = out * gelu'(aux_in)); dgamma / dbeta / dbias [C] accumulate (zero them first).
  */

@@ -134,13 +134,15 @@ __device__ __forceinline__ void ln_prologue(const LnGemmParams& p, const int m0,
                 const int c = c0 + 4 * q;
                 float yv[4];
                 ld4f(p.x + r * C + c, v[q]);
-                ld4h(p.y + r * C + c, yv);
+                if (p.y) {                                           // (NULL: a plain LayerNorm of x -- the pre-LN layer's first norm)
+                    ld4h(p.y + r * C + c, yv);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    if (p.thr) yv[i] = dropout_bits16(seed, rowh, (uint32_t)(c + i)) >= p.thr ? yv[i] * p.inv_keep : 0.f;
-                    v[q][i] += yv[i];
+                    for (int i = 0; i < 4; ++i) {
+                        if (p.thr) yv[i] = dropout_bits16(seed, rowh, (uint32_t)(c + i)) >= p.thr ? yv[i] * p.inv_keep : 0.f;
+                        v[q][i] += yv[i];
+                    }
                 }
-                if (side) *reinterpret_cast<float4*>(p.x1 + r * C + c) = make_float4(v[q][0], v[q][1], v[q][2], v[q][3]);
+                if (side && p.x1) *reinterpret_cast<float4*>(p.x1 + r * C + c) = make_float4(v[q][0], v[q][1], v[q][2], v[q][3]);
             }
 #pragma unroll
             for (int i = 0; i < 4; ++i) s += v[q][i];
@@ -388,7 +390,7 @@ extern "C" int mobgt_ln_gemm_fwd(const float* x, const void* y, float* x1, const
                                  void* out, int64_t ld_out, int epilogue, void* aux_out, int N, void* stream) {
     int rc = check_gemm(R, C, N, ldw, ld_out, false, weight, out);
     if (rc) return rc;
-    if (!x || !y || !x1 || !ln_w || !ln_b || !z || !mean || !rstd) return MOBGT_EBADDIM;
+    if (!x || (!y) != (!x1) || !ln_w || !ln_b || !z || !mean || !rstd) return MOBGT_EBADDIM;      // y, x1: both or neither
     if (epilogue == EPI_GELU ? !aux_out : epilogue != EPI_BIAS) return MOBGT_EBADDIM;
     LnGemmParams p = {};
     p.x = x; p.y = reinterpret_cast<const uint16_t*>(y); p.x1 = x1; p.w = ln_w; p.b = ln_b;

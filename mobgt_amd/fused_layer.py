@@ -371,7 +371,11 @@ class _FusedLayerFn(torch.autograd.Function):
             xa = xa_pre.view(R, C)
         elif stock:                                                   # y = self_attention_norm(x)  (model.py:480)
             xa = torch.empty(R, C, dtype=A, device=dev)
-            _k1_fwd(x, None, None, nxw, nxb, xa, None, stats[0], stats[1], R, C, 0.0, seed, sd, salt, act)
+            # (the first layer of a stack: norm + QKV projection as one launch when the own-GEMM path takes the layer -- below)
+            norm_in_gemm = (A == torch.bfloat16 and qkv_pre is None and _OWN_GEMM[0] and ops.layer_gemm_ok(xa, s_wqkv)
+                            and _ln_gemm_ok(C, x, s_wqkv, s_bqkv, nxw, nxb) and _os_ln.environ.get("MOBGT_NO_STOCK_LN_QKV") != "1")
+            if not norm_in_gemm:
+                _k1_fwd(x, None, None, nxw, nxb, xa, None, stats[0], stats[1], R, C, 0.0, seed, sd, salt, act)
         else:
             if A == torch.float32:
                 xa = x.view(R, C)
@@ -386,6 +390,10 @@ class _FusedLayerFn(torch.autograd.Function):
         ctx.own_gemm = own
         if qkv_pre is not None and qkv_pre.dtype == A and qkv_pre.numel() == 3 * R * C and (not stock or chained_in):
             qkv = qkv_pre.view(G, T, 3 * C)                            # written by the previous layer's chain kernel
+        elif stock and not chained_in and norm_in_gemm:
+            # round 4: xa = self_attention_norm(x) and qkv = xa Wqkv^T + b in ONE launch (csrc/lngemm.hip, no residual input)
+            qkv = _ln_gemm_fwd(x, None, None, nxw, nxb, xa, stats[0], stats[1], R, C, 0.0, seed, sd, salt, s_wqkv, s_bqkv,
+                               ops.GEMM_BIAS).view(G, T, 3 * C)
         elif own:
             qkv = ops.layer_gemm(xa, s_wqkv, s_bqkv).view(G, T, 3 * C)
         else:

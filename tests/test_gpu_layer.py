@@ -1027,6 +1027,46 @@ def test_stock_front_as_one_grid_is_bit_identical_to_its_three_launches(monkeypa
 
 
 @pytest.mark.gpu
+def test_stock_first_layer_norm_inside_its_qkv_projection(monkeypatch):
+    """Round 4: the first pre-LN layer's self_attention_norm (model.py:480) as the prologue of its QKV projection
+    (mobgt_ln_gemm_fwd with no residual input) against the two launches (MOBGT_NO_STOCK_LN_QKV=1): the norm's arithmetic is
+    the same code, the product is another kernel (other summation order in front of a bf16 rounding): eval logits to 5e-3 on
+    logits of magnitude ~1, every gradient to 1e-2 relative L2; the launch is taken once per forward."""
+    from mobgt_amd import ops, workloads, synth, fused_layer
+    uni, model, coll = workloads.build("fsq", DEV, seed=1, P=1500, variant="stock", model_overrides=dict(n_layers=2))
+    batch = coll(synth.make_batch_of_trajectories(seed=21, G=8, P=1500, n_user=1080, cat_of_poi=uni.cat_of_poi,
+                                                  n_nodes=[17, 3, 9, 2, 11, 5, 40, 23]))
+    model.eval()
+    calls = []
+    real = fused_layer._ln_gemm_fwd
+    monkeypatch.setattr(fused_layer, "_ln_gemm_fwd", lambda *a, **k: (calls.append(a[1] is None), real(*a, **k))[1])
+    res = {}
+    for off in ("", "1"):
+        if off:
+            monkeypatch.setenv("MOBGT_NO_STOCK_LN_QKV", "1")
+        else:
+            monkeypatch.delenv("MOBGT_NO_STOCK_LN_QKV", raising=False)
+        del calls[:]
+        for p in model.parameters():
+            p.grad = None
+        logits = model(batch)
+        n_calls = list(calls)
+        model.training_step(batch, 0).backward()
+        torch.cuda.synchronize()
+        res[off] = (logits.detach().float().clone(), {n: p.grad.detach().float().clone() for n, p in model.named_parameters()
+                                                      if p.grad is not None}, n_calls)
+    (la, ga, ca), (lb, gb, cb) = res[""], res["1"]
+    assert ca == [True] and cb == [], (ca, cb)
+    assert float((la - lb).abs().max()) < 5e-3 and float(lb.abs().max()) > 0.1
+    assert ga.keys() == gb.keys()
+    for n in ga:
+        if n.endswith("linear_k.bias"):
+            continue                # exactly 0 in exact arithmetic (softmax is shift-invariant over keys): round-off on both sides
+        d = float((ga[n] - gb[n]).norm() / (gb[n].norm() + 1e-30))
+        assert d < 1e-2, (n, d)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("C,G,T,p", [(128, 16, 38, 0.1), (128, 3, 130, 0.1), (128, 1, 17, 0.0), (256, 9, 130, 0.1)])
 def test_preln_layer_chain_kernel_matches_the_separate_launches(C, G, T, p):
     """Round 4: the chain kernels for graphormer/model.py's PRE-LN EncoderLayer (:463-489, the layer BASELINE.json's north_star
