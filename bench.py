@@ -323,7 +323,7 @@ def run_sub_workloads(args):
     for k in list(env):
         if k.startswith("PYTORCH_TUNABLEOP"):          # (each child picks its own file name)
             del env[k]
-    keep = ("value", "ms_per_step", "steps", "warmup", "final_loss", "long_run", "parity", "ms_per_step_chunks")
+    keep = ("value", "ms_per_step", "steps", "warmup", "final_loss", "long_run", "parity", "ms_per_step_chunks", "host_stalls")
     res = {}
     for name, extra in specs.items():
         t0 = time.perf_counter()
@@ -736,17 +736,36 @@ def main():
     n_chunks = 5 if args.steps >= 5 else 1
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(n_chunks + 1)]
     bounds = [round(k * args.steps / n_chunks) for k in range(n_chunks + 1)]
+    # Host hygiene (round 4): right behind the synchronisation the host is not ahead of the GPU, so a pause of the Python
+    # process lands in the measurement in full -- one final run of this round read 1.33 ms/step in its first fifth and 0.577 in
+    # the other four (+30 ms somewhere in 40 steps).  Python's collector is taken out of the timed region (collected before,
+    # switched off inside, as a long-running trainer does after start-up); the host's per-step gaps are recorded (one clock
+    # read per step) and reported as `host_stalls`, so that a pause that still happens (a neighbour on the box's CPU) can be
+    # told from a slow GPU step.
+    import gc
+    gc.collect()
+    gc_was_on = gc.isenabled()
+    gc.disable()
+    host_t = [0.0] * (args.steps + 1)
     t0 = time.perf_counter()
     marks[0].record()
+    host_t[0] = t0
     for i in range(args.steps):
         ts.step(args.warmup + i)
         if i + 1 in bounds[1:]:
             marks[bounds.index(i + 1)].record()
+        host_t[i + 1] = time.perf_counter()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    if gc_was_on:
+        gc.enable()
+    gaps = [(host_t[i + 1] - host_t[i]) * 1e3 for i in range(args.steps)]
+    gap_thr = max(2.0, 5.0 * elapsed * 1e3 / max(args.steps, 1))
+    host_stalls = {"gc": "collected before, disabled inside the timed region", "max_step_gap_ms": round(max(gaps), 3) if gaps else 0.0,
+                   "threshold_ms": round(gap_thr, 2), "gaps_over_threshold": [[i, round(g, 2)] for i, g in enumerate(gaps) if g > gap_thr][:8]}
     chunk_ms = [marks[k].elapsed_time(marks[k + 1]) / max(bounds[k + 1] - bounds[k], 1) for k in range(n_chunks)]
     loss = float(ts.loss_out.item())
     if loss != loss or abs(loss) == float("inf"):
@@ -963,7 +982,7 @@ def main():
                                      "attention_io": "bf16" if io_dt == torch.bfloat16 else "f32",
                                      "gcn_adjacency_product": args.dtype, "library_gemms": args.gemm_dtype if bf16 else "f32",
                                      "accumulate_softmax_layernorm_adamw": "f32"}},
-            "final_loss": loss, "ms_per_step_chunks": [round(c, 4) for c in chunk_ms], "long_run": long_run,
+            "final_loss": loss, "ms_per_step_chunks": [round(c, 4) for c in chunk_ms], "host_stalls": host_stalls, "long_run": long_run,
             "value_with_collate": with_collate,
             "comm_backend": comm_backend, "comm_ranks": comm_ranks, "grad_comm_dtype": args.grad_comm if world > 1 else None, "rccl_ranks": rccl_ranks, "allreduce_exposed_us": exposed_us,
             "parity": parity, "roofline": roof, "roofline_chain": roofc, "roofline_stress": roof5, "roofline_stress_bwd": roof5b,
