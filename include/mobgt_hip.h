@@ -392,6 +392,10 @@ int mobgt_stock_tail_bwd(const float* dy, const void* x, const void* in_degree, 
                          const uint64_t* seed_dev, uint32_t salt, const float* d_hop_table, const float* edge_encoder,
                          const float* edge_dis_encoder, float* d_edge_encoder, float* d_edge_dis_encoder, int D, int n_edge,
                          int H, int fp16_roundtrip, void* stream);
+/* Round 4: dst[i][e] = sum_{k < s[i]} src[i][k * numel[i] + e] for n <= 48 jobs in one launch (f32, numel % 4 == 0, 16-byte
+ * aligned): the sums over the library's split-K partial weight gradients ([s, M, N] from torch.bmm over row slices --
+ * fused_layer._mm_tn_f32), deferred to the end of the backward pass and written into the gradients' sinks. */
+int mobgt_partial_sum_multi(int n, const float* const* src, float* const* dst, const int* s, const int64_t* numel, void* stream);
 /* final_ln on the graph-token rows (model.py:211-217: the reference normalises every token, then reads row 0 of every graph):
  * y [G,C] = LayerNorm(enc[g,0,:]; ln_w, ln_b, eps), mean / rstd [G] kept for the backward (csrc/layer.hip).  enc [G,T,C] f32
  * contiguous, C <= 1024.

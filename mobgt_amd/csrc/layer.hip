@@ -1683,3 +1683,63 @@ extern "C" int mobgt_stock_tail_bwd(const float* dy, const void* x, const void* 
     hipLaunchKernelGGL(stock_tail_kernel, dim3(hop_blocks + tok_blocks), dim3(256), lds, (hipStream_t)stream, p, tok_blocks, hp, hop_blocks);
     return (int)hipGetLastError();
 }
+
+// ------------------------------------------------------------------------------------------------
+// Round 4: the sums over the library's split-K partial products, all of a step's in ONE launch.  Past 4 096 rows the
+// encoder layers' weight gradients are batched GEMMs over row slices, [s, M, N] f32 partial products each followed by a
+// `.sum(0)` launch -- 36 launches of ~5.5 us per S-BIG step for ~4 MB each.  Nothing but the optimizer reads a weight
+// gradient, so the sums wait for the end of the backward pass (ops.flush_deferred_wgrads) and run as one grid that writes
+// the gradients' sinks: dst[e] = sum_k src[k * numel + e].
+namespace {
+constexpr int PSUM_MAX = 48;
+struct PsumJobs {
+    const float* src[PSUM_MAX];
+    float* dst[PSUM_MAX];
+    int64_t numel[PSUM_MAX];                       // per slice, % 4 == 0
+    int s[PSUM_MAX];
+    int first_block[PSUM_MAX + 1];                 // 256 threads x 4 elements per block
+};
+__global__ __launch_bounds__(256) void partial_sum_multi_kernel(const PsumJobs jobs, int njobs) {
+    int job = 0;
+    const int b = (int)blockIdx.x;
+    while (job + 1 < njobs && b >= jobs.first_block[job + 1]) ++job;
+    const int64_t e = ((int64_t)(b - jobs.first_block[job]) * 256 + threadIdx.x) * 4;
+    const int64_t n = jobs.numel[job];
+    if (e >= n) return;
+    const float* src = jobs.src[job] + e;
+    const int S = jobs.s[job];
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    int k = 0;
+    for (; k + 4 <= S; k += 4) {                   // four slices' loads in flight
+        float4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const float4*>(src + (int64_t)(k + u) * n);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
+    }
+    for (; k < S; ++k) {
+        const float4 v = *reinterpret_cast<const float4*>(src + (int64_t)k * n);
+        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+    *reinterpret_cast<float4*>(jobs.dst[job] + e) = acc;
+}
+}  // namespace
+
+extern "C" int mobgt_partial_sum_multi(int n, const float* const* src, float* const* dst, const int* s, const int64_t* numel,
+                                       void* stream) {
+    if (n <= 0) return 0;
+    if (n > PSUM_MAX) return MOBGT_EBADDIM;
+    static PsumJobs jobs;                          // (by value into the launch; 1.3 KB)
+    jobs = PsumJobs{};
+    int blocks = 0;
+    for (int i = 0; i < n; ++i) {
+        if (s[i] <= 0 || numel[i] <= 0 || (numel[i] & 3)) return MOBGT_EBADDIM;
+        if (((uintptr_t)src[i] | (uintptr_t)dst[i]) & 15) return MOBGT_EALIGN;
+        jobs.src[i] = src[i]; jobs.dst[i] = dst[i]; jobs.s[i] = s[i]; jobs.numel[i] = numel[i];
+        jobs.first_block[i] = blocks;
+        blocks += (int)((numel[i] / 4 + 255) / 256);
+    }
+    jobs.first_block[n] = blocks;
+    hipLaunchKernelGGL(partial_sum_multi_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, jobs, n);
+    return (int)hipGetLastError();
+}

@@ -57,7 +57,7 @@ class _WgradBatch:
         """-> the dW tensor (filled when `flush` runs), or an immediately computed one for the library path.
         `sink`: a zero-initialised [M,N] f32 destination (the trainer's flat gradient slice) to accumulate into."""
         if not _wgrad_hip(g.dtype, g.shape[1], x.shape[1], g.shape[0]):
-            return _wgrad(g, x, db)
+            return _wgrad(g, x, db, sink=sink)
         dw = sink[:] if sink is not None else ops.zeros_f32((g.shape[1], x.shape[1]), g.device)
         self.items.append((g, x, dw, db))
         return dw
@@ -95,20 +95,21 @@ class _WgradBatch:
         return False
 
 
-def _wgrad(g, x, db=None):
+def _wgrad(g, x, db=None, sink=None):
     """Weight gradient g^T @ x (fp32) of a Linear layer; bf16 operands go to the split-K MFMA kernel
-    (csrc/wgrad.hip), which also accumulates the bias gradient g.sum(0) into `db` when given."""
+    (csrc/wgrad.hip), which also accumulates the bias gradient g.sum(0) into `db` when given.  `sink` (library path): the
+    gradient's destination in the trainer's flat buffer -- the sum over the split-K partial products may be parked for it."""
     if _wgrad_hip(g.dtype, g.shape[1], x.shape[1], g.shape[0]):
         return ops.linear_wgrad(g, x, db=db)[0]
     if db is not None:
         check(_lib.lib().mobgt_colsum(_p(g), _p(db), g.shape[0], g.shape[1], _DT[g.dtype], _stream()), "mobgt_colsum")
-    return _mm_tn_f32(g, x)
+    return _mm_tn_f32(g, x, sink=sink)
 
 
 _BMM_OUT_DTYPE = [None]
 
 
-def _mm_tn_f32(g, x):
+def _mm_tn_f32(g, x, sink=None):
     """g^T @ x for row-major g [R,M], x [R,N] with an fp32 result (library path: fp32 operands).
     The output is small and K = R is long, so K is split over a batch axis (strided views, no copies):
     a plain GEMM call maps a 192x192 output onto ONE workgroup and leaves the other 255 CUs idle."""
@@ -126,7 +127,11 @@ def _mm_tn_f32(g, x):
             except Exception:
                 _BMM_OUT_DTYPE[0] = False
         if g.dtype != torch.float32 and _BMM_OUT_DTYPE[0]:
-            return torch.bmm(ga, xa, out_dtype=torch.float32).sum(0)    # f32 partial sums: no cast launch, no bf16 rounding
+            part = torch.bmm(ga, xa, out_dtype=torch.float32)           # f32 partial sums: no cast launch, no bf16 rounding
+            # round 4: inside a train step the sum waits for the end of the backward pass, where all of the step's run as ONE
+            # launch into the gradients' sinks (36 `.sum(0)` launches of 5.5 us per S-BIG step)
+            parked = ops.defer_partial_sum(part, sink) if sink is not None else None
+            return parked if parked is not None else part.sum(0)
         part = torch.bmm(ga, xa)
         return part.float().sum(0) if part.dtype != torch.float32 else part.sum(0)
     if g.dtype == torch.float32:

@@ -1883,9 +1883,22 @@ def wgrad_deferral(on):
     """Switch the recording on / off.  Switching off DROPS anything still recorded: the trainer flushes explicitly after a
     successful backward pass, so leftovers exist only when that pass raised -- their buffers belong to a dead graph."""
     _WGRAD_DEFER["items"] = []
-    for k in ("hop", "hop_wide", "stock_tok"):
+    for k in ("hop", "hop_wide", "stock_tok", "psum"):
         _WGRAD_DEFER.pop(k, None)
     _WGRAD_DEFER["on"] = bool(on) and _WGRAD_DEFER_ENV
+
+
+def defer_partial_sum(part, dst):
+    """Park `dst = part.sum(0)` ([s, M, N] f32 split-K partial products of a library batched GEMM; dst: the gradient's sink)
+    until flush_deferred_wgrads, which issues all of a step's as ONE launch (mobgt_partial_sum_multi).  -> a fresh view of dst,
+    or None when the sum cannot be parked (no recording, layouts): the caller then sums now."""
+    if not (_WGRAD_DEFER["on"] and dst is not None and part.dtype == torch.float32 and dst.dtype == torch.float32
+            and part.is_contiguous() and dst.is_contiguous() and part.dim() == 3 and dst.numel() == part[0].numel()
+            and dst.numel() % 4 == 0 and part.data_ptr() % 16 == 0 and dst.data_ptr() % 16 == 0
+            and os.environ.get("MOBGT_NO_PSUM_DEFER") != "1"):
+        return None
+    _WGRAD_DEFER.setdefault("psum", []).append((part, dst))
+    return dst[:]
 
 
 def _wgrad_defer(g, x, g_mask, x_mask, mask_vals, dw, db, db_of_x):
@@ -1898,12 +1911,21 @@ def flush_deferred_wgrads():
         stages = [p_["stage"] for p_ in _TOKEN_PENDING.values()]
         _TOKEN_PENDING.clear()
         _WGRAD_DEFER["items"] = []
-        for k in ("hop", "hop_wide", "stock_tok"):
+        for k in ("hop", "hop_wide", "stock_tok", "psum"):
             _WGRAD_DEFER.pop(k, None)
         raise RuntimeError(f"a parked encoder-input backward chain was never completed (stages {stages}): gradients of this "
                            "step are invalid -- set MOBGT_NO_TOKEN_BWD_CHAIN=1 and report")
     items, _WGRAD_DEFER["items"] = _WGRAD_DEFER["items"], []
     hop = _WGRAD_DEFER.pop("hop", None)
+    psum = _WGRAD_DEFER.pop("psum", None) or []
+    for o in range(0, len(psum), 48):            # the sums over the library's split-K partial weight gradients: one launch
+        part = psum[o:o + 48]
+        n = len(part)
+        check(_lib.lib().mobgt_partial_sum_multi(n, (ctypes.c_void_p * n)(*[p_[0].data_ptr() for p_ in part]),
+                                                 (ctypes.c_void_p * n)(*[p_[1].data_ptr() for p_ in part]),
+                                                 (ctypes.c_int * n)(*[p_[0].shape[0] for p_ in part]),
+                                                 (ctypes.c_int64 * n)(*[p_[1].numel() for p_ in part]), _stream()),
+              "mobgt_partial_sum_multi")
     tok, wide = _WGRAD_DEFER.pop("stock_tok", None), _WGRAD_DEFER.pop("hop_wide", None)
     if tok is not None and wide is not None:     # the stock step's tail: both in one grid
         dtab, ew, dw_, d_ew, d_dw, D, E, rt = wide

@@ -587,6 +587,32 @@ def test_embed_scatter_of_long_batches_run_length_form(C, R, idt):
         np.testing.assert_allclose(dev_t[t].grad.double().cpu().numpy(), want.numpy(), rtol=1e-5, atol=2e-5 * float(want.abs().max()), err_msg=str(t))
 
 
+def test_partial_sum_multi_kernel_matches_sum_over_slices():
+    """mobgt_partial_sum_multi (round 4): dst_i = sum over the s_i slices of src_i, n jobs of different sizes in one launch;
+    against a float64 sum (and bit-equal to a sequential f32 sum in slice order)."""
+    import ctypes
+    from mobgt_amd import _lib
+    gen = torch.Generator().manual_seed(3)
+    jobs = [(1, 64), (3, 1028), (4, 256 * 1024), (7, 4100), (16, 768 * 256), (5, 4)]
+    srcs = [torch.randn(s, n, generator=gen).to(DEV) for s, n in jobs]
+    dsts = [torch.full((n,), float("nan"), device=DEV) for _, n in jobs]
+    k = len(jobs)
+    vp = ctypes.c_void_p
+    _lib.check(_lib.lib().mobgt_partial_sum_multi(k, (vp * k)(*[t.data_ptr() for t in srcs]), (vp * k)(*[t.data_ptr() for t in dsts]),
+                                                  (ctypes.c_int * k)(*[s for s, _ in jobs]), (ctypes.c_int64 * k)(*[n for _, n in jobs]),
+                                                  ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "mobgt_partial_sum_multi")
+    torch.cuda.synchronize()
+    for (s_, n), src, dst in zip(jobs, srcs, dsts):
+        seq = torch.zeros(n, device=DEV)
+        for i in range(s_):
+            seq = seq + src[i]
+        assert torch.equal(dst, seq), (s_, n)
+        np.testing.assert_allclose(dst.double().cpu().numpy(), src.double().sum(0).cpu().numpy(), rtol=0, atol=1e-5)
+    # a slice length that is not a multiple of 4 is refused
+    assert _lib.lib().mobgt_partial_sum_multi(1, (vp * 1)(srcs[0].data_ptr()), (vp * 1)(dsts[0].data_ptr()), (ctypes.c_int * 1)(1),
+                                              (ctypes.c_int64 * 1)(6), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)) != 0
+
+
 @pytest.mark.parametrize("all_hip", [False, True])
 @pytest.mark.parametrize("G,K,V", [(16, 448, 7857), (5, 448, 1030), (1, 64, 2048), (16, 512, 1024), (16, 448, 40001)])
 def test_skinny_linear_matches_torch(G, K, V, all_hip, monkeypatch):

@@ -396,6 +396,51 @@ def test_forward_passengers_of_the_category_gcn_launch_change_nothing(monkeypatc
     assert torch.isfinite(outs[0][0]).all()
 
 
+def test_long_batch_weight_gradients_sum_their_split_k_partials_in_one_launch(monkeypatch):
+    """Round 4: past 4 096 rows the layers' weight gradients are the library's batched GEMMs over row slices + a sum over the
+    slices; inside a train step the sums are parked and run as ONE launch into the gradients' sinks at the flush
+    (mobgt_partial_sum_multi; S-BIG: 36 `.sum(0)` launches per step).  Against the immediate sums (MOBGT_NO_PSUM_DEFER=1) from
+    one fixed state: the layers' weight gradients agree as closely as two runs of one form; the launch happened."""
+    from mobgt_amd import _lib, workloads, synth
+    from mobgt_amd.train import TrainStep
+    uni, model, coll = workloads.build("fsq", DEV, seed=1, P=1500, model_overrides=dict(n_layers=2))
+    batch = coll(synth.make_batch_of_trajectories(seed=5, G=8, P=1500, n_user=1080, cat_of_poi=uni.cat_of_poi, n_nodes=[560] * 8))
+    ts = TrainStep(model, [batch], use_graph=False, seed=1)
+    ts.prepare()
+    seen = []
+    real = _lib.lib()
+
+    class _Spy:
+        def __getattr__(self, name):
+            if name == "mobgt_partial_sum_multi":
+                seen.append(name)
+            return getattr(real, name)
+    monkeypatch.setattr(_lib, "lib", lambda: _Spy())
+    state = _state_of(ts)
+    names = {id(p): n for n, p in model.named_parameters()}
+    pick = [n for n in names.values() if n.startswith("layers.") and n.endswith(".weight") and ("linear_" in n or "layer1" in n or "layer2" in n
+                                                                                                  or "output_layer" in n)]
+    assert len(pick) == 12, pick
+
+    def grads():
+        del seen[:]
+        g, loss = _fixed_step_grads(ts, state)
+        by = {names[id(p)]: v.detach().clone() for p, v in zip(ts.flat.params, ts.flat.views)}
+        return {n: by[n] for n in pick}, loss, len(seen)
+    monkeypatch.delenv("MOBGT_NO_PSUM_DEFER", raising=False)
+    ga, la, na = grads()
+    ga2, _, _ = grads()
+    monkeypatch.setenv("MOBGT_NO_PSUM_DEFER", "1")
+    gb, lb, nb = grads()
+    assert na == 1 and nb == 0, (na, nb)
+    assert abs(la - lb) <= 2e-5 * abs(lb)
+    for n in pick:
+        rep = float((ga2[n] - ga[n]).norm() / (ga[n].norm() + 1e-30))
+        rel = float((gb[n] - ga[n]).norm() / (ga[n].norm() + 1e-30))
+        print("%-44s parked vs immediate relL2 %.2e (two runs of one form %.2e)" % (n, rel, rep))
+        assert float(ga[n].abs().max()) > 0 and rel < max(3 * rep, 3e-3), (n, rel, rep)
+
+
 def test_stock_tail_as_one_grid_gives_the_gradients_of_its_two_launches(monkeypatch):
     """Round 4: the backward of the stock encoder input and the hop table's backward (1 537 edge ids: too wide for the grouped
     weight-gradient launch's hop slot) are parked by the trainer's backward pass and issued as ONE grid at the flush
