@@ -40,7 +40,11 @@ def _wgrad_hip(dtype, M, N, R):
     and 256x1024 at R = 12 560: 48 / 50 us vs 29 us) the library's split-K GEMM with its 64x64+ tiles is the
     faster one; at R <= 4096 the kernel is on par or ahead for the 1024x192 FFN shapes as well (9 vs 10.6 us at
     R = 800, 16.6 vs 17.9 at R = 2432) and saves the reduce launch."""
-    return dtype == torch.bfloat16 and M % 2 == 0 and N % 2 == 0 and (M * N <= 131072 or R <= 4096)
+    return dtype == torch.bfloat16 and M % 2 == 0 and N % 2 == 0 and (M * N <= _WGRAD_HIP_MN[0] or R <= 4096)
+
+
+import os as _os_wg
+_WGRAD_HIP_MN = [int(_os_wg.environ.get("MOBGT_WGRAD_HIP_MN", "131072"))]      # outputs up to which long batches stay on csrc/wgrad.hip
 
 
 class _WgradBatch:
