@@ -43,6 +43,9 @@ def parse():
     ap.add_argument("--no-overlap", action="store_true", help="N > 1: one all-reduce after the whole backward instead of two overlapped buckets")
     ap.add_argument("--grad-comm", choices=["fp32", "bf16"], default="fp32",
                     help="N > 1: dtype the gradient buckets are all-reduced in (bf16 halves the bytes; DESIGN 5)")
+    ap.add_argument("--force-comm", action="store_true",
+                    help="N = 1 only: a process group of ONE rank over RCCL, the step in its data-parallel form (layer-wise buckets, "
+                         "all-reduces on RCCL's stream beside the replays): what the multi-rank structure costs without a wire")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true", help="skip the eval-step comparison with the oracle")
     ap.add_argument("--no-stress", action="store_true", help="skip the c5-shape attention roofline measurements")
@@ -677,6 +680,12 @@ def oracle_parity(model, batches, uni, n_layers):
 
 def main():
     args = ARGS
+    # ONE line on stdout, whatever else the process loads: RCCL prints a version banner (five lines) on stdout when its
+    # communicator comes up (seen on the GPU box, round 4), TunableOp and the profiler children have their own chatter.  The real
+    # stdout is kept aside for the JSON line; file descriptor 1 points at stderr from here on (C-level writers included).
+    sys.stdout.flush()
+    real_stdout = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -689,7 +698,16 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    force_comm = bool(args.force_comm) and world == 1
+    ddp = world > 1 or force_comm
+    if force_comm:
+        import socket
+        with socket.socket() as so:
+            so.bind(("127.0.0.1", 0))
+            port = so.getsockname()[1]
+        os.environ.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MOBGT_FORCE_COMM="1")
+        os.environ.setdefault("MASTER_PORT", str(port))
+    if ddp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if shared:
             dist.init_process_group("gloo")
@@ -729,7 +747,7 @@ def main():
     for i in range(args.warmup):
         ts.step(i)
     torch.cuda.synchronize()
-    if world > 1:
+    if ddp:
         dist.barrier()
     torch.cuda.synchronize()
     # the timed region: EXACTLY args.steps steps; events after every fifth of them give the spread without a host sync
@@ -756,7 +774,7 @@ def main():
             marks[bounds.index(i + 1)].record()
         host_t[i + 1] = time.perf_counter()
     torch.cuda.synchronize()
-    if world > 1:
+    if ddp:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
@@ -777,23 +795,23 @@ def main():
     if args.steps < 100:
         k_long = 200
         torch.cuda.synchronize()
-        if world > 1:
+        if ddp:
             dist.barrier()
         t1 = time.perf_counter()
         for i in range(k_long):
             ts.step(args.warmup + args.steps + i)
         torch.cuda.synchronize()
-        if world > 1:
+        if ddp:
             dist.barrier()
         torch.cuda.synchronize()
         el = time.perf_counter() - t1
-        if world > 1:
+        if ddp:
             tl = torch.tensor([el], device=dev, dtype=torch.float64)
             dist.all_reduce(tl, op=dist.ReduceOp.MAX)
             el = float(tl.item())
         long_run = dict(steps=k_long, ms_per_step=el / k_long * 1e3, value=args.batch_size * world * k_long / el)
     rccl_ranks, comm_ranks, comm_backend, exposed_us = None, None, None, None
-    if world > 1:
+    if ddp:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -834,7 +852,7 @@ def main():
         # (not for `big`: its raw format -- the reference's pickles hold DENSE N x N int64 count matrices, gen_pickles.py:820-832 --
         # is 16 x 784^2 x 8 B = 79 MB of host arrays per batch, and packing them takes the host 140 ms per step: a statement
         # about numpy, not about this path)
-        if world == 1 and not args.no_loop and not args.no_graph and not stock and name != "big":
+        if world == 1 and not force_comm and not args.no_loop and not args.no_graph and not stock and name != "big":
             try:
                 with_collate = time_epoch_loop(model, coll, name, uni, args)
             except Exception as e:                       # never lose the headline line over the secondary figure
@@ -859,7 +877,7 @@ def main():
         # --no-live-pmc): the figures of profiles/attn_pmc.json, labelled as such.
         mode_shape = max(uniq, key=lambda sh: (used.count(sh), sh[1]))
         pmc_live, pmc_file = None, {}
-        if bf16 and io_dt == torch.bfloat16 and not args.no_live_pmc and world == 1:
+        if bf16 and io_dt == torch.bfloat16 and not args.no_live_pmc and world == 1 and not force_comm:
             want = [(mode_shape[0], mode_shape[1], d)]
             if not args.no_stress and d != 32:
                 want.append((16, 785, 32))
@@ -899,7 +917,7 @@ def main():
                     pass
             cl = all(g * t <= 16 * 128 for g, t in used)             # (rows up to which the chain kernels run their cluster form)
             pm, pm_src = None, None
-            if C == 192 and not args.no_live_pmc and world == 1:
+            if C == 192 and not args.no_live_pmc and world == 1 and not force_comm:
                 mode_rows = max(rows, key=lambda r: sum(1 for g, t in used if g * t == r))
                 pm = live_chain_pmc(mode_rows, keep_dir=os.path.join(ROOT, "gpurun_out", "pmc_live"))
                 pm_src = "live: rocprofv3 --pmc child passes of this run (tools/chain_pmc.py, stand-alone launches behind a 64 MB filler)"
@@ -966,7 +984,7 @@ def main():
             cpu = (cpu_baseline_stock(model, batches, args, n_layers) if stock
                    else cpu_baseline(model, batches, [t for _, _, t in mine], uni, args, n_layers))
         subs = None
-        if world == 1 and name == "fsq" and not stock and not args.no_sub and not args.no_graph and not args.unfused and bf16:
+        if world == 1 and not force_comm and name == "fsq" and not stock and not args.no_sub and not args.no_graph and not args.unfused and bf16:
             subs = run_sub_workloads(args)
         G_total = args.batch_size * world
         out = {
@@ -984,12 +1002,13 @@ def main():
                                      "accumulate_softmax_layernorm_adamw": "f32"}},
             "final_loss": loss, "ms_per_step_chunks": [round(c, 4) for c in chunk_ms], "host_stalls": host_stalls, "long_run": long_run,
             "value_with_collate": with_collate,
-            "comm_backend": comm_backend, "comm_ranks": comm_ranks, "grad_comm_dtype": args.grad_comm if world > 1 else None, "rccl_ranks": rccl_ranks, "allreduce_exposed_us": exposed_us,
+            "comm_backend": comm_backend, "comm_ranks": comm_ranks, "grad_comm_dtype": args.grad_comm if ddp else None, "forced_comm": force_comm or None, "rccl_ranks": rccl_ranks, "allreduce_exposed_us": exposed_us,
             "parity": parity, "roofline": roof, "roofline_chain": roofc, "roofline_stress": roof5, "roofline_stress_bwd": roof5b,
             "cpu_baseline": cpu, "workloads": subs,
         }
-        print(json.dumps(out))
-    if world > 1:
+        real_stdout.write(json.dumps(out) + "\n")
+        real_stdout.flush()
+    if ddp:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -317,17 +317,21 @@ class TrainStep:
         self.graphs = {}
         self._loss_ref = torch.zeros((), device=dev)          # the loss tensor of the step that ran last
         self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        # MOBGT_FORCE_COMM=1 (tests): a process group of ONE rank takes the data-parallel path -- buckets, exchange on the
+        # collective's stream, bf16 exchange buffer -- so that the RCCL ("nccl") branch executes on a one-GPU box
+        self.force_comm = (os.environ.get("MOBGT_FORCE_COMM") == "1" and dist.is_available() and dist.is_initialized())
+        self.ddp = self.world > 1 or self.force_comm
         # Data parallel: split the backward at the encoder output so that the head bucket's all-reduce (61 % of the
         # bytes, ready after ~20 kernels) runs on RCCL's stream while the rest of the backward is still executing.
         # (overlap="force": the two-phase path at world size 1 as well -- tests)
-        self.overlap = bool(overlap and use_graph and (self.world > 1 or overlap == "force") and self.n_head > 0
+        self.overlap = bool(overlap and use_graph and (self.ddp or overlap == "force") and self.n_head > 0
                             and hasattr(model, "_enc_out"))
         self.graphs_b, self._g_enc, self._loss_slots = {}, {}, {}
         self._plan_buckets()
         self.comm = True        # False: skip the gradient exchange (bench.py measures the exposed all-reduce time that way)
         self._prepared = False
         self.comm_buf = (torch.empty(self.flat.flat.numel(), dtype=grad_comm_dtype, device=dev)
-                         if (grad_comm_dtype is not None and self.world > 1) else None)
+                         if (grad_comm_dtype is not None and self.ddp) else None)
         self.check_layout_across_ranks()
 
     def _plan_buckets(self):
@@ -616,7 +620,7 @@ class TrainStep:
         # Single process, no all-reduce between backward and optimizer: the optimizer rides at the end of every batch's
         # graph -- one graph launch per step instead of two (the boundary between two replayed graphs idles the device
         # for ~8.7 us: `tools/prof_gaps.sh`).  Every warm-up has run by now, so this second capture only records.
-        self.fused_opt = (not self.overlap and self.world == 1           # (never with ranks: `comm` may be toggled later)
+        self.fused_opt = (not self.overlap and not self.ddp              # (never with ranks: `comm` may be toggled later)
                           and os.environ.get("MOBGT_FUSED_OPT_GRAPH", "1") != "0")
         if self.fused_opt:
             for i in range(len(self.batches)):
@@ -645,7 +649,7 @@ class TrainStep:
         """Workgroups that gave up waiting for their cluster partners / at a grid barrier since the last check ({} = none;
         synchronises the device).  The steps since then may have trained on garbage gradients: "raise" -> RuntimeError."""
         f = ops.peer_wait_faults(reset=True)
-        if self.world > 1:                              # every rank must take the same decision
+        if self.ddp:                                    # every rank must take the same decision
             t = torch.tensor([float(sum(f.values()))], device=self.device)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             if float(t.item()) > 0 and not f:
@@ -716,7 +720,7 @@ class TrainStep:
         if self.overlap:
             j = i % len(self.batches)
             na = self.n_head_elems
-            comm = self.world > 1 and self.comm
+            comm = self.ddp and self.comm
             self.graphs[j].replay()
             cb = self.comm_buf
             # element ranges completed by phase A and by each part of phase B: every one is all-reduced (RCCL's stream) as soon
@@ -745,13 +749,15 @@ class TrainStep:
                 self.graphs[i % len(self.batches)].replay()
             else:
                 self._fwd_bwd(self.batches[i % len(self.batches)])
-            if self.world > 1 and self.comm:
+            if self.ddp and self.comm:
                 if self.comm_buf is not None:
                     self.comm_buf.copy_(self.flat.flat)
                     dist.all_reduce(self.comm_buf, op=dist.ReduceOp.SUM)
                     torch.mul(self.comm_buf, 1.0 / self.world, out=self.flat.flat)
-                else:
+                elif self.world > 1:
                     self.flat.all_reduce_mean()
+                else:                                  # (one forced rank: the collective itself, no division)
+                    dist.all_reduce(self.flat.flat, op=dist.ReduceOp.SUM)
         if self.use_graph:
             if not getattr(self, "fused_opt", False):
                 self.opt_graph.replay()
