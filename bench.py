@@ -836,6 +836,8 @@ def main():
         tt = torch.tensor(times, device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         exposed_us = float((tt[0] - tt[1]).item()) * 1e6
+        if getattr(ts, "one_graph", False):           # (the exchange is part of the step graph: `ts.comm` switches nothing off)
+            exposed_us = None
 
     if rank == 0:
         m = w["model"]
@@ -1002,7 +1004,7 @@ def main():
                                      "accumulate_softmax_layernorm_adamw": "f32"}},
             "final_loss": loss, "ms_per_step_chunks": [round(c, 4) for c in chunk_ms], "host_stalls": host_stalls, "long_run": long_run,
             "value_with_collate": with_collate,
-            "comm_backend": comm_backend, "comm_ranks": comm_ranks, "grad_comm_dtype": args.grad_comm if ddp else None, "forced_comm": force_comm or None, "rccl_ranks": rccl_ranks, "allreduce_exposed_us": exposed_us,
+            "comm_backend": comm_backend, "comm_ranks": comm_ranks, "grad_comm_dtype": args.grad_comm if ddp else None, "forced_comm": force_comm or None, "ddp_one_graph": bool(getattr(ts, "one_graph", False)) if ddp else None, "rccl_ranks": rccl_ranks, "allreduce_exposed_us": exposed_us,
             "parity": parity, "roofline": roof, "roofline_chain": roofc, "roofline_stress": roof5, "roofline_stress_bwd": roof5b,
             "cpu_baseline": cpu, "workloads": subs,
         }

@@ -328,6 +328,13 @@ class TrainStep:
                             and hasattr(model, "_enc_out"))
         self.graphs_b, self._g_enc, self._loss_slots = {}, {}, {}
         self._plan_buckets()
+        # MOBGT_DDP_ONE_GRAPH=1 (opt-in, end of round 4): the data-parallel step as ONE graph per batch -- the buckets' all-reduces
+        # are CAPTURED on a second stream that forks from / joins the step's inside the graph (RCCL collectives are capturable:
+        # tools/dbg/r4_rccl_capture_probe.py), instead of being issued by the host between four graph replays.  Measured with one
+        # rank only (DESIGN 5 g); the default stays the host-issued form until a node has run it.
+        self.one_graph = bool(self.overlap and self.ddp and os.environ.get("MOBGT_DDP_ONE_GRAPH") == "1"
+                              and dist.get_backend() == "nccl")             # (a gloo all-reduce is host work: not capturable)
+        self.comm_stream = torch.cuda.Stream(device=dev) if self.one_graph else None
         self.comm = True        # False: skip the gradient exchange (bench.py measures the exposed all-reduce time that way)
         self._prepared = False
         self.comm_buf = (torch.empty(self.flat.flat.numel(), dtype=grad_comm_dtype, device=dev)
@@ -572,6 +579,26 @@ class TrainStep:
             with torch.cuda.graph(g, pool=self.pool if os.environ.get("MOBGT_SHARED_POOL") else None, stream=self.stream):
                 self._fwd_bwd(batch, slot=i)
             return g
+        if self.one_graph:
+            na = self.n_head_elems
+            bounds = [(0, na)] + ([(e0, e1) for _, _, _, e0, e1 in self.parts] if self.parts else [(na, self.flat.flat.numel())])
+            with torch.cuda.graph(g, stream=self.stream):
+                self._phase_a(batch, i)
+                self._exchange_captured(*bounds[0])
+                if self.parts:
+                    for s in range(len(self.parts)):
+                        self._phase_b_part(i, s)
+                        self._exchange_captured(*bounds[s + 1])
+                else:
+                    self._phase_b(i)
+                    self._exchange_captured(*bounds[1])
+                torch.cuda.current_stream().wait_stream(self.comm_stream)          # join: every bucket has been exchanged
+                if self.comm_buf is not None:
+                    torch.mul(self.comm_buf, 1.0 / self.world, out=self.flat.flat)
+                elif self.world > 1:
+                    self.flat.flat.div_(self.world)
+            self.graphs_b[i] = []
+            return g
         # two graphs over ONE autograd graph: phase B is captured right after phase A and replays its kernels on the
         # activations phase A's replay leaves at the same addresses (A's private pool; nothing else writes there)
         with torch.cuda.graph(g, stream=self.stream):
@@ -590,6 +617,18 @@ class TrainStep:
             self._phase_b(i)
         self.graphs_b[i] = [gb]
         return g
+
+    def _exchange_captured(self, e0, e1):
+        """(inside a capture) all-reduce of gradient elements [e0, e1) on the collective's stream, forked from the step's here."""
+        if e1 <= e0:
+            return
+        self.comm_stream.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(self.comm_stream):
+            buf = self.flat.flat
+            if self.comm_buf is not None:
+                self.comm_buf[e0:e1].copy_(self.flat.flat[e0:e1])
+                buf = self.comm_buf
+            dist.all_reduce(buf[e0:e1], op=dist.ReduceOp.SUM)
 
     def prepare(self):
         """Capture one forward/backward graph per batch and one optimizer graph."""
@@ -717,7 +756,9 @@ class TrainStep:
         """One optimizer step on pre-collated batch i (model_fqandtoyo.py:1434-1478 + optimizer + scheduler)."""
         if self.use_graph:
             self._loss_ref = self._loss_slots[i % len(self.batches)]
-        if self.overlap:
+        if self.overlap and self.one_graph:
+            self.graphs[i % len(self.batches)].replay()         # (forward, backward parts and their captured exchanges)
+        elif self.overlap:
             j = i % len(self.batches)
             na = self.n_head_elems
             comm = self.ddp and self.comm

@@ -47,7 +47,7 @@ def main():
     torch.cuda.synchronize()
     torch.save(dict(losses=losses, params=ts.flat_params.tensor.detach().cpu(), grads=ts.flat.flat.cpu(),
                     exp_avg=ts.exp_avg.cpu(), exp_avg_sq=ts.exp_avg_sq.cpu(), overlap=ts.overlap, backend=dist.get_backend(),
-                    forced=ts.force_comm, parts=len(ts.parts), comm_dtype=str(ts.comm_buf.dtype) if ts.comm_buf is not None else None,
+                    forced=ts.force_comm, one_graph=ts.one_graph, parts=len(ts.parts), comm_dtype=str(ts.comm_buf.dtype) if ts.comm_buf is not None else None,
                     shadow=None if ts.shadow_flat is None else ts.shadow_flat.float().cpu()),
                os.path.join(out_dir, f"rank{rank}.pt"))
     dist.barrier()

@@ -152,11 +152,21 @@ def test_rccl_branch_executes_on_one_gpu(tmp_path):
     over one rank changes nothing: losses / gradients must be those of the same worker WITHOUT the forced exchange, up to what
     two runs of one step differ by (f32 atomics in front of bf16 rounding points) -- bf16 exchange: up to bf16 rounding."""
     runs = {}
-    for tag, env in (("plain", {}), ("fp32", {"MOBGT_FORCE_COMM": "1"}), ("bf16", {"MOBGT_FORCE_COMM": "1", "MOBGT_TEST_GRAD_COMM": "bf16"})):
+    for tag, env in (("plain", {}), ("fp32", {"MOBGT_FORCE_COMM": "1"}), ("bf16", {"MOBGT_FORCE_COMM": "1", "MOBGT_TEST_GRAD_COMM": "bf16"}),
+                     ("one", {"MOBGT_FORCE_COMM": "1", "MOBGT_DDP_ONE_GRAPH": "1"}),
+                     ("one16", {"MOBGT_FORCE_COMM": "1", "MOBGT_DDP_ONE_GRAPH": "1", "MOBGT_TEST_GRAD_COMM": "bf16"})):
         d = tmp_path / tag
         d.mkdir()
         runs[tag] = _run_one_rank(d, 3, env)
     a, b, c = runs["plain"], runs["fp32"], runs["bf16"]
+    # opt-in: the same step as ONE graph per batch with the buckets' all-reduces captured inside it (MOBGT_DDP_ONE_GRAPH=1)
+    for tag in ("one", "one16"):
+        r = runs[tag]
+        assert r["backend"] == "nccl" and r["forced"] and r["overlap"] and r["one_graph"]
+        assert all(np.isfinite(r["losses"]))
+        np.testing.assert_allclose(r["losses"], a["losses"], rtol=2e-2)
+        assert float((r["grads"] - a["grads"]).norm() / a["grads"].norm()) < 5e-2
+    assert not b["one_graph"]
     print("backend", b["backend"], "overlap", b["overlap"], "parts", b["parts"], "losses", a["losses"], b["losses"], c["losses"])
     assert a["backend"] == b["backend"] == c["backend"] == "nccl"
     assert not a["forced"] and not a["overlap"]
