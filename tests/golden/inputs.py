@@ -37,3 +37,35 @@ def encoder_case(variant, C, T, G):
     bias = rand_bias(rng, G, 8, T, n_real)
     gy = rng.standard_normal((G, T, C)).astype(np.float32)
     return seed, x, bias, gy, n_real
+
+
+# ------------------------------------------------------------------ G8: the real Gowalla universe (make_golden_real.py)
+def real_distance(poi_table):
+    """The stand-in for `poi_data/gowalla_distance.pkl` the G8 fixture was generated with: (P+1) x (P+1) float64 km,
+    row / column 0 = the pad POI, haversine of the POIs' real coordinates rounded to 1 m (the rounding makes the matrix
+    bit-reproducible across hosts; same expression as make_golden_real.real_distance)."""
+    from mobgt_amd.synth import haversine_km
+    lat, lon = poi_table[:, 2], poi_table[:, 3]
+    d = np.round(haversine_km(lat[:, None], lon[:, None], lat[None, :], lon[None, :]), 3)
+    out = np.zeros((len(lat) + 1, len(lat) + 1), dtype=np.float64)
+    out[1:, 1:] = d
+    return out
+
+
+def real_universe(z):
+    """g8_gowalla_real.npz -> synth.Universe of the real Gowalla POIs (P 3 679, 253 categories)."""
+    from mobgt_amd.synth import Universe
+    poi = z["uni/poi_table"]
+    P = poi.shape[0]
+    bits = np.unpackbits(z["uni/graph_dist_triu_bits"])[: P * (P - 1) // 2]
+    gd = np.zeros((P, P), dtype=np.float32)
+    gd[np.triu_indices(P, 1)] = bits
+    gd = gd + gd.T
+    return Universe(P=P, n_cat=int(len(np.unique(poi[:, 4]))), n_user=1080, poi_table=poi,
+                    graph_adj=np.zeros((1, 1), dtype=np.float32), graph_dist=gd, graph_cat=z["uni/graph_cat"],
+                    distance=real_distance(poi), poi_columns=tuple(str(c) for c in z["uni/poi_columns"]))
+
+
+def real_trajs(z, tag):
+    return [{k: z[f"{tag}/traj{i}/{k}"] for k in ("node_name", "edge_type", "target", "time", "time_normal", "user", "cat")}
+            for i in range(int(z[f"{tag}/trajcount"]))]

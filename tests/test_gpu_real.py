@@ -1,0 +1,107 @@
+"""Parity on REAL Gowalla data on the MI355X (golden G8, tests/golden/make_golden_real.py): the reference's own outputs for
+eight real trajectories (N = 1, 2, 5, 17, 94, 8, 12, 30) and the 329-node one on the real POI universe (P 3 679, 253
+categories, 653 distance bins), gowalla_nevda fq Graphormer at BASELINE configs[2] sizes.
+
+Tolerances: index tensors (SPD, paths, edge features, degrees, poi_pos bins) bit-exact.  Model outputs: the attention core
+rounds its MFMA operands to bf16 (fp32 accumulate) -> logits at 2e-2 absolute / relative against the reference's fp32
+values, loss 1e-3, gradients as tests/test_gpu_model.py::_check_grads."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from inputs import real_universe, real_trajs                       # noqa: E402
+from mobgt_amd import algos, synth, wrapper                      # noqa: E402
+from mobgt_amd.data import DeviceCollator, make_bin_table       # noqa: E402
+from test_oracle_model import seeded_state                        # noqa: E402
+from test_oracle_real import check_batch                          # noqa: E402
+from test_gpu_model import _check_grads                           # noqa: E402
+
+DEV = "cuda"
+
+
+@pytest.fixture(scope="module")
+def g8(golden_dir):
+    z = np.load(os.path.join(golden_dir, "g8_gowalla_real.npz"))
+    uni = real_universe(z)
+    num_bins, edges, table = make_bin_table(uni.distance)
+    assert num_bins == int(z["num_bins"]) and np.array_equal(edges, z["bin_edges"])
+    return z, uni, table
+
+
+def test_real_graphs_device_algos_and_preprocess_item_g8(g8):
+    """algos.floyd_warshall / gen_edge_input (csrc/spd.hip) and wrapper.preprocess_item on the real graphs, bit-exact."""
+    z = g8[0]
+    for tag in ("a", "b"):
+        for i, t in enumerate(real_trajs(z, tag)):
+            p = f"{tag}/item{i}/"
+            M, path = algos.floyd_warshall(t["edge_type"] != 0)
+            assert np.array_equal(M, z[p + "M"]) and np.array_equal(path, z[p + "path"]), p
+            it = wrapper.preprocess_item(synth.trajectory_to_item(t, idx=i))
+            assert np.array_equal(it.rel_pos.numpy(), z[p + "rel_pos"]), p
+            assert tuple(it.edge_input.shape) == tuple(z[p + "edge_input_shape"]), p
+            ei = it.edge_input[:, :, :20].numpy()
+            assert np.array_equal(ei if ei.shape[0] <= 100 else ei[::7], z[p + "edge_input20"]), p
+            assert it.edge_input.numpy().astype(np.float64).sum() == float(z[p + "edge_input_sum"]), p
+            for f in ("in_degree", "out_degree", "x", "user"):
+                assert np.array_equal(getattr(it, f).numpy(), z[p + f]), (p, f)
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_device_collator_matches_reference_on_real_trajectories_g8(g8, tag):
+    z, _, table = g8
+    coll = DeviceCollator(DEV, bin_table=table, multi_hop_max_dist=20, rel_pos_max=1024)
+    b = coll(real_trajs(z, tag))
+    torch.cuda.synchronize()
+    check_batch(z, tag, b, to_np=lambda t: t.cpu().numpy())
+
+
+@pytest.fixture(scope="module")
+def real_model(g8):
+    from mobgt_amd.model_fqandtoyo import Graphormer
+    z, uni, _ = g8
+    m = Graphormer(n_layers=6, num_heads=8, hidden_dim=128, dropout_rate=0.1, intput_dropout_rate=0.1, weight_decay=0.01,
+                   ffn_dim=1024, dataset_name="gowalla_nevda", warmup_updates=10, tot_updates=100, peak_lr=2e-4, end_lr=1e-9,
+                   edge_type="multi_hop", multi_hop_max_dist=20, attention_dropout_rate=0.1, universe=uni)
+    names = [str(n) for n in z["param_names"]]
+    shapes = [eval(str(s)) for s in z["param_shapes"]]
+    sd = {k: v.detach() for k, v in seeded_state(list(zip(names, shapes)), int(z["seed"])).items()}
+    m.load_state_dict(sd, strict=True)                 # the reference's parameter names and shapes on the real universe
+    return m.to(DEV).eval()
+
+
+def test_fq_graphormer_on_real_universe_logits_loss_grads_g8(g8, real_model):
+    z, _, table = g8
+    m = real_model
+    coll = DeviceCollator(DEV, bin_table=table, multi_hop_max_dist=20, rel_pos_max=1024)
+    b = coll(real_trajs(z, "a"))
+    bias = m.assemble_bias(b).dense().cpu().numpy()[:, :, ::7]
+    ref = z["a/bias_rows7"]
+    fin = np.isfinite(ref)
+    assert np.array_equal(np.isfinite(bias), fin)
+    np.testing.assert_allclose(bias[fin], ref[fin], rtol=1e-5, atol=1e-4)
+    out = m(b)
+    np.testing.assert_allclose(out[0].detach().cpu().numpy(), z["a/logits"], rtol=2e-2, atol=2e-2)
+    np.testing.assert_allclose(out[1].detach().cpu().numpy(), z["a/cat_logits"], rtol=2e-2, atol=2e-2)
+    loss = m.training_step(b, 0)                        # eval() mode, like the golden (no dropout)
+    np.testing.assert_allclose(loss.item(), z["a/loss"], rtol=1e-3)
+    loss.backward()
+    _check_grads(m, z, "a")
+
+
+def test_fq_graphormer_329_node_real_trajectory_logits_g8(g8, real_model):
+    z, _, table = g8
+    coll = DeviceCollator(DEV, bin_table=table, multi_hop_max_dist=20, rel_pos_max=1024)
+    b = coll(real_trajs(z, "b"))
+    with torch.no_grad():
+        bias = real_model.assemble_bias(b).dense()[:, :1, ::31].cpu().numpy()
+        out = real_model(b)
+    ref = z["b/bias_rows31_h0"]
+    fin = np.isfinite(ref)
+    assert np.array_equal(np.isfinite(bias), fin)
+    np.testing.assert_allclose(bias[fin], ref[fin], rtol=1e-5, atol=1e-4)
+    np.testing.assert_allclose(out[0].cpu().numpy(), z["b/logits"], rtol=2e-2, atol=2e-2)
+    np.testing.assert_allclose(out[1].cpu().numpy(), z["b/cat_logits"], rtol=2e-2, atol=2e-2)
