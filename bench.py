@@ -726,15 +726,20 @@ def main():
                                        fused=not args.unfused, P=args.pois, variant=args.variant)
     stock = args.variant == "stock"
     broadcast_parameters(model)
-    # Length-bucketed sharding (SURVEY §8e hazard): every rank draws the SAME pool of world x n_batches batches,
-    # the pool is ordered by padded size and dealt round-robin, so that at each synchronous step all ranks work
-    # on batches of neighbouring size (per-rank work is still n_batches x 16 trajectories: weak scaling).
+    # Length-balanced sharding (SURVEY §8e hazard): every rank draws the SAME pool of world x n_batches batches.  One rank: the
+    # pool's batches as they are.  More ranks: the pool's trajectories are dealt by `data.balanced_batches` -- the dealing
+    # `train.EpochLoop` uses -- so that at each synchronous step all ranks work on batches of the same or the neighbouring shape
+    # bucket (per-rank work is still n_batches x 16 trajectories: weak scaling).
     raw = workloads.make_pool(name, n_batches * world, args.batch_size, uni)
-    pool = sorted(((max(len(t["node_name"]) for t in trajs), i, trajs) for i, trajs in enumerate(raw)), key=lambda e: (e[0], e[1]))
-    order = sorted(range(n_batches), key=lambda j: pool[j * world][1])        # size-mixed order over time
-    mine = [pool[j * world + rank] for j in order]                            # same slot order on all ranks
+    if world > 1:
+        from mobgt_amd.data import balanced_batches
+        flat = [t for trajs in raw for t in trajs]
+        steps = balanced_batches([len(t["node_name"]) for t in flat], world, args.batch_size, epoch=0, seed=args.seed)
+        mine = [[flat[i] for i in s[rank]] for s in steps[:n_batches]]
+    else:
+        mine = raw
     batches, shapes = [], []
-    for _, _, trajs in mine:
+    for trajs in mine:
         b = coll(trajs)
         batches.append(b)
         shapes.append((len(b), b.x.shape[1] + 1))
@@ -810,6 +815,12 @@ def main():
             dist.all_reduce(tl, op=dist.ReduceOp.MAX)
             el = float(tl.item())
         long_run = dict(steps=k_long, ms_per_step=el / k_long * 1e3, value=args.batch_size * world * k_long / el)
+    # peer waits that gave up (csrc/chain.hip WS_FAULT & co.): a step whose cluster lost co-residency carries on with garbage
+    # sums -- a number measured over such steps is not a measurement.  Polled once, behind the timed region.
+    peer_faults = ts.check_faults(on_fault="return")
+    if peer_faults:
+        raise SystemExit(f"bench.py: workgroups gave up waiting for their peers during the timed steps {peer_faults} -- the gradients "
+                         "of those steps are invalid and so is the timing")
     rccl_ranks, comm_ranks, comm_backend, exposed_us = None, None, None, None
     if ddp:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)

@@ -53,6 +53,9 @@ const char* mobgt_build_info(void);
  *             key j; ld_bias % 64 == 0, ld_bias >= roundup(T,64) (rows are fetched as whole 64-key segments);
  *             columns >= T are ignored by the forward / dQ pass and must hold -inf in bias_t (the pack kernels write them).
  *             -inf entries are honoured (probability exactly 0).
+ * out_lo    : bf16 I/O only (ignored for f32; may be NULL): [G, T, H*d] bf16, row stride ldo -- the rounding residual
+ *             O - bf16(O) of `out`.  The backward's delta = rowsum(dO * O) needs O beyond bf16: its error is 2^-9 of |dO||O|,
+ *             un-cancelled, against a dS whose rows sum to zero (csrc/attn.hip header, "consistent softmax").
  * lse       : [G, H, T] f32 out, natural-log sum of exp of the biased scores (needed by bwd).
  * scale     : q is multiplied by it BEFORE the dot product (reference: att_size ** -0.5).
  * dropout_p : attention dropout on the probabilities (model.py:451); 0 disables.  The keep mask is
@@ -61,7 +64,7 @@ const char* mobgt_build_info(void);
  *             captured graph advance the seed without re-capture).
  */
 int mobgt_attn_bias_fwd(const void* q, const void* k, const void* v, const void* bias,
-                        void* out, float* lse,
+                        void* out, void* out_lo, float* lse,
                         int G, int H, int T, int d,
                         int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, int64_t ld_bias,
                         float scale, float dropout_p, uint64_t seed, const uint64_t* seed_dev,
@@ -70,6 +73,8 @@ int mobgt_attn_bias_fwd(const void* q, const void* k, const void* v, const void*
 /* Backward of the above (autograd of model.py:442-453).
  * bias_t : [G, H, T, ld_bias] the same bias with query/key transposed (bias_t[g,h,j,i] = bias[g,h,i,j]),
  *          produced by mobgt_build_bias / mobgt_bias_pack; read by the dK/dV pass.
+ * out, out_lo : what the forward wrote (out_lo: bf16 I/O only, may be NULL -- the gradients of q / k then carry the
+ *          un-cancelled rounding of `out`).
  * dout   : [G, T, H*d] (ldo), gradient of `out`.
  * dq,dk,dv : [G, T, H*d] `io_dtype`, row strides lddq/lddk/lddv; fully overwritten.
  * dbias  : [G, H, T, ld_bias] or NULL; columns >= T are left untouched.  The bias is shared by all L layers
@@ -80,10 +85,11 @@ int mobgt_attn_bias_fwd(const void* q, const void* k, const void* v, const void*
  *                                  ignored); mobgt_build_bias_bwd sums the L slices.  A quarter of the f32
  *                                  path's HBM traffic per layer; dS is rounded to bf16 exactly as it is for
  *                                  the dQ / dK contractions.
- * delta  : [G, H, T] f32 workspace (rowsum(dout*out)), written by the first pass.
+ * delta  : [G, H, T] f32 workspace (kept in the signature; since round 5 every pass forms its own rowsum(dout*out) from the
+ *          bf16 dout values its dP product multiplies).
  */
 int mobgt_attn_bias_bwd(const void* q, const void* k, const void* v, const void* bias, const void* bias_t,
-                        const void* out, const float* lse, const void* dout,
+                        const void* out, const void* out_lo, const float* lse, const void* dout,
                         void* dq, void* dk, void* dv, void* dbias, float* delta,
                         int G, int H, int T, int d,
                         int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo,
@@ -97,7 +103,7 @@ int mobgt_attn_bias_bwd(const void* q, const void* k, const void* v, const void*
  * reproducible from run to run, unlike the two passes).  Any other configuration, dq_acc = null or MOBGT_ATTN_TWO_PASS=1 in the
  * environment: exactly mobgt_attn_bias_bwd.  Replaces the autograd of graphormer/model.py:436-455 like that function. */
 int mobgt_attn_bias_bwd_fused(const void* q, const void* k, const void* v, const void* bias, const void* bias_t,
-                        const void* out, const float* lse, const void* dout,
+                        const void* out, const void* out_lo, const float* lse, const void* dout,
                         void* dq, void* dk, void* dv, void* dbias, float* delta,
                         int G, int H, int T, int d,
                         int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo,
@@ -108,7 +114,7 @@ int mobgt_attn_bias_bwd_fused(const void* q, const void* k, const void* v, const
  * all zeros again when the call's last launch has run; there is then no launch in front of the pass -- rowsum(dO * O) is formed
  * inside it from `out` and `dout` -- and `delta` is not written. */
 int mobgt_attn_bias_bwd_fused_z(const void* q, const void* k, const void* v, const void* bias, const void* bias_t,
-                                const void* out, const float* lse, const void* dout, void* dq, void* dk, void* dv,
+                                const void* out, const void* out_lo, const float* lse, const void* dout, void* dq, void* dk, void* dv,
                                 void* dbias, float* delta, int G, int H, int T, int d, int64_t ldq, int64_t ldk,
                                 int64_t ldv, int64_t ldo, int64_t lddq, int64_t lddk, int64_t lddv, int64_t ld_bias,
                                 float scale, float dropout_p, uint64_t seed, const uint64_t* seed_dev,

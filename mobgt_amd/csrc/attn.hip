@@ -13,6 +13,22 @@
 //   * P (and dS in the backward) is already the B operand of the following P.V product, no LDS trip.
 // K and V^T (fwd), K/V/K^T (dQ pass), Q/dO and their transposes (dK/dV pass) are staged per 64-row
 // chunk in LDS as bf16; fp32 inputs are rounded to bf16 while staging, accumulation is fp32.
+//
+// Consistent softmax (round 5).  The MFMA operands are bf16, so the probabilities that multiply V are P_b = bf16(2^(x - M))
+// -- and a backward pass that re-forms P in f32, or takes rowsum(dO O) from differently rounded dO / O, computes
+// dS_j = P_j (dP_j - delta) with a delta that is NOT sum_j P_j dP_j of the P and dP it uses.  The difference is 2^-9 of
+// |dO||O| per row, un-cancelled, while dQ = sum_j dS_j K_j and dK rely on sum_j dS_j = 0 to cancel the component all key rows
+// share (MobGT: the user embedding fused into every node of a trajectory): on real Gowalla trajectories the q / k weight
+// gradients of the top layers came out 10-50 % off (tests/test_gpu_real.py, golden G8).  Now every pass works with the SAME
+// probabilities and a delta that is exactly their dP-weighted mean:
+//   * the running maximum M is an INTEGER in the log2 domain (ceil), so the online rescale 2^(M_old - M_new) is exact and
+//     bf16 rounding commutes with it: P_b,j = bf16(2^(x_j - M)) for any integer M up to an exact power of two;
+//   * the row sum l is the sum of the ROUNDED probabilities (v_dot2c_f32_bf16 with packed ones on the MFMA operand words), so
+//     O = sum_j P_b,j V_b,j / sum_j P_b,j is a convex combination and sum_j P_j = 1 in the backward;
+//   * the backward takes M' = rint(lse log2e), re-forms the forward's P_b,j = bf16(2^(x_j - M')) bit for bit (times the exact
+//     2^(M - M')) and normalises with 2^(M' - lse log2e);
+//   * delta = dO_b . O with the very bf16 dO values the dP product multiplies and O in full precision: f32 O, or bf16 O plus
+//     the bf16 residual `out_lo` the forward writes beside it (2 more bytes per element: 3.5 % of the c5 traffic).
 #include <type_traits>
 
 #include "common.h"
@@ -40,27 +56,9 @@ namespace {
 #ifndef ATTN_DEADSKIP
 #define ATTN_DEADSKIP 1       // waves whose 32 rows all lie beyond T skip the tile loop
 #endif
-#ifndef ATTN_BWD_DEADSKIP
-#define ATTN_BWD_DEADSKIP 0   // the same in the two backward passes
-#endif
-#ifndef ATTN_BWD_EVEN
-#define ATTN_BWD_EVEN 0       // backward passes: deal the 32-row tiles out evenly over more workgroups (choose_nq)
-#endif
-#ifndef ATTN_BWD_CLAMPED
-#define ATTN_BWD_CLAMPED 1    // backward passes: staging loads with clamped rows instead of behind branches (exact wait counts)
-#endif
-#ifndef ATTN_LATE_PREFETCH
-#define ATTN_LATE_PREFETCH 0  // prologue: the loads the SECOND chunk needs (bias super-tile 1, K / V chunk 1) are requested behind the first barrier
-#endif
-#ifndef ATTN_PK_F32
-#define ATTN_PK_F32 0
-#endif
-#ifndef ATTN_EARLY_MASK
-#define ATTN_EARLY_MASK 0     // forward: the tile's dropout masks are computed in the shadow of the QK^T products (they do not depend on S)
-#endif
-#ifndef ATTN_PACKED_DROP
-#define ATTN_PACKED_DROP 1    // forward: dropout as a mask on the packed probabilities
-#endif
+// (round 4 measured and round 5 removed: dead-wave skipping and even tile dealing in the backward passes, a late prologue prefetch,
+//  packed-f32 arithmetic around the exponentials, dropout masks in the shadow of the QK^T products -- all inside the +-2 us
+//  run-to-run band at c5: profiles/r4_attn_ab.txt)
 
 constexpr int KC = 64;        // keys (or queries, in the dK/dV pass) staged per LDS chunk = 2 MFMA tiles
 constexpr int ROWP = 40;      // row-major tile row pitch in bf16 (32 + 8: odd multiple of 16 B)
@@ -74,6 +72,8 @@ struct AttnParams {
     void* dbias;              // f32 (read-modify-write when `accumulate`) or bf16 (write-only slice of this layer)
     int dbias_bf16;
     float* delta;
+    void* o_lo;               // forward, bf16 I/O: bf16 residual O - bf16(O) beside `o` (same layout), or null
+    const void* out_lo;       // backward, bf16 I/O: that residual, or null (delta then sees the rounded O only)
     float* dq_acc;            // one-pass backward: [G, T, H * d] f32, the dQ sums (zero-filled by a launch in front unless dq_acc_zero)
     int dq_acc_zero;          // the caller hands the accumulator over ZERO (it is zero again when the call's last launch has run)
     int G, H, T;
@@ -222,6 +222,24 @@ __device__ __forceinline__ float xhalf_sum(float v) {        // v + partner's v
     return lo + hi;
 }
 
+// bf16 pairs as they sit in an MFMA operand word (even element low): packing, the f32 values of a packed pair, and the sum of a
+// pair added to an f32 accumulator in ONE instruction (v_dot2c_f32_bf16 against packed ones: products with 1.0 are exact).
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pack2(float a, float b) {
+    const bf16x2_t v = {(bf16_t)a, (bf16_t)b};
+    return __builtin_bit_cast(uint32_t, v);
+}
+__device__ __forceinline__ float add_pair(uint32_t w, float acc) {
+    return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, w), __builtin_bit_cast(bf16x2_t, 0x3f803f80u), acc, false);
+}
+// the backward's view of a row's forward statistics: M' = rint(lse log2 e) (any integer serves: bf16 rounding commutes with
+// powers of two) and 1 / l' = 2^(M' - lse log2 e), l' = the sum of the row's bf16(2^(x - M'))
+__device__ __forceinline__ void row_norm(float lse, float& mq, float& il) {
+    const float lse2 = lse * MOBGT_LOG2E;
+    mq = __builtin_rintf(lse2);
+    il = fast_exp2(mq - lse2);
+}
+
 // ---- bias tiles: coalesced from HBM, re-distributed through a wave-private LDS image ------------------------------------------
 // The MFMA C operand wants lane (n, hi) to hold 16 contiguous keys of query row n.  Loaded that way (rounds 1-2) a wave's
 // load instruction touched 32 different rows -- 64 separate 16-byte pieces in 32 different 128-byte lines: the texture
@@ -349,7 +367,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const AttnParams p) {
     if (PIPE) {
 #pragma unroll
         for (int j = 0; j < BiasStage<TB>::NI; ++j) ring[1].off[j] = ring[0].off[j];
-        if (!ATTN_LATE_PREFETCH) ring[1].load(brows, min(1, nchunk - 1));
+        ring[1].load(brows, min(1, nchunk - 1));
     }
 
     uint32_t rowh = 0;
@@ -359,7 +377,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const AttnParams p) {
         rowh = dropout_row_hash(seed, (uint32_t)(gh * T + qc));
     }
 
-    float m = MOBGT_NEG_BIG, l = 0.f;
+    float m = MOBGT_NEG_BIG, l = 0.f;                  // m: running maximum in the LOG2 domain, integer-valued (header: consistent softmax)
     f32x16 o;
 #pragma unroll
     for (int i = 0; i < 16; ++i) o[i] = 0.f;
@@ -376,10 +394,8 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const AttnParams p) {
     if (PIPE) {
         kreg.template store<true, false, true>(1.f, Ksb[0], nullptr);
         vreg.template store<false, true, true>(1.f, nullptr, Vtb[0]);
-        if (!ATTN_LATE_PREFETCH) {
-            kreg.load_clamped(K, p.ldk, min(1, nchunk - 1) * KC, T);
-            vreg.load_clamped(V, p.ldv, min(1, nchunk - 1) * KC, T);
-        }
+        kreg.load_clamped(K, p.ldk, min(1, nchunk - 1) * KC, T);
+        vreg.load_clamped(V, p.ldv, min(1, nchunk - 1) * KC, T);
     } else {
         Slab<D, TQ, NT>::template direct<true, false, true>(K, p.ldk, 0, T, 1.f, Ksb[0], nullptr);
         Slab<D, TQ, NT>::template direct<false, true, true>(V, p.ldv, 0, T, 1.f, nullptr, Vtb[0]);
@@ -395,12 +411,6 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const AttnParams p) {
         qf[ks] = pack8(v);
     }
     __syncthreads();
-    if (PIPE && ATTN_LATE_PREFETCH) {
-        // (everything the first tile needs has arrived: only now the second chunk's share of the launch-wide cold burst)
-        ring[1].load(brows, min(1, nchunk - 1));
-        kreg.load_clamped(K, p.ldk, min(1, nchunk - 1) * KC, T);
-        vreg.load_clamped(V, p.ldv, min(1, nchunk - 1) * KC, T);
-    }
 
 #ifdef ATTN_STAMP
     uint32_t st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -438,102 +448,41 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const AttnParams p) {
                 const bf16x8 a = *reinterpret_cast<const bf16x8*>(&Ks[t * 32 + kappa(n)][ks * 16 + 8 * hi]);
                 s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, qf[ks], s, 0, 0, 0);
             }
-            uint32_t emask[8];
-            if (DROP && ATTN_EARLY_MASK && ATTN_PACKED_DROP) {
-                const uint32_t hb0 = attn_drop_block(seed, rowh, (uint32_t)((key0 >> 4) + hi));
-#pragma unroll
-                for (int k = 0; k < 8; ++k) emask[k] = attn_drop_keep_mask2(attn_drop_word(hb0, attn_drop_mult(k)), p.thr_s);
-                __builtin_amdgcn_sched_barrier(0);
-            }
 #ifdef ATTN_STAMP_FINE
             { float d_; asm volatile("v_mov_b32 %0, %1" : "=v"(d_) : "v"(s[15])); asm volatile("" :: "v"(d_)); }
             STAMP(1);                                      // bias tile from LDS + QK^T result available
 #endif
-            // online softmax over this lane's 16 keys + the partner half's 16
+            // online softmax over this lane's 16 keys + the partner half's 16; the running maximum is kept as an INTEGER in the
+            // log2 domain, so the rescale below is an exact power of two (header: consistent softmax)
             float tmax = s[0];
 #pragma unroll
             for (int i = 1; i < 16; ++i) tmax = fmaxf(tmax, s[i]);
             tmax = xhalf_max(tmax);
-            const float m_new = fmaxf(m, tmax);
+            const float m_new = fmaxf(m, __builtin_ceilf(tmax * MOBGT_LOG2E));
             if (__any(m_new > m)) {
-                const float alpha = fast_exp2((m - m_new) * MOBGT_LOG2E);
-#if ATTN_PK_F32
-                {
-                    typedef float f32x2_ __attribute__((ext_vector_type(2)));
-                    const f32x2_ av = {alpha, alpha};
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) {
-                        f32x2_ ov = {o[2 * i], o[2 * i + 1]};
-                        ov *= av;
-                        o[2 * i] = ov.x;
-                        o[2 * i + 1] = ov.y;
-                    }
-                }
-#else
+                const float alpha = fast_exp2(m - m_new);
 #pragma unroll
                 for (int i = 0; i < 16; ++i) o[i] *= alpha;
-#endif
                 l *= alpha;
                 m = m_new;
             }
-            const float ms = m * MOBGT_LOG2E;
-            float pr[16];
-#if ATTN_PK_F32
-            {
-                // (round 4) the exponent's argument and the row sum as PACKED f32 operations (v_pk_fma_f32 / v_pk_add_f32: two
-                // lanes' worth per issue slot; the build runs with -fno-slp-vectorize, so the compiler forms none by itself)
-                typedef float f32x2_ __attribute__((ext_vector_type(2)));
-                const f32x2_ l2e = {MOBGT_LOG2E, MOBGT_LOG2E}, nms = {-ms, -ms};
-                f32x2_ lacc = {0.f, 0.f};
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    const f32x2_ sv = {s[2 * i], s[2 * i + 1]};
-                    const f32x2_ a = __builtin_elementwise_fma(sv, l2e, nms);
-                    f32x2_ e;
-                    e.x = fast_exp2(a.x);
-                    e.y = fast_exp2(a.y);
-                    pr[2 * i] = e.x;
-                    pr[2 * i + 1] = e.y;
-                    lacc += e;
-                }
-                l += lacc.x + lacc.y;
-            }
-#else
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                pr[i] = fast_exp2(fmaf(s[i], MOBGT_LOG2E, -ms));
-                l += pr[i];
-            }
-#endif
             // dropout rule v2 (common.h; this lane's 16 keys = one block), applied to the PACKED probabilities: a pair's word w
             // carries two 16-bit uniforms in the order the pair is packed (even key low), so the pair's keep mask is two packed
             // 16-bit instructions -- saturating (thr - 1) - w, arithmetic shift by 15 -- and one AND on the packed pair, instead
             // of a sign extension, two compares and two selects on the f32 values.  1/(1-p) is applied once, to the output row.
             uint32_t hb = 0;
-            if (DROP && !ATTN_EARLY_MASK) hb = attn_drop_block(seed, rowh, (uint32_t)((key0 >> 4) + hi));
-#if !ATTN_PACKED_DROP
-            if (DROP) {
-#pragma unroll
-                for (int m = 0; m < 8; ++m) {
-                    const uint32_t w = attn_drop_word(hb, attn_drop_mult(m));
-                    pr[2 * m] = attn_drop_keep_even(w, p.thr_s) ? pr[2 * m] : 0.f;
-                    pr[2 * m + 1] = attn_drop_keep_odd(w, p.thr_s) ? pr[2 * m + 1] : 0.f;
-                }
-            }
-#endif
+            if (DROP) hb = attn_drop_block(seed, rowh, (uint32_t)((key0 >> 4) + hi));
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
-                float pv[8];
+                u32x4 pw;
 #pragma unroll
-                for (int j = 0; j < 8; ++j) pv[j] = pr[8 * s2 + j];
-                bf16x8 pb = pack8(pv);
-                if (DROP && ATTN_PACKED_DROP) {
-                    u32x4 pw = __builtin_bit_cast(u32x4, pb);
-#pragma unroll
-                    for (int k = 0; k < 4; ++k)
-                        pw[k] &= ATTN_EARLY_MASK ? emask[4 * s2 + k] : attn_drop_keep_mask2(attn_drop_word(hb, attn_drop_mult(4 * s2 + k)), p.thr_s);
-                    pb = __builtin_bit_cast(bf16x8, pw);
+                for (int k = 0; k < 4; ++k) {
+                    const int i = 8 * s2 + 2 * k;
+                    pw[k] = pack2(fast_exp2(fmaf(s[i], MOBGT_LOG2E, -m)), fast_exp2(fmaf(s[i + 1], MOBGT_LOG2E, -m)));
+                    l = add_pair(pw[k], l);                // the row sum of the ROUNDED probabilities, before dropout
+                    if (DROP) pw[k] &= attn_drop_keep_mask2(attn_drop_word(hb, attn_drop_mult(4 * s2 + k)), p.thr_s);
                 }
+                const bf16x8 pb = __builtin_bit_cast(bf16x8, pw);
                 const bf16x8 a = *reinterpret_cast<const bf16x8*>(&Vt[kappa(n)][t * 32 + 16 * hi + 8 * s2]);
                 o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, pb, o, 0, 0, 0);
             }
@@ -578,7 +527,25 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const AttnParams p) {
                 store8(O + 8 * j, v);
             }
         }
-        if (hi == 0) p.lse[(int64_t)gh * T + my_q] = m + logf(ltot);
+        if (hi == 0) p.lse[(int64_t)gh * T + my_q] = m * MOBGT_LN2 + logf(ltot);
+        if constexpr (std::is_same<TQ, bf16_t>::value) {
+            // bf16 output: the rounding residual beside it, for the backward's delta = dO . O (header: consistent softmax)
+            if (p.o_lo) {
+                bf16_t* OL = reinterpret_cast<bf16_t*>(p.o_lo) + ((int64_t)g * T + my_q) * p.ldo + h * D + 16 * hi;
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    if (16 * hi + 8 * j < D) {
+                        float v[8];
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) {
+                            const float x = o[8 * j + i] * inv;
+                            v[i] = x - (float)(bf16_t)x;
+                        }
+                        store8(OL + 8 * j, v);
+                    }
+                }
+            }
+        }
     }
 #ifdef ATTN_STAMP
     STAMP(6);                                              // epilogue
@@ -622,7 +589,6 @@ __device__ __forceinline__ void attn_bwd_dq_body(const AttnParams& p, const int 
     const TQ* O = reinterpret_cast<const TQ*>(p.out) + (int64_t)g * T * p.ldo + h * D;
     const TQ* dO = reinterpret_cast<const TQ*>(p.dout) + (int64_t)g * T * p.ldo + h * D;
     __shared__ __attribute__((aligned(16))) unsigned char Bs[NW][BiasStage<TB>::BYTES];
-    const bool wave_live = !ATTN_BWD_DEADSKIP || q0w < T;
     const TB* brows = reinterpret_cast<const TB*>(p.bias) + ((int64_t)gh * T + min(q0w, T - 1)) * p.ld_bias;
     const int brow_max = max(T - 1 - q0w, 0);
     unsigned char* bimg = Bs[wave];
@@ -648,22 +614,33 @@ __device__ __forceinline__ void attn_bwd_dq_body(const AttnParams& p, const int 
         }
     };
 
+    // Consistent softmax (header): this row's probabilities are re-formed as the forward's bf16 values P_b,j = bf16(2^(x_j - M')),
+    // their normalisation 1 / l' rides on the dO fragment (dO~ = bf16(dO / l'): the B operand of the dP product), and
+    // delta = dO~ . O -- with the ROUNDED dO~ and O in full precision -- is then exactly sum_j P_b,j dP_j / sum_j P_b,j.
+    float mq, il;
+    row_norm(p.lse_in[(int64_t)gh * T + qc], mq, il);
     bf16x8 qf[KS], dof[KS];
     float dpart = 0.f;
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
         const bool ok = q_ok && (ks * 16 + 8 * hi < D);
         load_frag(Q + (int64_t)qc * p.ldq + ks * 16 + 8 * hi, ok, p.scale, qf[ks]);
-        float dov[8], ov[8];
-        load_frag(dO + (int64_t)qc * p.ldo + ks * 16 + 8 * hi, ok, 1.f, dof[ks], &dov);
+        load_frag(dO + (int64_t)qc * p.ldo + ks * 16 + 8 * hi, ok, il, dof[ks]);
+        float ov[8];
         bf16x8 unused;
         load_frag(O + (int64_t)qc * p.ldo + ks * 16 + 8 * hi, ok, 1.f, unused, &ov);
+        if constexpr (std::is_same<TQ, bf16_t>::value) {
+            if (p.out_lo && ok) {
+                float lo[8];
+                load8(reinterpret_cast<const bf16_t*>(p.out_lo) + ((int64_t)g * T + qc) * p.ldo + h * D + ks * 16 + 8 * hi, lo);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) dpart = fmaf(dov[i], ov[i], dpart);
+                for (int i = 0; i < 8; ++i) ov[i] += lo[i];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) dpart = fmaf((float)dof[ks][i], ov[i], dpart);
     }
-    const float delta = xhalf_sum(dpart);                          // rowsum(dO * O)
-    if (q_ok && hi == 0) p.delta[(int64_t)gh * T + my_q] = delta;
-    const float lse2 = p.lse_in[(int64_t)gh * T + qc] * MOBGT_LOG2E;
+    const float delta = xhalf_sum(dpart);                          // rowsum(dO~ * O)
 
     uint32_t rowh = 0;
     uint64_t seed = 0;
@@ -686,16 +663,15 @@ __device__ __forceinline__ void attn_bwd_dq_body(const AttnParams& p, const int 
     if (PIPE) {
 #pragma unroll
         for (int j = 0; j < BiasStage<TB>::NI; ++j) ring[1].off[j] = ring[0].off[j];
-        if (!ATTN_LATE_PREFETCH) ring[1].load(brows, min(1, nchunk - 1));
+        ring[1].load(brows, min(1, nchunk - 1));
     }
     Slab<D, TQ, PIPE ? NT : KC * 4> kreg, vreg;
     if (PIPE) {
-        if (ATTN_BWD_CLAMPED) { kreg.load_clamped(K, p.ldk, 0, T); vreg.load_clamped(V, p.ldv, 0, T); }
-        else { kreg.load(K, p.ldk, 0, T); vreg.load(V, p.ldv, 0, T); }
-        if (ATTN_LATE_PREFETCH) ring[1].load(brows, min(1, nchunk - 1));       // (behind the first chunk's K / V rows: those are waited for first)
+        kreg.load_clamped(K, p.ldk, 0, T);
+        vreg.load_clamped(V, p.ldv, 0, T);
     }
     auto chunk = [&](const int c, BiasStage<TB>& bst) {
-        if (wave_live) bst.park(bimg, lane);                                   // (see the forward kernel)
+        bst.park(bimg, lane);                                                  // (see the forward kernel)
         if (PIPE) bst.load(brows, min(c + 2, nchunk - 1));                    // (never behind a branch: see the forward)
         __syncthreads();
         if (PIPE) {
@@ -706,14 +682,10 @@ __device__ __forceinline__ void attn_bwd_dq_body(const AttnParams& p, const int 
             Slab<D, TQ, NT>::template direct<true, false, true>(V, p.ldv, c * KC, T, 1.f, Vs, nullptr);
         }
         __syncthreads();
-        if (PIPE && ATTN_BWD_CLAMPED) {                                       // (unconditional, clamped: see the forward)
+        if (PIPE) {                                                            // (unconditional, clamped: see the forward)
             kreg.load_clamped(K, p.ldk, min(c + 1, nchunk - 1) * KC, T);
             vreg.load_clamped(V, p.ldv, min(c + 1, nchunk - 1) * KC, T);
-        } else if (PIPE && c + 1 < nchunk) {
-            kreg.load(K, p.ldk, (c + 1) * KC, T);
-            vreg.load(V, p.ldv, (c + 1) * KC, T);
         }
-        if (wave_live)                                                         // (see the forward kernel)
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             const int key0 = c * KC + t * 32;
@@ -741,16 +713,18 @@ __device__ __forceinline__ void attn_bwd_dq_body(const AttnParams& p, const int 
 #pragma unroll
             for (int m = 0; m < 8; ++m) {
                 const uint32_t w = DROP ? attn_drop_word(hb, attn_drop_mult(m)) : 0u;
+                // the forward's probabilities, bit for bit (up to the exact 2^(M - M')): rounded to bf16 as a pair, read back as f32
+                const uint32_t pw = pack2(fast_exp2(fmaf(s[2 * m], MOBGT_LOG2E, -mq)), fast_exp2(fmaf(s[2 * m + 1], MOBGT_LOG2E, -mq)));
 #pragma unroll
                 for (int u = 0; u < 2; ++u) {
                     const int i = 2 * m + u;
-                    const float pr = fast_exp2(fmaf(s[i], MOBGT_LOG2E, -lse2));
+                    const float pr = u ? bf16_hi(pw) : bf16_lo(pw);
                     float dd = DROP ? fmaf(dp[i], p.inv_keep, -delta) : dp[i] - delta;
                     if (DROP) {
                         const bool keep = u ? attn_drop_keep_odd(w, p.thr_s) : attn_drop_keep_even(w, p.thr_s);
                         dd = keep ? dd : -delta;
                     }
-                    ds[i] = pr * dd;
+                    ds[i] = pr * dd;                       // (1 / l' is inside dp and delta: it rode in on the dO fragment)
                 }
             }
             if (dbrow && q_ok) {
@@ -785,7 +759,7 @@ __device__ __forceinline__ void attn_bwd_dq_body(const AttnParams& p, const int 
                 dq = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, db, dq, 0, 0, 0);
             }
         }
-        if (wave_live) flush_dbias(c);
+        flush_dbias(c);
     };
     for (int c = 0; c < nchunk; c += 2) {
         chunk(c, ring[0]);
@@ -814,9 +788,10 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(const AttnParams p
 // ======================================================================= backward, pass 2: dK + dV
 // One wave = 32 keys (on the lanes), sweep over queries; reads the TRANSPOSED bias so that a lane's
 // 16 accumulator registers are again 16 contiguous elements (queries q0+16*hi .. +15 of its key row).
-// OWN_DELTA: rowsum(dO * O) is recomputed here instead of read from the dQ pass's `delta` output, so that the two
-// passes can share ONE launch (attn_bwd_both_kernel).
-template <int D, typename TQ, typename TB, int NW, bool DROP, bool OWN_DELTA>
+// Row statistics (header: consistent softmax): per query of the chunk M' (log2 domain), 1 / l' and delta = dO_b . O with the bf16 dO
+// values this pass stages and O in full precision -- formed HERE, by the thread that carries the row (the dQ pass folds 1 / l' into
+// its dO fragment before rounding, so its delta belongs to slightly different dP values; each pass is consistent in itself).
+template <int D, typename TQ, typename TB, int NW, bool DROP>
 __device__ __forceinline__ void attn_bwd_dkv_body(const AttnParams& p, const int bid, const int nwg) {
     constexpr int KS = (D + 15) / 16;
     constexpr int NT = NW * 64;
@@ -824,8 +799,9 @@ __device__ __forceinline__ void attn_bwd_dkv_body(const AttnParams& p, const int
     __shared__ __attribute__((aligned(16))) bf16_t dOs[KC][ROWP];
     __shared__ __attribute__((aligned(16))) bf16_t Qt[32][COLP];
     __shared__ __attribute__((aligned(16))) bf16_t dOt[32][COLP];
-    __shared__ __attribute__((aligned(16))) float lseS[KC];
-    __shared__ __attribute__((aligned(16))) float dlS[KC];
+    __shared__ __attribute__((aligned(16))) float lseS[KC];          // M' of the chunk's queries
+    __shared__ __attribute__((aligned(16))) float ilS[KC];           // 1 / l'
+    __shared__ __attribute__((aligned(16))) float dlS[KC];           // delta
     // dropout rule v2 (common.h): the w words of the chunk's 2 tiles x this workgroup's 2*NW key blocks x 8 key pairs x
     // 32 query rows, built cooperatively while the chunk is staged (one block hash + 8 mads per entry, 2 entries per thread)
     // (rows padded to 36 words: at 32 every row starts on bank 0 or 32 and a lane group's 16 rows collide 8 ways)
@@ -848,7 +824,6 @@ __device__ __forceinline__ void attn_bwd_dkv_body(const AttnParams& p, const int
     const TQ* V = reinterpret_cast<const TQ*>(p.v) + (int64_t)g * T * p.ldv + h * D;
     const TQ* dO = reinterpret_cast<const TQ*>(p.dout) + (int64_t)g * T * p.ldo + h * D;
     __shared__ __attribute__((aligned(16))) unsigned char Bs[NW][BiasStage<TB>::BYTES];
-    const bool wave_live = !ATTN_BWD_DEADSKIP || k0w < T;
     const TB* brows = reinterpret_cast<const TB*>(p.bias_t) + ((int64_t)gh * T + min(k0w, T - 1)) * p.ld_bias;
     const int brow_max = max(T - 1 - k0w, 0);
     unsigned char* bimg = Bs[wave];
@@ -880,42 +855,37 @@ __device__ __forceinline__ void attn_bwd_dkv_body(const AttnParams& p, const int
     bst.load(brows, 0);
     Slab<D, TQ, PIPE ? NT : KC * 4> qreg, doreg;
     if (PIPE) {
-        if (ATTN_BWD_CLAMPED) { qreg.load_clamped(Q, p.ldq, 0, T); doreg.load_clamped(dO, p.ldo, 0, T); }
-        else { qreg.load(Q, p.ldq, 0, T); doreg.load(dO, p.ldo, 0, T); }
+        qreg.load_clamped(Q, p.ldq, 0, T);
+        doreg.load_clamped(dO, p.ldo, 0, T);
     }
     float lse_r = 0.f, dl_r = 0.f;                         // thread it < KC carries query it of the chunk (NT >= KC)
     auto load_rowstats = [&](const int c) {
-        const int q = c * KC + (int)threadIdx.x;
-        const bool ok = threadIdx.x < KC && q < T;
-        if (ATTN_BWD_CLAMPED && !OWN_DELTA) {
-            // (every thread loads, from a clamped row: no branch around the loads; rows >= T have P = 0, any finite value serves)
-            const int64_t qi = (int64_t)gh * T + min(c * KC + (int)(threadIdx.x & (KC - 1)), T - 1);
-            lse_r = p.lse_in[qi];
-            dl_r = p.delta[qi];
-            return;
-        }
-        lse_r = ok ? p.lse_in[(int64_t)gh * T + q] : 0.f;
-        if (!OWN_DELTA) {
-            dl_r = ok ? p.delta[(int64_t)gh * T + q] : 0.f;
-        } else {
-            float d = 0.f;
-            if (ok) {
-                const TQ* O = reinterpret_cast<const TQ*>(p.out) + (int64_t)g * T * p.ldo + h * D;
+        // (every thread loads, from a clamped row: no branch around the loads; rows >= T have P = 0, any finite value serves)
+        const int q = min(c * KC + (int)(threadIdx.x & (KC - 1)), T - 1);
+        lse_r = p.lse_in[(int64_t)gh * T + q];
+        const TQ* O = reinterpret_cast<const TQ*>(p.out) + (int64_t)g * T * p.ldo + h * D;
+        float d = 0.f;
 #pragma unroll
-                for (int e = 0; e < D; e += 8) {
-                    float a[8], b[8];
-                    load8(dO + (int64_t)q * p.ldo + e, a);
-                    load8(O + (int64_t)q * p.ldo + e, b);
+        for (int e = 0; e < D; e += 8) {
+            float a[8], b[8];
+            load8(dO + (int64_t)q * p.ldo + e, a);
+            load8(O + (int64_t)q * p.ldo + e, b);
+            if constexpr (std::is_same<TQ, bf16_t>::value) {
+                if (p.out_lo) {
+                    float lo[8];
+                    load8(reinterpret_cast<const bf16_t*>(p.out_lo) + ((int64_t)g * T + q) * p.ldo + h * D + e, lo);
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) d = fmaf(a[j], b[j], d);
+                    for (int j = 0; j < 8; ++j) b[j] += lo[j];
                 }
             }
-            dl_r = d;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) d = fmaf((float)(bf16_t)a[j], b[j], d);       // the bf16 dO the dP product multiplies
         }
+        dl_r = d;
     };
     load_rowstats(0);
     auto chunk = [&](const int c) {
-        if (wave_live) bst.park(bimg, lane);                                   // (see the forward kernel)
+        bst.park(bimg, lane);                                                  // (see the forward kernel)
         if (PIPE) bst.load(brows, min(c + 1, nchunk - 1));                    // (never behind a branch: see the forward)
         __syncthreads();
         if (PIPE) {
@@ -926,10 +896,11 @@ __device__ __forceinline__ void attn_bwd_dkv_body(const AttnParams& p, const int
             Slab<D, TQ, NT>::template direct<true, true, true>(dO, p.ldo, c * KC, T, 1.f, dOs, dOt);
         }
         if (threadIdx.x < KC) {
-            const int q = c * KC + (int)threadIdx.x;
-            lseS[threadIdx.x] = lse_r * MOBGT_LOG2E;
+            float mq, il;
+            row_norm(lse_r, mq, il);
+            lseS[threadIdx.x] = mq;
+            ilS[threadIdx.x] = il;
             dlS[threadIdx.x] = dl_r;
-            (void)q;
         }
         if (DROP) {
             for (int e = threadIdx.x; e < 2 * NW * 2 * 32; e += NT) {
@@ -942,18 +913,11 @@ __device__ __forceinline__ void attn_bwd_dkv_body(const AttnParams& p, const int
             }
         }
         __syncthreads();
-        if (ATTN_BWD_CLAMPED && PIPE && !OWN_DELTA) {                        // (unconditional, clamped: see the forward)
+        if (PIPE) {                                                            // (unconditional, clamped: see the forward)
             qreg.load_clamped(Q, p.ldq, min(c + 1, nchunk - 1) * KC, T);
             doreg.load_clamped(dO, p.ldo, min(c + 1, nchunk - 1) * KC, T);
-            load_rowstats(min(c + 1, nchunk - 1));
-        } else if (c + 1 < nchunk) {
-            if (PIPE) {
-                qreg.load(Q, p.ldq, (c + 1) * KC, T);
-                doreg.load(dO, p.ldo, (c + 1) * KC, T);
-            }
-            load_rowstats(c + 1);
         }
-        if (wave_live)                                                         // (see the forward kernel)
+        load_rowstats(min(c + 1, nchunk - 1));
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             const int q0 = c * KC + t * 32;
@@ -975,15 +939,17 @@ __device__ __forceinline__ void attn_bwd_dkv_body(const AttnParams& p, const int
             // half starts: ~50 fewer live registers than all sixteen at once)
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
-                float lse8[8], dl8[8];
+                float lse8[8], il8[8], dl8[8];
                 uint32_t w8[8];
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
                     const int r0 = t * 32 + 16 * hi + 8 * s2 + 4 * j;
                     const float4 a = *reinterpret_cast<const float4*>(&lseS[r0]);
                     const float4 b = *reinterpret_cast<const float4*>(&dlS[r0]);
+                    const float4 e = *reinterpret_cast<const float4*>(&ilS[r0]);
                     lse8[4 * j] = a.x; lse8[4 * j + 1] = a.y; lse8[4 * j + 2] = a.z; lse8[4 * j + 3] = a.w;
                     dl8[4 * j] = b.x; dl8[4 * j + 1] = b.y; dl8[4 * j + 2] = b.z; dl8[4 * j + 3] = b.w;
+                    il8[4 * j] = e.x; il8[4 * j + 1] = e.y; il8[4 * j + 2] = e.z; il8[4 * j + 3] = e.w;
                     if (DROP) {     // this key's pair word for each query row (dropout rule v2, common.h)
                         const uint4 w = *reinterpret_cast<const uint4*>(
                             &dropW[t][wave * 2 + (n >> 4)][(n & 15) >> 1][16 * hi + 8 * s2 + 4 * j]);
@@ -992,19 +958,19 @@ __device__ __forceinline__ void attn_bwd_dkv_body(const AttnParams& p, const int
                 }
                 float a8[8], b8[8];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
+                for (int j = 0; j < 8; j += 2) {
                     const int i = 8 * s2 + j;
-                    const float pr = fast_exp2(fmaf(s[i], MOBGT_LOG2E, -lse8[j]));
-                    if (DROP) {
-                        // dS = P (M dP / (1-p) - delta) = X dP' - P delta with X = M P (what dV sums) and dP' = dO (V / (1-p))
-                        // even key: low half of w, moved to the top by the lane's shift; odd key: high half
-                        const bool keep = (int)(w8[j] << drop_sh) >= thr_hi;
+                    // the forward's probabilities of this key for two query rows (header: consistent softmax), rounded as a pair
+                    const uint32_t pw = pack2(fast_exp2(fmaf(s[i], MOBGT_LOG2E, -lse8[j])), fast_exp2(fmaf(s[i + 1], MOBGT_LOG2E, -lse8[j + 1])));
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        const float pr = u ? bf16_hi(pw) : bf16_lo(pw);
+                        // dS = (1 / l') P_b (M dP / (1-p) - delta) = (1 / l') (X dP' - P_b delta) with X = M P_b (what dV sums) and
+                        // dP' = dO (V / (1-p)); even key: low half of w, moved to the top by the lane's shift; odd key: high half
+                        const bool keep = !DROP || (int)(w8[j + u] << drop_sh) >= thr_hi;
                         const float x = keep ? pr : 0.f;           // 1/(1-p) of dV is applied once, at the end
-                        a8[j] = x;
-                        b8[j] = fmaf(x, dp[i], -pr * dl8[j]);
-                    } else {
-                        a8[j] = pr;
-                        b8[j] = pr * (dp[i] - dl8[j]);
+                        a8[j + u] = x * il8[j + u];
+                        b8[j + u] = il8[j + u] * fmaf(x, dp[i + u], -pr * dl8[j + u]);
                     }
                 }
                 const bf16x8 pb = pack8(a8), db = pack8(b8);
@@ -1036,7 +1002,7 @@ __device__ __forceinline__ void attn_bwd_dkv_body(const AttnParams& p, const int
 // (tried: amdgpu_waves_per_eu(3), i.e. <= 168 VGPRs instead of 184 -- 19 dwords of scratch per lane in the loop, 103 -> 123 us)
 template <int D, typename TQ, typename TB, int NW, bool DROP>
 __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_kernel(const AttnParams p) {
-    attn_bwd_dkv_body<D, TQ, TB, NW, DROP, false>(p, blockIdx.x, gridDim.x);
+    attn_bwd_dkv_body<D, TQ, TB, NW, DROP>(p, blockIdx.x, gridDim.x);
 }
 
 // Both backward passes in one launch (small graphs: each pass alone is 128-256 workgroups of 1-2 waves -- a fraction of
@@ -1045,7 +1011,7 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_kernel(const AttnParams 
 template <int D, typename TQ, typename TB, int NW, bool DROP>
 __global__ __launch_bounds__(NW * 64) void attn_bwd_both_kernel(const AttnParams p) {
     if ((int)blockIdx.x < p.n_first) attn_bwd_dq_body<D, TQ, TB, NW, DROP>(p, blockIdx.x, p.n_first);
-    else attn_bwd_dkv_body<D, TQ, TB, NW, DROP, true>(p, blockIdx.x - p.n_first, gridDim.x - p.n_first);
+    else attn_bwd_dkv_body<D, TQ, TB, NW, DROP>(p, blockIdx.x - p.n_first, gridDim.x - p.n_first);
 }
 
 
@@ -1152,7 +1118,12 @@ __global__ __launch_bounds__(ONE_NW * 64) void attn_bwd_one_kernel(const AttnPar
     const int64_t sld = is_q ? p.ldq : p.ldo;
     bf16_t (*srm)[ROWP] = is_q ? Qs : dOs;
     bf16_t (*strn)[COLP] = is_q ? Qt : dOt;
-    Raw8<TQ> sreg, oreg;
+    Raw8<TQ> sreg, oreg, lreg;
+    float lse_s = 0.f;                                          // (dO threads) lse of the row their piece belongs to
+    const bf16_t* OLo = p.out_lo ? reinterpret_cast<const bf16_t*>(p.out_lo) + (int64_t)g * T * p.ldo + h * D : nullptr;
+    // Consistent softmax (header): a dO row is staged as dO~ = bf16(dO / l') -- the normalisation of the row's probabilities rides
+    // on it, so the tile loop works with the forward's un-normalised P_b = bf16(2^(x - M')) and pays nothing per element for
+    // 1 / l' -- and delta = dO~ . (O + O_lo) is formed from the very values that were staged.
     // (round 4, second step) rowsum(dO O) is formed HERE: the threads that stage a piece of dO also request the same piece of O with
     // the same two-chunk lead and reduce the products over the four pieces of a row when the chunk is stored -- the launch in
     // front (attn_bwd_prep_kernel: 10.9 us at c5 for reading dO and O once more and zero-filling the accumulator) is gone; the
@@ -1161,10 +1132,14 @@ __global__ __launch_bounds__(ONE_NW * 64) void attn_bwd_one_kernel(const AttnPar
         if (D % 32 == 0 || sc0 < D) {
             sreg.load(ssrc + (int64_t)min(c * KC + sr, T - 1) * sld + sc0);
             oreg.load((is_q ? ssrc : Oo) + (int64_t)min(c * KC + sr, T - 1) * sld + sc0);      // (Q threads: a second read of their piece, unused)
+            if (OLo) lreg.load((is_q ? ssrc : OLo) + (int64_t)min(c * KC + sr, T - 1) * sld + sc0);
+            else lreg.zero();
         } else {
             sreg.zero();
             oreg.zero();
+            lreg.zero();
         }
+        lse_s = p.lse_in[(int64_t)gh * T + min(c * KC + sr, T - 1)];
     };
     float lse_r = 0.f;
     auto load_rowstats = [&](const int c) {      // thread it < KC carries query it of the chunk (every thread loads: no branch)
@@ -1176,18 +1151,26 @@ __global__ __launch_bounds__(ONE_NW * 64) void attn_bwd_one_kernel(const AttnPar
     // behind them (the counter retires in issue order: the atomics of chunk c then have the whole of tiles(c + 1) to complete,
     // and no wait count has to be exact across the loop's back edge -- where the compiler's merged counts are conservative).
     auto stage_store = [&](const int c) {
-        const bf16x8 b = sreg.as_bf16();
+        bf16x8 b = sreg.as_bf16();
+        if (!is_q) {                                     // (wave-uniform: waves 4 .. 7)
+            float mq, il, a8[8];
+            row_norm(lse_s, mq, il);
+            sreg.get(a8);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) a8[i] *= il;
+            b = pack8(a8);
+        }
         *reinterpret_cast<bf16x8*>(&srm[sr][sc0]) = b;
 #pragma unroll
         for (int i = 0; i < 8; ++i) strn[sc0 + i][sr] = b[i];
-        if (tid < KC) lseS[tid] = lse_r * MOBGT_LOG2E;
+        if (tid < KC) lseS[tid] = __builtin_rintf(lse_r * MOBGT_LOG2E);
         {
-            float a8[8], o8[8];
-            sreg.get(a8);
+            float o8[8], l8[8];
             oreg.get(o8);
+            lreg.get(l8);
             float d = 0.f;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) d = fmaf(a8[i], o8[i], d);
+            for (int i = 0; i < 8; ++i) d = fmaf((float)b[i], o8[i] + l8[i], d);
             d += __shfl_xor(d, 1, 64);                   // the four pieces of a row sit in four neighbouring lanes
             d += __shfl_xor(d, 2, 64);
             if (!is_q && (se & 3) == 0) dlS[sr] = d;
@@ -1250,49 +1233,25 @@ __global__ __launch_bounds__(ONE_NW * 64) void attn_bwd_one_kernel(const AttnPar
                     }
                 }
                 float a8[8], b8[8];
-#if ATTN_PK_F32
-                {
-                    // (round 4) packed f32 arithmetic around the exponentials: v_pk_fma_f32 / v_pk_mul_f32, two elements per issue slot
-                    typedef float f32x2_ __attribute__((ext_vector_type(2)));
-                    const f32x2_ l2e = {MOBGT_LOG2E, MOBGT_LOG2E};
 #pragma unroll
-                    for (int j = 0; j < 8; j += 2) {
-                        const int i = 8 * s2 + j;
-                        const f32x2_ sv = {s[i], s[i + 1]}, nl = {-lse8[j], -lse8[j + 1]}, dl2 = {dl8[j], dl8[j + 1]}, dp2 = {dp[i], dp[i + 1]};
-                        const f32x2_ a = __builtin_elementwise_fma(sv, l2e, nl);
-                        f32x2_ pr2;
-                        pr2.x = fast_exp2(a.x);
-                        pr2.y = fast_exp2(a.y);
+                for (int j = 0; j < 8; j += 2) {
+                    const int i = 8 * s2 + j;
+                    // the forward's probabilities of this key for two query rows, rounded to bf16 as a pair (header: consistent softmax)
+                    const uint32_t pw = pack2(fast_exp2(fmaf(s[i], MOBGT_LOG2E, -lse8[j])), fast_exp2(fmaf(s[i + 1], MOBGT_LOG2E, -lse8[j + 1])));
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        const float pr = u ? bf16_hi(pw) : bf16_lo(pw);
                         if (DROP) {
-                            f32x2_ x2;
-                            x2.x = (int)(w8[j] << drop_sh) >= thr_hi ? pr2.x : 0.f;
-                            x2.y = (int)(w8[j + 1] << drop_sh) >= thr_hi ? pr2.y : 0.f;
-                            const f32x2_ b2 = __builtin_elementwise_fma(x2, dp2, -(pr2 * dl2));
-                            a8[j] = x2.x; a8[j + 1] = x2.y;
-                            b8[j] = b2.x; b8[j + 1] = b2.y;
+                            const bool keep = (int)(w8[j + u] << drop_sh) >= thr_hi;
+                            const float x = keep ? pr : 0.f;
+                            a8[j + u] = x;
+                            b8[j + u] = fmaf(x, dp[i + u], -pr * dl8[j + u]);
                         } else {
-                            const f32x2_ b2 = pr2 * (dp2 - dl2);
-                            a8[j] = pr2.x; a8[j + 1] = pr2.y;
-                            b8[j] = b2.x; b8[j + 1] = b2.y;
+                            a8[j + u] = pr;
+                            b8[j + u] = pr * (dp[i + u] - dl8[j + u]);
                         }
                     }
                 }
-#else
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const int i = 8 * s2 + j;
-                    const float pr = fast_exp2(fmaf(s[i], MOBGT_LOG2E, -lse8[j]));
-                    if (DROP) {
-                        const bool keep = (int)(w8[j] << drop_sh) >= thr_hi;
-                        const float x = keep ? pr : 0.f;
-                        a8[j] = x;
-                        b8[j] = fmaf(x, dp[i], -pr * dl8[j]);
-                    } else {
-                        a8[j] = pr;
-                        b8[j] = pr * (dp[i] - dl8[j]);
-                    }
-                }
-#endif
                 const bf16x8 pb = pack8(a8);
                 u32x4 dbw = __builtin_bit_cast(u32x4, pack8(b8));
 #pragma unroll
@@ -1498,12 +1457,9 @@ hipError_t launch_one(const AttnParams& p0, hipStream_t st) {
             hipLaunchKernelGGL(attn_dq_finish_kernel, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, st, p.dq_acc,
                                reinterpret_cast<bf16_t*>(p.dq), (int64_t)p.G * p.T, C, p.lddq, p.scale);
         } else {
-            static const int cap_q = blocks_per_cu(attn_bwd_dq_kernel<D, TQ, TB, NW, DROP>, NW * 64);
-            static const int cap_k = blocks_per_cu(attn_bwd_dkv_kernel<D, TQ, TB, NW, DROP>, NW * 64);
             const int nq0 = ((p.T + 31) / 32 + NW - 1) / NW;
-            p.nq = ATTN_BWD_EVEN ? choose_nq(GH, p.T, NW, cap_q, cu_count()) : nq0;
+            p.nq = nq0;
             hipLaunchKernelGGL((attn_bwd_dq_kernel<D, TQ, TB, NW, DROP>), dim3(GH * p.nq), block, 0, st, p);
-            p.nq = ATTN_BWD_EVEN ? choose_nq(GH, p.T, NW, cap_k, cu_count()) : nq0;
             hipLaunchKernelGGL((attn_bwd_dkv_kernel<D, TQ, TB, NW, DROP>), dim3(GH * p.nq), block, 0, st, p);
         }
         return hipGetLastError();
@@ -1577,16 +1533,17 @@ void set_dropout(AttnParams& p, float dropout_p, uint64_t seed, const uint64_t* 
 
 }  // namespace
 
-extern "C" int mobgt_attn_bias_fwd(const void* q, const void* k, const void* v, const void* bias, void* out, float* lse,
+extern "C" int mobgt_attn_bias_fwd(const void* q, const void* k, const void* v, const void* bias, void* out, void* out_lo, float* lse,
                                    int G, int H, int T, int d, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo,
                                    int64_t ld_bias, float scale, float dropout_p, uint64_t seed,
                                    const uint64_t* seed_dev, int io_dtype, int bias_dtype, void* stream) {
     int rc = check_common(G, H, T, d, ld_bias, io_dtype, 8);
     if (rc) return rc;
-    if (!aligned16(q) || !aligned16(k) || !aligned16(v) || !aligned16(out) || !aligned16(bias)) return MOBGT_EALIGN;
+    if (!aligned16(q) || !aligned16(k) || !aligned16(v) || !aligned16(out) || !aligned16(bias) || !aligned16(out_lo)) return MOBGT_EALIGN;
     if ((ldq | ldk | ldv | ldo) % 8 != 0) return MOBGT_EALIGN;
     AttnParams p = {};
     p.q = q; p.k = k; p.v = v; p.bias = bias; p.o = out; p.lse = lse;
+    p.o_lo = io_dtype == MOBGT_BF16 ? out_lo : nullptr;
     p.G = G; p.H = H; p.T = T;
     p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo; p.ld_bias = ld_bias;
     p.scale = scale;
@@ -1595,7 +1552,7 @@ extern "C" int mobgt_attn_bias_fwd(const void* q, const void* k, const void* v, 
 }
 
 static int attn_bwd_impl(const void* q, const void* k, const void* v, const void* bias, const void* bias_t,
-                                   const void* out, const float* lse, const void* dout, void* dq, void* dk, void* dv,
+                                   const void* out, const void* out_lo, const float* lse, const void* dout, void* dq, void* dk, void* dv,
                                    void* dbias, float* delta, int G, int H, int T, int d, int64_t ldq, int64_t ldk,
                                    int64_t ldv, int64_t ldo, int64_t lddq, int64_t lddk, int64_t lddv, int64_t ld_bias,
                                    float scale, float dropout_p, uint64_t seed, const uint64_t* seed_dev,
@@ -1604,11 +1561,12 @@ static int attn_bwd_impl(const void* q, const void* k, const void* v, const void
     int rc = check_common(G, H, T, d, ld_bias, io_dtype, 8);
     if (rc) return rc;
     if (!aligned16(q) || !aligned16(k) || !aligned16(v) || !aligned16(out) || !aligned16(dout) || !aligned16(bias) ||
-        !aligned16(bias_t) || !aligned16(dq) || !aligned16(dk) || !aligned16(dv) || !aligned16(dbias))
+        !aligned16(bias_t) || !aligned16(dq) || !aligned16(dk) || !aligned16(dv) || !aligned16(dbias) || !aligned16(out_lo))
         return MOBGT_EALIGN;
     if ((ldq | ldk | ldv | ldo | lddq | lddk | lddv) % 8 != 0) return MOBGT_EALIGN;
     AttnParams p = {};
     p.q = q; p.k = k; p.v = v; p.bias = bias; p.bias_t = bias_t; p.out = out; p.dout = dout; p.lse_in = lse;
+    p.out_lo = io_dtype == MOBGT_BF16 ? out_lo : nullptr;
     p.dq = dq; p.dk = dk; p.dv = dv; p.dbias = dbias; p.delta = delta;
     p.dq_acc = (dq_acc && aligned16(dq_acc)) ? dq_acc : nullptr;
     p.dq_acc_zero = dq_acc_zero;
@@ -1627,12 +1585,12 @@ static int attn_bwd_impl(const void* q, const void* k, const void* v, const void
 }
 
 extern "C" int mobgt_attn_bias_bwd(const void* q, const void* k, const void* v, const void* bias, const void* bias_t,
-                                   const void* out, const float* lse, const void* dout, void* dq, void* dk, void* dv,
+                                   const void* out, const void* out_lo, const float* lse, const void* dout, void* dq, void* dk, void* dv,
                                    void* dbias, float* delta, int G, int H, int T, int d, int64_t ldq, int64_t ldk,
                                    int64_t ldv, int64_t ldo, int64_t lddq, int64_t lddk, int64_t lddv, int64_t ld_bias,
                                    float scale, float dropout_p, uint64_t seed, const uint64_t* seed_dev,
                                    int accumulate_dbias, int dbias_dtype, int io_dtype, int bias_dtype, void* stream) {
-    return attn_bwd_impl(q, k, v, bias, bias_t, out, lse, dout, dq, dk, dv, dbias, delta, G, H, T, d, ldq, ldk, ldv, ldo, lddq, lddk,
+    return attn_bwd_impl(q, k, v, bias, bias_t, out, out_lo, lse, dout, dq, dk, dv, dbias, delta, G, H, T, d, ldq, ldk, ldv, ldo, lddq, lddk,
                          lddv, ld_bias, scale, dropout_p, seed, seed_dev, accumulate_dbias, dbias_dtype, io_dtype, bias_dtype,
                          nullptr, stream);
 }
@@ -1642,12 +1600,12 @@ extern "C" int mobgt_attn_bias_bwd(const void* q, const void* k, const void* v, 
 // bias (attn_bwd_one_kernel: S / P / dS once per pair, bias_t read once, dBias written once, dQ summed over key blocks by f32
 // atomics -- so dQ is then NOT bitwise reproducible from run to run; MOBGT_ATTN_TWO_PASS=1 keeps the two deterministic passes).
 extern "C" int mobgt_attn_bias_bwd_fused(const void* q, const void* k, const void* v, const void* bias, const void* bias_t,
-                                   const void* out, const float* lse, const void* dout, void* dq, void* dk, void* dv,
+                                   const void* out, const void* out_lo, const float* lse, const void* dout, void* dq, void* dk, void* dv,
                                    void* dbias, float* delta, int G, int H, int T, int d, int64_t ldq, int64_t ldk,
                                    int64_t ldv, int64_t ldo, int64_t lddq, int64_t lddk, int64_t lddv, int64_t ld_bias,
                                    float scale, float dropout_p, uint64_t seed, const uint64_t* seed_dev,
                                    int accumulate_dbias, int dbias_dtype, int io_dtype, int bias_dtype, float* dq_acc, void* stream) {
-    return attn_bwd_impl(q, k, v, bias, bias_t, out, lse, dout, dq, dk, dv, dbias, delta, G, H, T, d, ldq, ldk, ldv, ldo, lddq, lddk,
+    return attn_bwd_impl(q, k, v, bias, bias_t, out, out_lo, lse, dout, dq, dk, dv, dbias, delta, G, H, T, d, ldq, ldk, ldv, ldo, lddq, lddk,
                          lddv, ld_bias, scale, dropout_p, seed, seed_dev, accumulate_dbias, dbias_dtype, io_dtype, bias_dtype,
                          dq_acc, stream);
 }
@@ -1655,12 +1613,12 @@ extern "C" int mobgt_attn_bias_bwd_fused(const void* q, const void* k, const voi
 /* mobgt_attn_bias_bwd_fused with an accumulator the caller keeps ZERO between calls: no launch in front of the pass (rowsum(dO O)
  * is formed inside it), and the finishing launch leaves dq_acc zero again. */
 extern "C" int mobgt_attn_bias_bwd_fused_z(const void* q, const void* k, const void* v, const void* bias, const void* bias_t,
-                                   const void* out, const float* lse, const void* dout, void* dq, void* dk, void* dv,
+                                   const void* out, const void* out_lo, const float* lse, const void* dout, void* dq, void* dk, void* dv,
                                    void* dbias, float* delta, int G, int H, int T, int d, int64_t ldq, int64_t ldk,
                                    int64_t ldv, int64_t ldo, int64_t lddq, int64_t lddk, int64_t lddv, int64_t ld_bias,
                                    float scale, float dropout_p, uint64_t seed, const uint64_t* seed_dev,
                                    int accumulate_dbias, int dbias_dtype, int io_dtype, int bias_dtype, float* dq_acc, void* stream) {
-    return attn_bwd_impl(q, k, v, bias, bias_t, out, lse, dout, dq, dk, dv, dbias, delta, G, H, T, d, ldq, ldk, ldv, ldo, lddq, lddk,
+    return attn_bwd_impl(q, k, v, bias, bias_t, out, out_lo, lse, dout, dq, dk, dv, dbias, delta, G, H, T, d, ldq, ldk, ldv, ldo, lddq, lddk,
                          lddv, ld_bias, scale, dropout_p, seed, seed_dev, accumulate_dbias, dbias_dtype, io_dtype, bias_dtype,
                          dq_acc, stream, 1);
 }

@@ -517,7 +517,8 @@ __global__ __launch_bounds__(NT) void layer_chain_fwd_kernel(const ChainParams p
 // round trips (measured 2.4-3.2 us per hand-over against ~1.3 here).  Members of a cluster sit on ONE XCD (block ids that
 // agree modulo 8; the sc1 accesses are correct on any placement).
 // Co-residency: the host picks NCL so that the live workgroups fit the device's compute units at one per unit; the poll is
-// bounded and traps.  Rounding: as the one-workgroup form except FFN-2 / du W1, whose f32 sums are added in NCL parts (then
+// bounded and GIVES UP into the fault word (WS_FAULT below; the host polls it: train.TrainStep.check_faults, called by
+// EpochLoop.run_epoch, bench.py and the tests' data-parallel worker).  Rounding: as the one-workgroup form except FFN-2 / du W1, whose f32 sums are added in NCL parts (then
 // rounded to bf16 at the same point).
 constexpr int WS_GEN_INTS = 1024;                                       // gen[<= 256 row blocks] (+ spare)
 // A member that does not see its partners' packets within the poll limit GIVES UP instead of trapping (a trap kills the

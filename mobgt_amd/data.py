@@ -222,6 +222,42 @@ BUCKETS = (tuple(range(4, 65, 4)) + tuple(range(72, 129, 8)) + tuple(range(144, 
            + tuple(range(576, 1025, 64)))
 
 
+def balanced_batches(lengths, world_size, batch_size, epoch=0, seed=0, shuffle=True, buckets=BUCKETS):
+    """Length-balanced dealing of one epoch over `world_size` ranks ("load imbalance across ranks": node
+    counts run from 1 to 814 on Gowalla, a step costs what its padded N costs, and a synchronous step lasts as long as its
+    slowest rank): -> steps[j][r] = sample ids of rank r in step j, the same list on every rank.
+
+    * the epoch's samples are exactly DistributedSampler's (`shard_indices`): the permutation seeded by seed + epoch, padded by
+      wrap-around to a multiple of world_size -- the union over ranks is the same multiset, every rank takes the same number of
+      samples and of steps, the last step is the short one on all ranks alike (drop_last=False, data.py:282-295);
+    * inside it the samples are ordered by the BUCKET their node count pads to (stable: samples of one bucket keep their random
+      order, so a batch's composition stays random) and cut into steps of world_size x batch_size; rank r takes the r-th run of a
+      step -- neighbouring runs of one sorted sequence, i.e. the same or the neighbouring bucket on all ranks;
+    * the steps are then visited in an order drawn from seed + epoch + 1 (sizes mixed over time: the learning-rate schedule
+      never sees 'all short graphs first')."""
+    n = len(lengths)
+    if shuffle:
+        g = torch.Generator()
+        g.manual_seed(seed + epoch)
+        order = torch.randperm(n, generator=g).tolist()
+    else:
+        order = list(range(n))
+    total = (n + world_size - 1) // world_size * world_size
+    order += order[: total - len(order)]
+    keyed = sorted(order, key=lambda i: bucket_nodes(int(lengths[i]), buckets))          # (stable)
+    per_step = world_size * batch_size
+    steps = []
+    for s in range(0, total, per_step):
+        chunk = keyed[s:s + per_step]
+        m = len(chunk) // world_size                                                     # (total is a multiple of world_size)
+        steps.append([chunk[r * m:(r + 1) * m] for r in range(world_size)])
+    if shuffle:
+        g = torch.Generator()
+        g.manual_seed(seed + epoch + 1)
+        steps = [steps[i] for i in torch.randperm(len(steps), generator=g).tolist()]
+    return steps
+
+
 def bucket_nodes(n, buckets=BUCKETS):
     """Smallest bucket >= n (beyond the largest: the next multiple of 256)."""
     for b in buckets:

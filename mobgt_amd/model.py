@@ -15,6 +15,7 @@ Lightning glue, FLAG, ogb/ZINC branches of the reference are out of scope (SURVE
 """
 import math
 import os
+import weakref
 
 import torch
 import torch.nn as nn
@@ -118,22 +119,50 @@ class MultiHeadAttention(nn.Module):
         return self._wqkv, self._bqkv
 
     def _packed(self, attn_bias, G, T, ref):
+        """The bias in kernel layout.  A dense tensor is packed once per TENSOR OBJECT (the L layers of a reference-style
+        `for layer in layers: layer(x, bias)` loop share the pack): the cache is keyed on the object's identity through a weak
+        reference plus its version counter -- never on its address, which the caching allocator hands to the next batch's
+        bias as soon as this one is freed (model.py:190 creates a fresh tensor per batch)."""
         if isinstance(attn_bias, ops.PackedBias):
             return attn_bias
         if attn_bias is None:
             attn_bias = torch.zeros(1, 1, T, T, device=ref.device)
-        key = (attn_bias.data_ptr(), attn_bias._version, tuple(attn_bias.shape), attn_bias.requires_grad)
         cache = MultiHeadAttention._shared_cache
-        if cache.get("key") != key:
-            cache["key"] = key
+        src = cache.get("src")
+        grad_mode = attn_bias.requires_grad and torch.is_grad_enabled()
+        if (src is None or src() is not attn_bias or cache.get("key") != (attn_bias._version, G, T, self.num_heads, grad_mode)
+                or cache["pack"].spent):
             cache["pack"] = ops.pack_bias(attn_bias, G, self.num_heads, T)
+            cache["src"] = weakref.ref(attn_bias)
+            cache["key"] = (attn_bias._version, G, T, self.num_heads, grad_mode)
         return cache["pack"]
 
     _shared_cache = {}
 
+    def _masked_forward(self, q, k, v, attn_bias, mask):
+        """model.py:446-448: `x.masked_fill(mask.unsqueeze(1), 0)` puts the SCORE (bias included) of a masked pair to 0 -- not to
+        -inf -- in front of the softmax, so it cannot be folded into an additive bias.  No caller of the reference passes a mask
+        (model.py:208, model_fqandtoyo.py:1350 `mask=None`); the branch is kept in its dense form, in fp32, op by op."""
+        G, Tq = q.shape[0], q.shape[1]
+        H, d = self.num_heads, self.att_size
+        qh = self.linear_q(q).float().view(G, -1, H, d).transpose(1, 2) * self.scale
+        kh = self.linear_k(k).float().view(G, -1, H, d).transpose(1, 2).transpose(2, 3)
+        vh = self.linear_v(v).float().view(G, -1, H, d).transpose(1, 2)
+        s = torch.matmul(qh, kh)
+        if attn_bias is not None:
+            if isinstance(attn_bias, ops.PackedBias):
+                attn_bias = attn_bias.dense()
+            s = s + attn_bias.float()
+        s = s.masked_fill(mask.unsqueeze(1), 0)
+        p = self.att_dropout(torch.softmax(s, dim=3))
+        x = torch.matmul(p, vh).transpose(1, 2).contiguous().view(G, Tq, H * d)
+        return self.output_layer(x.to(self.output_layer.weight.dtype))
+
     def forward(self, q, k, v, attn_bias=None, mask=None):
         if mask is not None:
-            raise NotImplementedError("mask is None at every call site of the reference (model.py:208)")
+            x = self._masked_forward(q, k, v, attn_bias, mask)
+            assert x.size() == q.size()
+            return x
         orig_q_size = q.size()
         G, T = q.shape[0], q.shape[1]
         pack = self._packed(attn_bias, G, T, q)
@@ -151,8 +180,6 @@ class MultiHeadAttention(nn.Module):
         x = self.output_layer(x)
         assert x.size() == orig_q_size
         return x
-
-
 
 
 def fused_layer_forward(layer, variant, x, attn_bias, n1, nx, next_layer=None):

@@ -39,6 +39,15 @@ def _ws_word(ws, off):
     return ws.view(torch.int32)[off // 4:off // 4 + 1]
 
 
+def _scrub_exchange_area(ws, fault_off):
+    """After a faulted launch the exchange area may hold packets of members that arrived late: member 0 raises the block's
+    generation whether or not it saw everybody, so a late member tags its packets gen + 2 -- the tag the NEXT launch waits
+    for.  The fault word is the last of the generation words and the packets start right behind it: zero them
+    (tag 0 is never a launch's; the generations stay).  The device is idle here (peer_wait_faults synchronised it)."""
+    ws[fault_off + 4:].zero_()
+    torch.cuda.synchronize()
+
+
 def peer_wait_faults(reset=True):
     """{site: count} of workgroups that gave up waiting for their peers since the last reset, on the current device (empty dict
     = none).  Synchronises the device (it reads device words): call between steps, never during a capture."""
@@ -50,20 +59,24 @@ def peer_wait_faults(reset=True):
     for key, ws in fused_layer._CHAIN_WS.items():           # (one workspace per device and launch geometry)
         if key[0] != dev:
             continue
-        w = _ws_word(ws, int(lib.mobgt_chain_ws_fault_offset()))
+        off = int(lib.mobgt_chain_ws_fault_offset())
+        w = _ws_word(ws, off)
         n = int(w.item())
         if n:
             out["chain"] = out.get("chain", 0) + n
             if reset:
                 w.zero_()
+                _scrub_exchange_area(ws, off)
     ws = _HEAD_WS.get(dev)
     if ws is not None:
-        w = _ws_word(ws, int(lib.mobgt_head_chain_ws_fault_offset()))
+        off = int(lib.mobgt_head_chain_ws_fault_offset())
+        w = _ws_word(ws, off)
         n = int(w.item())
         if n:
             out["head"] = n
             if reset:
                 w.zero_()
+                _scrub_exchange_area(ws, off)
     c = ctypes.c_uint32(0)
     check(lib.mobgt_small_gcn_faults(1 if reset else 0, ctypes.byref(c)), "mobgt_small_gcn_faults")
     if c.value:
@@ -208,6 +221,7 @@ class PackedBias:
         self.n_bwd = 0            # backward passes that have delivered theirs
         self.needs_grad = False
         self.token = None
+        self.spent = False        # its gradient has been handed out (_PackFn.backward): a later forward packs afresh
 
     def dense(self):
         """[G,H,T,T] float32 copy (tests)."""
@@ -268,6 +282,7 @@ class _PackFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, _g):
         pack = ctx.pack
+        pack.spent = True
         if pack.dbias is None:
             return torch.zeros(ctx.src_shape, dtype=ctx.src_dtype, device=pack.bias.device), None
         g = pack.grad_total()
@@ -440,15 +455,39 @@ def _check_rows(*ts):
             raise RuntimeError("mobgt attention: q/k/v rows must be unit-stride, 16-byte aligned, row stride % 8 == 0")
 
 
+def _lse_alloc(G, H, T, C, dtype, device):
+    """The forward's row statistics: [G, H, T] f32 log-sum-exp and, behind them in the SAME buffer for bf16 I/O, the bf16 rounding
+    residual of the output ([G, T, C] bf16 = G T C / 2 floats; csrc/attn.hip, "consistent softmax": the backward's
+    rowsum(dO O) needs O beyond bf16).  One tensor, so everything that saves / hands on `lse` carries the residual along."""
+    return torch.empty(lse_numel(G, H, T, C, dtype), dtype=torch.float32, device=device)
+
+
+def lse_numel(G, H, T, C, dtype):
+    n = G * H * T
+    extra = (G * T * C + 1) // 2 if dtype == torch.bfloat16 else 0
+    return (n + 3) // 4 * 4 + extra                # (the residual starts on a 16-byte boundary)
+
+
+def lse_rows(lse, G, H, T):
+    """[G, H, T] view of the log-sum-exp rows inside the buffer `_attn_fwd` returns."""
+    return lse[: G * H * T].view(G, H, T)
+
+
+def _out_lo_ptr(lse, G, H, T, dtype):
+    if dtype != torch.bfloat16:
+        return None
+    return lse.data_ptr() + 4 * ((G * H * T + 3) // 4 * 4)
+
+
 def _attn_fwd(q, k, v, pack, scale, p_drop, seed, seed_dev):
     G, T, C = q.shape
     H = pack.H
     out = torch.empty(G, T, C, dtype=q.dtype, device=q.device)
-    lse = torch.empty(G, H, T, dtype=torch.float32, device=q.device)
+    lse = _lse_alloc(G, H, T, C, q.dtype, q.device)
     _check_rows(q, k, v)
     if pack.needs_grad:
         pack.n_use += 1
-    check(_lib.lib().mobgt_attn_bias_fwd(_p(q), _p(k), _p(v), _p(pack.bias), _p(out), _p(lse), G, H, T, C // H,
+    check(_lib.lib().mobgt_attn_bias_fwd(_p(q), _p(k), _p(v), _p(pack.bias), _p(out), _out_lo_ptr(lse, G, H, T, q.dtype), _p(lse), G, H, T, C // H,
                                          q.stride(1), k.stride(1), v.stride(1), C, pack.ld, scale, p_drop, seed,
                                          _p(seed_dev), _DT[q.dtype], _DT[pack.dtype], _stream()), "mobgt_attn_bias_fwd")
     return out, lse
@@ -465,7 +504,7 @@ def _attn_bwd(q, k, v, out, lse, dout, dq, dk, dv, pack, scale, p_drop, seed, se
     if pack.needs_grad:
         dbias, acc = pack.next_grad_slice()
     delta = torch.empty(G, H, T, dtype=torch.float32, device=q.device)
-    args = (_p(q), _p(k), _p(v), _p(pack.bias), _p(pack.bias_t), _p(out), _p(lse), _p(dout),
+    args = (_p(q), _p(k), _p(v), _p(pack.bias), _p(pack.bias_t), _p(out), _out_lo_ptr(lse, G, H, T, q.dtype), _p(lse), _p(dout),
             _p(dq), _p(dk), _p(dv), _p(dbias), _p(delta), G, H, T, C // H,
             q.stride(1), k.stride(1), v.stride(1), C, dq.stride(1), dk.stride(1),
             dv.stride(1), pack.ld, scale, p_drop, seed, _p(seed_dev), acc,

@@ -30,7 +30,8 @@ _LIB_NS = "mobgt"
 @torch.library.custom_op(f"{_LIB_NS}::attention_forward", mutates_args=(), device_types="cuda")
 def attention_forward(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, attn_bias: torch.Tensor, num_heads: int, scale: float,
                       dropout_p: float, seed: int) -> Tuple[torch.Tensor, torch.Tensor]:
-    """-> (out [G,T,C], lse [G,H,T] f32)."""
+    """-> (out [G,T,C], row statistics: 1-D f32 -- [G,H,T] log-sum-exp values and, for bf16 I/O, the output's bf16 rounding
+    residual behind them (ops._lse_alloc; `ops.lse_rows` gives the [G,H,T] view))."""
     G, T, C = q.shape
     io = q.dtype if q.dtype in (torch.float32, torch.bfloat16) else torch.float32
     q, k, v = (t.to(io).contiguous() for t in (q, k, v))
@@ -43,7 +44,7 @@ def attention_forward(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, attn_bi
 def _(q, k, v, attn_bias, num_heads, scale, dropout_p, seed):
     G, T, C = q.shape
     io = q.dtype if q.dtype in (torch.float32, torch.bfloat16) else torch.float32
-    return q.new_empty((G, T, C), dtype=io), q.new_empty((G, num_heads, T), dtype=torch.float32)
+    return q.new_empty((G, T, C), dtype=io), q.new_empty((ops.lse_numel(G, num_heads, T, C, io),), dtype=torch.float32)
 
 
 @torch.library.custom_op(f"{_LIB_NS}::attention_backward", mutates_args=(), device_types="cuda")

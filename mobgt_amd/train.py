@@ -826,7 +826,10 @@ class EpochLoop:
     """
 
     def __init__(self, model, collator, dataset, batch_size=16, seed=1, use_graph=True, overlap=True, buckets=None, rank=None,
-                 world=None, shuffle=True, autocast_dtype=None, side_collate=True):
+                 world=None, shuffle=True, autocast_dtype=None, side_collate=True, balance=None):
+        """`balance`: deal every step's batches by length over the ranks (`data.balanced_batches`: neighbouring shape buckets on
+        all ranks in every synchronous step, the epoch's sample set still DistributedSampler's).  Default: on when there is more
+        than one rank; with one rank the order is the reference's (DistributedSampler order, consecutive batches)."""
         from .data import BUCKETS
         self.model, self.collator, self.dataset = model, collator, dataset
         self.batch_size, self.seed, self.shuffle = int(batch_size), int(seed), shuffle
@@ -834,6 +837,8 @@ class EpochLoop:
         ddp = dist.is_available() and dist.is_initialized()
         self.rank = rank if rank is not None else (dist.get_rank() if ddp else 0)
         self.world = world if world is not None else (dist.get_world_size() if ddp else 1)
+        self.balance = (self.world > 1) if balance is None else bool(balance)
+        self._lengths = None
         self.device = next(model.parameters()).device
         self.copy_stream = torch.cuda.Stream(device=self.device)
         self.slots = {}
@@ -850,7 +855,13 @@ class EpochLoop:
 
     # ---- data order -----------------------------------------------------------------------------------------------------
     def batches_of_epoch(self, epoch):
-        from .data import shard_indices
+        from .data import balanced_batches, shard_indices
+        if self.balance:
+            if self._lengths is None:
+                self._lengths = [len(t["node_name"]) for t in self.dataset]
+            steps = balanced_batches(self._lengths, self.world, self.batch_size, epoch=epoch, seed=self.seed, shuffle=self.shuffle,
+                                     buckets=self.buckets)
+            return [s[self.rank] for s in steps]
         idx = shard_indices(len(self.dataset), self.rank, self.world, epoch=epoch, seed=self.seed, shuffle=self.shuffle)
         B = self.batch_size
         return [idx[i:i + B] for i in range(0, len(idx), B)]
@@ -1000,4 +1011,8 @@ class EpochLoop:
             self.steps_done += 1
             if on_step is not None:
                 on_step(self.steps_done, loss)
+        # peer waits that gave up during the epoch (the kernels count and carry on, csrc/chain.hip WS_FAULT): raise here, once
+        # per epoch, rather than train on silently (one device synchronisation; every rank takes the same decision)
+        if self.ts is not None:
+            self.ts.check_faults(on_fault="raise")
         return dict(steps=steps, graphs=len(self.slots), sample_ids=seen)

@@ -45,6 +45,7 @@ def main():
     ts.prepare()
     losses = [float(ts.step(i)) for i in range(steps)]
     torch.cuda.synchronize()
+    ts.check_faults(on_fault="raise")                      # (two ranks may share one GPU here: a lost co-residency must be loud)
     torch.save(dict(losses=losses, params=ts.flat_params.tensor.detach().cpu(), grads=ts.flat.flat.cpu(),
                     exp_avg=ts.exp_avg.cpu(), exp_avg_sq=ts.exp_avg_sq.cpu(), overlap=ts.overlap, backend=dist.get_backend(),
                     forced=ts.force_comm, one_graph=ts.one_graph, parts=len(ts.parts), comm_dtype=str(ts.comm_buf.dtype) if ts.comm_buf is not None else None,

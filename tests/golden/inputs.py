@@ -39,6 +39,16 @@ def encoder_case(variant, C, T, G):
     return seed, x, bias, gy, n_real
 
 
+MASK_CASES = [("c128_t5", 128, 5, 3, 1024), ("c192_t33", 192, 33, 2, 1024)]
+
+
+def mask_case(variant, C, T, G):
+    """-> encoder_case(...) + mask [G,T,T] bool (about a fifth of the pairs; model.py:446-448)"""
+    seed, x, bias, gy, n_real = encoder_case(variant, C, T, G)
+    mask = np.random.RandomState(seed + 7).rand(G, T, T) < 0.2
+    return seed, x, bias, gy, n_real, mask
+
+
 # ------------------------------------------------------------------ G8: the real Gowalla universe (make_golden_real.py)
 def real_distance(poi_table):
     """The stand-in for `poi_data/gowalla_distance.pkl` the G8 fixture was generated with: (P+1) x (P+1) float64 km,

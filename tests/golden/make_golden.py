@@ -12,6 +12,8 @@ G4 EncoderLayer fwd+bwd, model.py and fq variants  (rows 1-3)
 G5 assembled graph_attn_bias, both variants        (rows 4-5)
 G6 end-to-end logits / loss / grads, both models   (rows 11-14)
 G7 PolynomialDecayLR, GradientTailLoss, get_acc    (row 14 + §8f)
+G8 real Gowalla trajectories + universe            (make_golden_real.py, its own script)
+G9 EncoderLayer with a `mask`                      (rows 1-2, model.py:446-448)
 """
 import os
 import sys
@@ -226,12 +228,12 @@ def make_g2_g3():
 
 
 if __name__ == "__main__":
-    which = set(sys.argv[1:]) or {"g1", "g2", "g4", "g5", "g6", "g7"}
+    which = set(sys.argv[1:]) or {"g1", "g2", "g4", "g5", "g6", "g7", "g9"}
     algos = _ref_import.install()
     if "g1" in which:
         make_g1(algos)
     if "g2" in which or "g3" in which:
         make_g2_g3()
-    if {"g4", "g5", "g6", "g7"} & which:
+    if {"g4", "g5", "g6", "g7", "g9"} & which:
         import make_golden_model
         make_golden_model.run(which)

@@ -72,6 +72,34 @@ def make_g4():
     save("g4_encoder.npz", **out)
 
 
+def make_g9():
+    """The `mask` branch of MultiHeadAttention.forward (model.py:446-448 / model_fqandtoyo.py:1697-1699) through the
+    reference's EncoderLayer, both variants: y, dx, dbias and gradient norms."""
+    import model as rmodel
+    import model_fqandtoyo as rfq
+    from inputs import MASK_CASES, mask_case
+    out = {}
+    for variant, mod in (("stock", rmodel), ("fq", rfq)):
+        for cname, C, T, G, ffn in MASK_CASES:
+            name = f"{variant}/{cname}"
+            seed, x_np, bias_np, gy_np, _, mask_np = mask_case(variant, C, T, G)
+            layer = mod.EncoderLayer(C, ffn, 0.1, 0.1, 8).eval()
+            fill_params(layer, seed + 1)
+            x = torch.from_numpy(x_np).requires_grad_(True)
+            bias = torch.from_numpy(bias_np).requires_grad_(True)
+            y = layer(x, bias, mask=torch.from_numpy(mask_np))
+            y.backward(torch.from_numpy(gy_np))
+            out[f"{name}/y"] = y.detach().numpy()
+            out[f"{name}/dx"] = x.grad.numpy()
+            out[f"{name}/dbias"] = bias.grad.numpy()
+            out[f"{name}/mask_count"] = np.array(int(mask_np.sum()))
+            for pn, p in layer.named_parameters():
+                if p.grad is not None:
+                    g = p.grad.double()
+                    out[f"{name}/gstat/{pn}"] = np.array([g.sum().item(), g.norm().item()])
+    save("g9_mask.npz", **out)
+
+
 def build_items(trajs):
     import wrapper
     from mobgt_amd import synth
@@ -243,3 +271,5 @@ def run(which):
         make_g5_g6()
     if "g7" in which:
         make_g7()
+    if "g9" in which:
+        make_g9()

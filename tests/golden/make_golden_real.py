@@ -202,6 +202,19 @@ def main():
             out[f"a/gstat/{pn}"] = np.array([g.sum().item(), g.norm().item()])
             if p.grad.numel() <= 40000:
                 out[f"a/grad/{pn}"] = grad_sample(p.grad.numpy())
+    # the edge tables' gradients pass through the reference's explicit .half() casts (model_fqandtoyo.py:1178-1198): at the plain
+    # loss, per-pair gradients below fp16's 6e-8 flush to zero INSIDE THE REFERENCE.  The reference trains with --precision 16
+    # (README.md:62), i.e. under Lightning's GradScaler, whose initial scale is 65536: the same backward at loss x 65536 is what
+    # its training sees -- stored (divided by the scale again) for those two tables
+    m.zero_grad()
+    with cpu_cuda_alias():
+        loss_s = m.training_step(ba, 0) * 65536.0
+    loss_s.backward()
+    for pn, p in m.named_parameters():
+        if pn.startswith("edge_") and p.grad is not None:
+            g = p.grad.double() / 65536.0
+            out[f"a_s65536/gstat/{pn}"] = np.array([g.sum().item(), g.norm().item()])
+            out[f"a_s65536/grad/{pn}"] = grad_sample((p.grad / 65536.0).numpy())
     save("g8_gowalla_real.npz", **out)
     print("batch A nodes", [int(t["node_name"].numel()) for t in mols_a], "padded", tuple(ba.x.shape),
           "| batch B", [int(t["node_name"].numel()) for t in mols_b], tuple(bb.x.shape), "| bins", nb,

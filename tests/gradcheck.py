@@ -32,3 +32,39 @@ def assert_grad_close(got, ref, name, max_rel_l2=4e-2, kink=4.0, scale=1.0):
     assert q999 <= scale and mx <= kink * scale, (name, "elementwise", q999, mx, rms)
     assert stray <= 1e-3 * rms + 1e-12, (name, "non-zero where the reference is exactly zero", stray)
     return rel_l2
+
+
+# ---------------------------------------------------------------------------------------------- LeakyReLU branch replay at the head
+# The classifier head (model_fqandtoyo.py:1353-1364) runs FuseEmbeddings -- Linear + LeakyReLU(0.2) -- on the G graph-token rows
+# only (16 x 384 units at bench sizes).  A pre-activation within the forward pass's round-off (1e-3 with bf16 operands) of zero
+# takes the other branch on one side, and ONE such unit moves the whole backward pass by ~1 % relative L2, two or three by 2-4 %
+# (measured on the CPU by emulating the kernels' rounding points inside the oracle: with the branch pattern held fixed the same
+# arithmetic is 0.2-0.6 % from fp32 on every parameter; DESIGN.md section 2).  Like the dropout masks, the pattern is therefore
+# REPLAYED: taken from the device run, imposed on the oracle -- the comparison is then between two evaluations of the same
+# piecewise-linear branch of the network, and the gates can be as tight as the arithmetic is.
+def device_head_pattern(model, batch):
+    """[G, W] bool (cpu): which units of embed_fuse_model3 are on the positive side in the device's forward of `batch` (taken from
+    the encoder output the device produced, in fp32: model._enc_out), and the pre-activations themselves."""
+    import torch
+    with torch.no_grad():
+        model(batch)
+        enc = model._enc_out[:, 0, :].float()
+        user = model.user_embed_model.user_embedding.weight[batch.user.long().view(-1) - 1].float()
+        lin = model.embed_fuse_model3.fuse_embed
+        pre = torch.cat([enc, user], 1) @ lin.weight.float().t() + lin.bias.float()
+    return (pre > 0).cpu(), pre.cpu()
+
+
+def replay_head(pattern, seen=None):
+    """`act` hook for oracle.model_oracle.graphormer_fq_forward: LeakyReLU(0.2) of the head's graph-token rows with the branch of
+    every unit taken from `pattern`; `seen` (dict) collects how many units the oracle alone would have put on the other side."""
+    import torch
+
+    def act(site, pre):
+        if not (isinstance(site, tuple) and site[0] == "embed_fuse_model3" and site[2] == 0):
+            return None
+        m = pattern[site[1]]
+        if seen is not None:
+            seen[site[1]] = int(((pre.detach() > 0) != m).sum())
+        return torch.where(m, pre, 0.2 * pre)
+    return act

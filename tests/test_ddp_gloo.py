@@ -113,3 +113,78 @@ def test_layout_digest_mismatch_aborts_on_every_rank(tmp_path):
         msg = torch.load(out + str(r))
         assert "differs between rank 0 and ranks [1]" in msg and "refusing to all-reduce" in msg, msg
 
+
+
+def _gowalla_lengths(n, seed=0):
+    """Node counts drawn from the empirical Gowalla histogram (tests/golden/gowalla_n_hist.npz: N 1 .. 814, mean 9.7)."""
+    from mobgt_amd.workloads import gowalla_node_counts
+    return [int(v) for v in gowalla_node_counts(n, seed)]
+
+
+def test_balanced_batches_keep_the_samplers_sample_set_and_neighbouring_buckets_per_step():
+    """`data.balanced_batches` over 8 simulated ranks on an S-GOW-sized pool (4 970 graphs = the train split of gowalla_nevda,
+    node counts from the empirical histogram: mean 9.7, 97 % below 32, ONE graph of 600+ nodes):
+    (a) the union over ranks is DistributedSampler's padded multiset of the epoch, every rank has the same number of steps and
+        the same batch sizes;
+    (b) in every synchronous step the ranks' padded node counts are within 1.25x of each other -- node counts below 32 count
+        as 32 (a step's time does not depend on N there: it is launch-latency-bound) -- except in the steps that hold
+        the 2 x 8 x 16 longest graphs, where the histogram's tail lives (rank maxima 60 .. 640 in the last step: whole batches of
+        16 cannot give eight ranks an equal share of ONE 626-node graph);
+    (c) what the dealing is for: the epoch's wall time = sum over steps of the SLOWEST rank's cost (~ padded N^2, floor 32) drops
+        to less than a third of what DistributedSampler order with consecutive batches costs -- there the few long graphs are
+        scattered over many steps and each of them stalls seven ranks."""
+    from collections import Counter
+    from mobgt_amd.data import balanced_batches, bucket_nodes
+    world, B, n = 8, 16, 4970
+    lengths = _gowalla_lengths(n)
+
+    def padded(ids):
+        return max(bucket_nodes(max(lengths[i] for i in ids)), 32)
+    for epoch in (0, 2):
+        steps = balanced_batches(lengths, world, B, epoch=epoch, seed=3)
+        union = Counter(i for s in steps for r in s for i in r)
+        ref = Counter(i for rank in range(world) for i in shard_indices(n, rank, world, epoch=epoch, seed=3))
+        assert union == ref
+        assert all(len(s) == world and len({len(r) for r in s}) == 1 for s in steps)
+        assert sum(len(s[0]) for s in steps) == len(shard_indices(n, 0, world, epoch=epoch, seed=3))
+        tail = set(sorted(range(n), key=lambda i: -lengths[i])[:2 * world * B])
+        ratios, wall = [], 0.0
+        for s in steps:
+            p = [padded(r) for r in s]
+            wall += max(p) ** 2
+            if not any(i in tail for r in s for i in r):
+                ratios.append(max(p) / min(p))
+        assert max(ratios) <= 1.25, max(ratios)
+        assert len(ratios) >= len(steps) - 3
+        # the same epoch in DistributedSampler order with consecutive batches (what the loop dealt before round 5)
+        shards = [shard_indices(n, rank, world, epoch=epoch, seed=3) for rank in range(world)]
+        wall_plain = sum(max(padded(sh[o:o + B]) for sh in shards) ** 2 for o in range(0, len(shards[0]), B))
+        assert wall <= wall_plain / 3, (wall, wall_plain)
+    # the time order of the steps is drawn at random: the long steps are not all at one end of the epoch
+    p0 = [max(padded(r) for r in s) for s in steps]
+    top = sorted(range(len(p0)), key=lambda j: -p0[j])[:3]
+    assert min(top) < len(p0) - 3 or max(top) > 2
+
+
+def test_epoch_loop_deals_by_length_on_every_rank_alike():
+    """`train.EpochLoop.batches_of_epoch` (no GPU needed for the order): with more than one rank the loop takes its rank's column
+    of `balanced_batches`; one rank keeps the reference's DistributedSampler order."""
+    from mobgt_amd.data import balanced_batches
+    from mobgt_amd.train import EpochLoop
+    lengths = _gowalla_lengths(403, seed=1)
+    data = [{"node_name": [0] * n} for n in lengths]
+    loops = []
+    for rank in range(4):
+        lp = EpochLoop.__new__(EpochLoop)                 # (the order needs no device state)
+        lp.dataset, lp.rank, lp.world, lp.batch_size, lp.seed, lp.shuffle = data, rank, 4, 16, 5, True
+        lp.balance, lp._lengths = True, None
+        from mobgt_amd.data import BUCKETS
+        lp.buckets = BUCKETS
+        loops.append(lp)
+    steps = balanced_batches(lengths, 4, 16, epoch=1, seed=5)
+    for rank, lp in enumerate(loops):
+        assert lp.batches_of_epoch(1) == [s[rank] for s in steps]
+    one = EpochLoop.__new__(EpochLoop)
+    one.dataset, one.rank, one.world, one.batch_size, one.seed, one.shuffle, one.balance, one._lengths = data, 0, 1, 16, 5, True, False, None
+    idx = shard_indices(403, 0, 1, epoch=1, seed=5)
+    assert one.batches_of_epoch(1) == [idx[i:i + 16] for i in range(0, 403, 16)]

@@ -28,6 +28,7 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
+from gradcheck import device_head_pattern, replay_head              # noqa: E402
 from mobgt_amd import synth, workloads                              # noqa: E402
 from oracle import model_oracle as mo                                # noqa: E402
 
@@ -58,9 +59,9 @@ def oracle_consts(uni, model, name):
 LOSS_SCALE = 65536.0
 
 
-def oracle_step(sd0, batch, consts, n_layers):
+def oracle_step(sd0, batch, consts, n_layers, act=None):
     sd = {k: v.detach().float().cpu().clone().requires_grad_(True) for k, v in sd0.items()}
-    logits, _ = mo.graphormer_fq_forward(sd, batch, consts, n_layers=n_layers, H=8, D=20)
+    logits, _ = mo.graphormer_fq_forward(sd, batch, consts, n_layers=n_layers, H=8, D=20, act=act)
     loss = mo.gradient_tail_loss(logits, batch.y - 1, 0.2)
     (loss * LOSS_SCALE).backward()
     return logits.detach(), float(loss.detach()), {k: (None if v.grad is None else v.grad / LOSS_SCALE) for k, v in sd.items()}
@@ -122,7 +123,15 @@ def fsq(request):
     # the eager check; the TrainStep check zeroes them on the module
     consts = oracle_consts(uni, model, name)
     sd0 = {k: v.detach().clone() for k, v in model.state_dict().items()}
-    ref = [oracle_step(sd0, cpu_batch(b), consts, 6) for b in batches]
+    # the head's LeakyReLU branch pattern of the DEVICE run is imposed on the oracle (tests/gradcheck.py: one of the 16 x 384 units
+    # crossing zero inside the forward's round-off moves every gradient by ~1 %)
+    model.eval()
+    ref = []
+    for b in batches:
+        pattern, _ = device_head_pattern(model, b)
+        seen = {}
+        ref.append(oracle_step(sd0, cpu_batch(b), consts, 6, act=replay_head(pattern, seen)))
+        print(f"[{name}] head units the oracle alone puts on the other side of the LeakyReLU kink: {sum(seen.values())} of {pattern.numel()}")
     model._workload_name = name
     return uni, model, batches, sd0, ref
 
@@ -191,6 +200,8 @@ def test_graph_replayed_train_step_vs_oracle(fsq):
         report, ok = [], True
         for name in GRAD_PARAMS:
             ok &= check_grad(name, params[name].grad, ref_grads[name], report)
+        for r in report:
+            print("%-48s rms_nz %.3e  relL2 %.4f  q999 %.3f  max %.3f  stray %.1e" % r)
         assert ok, bad_rows(report)
         if i == 0:
             # the first replayed optimizer step is AdamW's t = 1 at lr(1): p <- p (1 - lr wd) - lr sign(g) wherever g

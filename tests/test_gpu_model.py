@@ -137,13 +137,17 @@ def _load_seeded(model, names_shapes, seed):
     return sd
 
 
-def _check_grads(model, z, tag, rtol=5e-2):
+def _check_grads(model, z, tag, rtol=5e-2, edge_tag=None):
+    """`edge_tag`: fixture prefix that holds the edge tables' gradients taken at loss x 65536 (golden G8): the reference's own
+    .half() casts flush their small per-pair gradients at the plain loss, this path (fp32 behind the emulated round trip) does
+    not -- against the scaled golden the tables are held to the common 4 % instead of 8 %."""
     bad = []
     for pn, p in model.named_parameters():
         if f"{tag}/grad_none/{pn}" in z:
             assert p.grad is None or float(p.grad.abs().sum()) == 0.0, pn
             continue
-        ref_sum, ref_norm = z[f"{tag}/gstat/{pn}"]
+        gtag = edge_tag if (edge_tag and pn.startswith("edge_")) else tag
+        ref_sum, ref_norm = z[f"{gtag}/gstat/{pn}"]
         g = p.grad.double()
         # atol: d(linear_k.bias) is exactly 0 in exact arithmetic (softmax is shift-invariant over keys); the
         # reference leaves fp32 round-off (1e-8) there, the bf16 MFMA operands leave ~1e-4
@@ -151,14 +155,14 @@ def _check_grads(model, z, tag, rtol=5e-2):
             bad.append((pn, g.norm().item(), float(ref_norm)))
         # ELEMENTWISE against the reference's gradient (golden G6: parameters up to 64 k elements, large matrices by every
         # 7th row): relative L2 <= 4 %, elements within 0.15 rms + 5 % (tests/gradcheck.py)
-        if f"{tag}/grad/{pn}" in z and not pn.endswith("linear_k.bias"):
-            rms, rel_l2, q999, mx, stray = grad_errors(grad_sample(p.grad.cpu().numpy()), z[f"{tag}/grad/{pn}"])
+        if f"{gtag}/grad/{pn}" in z and not pn.endswith("linear_k.bias"):
+            rms, rel_l2, q999, mx, stray = grad_errors(grad_sample(p.grad.cpu().numpy()), z[f"{gtag}/grad/{pn}"])
             # relative-L2 allowance 8 % instead of 4 % for three tables: the edge tables (the reference's explicit fp16
             # casts, model_fqandtoyo.py:1178-1198, flush per-pair gradients below 6e-8 in this un-scaled golden run --
             # tests/test_gpu_bench_parity.py evaluates them at loss x 65536) and the time-slot table (its gradient is a
             # heavily cancelling sum, rms 20-40x below its neighbours: round-off of the attention's bf16 operands is
             # 5 % of what is left)
-            lim = 8e-2 if pn.startswith("edge_") or pn.startswith("time_embed") else 4e-2
+            lim = 8e-2 if (pn.startswith("edge_") and gtag == tag) or pn.startswith("time_embed") else 4e-2
             if rel_l2 > lim or q999 > 1.0 or mx > 4.0 or stray > 1e-3 * rms + 1e-12:
                 bad.append((pn, "elementwise", rel_l2, q999, mx, stray))
     assert not bad, bad

@@ -125,6 +125,27 @@ def test_stock_bias_and_logits_g5_g6(golden_dir):
     np.testing.assert_allclose(loss.item(), z6["stock/loss"], rtol=1e-5)
 
 
+@pytest.mark.parametrize("variant", ["stock", "fq"])
+def test_encoder_layer_with_mask_g9(golden_dir, variant):
+    """model.py:446-448: the masked pairs' scores (bias included) are set to 0 in front of the softmax."""
+    from inputs import MASK_CASES, mask_case
+    z = load(golden_dir, "g9_mask.npz")
+    for cname, C, T, G, ffn in MASK_CASES:
+        name = f"{variant}/{cname}"
+        seed, x, bias, gy, _, mask = mask_case(variant, C, T, G)
+        assert int(mask.sum()) == int(z[f"{name}/mask_count"])
+        sd = seeded_state([("L." + n, s) for n, s in encoder_param_list(variant, C, ffn)], seed + 1)
+        x = torch.from_numpy(x).requires_grad_(True)
+        bias = torch.from_numpy(bias).requires_grad_(True)
+        fn = mo.encoder_layer_stock if variant == "stock" else mo.encoder_layer_fq
+        y = fn(sd, "L", x, bias, 8, mask=torch.from_numpy(mask))
+        y.backward(torch.from_numpy(gy))
+        np.testing.assert_allclose(y.detach().numpy(), z[f"{name}/y"], **TOL)
+        np.testing.assert_allclose(x.grad.numpy(), z[f"{name}/dx"], rtol=1e-4, atol=1e-5)
+        np.testing.assert_allclose(bias.grad.numpy(), z[f"{name}/dbias"], rtol=1e-4, atol=1e-6)
+        assert float(bias.grad[torch.from_numpy(mask).unsqueeze(1).expand_as(bias)].abs().max()) == 0.0
+
+
 def _universe(z6):
     return synth.Universe(P=64, n_cat=8, n_user=8, poi_table=z6["uni/poi_table"], graph_adj=z6["uni/graph_adj"],
                           graph_dist=z6["uni/graph_dist"], graph_cat=z6["uni/graph_cat"], distance=z6["uni/distance"])

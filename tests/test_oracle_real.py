@@ -102,3 +102,10 @@ def test_real_fq_forward_loss_grads_g8(g8):
         if f"a/grad/{pn}" in z:
             refg = z[f"a/grad/{pn}"]
             np.testing.assert_allclose(grad_sample(p.grad.numpy()), refg, rtol=5e-3, atol=1e-3 * float(np.abs(refg).max()) + 1e-9, err_msg=pn)
+    # the edge tables at GradScaler's loss x 65536 (their small per-pair gradients survive the reference's .half() casts there)
+    for p in sd.values():
+        p.grad = None
+    (mo.fq_training_loss(sd, ba, consts, **kw) * 65536.0).backward()
+    for pn in ("edge_encoder.weight", "edge_dis_encoder.weight"):
+        refg = z[f"a_s65536/grad/{pn}"]
+        np.testing.assert_allclose(grad_sample((sd[pn].grad / 65536.0).numpy()), refg, rtol=5e-3, atol=1e-3 * float(np.abs(refg).max()) + 1e-9, err_msg=pn)
