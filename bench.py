@@ -847,8 +847,6 @@ def main():
         tt = torch.tensor(times, device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         exposed_us = float((tt[0] - tt[1]).item()) * 1e6
-        if getattr(ts, "one_graph", False):           # (the exchange is part of the step graph: `ts.comm` switches nothing off)
-            exposed_us = None
 
     if rank == 0:
         m = w["model"]

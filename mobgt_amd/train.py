@@ -227,7 +227,7 @@ def assert_same_across_ranks(digest, what, device=None):
 
 class TrainStep:
     def __init__(self, model, batches, autocast_dtype=None, use_graph=True, seed=1, overlap=True, batch_fn=None,
-                 grad_comm_dtype=None):
+                 grad_comm_dtype=None, keep_head_rows=False):
         """`batches`: pre-collated batches resident on the device (their tensors are the static inputs of the captured
         graphs).  `batch_fn`: optional callable applied to a batch INSIDE the step (and so inside its graph) before the model
         sees it -- `EpochLoop` passes raw, un-collated arrays + `DeviceCollator.finish`, so that collating a fresh batch is
@@ -235,6 +235,7 @@ class TrainStep:
         self.model = model
         self.batches = list(batches)
         self.batch_fn = batch_fn
+        self.keep_head_rows = bool(keep_head_rows)      # tests: TrainStep.enc_outs[i] = graph-token rows of batch i's last step
         # torch.bfloat16: the gradient exchange moves bf16 (half the bytes over xGMI; RCCL then also SUMS in bf16 -- 8 ranks:
         # relative error ~2^-8 per element on top of the gradient's own bf16-operand noise); the result is widened back
         # into the fp32 flat buffer the optimizer reads.  Default None: fp32 exchange (what the parity tests pin).
@@ -321,20 +322,26 @@ class TrainStep:
         # collective's stream, bf16 exchange buffer -- so that the RCCL ("nccl") branch executes on a one-GPU box
         self.force_comm = (os.environ.get("MOBGT_FORCE_COMM") == "1" and dist.is_available() and dist.is_initialized())
         self.ddp = self.world > 1 or self.force_comm
-        # Data parallel: split the backward at the encoder output so that the head bucket's all-reduce (61 % of the
-        # bytes, ready after ~20 kernels) runs on RCCL's stream while the rest of the backward is still executing.
-        # (overlap="force": the two-phase path at world size 1 as well -- tests)
-        self.overlap = bool(overlap and use_graph and (self.ddp or overlap == "force") and self.n_head > 0
+        # Data parallel, three forms of one step:
+        #  * default over RCCL -- `one_graph`: the WHOLE step is one hipGraph per batch: forward, backward, the gradient
+        #    all-reduce issued on the step's OWN stream (a synchronous c10d collective runs on the caller's stream; inside a
+        #    capture it becomes a node of the graph: no second stream, no cross-stream edge, no host call between replays),
+        #    the average and AdamW.  The exchange is serial with the backward -- nothing hides it -- but the step carries no
+        #    structure cost: round 4's four-replay form cost +25 % before any wire time (0.577 -> 0.724 ms with one forced
+        #    rank), more than the overlap can win back on a 0.6 ms step;
+        #  * MOBGT_DDP_OVERLAP=1 (or overlap="force": tests) -- `overlap`: the backward split at the encoder output (and, with
+        #    MOBGT_DDP_PARTS > 1, in front of a few layers) into graphs replayed one after the other, every completed slice
+        #    of the flat buffer all-reduced asynchronously on RCCL's stream beside the next replay;
+        #  * gloo (host collectives are not capturable) or MOBGT_DDP_HOST_EXCHANGE=1: forward + backward graph, all-reduce
+        #    issued by the host, optimizer graph.
+        want_overlap = overlap == "force" or (bool(overlap) and os.environ.get("MOBGT_DDP_OVERLAP") == "1")
+        self.overlap = bool(want_overlap and use_graph and (self.ddp or overlap == "force") and self.n_head > 0
                             and hasattr(model, "_enc_out"))
-        self.graphs_b, self._g_enc, self._loss_slots = {}, {}, {}
+        self.graphs_b, self._g_enc, self._loss_slots, self.enc_outs = {}, {}, {}, {}
         self._plan_buckets()
-        # MOBGT_DDP_ONE_GRAPH=1 (opt-in, end of round 4): the data-parallel step as ONE graph per batch -- the buckets' all-reduces
-        # are CAPTURED on a second stream that forks from / joins the step's inside the graph (RCCL collectives are capturable:
-        # tools/dbg/r4_rccl_capture_probe.py), instead of being issued by the host between four graph replays.  Measured with one
-        # rank only (DESIGN 5 g); the default stays the host-issued form until a node has run it.
-        self.one_graph = bool(self.overlap and self.ddp and os.environ.get("MOBGT_DDP_ONE_GRAPH") == "1"
-                              and dist.get_backend() == "nccl")             # (a gloo all-reduce is host work: not capturable)
-        self.comm_stream = torch.cuda.Stream(device=dev) if self.one_graph else None
+        self.one_graph = bool(self.ddp and use_graph and not self.overlap and dist.get_backend() == "nccl"
+                              and os.environ.get("MOBGT_DDP_HOST_EXCHANGE") != "1")
+        self.graphs_nocomm = {}
         self.comm = True        # False: skip the gradient exchange (bench.py measures the exposed all-reduce time that way)
         self._prepared = False
         self.comm_buf = (torch.empty(self.flat.flat.numel(), dtype=grad_comm_dtype, device=dev)
@@ -350,10 +357,11 @@ class TrainStep:
         part replays.  What is exposed at the end is the LAST bucket only (node features, GCNs, embedding and bias tables: a few
         MB) instead of everything behind the head (39 % of the bytes in round 3).  `self.parts`: [(cut layer or None, first
         parameter, end parameter, first element, end element)], in execution order; [] = the single phase B of round 3.
-        MOBGT_DDP_PARTS: number of parts (default 3; 1 = off)."""
+        MOBGT_DDP_PARTS: number of parts (default 1 = the single phase B; the layer-wise parts have run over RCCL with one rank
+        and over gloo with two, never on a multi-GPU node: ADVICE r4)."""
         self.parts = []
         layers = list(getattr(self.model, "layers", []))
-        n_parts = int(os.environ.get("MOBGT_DDP_PARTS", "3"))
+        n_parts = int(os.environ.get("MOBGT_DDP_PARTS", "1"))
         if not self.overlap or len(layers) < 2 or n_parts < 2:
             return
         pos = {id(p): i for i, p in enumerate(self.flat.params)}
@@ -486,6 +494,10 @@ class TrainStep:
     def _fwd_bwd(self, batch, slot=None):
         self._prologue()
         loss = self._loss(batch)
+        if slot is not None and self.keep_head_rows and getattr(self.model, "_enc_out", None) is not None:
+            # (parity tests: a copy of the encoder output's graph-token rows -- what the classifier head reads -- as one more node
+            #  of this batch's graph; the encoder output itself is overwritten in place by the backward pass)
+            self.enc_outs[slot] = self.model._enc_out[:, 0, :].detach().clone()
         ops.wgrad_deferral(self._defer)          # leaf weight gradients are recorded ...
         try:
             loss.backward(gradient=ops.unit_grad(loss.device))
@@ -579,26 +591,6 @@ class TrainStep:
             with torch.cuda.graph(g, pool=self.pool if os.environ.get("MOBGT_SHARED_POOL") else None, stream=self.stream):
                 self._fwd_bwd(batch, slot=i)
             return g
-        if self.one_graph:
-            na = self.n_head_elems
-            bounds = [(0, na)] + ([(e0, e1) for _, _, _, e0, e1 in self.parts] if self.parts else [(na, self.flat.flat.numel())])
-            with torch.cuda.graph(g, stream=self.stream):
-                self._phase_a(batch, i)
-                self._exchange_captured(*bounds[0])
-                if self.parts:
-                    for s in range(len(self.parts)):
-                        self._phase_b_part(i, s)
-                        self._exchange_captured(*bounds[s + 1])
-                else:
-                    self._phase_b(i)
-                    self._exchange_captured(*bounds[1])
-                torch.cuda.current_stream().wait_stream(self.comm_stream)          # join: every bucket has been exchanged
-                if self.comm_buf is not None:
-                    torch.mul(self.comm_buf, 1.0 / self.world, out=self.flat.flat)
-                elif self.world > 1:
-                    self.flat.flat.div_(self.world)
-            self.graphs_b[i] = []
-            return g
         # two graphs over ONE autograd graph: phase B is captured right after phase A and replays its kernels on the
         # activations phase A's replay leaves at the same addresses (A's private pool; nothing else writes there)
         with torch.cuda.graph(g, stream=self.stream):
@@ -618,17 +610,18 @@ class TrainStep:
         self.graphs_b[i] = [gb]
         return g
 
-    def _exchange_captured(self, e0, e1):
-        """(inside a capture) all-reduce of gradient elements [e0, e1) on the collective's stream, forked from the step's here."""
-        if e1 <= e0:
-            return
-        self.comm_stream.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(self.comm_stream):
-            buf = self.flat.flat
-            if self.comm_buf is not None:
-                self.comm_buf[e0:e1].copy_(self.flat.flat[e0:e1])
-                buf = self.comm_buf
-            dist.all_reduce(buf[e0:e1], op=dist.ReduceOp.SUM)
+    def _exchange(self):
+        """Sum of the flat gradient buffer over the ranks and the average, issued on the CURRENT stream (eager, or as nodes of the
+        step graph being captured): through the bf16 exchange buffer when there is one (half the bytes on the wire; the widening
+        pass applies 1 / world), else in place."""
+        if self.comm_buf is not None:
+            self.comm_buf.copy_(self.flat.flat)
+            dist.all_reduce(self.comm_buf, op=dist.ReduceOp.SUM)
+            torch.mul(self.comm_buf, 1.0 / self.world, out=self.flat.flat)
+        elif self.world > 1:
+            self.flat.all_reduce_mean()
+        else:                                  # (one forced rank: the collective itself, no division)
+            dist.all_reduce(self.flat.flat, op=dist.ReduceOp.SUM)
 
     def prepare(self):
         """Capture one forward/backward graph per batch and one optimizer graph."""
@@ -659,19 +652,32 @@ class TrainStep:
         # Single process, no all-reduce between backward and optimizer: the optimizer rides at the end of every batch's
         # graph -- one graph launch per step instead of two (the boundary between two replayed graphs idles the device
         # for ~8.7 us: `tools/prof_gaps.sh`).  Every warm-up has run by now, so this second capture only records.
-        self.fused_opt = (not self.overlap and not self.ddp              # (never with ranks: `comm` may be toggled later)
+        self.fused_opt = (not self.overlap and (not self.ddp or self.one_graph)
                           and os.environ.get("MOBGT_FUSED_OPT_GRAPH", "1") != "0")
         if self.fused_opt:
+            if self.one_graph:
+                with self._on_stream():            # (the collective's first call on these buffers: outside any capture)
+                    saved = self.flat.flat.clone()
+                    self._exchange()
+                    self.flat.flat.copy_(saved)
+                self._join()
             for i in range(len(self.batches)):
                 self._capture_with_opt(i)
         self._prepared = True
 
-    def _capture_with_opt(self, i):
+    def _capture_with_opt(self, i, comm=None):
+        """The whole step of batch i as ONE graph: forward + backward [+ gradient exchange on this stream: `one_graph`] + AdamW."""
+        comm = self.one_graph if comm is None else comm
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g, stream=self.stream):
             self._fwd_bwd(self.batches[i], slot=i)
+            if comm:
+                self._exchange()
             self._opt_step()
-        self.graphs[i] = g
+        if comm or not self.one_graph:
+            self.graphs[i] = g
+        else:
+            self.graphs_nocomm[i] = g
 
     # ---- peer waits that gave up (csrc/chain.hip WS_FAULT, head.hip, smallgcn.hip): detection and recovery ---------------
     def recapture(self):
@@ -679,6 +685,7 @@ class TrainStep:
         optimizer state and the step counter are left as they are."""
         if not (self.use_graph and self._prepared):
             return
+        self.graphs_nocomm.clear()
         for i in range(len(self.batches)):
             self.graphs[i] = self._capture(i)
             if self.fused_opt:
@@ -756,9 +763,18 @@ class TrainStep:
         """One optimizer step on pre-collated batch i (model_fqandtoyo.py:1434-1478 + optimizer + scheduler)."""
         if self.use_graph:
             self._loss_ref = self._loss_slots[i % len(self.batches)]
-        if self.overlap and self.one_graph:
-            self.graphs[i % len(self.batches)].replay()         # (forward, backward parts and their captured exchanges)
-        elif self.overlap:
+        if self.one_graph and self.use_graph and getattr(self, "fused_opt", False):
+            j = i % len(self.batches)
+            if self.comm:
+                self.graphs[j].replay()                         # (forward, backward, the captured exchange, AdamW)
+            else:
+                if j not in self.graphs_nocomm:                 # (bench.py: the same step without its exchange)
+                    self._capture_with_opt(j, comm=False)
+                self.graphs_nocomm[j].replay()
+            self.sched_state["step_count"] += 1
+            self._set_lr()
+            return self.loss_out
+        if self.overlap:
             j = i % len(self.batches)
             na = self.n_head_elems
             comm = self.ddp and self.comm
@@ -791,14 +807,7 @@ class TrainStep:
             else:
                 self._fwd_bwd(self.batches[i % len(self.batches)])
             if self.ddp and self.comm:
-                if self.comm_buf is not None:
-                    self.comm_buf.copy_(self.flat.flat)
-                    dist.all_reduce(self.comm_buf, op=dist.ReduceOp.SUM)
-                    torch.mul(self.comm_buf, 1.0 / self.world, out=self.flat.flat)
-                elif self.world > 1:
-                    self.flat.all_reduce_mean()
-                else:                                  # (one forced rank: the collective itself, no division)
-                    dist.all_reduce(self.flat.flat, op=dist.ReduceOp.SUM)
+                self._exchange()
         if self.use_graph:
             if not getattr(self, "fused_opt", False):
                 self.opt_graph.replay()

@@ -42,16 +42,21 @@ def assert_grad_close(got, ref, name, max_rel_l2=4e-2, kink=4.0, scale=1.0):
 # arithmetic is 0.2-0.6 % from fp32 on every parameter; DESIGN.md section 2).  Like the dropout masks, the pattern is therefore
 # REPLAYED: taken from the device run, imposed on the oracle -- the comparison is then between two evaluations of the same
 # piecewise-linear branch of the network, and the gates can be as tight as the arithmetic is.
-def device_head_pattern(model, batch):
+def device_head_pattern(model, batch, enc_out=None, state=None):
     """[G, W] bool (cpu): which units of embed_fuse_model3 are on the positive side in the device's forward of `batch` (taken from
-    the encoder output the device produced, in fp32: model._enc_out), and the pre-activations themselves."""
+    the encoder output the device produced, in fp32: model._enc_out after a forward here, or `enc_out` = the graph-token rows a
+    replayed step graph copied aside, train.TrainStep(keep_head_rows=True).enc_outs[i]), and the pre-activations themselves.
+    `state`: the state dict the step STARTED from (a replayed train step has already moved the model's parameters)."""
     import torch
     with torch.no_grad():
-        model(batch)
-        enc = model._enc_out[:, 0, :].float()
-        user = model.user_embed_model.user_embedding.weight[batch.user.long().view(-1) - 1].float()
-        lin = model.embed_fuse_model3.fuse_embed
-        pre = torch.cat([enc, user], 1) @ lin.weight.float().t() + lin.bias.float()
+        if enc_out is None:
+            model(batch)
+            enc_out = model._enc_out[:, 0, :]
+        enc = enc_out.float()                  # [G, C]: the graph-token rows
+        sd = state if state is not None else model.state_dict()
+        w = lambda k: sd[k].to(enc.device).float()
+        user = w("user_embed_model.user_embedding.weight")[batch.user.long().view(-1) - 1]
+        pre = torch.cat([enc, user], 1) @ w("embed_fuse_model3.fuse_embed.weight").t() + w("embed_fuse_model3.fuse_embed.bias")
     return (pre > 0).cpu(), pre.cpu()
 
 

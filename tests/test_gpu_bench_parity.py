@@ -101,8 +101,18 @@ def check_grad(name, got, ref, report):
     return not bad_rows([row])
 
 
+# Round 5: with the head's LeakyReLU branch pattern replayed into the oracle (tests/gradcheck.py) the relative L2 error is <= 0.9 %
+# on every parameter but the small cancelling tables (the bias tables: sums of bf16 dS over thousands of pairs and six layers; the
+# 48-slot time table), which reach 2.0-2.7 % on the long S-GOW batch: 1.5 % for everything else, the old 3 % for those.
+SMALL_TABLES = ("rel_pos_encoder", "poi_pos_encoder", "edge_encoder", "edge_dis_encoder", "time_embed_model_48", "graph_token_virtual_distance")
+
+
+def max_rel_l2(name):
+    return MAX_REL_L2 if name.split(".")[0] in SMALL_TABLES else 1.5e-2
+
+
 def bad_rows(report):
-    return [r for r in report if r[2] > MAX_REL_L2 or r[3] > _LIMIT.get(r[0], 1.0) or r[4] > KINK or r[5] > 1e-3 * r[1]]
+    return [r for r in report if r[2] > max_rel_l2(r[0]) or r[3] > _LIMIT.get(r[0], 1.0) or r[4] > KINK or r[5] > 1e-3 * r[1]]
 
 
 @pytest.fixture(scope="module", params=["fsq", "gow"])

@@ -78,7 +78,11 @@ def test_bucket_padded_batch_equals_the_unpadded_batch(fsq_small):
         if n.endswith("linear_k.bias"):
             continue            # exactly 0 in exact arithmetic (softmax is shift-invariant over keys): round-off on both sides
         scale = float(ga[n].abs().max())
-        np.testing.assert_allclose(gb[n].numpy(), ga[n].numpy(), rtol=0, atol=2e-3 * scale + 1e-12, err_msg=n)
+        # (the edge tables' gradients pass the emulated fp16 round trip of model_fqandtoyo.py:1178-1198 at the plain loss: their
+        #  entries are multiples of fp16's smallest subnormal, 5.96e-8, and an ulp of difference upstream -- the padded batch runs
+        #  other launch geometries -- moves an entry by one or two of those steps)
+        quanta = 2 * 5.97e-8 if n.startswith("edge_") else 0.0
+        np.testing.assert_allclose(gb[n].numpy(), ga[n].numpy(), rtol=0, atol=2e-3 * scale + quanta + 1e-12, err_msg=n)
 
 
 def _dataset(name, uni, n_batches, seed0):
@@ -103,7 +107,10 @@ def test_graph_loop_equals_eager_loop_step_by_step():
         losses.append((seq, sorted(loop.slots)))
     (a, ka), (b, kb) = losses
     assert ka == kb and len(ka) >= 2, ka            # several buckets, i.e. lazily captured graphs, took part
-    np.testing.assert_allclose(a, b, rtol=3e-4)      # (f32 atomics order differs run to run; other masks would differ by 1e-2)
+    # (f32 atomics order differs run to run, in front of bf16 rounding points: two runs of ONE form differ by ~1e-3 in their
+    #  gradients, AdamW's sign-like first steps turn that into loss differences of 3e-4 .. 8e-4 at this learning rate -- 7 % at
+    #  2e-3, see above; other masks or another step counter would show as 1e-2)
+    np.testing.assert_allclose(a, b, rtol=2e-3)
     assert len(set(a)) == len(a)                      # (the steps really differ)
 
 
@@ -115,12 +122,22 @@ def test_epoch_over_the_s_gow_pool_visits_the_distributed_samplers_set(rank, wor
     loop = EpochLoop(model, coll, data, batch_size=16, seed=11, use_graph=True, rank=rank, world=world)
     res = loop.run_epoch(epoch=2)
     want = shard_indices(n_train, rank, world, epoch=2, seed=11)
-    assert res["sample_ids"] == want and len(want) == -(-n_train // world)
+    if world == 1:
+        assert res["sample_ids"] == want                   # one rank: the reference's order (DistributedSampler, consecutive batches)
+    else:
+        # several ranks: this rank's column of the length-balanced dealing (data.balanced_batches; its union over the ranks is
+        # the sampler's multiset: tests/test_ddp_gloo.py), as many samples and steps as the sampler gives every rank
+        from mobgt_amd.data import balanced_batches
+        steps = balanced_batches([len(t["node_name"]) for t in data], world, 16, epoch=2, seed=11)
+        assert res["sample_ids"] == [i for s in steps for i in s[rank]]
+        others = [i for s in steps for r in range(world) if r != rank for i in s[r]]
+        assert sorted(res["sample_ids"] + others) == sorted(i for r in range(world) for i in shard_indices(n_train, r, world, epoch=2, seed=11))
+    assert len(res["sample_ids"]) == len(want) == -(-n_train // world)
     assert res["steps"] == -(-len(want) // 16)
     # one graph per (G, bucket) that occurred; buckets cover the workload's node counts up to its 814-node tail
     keys = sorted(loop.slots)
     assert all(k[1] in BUCKETS for k in keys) and len(keys) == res["graphs"]
-    lens = [len(data[i]["node_name"]) for i in want]
+    lens = [len(data[i]["node_name"]) for i in res["sample_ids"]]
     assert max(k[1] for k in keys) == bucket_nodes(max(lens))
     assert len(keys) <= len(loop.ts.graphs) <= 2 * len(keys)       # (round 4: one step graph per staging buffer of a bucket)
     assert np.isfinite(float(loop.ts.loss_out.item()))
@@ -129,3 +146,6 @@ def test_epoch_over_the_s_gow_pool_visits_the_distributed_samplers_set(rank, wor
     ds = DistributedSampler(range(n_train), num_replicas=world, rank=rank, shuffle=True, seed=11)
     ds.set_epoch(2)
     assert list(ds) == want
+    if world > 1:
+        plain = EpochLoop(model, coll, data, batch_size=16, seed=11, use_graph=True, rank=rank, world=world, balance=False)
+        assert [i for b in plain.batches_of_epoch(2) for i in b] == want     # balance=False: the sampler's order on every rank

@@ -147,31 +147,35 @@ def _run_one_rank(tmp_path, steps, extra_env=None):
 def test_rccl_branch_executes_on_one_gpu(tmp_path):
     """VERDICT r3 (a15, "the nccl branch has never executed anywhere"): a process group of ONE rank over RCCL ("nccl") on this
     box's GPU, `MOBGT_FORCE_COMM=1` so that TrainStep takes its data-parallel path: communicator creation with `device_id`,
-    the parameter broadcast, the layout all-gather, three step graphs per batch with the layer-wise buckets' asynchronous
-    all-reduces on RCCL's stream beside the replays (fp32, then through the bf16 exchange buffer), barrier, teardown.  A sum
-    over one rank changes nothing: losses / gradients must be those of the same worker WITHOUT the forced exchange, up to what
-    two runs of one step differ by (f32 atomics in front of bf16 rounding points) -- bf16 exchange: up to bf16 rounding."""
+    the parameter broadcast, the layout all-gather, then every form of the data-parallel step (train.TrainStep.__init__):
+      fp32 / bf16   the default -- ONE graph per batch with the all-reduce captured on the step's own stream (in place, then
+                    through the bf16 exchange buffer);
+      ovl / ovl16   MOBGT_DDP_OVERLAP=1, MOBGT_DDP_PARTS=3: three step graphs per batch, the layer-wise buckets' asynchronous
+                    all-reduces on RCCL's stream beside the replays;
+      host          MOBGT_DDP_HOST_EXCHANGE=1: the all-reduce issued by the host between the backward and the optimizer graph.
+    A sum over one rank changes nothing: losses / gradients must be those of the same worker WITHOUT the forced exchange, up to
+    what two runs of one step differ by (f32 atomics in front of bf16 rounding points) -- bf16 exchange: up to bf16 rounding."""
     runs = {}
+    ovl = {"MOBGT_FORCE_COMM": "1", "MOBGT_DDP_OVERLAP": "1", "MOBGT_DDP_PARTS": "3"}
     for tag, env in (("plain", {}), ("fp32", {"MOBGT_FORCE_COMM": "1"}), ("bf16", {"MOBGT_FORCE_COMM": "1", "MOBGT_TEST_GRAD_COMM": "bf16"}),
-                     ("one", {"MOBGT_FORCE_COMM": "1", "MOBGT_DDP_ONE_GRAPH": "1"}),
-                     ("one16", {"MOBGT_FORCE_COMM": "1", "MOBGT_DDP_ONE_GRAPH": "1", "MOBGT_TEST_GRAD_COMM": "bf16"})):
+                     ("ovl", ovl), ("ovl16", dict(ovl, MOBGT_TEST_GRAD_COMM="bf16")),
+                     ("host", {"MOBGT_FORCE_COMM": "1", "MOBGT_DDP_HOST_EXCHANGE": "1"})):
         d = tmp_path / tag
         d.mkdir()
         runs[tag] = _run_one_rank(d, 3, env)
     a, b, c = runs["plain"], runs["fp32"], runs["bf16"]
-    # opt-in: the same step as ONE graph per batch with the buckets' all-reduces captured inside it (MOBGT_DDP_ONE_GRAPH=1)
-    for tag in ("one", "one16"):
+    for tag in ("ovl", "ovl16", "host"):
         r = runs[tag]
-        assert r["backend"] == "nccl" and r["forced"] and r["overlap"] and r["one_graph"]
+        assert r["backend"] == "nccl" and r["forced"] and not r["one_graph"]
+        assert r["overlap"] == (tag != "host") and (r["parts"] >= 2) == (tag != "host")
         assert all(np.isfinite(r["losses"]))
         np.testing.assert_allclose(r["losses"], a["losses"], rtol=2e-2)
         assert float((r["grads"] - a["grads"]).norm() / a["grads"].norm()) < 5e-2
-    assert not b["one_graph"]
-    print("backend", b["backend"], "overlap", b["overlap"], "parts", b["parts"], "losses", a["losses"], b["losses"], c["losses"])
+    print("backend", b["backend"], "one graph", b["one_graph"], "losses", a["losses"], b["losses"], c["losses"])
     assert a["backend"] == b["backend"] == c["backend"] == "nccl"
-    assert not a["forced"] and not a["overlap"]
-    assert b["forced"] and b["overlap"] and b["parts"] >= 2 and b["comm_dtype"] is None
-    assert c["forced"] and c["overlap"] and c["comm_dtype"] == "torch.bfloat16"
+    assert not a["forced"] and not a["overlap"] and not a["one_graph"]
+    assert b["forced"] and b["one_graph"] and not b["overlap"] and b["comm_dtype"] is None
+    assert c["forced"] and c["one_graph"] and c["comm_dtype"] == "torch.bfloat16"
     for r in (b, c):
         assert all(np.isfinite(r["losses"]))
         np.testing.assert_allclose(r["losses"], a["losses"], rtol=2e-2)
@@ -199,30 +203,16 @@ def test_bf16_gradient_exchange_tracks_the_fp32_exchange(tmp_path):
     assert dp < 0.05 * 1.5e-3 * n ** 0.5, (dp, n)
 
 
-def test_two_rank_train_step_keeps_replicas_identical(tmp_path):
+@pytest.mark.parametrize("form", ["default", "overlap"])
+def test_two_rank_train_step_keeps_replicas_identical(tmp_path, form):
     """Two data-parallel ranks of TrainStep (RCCL when the box has two GPUs, otherwise gloo with both ranks on cuda:0):
     after three steps on different per-rank data every rank holds bit-identical parameters, Adam moments and bf16
-    shadows, and the averaged gradient buffer is the same on both."""
-    port = _free_port()
-    procs = []
-    for r in range(2):
-        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-                   HSA_ENABLE_IPC_MODE_LEGACY="0")
-        procs.append(subprocess.Popen([sys.executable, os.path.join(os.path.dirname(__file__), "_ddp_worker.py"), str(tmp_path), "3"],
-                                      env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
-    outs = []
-    for p in procs:
-        try:
-            o, _ = p.communicate(timeout=600)
-        except subprocess.TimeoutExpired:
-            for q in procs:
-                q.kill()
-            raise
-        outs.append(o.decode(errors="replace"))
-    assert all(p.returncode == 0 for p in procs), "\n".join(outs)
-    a, b = (torch.load(os.path.join(tmp_path, f"rank{r}.pt")) for r in range(2))
-    print("backend", a["backend"], "overlap", a["overlap"], "losses", a["losses"], b["losses"])
-    assert a["overlap"] and b["overlap"]                       # world size 2 takes the two-phase (overlapped) path
+    shadows, and the averaged gradient buffer is the same on both.  `default`: one graph with the captured all-reduce over
+    RCCL, the host-issued exchange over gloo; `overlap`: MOBGT_DDP_OVERLAP=1 with three layer-wise parts."""
+    a, b = _run_two_ranks(tmp_path, 3, {} if form == "default" else {"MOBGT_DDP_OVERLAP": "1", "MOBGT_DDP_PARTS": "3"})
+    print("backend", a["backend"], "overlap", a["overlap"], "one graph", a["one_graph"], "losses", a["losses"], b["losses"])
+    assert a["overlap"] == b["overlap"] == (form == "overlap")
+    assert a["one_graph"] == (form == "default" and a["backend"] == "nccl")
     assert a["losses"] != b["losses"]                          # different data per rank
     for k in ("params", "exp_avg", "exp_avg_sq", "grads", "shadow"):
         assert torch.equal(a[k], b[k]), k
@@ -356,7 +346,10 @@ def test_bias_tables_backward_as_passenger_of_the_category_gcn_launch(monkeypatc
     for n in names:
         sc = float(b[n].abs().max())
         err = float((a[n] - b[n]).abs().max())
-        assert sc > 0 and err <= 2e-3 * sc, (n, err, sc)
+        # (the edge tables' entries are multiples of fp16's smallest subnormal at the plain loss -- the emulated round trip of
+        #  model_fqandtoyo.py:1178-1198 --: an ulp of difference in the f32 sums moves an entry by one or two of those steps)
+        quanta = 2 * 5.97e-8 if n.startswith("edge_") else 0.0
+        assert sc > 0 and err <= 2e-3 * sc + quanta, (n, err, sc)
 
 
 def test_encoder_input_forward_in_one_launch_is_bit_identical_to_the_four_launches(monkeypatch):
@@ -691,7 +684,7 @@ def test_injected_peer_wait_fault_is_detected_and_the_step_rerun_in_the_safe_for
         ops.set_peer_wait_limit(0)
 
 
-def test_layerwise_gradient_buckets_on_the_benched_model_match_the_single_graph():
+def test_layerwise_gradient_buckets_on_the_benched_model_match_the_single_graph(monkeypatch):
     """VERDICT r3 next #3a: under data parallelism phase B of the step is cut in front of layers 3 and 0 of the S-FSQ model into
     three hipGraphs over one autograd graph (train.TrainStep._plan_buckets); the flat buffers are laid out [head | layer 5 | ...
     | layer 0 | rest] so that what each part completes is ONE slice, all-reduced beside the next part.  Here (one process,
@@ -700,6 +693,7 @@ def test_layerwise_gradient_buckets_on_the_benched_model_match_the_single_graph(
     from mobgt_amd import workloads
     from mobgt_amd.train import TrainStep
     res = {}
+    monkeypatch.setenv("MOBGT_DDP_PARTS", "3")
     for mode in (False, "force"):
         uni, model, coll = workloads.build("fsq", DEV, seed=1, model_overrides=dict(peak_lr=1e-12, end_lr=1e-13))
         batches = [coll(t) for t in workloads.make_pool("fsq", 2, 16, uni)]

@@ -24,6 +24,7 @@ pytestmark = pytest.mark.gpu
 
 from mobgt_amd import ops, workloads                                     # noqa: E402
 from oracle import model_oracle as mo                                     # noqa: E402
+from gradcheck import device_head_pattern, replay_head                  # noqa: E402
 from test_gpu_bench_parity import GRAD_PARAMS, LOSS_SCALE, bad_rows, check_grad, cpu_batch, oracle_consts   # noqa: E402,F401
 
 DEV = "cuda"
@@ -232,7 +233,7 @@ def test_s_fsq_train_step_with_dropout_on_vs_oracle_with_replayed_masks(name):
     sd0 = {k: v.detach().clone() for k, v in model.state_dict().items()}
     consts = oracle_consts(uni, model, name)
     host_seed = 5
-    ts = TrainStep(model, batches, use_graph=True, seed=host_seed)
+    ts = TrainStep(model, batches, use_graph=True, seed=host_seed, keep_head_rows=True)
     ts.prepare()
     params = dict(model.named_parameters())
     for i, b in enumerate(batches):
@@ -244,8 +245,13 @@ def test_s_fsq_train_step_with_dropout_on_vs_oracle_with_replayed_masks(name):
         masks = step_masks(model, b, step, host_seed)
         sd = {k: v.detach().float().cpu().clone().requires_grad_(True) for k, v in sd0.items()}
         cb = cpu_batch(b)
+        # ... and the head's LeakyReLU branch pattern of that very step (tests/gradcheck.py: one of its 16 x 384 units crossing zero
+        # inside the forward's round-off moves every gradient by ~1 %; replayed like the dropout masks)
+        pattern, _ = device_head_pattern(model, b, enc_out=ts.enc_outs[i], state=sd0)
+        seen = {}
         ref_loss = mo.fq_training_loss(sd, cb, consts, n_layers=6, H=8, D=20, p=0.1, p_in=0.1, p_att=0.1, training=True,
-                                       hidden=model.hidden_dim, drop=_drop_hook(masks))
+                                       hidden=model.hidden_dim, drop=_drop_hook(masks), act=replay_head(pattern, seen))
+        print("head units the oracle alone puts on the other side of the LeakyReLU kink:", sum(seen.values()), "of", pattern.numel())
         (ref_loss * LOSS_SCALE).backward()
         print("batch %d  loss hip %.7f  oracle %.7f" % (i, loss, float(ref_loss)))
         np.testing.assert_allclose(loss, float(ref_loss), rtol=3e-3)
@@ -269,5 +275,8 @@ def test_s_fsq_train_step_with_dropout_on_vs_oracle_with_replayed_masks(name):
         #  tables go from 1.2-2.4 % to 0.9-1.3 %, the edge tables only from 2.5-4.4 % to 1.5-3.2 %: what is left is the bf16 rounding of
         #  the attention's MFMA operands under heavy cancellation in sums over thousands of pairs, and the reference's own fp16
         #  rounding points.  A deterministic-order mode would therefore not reach 1 %; the gates are what is measured + margin: 6 %)
-        bad = [r for r in report if r[2] > (6e-2 if edge(r) else 4e-2) or (not edge(r) and (r[3] > 3.0 or r[4] > 6.0)) or r[5] > 1e-3 * r[1]]
+        # (round 5: with the head's branch pattern replayed -- 1 to 9 of its 5 120 units sit on the other side of the kink in the
+        #  oracle's own forward -- everything but the edge tables is within 1.5 % relative L2, measured; gate 2 %.  The edge tables
+        #  reach 2.9 % / 4.2 % on the S-GOW batches: 6 % stays)
+        bad = [r for r in report if r[2] > (6e-2 if edge(r) else 2e-2) or (not edge(r) and (r[3] > 3.0 or r[4] > 6.0)) or r[5] > 1e-3 * r[1]]
         assert not bad, bad
