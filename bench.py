@@ -50,6 +50,7 @@ def parse():
     ap.add_argument("--no-parity", action="store_true", help="skip the eval-step comparison with the oracle")
     ap.add_argument("--no-stress", action="store_true", help="skip the c5-shape attention roofline measurements")
     ap.add_argument("--no-loop", action="store_true", help="skip the fresh-batch-every-step measurement (value_with_collate)")
+    ap.add_argument("--no-tail", action="store_true", help="--workload gow: skip the 814-node tail batch (roofline_gow_tail)")
     ap.add_argument("--loop-steps", type=int, default=300, help="timed steps of the fresh-batch loop")
     ap.add_argument("--no-live-pmc", action="store_true",
                     help="do not start rocprofv3 child passes for roofline.traffic / mfma_busy_pct (fall back to profiles/attn_pmc.json)")
@@ -341,6 +342,8 @@ def run_sub_workloads(args):
             e = {k: j.get(k) for k in keep}
             e["workload"] = j["config"]["workload"]
             e["padded_nodes_per_batch"] = j["config"]["padded_nodes_per_batch"]
+            if j.get("roofline_gow_tail"):
+                e["tail"] = j["roofline_gow_tail"]
             if j.get("roofline"):
                 e["attn_fwd_at_timed_shapes"] = {k: j["roofline"].get(k) for k in ("achieved", "frac", "avg_launch_us", "bytes_per_launch")}
             if name == "big":
@@ -375,7 +378,7 @@ def run_sub_workloads(args):
                             break
                 b5f = attn_fwd_bytes(16, 785, 256, 8, 2, 2)
                 b5b = attn_bwd_bytes(16, 785, 256, 8, 2, 2, 2, one_pass="attn_bwd_one_us" in durs)
-                for pat, key in (("attn_bwd_prep_kernel", "attn_bwd_prep_us"), ("attn_dq_finish_kernel", "attn_dq_finish_us")):
+                for pat, key in (("attn_dq_finish_kernel", "attn_dq_finish_us"),):
                     v = [(int(x["End_Timestamp"]) - int(x["Start_Timestamp"])) / 1e3 for x in seg if pat in x["Kernel_Name"]]
                     if v:
                         durs[key] = v
@@ -385,7 +388,7 @@ def run_sub_workloads(args):
                            source="rocprofv3 --kernel-trace child pass of this run (6 replayed steps, the third from the end)")
                 if "attn_fwd_us" in ins:
                     ins["attn_fwd_frac_of_8TBs"] = round(b5f / (ins["attn_fwd_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 3)
-                tb = sum(ins.get(k, 0.0) for k in ("attn_bwd_dq_us", "attn_bwd_dkv_us", "attn_bwd_one_us", "attn_bwd_prep_us", "attn_dq_finish_us"))
+                tb = sum(ins.get(k, 0.0) for k in ("attn_bwd_dq_us", "attn_bwd_dkv_us", "attn_bwd_one_us", "attn_dq_finish_us"))
                 if tb > 0:
                     ins["attn_bwd_frac_of_8TBs"] = round(b5b / (tb * 1e-6) / 1e9 / HBM_PEAK_GBS, 3)
                 res["big"]["in_step"] = ins
@@ -400,6 +403,66 @@ def run_sub_workloads(args):
         finally:
             shutil.rmtree(tmp, ignore_errors=True)
     return res
+
+
+# --------------------------------------------------------------------------------- the Gowalla tail
+def time_gow_tail(model, coll, uni, ts, args, w):
+    """BASELINE configs[2] names "longer SPD paths" and BASELINE.md section 4 row 2 prices its long-N bucket (T 815, C 192, d 24:
+    attention forward <= 60 us): the timed S-GOW pool reaches 141 padded nodes, the data's ONE 814-node trajectory does not occur
+    in eight batches drawn from the histogram.  Here, under this run's clock: a batch of 16 trajectories that holds an 814-node
+    one (the other 15 drawn from the histogram) as a 9th batch of the SAME trainer -- its step time --, the bias assembly and its
+    backward on that batch, and the attention kernels at that shape with every input rotated through > 768 MB (all-cold)."""
+    from mobgt_amd import synth, workloads
+    ns = [814] + [int(v) for v in workloads.gowalla_node_counts(15, 4242)]
+    trajs = synth.make_batch_of_trajectories(seed=4242, G=16, P=w["P"], n_user=w["n_user"], cat_of_poi=uni.cat_of_poi, n_nodes=ns)
+    b = coll(trajs)
+    G, N = b.x.shape[:2]
+    T, H, L = N + 1, w["model"]["num_heads"], w["model"]["n_layers"]
+    out = dict(workload=f"S-GOW tail batch: node counts {sorted(ns, reverse=True)[:4]} ..., padded T {T}, C 192, d 24, {L} layers")
+    i = ts.add_batch(b)
+    for _ in range(3):
+        ts.step(i)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    k = 20
+    for _ in range(k):
+        ts.step(i)
+    torch.cuda.synchronize()
+    out["step_ms"] = (time.perf_counter() - t0) / k * 1e3
+    out["check_ins_per_s_at_this_batch"] = G / (out["step_ms"] * 1e-3)
+    # bias assembly forward / backward (six bf16 dBias slices summed into the tables' gradients) on this batch
+    model.eval()
+    with torch.no_grad():
+        t_bias = _graph_time(lambda: model.assemble_bias(b), 10)
+    model.train()
+    pack = model.assemble_bias(b)
+    pack.needs_grad, pack.n_use = True, L
+    buf = pack.grad_buffer()
+    buf.copy_(torch.randn(buf.shape[1:], device=buf.device).bfloat16().expand_as(buf))
+    pack.n_bwd = L
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    torch.cuda.synchronize()
+    ev[0].record()
+    pack.token.backward()
+    ev[1].record()
+    torch.cuda.synchronize()
+    ld = pack.ld
+    idx_b = b.rel_pos.numel() * b.rel_pos.element_size() + b.poi_pos.numel() * b.poi_pos.element_size() + b.edge_input.numel() * b.edge_input.element_size()
+    by_f = 2 * G * H * T * ld * 2 + idx_b                       # both bias copies written + every index read once
+    by_b = L * G * H * T * ld * 2 + idx_b                       # L dBias slices read + the indices
+    out["build_bias"] = dict(us=t_bias * 1e6, bytes=by_f, achieved_GBs=by_f / t_bias / 1e9, frac=by_f / t_bias / 1e9 / HBM_PEAK_GBS)
+    tb_ = ev[0].elapsed_time(ev[1]) * 1e-3
+    out["build_bias_bwd"] = dict(us=tb_ * 1e6, bytes=by_b, achieved_GBs=by_b / tb_ / 1e9, frac=by_b / tb_ / 1e9 / HBM_PEAK_GBS,
+                                 note="one eager call (hop-table backward and host launch gaps included): an upper bound")
+    # the attention kernels at this shape, all-cold
+    tf, tbw, nset = time_attention(16, H, 815, 24, torch.bfloat16, torch.bfloat16, reps=24, p_drop=0.1, backward=True)
+    bf_ = attn_fwd_bytes(16, 815, 192, H, 2, 2)
+    bb_ = attn_bwd_bytes(16, 815, 192, H, 2, 2, 2, one_pass=True)
+    out["attn_fwd"] = dict(us=tf * 1e6, bytes=bf_, achieved_GBs=bf_ / tf / 1e9, frac=bf_ / tf / 1e9 / HBM_PEAK_GBS, input_sets_rotated=nset,
+                           baseline_md_row2_target_us=60.0)
+    out["attn_bwd"] = dict(us=tbw * 1e6, bytes=bb_, achieved_GBs=bb_ / tbw / 1e9, frac=bb_ / tbw / 1e9 / HBM_PEAK_GBS,
+                           kernel="attn_bwd_one_kernel + attn_dq_finish_kernel")
+    return out
 
 
 # --------------------------------------------------------------------------------- fresh batch every step
@@ -944,6 +1007,12 @@ def main():
                          avg_launch_us=tt_ / len(used) * 1e6,
                          note="not HBM-bound at this size: per workgroup a chain of latency-bound phases (first touch, weight "
                               "stream through one L1, two LayerNorms, one hand-over); see DESIGN.md 3.5")
+        gow_tail = None
+        if name == "gow" and not args.no_tail and world == 1 and not force_comm and not stock and not args.no_graph and bf16:
+            try:
+                gow_tail = time_gow_tail(model, coll, uni, ts, args, w)
+            except Exception as e:                       # never lose the line over a secondary figure
+                gow_tail = dict(error=repr(e))
         roof5 = roof5b = None
         if not args.no_stress:
             # the same kernels at the HBM-roofline stress shape (BASELINE configs[4]: G16 x 784 nodes, C 256, d 32), training
@@ -962,7 +1031,6 @@ def main():
                                      "profiles/r3_bench_big_step_summary.txt)")
             from mobgt_amd import ops as _ops
             one = bool(_ops._ATTN_ONE_PASS[0]) and b_dt == torch.bfloat16
-            b5b2 = b5b
             if one:
                 b5b = attn_bwd_bytes(16, 785, 256, 8, s_b, s_b, s_g, one_pass=True)
                 tro, mbo, srco, eo = pmc_of(32, "one", "-")
@@ -972,12 +1040,9 @@ def main():
                               unit="GB/s", frac=b5b / t5b / 1e9 / HBM_PEAK_GBS, traffic=tro, mfma_busy_pct={"one": mbo},
                               valu_busy_pct=eo.get("valu_busy_pct"), wait_any_frac=eo.get("wait_any_frac"),
                               counters_source=srco, avg_launch_us=t5b * 1e6, bytes_per_launch=b5b, input_sets_rotated=nset5,
-                              two_pass_bytes=b5b2, frac_at_two_pass_bytes=b5b2 / t5b / 1e9 / HBM_PEAK_GBS,
-                              note="round 4: ONE backward pass (S / P / dS once per pair, transposed bias read once, dBias written "
-                                   "once; dQ summed over key blocks by f32 atomics).  `frac` uses the bytes THIS algorithm has to move "
-                                   "(367 MB); rounds 1-3 ran two passes whose 558 MB are kept as two_pass_bytes -- the same launch "
-                                   "time against them is frac_at_two_pass_bytes, the figure comparable with BENCH_r03 (0.375).  The pass "
-                                   "is bound by vector issue and latency, not by HBM: DESIGN 3.1")
+                              note="ONE backward pass (S / P / dS once per pair, transposed bias read once, dBias written once; dQ "
+                                   "summed over key blocks by f32 atomics).  `frac` uses the bytes THIS algorithm has to move.  The "
+                                   "pass is bound by vector issue and latency, not by HBM: DESIGN 3.1")
             else:
                 trq, mbq, srcq, _ = pmc_of(32, "dq", "c5_bwd_dq_drop_bf16")
                 trk, mbk, _, _ = pmc_of(32, "dkv", "c5_bwd_dkv_drop_bf16")
@@ -993,7 +1058,7 @@ def main():
         cpu = None
         if not args.no_cpu_baseline and uni.distance is not None:
             cpu = (cpu_baseline_stock(model, batches, args, n_layers) if stock
-                   else cpu_baseline(model, batches, [t for _, _, t in mine], uni, args, n_layers))
+                   else cpu_baseline(model, batches, list(mine), uni, args, n_layers))
         subs = None
         if world == 1 and not force_comm and name == "fsq" and not stock and not args.no_sub and not args.no_graph and not args.unfused and bf16:
             subs = run_sub_workloads(args)
@@ -1015,6 +1080,7 @@ def main():
             "value_with_collate": with_collate,
             "comm_backend": comm_backend, "comm_ranks": comm_ranks, "grad_comm_dtype": args.grad_comm if ddp else None, "forced_comm": force_comm or None, "ddp_one_graph": bool(getattr(ts, "one_graph", False)) if ddp else None, "rccl_ranks": rccl_ranks, "allreduce_exposed_us": exposed_us,
             "parity": parity, "roofline": roof, "roofline_chain": roofc, "roofline_stress": roof5, "roofline_stress_bwd": roof5b,
+            "roofline_gow_tail": gow_tail,
             "cpu_baseline": cpu, "workloads": subs,
         }
         real_stdout.write(json.dumps(out) + "\n")

@@ -96,23 +96,13 @@ int mobgt_attn_bias_bwd(const void* q, const void* k, const void* v, const void*
                         int64_t lddq, int64_t lddk, int64_t lddv, int64_t ld_bias,
                         float scale, float dropout_p, uint64_t seed, const uint64_t* seed_dev,
                         int accumulate_dbias, int dbias_dtype, int io_dtype, int bias_dtype, void* stream);
-/* The same backward with a scratch accumulator for dQ (round 4): dq_acc [G, T, H*d] f32, 16-byte aligned, contents irrelevant on
- * entry and on return.  With it, T > 64, bf16 I/O, a bf16 bias and a bf16 dBias slice the gradients are formed in ONE pass over
- * the bias (csrc/attn.hip: attn_bwd_one_kernel -- keys on the lanes, 256 keys per 8-wave workgroup: S / P / dS once per pair,
- * bias_t read once, dBias written once; dQ is summed over the key blocks by f32 atomics, so it is then NOT bitwise
- * reproducible from run to run, unlike the two passes).  Any other configuration, dq_acc = null or MOBGT_ATTN_TWO_PASS=1 in the
- * environment: exactly mobgt_attn_bias_bwd.  Replaces the autograd of graphormer/model.py:436-455 like that function. */
-int mobgt_attn_bias_bwd_fused(const void* q, const void* k, const void* v, const void* bias, const void* bias_t,
-                        const void* out, const void* out_lo, const float* lse, const void* dout,
-                        void* dq, void* dk, void* dv, void* dbias, float* delta,
-                        int G, int H, int T, int d,
-                        int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo,
-                        int64_t lddq, int64_t lddk, int64_t lddv, int64_t ld_bias,
-                        float scale, float dropout_p, uint64_t seed, const uint64_t* seed_dev,
-                        int accumulate_dbias, int dbias_dtype, int io_dtype, int bias_dtype, float* dq_acc, void* stream);
-/* The same with an accumulator the caller keeps ZERO between calls (round 4, second step): dq_acc must be all zeros on entry and is
- * all zeros again when the call's last launch has run; there is then no launch in front of the pass -- rowsum(dO * O) is formed
- * inside it from `out` and `dout` -- and `delta` is not written. */
+/* The same backward with an f32 accumulator for dQ: dq_acc [G, T, H*d], 16-byte aligned, ALL ZEROS on entry and all zeros again
+ * when the call's last launch has run (keep one per stream; never touch it in between).  With it, T > 64, bf16 I/O, a bf16 bias and
+ * a bf16 dBias slice the gradients are formed in ONE pass over the bias (csrc/attn.hip: attn_bwd_one_kernel -- keys on the lanes,
+ * 256 keys per 8-wave workgroup: S / P / dS once per pair, bias_t read once, dBias written once, rowsum(dO * O) formed inside the
+ * pass; dQ is summed over the key blocks by f32 atomics, so it is then NOT bitwise reproducible from run to run, unlike the two
+ * passes).  Any other configuration, dq_acc = null or MOBGT_ATTN_TWO_PASS=1 in the environment: exactly mobgt_attn_bias_bwd.
+ * Replaces the autograd of graphormer/model.py:436-455 like that function. */
 int mobgt_attn_bias_bwd_fused_z(const void* q, const void* k, const void* v, const void* bias, const void* bias_t,
                                 const void* out, const void* out_lo, const float* lse, const void* dout, void* dq, void* dk, void* dv,
                                 void* dbias, float* delta, int G, int H, int T, int d, int64_t ldq, int64_t ldk,

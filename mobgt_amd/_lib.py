@@ -24,7 +24,6 @@ SIGNATURES = {
     "mobgt_attn_bias_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i64, _i64, _i64, _i64, _i64,
                                  _f, _f, _u64, _vp, _i, _i, _vp]),
     "mobgt_attn_bias_bwd": (_i, [_vp] * 14 + [_i, _i, _i, _i] + [_i64] * 8 + [_f, _f, _u64, _vp, _i, _i, _i, _i, _vp]),
-    "mobgt_attn_bias_bwd_fused": (_i, [_vp] * 14 + [_i, _i, _i, _i] + [_i64] * 8 + [_f, _f, _u64, _vp, _i, _i, _i, _i, _vp, _vp]),
     "mobgt_attn_bias_bwd_fused_z": (_i, [_vp] * 14 + [_i, _i, _i, _i] + [_i64] * 8 + [_f, _f, _u64, _vp, _i, _i, _i, _i, _vp, _vp]),
     "mobgt_dropout_keep_host": (_i, [_u64, _i, _i, _i, _i, _i, _i, _f]),
     "mobgt_attn_dropout_mask_host": (_i, [_u64, _i, _i, _i, _f, _vp]),

@@ -74,8 +74,7 @@ struct AttnParams {
     float* delta;
     void* o_lo;               // forward, bf16 I/O: bf16 residual O - bf16(O) beside `o` (same layout), or null
     const void* out_lo;       // backward, bf16 I/O: that residual, or null (delta then sees the rounded O only)
-    float* dq_acc;            // one-pass backward: [G, T, H * d] f32, the dQ sums (zero-filled by a launch in front unless dq_acc_zero)
-    int dq_acc_zero;          // the caller hands the accumulator over ZERO (it is zero again when the call's last launch has run)
+    float* dq_acc;            // one-pass backward: [G, T, H * d] f32, the dQ sums; ZERO on entry, zero again when the call's last launch has run
     int G, H, T;
     int64_t ldq, ldk, ldv, ldo, lddq, lddk, lddv, ld_bias;
     float scale, inv_keep;
@@ -1027,8 +1026,8 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_both_kernel(const AttnParams
 //         the workgroup's keys is staged once): each wave owns ONE 16 x 16 tile of the chunk's 64 x 32 and sums it over all
 //         256 keys, so a chunk leaves the workgroup as 8 KB of f32 atomic adds into a zero-filled accumulator (ceil(T / 256) adds
 //         per element: 54 MB per launch at c5, where 128-key workgroups would add 90 MB);
-//   * rowsum(dO O) comes from a small launch in front (attn_bwd_prep_kernel, which also zero-fills the dQ accumulator): recomputed
-//     per chunk by one wave it was a dependent cold round trip on every chunk's critical path.
+//   * rowsum(dO~ O) is formed by the threads that stage dO (they request the same pieces of O and its bf16 residual with the same
+//     two-chunk lead); the f32 dQ accumulator is zero on entry and attn_dq_finish_kernel zeroes it again behind its read.
 // Bias traffic: bias_t read once + dBias written once (2 x 158 MB at c5; the two passes move 3 x 158 MB); exp, dropout, dS once.
 typedef short mobgt_v4s __attribute__((ext_vector_type(4)));
 typedef float f32x4v __attribute__((ext_vector_type(4)));
@@ -1124,10 +1123,9 @@ __global__ __launch_bounds__(ONE_NW * 64) void attn_bwd_one_kernel(const AttnPar
     // Consistent softmax (header): a dO row is staged as dO~ = bf16(dO / l') -- the normalisation of the row's probabilities rides
     // on it, so the tile loop works with the forward's un-normalised P_b = bf16(2^(x - M')) and pays nothing per element for
     // 1 / l' -- and delta = dO~ . (O + O_lo) is formed from the very values that were staged.
-    // (round 4, second step) rowsum(dO O) is formed HERE: the threads that stage a piece of dO also request the same piece of O with
-    // the same two-chunk lead and reduce the products over the four pieces of a row when the chunk is stored -- the launch in
-    // front (attn_bwd_prep_kernel: 10.9 us at c5 for reading dO and O once more and zero-filling the accumulator) is gone; the
-    // accumulator is zero on entry and attn_dq_finish_kernel zeroes it again behind its read.
+    // rowsum(dO~ O) is formed HERE: the threads that stage a piece of dO also request the same piece of O (and of its residual)
+    // with the same two-chunk lead and reduce the products over the four pieces of a row when the chunk is stored (a launch in
+    // front that read dO and O once more and zero-filled the accumulator cost 10.9 us at c5: round 4).
     auto stage_load = [&](const int c) {
         if (D % 32 == 0 || sc0 < D) {
             sreg.load(ssrc + (int64_t)min(c * KC + sr, T - 1) * sld + sc0);
@@ -1338,29 +1336,7 @@ __global__ __launch_bounds__(ONE_NW * 64) void attn_bwd_one_kernel(const AttnPar
     }
 }
 
-// In front of the one-pass backward: zero-fill of the f32 dQ accumulator and delta = rowsum(dO O) per (graph, head, query) -- one
-// thread per (row, head): its d columns of dO and O in, its d columns of the accumulator zeroed.  Behind it: scale + cast of dQ.
-template <int D>
-__global__ void attn_bwd_prep_kernel(const bf16_t* __restrict__ dout, const bf16_t* __restrict__ out, int64_t ldo, float* __restrict__ dq_acc,
-                                     float* __restrict__ delta, int G, int H, int T) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (int64_t)G * T * H) return;
-    const int h = (int)(i % H);
-    const int64_t row = i / H;                               // g * T + q
-    const int g = (int)(row / T), q = (int)(row % T);
-    float d = 0.f;
-#pragma unroll
-    for (int e = 0; e < D; e += 8) {
-        float a[8], b[8];
-        load8(dout + row * ldo + h * D + e, a);
-        load8(out + row * ldo + h * D + e, b);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) d = fmaf(a[j], b[j], d);
-        *reinterpret_cast<float4*>(dq_acc + row * (H * D) + h * D + e) = make_float4(0.f, 0.f, 0.f, 0.f);
-        *reinterpret_cast<float4*>(dq_acc + row * (H * D) + h * D + e + 4) = make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-    delta[((int64_t)g * H + h) * T + q] = d;
-}
+// Behind the one-pass backward: scale + cast of dQ; the accumulator is left zero for the next call.
 __global__ void attn_dq_finish_kernel(float* acc, bf16_t* dq, int64_t rows, int C, int64_t lddq, float scale) {
     const int64_t e = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 8;
     if (e >= rows * C) return;
@@ -1442,13 +1418,8 @@ hipError_t launch_one(const AttnParams& p0, hipStream_t st) {
             p.n_first = GH * p.nq;
             hipLaunchKernelGGL((attn_bwd_both_kernel<D, TQ, TB, NW, DROP>), dim3(2 * GH * p.nq), block, 0, st, p);
         } else if (std::is_same<TQ, bf16_t>::value && std::is_same<TB, bf16_t>::value && p.dq_acc && p.dbias_bf16 && !one_pass_off()) {
-            // ONE pass (attn_bwd_one_kernel): zero the dQ accumulator + rowsum(dO O), the pass, scale + cast of dQ
+            // ONE pass (attn_bwd_one_kernel) into the caller's zero accumulator, then scale + cast of dQ (which zeroes it again)
             const int C = p.H * D;
-            const int64_t nth = (int64_t)p.G * p.T * p.H;
-            if (!p.dq_acc_zero)                     // (an accumulator of unknown contents: zero-fill launch in front)
-                hipLaunchKernelGGL((attn_bwd_prep_kernel<D>), dim3((unsigned)((nth + 255) / 256)), dim3(256), 0, st,
-                                   reinterpret_cast<const bf16_t*>(p.dout), reinterpret_cast<const bf16_t*>(p.out), p.ldo, p.dq_acc, p.delta,
-                                   p.G, p.H, p.T);
             p.nq = ((p.T + 31) / 32 + ONE_NW - 1) / ONE_NW;
             hipLaunchKernelGGL((attn_bwd_one_kernel<D, DROP>), dim3(GH * p.nq), dim3(ONE_NW * 64), 0, st, p);
             const int64_t n8 = (int64_t)p.G * p.T * C / 8;
@@ -1556,8 +1527,7 @@ static int attn_bwd_impl(const void* q, const void* k, const void* v, const void
                                    void* dbias, float* delta, int G, int H, int T, int d, int64_t ldq, int64_t ldk,
                                    int64_t ldv, int64_t ldo, int64_t lddq, int64_t lddk, int64_t lddv, int64_t ld_bias,
                                    float scale, float dropout_p, uint64_t seed, const uint64_t* seed_dev,
-                                   int accumulate_dbias, int dbias_dtype, int io_dtype, int bias_dtype, float* dq_acc, void* stream,
-                                   int dq_acc_zero = 0) {
+                                   int accumulate_dbias, int dbias_dtype, int io_dtype, int bias_dtype, float* dq_acc, void* stream) {
     int rc = check_common(G, H, T, d, ld_bias, io_dtype, 8);
     if (rc) return rc;
     if (!aligned16(q) || !aligned16(k) || !aligned16(v) || !aligned16(out) || !aligned16(dout) || !aligned16(bias) ||
@@ -1569,7 +1539,6 @@ static int attn_bwd_impl(const void* q, const void* k, const void* v, const void
     p.out_lo = io_dtype == MOBGT_BF16 ? out_lo : nullptr;
     p.dq = dq; p.dk = dk; p.dv = dv; p.dbias = dbias; p.delta = delta;
     p.dq_acc = (dq_acc && aligned16(dq_acc)) ? dq_acc : nullptr;
-    p.dq_acc_zero = dq_acc_zero;
     p.G = G; p.H = H; p.T = T;
     p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo; p.lddq = lddq; p.lddk = lddk; p.lddv = lddv;
     p.ld_bias = ld_bias;
@@ -1595,23 +1564,11 @@ extern "C" int mobgt_attn_bias_bwd(const void* q, const void* k, const void* v, 
                          nullptr, stream);
 }
 
-// The same backward with a scratch accumulator for dQ: dq_acc [G, T, H * d] f32, 16-byte aligned, contents irrelevant on entry
-// and on return.  With it, T > 64, bf16 I/O, a bf16 bias and a bf16 dBias slice the gradients are formed in ONE pass over the
-// bias (attn_bwd_one_kernel: S / P / dS once per pair, bias_t read once, dBias written once, dQ summed over key blocks by f32
-// atomics -- so dQ is then NOT bitwise reproducible from run to run; MOBGT_ATTN_TWO_PASS=1 keeps the two deterministic passes).
-extern "C" int mobgt_attn_bias_bwd_fused(const void* q, const void* k, const void* v, const void* bias, const void* bias_t,
-                                   const void* out, const void* out_lo, const float* lse, const void* dout, void* dq, void* dk, void* dv,
-                                   void* dbias, float* delta, int G, int H, int T, int d, int64_t ldq, int64_t ldk,
-                                   int64_t ldv, int64_t ldo, int64_t lddq, int64_t lddk, int64_t lddv, int64_t ld_bias,
-                                   float scale, float dropout_p, uint64_t seed, const uint64_t* seed_dev,
-                                   int accumulate_dbias, int dbias_dtype, int io_dtype, int bias_dtype, float* dq_acc, void* stream) {
-    return attn_bwd_impl(q, k, v, bias, bias_t, out, out_lo, lse, dout, dq, dk, dv, dbias, delta, G, H, T, d, ldq, ldk, ldv, ldo, lddq, lddk,
-                         lddv, ld_bias, scale, dropout_p, seed, seed_dev, accumulate_dbias, dbias_dtype, io_dtype, bias_dtype,
-                         dq_acc, stream);
-}
-
-/* mobgt_attn_bias_bwd_fused with an accumulator the caller keeps ZERO between calls: no launch in front of the pass (rowsum(dO O)
- * is formed inside it), and the finishing launch leaves dq_acc zero again. */
+/* The same backward with an f32 accumulator for dQ: dq_acc [G, T, H * d], 16-byte aligned, ALL ZEROS on entry and all zeros again
+ * when the call's last launch has run (the caller keeps one per stream and never touches it).  With it, T > 64, bf16 I/O, a bf16
+ * bias and a bf16 dBias slice the gradients are formed in ONE pass over the bias (attn_bwd_one_kernel: S / P / dS once per pair,
+ * bias_t read once, dBias written once, rowsum(dO O) formed inside the pass, dQ summed over key blocks by f32 atomics -- so dQ is
+ * then NOT bitwise reproducible from run to run; MOBGT_ATTN_TWO_PASS=1 keeps the two deterministic passes). */
 extern "C" int mobgt_attn_bias_bwd_fused_z(const void* q, const void* k, const void* v, const void* bias, const void* bias_t,
                                    const void* out, const void* out_lo, const float* lse, const void* dout, void* dq, void* dk, void* dv,
                                    void* dbias, float* delta, int G, int H, int T, int d, int64_t ldq, int64_t ldk,
@@ -1620,7 +1577,7 @@ extern "C" int mobgt_attn_bias_bwd_fused_z(const void* q, const void* k, const v
                                    int accumulate_dbias, int dbias_dtype, int io_dtype, int bias_dtype, float* dq_acc, void* stream) {
     return attn_bwd_impl(q, k, v, bias, bias_t, out, out_lo, lse, dout, dq, dk, dv, dbias, delta, G, H, T, d, ldq, ldk, ldv, ldo, lddq, lddk,
                          lddv, ld_bias, scale, dropout_p, seed, seed_dev, accumulate_dbias, dbias_dtype, io_dtype, bias_dtype,
-                         dq_acc, stream, 1);
+                         dq_acc, stream);
 }
 
 extern "C" int mobgt_dropout_keep_host(uint64_t seed, int H, int T, int g, int h, int i, int j, float dropout_p) {

@@ -621,11 +621,11 @@ __device__ __forceinline__ void cluster_get(__amdgpu_buffer_rsrc_t area, int m, 
         }
     }
 }
-// block id -> (row block, member): ids that agree modulo 8 share an XCD; a cluster = NCL consecutive slots of one XCD.  Only
-// the first `nx` XCDs take clusters; the workgroups dealt to the others leave at once (blk = -1).  nx = 8 unless
-// MOBGT_CHAIN_XCDS says otherwise: confining the 152 live workgroups of R = 608 to the 5 XCDs they need cuts the launch's
-// fetches from 13.3 to 10.0 MB (every XCD that takes part pulls the layer's weights into its own L2 once) but the launch
-// gets SLOWER -- forward 11.8 -> 12.4 us, backward 15.0 -> 21.7 us (its weight-gradient passengers are left with 3 XCDs)
+// block id -> (row block, member): ids that agree modulo 8 share an XCD; a cluster = NCL consecutive slots of one XCD.  All 8
+// XCDs take clusters (nx = 8).  (Round 3 measured, round 5 removed the switch: confining the 152 live workgroups of R = 608 to
+// the 5 XCDs they need cuts the launch's fetches from 13.3 to 10.0 MB -- every XCD that takes part pulls the layer's weights
+// into its own L2 once -- but the launch gets SLOWER: forward 11.8 -> 12.4 us, backward 15.0 -> 21.7 us, its weight-gradient
+// passengers are left with 3 XCDs.)
 template <int NCL>
 __device__ __forceinline__ void cluster_ids(int bid, int nx, int& blk, int& m) {
     const int xcd = bid & 7, slot = bid >> 3;
@@ -633,15 +633,8 @@ __device__ __forceinline__ void cluster_ids(int bid, int nx, int& blk, int& m) {
     blk = xcd < nx ? (slot / NCL) * nx + xcd : -1;
 }
 inline int cluster_xcds(int nblk, int ncl) {
-    static int forced = -1;
-    if (forced < 0) {
-        const char* e = getenv("MOBGT_CHAIN_XCDS");
-        forced = e ? atoi(e) : 0;
-    }
-    const int need = (nblk * ncl + 31) / 32;                 // XCDs the live workgroups need at one per compute unit
-    int nx = 8;
-    if (forced >= 1 && forced <= 8) nx = forced > need ? forced : need;
-    return nx < 1 ? 1 : (nx > 8 ? 8 : nx);
+    (void)nblk; (void)ncl;
+    return 8;
 }
 
 // rows of an LDS bf16 tile [BM][LD] -> columns [c0, c0 + N) of global [R][LDG]

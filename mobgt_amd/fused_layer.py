@@ -159,7 +159,8 @@ _ADDMM_OUT_DTYPE = [None]
 import os as _os
 _os_ln = _os
 _TAIL = [_os.environ.get("MOBGT_NO_TAIL") != "1"]
-_CHAIN_BIG = [_os.environ.get("MOBGT_CHAIN_BIG") == "1"]       # the chain kernels also past 4 096 rows (the library keeps the QKV GEMM and the weight gradients)
+# (round 4 measured and round 5 removed: the 16-row chain kernels also past 4 096 rows -- S-BIG 9.53 -> 10.93 ms: a 16-row
+#  workgroup re-streams the layer's weights from L2 785 times and loses against the library's tiles there)
 _OWN_GEMM = [_os.environ.get("MOBGT_LIBRARY_GEMM") != "1"]     # MOBGT_LIBRARY_GEMM=1: the layer's GEMMs through torch (A/B runs)
 
 
@@ -411,7 +412,7 @@ class _FusedLayerFn(torch.autograd.Function):
         a, lse = ops._attn_fwd(q, k, v, cfg.pack, cfg.scale, cfg.p_att, seed ^ (salt * 0x9E3779B1), sd)
         F = s_w1.shape[0]
         cfg.out_qkv = None
-        use_chain = (not stock and (own or _CHAIN_BIG[0]) and A == torch.bfloat16 and cfg.packed is not None
+        use_chain = (not stock and own and A == torch.bfloat16 and cfg.packed is not None
                      and _chain_ok(C, F, x, a, s_bo, s_b1, s_b2, n1w, n1b, nxw, nxb, *cfg.packed))
         # pre-LN chain (round 4): out-projection ... second residual add in one launch, + the NEXT layer's self_attention_norm
         # and QKV projection when the model named that layer (cfg.next_norm / next_qkv); the backward is the chain's too
@@ -612,7 +613,7 @@ class _FusedLayerFn(torch.autograd.Function):
         if _PENDING_TAIL or _PENDING_CB[0] is not None:
             _drop_stale_pending()
         pend = _PENDING_TAIL.pop(_pending_key(dout), None) if _PENDING_TAIL else None
-        chain_b = getattr(ctx, "chain_bwd", False) and (db1_in_wgrad or _CHAIN_BIG[0]) and not stock
+        chain_b = getattr(ctx, "chain_bwd", False) and db1_in_wgrad and not stock
         host = pend is not None and chain_b and pend["R"] == R
         if pend is not None and not host:
             _complete_pending(pend)                                   # this layer cannot host it: finish it right here

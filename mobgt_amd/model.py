@@ -341,7 +341,7 @@ def pack_layer_weights(layers, defer=False, rows=None):
     # `rows`: the batch's token rows, when the caller knows them.  Past 4 096 rows the layers run the library's GEMMs (ops.layer_gemm_ok)
     # and nothing reads the packs but the token-assembly launch, which multiplies by the FIRST layer's QKV weight: S-BIG packed
     # 96 weights per step (38 us) for that one.
-    qkv0_only = rows is not None and rows > 4096 and not fused_layer._CHAIN_BIG[0]
+    qkv0_only = rows is not None and rows > 4096
     jobs = []
     for li, layer in enumerate(layers):
         layer._packed_fresh = layer._packed_t_fresh = False

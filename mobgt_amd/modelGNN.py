@@ -484,23 +484,15 @@ def _small_gcn_launch(ax, a, ws, slope, p_drop, seed, seed_dev, salt):
     return keep, out
 
 
-_SIDE = {}                  # device index -> (side stream, pending prelaunch or None)
-
-
 def prelaunch_small_gcn(gcn, x, adj, adj_x, adj_t, same_stream=False):
     """same_stream: launch the one-launch GCN's forward NOW on the calling stream (no autograd: GCN.forward, called later where
     the reference calls it, finds the result and builds the autograd node there -- so the backward keeps its place behind the
     bias tables' node).  The model uses this to run the network FIRST in the step, with the front-of-step launches that precede
     its other consumers as passengers (the weight pack, ops.front_deferral's jobs).  -> True when launched.
-    Otherwise: start the one-launch GCN's forward NOW on a side stream (no autograd: GCN.forward, called later where the reference calls
-    it, finds the result, makes the calling stream wait for it and builds the autograd node there -- so the backward keeps
-    its place).  The network depends on nothing but its weights and keeps 19 compute units busy for 26 us; the launches of the
-    distance GCN that follow on the main stream run beside it.  OPT-IN (MOBGT_GCN_SIDE_STREAM=1) and kept for the record only:
-    inside the captured step the fork / join makes the replay SLOWER -- S-FSQ 0.710 ms against 0.664 ms (measured, round 3; the
-    same finding as round 2's four-branch experiment: a cross-stream edge of a hipGraph costs more than the launch it hides)."""
+    (Rounds 2-3 also had a side-stream form: inside the captured step its fork / join made the replay SLOWER -- S-FSQ 0.710 ms
+    against 0.664 -- a cross-stream edge of a hipGraph costs more than the launch it hides; removed in round 5.)"""
     from . import ops
-    side_on = os.environ.get("MOBGT_GCN_SIDE_STREAM") == "1"
-    if not (side_on or same_stream) or not (torch.is_tensor(x) and x.is_cuda):
+    if not same_stream or not (torch.is_tensor(x) and x.is_cuda):
         return False
     if adj_x is not None and adj_x.shape[1] != gcn.gcn[0].in_features:
         adj_x = adj_x[:, :gcn.gcn[0].in_features]
@@ -511,25 +503,9 @@ def prelaunch_small_gcn(gcn, x, adj, adj_x, adj_t, same_stream=False):
     g0, g1, g2 = gcn.gcn
     ws = [w.detach().contiguous() for w in (g0.weight, g0.bias, g1.weight, g1.bias, g2.weight, g2.bias)]
     salt = (0x2000 + g2.out_features) & 0xFFFFFFFF
-    if not side_on:
-        with torch.autocast(device_type="cuda", enabled=False):
-            keep, out = _small_gcn_launch(adj_x, adj, ws, float(gcn.leaky_relu.negative_slope), float(p_drop), seed, seed_dev, salt)
-        gcn._prelaunched = ((float(p_drop), seed, id(seed_dev), salt), (keep, out, None))
-        return True
-    dev = x.device.index if x.device.index is not None else torch.cuda.current_device()
-    ent = _SIDE.get(dev)
-    if ent is None:
-        if torch.cuda.is_current_stream_capturing():
-            return False                                         # (the side stream is created by the eager warm-up step)
-        ent = _SIDE[dev] = [torch.cuda.Stream(device=x.device), None]
-    side = ent[0]
-    cur = torch.cuda.current_stream()
-    side.wait_stream(cur)
-    with torch.cuda.stream(side), torch.autocast(device_type="cuda", enabled=False):
+    with torch.autocast(device_type="cuda", enabled=False):
         keep, out = _small_gcn_launch(adj_x, adj, ws, float(gcn.leaky_relu.negative_slope), float(p_drop), seed, seed_dev, salt)
-        ev = torch.cuda.Event()
-        ev.record(side)
-    gcn._prelaunched = ((float(p_drop), seed, id(seed_dev), salt), (keep, out, ev))
+    gcn._prelaunched = ((float(p_drop), seed, id(seed_dev), salt), (keep, out, None))
     return True
 
 
@@ -543,13 +519,7 @@ class _SmallGcnFn(torch.autograd.Function):
         H1, H2, H3 = w0.shape[1], w1.shape[1], w2.shape[1]
         ws = [w.contiguous() for w in (w0, b0, w1, b1, w2, b2)]
         if pre is not None:
-            # launched earlier on the side stream (prelaunch_small_gcn): this stream waits for it here, in front of its consumer
-            keep, out, ev = pre
-            if ev is not None:                                   # (None: launched on this stream)
-                cur = torch.cuda.current_stream()
-                cur.wait_event(ev)
-                keep.record_stream(cur)
-                out.record_stream(cur)
+            keep, out, _ = pre                                   # launched earlier on this stream (prelaunch_small_gcn)
         else:
             keep, out = _small_gcn_launch(ax, a, ws, slope, p_drop, seed, seed_dev, salt)
         ctx.save_for_backward(ax, a_t, ws[2], ws[4], keep)

@@ -494,6 +494,7 @@ def _attn_fwd(q, k, v, pack, scale, p_drop, seed, seed_dev):
 
 
 _DQ_ACC = {}
+_DQ_ACC_RETIRED = []      # accumulators a failed call left in an unknown state: never freed (captured graphs may replay their address)
 
 
 def _attn_bwd(q, k, v, out, lse, dout, dq, dk, dv, pack, scale, p_drop, seed, seed_dev):
@@ -513,15 +514,16 @@ def _attn_bwd(q, k, v, out, lse, dout, dq, dk, dv, pack, scale, p_drop, seed, se
             and dbias.dtype == torch.bfloat16 and _ATTN_ONE_PASS[0]):
         # long graphs, training configuration: ONE pass over the bias (csrc/attn.hip: attn_bwd_one_kernel) -- needs an f32
         # scratch accumulator for dQ (summed over key blocks by atomics)
-        if os.environ.get("MOBGT_ATTN_PREP") == "1":           # (the form with a zero-fill + rowsum launch in front: A/B)
-            dq_acc = torch.empty(G, T, C, dtype=torch.float32, device=q.device)
-            check(_lib.lib().mobgt_attn_bias_bwd_fused(*args, _p(dq_acc), _stream()), "mobgt_attn_bias_bwd_fused")
-            return
-        # ONE accumulator per (device, size), zero between calls: the pass adds into it, the finishing launch reads and re-zeroes it
-        # (calls of one stream follow each other; `busy` catches a call that died between its launches)
-        key = (str(q.device), G * T * C)
+        # ONE accumulator per (device, STREAM, size), zero between calls: the pass adds into it, the finishing launch reads and
+        # re-zeroes it.  Calls of one stream follow each other; two streams (a trainer's step graph beside an eager or eval
+        # backward of the same size) each get their own -- their atomics must not meet in one buffer.  `busy` catches a
+        # call that died between its launches: that buffer is retired, not freed (a captured graph may hold its address).
+        # dQ is summed by f32 atomics over key blocks: not bitwise reproducible (MOBGT_ATTN_TWO_PASS=1: the two deterministic passes).
+        key = (str(q.device), int(torch.cuda.current_stream(q.device).cuda_stream), G * T * C)
         ent = _DQ_ACC.get(key)
         if ent is None or ent["busy"]:
+            if ent is not None:
+                _DQ_ACC_RETIRED.append(ent["buf"])
             ent = _DQ_ACC[key] = dict(buf=torch.zeros(G * T * C, dtype=torch.float32, device=q.device), busy=False)
         ent["busy"] = True
         check(_lib.lib().mobgt_attn_bias_bwd_fused_z(*args, _p(ent["buf"]), _stream()), "mobgt_attn_bias_bwd_fused_z")
@@ -688,12 +690,16 @@ class _HopTableFn(torch.autograd.Function):
         d_ew = k_e[:] if k_e is not None else torch.empty_like(ew)          # (written in full)
         d_dw = k_d[:] if k_d is not None else zeros_f32(tuple(dis_shape), ew.device)     # rows of hop slots >= D get no gradient
         dtab = dtab.contiguous()
-        if (_WGRAD_DEFER["on"] and H == 8 and E <= 256 and dtab.data_ptr() % 16 == 0 and dw.data_ptr() % 16 == 0
+        # (parked only into a FREE slot and only when both gradients land in sinks: a second hop table in the same backward pass --
+        #  two models, two tables -- would overwrite the first one's entry, whose gradient would then never be computed, and a
+        #  buffer allocated here would reach autograd before the deferred launch has filled it: ADVICE r4)
+        park = _WGRAD_DEFER["on"] and k_e is not None and k_d is not None
+        if (park and "hop" not in _WGRAD_DEFER and H == 8 and E <= 256 and dtab.data_ptr() % 16 == 0 and dw.data_ptr() % 16 == 0
                 and os.environ.get("MOBGT_NO_HOP_BWD_PASSENGER") != "1"):
             # rides in the step's grouped weight-gradient launch (flush_deferred_wgrads): nothing but the optimizer reads these
             _WGRAD_DEFER["hop"] = (dtab, ew, dw, d_ew, d_dw, D, E, rt)
             return d_ew[:], d_dw[:], None, None, None
-        if (_WGRAD_DEFER["on"] and H == 8 and E <= 2048 and dtab.data_ptr() % 16 == 0 and dw.data_ptr() % 16 == 0
+        if (park and "hop_wide" not in _WGRAD_DEFER and H == 8 and E <= 2048 and dtab.data_ptr() % 16 == 0 and dw.data_ptr() % 16 == 0
                 and os.environ.get("MOBGT_NO_STOCK_TAIL") != "1"):
             # too many edge ids for the grouped launch's hop slot (the stock variant's 1 537): parked until the flush, where it
             # shares ONE grid with the backward of the stock encoder input when that is parked too (csrc/layer.hip stock_tail_kernel)

@@ -575,20 +575,45 @@ class TrainStep:
             ops.set_zero_arena(None)
         self.flat.gather(lo, hi, grads=grads)
 
-    def _capture(self, i):
+    def _warmup(self, i, check=False):
+        """One eager pass of batch i on the capture stream (allocator, lazy initialisations) that does not count as a training
+        step: the step counter (dropout stream, AdamW's t) is put back, so that a replayed sequence draws the masks an eager
+        sequence draws, however many graphs were captured on the way.  `check` (add_batch): the trained-parameter set -- flat
+        layout, sinks, optimizer -- was fixed by the batches given at construction; a batch that reaches a parameter outside it
+        would leave that parameter silently untrained.  Looked for in THIS pass (no extra dry run: ADVICE r4), and the
+        verdict is agreed on by all ranks before anybody raises -- a rank that raised alone would leave the others hanging in
+        their next all-reduce."""
         batch = self.batches[i]
-        with self._on_stream():                    # warm-up on the side stream (allocator, lazy inits)
-            # ... which must not count as a training step: the step counter (dropout stream, AdamW's t) is put back, so that
-            # a replayed sequence draws the masks an eager sequence draws, however many graphs were captured on the way
+        known = {id(p) for p in self.flat.params}
+        with self._on_stream():
             saved = self.seed_dev.clone()
+            if check:
+                for p in self.model.parameters():
+                    if id(p) not in known:
+                        p.grad = None
             self._fwd_bwd(batch)
             self.seed_dev.copy_(saved)
+            extra = [n for n, p in self.model.named_parameters() if id(p) not in known and p.grad is not None] if check else []
         self._join()
+        if check:
+            bad = len(extra) > 0
+            if self.world > 1:
+                t = torch.tensor([float(bad)], device=self.device)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                bad = float(t.item()) > 0
+            if bad:
+                raise RuntimeError("TrainStep.add_batch: this batch reaches parameters the trainer was not built for: "
+                                   f"{extra[:5] if extra else '(on another rank)'}")
+
+    def _capture(self, i, warm=True):
+        batch = self.batches[i]
+        if warm:
+            self._warmup(i)
         g = torch.cuda.CUDAGraph()
         # private memory pool per graph: the graphs are replayed in data order, not capture order, and a shared
         # pool is only safe for capture-order replay (measured: NaNs on the second lap with a shared pool)
         if not self.overlap:
-            with torch.cuda.graph(g, pool=self.pool if os.environ.get("MOBGT_SHARED_POOL") else None, stream=self.stream):
+            with torch.cuda.graph(g, stream=self.stream):
                 self._fwd_bwd(batch, slot=i)
             return g
         # two graphs over ONE autograd graph: phase B is captured right after phase A and replays its kernels on the
@@ -738,25 +763,16 @@ class TrainStep:
         its step graph now (the capture's eager warm-up pass leaves the step counter and the parameters untouched)."""
         self.batches.append(batch)
         i = len(self.batches) - 1
-        # the trained-parameter set (flat layout, sinks, optimizer) was fixed by the batches given at construction: a batch
-        # that reaches a parameter outside it would leave that parameter silently untrained (ADVICE r3) -- check by a dry run
-        if os.environ.get("MOBGT_NO_ADD_BATCH_CHECK") != "1":
-            known = {id(p) for p in self.flat.params}
-            with self._on_stream():
-                saved = self.seed_dev.clone()
-                for p in self.model.parameters():
-                    if id(p) not in known:
-                        p.grad = None
-                self._fwd_bwd(batch)
-                self.seed_dev.copy_(saved)
-                extra = [n for n, p in self.model.named_parameters() if id(p) not in known and p.grad is not None]
-            self._join()
-            if extra:
-                raise RuntimeError(f"TrainStep.add_batch: this batch reaches parameters the trainer was not built for: {extra[:5]}")
+        try:
+            self._warmup(i, check=True)                 # (the capture's warm-up pass and the parameter-set check in one)
+        except Exception:
+            self.batches.pop()
+            raise
         if self.use_graph and self._prepared:
-            self.graphs[i] = self._capture(i)
             if self.fused_opt:
-                self._capture_with_opt(i)
+                self._capture_with_opt(i)               # (the whole step as one graph: no forward / backward-only graph beside it)
+            else:
+                self.graphs[i] = self._capture(i, warm=False)
         return i
 
     def step(self, i):
@@ -856,11 +872,9 @@ class EpochLoop:
         self.steps_done = 0
         self.limits = None
         self.side_collate = bool(side_collate) and os.environ.get("MOBGT_LOOP_INGRAPH_COLLATE") != "1"
-        # MOBGT_LOOP_DIRECT=1 (round 4, measured and NOT the default): every staging buffer of a bucket is a static batch of its
-        # OWN step graph -- the collated bytes are read where the copy stream put them, no device-to-device copy between two
-        # replays.  Slower than the copy on the S-FSQ pool (0.734 vs 0.700 ms per step, one box, same run): two graphs per
-        # bucket alternate between two sets of activation buffers, and the copy was not what the loop waited for.
-        self.direct = os.environ.get("MOBGT_LOOP_DIRECT") == "1"
+        # (round 4 measured and round 5 removed: one step graph per STAGING buffer, i.e. no device-to-device copy between two
+        #  replays -- 0.734 against 0.700 ms per step on the S-FSQ pool: two graphs per bucket alternate between two sets of
+        #  activation buffers, and the copy was not what the loop waited for)
 
     # ---- data order -----------------------------------------------------------------------------------------------------
     def batches_of_epoch(self, epoch):
@@ -892,14 +906,13 @@ class EpochLoop:
                      batch=self.collator.batch_from_views(views) if side else views,
                      copy_bytes=lay.copy_bytes if side else lay.nbytes)
             raw_bytes = lay.raw_bytes if side else lay.nbytes
-            s["direct"] = bool(side and self.direct)
             for _ in range(2):
                 pin = torch.zeros(raw_bytes, dtype=torch.uint8).pin_memory()
                 dev = torch.zeros(lay.nbytes, dtype=torch.uint8, device=self.device)
                 dv = lay.views_torch(dev) if side else None
                 s["stages"].append(dict(pin=pin, np=lay.views_np(pin.numpy()), dev=dev, dev_views=dv,
                                         work=None, ready=torch.cuda.Event(), free=None, used=False, index=None,
-                                        batch=self.collator.batch_from_views(dv) if s["direct"] else None))
+                                        batch=None))
             self.slots[key] = s
         return s
 
@@ -941,17 +954,12 @@ class EpochLoop:
         slot = self._slot(G, N)
         st = slot["stages"][slot["turn"]]
         slot["turn"] ^= 1
-        if slot["direct"]:
-            if st["used"]:
-                st["ready"].synchronize()              # the previous host-to-device copy out of this pinned buffer is done
-        elif st["free"] is not None:
+        if st["free"] is not None:
             st["free"].synchronize()                   # its previous device-to-device copy has been executed
         self.collator.pack_host(trajs, idx0=ids[:G] if len(ids) == G else 0, n_pad=N, out=st["np"])
         self._check_host(st["np"])
         st["used"] = True
         with torch.cuda.stream(self.copy_stream):
-            if slot["direct"] and st["free"] is not None:
-                self.copy_stream.wait_event(st["free"])            # the step that read this staging buffer last has run
             st["dev"][:st["pin"].numel()].copy_(st["pin"], non_blocking=True)
             if slot["side"]:
                 st["work"] = self.collator.finish_into(st["dev_views"], st["work"])
@@ -974,20 +982,6 @@ class EpochLoop:
     def _launch(self, slot, st):
         cur = torch.cuda.current_stream()                # (graphs replay on the current stream)
         cur.wait_event(st["ready"])
-        if slot["direct"]:
-            if self.ts is None:
-                self.ts = TrainStep(self.model, [st["batch"]], batch_fn=self._batch_fn, **self._ts_args)
-                self.ts.prepare()
-                st["index"] = 0
-            elif st["index"] is None:
-                st["index"] = self.ts.add_batch(st["batch"])
-            if slot["index"] is None:
-                slot["index"] = st["index"]              # (any of the bucket's graphs: bench.py's no-input replay)
-            loss = self.ts.step(st["index"])
-            if st["free"] is None:
-                st["free"] = torch.cuda.Event()
-            st["free"].record(cur)
-            return loss
         n = slot["copy_bytes"]
         slot["buf"][:n].copy_(st["dev"][:n], non_blocking=True)
         if st["free"] is None:

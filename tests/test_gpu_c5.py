@@ -75,10 +75,10 @@ def test_attention_all_gradients_at_t785_d32_elementwise(p_drop):
 
 
 def test_one_pass_backward_leaves_its_dq_accumulator_zero_and_repeats(monkeypatch):
-    """Round 4, second step (csrc/attn.hip, mobgt_attn_bias_bwd_fused_z): the f32 dQ accumulator is ONE persistent buffer per
-    (device, size) that a call finds zero and leaves zero (the finishing launch re-zeroes it), rowsum(dO O) is formed inside the
-    pass.  Two backward passes in a row (dropout on) give the same dK / dV bit for bit and the same dQ up to the order of its f32
-    atomics; the buffer is all zeros afterwards; the form with the zero-fill + rowsum launch in front (MOBGT_ATTN_PREP=1) agrees."""
+    """csrc/attn.hip, mobgt_attn_bias_bwd_fused_z: the f32 dQ accumulator is ONE persistent buffer per (device, stream, size)
+    that a call finds zero and leaves zero (the finishing launch re-zeroes it), rowsum(dO O) is formed inside the pass.  Two
+    backward passes in a row (dropout on) give the same dK / dV / dBias bit for bit and the same dQ up to the order of its f32
+    atomics; the buffer is all zeros afterwards; a backward on ANOTHER stream gets its own accumulator."""
     G, H, T, d = 2, 8, 300, 32
     C = H * d
     rng = np.random.RandomState(11)
@@ -94,19 +94,23 @@ def test_one_pass_backward_leaves_its_dq_accumulator_zero_and_repeats(monkeypatc
         out.backward(gy)
         torch.cuda.synchronize()
         return [x.grad.float().clone() for x in (qd, kd, vd, bd)]
-    monkeypatch.delenv("MOBGT_ATTN_PREP", raising=False)
     a = run()
-    key = (str(q.device), G * T * C)
+    key = (str(q.device), int(torch.cuda.current_stream().cuda_stream), G * T * C)
     assert key in ops._DQ_ACC and not ops._DQ_ACC[key]["busy"]
     assert float(ops._DQ_ACC[key]["buf"].abs().max()) == 0.0
     b = run()
     assert float(ops._DQ_ACC[key]["buf"].abs().max()) == 0.0
     assert torch.equal(a[1], b[1]) and torch.equal(a[2], b[2]) and torch.equal(a[3], b[3])
     assert _rel_l2(b[0], a[0]) < 1e-3
-    monkeypatch.setenv("MOBGT_ATTN_PREP", "1")
-    c = run()
-    assert torch.equal(a[1], c[1]) and torch.equal(a[2], c[2])
-    assert _rel_l2(c[0], a[0]) < 5e-3 and _rel_l2(c[3], a[3]) < 5e-3      # (rowsum(dO O) summed in another order)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        c = run()
+    torch.cuda.current_stream().wait_stream(side)
+    key2 = (str(q.device), int(side.cuda_stream), G * T * C)
+    assert key2 != key and key2 in ops._DQ_ACC and ops._DQ_ACC[key2]["buf"].data_ptr() != ops._DQ_ACC[key]["buf"].data_ptr()
+    assert float(ops._DQ_ACC[key2]["buf"].abs().max()) == 0.0
+    assert torch.equal(a[1], c[1]) and torch.equal(a[2], c[2]) and _rel_l2(c[0], a[0]) < 1e-3
 
 
 # --------------------------------------------------------------------------------------- full-size S-BIG

@@ -309,7 +309,7 @@ def test_hop_table_kernel_matches_torch_expression(fp16):
     assert float(c.grad[0].abs().max()) == 0.0 and float(d.grad.reshape(-1, H, H)[D:].abs().max()) == 0.0
 
 
-def test_two_phase_backward_matches_single_phase():
+def test_two_phase_backward_matches_single_phase(monkeypatch):
     """train.TrainStep's data-parallel path splits the backward at the encoder output (head bucket all-reduced
     while the rest runs).  Same gradients and the same parameters after two steps as the single-graph step."""
     from mobgt_amd.model_fqandtoyo import Graphormer
@@ -325,6 +325,7 @@ def test_two_phase_backward_matches_single_phase():
     batches = [coll(synth.make_batch_of_trajectories(seed=10 + i, G=4, P=400, n_user=1080, cat_of_poi=uni.cat_of_poi))
                for i in range(2)]
     res = {}
+    monkeypatch.setenv("MOBGT_DDP_PARTS", "3")          # (the layer-wise parts are opt-in since round 5: default one phase B)
     for mode in (False, "again", "force"):
         torch.manual_seed(0)
         model = Graphormer(universe=uni, num_bins=nb + 2, bias_dtype=torch.bfloat16, gcn_dtype=torch.bfloat16,
