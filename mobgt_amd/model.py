@@ -210,9 +210,15 @@ def fused_layer_forward(layer, variant, x, attn_bias, n1, nx, next_layer=None):
             sh = tuple(torch.empty_like(m, dtype=act) for m in masters)
             layer._shadows = sh
             layer._shadow_fresh = False
+            layer._shadow_ver = None
         if not getattr(layer, "_shadow_fresh", False) or act != getattr(layer, "act_dtype", torch.float32):
-            # (stand-alone layers, and AMP on a layer configured for fp32: copy here; a model refreshes all layers in one call)
-            torch._foreach_copy_(list(sh), [m.detach() for m in masters])
+            # (stand-alone layers, and AMP on a layer configured for fp32: copy here; a model refreshes all layers in one call.
+            #  Unchanged weights are not copied again -- refresh_shadows says why)
+            ver = _weights_version(layer)
+            if getattr(layer, "_shadow_ver", None) != ver and not getattr(layer, "_shadow_external", False):
+                torch._foreach_copy_(list(sh), [m.detach() for m in masters])
+                layer._shadow_ver = ver
+                layer._packed_ver = None
         layer._shadow_fresh = False
         shadows = sh
     training = layer.training
@@ -299,10 +305,24 @@ def _launch_pack(jobs):
                                                 (ci * n)(*[j[4] for j in part]), _stream()), "mobgt_pack_mfma_b")
 
 
+def _weights_version(layer):
+    """What the bf16 shadows / MFMA-order packs of a layer were derived from: (version counter, address) of each of its GEMM
+    parameters.  In-place updates through the parameter (optimizers, load_state_dict, copy_) bump the counter; writes through
+    `.data` or raw pointers do not -- such writers call `sync_external_shadows(model)` / set `layer._shadow_ver = None`."""
+    mha = layer.self_attention
+    ps = (mha.linear_q.weight, mha.linear_k.weight, mha.linear_v.weight, mha.linear_q.bias, mha.linear_k.bias, mha.linear_v.bias,
+          mha.output_layer.weight, mha.output_layer.bias, layer.ffn.layer1.weight, layer.ffn.layer1.bias, layer.ffn.layer2.weight,
+          layer.ffn.layer2.bias)
+    return tuple((p._version, p.data_ptr()) for p in ps)
+
+
 def refresh_shadows(layers, defer_pack=False, rows=None):
     """bf16 copies of every layer's GEMM weights in ONE multi-tensor copy (call once per forward).  `defer_pack`: the MFMA-order
     pack is not launched but left for the category GCN's forward launch to carry (take_pending_pack) -- the caller MUST call
-    flush_pending_pack() in front of the first consumer of the packs."""
+    flush_pending_pack() in front of the first consumer of the packs.
+    A layer whose weights have not changed since its shadows were made is left alone: the copy would rewrite tensors that a
+    PENDING backward pass saved (an eval forward between a training forward and its backward: autograd's version check fires --
+    loudly, but for nothing), and an evaluation loop would copy 26 MB per batch for nothing."""
     import os
     if os.environ.get("MOBGT_NO_BATCHED_SHADOWS"):
         return
@@ -318,11 +338,16 @@ def refresh_shadows(layers, defer_pack=False, rows=None):
         masters = (wqkv, bqkv, mha.output_layer.weight, mha.output_layer.bias, layer.ffn.layer1.weight, layer.ffn.layer1.bias,
                    layer.ffn.layer2.weight, layer.ffn.layer2.bias)
         sh = getattr(layer, "_shadows", None)
+        ver = _weights_version(layer)
         if sh is None or sh[0].device != wqkv.device or sh[0].dtype != layer.act_dtype:
             sh = tuple(torch.empty_like(m, dtype=layer.act_dtype) for m in masters)
             layer._shadows = sh
-        dst += list(sh)
-        src += [m.detach() for m in masters]
+            layer._shadow_ver = None
+        if getattr(layer, "_shadow_ver", None) != ver:
+            dst += list(sh)
+            src += [m.detach() for m in masters]
+            layer._shadow_ver = ver
+            layer._packed_ver = None
         layer._shadow_fresh = True
     if dst:
         torch._foreach_copy_(dst, src)
@@ -357,22 +382,35 @@ def pack_layer_weights(layers, defer=False, rows=None):
         if pk is None or pk[0].device != sh[0].device:
             pk = tuple(torch.empty_like(sh[i]) for i in (0, 2, 4, 6))
             layer._packed = pk
+            layer._packed_ver = None
+        want_t_l = bool(want_t and any(p.requires_grad for p in layer.parameters()))
+        pt = getattr(layer, "_packed_t", None)
+        if want_t_l and (pt is None or pt[0].device != sh[0].device):
+            pt = tuple(torch.empty_like(sh[i]) for i in (6, 4, 2, 0))
+            layer._packed_t = pt
+            layer._packed_ver = None
+        # packs made from these very shadows before (weights unchanged since: refresh_shadows) are reused, not rewritten -- a
+        # pending backward pass may have saved them.  Shadows a trainer's optimizer kernel rewrites every step carry no version.
+        ver = None if getattr(layer, "_shadow_external", False) else getattr(layer, "_shadow_ver", None)
+        have = getattr(layer, "_packed_ver", None)
+        what = "qkv" if qkv0_only else "all"
+        reuse = ver is not None and have is not None and have[0] == ver and have[1] == what and (have[2] or not want_t_l)
         if qkv0_only:
             if li == 0:
-                jobs.append((sh[0], pk[0], sh[0].shape[0], sh[0].shape[1], 0))
+                if not reuse:
+                    jobs.append((sh[0], pk[0], sh[0].shape[0], sh[0].shape[1], 0))
+                    layer._packed_ver = (ver, what, False)
                 layer._packed_fresh = "qkv"                 # (model.fused_layer_forward hands on a pack only when this is True)
             continue
-        for d, i in zip(pk, (0, 2, 4, 6)):
-            jobs.append((sh[i], d, sh[i].shape[0], sh[i].shape[1], 0))
+        if not reuse:
+            for d, i in zip(pk, (0, 2, 4, 6)):
+                jobs.append((sh[i], d, sh[i].shape[0], sh[i].shape[1], 0))
+            if want_t_l:
+                for d, i in zip(pt, (6, 4, 2, 0)):       # dX = dY W: W [K = out, N = in] is the operand, packed as [N][K]
+                    jobs.append((sh[i], d, sh[i].shape[1], sh[i].shape[0], 1))
+            layer._packed_ver = (ver, what, want_t_l)
         layer._packed_fresh = True
-        if want_t and any(p.requires_grad for p in layer.parameters()):
-            pt = getattr(layer, "_packed_t", None)
-            if pt is None or pt[0].device != sh[0].device:
-                pt = tuple(torch.empty_like(sh[i]) for i in (6, 4, 2, 0))
-                layer._packed_t = pt
-            for d, i in zip(pt, (6, 4, 2, 0)):       # dX = dY W: W [K = out, N = in] is the operand, packed as [N][K]
-                jobs.append((sh[i], d, sh[i].shape[1], sh[i].shape[0], 1))
-            layer._packed_t_fresh = True
+        layer._packed_t_fresh = want_t_l
     import os
     # (as a passenger only while the pack is short next to the 26 us host launch: 6.5 M elements at S-FSQ = 11.7 us alone.  At
     #  S-BIG -- 18.9 M -- the passengers outlasted the network: 102 us for 28 + 37, measured)
@@ -386,6 +424,8 @@ def pack_layer_weights(layers, defer=False, rows=None):
 def sync_external_shadows(model):
     """bf16 shadow weights owned by a trainer (train.TrainStep keeps them current from inside its optimizer kernel) go
     stale when something else writes the parameters; writers call this to have them re-derived."""
+    for layer in getattr(model, "layers", []):          # (shadows / packs a layer made itself: derived again at its next forward)
+        layer._shadow_ver = layer._packed_ver = None
     ref = model.__dict__.get("_shadow_sync")
     fn = ref() if ref is not None else None
     if fn is not None:
