@@ -1951,6 +1951,32 @@ def _wgrad_defer(g, x, g_mask, x_mask, mask_vals, dw, db, db_of_x):
     return dw[:]
 
 
+def step_state_leftovers():
+    """What the step's hand-over registries still hold -- {} when a forward + backward pass has consumed everything it parked.
+    The registries (the bias tables' backward job, the front-of-step jobs, the parked encoder-input chain, deferred weight
+    gradients, the fused layers' parked tails, the deferred weight pack) are process-wide by design: a job parked by the forward
+    pass on the caller's thread is taken by a launch the autograd engine issues from ITS thread, so they cannot be thread-local;
+    ONE step is in flight per process.  The trainer asserts this is empty behind every step (`TrainStep._fwd_bwd`):
+    a job left behind -- an exception on the way, a second model's forward in between that took or overwrote it -- is an error
+    of that step, not a surprise of the next one."""
+    from . import fused_layer, model as _model
+    left = {}
+    if _BIAS_BWD_JOB:
+        left["bias_bwd_job"] = list(_BIAS_BWD_JOB)
+    if _FRONT_DEFER["hop"] is not None or _FRONT_DEFER["ni"] is not None:
+        left["front_jobs"] = [k for k in ("hop", "ni") if _FRONT_DEFER[k] is not None]
+    if _TOKEN_PENDING:
+        left["token_pending"] = len(_TOKEN_PENDING)
+    extra = [k for k in _WGRAD_DEFER if k not in ("on", "items")]
+    if _WGRAD_DEFER["items"] or extra:
+        left["wgrad_defer"] = dict(items=len(_WGRAD_DEFER["items"]), slots=extra)
+    if fused_layer._PENDING_TAIL:
+        left["layer_tails"] = len(fused_layer._PENDING_TAIL)
+    if _model._PENDING_PACK:
+        left["weight_pack"] = len(_model._PENDING_PACK)
+    return left
+
+
 def flush_deferred_wgrads():
     if _TOKEN_PENDING:
         stages = [p_["stage"] for p_ in _TOKEN_PENDING.values()]

@@ -451,6 +451,13 @@ class TrainStep:
                                                self.betas[1], self.eps,
                                                float(self.model.weight_decay), _stream()), "mobgt_adamw_flat")
 
+    def _capturing(self, graph):
+        """torch.cuda.graph on the trainer's stream.  With a process group, captures use the THREAD-LOCAL error mode: c10d's
+        watchdog thread polls the events of earlier collectives (the layout all-gather, the eager warm-up exchange) with
+        hipEventQuery, which the default global mode turns into an error of that thread while THIS one is capturing -- the
+        process then dies in the watchdog (seen once in six runs of tests/test_gpu_train.py::test_rccl_branch_executes_on_one_gpu)."""
+        return torch.cuda.graph(graph, stream=self.stream, capture_error_mode="thread_local" if self.ddp else "global")
+
     def _on_stream(self):
         import contextlib
         if self.stream is None:
@@ -505,6 +512,10 @@ class TrainStep:
         finally:
             ops.wgrad_deferral(False)
         ops.set_zero_arena(None)
+        left = ops.step_state_leftovers()
+        if left:
+            raise RuntimeError(f"mobgt: the step left parked work behind {left} -- its gradients are incomplete (another model's "
+                               "forward / backward inside this step?)")
         self.flat.gather()
         self._keep_loss(loss, slot)
 
@@ -613,24 +624,24 @@ class TrainStep:
         # private memory pool per graph: the graphs are replayed in data order, not capture order, and a shared
         # pool is only safe for capture-order replay (measured: NaNs on the second lap with a shared pool)
         if not self.overlap:
-            with torch.cuda.graph(g, stream=self.stream):
+            with self._capturing(g):
                 self._fwd_bwd(batch, slot=i)
             return g
         # two graphs over ONE autograd graph: phase B is captured right after phase A and replays its kernels on the
         # activations phase A's replay leaves at the same addresses (A's private pool; nothing else writes there)
-        with torch.cuda.graph(g, stream=self.stream):
+        with self._capturing(g):
             self._phase_a(batch, i)
         if self.parts:
             gbs = []
             for s in range(len(self.parts)):
                 gb = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(gb, stream=self.stream):
+                with self._capturing(gb):
                     self._phase_b_part(i, s)
                 gbs.append(gb)
             self.graphs_b[i] = gbs
             return g
         gb = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(gb, stream=self.stream):
+        with self._capturing(gb):
             self._phase_b(i)
         self.graphs_b[i] = [gb]
         return g
@@ -672,7 +683,7 @@ class TrainStep:
             self._step_base = int(self.seed_dev.item())
         self._join()
         self.opt_graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.opt_graph, stream=self.stream):
+        with self._capturing(self.opt_graph):
             self._opt_step()
         # Single process, no all-reduce between backward and optimizer: the optimizer rides at the end of every batch's
         # graph -- one graph launch per step instead of two (the boundary between two replayed graphs idles the device
@@ -694,7 +705,7 @@ class TrainStep:
         """The whole step of batch i as ONE graph: forward + backward [+ gradient exchange on this stream: `one_graph`] + AdamW."""
         comm = self.one_graph if comm is None else comm
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g, stream=self.stream):
+        with self._capturing(g):
             self._fwd_bwd(self.batches[i], slot=i)
             if comm:
                 self._exchange()
