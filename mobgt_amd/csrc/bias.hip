@@ -913,7 +913,7 @@ int launch_build_bwd(const BuildParams& p, hipStream_t st) {
     // long batches: 8-wave workgroups, one per CU (each walks its units); short ones: 4-wave workgroups, up to 3 per CU
     // (more than 64 KB of dynamic LDS has to be asked for, per kernel)
 #define BWD_LDS(K, HH_, HM_, NW_) do { shm = tables + bwd_stage_bytes<HH_, HM_, NW_>(); if (shm > 48 * 1024 && hipFuncSetAttribute((const void*)(K), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm) != hipSuccess) return MOBGT_EBADDIM; } while (0)
-    static const int64_t long_from = getenv("MOBGT_BIAS_BWD_LONG") ? atoll(getenv("MOBGT_BIAS_BWD_LONG")) : (1 << 20);
+    static const int64_t long_from = (1 << 20);
     if (hopmm && pairs >= long_from) {
         const int n_units8 = ((T + 63) / 64) * ((T + 7) / 8) * p.G;
         const dim3 grid(n_units8 < 256 ? n_units8 : 256), block(512);

@@ -525,7 +525,7 @@ int pick_rows(int64_t R) {
     // Few rows: aim at ~128 workgroups (8 rows each, two per wave: one sweep) rather than one row per wave -- measured
     // on the whole step at R = 608: 12 rows (51 workgroups) 13.89 k check-ins/s, 8 rows (76) 14.05 k, 4 rows (152
     // workgroups x 576 atomics on the same addresses) 13.85 k.
-    static const int cap = getenv("MOBGT_ROWS_CAP") ? atoi(getenv("MOBGT_ROWS_CAP")) : 256;
+    static const int cap = 256;
     int64_t wgs = R / 16;
     wgs = wgs < 128 ? 128 : (wgs > cap ? cap : wgs);     // (256 vs 512 at R = 12 560: 11.33 vs 11.45 ms per S-BIG step)
     int rows = (int)((R + wgs - 1) / wgs);
@@ -535,7 +535,7 @@ int pick_rows(int64_t R) {
 
 // kernels without a per-workgroup atomic tail: one row per wave while that gives <= 512 workgroups
 int pick_rows_stream(int64_t R) {
-    static const int cap = getenv("MOBGT_ROWS_STREAM_CAP") ? atoi(getenv("MOBGT_ROWS_STREAM_CAP")) : 4096;
+    static const int cap = 4096;
     int rows = (int)((R + cap - 1) / cap);
     rows = (rows + 3) / 4 * 4;
     return rows < 4 ? 4 : rows;
@@ -588,9 +588,9 @@ extern "C" int mobgt_dropout_add_ln_bwd(const void* dz, const float* dz32, const
     p.dbias = dbias; p.R = R; p.C = C;
     set_drop(p, dy ? dropout_p : 0.f, seed, seed_dev, salt);
     const bool v4 = C % 4 == 0 && C <= 256 * V4_CH;
-    static const int64_t wide_from = getenv("MOBGT_LN_WIDE_FROM") ? atoll(getenv("MOBGT_LN_WIDE_FROM")) : 4096;
+    static const int64_t wide_from = 4096;
     const bool wide = v4 && R >= wide_from;
-    static const int wide_wgs = getenv("MOBGT_LN_WIDE_WGS") ? atoi(getenv("MOBGT_LN_WIDE_WGS")) : 256;    // S-BIG step: 64 / 128 / 256 / 384 / 512 -> 11.22 / 10.95 / 10.58-10.70 / 10.94 / 10.79 ms (narrow form: 11.06)
+    static const int wide_wgs = 256;    // S-BIG step: 64 / 128 / 256 / 384 / 512 -> 11.22 / 10.95 / 10.58-10.70 / 10.94 / 10.79 ms (narrow form: 11.06)
     p.rows_per_wg = wide ? (int)((R + wide_wgs - 1) / wide_wgs) : pick_rows(R);
     if (wide) p.rows_per_wg = (p.rows_per_wg + 15) / 16 * 16;
     const dim3 grid((unsigned)((R + p.rows_per_wg - 1) / p.rows_per_wg)), block(256), wgrid = grid;
@@ -625,8 +625,8 @@ extern "C" int mobgt_gelu_fwd(const void* u, void* h, int64_t n, int act_dtype, 
 extern "C" int mobgt_gelu_bwd_colsum(const void* dh, const void* u, void* du, float* dbias, int64_t R, int C,
                                      int act_dtype, void* stream) {
     if (R <= 0 || C <= 0) return 0;
-    static const int64_t wide_from = getenv("MOBGT_LN_WIDE_FROM") ? atoll(getenv("MOBGT_LN_WIDE_FROM")) : 4096;
-    static const int wide_wgs = getenv("MOBGT_COLSUM_WIDE_WGS") ? atoi(getenv("MOBGT_COLSUM_WIDE_WGS")) : 128;
+    static const int64_t wide_from = 4096;
+    static const int wide_wgs = 128;
     const bool wide = C % 4 == 0 && R >= wide_from;
     const int rows = wide ? (int)((R + wide_wgs - 1) / wide_wgs) : pick_rows(R);
     const bool v4 = C % 4 == 0 && (((uintptr_t)dh | (uintptr_t)u | (uintptr_t)du) & 15) == 0;
@@ -646,8 +646,8 @@ extern "C" int mobgt_gelu_bwd_colsum(const void* dh, const void* u, void* du, fl
 
 extern "C" int mobgt_colsum(const void* g, float* out, int64_t R, int C, int act_dtype, void* stream) {
     if (R <= 0 || C <= 0) return 0;
-    static const int64_t wide_from = getenv("MOBGT_LN_WIDE_FROM") ? atoll(getenv("MOBGT_LN_WIDE_FROM")) : 4096;
-    static const int wide_wgs = getenv("MOBGT_COLSUM_WIDE_WGS") ? atoi(getenv("MOBGT_COLSUM_WIDE_WGS")) : 128;
+    static const int64_t wide_from = 4096;
+    static const int wide_wgs = 128;
     const bool wide = C % 4 == 0 && R >= wide_from;
     const int rows = wide ? (int)((R + wide_wgs - 1) / wide_wgs) : pick_rows(R);
     const bool v4 = C % 4 == 0 && ((uintptr_t)g & 15) == 0;

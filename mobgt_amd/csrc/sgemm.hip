@@ -175,7 +175,7 @@ int run(SgemmParams& p, int b_is_nk, int c_dtype, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     // columns per wave: wide tiles reuse the A operand, narrow ones give more waves; aim at >= ~256 waves
     const int rows16 = (p.M + 15) / 16;
-    static const bool no_splitk = getenv("MOBGT_NO_SGEMM_SPLITK") != nullptr;
+    constexpr bool no_splitk = false;
     if (!no_splitk && !b_is_nk && vec && p.N <= 16 && p.K >= 128 && p.K <= 16 * 4 * 8 && rows16 >= 64) {
         hipLaunchKernelGGL(sgemm_splitk_kernel<4>, dim3(rows16), dim3(256), 0, st, p);
         return (int)hipGetLastError();

@@ -44,7 +44,7 @@ def _wgrad_hip(dtype, M, N, R):
 
 
 import os as _os_wg
-_WGRAD_HIP_MN = [int(_os_wg.environ.get("MOBGT_WGRAD_HIP_MN", "131072"))]      # outputs up to which long batches stay on csrc/wgrad.hip
+_WGRAD_HIP_MN = [131072]      # outputs up to which long batches stay on csrc/wgrad.hip
 
 
 class _WgradBatch:
@@ -141,10 +141,6 @@ def _mm_tn_f32(g, x, sink=None):
     if g.dtype == torch.float32:
         return g.t() @ x
     if _MM_OUT_DTYPE[0] is None:
-        import os
-        if os.environ.get("MOBGT_NO_OUT_DTYPE"):
-            _MM_OUT_DTYPE[0] = False
-    if _MM_OUT_DTYPE[0] is None:
         try:
             torch.mm(g.t(), x, out_dtype=torch.float32)
             _MM_OUT_DTYPE[0] = True
@@ -158,10 +154,10 @@ def _mm_tn_f32(g, x, sink=None):
 _ADDMM_OUT_DTYPE = [None]
 import os as _os
 _os_ln = _os
-_TAIL = [_os.environ.get("MOBGT_NO_TAIL") != "1"]
+_TAIL = [True]
 # (round 4 measured and round 5 removed: the 16-row chain kernels also past 4 096 rows -- S-BIG 9.53 -> 10.93 ms: a 16-row
 #  workgroup re-streams the layer's weights from L2 785 times and loses against the library's tiles there)
-_OWN_GEMM = [_os.environ.get("MOBGT_LIBRARY_GEMM") != "1"]     # MOBGT_LIBRARY_GEMM=1: the layer's GEMMs through torch (A/B runs)
+_OWN_GEMM = [True]            # (False: the layer's GEMMs through torch -- tests flip it)
 
 
 def _addmm_f32(c, a, b, inplace=False):
@@ -208,7 +204,7 @@ _CHAIN_BWD = [_os_ln.environ.get("MOBGT_NO_CHAIN_BWD") != "1"]      # ... and th
 # first norm and runs the weight gradients as extra workgroups (csrc/chain.hip).  A parked entry that no layer picks up is
 # an error, raised when the backward pass ends -- never a silently incomplete gradient.
 _DEFER = [_os_ln.environ.get("MOBGT_NO_DEFER_TAIL") != "1"]
-_DEFER_MAX_R = [int(_os_ln.environ.get("MOBGT_DEFER_MAX_R", "4096"))]      # S-GOW: 1024 / 2048 / 4096 / 16384 -> 18.96 / 19.33 / 19.65 / 19.5 k check-ins/s
+_DEFER_MAX_R = [4096]      # S-GOW: 1024 / 2048 / 4096 / 16384 -> 18.96 / 19.33 / 19.65 / 19.5 k check-ins/s
 _PENDING_TAIL = {}          # (graph task id, device index, address of dx1) -> parked work; see _pending_key
 _PENDING_CB = [None]        # graph task id for which the end-of-backward check is queued
 
@@ -674,8 +670,7 @@ class _FusedLayerFn(torch.autograd.Function):
             rode = True
             dx = dx1
         elif (stock and ops._WGRAD_DEFER["on"] and wb.items and R <= _DEFER_MAX_R[0] and all(k is not None for k in ctx.sinks)
-              and all(g_.dtype == torch.bfloat16 and x_.dtype == torch.bfloat16 for g_, x_, _, _ in wb.items)
-              and _os_ln.environ.get("MOBGT_NO_STOCK_WGRAD_DEFER") != "1"):
+              and all(g_.dtype == torch.bfloat16 and x_.dtype == torch.bfloat16 for g_, x_, _, _ in wb.items)):
             # stock variant inside a train step: nothing downstream reads a weight gradient and all four land in their sinks, so
             # they join the step's ONE grouped launch (ops.flush_deferred_wgrads) instead of one 7 us launch per layer -- parked
             # as FRESH views (see above: AccumulateGrad clones a returned gradient that anything else still references)
@@ -764,8 +759,7 @@ class _FusedLayerFn(torch.autograd.Function):
         # the four weight gradients: inside a train step they join the step's ONE grouped launch (as the separate-launch stock
         # layer's do), else their own grouped launch now
         if (ops._WGRAD_DEFER["on"] and wb.items and R <= _DEFER_MAX_R[0] and all(k_ is not None for k_ in ctx.sinks)
-                and all(g_.dtype == torch.bfloat16 and x_.dtype == torch.bfloat16 for g_, x_, _, _ in wb.items)
-                and _os_ln.environ.get("MOBGT_NO_STOCK_WGRAD_DEFER") != "1"):
+                and all(g_.dtype == torch.bfloat16 and x_.dtype == torch.bfloat16 for g_, x_, _, _ in wb.items)):
             for g_, x_, dw_, db_ in wb.items:
                 ops._WGRAD_DEFER["items"].append((g_, x_, None, None, (1.0, 1.0, 1.0), dw_[:], db_[:] if db_ is not None else None, False))
             wb.items = []

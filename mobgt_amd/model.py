@@ -323,9 +323,6 @@ def refresh_shadows(layers, defer_pack=False, rows=None):
     A layer whose weights have not changed since its shadows were made is left alone: the copy would rewrite tensors that a
     PENDING backward pass saved (an eval forward between a training forward and its backward: autograd's version check fires --
     loudly, but for nothing), and an evaluation loop would copy 26 MB per batch for nothing."""
-    import os
-    if os.environ.get("MOBGT_NO_BATCHED_SHADOWS"):
-        return
     dst, src = [], []
     for layer in layers:
         if getattr(layer, "act_dtype", torch.float32) == torch.float32 or not layer.fused:

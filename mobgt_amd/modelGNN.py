@@ -55,7 +55,7 @@ def _mm_f32(a, b, bias=None):
 
 
 import os as _os
-_SMALL_GEMM = _os.environ.get("MOBGT_SMALL_GEMM", "1") != "0"
+_SMALL_GEMM = True
 
 
 def _mm_small(a, b, b_is_nk=False, out_dtype=torch.float32):

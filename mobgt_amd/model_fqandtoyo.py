@@ -222,7 +222,7 @@ class Graphormer(nn.Module):
             # hidden GraphConvolution layers then never stream the dense matrix (the rows-only last layer still gathers
             # its <= G*N rows from it)
             packed = None
-            if gcn_dtype == torch.bfloat16 and os.environ.get("MOBGT_NO_MASK_ADJ") != "1":
+            if gcn_dtype == torch.bfloat16:
                 from .modelGNN import MaskAdj
                 packed = MaskAdj.from_dense01(uni.graph_dist)
             if packed is not None and d_ax.shape[1] % 16:

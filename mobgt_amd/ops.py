@@ -735,7 +735,7 @@ class _SkinnyLinearFn(torch.autograd.Function):
             y = torch.empty(G, V, dtype=torch.float32, device=x.device)
             check(_lib.lib().mobgt_skinny_linear_fwd(_p(x), _p(w), _p(bias), _p(y), G, K, V, _stream()),
                   "mobgt_skinny_linear_fwd")
-        elif K % 64 == 0 and K <= 448 and os.environ.get("MOBGT_SKINNY_FWD_LIB") != "1":
+        elif K % 64 == 0 and K <= 448:
             # one pass over W on the matrix cores (csrc/skinny.hip; the library's M = 16 GEMM: 9.2 us at K = 320, 29 us at K = 128)
             y = torch.empty(G, V, dtype=torch.float32, device=x.device)
             check(_lib.lib().mobgt_skinny_linear_fwd_mfma(_p(x), _p(w), _p(bias), _p(y), G, K, V, _stream()),
@@ -761,8 +761,8 @@ def _skinny_backward(ctx, dy):
     V = w.shape[0]
     dy = dy.contiguous()
     dx = None
-    dx_mfma = ctx.needs_input_grad[0] and not ctx.all_hip and K % 16 == 0 and K <= 512 and not os.environ.get("MOBGT_SKINNY_DX_LIB")
-    both = dx_mfma and ctx.needs_input_grad[1] and not os.environ.get("MOBGT_SKINNY_TWO_LAUNCHES")
+    dx_mfma = ctx.needs_input_grad[0] and not ctx.all_hip and K % 16 == 0 and K <= 512
+    both = dx_mfma and ctx.needs_input_grad[1]
     if dx_mfma:     # one pass over W at the full L1 rate (the library's 16x16 tiles: 26 us at V = 7857, K = 448)
         dx = zeros_f32((G, K), x.device)
         if not both:
@@ -1414,8 +1414,8 @@ class _LinearSplitKFn(torch.autograd.Function):
         return g @ w, dw, colsum(g), None, None, None
 
 
-_SMALL_LINEAR = int(__import__("os").environ.get("MOBGT_SMALL_LINEAR", "1"))
-_SMALL_ROWS = int(__import__("os").environ.get("MOBGT_SMALL_ROWS", "4096"))       # rows up to which csrc/sgemm.hip takes these layers
+_SMALL_LINEAR = 1
+_SMALL_ROWS = 4096       # rows up to which csrc/sgemm.hip takes these layers
 
 
 def _small_linear(x, w):

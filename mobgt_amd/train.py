@@ -289,7 +289,7 @@ class TrainStep:
         # which the parameter received no gradient)
         self._skip = None
         w = getattr(getattr(model, "out_proj", None), "weight", None)
-        if w is not None and os.environ.get("MOBGT_ZERO_ALL") != "1":
+        if w is not None:
             for i, q in enumerate(self.flat.params):
                 if q is w and w.numel() >= (1 << 20):
                     self._skip = (i, int(self.flat.offsets[i]), int(self.flat.offsets[i]) + w.numel())
@@ -688,8 +688,7 @@ class TrainStep:
         # Single process, no all-reduce between backward and optimizer: the optimizer rides at the end of every batch's
         # graph -- one graph launch per step instead of two (the boundary between two replayed graphs idles the device
         # for ~8.7 us: `tools/prof_gaps.sh`).  Every warm-up has run by now, so this second capture only records.
-        self.fused_opt = (not self.overlap and (not self.ddp or self.one_graph)
-                          and os.environ.get("MOBGT_FUSED_OPT_GRAPH", "1") != "0")
+        self.fused_opt = (not self.overlap and (not self.ddp or self.one_graph))
         if self.fused_opt:
             if self.one_graph:
                 with self._on_stream():            # (the collective's first call on these buffers: outside any capture)
@@ -858,7 +857,7 @@ class EpochLoop:
       its host-to-device copy and its device collate (`DeviceCollator.finish_into`: SPD / edge paths / degrees / distance
       bins) while the GPU runs the current step; then -- on the compute stream -- one device-to-device copy of the staged
       raw + derived bytes into the bucket's static batch and one graph replay.  Collators whose finish needs torch ops
-      (coordinate bins) keep the collate inside the step graph (`batch_fn = finish`; also `MOBGT_LOOP_INGRAPH_COLLATE=1`).
+      (coordinate bins) keep the collate inside the step graph (`batch_fn = finish`).
     """
 
     def __init__(self, model, collator, dataset, batch_size=16, seed=1, use_graph=True, overlap=True, buckets=None, rank=None,
@@ -882,7 +881,7 @@ class EpochLoop:
         self._ts_args = dict(autocast_dtype=autocast_dtype, use_graph=use_graph, seed=seed, overlap=overlap)
         self.steps_done = 0
         self.limits = None
-        self.side_collate = bool(side_collate) and os.environ.get("MOBGT_LOOP_INGRAPH_COLLATE") != "1"
+        self.side_collate = bool(side_collate)
         # (round 4 measured and round 5 removed: one step graph per STAGING buffer, i.e. no device-to-device copy between two
         #  replays -- 0.734 against 0.700 ms per step on the S-FSQ pool: two graphs per bucket alternate between two sets of
         #  activation buffers, and the copy was not what the loop waited for)
