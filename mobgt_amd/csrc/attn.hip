@@ -1473,10 +1473,14 @@ int launch_d(const AttnParams& p, int d, bool drop, hipStream_t st) {
     }
 }
 
+#include "attn_f32_body.h"
+
 template <Pass PASS>
 int launch(const AttnParams& p, int d, int io_dtype, int bias_dtype, bool drop, hipStream_t st) {
-    if (io_dtype == MOBGT_F32 && bias_dtype == MOBGT_F32) return launch_d<PASS, float, float>(p, d, drop, st);
-    if (io_dtype == MOBGT_F32 && bias_dtype == MOBGT_BF16) return launch_d<PASS, float, bf16_t>(p, d, drop, st);
+    // f32 I/O: the full-f32 instantiation (attn_f32_body.h: f32 matrix instruction, no bf16 rounding anywhere); the kernels above
+    // are instantiated for bf16 I/O only
+    if (io_dtype == MOBGT_F32 && bias_dtype == MOBGT_F32) return launch_f32<PASS == FWD, float>(p, d, drop, st);
+    if (io_dtype == MOBGT_F32 && bias_dtype == MOBGT_BF16) return launch_f32<PASS == FWD, bf16_t>(p, d, drop, st);
     if (io_dtype == MOBGT_BF16 && bias_dtype == MOBGT_F32) return launch_d<PASS, bf16_t, float>(p, d, drop, st);
     if (io_dtype == MOBGT_BF16 && bias_dtype == MOBGT_BF16) return launch_d<PASS, bf16_t, bf16_t>(p, d, drop, st);
     return MOBGT_EDTYPE;
