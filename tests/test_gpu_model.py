@@ -1,9 +1,10 @@
 """End-to-end parity on a real MI355X: the drop-in data path and both Graphormer variants against the
 reference's own outputs (goldens G1-G6).
 
-Tolerances: integer / index tensors bit-exact.  Model outputs: the attention core rounds its MFMA
-operands to bf16 (fp32 accumulate), everything else is fp32, so logits are compared at 2e-2 absolute /
-relative against the reference's fp32 values, losses at 1e-3, gradient norms at 5 %.
+Tolerances: integer / index tensors bit-exact.  Model outputs: these models run the f32 configuration, which is fp32 end to
+end since round 5 (attention: csrc/attn_f32_body.h) -> logits 2e-4 absolute / relative against the reference's fp32 values
+(measured 8e-6), loss 1e-5, every gradient elementwise within 0.2 % relative L2 (the edge tables 8 %: the reference's own fp16
+casts flush their small gradients in these un-scaled golden runs).
 """
 import os
 from types import SimpleNamespace
@@ -137,7 +138,7 @@ def _load_seeded(model, names_shapes, seed):
     return sd
 
 
-def _check_grads(model, z, tag, rtol=5e-2, edge_tag=None):
+def _check_grads(model, z, tag, rtol=5e-2, edge_tag=None, lim_l2=4e-2):
     """`edge_tag`: fixture prefix that holds the edge tables' gradients taken at loss x 65536 (golden G8): the reference's own
     .half() casts flush their small per-pair gradients at the plain loss, this path (fp32 behind the emulated round trip) does
     not -- against the scaled golden the tables are held to the common 4 % instead of 8 %."""
@@ -162,7 +163,12 @@ def _check_grads(model, z, tag, rtol=5e-2, edge_tag=None):
             # tests/test_gpu_bench_parity.py evaluates them at loss x 65536) and the time-slot table (its gradient is a
             # heavily cancelling sum, rms 20-40x below its neighbours: round-off of the attention's bf16 operands is
             # 5 % of what is left)
-            lim = 8e-2 if (pn.startswith("edge_") and gtag == tag) or pn.startswith("time_embed") else 4e-2
+            # (`lim_l2`: the f32 configuration runs fp32 end to end since round 5 -- callers pass 2e-3, measured < 5e-5)
+            lim = 8e-2 if (pn.startswith("edge_") and gtag == tag) or (pn.startswith("time_embed") and lim_l2 > 1e-2) else lim_l2
+            if gtag != tag:
+                # (the scaled golden of the edge tables: the reference's backward still rounds every per-pair gradient to fp16 on
+                #  its way through the .half() casts -- 2^-11 each, 0.33 % relative L2 measured on G8)
+                lim = max(lim, 1e-2)
             if rel_l2 > lim or q999 > 1.0 or mx > 4.0 or stray > 1e-3 * rms + 1e-12:
                 bad.append((pn, "elementwise", rel_l2, q999, mx, stray))
     assert not bad, bad
@@ -183,11 +189,11 @@ def test_stock_graphormer_logits_loss_grads_g6(golden_dir):
     assert np.array_equal(np.isfinite(bias), fin)
     np.testing.assert_allclose(bias[fin], ref[fin], rtol=1e-5, atol=1e-5)
     logits = m(b)
-    np.testing.assert_allclose(logits.detach().cpu().numpy(), z6["stock/logits"], rtol=2e-2, atol=2e-2)
+    np.testing.assert_allclose(logits.detach().cpu().numpy(), z6["stock/logits"], rtol=2e-4, atol=2e-4)
     loss = torch.nn.functional.cross_entropy(logits, b.y.view(-1))
-    np.testing.assert_allclose(loss.item(), z6["stock/loss"], rtol=1e-3)
+    np.testing.assert_allclose(loss.item(), z6["stock/loss"], rtol=1e-5)
     loss.backward()
-    _check_grads(m, z6, "stock")
+    _check_grads(m, z6, "stock", rtol=2e-3, lim_l2=2e-3)
 
 
 @pytest.mark.parametrize("tag,ds,narrow", [("fsq", "foursquaregraph", False), ("gow", "gowalla_nevda", True)])
@@ -210,12 +216,12 @@ def test_fq_graphormer_logits_loss_grads_g6(golden_dir, tag, ds, narrow):
     assert np.array_equal(np.isfinite(bias), fin)
     np.testing.assert_allclose(bias[fin], ref[fin], rtol=1e-5, atol=1e-4)
     out = m(b)
-    np.testing.assert_allclose(out[0].detach().cpu().numpy(), z6[f"{tag}/logits"], rtol=2e-2, atol=2e-2)
-    np.testing.assert_allclose(out[1].detach().cpu().numpy(), z6[f"{tag}/cat_logits"], rtol=2e-2, atol=2e-2)
+    np.testing.assert_allclose(out[0].detach().cpu().numpy(), z6[f"{tag}/logits"], rtol=2e-4, atol=2e-4)
+    np.testing.assert_allclose(out[1].detach().cpu().numpy(), z6[f"{tag}/cat_logits"], rtol=2e-4, atol=2e-4)
     loss = m.training_step(b, 0)                       # eval() mode, like the golden (no dropout)
-    np.testing.assert_allclose(loss.item(), z6[f"{tag}/loss"], rtol=1e-3)
+    np.testing.assert_allclose(loss.item(), z6[f"{tag}/loss"], rtol=1e-5)
     loss.backward()
-    _check_grads(m, z6, tag)
+    _check_grads(m, z6, tag, rtol=2e-3, lim_l2=2e-3)
 
 
 def test_gradient_tail_loss_kernel_matches_reference_g7(golden_dir):

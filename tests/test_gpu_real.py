@@ -2,11 +2,13 @@
 eight real trajectories (N = 1, 2, 5, 17, 94, 8, 12, 30) and the 329-node one on the real POI universe (P 3 679, 253
 categories, 653 distance bins), gowalla_nevda fq Graphormer at BASELINE configs[2] sizes.
 
-Tolerances: index tensors (SPD, paths, edge features, degrees, poi_pos bins) bit-exact.  Model outputs: the attention core
-rounds its MFMA operands to bf16 (fp32 accumulate) -> logits at 2e-2 absolute / relative against the reference's fp32
-values, loss 1e-3, gradients as tests/test_gpu_model.py::_check_grads: every parameter elementwise, relative L2 <= 4 %
-(time-slot table 8 %); the edge tables against the reference's backward at GradScaler's loss x 65536 (at the plain loss the
-reference's own fp16 casts flush 8 % of edge_encoder's gradient: make_golden_real.py).
+Tolerances: index tensors (SPD, paths, edge features, degrees, poi_pos bins) bit-exact.  Model outputs: the f32
+configuration is fp32 end to end (attention: csrc/attn_f32_body.h) -> logits at 2e-4 absolute / relative against the
+reference's fp32 values (measured 8e-6 on logits up to 5.1), loss 1e-5 (measured: equal to 16 digits), gradients as
+tests/test_gpu_model.py::_check_grads: every parameter elementwise, relative L2 <= 0.2 % (measured < 5e-5); the edge tables
+against the reference's backward at GradScaler's loss x 65536 (at the plain loss the reference's own fp16 casts flush 8 % of
+edge_encoder's gradient: make_golden_real.py).  The bf16 configuration -- what bench.py times -- is held to the oracle with
+replayed masks and head branch pattern in tests/test_gpu_bench_parity.py / test_gpu_train_parity.py (S-GOW batches).
 
 These real trajectories are what exposed the un-cancelled delta of rounds 1-4 (csrc/attn.hip header, "consistent softmax"):
 every node of a trajectory carries the same user embedding, so K rows share a large common component and dQ / dK live on
@@ -91,12 +93,12 @@ def test_fq_graphormer_on_real_universe_logits_loss_grads_g8(g8, real_model):
     assert np.array_equal(np.isfinite(bias), fin)
     np.testing.assert_allclose(bias[fin], ref[fin], rtol=1e-5, atol=1e-4)
     out = m(b)
-    np.testing.assert_allclose(out[0].detach().cpu().numpy(), z["a/logits"], rtol=2e-2, atol=2e-2)
-    np.testing.assert_allclose(out[1].detach().cpu().numpy(), z["a/cat_logits"], rtol=2e-2, atol=2e-2)
+    np.testing.assert_allclose(out[0].detach().cpu().numpy(), z["a/logits"], rtol=2e-4, atol=2e-4)
+    np.testing.assert_allclose(out[1].detach().cpu().numpy(), z["a/cat_logits"], rtol=2e-4, atol=2e-4)
     loss = m.training_step(b, 0)                        # eval() mode, like the golden (no dropout)
-    np.testing.assert_allclose(loss.item(), z["a/loss"], rtol=1e-3)
+    np.testing.assert_allclose(loss.item(), z["a/loss"], rtol=1e-5)
     loss.backward()
-    _check_grads(m, z, "a", edge_tag="a_s65536")
+    _check_grads(m, z, "a", rtol=2e-3, edge_tag="a_s65536", lim_l2=2e-3)
 
 
 def test_fq_graphormer_329_node_real_trajectory_logits_g8(g8, real_model):
@@ -110,5 +112,5 @@ def test_fq_graphormer_329_node_real_trajectory_logits_g8(g8, real_model):
     fin = np.isfinite(ref)
     assert np.array_equal(np.isfinite(bias), fin)
     np.testing.assert_allclose(bias[fin], ref[fin], rtol=1e-5, atol=1e-4)
-    np.testing.assert_allclose(out[0].cpu().numpy(), z["b/logits"], rtol=2e-2, atol=2e-2)
-    np.testing.assert_allclose(out[1].cpu().numpy(), z["b/cat_logits"], rtol=2e-2, atol=2e-2)
+    np.testing.assert_allclose(out[0].cpu().numpy(), z["b/logits"], rtol=2e-4, atol=2e-4)
+    np.testing.assert_allclose(out[1].cpu().numpy(), z["b/cat_logits"], rtol=2e-4, atol=2e-4)
