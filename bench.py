@@ -772,6 +772,9 @@ def main():
         os.environ.setdefault("MASTER_PORT", str(port))
     if ddp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        from mobgt_amd.train import recommended_env
+        for k_, v_ in recommended_env().items():
+            os.environ.setdefault(k_, v_)
         if shared:
             dist.init_process_group("gloo")
         else:

@@ -200,6 +200,13 @@ def used_parameters(model, loss_fns):
     return used
 
 
+def recommended_env():
+    """Environment a data-parallel process should set BEFORE `init_process_group("nccl")` when its steps are captured graphs
+    (bench.py and the tests' workers do): c10d's event cache off -- a recycled event that was last recorded inside a capture must
+    never reach the watchdog's polling (see TrainStep._quiesce_collectives)."""
+    return {"TORCH_NCCL_CUDA_EVENT_CACHE": "0"}
+
+
 def broadcast_parameters(model, src=0):
     """DDP's construction-time broadcast: every rank starts from rank `src`'s weights."""
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
@@ -456,7 +463,19 @@ class TrainStep:
         watchdog thread polls the events of earlier collectives (the layout all-gather, the eager warm-up exchange) with
         hipEventQuery, which the default global mode turns into an error of that thread while THIS one is capturing -- the
         process then dies in the watchdog (seen once in six runs of tests/test_gpu_train.py::test_rccl_branch_executes_on_one_gpu)."""
+        if self.ddp:
+            self._quiesce_collectives()
         return torch.cuda.graph(graph, stream=self.stream, capture_error_mode="thread_local" if self.ddp else "global")
+
+    def _quiesce_collectives(self):
+        """Let c10d's watchdog retire every eager collective before a capture starts (device idle, then two of its 100 ms polling
+        rounds): a step graph captures a collective, and a watchdog that still polls events while events are being recorded into
+        a capture has been seen to die on `hipErrorCapturedEvent` (one run in six; an event it held was recorded inside the
+        capture -- c10d recycles its events through a cache, `TORCH_NCCL_CUDA_EVENT_CACHE=0` in `recommended_env()` switches that
+        off).  Costs 0.25 s per captured graph, once."""
+        import time
+        torch.cuda.synchronize(self.device)
+        time.sleep(0.25)
 
     def _on_stream(self):
         import contextlib
@@ -591,9 +610,9 @@ class TrainStep:
         step: the step counter (dropout stream, AdamW's t) is put back, so that a replayed sequence draws the masks an eager
         sequence draws, however many graphs were captured on the way.  `check` (add_batch): the trained-parameter set -- flat
         layout, sinks, optimizer -- was fixed by the batches given at construction; a batch that reaches a parameter outside it
-        would leave that parameter silently untrained.  Looked for in THIS pass (no extra dry run: ADVICE r4), and the
-        verdict is agreed on by all ranks before anybody raises -- a rank that raised alone would leave the others hanging in
-        their next all-reduce."""
+        would leave that parameter silently untrained.  Looked for in THIS pass (no extra dry run: ADVICE r4).  The
+        error is raised on the rank that sees it: ranks meet new shape buckets at different steps, so no collective may run here
+        (it would pair with another rank's gradient exchange); under torch.distributed.run a rank that exits takes the job down."""
         batch = self.batches[i]
         known = {id(p) for p in self.flat.params}
         with self._on_stream():
@@ -606,15 +625,8 @@ class TrainStep:
             self.seed_dev.copy_(saved)
             extra = [n for n, p in self.model.named_parameters() if id(p) not in known and p.grad is not None] if check else []
         self._join()
-        if check:
-            bad = len(extra) > 0
-            if self.world > 1:
-                t = torch.tensor([float(bad)], device=self.device)
-                dist.all_reduce(t, op=dist.ReduceOp.MAX)
-                bad = float(t.item()) > 0
-            if bad:
-                raise RuntimeError("TrainStep.add_batch: this batch reaches parameters the trainer was not built for: "
-                                   f"{extra[:5] if extra else '(on another rank)'}")
+        if check and extra:
+            raise RuntimeError(f"TrainStep.add_batch: this batch reaches parameters the trainer was not built for: {extra[:5]}")
 
     def _capture(self, i, warm=True):
         batch = self.batches[i]

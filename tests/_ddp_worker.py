@@ -20,6 +20,9 @@ def main():
     multi = torch.cuda.device_count() >= world
     dev = torch.device("cuda", rank if multi else 0)
     torch.cuda.set_device(dev)
+    from mobgt_amd.train import recommended_env
+    for k_, v_ in recommended_env().items():
+        os.environ.setdefault(k_, v_)
     if multi:
         dist.init_process_group("nccl", device_id=dev)
     else:
