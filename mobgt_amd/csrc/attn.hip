@@ -1139,19 +1139,24 @@ __global__ __launch_bounds__(ONE_NW * 64) void attn_bwd_one_kernel(const AttnPar
         }
         lse_s = p.lse_in[(int64_t)gh * T + min(c * KC + sr, T - 1)];
     };
-    float lse_r = 0.f;
-    auto load_rowstats = [&](const int c) {      // thread it < KC carries query it of the chunk (every thread loads: no branch)
-        const int64_t qi = (int64_t)gh * T + min(c * KC + (tid & (KC - 1)), T - 1);
-        lse_r = p.lse_in[qi];
-    };
-    // Per chunk TWO barriers:   tiles(c) | A | staging of chunk c + 1, dBias / dQ of chunk c, requests for chunk c + 2 | B
-    // Every wait on a load sits in front of the chunk's stores and atomics in program order and the requests for chunk c + 2
-    // behind them (the counter retires in issue order: the atomics of chunk c then have the whole of tiles(c + 1) to complete,
-    // and no wait count has to be exact across the loop's back edge -- where the compiler's merged counts are conservative).
+    // ---- the chunk loop, pipelined by HALVES of a chunk (round 5) ----------------------------------------------------------
+    // Round 4 ran a chunk as   tiles(c) | barrier | staging of c + 1, dBias / dQ write-out of c | barrier   : the write-out (26 us
+    // of dBias stores, 11 of dQ products, 9 of atomics at c5) sat between two barriers with nothing beside it.  A chunk's two
+    // 32-query tiles use disjoint halves of every staging image and of the dS image, so a PHASE is now one tile, and phase p
+    // carries, beside its tile, the write-out of phase p - 1's half of dS and the staging of the half that phase p + 1 reads:
+    //     phase (c, 0):  tile (c, 0) | write-out of (c - 1, 1) | stage rows 32..63 of chunk c,     dropout words of tile (c, 1)
+    //     phase (c, 1):  tile (c, 1) | write-out of (c, 0)     | stage rows 0..31 of chunk c + 1,  dropout words of tile (c + 1, 0)
+    // one barrier per phase -- as many as before -- and the write-out's stores and atomics are in flight under the next tile.
+    // A wave's staging pieces all belong to one half (waves 0-1 / 4-5: rows 0..31 of Q / dO, waves 2-3 / 6-7: rows 32..63), so
+    // "stage" is wave-uniform; its registers are requested one chunk ahead, right behind the store that frees them.  The bias
+    // image is wave-private: a wave parks chunk c + 1's super-tile behind tile (c, 1), its last read of chunk c.
+    const int my_half = (wave >> 1) & 1;
     auto stage_store = [&](const int c) {
+        (void)c;
         bf16x8 b = sreg.as_bf16();
+        float mq = 0.f, il = 1.f;
         if (!is_q) {                                     // (wave-uniform: waves 4 .. 7)
-            float mq, il, a8[8];
+            float a8[8];
             row_norm(lse_s, mq, il);
             sreg.get(a8);
 #pragma unroll
@@ -1161,7 +1166,6 @@ __global__ __launch_bounds__(ONE_NW * 64) void attn_bwd_one_kernel(const AttnPar
         *reinterpret_cast<bf16x8*>(&srm[sr][sc0]) = b;
 #pragma unroll
         for (int i = 0; i < 8; ++i) strn[sc0 + i][sr] = b[i];
-        if (tid < KC) lseS[tid] = __builtin_rintf(lse_r * MOBGT_LOG2E);
         {
             float o8[8], l8[8];
             oreg.get(o8);
@@ -1171,134 +1175,121 @@ __global__ __launch_bounds__(ONE_NW * 64) void attn_bwd_one_kernel(const AttnPar
             for (int i = 0; i < 8; ++i) d = fmaf((float)b[i], o8[i] + l8[i], d);
             d += __shfl_xor(d, 1, 64);                   // the four pieces of a row sit in four neighbouring lanes
             d += __shfl_xor(d, 2, 64);
-            if (!is_q && (se & 3) == 0) dlS[sr] = d;
-        }
-        if (DROP) {
-            for (int e = tid; e < 2 * NW * 2 * 32; e += NT) {
-                const int row = e & 31, kbl = (e >> 5) % (NW * 2), t = e / (NW * 64);
-                const int q = c * KC + t * 32 + row;
-                const uint32_t rh = dropout_row_hash(seed, (uint32_t)(gh * T + (q < T ? q : T - 1)));
-                const uint32_t hb = attn_drop_block(seed, rh, (uint32_t)(wg_tile0(kt, nK, T) * 2 + kbl));
-#pragma unroll
-                for (int m = 0; m < 8; ++m) dropW[t][kbl][m][row] = attn_drop_word(hb, attn_drop_mult(m));
+            if (!is_q && (se & 3) == 0) {
+                dlS[sr] = d;
+                lseS[sr] = mq;                           // M' of the row (row_norm)
             }
         }
-        bst.park(bimg, lane);
     };
-    auto request = [&](const int c) {
-        stage_load(c);
-        load_rowstats(c);
-        bst.load(brows, c);
+    auto drop_build = [&](const int c, const int t) {   // the w words of tile (c, t): 16 key blocks x 32 query rows = one entry per thread
+        const int row = tid & 31, kbl = tid >> 5;
+        const int q = c * KC + t * 32 + row;
+        const uint32_t rh = dropout_row_hash(seed, (uint32_t)(gh * T + (q < T ? q : T - 1)));
+        const uint32_t hb = attn_drop_block(seed, rh, (uint32_t)(wg_tile0(kt, nK, T) * 2 + kbl));
+#pragma unroll
+        for (int m = 0; m < 8; ++m) dropW[t][kbl][m][row] = attn_drop_word(hb, attn_drop_mult(m));
     };
-    request(0);
-    stage_store(0);
-    request(min(1, nchunk - 1));
-    __syncthreads();
-
-    for (int c = 0; c < nchunk; ++c) {
+    auto tile = [&](const int c, const int t) {
+        const int q0 = c * KC + t * 32;
+        if (q0 >= T) return;               // (wave-uniform.  The tile's half of DSk keeps older values: they only reach dBias rows /
+                                           //  dQ rows >= T, which are never stored)
+        f32x16 s, dp;
+        BiasStage<TB>::to_acc(bimg, n, hi, t, s);
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            const int q0 = c * KC + t * 32;
-            if (q0 >= T) break;            // (wave-uniform.  The tile's part of DSk keeps the previous chunk's values: they only
-                                           //  reach dBias rows / dQ rows >= T, which are never stored)
-            f32x16 s, dp;
-            BiasStage<TB>::to_acc(bimg, n, hi, t, s);
+        for (int i = 0; i < 16; ++i) dp[i] = 0.f;
 #pragma unroll
-            for (int i = 0; i < 16; ++i) dp[i] = 0.f;
+        for (int ks = 0; ks < KS; ++ks) {
+            const bf16x8 aq = *reinterpret_cast<const bf16x8*>(&Qs[t * 32 + kappa(n)][ks * 16 + 8 * hi]);
+            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq, kf[ks], s, 0, 0, 0);
+            const bf16x8 ad = *reinterpret_cast<const bf16x8*>(&dOs[t * 32 + kappa(n)][ks * 16 + 8 * hi]);
+            dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ad, vf[ks], dp, 0, 0, 0);
+        }
+        // (query rows >= T of the last tile need no masking: their bias_t columns are -inf, hence P = 0 and dS = 0 there)
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                const bf16x8 aq = *reinterpret_cast<const bf16x8*>(&Qs[t * 32 + kappa(n)][ks * 16 + 8 * hi]);
-                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq, kf[ks], s, 0, 0, 0);
-                const bf16x8 ad = *reinterpret_cast<const bf16x8*>(&dOs[t * 32 + kappa(n)][ks * 16 + 8 * hi]);
-                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ad, vf[ks], dp, 0, 0, 0);
+        for (int s2 = 0; s2 < 2; ++s2) {
+            float lse8[8], dl8[8];
+            uint32_t w8[8];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int r0 = t * 32 + 16 * hi + 8 * s2 + 4 * j;
+                const float4 a = *reinterpret_cast<const float4*>(&lseS[r0]);
+                const float4 b = *reinterpret_cast<const float4*>(&dlS[r0]);
+                lse8[4 * j] = a.x; lse8[4 * j + 1] = a.y; lse8[4 * j + 2] = a.z; lse8[4 * j + 3] = a.w;
+                dl8[4 * j] = b.x; dl8[4 * j + 1] = b.y; dl8[4 * j + 2] = b.z; dl8[4 * j + 3] = b.w;
+                if (DROP) {
+                    const uint4 w = *reinterpret_cast<const uint4*>(
+                        &dropW[t][wave * 2 + (n >> 4)][(n & 15) >> 1][16 * hi + 8 * s2 + 4 * j]);
+                    w8[4 * j] = w.x; w8[4 * j + 1] = w.y; w8[4 * j + 2] = w.z; w8[4 * j + 3] = w.w;
+                }
             }
-            // (query rows >= T of the last tile need no masking: their bias_t columns are -inf, hence P = 0 and dS = 0 there)
+            float a8[8], b8[8];
 #pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2) {
-                float lse8[8], dl8[8];
-                uint32_t w8[8];
+            for (int j = 0; j < 8; j += 2) {
+                const int i = 8 * s2 + j;
+                // the forward's probabilities of this key for two query rows, rounded to bf16 as a pair (header: consistent softmax)
+                const uint32_t pw = pack2(fast_exp2(fmaf(s[i], MOBGT_LOG2E, -lse8[j])), fast_exp2(fmaf(s[i + 1], MOBGT_LOG2E, -lse8[j + 1])));
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const int r0 = t * 32 + 16 * hi + 8 * s2 + 4 * j;
-                    const float4 a = *reinterpret_cast<const float4*>(&lseS[r0]);
-                    const float4 b = *reinterpret_cast<const float4*>(&dlS[r0]);
-                    lse8[4 * j] = a.x; lse8[4 * j + 1] = a.y; lse8[4 * j + 2] = a.z; lse8[4 * j + 3] = a.w;
-                    dl8[4 * j] = b.x; dl8[4 * j + 1] = b.y; dl8[4 * j + 2] = b.z; dl8[4 * j + 3] = b.w;
+                for (int u = 0; u < 2; ++u) {
+                    const float pr = u ? bf16_hi(pw) : bf16_lo(pw);
                     if (DROP) {
-                        const uint4 w = *reinterpret_cast<const uint4*>(
-                            &dropW[t][wave * 2 + (n >> 4)][(n & 15) >> 1][16 * hi + 8 * s2 + 4 * j]);
-                        w8[4 * j] = w.x; w8[4 * j + 1] = w.y; w8[4 * j + 2] = w.z; w8[4 * j + 3] = w.w;
+                        const bool keep = (int)(w8[j + u] << drop_sh) >= thr_hi;
+                        const float x = keep ? pr : 0.f;
+                        a8[j + u] = x;
+                        b8[j + u] = fmaf(x, dp[i + u], -pr * dl8[j + u]);
+                    } else {
+                        a8[j + u] = pr;
+                        b8[j + u] = pr * (dp[i + u] - dl8[j + u]);
                     }
                 }
-                float a8[8], b8[8];
+            }
+            const bf16x8 pb = pack8(a8);
+            u32x4 dbw = __builtin_bit_cast(u32x4, pack8(b8));
 #pragma unroll
-                for (int j = 0; j < 8; j += 2) {
-                    const int i = 8 * s2 + j;
-                    // the forward's probabilities of this key for two query rows, rounded to bf16 as a pair (header: consistent softmax)
-                    const uint32_t pw = pack2(fast_exp2(fmaf(s[i], MOBGT_LOG2E, -lse8[j])), fast_exp2(fmaf(s[i + 1], MOBGT_LOG2E, -lse8[j + 1])));
+            for (int k = 0; k < 4; ++k) dbw[k] &= kmask;
+            const bf16x8 db = __builtin_bit_cast(bf16x8, dbw);
+            if (ONE_SKIP != 4) *reinterpret_cast<bf16x8*>(&DSk[32 * wave + n][t * 32 + 16 * hi + 8 * s2]) = db;
+            const bf16x8 ado = *reinterpret_cast<const bf16x8*>(&dOt[kappa(n)][t * 32 + 16 * hi + 8 * s2]);
+            dv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ado, pb, dv, 0, 0, 0);
+            const bf16x8 aq = *reinterpret_cast<const bf16x8*>(&Qt[kappa(n)][t * 32 + 16 * hi + 8 * s2]);
+            dk = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq, db, dk, 0, 0, 0);
+        }
+    };
+    // dBias and dQ of the half (c, t) of the dS image
+    auto writeout = [&](const int c, const int t) {
+        if (c * KC + t * 32 >= T) return;                       // (wave-uniform)
+        if (ONE_SKIP == 1 || ONE_SKIP == 4) return;
+        const int i16 = lane & 15, g4 = lane >> 4, q4 = i16 >> 2, p4 = i16 & 3;
+        // ---- dBias: wave w = 16 queries (w & 1) x 64 keys (w >> 1); a lane's piece j: query i16, keys 32 j + 8 g4 .. + 7
+        if (p.dbias && ONE_SKIP != 3) {
+            // (only this workgroup's own key columns: idle waves of a workgroup with fewer than 8 key tiles parked zeros at
+            //  rows that are the NEXT workgroup's keys)
+            const int kend = kt + 1 < nK ? wg_tile0(kt + 1, nK, T) * 32 : (int)p.ld_bias;
+            const int qg = wave & 1, kq = wave >> 1;
+            const int qglob = c * KC + 32 * t + 16 * qg + i16;
+            bf16_t* drow = reinterpret_cast<bf16_t*>(p.dbias) + ((int64_t)gh * T + min(qglob, T - 1)) * p.ld_bias;
 #pragma unroll
-                    for (int u = 0; u < 2; ++u) {
-                        const float pr = u ? bf16_hi(pw) : bf16_lo(pw);
-                        if (DROP) {
-                            const bool keep = (int)(w8[j + u] << drop_sh) >= thr_hi;
-                            const float x = keep ? pr : 0.f;
-                            a8[j + u] = x;
-                            b8[j + u] = fmaf(x, dp[i + u], -pr * dl8[j + u]);
-                        } else {
-                            a8[j + u] = pr;
-                            b8[j + u] = pr * (dp[i + u] - dl8[j + u]);
-                        }
-                    }
+            for (int j = 0; j < 2; ++j) {
+                const int kl = 64 * kq + 32 * j + 8 * g4;
+                const mobgt_v4s r0 = lds_tr16(&DSk[kl + q4][32 * t + 16 * qg + 4 * p4]);
+                const mobgt_v4s r1 = lds_tr16(&DSk[kl + 4 + q4][32 * t + 16 * qg + 4 * p4]);
+                const int kglob = k0g + kl;
+                if (qglob < T && kglob < kend) {
+                    typedef short v8s __attribute__((ext_vector_type(8)));
+                    const v8s v = {r0[0], r0[1], r0[2], r0[3], r1[0], r1[1], r1[2], r1[3]};
+                    *reinterpret_cast<v8s*>(drow + kglob) = v;
                 }
-                const bf16x8 pb = pack8(a8);
-                u32x4 dbw = __builtin_bit_cast(u32x4, pack8(b8));
-#pragma unroll
-                for (int k = 0; k < 4; ++k) dbw[k] &= kmask;
-                const bf16x8 db = __builtin_bit_cast(bf16x8, dbw);
-                if (ONE_SKIP != 4) *reinterpret_cast<bf16x8*>(&DSk[32 * wave + n][t * 32 + 16 * hi + 8 * s2]) = db;
-                const bf16x8 ado = *reinterpret_cast<const bf16x8*>(&dOt[kappa(n)][t * 32 + 16 * hi + 8 * s2]);
-                dv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ado, pb, dv, 0, 0, 0);
-                const bf16x8 aq = *reinterpret_cast<const bf16x8*>(&Qt[kappa(n)][t * 32 + 16 * hi + 8 * s2]);
-                dk = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq, db, dk, 0, 0, 0);
             }
         }
-        __syncthreads();                                        // A: every wave is done with the chunk's images; DSk is complete
-        // (measured and NOT kept: the chunk's stores and atomics issued unconditionally -- lanes without an element storing to a dump
-        //  area / adding zeros to clamped addresses -- so that the wait counts in front of the staging are exact on every path: the
-        //  dump area and the clamped atomics are hot spots, 135 -> 178 us; the stores behind their branches cost ~26 us of the
-        //  launch, the atomics ~9, the transposed reads + products of dQ ~11: profiles/r4_attn_onepass_probes.txt)
-        if (c + 1 < nchunk) stage_store(c + 1);                 // (wave-uniform)
-        if (ONE_SKIP != 1 && ONE_SKIP != 4) {
-            const int i16 = lane & 15, g4 = lane >> 4, q4 = i16 >> 2, p4 = i16 & 3;
-            // ---- dBias: wave w = 16 queries (w & 3) x 128 keys (w >> 2); a lane's piece j: query i16, keys 32 j + 8 g4 .. + 7
-            if (p.dbias && ONE_SKIP != 3) {
-                // (only this workgroup's own key columns: idle waves of a workgroup with fewer than 8 key tiles parked zeros at
-                //  rows that are the NEXT workgroup's keys)
-                const int kend = kt + 1 < nK ? wg_tile0(kt + 1, nK, T) * 32 : (int)p.ld_bias;
-                const int qg = wave & 3, kh = wave >> 2;
-                const int qglob = c * KC + 16 * qg + i16;
-                bf16_t* drow = reinterpret_cast<bf16_t*>(p.dbias) + ((int64_t)gh * T + min(qglob, T - 1)) * p.ld_bias;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int kl = 128 * kh + 32 * j + 8 * g4;
-                    const mobgt_v4s r0 = lds_tr16(&DSk[kl + q4][16 * qg + 4 * p4]);
-                    const mobgt_v4s r1 = lds_tr16(&DSk[kl + 4 + q4][16 * qg + 4 * p4]);
-                    const int kglob = k0g + kl;
-                    if (qglob < T && kglob < kend) {
-                        typedef short v8s __attribute__((ext_vector_type(8)));
-                        const v8s v = {r0[0], r0[1], r0[2], r0[3], r1[0], r1[1], r1[2], r1[3]};
-                        *reinterpret_cast<v8s*>(drow + kglob) = v;
-                    }
-                }
-            }
-            // ---- dQ: wave w owns the 16 x 16 tile (query tile w >> 2, queries 16 ((w >> 1) & 1) .., head columns 16 (w & 1) ..)
-            const int tq = wave >> 2, qh = (wave >> 1) & 1, dh = wave & 1;
+        // ---- dQ: the half's 32 queries x 32 head columns are four 16 x 16 tiles over all 256 keys: waves 0 .. 3 (queries
+        //      16 (w >> 1) .., head columns 16 (w & 1) ..).  lds_tr16 wants every lane active: the other waves skip as whole waves.
+        if (wave < 4) {
+            const int qh = (wave >> 1) & 1, dh = wave & 1;
             f32x4v acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int ks = 0; ks < NW; ++ks) {
                 const int kl = 32 * ks + 8 * g4;
-                const mobgt_v4s r0 = lds_tr16(&DSk[kl + q4][tq * 32 + qh * 16 + 4 * p4]);
-                const mobgt_v4s r1 = lds_tr16(&DSk[kl + 4 + q4][tq * 32 + qh * 16 + 4 * p4]);
+                const mobgt_v4s r0 = lds_tr16(&DSk[kl + q4][t * 32 + qh * 16 + 4 * p4]);
+                const mobgt_v4s r1 = lds_tr16(&DSk[kl + 4 + q4][t * 32 + qh * 16 + 4 * p4]);
                 typedef short v8s __attribute__((ext_vector_type(8)));
                 const v8s av = {r0[0], r0[1], r0[2], r0[3], r1[0], r1[1], r1[2], r1[3]};
                 const bf16x8 a = __builtin_bit_cast(bf16x8, av);
@@ -1310,15 +1301,54 @@ __global__ __launch_bounds__(ONE_NW * 64) void attn_bwd_one_kernel(const AttnPar
                 float* dst = p.dq_acc + ((int64_t)g * T) * (H * D) + h * D + dcol;
 #pragma unroll
                 for (int v = 0; v < 4; ++v) {
-                    const int qglob = c * KC + tq * 32 + qh * 16 + 4 * g4 + v;
+                    const int qglob = c * KC + t * 32 + qh * 16 + 4 * g4 + v;
                     if (qglob < T && ONE_SKIP != 2) atomicAdd(dst + (int64_t)qglob * (H * D), acc[v]);
                     if (ONE_SKIP == 2 && acc[v] == 12345.678f) dst[0] = acc[v];          // (keeps the products alive)
                 }
             }
         }
-        request(min(c + 2, nchunk - 1));
-        __syncthreads();                                        // B: chunk c + 1 is staged; DSk may be overwritten
+    };
+    // prologue: chunk 0 staged in full, chunk 1 requested
+    stage_load(0);
+    bst.load(brows, 0);
+    stage_store(0);
+    if (DROP) {
+        drop_build(0, 0);
+        drop_build(0, 1);
     }
+    bst.park(bimg, lane);
+    stage_load(min(1, nchunk - 1));
+    bst.load(brows, min(1, nchunk - 1));
+    __syncthreads();
+
+    // Inside a phase every wait on a load (staging registers, bias registers) sits in FRONT of the phase's stores and atomics in
+    // program order and the new requests behind them: the counter retires in issue order, so the stores of phase p have the whole
+    // tile of phase p + 1 to complete and no wait count has to be exact across the loop's back edge.
+    for (int c = 0; c < nchunk; ++c) {
+        // ---- phase (c, 0)
+        tile(c, 0);
+        if (c > 0) {
+            if (my_half == 1) stage_store(c);                   // rows 32 .. 63 of chunk c: read by the next phase
+            if (DROP) drop_build(c, 1);
+            writeout(c - 1, 1);
+            if (my_half == 1) stage_load(min(c + 1, nchunk - 1));
+        }
+        __syncthreads();
+        // ---- phase (c, 1)
+        tile(c, 1);
+        if (c + 1 < nchunk) {
+            if (my_half == 0) stage_store(c + 1);               // rows 0 .. 31 of chunk c + 1
+            if (DROP) drop_build(c + 1, 0);
+            bst.park(bimg, lane);                               // (the image's readers of chunk c are this wave's own earlier reads)
+        }
+        writeout(c, 0);
+        if (c + 1 < nchunk) {
+            if (my_half == 0) stage_load(min(c + 2, nchunk - 1));
+            bst.load(brows, min(c + 2, nchunk - 1));
+        }
+        __syncthreads();
+    }
+    writeout(nchunk - 1, 1);
 
     if (k_ok) {
         TQ* DK = reinterpret_cast<TQ*>(p.dk) + ((int64_t)g * T + my_k) * p.lddk + h * D + 16 * hi;
