@@ -1280,10 +1280,12 @@ __global__ __launch_bounds__(ONE_NW * 64) void attn_bwd_one_kernel(const AttnPar
                 }
             }
         }
-        // ---- dQ: the half's 32 queries x 32 head columns are four 16 x 16 tiles over all 256 keys: waves 0 .. 3 (queries
-        //      16 (w >> 1) .., head columns 16 (w & 1) ..).  lds_tr16 wants every lane active: the other waves skip as whole waves.
-        if (wave < 4) {
-            const int qh = (wave >> 1) & 1, dh = wave & 1;
+        // ---- dQ: the half's 32 queries x 32 head columns are four 16 x 16 tiles over all 256 keys, on the four waves that do
+        //      NOT stage in this phase (half t is written out in a phase that stages half 1 - t ... of the waves with
+        //      my_half == t): queries 16 (w >> 2) .., head columns 16 (w & 1) ...  lds_tr16 wants every lane active: the
+        //      other waves skip as whole waves.
+        if (my_half != t) {
+            const int qh = wave >> 2, dh = wave & 1;
             f32x4v acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int ks = 0; ks < NW; ++ks) {
