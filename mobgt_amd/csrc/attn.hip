@@ -1126,17 +1126,18 @@ __global__ __launch_bounds__(ONE_NW * 64) void attn_bwd_one_kernel(const AttnPar
     // rowsum(dO~ O) is formed HERE: the threads that stage a piece of dO also request the same piece of O (and of its residual)
     // with the same two-chunk lead and reduce the products over the four pieces of a row when the chunk is stored (a launch in
     // front that read dO and O once more and zero-filled the accumulator cost 10.9 us at c5: round 4).
+    // (no branch in here -- the loop's wait counts are exact only over straight-line code: a piece beyond the head dimension is
+    //  read from column 0 and zeroed when it is stored; without a residual the O piece is read twice and the copy weighted 0)
+    const bool col_ok = D % 32 == 0 || sc0 < D;
+    const int scl = col_ok ? sc0 : 0;
+    const TQ* osrc = is_q ? ssrc : Oo;
+    const TQ* lsrc = is_q ? ssrc : (OLo ? reinterpret_cast<const TQ*>(OLo) : Oo);
+    const float lw = OLo ? 1.f : 0.f;
     auto stage_load = [&](const int c) {
-        if (D % 32 == 0 || sc0 < D) {
-            sreg.load(ssrc + (int64_t)min(c * KC + sr, T - 1) * sld + sc0);
-            oreg.load((is_q ? ssrc : Oo) + (int64_t)min(c * KC + sr, T - 1) * sld + sc0);      // (Q threads: a second read of their piece, unused)
-            if (OLo) lreg.load((is_q ? ssrc : OLo) + (int64_t)min(c * KC + sr, T - 1) * sld + sc0);
-            else lreg.zero();
-        } else {
-            sreg.zero();
-            oreg.zero();
-            lreg.zero();
-        }
+        const int64_t ro = (int64_t)min(c * KC + sr, T - 1) * sld + scl;
+        sreg.load(ssrc + ro);
+        oreg.load(osrc + ro);                            // (Q threads: a second read of their piece, unused)
+        lreg.load(lsrc + ro);
         lse_s = p.lse_in[(int64_t)gh * T + min(c * KC + sr, T - 1)];
     };
     // ---- the chunk loop, pipelined by HALVES of a chunk (round 5) ----------------------------------------------------------
@@ -1163,6 +1164,12 @@ __global__ __launch_bounds__(ONE_NW * 64) void attn_bwd_one_kernel(const AttnPar
             for (int i = 0; i < 8; ++i) a8[i] *= il;
             b = pack8(a8);
         }
+        if (D % 32 != 0) {
+            u32x4 w = __builtin_bit_cast(u32x4, b);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) w[i] = col_ok ? w[i] : 0u;
+            b = __builtin_bit_cast(bf16x8, w);
+        }
         *reinterpret_cast<bf16x8*>(&srm[sr][sc0]) = b;
 #pragma unroll
         for (int i = 0; i < 8; ++i) strn[sc0 + i][sr] = b[i];
@@ -1172,7 +1179,7 @@ __global__ __launch_bounds__(ONE_NW * 64) void attn_bwd_one_kernel(const AttnPar
             lreg.get(l8);
             float d = 0.f;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) d = fmaf((float)b[i], o8[i] + l8[i], d);
+            for (int i = 0; i < 8; ++i) d = fmaf((float)b[i], fmaf(lw, l8[i], o8[i]), d);
             d += __shfl_xor(d, 1, 64);                   // the four pieces of a row sit in four neighbouring lanes
             d += __shfl_xor(d, 2, 64);
             if (!is_q && (se & 3) == 0) {
@@ -1255,36 +1262,21 @@ __global__ __launch_bounds__(ONE_NW * 64) void attn_bwd_one_kernel(const AttnPar
         }
     };
     // dBias and dQ of the half (c, t) of the dS image
-    auto writeout = [&](const int c, const int t) {
-        if (c * KC + t * 32 >= T) return;                       // (wave-uniform)
+    // (descriptors of this (graph, head)'s dBias slice and of the graph's dQ accumulator: both far below 2 GB)
+    const __amdgpu_buffer_rsrc_t db_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        reinterpret_cast<bf16_t*>(p.dbias) + (p.dbias ? (int64_t)gh * T * p.ld_bias : 0), 0, p.dbias ? (int)(T * p.ld_bias * 2) : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t dq_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        p.dq_acc + (int64_t)g * T * (H * D), 0, T * H * D * 4, 0x00020000);
+    // do_dq: this wave carries one of the half's four dQ tiles (compile-time at every call site).  Nothing in here branches: a
+    // lane (or a whole wave: half (-1, 1) of the first phase, halves beyond T) that has nothing to write carries an offset beyond
+    // the buffer and the hardware drops it, so the wait counts of the staging loads issued in FRONT of the write-out are exact
+    // and leave these stores and atomics in flight under the next tile.
+    auto writeout = [&](const int c, const int t, const bool do_dq) {
         if (ONE_SKIP == 1 || ONE_SKIP == 4) return;
         const int i16 = lane & 15, g4 = lane >> 4, q4 = i16 >> 2, p4 = i16 & 3;
-        // ---- dBias: wave w = 16 queries (w & 1) x 64 keys (w >> 1); a lane's piece j: query i16, keys 32 j + 8 g4 .. + 7
-        if (p.dbias && ONE_SKIP != 3) {
-            // (only this workgroup's own key columns: idle waves of a workgroup with fewer than 8 key tiles parked zeros at
-            //  rows that are the NEXT workgroup's keys)
-            const int kend = kt + 1 < nK ? wg_tile0(kt + 1, nK, T) * 32 : (int)p.ld_bias;
-            const int qg = wave & 1, kq = wave >> 1;
-            const int qglob = c * KC + 32 * t + 16 * qg + i16;
-            bf16_t* drow = reinterpret_cast<bf16_t*>(p.dbias) + ((int64_t)gh * T + min(qglob, T - 1)) * p.ld_bias;
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int kl = 64 * kq + 32 * j + 8 * g4;
-                const mobgt_v4s r0 = lds_tr16(&DSk[kl + q4][32 * t + 16 * qg + 4 * p4]);
-                const mobgt_v4s r1 = lds_tr16(&DSk[kl + 4 + q4][32 * t + 16 * qg + 4 * p4]);
-                const int kglob = k0g + kl;
-                if (qglob < T && kglob < kend) {
-                    typedef short v8s __attribute__((ext_vector_type(8)));
-                    const v8s v = {r0[0], r0[1], r0[2], r0[3], r1[0], r1[1], r1[2], r1[3]};
-                    *reinterpret_cast<v8s*>(drow + kglob) = v;
-                }
-            }
-        }
         // ---- dQ: the half's 32 queries x 32 head columns are four 16 x 16 tiles over all 256 keys, on the four waves that do
-        //      NOT stage in this phase (half t is written out in a phase that stages half 1 - t ... of the waves with
-        //      my_half == t): queries 16 (w >> 2) .., head columns 16 (w & 1) ...  lds_tr16 wants every lane active: the
-        //      other waves skip as whole waves.
-        if (my_half != t) {
+        //      not stage in this phase: queries 16 (w >> 2) .., head columns 16 (w & 1) ..
+        if (do_dq) {
             const int qh = wave >> 2, dh = wave & 1;
             f32x4v acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -1299,18 +1291,36 @@ __global__ __launch_bounds__(ONE_NW * 64) void attn_bwd_one_kernel(const AttnPar
                 acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc, 0, 0, 0);
             }
             const int dcol = dh * 16 + i16;
-            if (dcol < D) {
-                float* dst = p.dq_acc + ((int64_t)g * T) * (H * D) + h * D + dcol;
 #pragma unroll
-                for (int v = 0; v < 4; ++v) {
-                    const int qglob = c * KC + t * 32 + qh * 16 + 4 * g4 + v;
-                    if (qglob < T && ONE_SKIP != 2) atomicAdd(dst + (int64_t)qglob * (H * D), acc[v]);
-                    if (ONE_SKIP == 2 && acc[v] == 12345.678f) dst[0] = acc[v];          // (keeps the products alive)
-                }
+            for (int v = 0; v < 4; ++v) {
+                const int qglob = c * KC + t * 32 + qh * 16 + 4 * g4 + v;
+                const uint32_t off = (dcol < D && (unsigned)qglob < (unsigned)T) ? (uint32_t)(qglob * (H * D) + h * D + dcol) * 4u : 0x80000000u;
+                if (ONE_SKIP != 2) __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(acc[v], dq_rsrc, off, 0, 0);
+                if (ONE_SKIP == 2 && acc[v] == 12345.678f) p.dq_acc[0] = acc[v];          // (keeps the products alive)
+            }
+        }
+        // ---- dBias: wave w = 16 queries (w & 1) x 64 keys (w >> 1); a lane's piece j: query i16, keys 32 j + 8 g4 .. + 7
+        if (ONE_SKIP != 3) {
+            // (only this workgroup's own key columns: idle waves of a workgroup with fewer than 8 key tiles parked zeros at
+            //  rows that are the NEXT workgroup's keys.  No dBias wanted: the descriptor is empty)
+            const int kend = kt + 1 < nK ? wg_tile0(kt + 1, nK, T) * 32 : (int)p.ld_bias;
+            const int qg = wave & 1, kq = wave >> 1;
+            const int qglob = c * KC + 32 * t + 16 * qg + i16;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int kl = 64 * kq + 32 * j + 8 * g4;
+                const mobgt_v4s r0 = lds_tr16(&DSk[kl + q4][32 * t + 16 * qg + 4 * p4]);
+                const mobgt_v4s r1 = lds_tr16(&DSk[kl + 4 + q4][32 * t + 16 * qg + 4 * p4]);
+                const int kglob = k0g + kl;
+                typedef short v8s __attribute__((ext_vector_type(8)));
+                const v8s v = {r0[0], r0[1], r0[2], r0[3], r1[0], r1[1], r1[2], r1[3]};
+                const uint32_t off = ((unsigned)qglob < (unsigned)T && kglob < kend) ? (uint32_t)(qglob * (int)p.ld_bias + kglob) * 2u : 0x80000000u;
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), db_rsrc, off, 0, 0);
             }
         }
     };
-    // prologue: chunk 0 staged in full, chunk 1 requested
+    // prologue: chunk 0 staged in full; the waves of rows 0 .. 31 request chunk 1, the others chunk 0 once more (they stage
+    // their rows in phase (c, 0), also for c = 0: the loop body has no first-iteration case)
     stage_load(0);
     bst.load(brows, 0);
     stage_store(0);
@@ -1319,38 +1329,41 @@ __global__ __launch_bounds__(ONE_NW * 64) void attn_bwd_one_kernel(const AttnPar
         drop_build(0, 1);
     }
     bst.park(bimg, lane);
-    stage_load(min(1, nchunk - 1));
+    stage_load(my_half ? 0 : min(1, nchunk - 1));
     bst.load(brows, min(1, nchunk - 1));
     __syncthreads();
 
-    // Inside a phase every wait on a load (staging registers, bias registers) sits in FRONT of the phase's stores and atomics in
-    // program order and the new requests behind them: the counter retires in issue order, so the stores of phase p have the whole
-    // tile of phase p + 1 to complete and no wait count has to be exact across the loop's back edge.
-    for (int c = 0; c < nchunk; ++c) {
-        // ---- phase (c, 0)
-        tile(c, 0);
-        if (c > 0) {
-            if (my_half == 1) stage_store(c);                   // rows 32 .. 63 of chunk c: read by the next phase
+    // The loop is instantiated per staging half, and nothing in its body is conditional at run time (chunk numbers are clamped;
+    // what is staged or parked beyond the last chunk is never read): the compiler's wait counts are then exact, every wait on a
+    // staging / bias load leaves the write-out's stores and atomics of the phases behind it in flight.
+    auto phases = [&](auto mh_c) {
+        constexpr int MH = decltype(mh_c)::value;
+        for (int c = 0; c < nchunk; ++c) {
+            // ---- phase (c, 0)
+            tile(c, 0);
+            if (MH == 1) {                                      // rows 32 .. 63 of chunk c: read by the next phase
+                stage_store(c);
+                stage_load(min(c + 1, nchunk - 1));
+            }
             if (DROP) drop_build(c, 1);
-            writeout(c - 1, 1);
-            if (my_half == 1) stage_load(min(c + 1, nchunk - 1));
-        }
-        __syncthreads();
-        // ---- phase (c, 1)
-        tile(c, 1);
-        if (c + 1 < nchunk) {
-            if (my_half == 0) stage_store(c + 1);               // rows 0 .. 31 of chunk c + 1
-            if (DROP) drop_build(c + 1, 0);
+            writeout(c - 1, 1, MH == 0);
+            __syncthreads();
+            // ---- phase (c, 1)
+            tile(c, 1);
+            if (MH == 0) {                                      // rows 0 .. 31 of chunk c + 1
+                stage_store(c + 1);
+                stage_load(min(c + 2, nchunk - 1));
+            }
             bst.park(bimg, lane);                               // (the image's readers of chunk c are this wave's own earlier reads)
-        }
-        writeout(c, 0);
-        if (c + 1 < nchunk) {
-            if (my_half == 0) stage_load(min(c + 2, nchunk - 1));
             bst.load(brows, min(c + 2, nchunk - 1));
+            if (DROP) drop_build(c + 1, 0);
+            writeout(c, 0, MH == 1);
+            __syncthreads();
         }
-        __syncthreads();
-    }
-    writeout(nchunk - 1, 1);
+        writeout(nchunk - 1, 1, MH == 0);
+    };
+    if (my_half) phases(std::integral_constant<int, 1>{});
+    else phases(std::integral_constant<int, 0>{});
 
     if (k_ok) {
         TQ* DK = reinterpret_cast<TQ*>(p.dk) + ((int64_t)g * T + my_k) * p.lddk + h * D + 16 * hi;
