@@ -22,6 +22,7 @@
 // flight while the current one is multiplied.  Rounding points are those of the separate launches (y, u, h, f, qkv
 // rounded to bf16 exactly where a bf16 tensor used to be written), and the dropout masks are the same hashes
 // (mobgt_dropout_add_ln_fwd's), so the existing backward applies unchanged.
+#include <type_traits>
 #include "common.h"
 #include "mobgt_hip.h"
 #include "wgrad_body.h"
@@ -57,11 +58,14 @@ struct ChainParams {
 __device__ int* g_chain_dbg = nullptr;
 #define STAMP_DECL int st_[16] = {}
 #define STAMP(i) st_[i] = (int)wall_clock64()
-#define STAMP_DUMP() do { if (g_chain_dbg && threadIdx.x == 0) for (int q_ = 0; q_ < 16; ++q_) g_chain_dbg[blockIdx.x * 16 + q_] = st_[q_]; } while (0)
+#define STAMP_DUMP() do { if (g_chain_dbg && threadIdx.x == 0) for (int q_ = 0; q_ < 16; ++q_) if (st_[q_]) g_chain_dbg[blockIdx.x * 16 + q_] = st_[q_]; } while (0)
+// the FIRST time a helper passes slot i (thread 0; written straight to the buffer)
+#define STAMP_ONCE(i) do { if (g_chain_dbg && threadIdx.x == 0 && g_chain_dbg[blockIdx.x * 16 + (i)] == 0) g_chain_dbg[blockIdx.x * 16 + (i)] = (int)wall_clock64(); } while (0)
 #else
 #define STAMP_DECL
 #define STAMP(i)
 #define STAMP_DUMP()
+#define STAMP_ONCE(i)
 #endif
 
 __device__ __forceinline__ float wave_sum(float v) {
@@ -131,19 +135,19 @@ constexpr int chunk_steps(int S) { return S <= 8 ? S : (S % 8 == 0 ? 8 : (S % 7 
 // The first two weight chunks of a wave's share of a GEMM, requested EARLY: issue() before the LayerNorm pass / the
 // staging barrier that precedes the product, so that their round trip overlaps it instead of opening the GEMM (four
 // products per launch each started on an idle ~1 us wait).
-template <int N, int K, int SF = K / 32>
+template <int N, int K, int SF = K / 32, int CHO = 0, int NWV = NW>          // (NWV: the workgroup's waves -- 8 in the 64-row form)
 struct WPre {
-    static constexpr int S = K / 32, CH = chunk_steps(S), CPG = S / CH, G = N / 16;
+    static constexpr int S = K / 32, CH = CHO ? CHO : chunk_steps(S), CPG = S / CH, G = N / 16;     // (CHO: the 64-row form's shorter chunks)
     uint4 b0[CH], b1[CH];
     static __device__ __forceinline__ int nchunks() {
         const int wave = threadIdx.x >> 6;
-        return (wave < G ? (G - wave + NW - 1) / NW : 0) * CPG;
+        return (wave < G ? (G - wave + NWV - 1) / NWV : 0) * CPG;
     }
     // (g0, s0): the product multiplies a SLICE of the packed weight -- column groups [g0, g0 + G) and k-steps [s0, s0 + S) of
     // the SF steps a group has (the cluster kernels: a workgroup owns a column range or a K range of the layer's weight)
     static __device__ __forceinline__ void load(const uint16_t* __restrict__ W, uint4 (&b)[CH], int c, int g0 = 0, int s0 = 0) {
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-        const int g = g0 + wave + (c / CPG) * NW, st = s0 + (c % CPG) * CH;   // W is PACKED: one contiguous KB per (group, k-step)
+        const int g = g0 + wave + (c / CPG) * NWV, st = s0 + (c % CPG) * CH;   // W is PACKED: one contiguous KB per (group, k-step)
         const uint16_t* wp = W + ((int64_t)(g * SF + st) * 64 + lane) * 8;
 #pragma unroll
         for (int s = 0; s < CH; ++s) b[s] = *reinterpret_cast<const uint4*>(wp + 512 * s);
@@ -155,19 +159,19 @@ struct WPre {
     }
 };
 
-template <int BM, int N, int K, int LDA, typename EPI, int SF = K / 32>
-__device__ __forceinline__ void wg_gemm(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W, EPI&& epi, WPre<N, K, SF>& pre,
+template <int BM, int N, int K, int LDA, typename EPI, int SF = K / 32, int CHO = 0, int NWV = NW>
+__device__ __forceinline__ void wg_gemm(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W, EPI&& epi, WPre<N, K, SF, CHO, NWV>& pre,
                                         int g0 = 0, int s0 = 0) {
     constexpr int MT = BM / 16;
     constexpr int S = K / 32;                        // k-steps per group
-    constexpr int CH = chunk_steps(S);               // k-steps per chunk
+    constexpr int CH = WPre<N, K, SF, CHO, NWV>::CH;      // k-steps per chunk
     constexpr int CPG = S / CH;                      // chunks per group
-    constexpr bool AREG = S <= 8;                    // A operands held in registers
+    constexpr bool AREG = S <= 8 && MT <= 2;         // A operands held in registers (four row tiles x 8 steps would be 128 of them)
     static_assert(K % 32 == 0 && S % CH == 0 && N % 16 == 0, "shape");
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int j = lane & 15, q = lane >> 4;
     constexpr int G = N / 16;
-    const int ng = wave < G ? (G - wave + NW - 1) / NW : 0;       // this wave's groups
+    const int ng = wave < G ? (G - wave + NWV - 1) / NWV : 0;       // this wave's groups
     const int nchunks = ng * CPG;
     if (nchunks == 0) return;
     const uint16_t* a0 = A + j * LDA + 8 * q;
@@ -178,7 +182,7 @@ __device__ __forceinline__ void wg_gemm(const uint16_t* __restrict__ A, const ui
 #pragma unroll
             for (int s = 0; s < S; ++s) afr[t][s] = *reinterpret_cast<const uint4*>(a0 + 16 * t * LDA + 32 * s);
     }
-    auto load = [&](uint4 (&b)[CH], int c) { WPre<N, K, SF>::load(W, b, c, g0, s0); };
+    auto load = [&](uint4 (&b)[CH], int c) { WPre<N, K, SF, CHO, NWV>::load(W, b, c, g0, s0); };
     f32x4 acc[MT];
 #pragma unroll
     for (int t = 0; t < MT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -196,7 +200,7 @@ __device__ __forceinline__ void wg_gemm(const uint16_t* __restrict__ A, const ui
             }
         }
         if (c % CPG == CPG - 1) {
-            epi(wave + (c / CPG) * NW, acc);         // (the group's index INSIDE the slice)
+            epi(wave + (c / CPG) * NWV, acc);         // (the group's index INSIDE the slice)
 #pragma unroll
             for (int t = 0; t < MT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
@@ -236,7 +240,7 @@ struct LnW {
     }
 };
 
-template <int BM, int C, int LDX, int LDA>
+template <int BM, int C, int LDX, int LDA, int NWV = NW>
 __device__ __forceinline__ void ln_rows(const float* __restrict__ xb, uint16_t* __restrict__ dst_a, const LnW<C>& lw,
                                         float* __restrict__ g_pre, uint16_t* __restrict__ g_bf,
                                         float* __restrict__ g_f32, float* __restrict__ g_mean, float* __restrict__ g_rstd,
@@ -247,7 +251,7 @@ __device__ __forceinline__ void ln_rows(const float* __restrict__ xb, uint16_t* 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const float (&wv)[PER] = lw.w;
     const float (&bv)[PER] = lw.b;
-    for (int r = wave; r < BM; r += NW) {
+    for (int r = wave; r < BM; r += NWV) {
         const int64_t row = r0 + r;
         float v[PER], s = 0.f;
 #pragma unroll
@@ -352,10 +356,10 @@ __device__ __forceinline__ void ln_rows_hw(const float* __restrict__ xb, uint16_
 }
 
 // rows of the f32 residual tile [BM][LDX] -> global [R][C] (pre-LN layers without a successor in the chain: x2 leaves as it is)
-template <int BM, int C, int LDX>
+template <int BM, int C, int LDX, int NTV = NT>
 __device__ __forceinline__ void store_f32_rows(const float* __restrict__ xb, float* __restrict__ dst, int r0, int R, int own_mod = 1,
                                                int own_rem = 0) {
-    for (int e = threadIdx.x; e < BM * (C / 4); e += NT) {
+    for (int e = threadIdx.x; e < BM * (C / 4); e += NTV) {
         const int r = e / (C / 4), c = (e % (C / 4)) * 4;
         if (r0 + r < R && (own_mod == 1 || r % own_mod == own_rem))
             *reinterpret_cast<float4*>(dst + (int64_t)(r0 + r) * C + c) = *reinterpret_cast<const float4*>(xb + r * LDX + c);
@@ -363,9 +367,9 @@ __device__ __forceinline__ void store_f32_rows(const float* __restrict__ xb, flo
 }
 
 // rows of an LDS bf16 tile [BM][LD] -> global [R][N], 16 bytes per thread
-template <int BM, int N, int LD>
+template <int BM, int N, int LD, int NTV = NT>
 __device__ __forceinline__ void store_rows(const uint16_t* __restrict__ src, uint16_t* __restrict__ dst, int r0, int R) {
-    for (int e = threadIdx.x; e < BM * (N / 8); e += NT) {
+    for (int e = threadIdx.x; e < BM * (N / 8); e += NTV) {
         const int r = e / (N / 8), c = (e % (N / 8)) * 8;
         if (r0 + r < R) *reinterpret_cast<uint4*>(dst + (int64_t)(r0 + r) * N + c) = *reinterpret_cast<const uint4*>(src + r * LD + c);
     }
@@ -497,6 +501,315 @@ __global__ __launch_bounds__(NT) void layer_chain_fwd_kernel(const ChainParams p
     STAMP_DUMP();
 }
 
+
+// ---- the LONG-batch form of the forward chain (round 5): 64 rows per workgroup ------------------------------------------------
+// Past 4 096 rows a 16-row workgroup re-streams the layer's 1.5 MB of weights once per 16 rows (S-BIG: 785 workgroups, 1.2 GB of
+// L2 -> L1 traffic per layer) and lost against the library's GEMMs (round 4: 9.53 -> 10.93 ms).  Here a workgroup owns 64 rows --
+// a B operand feeds FOUR MFMAs, 197 workgroups at S-BIG's 12 560 rows -- and the FFN is walked in chunks of 384 hidden columns
+// (24 column groups: two per wave) so that the 1 024-wide intermediate never exists in LDS as a whole:
+//     u_c = z W1[c]^T + b1[c];  h_c = gelu(u_c)   -> LDS (the A operand of the next product) and, 16 bytes per thread, global
+//     f  += h_c W2[:, c]^T                         split-K over the chunks, the partial sums stay in the wave's registers
+// LDS: the bf16 operand tile [64][C + 8] (a -> z -> out_a), the f32 residual tile [64][C + 4] (x -> x1 -> x2) and ONE chunk tile
+// [64][392] bf16 (u, then h in place -- GELU runs in the coalesced pass that copies the chunk to global): 147 KB at C = 256; the
+// next layer's qkv tile overlays the last two.  Rounding points, dropout hashes and what is
+// saved for the backward are those of the 16-row form; FFN-2's f32 sum is formed in three parts (rounded to bf16 at the same
+// point).  The backward of such a layer runs the separate launches (its 64-row form is the step that is left).
+// The 64-row form's product: out[64 x N] = A[64 x K] (LDS) x W^T (packed as for wg_gemm; slice (g0, s0) likewise).  A wave owns the
+// column groups wave, wave + NWV, ... as in wg_gemm, but multiplies TWO of them at once: an A fragment read from LDS
+// feeds NG MFMAs instead of one (with four row tiles per B fragment the one-group loop is a chain of LDS round trips at two
+// waves per SIMD: measured ~150 clocks per MFMA), the 4 x NG accumulators are independent, and the whole K loop is unrolled
+// with the B operands three chunks deep.  epi(g, acc, bias) as wg_gemm's, once per group; `bias` (bf16 [N], null: 0) is requested
+// in FRONT of the K loop -- a load inside the epilogue is a memory round trip per group with nothing beside it (measured: ~1 us each).
+template <int BM, int NG, int K, int LDA, int SF, int NWV, int G, typename EPI>
+__device__ __forceinline__ void wide_pass(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W, const uint16_t* __restrict__ bias,
+                                          EPI&& epi, const int g0, const int s0, const int i0) {
+    constexpr int MT = BM / 16, S = K / 32, CH = S % 2 == 0 ? 2 : (S % 3 == 0 ? 3 : 1), NCH = S / CH;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = lane & 15, q = lane >> 4;
+    const uint16_t* a0 = A + j * LDA + 8 * q;
+    f32x4 acc[NG][MT];
+#pragma unroll
+    for (int i = 0; i < NG; ++i)
+#pragma unroll
+        for (int t = 0; t < MT; ++t) acc[i][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    uint16_t bv[NG];
+#pragma unroll
+    for (int i = 0; i < NG; ++i) bv[i] = bias[16 * min(wave + (i0 + i) * NWV, G - 1) + j];        // (never null: callers without a bias pass zeros)
+    uint4 b0[CH][NG], b1[CH][NG], b2[CH][NG];
+    auto load = [&](uint4 (&bb)[CH][NG], const int c) {
+#pragma unroll
+        for (int i = 0; i < NG; ++i) {
+            const int g = g0 + min(wave + (i0 + i) * NWV, G - 1);         // (a wave without an i-th group multiplies the last one again)
+            const uint16_t* wp = W + ((int64_t)(g * SF + s0 + c * CH) * 64 + lane) * 8;
+#pragma unroll
+            for (int s = 0; s < CH; ++s) bb[s][i] = *reinterpret_cast<const uint4*>(wp + 512 * s);
+        }
+    };
+    auto compute = [&](const uint4 (&bb)[CH][NG], const int c) {
+#pragma unroll
+        for (int s = 0; s < CH; ++s) {
+            bf16x8 af[MT];
+#pragma unroll
+            for (int t = 0; t < MT; ++t) af[t] = *reinterpret_cast<const bf16x8*>(a0 + 16 * t * LDA + 32 * (c * CH + s));
+#pragma unroll
+            for (int i = 0; i < NG; ++i) {
+                const bf16x8 bf = __builtin_bit_cast(bf16x8, bb[s][i]);
+#pragma unroll
+                for (int t = 0; t < MT; ++t) acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[t], bf, acc[i][t], 0, 0, 0);
+            }
+        }
+    };
+    // (the scheduling barriers pin every chunk request in FRONT of the products of the chunk two ahead of it: left alone, the
+    //  scheduler sinks the loads to their uses -- the kernel sits at its register limit -- and a wave then has two KB in flight
+    //  instead of 3 x CH x NG: measured 19 bytes per clock and CU)
+    load(b0, 0);
+    if (NCH > 1) load(b1, 1);
+    STAMP_ONCE(6);
+#pragma unroll 1
+    for (int c = 0; c < NCH; c += 3) {
+        if (c + 2 < NCH) load(b2, c + 2);
+        __builtin_amdgcn_sched_barrier(0);
+        compute(b0, c);
+        if (c + 1 >= NCH) break;
+        __builtin_amdgcn_sched_barrier(0);
+        if (c + 3 < NCH) load(b0, c + 3);
+        __builtin_amdgcn_sched_barrier(0);
+        compute(b1, c + 1);
+        if (c + 2 >= NCH) break;
+        __builtin_amdgcn_sched_barrier(0);
+        if (c + 4 < NCH) load(b1, c + 4);
+        __builtin_amdgcn_sched_barrier(0);
+        compute(b2, c + 2);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    STAMP_ONCE(14);
+#pragma unroll
+    for (int i = 0; i < NG; ++i)
+        if (wave + (i0 + i) * NWV < G) epi(wave + (i0 + i) * NWV, acc[i], bf16_val(bv[i]));
+    STAMP_ONCE(15);
+}
+template <int BM, int N, int K, int LDA, int SF, int NWV, typename EPI>
+__device__ __forceinline__ void wg_gemm_wide(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W, const uint16_t* __restrict__ bias,
+                                             EPI&& epi, const int g0 = 0, const int s0 = 0) {
+    constexpr int G = N / 16, PER = (G + NWV - 1) / NWV;
+    static_assert(N % 16 == 0 && K % 32 == 0 && PER >= 1 && PER <= 6, "shape");
+    // passes of TWO groups (three at once -- 48 accumulators and 72 B registers beside FFN-2's 32 partial sums -- spilled those
+    // partial sums to scratch: measured 6 us for the second residual add alone)
+    wide_pass<BM, (PER >= 2 ? 2 : 1), K, LDA, SF, NWV, G>(A, W, bias, epi, g0, s0, 0);
+    if constexpr (PER > 2) wide_pass<BM, (PER >= 4 ? 2 : 1), K, LDA, SF, NWV, G>(A, W, bias, epi, g0, s0, 2);
+    if constexpr (PER > 4) wide_pass<BM, (PER >= 6 ? 2 : 1), K, LDA, SF, NWV, G>(A, W, bias, epi, g0, s0, 4);
+}
+
+constexpr int BIG_NW = 8;
+template <int C, int F>
+__global__ __launch_bounds__(BIG_NW * 64) void layer_chain_fwd_big_kernel(const ChainParams p) {
+    constexpr int NWB = BIG_NW, NTB = NWB * 64;              // 8 waves: 2 per SIMD, 256 VGPRs; 16 / 24 / 48 column groups deal evenly
+    constexpr int BM = 64, MT = 4, LDA = C + 8, LDX = C + 4, FC = 384, LDC = FC + 8, LDQ = 3 * C + 8;
+    static_assert(F > 2 * FC && F <= 3 * FC && (F - 2 * FC) % 32 == 0 && C % 64 == 0, "three FFN chunks");
+    static_assert(BM * LDQ * 2 <= BM * LDX * 4 + BM * LDC * 2, "the qkv tile overlays the residual tile and the chunk tile");
+    constexpr int FL = F - 2 * FC;                                               // the last chunk's width (256)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    uint16_t* ab = reinterpret_cast<uint16_t*>(smem_raw);                        // [BM][LDA] bf16: a -> z -> out_a
+    float* xb = reinterpret_cast<float*>(ab + BM * LDA);                         // [BM][LDX] f32: x -> x1 -> x2
+    uint16_t* hb = reinterpret_cast<uint16_t*>(xb + BM * LDX);                   // [BM][LDC] bf16: a chunk of u, then of h in place
+    uint16_t* qb = reinterpret_cast<uint16_t*>(xb);                              // [BM][LDQ] bf16: the next layer's qkv (over xb | hb)
+    const int r0 = blockIdx.x * BM;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = lane & 15, q = lane >> 4;
+    const uint64_t seed = p.thr ? p.seed + (p.seed_dev ? *p.seed_dev : 0ull) : 0ull;
+    STAMP_DECL;
+    STAMP(0);
+
+    // the dropout masks' row hashes (two full-width multiplies each: 16 clocks apiece), once per row and residual add instead of
+    // once per ELEMENT in the epilogues (64 rows x 16 columns per lane and group: measured 2.2 us per product)
+    __shared__ uint32_t s_rowh[2][BM];
+    if (threadIdx.x < 2 * BM)
+        s_rowh[threadIdx.x / BM][threadIdx.x % BM] =
+            dropout_row_hash(seed, (uint32_t)(r0 + (int)(threadIdx.x % BM)) ^ (threadIdx.x < BM ? p.salt1 : p.salt2));
+    LnW<C> ln1, ln2;
+    ln1.issue(p.n1w, p.n1b);
+    if (p.nxw) ln2.issue(p.nxw, p.nxb);
+    for (int e = threadIdx.x; e < BM * (C / 8); e += NTB) {
+        const int r = e / (C / 8), c = (e % (C / 8)) * 8;
+        *reinterpret_cast<uint4*>(ab + r * LDA + c) = *reinterpret_cast<const uint4*>(p.a + (int64_t)min(r0 + r, p.R - 1) * C + c);
+    }
+    for (int e = threadIdx.x; e < BM * (C / 4); e += NTB) {
+        const int r = e / (C / 4), c = (e % (C / 4)) * 4;
+        *reinterpret_cast<float4*>(xb + r * LDX + c) = *reinterpret_cast<const float4*>(p.x + (int64_t)min(r0 + r, p.R - 1) * C + c);
+    }
+    __syncthreads();
+    STAMP(1);
+
+    // the residual tile += dropout(bf16(acc + bias)) at this lane's 4 x MT positions of column group g
+    // (the tile's 16 values are READ first and written last: sixteen read-modify-writes of LDS addresses the compiler cannot tell
+    //  apart run one after the other -- measured 2.5 us per product)
+    auto residual_add = [&](const int g, const f32x4 (&acc)[MT], const float bias, const int which) {
+        const int col = 16 * g + j;
+        float xv[MT][4];
+#pragma unroll
+        for (int t = 0; t < MT; ++t)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) xv[t][v] = xb[(16 * t + 4 * q + v) * LDX + col];
+        if (p.thr) {
+#pragma unroll
+            for (int t = 0; t < MT; ++t)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const int r = 16 * t + 4 * q + v;
+                    const float y = bf16_round(acc[t][v] + bias);
+                    xv[t][v] += dropout_bits16(seed, s_rowh[which][r], (uint32_t)col) >= p.thr ? y * p.inv_keep : 0.f;
+                }
+        } else {
+#pragma unroll
+            for (int t = 0; t < MT; ++t)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) xv[t][v] += bf16_round(acc[t][v] + bias);
+        }
+#pragma unroll
+        for (int t = 0; t < MT; ++t)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) xb[(16 * t + 4 * q + v) * LDX + col] = xv[t][v];
+    };
+    // ---- y = a Wo^T + bo;  x1 = x + dropout(y)
+    {
+        wg_gemm_wide<BM, C, C, LDA, C / 32, NWB>(ab, p.wo, p.bo, [&](int g, const f32x4 (&acc)[MT], float bias) { residual_add(g, acc, bias, 0); });
+    }
+    __syncthreads();
+    STAMP(2);
+    // ---- z = ffn_norm1(x1)
+    ln_rows<BM, C, LDX, LDA, NWB>(xb, ab, ln1, p.x1, p.z, nullptr, p.mean1, p.rstd1, r0, p.R);
+    __syncthreads();
+    STAMP(3);
+
+    // ---- the FFN in chunks.  f's partial sums (split-K over the chunks) live in the residual tile: x1 has left for global with
+    //      the norm's pass and is read back for the second residual add (this workgroup wrote it; 64 x C f32 through the L2).
+    //      (In registers -- 32 per lane across the three chunks -- they were spilled to scratch: 6 us for that add alone.)
+    uint16_t b2v[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) b2v[i] = p.b2[16 * min(wave + NWB * i, C / 16 - 1) + j];
+    auto ffn_chunk = [&](auto nc_c, const int c0) {
+        constexpr int NC = decltype(nc_c)::value;
+        {
+            wg_gemm_wide<BM, NC, C, LDA, C / 32, NWB>(ab, p.w1, p.b1 + c0, [&](int g, const f32x4 (&acc)[MT], float bias) {
+                const int col = 16 * g + j;
+#pragma unroll
+                for (int t = 0; t < MT; ++t)
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) hb[(16 * t + 4 * q + v) * LDC + col] = bf16_bits(acc[t][v] + bias);
+            }, c0 / 16, 0);
+        }
+        __syncthreads();
+        if (c0 == 0) STAMP(4);
+        // u (rounded) -> global; h = gelu(u) -> global and, IN PLACE, the tile: 16 bytes per thread and step (GELU in this pass
+        // and not in the product's epilogue: the epilogue is instantiated once per weight buffer)
+        for (int e = threadIdx.x; e < BM * (NC / 8); e += NTB) {
+            const int r = e / (NC / 8), c = (e % (NC / 8)) * 8;
+            uint4* tp = reinterpret_cast<uint4*>(hb + r * LDC + c);
+            const uint4 uv = *tp;
+            const uint32_t w[4] = {uv.x, uv.y, uv.z, uv.w};
+            uint32_t hw[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const uint32_t lo = bf16_bits(gelu_f(__builtin_bit_cast(float, w[i] << 16)));
+                const uint32_t hi = bf16_bits(gelu_f(__builtin_bit_cast(float, w[i] & 0xffff0000u)));
+                hw[i] = lo | (hi << 16);
+            }
+            const uint4 hv = make_uint4(hw[0], hw[1], hw[2], hw[3]);
+            *tp = hv;
+            if (r0 + r < p.R) {
+                *reinterpret_cast<uint4*>(p.u + (int64_t)(r0 + r) * F + c0 + c) = uv;
+                *reinterpret_cast<uint4*>(p.h + (int64_t)(r0 + r) * F + c0 + c) = hv;
+            }
+        }
+        __syncthreads();
+        if (c0 == 0) STAMP(5);
+        {
+            wg_gemm_wide<BM, C, NC, LDC, F / 32, NWB>(hb, p.w2, p.b2 /* (ignored: added with x2) */, [&](int g, const f32x4 (&acc)[MT], float) {
+                const int col = 16 * g + j;
+                float fv[MT][4];
+#pragma unroll
+                for (int t = 0; t < MT; ++t)
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) fv[t][v] = c0 ? xb[(16 * t + 4 * q + v) * LDX + col] : 0.f;
+#pragma unroll
+                for (int t = 0; t < MT; ++t)
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) xb[(16 * t + 4 * q + v) * LDX + col] = fv[t][v] + acc[t][v];
+            }, 0, c0 / 32);
+        }
+        __syncthreads();                                 // (the chunk's h has been multiplied: its tile may be overwritten)
+    };
+    ffn_chunk(std::integral_constant<int, FC>{}, 0);
+    STAMP(7);
+    ffn_chunk(std::integral_constant<int, FC>{}, FC);
+    STAMP(8);
+    ffn_chunk(std::integral_constant<int, FL>{}, 2 * FC);
+    STAMP(9);
+    // ---- x2 = x1 + dropout(f + b2)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int g = wave + NWB * i;
+        if (g < C / 16) {
+            const int col = 16 * g + j;
+            const float bias = bf16_val(b2v[i]);
+            float x1v[MT][4], fv[MT][4];
+#pragma unroll
+            for (int t = 0; t < MT; ++t)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const int r = 16 * t + 4 * q + v;
+                    x1v[t][v] = p.x1[(int64_t)min(r0 + r, p.R - 1) * C + col];
+                    fv[t][v] = xb[r * LDX + col];
+                }
+#pragma unroll
+            for (int t = 0; t < MT; ++t)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const int r = 16 * t + 4 * q + v;
+                    float f = bf16_round(fv[t][v] + bias);
+                    if (p.thr) f = dropout_bits16(seed, s_rowh[1][r], (uint32_t)col) >= p.thr ? f * p.inv_keep : 0.f;
+                    xb[r * LDX + col] = x1v[t][v] + f;
+                }
+        }
+    }
+    __syncthreads();
+    STAMP(10);
+    if (!p.nxw) {
+        store_f32_rows<BM, C, LDX, NTB>(xb, p.x2, r0, p.R);
+        return;
+    }
+    ln_rows<BM, C, LDX, LDA, NWB>(xb, ab, ln2, p.x2, p.out_a, p.out, p.mean2, p.rstd2, r0, p.R);
+    if (!p.wq) return;
+    __syncthreads();
+    STAMP(11);
+    // ---- the next layer's qkv = out Wqkv^T + bqkv
+    {
+        wg_gemm_wide<BM, 3 * C, C, LDA, C / 32, NWB>(ab, p.wq, p.bq, [&](int g, const f32x4 (&acc)[MT], float bias) {
+            const int col = 16 * g + j;
+#pragma unroll
+            for (int t = 0; t < MT; ++t)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) qb[(16 * t + 4 * q + v) * LDQ + col] = bf16_bits(acc[t][v] + bias);
+        });
+    }
+    __syncthreads();
+    STAMP(12);
+    store_rows<BM, 3 * C, LDQ, NTB>(qb, p.qkv, r0, p.R);
+    STAMP(13);
+    STAMP_DUMP();
+}
+
+constexpr int64_t CHAIN_BIG_ROWS = 4096;         // rows past which the forward chain takes the 64-row form (the host packs for it: model.pack_layer_weights)
+template <int C, int F>
+int launch_big(const ChainParams& p, hipStream_t st) {
+    constexpr int BM = 64, LDA = C + 8, LDX = C + 4, LDC = 384 + 8;
+    constexpr size_t lds = BM * LDA * 2 + BM * LDX * 4 + BM * LDC * 2;
+    static_assert(lds <= 152 * 1024, "LDS plan");
+    int rc = (int)hipFuncSetAttribute((const void*)layer_chain_fwd_big_kernel<C, F>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (rc) return rc;
+    hipLaunchKernelGGL((layer_chain_fwd_big_kernel<C, F>), dim3((p.R + BM - 1) / BM), dim3(BIG_NW * 64), lds, st, p);
+    return (int)hipGetLastError();
+}
 
 // ---- the CLUSTER form of the two chain kernels (short batches) -------------------------------------------------------------
 // With 16 rows per workgroup a batch of R rows occupies ceil(R / 16) compute units -- 38 of 256 at S-FSQ's R ~ 600 -- and
@@ -1771,6 +2084,12 @@ extern "C" int mobgt_layer_chain_fwd(const void* a, const float* x, const void* 
     p.inv_keep = p.thr ? 1.f / (1.f - (float)p.thr / 65536.f) : 1.f;
     p.seed = seed; p.seed_dev = seed_dev; p.salt1 = salt1; p.salt2 = salt2;
     hipStream_t st = (hipStream_t)stream;
+    if (R > CHAIN_BIG_ROWS) {                // long batches: 64 rows per workgroup (layer_chain_fwd_big_kernel)
+        if (C == 128 && F == 1024) return launch_big<128, 1024>(p, st);
+        if (C == 192 && F == 1024) return launch_big<192, 1024>(p, st);
+        if (C == 256 && F == 1024) return launch_big<256, 1024>(p, st);
+        return MOBGT_EBADDIM;
+    }
     const int ncl = pick_ncl(R, ws);
     if (ncl > 1) {
         p.ws_gen = reinterpret_cast<uint32_t*>(ws);

@@ -192,6 +192,7 @@ _LN_GEMM = [_os_ln.environ.get("MOBGT_NO_LN_GEMM") != "1"]      # MOBGT_NO_LN_GE
 _LN_GEMM_BWD = [_os_ln.environ.get("MOBGT_LN_GEMM_BWD") == "1"]
 # csrc/chain.hip: out-proj -> LN -> FFN -> LN -> the next layer's QKV in one launch (MOBGT_NO_CHAIN=1: the separate launches)
 _CHAIN = [_os_ln.environ.get("MOBGT_NO_CHAIN") != "1"]
+_CHAIN_BIG = [_os_ln.environ.get("MOBGT_NO_CHAIN_BIG") != "1"]      # ... past 4 096 rows: the 64-row forward chain (else the library's GEMMs)
 _CHAIN_BWD = [_os_ln.environ.get("MOBGT_NO_CHAIN_BWD") != "1"]      # ... and the same chain backwards (d(out) -> d(attention out))
 
 
@@ -408,7 +409,9 @@ class _FusedLayerFn(torch.autograd.Function):
         a, lse = ops._attn_fwd(q, k, v, cfg.pack, cfg.scale, cfg.p_att, seed ^ (salt * 0x9E3779B1), sd)
         F = s_w1.shape[0]
         cfg.out_qkv = None
-        use_chain = (not stock and own and A == torch.bfloat16 and cfg.packed is not None
+        # (past 4 096 rows `own` is off -- the library's GEMMs take the layer's products -- but the forward chain has its 64-row
+        #  form there: csrc/chain.hip, layer_chain_fwd_big_kernel; the backward then runs the library's launches)
+        use_chain = (not stock and (own or (R > 4096 and _CHAIN_BIG[0])) and A == torch.bfloat16 and cfg.packed is not None
                      and _chain_ok(C, F, x, a, s_bo, s_b1, s_b2, n1w, n1b, nxw, nxb, *cfg.packed))
         # pre-LN chain (round 4): out-projection ... second residual add in one launch, + the NEXT layer's self_attention_norm
         # and QKV projection when the model named that layer (cfg.next_norm / next_qkv); the backward is the chain's too
@@ -421,8 +424,10 @@ class _FusedLayerFn(torch.autograd.Function):
         ctx.chained_in = chained_in
         if chained_in and not stock_chain:
             raise RuntimeError("mobgt fused layer (pre-LN): the layer below chained into this one, which cannot run its chain kernels")
-        ctx.fuse_ln = use_chain
-        ctx.chain_bwd = bool(use_chain and _CHAIN_BWD[0] and cfg.packed_t is not None
+        ctx.fuse_ln = use_chain and own
+        # (past 4 096 rows the forward chain is the 64-row kernel and the backward the separate launches: the 16-row backward
+        #  chain re-streams the weights once per 16 rows and loses against the library's GEMMs there)
+        ctx.chain_bwd = bool(use_chain and _CHAIN_BWD[0] and cfg.packed_t is not None and R <= 4096
                              and all(t.is_contiguous() and t.data_ptr() % 16 == 0 for t in cfg.packed_t))
         # the layer below produced this layer's qkv in ITS chain launch and will run chain_bwd: it can host what this layer's
         # backward leaves undone (see _PENDING_TAIL)

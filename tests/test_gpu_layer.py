@@ -550,6 +550,64 @@ def test_layer_chain_kernel_matches_the_separate_launches(C, G, T, p):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("C,G,T,p", [(256, 7, 640, 0.1), (192, 9, 500, 0.0), (256, 6, 785, 0.1)])
+def test_long_batch_forward_chain_matches_the_library_launches(C, G, T, p):
+    """csrc/chain.hip, layer_chain_fwd_big_kernel (round 5): past 4 096 rows the forward of a layer's row-local part is ONE launch
+    with 64 rows per workgroup (FFN in chunks of 384 hidden columns, split-K partial sums in registers), the backward the
+    separate launches.  Against MOBGT_NO_CHAIN_BIG=1 (library GEMMs + csrc/layer.hip glue) on a 3-layer fq stack: same
+    rounding points, same dropout masks -- outputs, input gradient and every parameter gradient to bf16 round-off.  The
+    last row block is ragged in all three cases (4 480 = 70 x 64; 4 500 and 4 710 are not multiples of 64)."""
+    from mobgt_amd import fused_layer
+    from mobgt_amd.model import refresh_shadows
+    from mobgt_amd.model_fqandtoyo import EncoderLayer as FqLayer
+    torch.manual_seed(6)
+    H = 8
+    layers = torch.nn.ModuleList([FqLayer(C, 1024, p, p, H) for _ in range(3)]).to(DEV)
+    for li, l in enumerate(layers):
+        l.act_dtype = torch.bfloat16
+        l.self_attention.set_layer_index(li + 1)
+        l.self_attention.seed_dev = torch.tensor([13], dtype=torch.int64, device=DEV)
+    layers.train()
+    x0 = torch.randn(G, T, C, device=DEV)
+    bias = torch.randn(G, H, T, T, device=DEV) * 0.3
+    gy = torch.randn(G, T, C, device=DEV)
+    res = {}
+    for mode in ("big", "off"):
+        fused_layer._CHAIN_BIG[0] = mode == "big"
+        try:
+            for q in layers.parameters():
+                q.grad = None
+            x = x0.clone().requires_grad_(True)
+            refresh_shadows(layers, rows=G * T)
+            y = x
+            rode = []
+            for li, l in enumerate(layers):
+                y = l(y, bias, next_layer=layers[li + 1] if li + 1 < len(layers) else None)
+                rode.append(getattr(y, "_mobgt_qkv", None) is not None)
+            assert rode == ([True, True, False] if mode == "big" else [False, False, False])
+            assert not y.grad_fn.chain_bwd
+            y.backward(gy)
+            torch.cuda.synchronize()
+            res[mode] = (y.detach().clone(), x.grad.clone(), {n: q.grad.clone() for n, q in layers.named_parameters() if q.grad is not None})
+        finally:
+            fused_layer._CHAIN_BIG[0] = True
+
+    def close(a, b, name):
+        scale = float(b.abs().max()) + 1e-12
+        err = float((a - b).abs().max())
+        assert err <= 2e-2 * scale, (name, err, scale)
+    ya, dxa, ga = res["big"]
+    yb, dxb, gb = res["off"]
+    close(ya, yb, "y")
+    close(dxa, dxb, "dx")
+    assert ga.keys() == gb.keys()
+    for n in ga:
+        if n.endswith("linear_k.bias"):
+            continue                                          # exactly zero in exact arithmetic: round-off only
+        close(ga[n], gb[n], n)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("R,K,N", [(608, 160, 160), (37, 192, 192), (16, 448, 224)])
 def test_linear_with_leaky_epilogue_matches_torch(R, K, N):
     """ops.linear_splitk(..., slope): FuseEmbeddings' Linear + LeakyReLU (model_fqandtoyo.py:452-455) with the activation in
