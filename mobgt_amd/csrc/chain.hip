@@ -515,28 +515,24 @@ __global__ __launch_bounds__(NT) void layer_chain_fwd_kernel(const ChainParams p
 // saved for the backward are those of the 16-row form; FFN-2's f32 sum is formed in three parts (rounded to bf16 at the same
 // point).  The backward of such a layer runs the separate launches (its 64-row form is the step that is left).
 // The 64-row form's product: out[64 x N] = A[64 x K] (LDS) x W^T (packed as for wg_gemm; slice (g0, s0) likewise).  A wave owns the
-// column groups wave, wave + NWV, ... as in wg_gemm, but multiplies TWO of them at once: an A fragment read from LDS
-// feeds NG MFMAs instead of one (with four row tiles per B fragment the one-group loop is a chain of LDS round trips at two
-// waves per SIMD: measured ~150 clocks per MFMA), the 4 x NG accumulators are independent, and the whole K loop is unrolled
-// with the B operands three chunks deep.  epi(g, acc, bias) as wg_gemm's, once per group; `bias` (bf16 [N], null: 0) is requested
-// in FRONT of the K loop -- a load inside the epilogue is a memory round trip per group with nothing beside it (measured: ~1 us each).
-template <int BM, int NG, int K, int LDA, int SF, int NWV, int G, typename EPI>
-__device__ __forceinline__ void wide_pass(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W, const uint16_t* __restrict__ bias,
-                                          EPI&& epi, const int g0, const int s0, const int i0) {
-    constexpr int MT = BM / 16, S = K / 32, CH = S % 2 == 0 ? 2 : (S % 3 == 0 ? 3 : 1), NCH = S / CH;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int j = lane & 15, q = lane >> 4;
-    const uint16_t* a0 = A + j * LDA + 8 * q;
-    f32x4 acc[NG][MT];
-#pragma unroll
-    for (int i = 0; i < NG; ++i)
-#pragma unroll
-        for (int t = 0; t < MT; ++t) acc[i][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+// column groups wave, wave + NWV, ... as in wg_gemm, but multiplies up to THREE of them at once: an A fragment read from LDS feeds
+// NG MFMAs instead of one (with four row tiles per B fragment the one-group loop is a chain of LDS round trips at two waves per
+// SIMD: measured ~150 clocks per MFMA) and the 4 x NG accumulators are independent.  The B operands run three chunks deep.
+// epi(g, acc, bias) as wg_gemm's, once per group; `bias` (bf16 [N]) is requested with the first chunks -- a load inside the
+// epilogue is a memory round trip per group with nothing beside it (measured: ~1 us each).
+// A pass is an object: issue() requests its bias values and first two weight chunks, run() multiplies, finish() runs the
+// epilogues.  The caller issues a product's FIRST pass ahead of whatever precedes the product (a barrier, a norm, the GELU
+// pass), and a product of several passes issues pass k + 1 between run(k) and finish(k): no product and no pass opens on an
+// idle memory round trip (measured ~1 us each, 13 of them per workgroup).
+template <int BM, int NG, int K, int LDA, int SF, int NWV, int G>
+struct WidePass {
+    static constexpr int MT = BM / 16, S = K / 32, CH = S % 2 == 0 ? 2 : (S % 3 == 0 ? 3 : 1), NCH = S / CH;
+    uint4 b0[CH][NG], b1[CH][NG];
     uint16_t bv[NG];
-#pragma unroll
-    for (int i = 0; i < NG; ++i) bv[i] = bias[16 * min(wave + (i0 + i) * NWV, G - 1) + j];        // (never null: callers without a bias pass zeros)
-    uint4 b0[CH][NG], b1[CH][NG], b2[CH][NG];
-    auto load = [&](uint4 (&bb)[CH][NG], const int c) {
+    f32x4 acc[NG][MT];
+    static __device__ __forceinline__ void load(const uint16_t* __restrict__ W, uint4 (&bb)[CH][NG], const int c, const int g0,
+                                                const int s0, const int i0) {
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
         for (int i = 0; i < NG; ++i) {
             const int g = g0 + min(wave + (i0 + i) * NWV, G - 1);         // (a wave without an i-th group multiplies the last one again)
@@ -544,61 +540,101 @@ __device__ __forceinline__ void wide_pass(const uint16_t* __restrict__ A, const 
 #pragma unroll
             for (int s = 0; s < CH; ++s) bb[s][i] = *reinterpret_cast<const uint4*>(wp + 512 * s);
         }
-    };
-    auto compute = [&](const uint4 (&bb)[CH][NG], const int c) {
-#pragma unroll
-        for (int s = 0; s < CH; ++s) {
-            bf16x8 af[MT];
-#pragma unroll
-            for (int t = 0; t < MT; ++t) af[t] = *reinterpret_cast<const bf16x8*>(a0 + 16 * t * LDA + 32 * (c * CH + s));
-#pragma unroll
-            for (int i = 0; i < NG; ++i) {
-                const bf16x8 bf = __builtin_bit_cast(bf16x8, bb[s][i]);
-#pragma unroll
-                for (int t = 0; t < MT; ++t) acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[t], bf, acc[i][t], 0, 0, 0);
-            }
-        }
-    };
-    // (the scheduling barriers pin every chunk request in FRONT of the products of the chunk two ahead of it: left alone, the
-    //  scheduler sinks the loads to their uses -- the kernel sits at its register limit -- and a wave then has two KB in flight
-    //  instead of 3 x CH x NG: measured 19 bytes per clock and CU)
-    load(b0, 0);
-    if (NCH > 1) load(b1, 1);
-    STAMP_ONCE(6);
-#pragma unroll 1
-    for (int c = 0; c < NCH; c += 3) {
-        if (c + 2 < NCH) load(b2, c + 2);
-        __builtin_amdgcn_sched_barrier(0);
-        compute(b0, c);
-        if (c + 1 >= NCH) break;
-        __builtin_amdgcn_sched_barrier(0);
-        if (c + 3 < NCH) load(b0, c + 3);
-        __builtin_amdgcn_sched_barrier(0);
-        compute(b1, c + 1);
-        if (c + 2 >= NCH) break;
-        __builtin_amdgcn_sched_barrier(0);
-        if (c + 4 < NCH) load(b1, c + 4);
-        __builtin_amdgcn_sched_barrier(0);
-        compute(b2, c + 2);
-        __builtin_amdgcn_sched_barrier(0);
     }
-    STAMP_ONCE(14);
+    __device__ __forceinline__ void issue(const uint16_t* __restrict__ W, const uint16_t* __restrict__ bias, const int g0, const int s0,
+                                          const int i0) {
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
-    for (int i = 0; i < NG; ++i)
-        if (wave + (i0 + i) * NWV < G) epi(wave + (i0 + i) * NWV, acc[i], bf16_val(bv[i]));
-    STAMP_ONCE(15);
-}
-template <int BM, int N, int K, int LDA, int SF, int NWV, typename EPI>
-__device__ __forceinline__ void wg_gemm_wide(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W, const uint16_t* __restrict__ bias,
-                                             EPI&& epi, const int g0 = 0, const int s0 = 0) {
-    constexpr int G = N / 16, PER = (G + NWV - 1) / NWV;
-    static_assert(N % 16 == 0 && K % 32 == 0 && PER >= 1 && PER <= 6, "shape");
-    // passes of TWO groups (three at once -- 48 accumulators and 72 B registers beside FFN-2's 32 partial sums -- spilled those
-    // partial sums to scratch: measured 6 us for the second residual add alone)
-    wide_pass<BM, (PER >= 2 ? 2 : 1), K, LDA, SF, NWV, G>(A, W, bias, epi, g0, s0, 0);
-    if constexpr (PER > 2) wide_pass<BM, (PER >= 4 ? 2 : 1), K, LDA, SF, NWV, G>(A, W, bias, epi, g0, s0, 2);
-    if constexpr (PER > 4) wide_pass<BM, (PER >= 6 ? 2 : 1), K, LDA, SF, NWV, G>(A, W, bias, epi, g0, s0, 4);
-}
+        for (int i = 0; i < NG; ++i) bv[i] = bias[16 * min(wave + (i0 + i) * NWV, G - 1) + (lane & 15)];
+        load(W, b0, 0, g0, s0, i0);
+        if (NCH > 1) load(W, b1, 1, g0, s0, i0);
+    }
+    __device__ __forceinline__ void run(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W, const int g0, const int s0,
+                                        const int i0) {
+        const int lane = threadIdx.x & 63;
+        const uint16_t* a0 = A + (lane & 15) * LDA + 8 * (lane >> 4);
+#pragma unroll
+        for (int i = 0; i < NG; ++i)
+#pragma unroll
+            for (int t = 0; t < MT; ++t) acc[i][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        uint4 b2[CH][NG];
+        auto compute = [&](const uint4 (&bb)[CH][NG], const int c) {
+#pragma unroll
+            for (int s = 0; s < CH; ++s) {
+                bf16x8 af[MT];
+#pragma unroll
+                for (int t = 0; t < MT; ++t) af[t] = *reinterpret_cast<const bf16x8*>(a0 + 16 * t * LDA + 32 * (c * CH + s));
+#pragma unroll
+                for (int i = 0; i < NG; ++i) {
+                    const bf16x8 bf = __builtin_bit_cast(bf16x8, bb[s][i]);
+#pragma unroll
+                    for (int t = 0; t < MT; ++t) acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[t], bf, acc[i][t], 0, 0, 0);
+                }
+            }
+        };
+        // (the scheduling barriers pin every chunk request in FRONT of the products of the chunk two ahead of it: left alone, the
+        //  scheduler sinks the loads to their uses -- the kernel sits at its register limit -- and a wave then has two KB in
+        //  flight instead of 3 x CH x NG: measured 19 bytes per clock and CU)
+#pragma unroll 1
+        for (int c = 0; c < NCH; c += 3) {
+            if (c + 2 < NCH) load(W, b2, c + 2, g0, s0, i0);
+            __builtin_amdgcn_sched_barrier(0);
+            compute(b0, c);
+            if (c + 1 >= NCH) break;
+            __builtin_amdgcn_sched_barrier(0);
+            if (c + 3 < NCH) load(W, b0, c + 3, g0, s0, i0);
+            __builtin_amdgcn_sched_barrier(0);
+            compute(b1, c + 1);
+            if (c + 2 >= NCH) break;
+            __builtin_amdgcn_sched_barrier(0);
+            if (c + 4 < NCH) load(W, b1, c + 4, g0, s0, i0);
+            __builtin_amdgcn_sched_barrier(0);
+            compute(b2, c + 2);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    template <typename EPI>
+    __device__ __forceinline__ void finish(EPI&& epi, const int i0) {
+        const int wave = threadIdx.x >> 6;
+#pragma unroll
+        for (int i = 0; i < NG; ++i)
+            if (wave + (i0 + i) * NWV < G) epi(wave + (i0 + i) * NWV, acc[i], bf16_val(bv[i]));
+    }
+};
+// a product: passes of up to WIDE_NG groups per wave (PER groups per wave in all)
+constexpr int WIDE_NG = 3;
+template <int BM, int N, int K, int LDA, int SF, int NWV>
+struct WideGemm {
+    static constexpr int G = N / 16, PER = (G + NWV - 1) / NWV;
+    static_assert(N % 16 == 0 && K % 32 == 0 && PER >= 1 && PER <= 3 * WIDE_NG, "shape");
+    static constexpr int N0 = PER < WIDE_NG ? PER : WIDE_NG, R1 = PER - N0, N1 = R1 < WIDE_NG ? R1 : WIDE_NG, N2 = R1 - N1;
+    WidePass<BM, N0, K, LDA, SF, NWV, G> p0;
+    __device__ __forceinline__ void issue(const uint16_t* __restrict__ W, const uint16_t* __restrict__ bias, const int g0 = 0, const int s0 = 0) {
+        p0.issue(W, bias, g0, s0, 0);
+    }
+    template <typename EPI>
+    __device__ __forceinline__ void run(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W, const uint16_t* __restrict__ bias,
+                                        EPI&& epi, const int g0 = 0, const int s0 = 0) {
+        p0.run(A, W, g0, s0, 0);
+        if constexpr (N1 > 0) {
+            WidePass<BM, N1, K, LDA, SF, NWV, G> p1;
+            p1.issue(W, bias, g0, s0, N0);
+            p0.finish(epi, 0);
+            p1.run(A, W, g0, s0, N0);
+            if constexpr (N2 > 0) {
+                WidePass<BM, N2, K, LDA, SF, NWV, G> p2;
+                p2.issue(W, bias, g0, s0, N0 + N1);
+                p1.finish(epi, N0);
+                p2.run(A, W, g0, s0, N0 + N1);
+                p2.finish(epi, N0 + N1);
+            } else {
+                p1.finish(epi, N0);
+            }
+        } else {
+            p0.finish(epi, 0);
+        }
+    }
+};
 
 constexpr int BIG_NW = 8;
 template <int C, int F>
@@ -626,13 +662,23 @@ __global__ __launch_bounds__(BIG_NW * 64) void layer_chain_fwd_big_kernel(const 
     if (threadIdx.x < 2 * BM)
         s_rowh[threadIdx.x / BM][threadIdx.x % BM] =
             dropout_row_hash(seed, (uint32_t)(r0 + (int)(threadIdx.x % BM)) ^ (threadIdx.x < BM ? p.salt1 : p.salt2));
-    LnW<C> ln1, ln2;
+    WideGemm<BM, C, C, LDA, C / 32, NWB> g_wo;
+    g_wo.issue(p.wo, p.bo);
+    // the norms: HALF a wave per row (ln_rows_hw, bit-identical to the wave-per-row form), 16 rows per pass and four passes whose
+    // reductions the compiler interleaves -- a wave per row walked 8 rows one after the other: 4.4 us per norm
+    LnWH<C> ln1;
     ln1.issue(p.n1w, p.n1b);
-    if (p.nxw) ln2.issue(p.nxw, p.nxb);
+    auto norm_rows = [&](const LnWH<C>& lw, float* g_pre, uint16_t* g_bf, float* g_f32, float* g_mean, float* g_rstd) {
+#pragma unroll
+        for (int it = 0; it < BM / 16; ++it)
+            ln_rows_hw<16, C, LDX, LDA>(xb + 16 * it * LDX, ab + 16 * it * LDA, lw, g_pre, g_bf, g_f32, g_mean, g_rstd, r0 + 16 * it, p.R, 1, 0);
+    };
+#pragma unroll
     for (int e = threadIdx.x; e < BM * (C / 8); e += NTB) {
         const int r = e / (C / 8), c = (e % (C / 8)) * 8;
         *reinterpret_cast<uint4*>(ab + r * LDA + c) = *reinterpret_cast<const uint4*>(p.a + (int64_t)min(r0 + r, p.R - 1) * C + c);
     }
+#pragma unroll
     for (int e = threadIdx.x; e < BM * (C / 4); e += NTB) {
         const int r = e / (C / 4), c = (e % (C / 4)) * 4;
         *reinterpret_cast<float4*>(xb + r * LDX + c) = *reinterpret_cast<const float4*>(p.x + (int64_t)min(r0 + r, p.R - 1) * C + c);
@@ -671,13 +717,13 @@ __global__ __launch_bounds__(BIG_NW * 64) void layer_chain_fwd_big_kernel(const 
             for (int v = 0; v < 4; ++v) xb[(16 * t + 4 * q + v) * LDX + col] = xv[t][v];
     };
     // ---- y = a Wo^T + bo;  x1 = x + dropout(y)
-    {
-        wg_gemm_wide<BM, C, C, LDA, C / 32, NWB>(ab, p.wo, p.bo, [&](int g, const f32x4 (&acc)[MT], float bias) { residual_add(g, acc, bias, 0); });
-    }
+    g_wo.run(ab, p.wo, p.bo, [&](int g, const f32x4 (&acc)[MT], float bias) { residual_add(g, acc, bias, 0); });
+    WideGemm<BM, FC, C, LDA, C / 32, NWB> g_w1a;
+    g_w1a.issue(p.w1, p.b1, 0, 0);                      // (ahead of the barrier and the norm)
     __syncthreads();
     STAMP(2);
     // ---- z = ffn_norm1(x1)
-    ln_rows<BM, C, LDX, LDA, NWB>(xb, ab, ln1, p.x1, p.z, nullptr, p.mean1, p.rstd1, r0, p.R);
+    norm_rows(ln1, p.x1, p.z, nullptr, p.mean1, p.rstd1);
     __syncthreads();
     STAMP(3);
 
@@ -687,21 +733,22 @@ __global__ __launch_bounds__(BIG_NW * 64) void layer_chain_fwd_big_kernel(const 
     uint16_t b2v[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) b2v[i] = p.b2[16 * min(wave + NWB * i, C / 16 - 1) + j];
-    auto ffn_chunk = [&](auto nc_c, const int c0) {
+    // one chunk: `g1` (issued by the caller) multiplies z by W1's rows c0 .., the GELU pass, then h_c by W2's columns c0 ..
+    auto ffn_chunk = [&](auto nc_c, const int c0, auto& g1) {
         constexpr int NC = decltype(nc_c)::value;
-        {
-            wg_gemm_wide<BM, NC, C, LDA, C / 32, NWB>(ab, p.w1, p.b1 + c0, [&](int g, const f32x4 (&acc)[MT], float bias) {
-                const int col = 16 * g + j;
+        g1.run(ab, p.w1, p.b1 + c0, [&](int g, const f32x4 (&acc)[MT], float bias) {
+            const int col = 16 * g + j;
 #pragma unroll
-                for (int t = 0; t < MT; ++t)
+            for (int t = 0; t < MT; ++t)
 #pragma unroll
-                    for (int v = 0; v < 4; ++v) hb[(16 * t + 4 * q + v) * LDC + col] = bf16_bits(acc[t][v] + bias);
-            }, c0 / 16, 0);
-        }
+                for (int v = 0; v < 4; ++v) hb[(16 * t + 4 * q + v) * LDC + col] = bf16_bits(acc[t][v] + bias);
+        }, c0 / 16, 0);
+        WideGemm<BM, C, NC, LDC, F / 32, NWB> g2;
+        g2.issue(p.w2, p.b2 /* (ignored: added with x2) */, 0, c0 / 32);
         __syncthreads();
         if (c0 == 0) STAMP(4);
         // u (rounded) -> global; h = gelu(u) -> global and, IN PLACE, the tile: 16 bytes per thread and step (GELU in this pass
-        // and not in the product's epilogue: the epilogue is instantiated once per weight buffer)
+        // and not in the product's epilogue: all waves meet the vector pipe once, on coalesced 16-byte pieces)
         for (int e = threadIdx.x; e < BM * (NC / 8); e += NTB) {
             const int r = e / (NC / 8), c = (e % (NC / 8)) * 8;
             uint4* tp = reinterpret_cast<uint4*>(hb + r * LDC + c);
@@ -723,27 +770,35 @@ __global__ __launch_bounds__(BIG_NW * 64) void layer_chain_fwd_big_kernel(const 
         }
         __syncthreads();
         if (c0 == 0) STAMP(5);
-        {
-            wg_gemm_wide<BM, C, NC, LDC, F / 32, NWB>(hb, p.w2, p.b2 /* (ignored: added with x2) */, [&](int g, const f32x4 (&acc)[MT], float) {
-                const int col = 16 * g + j;
-                float fv[MT][4];
+        g2.run(hb, p.w2, p.b2, [&](int g, const f32x4 (&acc)[MT], float) {
+            const int col = 16 * g + j;
+            float fv[MT][4];
 #pragma unroll
-                for (int t = 0; t < MT; ++t)
+            for (int t = 0; t < MT; ++t)
 #pragma unroll
-                    for (int v = 0; v < 4; ++v) fv[t][v] = c0 ? xb[(16 * t + 4 * q + v) * LDX + col] : 0.f;
+                for (int v = 0; v < 4; ++v) fv[t][v] = c0 ? xb[(16 * t + 4 * q + v) * LDX + col] : 0.f;
 #pragma unroll
-                for (int t = 0; t < MT; ++t)
+            for (int t = 0; t < MT; ++t)
 #pragma unroll
-                    for (int v = 0; v < 4; ++v) xb[(16 * t + 4 * q + v) * LDX + col] = fv[t][v] + acc[t][v];
-            }, 0, c0 / 32);
-        }
-        __syncthreads();                                 // (the chunk's h has been multiplied: its tile may be overwritten)
+                for (int v = 0; v < 4; ++v) xb[(16 * t + 4 * q + v) * LDX + col] = fv[t][v] + acc[t][v];
+        }, 0, c0 / 32);
     };
-    ffn_chunk(std::integral_constant<int, FC>{}, 0);
+    ffn_chunk(std::integral_constant<int, FC>{}, 0, g_w1a);
+    WideGemm<BM, FC, C, LDA, C / 32, NWB> g_w1b;
+    g_w1b.issue(p.w1, p.b1 + FC, FC / 16, 0);
+    __syncthreads();                                     // (the chunk's h has been multiplied: its tile may be overwritten)
     STAMP(7);
-    ffn_chunk(std::integral_constant<int, FC>{}, FC);
+    ffn_chunk(std::integral_constant<int, FC>{}, FC, g_w1b);
+    WideGemm<BM, FL, C, LDA, C / 32, NWB> g_w1c;
+    g_w1c.issue(p.w1, p.b1 + 2 * FC, 2 * FC / 16, 0);
+    __syncthreads();
     STAMP(8);
-    ffn_chunk(std::integral_constant<int, FL>{}, 2 * FC);
+    ffn_chunk(std::integral_constant<int, FL>{}, 2 * FC, g_w1c);
+    WideGemm<BM, 3 * C, C, LDA, C / 32, NWB> g_wq;
+    if (p.wq) g_wq.issue(p.wq, p.bq);                   // (ahead of the second residual add and norm)
+    LnWH<C> ln2;
+    if (p.nxw) ln2.issue(p.nxw, p.nxb);
+    __syncthreads();
     STAMP(9);
     // ---- x2 = x1 + dropout(f + b2)
 #pragma unroll
@@ -778,20 +833,18 @@ __global__ __launch_bounds__(BIG_NW * 64) void layer_chain_fwd_big_kernel(const 
         store_f32_rows<BM, C, LDX, NTB>(xb, p.x2, r0, p.R);
         return;
     }
-    ln_rows<BM, C, LDX, LDA, NWB>(xb, ab, ln2, p.x2, p.out_a, p.out, p.mean2, p.rstd2, r0, p.R);
+    norm_rows(ln2, p.x2, p.out_a, p.out, p.mean2, p.rstd2);
     if (!p.wq) return;
     __syncthreads();
     STAMP(11);
     // ---- the next layer's qkv = out Wqkv^T + bqkv
-    {
-        wg_gemm_wide<BM, 3 * C, C, LDA, C / 32, NWB>(ab, p.wq, p.bq, [&](int g, const f32x4 (&acc)[MT], float bias) {
-            const int col = 16 * g + j;
+    g_wq.run(ab, p.wq, p.bq, [&](int g, const f32x4 (&acc)[MT], float bias) {
+        const int col = 16 * g + j;
 #pragma unroll
-            for (int t = 0; t < MT; ++t)
+        for (int t = 0; t < MT; ++t)
 #pragma unroll
-                for (int v = 0; v < 4; ++v) qb[(16 * t + 4 * q + v) * LDQ + col] = bf16_bits(acc[t][v] + bias);
-        });
-    }
+            for (int v = 0; v < 4; ++v) qb[(16 * t + 4 * q + v) * LDQ + col] = bf16_bits(acc[t][v] + bias);
+    });
     __syncthreads();
     STAMP(12);
     store_rows<BM, 3 * C, LDQ, NTB>(qb, p.qkv, r0, p.R);
