@@ -2086,6 +2086,215 @@ int launch_bwd_cl(ChainBwdParams& p, hipStream_t st) {
     return (int)hipGetLastError();
 }
 
+// ---- the LONG-batch form of the backward chain (round 5): 64 rows per workgroup ------------------------------------------------
+// d(out) -> ffn_norm2' -> dropout' -> (W2, gelu') -> W1 -> ffn_norm1' + residual -> dropout' -> Wo for 64 rows (see
+// layer_chain_fwd_big_kernel: the 16-row form re-streams the weights once per 16 rows).  The FFN is walked in the forward's chunks
+// of 384 hidden columns:   du_c = (df W2[:, c]) gelu'(u_c)  -- u_c staged in the chunk tile, du_c written over it --  -> global
+// (the weight-gradient launches read it) and   dz += du_c W1[c, :]   split-K into the f32 tile.  dx2 leaves for global (in the
+// dx1 buffer) with the first norm's backward and is read back for the second.  LDS: dz f32 [64][C + 4], df / dy bf16
+// [64][C + 8], the chunk tile [64][392] (its first 24 KB double as the column-sum partials between the phases): 147 KB at
+// C = 256.  Eight waves (two per SIMD, 256 VGPRs).  No passengers and no hosted tail (the layer above finishes its own input
+// gradient past 4 096 rows); b1's gradient is the caller's column sum of du.  fq (post-LN) layers only.
+template <int C, int F>
+__global__ __launch_bounds__(BIG_NW * 64) void layer_chain_bwd_big_kernel(const ChainBwdParams p) {
+    constexpr int NWB = BIG_NW, NTB = NWB * 64;
+    constexpr int BM = 64, MT = 4, LDA = C + 8, LDX = C + 4, FC = 384, LDC = FC + 8, PER = C / 64, NR = BM / NWB;
+    static_assert(F > 2 * FC && F <= 3 * FC && (F - 2 * FC) % 32 == 0 && C % 64 == 0 && C <= LDC - 8, "three FFN chunks");
+    static_assert(3 * NWB * C * 4 <= BM * LDC * 2, "the column-sum partials fit the chunk tile");
+    constexpr int FL = F - 2 * FC;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float* dzb = reinterpret_cast<float*>(smem_raw);                             // [BM][LDX] f32: dz
+    uint16_t* gb = reinterpret_cast<uint16_t*>(dzb + BM * LDX);                  // [BM][LDA] bf16: df, then dy
+    uint16_t* tb = gb + BM * LDA;                                                // [BM][LDC] bf16: a chunk of u, then of du in place; da
+    float* red = reinterpret_cast<float*>(tb);                                   // [3][NWB][C] f32 column-sum partials (between the phases)
+    __shared__ uint32_t s_rowh[2][BM];
+    const int r0 = blockIdx.x * BM;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = lane & 15, q = lane >> 4;
+    const uint64_t seed = p.thr ? p.seed + (p.seed_dev ? *p.seed_dev : 0ull) : 0ull;
+    if (threadIdx.x < 2 * BM)
+        s_rowh[threadIdx.x / BM][threadIdx.x % BM] =
+            dropout_row_hash(seed, (uint32_t)(r0 + (int)(threadIdx.x % BM)) ^ (threadIdx.x < BM ? p.salt1 : p.salt2));
+    const uint16_t* nobias = p.u;                        // (a product without a bias: any readable bf16 vector of >= 384 entries)
+    WideGemm<BM, FC, C, LDA, C / 32, NWB> g_2a;
+    g_2a.issue(p.w2t, nobias, 0, 0);
+    __syncthreads();
+
+    // One norm backwards over the block's rows, a wave per row (rows wave, wave + 8, ...: everything a row needs is requested up
+    // front), exactly ln_bwd_rows' arithmetic:  t = rstd (g - mean(g) - xh mean(g xh)) [+ res],  y = dropout'(t)
+    //   d: the incoming gradient -- global f32 [R][C], or (null) the dz tile, rounded to bf16 as the separate launch's tensor was
+    //   res_g: added behind the norm (null: nothing);  dx_g <- t (f32);  gb, dy_g <- y (bf16);  column sums of d xh, d, y -> red
+    auto ln_bwd = [&](const float* __restrict__ d_g, const float* __restrict__ xpre, const float* __restrict__ g_mean,
+                      const float* __restrict__ g_rstd, const float* __restrict__ wp, const float* res_g, float* dx_g,
+                      uint16_t* __restrict__ dy_g, const int which) {
+        float w[PER], ag[PER], ab[PER], ay[PER];
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            w[k] = wp[lane + 64 * k];
+            ag[k] = ab[k] = ay[k] = 0.f;
+        }
+        float xr[NR][PER], dr[NR][PER], rr[NR][PER], mu[NR], rs[NR];
+#pragma unroll
+        for (int i = 0; i < NR; ++i) {
+            const int r = wave + NWB * i;
+            const int64_t row = min(r0 + r, p.R - 1);
+            mu[i] = g_mean[row];
+            rs[i] = g_rstd[row];
+#pragma unroll
+            for (int k = 0; k < PER; ++k) {
+                const int c = lane + 64 * k;
+                xr[i][k] = xpre[row * C + c];
+                dr[i][k] = d_g ? d_g[row * C + c] : bf16_round(dzb[r * LDX + c]);
+                rr[i][k] = res_g ? res_g[row * C + c] : 0.f;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NR; ++i) {
+            const int r = wave + NWB * i;
+            const int64_t row = min(r0 + r, p.R - 1);
+            const bool on = r0 + r < p.R;
+            float d[PER], xh[PER], gg[PER], s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int k = 0; k < PER; ++k) {
+                d[k] = on ? dr[i][k] : 0.f;
+                xh[k] = on ? (xr[i][k] - mu[i]) * rs[i] : 0.f;
+                gg[k] = d[k] * w[k];
+                ag[k] += d[k] * xh[k];
+                ab[k] += d[k];
+                s1 += gg[k];
+                s2 += gg[k] * xh[k];
+            }
+            s1 = wave64_sum(s1) * (1.f / C);
+            s2 = wave64_sum(s2) * (1.f / C);
+#pragma unroll
+            for (int k = 0; k < PER; ++k) {
+                const int c = lane + 64 * k;
+                float t = rs[i] * (gg[k] - s1 - xh[k] * s2) + rr[i][k];
+                if (!on) t = 0.f;
+                float yv = t;
+                if (p.thr) yv = dropout_bits16(seed, s_rowh[which][r], (uint32_t)c) >= p.thr ? t * p.inv_keep : 0.f;
+                ay[k] += yv;
+                const uint16_t yb = bf16_bits(yv);
+                gb[r * LDA + c] = yb;
+                if (on) {
+                    dx_g[row * C + c] = t;
+                    dy_g[row * C + c] = yb;
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const int c = lane + 64 * k;
+            red[(0 * NWB + wave) * C + c] = ag[k];
+            red[(1 * NWB + wave) * C + c] = ab[k];
+            red[(2 * NWB + wave) * C + c] = ay[k];
+        }
+    };
+    auto flush = [&](float* g0, float* g1, float* g2) {
+        for (int e = threadIdx.x; e < 3 * C; e += NTB) {
+            const int which = e / C, c = e % C;
+            float s = 0.f;
+#pragma unroll
+            for (int w = 0; w < NWB; ++w) s += red[(which * NWB + w) * C + c];
+            float* dst = which == 0 ? g0 : (which == 1 ? g1 : g2);
+            if (dst) atomicAdd(dst + c, s);
+        }
+    };
+    // ---- dx2 = ffn_norm2'(dout) -> global (in the dx1 buffer);  df = dropout'(dx2)
+    ln_bwd(p.dout, p.x2, p.mean2, p.rstd2, p.nxw, nullptr, p.dx1, p.df, 1);
+    __syncthreads();
+    flush(p.dnxw, p.dnxb, p.db2);
+    __syncthreads();
+    // ---- the FFN backwards, in chunks
+    auto stage_u = [&](auto nc_c, const int c0) {
+        constexpr int NC = decltype(nc_c)::value;
+        for (int e = threadIdx.x; e < BM * (NC / 8); e += NTB) {
+            const int r = e / (NC / 8), c = (e % (NC / 8)) * 8;
+            *reinterpret_cast<uint4*>(tb + r * LDC + c) = *reinterpret_cast<const uint4*>(p.u + (int64_t)min(r0 + r, p.R - 1) * F + c0 + c);
+        }
+    };
+    auto chunk = [&](auto nc_c, const int c0, auto& g2) {
+        constexpr int NC = decltype(nc_c)::value;
+        // du_c = (df W2[:, c]) gelu'(u_c), in place over u_c
+        g2.run(gb, p.w2t, nobias, [&](int g, const f32x4 (&acc)[MT], float) {
+            const int col = 16 * g + j;
+            float uv[MT][4];
+#pragma unroll
+            for (int t = 0; t < MT; ++t)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) uv[t][v] = bf16_val(tb[(16 * t + 4 * q + v) * LDC + col]);
+#pragma unroll
+            for (int t = 0; t < MT; ++t)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) tb[(16 * t + 4 * q + v) * LDC + col] = bf16_bits(acc[t][v] * gelu_grad_f(uv[t][v]));
+        }, c0 / 16, 0);
+        WideGemm<BM, C, NC, LDC, F / 32, NWB> g1;
+        g1.issue(p.w1t, nobias, 0, c0 / 32);
+        __syncthreads();
+        for (int e = threadIdx.x; e < BM * (NC / 8); e += NTB) {
+            const int r = e / (NC / 8), c = (e % (NC / 8)) * 8;
+            if (r0 + r < p.R) *reinterpret_cast<uint4*>(p.du + (int64_t)(r0 + r) * F + c0 + c) = *reinterpret_cast<const uint4*>(tb + r * LDC + c);
+        }
+        // dz (+)= du_c W1[c, :]
+        g1.run(tb, p.w1t, nobias, [&](int g, const f32x4 (&acc)[MT], float) {
+            const int col = 16 * g + j;
+            float fv[MT][4];
+#pragma unroll
+            for (int t = 0; t < MT; ++t)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) fv[t][v] = c0 ? dzb[(16 * t + 4 * q + v) * LDX + col] : 0.f;
+#pragma unroll
+            for (int t = 0; t < MT; ++t)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) dzb[(16 * t + 4 * q + v) * LDX + col] = fv[t][v] + acc[t][v];
+        }, 0, c0 / 32);
+    };
+    stage_u(std::integral_constant<int, FC>{}, 0);
+    __syncthreads();
+    chunk(std::integral_constant<int, FC>{}, 0, g_2a);
+    WideGemm<BM, FC, C, LDA, C / 32, NWB> g_2b;
+    g_2b.issue(p.w2t, nobias, FC / 16, 0);
+    __syncthreads();                                     // (the chunk's du has been multiplied and stored: its tile may be overwritten)
+    stage_u(std::integral_constant<int, FC>{}, FC);
+    __syncthreads();
+    chunk(std::integral_constant<int, FC>{}, FC, g_2b);
+    WideGemm<BM, FL, C, LDA, C / 32, NWB> g_2c;
+    g_2c.issue(p.w2t, nobias, 2 * FC / 16, 0);
+    __syncthreads();
+    stage_u(std::integral_constant<int, FL>{}, 2 * FC);
+    __syncthreads();
+    chunk(std::integral_constant<int, FL>{}, 2 * FC, g_2c);
+    WideGemm<BM, C, C, LDA, C / 32, NWB> g_o;
+    g_o.issue(p.wot, nobias);
+    __syncthreads();
+    // ---- dx1 = dx2 + ffn_norm1'(dz);  dy = dropout'(dx1)
+    ln_bwd(nullptr, p.x1, p.mean1, p.rstd1, p.n1w, p.dx1, p.dx1, p.dy, 0);
+    __syncthreads();
+    flush(p.dn1w, p.dn1b, p.dbo);
+    __syncthreads();
+    // ---- da = dy Wo
+    g_o.run(gb, p.wot, nobias, [&](int g, const f32x4 (&acc)[MT], float) {
+        const int col = 16 * g + j;
+#pragma unroll
+        for (int t = 0; t < MT; ++t)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) tb[(16 * t + 4 * q + v) * LDC + col] = bf16_bits(acc[t][v]);
+    });
+    __syncthreads();
+    store_rows<BM, C, LDC, NTB>(tb, p.da, r0, p.R);
+}
+
+template <int C, int F>
+int launch_bwd_big(const ChainBwdParams& p, hipStream_t st) {
+    constexpr int BM = 64, LDA = C + 8, LDX = C + 4, LDC = 384 + 8;
+    constexpr size_t lds = BM * LDX * 4 + BM * LDA * 2 + BM * LDC * 2;
+    static_assert(lds <= 152 * 1024, "LDS plan");
+    int rc = (int)hipFuncSetAttribute((const void*)layer_chain_bwd_big_kernel<C, F>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (rc) return rc;
+    hipLaunchKernelGGL((layer_chain_bwd_big_kernel<C, F>), dim3((p.R + BM - 1) / BM), dim3(BIG_NW * 64), lds, st, p);
+    return (int)hipGetLastError();
+}
+
 template <int BM, int C, int F>
 int launch_bwd(const ChainBwdParams& p, hipStream_t st) {
     constexpr size_t lds = 2 * BM * (C + 4) * 4 + 3 * NW * C * 4 + BM * (C + 8) * 2 + 2 * BM * (F + 8) * 2;
@@ -2186,6 +2395,13 @@ static int chain_bwd_impl(int pre_ln, const float* dout, const float* x2, const 
     p.seed = seed; p.seed_dev = seed_dev; p.salt1 = salt1; p.salt2 = salt2;
     p.t_dqkv = (cu)tail_dqkv; p.t_wqt = (cu)tail_wqkv_t;
     p.pre_ln = pre_ln ? 1 : 0;
+    if (R > CHAIN_BIG_ROWS) {                // long batches: 64 rows per workgroup; no guests (see layer_chain_bwd_big_kernel)
+        if (pre_ln || tail_dqkv || n_wg || !nxw) return MOBGT_EBADDIM;
+        if (C == 128 && F == 1024) return launch_bwd_big<128, 1024>(p, (hipStream_t)stream);
+        if (C == 192 && F == 1024) return launch_bwd_big<192, 1024>(p, (hipStream_t)stream);
+        if (C == 256 && F == 1024) return launch_bwd_big<256, 1024>(p, (hipStream_t)stream);
+        return MOBGT_EBADDIM;
+    }
     p.n_chain = (int)((R + 15) / 16);
     p.n_wg = n_wg;
     int total = 0;

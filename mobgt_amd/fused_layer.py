@@ -425,13 +425,12 @@ class _FusedLayerFn(torch.autograd.Function):
         if chained_in and not stock_chain:
             raise RuntimeError("mobgt fused layer (pre-LN): the layer below chained into this one, which cannot run its chain kernels")
         ctx.fuse_ln = use_chain and own
-        # (past 4 096 rows the forward chain is the 64-row kernel and the backward the separate launches: the 16-row backward
-        #  chain re-streams the weights once per 16 rows and loses against the library's GEMMs there)
-        ctx.chain_bwd = bool(use_chain and _CHAIN_BWD[0] and cfg.packed_t is not None and R <= 4096
+        # (past 4 096 rows both chains are the 64-row kernels of csrc/chain.hip; they take no guests: see below_hosts)
+        ctx.chain_bwd = bool(use_chain and _CHAIN_BWD[0] and cfg.packed_t is not None and (R <= 4096 or _CHAIN_BIG[0])
                              and all(t.is_contiguous() and t.data_ptr() % 16 == 0 for t in cfg.packed_t))
         # the layer below produced this layer's qkv in ITS chain launch and will run chain_bwd: it can host what this layer's
         # backward leaves undone (see _PENDING_TAIL)
-        ctx.below_hosts = bool(cfg.from_layer and qkv_pre is not None and ctx.chain_bwd and len(cfg.packed_t) > 3)
+        ctx.below_hosts = bool(cfg.from_layer and qkv_pre is not None and ctx.chain_bwd and len(cfg.packed_t) > 3 and R <= 4096)
         if use_chain:               # everything row-local of the layer (+ the next layer's QKV projection) in one launch
             bf = dict(dtype=A, device=dev)
             x1, x2, out = torch.empty(R, C, **f32), torch.empty(R, C, **f32), torch.empty(R, C, **f32)
@@ -614,7 +613,9 @@ class _FusedLayerFn(torch.autograd.Function):
         if _PENDING_TAIL or _PENDING_CB[0] is not None:
             _drop_stale_pending()
         pend = _PENDING_TAIL.pop(_pending_key(dout), None) if _PENDING_TAIL else None
-        chain_b = getattr(ctx, "chain_bwd", False) and db1_in_wgrad and not stock
+        # (the 64-row backward chain, R > 4096: b1's gradient is a column sum of du behind it -- the weight gradients are the
+        #  library's there)
+        chain_b = getattr(ctx, "chain_bwd", False) and (db1_in_wgrad or R > 4096) and not stock
         host = pend is not None and chain_b and pend["R"] == R
         if pend is not None and not host:
             _complete_pending(pend)                                   # this layer cannot host it: finish it right here
@@ -647,7 +648,9 @@ class _FusedLayerFn(torch.autograd.Function):
                                                    (salt + 2) & 0xFFFFFFFF, *extra, _p(chain_workspace(dev, C, R)), _stream()), "mobgt_layer_chain_bwd")
             da = da.view(G, T, C)
             dw2 = wb.add(df, h, sink=k_w2)
-            dw1 = wb.add(du, z, db=db1, sink=k_w1)
+            if not db1_in_wgrad:
+                check(_lib.lib().mobgt_colsum(_p(du), _p(db1), R, F, act, _stream()), "mobgt_colsum")
+            dw1 = wb.add(du, z, db=db1 if db1_in_wgrad else None, sink=k_w1)
             dwo = wb.add(dy, a.view(R, C), sink=k_wo)
         else:
             da, dx1, dw2, dw1, dwo = _FusedLayerFn._bwd_launches(ctx, cfg, wb, dout, x1, z, u, h, x2, a, stats, s_wo, s_w1, s_w2,

@@ -361,12 +361,12 @@ def pack_layer_weights(layers, defer=False, rows=None):
         return
     want_t = torch.is_grad_enabled() and fused_layer._CHAIN_BWD[0]
     # `rows`: the batch's token rows, when the caller knows them.  Past 4 096 rows the FORWARD runs the 64-row chain kernel
-    # (csrc/chain.hip: layer_chain_fwd_big_kernel, round 5) and the backward the library's GEMMs: the forward packs only.
+    # (csrc/chain.hip: layer_chain_fwd_big_kernel / layer_chain_bwd_big_kernel, round 5): the same packs as below them.
     # MOBGT_NO_CHAIN_BIG=1: the library's GEMMs forward as well -- nothing reads a pack then but the token-assembly launch, which
     # multiplies by the FIRST layer's QKV weight.
     big = rows is not None and rows > 4096
     qkv0_only = big and not fused_layer._CHAIN_BIG[0]
-    if big:
+    if big and not fused_layer._CHAIN_BIG[0]:
         want_t = False
     jobs = []
     for li, layer in enumerate(layers):
@@ -394,7 +394,7 @@ def pack_layer_weights(layers, defer=False, rows=None):
         # pending backward pass may have saved them.  Shadows a trainer's optimizer kernel rewrites every step carry no version.
         ver = None if getattr(layer, "_shadow_external", False) else getattr(layer, "_shadow_ver", None)
         have = getattr(layer, "_packed_ver", None)
-        what = "qkv" if qkv0_only else ("fwd" if big else "all")
+        what = "qkv" if qkv0_only else "all"
         reuse = ver is not None and have is not None and have[0] == ver and have[1] == what and (have[2] or not want_t_l)
         if qkv0_only:
             if li == 0:
