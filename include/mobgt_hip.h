@@ -576,7 +576,9 @@ int mobgt_small_gemm_f32_act(const float* a, int64_t lda, const float* a_mask, f
  * a [R,C] bf16; x [R,C] f32; weights bf16 [out,in] PACKED by mobgt_pack_mfma_b; biases bf16; LayerNorm weights f32.
  * Written: x1, x2, out f32 [R,C]; z, out_a (= bf16(out)) [R,C], u, h [R,F], qkv_next [R,3C] bf16; mean / rstd [R] f32 of
  * both norms.  wq_next / bq_next / qkv_next null for the last layer.  Dropout masks: those of mobgt_dropout_add_ln_fwd
- * with salt1 / salt2.  (C, F) in {(128, 1024), (192, 1024), (256, 1024)}.  ws: see mobgt_chain_ws_bytes (may be null). */
+ * with salt1 / salt2.  (C, F) in {(128, 1024), (192, 1024), (256, 1024)}.  ws: see mobgt_chain_ws_bytes (may be null).
+ * R <= 4096: 16-row blocks on clusters of workgroups (one workgroup per block without ws); R > 4096: 64-row workgroups
+ * (layer_chain_fwd_big_kernel), same results up to the f32 summation order of h w2^T (three parts). */
 /* bf16 weight [N,K] row-major -> MFMA operand order (chain.hip): the 16 bytes W[16g + j][32s + 8q .. +7] go to byte offset
  * ((g K/32 + s) 64 + j + 16q) * 16, so that a wave's B-operand load is one contiguous KB.  n <= 96 jobs in one launch;
  * N % 16 == 0, K % 32 == 0.  transposed[i] != 0: src is [K,N] row-major and its TRANSPOSE is packed (the operand of
@@ -598,7 +600,9 @@ int mobgt_layer_chain_fwd(const void* a, const float* x, const void* wo, const v
  * What the layer ABOVE may leave to this launch (all optional): tail_dqkv [R,3C] bf16 + tail_wqkv_t (its Wqkv^T, packed): `dout`
  * then holds only that layer's dx1 and dout + dqkv Wqkv is formed here, per row block; wg_*: n_wg <= 4 weight-gradient
  * problems dW [M,N] += g^T x (+ db [M] += column sums of g) over the same R rows, bf16 operands as mobgt_linear_wgrad, run
- * by extra workgroups of this launch on the compute units its 16-row blocks leave idle. */
+ * by extra workgroups of this launch on the compute units its 16-row blocks leave idle.
+ * R > 4096: the 64-row form (layer_chain_bwd_big_kernel) -- post-LN layers only, WITHOUT guests: tail_dqkv / tail_wqkv_t null
+ * and n_wg == 0, else MOBGT_EBADDIM; b1's gradient is then the caller's mobgt_colsum of du. */
 int mobgt_layer_chain_bwd(const float* dout, const float* x2, const float* x1, const void* u, const float* mean1,
                           const float* rstd1, const float* mean2, const float* rstd2, const float* n1w, const float* nxw,
                           const void* w2t, const void* w1t, const void* wot, void* df, void* du, void* dy, void* da, float* dx1,
