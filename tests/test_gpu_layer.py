@@ -550,13 +550,13 @@ def test_layer_chain_kernel_matches_the_separate_launches(C, G, T, p):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("C,G,T,p", [(256, 7, 640, 0.1), (192, 9, 500, 0.0), (256, 6, 785, 0.1)])
+@pytest.mark.parametrize("C,G,T,p", [(256, 7, 640, 0.1), (192, 9, 500, 0.0), (256, 6, 785, 0.1), (128, 11, 401, 0.1)])
 def test_long_batch_forward_chain_matches_the_library_launches(C, G, T, p):
     """csrc/chain.hip, layer_chain_fwd_big_kernel / layer_chain_bwd_big_kernel (round 5): past 4 096 rows a layer's row-local part
     is ONE launch each way with 64 rows per workgroup (FFN in chunks of 384 hidden columns, split-K partial sums in the f32
     tile).  Against MOBGT_NO_CHAIN_BIG=1 (library GEMMs + csrc/layer.hip glue) on a 3-layer fq stack: same
     rounding points, same dropout masks -- outputs, input gradient and every parameter gradient to bf16 round-off.  The
-    last row block is ragged in all three cases (4 480 = 70 x 64; 4 500 and 4 710 are not multiples of 64)."""
+    last row block is full in the first case (4 480 = 70 x 64) and ragged in the others (4 500, 4 710, 4 411 rows)."""
     from mobgt_amd import fused_layer
     from mobgt_amd.model import refresh_shadows
     from mobgt_amd.model_fqandtoyo import EncoderLayer as FqLayer
