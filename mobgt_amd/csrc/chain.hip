@@ -664,14 +664,37 @@ __global__ __launch_bounds__(BIG_NW * 64) void layer_chain_fwd_big_kernel(const 
             dropout_row_hash(seed, (uint32_t)(r0 + (int)(threadIdx.x % BM)) ^ (threadIdx.x < BM ? p.salt1 : p.salt2));
     WideGemm<BM, C, C, LDA, C / 32, NWB> g_wo;
     g_wo.issue(p.wo, p.bo);
-    // the norms: HALF a wave per row (ln_rows_hw, bit-identical to the wave-per-row form), 16 rows per pass and four passes whose
-    // reductions the compiler interleaves -- a wave per row walked 8 rows one after the other: 4.4 us per norm
-    LnWH<C> ln1;
-    ln1.issue(p.n1w, p.n1b);
-    auto norm_rows = [&](const LnWH<C>& lw, float* g_pre, uint16_t* g_bf, float* g_f32, float* g_mean, float* g_rstd) {
+    // The norms: a wave per row, FOUR consecutive columns per lane -- the row's global copies (x1 / x2 f32, z / out_a bf16, out
+    // f32) leave as 16- and 8-byte pieces, three store instructions per row.  (The 16-row kernels' layout -- column lane + 64 k --
+    // costs 4- and 2-byte stores: 96 store instructions per wave and norm, and the load / store unit takes 16 clocks per
+    // instruction whatever its width: 4.4 us per norm.)  Two-pass mean / variance as there; the sums run in another order.
+    constexpr int LPR = C / 4;                           // lanes that hold columns
+    const bool lact = lane < LPR;
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 n1w4 = lact ? *reinterpret_cast<const float4*>(p.n1w + 4 * lane) : z4;
+    const float4 n1b4 = lact ? *reinterpret_cast<const float4*>(p.n1b + 4 * lane) : z4;
+    auto norm_rows = [&](const float4 w4, const float4 b4, float* __restrict__ g_pre, uint16_t* __restrict__ g_bf,
+                         float* __restrict__ g_f32, float* __restrict__ g_mean, float* __restrict__ g_rstd) {
 #pragma unroll
-        for (int it = 0; it < BM / 16; ++it)
-            ln_rows_hw<16, C, LDX, LDA>(xb + 16 * it * LDX, ab + 16 * it * LDA, lw, g_pre, g_bf, g_f32, g_mean, g_rstd, r0 + 16 * it, p.R, 1, 0);
+        for (int i = 0; i < BM / NWB; ++i) {
+            const int r = wave + NWB * i;
+            const int64_t row = r0 + r;
+            const float4 v = lact ? *reinterpret_cast<const float4*>(xb + r * LDX + 4 * lane) : z4;
+            const float mu = wave64_sum((v.x + v.y) + (v.z + v.w)) * (1.f / C);
+            const float4 d = lact ? make_float4(v.x - mu, v.y - mu, v.z - mu, v.w - mu) : z4;
+            const float rs = rsqrtf(wave64_sum((d.x * d.x + d.y * d.y) + (d.z * d.z + d.w * d.w)) * (1.f / C) + 1e-5f);
+            const float4 o = make_float4(d.x * rs * w4.x + b4.x, d.y * rs * w4.y + b4.y, d.z * rs * w4.z + b4.z, d.w * rs * w4.w + b4.w);
+            const uint2 ob = make_uint2(bf16_bits(o.x) | ((uint32_t)bf16_bits(o.y) << 16), bf16_bits(o.z) | ((uint32_t)bf16_bits(o.w) << 16));
+            if (lact) {
+                *reinterpret_cast<uint2*>(ab + r * LDA + 4 * lane) = ob;
+                if (row < p.R) {
+                    if (g_pre) *reinterpret_cast<float4*>(g_pre + row * C + 4 * lane) = v;
+                    *reinterpret_cast<uint2*>(g_bf + row * C + 4 * lane) = ob;
+                    if (g_f32) *reinterpret_cast<float4*>(g_f32 + row * C + 4 * lane) = o;
+                }
+            }
+            if (lane == 0 && row < p.R) { g_mean[row] = mu; g_rstd[row] = rs; }
+        }
     };
 #pragma unroll
     for (int e = threadIdx.x; e < BM * (C / 8); e += NTB) {
@@ -723,7 +746,7 @@ __global__ __launch_bounds__(BIG_NW * 64) void layer_chain_fwd_big_kernel(const 
     __syncthreads();
     STAMP(2);
     // ---- z = ffn_norm1(x1)
-    norm_rows(ln1, p.x1, p.z, nullptr, p.mean1, p.rstd1);
+    norm_rows(n1w4, n1b4, p.x1, p.z, nullptr, p.mean1, p.rstd1);
     __syncthreads();
     STAMP(3);
 
@@ -796,8 +819,8 @@ __global__ __launch_bounds__(BIG_NW * 64) void layer_chain_fwd_big_kernel(const 
     ffn_chunk(std::integral_constant<int, FL>{}, 2 * FC, g_w1c);
     WideGemm<BM, 3 * C, C, LDA, C / 32, NWB> g_wq;
     if (p.wq) g_wq.issue(p.wq, p.bq);                   // (ahead of the second residual add and norm)
-    LnWH<C> ln2;
-    if (p.nxw) ln2.issue(p.nxw, p.nxb);
+    const float4 nxw4 = (p.nxw && lact) ? *reinterpret_cast<const float4*>(p.nxw + 4 * lane) : z4;
+    const float4 nxb4 = (p.nxw && lact) ? *reinterpret_cast<const float4*>(p.nxb + 4 * lane) : z4;
     __syncthreads();
     STAMP(9);
     // ---- x2 = x1 + dropout(f + b2)
@@ -833,7 +856,7 @@ __global__ __launch_bounds__(BIG_NW * 64) void layer_chain_fwd_big_kernel(const 
         store_f32_rows<BM, C, LDX, NTB>(xb, p.x2, r0, p.R);
         return;
     }
-    norm_rows(ln2, p.x2, p.out_a, p.out, p.mean2, p.rstd2);
+    norm_rows(nxw4, nxb4, p.x2, p.out_a, p.out, p.mean2, p.rstd2);
     if (!p.wq) return;
     __syncthreads();
     STAMP(11);
@@ -2098,7 +2121,7 @@ int launch_bwd_cl(ChainBwdParams& p, hipStream_t st) {
 template <int C, int F>
 __global__ __launch_bounds__(BIG_NW * 64) void layer_chain_bwd_big_kernel(const ChainBwdParams p) {
     constexpr int NWB = BIG_NW, NTB = NWB * 64;
-    constexpr int BM = 64, MT = 4, LDA = C + 8, LDX = C + 4, FC = 384, LDC = FC + 8, PER = C / 64, NR = BM / NWB;
+    constexpr int BM = 64, MT = 4, LDA = C + 8, LDX = C + 4, FC = 384, LDC = FC + 8, NR = BM / NWB;
     static_assert(F > 2 * FC && F <= 3 * FC && (F - 2 * FC) % 32 == 0 && C % 64 == 0 && C <= LDC - 8, "three FFN chunks");
     static_assert(3 * NWB * C * 4 <= BM * LDC * 2, "the column-sum partials fit the chunk tile");
     constexpr int FL = F - 2 * FC;
@@ -2112,6 +2135,8 @@ __global__ __launch_bounds__(BIG_NW * 64) void layer_chain_bwd_big_kernel(const 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int j = lane & 15, q = lane >> 4;
     const uint64_t seed = p.thr ? p.seed + (p.seed_dev ? *p.seed_dev : 0ull) : 0ull;
+    STAMP_DECL;
+    STAMP(0);
     if (threadIdx.x < 2 * BM)
         s_rowh[threadIdx.x / BM][threadIdx.x % BM] =
             dropout_row_hash(seed, (uint32_t)(r0 + (int)(threadIdx.x % BM)) ^ (threadIdx.x < BM ? p.salt1 : p.salt2));
@@ -2121,44 +2146,47 @@ __global__ __launch_bounds__(BIG_NW * 64) void layer_chain_bwd_big_kernel(const 
     __syncthreads();
 
     // One norm backwards over the block's rows, a wave per row (rows wave, wave + 8, ...: everything a row needs is requested up
-    // front), exactly ln_bwd_rows' arithmetic:  t = rstd (g - mean(g) - xh mean(g xh)) [+ res],  y = dropout'(t)
-    //   d: the incoming gradient -- global f32 [R][C], or (null) the dz tile, rounded to bf16 as the separate launch's tensor was
+    // front) and FOUR consecutive columns per lane (16- / 8-byte pieces: see the forward kernel's norms), ln_bwd_rows' arithmetic:
+    //     t = rstd (g - mean(g) - xh mean(g xh)) [+ res],  y = dropout'(t)
+    //   d: the incoming gradient -- global f32 [R][C], or (from_tile) the dz tile, rounded to bf16 as the separate launch's tensor was
     //   res_g: added behind the norm (null: nothing);  dx_g <- t (f32);  gb, dy_g <- y (bf16);  column sums of d xh, d, y -> red
-    auto ln_bwd = [&](const float* __restrict__ d_g, const float* __restrict__ xpre, const float* __restrict__ g_mean,
+    constexpr int LPR = C / 4;
+    const bool lact = lane < LPR;
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto ln_bwd = [&](auto from_tile, const float* __restrict__ d_g, const float* __restrict__ xpre, const float* __restrict__ g_mean,
                       const float* __restrict__ g_rstd, const float* __restrict__ wp, const float* res_g, float* dx_g,
                       uint16_t* __restrict__ dy_g, const int which) {
-        float w[PER], ag[PER], ab[PER], ay[PER];
-#pragma unroll
-        for (int k = 0; k < PER; ++k) {
-            w[k] = wp[lane + 64 * k];
-            ag[k] = ab[k] = ay[k] = 0.f;
-        }
-        float xr[NR][PER], dr[NR][PER], rr[NR][PER], mu[NR], rs[NR];
+        const float4 w4 = lact ? *reinterpret_cast<const float4*>(wp + 4 * lane) : z4;
+        float ag[4] = {0.f, 0.f, 0.f, 0.f}, ab[4] = {0.f, 0.f, 0.f, 0.f}, ay[4] = {0.f, 0.f, 0.f, 0.f};
+        float4 xr[NR], dr[NR], rr[NR];
+        float mu[NR], rs[NR];
 #pragma unroll
         for (int i = 0; i < NR; ++i) {
             const int r = wave + NWB * i;
             const int64_t row = min(r0 + r, p.R - 1);
             mu[i] = g_mean[row];
             rs[i] = g_rstd[row];
-#pragma unroll
-            for (int k = 0; k < PER; ++k) {
-                const int c = lane + 64 * k;
-                xr[i][k] = xpre[row * C + c];
-                dr[i][k] = d_g ? d_g[row * C + c] : bf16_round(dzb[r * LDX + c]);
-                rr[i][k] = res_g ? res_g[row * C + c] : 0.f;
+            xr[i] = lact ? *reinterpret_cast<const float4*>(xpre + row * C + 4 * lane) : z4;
+            if constexpr (!decltype(from_tile)::value) dr[i] = lact ? *reinterpret_cast<const float4*>(d_g + row * C + 4 * lane) : z4;
+            else {
+                const float4 t = lact ? *reinterpret_cast<const float4*>(dzb + r * LDX + 4 * lane) : z4;
+                dr[i] = make_float4(bf16_round(t.x), bf16_round(t.y), bf16_round(t.z), bf16_round(t.w));
             }
+            rr[i] = (res_g && lact) ? *reinterpret_cast<const float4*>(res_g + row * C + 4 * lane) : z4;
         }
 #pragma unroll
         for (int i = 0; i < NR; ++i) {
             const int r = wave + NWB * i;
             const int64_t row = min(r0 + r, p.R - 1);
-            const bool on = r0 + r < p.R;
-            float d[PER], xh[PER], gg[PER], s1 = 0.f, s2 = 0.f;
+            const bool on = r0 + r < p.R && lact;
+            const float dv[4] = {dr[i].x, dr[i].y, dr[i].z, dr[i].w}, xv[4] = {xr[i].x, xr[i].y, xr[i].z, xr[i].w};
+            const float wv[4] = {w4.x, w4.y, w4.z, w4.w}, rv[4] = {rr[i].x, rr[i].y, rr[i].z, rr[i].w};
+            float d[4], xh[4], gg[4], s1 = 0.f, s2 = 0.f;
 #pragma unroll
-            for (int k = 0; k < PER; ++k) {
-                d[k] = on ? dr[i][k] : 0.f;
-                xh[k] = on ? (xr[i][k] - mu[i]) * rs[i] : 0.f;
-                gg[k] = d[k] * w[k];
+            for (int k = 0; k < 4; ++k) {
+                d[k] = on ? dv[k] : 0.f;
+                xh[k] = on ? (xv[k] - mu[i]) * rs[i] : 0.f;
+                gg[k] = d[k] * wv[k];
                 ag[k] += d[k] * xh[k];
                 ab[k] += d[k];
                 s1 += gg[k];
@@ -2166,28 +2194,32 @@ __global__ __launch_bounds__(BIG_NW * 64) void layer_chain_bwd_big_kernel(const 
             }
             s1 = wave64_sum(s1) * (1.f / C);
             s2 = wave64_sum(s2) * (1.f / C);
+            float t[4], yv[4];
+            uint32_t hw[2] = {0u, 0u};
+            if (p.thr) {                                   // (columns 2 m and 2 m + 1 share a hash word: dropout_bits16)
+                hw[0] = dropout_bits16(seed, s_rowh[which][r], (uint32_t)(4 * lane)) | (dropout_bits16(seed, s_rowh[which][r], (uint32_t)(4 * lane + 1)) << 16);
+                hw[1] = dropout_bits16(seed, s_rowh[which][r], (uint32_t)(4 * lane + 2)) | (dropout_bits16(seed, s_rowh[which][r], (uint32_t)(4 * lane + 3)) << 16);
+            }
 #pragma unroll
-            for (int k = 0; k < PER; ++k) {
-                const int c = lane + 64 * k;
-                float t = rs[i] * (gg[k] - s1 - xh[k] * s2) + rr[i][k];
-                if (!on) t = 0.f;
-                float yv = t;
-                if (p.thr) yv = dropout_bits16(seed, s_rowh[which][r], (uint32_t)c) >= p.thr ? t * p.inv_keep : 0.f;
-                ay[k] += yv;
-                const uint16_t yb = bf16_bits(yv);
-                gb[r * LDA + c] = yb;
+            for (int k = 0; k < 4; ++k) {
+                t[k] = on ? rs[i] * (gg[k] - s1 - xh[k] * s2) + rv[k] : 0.f;
+                yv[k] = t[k];
+                if (p.thr) yv[k] = ((hw[k >> 1] >> (16 * (k & 1))) & 0xffffu) >= p.thr ? t[k] * p.inv_keep : 0.f;
+                ay[k] += yv[k];
+            }
+            const uint2 yb = make_uint2(bf16_bits(yv[0]) | ((uint32_t)bf16_bits(yv[1]) << 16), bf16_bits(yv[2]) | ((uint32_t)bf16_bits(yv[3]) << 16));
+            if (lact) {
+                *reinterpret_cast<uint2*>(gb + r * LDA + 4 * lane) = yb;
                 if (on) {
-                    dx_g[row * C + c] = t;
-                    dy_g[row * C + c] = yb;
+                    *reinterpret_cast<float4*>(dx_g + row * C + 4 * lane) = make_float4(t[0], t[1], t[2], t[3]);
+                    *reinterpret_cast<uint2*>(dy_g + row * C + 4 * lane) = yb;
                 }
             }
         }
-#pragma unroll
-        for (int k = 0; k < PER; ++k) {
-            const int c = lane + 64 * k;
-            red[(0 * NWB + wave) * C + c] = ag[k];
-            red[(1 * NWB + wave) * C + c] = ab[k];
-            red[(2 * NWB + wave) * C + c] = ay[k];
+        if (lact) {
+            *reinterpret_cast<float4*>(red + (0 * NWB + wave) * C + 4 * lane) = make_float4(ag[0], ag[1], ag[2], ag[3]);
+            *reinterpret_cast<float4*>(red + (1 * NWB + wave) * C + 4 * lane) = make_float4(ab[0], ab[1], ab[2], ab[3]);
+            *reinterpret_cast<float4*>(red + (2 * NWB + wave) * C + 4 * lane) = make_float4(ay[0], ay[1], ay[2], ay[3]);
         }
     };
     auto flush = [&](float* g0, float* g1, float* g2) {
@@ -2201,13 +2233,16 @@ __global__ __launch_bounds__(BIG_NW * 64) void layer_chain_bwd_big_kernel(const 
         }
     };
     // ---- dx2 = ffn_norm2'(dout) -> global (in the dx1 buffer);  df = dropout'(dx2)
-    ln_bwd(p.dout, p.x2, p.mean2, p.rstd2, p.nxw, nullptr, p.dx1, p.df, 1);
+    ln_bwd(std::false_type{}, p.dout, p.x2, p.mean2, p.rstd2, p.nxw, nullptr, p.dx1, p.df, 1);
     __syncthreads();
+    STAMP(1);
     flush(p.dnxw, p.dnxb, p.db2);
     __syncthreads();
+    STAMP(2);
     // ---- the FFN backwards, in chunks
     auto stage_u = [&](auto nc_c, const int c0) {
         constexpr int NC = decltype(nc_c)::value;
+#pragma unroll
         for (int e = threadIdx.x; e < BM * (NC / 8); e += NTB) {
             const int r = e / (NC / 8), c = (e % (NC / 8)) * 8;
             *reinterpret_cast<uint4*>(tb + r * LDC + c) = *reinterpret_cast<const uint4*>(p.u + (int64_t)min(r0 + r, p.R - 1) * F + c0 + c);
@@ -2231,6 +2266,7 @@ __global__ __launch_bounds__(BIG_NW * 64) void layer_chain_bwd_big_kernel(const 
         WideGemm<BM, C, NC, LDC, F / 32, NWB> g1;
         g1.issue(p.w1t, nobias, 0, c0 / 32);
         __syncthreads();
+        if (c0 == 0) STAMP(4);
         for (int e = threadIdx.x; e < BM * (NC / 8); e += NTB) {
             const int r = e / (NC / 8), c = (e % (NC / 8)) * 8;
             if (r0 + r < p.R) *reinterpret_cast<uint4*>(p.du + (int64_t)(r0 + r) * F + c0 + c) = *reinterpret_cast<const uint4*>(tb + r * LDC + c);
@@ -2251,27 +2287,33 @@ __global__ __launch_bounds__(BIG_NW * 64) void layer_chain_bwd_big_kernel(const 
     };
     stage_u(std::integral_constant<int, FC>{}, 0);
     __syncthreads();
+    STAMP(3);
     chunk(std::integral_constant<int, FC>{}, 0, g_2a);
     WideGemm<BM, FC, C, LDA, C / 32, NWB> g_2b;
     g_2b.issue(p.w2t, nobias, FC / 16, 0);
     __syncthreads();                                     // (the chunk's du has been multiplied and stored: its tile may be overwritten)
+    STAMP(5);
     stage_u(std::integral_constant<int, FC>{}, FC);
     __syncthreads();
     chunk(std::integral_constant<int, FC>{}, FC, g_2b);
     WideGemm<BM, FL, C, LDA, C / 32, NWB> g_2c;
     g_2c.issue(p.w2t, nobias, 2 * FC / 16, 0);
     __syncthreads();
+    STAMP(6);
     stage_u(std::integral_constant<int, FL>{}, 2 * FC);
     __syncthreads();
     chunk(std::integral_constant<int, FL>{}, 2 * FC, g_2c);
     WideGemm<BM, C, C, LDA, C / 32, NWB> g_o;
     g_o.issue(p.wot, nobias);
     __syncthreads();
+    STAMP(7);
     // ---- dx1 = dx2 + ffn_norm1'(dz);  dy = dropout'(dx1)
-    ln_bwd(nullptr, p.x1, p.mean1, p.rstd1, p.n1w, p.dx1, p.dx1, p.dy, 0);
+    ln_bwd(std::true_type{}, nullptr, p.x1, p.mean1, p.rstd1, p.n1w, p.dx1, p.dx1, p.dy, 0);
     __syncthreads();
+    STAMP(8);
     flush(p.dn1w, p.dn1b, p.dbo);
     __syncthreads();
+    STAMP(9);
     // ---- da = dy Wo
     g_o.run(gb, p.wot, nobias, [&](int g, const f32x4 (&acc)[MT], float) {
         const int col = 16 * g + j;
@@ -2281,7 +2323,10 @@ __global__ __launch_bounds__(BIG_NW * 64) void layer_chain_bwd_big_kernel(const 
             for (int v = 0; v < 4; ++v) tb[(16 * t + 4 * q + v) * LDC + col] = bf16_bits(acc[t][v]);
     });
     __syncthreads();
+    STAMP(10);
     store_rows<BM, C, LDC, NTB>(tb, p.da, r0, p.R);
+    STAMP(11);
+    STAMP_DUMP();
 }
 
 template <int C, int F>
