@@ -664,37 +664,14 @@ __global__ __launch_bounds__(BIG_NW * 64) void layer_chain_fwd_big_kernel(const 
             dropout_row_hash(seed, (uint32_t)(r0 + (int)(threadIdx.x % BM)) ^ (threadIdx.x < BM ? p.salt1 : p.salt2));
     WideGemm<BM, C, C, LDA, C / 32, NWB> g_wo;
     g_wo.issue(p.wo, p.bo);
-    // The norms: a wave per row, FOUR consecutive columns per lane -- the row's global copies (x1 / x2 f32, z / out_a bf16, out
-    // f32) leave as 16- and 8-byte pieces, three store instructions per row.  (The 16-row kernels' layout -- column lane + 64 k --
-    // costs 4- and 2-byte stores: 96 store instructions per wave and norm, and the load / store unit takes 16 clocks per
-    // instruction whatever its width: 4.4 us per norm.)  Two-pass mean / variance as there; the sums run in another order.
-    constexpr int LPR = C / 4;                           // lanes that hold columns
-    const bool lact = lane < LPR;
-    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    const float4 n1w4 = lact ? *reinterpret_cast<const float4*>(p.n1w + 4 * lane) : z4;
-    const float4 n1b4 = lact ? *reinterpret_cast<const float4*>(p.n1b + 4 * lane) : z4;
-    auto norm_rows = [&](const float4 w4, const float4 b4, float* __restrict__ g_pre, uint16_t* __restrict__ g_bf,
-                         float* __restrict__ g_f32, float* __restrict__ g_mean, float* __restrict__ g_rstd) {
+    // the norms: HALF a wave per row (ln_rows_hw, bit-identical to the wave-per-row form), 16 rows per pass and four passes whose
+    // reductions the compiler interleaves -- a wave per row walked 8 rows one after the other: 4.4 us per norm
+    LnWH<C> ln1;
+    ln1.issue(p.n1w, p.n1b);
+    auto norm_rows = [&](const LnWH<C>& lw, float* g_pre, uint16_t* g_bf, float* g_f32, float* g_mean, float* g_rstd) {
 #pragma unroll
-        for (int i = 0; i < BM / NWB; ++i) {
-            const int r = wave + NWB * i;
-            const int64_t row = r0 + r;
-            const float4 v = lact ? *reinterpret_cast<const float4*>(xb + r * LDX + 4 * lane) : z4;
-            const float mu = wave64_sum((v.x + v.y) + (v.z + v.w)) * (1.f / C);
-            const float4 d = lact ? make_float4(v.x - mu, v.y - mu, v.z - mu, v.w - mu) : z4;
-            const float rs = rsqrtf(wave64_sum((d.x * d.x + d.y * d.y) + (d.z * d.z + d.w * d.w)) * (1.f / C) + 1e-5f);
-            const float4 o = make_float4(d.x * rs * w4.x + b4.x, d.y * rs * w4.y + b4.y, d.z * rs * w4.z + b4.z, d.w * rs * w4.w + b4.w);
-            const uint2 ob = make_uint2(bf16_bits(o.x) | ((uint32_t)bf16_bits(o.y) << 16), bf16_bits(o.z) | ((uint32_t)bf16_bits(o.w) << 16));
-            if (lact) {
-                *reinterpret_cast<uint2*>(ab + r * LDA + 4 * lane) = ob;
-                if (row < p.R) {
-                    if (g_pre) *reinterpret_cast<float4*>(g_pre + row * C + 4 * lane) = v;
-                    *reinterpret_cast<uint2*>(g_bf + row * C + 4 * lane) = ob;
-                    if (g_f32) *reinterpret_cast<float4*>(g_f32 + row * C + 4 * lane) = o;
-                }
-            }
-            if (lane == 0 && row < p.R) { g_mean[row] = mu; g_rstd[row] = rs; }
-        }
+        for (int it = 0; it < BM / 16; ++it)
+            ln_rows_hw<16, C, LDX, LDA>(xb + 16 * it * LDX, ab + 16 * it * LDA, lw, g_pre, g_bf, g_f32, g_mean, g_rstd, r0 + 16 * it, p.R, 1, 0);
     };
 #pragma unroll
     for (int e = threadIdx.x; e < BM * (C / 8); e += NTB) {
@@ -746,7 +723,7 @@ __global__ __launch_bounds__(BIG_NW * 64) void layer_chain_fwd_big_kernel(const 
     __syncthreads();
     STAMP(2);
     // ---- z = ffn_norm1(x1)
-    norm_rows(n1w4, n1b4, p.x1, p.z, nullptr, p.mean1, p.rstd1);
+    norm_rows(ln1, p.x1, p.z, nullptr, p.mean1, p.rstd1);
     __syncthreads();
     STAMP(3);
 
@@ -819,8 +796,8 @@ __global__ __launch_bounds__(BIG_NW * 64) void layer_chain_fwd_big_kernel(const 
     ffn_chunk(std::integral_constant<int, FL>{}, 2 * FC, g_w1c);
     WideGemm<BM, 3 * C, C, LDA, C / 32, NWB> g_wq;
     if (p.wq) g_wq.issue(p.wq, p.bq);                   // (ahead of the second residual add and norm)
-    const float4 nxw4 = (p.nxw && lact) ? *reinterpret_cast<const float4*>(p.nxw + 4 * lane) : z4;
-    const float4 nxb4 = (p.nxw && lact) ? *reinterpret_cast<const float4*>(p.nxb + 4 * lane) : z4;
+    LnWH<C> ln2;
+    if (p.nxw) ln2.issue(p.nxw, p.nxb);
     __syncthreads();
     STAMP(9);
     // ---- x2 = x1 + dropout(f + b2)
@@ -856,7 +833,7 @@ __global__ __launch_bounds__(BIG_NW * 64) void layer_chain_fwd_big_kernel(const 
         store_f32_rows<BM, C, LDX, NTB>(xb, p.x2, r0, p.R);
         return;
     }
-    norm_rows(nxw4, nxb4, p.x2, p.out_a, p.out, p.mean2, p.rstd2);
+    norm_rows(ln2, p.x2, p.out_a, p.out, p.mean2, p.rstd2);
     if (!p.wq) return;
     __syncthreads();
     STAMP(11);
