@@ -12,10 +12,11 @@ import csv, glob, collections
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob("gpurun_out/sq_*/**/r_counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        if "attn" in r["Kernel_Name"]:
-            k = "fwd" if "attn_fwd" in r["Kernel_Name"] else ("dq" if "bwd_dq" in r["Kernel_Name"] else "dkv")
+        n = r["Kernel_Name"]
+        if "attn_fwd" in n or "attn_bwd" in n:           # (not attn_dq_finish_kernel: it would halve the one-pass kernel's averages)
+            k = "fwd" if "attn_fwd" in n else ("one" if "bwd_one" in n else ("dq" if "bwd_dq" in n else "dkv"))
             acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
-for k in ("fwd", "dq", "dkv"):
+for k in ("fwd", "one", "dq", "dkv"):
     print(k, {c: round(sum(v[1:]) / max(len(v) - 1, 1) / 1e6, 3) for c, v in sorted(acc[k].items())})
 PY
 rm -rf gpurun_out/sq_*
