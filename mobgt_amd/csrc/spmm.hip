@@ -62,6 +62,54 @@ __global__ __launch_bounds__(256) void spmm_kernel(const SpmmParams p) {
     }
 }
 
+// The same product for narrow feature rows (C = 64 / 128: LPR = C / 4 = 16 / 32 lanes cover a row): the wave's 64 / LPR lane
+// groups gather DIFFERENT neighbours at once and the groups' sums meet in a shuffle at the end.  With one neighbour per load
+// instruction three quarters (C = 64) of every instruction's lanes were idle, and the load unit takes its 16 clocks per wave
+// instruction whatever it carries: 3 M instructions per product at P = 100 000 -- col, val and the row, per edge -- were the
+// kernel's time (round 5: 124 us per product).  Here col / val / row are one instruction each per 64 / LPR edges.
+template <int LPR>
+__global__ __launch_bounds__(256) void spmm_narrow_kernel(const SpmmParams p) {
+    constexpr int NGR = 64 / LPR;
+    const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= p.R) return;
+    const int lane = threadIdx.x & 63, grp = lane / LPR, c = (lane % LPR) * 4;
+    const int64_t r = p.rows ? p.rows[i] : i;
+    const int64_t e0 = p.rowptr[r], e1 = p.rowptr[r + 1];
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    int64_t e = e0 + grp;
+    for (; e + 3 * NGR < e1; e += 4 * NGR) {             // four edges per group in flight
+        float4 v[4];
+        float w[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            w[u] = p.val[e + u * NGR];
+            v[u] = *reinterpret_cast<const float4*>(p.B + (int64_t)p.col[e + u * NGR] * p.ldb + c);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            acc.x = fmaf(w[u], v[u].x, acc.x); acc.y = fmaf(w[u], v[u].y, acc.y);
+            acc.z = fmaf(w[u], v[u].z, acc.z); acc.w = fmaf(w[u], v[u].w, acc.w);
+        }
+    }
+    for (; e < e1; e += NGR) {
+        const float w = p.val[e];
+        const float4 v = *reinterpret_cast<const float4*>(p.B + (int64_t)p.col[e] * p.ldb + c);
+        acc.x = fmaf(w, v.x, acc.x); acc.y = fmaf(w, v.y, acc.y); acc.z = fmaf(w, v.z, acc.z); acc.w = fmaf(w, v.w, acc.w);
+    }
+#pragma unroll
+    for (int o = LPR; o < 64; o <<= 1) {
+        acc.x += __shfl_xor(acc.x, o, 64); acc.y += __shfl_xor(acc.y, o, 64);
+        acc.z += __shfl_xor(acc.z, o, 64); acc.w += __shfl_xor(acc.w, o, 64);
+    }
+    if (grp == 0) {
+        if (p.bias) {
+            const float4 b = *reinterpret_cast<const float4*>(p.bias + c);
+            acc.x += b.x; acc.y += b.y; acc.z += b.z; acc.w += b.w;
+        }
+        *reinterpret_cast<float4*>(p.out + i * p.ldo + c) = acc;
+    }
+}
+
 __global__ __launch_bounds__(256) void spmm_t_rows_kernel(const SpmmParams p) {
     const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (i >= p.R) return;
@@ -169,7 +217,10 @@ extern "C" int mobgt_spmm_csr(const int64_t* rowptr, const int32_t* col, const f
     SpmmParams p = {};
     p.rowptr = rowptr; p.col = col; p.val = val; p.rows = rows; p.B = b; p.bias = bias; p.out = out;
     p.R = R; p.ldb = ldb; p.ldo = ld_out; p.C = C;
-    hipLaunchKernelGGL(spmm_kernel, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, (hipStream_t)stream, p);
+    const dim3 grid((unsigned)((R + 3) / 4)), block(256);
+    if (C == 64) hipLaunchKernelGGL(spmm_narrow_kernel<16>, grid, block, 0, (hipStream_t)stream, p);
+    else if (C == 128) hipLaunchKernelGGL(spmm_narrow_kernel<32>, grid, block, 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL(spmm_kernel, grid, block, 0, (hipStream_t)stream, p);
     return (int)hipGetLastError();
 }
 
