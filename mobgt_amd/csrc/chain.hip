@@ -1580,6 +1580,7 @@ struct ChainBwdParams {
     uint16_t *df, *du, *dy, *da;             // bf16 [R,C] [R,F] [R,C] [R,C]
     float* dx1;                              // [R,C] f32
     float *dnxw, *dnxb, *db2, *dn1w, *dn1b, *dbo;     // [C] f32, accumulated
+    float* db1;                              // [F] f32, accumulated: the 64-row form only (null: the caller sums du's columns)
     int R;
     uint32_t thr;
     float inv_keep;
@@ -2235,10 +2236,20 @@ __global__ __launch_bounds__(BIG_NW * 64) void layer_chain_bwd_big_kernel(const 
             for (int t = 0; t < MT; ++t)
 #pragma unroll
                 for (int v = 0; v < 4; ++v) uv[t][v] = bf16_val(tb[(16 * t + 4 * q + v) * LDC + col]);
+            float cs = 0.f;                              // b1's gradient: the column sum of the ROUNDED du (rows >= R: df is zero there)
 #pragma unroll
             for (int t = 0; t < MT; ++t)
 #pragma unroll
-                for (int v = 0; v < 4; ++v) tb[(16 * t + 4 * q + v) * LDC + col] = bf16_bits(acc[t][v] * gelu_grad_f(uv[t][v]));
+                for (int v = 0; v < 4; ++v) {
+                    const uint16_t db = bf16_bits(acc[t][v] * gelu_grad_f(uv[t][v]));
+                    tb[(16 * t + 4 * q + v) * LDC + col] = db;
+                    cs += bf16_val(db);
+                }
+            if (p.db1) {
+                cs += __shfl_xor(cs, 16, 64);
+                cs += __shfl_xor(cs, 32, 64);
+                if (q == 0) atomicAdd(p.db1 + c0 + col, cs);
+            }
         }, c0 / 16, 0);
         WideGemm<BM, C, NC, LDC, F / 32, NWB> g1;
         g1.issue(p.w1t, nobias, 0, c0 / 32);
@@ -2478,6 +2489,33 @@ extern "C" int mobgt_layer_chain_bwd_preln(const float* dout, const float* x2, c
                                      const void* const* wg_x, const int64_t* wg_ldx, float* const* wg_dw, const int64_t* wg_ldw,
                                      float* const* wg_db, const int* wg_M, const int* wg_N, void* ws, void* stream) {
     return chain_bwd_impl(1, CHAIN_BWD_ARGS);
+}
+
+/* The 64-row backward chain on its own entry point (R of any size): mobgt_layer_chain_bwd's arguments without the guests, plus
+ * db1 [F] f32 (accumulated; may be null). */
+extern "C" int mobgt_layer_chain_bwd_big(const float* dout, const float* x2, const float* x1, const void* u, const float* mean1,
+                                         const float* rstd1, const float* mean2, const float* rstd2, const float* n1w,
+                                         const float* nxw, const void* w2t, const void* w1t, const void* wot, void* df, void* du,
+                                         void* dy, void* da, float* dx1, float* dnxw, float* dnxb, float* db2, float* dn1w,
+                                         float* dn1b, float* dbo, float* db1, int64_t R, int C, int F, float dropout_p, uint64_t seed,
+                                         const uint64_t* seed_dev, uint32_t salt1, uint32_t salt2, void* stream) {
+    if (R <= 0) return 0;
+    if (!nxw || R > 0x7fffffff) return MOBGT_EBADDIM;
+    if (((uintptr_t)u | (uintptr_t)w2t | (uintptr_t)w1t | (uintptr_t)wot | (uintptr_t)du | (uintptr_t)da | (uintptr_t)dout | (uintptr_t)x1 |
+         (uintptr_t)x2 | (uintptr_t)dx1 | (uintptr_t)df | (uintptr_t)dy) & 15) return MOBGT_EALIGN;
+    ChainBwdParams p = {};
+    typedef const uint16_t* cu;
+    p.dout = dout; p.x2 = x2; p.x1 = x1; p.u = (cu)u; p.mean1 = mean1; p.rstd1 = rstd1; p.mean2 = mean2; p.rstd2 = rstd2;
+    p.n1w = n1w; p.nxw = nxw; p.w2t = (cu)w2t; p.w1t = (cu)w1t; p.wot = (cu)wot;
+    p.df = (uint16_t*)df; p.du = (uint16_t*)du; p.dy = (uint16_t*)dy; p.da = (uint16_t*)da; p.dx1 = dx1;
+    p.dnxw = dnxw; p.dnxb = dnxb; p.db2 = db2; p.dn1w = dn1w; p.dn1b = dn1b; p.dbo = dbo; p.db1 = db1; p.R = (int)R;
+    p.thr = dropout_p > 0.f ? dropout_threshold(dropout_p) : 0u;
+    p.inv_keep = p.thr ? 1.f / (1.f - (float)p.thr / 65536.f) : 1.f;
+    p.seed = seed; p.seed_dev = seed_dev; p.salt1 = salt1; p.salt2 = salt2;
+    if (C == 128 && F == 1024) return launch_bwd_big<128, 1024>(p, (hipStream_t)stream);
+    if (C == 192 && F == 1024) return launch_bwd_big<192, 1024>(p, (hipStream_t)stream);
+    if (C == 256 && F == 1024) return launch_bwd_big<256, 1024>(p, (hipStream_t)stream);
+    return MOBGT_EBADDIM;
 }
 
 extern "C" int64_t mobgt_chain_ws_bytes(void) {

@@ -641,15 +641,23 @@ class _FusedLayerFn(torch.autograd.Function):
                          (ci * n)(*[t[0].shape[1] for t in it]), (ci * n)(*[t[1].shape[1] for t in it]))
             else:
                 extra = (None, None, 0, None, None, None, None, None, None, None, None, None)
-            check(_lib.lib().mobgt_layer_chain_bwd(_p(dout), _p(x2), _p(x1), _p(u), _p(stats[2]), _p(stats[3]), _p(stats[4]),
-                                                   _p(stats[5]), _p(n1w), _p(nxw), _p(w2t), _p(w1t), _p(wot), _p(df), _p(du),
-                                                   _p(dy), _p(da), _p(dx1), _p(dnxw), _p(dnxb), _p(db2), _p(dn1w), _p(dn1b),
-                                                   _p(dbo), R, C, F, cfg.p, seed, _p(sd), (salt + 1) & 0xFFFFFFFF,
-                                                   (salt + 2) & 0xFFFFFFFF, *extra, _p(chain_workspace(dev, C, R)), _stream()), "mobgt_layer_chain_bwd")
+            if R > 4096 and pend is None:       # the 64-row form: b1's gradient is summed inside (db1 is zero-filled: `small`)
+                check(_lib.lib().mobgt_layer_chain_bwd_big(_p(dout), _p(x2), _p(x1), _p(u), _p(stats[2]), _p(stats[3]), _p(stats[4]),
+                                                           _p(stats[5]), _p(n1w), _p(nxw), _p(w2t), _p(w1t), _p(wot), _p(df), _p(du),
+                                                           _p(dy), _p(da), _p(dx1), _p(dnxw), _p(dnxb), _p(db2), _p(dn1w), _p(dn1b),
+                                                           _p(dbo), _p(None if db1_in_wgrad else db1), R, C, F, cfg.p, seed, _p(sd),
+                                                           (salt + 1) & 0xFFFFFFFF, (salt + 2) & 0xFFFFFFFF, _stream()),
+                      "mobgt_layer_chain_bwd_big")
+            else:
+                check(_lib.lib().mobgt_layer_chain_bwd(_p(dout), _p(x2), _p(x1), _p(u), _p(stats[2]), _p(stats[3]), _p(stats[4]),
+                                                       _p(stats[5]), _p(n1w), _p(nxw), _p(w2t), _p(w1t), _p(wot), _p(df), _p(du),
+                                                       _p(dy), _p(da), _p(dx1), _p(dnxw), _p(dnxb), _p(db2), _p(dn1w), _p(dn1b),
+                                                       _p(dbo), R, C, F, cfg.p, seed, _p(sd), (salt + 1) & 0xFFFFFFFF,
+                                                       (salt + 2) & 0xFFFFFFFF, *extra, _p(chain_workspace(dev, C, R)), _stream()), "mobgt_layer_chain_bwd")
+                if not db1_in_wgrad:
+                    check(_lib.lib().mobgt_colsum(_p(du), _p(db1), R, F, act, _stream()), "mobgt_colsum")
             da = da.view(G, T, C)
             dw2 = wb.add(df, h, sink=k_w2)
-            if not db1_in_wgrad:
-                check(_lib.lib().mobgt_colsum(_p(du), _p(db1), R, F, act, _stream()), "mobgt_colsum")
             dw1 = wb.add(du, z, db=db1 if db1_in_wgrad else None, sink=k_w1)
             dwo = wb.add(dy, a.view(R, C), sink=k_wo)
         else:
