@@ -63,6 +63,34 @@ def test_spmm_kernels_match_dense_products():
     assert bool((adj._rows_head == -1).all())                # the per-row lists are unthreaded again after every call
 
 
+@pytest.mark.parametrize("C", [64, 128, 96, 256])
+def test_spmm_row_widths_and_empty_rows(C):
+    """csrc/spmm.hip: C = 64 / 128 take spmm_narrow_kernel (the wave's 4 / 2 lane groups gather different neighbours and meet in a
+    shuffle), any other width the one-neighbour-per-instruction kernel; rows without neighbours (an isolated POI) give the bias;
+    neighbour counts that are not multiples of the group count or of the unroll (1 .. 40 per row) exercise both loop tails."""
+    from scipy import sparse
+    P = 700
+    rng = np.random.RandomState(C)
+    rows_, cols_, vals_ = [], [], []
+    for i in range(P):
+        k = 0 if i % 17 == 0 else 1 + (i * 7) % 40
+        cs = rng.choice(P, size=k, replace=False)
+        rows_ += [i] * k
+        cols_ += list(cs)
+        vals_ += list(rng.rand(k).astype(np.float32) + 0.1)
+    a = sparse.csr_matrix((np.array(vals_, np.float32), (np.array(rows_), np.array(cols_))), shape=(P, P))
+    adj = CsrAdj(*[t.to(DEV) for t in CsrAdj.from_scipy(a)])
+    dense = torch.from_numpy(a.toarray()).to(DEV)
+    g = torch.Generator().manual_seed(C)
+    b = torch.randn(P, C, generator=g).to(DEV)
+    bias = torch.randn(C, generator=g).to(DEV)
+    out = spmm(adj, b, bias)
+    np.testing.assert_allclose(out.cpu().numpy(), (dense @ b + bias).cpu().numpy(), rtol=1e-5, atol=1e-5)
+    assert torch.equal(out[0], bias) and torch.equal(out[17], bias)              # isolated rows
+    sub = torch.randperm(P, generator=g)[:123].to(DEV)
+    np.testing.assert_allclose(spmm(adj, b, None, sub).cpu().numpy(), (dense[sub] @ b).cpu().numpy(), rtol=1e-5, atol=1e-5)
+
+
 def _cpu_batch(b):
     c = SimpleNamespace()
     for f in ("attn_bias", "rel_pos", "poi_pos", "edge_input", "x", "in_degree", "out_degree", "user", "y", "time_normal"):
