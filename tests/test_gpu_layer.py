@@ -764,6 +764,87 @@ def test_chain_cluster_form_equals_the_one_workgroup_form(C, R, p):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("C,R,p", [(192, 185, 0.1), (256, 140, 0.0), (256, 333, 0.1), (128, 70, 0.1)])
+def test_chain_64_row_backward_entry_equals_the_16_row_form(C, R, p):
+    """csrc/chain.hip through the C ABI: mobgt_layer_chain_bwd_big (64-row workgroups, FFN in three chunks, norms with four
+    columns per lane, b1's gradient summed inside) against mobgt_layer_chain_bwd in its one-workgroup 16-row form on the same
+    saved tensors of a 16-row forward, at ragged R (one to six row blocks): df is bit-identical up to the norm's summation
+    order, everything behind it to bf16 round-off; db1 against the column sums of du.  And the dispatch rule: past 4 096 rows
+    mobgt_layer_chain_bwd takes the 64-row form, which has no guests -- a hosted tail is refused (MOBGT_EBADDIM)."""
+    import ctypes
+    from mobgt_amd import _lib
+    from mobgt_amd.ops import _p, _stream
+    lib = _lib.lib()
+    F = 1024
+    g = torch.Generator().manual_seed(3 * C + R)
+    bf = lambda *s, k=1.0: (torch.randn(*s, generator=g) * k).to(DEV).bfloat16()
+    f32 = lambda *s, k=1.0: (torch.randn(*s, generator=g) * k).to(DEV)
+
+    def pack(w, transposed=False):
+        out = torch.empty(w.numel(), dtype=torch.bfloat16, device=DEV)
+        vp, ci = ctypes.c_void_p, ctypes.c_int
+        N, K = (w.shape[1], w.shape[0]) if transposed else w.shape
+        _lib.check(lib.mobgt_pack_mfma_b(1, (vp * 1)(w.data_ptr()), (vp * 1)(out.data_ptr()), (ci * 1)(N), (ci * 1)(K),
+                                         (ci * 1)(1 if transposed else 0), _stream()), "mobgt_pack_mfma_b")
+        return out
+    wo, w1, w2 = bf(C, C, k=C ** -0.5), bf(F, C, k=C ** -0.5), bf(C, F, k=F ** -0.5)
+    bo, b1, b2 = bf(C, k=0.1), bf(F, k=0.1), bf(C, k=0.1)
+    n1w, n1b, nxw, nxb = 1 + f32(C, k=0.1), f32(C, k=0.1), 1 + f32(C, k=0.1), f32(C, k=0.1)
+    a, x = bf(R, C), f32(R, C)
+    pk = {k: pack(w) for k, w in (("wo", wo), ("w1", w1), ("w2", w2))}
+    pkt = {k: pack(w, True) for k, w in (("wo", wo), ("w1", w1), ("w2", w2))}
+    seed_dev = torch.tensor([5], dtype=torch.int64, device=DEV)
+    fw = dict(x1=torch.empty(R, C, device=DEV), x2=torch.empty(R, C, device=DEV), out=torch.empty(R, C, device=DEV),
+              z=bf(R, C), out_a=bf(R, C), u=bf(R, F), h=bf(R, F), st=torch.empty(4, R, device=DEV))
+    _lib.check(lib.mobgt_layer_chain_fwd(_p(a), _p(x), _p(pk["wo"]), _p(bo), _p(n1w), _p(n1b), _p(pk["w1"]), _p(b1), _p(pk["w2"]), _p(b2),
+                                         _p(nxw), _p(nxb), None, None, _p(fw["x1"]), _p(fw["z"]), _p(fw["u"]), _p(fw["h"]), _p(fw["x2"]),
+                                         _p(fw["out"]), _p(fw["out_a"]), None, _p(fw["st"][0]), _p(fw["st"][1]), _p(fw["st"][2]),
+                                         _p(fw["st"][3]), R, C, F, p, 77, _p(seed_dev), 9, 10, None, _stream()), "mobgt_layer_chain_fwd")
+    dout = f32(R, C)
+
+    def outs():
+        return dict(df=bf(R, C), du=bf(R, F), dy=bf(R, C), da=bf(R, C), dx1=torch.empty(R, C, device=DEV),
+                    sums=torch.zeros(6, C, device=DEV), db1=torch.zeros(F, device=DEV))
+    small, big = outs(), outs()
+    s = small["sums"]
+    _lib.check(lib.mobgt_layer_chain_bwd(_p(dout), _p(fw["x2"]), _p(fw["x1"]), _p(fw["u"]), _p(fw["st"][0]), _p(fw["st"][1]), _p(fw["st"][2]),
+                                         _p(fw["st"][3]), _p(n1w), _p(nxw), _p(pkt["w2"]), _p(pkt["w1"]), _p(pkt["wo"]), _p(small["df"]),
+                                         _p(small["du"]), _p(small["dy"]), _p(small["da"]), _p(small["dx1"]), _p(s[0]), _p(s[1]), _p(s[2]),
+                                         _p(s[3]), _p(s[4]), _p(s[5]), R, C, F, p, 77, _p(seed_dev), 9, 10, None, None, 0, None, None,
+                                         None, None, None, None, None, None, None, None, _stream()), "mobgt_layer_chain_bwd")
+    s = big["sums"]
+    _lib.check(lib.mobgt_layer_chain_bwd_big(_p(dout), _p(fw["x2"]), _p(fw["x1"]), _p(fw["u"]), _p(fw["st"][0]), _p(fw["st"][1]),
+                                             _p(fw["st"][2]), _p(fw["st"][3]), _p(n1w), _p(nxw), _p(pkt["w2"]), _p(pkt["w1"]), _p(pkt["wo"]),
+                                             _p(big["df"]), _p(big["du"]), _p(big["dy"]), _p(big["da"]), _p(big["dx1"]), _p(s[0]), _p(s[1]),
+                                             _p(s[2]), _p(s[3]), _p(s[4]), _p(s[5]), _p(big["db1"]), R, C, F, p, 77, _p(seed_dev), 9, 10,
+                                             _stream()), "mobgt_layer_chain_bwd_big")
+    torch.cuda.synchronize()
+    for k in ("df", "du", "dy", "da", "dx1"):
+        sc = max(1.0, float(small[k].float().abs().max()))
+        d = float((small[k].float() - big[k].float()).abs().max())
+        assert d <= 2 ** -6 * sc, (k, d, sc)
+        if small[k].dtype == torch.bfloat16:                                               # (most values round to the same bf16)
+            assert float((small[k].float() != big[k].float()).float().mean()) < 0.2, k
+    sc = small["sums"].abs().amax(1, keepdim=True).clamp_min(1e-6)
+    assert float(((small["sums"] - big["sums"]).abs() / sc).max()) <= 1e-2
+    ref_db1 = big["du"].float().sum(0)
+    assert float((big["db1"] - ref_db1).abs().max()) <= 1e-3 * max(1.0, float(ref_db1.abs().max()))
+    # the dispatch rule of the 16-row entry point: a hosted tail past 4 096 rows is refused
+    Rb = 4100
+    z16 = torch.zeros(Rb, 3 * C, dtype=torch.bfloat16, device=DEV)
+    zf = torch.zeros(Rb, C, device=DEV)
+    zu = torch.zeros(Rb, F, dtype=torch.bfloat16, device=DEV)
+    zs = torch.ones(Rb, device=DEV)
+    wqt = torch.zeros(3 * C * C, dtype=torch.bfloat16, device=DEV)
+    rc = lib.mobgt_layer_chain_bwd(_p(zf), _p(zf), _p(zf), _p(zu), _p(zs), _p(zs), _p(zs), _p(zs), _p(n1w), _p(nxw), _p(pkt["w2"]),
+                                   _p(pkt["w1"]), _p(pkt["wo"]), _p(z16[:, :C].contiguous()), _p(zu.clone()), _p(z16[:, :C].contiguous()),
+                                   _p(z16[:, :C].contiguous()), _p(zf.clone()), _p(s[0]), _p(s[1]), _p(s[2]), _p(s[3]), _p(s[4]), _p(s[5]),
+                                   Rb, C, F, p, 77, _p(seed_dev), 9, 10, _p(z16), _p(wqt), 0, None, None, None, None, None, None, None,
+                                   None, None, None, _stream())
+    assert rc == -1, rc                                     # MOBGT_EBADDIM
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("G,T,C,p", [(16, 38, 192, 0.1), (5, 9, 192, 0.0), (16, 20, 256, 0.1), (33, 12, 192, 0.1)])
 def test_head_chain_equals_the_three_launches(G, T, C, p):
     """csrc/head.hip (token row | user row -> FuseEmbeddings' Linear -> LeakyReLU -> LayerNorm -> ELU -> dropout, one launch
