@@ -2379,7 +2379,12 @@ extern "C" int mobgt_layer_chain_fwd(const void* a, const float* x, const void* 
     p.inv_keep = p.thr ? 1.f / (1.f - (float)p.thr / 65536.f) : 1.f;
     p.seed = seed; p.seed_dev = seed_dev; p.salt1 = salt1; p.salt2 = salt2;
     hipStream_t st = (hipStream_t)stream;
-    if (R > CHAIN_BIG_ROWS) {                // long batches: 64 rows per workgroup (layer_chain_fwd_big_kernel)
+    static int64_t big_rows = -1;            // (MOBGT_CHAIN_BIG_ROWS: a measurement aid -- the forward alone may switch forms at any R)
+    if (big_rows < 0) {
+        const char* e = getenv("MOBGT_CHAIN_BIG_ROWS");
+        big_rows = e ? atoll(e) : CHAIN_BIG_ROWS;
+    }
+    if (R > big_rows) {                      // long batches: 64 rows per workgroup (layer_chain_fwd_big_kernel)
         if (C == 128 && F == 1024) return launch_big<128, 1024>(p, st);
         if (C == 192 && F == 1024) return launch_big<192, 1024>(p, st);
         if (C == 256 && F == 1024) return launch_big<256, 1024>(p, st);
