@@ -32,6 +32,12 @@
 #include <type_traits>
 
 #include "common.h"
+#ifndef DB_AUX
+#define DB_AUX 0              // cache policy bits of the dBias stores (timing experiments: 2 = nt)
+#endif
+#ifndef BIAS_NT
+#define BIAS_NT 1              // the bias tiles are read ONCE per launch: non-temporal loads (0: plain)
+#endif
 #include "mobgt_hip.h"
 
 namespace {
@@ -273,7 +279,7 @@ struct BiasStage {
     __device__ __forceinline__ void load(const TB* __restrict__ rows, int c) {
         const unsigned char* base = reinterpret_cast<const unsigned char*>(rows + c * 64);
 #pragma unroll
-        for (int j = 0; j < NI; ++j) r[j] = *reinterpret_cast<const u32x4*>(base + off[j]);
+        for (int j = 0; j < NI; ++j) r[j] = BIAS_NT ? __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(base + off[j])) : *reinterpret_cast<const u32x4*>(base + off[j]);
     }
     __device__ __forceinline__ void park(unsigned char* img, int lane) const {
 #pragma unroll
@@ -1315,7 +1321,7 @@ __global__ __launch_bounds__(ONE_NW * 64) void attn_bwd_one_kernel(const AttnPar
                 typedef short v8s __attribute__((ext_vector_type(8)));
                 const v8s v = {r0[0], r0[1], r0[2], r0[3], r1[0], r1[1], r1[2], r1[3]};
                 const uint32_t off = ((unsigned)qglob < (unsigned)T && kglob < kend) ? (uint32_t)(qglob * (int)p.ld_bias + kglob) * 2u : 0x80000000u;
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), db_rsrc, off, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), db_rsrc, off, 0, DB_AUX);
             }
         }
     };
