@@ -35,9 +35,6 @@
 #ifndef DB_AUX
 #define DB_AUX 0              // cache policy bits of the dBias stores (timing experiments: 2 = nt)
 #endif
-#ifndef BIAS_NT
-#define BIAS_NT 1              // the bias tiles are read ONCE per launch: non-temporal loads (0: plain)
-#endif
 #include "mobgt_hip.h"
 
 namespace {
@@ -256,7 +253,9 @@ __device__ __forceinline__ void row_norm(float lse, float& mq, float& il) {
 // wave-private LDS image two chunks later and every lane reads its 16 keys per MFMA tile from there (row pitch +16 B: the
 // 16 rows of a ds_read_b128 lane group fall on different banks).  Rows are line-aligned because ld_bias % 64 == 0.
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-template <typename TB>
+// NT: the tiles are read with non-temporal loads -- long batches (T > 64), where a launch reads its bias exactly once: c5 forward
+// 51.7 -> 50.2 us, 55.5 -> 53.6 us inside the S-BIG step.  Short batches re-read one small bias in every layer: plain loads.
+template <typename TB, bool NT = false>
 struct BiasStage {
     static constexpr int SEG = 64 * (int)sizeof(TB);         // bytes of a row segment (64 keys)
     static constexpr int PITCH = SEG + 16;                   // LDS row pitch
@@ -279,7 +278,7 @@ struct BiasStage {
     __device__ __forceinline__ void load(const TB* __restrict__ rows, int c) {
         const unsigned char* base = reinterpret_cast<const unsigned char*>(rows + c * 64);
 #pragma unroll
-        for (int j = 0; j < NI; ++j) r[j] = BIAS_NT ? __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(base + off[j])) : *reinterpret_cast<const u32x4*>(base + off[j]);
+        for (int j = 0; j < NI; ++j) r[j] = NT ? __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(base + off[j])) : *reinterpret_cast<const u32x4*>(base + off[j]);
     }
     __device__ __forceinline__ void park(unsigned char* img, int lane) const {
 #pragma unroll
@@ -366,7 +365,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const AttnParams p) {
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks)          // (a fragment beyond D is read from column 0 and multiplied by zero below)
         qraw[ks].load(Q + (int64_t)qc * p.ldq + (ks * 16 + 8 * hi < D ? ks * 16 + 8 * hi : 0));
-    BiasStage<TB> ring[2];
+    BiasStage<TB, PIPE> ring[2];
     ring[0].init(p.ld_bias, brow_max, lane);
     ring[0].load(brows, 0);
     if (PIPE) {
@@ -423,7 +422,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const AttnParams p) {
     asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_real0)::"memory");      // 100 MHz wall clock
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_last)::"memory");
 #endif
-    auto chunk = [&](const int c, BiasStage<TB>& bst, const int b) {
+    auto chunk = [&](const int c, BiasStage<TB, PIPE>& bst, const int b) {
         bf16_t (*Ks)[ROWP] = Ksb[PIPE ? b : 0];
         bf16_t (*Vt)[COLP] = Vtb[PIPE ? b : 0];
         // this wave's bias super-tile: registers -> its LDS image (the image's readers of the previous chunk are this very
@@ -662,7 +661,7 @@ __device__ __forceinline__ void attn_bwd_dq_body(const AttnParams& p, const int 
     // same speed with and without dropout -- it was waiting for its bias tiles, not computing)
     const int nchunk = (T + KC - 1) / KC;
     constexpr bool PIPE = NW == 4;
-    BiasStage<TB> ring[2];
+    BiasStage<TB, PIPE> ring[2];
     ring[0].init(p.ld_bias, brow_max, lane);
     ring[0].load(brows, 0);
     if (PIPE) {
@@ -675,7 +674,7 @@ __device__ __forceinline__ void attn_bwd_dq_body(const AttnParams& p, const int 
         kreg.load_clamped(K, p.ldk, 0, T);
         vreg.load_clamped(V, p.ldv, 0, T);
     }
-    auto chunk = [&](const int c, BiasStage<TB>& bst) {
+    auto chunk = [&](const int c, BiasStage<TB, PIPE>& bst) {
         bst.park(bimg, lane);                                                  // (see the forward kernel)
         if (PIPE) bst.load(brows, min(c + 2, nchunk - 1));                    // (never behind a branch: see the forward)
         __syncthreads();
@@ -855,7 +854,7 @@ __device__ __forceinline__ void attn_bwd_dkv_body(const AttnParams& p, const int
     constexpr bool PIPE = NW == 4;
     // one super-tile (a chunk's 32 keys x 64 queries of bias_t) in registers, requested one chunk ahead (this pass is
     // compute-bound and short of registers: a deeper ring cost 26 VGPRs and bought nothing)
-    BiasStage<TB> bst;
+    BiasStage<TB, PIPE> bst;
     bst.init(p.ld_bias, brow_max, lane);
     bst.load(brows, 0);
     Slab<D, TQ, PIPE ? NT : KC * 4> qreg, doreg;
@@ -1114,7 +1113,7 @@ __global__ __launch_bounds__(ONE_NW * 64) void attn_bwd_one_kernel(const AttnPar
     for (int i = 0; i < 16; ++i) { dk[i] = 0.f; dv[i] = 0.f; }
 
     const int nchunk = (T + KC - 1) / KC;
-    BiasStage<TB> bst;
+    BiasStage<TB, true> bst;
     bst.init(p.ld_bias, brow_max, lane);
     // staging of a chunk: threads 0 .. 255 carry one 16-byte piece of Q each, threads 256 .. 511 one of dO
     const bool is_q = tid < 256;
