@@ -321,8 +321,9 @@ __device__ __forceinline__ int wave_row0(int qt, int nq, int T, int wave_uniform
 }
 __device__ __forceinline__ int wg_tile0(int qt, int nq, int T) { return qt * ((T + 31) >> 5) / nq; }
 // =================================================================================== forward
+// (four waves per SIMD for the long-batch instantiation -- the d = 24 one with dropout had come out at 130 registers: three)
 template <int D, typename TQ, typename TB, int NW, bool DROP>
-__global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const AttnParams p) {
+__global__ __launch_bounds__(NW * 64, (NW == 4 && sizeof(TB) == 2) ? 4 : 1) void attn_fwd_kernel(const AttnParams p) {
     constexpr int KS = (D + 15) / 16;
     constexpr int NT = NW * 64;
     constexpr bool PIPE = NW == 4;                     // NW < 4 is launched for T <= 64 only: one chunk, two tiles
