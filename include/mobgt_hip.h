@@ -612,14 +612,15 @@ int mobgt_layer_chain_bwd(const float* dout, const float* x2, const float* x1, c
                           const int64_t* wg_ldg, const void* const* wg_x, const int64_t* wg_ldx, float* const* wg_dw,
                           const int64_t* wg_ldw, float* const* wg_db, const int* wg_M, const int* wg_N, void* ws, void* stream);
 /* The 64-row form of mobgt_layer_chain_bwd on its own entry point (what that call dispatches to past 4 096 rows, for R of any
- * size): the same arguments without the guests and the workspace, plus db1 [F] f32 -- b1's gradient, the column sums of du,
- * ACCUMULATED like the other small gradients (null: not formed).  The float / bf16 row tensors 16-byte aligned. */
+ * size): the same arguments without the weight-gradient passengers and the workspace, plus db1 [F] f32 -- b1's gradient, the
+ * column sums of du, ACCUMULATED like the other small gradients (null: not formed).  tail_dqkv / tail_wqkv_t as there (the layer
+ * above's input gradient dout + dqkv Wqkv finished in front of the first norm; both null: none).  Row tensors 16-byte aligned. */
 int mobgt_layer_chain_bwd_big(const float* dout, const float* x2, const float* x1, const void* u, const float* mean1,
                               const float* rstd1, const float* mean2, const float* rstd2, const float* n1w, const float* nxw,
                               const void* w2t, const void* w1t, const void* wot, void* df, void* du, void* dy, void* da,
                               float* dx1, float* dnxw, float* dnxb, float* db2, float* dn1w, float* dn1b, float* dbo, float* db1,
                               int64_t R, int C, int F, float dropout_p, uint64_t seed, const uint64_t* seed_dev, uint32_t salt1,
-                              uint32_t salt2, void* stream);
+                              uint32_t salt2, const void* tail_dqkv, const void* tail_wqkv_t, void* stream);
 /* The two chain launches for PRE-LN layers -- graphormer/model.py:463-489, the EncoderLayer BASELINE.json's north_star names:
  *     y = self_attention_norm(x); y = attention(y); x = x + dropout(y); y = ffn_norm(x); y = ffn(y); x = x + dropout(y)
  * (round 4; (C, F) = (128, 1024) is instantiated for it).  Forward = mobgt_layer_chain_fwd with

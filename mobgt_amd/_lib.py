@@ -106,7 +106,7 @@ SIGNATURES = {
     "mobgt_spmm_csr_t_rows_gather": (_i, [_vp] * 7 + [_i64, _vp, _i64, _i64, _i64, _i, _vp]),
     "mobgt_pack_mfma_b": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mobgt_layer_chain_bwd": (_i, [_vp] * 24 + [_i64, _i, _i, _f, _u64, _vp, _c.c_uint32, _c.c_uint32, _vp, _vp, _i] + [_vp] * 9 + [_vp, _vp]),
-    "mobgt_layer_chain_bwd_big": (_i, [_vp] * 25 + [_i64, _i, _i, _f, _u64, _vp, _c.c_uint32, _c.c_uint32, _vp]),
+    "mobgt_layer_chain_bwd_big": (_i, [_vp] * 25 + [_i64, _i, _i, _f, _u64, _vp, _c.c_uint32, _c.c_uint32, _vp, _vp, _vp]),
     "mobgt_layer_chain_bwd_preln": (_i, [_vp] * 24 + [_i64, _i, _i, _f, _u64, _vp, _c.c_uint32, _c.c_uint32, _vp, _vp, _i] + [_vp] * 9 + [_vp, _vp]),
     "mobgt_layer_chain_fwd": (_i, [_vp] * 26 + [_i64, _i, _i, _f, _u64, _vp, _c.c_uint32, _c.c_uint32, _vp, _vp]),
     "mobgt_chain_ws_bytes": (_i64, []),

@@ -2094,8 +2094,8 @@ int launch_bwd_cl(ChainBwdParams& p, hipStream_t st) {
 // (the weight-gradient launches read it) and   dz += du_c W1[c, :]   split-K into the f32 tile.  dx2 leaves for global (in the
 // dx1 buffer) with the first norm's backward and is read back for the second.  LDS: dz f32 [64][C + 4], df / dy bf16
 // [64][C + 8], the chunk tile [64][392] (its first 24 KB double as the column-sum partials between the phases): 147 KB at
-// C = 256.  Eight waves (two per SIMD, 256 VGPRs).  No passengers and no hosted tail (the layer above finishes its own input
-// gradient past 4 096 rows); b1's gradient is the caller's column sum of du.  fq (post-LN) layers only.
+// C = 256.  Eight waves (two per SIMD, 256 VGPRs).  The layer above's tail (dout + dqkv Wqkv) can be hosted as in the 16-row form;
+// no weight-gradient passengers (past 4 096 rows they are the library's); b1's gradient is summed inside.  fq (post-LN) layers.
 template <int C, int F>
 __global__ __launch_bounds__(BIG_NW * 64) void layer_chain_bwd_big_kernel(const ChainBwdParams p) {
     constexpr int NWB = BIG_NW, NTB = NWB * 64;
@@ -2119,21 +2119,59 @@ __global__ __launch_bounds__(BIG_NW * 64) void layer_chain_bwd_big_kernel(const 
         s_rowh[threadIdx.x / BM][threadIdx.x % BM] =
             dropout_row_hash(seed, (uint32_t)(r0 + (int)(threadIdx.x % BM)) ^ (threadIdx.x < BM ? p.salt1 : p.salt2));
     const uint16_t* nobias = p.u;                        // (a product without a bias: any readable bf16 vector of >= 384 entries)
+    const bool hosted = p.t_dqkv != nullptr;
+    if (hosted) {
+        // ---- the layer ABOVE's input gradient, finished here (as the 16-row form hosts it): `dout` holds that layer's dx1; the
+        //      product dqkv Wqkv goes to the dz tile (f32) once every wave has left the dqkv tile under it, and the first norm
+        //      reads  d = dout + tile
+        constexpr int LDQ = 3 * C + 8;
+        static_assert(BM * LDQ * 2 <= BM * LDX * 4 + BM * LDA * 2, "the dqkv tile overlays the dz and df tiles");
+        uint16_t* tq = reinterpret_cast<uint16_t*>(smem_raw);
+        WideGemm<BM, C, 3 * C, LDQ, 3 * C / 32, NWB> g_t;
+        g_t.issue(p.t_wqt, nobias);
+#pragma unroll
+        for (int e = threadIdx.x; e < BM * (3 * C / 8); e += NTB) {
+            const int r = e / (3 * C / 8), c = (e % (3 * C / 8)) * 8;
+            *reinterpret_cast<uint4*>(tq + r * LDQ + c) = *reinterpret_cast<const uint4*>(p.t_dqkv + (int64_t)min(r0 + r, p.R - 1) * (3 * C) + c);
+        }
+        __syncthreads();
+        constexpr int PERG = (C / 16 + NWB - 1) / NWB;           // column groups of C per wave (2 at C = 256)
+        f32x4 keep[PERG][MT];
+        g_t.run(tq, p.t_wqt, nobias, [&](int g, const f32x4 (&acc)[MT], float) {
+#pragma unroll
+            for (int i = 0; i < PERG; ++i)
+                if (g == wave + NWB * i) {
+#pragma unroll
+                    for (int t = 0; t < MT; ++t) keep[i][t] = acc[t];
+                }
+        });
+        __syncthreads();                                 // (the dqkv tile has been multiplied by every wave)
+#pragma unroll
+        for (int i = 0; i < PERG; ++i) {
+            const int g = wave + NWB * i;
+            if (g < C / 16) {
+#pragma unroll
+                for (int t = 0; t < MT; ++t)
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) dzb[(16 * t + 4 * q + v) * LDX + 16 * g + j] = keep[i][t][v];
+            }
+        }
+    }
     WideGemm<BM, FC, C, LDA, C / 32, NWB> g_2a;
     g_2a.issue(p.w2t, nobias, 0, 0);
-    __syncthreads();
+    __syncthreads();                                     // (also: the sums above are visible to the waves that read their rows below)
 
     // One norm backwards over the block's rows, a wave per row (rows wave, wave + 8, ...: everything a row needs is requested up
     // front) and FOUR consecutive columns per lane (16- / 8-byte pieces: see the forward kernel's norms), ln_bwd_rows' arithmetic:
     //     t = rstd (g - mean(g) - xh mean(g xh)) [+ res],  y = dropout'(t)
-    //   d: the incoming gradient -- global f32 [R][C], or (from_tile) the dz tile, rounded to bf16 as the separate launch's tensor was
+    //   d: the incoming gradient -- global f32 [R][C] (+ the dz tile: add_tile), or (from_tile) the dz tile, rounded to bf16 as the separate launch's tensor was
     //   res_g: added behind the norm (null: nothing);  dx_g <- t (f32);  gb, dy_g <- y (bf16);  column sums of d xh, d, y -> red
     constexpr int LPR = C / 4;
     const bool lact = lane < LPR;
     const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
     auto ln_bwd = [&](auto from_tile, const float* __restrict__ d_g, const float* __restrict__ xpre, const float* __restrict__ g_mean,
                       const float* __restrict__ g_rstd, const float* __restrict__ wp, const float* res_g, float* dx_g,
-                      uint16_t* __restrict__ dy_g, const int which) {
+                      uint16_t* __restrict__ dy_g, const int which, const bool add_tile) {
         const float4 w4 = lact ? *reinterpret_cast<const float4*>(wp + 4 * lane) : z4;
         float ag[4] = {0.f, 0.f, 0.f, 0.f}, ab[4] = {0.f, 0.f, 0.f, 0.f}, ay[4] = {0.f, 0.f, 0.f, 0.f};
         float4 xr[NR], dr[NR], rr[NR];
@@ -2145,8 +2183,13 @@ __global__ __launch_bounds__(BIG_NW * 64) void layer_chain_bwd_big_kernel(const 
             mu[i] = g_mean[row];
             rs[i] = g_rstd[row];
             xr[i] = lact ? *reinterpret_cast<const float4*>(xpre + row * C + 4 * lane) : z4;
-            if constexpr (!decltype(from_tile)::value) dr[i] = lact ? *reinterpret_cast<const float4*>(d_g + row * C + 4 * lane) : z4;
-            else {
+            if constexpr (!decltype(from_tile)::value) {
+                dr[i] = lact ? *reinterpret_cast<const float4*>(d_g + row * C + 4 * lane) : z4;
+                if (add_tile) {                          // (wave-uniform: the hosted tail's product, f32, from the dz tile)
+                    const float4 t = lact ? *reinterpret_cast<const float4*>(dzb + r * LDX + 4 * lane) : z4;
+                    dr[i].x += t.x; dr[i].y += t.y; dr[i].z += t.z; dr[i].w += t.w;
+                }
+            } else {
                 const float4 t = lact ? *reinterpret_cast<const float4*>(dzb + r * LDX + 4 * lane) : z4;
                 dr[i] = make_float4(bf16_round(t.x), bf16_round(t.y), bf16_round(t.z), bf16_round(t.w));
             }
@@ -2211,7 +2254,7 @@ __global__ __launch_bounds__(BIG_NW * 64) void layer_chain_bwd_big_kernel(const 
         }
     };
     // ---- dx2 = ffn_norm2'(dout) -> global (in the dx1 buffer);  df = dropout'(dx2)
-    ln_bwd(std::false_type{}, p.dout, p.x2, p.mean2, p.rstd2, p.nxw, nullptr, p.dx1, p.df, 1);
+    ln_bwd(std::false_type{}, p.dout, p.x2, p.mean2, p.rstd2, p.nxw, nullptr, p.dx1, p.df, 1, hosted);
     __syncthreads();
     STAMP(1);
     flush(p.dnxw, p.dnxb, p.db2);
@@ -2296,7 +2339,7 @@ __global__ __launch_bounds__(BIG_NW * 64) void layer_chain_bwd_big_kernel(const 
     __syncthreads();
     STAMP(7);
     // ---- dx1 = dx2 + ffn_norm1'(dz);  dy = dropout'(dx1)
-    ln_bwd(std::true_type{}, nullptr, p.x1, p.mean1, p.rstd1, p.n1w, p.dx1, p.dx1, p.dy, 0);
+    ln_bwd(std::true_type{}, nullptr, p.x1, p.mean1, p.rstd1, p.n1w, p.dx1, p.dx1, p.dy, 0, false);
     __syncthreads();
     STAMP(8);
     flush(p.dn1w, p.dn1b, p.dbo);
@@ -2496,16 +2539,18 @@ extern "C" int mobgt_layer_chain_bwd_preln(const float* dout, const float* x2, c
     return chain_bwd_impl(1, CHAIN_BWD_ARGS);
 }
 
-/* The 64-row backward chain on its own entry point (R of any size): mobgt_layer_chain_bwd's arguments without the guests, plus
- * db1 [F] f32 (accumulated; may be null). */
+/* The 64-row backward chain on its own entry point (R of any size): mobgt_layer_chain_bwd's arguments without the weight-gradient
+ * passengers and the workspace, plus db1 [F] f32 (accumulated; may be null). */
 extern "C" int mobgt_layer_chain_bwd_big(const float* dout, const float* x2, const float* x1, const void* u, const float* mean1,
                                          const float* rstd1, const float* mean2, const float* rstd2, const float* n1w,
                                          const float* nxw, const void* w2t, const void* w1t, const void* wot, void* df, void* du,
                                          void* dy, void* da, float* dx1, float* dnxw, float* dnxb, float* db2, float* dn1w,
                                          float* dn1b, float* dbo, float* db1, int64_t R, int C, int F, float dropout_p, uint64_t seed,
-                                         const uint64_t* seed_dev, uint32_t salt1, uint32_t salt2, void* stream) {
+                                         const uint64_t* seed_dev, uint32_t salt1, uint32_t salt2, const void* tail_dqkv,
+                                         const void* tail_wqkv_t, void* stream) {
     if (R <= 0) return 0;
-    if (!nxw || R > 0x7fffffff) return MOBGT_EBADDIM;
+    if (!nxw || R > 0x7fffffff || (tail_dqkv == nullptr) != (tail_wqkv_t == nullptr)) return MOBGT_EBADDIM;
+    if (((uintptr_t)tail_dqkv | (uintptr_t)tail_wqkv_t) & 15) return MOBGT_EALIGN;
     if (((uintptr_t)u | (uintptr_t)w2t | (uintptr_t)w1t | (uintptr_t)wot | (uintptr_t)du | (uintptr_t)da | (uintptr_t)dout | (uintptr_t)x1 |
          (uintptr_t)x2 | (uintptr_t)dx1 | (uintptr_t)df | (uintptr_t)dy) & 15) return MOBGT_EALIGN;
     ChainBwdParams p = {};
@@ -2517,6 +2562,7 @@ extern "C" int mobgt_layer_chain_bwd_big(const float* dout, const float* x2, con
     p.thr = dropout_p > 0.f ? dropout_threshold(dropout_p) : 0u;
     p.inv_keep = p.thr ? 1.f / (1.f - (float)p.thr / 65536.f) : 1.f;
     p.seed = seed; p.seed_dev = seed_dev; p.salt1 = salt1; p.salt2 = salt2;
+    p.t_dqkv = (cu)tail_dqkv; p.t_wqt = (cu)tail_wqkv_t;
     if (C == 128 && F == 1024) return launch_bwd_big<128, 1024>(p, (hipStream_t)stream);
     if (C == 192 && F == 1024) return launch_bwd_big<192, 1024>(p, (hipStream_t)stream);
     if (C == 256 && F == 1024) return launch_bwd_big<256, 1024>(p, (hipStream_t)stream);

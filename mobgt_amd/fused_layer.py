@@ -239,6 +239,9 @@ def _complete_pending(pend):
         # (a pre-LN layer's tail goes back through a norm whose parameters and statistics only its host holds)
         raise RuntimeError("mobgt fused layer (pre-LN): the parked input gradient of a chained layer found no host "
                            "(was the layer's input used by something else as well?); set MOBGT_NO_DEFER_TAIL=1")
+    if pend.get("big"):                                   # (past 4 096 rows: the library's GEMM, onto dx1 in place)
+        _addmm_f32(pend["dx1"], pend["dqkv"], pend["wqkv"], inplace=True)
+        return
     wb = _WgradBatch()
     wb.items = pend["items"]
     if not wb.flush(tail=(pend["dqkv"], pend["wqkv"], pend["dx1"])):
@@ -430,7 +433,7 @@ class _FusedLayerFn(torch.autograd.Function):
                              and all(t.is_contiguous() and t.data_ptr() % 16 == 0 for t in cfg.packed_t))
         # the layer below produced this layer's qkv in ITS chain launch and will run chain_bwd: it can host what this layer's
         # backward leaves undone (see _PENDING_TAIL)
-        ctx.below_hosts = bool(cfg.from_layer and qkv_pre is not None and ctx.chain_bwd and len(cfg.packed_t) > 3 and R <= 4096)
+        ctx.below_hosts = bool(cfg.from_layer and qkv_pre is not None and ctx.chain_bwd and len(cfg.packed_t) > 3)
         if use_chain:               # everything row-local of the layer (+ the next layer's QKV projection) in one launch
             bf = dict(dtype=A, device=dev)
             x1, x2, out = torch.empty(R, C, **f32), torch.empty(R, C, **f32), torch.empty(R, C, **f32)
@@ -641,12 +644,16 @@ class _FusedLayerFn(torch.autograd.Function):
                          (ci * n)(*[t[0].shape[1] for t in it]), (ci * n)(*[t[1].shape[1] for t in it]))
             else:
                 extra = (None, None, 0, None, None, None, None, None, None, None, None, None)
-            if R > 4096 and pend is None:       # the 64-row form: b1's gradient is summed inside (db1 is zero-filled: `small`)
+            if R > 4096 and (pend is None or not pend["items"]):
+                # the 64-row form: b1's gradient is summed inside (db1 is zero-filled: `small`); it hosts the upper layer's tail
+                # (dout = that layer's dx1; dout + dqkv Wqkv is finished in front of the first norm), not its weight gradients
                 check(_lib.lib().mobgt_layer_chain_bwd_big(_p(dout), _p(x2), _p(x1), _p(u), _p(stats[2]), _p(stats[3]), _p(stats[4]),
                                                            _p(stats[5]), _p(n1w), _p(nxw), _p(w2t), _p(w1t), _p(wot), _p(df), _p(du),
                                                            _p(dy), _p(da), _p(dx1), _p(dnxw), _p(dnxb), _p(db2), _p(dn1w), _p(dn1b),
                                                            _p(dbo), _p(None if db1_in_wgrad else db1), R, C, F, cfg.p, seed, _p(sd),
-                                                           (salt + 1) & 0xFFFFFFFF, (salt + 2) & 0xFFFFFFFF, _stream()),
+                                                           (salt + 1) & 0xFFFFFFFF, (salt + 2) & 0xFFFFFFFF,
+                                                           _p(pend["dqkv"]) if pend is not None else None,
+                                                           _p(pend["wqt"]) if pend is not None else None, _stream()),
                       "mobgt_layer_chain_bwd_big")
             else:
                 check(_lib.lib().mobgt_layer_chain_bwd(_p(dout), _p(x2), _p(x1), _p(u), _p(stats[2]), _p(stats[3]), _p(stats[4]),
@@ -673,7 +680,19 @@ class _FusedLayerFn(torch.autograd.Function):
         defer = (_DEFER[0] and getattr(ctx, "below_hosts", False) and own and not stock and _TAIL[0] and len(wb.items) == 4
                  and R <= _DEFER_MAX_R[0] and dx1.data_ptr() % 16 == 0 and dqkv2.is_contiguous() and ctx.small_sink is not None
                  and all(k is not None for k in ctx.sinks))
-        if defer:
+        big_defer = (not defer and _DEFER[0] and getattr(ctx, "below_hosts", False) and not stock and _TAIL[0] and R > 4096
+                     and dx1.data_ptr() % 16 == 0 and dqkv2.is_contiguous() and dqkv2.data_ptr() % 16 == 0)
+        if big_defer:
+            # past 4 096 rows: the 64-row chain of the layer below finishes dx = dx1 + dqkv Wqkv in front of its first norm (a
+            # 20 us library GEMM otherwise); the weight gradients are the library's and are issued here
+            wb.flush(tail=None)
+            _PENDING_TAIL[_pending_key(dx1)] = dict(dx1=dx1[:], dqkv=dqkv2, wqkv=s_wqkv, wqt=cfg.packed_t[3], items=[], R=R, big=True)
+            if _PENDING_CB[0] != _task_id():
+                _PENDING_CB[0] = _task_id()
+                torch.autograd.Variable._execution_engine.queue_callback(_pending_check)
+            rode = True
+            dx = dx1
+        elif defer:
             # nothing more is launched for this layer: the chain launch of the layer below finishes dx and the weight gradients
             # (parked as FRESH views of the gradient buffers: autograd's AccumulateGrad clones a returned gradient that anything
             # else still references, and the clone -- taken before the buffers are filled -- would later be copied over them)

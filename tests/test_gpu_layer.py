@@ -817,7 +817,7 @@ def test_chain_64_row_backward_entry_equals_the_16_row_form(C, R, p):
                                              _p(fw["st"][2]), _p(fw["st"][3]), _p(n1w), _p(nxw), _p(pkt["w2"]), _p(pkt["w1"]), _p(pkt["wo"]),
                                              _p(big["df"]), _p(big["du"]), _p(big["dy"]), _p(big["da"]), _p(big["dx1"]), _p(s[0]), _p(s[1]),
                                              _p(s[2]), _p(s[3]), _p(s[4]), _p(s[5]), _p(big["db1"]), R, C, F, p, 77, _p(seed_dev), 9, 10,
-                                             _stream()), "mobgt_layer_chain_bwd_big")
+                                             None, None, _stream()), "mobgt_layer_chain_bwd_big")
     torch.cuda.synchronize()
     for k in ("df", "du", "dy", "da", "dx1"):
         sc = max(1.0, float(small[k].float().abs().max()))
@@ -829,17 +829,40 @@ def test_chain_64_row_backward_entry_equals_the_16_row_form(C, R, p):
     assert float(((small["sums"] - big["sums"]).abs() / sc).max()) <= 1e-2
     ref_db1 = big["du"].float().sum(0)
     assert float((big["db1"] - ref_db1).abs().max()) <= 1e-3 * max(1.0, float(ref_db1.abs().max()))
+    # ... and with the upper layer's tail hosted by both (dout = its dx1; dout + dqkv Wqkv in front of the first norm)
+    dqkv = bf(R, 3 * C, k=0.3)
+    wq = bf(3 * C, C, k=C ** -0.5)
+    wqt = pack(wq, True)
+    small2, big2 = outs(), outs()
+    s = small2["sums"]
+    _lib.check(lib.mobgt_layer_chain_bwd(_p(dout), _p(fw["x2"]), _p(fw["x1"]), _p(fw["u"]), _p(fw["st"][0]), _p(fw["st"][1]), _p(fw["st"][2]),
+                                         _p(fw["st"][3]), _p(n1w), _p(nxw), _p(pkt["w2"]), _p(pkt["w1"]), _p(pkt["wo"]), _p(small2["df"]),
+                                         _p(small2["du"]), _p(small2["dy"]), _p(small2["da"]), _p(small2["dx1"]), _p(s[0]), _p(s[1]), _p(s[2]),
+                                         _p(s[3]), _p(s[4]), _p(s[5]), R, C, F, p, 77, _p(seed_dev), 9, 10, _p(dqkv), _p(wqt), 0, None, None,
+                                         None, None, None, None, None, None, None, None, _stream()), "mobgt_layer_chain_bwd")
+    s = big2["sums"]
+    _lib.check(lib.mobgt_layer_chain_bwd_big(_p(dout), _p(fw["x2"]), _p(fw["x1"]), _p(fw["u"]), _p(fw["st"][0]), _p(fw["st"][1]),
+                                             _p(fw["st"][2]), _p(fw["st"][3]), _p(n1w), _p(nxw), _p(pkt["w2"]), _p(pkt["w1"]), _p(pkt["wo"]),
+                                             _p(big2["df"]), _p(big2["du"]), _p(big2["dy"]), _p(big2["da"]), _p(big2["dx1"]), _p(s[0]), _p(s[1]),
+                                             _p(s[2]), _p(s[3]), _p(s[4]), _p(s[5]), _p(big2["db1"]), R, C, F, p, 77, _p(seed_dev), 9, 10,
+                                             _p(dqkv), _p(wqt), _stream()), "mobgt_layer_chain_bwd_big")
+    torch.cuda.synchronize()
+    assert not torch.equal(small2["df"], small["df"])                       # (the tail did change the gradient)
+    for k in ("df", "du", "dy", "da", "dx1"):
+        sc = max(1.0, float(small2[k].float().abs().max()))
+        d = float((small2[k].float() - big2[k].float()).abs().max())
+        assert d <= 2 ** -6 * sc, ("tail", k, d, sc)
     # the dispatch rule of the 16-row entry point: a hosted tail past 4 096 rows is refused
     Rb = 4100
     z16 = torch.zeros(Rb, 3 * C, dtype=torch.bfloat16, device=DEV)
     zf = torch.zeros(Rb, C, device=DEV)
     zu = torch.zeros(Rb, F, dtype=torch.bfloat16, device=DEV)
     zs = torch.ones(Rb, device=DEV)
-    wqt = torch.zeros(3 * C * C, dtype=torch.bfloat16, device=DEV)
+    wqt0 = torch.zeros(3 * C * C, dtype=torch.bfloat16, device=DEV)
     rc = lib.mobgt_layer_chain_bwd(_p(zf), _p(zf), _p(zf), _p(zu), _p(zs), _p(zs), _p(zs), _p(zs), _p(n1w), _p(nxw), _p(pkt["w2"]),
                                    _p(pkt["w1"]), _p(pkt["wo"]), _p(z16[:, :C].contiguous()), _p(zu.clone()), _p(z16[:, :C].contiguous()),
                                    _p(z16[:, :C].contiguous()), _p(zf.clone()), _p(s[0]), _p(s[1]), _p(s[2]), _p(s[3]), _p(s[4]), _p(s[5]),
-                                   Rb, C, F, p, 77, _p(seed_dev), 9, 10, _p(z16), _p(wqt), 0, None, None, None, None, None, None, None,
+                                   Rb, C, F, p, 77, _p(seed_dev), 9, 10, _p(z16), _p(wqt0), 0, None, None, None, None, None, None, None,
                                    None, None, None, _stream())
     assert rc == -1, rc                                     # MOBGT_EBADDIM
 
