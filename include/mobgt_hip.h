@@ -601,8 +601,9 @@ int mobgt_layer_chain_fwd(const void* a, const float* x, const void* wo, const v
  * then holds only that layer's dx1 and dout + dqkv Wqkv is formed here, per row block; wg_*: n_wg <= 4 weight-gradient
  * problems dW [M,N] += g^T x (+ db [M] += column sums of g) over the same R rows, bf16 operands as mobgt_linear_wgrad, run
  * by extra workgroups of this launch on the compute units its 16-row blocks leave idle.
- * R > 4096: the 64-row form (layer_chain_bwd_big_kernel) -- post-LN layers only, WITHOUT guests: tail_dqkv / tail_wqkv_t null
- * and n_wg == 0, else MOBGT_EBADDIM; b1's gradient is then the caller's mobgt_colsum of du. */
+ * R > 4096: the 64-row form (layer_chain_bwd_big_kernel) -- post-LN layers only, and through THIS entry point without guests:
+ * tail_dqkv / tail_wqkv_t null and n_wg == 0, else MOBGT_EBADDIM (mobgt_layer_chain_bwd_big hosts a tail); b1's gradient is then
+ * the caller's mobgt_colsum of du. */
 int mobgt_layer_chain_bwd(const float* dout, const float* x2, const float* x1, const void* u, const float* mean1,
                           const float* rstd1, const float* mean2, const float* rstd2, const float* n1w, const float* nxw,
                           const void* w2t, const void* w1t, const void* wot, void* df, void* du, void* dy, void* da, float* dx1,

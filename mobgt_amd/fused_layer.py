@@ -428,7 +428,7 @@ class _FusedLayerFn(torch.autograd.Function):
         if chained_in and not stock_chain:
             raise RuntimeError("mobgt fused layer (pre-LN): the layer below chained into this one, which cannot run its chain kernels")
         ctx.fuse_ln = use_chain and own
-        # (past 4 096 rows both chains are the 64-row kernels of csrc/chain.hip; they take no guests: see below_hosts)
+        # (past 4 096 rows both chains are the 64-row kernels of csrc/chain.hip; the backward hosts the upper layer's tail only)
         ctx.chain_bwd = bool(use_chain and _CHAIN_BWD[0] and cfg.packed_t is not None and (R <= 4096 or _CHAIN_BIG[0])
                              and all(t.is_contiguous() and t.data_ptr() % 16 == 0 for t in cfg.packed_t))
         # the layer below produced this layer's qkv in ITS chain launch and will run chain_bwd: it can host what this layer's
