@@ -38,6 +38,10 @@ extern "C" {
 #define MOBGT_EDTYPE (-3)    /* unknown dtype code                                   */
 
 /* Library / device identification (no GPU work). */
+/* Bumped on every incompatible change of a signature below (round 5 inserted `out_lo` into the attention entry points under
+ * version 1 -- ADVICE r5; version 2 = that ABI; version 3 = round 6).  mobgt_amd/_lib.py refuses a library whose
+ * version differs from the one its SIGNATURES table was written for. */
+#define MOBGT_ABI_VERSION 3
 int mobgt_abi_version(void);
 const char* mobgt_build_info(void);
 

@@ -18,6 +18,8 @@ I64, I32, I16, U8 = 0, 1, 2, 3
 _c = ctypes
 _vp, _i, _i64, _f, _u64, _u32 = _c.c_void_p, _c.c_int, _c.c_int64, _c.c_float, _c.c_uint64, _c.c_uint32
 
+ABI_VERSION = 3          # include/mobgt_hip.h: MOBGT_ABI_VERSION the table below was written for
+
 SIGNATURES = {
     "mobgt_abi_version": (_i, []),
     "mobgt_build_info": (_c.c_char_p, []),
@@ -165,6 +167,11 @@ def lib():
         # with one, torch's streams and buffers owned by the other (every launch fails with hipErrorNoDevice).
         import torch  # noqa: F401
         handle = ctypes.CDLL(LIB_PATH)
+        handle.mobgt_abi_version.restype = _i
+        have = handle.mobgt_abi_version()
+        if have != ABI_VERSION:
+            raise RuntimeError(f"{LIB_PATH} has ABI version {have}, this binding was written for {ABI_VERSION}: a stale build "
+                               "(arguments would be shifted silently) -- rebuild with __graft_entry__.build()")
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(handle, name)          # AttributeError here = header/library mismatch
             fn.restype = res

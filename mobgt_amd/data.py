@@ -222,7 +222,7 @@ BUCKETS = (tuple(range(4, 65, 4)) + tuple(range(72, 129, 8)) + tuple(range(144, 
            + tuple(range(576, 1025, 64)))
 
 
-def balanced_batches(lengths, world_size, batch_size, epoch=0, seed=0, shuffle=True, buckets=BUCKETS):
+def balanced_batches(lengths, world_size, batch_size, epoch=0, seed=0, shuffle=True, buckets=BUCKETS, window=None):
     """Length-balanced dealing of one epoch over `world_size` ranks ("load imbalance across ranks": node
     counts run from 1 to 814 on Gowalla, a step costs what its padded N costs, and a synchronous step lasts as long as its
     slowest rank): -> steps[j][r] = sample ids of rank r in step j, the same list on every rank.
@@ -234,7 +234,12 @@ def balanced_batches(lengths, world_size, batch_size, epoch=0, seed=0, shuffle=T
       order, so a batch's composition stays random) and cut into steps of world_size x batch_size; rank r takes the r-th run of a
       step -- neighbouring runs of one sorted sequence, i.e. the same or the neighbouring bucket on all ranks;
     * the steps are then visited in an order drawn from seed + epoch + 1 (sizes mixed over time: the learning-rate schedule
-      never sees 'all short graphs first')."""
+      never sees 'all short graphs first');
+    * `window` (steps; None = the whole epoch): the sort runs inside consecutive windows of window x world_size x batch_size
+      samples of the permuted epoch only -- every window is a uniform random sample of the dataset, so a step's batches are
+      length-homogeneous only with respect to the ~window x world x batch samples around them, and the long graphs of an epoch are
+      spread over its windows instead of sharing one step (whole-epoch sorting changes SGD's batch statistics against
+      the reference's i.i.d. DistributedSampler batches; `train.EpochLoop` therefore uses a bounded window by default)."""
     n = len(lengths)
     if shuffle:
         g = torch.Generator()
@@ -244,13 +249,16 @@ def balanced_batches(lengths, world_size, batch_size, epoch=0, seed=0, shuffle=T
         order = list(range(n))
     total = (n + world_size - 1) // world_size * world_size
     order += order[: total - len(order)]
-    keyed = sorted(order, key=lambda i: bucket_nodes(int(lengths[i]), buckets))          # (stable)
     per_step = world_size * batch_size
+    span = total if window is None else max(1, int(window)) * per_step
     steps = []
-    for s in range(0, total, per_step):
-        chunk = keyed[s:s + per_step]
-        m = len(chunk) // world_size                                                     # (total is a multiple of world_size)
-        steps.append([chunk[r * m:(r + 1) * m] for r in range(world_size)])
+    for w0 in range(0, total, span):
+        keyed = sorted(order[w0:w0 + span], key=lambda i: bucket_nodes(int(lengths[i]), buckets))          # (stable)
+        for s in range(0, len(keyed), per_step):
+            chunk = keyed[s:s + per_step]
+            m = len(chunk) // world_size                                                 # (total is a multiple of world_size)
+            steps.append([chunk[r * m:(r + 1) * m] for r in range(world_size)])
+    # (windows: only the epoch's LAST step can be short -- every window but the last holds whole steps)
     if shuffle:
         g = torch.Generator()
         g.manual_seed(seed + epoch + 1)

@@ -590,6 +590,9 @@ class _FusedLayerFn(torch.autograd.Function):
         G, T, C = ctx.shapes
         R = G * T
         x, xa, qkv, a, lse, x1, z, u, h, x2, stats, s_wqkv, s_wo, s_w1, s_w2, n1w, nxw, nnw = ctx.saved_tensors
+        pend = getattr(ctx, "_mobgt_pending", None)     # (model.note_pending_backward: the layer's shadows may be rewritten again)
+        if pend is not None:
+            pend.done()
         if getattr(ctx, "stock_chain", False):
             return _FusedLayerFn._backward_preln_chain(ctx, dout, x, xa, qkv, a, lse, x1, z, u, h, x2, stats, s_wqkv, n1w, nxw, nnw)
         A = cfg.act_dtype

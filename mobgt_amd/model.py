@@ -215,7 +215,8 @@ def fused_layer_forward(layer, variant, x, attn_bias, n1, nx, next_layer=None):
             # (stand-alone layers, and AMP on a layer configured for fp32: copy here; a model refreshes all layers in one call.
             #  Unchanged weights are not copied again -- refresh_shadows says why)
             ver = _weights_version(layer)
-            if getattr(layer, "_shadow_ver", None) != ver and not getattr(layer, "_shadow_external", False):
+            if ((getattr(layer, "_shadow_ver", None) != ver or not _may_skip_shadow_copy(layer))
+                    and not getattr(layer, "_shadow_external", False)):
                 torch._foreach_copy_(list(sh), [m.detach() for m in masters])
                 layer._shadow_ver = ver
                 layer._packed_ver = None
@@ -270,9 +271,13 @@ def fused_layer_forward(layer, variant, x, attn_bias, n1, nx, next_layer=None):
         params = params + ((nn_[0], nn_[1]) if nn_ is not None else (None, None))
     if amp:
         with torch.autocast("cuda", enabled=False):
-            return fused_encoder_layer(x.float(), pack, cfg, shadows, params, xa_pre=getattr(x, "_mobgt_act", None))
-    return fused_encoder_layer(x.float(), pack, cfg, shadows, params, xa_pre=getattr(x, "_mobgt_act", None),
-                               qkv_pre=getattr(x, "_mobgt_qkv", None))
+            out = fused_encoder_layer(x.float(), pack, cfg, shadows, params, xa_pre=getattr(x, "_mobgt_act", None))
+    else:
+        out = fused_encoder_layer(x.float(), pack, cfg, shadows, params, xa_pre=getattr(x, "_mobgt_act", None),
+                                  qkv_pre=getattr(x, "_mobgt_qkv", None))
+    if act != torch.float32 and out.requires_grad:
+        note_pending_backward(layer, out)          # (its backward reads the bf16 shadows / packs saved above)
+    return out
 
 
 _PENDING_PACK = []          # jobs of a deferred weight pack (see pack_layer_weights(defer=True))
@@ -305,10 +310,47 @@ def _launch_pack(jobs):
                                                 (ci * n)(*[j[4] for j in part]), _stream()), "mobgt_pack_mfma_b")
 
 
+class _PendingBackward:
+    """One forward pass of a fused layer whose backward has not run yet: lives on the autograd node (`out.grad_fn`), so it goes
+    away with the graph; `done()` is called by the layer's backward."""
+    __slots__ = ("pending", "__weakref__")
+
+    def __init__(self, pending):
+        self.pending = pending
+        pending.add(id(self))
+        weakref.finalize(self, pending.discard, id(self))
+
+    def done(self):
+        self.pending.discard(id(self))
+
+
+def note_pending_backward(layer, out):
+    """`out` of a fused layer forward that saved the layer's bf16 shadows / packs for its backward."""
+    fn = getattr(out, "grad_fn", None)
+    if fn is None:
+        return
+    pend = layer.__dict__.setdefault("_pending_bwd", set())
+    try:
+        fn._mobgt_pending = _PendingBackward(pend)
+    except Exception:                 # (a node that takes no Python attributes: the version check alone then decides)
+        pass
+
+
+def _may_skip_shadow_copy(layer):
+    """Re-deriving the bf16 shadows is skipped on an unchanged version counter ONLY where rewriting them is the wrong thing to do:
+    while a backward pass that saved them is pending (an eval forward between a training forward and its backward: the copy would
+    trip autograd's version check for nothing), or when the owner declared the weights frozen (`layer._weights_frozen = True`: an
+    evaluation loop that does not want 26 MB copied per batch).  Everywhere else the copy is unconditional: a version
+    counter does not see `p.data.add_()` / `p.data.copy_()` (the model's own init_params, many third-party optimizers), raw-pointer
+    writers or an optimizer step replayed inside a captured graph, and skipping there would silently train / evaluate on stale
+    bf16 weights while the fp32 masters move."""
+    return bool(getattr(layer, "_pending_bwd", None)) or bool(getattr(layer, "_weights_frozen", False))
+
+
 def _weights_version(layer):
     """What the bf16 shadows / MFMA-order packs of a layer were derived from: (version counter, address) of each of its GEMM
     parameters.  In-place updates through the parameter (optimizers, load_state_dict, copy_) bump the counter; writes through
-    `.data` or raw pointers do not -- such writers call `sync_external_shadows(model)` / set `layer._shadow_ver = None`."""
+    `.data` or raw pointers do not -- which is why an unchanged version only spares the copy under _may_skip_shadow_copy."""
     mha = layer.self_attention
     ps = (mha.linear_q.weight, mha.linear_k.weight, mha.linear_v.weight, mha.linear_q.bias, mha.linear_k.bias, mha.linear_v.bias,
           mha.output_layer.weight, mha.output_layer.bias, layer.ffn.layer1.weight, layer.ffn.layer1.bias, layer.ffn.layer2.weight,
@@ -320,9 +362,10 @@ def refresh_shadows(layers, defer_pack=False, rows=None):
     """bf16 copies of every layer's GEMM weights in ONE multi-tensor copy (call once per forward).  `defer_pack`: the MFMA-order
     pack is not launched but left for the category GCN's forward launch to carry (take_pending_pack) -- the caller MUST call
     flush_pending_pack() in front of the first consumer of the packs.
-    A layer whose weights have not changed since its shadows were made is left alone: the copy would rewrite tensors that a
-    PENDING backward pass saved (an eval forward between a training forward and its backward: autograd's version check fires --
-    loudly, but for nothing), and an evaluation loop would copy 26 MB per batch for nothing."""
+    A layer whose weights have not changed since its shadows were made is left alone WHILE A BACKWARD PASS THAT SAVED THEM IS
+    PENDING (an eval forward between a training forward and its backward: the copy would rewrite saved tensors and autograd's
+    version check fires -- loudly, but for nothing) or when its owner set `layer._weights_frozen` (evaluation loops);
+    otherwise the copy is unconditional -- see _may_skip_shadow_copy."""
     dst, src = [], []
     for layer in layers:
         if getattr(layer, "act_dtype", torch.float32) == torch.float32 or not layer.fused:
@@ -340,7 +383,7 @@ def refresh_shadows(layers, defer_pack=False, rows=None):
             sh = tuple(torch.empty_like(m, dtype=layer.act_dtype) for m in masters)
             layer._shadows = sh
             layer._shadow_ver = None
-        if getattr(layer, "_shadow_ver", None) != ver:
+        if getattr(layer, "_shadow_ver", None) != ver or not _may_skip_shadow_copy(layer):
             dst += list(sh)
             src += [m.detach() for m in masters]
             layer._shadow_ver = ver

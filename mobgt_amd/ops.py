@@ -500,6 +500,13 @@ _DQ_ACC_RETIRED = []      # accumulators a failed call left in an unknown state:
 def _attn_bwd(q, k, v, out, lse, dout, dq, dk, dv, pack, scale, p_drop, seed, seed_dev):
     G, T, C = q.shape
     H = pack.H
+    #  `lse` is the flat buffer _attn_fwd returns: [G,H,T] f32 rows and, for bf16 I/O, the bf16 residual of `out` behind
+    # them.  A caller-made [G,H,T] tensor (the contract of round 4; mobgt::attention_backward takes any tensor) would make the
+    # kernels read G*T*C bf16 past its end.
+    need = lse_numel(G, H, T, C, q.dtype) if q.dtype == torch.bfloat16 else G * H * T
+    if lse.dtype != torch.float32 or lse.numel() < need:
+        raise ValueError(f"attention backward: `lse` must be the float32 buffer of {need} elements the "
+                         f"forward returned (log-sum-exp rows + the bf16 residual of `out`), got {lse.dtype} x {lse.numel()}")
     dbias = None
     acc = 0
     if pack.needs_grad:

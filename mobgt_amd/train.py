@@ -345,6 +345,7 @@ class TrainStep:
         self.overlap = bool(want_overlap and use_graph and (self.ddp or overlap == "force") and self.n_head > 0
                             and hasattr(model, "_enc_out"))
         self.graphs_b, self._g_enc, self._loss_slots, self.enc_outs = {}, {}, {}, {}
+        self._loss_slots_nocomm = {}
         self._plan_buckets()
         self.one_graph = bool(self.ddp and use_graph and not self.overlap and dist.get_backend() == "nccl"
                               and os.environ.get("MOBGT_DDP_HOST_EXCHANGE") != "1")
@@ -716,15 +717,22 @@ class TrainStep:
         """The whole step of batch i as ONE graph: forward + backward [+ gradient exchange on this stream: `one_graph`] + AdamW."""
         comm = self.one_graph if comm is None else comm
         g = torch.cuda.CUDAGraph()
+        main = comm or not self.one_graph
+        kept = self._loss_slots.get(i)
         with self._capturing(g):
             self._fwd_bwd(self.batches[i], slot=i)
             if comm:
                 self._exchange()
             self._opt_step()
-        if comm or not self.one_graph:
+        if main:
             self.graphs[i] = g
         else:
+            # (ADVICE r5: the no-exchange twin writes its loss into its OWN static tensor -- the main graph's slot keeps pointing at
+            #  the main graph's output, whichever of the two was captured last)
             self.graphs_nocomm[i] = g
+            self._loss_slots_nocomm[i] = self._loss_slots[i]
+            if kept is not None:
+                self._loss_slots[i] = kept
 
     # ---- peer waits that gave up (csrc/chain.hip WS_FAULT, head.hip, smallgcn.hip): detection and recovery ---------------
     def recapture(self):
@@ -808,6 +816,7 @@ class TrainStep:
             else:
                 if j not in self.graphs_nocomm:                 # (bench.py: the same step without its exchange)
                     self._capture_with_opt(j, comm=False)
+                self._loss_ref = self._loss_slots_nocomm[j]     # (the loss of the graph that is replayed)
                 self.graphs_nocomm[j].replay()
             self.sched_state["step_count"] += 1
             self._set_lr()
@@ -873,10 +882,14 @@ class EpochLoop:
     """
 
     def __init__(self, model, collator, dataset, batch_size=16, seed=1, use_graph=True, overlap=True, buckets=None, rank=None,
-                 world=None, shuffle=True, autocast_dtype=None, side_collate=True, balance=None):
+                 world=None, shuffle=True, autocast_dtype=None, side_collate=True, balance=None, balance_window=32):
         """`balance`: deal every step's batches by length over the ranks (`data.balanced_batches`: neighbouring shape buckets on
         all ranks in every synchronous step, the epoch's sample set still DistributedSampler's).  Default: on when there is more
-        than one rank; with one rank the order is the reference's (DistributedSampler order, consecutive batches)."""
+        than one rank; with one rank the order is the reference's (DistributedSampler order, consecutive batches).
+        `balance_window`: the length sort runs inside windows of that many steps of the permuted epoch (default 32: a
+        mega-batch of 32 x world x batch_size i.i.d. samples -- batches stay mixed over the epoch and its long graphs are spread
+        over the windows; DEVIATION from the reference's i.i.d. batches, bounded by the window; None = sort the whole epoch, the
+        tightest balance; balance=False = the reference's sampler order exactly)."""
         from .data import BUCKETS
         self.model, self.collator, self.dataset = model, collator, dataset
         self.batch_size, self.seed, self.shuffle = int(batch_size), int(seed), shuffle
@@ -885,6 +898,7 @@ class EpochLoop:
         self.rank = rank if rank is not None else (dist.get_rank() if ddp else 0)
         self.world = world if world is not None else (dist.get_world_size() if ddp else 1)
         self.balance = (self.world > 1) if balance is None else bool(balance)
+        self.balance_window = balance_window
         self._lengths = None
         self.device = next(model.parameters()).device
         self.copy_stream = torch.cuda.Stream(device=self.device)
@@ -905,7 +919,7 @@ class EpochLoop:
             if self._lengths is None:
                 self._lengths = [len(t["node_name"]) for t in self.dataset]
             steps = balanced_batches(self._lengths, self.world, self.batch_size, epoch=epoch, seed=self.seed, shuffle=self.shuffle,
-                                     buckets=self.buckets)
+                                     buckets=self.buckets, window=self.balance_window)
             return [s[self.rank] for s in steps]
         idx = shard_indices(len(self.dataset), self.rank, self.world, epoch=epoch, seed=self.seed, shuffle=self.shuffle)
         B = self.batch_size

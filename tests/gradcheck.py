@@ -60,9 +60,12 @@ def device_head_pattern(model, batch, enc_out=None, state=None):
     return (pre > 0).cpu(), pre.cpu()
 
 
-def replay_head(pattern, seen=None):
+def replay_head(pattern, seen=None, pre_dev=None):
     """`act` hook for oracle.model_oracle.graphormer_fq_forward: LeakyReLU(0.2) of the head's graph-token rows with the branch of
-    every unit taken from `pattern`; `seen` (dict) collects how many units the oracle alone would have put on the other side."""
+    every unit taken from `pattern`; `seen` (dict) collects, per graph, how many units the oracle alone would have put on the other
+    side and -- key ("pre", g) -- the largest |pre-activation| among them on the oracle's side and (with `pre_dev`, the device's
+    pre-activations from device_head_pattern) on the device's: a replayed unit must sit within the forward's round-off of the
+    kink on BOTH sides, or the replay would follow a wrong device value instead of catching it (assert_replay_bounded)."""
     import torch
 
     def act(site, pre):
@@ -70,6 +73,30 @@ def replay_head(pattern, seen=None):
             return None
         m = pattern[site[1]]
         if seen is not None:
-            seen[site[1]] = int(((pre.detach() > 0) != m).sum())
+            flipped = (pre.detach() > 0) != m
+            seen[site[1]] = int(flipped.sum())
+            big = float(pre.detach().abs()[flipped].max()) if bool(flipped.any()) else 0.0
+            if pre_dev is not None and bool(flipped.any()):
+                big = max(big, float(pre_dev[site[1]].abs()[flipped].max()))
+            seen[("pre", site[1])] = big
         return torch.where(m, pre, 0.2 * pre)
     return act
+
+
+MAX_FLIPPED, MAX_FLIPPED_PRE = 16, 5e-3
+
+
+def n_flipped(seen):
+    return sum(v for k, v in seen.items() if not isinstance(k, tuple))
+
+
+def assert_replay_bounded(seen, max_units=MAX_FLIPPED, max_pre=MAX_FLIPPED_PRE):
+    """The replay may only decide units that are UNDECIDED within the forward's round-off: at most `max_units` of the G x W units of
+    a batch differ between the oracle's own forward and the device's, and each of them has |pre-activation| <= `max_pre` on both
+    sides (bf16 operands: the forward's error on these O(0.3) values is ~1e-3).  A device pre-activation that is wrong by more
+    than that fails here instead of being followed."""
+    n = n_flipped(seen)
+    worst = max([v for k, v in seen.items() if isinstance(k, tuple)] or [0.0])
+    assert n <= max_units, ("LeakyReLU replay: too many head units differ between device and oracle", n)
+    assert worst <= max_pre, ("LeakyReLU replay: a replayed unit is not within round-off of the kink", worst)
+    return n, worst

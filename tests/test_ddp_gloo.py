@@ -177,7 +177,7 @@ def test_epoch_loop_deals_by_length_on_every_rank_alike():
     for rank in range(4):
         lp = EpochLoop.__new__(EpochLoop)                 # (the order needs no device state)
         lp.dataset, lp.rank, lp.world, lp.batch_size, lp.seed, lp.shuffle = data, rank, 4, 16, 5, True
-        lp.balance, lp._lengths = True, None
+        lp.balance, lp._lengths, lp.balance_window = True, None, None
         from mobgt_amd.data import BUCKETS
         lp.buckets = BUCKETS
         loops.append(lp)
@@ -188,3 +188,35 @@ def test_epoch_loop_deals_by_length_on_every_rank_alike():
     one.dataset, one.rank, one.world, one.batch_size, one.seed, one.shuffle, one.balance, one._lengths = data, 0, 1, 16, 5, True, False, None
     idx = shard_indices(403, 0, 1, epoch=1, seed=5)
     assert one.batches_of_epoch(1) == [idx[i:i + 16] for i in range(0, 403, 16)]
+    # the default of a real EpochLoop: the sort inside windows of 32 steps
+    import inspect
+    assert inspect.signature(EpochLoop.__init__).parameters["balance_window"].default == 32
+    loops[2].balance_window = 3
+    assert loops[2].batches_of_epoch(1) == [s[2] for s in balanced_batches(lengths, 4, 16, epoch=1, seed=5, window=3)]
+
+
+def test_windowed_dealing_keeps_batches_mixed_and_the_sample_set():
+    """`balanced_batches(window=w)` (the loop's default, w = 32): the length sort runs inside windows of w steps of the permuted
+    epoch.  (a) same multiset, step count and batch sizes as DistributedSampler; (b) every window is a random sample of the data:
+    the long graphs are spread over the epoch's windows instead of sharing its last steps -- the 64 longest of 4 970 graphs land in
+    at least 4 steps (one or more per window of the 5) at world 4 x batch 16 x window 16, where whole-epoch sorting packs them into ONE step; (c) still
+    balanced: the epoch's wall cost (sum over steps of the slowest rank's padded N^2) stays below half of sampler order's (0.44 here; 0.34 at the
+    loop's default window of 32 steps, 0.22 for the whole-epoch sort, 0.75 at window 4)."""
+    from collections import Counter
+    from mobgt_amd.data import balanced_batches, bucket_nodes
+    world, B, n, w = 4, 16, 4970, 16
+    lengths = _gowalla_lengths(n)
+    padded = lambda ids: max(bucket_nodes(max(lengths[i] for i in ids)), 32)
+    steps = balanced_batches(lengths, world, B, epoch=1, seed=3, window=w, shuffle=True)
+    whole = balanced_batches(lengths, world, B, epoch=1, seed=3, window=None, shuffle=True)
+    ref = Counter(i for rank in range(world) for i in shard_indices(n, rank, world, epoch=1, seed=3))
+    assert Counter(i for s in steps for r in s for i in r) == ref
+    assert len(steps) == len(whole) and sorted(len(s[0]) for s in steps) == sorted(len(s[0]) for s in whole)
+    assert all(len(s) == world and len({len(r) for r in s}) == 1 for s in steps)
+    longest = set(sorted(range(n), key=lambda i: -lengths[i])[:64])
+    hold = lambda st: sum(1 for s in st if any(i in longest for r in s for i in r))
+    assert hold(whole) <= 2 and hold(steps) >= 4, (hold(whole), hold(steps))
+    shards = [shard_indices(n, rank, world, epoch=1, seed=3) for rank in range(world)]
+    wall_plain = sum(max(padded(sh[o:o + B]) for sh in shards) ** 2 for o in range(0, len(shards[0]), B))
+    wall = sum(max(padded(r) for r in s) ** 2 for s in steps)
+    assert wall <= wall_plain / 2, (wall, wall_plain)

@@ -28,7 +28,7 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-from gradcheck import device_head_pattern, replay_head              # noqa: E402
+from gradcheck import assert_replay_bounded, device_head_pattern, n_flipped, replay_head              # noqa: E402
 from mobgt_amd import synth, workloads                              # noqa: E402
 from oracle import model_oracle as mo                                # noqa: E402
 
@@ -138,10 +138,12 @@ def fsq(request):
     model.eval()
     ref = []
     for b in batches:
-        pattern, _ = device_head_pattern(model, b)
+        pattern, pre_dev = device_head_pattern(model, b)
         seen = {}
-        ref.append(oracle_step(sd0, cpu_batch(b), consts, 6, act=replay_head(pattern, seen)))
-        print(f"[{name}] head units the oracle alone puts on the other side of the LeakyReLU kink: {sum(seen.values())} of {pattern.numel()}")
+        ref.append(oracle_step(sd0, cpu_batch(b), consts, 6, act=replay_head(pattern, seen, pre_dev)))
+        #  the replay only decides units within round-off of the kink on BOTH sides: <= 16 units, |pre| <= 5e-3
+        n, worst = assert_replay_bounded(seen)
+        print(f"[{name}] head units the oracle alone puts on the other side of the LeakyReLU kink: {n} of {pattern.numel()}, largest |pre| {worst:.2e}")
     model._workload_name = name
     return uni, model, batches, sd0, ref
 

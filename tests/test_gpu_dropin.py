@@ -147,3 +147,42 @@ def test_mask_with_a_packed_bias_and_without_a_bias():
             ref = mo.multi_head_attention(sd, "A", x, x, x, b_cpu, 8, mask=mask)
             got = mha(x.to(DEV), x.to(DEV), x.to(DEV), b_dev, mask=mask.to(DEV))
             np.testing.assert_allclose(got.cpu().numpy(), ref.numpy(), atol=1e-4, rtol=1e-4)
+
+
+@pytest.mark.parametrize("variant", ["stock", "fq"])
+def test_writes_through_dot_data_reach_the_next_forward(variant):
+    """the bf16 shadow weights / MFMA packs of a fused layer were re-derived only when a parameter's version
+    counter moved -- `p.data.mul_()` / `p.data.copy_()` (the reference's own `init_params`, model.py:30-34; many optimizers) do
+    not move it, and the next forward ran on stale bf16 weights.  Now the copy is unconditional unless a backward that saved the
+    shadows is pending or the owner set `layer._weights_frozen`: a `.data` write between two forwards must show in the second
+    one exactly as in a layer built with the new weights; with the opt-in flag set the old weights stay (documented)."""
+    import copy
+    C, T, G, ffn = 192 if variant == "fq" else 128, 33, 2, 1024
+    seed, x, _, _, n_real = encoder_case(variant, C, T, G)
+    layer = build_layer(variant, C, ffn, seed + 1)
+    layer.act_dtype = torch.bfloat16
+    layer.eval()
+    rng = np.random.RandomState(9)
+    bd = torch.from_numpy(rand_bias(rng, G, 8, T, n_real)).to(DEV)
+    xd = torch.from_numpy(x).to(DEV)
+    with torch.no_grad():
+        y0 = layer(xd, bd).float().clone()
+        for p in (layer.ffn.layer2.weight, layer.self_attention.linear_v.weight, layer.self_attention.output_layer.bias):
+            v0 = p._version
+            p.data.mul_(0.5)                            # version counter untouched
+            assert p._version == v0
+        y1 = layer(xd, bd).float().clone()
+        fresh = copy.deepcopy(layer)
+        for a in ("_shadows", "_packed", "_packed_t", "_shadow_ver", "_packed_ver"):
+            fresh.__dict__.pop(a, None)
+        fresh.self_attention.__dict__.pop("_wqkv", None)
+        y_ref = fresh(xd, bd).float()
+        assert float((y1 - y0).abs().max()) > 1e-2     # the write matters ...
+        assert torch.equal(y1, y_ref)                   # ... and the forward after it is the forward of the new weights
+        layer._weights_frozen = True                    # opt-in: the owner vouches that nothing writes the weights
+        layer.ffn.layer2.weight.data.mul_(2.0)
+        y2 = layer(xd, bd).float()
+        assert torch.equal(y2, y1)
+        layer._weights_frozen = False
+        y3 = layer(xd, bd).float()
+        assert float((y3 - y1).abs().max()) > 1e-2

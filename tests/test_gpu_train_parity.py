@@ -24,7 +24,7 @@ pytestmark = pytest.mark.gpu
 
 from mobgt_amd import ops, workloads                                     # noqa: E402
 from oracle import model_oracle as mo                                     # noqa: E402
-from gradcheck import device_head_pattern, replay_head                  # noqa: E402
+from gradcheck import assert_replay_bounded, device_head_pattern, n_flipped, replay_head                  # noqa: E402
 from test_gpu_bench_parity import GRAD_PARAMS, LOSS_SCALE, bad_rows, check_grad, cpu_batch, oracle_consts   # noqa: E402,F401
 
 DEV = "cuda"
@@ -247,11 +247,12 @@ def test_s_fsq_train_step_with_dropout_on_vs_oracle_with_replayed_masks(name):
         cb = cpu_batch(b)
         # ... and the head's LeakyReLU branch pattern of that very step (tests/gradcheck.py: one of its 16 x 384 units crossing zero
         # inside the forward's round-off moves every gradient by ~1 %; replayed like the dropout masks)
-        pattern, _ = device_head_pattern(model, b, enc_out=ts.enc_outs[i], state=sd0)
+        pattern, pre_dev = device_head_pattern(model, b, enc_out=ts.enc_outs[i], state=sd0)
         seen = {}
         ref_loss = mo.fq_training_loss(sd, cb, consts, n_layers=6, H=8, D=20, p=0.1, p_in=0.1, p_att=0.1, training=True,
-                                       hidden=model.hidden_dim, drop=_drop_hook(masks), act=replay_head(pattern, seen))
-        print("head units the oracle alone puts on the other side of the LeakyReLU kink:", sum(seen.values()), "of", pattern.numel())
+                                       hidden=model.hidden_dim, drop=_drop_hook(masks), act=replay_head(pattern, seen, pre_dev))
+        n, worst = assert_replay_bounded(seen)          # <= 16 replayed units, each within 5e-3 of the kink on both sides
+        print("head units the oracle alone puts on the other side of the LeakyReLU kink:", n, "of", pattern.numel(), "largest |pre| %.2e" % worst)
         (ref_loss * LOSS_SCALE).backward()
         print("batch %d  loss hip %.7f  oracle %.7f" % (i, loss, float(ref_loss)))
         np.testing.assert_allclose(loss, float(ref_loss), rtol=3e-3)
