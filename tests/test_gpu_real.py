@@ -114,3 +114,96 @@ def test_fq_graphormer_329_node_real_trajectory_logits_g8(g8, real_model):
     np.testing.assert_allclose(bias[fin], ref[fin], rtol=1e-5, atol=1e-4)
     np.testing.assert_allclose(out[0].cpu().numpy(), z["b/logits"], rtol=2e-4, atol=2e-4)
     np.testing.assert_allclose(out[1].cpu().numpy(), z["b/cat_logits"], rtol=2e-4, atol=2e-4)
+
+
+def test_benched_bf16_configuration_on_the_real_batch_vs_oracle_g8(g8):
+    """the configuration bench.py TIMES (bf16 bias / GCN adjacency product / GEMM-facing activations, bf16 MFMA
+    operands) on the real Gowalla batch A of G8, with stated bounds.  The comparison partner is the oracle on the same real batch
+    (pinned to G8's logits / loss / gradients at 2e-4 / 1e-5 / 5e-3 by tests/test_oracle_real.py) rather than the fixture itself,
+    because the head's LeakyReLU branch pattern must be replayed (tests/gradcheck.py: bounded -- <= 16 units, each within 5e-3 of
+    the kink on both sides), which a stored gradient cannot do.
+
+    What bf16 operands cost here (tools/g8_bf16_stages.py, profiles/r6_g8_bf16_stages.txt): every rounding point of a layer adds
+    0.15-0.2 % relative L2 (xa 0.17 %, qkv 0.28 %, a 0.25 %, x1 0.30 %, z 0.34 %, u 0.41 %, h 0.47 %, x2 / out 0.49 %), layers add up
+    in quadrature (0.50 % after layer 0 ... 0.99 % after layer 5), logits 1.1 % relative L2.  The absolute logit error (0.070) is
+    larger than on the synthetic batches (3-7e-3) because G8's seeded weights give logits up to 5.06 (rms 1.33) where the
+    default-initialised S-FSQ model's are O(0.1): the RELATIVE error is the same.
+
+    Bounds (measured in round 6 with the head pattern replayed, in brackets): logits relative L2 <= 2 % [1.10 %] and
+    max |err| <= 2e-2 x max |logit| [0.070 on 5.06 = 1.4e-2]; loss 1e-3 [1.9e-4]; gradients by relative L2, elementwise bound
+    and exact zero pattern:
+      * <= 4 % for every parameter that is not listed below [0.5-1.6 % for the 100+ layer / head / GCN / fuse tensors; 2.8 % on
+        the distance GCN's second layer and 3.6 % on the two GCNs' FIRST layers, whose input is the raw, un-normalised POI
+        feature matrix (check-in counts next to latitudes: model_fqandtoyo.py:650-700)];
+      * <= 6 % for linear_q / linear_k (weight and bias) [2.7-5.4 %]: these gradients are 100-1000 x smaller than linear_v's
+        (rms 2e-6 ... 5e-5 against 1e-3: every node of a trajectory carries the same user embedding, the scores barely depend on q
+        and k) and live on sum_j dS_ij = 0.  A CPU emulation of the attention kernels' rounding points inside the oracle with
+        everything else in fp32 (round 5's scratch emulation, re-run in round 6) gives 0.7-2.5 % for them from the attention's bf16
+        operands alone; centring K per (graph, head) before its rounding, error-feedback rounding of dS along the key axis and
+        unrounded dq / dk / dv were tried there and move nothing (+-0.3 %): the rest is the bf16 rounding of the layers' other
+        GEMM operands reaching a heavily cancelled quantity.  VERDICT r5 asked for <= 3 %: NOT met on these;
+      * <= 8 % for the small cancelling tables (rel_pos / poi_pos / time slots / virtual distance) [2.9-6.7 %], <= 12 % for the
+        two edge tables [3.6 %; 7.3-7.8 % on the long batch of tests/test_gpu_long_parity.py, where the mechanism is spelled
+        out]."""
+    from gradcheck import assert_replay_bounded, device_head_pattern, replay_head
+    from mobgt_amd.model_fqandtoyo import Graphormer
+    from oracle import model_oracle as mo
+    from test_gpu_bench_parity import LOSS_SCALE, SMALL_TABLES, check_grad
+    from test_oracle_real import _collate
+    z, uni, table = g8
+    m = Graphormer(n_layers=6, num_heads=8, hidden_dim=128, dropout_rate=0.1, intput_dropout_rate=0.1, weight_decay=0.01,
+                   ffn_dim=1024, dataset_name="gowalla_nevda", warmup_updates=10, tot_updates=100, peak_lr=2e-4, end_lr=1e-9,
+                   edge_type="multi_hop", multi_hop_max_dist=20, attention_dropout_rate=0.1, universe=uni,
+                   bias_dtype=torch.bfloat16, gcn_dtype=torch.bfloat16, act_dtype=torch.bfloat16)
+    names = [str(n) for n in z["param_names"]]
+    shapes = [eval(str(s)) for s in z["param_shapes"]]
+    sd0 = {k: v.detach() for k, v in seeded_state(list(zip(names, shapes)), int(z["seed"])).items()}
+    m.load_state_dict(sd0, strict=True)
+    m = m.to(DEV).eval()
+    b = DeviceCollator(DEV, bin_table=table, multi_hop_max_dist=20, rel_pos_max=1024)(real_trajs(z, "a"))
+    pattern, pre_dev = device_head_pattern(m, b)
+    # ---- oracle on the same real batch, the device's head pattern imposed
+    consts = mo.fq_constants(uni, "gowalla_nevda", num_bins=int(z["num_bins"]))
+    sd = {k: v.detach().float().clone().requires_grad_(True) for k, v in sd0.items()}
+    cb = _collate(z, uni, "a")
+    seen = {}
+    ref_logits, _ = mo.graphormer_fq_forward(sd, cb, consts, n_layers=6, H=8, D=20, act=replay_head(pattern, seen, pre_dev))
+    print("head pre-activations: rms %.3f" % float(pre_dev.pow(2).mean().sqrt()), {k: v for k, v in seen.items() if v})
+    n, worst = assert_replay_bounded(seen, pre_dev=pre_dev)           # (G8's seeded weights: pre-activations of rms ~1)
+    print("replayed head units: %d of %d, largest |pre| %.2e" % (n, pattern.numel(), worst))
+    ref_loss = mo.gradient_tail_loss(ref_logits, cb.y - 1, 0.2)
+    (ref_loss * LOSS_SCALE).backward()
+    # (the replay moves the oracle off the golden only by the replayed units' 0.8 |pre| <= 4e-3 each)
+    np.testing.assert_allclose(ref_logits.detach().numpy(), z["a/logits"], atol=2e-2)
+    # ---- device, benched configuration
+    out = m(b)[0].detach().float().cpu()
+    r = ref_logits.detach()
+    rel = float((out - r).double().norm() / r.double().norm())
+    err, top = float((out - r).abs().max()), float(r.abs().max())
+    print("logits: relative L2 %.4f  max|err| %.4f  max|ref| %.3f  rms %.3f" % (rel, err, top, float(r.pow(2).mean().sqrt())))
+    assert rel <= 2e-2 and err <= 2e-2 * top, (rel, err, top)
+    for p in m.parameters():
+        p.grad = None
+    loss = m.training_step(b, 0)
+    print("loss %.7f  oracle %.7f" % (float(loss), float(ref_loss)))
+    np.testing.assert_allclose(float(loss), float(ref_loss), rtol=1e-3)
+    loss.backward()
+    report = []
+    for k, p in m.named_parameters():
+        if sd[k].grad is None or p.grad is None or k.endswith("linear_k.bias"):
+            continue
+        check_grad(k, p.grad, sd[k].grad / LOSS_SCALE, report)
+    for row in report:
+        print("%-48s rms_nz %.3e  relL2 %.4f  q999 %.3f  max %.3f  stray %.1e" % row)
+    assert len(report) > 100
+
+    def lim(name):
+        if name.startswith("edge_"):
+            return 0.12
+        if name.split(".")[0] in SMALL_TABLES:
+            return 0.08
+        return 0.06 if (".linear_q." in name or ".linear_k." in name) else 0.04
+    loose = lambda nm: nm.split(".")[0] in SMALL_TABLES or ".linear_q." in nm or ".linear_k." in nm
+    bad = [row for row in report if row[2] > lim(row[0]) or row[5] > 1e-3 * row[1]
+           or (not loose(row[0]) and (row[3] > 1.5 or row[4] > 6.0))]
+    assert not bad, bad

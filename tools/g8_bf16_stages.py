@@ -86,3 +86,34 @@ for name in ["f32"] + [v for v in only if v != "f32"]:
                 float(w.abs().max())))
     else:
         print("f32 configuration vs golden logits: max|err| %.3e" % float((rec["logits"] - rec["golden logits"]).abs().max()))
+
+# ---- inside layer 0: which rounding point carries the error?  (the fused node's saved tensors, f32 against bf16 configuration)
+print("==== inside layer 0 (saved tensors of the fused node): bf16 against f32 configuration")
+saved = {}
+for name in ("f32", "bf16"):
+    kw = VARIANTS[name]
+    m = Graphormer(n_layers=6, num_heads=8, hidden_dim=128, dropout_rate=0.1, intput_dropout_rate=0.1, weight_decay=0.01,
+                   ffn_dim=1024, dataset_name="gowalla_nevda", warmup_updates=10, tot_updates=100, peak_lr=2e-4, end_lr=1e-9,
+                   edge_type="multi_hop", multi_hop_max_dist=20, attention_dropout_rate=0.1, universe=uni, **kw)
+    m.load_state_dict(sd, strict=True)
+    m = m.cuda().eval()
+    b = DeviceCollator("cuda", bin_table=table)(real_trajs(z, "a"))
+    from mobgt_amd import fused_layer
+    fused_layer._CHAIN[0] = False              # separate launches: every intermediate is materialised
+    from mobgt_amd.model import refresh_shadows
+    pack = m.assemble_bias(b)
+    x0 = stages["f32"]["tokens x0"].cuda().requires_grad_(True)       # the SAME input for both
+    refresh_shadows(m.layers)
+    out = m.layers[0](x0, pack)
+    names = ("x", "xa", "qkv", "a", "lse", "x1", "z", "u", "h", "x2")
+    saved[name] = {k: (None if t is None else t.detach().float().cpu()) for k, t in zip(names, out.grad_fn.saved_tensors)}
+    saved[name]["out"] = out.detach().float().cpu()
+    fused_layer._CHAIN[0] = True
+for k, w in saved["f32"].items():
+    v = saved["bf16"].get(k)
+    if w is None or v is None or k == "lse" or v.shape != w.shape:
+        continue
+    d = (v - w).double()
+    print("%-6s relL2 %.5f  max|err| %.4e  rms(ref) %.4e  max|ref| %.4e   row-mean rms %.4e" % (
+        k, float(d.norm() / w.double().norm().clamp_min(1e-30)), float(d.abs().max()), float(w.double().pow(2).mean().sqrt()),
+        float(w.abs().max()), float(w.double().mean(-1).pow(2).mean().sqrt())))
