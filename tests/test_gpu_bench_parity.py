@@ -74,14 +74,13 @@ MAX_REL_L2, K_RMS, KINK = 3e-2, 0.13, 4.0       # (round 3: tightened from 4e-2 
 
 
 # Tables with fewer than 2 000 entries (the bias tables, the 48-slot time embedding) are judged by the MAXIMUM of the elementwise
-# ratio, not by a 99.9 % quantile, and their gradients are the smallest of the model (rms 4e-7 .. 6e-6 against 1e-5 .. 2e-4
-# elsewhere: sums over all pairs of all graphs that cancel almost completely), so the statistic is the extreme value of a few
-# hundred noise-dominated entries.  Round 4: with the distance GCN as three launches (exact f32 row scales instead of the dense
-# adjacency's bf16 entries; closer to float64 in tests/test_gpu_distgcn.py) batch 1 of the S-FSQ fixture moved from 0.32-0.70 to
-# 1.06-1.49 on rel_pos / poi_pos / edge_dis / time_embed, at relative L2 1.2-2.2 % -> 2.0-2.8 % (gate 3 %), while two runs of ONE
-# path already differ by 0.1-0.5 % relative L2 there (tools/dbg/r4_distgcn_probe.py).  The maximum of such a table is gated at
-# 1.6 (0.21 rms + 0.08 |ref|); the 99.9 % quantile of the large tensors stays at 1.0.
-SMALL_TABLE_MAX = 1.6
+# ratio, not by a 99.9 % quantile.  Round 4 had widened that maximum to 1.6 for all of them; with the head's LeakyReLU pattern
+# replayed (round 5) the bias tables sit at 0.06-0.56 and are back at 1.0 (round 6).  ONE table keeps an
+# allowance, justified by what it is: `time_embed_model_48.weight` -- its gradient has rms 4e-7, 50-500 x below every other
+# gradient of the model (1.7e-6 ... 2.3e-4: a 48 x 32 table reached through FuseEmbeddings by every node of every graph, its rows'
+# contributions cancelling almost completely), so the worst of its ~1 500 entries is the extreme value of round-off noise at
+# relative L2 2.0 %: measured 1.51-1.53 on batch 0 of the S-FSQ fixture, eager and replayed alike; gate 1.6 (0.21 rms + 0.08 |ref|).
+SMALL_TABLE_MAX = {"time_embed_model_48.weight": 1.6}
 _LIMIT = {}
 
 
@@ -95,7 +94,7 @@ def check_grad(name, got, ref, report):
     ratio = err[nz] / (K_RMS * rms + 0.05 * np.abs(ref[nz])) if nz.any() else np.zeros(1)
     worst = float(np.quantile(ratio, 0.999)) if ratio.size >= 2000 else float(ratio.max())
     stray = float(np.abs(got[~nz]).max()) if (~nz).any() else 0.0      # where the reference has exactly 0
-    _LIMIT[name] = 1.0 if ratio.size >= 2000 else SMALL_TABLE_MAX
+    _LIMIT[name] = 1.0 if ratio.size >= 2000 else SMALL_TABLE_MAX.get(name, 1.0)
     row = (name, rms, rel_l2, worst, float(ratio.max()), stray)
     report.append(row)
     return not bad_rows([row])
