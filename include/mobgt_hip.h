@@ -396,6 +396,20 @@ int mobgt_stock_tail_bwd(const float* dy, const void* x, const void* in_degree, 
  * aligned): the sums over the library's split-K partial weight gradients ([s, M, N] from torch.bmm over row slices --
  * fused_layer._mm_tn_f32), deferred to the end of the backward pass and written into the gradients' sinks. */
 int mobgt_partial_sum_multi(int n, const float* const* src, float* const* dst, const int* s, const int64_t* numel, void* stream);
+/* Round 6: the weight gradients of one encoder layer past 4 096 rows in ONE launch -- autograd of the layer's F.linear calls
+ * (graphormer/model.py:436-438 linear_q/k/v, :455 output_layer, :393-405 ffn layer1 / layer2; fq: model_fqandtoyo.py:1687-1712):
+ *     part[i][s] = G_i[rows of range s]^T X_i[rows of range s]        i < n <= 4 products, s < S row ranges
+ * G_i [R, M_i] (row stride ldg[i]) = the gradient of the Linear's output, X_i [R, N_i] (ldx[i]) = its input, both bf16 row-major;
+ * part[i]: [S, M_i, N_i] f32, fully overwritten (the sum over s is the weight gradient: mobgt_partial_sum_multi, or any
+ * reduction of the caller's); colsum (or colsum[i]) may be NULL, else [M_i] f32 that receives += column sums of G_i (the bias
+ * gradient) by atomics -- zero it first.  M_i, N_i, ldg, ldx multiples of 8, pointers 16-byte aligned, S <= ceil(R / 64).
+ * Output tiles of 128 x 256 on v_mfma_f32_32x32x16_bf16, operands staged as they lie in memory and read transposed
+ * (ds_read_b64_tr_b16).  mobgt_layer_wgrad_big_tiles(M, N): tiles of one product; mobgt_layer_wgrad_big_splits(R, ntiles): the S
+ * that gives about one workgroup per compute unit. */
+int mobgt_layer_wgrad_big(int n, const void* const* g, const int64_t* ldg, const void* const* x, const int64_t* ldx,
+                          float* const* part, float* const* colsum, const int* M, const int* N, int64_t R, int S, void* stream);
+int mobgt_layer_wgrad_big_tiles(int M, int N);
+int mobgt_layer_wgrad_big_splits(int64_t R, int ntiles);
 /* final_ln on the graph-token rows (model.py:211-217: the reference normalises every token, then reads row 0 of every graph):
  * y [G,C] = LayerNorm(enc[g,0,:]; ln_w, ln_b, eps), mean / rstd [G] kept for the backward (csrc/layer.hip).  enc [G,T,C] f32
  * contiguous, C <= 1024.

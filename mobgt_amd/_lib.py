@@ -47,6 +47,9 @@ SIGNATURES = {
     "mobgt_gelu_bwd_colsum": (_i, [_vp, _vp, _vp, _vp, _i64, _i, _i, _vp]),
     "mobgt_stock_tokens_fwd": (_i, [_vp, _vp, _vp, _i, _i] + [_vp] * 5 + [_i, _i, _i, _i64, _i64, _i64, _f, _u64, _vp, _c.c_uint32, _vp]),
     "mobgt_partial_sum_multi": (_i, [_i, _vp, _vp, _vp, _vp, _vp]),
+    "mobgt_layer_wgrad_big": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _vp]),
+    "mobgt_layer_wgrad_big_tiles": (_i, [_i, _i]),
+    "mobgt_layer_wgrad_big_splits": (_i, [_i64, _i]),
     "mobgt_stock_tail_bwd": (_i, [_vp, _vp, _vp, _vp, _i, _i] + [_vp] * 4 + [_i, _i, _i, _i64, _i64, _i64, _i64, _f, _u64, _vp, _c.c_uint32]
                              + [_vp] * 5 + [_i, _i, _i, _i] + [_vp]),
     "mobgt_stock_front_fwd": (_i, [_vp, _vp, _vp, _i, _i] + [_vp] * 5 + [_i, _i, _i, _i64, _i64, _i64, _f, _u64, _vp, _c.c_uint32]

@@ -193,7 +193,8 @@ _LN_GEMM_BWD = [_os_ln.environ.get("MOBGT_LN_GEMM_BWD") == "1"]
 # csrc/chain.hip: out-proj -> LN -> FFN -> LN -> the next layer's QKV in one launch (MOBGT_NO_CHAIN=1: the separate launches)
 _CHAIN = [_os_ln.environ.get("MOBGT_NO_CHAIN") != "1"]
 _CHAIN_BIG = [_os_ln.environ.get("MOBGT_NO_CHAIN_BIG") != "1"]      # ... past 4 096 rows: the 64-row forward chain (else the library's GEMMs)
-_CHAIN_BWD = [_os_ln.environ.get("MOBGT_NO_CHAIN_BWD") != "1"]      # ... and the same chain backwards (d(out) -> d(attention out))
+_CHAIN_BWD = [_os_ln.environ.get("MOBGT_NO_CHAIN_BWD") != "1"]
+_WGRAD_BIG = [_os_ln.environ.get("MOBGT_NO_WGRAD_BIG") != "1"]      # past 4 096 rows: the layer's weight gradients as one launch (csrc/wgradbig.hip)      # ... and the same chain backwards (d(out) -> d(attention out))
 
 
 # ---- what a layer's backward may leave to the backward of the layer BELOW it --------------------------------------------------
@@ -667,10 +668,19 @@ class _FusedLayerFn(torch.autograd.Function):
                 if not db1_in_wgrad:
                     check(_lib.lib().mobgt_colsum(_p(du), _p(db1), R, F, act, _stream()), "mobgt_colsum")
             da = da.view(G, T, C)
-            dw2 = wb.add(df, h, sink=k_w2)
-            dw1 = wb.add(du, z, db=db1 if db1_in_wgrad else None, sink=k_w1)
-            dwo = wb.add(dy, a.view(R, C), sink=k_wo)
+            big_items = None
+            if R > 4096 and _WGRAD_BIG[0] and A == torch.bfloat16 and not db1_in_wgrad:
+                # past 4 096 rows: all four weight gradients of the layer (and dbqkv) as ONE launch behind the attention backward
+                # (csrc/wgradbig.hip, round 6; before: three library split-K GEMMs, the grouped kernel for dWo, a column-sum launch)
+                big_items = [(df, h, None, k_w2), (du, z, None, k_w1), (dy, a.view(R, C), None, k_wo)]
+                if not ops.layer_wgrad_big_ok(big_items):
+                    big_items = None
+            if big_items is None:
+                dw2 = wb.add(df, h, sink=k_w2)
+                dw1 = wb.add(du, z, db=db1 if db1_in_wgrad else None, sink=k_w1)
+                dwo = wb.add(dy, a.view(R, C), sink=k_wo)
         else:
+            big_items = None
             da, dx1, dw2, dw1, dwo = _FusedLayerFn._bwd_launches(ctx, cfg, wb, dout, x1, z, u, h, x2, a, stats, s_wo, s_w1, s_w2,
                                                                 n1w, nxw, dbo, db1, db2, dn1w, dn1b, dnxw, dnxb, G, T, C, F, A,
                                                                 act, dev, own, stock, db1_in_wgrad)
@@ -679,7 +689,12 @@ class _FusedLayerFn(torch.autograd.Function):
         ops._attn_bwd(q, k, v, a, lse, da, dqkv[..., :C], dqkv[..., C:2 * C], dqkv[..., 2 * C:], cfg.pack, cfg.scale,
                       cfg.p_att, seed ^ (salt * 0x9E3779B1), sd)
         dqkv2 = dqkv.view(R, 3 * C)
-        dwqkv = wb.add(dqkv2, xa, db=dbqkv, sink=k_qkv)
+        if big_items is not None and ops.layer_wgrad_big_ok([(dqkv2, xa.view(R, C), dbqkv, k_qkv)]):
+            dw2, dw1, dwo, dwqkv = ops.layer_wgrad_big(big_items + [(dqkv2, xa.view(R, C), dbqkv, k_qkv)], R)
+        else:
+            if big_items is not None:
+                dw2, dw1, dwo = ops.layer_wgrad_big(big_items, R)
+            dwqkv = wb.add(dqkv2, xa, db=dbqkv, sink=k_qkv)
         defer = (_DEFER[0] and getattr(ctx, "below_hosts", False) and own and not stock and _TAIL[0] and len(wb.items) == 4
                  and R <= _DEFER_MAX_R[0] and dx1.data_ptr() % 16 == 0 and dqkv2.is_contiguous() and ctx.small_sink is not None
                  and all(k is not None for k in ctx.sinks))

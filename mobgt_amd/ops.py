@@ -1953,6 +1953,39 @@ def defer_partial_sum(part, dst):
     return dst[:]
 
 
+def layer_wgrad_big(items, R):
+    """The weight gradients of one encoder layer past 4 096 rows as ONE launch (csrc/wgradbig.hip, mobgt_layer_wgrad_big):
+    items = [(g [R, M] bf16, x [R, N] bf16, db [M] f32 zero-filled or None, sink or None)], at most four -> [dW [M, N] f32].
+    The launch leaves split-K partial products [S, M, N]; inside a train step their sums are parked for the step's one
+    reduction launch into the gradients' sinks (defer_partial_sum), else they are summed here."""
+    lib = _lib.lib()
+    n = len(items)
+    vp, i64, ci = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int
+    tiles = sum(lib.mobgt_layer_wgrad_big_tiles(g.shape[1], x.shape[1]) for g, x, _, _ in items)
+    S = lib.mobgt_layer_wgrad_big_splits(R, tiles)
+    dev = items[0][0].device
+    parts = [torch.empty(S, g.shape[1], x.shape[1], dtype=torch.float32, device=dev) for g, x, _, _ in items]
+    check(lib.mobgt_layer_wgrad_big(n, (vp * n)(*[t[0].data_ptr() for t in items]), (i64 * n)(*[t[0].stride(0) for t in items]),
+                                    (vp * n)(*[t[1].data_ptr() for t in items]), (i64 * n)(*[t[1].stride(0) for t in items]),
+                                    (vp * n)(*[q.data_ptr() for q in parts]),
+                                    (vp * n)(*[(t[2].data_ptr() if t[2] is not None else None) for t in items]),
+                                    (ci * n)(*[t[0].shape[1] for t in items]), (ci * n)(*[t[1].shape[1] for t in items]), R, S,
+                                    _stream()), "mobgt_layer_wgrad_big")
+    outs = []
+    for part, (_, _, _, sink) in zip(parts, items):
+        parked = defer_partial_sum(part, sink) if sink is not None else None
+        outs.append(parked if parked is not None else part.sum(0))
+    return outs
+
+
+def layer_wgrad_big_ok(items):
+    return (1 <= len(items) <= 4 and all(
+        g.dtype == torch.bfloat16 and x.dtype == torch.bfloat16 and g.dim() == 2 and x.dim() == 2 and g.shape[0] == x.shape[0]
+        and g.stride(1) == 1 and x.stride(1) == 1 and g.shape[1] % 8 == 0 and x.shape[1] % 8 == 0 and g.stride(0) % 8 == 0
+        and x.stride(0) % 8 == 0 and g.data_ptr() % 16 == 0 and x.data_ptr() % 16 == 0
+        and g.shape[0] * g.stride(0) * 2 < (1 << 31) and x.shape[0] * x.stride(0) * 2 < (1 << 31) for g, x, _, _ in items))
+
+
 def _wgrad_defer(g, x, g_mask, x_mask, mask_vals, dw, db, db_of_x):
     _WGRAD_DEFER["items"].append((g, x, g_mask, x_mask, tuple(float(v) for v in mask_vals), dw, db, bool(db_of_x)))
     return dw[:]

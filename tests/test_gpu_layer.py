@@ -1291,3 +1291,38 @@ def test_preln_layer_chain_kernel_matches_the_separate_launches(C, G, T, p):
         if n.endswith("linear_k.bias"):
             continue                                      # exactly zero in exact arithmetic: round-off only
         close(ga[n], gb[n], n)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("R,C,F", [(12560, 256, 1024), (4710, 256, 1024), (13040, 192, 1024), (4411, 128, 1024), (4200, 256, 1024)])
+def test_long_batch_weight_gradients_in_one_launch_match_fp32(R, C, F):
+    """csrc/wgradbig.hip, mobgt_layer_wgrad_big (round 6): the four weight gradients of an encoder layer past 4 096 rows --
+    dWqkv = dqkv^T xa (with dbqkv = column sums of dqkv), dWo = dy^T a, dW1 = du^T z, dW2 = df^T h (autograd of F.linear,
+    model.py:393-405, 436-455) -- as ONE launch of 128 x 256 output tiles over S row ranges, against fp32 torch on the same
+    bf16 operands.  The products of bf16 values are exact in f32; the sums over up to 13 040 rows differ by summation order only:
+    |err| <= 2e-5 x the largest |entry| (measured ~2e-6).  Shapes: S-BIG (all tiles full), 4 710 rows (ragged last chunk: 38
+    rows), C = 192 (S-GOW's tail batch: ragged M = 576 / N = 192 tiles), C = 128, and a strided G (dq | dk | dv as one [R, 3C]
+    row-major block, which is what the layer hands over)."""
+    from mobgt_amd import ops
+    torch.manual_seed(R + C)
+    bf = dict(dtype=torch.bfloat16, device=DEV)
+    dqkv, xa = torch.randn(R, 3 * C, **bf), torch.randn(R, C, **bf)
+    dy, a = torch.randn(R, C, **bf), torch.randn(R, C, **bf)
+    du, z = torch.randn(R, F, **bf) * 0.5, torch.randn(R, C, **bf)
+    df, h = torch.randn(R, C, **bf), torch.randn(R, F, **bf).abs()
+    dbqkv = torch.zeros(3 * C, device=DEV)
+    items = [(df, h, None, None), (du, z, None, None), (dy, a, None, None), (dqkv, xa, dbqkv, None)]
+    assert ops.layer_wgrad_big_ok(items)
+    outs = ops.layer_wgrad_big(items, R)
+    torch.cuda.synchronize()
+    for (g, x, db, _), got in zip(items, outs):
+        want = g.float().t() @ x.float()
+        assert got.shape == want.shape and got.dtype == torch.float32
+        err, top = float((got - want).abs().max()), float(want.abs().max())
+        assert err <= 2e-5 * top, (tuple(want.shape), err, top)
+    want_db = dqkv.float().sum(0)
+    assert float((dbqkv - want_db).abs().max()) <= 2e-5 * float(want_db.abs().max()) + 1e-3
+    # column views of a wider row-major block as G (row stride 3C): the q third alone
+    part = ops.layer_wgrad_big([(dqkv[:, C:2 * C], xa, None, None)], R)[0]
+    want = dqkv[:, C:2 * C].float().t() @ xa.float()
+    assert float((part - want).abs().max()) <= 2e-5 * float(want.abs().max())
