@@ -166,11 +166,15 @@ class Graphormer(nn.Module):
                  universe=None, num_bins=None, bias_dtype=torch.float32, gcn_dtype=torch.float32,
                  act_dtype=torch.float32, fused_layers=True):
         super().__init__()
-        if dataset_name not in ("foursquaregraph", "gowalla_nevda", "gowalla_7day"):
+        if dataset_name not in ("foursquaregraph", "gowalla_nevda", "gowalla_7day", "toyotagraph"):
             raise NotImplementedError(f"dataset_name={dataset_name!r}: only the POI-graph datasets are in scope")
         if edge_type != "multi_hop":
             raise NotImplementedError("only edge_type='multi_hop' is used by MobGT (README.md:62)")
         fsq = dataset_name == "foursquaregraph"
+        # `toyotagraph` (model_fqandtoyo.py:902-1039; README.md:72-83): the gowalla-style body with 995 + 1 user rows, a plain
+        # 48-slot time table (no padding row), no cat_embed_model, a num_cats-way category head, a log_softmax POI head
+        # (:1417-1428) and loss = GradientTailLoss(category logits, category of the target, 0.1) + NLLLoss(ignore_index=0) (:1462-1471)
+        toyota = dataset_name == "toyotagraph"
         self.num_virtual_tokens = 1
         self.num_heads = num_heads
         self.dataset_name = dataset_name
@@ -249,7 +253,7 @@ class Graphormer(nn.Module):
         self.fuse_embed = nn.Linear(2 * hidden_dim, hidden_dim)                                                  # unused
         self.user_embed_dim = self.poi_embed_dim = hidden_dim
         self.time_embed_dim = self.cat_embed_dim = 32
-        self.num_users = 937 if dataset_name == "gowalla_7day" else 1080
+        self.num_users = 937 if dataset_name == "gowalla_7day" else (996 if toyota else 1080)     # (:1002: UserEmbeddings(995 + 1))
         self.poi_distance_model = GCN(ninput=self.gcn_nfeat, nhid=self.gcn_nhid, noutput=hidden_dim, dropout=0.3)
         if getattr(self, "_d_ax_pad", 0):
             # the first layer's weight gradient is computed with the rows of zero products of the padded A X: room for them behind
@@ -258,11 +262,12 @@ class Graphormer(nn.Module):
             w0._mobgt_flat_slack = self._d_ax_pad * w0.shape[1]
         self.poi_cat_model = GCN(ninput=C_X.shape[1], nhid=self.gcn_nhid, noutput=self.cat_embed_dim, dropout=0.1)
         self.user_embed_model = UserEmbeddings(self.num_users, self.user_embed_dim)
-        self.time_embed_model_48 = nn.Embedding(48 + 1 if fsq else 48, self.time_embed_dim, padding_idx=0)
-        self.cat_embed_model = CategoryEmbeddings(num_cats if fsq else num_cats + 1, self.cat_embed_dim)        # unused
+        self.time_embed_model_48 = nn.Embedding(48 + 1 if fsq else 48, self.time_embed_dim, padding_idx=None if toyota else 0)
+        if not toyota:
+            self.cat_embed_model = CategoryEmbeddings(num_cats if fsq else num_cats + 1, self.cat_embed_dim)    # unused
         C = hidden_dim + self.time_embed_dim + self.cat_embed_dim
         Cout = hidden_dim * 2 + self.time_embed_dim + self.cat_embed_dim
-        self.cat_decoder = nn.Linear(Cout, num_cats if fsq else num_cats + 1)
+        self.cat_decoder = nn.Linear(Cout, num_cats if (fsq or toyota) else num_cats + 1)
         self.embed_fuse_model1 = FuseEmbeddings(self.user_embed_dim, self.poi_embed_dim)                         # unused
         self.embed_fuse_model2 = FuseEmbeddings(self.poi_embed_dim, self.time_embed_dim)
         self.embed_fuse_model3 = FuseEmbeddings(self.user_embed_dim, C)
@@ -388,7 +393,7 @@ class Graphormer(nn.Module):
                 [(poidist, poi_idx, 0, 0, False, None)] +
                 # (round 4: the distance GCN's output may arrive as partial tables -- modelGNN._DistGcnFn -- added here, in order)
                 [(part, poi_idx, 0, 0, 2, None) for part in getattr(poidist, "_mobgt_parts", ())] +
-                [(self.time_embed_model_48.weight, time_idx, 0, Wp, False, 0),
+                [(self.time_embed_model_48.weight, time_idx, 0, Wp, False, self.time_embed_model_48.padding_idx),
                  (catemb, cat_idx, 1, Wp + Wt, False, None),
                  (self.fre_embed_model.weight, zero_idx, 2, 0, False, 0), (self.in_degree_encoder.weight, in_deg, 2, 0, True, 0),
                  (self.out_degree_encoder.weight, out_deg, 2, 0, True, 0), (self.pos_embed.pe, pos_idx, 2, 0, True, None)],
@@ -410,7 +415,8 @@ class Graphormer(nn.Module):
         else:
             # many positions (S-BIG: 12.5 k rows): the separate gathers, whose backward combines runs of equal indices in
             # registers (scatter_add_runs_kernel) instead of serialising thousands of atomics on a handful of degree rows
-            pt = ops.embed_gather_concat([poidist, self.time_embed_model_48.weight], [poi_idx, time_idx], padding_idx=[None, 0])
+            pt = ops.embed_gather_concat([poidist, self.time_embed_model_48.weight], [poi_idx, time_idx],
+                                         padding_idx=[None, self.time_embed_model_48.padding_idx])
             f2 = ops.linear_splitk(pt, self.embed_fuse_model2.fuse_embed.weight, self.embed_fuse_model2.fuse_embed.bias,
                                    self.act_dtype == torch.bfloat16, slope=self.embed_fuse_model2.leaky_relu.negative_slope)
             nf = f4(f2, ops.embed_gather_sum([catemb], [cat_idx]))
@@ -527,7 +533,8 @@ class Graphormer(nn.Module):
             tok = ops.dropout(self.ELU(self.final_ln(tok)), self.output_dropout.p, self.training, 0x1004)   # :1360-1364
         ops.trace_nan("tok", tok)
         y_head = getattr(self, "_loss_in_head", None)
-        if y_head is not None and ops.skinny_linear_gtl_ok(tok, self.out_proj.weight):
+        toyota = self.dataset_name == "toyotagraph"
+        if y_head is not None and not toyota and ops.skinny_linear_gtl_ok(tok, self.out_proj.weight):
             # training_step: the classifier and GradientTailLoss(alpha = 0.2) on y - 1 (:1394, :1446-1460) in ONE launch; the
             # logits are never stored
             self._head_loss = ops.skinny_linear_gtl(tok, self.out_proj.weight, self.out_proj.bias, y_head, 0.2, target_offset=-1)
@@ -537,6 +544,11 @@ class Graphormer(nn.Module):
         else:
             logits = self.out_proj(tok)
         ops.trace_nan("logits", logits)
+        if toyota:
+            # :1417-1428: the POI head returns log-probabilities.  training_step (below) takes the raw logits instead -- its
+            # fused log-softmax + NLL kernel (mobgt_cross_entropy) is NLLLoss(log_softmax(logits)) -- through `_toyota_logits`
+            self._toyota_logits = logits
+            return [torch.log_softmax(logits.float(), dim=1), self.cat_decoder(tok)]
         if getattr(self, "_poi_logits_only", False):     # training_step reads logits[0] only (:1446-1460)
             return [logits, None]
         return [logits, self.cat_decoder(tok)]                                                 # :1394-1396
@@ -546,7 +558,20 @@ class Graphormer(nn.Module):
     head_modules = ("out_proj", "final_ln", "embed_fuse_model3", "user_embed_model", "cat_decoder")
 
     def training_step(self, batched_data, batch_idx=0):
-        """model_fqandtoyo.py:1446-1460: y-1 targets, GradientTailLoss(alpha=0.2) on the POI logits only."""
+        """model_fqandtoyo.py:1446-1460: y-1 targets, GradientTailLoss(alpha=0.2) on the POI logits only.
+        toyotagraph (:1462-1471): GradientTailLoss(category logits, category of the target POI - 1, alpha = 0.1) +
+        NLLLoss(ignore_index=0)(log_softmax(POI logits), y) -- y unshifted, the category target as :1262 derives it."""
+        if self.dataset_name == "toyotagraph":
+            out = self(batched_data)
+            logits = self.__dict__.pop("_toyota_logits")
+            y = batched_data.y.long().view(-1)
+            cat_target = self.poi2cat[y] - 1                                                   # :1262 (poi_idx2cat_idx_dict[y] - 1)
+            loss_cat = ops.gradient_tail_loss(out[1], cat_target, 0.1, target_offset=0)
+            if ops.cross_entropy_ok(logits, y):
+                loss_poi = ops.cross_entropy(logits, y, ignore_index=0)
+            else:
+                loss_poi = torch.nn.functional.nll_loss(out[0], y, ignore_index=0)
+            return loss_cat + loss_poi
         self._poi_logits_only = True
         self._loss_in_head = batched_data.y              # (forward() may fold the loss into the classifier's launch)
         try:

@@ -222,8 +222,10 @@ def fuse(sd, prefix, a, b, act=None, site=None):
 
 
 def graphormer_fq_forward(sd, batch, consts, n_layers, H, D, p=0.0, p_in=0.0, p_att=0.0, training=False,
-                          hidden=128, time_dim=32, cat_dim=32, drop=None, act=None):
-    """model_fqandtoyo.py:1123-1432 for foursquaregraph / gowalla_*: returns (poi_logits, cat_logits)."""
+                          hidden=128, time_dim=32, cat_dim=32, drop=None, act=None, dataset="foursquaregraph"):
+    """model_fqandtoyo.py:1123-1432 for foursquaregraph / gowalla_*: returns (poi_logits, cat_logits).
+    `dataset="toyotagraph"` (:902-1039, :1417-1428): the 48-slot time table is a plain nn.Embedding there (no padding_idx: row
+    0 trains), and the POI head returns log-probabilities (F.log_softmax of the out_proj logits)."""
     x = batch.x
     G, N = x.size()[:2]
     C = hidden + time_dim + cat_dim
@@ -236,7 +238,8 @@ def graphormer_fq_forward(sd, batch, consts, n_layers, H, D, p=0.0, p_in=0.0, p_
     for pi in range(G):                                                               # :1257-1269
         n = int(indx[pi][0])
         cat_e = catemb[torch.LongTensor([consts.poi2cat[int(x[pi][q])] - 1 for q in range(n)])]
-        time_e = F.embedding((batch.time_normal[pi][:n] * 48).long(), sd["time_embed_model_48.weight"], padding_idx=0).squeeze(1)
+        time_e = F.embedding((batch.time_normal[pi][:n] * 48).long(), sd["time_embed_model_48.weight"],
+                             padding_idx=None if dataset == "toyotagraph" else 0).squeeze(1)
         poi_e = poidist[x[pi][:n] - 1].squeeze(1)
         f2 = fuse(sd, "embed_fuse_model2", poi_e, time_e)
         node_features[pi][:n] = fuse(sd, "embed_fuse_model4", f2, cat_e)
@@ -260,7 +263,10 @@ def graphormer_fq_forward(sd, batch, consts, n_layers, H, D, p=0.0, p_in=0.0, p_
         rows.append(torch.stack([fuse(sd, "embed_fuse_model3", out[pi][q], user_emb[pi], act, ("embed_fuse_model3", pi, q)) for q in range(N)]))
     tmp = torch.stack(rows)
     o = _dropout(F.elu(layer_norm(sd, "final_ln", tmp)), p_in, training, drop, "output")   # :1360-1364
-    return linear(sd, "out_proj", o[:, 0, :]), linear(sd, "cat_decoder", o[:, 0, :])  # :1394-1396
+    poi = linear(sd, "out_proj", o[:, 0, :])
+    if dataset == "toyotagraph":
+        poi = F.log_softmax(poi, dim=1)                                               # :1417-1428
+    return poi, linear(sd, "cat_decoder", o[:, 0, :])                                 # :1394-1396
 
 
 def gradient_tail_loss(inputs, targets, alpha=0.25, beta=1, k=1):
@@ -276,6 +282,15 @@ def fq_training_loss(sd, batch, consts, **kw):
     """model_fqandtoyo.py:1446-1460: y-1 targets, GradientTailLoss(alpha=0.2) on the POI head only."""
     logits, _ = graphormer_fq_forward(sd, batch, consts, **kw)
     return gradient_tail_loss(logits, batch.y - 1, 0.2)
+
+
+def toyota_training_loss(sd, batch, consts, **kw):
+    """model_fqandtoyo.py:1462-1471 (with :1262 for the category target): GradientTailLoss(category logits, category of the
+    TARGET POI - 1, alpha = 0.1) + NLLLoss(ignore_index=0)(log-probabilities, y) -- y is NOT shifted here."""
+    logp, cat_logits = graphormer_fq_forward(sd, batch, consts, dataset="toyotagraph", **kw)
+    y = batch.y.view(-1)
+    cat_target = torch.tensor([consts.poi2cat[int(v)] - 1 for v in y], dtype=torch.long)
+    return gradient_tail_loss(cat_logits, cat_target, 0.1) + F.nll_loss(logp, y, ignore_index=0)
 
 
 # ------------------------------------------------------------------------- schedule / metrics (§8f)

@@ -41,7 +41,9 @@ def main():
                        act_dtype=torch.bfloat16, **args).to(dev)
     broadcast_parameters(model)
     coll = DeviceCollator(dev, bin_table=table)
-    batches = [coll(synth.make_batch_of_trajectories(seed=10 + 7 * rank + i, G=4, P=400, n_user=1080, cat_of_poi=uni.cat_of_poi))
+    # (MOBGT_TEST_DATA_RANK: a ONE-rank run on the data another rank of a two-rank run sees -- the mean-of-gradients test)
+    drank = int(os.environ.get("MOBGT_TEST_DATA_RANK", rank))
+    batches = [coll(synth.make_batch_of_trajectories(seed=10 + 7 * drank + i, G=4, P=400, n_user=1080, cat_of_poi=uni.cat_of_poi))
                for i in range(2)]                         # different data per rank
     comm = os.environ.get("MOBGT_TEST_GRAD_COMM")
     ts = TrainStep(model, batches, use_graph=True, seed=5, grad_comm_dtype=torch.bfloat16 if comm == "bf16" else None)

@@ -126,12 +126,12 @@ def make_g1(algos):
 
 
 # --------------------------------------------------------------------------------------- workspace
-def write_universe(uni, city_pkls=("tky_distance.pkl", "gowalla_distance.pkl")):
+def write_universe(uni, city_pkls=("tky_distance.pkl", "gowalla_distance.pkl", "toyota_distance.pkl")):
     """Materialise a synthetic POI universe where the reference looks for it (relative to cwd)."""
     import pandas as pd
     os.makedirs(os.path.join(WS, "graphormer"), exist_ok=True)
     os.makedirs(os.path.join(WS, "dataset", "poi_data"), exist_ok=True)
-    for ds in ("foursquaregraph", "gowalla_nevda"):
+    for ds in ("foursquaregraph", "gowalla_nevda", "toyotagraph"):
         raw = os.path.join(WS, "dataset", ds, "raw")
         os.makedirs(raw, exist_ok=True)
         df = pd.DataFrame(uni.poi_table, columns=list(uni.poi_columns))
@@ -228,12 +228,12 @@ def make_g2_g3():
 
 
 if __name__ == "__main__":
-    which = set(sys.argv[1:]) or {"g1", "g2", "g4", "g5", "g6", "g7", "g9"}
+    which = set(sys.argv[1:]) or {"g1", "g2", "g4", "g5", "g6", "g7", "g9", "g11"}
     algos = _ref_import.install()
     if "g1" in which:
         make_g1(algos)
     if "g2" in which or "g3" in which:
         make_g2_g3()
-    if {"g4", "g5", "g6", "g7", "g9"} & which:
+    if {"g4", "g5", "g6", "g7", "g9", "g11"} & which:
         import make_golden_model
         make_golden_model.run(which)

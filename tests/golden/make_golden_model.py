@@ -221,6 +221,54 @@ def make_g5_g6():
     save("g6_e2e.npz", **out6)
 
 
+def make_g11():
+    """The `toyotagraph` branch of the fq Graphormer (model_fqandtoyo.py:902-1039 constructor, :1417-1428 log_softmax head,
+    :1462-1471 loss = GradientTailLoss(category logits, category of the target, 0.1) + NLLLoss(ignore_index=0)) on the synthetic
+    universe of G5 / G6 -- the Toyota data itself is private (README.md:72-83): `collator_toyota`, outputs, loss, gradients."""
+    import collator as rcoll
+    import model_fqandtoyo as rfq
+    from mobgt_amd import synth
+    uni = synth.make_universe(P=64, n_cat=8, n_user=8, seed=3)
+    write_universe(uni)
+    trajs = synth.make_batch_of_trajectories(seed=9, G=6, P=64, n_user=8, cat_of_poi=uni.cat_of_poi, n_nodes=[4, 12, 2, 7, 9, 3])
+    out = {}
+    items = build_items(trajs)
+    with in_ws():
+        batch = rcoll.collator_toyota(copy.deepcopy(items), max_node=30000, multi_hop_max_dist=20, rel_pos_max=1024)
+        args = dict(STOCK_ARGS)
+        args["dataset_name"] = "toyotagraph"
+        m = rfq.Graphormer(**args).eval()
+    nb = m.poi_pos_encoder.weight.shape[0]
+    batch.poi_pos = batch.poi_pos.clamp(max=nb - 1)      # avoid the reference's latent OOB (SURVEY App. A)
+    fill_params(m, 79)
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")                  # (F.log_softmax without dim, :1425)
+        outs = m(batch)
+        out.update(batch_arrays("toy/batch/", batch, skip=("feature_matrix",)))
+        out["toy/num_bins"] = np.array(nb)
+        out["toy/logits"] = outs[0].detach().numpy()         # log-probabilities
+        out["toy/cat_logits"] = outs[1].detach().numpy()
+        out["toy/seed"] = np.array(79)
+        out["toy/param_names"] = np.array([n for n, _ in m.named_parameters()])
+        out["toy/param_shapes"] = np.array([str(tuple(p.shape)) for _, p in m.named_parameters()])
+        m.zero_grad()
+        with cpu_cuda_alias():
+            loss = m.training_step(batch, 0)
+    loss.backward()
+    out["toy/loss"] = np.array(loss.item())
+    out["toy/cat_target"] = m.cat_target.detach().numpy()
+    for pn, p in m.named_parameters():
+        if p.grad is None:
+            out[f"toy/grad_none/{pn}"] = np.array(1)
+        else:
+            g = p.grad.double()
+            out[f"toy/gstat/{pn}"] = np.array([g.sum().item(), g.norm().item()])
+            if p.grad.numel() <= 65536:
+                out[f"toy/grad/{pn}"] = grad_sample(p.grad.numpy())
+    save("g11_toyota.npz", **out)
+
+
 def make_g7():
     import lr as rlr
     import model_fqandtoyo as rfq
@@ -273,3 +321,5 @@ def run(which):
         make_g7()
     if "g9" in which:
         make_g9()
+    if "g11" in which:
+        make_g11()

@@ -224,6 +224,44 @@ def test_fq_graphormer_logits_loss_grads_g6(golden_dir, tag, ds, narrow):
     _check_grads(m, z6, tag, rtol=2e-3, lim_l2=2e-3)
 
 
+@pytest.mark.parametrize("cfg", ["f32", "bf16"])
+def test_toyotagraph_branch_logits_loss_grads_g11(golden_dir, cfg):
+    """Golden G11 (the reference's own `toyotagraph` branch on the synthetic universe: model_fqandtoyo.py:902-1039 constructor,
+    :1417-1428 log_softmax POI head, :1462-1471 loss = GradientTailLoss(category logits, 0.1) + NLLLoss(ignore_index=0); the
+    Toyota data is private, README.md:72-83): log-probabilities, category logits, loss, every gradient -- f32 configuration at
+    the fp32 tolerances of G6 (2e-4 / 1e-5 / 0.2 % relative L2), bf16 configuration at the bf16 gates (3e-2 on the
+    log-probabilities, loss 2e-3, gradients 4 % relative L2 elementwise)."""
+    from mobgt_amd.model_fqandtoyo import Graphormer
+    z6, z = _load(golden_dir, "g6_e2e.npz"), _load(golden_dir, "g11_toyota.npz")
+    uni = synth.Universe(P=64, n_cat=8, n_user=8, poi_table=z6["uni/poi_table"], graph_adj=z6["uni/graph_adj"],
+                         graph_dist=z6["uni/graph_dist"], graph_cat=z6["uni/graph_cat"], distance=z6["uni/distance"])
+    kw = {} if cfg == "f32" else dict(bias_dtype=torch.bfloat16, gcn_dtype=torch.bfloat16, act_dtype=torch.bfloat16)
+    m = Graphormer(n_layers=2, num_heads=8, hidden_dim=128, dropout_rate=0.1, intput_dropout_rate=0.1, weight_decay=0.01,
+                   ffn_dim=256, dataset_name="toyotagraph", warmup_updates=10, tot_updates=100, peak_lr=2e-4, end_lr=1e-9,
+                   edge_type="multi_hop", multi_hop_max_dist=20, attention_dropout_rate=0.1, universe=uni, **kw)
+    names = [str(n) for n in z["toy/param_names"]]
+    shapes = [eval(str(s)) for s in z["toy/param_shapes"]]
+    assert [n for n, _ in m.named_parameters()] == names and [tuple(p.shape) for p in m.parameters()] == shapes
+    _load_seeded(m, list(zip(names, shapes)), int(z["toy/seed"]))
+    m = m.to(DEV).eval()
+    b = _to_dev(_batch(z, "toy/batch/", FQ_FIELDS), narrow=True)
+    out = m(b)
+    tol = 2e-4 if cfg == "f32" else 3e-2
+    np.testing.assert_allclose(out[0].detach().cpu().numpy(), z["toy/logits"], rtol=tol, atol=tol)
+    np.testing.assert_allclose(out[1].detach().cpu().numpy(), z["toy/cat_logits"], rtol=tol, atol=tol)
+    for p in m.parameters():
+        p.grad = None
+    loss = m.training_step(b, 0)                       # eval() mode, like the golden (no dropout)
+    np.testing.assert_allclose(loss.item(), z["toy/loss"], rtol=1e-5 if cfg == "f32" else 2e-3)
+    loss.backward()
+    # the plain 48-slot time table of this branch (no padding_idx): its row 0 trains
+    assert "toy/grad/time_embed_model_48.weight" in z and m.time_embed_model_48.padding_idx is None
+    if cfg == "f32":
+        _check_grads(m, z, "toy", rtol=2e-3, lim_l2=2e-3)
+    else:
+        _check_grads(m, z, "toy", rtol=5e-2, lim_l2=4e-2)
+
+
 def test_gradient_tail_loss_kernel_matches_reference_g7(golden_dir):
     from mobgt_amd import ops
     z = _load(golden_dir, "g7_lr_loss.npz")

@@ -219,6 +219,41 @@ def test_two_rank_train_step_keeps_replicas_identical(tmp_path, form):
     assert float(a["exp_avg"].abs().max()) > 0 and all(np.isfinite(a["losses"]))
 
 
+@pytest.mark.parametrize("comm", ["fp32", "bf16"])
+def test_exchanged_gradient_is_the_mean_of_the_two_ranks_gradients(tmp_path, comm):
+    """the two-rank test above shows the replicas AGREE; this one shows WHAT they agree on.  After one step of
+    two data-parallel ranks on different batches, the gradient buffer every rank holds must be (g_rank0 + g_rank1) / 2 --
+    entry.py:141,161's DDP mean -- where g_r is the gradient ONE process computes alone on rank r's batch from the same
+    (broadcast) initial parameters and the same dropout stream.  fp32 exchange in place and the bf16 exchange buffer
+    (`grad_comm_dtype`).  Bounds: relative L2 of the whole flat buffer <= 1e-2 (fp32; two runs of one step differ by the order
+    of their f32 atomics in front of bf16 rounding points) / 2e-2 (bf16 buffer: 2^-9 per entry on top); 99.9 % of the entries
+    within 0.1 rms + 5 %; and the buffer is far from either rank's own gradient and from their SUM (a missing or un-averaged
+    exchange)."""
+    env = {"MOBGT_TEST_GRAD_COMM": "bf16"} if comm == "bf16" else {}
+    d2, d0, d1 = tmp_path / "two", tmp_path / "solo0", tmp_path / "solo1"
+    for d in (d2, d0, d1):
+        d.mkdir()
+    a, b = _run_two_ranks(d2, 1, env)
+    s0 = _run_one_rank(d0, 1, {"MOBGT_TEST_DATA_RANK": "0"})
+    s1 = _run_one_rank(d1, 1, {"MOBGT_TEST_DATA_RANK": "1"})
+    assert torch.equal(a["grads"], b["grads"])
+    assert a["losses"] != b["losses"] and abs(a["losses"][0] - s0["losses"][0]) < 1e-3 * abs(s0["losses"][0]) \
+        and abs(b["losses"][0] - s1["losses"][0]) < 1e-3 * abs(s1["losses"][0])      # each rank computed ITS batch's loss
+    g, g0, g1 = a["grads"].double(), s0["grads"].double(), s1["grads"].double()
+    mean = (g0 + g1) / 2
+    rel = float((g - mean).norm() / mean.norm())
+    print("backend", a["backend"], "one graph", a["one_graph"], "comm dtype", a["comm_dtype"], "relative L2 to the mean %.2e" % rel,
+          " to rank 0 alone %.2f  rank 1 alone %.2f  the sum %.2f" % tuple(float((g - x).norm() / x.norm()) for x in (g0, g1, g0 + g1)))
+    assert rel <= (2e-2 if comm == "bf16" else 1e-2), rel
+    nz = mean != 0
+    rms = float(mean[nz].pow(2).mean().sqrt())
+    ratio = ((g - mean).abs()[nz] / (0.1 * rms + 0.05 * mean[nz].abs()))
+    assert float(torch.quantile(ratio[:: max(1, ratio.numel() // 1000000)], 0.999)) <= 1.0
+    assert float(g[~nz].abs().max()) <= 1e-3 * rms if bool((~nz).any()) else True
+    for other in (g0, g1, g0 + g1):
+        assert float((g - other).norm() / other.norm()) > 0.2
+
+
 def test_bench_launches_two_ranks_and_reports_them(tmp_path):
     """`python bench.py --gpus 2` as the driver calls it (no torch.distributed environment): the script launches its own two
     ranks through torch.distributed.run, both take part in the gradient all-reduce, rank 0 prints ONE JSON line.  On a

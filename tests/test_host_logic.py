@@ -154,6 +154,12 @@ def test_state_dict_names_match_reference(golden_dir):
         shapes = [str(tuple(p.shape)) for _, p in m.named_parameters()]
         assert names == [str(n) for n in z6[f"{tag}/param_names"]]
         assert shapes == [str(s) for s in z6[f"{tag}/param_shapes"]]
+    # the toyotagraph branch (golden G11: 996 user rows, no cat_embed_model, a num_cats-way category head)
+    z11 = np.load(os.path.join(golden_dir, "g11_toyota.npz"))
+    m = Graphormer(dataset_name="toyotagraph", universe=uni, **args)
+    assert [n for n, _ in m.named_parameters()] == [str(n) for n in z11["toy/param_names"]]
+    assert [str(tuple(p.shape)) for _, p in m.named_parameters()] == [str(s) for s in z11["toy/param_shapes"]]
+    assert m.time_embed_model_48.padding_idx is None and m.user_embed_model.user_embedding.num_embeddings == 996
 
 
 def test_metrics_match_reference_g7(golden_dir):

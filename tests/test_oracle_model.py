@@ -187,6 +187,38 @@ def test_fq_bias_logits_loss_grads_g5_g6(golden_dir, tag, ds):
             np.testing.assert_allclose(grad_sample(p.grad.numpy()), refg, rtol=5e-3, atol=1e-3 * float(np.abs(refg).max()) + 1e-9, err_msg=pn)
 
 
+def test_toyotagraph_branch_logits_loss_grads_g11(golden_dir):
+    """Golden G11: the reference's `toyotagraph` branch (model_fqandtoyo.py:902-1039, :1417-1428, :1462-1471) on the synthetic
+    universe -- log-probabilities, category logits, loss = GradientTailLoss(cat, 0.1) + NLLLoss, every gradient."""
+    z6, z = load(golden_dir, "g6_e2e.npz"), load(golden_dir, "g11_toyota.npz")
+    consts = mo.fq_constants(_universe(z6), "toyotagraph")
+    assert consts.num_bins == int(z["toy/num_bins"])
+    names = [str(n) for n in z["toy/param_names"]]
+    shapes = [eval(str(s)) for s in z["toy/param_shapes"]]
+    sd = seeded_state(list(zip(names, shapes)), int(z["toy/seed"]))
+    b = _batch(z, "toy/batch/", FQ_FIELDS)
+    kw = dict(n_layers=2, H=8, D=20)
+    logp, cat_logits = mo.graphormer_fq_forward(sd, b, consts, dataset="toyotagraph", **kw)
+    np.testing.assert_allclose(logp.detach().numpy(), z["toy/logits"], rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(cat_logits.detach().numpy(), z["toy/cat_logits"], rtol=1e-4, atol=1e-5)
+    assert abs(float(logp.exp().sum(1).mean()) - 1.0) < 1e-5
+    loss = mo.toyota_training_loss(sd, b, consts, **kw)
+    np.testing.assert_allclose(loss.item(), z["toy/loss"], rtol=1e-5)
+    loss.backward()
+    for pn, p in sd.items():
+        if f"toy/grad_none/{pn}" in z:
+            assert p.grad is None, pn
+            continue
+        g = p.grad.double()
+        if pn in ("edge_encoder.weight", "rel_pos_encoder.weight", "poi_pos_encoder.weight", "in_degree_encoder.weight",
+                  "out_degree_encoder.weight"):
+            assert float(g[0].abs().sum()) == 0.0, pn  # padding_idx=0 rows receive no gradient in the reference
+        np.testing.assert_allclose([g.sum().item(), g.norm().item()], z[f"toy/gstat/{pn}"], rtol=2e-3, atol=1e-6, err_msg=pn)
+        if f"toy/grad/{pn}" in z:
+            refg = z[f"toy/grad/{pn}"]
+            np.testing.assert_allclose(grad_sample(p.grad.numpy()), refg, rtol=5e-3, atol=1e-3 * float(np.abs(refg).max()) + 1e-9, err_msg=pn)
+
+
 def test_lr_loss_metrics_g7(golden_dir):
     z = load(golden_dir, "g7_lr_loss.npz")
     w, t, lr, end, power = z["lr/args"]
