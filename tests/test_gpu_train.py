@@ -225,8 +225,8 @@ def test_exchanged_gradient_is_the_mean_of_the_two_ranks_gradients(tmp_path, com
     two data-parallel ranks on different batches, the gradient buffer every rank holds must be (g_rank0 + g_rank1) / 2 --
     entry.py:141,161's DDP mean -- where g_r is the gradient ONE process computes alone on rank r's batch from the same
     (broadcast) initial parameters and the same dropout stream.  fp32 exchange in place and the bf16 exchange buffer
-    (`grad_comm_dtype`).  Bounds: relative L2 of the whole flat buffer <= 1e-2 (fp32; two runs of one step differ by the order
-    of their f32 atomics in front of bf16 rounding points) / 2e-2 (bf16 buffer: 2^-9 per entry on top); 99.9 % of the entries
+    (`grad_comm_dtype`).  Bounds: relative L2 of the whole flat buffer <= 1e-5 (fp32 exchange; measured 2e-8: the solo runs
+    reproduce the ranks' gradients to f32 round-off) / 5e-3 (bf16 buffer: 2^-9 per entry; measured 2.3e-3); 99.9 % of the entries
     within 0.1 rms + 5 %; and the buffer is far from either rank's own gradient and from their SUM (a missing or un-averaged
     exchange)."""
     env = {"MOBGT_TEST_GRAD_COMM": "bf16"} if comm == "bf16" else {}
@@ -244,7 +244,7 @@ def test_exchanged_gradient_is_the_mean_of_the_two_ranks_gradients(tmp_path, com
     rel = float((g - mean).norm() / mean.norm())
     print("backend", a["backend"], "one graph", a["one_graph"], "comm dtype", a["comm_dtype"], "relative L2 to the mean %.2e" % rel,
           " to rank 0 alone %.2f  rank 1 alone %.2f  the sum %.2f" % tuple(float((g - x).norm() / x.norm()) for x in (g0, g1, g0 + g1)))
-    assert rel <= (2e-2 if comm == "bf16" else 1e-2), rel
+    assert rel <= (5e-3 if comm == "bf16" else 1e-5), rel       # (measured: 2.3e-3 / 2.2e-8)
     nz = mean != 0
     rms = float(mean[nz].pow(2).mean().sqrt())
     ratio = ((g - mean).abs()[nz] / (0.1 * rms + 0.05 * mean[nz].abs()))
