@@ -88,16 +88,11 @@ def ref_item(mol, idx):
     return data
 
 
-def main():
+def setup_real_workspace():
+    """The shipped archive's real POI universe written where the reference looks for it (relative to the workspace's
+    graphormer/ directory) + the haversine stand-in for the one missing file; -> (archive files, poi frame, poi table, Graph_dist,
+    Graph_cat, distance matrix)."""
     import pandas as pd
-    import torch
-    algos = _ref_import.install()
-    import wrapper
-    import collator as rcoll
-    import model_fqandtoyo as rfq
-    from inputs import fill_params
-    from make_golden_model import cpu_cuda_alias, grad_sample
-
     files = read_archive(ARCHIVE)
     raw = os.path.join(WS, "dataset", "gowalla_nevda", "raw")
     os.makedirs(raw, exist_ok=True)
@@ -116,6 +111,20 @@ def main():
     assert np.array_equal(gdist, gdist.T) and set(np.unique(gdist)) <= {0.0, 1.0}
     with open(os.path.join(WS, "dataset", "poi_data", "gowalla_distance.pkl"), "wb") as f:
         pickle.dump(dist, f)
+    return files, poi_df, poi, gdist, gcat, dist
+
+
+def main():
+    import pandas as pd
+    import torch
+    algos = _ref_import.install()
+    import wrapper
+    import collator as rcoll
+    import model_fqandtoyo as rfq
+    from inputs import fill_params
+    from make_golden_model import cpu_cuda_alias, grad_sample
+
+    files, poi_df, poi, gdist, gcat, dist = setup_real_workspace()
 
     data = pickle.load(io.BytesIO(files["gowalla_nevda/raw/train.pickle"]))
     keys_a, by_n = pick(data, SIZES_A)

@@ -109,3 +109,78 @@ def test_real_fq_forward_loss_grads_g8(g8):
     for pn in ("edge_encoder.weight", "edge_dis_encoder.weight"):
         refg = z[f"a_s65536/grad/{pn}"]
         np.testing.assert_allclose(grad_sample((sd[pn].grad / 65536.0).numpy()), refg, rtol=5e-3, atol=1e-3 * float(np.abs(refg).max()) + 1e-9, err_msg=pn)
+
+
+# ------------------------------------------------------------------------------------------------ G10: a training trajectory
+def g10_batches(z, uni, split, n_batches, batch=16):
+    trajs = real_trajs(z, split)
+    out = []
+    for s in range(n_batches):
+        items = [co.preprocess_item(synth.trajectory_to_item(t, idx=s * batch + i)) for i, t in enumerate(trajs[s * batch:(s + 1) * batch])]
+        out.append(co.collator_poi(items, uni.distance, max_node=30000, multi_hop_max_dist=20, rel_pos_max=1024))
+    return out
+
+
+def g10_metrics(batches_logits_targets):
+    """test_epoch_end's bookkeeping (model_fqandtoyo.py:1546-1597) with the oracle's metric functions."""
+    tot, mrr, n = np.zeros(8), 0.0, 0
+    for logits, y_true in batches_logits_targets:
+        a, d = mo.get_acc(y_true, logits)
+        a, d = np.asarray(a).reshape(4), np.asarray(d).reshape(4)
+        tot += np.array([a[2], a[1], a[0], d[2], d[1], d[0], a[3], d[3]])
+        mrr += float(mo.mrr_metric(y_true, logits))
+        n += len(y_true)
+    return tot / n, mrr / n
+
+
+def test_training_trajectory_of_30_updates_g10(g8, golden_dir):
+    """Golden G10 (tests/golden/make_golden_traj.py): the REFERENCE trained for 30 AdamW updates (PolynomialDecayLR, warm-up 10,
+    peak 1e-3) on 480 real Gowalla trajectories, then evaluated on 256 real test trajectories.  The oracle -- its forward /
+    loss, torch's AdamW on its parameter dict, its restatement of the schedule (lr.py:17-31) -- must walk the same trajectory:
+    the learning rate of every update exactly, the loss of every update within 2e-4 relative (fp32 round-off through 30
+    updates; measured: see the printout), a sample of every parameter after update 30 within 2 % of that parameter's MOVEMENT
+    (rms of final - initial; linear_k.bias, whose gradient is exactly zero in exact arithmetic, excepted), the test logits of the
+    first 16 test trajectories within 1e-3, and test_epoch_end's metrics."""
+    z8, uni = g8
+    z = np.load(os.path.join(golden_dir, "g10_traj.npz"))
+    steps, batch, n_test = (int(v) for v in z["args/steps_batch_ntest"])
+    warm, tot, peak, end, wd = (float(v) for v in z["args/lr"])
+    consts = mo.fq_constants(uni, "gowalla_nevda", num_bins=int(z8["num_bins"]))
+    names = [str(n) for n in z["param_names"]]
+    shapes = [eval(str(s)) for s in z["param_shapes"]]
+    sd = seeded_state(list(zip(names, shapes)), int(z["seed"]))
+    init = {k: v.detach().clone() for k, v in sd.items()}
+    opt = torch.optim.AdamW(list(sd.values()), lr=peak, weight_decay=wd)
+    kw = dict(n_layers=6, H=8, D=20)
+    worst = 0.0
+    for s, b in enumerate(g10_batches(z, uni, "train", steps, batch)):
+        lr = mo.polynomial_decay_lr(s + 1, warm, tot, peak, end, 1.0)
+        assert lr == float(z["lrs"][s]), (s, lr)
+        for g in opt.param_groups:
+            g["lr"] = lr
+        loss = mo.fq_training_loss(sd, b, consts, **kw)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        rel = abs(loss.item() - float(z["losses"][s])) / float(z["losses"][s])
+        worst = max(worst, rel)
+        assert rel <= 2e-4, (s, loss.item(), float(z["losses"][s]))
+    print("largest relative loss deviation over 30 updates: %.2e" % worst)
+    from traj_helpers import param_sample
+    for pn, p in sd.items():
+        if pn.endswith("linear_k.bias"):
+            continue
+        ref = z[f"final/{pn}"]
+        got, ini = param_sample(p.detach().numpy()), param_sample(init[pn].numpy())
+        move = float(np.sqrt(((ref - ini) ** 2).mean()))
+        assert float(np.abs(got - ref).max()) <= 2e-2 * move + 1e-7, (pn, float(np.abs(got - ref).max()), move)
+    with torch.no_grad():
+        evals = []
+        for s, b in enumerate(g10_batches(z, uni, "test", n_test // batch, batch)):
+            logits, _ = mo.graphormer_fq_forward(sd, b, consts, **kw)
+            if s == 0:
+                np.testing.assert_allclose(logits.numpy(), z["test/logits0"], rtol=1e-3, atol=1e-3)
+            evals.append((logits, b.y - 1))
+    acc, mrr = g10_metrics(evals)
+    np.testing.assert_allclose(acc, z["metrics/acc1_5_10_ndcg1_5_10_acc20_ndcg20"], atol=1.0 / n_test + 1e-12)
+    np.testing.assert_allclose(mrr, float(z["metrics/mrr"]), rtol=2e-2)
