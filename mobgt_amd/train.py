@@ -734,6 +734,40 @@ class TrainStep:
             if kept is not None:
                 self._loss_slots[i] = kept
 
+    # ---- several steps per graph replay (round 6) -----------------------------------------------------------------------
+    # Between two replayed step graphs the device idles (~60 us of a 0.595 ms S-FSQ step in round 5: 0.534 ms of graph wall
+    # time): the replay that follows cannot start before the runtime has retired the one in front of it.  Nothing of a step
+    # lives on the host -- the dropout stream, AdamW's t and the learning-rate schedule are device counters the step's own
+    # kernels advance -- so k consecutive steps on pre-collated batches can be ONE graph: k x (forward, backward [, exchange],
+    # AdamW), one replay, no host round trip between them.  The graph holds k steps' activations (S-FSQ: ~30 MB per step).
+    def _capture_group(self, i0, k):
+        if not (self.use_graph and self._prepared and getattr(self, "fused_opt", False) and self.sched_dev is not None):
+            raise RuntimeError("TrainStep.step_group needs prepare(), hipGraphs, the one-graph step form and the device-side schedule")
+        nb = len(self.batches)
+        g = torch.cuda.CUDAGraph()
+        with self._capturing(g):
+            for j in range(k):
+                self._fwd_bwd(self.batches[(i0 + j) % nb], slot=("group", i0, k, j))
+                if self.one_graph:
+                    self._exchange()
+                self._opt_step()
+        self.graphs_group[(i0, k)] = g
+
+    def step_group(self, i, k):
+        """Steps i, i + 1, ... i + k - 1 (batches taken cyclically from the pre-collated pool, like k calls of `step`) as ONE
+        graph replay; -> the last step's loss tensor.  Same arithmetic, same counters, same order as k single steps."""
+        nb = len(self.batches)
+        key = (i % nb, int(k))
+        if not hasattr(self, "graphs_group"):
+            self.graphs_group = {}
+        if key not in self.graphs_group:
+            self._capture_group(*key)
+        self._loss_ref = self._loss_slots[("group", key[0], key[1], key[1] - 1)]
+        self.graphs_group[key].replay()
+        self.sched_state["step_count"] += key[1]
+        self._set_lr()
+        return self.loss_out
+
     # ---- peer waits that gave up (csrc/chain.hip WS_FAULT, head.hip, smallgcn.hip): detection and recovery ---------------
     def recapture(self):
         """Capture every step graph again (after ops.SAFE_FORMS changed which kernels a step launches).  Parameters,
