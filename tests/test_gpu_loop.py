@@ -128,7 +128,9 @@ def test_epoch_over_the_s_gow_pool_visits_the_distributed_samplers_set(rank, wor
         # several ranks: this rank's column of the length-balanced dealing (data.balanced_batches; its union over the ranks is
         # the sampler's multiset: tests/test_ddp_gloo.py), as many samples and steps as the sampler gives every rank
         from mobgt_amd.data import balanced_batches
-        steps = balanced_batches([len(t["node_name"]) for t in data], world, 16, epoch=2, seed=11)
+        # (round 6: the loop's default sorts inside windows of 32 steps -- EpochLoop(balance_window=32) -- not over the whole epoch)
+        steps = balanced_batches([len(t["node_name"]) for t in data], world, 16, epoch=2, seed=11, window=loop.balance_window)
+        assert loop.balance_window == 32
         assert res["sample_ids"] == [i for s in steps for i in s[rank]]
         others = [i for s in steps for r in range(world) if r != rank for i in s[r]]
         assert sorted(res["sample_ids"] + others) == sorted(i for r in range(world) for i in shard_indices(n_train, r, world, epoch=2, seed=11))
