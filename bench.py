@@ -41,6 +41,9 @@ def parse():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--unfused", action="store_true", help="op-by-op encoder layers (torch ops + HIP attention)")
     ap.add_argument("--no-overlap", action="store_true", help="N > 1: one all-reduce after the whole backward instead of two overlapped buckets")
+    ap.add_argument("--ddp-form", default="auto", choices=["auto", "default"],
+                    help="N > 1: 'auto' times the one-graph step and the overlapped forms for 20 steps on this job's ranks and takes the "
+                         "fastest (train.choose_ddp_form); 'default': the one-graph step (or what MOBGT_DDP_OVERLAP / MOBGT_DDP_PARTS say)")
     ap.add_argument("--grad-comm", choices=["fp32", "bf16"], default="fp32",
                     help="N > 1: dtype the gradient buckets are all-reduced in (bf16 halves the bytes; DESIGN 5)")
     ap.add_argument("--force-comm", action="store_true",
@@ -833,9 +836,20 @@ def main():
         shapes.append((len(b), b.x.shape[1] + 1))
     torch.cuda.synchronize()
 
-    ts = TrainStep(model, batches, autocast_dtype=torch.bfloat16 if (bf16 and args.gemm_dtype == "bf16" and args.unfused) else None,
-                   use_graph=not args.no_graph, overlap=not args.no_overlap, seed=args.seed,
-                   grad_comm_dtype=torch.bfloat16 if args.grad_comm == "bf16" else None)
+    ts_kw = dict(autocast_dtype=torch.bfloat16 if (bf16 and args.gemm_dtype == "bf16" and args.unfused) else None,
+                 use_graph=not args.no_graph, overlap=not args.no_overlap, seed=args.seed,
+                 grad_comm_dtype=torch.bfloat16 if args.grad_comm == "bf16" else None)
+    ddp_form, ddp_form_ms = None, None
+    if (ddp and world > 1 and args.ddp_form == "auto" and not args.no_graph and not args.no_overlap
+            and os.environ.get("MOBGT_DDP_OVERLAP") is None and os.environ.get("MOBGT_DDP_HOST_EXCHANGE") is None):
+        # (round 6) which form of the data-parallel step wins is a property of the node, not of this script: measured here, on
+        # the ranks of this very job, agreed on across them
+        from mobgt_amd.train import choose_ddp_form
+        ddp_form, form_kw, ddp_form_ms = choose_ddp_form(model, batches, steps=20, warmup=5, **ts_kw)
+        for k_, v_ in form_kw.pop("_env", {}).items():
+            os.environ[k_] = v_
+        ts_kw.update(form_kw)
+    ts = TrainStep(model, batches, **ts_kw)
     ts.prepare()
     for i in range(args.warmup):
         ts.step(i)
@@ -1145,7 +1159,7 @@ def main():
                                      "accumulate_softmax_layernorm_adamw": "f32"}},
             "final_loss": loss, "ms_per_step_chunks": [round(c, 4) for c in chunk_ms], "host_stalls": host_stalls, "long_run": long_run, "grouped_run": grouped_run,
             "value_with_collate": with_collate,
-            "comm_backend": comm_backend, "comm_ranks": comm_ranks, "grad_comm_dtype": args.grad_comm if ddp else None, "forced_comm": force_comm or None, "ddp_one_graph": bool(getattr(ts, "one_graph", False)) if ddp else None, "rccl_ranks": rccl_ranks, "allreduce_exposed_us": exposed_us,
+            "comm_backend": comm_backend, "comm_ranks": comm_ranks, "grad_comm_dtype": args.grad_comm if ddp else None, "forced_comm": force_comm or None, "ddp_one_graph": bool(getattr(ts, "one_graph", False)) if ddp else None, "ddp_form": ddp_form, "ddp_form_ms_per_step": ddp_form_ms, "rccl_ranks": rccl_ranks, "allreduce_exposed_us": exposed_us,
             "parity": parity, "roofline": roof, "roofline_chain": roofc, "roofline_stress": roof5, "roofline_stress_bwd": roof5b,
             "roofline_gow_tail": gow_tail,
             "cpu_baseline": cpu, "workloads": subs,

@@ -232,6 +232,59 @@ def assert_same_across_ranks(digest, what, device=None):
         raise RuntimeError(f"mobgt: {what} differs between rank 0 and ranks {bad} -- refusing to all-reduce")
 
 
+def choose_ddp_form(model, batches, steps=20, warmup=5, candidates=None, **ts_kw):
+    """Which form of the data-parallel step is the fastest ON THIS JOB'S RANKS (VERDICT r5 next #7b): every candidate
+    -- the one-graph step with the exchange captured on the step's stream (host-issued over gloo), the two-phase overlap, the
+    layer-wise overlap in three parts -- is built, prepared and timed for `steps` steps behind a barrier (MAX over ranks), the
+    model's parameters are put back after each, and all ranks agree on the choice (`assert_same_across_ranks`).
+    -> (name, TrainStep constructor arguments incl. the environment to set, {name: ms per step}).  With one rank or no process
+    group: the default form, nothing timed.  No multi-GPU node has run this yet: the forms' order there is the measurement this
+    function exists to make (the one-rank figures of rounds 4-5 cannot show what an overlap hides)."""
+    import time
+    forms = candidates or [("one_graph", dict(overlap=False), {}),
+                           ("overlap_2", dict(overlap="force"), {"MOBGT_DDP_PARTS": "1"}),
+                           ("overlap_3", dict(overlap="force"), {"MOBGT_DDP_PARTS": "3"})]
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() <= 1:
+        return forms[0][0], forms[0][1], {}
+    dev = next(model.parameters()).device
+    sd0 = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    saved_env = {k: os.environ.get(k) for _, _, env in forms for k in env}
+    timings = {}
+    for name, kw, env in forms:
+        for k, v in env.items():
+            os.environ[k] = v
+        try:
+            ts = TrainStep(model, batches, **dict(ts_kw, **kw))
+            ts.prepare()
+            for i in range(warmup):
+                ts.step(i)
+            torch.cuda.synchronize(dev)
+            dist.barrier()
+            t0 = time.perf_counter()
+            for i in range(steps):
+                ts.step(warmup + i)
+            torch.cuda.synchronize(dev)
+            el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
+            dist.all_reduce(el, op=dist.ReduceOp.MAX)
+            timings[name] = float(el.item()) / steps * 1e3
+            faults = ts.check_faults(on_fault="return")
+            if faults:
+                timings[name] = float("inf")
+        finally:
+            for k, v in saved_env.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
+        with torch.no_grad():
+            model.load_state_dict(sd0)
+        del ts
+    best = min(timings, key=lambda n: (timings[n], n))
+    assert_same_across_ranks(best.encode().ljust(16, b" "), "the chosen data-parallel step form", dev)
+    kw, env = next((kw, env) for n, kw, env in forms if n == best)
+    return best, dict(kw, _env=env), timings
+
+
 class TrainStep:
     def __init__(self, model, batches, autocast_dtype=None, use_graph=True, seed=1, overlap=True, batch_fn=None,
                  grad_comm_dtype=None, keep_head_rows=False):

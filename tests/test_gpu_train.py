@@ -283,6 +283,12 @@ def test_bench_launches_two_ranks_and_reports_them(tmp_path):
         assert j["comm_backend"] == "nccl" and j["rccl_ranks"] == 2
     assert j["steps"] == 5 and j["value"] > 0 and np.isfinite(j["final_loss"]) and j["allreduce_exposed_us"] is not None
     assert j["long_run"]["steps"] == 200
+    # (round 6) the form of the data-parallel step was MEASURED on this job's ranks -- one graph / two-phase overlap / three parts,
+    # 20 steps each behind a barrier, max over ranks -- and agreed on across them (train.choose_ddp_form)
+    assert set(j["ddp_form_ms_per_step"]) == {"one_graph", "overlap_2", "overlap_3"} and j["ddp_form"] in j["ddp_form_ms_per_step"]
+    assert all(v > 0 and np.isfinite(v) for v in j["ddp_form_ms_per_step"].values())
+    assert j["ddp_form_ms_per_step"][j["ddp_form"]] == min(j["ddp_form_ms_per_step"].values())
+    print("forms (ms / step):", j["ddp_form_ms_per_step"], "->", j["ddp_form"], "| exposed all-reduce", j["allreduce_exposed_us"], "us")
 
 
 
