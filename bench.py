@@ -506,7 +506,7 @@ def time_epoch_loop(model, coll, name, uni, args):
     torch.cuda.synchronize()
     graphs_before = len(loop.slots)
     steps, ep = 0, 2
-    # The host has ~300 us of slack per step here (tools/dbg/r4_loop_probe2.py): a generation-2 pass of Python's collector over a
+    # The host has ~300 us of slack per step here (a round-4 probe: docs/NOTEBOOK.md): a generation-2 pass of Python's collector over a
     # large heap (tens of ms) would show up as +0.05-0.1 ms per step over a 0.2 s timed region.  What exists is moved out of the
     # collector's sight, as a long-running trainer would do once after start-up; the loop's own garbage is still collected.
     import gc
@@ -991,7 +991,7 @@ def main():
         H, C = m["num_heads"], m["hidden_dim"] + (0 if stock else 64)
         # (round 4: this leg runs FIRST, right behind the timed region.  Behind the roofline legs below -- graph-timed attention /
         # chain launches over > 1 GB of rotating buffers -- the same loop measured 0.70 instead of 0.63 ms per step while the
-        # replay of the same graphs without new input stayed at 0.61; the cause was not found: tools/dbg/r4_loop_probe{5,6}.py,
+        # replay of the same graphs without new input stayed at 0.61; the cause was not found: two round-4 probes (docs/NOTEBOOK.md),
         # which run the c5 stress measurement in front of the loop, do not reproduce it.)
         # ---- the same step fed like the reference feeds it: a NEW batch every step (data.py:282-295), collated inside the
         # replayed step (train.EpochLoop: raw trajectories -> pinned staging -> one H2D copy -> [DeviceCollator.finish +

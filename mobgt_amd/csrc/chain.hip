@@ -53,7 +53,7 @@ struct ChainParams {
     int nx;                                  // ... and the number of XCDs that take clusters
 };
 
-// in-kernel timeline for tools/chain_debug.py (-DCH_DEBUG): stamps of workgroup 0 / thread 0, written at the end
+// in-kernel timeline (-DCH_DEBUG; the reader script left the tree in round 5): stamps of workgroup 0 / thread 0, written at the end
 #ifdef CH_DEBUG
 __device__ int* g_chain_dbg = nullptr;
 #define STAMP_DECL int st_[16] = {}

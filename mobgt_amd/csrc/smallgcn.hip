@@ -88,7 +88,7 @@ __device__ __forceinline__ float4 coh_load4(const float* p) {
                        __uint_as_float((uint32_t)(b >> 32)));
 }
 
-// in-kernel timeline for tools/sg_debug.py (-DSG_DEBUG): stamps stay in registers and are written at the end -- a store
+// in-kernel timeline (-DSG_DEBUG; the reader script left the tree in round 5): stamps stay in registers and are written at the end -- a store
 // in front of a barrier would add its own round trip to what it measures
 #ifdef SG_DEBUG
 #define STAMP_DECL int st_[16] = {}
@@ -107,7 +107,7 @@ __device__ __forceinline__ float leaky(float v, float slope) { return v > 0.f ? 
 
 // ---- how the 16 x C x K products run -------------------------------------------------------------------------------------
 // Every layer is "this workgroup's 16 rows of L times ALL of R".  Measured on the way here (in-kernel timestamps,
-// tools/sg_debug.py): a thread-per-output loop over global memory is a chain of K dependent L2 round trips (270 us for the
+// round-3 stamps): a thread-per-output loop over global memory is a chain of K dependent L2 round trips (270 us for the
 // network); from LDS with scalar FMA tiles a product still took 5-7 us (a wave64 FMA costs four cycles whether 16 or 64
 // lanes are live, and every k waits an LDS latency), the little [16 x H] x [H x H'] products of the epilogues 2-3 us each
 // for the same reason; and with ONE wave per SIMD nothing hides a taken branch, so predicated loads / runtime tile counts

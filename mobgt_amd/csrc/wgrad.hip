@@ -140,7 +140,7 @@ extern "C" int mobgt_linear_wgrad_multi_hop(int n, const void* const* g, const i
         if ((g_mask[q] || x_mask[q]) && !in_f32[q]) return MOBGT_EDTYPE;          // masks exist for f32 operands only
         // Workgroups per problem: 1024 slots shared by the problems, at least 64 each -- fill_problem caps a problem at one
         // workgroup per 16-wave slab of rows, i.e. a 7 856-row problem gets its 16 splits and every wave ONE 32-row step: the
-        // launch is load -> MFMA -> reduce -> atomics once, whatever the row count.  (Round 4, tools/dbg/wgrad_group_bench.py, the
+        // launch is load -> MFMA -> reduce -> atomics once, whatever the row count.  (Round 4 probe, docs/NOTEBOOK.md, the
         // S-FSQ step's six problems together: 512 slots 24.4 us, 1024 slots 19.7, more: no change; FEWER workgroups -- one round
         // of resident ones, 256 -- 30 us: the chain of 32-row steps per wave is what costs, not the second round.)
         const int slots = 1024;
