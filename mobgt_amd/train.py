@@ -669,14 +669,34 @@ class TrainStep:
         (it would pair with another rank's gradient exchange); under torch.distributed.run a rank that exits takes the job down."""
         batch = self.batches[i]
         known = {id(p) for p in self.flat.params}
+        import warnings
+        warn_always = torch.is_warn_always_enabled()
+        torch.set_warn_always(True)                   # (torch raises this warning once per process otherwise)
+        try:
+            with warnings.catch_warnings(record=True) as seen:
+                warnings.simplefilter("always")
+                with self._on_stream():
+                    saved = self.seed_dev.clone()
+                    if check:
+                        for p in self.model.parameters():
+                            if id(p) not in known:
+                                p.grad = None
+                    self._fwd_bwd(batch)
+                    self.seed_dev.copy_(saved)
+        finally:
+            torch.set_warn_always(warn_always)
+        for w_ in seen:
+            if "AccumulateGrad node's stream does not match" in str(w_.message):
+                # An autograd graph of an EARLIER forward pass of this model is still alive (a loss tensor kept by the caller, a
+                # traceback that holds one): its AccumulateGrad nodes are bound to the stream of that pass, this warm-up ran on
+                # the trainer's capture stream, and the capture that follows would record a cross-stream wait on the legacy
+                # stream -- hipStreamEndCapture then takes the process down (a core dump, seen in round 6 behind a failed test).
+                raise RuntimeError("mobgt TrainStep: an autograd graph of an earlier forward pass of this model is still alive (a loss "
+                                   "tensor or an exception traceback holding one?).  Its AccumulateGrad nodes belong to another stream and "
+                                   "a hipGraph capture of the backward pass would abort the process.  Delete every reference to earlier "
+                                   "losses / outputs of the model (del loss; gc.collect()) before TrainStep.prepare().")
+            warnings.warn_explicit(w_.message, w_.category, w_.filename, w_.lineno)
         with self._on_stream():
-            saved = self.seed_dev.clone()
-            if check:
-                for p in self.model.parameters():
-                    if id(p) not in known:
-                        p.grad = None
-            self._fwd_bwd(batch)
-            self.seed_dev.copy_(saved)
             extra = [n for n, p in self.model.named_parameters() if id(p) not in known and p.grad is not None] if check else []
         self._join()
         if check and extra:

@@ -891,3 +891,47 @@ def test_several_steps_in_one_graph_replay_are_those_steps():
     assert float(a["move"].norm()) > 0
     assert float((a["move"] - b["move"]).norm() / a["move"].norm()) <= 2e-2
     assert float((a["m"] - b["m"]).norm() / a["m"].norm()) <= 2e-2
+
+
+def test_a_stale_autograd_graph_is_refused_instead_of_crashing_the_capture(tmp_path):
+    """Round 6: a loss tensor of an EARLIER eager forward pass that somebody still holds (a failed test's traceback, a logging list)
+    keeps that pass's AccumulateGrad nodes alive, bound to the stream it ran on; capturing the trainer's backward on the capture
+    stream then aborted the process inside hipStreamEndCapture (core dump).  `TrainStep.prepare()` now recognises the situation
+    in its warm-up pass and raises a RuntimeError that says what to delete.  In a child process: a crash must not take pytest down."""
+    script = tmp_path / "stale.py"
+    script.write_text('''
+import sys, os
+sys.path.insert(0, %r)
+import torch
+from mobgt_amd import workloads
+from mobgt_amd.train import TrainStep
+uni, model, coll = workloads.build("fsq", "cuda", seed=1, model_overrides=dict(n_layers=2))
+batches = [coll(t) for t in workloads.make_pool("fsq", 2, 16, uni)]
+model.eval()
+held = []
+for b in batches:
+    loss = model.training_step(b, 0)
+    loss.backward()
+    held.append(loss)                      # the earlier pass's graph stays alive
+model.train()
+ts, refused = None, False
+try:
+    ts = TrainStep(model, batches, use_graph=True, seed=1)
+    ts.prepare()
+except RuntimeError as e:
+    print("REFUSED:", str(e)[:120])
+    refused = True
+assert refused
+ts = loss = None                           # (the refused trainer's own warm-up graph goes with it)
+held.clear()
+import gc; gc.collect()
+for p in model.parameters():
+    p.grad = None
+ts = TrainStep(model, batches, use_graph=True, seed=1)      # ... and with the references gone it works
+ts.prepare()
+print("OK", float(ts.step(0)))
+''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    r = subprocess.run([sys.executable, str(script)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    out = r.stdout.decode(errors="replace")
+    assert r.returncode == 0, (r.returncode, out[-1500:], r.stderr.decode(errors="replace")[-3000:])
+    assert "REFUSED: mobgt TrainStep: an autograd graph of an earlier forward pass" in out and "\nOK " in out, out[-1500:]
