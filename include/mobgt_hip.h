@@ -170,6 +170,12 @@ int mobgt_build_bias_bwd(const void* dbias, int dbias_dtype, int n_slices, int64
                          float* d_rel_table, float* d_poi_table, float* d_hop_table, float* d_vdist,
                          int G, int N, int H, int D_in, int D, int F, int n_rel, int n_poi, int n_edge,
                          int64_t ld_bias, int idx_dtype, int edge_dtype, void* stream);
+/* Round 6: the persistent workgroups of the LONG-batch form of mobgt_build_bias_bwd (G (N+1)^2 >= 2^20 pairs: one 8-wave
+ * workgroup per compute unit walks the pairs) for the launches that follow: 0 = one per compute unit (default), n = at most n.  A
+ * caller that issues the launch on a side stream under other work (the tail of the backward pass: autograd of
+ * model_fqandtoyo.py:1143-1216 needs nothing but the dBias slices) leaves a quarter of the units to that work; no effect on
+ * results.  Host-side state, not thread-safe. */
+int mobgt_build_bias_bwd_set_workgroups(int n);
 
 /* Hop table of the multi-hop edge term (model.py:166-176; fq: model_fqandtoyo.py:1178-1198):
  *   table[d, e, h] = sum_h' edge_encoder[e, h'] * edge_dis_encoder[d, h', h]     [D, n_edge, H] f32

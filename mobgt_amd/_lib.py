@@ -33,6 +33,7 @@ SIGNATURES = {
     "mobgt_bias_pack": (_i, [_vp, _i, _i64, _i64, _i64, _i64, _vp, _vp, _i, _i, _i, _i, _i64, _vp]),
     "mobgt_build_bias": (_i, [_vp] * 10 + [_i] * 9 + [_i64, _i, _i, _i, _vp]),
     "mobgt_build_bias_bwd": (_i, [_vp, _i, _i, _i64] + [_vp] * 8 + [_i] * 9 + [_i64, _i, _i, _vp]),
+    "mobgt_build_bias_bwd_set_workgroups": (_i, [_i]),
     "mobgt_spd_workspace_bytes": (_i64, [_i, _i]),
     "mobgt_spd_batched": (_i, [_vp] * 9 + [_i, _i, _i, _vp]),
     "mobgt_spd_set_spin_limit": (_i, [_i64]),

@@ -901,6 +901,8 @@ int launch_build_b(const BuildParams& p, int bias_dtype, hipStream_t st) {
     return MOBGT_EDTYPE;
 }
 
+int g_bwd_workgroups = 0;           // host side, one thread: 0 = one workgroup per compute unit (long-batch form)
+
 template <typename TI, typename TE>
 int launch_build_bwd(const BuildParams& p, hipStream_t st) {
     const int T = p.N + 1;
@@ -916,7 +918,11 @@ int launch_build_bwd(const BuildParams& p, hipStream_t st) {
     static const int64_t long_from = (1 << 20);
     if (hopmm && pairs >= long_from) {
         const int n_units8 = ((T + 63) / 64) * ((T + 7) / 8) * p.G;
-        const dim3 grid(n_units8 < 256 ? n_units8 : 256), block(512);
+        // (one persistent workgroup per compute unit; a caller that runs this launch BESIDE other work -- ops._bias_bwd_beside: on a
+        //  side stream under the tail of the backward pass -- asks for fewer, so that the other stream's kernels find free units:
+        //  mobgt_build_bias_bwd_set_workgroups)
+        const int wgs_cap = (g_bwd_workgroups > 0 && g_bwd_workgroups < 256) ? g_bwd_workgroups : 256;
+        const dim3 grid(n_units8 < wgs_cap ? n_units8 : wgs_cap), block(512);
         BWD_LDS((build_bias_bwd_kernel<TI, TE, 8, true, 8>), 8, true, 8);
         hipLaunchKernelGGL((build_bias_bwd_kernel<TI, TE, 8, true, 8>), grid, block, shm, st, p, lds_rel, lds_poi);
         return (int)hipGetLastError();
@@ -1038,6 +1044,12 @@ int fill_bias_bwd(BuildParams& p, const void* dbias, int dbias_dtype, int n_slic
     return 0;
 }
 }  // namespace
+
+extern "C" int mobgt_build_bias_bwd_set_workgroups(int n) {
+    if (n < 0) return MOBGT_EBADDIM;
+    g_bwd_workgroups = n;
+    return 0;
+}
 
 extern "C" int mobgt_build_bias_bwd(const void* dbias, int dbias_dtype, int n_slices, int64_t slice_stride,
                                     const float* attn_bias, const void* rel_pos, const void* poi_pos,

@@ -406,8 +406,11 @@ class _BuildBiasFn(torch.autograd.Function):
     def backward(ctx, _g):
         pack = ctx.pack
         dev = pack.bias.device
-        if ctx.job["done"] is not None:            # computed by the passengers of the category GCN's backward launch
-            d_rel, d_poi, d_hop, d_vd = ctx.job["done"]
+        if ctx.job["done"] is not None:            # computed by the passengers of the category GCN's backward launch, or beside
+            d_rel, d_poi, d_hop, d_vd = ctx.job["done"]         # the rest of the pass on the side stream (long batches)
+            ev = ctx.job.pop("done_event", None)
+            if ev is not None:
+                torch.cuda.current_stream(pack.bias.device).wait_event(ev)
             ctx.job["done"] = None
             return d_rel, d_poi, d_hop, d_vd, None, None, None, None, None, None, None
         if _BIAS_BWD_JOB.get("cur") is ctx.job:
@@ -535,8 +538,54 @@ def _attn_bwd(q, k, v, out, lse, dout, dq, dk, dv, pack, scale, p_drop, seed, se
         ent["busy"] = True
         check(_lib.lib().mobgt_attn_bias_bwd_fused_z(*args, _p(ent["buf"]), _stream()), "mobgt_attn_bias_bwd_fused_z")
         ent["busy"] = False
+        _bias_bwd_beside(pack)
         return
     check(_lib.lib().mobgt_attn_bias_bwd(*args, _stream()), "mobgt_attn_bias_bwd")
+    _bias_bwd_beside(pack)
+
+
+# Long batches (round 6): the bias tables' backward (mobgt_build_bias_bwd: 0.7 ms at S-BIG) depends on nothing but the dBias
+# slices, which are complete when the LAST attention backward of the pass has run -- and behind that point the backward pass
+# still has ~0.7 ms of small launches to go (the encoder input's, the embedding tables', the GCNs': latency-bound, a few
+# workgroups each).  The moment the last slice has been written the job is therefore launched on a SIDE stream (an event fork;
+# inside a hipGraph capture: a parallel branch of the graph), and _BuildBiasFn.backward -- which autograd runs last -- only waits
+# for it.  Short batches keep the passenger form (the category GCN's backward launch carries the job: take_bias_bwd_job).
+# MOBGT_NO_BIAS_BWD_BESIDE=1: the launch stays where autograd reaches it.
+_BIAS_BWD_BESIDE = [os.environ.get("MOBGT_NO_BIAS_BWD_BESIDE") != "1"]
+_SIDE_STREAMS = {}
+
+
+def _bias_bwd_beside(pack):
+    job = _BIAS_BWD_JOB.get("cur")
+    if (job is None or not _BIAS_BWD_BESIDE[0] or job["pack"]() is not pack or not pack.sliced or pack.dbias is None
+            or pack.n_use < 1 or pack.n_bwd < pack.n_use or job["done"] is not None):
+        return
+    G, N = job["args"][0], job["args"][1]
+    if G * (N + 1) * (N + 1) < (1 << 20) or job["idx"][3] is None:     # (short batches: the passenger of the GCN's backward launch)
+        return
+    dev = pack.bias.device
+    main = torch.cuda.current_stream(dev)
+    side = _SIDE_STREAMS.get(dev)
+    if side is None:
+        side = _SIDE_STREAMS[dev] = torch.cuda.Stream(device=dev)
+    del _BIAS_BWD_JOB["cur"]
+    outs, args = bias_bwd_job_args(job)             # (allocated on the main stream: zero-filled sinks / arena views)
+    fork = torch.cuda.Event()
+    fork.record(main)
+    side.wait_event(fork)
+    # three quarters of the compute units for this launch (one persistent workgroup each), the rest for the main stream's small
+    # launches beside it: S-BIG 7.17 ms (launch in autograd's order) / 7.25 (beside, all units) / 6.95 (beside, 192 of 256) /
+    # 7.09 (160) / 7.39 (128), back to back on one box
+    cus = torch.cuda.get_device_properties(dev).multi_processor_count
+    lib = _lib.lib()
+    lib.mobgt_build_bias_bwd_set_workgroups(max(1, cus * 3 // 4))
+    try:
+        check(lib.mobgt_build_bias_bwd(*args, ctypes.c_void_p(side.cuda_stream)), "mobgt_build_bias_bwd")
+    finally:
+        lib.mobgt_build_bias_bwd_set_workgroups(0)
+    done = torch.cuda.Event()
+    done.record(side)
+    job["done"], job["done_event"] = outs, done
 
 
 class _AttnFn(torch.autograd.Function):
