@@ -528,6 +528,15 @@ class TrainStep:
         capture -- c10d recycles its events through a cache, `TORCH_NCCL_CUDA_EVENT_CACHE=0` in `recommended_env()` switches that
         off).  Costs 0.25 s per captured graph, once."""
         import time
+        if not getattr(TrainStep, "_env_warned", False) and dist.get_backend() == "nccl":
+            missing = {k: v for k, v in recommended_env().items() if os.environ.get(k) != v}
+            if missing:
+                # (ADVICE r5: the pause below is a timing heuristic; what removes the race is the watchdog not recycling events)
+                import warnings
+                TrainStep._env_warned = True
+                warnings.warn(f"mobgt TrainStep: capturing a step graph under a process group without {missing} in the environment "
+                              "(train.recommended_env(), to be set BEFORE init_process_group): c10d's watchdog may poll an event that "
+                              "is being recorded into the capture")
         torch.cuda.synchronize(self.device)
         time.sleep(0.25)
 
