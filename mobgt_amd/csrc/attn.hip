@@ -1042,6 +1042,14 @@ __device__ __forceinline__ mobgt_v4s lds_tr16(const bf16_t* p) {
     // column i of the 4 rows (cdna_hip_programming.md T10).  EXEC must be all ones at every call.
     return __builtin_amdgcn_ds_read_tr16_b64_v4i16((mobgt_v4s __attribute__((address_space(3)))*)(p));
 }
+// value of lane (i ^ 4): row_half_mirror (i -> 7 - i within 8 lanes) then the quad reversed (two DPP moves, no LDS round trip)
+__device__ __forceinline__ uint32_t lane_xor4(uint32_t x) {
+    const int y = __builtin_amdgcn_update_dpp(0, (int)x, 0x141, 0xf, 0xf, false);
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, y, 0x1B, 0xf, 0xf, false);             // quad_perm [3,2,1,0]
+}
+#ifndef ONE_TR_B16
+#define ONE_TR_B16 0          // timing probe only (tools/attn_ab.sh): 1 = the transposed staging copies as eight 2-byte stores (rounds 4-5)
+#endif
 #ifndef ONE_SKIP
 #define ONE_SKIP 0            // timing probes only (tools/attn_ab.sh): 1 = no dBias / dQ section, 2 = no atomics, 3 = no dBias stores, 4 = no DSk parking either
 #endif
@@ -1177,8 +1185,28 @@ __global__ __launch_bounds__(ONE_NW * 64) void attn_bwd_one_kernel(const AttnPar
             b = __builtin_bit_cast(bf16x8, w);
         }
         *reinterpret_cast<bf16x8*>(&srm[sr][sc0]) = b;
+#if ONE_TR_B16
 #pragma unroll
         for (int i = 0; i < 8; ++i) strn[sc0 + i][sr] = b[i];
+#else
+        {
+            // the transposed copy, two rows at a time (round 6): the lanes of rows 2i and 2i + 1 of one piece (4 lanes apart) swap half
+            // of their piece through two DPP moves per dword, so that the even row's lane holds head columns 0..3 of BOTH rows and
+            // the odd row's lane columns 4..7 -- four 4-byte stores [column][2i, 2i + 1] per lane where eight 2-byte stores
+            // [column][row] went (two lanes writing the two halves of one dword: 9 LDS writes per piece -> 5).
+            const u32x4 w = __builtin_bit_cast(u32x4, b);
+            const bool odd = sr & 1;
+            const uint32_t s0 = odd ? w[0] : w[2], s1 = odd ? w[1] : w[3];
+            const uint32_t k0 = odd ? w[2] : w[0], k1 = odd ? w[3] : w[1];
+            const uint32_t r0 = lane_xor4(s0), r1 = lane_xor4(s1);
+            const uint32_t lo0 = odd ? r0 : k0, hi0 = odd ? k0 : r0, lo1 = odd ? r1 : k1, hi1 = odd ? k1 : r1;
+            const int cb = sc0 + (odd ? 4 : 0), rp = sr & ~1;
+            *reinterpret_cast<uint32_t*>(&strn[cb + 0][rp]) = __builtin_amdgcn_perm(hi0, lo0, 0x05040100u);
+            *reinterpret_cast<uint32_t*>(&strn[cb + 1][rp]) = __builtin_amdgcn_perm(hi0, lo0, 0x07060302u);
+            *reinterpret_cast<uint32_t*>(&strn[cb + 2][rp]) = __builtin_amdgcn_perm(hi1, lo1, 0x05040100u);
+            *reinterpret_cast<uint32_t*>(&strn[cb + 3][rp]) = __builtin_amdgcn_perm(hi1, lo1, 0x07060302u);
+        }
+#endif
         {
             float o8[8], l8[8];
             oreg.get(o8);
