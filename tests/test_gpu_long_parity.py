@@ -264,3 +264,45 @@ def test_long_batch_train_step_vs_oracle_with_replayed_masks(monkeypatch):
         e_ref, e_exact, own = rel(g, ref_g), rel(g, ex_g), rel(ref_g, ex_g)
         print("%-28s relL2 vs reference %.4f  vs exact fp32 %.4f   reference vs exact %.4f" % (k, e_ref, e_exact, own))
         assert min(e_ref, e_exact) <= EDGE_TABLE_REL_L2, (k, e_ref, e_exact)
+
+
+def test_long_batch_step_forms_agree():
+    """The two round-6 forms of the long-batch step against the forms they replaced, on the same model and batch (dropout off, so
+    nothing but the summation order differs): the layer's weight gradients as ONE launch (csrc/wgradbig.hip; MOBGT_NO_WGRAD_BIG=1:
+    library split-K products + `wgrad_group` + parked partial sums) and the bias tables' backward on the side stream beside the
+    tail of the backward pass (ops._bias_bwd_beside; MOBGT_NO_BIAS_BWD_BESIDE=1: where autograd reaches it).  One captured
+    `TrainStep` each; every parameter gradient of the model."""
+    import gc
+    from mobgt_amd import fused_layer
+    from mobgt_amd.train import TrainStep
+    grads, losses = {}, {}
+    for mode in ("round6", "before"):
+        fused_layer._WGRAD_BIG[0] = ops._BIAS_BWD_BESIDE[0] = mode == "round6"
+        try:
+            uni, model, batch = _build(192, dropout_rate=0.0, intput_dropout_rate=0.0, attention_dropout_rate=0.0)
+            sd0 = {k: v.detach().clone() for k, v in model.state_dict().items()}
+            ts = TrainStep(model, [batch], use_graph=True, seed=5)
+            ts.prepare()
+            with torch.no_grad():
+                model.load_state_dict(sd0)                    # (the warm-up steps of prepare() are real AdamW updates)
+                ts.sync_shadows()
+            losses[mode] = float(ts.step(0))
+            torch.cuda.synchronize()
+            assert not ops.step_state_leftovers()
+            grads[mode] = {n: q.grad.detach().float().clone() for n, q in model.named_parameters() if q.grad is not None}
+            del ts, model, batch, uni
+            gc.collect()
+        finally:
+            fused_layer._WGRAD_BIG[0] = ops._BIAS_BWD_BESIDE[0] = True
+    assert losses["round6"] == pytest.approx(losses["before"], rel=1e-5)
+    a, b = grads["round6"], grads["before"]
+    assert a.keys() == b.keys() and len(a) > 60
+    worst = ("", 0.0)
+    for n in a:
+        if n.endswith("linear_k.bias"):
+            continue                                          # exactly zero in exact arithmetic: round-off only
+        ref = b[n].double()
+        rel = float((a[n].double() - ref).norm() / ref.norm().clamp_min(1e-300))
+        worst = max(worst, (n, rel), key=lambda t: t[1])
+        assert rel <= (5e-3 if n.startswith("edge_") else 1e-3), (n, rel)      # (measured: 8.7e-5 at most)
+    print("largest relative L2 between the forms: %s %.2e" % worst)
