@@ -1215,15 +1215,8 @@ int device_cus() {
 // members per row block: as many (4, 2) as keeps every live workgroup on a compute unit of its own; 1 = the one-workgroup form
 int pick_ncl(int64_t R, const void* ws) {
     if (!ws) return 1;
-    static int forced = -1;
-    if (forced < 0) {
-        const char* e = getenv("MOBGT_CHAIN_NCL");
-        forced = e ? atoi(e) : 0;
-    }
     const int nblk = (int)((R + 15) / 16), cus = device_cus() < 256 ? device_cus() : 256;
-    int ncl = nblk * 4 <= cus ? 4 : (nblk * 2 <= cus ? 2 : 1);
-    if ((forced == 1 || forced == 2 || forced == 4) && forced < ncl) ncl = forced;
-    return ncl;
+    return nblk * 4 <= cus ? 4 : (nblk * 2 <= cus ? 2 : 1);
 }
 
 template <int BM, int C, int F, int NCL>
@@ -2422,12 +2415,7 @@ extern "C" int mobgt_layer_chain_fwd(const void* a, const float* x, const void* 
     p.inv_keep = p.thr ? 1.f / (1.f - (float)p.thr / 65536.f) : 1.f;
     p.seed = seed; p.seed_dev = seed_dev; p.salt1 = salt1; p.salt2 = salt2;
     hipStream_t st = (hipStream_t)stream;
-    static int64_t big_rows = -1;            // (MOBGT_CHAIN_BIG_ROWS: a measurement aid -- the forward alone may switch forms at any R)
-    if (big_rows < 0) {
-        const char* e = getenv("MOBGT_CHAIN_BIG_ROWS");
-        big_rows = e ? atoll(e) : CHAIN_BIG_ROWS;
-    }
-    if (R > big_rows) {                      // long batches: 64 rows per workgroup (layer_chain_fwd_big_kernel)
+    if (R > CHAIN_BIG_ROWS) {                      // long batches: 64 rows per workgroup (layer_chain_fwd_big_kernel)
         if (C == 128 && F == 1024) return launch_big<128, 1024>(p, st);
         if (C == 192 && F == 1024) return launch_big<192, 1024>(p, st);
         if (C == 256 && F == 1024) return launch_big<256, 1024>(p, st);

@@ -181,7 +181,7 @@ def _k1_fwd(x, y, x1, w, b, z, z32, mean, rstd, R, C, p, seed, seed_dev, salt, a
                                               p, seed, _p(seed_dev), salt, act, _stream()), "mobgt_dropout_add_ln_fwd")
 
 
-_LN_GEMM = [_os_ln.environ.get("MOBGT_NO_LN_GEMM") != "1"]      # MOBGT_NO_LN_GEMM=1: the two-launch form (A/B runs, tests)
+_LN_GEMM = [True]                                               # False: the two-launch form (tests)
 # Measured on the S-FSQ step (608 rows, C = 192), kernel durations inside the replayed graph:
 #   forward   dropout_add_ln 4.8 us + FFN-1 GEMM 5.2 us  ->  fused 9.1 us
 #   backward  dropout_add_ln' 5.7 us + GEMM 5.7 us       ->  fused 12.9 - 14.4 us (the first column tile of every row block
@@ -193,8 +193,8 @@ _LN_GEMM_BWD = [_os_ln.environ.get("MOBGT_LN_GEMM_BWD") == "1"]
 # csrc/chain.hip: out-proj -> LN -> FFN -> LN -> the next layer's QKV in one launch (MOBGT_NO_CHAIN=1: the separate launches)
 _CHAIN = [_os_ln.environ.get("MOBGT_NO_CHAIN") != "1"]
 _CHAIN_BIG = [_os_ln.environ.get("MOBGT_NO_CHAIN_BIG") != "1"]      # ... past 4 096 rows: the 64-row forward chain (else the library's GEMMs)
-_CHAIN_BWD = [_os_ln.environ.get("MOBGT_NO_CHAIN_BWD") != "1"]
-_WGRAD_BIG = [_os_ln.environ.get("MOBGT_NO_WGRAD_BIG") != "1"]      # past 4 096 rows: the layer's weight gradients as one launch (csrc/wgradbig.hip)      # ... and the same chain backwards (d(out) -> d(attention out))
+_CHAIN_BWD = [True]
+_WGRAD_BIG = [True]      # past 4 096 rows: the layer's weight gradients as one launch (csrc/wgradbig.hip)      # ... and the same chain backwards (d(out) -> d(attention out))
 
 
 # ---- what a layer's backward may leave to the backward of the layer BELOW it --------------------------------------------------
@@ -278,8 +278,8 @@ def chain_workspace(dev, C=192, R=None):
     geometry (model width C, cluster size 4 / 2 -- csrc/chain.hip: pick_ncl): a row block's exchange area is addressed as
     block x members x 16 x C, so launches of different geometry on one workspace would poll words another block wrote, and
     a stale packet whose generation happens to match would be accepted.  Must exist before a graph capture starts
-    (an eager warm-up step creates it).  MOBGT_CHAIN_NCL=1 / ops.SAFE_FORMS -> None (one-workgroup form)."""
-    if _os_ln.environ.get("MOBGT_CHAIN_NCL") == "1" or ops.SAFE_FORMS[0]:
+    (an eager warm-up step creates it).  ops.SAFE_FORMS -> None (one-workgroup form)."""
+    if ops.SAFE_FORMS[0]:
         return None
     idx = dev.index if dev.index is not None else torch.cuda.current_device()
     nblk = (int(R) + 15) // 16 if R is not None else 1

@@ -339,7 +339,7 @@ def spmm(adj, b, bias=None, rows=None, transposed=False):
 
 
 import os as _os_sp
-_SP_GATHER = [_os_sp.environ.get("MOBGT_SPMM_SCATTER") != "1"]     # MOBGT_SPMM_SCATTER=1: the atomic scatter (A/B runs, tests)
+_SP_GATHER = [True]                                                # False: the atomic scatter (tests)
 
 
 class _SpConvFn(torch.autograd.Function):

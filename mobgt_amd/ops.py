@@ -550,8 +550,8 @@ def _attn_bwd(q, k, v, out, lse, dout, dq, dk, dv, pack, scale, p_drop, seed, se
 # workgroups each).  The moment the last slice has been written the job is therefore launched on a SIDE stream (an event fork;
 # inside a hipGraph capture: a parallel branch of the graph), and _BuildBiasFn.backward -- which autograd runs last -- only waits
 # for it.  Short batches keep the passenger form (the category GCN's backward launch carries the job: take_bias_bwd_job).
-# MOBGT_NO_BIAS_BWD_BESIDE=1: the launch stays where autograd reaches it.
-_BIAS_BWD_BESIDE = [os.environ.get("MOBGT_NO_BIAS_BWD_BESIDE") != "1"]
+# _BIAS_BWD_BESIDE[0] = False (tests): the launch stays where autograd reaches it.
+_BIAS_BWD_BESIDE = [True]
 _SIDE_STREAMS = {}
 
 
@@ -750,8 +750,7 @@ class _HopTableFn(torch.autograd.Function):
         #  two models, two tables -- would overwrite the first one's entry, whose gradient would then never be computed, and a
         #  buffer allocated here would reach autograd before the deferred launch has filled it: ADVICE r4)
         park = _WGRAD_DEFER["on"] and k_e is not None and k_d is not None
-        if (park and "hop" not in _WGRAD_DEFER and H == 8 and E <= 256 and dtab.data_ptr() % 16 == 0 and dw.data_ptr() % 16 == 0
-                and os.environ.get("MOBGT_NO_HOP_BWD_PASSENGER") != "1"):
+        if (park and "hop" not in _WGRAD_DEFER and H == 8 and E <= 256 and dtab.data_ptr() % 16 == 0 and dw.data_ptr() % 16 == 0):
             # rides in the step's grouped weight-gradient launch (flush_deferred_wgrads): nothing but the optimizer reads these
             _WGRAD_DEFER["hop"] = (dtab, ew, dw, d_ew, d_dw, D, E, rt)
             return d_ew[:], d_dw[:], None, None, None
@@ -874,8 +873,7 @@ class _SkinnyLinearGtlFn(torch.autograd.Function):
 
 
 def skinny_linear_gtl_ok(x, weight):
-    return (skinny_linear_ok(x, weight) and x.shape[1] % 64 == 0 and x.shape[1] <= 448
-            and os.environ.get("MOBGT_NO_FUSED_LOSS") != "1")
+    return (skinny_linear_ok(x, weight) and x.shape[1] % 64 == 0 and x.shape[1] <= 448)
 
 
 def skinny_linear_gtl(x, weight, bias, targets, alpha=0.25, target_offset=0, logits_out=None):
@@ -1208,8 +1206,7 @@ class _StockTokensFn(torch.autograd.Function):
 
 def stock_tokens_ok(x, atom, indeg, outdeg, gtok):
     return (x.is_cuda and x.dim() == 2 and x.dtype in _IT and atom.shape[1] % 4 == 0
-            and all(t.dtype == torch.float32 and t.is_contiguous() and t.data_ptr() % 16 == 0 for t in (atom, indeg, outdeg, gtok))
-            and os.environ.get("MOBGT_NO_STOCK_TOKENS") != "1")
+            and all(t.dtype == torch.float32 and t.is_contiguous() and t.data_ptr() % 16 == 0 for t in (atom, indeg, outdeg, gtok)))
 
 
 def stock_tokens(x, in_degree, out_degree, atom, indeg, outdeg, graph_token, p, training, salt, padding_idx=0):
@@ -1254,7 +1251,7 @@ class _TokenLayerNormFn(torch.autograd.Function):
 
 def token_layer_norm_ok(enc, weight):
     return (enc.is_cuda and enc.dim() == 3 and enc.dtype == torch.float32 and weight.dtype == torch.float32
-            and enc.shape[2] <= 1024 and os.environ.get("MOBGT_NO_TOKEN_LN") != "1")
+            and enc.shape[2] <= 1024)
 
 
 def token_layer_norm(enc, weight, bias, eps=1e-5):
@@ -1286,7 +1283,7 @@ class _CrossEntropyFn(torch.autograd.Function):
 
 def cross_entropy_ok(logits, targets):
     return (logits.is_cuda and logits.dim() == 2 and 0 < logits.shape[0] <= 4095 and logits.shape[1] <= 10240
-            and targets.numel() == logits.shape[0] and os.environ.get("MOBGT_NO_FUSED_CE") != "1")
+            and targets.numel() == logits.shape[0])
 
 
 def cross_entropy(logits, targets, ignore_index=-100):
@@ -1687,14 +1684,13 @@ def head_chain_ok(enc, table, user, w3):
     return (enc.is_cuda and enc.dim() == 3 and enc.dtype == torch.float32 and table.dtype == torch.float32 and table.is_contiguous()
             and W in (320, 384) and tuple(w3.shape) == (W, W) and w3.dtype == torch.float32 and w3.is_contiguous()
             and user.dtype in (torch.int64, torch.int32) and user.numel() == enc.shape[0] and enc.shape[0] <= 160
-            and enc.shape[-1] % 16 == 0 and table.shape[1] % 16 == 0 and not __import__("os").environ.get("MOBGT_NO_HEAD_CHAIN")
-            and not SAFE_FORMS[0])
+            and enc.shape[-1] % 16 == 0 and table.shape[1] % 16 == 0 and not SAFE_FORMS[0])
 
 
 def head_chain(enc, user_table, user, user_offset, w3, b3, ln_weight, ln_bias, eps, slope, p_drop, training, salt, bf16_wgrad=False):
     """tok [G, C+U] = dropout(ELU(LayerNorm(LeakyReLU(Linear([enc[:, 0] | user_table[user + user_offset]]))))) -- the classifier
-    head in front of out_proj (model_fqandtoyo.py:1239-1240, 1353-1364) in one launch each way.  MOBGT_NO_HEAD_CHAIN=1: callers
-    fall back to head_input + linear_splitk + head_act."""
+    head in front of out_proj (model_fqandtoyo.py:1239-1240, 1353-1364) in one launch each way.  Where head_chain_ok says no (and under
+    ops.SAFE_FORMS) callers fall back to head_input + linear_splitk + head_act."""
     _require_cuda(enc, user_table, user, w3)
     if not training:
         p_drop = 0.0
@@ -1977,7 +1973,6 @@ def act_mask_values(slope, p_drop):
 # references that tensor object, and the record holds the base -- the kernel's late writes land in the tensor the parameter
 # ends up with (the rule fused_layer.py follows for its parked tails).  Off by default: eager callers get the launch at once.
 _WGRAD_DEFER = {"on": False, "items": []}
-_WGRAD_DEFER_ENV = __import__("os").environ.get("MOBGT_NO_DEFER_WGRAD") != "1"
 
 
 def wgrad_deferral(on):
@@ -1986,7 +1981,7 @@ def wgrad_deferral(on):
     _WGRAD_DEFER["items"] = []
     for k in ("hop", "hop_wide", "stock_tok", "psum"):
         _WGRAD_DEFER.pop(k, None)
-    _WGRAD_DEFER["on"] = bool(on) and _WGRAD_DEFER_ENV
+    _WGRAD_DEFER["on"] = bool(on)
 
 
 def defer_partial_sum(part, dst):

@@ -268,9 +268,9 @@ def test_long_batch_train_step_vs_oracle_with_replayed_masks(monkeypatch):
 
 def test_long_batch_step_forms_agree():
     """The two round-6 forms of the long-batch step against the forms they replaced, on the same model and batch (dropout off, so
-    nothing but the summation order differs): the layer's weight gradients as ONE launch (csrc/wgradbig.hip; MOBGT_NO_WGRAD_BIG=1:
+    nothing but the summation order differs): the layer's weight gradients as ONE launch (csrc/wgradbig.hip; fused_layer._WGRAD_BIG off:
     library split-K products + `wgrad_group` + parked partial sums) and the bias tables' backward on the side stream beside the
-    tail of the backward pass (ops._bias_bwd_beside; MOBGT_NO_BIAS_BWD_BESIDE=1: where autograd reaches it).  One captured
+    tail of the backward pass (ops._bias_bwd_beside; ops._BIAS_BWD_BESIDE off: where autograd reaches it).  One captured
     `TrainStep` each; every parameter gradient of the model."""
     import gc
     from mobgt_amd import fused_layer
@@ -304,5 +304,7 @@ def test_long_batch_step_forms_agree():
         ref = b[n].double()
         rel = float((a[n].double() - ref).norm() / ref.norm().clamp_min(1e-300))
         worst = max(worst, (n, rel), key=lambda t: t[1])
-        assert rel <= (5e-3 if n.startswith("edge_") else 1e-3), (n, rel)      # (measured: 8.7e-5 at most)
+        # (two runs of ONE form already differ by up to 2.1e-3 -- 3.5 % on the two edge tables, whose sums cancel 30-70 x --: float
+        #  atomics in front of bf16 rounding points, profiles/r6_backward_run_to_run.txt; most pairs of runs agree to 9e-5)
+        assert rel <= (1e-1 if n.startswith("edge_") else 1e-2), (n, rel)
     print("largest relative L2 between the forms: %s %.2e" % worst)
